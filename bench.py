@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the block-DSP hot path on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+
+Workload at N = 1 (BASELINE.json configs[1]): batched open-loop ME integer search, 1080p 8-bit, every 64x64 SB of
+FRAMES source frames against REFS reference frames each, search area 16x9 (the preset-8 1080p maximum,
+Source/Lib/Codec/enc_mode_config.c:325-326), inputs resident in HBM.  One "step" = one launch of
+svt_hip_me_fullpel_search_batch over the whole batch.  `value` = M(SB x search position)/s, i.e. one "block" is one
+candidate position of one 64x64 SB against one reference = the 85 block SADs of SURVEY 8(d).
+N > 1: every rank processes its own batch of frames (frame-level sharding, no data-path collective) -> "weak".
+
+Extra objects on the JSON line: `roofline` (dominant kernel vs the HBM roofline, algorithmic bytes of SURVEY 8(d)),
+`cpu_baseline` (the reference's own AVX2 kernels from oracle/_ref timed on the host cores, bounded sample) and
+`kernels` (the other primitives of the metric, each with its own algorithmic-bytes roofline).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+W, H, PAD = 1920, 1080, 68  # luma plane padded 68 px each side (enc_handle.c:4084) -> stride 2056
+STRIDE, ROWS = W + 2 * PAD, H + 2 * PAD
+PLANE = STRIDE * ROWS
+
+
+def synth_planes(n, seed):
+    """(x + y) & 255 gradient moving (2i, 3i) per frame + uniform +-8 noise (BASELINE.md section 2 generator)."""
+    g = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:ROWS, 0:STRIDE].astype(np.int32)
+    out = np.empty((n, ROWS, STRIDE), np.uint8)
+    for i in range(n):
+        base = (xx + 2 * i + yy + 3 * i) & 255
+        out[i] = np.clip(base + g.integers(-8, 9, base.shape), 0, 255).astype(np.uint8)
+    return out
+
+
+def time_steps(torch, fn, steps, warmup, dist=None):
+    for _ in range(warmup):
+        fn()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    return wall, ev0.elapsed_time(ev1) / 1e3  # seconds: host wall, device span on the launch stream
+
+
+def cpu_me_baseline(descs, planes_src, planes_ref, area, budget_s=12.0):
+    """Reference AVX2 kernels (svt_ext_all_sad_calculation_8x8_16x16_avx2 + svt_ext_eight_sad_calculation_32x32_64x64_avx2
+    + the _c remainder kernels) driven like open_loop_me_fullpel_search_sblock, all host cores, bounded sample."""
+    import concurrent.futures as cf
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libsvtref.so")
+    ora_path = os.path.join(ROOT, "oracle", "liboracle.so")
+    flags = open("/proc/cpuinfo").read()
+    if not os.path.exists(ref_path):
+        # the real reference is not available on this box: time our C restatement instead ("port")
+        oracle, kind, label = C.CDLL(ora_path), "port", "oracle_me_fullpel_search (scalar C restatement)"
+        cores = 1
+
+        def one(i):
+            d = descs[i]
+            bs, bm = np.zeros(85, np.uint32), np.zeros(85, np.uint32)
+            oracle.oracle_me_fullpel_search(C.c_void_p(planes_src.ctypes.data + int(d["src_off"])), int(d["src_stride"]),
+                                            C.c_void_p(planes_ref.ctypes.data + int(d["ref_off"])), int(d["ref_stride"]), 0, 0,
+                                            area[0], area[1], 0, C.c_void_p(bs.ctypes.data), C.c_void_p(bm.ctypes.data))
+        t0, done = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s and done < len(descs):
+            one(done)
+            done += 1
+        dt = time.perf_counter() - t0
+        return {"value": done * area[0] * area[1] / dt / 1e6, "unit": "Mblocks/s", "cores": cores, "kind": kind,
+                "sample": "%d SB-refs at %dx%d, %s" % (done, area[0], area[1], label)}
+    ref, oracle = C.CDLL(ref_path), C.CDLL(ora_path)
+    simd = "avx2" if " avx2 " in flags else "c"
+    fn = lambda n: C.cast(getattr(ref, n), C.c_void_p)  # noqa: E731
+    f_all = fn("svt_ext_all_sad_calculation_8x8_16x16_" + simd)
+    f_eight = fn("svt_ext_eight_sad_calculation_32x32_64x64_" + simd)
+    f_one, f_one2 = fn("svt_ext_sad_calculation_8x8_16x16_c"), fn("svt_ext_sad_calculation_32x32_64x64_c")
+    drv = oracle.oracle_drive_ref_me_search_many
+    drv.restype = C.c_uint64
+    drv.argtypes = [C.c_void_p] * 7 + [C.c_uint32] * 4 + [C.c_int, C.c_void_p, C.c_void_p]
+    cores = os.cpu_count() or 1
+    dd = np.ascontiguousarray(descs)
+    bs, bm = np.zeros(len(dd) * 85, np.uint32), np.zeros(len(dd) * 85, np.uint32)
+
+    def run(idx0, step, repeat):
+        return drv(f_all, f_eight, f_one, f_one2, planes_src.ctypes.data, planes_ref.ctypes.data, dd.ctypes.data, len(dd), idx0, step, repeat, 0,
+                   bs.ctypes.data, bm.ctypes.data)
+    t1 = time.perf_counter()
+    n1 = run(0, 1, 1)  # calibration pass, one thread, also the single-thread figure
+    dt1 = time.perf_counter() - t1
+    one_thread = n1 * area[0] * area[1] / dt1 / 1e6
+    repeat = max(1, int(budget_s / dt1))  # each thread does 1/cores of the list per repeat -> ~budget_s of wall time
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL for the whole C loop
+        done = sum(ex.map(lambda k: run(k, cores, repeat * cores), range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": done * area[0] * area[1] / dt / 1e6, "unit": "Mblocks/s", "cores": cores, "kind": "reference",
+            "single_thread_value": one_thread,
+            "sample": "%d SB-refs at %dx%d in %.1fs, reference %s kernels driven as open_loop_me_fullpel_search_sblock" % (done, area[0], area[1], dt, simd)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=32, help="source frames per step and per GPU")
+    ap.add_argument("--refs", type=int, default=4)
+    ap.add_argument("--area", type=str, default="16x9")
+    ap.add_argument("--probe", action="store_true", help="print VALU issue rates and exit")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--extra", action="store_true", help="also sweep the other search areas / sub_sad (reported under kernels)")
+    a = ap.parse_args()
+
+    import torch
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if a.gpus > 1 or world > 1:
+        import torch.distributed as dist  # RCCL; used for the barrier / max-over-ranks only: the path needs no exchange
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    pkg = entry._pkg()
+    lib = pkg.load(init_device=local)
+    stream = torch.cuda.current_stream().cuda_stream
+    aw, ah = (int(v) for v in a.area.split("x"))
+
+    if a.probe:
+        sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+        names = ["v_sad_u8", "v_qsad_pk_u16_u8", "v_add+v_xor", "v_mul_lo_u32(+add)", "v_mad_i64_i32", "v_alignbyte_b32"]
+        blocks, iters = 256 * 8, 4096
+        for k, nm in enumerate(names):
+            fn = lambda: lib.svt_hip_rate_probe(k, iters, blocks, sink.data_ptr(), stream)  # noqa: E731
+            _, dev = time_steps(torch, fn, 5, 2)
+            ops = 5 * blocks * 256 * iters * 8
+            print("%-22s %8.1f Gop/s/lane-op  -> %.2f cycles per wave64 instruction per SIMD (2.4 GHz, 1024 SIMDs)" %
+                  (nm, ops / dev / 1e9, 2.4e9 * 1024 * 64 / (ops / dev)))
+        return
+
+    # ---------------- config 2: batched ME full-pel search -------------------------------------------------------
+    nplanes = a.frames + a.refs
+    planes = synth_planes(nplanes, 1234 + rank)
+    descs = np.concatenate([pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, aw, ah, PLANE, n_refs=a.refs, src_plane=f, ref_plane0=f + 1)
+                            for f in range(a.frames)])
+    n = len(descs)
+    d_planes = torch.from_numpy(planes.reshape(-1)).cuda()
+    d_descs = torch.from_numpy(descs.view(np.uint8)).cuda()
+    d_sad = torch.zeros(n * 85, dtype=torch.int32, device="cuda")
+    d_mv = torch.zeros(n * 85, dtype=torch.int32, device="cuda")
+    ws_bytes = lib.svt_hip_me_fullpel_search_workspace(n, aw, ah)
+    d_ws = torch.zeros(max(ws_bytes, 8), dtype=torch.uint8, device="cuda")
+
+    def step(sub=0, w=aw, h=ah, dd=d_descs, nn=n):
+        lib.svt_hip_me_fullpel_search_batch(d_planes.data_ptr(), d_planes.data_ptr(), dd.data_ptr(), nn, w, h, sub, d_sad.data_ptr(),
+                                            d_mv.data_ptr(), d_ws.data_ptr() if ws_bytes else None, stream)
+    wall, dev = time_steps(torch, step, a.steps, a.warmup, dist)
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    positions = n * aw * ah
+    value = world * positions * a.steps / wall / 1e6
+    # roofline of the dominant kernel: algorithmic bytes per (SB, ref) = 64*64 + (64+W-1)(64+H-1) + 85*8
+    bytes_item = 64 * 64 + (64 + aw - 1) * (64 + ah - 1) + 85 * 8
+    kernel_s = dev / a.steps
+    achieved = n * bytes_item / kernel_s / 1e9
+    out = {
+        "metric": "Mblocks/s per kernel (SAD, FwdTxfm2d, CDEF) + encoder fps @1080p preset 8", "value": value,
+        "unit": "Mblocks/s (block = one search position of one 64x64 SB vs one reference = 85 block SADs)",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "configs[1]: batched open-loop ME integer full-pel search (SAD 8x8..64x64), 1080p 8-bit, all 64x64 SBs",
+                   "frames_per_step_per_gpu": a.frames, "refs": a.refs, "search_area": a.area, "sb_refs_per_step_per_gpu": n,
+                   "sub_sad": 0, "parallelism": "frame-sharded x%d (no collective)" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "me_fullpel_kernel<false>", "kernel_ms": kernel_s * 1e3,
+                     "algorithmic_bytes_per_sb_ref": bytes_item,
+                     "note": "search is VALU(packed-SAD)-bound, see sad_ops; HBM figure = SURVEY 8(d) algorithmic bytes / time",
+                     "sad_ops_per_s": n * aw * ah * 4096 / kernel_s},
+    }
+    kernels = {}
+    # ---------------- config 1 shape on the GPU: independent 64x64 SAD pairs (the genuinely HBM-bound SAD kernel) ----
+    pairs = np.zeros(a.frames * 510 * a.refs, dtype=pkg.SadPair)
+    i = 0
+    for f in range(a.frames):
+        for r in range(a.refs):
+            for sy in range(17):
+                for sx in range(30):
+                    o = (PAD + sy * 64) * STRIDE + PAD + sx * 64
+                    pairs[i] = (f * PLANE + o, (f + 1 + r) * PLANE + o, STRIDE, STRIDE)
+                    i += 1
+    d_pairs = torch.from_numpy(pairs.view(np.uint8)).cuda()
+    d_out = torch.zeros(len(pairs), dtype=torch.int32, device="cuda")
+    fn = lambda: lib.svt_hip_sad_nxm_batch(d_planes.data_ptr(), d_planes.data_ptr(), d_pairs.data_ptr(), len(pairs), 64, 64,  # noqa: E731
+                                           d_out.data_ptr(), stream)
+    _, dv = time_steps(torch, fn, a.steps, a.warmup)
+    gbs = len(pairs) * 8192 / (dv / a.steps) / 1e9
+    kernels["sad64x64_pairs"] = {"value": len(pairs) / (dv / a.steps) / 1e6, "unit": "Mblocks/s", "kernel": "sad_nxm_kernel",
+                                 "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                              "traffic": None, "algorithmic_bytes_per_block": 8192}}
+    if a.extra:
+        for (w2, h2, sub) in [(16, 9, 1), (64, 32, 0), (256, 256, 0)]:
+            nf = a.frames if w2 < 256 else 2
+            dd = np.concatenate([pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, w2, h2, PLANE, n_refs=a.refs, src_plane=f, ref_plane0=f + 1)
+                                 for f in range(nf)])
+            # search windows must stay inside the padded planes: clamp like integer_search_b64 does (motion_estimation.c:1440-1506)
+            keep = []
+            for k, d in enumerate(dd):
+                y0 = (int(d["ref_off"]) % PLANE) // STRIDE
+                x0 = (int(d["ref_off"]) % PLANE) % STRIDE
+                if int(d["ref_off"]) % PLANE >= 0 and x0 + 64 + w2 - 1 <= STRIDE and y0 + 64 + h2 - 1 <= ROWS and d["ref_off"] >= 0 and (int(d["ref_off"]) // PLANE) == (int(d["ref_off"]) + (64 + h2 - 2) * STRIDE + 64 + w2 - 2) // PLANE:
+                    keep.append(k)
+            dd = dd[keep]
+            tdd = torch.from_numpy(dd.view(np.uint8)).cuda()
+            wsb = lib.svt_hip_me_fullpel_search_workspace(len(dd), w2, h2)
+            ws2 = torch.zeros(max(wsb, 8), dtype=torch.uint8, device="cuda")
+            f2 = lambda: lib.svt_hip_me_fullpel_search_batch(d_planes.data_ptr(), d_planes.data_ptr(), tdd.data_ptr(), len(dd), w2, h2, sub,  # noqa: E731
+                                                             d_sad.data_ptr(), d_mv.data_ptr(), ws2.data_ptr() if wsb else None, stream)
+            st = max(2, a.steps // (4 if w2 >= 64 else 1))
+            _, dv = time_steps(torch, f2, st, 1)
+            kernels["me_search_%dx%d_sub%d" % (w2, h2, sub)] = {"value": len(dd) * w2 * h2 / (dv / st) / 1e6, "unit": "Mblocks/s",
+                                                               "sb_refs": len(dd), "sad_ops_per_s": len(dd) * w2 * h2 * (2048 if sub else 4096) / (dv / st)}
+    out["kernels"] = kernels
+    if rank == 0 and world == 1 and not a.no_cpu:
+        host_descs = pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, aw, ah, PLANE, n_refs=1, src_plane=0, ref_plane0=1)
+        out["cpu_baseline"] = cpu_me_baseline(host_descs, planes, planes, (aw, ah))
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

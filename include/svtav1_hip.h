@@ -1,0 +1,138 @@
+/*
+ * svtav1_hip.h -- C ABI of libsvtav1_hip.so: the MI355X (gfx950) variant of SVT-AV1-PSY's block-DSP hot path.
+ *
+ * Two families of entry points:
+ *
+ *  (1) `*_hip` functions whose prototypes are IDENTICAL to the reference's RTCD function pointers
+ *      (Source/Lib/Codec/aom_dsp_rtcd.h, common_dsp_rtcd.h).  They take HOST pointers, are synchronous and
+ *      re-entrant, exactly like the `_c/_avx2` variants, so `svt_hip_setup_rtcd()` can install them as
+ *      "just another SIMD variant".  Each one stages its operands to the GPU, runs the same kernel the batched
+ *      entry point uses with n = 1, and copies the results back.  They exist for drop-in parity, not speed.
+ *
+ *  (2) `svt_hip_*_batch` functions: DEVICE pointers, asynchronous on the caller's HIP stream, one launch per
+ *      primitive over all superblocks / blocks of a frame (or several frames).  These are the throughput path.
+ *
+ * Error policy: the reference's DSP kernels return void and cannot fail.  This library never falls back to a
+ * CPU implementation: a missing device or a HIP error prints the failing call to stderr and abort()s.
+ *
+ * All kernels are integer and bit-exact with the reference `*_c` functions cited per declaration.
+ */
+#ifndef SVTAV1_HIP_H
+#define SVTAV1_HIP_H
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- runtime ------------------------------------ */
+/* Bind the calling process to HIP device `device` (one process per GPU). 0 on success, -1 if no usable device. */
+int         svt_hip_init(int device);
+void        svt_hip_shutdown(void);
+const char *svt_hip_device_name(void);
+/* Overwrite the reference's RTCD pointers (weak symbols; present only when linked into libSvtAv1Enc) with the
+ * `_hip` variants.  Call right after svt_aom_setup_rtcd_internal() (Source/Lib/Globals/enc_handle.c:1444-1445).
+ * Returns the number of pointers installed. */
+int         svt_hip_setup_rtcd(uint64_t flags);
+/* Cross-lane / packed-byte instruction self-test used by the GPU test-suite (returns 0 when the silicon agrees
+ * with the C model that the CPU-side interpreter in tests/emu uses). */
+int         svt_hip_selftest(uint32_t *results /* device, 64*8 u32 */, void *stream);
+
+/* VALU issue-rate probe (kind: 0 v_sad_u8, 1 v_qsad_pk_u16_u8, 2 v_add/xor pair, 3 v_mul_lo_u32+add, 4 v_mad_i64_i32,
+ * 5 v_alignbyte): each of blocks*256 lanes issues iters*8 independent ops.  Used by bench.py --probe. */
+void        svt_hip_rate_probe(int kind, uint32_t iters, uint32_t blocks, uint32_t *sink, void *stream);
+
+/* ---------------------------------------------------------------- SAD family (a1-a6) -------------- */
+/* a1. svt_nxm_sad_kernel -> svt_nxm_sad_kernel_helper_c (Source/Lib/C_DEFAULT/compute_sad_c.c:209, body :20-37) */
+uint32_t svt_nxm_sad_kernel_hip(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
+                                uint32_t height, uint32_t width);
+/*     svt_aom_sad_16b_kernel_c (compute_sad_c.c:39-56) */
+uint32_t svt_aom_sad_16b_kernel_hip(uint16_t *src, uint32_t src_stride, uint16_t *ref, uint32_t ref_stride,
+                                    uint32_t height, uint32_t width);
+/*     svt_aom_sad{W}x{H}_c / x4d (compute_sad_c.c:117-131): generic-size forms; the 22 fixed-size symbols
+ *     svt_aom_sadWxH_hip / svt_aom_sadWxHx4d_hip are generated from these in sad.hip. */
+uint32_t svt_aom_sad_wxh_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int w, int h);
+void     svt_aom_sad_wxh_x4d_hip(const uint8_t *src, int src_stride, const uint8_t *const ref_array[4], int ref_stride,
+                                 uint32_t *sad_array, int w, int h);
+
+/* a2. svt_sad_loop_kernel -> svt_sad_loop_kernel_c (compute_sad_c.c:58-100) */
+void svt_sad_loop_kernel_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height,
+                             uint32_t block_width, uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center,
+                             uint32_t src_stride_raw, uint8_t skip_search_line, int16_t search_area_width,
+                             int16_t search_area_height);
+
+/* a3. svt_ext_all_sad_calculation_8x8_16x16 -> _c (Source/Lib/Codec/motion_estimation.c:335-362) */
+void svt_ext_all_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride,
+                                               uint32_t mv, uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16,
+                                               uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16,
+                                               uint32_t p_eight_sad16x16[16][8], uint32_t p_eight_sad8x8[64][8],
+                                               bool sub_sad);
+/* a4. svt_ext_eight_sad_calculation_32x32_64x64 -> _c (motion_estimation.c:369-425) */
+void svt_ext_eight_sad_calculation_32x32_64x64_hip(uint32_t p_sad16x16[16][8], uint32_t *p_best_sad_32x32,
+                                                   uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32,
+                                                   uint32_t *p_best_mv64x64, uint32_t mv, uint32_t p_sad32x32[4][8]);
+/* a5. svt_ext_sad_calculation_8x8_16x16 -> _c (motion_estimation.c:98-164), ..._32x32_64x64 -> _c (:171-205) */
+void svt_ext_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride,
+                                           uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8,
+                                           uint32_t *p_best_mv16x16, uint32_t mv, uint32_t *p_sad16x16,
+                                           uint32_t *p_sad8x8, bool sub_sad);
+void svt_ext_sad_calculation_32x32_64x64_hip(uint32_t *p_sad16x16, uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64,
+                                             uint32_t *p_best_mv32x32, uint32_t *p_best_mv64x64, uint32_t mv,
+                                             uint32_t *p_sad32x32);
+/* a6. svt_initialize_buffer_32bits -> _c (Source/Lib/Codec/me_sad_calculation.c:14-17) */
+void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value);
+
+/* ---- batched forms (device pointers) ---- */
+typedef struct SvtHipSadPair {
+    uint64_t src_off;    /* byte offset of the block's top-left sample from src_base */
+    uint64_t ref_off;    /* same, from ref_base */
+    uint32_t src_stride; /* bytes */
+    uint32_t ref_stride;
+} SvtHipSadPair;
+/* n independent WxH SADs (a1 batched; BASELINE config 1 = 64x64 over all co-located SBs). sad_out[n]. */
+void svt_hip_sad_nxm_batch(const uint8_t *src_base, const uint8_t *ref_base, const SvtHipSadPair *pairs, uint32_t n,
+                           uint32_t width, uint32_t height, uint32_t *sad_out, void *stream);
+
+typedef struct SvtHipSadLoopDesc {
+    uint64_t src_off, ref_off;
+    uint32_t src_stride, ref_stride, src_stride_raw;
+    uint16_t block_width, block_height;
+    int16_t  search_area_width, search_area_height;
+    uint8_t  skip_search_line, pad[3];
+} SvtHipSadLoopDesc;
+typedef struct SvtHipSadLoopResult {
+    uint64_t best_sad;
+    int16_t  x_search_center, y_search_center;
+    uint32_t valid; /* 0 when the search area was empty (reference leaves x/y untouched, best_sad = 0xffffff) */
+} SvtHipSadLoopResult;
+/* n exhaustive searches (a2 batched: pre-HME / HME level 0-2 of every SB). `keys` = device scratch, n*8 bytes. */
+void svt_hip_sad_loop_batch(const uint8_t *src_base, const uint8_t *ref_base, const SvtHipSadLoopDesc *descs, uint32_t n,
+                            SvtHipSadLoopResult *results, uint64_t *keys, void *stream);
+
+/* Frame-batched integer full-pel search = open_loop_me_fullpel_search_sblock (motion_estimation.c:781-816), i.e.
+ * a3+a4+a5+a6 fused: for every (64x64 SB, reference) item, all 85 block SADs (8x8..64x64) at every position of the
+ * search area, keeping the first minimum in raster order (strict `<`), bests initialised to MAX_SAD_VALUE
+ * (motion_estimation.h:85).  Output layout per item = p_sb_best_sad / p_sb_best_mv[85]: 64x64 @0, 32x32 @1-4,
+ * 16x16 @5-20, 8x8 @21-84 (me_context.h:52-138); mv = (y << 16) | (uint16_t)x (motion_estimation.c:448-450). */
+typedef struct SvtHipMeSearchDesc {
+    uint64_t src_off;              /* me_ctx->b64_src_ptr relative to src_base */
+    uint64_t ref_off;              /* top-left sample of the search area relative to ref_base */
+    uint32_t src_stride;           /* me_ctx->b64_src_stride */
+    uint32_t ref_stride;           /* interpolated_full_stride[list][ref] */
+    int16_t  x_search_area_origin; /* added to the x index to form the MV */
+    int16_t  y_search_area_origin;
+    uint16_t search_area_width;
+    uint16_t search_area_height;
+} SvtHipMeSearchDesc;
+#define SVT_HIP_ME_NUM_BLOCKS 85
+/* bytes of device scratch needed for n items whose largest search area is max_w x max_h (0 for areas <= 64x32) */
+size_t svt_hip_me_fullpel_search_workspace(uint32_t n, uint32_t max_w, uint32_t max_h);
+void   svt_hip_me_fullpel_search_batch(const uint8_t *src_base, const uint8_t *ref_base, const SvtHipMeSearchDesc *descs,
+                                       uint32_t n, uint32_t max_w, uint32_t max_h, int sub_sad, uint32_t *best_sad,
+                                       uint32_t *best_mv, void *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVTAV1_HIP_H */

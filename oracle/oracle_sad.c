@@ -1,0 +1,191 @@
+/*
+ * oracle_sad.c -- TEST INFRASTRUCTURE: plain-C restatement of the reference's SAD family, used only as the checker
+ * in tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing in the product links or loads this.
+ *
+ * Each function restates the algorithm of the reference function cited above it (paths relative to
+ * /root/reference/Source/Lib).  Parity of this restatement is pinned in tests/test_oracle_pin.py against
+ *   (a) oracle/_ref/libsvtref.so = the reference's own `*_c` functions compiled from the mounted sources, and
+ *   (b) golden vectors under tests/golden/ produced by (a) with tools/gen_golden.py.
+ */
+#include <stdint.h>
+#include <string.h>
+
+#define MAX_SAD_VALUE (128 * 128 * 255) /* Codec/motion_estimation.h:85 */
+
+static inline uint32_t absd(int a, int b) { return (uint32_t)(a > b ? a - b : b - a); }
+
+/* C_DEFAULT/compute_sad_c.c:20-37 (svt_fast_loop_nxm_sad_kernel) == :209 svt_nxm_sad_kernel_helper_c
+ * and the sadMxN macro family (:104-120). */
+uint32_t oracle_sad_nxm(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height,
+                        uint32_t width) {
+    uint32_t sad = 0;
+    for (uint32_t y = 0; y < height; y++)
+        for (uint32_t x = 0; x < width; x++) sad += absd(src[y * src_stride + x], ref[y * ref_stride + x]);
+    return sad;
+}
+
+/* C_DEFAULT/compute_sad_c.c:39-56 (svt_aom_sad_16b_kernel_c) */
+uint32_t oracle_sad_16b(const uint16_t *src, uint32_t src_stride, const uint16_t *ref, uint32_t ref_stride, uint32_t height,
+                        uint32_t width) {
+    uint32_t sad = 0;
+    for (uint32_t y = 0; y < height; y++)
+        for (uint32_t x = 0; x < width; x++) sad += absd(src[y * src_stride + x], ref[y * ref_stride + x]);
+    return sad;
+}
+
+/* C_DEFAULT/compute_sad_c.c:58-100 (svt_sad_loop_kernel_c): exhaustive search, raster order, strict '<',
+ * best initialised to 0xffffff, even search lines skipped when (width == 16 && height <= 16 && skip_search_line). */
+void oracle_sad_loop(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t block_height,
+                     uint32_t block_width, uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center,
+                     uint32_t src_stride_raw, uint8_t skip_search_line, int16_t search_area_width, int16_t search_area_height) {
+    *best_sad = 0xffffff;
+    for (int yy = 0; yy < search_area_height; yy++) {
+        const uint8_t *line = ref + (size_t)yy * src_stride_raw;
+        if (block_width == 16 && block_height <= 16 && skip_search_line && (yy & 1) == 0) continue;
+        for (int xx = 0; xx < search_area_width; xx++) {
+            uint32_t sad = 0;
+            for (uint32_t y = 0; y < block_height; y++)
+                for (uint32_t x = 0; x < block_width; x++) sad += absd(src[y * src_stride + x], line[xx + y * ref_stride + x]);
+            if (sad < *best_sad) {
+                *best_sad        = sad;
+                *x_search_center = (int16_t)xx;
+                *y_search_center = (int16_t)yy;
+            }
+        }
+    }
+}
+
+/* 8x8 SAD, or 8x4 on the even rows doubled when sub_sad (Codec/motion_estimation.c:36-95, :105-126) */
+static uint32_t sad8x8(const uint8_t *s, uint32_t ss, const uint8_t *r, uint32_t rs, int sub_sad) {
+    uint32_t sad = 0;
+    for (int y = 0; y < 8; y += sub_sad ? 2 : 1)
+        for (int x = 0; x < 8; x++) sad += absd(s[y * ss + x], r[y * rs + x]);
+    return sub_sad ? sad << 1 : sad;
+}
+
+static inline uint32_t pack_mv(int x, int y) { return ((uint32_t)(uint16_t)(int16_t)y << 16) | (uint16_t)(int16_t)x; }
+
+/* The reference numbers the 64 8x8 blocks of a 64x64 SB in Z order: block index = 4 * (16x16 index) + (dy * 2 + dx),
+ * and the 16 16x16 blocks themselves in Z order inside the 4 32x32 (offsets table, motion_estimation.c:341). */
+static inline int z8(int bx, int by) { /* bx,by in 0..7 -> p_best_sad_8x8 index */
+    return (bx & 1) | ((by & 1) << 1) | (((bx >> 1) & 1) << 2) | (((by >> 1) & 1) << 3) | ((bx >> 2) << 4) | ((by >> 2) << 5);
+}
+
+/* Codec/motion_estimation.c:781-816 (open_loop_me_fullpel_search_sblock) driving :429-474 (eight positions:
+ * svt_ext_all_sad_calculation_8x8_16x16_c :335-362 + svt_ext_eight_sad_calculation_32x32_64x64_c :369-425) and
+ * :476-779 (single position).  Both paths update the same per-block bests with strict '<' while positions are
+ * visited in raster order, so the result is the first raster-order minimum per block.
+ * Output layout: [0] 64x64, [1..4] 32x32, [5..20] 16x16, [21..84] 8x8 (me_context.h ME_TIER_ZERO_PU_*). */
+void oracle_me_fullpel_search(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, int x_origin,
+                              int y_origin, int width, int height, int sub_sad, uint32_t *best_sad /*85*/,
+                              uint32_t *best_mv /*85*/) {
+    for (int i = 0; i < 85; i++) { /* svt_initialize_buffer_32bits(p_sb_best_sad, 21, 1, MAX_SAD_VALUE), :1366 */
+        best_sad[i] = MAX_SAD_VALUE;
+        best_mv[i]  = 0;
+    }
+    for (int yy = 0; yy < height; yy++)
+        for (int xx = 0; xx < width; xx++) {
+            const uint8_t *r  = ref + (size_t)yy * ref_stride + xx;
+            const uint32_t mv = pack_mv(xx + x_origin, yy + y_origin);
+            uint32_t       s16[16], s32[4], s64 = 0;
+            memset(s16, 0, sizeof(s16));
+            memset(s32, 0, sizeof(s32));
+            for (int by = 0; by < 8; by++)
+                for (int bx = 0; bx < 8; bx++) {
+                    const int      i8 = z8(bx, by);
+                    const uint32_t v  = sad8x8(src + by * 8 * src_stride + bx * 8, src_stride, r + by * 8 * ref_stride + bx * 8,
+                                               ref_stride, sub_sad);
+                    s16[i8 >> 2] += v;
+                    if (v < best_sad[21 + i8]) { best_sad[21 + i8] = v; best_mv[21 + i8] = mv; }
+                }
+            for (int i = 0; i < 16; i++) {
+                s32[i >> 2] += s16[i];
+                if (s16[i] < best_sad[5 + i]) { best_sad[5 + i] = s16[i]; best_mv[5 + i] = mv; }
+            }
+            for (int i = 0; i < 4; i++) {
+                s64 += s32[i];
+                if (s32[i] < best_sad[1 + i]) { best_sad[1 + i] = s32[i]; best_mv[1 + i] = mv; }
+            }
+            if (s64 < best_sad[0]) { best_sad[0] = s64; best_mv[0] = mv; }
+        }
+}
+
+/* Codec/motion_estimation.c:335-362 + :210-333 (svt_ext_all_sad_calculation_8x8_16x16_c): 8 consecutive x positions */
+void oracle_ext_all_sad_calculation_8x8_16x16(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
+                                              uint32_t mv, uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16,
+                                              uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t p_eight_sad16x16[16][8],
+                                              int sub_sad) {
+    const int16_t xm = (int16_t)(mv & 0xffff), ym = (int16_t)(mv >> 16);
+    for (int by = 0; by < 4; by++)
+        for (int bx = 0; bx < 4; bx++) {
+            const int i16 = z8(bx * 2, by * 2) >> 2;
+            for (int k = 0; k < 8; k++) {
+                uint32_t sum = 0;
+                for (int sub = 0; sub < 4; sub++) {
+                    const int      ox = bx * 16 + (sub & 1) * 8, oy = by * 16 + (sub >> 1) * 8;
+                    const uint32_t v  = sad8x8(src + oy * src_stride + ox, src_stride, ref + oy * ref_stride + ox + k, ref_stride, sub_sad);
+                    sum += v;
+                    if (v < p_best_sad_8x8[4 * i16 + sub]) {
+                        p_best_sad_8x8[4 * i16 + sub] = v;
+                        p_best_mv8x8[4 * i16 + sub]   = pack_mv(xm + k, ym);
+                    }
+                }
+                p_eight_sad16x16[i16][k] = sum;
+                if (sum < p_best_sad_16x16[i16]) {
+                    p_best_sad_16x16[i16] = sum;
+                    p_best_mv16x16[i16]   = pack_mv(xm + k, ym);
+                }
+            }
+        }
+}
+
+/* Codec/motion_estimation.c:369-425 (svt_ext_eight_sad_calculation_32x32_64x64_c) */
+void oracle_ext_eight_sad_calculation_32x32_64x64(uint32_t p_sad16x16[16][8], uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64,
+                                                  uint32_t *p_best_mv32x32, uint32_t *p_best_mv64x64, uint32_t mv,
+                                                  uint32_t p_sad32x32[4][8]) {
+    const int16_t xm = (int16_t)(mv & 0xffff), ym = (int16_t)(mv >> 16);
+    for (int k = 0; k < 8; k++) {
+        uint32_t s64 = 0;
+        for (int i = 0; i < 4; i++) {
+            const uint32_t v = p_sad16x16[4 * i][k] + p_sad16x16[4 * i + 1][k] + p_sad16x16[4 * i + 2][k] + p_sad16x16[4 * i + 3][k];
+            p_sad32x32[i][k] = v;
+            s64 += v;
+            if (v < p_best_sad_32x32[i]) { p_best_sad_32x32[i] = v; p_best_mv32x32[i] = pack_mv(xm + k, ym); }
+        }
+        if (s64 < p_best_sad_64x64[0]) { p_best_sad_64x64[0] = s64; p_best_mv64x64[0] = pack_mv(xm + k, ym); }
+    }
+}
+
+/* Codec/motion_estimation.c:98-164 (svt_ext_sad_calculation_8x8_16x16_c): one 16x16 block, one position */
+void oracle_ext_sad_calculation_8x8_16x16(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
+                                          uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8,
+                                          uint32_t *p_best_mv16x16, uint32_t mv, uint32_t *p_sad16x16, uint32_t *p_sad8x8, int sub_sad) {
+    uint32_t sum = 0;
+    for (int sub = 0; sub < 4; sub++) {
+        const int ox = (sub & 1) * 8, oy = (sub >> 1) * 8;
+        p_sad8x8[sub] = sad8x8(src + oy * src_stride + ox, src_stride, ref + oy * ref_stride + ox, ref_stride, sub_sad);
+        sum += p_sad8x8[sub];
+        if (p_sad8x8[sub] < p_best_sad_8x8[sub]) { p_best_sad_8x8[sub] = p_sad8x8[sub]; p_best_mv8x8[sub] = mv; }
+    }
+    if (sum < p_best_sad_16x16[0]) { p_best_sad_16x16[0] = sum; p_best_mv16x16[0] = mv; }
+    *p_sad16x16 = sum;
+}
+
+/* Codec/motion_estimation.c:171-205 (svt_ext_sad_calculation_32x32_64x64_c) */
+void oracle_ext_sad_calculation_32x32_64x64(const uint32_t *p_sad16x16, uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64,
+                                            uint32_t *p_best_mv32x32, uint32_t *p_best_mv64x64, uint32_t mv, uint32_t *p_sad32x32) {
+    uint32_t s64 = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t v = p_sad16x16[4 * i] + p_sad16x16[4 * i + 1] + p_sad16x16[4 * i + 2] + p_sad16x16[4 * i + 3];
+        p_sad32x32[i] = v;
+        s64 += v;
+        if (v < p_best_sad_32x32[i]) { p_best_sad_32x32[i] = v; p_best_mv32x32[i] = mv; }
+    }
+    if (s64 < p_best_sad_64x64[0]) { p_best_sad_64x64[0] = s64; p_best_mv64x64[0] = mv; }
+}
+
+/* Codec/me_sad_calculation.c:14-17 (svt_initialize_buffer_32bits_c) */
+void oracle_initialize_buffer_32bits(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value) {
+    const uint32_t n = count128 * 4 + count32;
+    for (uint32_t i = 0; i < n; i++) pointer[i] = value;
+}

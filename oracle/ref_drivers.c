@@ -1,0 +1,70 @@
+/*
+ * ref_drivers.c -- TEST INFRASTRUCTURE.  Drives the REAL reference kernels (function pointers resolved from
+ * oracle/_ref/libsvtref.so by the caller) in the same order the reference's own static driver functions do, so that
+ * the oracle restatement can be pinned against "the reference run here" for paths whose driver is `static` in the
+ * reference and therefore not callable by symbol.
+ */
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef void (*ExtAllFn)(uint8_t *, uint32_t, uint8_t *, uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t[16][8],
+                         uint32_t[64][8], bool);
+typedef void (*ExtEightFn)(uint32_t[16][8], uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t[4][8]);
+typedef void (*ExtOne816Fn)(uint8_t *, uint32_t, uint8_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *,
+                            uint32_t *, bool);
+typedef void (*ExtOne3264Fn)(uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *);
+
+/* Sequence of Codec/motion_estimation.c:781-816 (open_loop_me_fullpel_search_sblock): groups of 8 x-positions through
+ * :429-474, remainder columns one at a time through :476-779 (16 calls in the 16x16 order 0,1,4,5,2,3,6,7,8,9,12,13,10,
+ * 11,14,15 then the 32x32/64x64 call).  Result layout as p_sb_best_sad/mv[85] (me_context.h). */
+void oracle_drive_ref_me_search(ExtAllFn all, ExtEightFn eight, ExtOne816Fn one816, ExtOne3264Fn one3264, uint8_t *src,
+                                uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, int x_origin, int y_origin, int width, int height,
+                                int sub_sad, uint32_t *best_sad, uint32_t *best_mv) {
+    uint32_t        eight16[16][8], eight8[64][8], eight32[4][8]; /* stack: the driver is called from several threads */
+    uint32_t        sad16[16], sad8[64], sad32[4];
+    for (int i = 0; i < 85; i++) { best_sad[i] = 128 * 128 * 255; best_mv[i] = 0; }
+    uint32_t *b64 = best_sad, *b32 = best_sad + 1, *b16 = best_sad + 5, *b8 = best_sad + 21;
+    uint32_t *m64 = best_mv, *m32 = best_mv + 1, *m16 = best_mv + 5, *m8 = best_mv + 21;
+    static const int order[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+    const int w8 = width & ~7;
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < w8; x += 8) {
+            const uint32_t mv = ((uint32_t)(y + y_origin) << 16) | (uint16_t)(x + x_origin);
+            all(src, src_stride, ref + y * ref_stride + x, ref_stride, mv, b8, b16, m8, m16, eight16, eight8, sub_sad != 0);
+            eight(eight16, b32, b64, m32, m64, mv, eight32);
+        }
+        for (int x = w8; x < width; x++) {
+            const uint32_t mv = ((uint32_t)(y + y_origin) << 16) | (uint16_t)(x + x_origin);
+            for (int by = 0; by < 4; by++)
+                for (int bx = 0; bx < 4; bx++) {
+                    const int i = order[by * 4 + bx];
+                    one816(src + by * 16 * src_stride + bx * 16, src_stride, ref + (y + by * 16) * ref_stride + x + bx * 16, ref_stride,
+                           &b8[4 * i], &b16[i], &m8[4 * i], &m16[i], mv, &sad16[i], &sad8[4 * i], sub_sad != 0);
+                }
+            one3264(sad16, b32, b64, m32, m64, mv, sad32);
+        }
+    }
+}
+
+/* Many (SB, ref) items in one call (bench.py cpu_baseline: no Python in the timed loop).  Items idx0, idx0+step, ...
+ * of the n descriptors are searched `repeat` times; returns the number of SB-ref searches done. */
+typedef struct {
+    uint64_t src_off, ref_off;
+    uint32_t src_stride, ref_stride;
+    int16_t  x_origin, y_origin;
+    uint16_t width, height;
+} OracleMeDesc; /* same layout as SvtHipMeSearchDesc */
+uint64_t oracle_drive_ref_me_search_many(ExtAllFn all, ExtEightFn eight, ExtOne816Fn one816, ExtOne3264Fn one3264, uint8_t *src_base,
+                                         uint8_t *ref_base, const OracleMeDesc *d, uint32_t n, uint32_t idx0, uint32_t step, uint32_t repeat,
+                                         int sub_sad, uint32_t *best_sad, uint32_t *best_mv) {
+    uint64_t done = 0;
+    for (uint32_t r = 0; r < repeat; r++)
+        for (uint32_t i = idx0; i < n; i += step) {
+            oracle_drive_ref_me_search(all, eight, one816, one3264, src_base + d[i].src_off, d[i].src_stride, ref_base + d[i].ref_off,
+                                       d[i].ref_stride, d[i].x_origin, d[i].y_origin, d[i].width, d[i].height, sub_sad,
+                                       best_sad + (size_t)i * 85, best_mv + (size_t)i * 85);
+            done++;
+        }
+    return done;
+}

@@ -1,0 +1,116 @@
+"""svt-av1-psy_amd -- host-side binding of libsvtav1_hip.so (MI355X / gfx950 variant of SVT-AV1-PSY's block-DSP hot path).
+
+The product is the C-ABI shared library declared in ``include/svtav1_hip.h``; the reference's host code is C and binds
+it through its RTCD function-pointer table.  This module is the thin ctypes mirror used by
+``bench.py``, ``__graft_entry__.py`` and the tests: it loads the library, declares every prototype, and offers
+numpy/torch-friendly descriptors.  It has NO CPU implementation: if the HIP library is missing or no GPU is present,
+``load()`` raises / the library aborts -- nothing silently falls back.
+
+The directory name contains a hyphen (it mirrors the reference's name), so import it with
+``importlib`` -- see ``tests/conftest.py::load_pkg``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvtav1_hip.so")
+ME_NUM_BLOCKS = 85
+MAX_SAD_VALUE = 128 * 128 * 255
+
+u8p, u16p, u32p, u64p, i16p, i32p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64, C.c_int16, C.c_int32))
+vp = C.c_void_p
+
+# numpy views of the descriptor structs of include/svtav1_hip.h
+SadPair = np.dtype([("src_off", "<u8"), ("ref_off", "<u8"), ("src_stride", "<u4"), ("ref_stride", "<u4")])
+SadLoopDesc = np.dtype([("src_off", "<u8"), ("ref_off", "<u8"), ("src_stride", "<u4"), ("ref_stride", "<u4"),
+                        ("src_stride_raw", "<u4"), ("block_width", "<u2"), ("block_height", "<u2"),
+                        ("search_area_width", "<i2"), ("search_area_height", "<i2"), ("skip_search_line", "u1"),
+                        ("pad", "u1", (3,))], align=True)
+SadLoopResult = np.dtype([("best_sad", "<u8"), ("x", "<i2"), ("y", "<i2"), ("valid", "<u4")])
+MeSearchDesc = np.dtype([("src_off", "<u8"), ("ref_off", "<u8"), ("src_stride", "<u4"), ("ref_stride", "<u4"),
+                         ("x_origin", "<i2"), ("y_origin", "<i2"), ("width", "<u2"), ("height", "<u2")])
+assert SadPair.itemsize == 24 and SadLoopDesc.itemsize == 40 and SadLoopResult.itemsize == 16 and MeSearchDesc.itemsize == 32
+
+# symbol -> (restype, argtypes); everything include/svtav1_hip.h declares must be listed here (tests check both ways)
+PROTOTYPES = {
+    "svt_hip_init": (C.c_int, [C.c_int]),
+    "svt_hip_shutdown": (None, []),
+    "svt_hip_device_name": (C.c_char_p, []),
+    "svt_hip_setup_rtcd": (C.c_int, [C.c_uint64]),
+    "svt_hip_selftest": (C.c_int, [vp, vp]),
+    "svt_hip_rate_probe": (None, [C.c_int, C.c_uint32, C.c_uint32, vp, vp]),
+    # SAD family
+    "svt_nxm_sad_kernel_hip": (C.c_uint32, [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svt_aom_sad_16b_kernel_hip": (C.c_uint32, [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svt_aom_sad_wxh_hip": (C.c_uint32, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
+    "svt_aom_sad_wxh_x4d_hip": (None, [vp, C.c_int, C.POINTER(vp), C.c_int, vp, C.c_int, C.c_int]),
+    "svt_sad_loop_kernel_hip": (None, [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, u64p, i16p, i16p, C.c_uint32,
+                                       C.c_uint8, C.c_int16, C.c_int16]),
+    "svt_ext_all_sad_calculation_8x8_16x16_hip": (None, [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_bool]),
+    "svt_ext_eight_sad_calculation_32x32_64x64_hip": (None, [vp, vp, vp, vp, vp, C.c_uint32, vp]),
+    "svt_ext_sad_calculation_8x8_16x16_hip": (None, [vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_bool]),
+    "svt_ext_sad_calculation_32x32_64x64_hip": (None, [vp, vp, vp, vp, vp, C.c_uint32, vp]),
+    "svt_initialize_buffer_32bits_hip": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svt_hip_sad_nxm_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
+    "svt_hip_sad_loop_batch": (None, [vp, vp, vp, C.c_uint32, vp, vp, vp]),
+    "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svt_hip_me_fullpel_search_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp, vp]),
+}
+for _m, _n in [(128, 128), (128, 64), (64, 128), (64, 64), (64, 32), (32, 64), (32, 32), (32, 16), (16, 32), (16, 16), (16, 8),
+               (8, 16), (8, 8), (8, 4), (4, 8), (4, 4), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]:
+    PROTOTYPES["svt_aom_sad%dx%d_hip" % (_m, _n)] = (C.c_uint32, [vp, C.c_int, vp, C.c_int])
+    PROTOTYPES["svt_aom_sad%dx%dx4d_hip" % (_m, _n)] = (None, [vp, C.c_int, C.POINTER(vp), C.c_int, vp])
+
+
+def bind(lib):
+    """Declare argtypes/restype on a loaded library (the product .so, or the test-only emulated build)."""
+    missing = []
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            f = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        f.restype = res
+        f.argtypes = args
+    if missing:
+        raise RuntimeError("libsvtav1_hip: missing symbols: " + ", ".join(missing))
+    return lib
+
+
+_lib = None
+
+
+def load(init_device=None):
+    """Load libsvtav1_hip.so (built in-tree by ``__graft_entry__.build()``).  Fails loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        _lib = bind(C.CDLL(LIB_PATH))
+    if init_device is not None:
+        if _lib.svt_hip_init(int(init_device)) != 0:
+            raise RuntimeError("svt_hip_init(%d) failed: no usable HIP device; libsvtav1_hip has no CPU path" % init_device)
+    return _lib
+
+
+def me_descs_for_frame(width, height, stride, org_x, org_y, area_w, area_h, plane_bytes, n_refs=1, src_plane=0, ref_plane0=0,
+                       sb=64):
+    """Descriptor table for config 2 of BASELINE.json: every 64x64 SB of one padded luma plane against ``n_refs``
+    reference planes, fixed search area ``area_w x area_h`` centred on the co-located block, exactly the operands
+    open_loop_me_fullpel_search_sblock (motion_estimation.c:781) receives for a (0,0) search centre."""
+    sbs_x, sbs_y = (width + sb - 1) // sb, (height + sb - 1) // sb
+    d = np.zeros(sbs_x * sbs_y * n_refs, dtype=MeSearchDesc)
+    xo, yo = -(area_w >> 1), -(area_h >> 1)
+    i = 0
+    for r in range(n_refs):
+        for sy in range(sbs_y):
+            for sx in range(sbs_x):
+                px, py = org_x + sx * sb, org_y + sy * sb
+                d[i] = (src_plane * plane_bytes + py * stride + px,
+                        (ref_plane0 + r) * plane_bytes + (py + yo) * stride + (px + xo), stride, stride, xo, yo, area_w, area_h)
+                i += 1
+    return d

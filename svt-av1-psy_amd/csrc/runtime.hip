@@ -1,0 +1,195 @@
+// runtime.hip -- device binding, per-thread host-call context, instruction self-test.
+#include "svt_hip_common.h"
+#include "../../include/svtav1_hip.h"
+
+namespace svthip {
+
+static int  g_device      = -1;
+static bool g_initialised = false;
+static char g_name[256]   = "uninitialised";
+
+void ensure_device() {
+    if (!g_initialised) {
+        if (svt_hip_init(0) != 0) {
+            fprintf(stderr,
+                    "libsvtav1_hip: no usable HIP device (gfx950 expected). This library has no CPU path; "
+                    "use the reference's own C/AVX2 variants instead.\n");
+            abort();
+        }
+    }
+}
+
+static thread_local HostCall t_call;
+
+HostCall& host_call() {
+    ensure_device();
+    if (!t_call.stream) HIP_CHECK(hipStreamCreateWithFlags(&t_call.stream, hipStreamNonBlocking));
+    return t_call;
+}
+
+void HostCall::begin() {
+    dev_used = 0;
+    pin_used = 0;
+}
+void HostCall::reserve(size_t dev_bytes, size_t pin_bytes) {
+    dev_bytes += 4096;
+    pin_bytes += 4096;
+    if (dev_bytes > dev_cap) {
+        if (dev) HIP_CHECK(hipFree(dev));
+        dev_cap = align_up(dev_bytes * 2, 1 << 20);
+        HIP_CHECK(hipMalloc((void**)&dev, dev_cap));
+    }
+    if (pin_bytes > pin_cap) {
+        if (pin) HIP_CHECK(hipHostFree(pin));
+        pin_cap = align_up(pin_bytes * 2, 1 << 20);
+        HIP_CHECK(hipHostMalloc((void**)&pin, pin_cap, hipHostMallocDefault));
+    }
+}
+void* HostCall::dalloc(size_t bytes) {
+    size_t off = align_up(dev_used, 256);
+    if (off + bytes > dev_cap) {
+        fprintf(stderr, "libsvtav1_hip: host-call device arena overflow (%zu + %zu > %zu)\n", off, bytes, dev_cap);
+        abort();
+    }
+    dev_used = off + bytes;
+    return dev + off;
+}
+void* HostCall::palloc(size_t bytes) {
+    size_t off = align_up(pin_used, 64);
+    if (off + bytes > pin_cap) {
+        fprintf(stderr, "libsvtav1_hip: host-call pinned arena overflow\n");
+        abort();
+    }
+    pin_used = off + bytes;
+    return pin + off;
+}
+void HostCall::up2d(void* ddst, size_t dpitch, const void* hsrc, size_t spitch, size_t width_bytes, size_t rows) {
+    // pack through the pinned buffer so the device copy is one contiguous DMA
+    uint8_t* p = (uint8_t*)palloc(dpitch * rows);
+    for (size_t y = 0; y < rows; y++) memcpy(p + y * dpitch, (const uint8_t*)hsrc + y * spitch, width_bytes);
+    HIP_CHECK(hipMemcpyAsync(ddst, p, dpitch * rows, hipMemcpyHostToDevice, stream));
+}
+void HostCall::up(void* ddst, const void* hsrc, size_t bytes) {
+    uint8_t* p = (uint8_t*)palloc(bytes);
+    memcpy(p, hsrc, bytes);
+    HIP_CHECK(hipMemcpyAsync(ddst, p, bytes, hipMemcpyHostToDevice, stream));
+}
+void HostCall::down(void* hdst, const void* dsrc, size_t bytes) {
+    uint8_t* p = (uint8_t*)palloc(bytes);
+    HIP_CHECK(hipMemcpyAsync(p, dsrc, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    memcpy(hdst, p, bytes);
+}
+void HostCall::down2d(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch, size_t width_bytes, size_t rows) {
+    uint8_t* p = (uint8_t*)palloc(dpitch * rows);
+    HIP_CHECK(hipMemcpyAsync(p, dsrc, dpitch * rows, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for (size_t y = 0; y < rows; y++) memcpy((uint8_t*)hdst + y * hpitch, p + y * dpitch, width_bytes);
+}
+void HostCall::sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
+
+} // namespace svthip
+
+// ---------------------------------------------------------------------------------------------------------------
+// Instruction self-test: one wave executes each cross-lane / packed-byte primitive the kernels rely on and dumps
+// the results; tests/test_gpu_primitives.py compares them with the C models in tests/emu/hipemu.h, so that a wrong
+// reading of the ISA shows up as ONE named mismatch instead of as a parity failure deep inside a kernel.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void svt_hip_selftest_kernel(uint32_t* out) {
+    const int      l = threadIdx.x;
+    const uint32_t a = 0x01020304u * (uint32_t)(l + 1) + 0x9e3779b9u * (uint32_t)l;
+    const uint32_t b = 0x10305070u ^ (0x85ebca6bu * (uint32_t)(l + 3));
+    const uint64_t w = ((uint64_t)b << 32) | a;
+    out[0 * 64 + l]  = __builtin_amdgcn_sad_u8(a, b, 7u);
+    uint64_t q       = __builtin_amdgcn_qsad_pk_u16_u8(w, a ^ 0x55aa00ffu, 0x0001000200030004ull);
+    out[1 * 64 + l]  = (uint32_t)q;
+    out[2 * 64 + l]  = (uint32_t)(q >> 32);
+    out[3 * 64 + l]  = __builtin_amdgcn_alignbyte(b, a, (uint32_t)l);
+    out[4 * 64 + l]  = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)a, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+    out[5 * 64 + l]  = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)a, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+    out[6 * 64 + l]  = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)a, 0x124, 0xf, 0xf, false); // row_ror:4
+    out[7 * 64 + l]  = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)a, 0x128, 0xf, 0xf, false); // row_ror:8
+    out[8 * 64 + l]  = (uint32_t)__shfl_xor((int)a, 16);
+    out[9 * 64 + l]  = (uint32_t)__shfl_xor((int)a, 32);
+    out[10 * 64 + l] = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)a, 0x111, 0xf, 0xf, false); // row_shr:1
+    out[11 * 64 + l] = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)a, 0x101, 0xf, 0xf, false); // row_shl:1
+}
+
+// Instruction-rate probe (DESIGN.md "measured instruction rates"): every lane runs `iters` rounds of 8 independent
+// chains of one VALU opcode, so time / (iters * 8 * lanes) is that opcode's issue cost.
+template <int KIND> __global__ __launch_bounds__(256) void svt_hip_rate_kernel(uint32_t iters, uint32_t* sink) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t       a[8];
+    uint64_t       w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        a[i] = t * 2654435761u + i * 40503u;
+        w[i] = ((uint64_t)a[i] << 32) | (a[i] ^ 0x5bd1e995u);
+    }
+    const uint32_t k = t | 1u;
+    for (uint32_t it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (KIND == 0) a[i] = __builtin_amdgcn_sad_u8(a[i], k, a[i]);
+            if (KIND == 1) w[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[i], k, w[i]);
+            if (KIND == 2) a[i] = a[i] + (a[i] ^ k);
+            if (KIND == 3) a[i] = a[i] * k + 1u;
+            if (KIND == 4) w[i] = (uint64_t)((int64_t)(int32_t)a[i] * (int64_t)(int32_t)k + (int64_t)w[i]);
+            if (KIND == 5) a[i] = __builtin_amdgcn_alignbyte(a[i], k, a[i]);
+        }
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r ^= a[i] ^ (uint32_t)w[i] ^ (uint32_t)(w[i] >> 32);
+    if (r == 0x12345u) sink[0] = r;
+}
+
+extern "C" {
+
+void svt_hip_rate_probe(int kind, uint32_t iters, uint32_t blocks, uint32_t* sink, void* stream) {
+    svthip::ensure_device();
+    hipStream_t st = (hipStream_t)stream;
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(svt_hip_rate_kernel<0>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
+    case 1: hipLaunchKernelGGL(svt_hip_rate_kernel<1>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
+    case 2: hipLaunchKernelGGL(svt_hip_rate_kernel<2>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
+    case 3: hipLaunchKernelGGL(svt_hip_rate_kernel<3>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
+    case 4: hipLaunchKernelGGL(svt_hip_rate_kernel<4>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
+    default: hipLaunchKernelGGL(svt_hip_rate_kernel<5>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
+    }
+    SVT_LAUNCH_CHECK();
+}
+
+int svt_hip_init(int device) {
+    using namespace svthip;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -1;
+    if (device < 0 || device >= n) return -1;
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
+    snprintf(g_name, sizeof(g_name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    g_device      = device;
+    g_initialised = true;
+    return 0;
+}
+
+void svt_hip_shutdown(void) {
+    using namespace svthip;
+    if (t_call.dev) (void)hipFree(t_call.dev);
+    if (t_call.pin) (void)hipHostFree(t_call.pin);
+    if (t_call.stream) (void)hipStreamDestroy(t_call.stream);
+    t_call        = HostCall();
+    g_initialised = false;
+}
+
+const char* svt_hip_device_name(void) { return svthip::g_name; }
+
+int svt_hip_selftest(uint32_t* results, void* stream) {
+    svthip::ensure_device();
+    hipLaunchKernelGGL(svt_hip_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, results);
+    SVT_LAUNCH_CHECK();
+    return 0;
+}
+
+} // extern "C"

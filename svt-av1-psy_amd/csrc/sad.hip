@@ -1,0 +1,786 @@
+// sad.hip -- SAD family for gfx950.
+//
+//   me_fullpel_kernel : frame-batched integer full-pel search (open_loop_me_fullpel_search_sblock,
+//                       Source/Lib/Codec/motion_estimation.c:781-816 == a3+a4+a5+a6 fused).  One workgroup per
+//                       (64x64 SB, reference, <=64x32 search tile).  Lane = one 8x8 block (Morton order, which IS
+//                       the reference's p_best_sad_8x8 numbering), wave = one strip of 4 adjacent x positions.
+//                       The 8x8 source block lives in 16 VGPRs for the whole search, the reference window in LDS,
+//                       an 8-row register ring slides down the strip so each step costs ONE new 12-byte LDS row
+//                       and 16 v_qsad_pk_u16_u8 (4 positions x 64 |a-b| each).  16x16/32x32/64x64 SADs are
+//                       DPP quad / row-rotate / cross-row sums of the packed u16 lanes; "first minimum in raster
+//                       order" is a single v_min_u32 on (sad << 11 | tile_raster_index).
+//   sad_nxm_kernel    : n independent WxH SADs, one wave per pair, 16-byte loads (HBM bound).
+//   sad_loop_kernel   : generic exhaustive search (svt_sad_loop_kernel, HME levels), 4 positions per lane.
+//   ext_*             : single-call forms of the reference's ext_* pointers.
+#include "svt_hip_common.h"
+#include "../../include/svtav1_hip.h"
+#include <vector>
+
+namespace {
+
+struct __attribute__((packed, aligned(4))) U64A4 { unsigned long long v; }; // 8-byte LDS window, dword aligned
+struct __attribute__((aligned(4))) u32x4_a4 { uint32_t x, y, z, w; }; // 16-byte load that only promises dword alignment
+
+constexpr uint32_t MAX_SAD_VALUE = 128 * 128 * 255; // motion_estimation.h:85
+constexpr int      ME_TW         = 64;              // search tile, positions
+constexpr int      ME_TH         = 32;
+constexpr int      KEY_POS_BITS  = 11; // tile raster index: yl * 64 + xl < 2048
+
+// ---- helpers -------------------------------------------------------------------------------------------------
+// Copy rows x width bytes (arbitrary global alignment / stride) into LDS rows of pitch_dw dwords, zero padded.
+__device__ __forceinline__ void stage_rows_u8(uint32_t* lds, int pitch_dw, const uint8_t* g, uint32_t gstride, int width,
+                                              int rows, int tid, int nthreads) {
+    const int total = rows * pitch_dw;
+    for (int i = tid; i < total; i += nthreads) {
+        const int r   = i / pitch_dw;
+        const int k   = i - r * pitch_dw;
+        const int col = k * 4;
+        uint32_t  v   = 0;
+        if (col < width) {
+            const uint8_t*  p    = g + (size_t)r * gstride + col;
+            const uint32_t  sh   = (uint32_t)((uintptr_t)p & 3);
+            const uint32_t* ap   = (const uint32_t*)(p - sh);
+            const int       need = (width - col) < 4 ? (width - col) : 4;
+            const uint32_t  lo   = ap[0];
+            uint32_t        hi   = 0;
+            if ((int)sh + need > 4) hi = ap[1];
+            v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+            if (need < 4) v &= (1u << (8 * need)) - 1u;
+        }
+        lds[i] = v;
+    }
+}
+
+__device__ __forceinline__ uint32_t dpp_add_quad_xor1(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t dpp_add_quad_xor2(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t dpp_add_row_ror4(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t dpp_add_row_ror8(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// XCD-aware item order: hardware places workgroup b on XCD b % 8; give each XCD a contiguous run of items so
+// neighbouring superblocks (whose reference windows overlap) share one L2.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
+    const uint32_t per = n >> 3;
+    if (per == 0 || b >= per * 8) return b;
+    return (b & 7) * per + (b >> 3);
+}
+
+// ---- frame-batched integer full-pel ME search ---------------------------------------------------------------
+template <bool SUB>
+__global__ __launch_bounds__(256, 4) void me_fullpel_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                         const SvtHipMeSearchDesc* __restrict__ descs, uint32_t n,
+                                                         uint32_t tiles_x, int pitch_dw, int win_rows,
+                                                         uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv,
+                                                         unsigned long long* __restrict__ keys) {
+    HIP_DYNAMIC_SHARED(uint32_t, smem)
+    uint32_t* src_lds  = smem;             // 64 rows x 16 dwords
+    uint32_t* best_lds = smem + 64 * 16;   // 85 (+3 pad)
+    uint32_t* win      = smem + 64 * 16 + 88;
+
+    const int      tid  = threadIdx.x;
+    const uint32_t item = xcd_remap(blockIdx.x, n);
+    const uint32_t tile = blockIdx.y;
+    const SvtHipMeSearchDesc d = descs[item];
+    const int W   = d.search_area_width, H = d.search_area_height;
+    const int tx0 = (int)(tile % tiles_x) * ME_TW;
+    const int ty0 = (int)(tile / tiles_x) * ME_TH;
+    if (tx0 >= W || ty0 >= H) {
+        // empty tile; tile 0 of an empty search area still reports "nothing found"
+        if (tile == 0 && keys == nullptr && tid < SVT_HIP_ME_NUM_BLOCKS) {
+            best_sad[(size_t)item * SVT_HIP_ME_NUM_BLOCKS + tid] = MAX_SAD_VALUE;
+            best_mv[(size_t)item * SVT_HIP_ME_NUM_BLOCKS + tid]  = 0;
+        }
+        return;
+    }
+    const int Wt = (W - tx0) < ME_TW ? (W - tx0) : ME_TW;
+    const int Ht = (H - ty0) < ME_TH ? (H - ty0) : ME_TH;
+
+    stage_rows_u8(src_lds, 16, src_base + d.src_off, d.src_stride, 64, 64, tid, 256);
+    stage_rows_u8(win, pitch_dw, ref_base + d.ref_off + (size_t)ty0 * d.ref_stride + tx0, d.ref_stride, 64 + Wt - 1,
+                  64 + Ht - 1, tid, 256);
+    // rows the ring may touch beyond the staged ones do not exist: win_rows >= 64 + Ht - 1 always holds.
+    (void)win_rows;
+    if (tid < 88) best_lds[tid] = 0xffffffffu;
+    __syncthreads();
+
+    const int l  = tid & 63;
+    const int wv = tid >> 6;
+    const int bx = (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4);
+    const int by = ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4);
+    const int q  = l & 3;
+
+    uint32_t s[8][2];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        s[r][0] = src_lds[(by * 8 + r) * 16 + bx * 2 + 0];
+        s[r][1] = src_lds[(by * 8 + r) * 16 + bx * 2 + 1];
+    }
+
+    // keys: 8x8 -> (sad16 << 16) | pos   (one v_lshl_or / v_and_or per position, straight from the packed u16 lanes)
+    //       16x16/32x32/64x64 -> (sad << 11) | pos   (sad64 < 2^20, pos < 2^11)
+    uint32_t best8 = 0xffffffffu, best16 = 0xffffffffu, best32 = 0xffffffffu, best64 = 0xffffffffu;
+    const int      G    = (Wt + 3) >> 2;
+    const uint32_t qsh  = (uint32_t)(q & 1) * 16u;
+    const int      bp16 = (l ^ 16) << 2, bp32 = (l ^ 32) << 2; // ds_bpermute byte addresses of the partner rows
+    for (int g = wv; g < G; g += 4) {
+        const uint32_t* colp   = win + (by * 8) * pitch_dw + bx * 2 + g;
+        const int       nvalid = (Wt - 4 * g) < 4 ? (Wt - 4 * g) : 4;
+        // invalid positions (last strip when Wt % 4 != 0) are pushed to the top of the key space
+        const uint32_t inv1 = nvalid > 1 ? 0u : 0xffffffffu, inv2 = nvalid > 2 ? 0u : 0xffffffffu, inv3 = nvalid > 3 ? 0u : 0xffffffffu;
+        const uint32_t invq = q < nvalid ? 0u : 0xffffffffu;
+        // 8-row ring; each row is kept as the two overlapping 8-byte windows v_qsad_pk_u16_u8 consumes
+        U64A4 ra[8], rb[8];
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            ra[r] = *(const U64A4*)(colp + r * pitch_dw);
+            rb[r] = *(const U64A4*)(colp + r * pitch_dw + 1);
+        }
+        for (int yb = 0; yb < Ht; yb += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int y = yb + i;
+                if (y < Ht) {
+                    const uint32_t* np = colp + (y + 7) * pitch_dw;
+                    ra[(i + 7) & 7] = *(const U64A4*)(np);
+                    rb[(i + 7) & 7] = *(const U64A4*)(np + 1);
+                    unsigned long long acc = 0;
+#pragma unroll
+                    for (int r = 0; r < 8; r += (SUB ? 2 : 1)) {
+                        acc = __builtin_amdgcn_qsad_pk_u16_u8(ra[(i + r) & 7].v, s[r][0], acc);
+                        acc = __builtin_amdgcn_qsad_pk_u16_u8(rb[(i + r) & 7].v, s[r][1], acc);
+                    }
+                    if (SUB) acc <<= 1; // 8x4 on even rows, doubled (motion_estimation.c:105-126); u16 lanes cannot carry
+                    const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+                    const uint32_t pos = (uint32_t)(y * ME_TW + 4 * g);
+                    // 8x8: this lane's block, 4 positions
+                    best8 = umin32(best8, (lo << 16) | pos);
+                    best8 = umin32(best8, ((lo & 0xffff0000u) | (pos + 1)) | inv1);
+                    best8 = umin32(best8, ((hi << 16) | (pos + 2)) | inv2);
+                    best8 = umin32(best8, ((hi & 0xffff0000u) | (pos + 3)) | inv3);
+                    // 16x16 = the quad's four 8x8 (u16 lanes: 4 * 16320 < 65536, so plain adds never carry)
+                    const uint32_t tlo = dpp_add_quad_xor2(dpp_add_quad_xor1(lo));
+                    const uint32_t thi = dpp_add_quad_xor2(dpp_add_quad_xor1(hi));
+                    // lane q of the quad takes position q from here on
+                    const uint32_t sad16 = __builtin_amdgcn_ubfe((q & 2) ? thi : tlo, qsh, 16u);
+                    const uint32_t posq  = (pos + (uint32_t)q) | invq;
+                    best16 = umin32(best16, (sad16 << KEY_POS_BITS) | posq);
+                    // 32x32 = 4 quads of a 16-lane row; 64x64 = 4 rows
+                    const uint32_t sad32 = dpp_add_row_ror8(dpp_add_row_ror4(sad16));
+                    best32 = umin32(best32, (sad32 << KEY_POS_BITS) | posq);
+                    uint32_t sad64 = sad32 + (uint32_t)__builtin_amdgcn_ds_bpermute(bp16, (int)sad32);
+                    sad64 += (uint32_t)__builtin_amdgcn_ds_bpermute(bp32, (int)sad64);
+                    best64 = umin32(best64, (sad64 << KEY_POS_BITS) | posq);
+                }
+            }
+        }
+    }
+
+    atomicMin(&best_lds[21 + l], best8);
+    atomicMin(&best_lds[5 + (l >> 2)], best16);
+    atomicMin(&best_lds[1 + (l >> 4)], best32);
+    atomicMin(&best_lds[0], best64);
+    __syncthreads();
+    if (tid < SVT_HIP_ME_NUM_BLOCKS) {
+        const uint32_t key = best_lds[tid];
+        const uint32_t sad = tid >= 21 ? (key >> 16) : (key >> KEY_POS_BITS);
+        const int      X   = tx0 + (int)(key & 63u);
+        const int      Y   = ty0 + (int)((key >> 6) & 31u);
+        const size_t   o   = (size_t)item * SVT_HIP_ME_NUM_BLOCKS + tid;
+        if (keys == nullptr) {
+            best_sad[o] = sad;
+            best_mv[o]  = ((uint32_t)(uint16_t)(Y + d.y_search_area_origin) << 16) | (uint16_t)(X + d.x_search_area_origin);
+        } else {
+            atomicMin(&keys[o], ((unsigned long long)sad << 32) | (unsigned long long)(uint32_t)(Y * W + X));
+        }
+    }
+}
+
+__global__ void me_finalize_kernel(const SvtHipMeSearchDesc* __restrict__ descs, uint32_t n, const unsigned long long* __restrict__ keys,
+                                   uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * SVT_HIP_ME_NUM_BLOCKS) return;
+    const SvtHipMeSearchDesc d   = descs[i / SVT_HIP_ME_NUM_BLOCKS];
+    const unsigned long long key = keys[i];
+    if (key == ~0ull) {
+        best_sad[i] = MAX_SAD_VALUE;
+        best_mv[i]  = 0;
+        return;
+    }
+    const uint32_t pos = (uint32_t)key;
+    const int      W   = d.search_area_width;
+    const int      X = (int)(pos % (uint32_t)W), Y = (int)(pos / (uint32_t)W);
+    best_sad[i]        = (uint32_t)(key >> 32);
+    best_mv[i]         = ((uint32_t)(uint16_t)(Y + d.y_search_area_origin) << 16) | (uint16_t)(X + d.x_search_area_origin);
+}
+
+// ---- n independent WxH SADs: one wave per pair -----------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    v += (uint32_t)__shfl_xor((int)v, 32);
+    v += (uint32_t)__shfl_xor((int)v, 16);
+    v = dpp_add_row_ror8(v);
+    v = dpp_add_row_ror4(v);
+    v = dpp_add_quad_xor2(v);
+    v = dpp_add_quad_xor1(v);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void sad_nxm_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                      const SvtHipSadPair* __restrict__ pairs, uint32_t n, int width, int height,
+                                                      uint32_t* __restrict__ sad_out) {
+    const int      l    = threadIdx.x & 63;
+    const uint32_t pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= n) return;
+    const SvtHipSadPair p   = pairs[pair];
+    const uint8_t*      src = src_base + p.src_off;
+    const uint8_t*      ref = ref_base + p.ref_off;
+    uint32_t            sad = 0;
+    const bool fast = ((width & 15) == 0) && ((((uintptr_t)src | (uintptr_t)ref | p.src_stride | p.ref_stride) & 3) == 0);
+    if (fast) {
+        const int cpr   = width >> 4; // 16-byte chunks per row
+        const int total = cpr * height;
+        for (int i = l; i < total; i += 64) {
+            const int       r = i / cpr, c = i - r * cpr;
+            const u32x4_a4  a = *(const u32x4_a4*)(src + (size_t)r * p.src_stride + c * 16);
+            const u32x4_a4  b = *(const u32x4_a4*)(ref + (size_t)r * p.ref_stride + c * 16);
+            sad = __builtin_amdgcn_sad_u8(a.x, b.x, sad);
+            sad = __builtin_amdgcn_sad_u8(a.y, b.y, sad);
+            sad = __builtin_amdgcn_sad_u8(a.z, b.z, sad);
+            sad = __builtin_amdgcn_sad_u8(a.w, b.w, sad);
+        }
+    } else {
+        const int total = width * height;
+        for (int i = l; i < total; i += 64) {
+            const int r = i / width, c = i - r * width;
+            const int a = src[(size_t)r * p.src_stride + c], b = ref[(size_t)r * p.ref_stride + c];
+            sad += (uint32_t)(a > b ? a - b : b - a);
+        }
+    }
+    sad = wave_sum(sad);
+    if (l == 0) sad_out[pair] = sad;
+}
+
+__global__ __launch_bounds__(64) void sad_16b_kernel(const uint16_t* __restrict__ src, uint32_t src_stride, const uint16_t* __restrict__ ref,
+                                                     uint32_t ref_stride, int width, int height, uint32_t* __restrict__ out) {
+    const int l     = threadIdx.x;
+    uint32_t  sad   = 0;
+    const int total = width * height;
+    for (int i = l; i < total; i += 64) {
+        const int r = i / width, c = i - r * width;
+        const int a = src[(size_t)r * src_stride + c], b = ref[(size_t)r * ref_stride + c];
+        sad += (uint32_t)(a > b ? a - b : b - a);
+    }
+    sad = wave_sum(sad);
+    if (l == 0) out[0] = sad;
+}
+
+// ---- generic exhaustive search (svt_sad_loop_kernel) ----------------------------------------------------------
+// One workgroup = one (item, 64x16 position tile): 256 lanes = 16 x-groups of 4 positions x 16 rows.
+constexpr int SL_TW = 64, SL_TH = 16;
+__global__ __launch_bounds__(256) void sad_loop_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                       const SvtHipSadLoopDesc* __restrict__ descs, uint32_t tiles_x,
+                                                       unsigned long long* __restrict__ keys) {
+    HIP_DYNAMIC_SHARED(uint32_t, smem)
+    __shared__ unsigned long long wg_best;
+    const int               tid  = threadIdx.x;
+    const uint32_t          item = blockIdx.x, tile = blockIdx.y;
+    const SvtHipSadLoopDesc d    = descs[item];
+    const int W = d.search_area_width, H = d.search_area_height;
+    const int bw = d.block_width, bh = d.block_height;
+    const int tx0 = (int)(tile % tiles_x) * SL_TW, ty0 = (int)(tile / tiles_x) * SL_TH;
+    if (tx0 >= W || ty0 >= H) return;
+    const int Wt = (W - tx0) < SL_TW ? (W - tx0) : SL_TW;
+    const int Ht = (H - ty0) < SL_TH ? (H - ty0) : SL_TH;
+    const int src_pitch = (bw + 3) >> 2;                 // dwords
+    const int win_w     = bw + Wt - 1;                   // bytes actually read by the reference
+    const int win_pitch = ((bw + SL_TW + 3) >> 2) + 2;   // dwords (covers the 4-position over-read of the last group)
+    uint32_t* src_lds   = smem;
+    uint32_t* win       = smem + src_pitch * bh;
+    // source rows are src_stride apart; search rows advance by src_stride_raw, block rows by ref_stride
+    // (compute_sad_c.c:72-97: `ref += src_stride_raw` per search line, `ref[... + y * ref_stride ...]` per block line)
+    stage_rows_u8(src_lds, src_pitch, src_base + d.src_off, d.src_stride, bw, bh, tid, 256);
+    if (tid == 0) wg_best = ~0ull;
+    // window row index = search line yy (0..Ht-1) and block line y: address = (ty0+yy)*raw + y*ref_stride.
+    // When ref_stride == src_stride_raw (full SAD) rows coincide; otherwise (sub-sampled HME: ref_stride = 2*raw)
+    // they interleave, so stage per (yy, y) pair only when needed.  General and simple: stage Ht*bh rows.
+    const bool coincide = d.ref_stride == d.src_stride_raw;
+    const int  win_rows = coincide ? (Ht + bh - 1) : Ht * bh;
+    if (coincide) {
+        stage_rows_u8(win, win_pitch, ref_base + d.ref_off + (size_t)ty0 * d.src_stride_raw + tx0, d.src_stride_raw, win_w,
+                      win_rows, tid, 256);
+    } else {
+        for (int yy = 0; yy < Ht; yy++)
+            stage_rows_u8(win + yy * bh * win_pitch, win_pitch,
+                          ref_base + d.ref_off + (size_t)(ty0 + yy) * d.src_stride_raw + tx0, d.ref_stride, win_w, bh, tid, 256);
+    }
+    __syncthreads();
+
+    const int gx = tid & 15, yy = tid >> 4;
+    const bool skip_rule = (bw == 16) && (bh <= 16) && d.skip_search_line; // compute_sad_c.c:74-79: even lines skipped
+    unsigned long long best = ~0ull;
+    if (yy < Ht && 4 * gx < Wt && !(skip_rule && (((ty0 + yy) & 1) == 0))) {
+        uint32_t sad[4] = {0, 0, 0, 0};
+        const int full_dw = bw >> 2, tail = bw & 3;
+        for (int y = 0; y < bh; y++) {
+            const uint32_t* rrow = win + (coincide ? (yy + y) : (yy * bh + y)) * win_pitch + gx;
+            const uint32_t* srow = src_lds + y * src_pitch;
+            unsigned long long acc = 0;
+            uint32_t prev = rrow[0];
+            for (int k = 0; k < full_dw; k++) {
+                const uint32_t next = rrow[k + 1];
+                acc  = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)next << 32) | prev, srow[k], acc);
+                prev = next;
+                if ((k & 15) == 15) { // flush before a u16 lane can overflow (64 bytes * 255 = 16320 per flush)
+                    sad[0] += (uint32_t)acc & 0xffffu; sad[1] += (uint32_t)(acc >> 16) & 0xffffu;
+                    sad[2] += (uint32_t)(acc >> 32) & 0xffffu; sad[3] += (uint32_t)(acc >> 48);
+                    acc = 0;
+                }
+            }
+            sad[0] += (uint32_t)acc & 0xffffu; sad[1] += (uint32_t)(acc >> 16) & 0xffffu;
+            sad[2] += (uint32_t)(acc >> 32) & 0xffffu; sad[3] += (uint32_t)(acc >> 48);
+            if (tail) {
+                const uint32_t mask = (1u << (8 * tail)) - 1u;
+                const uint32_t next = rrow[full_dw + 1];
+                const uint32_t sv   = srow[full_dw] & mask;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t rv = __builtin_amdgcn_alignbyte(next, prev, (uint32_t)j) & mask;
+                    sad[j]            = __builtin_amdgcn_sad_u8(rv, sv, sad[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int X = tx0 + 4 * gx + j;
+            if (4 * gx + j < Wt) {
+                const unsigned long long key = ((unsigned long long)sad[j] << 32) | (uint32_t)((ty0 + yy) * W + X);
+                best = key < best ? key : best;
+            }
+        }
+    }
+    atomicMin(&wg_best, best);
+    __syncthreads();
+    if (tid == 0 && wg_best != ~0ull) atomicMin(&keys[item], wg_best);
+}
+
+__global__ void sad_loop_finalize_kernel(const SvtHipSadLoopDesc* __restrict__ descs, uint32_t n, const unsigned long long* __restrict__ keys,
+                                         SvtHipSadLoopResult* __restrict__ res) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = keys[i];
+    SvtHipSadLoopResult      r;
+    const uint32_t sad = (uint32_t)(key >> 32);
+    // reference: *best_sad = 0xffffff, update only when sad < best (compute_sad_c.c:71,91)
+    if (key == ~0ull || sad >= 0xffffffu) {
+        r.best_sad = 0xffffff; r.x_search_center = 0; r.y_search_center = 0; r.valid = 0;
+    } else {
+        const uint32_t pos = (uint32_t)key, W = (uint32_t)descs[i].search_area_width;
+        r.best_sad = sad; r.x_search_center = (int16_t)(pos % W); r.y_search_center = (int16_t)(pos / W); r.valid = 1;
+    }
+    res[i] = r;
+}
+
+// ---- single-call ext_* kernels ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sad8x8_bytes(const uint8_t* s, uint32_t ss, const uint8_t* r, uint32_t rs, bool sub) {
+    uint32_t sad = 0;
+    for (int y = 0; y < 8; y += (sub ? 2 : 1))
+        for (int x = 0; x < 8; x++) {
+            const int a = s[y * ss + x], b = r[y * rs + x];
+            sad += (uint32_t)(a > b ? a - b : b - a);
+        }
+    return sub ? sad << 1 : sad;
+}
+// 512 threads: (8x8 block b8 in reference numbering, search_index p)
+__global__ __launch_bounds__(512) void ext_all_sad_kernel(const uint8_t* src, uint32_t ss, const uint8_t* ref, uint32_t rs, uint32_t mv,
+                                                          uint32_t* best8, uint32_t* best16, uint32_t* mv8, uint32_t* mv16,
+                                                          uint32_t* eight16 /*[16][8]*/, int sub) {
+    __shared__ uint32_t s8[64][8];
+    __shared__ uint32_t s16[16][8];
+    const int tid = threadIdx.x, b8 = tid >> 3, p = tid & 7;
+    const int bx = (b8 & 1) | ((b8 >> 1) & 2) | ((b8 >> 2) & 4), by = ((b8 >> 1) & 1) | ((b8 >> 2) & 2) | ((b8 >> 3) & 4);
+    s8[b8][p] = sad8x8_bytes(src + by * 8 * ss + bx * 8, ss, ref + by * 8 * rs + bx * 8 + p, rs, sub != 0);
+    __syncthreads();
+    if (tid < 128) {
+        const int i16 = tid >> 3;
+        const uint32_t v = s8[4 * i16][p] + s8[4 * i16 + 1][p] + s8[4 * i16 + 2][p] + s8[4 * i16 + 3][p];
+        s16[i16][p] = v;
+        eight16[i16 * 8 + p] = v;
+    }
+    __syncthreads();
+    const int16_t xm = (int16_t)(mv & 0xffff), ym = (int16_t)(mv >> 16);
+    if (tid < 64) {
+        uint32_t b = best8[tid], m = mv8[tid];
+        for (int k = 0; k < 8; k++)
+            if (s8[tid][k] < b) { b = s8[tid][k]; m = ((uint32_t)(uint16_t)ym << 16) | (uint16_t)(int16_t)(xm + k); }
+        best8[tid] = b; mv8[tid] = m;
+    } else if (tid < 80) {
+        const int i = tid - 64;
+        uint32_t  b = best16[i], m = mv16[i];
+        for (int k = 0; k < 8; k++)
+            if (s16[i][k] < b) { b = s16[i][k]; m = ((uint32_t)(uint16_t)ym << 16) | (uint16_t)(int16_t)(xm + k); }
+        best16[i] = b; mv16[i] = m;
+    }
+}
+__global__ __launch_bounds__(64) void ext_eight_32_64_kernel(const uint32_t* sad16 /*[16][8]*/, uint32_t* best32, uint32_t* best64,
+                                                             uint32_t* mv32, uint32_t* mv64, uint32_t mv, uint32_t* sad32 /*[4][8]*/) {
+    __shared__ uint32_t s32[4][8];
+    const int tid = threadIdx.x;
+    if (tid < 32) {
+        const int k = tid >> 3, p = tid & 7;
+        const uint32_t v = sad16[(4 * k) * 8 + p] + sad16[(4 * k + 1) * 8 + p] + sad16[(4 * k + 2) * 8 + p] + sad16[(4 * k + 3) * 8 + p];
+        s32[k][p] = v; sad32[k * 8 + p] = v;
+    }
+    __syncthreads();
+    const int16_t xm = (int16_t)(mv & 0xffff), ym = (int16_t)(mv >> 16);
+    if (tid < 4) {
+        uint32_t b = best32[tid], m = mv32[tid];
+        for (int k = 0; k < 8; k++)
+            if (s32[tid][k] < b) { b = s32[tid][k]; m = ((uint32_t)(uint16_t)ym << 16) | (uint16_t)(int16_t)(xm + k); }
+        best32[tid] = b; mv32[tid] = m;
+    } else if (tid == 4) {
+        uint32_t b = best64[0], m = mv64[0];
+        for (int k = 0; k < 8; k++) {
+            const uint32_t v = s32[0][k] + s32[1][k] + s32[2][k] + s32[3][k];
+            if (v < b) { b = v; m = ((uint32_t)(uint16_t)ym << 16) | (uint16_t)(int16_t)(xm + k); }
+        }
+        best64[0] = b; mv64[0] = m;
+    }
+}
+__global__ __launch_bounds__(64) void ext_one_8_16_kernel(const uint8_t* src, uint32_t ss, const uint8_t* ref, uint32_t rs, uint32_t* best8,
+                                                          uint32_t* best16, uint32_t* mv8, uint32_t* mv16, uint32_t mv, uint32_t* sad16,
+                                                          uint32_t* sad8, int sub) {
+    __shared__ uint32_t s[4];
+    const int tid = threadIdx.x;
+    if (tid < 4) {
+        const int      dx = (tid & 1) * 8, dy = (tid >> 1) * 8;
+        const uint32_t v  = sad8x8_bytes(src + dy * ss + dx, ss, ref + dy * rs + dx, rs, sub != 0);
+        s[tid] = v; sad8[tid] = v;
+        if (v < best8[tid]) { best8[tid] = v; mv8[tid] = mv; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t v = s[0] + s[1] + s[2] + s[3];
+        if (v < best16[0]) { best16[0] = v; mv16[0] = mv; }
+        sad16[0] = v;
+    }
+}
+__global__ __launch_bounds__(64) void ext_one_32_64_kernel(const uint32_t* sad16, uint32_t* best32, uint32_t* best64, uint32_t* mv32,
+                                                           uint32_t* mv64, uint32_t mv, uint32_t* sad32) {
+    __shared__ uint32_t s[4];
+    const int tid = threadIdx.x;
+    if (tid < 4) {
+        const uint32_t v = sad16[4 * tid] + sad16[4 * tid + 1] + sad16[4 * tid + 2] + sad16[4 * tid + 3];
+        s[tid] = v; sad32[tid] = v;
+        if (v < best32[tid]) { best32[tid] = v; mv32[tid] = mv; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t v = s[0] + s[1] + s[2] + s[3];
+        if (v < best64[0]) { best64[0] = v; mv64[0] = mv; }
+    }
+}
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t n, uint32_t v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+} // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+void svt_hip_sad_nxm_batch(const uint8_t* src_base, const uint8_t* ref_base, const SvtHipSadPair* pairs, uint32_t n, uint32_t width,
+                           uint32_t height, uint32_t* sad_out, void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    hipLaunchKernelGGL(sad_nxm_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src_base, ref_base, pairs, n, (int)width,
+                       (int)height, sad_out);
+    SVT_LAUNCH_CHECK();
+}
+
+void svt_hip_sad_loop_batch(const uint8_t* src_base, const uint8_t* ref_base, const SvtHipSadLoopDesc* descs, uint32_t n,
+                            SvtHipSadLoopResult* results, uint64_t* keys, void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    // geometry is taken from a host copy of the descriptors' maxima; callers with device-only descriptors pass
+    // uniform work (HME levels), so read them back once.
+    std::vector<SvtHipSadLoopDesc> h(n);
+    HIP_CHECK(hipMemcpyAsync(h.data(), descs, n * sizeof(SvtHipSadLoopDesc), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    int max_w = 1, max_h = 1, max_bw = 4, max_bh = 1, any_interleaved = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        max_w  = h[i].search_area_width > max_w ? h[i].search_area_width : max_w;
+        max_h  = h[i].search_area_height > max_h ? h[i].search_area_height : max_h;
+        max_bw = h[i].block_width > max_bw ? h[i].block_width : max_bw;
+        max_bh = h[i].block_height > max_bh ? h[i].block_height : max_bh;
+        any_interleaved |= h[i].ref_stride != h[i].src_stride_raw;
+    }
+    const uint32_t tiles_x   = (max_w + SL_TW - 1) / SL_TW, tiles_y = (max_h + SL_TH - 1) / SL_TH;
+    const int      src_pitch = (max_bw + 3) >> 2, win_pitch = ((max_bw + SL_TW + 3) >> 2) + 2;
+    const int      win_rows  = any_interleaved ? SL_TH * max_bh : (SL_TH + max_bh - 1);
+    const size_t   shmem     = (size_t)(src_pitch * max_bh + win_pitch * win_rows) * 4 + 64;
+    HIP_CHECK(hipMemsetAsync(keys, 0xff, (size_t)n * 8, (hipStream_t)stream));
+    hipLaunchKernelGGL(sad_loop_kernel, dim3(n, tiles_x * tiles_y), dim3(256), shmem, (hipStream_t)stream, src_base, ref_base, descs,
+                       tiles_x, (unsigned long long*)keys);
+    SVT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sad_loop_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, descs, n,
+                       (const unsigned long long*)keys, results);
+    SVT_LAUNCH_CHECK();
+}
+
+size_t svt_hip_me_fullpel_search_workspace(uint32_t n, uint32_t max_w, uint32_t max_h) {
+    if (max_w <= (uint32_t)ME_TW && max_h <= (uint32_t)ME_TH) return 0;
+    return (size_t)n * SVT_HIP_ME_NUM_BLOCKS * sizeof(uint64_t);
+}
+
+void svt_hip_me_fullpel_search_batch(const uint8_t* src_base, const uint8_t* ref_base, const SvtHipMeSearchDesc* descs, uint32_t n,
+                                     uint32_t max_w, uint32_t max_h, int sub_sad, uint32_t* best_sad, uint32_t* best_mv,
+                                     void* workspace, void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    if (max_w == 0) max_w = 1;
+    if (max_h == 0) max_h = 1;
+    const uint32_t tiles_x = (max_w + ME_TW - 1) / ME_TW, tiles_y = (max_h + ME_TH - 1) / ME_TH;
+    const int      tw = max_w < (uint32_t)ME_TW ? (int)max_w : ME_TW, th = max_h < (uint32_t)ME_TH ? (int)max_h : ME_TH;
+    const int      pitch_dw = (((tw + 3) >> 2) + 16) | 1;
+    const int      win_rows = 64 + th - 1;
+    const size_t   shmem    = (size_t)(64 * 16 + 88 + pitch_dw * win_rows) * 4;
+    const bool     multi    = tiles_x * tiles_y > 1;
+    unsigned long long* keys = multi ? (unsigned long long*)workspace : nullptr;
+    if (multi) {
+        if (!workspace) { fprintf(stderr, "libsvtav1_hip: me_fullpel_search_batch needs a workspace for areas > 64x32\n"); abort(); }
+        HIP_CHECK(hipMemsetAsync(keys, 0xff, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 8, (hipStream_t)stream));
+    }
+    if (sub_sad)
+        hipLaunchKernelGGL(me_fullpel_kernel<true>, dim3(n, tiles_x * tiles_y), dim3(256), shmem, (hipStream_t)stream, src_base, ref_base,
+                           descs, n, tiles_x, pitch_dw, win_rows, best_sad, best_mv, keys);
+    else
+        hipLaunchKernelGGL(me_fullpel_kernel<false>, dim3(n, tiles_x * tiles_y), dim3(256), shmem, (hipStream_t)stream, src_base, ref_base,
+                           descs, n, tiles_x, pitch_dw, win_rows, best_sad, best_mv, keys);
+    SVT_LAUNCH_CHECK();
+    if (multi) {
+        const uint32_t tot = n * SVT_HIP_ME_NUM_BLOCKS;
+        hipLaunchKernelGGL(me_finalize_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, descs, n, keys, best_sad, best_mv);
+        SVT_LAUNCH_CHECK();
+    }
+}
+
+// ---- RTCD-signature single-call forms (host pointers) --------------------------------------------------------------
+uint32_t svt_nxm_sad_kernel_hip(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride, uint32_t height,
+                                uint32_t width) {
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    const size_t pitch = svthip::align_up(width, 16);
+    c.reserve(2 * pitch * height + 1024, 2 * pitch * height + 1024);
+    uint8_t*       ds = (uint8_t*)c.dalloc(pitch * height);
+    uint8_t*       dr = (uint8_t*)c.dalloc(pitch * height);
+    SvtHipSadPair* dp = (SvtHipSadPair*)c.dalloc(sizeof(SvtHipSadPair));
+    uint32_t*      dout = (uint32_t*)c.dalloc(4);
+    c.up2d(ds, pitch, src, src_stride, width, height);
+    c.up2d(dr, pitch, ref, ref_stride, width, height);
+    SvtHipSadPair p = {0, 0, (uint32_t)pitch, (uint32_t)pitch};
+    c.up(dp, &p, sizeof(p));
+    svt_hip_sad_nxm_batch(ds, dr, dp, 1, width, height, dout, c.stream);
+    uint32_t out;
+    c.down(&out, dout, 4);
+    return out;
+}
+
+uint32_t svt_aom_sad_16b_kernel_hip(uint16_t* src, uint32_t src_stride, uint16_t* ref, uint32_t ref_stride, uint32_t height,
+                                    uint32_t width) {
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    const size_t pitch = svthip::align_up(width * 2, 16);
+    c.reserve(2 * pitch * height + 1024, 2 * pitch * height + 1024);
+    uint16_t* ds   = (uint16_t*)c.dalloc(pitch * height);
+    uint16_t* dr   = (uint16_t*)c.dalloc(pitch * height);
+    uint32_t* dout = (uint32_t*)c.dalloc(4);
+    c.up2d(ds, pitch, src, src_stride * 2, width * 2, height);
+    c.up2d(dr, pitch, ref, ref_stride * 2, width * 2, height);
+    hipLaunchKernelGGL(sad_16b_kernel, dim3(1), dim3(64), 0, c.stream, (const uint16_t*)ds, (uint32_t)(pitch / 2), (const uint16_t*)dr,
+                       (uint32_t)(pitch / 2), (int)width, (int)height, dout);
+    SVT_LAUNCH_CHECK();
+    uint32_t out;
+    c.down(&out, dout, 4);
+    return out;
+}
+
+uint32_t svt_aom_sad_wxh_hip(const uint8_t* src, int src_stride, const uint8_t* ref, int ref_stride, int w, int h) {
+    return svt_nxm_sad_kernel_hip(src, (uint32_t)src_stride, ref, (uint32_t)ref_stride, (uint32_t)h, (uint32_t)w);
+}
+void svt_aom_sad_wxh_x4d_hip(const uint8_t* src, int src_stride, const uint8_t* const ref_array[4], int ref_stride, uint32_t* sad_array,
+                             int w, int h) {
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    const size_t pitch = svthip::align_up((size_t)w, 16);
+    c.reserve(5 * pitch * h + 1024, 5 * pitch * h + 1024);
+    uint8_t*       ds = (uint8_t*)c.dalloc(pitch * h);
+    uint8_t*       dr = (uint8_t*)c.dalloc(4 * pitch * h);
+    SvtHipSadPair* dp = (SvtHipSadPair*)c.dalloc(4 * sizeof(SvtHipSadPair));
+    uint32_t*      dout = (uint32_t*)c.dalloc(16);
+    c.up2d(ds, pitch, src, src_stride, w, h);
+    SvtHipSadPair p[4];
+    for (int i = 0; i < 4; i++) {
+        c.up2d(dr + i * pitch * h, pitch, ref_array[i], ref_stride, w, h);
+        p[i] = {0, (uint64_t)(i * pitch * h), (uint32_t)pitch, (uint32_t)pitch};
+    }
+    c.up(dp, p, sizeof(p));
+    svt_hip_sad_nxm_batch(ds, dr, dp, 4, w, h, dout, c.stream);
+    c.down(sad_array, dout, 16);
+}
+#define SVT_SAD_MXN(m, n)                                                                                                         \
+    uint32_t svt_aom_sad##m##x##n##_hip(const uint8_t* src, int src_stride, const uint8_t* ref, int ref_stride) {                \
+        return svt_aom_sad_wxh_hip(src, src_stride, ref, ref_stride, m, n);                                                      \
+    }                                                                                                                             \
+    void svt_aom_sad##m##x##n##x4d_hip(const uint8_t* src, int src_stride, const uint8_t* const ref_array[], int ref_stride,     \
+                                       uint32_t* sad_array) {                                                                     \
+        svt_aom_sad_wxh_x4d_hip(src, src_stride, ref_array, ref_stride, sad_array, m, n);                                        \
+    }
+SVT_SAD_MXN(128, 128) SVT_SAD_MXN(128, 64) SVT_SAD_MXN(64, 128) SVT_SAD_MXN(64, 64) SVT_SAD_MXN(64, 32) SVT_SAD_MXN(32, 64)
+SVT_SAD_MXN(32, 32) SVT_SAD_MXN(32, 16) SVT_SAD_MXN(16, 32) SVT_SAD_MXN(16, 16) SVT_SAD_MXN(16, 8) SVT_SAD_MXN(8, 16)
+SVT_SAD_MXN(8, 8) SVT_SAD_MXN(8, 4) SVT_SAD_MXN(4, 8) SVT_SAD_MXN(4, 4) SVT_SAD_MXN(4, 16) SVT_SAD_MXN(16, 4)
+SVT_SAD_MXN(8, 32) SVT_SAD_MXN(32, 8) SVT_SAD_MXN(16, 64) SVT_SAD_MXN(64, 16)
+
+void svt_sad_loop_kernel_hip(uint8_t* src, uint32_t src_stride, uint8_t* ref, uint32_t ref_stride, uint32_t block_height,
+                             uint32_t block_width, uint64_t* best_sad, int16_t* x_search_center, int16_t* y_search_center,
+                             uint32_t src_stride_raw, uint8_t skip_search_line, int16_t search_area_width, int16_t search_area_height) {
+    *best_sad = 0xffffff;
+    if (search_area_width <= 0 || search_area_height <= 0) return;
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    // Upload the exact byte ranges the reference reads. Source rows: block_height rows src_stride apart.
+    // Reference: rows r = yy*raw + y*ref_stride, yy < H, y < bh; upload the covering span as one rectangle of
+    // `raw`-strided lines when ref_stride is a multiple of raw (always true: ref_stride is raw or 2*raw).
+    const size_t sp = svthip::align_up(block_width, 16);
+    const size_t ww = (size_t)block_width + search_area_width - 1;
+    const size_t rp = svthip::align_up(ww, 16);
+    const uint32_t step  = ref_stride / src_stride_raw; // 1 (full) or 2 (sub-sampled HME)
+    const size_t   lines = (size_t)(search_area_height - 1) + (size_t)(block_height - 1) * step + 1;
+    c.reserve(sp * block_height + rp * lines + 4096, sp * block_height + rp * lines + 4096);
+    uint8_t* ds = (uint8_t*)c.dalloc(sp * block_height);
+    uint8_t* dr = (uint8_t*)c.dalloc(rp * lines);
+    SvtHipSadLoopDesc*   dd = (SvtHipSadLoopDesc*)c.dalloc(sizeof(SvtHipSadLoopDesc));
+    SvtHipSadLoopResult* dres = (SvtHipSadLoopResult*)c.dalloc(sizeof(SvtHipSadLoopResult));
+    uint64_t*            dk = (uint64_t*)c.dalloc(8);
+    c.up2d(ds, sp, src, src_stride, block_width, block_height);
+    c.up2d(dr, rp, ref, src_stride_raw, ww, lines);
+    SvtHipSadLoopDesc d;
+    memset(&d, 0, sizeof(d));
+    d.src_stride = (uint32_t)sp; d.ref_stride = (uint32_t)(rp * step); d.src_stride_raw = (uint32_t)rp;
+    d.block_width = (uint16_t)block_width; d.block_height = (uint16_t)block_height;
+    d.search_area_width = search_area_width; d.search_area_height = search_area_height; d.skip_search_line = skip_search_line;
+    c.up(dd, &d, sizeof(d));
+    svt_hip_sad_loop_batch(ds, dr, dd, 1, dres, dk, c.stream);
+    SvtHipSadLoopResult r;
+    c.down(&r, dres, sizeof(r));
+    *best_sad = r.best_sad;
+    if (r.valid) { *x_search_center = r.x_search_center; *y_search_center = r.y_search_center; }
+}
+
+void svt_ext_all_sad_calculation_8x8_16x16_hip(uint8_t* src, uint32_t src_stride, uint8_t* ref, uint32_t ref_stride, uint32_t mv,
+                                               uint32_t* p_best_sad_8x8, uint32_t* p_best_sad_16x16, uint32_t* p_best_mv8x8,
+                                               uint32_t* p_best_mv16x16, uint32_t p_eight_sad16x16[16][8],
+                                               uint32_t p_eight_sad8x8[64][8], bool sub_sad) {
+    (void)p_eight_sad8x8; // unused by the reference as well (motion_estimation.c:218)
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve(64 * 64 + 64 * 80 + 4096, 64 * 64 + 64 * 80 + 4096);
+    uint8_t*  ds = (uint8_t*)c.dalloc(64 * 64);
+    uint8_t*  dr = (uint8_t*)c.dalloc(64 * 80);
+    uint32_t* dv = (uint32_t*)c.dalloc((64 + 16 + 64 + 16 + 128) * 4);
+    uint32_t *b8 = dv, *b16 = dv + 64, *m8 = dv + 80, *m16 = dv + 144, *e16 = dv + 160;
+    c.up2d(ds, 64, src, src_stride, 64, 64);
+    c.up2d(dr, 80, ref, ref_stride, 71, 64);
+    c.up(b8, p_best_sad_8x8, 64 * 4); c.up(b16, p_best_sad_16x16, 16 * 4);
+    c.up(m8, p_best_mv8x8, 64 * 4);   c.up(m16, p_best_mv16x16, 16 * 4);
+    hipLaunchKernelGGL(ext_all_sad_kernel, dim3(1), dim3(512), 0, c.stream, (const uint8_t*)ds, 64u, (const uint8_t*)dr, 80u, mv, b8, b16, m8,
+                       m16, e16, sub_sad ? 1 : 0);
+    SVT_LAUNCH_CHECK();
+    uint32_t h[64 + 16 + 64 + 16 + 128];
+    c.down(h, dv, sizeof(h));
+    memcpy(p_best_sad_8x8, h, 64 * 4); memcpy(p_best_sad_16x16, h + 64, 16 * 4);
+    memcpy(p_best_mv8x8, h + 80, 64 * 4); memcpy(p_best_mv16x16, h + 144, 16 * 4);
+    memcpy(p_eight_sad16x16, h + 160, 128 * 4);
+}
+
+void svt_ext_eight_sad_calculation_32x32_64x64_hip(uint32_t p_sad16x16[16][8], uint32_t* p_best_sad_32x32, uint32_t* p_best_sad_64x64,
+                                                   uint32_t* p_best_mv32x32, uint32_t* p_best_mv64x64, uint32_t mv,
+                                                   uint32_t p_sad32x32[4][8]) {
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve(4096, 4096);
+    uint32_t* dv = (uint32_t*)c.dalloc((128 + 4 + 1 + 4 + 1 + 32) * 4);
+    uint32_t *s16 = dv, *b32 = dv + 128, *b64 = dv + 132, *m32 = dv + 133, *m64 = dv + 137, *s32 = dv + 138;
+    c.up(s16, p_sad16x16, 128 * 4); c.up(b32, p_best_sad_32x32, 16); c.up(b64, p_best_sad_64x64, 4);
+    c.up(m32, p_best_mv32x32, 16);  c.up(m64, p_best_mv64x64, 4);
+    hipLaunchKernelGGL(ext_eight_32_64_kernel, dim3(1), dim3(64), 0, c.stream, (const uint32_t*)s16, b32, b64, m32, m64, mv, s32);
+    SVT_LAUNCH_CHECK();
+    uint32_t h[170];
+    c.down(h, dv, sizeof(h));
+    memcpy(p_best_sad_32x32, h + 128, 16); p_best_sad_64x64[0] = h[132];
+    memcpy(p_best_mv32x32, h + 133, 16);   p_best_mv64x64[0] = h[137];
+    memcpy(p_sad32x32, h + 138, 32 * 4);
+}
+
+void svt_ext_sad_calculation_8x8_16x16_hip(uint8_t* src, uint32_t src_stride, uint8_t* ref, uint32_t ref_stride, uint32_t* p_best_sad_8x8,
+                                           uint32_t* p_best_sad_16x16, uint32_t* p_best_mv8x8, uint32_t* p_best_mv16x16, uint32_t mv,
+                                           uint32_t* p_sad16x16, uint32_t* p_sad8x8, bool sub_sad) {
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve(4096, 4096);
+    uint8_t*  ds = (uint8_t*)c.dalloc(16 * 16);
+    uint8_t*  dr = (uint8_t*)c.dalloc(16 * 16);
+    uint32_t* dv = (uint32_t*)c.dalloc(16 * 4);
+    c.up2d(ds, 16, src, src_stride, 16, 16);
+    c.up2d(dr, 16, ref, ref_stride, 16, 16);
+    uint32_t h[16] = {0};
+    memcpy(h, p_best_sad_8x8, 16); h[4] = p_best_sad_16x16[0]; memcpy(h + 5, p_best_mv8x8, 16); h[9] = p_best_mv16x16[0];
+    c.up(dv, h, sizeof(h));
+    hipLaunchKernelGGL(ext_one_8_16_kernel, dim3(1), dim3(64), 0, c.stream, (const uint8_t*)ds, 16u, (const uint8_t*)dr, 16u, dv, dv + 4,
+                       dv + 5, dv + 9, mv, dv + 10, dv + 11, sub_sad ? 1 : 0);
+    SVT_LAUNCH_CHECK();
+    c.down(h, dv, sizeof(h));
+    memcpy(p_best_sad_8x8, h, 16); p_best_sad_16x16[0] = h[4]; memcpy(p_best_mv8x8, h + 5, 16); p_best_mv16x16[0] = h[9];
+    p_sad16x16[0] = h[10]; memcpy(p_sad8x8, h + 11, 16);
+}
+
+void svt_ext_sad_calculation_32x32_64x64_hip(uint32_t* p_sad16x16, uint32_t* p_best_sad_32x32, uint32_t* p_best_sad_64x64,
+                                             uint32_t* p_best_mv32x32, uint32_t* p_best_mv64x64, uint32_t mv, uint32_t* p_sad32x32) {
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve(4096, 4096);
+    uint32_t* dv = (uint32_t*)c.dalloc(32 * 4);
+    uint32_t  h[32] = {0};
+    memcpy(h, p_sad16x16, 64); memcpy(h + 16, p_best_sad_32x32, 16); h[20] = p_best_sad_64x64[0];
+    memcpy(h + 21, p_best_mv32x32, 16); h[25] = p_best_mv64x64[0];
+    c.up(dv, h, sizeof(h));
+    hipLaunchKernelGGL(ext_one_32_64_kernel, dim3(1), dim3(64), 0, c.stream, (const uint32_t*)dv, dv + 16, dv + 20, dv + 21, dv + 25, mv,
+                       dv + 26);
+    SVT_LAUNCH_CHECK();
+    c.down(h, dv, sizeof(h));
+    memcpy(p_best_sad_32x32, h + 16, 16); p_best_sad_64x64[0] = h[20]; memcpy(p_best_mv32x32, h + 21, 16); p_best_mv64x64[0] = h[25];
+    memcpy(p_sad32x32, h + 26, 16);
+}
+
+void svt_initialize_buffer_32bits_hip(uint32_t* pointer, uint32_t count128, uint32_t count32, uint32_t value) {
+    const uint32_t n = count128 * 4 + count32;
+    if (n == 0) return;
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve((size_t)n * 4 + 1024, (size_t)n * 4 + 1024);
+    uint32_t* d = (uint32_t*)c.dalloc((size_t)n * 4);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, d, n, value);
+    SVT_LAUNCH_CHECK();
+    c.down(pointer, d, (size_t)n * 4);
+}
+
+} // extern "C"

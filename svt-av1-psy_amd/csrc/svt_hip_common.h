@@ -1,0 +1,54 @@
+// svt_hip_common.h -- host-side plumbing shared by every kernel family of libsvtav1_hip.so.
+//  * HIP_CHECK: fail loudly (the reference's DSP kernels cannot report errors, and this library has no CPU path).
+//  * HostCall: per-thread stream + growable device arena + pinned staging, used by the `*_hip` RTCD-signature
+//    functions that receive plain host pointers (Source/Lib/Codec/aom_dsp_rtcd.h contract: synchronous,
+//    re-entrant, caller owns every buffer, arbitrary strides).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define HIP_CHECK(expr)                                                                                         \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) {                                                                                 \
+            fprintf(stderr, "libsvtav1_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, \
+                    __LINE__);                                                                                  \
+            abort();                                                                                            \
+        }                                                                                                       \
+    } while (0)
+
+#define SVT_LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
+
+namespace svthip {
+
+void ensure_device(); // aborts with a clear message when svt_hip_init() found no GPU
+
+// Bump allocator over one device buffer and one pinned host buffer; reset at the start of every host call.
+struct HostCall {
+    hipStream_t stream   = nullptr;
+    uint8_t*    dev      = nullptr;
+    size_t      dev_cap  = 0, dev_used = 0;
+    uint8_t*    pin      = nullptr;
+    size_t      pin_cap  = 0, pin_used = 0;
+
+    void begin();
+    // device allocation of `bytes` (256-B aligned); may grow the arena (only legal before any kernel was queued
+    // in this call, which is how every wrapper uses it: reserve(total) first, then carve).
+    void  reserve(size_t dev_bytes, size_t pin_bytes);
+    void* dalloc(size_t bytes);
+    void* palloc(size_t bytes);
+    // strided host rectangle -> packed device rectangle (row pitch = width bytes rounded up to `dpitch`)
+    void up2d(void* ddst, size_t dpitch, const void* hsrc, size_t spitch, size_t width_bytes, size_t rows);
+    void up(void* ddst, const void* hsrc, size_t bytes);
+    void down(void* hdst, const void* dsrc, size_t bytes);
+    void down2d(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch, size_t width_bytes, size_t rows);
+    void sync();
+};
+HostCall& host_call();
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace svthip

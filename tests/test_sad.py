@@ -1,0 +1,270 @@
+"""SAD family: HIP path vs the oracle, bit-exact.
+
+Patterns follow the reference's own fixtures (test/SadTest.cc:150-260): REF_MAX (src 0 / ref 255), SRC_MAX (all 255:
+every position ties, which pins the raster-order first-minimum rule), RANDOM, UNALIGN (stride 127).
+The same test bodies run on the CPU lock-step build (`emu`) and, under `-m gpu`, on the MI355X through the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import p, rng
+
+PATTERNS = ["REF_MAX", "SRC_MAX", "RANDOM", "UNALIGN"]
+# test/SadTest.cc:62-76 (TEST_BLOCK_SIZES) -- a representative subset incl. every odd shape class
+BLOCK_SIZES = [(4, 10), (8, 12), (24, 10), (40, 14), (56, 14), (16, 5), (32, 20), (64, 20), (64, 64), (64, 32), (32, 64),
+               (32, 32), (16, 16), (8, 8), (4, 4), (4, 16), (16, 64), (48, 48), (6, 2), (6, 16), (12, 8)]
+
+
+def make_planes(pattern, g, sh=192, sw=192, ref_extra=0):
+    """src plane (sh x sw, stride sw) and ref plane; UNALIGN uses the odd stride 127-like (sw-1)."""
+    src_stride = sw
+    ref_stride = sw + ref_extra - (1 if pattern == "UNALIGN" else 0)
+    rows = sh + ref_extra
+    if pattern == "REF_MAX":
+        src = np.zeros(sh * src_stride, np.uint8)
+        ref = np.full(rows * ref_stride + 64, 255, np.uint8)
+    elif pattern == "SRC_MAX":
+        src = np.full(sh * src_stride, 255, np.uint8)
+        ref = np.full(rows * ref_stride + 64, 255, np.uint8)
+    else:
+        src = g.integers(0, 256, sh * src_stride, dtype=np.uint8)
+        ref = g.integers(0, 256, rows * ref_stride + 64, dtype=np.uint8)
+    return src, src_stride, ref, ref_stride
+
+
+@pytest.mark.parametrize("pattern", PATTERNS)
+def test_nxm_sad_single_call(be, oracle, pattern):
+    """svt_nxm_sad_kernel_hip == svt_nxm_sad_kernel_helper_c restatement (SadTest.cc SADTest :362-404)."""
+    g = rng()
+    oracle.oracle_sad_nxm.restype = C.c_uint32
+    sizes = BLOCK_SIZES if be.is_gpu else BLOCK_SIZES[::3]
+    for (w, h) in sizes:
+        src, ss, ref, rs = make_planes(pattern, g, 64, 128)
+        off = 1 if pattern == "UNALIGN" else 0
+        want = oracle.oracle_sad_nxm(p(src), ss, C.c_void_p(ref.ctypes.data + off), rs, h, w)
+        got = be.lib.svt_nxm_sad_kernel_hip(p(src), ss, C.c_void_p(ref.ctypes.data + off), rs, h, w)
+        assert got == want, (pattern, w, h)
+
+
+def test_sad_16b_single_call(be, oracle):
+    g = rng(7)
+    oracle.oracle_sad_16b.restype = C.c_uint32
+    for (w, h) in [(16, 16), (64, 64), (24, 10), (8, 4)]:
+        src = g.integers(0, 1024, 64 * 80, dtype=np.uint16)
+        ref = g.integers(0, 1024, 64 * 96, dtype=np.uint16)
+        want = oracle.oracle_sad_16b(p(src), 80, p(ref), 96, h, w)
+        got = be.lib.svt_aom_sad_16b_kernel_hip(p(src), 80, p(ref), 96, h, w)
+        assert got == want
+
+
+def test_aom_sad_fixed_size_symbols(be, oracle):
+    """svt_aom_sadWxH_hip / x4d (compute_sad_c.c:104-131; test/MotionEstimationTest.cc:117-160)."""
+    g = rng(3)
+    oracle.oracle_sad_nxm.restype = C.c_uint32
+    src, ss, ref, rs = make_planes("RANDOM", g, 160, 160)
+    for (w, h) in [(64, 64), (16, 8), (4, 16), (128, 128)]:
+        f = getattr(be.lib, "svt_aom_sad%dx%d_hip" % (w, h))
+        assert f(p(src), ss, p(ref), rs) == oracle.oracle_sad_nxm(p(src), ss, p(ref), rs, h, w)
+        f4 = getattr(be.lib, "svt_aom_sad%dx%dx4d_hip" % (w, h))
+        offs = [0, 3, rs * 2 + 1, rs * 5 + 7]
+        arr = (C.c_void_p * 4)(*[ref.ctypes.data + o for o in offs])
+        out = np.zeros(4, np.uint32)
+        f4(p(src), ss, arr, rs, p(out))
+        want = [oracle.oracle_sad_nxm(p(src), ss, C.c_void_p(ref.ctypes.data + o), rs, h, w) for o in offs]
+        assert out.tolist() == want
+
+
+def test_nxm_sad_batch_frame(be, oracle):
+    """BASELINE config 1 shape: 64x64 SAD of every co-located SB pair of two padded luma planes (device-resident)."""
+    g = rng(1234)
+    W, H = (1920, 1080) if be.is_gpu else (256, 136)
+    pad = 68
+    stride = W + 2 * pad
+    rows = H + 2 * pad
+    a = g.integers(0, 256, (rows, stride), dtype=np.uint8)
+    b = (a.astype(np.int16) + g.integers(-8, 9, a.shape)).clip(0, 255).astype(np.uint8)
+    sbx, sby = (W + 63) // 64, (H + 63) // 64
+    pairs = np.zeros(sbx * sby, dtype=be.pkg.SadPair)
+    for i in range(sbx * sby):
+        o = (pad + (i // sbx) * 64) * stride + pad + (i % sbx) * 64
+        pairs[i] = (o, o + 3 + 2 * stride, stride, stride)  # ref displaced by (+3,+2): unaligned loads
+    da, db, dp = be.dev(a), be.dev(b), be.dev(pairs)
+    out = be.empty(len(pairs), np.uint32)
+    be.lib.svt_hip_sad_nxm_batch(be.ptr(da), be.ptr(db), be.ptr(dp), len(pairs), 64, 64, be.ptr(out), be.stream)
+    got = be.host(out)
+    oracle.oracle_sad_nxm.restype = C.c_uint32
+    for i in range(len(pairs)):
+        want = oracle.oracle_sad_nxm(C.c_void_p(a.ctypes.data + int(pairs[i]["src_off"])), stride,
+                                     C.c_void_p(b.ctypes.data + int(pairs[i]["ref_off"])), stride, 64, 64)
+        assert got[i] == want, i
+
+
+LOOP_AREAS = [(8, 15), (16, 31), (12, 31), (64, 25), (15, 6), (32, 12), (96, 24), (70, 40)]  # SadTest.cc:433-444 subset
+
+
+@pytest.mark.parametrize("pattern", PATTERNS)
+@pytest.mark.parametrize("skip", [0, 1])
+def test_sad_loop_single_call(be, oracle, pattern, skip):
+    """svt_sad_loop_kernel_hip == svt_sad_loop_kernel_c restatement (SadTest.cc sad_LoopTest :474-649)."""
+    g = rng(11)
+    areas = LOOP_AREAS if be.is_gpu else [(8, 15), (15, 6), (70, 20)]
+    blocks = [(16, 16), (32, 32), (64, 64), (16, 8), (24, 10), (6, 4), (12, 8), (64, 20), (4, 4)]
+    if not be.is_gpu:
+        blocks = [(16, 16), (16, 8), (24, 10), (6, 4), (64, 20)]
+    for (aw, ah) in areas:
+        for (w, h) in blocks:
+            src, ss, ref, rs = make_planes(pattern, g, 64, 64, ref_extra=aw + 40 if aw > ah else ah + 40)
+            ref = np.resize(ref, (64 + ah + 8) * max(rs, 64 + aw + 8) + 256)
+            rs2 = max(rs, 64 + aw + 7) - (1 if pattern == "UNALIGN" else 0)
+            bs0, bs1 = C.c_uint64(0), C.c_uint64(0)
+            x0, y0, x1, y1 = C.c_int16(0), C.c_int16(0), C.c_int16(0), C.c_int16(0)
+            oracle.oracle_sad_loop(p(src), ss, p(ref), rs2, h, w, C.byref(bs0), C.byref(x0), C.byref(y0), rs2, skip, aw, ah)
+            be.lib.svt_sad_loop_kernel_hip(p(src), ss, p(ref), rs2, h, w, C.byref(bs1), C.byref(x1), C.byref(y1), rs2, skip, aw, ah)
+            assert (bs0.value, x0.value, y0.value) == (bs1.value, x1.value, y1.value), (pattern, aw, ah, w, h, skip)
+
+
+def test_sad_loop_subsampled_hme_form(be, oracle):
+    """HME calls the kernel with src/ref strides doubled and half the height (motion_estimation.c:891-908)."""
+    g = rng(5)
+    src = g.integers(0, 256, 64 * 64, dtype=np.uint8)
+    ref = g.integers(0, 256, 200 * 160, dtype=np.uint8)
+    for (w, h, aw, ah) in [(16, 8, 24, 9), (32, 16, 8, 3), (64, 32, 8, 3)]:
+        bs0, bs1 = C.c_uint64(0), C.c_uint64(0)
+        x0, y0, x1, y1 = C.c_int16(0), C.c_int16(0), C.c_int16(0), C.c_int16(0)
+        oracle.oracle_sad_loop(p(src), 128, p(ref), 320, h, w, C.byref(bs0), C.byref(x0), C.byref(y0), 160, 0, aw, ah)
+        be.lib.svt_sad_loop_kernel_hip(p(src), 128, p(ref), 320, h, w, C.byref(bs1), C.byref(x1), C.byref(y1), 160, 0, aw, ah)
+        assert (bs0.value, x0.value, y0.value) == (bs1.value, x1.value, y1.value)
+
+
+ME_AREAS = [(16, 9), (8, 3), (15, 6), (64, 32), (21, 5), (1, 1), (70, 35), (130, 40)]
+
+
+def run_me_batch(be, src, ref, descs, max_w, max_h, sub_sad):
+    ds, dr, dd = be.dev(src), be.dev(ref), be.dev(descs)
+    n = len(descs)
+    bs = be.empty(n * 85, np.uint32)
+    bm = be.empty(n * 85, np.uint32)
+    ws_bytes = be.lib.svt_hip_me_fullpel_search_workspace(n, max_w, max_h)
+    ws = be.empty(max(ws_bytes, 8), np.uint8)
+    be.lib.svt_hip_me_fullpel_search_batch(be.ptr(ds), be.ptr(dr), be.ptr(dd), n, max_w, max_h, sub_sad, be.ptr(bs), be.ptr(bm),
+                                           be.ptr(ws) if ws_bytes else None, be.stream)
+    return be.host(bs).reshape(n, 85), be.host(bm).reshape(n, 85)
+
+
+def oracle_me(oracle, src, ref, d, sub_sad):
+    bs = np.zeros(85, np.uint32)
+    bm = np.zeros(85, np.uint32)
+    oracle.oracle_me_fullpel_search(C.c_void_p(src.ctypes.data + int(d["src_off"])), int(d["src_stride"]),
+                                    C.c_void_p(ref.ctypes.data + int(d["ref_off"])), int(d["ref_stride"]), int(d["x_origin"]),
+                                    int(d["y_origin"]), int(d["width"]), int(d["height"]), sub_sad, p(bs), p(bm))
+    return bs, bm
+
+
+@pytest.mark.parametrize("pattern", ["RANDOM", "SRC_MAX", "REF_MAX", "SMOOTH"])
+@pytest.mark.parametrize("sub_sad", [0, 1])
+def test_me_fullpel_search_batch(be, oracle, pattern, sub_sad):
+    """Frame-batched full-pel search == open_loop_me_fullpel_search_sblock restatement: 85 SADs + MVs per (SB, ref)."""
+    g = rng(99)
+    areas = ME_AREAS if be.is_gpu else [(16, 9), (15, 6), (70, 35)]
+    n_sb = 6 if be.is_gpu else 2
+    for (aw, ah) in areas:
+        stride = 64 * n_sb + aw + 80 + (1 if pattern == "RANDOM" else 0)
+        rows = 64 + ah + 16
+        if pattern == "SMOOTH":  # low-noise gradient: many near-ties, realistic SAD surface
+            yy, xx = np.mgrid[0:rows, 0:stride]
+            src = ((xx + yy) & 255).astype(np.uint8)
+            ref = ((xx + yy + 3) & 255).astype(np.uint8) + g.integers(0, 2, (rows, stride), dtype=np.uint8)
+        elif pattern == "RANDOM":
+            src = g.integers(0, 256, (rows, stride), dtype=np.uint8)
+            ref = g.integers(0, 256, (rows, stride), dtype=np.uint8)
+        else:
+            src = np.full((rows, stride), 255 if pattern == "SRC_MAX" else 0, np.uint8)
+            ref = np.full((rows, stride), 255, np.uint8)
+        descs = np.zeros(n_sb, dtype=be.pkg.MeSearchDesc)
+        for i in range(n_sb):
+            # odd offsets: exercise every byte alignment of source block and search window
+            descs[i] = (i * 64 + (i % 4), i * 64 + ((i * 3 + 1) % 5), stride, stride, -(aw >> 1), -(ah >> 1), aw, ah)
+        bs, bm = run_me_batch(be, src, ref, descs, aw, ah, sub_sad)
+        for i in range(n_sb):
+            ws, wm = oracle_me(oracle, src, ref, descs[i], sub_sad)
+            assert np.array_equal(bs[i], ws), (pattern, aw, ah, i, np.nonzero(bs[i] != ws)[0][:8])
+            assert np.array_equal(bm[i], wm), (pattern, aw, ah, i, np.nonzero(bm[i] != wm)[0][:8])
+
+
+def test_me_fullpel_mixed_areas_and_empty(be, oracle):
+    """Items of one launch may have different (smaller) search areas; an empty area reports MAX_SAD_VALUE."""
+    g = rng(4)
+    stride, rows = 400, 140
+    src = g.integers(0, 256, (rows, stride), dtype=np.uint8)
+    ref = g.integers(0, 256, (rows, stride), dtype=np.uint8)
+    descs = np.zeros(3, dtype=be.pkg.MeSearchDesc)
+    descs[0] = (0, 5, stride, stride, -3, -1, 7, 3)
+    descs[1] = (64, 70, stride, stride, 0, 0, 16, 9)
+    descs[2] = (128, 130, stride, stride, 0, 0, 0, 0)
+    bs, bm = run_me_batch(be, src, ref, descs, 16, 9, 0)
+    for i in range(2):
+        ws, wm = oracle_me(oracle, src, ref, descs[i], 0)
+        assert np.array_equal(bs[i], ws) and np.array_equal(bm[i], wm)
+    assert (bs[2] == be.pkg.MAX_SAD_VALUE).all()
+
+
+@pytest.mark.parametrize("sub_sad", [0, 1])
+def test_ext_sad_single_calls(be, oracle, sub_sad):
+    """svt_ext_all/eight/one_*_hip == the `_c` restatements (SadTest.cc :731-1260)."""
+    g = rng(21)
+    src = g.integers(0, 256, 64 * 72, dtype=np.uint8)
+    ref = g.integers(0, 256, 64 * 96 + 16, dtype=np.uint8)
+    mv = ((7 & 0xffff) << 16) | (0xfff5)  # y = 7, x = -11
+    for init in (be.pkg.MAX_SAD_VALUE, 3000):
+        b8 = [np.full(64, init, np.uint32) for _ in range(2)]
+        b16 = [np.full(16, init * 4, np.uint32) for _ in range(2)]
+        m8 = [np.zeros(64, np.uint32) for _ in range(2)]
+        m16 = [np.zeros(16, np.uint32) for _ in range(2)]
+        e16 = [np.zeros((16, 8), np.uint32) for _ in range(2)]
+        e8 = np.zeros((64, 8), np.uint32)
+        oracle.oracle_ext_all_sad_calculation_8x8_16x16(p(src), 72, p(ref), 96, mv, p(b8[0]), p(b16[0]), p(m8[0]), p(m16[0]),
+                                                        p(e16[0]), sub_sad)
+        be.lib.svt_ext_all_sad_calculation_8x8_16x16_hip(p(src), 72, p(ref), 96, mv, p(b8[1]), p(b16[1]), p(m8[1]), p(m16[1]),
+                                                         p(e16[1]), p(e8), bool(sub_sad))
+        for a in (b8, b16, m8, m16, e16):
+            assert np.array_equal(a[0], a[1])
+        b32 = [np.full(4, init * 16, np.uint32) for _ in range(2)]
+        b64 = [np.full(1, init * 64, np.uint32) for _ in range(2)]
+        m32 = [np.zeros(4, np.uint32) for _ in range(2)]
+        m64 = [np.zeros(1, np.uint32) for _ in range(2)]
+        s32 = [np.zeros((4, 8), np.uint32) for _ in range(2)]
+        oracle.oracle_ext_eight_sad_calculation_32x32_64x64(p(e16[0]), p(b32[0]), p(b64[0]), p(m32[0]), p(m64[0]), mv, p(s32[0]))
+        be.lib.svt_ext_eight_sad_calculation_32x32_64x64_hip(p(e16[0]), p(b32[1]), p(b64[1]), p(m32[1]), p(m64[1]), mv, p(s32[1]))
+        for a in (b32, b64, m32, m64, s32):
+            assert np.array_equal(a[0], a[1])
+        # single-position forms
+        o8 = [np.full(4, init, np.uint32) for _ in range(2)]
+        o16 = [np.full(1, init * 4, np.uint32) for _ in range(2)]
+        om8 = [np.zeros(4, np.uint32) for _ in range(2)]
+        om16 = [np.zeros(1, np.uint32) for _ in range(2)]
+        s16 = [np.zeros(1, np.uint32) for _ in range(2)]
+        s8 = [np.zeros(4, np.uint32) for _ in range(2)]
+        oracle.oracle_ext_sad_calculation_8x8_16x16(p(src), 72, p(ref), 96, p(o8[0]), p(o16[0]), p(om8[0]), p(om16[0]), mv, p(s16[0]),
+                                                    p(s8[0]), sub_sad)
+        be.lib.svt_ext_sad_calculation_8x8_16x16_hip(p(src), 72, p(ref), 96, p(o8[1]), p(o16[1]), p(om8[1]), p(om16[1]), mv, p(s16[1]),
+                                                     p(s8[1]), bool(sub_sad))
+        for a in (o8, o16, om8, om16, s16, s8):
+            assert np.array_equal(a[0], a[1])
+        flat16 = np.ascontiguousarray(e16[0][:, 0])
+        q32 = [np.full(4, init * 16, np.uint32) for _ in range(2)]
+        q64 = [np.full(1, init * 64, np.uint32) for _ in range(2)]
+        qm32 = [np.zeros(4, np.uint32) for _ in range(2)]
+        qm64 = [np.zeros(1, np.uint32) for _ in range(2)]
+        t32 = [np.zeros(4, np.uint32) for _ in range(2)]
+        oracle.oracle_ext_sad_calculation_32x32_64x64(p(flat16), p(q32[0]), p(q64[0]), p(qm32[0]), p(qm64[0]), mv, p(t32[0]))
+        be.lib.svt_ext_sad_calculation_32x32_64x64_hip(p(flat16), p(q32[1]), p(q64[1]), p(qm32[1]), p(qm64[1]), mv, p(t32[1]))
+        for a in (q32, q64, qm32, qm64, t32):
+            assert np.array_equal(a[0], a[1])
+
+
+def test_initialize_buffer_32bits(be):
+    buf = np.zeros(85 + 3, np.uint32)
+    be.lib.svt_initialize_buffer_32bits_hip(p(buf), 21, 1, be.pkg.MAX_SAD_VALUE)
+    assert (buf[:85] == be.pkg.MAX_SAD_VALUE).all() and (buf[85:] == 0).all()
