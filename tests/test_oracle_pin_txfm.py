@@ -1,0 +1,137 @@
+"""Pins the generated 1-D flow graphs (tools/gen_txfm.py) and the 2-D drivers of oracle/oracle_txfm.c against the REAL
+reference (oracle/_ref) and against golden vectors (tests/golden/txfm.npz).  CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, p, rng
+
+TX_SIZES = ["4x4", "8x8", "16x16", "32x32", "64x64", "4x8", "8x4", "8x16", "16x8", "16x32", "32x16", "32x64", "64x32", "4x16", "16x4",
+            "8x32", "32x8", "16x64", "64x16"]
+TXW = [int(s.split("x")[0]) for s in TX_SIZES]
+TXH = [int(s.split("x")[1]) for s in TX_SIZES]
+DCT_DCT, IDTX, V_DCT, H_DCT = 0, 9, 10, 11
+
+
+def allowed_types(ts):  # test/TxfmCommon.h:160-209
+    name = TX_SIZES[ts]
+    if name == "32x32":
+        return [DCT_DCT, IDTX, V_DCT, H_DCT]
+    if name in ("32x64", "64x32", "16x64", "64x16"):
+        return [DCT_DCT]
+    if name in ("16x32", "32x16", "64x64", "8x32", "32x8"):
+        return [DCT_DCT, IDTX]
+    return list(range(16))
+
+
+def fwd_ref_name(ts, pf=0):
+    w, h = TXW[ts], TXH[ts]
+    sfx = ["", "_N2", "_N4"][pf]
+    if w == h:
+        return ("svt_av1_transform_two_d_%dx%d%s_c" if pf == 0 else "svt_aom_transform_two_d_%dx%d%s_c") % (w, h, sfx)
+    return "svt_av1_fwd_txfm2d_%dx%d%s_c" % (w, h, sfx)
+
+
+def call_ref_inv(ref, ts, coeff, pred, stride, out, tx_type, bd):
+    w, h = TXW[ts], TXH[ts]
+    f = getattr(ref, "svt_av1_inv_txfm2d_add_%dx%d_c" % (w, h))
+    if w == h:
+        f(p(coeff), p(pred), stride, p(out), stride, tx_type, bd)
+    elif (w, h) in ((4, 8), (8, 4), (4, 16), (16, 4)):  # no eob argument (inv_transforms.c:2583,2590,2689,2696)
+        f(p(coeff), p(pred), stride, p(out), stride, tx_type, ts, bd)
+    else:
+        f(p(coeff), p(pred), stride, p(out), stride, tx_type, ts, w * h, bd)
+
+
+def test_trig_tables(oracle, ref):
+    cos = (C.c_int32 * (7 * 64)).in_dll(ref, "svt_aom_eb_av1_cospi_arr_data")
+    sin = (C.c_int32 * (7 * 5)).in_dll(ref, "svt_aom_eb_av1_sinpi_arr_data")
+    oracle.oracle_cospi_table.restype = C.POINTER(C.c_int32)
+    oracle.oracle_sinpi_table.restype = C.POINTER(C.c_int32)
+    for bit in range(10, 17):
+        a, b = oracle.oracle_cospi_table(bit), oracle.oracle_sinpi_table(bit)
+        assert [a[i] for i in range(64)] == list(cos)[(bit - 10) * 64:(bit - 9) * 64]
+        assert [b[i] for i in range(5)] == list(sin)[(bit - 10) * 5:(bit - 9) * 5]
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64])
+def test_1d_kernels_vs_reference(oracle, ref, n):
+    g = rng(n)
+    sr = (C.c_int8 * 16)(*([18] * 16))
+    cases = [(0, "dct")] + ([(1, "adst")] if n <= 16 else [])
+    for kind, nm in cases:
+        for cos_bit in (10, 11, 12, 13):
+            for amp in (1 << 10, 1 << 15, 1 << 17):
+                for _ in range(50):
+                    x = g.integers(-amp, amp + 1, n).astype(np.int32)
+                    a, b = np.zeros(n, np.int32), np.zeros(n, np.int32)
+                    oracle.oracle_fwd_txfm1d(kind, n, p(x), p(a), cos_bit)
+                    getattr(ref, "svt_av1_f%s%d_new" % (nm, n))(p(x), p(b), cos_bit, sr)
+                    assert np.array_equal(a, b), ("fwd", nm, n, cos_bit, amp)
+                    for clamp in (16, 18, 20):
+                        srr = (C.c_int8 * 16)(*([clamp] * 16))
+                        oracle.oracle_inv_txfm1d(kind, n, p(x), p(a), cos_bit, clamp)
+                        getattr(ref, "svt_av1_i%s%d_new" % (nm, n))(p(x), p(b), cos_bit, srr)
+                        assert np.array_equal(a, b), ("inv", nm, n, cos_bit, amp, clamp)
+
+
+def ref_fwd(ref, ts, res, stride, tx_type, bd, pf=0):
+    out = np.zeros(TXW[ts] * TXH[ts], np.int32)
+    getattr(ref, fwd_ref_name(ts, pf))(p(res), p(out), stride, tx_type, bd)
+    return out
+
+
+@pytest.mark.parametrize("ts", range(19))
+def test_2d_fwd_inv_vs_reference(oracle, ref, ts):
+    """Same generators as test/FwdTxfm2dAsmTest.cc:272-330 (residual in +-(2^bd - 1)) and test/InvTxfm2dAsmTest.cc:92-145
+    (inverse input = C forward transform of a random residual)."""
+    g = rng(100 + ts)
+    w, h = TXW[ts], TXH[ts]
+    stride = w + 5
+    for bd in (8, 10):
+        for tx_type in allowed_types(ts):
+            for it in range(6):
+                amp = (1 << bd) - 1
+                res = g.integers(-amp, amp + 1, h * stride).astype(np.int16)
+                if it == 0:
+                    res[:] = amp
+                if it == 1:
+                    res[:] = -amp
+                for pf in (0, 1, 2):
+                    a = np.zeros(w * h, np.int32)
+                    oracle.oracle_fwd_txfm2d(p(res), p(a), stride, tx_type, ts, bd, pf)
+                    b = ref_fwd(ref, ts, res, stride, tx_type, bd, pf)
+                    if pf:  # the reference's N2/N4 kernels leave the dropped area unwritten; the test zeroes it (FwdTxfm2dAsmTest.cc:333-356)
+                        bb = b.reshape(h, w)
+                        bb[h >> pf:, :] = 0
+                        bb[:, w >> pf:] = 0
+                    assert np.array_equal(a, b), ("fwd", TX_SIZES[ts], tx_type, bd, pf, it)
+                coeff = ref_fwd(ref, ts, res, stride, tx_type, bd)
+                iw, ih = min(w, 32), min(h, 32)
+                packed = np.ascontiguousarray(coeff.reshape(h, w)[:ih, :iw]).reshape(-1)
+                pred = g.integers(0, 1 << bd, h * stride).astype(np.uint16)
+                o1, o2 = np.zeros(h * stride, np.uint16), np.zeros(h * stride, np.uint16)
+                oracle.oracle_inv_txfm2d_add(p(packed), p(pred), stride, p(o1), stride, tx_type, ts, bd)
+                call_ref_inv(ref, ts, packed, pred, stride, o2, tx_type, bd)
+                assert np.array_equal(o1, o2), ("inv", TX_SIZES[ts], tx_type, bd, it)
+
+
+def test_txfm_oracle_vs_golden(oracle):
+    path = os.path.join(GOLDEN, "txfm.npz")
+    assert os.path.exists(path), "run tools/gen_golden.py txfm"
+    z = np.load(path)
+    for i, (ts, tx_type, bd) in enumerate(z["cfg"]):
+        ts, tx_type, bd = int(ts), int(tx_type), int(bd)
+        w, h = TXW[ts], TXH[ts]
+        res = z["res_%d" % i]
+        a = np.zeros(w * h, np.int32)
+        oracle.oracle_fwd_txfm2d(p(res), p(a), w, tx_type, ts, bd, 0)
+        assert np.array_equal(a, z["coeff_%d" % i])
+        pred = z["pred_%d" % i]
+        o = np.zeros(w * h, np.uint16)
+        iw, ih = min(w, 32), min(h, 32)
+        packed = np.ascontiguousarray(a.reshape(h, w)[:ih, :iw]).reshape(-1)
+        oracle.oracle_inv_txfm2d_add(p(packed), p(pred), w, p(o), w, tx_type, ts, bd)
+        assert np.array_equal(o, z["recon_%d" % i])

@@ -39,7 +39,30 @@ def gen_sad(ref, oracle):
                         loop_cfg=loop_cfg, loop_out=np.array(loop_out, np.int64), me_cfg=me_cfg, me_sad=np.array(me_sad), me_mv=np.array(me_mv))
 
 
-FAMILIES = {"sad": gen_sad}
+def gen_txfm(ref, oracle):
+    from test_oracle_pin_txfm import TXW, TXH, allowed_types, ref_fwd, call_ref_inv
+    g = np.random.default_rng(77)
+    cfg, arrays = [], {}
+    for ts in range(19):
+        types = allowed_types(ts)
+        for bd in (8, 10):
+            for tx_type in sorted(set([types[0], types[-1], types[len(types) // 2]])):
+                w, h = TXW[ts], TXH[ts]
+                amp = (1 << bd) - 1
+                res = g.integers(-amp, amp + 1, h * w).astype(np.int16)
+                coeff = ref_fwd(ref, ts, res, w, tx_type, bd)
+                pred = g.integers(0, 1 << bd, h * w).astype(np.uint16)
+                recon = np.zeros(h * w, np.uint16)
+                iw, ih = min(w, 32), min(h, 32)
+                packed = np.ascontiguousarray(coeff.reshape(h, w)[:ih, :iw]).reshape(-1)
+                call_ref_inv(ref, ts, packed, pred, w, recon, tx_type, bd)
+                i = len(cfg)
+                cfg.append((ts, tx_type, bd))
+                arrays["res_%d" % i], arrays["coeff_%d" % i], arrays["pred_%d" % i], arrays["recon_%d" % i] = res, coeff, pred, recon
+    np.savez_compressed(os.path.join(GOLDEN, "txfm.npz"), cfg=np.array(cfg, np.int32), **arrays)
+
+
+FAMILIES = {"sad": gen_sad, "txfm": gen_txfm}
 
 if __name__ == "__main__":
     os.system("make -s -C %s oracle ref" % os.path.join(ROOT, "oracle"))
