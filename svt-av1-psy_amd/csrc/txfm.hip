@@ -1,0 +1,391 @@
+// txfm.hip -- forward / inverse 2-D AV1 transforms for gfx950.
+//
+// Bit-exactness forces the reference's butterfly networks (one rounding shift per rotation, half_btf), so the 1-D
+// kernels are the generated straight-line flow graphs of txfm1d_gen.h (tools/gen_txfm.py), NOT dense contractions:
+// MFMA would round once per output instead of once per rotation and produce different LSBs.
+//
+// Mapping: one lane owns one column (pass 1) and then one row (pass 2) with the whole 1-D vector in VGPRs; the
+// transpose goes through an LDS tile with row pitch W+1 (conflict-free both ways).  max(W,H) lanes per TX block,
+// 256/max(W,H) blocks per workgroup; global loads/stores are lane-contiguous (coefficients leave through LDS so the
+// stores are linear).  Forward: av1_tranform_two_d_core_c (Source/Lib/Codec/transforms.c:2259-2324); inverse:
+// inv_txfm2d_add_c (inv_transforms.c:2459-2535).
+#include "svt_hip_common.h"
+#include "../../include/svtav1_hip.h"
+#include "txfm1d_gen.h"
+
+namespace {
+
+enum { K_DCT = 0, K_ADST = 1, K_IDTX = 2 };
+// TxType -> column kind / row kind / flips (vtx_tab, htx_tab, set_flip_cfg in inv_transforms.h)
+__device__ constexpr uint8_t kColKind[16] = {K_DCT, K_ADST, K_DCT, K_ADST, K_ADST, K_DCT, K_ADST, K_ADST, K_ADST, K_IDTX, K_DCT, K_IDTX, K_ADST, K_IDTX, K_ADST, K_IDTX};
+__device__ constexpr uint8_t kRowKind[16] = {K_DCT, K_DCT, K_ADST, K_ADST, K_DCT, K_ADST, K_ADST, K_ADST, K_ADST, K_IDTX, K_IDTX, K_DCT, K_IDTX, K_ADST, K_IDTX, K_ADST};
+__device__ constexpr uint8_t kUdFlip[16]  = {0, 0, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 1, 0};
+__device__ constexpr uint8_t kLrFlip[16]  = {0, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 1};
+// sinpi (svt_aom_eb_av1_sinpi_arr_data, inv_transforms.c:3228), bits 10..13
+__device__ constexpr int32_t kSinpi[4][5] = {{0, 330, 621, 836, 951}, {0, 660, 1241, 1672, 1901}, {0, 1321, 2482, 3344, 3803}, {0, 2642, 4964, 6689, 7606}};
+
+constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+// transforms.h:27-50 as functions of (W, H)
+constexpr int fwd_shift0(int w, int h) { return ((w == 64 && h == 64) || (w == 32 && h == 64) || (w == 16 && h == 64)) ? 0 : 2; }
+constexpr int fwd_shift1(int w, int h) {
+    const int m = w > h ? w : h, s = w < h ? w : h;
+    if (w == 64 && h == 64) return -2;
+    if ((w == 32 && h == 64) || (w == 16 && h == 64)) return -2;
+    if (w == 64 && (h == 32 || h == 16)) return -4;
+    if (m == 4) return 0;
+    if (m == 8) return -1;
+    if (m == 16) return s == 4 ? -1 : -2;
+    return s == 8 ? -2 : -4; // m == 32
+}
+constexpr int fwd_shift2(int w, int h) { return ((w == 64 && h == 64) || (w == 32 && h == 64) || (w == 64 && h == 32)) ? -2 : 0; }
+constexpr int kFwdCosCol[5][5] = {{13, 13, 13, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 13, 12, 13}, {0, 13, 13, 12, 13}, {0, 0, 13, 12, 13}};
+constexpr int kFwdCosRow[5][5] = {{13, 13, 12, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 12, 13, 12}, {0, 12, 13, 12, 11}, {0, 0, 12, 11, 10}};
+// inv_transforms.c:17-35
+constexpr int inv_shift0(int w, int h) {
+    const int m = w > h ? w : h, s = w < h ? w : h;
+    if (w == h) return w == 4 ? 0 : (w == 8 ? -1 : -2);
+    if (m == 8) return 0;                 // 4x8, 8x4
+    if (m == 16) return -1;               // 8x16, 16x8, 4x16, 16x4
+    if (m == 32) return s == 16 ? -1 : -2; // 16x32/32x16: -1 ; 8x32/32x8: -2
+    return s == 32 ? -1 : -2;             // 32x64/64x32: -1 ; 16x64/64x16: -2
+}
+constexpr int INV_COS_BIT = 12;
+
+__device__ __forceinline__ int32_t rshift_round(const int32_t x, const int bit) { // round_shift(), exact for every int32
+    return (x >> bit) + ((x >> (bit - 1)) & 1);
+}
+__device__ __forceinline__ int32_t mul_sqrt2_like(const int32_t x, const int32_t k) { // round_shift((int64)x * k, 12)
+    return (int32_t)(((int64_t)x * k + 2048) >> 12);
+}
+template <int CB> __device__ __forceinline__ int32_t rshift64_i32(const int32_t v) { return (int32_t)(((int64_t)v + ((int64_t)1 << (CB - 1))) >> CB); }
+
+template <int CB> __device__ __forceinline__ void fadst4(int32_t (&v)[4]) { // transforms.c:1415-1502
+    const int32_t  s1 = kSinpi[CB - 10][1], s2 = kSinpi[CB - 10][2], s3 = kSinpi[CB - 10][3], s4 = kSinpi[CB - 10][4];
+    const uint32_t x0 = (uint32_t)v[0], x1 = (uint32_t)v[1], x2 = (uint32_t)v[2], x3 = (uint32_t)v[3];
+    const uint32_t a0 = s1 * x0 + s2 * x1 + s4 * x3, a1 = s3 * (x0 + x1 - x3), a2 = s4 * x0 - s1 * x1 + s2 * x3, a3 = s3 * x2;
+    v[0] = rshift64_i32<CB>((int32_t)(a0 + a3));
+    v[1] = rshift64_i32<CB>((int32_t)a1);
+    v[2] = rshift64_i32<CB>((int32_t)(a2 - a3));
+    v[3] = rshift64_i32<CB>((int32_t)(a2 - a0 + a3));
+}
+template <int CB> __device__ __forceinline__ void iadst4(int32_t (&v)[4]) { // inv_transforms.c:722-800
+    const int32_t  s1 = kSinpi[CB - 10][1], s2 = kSinpi[CB - 10][2], s3 = kSinpi[CB - 10][3], s4 = kSinpi[CB - 10][4];
+    const uint32_t x0 = (uint32_t)v[0], x1 = (uint32_t)v[1], x2 = (uint32_t)v[2], x3 = (uint32_t)v[3];
+    const uint32_t t0 = s1 * x0 + s4 * x2 + s2 * x3, t1 = s2 * x0 - s1 * x2 - s4 * x3, t3 = s3 * x1, t2 = s3 * (x0 - x2 + x3);
+    v[0] = rshift64_i32<CB>((int32_t)(t0 + t3));
+    v[1] = rshift64_i32<CB>((int32_t)(t1 + t3));
+    v[2] = rshift64_i32<CB>((int32_t)t2);
+    v[3] = rshift64_i32<CB>((int32_t)(t0 + t1 - t3));
+}
+template <int N> __device__ __forceinline__ void identity(int32_t (&v)[N]) { // transforms.c:2205-2234 / inv_transforms.c:2331-2366
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (N == 4) v[i] = mul_sqrt2_like(v[i], 5793);
+        else if (N == 8) v[i] = (int32_t)((uint32_t)v[i] * 2u);
+        else if (N == 16) v[i] = mul_sqrt2_like(v[i], 2 * 5793);
+        else if (N == 32) v[i] = (int32_t)((uint32_t)v[i] * 4u);
+        else v[i] = mul_sqrt2_like(v[i], 4 * 5793);
+    }
+}
+template <int N, int CB> __device__ __forceinline__ void fwd1d(const int kind, int32_t (&v)[N]) {
+    if (kind == K_IDTX) {
+        identity<N>(v);
+    } else if (kind == K_DCT) {
+        if constexpr (N == 4) txfm1d::fdct4<CB>(v);
+        else if constexpr (N == 8) txfm1d::fdct8<CB>(v);
+        else if constexpr (N == 16) txfm1d::fdct16<CB>(v);
+        else if constexpr (N == 32) txfm1d::fdct32<CB>(v);
+        else txfm1d::fdct64<CB>(v);
+    } else {
+        if constexpr (N == 4) fadst4<CB>(v);
+        else if constexpr (N == 8) txfm1d::fadst8<CB>(v);
+        else if constexpr (N == 16) txfm1d::fadst16<CB>(v);
+    }
+}
+template <int N> __device__ __forceinline__ void inv1d(const int kind, int32_t (&v)[N], const int32_t lo, const int32_t hi) {
+    if (kind == K_IDTX) {
+        identity<N>(v);
+    } else if (kind == K_DCT) {
+        if constexpr (N == 4) txfm1d::idct4<INV_COS_BIT>(v, lo, hi);
+        else if constexpr (N == 8) txfm1d::idct8<INV_COS_BIT>(v, lo, hi);
+        else if constexpr (N == 16) txfm1d::idct16<INV_COS_BIT>(v, lo, hi);
+        else if constexpr (N == 32) txfm1d::idct32<INV_COS_BIT>(v, lo, hi);
+        else txfm1d::idct64<INV_COS_BIT>(v, lo, hi);
+    } else {
+        if constexpr (N == 4) iadst4<INV_COS_BIT>(v);
+        else if constexpr (N == 8) txfm1d::iadst8<INV_COS_BIT>(v, lo, hi);
+        else if constexpr (N == 16) txfm1d::iadst16<INV_COS_BIT>(v, lo, hi);
+    }
+}
+
+// ---- forward ----------------------------------------------------------------------------------------------------
+template <int W, int H>
+__global__ __launch_bounds__(256) void fwd_txfm2d_kernel(const int16_t* __restrict__ base, const SvtHipFwdTxfmDesc* __restrict__ descs,
+                                                         const uint32_t n, const int pf, int32_t* __restrict__ out) {
+    constexpr int T = W > H ? W : H, BPW = 256 / T, PITCH = W + 1;
+    constexpr int S0 = fwd_shift0(W, H), S1 = -fwd_shift1(W, H), S2 = -fwd_shift2(W, H);
+    constexpr int CBC = kFwdCosCol[ilog2c(W) - 2][ilog2c(H) - 2], CBR = kFwdCosRow[ilog2c(W) - 2][ilog2c(H) - 2];
+    constexpr bool RECT1 = (W == 2 * H) || (H == 2 * W);
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    const int      tid = threadIdx.x, sub = tid / T, t = tid % T;
+    const uint32_t blk = blockIdx.x * BPW + sub;
+    const bool     active = blk < n;
+    int32_t*       buf = smem + sub * (H * PITCH);
+    const SvtHipFwdTxfmDesc d = descs[active ? blk : 0];
+    const int tx = d.tx_type & 15;
+    if (active && t < W) {
+        int32_t        v[H];
+        const int16_t* in = base + d.in_off + t;
+#pragma unroll
+        for (int r = 0; r < H; r++) {
+            const int rr = kUdFlip[tx] ? (H - 1 - r) : r;
+            v[r]         = (int32_t)((uint32_t)(int32_t)in[(size_t)rr * d.in_stride] << S0);
+        }
+        fwd1d<H, CBC>(kColKind[tx], v);
+        const int cc = kLrFlip[tx] ? (W - 1 - t) : t;
+#pragma unroll
+        for (int r = 0; r < H; r++) buf[r * PITCH + cc] = S1 ? rshift_round(v[r], S1 ? S1 : 1) : v[r];
+    }
+    __syncthreads();
+    if (active && t < H) {
+        int32_t v[W];
+#pragma unroll
+        for (int c = 0; c < W; c++) v[c] = buf[t * PITCH + c];
+        fwd1d<W, CBR>(kRowKind[tx], v);
+        const int kw = W >> pf, kh = H >> pf; // partial-frequency shapes keep the top-left corner only (transforms.c:5202-5273)
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+            int32_t x = S2 ? rshift_round(v[c], S2 ? S2 : 1) : v[c];
+            if (RECT1) x = mul_sqrt2_like(x, 5793);
+            buf[t * PITCH + c] = (t < kh && c < kw) ? x : 0;
+        }
+    }
+    __syncthreads();
+    if (active) {
+        int32_t* o = out + (size_t)blk * (W * H);
+        for (int i = t; i < W * H; i += T) o[i] = buf[(i / W) * PITCH + (i % W)];
+    }
+}
+
+// ---- inverse -----------------------------------------------------------------------------------------------------
+template <typename PIX, int W, int H>
+__global__ __launch_bounds__(256) void inv_txfm2d_kernel(const int32_t* __restrict__ coeff_base, const PIX* __restrict__ pred_base,
+                                                         PIX* __restrict__ recon_base, const SvtHipInvTxfmDesc* __restrict__ descs,
+                                                         const uint32_t n, const int bd) {
+    constexpr int T = W > H ? W : H, BPW = 256 / T, PITCH = W + 1;
+    constexpr int IW = W > 32 ? 32 : W, IH = H > 32 ? 32 : H; // 64-point inputs arrive packed 32 wide / 32 high (inv_transforms.c:2567-2580)
+    constexpr int S0 = -inv_shift0(W, H);
+    constexpr bool RECT1 = (W == 2 * H) || (H == 2 * W);
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    const int      tid = threadIdx.x, sub = tid / T, t = tid % T;
+    const uint32_t blk = blockIdx.x * BPW + sub;
+    const bool     active = blk < n;
+    int32_t*       buf = smem + sub * (H * PITCH);
+    const SvtHipInvTxfmDesc d = descs[active ? blk : 0];
+    const int tx = d.tx_type & 15;
+    const int32_t rhi = (1 << (bd + 7)) - 1, rlo = -(1 << (bd + 7));                   // clamp to bd + 8 bits
+    const int     cb  = (bd + 6 > 16) ? bd + 6 : 16;
+    const int32_t chi = (1 << (cb - 1)) - 1, clo = -(1 << (cb - 1));
+    if (active) {
+        const int32_t* in = coeff_base + d.coeff_off;
+        for (int i = t; i < IW * IH; i += T) buf[(i / IW) * PITCH + (i % IW)] = in[i];
+    }
+    __syncthreads();
+    if (active && t < H) {
+        int32_t v[W];
+        const bool have = t < IH;
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+            int32_t x = (have && c < IW) ? buf[t * PITCH + c] : 0;
+            if (RECT1) x = mul_sqrt2_like(x, 2896);
+            v[c] = txfm1d::clamp_i32(x, rlo, rhi);
+        }
+        inv1d<W>(kRowKind[tx], v, rlo, rhi);
+#pragma unroll
+        for (int c = 0; c < W; c++) buf[t * PITCH + c] = S0 ? rshift_round(v[c], S0 ? S0 : 1) : v[c];
+    }
+    __syncthreads();
+    if (active && t < W) {
+        int32_t   v[H];
+        const int cc = kLrFlip[tx] ? (W - 1 - t) : t;
+#pragma unroll
+        for (int r = 0; r < H; r++) v[r] = txfm1d::clamp_i32(buf[r * PITCH + cc], clo, chi);
+        inv1d<H>(kColKind[tx], v, clo, chi);
+        const PIX*    pr = pred_base + d.pred_off + t;
+        PIX*          rc = recon_base + d.recon_off + t;
+        const int32_t mx = (1 << bd) - 1;
+#pragma unroll
+        for (int r = 0; r < H; r++) {
+            const int32_t res = rshift_round(v[kUdFlip[tx] ? (H - 1 - r) : r], 4);
+            int32_t       px  = (int32_t)((uint32_t)pr[(size_t)r * d.pred_stride] + (uint32_t)res);
+            px                = px < 0 ? 0 : (px > mx ? mx : px);
+            rc[(size_t)r * d.recon_stride] = (PIX)px;
+        }
+    }
+}
+
+constexpr int kTxW[19] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64};
+constexpr int kTxH[19] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16};
+
+template <int W, int H> void launch_fwd(const int16_t* base, const SvtHipFwdTxfmDesc* descs, uint32_t n, int pf, int32_t* out, hipStream_t st) {
+    constexpr int T = W > H ? W : H, BPW = 256 / T;
+    const size_t  shmem = (size_t)BPW * H * (W + 1) * 4;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd_txfm2d_kernel<W, H>), dim3((n + BPW - 1) / BPW), dim3(256), shmem, st, base, descs, n, pf, out);
+    SVT_LAUNCH_CHECK();
+}
+template <typename PIX, int W, int H>
+void launch_inv(const int32_t* coeff, const PIX* pred, PIX* recon, const SvtHipInvTxfmDesc* descs, uint32_t n, int bd, hipStream_t st) {
+    constexpr int T = W > H ? W : H, BPW = 256 / T;
+    const size_t  shmem = (size_t)BPW * H * (W + 1) * 4;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(inv_txfm2d_kernel<PIX, W, H>), dim3((n + BPW - 1) / BPW), dim3(256), shmem, st, coeff, pred, recon, descs, n, bd);
+    SVT_LAUNCH_CHECK();
+}
+#define FOR_ALL_TX_SIZES(X) \
+    X(0, 4, 4) X(1, 8, 8) X(2, 16, 16) X(3, 32, 32) X(4, 64, 64) X(5, 4, 8) X(6, 8, 4) X(7, 8, 16) X(8, 16, 8) X(9, 16, 32) X(10, 32, 16) \
+    X(11, 32, 64) X(12, 64, 32) X(13, 4, 16) X(14, 16, 4) X(15, 8, 32) X(16, 32, 8) X(17, 16, 64) X(18, 64, 16)
+
+template <typename PIX> void inv_dispatch(const int32_t* coeff, const PIX* pred, PIX* recon, const SvtHipInvTxfmDesc* descs, uint32_t n, int tx_size,
+                                          int bd, hipStream_t st) {
+    switch (tx_size) {
+#define X(ID, W, H) case ID: launch_inv<PIX, W, H>(coeff, pred, recon, descs, n, bd, st); break;
+        FOR_ALL_TX_SIZES(X)
+#undef X
+    default: fprintf(stderr, "libsvtav1_hip: bad tx_size %d\n", tx_size); abort();
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+void svt_hip_fwd_txfm2d_batch(const int16_t* residual_base, const SvtHipFwdTxfmDesc* descs, uint32_t n, int tx_size, int bit_depth,
+                              int pf_shape, int32_t* coeff_out, void* stream) {
+    (void)bit_depth; // only feeds range asserts in the reference (transforms.c:2275)
+    svthip::ensure_device();
+    if (n == 0) return;
+    hipStream_t st = (hipStream_t)stream;
+    switch (tx_size) {
+#define X(ID, W, H) case ID: launch_fwd<W, H>(residual_base, descs, n, pf_shape, coeff_out, st); break;
+        FOR_ALL_TX_SIZES(X)
+#undef X
+    default: fprintf(stderr, "libsvtav1_hip: bad tx_size %d\n", tx_size); abort();
+    }
+}
+
+void svt_hip_inv_txfm2d_add_batch(const int32_t* coeff_base, const uint16_t* pred_base, uint16_t* recon_base, const SvtHipInvTxfmDesc* descs,
+                                  uint32_t n, int tx_size, int bd, void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    inv_dispatch<uint16_t>(coeff_base, pred_base, recon_base, descs, n, tx_size, bd, (hipStream_t)stream);
+}
+void svt_hip_inv_txfm2d_add_batch_u8(const int32_t* coeff_base, const uint8_t* pred_base, uint8_t* recon_base, const SvtHipInvTxfmDesc* descs,
+                                     uint32_t n, int tx_size, void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    inv_dispatch<uint8_t>(coeff_base, pred_base, recon_base, descs, n, tx_size, 8, (hipStream_t)stream);
+}
+
+// ---- RTCD-signature single-call forms --------------------------------------------------------------------------------
+void svt_av1_fwd_txfm2d_hip(int16_t* input, int32_t* output, uint32_t input_stride, int tx_type, int tx_size, uint8_t bit_depth, int pf) {
+    const int w = kTxW[tx_size], h = kTxH[tx_size];
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    const size_t pitch = svthip::align_up((size_t)w * 2, 16);
+    c.reserve(pitch * h + (size_t)w * h * 4 + 4096, pitch * h + (size_t)w * h * 4 + 4096);
+    int16_t*           din = (int16_t*)c.dalloc(pitch * h);
+    SvtHipFwdTxfmDesc* dd  = (SvtHipFwdTxfmDesc*)c.dalloc(sizeof(SvtHipFwdTxfmDesc));
+    int32_t*           dout = (int32_t*)c.dalloc((size_t)w * h * 4);
+    c.up2d(din, pitch, input, (size_t)input_stride * 2, (size_t)w * 2, h);
+    SvtHipFwdTxfmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.in_stride = (uint32_t)(pitch / 2);
+    d.tx_type   = (uint8_t)tx_type;
+    c.up(dd, &d, sizeof(d));
+    svt_hip_fwd_txfm2d_batch(din, dd, 1, tx_size, bit_depth, pf, dout, c.stream);
+    c.down(output, dout, (size_t)w * h * 4);
+}
+
+void svt_av1_inv_txfm2d_add_hip(const int32_t* input, uint16_t* output_r, int32_t stride_r, uint16_t* output_w, int32_t stride_w, int tx_type,
+                                int tx_size, int32_t bd) {
+    const int w = kTxW[tx_size], h = kTxH[tx_size];
+    const int iw = w > 32 ? 32 : w, ih = h > 32 ? 32 : h;
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    const size_t pitch = svthip::align_up((size_t)w * 2, 16);
+    c.reserve((size_t)iw * ih * 4 + 2 * pitch * h + 4096, (size_t)iw * ih * 4 + 3 * pitch * h + 4096);
+    int32_t*           dco = (int32_t*)c.dalloc((size_t)iw * ih * 4);
+    uint16_t*          dpr = (uint16_t*)c.dalloc(pitch * h);
+    uint16_t*          drc = (uint16_t*)c.dalloc(pitch * h);
+    SvtHipInvTxfmDesc* dd  = (SvtHipInvTxfmDesc*)c.dalloc(sizeof(SvtHipInvTxfmDesc));
+    c.up(dco, input, (size_t)iw * ih * 4);
+    c.up2d(dpr, pitch, output_r, (size_t)stride_r * 2, (size_t)w * 2, h);
+    SvtHipInvTxfmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.pred_stride = d.recon_stride = (uint32_t)(pitch / 2);
+    d.tx_type = (uint8_t)tx_type;
+    c.up(dd, &d, sizeof(d));
+    svt_hip_inv_txfm2d_add_batch(dco, dpr, drc, dd, 1, tx_size, bd, c.stream);
+    c.down2d(output_w, (size_t)stride_w * 2, drc, pitch, (size_t)w * 2, h);
+}
+
+// svt_av1_inv_txfm_add -> svt_av1_inv_txfm_add_c (inv_transforms.c:3177-3192): 8-bit destination form
+void svt_av1_inv_txfm_add_u8_hip(const int32_t* dqcoeff, uint8_t* dst_r, int32_t stride_r, uint8_t* dst_w, int32_t stride_w, int tx_type,
+                                 int tx_size) {
+    const int w = kTxW[tx_size], h = kTxH[tx_size];
+    const int iw = w > 32 ? 32 : w, ih = h > 32 ? 32 : h;
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    const size_t pitch = svthip::align_up((size_t)w, 16);
+    c.reserve((size_t)iw * ih * 4 + 2 * pitch * h + 4096, (size_t)iw * ih * 4 + 3 * pitch * h + 4096);
+    int32_t*           dco = (int32_t*)c.dalloc((size_t)iw * ih * 4);
+    uint8_t*           dpr = (uint8_t*)c.dalloc(pitch * h);
+    uint8_t*           drc = (uint8_t*)c.dalloc(pitch * h);
+    SvtHipInvTxfmDesc* dd  = (SvtHipInvTxfmDesc*)c.dalloc(sizeof(SvtHipInvTxfmDesc));
+    c.up(dco, dqcoeff, (size_t)iw * ih * 4);
+    c.up2d(dpr, pitch, dst_r, (size_t)stride_r, (size_t)w, h);
+    SvtHipInvTxfmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.pred_stride = d.recon_stride = (uint32_t)pitch;
+    d.tx_type = (uint8_t)tx_type;
+    c.up(dd, &d, sizeof(d));
+    svt_hip_inv_txfm2d_add_batch_u8(dco, dpr, drc, dd, 1, tx_size, c.stream);
+    c.down2d(dst_w, (size_t)stride_w, drc, pitch, (size_t)w, h);
+}
+
+// the 19 (+38 partial-frequency) forward and 19 inverse fixed-size symbols of the RTCD tables
+#define X(ID, W, H)                                                                                                                       \
+    void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t* input, int32_t* output, uint32_t stride, int tx_type, uint8_t bd) {                    \
+        svt_av1_fwd_txfm2d_hip(input, output, stride, tx_type, ID, bd, 0);                                                               \
+    }                                                                                                                                     \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t* input, int32_t* output, uint32_t stride, int tx_type, uint8_t bd) {                 \
+        svt_av1_fwd_txfm2d_hip(input, output, stride, tx_type, ID, bd, 1);                                                               \
+    }                                                                                                                                     \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t* input, int32_t* output, uint32_t stride, int tx_type, uint8_t bd) {                 \
+        svt_av1_fwd_txfm2d_hip(input, output, stride, tx_type, ID, bd, 2);                                                               \
+    }
+FOR_ALL_TX_SIZES(X)
+#undef X
+// inverse: squares (input, r, stride_r, w, stride_w, tx_type, bd); 4x8/8x4/4x16/16x4 add tx_size; the rest add tx_size, eob
+// (common_dsp_rtcd.h:106-116, inv_transforms.c:2545-2716)
+#define INV_SQ(ID, N)                                                                                                                     \
+    void svt_av1_inv_txfm2d_add_##N##x##N##_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* w, int32_t sw, int tx_type, int32_t bd) { \
+        svt_av1_inv_txfm2d_add_hip(in, r, sr, w, sw, tx_type, ID, bd);                                                                    \
+    }
+INV_SQ(0, 4) INV_SQ(1, 8) INV_SQ(2, 16) INV_SQ(3, 32) INV_SQ(4, 64)
+#define INV_R1(ID, W, H)                                                                                                                  \
+    void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* w, int32_t sw, int tx_type, int tx_size, \
+                                                int32_t bd) {                                                                             \
+        (void)tx_size;                                                                                                                    \
+        svt_av1_inv_txfm2d_add_hip(in, r, sr, w, sw, tx_type, ID, bd);                                                                    \
+    }
+INV_R1(5, 4, 8) INV_R1(6, 8, 4) INV_R1(13, 4, 16) INV_R1(14, 16, 4)
+#define INV_R2(ID, W, H)                                                                                                                  \
+    void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* w, int32_t sw, int tx_type, int tx_size, \
+                                                int32_t eob, int32_t bd) {                                                                \
+        (void)tx_size; (void)eob;                                                                                                         \
+        svt_av1_inv_txfm2d_add_hip(in, r, sr, w, sw, tx_type, ID, bd);                                                                    \
+    }
+INV_R2(7, 8, 16) INV_R2(8, 16, 8) INV_R2(9, 16, 32) INV_R2(10, 32, 16) INV_R2(11, 32, 64) INV_R2(12, 64, 32) INV_R2(15, 8, 32)
+INV_R2(16, 32, 8) INV_R2(17, 16, 64) INV_R2(18, 64, 16)
+
+} // extern "C"
