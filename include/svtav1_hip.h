@@ -132,6 +132,41 @@ void   svt_hip_me_fullpel_search_batch(const uint8_t *src_base, const uint8_t *r
                                        uint32_t n, uint32_t max_w, uint32_t max_h, int sub_sad, uint32_t *best_sad,
                                        uint32_t *best_mv, void *workspace, void *stream);
 
+/* ---------------------------------------------------------------- transforms (a10, a12, a13, a14) --- */
+/* TxSize / TxType numbering = Source/Lib/Codec/definitions.h (TX_4X4=0 .. TX_64X16=18; DCT_DCT=0 .. H_FLIPADST=15). */
+typedef struct SvtHipFwdTxfmDesc {
+    uint64_t in_off;    /* int16 elements from residual_base to the block's top-left residual */
+    uint32_t in_stride; /* int16 elements */
+    uint8_t  tx_type;
+    uint8_t  pad[3];
+} SvtHipFwdTxfmDesc;
+/* n forward 2-D transforms of ONE tx_size (svt_av1_fwd_txfm2d_WxH -> av1_tranform_two_d_core_c, transforms.c:2259-2324).
+ * pf_shape 0 = DEFAULT, 1 = N2, 2 = N4 (transforms.c:5202-5273: only the top-left 1/2, 1/4 corner is produced, rest 0).
+ * coeff_out: n blocks of W*H int32, row-major, full W x H also for 64-point sizes (as the reference's output). */
+void svt_hip_fwd_txfm2d_batch(const int16_t *residual_base, const SvtHipFwdTxfmDesc *descs, uint32_t n, int tx_size, int bit_depth,
+                              int pf_shape, int32_t *coeff_out, void *stream);
+typedef struct SvtHipInvTxfmDesc {
+    uint64_t coeff_off;  /* int32 elements from coeff_base; block = min(W,32) x min(H,32) packed (inv_transforms.c:2567-2580) */
+    uint64_t pred_off;   /* pixels from pred_base  (output_r) */
+    uint64_t recon_off;  /* pixels from recon_base (output_w; may alias the prediction) */
+    uint32_t pred_stride, recon_stride;
+    uint8_t  tx_type;
+    uint8_t  pad[7];
+} SvtHipInvTxfmDesc;
+/* n inverse 2-D transforms + reconstruction (svt_av1_inv_txfm2d_add_WxH -> inv_txfm2d_add_c, inv_transforms.c:2459-2535) */
+void svt_hip_inv_txfm2d_add_batch(const int32_t *coeff_base, const uint16_t *pred_base, uint16_t *recon_base,
+                                  const SvtHipInvTxfmDesc *descs, uint32_t n, int tx_size, int bd, void *stream);
+/* 8-bit pixel form (svt_av1_inv_txfm_add -> svt_av1_inv_txfm_add_c, inv_transforms.c:3177-3192) */
+void svt_hip_inv_txfm2d_add_batch_u8(const int32_t *coeff_base, const uint8_t *pred_base, uint8_t *recon_base,
+                                     const SvtHipInvTxfmDesc *descs, uint32_t n, int tx_size, void *stream);
+/* single-call generic forms; the fixed-size RTCD symbols svt_av1_fwd_txfm2d_WxH[_N2|_N4]_hip (57) and
+ * svt_av1_inv_txfm2d_add_WxH_hip (19, three signature shapes, common_dsp_rtcd.h:106-116) are generated from these. */
+void svt_av1_fwd_txfm2d_hip(int16_t *input, int32_t *output, uint32_t input_stride, int tx_type, int tx_size, uint8_t bit_depth, int pf);
+void svt_av1_inv_txfm2d_add_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w,
+                                int tx_type, int tx_size, int32_t bd);
+void svt_av1_inv_txfm_add_u8_hip(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w, int tx_type,
+                                 int tx_size);
+
 #ifdef __cplusplus
 }
 #endif

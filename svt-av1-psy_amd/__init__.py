@@ -58,6 +58,30 @@ PROTOTYPES = {
     "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "svt_hip_me_fullpel_search_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp, vp]),
 }
+TX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16), (32, 64), (64, 32), (4, 16),
+            (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]  # TxSize order of definitions.h
+FwdTxfmDesc = np.dtype([("in_off", "<u8"), ("in_stride", "<u4"), ("tx_type", "u1"), ("pad", "u1", (3,))])
+InvTxfmDesc = np.dtype([("coeff_off", "<u8"), ("pred_off", "<u8"), ("recon_off", "<u8"), ("pred_stride", "<u4"), ("recon_stride", "<u4"),
+                        ("tx_type", "u1"), ("pad", "u1", (7,))])
+assert FwdTxfmDesc.itemsize == 16 and InvTxfmDesc.itemsize == 40
+PROTOTYPES.update({
+    "svt_hip_fwd_txfm2d_batch": (None, [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "svt_hip_inv_txfm2d_add_batch": (None, [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp]),
+    "svt_hip_inv_txfm2d_add_batch_u8": (None, [vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),
+    "svt_av1_fwd_txfm2d_hip": (None, [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_uint8, C.c_int]),
+    "svt_av1_inv_txfm2d_add_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int, C.c_int32]),
+    "svt_av1_inv_txfm_add_u8_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int]),
+})
+for _i, (_w, _h) in enumerate(TX_SIZES):
+    for _sfx in ("", "_N2", "_N4"):
+        PROTOTYPES["svt_av1_fwd_txfm2d_%dx%d%s_hip" % (_w, _h, _sfx)] = (None, [vp, vp, C.c_uint32, C.c_int, C.c_uint8])
+    if _w == _h:
+        _a = [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int32]
+    elif (_w, _h) in ((4, 8), (8, 4), (4, 16), (16, 4)):
+        _a = [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int, C.c_int32]
+    else:
+        _a = [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int, C.c_int32, C.c_int32]
+    PROTOTYPES["svt_av1_inv_txfm2d_add_%dx%d_hip" % (_w, _h)] = (None, _a)
 for _m, _n in [(128, 128), (128, 64), (64, 128), (64, 64), (64, 32), (32, 64), (32, 32), (32, 16), (16, 32), (16, 16), (16, 8),
                (8, 16), (8, 8), (8, 4), (4, 8), (4, 4), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]:
     PROTOTYPES["svt_aom_sad%dx%d_hip" % (_m, _n)] = (C.c_uint32, [vp, C.c_int, vp, C.c_int])
