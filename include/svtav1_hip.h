@@ -167,6 +167,33 @@ void svt_av1_inv_txfm2d_add_hip(const int32_t *input, uint16_t *output_r, int32_
 void svt_av1_inv_txfm_add_u8_hip(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w, int tx_type,
                                  int tx_size);
 
+/* ---------------------------------------------------------------- quantization (a11, a15, a16) ------- */
+typedef struct SvtHipQuantParams { /* DC/AC pairs of MacroblockPlane's tables (md_config_process.c:111-189) */
+    int16_t zbin[2], round[2], quant[2], quant_shift[2], dequant[2];
+    int32_t log_scale; /* 0, 1 (32x32-class), 2 (64-point) -- full_loop.c:1690 */
+} SvtHipQuantParams;
+typedef struct SvtHipQuantDesc {
+    uint32_t qparam_idx; /* row of qparams[]                                  */
+    uint32_t iscan_idx;  /* row of iscan_tables[][n_coeffs] (ScanOrder.iscan) */
+    uint32_t qm_idx;     /* row of qm_tables / iqm_tables (ignored when those are NULL) */
+    uint32_t reserved;
+} SvtHipQuantDesc;
+/* n blocks of n_coeffs (16..1024, power of two) coefficients, blocks contiguous.  mode 0 = svt_aom_quantize_b_c_ii,
+ * 1 = svt_aom_highbd_quantize_b_c, 2 = quantize_fp_helper_c, 3 = highbd_quantize_fp_helper_c (full_loop.c:29-453).
+ * Outputs: qcoeff/dqcoeff [n][n_coeffs] (every element written), eob[n]. */
+void svt_hip_quantize_batch(int mode, const int32_t *coeff, uint32_t n, uint32_t n_coeffs, const SvtHipQuantParams *qparams,
+                            const int16_t *iscan_tables, const uint8_t *qm_tables, const uint8_t *iqm_tables,
+                            const SvtHipQuantDesc *descs, int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob, void *stream);
+/* svt_handle_transform{64x64,32x64,64x32,16x64,64x16}[_N2_N4]_c (transforms.c:2374-2542), in place on n blocks of W*H:
+ * energy[n] of the discarded high-frequency area + repack of 64-wide rows to stride 32. */
+void svt_hip_handle_transform_batch(int32_t *coeff, uint32_t n, int tx_size, int n2_n4, uint64_t *energy, void *stream);
+/* single-call forms; the ten RTCD quantizer symbols and the ten svt_handle_transformWxH[_N2_N4]_hip are thin aliases */
+void     svt_quantize_hip(int mode, const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr,
+                          const int16_t *quant_ptr, const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr,
+                          const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, const int16_t *iscan,
+                          const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int log_scale);
+uint64_t svt_handle_transform_hip(int32_t *output, int tx_size, int n2_n4);
+
 #ifdef __cplusplus
 }
 #endif

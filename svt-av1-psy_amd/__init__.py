@@ -82,6 +82,26 @@ for _i, (_w, _h) in enumerate(TX_SIZES):
     else:
         _a = [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int, C.c_int32, C.c_int32]
     PROTOTYPES["svt_av1_inv_txfm2d_add_%dx%d_hip" % (_w, _h)] = (None, _a)
+QuantParams = np.dtype([("zbin", "<i2", (2,)), ("round", "<i2", (2,)), ("quant", "<i2", (2,)), ("quant_shift", "<i2", (2,)),
+                        ("dequant", "<i2", (2,)), ("log_scale", "<i4")])
+QuantDesc = np.dtype([("qparam_idx", "<u4"), ("iscan_idx", "<u4"), ("qm_idx", "<u4"), ("reserved", "<u4")])
+assert QuantParams.itemsize == 24 and QuantDesc.itemsize == 16
+_Q = [vp, C.c_ssize_t, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+PROTOTYPES.update({
+    "svt_hip_quantize_batch": (None, [C.c_int, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "svt_hip_handle_transform_batch": (None, [vp, C.c_uint32, C.c_int, C.c_int, vp, vp]),
+    "svt_quantize_hip": (None, [C.c_int] + _Q + [vp, vp, C.c_int]),
+    "svt_handle_transform_hip": (C.c_uint64, [vp, C.c_int, C.c_int]),
+    "svt_aom_quantize_b_hip": (None, _Q + [vp, vp, C.c_int32]),
+    "svt_aom_highbd_quantize_b_hip": (None, _Q + [vp, vp, C.c_int32]),
+    "svt_av1_quantize_fp_hip": (None, _Q), "svt_av1_quantize_fp_32x32_hip": (None, _Q), "svt_av1_quantize_fp_64x64_hip": (None, _Q),
+    "svt_av1_quantize_fp_qm_hip": (None, _Q + [vp, vp, C.c_int16]),
+    "svt_av1_highbd_quantize_fp_hip": (None, _Q + [C.c_int16]),
+    "svt_av1_highbd_quantize_fp_qm_hip": (None, _Q + [vp, vp, C.c_int16]),
+})
+for _n in ("64x64", "32x64", "64x32", "16x64", "64x16"):
+    PROTOTYPES["svt_handle_transform%s_hip" % _n] = (C.c_uint64, [vp])
+    PROTOTYPES["svt_handle_transform%s_N2_N4_hip" % _n] = (C.c_uint64, [vp])
 for _m, _n in [(128, 128), (128, 64), (64, 128), (64, 64), (64, 32), (32, 64), (32, 32), (32, 16), (16, 32), (16, 16), (16, 8),
                (8, 16), (8, 8), (8, 4), (4, 8), (4, 4), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]:
     PROTOTYPES["svt_aom_sad%dx%d_hip" % (_m, _n)] = (C.c_uint32, [vp, C.c_int, vp, C.c_int])
