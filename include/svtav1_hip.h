@@ -194,6 +194,42 @@ void     svt_quantize_hip(int mode, const int32_t *coeff_ptr, intptr_t n_coeffs,
                           const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int log_scale);
 uint64_t svt_handle_transform_hip(int32_t *output, int tx_size, int n2_n4);
 
+/* ---------------------------------------------------------------- CDEF (a17-a20) --------------------- */
+/* One plane of one frame.  Filter-block grid = ceil(width / (64 >> xdec)) x ceil(height / (64 >> ydec)); tile
+ * construction as cdef_seg_search (cdef_process.c:208-228).  Call once per plane, luma first (it produces dir/var). */
+typedef struct SvtHipCdefParams {
+    const void *recon;   /* deblocked reconstruction (input), PIX = uint8_t or uint16_t            */
+    const void *source;  /* original picture (search mode only)                                    */
+    void       *out;     /* apply mode: filtered plane, OUT OF PLACE; caller pre-copies recon->out
+                            (skipped units / zero-strength blocks are not touched)                  */
+    uint32_t recon_stride, source_stride, out_stride; /* pixels */
+    uint32_t width, height;                           /* plane size in pixels */
+    uint8_t  xdec, ydec, pli, is_16bit;
+    uint8_t  coeff_shift, pri_damping, sec_damping, subsampling; /* dampings before the per-plane adjustment of cdef.c:349-350 */
+    uint32_t ncand;       /* search: number of (pri, sec) candidates */
+    const uint8_t *skip;  /* [(fb rows * 8)][(fb cols * 8)] 1 = 8x8 luma unit is skipped (svt_sb_compute_cdef_list) */
+    const int32_t *pri;   /* search: [ncand] primary levels; apply: [nfb]                           */
+    const int32_t *sec;   /* search: [ncand] secondary strengths in {0,1,2,4}; apply: [nfb]         */
+    uint8_t       *dir;   /* [nfb][64] written when pli == 0, read otherwise                        */
+    int32_t       *var;   /* [nfb][64]                                                              */
+    uint64_t      *mse;   /* search: [nfb][ncand] = svt_compute_cdef_dist of every candidate        */
+} SvtHipCdefParams;
+/* mode 0 = apply (svt_cdef_filter_fb over the frame, enc_cdef.c:284), 1 = strength search (cdef_process.c:106).
+ * All pointers inside `params` are DEVICE pointers; the struct itself is read on the host. */
+void svt_hip_cdef_frame(int mode, const SvtHipCdefParams *params, void *stream);
+/* RTCD-signature single-call forms (common_dsp_rtcd.h:1010-1029, aom_dsp_rtcd.h:208-209) */
+uint8_t  svt_aom_cdef_find_dir_hip(const uint16_t *img, int32_t stride, int32_t *var, int32_t coeff_shift);
+void     svt_aom_cdef_find_dir_dual_hip(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2,
+                                        int32_t coeff_shift, uint8_t *out1, uint8_t *out2);
+void     svt_cdef_filter_block_hip(uint8_t *dst8, uint16_t *dst16, int32_t dstride, const uint16_t *in, int32_t pri_strength,
+                                   int32_t sec_strength, int32_t dir, int32_t pri_damping, int32_t sec_damping, int32_t bsize,
+                                   int32_t coeff_shift, uint8_t subsampling_factor);
+uint64_t svt_compute_cdef_dist_16bit_hip(const uint16_t *dst, int32_t dstride, const uint16_t *src, const void *dlist, int32_t cdef_count,
+                                         int bsize, int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
+uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t *dst8, int32_t dstride, const uint8_t *src8, const void *dlist, int32_t cdef_count,
+                                        int bsize, int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
+void     svt_aom_copy_rect8_8bit_to_16bit_hip(uint16_t *dst, int32_t dstride, const uint8_t *src, int32_t sstride, int32_t v, int32_t h);
+
 #ifdef __cplusplus
 }
 #endif

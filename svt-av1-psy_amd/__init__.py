@@ -102,6 +102,24 @@ PROTOTYPES.update({
 for _n in ("64x64", "32x64", "64x32", "16x64", "64x16"):
     PROTOTYPES["svt_handle_transform%s_hip" % _n] = (C.c_uint64, [vp])
     PROTOTYPES["svt_handle_transform%s_N2_N4_hip" % _n] = (C.c_uint64, [vp])
+
+
+class CdefParams(C.Structure):
+    _fields_ = [("recon", vp), ("source", vp), ("out", vp), ("recon_stride", C.c_uint32), ("source_stride", C.c_uint32), ("out_stride", C.c_uint32),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("xdec", C.c_uint8), ("ydec", C.c_uint8), ("pli", C.c_uint8), ("is_16bit", C.c_uint8),
+                ("coeff_shift", C.c_uint8), ("pri_damping", C.c_uint8), ("sec_damping", C.c_uint8), ("subsampling", C.c_uint8), ("ncand", C.c_uint32),
+                ("skip", vp), ("pri", vp), ("sec", vp), ("dir", vp), ("var", vp), ("mse", vp)]
+
+
+PROTOTYPES.update({
+    "svt_hip_cdef_frame": (None, [C.c_int, C.POINTER(CdefParams), vp]),
+    "svt_aom_cdef_find_dir_hip": (C.c_uint8, [vp, C.c_int32, vp, C.c_int32]),
+    "svt_aom_cdef_find_dir_dual_hip": (None, [vp, vp, C.c_int, vp, vp, C.c_int32, vp, vp]),
+    "svt_cdef_filter_block_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint8]),
+    "svt_compute_cdef_dist_16bit_hip": (C.c_uint64, [vp, C.c_int32, vp, vp, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_uint8]),
+    "svt_compute_cdef_dist_8bit_hip": (C.c_uint64, [vp, C.c_int32, vp, vp, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_uint8]),
+    "svt_aom_copy_rect8_8bit_to_16bit_hip": (None, [vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32]),
+})
 for _m, _n in [(128, 128), (128, 64), (64, 128), (64, 64), (64, 32), (32, 64), (32, 32), (32, 16), (16, 32), (16, 16), (16, 8),
                (8, 16), (8, 8), (8, 4), (4, 8), (4, 4), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]:
     PROTOTYPES["svt_aom_sad%dx%d_hip" % (_m, _n)] = (C.c_uint32, [vp, C.c_int, vp, C.c_int])
