@@ -220,8 +220,8 @@ def main():
                                               "traffic": None, "algorithmic_bytes_per_block": 8192}}
     if a.extra:
         for (w2, h2, sub) in [(16, 9, 1), (64, 32, 0), (256, 256, 0)]:
-            nf = a.frames if w2 < 256 else 2
-            dd = np.concatenate([pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, w2, h2, PLANE, n_refs=a.refs, src_plane=f, ref_plane0=f + 1)
+            nf = a.frames if w2 < 64 else (4 if w2 < 256 else 1)
+            dd = np.concatenate([pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, w2, h2, PLANE, n_refs=(a.refs if w2 < 256 else 1), src_plane=f, ref_plane0=f + 1)
                                  for f in range(nf)])
             # search windows must stay inside the padded planes: clamp like integer_search_b64 does (motion_estimation.c:1440-1506)
             keep = []
@@ -236,7 +236,7 @@ def main():
             ws2 = torch.zeros(max(wsb, 8), dtype=torch.uint8, device="cuda")
             f2 = lambda: lib.svt_hip_me_fullpel_search_batch(d_planes.data_ptr(), d_planes.data_ptr(), tdd.data_ptr(), len(dd), w2, h2, sub,  # noqa: E731
                                                              d_sad.data_ptr(), d_mv.data_ptr(), ws2.data_ptr() if wsb else None, stream)
-            st = max(2, a.steps // (4 if w2 >= 64 else 1))
+            st = a.steps if w2 < 64 else 2
             _, dv = time_steps(torch, f2, st, 1)
             kernels["me_search_%dx%d_sub%d" % (w2, h2, sub)] = {"value": len(dd) * w2 * h2 / (dv / st) / 1e6, "unit": "Mblocks/s",
                                                                "sb_refs": len(dd), "sad_ops_per_s": len(dd) * w2 * h2 * (2048 if sub else 4096) / (dv / st)}
