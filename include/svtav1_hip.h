@@ -230,6 +230,38 @@ uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t *dst8, int32_t dstride, co
                                         int bsize, int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
 void     svt_aom_copy_rect8_8bit_to_16bit_hip(uint16_t *dst, int32_t dstride, const uint8_t *src, int32_t sstride, int32_t v, int32_t h);
 
+/* ---------------------------------------------------------------- loop restoration (a21-a23) ---------- */
+typedef struct SvtHipLrUnit {          /* RestorationUnitInfo (restoration.h:184-188) without its alignment padding */
+    int32_t rtype;                     /* RestorationType: 0 RESTORE_NONE, 1 RESTORE_WIENER, 2 RESTORE_SGRPROJ */
+    int16_t vfilter[8], hfilter[8];    /* WienerInfo: 7 symmetric taps + a trailing 0 */
+    int32_t ep, xqd[2];                /* SgrprojInfo */
+} SvtHipLrUnit;
+/* One plane of svt_av1_loop_restoration_filter_frame (restoration.c:1179): restoration units of unit_size pixels
+ * (shifted up by 8 >> ss_y, the last one absorbing a remainder < 3/2 unit), 64 >> ss_y row stripes, 64 >> ss_x column
+ * processing units, stripe boundaries taken from the saved deblocked lines (2 rows per stripe, restoration.c:288-332),
+ * frame edges replicated (svt_extend_frame).  Out of place.  All pointers are device pointers. */
+typedef struct SvtHipLrParams {
+    const void *data;            /* CDEF output plane */
+    const void *boundary_above;  /* rsb->stripe_boundary_above: rows 2*stripe, 2*stripe+1 */
+    const void *boundary_below;
+    void       *dst;
+    uint32_t stride, boundary_stride, dst_stride; /* pixels */
+    uint32_t width, height, unit_size;
+    uint8_t  ss_x, ss_y, highbd, bit_depth;
+    const SvtHipLrUnit *units;   /* [vert units][horz units] */
+} SvtHipLrParams;
+void svt_hip_lr_filter_frame(const SvtHipLrParams *params, void *stream);
+/* RTCD-signature single-call forms (common_dsp_rtcd.h:144-181); highbd pointers use the CONVERT_TO_BYTEPTR convention */
+void svt_av1_wiener_convolve_add_src_hip(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x,
+                                         const int16_t *filter_y, int32_t w, int32_t h, const void *conv_params);
+void svt_av1_highbd_wiener_convolve_add_src_hip(const uint8_t *src8, ptrdiff_t src_stride, uint8_t *dst8, ptrdiff_t dst_stride,
+                                                const int16_t *filter_x, const int16_t *filter_y, int32_t w, int32_t h,
+                                                const void *conv_params, int32_t bd);
+void svt_av1_selfguided_restoration_hip(const uint8_t *dgd8, int32_t width, int32_t height, int32_t dgd_stride, int32_t *flt0, int32_t *flt1,
+                                        int32_t flt_stride, int32_t sgr_params_idx, int32_t bit_depth, int32_t highbd);
+void svt_apply_selfguided_restoration_hip(const uint8_t *dat8, int32_t width, int32_t height, int32_t stride, int32_t eps, const int32_t *xqd,
+                                          uint8_t *dst8, int32_t dst_stride, int32_t *tmpbuf, int32_t bit_depth, int32_t highbd);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,6 +120,23 @@ PROTOTYPES.update({
     "svt_compute_cdef_dist_8bit_hip": (C.c_uint64, [vp, C.c_int32, vp, vp, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_uint8]),
     "svt_aom_copy_rect8_8bit_to_16bit_hip": (None, [vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32]),
 })
+LrUnit = np.dtype([("rtype", "<i4"), ("vfilter", "<i2", (8,)), ("hfilter", "<i2", (8,)), ("ep", "<i4"), ("xqd", "<i4", (2,))])
+assert LrUnit.itemsize == 48
+
+
+class LrParams(C.Structure):
+    _fields_ = [("data", vp), ("boundary_above", vp), ("boundary_below", vp), ("dst", vp), ("stride", C.c_uint32), ("boundary_stride", C.c_uint32),
+                ("dst_stride", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("unit_size", C.c_uint32), ("ss_x", C.c_uint8),
+                ("ss_y", C.c_uint8), ("highbd", C.c_uint8), ("bit_depth", C.c_uint8), ("units", vp)]
+
+
+PROTOTYPES.update({
+    "svt_hip_lr_filter_frame": (None, [C.POINTER(LrParams), vp]),
+    "svt_av1_wiener_convolve_add_src_hip": (None, [vp, C.c_ssize_t, vp, C.c_ssize_t, vp, vp, C.c_int32, C.c_int32, vp]),
+    "svt_av1_highbd_wiener_convolve_add_src_hip": (None, [vp, C.c_ssize_t, vp, C.c_ssize_t, vp, vp, C.c_int32, C.c_int32, vp, C.c_int32]),
+    "svt_av1_selfguided_restoration_hip": (None, [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "svt_apply_selfguided_restoration_hip": (None, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32]),
+})
 for _m, _n in [(128, 128), (128, 64), (64, 128), (64, 64), (64, 32), (32, 64), (32, 32), (32, 16), (16, 32), (16, 16), (16, 8),
                (8, 16), (8, 8), (8, 4), (4, 8), (4, 4), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]:
     PROTOTYPES["svt_aom_sad%dx%d_hip" % (_m, _n)] = (C.c_uint32, [vp, C.c_int, vp, C.c_int])

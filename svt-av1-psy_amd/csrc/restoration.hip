@@ -1,0 +1,344 @@
+// restoration.hip -- loop restoration for gfx950: separable 7-tap Wiener with "add src",
+// self-guided (box r = 2 "fast" + r = 1) filter, and the stripe / restoration-unit frame driver.
+//
+// One workgroup filters one processing unit (64 >> ss_x columns of one 64 >> ss_y row stripe).  The unit plus its
+// 3-pixel halo is staged into LDS once, with the stripe-boundary substitution of restoration.c:288-332 (rows above /
+// below a stripe come from the saved deblocked lines, frame edges are edge-extended) folded into the staging, so the
+// filters themselves never touch HBM again: Wiener keeps its clamped horizontal pass in LDS; the self-guided filter
+// builds A/B (box sums -> x_by_xplus1 / one_by_x tables, restoration.c:705-764) in LDS and applies the 3x3 weighting
+// from there.  Out of place, 2 B/px in + 2 B/px out at 10 bit = the 4 B/px of SURVEY 8(d).
+#include "svt_hip_common.h"
+#include "../../include/svtav1_hip.h"
+
+namespace {
+
+constexpr int FILTER_BITS = 7;
+constexpr int TW = 64 + 8;          // LDS tile pitch (u16): 64 columns + 3 left + up to 5 right (3 halo + the 8th-tap column)
+constexpr int TH = 64 + 6;          // rows
+__device__ __forceinline__ int rpot(const int v, const int n) { return (v + ((1 << n) >> 1)) >> n; }
+__device__ __forceinline__ uint32_t rpotu(const uint32_t v, const int n) { return (v + ((1u << n) >> 1)) >> n; }
+__device__ __forceinline__ int clampi(const int v, const int lo, const int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// svt_aom_eb_sgr_params (restoration.c:85-103)
+__device__ constexpr int16_t kSgrR[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {2, 0}, {2, 0}};
+__device__ constexpr int16_t kSgrS[16][2] = {{140, 3236}, {112, 2158}, {93, 1618}, {80, 1438}, {70, 1295}, {58, 1177}, {47, 1079}, {37, 996},
+                                             {30, 925},   {25, 863},   {-1, 2589}, {-1, 1618}, {-1, 1177}, {-1, 925},  {56, -1},   {22, -1}};
+// svt_aom_eb_x_by_xplus1 = round(256 z / (z + 1)), [0] = 1, [255] = 256; svt_aom_eb_one_by_x = round(4096 / n) (restoration.c:647-667)
+__device__ __forceinline__ int x_by_xplus1(const uint32_t z) { return z == 0 ? 1 : (z >= 255 ? 256 : (int)((256 * z + (z + 1) / 2) / (z + 1))); }
+__device__ __forceinline__ uint32_t one_by_x(const uint32_t n) { return (4096 + n / 2) / n; }
+
+struct TileSrc { // where a processing unit's pixels come from
+    const void* data; const void* above; const void* below;
+    int stride, bstride, w, h, highbd;     // plane size (frame mode) or unbounded (raw mode: w = h = 0)
+    int x0, y0, uw, uh;                    // unit origin and size inside the plane
+    int stripe_top, stripe_bot, stripe_idx;
+};
+__device__ __forceinline__ int rd_px(const void* p, const int highbd, const size_t off) {
+    return highbd ? ((const uint16_t*)p)[off] : ((const uint8_t*)p)[off];
+}
+// restoration.c:288-332 (stripe boundary substitution) + svt_extend_frame (edge replication); raw mode reads as is
+__device__ __forceinline__ int src_px(const TileSrc& s, int y, int x) {
+    if (s.w == 0) return rd_px(s.data, s.highbd, (size_t)((long long)y * s.stride + x));
+    x = clampi(x, 0, s.w - 1);
+    if (y < s.stripe_top) {
+        if (s.stripe_top == 0) return rd_px(s.data, s.highbd, (size_t)clampi(y, 0, s.h - 1) * s.stride + x);
+        const int i = y - s.stripe_top;
+        return rd_px(s.above, s.highbd, (size_t)(2 * s.stripe_idx + (i + 2 > 0 ? i + 2 : 0)) * s.bstride + x);
+    }
+    if (y >= s.stripe_bot) {
+        if (s.stripe_bot >= s.h) return rd_px(s.data, s.highbd, (size_t)clampi(y, 0, s.h - 1) * s.stride + x);
+        const int i = y - s.stripe_bot;
+        return rd_px(s.below, s.highbd, (size_t)(2 * s.stripe_idx + (i < 1 ? i : 1)) * s.bstride + x);
+    }
+    return rd_px(s.data, s.highbd, (size_t)y * s.stride + x);
+}
+// tile[(r) * TW + c] <- pixel (y0 - 3 + r, x0 - 3 + c), r < uh + 6, c < uw + 8 (the extra columns feed tap 7, always x 0)
+__device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, const int tid) {
+    const int rows = s.uh + 6, cols = s.uw + 6;
+    for (int i = tid; i < rows * TW; i += 256) {
+        const int r = i / TW, c = i - r * TW;
+        tile[i]     = c < cols ? (uint16_t)src_px(s, s.y0 - 3 + r, s.x0 - 3 + c) : (uint16_t)0;
+    }
+}
+
+struct WienerTaps { int16_t fx[8], fy[8]; };
+// Wiener on a staged tile: horizontal pass (clamped, convolve.c:63-83 / :156-176) into `mid`, vertical pass to `out(y, x)`
+template <typename OUT> __device__ __forceinline__ void wiener_tile(const uint16_t* tile, uint16_t* mid, const WienerTaps& t, const int uw, const int uh,
+                                                                    const int bd, const int tid, OUT out) {
+    int r0 = 3, r1 = 2 * FILTER_BITS - 3; // get_conv_params_wiener, convolve.h:70-88
+    const int range = bd + FILTER_BITS - r0 + 2;
+    if (range > 16) { r0 += range - 16; r1 -= range - 16; }
+    const int lim = (1 << (bd + 1 + FILTER_BITS - r0)) - 1;
+    for (int i = tid; i < (uh + 6) * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        if (c < uw) {
+            const uint16_t* p   = tile + r * TW + c; // p[3] is the centre pixel
+            int             sum = ((int)p[3] << FILTER_BITS) + (1 << (bd + FILTER_BITS - 1));
+#pragma unroll
+            for (int k = 0; k < 8; k++) sum += (int)p[k] * t.fx[k];
+            mid[i] = (uint16_t)clampi(rpot(sum, r0), 0, lim);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < uh * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        if (c < uw) {
+            const uint16_t* p   = mid + r * 64 + c; // rows r .. r+6 <-> y-3 .. y+3
+            int             sum = ((int)p[3 * 64] << FILTER_BITS) - (1 << (bd + r1 - 1));
+#pragma unroll
+            for (int k = 0; k < 7; k++) sum += (int)p[k * 64] * t.fy[k]; // tap 7 multiplies the zeroed row of convolve.c:118
+            out(r, c, clampi(rpot(sum, r1), 0, (1 << bd) - 1));
+        }
+    }
+}
+
+// Self-guided filter on a staged tile.  AB holds A then B for positions (i, j) in [-1, uh] x [-1, uw] (pitch 66).
+// pass 0: r = 2, A/B on odd i only ("fast", restoration.c:669-800); pass 1: r = 1 (restoration.c:801-880).
+__device__ __forceinline__ void sgr_ab_pass(const uint16_t* tile, int32_t* AB, const int pass, const int idx, const int uw, const int uh, const int bd,
+                                            const int tid) {
+    const int      r = kSgrR[idx][pass];
+    const uint32_t s = (uint32_t)kSgrS[idx][pass], n = (uint32_t)((2 * r + 1) * (2 * r + 1)), obx = one_by_x(n);
+    for (int e = tid; e < 66 * 66; e += 256) {
+        const int ii = e / 66, jj = e - ii * 66; // i = ii - 1, j = jj - 1
+        if (ii > uh + 1 || jj > uw + 1) continue;
+        if (pass == 0 && (ii & 1)) continue;    // i even -> not needed by the fast filter (i = ii - 1 odd <=> ii even)
+        const uint16_t* p = tile + (ii + 2) * TW + (jj + 2); // pixel (i, j) sits at tile[(i + 3) * TW + j + 3]
+        uint32_t        sum = 0, sq = 0;
+        for (int dy = -r; dy <= r; dy++)
+            for (int dx = -r; dx <= r; dx++) {
+                const uint32_t v = p[dy * TW + dx];
+                sum += v;
+                sq += v * v;
+            }
+        const uint32_t a = rpotu(sq, 2 * (bd - 8)), b = rpotu(sum, bd - 8);
+        const uint32_t pp = (a * n < b * b) ? 0 : a * n - b * b;
+        const uint32_t z  = rpotu(pp * s, 20);
+        const int      av = x_by_xplus1(z > 255 ? 255 : z);
+        AB[e]             = av;
+        AB[66 * 66 + e]   = (int32_t)rpotu((uint32_t)(256 - av) * sum * obx, 12);
+    }
+}
+__device__ __forceinline__ int32_t sgr_flt_px(const uint16_t* tile, const int32_t* AB, const int pass, const int i, const int j) {
+    const int32_t *A = AB + (i + 1) * 66 + (j + 1), *B = A + 66 * 66;
+    int32_t        a, b, nb;
+    if (pass == 0) {
+        if (!(i & 1)) {
+            nb = 5;
+            a  = (A[-66] + A[66]) * 6 + (A[-67] + A[65] + A[-65] + A[67]) * 5;
+            b  = (B[-66] + B[66]) * 6 + (B[-67] + B[65] + B[-65] + B[67]) * 5;
+        } else {
+            nb = 4;
+            a  = A[0] * 6 + (A[-1] + A[1]) * 5;
+            b  = B[0] * 6 + (B[-1] + B[1]) * 5;
+        }
+    } else {
+        nb = 5;
+        a  = (A[0] + A[-1] + A[1] + A[-66] + A[66]) * 4 + (A[-67] + A[65] + A[-65] + A[67]) * 3;
+        b  = (B[0] + B[-1] + B[1] + B[-66] + B[66]) * 4 + (B[-67] + B[65] + B[-65] + B[67]) * 3;
+    }
+    const int32_t v = a * (int32_t)tile[(i + 3) * TW + j + 3] + b;
+    return rpot(v, 8 + nb - 4);
+}
+
+// flt[] (int32, pitch 64) is produced per pass; MODE_APPLY combines with xqd (svt_apply_selfguided_restoration_c :957-992)
+template <typename OUT0, typename OUT1>
+__device__ __forceinline__ void sgr_tile(const uint16_t* tile, int32_t* AB, int32_t* flt0, const int idx, const int uw, const int uh, const int bd,
+                                         const int tid, OUT0 out_flt0, OUT1 out_flt1_or_apply) {
+    const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
+    if (p0) {
+        sgr_ab_pass(tile, AB, 0, idx, uw, uh, bd, tid);
+        __syncthreads();
+        for (int i = tid; i < uh * 64; i += 256) {
+            const int r = i >> 6, c = i & 63;
+            if (c < uw) {
+                const int32_t f = sgr_flt_px(tile, AB, 0, r, c);
+                flt0[i]         = f;
+                out_flt0(r, c, f);
+            }
+        }
+        __syncthreads();
+    }
+    if (p1) sgr_ab_pass(tile, AB, 1, idx, uw, uh, bd, tid);
+    __syncthreads();
+    for (int i = tid; i < uh * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        if (c < uw) out_flt1_or_apply(r, c, p0 ? flt0[i] : 0, p1 ? sgr_flt_px(tile, AB, 1, r, c) : 0);
+    }
+}
+__device__ __forceinline__ int sgr_combine(const int px, const int32_t f0, const int32_t f1, const int idx, const int32_t xqd0, const int32_t xqd1, const int bd) {
+    int xq0, xq1; // svt_decode_xq, restoration.c:634-645
+    if (kSgrR[idx][0] == 0) { xq0 = 0; xq1 = 128 - xqd1; }
+    else if (kSgrR[idx][1] == 0) { xq0 = xqd0; xq1 = 0; }
+    else { xq0 = xqd0; xq1 = 128 - xq0 - xqd1; }
+    const int32_t u = px << 4;
+    int32_t       v = u << 7;
+    if (kSgrR[idx][0] > 0) v += xq0 * (f0 - u);
+    if (kSgrR[idx][1] > 0) v += xq1 * (f1 - u);
+    const int16_t w = (int16_t)rpot(v, 11);
+    return clampi(w, 0, (1 << bd) - 1);
+}
+
+constexpr int kSgrRH[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {2, 0}, {2, 0}}; // host copy
+constexpr size_t LR_SMEM = (size_t)TH * TW * 2 + (size_t)TH * 64 * 2 + (size_t)2 * 66 * 66 * 4 + (size_t)64 * 64 * 4;
+
+// ---- frame kernel ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P) {
+    HIP_DYNAMIC_SHARED(uint16_t, smem)
+    uint16_t* tile = smem;
+    uint16_t* mid  = tile + TH * TW;
+    int32_t*  AB   = (int32_t*)(mid + TH * 64);
+    int32_t*  flt0 = AB + 2 * 66 * 66;
+    const int tid = threadIdx.x;
+    const int pw = (int)P.width, ph = (int)P.height, off = 8 >> P.ss_y, sh = 64 >> P.ss_y, cw = 64 >> P.ss_x;
+    TileSrc s;
+    s.data = P.data; s.above = P.boundary_above; s.below = P.boundary_below;
+    s.stride = (int)P.stride; s.bstride = (int)P.boundary_stride; s.w = pw; s.h = ph; s.highbd = P.highbd;
+    s.stripe_idx = blockIdx.y;
+    s.stripe_top = s.stripe_idx * sh - off < 0 ? 0 : s.stripe_idx * sh - off;
+    s.stripe_bot = (s.stripe_idx + 1) * sh - off > ph ? ph : (s.stripe_idx + 1) * sh - off;
+    s.x0 = blockIdx.x * cw; s.y0 = s.stripe_top;
+    s.uw = pw - s.x0 < cw ? pw - s.x0 : cw; s.uh = s.stripe_bot - s.stripe_top;
+    if (s.uh <= 0 || s.uw <= 0) return;
+    const int us  = (int)P.unit_size;
+    int       nvu = (ph + (us >> 1)) / us, nhu = (pw + (us >> 1)) / us;
+    nvu = nvu > 0 ? nvu : 1; nhu = nhu > 0 ? nhu : 1;
+    int ur = (s.y0 + off) / us, uc = s.x0 / us;
+    ur = ur >= nvu ? nvu - 1 : ur; uc = uc >= nhu ? nhu - 1 : uc;
+    const SvtHipLrUnit u = P.units[ur * nhu + uc];
+    const int highbd = P.highbd, bd = P.bit_depth;
+    void* dst = P.dst;
+    const size_t dstride = P.dst_stride;
+    const int x0 = s.x0, y0 = s.y0;
+    auto store = [&](int r, int c, int v) {
+        if (highbd) ((uint16_t*)dst)[(size_t)(y0 + r) * dstride + x0 + c] = (uint16_t)v;
+        else ((uint8_t*)dst)[(size_t)(y0 + r) * dstride + x0 + c] = (uint8_t)v;
+    };
+    stage_tile(tile, s, tid);
+    __syncthreads();
+    if (u.rtype == 1) {
+        WienerTaps t;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { t.fx[k] = u.hfilter[k]; t.fy[k] = u.vfilter[k]; }
+        wiener_tile(tile, mid, t, s.uw, s.uh, bd, tid, store);
+    } else if (u.rtype == 2) {
+        const int idx = u.ep & 15;
+        sgr_tile(tile, AB, flt0, idx, s.uw, s.uh, bd, tid, [](int, int, int32_t) {},
+                 [&](int r, int c, int32_t f0, int32_t f1) { store(r, c, sgr_combine(tile[(r + 3) * TW + c + 3], f0, f1, idx, u.xqd[0], u.xqd[1], bd)); });
+    } else {
+        for (int i = tid; i < s.uh * 64; i += 256) {
+            const int r = i >> 6, c = i & 63;
+            if (c < s.uw) store(r, c, tile[(r + 3) * TW + c + 3]);
+        }
+    }
+}
+
+// ---- single-call kernels: a w x h area whose source carries its own 3-pixel border (the RTCD contracts) ------------------
+// kind 0: wiener -> dst pixels; 1: self-guided apply -> dst pixels; 2: self-guided flt0 / flt1 (int32)
+__global__ __launch_bounds__(256) void lr_block_kernel(const void* src /* origin at pixel (0,0); border readable */, int sstride, void* dst, int dstride, int w, int h,
+                                                       int highbd, int bd, int kind, WienerTaps taps, int idx, int xqd0, int xqd1, int32_t* f0out, int32_t* f1out,
+                                                       int fstride) {
+    HIP_DYNAMIC_SHARED(uint16_t, smem)
+    uint16_t* tile = smem;
+    uint16_t* mid  = tile + TH * TW;
+    int32_t*  AB   = (int32_t*)(mid + TH * 64);
+    int32_t*  flt0 = AB + 2 * 66 * 66;
+    const int tid = threadIdx.x;
+    TileSrc s;
+    s.data = src; s.above = s.below = nullptr; s.stride = sstride; s.bstride = 0; s.w = 0; s.h = 0; s.highbd = highbd;
+    s.stripe_idx = 0; s.stripe_top = 0; s.stripe_bot = 0;
+    s.x0 = blockIdx.x * 64; s.y0 = blockIdx.y * 64;
+    s.uw = w - s.x0 < 64 ? w - s.x0 : 64; s.uh = h - s.y0 < 64 ? h - s.y0 : 64;
+    const int x0 = s.x0, y0 = s.y0;
+    auto store = [&](int r, int c, int v) {
+        if (highbd) ((uint16_t*)dst)[(size_t)(y0 + r) * dstride + x0 + c] = (uint16_t)v;
+        else ((uint8_t*)dst)[(size_t)(y0 + r) * dstride + x0 + c] = (uint8_t)v;
+    };
+    stage_tile(tile, s, tid);
+    __syncthreads();
+    if (kind == 0) {
+        wiener_tile(tile, mid, taps, s.uw, s.uh, bd, tid, store);
+    } else if (kind == 1) {
+        sgr_tile(tile, AB, flt0, idx, s.uw, s.uh, bd, tid, [](int, int, int32_t) {},
+                 [&](int r, int c, int32_t a, int32_t b) { store(r, c, sgr_combine(tile[(r + 3) * TW + c + 3], a, b, idx, xqd0, xqd1, bd)); });
+    } else {
+        const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
+        sgr_tile(tile, AB, flt0, idx, s.uw, s.uh, bd, tid, [&](int r, int c, int32_t v) { if (p0) f0out[(size_t)(y0 + r) * fstride + x0 + c] = v; },
+                 [&](int r, int c, int32_t, int32_t b) { if (p1) f1out[(size_t)(y0 + r) * fstride + x0 + c] = b; });
+    }
+}
+
+// host helper for the single-call forms: upload (h + 7) x (w + 8) pixels around the block, run, download
+void lr_block_host(const void* src, int sstride, void* dst, int dstride, int w, int h, int highbd, int bd, int kind, const int16_t* fx, const int16_t* fy,
+                   int idx, const int32_t* xqd, int32_t* flt0, int32_t* flt1, int fstride) {
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    const size_t px = highbd ? 2 : 1;
+    const size_t pw = svthip::align_up((size_t)(w + 8) * px, 16), rows = (size_t)h + 6;
+    const size_t dpitch = svthip::align_up((size_t)w * px, 16);
+    const size_t fbytes = kind == 2 ? (size_t)w * h * 4 : 0;
+    c.reserve(pw * rows + dpitch * h + 2 * fbytes + 8192, pw * rows + 2 * dpitch * h + 2 * fbytes + 8192);
+    uint8_t* ds = (uint8_t*)c.dalloc(pw * rows);
+    uint8_t* dd = (uint8_t*)c.dalloc(dpitch * h + 16);
+    int32_t* d0 = kind == 2 ? (int32_t*)c.dalloc(fbytes) : nullptr;
+    int32_t* d1 = kind == 2 ? (int32_t*)c.dalloc(fbytes) : nullptr;
+    // the reference reads rows -3..h+2 and columns -3..w+3 (tap 7 = 0 still dereferences x+4 only inside the multiply; we
+    // upload -3..w+2 and zero-fill the rest)
+    c.up2d(ds, pw, (const uint8_t*)src - ((size_t)3 * sstride + 3) * px, (size_t)sstride * px, (size_t)(w + 6) * px, rows);
+    WienerTaps t;
+    memset(&t, 0, sizeof(t));
+    if (fx) { memcpy(t.fx, fx, 16); memcpy(t.fy, fy, 16); }
+    const void* origin = ds + (3 * pw + 3 * px);
+    hipLaunchKernelGGL(lr_block_kernel, dim3((w + 63) / 64, (h + 63) / 64), dim3(256), LR_SMEM, c.stream, origin, (int)(pw / px), (void*)dd, (int)(dpitch / px), w, h,
+                       highbd, bd, kind, t, idx, xqd ? xqd[0] : 0, xqd ? xqd[1] : 0, d0, d1, w);
+    SVT_LAUNCH_CHECK();
+    if (kind == 2) {
+        if (kSgrRH[idx][0]) c.down2d(flt0, (size_t)fstride * 4, d0, (size_t)w * 4, (size_t)w * 4, h);
+        if (kSgrRH[idx][1]) c.down2d(flt1, (size_t)fstride * 4, d1, (size_t)w * 4, (size_t)w * 4, h);
+        c.sync();
+    } else {
+        c.down2d(dst, (size_t)dstride * px, dd, dpitch, (size_t)w * px, h);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+void svt_hip_lr_filter_frame(const SvtHipLrParams* params, void* stream) {
+    svthip::ensure_device();
+    const SvtHipLrParams& P = *params;
+    const int sh = 64 >> P.ss_y, off = 8 >> P.ss_y, cw = 64 >> P.ss_x;
+    const int n_stripes = ((int)P.height + off + sh - 1) / sh;
+    const int n_cols    = ((int)P.width + cw - 1) / cw;
+    hipLaunchKernelGGL(lr_frame_kernel, dim3(n_cols, n_stripes), dim3(256), LR_SMEM, (hipStream_t)stream, P);
+    SVT_LAUNCH_CHECK();
+}
+
+// svt_av1_wiener_convolve_add_src -> _c (convolve.c:100-147); conv_params is rebuilt from the bit depth exactly as
+// get_conv_params_wiener does (convolve.h:70-88), which is what every caller passes (restoration.c:443, :1021)
+void svt_av1_wiener_convolve_add_src_hip(const uint8_t* src, ptrdiff_t src_stride, uint8_t* dst, ptrdiff_t dst_stride, const int16_t* filter_x,
+                                         const int16_t* filter_y, int32_t w, int32_t h, const void* conv_params) {
+    (void)conv_params;
+    lr_block_host(src, (int)src_stride, dst, (int)dst_stride, w, h, 0, 8, 0, filter_x, filter_y, 0, nullptr, nullptr, nullptr, 0);
+}
+// highbd forms take CONVERT_TO_BYTEPTR()-style pointers: real address = (uintptr_t)p << 1 (definitions.h)
+void svt_av1_highbd_wiener_convolve_add_src_hip(const uint8_t* src8, ptrdiff_t src_stride, uint8_t* dst8, ptrdiff_t dst_stride, const int16_t* filter_x,
+                                                const int16_t* filter_y, int32_t w, int32_t h, const void* conv_params, int32_t bd) {
+    (void)conv_params;
+    lr_block_host((const void*)((uintptr_t)src8 << 1), (int)src_stride, (void*)((uintptr_t)dst8 << 1), (int)dst_stride, w, h, 1, bd, 0, filter_x, filter_y, 0,
+                  nullptr, nullptr, nullptr, 0);
+}
+void svt_av1_selfguided_restoration_hip(const uint8_t* dgd8, int32_t width, int32_t height, int32_t dgd_stride, int32_t* flt0, int32_t* flt1,
+                                        int32_t flt_stride, int32_t sgr_params_idx, int32_t bit_depth, int32_t highbd) {
+    const void* src = highbd ? (const void*)((uintptr_t)dgd8 << 1) : (const void*)dgd8;
+    lr_block_host(src, dgd_stride, nullptr, 0, width, height, highbd, bit_depth, 2, nullptr, nullptr, sgr_params_idx, nullptr, flt0, flt1, flt_stride);
+}
+void svt_apply_selfguided_restoration_hip(const uint8_t* dat8, int32_t width, int32_t height, int32_t stride, int32_t eps, const int32_t* xqd,
+                                          uint8_t* dst8, int32_t dst_stride, int32_t* tmpbuf, int32_t bit_depth, int32_t highbd) {
+    (void)tmpbuf;
+    const void* src = highbd ? (const void*)((uintptr_t)dat8 << 1) : (const void*)dat8;
+    void*       dst = highbd ? (void*)((uintptr_t)dst8 << 1) : (void*)dst8;
+    lr_block_host(src, stride, dst, dst_stride, width, height, highbd, bit_depth, 1, nullptr, nullptr, eps, xqd, nullptr, nullptr, 0);
+}
+
+} // extern "C"
