@@ -94,24 +94,26 @@ def cpu_me_baseline(descs, planes_src, planes_ref, area, budget_s=12.0):
     f_all = fn("svt_ext_all_sad_calculation_8x8_16x16_" + simd)
     f_eight = fn("svt_ext_eight_sad_calculation_32x32_64x64_" + simd)
     f_one, f_one2 = fn("svt_ext_sad_calculation_8x8_16x16_c"), fn("svt_ext_sad_calculation_32x32_64x64_c")
-    drv = oracle.oracle_drive_ref_me_search_many
+    drv = oracle.oracle_drive_ref_me_search_timed
     drv.restype = C.c_uint64
-    drv.argtypes = [C.c_void_p] * 7 + [C.c_uint32] * 4 + [C.c_int, C.c_void_p, C.c_void_p]
-    cores = os.cpu_count() or 1
+    drv.argtypes = [C.c_void_p] * 7 + [C.c_uint32] * 3 + [C.c_double, C.c_int]
+    cores = len(os.sched_getaffinity(0))
+    try:  # honour a cgroup CPU quota if the box has one
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except Exception:
+        pass
     dd = np.ascontiguousarray(descs)
-    bs, bm = np.zeros(len(dd) * 85, np.uint32), np.zeros(len(dd) * 85, np.uint32)
 
-    def run(idx0, step, repeat):
-        return drv(f_all, f_eight, f_one, f_one2, planes_src.ctypes.data, planes_ref.ctypes.data, dd.ctypes.data, len(dd), idx0, step, repeat, 0,
-                   bs.ctypes.data, bm.ctypes.data)
+    def run(idx0, step, seconds):
+        return drv(f_all, f_eight, f_one, f_one2, planes_src.ctypes.data, planes_ref.ctypes.data, dd.ctypes.data, len(dd), idx0, step, seconds, 0)
     t1 = time.perf_counter()
-    n1 = run(0, 1, 1)  # calibration pass, one thread, also the single-thread figure
-    dt1 = time.perf_counter() - t1
-    one_thread = n1 * area[0] * area[1] / dt1 / 1e6
-    repeat = max(1, int(budget_s / dt1))  # each thread does 1/cores of the list per repeat -> ~budget_s of wall time
+    n1 = run(0, 1, 2.0)  # single thread figure
+    one_thread = n1 * area[0] * area[1] / (time.perf_counter() - t1) / 1e6
     t0 = time.perf_counter()
     with cf.ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL for the whole C loop
-        done = sum(ex.map(lambda k: run(k, cores, repeat * cores), range(cores)))
+        done = sum(ex.map(lambda k: run(k, cores, budget_s), range(cores)))
     dt = time.perf_counter() - t0
     return {"value": done * area[0] * area[1] / dt / 1e6, "unit": "Mblocks/s", "cores": cores, "kind": "reference",
             "single_thread_value": one_thread,

@@ -262,6 +262,47 @@ void svt_av1_selfguided_restoration_hip(const uint8_t *dgd8, int32_t width, int3
 void svt_apply_selfguided_restoration_hip(const uint8_t *dat8, int32_t width, int32_t height, int32_t stride, int32_t eps, const int32_t *xqd,
                                           uint8_t *dst8, int32_t dst_stride, int32_t *tmpbuf, int32_t bit_depth, int32_t highbd);
 
+/* ---------------------------------------------------------------- SATD / Hadamard (a8, a9), LR search statistics (a24) ------ */
+typedef struct SvtHipSatdDesc {
+    uint64_t in_off, pred_off;       /* elements from input_base / pred_base */
+    uint32_t in_stride, pred_stride;
+} SvtHipSatdDesc;
+/* n transform blocks of tx_n x tx_n (4, 8, 16, 32) 8-bit pixels: residual -> svt_aom_hadamard_NxN -> svt_aom_satd, i.e. the body
+ * of hadamard_path_c (enc_mode_config.c:2147-2215).  satd_out[n]; coeff_out (optional) [n][tx_n^2] in the reference's order. */
+void svt_hip_hadamard_satd_batch(const uint8_t *input_base, const uint8_t *pred_base, const SvtHipSatdDesc *descs, uint32_t n, int tx_n,
+                                 uint32_t *satd_out, int32_t *coeff_out, void *stream);
+typedef struct SvtHipRect { int32_t h_start, h_end, v_start, v_end; } SvtHipRect;
+/* n restoration units: Wiener auto/cross-correlation M[n][49], H[n][49*49] (only win^2 / win^4 entries used),
+ * svt_av1_compute_stats_c / _highbd_c (restoration_pick.c:659-745).  dgd needs a (win/2)-pixel readable border. */
+void svt_hip_lr_compute_stats_batch(const void *dgd, const void *src, const SvtHipRect *rects, uint32_t n, int dgd_stride, int src_stride,
+                                    int wiener_win, int bit_depth, int64_t *M, int64_t *H, void *stream);
+/* single-call forms (aom_dsp_rtcd.h:62-81,210-215,276; common_dsp_rtcd.h:1075-1087) */
+int      svt_aom_satd_hip(const int32_t *coeff, int length);
+void     svt_aom_hadamard_nxn_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff, int n);
+void     svt_aom_hadamard_4x4_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
+void     svt_aom_hadamard_8x8_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
+void     svt_aom_hadamard_16x16_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
+void     svt_aom_hadamard_32x32_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
+uint32_t svt_hadamard_path_hip(const uint8_t *input, uint32_t in_stride, const uint8_t *pred, uint32_t pred_stride, int block_size);
+void     svt_residual_kernel8bit_hip(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, int16_t *residual,
+                                     uint32_t residual_stride, uint32_t area_width, uint32_t area_height);
+void     svt_residual_kernel16bit_hip(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual,
+                                      uint32_t residual_stride, uint32_t area_width, uint32_t area_height);
+void     svt_av1_compute_stats_hip(int32_t wiener_win, const uint8_t *dgd, const uint8_t *src, int32_t h_start, int32_t h_end, int32_t v_start,
+                                   int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H);
+void     svt_av1_compute_stats_highbd_hip(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end,
+                                          int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H,
+                                          int bit_depth);
+int64_t  svt_av1_lowbd_pixel_proj_error_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8,
+                                            int32_t dat_stride, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride,
+                                            int32_t xq[2], const void *params);
+int64_t  svt_av1_highbd_pixel_proj_error_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8,
+                                             int32_t dat_stride, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride,
+                                             int32_t xq[2], const void *params);
+void     svt_get_proj_subspace_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8, int32_t dat_stride,
+                                   int32_t use_highbitdepth, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride, int32_t *xq,
+                                   const void *params);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,3 +68,22 @@ uint64_t oracle_drive_ref_me_search_many(ExtAllFn all, ExtEightFn eight, ExtOne8
         }
     return done;
 }
+
+/* Time-bounded form: thread `idx0` of `step` keeps searching its share of the list until `seconds` of wall time have
+ * passed (checked every item), so the cpu_baseline leg of bench.py has a hard duration whatever the host gives us. */
+#include <time.h>
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+uint64_t oracle_drive_ref_me_search_timed(ExtAllFn all, ExtEightFn eight, ExtOne816Fn one816, ExtOne3264Fn one3264, uint8_t *src_base,
+                                          uint8_t *ref_base, const OracleMeDesc *d, uint32_t n, uint32_t idx0, uint32_t step, double seconds,
+                                          int sub_sad) {
+    uint32_t     bs[85], bm[85];
+    uint64_t     done = 0;
+    const double t_end = now_s() + seconds;
+    for (;;)
+        for (uint32_t i = idx0; i < n; i += step) {
+            oracle_drive_ref_me_search(all, eight, one816, one3264, src_base + d[i].src_off, d[i].src_stride, ref_base + d[i].ref_off,
+                                       d[i].ref_stride, d[i].x_origin, d[i].y_origin, d[i].width, d[i].height, sub_sad, bs, bm);
+            done++;
+            if (now_s() >= t_end) return done;
+        }
+}

@@ -137,6 +137,25 @@ PROTOTYPES.update({
     "svt_av1_selfguided_restoration_hip": (None, [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "svt_apply_selfguided_restoration_hip": (None, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32]),
 })
+SatdDesc = np.dtype([("in_off", "<u8"), ("pred_off", "<u8"), ("in_stride", "<u4"), ("pred_stride", "<u4")])
+Rect = np.dtype([("h_start", "<i4"), ("h_end", "<i4"), ("v_start", "<i4"), ("v_end", "<i4")])
+_PE = [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, vp, vp]
+PROTOTYPES.update({
+    "svt_hip_hadamard_satd_batch": (None, [vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp]),
+    "svt_hip_lr_compute_stats_batch": (None, [vp, vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "svt_aom_satd_hip": (C.c_int, [vp, C.c_int]),
+    "svt_aom_hadamard_nxn_hip": (None, [vp, C.c_ssize_t, vp, C.c_int]),
+    "svt_hadamard_path_hip": (C.c_uint32, [vp, C.c_uint32, vp, C.c_uint32, C.c_int]),
+    "svt_residual_kernel8bit_hip": (None, [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svt_residual_kernel16bit_hip": (None, [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svt_av1_compute_stats_hip": (None, [C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp]),
+    "svt_av1_compute_stats_highbd_hip": (None, [C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int]),
+    "svt_av1_lowbd_pixel_proj_error_hip": (C.c_int64, _PE),
+    "svt_av1_highbd_pixel_proj_error_hip": (C.c_int64, _PE),
+    "svt_get_proj_subspace_hip": (None, [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, C.c_int32, vp, C.c_int32, vp, vp]),
+})
+for _n in (4, 8, 16, 32):
+    PROTOTYPES["svt_aom_hadamard_%dx%d_hip" % (_n, _n)] = (None, [vp, C.c_ssize_t, vp])
 for _m, _n in [(128, 128), (128, 64), (64, 128), (64, 64), (64, 32), (32, 64), (32, 32), (32, 16), (16, 32), (16, 16), (16, 8),
                (8, 16), (8, 8), (8, 4), (4, 8), (4, 4), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]:
     PROTOTYPES["svt_aom_sad%dx%d_hip" % (_m, _n)] = (C.c_uint32, [vp, C.c_int, vp, C.c_int])

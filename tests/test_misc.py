@@ -1,0 +1,142 @@
+"""SATD / Hadamard / residual and LR search statistics (a24).  test_misc_oracle_vs_reference pins the
+oracle against the real reference (when oracle/_ref is available); the other tests check the HIP path against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import p, rng
+from test_oracle_pin_restoration import byteptr
+
+
+class Sgr(C.Structure):
+    _fields_ = [("r", C.c_int32 * 2), ("s", C.c_int32 * 2)]
+
+
+def test_hadamard_satd_residual(be, oracle):
+    g = rng(1)
+    for n in (4, 8, 16, 32):
+        for it in range(3):
+            amp = [255, 255, 32][it]
+            res = g.integers(-amp, amp + 1, (n, n + 3)).astype(np.int16)
+            if it == 0:
+                res[:] = 255
+            a, b = np.zeros(n * n, np.int32), np.zeros(n * n, np.int32)
+            oracle.oracle_hadamard(p(res), n + 3, p(a), n)
+            getattr(be.lib, "svt_aom_hadamard_%dx%d_hip" % (n, n))(p(res), n + 3, p(b))
+            assert np.array_equal(a, b), (n, it)
+            assert be.lib.svt_aom_satd_hip(p(a), n * n) == oracle.oracle_satd(p(a), n * n)
+    for length in (16, 64, 256, 1024):  # SatdTest.cc:118-130 constant-answer cases
+        for v in (524287, -524287):
+            c = np.full(length, v, np.int32)
+            assert be.lib.svt_aom_satd_hip(p(c), length) == 524287 * length
+    inp = g.integers(0, 256, (96, 160)).astype(np.uint8)
+    prd = np.clip(inp.astype(np.int16) + g.integers(-20, 21, inp.shape), 0, 255).astype(np.uint8)
+    oracle.oracle_hadamard_satd.restype = C.c_uint32
+    for n in (4, 8, 16, 32):
+        descs = np.zeros(6, dtype=be.pkg.SatdDesc)
+        for i in range(6):
+            descs[i] = (i * n + 160 * (i % 3), i * n + 160 * (i % 3) + 1, 160, 160)
+        di, dp_, dd = be.dev(inp), be.dev(prd), be.dev(descs)
+        out = be.empty(6, np.uint32)
+        be.lib.svt_hip_hadamard_satd_batch(be.ptr(di), be.ptr(dp_), be.ptr(dd), 6, n, be.ptr(out), None, be.stream)
+        got = be.host(out)
+        for i in range(6):
+            want = oracle.oracle_hadamard_satd(C.c_void_p(inp.ctypes.data + int(descs[i]["in_off"])), 160, C.c_void_p(prd.ctypes.data + int(descs[i]["pred_off"])), 160, n)
+            assert got[i] == want, (n, i)
+    for bs in (8, 32, 64):
+        t = min(bs, 32)
+        want = sum(oracle.oracle_hadamard_satd(C.c_void_p(inp.ctypes.data + r * 160 + c), 160, C.c_void_p(prd.ctypes.data + r * 160 + c), 160, t)
+                   for r in range(0, bs, t) for c in range(0, bs, t))
+        assert be.lib.svt_hadamard_path_hip(p(inp), 160, p(prd), 160, bs) == want
+    r0, r1 = np.zeros((24, 40), np.int16), np.zeros((24, 40), np.int16)
+    oracle.oracle_residual(p(inp), 160, p(prd), 160, p(r0), 40, 33, 24, 0)
+    be.lib.svt_residual_kernel8bit_hip(p(inp), 160, p(prd), 160, p(r1), 40, 33, 24)
+    assert np.array_equal(r0, r1)
+    i16, p16 = inp.astype(np.uint16) * 4, prd.astype(np.uint16) * 4 + 1
+    oracle.oracle_residual(p(i16), 160, p(p16), 160, p(r0), 40, 33, 24, 1)
+    be.lib.svt_residual_kernel16bit_hip(p(i16), 160, p(p16), 160, p(r1), 40, 33, 24)
+    assert np.array_equal(r0, r1)
+
+
+def test_misc_oracle_vs_reference(oracle, ref):
+    g = rng(2)
+    for n in (4, 8, 16, 32):
+        res = g.integers(-255, 256, (n, n)).astype(np.int16)
+        a, b = np.zeros(n * n, np.int32), np.zeros(n * n, np.int32)
+        oracle.oracle_hadamard(p(res), n, p(a), n)
+        getattr(ref, "svt_aom_hadamard_%dx%d_c" % (n, n))(p(res), C.c_ssize_t(n), p(b))
+        assert np.array_equal(a, b)
+        assert oracle.oracle_satd(p(a), n * n) == ref.svt_aom_satd_c(p(a), n * n)
+    ref.svt_av1_lowbd_pixel_proj_error_c.restype = C.c_int64
+    ref.svt_av1_highbd_pixel_proj_error_c.restype = C.c_int64
+    oracle.oracle_pixel_proj_error.restype = C.c_int64
+    for bd in (8, 10, 12):
+        dt = np.uint16 if bd > 8 else np.uint8
+        S, W, H = 90, 70, 50
+        dgd = g.integers(0, 1 << bd, (H + 8, S)).astype(dt)
+        src = np.clip(dgd.astype(np.int32) + g.integers(-9, 10, dgd.shape), 0, (1 << bd) - 1).astype(dt)
+        for win in (7, 5, 3):
+            M0, H0, M1, H1 = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64), np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
+            oracle.oracle_compute_stats(win, p(dgd), p(src), 5, 5 + W, 4, 4 + H, S, S, p(M0), p(H0), bd)
+            if bd == 8:
+                ref.svt_av1_compute_stats_c(win, p(dgd), p(src), 5, 5 + W, 4, 4 + H, S, S, p(M1), p(H1))
+            else:
+                ref.svt_av1_compute_stats_highbd_c(win, byteptr(dgd), byteptr(src), 5, 5 + W, 4, 4 + H, S, S, p(M1), p(H1), bd)
+            assert np.array_equal(M0[:win * win], M1[:win * win]) and np.array_equal(H0[:win ** 4], H1[:win ** 4]), (bd, win)
+        f0 = np.ascontiguousarray(((dgd[:H, :W].astype(np.int32) << 4) + g.integers(-300, 301, (H, W))).astype(np.int32))
+        f1 = np.ascontiguousarray(((dgd[:H, :W].astype(np.int32) << 4) + g.integers(-300, 301, (H, W))).astype(np.int32))
+        for (r0, r1) in ((2, 1), (0, 1), (2, 0)):
+            prm = Sgr((C.c_int32 * 2)(r0, r1), (C.c_int32 * 2)(1, 1))
+            xq = np.array([int(g.integers(-90, 30)), int(g.integers(-30, 90))], np.int32)
+            e0 = oracle.oracle_pixel_proj_error(p(src), W, H, S, p(dgd), S, p(f0), W, p(f1), W, p(xq), r0, r1, int(bd > 8))
+            fr = ref.svt_av1_highbd_pixel_proj_error_c if bd > 8 else ref.svt_av1_lowbd_pixel_proj_error_c
+            e1 = fr(byteptr(src) if bd > 8 else p(src), W, H, S, byteptr(dgd) if bd > 8 else p(dgd), S, p(f0), W, p(f1), W, p(xq), C.byref(prm))
+            assert e0 == e1, (bd, r0, r1)
+            x0, x1 = np.zeros(2, np.int32), np.zeros(2, np.int32)
+            oracle.oracle_get_proj_subspace(p(src), W, H, S, p(dgd), S, int(bd > 8), p(f0), W, p(f1), W, p(x0), r0, r1)
+            ref.svt_get_proj_subspace_c(byteptr(src) if bd > 8 else p(src), W, H, S, byteptr(dgd) if bd > 8 else p(dgd), S, int(bd > 8), p(f0), W, p(f1), W, p(x1), C.byref(prm))
+            assert np.array_equal(x0, x1), (bd, r0, r1, x0, x1)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_lr_search_statistics(be, oracle, bd):
+    g = rng(60 + bd)
+    dt = np.uint16 if bd > 8 else np.uint8
+    oracle.oracle_pixel_proj_error.restype = C.c_int64
+    S, Hh = (400, 300) if be.is_gpu else (120, 90)
+    dgd = g.integers(0, 1 << bd, (Hh, S)).astype(dt)
+    src = np.clip(dgd.astype(np.int32) + g.integers(-9, 10, dgd.shape), 0, (1 << bd) - 1).astype(dt)
+    rect_list = [(5, 69, 4, 68), (70, 110, 10, 43), (8, 9 + 33, 40, 40 + 17)] + ([(100, 356, 20, 276)] if be.is_gpu else [])
+    rects = np.array(rect_list, np.int32).view(be.pkg.Rect).reshape(-1)
+    for win in ((7, 5) if be.is_gpu else (7,)):
+        dd, ds, dr = be.dev(dgd), be.dev(src), be.dev(rects)
+        M, Hm = be.empty((len(rects), 49), np.int64), be.empty((len(rects), 49 * 49), np.int64)
+        be.lib.svt_hip_lr_compute_stats_batch(be.ptr(dd), be.ptr(ds), be.ptr(dr), len(rects), S, S, win, bd, be.ptr(M), be.ptr(Hm), be.stream)
+        gM, gH = be.host(M), be.host(Hm)
+        for i, (hs, he, vs, ve) in enumerate(rect_list):
+            M0, H0 = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
+            oracle.oracle_compute_stats(win, p(dgd), p(src), hs, he, vs, ve, S, S, p(M0), p(H0), bd)
+            assert np.array_equal(gM[i][:win * win], M0[:win * win]) and np.array_equal(gH[i][:win ** 4], H0[:win ** 4]), (bd, win, i)
+    W, H = 48, 30
+    M0, H0, M1, H1 = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64), np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
+    oracle.oracle_compute_stats(7, p(dgd), p(src), 6, 6 + W, 5, 5 + H, S, S, p(M0), p(H0), bd)
+    if bd == 8:
+        be.lib.svt_av1_compute_stats_hip(7, p(dgd), p(src), 6, 6 + W, 5, 5 + H, S, S, p(M1), p(H1))
+    else:
+        be.lib.svt_av1_compute_stats_highbd_hip(7, byteptr(dgd), byteptr(src), 6, 6 + W, 5, 5 + H, S, S, p(M1), p(H1), bd)
+    assert np.array_equal(M0, M1) and np.array_equal(H0, H1)
+    f0 = np.ascontiguousarray(((dgd[:H, :W].astype(np.int32) << 4) + g.integers(-300, 301, (H, W))).astype(np.int32))
+    f1 = np.ascontiguousarray(((dgd[:H, :W].astype(np.int32) << 4) + g.integers(-300, 301, (H, W))).astype(np.int32))
+    for (r0, r1) in ((2, 1), (0, 1), (2, 0)):
+        prm = Sgr((C.c_int32 * 2)(r0, r1), (C.c_int32 * 2)(1, 1))
+        xq = np.array([int(g.integers(-90, 30)), int(g.integers(-30, 90))], np.int32)
+        e0 = oracle.oracle_pixel_proj_error(p(src), W, H, S, p(dgd), S, p(f0), W, p(f1), W, p(xq), r0, r1, int(bd > 8))
+        f = be.lib.svt_av1_highbd_pixel_proj_error_hip if bd > 8 else be.lib.svt_av1_lowbd_pixel_proj_error_hip
+        e1 = f(byteptr(src) if bd > 8 else p(src), W, H, S, byteptr(dgd) if bd > 8 else p(dgd), S, p(f0), W, p(f1), W, p(xq), C.cast(C.byref(prm), C.c_void_p))
+        assert e0 == e1, (bd, r0, r1)
+        x0, x1 = np.zeros(2, np.int32), np.zeros(2, np.int32)
+        oracle.oracle_get_proj_subspace(p(src), W, H, S, p(dgd), S, int(bd > 8), p(f0), W, p(f1), W, p(x0), r0, r1)
+        be.lib.svt_get_proj_subspace_hip(byteptr(src) if bd > 8 else p(src), W, H, S, byteptr(dgd) if bd > 8 else p(dgd), S, int(bd > 8), p(f0), W, p(f1), W, p(x1),
+                                         C.cast(C.byref(prm), C.c_void_p))
+        assert np.array_equal(x0, x1), (bd, r0, r1)
