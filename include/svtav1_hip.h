@@ -225,9 +225,9 @@ void     svt_cdef_filter_block_hip(uint8_t *dst8, uint16_t *dst16, int32_t dstri
                                    int32_t sec_strength, int32_t dir, int32_t pri_damping, int32_t sec_damping, int32_t bsize,
                                    int32_t coeff_shift, uint8_t subsampling_factor);
 uint64_t svt_compute_cdef_dist_16bit_hip(const uint16_t *dst, int32_t dstride, const uint16_t *src, const void *dlist, int32_t cdef_count,
-                                         int bsize, int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
+                                         uint8_t bsize, int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
 uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t *dst8, int32_t dstride, const uint8_t *src8, const void *dlist, int32_t cdef_count,
-                                        int bsize, int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
+                                        uint8_t bsize, int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
 void     svt_aom_copy_rect8_8bit_to_16bit_hip(uint16_t *dst, int32_t dstride, const uint8_t *src, int32_t sstride, int32_t v, int32_t h);
 
 /* ---------------------------------------------------------------- loop restoration (a21-a23) ---------- */

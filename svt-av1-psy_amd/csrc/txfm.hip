@@ -354,13 +354,13 @@ void svt_av1_inv_txfm_add_u8_hip(const int32_t* dqcoeff, uint8_t* dst_r, int32_t
 
 // the 19 (+38 partial-frequency) forward and 19 inverse fixed-size symbols of the RTCD tables
 #define X(ID, W, H)                                                                                                                       \
-    void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t* input, int32_t* output, uint32_t stride, int tx_type, uint8_t bd) {                    \
+    void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t* input, int32_t* output, uint32_t stride, uint8_t tx_type, uint8_t bd) {                    \
         svt_av1_fwd_txfm2d_hip(input, output, stride, tx_type, ID, bd, 0);                                                               \
     }                                                                                                                                     \
-    void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t* input, int32_t* output, uint32_t stride, int tx_type, uint8_t bd) {                 \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t* input, int32_t* output, uint32_t stride, uint8_t tx_type, uint8_t bd) {                 \
         svt_av1_fwd_txfm2d_hip(input, output, stride, tx_type, ID, bd, 1);                                                               \
     }                                                                                                                                     \
-    void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t* input, int32_t* output, uint32_t stride, int tx_type, uint8_t bd) {                 \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t* input, int32_t* output, uint32_t stride, uint8_t tx_type, uint8_t bd) {                 \
         svt_av1_fwd_txfm2d_hip(input, output, stride, tx_type, ID, bd, 2);                                                               \
     }
 FOR_ALL_TX_SIZES(X)
@@ -368,19 +368,19 @@ FOR_ALL_TX_SIZES(X)
 // inverse: squares (input, r, stride_r, w, stride_w, tx_type, bd); 4x8/8x4/4x16/16x4 add tx_size; the rest add tx_size, eob
 // (common_dsp_rtcd.h:106-116, inv_transforms.c:2545-2716)
 #define INV_SQ(ID, N)                                                                                                                     \
-    void svt_av1_inv_txfm2d_add_##N##x##N##_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* w, int32_t sw, int tx_type, int32_t bd) { \
+    void svt_av1_inv_txfm2d_add_##N##x##N##_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* w, int32_t sw, uint8_t tx_type, int32_t bd) { \
         svt_av1_inv_txfm2d_add_hip(in, r, sr, w, sw, tx_type, ID, bd);                                                                    \
     }
 INV_SQ(0, 4) INV_SQ(1, 8) INV_SQ(2, 16) INV_SQ(3, 32) INV_SQ(4, 64)
 #define INV_R1(ID, W, H)                                                                                                                  \
-    void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* w, int32_t sw, int tx_type, int tx_size, \
+    void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* w, int32_t sw, uint8_t tx_type, uint8_t tx_size, \
                                                 int32_t bd) {                                                                             \
         (void)tx_size;                                                                                                                    \
         svt_av1_inv_txfm2d_add_hip(in, r, sr, w, sw, tx_type, ID, bd);                                                                    \
     }
 INV_R1(5, 4, 8) INV_R1(6, 8, 4) INV_R1(13, 4, 16) INV_R1(14, 16, 4)
 #define INV_R2(ID, W, H)                                                                                                                  \
-    void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* w, int32_t sw, int tx_type, int tx_size, \
+    void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* w, int32_t sw, uint8_t tx_type, uint8_t tx_size, \
                                                 int32_t eob, int32_t bd) {                                                                \
         (void)tx_size; (void)eob;                                                                                                         \
         svt_av1_inv_txfm2d_add_hip(in, r, sr, w, sw, tx_type, ID, bd);                                                                    \
