@@ -120,6 +120,157 @@ def cpu_me_baseline(descs, planes_src, planes_ref, area, budget_s=12.0):
             "sample": "%d SB-refs at %dx%d in %.1fs, reference %s kernels driven as open_loop_me_fullpel_search_sblock" % (done, area[0], area[1], dt, simd)}
 
 
+def aligned_zeros(n, dtype, al=64):
+    raw = np.zeros(n * np.dtype(dtype).itemsize + al, np.uint8)
+    off = (-raw.ctypes.data) % al
+    return raw[off:off + n * np.dtype(dtype).itemsize].view(dtype)
+
+
+def host_cores():
+    cores = len(os.sched_getaffinity(0))
+    try:  # honour a cgroup CPU quota if the box has one
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return cores
+
+
+def cpu_pool(run, seconds):
+    """run(idx0, step, seconds) -> units done, on every host core (ctypes drops the GIL inside the C loop)."""
+    import concurrent.futures as cf
+    cores = host_cores()
+    t1 = time.perf_counter()
+    n1 = run(0, 1, min(2.0, seconds))
+    one = n1 / (time.perf_counter() - t1)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(lambda k: run(k, cores, seconds), range(cores)))
+    return done / (time.perf_counter() - t0), one, cores
+
+
+def ref_libs():
+    ref_path, ora_path = os.path.join(ROOT, "oracle", "_ref", "libsvtref.so"), os.path.join(ROOT, "oracle", "liboracle.so")
+    if not (os.path.exists(ref_path) and os.path.exists(ora_path)):
+        return None, None
+    return C.CDLL(ref_path), C.CDLL(ora_path)
+
+
+def bench_sad_pairs(torch, lib, pkg, stream, a):
+    """config 1 on the GPU: 64x64 SAD of co-located SB pairs, 120 distinct planes (300 MB > the 256 MB Infinity Cache) so the
+    byte rate is an HBM rate: algorithmic bytes = 2 * 64 * 64 per block."""
+    nplanes = 120
+    planes = torch.randint(0, 256, (nplanes * PLANE,), dtype=torch.uint8, device="cuda")
+    pairs = np.zeros((nplanes - 1) * 510, dtype=pkg.SadPair)
+    i = 0
+    for f in range(nplanes - 1):
+        for sy in range(17):
+            for sx in range(30):
+                o = (PAD + sy * 64) * STRIDE + PAD + sx * 64
+                pairs[i] = (f * PLANE + o, (f + 1) * PLANE + o + 3 + 2 * STRIDE, STRIDE, STRIDE)
+                i += 1
+    d_pairs = torch.from_numpy(pairs.view(np.uint8)).cuda()
+    d_out = torch.zeros(len(pairs), dtype=torch.int32, device="cuda")
+    fn = lambda: lib.svt_hip_sad_nxm_batch(planes.data_ptr(), planes.data_ptr(), d_pairs.data_ptr(), len(pairs), 64, 64, d_out.data_ptr(), stream)  # noqa: E731
+    _, dv = time_steps(torch, fn, a.steps, a.warmup)
+    gbs = len(pairs) * 8192 / (dv / a.steps) / 1e9
+    return {"value": len(pairs) / (dv / a.steps) / 1e6, "unit": "Mblocks/s (64x64 pairs)", "kernel": "sad_nxm_kernel", "footprint_MB": nplanes * PLANE / 1e6,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_block": 8192}}
+
+
+def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
+    """config 3 slice named by the metric: 32x32 forward transform, 10-bit residuals, DCT_DCT; 2 B/px in + 4 B/px out = 6144 B/block."""
+    n, ts = 65536, 3
+    g = np.random.default_rng(13596)
+    res = g.integers(-1023, 1024, n * 1024).astype(np.int16)
+    descs = np.zeros(n, dtype=pkg.FwdTxfmDesc)
+    descs["in_off"] = np.arange(n, dtype=np.uint64) * 1024
+    descs["in_stride"] = 32
+    d_res, d_desc = torch.from_numpy(res).cuda(), torch.from_numpy(descs.view(np.uint8)).cuda()
+    d_out = torch.zeros(n * 1024, dtype=torch.int32, device="cuda")
+    fn = lambda: lib.svt_hip_fwd_txfm2d_batch(d_res.data_ptr(), d_desc.data_ptr(), n, ts, 10, 0, d_out.data_ptr(), stream)  # noqa: E731
+    _, dv = time_steps(torch, fn, a.steps, a.warmup)
+    gbs = n * 6144 / (dv / a.steps) / 1e9
+    out = {"value": n / (dv / a.steps) / 1e6, "unit": "Mblocks/s (32x32)", "kernel": "fwd_txfm2d_kernel<32,32>", "blocks_per_step": n,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_block": 6144, "note": "butterfly network: VALU/int32-multiply bound, not a dense contraction (DESIGN.md 4.2)"}}
+    if cpu:
+        ref, oracle = ref_libs()
+        if ref is not None and " avx2 " in open("/proc/cpuinfo").read():
+            f = oracle.oracle_time_fwd_txfm
+            f.restype = C.c_uint64
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32, C.c_double]
+            fnp = C.cast(ref.svt_av1_fwd_txfm2d_32x32_avx2, C.c_void_p)
+            ns = 512  # private input / output per thread (shared buffers serialise the cores through the cache hierarchy)
+            bufs = [(aligned_zeros(ns * 1024, np.int16), aligned_zeros(2048, np.int32)) for _ in range(host_cores())]
+            for b_in, _ in bufs:
+                b_in[:] = res[:ns * 1024]
+            run = lambda i0, st, sec: f(fnp, bufs[i0][0].ctypes.data, ns, 32, 32, bufs[i0][1].ctypes.data, 0, 10, 0, 1, sec)  # noqa: E731
+            rate, one, cores = cpu_pool(run, 4.0)
+            out["cpu_baseline"] = {"value": rate / 1e6, "unit": "Mblocks/s (32x32)", "cores": cores, "kind": "reference", "single_thread_value": one / 1e6,
+                                   "sample": "svt_av1_fwd_txfm2d_32x32_avx2, 512 private blocks per thread, 4 s per leg"}
+    return out
+
+
+def bench_cdef(torch, lib, pkg, stream, a, cpu):
+    """config 4: CDEF over a 4K 10-bit luma plane: strength search (all 64 luma strengths) and apply (pri 4, sec 2)."""
+    Wc, Hc, bd = 3840, 2160, 10
+    g = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:Hc, 0:Wc]
+    plane = np.clip(((xx * 2 + yy * 3) % 1024) // 2 + (((xx // 8 + yy // 8) % 5) << 5) + g.integers(-16, 17, (Hc, Wc)), 0, 1023).astype(np.uint16)
+    src = np.clip(plane.astype(np.int32) + g.integers(-6, 7, plane.shape), 0, 1023).astype(np.uint16)
+    nhfb, nvfb = Wc // 64, (Hc + 63) // 64
+    nfb = nhfb * nvfb
+    skip = np.zeros((nvfb * 8, nhfb * 8), np.uint8)
+    cands = [(pr, sc) for pr in range(16) for sc in (0, 1, 2, 4)]
+    pri, sec = np.array([c[0] for c in cands], np.int32), np.array([c[1] for c in cands], np.int32)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1)).cuda()  # noqa: E731
+    d_pl, d_src, d_out, d_skip, d_pri, d_sec = t(plane), t(src), t(plane), t(skip), t(pri), t(sec)
+    d_dir, d_var = torch.zeros(nfb * 64, dtype=torch.uint8, device="cuda"), torch.zeros(nfb * 64, dtype=torch.int32, device="cuda")
+    d_mse = torch.zeros(nfb * 64, dtype=torch.int64, device="cuda")
+    apri, asec = t(np.full(nfb, 4, np.int32)), t(np.full(nfb, 2, np.int32))
+
+    def params(mode):
+        return pkg.CdefParams(d_pl.data_ptr(), d_src.data_ptr(), d_out.data_ptr(), Wc, Wc, Wc, Wc, Hc, 0, 0, 0, 1, bd - 8, 4, 4, 1, 64 if mode else 0,
+                              d_skip.data_ptr(), (d_pri if mode else apri).data_ptr(), (d_sec if mode else asec).data_ptr(), d_dir.data_ptr(), d_var.data_ptr(),
+                              d_mse.data_ptr())
+    out = {}
+    n8 = (Wc // 8) * (Hc // 8)
+    for mode, name in ((1, "cdef_search_4k10_64strengths"), (0, "cdef_apply_4k10")):
+        P = params(mode)
+        fn = lambda: lib.svt_hip_cdef_frame(mode, C.byref(P), stream)  # noqa: E731
+        st = max(3, a.steps // 4)
+        _, dv = time_steps(torch, fn, st, 1)
+        per = dv / st
+        units = n8 * (64 if mode else 1)
+        bytes_alg = Wc * Hc * 2 * (2 if mode == 0 else 2) + (nfb * 64 * 8 if mode else 0)  # apply: read + write; search: recon + source, 8 B per (fb, strength)
+        gbs = bytes_alg / per / 1e9
+        out[name] = {"value": units / per / 1e6, "unit": "M(8x8 block x strength)/s" if mode else "M(8x8 blocks)/s", "frames_per_s": 1 / per, "kernel": "cdef_frame_kernel",
+                     "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                  "algorithmic_bytes_per_frame": bytes_alg}}
+    if cpu:
+        ref, oracle = ref_libs()
+        if ref is not None and " avx2 " in open("/proc/cpuinfo").read():
+            ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))
+            ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
+            for ptr, fnn in (("svt_aom_cdef_find_dir", "svt_aom_cdef_find_dir_avx2"), ("svt_aom_cdef_find_dir_dual", "svt_aom_cdef_find_dir_dual_avx2"),
+                             ("svt_cdef_filter_block", "svt_cdef_filter_block_avx2")):
+                C.c_void_p.in_dll(ref, ptr).value = C.cast(getattr(ref, fnn), C.c_void_p).value  # what RTCD would select with AVX2 detected
+            f = oracle.oracle_time_cdef_apply
+            f.restype = C.c_uint64
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_double]
+            fb = C.cast(ref.svt_cdef_filter_fb, C.c_void_p)
+            cpu_out = np.zeros_like(plane)
+            run = lambda i0, stp, s: f(fb, plane.ctypes.data, Wc, Wc, Hc, cpu_out.ctypes.data, 4, 2, 4, 2, i0, stp, s)  # noqa: E731
+            rate, one, cores = cpu_pool(run, 4.0)
+            out["cdef_apply_4k10"]["cpu_baseline"] = {"value": rate * 64 / 1e6, "unit": "M(8x8 blocks)/s", "cores": cores, "kind": "reference",
+                                                      "single_thread_value": one * 64 / 1e6,
+                                                      "sample": "svt_cdef_filter_fb + svt_cdef_filter_block_avx2 / find_dir_dual_avx2 over the same 4K plane, 4 s per leg"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,25 +352,9 @@ def main():
                      "sad_ops_per_s": n * aw * ah * 4096 / kernel_s},
     }
     kernels = {}
-    # ---------------- config 1 shape on the GPU: independent 64x64 SAD pairs (the genuinely HBM-bound SAD kernel) ----
-    pairs = np.zeros(a.frames * 510 * a.refs, dtype=pkg.SadPair)
-    i = 0
-    for f in range(a.frames):
-        for r in range(a.refs):
-            for sy in range(17):
-                for sx in range(30):
-                    o = (PAD + sy * 64) * STRIDE + PAD + sx * 64
-                    pairs[i] = (f * PLANE + o, (f + 1 + r) * PLANE + o, STRIDE, STRIDE)
-                    i += 1
-    d_pairs = torch.from_numpy(pairs.view(np.uint8)).cuda()
-    d_out = torch.zeros(len(pairs), dtype=torch.int32, device="cuda")
-    fn = lambda: lib.svt_hip_sad_nxm_batch(d_planes.data_ptr(), d_planes.data_ptr(), d_pairs.data_ptr(), len(pairs), 64, 64,  # noqa: E731
-                                           d_out.data_ptr(), stream)
-    _, dv = time_steps(torch, fn, a.steps, a.warmup)
-    gbs = len(pairs) * 8192 / (dv / a.steps) / 1e9
-    kernels["sad64x64_pairs"] = {"value": len(pairs) / (dv / a.steps) / 1e6, "unit": "Mblocks/s", "kernel": "sad_nxm_kernel",
-                                 "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                              "traffic": None, "algorithmic_bytes_per_block": 8192}}
+    kernels["sad64x64_pairs"] = bench_sad_pairs(torch, lib, pkg, stream, a)
+    kernels["fwd_txfm2d_32x32"] = bench_fwd_txfm(torch, lib, pkg, stream, a, cpu=(rank == 0 and world == 1 and not a.no_cpu))
+    kernels.update(bench_cdef(torch, lib, pkg, stream, a, cpu=(rank == 0 and world == 1 and not a.no_cpu)))
     if a.extra:
         for (w2, h2, sub) in [(16, 9, 1), (64, 32, 0), (256, 256, 0)]:
             nf = a.frames if w2 < 64 else (4 if w2 < 256 else 1)

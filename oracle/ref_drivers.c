@@ -7,6 +7,8 @@
 #include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 typedef void (*ExtAllFn)(uint8_t *, uint32_t, uint8_t *, uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t[16][8],
                          uint32_t[64][8], bool);
@@ -85,5 +87,49 @@ uint64_t oracle_drive_ref_me_search_timed(ExtAllFn all, ExtEightFn eight, ExtOne
                                        d[i].ref_stride, d[i].x_origin, d[i].y_origin, d[i].width, d[i].height, sub_sad, bs, bm);
             done++;
             if (now_s() >= t_end) return done;
+        }
+}
+
+/* ---- timed loops over other reference kernels (bench.py cpu_baseline legs) ------------------------------------------ */
+typedef void (*FwdTxfmFn)(int16_t *, int32_t *, uint32_t, uint8_t, uint8_t);
+/* blocks idx0, idx0+step, ... of `n` contiguous w*h residual blocks, until `seconds` elapse; returns blocks transformed */
+uint64_t oracle_time_fwd_txfm(FwdTxfmFn fn, int16_t *in, uint32_t n, int w, int h, int32_t *out_scratch /* step * w*h */, uint8_t tx_type, uint8_t bd,
+                              uint32_t idx0, uint32_t step, double seconds) {
+    uint64_t     done = 0;
+    const double t_end = now_s() + seconds;
+    int32_t     *out = out_scratch + (size_t)idx0 * w * h;
+    for (;;)
+        for (uint32_t i = idx0; i < n; i += step) {
+            fn(in + (size_t)i * w * h, out, (uint32_t)w, tx_type, bd);
+            if ((++done & 63) == 0 && now_s() >= t_end) return done;
+        }
+}
+typedef void (*CdefFilterFbFn)(uint8_t *, uint16_t *, int32_t, uint16_t *, int32_t, int32_t, uint8_t (*)[16], int32_t *, int32_t (*)[16], int32_t, void *, int32_t,
+                               int32_t, int32_t, int32_t, int32_t, int32_t, uint8_t);
+/* CDEF apply of a 16-bit luma plane, filter blocks idx0, idx0+step, ...: tile construction as cdef_seg_search
+ * (cdef_process.c:208-228) + the reference's svt_cdef_filter_fb (which dispatches through the RTCD pointers the caller has
+ * pointed at the AVX2 kernels).  Returns the number of 64x64 filter blocks processed. */
+uint64_t oracle_time_cdef_apply(CdefFilterFbFn fb, const uint16_t *plane, int stride, int w, int h, uint16_t *out, int level, int sec, int damping,
+                                int coeff_shift, uint32_t idx0, uint32_t step, double seconds) {
+    const int    nhfb = (w + 63) / 64, nvfb = (h + 63) / 64, nfb = nhfb * nvfb;
+    uint16_t    *tile = (uint16_t *)malloc(sizeof(uint16_t) * 70 * 144);
+    uint64_t     done = 0;
+    const double t_end = now_s() + seconds;
+    for (;;)
+        for (int f = (int)idx0; f < nfb; f += (int)step) {
+            const int fbr = f / nhfb, fbc = f % nhfb;
+            for (int i = 0; i < 70 * 144; i++) tile[i] = 0x7f7f;
+            const int x0 = fbc * 64, y0 = fbr * 64;
+            const int xs = x0 - (fbc ? 8 : 0), ys = y0 - (fbr ? 3 : 0);
+            const int xe = (x0 + 64 < w ? x0 + 64 : w) + (fbc + 1 < nhfb ? 8 : 0), ye = (y0 + 64 < h ? y0 + 64 : h) + (fbr + 1 < nvfb ? 3 : 0);
+            uint16_t *in = tile + 3 * 144 + 8;
+            for (int y = ys; y < ye; y++) memcpy(in + (y - y0) * 144 + (xs - x0), plane + (size_t)y * stride + xs, sizeof(uint16_t) * (xe - xs));
+            uint8_t dl[128], dir[16][16];
+            int32_t var[16][16], dirinit = 0, cnt = 0;
+            for (int by = 0; by < 8 && y0 + by * 8 < h; by++)
+                for (int bx = 0; bx < 8 && x0 + bx * 8 < w; bx++) { dl[2 * cnt] = (uint8_t)by; dl[2 * cnt + 1] = (uint8_t)bx; cnt++; }
+            fb(NULL, out + (size_t)y0 * stride + x0, stride, in, 0, 0, dir, &dirinit, var, 0, dl, cnt, level, sec, damping, damping, coeff_shift, 1);
+            done++;
+            if (now_s() >= t_end) { free(tile); return done; }
         }
 }
