@@ -256,14 +256,17 @@ def bench_cdef(torch, lib, pkg, stream, a, cpu):
             ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))
             ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
             for ptr, fnn in (("svt_aom_cdef_find_dir", "svt_aom_cdef_find_dir_avx2"), ("svt_aom_cdef_find_dir_dual", "svt_aom_cdef_find_dir_dual_avx2"),
-                             ("svt_cdef_filter_block", "svt_cdef_filter_block_avx2")):
+                             ("svt_cdef_filter_block", "svt_cdef_filter_block_avx2"),
+                             ("svt_cdef_filter_block_8xn_16", "svt_cdef_filter_block_8xn_16_avx2")):  # SIMD-internal pointer, NULL in a C-only setup
                 C.c_void_p.in_dll(ref, ptr).value = C.cast(getattr(ref, fnn), C.c_void_p).value  # what RTCD would select with AVX2 detected
             f = oracle.oracle_time_cdef_apply
             f.restype = C.c_uint64
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_double]
             fb = C.cast(ref.svt_cdef_filter_fb, C.c_void_p)
-            cpu_out = np.zeros_like(plane)
-            run = lambda i0, stp, s: f(fb, plane.ctypes.data, Wc, Wc, Hc, cpu_out.ctypes.data, 4, 2, 4, 2, i0, stp, s)  # noqa: E731
+            pl = aligned_zeros(Wc * Hc, np.uint16).reshape(Hc, Wc)  # the AVX2 kernels use aligned loads / stores
+            pl[:] = plane
+            cpu_out = aligned_zeros(Wc * Hc, np.uint16).reshape(Hc, Wc)
+            run = lambda i0, stp, s: f(fb, pl.ctypes.data, Wc, Wc, Hc, cpu_out.ctypes.data, 4, 2, 4, 2, i0, stp, s)  # noqa: E731
             rate, one, cores = cpu_pool(run, 4.0)
             out["cdef_apply_4k10"]["cpu_baseline"] = {"value": rate * 64 / 1e6, "unit": "M(8x8 blocks)/s", "cores": cores, "kind": "reference",
                                                       "single_thread_value": one * 64 / 1e6,

@@ -4,6 +4,7 @@
  * the oracle restatement can be pinned against "the reference run here" for paths whose driver is `static` in the
  * reference and therefore not callable by symbol.
  */
+#define _POSIX_C_SOURCE 200809L
 #include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -112,7 +113,8 @@ typedef void (*CdefFilterFbFn)(uint8_t *, uint16_t *, int32_t, uint16_t *, int32
 uint64_t oracle_time_cdef_apply(CdefFilterFbFn fb, const uint16_t *plane, int stride, int w, int h, uint16_t *out, int level, int sec, int damping,
                                 int coeff_shift, uint32_t idx0, uint32_t step, double seconds) {
     const int    nhfb = (w + 63) / 64, nvfb = (h + 63) / 64, nfb = nhfb * nvfb;
-    uint16_t    *tile = (uint16_t *)malloc(sizeof(uint16_t) * 70 * 144);
+    uint16_t    *tile = NULL; /* the AVX2 kernels use aligned loads */
+    if (posix_memalign((void **)&tile, 64, sizeof(uint16_t) * 70 * 144 + 64)) return 0;
     uint64_t     done = 0;
     const double t_end = now_s() + seconds;
     for (;;)

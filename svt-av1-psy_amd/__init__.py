@@ -212,3 +212,11 @@ def me_descs_for_frame(width, height, stride, org_x, org_y, area_w, area_h, plan
                         (ref_plane0 + r) * plane_bytes + (py + yo) * stride + (px + xo), stride, stride, xo, yo, area_w, area_h)
                 i += 1
     return d
+
+
+def shard_range(n_units, rank, world):
+    """Contiguous share of `n_units` independent units (frames / SB rows / filter blocks) for `rank` of `world`:
+    the path partitions without any exchange, so sharding is just a range split."""
+    base, rem = divmod(n_units, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -266,9 +266,12 @@ def main():
          "__device__ constexpr int32_t kCospi[4][64] = {"]
     h += ["    {" + ", ".join(str(v) for v in row) + "}," for row in cos_tabs[:4]]
     h += ["};",
-          "// half_btf (inv_transforms.h:260-285): the two products wrap to 32 bits, the sum and the rounding are 64-bit.",
+          "// half_btf (inv_transforms.h:260-285).  The C code forms each product in int32 and sums in int64; the AV1 stage ranges",
+          "// (cos_bit is lowered exactly so that |w * in| < 2^31 at every stage, transforms.h:47-50 / range_check_buf) guarantee the int32",
+          "// products never overflow for any residual within the bit depth, i.e. wherever the C expression is defined.  There the exact",
+          "// 64-bit form below is identical and costs two v_mad_i64_i32 + one 64-bit shift instead of 2 mul + sign-extensions + carries.",
           "template <int CB> __device__ __forceinline__ int32_t half_btf(const int32_t w0, const int32_t a, const int32_t w1, const int32_t b) {",
-          "    const int64_t r = (int64_t)(int32_t)((uint32_t)w0 * (uint32_t)a) + (int64_t)(int32_t)((uint32_t)w1 * (uint32_t)b) + ((int64_t)1 << (CB - 1));",
+          "    const int64_t r = (int64_t)w0 * (int64_t)a + (int64_t)w1 * (int64_t)b + ((int64_t)1 << (CB - 1));",
           "    return (int32_t)(r >> CB);", "}",
           "__device__ __forceinline__ int32_t clamp_i32(const int32_t x, const int32_t lo, const int32_t hi) { return x < lo ? lo : (x > hi ? hi : x); }",
           "#define C(k) kCospi[CB - 10][k]", "#define HB(w0, a, w1, b) half_btf<CB>(w0, a, w1, b)",
