@@ -28,9 +28,23 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+QSAD_PEAK = 1024 * 2.4e9 / 22.4 * 64 * 16  # |a-b| per second if every SIMD issued nothing but v_qsad_pk_u16_u8 (16 per lane)
 W, H, PAD = 1920, 1080, 68  # luma plane padded 68 px each side (enc_handle.c:4084) -> stride 2056
 STRIDE, ROWS = W + 2 * PAD, H + 2 * PAD
 PLANE = STRIDE * ROWS
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_traffic.json, written by
+    tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command's default workload).
+    bench.py cannot read PMC counters itself; None when no summary is committed or the workload flags differ from the profiled ones."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
+    return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "read": k["hbm_read_bytes_per_launch"],
+                                   "write": k["hbm_write_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}
 
 
 def synth_planes(n, seed):
@@ -176,8 +190,9 @@ def bench_sad_pairs(torch, lib, pkg, stream, a):
     _, dv = time_steps(torch, fn, a.steps, a.warmup)
     gbs = len(pairs) * 8192 / (dv / a.steps) / 1e9
     return {"value": len(pairs) / (dv / a.steps) / 1e6, "unit": "Mblocks/s (64x64 pairs)", "kernel": "sad_nxm_kernel", "footprint_MB": nplanes * PLANE / 1e6,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_block": 8192}}
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": (pmc_traffic("sad_nxm_kernel") or {}).get("hbm_bytes_per_launch"), "traffic_detail": pmc_traffic("sad_nxm_kernel"),
+                         "algorithmic_bytes_per_launch": len(pairs) * 8192, "algorithmic_bytes_per_block": 8192}}
 
 
 def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
@@ -194,7 +209,9 @@ def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
     _, dv = time_steps(torch, fn, a.steps, a.warmup)
     gbs = n * 6144 / (dv / a.steps) / 1e9
     out = {"value": n / (dv / a.steps) / 1e6, "unit": "Mblocks/s (32x32)", "kernel": "fwd_txfm2d_kernel<32,32>", "blocks_per_step": n,
-           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "traffic": (pmc_traffic("fwd_txfm2d_kernel<32, 32>") or {}).get("hbm_bytes_per_launch"),
+                        "traffic_detail": pmc_traffic("fwd_txfm2d_kernel<32, 32>"), "algorithmic_bytes_per_launch": n * 6144,
                         "algorithmic_bytes_per_block": 6144, "note": "butterfly network: VALU/int32-multiply bound, not a dense contraction (DESIGN.md 4.2)"}}
     if cpu:
         ref, oracle = ref_libs()
@@ -340,6 +357,8 @@ def main():
     bytes_item = 64 * 64 + (64 + aw - 1) * (64 + ah - 1) + 85 * 8
     kernel_s = dev / a.steps
     achieved = n * bytes_item / kernel_s / 1e9
+    default_workload = (a.frames, a.refs, a.area) == (32, 4, "16x9")  # the workload the committed PMC passes were run on
+    me_traffic = (pmc_traffic("me_fullpel_kernel<false>") or {}) if default_workload else {}
     out = {
         "metric": "Mblocks/s per kernel (SAD, FwdTxfm2d, CDEF) + encoder fps @1080p preset 8", "value": value,
         "unit": "Mblocks/s (block = one search position of one 64x64 SB vs one reference = 85 block SADs)",
@@ -349,10 +368,13 @@ def main():
                    "frames_per_step_per_gpu": a.frames, "refs": a.refs, "search_area": a.area, "sb_refs_per_step_per_gpu": n,
                    "sub_sad": 0, "parallelism": "frame-sharded x%d (no collective)" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "me_fullpel_kernel<false>", "kernel_ms": kernel_s * 1e3,
+                     "traffic": me_traffic.get("hbm_bytes_per_launch"), "traffic_detail": me_traffic or None,
+                     "algorithmic_bytes_per_launch": n * bytes_item, "kernel": "me_fullpel_kernel<false>", "kernel_ms": kernel_s * 1e3,
                      "algorithmic_bytes_per_sb_ref": bytes_item,
                      "note": "search is VALU(packed-SAD)-bound, see sad_ops; HBM figure = SURVEY 8(d) algorithmic bytes / time",
-                     "sad_ops_per_s": n * aw * ah * 4096 / kernel_s},
+                     "sad_ops_per_s": n * aw * ah * 4096 / kernel_s,
+                     # measured v_qsad_pk_u16_u8 issue cost: 22.4 cycles per wave64 instruction per SIMD (profiles/r01_call1_valu_issue_rates.txt)
+                     "valu_peak_sad_ops_per_s": QSAD_PEAK, "valu_frac": n * aw * ah * 4096 / kernel_s / QSAD_PEAK},
     }
     kernels = {}
     kernels["sad64x64_pairs"] = bench_sad_pairs(torch, lib, pkg, stream, a)

@@ -51,6 +51,60 @@ __device__ __forceinline__ void stage_rows_u8(uint32_t* lds, int pitch_dw, const
     }
 }
 
+struct __attribute__((packed, aligned(1))) u32x4_a1 { uint32_t x, y, z, w; }; // 16-byte load at any byte address (gfx950 global loads are unaligned-capable)
+struct __attribute__((packed, aligned(1))) u32_a1 { uint32_t x; };
+struct __attribute__((aligned(8))) u32x2_a8 { uint32_t x, y; };
+
+// Same contract as stage_rows_u8 for rows of at most 128 bytes, built for latency: a row is cut into eight 16-byte chunks, thread t owns
+// chunks t, t+256, ... and issues ALL of its global loads (one unaligned dwordx4 each) before the first LDS store, so a block pays one
+// memory round trip instead of one per loop iteration. Only the last, partial chunk of a row takes the dword-exact path (it must not
+// read past the end of the row: the caller owns nothing beyond it). pitch_dw must be even (8-byte LDS stores).
+template <int NIT, int CL2> // CL2 = log2(chunks per row): 3 for rows up to 128 bytes, 2 for 64-byte rows; width >= 16
+__device__ __forceinline__ void stage_rows_load(uint32_t (&v)[NIT][4], const uint8_t* g, uint32_t gstride, int width, int rows, int tid) {
+    // issue phase: straight-line, one dwordx4 per chunk. A partial last chunk (left < 16 bytes) is fetched as the 16 bytes that END at
+    // the row end and shifted down afterwards; dead chunks re-read byte 0 and are zeroed. Nothing outside [row, row + width) is touched.
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int  idx = tid + 256 * k, r = idx >> CL2, col = (idx & ((1 << CL2) - 1)) * 16;
+        const bool live = r < rows && col < width;
+        const int  left = width - col;
+        const int  back = (live && left < 16) ? 16 - left : 0;
+        const uint8_t* p = g + (live ? (size_t)r * gstride + (size_t)(col - back) : (size_t)0);
+        const u32x4_a1 t = *(const u32x4_a1*)p;
+        v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int  idx = tid + 256 * k, r = idx >> CL2, col = (idx & ((1 << CL2) - 1)) * 16;
+        const bool live = r < rows && col < width;
+        const int  left = width - col;
+        uint32_t   x0 = live ? v[k][0] : 0u, x1 = live ? v[k][1] : 0u, x2 = live ? v[k][2] : 0u, x3 = live ? v[k][3] : 0u;
+        if (live && left < 16) { // shift the 128-bit value right by 16 - left bytes, zero fill
+            const int back = 16 - left;
+            if (back & 4) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
+            if (back & 8) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
+            const uint32_t bs = (uint32_t)back & 3u;
+            x0 = __builtin_amdgcn_alignbyte(x1, x0, bs);
+            x1 = __builtin_amdgcn_alignbyte(x2, x1, bs);
+            x2 = __builtin_amdgcn_alignbyte(x3, x2, bs);
+            x3 = __builtin_amdgcn_alignbyte(0u, x3, bs);
+        }
+        v[k][0] = x0; v[k][1] = x1; v[k][2] = x2; v[k][3] = x3;
+    }
+}
+template <int NIT, int CL2>
+__device__ __forceinline__ void stage_rows_store(const uint32_t (&v)[NIT][4], uint32_t* lds, int pitch_dw, int rows, int tid) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int idx = tid + 256 * k, r = idx >> CL2, c4 = (idx & ((1 << CL2) - 1)) * 4;
+        if (r < rows) {
+            uint32_t* o = lds + r * pitch_dw + c4;
+            if (c4 + 0 < pitch_dw) *(u32x2_a8*)(o + 0) = u32x2_a8{v[k][0], v[k][1]};
+            if (c4 + 2 < pitch_dw) *(u32x2_a8*)(o + 2) = u32x2_a8{v[k][2], v[k][3]};
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t dpp_add_quad_xor1(uint32_t v) {
     return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
 }
@@ -74,10 +128,81 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 }
 
 // ---- frame-batched integer full-pel ME search ---------------------------------------------------------------
+constexpr int ME_PITCH = 34; // window row pitch in dwords: >= 17 + 64 / 4, even (8-byte LDS stores) and = 2 mod 8, so the 8 block rows x
+                             // 8 block columns a half-wave reads fall into 64 distinct LDS banks (8 * 34 = 16 mod 64)
+
+// All strips of one wave. keys: 8x8 -> (sad16 << 16) | pos   (one v_lshl_or / v_and_or per position, straight from the packed u16 lanes)
+//                               16x16/32x32/64x64 -> (sad << 11) | pos   (sad64 < 2^20, pos < 2^11)
+// FULL: the tile width is a multiple of 4, no strip has invalid positions.
+template <bool SUB, bool FULL>
+__device__ __forceinline__ void me_search_strips(const uint32_t* __restrict__ win, const uint32_t (&s)[8][2], int Wt, int Ht, int wv, int l,
+                                                 uint32_t& best8, uint32_t& best16, uint32_t& best32, uint32_t& best64) {
+    const int bx = (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4);
+    const int by = ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4);
+    const int q  = l & 3;
+    const int      G    = (Wt + 3) >> 2;
+    const uint32_t qsel = 0x0c0c0100u + 0x0202u * (uint32_t)q; // v_perm_b32 selector: u16 number q of {thi:tlo}, zero extended
+    const int      bp16 = (l ^ 16) << 2, bp32 = (l ^ 32) << 2; // ds_bpermute byte addresses of the partner rows
+    for (int g = wv; g < G; g += 4) {
+        const uint32_t* colp   = win + (by * 8) * ME_PITCH + bx * 2 + g;
+        const int       nvalid = (Wt - 4 * g) < 4 ? (Wt - 4 * g) : 4;
+        // invalid positions (last strip when Wt % 4 != 0) are pushed to the top of the key space
+        const uint32_t inv1 = nvalid > 1 ? 0u : 0xffffffffu, inv2 = nvalid > 2 ? 0u : 0xffffffffu, inv3 = nvalid > 3 ? 0u : 0xffffffffu;
+        const uint32_t invq = q < nvalid ? 0u : 0xffffffffu;
+        // 8-row ring; each row is kept as the two overlapping 8-byte windows v_qsad_pk_u16_u8 consumes
+        U64A4 ra[8], rb[8];
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            ra[r] = *(const U64A4*)(colp + r * ME_PITCH);
+            rb[r] = *(const U64A4*)(colp + r * ME_PITCH + 1);
+        }
+        uint32_t pos = (uint32_t)(4 * g), posq = (uint32_t)(4 * g + q);
+        for (int yb = 0; yb < Ht; yb += 8) {
+            const uint32_t* rowp = colp + (yb + 7) * ME_PITCH;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (yb + i < Ht) {
+                    ra[(i + 7) & 7] = *(const U64A4*)(rowp + i * ME_PITCH);
+                    rb[(i + 7) & 7] = *(const U64A4*)(rowp + i * ME_PITCH + 1);
+                    unsigned long long acc = 0;
+#pragma unroll
+                    for (int r = 0; r < 8; r += (SUB ? 2 : 1)) {
+                        acc = __builtin_amdgcn_qsad_pk_u16_u8(ra[(i + r) & 7].v, s[r][0], acc);
+                        acc = __builtin_amdgcn_qsad_pk_u16_u8(rb[(i + r) & 7].v, s[r][1], acc);
+                    }
+                    if (SUB) acc <<= 1; // 8x4 on even rows, doubled (motion_estimation.c:105-126); u16 lanes cannot carry
+                    const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+                    // 8x8: this lane's block, 4 positions
+                    uint32_t k0 = (lo << 16) | pos, k1 = (lo & 0xffff0000u) | (pos + 1), k2 = (hi << 16) | (pos + 2),
+                             k3 = (hi & 0xffff0000u) | (pos + 3);
+                    if (!FULL) { k1 |= inv1; k2 |= inv2; k3 |= inv3; }
+                    best8 = umin32(umin32(best8, k0), k1);
+                    best8 = umin32(umin32(best8, k2), k3);
+                    // 16x16 = the quad's four 8x8 (u16 lanes: 4 * 16320 < 65536, so plain adds never carry)
+                    const uint32_t tlo = dpp_add_quad_xor2(dpp_add_quad_xor1(lo));
+                    const uint32_t thi = dpp_add_quad_xor2(dpp_add_quad_xor1(hi));
+                    // lane q of the quad takes position q from here on
+                    const uint32_t sad16 = __builtin_amdgcn_perm(thi, tlo, qsel);
+                    const uint32_t pq    = FULL ? posq : (posq | invq);
+                    best16 = umin32(best16, (sad16 << KEY_POS_BITS) | pq);
+                    // 32x32 = 4 quads of a 16-lane row; 64x64 = 4 rows
+                    const uint32_t sad32 = dpp_add_row_ror8(dpp_add_row_ror4(sad16));
+                    best32 = umin32(best32, (sad32 << KEY_POS_BITS) | pq);
+                    uint32_t sad64 = sad32 + (uint32_t)__builtin_amdgcn_ds_bpermute(bp16, (int)sad32);
+                    sad64 += (uint32_t)__builtin_amdgcn_ds_bpermute(bp32, (int)sad64);
+                    best64 = umin32(best64, (sad64 << KEY_POS_BITS) | pq);
+                    pos += ME_TW;
+                    posq += ME_TW;
+                }
+            }
+        }
+    }
+}
+
 template <bool SUB>
 __global__ __launch_bounds__(256, 4) void me_fullpel_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
                                                          const SvtHipMeSearchDesc* __restrict__ descs, uint32_t n,
-                                                         uint32_t tiles_x, int pitch_dw, int win_rows,
+                                                         uint32_t tiles_x,
                                                          uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv,
                                                          unsigned long long* __restrict__ keys) {
     HIP_DYNAMIC_SHARED(uint32_t, smem)
@@ -103,85 +228,31 @@ __global__ __launch_bounds__(256, 4) void me_fullpel_kernel(const uint8_t* __res
     const int Wt = (W - tx0) < ME_TW ? (W - tx0) : ME_TW;
     const int Ht = (H - ty0) < ME_TH ? (H - ty0) : ME_TH;
 
-    stage_rows_u8(src_lds, 16, src_base + d.src_off, d.src_stride, 64, 64, tid, 256);
-    stage_rows_u8(win, pitch_dw, ref_base + d.ref_off + (size_t)ty0 * d.ref_stride + tx0, d.ref_stride, 64 + Wt - 1,
-                  64 + Ht - 1, tid, 256);
-    // rows the ring may touch beyond the staged ones do not exist: win_rows >= 64 + Ht - 1 always holds.
-    (void)win_rows;
+    {
+        uint32_t vs[1][4], vw[3][4]; // 64 x 64 source = 256 chunks; window <= 95 rows x 8 chunks
+        stage_rows_load<1, 2>(vs, src_base + d.src_off, d.src_stride, 64, 64, tid);
+        stage_rows_load<3, 3>(vw, ref_base + d.ref_off + (size_t)ty0 * d.ref_stride + tx0, d.ref_stride, 64 + Wt - 1, 64 + Ht - 1, tid);
+        stage_rows_store<1, 2>(vs, src_lds, 16, 64, tid);
+        stage_rows_store<3, 3>(vw, win, ME_PITCH, 64 + Ht - 1, tid);
+    }
     if (tid < 88) best_lds[tid] = 0xffffffffu;
     __syncthreads();
 
     const int l  = tid & 63;
     const int wv = tid >> 6;
-    const int bx = (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4);
-    const int by = ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4);
-    const int q  = l & 3;
-
     uint32_t s[8][2];
+    {
+        const int bx = (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4);
+        const int by = ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        s[r][0] = src_lds[(by * 8 + r) * 16 + bx * 2 + 0];
-        s[r][1] = src_lds[(by * 8 + r) * 16 + bx * 2 + 1];
+        for (int r = 0; r < 8; r++) {
+            s[r][0] = src_lds[(by * 8 + r) * 16 + bx * 2 + 0];
+            s[r][1] = src_lds[(by * 8 + r) * 16 + bx * 2 + 1];
+        }
     }
-
-    // keys: 8x8 -> (sad16 << 16) | pos   (one v_lshl_or / v_and_or per position, straight from the packed u16 lanes)
-    //       16x16/32x32/64x64 -> (sad << 11) | pos   (sad64 < 2^20, pos < 2^11)
     uint32_t best8 = 0xffffffffu, best16 = 0xffffffffu, best32 = 0xffffffffu, best64 = 0xffffffffu;
-    const int      G    = (Wt + 3) >> 2;
-    const uint32_t qsh  = (uint32_t)(q & 1) * 16u;
-    const int      bp16 = (l ^ 16) << 2, bp32 = (l ^ 32) << 2; // ds_bpermute byte addresses of the partner rows
-    for (int g = wv; g < G; g += 4) {
-        const uint32_t* colp   = win + (by * 8) * pitch_dw + bx * 2 + g;
-        const int       nvalid = (Wt - 4 * g) < 4 ? (Wt - 4 * g) : 4;
-        // invalid positions (last strip when Wt % 4 != 0) are pushed to the top of the key space
-        const uint32_t inv1 = nvalid > 1 ? 0u : 0xffffffffu, inv2 = nvalid > 2 ? 0u : 0xffffffffu, inv3 = nvalid > 3 ? 0u : 0xffffffffu;
-        const uint32_t invq = q < nvalid ? 0u : 0xffffffffu;
-        // 8-row ring; each row is kept as the two overlapping 8-byte windows v_qsad_pk_u16_u8 consumes
-        U64A4 ra[8], rb[8];
-#pragma unroll
-        for (int r = 0; r < 7; r++) {
-            ra[r] = *(const U64A4*)(colp + r * pitch_dw);
-            rb[r] = *(const U64A4*)(colp + r * pitch_dw + 1);
-        }
-        for (int yb = 0; yb < Ht; yb += 8) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int y = yb + i;
-                if (y < Ht) {
-                    const uint32_t* np = colp + (y + 7) * pitch_dw;
-                    ra[(i + 7) & 7] = *(const U64A4*)(np);
-                    rb[(i + 7) & 7] = *(const U64A4*)(np + 1);
-                    unsigned long long acc = 0;
-#pragma unroll
-                    for (int r = 0; r < 8; r += (SUB ? 2 : 1)) {
-                        acc = __builtin_amdgcn_qsad_pk_u16_u8(ra[(i + r) & 7].v, s[r][0], acc);
-                        acc = __builtin_amdgcn_qsad_pk_u16_u8(rb[(i + r) & 7].v, s[r][1], acc);
-                    }
-                    if (SUB) acc <<= 1; // 8x4 on even rows, doubled (motion_estimation.c:105-126); u16 lanes cannot carry
-                    const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
-                    const uint32_t pos = (uint32_t)(y * ME_TW + 4 * g);
-                    // 8x8: this lane's block, 4 positions
-                    best8 = umin32(best8, (lo << 16) | pos);
-                    best8 = umin32(best8, ((lo & 0xffff0000u) | (pos + 1)) | inv1);
-                    best8 = umin32(best8, ((hi << 16) | (pos + 2)) | inv2);
-                    best8 = umin32(best8, ((hi & 0xffff0000u) | (pos + 3)) | inv3);
-                    // 16x16 = the quad's four 8x8 (u16 lanes: 4 * 16320 < 65536, so plain adds never carry)
-                    const uint32_t tlo = dpp_add_quad_xor2(dpp_add_quad_xor1(lo));
-                    const uint32_t thi = dpp_add_quad_xor2(dpp_add_quad_xor1(hi));
-                    // lane q of the quad takes position q from here on
-                    const uint32_t sad16 = __builtin_amdgcn_ubfe((q & 2) ? thi : tlo, qsh, 16u);
-                    const uint32_t posq  = (pos + (uint32_t)q) | invq;
-                    best16 = umin32(best16, (sad16 << KEY_POS_BITS) | posq);
-                    // 32x32 = 4 quads of a 16-lane row; 64x64 = 4 rows
-                    const uint32_t sad32 = dpp_add_row_ror8(dpp_add_row_ror4(sad16));
-                    best32 = umin32(best32, (sad32 << KEY_POS_BITS) | posq);
-                    uint32_t sad64 = sad32 + (uint32_t)__builtin_amdgcn_ds_bpermute(bp16, (int)sad32);
-                    sad64 += (uint32_t)__builtin_amdgcn_ds_bpermute(bp32, (int)sad64);
-                    best64 = umin32(best64, (sad64 << KEY_POS_BITS) | posq);
-                }
-            }
-        }
-    }
+    if ((Wt & 3) == 0) me_search_strips<SUB, true>(win, s, Wt, Ht, wv, l, best8, best16, best32, best64);
+    else me_search_strips<SUB, false>(win, s, Wt, Ht, wv, l, best8, best16, best32, best64);
 
     atomicMin(&best_lds[21 + l], best8);
     atomicMin(&best_lds[5 + (l >> 2)], best16);
@@ -232,6 +303,41 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// One wave per pair. A block row is cut into 16-byte chunks (widths >= 16) or 4-byte chunks (widths 4, 8, 12); every lane issues up to four
+// chunk loads per operand before the first v_sad_u8 so that a 64x64 pair (8 KB) is fully in flight after one issue burst.
+template <int CHUNK> // bytes per lane-chunk: 16 or 4
+__device__ __forceinline__ uint32_t sad_chunks(const uint8_t* __restrict__ src, const uint8_t* __restrict__ ref, uint32_t ss, uint32_t rs,
+                                               int cpr, int cshift, int total, int l) {
+    uint32_t sad = 0;
+    for (int i0 = l; i0 < total; i0 += 256) {
+        uint32_t av[4][CHUNK / 4], bv[4][CHUNK / 4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int  i  = i0 + 64 * k;
+            const bool in = i < total;
+            const int  r  = cshift >= 0 ? (i >> cshift) : (i / cpr);
+            const int  c  = i - r * cpr;
+            const uint8_t* pa = src + (size_t)r * ss + c * CHUNK;
+            const uint8_t* pb = ref + (size_t)r * rs + c * CHUNK;
+            if (CHUNK == 16) {
+                u32x4_a1 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+                if (in) { a = *(const u32x4_a1*)pa; b = *(const u32x4_a1*)pb; }
+                av[k][0] = a.x; av[k][CHUNK / 4 > 1 ? 1 : 0] = a.y; av[k][CHUNK / 4 > 2 ? 2 : 0] = a.z; av[k][CHUNK / 4 > 3 ? 3 : 0] = a.w;
+                bv[k][0] = b.x; bv[k][CHUNK / 4 > 1 ? 1 : 0] = b.y; bv[k][CHUNK / 4 > 2 ? 2 : 0] = b.z; bv[k][CHUNK / 4 > 3 ? 3 : 0] = b.w;
+            } else {
+                u32_a1 a = {0}, b = {0};
+                if (in) { a = *(const u32_a1*)pa; b = *(const u32_a1*)pb; }
+                av[k][0] = a.x; bv[k][0] = b.x;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < CHUNK / 4; ++j) sad = __builtin_amdgcn_sad_u8(av[k][j], bv[k][j], sad);
+    }
+    return sad;
+}
+
 __global__ __launch_bounds__(256) void sad_nxm_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
                                                       const SvtHipSadPair* __restrict__ pairs, uint32_t n, int width, int height,
                                                       uint32_t* __restrict__ sad_out) {
@@ -242,19 +348,12 @@ __global__ __launch_bounds__(256) void sad_nxm_kernel(const uint8_t* __restrict_
     const uint8_t*      src = src_base + p.src_off;
     const uint8_t*      ref = ref_base + p.ref_off;
     uint32_t            sad = 0;
-    const bool fast = ((width & 15) == 0) && ((((uintptr_t)src | (uintptr_t)ref | p.src_stride | p.ref_stride) & 3) == 0);
-    if (fast) {
-        const int cpr   = width >> 4; // 16-byte chunks per row
-        const int total = cpr * height;
-        for (int i = l; i < total; i += 64) {
-            const int       r = i / cpr, c = i - r * cpr;
-            const u32x4_a4  a = *(const u32x4_a4*)(src + (size_t)r * p.src_stride + c * 16);
-            const u32x4_a4  b = *(const u32x4_a4*)(ref + (size_t)r * p.ref_stride + c * 16);
-            sad = __builtin_amdgcn_sad_u8(a.x, b.x, sad);
-            sad = __builtin_amdgcn_sad_u8(a.y, b.y, sad);
-            sad = __builtin_amdgcn_sad_u8(a.z, b.z, sad);
-            sad = __builtin_amdgcn_sad_u8(a.w, b.w, sad);
-        }
+    if ((width & 15) == 0) {
+        const int cpr = width >> 4;
+        sad = sad_chunks<16>(src, ref, p.src_stride, p.ref_stride, cpr, (cpr & (cpr - 1)) ? -1 : __builtin_ctz(cpr), cpr * height, l);
+    } else if ((width & 3) == 0) {
+        const int cpr = width >> 2;
+        sad = sad_chunks<4>(src, ref, p.src_stride, p.ref_stride, cpr, (cpr & (cpr - 1)) ? -1 : __builtin_ctz(cpr), cpr * height, l);
     } else {
         const int total = width * height;
         for (int i = l; i < total; i += 64) {
@@ -551,9 +650,8 @@ void svt_hip_me_fullpel_search_batch(const uint8_t* src_base, const uint8_t* ref
     if (max_h == 0) max_h = 1;
     const uint32_t tiles_x = (max_w + ME_TW - 1) / ME_TW, tiles_y = (max_h + ME_TH - 1) / ME_TH;
     const int      tw = max_w < (uint32_t)ME_TW ? (int)max_w : ME_TW, th = max_h < (uint32_t)ME_TH ? (int)max_h : ME_TH;
-    const int      pitch_dw = (((tw + 3) >> 2) + 16) | 1;
     const int      win_rows = 64 + th - 1;
-    const size_t   shmem    = (size_t)(64 * 16 + 88 + pitch_dw * win_rows) * 4;
+    const size_t   shmem    = (size_t)(64 * 16 + 88 + ME_PITCH * win_rows) * 4;
     const bool     multi    = tiles_x * tiles_y > 1;
     unsigned long long* keys = multi ? (unsigned long long*)workspace : nullptr;
     if (multi) {
@@ -562,10 +660,10 @@ void svt_hip_me_fullpel_search_batch(const uint8_t* src_base, const uint8_t* ref
     }
     if (sub_sad)
         hipLaunchKernelGGL(me_fullpel_kernel<true>, dim3(n, tiles_x * tiles_y), dim3(256), shmem, (hipStream_t)stream, src_base, ref_base,
-                           descs, n, tiles_x, pitch_dw, win_rows, best_sad, best_mv, keys);
+                           descs, n, tiles_x, best_sad, best_mv, keys);
     else
         hipLaunchKernelGGL(me_fullpel_kernel<false>, dim3(n, tiles_x * tiles_y), dim3(256), shmem, (hipStream_t)stream, src_base, ref_base,
-                           descs, n, tiles_x, pitch_dw, win_rows, best_sad, best_mv, keys);
+                           descs, n, tiles_x, best_sad, best_mv, keys);
     SVT_LAUNCH_CHECK();
     if (multi) {
         const uint32_t tot = n * SVT_HIP_ME_NUM_BLOCKS;

@@ -1,0 +1,11 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/r4_pytest.log 2>&1; echo "pytest rc=$?"
+tail -3 gpurun_out/r4_pytest.log
+timeout 900 python bench.py --steps 20 --warmup 3 --extra > gpurun_out/r4_bench.json 2> gpurun_out/r4_bench.err; echo "bench rc=$?"
+tail -c 600 gpurun_out/r4_bench.err
+head -c 3000 gpurun_out/r4_bench.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r4 -o run -- python bench.py --steps 20 --warmup 3 --no-cpu > gpurun_out/r4_prof.log 2>&1; echo "prof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc4_fetch -o run -- python bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/r4_pmc_fetch.log 2>&1; echo "pmcf rc=$?"
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc4_write -o run -- python bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/r4_pmc_write.log 2>&1; echo "pmcw rc=$?"
+ls gpurun_out/prof_r4 gpurun_out/pmc4_fetch
