@@ -402,6 +402,10 @@ def main():
             _, dv = time_steps(torch, f2, st, 1)
             kernels["me_search_%dx%d_sub%d" % (w2, h2, sub)] = {"value": len(dd) * w2 * h2 / (dv / st) / 1e6, "unit": "Mblocks/s",
                                                                "sb_refs": len(dd), "sad_ops_per_s": len(dd) * w2 * h2 * (2048 if sub else 4096) / (dv / st)}
+        import bench_legs
+        kernels.update(bench_legs.hme_sad_loop(torch, lib, pkg, stream, a.steps, a.warmup))
+        kernels.update(bench_legs.lr_frames(torch, lib, pkg, stream, max(a.steps // 2, 2), 2))
+        kernels["txfm_quant_roundtrip"] = bench_legs.txfm_roundtrip(torch, lib, pkg, stream, max(a.steps // 4, 3), 1)
     out["kernels"] = kernels
     if rank == 0 and world == 1 and not a.no_cpu:
         host_descs = pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, aw, ah, PLANE, n_refs=1, src_plane=0, ref_plane0=1)

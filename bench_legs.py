@@ -1,0 +1,173 @@
+"""Extra measurement legs of bench.py (`--extra`): BASELINE configs 3 and 4 beyond the slices the headline metric names, and the
+HME levels of config 2.  Same rules as bench.py: inputs resident in HBM before the timed region, HIP events on the launch stream,
+algorithmic bytes / kernel time against the 8 TB/s HBM peak.  Nothing here touches oracle/ (parity lives in tests/)."""
+import ctypes as C
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _time(torch, fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 1e3 / steps
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+
+
+def _qparams(pkg, dq_dc, dq_ac, log_scale):
+    """invert_quant() / zbin / round as svt_av1_build_quantizer derives them (md_config_process.c:111-189)."""
+    P = np.zeros(1, dtype=pkg.QuantParams)
+    for k, d in enumerate((dq_dc, dq_ac)):
+        t = int(d).bit_length() - 1
+        m = 1 + (1 << (16 + t)) // d
+        P["quant"][0][k] = np.int16(np.uint16((m - (1 << 16)) & 0xffff))
+        P["quant_shift"][0][k] = min(1 << (16 - t), 32767)
+        P["zbin"][0][k] = (84 * d + 64) >> 7
+        P["round"][0][k] = (48 * d) >> 7
+        P["dequant"][0][k] = d
+    P["log_scale"] = log_scale
+    return P
+
+
+def txfm_roundtrip(torch, lib, pkg, stream, steps, warmup):
+    """config 3: FwdTxfm2d (+ svt_handle_transform for 64-point sizes) -> quantize_b -> InvTxfm2d_add, all 19 TX sizes, 8 and 10 bit.
+    N per launch as SURVEY 8(d): 65536 (<= 16-point), 16384 (32-point), 4096 (64-point); tx_type cycles through the allowed set."""
+    out = {}
+    g = np.random.default_rng(13596)
+    for ts, (w, h) in enumerate(pkg.TX_SIZES):
+        big = max(w, h)
+        n = 65536 if big <= 16 else (16384 if big == 32 else 4096)
+        iw, ih = min(w, 32), min(h, 32)
+        ncoef = iw * ih
+        pels = w * h
+        ls = int(pels > 256) + int(pels > 1024)
+        types = pkg.allowed_tx_types(ts)
+        for bd in (8, 10):
+            amp = (1 << bd) - 1
+            res = g.integers(-amp, amp + 1, n * pels, dtype=np.int16)
+            fd = np.zeros(n, dtype=pkg.FwdTxfmDesc)
+            fd["in_off"] = np.arange(n, dtype=np.uint64) * pels
+            fd["in_stride"] = w
+            fd["tx_type"] = np.array(types, np.uint8)[np.arange(n) % len(types)]
+            idesc = np.zeros(n, dtype=pkg.InvTxfmDesc)
+            idesc["coeff_off"] = np.arange(n, dtype=np.uint64) * ncoef
+            idesc["pred_off"] = idesc["recon_off"] = np.arange(n, dtype=np.uint64) * pels
+            idesc["pred_stride"] = idesc["recon_stride"] = w
+            idesc["tx_type"] = fd["tx_type"]
+            qd = np.zeros(n, dtype=pkg.QuantDesc)
+            d_res, d_fd, d_id, d_qd = _dev(torch, res), _dev(torch, fd), _dev(torch, idesc), _dev(torch, qd)
+            d_qp = _dev(torch, _qparams(pkg, 88, 112, ls))
+            d_iscan = _dev(torch, np.arange(ncoef, dtype=np.int16))
+            d_pred = _dev(torch, g.integers(0, 1 << bd, n * pels, dtype=np.uint16))
+            d_coef = torch.zeros(n * pels, dtype=torch.int32, device="cuda")
+            d_q = torch.zeros(n * ncoef, dtype=torch.int32, device="cuda")
+            d_dq = torch.zeros(n * ncoef, dtype=torch.int32, device="cuda")
+            d_eob = torch.zeros(n, dtype=torch.int16, device="cuda")
+            d_en = torch.zeros(n, dtype=torch.int64, device="cuda")
+            d_rec = torch.zeros(n * pels, dtype=torch.int16, device="cuda")
+            mode = 1 if bd > 8 else 0
+
+            def fwd():
+                lib.svt_hip_fwd_txfm2d_batch(d_res.data_ptr(), d_fd.data_ptr(), n, ts, bd, 0, d_coef.data_ptr(), stream)
+                if big == 64:
+                    lib.svt_hip_handle_transform_batch(d_coef.data_ptr(), n, ts, 0, d_en.data_ptr(), stream)
+
+            def quant():
+                lib.svt_hip_quantize_batch(mode, d_coef.data_ptr(), n, ncoef, d_qp.data_ptr(), d_iscan.data_ptr(), None, None, d_qd.data_ptr(),
+                                           d_q.data_ptr(), d_dq.data_ptr(), d_eob.data_ptr(), stream)
+
+            def inv():
+                lib.svt_hip_inv_txfm2d_add_batch(d_dq.data_ptr(), d_pred.data_ptr(), d_rec.data_ptr(), d_id.data_ptr(), n, ts, bd, stream)
+
+            def chain():
+                fwd()
+                quant()
+                inv()
+            # note: for 64-point sizes handle_transform repacks in place, so quant reads the packed layout; chain order keeps that valid
+            tf, tc = _time(torch, fwd, steps, warmup), None
+            if big == 64:  # re-run fwd once so that d_coef holds a packed block set for the isolated quant timing
+                fwd()
+            tq = _time(torch, quant, steps, warmup)
+            ti = _time(torch, inv, steps, warmup)
+            tc = _time(torch, chain, steps, warmup)
+            # algorithmic bytes per block: fwd 2*pels in + 4*pels out; quant 4*ncoef in + 8*ncoef out + 2; inv 4*ncoef in + 2*pels pred + 2*pels recon
+            b_f, b_q, b_i = 6 * pels, 12 * ncoef + 2, 4 * ncoef + 4 * pels
+            out["%dx%d_bd%d" % (w, h, bd)] = {
+                "blocks": n, "chain_Mblocks_s": n / tc / 1e6, "fwd_Mblocks_s": n / tf / 1e6, "quant_Mblocks_s": n / tq / 1e6, "inv_Mblocks_s": n / ti / 1e6,
+                "chain_GBs": n * (b_f + b_q + b_i) / tc / 1e9, "fwd_GBs": n * b_f / tf / 1e9, "quant_GBs": n * b_q / tq / 1e9, "inv_GBs": n * b_i / ti / 1e9,
+                "chain_hbm_frac": n * (b_f + b_q + b_i) / tc / 1e9 / HBM_PEAK_GBS}
+            del d_res, d_coef, d_q, d_dq, d_rec, d_pred
+    return out
+
+
+def lr_frames(torch, lib, pkg, stream, steps, warmup):
+    """config 4, restoration half: one 3840x2160 10-bit luma plane, 256x256 units, every unit Wiener / every unit self-guided / mixed."""
+    Wc, Hc, bd, us = 3840, 2160, 10, 256
+    g = np.random.default_rng(44)
+    yy, xx = np.mgrid[0:Hc, 0:Wc]
+    plane = np.clip(((xx * 3 + yy * 2) % 1024) // 2 + ((xx // 8 + yy // 8) % 2) * 24 + g.integers(0, 64, (Hc, Wc)), 0, 1023).astype(np.uint16)
+    nstripes = (Hc + 8 + 63) // 64
+    above = g.integers(0, 1024, (2 * nstripes, Wc)).astype(np.uint16)
+    below = g.integers(0, 1024, (2 * nstripes, Wc)).astype(np.uint16)
+    nvu, nhu = max((Hc + us // 2) // us, 1), max((Wc + us // 2) // us, 1)
+    d_pl, d_ab, d_bl = _dev(torch, plane), _dev(torch, above), _dev(torch, below)
+    d_out = torch.zeros(Hc * Wc, dtype=torch.int16, device="cuda")
+    out = {}
+    for name, tsel in (("wiener", [1]), ("sgrproj", [2]), ("mixed", [1, 2, 0, 2, 1])):
+        units = np.zeros(nvu * nhu, dtype=pkg.LrUnit)
+        for i in range(len(units)):
+            f = [int(g.integers(-5, 11)), int(g.integers(-23, 9)), int(g.integers(-17, 47))]
+            taps = [f[0], f[1], f[2], -2 * sum(f), f[2], f[1], f[0], 0]
+            units[i] = (tsel[i % len(tsel)], taps, taps, int(g.integers(0, 16)), (int(g.integers(-96, 32)), int(g.integers(-32, 96))))
+        d_un = _dev(torch, units)
+        P = pkg.LrParams(d_pl.data_ptr(), d_ab.data_ptr(), d_bl.data_ptr(), d_out.data_ptr(), Wc, Wc, Wc, Wc, Hc, us, 0, 0, 1, bd, d_un.data_ptr())
+        t = _time(torch, lambda: lib.svt_hip_lr_filter_frame(C.byref(P), stream), steps, warmup)
+        nbytes = Wc * Hc * 4 + 4 * nstripes * Wc * 2
+        out["lr_%s_4k10" % name] = {"frames_per_s": 1 / t, "Mpx_s": Wc * Hc / t / 1e6, "ms": t * 1e3,
+                                    "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": nbytes / t / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": nbytes}}
+    return out
+
+
+def hme_sad_loop(torch, lib, pkg, stream, steps, warmup, nframes=32):
+    """config 2, hierarchical levels: svt_sad_loop_kernel over the 1/16 plane (16x16 block per SB, 32x16 area) and the 1/4 plane
+    (32x32 block, 16x16 area) of 1080p, all 510 SBs x nframes frames per launch."""
+    out = {}
+    g = np.random.default_rng(7)
+    for name, scale, area in (("hme_l0_sixteenth", 4, (32, 16)), ("hme_l1_quarter", 2, (16, 16))):
+        pw, ph, pad = 1920 // scale, 1080 // scale, 64 // scale * 2
+        stride, rows = pw + 2 * pad, ph + 2 * pad
+        planes = g.integers(0, 256, (nframes + 1, rows, stride), dtype=np.uint8)
+        bs = 64 // scale
+        aw, ah = area
+        descs = []
+        for f in range(nframes):
+            for sy in range((ph + bs - 1) // bs):
+                for sx in range((pw + bs - 1) // bs):
+                    x0, y0 = pad + sx * bs, pad + sy * bs
+                    rx = min(max(x0 - aw // 2, 0), stride - bs - aw)
+                    ry = min(max(y0 - ah // 2, 0), rows - bs - ah)
+                    bh = min(bs, ph - sy * bs)
+                    descs.append((f * rows * stride + y0 * stride + x0, (f + 1) * rows * stride + ry * stride + rx, stride, stride, stride, bs, bh,
+                                  aw, ah, 0, (0, 0, 0)))
+        d = np.array(descs, dtype=pkg.SadLoopDesc)
+        n = len(d)
+        d_pl, d_d = _dev(torch, planes), _dev(torch, d)
+        d_res = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+        d_keys = torch.zeros(n, dtype=torch.int64, device="cuda")
+        t = _time(torch, lambda: lib.svt_hip_sad_loop_batch(d_pl.data_ptr(), d_pl.data_ptr(), d_d.data_ptr(), n, d_res.data_ptr(), d_keys.data_ptr(), stream),
+                  steps, warmup)
+        out[name] = {"value": n * aw * ah / t / 1e6, "unit": "M(block x position)/s", "searches": n, "block": "%dx%d" % (bs, bs), "area": "%dx%d" % area,
+                     "ms": t * 1e3, "sad_ops_per_s": float(np.sum(d["block_width"].astype(np.int64) * d["block_height"])) * aw * ah / t}
+    return out

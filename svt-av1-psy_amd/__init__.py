@@ -60,6 +60,21 @@ PROTOTYPES = {
 }
 TX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16), (32, 64), (64, 32), (4, 16),
             (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]  # TxSize order of definitions.h
+
+
+def allowed_tx_types(tx_size):
+    """TxType values legal for a TxSize index: 64-point and 2:1/4:1 shapes touching 64 carry DCT_DCT only, 32-point shapes DCT_DCT and
+    IDTX (32x32 also V_DCT / H_DCT), everything else all 16 (is_txfm_allowed, test/TxfmCommon.h:160-209)."""
+    w, h = TX_SIZES[tx_size]
+    if (w, h) == (32, 32):
+        return [0, 9, 10, 11]
+    if (w, h) in ((32, 64), (64, 32), (16, 64), (64, 16)):
+        return [0]
+    if max(w, h) >= 32:
+        return [0, 9]
+    return list(range(16))
+
+
 FwdTxfmDesc = np.dtype([("in_off", "<u8"), ("in_stride", "<u4"), ("tx_type", "u1"), ("pad", "u1", (3,))])
 InvTxfmDesc = np.dtype([("coeff_off", "<u8"), ("pred_off", "<u8"), ("recon_off", "<u8"), ("pred_stride", "<u4"), ("recon_stride", "<u4"),
                         ("tx_type", "u1"), ("pad", "u1", (7,))])

@@ -15,7 +15,7 @@ namespace {
 
 constexpr int VERY_LARGE = 0x7f7f; // CDEF_VERY_LARGE (cdef.h:38)
 constexpr int VB = 3, HB = 8;      // CDEF_VBORDER / CDEF_HBORDER
-constexpr int CAND_CHUNK = 8;
+constexpr int CAND_CHUNK = 16;
 
 __device__ __forceinline__ int msb_u32(uint32_t n) { return 31 - __clz(n); }
 
@@ -140,11 +140,313 @@ __device__ __forceinline__ void quad_find_dir(const uint16_t* img, const int pit
     var      = (c - o) >> 10;
 }
 
+// ---- packed 16-bit arithmetic: two horizontally adjacent pixels per VGPR (v_pk_*_i16 / v_dot2_u32_u16) ----------------------
+// Everything in svt_cdef_filter_block_c fits int16: pixels <= 4095, CDEF_VERY_LARGE = 0x7f7f, |sum| <= 12 * 4 * 240, and the reference itself
+// accumulates `sum` in int16 (cdef.c:265).
+typedef short          s16x2 __attribute__((vector_size(4)));
+typedef unsigned short u16x2 __attribute__((vector_size(4)));
+typedef unsigned short us2e __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(2))) PairA2 { uint32_t v; };
+struct __attribute__((packed, aligned(2))) Row8A2 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) Row8A1 { uint32_t v[2]; };
+struct __attribute__((aligned(16))) Row8A16 { uint32_t v[4]; };
+
+__device__ __forceinline__ s16x2    as_pk(const uint32_t v) { s16x2 r; __builtin_memcpy(&r, &v, 4); return r; }
+__device__ __forceinline__ uint32_t as_u32(const s16x2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
+__device__ __forceinline__ s16x2    splat(const int v) { const short h = (short)v; return s16x2{h, h}; }
+__device__ __forceinline__ s16x2    pk_max(const s16x2 a, const s16x2 b) { return a > b ? a : b; }
+__device__ __forceinline__ s16x2    pk_min(const s16x2 a, const s16x2 b) { return a < b ? a : b; }
+__device__ __forceinline__ s16x2    pk_maxu(const s16x2 a, const s16x2 b) { const u16x2 x = (u16x2)a, y = (u16x2)b; return (s16x2)(x > y ? x : y); }
+__device__ __forceinline__ s16x2    ld_pair(const uint16_t* p) { return as_pk(((const PairA2*)p)->v); } // ds_read_b32 at any 2-byte address
+__device__ __forceinline__ uint32_t dot2(const uint32_t a, const uint32_t b, const uint32_t c) { // c + a.lo * b.lo + a.hi * b.hi
+    us2e x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    return __builtin_amdgcn_udot2(x, y, c, false);
+}
+// constrain() of cdef.c:85-91 on a pixel pair; threshold 0 yields 0 for any shift
+__device__ __forceinline__ s16x2 constrain2(const s16x2 diff, const s16x2 thr, const s16x2 shift) {
+    const s16x2 z  = {0, 0};
+    const s16x2 ad = pk_max(diff, z - diff);
+    const s16x2 v  = pk_min(ad, pk_max(thr - (ad >> shift), z));
+    const s16x2 sg = diff >> 15;
+    return (v ^ sg) - sg;
+}
+struct TapOffs { int p0, p1, a0, a1, b0, b1; }; // primary k = 0, 1; secondary (dir + 2) k = 0, 1; secondary (dir + 6) k = 0, 1
+__device__ __forceinline__ TapOffs tap_offs(const int dir, const int pitch) {
+    return TapOffs{dir_off(dir, 0, pitch), dir_off(dir, 1, pitch), dir_off(dir + 2, 0, pitch), dir_off(dir + 2, 1, pitch), dir_off(dir + 6, 0, pitch),
+                   dir_off(dir + 6, 1, pitch)};
+}
+// t[0..3] primary (k0+, k0-, k1+, k1-), t[4..7] secondary k = 0 (weight 2), t[8..11] secondary k = 1 (weight 1); min / max over all twelve and
+// the centre, CDEF_VERY_LARGE excluded from the max (cdef.c:277-301): adding 0x8081 maps it to 0 and real pixels to 0x8081.., compared unsigned
+__device__ __forceinline__ void load_taps(const uint16_t* p, const TapOffs& o, const s16x2 x, s16x2 (&t)[12], s16x2& mn, s16x2& mx) {
+    t[0] = ld_pair(p + o.p0); t[1] = ld_pair(p - o.p0); t[2] = ld_pair(p + o.p1); t[3] = ld_pair(p - o.p1);
+    t[4] = ld_pair(p + o.a0); t[5] = ld_pair(p - o.a0); t[6] = ld_pair(p + o.b0); t[7] = ld_pair(p - o.b0);
+    t[8] = ld_pair(p + o.a1); t[9] = ld_pair(p - o.a1); t[10] = ld_pair(p + o.b1); t[11] = ld_pair(p - o.b1);
+    const s16x2 bias = splat(0x8081 - 0x10000);
+    s16x2 mxb = x + bias;
+    mn = x;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        mn  = pk_min(mn, t[k]);
+        mxb = pk_maxu(mxb, t[k] + bias);
+    }
+    mx = mxb - bias;
+}
+__device__ __forceinline__ s16x2 pri_sum(const s16x2 x, const s16x2 (&t)[12], const s16x2 thr, const s16x2 sh, const s16x2 w0, const s16x2 w1) {
+    return w0 * (constrain2(t[0] - x, thr, sh) + constrain2(t[1] - x, thr, sh)) + w1 * (constrain2(t[2] - x, thr, sh) + constrain2(t[3] - x, thr, sh));
+}
+__device__ __forceinline__ s16x2 sec_sum(const s16x2 x, const s16x2 (&t)[12], const s16x2 thr, const s16x2 sh) {
+    const s16x2 k0 = constrain2(t[4] - x, thr, sh) + constrain2(t[5] - x, thr, sh) + constrain2(t[6] - x, thr, sh) + constrain2(t[7] - x, thr, sh);
+    const s16x2 k1 = constrain2(t[8] - x, thr, sh) + constrain2(t[9] - x, thr, sh) + constrain2(t[10] - x, thr, sh) + constrain2(t[11] - x, thr, sh);
+    return k0 + k0 + k1;
+}
+__device__ __forceinline__ s16x2 finish_px(const s16x2 x, const s16x2 sum, const s16x2 mn, const s16x2 mx) { // cdef.c:302-303
+    const s16x2 y = x + ((sum + splat(8) + (sum >> 15)) >> 4);
+    return pk_min(pk_max(y, mn), mx);
+}
+
+// Stage rows x (8 * cpr) pixels as u16 into LDS (pitch = 8 * cpr): pixels inside [ys, ye) x [xs, xe) come from the plane, the rest is `fill`.
+// A thread owns 8-pixel chunks; chunks that lie fully inside are fetched with one vector load each, all issued before the first LDS store.
+template <typename PIX, int NIT>
+__device__ __forceinline__ void stage_tile(uint16_t* lds, const int rows, const int cpr, const PIX* plane, const size_t stride, const int gy0, const int gx0,
+                                           const int ys, const int ye, const int xs, const int xe, const int fill, const int tid) {
+    uint32_t  v[NIT][4];
+    const int total = rows * cpr;
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int  i = tid + 256 * k, r = i / cpr, c = i - r * cpr;
+        const int  gy = gy0 + r, gx = gx0 + 8 * c;
+        const bool full = i < total && gy >= ys && gy < ye && gx >= xs && gx + 8 <= xe;
+        const PIX* src = plane + (full ? (size_t)gy * stride + gx : (size_t)ys * stride + xs);
+        if (sizeof(PIX) == 2) {
+            const Row8A2 t = *(const Row8A2*)src;
+            v[k][0] = t.v[0]; v[k][1] = t.v[1]; v[k][2] = t.v[2]; v[k][3] = t.v[3];
+        } else {
+            const Row8A1 t = *(const Row8A1*)src;
+            v[k][0] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c010c00u); v[k][1] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c030c02u);
+            v[k][2] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c010c00u); v[k][3] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c030c02u);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int i = tid + 256 * k, r = i / cpr, c = i - r * cpr;
+        if (i >= total) continue;
+        const int  gy = gy0 + r, gx = gx0 + 8 * c;
+        const bool rowok = gy >= ys && gy < ye;
+        if (!(rowok && gx >= xs && gx + 8 <= xe)) { // frame / filter-block border: pixel-exact
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int  xa = gx + 2 * e, xb = xa + 1;
+                const uint32_t lo = (rowok && xa >= xs && xa < xe) ? (uint32_t)plane[(size_t)gy * stride + xa] : (uint32_t)fill;
+                const uint32_t hi = (rowok && xb >= xs && xb < xe) ? (uint32_t)plane[(size_t)gy * stride + xb] : (uint32_t)fill;
+                v[k][e] = lo | (hi << 16);
+            }
+        }
+        *(Row8A16*)(lds + (size_t)i * 8) = Row8A16{{v[k][0], v[k][1], v[k][2], v[k][3]}};
+    }
+}
+
+// 8x8 direction search on registers: px[i][j] = pixel pair (2j, 2j+1) of row i, already (>> coeff_shift) - 128 (svt_aom_cdef_find_dir_c, cdef.c:150-199)
+template <int D> __device__ __forceinline__ int dir_cost_regs(const s16x2 (&px)[8][4]) {
+    int partial[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) partial[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int x   = (int)px[i][j >> 1][j & 1];
+            const int idx = D == 0 ? i + j : D == 1 ? i + j / 2 : D == 2 ? i : D == 3 ? 3 + i - j / 2 : D == 4 ? 7 + i - j : D == 5 ? 3 - i / 2 + j : D == 6 ? j : i / 2 + j;
+            partial[idx] += x;
+        }
+    int cost = 0;
+    if (D == 2 || D == 6) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) cost += partial[i] * partial[i];
+        cost *= 105;
+    } else if (D == 0 || D == 4) {
+        constexpr int div[8] = {840, 420, 280, 210, 168, 140, 120, 105};
+#pragma unroll
+        for (int i = 0; i < 7; i++) cost += (partial[i] * partial[i] + partial[14 - i] * partial[14 - i]) * div[i];
+        cost += partial[7] * partial[7] * 105;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; j++) cost += partial[3 + j] * partial[3 + j];
+        cost *= 105;
+        constexpr int div2[3] = {420, 210, 140};
+#pragma unroll
+        for (int j = 0; j < 3; j++) cost += (partial[j] * partial[j] + partial[10 - j] * partial[10 - j]) * div2[j];
+    }
+    return cost;
+}
+// same contract as quad_find_dir, the unit is read with eight 16-byte LDS loads (img 16-byte aligned, pitch a multiple of 8)
+__device__ __forceinline__ void quad_find_dir_tile(const uint16_t* img, const int pitch, const int coeff_shift, const int q, int& best_dir, int& var) {
+    s16x2 px[8][4];
+    const s16x2 csv = splat(coeff_shift), c128 = splat(128);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const Row8A16 r = *(const Row8A16*)(img + i * pitch);
+#pragma unroll
+        for (int j = 0; j < 4; j++) px[i][j] = (as_pk(r.v[j]) >> csv) - c128;
+    }
+    int a, b;
+    if (q == 0) { a = dir_cost_regs<0>(px); b = dir_cost_regs<4>(px); }
+    else if (q == 1) { a = dir_cost_regs<1>(px); b = dir_cost_regs<5>(px); }
+    else if (q == 2) { a = dir_cost_regs<2>(px); b = dir_cost_regs<6>(px); }
+    else { a = dir_cost_regs<3>(px); b = dir_cost_regs<7>(px); }
+    int c = a, d = q, o = b;
+    if (b > a) { c = b; d = q + 4; o = a; }
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
+        const int c2 = __shfl_xor(c, m), d2 = __shfl_xor(d, m), o2 = __shfl_xor(o, m);
+        if (c2 > c || (c2 == c && d2 < d)) { c = c2; d = d2; o = o2; }
+    }
+    best_dir = d;
+    var      = (c - o) >> 10;
+}
+__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); // quad_perm [2,3,0,1]
+    return v;
+}
+
+typedef uint32_t acc16 __attribute__((vector_size(64)));
+
+// Per-lane geometry and strength context of the filter passes
+struct LaneCtx {
+    const uint16_t* in;  // tile origin (pixel 0,0 of the filter block), u16, pitch `pitch`
+    const uint16_t* org; // search mode: source block, pitch bw
+    int pitch, bw, by, bx, uw, uh, q, sub, cs, pdamp, sdamp, vm;
+};
+__device__ __forceinline__ s16x2 pri_sum_level(const LaneCtx& L, const int lvl, const s16x2 x, const s16x2 (&t)[12]) {
+    const int t_  = ((lvl << L.cs) * L.vm + 8) >> 4; // adjust_strength (cdef.c:130-134); lane-varying for luma, identity for chroma (vm = 16)
+    int       sh  = L.pdamp - msb_u32((uint32_t)t_);
+    sh            = sh < 0 ? 0 : sh;
+    const int odd = (t_ >> L.cs) & 1; // svt_aom_eb_cdef_pri_taps (cdef.c:249)
+    return pri_sum(x, t, splat(t_), splat(sh), splat(4 - odd), splat(2 + odd));
+}
+__device__ __forceinline__ s16x2 sec_sum_strength(const LaneCtx& L, const int sec, const s16x2 x, const s16x2 (&t)[12]) {
+    const int st = sec << L.cs;
+    int       sh = L.sdamp - msb_u32((uint32_t)st);
+    sh           = sh < 0 ? 0 : sh;
+    return sec_sum(x, t, splat(st), splat(sh));
+}
+
+// Search: one pass over the lane's pixel pairs for a static grid of NP primary levels (lv[], uniform) x the four secondary strengths
+// {0,1,2,4}; NP = 0 is the pass for primary level 0, which the reference filters with dir = 0 (cdef.c:411).  Pixel-pair-major: the twelve
+// taps are read from LDS once per pair, the three secondary sums and the NP primary sums are evaluated once, and each of the grid's cells only
+// adds, rounds, clamps and updates its three running sums (sum s, sum s^2, sum s*d).  Nothing filtered is written.
+template <int NP>
+__device__ __forceinline__ void search_pass(const LaneCtx& L, const TapOffs& o, const int (&lv)[4], const bool acc_src,
+                                            acc16& a_s, acc16& a_s2, acc16& a_sd, uint32_t& d_s, uint32_t& d_s2) {
+    const int rows = L.uh >> 2; // rows per lane: 2 (8-row unit) or 1 (4-row unit)
+    for (int rr = 0; rr < rows; rr++) {
+        const int r = L.uh == 8 ? 2 * L.q + rr : L.q;
+        if ((r & (L.sub - 1)) != 0) continue;
+        const uint16_t* row  = L.in + (L.by * L.uh + r) * L.pitch + L.bx * L.uw;
+        const uint16_t* orow = L.org + (L.by * L.uh + r) * L.bw + L.bx * L.uw;
+        for (int j = 0; j < (L.uw >> 1); j++) {
+            const uint16_t* p = row + 2 * j;
+            const s16x2     x = ld_pair(p);
+            s16x2 t[12], mn, mx, S[4];
+            load_taps(p, o, x, t, mn, mx);
+            S[0] = splat(0);
+            S[1] = sec_sum_strength(L, 1, x, t);
+            S[2] = sec_sum_strength(L, 2, x, t);
+            S[3] = sec_sum_strength(L, 4, x, t);
+            const uint32_t dpair = as_u32(ld_pair(orow + 2 * j));
+            if (acc_src) {
+                d_s += dpair; // u16 halves: at most 8 pixels of 4095 each per half
+                d_s2 = dot2(dpair, dpair, d_s2);
+            }
+#pragma unroll
+            for (int pi = 0; pi < (NP ? NP : 1); pi++) {
+                const s16x2 Pv = NP ? pri_sum_level(L, lv[pi], x, t) : splat(0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t yu = as_u32(finish_px(x, Pv + S[k], mn, mx));
+                    const int      c  = 4 * pi + k;
+                    a_s[c] += yu;
+                    a_s2[c] = dot2(yu, yu, a_s2[c]);
+                    a_sd[c] = dot2(yu, dpair, a_sd[c]);
+                }
+            }
+        }
+    }
+}
+// quad totals in every lane, then lane q evaluates cells q, q + 4, ... (the double-precision distortion is the long pole) and adds them to
+// the block's per-cell totals cells[0 .. 4 * NG)
+template <int NG>
+__device__ __forceinline__ void search_reduce(acc16& a_s, acc16& a_s2, acc16& a_sd, const uint32_t d_s, const uint32_t d_s2,
+                                              const int q, const bool act, const bool weighted, const int cs, unsigned long long* cells) {
+    const unsigned long long sd = quad_sum((d_s & 0xffffu) + (d_s >> 16)), sd2 = quad_sum(d_s2);
+#pragma unroll
+    for (int c = 0; c < 4 * NG; c++) {
+        a_s[c]  = quad_sum((a_s[c] & 0xffffu) + (a_s[c] >> 16));
+        a_s2[c] = quad_sum(a_s2[c]);
+        a_sd[c] = quad_sum(a_sd[c]);
+    }
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const unsigned long long ss  = q == 0 ? a_s[4 * k] : q == 1 ? a_s[4 * k + 1] : q == 2 ? a_s[4 * k + 2] : a_s[4 * k + 3];
+        const unsigned long long ss2 = q == 0 ? a_s2[4 * k] : q == 1 ? a_s2[4 * k + 1] : q == 2 ? a_s2[4 * k + 2] : a_s2[4 * k + 3];
+        const unsigned long long ssd = q == 0 ? a_sd[4 * k] : q == 1 ? a_sd[4 * k + 1] : q == 2 ? a_sd[4 * k + 2] : a_sd[4 * k + 3];
+        if (act) {
+            unsigned long long dist = sd2 + ss2 - 2 * ssd; // = sum (d - s)^2
+            if (weighted) { // dist_8xn_*_c, enc_cdef.c:23-48: IEEE double, no contraction (-ffp-contract=off)
+                const unsigned long long svar = ss2 - ((ss * ss + 32) >> 6), dvar = sd2 - ((sd * sd + 32) >> 6);
+                const double num = (double)(sd2 + ss2 - 2 * ssd) * .5 * (double)(svar + dvar + (unsigned long long)(400 << 2 * cs));
+                const double den = sqrt((double)(20000 << 4 * cs) + (double)svar * (double)dvar);
+                dist = (unsigned long long)floor(.5 + num / den);
+            }
+            atomicAdd(&cells[4 * k + q], dist);
+        }
+    }
+}
+// Apply: the block's own (level, secondary strength); a lane writes whole rows (16 / 8 bytes) of its unit
+template <typename PIX>
+__device__ __forceinline__ void apply_pass(const LaneCtx& L, const TapOffs& o, const int lvl, const int sec, PIX* out, const size_t out_stride,
+                                           const int fbr, const int fbc) {
+    const int rows = L.uh >> 2;
+    for (int rr = 0; rr < rows; rr++) {
+        const int       r   = L.uh == 8 ? 2 * L.q + rr : L.q;
+        const uint16_t* row = L.in + (L.by * L.uh + r) * L.pitch + L.bx * L.uw;
+        uint32_t        yrow[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j < (L.uw >> 1)) {
+                const uint16_t* p = row + 2 * j;
+                const s16x2     x = ld_pair(p);
+                s16x2 t[12], mn, mx, sum = splat(0);
+                load_taps(p, o, x, t, mn, mx);
+                if (lvl) sum = pri_sum_level(L, lvl, x, t);
+                if (sec) sum = sum + sec_sum_strength(L, sec, x, t);
+                yrow[j] = as_u32(finish_px(x, sum, mn, mx));
+            }
+        }
+        const size_t gy = (size_t)(fbr * (L.uh * 8) + L.by * L.uh + r);
+        const int    gx = fbc * L.bw + L.bx * L.uw;
+        PIX*         op = out + gy * out_stride + gx;
+        if (sizeof(PIX) == 2) {
+            if (L.uw == 8) *(Row8A2*)op = Row8A2{{yrow[0], yrow[1], yrow[2], yrow[3]}};
+            else *(Row8A1*)op = Row8A1{{yrow[0], yrow[1]}};
+        } else {
+            const uint32_t w0 = __builtin_amdgcn_perm(yrow[1], yrow[0], 0x06040200u);
+            if (L.uw == 8) *(Row8A1*)op = Row8A1{{w0, __builtin_amdgcn_perm(yrow[3], yrow[2], 0x06040200u)}};
+            else *(PairA2*)op = PairA2{w0};
+        }
+    }
+}
+
+// One workgroup = one 64x64 filter block (apply) or one filter block x one group of four primary levels (search: blockIdx.y = g takes the
+// 4g-th .. (4g+3)-th distinct non-zero primary levels of the candidate list, each against all four secondary strengths; g = 0 also takes
+// primary level 0).  A quad owns an 8x8 (4x4 / 4x8 / 8x4 for subsampled chroma) unit; a lane filters uh / 4 rows, two pixels per packed op.
 template <typename PIX, int MODE>
-__global__ __launch_bounds__(256) void cdef_frame_kernel(const SvtHipCdefParams P) {
+__global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefParams P) {
     HIP_DYNAMIC_SHARED(uint16_t, tile_raw)
-    __shared__ int                sh_dir[64], sh_var[64], sh_active[64], sh_count;
-    __shared__ unsigned long long sh_mse[CAND_CHUNK];
+    __shared__ int                sh_any;
+    __shared__ unsigned long long sh_cells[20]; // [4 levels][4 secondary] + [level 0][4 secondary]
     const int tid = threadIdx.x;
     const int xdec = P.xdec, ydec = P.ydec, pli = P.pli, cs = P.coeff_shift;
     const int bw = 64 >> xdec, bh = 64 >> ydec, uw = 8 >> xdec, uh = 8 >> ydec;
@@ -152,117 +454,106 @@ __global__ __launch_bounds__(256) void cdef_frame_kernel(const SvtHipCdefParams 
     const int nhfb = (pw + bw - 1) / bw, nvfb = (ph + bh - 1) / bh;
     const int fb = blockIdx.x, fbr = fb / nhfb, fbc = fb % nhfb;
     const int pitch = bw + 2 * HB;
-    uint16_t* in = tile_raw + VB * pitch + HB;
-    const int c0 = blockIdx.y * CAND_CHUNK;
-    const int c1 = MODE == 1 ? ((c0 + CAND_CHUNK) < (int)P.ncand ? (c0 + CAND_CHUNK) : (int)P.ncand) : 1;
+    const int g = blockIdx.y, ncand = MODE == 1 ? (int)P.ncand : 0;
 
-    if (tid == 0) sh_count = 0;
-    if (tid < CAND_CHUNK) sh_mse[tid] = 0;
-    __syncthreads();
-    if (tid < 64) {
-        const int by = tid >> 3, bx = tid & 7;
-        const bool inside = (fbc * 8 + bx) * uw < pw && (fbr * 8 + by) * uh < ph;
-        const int  act    = inside && !P.skip[(size_t)(fbr * 8 + by) * (nhfb * 8) + fbc * 8 + bx];
-        sh_active[tid]    = act;
-        if (act) atomicAdd(&sh_count, 1);
+    // search: which primary levels does this group own?  (uniform; the list has at most 64 entries)
+    int  lv[4] = {0, 0, 0, 0}, nlv = 0;
+    bool do0 = false;
+    if (MODE == 1) {
+        uint32_t levels = 0;
+        for (int c = 0; c < ncand; c++) levels |= 1u << (P.pri[c] & 15);
+        do0 = (levels & 1u) && g == 0;
+        levels &= ~1u;
+        for (int k = 0; k < 4 * g && levels; k++) levels &= levels - 1; // drop the levels of the groups before this one
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (levels) { lv[k] = __builtin_ctz(levels); levels &= levels - 1; nlv = k + 1; }
+        if (nlv == 0 && !do0 && g != 0) return;
     }
+
+    const int b = tid >> 2, q = tid & 3, by = b >> 3, bx = b & 7;
+    const bool inside = (fbc * 8 + bx) * uw < pw && (fbr * 8 + by) * uh < ph;
+    const int  act    = inside && !P.skip[(size_t)(fbr * 8 + by) * (nhfb * 8) + fbc * 8 + bx];
+    if (tid == 0) sh_any = 0;
+    if (tid < 20) sh_cells[tid] = 0;
     __syncthreads();
-    if (sh_count == 0) {
-        if (MODE == 1)
-            for (int c = c0 + tid; c < c1; c += 256) P.mse[(size_t)fb * P.ncand + c] = 0;
+    if (act) sh_any = 1;
+    __syncthreads();
+    if (sh_any == 0) {
+        if (MODE == 1 && g == 0)
+            for (int c = tid; c < ncand; c += 256) P.mse[(size_t)fb * P.ncand + c] = 0;
         return;
     }
-    {   // stage the tile (cdef_process.c:208-228): real pixels where the neighbouring filter block exists, else VERY_LARGE
-        const PIX* plane = (const PIX*)P.recon;
+    {   // stage the tile (cdef_process.c:208-228): real pixels where the neighbouring filter block exists, else CDEF_VERY_LARGE
         const int x0 = fbc * bw, y0 = fbr * bh;
         const int xs = x0 - (fbc != 0 ? HB : 0), ys = y0 - (fbr != 0 ? VB : 0);
-        int       xe = (x0 + bw < pw ? x0 + bw : pw) + (fbc + 1 < nhfb ? HB : 0);
-        int       ye = (y0 + bh < ph ? y0 + bh : ph) + (fbr + 1 < nvfb ? VB : 0);
-        const int total = (bh + 2 * VB) * pitch;
-        for (int i = tid; i < total; i += 256) {
-            const int r = i / pitch, c = i - r * pitch;
-            const int gy = y0 - VB + r, gx = x0 - HB + c;
-            const bool ok = gx >= xs && gx < xe && gy >= ys && gy < ye;
-            tile_raw[i]   = ok ? (uint16_t)plane[(size_t)gy * P.recon_stride + gx] : (uint16_t)VERY_LARGE;
-        }
+        const int xe = (x0 + bw < pw ? x0 + bw : pw) + (fbc + 1 < nhfb ? HB : 0);
+        const int ye = (y0 + bh < ph ? y0 + bh : ph) + (fbr + 1 < nvfb ? VB : 0);
+        stage_tile<PIX, 3>(tile_raw, bh + 2 * VB, pitch >> 3, (const PIX*)P.recon, P.recon_stride, y0 - VB, x0 - HB, ys, ye, xs, xe, VERY_LARGE, tid);
+        if (MODE == 1)
+            stage_tile<PIX, 2>(tile_raw + (bh + 2 * VB) * pitch, bh, bw >> 3, (const PIX*)P.source, P.source_stride, y0, x0, y0,
+                               y0 + bh < ph ? y0 + bh : ph, x0, x0 + bw < pw ? x0 + bw : pw, 0, tid);
     }
     __syncthreads();
-    const int b = tid >> 2, q = tid & 3, by = b >> 3, bx = b & 7;
-    const int act = sh_active[b];
+    LaneCtx L;
+    L.in  = tile_raw + VB * pitch + HB;
+    L.org = tile_raw + (bh + 2 * VB) * pitch; // search mode: the source block, pitch bw
+    int dir = 0, var = 0;
     if (pli == 0) {
-        int d = 0, v = 0;
-        // a whole quad is either active or not, so the quad shuffles inside are convergent per quad; inactive quads
-        // still execute them (results unused) to keep the wave convergent
-        quad_find_dir(in + (by * 8) * pitch + bx * 8, pitch, cs, q, d, v);
-        if (q == 0) {
-            sh_dir[b] = act ? d : 0;
-            sh_var[b] = act ? v : 0;
-            if (blockIdx.y == 0) { P.dir[(size_t)fb * 64 + b] = (uint8_t)(act ? d : 0); P.var[(size_t)fb * 64 + b] = act ? v : 0; }
-        }
-    } else if (q == 0) {
-        int d = P.dir[(size_t)fb * 64 + b];
-        if (xdec != ydec) { // cdef.c:388-395
-            const int conv422[8] = {7, 0, 2, 4, 5, 6, 6, 6}, conv440[8] = {1, 2, 2, 2, 3, 4, 6, 0};
-            d = xdec ? conv422[d & 7] : conv440[d & 7];
-        }
-        sh_dir[b] = d;
-        sh_var[b] = P.var[(size_t)fb * 64 + b];
+        // a whole quad is either active or not; inactive quads run the search too (results unused) so the quad shuffles stay convergent
+        quad_find_dir_tile(L.in + (by * 8) * pitch + bx * 8, pitch, cs, q, dir, var);
+        if (!act) { dir = 0; var = 0; }
+        if (q == 0 && g == 0) { P.dir[(size_t)fb * 64 + b] = (uint8_t)dir; P.var[(size_t)fb * 64 + b] = var; }
+    } else {
+        dir = P.dir[(size_t)fb * 64 + b] & 7;
+        if (xdec != ydec) // cdef.c:388-395: conv422 = {7,0,2,4,5,6,6,6}, conv440 = {1,2,2,2,3,4,6,0}, one nibble per direction
+            dir = (int)(((xdec ? 0x66654207u : 0x06432221u) >> (4 * dir)) & 7u);
+        var = P.var[(size_t)fb * 64 + b];
+    }
+    L.pitch = pitch; L.bw = bw; L.by = by; L.bx = bx; L.uw = uw; L.uh = uh; L.q = q; L.cs = cs;
+    L.sub   = MODE == 1 ? P.subsampling : 1;
+    L.pdamp = P.pri_damping + cs - (pli != 0);
+    L.sdamp = P.sec_damping + cs - (pli != 0);
+    // adjust_strength (cdef.c:130-134) = (strength * vm + 8) >> 4 with vm = var ? 4 + min(msb(var >> 6), 12) : 0; chroma: vm = 16 (identity)
+    L.vm = 16;
+    if (pli == 0) {
+        const int v6 = var >> 6;
+        int       i  = v6 ? msb_u32((uint32_t)v6) : 0;
+        i            = i > 12 ? 12 : i;
+        L.vm         = var ? 4 + i : 0;
+    }
+    if (MODE == 0) {
+        const int lvl = P.pri[fb], sec = P.sec[fb];
+        if (lvl == 0 && sec == 0) return; // zero strength leaves the block unchanged (enc_cdef.c:571); dir / var are still reported
+        if (act) apply_pass<PIX>(L, tap_offs(lvl ? dir : 0, pitch), lvl, sec, (PIX*)P.out, P.out_stride, fbr, fbc);
+        return;
+    }
+    const bool weighted = pli == 0 && uw == 8 && uh == 8;
+    acc16    a_s, a_s2, a_sd; // vector values, not arrays: they must never become stack objects
+    uint32_t d_s = 0, d_s2 = 0;
+    if (nlv) {
+        a_s = a_s2 = a_sd = acc16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (act) search_pass<4>(L, tap_offs(dir, pitch), lv, true, a_s, a_s2, a_sd, d_s, d_s2);
+        search_reduce<4>(a_s, a_s2, a_sd, d_s, d_s2, q, act, weighted, cs, sh_cells);
+    }
+    if (do0) {
+        a_s = a_s2 = a_sd = acc16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const bool again = nlv != 0; // the source sums are already there
+        if (act) search_pass<0>(L, tap_offs(0, pitch), lv, !again, a_s, a_s2, a_sd, d_s, d_s2);
+        search_reduce<1>(a_s, a_s2, a_sd, d_s, d_s2, q, act, weighted, cs, sh_cells + 16);
     }
     __syncthreads();
-    const int sub = MODE == 1 ? P.subsampling : 1;
-    for (int c = c0; c < c1; c++) {
-        const int level = MODE == 1 ? P.pri[c] : P.pri[fb];
-        const int secl  = MODE == 1 ? P.sec[c] : P.sec[fb];
-        if (MODE == 0 && level == 0 && secl == 0) break; // zero strength leaves the block unchanged (enc_cdef.c:571)
-        const int pri_strength = level << cs, sec_strength = secl << cs;
-        const int pdamp = P.pri_damping + cs - (pli != 0), sdamp = P.sec_damping + cs - (pli != 0);
-        const int t = pli ? pri_strength : adjust_strength(pri_strength, sh_var[b]);
-        const FilterCtx ctx = make_ctx(t, sec_strength, pri_strength ? sh_dir[b] : 0, pdamp, sdamp, cs, pitch);
-        unsigned long long ss = 0, sd = 0, ss2 = 0, sd2 = 0, ssd = 0, mse = 0;
-        if (act) {
-            const int rows = uh >> 2; // rows per lane: 2 (8-row unit) or 1 (4-row unit)
-            for (int rr = 0; rr < rows; rr++) {
-                const int r = uh == 8 ? 2 * q + rr : q;
-                if (r >= uh || (r % sub) != 0) continue;
-                const uint16_t* row = in + (by * uh + r) * pitch + bx * uw;
-                const size_t    gy  = (size_t)(fbr * bh + by * uh + r);
-                const int       gx  = fbc * bw + bx * uw;
-                for (int j = 0; j < uw; j++) {
-                    const int y = filter_px(row + j, ctx);
-                    if (MODE == 0) {
-                        ((PIX*)P.out)[gy * P.out_stride + gx + j] = (PIX)y;
-                    } else {
-                        const unsigned dpx = ((const PIX*)P.source)[gy * P.source_stride + gx + j], s = (unsigned)y;
-                        ss += s; sd += dpx; ss2 += s * s; sd2 += dpx * dpx; ssd += s * dpx;
-                        const int e = (int)dpx - (int)s;
-                        mse += (unsigned long long)(long long)(e * e);
-                    }
-                }
-            }
-        }
-        if (MODE == 1) {
-            // reduce the five sums over the quad (values < 2^32: 64 * 4095^2), then one lane evaluates the block distortion
+    for (int c = tid; c < ncand; c += 256) { // every candidate is reported by exactly one group
+        const int lvl = P.pri[c] & 15, sec = P.sec[c];
+        const int k   = sec == 0 ? 0 : sec == 1 ? 1 : sec == 2 ? 2 : 3;
+        int cell = -1;
+        if (lvl == 0) { if (g == 0) cell = 16 + k; }
+        else {
 #pragma unroll
-            for (int m = 1; m <= 2; m <<= 1) {
-                ss += (unsigned)__shfl_xor((int)(unsigned)ss, m); sd += (unsigned)__shfl_xor((int)(unsigned)sd, m);
-                ss2 += (unsigned)__shfl_xor((int)(unsigned)ss2, m); sd2 += (unsigned)__shfl_xor((int)(unsigned)sd2, m);
-                ssd += (unsigned)__shfl_xor((int)(unsigned)ssd, m); mse += (unsigned)__shfl_xor((int)(unsigned)mse, m);
-            }
-            if (act && q == 0) {
-                unsigned long long dist = mse;
-                if (pli == 0 && uw == 8 && uh == 8) { // dist_8xn_*_c, enc_cdef.c:23-48: IEEE double, no contraction (-ffp-contract=off)
-                    const unsigned long long svar = ss2 - ((ss * ss + 32) >> 6), dvar = sd2 - ((sd * sd + 32) >> 6);
-                    const double num = (double)(sd2 + ss2 - 2 * ssd) * .5 * (double)(svar + dvar + (unsigned long long)(400 << 2 * cs));
-                    const double den = sqrt((double)(20000 << 4 * cs) + (double)svar * (double)dvar);
-                    dist = (unsigned long long)floor(.5 + num / den);
-                }
-                atomicAdd(&sh_mse[c - c0], dist);
-            }
+            for (int pi = 0; pi < 4; pi++)
+                if (pi < nlv && lv[pi] == lvl) cell = 4 * pi + k;
         }
-    }
-    if (MODE == 1) {
-        __syncthreads();
-        if (tid < c1 - c0) P.mse[(size_t)fb * P.ncand + c0 + tid] = sh_mse[tid] >> (2 * cs);
+        if (cell >= 0) P.mse[(size_t)fb * P.ncand + c] = sh_cells[cell] >> (2 * cs);
     }
 }
 
@@ -316,8 +607,8 @@ __global__ void copy_rect8_to_16_kernel(uint16_t* dst, const uint8_t* src, int n
 template <int MODE> void launch_frame(const SvtHipCdefParams& P, hipStream_t st) {
     const int bw = 64 >> P.xdec, bh = 64 >> P.ydec;
     const int nhfb = ((int)P.width + bw - 1) / bw, nvfb = ((int)P.height + bh - 1) / bh;
-    const size_t shmem = (size_t)(bh + 2 * VB) * (bw + 2 * HB) * 2 + 64;
-    const dim3 grid(nhfb * nvfb, MODE == 1 ? (P.ncand + CAND_CHUNK - 1) / CAND_CHUNK : 1);
+    const size_t shmem = (size_t)((bh + 2 * VB) * (bw + 2 * HB) + (MODE == 1 ? bh * bw : 0)) * 2 + 64;
+    const dim3 grid(nhfb * nvfb, MODE == 1 ? 4 : 1); // search: four groups of four primary levels
     if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE>), grid, dim3(256), shmem, st, P);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE>), grid, dim3(256), shmem, st, P);
     SVT_LAUNCH_CHECK();

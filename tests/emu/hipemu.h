@@ -358,6 +358,12 @@ inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh)
     unsigned long long v = ((unsigned long long)hi << 32) | lo;
     return (unsigned)(v >> (sh & 31));
 }
+// clang's ext_vector_type is only used for the <2 x u16> operands of v_dot2_u32_u16; g++ spells the same 4-byte vector vector_size(4)
+#define ext_vector_type(N) vector_size((N) * 2)
+typedef unsigned short hipemu_us2 __attribute__((vector_size(4)));
+inline unsigned __builtin_amdgcn_udot2(hipemu_us2 a, hipemu_us2 b, unsigned c, bool) {
+    return c + (unsigned)a[0] * (unsigned)b[0] + (unsigned)a[1] * (unsigned)b[1];
+}
 inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned sel) {
     unsigned long long v = ((unsigned long long)a << 32) | b;
     unsigned           r = 0;

@@ -65,9 +65,9 @@ def test_cdef_frame_apply_and_search(be, oracle, bd):
         cands = [(pr, sc) for pr in range(16) for sc in (0, 1, 2, 4)] if be.is_gpu else [(0, 0), (4, 2), (15, 4), (1, 0), (0, 1), (7, 1), (9, 0), (2, 4), (5, 2)]
         pri, sec = np.array([c[0] for c in cands], np.int32), np.array([c[1] for c in cands], np.int32)
         d, v = run_frame(be, oracle, 1, luma, src_l, 0, 0, 0, bd, skip, pri, sec, dir0, var0, sub=2 if skip_frac else 1)
-        # apply: per-block strengths, fixed (4, 2) with some zero-strength blocks
+        # apply: per-block strengths, (4, 2) with some zero-strength and some secondary-only blocks
         apri = np.where(g.random(nfb) < 0.2, 0, 4).astype(np.int32)
-        asec = np.where(apri == 0, 0, 2).astype(np.int32)
+        asec = np.where(apri == 0, (g.random(nfb) < 0.5) * 1, 2).astype(np.int32)  # level 0 with a secondary strength filters along dir 0
         run_frame(be, oracle, 0, luma, src_l, 0, 0, 0, bd, skip, apri, asec, dir0, var0)
         # chroma 4:2:0 uses the luma directions
         cw, ch = W // 2, H // 2
