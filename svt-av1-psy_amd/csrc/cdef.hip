@@ -150,6 +150,7 @@ struct __attribute__((packed, aligned(2))) PairA2 { uint32_t v; };
 struct __attribute__((packed, aligned(2))) Row8A2 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(1))) Row8A1 { uint32_t v[2]; };
 struct __attribute__((aligned(16))) Row8A16 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) U16A1 { uint16_t v; };
 
 __device__ __forceinline__ s16x2    as_pk(const uint32_t v) { s16x2 r; __builtin_memcpy(&r, &v, 4); return r; }
 __device__ __forceinline__ uint32_t as_u32(const s16x2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
@@ -157,41 +158,59 @@ __device__ __forceinline__ s16x2    splat(const int v) { const short h = (short)
 __device__ __forceinline__ s16x2    pk_max(const s16x2 a, const s16x2 b) { return a > b ? a : b; }
 __device__ __forceinline__ s16x2    pk_min(const s16x2 a, const s16x2 b) { return a < b ? a : b; }
 __device__ __forceinline__ s16x2    pk_maxu(const s16x2 a, const s16x2 b) { const u16x2 x = (u16x2)a, y = (u16x2)b; return (s16x2)(x > y ? x : y); }
-__device__ __forceinline__ s16x2    ld_pair(const uint16_t* p) { return as_pk(((const PairA2*)p)->v); } // ds_read_b32 at any 2-byte address
+struct __attribute__((aligned(4))) DwPairA4 { uint32_t lo, hi; };
+// pixel pair at an even pixel offset of the tile: one aligned ds_read_b32
+__device__ __forceinline__ s16x2 ld_pair_even(const uint16_t* p) { return as_pk(*(const uint32_t*)p); }
+// A pixel pair at an odd pixel offset is fetched as the two dwords around it (one ds_read2_b32) plus a funnel shift (load_taps): a dword-misaligned
+// ds_read_b32 is legal but costs ~45 LDS cycles per wave instruction on gfx950 (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS, profiles/r01_call6_cdef_lds.txt).
 __device__ __forceinline__ uint32_t dot2(const uint32_t a, const uint32_t b, const uint32_t c) { // c + a.lo * b.lo + a.hi * b.hi
     us2e x, y;
     __builtin_memcpy(&x, &a, 4);
     __builtin_memcpy(&y, &b, 4);
     return __builtin_amdgcn_udot2(x, y, c, false);
 }
-// constrain() of cdef.c:85-91 on a pixel pair; threshold 0 yields 0 for any shift
+// constrain() of cdef.c:85-91 on a pixel pair = clamp(diff, -m, m) with m = max(0, threshold - (|diff| >> shift)), one saturating
+// v_pk_sub_u16 for the max(0, .); threshold 0 yields 0 for any shift
 __device__ __forceinline__ s16x2 constrain2(const s16x2 diff, const s16x2 thr, const s16x2 shift) {
     const s16x2 z  = {0, 0};
     const s16x2 ad = pk_max(diff, z - diff);
-    const s16x2 v  = pk_min(ad, pk_max(thr - (ad >> shift), z));
-    const s16x2 sg = diff >> 15;
-    return (v ^ sg) - sg;
+    const s16x2 m  = (s16x2)__builtin_elementwise_sub_sat((u16x2)thr, (u16x2)(ad >> shift));
+    return pk_max(pk_min(diff, m), z - m);
 }
-struct TapOffs { int p0, p1, a0, a1, b0, b1; }; // primary k = 0, 1; secondary (dir + 2) k = 0, 1; secondary (dir + 6) k = 0, 1
+// Out-of-frame pixels of the frame kernel's tile.  The reference marks them CDEF_VERY_LARGE (0x7f7f): constrain() of such a tap is 0 and the tap
+// is left out of the max (cdef.c:277-301) while it can never win the min.  0x8000 has the same three properties at two packed ops per tap
+// instead of three: signed max ignores it (-32768), unsigned min ignores it (32768), and |0x8000 - x| >> shift still exceeds every threshold.
+constexpr int OUTSIDE = 0x8000;
+__device__ __forceinline__ s16x2 pk_minu(const s16x2 a, const s16x2 b) { const u16x2 x = (u16x2)a, y = (u16x2)b; return (s16x2)(x < y ? x : y); }
+
+// Tap k of a lane: byte offset (dword aligned) from the lane's own pixel pair and funnel-shift amount.  The pair sits at an even pixel index, so
+// both depend on the direction only and are computed once per unit, not once per pixel.
+struct TapOffs { int oa[12]; uint32_t sh[6]; };
 __device__ __forceinline__ TapOffs tap_offs(const int dir, const int pitch) {
-    return TapOffs{dir_off(dir, 0, pitch), dir_off(dir, 1, pitch), dir_off(dir + 2, 0, pitch), dir_off(dir + 2, 1, pitch), dir_off(dir + 6, 0, pitch),
-                   dir_off(dir + 6, 1, pitch)};
+    // order: primary k = 0 (+,-), k = 1 (+,-); secondary (dir + 2) k = 0 (+,-), (dir + 6) k = 0 (+,-); secondary (dir + 2) k = 1 (+,-), (dir + 6) k = 1 (+,-)
+    const int e[6] = {dir_off(dir, 0, pitch), dir_off(dir, 1, pitch), dir_off(dir + 2, 0, pitch), dir_off(dir + 6, 0, pitch), dir_off(dir + 2, 1, pitch),
+                      dir_off(dir + 6, 1, pitch)};
+    TapOffs o;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        o.oa[2 * k]     = (2 * e[k]) & ~3;  // floor to a dword, also for negative offsets
+        o.oa[2 * k + 1] = (-2 * e[k]) & ~3;
+        o.sh[k]         = (uint32_t)(2 * e[k]) & 2u; // same parity for +e and -e
+    }
+    return o;
 }
 // t[0..3] primary (k0+, k0-, k1+, k1-), t[4..7] secondary k = 0 (weight 2), t[8..11] secondary k = 1 (weight 1); min / max over all twelve and
-// the centre, CDEF_VERY_LARGE excluded from the max (cdef.c:277-301): adding 0x8081 maps it to 0 and real pixels to 0x8081.., compared unsigned
-__device__ __forceinline__ void load_taps(const uint16_t* p, const TapOffs& o, const s16x2 x, s16x2 (&t)[12], s16x2& mn, s16x2& mx) {
-    t[0] = ld_pair(p + o.p0); t[1] = ld_pair(p - o.p0); t[2] = ld_pair(p + o.p1); t[3] = ld_pair(p - o.p1);
-    t[4] = ld_pair(p + o.a0); t[5] = ld_pair(p - o.a0); t[6] = ld_pair(p + o.b0); t[7] = ld_pair(p - o.b0);
-    t[8] = ld_pair(p + o.a1); t[9] = ld_pair(p - o.a1); t[10] = ld_pair(p + o.b1); t[11] = ld_pair(p - o.b1);
-    const s16x2 bias = splat(0x8081 - 0x10000);
-    s16x2 mxb = x + bias;
+// the centre.  `pair` = LDS address of the lane's pixel pair (dword aligned); one ds_read2_b32 + one v_alignbyte_b32 per tap.
+__device__ __forceinline__ void load_taps(const uint16_t* pair, const TapOffs& o, const s16x2 x, s16x2 (&t)[12], s16x2& mn, s16x2& mx) {
     mn = x;
+    mx = x;
 #pragma unroll
     for (int k = 0; k < 12; k++) {
-        mn  = pk_min(mn, t[k]);
-        mxb = pk_maxu(mxb, t[k] + bias);
+        const DwPairA4 v = *(const DwPairA4*)((const char*)pair + o.oa[k]);
+        t[k] = as_pk(__builtin_amdgcn_alignbyte(v.hi, v.lo, o.sh[k >> 1]));
+        mn   = pk_minu(mn, t[k]);
+        mx   = pk_max(mx, t[k]);
     }
-    mx = mxb - bias;
 }
 __device__ __forceinline__ s16x2 pri_sum(const s16x2 x, const s16x2 (&t)[12], const s16x2 thr, const s16x2 sh, const s16x2 w0, const s16x2 w1) {
     return w0 * (constrain2(t[0] - x, thr, sh) + constrain2(t[1] - x, thr, sh)) + w1 * (constrain2(t[2] - x, thr, sh) + constrain2(t[3] - x, thr, sh));
@@ -206,10 +225,10 @@ __device__ __forceinline__ s16x2 finish_px(const s16x2 x, const s16x2 sum, const
     return pk_min(pk_max(y, mn), mx);
 }
 
-// Stage rows x (8 * cpr) pixels as u16 into LDS (pitch = 8 * cpr): pixels inside [ys, ye) x [xs, xe) come from the plane, the rest is `fill`.
+// Stage rows x (8 * cpr) pixels as u16 into LDS rows of `pitch` pixels: pixels inside [ys, ye) x [xs, xe) come from the plane, the rest is `fill`.
 // A thread owns 8-pixel chunks; chunks that lie fully inside are fetched with one vector load each, all issued before the first LDS store.
 template <typename PIX, int NIT>
-__device__ __forceinline__ void stage_tile(uint16_t* lds, const int rows, const int cpr, const PIX* plane, const size_t stride, const int gy0, const int gx0,
+__device__ __forceinline__ void stage_tile(uint16_t* lds, const int pitch, const int rows, const int cpr, const PIX* plane, const size_t stride, const int gy0, const int gx0,
                                            const int ys, const int ye, const int xs, const int xe, const int fill, const int tid) {
     uint32_t  v[NIT][4];
     const int total = rows * cpr;
@@ -243,7 +262,7 @@ __device__ __forceinline__ void stage_tile(uint16_t* lds, const int rows, const 
                 v[k][e] = lo | (hi << 16);
             }
         }
-        *(Row8A16*)(lds + (size_t)i * 8) = Row8A16{{v[k][0], v[k][1], v[k][2], v[k][3]}};
+        *(Row8A16*)(lds + r * pitch + c * 8) = Row8A16{{v[k][0], v[k][1], v[k][2], v[k][3]}};
     }
 }
 
@@ -280,26 +299,37 @@ template <int D> __device__ __forceinline__ int dir_cost_regs(const s16x2 (&px)[
     }
     return cost;
 }
-// same contract as quad_find_dir, the unit is read with eight 16-byte LDS loads (img 16-byte aligned, pitch a multiple of 8)
-__device__ __forceinline__ void quad_find_dir_tile(const uint16_t* img, const int pitch, const int coeff_shift, const int q, int& best_dir, int& var) {
-    s16x2 px[8][4];
-    const s16x2 csv = splat(coeff_shift), c128 = splat(128);
+// Direction search of all 64 units of a filter block by the whole workgroup, free of divergence: wave w evaluates directions w and w + 4
+// (a wave-uniform choice) for unit = lane, reading the unit with eight 16-byte LDS loads; the four partial winners meet in LDS.
+// Returns, for the unit `b` of the calling lane, the first maximum in index order (strict '>' from best_cost = 0, cdef.c:200-205; costs are sums
+// of squares, so "nothing beat 0" means every cost is 0 -> dir 0, var 0, the same result) and var = (best - cost[dir ^ 4]) >> 10.
+__device__ __forceinline__ void block_find_dir(const uint16_t* in, const int pitch, const int coeff_shift, const int tid, const int b,
+                                               int (*sh_c)[64], int (*sh_d)[64], int (*sh_o)[64], int& best_dir, int& var) {
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), u = tid & 63;
+    {
+        const uint16_t* img = in + ((u >> 3) * 8) * pitch + (u & 7) * 8;
+        s16x2 px[8][4];
+        const s16x2 csv = splat(coeff_shift), c128 = splat(128);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const Row8A16 r = *(const Row8A16*)(img + i * pitch);
+        for (int i = 0; i < 8; i++) {
+            const Row8A16 r = *(const Row8A16*)(img + i * pitch);
 #pragma unroll
-        for (int j = 0; j < 4; j++) px[i][j] = (as_pk(r.v[j]) >> csv) - c128;
+            for (int j = 0; j < 4; j++) px[i][j] = (as_pk(r.v[j]) >> csv) - c128;
+        }
+        int a, o;
+        if (w == 0) { a = dir_cost_regs<0>(px); o = dir_cost_regs<4>(px); }
+        else if (w == 1) { a = dir_cost_regs<1>(px); o = dir_cost_regs<5>(px); }
+        else if (w == 2) { a = dir_cost_regs<2>(px); o = dir_cost_regs<6>(px); }
+        else { a = dir_cost_regs<3>(px); o = dir_cost_regs<7>(px); }
+        int d = w;
+        if (o > a) { const int t = a; a = o; o = t; d = w + 4; }
+        sh_c[w][u] = a; sh_d[w][u] = d; sh_o[w][u] = o;
     }
-    int a, b;
-    if (q == 0) { a = dir_cost_regs<0>(px); b = dir_cost_regs<4>(px); }
-    else if (q == 1) { a = dir_cost_regs<1>(px); b = dir_cost_regs<5>(px); }
-    else if (q == 2) { a = dir_cost_regs<2>(px); b = dir_cost_regs<6>(px); }
-    else { a = dir_cost_regs<3>(px); b = dir_cost_regs<7>(px); }
-    int c = a, d = q, o = b;
-    if (b > a) { c = b; d = q + 4; o = a; }
+    __syncthreads();
+    int c = sh_c[0][b], d = sh_d[0][b], o = sh_o[0][b];
 #pragma unroll
-    for (int m = 1; m <= 2; m <<= 1) {
-        const int c2 = __shfl_xor(c, m), d2 = __shfl_xor(d, m), o2 = __shfl_xor(o, m);
+    for (int k = 1; k < 4; k++) {
+        const int c2 = sh_c[k][b], d2 = sh_d[k][b], o2 = sh_o[k][b];
         if (c2 > c || (c2 == c && d2 < d)) { c = c2; d = d2; o = o2; }
     }
     best_dir = d;
@@ -312,6 +342,14 @@ __device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
 }
 
 typedef uint32_t acc16 __attribute__((vector_size(64)));
+
+// Tile row pitch in pixels: block + two 8-pixel halos, padded by whole 8-pixel chunks until one row of units (uh pixel rows) is half the LDS
+// bank space (32 dwords mod 64) away from the next, so the two unit rows a wave touches in one instruction do not share banks.
+__host__ __device__ inline int tile_pitch(const int bw, const int uh) {
+    int p = bw + 2 * HB;
+    while (((uh * p / 2) & 63) != 32) p += 8;
+    return p;
+}
 
 // Per-lane geometry and strength context of the filter passes
 struct LaneCtx {
@@ -340,22 +378,22 @@ __device__ __forceinline__ s16x2 sec_sum_strength(const LaneCtx& L, const int se
 template <int NP>
 __device__ __forceinline__ void search_pass(const LaneCtx& L, const TapOffs& o, const int (&lv)[4], const bool acc_src,
                                             acc16& a_s, acc16& a_s2, acc16& a_sd, uint32_t& d_s, uint32_t& d_s2) {
-    const int rows = L.uh >> 2; // rows per lane: 2 (8-row unit) or 1 (4-row unit)
-    for (int rr = 0; rr < rows; rr++) {
-        const int r = L.uh == 8 ? 2 * L.q + rr : L.q;
+    // the quad's lanes sit side by side on one pixel row (lane = pixel pair; 4-wide units: two rows of two pairs) and walk down the unit:
+    // a wave instruction then reads two runs of 64 adjacent pixels, which is what the LDS banks like
+    const int ppr = L.uw >> 1, jq = L.q & (ppr - 1), r0 = L.uw == 8 ? 0 : L.q >> 1, rstep = 4 / ppr;
+    for (int r = r0; r < L.uh; r += rstep) {
         if ((r & (L.sub - 1)) != 0) continue;
-        const uint16_t* row  = L.in + (L.by * L.uh + r) * L.pitch + L.bx * L.uw;
-        const uint16_t* orow = L.org + (L.by * L.uh + r) * L.bw + L.bx * L.uw;
-        for (int j = 0; j < (L.uw >> 1); j++) {
-            const uint16_t* p = row + 2 * j;
-            const s16x2     x = ld_pair(p);
+        {
+            const int       ri   = (L.by * L.uh + r) * L.pitch + L.bx * L.uw + 2 * jq; // pixel index of this lane's pair relative to L.in (even)
+            const uint16_t* orow = L.org + (L.by * L.uh + r) * L.bw + L.bx * L.uw + 2 * jq;
+            const s16x2 x = ld_pair_even(L.in + ri);
             s16x2 t[12], mn, mx, S[4];
-            load_taps(p, o, x, t, mn, mx);
+            load_taps(L.in + ri, o, x, t, mn, mx);
             S[0] = splat(0);
             S[1] = sec_sum_strength(L, 1, x, t);
             S[2] = sec_sum_strength(L, 2, x, t);
             S[3] = sec_sum_strength(L, 4, x, t);
-            const uint32_t dpair = as_u32(ld_pair(orow + 2 * j));
+            const uint32_t dpair = as_u32(ld_pair_even(orow));
             if (acc_src) {
                 d_s += dpair; // u16 halves: at most 8 pixels of 4095 each per half
                 d_s2 = dot2(dpair, dpair, d_s2);
@@ -408,34 +446,20 @@ __device__ __forceinline__ void search_reduce(acc16& a_s, acc16& a_s2, acc16& a_
 template <typename PIX>
 __device__ __forceinline__ void apply_pass(const LaneCtx& L, const TapOffs& o, const int lvl, const int sec, PIX* out, const size_t out_stride,
                                            const int fbr, const int fbc) {
-    const int rows = L.uh >> 2;
-    for (int rr = 0; rr < rows; rr++) {
-        const int       r   = L.uh == 8 ? 2 * L.q + rr : L.q;
-        const uint16_t* row = L.in + (L.by * L.uh + r) * L.pitch + L.bx * L.uw;
-        uint32_t        yrow[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (j < (L.uw >> 1)) {
-                const uint16_t* p = row + 2 * j;
-                const s16x2     x = ld_pair(p);
-                s16x2 t[12], mn, mx, sum = splat(0);
-                load_taps(p, o, x, t, mn, mx);
-                if (lvl) sum = pri_sum_level(L, lvl, x, t);
-                if (sec) sum = sum + sec_sum_strength(L, sec, x, t);
-                yrow[j] = as_u32(finish_px(x, sum, mn, mx));
-            }
-        }
-        const size_t gy = (size_t)(fbr * (L.uh * 8) + L.by * L.uh + r);
-        const int    gx = fbc * L.bw + L.bx * L.uw;
-        PIX*         op = out + gy * out_stride + gx;
-        if (sizeof(PIX) == 2) {
-            if (L.uw == 8) *(Row8A2*)op = Row8A2{{yrow[0], yrow[1], yrow[2], yrow[3]}};
-            else *(Row8A1*)op = Row8A1{{yrow[0], yrow[1]}};
-        } else {
-            const uint32_t w0 = __builtin_amdgcn_perm(yrow[1], yrow[0], 0x06040200u);
-            if (L.uw == 8) *(Row8A1*)op = Row8A1{{w0, __builtin_amdgcn_perm(yrow[3], yrow[2], 0x06040200u)}};
-            else *(PairA2*)op = PairA2{w0};
-        }
+    const int ppr = L.uw >> 1, jq = L.q & (ppr - 1), r0 = L.uw == 8 ? 0 : L.q >> 1, rstep = 4 / ppr; // same lane layout as search_pass
+    for (int r = r0; r < L.uh; r += rstep) {
+        const int   ri = (L.by * L.uh + r) * L.pitch + L.bx * L.uw + 2 * jq;
+        const s16x2 x  = ld_pair_even(L.in + ri);
+        s16x2 t[12], mn, mx, sum = splat(0);
+        load_taps(L.in + ri, o, x, t, mn, mx);
+        if (lvl) sum = pri_sum_level(L, lvl, x, t);
+        if (sec) sum = sum + sec_sum_strength(L, sec, x, t);
+        const uint32_t y  = as_u32(finish_px(x, sum, mn, mx));
+        const size_t   gy = (size_t)(fbr * (L.uh * 8) + L.by * L.uh + r);
+        const int      gx = fbc * L.bw + L.bx * L.uw + 2 * jq;
+        PIX*           op = out + gy * out_stride + gx;
+        if (sizeof(PIX) == 2) *(PairA2*)op = PairA2{y}; // the quad writes 16 (8) contiguous bytes of the row
+        else *(U16A1*)op = U16A1{(uint16_t)((y & 0xffu) | ((y >> 8) & 0xff00u))};
     }
 }
 
@@ -445,7 +469,7 @@ __device__ __forceinline__ void apply_pass(const LaneCtx& L, const TapOffs& o, c
 template <typename PIX, int MODE>
 __global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefParams P) {
     HIP_DYNAMIC_SHARED(uint16_t, tile_raw)
-    __shared__ int                sh_any;
+    __shared__ int                sh_any, sh_dc[4][64], sh_dd[4][64], sh_do[4][64];
     __shared__ unsigned long long sh_cells[20]; // [4 levels][4 secondary] + [level 0][4 secondary]
     const int tid = threadIdx.x;
     const int xdec = P.xdec, ydec = P.ydec, pli = P.pli, cs = P.coeff_shift;
@@ -453,7 +477,7 @@ __global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefPara
     const int pw = (int)P.width, ph = (int)P.height;
     const int nhfb = (pw + bw - 1) / bw, nvfb = (ph + bh - 1) / bh;
     const int fb = blockIdx.x, fbr = fb / nhfb, fbc = fb % nhfb;
-    const int pitch = bw + 2 * HB;
+    const int pitch = tile_pitch(bw, uh);
     const int g = blockIdx.y, ncand = MODE == 1 ? (int)P.ncand : 0;
 
     // search: which primary levels does this group own?  (uniform; the list has at most 64 entries)
@@ -484,14 +508,14 @@ __global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefPara
             for (int c = tid; c < ncand; c += 256) P.mse[(size_t)fb * P.ncand + c] = 0;
         return;
     }
-    {   // stage the tile (cdef_process.c:208-228): real pixels where the neighbouring filter block exists, else CDEF_VERY_LARGE
+    {   // stage the tile (cdef_process.c:208-228): real pixels where the neighbouring filter block exists, else OUTSIDE
         const int x0 = fbc * bw, y0 = fbr * bh;
         const int xs = x0 - (fbc != 0 ? HB : 0), ys = y0 - (fbr != 0 ? VB : 0);
         const int xe = (x0 + bw < pw ? x0 + bw : pw) + (fbc + 1 < nhfb ? HB : 0);
         const int ye = (y0 + bh < ph ? y0 + bh : ph) + (fbr + 1 < nvfb ? VB : 0);
-        stage_tile<PIX, 3>(tile_raw, bh + 2 * VB, pitch >> 3, (const PIX*)P.recon, P.recon_stride, y0 - VB, x0 - HB, ys, ye, xs, xe, VERY_LARGE, tid);
+        stage_tile<PIX, 3>(tile_raw, pitch, bh + 2 * VB, (bw + 2 * HB) >> 3, (const PIX*)P.recon, P.recon_stride, y0 - VB, x0 - HB, ys, ye, xs, xe, OUTSIDE, tid);
         if (MODE == 1)
-            stage_tile<PIX, 2>(tile_raw + (bh + 2 * VB) * pitch, bh, bw >> 3, (const PIX*)P.source, P.source_stride, y0, x0, y0,
+            stage_tile<PIX, 2>(tile_raw + (bh + 2 * VB) * pitch, bw, bh, bw >> 3, (const PIX*)P.source, P.source_stride, y0, x0, y0,
                                y0 + bh < ph ? y0 + bh : ph, x0, x0 + bw < pw ? x0 + bw : pw, 0, tid);
     }
     __syncthreads();
@@ -500,8 +524,7 @@ __global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefPara
     L.org = tile_raw + (bh + 2 * VB) * pitch; // search mode: the source block, pitch bw
     int dir = 0, var = 0;
     if (pli == 0) {
-        // a whole quad is either active or not; inactive quads run the search too (results unused) so the quad shuffles stay convergent
-        quad_find_dir_tile(L.in + (by * 8) * pitch + bx * 8, pitch, cs, q, dir, var);
+        block_find_dir(L.in, pitch, cs, tid, b, sh_dc, sh_dd, sh_do, dir, var); // every unit is searched (inactive ones: result unused)
         if (!act) { dir = 0; var = 0; }
         if (q == 0 && g == 0) { P.dir[(size_t)fb * 64 + b] = (uint8_t)dir; P.var[(size_t)fb * 64 + b] = var; }
     } else {
@@ -607,7 +630,7 @@ __global__ void copy_rect8_to_16_kernel(uint16_t* dst, const uint8_t* src, int n
 template <int MODE> void launch_frame(const SvtHipCdefParams& P, hipStream_t st) {
     const int bw = 64 >> P.xdec, bh = 64 >> P.ydec;
     const int nhfb = ((int)P.width + bw - 1) / bw, nvfb = ((int)P.height + bh - 1) / bh;
-    const size_t shmem = (size_t)((bh + 2 * VB) * (bw + 2 * HB) + (MODE == 1 ? bh * bw : 0)) * 2 + 64;
+    const size_t shmem = (size_t)((bh + 2 * VB) * tile_pitch(bw, 8 >> P.ydec) + (MODE == 1 ? bh * bw : 0)) * 2 + 64;
     const dim3 grid(nhfb * nvfb, MODE == 1 ? 4 : 1); // search: four groups of four primary levels
     if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE>), grid, dim3(256), shmem, st, P);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE>), grid, dim3(256), shmem, st, P);

@@ -358,6 +358,8 @@ inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh)
     unsigned long long v = ((unsigned long long)hi << 32) | lo;
     return (unsigned)(v >> (sh & 31));
 }
+// clang element-wise saturating subtraction on unsigned vectors (v_pk_sub_u16 clamp)
+template <class V> inline V __builtin_elementwise_sub_sat(V a, V b) { return (a > b) ? (a - b) : (a - a); }
 // clang's ext_vector_type is only used for the <2 x u16> operands of v_dot2_u32_u16; g++ spells the same 4-byte vector vector_size(4)
 #define ext_vector_type(N) vector_size((N) * 2)
 typedef unsigned short hipemu_us2 __attribute__((vector_size(4)));

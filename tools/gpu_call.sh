@@ -1,11 +1,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/r4_pytest.log 2>&1; echo "pytest rc=$?"
-tail -3 gpurun_out/r4_pytest.log
-timeout 900 python bench.py --steps 20 --warmup 3 --extra > gpurun_out/r4_bench.json 2> gpurun_out/r4_bench.err; echo "bench rc=$?"
-tail -c 600 gpurun_out/r4_bench.err
-head -c 3000 gpurun_out/r4_bench.json
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r4 -o run -- python bench.py --steps 20 --warmup 3 --no-cpu > gpurun_out/r4_prof.log 2>&1; echo "prof rc=$?"
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc4_fetch -o run -- python bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/r4_pmc_fetch.log 2>&1; echo "pmcf rc=$?"
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc4_write -o run -- python bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/r4_pmc_write.log 2>&1; echo "pmcw rc=$?"
-ls gpurun_out/prof_r4 gpurun_out/pmc4_fetch
+timeout 300 python -m pytest tests/test_cdef.py -m gpu -x -q 2>&1 | tail -2
+python tools/microbench.py cdef > gpurun_out/r11_micro.json 2> gpurun_out/r11_micro.err; echo "micro rc=$?"; cat gpurun_out/r11_micro.json | cut -c1-900
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+  tag=$(echo $set | cut -c1-12 | tr ' ' '_')
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc11_$tag -o run -- python tools/microbench.py cdef --steps 3 --warmup 1 > gpurun_out/r11_pmc_$tag.log 2>&1; echo "pmc $tag rc=$?"
+done
