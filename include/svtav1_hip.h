@@ -83,6 +83,23 @@ void svt_ext_sad_calculation_32x32_64x64_hip(uint32_t *p_sad16x16, uint32_t *p_b
 /* a6. svt_initialize_buffer_32bits -> _c (Source/Lib/Codec/me_sad_calculation.c:14-17) */
 void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value);
 
+/* a7. svt_pme_sad_loop_kernel -> svt_pme_sad_loop_kernel_c (aom_dsp_rtcd.h:868, product_coding_loop.c:1900-1951): SAD + MV-rate search
+ * of MD's predictive ME.  SvtHipMvCostParams is layout-identical to the reference's MV_COST_PARAMS (`struct svt_mv_cost_param`,
+ * mcomp.h:37-48; MV = {int16 row, col}, block_structures.h:26; MV_COST_TYPE is a 1-byte enum, mcomp.h:29-36). */
+typedef struct SvtHipMv { int16_t row, col; } SvtHipMv;
+typedef struct SvtHipMvCostParams {
+    const SvtHipMv *ref_mv;
+    SvtHipMv        full_ref_mv;
+    uint8_t         mv_cost_type; /* 0 ENTROPY, 1 L1_LOWRES, 2 L1_MIDRES, 3 L1_HDRES, 4 OPT, 5 NONE */
+    const int      *mvjcost;
+    const int      *mvcost[2];    /* centred tables, index range [MV_LOW, MV_UPP] */
+    int             error_per_bit, early_exit_th, sad_per_bit;
+} SvtHipMvCostParams;
+void svt_pme_sad_loop_kernel_hip(const SvtHipMvCostParams *mv_cost_params, uint8_t *src, uint32_t src_stride, uint8_t *ref,
+                                 uint32_t ref_stride, uint32_t block_height, uint32_t block_width, uint32_t *best_cost, int16_t *best_mvx,
+                                 int16_t *best_mvy, int16_t search_position_start_x, int16_t search_position_start_y,
+                                 int16_t search_area_width, int16_t search_area_height, int16_t search_step, int16_t mvx, int16_t mvy);
+
 /* ---- batched forms (device pointers) ---- */
 typedef struct SvtHipSadPair {
     uint64_t src_off;    /* byte offset of the block's top-left sample from src_base */

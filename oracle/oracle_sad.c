@@ -9,6 +9,7 @@
  */
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 #define MAX_SAD_VALUE (128 * 128 * 255) /* Codec/motion_estimation.h:85 */
 
@@ -188,4 +189,55 @@ void oracle_ext_sad_calculation_32x32_64x64(const uint32_t *p_sad16x16, uint32_t
 void oracle_initialize_buffer_32bits(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value) {
     const uint32_t n = count128 * 4 + count32;
     for (uint32_t i = 0; i < n; i++) pointer[i] = value;
+}
+
+/* ---- a7: svt_pme_sad_loop_kernel_c (product_coding_loop.c:1900-1951) with svt_mv_err_cost (mcomp.c:44-68),
+ * svt_mv_cost (mcomp.h:135-138) and svt_av1_get_mv_joint (rd_cost.c:55-60).  Parameters are passed flat (no reference structs). */
+static int oracle_mv_rate(int16_t mv_row, int16_t mv_col, int16_t ref_row, int16_t ref_col, int cost_type, const int *mvjcost, const int *mvcost0,
+                          const int *mvcost1, int error_per_bit) {
+    const int16_t drow = (int16_t)(mv_row - ref_row), dcol = (int16_t)(mv_col - ref_col);
+    const int16_t arow = (int16_t)abs(drow), acol = (int16_t)abs(dcol);
+    switch (cost_type) {
+    case 0:
+        if (mvcost0 && mvcost1 && mvjcost) {
+            const int joint = drow == 0 ? (dcol == 0 ? 0 : 1) : (dcol == 0 ? 2 : 3);
+            const int cr = drow < -(1 << 14) ? -(1 << 14) : (drow > (1 << 14) ? (1 << 14) : drow);
+            const int cc = dcol < -(1 << 14) ? -(1 << 14) : (dcol > (1 << 14) ? (1 << 14) : dcol);
+            const int64_t v = (int64_t)(mvjcost[joint] + mvcost0[cr] + mvcost1[cc]) * error_per_bit;
+            return (int)((v + ((int64_t)1 << 13)) >> 14); /* RDDIV_BITS 7 + AV1_PROB_COST_SHIFT 9 - RD_EPB_SHIFT 6 + PIXEL_TRANSFORM_ERROR_SCALE 4 */
+        }
+        return 0;
+    case 1: return (2 * (arow + acol)) >> 3;
+    case 2: return (0 * (arow + acol)) >> 3;
+    case 3: return (1 * (arow + acol)) >> 3;
+    case 4: {
+        const int64_t v = (int64_t)((arow + acol) << 8) * error_per_bit;
+        return (int)((v + ((int64_t)1 << 13)) >> 14);
+    }
+    default: return 0;
+    }
+}
+void oracle_pme_sad_loop(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t block_height,
+                         uint32_t block_width, uint32_t *best_cost, int16_t *best_mvx, int16_t *best_mvy, int16_t start_x, int16_t start_y,
+                         int16_t search_area_width, int16_t search_area_height, int16_t search_step, int16_t mvx, int16_t mvy, int16_t ref_row,
+                         int16_t ref_col, int cost_type, const int *mvjcost, const int *mvcost0, const int *mvcost1, int error_per_bit) {
+    int16_t col_num = 0, search_step_x = 1;
+    for (int16_t ys = 0; ys < search_area_height; ys += search_step) {
+        for (int16_t xs = 0; xs < search_area_width; xs += search_step_x) {
+            if (((search_area_width - xs) < 8) && (col_num == 0)) continue;
+            if (col_num == 7) { col_num = 0; search_step_x = search_step; }
+            else { col_num++; search_step_x = 1; }
+            uint32_t cost = 0;
+            for (uint32_t y = 0; y < block_height; y++)
+                for (uint32_t x = 0; x < block_width; x++) {
+                    const int a = src[y * src_stride + x], b = ref[xs + y * ref_stride + x];
+                    cost += (uint32_t)(a > b ? a - b : b - a);
+                }
+            const uint32_t px = (uint32_t)(start_x + xs), py = (uint32_t)(start_y + ys);
+            const int16_t  mc = (int16_t)(mvx + (px * 8)), mr = (int16_t)(mvy + (py * 8));
+            cost += (uint32_t)oracle_mv_rate(mr, mc, ref_row, ref_col, cost_type, mvjcost, mvcost0, mvcost1, error_per_bit);
+            if (cost < *best_cost) { *best_mvx = mc; *best_mvy = mr; *best_cost = cost; }
+        }
+        ref += search_step * ref_stride;
+    }
 }

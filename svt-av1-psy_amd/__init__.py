@@ -53,6 +53,8 @@ PROTOTYPES = {
     "svt_ext_sad_calculation_8x8_16x16_hip": (None, [vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_bool]),
     "svt_ext_sad_calculation_32x32_64x64_hip": (None, [vp, vp, vp, vp, vp, C.c_uint32, vp]),
     "svt_initialize_buffer_32bits_hip": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svt_pme_sad_loop_kernel_hip": (None, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, i16p, i16p, C.c_int16, C.c_int16,
+                                           C.c_int16, C.c_int16, C.c_int16, C.c_int16, C.c_int16]),
     "svt_hip_sad_nxm_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_sad_loop_batch": (None, [vp, vp, vp, C.c_uint32, vp, vp, vp]),
     "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -117,6 +119,16 @@ PROTOTYPES.update({
 for _n in ("64x64", "32x64", "64x32", "16x64", "64x16"):
     PROTOTYPES["svt_handle_transform%s_hip" % _n] = (C.c_uint64, [vp])
     PROTOTYPES["svt_handle_transform%s_N2_N4_hip" % _n] = (C.c_uint64, [vp])
+
+
+class Mv(C.Structure):
+    _fields_ = [("row", C.c_int16), ("col", C.c_int16)]
+
+
+class MvCostParams(C.Structure):
+    """MV_COST_PARAMS (mcomp.h:37-48)."""
+    _fields_ = [("ref_mv", C.POINTER(Mv)), ("full_ref_mv", Mv), ("mv_cost_type", C.c_uint8), ("mvjcost", C.POINTER(C.c_int)),
+                ("mvcost", C.POINTER(C.c_int) * 2), ("error_per_bit", C.c_int), ("early_exit_th", C.c_int), ("sad_per_bit", C.c_int)]
 
 
 class CdefParams(C.Structure):

@@ -1,8 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_cdef.py -m gpu -x -q 2>&1 | tail -2
-python tools/microbench.py cdef > gpurun_out/r11_micro.json 2> gpurun_out/r11_micro.err; echo "micro rc=$?"; cat gpurun_out/r11_micro.json | cut -c1-900
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   tag=$(echo $set | cut -c1-12 | tr ' ' '_')
-  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc11_$tag -o run -- python tools/microbench.py cdef --steps 3 --warmup 1 > gpurun_out/r11_pmc_$tag.log 2>&1; echo "pmc $tag rc=$?"
+  timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc12_$tag -o run -- python tools/microbench.py txfm lr hme sad fwd32 --steps 2 --warmup 1 > gpurun_out/r12_pmc_$tag.log 2>&1; echo "pmc $tag rc=$?"
 done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r12 -o run -- python tools/microbench.py txfm lr hme --steps 5 --warmup 1 > gpurun_out/r12_prof.log 2>&1; echo "prof rc=$?"
