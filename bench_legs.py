@@ -171,3 +171,30 @@ def hme_sad_loop(torch, lib, pkg, stream, steps, warmup, nframes=32):
         out[name] = {"value": n * aw * ah / t / 1e6, "unit": "M(block x position)/s", "searches": n, "block": "%dx%d" % (bs, bs), "area": "%dx%d" % area,
                      "ms": t * 1e3, "sad_ops_per_s": float(np.sum(d["block_width"].astype(np.int64) * d["block_height"])) * aw * ah / t}
     return out
+
+
+def picprep(torch, lib, pkg, stream, steps, warmup, nframes=32):
+    """per 1080p frame, border replication of the full-resolution luma plane (pad 68) + 1/4 (pad 32) + 1/16 (pad 16)
+    planes as svt_aom_downsample_filtering_input_picture; three launches per frame, nframes frames per step."""
+    w, h, pad = 1920, 1080, 68
+    stride, rows = w + 2 * pad, h + 2 * pad
+    g = np.random.default_rng(5)
+    full = torch.from_numpy(g.integers(0, 256, (nframes, rows, stride), dtype=np.uint8)).cuda()
+    qw, qh, sw, sh = w // 2, h // 2, w // 4, h // 4
+    qs, ss = qw + 64, sw + 32
+    quarter = torch.zeros((nframes, qh + 64, qs), dtype=torch.uint8, device="cuda")
+    sixteenth = torch.zeros((nframes, sh + 32, ss), dtype=torch.uint8, device="cuda")
+
+    def fn():
+        for f in range(nframes):
+            fb = full.data_ptr() + f * rows * stride
+            qb = quarter.data_ptr() + f * (qh + 64) * qs
+            sb = sixteenth.data_ptr() + f * (sh + 32) * ss
+            lib.svt_hip_generate_padding(fb, stride, w, h, pad, pad, stream)
+            lib.svt_hip_downsample_2d_padded(fb + pad * stride + pad, stride, w, h, qb, qs, 32, 32, 2, stream)
+            lib.svt_hip_downsample_2d_padded(qb + 32 * qs + 32, qs, qw, qh, sb, ss, 16, 16, 2, stream)
+    t = _time(torch, fn, steps, warmup)
+    nbytes = nframes * (w * h + (rows * stride - w * h) + (qh + 64) * qs + qw * qh + (sh + 32) * ss)  # reads + writes per frame
+    return {"picprep_1080p": {"frames_per_s": nframes / t, "us_per_frame": t / nframes * 1e6,
+                              "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS,
+                                           "algorithmic_bytes_per_frame": nbytes // nframes, "note": "three launches per frame; launch-latency bound at 1080p"}}}

@@ -211,6 +211,19 @@ void     svt_quantize_hip(int mode, const int32_t *coeff_ptr, intptr_t n_coeffs,
                           const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int log_scale);
 uint64_t svt_handle_transform_hip(int32_t *output, int tx_size, int n2_n4);
 
+/* ------------------------------------------- picture preparation for ME ------------------------- */
+/* downsample_2d -> svt_aom_downsample_2d_c (aom_dsp_rtcd.h:841, pic_analysis_process.c:130-160): out(x, y) = (2x2 box at the centre of cell
+ * (x, y) of decim_step x decim_step input pixels + 2) >> 2; host pointers (RTCD form). */
+void svt_aom_downsample_2d_hip(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height,
+                               uint8_t *decim_samples, uint32_t decim_stride, uint32_t decim_step);
+/* Device-resident form of one level of svt_aom_downsample_filtering_input_picture (pic_analysis_process.c:2138-2200): decimate the picture
+ * whose first pixel is `in_origin` into the interior of the padded plane `out_base` (interior origin at (pad_x, pad_y)) AND replicate the
+ * pad_x / pad_y wide borders (svt_aom_generate_padding, pic_operators.c:397-441) in the same launch. */
+void svt_hip_downsample_2d_padded(const uint8_t *in_origin, uint32_t in_stride, uint32_t in_width, uint32_t in_height, uint8_t *out_base,
+                                  uint32_t out_stride, uint32_t pad_x, uint32_t pad_y, uint32_t step, void *stream);
+/* svt_aom_generate_padding on a device plane, in place: `base` = top-left of the padded plane */
+void svt_hip_generate_padding(uint8_t *base, uint32_t stride, uint32_t width, uint32_t height, uint32_t pad_x, uint32_t pad_y, void *stream);
+
 /* ---------------------------------------------------------------- CDEF (a17-a20) --------------------- */
 /* One plane of one frame.  Filter-block grid = ceil(width / (64 >> xdec)) x ceil(height / (64 >> ydec)); tile
  * construction as cdef_seg_search (cdef_process.c:208-228).  Call once per plane, luma first (it produces dir/var). */

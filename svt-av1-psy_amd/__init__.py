@@ -55,6 +55,9 @@ PROTOTYPES = {
     "svt_initialize_buffer_32bits_hip": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "svt_pme_sad_loop_kernel_hip": (None, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, i16p, i16p, C.c_int16, C.c_int16,
                                            C.c_int16, C.c_int16, C.c_int16, C.c_int16, C.c_int16]),
+    "svt_aom_downsample_2d_hip": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32]),
+    "svt_hip_downsample_2d_padded": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
+    "svt_hip_generate_padding": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "svt_hip_sad_nxm_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_sad_loop_batch": (None, [vp, vp, vp, C.c_uint32, vp, vp, vp]),
     "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),

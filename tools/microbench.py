@@ -33,6 +33,8 @@ def main():
             out["txfm_quant_roundtrip"] = bench_legs.txfm_roundtrip(torch, lib, pkg, stream, a.steps, a.warmup)
         elif leg == "hme":
             out.update(bench_legs.hme_sad_loop(torch, lib, pkg, stream, a.steps, a.warmup))
+        elif leg == "picprep":
+            out.update(bench_legs.picprep(torch, lib, pkg, stream, a.steps, a.warmup))
         elif leg == "sad":
             out["sad64x64_pairs"] = bench.bench_sad_pairs(torch, lib, pkg, stream, a)
         elif leg == "fwd32":
