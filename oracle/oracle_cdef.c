@@ -274,3 +274,29 @@ void oracle_cdef_frame(int mode, const void *recon, int rstride, const void *sou
     free(tile);
     free(tmp);
 }
+
+/* svt_search_one_dual_c (enc_cdef.c:627-683) over flat [sb_count][64] tables */
+uint64_t oracle_search_one_dual(int *lev0, int *lev1, int nb_strengths, const uint64_t *mse0, const uint64_t *mse1, int sb_count, int start_gi, int end_gi) {
+    static uint64_t tot[64][64];
+    uint64_t        best_tot = (uint64_t)1 << 63;
+    int             best0 = 0, best1 = 0;
+    memset(tot, 0, sizeof(tot));
+    for (int i = 0; i < sb_count; i++) {
+        uint64_t best = (uint64_t)1 << 63;
+        for (int gi = 0; gi < nb_strengths; gi++) {
+            const uint64_t c = mse0[(size_t)i * 64 + lev0[gi]] + mse1[(size_t)i * 64 + lev1[gi]];
+            if (c < best) best = c;
+        }
+        for (int j = start_gi; j < end_gi; j++)
+            for (int k = start_gi; k < end_gi; k++) {
+                const uint64_t c = mse0[(size_t)i * 64 + j] + mse1[(size_t)i * 64 + k];
+                tot[j][k] += c < best ? c : best;
+            }
+    }
+    for (int j = start_gi; j < end_gi; j++)
+        for (int k = start_gi; k < end_gi; k++)
+            if (tot[j][k] < best_tot) { best_tot = tot[j][k]; best0 = j; best1 = k; }
+    lev0[nb_strengths] = best0;
+    lev1[nb_strengths] = best1;
+    return best_tot;
+}
