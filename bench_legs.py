@@ -166,7 +166,7 @@ def hme_sad_loop(torch, lib, pkg, stream, steps, warmup, nframes=32):
         d_pl, d_d = _dev(torch, planes), _dev(torch, d)
         d_res = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
         d_keys = torch.zeros(n, dtype=torch.int64, device="cuda")
-        t = _time(torch, lambda: lib.svt_hip_sad_loop_batch(d_pl.data_ptr(), d_pl.data_ptr(), d_d.data_ptr(), n, d_res.data_ptr(), d_keys.data_ptr(), stream),
+        t = _time(torch, lambda: lib.svt_hip_sad_loop_batch(d_pl.data_ptr(), d_pl.data_ptr(), d_d.data_ptr(), n, aw, ah, bs, bs, 1, d_res.data_ptr(), d_keys.data_ptr(), stream),
                   steps, warmup)
         out[name] = {"value": n * aw * ah / t / 1e6, "unit": "M(block x position)/s", "searches": n, "block": "%dx%d" % (bs, bs), "area": "%dx%d" % area,
                      "ms": t * 1e3, "sad_ops_per_s": float(np.sum(d["block_width"].astype(np.int64) * d["block_height"])) * aw * ah / t}

@@ -123,9 +123,13 @@ typedef struct SvtHipSadLoopResult {
     int16_t  x_search_center, y_search_center;
     uint32_t valid; /* 0 when the search area was empty (reference leaves x/y untouched, best_sad = 0xffffff) */
 } SvtHipSadLoopResult;
-/* n exhaustive searches (a2 batched: pre-HME / HME level 0-2 of every SB). `keys` = device scratch, n*8 bytes. */
+/* n exhaustive searches (a2 batched: pre-HME / HME level 0-2 of every SB). `keys` = device scratch, n*8 bytes.  The maxima over the batch
+ * size the position tile and the LDS window (descriptors live on the device and are not read back): widest / tallest search area, widest /
+ * tallest block, and the largest ref_stride / src_stride_raw (1 = full SAD, 2 = sub-sampled HME form; ref_stride must be a multiple of
+ * src_stride_raw, as it is at every reference call site). */
 void svt_hip_sad_loop_batch(const uint8_t *src_base, const uint8_t *ref_base, const SvtHipSadLoopDesc *descs, uint32_t n,
-                            SvtHipSadLoopResult *results, uint64_t *keys, void *stream);
+                            uint32_t max_area_width, uint32_t max_area_height, uint32_t max_block_width, uint32_t max_block_height,
+                            int max_ref_step, SvtHipSadLoopResult *results, uint64_t *keys, void *stream);
 
 /* Frame-batched integer full-pel search = open_loop_me_fullpel_search_sblock (motion_estimation.c:781-816), i.e.
  * a3+a4+a5+a6 fused: for every (64x64 SB, reference) item, all 85 block SADs (8x8..64x64) at every position of the

@@ -20,6 +20,7 @@ namespace {
 
 struct __attribute__((packed, aligned(4))) U64A4 { unsigned long long v; }; // 8-byte LDS window, dword aligned
 struct __attribute__((aligned(4))) u32x4_a4 { uint32_t x, y, z, w; }; // 16-byte load that only promises dword alignment
+struct __attribute__((aligned(16))) u32x4_a16 { uint32_t x, y, z, w; };
 
 constexpr uint32_t MAX_SAD_VALUE = 128 * 128 * 255; // motion_estimation.h:85
 constexpr int      ME_TW         = 64;              // search tile, positions
@@ -101,6 +102,44 @@ __device__ __forceinline__ void stage_rows_store(const uint32_t (&v)[NIT][4], ui
             uint32_t* o = lds + r * pitch_dw + c4;
             if (c4 + 0 < pitch_dw) *(u32x2_a8*)(o + 0) = u32x2_a8{v[k][0], v[k][1]};
             if (c4 + 2 < pitch_dw) *(u32x2_a8*)(o + 2) = u32x2_a8{v[k][2], v[k][3]};
+        }
+    }
+}
+
+// stage_rows_u8 for any number of rows / chunks per row, four 16-byte loads in flight per thread (same tail rule as stage_rows_load:
+// nothing outside [row, row + width) is read).  Needs width >= 16 and an even pitch_dw.
+__device__ __forceinline__ void stage_rows_wide_any(uint32_t* lds, int pitch_dw, const uint8_t* g, uint32_t gstride, int width, int rows, int tid) {
+    const int cpr = (pitch_dw + 3) >> 2, total = rows * cpr; // chunks per LDS row (the last may be partial in LDS too)
+    for (int base = 0; base < total; base += 1024) {
+        uint32_t v[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int  idx = base + tid + 256 * k, r = idx / cpr, col = (idx - r * cpr) * 16;
+            const bool live = idx < total && col < width;
+            const int  left = width - col;
+            const int  back = (live && left < 16) ? 16 - left : 0;
+            const uint8_t* p = g + (live ? (size_t)r * gstride + (size_t)(col - back) : (size_t)0);
+            const u32x4_a1 t = *(const u32x4_a1*)p;
+            uint32_t x0 = live ? t.x : 0u, x1 = live ? t.y : 0u, x2 = live ? t.z : 0u, x3 = live ? t.w : 0u;
+            if (back) {
+                if (back & 4) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
+                if (back & 8) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
+                const uint32_t bs = (uint32_t)back & 3u;
+                x0 = __builtin_amdgcn_alignbyte(x1, x0, bs);
+                x1 = __builtin_amdgcn_alignbyte(x2, x1, bs);
+                x2 = __builtin_amdgcn_alignbyte(x3, x2, bs);
+                x3 = __builtin_amdgcn_alignbyte(0u, x3, bs);
+            }
+            v[k][0] = x0; v[k][1] = x1; v[k][2] = x2; v[k][3] = x3;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = base + tid + 256 * k, r = idx / cpr, c4 = (idx - r * cpr) * 4;
+            if (idx < total) {
+                uint32_t* o = lds + r * pitch_dw + c4;
+                if (c4 + 0 < pitch_dw) *(u32x2_a8*)(o + 0) = u32x2_a8{v[k][0], v[k][1]};
+                if (c4 + 2 < pitch_dw) *(u32x2_a8*)(o + 2) = u32x2_a8{v[k][2], v[k][3]};
+            }
         }
     }
 }
@@ -381,11 +420,14 @@ __global__ __launch_bounds__(64) void sad_16b_kernel(const uint16_t* __restrict_
 }
 
 // ---- generic exhaustive search (svt_sad_loop_kernel) ----------------------------------------------------------
-// One workgroup = one (item, 64x16 position tile): 256 lanes = 16 x-groups of 4 positions x 16 rows.
-constexpr int SL_TW = 64, SL_TH = 16;
+// One workgroup = one (item, position tile of (4 << LXG) x (256 >> LXG)): 256 lanes = (1 << LXG) x-groups of 4 positions x (256 >> LXG) search
+// rows.  The host picks the narrowest tile that covers the widest search area of the batch (16, 32 or 64 positions wide), so the small HME
+// areas keep every lane busy.
+template <int LXG>
 __global__ __launch_bounds__(256) void sad_loop_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
                                                        const SvtHipSadLoopDesc* __restrict__ descs, uint32_t tiles_x,
                                                        unsigned long long* __restrict__ keys) {
+    constexpr int TW = 4 << LXG, TH = 256 >> LXG;
     HIP_DYNAMIC_SHARED(uint32_t, smem)
     __shared__ unsigned long long wg_best;
     const int               tid  = threadIdx.x;
@@ -393,54 +435,60 @@ __global__ __launch_bounds__(256) void sad_loop_kernel(const uint8_t* __restrict
     const SvtHipSadLoopDesc d    = descs[item];
     const int W = d.search_area_width, H = d.search_area_height;
     const int bw = d.block_width, bh = d.block_height;
-    const int tx0 = (int)(tile % tiles_x) * SL_TW, ty0 = (int)(tile / tiles_x) * SL_TH;
+    const int tx0 = (int)(tile % tiles_x) * TW, ty0 = (int)(tile / tiles_x) * TH;
     if (tx0 >= W || ty0 >= H) return;
-    const int Wt = (W - tx0) < SL_TW ? (W - tx0) : SL_TW;
-    const int Ht = (H - ty0) < SL_TH ? (H - ty0) : SL_TH;
-    const int src_pitch = (bw + 3) >> 2;                 // dwords
+    const int Wt = (W - tx0) < TW ? (W - tx0) : TW;
+    const int Ht = (H - ty0) < TH ? (H - ty0) : TH;
+    const int src_pitch = ((bw + 15) >> 4) << 2;        // dwords, rows 16-byte aligned
     const int win_w     = bw + Wt - 1;                   // bytes actually read by the reference
-    const int win_pitch = ((bw + SL_TW + 3) >> 2) + 2;   // dwords (covers the 4-position over-read of the last group)
+    const int win_pitch = (((bw + TW + 3) >> 2) + 3) & ~1; // dwords, even (covers the 4-position over-read of the last group)
     uint32_t* src_lds   = smem;
     uint32_t* win       = smem + src_pitch * bh;
     // source rows are src_stride apart; search rows advance by src_stride_raw, block rows by ref_stride
     // (compute_sad_c.c:72-97: `ref += src_stride_raw` per search line, `ref[... + y * ref_stride ...]` per block line)
     stage_rows_u8(src_lds, src_pitch, src_base + d.src_off, d.src_stride, bw, bh, tid, 256);
     if (tid == 0) wg_best = ~0ull;
-    // window row index = search line yy (0..Ht-1) and block line y: address = (ty0+yy)*raw + y*ref_stride.
-    // When ref_stride == src_stride_raw (full SAD) rows coincide; otherwise (sub-sampled HME: ref_stride = 2*raw)
-    // they interleave, so stage per (yy, y) pair only when needed.  General and simple: stage Ht*bh rows.
-    const bool coincide = d.ref_stride == d.src_stride_raw;
-    const int  win_rows = coincide ? (Ht + bh - 1) : Ht * bh;
-    if (coincide) {
-        stage_rows_u8(win, win_pitch, ref_base + d.ref_off + (size_t)ty0 * d.src_stride_raw + tx0, d.src_stride_raw, win_w,
-                      win_rows, tid, 256);
-    } else {
-        for (int yy = 0; yy < Ht; yy++)
-            stage_rows_u8(win + yy * bh * win_pitch, win_pitch,
-                          ref_base + d.ref_off + (size_t)(ty0 + yy) * d.src_stride_raw + tx0, d.ref_stride, win_w, bh, tid, 256);
-    }
+    // window row r of the staged tile = reference line ty0 + r (lines are src_stride_raw apart).  Search line yy, block line y reads line
+    // yy + rstep * y with rstep = ref_stride / src_stride_raw: 1 for the full SAD, 2 for the sub-sampled HME form
+    // (motion_estimation.c:891-908); the lines a tile needs are the contiguous run 0 .. Ht - 1 + rstep * (bh - 1).
+    const int rstep    = (int)(d.ref_stride / d.src_stride_raw);
+    const int win_rows = Ht + rstep * (bh - 1);
+    const uint8_t* wsrc = ref_base + d.ref_off + (size_t)ty0 * d.src_stride_raw + tx0;
+    if (win_w >= 16) stage_rows_wide_any(win, win_pitch, wsrc, d.src_stride_raw, win_w, win_rows, tid);
+    else stage_rows_u8(win, win_pitch, wsrc, d.src_stride_raw, win_w, win_rows, tid, 256);
     __syncthreads();
 
-    const int gx = tid & 15, yy = tid >> 4;
+    const int gx = tid & ((1 << LXG) - 1), yy = tid >> LXG;
     const bool skip_rule = (bw == 16) && (bh <= 16) && d.skip_search_line; // compute_sad_c.c:74-79: even lines skipped
     unsigned long long best = ~0ull;
     if (yy < Ht && 4 * gx < Wt && !(skip_rule && (((ty0 + yy) & 1) == 0))) {
         uint32_t sad[4] = {0, 0, 0, 0};
         const int full_dw = bw >> 2, tail = bw & 3;
         for (int y = 0; y < bh; y++) {
-            const uint32_t* rrow = win + (coincide ? (yy + y) : (yy * bh + y)) * win_pitch + gx;
+            const uint32_t* rrow = win + (yy + rstep * y) * win_pitch + gx;
             const uint32_t* srow = src_lds + y * src_pitch;
             unsigned long long acc = 0;
             uint32_t prev = rrow[0];
-            for (int k = 0; k < full_dw; k++) {
-                const uint32_t next = rrow[k + 1];
-                acc  = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)next << 32) | prev, srow[k], acc);
-                prev = next;
-                if ((k & 15) == 15) { // flush before a u16 lane can overflow (64 bytes * 255 = 16320 per flush)
+            int      k    = 0;
+            for (; k + 4 <= full_dw; k += 4) { // 16 source bytes per step: one ds_read_b128 (source, wave-uniform) + two ds_read2_b32 (window)
+                const u32x4_a16 sv = *(const u32x4_a16*)(srow + k);
+                const U64A4     n0 = *(const U64A4*)(rrow + k + 1), n1 = *(const U64A4*)(rrow + k + 3);
+                const uint32_t  r1 = (uint32_t)n0.v, r2 = (uint32_t)(n0.v >> 32), r3 = (uint32_t)n1.v, r4 = (uint32_t)(n1.v >> 32);
+                acc  = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)r1 << 32) | prev, sv.x, acc);
+                acc  = __builtin_amdgcn_qsad_pk_u16_u8(n0.v, sv.y, acc);
+                acc  = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)r3 << 32) | r2, sv.z, acc);
+                acc  = __builtin_amdgcn_qsad_pk_u16_u8(n1.v, sv.w, acc);
+                prev = r4;
+                if ((k & 12) == 12) { // every 64 source bytes: flush before a u16 lane can overflow (64 * 255 = 16320)
                     sad[0] += (uint32_t)acc & 0xffffu; sad[1] += (uint32_t)(acc >> 16) & 0xffffu;
                     sad[2] += (uint32_t)(acc >> 32) & 0xffffu; sad[3] += (uint32_t)(acc >> 48);
                     acc = 0;
                 }
+            }
+            for (; k < full_dw; k++) { // at most 3 dwords (48 further bytes: no overflow before the flush below)
+                const uint32_t next = rrow[k + 1];
+                acc  = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)next << 32) | prev, srow[k], acc);
+                prev = next;
             }
             sad[0] += (uint32_t)acc & 0xffffu; sad[1] += (uint32_t)(acc >> 16) & 0xffffu;
             sad[2] += (uint32_t)(acc >> 32) & 0xffffu; sad[3] += (uint32_t)(acc >> 48);
@@ -607,29 +655,32 @@ void svt_hip_sad_nxm_batch(const uint8_t* src_base, const uint8_t* ref_base, con
 }
 
 void svt_hip_sad_loop_batch(const uint8_t* src_base, const uint8_t* ref_base, const SvtHipSadLoopDesc* descs, uint32_t n,
-                            SvtHipSadLoopResult* results, uint64_t* keys, void* stream) {
+                            uint32_t max_area_width, uint32_t max_area_height, uint32_t max_block_width, uint32_t max_block_height,
+                            int max_ref_step, SvtHipSadLoopResult* results, uint64_t* keys, void* stream) {
     svthip::ensure_device();
     if (n == 0) return;
-    // geometry is taken from a host copy of the descriptors' maxima; callers with device-only descriptors pass
-    // uniform work (HME levels), so read them back once.
-    std::vector<SvtHipSadLoopDesc> h(n);
-    HIP_CHECK(hipMemcpyAsync(h.data(), descs, n * sizeof(SvtHipSadLoopDesc), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    int max_w = 1, max_h = 1, max_bw = 4, max_bh = 1, any_interleaved = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        max_w  = h[i].search_area_width > max_w ? h[i].search_area_width : max_w;
-        max_h  = h[i].search_area_height > max_h ? h[i].search_area_height : max_h;
-        max_bw = h[i].block_width > max_bw ? h[i].block_width : max_bw;
-        max_bh = h[i].block_height > max_bh ? h[i].block_height : max_bh;
-        any_interleaved |= h[i].ref_stride != h[i].src_stride_raw;
+    const int max_w = max_area_width ? (int)max_area_width : 1, max_h = max_area_height ? (int)max_area_height : 1;
+    const int max_bw = max_block_width < 4 ? 4 : (int)max_block_width, max_bh = max_block_height ? (int)max_block_height : 1;
+    // narrowest tile that covers the widest area; widen (= fewer search rows per tile) while the window does not fit 60 KB of LDS
+    int lxg = max_w <= 16 ? 2 : (max_w <= 32 ? 3 : 4);
+    size_t shmem = 0;
+    for (;; lxg++) {
+        const int tw = 4 << lxg, th = 256 >> lxg;
+        const int src_pitch = ((max_bw + 15) >> 4) << 2, win_pitch = (((max_bw + tw + 3) >> 2) + 3) & ~1;
+        const int win_rows  = th + (max_ref_step < 1 ? 1 : max_ref_step) * (max_bh - 1);
+        shmem = (size_t)(src_pitch * max_bh + win_pitch * win_rows) * 4 + 64;
+        if (shmem <= 60 * 1024 || lxg == 4) break;
     }
-    const uint32_t tiles_x   = (max_w + SL_TW - 1) / SL_TW, tiles_y = (max_h + SL_TH - 1) / SL_TH;
-    const int      src_pitch = (max_bw + 3) >> 2, win_pitch = ((max_bw + SL_TW + 3) >> 2) + 2;
-    const int      win_rows  = any_interleaved ? SL_TH * max_bh : (SL_TH + max_bh - 1);
-    const size_t   shmem     = (size_t)(src_pitch * max_bh + win_pitch * win_rows) * 4 + 64;
+    const int      tw = 4 << lxg, th = 256 >> lxg;
+    const uint32_t tiles_x = (max_w + tw - 1) / tw, tiles_y = (max_h + th - 1) / th;
     HIP_CHECK(hipMemsetAsync(keys, 0xff, (size_t)n * 8, (hipStream_t)stream));
-    hipLaunchKernelGGL(sad_loop_kernel, dim3(n, tiles_x * tiles_y), dim3(256), shmem, (hipStream_t)stream, src_base, ref_base, descs,
-                       tiles_x, (unsigned long long*)keys);
+    const dim3 grid(n, tiles_x * tiles_y);
+    if (lxg == 2)
+        hipLaunchKernelGGL(sad_loop_kernel<2>, grid, dim3(256), shmem, (hipStream_t)stream, src_base, ref_base, descs, tiles_x, (unsigned long long*)keys);
+    else if (lxg == 3)
+        hipLaunchKernelGGL(sad_loop_kernel<3>, grid, dim3(256), shmem, (hipStream_t)stream, src_base, ref_base, descs, tiles_x, (unsigned long long*)keys);
+    else
+        hipLaunchKernelGGL(sad_loop_kernel<4>, grid, dim3(256), shmem, (hipStream_t)stream, src_base, ref_base, descs, tiles_x, (unsigned long long*)keys);
     SVT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sad_loop_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, descs, n,
                        (const unsigned long long*)keys, results);
@@ -777,7 +828,8 @@ void svt_sad_loop_kernel_hip(uint8_t* src, uint32_t src_stride, uint8_t* ref, ui
     d.block_width = (uint16_t)block_width; d.block_height = (uint16_t)block_height;
     d.search_area_width = search_area_width; d.search_area_height = search_area_height; d.skip_search_line = skip_search_line;
     c.up(dd, &d, sizeof(d));
-    svt_hip_sad_loop_batch(ds, dr, dd, 1, dres, dk, c.stream);
+    svt_hip_sad_loop_batch(ds, dr, dd, 1, (uint32_t)search_area_width, (uint32_t)search_area_height, block_width, block_height, (int)step, dres, dk,
+                           c.stream);
     SvtHipSadLoopResult r;
     c.down(&r, dres, sizeof(r));
     *best_sad = r.best_sad;

@@ -138,6 +138,40 @@ def test_sad_loop_subsampled_hme_form(be, oracle):
         assert (bs0.value, x0.value, y0.value) == (bs1.value, x1.value, y1.value)
 
 
+def test_sad_loop_batch_mixed(be, oracle):
+    """svt_hip_sad_loop_batch: many searches of different block sizes / areas in one launch (HME level shapes), every tile shape the host
+    can pick (areas up to 16, 32, 64 wide and multi-tile), full and sub-sampled forms mixed."""
+    g = rng(21)
+    rows, stride = 220, 300
+    plane = g.integers(0, 256, rows * stride, dtype=np.uint8)
+    src = g.integers(0, 256, 128 * 128, dtype=np.uint8)
+    for (maxw, maxh) in ([(16, 16), (32, 16), (64, 20), (100, 40)] if be.is_gpu else [(16, 9), (24, 5)]):
+        shapes = [(16, 16), (32, 32), (8, 8), (64, 64), (16, 8), (24, 12), (128, 64)] if be.is_gpu else [(16, 16), (8, 8), (24, 12)]
+        descs = np.zeros(len(shapes) * 3, dtype=be.pkg.SadLoopDesc)
+        want = []
+        for i in range(len(descs)):
+            bw, bh = shapes[i % len(shapes)]
+            aw, ah = int(g.integers(1, maxw + 1)), int(g.integers(1, maxh + 1))
+            sub = (i % 3 == 2)
+            rs = stride * (2 if sub else 1)
+            hh = bh // 2 if sub else bh
+            x0, y0 = int(g.integers(0, stride - bw - aw)), int(g.integers(0, rows - (hh - 1) * (2 if sub else 1) - ah - 1))
+            descs[i] = (int(g.integers(0, 64)), y0 * stride + x0, 128 * (2 if sub else 1), rs, stride, bw, hh, aw, ah, int(bw == 16 and i % 2), (0, 0, 0))
+            bs, xs, ys = C.c_uint64(0), C.c_int16(0), C.c_int16(0)
+            oracle.oracle_sad_loop(C.c_void_p(src.ctypes.data + int(descs[i]["src_off"])), int(descs[i]["src_stride"]), C.c_void_p(plane.ctypes.data + int(descs[i]["ref_off"])), rs, hh, bw,
+                                   C.byref(bs), C.byref(xs), C.byref(ys), stride, int(descs[i]["skip_search_line"]), aw, ah)
+            want.append((bs.value, xs.value, ys.value))
+        d_src, d_pl, d_d = be.dev(src), be.dev(plane), be.dev(descs)
+        res, keys = be.empty(len(descs), be.pkg.SadLoopResult), be.empty(len(descs), np.uint64)
+        be.lib.svt_hip_sad_loop_batch(be.ptr(d_src), be.ptr(d_pl), be.ptr(d_d), len(descs), maxw, maxh, 128, 64, 2, be.ptr(res), be.ptr(keys), be.stream)
+        got = be.host(res)
+        for i in range(len(descs)):
+            if want[i][0] == 0xffffff:
+                assert int(got[i]["best_sad"]) == 0xffffff
+            else:
+                assert (int(got[i]["best_sad"]), int(got[i]["x"]), int(got[i]["y"])) == want[i], (maxw, maxh, i, descs[i])
+
+
 ME_AREAS = [(16, 9), (8, 3), (15, 6), (64, 32), (21, 5), (1, 1), (70, 35), (130, 40)]
 
 
