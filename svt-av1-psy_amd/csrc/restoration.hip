@@ -52,15 +52,71 @@ __device__ __forceinline__ int src_px(const TileSrc& s, int y, int x) {
     }
     return rd_px(s.data, s.highbd, (size_t)y * s.stride + x);
 }
-// tile[(r) * TW + c] <- pixel (y0 - 3 + r, x0 - 3 + c), r < uh + 6, c < uw + 8 (the extra columns feed tap 7, always x 0)
+// Source row of plane row y for this unit (restoration.c:288-332 stripe boundary substitution + svt_extend_frame row replication); the
+// column is clamped by the caller.  Raw mode (w == 0): the block's own rows.
+__device__ __forceinline__ const void* src_row(const TileSrc& s, const int y) {
+    const size_t px = s.highbd ? 2 : 1;
+    if (s.w == 0) return (const uint8_t*)s.data + (long long)y * s.stride * (long long)px;
+    if (y < s.stripe_top && s.stripe_top != 0) {
+        const int i = y - s.stripe_top;
+        return (const uint8_t*)s.above + (size_t)(2 * s.stripe_idx + (i + 2 > 0 ? i + 2 : 0)) * s.bstride * px;
+    }
+    if (y >= s.stripe_bot && s.stripe_bot < s.h) {
+        const int i = y - s.stripe_bot;
+        return (const uint8_t*)s.below + (size_t)(2 * s.stripe_idx + (i < 1 ? i : 1)) * s.bstride * px;
+    }
+    return (const uint8_t*)s.data + (size_t)clampi(y, 0, s.h - 1) * s.stride * px;
+}
+struct __attribute__((packed, aligned(2))) LrRow8A2 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) LrRow8A1 { uint32_t v[2]; };
+struct __attribute__((aligned(16))) LrRow8A16 { uint32_t v[4]; };
+// tile[(r) * TW + c] <- pixel (y0 - 3 + r, x0 - 3 + c), r < uh + 6, c < uw + 6, zero beyond (the extra columns feed tap 7, always x 0).
+// A thread owns 8-pixel chunks (9 per row); chunks that lie inside the plane are fetched with one vector load each, all issued before the
+// first LDS store, so a workgroup pays one memory round trip; only chunks that cross the plane's left / right edge or the unit's last
+// column go pixel by pixel.
 __device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, const int tid) {
-    const int rows = s.uh + 6, cols = s.uw + 6;
-    for (int i = tid; i < rows * TW; i += 256) {
-        const int r = i / TW, c = i - r * TW;
-        tile[i]     = c < cols ? (uint16_t)src_px(s, s.y0 - 3 + r, s.x0 - 3 + c) : (uint16_t)0;
+    const int rows = s.uh + 6, cols = s.uw + 6, total = rows * 9;
+    uint32_t  v[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int  i = tid + 256 * k, r = i / 9, c = i - r * 9;
+        const int  x = s.x0 - 3 + 8 * c;
+        const bool fast = i < total && 8 * c + 8 <= cols && (s.w == 0 || (x >= 0 && x + 8 <= s.w));
+        const uint8_t* row = (const uint8_t*)src_row(s, s.y0 - 3 + (i < total ? r : 0));
+        const uint8_t* p   = fast ? row + (long long)x * (s.highbd ? 2 : 1) : (const uint8_t*)src_row(s, s.y0);
+        if (s.highbd) {
+            const LrRow8A2 t = *(const LrRow8A2*)p;
+            v[k][0] = t.v[0]; v[k][1] = t.v[1]; v[k][2] = t.v[2]; v[k][3] = t.v[3];
+        } else {
+            const LrRow8A1 t = *(const LrRow8A1*)p;
+            v[k][0] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c010c00u); v[k][1] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c030c02u);
+            v[k][2] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c010c00u); v[k][3] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c030c02u);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = tid + 256 * k, r = i / 9, c = i - r * 9;
+        if (i >= total) continue;
+        const int  x = s.x0 - 3 + 8 * c;
+        const bool fast = 8 * c + 8 <= cols && (s.w == 0 || (x >= 0 && x + 8 <= s.w));
+        if (!fast) {
+            const void* row = src_row(s, s.y0 - 3 + r);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uint32_t px[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int cc = 8 * c + 2 * e + h;
+                    int       xx = x + 2 * e + h;
+                    if (s.w != 0) xx = clampi(xx, 0, s.w - 1);
+                    px[h] = cc < cols ? (uint32_t)rd_px(row, s.highbd, (size_t)0 + (long long)xx) : 0u;
+                }
+                v[k][e] = px[0] | (px[1] << 16);
+            }
+        }
+        *(LrRow8A16*)(tile + r * TW + 8 * c) = LrRow8A16{{v[k][0], v[k][1], v[k][2], v[k][3]}};
     }
 }
-
 struct WienerTaps { int16_t fx[8], fy[8]; };
 // Wiener on a staged tile: horizontal pass (clamped, convolve.c:63-83 / :156-176) into `mid`, vertical pass to `out(y, x)`
 template <typename OUT> __device__ __forceinline__ void wiener_tile(const uint16_t* tile, uint16_t* mid, const WienerTaps& t, const int uw, const int uh,
@@ -94,32 +150,64 @@ template <typename OUT> __device__ __forceinline__ void wiener_tile(const uint16
 
 // Self-guided filter on a staged tile.  AB holds A then B for positions (i, j) in [-1, uh] x [-1, uw] (pitch 66).
 // pass 0: r = 2, A/B on odd i only ("fast", restoration.c:669-800); pass 1: r = 1 (restoration.c:801-880).
-__device__ __forceinline__ void sgr_ab_pass(const uint16_t* tile, int32_t* AB, const int pass, const int idx, const int uw, const int uh, const int bd,
-                                            const int tid) {
+typedef unsigned short lr_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lr_dot2(const uint32_t a, const uint32_t b, const uint32_t c) { // c + a.lo * b.lo + a.hi * b.hi (v_dot2_u32_u16)
+    lr_us2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    return __builtin_amdgcn_udot2(x, y, c, false);
+}
+struct __attribute__((aligned(4))) LrDw3 { uint32_t d0, d1, d2; };
+// Box sums for TWO horizontally adjacent A/B positions per thread: the union of their (2r+1)-wide windows is six pixels = three aligned
+// dwords of a tile row, so a row costs two LDS reads and a handful of v_dot2_u32_u16 (sum: multiply by {1,1}; sum of squares: by itself)
+// instead of 2 x (2r+1) scalar reads.  xlut = svt_aom_eb_x_by_xplus1 built once per workgroup (the table entries need an integer division).
+__device__ __forceinline__ void sgr_ab_pass(const uint16_t* tile, uint16_t* A16, int32_t* B32, const uint16_t* xlut, const int pass, const int idx, const int uw,
+                                            const int uh, const int bd, const int tid) {
     const int      r = kSgrR[idx][pass];
     const uint32_t s = (uint32_t)kSgrS[idx][pass], n = (uint32_t)((2 * r + 1) * (2 * r + 1)), obx = one_by_x(n);
-    for (int e = tid; e < 66 * 66; e += 256) {
-        const int ii = e / 66, jj = e - ii * 66; // i = ii - 1, j = jj - 1
+    const int      nrows = pass == 0 ? 33 : 66; // pass 0 only needs the positions with ii even (i = ii - 1 odd)
+    for (int e = tid; e < nrows * 33; e += 256) {
+        const int rr = e / 33, jj = (e - rr * 33) * 2, ii = pass == 0 ? 2 * rr : rr; // i = ii - 1, j = jj - 1 (and jj)
         if (ii > uh + 1 || jj > uw + 1) continue;
-        if (pass == 0 && (ii & 1)) continue;    // i even -> not needed by the fast filter (i = ii - 1 odd <=> ii even)
-        const uint16_t* p = tile + (ii + 2) * TW + (jj + 2); // pixel (i, j) sits at tile[(i + 3) * TW + j + 3]
-        uint32_t        sum = 0, sq = 0;
-        for (int dy = -r; dy <= r; dy++)
-            for (int dx = -r; dx <= r; dx++) {
-                const uint32_t v = p[dy * TW + dx];
-                sum += v;
-                sq += v * v;
+        const uint16_t* p = tile + (ii + 2 - r) * TW + jj; // first of the six pixels jj .. jj + 5 of the window's top row (dword aligned)
+        uint32_t tot = 0, tot2 = 0, ea = 0, ea2 = 0, eb = 0, eb2 = 0; // r = 2: totals over six pixels minus an edge; r = 1: centre pair plus an edge
+        for (int dy = 0; dy <= 2 * r; dy++) {
+            const LrDw3 v = *(const LrDw3*)(p + dy * TW);
+            if (r == 2) {
+                tot  = lr_dot2(v.d0, 0x00010001u, lr_dot2(v.d1, 0x00010001u, lr_dot2(v.d2, 0x00010001u, tot)));
+                tot2 = lr_dot2(v.d0, v.d0, lr_dot2(v.d1, v.d1, lr_dot2(v.d2, v.d2, tot2)));
+                ea   = lr_dot2(v.d2, 0x00010000u, ea);            // pixel 5: not in the left window
+                ea2  = lr_dot2(v.d2 & 0xffff0000u, v.d2, ea2);
+                eb   = lr_dot2(v.d0, 0x00000001u, eb);            // pixel 0: not in the right window
+                eb2  = lr_dot2(v.d0 & 0x0000ffffu, v.d0, eb2);
+            } else {
+                tot  = lr_dot2(v.d1, 0x00010001u, tot);           // pixels 2, 3: in both windows
+                tot2 = lr_dot2(v.d1, v.d1, tot2);
+                ea   = lr_dot2(v.d0, 0x00010000u, ea);            // pixel 1: left window only
+                ea2  = lr_dot2(v.d0 & 0xffff0000u, v.d0, ea2);
+                eb   = lr_dot2(v.d2, 0x00000001u, eb);            // pixel 4: right window only
+                eb2  = lr_dot2(v.d2 & 0x0000ffffu, v.d2, eb2);
             }
-        const uint32_t a = rpotu(sq, 2 * (bd - 8)), b = rpotu(sum, bd - 8);
-        const uint32_t pp = (a * n < b * b) ? 0 : a * n - b * b;
-        const uint32_t z  = rpotu(pp * s, 20);
-        const int      av = x_by_xplus1(z > 255 ? 255 : z);
-        AB[e]             = av;
-        AB[66 * 66 + e]   = (int32_t)rpotu((uint32_t)(256 - av) * sum * obx, 12);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t sum = r == 2 ? tot - (h ? eb : ea) : tot + (h ? eb : ea);
+            const uint32_t sq  = r == 2 ? tot2 - (h ? eb2 : ea2) : tot2 + (h ? eb2 : ea2);
+            const uint32_t a = rpotu(sq, 2 * (bd - 8)), b = rpotu(sum, bd - 8);
+            const uint32_t pp = (a * n < b * b) ? 0 : a * n - b * b;
+            const uint32_t z  = rpotu(pp * s, 20);
+            const int      av = xlut[z > 255 ? 255 : z];
+            const int      o  = ii * 66 + jj + h;
+            if (jj + h < 66) {
+                A16[o] = (uint16_t)av; // 1 .. 256
+                B32[o] = (int32_t)rpotu((uint32_t)(256 - av) * sum * obx, 12);
+            }
+        }
     }
 }
-__device__ __forceinline__ int32_t sgr_flt_px(const uint16_t* tile, const int32_t* AB, const int pass, const int i, const int j) {
-    const int32_t *A = AB + (i + 1) * 66 + (j + 1), *B = A + 66 * 66;
+__device__ __forceinline__ int32_t sgr_flt_px(const uint16_t* tile, const uint16_t* A16, const int32_t* B32, const int pass, const int i, const int j) {
+    const uint16_t* A = A16 + (i + 1) * 66 + (j + 1);
+    const int32_t*  B = B32 + (i + 1) * 66 + (j + 1);
     int32_t        a, b, nb;
     if (pass == 0) {
         if (!(i & 1)) {
@@ -140,29 +228,36 @@ __device__ __forceinline__ int32_t sgr_flt_px(const uint16_t* tile, const int32_
     return rpot(v, 8 + nb - 4);
 }
 
-// flt[] (int32, pitch 64) is produced per pass; MODE_APPLY combines with xqd (svt_apply_selfguided_restoration_c :957-992)
+// The r = 2 output of a thread's sixteen pixels (i = tid + 256 k) stays in registers until the r = 1 pass has its A / B tables; MODE_APPLY
+// combines with xqd (svt_apply_selfguided_restoration_c :957-992)
 template <typename OUT0, typename OUT1>
-__device__ __forceinline__ void sgr_tile(const uint16_t* tile, int32_t* AB, int32_t* flt0, const int idx, const int uw, const int uh, const int bd,
-                                         const int tid, OUT0 out_flt0, OUT1 out_flt1_or_apply) {
+__device__ __forceinline__ void sgr_tile(const uint16_t* tile, uint16_t* A16, int32_t* B32, uint16_t* xlut, const int idx, const int uw, const int uh,
+                                         const int bd, const int tid, OUT0 out_flt0, OUT1 out_flt1_or_apply) {
     const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
+    xlut[tid] = (uint16_t)x_by_xplus1((uint32_t)tid); // 256 threads, 256 entries
+    __syncthreads();
+    int32_t f0[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) f0[k] = 0;
     if (p0) {
-        sgr_ab_pass(tile, AB, 0, idx, uw, uh, bd, tid);
+        sgr_ab_pass(tile, A16, B32, xlut, 0, idx, uw, uh, bd, tid);
         __syncthreads();
-        for (int i = tid; i < uh * 64; i += 256) {
-            const int r = i >> 6, c = i & 63;
-            if (c < uw) {
-                const int32_t f = sgr_flt_px(tile, AB, 0, r, c);
-                flt0[i]         = f;
-                out_flt0(r, c, f);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = tid + 256 * k, r = i >> 6, c = i & 63;
+            if (r < uh && c < uw) {
+                f0[k] = sgr_flt_px(tile, A16, B32, 0, r, c);
+                out_flt0(r, c, f0[k]);
             }
         }
         __syncthreads();
     }
-    if (p1) sgr_ab_pass(tile, AB, 1, idx, uw, uh, bd, tid);
+    if (p1) sgr_ab_pass(tile, A16, B32, xlut, 1, idx, uw, uh, bd, tid);
     __syncthreads();
-    for (int i = tid; i < uh * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        if (c < uw) out_flt1_or_apply(r, c, p0 ? flt0[i] : 0, p1 ? sgr_flt_px(tile, AB, 1, r, c) : 0);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int i = tid + 256 * k, r = i >> 6, c = i & 63;
+        if (r < uh && c < uw) out_flt1_or_apply(r, c, f0[k], p1 ? sgr_flt_px(tile, A16, B32, 1, r, c) : 0);
     }
 }
 __device__ __forceinline__ int sgr_combine(const int px, const int32_t f0, const int32_t f1, const int idx, const int32_t xqd0, const int32_t xqd1, const int bd) {
@@ -179,15 +274,18 @@ __device__ __forceinline__ int sgr_combine(const int px, const int32_t f0, const
 }
 
 constexpr int kSgrRH[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {2, 0}, {2, 0}}; // host copy
-constexpr size_t LR_SMEM = (size_t)TH * TW * 2 + (size_t)TH * 64 * 2 + (size_t)2 * 66 * 66 * 4 + (size_t)64 * 64 * 4;
+// LDS: tile | union { Wiener mid (u16 [TH][64]) ; self-guided A (u16 [66][66], padded to a dword multiple) + B (i32 [66][66]) } = 36.2 KB -> 4 workgroups / CU
+constexpr size_t LR_A_BYTES = (size_t)66 * 66 * 2 + 8;
+constexpr size_t LR_SMEM    = (size_t)TH * TW * 2 + LR_A_BYTES + (size_t)66 * 66 * 4 + 512; // + x_by_xplus1 table
 
 // ---- frame kernel ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
     uint16_t* tile = smem;
-    uint16_t* mid  = tile + TH * TW;
-    int32_t*  AB   = (int32_t*)(mid + TH * 64);
-    int32_t*  flt0 = AB + 2 * 66 * 66;
+    uint16_t* mid  = tile + TH * TW;                           // Wiener only
+    uint16_t* A16  = mid;                                      // self-guided only (aliases mid)
+    int32_t*  B32  = (int32_t*)((uint8_t*)mid + LR_A_BYTES);
+    uint16_t* xlut = (uint16_t*)(B32 + 66 * 66);
     const int tid = threadIdx.x;
     const int pw = (int)P.width, ph = (int)P.height, off = 8 >> P.ss_y, sh = 64 >> P.ss_y, cw = 64 >> P.ss_x;
     TileSrc s;
@@ -222,7 +320,7 @@ __global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P) {
         wiener_tile(tile, mid, t, s.uw, s.uh, bd, tid, store);
     } else if (u.rtype == 2) {
         const int idx = u.ep & 15;
-        sgr_tile(tile, AB, flt0, idx, s.uw, s.uh, bd, tid, [](int, int, int32_t) {},
+        sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, bd, tid, [](int, int, int32_t) {},
                  [&](int r, int c, int32_t f0, int32_t f1) { store(r, c, sgr_combine(tile[(r + 3) * TW + c + 3], f0, f1, idx, u.xqd[0], u.xqd[1], bd)); });
     } else {
         for (int i = tid; i < s.uh * 64; i += 256) {
@@ -239,9 +337,10 @@ __global__ __launch_bounds__(256) void lr_block_kernel(const void* src /* origin
                                                        int fstride) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
     uint16_t* tile = smem;
-    uint16_t* mid  = tile + TH * TW;
-    int32_t*  AB   = (int32_t*)(mid + TH * 64);
-    int32_t*  flt0 = AB + 2 * 66 * 66;
+    uint16_t* mid  = tile + TH * TW;                           // Wiener only
+    uint16_t* A16  = mid;                                      // self-guided only (aliases mid)
+    int32_t*  B32  = (int32_t*)((uint8_t*)mid + LR_A_BYTES);
+    uint16_t* xlut = (uint16_t*)(B32 + 66 * 66);
     const int tid = threadIdx.x;
     TileSrc s;
     s.data = src; s.above = s.below = nullptr; s.stride = sstride; s.bstride = 0; s.w = 0; s.h = 0; s.highbd = highbd;
@@ -258,11 +357,11 @@ __global__ __launch_bounds__(256) void lr_block_kernel(const void* src /* origin
     if (kind == 0) {
         wiener_tile(tile, mid, taps, s.uw, s.uh, bd, tid, store);
     } else if (kind == 1) {
-        sgr_tile(tile, AB, flt0, idx, s.uw, s.uh, bd, tid, [](int, int, int32_t) {},
+        sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, bd, tid, [](int, int, int32_t) {},
                  [&](int r, int c, int32_t a, int32_t b) { store(r, c, sgr_combine(tile[(r + 3) * TW + c + 3], a, b, idx, xqd0, xqd1, bd)); });
     } else {
         const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
-        sgr_tile(tile, AB, flt0, idx, s.uw, s.uh, bd, tid, [&](int r, int c, int32_t v) { if (p0) f0out[(size_t)(y0 + r) * fstride + x0 + c] = v; },
+        sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, bd, tid, [&](int r, int c, int32_t v) { if (p0) f0out[(size_t)(y0 + r) * fstride + x0 + c] = v; },
                  [&](int r, int c, int32_t, int32_t b) { if (p1) f1out[(size_t)(y0 + r) * fstride + x0 + c] = b; });
     }
 }

@@ -1,6 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT SQ_WAVES_EQ_64"; do
-  tag=$(echo $set | cut -c1-12 | tr ' ' '_')
-  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc16_$tag -o run -- python bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/r16_pmc_$tag.log 2>&1; echo "pmc $tag rc=$?"
-done
+timeout 900 python -m pytest tests/test_restoration.py -m gpu -x -q 2>&1 | tail -3
+python tools/microbench.py lr > gpurun_out/r18_micro.json 2> gpurun_out/r18_micro.err; echo "micro rc=$?"; tail -c 300 gpurun_out/r18_micro.err; cat gpurun_out/r18_micro.json | cut -c1-1500
