@@ -216,10 +216,13 @@ __global__ __launch_bounds__(256) void inv_txfm2d_kernel(const int32_t* __restri
         const int32_t mx = (1 << bd) - 1;
 #pragma unroll
         for (int r = 0; r < H; r++) {
-            const int32_t res = rshift_round(v[kUdFlip[tx] ? (H - 1 - r) : r], 4);
-            int32_t       px  = (int32_t)((uint32_t)pr[(size_t)r * d.pred_stride] + (uint32_t)res);
+            // up-down flip (inv_transforms.c:2509-2527): output row rr takes v[H - 1 - rr]; flip the ADDRESS, never the register index
+            // (a run-time index into v[] turns into an H-way select chain per row)
+            const int     rr  = kUdFlip[tx] ? (H - 1 - r) : r;
+            const int32_t res = rshift_round(v[r], 4);
+            int32_t       px  = (int32_t)((uint32_t)pr[(size_t)rr * d.pred_stride] + (uint32_t)res);
             px                = px < 0 ? 0 : (px > mx ? mx : px);
-            rc[(size_t)r * d.recon_stride] = (PIX)px;
+            rc[(size_t)rr * d.recon_stride] = (PIX)px;
         }
     }
 }

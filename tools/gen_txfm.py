@@ -273,7 +273,7 @@ def main():
           "template <int CB> __device__ __forceinline__ int32_t half_btf(const int32_t w0, const int32_t a, const int32_t w1, const int32_t b) {",
           "    const int64_t r = (int64_t)w0 * (int64_t)a + (int64_t)w1 * (int64_t)b + ((int64_t)1 << (CB - 1));",
           "    return (int32_t)(r >> CB);", "}",
-          "__device__ __forceinline__ int32_t clamp_i32(const int32_t x, const int32_t lo, const int32_t hi) { return x < lo ? lo : (x > hi ? hi : x); }",
+          "__device__ __forceinline__ int32_t clamp_i32(const int32_t x, const int32_t lo, const int32_t hi) { const int32_t t = x > lo ? x : lo; return t < hi ? t : hi; } // v_max_i32 + v_min_i32 (lo <= hi)",
           "#define C(k) kCospi[CB - 10][k]", "#define HB(w0, a, w1, b) half_btf<CB>(w0, a, w1, b)",
           "// inverse adds: the C code adds in int32 (wrapping) and then clamps the int32 value (inv_transforms.c:86-92)",
           "#define ADD(a, b) ((int32_t)((uint32_t)(a) + (uint32_t)(b)))", "#define SUB(a, b) ((int32_t)((uint32_t)(a) - (uint32_t)(b)))",
