@@ -198,3 +198,37 @@ def picprep(torch, lib, pkg, stream, steps, warmup, nframes=32):
     return {"picprep_1080p": {"frames_per_s": nframes / t, "us_per_frame": t / nframes * 1e6,
                               "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS,
                                            "algorithmic_bytes_per_frame": nbytes // nframes, "note": "three launches per frame; launch-latency bound at 1080p"}}}
+
+
+def deblock(torch, lib, pkg, stream, steps, warmup):
+    """deblocking of a 3840x2160 10-bit luma plane, edges on a 16-sample grid with 14-tap filters in even 4-sample segments and on an
+    8-sample grid with 8-tap filters in odd ones, vertical pass then horizontal pass = two launches per frame."""
+    w, h, bd = 3840, 2160, 10
+    g = np.random.default_rng(6)
+    yy, xx = np.mgrid[0:h, 0:w]
+    plane = np.clip(((xx * 3 + yy * 2) % 1024) // 2 + ((xx // 8 + yy // 8) % 2) * 6 + g.integers(0, 3, (h, w)), 0, 1023).astype(np.uint16)
+    passes = []
+    for vert in (1, 0):
+        # even 4-sample segments: 16-sample grid with 14-tap filters; odd segments: 8-sample grid with 8-tap filters (a legal, overlap-free layout)
+        along_n, across_n = (h, w) if vert else (w, h)
+        parts = []
+        for par, grid, length in ((0, 16, 14), (1, 8, 8)):
+            cs, as_ = np.meshgrid(np.arange(grid, across_n, grid), np.arange(4 * par, along_n, 8))
+            parts.append((cs.ravel(), as_.ravel(), np.full(cs.size, length)))
+        cs, as_, ln = (np.concatenate([q[i] for q in parts]) for i in range(3))
+        xs, ys = (cs, as_) if vert else (as_, cs)
+        e = np.zeros(xs.size, dtype=pkg.LpfEdge)
+        e["x"], e["y"], e["vertical"], e["length"] = xs.ravel(), ys.ravel(), vert, ln.ravel()
+        e["blimit"], e["limit"], e["thresh"] = 60, 12, 2
+        passes.append((_dev(torch, e), len(e)))
+    d_plane = _dev(torch, plane)
+
+    def fn():
+        for d_e, n in passes:
+            lib.svt_hip_lpf_edges_batch(d_plane.data_ptr(), w, 1, bd, d_e.data_ptr(), n, stream)
+    t = _time(torch, fn, steps, warmup)
+    nedges = sum(n for _, n in passes)
+    nbytes = 2 * (w * h * 2 * 2) + nedges * 16  # each pass reads and writes (nearly) every sample once + the edge list
+    return {"deblock_4k10": {"frames_per_s": 1 / t, "ms": t * 1e3, "Medges_s": nedges / t / 1e6,
+                             "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS,
+                                          "algorithmic_bytes_per_frame": nbytes}}}

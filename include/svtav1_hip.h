@@ -228,6 +228,29 @@ void svt_hip_downsample_2d_padded(const uint8_t *in_origin, uint32_t in_stride, 
 /* svt_aom_generate_padding on a device plane, in place: `base` = top-left of the padded plane */
 void svt_hip_generate_padding(uint8_t *base, uint32_t stride, uint32_t width, uint32_t height, uint32_t pad_x, uint32_t pad_y, void *stream);
 
+/* --------------------------------------------------- deblocking edge filters ---------------------- */
+/* svt_aom_lpf_{horizontal,vertical}_{4,6,8,14} / svt_aom_highbd_lpf_* -> `_c` (common_dsp_rtcd.h:1037-1067, Codec/deblocking_common.c:141-865).
+ * Batched form: n edge segments of 4 samples over a device plane; (x, y) = the q0 sample of the segment's first position; vertical = 1 for a
+ * column boundary (filtering along x); length in {4, 6, 8, 14}; blimit / limit / thresh as the reference's per-edge LoopFilterThresh bytes.
+ * Segments of one launch must not overlap (the reference filters all vertical edges of a picture before the horizontal ones). */
+typedef struct SvtHipLpfEdge {
+    uint32_t x, y;
+    uint8_t  vertical, length, blimit, limit, thresh, pad[3];
+} SvtHipLpfEdge; /* 16 bytes */
+void svt_hip_lpf_edges_batch(void *plane, uint32_t stride, int is_16bit, int bd, const SvtHipLpfEdge *edges, uint32_t n, void *stream);
+#define SVT_HIP_LPF_DECL(LEN)                                                                                                              \
+    void svt_aom_lpf_horizontal_##LEN##_hip(uint8_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh); \
+    void svt_aom_lpf_vertical_##LEN##_hip(uint8_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh);   \
+    void svt_aom_highbd_lpf_horizontal_##LEN##_hip(uint16_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit,                 \
+                                                   const uint8_t *thresh, int32_t bd);                                                     \
+    void svt_aom_highbd_lpf_vertical_##LEN##_hip(uint16_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit,                   \
+                                                 const uint8_t *thresh, int32_t bd);
+SVT_HIP_LPF_DECL(4)
+SVT_HIP_LPF_DECL(6)
+SVT_HIP_LPF_DECL(8)
+SVT_HIP_LPF_DECL(14)
+#undef SVT_HIP_LPF_DECL
+
 /* ---------------------------------------------------------------- CDEF (a17-a20) --------------------- */
 /* One plane of one frame.  Filter-block grid = ceil(width / (64 >> xdec)) x ceil(height / (64 >> ydec)); tile
  * construction as cdef_seg_search (cdef_process.c:208-228).  Call once per plane, luma first (it produces dir/var). */

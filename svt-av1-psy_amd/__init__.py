@@ -60,6 +60,7 @@ PROTOTYPES = {
     "svt_hip_generate_padding": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "svt_hip_cdef_search_one_dual": (None, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "svt_search_one_dual_hip": (C.c_uint64, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
+    "svt_hip_lpf_edges_batch": (None, [vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_uint32, vp]),
     "svt_hip_sad_nxm_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_sad_loop_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -124,6 +125,14 @@ PROTOTYPES.update({
 for _n in ("64x64", "32x64", "64x32", "16x64", "64x16"):
     PROTOTYPES["svt_handle_transform%s_hip" % _n] = (C.c_uint64, [vp])
     PROTOTYPES["svt_handle_transform%s_N2_N4_hip" % _n] = (C.c_uint64, [vp])
+
+
+LpfEdge = np.dtype([("x", "<u4"), ("y", "<u4"), ("vertical", "u1"), ("length", "u1"), ("blimit", "u1"), ("limit", "u1"), ("thresh", "u1"), ("pad", "u1", (3,))])
+assert LpfEdge.itemsize == 16
+for _len in (4, 6, 8, 14):
+    for _d in ("horizontal", "vertical"):
+        PROTOTYPES["svt_aom_lpf_%s_%d_hip" % (_d, _len)] = (None, [vp, C.c_int32, vp, vp, vp])
+        PROTOTYPES["svt_aom_highbd_lpf_%s_%d_hip" % (_d, _len)] = (None, [vp, C.c_int32, vp, vp, vp, C.c_int32])
 
 
 class Mv(C.Structure):
