@@ -279,23 +279,32 @@ constexpr size_t LR_A_BYTES = (size_t)66 * 66 * 2 + 8;
 constexpr size_t LR_SMEM    = (size_t)TH * TW * 2 + LR_A_BYTES + (size_t)66 * 66 * 4 + 512; // + x_by_xplus1 table
 
 // ---- frame kernel ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P) {
+// One workgroup = 64 >> ss_x columns x at most LR_UR rows of one stripe (a 64-row luma stripe is cut in two: twice the workgroups, half the
+// LDS -> 8 resident workgroups per CU to hide the staging round trip; the cut is invisible to the filters because the rows on the far
+// side of it are ordinary rows of the same stripe).
+constexpr int    LR_UR        = 32;
+constexpr size_t LR_FRAME_A   = (size_t)(LR_UR + 2) * 66 * 2 + 8;
+constexpr size_t LR_FRAME_MID = (size_t)(LR_UR + 6) * 64 * 2;
+constexpr size_t LR_FRAME_AB  = LR_FRAME_A + (size_t)(LR_UR + 2) * 66 * 4;
+constexpr size_t LR_FRAME_SMEM = (size_t)(LR_UR + 6) * TW * 2 + (LR_FRAME_AB > LR_FRAME_MID ? LR_FRAME_AB : LR_FRAME_MID) + 512;
+__global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, const int nsplit) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
     uint16_t* tile = smem;
-    uint16_t* mid  = tile + TH * TW;                           // Wiener only
+    uint16_t* mid  = tile + (LR_UR + 6) * TW;                  // Wiener only
     uint16_t* A16  = mid;                                      // self-guided only (aliases mid)
-    int32_t*  B32  = (int32_t*)((uint8_t*)mid + LR_A_BYTES);
-    uint16_t* xlut = (uint16_t*)(B32 + 66 * 66);
+    int32_t*  B32  = (int32_t*)((uint8_t*)mid + LR_FRAME_A);
+    uint16_t* xlut = (uint16_t*)((uint8_t*)mid + (LR_FRAME_AB > LR_FRAME_MID ? LR_FRAME_AB : LR_FRAME_MID));
     const int tid = threadIdx.x;
     const int pw = (int)P.width, ph = (int)P.height, off = 8 >> P.ss_y, sh = 64 >> P.ss_y, cw = 64 >> P.ss_x;
     TileSrc s;
     s.data = P.data; s.above = P.boundary_above; s.below = P.boundary_below;
     s.stride = (int)P.stride; s.bstride = (int)P.boundary_stride; s.w = pw; s.h = ph; s.highbd = P.highbd;
-    s.stripe_idx = blockIdx.y;
+    s.stripe_idx = blockIdx.y / nsplit;
     s.stripe_top = s.stripe_idx * sh - off < 0 ? 0 : s.stripe_idx * sh - off;
     s.stripe_bot = (s.stripe_idx + 1) * sh - off > ph ? ph : (s.stripe_idx + 1) * sh - off;
-    s.x0 = blockIdx.x * cw; s.y0 = s.stripe_top;
-    s.uw = pw - s.x0 < cw ? pw - s.x0 : cw; s.uh = s.stripe_bot - s.stripe_top;
+    s.x0 = blockIdx.x * cw; s.y0 = s.stripe_top + (int)(blockIdx.y % nsplit) * LR_UR;
+    s.uw = pw - s.x0 < cw ? pw - s.x0 : cw;
+    s.uh = s.stripe_bot - s.y0 < LR_UR ? s.stripe_bot - s.y0 : LR_UR;
     if (s.uh <= 0 || s.uw <= 0) return;
     const int us  = (int)P.unit_size;
     int       nvu = (ph + (us >> 1)) / us, nhu = (pw + (us >> 1)) / us;
@@ -409,7 +418,8 @@ void svt_hip_lr_filter_frame(const SvtHipLrParams* params, void* stream) {
     const int sh = 64 >> P.ss_y, off = 8 >> P.ss_y, cw = 64 >> P.ss_x;
     const int n_stripes = ((int)P.height + off + sh - 1) / sh;
     const int n_cols    = ((int)P.width + cw - 1) / cw;
-    hipLaunchKernelGGL(lr_frame_kernel, dim3(n_cols, n_stripes), dim3(256), LR_SMEM, (hipStream_t)stream, P);
+    const int nsplit    = (sh + LR_UR - 1) / LR_UR;
+    hipLaunchKernelGGL(lr_frame_kernel, dim3(n_cols, n_stripes * nsplit), dim3(256), LR_FRAME_SMEM, (hipStream_t)stream, P, nsplit);
     SVT_LAUNCH_CHECK();
 }
 

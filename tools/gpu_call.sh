@@ -1,4 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r20_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r20_pytest.log
-python tools/microbench.py deblock lr picprep > gpurun_out/r20_micro.json 2> gpurun_out/r20_micro.err; echo "micro rc=$?"; tail -c 300 gpurun_out/r20_micro.err
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+  tag=$(echo $set | cut -c1-12 | tr ' ' '_')
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc22_$tag -o run -- python tools/microbench.py lr --steps 2 --warmup 1 > gpurun_out/r22_pmc_$tag.log 2>&1; echo "pmc $tag rc=$?"
+done
