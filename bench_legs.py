@@ -232,3 +232,33 @@ def deblock(torch, lib, pkg, stream, steps, warmup):
     return {"deblock_4k10": {"frames_per_s": 1 / t, "ms": t * 1e3, "Medges_s": nedges / t / 1e6,
                              "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS,
                                           "algorithmic_bytes_per_frame": nbytes}}}
+
+
+def lr_stats(torch, lib, pkg, stream, steps, warmup):
+    """a24: Wiener search statistics (svt_av1_compute_stats_highbd) of every 256x256 restoration unit of a 3840x2160 10-bit luma plane, win 7:
+    H = Z^T Z on the matrix cores.  Algorithmic integer MACs = pixels x 50 x 51 / 2 (upper triangle + M); the int8 digit split issues 3 x 64 x 64
+    MACs per pixel to the MFMA pipe (padding and the two-digit products included)."""
+    w, h, bd, us = 3840, 2160, 10, 256
+    g = np.random.default_rng(8)
+    pad = 4
+    dgd = g.integers(0, 1 << bd, (h + 2 * pad, w + 2 * pad), dtype=np.uint16)
+    src = np.clip(dgd.astype(np.int32) + g.integers(-9, 10, dgd.shape), 0, (1 << bd) - 1).astype(np.uint16)
+    rects = []
+    nvu, nhu = max((h + us // 2) // us, 1), max((w + us // 2) // us, 1)
+    for r in range(nvu):
+        for c in range(nhu):
+            rects.append((pad + c * us, pad + (w if c == nhu - 1 else (c + 1) * us), pad + r * us, pad + (h if r == nvu - 1 else (r + 1) * us)))
+    rr = np.array(rects, np.int32)
+    d_dgd, d_src, d_r = _dev(torch, dgd), _dev(torch, src), _dev(torch, rr)
+    n = len(rects)
+    d_M = torch.zeros(n * 49, dtype=torch.int64, device="cuda")
+    d_H = torch.zeros(n * 49 * 49, dtype=torch.int64, device="cuda")
+    mw, mh = int((rr[:, 1] - rr[:, 0]).max()), int((rr[:, 3] - rr[:, 2]).max())
+    stride = w + 2 * pad
+    t = _time(torch, lambda: lib.svt_hip_lr_compute_stats_batch(d_dgd.data_ptr(), d_src.data_ptr(), d_r.data_ptr(), n, mw, mh, stride, stride, 7, bd, d_M.data_ptr(),
+                                                                 d_H.data_ptr(), stream), steps, warmup)
+    issued = 3 * 64 * 64 * w * h * 2  # int8 ops (multiply + add) handed to the matrix cores
+    return {"lr_compute_stats_4k10_win7": {"frames_per_s": 1 / t, "ms": t * 1e3, "units": n, "algorithmic_GMAC_s": w * h * 50 * 51 / 2 / t / 1e9,
+                                           "roofline": {"bound": "mfma", "achieved": issued / t / 1e12, "peak": 5000.0, "unit": "TOP/s (int8, dense)",
+                                                        "frac": issued / t / 1e12 / 5000.0,
+                                                        "note": "issued int8 ops incl. 64-column padding and the three digit products; peak = 2x the 2.5 PFLOP/s bf16 dense figure"}}}

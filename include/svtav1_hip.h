@@ -337,9 +337,11 @@ void svt_hip_hadamard_satd_batch(const uint8_t *input_base, const uint8_t *pred_
                                  uint32_t *satd_out, int32_t *coeff_out, void *stream);
 typedef struct SvtHipRect { int32_t h_start, h_end, v_start, v_end; } SvtHipRect;
 /* n restoration units: Wiener auto/cross-correlation M[n][49], H[n][49*49] (only win^2 / win^4 entries used),
- * svt_av1_compute_stats_c / _highbd_c (restoration_pick.c:659-745).  dgd needs a (win/2)-pixel readable border. */
-void svt_hip_lr_compute_stats_batch(const void *dgd, const void *src, const SvtHipRect *rects, uint32_t n, int dgd_stride, int src_stride,
-                                    int wiener_win, int bit_depth, int64_t *M, int64_t *H, void *stream);
+ * svt_av1_compute_stats_c / _highbd_c (restoration_pick.c:659-745).  dgd needs a (win/2)-pixel readable border.  max_rect_width / height =
+ * the largest unit of the batch (sizes the launch; the rects themselves stay on the device).  Runs on the matrix cores (int8 digit split,
+ * int32 / int64 accumulation: exact). */
+void svt_hip_lr_compute_stats_batch(const void *dgd, const void *src, const SvtHipRect *rects, uint32_t n, int max_rect_width, int max_rect_height,
+                                    int dgd_stride, int src_stride, int wiener_win, int bit_depth, int64_t *M, int64_t *H, void *stream);
 /* single-call forms (aom_dsp_rtcd.h:62-81,210-215,276; common_dsp_rtcd.h:1075-1087) */
 int      svt_aom_satd_hip(const int32_t *coeff, int length);
 void     svt_aom_hadamard_nxn_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff, int n);

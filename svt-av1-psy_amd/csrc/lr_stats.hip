@@ -1,0 +1,310 @@
+// lr_stats.hip -- Wiener search statistics on the matrix cores: svt_av1_compute_stats / _highbd ->
+// svt_av1_compute_stats_c / svt_av1_compute_stats_highbd_c (Codec/restoration_pick.c:659-745).
+//
+// This is the one kernel of the path that IS a dense contraction: with z_t(p) = dgd(p + offset_t) - avg for the win^2 taps and
+// z_x(p) = src(p) - avg, the outputs are H = Z^T Z (win^2 x win^2) and M = Z^T z_x, sums over every pixel p of the restoration unit.
+// It must be exact (int64 in the reference), so the operands are integers: every centred sample v (|v| < 4096) is split into two int8
+// digits, v = 128 h + l with h = v >> 7 in [-32, 31] and l = v & 127, and
+//     sum z_a z_b = 16384 sum h_a h_b + 128 (sum h_a l_b + sum l_a h_b) + sum l_a l_b
+// is three int8 matrix products accumulated in int32 by v_mfma_i32_16x16x64_i8 (exact: a workgroup sees 4096 pixels, 4096 * 127^2 < 2^31)
+// and combined in int64.  Taps + the source column are padded to 64 (win 7) or 32 (win 5) columns = 4 or 2 groups of 16; HH and LL are
+// symmetric (upper tile triangle only), HL is not.
+//
+// MFMA operand for (tap t, 64 consecutive pixels of a row): lane (t & 15, kg = lane >> 4) holds the 16 bytes of digit plane samples of pixels
+// 16 kg .. 16 kg + 15 displaced by the tap's offset = sixteen CONSECUTIVE bytes of an LDS digit plane -> five aligned dwords + v_alignbyte.
+// The same registers serve as A (rows of Z^T) and as B (columns of Z): both use the lane <-> (tap, pixel) assignment, so the sum over K
+// visits every pixel exactly once whatever order the hardware walks K in.
+#include "svt_hip_common.h"
+#include "../../include/svtav1_hip.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef int i32x4 __attribute__((vector_size(16)));
+
+constexpr int TR = 16, TC = 256;      // pixel tile staged at a time: 16 rows x 256 columns = 64 chunks of 64 pixels, 16 chunks per wave
+constexpr int BANDS = 4;              // a workgroup walks 4 such tiles (64 rows) with its accumulators in registers: 16384 pixels, still exact in
+                                      // int32 (16384 * 127^2 < 2^31), a quarter of the merge traffic
+constexpr int PP = TC + 16;           // dgd digit-plane pitch (bytes); tile pixel (r, c) sits at byte (r + 3) * PP + c + 4
+constexpr int DGD_PLANE = (TR + 6) * PP;
+constexpr int SRC_PLANE = TR * TC;    // src digit plane, pitch TC, no halo
+constexpr int LDS_PLANES = 2 * DGD_PLANE + 2 * SRC_PLANE;
+
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ int rd(const void* p, const int is16, const size_t off) { return is16 ? ((const uint16_t*)p)[off] : ((const uint8_t*)p)[off]; }
+
+// find_average / find_average_highbd (restoration_pick.h): floor(sum / count) of the degraded unit.  One workgroup per (unit, 16-row band) adds its
+// partial sum to a lower-triangle slot of H (free until the finalize kernel mirrors the upper triangle); the consumers divide.
+__global__ __launch_bounds__(256) void stats_sum_kernel(const void* dgd, const SvtHipRect* rects, const int dgd_stride, const int is16, const int w2,
+                                                        long long* H) {
+    __shared__ long long wsum[4];
+    const int        tid = threadIdx.x;
+    const SvtHipRect R   = rects[blockIdx.y];
+    const int        W = R.h_end - R.h_start, Hh = R.v_end - R.v_start, r0 = blockIdx.x * 16;
+    if (r0 >= Hh || W <= 0) return;
+    const int rows = Hh - r0 < 16 ? Hh - r0 : 16;
+    long long s = 0;
+    for (int r = tid >> 6; r < rows; r += 4) { // a wave per row: coalesced
+        const size_t base = (size_t)((long long)(R.v_start + r0 + r) * dgd_stride + R.h_start);
+        for (int x = tid & 63; x < W; x += 64) s += rd(dgd, is16, base + x);
+    }
+    s = wave_sum_ll(s);
+    if ((tid & 63) == 0) wsum[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) atomicAdd((unsigned long long*)&H[(size_t)blockIdx.y * 49 * 49 + w2], (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
+}
+
+__device__ __forceinline__ uint32_t pack_digits_hi(const int v0, const int v1, const int v2, const int v3) {
+    return (uint32_t)((v0 >> 7) & 255) | ((uint32_t)((v1 >> 7) & 255) << 8) | ((uint32_t)((v2 >> 7) & 255) << 16) | ((uint32_t)((v3 >> 7) & 255) << 24);
+}
+__device__ __forceinline__ uint32_t pack_digits_lo(const int v0, const int v1, const int v2, const int v3) {
+    return (uint32_t)(v0 & 127) | ((uint32_t)(v1 & 127) << 8) | ((uint32_t)(v2 & 127) << 16) | ((uint32_t)(v3 & 127) << 24);
+}
+
+struct __attribute__((aligned(4))) Dw5 { uint32_t w[5]; };
+
+// NG = 4 (win 7: 49 taps + source = 50 columns) or 2 (win 5: 26 columns)
+template <int NG>
+__global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, const void* src, const SvtHipRect* rects, const int dgd_stride, const int src_stride,
+                                                         const int win, const int is16, long long* Mout, long long* Hout) {
+    constexpr int NTRI = NG * (NG + 1) / 2, NTILE = 2 * NTRI + NG * NG;
+    HIP_DYNAMIC_SHARED(uint32_t, smem)
+    uint8_t* planes = (uint8_t*)smem; // [dgd hi][dgd lo][src hi][src lo]; later reused as int32 [NTILE][256]
+    const int        tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+    const int        unit = blockIdx.z;
+    const SvtHipRect R = rects[unit];
+    const int w2 = win * win, hw = win >> 1;
+    const int W = R.h_end - R.h_start, Hh = R.v_end - R.v_start;
+    const int c0 = blockIdx.x * TC, rb0 = blockIdx.y * TR * BANDS; // origin of the workgroup's 64-row band group inside the unit
+    if (c0 >= W || rb0 >= Hh) return;
+    const int tw = W - c0 < TC ? W - c0 : TC;
+    long long* H = Hout + (size_t)unit * 49 * 49;
+    long long* M = Mout + (size_t)unit * 49;
+    const int  avg = (int)((unsigned long long)H[w2] / (unsigned long long)((long long)W * Hh)); // H[w2] = sum of the degraded unit (stats_sum_kernel)
+
+    // ---- per-lane operand addressing: group g -> tap t = 16 g + (l & 15); kg = l >> 4 selects pixels 16 kg .. 16 kg + 15 of a chunk ----
+    int      opoff[NG], oppitch[NG], ophi[NG], oplo[NG];
+    uint32_t opsh[NG], opmask[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const int t = 16 * g + (l & 15), kg = l >> 4;
+        if (t < w2) { // tap index = (dx + hw) * win + (dy + hw)   (restoration_pick.c:673-679: k over columns, l over rows)
+            const int dx = t / win - hw, dy = t % win - hw;
+            const int off = (3 + dy) * PP + 4 + 16 * kg + dx;
+            opoff[g] = off & ~3; opsh[g] = (uint32_t)off & 3u; oppitch[g] = PP; ophi[g] = 0; oplo[g] = DGD_PLANE; opmask[g] = ~0u;
+        } else { // the source column (t == w2) or padding (contributes zeros)
+            opoff[g] = 16 * kg; opsh[g] = 0; oppitch[g] = TC; ophi[g] = 2 * DGD_PLANE; oplo[g] = 2 * DGD_PLANE + SRC_PLANE; opmask[g] = t == w2 ? ~0u : 0u;
+        }
+    }
+    i32x4 accHH[NTRI], accLL[NTRI], accHL[NG * NG];
+#pragma unroll
+    for (int i = 0; i < NTRI; i++) { accHH[i] = i32x4{0, 0, 0, 0}; accLL[i] = i32x4{0, 0, 0, 0}; }
+#pragma unroll
+    for (int i = 0; i < NG * NG; i++) accHL[i] = i32x4{0, 0, 0, 0};
+
+    for (int band = 0; band < BANDS; band++) {
+    const int r0 = rb0 + band * TR;
+    if (r0 >= Hh) break;
+    const int th = Hh - r0 < TR ? Hh - r0 : TR;
+    if (band) __syncthreads(); // everyone is done reading the previous tile
+    // ---- stage the digit planes: four samples per step, loads issued before the stores ----
+    {
+        constexpr int SLOTS = PP / 4, NIT = ((TR + 6) * SLOTS + 255) / 256;
+        int v[NIT][4];
+#pragma unroll
+        for (int k = 0; k < NIT; k++) {
+            const int i = tid + 256 * k, r = i / SLOTS, s = i - r * SLOTS; // plane row r <-> tile row r - 3, slot s <-> tile columns 4 s - 4 ..
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int tr = r - 3, tc = 4 * s - 4 + e;
+                const bool ok = i < (TR + 6) * SLOTS && tr >= -hw && tr < th + hw && tc >= -hw && tc < tw + hw;
+                v[k][e] = ok ? rd(dgd, is16, (size_t)((long long)(R.v_start + r0 + tr) * dgd_stride + (R.h_start + c0 + tc))) - avg : 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; k++) {
+            const int i = tid + 256 * k;
+            if (i < (TR + 6) * SLOTS) {
+                ((uint32_t*)planes)[i]                   = pack_digits_hi(v[k][0], v[k][1], v[k][2], v[k][3]);
+                ((uint32_t*)(planes + DGD_PLANE))[i]     = pack_digits_lo(v[k][0], v[k][1], v[k][2], v[k][3]);
+            }
+        }
+        constexpr int SSLOTS = TC / 4, SNIT = (TR * SSLOTS + 255) / 256;
+        int x[SNIT][4];
+#pragma unroll
+        for (int k = 0; k < SNIT; k++) {
+            const int i = tid + 256 * k, r = i / SSLOTS, s = i - r * SSLOTS;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int tc = 4 * s + e;
+                x[k][e] = (r < th && tc < tw) ? rd(src, is16, (size_t)((long long)(R.v_start + r0 + r) * src_stride + (R.h_start + c0 + tc))) - avg : 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SNIT; k++) {
+            const int i = tid + 256 * k;
+            ((uint32_t*)(planes + 2 * DGD_PLANE))[i]             = pack_digits_hi(x[k][0], x[k][1], x[k][2], x[k][3]);
+            ((uint32_t*)(planes + 2 * DGD_PLANE + SRC_PLANE))[i] = pack_digits_lo(x[k][0], x[k][1], x[k][2], x[k][3]);
+        }
+    }
+    __syncthreads();
+    {   // this wave's chunks of the tile: rows 4 wv .. 4 wv + 3, nch chunks each, flattened; software pipelined: the operands of chunk it + 1
+        // are fetched (LDS + funnel shifts) while the matrix pipe works through the 36 (10) MFMAs of chunk it
+        const int nch = (tw + 63) >> 6;
+        int nrow = th - wv * (TR / 4);
+        nrow = nrow < 0 ? 0 : (nrow > TR / 4 ? TR / 4 : nrow);
+        const int nit = nrow * nch;
+        auto fetch = [&](const int it, i32x4 (&oH)[NG], i32x4 (&oL)[NG], auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value; // every chunk of the tile is 64 pixels wide: no per-byte masks
+            const int row = wv * (TR / 4) + it / nch, ch = it % nch;
+            const int nvalid = tw - ch * 64; // pixels of this chunk inside the unit (>= 64: all)
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const int a  = row * oppitch[g] + 64 * ch + opoff[g];
+                const Dw5 vh = *(const Dw5*)(planes + ophi[g] + a), vl = *(const Dw5*)(planes + oplo[g] + a);
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    uint32_t m = g == NG - 1 ? opmask[g] : ~0u; // only the last group holds the source column and padding
+                    if (!FULL && nvalid < 64) { // pixel 16 kg + 4 d + e of the chunk is outside the unit -> its byte must be zero in every operand
+                        const int first = 16 * (l >> 4) + 4 * d, left = nvalid - first;
+                        m &= left >= 4 ? ~0u : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
+                    }
+                    oH[g][d] = (int)(__builtin_amdgcn_alignbyte(vh.w[d + 1], vh.w[d], opsh[g]) & m);
+                    oL[g][d] = (int)(__builtin_amdgcn_alignbyte(vl.w[d + 1], vl.w[d], opsh[g]) & m);
+                }
+            }
+        };
+        auto multiply = [&](const i32x4 (&oH)[NG], const i32x4 (&oL)[NG]) {
+            int ti = 0;
+#pragma unroll
+            for (int ga = 0; ga < NG; ga++)
+#pragma unroll
+                for (int gb = ga; gb < NG; gb++, ti++) {
+                    accHH[ti] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oH[ga], oH[gb], accHH[ti], 0, 0, 0);
+                    accLL[ti] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oL[ga], oL[gb], accLL[ti], 0, 0, 0);
+                }
+#pragma unroll
+            for (int ga = 0; ga < NG; ga++)
+#pragma unroll
+                for (int gb = 0; gb < NG; gb++) accHL[ga * NG + gb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oH[ga], oL[gb], accHL[ga * NG + gb], 0, 0, 0);
+        };
+        i32x4 aH[NG], aL[NG], bH[NG], bL[NG];
+        if ((tw & 63) == 0 && nit > 0) {
+            // Straight-line two-chunk body (fetches clamp to the last chunk instead of branching; an odd tail multiplies zeros) so that the
+            // scheduler can place the next chunk's LDS reads and funnel shifts in the shadow of the current chunk's MFMAs: a wave issues in
+            // order, and 36 back-to-back MFMAs would otherwise keep the VALU idle for their whole 16-cycle latencies.
+            fetch(0, aH, aL, std::true_type{});
+            for (int it = 0; it < nit; it += 2) {
+                const int i1 = it + 1 < nit ? it + 1 : nit - 1, i2 = it + 2 < nit ? it + 2 : nit - 1;
+                fetch(i1, bH, bL, std::true_type{});
+                if (it + 1 >= nit) {
+#pragma unroll
+                    for (int g = 0; g < NG; g++) { bH[g] = i32x4{0, 0, 0, 0}; bL[g] = i32x4{0, 0, 0, 0}; }
+                }
+                multiply(aH, aL);
+                fetch(i2, aH, aL, std::true_type{});
+                multiply(bH, bL);
+#pragma unroll
+                for (int k = 0; k < 2 * NTILE; k++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one LDS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); // three VALU
+                }
+            }
+        } else {
+            for (int it = 0; it < nit; it++) {
+                fetch(it, aH, aL, std::false_type{});
+                multiply(aH, aL);
+            }
+        }
+    }
+    }
+
+    // ---- merge the four waves in LDS (int32 is still exact: 4096 pixels), then one int64 atomic per matrix entry ----
+    __syncthreads();
+    int* part = (int*)smem; // [NTILE][64 lanes][4]: HH tiles, LL tiles, HL tiles
+    for (int i = tid; i < NTILE * 256; i += 256) part[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NTRI; i++)
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            atomicAdd(&part[(i * 64 + l) * 4 + d], accHH[i][d]);
+            atomicAdd(&part[((NTRI + i) * 64 + l) * 4 + d], accLL[i][d]);
+        }
+#pragma unroll
+    for (int i = 0; i < NG * NG; i++)
+#pragma unroll
+        for (int d = 0; d < 4; d++) atomicAdd(&part[((2 * NTRI + i) * 64 + l) * 4 + d], accHL[i][d]);
+    __syncthreads();
+    // C/D layout of the 16x16 MFMAs: lane = col + 16 * (row >> 2), register = row & 3
+    const int ncol = w2 + 1; // taps + source column
+    for (int e = tid; e < ncol * (ncol + 1) / 2; e += 256) {
+        int a = 0, rem = e;
+        while (rem >= ncol - a) { rem -= ncol - a; a++; }
+        const int b = a + rem; // a <= b
+        if (a == w2) continue;  // (source, source) is not an output
+        const int ga = a >> 4, ra = a & 15, gb = b >> 4, cb = b & 15, rb = b & 15, ca = a & 15;
+        const int tri = ga * NG - ga * (ga - 1) / 2 + (gb - ga);
+        const int eab = (cb + 16 * (ra >> 2)) * 4 + (ra & 3), eba = (ca + 16 * (rb >> 2)) * 4 + (rb & 3);
+        const long long hh = part[tri * 256 + eab], ll = part[(NTRI + tri) * 256 + eab];
+        const long long hl = part[(2 * NTRI + ga * NG + gb) * 256 + eab], lh = part[(2 * NTRI + gb * NG + ga) * 256 + eba];
+        const long long v  = 16384 * hh + 128 * (hl + lh) + ll;
+        unsigned long long* dst = (unsigned long long*)(b == w2 ? &M[a] : &H[a * w2 + b]);
+        atomicAdd(dst, (unsigned long long)v);
+    }
+}
+
+// upper triangle / M -> divide as the reference's `/=` (truncation toward zero, restoration_pick.c:733-742), mirror to the lower triangle
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const int win, const int bit_depth, long long* Mout, long long* Hout) {
+    const int w2 = win * win, div = bit_depth == 12 ? 16 : (bit_depth == 10 ? 4 : 1);
+    long long* H = Hout + (size_t)blockIdx.x * 49 * 49;
+    long long* M = Mout + (size_t)blockIdx.x * 49;
+    for (int e = threadIdx.x; e < w2 * w2; e += 256) {
+        const int k = e / w2, l2 = e - k * w2;
+        if (k < l2) {
+            const long long v = H[e] / div;
+            H[e]              = v;
+            H[l2 * w2 + k]    = v;
+        } else if (k == l2) {
+            H[e] = H[e] / div;
+        }
+    }
+    for (int k = threadIdx.x; k < w2; k += 256) M[k] = M[k] / div;
+}
+
+} // namespace
+
+extern "C" {
+
+void svt_hip_lr_compute_stats_batch(const void* dgd, const void* src, const SvtHipRect* rects, uint32_t n, int max_rect_width, int max_rect_height, int dgd_stride,
+                                    int src_stride, int wiener_win, int bit_depth, int64_t* M, int64_t* H, void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    hipStream_t st = (hipStream_t)stream;
+    const int   is16 = bit_depth > 8, w2 = wiener_win * wiener_win;
+    HIP_CHECK(hipMemsetAsync(M, 0, (size_t)n * 49 * 8, st));
+    HIP_CHECK(hipMemsetAsync(H, 0, (size_t)n * 49 * 49 * 8, st));
+    hipLaunchKernelGGL(stats_sum_kernel, dim3((max_rect_height + 15) / 16, n), dim3(256), 0, st, dgd, rects, dgd_stride, is16, w2, (long long*)H);
+    SVT_LAUNCH_CHECK();
+    const dim3 grid((max_rect_width + TC - 1) / TC, (max_rect_height + TR * BANDS - 1) / (TR * BANDS), n);
+    if (grid.x && grid.y) {
+        if (wiener_win == 7) {
+            const size_t shmem = (size_t)(36 * 256 * 4 > LDS_PLANES ? 36 * 256 * 4 : LDS_PLANES) + 64;
+            hipLaunchKernelGGL(stats_mfma_kernel<4>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, wiener_win, is16, (long long*)M, (long long*)H);
+        } else {
+            const size_t shmem = (size_t)(10 * 256 * 4 > LDS_PLANES ? 10 * 256 * 4 : LDS_PLANES) + 64;
+            hipLaunchKernelGGL(stats_mfma_kernel<2>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, wiener_win, is16, (long long*)M, (long long*)H);
+        }
+        SVT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(n), dim3(256), 0, st, wiener_win, bit_depth, (long long*)M, (long long*)H);
+    SVT_LAUNCH_CHECK();
+}
+
+} // extern "C"

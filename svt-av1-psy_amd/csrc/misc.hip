@@ -115,84 +115,7 @@ __global__ void residual_kernel(const void* in, uint32_t is, const void* pr, uin
     res[y * rs + x] = (int16_t)(a - b);
 }
 
-// ---- Wiener statistics -------------------------------------------------------------------------------------------------
-constexpr int ST = 32; // tile of pixels staged per iteration
-__global__ __launch_bounds__(256) void stats_kernel(const void* dgd, const void* src, const SvtHipRect* rects, int dgd_stride, int src_stride, int win, int bit_depth,
-                                                    long long* Mout, long long* Hout) {
-    __shared__ int16_t  ty[(ST + 6) * (ST + 6)];
-    __shared__ int16_t  tx[ST * ST];
-    __shared__ long long wsum[4];
-    const int tid = threadIdx.x, is16 = bit_depth > 8;
-    const SvtHipRect R = rects[blockIdx.x];
-    const int w2 = win * win, hw = win >> 1, npair = w2 * (w2 + 1) / 2, nacc = npair + w2;
-    const int W = R.h_end - R.h_start, Hh = R.v_end - R.v_start;
-    // average of the degraded unit (find_average, restoration_pick.h:24-44)
-    long long s = 0;
-    for (int i = tid; i < W * Hh; i += 256) {
-        const int y = R.v_start + i / W, x = R.h_start + i % W;
-        s += is16 ? ((const uint16_t*)dgd)[(size_t)y * dgd_stride + x] : ((const uint8_t*)dgd)[(size_t)y * dgd_stride + x];
-    }
-    s = wave_sum_i64(s);
-    if ((tid & 63) == 0) wsum[tid >> 6] = s;
-    __syncthreads();
-    const int avg = (int)((unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (unsigned long long)(W * Hh));
-    // lane-owned accumulators: accumulator a < npair is the pair (k <= l) in row-major upper-triangular order, a >= npair is M[a - npair]
-    constexpr int MAXA = 5; // ceil((1225 + 49) / 256)
-    int       ok[MAXA], ol[MAXA]; // LDS offsets of tap k / tap l relative to the pixel (tap index = column-major: k over columns, l over rows)
-    long long acc[MAXA];
-#pragma unroll
-    for (int a = 0; a < MAXA; a++) {
-        acc[a] = 0;
-        const int id = tid + 256 * a;
-        int k = 0, l = 0;
-        if (id < npair) { int rem = id; while (rem >= w2 - k) { rem -= w2 - k; k++; } l = k + rem; }
-        else if (id < nacc) { k = id - npair; l = -1; }
-        ok[a] = id < nacc ? ((k % win) * (ST + 6) + (k / win)) : -1;
-        ol[a] = l >= 0 ? ((l % win) * (ST + 6) + (l / win)) : -1;
-    }
-    for (int ty0 = 0; ty0 < Hh; ty0 += ST)
-        for (int tx0 = 0; tx0 < W; tx0 += ST) {
-            const int th = Hh - ty0 < ST ? Hh - ty0 : ST, tw = W - tx0 < ST ? W - tx0 : ST;
-            __syncthreads();
-            for (int i = tid; i < (th + 2 * hw) * (tw + 2 * hw); i += 256) {
-                const int r = i / (tw + 2 * hw), c = i - r * (tw + 2 * hw);
-                const size_t o = (size_t)(R.v_start + ty0 - hw + r) * dgd_stride + (R.h_start + tx0 - hw + c);
-                ty[r * (ST + 6) + c] = (int16_t)((is16 ? ((const uint16_t*)dgd)[o] : ((const uint8_t*)dgd)[o]) - avg);
-            }
-            for (int i = tid; i < th * tw; i += 256) {
-                const int r = i / tw, c = i - r * tw;
-                const size_t o = (size_t)(R.v_start + ty0 + r) * src_stride + (R.h_start + tx0 + c);
-                tx[r * ST + c] = (int16_t)((is16 ? ((const uint16_t*)src)[o] : ((const uint8_t*)src)[o]) - avg);
-            }
-            __syncthreads();
-            for (int r = 0; r < th; r++)
-                for (int c = 0; c < tw; c++) {
-                    const int16_t* p = ty + r * (ST + 6) + c; // window origin (tap row 0, column 0)
-                    const int      x = tx[r * ST + c];
-#pragma unroll
-                    for (int a = 0; a < MAXA; a++)
-                        if (ok[a] >= 0) acc[a] += (long long)((int)p[ok[a]] * (ol[a] >= 0 ? (int)p[ol[a]] : x));
-                }
-        }
-    const int div = is16 ? (bit_depth == 12 ? 16 : 4) : 1;
-    long long* M = Mout + (size_t)blockIdx.x * 49;
-    long long* H = Hout + (size_t)blockIdx.x * 49 * 49;
-#pragma unroll
-    for (int a = 0; a < MAXA; a++) {
-        const int id = tid + 256 * a;
-        if (id >= nacc) continue;
-        const long long v = acc[a] / div; // C division truncates toward zero, as the reference's `/=` (:733-742)
-        if (id < npair) {
-            int k = 0, rem = id;
-            while (rem >= w2 - k) { rem -= w2 - k; k++; }
-            const int l = k + rem;
-            H[k * w2 + l] = v;
-            H[l * w2 + k] = v;
-        } else {
-            M[id - npair] = v;
-        }
-    }
-}
+// ---- Wiener statistics: csrc/lr_stats.hip (matrix cores) ----
 
 // ---- self-guided projection ------------------------------------------------------------------------------------------
 // mode 0: pixel_proj_error -> out[0]; mode 1: get_proj_subspace -> xq[0..1]
@@ -261,15 +184,6 @@ void svt_hip_hadamard_satd_batch(const uint8_t* input_base, const uint8_t* pred_
     hipLaunchKernelGGL(hadamard_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, (const int16_t*)nullptr, input_base, pred_base, descs, tx_n, coeff_out, satd_out);
     SVT_LAUNCH_CHECK();
 }
-void svt_hip_lr_compute_stats_batch(const void* dgd, const void* src, const SvtHipRect* rects, uint32_t n, int dgd_stride, int src_stride, int wiener_win,
-                                    int bit_depth, int64_t* M, int64_t* H, void* stream) {
-    svthip::ensure_device();
-    if (n == 0) return;
-    hipLaunchKernelGGL(stats_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dgd, src, rects, dgd_stride, src_stride, wiener_win, bit_depth, (long long*)M,
-                       (long long*)H);
-    SVT_LAUNCH_CHECK();
-}
-
 // ---- RTCD-signature single-call forms ---------------------------------------------------------------------------------
 int svt_aom_satd_hip(const int32_t* coeff, int length) {
     svthip::HostCall& c = svthip::host_call();
@@ -364,7 +278,7 @@ static void stats_host(int win, const void* dgd, const void* src, int h_start, i
     SvtHipRect R = {0, W, 0, Hh};
     c.up(dr, &R, sizeof(R));
     // origin of the uploaded dgd rectangle is (hw, hw)
-    svt_hip_lr_compute_stats_batch(dd + (hw * dp + hw * px), ds, dr, 1, (int)(dp / px), (int)(sp / px), win, bit_depth, dM, dH, c.stream);
+    svt_hip_lr_compute_stats_batch(dd + (hw * dp + hw * px), ds, dr, 1, W, Hh, (int)(dp / px), (int)(sp / px), win, bit_depth, dM, dH, c.stream);
     const int w2 = win * win;
     int64_t   hM[49], hH[49 * 49];
     c.down(hM, dM, 49 * 8);

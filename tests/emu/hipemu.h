@@ -229,6 +229,7 @@ template <typename... P, typename... A> inline void launch_k(void (*k)(P...), di
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __threadfence() {}
 inline void __threadfence_block() {}
@@ -357,6 +358,25 @@ inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh
 inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {
     unsigned long long v = ((unsigned long long)hi << 32) | lo;
     return (unsigned)(v >> (sh & 31));
+}
+// v_mfma_i32_16x16x64_i8: D[i][j] = C[i][j] + sum over the 64 k of A[i][k] * B[k][j], signed int8.  Lane l holds A[l & 15][16 (l >> 4) .. +15] and
+// B[16 (l >> 4) .. +15][l & 15] (16 bytes each) and C/D[4 (l >> 4) + r][l & 15], r = 0..3.  Implemented with the wave exchange primitive.
+typedef int hipemu_i32x4 __attribute__((vector_size(16)));
+inline hipemu_i32x4 __builtin_amdgcn_mfma_i32_16x16x64_i8(hipemu_i32x4 a, hipemu_i32x4 b, hipemu_i32x4 c, int, int, int) {
+    const int lane = hipemu::lane_id(), col = lane & 15, rg = lane >> 4;
+    hipemu_i32x4 d = c;
+    for (int kg = 0; kg < 4; kg++) {
+        unsigned bw[4];
+        for (int w = 0; w < 4; w++) bw[w] = (unsigned)hipemu::wave_xchg((unsigned)b[w], col + 16 * kg);
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * rg + r;
+            for (int w = 0; w < 4; w++) {
+                const unsigned aw = (unsigned)hipemu::wave_xchg((unsigned)a[w], row + 16 * kg);
+                for (int e = 0; e < 4; e++) d[r] += (int)(signed char)(aw >> (8 * e)) * (int)(signed char)(bw[w] >> (8 * e));
+            }
+        }
+    }
+    return d;
 }
 // clang element-wise saturating subtraction on unsigned vectors (v_pk_sub_u16 clamp)
 template <class V> inline V __builtin_elementwise_sub_sat(V a, V b) { return (a > b) ? (a - b) : (a - a); }

@@ -112,7 +112,8 @@ def test_lr_search_statistics(be, oracle, bd):
     for win in ((7, 5) if be.is_gpu else (7,)):
         dd, ds, dr = be.dev(dgd), be.dev(src), be.dev(rects)
         M, Hm = be.empty((len(rects), 49), np.int64), be.empty((len(rects), 49 * 49), np.int64)
-        be.lib.svt_hip_lr_compute_stats_batch(be.ptr(dd), be.ptr(ds), be.ptr(dr), len(rects), S, S, win, bd, be.ptr(M), be.ptr(Hm), be.stream)
+        be.lib.svt_hip_lr_compute_stats_batch(be.ptr(dd), be.ptr(ds), be.ptr(dr), len(rects), max(r[1] - r[0] for r in rect_list), max(r[3] - r[2] for r in rect_list), S, S, win, bd,
+                                              be.ptr(M), be.ptr(Hm), be.stream)
         gM, gH = be.host(M), be.host(Hm)
         for i, (hs, he, vs, ve) in enumerate(rect_list):
             M0, H0 = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
