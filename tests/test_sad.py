@@ -227,6 +227,50 @@ def test_me_fullpel_search_batch(be, oracle, pattern, sub_sad):
             assert np.array_equal(bm[i], wm), (pattern, aw, ah, i, np.nonzero(bm[i] != wm)[0][:8])
 
 
+def test_me_full_frame_properties(be, oracle):
+    """BASELINE configs[1] at full size (1080p, every 64x64 SB, 4 references, 16x9 and 64x32): size-independent properties instead of a CPU
+    oracle pass over 2040 x 85 searches -- (1) a planted pure translation inside the search area is found by all 85 blocks with SAD 0 and the
+    planted MV; (2) min-of-sums >= sum-of-mins up the 8x8 -> 16x16 -> 32x32 -> 64x64 hierarchy; (3) every MV lies inside its search area;
+    (4) a sample of SBs equals the oracle."""
+    if not be.is_gpu:
+        pytest.skip("full-size frame: GPU only")
+    g = rng(123)
+    W, H, PAD = 1920, 1080, 68
+    stride, rows = W + 2 * PAD, H + 2 * PAD
+    plane = rows * stride
+    base = g.integers(0, 256, (rows + 40, stride + 40), dtype=np.uint8)
+    planes = np.empty((5, rows, stride), np.uint8)
+    planes[0] = base[20:20 + rows, 20:20 + stride]
+    shifts = [(3, -2), (-5, 1), (0, 0), (7, 4)]  # (dx, dy) of reference k+1 relative to the source: ref(x, y) = src(x - dx, y - dy)
+    for k, (dx, dy) in enumerate(shifts):
+        planes[k + 1] = base[20 - dy:20 - dy + rows, 20 - dx:20 - dx + stride]
+    for (aw, ah) in ((16, 9), (64, 32)):
+        descs = be.pkg.me_descs_for_frame(W, H, stride, PAD, PAD, aw, ah, plane, n_refs=4, src_plane=0, ref_plane0=1)
+        bs, bm = run_me_batch(be, planes.reshape(-1), planes.reshape(-1), descs, aw, ah, 0)
+        nsb = len(descs) // 4
+        mvx, mvy = (bm & 0xffff).astype(np.int16).astype(np.int32), (bm >> 16).astype(np.int16).astype(np.int32)
+        # item order of me_descs_for_frame: find the items of reference k by their ref_off plane index
+        ref_plane = (descs["ref_off"].astype(np.int64) + (ah >> 1) * stride + (aw >> 1)) // plane
+        for k, (dx, dy) in enumerate(shifts):
+            it = np.nonzero(ref_plane == k + 1)[0]
+            inside = -(aw >> 1) <= dx < aw - (aw >> 1) and -(ah >> 1) <= dy < ah - (ah >> 1)
+            if inside:  # full 64x64 SBs only (the last SB row is 56 high: its padded rows still match because the padding is shifted data too)
+                assert np.all(bs[it] == 0), (aw, ah, k)
+                assert np.all(mvx[it] == dx) and np.all(mvy[it] == dy), (aw, ah, k)
+        # hierarchy: best64 >= sum best32 >= ... (min of sums >= sum of mins)
+        assert np.all(bs[:, 0].astype(np.int64) >= bs[:, 1:5].astype(np.int64).sum(1))
+        s16 = bs[:, 5:21].astype(np.int64)
+        for q in range(4):
+            assert np.all(bs[:, 1 + q].astype(np.int64) >= s16[:, 4 * q:4 * q + 4].sum(1))
+        s8 = bs[:, 21:85].astype(np.int64)
+        for q in range(16):
+            assert np.all(s16[:, q] >= s8[:, 4 * q:4 * q + 4].sum(1))
+        assert np.all((mvx >= -(aw >> 1)) & (mvx < aw - (aw >> 1)) & (mvy >= -(ah >> 1)) & (mvy < ah - (ah >> 1)))
+        for i in g.choice(len(descs), 12, replace=False):
+            ws, wm = oracle_me(oracle, planes.reshape(-1), planes.reshape(-1), descs[i], 0)
+            assert np.array_equal(bs[i], ws) and np.array_equal(bm[i], wm), (aw, ah, int(i))
+
+
 def test_me_fullpel_mixed_areas_and_empty(be, oracle):
     """Items of one launch may have different (smaller) search areas; an empty area reports MAX_SAD_VALUE."""
     g = rng(4)
