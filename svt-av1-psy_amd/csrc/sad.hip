@@ -108,13 +108,14 @@ __device__ __forceinline__ void stage_rows_store(const uint32_t (&v)[NIT][4], ui
 
 // stage_rows_u8 for any number of rows / chunks per row, four 16-byte loads in flight per thread (same tail rule as stage_rows_load:
 // nothing outside [row, row + width) is read).  Needs width >= 16 and an even pitch_dw.
+template <int NT = 256> // cooperating threads (256 = workgroup, 64 = one wave)
 __device__ __forceinline__ void stage_rows_wide_any(uint32_t* lds, int pitch_dw, const uint8_t* g, uint32_t gstride, int width, int rows, int tid) {
     const int cpr = (pitch_dw + 3) >> 2, total = rows * cpr; // chunks per LDS row (the last may be partial in LDS too)
-    for (int base = 0; base < total; base += 1024) {
+    for (int base = 0; base < total; base += 4 * NT) {
         uint32_t v[4][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int  idx = base + tid + 256 * k, r = idx / cpr, col = (idx - r * cpr) * 16;
+            const int  idx = base + tid + NT * k, r = idx / cpr, col = (idx - r * cpr) * 16;
             const bool live = idx < total && col < width;
             const int  left = width - col;
             const int  back = (live && left < 16) ? 16 - left : 0;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void stage_rows_wide_any(uint32_t* lds, int pitch_dw,
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int idx = base + tid + 256 * k, r = idx / cpr, c4 = (idx - r * cpr) * 4;
+            const int idx = base + tid + NT * k, r = idx / cpr, c4 = (idx - r * cpr) * 4;
             if (idx < total) {
                 uint32_t* o = lds + r * pitch_dw + c4;
                 if (c4 + 0 < pitch_dw) *(u32x2_a8*)(o + 0) = u32x2_a8{v[k][0], v[k][1]};
@@ -424,15 +425,11 @@ __global__ __launch_bounds__(64) void sad_16b_kernel(const uint16_t* __restrict_
 // rows.  The host picks the narrowest tile that covers the widest search area of the batch (16, 32 or 64 positions wide), so the small HME
 // areas keep every lane busy.
 template <int LXG>
-__global__ __launch_bounds__(256) void sad_loop_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
-                                                       const SvtHipSadLoopDesc* __restrict__ descs, uint32_t tiles_x,
-                                                       unsigned long long* __restrict__ keys) {
+__device__ __forceinline__ void sad_loop_item(uint32_t* smem, unsigned long long& wg_best, const uint8_t* __restrict__ src_base,
+                                              const uint8_t* __restrict__ ref_base, const SvtHipSadLoopDesc& d, const uint32_t item, const uint32_t tile,
+                                              const uint32_t tiles_x, unsigned long long* __restrict__ keys) {
     constexpr int TW = 4 << LXG, TH = 256 >> LXG;
-    HIP_DYNAMIC_SHARED(uint32_t, smem)
-    __shared__ unsigned long long wg_best;
-    const int               tid  = threadIdx.x;
-    const uint32_t          item = blockIdx.x, tile = blockIdx.y;
-    const SvtHipSadLoopDesc d    = descs[item];
+    const int tid = threadIdx.x;
     const int W = d.search_area_width, H = d.search_area_height;
     const int bw = d.block_width, bh = d.block_height;
     const int tx0 = (int)(tile % tiles_x) * TW, ty0 = (int)(tile / tiles_x) * TH;
@@ -515,6 +512,140 @@ __global__ __launch_bounds__(256) void sad_loop_kernel(const uint8_t* __restrict
     atomicMin(&wg_best, best);
     __syncthreads();
     if (tid == 0 && wg_best != ~0ull) atomicMin(&keys[item], wg_best);
+}
+template <int LXG>
+__global__ __launch_bounds__(256) void sad_loop_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                       const SvtHipSadLoopDesc* __restrict__ descs, const uint32_t* __restrict__ todo, const uint32_t tiles_x,
+                                                       unsigned long long* __restrict__ keys) {
+    HIP_DYNAMIC_SHARED(uint32_t, smem)
+    __shared__ unsigned long long wg_best;
+    const uint32_t count = todo[0]; // items sad_loop_ring_kernel left for this kernel (usually none: the launch is then a few thousand empty workgroups)
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t          item = todo[1 + i];
+        const SvtHipSadLoopDesc d    = descs[item];
+        __syncthreads(); // the previous item's LDS tile and wg_best are no longer in use
+        sad_loop_item<LXG>(smem, wg_best, src_base, ref_base, d, item, blockIdx.y, tiles_x, keys);
+    }
+}
+
+// ---- svt_sad_loop_kernel, ring form: the HME shapes -------------------------------------------------------------------------------------
+// Items whose block is 16x16 / 32x32 / 64x64 (or the sub-sampled 16x8 / 32x16 / 64x32 with ref_stride = 2 * src_stride_raw), whose search area has
+// at most 4096 positions and whose window fits SLR_WIN_BYTES of LDS take this path; everything else is appended to a work list for sad_loop_kernel.
+//
+// One WAVE per item.  The block is cut into 8x8 sub-blocks (8x4 used rows in the sub-sampled form) exactly as me_fullpel_kernel does: lane =
+// (x-group of 4 positions, sub-block), the lane keeps its sub-block of the source in registers and slides an 8-row (4-row) register ring down the
+// search column, 16 (8) v_qsad_pk_u16_u8 per step; the sub-block SADs meet through DPP quad / row adds (and ds_bpermute for 64x64).  A 16x16 item
+// therefore searches 64 positions per step, a 32x32 item 16, a 64x64 item 4.
+constexpr int SLR_WIN_BYTES = 10240, SLR_SRC_BYTES = 4096; // upper limits per wave; the launch sizes the slices from the batch maxima
+__device__ __forceinline__ bool sad_loop_ring_eligible(const SvtHipSadLoopDesc& d, const int win_budget, const int src_budget) {
+    const int bw = d.block_width, bh = d.block_height, W = d.search_area_width, H = d.search_area_height;
+    if (!(bw == 16 || bw == 32 || bw == 64) || d.src_stride_raw == 0 || d.ref_stride % d.src_stride_raw != 0) return false;
+    const int rstep = (int)(d.ref_stride / d.src_stride_raw);
+    if ((rstep != 1 && rstep != 2) || bh * rstep != bw || W <= 0 || H <= 0 || W * H > 4096) return false;
+    const int pitch = (((bw + W + 3) >> 2) + 3) & ~1, lines = H + rstep * (bh - 1);
+    return pitch * 4 * lines <= win_budget && bw * bh <= src_budget;
+}
+__global__ __launch_bounds__(256) void sad_loop_ring_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                            const SvtHipSadLoopDesc* __restrict__ descs, const uint32_t n,
+                                                            unsigned long long* __restrict__ keys, uint32_t* __restrict__ todo, const int win_budget,
+                                                            const int src_budget) {
+    HIP_DYNAMIC_SHARED(uint32_t, smem)
+    const int      l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t item = blockIdx.x * 4 + wv;
+    const bool     have = item < n;
+    const SvtHipSadLoopDesc d = descs[have ? item : 0];
+    const bool     mine = have && sad_loop_ring_eligible(d, win_budget, src_budget);
+    if (have && !mine && l == 0) todo[1 + atomicAdd(&todo[0], 1u)] = item; // work list of the generic kernel: todo[0] = count, todo[1..] = items
+    uint32_t* src_lds = smem + wv * ((win_budget + src_budget) / 4);
+    uint32_t* win     = src_lds + src_budget / 4;
+    const int bw = d.block_width, bh = d.block_height, W = d.search_area_width, H = d.search_area_height;
+    const int rstep = mine ? (int)(d.ref_stride / d.src_stride_raw) : 1;
+    const int src_pitch = bw >> 2, win_pitch = (((bw + W + 3) >> 2) + 3) & ~1, lines = H + rstep * (bh - 1);
+    if (mine) {
+        stage_rows_wide_any<64>(src_lds, src_pitch, src_base + d.src_off, d.src_stride, bw, bh, l);
+        stage_rows_wide_any<64>(win, win_pitch, ref_base + d.ref_off, d.src_stride_raw, bw + W - 1, lines, l);
+    }
+    __syncthreads(); // the only barrier: from here on a wave works alone on its own LDS slice
+    if (!mine) return;
+
+    const int sbc  = bw >> 3, nsb = sbc * sbc;           // sub-block grid sbc x sbc: 4, 16 or 64 lanes per x-group
+    const int RB   = 8 / rstep;                          // used rows per sub-block
+    const int sub  = l & (nsb - 1), xg = l / nsb, XG = 64 / nsb;
+    const int sx   = sub % sbc, sy = sub / sbc;
+    const int q    = l & 3;
+    uint32_t s[8][2];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int rr = r < RB ? r : 0;
+        s[r][0] = src_lds[(sy * RB + rr) * src_pitch + sx * 2 + 0];
+        s[r][1] = src_lds[(sy * RB + rr) * src_pitch + sx * 2 + 1];
+    }
+    const bool     skip_rule = (bw == 16) && (bh <= 16) && d.skip_search_line; // compute_sad_c.c:74-79: even search lines are skipped
+    const uint32_t qsel = 0x0c0c0100u + 0x0202u * (uint32_t)q;
+    const int      bp16 = (l ^ 16) << 2, bp32 = (l ^ 32) << 2;
+    uint32_t best = 0xffffffffu; // (sad << 12) | (yy * W + x): sad < 2^20, position < 2^12
+    for (int g0 = 0; 4 * g0 < W; g0 += XG) {
+        const int  g   = g0 + xg;        // this lane's x-group: positions 4 g .. 4 g + 3
+        const bool gok = 4 * g < W;
+        const int  x   = 4 * g + q;      // the position this lane reports after the quad reduction
+        const uint32_t* colp = win + (rstep * sy * RB) * win_pitch + sx * 2 + (gok ? g : 0);
+        for (int par = 0; par < rstep; par++) {
+            U64A4 ra[8], rb[8];
+#pragma unroll
+            for (int r = 0; r < 7; r++) {
+                const int rr = r < RB - 1 ? r : 0;
+                ra[r] = *(const U64A4*)(colp + (par + rstep * rr) * win_pitch);
+                rb[r] = *(const U64A4*)(colp + (par + rstep * rr) * win_pitch + 1);
+            }
+            // ring slot of block row r at step k is (k + r) % RB; RB is 8 or 4, so the 8-way unrolled body indexes registers statically
+            for (int yb = par; yb < H; yb += 8 * rstep) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int yy = yb + i * rstep;
+                    if (yy < H) {
+                        const uint32_t* np = colp + (yy + rstep * (RB - 1)) * win_pitch;
+                        unsigned long long acc = 0;
+                        if (RB == 8) {
+                            ra[(i + 7) & 7] = *(const U64A4*)(np);
+                            rb[(i + 7) & 7] = *(const U64A4*)(np + 1);
+#pragma unroll
+                            for (int r = 0; r < 8; r++) {
+                                acc = __builtin_amdgcn_qsad_pk_u16_u8(ra[(i + r) & 7].v, s[r][0], acc);
+                                acc = __builtin_amdgcn_qsad_pk_u16_u8(rb[(i + r) & 7].v, s[r][1], acc);
+                            }
+                        } else {
+                            ra[(i + 3) & 3] = *(const U64A4*)(np);
+                            rb[(i + 3) & 3] = *(const U64A4*)(np + 1);
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                acc = __builtin_amdgcn_qsad_pk_u16_u8(ra[(i + r) & 3].v, s[r][0], acc);
+                                acc = __builtin_amdgcn_qsad_pk_u16_u8(rb[(i + r) & 3].v, s[r][1], acc);
+                            }
+                        }
+                        const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+                        // quad = the four sub-blocks of a 16x16 (u16 lanes: 4 * 16320 < 65536); lane q then takes position q
+                        const uint32_t tlo = dpp_add_quad_xor2(dpp_add_quad_xor1(lo));
+                        const uint32_t thi = dpp_add_quad_xor2(dpp_add_quad_xor1(hi));
+                        uint32_t sad = __builtin_amdgcn_perm(thi, tlo, qsel);
+                        if (nsb >= 16) sad = dpp_add_row_ror8(dpp_add_row_ror4(sad));
+                        if (nsb == 64) {
+                            sad += (uint32_t)__builtin_amdgcn_ds_bpermute(bp16, (int)sad);
+                            sad += (uint32_t)__builtin_amdgcn_ds_bpermute(bp32, (int)sad);
+                        }
+                        const bool ok = gok && x < W && !(skip_rule && ((yy & 1) == 0));
+                        const uint32_t key = ok ? ((sad << 12) | (uint32_t)(yy * W + x)) : 0xffffffffu;
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)best, m);
+        best = o < best ? o : best;
+    }
+    if (l == 0 && best != 0xffffffffu) keys[item] = ((unsigned long long)(best >> 12) << 32) | (unsigned long long)(best & 0xfffu);
 }
 
 __global__ void sad_loop_finalize_kernel(const SvtHipSadLoopDesc* __restrict__ descs, uint32_t n, const unsigned long long* __restrict__ keys,
@@ -674,13 +805,22 @@ void svt_hip_sad_loop_batch(const uint8_t* src_base, const uint8_t* ref_base, co
     const int      tw = 4 << lxg, th = 256 >> lxg;
     const uint32_t tiles_x = (max_w + tw - 1) / tw, tiles_y = (max_h + th - 1) / th;
     HIP_CHECK(hipMemsetAsync(keys, 0xff, (size_t)n * 8, (hipStream_t)stream));
-    const dim3 grid(n, tiles_x * tiles_y);
+    uint32_t* todo = (uint32_t*)results; // (n + 1) dwords of the result array (16 bytes per item) serve as the work list until the finalize kernel fills it
+    HIP_CHECK(hipMemsetAsync(todo, 0, 4, (hipStream_t)stream));
+    // per-wave LDS slices of the ring kernel, from the batch maxima (small HME shapes then leave room for 4 workgroups per CU)
+    int src_budget = max_bw * max_bh, win_budget = ((((max_bw + max_w + 3) >> 2) + 3) & ~1) * 4 * (max_h + (max_ref_step < 1 ? 1 : max_ref_step) * (max_bh - 1));
+    src_budget = (src_budget > SLR_SRC_BYTES ? SLR_SRC_BYTES : src_budget + 15) & ~15;
+    win_budget = (win_budget > SLR_WIN_BYTES ? SLR_WIN_BYTES : win_budget + 15) & ~15;
+    hipLaunchKernelGGL(sad_loop_ring_kernel, dim3((n + 3) / 4), dim3(256), 4 * (size_t)(src_budget + win_budget) + 64, (hipStream_t)stream, src_base, ref_base, descs, n,
+                       (unsigned long long*)keys, todo, win_budget, src_budget);
+    SVT_LAUNCH_CHECK();
+    const dim3 grid(n < 2048 ? n : 2048, tiles_x * tiles_y);
     if (lxg == 2)
-        hipLaunchKernelGGL(sad_loop_kernel<2>, grid, dim3(256), shmem, (hipStream_t)stream, src_base, ref_base, descs, tiles_x, (unsigned long long*)keys);
+        hipLaunchKernelGGL(sad_loop_kernel<2>, grid, dim3(256), shmem, (hipStream_t)stream, src_base, ref_base, descs, (const uint32_t*)todo, tiles_x, (unsigned long long*)keys);
     else if (lxg == 3)
-        hipLaunchKernelGGL(sad_loop_kernel<3>, grid, dim3(256), shmem, (hipStream_t)stream, src_base, ref_base, descs, tiles_x, (unsigned long long*)keys);
+        hipLaunchKernelGGL(sad_loop_kernel<3>, grid, dim3(256), shmem, (hipStream_t)stream, src_base, ref_base, descs, (const uint32_t*)todo, tiles_x, (unsigned long long*)keys);
     else
-        hipLaunchKernelGGL(sad_loop_kernel<4>, grid, dim3(256), shmem, (hipStream_t)stream, src_base, ref_base, descs, tiles_x, (unsigned long long*)keys);
+        hipLaunchKernelGGL(sad_loop_kernel<4>, grid, dim3(256), shmem, (hipStream_t)stream, src_base, ref_base, descs, (const uint32_t*)todo, tiles_x, (unsigned long long*)keys);
     SVT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sad_loop_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, descs, n,
                        (const unsigned long long*)keys, results);

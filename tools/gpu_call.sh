@@ -1,8 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r30_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r30_pytest.log
-timeout 900 python bench.py --steps 20 --warmup 3 --extra > gpurun_out/r30_bench.json 2> gpurun_out/r30_bench.err; echo "bench rc=$?"; tail -c 400 gpurun_out/r30_bench.err
-timeout 600 python bench.py > gpurun_out/r30_bench_default.json 2> gpurun_out/r30_bench_default.err; echo "bench default rc=$?"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r30 -o run -- python bench.py --steps 20 --warmup 3 --no-cpu > gpurun_out/r30_prof.log 2>&1; echo "prof rc=$?"
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc30_fetch -o run -- python bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/r30_pmc_fetch.log 2>&1; echo "pmcf rc=$?"
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc30_write -o run -- python bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/r30_pmc_write.log 2>&1; echo "pmcw rc=$?"
+timeout 900 python -m pytest tests/test_sad.py -m gpu -x -q 2>&1 | tail -2
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r33 -o run -- python tools/microbench.py hme --steps 5 --warmup 1 > gpurun_out/r33_prof.log 2>&1; echo "prof rc=$?"
+python tools/microbench.py hme 2>/dev/null | cut -c1-600
