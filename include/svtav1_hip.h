@@ -41,6 +41,15 @@ int         svt_hip_selftest(uint32_t *results /* device, 64*8 u32 */, void *str
 
 /* VALU issue-rate probe (kind: 0 v_sad_u8, 1 v_qsad_pk_u16_u8, 2 v_add/xor pair, 3 v_mul_lo_u32+add, 4 v_mad_i64_i32,
  * 5 v_alignbyte): each of blocks*256 lanes issues iters*8 independent ops.  Used by bench.py --probe. */
+/* Streams and HIP graphs.  Every svt_hip_*_batch / *_frame entry point only enqueues work on the stream it is given (no host synchronisation),
+ * so a per-picture launch sequence can be captured once (begin ... calls ... end) and replayed with one launch per picture. */
+void       *svt_hip_stream_create(void);
+void        svt_hip_stream_destroy(void *stream);
+void        svt_hip_stream_synchronize(void *stream);
+void        svt_hip_graph_capture_begin(void *stream);
+void       *svt_hip_graph_capture_end(void *stream);   /* returns an executable graph */
+void        svt_hip_graph_launch(void *graph_exec, void *stream);
+void        svt_hip_graph_destroy(void *graph_exec);
 void        svt_hip_rate_probe(int kind, uint32_t iters, uint32_t blocks, uint32_t *sink, void *stream);
 
 /* ---------------------------------------------------------------- SAD family (a1-a6) -------------- */

@@ -61,6 +61,13 @@ PROTOTYPES = {
     "svt_hip_cdef_search_one_dual": (None, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "svt_search_one_dual_hip": (C.c_uint64, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
     "svt_hip_lpf_edges_batch": (None, [vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_uint32, vp]),
+    "svt_hip_stream_create": (vp, []),
+    "svt_hip_stream_destroy": (None, [vp]),
+    "svt_hip_stream_synchronize": (None, [vp]),
+    "svt_hip_graph_capture_begin": (None, [vp]),
+    "svt_hip_graph_capture_end": (vp, [vp]),
+    "svt_hip_graph_launch": (None, [vp, vp]),
+    "svt_hip_graph_destroy": (None, [vp]),
     "svt_hip_sad_nxm_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_sad_loop_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),

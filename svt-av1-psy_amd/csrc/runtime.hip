@@ -185,6 +185,28 @@ void svt_hip_shutdown(void) {
 
 const char* svt_hip_device_name(void) { return svthip::g_name; }
 
+// ---- HIP graphs: every batched entry point only enqueues work on the stream it is given (no host synchronisation, no host-side state), so a
+// whole per-picture sequence (padding + decimations, the transform chain, the in-loop filter chain) can be captured once and replayed.
+void* svt_hip_stream_create(void) {
+    svthip::ensure_device();
+    hipStream_t st;
+    HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    return (void*)st;
+}
+void svt_hip_stream_destroy(void* stream) { HIP_CHECK(hipStreamDestroy((hipStream_t)stream)); }
+void svt_hip_stream_synchronize(void* stream) { HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }
+void svt_hip_graph_capture_begin(void* stream) { HIP_CHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal)); }
+void* svt_hip_graph_capture_end(void* stream) {
+    hipGraph_t     graph = nullptr;
+    hipGraphExec_t exec  = nullptr;
+    HIP_CHECK(hipStreamEndCapture((hipStream_t)stream, &graph));
+    HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIP_CHECK(hipGraphDestroy(graph));
+    return (void*)exec;
+}
+void svt_hip_graph_launch(void* graph_exec, void* stream) { HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream)); }
+void svt_hip_graph_destroy(void* graph_exec) { HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)graph_exec)); }
+
 int svt_hip_selftest(uint32_t* results, void* stream) {
     svthip::ensure_device();
     hipLaunchKernelGGL(svt_hip_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, results);
