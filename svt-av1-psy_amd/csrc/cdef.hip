@@ -157,7 +157,6 @@ __device__ __forceinline__ uint32_t as_u32(const s16x2 v) { uint32_t r; __builti
 __device__ __forceinline__ s16x2    splat(const int v) { const short h = (short)v; return s16x2{h, h}; }
 __device__ __forceinline__ s16x2    pk_max(const s16x2 a, const s16x2 b) { return a > b ? a : b; }
 __device__ __forceinline__ s16x2    pk_min(const s16x2 a, const s16x2 b) { return a < b ? a : b; }
-__device__ __forceinline__ s16x2    pk_maxu(const s16x2 a, const s16x2 b) { const u16x2 x = (u16x2)a, y = (u16x2)b; return (s16x2)(x > y ? x : y); }
 struct __attribute__((aligned(4))) DwPairA4 { uint32_t lo, hi; };
 // pixel pair at an even pixel offset of the tile: one aligned ds_read_b32
 __device__ __forceinline__ s16x2 ld_pair_even(const uint16_t* p) { return as_pk(*(const uint32_t*)p); }

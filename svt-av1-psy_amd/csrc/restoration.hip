@@ -36,22 +36,6 @@ struct TileSrc { // where a processing unit's pixels come from
 __device__ __forceinline__ int rd_px(const void* p, const int highbd, const size_t off) {
     return highbd ? ((const uint16_t*)p)[off] : ((const uint8_t*)p)[off];
 }
-// restoration.c:288-332 (stripe boundary substitution) + svt_extend_frame (edge replication); raw mode reads as is
-__device__ __forceinline__ int src_px(const TileSrc& s, int y, int x) {
-    if (s.w == 0) return rd_px(s.data, s.highbd, (size_t)((long long)y * s.stride + x));
-    x = clampi(x, 0, s.w - 1);
-    if (y < s.stripe_top) {
-        if (s.stripe_top == 0) return rd_px(s.data, s.highbd, (size_t)clampi(y, 0, s.h - 1) * s.stride + x);
-        const int i = y - s.stripe_top;
-        return rd_px(s.above, s.highbd, (size_t)(2 * s.stripe_idx + (i + 2 > 0 ? i + 2 : 0)) * s.bstride + x);
-    }
-    if (y >= s.stripe_bot) {
-        if (s.stripe_bot >= s.h) return rd_px(s.data, s.highbd, (size_t)clampi(y, 0, s.h - 1) * s.stride + x);
-        const int i = y - s.stripe_bot;
-        return rd_px(s.below, s.highbd, (size_t)(2 * s.stripe_idx + (i < 1 ? i : 1)) * s.bstride + x);
-    }
-    return rd_px(s.data, s.highbd, (size_t)y * s.stride + x);
-}
 // Source row of plane row y for this unit (restoration.c:288-332 stripe boundary substitution + svt_extend_frame row replication); the
 // column is clamped by the caller.  Raw mode (w == 0): the block's own rows.
 __device__ __forceinline__ const void* src_row(const TileSrc& s, const int y) {
