@@ -245,6 +245,16 @@ void oracle_cdef_frame(int mode, const void *recon, int rstride, const void *sou
             if (pli)
                 for (int b = 0; b < 64; b++) { dir[b >> 3][b & 7] = dir_all[fb * 64 + b]; var[b >> 3][b & 7] = var_all[fb * 64 + b]; }
             int dirinit = 0;
+            /* Chroma of non-4:2:0 formats: svt_cdef_filter_fb remaps the luma directions IN PLACE on every pli == 1 call (cdef.c:388-395), which is
+             * right for the one call per plane of the apply path (plane 2 then sees plane 1's remapped array) but would remap again per candidate
+             * in a strength search.  SVT-AV1 only encodes 4:2:0 (xdec == ydec), where the remap never runs; the frame drivers here define the
+             * non-4:2:0 case as "every chroma call sees the luma directions remapped exactly once" and therefore call the block driver with
+             * pli = 2 (no in-place remap) on a freshly remapped copy. */
+            const int pli_call = pli ? 2 : 0;
+            if (pli && xdec != ydec) {
+                static const uint8_t conv422[8] = {7, 0, 2, 4, 5, 6, 6, 6}, conv440[8] = {1, 2, 2, 2, 3, 4, 6, 0};
+                for (int b = 0; b < 64; b++) dir[b >> 3][b & 7] = (xdec ? conv422 : conv440)[dir[b >> 3][b & 7] & 7];
+            }
             for (int c = 0; c < (mode == 1 ? ncand : 1); c++) {
                 const int lvl = mode == 1 ? pri[c] : pri[fb], sc = mode == 1 ? sec[c] : sec[fb];
                 if (mode == 0) {
@@ -252,12 +262,12 @@ void oracle_cdef_frame(int mode, const void *recon, int rstride, const void *sou
                     } else {
                         uint8_t  *o8  = is16 ? NULL : (uint8_t *)out + (size_t)(fbr * bh) * ostride + fbc * bw;
                         uint16_t *o16 = is16 ? (uint16_t *)out + (size_t)(fbr * bh) * ostride + fbc * bw : NULL;
-                        oracle_cdef_filter_fb(o8, o16, ostride, in, xdec, ydec, dir, &dirinit, var, pli, dlist, cnt, lvl, sc, pri_damping, sec_damping,
+                        oracle_cdef_filter_fb(o8, o16, ostride, in, xdec, ydec, dir, &dirinit, var, pli_call, dlist, cnt, lvl, sc, pri_damping, sec_damping,
                                               coeff_shift, 1);
                     }
                 } else {
                     /* the first non-zero candidate initialises dir/var; a zero-strength candidate does not need them */
-                    oracle_cdef_filter_fb(is16 ? NULL : (uint8_t *)tmp, is16 ? tmp : NULL, 0, in, xdec, ydec, dir, &dirinit, var, pli, dlist, cnt, lvl, sc,
+                    oracle_cdef_filter_fb(is16 ? NULL : (uint8_t *)tmp, is16 ? tmp : NULL, 0, in, xdec, ydec, dir, &dirinit, var, pli_call, dlist, cnt, lvl, sc,
                                           pri_damping, sec_damping, coeff_shift, subsampling);
                     const uint8_t *sp = (const uint8_t *)source + ((size_t)(fbr * bh) * sstride + fbc * bw) * px;
                     mse[(size_t)fb * ncand + c] = oracle_cdef_dist(sp, sstride, tmp, dlist, cnt, 8 >> xdec, 8 >> ydec, coeff_shift, pli, subsampling, is16);

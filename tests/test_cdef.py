@@ -50,10 +50,10 @@ def run_frame(be, oracle, mode, recon, source, xdec, ydec, pli, bd, skip, pri, s
     return o_dir, o_var
 
 
-@pytest.mark.parametrize("bd", [8, 10])
-def test_cdef_frame_apply_and_search(be, oracle, bd):
-    g = rng(50 + bd)
-    W, H = ((3840, 2160) if bd == 10 else (1920, 1080)) if be.is_gpu else (200, 136)
+@pytest.mark.parametrize("bd,damping", [(8, 5), (10, 5), (12, 6), (10, 3)])
+def test_cdef_frame_apply_and_search(be, oracle, bd, damping):
+    g = rng(50 + bd + damping)
+    W, H = ((3840, 2160) if (bd, damping) == (10, 5) else (1920, 1080)) if be.is_gpu else (200, 136)
     luma = synth_plane(g, W, H, bd)
     src_l = np.clip(luma + g.integers(-6, 7, luma.shape), 0, (1 << bd) - 1)
     nhfb, nvfb = (W + 63) // 64, (H + 63) // 64
@@ -64,17 +64,23 @@ def test_cdef_frame_apply_and_search(be, oracle, bd):
         # search: all 64 luma strengths on the GPU (pri 0..15 x sec {0,1,2,4}), a subset on the interpreter
         cands = [(pr, sc) for pr in range(16) for sc in (0, 1, 2, 4)] if be.is_gpu else [(0, 0), (4, 2), (15, 4), (1, 0), (0, 1), (7, 1), (9, 0), (2, 4), (5, 2)]
         pri, sec = np.array([c[0] for c in cands], np.int32), np.array([c[1] for c in cands], np.int32)
-        d, v = run_frame(be, oracle, 1, luma, src_l, 0, 0, 0, bd, skip, pri, sec, dir0, var0, sub=2 if skip_frac else 1)
+        d, v = run_frame(be, oracle, 1, luma, src_l, 0, 0, 0, bd, skip, pri, sec, dir0, var0, sub=2 if skip_frac else 1, damping=damping)
         # apply: per-block strengths, (4, 2) with some zero-strength and some secondary-only blocks
         apri = np.where(g.random(nfb) < 0.2, 0, 4).astype(np.int32)
         asec = np.where(apri == 0, (g.random(nfb) < 0.5) * 1, 2).astype(np.int32)  # level 0 with a secondary strength filters along dir 0
-        run_frame(be, oracle, 0, luma, src_l, 0, 0, 0, bd, skip, apri, asec, dir0, var0)
+        run_frame(be, oracle, 0, luma, src_l, 0, 0, 0, bd, skip, apri, asec, dir0, var0, damping=damping)
         # chroma 4:2:0 uses the luma directions
         cw, ch = W // 2, H // 2
         chroma = synth_plane(g, cw, ch, bd)
         src_c = np.clip(chroma + g.integers(-6, 7, chroma.shape), 0, (1 << bd) - 1)
-        run_frame(be, oracle, 1, chroma, src_c, 1, 1, 1, bd, skip, pri[:9], sec[:9], d, v)
-        run_frame(be, oracle, 0, chroma, src_c, 1, 1, 2, bd, skip, apri, asec, d, v)
+        run_frame(be, oracle, 1, chroma, src_c, 1, 1, 1, bd, skip, pri[:9], sec[:9], d, v, damping=damping)
+        run_frame(be, oracle, 0, chroma, src_c, 1, 1, 2, bd, skip, apri, asec, d, v, damping=damping)
+        if not be.is_gpu or (bd, damping) == (8, 5):  # 4:2:2 and 4:4:0 chroma: 4x8 / 8x4 units and the direction remap of cdef.c:388-395
+            for (xd, yd) in ((1, 0), (0, 1)):
+                c2 = synth_plane(g, W >> xd, H >> yd, bd)
+                s2 = np.clip(c2 + g.integers(-6, 7, c2.shape), 0, (1 << bd) - 1)
+                run_frame(be, oracle, 1, c2, s2, xd, yd, 1, bd, skip, pri[:9], sec[:9], d, v, damping=damping)
+                run_frame(be, oracle, 0, c2, s2, xd, yd, 2, bd, skip, apri, asec, d, v, damping=damping)
 
 
 def test_cdef_single_call_symbols(be, oracle):
