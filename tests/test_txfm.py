@@ -24,7 +24,7 @@ def test_fwd_txfm2d_batch(be, oracle, ts):
     if not be.is_gpu and w * h >= 2048:
         types, n = types[:2], min(n, 2)
     stride = w + 3
-    for bd in ((8, 10) if be.is_gpu else (10,)):
+    for bd in ((8, 10, 12) if be.is_gpu else (10, 12)):
         amp = (1 << bd) - 1
         res = g.integers(-amp, amp + 1, (n, h * stride)).astype(np.int16)
         res[0, :] = amp  # extreme block
@@ -51,7 +51,7 @@ def test_inv_txfm2d_add_batch(be, oracle, ts):
     if not be.is_gpu and w * h >= 2048:
         types, n = types[:2], 2
     stride = w + 5
-    for bd in ((8, 10) if be.is_gpu else (10,)):
+    for bd in ((8, 10, 12) if be.is_gpu else (10, 12)):
         amp = (1 << bd) - 1
         coeffs = np.zeros((n, iw * ih), np.int32)
         pred = g.integers(0, 1 << bd, (n, h * stride)).astype(np.uint16)
