@@ -279,3 +279,58 @@ def lr_stats(torch, lib, pkg, stream, steps, warmup):
                                            "roofline": {"bound": "mfma", "achieved": issued / t / 1e12, "peak": 5000.0, "unit": "TOP/s (int8, dense)",
                                                         "frac": issued / t / 1e12 / 5000.0,
                                                         "note": "issued int8 ops incl. 64-column padding and the three digit products; peak = 2x the 2.5 PFLOP/s bf16 dense figure"}}}
+
+
+def cdef_chain(torch, lib, pkg, stream, steps, warmup):
+    """config 4, the whole CDEF stage of a 3840x2160 10-bit 4:2:0 picture, device resident: strength search over all 64 strengths on Y, U and V
+    (cdef_process.c:106) -> joint_strength_search_dual with 8 pairs (enc_cdef.c:697) -> per-filter-block assignment (enc_cdef.c:916) -> apply on
+    the three planes (enc_cdef.c:284).  torch only glues tables between the calls (U + V distortion, strength index -> (pri, sec))."""
+    Wc, Hc, bd = 3840, 2160, 10
+    g = np.random.default_rng(14)
+
+    def plane(w, h):
+        yy, xx = np.mgrid[0:h, 0:w]
+        rec = np.clip(((xx * 2 + yy * 3) % 1024) // 2 + (((xx // 8 + yy // 8) % 5) << 5) + g.integers(-16, 17, (h, w)), 0, 1023).astype(np.uint16)
+        return rec, np.clip(rec.astype(np.int32) + g.integers(-6, 7, rec.shape), 0, 1023).astype(np.uint16)
+    nhfb, nvfb = Wc // 64, (Hc + 63) // 64
+    nfb = nhfb * nvfb
+    planes = [plane(Wc, Hc), plane(Wc // 2, Hc // 2), plane(Wc // 2, Hc // 2)]
+    d_rec = [_dev(torch, r) for r, _ in planes]
+    d_src = [_dev(torch, s_) for _, s_ in planes]
+    d_out = [_dev(torch, r) for r, _ in planes]
+    d_skip = _dev(torch, np.zeros((nvfb * 8, nhfb * 8), np.uint8))
+    cands = [(pr, sc) for pr in range(16) for sc in (0, 1, 2, 4)]
+    d_pri, d_sec = _dev(torch, np.array([c[0] for c in cands], np.int32)), _dev(torch, np.array([c[1] for c in cands], np.int32))
+    d_dir, d_var = torch.zeros(nfb * 64, dtype=torch.uint8, device="cuda"), torch.zeros(nfb * 64, dtype=torch.int32, device="cuda")
+    d_mse = [torch.zeros(nfb * 64, dtype=torch.int64, device="cuda") for _ in range(3)]
+    d_lev0, d_lev1 = torch.zeros(65, dtype=torch.int32, device="cuda"), torch.zeros(65, dtype=torch.int32, device="cuda")
+    d_best, d_ws = torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(4096 + nfb, dtype=torch.int64, device="cuda")
+    d_gi = torch.zeros(nfb, dtype=torch.int8, device="cuda")
+    sec_map = torch.tensor([0, 1, 2, 4], dtype=torch.int32, device="cuda")
+    a_pri = [torch.zeros(nfb, dtype=torch.int32, device="cuda") for _ in range(2)]
+    a_sec = [torch.zeros(nfb, dtype=torch.int32, device="cuda") for _ in range(2)]
+
+    def params(mode, pl, pri_t, sec_t):
+        w, h, dec = (Wc, Hc, 0) if pl == 0 else (Wc // 2, Hc // 2, 1)
+        return pkg.CdefParams(d_rec[pl].data_ptr(), d_src[pl].data_ptr(), d_out[pl].data_ptr(), w, w, w, w, h, dec, dec, pl, 1, bd - 8, 4, 4, 1, 64 if mode else 0,
+                              d_skip.data_ptr(), pri_t.data_ptr(), sec_t.data_ptr(), d_dir.data_ptr(), d_var.data_ptr(), d_mse[pl].data_ptr())
+    P_search = [params(1, pl, d_pri, d_sec) for pl in range(3)]
+    P_apply = [params(0, pl, a_pri[min(pl, 1)], a_sec[min(pl, 1)]) for pl in range(3)]
+
+    def fn():
+        for pl in range(3):
+            lib.svt_hip_cdef_frame(1, C.byref(P_search[pl]), stream)
+        d_mse[1].add_(d_mse[2])
+        lib.svt_hip_cdef_joint_strength_search(d_mse[0].data_ptr(), d_mse[1].data_ptr(), d_lev0.data_ptr(), d_lev1.data_ptr(), 8, nfb, 0, 64, d_best.data_ptr(),
+                                               d_ws.data_ptr(), stream)
+        lib.svt_hip_cdef_assign_fb_strengths(d_mse[0].data_ptr(), d_mse[1].data_ptr(), d_lev0.data_ptr(), d_lev1.data_ptr(), 8, nfb, d_gi.data_ptr(), stream)
+        gi = d_gi.long()
+        for k, lev in enumerate((d_lev0, d_lev1)):
+            st = lev[gi]
+            a_pri[k].copy_(st // 4)
+            a_sec[k].copy_(sec_map[(st % 4).long()])
+        for pl in range(3):
+            lib.svt_hip_cdef_frame(0, C.byref(P_apply[pl]), stream)
+    t = _time(torch, fn, steps, warmup)
+    return {"cdef_stage_4k10_420": {"frames_per_s": 1 / t, "ms": t * 1e3, "filter_blocks": nfb, "strengths_searched": 64, "pairs_selected": 8,
+                                    "note": "Y+U+V search, joint strength search (8 greedy + 32 refinement rounds), per-block assignment, Y+U+V apply"}}

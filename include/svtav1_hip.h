@@ -286,10 +286,17 @@ void svt_hip_cdef_frame(int mode, const SvtHipCdefParams *params, void *stream);
 /* Strength selection over the search output: svt_search_one_dual -> svt_search_one_dual_c (aom_dsp_rtcd.h:242,
  * enc_cdef.c:627-683).  mse0 / mse1 = [sb_count][64] luma / chroma distortion tables (device; svt_hip_cdef_frame(mode 1) writes exactly this
  * layout), lev0 / lev1 = device arrays holding the nb_strengths pairs selected so far, entry [nb_strengths] receives the new pair,
- * best_tot_mse[1] the frame total.  workspace: 768 bytes of device scratch. */
+ * best_tot_mse[1] the frame total.  workspace: (4096 + sb_count) * 8 bytes of device scratch. */
 void svt_hip_cdef_search_one_dual(const uint64_t *mse0, const uint64_t *mse1, int *lev0, int *lev1, int nb_strengths, int sb_count, int start_gi,
                                   int end_gi, uint64_t *best_tot_mse, void *workspace, void *stream);
 uint64_t svt_search_one_dual_hip(int *lev0, int *lev1, int nb_strengths, uint64_t **mse[2], int sb_count, int start_gi, int end_gi);
+/* joint_strength_search_dual (enc_cdef.c:697-726): nb_strengths greedy additions followed by 4 * nb_strengths refinement rounds, every step a
+ * svt_search_one_dual on the device; lev0 / lev1 (device, >= nb_strengths entries) receive the selected pairs, best_tot_mse[1] the frame total. */
+void svt_hip_cdef_joint_strength_search(const uint64_t *mse0, const uint64_t *mse1, int *lev0, int *lev1, int nb_strengths, int sb_count,
+                                        int start_gi, int end_gi, uint64_t *best_tot_mse, void *workspace, void *stream);
+/* per filter block: index of the selected pair with the smallest luma + chroma distortion (finish_cdef_search, enc_cdef.c:916-931) */
+void svt_hip_cdef_assign_fb_strengths(const uint64_t *mse0, const uint64_t *mse1, const int *lev0, const int *lev1, int nb_strengths, int sb_count,
+                                      int8_t *best_gi, void *stream);
 /* RTCD-signature single-call forms (common_dsp_rtcd.h:1010-1029, aom_dsp_rtcd.h:208-209) */
 uint8_t  svt_aom_cdef_find_dir_hip(const uint16_t *img, int32_t stride, int32_t *var, int32_t coeff_shift);
 void     svt_aom_cdef_find_dir_dual_hip(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2,

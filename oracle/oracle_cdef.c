@@ -310,3 +310,26 @@ uint64_t oracle_search_one_dual(int *lev0, int *lev1, int nb_strengths, const ui
     lev1[nb_strengths] = best1;
     return best_tot;
 }
+
+/* joint_strength_search_dual (enc_cdef.c:697-726) */
+uint64_t oracle_joint_strength_search(int *lev0, int *lev1, int nb_strengths, const uint64_t *mse0, const uint64_t *mse1, int sb_count, int start_gi, int end_gi) {
+    uint64_t best = (uint64_t)1 << 63;
+    for (int i = 0; i < nb_strengths; i++) best = oracle_search_one_dual(lev0, lev1, i, mse0, mse1, sb_count, start_gi, end_gi);
+    for (int i = 0; i < 4 * nb_strengths; i++) {
+        for (int j = 0; j < nb_strengths - 1; j++) { lev0[j] = lev0[j + 1]; lev1[j] = lev1[j + 1]; }
+        best = oracle_search_one_dual(lev0, lev1, nb_strengths - 1, mse0, mse1, sb_count, start_gi, end_gi);
+    }
+    return best;
+}
+/* finish_cdef_search's per-filter-block assignment (enc_cdef.c:916-931) */
+void oracle_assign_fb_strengths(const uint64_t *mse0, const uint64_t *mse1, const int *lev0, const int *lev1, int nb_strengths, int sb_count, int8_t *best_gi) {
+    for (int i = 0; i < sb_count; i++) {
+        uint64_t best = (uint64_t)1 << 63;
+        int      arg  = 0;
+        for (int gi = 0; gi < nb_strengths; gi++) {
+            const uint64_t c = mse0[(size_t)i * 64 + lev0[gi]] + mse1[(size_t)i * 64 + lev1[gi]];
+            if (c < best) { best = c; arg = gi; }
+        }
+        best_gi[i] = (int8_t)arg;
+    }
+}

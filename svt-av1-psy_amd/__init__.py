@@ -68,6 +68,8 @@ PROTOTYPES = {
     "svt_hip_graph_capture_end": (vp, [vp]),
     "svt_hip_graph_launch": (None, [vp, vp]),
     "svt_hip_graph_destroy": (None, [vp]),
+    "svt_hip_cdef_joint_strength_search": (None, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "svt_hip_cdef_assign_fb_strengths": (None, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "svt_hip_sad_nxm_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_sad_loop_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),

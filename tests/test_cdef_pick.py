@@ -52,7 +52,7 @@ def test_search_one_dual_hip(be, oracle):
         ha, hb = np.zeros(9, np.int32), np.zeros(9, np.int32)
         d0, d1 = be.dev(m0), be.dev(m1)
         dla, dlb = be.dev(np.zeros(65, np.int32)), be.dev(np.zeros(65, np.int32))
-        dbest, ws = be.empty(1, np.uint64), be.empty(96, np.uint64)
+        dbest, ws = be.empty(1, np.uint64), be.empty(4096 + max(n, 1), np.uint64)
         for nb in range(3):
             want = oracle.oracle_search_one_dual(p(la), p(lb), nb, p(m0), p(m1), n, s, e)
             got = be.lib.svt_search_one_dual_hip(p(ha), p(hb), nb, arr, n, s, e)  # RTCD form, host pointer arrays
@@ -60,3 +60,23 @@ def test_search_one_dual_hip(be, oracle):
             be.lib.svt_hip_cdef_search_one_dual(be.ptr(d0), be.ptr(d1), be.ptr(dla), be.ptr(dlb), nb, n, s, e, be.ptr(dbest), be.ptr(ws), be.stream)  # device-resident form
             assert int(be.host(dbest)[0]) == want
             assert np.array_equal(be.host(dla)[:nb + 1], la[:nb + 1]) and np.array_equal(be.host(dlb)[:nb + 1], lb[:nb + 1])
+
+
+def test_joint_strength_search_and_assignment(be, oracle):
+    """joint_strength_search_dual + the per-filter-block assignment of finish_cdef_search, device-resident on the search tables."""
+    g = rng(33)
+    oracle.oracle_joint_strength_search.restype = C.c_uint64
+    for (n, s, e, nb) in ([(510, 0, 64, 8), (77, 0, 16, 4), (40, 4, 20, 2), (9, 0, 64, 1)] if be.is_gpu else [(40, 0, 16, 2), (9, 0, 8, 1)]):
+        m0, m1 = tables(g, n)
+        la, lb = np.zeros(9, np.int32), np.zeros(9, np.int32)
+        want = oracle.oracle_joint_strength_search(p(la), p(lb), nb, p(m0), p(m1), n, s, e)
+        wgi = np.zeros(n, np.int8)
+        oracle.oracle_assign_fb_strengths(p(m0), p(m1), p(la), p(lb), nb, n, p(wgi))
+        d0, d1 = be.dev(m0), be.dev(m1)
+        dla, dlb = be.dev(np.zeros(65, np.int32)), be.dev(np.zeros(65, np.int32))
+        dbest, ws, dgi = be.empty(1, np.uint64), be.empty(4096 + max(n, 1), np.uint64), be.empty(n, np.int8)
+        be.lib.svt_hip_cdef_joint_strength_search(be.ptr(d0), be.ptr(d1), be.ptr(dla), be.ptr(dlb), nb, n, s, e, be.ptr(dbest), be.ptr(ws), be.stream)
+        be.lib.svt_hip_cdef_assign_fb_strengths(be.ptr(d0), be.ptr(d1), be.ptr(dla), be.ptr(dlb), nb, n, be.ptr(dgi), be.stream)
+        assert int(be.host(dbest)[0]) == want, (n, s, e, nb)
+        assert np.array_equal(be.host(dla)[:nb], la[:nb]) and np.array_equal(be.host(dlb)[:nb], lb[:nb]), (n, s, e, nb)
+        assert np.array_equal(be.host(dgi), wgi), (n, s, e, nb)
