@@ -102,38 +102,61 @@ __device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, con
     }
 }
 struct WienerTaps { int16_t fx[8], fy[8]; };
-// Wiener on a staged tile: horizontal pass (clamped, convolve.c:63-83 / :156-176) into `mid`, vertical pass to `out(y, x)`
+typedef short lr_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int lr_sdot2(const uint32_t a, const uint32_t b, const int c) { // c + a.lo * b.lo + a.hi * b.hi, signed 16-bit (v_dot2_i32_i16)
+    lr_s2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    return __builtin_amdgcn_sdot2(x, y, c, false);
+}
+__device__ __forceinline__ uint32_t lr_pack(const int lo, const int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+struct __attribute__((aligned(4))) LrDw5 { uint32_t d[5]; };
+// Wiener on a staged tile: horizontal pass (clamped, convolve.c:63-83 / :156-176) into `mid`, vertical pass to `out(y, x)`.  A thread produces two
+// horizontally adjacent samples per step from packed pairs: the horizontal pass reads five aligned dwords and runs eight v_dot2_i32_i16 (the odd
+// output on funnel-shifted pairs), the vertical pass regroups vertically adjacent rows with v_perm_b32 and runs eight more.  The reference's
+// "+ (centre << FILTER_BITS)" is tap 3 plus 128.  Every operand fits int16: pixels <= 4095, mid <= 2^15 - 1 (WIENER_CLAMP_LIMIT), taps < 2^8.
 template <typename OUT> __device__ __forceinline__ void wiener_tile(const uint16_t* tile, uint16_t* mid, const WienerTaps& t, const int uw, const int uh,
                                                                     const int bd, const int tid, OUT out) {
     int r0 = 3, r1 = 2 * FILTER_BITS - 3; // get_conv_params_wiener, convolve.h:70-88
     const int range = bd + FILTER_BITS - r0 + 2;
     if (range > 16) { r0 += range - 16; r1 -= range - 16; }
     const int lim = (1 << (bd + 1 + FILTER_BITS - r0)) - 1;
-    for (int i = tid; i < (uh + 6) * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
+    const uint32_t f01 = lr_pack(t.fx[0], t.fx[1]), f23 = lr_pack(t.fx[2], t.fx[3] + (1 << FILTER_BITS)), f45 = lr_pack(t.fx[4], t.fx[5]), f67 = lr_pack(t.fx[6], t.fx[7]);
+    for (int i = tid; i < (uh + 6) * 32; i += 256) {
+        const int r = i >> 5, c = (i & 31) * 2;
         if (c < uw) {
-            const uint16_t* p   = tile + r * TW + c; // p[3] is the centre pixel
-            int             sum = ((int)p[3] << FILTER_BITS) + (1 << (bd + FILTER_BITS - 1));
-#pragma unroll
-            for (int k = 0; k < 8; k++) sum += (int)p[k] * t.fx[k];
-            mid[i] = (uint16_t)clampi(rpot(sum, r0), 0, lim);
+            const LrDw5 v = *(const LrDw5*)(tile + r * TW + c); // pixels c .. c + 9; pixel c + 3 is the centre of output c
+            const int   o = 1 << (bd + FILTER_BITS - 1);
+            const int   s0 = lr_sdot2(v.d[0], f01, lr_sdot2(v.d[1], f23, lr_sdot2(v.d[2], f45, lr_sdot2(v.d[3], f67, o))));
+            const uint32_t e0 = __builtin_amdgcn_alignbyte(v.d[1], v.d[0], 2), e1 = __builtin_amdgcn_alignbyte(v.d[2], v.d[1], 2),
+                           e2 = __builtin_amdgcn_alignbyte(v.d[3], v.d[2], 2), e3 = __builtin_amdgcn_alignbyte(v.d[4], v.d[3], 2);
+            const int   s1 = lr_sdot2(e0, f01, lr_sdot2(e1, f23, lr_sdot2(e2, f45, lr_sdot2(e3, f67, o))));
+            *(uint32_t*)(mid + r * 64 + c) = lr_pack(clampi(rpot(s0, r0), 0, lim), clampi(rpot(s1, r0), 0, lim));
         }
     }
     __syncthreads();
-    for (int i = tid; i < uh * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
+    const uint32_t g01 = lr_pack(t.fy[0], t.fy[1]), g23 = lr_pack(t.fy[2], t.fy[3] + (1 << FILTER_BITS)), g45 = lr_pack(t.fy[4], t.fy[5]), g6 = lr_pack(t.fy[6], 0);
+    for (int i = tid; i < uh * 32; i += 256) {
+        const int r = i >> 5, c = (i & 31) * 2;
         if (c < uw) {
-            const uint16_t* p   = mid + r * 64 + c; // rows r .. r+6 <-> y-3 .. y+3
-            int             sum = ((int)p[3 * 64] << FILTER_BITS) - (1 << (bd + r1 - 1));
+            const uint16_t* p = mid + r * 64 + c; // rows r .. r + 6 <-> y - 3 .. y + 3; tap 7 multiplies the zeroed row of convolve.c:118
+            uint32_t d[7];
 #pragma unroll
-            for (int k = 0; k < 7; k++) sum += (int)p[k * 64] * t.fy[k]; // tap 7 multiplies the zeroed row of convolve.c:118
-            out(r, c, clampi(rpot(sum, r1), 0, (1 << bd) - 1));
+            for (int k = 0; k < 7; k++) d[k] = *(const uint32_t*)(p + k * 64);
+            const int o = -(1 << (bd + r1 - 1));
+            // column c: low halves of consecutive rows paired; column c + 1: high halves
+            const int sl = lr_sdot2(__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), g01,
+                           lr_sdot2(__builtin_amdgcn_perm(d[3], d[2], 0x05040100u), g23,
+                           lr_sdot2(__builtin_amdgcn_perm(d[5], d[4], 0x05040100u), g45, lr_sdot2(d[6] & 0xffffu, g6, o))));
+            const int sh = lr_sdot2(__builtin_amdgcn_perm(d[1], d[0], 0x07060302u), g01,
+                           lr_sdot2(__builtin_amdgcn_perm(d[3], d[2], 0x07060302u), g23,
+                           lr_sdot2(__builtin_amdgcn_perm(d[5], d[4], 0x07060302u), g45, lr_sdot2(d[6] >> 16, g6, o))));
+            out(r, c, clampi(rpot(sl, r1), 0, (1 << bd) - 1));
+            if (c + 1 < uw) out(r, c + 1, clampi(rpot(sh, r1), 0, (1 << bd) - 1));
         }
     }
 }
 
-// Self-guided filter on a staged tile.  AB holds A then B for positions (i, j) in [-1, uh] x [-1, uw] (pitch 66).
-// pass 0: r = 2, A/B on odd i only ("fast", restoration.c:669-800); pass 1: r = 1 (restoration.c:801-880).
 typedef unsigned short lr_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t lr_dot2(const uint32_t a, const uint32_t b, const uint32_t c) { // c + a.lo * b.lo + a.hi * b.hi (v_dot2_u32_u16)
     lr_us2 x, y;

@@ -359,6 +359,8 @@ inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh)
     unsigned long long v = ((unsigned long long)hi << 32) | lo;
     return (unsigned)(v >> (sh & 31));
 }
+typedef short hipemu_s2 __attribute__((vector_size(4)));
+inline int __builtin_amdgcn_sdot2(hipemu_s2 a, hipemu_s2 b, int c, bool) { return c + (int)a[0] * (int)b[0] + (int)a[1] * (int)b[1]; }
 // v_mfma_i32_16x16x64_i8: D[i][j] = C[i][j] + sum over the 64 k of A[i][k] * B[k][j], signed int8.  Lane l holds A[l & 15][16 (l >> 4) .. +15] and
 // B[16 (l >> 4) .. +15][l & 15] (16 bytes each) and C/D[4 (l >> 4) + r][l & 15], r = 0..3.  Implemented with the wave exchange primitive.
 typedef int hipemu_i32x4 __attribute__((vector_size(16)));
