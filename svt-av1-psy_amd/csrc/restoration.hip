@@ -212,27 +212,53 @@ __device__ __forceinline__ void sgr_ab_pass(const uint16_t* tile, uint16_t* A16,
         }
     }
 }
-__device__ __forceinline__ int32_t sgr_flt_px(const uint16_t* tile, const uint16_t* A16, const int32_t* B32, const int pass, const int i, const int j) {
-    const uint16_t* A = A16 + (i + 1) * 66 + (j + 1);
-    const int32_t*  B = B32 + (i + 1) * 66 + (j + 1);
-    int32_t        a, b, nb;
-    if (pass == 0) {
-        if (!(i & 1)) {
-            nb = 5;
-            a  = (A[-66] + A[66]) * 6 + (A[-67] + A[65] + A[-65] + A[67]) * 5;
-            b  = (B[-66] + B[66]) * 6 + (B[-67] + B[65] + B[-65] + B[67]) * 5;
-        } else {
-            nb = 4;
-            a  = A[0] * 6 + (A[-1] + A[1]) * 5;
-            b  = B[0] * 6 + (B[-1] + B[1]) * 5;
-        }
+typedef unsigned short lr_u16x2 __attribute__((vector_size(4)));
+__device__ __forceinline__ lr_u16x2 lr_as_pk(const uint32_t v) { lr_u16x2 r; __builtin_memcpy(&r, &v, 4); return r; }
+__device__ __forceinline__ lr_u16x2 lr_splat(const int v) { const unsigned short h = (unsigned short)v; return lr_u16x2{h, h}; }
+struct __attribute__((aligned(8))) LrInt4 { int32_t v[4]; };
+struct __attribute__((aligned(4))) LrDw2 { uint32_t lo, hi; };
+// Weighted 3x3 sums of the A / B tables for the output pair (i, j), (i, j + 1), j even (restoration.c:770-800 "fast" r = 2 pass on alternate rows,
+// :850-880 r = 1 pass).  A <= 256 and the weights sum to 32, so the A side runs on packed u16 pairs: per table row the two dwords holding columns
+// j - 1 .. j + 2 give the "left" pair, the "right" pair and (one funnel shift) the "centre" pair of the two outputs.
+__device__ __forceinline__ void sgr_flt_pair(const uint16_t* tile, const uint16_t* A16, const int32_t* B32, const int pass, const int i, const int j, int32_t (&f)[2]) {
+    const uint16_t* A = A16 + (i + 1) * 66 + j; // column j - 1 of table row i (dword aligned: j even, 66 even)
+    const int32_t*  B = B32 + (i + 1) * 66 + j;
+    lr_u16x2 a;
+    int32_t  b0, b1, nb;
+    auto rowA = [&](const int dr, lr_u16x2& L, lr_u16x2& Cc, lr_u16x2& R) {
+        const LrDw2 v = *(const LrDw2*)(A + dr * 66);
+        L = lr_as_pk(v.lo); R = lr_as_pk(v.hi); Cc = lr_as_pk(__builtin_amdgcn_alignbyte(v.hi, v.lo, 2));
+    };
+    if (pass == 0 && (i & 1)) {
+        nb = 4;
+        lr_u16x2 L, Cc, R;
+        rowA(0, L, Cc, R);
+        a = Cc * lr_splat(6) + (L + R) * lr_splat(5);
+        const LrInt4 q = *(const LrInt4*)B;
+        b0 = q.v[1] * 6 + (q.v[0] + q.v[2]) * 5;
+        b1 = q.v[2] * 6 + (q.v[1] + q.v[3]) * 5;
     } else {
         nb = 5;
-        a  = (A[0] + A[-1] + A[1] + A[-66] + A[66]) * 4 + (A[-67] + A[65] + A[-65] + A[67]) * 3;
-        b  = (B[0] + B[-1] + B[1] + B[-66] + B[66]) * 4 + (B[-67] + B[65] + B[-65] + B[67]) * 3;
+        lr_u16x2 Lm, Cm, Rm, Lp, Cp, Rp;
+        rowA(-1, Lm, Cm, Rm);
+        rowA(1, Lp, Cp, Rp);
+        const LrInt4 qm = *(const LrInt4*)(B - 66), qp = *(const LrInt4*)(B + 66);
+        if (pass == 0) {
+            a  = (Cm + Cp) * lr_splat(6) + (Lm + Rm + Lp + Rp) * lr_splat(5);
+            b0 = (qm.v[1] + qp.v[1]) * 6 + (qm.v[0] + qm.v[2] + qp.v[0] + qp.v[2]) * 5;
+            b1 = (qm.v[2] + qp.v[2]) * 6 + (qm.v[1] + qm.v[3] + qp.v[1] + qp.v[3]) * 5;
+        } else {
+            lr_u16x2 L0, C0, R0;
+            rowA(0, L0, C0, R0);
+            const LrInt4 q0 = *(const LrInt4*)B;
+            a  = (C0 + L0 + R0 + Cm + Cp) * lr_splat(4) + (Lm + Rm + Lp + Rp) * lr_splat(3);
+            b0 = (q0.v[1] + q0.v[0] + q0.v[2] + qm.v[1] + qp.v[1]) * 4 + (qm.v[0] + qm.v[2] + qp.v[0] + qp.v[2]) * 3;
+            b1 = (q0.v[2] + q0.v[1] + q0.v[3] + qm.v[2] + qp.v[2]) * 4 + (qm.v[1] + qm.v[3] + qp.v[1] + qp.v[3]) * 3;
+        }
     }
-    const int32_t v = a * (int32_t)tile[(i + 3) * TW + j + 3] + b;
-    return rpot(v, 8 + nb - 4);
+    const uint16_t* px = tile + (i + 3) * TW + j + 3;
+    f[0] = rpot((int32_t)a[0] * (int32_t)px[0] + b0, 8 + nb - 4);
+    f[1] = rpot((int32_t)a[1] * (int32_t)px[1] + b1, 8 + nb - 4);
 }
 
 // The r = 2 output of a thread's sixteen pixels (i = tid + 256 k) stays in registers until the r = 1 pass has its A / B tables; MODE_APPLY
@@ -243,18 +269,21 @@ __device__ __forceinline__ void sgr_tile(const uint16_t* tile, uint16_t* A16, in
     const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
     xlut[tid] = (uint16_t)x_by_xplus1((uint32_t)tid); // 256 threads, 256 entries
     __syncthreads();
-    int32_t f0[16];
+    int32_t f0[16]; // eight output pairs per thread: pair p = tid + 256 k <-> row p >> 5, columns 2 (p & 31), + 1
 #pragma unroll
     for (int k = 0; k < 16; k++) f0[k] = 0;
     if (p0) {
         sgr_ab_pass(tile, A16, B32, xlut, 0, idx, uw, uh, bd, tid);
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int i = tid + 256 * k, r = i >> 6, c = i & 63;
+        for (int k = 0; k < 8; k++) {
+            const int i = tid + 256 * k, r = i >> 5, c = (i & 31) * 2;
             if (r < uh && c < uw) {
-                f0[k] = sgr_flt_px(tile, A16, B32, 0, r, c);
-                out_flt0(r, c, f0[k]);
+                int32_t f[2];
+                sgr_flt_pair(tile, A16, B32, 0, r, c, f);
+                f0[2 * k] = f[0]; f0[2 * k + 1] = f[1];
+                out_flt0(r, c, f[0]);
+                if (c + 1 < uw) out_flt0(r, c + 1, f[1]);
             }
         }
         __syncthreads();
@@ -262,9 +291,14 @@ __device__ __forceinline__ void sgr_tile(const uint16_t* tile, uint16_t* A16, in
     if (p1) sgr_ab_pass(tile, A16, B32, xlut, 1, idx, uw, uh, bd, tid);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int i = tid + 256 * k, r = i >> 6, c = i & 63;
-        if (r < uh && c < uw) out_flt1_or_apply(r, c, f0[k], p1 ? sgr_flt_px(tile, A16, B32, 1, r, c) : 0);
+    for (int k = 0; k < 8; k++) {
+        const int i = tid + 256 * k, r = i >> 5, c = (i & 31) * 2;
+        if (r < uh && c < uw) {
+            int32_t f[2] = {0, 0};
+            if (p1) sgr_flt_pair(tile, A16, B32, 1, r, c, f);
+            out_flt1_or_apply(r, c, f0[2 * k], f[0]);
+            if (c + 1 < uw) out_flt1_or_apply(r, c + 1, f0[2 * k + 1], f[1]);
+        }
     }
 }
 __device__ __forceinline__ int sgr_combine(const int px, const int32_t f0, const int32_t f1, const int idx, const int32_t xqd0, const int32_t xqd1, const int bd) {
