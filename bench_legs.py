@@ -334,3 +334,54 @@ def cdef_chain(torch, lib, pkg, stream, steps, warmup):
     t = _time(torch, fn, steps, warmup)
     return {"cdef_stage_4k10_420": {"frames_per_s": 1 / t, "ms": t * 1e3, "filter_blocks": nfb, "strengths_searched": 64, "pairs_selected": 8,
                                     "note": "Y+U+V search, joint strength search (8 greedy + 32 refinement rounds), per-block assignment, Y+U+V apply"}}
+
+
+def me_session(torch, lib, pkg, stream, steps, warmup, npics=32):
+    """PCIe-inclusive ME stage: 1080p pictures in pinned HOST memory go through svt_hip_me_session (upload once, reference by id, 4 references per
+    picture, 16x9 area, results downloaded to pinned host memory), two submissions in flight.  This is the rate a caller that owns host buffers
+    sees; it is never bench.py's `value` (inputs resident in HBM)."""
+    import time as _t
+    W, H, PAD = 1920, 1080, 68
+    stride, rows = W + 2 * PAD, H + 2 * PAD
+    nbytes = stride * rows
+    g = np.random.default_rng(3)
+    sbs = ((W + 63) // 64) * ((H + 63) // 64)
+    hp = [lib.svt_hip_host_alloc(nbytes) for _ in range(8)]
+    for q in hp:
+        C.memmove(q, g.integers(0, 256, nbytes, dtype=np.uint8).ctypes.data, nbytes)
+    res = [(lib.svt_hip_host_alloc(4 * sbs * 85 * 4), lib.svt_hip_host_alloc(4 * sbs * 85 * 4)) for _ in range(2)]
+    sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, 2)
+
+    def run(n):
+        pending = []
+        for k in range(n):
+            nref = min(k, 4)
+            refs = np.array([k - 1 - r for r in range(nref)], np.int64)
+            out = res[k & 1]
+            slot = lib.svt_hip_me_session_submit(sess, k, hp[k % 8], refs.ctypes.data if nref else None, nref, 16, 9, 0, out[0], out[1])
+            assert slot >= 0, slot
+            pending.append(slot)
+            if len(pending) == 2:
+                lib.svt_hip_me_session_wait(sess, pending.pop(0))
+        for slot in pending:
+            lib.svt_hip_me_session_wait(sess, slot)
+    lib.svt_hip_me_session_destroy(sess)
+    sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, 2)
+    run(8)
+    lib.svt_hip_me_session_destroy(sess)
+    ts = []
+    for _ in range(max(steps // 4, 2)):
+        sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, 2)
+        t0 = _t.perf_counter()
+        run(npics)
+        ts.append(_t.perf_counter() - t0)
+        lib.svt_hip_me_session_destroy(sess)
+    t = min(ts)
+    for q in hp:
+        lib.svt_hip_host_free(q)
+    for a, b in res:
+        lib.svt_hip_host_free(a)
+        lib.svt_hip_host_free(b)
+    sbrefs = sbs * sum(min(k, 4) for k in range(npics))
+    return {"me_session_1080p_host": {"pictures_per_s": npics / t, "us_per_picture": t / npics * 1e6, "value": sbrefs * 144 / t / 1e6,
+                                      "unit": "M(SB x position)/s, PCIe inclusive", "h2d_MB_per_picture": nbytes / 1e6, "d2h_MB_per_picture": 4 * sbs * 85 * 8 / 1e6}}

@@ -109,6 +109,22 @@ void svt_pme_sad_loop_kernel_hip(const SvtHipMvCostParams *mv_cost_params, uint8
                                  int16_t *best_mvy, int16_t search_position_start_x, int16_t search_position_start_y,
                                  int16_t search_area_width, int16_t search_area_height, int16_t search_step, int16_t mvx, int16_t mvy);
 
+/* ---- the ME stage as a per-picture service over HOST pictures (the caller owns host buffers) ----
+ * A session keeps the last `ring_planes` padded luma planes (stride * rows bytes each, picture origin at (org_x, org_y)) resident in HBM: a picture is
+ * uploaded once, when it is submitted as a source, and then serves as a reference by id.  Each submission runs on its own stream (upload -> descriptor
+ * build -> svt_hip_me_fullpel_search_batch over every 64x64 SB x n_refs, search centre (0, 0) -> result download), so the copies of one picture overlap
+ * the search of another.  Host buffers should come from svt_hip_host_alloc (pinned) for the copies to be asynchronous.
+ * submit returns a slot (>= 0) to wait on; -1: a reference (or the unsent source) is not resident, -2: n_refs > max_refs, -3: ring too small.
+ * Results: best_sad_host / best_mv_host [n_refs][SBs][85], valid after svt_hip_me_session_wait(slot). */
+void *svt_hip_host_alloc(size_t bytes);
+void  svt_hip_host_free(void *p);
+void *svt_hip_me_session_create(uint32_t width, uint32_t height, uint32_t stride, uint32_t org_x, uint32_t org_y, uint32_t rows, uint32_t ring_planes,
+                                uint32_t max_refs, uint32_t max_area_width, uint32_t max_area_height, uint32_t n_slots);
+void  svt_hip_me_session_destroy(void *session);
+int   svt_hip_me_session_submit(void *session, int64_t pic_id, const uint8_t *plane_host, const int64_t *ref_ids, uint32_t n_refs, uint32_t area_w,
+                                uint32_t area_h, int sub_sad, uint32_t *best_sad_host, uint32_t *best_mv_host);
+void  svt_hip_me_session_wait(void *session, int slot);
+
 /* ---- batched forms (device pointers) ---- */
 typedef struct SvtHipSadPair {
     uint64_t src_off;    /* byte offset of the block's top-left sample from src_base */

@@ -70,6 +70,12 @@ PROTOTYPES = {
     "svt_hip_graph_destroy": (None, [vp]),
     "svt_hip_cdef_joint_strength_search": (None, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "svt_hip_cdef_assign_fb_strengths": (None, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "svt_hip_host_alloc": (vp, [C.c_size_t]),
+    "svt_hip_host_free": (None, [vp]),
+    "svt_hip_me_session_create": (vp, [C.c_uint32] * 11),
+    "svt_hip_me_session_destroy": (None, [vp]),
+    "svt_hip_me_session_submit": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
+    "svt_hip_me_session_wait": (None, [vp, C.c_int]),
     "svt_hip_sad_nxm_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_sad_loop_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),

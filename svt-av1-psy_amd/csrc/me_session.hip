@@ -1,0 +1,166 @@
+// me_session.hip -- the open-loop ME stage as a per-picture service over HOST pictures (the reference's contract, SURVEY 8b: the caller owns
+// host buffers; me_process.c hands one picture at a time to motion_estimation.c).  A session keeps the last `ring` luma planes resident in HBM,
+// so a picture is uploaded once (as the source) and then serves as a reference for later pictures without crossing PCIe again.  Every
+// submission runs on its own HIP stream: upload (copy engine) -> descriptor build -> me_fullpel search -> result download, so the copies of
+// picture N + 1 overlap the search of picture N.  Dependencies are events: a search waits for the uploads of its references, an upload into a
+// ring slot waits for every search that may still read the plane it replaces.
+#include "svt_hip_common.h"
+#include "../../include/svtav1_hip.h"
+
+#include <vector>
+
+namespace {
+
+struct Slot {
+    hipStream_t         st    = nullptr;
+    hipEvent_t          done  = nullptr;
+    SvtHipMeSearchDesc* descs = nullptr;
+    uint32_t *          sad = nullptr, *mv = nullptr;
+    void*               ws    = nullptr;
+    bool                busy  = false;
+};
+struct Session {
+    uint32_t width, height, stride, org_x, org_y, rows, ring, max_refs, sbs;
+    size_t   plane_bytes, ws_bytes;
+    uint8_t* planes = nullptr;           // ring x plane_bytes
+    std::vector<int64_t>    ids;         // picture id resident in ring slot r (-1 = empty)
+    std::vector<hipEvent_t> uploaded;    // upload of ring slot r finished
+    std::vector<Slot>       slots;
+    uint32_t next_ring = 0, next_slot = 0;
+};
+
+// all 64x64 SBs of the picture against n_refs resident planes, search area centred on the co-located block (search centre (0, 0)), exactly the
+// operands open_loop_me_fullpel_search_sblock receives (motion_estimation.c:781); item order = reference-major like me_descs_for_frame
+__global__ void me_build_descs_kernel(SvtHipMeSearchDesc* descs, uint32_t sbs_x, uint32_t sbs, uint32_t n_refs, uint32_t stride, uint32_t org_x, uint32_t org_y,
+                                      unsigned long long src_off, const unsigned long long* ref_offs, int area_w, int area_h) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sbs * n_refs) return;
+    const uint32_t r = i / sbs, sb = i - r * sbs, sx = sb % sbs_x, sy = sb / sbs_x;
+    const int      xo = -(area_w >> 1), yo = -(area_h >> 1);
+    const unsigned long long px = org_x + sx * 64, py = org_y + sy * 64;
+    SvtHipMeSearchDesc d;
+    d.src_off = src_off + py * stride + px;
+    d.ref_off = ref_offs[r] + (unsigned long long)((long long)py + yo) * stride + (unsigned long long)((long long)px + xo);
+    d.src_stride = stride; d.ref_stride = stride;
+    d.x_search_area_origin = (int16_t)xo; d.y_search_area_origin = (int16_t)yo;
+    d.search_area_width = (uint16_t)area_w; d.search_area_height = (uint16_t)area_h;
+    descs[i] = d;
+}
+
+} // namespace
+
+extern "C" {
+
+void* svt_hip_host_alloc(size_t bytes) {
+    svthip::ensure_device();
+    void* p = nullptr;
+    HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+    return p;
+}
+void svt_hip_host_free(void* p) { if (p) HIP_CHECK(hipHostFree(p)); }
+
+void* svt_hip_me_session_create(uint32_t width, uint32_t height, uint32_t stride, uint32_t org_x, uint32_t org_y, uint32_t rows, uint32_t ring_planes,
+                                uint32_t max_refs, uint32_t max_area_width, uint32_t max_area_height, uint32_t n_slots) {
+    svthip::ensure_device();
+    Session* s = new Session;
+    s->width = width; s->height = height; s->stride = stride; s->org_x = org_x; s->org_y = org_y; s->rows = rows;
+    s->ring = ring_planes < 2 ? 2 : ring_planes; s->max_refs = max_refs ? max_refs : 1;
+    s->sbs = ((width + 63) / 64) * ((height + 63) / 64);
+    s->plane_bytes = (size_t)stride * rows;
+    HIP_CHECK(hipMalloc((void**)&s->planes, s->plane_bytes * s->ring));
+    s->ids.assign(s->ring, -1);
+    s->uploaded.resize(s->ring);
+    for (auto& e : s->uploaded) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const size_t n = (size_t)s->sbs * s->max_refs;
+    s->ws_bytes    = svt_hip_me_fullpel_search_workspace((uint32_t)n, max_area_width, max_area_height);
+    s->slots.resize(n_slots ? n_slots : 2);
+    for (auto& sl : s->slots) {
+        HIP_CHECK(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        HIP_CHECK(hipMalloc((void**)&sl.descs, n * sizeof(SvtHipMeSearchDesc) + s->max_refs * 8));
+        HIP_CHECK(hipMalloc((void**)&sl.sad, n * SVT_HIP_ME_NUM_BLOCKS * 4));
+        HIP_CHECK(hipMalloc((void**)&sl.mv, n * SVT_HIP_ME_NUM_BLOCKS * 4));
+        if (s->ws_bytes) HIP_CHECK(hipMalloc(&sl.ws, s->ws_bytes));
+    }
+    return s;
+}
+
+void svt_hip_me_session_destroy(void* session) {
+    Session* s = (Session*)session;
+    if (!s) return;
+    for (auto& sl : s->slots) {
+        HIP_CHECK(hipStreamSynchronize(sl.st));
+        HIP_CHECK(hipStreamDestroy(sl.st));
+        HIP_CHECK(hipEventDestroy(sl.done));
+        HIP_CHECK(hipFree(sl.descs)); HIP_CHECK(hipFree(sl.sad)); HIP_CHECK(hipFree(sl.mv));
+        if (sl.ws) HIP_CHECK(hipFree(sl.ws));
+    }
+    for (auto& e : s->uploaded) HIP_CHECK(hipEventDestroy(e));
+    HIP_CHECK(hipFree(s->planes));
+    delete s;
+}
+
+int svt_hip_me_session_submit(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
+                              uint32_t area_h, int sub_sad, uint32_t* best_sad_host, uint32_t* best_mv_host) {
+    Session* s = (Session*)session;
+    if (n_refs > s->max_refs) return -2;
+    const int si = (int)s->next_slot;
+    Slot&     sl = s->slots[si];
+    if (sl.busy) { HIP_CHECK(hipEventSynchronize(sl.done)); sl.busy = false; } // the slot's previous picture (results already fetched or abandoned)
+    // the source plane: resident already, or uploaded into the next ring slot
+    int src_r = -1;
+    for (uint32_t r = 0; r < s->ring; r++)
+        if (s->ids[r] == pic_id) src_r = (int)r;
+    std::vector<int> ref_r(n_refs);
+    for (uint32_t k = 0; k < n_refs; k++) {
+        ref_r[k] = -1;
+        for (uint32_t r = 0; r < s->ring; r++)
+            if (s->ids[r] == ref_ids[k]) ref_r[k] = (int)r;
+        if (ref_r[k] < 0) return -1; // reference not resident (evicted or never submitted)
+    }
+    if (src_r < 0) {
+        if (!plane_host) return -1;
+        // pick the next ring slot that is not one of this picture's references
+        for (uint32_t tries = 0; tries < s->ring; tries++) {
+            const uint32_t r = (s->next_ring + tries) % s->ring;
+            bool used = false;
+            for (uint32_t k = 0; k < n_refs; k++) used |= ref_r[k] == (int)r;
+            if (!used) { src_r = (int)r; s->next_ring = (r + 1) % s->ring; break; }
+        }
+        if (src_r < 0) return -3; // ring smaller than n_refs + 1
+        for (auto& other : s->slots) // searches in flight may still read the plane being replaced
+            if (other.busy) HIP_CHECK(hipStreamWaitEvent(sl.st, other.done, 0));
+        HIP_CHECK(hipMemcpyAsync(s->planes + (size_t)src_r * s->plane_bytes, plane_host, s->plane_bytes, hipMemcpyHostToDevice, sl.st));
+        HIP_CHECK(hipEventRecord(s->uploaded[src_r], sl.st));
+        s->ids[src_r] = pic_id;
+    } else {
+        HIP_CHECK(hipStreamWaitEvent(sl.st, s->uploaded[src_r], 0));
+    }
+    if (n_refs == 0) { sl.busy = true; HIP_CHECK(hipEventRecord(sl.done, sl.st)); s->next_slot = (s->next_slot + 1) % (uint32_t)s->slots.size(); return si; }
+    unsigned long long offs[64];
+    for (uint32_t k = 0; k < n_refs && k < 64; k++) {
+        HIP_CHECK(hipStreamWaitEvent(sl.st, s->uploaded[ref_r[k]], 0));
+        offs[k] = (unsigned long long)ref_r[k] * s->plane_bytes;
+    }
+    const uint32_t n = s->sbs * n_refs;
+    unsigned long long* d_offs = (unsigned long long*)(sl.descs + (size_t)s->sbs * s->max_refs);
+    HIP_CHECK(hipMemcpyAsync(d_offs, offs, n_refs * 8, hipMemcpyHostToDevice, sl.st));
+    hipLaunchKernelGGL(me_build_descs_kernel, dim3((n + 255) / 256), dim3(256), 0, sl.st, sl.descs, (s->width + 63) / 64, s->sbs, n_refs, s->stride, s->org_x, s->org_y,
+                       (unsigned long long)src_r * s->plane_bytes, (const unsigned long long*)d_offs, (int)area_w, (int)area_h);
+    SVT_LAUNCH_CHECK();
+    svt_hip_me_fullpel_search_batch(s->planes, s->planes, sl.descs, n, area_w, area_h, sub_sad, sl.sad, sl.mv, sl.ws, sl.st);
+    HIP_CHECK(hipMemcpyAsync(best_sad_host, sl.sad, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
+    HIP_CHECK(hipMemcpyAsync(best_mv_host, sl.mv, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
+    HIP_CHECK(hipEventRecord(sl.done, sl.st));
+    sl.busy      = true;
+    s->next_slot = (s->next_slot + 1) % (uint32_t)s->slots.size();
+    return si;
+}
+
+void svt_hip_me_session_wait(void* session, int slot) {
+    Session* s = (Session*)session;
+    if (slot < 0 || slot >= (int)s->slots.size()) return;
+    HIP_CHECK(hipEventSynchronize(s->slots[slot].done));
+}
+
+} // extern "C"

@@ -470,6 +470,10 @@ inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, void*, void
 inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+#define hipHostMallocDefault 0u
+#define hipEventDisableTiming 2u
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemuEvent{0}; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{0}; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }

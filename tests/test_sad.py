@@ -346,3 +346,35 @@ def test_initialize_buffer_32bits(be):
     buf = np.zeros(85 + 3, np.uint32)
     be.lib.svt_initialize_buffer_32bits_hip(p(buf), 21, 1, be.pkg.MAX_SAD_VALUE)
     assert (buf[:85] == be.pkg.MAX_SAD_VALUE).all() and (buf[85:] == 0).all()
+
+
+def test_me_session_host_pictures(be, oracle):
+    """The ME stage as a service over host pictures: planes are uploaded once as sources and then referenced by id; results of overlapping
+    submissions equal the oracle's open_loop_me_fullpel_search_sblock for every (SB, reference)."""
+    g = rng(77)
+    W, H, PAD = (384, 200, 68) if be.is_gpu else (128, 72, 20)
+    stride, rows = W + 2 * PAD, H + 2 * PAD + 64  # the last SB row overhangs the picture: real planes carry >= 64 rows of bottom padding
+    aw, ah = 16, 9
+    lib = be.lib
+    sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 4, 2, aw, ah, 2)
+    pics = [g.integers(0, 256, (rows, stride), dtype=np.uint8) for _ in range(4)]
+    sbs = ((W + 63) // 64) * ((H + 63) // 64)
+    outs = []
+    # picture 0: upload only; pictures 1.. search against the previous one or two pictures
+    assert lib.svt_hip_me_session_submit(sess, 0, p(pics[0]), None, 0, aw, ah, 0, None, None) >= 0
+    for k in range(1, 4):
+        refs = np.array([k - 1] + ([k - 2] if k >= 2 else []), np.int64)
+        bs, bm = np.zeros((len(refs), sbs, 85), np.uint32), np.zeros((len(refs), sbs, 85), np.uint32)
+        slot = lib.svt_hip_me_session_submit(sess, k, p(pics[k]), p(refs), len(refs), aw, ah, 0, p(bs), p(bm))
+        assert slot >= 0
+        outs.append((k, refs, bs, bm, slot))
+    assert lib.svt_hip_me_session_submit(sess, 9, None, p(np.array([0], np.int64)), 1, aw, ah, 0, None, None) == -1  # unsent source
+    for (k, refs, bs, bm, slot) in outs:
+        lib.svt_hip_me_session_wait(sess, slot)
+        for ri, rid in enumerate(refs):
+            planes = np.stack([pics[k], pics[int(rid)]])
+            descs = be.pkg.me_descs_for_frame(W, H, stride, PAD, PAD, aw, ah, rows * stride, n_refs=1, src_plane=0, ref_plane0=1)
+            for i in (range(sbs) if not be.is_gpu else g.choice(sbs, 6, replace=False)):
+                ws, wm = oracle_me(oracle, planes.reshape(-1), planes.reshape(-1), descs[i], 0)
+                assert np.array_equal(bs[ri][i], ws) and np.array_equal(bm[ri][i], wm), (k, int(rid), int(i))
+    lib.svt_hip_me_session_destroy(sess)

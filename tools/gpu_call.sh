@@ -1,6 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_restoration.py -m gpu -x -q 2>&1 | tail -2
-python tools/microbench.py lr 2>/dev/null | python -c "
-import json,sys; j=json.load(sys.stdin)
-for k,v in j.items(): print(k, round(v['ms']*1000,1),'us')"
+timeout 900 python -m pytest tests/test_sad.py -m gpu -x -q -k "session or full_frame" 2>&1 | tail -2
+python tools/microbench.py mesession 2>&1 | tail -1 | cut -c1-500
