@@ -39,6 +39,112 @@ def gen_sad(ref, oracle):
                         loop_cfg=loop_cfg, loop_out=np.array(loop_out, np.int64), me_cfg=me_cfg, me_sad=np.array(me_sad), me_mv=np.array(me_mv))
 
 
+def gen_filters(ref, oracle):
+    """CDEF (find_dir, filter_block), Wiener, self-guided, deblocking edge filters, 2x2 decimation, svt_search_one_dual, svt_compute_stats,
+    quantize_b: inputs + the REAL reference's outputs for a handful of seeded cases per family."""
+    from test_oracle_pin_cdef import BLOCK, BSTRIDE, in_ptr, make_tile
+    from test_oracle_pin_restoration import aligned_i16, byteptr, conv_params, wiener_taps
+    from test_deblock import lim_arrays, make_patch
+    from test_cdef_pick import ptr_tables, tables
+    from test_oracle_pin_quant import gen_coeff, run_ref
+    from quant_common import make_qparams, make_scan
+    g = np.random.default_rng(424242)
+    ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))
+    ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
+    out = {}
+    # ---- CDEF
+    cd_cfg, cd_dir, cd_out = [], [], []
+    tiles = []
+    for bd in (8, 10, 12):
+        cs = bd - 8
+        t = make_tile(g, bd, 5)
+        tiles.append(t.copy())
+        for (by, bx) in ((0, 0), (3, 4), (7, 7)):
+            off = by * 8 * BSTRIDE + bx * 8
+            v = C.c_int32(0)
+            d = ref.svt_aom_cdef_find_dir_c(in_ptr(t, off), BSTRIDE, C.byref(v), cs)
+            cd_dir.append((bd, by, bx, d & 255, v.value))
+            for (pri, sec, damp, dirn, sub) in ((4, 2, 5, d & 7, 1), (15, 4, 3, 3, 1), (0, 1, 6, 0, 2), (1, 0, 4, 7, 1)):
+                o = np.zeros(64, np.uint16)
+                ref.svt_cdef_filter_block_c(None, p(o), 8, in_ptr(t, off), pri << cs, sec << cs, dirn, damp + cs, damp + cs - 1, BLOCK[(8, 8)], cs, sub)
+                cd_cfg.append((bd, by, bx, pri, sec, damp, dirn, sub))
+                cd_out.append(o)
+    out.update(cdef_tiles=np.stack(tiles), cdef_dir=np.array(cd_dir, np.int32), cdef_cfg=np.array(cd_cfg, np.int32), cdef_out=np.stack(cd_out))
+    # ---- Wiener / self-guided (10-bit and 8-bit)
+    S, w, h = 96, 48, 20
+    for bd in (8, 10):
+        hb = bd > 8
+        dt = np.uint16 if hb else np.uint8
+        src = g.integers(0, 1 << bd, (h + 12, S)).astype(dt)
+        org = 6 * S + 8
+        taps = np.stack([wiener_taps(g, 0)[:8], wiener_taps(g, 2)[:8]])
+        fx, fy = aligned_i16(taps[0]), aligned_i16(taps[1])
+        d1 = np.zeros((h, S), dt)
+        cp = conv_params(bd)
+        if hb:
+            ref.svt_av1_highbd_wiener_convolve_add_src_c(byteptr(src, org), C.c_ssize_t(S), byteptr(d1), C.c_ssize_t(S), p(fx), p(fy), w, h, C.byref(cp), bd)
+        else:
+            ref.svt_av1_wiener_convolve_add_src_c(C.c_void_p(src.ctypes.data + org), C.c_ssize_t(S), p(d1), C.c_ssize_t(S), p(fx), p(fy), w, h, C.byref(cp))
+        sg = []
+        sp = C.c_void_p(src.ctypes.data + org * src.itemsize)
+        for idx in (0, 7, 10, 14):
+            b0, b1 = np.full((h, w), -7, np.int32), np.full((h, w), -7, np.int32)
+            ref.svt_av1_selfguided_restoration_c(byteptr(src, org) if hb else sp, w, h, S, p(b0), p(b1), w, idx, bd, int(hb))
+            sg.append(np.stack([b0, b1]))
+        out["lr_src_%d" % bd], out["lr_taps_%d" % bd], out["lr_wiener_%d" % bd], out["lr_sgr_%d" % bd] = src, taps, d1[:, :w].copy(), np.stack(sg)
+    # ---- deblocking
+    lp_cfg, lp_in, lp_out = [], [], []
+    for bd in (8, 10):
+        for ln in (4, 6, 8, 14):
+            for vert in (0, 1):
+                for kind in (0, 1, 2):
+                    a = make_patch(g, bd, kind).astype(np.uint16)
+                    b = a.astype(np.uint8 if bd == 8 else np.uint16)
+                    bl, li, th = (60 + 40 * kind, 10 + 8 * kind, kind)
+                    keep = lim_arrays(bl, li, th)
+                    f = getattr(ref, "svt_aom_%slpf_%s_%d_c" % ("" if bd == 8 else "highbd_", "vertical" if vert else "horizontal", ln))
+                    args = [C.c_void_p(b.ctypes.data + (16 * 32 + 16) * b.itemsize), C.c_int32(32)] + [p(k) for k in keep]
+                    if bd > 8:
+                        args.append(C.c_int32(bd))
+                    f(*args)
+                    lp_cfg.append((bd, ln, vert, bl, li, th))
+                    lp_in.append(a)
+                    lp_out.append(b.astype(np.uint16))
+    out.update(lpf_cfg=np.array(lp_cfg, np.int32), lpf_in=np.stack(lp_in), lpf_out=np.stack(lp_out))
+    # ---- 2x2 decimation
+    dsrc = g.integers(0, 256, (41, 70), dtype=np.uint8)
+    for step in (2, 4):
+        o = np.zeros((24, 40), np.uint8)
+        ref.svt_aom_downsample_2d_c(p(dsrc), C.c_uint32(70), C.c_uint32(66), C.c_uint32(40), p(o), C.c_uint32(40), C.c_uint32(step))
+        out["down_%d" % step] = o
+    out["down_src"] = dsrc
+    # ---- CDEF strength selection
+    m0, m1 = tables(g, 57)
+    arr, keep = ptr_tables(m0, m1)
+    ref.svt_search_one_dual_c.restype = C.c_uint64
+    la, lb = np.zeros(9, np.int32), np.zeros(9, np.int32)
+    tot = [ref.svt_search_one_dual_c(p(la), p(lb), nb, arr, 57, 0, 64) for nb in range(4)]
+    out.update(pick_m0=m0, pick_m1=m1, pick_lev0=la, pick_lev1=lb, pick_tot=np.array(tot, np.uint64))
+    # ---- Wiener statistics
+    dgd = g.integers(0, 1024, (60, 80)).astype(np.uint16)
+    ssrc = np.clip(dgd.astype(np.int32) + g.integers(-9, 10, dgd.shape), 0, 1023).astype(np.uint16)
+    M, H = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
+    ref.svt_av1_compute_stats_highbd_c(7, byteptr(dgd), byteptr(ssrc), 5, 69, 4, 52, 80, 80, p(M), p(H), 10)
+    out.update(stats_dgd=dgd, stats_src=ssrc, stats_M=M, stats_H=H)
+    # ---- quantize_b (low and high bit depth), 16x16
+    P = make_qparams(88, 112, fp=False)
+    scan, iscan = make_scan(256, g)
+    qz = []
+    coeffs = []
+    for mode in (0, 1):
+        coeff = gen_coeff(g, 256, 1 << 11, 1)
+        q, dq, eob = run_ref(ref, mode, False, coeff, 256, P, scan, iscan, None, None, 0)
+        coeffs.append(coeff)
+        qz.append(np.concatenate([q, dq, [eob]]))
+    out.update(quant_coeff=np.stack(coeffs), quant_scan=scan, quant_iscan=iscan, quant_out=np.stack(qz))
+    np.savez_compressed(os.path.join(GOLDEN, "filters.npz"), **out)
+
+
 def gen_txfm(ref, oracle):
     from test_oracle_pin_txfm import TXW, TXH, allowed_types, ref_fwd, call_ref_inv
     g = np.random.default_rng(77)
@@ -62,7 +168,7 @@ def gen_txfm(ref, oracle):
     np.savez_compressed(os.path.join(GOLDEN, "txfm.npz"), cfg=np.array(cfg, np.int32), **arrays)
 
 
-FAMILIES = {"sad": gen_sad, "txfm": gen_txfm}
+FAMILIES = {"sad": gen_sad, "txfm": gen_txfm, "filters": gen_filters}
 
 if __name__ == "__main__":
     os.system("make -s -C %s oracle ref" % os.path.join(ROOT, "oracle"))
