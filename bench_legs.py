@@ -385,3 +385,78 @@ def me_session(torch, lib, pkg, stream, steps, warmup, npics=32):
     sbrefs = sbs * sum(min(k, 4) for k in range(npics))
     return {"me_session_1080p_host": {"pictures_per_s": npics / t, "us_per_picture": t / npics * 1e6, "value": sbrefs * 144 / t / 1e6,
                                       "unit": "M(SB x position)/s, PCIe inclusive", "h2d_MB_per_picture": nbytes / 1e6, "d2h_MB_per_picture": 4 * sbs * 85 * 8 / 1e6}}
+
+
+def me_results(torch, lib, pkg, stream, steps, warmup, npics=32):
+    """ME result formatting.  (1) the formatting kernel alone over one 1080p picture's search tables resident in HBM, 4 + 3
+    references; (2) the ME session returning the final product (MeSbResults + per-SB statistics) to pinned host memory instead of the raw tables,
+    2 + 2 references, 16x9 area -- the PCIe-inclusive rate of the whole stage."""
+    import time as _t
+    g = np.random.default_rng(5)
+    sbs = 510
+    P = pkg.MeResultsParams()
+    P.n_sb, P.num_of_list_to_search = sbs, 2
+    P.num_of_ref_pic_to_search[0], P.num_of_ref_pic_to_search[1] = 4, 3
+    P.max_refs, P.max_cand = pkg.me_max_allocated_refs(4, 3)
+    P.max_l0, P.enable_me_16x16, P.enable_me_8x8, P.prune_ref, P.gm_enabled = 4, 1, 1, 1, 1
+    P.prune_ref_if_me_sad_dev_bigger_than_th, P.prune_me_candidates_th, P.picture_number = 30, 65, 16
+    for l in range(2):
+        for r in range(4):
+            P.ref_picture_number[l][r] = 16 + (1 if l else -1) * (r + 1)
+    dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
+    sad = dev(g.integers(100, 60000, (7, sbs, 85)).astype(np.uint32))
+    mv = dev(g.integers(0, 1 << 32, (7, sbs, 85), dtype=np.uint64).astype(np.uint32))
+    do_ref = dev(np.ones((sbs, 8), np.uint8))
+    sz = dev(np.full((sbs, 2), 64, np.uint8))
+    tot, mvs = torch.zeros(sbs * 85, dtype=torch.uint8, device="cuda"), torch.zeros(sbs * 85 * P.max_refs * 4, dtype=torch.uint8, device="cuda")
+    cands, st = torch.zeros(sbs * 85 * P.max_cand, dtype=torch.uint8, device="cuda"), torch.zeros(sbs * 28, dtype=torch.uint8, device="cuda")
+    t = _time(torch, lambda: lib.svt_hip_me_results_batch(C.addressof(P), sad.data_ptr(), mv.data_ptr(), do_ref.data_ptr(), sz.data_ptr(), tot.data_ptr(),
+                                                          mvs.data_ptr(), cands.data_ptr(), st.data_ptr(), stream), steps, warmup)
+    out = {"me_results_1080p_7refs": {"us": t * 1e6, "Msb_per_s": sbs / t / 1e6, "GBps_algorithmic": (7 * sbs * 85 * 8 + sbs * 85 * (1 + P.max_cand + 4 * P.max_refs)) / t / 1e9}}
+
+    W, H, PAD = 1920, 1080, 68
+    stride, rows = W + 2 * PAD, H + 2 * PAD
+    nbytes = stride * rows
+    hp = [lib.svt_hip_host_alloc(nbytes) for _ in range(8)]
+    for q in hp:
+        C.memmove(q, g.integers(0, 256, nbytes, dtype=np.uint8).ctypes.data, nbytes)
+    Q = pkg.MeResultsParams()
+    C.memmove(C.addressof(Q), C.addressof(P), C.sizeof(P))
+    Q.num_of_ref_pic_to_search[0], Q.num_of_ref_pic_to_search[1] = 2, 2
+    Q.max_refs, Q.max_cand = pkg.me_max_allocated_refs(2, 2)
+    Q.max_l0 = 2
+    sizes = [sbs * 85, sbs * 85 * Q.max_refs * 4, sbs * 85 * Q.max_cand, sbs * 28]
+    hosts = []
+    for _ in range(2):
+        b = [lib.svt_hip_host_alloc(n) for n in sizes]
+        hosts.append((b, pkg.MeResultsHost(None, b[0], b[1], b[2], b[3], None, None)))
+
+    def run(sess, n):
+        pending = []
+        for k in range(n):
+            slot = (lib.svt_hip_me_session_submit(sess, k, hp[k % 8], None, 0, 16, 9, 0, None, None) if k < 4 else
+                    lib.svt_hip_me_session_submit_results(sess, k, hp[k % 8], np.array([k - 1, k - 2, k - 3, k - 4], np.int64).ctypes.data, 4, 16, 9, 0,
+                                                          C.addressof(Q), C.addressof(hosts[k & 1][1])))
+            assert slot >= 0, slot
+            pending.append(slot)
+            if len(pending) == 2:
+                lib.svt_hip_me_session_wait(sess, pending.pop(0))
+        for slot in pending:
+            lib.svt_hip_me_session_wait(sess, slot)
+    ts = []
+    for it in range(max(steps // 4, 2) + 1):
+        sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, 2)
+        t0 = _t.perf_counter()
+        run(sess, npics if it else 8)
+        if it:
+            ts.append(_t.perf_counter() - t0)
+        lib.svt_hip_me_session_destroy(sess)
+    for q in hp:
+        lib.svt_hip_host_free(q)
+    for b, _ in hosts:
+        for q in b:
+            lib.svt_hip_host_free(q)
+    t = min(ts)
+    out["me_session_1080p_host_formatted"] = {"pictures_per_s": npics / t, "us_per_picture": t / npics * 1e6, "d2h_MB_per_picture": sum(sizes) / 1e6,
+                                              "note": "4 references (2 + 2), MeSbResults + per-SB statistics returned instead of the raw tables"}
+    return out

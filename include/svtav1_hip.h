@@ -178,6 +178,55 @@ void   svt_hip_me_fullpel_search_batch(const uint8_t *src_base, const uint8_t *r
                                        uint32_t n, uint32_t max_w, uint32_t max_h, int sub_sad, uint32_t *best_sad,
                                        uint32_t *best_mv, void *workspace, void *stream);
 
+/* ---- ME result formatting: what svt_aom_motion_estimation_b64 does with the integer-search tables after the search,
+ * motion_estimation.c:3121-3152 -- me_prune_ref (:1522-1566), construct_me_candidate_array{,_mrp_off,_single_ref} (:2532-2828),
+ * compute_distortion (:2964-3008), perform_gm_detection (:2833-2961) -- for every 64x64 SB of a picture in one launch.
+ * Inputs (device): best_sad / best_mv [ref slot][n_sb][85] as written by svt_hip_me_fullpel_search_batch with items ordered
+ * slot * n_sb + sb, slot = (list ? num_of_ref_pic_to_search[0] : 0) + ref (a slot the search never wrote must hold 0 MVs, as
+ * init_me_hme_data leaves them, :3049-3052); do_ref [n_sb][2][4] = search_results[list][ref].do_ref after HME pruning, updated in place;
+ * sb_size [n_sb][2] = B64Geom width, height.
+ * Outputs (device), addressed exactly as MeSbResults (me_sb_results.h:28-53) with n_pus = 85 / 21 / 5 (pcs.c:107-111):
+ * total_me_candidate_index [n_sb][n_pus], me_mv_array [n_sb][n_pus * max_refs] (MvCandidate.as_int), me_candidate_array
+ * [n_sb][n_pus * max_cand] (MeCandidate bit-field bytes).  Entries the reference does not write are left as the caller filled them. */
+typedef struct SvtHipMeResultsParams {
+    uint32_t n_sb;
+    uint8_t  num_of_list_to_search;         /* MeContext */
+    uint8_t  num_of_ref_pic_to_search[2];
+    uint8_t  max_cand, max_refs, max_l0;    /* MotionEstimationData (pcs.h:500-502; svt_aom_get_max_allocated_me_refs, pcs.c:91-96) */
+    uint8_t  enable_me_16x16, enable_me_8x8; /* PictureParentControlSet */
+    uint8_t  only_l_bwd;                    /* scs->mrp_ctrls.only_l_bwd */
+    uint8_t  use_best_unipred_cand_only;    /* MeContext */
+    uint8_t  prune_ref;                     /* prune_ref && me_hme_prune_ctrls.enable_me_hme_ref_pruning (:3122) */
+    uint8_t  low_resolution;                /* scs->input_resolution <= INPUT_SIZE_480p_RANGE */
+    uint8_t  gm_enabled, gm_use_distance_based_active_th; /* pcs->gm_ctrls */
+    uint16_t prune_ref_if_me_sad_dev_bigger_than_th;
+    int32_t  prune_me_candidates_th;
+    uint64_t picture_number;
+    uint64_t ref_picture_number[2][4];      /* me_ds_ref_array[list][ref].picture_number */
+} SvtHipMeResultsParams;
+typedef struct SvtHipMeSbStats { /* the per-SB entries of the pcs arrays written by compute_distortion / perform_gm_detection */
+    uint32_t me_64x64_distortion, me_32x32_distortion, me_16x16_distortion, me_8x8_distortion, me_8x8_cost_variance, rc_me_distortion;
+    uint8_t  stationary_block_present_sb, rc_me_allow_gm, pad[2];
+} SvtHipMeSbStats;
+void svt_hip_me_results_batch(const SvtHipMeResultsParams *params, const uint32_t *best_sad, const uint32_t *best_mv, uint8_t *do_ref,
+                              const uint8_t *sb_size, uint8_t *total_me_candidate_index, uint32_t *me_mv_array, uint8_t *me_candidate_array,
+                              SvtHipMeSbStats *sb_stats, void *stream);
+/* The session form: search as svt_hip_me_session_submit, then format on the device and download the final product instead of (or besides) the raw
+ * tables.  params->n_sb is filled in by the session; num_of_ref_pic_to_search[0] + [1] must equal n_refs (list 0 references first in ref_ids),
+ * else -4.  Host buffers (pinned for asynchronous copies): sizes as the device arrays above with n_pus from enable_me_16x16 / enable_me_8x8;
+ * do_ref may be NULL (every reference allowed, nothing returned); best_sad / best_mv may be NULL.  Entries the reference leaves unwritten are 0. */
+typedef struct SvtHipMeResultsHost {
+    uint8_t         *do_ref;                   /* [n_sb][2][4] in/out, or NULL */
+    uint8_t         *total_me_candidate_index; /* [n_sb][n_pus] */
+    uint32_t        *me_mv_array;              /* [n_sb][n_pus * max_refs] */
+    uint8_t         *me_candidate_array;       /* [n_sb][n_pus * max_cand] */
+    SvtHipMeSbStats *sb_stats;                 /* [n_sb] */
+    uint32_t        *best_sad, *best_mv;       /* [n_refs][n_sb][85], or NULL */
+} SvtHipMeResultsHost;
+int svt_hip_me_session_submit_results(void *session, int64_t pic_id, const uint8_t *plane_host, const int64_t *ref_ids, uint32_t n_refs,
+                                      uint32_t area_w, uint32_t area_h, int sub_sad, const SvtHipMeResultsParams *params,
+                                      const SvtHipMeResultsHost *out);
+
 /* ---------------------------------------------------------------- transforms (a10, a12, a13, a14) --- */
 /* TxSize / TxType numbering = Source/Lib/Codec/definitions.h (TX_4X4=0 .. TX_64X16=18; DCT_DCT=0 .. H_FLIPADST=15). */
 typedef struct SvtHipFwdTxfmDesc {

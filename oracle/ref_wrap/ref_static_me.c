@@ -1,0 +1,100 @@
+/*
+ * ref_static_me.c -- TEST INFRASTRUCTURE, built only into oracle/_ref/libsvtref_me.so (make -C oracle ref).
+ *
+ * The reference's ME result formatting (me_prune_ref, construct_me_candidate_array{,_mrp_off,_single_ref}, compute_distortion,
+ * perform_gm_detection; Codec/motion_estimation.c:1522-1566, 2532-3008) is `static`, so it cannot be called by symbol from
+ * libsvtref.so.  This translation unit compiles that reference source file WHERE IT LIES (the #include below resolves through
+ * -I$(REF)/Source/Lib/Codec; nothing is copied) and adds one plain-C entry point that fills the handful of context fields those
+ * functions read and runs them in the order of svt_aom_motion_estimation_b64 (motion_estimation.c:3121-3152).
+ */
+#include "motion_estimation.c"
+
+typedef struct RefMeResultsParams { /* same layout as SvtHipMeResultsParams (include/svtav1_hip.h) */
+    uint32_t n_sb;
+    uint8_t  num_of_list_to_search, num_of_ref_pic_to_search[2];
+    uint8_t  max_cand, max_refs, max_l0;
+    uint8_t  enable_me_16x16, enable_me_8x8, only_l_bwd, use_best_unipred_cand_only;
+    uint8_t  prune_ref, low_resolution, gm_enabled, gm_use_distance_based_active_th;
+    uint16_t prune_ref_if_me_sad_dev_bigger_than_th;
+    int32_t  prune_me_candidates_th;
+    uint64_t picture_number;
+    uint64_t ref_picture_number[2][4];
+} RefMeResultsParams;
+
+typedef struct RefMeSbStats { /* = SvtHipMeSbStats */
+    uint32_t me_64x64_distortion, me_32x32_distortion, me_16x16_distortion, me_8x8_distortion, me_8x8_cost_variance, rc_me_distortion;
+    uint8_t  stationary_block_present_sb, rc_me_allow_gm, pad[2];
+} RefMeSbStats;
+
+void ref_me_results_sb(const RefMeResultsParams *P, const uint32_t *best_sad /*[2][4][85]*/, const uint32_t *best_mv, uint8_t *do_ref /*[2][4] in/out*/,
+                       uint8_t sb_width, uint8_t sb_height, uint8_t *total_me_candidate_index, uint32_t *me_mv_array, uint8_t *me_candidate_array,
+                       RefMeSbStats *st) {
+    static PictureParentControlSet *pcs;
+    static SequenceControlSet      *scs;
+    static MeContext               *ctx;
+    static MotionEstimationData    *med;
+    static MeSbResults             *res, *res_tab[1];
+    static B64Geom                  geom;
+    static uint32_t                 u32s[6];
+    static uint8_t                  u8s[2];
+    if (!pcs) {
+        pcs = calloc(1, sizeof(*pcs));
+        scs = calloc(1, sizeof(*scs));
+        ctx = calloc(1, sizeof(*ctx));
+        med = calloc(1, sizeof(*med));
+        res = calloc(1, sizeof(*res));
+    }
+    pcs->scs = scs;
+    pcs->pa_me_data = med;
+    res_tab[0] = res;
+    med->me_results = res_tab;
+    med->max_cand = P->max_cand; med->max_refs = P->max_refs; med->max_l0 = P->max_l0;
+    res->total_me_candidate_index = total_me_candidate_index;
+    res->me_mv_array              = (MvCandidate *)me_mv_array;
+    res->me_candidate_array       = (MeCandidate *)me_candidate_array;
+    pcs->enable_me_16x16 = P->enable_me_16x16; pcs->enable_me_8x8 = P->enable_me_8x8;
+    pcs->max_number_of_pus_per_sb = SQUARE_PU_COUNT; /* resource_coordination_process.c:425 */
+    scs->mrp_ctrls.only_l_bwd = P->only_l_bwd;
+    scs->input_resolution = P->low_resolution ? INPUT_SIZE_480p_RANGE : INPUT_SIZE_1080p_RANGE;
+    geom.width = sb_width; geom.height = sb_height;
+    pcs->b64_geom = &geom;
+    pcs->me_64x64_distortion = &u32s[0]; pcs->me_32x32_distortion = &u32s[1]; pcs->me_16x16_distortion = &u32s[2];
+    pcs->me_8x8_distortion = &u32s[3]; pcs->me_8x8_cost_variance = &u32s[4]; pcs->rc_me_distortion = &u32s[5];
+    pcs->stationary_block_present_sb = &u8s[0]; pcs->rc_me_allow_gm = &u8s[1];
+    pcs->gm_ctrls.enabled = P->gm_enabled; pcs->gm_ctrls.use_distance_based_active_th = P->gm_use_distance_based_active_th;
+    pcs->picture_number = P->picture_number;
+
+    ctx->num_of_list_to_search = P->num_of_list_to_search;
+    ctx->num_of_ref_pic_to_search[0] = P->num_of_ref_pic_to_search[0]; ctx->num_of_ref_pic_to_search[1] = P->num_of_ref_pic_to_search[1];
+    ctx->me_hme_prune_ctrls.enable_me_hme_ref_pruning = P->prune_ref;
+    ctx->me_hme_prune_ctrls.prune_ref_if_me_sad_dev_bigger_than_th = P->prune_ref_if_me_sad_dev_bigger_than_th;
+    ctx->prune_me_candidates_th = P->prune_me_candidates_th;
+    ctx->use_best_unipred_cand_only = P->use_best_unipred_cand_only;
+    memcpy(ctx->p_sb_best_sad, best_sad, sizeof(ctx->p_sb_best_sad));
+    memcpy(ctx->p_sb_best_mv, best_mv, sizeof(ctx->p_sb_best_mv));
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < 4; r++) {
+            ctx->search_results[l][r].do_ref  = do_ref[l * 4 + r];
+            ctx->search_results[l][r].hme_sad = MAX_U32; /* init_me_hme_data, motion_estimation.c:3061 (refs HME never touched) */
+            ctx->me_ds_ref_array[l][r].picture_number = P->ref_picture_number[l][r];
+        }
+    /* order of svt_aom_motion_estimation_b64, motion_estimation.c:3121-3152 */
+    if (P->prune_ref) me_prune_ref(ctx);
+    if (ctx->num_of_ref_pic_to_search[0] == 1 && ctx->num_of_ref_pic_to_search[1] == 0)
+        construct_me_candidate_array_single_ref(pcs, ctx, P->num_of_list_to_search, 0);
+    else if (ctx->num_of_ref_pic_to_search[0] == 1 && ctx->num_of_ref_pic_to_search[1] == 1)
+        construct_me_candidate_array_mrp_off(pcs, ctx, P->num_of_list_to_search, 0);
+    else
+        construct_me_candidate_array(pcs, ctx, P->num_of_list_to_search, 0);
+    compute_distortion(pcs, 0, ctx);
+    pcs->stationary_block_present_sb[0] = 0;
+    pcs->rc_me_allow_gm[0]              = 0;
+    if (pcs->gm_ctrls.enabled) perform_gm_detection(pcs, 0, ctx);
+
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < 4; r++) do_ref[l * 4 + r] = ctx->search_results[l][r].do_ref;
+    st->me_64x64_distortion = u32s[0]; st->me_32x32_distortion = u32s[1]; st->me_16x16_distortion = u32s[2];
+    st->me_8x8_distortion = u32s[3]; st->me_8x8_cost_variance = u32s[4]; st->rc_me_distortion = u32s[5];
+    st->stationary_block_present_sb = u8s[0]; st->rc_me_allow_gm = u8s[1];
+    st->pad[0] = st->pad[1] = 0;
+}

@@ -76,6 +76,8 @@ PROTOTYPES = {
     "svt_hip_me_session_destroy": (None, [vp]),
     "svt_hip_me_session_submit": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
     "svt_hip_me_session_wait": (None, [vp, C.c_int]),
+    "svt_hip_me_session_submit_results": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
+    "svt_hip_me_results_batch": (None, [vp] * 10),
     "svt_hip_sad_nxm_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_sad_loop_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -158,6 +160,35 @@ class MvCostParams(C.Structure):
     """MV_COST_PARAMS (mcomp.h:37-48)."""
     _fields_ = [("ref_mv", C.POINTER(Mv)), ("full_ref_mv", Mv), ("mv_cost_type", C.c_uint8), ("mvjcost", C.POINTER(C.c_int)),
                 ("mvcost", C.POINTER(C.c_int) * 2), ("error_per_bit", C.c_int), ("early_exit_th", C.c_int), ("sad_per_bit", C.c_int)]
+
+
+class MeResultsParams(C.Structure):
+    """SvtHipMeResultsParams (include/svtav1_hip.h)."""
+    _fields_ = [("n_sb", C.c_uint32), ("num_of_list_to_search", C.c_uint8), ("num_of_ref_pic_to_search", C.c_uint8 * 2), ("max_cand", C.c_uint8),
+                ("max_refs", C.c_uint8), ("max_l0", C.c_uint8), ("enable_me_16x16", C.c_uint8), ("enable_me_8x8", C.c_uint8), ("only_l_bwd", C.c_uint8),
+                ("use_best_unipred_cand_only", C.c_uint8), ("prune_ref", C.c_uint8), ("low_resolution", C.c_uint8), ("gm_enabled", C.c_uint8),
+                ("gm_use_distance_based_active_th", C.c_uint8), ("prune_ref_if_me_sad_dev_bigger_than_th", C.c_uint16),
+                ("prune_me_candidates_th", C.c_int32), ("picture_number", C.c_uint64), ("ref_picture_number", (C.c_uint64 * 4) * 2)]
+
+
+assert C.sizeof(MeResultsParams) == 96
+
+
+class MeResultsHost(C.Structure):
+    """SvtHipMeResultsHost: host destinations of svt_hip_me_session_submit_results."""
+    _fields_ = [("do_ref", vp), ("total_me_candidate_index", vp), ("me_mv_array", vp), ("me_candidate_array", vp), ("sb_stats", vp), ("best_sad", vp),
+                ("best_mv", vp)]
+
+
+MeSbStats = np.dtype([("me_64x64_distortion", "<u4"), ("me_32x32_distortion", "<u4"), ("me_16x16_distortion", "<u4"), ("me_8x8_distortion", "<u4"),
+                      ("me_8x8_cost_variance", "<u4"), ("rc_me_distortion", "<u4"), ("stationary_block_present_sb", "u1"), ("rc_me_allow_gm", "u1"),
+                      ("pad", "u1", (2,))])
+assert MeSbStats.itemsize == 28
+
+
+def me_max_allocated_refs(l0, l1):
+    """svt_aom_get_max_allocated_me_refs (pcs.c:91-96) -> (max_refs, max_cand)."""
+    return l0 + l1, l0 + l1 + l0 * l1 + (l0 - 1) + (1 if l1 == 3 else 0)
 
 
 class CdefParams(C.Structure):

@@ -17,11 +17,14 @@ struct Slot {
     SvtHipMeSearchDesc* descs = nullptr;
     uint32_t *          sad = nullptr, *mv = nullptr;
     void*               ws    = nullptr;
+    uint8_t*            fmt   = nullptr; // formatted results: do_ref | total | cand | pad | mv | stats (see fmt_layout)
     bool                busy  = false;
 };
 struct Session {
     uint32_t width, height, stride, org_x, org_y, rows, ring, max_refs, sbs;
     size_t   plane_bytes, ws_bytes;
+    uint8_t* sb_size = nullptr;          // [sbs][2] B64Geom width, height
+    uint32_t max_cand = 0;               // bound over every (l0, l1) split of max_refs
     uint8_t* planes = nullptr;           // ring x plane_bytes
     std::vector<int64_t>    ids;         // picture id resident in ring slot r (-1 = empty)
     std::vector<hipEvent_t> uploaded;    // upload of ring slot r finished
@@ -45,6 +48,27 @@ __global__ void me_build_descs_kernel(SvtHipMeSearchDesc* descs, uint32_t sbs_x,
     d.x_search_area_origin = (int16_t)xo; d.y_search_area_origin = (int16_t)yo;
     d.search_area_width = (uint16_t)area_w; d.search_area_height = (uint16_t)area_h;
     descs[i] = d;
+}
+
+// B64Geom width / height of every SB: MIN(64, aligned_width - org_x) with the picture size rounded up to a multiple of 8 (pcs.c:1496-1518;
+// motion_estimation.c:3093-3100)
+__global__ void me_sb_size_kernel(uint8_t* sb_size, uint32_t sbs_x, uint32_t sbs, uint32_t width, uint32_t height) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sbs) return;
+    const uint32_t aw = (width + 7) & ~7u, ah = (height + 7) & ~7u, x = (i % sbs_x) * 64, y = (i / sbs_x) * 64;
+    sb_size[2 * i]     = (uint8_t)(aw - x < 64 ? aw - x : 64);
+    sb_size[2 * i + 1] = (uint8_t)(ah - y < 64 ? ah - y : 64);
+}
+struct FmtLayout { size_t do_ref, total, cand, mv, stats, bytes; };
+inline FmtLayout fmt_layout(uint32_t sbs, uint32_t n_pus, uint32_t max_refs, uint32_t max_cand) {
+    FmtLayout L;
+    L.do_ref = 0;
+    L.total  = svthip::align_up((size_t)sbs * 8, 16);
+    L.cand   = svthip::align_up(L.total + (size_t)sbs * n_pus, 16);
+    L.mv     = svthip::align_up(L.cand + (size_t)sbs * n_pus * max_cand, 16);
+    L.stats  = svthip::align_up(L.mv + (size_t)sbs * n_pus * max_refs * 4, 16);
+    L.bytes  = L.stats + (size_t)sbs * sizeof(SvtHipMeSbStats);
+    return L;
 }
 
 } // namespace
@@ -73,6 +97,11 @@ void* svt_hip_me_session_create(uint32_t width, uint32_t height, uint32_t stride
     for (auto& e : s->uploaded) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const size_t n = (size_t)s->sbs * s->max_refs;
     s->ws_bytes    = svt_hip_me_fullpel_search_workspace((uint32_t)n, max_area_width, max_area_height);
+    s->max_cand = 2 * s->max_refs + (s->max_refs * s->max_refs + 3) / 4 + 1; // >= refs + l0 * l1 + (l0 - 1) + 1 for every split (pcs.c:91-96)
+    HIP_CHECK(hipMalloc((void**)&s->sb_size, (size_t)s->sbs * 2));
+    hipLaunchKernelGGL(me_sb_size_kernel, dim3((s->sbs + 255) / 256), dim3(256), 0, 0, s->sb_size, (width + 63) / 64, s->sbs, width, height);
+    SVT_LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(0));
     s->slots.resize(n_slots ? n_slots : 2);
     for (auto& sl : s->slots) {
         HIP_CHECK(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
@@ -81,6 +110,7 @@ void* svt_hip_me_session_create(uint32_t width, uint32_t height, uint32_t stride
         HIP_CHECK(hipMalloc((void**)&sl.sad, n * SVT_HIP_ME_NUM_BLOCKS * 4));
         HIP_CHECK(hipMalloc((void**)&sl.mv, n * SVT_HIP_ME_NUM_BLOCKS * 4));
         if (s->ws_bytes) HIP_CHECK(hipMalloc(&sl.ws, s->ws_bytes));
+        HIP_CHECK(hipMalloc((void**)&sl.fmt, fmt_layout(s->sbs, SVT_HIP_ME_NUM_BLOCKS, s->max_refs, s->max_cand).bytes));
     }
     return s;
 }
@@ -94,16 +124,22 @@ void svt_hip_me_session_destroy(void* session) {
         HIP_CHECK(hipEventDestroy(sl.done));
         HIP_CHECK(hipFree(sl.descs)); HIP_CHECK(hipFree(sl.sad)); HIP_CHECK(hipFree(sl.mv));
         if (sl.ws) HIP_CHECK(hipFree(sl.ws));
+        HIP_CHECK(hipFree(sl.fmt));
     }
+    HIP_CHECK(hipFree(s->sb_size));
     for (auto& e : s->uploaded) HIP_CHECK(hipEventDestroy(e));
     HIP_CHECK(hipFree(s->planes));
     delete s;
 }
 
-int svt_hip_me_session_submit(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
-                              uint32_t area_h, int sub_sad, uint32_t* best_sad_host, uint32_t* best_mv_host) {
+static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
+                             uint32_t area_h, int sub_sad, uint32_t* best_sad_host, uint32_t* best_mv_host, const SvtHipMeResultsParams* fmt,
+                             const SvtHipMeResultsHost* out) {
     Session* s = (Session*)session;
     if (n_refs > s->max_refs) return -2;
+    if (fmt && ((uint32_t)fmt->num_of_ref_pic_to_search[0] + fmt->num_of_ref_pic_to_search[1] != n_refs || n_refs == 0 || fmt->max_refs > s->max_refs ||
+                fmt->max_cand > s->max_cand))
+        return -4;
     const int si = (int)s->next_slot;
     Slot&     sl = s->slots[si];
     if (sl.busy) { HIP_CHECK(hipEventSynchronize(sl.done)); sl.busy = false; } // the slot's previous picture (results already fetched or abandoned)
@@ -149,12 +185,37 @@ int svt_hip_me_session_submit(void* session, int64_t pic_id, const uint8_t* plan
                        (unsigned long long)src_r * s->plane_bytes, (const unsigned long long*)d_offs, (int)area_w, (int)area_h);
     SVT_LAUNCH_CHECK();
     svt_hip_me_fullpel_search_batch(s->planes, s->planes, sl.descs, n, area_w, area_h, sub_sad, sl.sad, sl.mv, sl.ws, sl.st);
-    HIP_CHECK(hipMemcpyAsync(best_sad_host, sl.sad, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
-    HIP_CHECK(hipMemcpyAsync(best_mv_host, sl.mv, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
+    if (best_sad_host) HIP_CHECK(hipMemcpyAsync(best_sad_host, sl.sad, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
+    if (best_mv_host) HIP_CHECK(hipMemcpyAsync(best_mv_host, sl.mv, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
+    if (fmt) { // the stage's final product: MeSbResults + per-SB statistics, formatted on the device from the tables just written
+        SvtHipMeResultsParams P = *fmt;
+        P.n_sb = s->sbs;
+        const uint32_t  n_pus = P.enable_me_16x16 ? (P.enable_me_8x8 ? 85 : 21) : 5;
+        const FmtLayout L     = fmt_layout(s->sbs, n_pus, P.max_refs, P.max_cand);
+        HIP_CHECK(hipMemsetAsync(sl.fmt, 0, L.stats, sl.st)); // entries the reference leaves unwritten read as 0
+        if (out->do_ref) HIP_CHECK(hipMemcpyAsync(sl.fmt + L.do_ref, out->do_ref, (size_t)s->sbs * 8, hipMemcpyHostToDevice, sl.st));
+        else HIP_CHECK(hipMemsetAsync(sl.fmt + L.do_ref, 1, (size_t)s->sbs * 8, sl.st));
+        svt_hip_me_results_batch(&P, sl.sad, sl.mv, sl.fmt + L.do_ref, s->sb_size, sl.fmt + L.total, (uint32_t*)(sl.fmt + L.mv), sl.fmt + L.cand,
+                                 (SvtHipMeSbStats*)(sl.fmt + L.stats), sl.st);
+        if (out->do_ref) HIP_CHECK(hipMemcpyAsync(out->do_ref, sl.fmt + L.do_ref, (size_t)s->sbs * 8, hipMemcpyDeviceToHost, sl.st));
+        HIP_CHECK(hipMemcpyAsync(out->total_me_candidate_index, sl.fmt + L.total, (size_t)s->sbs * n_pus, hipMemcpyDeviceToHost, sl.st));
+        HIP_CHECK(hipMemcpyAsync(out->me_candidate_array, sl.fmt + L.cand, (size_t)s->sbs * n_pus * P.max_cand, hipMemcpyDeviceToHost, sl.st));
+        HIP_CHECK(hipMemcpyAsync(out->me_mv_array, sl.fmt + L.mv, (size_t)s->sbs * n_pus * P.max_refs * 4, hipMemcpyDeviceToHost, sl.st));
+        HIP_CHECK(hipMemcpyAsync(out->sb_stats, sl.fmt + L.stats, (size_t)s->sbs * sizeof(SvtHipMeSbStats), hipMemcpyDeviceToHost, sl.st));
+    }
     HIP_CHECK(hipEventRecord(sl.done, sl.st));
     sl.busy      = true;
     s->next_slot = (s->next_slot + 1) % (uint32_t)s->slots.size();
     return si;
+}
+
+int svt_hip_me_session_submit(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
+                              uint32_t area_h, int sub_sad, uint32_t* best_sad_host, uint32_t* best_mv_host) {
+    return me_session_submit(session, pic_id, plane_host, ref_ids, n_refs, area_w, area_h, sub_sad, best_sad_host, best_mv_host, nullptr, nullptr);
+}
+int svt_hip_me_session_submit_results(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
+                                      uint32_t area_h, int sub_sad, const SvtHipMeResultsParams* params, const SvtHipMeResultsHost* out) {
+    return me_session_submit(session, pic_id, plane_host, ref_ids, n_refs, area_w, area_h, sub_sad, out->best_sad, out->best_mv, params, out);
 }
 
 void svt_hip_me_session_wait(void* session, int slot) {

@@ -1,4 +1,8 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# scratch: call 31 -- ME result formatting parity + timing
+cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_sad.py -m gpu -x -q -k "session or full_frame" 2>&1 | tail -2
-python tools/microbench.py mesession 2>&1 | tail -1 | cut -c1-500
+true
+true
+timeout 300 python tools/microbench.py meresults mesession --steps 20 --warmup 3 > gpurun_out/c31_micro.json 2> gpurun_out/c31_micro.err
+cat gpurun_out/c31_micro.json; tail -3 gpurun_out/c31_micro.err

@@ -43,6 +43,8 @@ def main():
             out.update(bench_legs.cdef_chain(torch, lib, pkg, stream, a.steps, a.warmup))
         elif leg == "mesession":
             out.update(bench_legs.me_session(torch, lib, pkg, stream, a.steps, a.warmup))
+        elif leg == "meresults":
+            out.update(bench_legs.me_results(torch, lib, pkg, stream, a.steps, a.warmup))
         elif leg == "sad":
             out["sad64x64_pairs"] = bench.bench_sad_pairs(torch, lib, pkg, stream, a)
         elif leg == "fwd32":
