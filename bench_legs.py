@@ -460,3 +460,43 @@ def me_results(torch, lib, pkg, stream, steps, warmup, npics=32):
     out["me_session_1080p_host_formatted"] = {"pictures_per_s": npics / t, "us_per_picture": t / npics * 1e6, "d2h_MB_per_picture": sum(sizes) / 1e6,
                                               "note": "4 references (2 + 2), MeSbResults + per-SB statistics returned instead of the raw tables"}
     return out
+
+
+def tf_frames(torch, lib, pkg, stream, steps, warmup):
+    """Temporal filter, whole picture in one launch (central + 6 motion-compensated references + normalisation): 1080p 8-bit and 4K 10-bit 4:2:0.
+    HBM-bound: (n_refs + 2) samples per pixel (read central and every prediction once, write the filtered picture)."""
+    out = {}
+    g = np.random.default_rng(11)
+    for (name, W, H, bd) in (("tf_1080p8_420_6refs", 1920, 1088, 8), ("tf_4k10_420_6refs", 3840, 2176, 10)):
+        n_refs, nbx, nby = 6, W // 32, H // 32
+        dt, tdt = (np.uint8, torch.uint8) if bd == 8 else (np.uint16, torch.int16)
+        P = pkg.TfParams()
+        for c in range(3):
+            P.tf_decay_factor_fp16[c] = 1 << 19
+        P.tf_mv_dist_th, P.tf_chroma, P.use_zz_based_filter, P.encoder_bit_depth, P.ss_x, P.ss_y = 16, 1, 0, bd, 1, 1
+        ys, cs = W + 64, W // 2 + 32
+
+        def planes():
+            t = [torch.from_numpy(g.integers(0, 1 << bd, (H, ys)).astype(dt).view(np.int16 if bd > 8 else np.uint8)).cuda(),
+                 torch.from_numpy(g.integers(0, 1 << bd, (H // 2, cs)).astype(dt).view(np.int16 if bd > 8 else np.uint8)).cuda(),
+                 torch.from_numpy(g.integers(0, 1 << bd, (H // 2, cs)).astype(dt).view(np.int16 if bd > 8 else np.uint8)).cuda()]
+            return t, pkg.TfPlanes(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), ys, cs)
+        cen_t, cen = planes()
+        out_t, outp = planes()
+        refs = [planes() for _ in range(n_refs)]
+        prs = (pkg.TfPlanes * n_refs)(*[r[1] for r in refs])
+        B = np.zeros(n_refs * nbx * nby, pkg.TfBlock)
+        B["split"] = g.integers(0, 2, len(B))
+        B["block_error"] = g.integers(0, 4096, (len(B), 4)) << (0 if bd == 8 else 4)
+        B["mv_x"], B["mv_y"] = g.integers(-8, 9, (len(B), 4)), g.integers(-8, 9, (len(B), 4))
+        d_b = torch.from_numpy(B.view(np.uint8).reshape(-1)).cuda()
+        t = _time(torch, lambda: lib.svt_hip_tf_filter_frame(C.addressof(P), C.addressof(cen), C.addressof(prs), n_refs, d_b.data_ptr(), nbx, nby,
+                                                              C.addressof(outp), stream), steps, warmup)
+        nbytes = W * H * 1.5 * (n_refs + 2) * (1 if bd == 8 else 2)
+        out[name] = {"us": t * 1e6, "frames_per_s": 1 / t, "GBps_algorithmic": nbytes / t / 1e9, "hbm_frac": nbytes / t / 8e12}
+    # noise estimate of a 1080p luma plane (one launch + finalize)
+    a = torch.from_numpy(g.integers(90, 110, (1080, 2056), dtype=np.uint8)).cuda()
+    res, ws = torch.zeros(4, dtype=torch.int32, device="cuda"), torch.zeros(lib.svt_hip_estimate_noise_workspace(1920, 1080), dtype=torch.uint8, device="cuda")
+    t = _time(torch, lambda: lib.svt_hip_estimate_noise_batch(a.data_ptr(), 1920, 1080, 2056, 8, res.data_ptr(), ws.data_ptr(), stream), steps, warmup)
+    out["noise_estimate_1080p8"] = {"us": t * 1e6, "GBps_algorithmic": 1920 * 1080 / t / 1e9}
+    return out

@@ -227,6 +227,72 @@ int svt_hip_me_session_submit_results(void *session, int64_t pic_id, const uint8
                                       uint32_t area_w, uint32_t area_h, int sub_sad, const SvtHipMeResultsParams *params,
                                       const SvtHipMeResultsHost *out);
 
+/* ---- temporal filter pixel kernels (the DSP part of Codec/temporal_filtering.c; fixed point) ----
+ * The reference's RTCD pointers take a `struct MeContext *` (aom_dsp_rtcd.h:797-826); its layout is private to the encoder, so the `_hip`
+ * functions take the handful of fields the kernels read as two plain structs instead (INTEGRATION.md shows the 12-line adapter that fills
+ * them from a MeContext).  Everything else of each prototype is the reference's. */
+typedef struct SvtHipTfParams { /* per picture */
+    uint32_t tf_decay_factor_fp16[3]; /* me_ctx->tf_decay_factor_fp16[C_Y, C_U, C_V] (me_context.h:372) */
+    uint16_t tf_mv_dist_th;           /* me_context.h:490 */
+    uint8_t  tf_chroma;               /* :469 */
+    uint8_t  use_zz_based_filter;     /* tf_ctrls.use_zz_based_filter (frame form only: selects the kernel) */
+    uint8_t  encoder_bit_depth;       /* frame form only; the symbols below take it as an argument like the reference */
+    uint8_t  ss_x, ss_y;              /* frame form only */
+    uint8_t  pad;
+} SvtHipTfParams;
+typedef struct SvtHipTfBlock { /* per 32x32 luma block (idx_32x32 = tf_block_col + 2 * tf_block_row) and reference picture */
+    uint64_t block_error[4]; /* split: tf_16x16_block_error[4 idx + i]; else [0] = tf_32x32_block_error[idx] (me_context.h:477,485) */
+    int16_t  mv_x[4];        /* split: tf_16x16_mv_x[4 idx + i]; else [0] = tf_32x32_mv_x[idx] */
+    int16_t  mv_y[4];
+    uint8_t  split;          /* tf_32x32_block_split_flag[idx] */
+    uint8_t  pad[7];
+} SvtHipTfBlock;
+/* svt_av1_apply_temporal_filter_planewise_medium{,_hbd} -> _c (temporal_filtering.c:1145-1196, 1332-1400), aom_dsp_rtcd.h:813-826 */
+void svt_av1_apply_temporal_filter_planewise_medium_hip(const SvtHipTfParams *params, const SvtHipTfBlock *block, const uint8_t *y_src,
+                                                        int y_src_stride, const uint8_t *y_pre, int y_pre_stride, const uint8_t *u_src,
+                                                        const uint8_t *v_src, int uv_src_stride, const uint8_t *u_pre, const uint8_t *v_pre,
+                                                        int uv_pre_stride, unsigned int block_width, unsigned int block_height, int ss_x, int ss_y,
+                                                        uint32_t *y_accum, uint16_t *y_count, uint32_t *u_accum, uint16_t *u_count, uint32_t *v_accum,
+                                                        uint16_t *v_count);
+void svt_av1_apply_temporal_filter_planewise_medium_hbd_hip(const SvtHipTfParams *params, const SvtHipTfBlock *block, const uint16_t *y_src,
+                                                            int y_src_stride, const uint16_t *y_pre, int y_pre_stride, const uint16_t *u_src,
+                                                            const uint16_t *v_src, int uv_src_stride, const uint16_t *u_pre, const uint16_t *v_pre,
+                                                            int uv_pre_stride, unsigned int block_width, unsigned int block_height, int ss_x,
+                                                            int ss_y, uint32_t *y_accum, uint16_t *y_count, uint32_t *u_accum, uint16_t *u_count,
+                                                            uint32_t *v_accum, uint16_t *v_count, uint32_t encoder_bit_depth);
+/* svt_av1_apply_zz_based_temporal_filter_planewise_medium{,_hbd} -> _c (temporal_filtering.c:867-903, 970-1013), aom_dsp_rtcd.h:798-811 */
+void svt_av1_apply_zz_based_temporal_filter_planewise_medium_hip(const SvtHipTfParams *params, const SvtHipTfBlock *block, const uint8_t *y_pre,
+                                                                 int y_pre_stride, const uint8_t *u_pre, const uint8_t *v_pre, int uv_pre_stride,
+                                                                 unsigned int block_width, unsigned int block_height, int ss_x, int ss_y,
+                                                                 uint32_t *y_accum, uint16_t *y_count, uint32_t *u_accum, uint16_t *u_count,
+                                                                 uint32_t *v_accum, uint16_t *v_count);
+void svt_av1_apply_zz_based_temporal_filter_planewise_medium_hbd_hip(const SvtHipTfParams *params, const SvtHipTfBlock *block,
+                                                                     const uint16_t *y_pre, int y_pre_stride, const uint16_t *u_pre,
+                                                                     const uint16_t *v_pre, int uv_pre_stride, unsigned int block_width,
+                                                                     unsigned int block_height, int ss_x, int ss_y, uint32_t *y_accum,
+                                                                     uint16_t *y_count, uint32_t *u_accum, uint16_t *u_count, uint32_t *v_accum,
+                                                                     uint16_t *v_count, uint32_t encoder_bit_depth);
+/* svt_estimate_noise_fp16 / svt_estimate_noise_highbd_fp16 -> _c (temporal_filtering.c:3847-3920), aom_dsp_rtcd.h:876-879; RTCD-hooked */
+int32_t svt_estimate_noise_fp16_hip(const uint8_t *src, uint16_t width, uint16_t height, uint16_t stride_y);
+int32_t svt_estimate_noise_highbd_fp16_hip(const uint16_t *src, int width, int height, int stride, int bd);
+/* device form: plane in HBM (stride in samples), result written to noise_out[0]; workspace: svt_hip_estimate_noise_workspace() bytes, any content */
+size_t svt_hip_estimate_noise_workspace(uint32_t width, uint32_t height);
+void svt_hip_estimate_noise_batch(const void *plane, uint32_t width, uint32_t height, uint32_t stride, int bit_depth, int32_t *noise_out,
+                                  void *workspace, void *stream);
+/* Whole-picture temporal filtering given the motion-compensated predictions: for every 32x32 luma block (and its chroma blocks) the
+ * accumulators start from the central picture with weight 1000 (svt_aom_apply_filtering_central{,_highbd}_c, :350-425), each reference adds
+ * its plane-wise term (the functions above, chosen by use_zz_based_filter / encoder_bit_depth), and (accum + count / 2) / count is written
+ * out (svt_aom_get_final_filtered_pixels_c, :2608-2672) -- produce_temporally_filtered_pic's steps 2-3 (:3360-3400) in one launch, accum and
+ * count never leaving registers.  Planes are device pointers, strides in samples; out may alias central.  blocks: device,
+ * [n_refs][nby][nbx]; nbx x nby 32x32 blocks are processed (the planes must cover them, as the reference's padded pictures do). */
+#define SVT_HIP_TF_MAX_REFS 8
+typedef struct SvtHipTfPlanes {
+    void    *y, *u, *v;
+    uint32_t y_stride, uv_stride;
+} SvtHipTfPlanes;
+void svt_hip_tf_filter_frame(const SvtHipTfParams *params, const SvtHipTfPlanes *central, const SvtHipTfPlanes *preds, uint32_t n_refs,
+                             const SvtHipTfBlock *blocks, uint32_t nbx, uint32_t nby, const SvtHipTfPlanes *out, void *stream);
+
 /* ---------------------------------------------------------------- transforms (a10, a12, a13, a14) --- */
 /* TxSize / TxType numbering = Source/Lib/Codec/definitions.h (TX_4X4=0 .. TX_64X16=18; DCT_DCT=0 .. H_FLIPADST=15). */
 typedef struct SvtHipFwdTxfmDesc {

@@ -78,6 +78,15 @@ PROTOTYPES = {
     "svt_hip_me_session_wait": (None, [vp, C.c_int]),
     "svt_hip_me_session_submit_results": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
     "svt_hip_me_results_batch": (None, [vp] * 10),
+    "svt_av1_apply_temporal_filter_planewise_medium_hip": (None, [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "svt_av1_apply_temporal_filter_planewise_medium_hbd_hip": (None, [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp] + [C.c_uint32]),
+    "svt_av1_apply_zz_based_temporal_filter_planewise_medium_hip": (None, [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "svt_av1_apply_zz_based_temporal_filter_planewise_medium_hbd_hip": (None, [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp] + [C.c_uint32]),
+    "svt_estimate_noise_fp16_hip": (C.c_int32, [vp, C.c_uint16, C.c_uint16, C.c_uint16]),
+    "svt_estimate_noise_highbd_fp16_hip": (C.c_int32, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "svt_hip_estimate_noise_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "svt_hip_estimate_noise_batch": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
+    "svt_hip_tf_filter_frame": (None, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_sad_nxm_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_sad_loop_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -172,6 +181,22 @@ class MeResultsParams(C.Structure):
 
 
 assert C.sizeof(MeResultsParams) == 96
+
+
+class TfParams(C.Structure):
+    """SvtHipTfParams: the per-picture MeContext fields read by the temporal filter's pixel kernels."""
+    _fields_ = [("tf_decay_factor_fp16", C.c_uint32 * 3), ("tf_mv_dist_th", C.c_uint16), ("tf_chroma", C.c_uint8), ("use_zz_based_filter", C.c_uint8),
+                ("encoder_bit_depth", C.c_uint8), ("ss_x", C.c_uint8), ("ss_y", C.c_uint8), ("pad", C.c_uint8)]
+
+
+assert C.sizeof(TfParams) == 20
+TfBlock = np.dtype([("block_error", "<u8", (4,)), ("mv_x", "<i2", (4,)), ("mv_y", "<i2", (4,)), ("split", "u1"), ("pad", "u1", (7,))])
+assert TfBlock.itemsize == 56
+
+
+class TfPlanes(C.Structure):
+    """SvtHipTfPlanes: device planes (strides in samples)."""
+    _fields_ = [("y", vp), ("u", vp), ("v", vp), ("y_stride", C.c_uint32), ("uv_stride", C.c_uint32)]
 
 
 class MeResultsHost(C.Structure):

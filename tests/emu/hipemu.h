@@ -228,6 +228,7 @@ template <typename... P, typename... A> inline void launch_k(void (*k)(P...), di
 
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
+inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); } // lanes run as fibers here: same-wave LDS hand-offs need the rendezvous
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
@@ -387,6 +388,10 @@ template <class V> inline V __builtin_elementwise_sub_sat(V a, V b) { return (a 
 typedef unsigned short hipemu_us2 __attribute__((vector_size(4)));
 inline unsigned __builtin_amdgcn_udot2(hipemu_us2 a, hipemu_us2 b, unsigned c, bool) {
     return c + (unsigned)a[0] * (unsigned)b[0] + (unsigned)a[1] * (unsigned)b[1];
+}
+inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) { // v_dot4_u32_u8
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xff) * ((b >> (8 * i)) & 0xff);
+    return c;
 }
 inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned sel) {
     unsigned long long v = ((unsigned long long)a << 32) | b;
