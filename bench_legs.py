@@ -8,17 +8,21 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0
 
 
-def _time(torch, fn, steps, warmup):
+def _time(torch, fn, steps, warmup, batches=5):
+    """seconds per call: median over `batches` event-timed runs of `steps` back-to-back launches (short kernels see clock ramps)"""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(steps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / 1e3 / steps
+    ts = []
+    for _ in range(batches):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 1e3 / steps)
+    return sorted(ts)[len(ts) // 2]
 
 
 def _dev(torch, a):

@@ -1,9 +1,7 @@
 #!/bin/bash
-# scratch: call 34 -- TF kernel trace
+# scratch: call 35 -- TF timing (no profiler) + parity
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d gpurun_out/c34_prof -o tf -- python tools/microbench.py tf --steps 20 --warmup 3 > gpurun_out/c34_micro.json 2> gpurun_out/c34_micro.err
-cat gpurun_out/c34_micro.json
-find gpurun_out/c34_prof -name "*kernel_stats*" | head -2
-f=$(find gpurun_out/c34_prof -name "*kernel_stats.csv" | head -1); head -8 "$f" | cut -c1-220
+python tools/microbench.py tf --steps 40 --warmup 5 > gpurun_out/c35_micro.json 2> gpurun_out/c35_micro.err
+cat gpurun_out/c35_micro.json
+timeout 600 python -m pytest tests/test_tf.py tests/test_rtcd_hook.py -q -m gpu -x 2>&1 | tail -2
