@@ -145,6 +145,60 @@ def gen_filters(ref, oracle):
     np.savez_compressed(os.path.join(GOLDEN, "filters.npz"), **out)
 
 
+def gen_stage(ref, oracle):
+    """ME result formatting and temporal-filter kernels: inputs + outputs of the reference's own functions (static ones through
+    oracle/_ref/libsvtref_me.so, see oracle/ref_wrap/)."""
+    import test_me_results as M
+    import test_tf as T
+    from conftest import load_pkg
+    pkg = load_pkg()
+    refme = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libsvtref_me.so"))
+    ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))
+    out = {}
+    # ---- MeSbResults
+    for k, ci in enumerate((3, 6, 8, 10)):
+        cfg, g = M.CONFIGS[ci], np.random.default_rng(7000 + ci)
+        P = M.make_params(pkg, cfg, 12, g)
+        sad, mv, do_ref, sb_size = M.make_tables(g, cfg, 12)
+        tot, mvs, cands, stats, dr = M.run_cpu(refme.ref_me_results_sb, pkg, P, cfg, sad, mv, do_ref, sb_size, 0xaa)
+        out.update({"me%d_cfg" % k: np.array(cfg, np.int32), "me%d_params" % k: np.frombuffer(bytes(P), np.uint8).copy(), "me%d_sad" % k: sad, "me%d_mv" % k: mv,
+                    "me%d_do_ref" % k: do_ref, "me%d_sb_size" % k: sb_size, "me%d_total" % k: tot, "me%d_mvs" % k: mvs, "me%d_cands" % k: cands,
+                    "me%d_stats" % k: stats.view(np.uint8).reshape(len(stats), -1), "me%d_do_ref_out" % k: dr})
+    # ---- temporal filter, one 64x64 block through the reference's chain (central -> plane-wise per reference -> normalisation)
+    k = 0
+    for bd in (8, 10):
+        for zz in (0, 1):
+            g = np.random.default_rng(7100 + bd + zz)
+            ss = (1, 1)
+            P = T.make_params(pkg, g, bd, zz, 1, ss)
+            cstride = [96, 48]
+            central = [T.make_pair(g, bd, (64, 96))[0], T.make_pair(g, bd, (32, 48))[0], T.make_pair(g, bd, (32, 48))[0]]
+            preds = []
+            for r in range(3):
+                pl = []
+                for c in range(3):
+                    w, h = (64, 64) if c == 0 else (32, 32)
+                    noise = int(g.choice([2, 8, 30])) << (bd - 8)
+                    pl.append(np.clip(central[c][:h, :w].astype(np.int32) + g.integers(-noise, noise + 1, (h, w)), 0, (1 << bd) - 1).astype(central[c].dtype))
+                preds.append(pl)
+            blocks = T.make_blocks(pkg, g, 12, bd).reshape(3, 2, 2)
+            want = T.ref_frame_chain(refme, pkg, P, central, cstride, preds, blocks, 3, int(bd > 8))
+            out.update({"tf%d_params" % k: np.frombuffer(bytes(P), np.uint8).copy(), "tf%d_blocks" % k: blocks.view(np.uint8).reshape(3, 2, 2, -1)})
+            for c in range(3):
+                out["tf%d_central%d" % (k, c)] = central[c]
+                out["tf%d_out%d" % (k, c)] = want[c]
+                for r in range(3):
+                    out["tf%d_pred%d_%d" % (k, r, c)] = preds[r][c]
+            k += 1
+    # ---- noise estimate
+    g = np.random.default_rng(7200)
+    a8 = np.clip(100 + np.add.outer(np.arange(40), np.arange(72)) + g.integers(-5, 6, (40, 72)), 0, 255).astype(np.uint8)
+    a10 = (a8.astype(np.uint16) << 2) + g.integers(0, 4, a8.shape).astype(np.uint16)
+    out.update(noise_a8=a8, noise_a10=a10, noise_out=np.array([ref.svt_estimate_noise_fp16_c(p(a8), 64, 40, 72),
+                                                              ref.svt_estimate_noise_highbd_fp16_c(p(a10), 64, 40, 72, 10)], np.int32))
+    np.savez_compressed(os.path.join(GOLDEN, "stage.npz"), **out)
+
+
 def gen_txfm(ref, oracle):
     from test_oracle_pin_txfm import TXW, TXH, allowed_types, ref_fwd, call_ref_inv
     g = np.random.default_rng(77)
@@ -168,7 +222,7 @@ def gen_txfm(ref, oracle):
     np.savez_compressed(os.path.join(GOLDEN, "txfm.npz"), cfg=np.array(cfg, np.int32), **arrays)
 
 
-FAMILIES = {"sad": gen_sad, "txfm": gen_txfm, "filters": gen_filters}
+FAMILIES = {"sad": gen_sad, "txfm": gen_txfm, "filters": gen_filters, "stage": gen_stage}
 
 if __name__ == "__main__":
     os.system("make -s -C %s oracle ref" % os.path.join(ROOT, "oracle"))
