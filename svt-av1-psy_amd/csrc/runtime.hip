@@ -17,6 +17,13 @@ void ensure_device() {
             abort();
         }
     }
+    // the current device is per host thread: the encoder's worker threads (pointers are called concurrently from ME / EncDec /
+    // CDEF / REST threads) bind to the device chosen at svt_hip_init the first time they enter the library
+    static thread_local bool t_bound = false;
+    if (!t_bound) {
+        HIP_CHECK(hipSetDevice(g_device));
+        t_bound = true;
+    }
 }
 
 static thread_local HostCall t_call;
