@@ -234,7 +234,11 @@ def deblock(torch, lib, pkg, stream, steps, warmup):
         along_n, across_n = (h, w) if vert else (w, h)
         parts = []
         for par, grid, length in ((0, 16, 14), (1, 8, 8)):
-            cs, as_ = np.meshgrid(np.arange(grid, across_n, grid), np.arange(4 * par, along_n, 8))
+            # raster order (x fastest) in both passes: consecutive threads then touch consecutive addresses
+            if vert:
+                cs, as_ = np.meshgrid(np.arange(grid, across_n, grid), np.arange(4 * par, along_n, 8))
+            else:
+                as_, cs = np.meshgrid(np.arange(4 * par, along_n, 8), np.arange(grid, across_n, grid))
             parts.append((cs.ravel(), as_.ravel(), np.full(cs.size, length)))
         cs, as_, ln = (np.concatenate([q[i] for q in parts]) for i in range(3))
         xs, ys = (cs, as_) if vert else (as_, cs)

@@ -372,7 +372,9 @@ void svt_hip_generate_padding(uint8_t *base, uint32_t stride, uint32_t width, ui
 /* svt_aom_lpf_{horizontal,vertical}_{4,6,8,14} / svt_aom_highbd_lpf_* -> `_c` (common_dsp_rtcd.h:1037-1067, Codec/deblocking_common.c:141-865).
  * Batched form: n edge segments of 4 samples over a device plane; (x, y) = the q0 sample of the segment's first position; vertical = 1 for a
  * column boundary (filtering along x); length in {4, 6, 8, 14}; blimit / limit / thresh as the reference's per-edge LoopFilterThresh bytes.
- * Segments of one launch must not overlap (the reference filters all vertical edges of a picture before the horizontal ones). */
+ * Segments of one launch must not overlap (the reference filters all vertical edges of a picture before the horizontal ones).  One thread per
+ * segment: list the segments in raster order (x fastest) and grouped by length, so that neighbouring threads touch neighbouring addresses and
+ * take the same filter path; a vertical edge reads up to 8 samples either side of x (4 for lengths < 14), which must lie inside the allocation. */
 typedef struct SvtHipLpfEdge {
     uint32_t x, y;
     uint8_t  vertical, length, blimit, limit, thresh, pad[3];

@@ -1,6 +1,7 @@
 // deblock.hip -- AV1 deblocking edge filters: svt_aom_lpf_{horizontal,vertical}_{4,6,8,14} and the svt_aom_highbd_lpf_*
 // family (common_dsp_rtcd.h:1037-1067; C: Codec/deblocking_common.c:141-865).  One thread filters one pixel position of an edge: it loads
-// the 2 / 3 / 4 / 7 samples on either side, evaluates the filter / flat / flat2 masks and writes the modified samples back.  The 8-bit
+// the 2 / 3 / 4 / 7 samples on either side, evaluates the filter / flat / flat2 masks and writes the modified samples back; one thread
+// handles the four positions of a 4-sample segment with vector accesses.  The 8-bit
 // functions are the high-bit-depth ones at bd = 8, so one routine serves both families.
 //
 // Batched form: a list of 4-sample edge segments over a device plane.  The caller orders the passes exactly as the reference's frame driver
@@ -82,32 +83,67 @@ template <int LEN> __device__ __forceinline__ void lpf_px(int (&p)[7], int (&q)[
     }
 }
 
+// N consecutive samples as one (possibly unaligned) vector access
+template <typename PIX, int N> struct __attribute__((packed, aligned(1))) PxN { PIX v[N]; };
+
+// One thread filters a whole 4-sample segment (4 independent evaluations of lpf_px).  The rows of a vertical edge are read as one span
+// centred on the edge (16 samples for the 14-tap filters, 8 otherwise) and only the span that the filter may modify is written back --
+// 12 / 6 / 4 samples -- because the samples beyond it belong to the neighbouring edges of the same pass.  A horizontal edge is read and
+// written as 4-sample row vectors.  This replaced one thread per sample with up to 14 + 12 scalar accesses each.
 template <typename PIX, int LEN>
-__device__ __forceinline__ void lpf_at(PIX* s, const long across, const int blimit, const int limit, const int thresh, const int bd) {
+__device__ __forceinline__ void lpf_segment(PIX* s, const uint32_t stride, const bool vertical, const int blimit, const int limit, const int thresh,
+                                            const int bd) {
     constexpr int HALF = LEN == 14 ? 7 : LEN / 2, WR = LEN == 14 ? 6 : (LEN == 8 ? 3 : 2); // samples read / possibly modified per side
-    int p[7], q[7];
+    constexpr int RD = LEN == 14 ? 8 : 4;                                                  // samples fetched per side of a vertical edge
+    if (vertical) {
+        PxN<PIX, 2 * RD> in[4]; // all four rows are fetched before the (branchy) filter runs: one memory round trip per segment
 #pragma unroll
-    for (int k = 0; k < HALF; k++) { p[k] = s[-(long)(k + 1) * across]; q[k] = s[(long)k * across]; }
-    lpf_px<LEN>(p, q, blimit, limit, thresh, bd);
+        for (int r = 0; r < 4; r++) in[r] = *(const PxN<PIX, 2 * RD>*)(s + (size_t)r * stride - RD);
 #pragma unroll
-    for (int k = 0; k < WR; k++) { s[-(long)(k + 1) * across] = (PIX)p[k]; s[(long)k * across] = (PIX)q[k]; }
+        for (int r = 0; r < 4; r++) {
+            int p[7], q[7];
+#pragma unroll
+            for (int k = 0; k < HALF; k++) { p[k] = in[r].v[RD - 1 - k]; q[k] = in[r].v[RD + k]; }
+            lpf_px<LEN>(p, q, blimit, limit, thresh, bd);
+            PxN<PIX, 2 * WR> out;
+#pragma unroll
+            for (int k = 0; k < WR; k++) { out.v[WR - 1 - k] = (PIX)p[k]; out.v[WR + k] = (PIX)q[k]; }
+            *(PxN<PIX, 2 * WR>*)(s + (size_t)r * stride - WR) = out;
+        }
+    } else {
+        int p[4][7], q[4][7];
+#pragma unroll
+        for (int k = 0; k < HALF; k++) {
+            const PxN<PIX, 4> a = *(const PxN<PIX, 4>*)(s - (size_t)(k + 1) * stride), b = *(const PxN<PIX, 4>*)(s + (size_t)k * stride);
+#pragma unroll
+            for (int c = 0; c < 4; c++) { p[c][k] = a.v[c]; q[c][k] = b.v[c]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) lpf_px<LEN>(p[c], q[c], blimit, limit, thresh, bd);
+#pragma unroll
+        for (int k = 0; k < WR; k++) {
+            PxN<PIX, 4> a, b;
+#pragma unroll
+            for (int c = 0; c < 4; c++) { a.v[c] = (PIX)p[c][k]; b.v[c] = (PIX)q[c][k]; }
+            *(PxN<PIX, 4>*)(s - (size_t)(k + 1) * stride) = a;
+            *(PxN<PIX, 4>*)(s + (size_t)k * stride)       = b;
+        }
+    }
 }
 
-// one thread per (segment, sample along the edge)
+// one thread per 4-sample segment
 template <typename PIX>
 __global__ __launch_bounds__(256) void lpf_edges_kernel(PIX* __restrict__ plane, const uint32_t stride, const int bd, const SvtHipLpfEdge* __restrict__ edges,
                                                         const uint32_t n) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n * 4) return;
-    const SvtHipLpfEdge e = edges[id >> 2];
-    const int  i = id & 3;
-    const long along = e.vertical ? (long)stride : 1, across = e.vertical ? 1 : (long)stride;
-    PIX* s = plane + (size_t)e.y * stride + e.x + i * along;
+    if (id >= n) return;
+    const SvtHipLpfEdge e = edges[id];
+    PIX* s = plane + (size_t)e.y * stride + e.x;
     switch (e.length) {
-    case 4: lpf_at<PIX, 4>(s, across, e.blimit, e.limit, e.thresh, bd); break;
-    case 6: lpf_at<PIX, 6>(s, across, e.blimit, e.limit, e.thresh, bd); break;
-    case 8: lpf_at<PIX, 8>(s, across, e.blimit, e.limit, e.thresh, bd); break;
-    default: lpf_at<PIX, 14>(s, across, e.blimit, e.limit, e.thresh, bd); break;
+    case 4: lpf_segment<PIX, 4>(s, stride, e.vertical != 0, e.blimit, e.limit, e.thresh, bd); break;
+    case 6: lpf_segment<PIX, 6>(s, stride, e.vertical != 0, e.blimit, e.limit, e.thresh, bd); break;
+    case 8: lpf_segment<PIX, 8>(s, stride, e.vertical != 0, e.blimit, e.limit, e.thresh, bd); break;
+    default: lpf_segment<PIX, 14>(s, stride, e.vertical != 0, e.blimit, e.limit, e.thresh, bd); break;
     }
 }
 
@@ -120,18 +156,20 @@ void lpf_host(void* s, int pitch, int is16, int vertical, int len, int blimit, i
     const int    half = len == 14 ? 7 : len / 2;
     const int    rw = vertical ? 2 * half : 4, rh = vertical ? 4 : 2 * half;
     const size_t dp = 64; // device pitch in bytes
-    c.reserve(dp * rh + 256, dp * rh + 256);
+    const int    mx = vertical ? 8 - half : 0; // the kernel fetches 4 / 8 samples per side of a vertical edge: margin inside the staging rectangle
+    c.reserve(dp * rh + 256, 2 * dp * rh + 256);
     uint8_t* d = (uint8_t*)c.dalloc(dp * rh);
     SvtHipLpfEdge* de = (SvtHipLpfEdge*)c.dalloc(sizeof(SvtHipLpfEdge));
     uint8_t* h0 = (uint8_t*)s - (vertical ? (size_t)half * px : (size_t)half * pitch * px);
-    c.up2d(d, dp, h0, (size_t)pitch * px, rw * px, rh);
+    HIP_CHECK(hipMemsetAsync(d, 0, dp * rh, c.stream));
+    c.up2d(d + mx * px, dp, h0, (size_t)pitch * px, rw * px, rh);
     SvtHipLpfEdge e;
     memset(&e, 0, sizeof(e));
-    e.x = vertical ? half : 0; e.y = vertical ? 0 : half; e.vertical = (uint8_t)vertical; e.length = (uint8_t)len;
+    e.x = vertical ? mx + half : 0; e.y = vertical ? 0 : half; e.vertical = (uint8_t)vertical; e.length = (uint8_t)len;
     e.blimit = (uint8_t)blimit; e.limit = (uint8_t)limit; e.thresh = (uint8_t)thresh;
     c.up(de, &e, sizeof(e));
     svt_hip_lpf_edges_batch(d, (uint32_t)(dp / px), is16, bd, de, 1, c.stream);
-    c.down2d(h0, (size_t)pitch * px, d, dp, rw * px, rh);
+    c.down2d(h0, (size_t)pitch * px, d + mx * px, dp, rw * px, rh);
 }
 
 } // namespace
@@ -141,7 +179,7 @@ extern "C" {
 void svt_hip_lpf_edges_batch(void* plane, uint32_t stride, int is_16bit, int bd, const SvtHipLpfEdge* edges, uint32_t n, void* stream) {
     svthip::ensure_device();
     if (n == 0) return;
-    const dim3 grid((n * 4 + 255) / 256);
+    const dim3 grid((n + 255) / 256);
     if (is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(lpf_edges_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (uint16_t*)plane, stride, bd, edges, n);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(lpf_edges_kernel<uint8_t>), grid, dim3(256), 0, (hipStream_t)stream, (uint8_t*)plane, stride, 8, edges, n);
     SVT_LAUNCH_CHECK();

@@ -201,10 +201,10 @@ def test_tf_planewise_symbols_hip(be, oracle, bd, zz):
 def test_tf_filter_frame_hip(be, oracle, bd, zz):
     """Whole-picture form: central + n references + normalisation in one launch vs the oracle's per-block chain; in place and out of place."""
     pkg, g = load_pkg(), rng(1400 + bd + zz)
-    for it, ss in enumerate([(1, 1), (1, 0), (0, 0), (1, 1), (0, 1)]):
+    for it, ss in enumerate([(1, 1), (1, 0), (0, 0), (1, 1), (0, 1), (1, 1)]):
         chroma = it != 3
         nbx, nby = (3, 2) if not be.is_gpu else (9, 5)
-        n_refs = [3, 1, 6, 0, 2][it] if be.is_gpu or it != 2 else 2
+        n_refs = [3, 1, 6, 0, 2, 8][it] if be.is_gpu or it != 2 else 2
         P = make_params(pkg, g, bd, zz, chroma, ss)
         W, H = nbx * 32, nby * 32
         cw, chh = W >> ss[0], H >> ss[1]
