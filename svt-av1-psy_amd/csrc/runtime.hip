@@ -120,6 +120,13 @@ __global__ void svt_hip_selftest_kernel(uint32_t* out) {
     out[9 * 64 + l]  = (uint32_t)__shfl_xor((int)a, 32);
     out[10 * 64 + l] = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)a, 0x111, 0xf, 0xf, false); // row_shr:1
     out[11 * 64 + l] = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)a, 0x101, 0xf, 0xf, false); // row_shl:1
+    const auto s16 = __builtin_amdgcn_permlane16_swap(a, b, false, false); // gfx950: rows 1, 3 of vdst <-> rows 0, 2 of src0
+    out[12 * 64 + l] = s16[0];
+    out[13 * 64 + l] = s16[1];
+    const auto s32 = __builtin_amdgcn_permlane32_swap(a, b, false, false); // lanes 32-63 of vdst <-> lanes 0-31 of src0
+    out[14 * 64 + l] = s32[0];
+    out[15 * 64 + l] = s32[1];
+    out[16 * 64 + l] = __builtin_amdgcn_udot4(a, b, 7u, false);
 }
 
 // Instruction-rate probe (DESIGN.md "measured instruction rates"): every lane runs `iters` rounds of 8 independent

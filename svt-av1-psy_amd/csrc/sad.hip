@@ -182,7 +182,6 @@ __device__ __forceinline__ void me_search_strips(const uint32_t* __restrict__ wi
     const int q  = l & 3;
     const int      G    = (Wt + 3) >> 2;
     const uint32_t qsel = 0x0c0c0100u + 0x0202u * (uint32_t)q; // v_perm_b32 selector: u16 number q of {thi:tlo}, zero extended
-    const int      bp16 = (l ^ 16) << 2, bp32 = (l ^ 32) << 2; // ds_bpermute byte addresses of the partner rows
     for (int g = wv; g < G; g += 4) {
         const uint32_t* colp   = win + (by * 8) * ME_PITCH + bx * 2 + g;
         const int       nvalid = (Wt - 4 * g) < 4 ? (Wt - 4 * g) : 4;
@@ -228,8 +227,11 @@ __device__ __forceinline__ void me_search_strips(const uint32_t* __restrict__ wi
                     // 32x32 = 4 quads of a 16-lane row; 64x64 = 4 rows
                     const uint32_t sad32 = dpp_add_row_ror8(dpp_add_row_ror4(sad16));
                     best32 = umin32(best32, (sad32 << KEY_POS_BITS) | pq);
-                    uint32_t sad64 = sad32 + (uint32_t)__builtin_amdgcn_ds_bpermute(bp16, (int)sad32);
-                    sad64 += (uint32_t)__builtin_amdgcn_ds_bpermute(bp32, (int)sad64);
+                    // row sums across the wave with the gfx950 row / half swaps (VALU; a ds_bpermute pair sat in the dependent chain before)
+                    const auto     x16   = __builtin_amdgcn_permlane16_swap(sad32, sad32, false, false);
+                    const uint32_t pair  = x16[0] + x16[1];
+                    const auto     x32   = __builtin_amdgcn_permlane32_swap(pair, pair, false, false);
+                    const uint32_t sad64 = x32[0] + x32[1];
                     best64 = umin32(best64, (sad64 << KEY_POS_BITS) | pq);
                     pos += ME_TW;
                     posq += ME_TW;

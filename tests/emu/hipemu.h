@@ -389,6 +389,20 @@ typedef unsigned short hipemu_us2 __attribute__((vector_size(4)));
 inline unsigned __builtin_amdgcn_udot2(hipemu_us2 a, hipemu_us2 b, unsigned c, bool) {
     return c + (unsigned)a[0] * (unsigned)b[0] + (unsigned)a[1] * (unsigned)b[1];
 }
+// gfx950 v_permlane16_swap_b32 / v_permlane32_swap_b32: exchange rows (halves) between the two operands; both results are returned
+struct hipemu_u2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+inline hipemu_u2 __builtin_amdgcn_permlane16_swap(unsigned vdst, unsigned src0, bool, bool) {
+    const int      l  = hipemu::lane_id();
+    const unsigned ps = (unsigned)hipemu::wave_xchg(src0, l ^ 16), pd = (unsigned)hipemu::wave_xchg(vdst, l ^ 16);
+    const bool     odd = (l >> 4) & 1;
+    return hipemu_u2{{odd ? ps : vdst, odd ? src0 : pd}};
+}
+inline hipemu_u2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src0, bool, bool) {
+    const int      l  = hipemu::lane_id();
+    const unsigned ps = (unsigned)hipemu::wave_xchg(src0, l ^ 32), pd = (unsigned)hipemu::wave_xchg(vdst, l ^ 32);
+    const bool     hi = l >= 32;
+    return hipemu_u2{{hi ? ps : vdst, hi ? src0 : pd}};
+}
 inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) { // v_dot4_u32_u8
     for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xff) * ((b >> (8 * i)) & 0xff);
     return c;
