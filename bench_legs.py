@@ -508,3 +508,42 @@ def tf_frames(torch, lib, pkg, stream, steps, warmup):
     t = _time(torch, lambda: lib.svt_hip_estimate_noise_batch(a.data_ptr(), 1920, 1080, 2056, 8, res.data_ptr(), ws.data_ptr(), stream), steps, warmup)
     out["noise_estimate_1080p8"] = {"us": t * 1e6, "GBps_algorithmic": 1920 * 1080 / t / 1e9}
     return out
+
+
+def hme_chain(torch, lib, pkg, stream, steps, warmup):
+    """The three HME levels of a 1080p picture against 4 references, chained on the device (svt_hip_hme_level_batch x 3: descriptor kernel ->
+    svt_hip_sad_loop_batch -> rescale kernel per level): level 0 on the 1/16-area planes (2 x 2 regions of 16x16), levels 1 and 2 with 8x3 areas
+    around the previous level's centres -- the preset-8 shape (enc_mode_config.c:141-216)."""
+    g = np.random.default_rng(12)
+    W, H, n_refs, nw, nh = 1920, 1080, 4, 2, 2
+    aw, ah = W, (H + 7) & ~7
+    sbs_x, sbs_y = (aw + 63) // 64, (ah + 63) // 64
+    n = n_refs * sbs_x * sbs_y * nw * nh
+    org = {0: 16, 1: 32, 2: 68}
+    sa = {0: (16, 16), 1: (8, 3), 2: (8, 3)}
+    stages = []
+    for lv in (0, 1, 2):
+        sh = 2 - lv
+        w, h, o = W >> sh, H >> sh, org[lv]
+        stride, rows = w + 2 * o, h + 2 * o + (64 >> sh)
+        planes = torch.from_numpy(g.integers(0, 256, (1 + n_refs, rows, stride), dtype=np.uint8)).cuda()
+        P = pkg.HmeLevelParams()
+        P.level, P.sub_sampled, P.num_hme_sa_w, P.num_hme_sa_h, P.sa_width, P.sa_height = lv, 0, nw, nh, sa[lv][0], sa[lv][1]
+        P.sbs_x, P.sbs_y, P.n_refs, P.prev_shift, P.aligned_width, P.aligned_height = sbs_x, sbs_y, n_refs, int(lv == 1), aw, ah
+        P.src_off, P.src_stride = o * stride + o, stride
+        P.ref_stride, P.ref_org_x, P.ref_org_y, P.ref_width, P.ref_height = stride, o, o, w, h
+        for r in range(n_refs):
+            P.ref_off[r] = (1 + r) * rows * stride
+        ws = torch.zeros(lib.svt_hip_hme_level_workspace(C.addressof(P)), dtype=torch.uint8, device="cuda")
+        stages.append((P, planes, ws, torch.zeros(n, dtype=torch.int64, device="cuda"), torch.zeros(2 * n, dtype=torch.int16, device="cuda")))
+    zero = torch.zeros(2 * n, dtype=torch.int16, device="cuda")
+
+    def fn():
+        prev = zero
+        for (P, planes, ws, sad, sc) in stages:
+            lib.svt_hip_hme_level_batch(C.addressof(P), planes.data_ptr(), planes.data_ptr(), prev.data_ptr(), sad.data_ptr(), sc.data_ptr(), ws.data_ptr(),
+                                        stream)
+            prev = sc
+    t = _time(torch, fn, steps, warmup)
+    return {"hme_3level_1080p_4refs": {"us_per_picture": t * 1e6, "pictures_per_s": 1 / t, "searches_per_level": n, "launches": 9,
+                                       "note": "level 0: 2x2 regions of 16x16 on 1/16-area planes; levels 1, 2: 8x3"}}

@@ -156,6 +156,30 @@ void svt_hip_sad_loop_batch(const uint8_t *src_base, const uint8_t *ref_base, co
                             uint32_t max_area_width, uint32_t max_area_height, uint32_t max_block_width, uint32_t max_block_height,
                             int max_ref_step, SvtHipSadLoopResult *results, uint64_t *keys, void *stream);
 
+/* One hierarchical-ME level for a whole picture = hme_level_0 / hme_level_1 / hme_level_2 (motion_estimation.c:820-921, 923-1018, 1020-1116) for
+ * every (reference, 64x64 SB, search region): search-area placement (level 0: the region's cell of the num_hme_sa_w x num_hme_sa_h grid around
+ * the co-located block; levels 1-2: centred on the previous level's result), clipping to the reference picture, svt_sad_loop_kernel, result
+ * scaled to the next level's resolution (x4, x2, x1).  Descriptors are built and results post-processed on the device; the search itself is
+ * svt_hip_sad_loop_batch.  Items are ordered ((ref * n_sb + sb) * num_hme_sa_h + sr_h) * num_hme_sa_w + sr_w.
+ * prev_sc: [items][2] int16 (x, y) = the previous level's centres (levels 1, 2; ignored at level 0).  sad_out [items]; sc_out [items][2] is in/out:
+ * an empty clipped area leaves the reference's centre variable untouched, so pre-fill with what init_me_hme_data leaves there (0). */
+typedef struct SvtHipHmeLevelParams {
+    uint8_t  level;                  /* 0: 1/16-area planes (x, y / 4), 1: quarter planes (/ 2), 2: full resolution */
+    uint8_t  sub_sampled;            /* me_ctx->hme_search_method != FULL_SAD_SEARCH: every other block row, SAD doubled */
+    uint8_t  num_hme_sa_w, num_hme_sa_h;
+    int16_t  sa_width, sa_height;    /* per-region area: get_hme_l0_search_area at level 0, hme_l1_sa / hme_l2_sa above */
+    uint32_t sbs_x, sbs_y, n_refs;   /* n_refs <= 8 */
+    uint32_t prev_shift;             /* prev_sc >> prev_shift before use: 1 when level 1 is fed with level-0 output (hme_level1_b64, :2105-2110), else 0 */
+    uint32_t aligned_width, aligned_height; /* full-resolution picture size rounded up to 8 (b64_width / b64_height, :3093-3100) */
+    uint64_t src_off;                /* picture sample (0, 0) of the source plane at this level's resolution, from src_base */
+    uint32_t src_stride;
+    uint32_t ref_stride, ref_org_x, ref_org_y, ref_width, ref_height; /* EbPictureBufferDesc of the references at this resolution */
+    uint64_t ref_off[8];             /* buffer_y[0] of each reference, from ref_base */
+} SvtHipHmeLevelParams;
+size_t svt_hip_hme_level_workspace(const SvtHipHmeLevelParams *params);
+void   svt_hip_hme_level_batch(const SvtHipHmeLevelParams *params, const uint8_t *src_base, const uint8_t *ref_base, const int16_t *prev_sc,
+                               uint64_t *sad_out, int16_t *sc_out, void *workspace, void *stream);
+
 /* Frame-batched integer full-pel search = open_loop_me_fullpel_search_sblock (motion_estimation.c:781-816), i.e.
  * a3+a4+a5+a6 fused: for every (64x64 SB, reference) item, all 85 block SADs (8x8..64x64) at every position of the
  * search area, keeping the first minimum in raster order (strict `<`), bests initialised to MAX_SAD_VALUE

@@ -241,3 +241,52 @@ void oracle_pme_sad_loop(const uint8_t *src, uint32_t src_stride, const uint8_t 
         ref += search_step * ref_stride;
     }
 }
+
+/* ---- one HME level for one (64x64 SB, reference, search region): hme_level_0 / hme_level_1 / hme_level_2 (Codec/motion_estimation.c:820-921,
+ * :923-1018, :1020-1116).  Search-area placement (level 0: the region's cell of the num_hme_sa_w x num_hme_sa_h grid centred on the co-located
+ * block; levels 1-2: centred on the previous level's result), clipping to the reference picture, svt_sad_loop_kernel over the clipped area (on
+ * every other row, SAD doubled, unless FULL_SAD_SEARCH), result scaled to the next level's resolution.  All arithmetic in int16_t like the
+ * reference.  ref_plane = buffer_y[0] of the (padded) reference at this level's resolution; src = the block's first sample. */
+void oracle_hme_level(int level, int sub_sampled, int num_hme_sa_w, int num_hme_sa_h, int sr_w, int sr_h, const uint8_t *src, uint32_t src_stride,
+                      const uint8_t *ref_plane, uint32_t ref_stride, int ref_org_x, int ref_org_y, int ref_width, int ref_height, int16_t org_x,
+                      int16_t org_y, uint32_t block_width, uint32_t block_height, int16_t sa_width, int16_t sa_height, int16_t prev_sc_x,
+                      int16_t prev_sc_y, uint64_t *best_sad, int16_t *sc_x, int16_t *sc_y) {
+    sa_width = (int16_t)((sa_width + 7) & ~0x07);
+    const int16_t pad_width = (int16_t)(level == 2 ? 63 : ref_org_x - 1), pad_height = (int16_t)(level == 2 ? 63 : ref_org_y - 1);
+    int16_t sa_origin_x, sa_origin_y;
+    if (level == 0) {
+        sa_origin_x = (int16_t)(-(int16_t)((sa_width * num_hme_sa_w) >> 1) + (int16_t)(sa_width * sr_w));
+        sa_origin_y = (int16_t)(-(int16_t)((sa_height * num_hme_sa_h) >> 1) + (int16_t)(sa_height * sr_h));
+    } else {
+        sa_origin_x = (int16_t)(-(sa_width >> 1) + prev_sc_x);
+        sa_origin_y = (int16_t)(-(sa_height >> 1) + prev_sc_y);
+    }
+    if ((org_x + sa_origin_x) < -pad_width) {
+        sa_origin_x = (int16_t)(-pad_width - org_x);
+        sa_width    = (int16_t)(sa_width - (-pad_width - (org_x + sa_origin_x)));
+    }
+    if ((org_x + sa_origin_x) > (int16_t)ref_width - 1) sa_origin_x = (int16_t)(sa_origin_x - ((org_x + sa_origin_x) - ((int16_t)ref_width - 1)));
+    if ((org_x + sa_origin_x + sa_width) > (int16_t)ref_width) {
+        const int w = sa_width - ((org_x + sa_origin_x + sa_width) - (int16_t)ref_width);
+        sa_width    = (int16_t)(w > 1 ? w : 1);
+    }
+    sa_width = (int16_t)(sa_width < 8 ? sa_width : sa_width & ~0x07);
+    if ((org_y + sa_origin_y) < -pad_height) {
+        sa_origin_y = (int16_t)(-pad_height - org_y);
+        sa_height   = (int16_t)(sa_height - (-pad_height - (org_y + sa_origin_y)));
+    }
+    if ((org_y + sa_origin_y) > (int16_t)ref_height - 1) sa_origin_y = (int16_t)(sa_origin_y - ((org_y + sa_origin_y) - ((int16_t)ref_height - 1)));
+    if ((org_y + sa_origin_y + sa_height) > (int16_t)ref_height) {
+        const int h = sa_height - ((org_y + sa_origin_y + sa_height) - (int16_t)ref_height);
+        sa_height   = (int16_t)(h > 1 ? h : 1);
+    }
+    const int16_t x_tl = (int16_t)(((int16_t)ref_org_x + org_x) + sa_origin_x), y_tl = (int16_t)(((int16_t)ref_org_y + org_y) + sa_origin_y);
+    const uint32_t index = (uint32_t)(x_tl + y_tl * (int)ref_stride);
+    const int full = !sub_sampled;
+    oracle_sad_loop(src, full ? src_stride : src_stride * 2, ref_plane + index, full ? ref_stride : ref_stride * 2, full ? block_height : block_height >> 1,
+                    block_width, best_sad, sc_x, sc_y, ref_stride, 0, sa_width, sa_height);
+    if (!full) *best_sad *= 2;
+    const int scale = level == 0 ? 4 : (level == 1 ? 2 : 1);
+    *sc_x = (int16_t)((int16_t)(*sc_x + sa_origin_x) * scale);
+    *sc_y = (int16_t)((int16_t)(*sc_y + sa_origin_y) * scale);
+}

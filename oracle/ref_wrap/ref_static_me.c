@@ -98,3 +98,25 @@ void ref_me_results_sb(const RefMeResultsParams *P, const uint32_t *best_sad /*[
     st->stationary_block_present_sb = u8s[0]; st->rc_me_allow_gm = u8s[1];
     st->pad[0] = st->pad[1] = 0;
 }
+
+/* One HME level through the reference's own leaf drivers hme_level_0 / hme_level_1 (static) / hme_level_2, which call svt_sad_loop_kernel through the
+ * RTCD pointer (set it up with svt_aom_setup_rtcd_internal first).  Same plain arguments as oracle_hme_level. */
+void ref_hme_level(int level, int sub_sampled, int num_hme_sa_w, int num_hme_sa_h, int sr_w, int sr_h, uint8_t *src, uint32_t src_stride,
+                   uint8_t *ref_plane, uint32_t ref_stride, int ref_org_x, int ref_org_y, int ref_width, int ref_height, int16_t org_x, int16_t org_y,
+                   uint32_t block_width, uint32_t block_height, int16_t sa_width, int16_t sa_height, int16_t prev_sc_x, int16_t prev_sc_y,
+                   uint64_t *best_sad, int16_t *sc_x, int16_t *sc_y) {
+    static MeContext   *ctx;
+    EbPictureBufferDesc pic;
+    if (!ctx) ctx = calloc(1, sizeof(*ctx));
+    memset(&pic, 0, sizeof(pic));
+    pic.buffer_y = ref_plane; pic.stride_y = (uint16_t)ref_stride; pic.org_x = (uint16_t)ref_org_x; pic.org_y = (uint16_t)ref_org_y;
+    pic.width = (uint16_t)ref_width; pic.height = (uint16_t)ref_height;
+    ctx->num_hme_sa_w = (uint16_t)num_hme_sa_w; ctx->num_hme_sa_h = (uint16_t)num_hme_sa_h;
+    ctx->hme_search_method = sub_sampled ? SUB_SAD_SEARCH : FULL_SAD_SEARCH;
+    ctx->sixteenth_b64_buffer = src; ctx->sixteenth_b64_buffer_stride = src_stride;
+    ctx->quarter_b64_buffer = src; ctx->quarter_b64_buffer_stride = src_stride;
+    ctx->b64_src_ptr = src; ctx->b64_src_stride = src_stride;
+    if (level == 0) hme_level_0(ctx, org_x, org_y, block_width, block_height, sa_width, sa_height, &pic, (uint32_t)sr_w, (uint32_t)sr_h, best_sad, sc_x, sc_y);
+    else if (level == 1) hme_level_1(ctx, org_x, org_y, block_width, block_height, &pic, sa_width, sa_height, prev_sc_x, prev_sc_y, best_sad, sc_x, sc_y);
+    else hme_level_2(ctx, org_x, org_y, block_width, block_height, &pic, sa_width, sa_height, prev_sc_x, prev_sc_y, best_sad, sc_x, sc_y);
+}

@@ -78,6 +78,8 @@ PROTOTYPES = {
     "svt_hip_me_session_wait": (None, [vp, C.c_int]),
     "svt_hip_me_session_submit_results": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
     "svt_hip_me_results_batch": (None, [vp] * 10),
+    "svt_hip_hme_level_workspace": (C.c_size_t, [vp]),
+    "svt_hip_hme_level_batch": (None, [vp] * 8),
     "svt_av1_apply_temporal_filter_planewise_medium_hip": (None, [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "svt_av1_apply_temporal_filter_planewise_medium_hbd_hip": (None, [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp] + [C.c_uint32]),
     "svt_av1_apply_zz_based_temporal_filter_planewise_medium_hip": (None, [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
@@ -181,6 +183,14 @@ class MeResultsParams(C.Structure):
 
 
 assert C.sizeof(MeResultsParams) == 96
+
+
+class HmeLevelParams(C.Structure):
+    """SvtHipHmeLevelParams (include/svtav1_hip.h)."""
+    _fields_ = [("level", C.c_uint8), ("sub_sampled", C.c_uint8), ("num_hme_sa_w", C.c_uint8), ("num_hme_sa_h", C.c_uint8), ("sa_width", C.c_int16),
+                ("sa_height", C.c_int16), ("sbs_x", C.c_uint32), ("sbs_y", C.c_uint32), ("n_refs", C.c_uint32), ("prev_shift", C.c_uint32), ("aligned_width", C.c_uint32),
+                ("aligned_height", C.c_uint32), ("src_off", C.c_uint64), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32), ("ref_org_x", C.c_uint32),
+                ("ref_org_y", C.c_uint32), ("ref_width", C.c_uint32), ("ref_height", C.c_uint32), ("ref_off", C.c_uint64 * 8)]
 
 
 class TfParams(C.Structure):

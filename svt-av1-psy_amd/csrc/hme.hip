@@ -1,0 +1,130 @@
+// hme.hip -- one hierarchical-ME level for a whole picture (the callers of a2): hme_level_0 / hme_level_1 / hme_level_2
+// (Codec/motion_estimation.c:820-921, 923-1018, 1020-1116) for every (reference, 64x64 SB, search region).  The reference runs these leaf
+// drivers per SB on a worker thread; here a descriptor kernel reproduces their search-area placement and clipping (int16_t arithmetic, as the
+// reference), the search is svt_hip_sad_loop_batch over all items at once, and a second kernel applies the sub-sampling factor and rescales the
+// winning position to the next level's resolution.  Nothing goes through the host between the levels.
+#include "svt_hip_common.h"
+#include "../../include/svtav1_hip.h"
+
+namespace {
+
+struct HmeItem { // geometry of one item, shared by the two kernels
+    int16_t sa_origin_x, sa_origin_y;
+};
+
+__global__ __launch_bounds__(256) void hme_descs_kernel(const SvtHipHmeLevelParams P, const int16_t* __restrict__ prev_sc, SvtHipSadLoopDesc* __restrict__ descs,
+                                                        HmeItem* __restrict__ items, const uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t regions = (uint32_t)P.num_hme_sa_w * P.num_hme_sa_h, n_sb = P.sbs_x * P.sbs_y;
+    const uint32_t sr = i % regions, rs = i / regions, sb = rs % n_sb, r = rs / n_sb;
+    const int      sr_w = (int)(sr % P.num_hme_sa_w), sr_h = (int)(sr / P.num_hme_sa_w);
+    const int      shift = P.level == 0 ? 2 : (P.level == 1 ? 1 : 0);
+    const uint32_t fx = (sb % P.sbs_x) * 64, fy = (sb / P.sbs_x) * 64; // full-resolution SB origin
+    const uint32_t b64_w = P.aligned_width - fx < 64 ? P.aligned_width - fx : 64, b64_h = P.aligned_height - fy < 64 ? P.aligned_height - fy : 64;
+    const int16_t  org_x = (int16_t)((int16_t)fx >> shift), org_y = (int16_t)((int16_t)fy >> shift);
+    const uint32_t block_width = b64_w >> shift, block_height = b64_h >> shift;
+
+    int16_t       sa_width = (int16_t)((P.sa_width + 7) & ~0x07), sa_height = P.sa_height;
+    const int16_t pad_width = (int16_t)(P.level == 2 ? 63 : (int)P.ref_org_x - 1), pad_height = (int16_t)(P.level == 2 ? 63 : (int)P.ref_org_y - 1);
+    const int16_t ref_w = (int16_t)P.ref_width, ref_h = (int16_t)P.ref_height;
+    int16_t       sa_origin_x, sa_origin_y;
+    if (P.level == 0) {
+        sa_origin_x = (int16_t)(-(int16_t)((sa_width * P.num_hme_sa_w) >> 1) + (int16_t)(sa_width * sr_w));
+        sa_origin_y = (int16_t)(-(int16_t)((sa_height * P.num_hme_sa_h) >> 1) + (int16_t)(sa_height * sr_h));
+    } else {
+        sa_origin_x = (int16_t)(-(sa_width >> 1) + (int16_t)(prev_sc[2 * i] >> P.prev_shift));
+        sa_origin_y = (int16_t)(-(sa_height >> 1) + (int16_t)(prev_sc[2 * i + 1] >> P.prev_shift));
+    }
+    // clip to the reference picture, left / right / top / bottom in the reference's order
+    if ((org_x + sa_origin_x) < -pad_width) {
+        sa_origin_x = (int16_t)(-pad_width - org_x);
+        sa_width    = (int16_t)(sa_width - (-pad_width - (org_x + sa_origin_x)));
+    }
+    if ((org_x + sa_origin_x) > ref_w - 1) sa_origin_x = (int16_t)(sa_origin_x - ((org_x + sa_origin_x) - (ref_w - 1)));
+    if ((org_x + sa_origin_x + sa_width) > ref_w) {
+        const int w = sa_width - ((org_x + sa_origin_x + sa_width) - ref_w);
+        sa_width    = (int16_t)(w > 1 ? w : 1);
+    }
+    sa_width = (int16_t)(sa_width < 8 ? sa_width : sa_width & ~0x07);
+    if ((org_y + sa_origin_y) < -pad_height) {
+        sa_origin_y = (int16_t)(-pad_height - org_y);
+        sa_height   = (int16_t)(sa_height - (-pad_height - (org_y + sa_origin_y)));
+    }
+    if ((org_y + sa_origin_y) > ref_h - 1) sa_origin_y = (int16_t)(sa_origin_y - ((org_y + sa_origin_y) - (ref_h - 1)));
+    if ((org_y + sa_origin_y + sa_height) > ref_h) {
+        const int h = sa_height - ((org_y + sa_origin_y + sa_height) - ref_h);
+        sa_height   = (int16_t)(h > 1 ? h : 1);
+    }
+    const int16_t  x_tl = (int16_t)(((int16_t)P.ref_org_x + org_x) + sa_origin_x), y_tl = (int16_t)(((int16_t)P.ref_org_y + org_y) + sa_origin_y);
+    const uint32_t index = (uint32_t)(x_tl + y_tl * (int)P.ref_stride);
+    const uint32_t step = P.sub_sampled ? 2 : 1;
+    SvtHipSadLoopDesc d;
+    d.src_off            = P.src_off + (uint64_t)org_y * P.src_stride + (uint64_t)org_x;
+    d.ref_off            = P.ref_off[r] + index;
+    d.src_stride         = P.src_stride * step;
+    d.ref_stride         = P.ref_stride * step;
+    d.src_stride_raw     = P.ref_stride;
+    d.block_width        = (uint16_t)block_width;
+    d.block_height       = (uint16_t)(block_height / step);
+    d.search_area_width  = sa_width;
+    d.search_area_height = sa_height;
+    d.skip_search_line   = 0;
+    d.pad[0] = d.pad[1] = d.pad[2] = 0;
+    descs[i] = d;
+    items[i] = HmeItem{sa_origin_x, sa_origin_y};
+}
+
+__global__ __launch_bounds__(256) void hme_post_kernel(const SvtHipSadLoopResult* __restrict__ res, const HmeItem* __restrict__ items, const int sub_sampled,
+                                                       const int scale, unsigned long long* __restrict__ sad_out, int16_t* __restrict__ sc_out, const uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SvtHipSadLoopResult r = res[i];
+    const int16_t x = r.valid ? r.x_search_center : sc_out[2 * i], y = r.valid ? r.y_search_center : sc_out[2 * i + 1];
+    sad_out[i]        = sub_sampled ? r.best_sad * 2 : r.best_sad;
+    sc_out[2 * i]     = (int16_t)((int16_t)(x + items[i].sa_origin_x) * scale);
+    sc_out[2 * i + 1] = (int16_t)((int16_t)(y + items[i].sa_origin_y) * scale);
+}
+
+inline uint32_t hme_items(const SvtHipHmeLevelParams* P) { return P->n_refs * P->sbs_x * P->sbs_y * P->num_hme_sa_w * P->num_hme_sa_h; }
+struct HmeWs { size_t descs, res, keys, items, bytes; };
+inline HmeWs hme_ws(uint32_t n) {
+    HmeWs w;
+    w.descs = 0;
+    w.res   = svthip::align_up(w.descs + (size_t)n * sizeof(SvtHipSadLoopDesc), 256);
+    w.keys  = svthip::align_up(w.res + (size_t)n * sizeof(SvtHipSadLoopResult), 256);
+    w.items = svthip::align_up(w.keys + (size_t)n * 8, 256);
+    w.bytes = svthip::align_up(w.items + (size_t)n * sizeof(HmeItem), 256);
+    return w;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t svt_hip_hme_level_workspace(const SvtHipHmeLevelParams* params) { return hme_ws(hme_items(params)).bytes; }
+
+void svt_hip_hme_level_batch(const SvtHipHmeLevelParams* params, const uint8_t* src_base, const uint8_t* ref_base, const int16_t* prev_sc, uint64_t* sad_out,
+                             int16_t* sc_out, void* workspace, void* stream) {
+    svthip::ensure_device();
+    const uint32_t n = hme_items(params);
+    if (n == 0) return;
+    if (params->n_refs > 8 || params->level > 2) { fprintf(stderr, "libsvtav1_hip: svt_hip_hme_level_batch: bad parameters\n"); abort(); }
+    const HmeWs        w = hme_ws(n);
+    uint8_t*           ws = (uint8_t*)workspace;
+    SvtHipSadLoopDesc* descs = (SvtHipSadLoopDesc*)(ws + w.descs);
+    SvtHipSadLoopResult* res = (SvtHipSadLoopResult*)(ws + w.res);
+    HmeItem*           items = (HmeItem*)(ws + w.items);
+    hipStream_t        st = (hipStream_t)stream;
+    hipLaunchKernelGGL(hme_descs_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *params, prev_sc, descs, items, n);
+    SVT_LAUNCH_CHECK();
+    const int      shift = params->level == 0 ? 2 : (params->level == 1 ? 1 : 0);
+    const uint32_t blk = 64u >> shift, step = params->sub_sampled ? 2 : 1;
+    svt_hip_sad_loop_batch(src_base, ref_base, descs, n, (uint32_t)((params->sa_width + 7) & ~7), (uint32_t)params->sa_height, blk, blk / step, (int)step, res,
+                           (uint64_t*)(ws + w.keys), stream);
+    hipLaunchKernelGGL(hme_post_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const SvtHipSadLoopResult*)res, (const HmeItem*)items,
+                       (int)params->sub_sampled, params->level == 0 ? 4 : (params->level == 1 ? 2 : 1), (unsigned long long*)sad_out, sc_out, n);
+    SVT_LAUNCH_CHECK();
+}
+
+} // extern "C"

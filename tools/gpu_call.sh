@@ -1,4 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_primitives.py tests/test_sad.py -m gpu -x -q 2>&1 | tail -3
-python bench.py --steps 20 --warmup 3 --no-cpu 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['valu_frac'])"
-python bench.py --steps 20 --warmup 3 --no-cpu 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['valu_frac'])"
+timeout 600 python -m pytest tests/test_hme.py -m gpu -x -q 2>&1 | tail -3
+python tools/microbench.py hmechain --steps 20 --warmup 3 2>/dev/null
