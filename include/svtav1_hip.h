@@ -180,6 +180,37 @@ size_t svt_hip_hme_level_workspace(const SvtHipHmeLevelParams *params);
 void   svt_hip_hme_level_batch(const SvtHipHmeLevelParams *params, const uint8_t *src_base, const uint8_t *ref_base, const int16_t *prev_sc,
                                uint64_t *sad_out, int16_t *sc_out, void *workspace, void *stream);
 
+/* Integer ME of a whole picture from its HME results = set_final_seach_centre_sb (motion_estimation.c:2182-2368: per (reference, SB) the first
+ * strictly smallest SAD over the search regions) + integer_search_b64's search-area geometry (:1294-1325, :1458-1508: min(sa_min * dist, sa_max),
+ * enlargement for long search-centre components, division by reduce_me_sr_divisor, width rounded up to 8, centred on the HME result, clipped to the
+ * picture + 63-sample border) + svt_hip_me_fullpel_search_batch.  Covers the option set without content-dependent probes (me_early_exit_th = 0,
+ * is_ref = 0, me_sr_adjustment < 2, me_8x8_var off), which need a pre-search per SB and stay with the caller.
+ * hme_sad / hme_sc: the last HME level's outputs in svt_hip_hme_level_batch's item order ((ref * n_sb + sb) * regions + region).
+ * do_ref ([n_sb][n_refs], or NULL = all) : a 0 entry gets a 1 x 1 placeholder search whose results must be ignored (the reference skips the
+ * reference picture, :1292-1293).  divisor ([n_sb][n_refs] uint32, or NULL = 1) = me_ctx->reduce_me_sr_divisor.
+ * Outputs: best_sad / best_mv [ref][sb][85] (as svt_hip_me_fullpel_search_batch), sc_out [ref][sb][2] + sad_out [ref][sb] = search_results[].hme_sc_x/y,
+ * hme_sad. */
+typedef struct SvtHipMeIntegerSearchParams {
+    uint32_t sbs_x, sbs_y, n_refs;            /* reference slots (list 0 first), <= 8 */
+    uint32_t regions;                         /* num_hme_sa_w * num_hme_sa_h entries per (ref, SB) in hme_sad / hme_sc */
+    uint32_t aligned_width, aligned_height;   /* pcs->aligned_width / aligned_height */
+    int16_t  sa_min_width, sa_min_height, sa_max_width, sa_max_height; /* me_ctx->me_sa */
+    uint8_t  sub_sad;                         /* me_search_method == SUB_SAD_SEARCH */
+    uint8_t  mv_adj_enabled, mv_adj_nearest_ref_only; /* me_ctx->mv_based_sa_adj */
+    uint8_t  pad0;
+    uint16_t mv_adj_mv_size_th, mv_adj_sa_multiplier;
+    uint16_t dist[8];                         /* per slot: picture distance, through svt_aom_get_scaled_picture_distance unless ME_MCTF (:1300-1302) */
+    uint8_t  ref_pic_index[8];                /* per slot: index inside its list (nearest_ref_only) */
+    uint64_t src_off;                         /* picture sample (0, 0) of the source plane, from src_base */
+    uint32_t src_stride;
+    uint32_t ref_stride, ref_org_x, ref_org_y;
+    uint64_t ref_off[8];                      /* buffer_y[0] of each reference, from ref_base */
+} SvtHipMeIntegerSearchParams;
+size_t svt_hip_me_integer_search_workspace(const SvtHipMeIntegerSearchParams *params);
+void   svt_hip_me_integer_search_batch(const SvtHipMeIntegerSearchParams *params, const uint8_t *src_base, const uint8_t *ref_base,
+                                       const uint64_t *hme_sad, const int16_t *hme_sc, const uint8_t *do_ref, const uint32_t *divisor,
+                                       uint32_t *best_sad, uint32_t *best_mv, int16_t *sc_out, uint64_t *sad_out, void *workspace, void *stream);
+
 /* Frame-batched integer full-pel search = open_loop_me_fullpel_search_sblock (motion_estimation.c:781-816), i.e.
  * a3+a4+a5+a6 fused: for every (64x64 SB, reference) item, all 85 block SADs (8x8..64x64) at every position of the
  * search area, keeping the first minimum in raster order (strict `<`), bests initialised to MAX_SAD_VALUE

@@ -7,6 +7,7 @@
  *   (a) oracle/_ref/libsvtref.so = the reference's own `*_c` functions compiled from the mounted sources, and
  *   (b) golden vectors under tests/golden/ produced by (a) with tools/gen_golden.py.
  */
+#include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
@@ -289,4 +290,67 @@ void oracle_hme_level(int level, int sub_sampled, int num_hme_sa_w, int num_hme_
     const int scale = level == 0 ? 4 : (level == 1 ? 2 : 1);
     *sc_x = (int16_t)((int16_t)(*sc_x + sa_origin_x) * scale);
     *sc_y = (int16_t)((int16_t)(*sc_y + sa_origin_y) * scale);
+}
+
+/* ---- integer ME of one (SB, reference) from its HME results = set_final_seach_centre_sb (motion_estimation.c:2182-2368: the first strictly
+ * smallest SAD over the search regions, regions walked sr_h outer / sr_w inner) followed by integer_search_b64's geometry (:1294-1325, :1458-1508:
+ * area = min(sa_min * dist, sa_max), optional enlargement for long search-centre components, division by the per-reference divisor, width
+ * rounded up to 8, area centred on the HME result and clipped to the picture + 63-sample border) and open_loop_me_fullpel_search_sblock.
+ * Restated for the option set without content-dependent probes: me_early_exit_th = 0, is_ref = 0, me_sr_adjustment < 2, me_8x8_var off.
+ * plane pointers = buffer_y[0]; outputs p_sb_best_sad / p_sb_best_mv[85] plus the selected centre. */
+typedef struct OracleIntSearch {
+    int16_t  sa_min_w, sa_min_h, sa_max_w, sa_max_h;
+    uint16_t dist;       /* already through svt_aom_get_scaled_picture_distance unless ME_MCTF */
+    uint8_t  mv_adj_enabled, mv_adj_nearest_ref_only, ref_pic_index, sub_sad;
+    uint16_t mv_size_th, sa_multiplier;
+    uint32_t divisor;    /* reduce_me_sr_divisor[list][ref] */
+} OracleIntSearch;
+void oracle_me_integer_search(const OracleIntSearch *P, int n_regions, const uint64_t *hme_sad, const int16_t *hme_sc /*[n_regions][2]*/,
+                              const uint8_t *src_plane, uint32_t src_stride, int src_org_x, int src_org_y, const uint8_t *ref_plane,
+                              uint32_t ref_stride, int ref_org_x, int ref_org_y, int b64_origin_x, int b64_origin_y, int picture_width,
+                              int picture_height, int16_t *sc_out /*[2]*/, uint64_t *sad_out, int16_t *area_out /*[4]: origin x, y, width, height*/,
+                              uint32_t *best_sad, uint32_t *best_mv) {
+    int16_t  x_search_center = hme_sc[0], y_search_center = hme_sc[1];
+    uint64_t best = hme_sad[0];
+    for (int i = 1; i < n_regions; i++)
+        if (hme_sad[i] < best) { best = hme_sad[i]; x_search_center = hme_sc[2 * i]; y_search_center = hme_sc[2 * i + 1]; }
+    sc_out[0] = x_search_center; sc_out[1] = y_search_center; *sad_out = best;
+
+    const int16_t pad_width = 63, pad_height = 63, org_x = (int16_t)b64_origin_x, org_y = (int16_t)b64_origin_y;
+    int16_t search_area_width = P->sa_min_w, search_area_height = P->sa_min_h;
+    { const int w = search_area_width * P->dist, h = search_area_height * P->dist;
+      search_area_width = (int16_t)(w < (uint16_t)P->sa_max_w ? w : (uint16_t)P->sa_max_w);
+      search_area_height = (int16_t)(h < (uint16_t)P->sa_max_h ? h : (uint16_t)P->sa_max_h); }
+    if (P->mv_adj_enabled && (!P->mv_adj_nearest_ref_only || P->ref_pic_index == 0)) {
+        if ((x_search_center < 0 ? -x_search_center : x_search_center) > P->mv_size_th) search_area_width = (int16_t)(search_area_width * P->sa_multiplier);
+        if ((y_search_center < 0 ? -y_search_center : y_search_center) > P->mv_size_th) search_area_height = (int16_t)(search_area_height * P->sa_multiplier);
+    }
+    { const uint32_t w = (uint32_t)search_area_width / P->divisor, h = (uint32_t)search_area_height / P->divisor; /* unsigned division, as the reference */
+      search_area_width = (int16_t)(((w > 1 ? w : 1) + 7) & ~0x07u);
+      search_area_height = (int16_t)(h > 3 ? h : 3); }
+    int16_t x_search_area_origin = (int16_t)(x_search_center - (search_area_width >> 1));
+    int16_t y_search_area_origin = (int16_t)(y_search_center - (search_area_height >> 1));
+    /* the reference updates origin and size in two separate conditional expressions, the second evaluated with the corrected origin (:1462-1467) */
+    x_search_area_origin = (int16_t)(((org_x + x_search_area_origin) < -pad_width) ? -pad_width - org_x : x_search_area_origin);
+    search_area_width = (int16_t)(((org_x + x_search_area_origin) < -pad_width) ? search_area_width - (-pad_width - (org_x + x_search_area_origin)) : search_area_width);
+    x_search_area_origin = (int16_t)(((org_x + x_search_area_origin) > picture_width - 1) ? x_search_area_origin - ((org_x + x_search_area_origin) - (picture_width - 1))
+                                                                                            : x_search_area_origin);
+    if ((org_x + x_search_area_origin + search_area_width) > picture_width) {
+        const int w = search_area_width - ((org_x + x_search_area_origin + search_area_width) - picture_width);
+        search_area_width = (int16_t)(w > 1 ? w : 1);
+    }
+    search_area_width = (int16_t)(search_area_width < 8 ? search_area_width : search_area_width & ~0x07);
+    y_search_area_origin = (int16_t)(((org_y + y_search_area_origin) < -pad_height) ? -pad_height - org_y : y_search_area_origin);
+    search_area_height = (int16_t)(((org_y + y_search_area_origin) < -pad_height) ? search_area_height - (-pad_height - (org_y + y_search_area_origin)) : search_area_height);
+    y_search_area_origin = (int16_t)(((org_y + y_search_area_origin) > picture_height - 1) ? y_search_area_origin - ((org_y + y_search_area_origin) - (picture_height - 1))
+                                                                                             : y_search_area_origin);
+    if ((org_y + y_search_area_origin + search_area_height) > picture_height) {
+        const int h = search_area_height - ((org_y + y_search_area_origin + search_area_height) - picture_height);
+        search_area_height = (int16_t)(h > 1 ? h : 1);
+    }
+    area_out[0] = x_search_area_origin; area_out[1] = y_search_area_origin; area_out[2] = search_area_width; area_out[3] = search_area_height;
+    const uint8_t *src = src_plane + (size_t)(src_org_y + b64_origin_y) * src_stride + src_org_x + b64_origin_x;
+    const uint8_t *ref = ref_plane + (ptrdiff_t)(ref_org_y + b64_origin_y + y_search_area_origin) * ref_stride + ref_org_x + b64_origin_x + x_search_area_origin;
+    oracle_me_fullpel_search(src, src_stride, ref, ref_stride, x_search_area_origin, y_search_area_origin, search_area_width, search_area_height, P->sub_sad,
+                             best_sad, best_mv);
 }

@@ -120,3 +120,64 @@ void ref_hme_level(int level, int sub_sampled, int num_hme_sa_w, int num_hme_sa_
     else if (level == 1) hme_level_1(ctx, org_x, org_y, block_width, block_height, &pic, sa_width, sa_height, prev_sc_x, prev_sc_y, best_sad, sc_x, sc_y);
     else hme_level_2(ctx, org_x, org_y, block_width, block_height, &pic, sa_width, sa_height, prev_sc_x, prev_sc_y, best_sad, sc_x, sc_y);
 }
+
+/* set_final_seach_centre_sb + integer_search_b64 (static) for ONE reference slot of one SB, with the option set the restatement covers
+ * (no early exit, is_ref = 0, no search-range adjustment pass, no 8x8-variance probe).  HME results enter as the level-2 arrays. */
+typedef struct RefIntSearch { /* = OracleIntSearch */
+    int16_t  sa_min_w, sa_min_h, sa_max_w, sa_max_h;
+    uint16_t dist;
+    uint8_t  mv_adj_enabled, mv_adj_nearest_ref_only, ref_pic_index, sub_sad;
+    uint16_t mv_size_th, sa_multiplier;
+    uint32_t divisor;
+} RefIntSearch;
+void ref_me_integer_search(const RefIntSearch *P, int num_sa_w, int num_sa_h, const uint64_t *hme_sad, const int16_t *hme_sc, uint8_t *src_plane,
+                           uint32_t src_stride, int src_org_x, int src_org_y, uint8_t *ref_plane, uint32_t ref_stride, int ref_org_x, int ref_org_y,
+                           int pic_w, int pic_h, int b64_origin_x, int b64_origin_y, int picture_width, int picture_height, int16_t *sc_out,
+                           uint64_t *sad_out, uint32_t *best_sad, uint32_t *best_mv) {
+    static MeContext               *ctx;
+    static PictureParentControlSet *pcs;
+    static EbPictureBufferDesc      refp, inp;
+    if (!ctx) { ctx = calloc(1, sizeof(*ctx)); pcs = calloc(1, sizeof(*pcs)); }
+    const int l = 0, r = P->ref_pic_index;
+    memset(ctx->search_results, 0, sizeof(ctx->search_results));
+    ctx->num_of_list_to_search = 1;
+    ctx->num_of_ref_pic_to_search[0] = (uint8_t)(r + 1); ctx->num_of_ref_pic_to_search[1] = 0;
+    ctx->temporal_layer_index = 1;
+    ctx->enable_hme_flag = 1; ctx->enable_hme_level0_flag = 1; ctx->enable_hme_level1_flag = 1; ctx->enable_hme_level2_flag = 1;
+    ctx->num_hme_sa_w = (uint16_t)num_sa_w; ctx->num_hme_sa_h = (uint16_t)num_sa_h;
+    for (int rr = 0; rr <= r; rr++) { /* earlier slots: not searched (do_ref = 0) */
+        ctx->search_results[l][rr].do_ref = rr == r;
+        ctx->reduce_me_sr_divisor[l][rr]  = P->divisor;
+        for (int h = 0; h < num_sa_h; h++)
+            for (int w = 0; w < num_sa_w; w++) {
+                ctx->hme_level2_sad[l][rr][w][h]             = hme_sad[h * num_sa_w + w];
+                ctx->x_hme_level2_search_center[l][rr][w][h] = hme_sc[2 * (h * num_sa_w + w)];
+                ctx->y_hme_level2_search_center[l][rr][w][h] = hme_sc[2 * (h * num_sa_w + w) + 1];
+            }
+        ctx->me_ds_ref_array[l][rr].picture_ptr    = &refp;
+        ctx->me_ds_ref_array[l][rr].picture_number = 100;
+    }
+    set_final_seach_centre_sb(pcs, ctx);
+    sc_out[0] = ctx->search_results[l][r].hme_sc_x; sc_out[1] = ctx->search_results[l][r].hme_sc_y; *sad_out = ctx->search_results[l][r].hme_sad;
+
+    memset(&refp, 0, sizeof(refp)); memset(&inp, 0, sizeof(inp));
+    refp.buffer_y = ref_plane; refp.stride_y = (uint16_t)ref_stride; refp.org_x = (uint16_t)ref_org_x; refp.org_y = (uint16_t)ref_org_y;
+    refp.width = (uint16_t)pic_w; refp.height = (uint16_t)pic_h;
+    inp.width = (uint16_t)pic_w; inp.height = (uint16_t)pic_h;
+    pcs->aligned_width = (uint16_t)picture_width; pcs->aligned_height = (uint16_t)picture_height;
+    pcs->picture_number = 100 + P->dist; /* ME_MCTF: the distance is used as it is (:1300-1302), so the test passes the final value */
+    ctx->me_type = ME_MCTF;
+    ctx->me_sa.sa_min.width = (uint16_t)P->sa_min_w; ctx->me_sa.sa_min.height = (uint16_t)P->sa_min_h;
+    ctx->me_sa.sa_max.width = (uint16_t)P->sa_max_w; ctx->me_sa.sa_max.height = (uint16_t)P->sa_max_h;
+    ctx->mv_based_sa_adj.enabled = P->mv_adj_enabled; ctx->mv_based_sa_adj.nearest_ref_only = P->mv_adj_nearest_ref_only;
+    ctx->mv_based_sa_adj.mv_size_th = P->mv_size_th; ctx->mv_based_sa_adj.sa_multiplier = P->sa_multiplier;
+    ctx->me_early_exit_th = 0; ctx->is_ref = false; ctx->me_sr_adjustment_ctrls.enable_me_sr_adjustment = 0; ctx->me_8x8_var_ctrls.enabled = 0;
+    ctx->me_search_method = P->sub_sad ? SUB_SAD_SEARCH : FULL_SAD_SEARCH;
+    ctx->b64_width  = (uint32_t)((picture_width - b64_origin_x) < 64 ? picture_width - b64_origin_x : 64);
+    ctx->b64_height = (uint32_t)((picture_height - b64_origin_y) < 64 ? picture_height - b64_origin_y : 64);
+    ctx->b64_src_ptr = src_plane + (size_t)(src_org_y + b64_origin_y) * src_stride + src_org_x + b64_origin_x;
+    ctx->b64_src_stride = src_stride;
+    integer_search_b64(pcs, ctx, (uint32_t)b64_origin_x, (uint32_t)b64_origin_y, &inp);
+    memcpy(best_sad, ctx->p_sb_best_sad[l][r], 85 * 4);
+    memcpy(best_mv, ctx->p_sb_best_mv[l][r], 85 * 4);
+}

@@ -78,6 +78,8 @@ PROTOTYPES = {
     "svt_hip_me_session_wait": (None, [vp, C.c_int]),
     "svt_hip_me_session_submit_results": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
     "svt_hip_me_results_batch": (None, [vp] * 10),
+    "svt_hip_me_integer_search_workspace": (C.c_size_t, [vp]),
+    "svt_hip_me_integer_search_batch": (None, [vp] * 13),
     "svt_hip_hme_level_workspace": (C.c_size_t, [vp]),
     "svt_hip_hme_level_batch": (None, [vp] * 8),
     "svt_av1_apply_temporal_filter_planewise_medium_hip": (None, [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
@@ -191,6 +193,16 @@ class HmeLevelParams(C.Structure):
                 ("sa_height", C.c_int16), ("sbs_x", C.c_uint32), ("sbs_y", C.c_uint32), ("n_refs", C.c_uint32), ("prev_shift", C.c_uint32), ("aligned_width", C.c_uint32),
                 ("aligned_height", C.c_uint32), ("src_off", C.c_uint64), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32), ("ref_org_x", C.c_uint32),
                 ("ref_org_y", C.c_uint32), ("ref_width", C.c_uint32), ("ref_height", C.c_uint32), ("ref_off", C.c_uint64 * 8)]
+
+
+class MeIntegerSearchParams(C.Structure):
+    """SvtHipMeIntegerSearchParams (include/svtav1_hip.h)."""
+    _fields_ = [("sbs_x", C.c_uint32), ("sbs_y", C.c_uint32), ("n_refs", C.c_uint32), ("regions", C.c_uint32), ("aligned_width", C.c_uint32),
+                ("aligned_height", C.c_uint32), ("sa_min_width", C.c_int16), ("sa_min_height", C.c_int16), ("sa_max_width", C.c_int16),
+                ("sa_max_height", C.c_int16), ("sub_sad", C.c_uint8), ("mv_adj_enabled", C.c_uint8), ("mv_adj_nearest_ref_only", C.c_uint8),
+                ("pad0", C.c_uint8), ("mv_adj_mv_size_th", C.c_uint16), ("mv_adj_sa_multiplier", C.c_uint16), ("dist", C.c_uint16 * 8),
+                ("ref_pic_index", C.c_uint8 * 8), ("src_off", C.c_uint64), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32),
+                ("ref_org_x", C.c_uint32), ("ref_org_y", C.c_uint32), ("ref_off", C.c_uint64 * 8)]
 
 
 class TfParams(C.Structure):

@@ -149,3 +149,104 @@ def test_hme_three_level_chain_hip(be, oracle):
         assert np.array_equal(be.host(d_sad), sad_o) and np.array_equal(be.host(d_sc), prev_o), lv
         d_prev = d_sc
     assert np.abs(prev_o).max() > 0
+
+
+# ------------------------------------------------------------------ integer ME from HME results (set_final_seach_centre_sb + integer_search_b64)
+class IntSearch(C.Structure):
+    _fields_ = [("sa_min_w", C.c_int16), ("sa_min_h", C.c_int16), ("sa_max_w", C.c_int16), ("sa_max_h", C.c_int16), ("dist", C.c_uint16),
+                ("mv_adj_enabled", C.c_uint8), ("mv_adj_nearest_ref_only", C.c_uint8), ("ref_pic_index", C.c_uint8), ("sub_sad", C.c_uint8),
+                ("mv_size_th", C.c_uint16), ("sa_multiplier", C.c_uint16), ("divisor", C.c_uint32)]
+
+
+INT_CASES = [dict(sa=(8, 3, 16, 9), dist=1, adj=(0, 0, 0, 1), r=0, sub=0, div=1), dict(sa=(8, 5, 64, 32), dist=3, adj=(1, 0, 6, 2), r=1, sub=0, div=1),
+             dict(sa=(16, 9, 48, 24), dist=2, adj=(1, 1, 4, 2), r=0, sub=1, div=2), dict(sa=(8, 3, 24, 12), dist=5, adj=(1, 1, 4, 3), r=2, sub=0, div=4),
+             dict(sa=(12, 7, 30, 20), dist=1, adj=(0, 0, 0, 1), r=0, sub=1, div=3)]
+
+
+def int_params(c):
+    P = IntSearch()
+    P.sa_min_w, P.sa_min_h, P.sa_max_w, P.sa_max_h = c["sa"]
+    P.dist, P.ref_pic_index, P.sub_sad, P.divisor = c["dist"], c["r"], c["sub"], c["div"]
+    P.mv_adj_enabled, P.mv_adj_nearest_ref_only, P.mv_size_th, P.sa_multiplier = c["adj"]
+    return P
+
+
+def make_hme_results(g, n_items, regions, W, H):
+    sad = g.integers(100, 100000, (n_items, regions)).astype(np.uint64)
+    sad[::4, 1:] = sad[::4, :1]  # ties: the first region must win
+    sc = np.stack([g.integers(-W // 3, W // 3, (n_items, regions)), g.integers(-H // 3, H // 3, (n_items, regions))], 2).astype(np.int16)
+    sc[1::3] //= 16
+    return sad, sc
+
+
+@pytest.mark.parametrize("ci", range(len(INT_CASES)))
+def test_me_integer_search_oracle_vs_reference(oracle, ref, ci):
+    if not os.path.exists(REF_ME_LIB):
+        pytest.skip("oracle/_ref/libsvtref_me.so not available")
+    refme = C.CDLL(REF_ME_LIB)
+    ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))
+    ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
+    c, g = INT_CASES[ci], rng(1900 + ci)
+    P = int_params(c)
+    W, H = 200, 136
+    src, refs, w, h, org, stride = make_planes(g, W, H, 2, 1)
+    aw, ah = (W + 7) & ~7, (H + 7) & ~7
+    sbs_x, sbs_y, nw, nh = (aw + 63) // 64, (ah + 63) // 64, 2, 2
+    sad, sc = make_hme_results(g, sbs_x * sbs_y, nw * nh, W, H)
+    for sb in range(sbs_x * sbs_y):
+        fx, fy = (sb % sbs_x) * 64, (sb // sbs_x) * 64
+        o_sc, r_sc, o_sad, r_sad = np.zeros(2, np.int16), np.zeros(2, np.int16), C.c_uint64(0), C.c_uint64(0)
+        area = np.zeros(4, np.int16)
+        bs0, bm0, bs1, bm1 = (np.zeros(85, np.uint32) for _ in range(4))
+        oracle.oracle_me_integer_search(C.byref(P), nw * nh, p(sad[sb]), p(sc[sb]), p(src), stride, org, org, p(refs[0]), stride, org, org, fx, fy, aw, ah, p(o_sc),
+                                        C.byref(o_sad), p(area), p(bs0), p(bm0))
+        refme.ref_me_integer_search(C.byref(P), nw, nh, p(sad[sb]), p(sc[sb]), p(src), stride, org, org, p(refs[0]), stride, org, org, W, H, fx, fy, aw, ah,
+                                    p(r_sc), C.byref(r_sad), p(bs1), p(bm1))
+        assert np.array_equal(o_sc, r_sc) and o_sad.value == r_sad.value, (ci, sb)
+        assert np.array_equal(bs0, bs1) and np.array_equal(bm0, bm1), (ci, sb, area)
+
+
+@pytest.mark.parametrize("ci", range(len(INT_CASES)))
+def test_me_integer_search_hip(be, oracle, ci):
+    pkg, c, g = load_pkg(), INT_CASES[ci], rng(2000 + ci)
+    W, H = (200, 136) if not be.is_gpu else (712, 400)
+    n_refs, nw, nh = 3, 2, 2
+    src, refs, w, h, org, stride = make_planes(g, W, H, 2, n_refs)
+    aw, ah = (W + 7) & ~7, (H + 7) & ~7
+    sbs_x, sbs_y = (aw + 63) // 64, (ah + 63) // 64
+    n_sb = sbs_x * sbs_y
+    sad, sc = make_hme_results(g, n_refs * n_sb, nw * nh, W, H)
+    dist, rpi = [c["dist"], max(1, c["dist"] - 1), c["dist"] + 1], [c["r"], 0, 1]
+    do_ref = (g.random((n_sb, n_refs)) < 0.85).astype(np.uint8)
+    div = np.where(g.random((n_sb, n_refs)) < 0.5, c["div"], 1).astype(np.uint32)
+    P = pkg.MeIntegerSearchParams()
+    P.sbs_x, P.sbs_y, P.n_refs, P.regions, P.aligned_width, P.aligned_height = sbs_x, sbs_y, n_refs, nw * nh, aw, ah
+    P.sa_min_width, P.sa_min_height, P.sa_max_width, P.sa_max_height = c["sa"]
+    P.sub_sad, P.mv_adj_enabled, P.mv_adj_nearest_ref_only, P.mv_adj_mv_size_th, P.mv_adj_sa_multiplier = c["sub"], *c["adj"]
+    for r in range(n_refs):
+        P.dist[r], P.ref_pic_index[r], P.ref_off[r] = dist[r], rpi[r], (1 + r) * src.size
+    P.src_off, P.src_stride, P.ref_stride, P.ref_org_x, P.ref_org_y = org * stride + org, stride, stride, org, org
+    planes = np.stack([src] + refs)
+    d_pl, d_sad, d_sc, d_do, d_div = be.dev(planes), be.dev(sad), be.dev(sc), be.dev(do_ref), be.dev(div)
+    d_bs, d_bm = be.empty((n_refs, n_sb, 85), np.uint32), be.empty((n_refs, n_sb, 85), np.uint32)
+    d_sco, d_sado = be.empty((n_refs, n_sb, 2), np.int16), be.empty((n_refs, n_sb), np.uint64)
+    d_ws = be.empty(be.lib.svt_hip_me_integer_search_workspace(C.addressof(P)), np.uint8)
+    be.lib.svt_hip_me_integer_search_batch(C.addressof(P), be.ptr(d_pl), be.ptr(d_pl), be.ptr(d_sad), be.ptr(d_sc), be.ptr(d_do), be.ptr(d_div), be.ptr(d_bs),
+                                           be.ptr(d_bm), be.ptr(d_sco), be.ptr(d_sado), be.ptr(d_ws), be.stream)
+    bs, bm, sco, sado = be.host(d_bs), be.host(d_bm), be.host(d_sco), be.host(d_sado)
+    checked = 0
+    for r in range(n_refs):
+        Q = int_params(dict(c, dist=dist[r], r=rpi[r]))
+        for sb in (range(n_sb) if not be.is_gpu else g.choice(n_sb, 12, replace=False)):
+            sb = int(sb)
+            Q.divisor = int(div[sb, r])
+            i = r * n_sb + sb
+            o_sc, o_sad, area = np.zeros(2, np.int16), C.c_uint64(0), np.zeros(4, np.int16)
+            ws_, wm_ = np.zeros(85, np.uint32), np.zeros(85, np.uint32)
+            oracle.oracle_me_integer_search(C.byref(Q), nw * nh, p(sad[i]), p(sc[i]), p(src), stride, org, org, p(refs[r]), stride, org, org, (sb % sbs_x) * 64,
+                                            (sb // sbs_x) * 64, aw, ah, p(o_sc), C.byref(o_sad), p(area), p(ws_), p(wm_))
+            assert np.array_equal(sco[r, sb], o_sc) and int(sado[r, sb]) == o_sad.value, (ci, r, sb)
+            if do_ref[sb, r]:
+                assert np.array_equal(bs[r, sb], ws_) and np.array_equal(bm[r, sb], wm_), (ci, r, sb, area)
+                checked += 1
+    assert checked > 10
