@@ -547,3 +547,75 @@ def hme_chain(torch, lib, pkg, stream, steps, warmup):
     t = _time(torch, fn, steps, warmup)
     return {"hme_3level_1080p_4refs": {"us_per_picture": t * 1e6, "pictures_per_s": 1 / t, "searches_per_level": n, "launches": 9,
                                        "note": "level 0: 2x2 regions of 16x16 on 1/16-area planes; levels 1, 2: 8x3"}}
+
+
+def me_stage(torch, lib, pkg, stream, steps, warmup):
+    """The open-loop ME stage of one 1080p picture against 4 references, resident in HBM, chained on the device with no host round trip:
+    decimation of the source to the 1/4 and 1/16-area planes (2 launches) -> HME level 0 / 1 / 2 -> final search centre + integer full-pel search
+    (8x3 .. 16x9 areas around the HME result) -> MeSbResults formatting.  Everything the reference's ME thread does per SB except the
+    content-dependent search-range probes."""
+    g = np.random.default_rng(13)
+    W, H, n_refs, nw, nh = 1920, 1080, 4, 2, 2
+    aw, ah = W, (H + 7) & ~7
+    sbs_x, sbs_y = (aw + 63) // 64, (ah + 63) // 64
+    n_sb = sbs_x * sbs_y
+    org = {0: 16, 1: 32, 2: 68}
+    geo, bufs = {}, {}
+    for lv in (0, 1, 2):
+        sh = 2 - lv
+        w, h, o = W >> sh, H >> sh, org[lv]
+        stride, rows = w + 2 * o, h + 2 * o + (64 >> sh)
+        geo[lv] = (w, h, o, stride, rows)
+        bufs[lv] = torch.from_numpy(g.integers(0, 256, (1 + n_refs, rows, stride), dtype=np.uint8)).cuda()
+    n_items = n_refs * n_sb * nw * nh
+    sa = {0: (16, 16), 1: (8, 3), 2: (8, 3)}
+    hp = []
+    for lv in (0, 1, 2):
+        w, h, o, stride, rows = geo[lv]
+        P = pkg.HmeLevelParams()
+        P.level, P.sub_sampled, P.num_hme_sa_w, P.num_hme_sa_h, P.sa_width, P.sa_height = lv, 0, nw, nh, sa[lv][0], sa[lv][1]
+        P.sbs_x, P.sbs_y, P.n_refs, P.prev_shift, P.aligned_width, P.aligned_height = sbs_x, sbs_y, n_refs, int(lv == 1), aw, ah
+        P.src_off, P.src_stride = o * stride + o, stride
+        P.ref_stride, P.ref_org_x, P.ref_org_y, P.ref_width, P.ref_height = stride, o, o, w, h
+        for r in range(n_refs):
+            P.ref_off[r] = (1 + r) * rows * stride
+        ws = torch.zeros(lib.svt_hip_hme_level_workspace(C.addressof(P)), dtype=torch.uint8, device="cuda")
+        hp.append((P, ws, torch.zeros(n_items, dtype=torch.int64, device="cuda"), torch.zeros(2 * n_items, dtype=torch.int16, device="cuda")))
+    w, h, o, stride, rows = geo[2]
+    Q = pkg.MeIntegerSearchParams()
+    Q.sbs_x, Q.sbs_y, Q.n_refs, Q.regions, Q.aligned_width, Q.aligned_height = sbs_x, sbs_y, n_refs, nw * nh, aw, ah
+    Q.sa_min_width, Q.sa_min_height, Q.sa_max_width, Q.sa_max_height = 8, 3, 16, 9  # preset-8 1080p (enc_mode_config.c:325-326)
+    for r in range(n_refs):
+        Q.dist[r], Q.ref_pic_index[r], Q.ref_off[r] = 1 + r, r % 2, (1 + r) * rows * stride
+    Q.src_off, Q.src_stride, Q.ref_stride, Q.ref_org_x, Q.ref_org_y = o * stride + o, stride, stride, o, o
+    ws_i = torch.zeros(lib.svt_hip_me_integer_search_workspace(C.addressof(Q)), dtype=torch.uint8, device="cuda")
+    bs, bm = torch.zeros(n_refs * n_sb * 85, dtype=torch.int32, device="cuda"), torch.zeros(n_refs * n_sb * 85, dtype=torch.int32, device="cuda")
+    sco, sado = torch.zeros(n_refs * n_sb * 2, dtype=torch.int16, device="cuda"), torch.zeros(n_refs * n_sb, dtype=torch.int64, device="cuda")
+    R = pkg.MeResultsParams()
+    R.n_sb, R.num_of_list_to_search = n_sb, 2
+    R.num_of_ref_pic_to_search[0], R.num_of_ref_pic_to_search[1] = 2, 2
+    R.max_refs, R.max_cand = pkg.me_max_allocated_refs(2, 2)
+    R.max_l0, R.enable_me_16x16, R.enable_me_8x8, R.prune_ref, R.gm_enabled = 2, 1, 1, 1, 1
+    R.prune_ref_if_me_sad_dev_bigger_than_th, R.prune_me_candidates_th, R.picture_number = 30, 65, 16
+    do_ref = torch.ones(n_sb * 8, dtype=torch.uint8, device="cuda")
+    sz = torch.full((n_sb * 2,), 64, dtype=torch.uint8, device="cuda")
+    tot, mvs = torch.zeros(n_sb * 85, dtype=torch.uint8, device="cuda"), torch.zeros(n_sb * 85 * R.max_refs * 4, dtype=torch.uint8, device="cuda")
+    cands, st = torch.zeros(n_sb * 85 * R.max_cand, dtype=torch.uint8, device="cuda"), torch.zeros(n_sb * 28, dtype=torch.uint8, device="cuda")
+    zero = torch.zeros(2 * n_items, dtype=torch.int16, device="cuda")
+    full = bufs[2].data_ptr() + geo[2][2] * geo[2][3] + geo[2][2]
+
+    def fn():
+        lib.svt_hip_downsample_2d_padded(full, geo[2][3], W, H, bufs[1].data_ptr(), geo[1][3], geo[1][2], geo[1][2], 2, stream)
+        lib.svt_hip_downsample_2d_padded(full, geo[2][3], W, H, bufs[0].data_ptr(), geo[0][3], geo[0][2], geo[0][2], 4, stream)
+        prev = zero
+        for lv, (P, ws, sad, sc) in enumerate(hp):
+            lib.svt_hip_hme_level_batch(C.addressof(P), bufs[lv].data_ptr(), bufs[lv].data_ptr(), prev.data_ptr(), sad.data_ptr(), sc.data_ptr(), ws.data_ptr(),
+                                        stream)
+            prev = sc
+        lib.svt_hip_me_integer_search_batch(C.addressof(Q), bufs[2].data_ptr(), bufs[2].data_ptr(), hp[2][2].data_ptr(), hp[2][3].data_ptr(), None, None,
+                                            bs.data_ptr(), bm.data_ptr(), sco.data_ptr(), sado.data_ptr(), ws_i.data_ptr(), stream)
+        lib.svt_hip_me_results_batch(C.addressof(R), bs.data_ptr(), bm.data_ptr(), do_ref.data_ptr(), sz.data_ptr(), tot.data_ptr(), mvs.data_ptr(),
+                                     cands.data_ptr(), st.data_ptr(), stream)
+    t = _time(torch, fn, steps, warmup)
+    return {"me_stage_1080p_4refs": {"us_per_picture": t * 1e6, "pictures_per_s": 1 / t, "sb_refs": n_refs * n_sb,
+                                     "note": "decimate x2, HME L0/L1/L2, final centre + integer search (8x3..16x9), MeSbResults: device-resident chain"}}
