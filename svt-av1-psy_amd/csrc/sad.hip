@@ -539,52 +539,44 @@ __global__ __launch_bounds__(256) void sad_loop_kernel(const uint8_t* __restrict
 // search column, 16 (8) v_qsad_pk_u16_u8 per step; the sub-block SADs meet through DPP quad / row adds (and ds_bpermute for 64x64).  A 16x16 item
 // therefore searches 64 positions per step, a 32x32 item 16, a 64x64 item 4.
 constexpr int SLR_WIN_BYTES = 10240, SLR_SRC_BYTES = 4096; // upper limits per wave; the launch sizes the slices from the batch maxima
+// Blocks shorter than they are wide (the last SB row of a picture: 56 of 64 rows, 14 of 16 at the 1/16 level) also qualify: the sub-block rows
+// beyond block_height are skipped under an exec mask (PARTIAL instantiation of the wave routine).
 __device__ __forceinline__ bool sad_loop_ring_eligible(const SvtHipSadLoopDesc& d, const int win_budget, const int src_budget) {
     const int bw = d.block_width, bh = d.block_height, W = d.search_area_width, H = d.search_area_height;
     if (!(bw == 16 || bw == 32 || bw == 64) || d.src_stride_raw == 0 || d.ref_stride % d.src_stride_raw != 0) return false;
     const int rstep = (int)(d.ref_stride / d.src_stride_raw);
-    if ((rstep != 1 && rstep != 2) || bh * rstep != bw || W <= 0 || H <= 0 || W * H > 4096) return false;
+    if ((rstep != 1 && rstep != 2) || bh <= 0 || bh * rstep > bw || W <= 0 || H <= 0 || W * H > 4096) return false;
     const int pitch = (((bw + W + 3) >> 2) + 3) & ~1, lines = H + rstep * (bh - 1);
     return pitch * 4 * lines <= win_budget && bw * bh <= src_budget;
 }
-__global__ __launch_bounds__(256) void sad_loop_ring_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
-                                                            const SvtHipSadLoopDesc* __restrict__ descs, const uint32_t n,
-                                                            unsigned long long* __restrict__ keys, uint32_t* __restrict__ todo, const int win_budget,
-                                                            const int src_budget) {
-    HIP_DYNAMIC_SHARED(uint32_t, smem)
-    const int      l = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t item = blockIdx.x * 4 + wv;
-    const bool     have = item < n;
-    const SvtHipSadLoopDesc d = descs[have ? item : 0];
-    const bool     mine = have && sad_loop_ring_eligible(d, win_budget, src_budget);
-    if (have && !mine && l == 0) todo[1 + atomicAdd(&todo[0], 1u)] = item; // work list of the generic kernel: todo[0] = count, todo[1..] = items
-    uint32_t* src_lds = smem + wv * ((win_budget + src_budget) / 4);
-    uint32_t* win     = src_lds + src_budget / 4;
+// One wave searches one item: stages the source block and the reference window into its own LDS slices, returns (sad << 12) | (yy * W + x) of
+// the first raster-order minimum (0xffffffff when every position was skipped).  Only wave-level synchronisation.
+template <bool PARTIAL>
+__device__ __forceinline__ uint32_t sad_loop_ring_wave(uint32_t* src_lds, uint32_t* win, const uint8_t* __restrict__ src_base,
+                                                       const uint8_t* __restrict__ ref_base, const SvtHipSadLoopDesc& d, const int l) {
     const int bw = d.block_width, bh = d.block_height, W = d.search_area_width, H = d.search_area_height;
-    const int rstep = mine ? (int)(d.ref_stride / d.src_stride_raw) : 1;
+    const int rstep = (int)(d.ref_stride / d.src_stride_raw);
     const int src_pitch = bw >> 2, win_pitch = (((bw + W + 3) >> 2) + 3) & ~1, lines = H + rstep * (bh - 1);
-    if (mine) {
-        stage_rows_wide_any<64>(src_lds, src_pitch, src_base + d.src_off, d.src_stride, bw, bh, l);
-        stage_rows_wide_any<64>(win, win_pitch, ref_base + d.ref_off, d.src_stride_raw, bw + W - 1, lines, l);
-    }
-    __syncthreads(); // the only barrier: from here on a wave works alone on its own LDS slice
-    if (!mine) return;
+    stage_rows_wide_any<64>(src_lds, src_pitch, src_base + d.src_off, d.src_stride, bw, bh, l);
+    stage_rows_wide_any<64>(win, win_pitch, ref_base + d.ref_off, d.src_stride_raw, bw + W - 1, lines, l);
+    __builtin_amdgcn_wave_barrier(); // the slices belong to this wave alone: LDS program order is enough on the hardware
 
     const int sbc  = bw >> 3, nsb = sbc * sbc;           // sub-block grid sbc x sbc: 4, 16 or 64 lanes per x-group
     const int RB   = 8 / rstep;                          // used rows per sub-block
     const int sub  = l & (nsb - 1), xg = l / nsb, XG = 64 / nsb;
     const int sx   = sub % sbc, sy = sub / sbc;
     const int q    = l & 3;
+    const int nrow = PARTIAL ? bh - sy * RB : RB;        // valid rows of this lane's sub-block (<= 0: the sub-block lies below the block)
     uint32_t s[8][2];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const int rr = r < RB ? r : 0;
-        s[r][0] = src_lds[(sy * RB + rr) * src_pitch + sx * 2 + 0];
-        s[r][1] = src_lds[(sy * RB + rr) * src_pitch + sx * 2 + 1];
+        const int rr = (r < RB && (!PARTIAL || r < nrow)) ? r : 0;
+        const int row = PARTIAL && nrow <= 0 ? 0 : sy * RB + rr;
+        s[r][0] = src_lds[row * src_pitch + sx * 2 + 0];
+        s[r][1] = src_lds[row * src_pitch + sx * 2 + 1];
     }
     const bool     skip_rule = (bw == 16) && (bh <= 16) && d.skip_search_line; // compute_sad_c.c:74-79: even search lines are skipped
     const uint32_t qsel = 0x0c0c0100u + 0x0202u * (uint32_t)q;
-    const int      bp16 = (l ^ 16) << 2, bp32 = (l ^ 32) << 2;
     uint32_t best = 0xffffffffu; // (sad << 12) | (yy * W + x): sad < 2^20, position < 2^12
     for (int g0 = 0; 4 * g0 < W; g0 += XG) {
         const int  g   = g0 + xg;        // this lane's x-group: positions 4 g .. 4 g + 3
@@ -612,16 +604,20 @@ __global__ __launch_bounds__(256) void sad_loop_ring_kernel(const uint8_t* __res
                             rb[(i + 7) & 7] = *(const U64A4*)(np + 1);
 #pragma unroll
                             for (int r = 0; r < 8; r++) {
-                                acc = __builtin_amdgcn_qsad_pk_u16_u8(ra[(i + r) & 7].v, s[r][0], acc);
-                                acc = __builtin_amdgcn_qsad_pk_u16_u8(rb[(i + r) & 7].v, s[r][1], acc);
+                                if (!PARTIAL || r < nrow) {
+                                    acc = __builtin_amdgcn_qsad_pk_u16_u8(ra[(i + r) & 7].v, s[r][0], acc);
+                                    acc = __builtin_amdgcn_qsad_pk_u16_u8(rb[(i + r) & 7].v, s[r][1], acc);
+                                }
                             }
                         } else {
                             ra[(i + 3) & 3] = *(const U64A4*)(np);
                             rb[(i + 3) & 3] = *(const U64A4*)(np + 1);
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
-                                acc = __builtin_amdgcn_qsad_pk_u16_u8(ra[(i + r) & 3].v, s[r][0], acc);
-                                acc = __builtin_amdgcn_qsad_pk_u16_u8(rb[(i + r) & 3].v, s[r][1], acc);
+                                if (!PARTIAL || r < nrow) {
+                                    acc = __builtin_amdgcn_qsad_pk_u16_u8(ra[(i + r) & 3].v, s[r][0], acc);
+                                    acc = __builtin_amdgcn_qsad_pk_u16_u8(rb[(i + r) & 3].v, s[r][1], acc);
+                                }
                             }
                         }
                         const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
@@ -631,8 +627,10 @@ __global__ __launch_bounds__(256) void sad_loop_ring_kernel(const uint8_t* __res
                         uint32_t sad = __builtin_amdgcn_perm(thi, tlo, qsel);
                         if (nsb >= 16) sad = dpp_add_row_ror8(dpp_add_row_ror4(sad));
                         if (nsb == 64) {
-                            sad += (uint32_t)__builtin_amdgcn_ds_bpermute(bp16, (int)sad);
-                            sad += (uint32_t)__builtin_amdgcn_ds_bpermute(bp32, (int)sad);
+                            const auto     x16  = __builtin_amdgcn_permlane16_swap(sad, sad, false, false);
+                            const uint32_t pair = x16[0] + x16[1];
+                            const auto     x32  = __builtin_amdgcn_permlane32_swap(pair, pair, false, false);
+                            sad = x32[0] + x32[1];
                         }
                         const bool ok = gok && x < W && !(skip_rule && ((yy & 1) == 0));
                         const uint32_t key = ok ? ((sad << 12) | (uint32_t)(yy * W + x)) : 0xffffffffu;
@@ -647,6 +645,25 @@ __global__ __launch_bounds__(256) void sad_loop_ring_kernel(const uint8_t* __res
         const uint32_t o = (uint32_t)__shfl_xor((int)best, m);
         best = o < best ? o : best;
     }
+    return best;
+}
+__global__ __launch_bounds__(256) void sad_loop_ring_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                            const SvtHipSadLoopDesc* __restrict__ descs, const uint32_t n,
+                                                            unsigned long long* __restrict__ keys, uint32_t* __restrict__ todo, const int win_budget,
+                                                            const int src_budget) {
+    HIP_DYNAMIC_SHARED(uint32_t, smem)
+    const int      l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t item = blockIdx.x * 4 + wv;
+    const bool     have = item < n;
+    const SvtHipSadLoopDesc d = descs[have ? item : 0];
+    const bool     mine = have && sad_loop_ring_eligible(d, win_budget, src_budget);
+    if (have && !mine && l == 0) todo[1 + atomicAdd(&todo[0], 1u)] = item; // work list of the generic kernel: todo[0] = count, todo[1..] = items
+    if (!mine) return;
+    uint32_t* src_lds = smem + wv * ((win_budget + src_budget) / 4);
+    uint32_t* win     = src_lds + src_budget / 4;
+    const int rstep = (int)(d.ref_stride / d.src_stride_raw);
+    const uint32_t best = d.block_height * rstep == d.block_width ? sad_loop_ring_wave<false>(src_lds, win, src_base, ref_base, d, l)
+                                                                  : sad_loop_ring_wave<true>(src_lds, win, src_base, ref_base, d, l);
     if (l == 0 && best != 0xffffffffu) keys[item] = ((unsigned long long)(best >> 12) << 32) | (unsigned long long)(best & 0xfffu);
 }
 
