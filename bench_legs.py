@@ -545,8 +545,14 @@ def hme_chain(torch, lib, pkg, stream, steps, warmup):
                                         stream)
             prev = sc
     t = _time(torch, fn, steps, warmup)
-    return {"hme_3level_1080p_4refs": {"us_per_picture": t * 1e6, "pictures_per_s": 1 / t, "searches_per_level": n, "launches": 9,
-                                       "note": "level 0: 2x2 regions of 16x16 on 1/16-area planes; levels 1, 2: 8x3"}}
+    PA = (pkg.HmeLevelParams * 3)(*[st[0] for st in stages])
+    pl = (C.c_void_p * 3)(*[st[1].data_ptr() for st in stages])
+    sp = (C.c_void_p * 3)(*[st[3].data_ptr() for st in stages])
+    cp = (C.c_void_p * 3)(*[st[4].data_ptr() for st in stages])
+    tf = _time(torch, lambda: lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(pl), C.addressof(pl), C.addressof(sp), C.addressof(cp), stream), steps, warmup)
+    return {"hme_3level_1080p_4refs": {"us_per_picture": tf * 1e6, "pictures_per_s": 1 / tf, "searches_per_level": n, "launches": 1,
+                                       "us_per_picture_level_by_level": t * 1e6,
+                                       "note": "level 0: 2x2 regions of 16x16 on 1/16-area planes; levels 1, 2: 8x3; one fused launch vs three level calls"}}
 
 
 def me_stage(torch, lib, pkg, stream, steps, warmup):
@@ -601,21 +607,20 @@ def me_stage(torch, lib, pkg, stream, steps, warmup):
     sz = torch.full((n_sb * 2,), 64, dtype=torch.uint8, device="cuda")
     tot, mvs = torch.zeros(n_sb * 85, dtype=torch.uint8, device="cuda"), torch.zeros(n_sb * 85 * R.max_refs * 4, dtype=torch.uint8, device="cuda")
     cands, st = torch.zeros(n_sb * 85 * R.max_cand, dtype=torch.uint8, device="cuda"), torch.zeros(n_sb * 28, dtype=torch.uint8, device="cuda")
-    zero = torch.zeros(2 * n_items, dtype=torch.int16, device="cuda")
+    PA = (pkg.HmeLevelParams * 3)(*[h[0] for h in hp])
+    pl = (C.c_void_p * 3)(*[bufs[lv].data_ptr() for lv in (0, 1, 2)])
+    sp = (C.c_void_p * 3)(*[h[2].data_ptr() for h in hp])
+    cp = (C.c_void_p * 3)(*[h[3].data_ptr() for h in hp])
     full = bufs[2].data_ptr() + geo[2][2] * geo[2][3] + geo[2][2]
 
     def fn():
         lib.svt_hip_downsample_2d_padded(full, geo[2][3], W, H, bufs[1].data_ptr(), geo[1][3], geo[1][2], geo[1][2], 2, stream)
         lib.svt_hip_downsample_2d_padded(full, geo[2][3], W, H, bufs[0].data_ptr(), geo[0][3], geo[0][2], geo[0][2], 4, stream)
-        prev = zero
-        for lv, (P, ws, sad, sc) in enumerate(hp):
-            lib.svt_hip_hme_level_batch(C.addressof(P), bufs[lv].data_ptr(), bufs[lv].data_ptr(), prev.data_ptr(), sad.data_ptr(), sc.data_ptr(), ws.data_ptr(),
-                                        stream)
-            prev = sc
+        lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(pl), C.addressof(pl), C.addressof(sp), C.addressof(cp), stream)
         lib.svt_hip_me_integer_search_batch(C.addressof(Q), bufs[2].data_ptr(), bufs[2].data_ptr(), hp[2][2].data_ptr(), hp[2][3].data_ptr(), None, None,
                                             bs.data_ptr(), bm.data_ptr(), sco.data_ptr(), sado.data_ptr(), ws_i.data_ptr(), stream)
         lib.svt_hip_me_results_batch(C.addressof(R), bs.data_ptr(), bm.data_ptr(), do_ref.data_ptr(), sz.data_ptr(), tot.data_ptr(), mvs.data_ptr(),
                                      cands.data_ptr(), st.data_ptr(), stream)
     t = _time(torch, fn, steps, warmup)
     return {"me_stage_1080p_4refs": {"us_per_picture": t * 1e6, "pictures_per_s": 1 / t, "sb_refs": n_refs * n_sb,
-                                     "note": "decimate x2, HME L0/L1/L2, final centre + integer search (8x3..16x9), MeSbResults: device-resident chain"}}
+                                     "note": "decimate x2, HME L0-L2 (one fused launch), final centre + integer search (8x3..16x9), MeSbResults: device-resident chain"}}

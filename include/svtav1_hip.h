@@ -179,6 +179,11 @@ typedef struct SvtHipHmeLevelParams {
 size_t svt_hip_hme_level_workspace(const SvtHipHmeLevelParams *params);
 void   svt_hip_hme_level_batch(const SvtHipHmeLevelParams *params, const uint8_t *src_base, const uint8_t *ref_base, const int16_t *prev_sc,
                                uint64_t *sad_out, int16_t *sc_out, void *workspace, void *stream);
+/* Levels 0, 1 and 2 of every item in ONE launch (one wave walks an item through the three levels: level N+1 only needs level N's result of the same
+ * item).  params[3] = the three levels (same n_refs / SB grid / regions; params[1].prev_shift = 1); src_base / ref_base / sad_out / sc_out: one
+ * pointer per level; results identical to three svt_hip_hme_level_batch calls.  sc_out[lv] is in/out like there. */
+void   svt_hip_hme_chain_batch(const SvtHipHmeLevelParams *params, const uint8_t *const *src_base, const uint8_t *const *ref_base,
+                               uint64_t *const *sad_out, int16_t *const *sc_out, void *stream);
 
 /* Integer ME of a whole picture from its HME results = set_final_seach_centre_sb (motion_estimation.c:2182-2368: per (reference, SB) the first
  * strictly smallest SAD over the search regions) + integer_search_b64's search-area geometry (:1294-1325, :1458-1508: min(sa_min * dist, sa_max),

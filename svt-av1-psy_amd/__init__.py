@@ -80,6 +80,7 @@ PROTOTYPES = {
     "svt_hip_me_results_batch": (None, [vp] * 10),
     "svt_hip_me_integer_search_workspace": (C.c_size_t, [vp]),
     "svt_hip_me_integer_search_batch": (None, [vp] * 13),
+    "svt_hip_hme_chain_batch": (None, [vp] * 6),
     "svt_hip_hme_level_workspace": (C.c_size_t, [vp]),
     "svt_hip_hme_level_batch": (None, [vp] * 8),
     "svt_av1_apply_temporal_filter_planewise_medium_hip": (None, [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),

@@ -14,6 +14,7 @@
 //   ext_*             : single-call forms of the reference's ext_* pointers.
 #include "svt_hip_common.h"
 #include "../../include/svtav1_hip.h"
+#include "hme_geom.h"
 #include <vector>
 
 namespace {
@@ -667,6 +668,83 @@ __global__ __launch_bounds__(256) void sad_loop_ring_kernel(const uint8_t* __res
     if (l == 0 && best != 0xffffffffu) keys[item] = ((unsigned long long)(best >> 12) << 32) | (unsigned long long)(best & 0xfffu);
 }
 
+// ---- the three HME levels of one (reference, SB, region) item in ONE wave: level N+1 only needs level N's winner of the same item, so the
+// chain needs no grid-wide step.  Per level: hme_item_geometry (the reference's placement / clipping), the ring search above (or, for shapes it
+// does not take -- block widths other than 16 / 32 / 64 at a ragged right picture edge -- a plain lane-per-position search), the sub-sampling
+// factor and the rescale to the next level.  One launch instead of 3 x (descriptors, ring search, generic search, finalize, rescale).
+__device__ __forceinline__ unsigned long long sad_loop_plain_wave(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                                  const SvtHipSadLoopDesc& d, const int l) {
+    const int bw = d.block_width, bh = d.block_height, W = d.search_area_width, H = d.search_area_height;
+    unsigned long long best = ~0ull; // (sad << 32) | raster position
+    for (int p = l; p < W * H; p += 64) {
+        const int yy = p / W, xx = p - yy * W;
+        const uint8_t* s = src_base + d.src_off;
+        const uint8_t* r = ref_base + d.ref_off + (size_t)yy * d.src_stride_raw + xx;
+        uint32_t sad = 0;
+        for (int y = 0; y < bh; y++)
+            for (int x = 0; x < bw; x++) {
+                const int df = (int)s[(size_t)y * d.src_stride + x] - (int)r[(size_t)y * d.ref_stride + x];
+                sad += (uint32_t)(df < 0 ? -df : df);
+            }
+        const unsigned long long key = ((unsigned long long)sad << 32) | (uint32_t)p;
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)best, m);
+        best = o < best ? o : best;
+    }
+    return best;
+}
+struct HmeChainArgs {
+    SvtHipHmeLevelParams P[3];
+    const uint8_t *src[3], *ref[3];
+    unsigned long long* sad_out[3];
+    int16_t* sc_out[3];
+    uint32_t n;
+    int win_budget, src_budget;
+};
+__global__ __launch_bounds__(256) void hme_chain_kernel(const HmeChainArgs A) {
+    HIP_DYNAMIC_SHARED(uint32_t, smem)
+    const int      l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t item = blockIdx.x * 4 + wv;
+    if (item >= A.n) return;
+    uint32_t* src_lds = smem + wv * ((A.win_budget + A.src_budget) / 4);
+    uint32_t* win     = src_lds + A.src_budget / 4;
+    int16_t px = 0, py = 0;
+#pragma unroll 1
+    for (int lv = 0; lv < 3; lv++) {
+        const SvtHipHmeLevelParams& P = A.P[lv];
+        SvtHipSadLoopDesc d;
+        int16_t ox, oy;
+        hme_item_geometry(P, item, px, py, d, ox, oy);
+        const int W = d.search_area_width;
+        uint32_t sad = 0xffffff; // svt_sad_loop_kernel's initial best (compute_sad_c.c:71)
+        int      pos = -1;
+        if (sad_loop_ring_eligible(d, A.win_budget, A.src_budget)) {
+            const int      rstep = (int)(d.ref_stride / d.src_stride_raw);
+            const uint32_t best  = d.block_height * rstep == d.block_width ? sad_loop_ring_wave<false>(src_lds, win, A.src[lv], A.ref[lv], d, l)
+                                                                           : sad_loop_ring_wave<true>(src_lds, win, A.src[lv], A.ref[lv], d, l);
+            if (best != 0xffffffffu && (best >> 12) < sad) { sad = best >> 12; pos = (int)(best & 0xfffu); }
+            __builtin_amdgcn_wave_barrier(); // the LDS slices are restaged by the next level
+        } else if (W > 0 && d.search_area_height > 0) {
+            const unsigned long long best = sad_loop_plain_wave(A.src[lv], A.ref[lv], d, l);
+            if ((uint32_t)(best >> 32) < sad) { sad = (uint32_t)(best >> 32); pos = (int)(uint32_t)best; }
+        }
+        // an empty or all-skipped area leaves the reference's centre variable untouched: sc_out is in/out, like svt_hip_hme_level_batch
+        int16_t x = A.sc_out[lv][2 * item], y = A.sc_out[lv][2 * item + 1];
+        if (pos >= 0) { y = (int16_t)(pos / W); x = (int16_t)(pos - (pos / W) * W); }
+        const int scale = P.level == 0 ? 4 : (P.level == 1 ? 2 : 1);
+        px = (int16_t)((int16_t)(x + ox) * scale);
+        py = (int16_t)((int16_t)(y + oy) * scale);
+        if (l == 0) {
+            A.sad_out[lv][item]        = P.sub_sampled ? (unsigned long long)sad * 2 : (unsigned long long)sad;
+            A.sc_out[lv][2 * item]     = px;
+            A.sc_out[lv][2 * item + 1] = py;
+        }
+    }
+}
+
 __global__ void sad_loop_finalize_kernel(const SvtHipSadLoopDesc* __restrict__ descs, uint32_t n, const unsigned long long* __restrict__ keys,
                                          SvtHipSadLoopResult* __restrict__ res) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -843,6 +921,34 @@ void svt_hip_sad_loop_batch(const uint8_t* src_base, const uint8_t* ref_base, co
     SVT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sad_loop_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, descs, n,
                        (const unsigned long long*)keys, results);
+    SVT_LAUNCH_CHECK();
+}
+
+void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* const* src_base, const uint8_t* const* ref_base, uint64_t* const* sad_out,
+                             int16_t* const* sc_out, void* stream) {
+    svthip::ensure_device();
+    const uint32_t n = params[0].n_refs * params[0].sbs_x * params[0].sbs_y * params[0].num_hme_sa_w * params[0].num_hme_sa_h;
+    if (n == 0) return;
+    HmeChainArgs A;
+    memset(&A, 0, sizeof(A));
+    int src_budget = 0, win_budget = 0;
+    for (int lv = 0; lv < 3; lv++) {
+        const SvtHipHmeLevelParams& P = params[lv];
+        if (P.level != lv || P.n_refs != params[0].n_refs || P.sbs_x != params[0].sbs_x || P.sbs_y != params[0].sbs_y ||
+            P.num_hme_sa_w != params[0].num_hme_sa_w || P.num_hme_sa_h != params[0].num_hme_sa_h || P.n_refs > 8) {
+            fprintf(stderr, "libsvtav1_hip: svt_hip_hme_chain_batch: the three levels must describe the same items (level %d)\n", lv);
+            abort();
+        }
+        A.P[lv] = P; A.src[lv] = src_base[lv]; A.ref[lv] = ref_base[lv]; A.sad_out[lv] = (unsigned long long*)sad_out[lv]; A.sc_out[lv] = sc_out[lv];
+        const int bw = 64 >> (2 - lv), step = P.sub_sampled ? 2 : 1, bh = bw / step, mw = (P.sa_width + 7) & ~7, mh = P.sa_height;
+        const int sb = bw * bh, wb = ((((bw + mw + 3) >> 2) + 3) & ~1) * 4 * (mh + step * (bh - 1));
+        src_budget = sb > src_budget ? sb : src_budget;
+        win_budget = wb > win_budget ? wb : win_budget;
+    }
+    src_budget = (src_budget > SLR_SRC_BYTES ? SLR_SRC_BYTES : src_budget + 15) & ~15;
+    win_budget = (win_budget > SLR_WIN_BYTES ? SLR_WIN_BYTES : win_budget + 15) & ~15;
+    A.n = n; A.win_budget = win_budget; A.src_budget = src_budget;
+    hipLaunchKernelGGL(hme_chain_kernel, dim3((n + 3) / 4), dim3(256), 4 * (size_t)(src_budget + win_budget) + 64, (hipStream_t)stream, A);
     SVT_LAUNCH_CHECK();
 }
 

@@ -130,6 +130,7 @@ def test_hme_three_level_chain_hip(be, oracle):
     sa = {0: (16, 8), 1: (8, 3), 2: (8, 3)}
     prev_o = np.zeros((n, 2), np.int16)
     d_prev = be.dev(prev_o)
+    fused = []
     for lv in (0, 1, 2):
         src, refs, w, h, org, stride = levels[lv]
         pin = prev_o >> 1 if lv == 1 else prev_o
@@ -148,7 +149,16 @@ def test_hme_three_level_chain_hip(be, oracle):
         be.lib.svt_hip_hme_level_batch(C.addressof(P), be.ptr(d_pl), be.ptr(d_pl), be.ptr(d_prev), be.ptr(d_sad), be.ptr(d_sc), be.ptr(d_ws), be.stream)
         assert np.array_equal(be.host(d_sad), sad_o) and np.array_equal(be.host(d_sc), prev_o), lv
         d_prev = d_sc
+        fused.append((P, d_pl, sad_o, prev_o))
     assert np.abs(prev_o).max() > 0
+    # the same chain in one launch
+    PA = (pkg.HmeLevelParams * 3)(*[f[0] for f in fused])
+    planes_p = (C.c_void_p * 3)(*[be.ptr(f[1]) for f in fused])
+    d_sads, d_scs = [be.empty(n, np.uint64) for _ in range(3)], [be.dev(np.zeros((n, 2), np.int16)) for _ in range(3)]
+    sad_p, sc_p = (C.c_void_p * 3)(*[be.ptr(x) for x in d_sads]), (C.c_void_p * 3)(*[be.ptr(x) for x in d_scs])
+    be.lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(planes_p), C.addressof(planes_p), C.addressof(sad_p), C.addressof(sc_p), be.stream)
+    for lv in range(3):
+        assert np.array_equal(be.host(d_sads[lv]), fused[lv][2]) and np.array_equal(be.host(d_scs[lv]), fused[lv][3]), ("fused", lv)
 
 
 # ------------------------------------------------------------------ integer ME from HME results (set_final_seach_centre_sb + integer_search_b64)

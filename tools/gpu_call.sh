@@ -1,3 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_hme.py tests/test_sad.py -m gpu -x -q 2>&1 | tail -3
-python tools/microbench.py hmechain mestage hme --steps 20 --warmup 3 2>/dev/null | tail -1
+timeout 900 python -m pytest tests/test_hme.py -m gpu -x -q 2>&1 | tail -3
+python tools/microbench.py hmechain mestage --steps 20 --warmup 3 2>&1 | tail -1
