@@ -579,26 +579,38 @@ __device__ __forceinline__ uint32_t sad_loop_ring_wave(uint32_t* src_lds, uint32
     const bool     skip_rule = (bw == 16) && (bh <= 16) && d.skip_search_line; // compute_sad_c.c:74-79: even search lines are skipped
     const uint32_t qsel = 0x0c0c0100u + 0x0202u * (uint32_t)q;
     uint32_t best = 0xffffffffu; // (sad << 12) | (yy * W + x): sad < 2^20, position < 2^12
-    for (int g0 = 0; 4 * g0 < W; g0 += XG) {
-        const int  g   = g0 + xg;        // this lane's x-group: positions 4 g .. 4 g + 3
-        const bool gok = 4 * g < W;
+    // The XG lane groups of a wave cover the x-groups of the area; when the area is narrower than 4 * XG positions (the HME shapes: 16 or 8
+    // wide against 64 / 16 positions per step) the spare groups take contiguous chunks of the search lines instead of idling.
+    const int GX = (W + 3) >> 2;
+    int       gxp = 1;
+    while (gxp < GX && gxp < XG) gxp <<= 1; // x-groups per pass: a power of two <= XG
+    const int YG = XG / gxp, gx = xg & (gxp - 1), yg = xg / gxp;
+    for (int g0 = 0; g0 < GX; g0 += gxp) {
+        const int  g   = g0 + gx;        // this lane's x-group: positions 4 g .. 4 g + 3
+        const bool gok = g < GX;
         const int  x   = 4 * g + q;      // the position this lane reports after the quad reduction
         const uint32_t* colp = win + (rstep * sy * RB) * win_pitch + sx * 2 + (gok ? g : 0);
         for (int par = 0; par < rstep; par++) {
+            const int K  = (H - par + rstep - 1) / rstep; // search lines of this parity: yy = par + rstep * k
+            const int CH = (K + YG - 1) / YG, k0 = yg * CH; // lines per y-group; this lane starts at line k0
+            // window line of block row r at search line k: par + rstep * (k + r) below this lane's first sub-block line; idle y-groups (k >= K)
+            // are clamped to the last staged line so that nothing outside the slice is touched
+            const int last = lines - 1 - rstep * sy * RB;
             U64A4 ra[8], rb[8];
 #pragma unroll
             for (int r = 0; r < 7; r++) {
-                const int rr = r < RB - 1 ? r : 0;
-                ra[r] = *(const U64A4*)(colp + (par + rstep * rr) * win_pitch);
-                rb[r] = *(const U64A4*)(colp + (par + rstep * rr) * win_pitch + 1);
+                const int rr = r < RB - 1 ? r : 0, ln = par + rstep * (k0 + rr);
+                ra[r] = *(const U64A4*)(colp + (ln < last ? ln : last) * win_pitch);
+                rb[r] = *(const U64A4*)(colp + (ln < last ? ln : last) * win_pitch + 1);
             }
             // ring slot of block row r at step k is (k + r) % RB; RB is 8 or 4, so the 8-way unrolled body indexes registers statically
-            for (int yb = par; yb < H; yb += 8 * rstep) {
+            for (int kb = 0; kb < CH; kb += 8) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const int yy = yb + i * rstep;
-                    if (yy < H) {
-                        const uint32_t* np = colp + (yy + rstep * (RB - 1)) * win_pitch;
+                    if (kb + i < CH) {
+                        const int k = k0 + kb + i, yy = par + rstep * k;
+                        const int       ln = par + rstep * (k + RB - 1);
+                        const uint32_t* np = colp + (ln < last ? ln : last) * win_pitch;
                         unsigned long long acc = 0;
                         if (RB == 8) {
                             ra[(i + 7) & 7] = *(const U64A4*)(np);
@@ -633,7 +645,7 @@ __device__ __forceinline__ uint32_t sad_loop_ring_wave(uint32_t* src_lds, uint32
                             const auto     x32  = __builtin_amdgcn_permlane32_swap(pair, pair, false, false);
                             sad = x32[0] + x32[1];
                         }
-                        const bool ok = gok && x < W && !(skip_rule && ((yy & 1) == 0));
+                        const bool ok = gok && x < W && k < K && !(skip_rule && ((yy & 1) == 0));
                         const uint32_t key = ok ? ((sad << 12) | (uint32_t)(yy * W + x)) : 0xffffffffu;
                         best = key < best ? key : best;
                     }
