@@ -48,3 +48,31 @@ def test_noise_golden(oracle, z):
     a8, a10 = np.ascontiguousarray(z["noise_a8"]), np.ascontiguousarray(z["noise_a10"])
     assert oracle.oracle_estimate_noise_fp16(p(a8), 64, 40, 72, 8) == int(z["noise_out"][0]) > 0
     assert oracle.oracle_estimate_noise_fp16(p(a10), 64, 40, 72, 10) == int(z["noise_out"][1]) > 0
+
+
+def test_hme_levels_golden(oracle, z):
+    import test_hme as Hm
+    W, H = 200, 136
+    for k in range(3):
+        level, sub, nw, nh, sa_w, sa_h = (int(v) for v in z["hme%d_case" % k])
+        src, refs = np.ascontiguousarray(z["hme%d_src" % k]), [np.ascontiguousarray(z["hme%d_ref0" % k]), np.ascontiguousarray(z["hme%d_ref1" % k])]
+        sh, org = {0: 2, 1: 1, 2: 0}[level], Hm.ORG[level]
+        sad, sc = Hm.cpu_level(oracle.oracle_hme_level, level, sub, nw, nh, src, refs, W >> sh, H >> sh, org, src.shape[1], W, H, sa_w, sa_h, z["hme%d_prev" % k])
+        assert np.array_equal(sad, z["hme%d_sad" % k]) and np.array_equal(sc, z["hme%d_sc" % k]), k
+
+
+def test_integer_search_golden(oracle, z):
+    import test_hme as Hm
+    W, H, org = 200, 136, Hm.ORG[2]
+    for k in range(2):
+        P = Hm.int_params(Hm.INT_CASES[int(z["int%d_case" % k][0])])
+        src, ref = np.ascontiguousarray(z["int%d_src" % k]), np.ascontiguousarray(z["int%d_ref" % k])
+        sad, sc = np.ascontiguousarray(z["int%d_hme_sad" % k]), np.ascontiguousarray(z["int%d_hme_sc" % k])
+        stride = src.shape[1]
+        for sb in range(12):
+            o_sc, o_sad, area = np.zeros(2, np.int16), C.c_uint64(0), np.zeros(4, np.int16)
+            bs, bm = np.zeros(85, np.uint32), np.zeros(85, np.uint32)
+            oracle.oracle_me_integer_search(C.byref(P), 4, p(sad[sb]), p(sc[sb]), p(src), stride, org, org, p(ref), stride, org, org, (sb % 4) * 64, (sb // 4) * 64,
+                                            (W + 7) & ~7, (H + 7) & ~7, p(o_sc), C.byref(o_sad), p(area), p(bs), p(bm))
+            assert np.array_equal(o_sc, z["int%d_sc" % k][sb]) and o_sad.value == int(z["int%d_sad" % k][sb]), (k, sb)
+            assert np.array_equal(bs, z["int%d_bs" % k][sb]) and np.array_equal(bm, z["int%d_bm" % k][sb]), (k, sb)

@@ -196,6 +196,35 @@ def gen_stage(ref, oracle):
     a10 = (a8.astype(np.uint16) << 2) + g.integers(0, 4, a8.shape).astype(np.uint16)
     out.update(noise_a8=a8, noise_a10=a10, noise_out=np.array([ref.svt_estimate_noise_fp16_c(p(a8), 64, 40, 72),
                                                               ref.svt_estimate_noise_highbd_fp16_c(p(a10), 64, 40, 72, 10)], np.int32))
+    # ---- HME leaf drivers and integer_search_b64 (static in the reference)
+    import test_hme as Hm
+    ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
+    W, H = 200, 136
+    for k, case in enumerate(((0, 0, 2, 2, 16, 8), (1, 1, 2, 2, 16, 8), (2, 0, 2, 2, 8, 3))):
+        level, sub, nw, nh, sa_w, sa_h = case
+        g = np.random.default_rng(7300 + k)
+        src, refs, w, h, org, stride = Hm.make_planes(g, W, H, level, 2)
+        n = 2 * 4 * 3 * nw * nh
+        prev = np.stack([g.integers(-3 * w // 4, 3 * w // 4, n), g.integers(-3 * h // 4, 3 * h // 4, n)], 1).astype(np.int16)
+        prev[::3] //= 8
+        sad, sc = Hm.cpu_level(refme.ref_hme_level, level, sub, nw, nh, src, refs, w, h, org, stride, W, H, sa_w, sa_h, prev)
+        out.update({"hme%d_case" % k: np.array(case, np.int32), "hme%d_src" % k: src, "hme%d_ref0" % k: refs[0], "hme%d_ref1" % k: refs[1],
+                    "hme%d_prev" % k: prev, "hme%d_sad" % k: sad, "hme%d_sc" % k: sc})
+    for k, ci in enumerate((1, 3)):
+        c, g = Hm.INT_CASES[ci], np.random.default_rng(7400 + k)
+        P = Hm.int_params(c)
+        src, refs, w, h, org, stride = Hm.make_planes(g, W, H, 2, 1)
+        aw, ah = (W + 7) & ~7, (H + 7) & ~7
+        sad, sc = Hm.make_hme_results(g, 12, 4, W, H)
+        bs, bm, fsc, fsad = np.zeros((12, 85), np.uint32), np.zeros((12, 85), np.uint32), np.zeros((12, 2), np.int16), np.zeros(12, np.uint64)
+        for sb in range(12):
+            o_sad = C.c_uint64(0)
+            refme.ref_me_integer_search(C.byref(P), 2, 2, p(sad[sb]), p(sc[sb]), p(src), stride, org, org, p(refs[0]), stride, org, org, W, H, (sb % 4) * 64,
+                                        (sb // 4) * 64, aw, ah, C.c_void_p(fsc[sb].ctypes.data), C.byref(o_sad), C.c_void_p(bs[sb].ctypes.data),
+                                        C.c_void_p(bm[sb].ctypes.data))
+            fsad[sb] = o_sad.value
+        out.update({"int%d_case" % k: np.array([ci], np.int32), "int%d_src" % k: src, "int%d_ref" % k: refs[0], "int%d_hme_sad" % k: sad, "int%d_hme_sc" % k: sc,
+                    "int%d_bs" % k: bs, "int%d_bm" % k: bm, "int%d_sc" % k: fsc, "int%d_sad" % k: fsad})
     np.savez_compressed(os.path.join(GOLDEN, "stage.npz"), **out)
 
 
