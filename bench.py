@@ -413,6 +413,7 @@ def main():
         kernels.update(bench_legs.me_results(torch, lib, pkg, stream, a.steps, 1))
         kernels.update(bench_legs.hme_chain(torch, lib, pkg, stream, a.steps, 1))
         kernels.update(bench_legs.me_stage(torch, lib, pkg, stream, a.steps, 1))
+        kernels.update(bench_legs.me_session_stage(torch, lib, pkg, stream, a.steps, 1))
         kernels.update(bench_legs.tf_frames(torch, lib, pkg, stream, a.steps, 1))
         kernels["txfm_quant_roundtrip"] = bench_legs.txfm_roundtrip(torch, lib, pkg, stream, max(a.steps // 4, 3), 1)
     out["kernels"] = kernels

@@ -642,3 +642,66 @@ def me_stage(torch, lib, pkg, stream, steps, warmup):
     lib.svt_hip_stream_destroy(gs)
     return {"me_stage_1080p_4refs": {"us_per_picture": t * 1e6, "pictures_per_s": 1 / t, "hip_graph_us_per_picture": tg * 1e6, "sb_refs": n_refs * n_sb,
                                      "note": "decimate x2, HME L0-L2 (one fused launch), final centre + integer search (8x3..16x9), MeSbResults: device-resident chain"}}
+
+
+def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=32):
+    """PCIe-inclusive WHOLE ME stage from pinned host pictures: upload once, quarter / sixteenth planes on the device, HME levels 0-2, final centre +
+    integer search, MeSbResults returned to pinned host memory; 4 references (2 + 2), two submissions in flight."""
+    import time as _t
+    W, H, PAD = 1920, 1080, 68
+    stride, rows = W + 2 * PAD, H + 2 * PAD
+    nbytes = stride * rows
+    g = np.random.default_rng(14)
+    sbs = ((W + 63) // 64) * ((H + 63) // 64)
+    hp = [lib.svt_hip_host_alloc(nbytes) for _ in range(8)]
+    for q in hp:
+        C.memmove(q, g.integers(0, 256, nbytes, dtype=np.uint8).ctypes.data, nbytes)
+    S = pkg.MeStageParams()
+    S.num_hme_sa_w, S.num_hme_sa_h = 2, 2
+    for lv, (a, b) in enumerate(((16, 16), (8, 3), (8, 3))):
+        S.hme_sa_width[lv], S.hme_sa_height[lv] = a, b
+    S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = 8, 3, 16, 9
+    for r in range(4):
+        S.dist[r], S.ref_pic_index[r] = 1 + r, r % 2
+    R = S.results
+    R.num_of_list_to_search = 2
+    R.num_of_ref_pic_to_search[0], R.num_of_ref_pic_to_search[1] = 2, 2
+    R.max_refs, R.max_cand = pkg.me_max_allocated_refs(2, 2)
+    R.max_l0, R.enable_me_16x16, R.enable_me_8x8, R.prune_ref, R.gm_enabled = 2, 1, 1, 1, 1
+    R.prune_ref_if_me_sad_dev_bigger_than_th, R.prune_me_candidates_th, R.picture_number = 30, 65, 16
+    sizes = [sbs * 85, sbs * 85 * R.max_refs * 4, sbs * 85 * R.max_cand, sbs * 28]
+    hosts = []
+    for _ in range(2):
+        b = [lib.svt_hip_host_alloc(n) for n in sizes]
+        hosts.append((b, pkg.MeResultsHost(None, b[0], b[1], b[2], b[3], None, None)))
+
+    def run(sess, n):
+        pending = []
+        for k in range(n):
+            refs = np.array([k - 1, k - 2, k - 3, k - 4], np.int64)
+            slot = lib.svt_hip_me_session_submit_stage(sess, k, hp[k % 8], refs.ctypes.data if k >= 4 else None, 4 if k >= 4 else 0, C.addressof(S),
+                                                       C.addressof(hosts[k & 1][1]) if k >= 4 else None)
+            assert slot >= 0, slot
+            pending.append(slot)
+            if len(pending) == 2:
+                lib.svt_hip_me_session_wait(sess, pending.pop(0))
+        for slot in pending:
+            lib.svt_hip_me_session_wait(sess, slot)
+    ts = []
+    for it in range(max(steps // 4, 2) + 1):
+        sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, 2)
+        assert lib.svt_hip_me_session_enable_stage(sess, 32, 16, 4, 16, 9) == 0
+        t0 = _t.perf_counter()
+        run(sess, npics if it else 8)
+        if it:
+            ts.append(_t.perf_counter() - t0)
+        lib.svt_hip_me_session_destroy(sess)
+    for q in hp:
+        lib.svt_hip_host_free(q)
+    for b, _ in hosts:
+        for q in b:
+            lib.svt_hip_host_free(q)
+    t = min(ts)
+    return {"me_session_stage_1080p_host": {"pictures_per_s": npics / t, "us_per_picture": t / npics * 1e6, "h2d_MB_per_picture": nbytes / 1e6,
+                                            "d2h_MB_per_picture": sum(sizes) / 1e6,
+                                            "note": "decimation + HME 0-2 + integer search + MeSbResults per picture, 4 references, PCIe inclusive"}}

@@ -353,6 +353,30 @@ typedef struct SvtHipTfPlanes {
 void svt_hip_tf_filter_frame(const SvtHipTfParams *params, const SvtHipTfPlanes *central, const SvtHipTfPlanes *preds, uint32_t n_refs,
                              const SvtHipTfBlock *blocks, uint32_t nbx, uint32_t nby, const SvtHipTfPlanes *out, void *stream);
 
+/* The whole open-loop ME stage from a HOST picture: upload -> quarter / sixteenth planes (made once per picture on the device, kept in the ring
+ * with the full plane) -> HME levels 0-2 -> final search centre + integer_search_b64 geometry + full-pel search -> MeSbResults (+ raw tables on
+ * request) -> download, on the submission's own stream like svt_hip_me_session_submit.  svt_hip_me_session_enable_stage sizes the extra
+ * buffers once (decimated-plane padding as the reference's 32 / 16; max_regions = num_hme_sa_w * num_hme_sa_h; the largest ME area the stage
+ * parameters can produce).  ref_ids: list-0 references first; results.num_of_ref_pic_to_search[0] + [1] must equal n_refs.  Every picture that
+ * will serve as a reference must have been submitted after enable_stage (its decimated planes are made at upload time).  -5: not enabled, too
+ * many regions, or areas beyond the enabled maximum. */
+typedef struct SvtHipMeStageParams {
+    uint8_t  num_hme_sa_w, num_hme_sa_h; /* me_ctx->num_hme_sa_w / num_hme_sa_h */
+    uint8_t  hme_sub_sampled;            /* hme_search_method != FULL_SAD_SEARCH */
+    uint8_t  me_sub_sad;                 /* me_search_method == SUB_SAD_SEARCH */
+    int16_t  hme_sa_width[3], hme_sa_height[3]; /* per level: get_hme_l0_search_area, hme_l1_sa, hme_l2_sa */
+    int16_t  me_sa_min_width, me_sa_min_height, me_sa_max_width, me_sa_max_height;
+    uint8_t  mv_adj_enabled, mv_adj_nearest_ref_only;
+    uint16_t mv_adj_mv_size_th, mv_adj_sa_multiplier;
+    uint16_t dist[8];                    /* as SvtHipMeIntegerSearchParams */
+    uint8_t  ref_pic_index[8];
+    SvtHipMeResultsParams results;       /* formatting parameters (n_sb is filled in by the session) */
+} SvtHipMeStageParams;
+int svt_hip_me_session_enable_stage(void *session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,
+                                    uint32_t max_me_area_height);
+int svt_hip_me_session_submit_stage(void *session, int64_t pic_id, const uint8_t *plane_host, const int64_t *ref_ids, uint32_t n_refs,
+                                    const SvtHipMeStageParams *stage, const SvtHipMeResultsHost *out);
+
 /* ---------------------------------------------------------------- transforms (a10, a12, a13, a14) --- */
 /* TxSize / TxType numbering = Source/Lib/Codec/definitions.h (TX_4X4=0 .. TX_64X16=18; DCT_DCT=0 .. H_FLIPADST=15). */
 typedef struct SvtHipFwdTxfmDesc {

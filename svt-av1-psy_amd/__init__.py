@@ -76,6 +76,8 @@ PROTOTYPES = {
     "svt_hip_me_session_destroy": (None, [vp]),
     "svt_hip_me_session_submit": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
     "svt_hip_me_session_wait": (None, [vp, C.c_int]),
+    "svt_hip_me_session_enable_stage": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "svt_hip_me_session_submit_stage": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, vp, vp]),
     "svt_hip_me_session_submit_results": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
     "svt_hip_me_results_batch": (None, [vp] * 10),
     "svt_hip_me_integer_search_workspace": (C.c_size_t, [vp]),
@@ -220,6 +222,15 @@ assert TfBlock.itemsize == 56
 class TfPlanes(C.Structure):
     """SvtHipTfPlanes: device planes (strides in samples)."""
     _fields_ = [("y", vp), ("u", vp), ("v", vp), ("y_stride", C.c_uint32), ("uv_stride", C.c_uint32)]
+
+
+class MeStageParams(C.Structure):
+    """SvtHipMeStageParams (include/svtav1_hip.h)."""
+    _fields_ = [("num_hme_sa_w", C.c_uint8), ("num_hme_sa_h", C.c_uint8), ("hme_sub_sampled", C.c_uint8), ("me_sub_sad", C.c_uint8),
+                ("hme_sa_width", C.c_int16 * 3), ("hme_sa_height", C.c_int16 * 3), ("me_sa_min_width", C.c_int16), ("me_sa_min_height", C.c_int16),
+                ("me_sa_max_width", C.c_int16), ("me_sa_max_height", C.c_int16), ("mv_adj_enabled", C.c_uint8), ("mv_adj_nearest_ref_only", C.c_uint8),
+                ("mv_adj_mv_size_th", C.c_uint16), ("mv_adj_sa_multiplier", C.c_uint16), ("dist", C.c_uint16 * 8), ("ref_pic_index", C.c_uint8 * 8),
+                ("results", MeResultsParams)]
 
 
 class MeResultsHost(C.Structure):

@@ -18,6 +18,7 @@ struct Slot {
     uint32_t *          sad = nullptr, *mv = nullptr;
     void*               ws    = nullptr;
     uint8_t*            fmt   = nullptr; // formatted results: do_ref | total | cand | pad | mv | stats (see fmt_layout)
+    uint8_t*            hme   = nullptr; // stage form: per level sad (u64) and centres (2 x i16) of every item, then final centre / sad, then workspace
     bool                busy  = false;
 };
 struct Session {
@@ -30,6 +31,11 @@ struct Session {
     std::vector<hipEvent_t> uploaded;    // upload of ring slot r finished
     std::vector<Slot>       slots;
     uint32_t next_ring = 0, next_slot = 0;
+    // stage form (svt_hip_me_session_enable_stage): quarter and sixteenth planes of every ring entry, made on the device right after the upload
+    bool     stage = false;
+    uint32_t lvl_pad[2] = {0, 0}, lvl_stride[2] = {0, 0}, lvl_rows[2] = {0, 0}, max_regions = 0, max_area_w = 0, max_area_h = 0;
+    size_t   lvl_bytes[2] = {0, 0}, hme_items = 0, int_ws = 0;
+    uint8_t* lvl_planes[2] = {nullptr, nullptr}; // [0] quarter, [1] sixteenth: ring x lvl_bytes
 };
 
 // all 64x64 SBs of the picture against n_refs resident planes, search area centred on the co-located block (search centre (0, 0)), exactly the
@@ -125,7 +131,10 @@ void svt_hip_me_session_destroy(void* session) {
         HIP_CHECK(hipFree(sl.descs)); HIP_CHECK(hipFree(sl.sad)); HIP_CHECK(hipFree(sl.mv));
         if (sl.ws) HIP_CHECK(hipFree(sl.ws));
         HIP_CHECK(hipFree(sl.fmt));
+        if (sl.hme) HIP_CHECK(hipFree(sl.hme));
     }
+    for (int k = 0; k < 2; k++)
+        if (s->lvl_planes[k]) HIP_CHECK(hipFree(s->lvl_planes[k]));
     HIP_CHECK(hipFree(s->sb_size));
     for (auto& e : s->uploaded) HIP_CHECK(hipEventDestroy(e));
     HIP_CHECK(hipFree(s->planes));
@@ -134,9 +143,12 @@ void svt_hip_me_session_destroy(void* session) {
 
 static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
                              uint32_t area_h, int sub_sad, uint32_t* best_sad_host, uint32_t* best_mv_host, const SvtHipMeResultsParams* fmt,
-                             const SvtHipMeResultsHost* out) {
+                             const SvtHipMeResultsHost* out, const SvtHipMeStageParams* stage = nullptr) {
     Session* s = (Session*)session;
     if (n_refs > s->max_refs) return -2;
+    if (stage && (!s->stage || n_refs > 8 || (uint32_t)stage->num_hme_sa_w * stage->num_hme_sa_h > s->max_regions ||
+                  stage->num_hme_sa_w == 0 || stage->num_hme_sa_h == 0))
+        return -5;
     if (fmt && ((uint32_t)fmt->num_of_ref_pic_to_search[0] + fmt->num_of_ref_pic_to_search[1] != n_refs || n_refs == 0 || fmt->max_refs > s->max_refs ||
                 fmt->max_cand > s->max_cand))
         return -4;
@@ -167,6 +179,14 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         for (auto& other : s->slots) // searches in flight may still read the plane being replaced
             if (other.busy) HIP_CHECK(hipStreamWaitEvent(sl.st, other.done, 0));
         HIP_CHECK(hipMemcpyAsync(s->planes + (size_t)src_r * s->plane_bytes, plane_host, s->plane_bytes, hipMemcpyHostToDevice, sl.st));
+        if (s->stage) { // quarter from the full picture, sixteenth from the quarter, each with its replicated border (pic_analysis_process.c:2138-2200)
+            const uint8_t* full = s->planes + (size_t)src_r * s->plane_bytes + (size_t)s->org_y * s->stride + s->org_x;
+            uint8_t*       q    = s->lvl_planes[0] + (size_t)src_r * s->lvl_bytes[0];
+            uint8_t*       x    = s->lvl_planes[1] + (size_t)src_r * s->lvl_bytes[1];
+            svt_hip_downsample_2d_padded(full, s->stride, s->width, s->height, q, s->lvl_stride[0], s->lvl_pad[0], s->lvl_pad[0], 2, sl.st);
+            svt_hip_downsample_2d_padded(q + (size_t)s->lvl_pad[0] * s->lvl_stride[0] + s->lvl_pad[0], s->lvl_stride[0], s->width >> 1, s->height >> 1, x,
+                                         s->lvl_stride[1], s->lvl_pad[1], s->lvl_pad[1], 2, sl.st);
+        }
         HIP_CHECK(hipEventRecord(s->uploaded[src_r], sl.st));
         s->ids[src_r] = pic_id;
     } else {
@@ -181,10 +201,57 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
     const uint32_t n = s->sbs * n_refs;
     unsigned long long* d_offs = (unsigned long long*)(sl.descs + (size_t)s->sbs * s->max_refs);
     HIP_CHECK(hipMemcpyAsync(d_offs, offs, n_refs * 8, hipMemcpyHostToDevice, sl.st));
-    hipLaunchKernelGGL(me_build_descs_kernel, dim3((n + 255) / 256), dim3(256), 0, sl.st, sl.descs, (s->width + 63) / 64, s->sbs, n_refs, s->stride, s->org_x, s->org_y,
-                       (unsigned long long)src_r * s->plane_bytes, (const unsigned long long*)d_offs, (int)area_w, (int)area_h);
-    SVT_LAUNCH_CHECK();
-    svt_hip_me_fullpel_search_batch(s->planes, s->planes, sl.descs, n, area_w, area_h, sub_sad, sl.sad, sl.mv, sl.ws, sl.st);
+    if (!stage) {
+        hipLaunchKernelGGL(me_build_descs_kernel, dim3((n + 255) / 256), dim3(256), 0, sl.st, sl.descs, (s->width + 63) / 64, s->sbs, n_refs, s->stride, s->org_x,
+                           s->org_y, (unsigned long long)src_r * s->plane_bytes, (const unsigned long long*)d_offs, (int)area_w, (int)area_h);
+        SVT_LAUNCH_CHECK();
+        svt_hip_me_fullpel_search_batch(s->planes, s->planes, sl.descs, n, area_w, area_h, sub_sad, sl.sad, sl.mv, sl.ws, sl.st);
+    } else { // HME levels 0-2 (one launch) -> final search centre + integer_search_b64 geometry + full-pel search
+        const uint32_t sbs_x = (s->width + 63) / 64, sbs_y = s->sbs / sbs_x, aw = (s->width + 7) & ~7u, ah = (s->height + 7) & ~7u;
+        const uint32_t regions = (uint32_t)stage->num_hme_sa_w * stage->num_hme_sa_h;
+        const size_t   items = (size_t)n_refs * s->sbs * regions;
+        SvtHipHmeLevelParams P[3];
+        const uint8_t*       bases[3] = {s->lvl_planes[1], s->lvl_planes[0], s->planes};
+        unsigned long long*  sads[3];
+        int16_t*             scs[3];
+        uint8_t* hp = sl.hme;
+        for (int lv = 0; lv < 3; lv++) {
+            sads[lv] = (unsigned long long*)hp; hp += svthip::align_up(s->hme_items * 8, 256);
+            scs[lv]  = (int16_t*)hp;            hp += svthip::align_up(s->hme_items * 4, 256);
+        }
+        int16_t*            fin_sc  = (int16_t*)hp;            hp += svthip::align_up((size_t)s->max_refs * s->sbs * 4, 256);
+        unsigned long long* fin_sad = (unsigned long long*)hp; hp += svthip::align_up((size_t)s->max_refs * s->sbs * 8, 256);
+        void*               int_ws  = hp;
+        for (int lv = 0; lv < 3; lv++) {
+            SvtHipHmeLevelParams& L = P[lv];
+            memset(&L, 0, sizeof(L));
+            L.level = (uint8_t)lv; L.sub_sampled = stage->hme_sub_sampled; L.num_hme_sa_w = stage->num_hme_sa_w; L.num_hme_sa_h = stage->num_hme_sa_h;
+            L.sa_width = stage->hme_sa_width[lv]; L.sa_height = stage->hme_sa_height[lv];
+            L.sbs_x = sbs_x; L.sbs_y = sbs_y; L.n_refs = n_refs; L.prev_shift = lv == 1; L.aligned_width = aw; L.aligned_height = ah;
+            const uint32_t stride = lv == 2 ? s->stride : s->lvl_stride[1 - lv], pad_x = lv == 2 ? s->org_x : s->lvl_pad[1 - lv],
+                           pad_y = lv == 2 ? s->org_y : s->lvl_pad[1 - lv];
+            const size_t   pb = lv == 2 ? s->plane_bytes : s->lvl_bytes[1 - lv];
+            L.src_off = (uint64_t)src_r * pb + (uint64_t)pad_y * stride + pad_x;
+            L.src_stride = stride; L.ref_stride = stride; L.ref_org_x = pad_x; L.ref_org_y = pad_y;
+            L.ref_width = s->width >> (2 - lv); L.ref_height = s->height >> (2 - lv);
+            for (uint32_t k = 0; k < n_refs; k++) L.ref_off[k] = (uint64_t)ref_r[k] * pb;
+            HIP_CHECK(hipMemsetAsync(scs[lv], 0, items * 4, sl.st)); // init_me_hme_data leaves the centres at 0
+        }
+        svt_hip_hme_chain_batch(P, bases, bases, (uint64_t* const*)sads, scs, sl.st);
+        SvtHipMeIntegerSearchParams Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.sbs_x = sbs_x; Q.sbs_y = sbs_y; Q.n_refs = n_refs; Q.regions = regions; Q.aligned_width = aw; Q.aligned_height = ah;
+        Q.sa_min_width = stage->me_sa_min_width; Q.sa_min_height = stage->me_sa_min_height;
+        Q.sa_max_width = stage->me_sa_max_width; Q.sa_max_height = stage->me_sa_max_height;
+        Q.sub_sad = stage->me_sub_sad; Q.mv_adj_enabled = stage->mv_adj_enabled; Q.mv_adj_nearest_ref_only = stage->mv_adj_nearest_ref_only;
+        Q.mv_adj_mv_size_th = stage->mv_adj_mv_size_th; Q.mv_adj_sa_multiplier = stage->mv_adj_sa_multiplier;
+        for (uint32_t k = 0; k < n_refs; k++) { Q.dist[k] = stage->dist[k]; Q.ref_pic_index[k] = stage->ref_pic_index[k]; Q.ref_off[k] = (uint64_t)ref_r[k] * s->plane_bytes; }
+        Q.src_off = (uint64_t)src_r * s->plane_bytes + (uint64_t)s->org_y * s->stride + s->org_x;
+        Q.src_stride = s->stride; Q.ref_stride = s->stride; Q.ref_org_x = s->org_x; Q.ref_org_y = s->org_y;
+        if (svt_hip_me_integer_search_workspace(&Q) > s->int_ws) return -5; // areas larger than the session was sized for
+        svt_hip_me_integer_search_batch(&Q, s->planes, s->planes, (const uint64_t*)sads[2], scs[2], nullptr, nullptr, sl.sad, sl.mv, fin_sc, (uint64_t*)fin_sad,
+                                        int_ws, sl.st);
+    }
     if (best_sad_host) HIP_CHECK(hipMemcpyAsync(best_sad_host, sl.sad, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
     if (best_mv_host) HIP_CHECK(hipMemcpyAsync(best_mv_host, sl.mv, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
     if (fmt) { // the stage's final product: MeSbResults + per-SB statistics, formatted on the device from the tables just written
@@ -216,6 +283,39 @@ int svt_hip_me_session_submit(void* session, int64_t pic_id, const uint8_t* plan
 int svt_hip_me_session_submit_results(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
                                       uint32_t area_h, int sub_sad, const SvtHipMeResultsParams* params, const SvtHipMeResultsHost* out) {
     return me_session_submit(session, pic_id, plane_host, ref_ids, n_refs, area_w, area_h, sub_sad, out->best_sad, out->best_mv, params, out);
+}
+
+int svt_hip_me_session_enable_stage(void* session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,
+                                    uint32_t max_me_area_height) {
+    Session* s = (Session*)session;
+    if (s->stage || !max_regions || s->max_refs > 8) return -1;
+    const uint32_t pads[2] = {quarter_pad, sixteenth_pad};
+    for (int k = 0; k < 2; k++) {
+        const uint32_t w = s->width >> (k + 1), h = s->height >> (k + 1);
+        s->lvl_pad[k]    = pads[k];
+        s->lvl_stride[k] = w + 2 * pads[k];
+        s->lvl_rows[k]   = h + 2 * pads[k] + (64u >> (k + 1)); // the last SB row overhangs the picture
+        s->lvl_bytes[k]  = (size_t)s->lvl_stride[k] * s->lvl_rows[k];
+        HIP_CHECK(hipMalloc((void**)&s->lvl_planes[k], s->lvl_bytes[k] * s->ring));
+        HIP_CHECK(hipMemset(s->lvl_planes[k], 0, s->lvl_bytes[k] * s->ring));
+    }
+    s->max_regions = max_regions; s->max_area_w = max_me_area_width; s->max_area_h = max_me_area_height;
+    s->hme_items = (size_t)s->max_refs * s->sbs * max_regions;
+    const size_t n = (size_t)s->sbs * s->max_refs;
+    s->int_ws = svthip::align_up(n * sizeof(SvtHipMeSearchDesc), 256) +
+                svt_hip_me_fullpel_search_workspace((uint32_t)n, (max_me_area_width + 7) & ~7u, max_me_area_height < 3 ? 3 : max_me_area_height);
+    const size_t per_slot = 3 * (svthip::align_up(s->hme_items * 8, 256) + svthip::align_up(s->hme_items * 4, 256)) + svthip::align_up(n * 4, 256) +
+                            svthip::align_up(n * 8, 256) + s->int_ws + 256;
+    for (auto& sl : s->slots) HIP_CHECK(hipMalloc((void**)&sl.hme, per_slot));
+    s->stage = true;
+    return 0;
+}
+int svt_hip_me_session_submit_stage(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs,
+                                    const SvtHipMeStageParams* stage, const SvtHipMeResultsHost* out) {
+    if (!stage) return -5;
+    const bool fmt = n_refs > 0 && out && out->total_me_candidate_index;
+    return me_session_submit(session, pic_id, plane_host, ref_ids, n_refs, 0, 0, 0, out ? out->best_sad : nullptr, out ? out->best_mv : nullptr,
+                             fmt ? &stage->results : nullptr, out, stage);
 }
 
 void svt_hip_me_session_wait(void* session, int slot) {

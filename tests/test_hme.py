@@ -260,3 +260,84 @@ def test_me_integer_search_hip(be, oracle, ci):
                 assert np.array_equal(bs[r, sb], ws_) and np.array_equal(bm[r, sb], wm_), (ci, r, sb, area)
                 checked += 1
     assert checked > 10
+
+
+def test_me_session_stage_from_host_pictures(be, oracle):
+    """The whole open-loop ME stage from host pictures (upload -> decimation -> HME 0-2 -> integer search -> MeSbResults) vs the same chain composed
+    from the oracle's pieces (each pinned against the reference separately)."""
+    import test_me_results as M
+    pkg, g, lib = load_pkg(), rng(2100), be.lib
+    W, H, PAD = (192, 136, 68) if not be.is_gpu else (448, 264, 68)
+    stride, rows = W + 2 * PAD, H + 2 * PAD + 64
+    n_pics, nw, nh = 4, 2, 2
+    base = g.integers(0, 256, (rows + 16, stride + 16), dtype=np.uint8) // 3 + (np.add.outer(np.arange(rows + 16), np.arange(stride + 16)) * 5 % 170).astype(np.uint8)
+    pics = []
+    for k in range(n_pics):
+        a = np.zeros((rows, stride), np.uint8)
+        a[PAD:PAD + H, PAD:PAD + W] = base[8 + k:8 + k + H, 8 + 2 * k:8 + 2 * k + W] + g.integers(0, 4, (H, W), dtype=np.uint8)
+        oracle.oracle_generate_padding(p(a), stride, W, H, PAD, PAD)  # what the encoder hands over: the padded input picture
+        pics.append(a)
+    sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 4, 3, 32, 16, 2)
+    assert lib.svt_hip_me_session_enable_stage(sess, 32, 16, nw * nh, 32, 16) == 0
+    S = pkg.MeStageParams()
+    S.num_hme_sa_w, S.num_hme_sa_h, S.hme_sub_sampled, S.me_sub_sad = nw, nh, 0, 0
+    for lv, (a, b) in enumerate(((16, 8), (8, 3), (8, 3))):
+        S.hme_sa_width[lv], S.hme_sa_height[lv] = a, b
+    S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = 8, 3, 24, 12
+    S.mv_adj_enabled, S.mv_adj_nearest_ref_only, S.mv_adj_mv_size_th, S.mv_adj_sa_multiplier = 1, 1, 4, 2
+    dist, rpi = [1, 2, 3], [0, 1, 0]
+    for r in range(3):
+        S.dist[r], S.ref_pic_index[r] = dist[r], rpi[r]
+    cfg = (2, 2, 1, 1, 1, 0, 0, 1, 30, 40, 0, 1, 1)
+    R = M.make_params(pkg, cfg, 0, g)
+    C.memmove(C.addressof(S.results), C.addressof(R), C.sizeof(R))
+    for k in range(3):
+        assert lib.svt_hip_me_session_submit_stage(sess, k, p(pics[k]), None, 0, C.addressof(S), None) >= 0
+    aw, ah = (W + 7) & ~7, (H + 7) & ~7
+    sbs_x, sbs_y = (aw + 63) // 64, (ah + 63) // 64
+    n_sb = sbs_x * sbs_y
+    out = dict(total=np.full((n_sb, 85), 7, np.uint8), mv=np.full((n_sb, 85 * R.max_refs), 7, np.uint32), cand=np.full((n_sb, 85 * R.max_cand), 7, np.uint8),
+               stats=np.zeros(n_sb, pkg.MeSbStats), bs=np.zeros((3, n_sb, 85), np.uint32), bm=np.zeros((3, n_sb, 85), np.uint32))
+    Hst = pkg.MeResultsHost(None, p(out["total"]), p(out["mv"]), p(out["cand"]), p(out["stats"]), p(out["bs"]), p(out["bm"]))
+    refs = np.array([2, 1, 0], np.int64)  # list 0: pictures 2, 1; list 1: picture 0
+    slot = lib.svt_hip_me_session_submit_stage(sess, 3, p(pics[3]), p(refs), 3, C.addressof(S), C.addressof(Hst))
+    assert slot >= 0
+    lib.svt_hip_me_session_wait(sess, slot)
+    lib.svt_hip_me_session_destroy(sess)
+
+    # ---- the same chain through the oracle
+    def decimate(full):
+        qw, qh, sw, sh = W // 2, H // 2, W // 4, H // 4
+        q = np.zeros((qh + 64 + 32, qw + 64), np.uint8)
+        oracle.oracle_downsample_2d(vp(full, PAD * stride + PAD), stride, W, H, vp(q, 32 * (qw + 64) + 32), qw + 64, 2)
+        oracle.oracle_generate_padding(p(q), qw + 64, qw, qh, 32, 32)
+        x = np.zeros((sh + 32 + 16, sw + 32), np.uint8)
+        oracle.oracle_downsample_2d(vp(q, 32 * (qw + 64) + 32), qw + 64, qw, qh, vp(x, 16 * (sw + 32) + 16), sw + 32, 2)
+        oracle.oracle_generate_padding(p(x), sw + 32, sw, sh, 16, 16)
+        return {2: full, 1: q, 0: x}
+    lv_planes = [decimate(pc) for pc in pics]
+    order = [2, 1, 0]
+    n_items = 3 * n_sb * nw * nh
+    prev = np.zeros((n_items, 2), np.int16)
+    for lv in (0, 1, 2):
+        sh_ = 2 - lv
+        org = {0: 16, 1: 32, 2: PAD}[lv]
+        src = lv_planes[3][lv]
+        rf = [lv_planes[i][lv] for i in order]
+        pin = prev >> 1 if lv == 1 else prev
+        sad, prev = cpu_level(oracle.oracle_hme_level, lv, 0, nw, nh, src, rf, W >> sh_, H >> sh_, org, src.shape[1], W, H, S.hme_sa_width[lv], S.hme_sa_height[lv], pin)
+    sad = sad.reshape(3 * n_sb, nw * nh)
+    sc = prev.reshape(3 * n_sb, nw * nh, 2)
+    want_bs, want_bm = np.zeros((3, n_sb, 85), np.uint32), np.zeros((3, n_sb, 85), np.uint32)
+    for r in range(3):
+        Q = int_params(dict(sa=(8, 3, 24, 12), dist=dist[r], adj=(1, 1, 4, 2), r=rpi[r], sub=0, div=1))
+        for sb in range(n_sb):
+            i = r * n_sb + sb
+            o_sc, o_sad, area = np.zeros(2, np.int16), C.c_uint64(0), np.zeros(4, np.int16)
+            oracle.oracle_me_integer_search(C.byref(Q), nw * nh, p(sad[i]), p(sc[i]), p(pics[3]), stride, PAD, PAD, p(pics[order[r]]), stride, PAD, PAD,
+                                            (sb % sbs_x) * 64, (sb // sbs_x) * 64, aw, ah, p(o_sc), C.byref(o_sad), p(area), vp(want_bs[r, sb]), vp(want_bm[r, sb]))
+    assert np.array_equal(out["bs"], want_bs) and np.array_equal(out["bm"], want_bm)
+    sb_size = np.array([[min(64, aw - 64 * (i % sbs_x)), min(64, ah - 64 * (i // sbs_x))] for i in range(n_sb)], np.uint8)
+    R.n_sb = n_sb
+    want = M.run_cpu(oracle.oracle_me_results_sb, pkg, R, cfg, want_bs, want_bm, np.ones((n_sb, 2, 4), np.uint8), sb_size, 0)
+    M.same(want, (out["total"], out["mv"], out["cand"], out["stats"], None), "stage session")

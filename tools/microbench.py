@@ -47,6 +47,8 @@ def main():
             out.update(bench_legs.hme_chain(torch, lib, pkg, stream, a.steps, a.warmup))
         elif leg == "mestage":
             out.update(bench_legs.me_stage(torch, lib, pkg, stream, a.steps, a.warmup))
+        elif leg == "mesessionstage":
+            out.update(bench_legs.me_session_stage(torch, lib, pkg, stream, a.steps, a.warmup))
         elif leg == "tf":
             out.update(bench_legs.tf_frames(torch, lib, pkg, stream, a.steps, a.warmup))
         elif leg == "meresults":
