@@ -181,3 +181,114 @@ void ref_me_integer_search(const RefIntSearch *P, int num_sa_w, int num_sa_h, co
     memcpy(best_sad, ctx->p_sb_best_sad[l][r], 85 * 4);
     memcpy(best_mv, ctx->p_sb_best_mv[l][r], 85 * 4);
 }
+
+/* The reference's TOP-LEVEL open-loop ME of one SB: svt_aom_motion_estimation_b64 (motion_estimation.c:3076-3152) = hme_b64 -> reference pruning ->
+ * integer_search_b64 -> me_prune_ref -> construct_me_candidate_array* -> compute_distortion -> GM detection, with the per-SB set-up of
+ * me_process.c:183-266.  Everything enters through plain structs; used to pin the device stage end to end. */
+typedef struct RefPlane { uint8_t *buf; uint32_t stride, org_x, org_y, width, height; } RefPlane; /* buffer_y[0] of a padded plane */
+typedef struct RefPicture { RefPlane lvl[3]; /* [0] sixteenth, [1] quarter, [2] full */ uint64_t picture_number; } RefPicture;
+typedef struct RefMeStageOptions {
+    uint8_t  num_hme_sa_w, num_hme_sa_h, hme_sub_sampled, me_sub_sad;
+    uint16_t hme_l0_min_w, hme_l0_min_h, hme_l0_max_w, hme_l0_max_h; /* TOTAL level-0 area (hme_l0_sa) */
+    uint16_t hme_l1_w, hme_l1_h, hme_l2_w, hme_l2_h;
+    uint16_t me_min_w, me_min_h, me_max_w, me_max_h;
+    uint8_t  mv_adj_enabled, mv_adj_nearest_ref_only; uint16_t mv_adj_mv_size_th, mv_adj_sa_multiplier;
+    uint8_t  temporal_layer_index, is_ref;
+    uint32_t me_early_exit_th;
+    uint8_t  sr_adjustment, me_8x8_var_enabled; uint32_t me_sr_div4_th, me_sr_div2_th, me_sr_mult2_th;
+    uint8_t  hme_prune_enabled; uint16_t prune_ref_if_hme_sad_dev_bigger_than_th;
+    uint16_t reduce_me_sr_based_on_mv_length_th, stationary_hme_sad_abs_th, stationary_me_sr_divisor, reduce_me_sr_based_on_hme_sad_abs_th,
+             me_sr_divisor_for_low_hme_sad;
+    uint8_t  distance_based_hme_resizing;
+} RefMeStageOptions;
+void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsParams *P, const RefPicture *src, const RefPicture *refs /*[2][4]*/,
+                               int pic_width, int pic_height, int b64_origin_x, int b64_origin_y, uint8_t *total_me_candidate_index,
+                               uint32_t *me_mv_array, uint8_t *me_candidate_array, RefMeSbStats *st, uint32_t *best_sad /*[2][4][85]*/,
+                               uint32_t *best_mv, uint8_t *do_ref_out /*[2][4]*/) {
+    static PictureParentControlSet *pcs;
+    static SequenceControlSet      *scs;
+    static MeContext               *ctx;
+    static MotionEstimationData    *med;
+    static MeSbResults             *res, *res_tab[1];
+    static B64Geom                  geom;
+    static uint32_t                 u32s[6];
+    static uint8_t                  u8s[2];
+    static EbPictureBufferDesc      pics[1 + 8][3];
+    if (!pcs) {
+        pcs = calloc(1, sizeof(*pcs)); scs = calloc(1, sizeof(*scs)); ctx = calloc(1, sizeof(*ctx)); med = calloc(1, sizeof(*med)); res = calloc(1, sizeof(*res));
+    }
+    memset(ctx, 0, sizeof(*ctx));
+    pcs->scs = scs; pcs->pa_me_data = med; res_tab[0] = res; med->me_results = res_tab;
+    med->max_cand = P->max_cand; med->max_refs = P->max_refs; med->max_l0 = P->max_l0;
+    res->total_me_candidate_index = total_me_candidate_index; res->me_mv_array = (MvCandidate *)me_mv_array; res->me_candidate_array = (MeCandidate *)me_candidate_array;
+    pcs->enable_me_16x16 = P->enable_me_16x16; pcs->enable_me_8x8 = P->enable_me_8x8; pcs->max_number_of_pus_per_sb = SQUARE_PU_COUNT;
+    scs->mrp_ctrls.only_l_bwd = P->only_l_bwd;
+    scs->input_resolution = P->low_resolution ? INPUT_SIZE_480p_RANGE : INPUT_SIZE_1080p_RANGE;
+    pcs->aligned_width = (uint16_t)((pic_width + 7) & ~7); pcs->aligned_height = (uint16_t)((pic_height + 7) & ~7);
+    geom.width  = (uint8_t)((pcs->aligned_width - b64_origin_x) < 64 ? pcs->aligned_width - b64_origin_x : 64);
+    geom.height = (uint8_t)((pcs->aligned_height - b64_origin_y) < 64 ? pcs->aligned_height - b64_origin_y : 64);
+    pcs->b64_geom = &geom;
+    pcs->me_64x64_distortion = &u32s[0]; pcs->me_32x32_distortion = &u32s[1]; pcs->me_16x16_distortion = &u32s[2];
+    pcs->me_8x8_distortion = &u32s[3]; pcs->me_8x8_cost_variance = &u32s[4]; pcs->rc_me_distortion = &u32s[5];
+    pcs->stationary_block_present_sb = &u8s[0]; pcs->rc_me_allow_gm = &u8s[1];
+    pcs->gm_ctrls.enabled = P->gm_enabled; pcs->gm_ctrls.use_distance_based_active_th = P->gm_use_distance_based_active_th;
+    pcs->picture_number = src->picture_number;
+#define FILL(dst, pl) do { memset(&(dst), 0, sizeof(dst)); (dst).buffer_y = (pl).buf; (dst).stride_y = (uint16_t)(pl).stride; (dst).org_x = (uint16_t)(pl).org_x; \
+                           (dst).org_y = (uint16_t)(pl).org_y; (dst).width = (uint16_t)(pl).width; (dst).height = (uint16_t)(pl).height; } while (0)
+    for (int k = 0; k < 3; k++) FILL(pics[0][k], src->lvl[k]);
+    ctx->me_type = ME_OPEN_LOOP;
+    ctx->num_of_list_to_search = P->num_of_list_to_search;
+    ctx->num_of_ref_pic_to_search[0] = P->num_of_ref_pic_to_search[0]; ctx->num_of_ref_pic_to_search[1] = P->num_of_ref_pic_to_search[1];
+    ctx->temporal_layer_index = O->temporal_layer_index; ctx->is_ref = O->is_ref;
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < 4; r++) {
+            const RefPicture *rp = &refs[l * 4 + r];
+            if (!rp->lvl[2].buf) continue;
+            for (int k = 0; k < 3; k++) FILL(pics[1 + l * 4 + r][k], rp->lvl[k]);
+            ctx->me_ds_ref_array[l][r].sixteenth_picture_ptr = &pics[1 + l * 4 + r][0];
+            ctx->me_ds_ref_array[l][r].quarter_picture_ptr   = &pics[1 + l * 4 + r][1];
+            ctx->me_ds_ref_array[l][r].picture_ptr           = &pics[1 + l * 4 + r][2];
+            ctx->me_ds_ref_array[l][r].picture_number        = rp->picture_number;
+        }
+    /* per-SB set-up of me_process.c:196-215 */
+    ctx->b64_src_ptr = pics[0][2].buffer_y + (pics[0][2].org_y + b64_origin_y) * pics[0][2].stride_y + pics[0][2].org_x + b64_origin_x;
+    ctx->b64_src_stride = pics[0][2].stride_y;
+    ctx->quarter_b64_buffer = pics[0][1].buffer_y + (pics[0][1].org_y + (b64_origin_y >> 1)) * pics[0][1].stride_y + pics[0][1].org_x + (b64_origin_x >> 1);
+    ctx->quarter_b64_buffer_stride = pics[0][1].stride_y;
+    ctx->sixteenth_b64_buffer = pics[0][0].buffer_y + (pics[0][0].org_y + (b64_origin_y >> 2)) * pics[0][0].stride_y + pics[0][0].org_x + (b64_origin_x >> 2);
+    ctx->sixteenth_b64_buffer_stride = pics[0][0].stride_y;
+    ctx->enable_hme_flag = 1; ctx->enable_hme_level0_flag = 1; ctx->enable_hme_level1_flag = 1; ctx->enable_hme_level2_flag = 1;
+    ctx->num_hme_sa_w = O->num_hme_sa_w; ctx->num_hme_sa_h = O->num_hme_sa_h;
+    ctx->hme_search_method = O->hme_sub_sampled ? SUB_SAD_SEARCH : FULL_SAD_SEARCH;
+    ctx->me_search_method  = O->me_sub_sad ? SUB_SAD_SEARCH : FULL_SAD_SEARCH;
+    ctx->hme_l0_sa.sa_min.width = O->hme_l0_min_w; ctx->hme_l0_sa.sa_min.height = O->hme_l0_min_h;
+    ctx->hme_l0_sa.sa_max.width = O->hme_l0_max_w; ctx->hme_l0_sa.sa_max.height = O->hme_l0_max_h;
+    ctx->hme_l1_sa.width = O->hme_l1_w; ctx->hme_l1_sa.height = O->hme_l1_h; ctx->hme_l2_sa.width = O->hme_l2_w; ctx->hme_l2_sa.height = O->hme_l2_h;
+    ctx->me_sa.sa_min.width = O->me_min_w; ctx->me_sa.sa_min.height = O->me_min_h; ctx->me_sa.sa_max.width = O->me_max_w; ctx->me_sa.sa_max.height = O->me_max_h;
+    ctx->mv_based_sa_adj.enabled = O->mv_adj_enabled; ctx->mv_based_sa_adj.nearest_ref_only = O->mv_adj_nearest_ref_only;
+    ctx->mv_based_sa_adj.mv_size_th = O->mv_adj_mv_size_th; ctx->mv_based_sa_adj.sa_multiplier = O->mv_adj_sa_multiplier;
+    ctx->me_early_exit_th = O->me_early_exit_th;
+    ctx->me_sr_adjustment_ctrls.enable_me_sr_adjustment = O->sr_adjustment;
+    ctx->me_sr_adjustment_ctrls.distance_based_hme_resizing = O->distance_based_hme_resizing;
+    ctx->me_sr_adjustment_ctrls.reduce_me_sr_based_on_mv_length_th = O->reduce_me_sr_based_on_mv_length_th;
+    ctx->me_sr_adjustment_ctrls.stationary_hme_sad_abs_th = O->stationary_hme_sad_abs_th;
+    ctx->me_sr_adjustment_ctrls.stationary_me_sr_divisor = O->stationary_me_sr_divisor;
+    ctx->me_sr_adjustment_ctrls.reduce_me_sr_based_on_hme_sad_abs_th = O->reduce_me_sr_based_on_hme_sad_abs_th;
+    ctx->me_sr_adjustment_ctrls.me_sr_divisor_for_low_hme_sad = O->me_sr_divisor_for_low_hme_sad;
+    ctx->me_8x8_var_ctrls.enabled = O->me_8x8_var_enabled; ctx->me_8x8_var_ctrls.me_sr_div4_th = O->me_sr_div4_th;
+    ctx->me_8x8_var_ctrls.me_sr_div2_th = O->me_sr_div2_th; ctx->me_8x8_var_ctrls.me_sr_mult2_th = O->me_sr_mult2_th;
+    ctx->me_hme_prune_ctrls.enable_me_hme_ref_pruning = O->hme_prune_enabled || P->prune_ref;
+    ctx->me_hme_prune_ctrls.prune_ref_if_hme_sad_dev_bigger_than_th = O->hme_prune_enabled ? O->prune_ref_if_hme_sad_dev_bigger_than_th : (uint16_t)~0;
+    ctx->me_hme_prune_ctrls.prune_ref_if_me_sad_dev_bigger_than_th  = P->prune_ref ? P->prune_ref_if_me_sad_dev_bigger_than_th : (uint16_t)~0;
+    ctx->prune_me_candidates_th = P->prune_me_candidates_th;
+    ctx->use_best_unipred_cand_only = P->use_best_unipred_cand_only;
+    svt_aom_motion_estimation_b64(pcs, 0, (uint32_t)b64_origin_x, (uint32_t)b64_origin_y, ctx, &pics[0][2]);
+    st->me_64x64_distortion = u32s[0]; st->me_32x32_distortion = u32s[1]; st->me_16x16_distortion = u32s[2];
+    st->me_8x8_distortion = u32s[3]; st->me_8x8_cost_variance = u32s[4]; st->rc_me_distortion = u32s[5];
+    st->stationary_block_present_sb = u8s[0]; st->rc_me_allow_gm = u8s[1]; st->pad[0] = st->pad[1] = 0;
+    memcpy(best_sad, ctx->p_sb_best_sad, sizeof(ctx->p_sb_best_sad));
+    memcpy(best_mv, ctx->p_sb_best_mv, sizeof(ctx->p_sb_best_mv));
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < 4; r++) do_ref_out[l * 4 + r] = ctx->search_results[l][r].do_ref;
+#undef FILL
+}

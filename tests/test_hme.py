@@ -341,3 +341,126 @@ def test_me_session_stage_from_host_pictures(be, oracle):
     R.n_sb = n_sb
     want = M.run_cpu(oracle.oracle_me_results_sb, pkg, R, cfg, want_bs, want_bm, np.ones((n_sb, 2, 4), np.uint8), sb_size, 0)
     M.same(want, (out["total"], out["mv"], out["cand"], out["stats"], None), "stage session")
+
+
+# ------------------------------------------------------ the device stage vs the reference's TOP-LEVEL svt_aom_motion_estimation_b64, SB by SB
+class RefPlane(C.Structure):
+    _fields_ = [("buf", C.c_void_p), ("stride", C.c_uint32), ("org_x", C.c_uint32), ("org_y", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class RefPicture(C.Structure):
+    _fields_ = [("lvl", RefPlane * 3), ("picture_number", C.c_uint64)]
+
+
+class RefMeStageOptions(C.Structure):
+    _fields_ = [("num_hme_sa_w", C.c_uint8), ("num_hme_sa_h", C.c_uint8), ("hme_sub_sampled", C.c_uint8), ("me_sub_sad", C.c_uint8),
+                ("hme_l0_min_w", C.c_uint16), ("hme_l0_min_h", C.c_uint16), ("hme_l0_max_w", C.c_uint16), ("hme_l0_max_h", C.c_uint16),
+                ("hme_l1_w", C.c_uint16), ("hme_l1_h", C.c_uint16), ("hme_l2_w", C.c_uint16), ("hme_l2_h", C.c_uint16),
+                ("me_min_w", C.c_uint16), ("me_min_h", C.c_uint16), ("me_max_w", C.c_uint16), ("me_max_h", C.c_uint16),
+                ("mv_adj_enabled", C.c_uint8), ("mv_adj_nearest_ref_only", C.c_uint8), ("mv_adj_mv_size_th", C.c_uint16), ("mv_adj_sa_multiplier", C.c_uint16),
+                ("temporal_layer_index", C.c_uint8), ("is_ref", C.c_uint8), ("me_early_exit_th", C.c_uint32),
+                ("sr_adjustment", C.c_uint8), ("me_8x8_var_enabled", C.c_uint8), ("me_sr_div4_th", C.c_uint32), ("me_sr_div2_th", C.c_uint32),
+                ("me_sr_mult2_th", C.c_uint32), ("hme_prune_enabled", C.c_uint8), ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16),
+                ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16), ("stationary_me_sr_divisor", C.c_uint16),
+                ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("distance_based_hme_resizing", C.c_uint8)]
+
+
+def scaled_distance(d):  # svt_aom_get_scaled_picture_distance (motion_estimation.c:1239-1243)
+    return d * 5 // 8 + (1 if d % 8 else 0)
+
+
+def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref):
+    """End to end: host pictures -> svt_hip_me_session_submit_stage vs the reference's own svt_aom_motion_estimation_b64 run on every SB (HME 0-2,
+    final centre, integer search, reference pruning on ME SADs, MeSbResults, distortion statistics, GM flags); probes / early exits off."""
+    if not os.path.exists(REF_ME_LIB):
+        pytest.skip("oracle/_ref/libsvtref_me.so not available")
+    import test_me_results as M
+    refme = C.CDLL(REF_ME_LIB)
+    ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))
+    ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
+    pkg, g, lib = load_pkg(), rng(2200), be.lib
+    W, H, PAD = (192, 136, 68) if not be.is_gpu else (448, 264, 68)
+    stride, rows = W + 2 * PAD, H + 2 * PAD + 64
+    nw, nh = 2, 2
+    base = g.integers(0, 256, (rows + 16, stride + 16), dtype=np.uint8) // 3 + (np.add.outer(np.arange(rows + 16), np.arange(stride + 16)) * 5 % 170).astype(np.uint8)
+    pics = []
+    for k in range(4):
+        a = np.zeros((rows, stride), np.uint8)
+        a[PAD:PAD + H, PAD:PAD + W] = base[8 + k:8 + k + H, 8 + 2 * k:8 + 2 * k + W] + g.integers(0, 4, (H, W), dtype=np.uint8)
+        oracle.oracle_generate_padding(p(a), stride, W, H, PAD, PAD)
+        pics.append(a)
+    numbers = {0: 41, 1: 38, 2: 39, 3: 40}  # picture 3 is the source; list 0 = pictures 2, 1 (past), list 1 = picture 0 (future)
+    order = [2, 1, 0]
+    dist = [scaled_distance(abs(numbers[3] - numbers[i])) for i in order]
+    sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 4, 3, 48, 24, 2)
+    assert lib.svt_hip_me_session_enable_stage(sess, 32, 16, nw * nh, 48, 24) == 0
+    S = pkg.MeStageParams()
+    S.num_hme_sa_w, S.num_hme_sa_h, S.hme_sub_sampled, S.me_sub_sad = nw, nh, 0, 0
+    for lv, (a, b) in enumerate(((16, 8), (8, 3), (8, 3))):
+        S.hme_sa_width[lv], S.hme_sa_height[lv] = a, b
+    S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = 8, 3, 24, 12
+    S.mv_adj_enabled, S.mv_adj_nearest_ref_only, S.mv_adj_mv_size_th, S.mv_adj_sa_multiplier = 1, 1, 4, 2
+    rpi = [0, 1, 0]
+    for r in range(3):
+        S.dist[r], S.ref_pic_index[r] = dist[r], rpi[r]
+    cfg = (2, 2, 1, 1, 1, 0, 0, 1, 30, 40, 0, 1, 1)
+    R = M.make_params(pkg, cfg, 0, g)
+    R.picture_number = numbers[3]
+    for r in range(2):
+        R.ref_picture_number[0][r] = numbers[order[r]]
+    R.ref_picture_number[1][0] = numbers[order[2]]
+    C.memmove(C.addressof(S.results), C.addressof(R), C.sizeof(R))
+    for k in range(3):
+        assert lib.svt_hip_me_session_submit_stage(sess, k, p(pics[k]), None, 0, C.addressof(S), None) >= 0
+    aw, ah = (W + 7) & ~7, (H + 7) & ~7
+    sbs_x, sbs_y = (aw + 63) // 64, (ah + 63) // 64
+    n_sb = sbs_x * sbs_y
+    out = dict(total=np.zeros((n_sb, 85), np.uint8), mv=np.zeros((n_sb, 85 * R.max_refs), np.uint32), cand=np.zeros((n_sb, 85 * R.max_cand), np.uint8),
+               stats=np.zeros(n_sb, pkg.MeSbStats), bs=np.zeros((3, n_sb, 85), np.uint32), bm=np.zeros((3, n_sb, 85), np.uint32),
+               do_ref=np.ones((n_sb, 2, 4), np.uint8))
+    Hst = pkg.MeResultsHost(p(out["do_ref"]), p(out["total"]), p(out["mv"]), p(out["cand"]), p(out["stats"]), p(out["bs"]), p(out["bm"]))
+    slot = lib.svt_hip_me_session_submit_stage(sess, 3, p(pics[3]), p(np.array(order, np.int64)), 3, C.addressof(S), C.addressof(Hst))
+    assert slot >= 0
+    lib.svt_hip_me_session_wait(sess, slot)
+    lib.svt_hip_me_session_destroy(sess)
+
+    # ---- the reference, SB by SB, on planes decimated by the (pinned) oracle
+    def decimate(full):
+        qw, qh, sw, sh = W // 2, H // 2, W // 4, H // 4
+        q = np.zeros((qh + 64 + 32, qw + 64), np.uint8)
+        oracle.oracle_downsample_2d(vp(full, PAD * stride + PAD), stride, W, H, vp(q, 32 * (qw + 64) + 32), qw + 64, 2)
+        oracle.oracle_generate_padding(p(q), qw + 64, qw, qh, 32, 32)
+        x = np.zeros((sh + 32 + 16, sw + 32), np.uint8)
+        oracle.oracle_downsample_2d(vp(q, 32 * (qw + 64) + 32), qw + 64, qw, qh, vp(x, 16 * (sw + 32) + 16), sw + 32, 2)
+        oracle.oracle_generate_padding(p(x), sw + 32, sw, sh, 16, 16)
+        return [x, q, full]
+    lv = [decimate(pc) for pc in pics]
+
+    def picture(i):
+        P_ = RefPicture()
+        for k, (o, sh_) in enumerate(((16, 2), (32, 1), (PAD, 0))):
+            a = lv[i][k]
+            P_.lvl[k] = RefPlane(a.ctypes.data, a.shape[1], o, o, W >> sh_, H >> sh_)
+        P_.picture_number = numbers[i]
+        return P_
+    refs = (RefPicture * 8)()
+    refs[0], refs[1], refs[4] = picture(2), picture(1), picture(0)
+    srcp = picture(3)
+    O = RefMeStageOptions()
+    O.num_hme_sa_w, O.num_hme_sa_h = nw, nh
+    O.hme_l0_min_w = O.hme_l0_max_w = 32
+    O.hme_l0_min_h = O.hme_l0_max_h = 16
+    O.hme_l1_w, O.hme_l1_h, O.hme_l2_w, O.hme_l2_h = 8, 3, 8, 3
+    O.me_min_w, O.me_min_h, O.me_max_w, O.me_max_h = 8, 3, 24, 12
+    O.mv_adj_enabled, O.mv_adj_nearest_ref_only, O.mv_adj_mv_size_th, O.mv_adj_sa_multiplier = 1, 1, 4, 2
+    O.temporal_layer_index, O.is_ref = 1, 0
+    for sb in range(n_sb):
+        tot, mvs, cands = np.zeros(85, np.uint8), np.zeros(85 * R.max_refs, np.uint32), np.zeros(85 * R.max_cand, np.uint8)
+        st, bs, bm, dr = np.zeros(1, pkg.MeSbStats), np.zeros((2, 4, 85), np.uint32), np.zeros((2, 4, 85), np.uint32), np.zeros((2, 4), np.uint8)
+        refme.ref_motion_estimation_b64(C.byref(O), C.byref(R), C.byref(srcp), C.byref(refs), W, H, (sb % sbs_x) * 64, (sb // sbs_x) * 64, p(tot), p(mvs), p(cands),
+                                        p(st), p(bs), p(bm), p(dr))
+        for r, (l, ri) in enumerate(((0, 0), (0, 1), (1, 0))):
+            assert np.array_equal(out["bs"][r, sb], bs[l, ri]) and np.array_equal(out["bm"][r, sb], bm[l, ri]), ("tables", sb, r)
+        assert np.array_equal(out["do_ref"][sb, 0, :2], dr[0, :2]) and out["do_ref"][sb, 1, 0] == dr[1, 0], ("do_ref", sb)
+        assert np.array_equal(out["total"][sb], tot) and np.array_equal(out["cand"][sb], cands) and np.array_equal(out["mv"][sb], mvs), ("MeSbResults", sb)
+        assert out["stats"][sb] == st[0], ("stats", sb, out["stats"][sb], st[0])
