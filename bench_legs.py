@@ -541,7 +541,7 @@ def hme_chain(torch, lib, pkg, stream, steps, warmup):
     def fn():
         prev = zero
         for (P, planes, ws, sad, sc) in stages:
-            lib.svt_hip_hme_level_batch(C.addressof(P), planes.data_ptr(), planes.data_ptr(), prev.data_ptr(), sad.data_ptr(), sc.data_ptr(), ws.data_ptr(),
+            lib.svt_hip_hme_level_batch(C.addressof(P), planes.data_ptr(), planes.data_ptr(), prev.data_ptr(), None, sad.data_ptr(), sc.data_ptr(), ws.data_ptr(),
                                         stream)
             prev = sc
     t = _time(torch, fn, steps, warmup)
@@ -549,7 +549,7 @@ def hme_chain(torch, lib, pkg, stream, steps, warmup):
     pl = (C.c_void_p * 3)(*[st[1].data_ptr() for st in stages])
     sp = (C.c_void_p * 3)(*[st[3].data_ptr() for st in stages])
     cp = (C.c_void_p * 3)(*[st[4].data_ptr() for st in stages])
-    tf = _time(torch, lambda: lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(pl), C.addressof(pl), C.addressof(sp), C.addressof(cp), stream), steps, warmup)
+    tf = _time(torch, lambda: lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(pl), C.addressof(pl), None, C.addressof(sp), C.addressof(cp), stream), steps, warmup)
     return {"hme_3level_1080p_4refs": {"us_per_picture": tf * 1e6, "pictures_per_s": 1 / tf, "searches_per_level": n, "launches": 1,
                                        "us_per_picture_level_by_level": t * 1e6,
                                        "note": "level 0: 2x2 regions of 16x16 on 1/16-area planes; levels 1, 2: 8x3; one fused launch vs three level calls"}}
@@ -616,8 +616,8 @@ def me_stage(torch, lib, pkg, stream, steps, warmup):
     def run(st_):
         lib.svt_hip_downsample_2d_padded(full, geo[2][3], W, H, bufs[1].data_ptr(), geo[1][3], geo[1][2], geo[1][2], 2, st_)
         lib.svt_hip_downsample_2d_padded(full, geo[2][3], W, H, bufs[0].data_ptr(), geo[0][3], geo[0][2], geo[0][2], 4, st_)
-        lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(pl), C.addressof(pl), C.addressof(sp), C.addressof(cp), st_)
-        lib.svt_hip_me_integer_search_batch(C.addressof(Q), bufs[2].data_ptr(), bufs[2].data_ptr(), hp[2][2].data_ptr(), hp[2][3].data_ptr(), None, None,
+        lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(pl), C.addressof(pl), None, C.addressof(sp), C.addressof(cp), st_)
+        lib.svt_hip_me_integer_search_batch(C.addressof(Q), bufs[2].data_ptr(), bufs[2].data_ptr(), hp[2][2].data_ptr(), hp[2][3].data_ptr(), None, None, None,
                                             bs.data_ptr(), bm.data_ptr(), sco.data_ptr(), sado.data_ptr(), ws_i.data_ptr(), st_)
         lib.svt_hip_me_results_batch(C.addressof(R), bs.data_ptr(), bm.data_ptr(), do_ref.data_ptr(), sz.data_ptr(), tot.data_ptr(), mvs.data_ptr(),
                                      cands.data_ptr(), st.data_ptr(), st_)

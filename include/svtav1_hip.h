@@ -175,15 +175,20 @@ typedef struct SvtHipHmeLevelParams {
     uint32_t src_stride;
     uint32_t ref_stride, ref_org_x, ref_org_y, ref_width, ref_height; /* EbPictureBufferDesc of the references at this resolution */
     uint64_t ref_off[8];             /* buffer_y[0] of each reference, from ref_base */
+    uint8_t  per_ref_area;           /* 1: level-0 areas differ per reference (get_hme_l0_search_area, :1800-1866): use sa_*_ref[ref] instead of sa_width / sa_height */
+    uint8_t  pad1[3];
+    int16_t  sa_width_ref[8], sa_height_ref[8];
+    uint32_t zz_skip_th;             /* me_early_exit_th >> 2 (0 = off): items whose zero-motion SAD zz_sad[ref][sb] is below it skip the level with centre (0, 0) and SAD 0 (hme_level0_b64 :1922-1935, hme_level1_b64 :2057-2070; never applied at level 2) */
 } SvtHipHmeLevelParams;
 size_t svt_hip_hme_level_workspace(const SvtHipHmeLevelParams *params);
 void   svt_hip_hme_level_batch(const SvtHipHmeLevelParams *params, const uint8_t *src_base, const uint8_t *ref_base, const int16_t *prev_sc,
-                               uint64_t *sad_out, int16_t *sc_out, void *workspace, void *stream);
+                               const uint32_t *zz_sad, uint64_t *sad_out, int16_t *sc_out, void *workspace, void *stream);
 /* Levels 0, 1 and 2 of every item in ONE launch (one wave walks an item through the three levels: level N+1 only needs level N's result of the same
  * item).  params[3] = the three levels (same n_refs / SB grid / regions; params[1].prev_shift = 1); src_base / ref_base / sad_out / sc_out: one
- * pointer per level; results identical to three svt_hip_hme_level_batch calls.  sc_out[lv] is in/out like there. */
+ * pointer per level; results identical to three svt_hip_hme_level_batch calls.  sc_out[lv] is in/out like there.  zz_sad (device, [ref][sb], or NULL):
+ * see zz_skip_th. */
 void   svt_hip_hme_chain_batch(const SvtHipHmeLevelParams *params, const uint8_t *const *src_base, const uint8_t *const *ref_base,
-                               uint64_t *const *sad_out, int16_t *const *sc_out, void *stream);
+                               const uint32_t *zz_sad, uint64_t *const *sad_out, int16_t *const *sc_out, void *stream);
 
 /* Integer ME of a whole picture from its HME results = set_final_seach_centre_sb (motion_estimation.c:2182-2368: per (reference, SB) the first
  * strictly smallest SAD over the search regions) + integer_search_b64's search-area geometry (:1294-1325, :1458-1508: min(sa_min * dist, sa_max),
@@ -191,8 +196,10 @@ void   svt_hip_hme_chain_batch(const SvtHipHmeLevelParams *params, const uint8_t
  * picture + 63-sample border) + svt_hip_me_fullpel_search_batch.  Covers the option set without content-dependent probes (me_early_exit_th = 0,
  * is_ref = 0, me_sr_adjustment < 2, me_8x8_var off), which need a pre-search per SB and stay with the caller.
  * hme_sad / hme_sc: the last HME level's outputs in svt_hip_hme_level_batch's item order ((ref * n_sb + sb) * regions + region).
- * do_ref ([n_sb][n_refs], or NULL = all) : a 0 entry gets a 1 x 1 placeholder search whose results must be ignored (the reference skips the
- * reference picture, :1292-1293).  divisor ([n_sb][n_refs] uint32, or NULL = 1) = me_ctx->reduce_me_sr_divisor.
+ * do_ref ([n_sb][2][4] = search_results[list][ref].do_ref as svt_hip_me_results_batch takes it, or NULL = all; in/out: HME-based pruning clears entries): a 0 entry gets a 1 x 1 placeholder search whose results must
+ * be ignored (the reference skips the reference picture, :1292-1293).  divisor ([n_sb][n_refs] uint32, or NULL = 1) = me_ctx->reduce_me_sr_divisor
+ * as an input when sr_adjustment = 0; with sr_adjustment = 1 it is derived from the HME results (and written back when non-NULL).
+ * zz_sad ([ref][sb], needed when me_early_exit_th != 0): svt_hip_me_zz_sad_batch.
  * Outputs: best_sad / best_mv [ref][sb][85] (as svt_hip_me_fullpel_search_batch), sc_out [ref][sb][2] + sad_out [ref][sb] = search_results[].hme_sc_x/y,
  * hme_sad. */
 typedef struct SvtHipMeIntegerSearchParams {
@@ -210,11 +217,24 @@ typedef struct SvtHipMeIntegerSearchParams {
     uint32_t src_stride;
     uint32_t ref_stride, ref_org_x, ref_org_y;
     uint64_t ref_off[8];                      /* buffer_y[0] of each reference, from ref_base */
+    /* hme_prune_ref_and_adjust_sr (:2477-2518), between the final centres and the search: */
+    uint8_t  n_refs_list0;                    /* slots [0, n_refs_list0) are list 0 */
+    uint8_t  hme_prune_enabled;               /* me_hme_prune_ctrls.enable_me_hme_ref_pruning with a threshold != (uint16_t)~0 */
+    uint16_t prune_ref_if_hme_sad_dev_bigger_than_th;
+    uint8_t  sr_adjustment;                   /* me_sr_adjustment_ctrls.enable_me_sr_adjustment: 0 or 1 (2 adds content-dependent probes: not covered) */
+    uint8_t  pad2;
+    uint16_t reduce_me_sr_based_on_mv_length_th, stationary_hme_sad_abs_th, stationary_me_sr_divisor, reduce_me_sr_based_on_hme_sad_abs_th,
+             me_sr_divisor_for_low_hme_sad;
+    uint32_t me_early_exit_th;                /* 0 = off; else zz_sad < th / 6 searches a single point (:1322-1327) */
 } SvtHipMeIntegerSearchParams;
 size_t svt_hip_me_integer_search_workspace(const SvtHipMeIntegerSearchParams *params);
 void   svt_hip_me_integer_search_batch(const SvtHipMeIntegerSearchParams *params, const uint8_t *src_base, const uint8_t *ref_base,
-                                       const uint64_t *hme_sad, const int16_t *hme_sc, const uint8_t *do_ref, const uint32_t *divisor,
+                                       const uint64_t *hme_sad, const int16_t *hme_sc, uint8_t *do_ref, uint32_t *divisor, const uint32_t *zz_sad,
                                        uint32_t *best_sad, uint32_t *best_mv, int16_t *sc_out, uint64_t *sad_out, void *workspace, void *stream);
+/* init_zz_sad's per-(reference, SB) value (motion_estimation.c:2382-2400, get_zz_sad :1667-1689): SAD of the 64x64 block against the co-located
+ * reference block on every other row, doubled, normalised by 4096 / (b64 width x height).  Geometry fields of params only.  zz_out [ref][sb]. */
+void   svt_hip_me_zz_sad_batch(const SvtHipMeIntegerSearchParams *params, const uint8_t *src_base, const uint8_t *ref_base, uint32_t *zz_out,
+                               void *stream);
 
 /* Frame-batched integer full-pel search = open_loop_me_fullpel_search_sblock (motion_estimation.c:781-816), i.e.
  * a3+a4+a5+a6 fused: for every (64x64 SB, reference) item, all 85 block SADs (8x8..64x64) at every position of the
@@ -370,6 +390,13 @@ typedef struct SvtHipMeStageParams {
     uint16_t mv_adj_mv_size_th, mv_adj_sa_multiplier;
     uint16_t dist[8];                    /* as SvtHipMeIntegerSearchParams */
     uint8_t  ref_pic_index[8];
+    uint8_t  hme_l0_per_ref;             /* level-0 areas per reference (get_hme_l0_search_area) instead of hme_sa_width/height[0] */
+    uint8_t  hme_prune_enabled, sr_adjustment, pad0; /* as SvtHipMeIntegerSearchParams */
+    int16_t  hme_l0_sa_width_ref[8], hme_l0_sa_height_ref[8];
+    uint16_t prune_ref_if_hme_sad_dev_bigger_than_th;
+    uint16_t reduce_me_sr_based_on_mv_length_th, stationary_hme_sad_abs_th, stationary_me_sr_divisor, reduce_me_sr_based_on_hme_sad_abs_th,
+             me_sr_divisor_for_low_hme_sad;
+    uint32_t me_early_exit_th;           /* 0 = off */
     SvtHipMeResultsParams results;       /* formatting parameters (n_sb is filled in by the session) */
 } SvtHipMeStageParams;
 int svt_hip_me_session_enable_stage(void *session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,

@@ -81,10 +81,11 @@ PROTOTYPES = {
     "svt_hip_me_session_submit_results": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
     "svt_hip_me_results_batch": (None, [vp] * 10),
     "svt_hip_me_integer_search_workspace": (C.c_size_t, [vp]),
-    "svt_hip_me_integer_search_batch": (None, [vp] * 13),
-    "svt_hip_hme_chain_batch": (None, [vp] * 6),
+    "svt_hip_me_integer_search_batch": (None, [vp] * 14),
+    "svt_hip_hme_chain_batch": (None, [vp] * 7),
+    "svt_hip_me_zz_sad_batch": (None, [vp] * 5),
     "svt_hip_hme_level_workspace": (C.c_size_t, [vp]),
-    "svt_hip_hme_level_batch": (None, [vp] * 8),
+    "svt_hip_hme_level_batch": (None, [vp] * 9),
     "svt_av1_apply_temporal_filter_planewise_medium_hip": (None, [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "svt_av1_apply_temporal_filter_planewise_medium_hbd_hip": (None, [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp] + [C.c_uint32]),
     "svt_av1_apply_zz_based_temporal_filter_planewise_medium_hip": (None, [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
@@ -195,7 +196,9 @@ class HmeLevelParams(C.Structure):
     _fields_ = [("level", C.c_uint8), ("sub_sampled", C.c_uint8), ("num_hme_sa_w", C.c_uint8), ("num_hme_sa_h", C.c_uint8), ("sa_width", C.c_int16),
                 ("sa_height", C.c_int16), ("sbs_x", C.c_uint32), ("sbs_y", C.c_uint32), ("n_refs", C.c_uint32), ("prev_shift", C.c_uint32), ("aligned_width", C.c_uint32),
                 ("aligned_height", C.c_uint32), ("src_off", C.c_uint64), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32), ("ref_org_x", C.c_uint32),
-                ("ref_org_y", C.c_uint32), ("ref_width", C.c_uint32), ("ref_height", C.c_uint32), ("ref_off", C.c_uint64 * 8)]
+                ("ref_org_y", C.c_uint32), ("ref_width", C.c_uint32), ("ref_height", C.c_uint32), ("ref_off", C.c_uint64 * 8),
+                ("per_ref_area", C.c_uint8), ("pad1", C.c_uint8 * 3), ("sa_width_ref", C.c_int16 * 8), ("sa_height_ref", C.c_int16 * 8),
+                ("zz_skip_th", C.c_uint32)]
 
 
 class MeIntegerSearchParams(C.Structure):
@@ -205,7 +208,10 @@ class MeIntegerSearchParams(C.Structure):
                 ("sa_max_height", C.c_int16), ("sub_sad", C.c_uint8), ("mv_adj_enabled", C.c_uint8), ("mv_adj_nearest_ref_only", C.c_uint8),
                 ("pad0", C.c_uint8), ("mv_adj_mv_size_th", C.c_uint16), ("mv_adj_sa_multiplier", C.c_uint16), ("dist", C.c_uint16 * 8),
                 ("ref_pic_index", C.c_uint8 * 8), ("src_off", C.c_uint64), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32),
-                ("ref_org_x", C.c_uint32), ("ref_org_y", C.c_uint32), ("ref_off", C.c_uint64 * 8)]
+                ("ref_org_x", C.c_uint32), ("ref_org_y", C.c_uint32), ("ref_off", C.c_uint64 * 8), ("n_refs_list0", C.c_uint8),
+                ("hme_prune_enabled", C.c_uint8), ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16), ("sr_adjustment", C.c_uint8), ("pad2", C.c_uint8),
+                ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16), ("stationary_me_sr_divisor", C.c_uint16),
+                ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("me_early_exit_th", C.c_uint32)]
 
 
 class TfParams(C.Structure):
@@ -230,6 +236,10 @@ class MeStageParams(C.Structure):
                 ("hme_sa_width", C.c_int16 * 3), ("hme_sa_height", C.c_int16 * 3), ("me_sa_min_width", C.c_int16), ("me_sa_min_height", C.c_int16),
                 ("me_sa_max_width", C.c_int16), ("me_sa_max_height", C.c_int16), ("mv_adj_enabled", C.c_uint8), ("mv_adj_nearest_ref_only", C.c_uint8),
                 ("mv_adj_mv_size_th", C.c_uint16), ("mv_adj_sa_multiplier", C.c_uint16), ("dist", C.c_uint16 * 8), ("ref_pic_index", C.c_uint8 * 8),
+                ("hme_l0_per_ref", C.c_uint8), ("hme_prune_enabled", C.c_uint8), ("sr_adjustment", C.c_uint8), ("pad0", C.c_uint8),
+                ("hme_l0_sa_width_ref", C.c_int16 * 8), ("hme_l0_sa_height_ref", C.c_int16 * 8), ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16),
+                ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16), ("stationary_me_sr_divisor", C.c_uint16),
+                ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("me_early_exit_th", C.c_uint32),
                 ("results", MeResultsParams)]
 
 

@@ -13,21 +13,28 @@ struct HmeItem { // geometry of one item, shared by the two kernels
     int16_t sa_origin_x, sa_origin_y;
 };
 
-__global__ __launch_bounds__(256) void hme_descs_kernel(const SvtHipHmeLevelParams P, const int16_t* __restrict__ prev_sc, SvtHipSadLoopDesc* __restrict__ descs,
-                                                        HmeItem* __restrict__ items, const uint32_t n) {
+__device__ __forceinline__ bool hme_item_skipped(const SvtHipHmeLevelParams& P, const uint32_t* __restrict__ zz_sad, const uint32_t i) {
+    if (!P.zz_skip_th || !zz_sad || P.level == 2) return false;
+    return zz_sad[i / ((uint32_t)P.num_hme_sa_w * P.num_hme_sa_h)] < P.zz_skip_th; // [ref][sb] = item / regions
+}
+__global__ __launch_bounds__(256) void hme_descs_kernel(const SvtHipHmeLevelParams P, const int16_t* __restrict__ prev_sc, const uint32_t* __restrict__ zz_sad,
+                                                        SvtHipSadLoopDesc* __restrict__ descs, HmeItem* __restrict__ items, const uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     SvtHipSadLoopDesc d;
     int16_t           ox, oy;
     hme_item_geometry(P, i, P.level ? prev_sc[2 * i] : (int16_t)0, P.level ? prev_sc[2 * i + 1] : (int16_t)0, d, ox, oy);
+    if (hme_item_skipped(P, zz_sad, i)) { d.search_area_width = 1; d.search_area_height = 1; } // result overwritten by the rescale kernel
     descs[i] = d;
     items[i] = HmeItem{ox, oy};
 }
 
-__global__ __launch_bounds__(256) void hme_post_kernel(const SvtHipSadLoopResult* __restrict__ res, const HmeItem* __restrict__ items, const int sub_sampled,
-                                                       const int scale, unsigned long long* __restrict__ sad_out, int16_t* __restrict__ sc_out, const uint32_t n) {
+__global__ __launch_bounds__(256) void hme_post_kernel(const SvtHipHmeLevelParams P, const uint32_t* __restrict__ zz_sad, const SvtHipSadLoopResult* __restrict__ res,
+                                                       const HmeItem* __restrict__ items, const int sub_sampled, const int scale,
+                                                       unsigned long long* __restrict__ sad_out, int16_t* __restrict__ sc_out, const uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (hme_item_skipped(P, zz_sad, i)) { sad_out[i] = 0; sc_out[2 * i] = 0; sc_out[2 * i + 1] = 0; return; }
     const SvtHipSadLoopResult r = res[i];
     const int16_t x = r.valid ? r.x_search_center : sc_out[2 * i], y = r.valid ? r.y_search_center : sc_out[2 * i + 1];
     sad_out[i]        = sub_sampled ? r.best_sad * 2 : r.best_sad;
@@ -47,78 +54,128 @@ inline HmeWs hme_ws(uint32_t n) {
     return w;
 }
 
-// ---- integer ME from the HME results: final search centre per (reference, SB) + integer_search_b64's area geometry -> SvtHipMeSearchDesc
-__global__ __launch_bounds__(256) void me_int_descs_kernel(const SvtHipMeIntegerSearchParams P, const unsigned long long* __restrict__ hme_sad,
-                                                           const int16_t* __restrict__ hme_sc, const uint8_t* __restrict__ do_ref,
-                                                           const uint32_t* __restrict__ divisor, SvtHipMeSearchDesc* __restrict__ descs,
-                                                           int16_t* __restrict__ sc_out, unsigned long long* __restrict__ sad_out, const uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- integer ME from the HME results.  One thread per SB walks its reference slots three times, as the reference's per-SB code does: final search
+// centre per slot (set_final_seach_centre_sb), then hme_prune_ref_and_adjust_sr over all slots (needs the best HME SAD of the SB), then
+// integer_search_b64's area geometry per slot -> SvtHipMeSearchDesc.  Item index = ref * n_sb + sb.
+__global__ __launch_bounds__(64) void me_int_descs_kernel(const SvtHipMeIntegerSearchParams P, const unsigned long long* __restrict__ hme_sad,
+                                                          const int16_t* __restrict__ hme_sc, uint8_t* __restrict__ do_ref, uint32_t* __restrict__ divisor,
+                                                          const uint32_t* __restrict__ zz_sad, SvtHipMeSearchDesc* __restrict__ descs,
+                                                          int16_t* __restrict__ sc_out, unsigned long long* __restrict__ sad_out) {
+    const uint32_t n_sb = P.sbs_x * P.sbs_y, sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= n_sb) return;
+    int16_t            cx[8], cy[8];
+    unsigned long long csad[8], best_all = 0xffffffffull; // slots HME never touched keep MAX_U32 (init_me_hme_data, :3061)
+    for (uint32_t r = 0; r < P.n_refs; r++) {
+        const uint32_t i = r * n_sb + sb;
+        // set_final_seach_centre_sb: first strictly smaller SAD, regions in sr_h-outer / sr_w-inner order
+        const unsigned long long* ps = hme_sad + (size_t)i * P.regions;
+        const int16_t*            pc = hme_sc + (size_t)i * P.regions * 2;
+        unsigned long long best = ps[0];
+        int16_t            x = pc[0], y = pc[1];
+        for (uint32_t k = 1; k < P.regions; k++)
+            if (ps[k] < best) { best = ps[k]; x = pc[2 * k]; y = pc[2 * k + 1]; }
+        cx[r] = x; cy[r] = y; csad[r] = best;
+        sc_out[2 * i] = x; sc_out[2 * i + 1] = y; sad_out[i] = best;
+        best_all = best < best_all ? best : best_all;
+    }
+    for (uint32_t r = 0; r < P.n_refs; r++) {
+        const uint32_t i = r * n_sb + sb;
+        const size_t dri = (size_t)sb * 8 + (r < P.n_refs_list0 ? 0 : 4) + P.ref_pic_index[r]; // search_results[list][ref] layout, as svt_hip_me_results_batch
+        bool     live = do_ref ? do_ref[dri] != 0 : true;
+        // hme_prune_ref_and_adjust_sr: references (other than the first of each list) whose HME SAD is th % above the best are dropped ...
+        if (P.hme_prune_enabled && P.ref_pic_index[r] != 0 && (csad[r] - best_all) * 100 > (unsigned long long)P.prune_ref_if_hme_sad_dev_bigger_than_th * best_all) {
+            live = false;
+            if (do_ref) do_ref[dri] = 0;
+        }
+        // ... and the ME search range shrinks when the HME result is stationary or already good
+        uint32_t div = (!P.sr_adjustment && divisor) ? divisor[(size_t)sb * P.n_refs + r] : 1u;
+        if (P.sr_adjustment) {
+            const int ax = cx[r] < 0 ? -cx[r] : cx[r], ay = cy[r] < 0 ? -cy[r] : cy[r];
+            if (ax <= P.reduce_me_sr_based_on_mv_length_th && ay <= P.reduce_me_sr_based_on_mv_length_th && csad[r] < P.stationary_hme_sad_abs_th)
+                div = P.stationary_me_sr_divisor;
+            else if (csad[r] < P.reduce_me_sr_based_on_hme_sad_abs_th)
+                div = P.me_sr_divisor_for_low_hme_sad;
+            if (divisor) divisor[(size_t)sb * P.n_refs + r] = div;
+        }
+        const int16_t x_search_center = cx[r], y_search_center = cy[r];
+
+        const int      b64_origin_x = (int)(sb % P.sbs_x) * 64, b64_origin_y = (int)(sb / P.sbs_x) * 64;
+        const int16_t  pad_width = 63, pad_height = 63, org_x = (int16_t)b64_origin_x, org_y = (int16_t)b64_origin_y;
+        const int      picture_width = (int16_t)P.aligned_width, picture_height = (int16_t)P.aligned_height;
+        int16_t search_area_width = P.sa_min_width, search_area_height = P.sa_min_height;
+        {
+            const int w = search_area_width * P.dist[r], h = search_area_height * P.dist[r];
+            search_area_width  = (int16_t)(w < (uint16_t)P.sa_max_width ? w : (uint16_t)P.sa_max_width);
+            search_area_height = (int16_t)(h < (uint16_t)P.sa_max_height ? h : (uint16_t)P.sa_max_height);
+        }
+        if (P.mv_adj_enabled && (!P.mv_adj_nearest_ref_only || P.ref_pic_index[r] == 0)) {
+            if ((x_search_center < 0 ? -x_search_center : x_search_center) > P.mv_adj_mv_size_th) search_area_width = (int16_t)(search_area_width * P.mv_adj_sa_multiplier);
+            if ((y_search_center < 0 ? -y_search_center : y_search_center) > P.mv_adj_mv_size_th) search_area_height = (int16_t)(search_area_height * P.mv_adj_sa_multiplier);
+        }
+        {
+            const uint32_t w = (uint32_t)search_area_width / div, h = (uint32_t)search_area_height / div; // unsigned division, as the reference
+            search_area_width  = (int16_t)(((w > 1 ? w : 1) + 7) & ~0x07u);
+            search_area_height = (int16_t)(h > 3 ? h : 3);
+        }
+        if (P.me_early_exit_th && zz_sad[i] < P.me_early_exit_th / 6) { search_area_width = 1; search_area_height = 1; } // :1322-1327
+        int16_t x_search_area_origin = (int16_t)(x_search_center - (search_area_width >> 1));
+        int16_t y_search_area_origin = (int16_t)(y_search_center - (search_area_height >> 1));
+        // origin and size are corrected by separate conditionals, the size one evaluated with the corrected origin (:1462-1467): the left / top
+        // correction therefore never shrinks the area
+        x_search_area_origin = (int16_t)(((org_x + x_search_area_origin) < -pad_width) ? -pad_width - org_x : x_search_area_origin);
+        search_area_width    = (int16_t)(((org_x + x_search_area_origin) < -pad_width) ? search_area_width - (-pad_width - (org_x + x_search_area_origin)) : search_area_width);
+        x_search_area_origin = (int16_t)(((org_x + x_search_area_origin) > picture_width - 1) ? x_search_area_origin - ((org_x + x_search_area_origin) - (picture_width - 1))
+                                                                                                : x_search_area_origin);
+        if ((org_x + x_search_area_origin + search_area_width) > picture_width) {
+            const int w = search_area_width - ((org_x + x_search_area_origin + search_area_width) - picture_width);
+            search_area_width = (int16_t)(w > 1 ? w : 1);
+        }
+        search_area_width    = (int16_t)(search_area_width < 8 ? search_area_width : search_area_width & ~0x07);
+        y_search_area_origin = (int16_t)(((org_y + y_search_area_origin) < -pad_height) ? -pad_height - org_y : y_search_area_origin);
+        search_area_height   = (int16_t)(((org_y + y_search_area_origin) < -pad_height) ? search_area_height - (-pad_height - (org_y + y_search_area_origin)) : search_area_height);
+        y_search_area_origin = (int16_t)(((org_y + y_search_area_origin) > picture_height - 1) ? y_search_area_origin - ((org_y + y_search_area_origin) - (picture_height - 1))
+                                                                                                 : y_search_area_origin);
+        if ((org_y + y_search_area_origin + search_area_height) > picture_height) {
+            const int h = search_area_height - ((org_y + y_search_area_origin + search_area_height) - picture_height);
+            search_area_height = (int16_t)(h > 1 ? h : 1);
+        }
+        if (!live) { // not searched by the reference: placeholder
+            x_search_area_origin = y_search_area_origin = 0;
+            search_area_width = search_area_height = 1;
+        }
+        SvtHipMeSearchDesc d;
+        d.src_off    = P.src_off + (uint64_t)b64_origin_y * P.src_stride + (uint64_t)b64_origin_x;
+        d.ref_off    = P.ref_off[r] + (uint64_t)((long long)((int)P.ref_org_y + b64_origin_y + y_search_area_origin) * (long long)P.ref_stride +
+                                                 (long long)((int)P.ref_org_x + b64_origin_x + x_search_area_origin));
+        d.src_stride = P.src_stride;
+        d.ref_stride = P.ref_stride;
+        d.x_search_area_origin = x_search_area_origin;
+        d.y_search_area_origin = y_search_area_origin;
+        d.search_area_width    = (uint16_t)search_area_width;
+        d.search_area_height   = (uint16_t)search_area_height;
+        descs[i] = d;
+    }
+}
+
+// init_zz_sad: one wave per (reference, SB): lane = (row pair of the sub-sampled block, half row); sub-sampled SAD at the co-located position
+__global__ __launch_bounds__(256) void me_zz_sad_kernel(const SvtHipMeIntegerSearchParams P, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                        uint32_t* __restrict__ zz_out, const uint32_t n) {
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
     if (i >= n) return;
     const uint32_t n_sb = P.sbs_x * P.sbs_y, sb = i % n_sb, r = i / n_sb;
-    // set_final_seach_centre_sb: first strictly smaller SAD, regions in sr_h-outer / sr_w-inner order
-    const unsigned long long* ps = hme_sad + (size_t)i * P.regions;
-    const int16_t*            pc = hme_sc + (size_t)i * P.regions * 2;
-    unsigned long long best = ps[0];
-    int16_t            x_search_center = pc[0], y_search_center = pc[1];
-    for (uint32_t k = 1; k < P.regions; k++)
-        if (ps[k] < best) { best = ps[k]; x_search_center = pc[2 * k]; y_search_center = pc[2 * k + 1]; }
-    sc_out[2 * i] = x_search_center; sc_out[2 * i + 1] = y_search_center; sad_out[i] = best;
-
-    const int      b64_origin_x = (int)(sb % P.sbs_x) * 64, b64_origin_y = (int)(sb / P.sbs_x) * 64;
-    const int16_t  pad_width = 63, pad_height = 63, org_x = (int16_t)b64_origin_x, org_y = (int16_t)b64_origin_y;
-    const int      picture_width = (int16_t)P.aligned_width, picture_height = (int16_t)P.aligned_height;
-    const uint32_t div = divisor ? divisor[(size_t)sb * P.n_refs + r] : 1u;
-    int16_t search_area_width = P.sa_min_width, search_area_height = P.sa_min_height;
-    {
-        const int w = search_area_width * P.dist[r], h = search_area_height * P.dist[r];
-        search_area_width  = (int16_t)(w < (uint16_t)P.sa_max_width ? w : (uint16_t)P.sa_max_width);
-        search_area_height = (int16_t)(h < (uint16_t)P.sa_max_height ? h : (uint16_t)P.sa_max_height);
-    }
-    if (P.mv_adj_enabled && (!P.mv_adj_nearest_ref_only || P.ref_pic_index[r] == 0)) {
-        if ((x_search_center < 0 ? -x_search_center : x_search_center) > P.mv_adj_mv_size_th) search_area_width = (int16_t)(search_area_width * P.mv_adj_sa_multiplier);
-        if ((y_search_center < 0 ? -y_search_center : y_search_center) > P.mv_adj_mv_size_th) search_area_height = (int16_t)(search_area_height * P.mv_adj_sa_multiplier);
-    }
-    {
-        const uint32_t w = (uint32_t)search_area_width / div, h = (uint32_t)search_area_height / div; // unsigned division, as the reference
-        search_area_width  = (int16_t)(((w > 1 ? w : 1) + 7) & ~0x07u);
-        search_area_height = (int16_t)(h > 3 ? h : 3);
-    }
-    int16_t x_search_area_origin = (int16_t)(x_search_center - (search_area_width >> 1));
-    int16_t y_search_area_origin = (int16_t)(y_search_center - (search_area_height >> 1));
-    // origin and size are corrected by separate conditionals, the size one evaluated with the corrected origin (:1462-1467): the left / top
-    // correction therefore never shrinks the area
-    x_search_area_origin = (int16_t)(((org_x + x_search_area_origin) < -pad_width) ? -pad_width - org_x : x_search_area_origin);
-    search_area_width    = (int16_t)(((org_x + x_search_area_origin) < -pad_width) ? search_area_width - (-pad_width - (org_x + x_search_area_origin)) : search_area_width);
-    x_search_area_origin = (int16_t)(((org_x + x_search_area_origin) > picture_width - 1) ? x_search_area_origin - ((org_x + x_search_area_origin) - (picture_width - 1))
-                                                                                            : x_search_area_origin);
-    if ((org_x + x_search_area_origin + search_area_width) > picture_width) {
-        const int w = search_area_width - ((org_x + x_search_area_origin + search_area_width) - picture_width);
-        search_area_width = (int16_t)(w > 1 ? w : 1);
-    }
-    search_area_width    = (int16_t)(search_area_width < 8 ? search_area_width : search_area_width & ~0x07);
-    y_search_area_origin = (int16_t)(((org_y + y_search_area_origin) < -pad_height) ? -pad_height - org_y : y_search_area_origin);
-    search_area_height   = (int16_t)(((org_y + y_search_area_origin) < -pad_height) ? search_area_height - (-pad_height - (org_y + y_search_area_origin)) : search_area_height);
-    y_search_area_origin = (int16_t)(((org_y + y_search_area_origin) > picture_height - 1) ? y_search_area_origin - ((org_y + y_search_area_origin) - (picture_height - 1))
-                                                                                             : y_search_area_origin);
-    if ((org_y + y_search_area_origin + search_area_height) > picture_height) {
-        const int h = search_area_height - ((org_y + y_search_area_origin + search_area_height) - picture_height);
-        search_area_height = (int16_t)(h > 1 ? h : 1);
-    }
-    if (do_ref && !do_ref[(size_t)sb * P.n_refs + r]) { // not searched by the reference: placeholder
-        x_search_area_origin = y_search_area_origin = 0;
-        search_area_width = search_area_height = 1;
-    }
-    SvtHipMeSearchDesc d;
-    d.src_off    = P.src_off + (uint64_t)b64_origin_y * P.src_stride + (uint64_t)b64_origin_x;
-    d.ref_off    = P.ref_off[r] + (uint64_t)((long long)((int)P.ref_org_y + b64_origin_y + y_search_area_origin) * (long long)P.ref_stride +
-                                             (long long)((int)P.ref_org_x + b64_origin_x + x_search_area_origin));
-    d.src_stride = P.src_stride;
-    d.ref_stride = P.ref_stride;
-    d.x_search_area_origin = x_search_area_origin;
-    d.y_search_area_origin = y_search_area_origin;
-    d.search_area_width    = (uint16_t)search_area_width;
-    d.search_area_height   = (uint16_t)search_area_height;
-    descs[i] = d;
+    const uint32_t fx = (sb % P.sbs_x) * 64, fy = (sb / P.sbs_x) * 64;
+    const uint32_t bw = P.aligned_width - fx < 64 ? P.aligned_width - fx : 64, bh = P.aligned_height - fy < 64 ? P.aligned_height - fy : 64;
+    const uint8_t* s = src_base + P.src_off + (size_t)fy * P.src_stride + fx;
+    const uint8_t* f = ref_base + P.ref_off[r] + (size_t)(P.ref_org_y + fy) * P.ref_stride + P.ref_org_x + fx;
+    uint32_t sad = 0;
+    for (uint32_t y = l >> 1; y < (bh >> 1); y += 32) // rows 0, 2, 4, ... of the block (stride << 1, height >> 1)
+        for (uint32_t x = (l & 1) * 32; x < bw && x < (l & 1) * 32 + 32; x++) {
+            const int d = (int)s[(size_t)(2 * y) * P.src_stride + x] - (int)f[(size_t)(2 * y) * P.ref_stride + x];
+            sad += (uint32_t)(d < 0 ? -d : d);
+        }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sad += (uint32_t)__shfl_xor((int)sad, m);
+    if (l == 0) zz_out[i] = ((sad << 1) * 64u * 64u) / (bw * bh);
 }
 
 // upper bounds of the area the geometry above can produce (host side, for the search kernel's tile / workspace sizing)
@@ -139,8 +196,8 @@ extern "C" {
 
 size_t svt_hip_hme_level_workspace(const SvtHipHmeLevelParams* params) { return hme_ws(hme_items(params)).bytes; }
 
-void svt_hip_hme_level_batch(const SvtHipHmeLevelParams* params, const uint8_t* src_base, const uint8_t* ref_base, const int16_t* prev_sc, uint64_t* sad_out,
-                             int16_t* sc_out, void* workspace, void* stream) {
+void svt_hip_hme_level_batch(const SvtHipHmeLevelParams* params, const uint8_t* src_base, const uint8_t* ref_base, const int16_t* prev_sc,
+                             const uint32_t* zz_sad, uint64_t* sad_out, int16_t* sc_out, void* workspace, void* stream) {
     svthip::ensure_device();
     const uint32_t n = hme_items(params);
     if (n == 0) return;
@@ -151,13 +208,21 @@ void svt_hip_hme_level_batch(const SvtHipHmeLevelParams* params, const uint8_t* 
     SvtHipSadLoopResult* res = (SvtHipSadLoopResult*)(ws + w.res);
     HmeItem*           items = (HmeItem*)(ws + w.items);
     hipStream_t        st = (hipStream_t)stream;
-    hipLaunchKernelGGL(hme_descs_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *params, prev_sc, descs, items, n);
+    hipLaunchKernelGGL(hme_descs_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *params, prev_sc, zz_sad, descs, items, n);
     SVT_LAUNCH_CHECK();
     const int      shift = params->level == 0 ? 2 : (params->level == 1 ? 1 : 0);
     const uint32_t blk = 64u >> shift, step = params->sub_sampled ? 2 : 1;
-    svt_hip_sad_loop_batch(src_base, ref_base, descs, n, (uint32_t)((params->sa_width + 7) & ~7), (uint32_t)params->sa_height, blk, blk / step, (int)step, res,
+    int maw = params->sa_width, mah = params->sa_height;
+    if (params->per_ref_area) {
+        maw = mah = 1;
+        for (uint32_t r = 0; r < params->n_refs; r++) {
+            maw = params->sa_width_ref[r] > maw ? params->sa_width_ref[r] : maw;
+            mah = params->sa_height_ref[r] > mah ? params->sa_height_ref[r] : mah;
+        }
+    }
+    svt_hip_sad_loop_batch(src_base, ref_base, descs, n, (uint32_t)((maw + 7) & ~7), (uint32_t)mah, blk, blk / step, (int)step, res,
                            (uint64_t*)(ws + w.keys), stream);
-    hipLaunchKernelGGL(hme_post_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const SvtHipSadLoopResult*)res, (const HmeItem*)items,
+    hipLaunchKernelGGL(hme_post_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *params, zz_sad, (const SvtHipSadLoopResult*)res, (const HmeItem*)items,
                        (int)params->sub_sampled, params->level == 0 ? 4 : (params->level == 1 ? 2 : 1), (unsigned long long*)sad_out, sc_out, n);
     SVT_LAUNCH_CHECK();
 }
@@ -170,17 +235,29 @@ size_t svt_hip_me_integer_search_workspace(const SvtHipMeIntegerSearchParams* pa
     return svthip::align_up((size_t)n * sizeof(SvtHipMeSearchDesc), 256) + svt_hip_me_fullpel_search_workspace(n, mw, mh);
 }
 
+void svt_hip_me_zz_sad_batch(const SvtHipMeIntegerSearchParams* params, const uint8_t* src_base, const uint8_t* ref_base, uint32_t* zz_out, void* stream) {
+    svthip::ensure_device();
+    const uint32_t n = params->n_refs * params->sbs_x * params->sbs_y;
+    if (n == 0) return;
+    hipLaunchKernelGGL(me_zz_sad_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, *params, src_base, ref_base, zz_out, n);
+    SVT_LAUNCH_CHECK();
+}
+
 void svt_hip_me_integer_search_batch(const SvtHipMeIntegerSearchParams* params, const uint8_t* src_base, const uint8_t* ref_base, const uint64_t* hme_sad,
-                                     const int16_t* hme_sc, const uint8_t* do_ref, const uint32_t* divisor, uint32_t* best_sad, uint32_t* best_mv,
+                                     const int16_t* hme_sc, uint8_t* do_ref, uint32_t* divisor, const uint32_t* zz_sad, uint32_t* best_sad, uint32_t* best_mv,
                                      int16_t* sc_out, uint64_t* sad_out, void* workspace, void* stream) {
     svthip::ensure_device();
     const uint32_t n = params->n_refs * params->sbs_x * params->sbs_y;
     if (n == 0) return;
-    if (params->n_refs > 8 || params->regions == 0) { fprintf(stderr, "libsvtav1_hip: svt_hip_me_integer_search_batch: bad parameters\n"); abort(); }
+    if (params->n_refs > 8 || params->regions == 0 || params->sr_adjustment > 1 || (params->me_early_exit_th && !zz_sad)) {
+        fprintf(stderr, "libsvtav1_hip: svt_hip_me_integer_search_batch: bad parameters\n");
+        abort();
+    }
     SvtHipMeSearchDesc* descs = (SvtHipMeSearchDesc*)workspace;
     void*               ws2   = (uint8_t*)workspace + svthip::align_up((size_t)n * sizeof(SvtHipMeSearchDesc), 256);
-    hipLaunchKernelGGL(me_int_descs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *params, (const unsigned long long*)hme_sad, hme_sc, do_ref,
-                       divisor, descs, sc_out, (unsigned long long*)sad_out, n);
+    const uint32_t n_sb = params->sbs_x * params->sbs_y;
+    hipLaunchKernelGGL(me_int_descs_kernel, dim3((n_sb + 63) / 64), dim3(64), 0, (hipStream_t)stream, *params, (const unsigned long long*)hme_sad, hme_sc, do_ref,
+                       divisor, zz_sad, descs, sc_out, (unsigned long long*)sad_out);
     SVT_LAUNCH_CHECK();
     uint32_t mw, mh;
     me_int_max_area(params, mw, mh);

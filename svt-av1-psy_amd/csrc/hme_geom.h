@@ -15,7 +15,7 @@ __device__ __forceinline__ void hme_item_geometry(const SvtHipHmeLevelParams& P,
     const int16_t  org_x = (int16_t)((int16_t)fx >> shift), org_y = (int16_t)((int16_t)fy >> shift);
     const uint32_t block_width = b64_w >> shift, block_height = b64_h >> shift;
 
-    int16_t       sa_width = (int16_t)((P.sa_width + 7) & ~0x07), sa_height = P.sa_height;
+    int16_t       sa_width = (int16_t)(((P.per_ref_area ? P.sa_width_ref[r] : P.sa_width) + 7) & ~0x07), sa_height = P.per_ref_area ? P.sa_height_ref[r] : P.sa_height;
     const int16_t pad_width = (int16_t)(P.level == 2 ? 63 : (int)P.ref_org_x - 1), pad_height = (int16_t)(P.level == 2 ? 63 : (int)P.ref_org_y - 1);
     const int16_t ref_w = (int16_t)P.ref_width, ref_h = (int16_t)P.ref_height;
     int16_t       sa_origin_x, sa_origin_y;

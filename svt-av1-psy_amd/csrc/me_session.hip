@@ -237,7 +237,23 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
             for (uint32_t k = 0; k < n_refs; k++) L.ref_off[k] = (uint64_t)ref_r[k] * pb;
             HIP_CHECK(hipMemsetAsync(scs[lv], 0, items * 4, sl.st)); // init_me_hme_data leaves the centres at 0
         }
-        svt_hip_hme_chain_batch(P, bases, bases, (uint64_t* const*)sads, scs, sl.st);
+        uint32_t* zz = nullptr;
+        if (stage->me_early_exit_th) { // init_zz_sad: the zero-motion SAD gates HME levels 0 / 1 and the integer search
+            zz = (uint32_t*)((uint8_t*)int_ws + s->int_ws);
+            SvtHipMeIntegerSearchParams Z;
+            memset(&Z, 0, sizeof(Z));
+            Z.sbs_x = sbs_x; Z.sbs_y = sbs_y; Z.n_refs = n_refs; Z.aligned_width = aw; Z.aligned_height = ah;
+            Z.src_off = (uint64_t)src_r * s->plane_bytes + (uint64_t)s->org_y * s->stride + s->org_x;
+            Z.src_stride = s->stride; Z.ref_stride = s->stride; Z.ref_org_x = s->org_x; Z.ref_org_y = s->org_y;
+            for (uint32_t k = 0; k < n_refs; k++) Z.ref_off[k] = (uint64_t)ref_r[k] * s->plane_bytes;
+            svt_hip_me_zz_sad_batch(&Z, s->planes, s->planes, zz, sl.st);
+            P[0].zz_skip_th = P[1].zz_skip_th = stage->me_early_exit_th >> 2;
+        }
+        if (stage->hme_l0_per_ref) {
+            P[0].per_ref_area = 1;
+            for (uint32_t k = 0; k < n_refs; k++) { P[0].sa_width_ref[k] = stage->hme_l0_sa_width_ref[k]; P[0].sa_height_ref[k] = stage->hme_l0_sa_height_ref[k]; }
+        }
+        svt_hip_hme_chain_batch(P, bases, bases, zz, (uint64_t* const*)sads, scs, sl.st);
         SvtHipMeIntegerSearchParams Q;
         memset(&Q, 0, sizeof(Q));
         Q.sbs_x = sbs_x; Q.sbs_y = sbs_y; Q.n_refs = n_refs; Q.regions = regions; Q.aligned_width = aw; Q.aligned_height = ah;
@@ -249,8 +265,23 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         Q.src_off = (uint64_t)src_r * s->plane_bytes + (uint64_t)s->org_y * s->stride + s->org_x;
         Q.src_stride = s->stride; Q.ref_stride = s->stride; Q.ref_org_x = s->org_x; Q.ref_org_y = s->org_y;
         if (svt_hip_me_integer_search_workspace(&Q) > s->int_ws) return -5; // areas larger than the session was sized for
-        svt_hip_me_integer_search_batch(&Q, s->planes, s->planes, (const uint64_t*)sads[2], scs[2], nullptr, nullptr, sl.sad, sl.mv, fin_sc, (uint64_t*)fin_sad,
-                                        int_ws, sl.st);
+        Q.n_refs_list0 = stage->results.num_of_ref_pic_to_search[0];
+        Q.hme_prune_enabled = stage->hme_prune_enabled; Q.prune_ref_if_hme_sad_dev_bigger_than_th = stage->prune_ref_if_hme_sad_dev_bigger_than_th;
+        Q.sr_adjustment = stage->sr_adjustment; Q.reduce_me_sr_based_on_mv_length_th = stage->reduce_me_sr_based_on_mv_length_th;
+        Q.stationary_hme_sad_abs_th = stage->stationary_hme_sad_abs_th; Q.stationary_me_sr_divisor = stage->stationary_me_sr_divisor;
+        Q.reduce_me_sr_based_on_hme_sad_abs_th = stage->reduce_me_sr_based_on_hme_sad_abs_th;
+        Q.me_sr_divisor_for_low_hme_sad = stage->me_sr_divisor_for_low_hme_sad; Q.me_early_exit_th = stage->me_early_exit_th;
+        // search_results[].do_ref of the stage lives where the formatting step expects it, so HME-based pruning carries over to me_prune_ref
+        uint8_t* d_do_ref = nullptr;
+        if (fmt) {
+            const uint32_t  n_pus = fmt->enable_me_16x16 ? (fmt->enable_me_8x8 ? 85 : 21) : 5;
+            const FmtLayout L     = fmt_layout(s->sbs, n_pus, fmt->max_refs, fmt->max_cand);
+            d_do_ref = sl.fmt + L.do_ref;
+            if (out->do_ref) HIP_CHECK(hipMemcpyAsync(d_do_ref, out->do_ref, (size_t)s->sbs * 8, hipMemcpyHostToDevice, sl.st));
+            else HIP_CHECK(hipMemsetAsync(d_do_ref, 1, (size_t)s->sbs * 8, sl.st));
+        }
+        svt_hip_me_integer_search_batch(&Q, s->planes, s->planes, (const uint64_t*)sads[2], scs[2], d_do_ref, nullptr, zz, sl.sad, sl.mv, fin_sc,
+                                        (uint64_t*)fin_sad, int_ws, sl.st);
     }
     if (best_sad_host) HIP_CHECK(hipMemcpyAsync(best_sad_host, sl.sad, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
     if (best_mv_host) HIP_CHECK(hipMemcpyAsync(best_mv_host, sl.mv, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
@@ -259,9 +290,11 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         P.n_sb = s->sbs;
         const uint32_t  n_pus = P.enable_me_16x16 ? (P.enable_me_8x8 ? 85 : 21) : 5;
         const FmtLayout L     = fmt_layout(s->sbs, n_pus, P.max_refs, P.max_cand);
-        HIP_CHECK(hipMemsetAsync(sl.fmt, 0, L.stats, sl.st)); // entries the reference leaves unwritten read as 0
-        if (out->do_ref) HIP_CHECK(hipMemcpyAsync(sl.fmt + L.do_ref, out->do_ref, (size_t)s->sbs * 8, hipMemcpyHostToDevice, sl.st));
-        else HIP_CHECK(hipMemsetAsync(sl.fmt + L.do_ref, 1, (size_t)s->sbs * 8, sl.st));
+        HIP_CHECK(hipMemsetAsync(sl.fmt + L.total, 0, L.stats - L.total, sl.st)); // entries the reference leaves unwritten read as 0
+        if (!stage) { // (the stage form initialised do_ref before the integer search, which may have pruned references)
+            if (out->do_ref) HIP_CHECK(hipMemcpyAsync(sl.fmt + L.do_ref, out->do_ref, (size_t)s->sbs * 8, hipMemcpyHostToDevice, sl.st));
+            else HIP_CHECK(hipMemsetAsync(sl.fmt + L.do_ref, 1, (size_t)s->sbs * 8, sl.st));
+        }
         svt_hip_me_results_batch(&P, sl.sad, sl.mv, sl.fmt + L.do_ref, s->sb_size, sl.fmt + L.total, (uint32_t*)(sl.fmt + L.mv), sl.fmt + L.cand,
                                  (SvtHipMeSbStats*)(sl.fmt + L.stats), sl.st);
         if (out->do_ref) HIP_CHECK(hipMemcpyAsync(out->do_ref, sl.fmt + L.do_ref, (size_t)s->sbs * 8, hipMemcpyDeviceToHost, sl.st));
@@ -305,7 +338,7 @@ int svt_hip_me_session_enable_stage(void* session, uint32_t quarter_pad, uint32_
     s->int_ws = svthip::align_up(n * sizeof(SvtHipMeSearchDesc), 256) +
                 svt_hip_me_fullpel_search_workspace((uint32_t)n, (max_me_area_width + 7) & ~7u, max_me_area_height < 3 ? 3 : max_me_area_height);
     const size_t per_slot = 3 * (svthip::align_up(s->hme_items * 8, 256) + svthip::align_up(s->hme_items * 4, 256)) + svthip::align_up(n * 4, 256) +
-                            svthip::align_up(n * 8, 256) + s->int_ws + 256;
+                            svthip::align_up(n * 8, 256) + s->int_ws + svthip::align_up(n * 4, 256) + 256; // ... + zz_sad
     for (auto& sl : s->slots) HIP_CHECK(hipMalloc((void**)&sl.hme, per_slot));
     s->stage = true;
     return 0;

@@ -713,6 +713,7 @@ struct HmeChainArgs {
     const uint8_t *src[3], *ref[3];
     unsigned long long* sad_out[3];
     int16_t* sc_out[3];
+    const uint32_t* zz_sad;
     uint32_t n;
     int win_budget, src_budget;
 };
@@ -727,6 +728,11 @@ __global__ __launch_bounds__(256) void hme_chain_kernel(const HmeChainArgs A) {
 #pragma unroll 1
     for (int lv = 0; lv < 3; lv++) {
         const SvtHipHmeLevelParams& P = A.P[lv];
+        if (P.zz_skip_th && A.zz_sad && lv < 2 && A.zz_sad[item / ((uint32_t)P.num_hme_sa_w * P.num_hme_sa_h)] < P.zz_skip_th) { // zero-motion SAD already low
+            px = py = 0;
+            if (l == 0) { A.sad_out[lv][item] = 0; A.sc_out[lv][2 * item] = 0; A.sc_out[lv][2 * item + 1] = 0; }
+            continue;
+        }
         SvtHipSadLoopDesc d;
         int16_t ox, oy;
         hme_item_geometry(P, item, px, py, d, ox, oy);
@@ -936,8 +942,8 @@ void svt_hip_sad_loop_batch(const uint8_t* src_base, const uint8_t* ref_base, co
     SVT_LAUNCH_CHECK();
 }
 
-void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* const* src_base, const uint8_t* const* ref_base, uint64_t* const* sad_out,
-                             int16_t* const* sc_out, void* stream) {
+void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* const* src_base, const uint8_t* const* ref_base, const uint32_t* zz_sad,
+                             uint64_t* const* sad_out, int16_t* const* sc_out, void* stream) {
     svthip::ensure_device();
     const uint32_t n = params[0].n_refs * params[0].sbs_x * params[0].sbs_y * params[0].num_hme_sa_w * params[0].num_hme_sa_h;
     if (n == 0) return;
@@ -952,14 +958,19 @@ void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* 
             abort();
         }
         A.P[lv] = P; A.src[lv] = src_base[lv]; A.ref[lv] = ref_base[lv]; A.sad_out[lv] = (unsigned long long*)sad_out[lv]; A.sc_out[lv] = sc_out[lv];
-        const int bw = 64 >> (2 - lv), step = P.sub_sampled ? 2 : 1, bh = bw / step, mw = (P.sa_width + 7) & ~7, mh = P.sa_height;
+        int maw = P.sa_width, mah = P.sa_height;
+        if (P.per_ref_area) {
+            maw = mah = 1;
+            for (uint32_t r = 0; r < P.n_refs; r++) { maw = P.sa_width_ref[r] > maw ? P.sa_width_ref[r] : maw; mah = P.sa_height_ref[r] > mah ? P.sa_height_ref[r] : mah; }
+        }
+        const int bw = 64 >> (2 - lv), step = P.sub_sampled ? 2 : 1, bh = bw / step, mw = (maw + 7) & ~7, mh = mah;
         const int sb = bw * bh, wb = ((((bw + mw + 3) >> 2) + 3) & ~1) * 4 * (mh + step * (bh - 1));
         src_budget = sb > src_budget ? sb : src_budget;
         win_budget = wb > win_budget ? wb : win_budget;
     }
     src_budget = (src_budget > SLR_SRC_BYTES ? SLR_SRC_BYTES : src_budget + 15) & ~15;
     win_budget = (win_budget > SLR_WIN_BYTES ? SLR_WIN_BYTES : win_budget + 15) & ~15;
-    A.n = n; A.win_budget = win_budget; A.src_budget = src_budget;
+    A.n = n; A.win_budget = win_budget; A.src_budget = src_budget; A.zz_sad = zz_sad;
     hipLaunchKernelGGL(hme_chain_kernel, dim3((n + 3) / 4), dim3(256), 4 * (size_t)(src_budget + win_budget) + 64, (hipStream_t)stream, A);
     SVT_LAUNCH_CHECK();
 }

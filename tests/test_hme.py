@@ -104,7 +104,7 @@ def test_hme_level_hip(be, oracle, case):
     d_pl, d_prev = be.dev(planes), be.dev(prev)
     d_sad, d_sc = be.empty(n, np.uint64), be.dev(np.zeros((n, 2), np.int16))
     d_ws = be.empty(be.lib.svt_hip_hme_level_workspace(C.addressof(P)), np.uint8)
-    be.lib.svt_hip_hme_level_batch(C.addressof(P), be.ptr(d_pl), be.ptr(d_pl), be.ptr(d_prev), be.ptr(d_sad), be.ptr(d_sc), be.ptr(d_ws), be.stream)
+    be.lib.svt_hip_hme_level_batch(C.addressof(P), be.ptr(d_pl), be.ptr(d_pl), be.ptr(d_prev), None, be.ptr(d_sad), be.ptr(d_sc), be.ptr(d_ws), be.stream)
     assert np.array_equal(be.host(d_sad), want[0]), case
     assert np.array_equal(be.host(d_sc), want[1]), case
 
@@ -146,7 +146,7 @@ def test_hme_three_level_chain_hip(be, oracle):
         d_pl = be.dev(planes)
         d_sad, d_sc = be.empty(n, np.uint64), be.dev(np.zeros((n, 2), np.int16))
         d_ws = be.empty(be.lib.svt_hip_hme_level_workspace(C.addressof(P)), np.uint8)
-        be.lib.svt_hip_hme_level_batch(C.addressof(P), be.ptr(d_pl), be.ptr(d_pl), be.ptr(d_prev), be.ptr(d_sad), be.ptr(d_sc), be.ptr(d_ws), be.stream)
+        be.lib.svt_hip_hme_level_batch(C.addressof(P), be.ptr(d_pl), be.ptr(d_pl), be.ptr(d_prev), None, be.ptr(d_sad), be.ptr(d_sc), be.ptr(d_ws), be.stream)
         assert np.array_equal(be.host(d_sad), sad_o) and np.array_equal(be.host(d_sc), prev_o), lv
         d_prev = d_sc
         fused.append((P, d_pl, sad_o, prev_o))
@@ -156,7 +156,7 @@ def test_hme_three_level_chain_hip(be, oracle):
     planes_p = (C.c_void_p * 3)(*[be.ptr(f[1]) for f in fused])
     d_sads, d_scs = [be.empty(n, np.uint64) for _ in range(3)], [be.dev(np.zeros((n, 2), np.int16)) for _ in range(3)]
     sad_p, sc_p = (C.c_void_p * 3)(*[be.ptr(x) for x in d_sads]), (C.c_void_p * 3)(*[be.ptr(x) for x in d_scs])
-    be.lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(planes_p), C.addressof(planes_p), C.addressof(sad_p), C.addressof(sc_p), be.stream)
+    be.lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(planes_p), C.addressof(planes_p), None, C.addressof(sad_p), C.addressof(sc_p), be.stream)
     for lv in range(3):
         assert np.array_equal(be.host(d_sads[lv]), fused[lv][2]) and np.array_equal(be.host(d_scs[lv]), fused[lv][3]), ("fused", lv)
 
@@ -228,6 +228,9 @@ def test_me_integer_search_hip(be, oracle, ci):
     sad, sc = make_hme_results(g, n_refs * n_sb, nw * nh, W, H)
     dist, rpi = [c["dist"], max(1, c["dist"] - 1), c["dist"] + 1], [c["r"], 0, 1]
     do_ref = (g.random((n_sb, n_refs)) < 0.85).astype(np.uint8)
+    do_ref8 = np.ones((n_sb, 2, 4), np.uint8)  # search_results[list][ref] layout: slot 0 = list 0, slots 1, 2 = list 1
+    for r in range(n_refs):
+        do_ref8[:, int(r >= 1), rpi[r]] = do_ref[:, r]
     div = np.where(g.random((n_sb, n_refs)) < 0.5, c["div"], 1).astype(np.uint32)
     P = pkg.MeIntegerSearchParams()
     P.sbs_x, P.sbs_y, P.n_refs, P.regions, P.aligned_width, P.aligned_height = sbs_x, sbs_y, n_refs, nw * nh, aw, ah
@@ -236,12 +239,13 @@ def test_me_integer_search_hip(be, oracle, ci):
     for r in range(n_refs):
         P.dist[r], P.ref_pic_index[r], P.ref_off[r] = dist[r], rpi[r], (1 + r) * src.size
     P.src_off, P.src_stride, P.ref_stride, P.ref_org_x, P.ref_org_y = org * stride + org, stride, stride, org, org
+    P.n_refs_list0 = 1
     planes = np.stack([src] + refs)
-    d_pl, d_sad, d_sc, d_do, d_div = be.dev(planes), be.dev(sad), be.dev(sc), be.dev(do_ref), be.dev(div)
+    d_pl, d_sad, d_sc, d_do, d_div = be.dev(planes), be.dev(sad), be.dev(sc), be.dev(do_ref8), be.dev(div)
     d_bs, d_bm = be.empty((n_refs, n_sb, 85), np.uint32), be.empty((n_refs, n_sb, 85), np.uint32)
     d_sco, d_sado = be.empty((n_refs, n_sb, 2), np.int16), be.empty((n_refs, n_sb), np.uint64)
     d_ws = be.empty(be.lib.svt_hip_me_integer_search_workspace(C.addressof(P)), np.uint8)
-    be.lib.svt_hip_me_integer_search_batch(C.addressof(P), be.ptr(d_pl), be.ptr(d_pl), be.ptr(d_sad), be.ptr(d_sc), be.ptr(d_do), be.ptr(d_div), be.ptr(d_bs),
+    be.lib.svt_hip_me_integer_search_batch(C.addressof(P), be.ptr(d_pl), be.ptr(d_pl), be.ptr(d_sad), be.ptr(d_sc), be.ptr(d_do), be.ptr(d_div), None, be.ptr(d_bs),
                                            be.ptr(d_bm), be.ptr(d_sco), be.ptr(d_sado), be.ptr(d_ws), be.stream)
     bs, bm, sco, sado = be.host(d_bs), be.host(d_bm), be.host(d_sco), be.host(d_sado)
     checked = 0
@@ -369,9 +373,19 @@ def scaled_distance(d):  # svt_aom_get_scaled_picture_distance (motion_estimatio
     return d * 5 // 8 + (1 if d % 8 else 0)
 
 
-def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref):
-    """End to end: host pictures -> svt_hip_me_session_submit_stage vs the reference's own svt_aom_motion_estimation_b64 run on every SB (HME 0-2,
-    final centre, integer search, reference pruning on ME SADs, MeSbResults, distortion statistics, GM flags); probes / early exits off."""
+STAGE_OPTS = [dict(name="baseline"),
+              dict(name="early_exit", me_early_exit_th=64 * 64 * 8),
+              dict(name="early_exit_low", me_early_exit_th=64 * 64 * 3, l0=(32, 16, 96, 48)),
+              dict(name="hme_prune_sr_adjust", hme_prune=25, sr=(1, 6, 9000, 4, 20000, 2), l0=(32, 16, 64, 32)),
+              dict(name="all", me_early_exit_th=64 * 64 * 6, hme_prune=40, sr=(1, 4, 12000, 3, 30000, 2), l0=(48, 24, 96, 48))]
+
+
+@pytest.mark.parametrize("oi", range(len(STAGE_OPTS)))
+def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
+    """End to end: host pictures -> svt_hip_me_session_submit_stage vs the reference's own svt_aom_motion_estimation_b64 run on every SB (zero-motion
+    SAD gating, HME 0-2 with per-reference level-0 areas, final centre, HME-based reference pruning and search-range divisors, integer search,
+    reference pruning on ME SADs, MeSbResults, distortion statistics, GM flags)."""
+    opt = STAGE_OPTS[oi]
     if not os.path.exists(REF_ME_LIB):
         pytest.skip("oracle/_ref/libsvtref_me.so not available")
     import test_me_results as M
@@ -387,6 +401,8 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref):
     for k in range(4):
         a = np.zeros((rows, stride), np.uint8)
         a[PAD:PAD + H, PAD:PAD + W] = base[8 + k:8 + k + H, 8 + 2 * k:8 + 2 * k + W] + g.integers(0, 4, (H, W), dtype=np.uint8)
+        # a static region (zero-motion SAD small enough for the early exits) next to the moving one
+        a[PAD:PAD + H, PAD:PAD + 100] = base[8:8 + H, 8:8 + 100] + g.integers(0, 2, (H, 100), dtype=np.uint8)
         oracle.oracle_generate_padding(p(a), stride, W, H, PAD, PAD)
         pics.append(a)
     numbers = {0: 41, 1: 38, 2: 39, 3: 40}  # picture 3 is the source; list 0 = pictures 2, 1 (past), list 1 = picture 0 (future)
@@ -403,6 +419,17 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref):
     rpi = [0, 1, 0]
     for r in range(3):
         S.dist[r], S.ref_pic_index[r] = dist[r], rpi[r]
+    l0 = opt.get("l0", (32, 16, 32, 16))  # total level-0 area: min w, min h, max w, max h (hme_l0_sa)
+    S.hme_l0_per_ref = 1
+    for r in range(3):  # get_hme_l0_search_area (:1853-1866) without distance-based resizing
+        S.hme_l0_sa_width_ref[r] = min((((l0[0] // nw) * dist[r]) + 15) & ~15, ((l0[2] // nw) + 15) & ~15)
+        S.hme_l0_sa_height_ref[r] = min((l0[1] // nh) * dist[r], l0[3] // nh)
+    S.me_early_exit_th = opt.get("me_early_exit_th", 0)
+    if "hme_prune" in opt:
+        S.hme_prune_enabled, S.prune_ref_if_hme_sad_dev_bigger_than_th = 1, opt["hme_prune"]
+    if "sr" in opt:
+        (S.sr_adjustment, S.reduce_me_sr_based_on_mv_length_th, S.stationary_hme_sad_abs_th, S.stationary_me_sr_divisor, S.reduce_me_sr_based_on_hme_sad_abs_th,
+         S.me_sr_divisor_for_low_hme_sad) = opt["sr"]
     cfg = (2, 2, 1, 1, 1, 0, 0, 1, 30, 40, 0, 1, 1)
     R = M.make_params(pkg, cfg, 0, g)
     R.picture_number = numbers[3]
@@ -435,6 +462,9 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref):
         oracle.oracle_generate_padding(p(x), sw + 32, sw, sh, 16, 16)
         return [x, q, full]
     lv = [decimate(pc) for pc in pics]
+    if opt.get("me_early_exit_th"):  # the static first SB column really takes the early exits, the moving one does not
+        zz = lambda x0: 2 * int(np.abs(pics[3][PAD:PAD + 64:2, PAD + x0:PAD + x0 + 64].astype(np.int32) - pics[2][PAD:PAD + 64:2, PAD + x0:PAD + x0 + 64]).sum())
+        assert zz(0) < opt["me_early_exit_th"] // 4 < zz(128), (zz(0), zz(128))  # (with the 64*64*8 threshold also below th / 6: single-point ME)
 
     def picture(i):
         P_ = RefPicture()
@@ -448,8 +478,13 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref):
     srcp = picture(3)
     O = RefMeStageOptions()
     O.num_hme_sa_w, O.num_hme_sa_h = nw, nh
-    O.hme_l0_min_w = O.hme_l0_max_w = 32
-    O.hme_l0_min_h = O.hme_l0_max_h = 16
+    O.hme_l0_min_w, O.hme_l0_min_h, O.hme_l0_max_w, O.hme_l0_max_h = l0
+    O.me_early_exit_th = opt.get("me_early_exit_th", 0)
+    if "hme_prune" in opt:
+        O.hme_prune_enabled, O.prune_ref_if_hme_sad_dev_bigger_than_th = 1, opt["hme_prune"]
+    if "sr" in opt:
+        (O.sr_adjustment, O.reduce_me_sr_based_on_mv_length_th, O.stationary_hme_sad_abs_th, O.stationary_me_sr_divisor, O.reduce_me_sr_based_on_hme_sad_abs_th,
+         O.me_sr_divisor_for_low_hme_sad) = opt["sr"]
     O.hme_l1_w, O.hme_l1_h, O.hme_l2_w, O.hme_l2_h = 8, 3, 8, 3
     O.me_min_w, O.me_min_h, O.me_max_w, O.me_max_h = 8, 3, 24, 12
     O.mv_adj_enabled, O.mv_adj_nearest_ref_only, O.mv_adj_mv_size_th, O.mv_adj_sa_multiplier = 1, 1, 4, 2
@@ -459,8 +494,9 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref):
         st, bs, bm, dr = np.zeros(1, pkg.MeSbStats), np.zeros((2, 4, 85), np.uint32), np.zeros((2, 4, 85), np.uint32), np.zeros((2, 4), np.uint8)
         refme.ref_motion_estimation_b64(C.byref(O), C.byref(R), C.byref(srcp), C.byref(refs), W, H, (sb % sbs_x) * 64, (sb // sbs_x) * 64, p(tot), p(mvs), p(cands),
                                         p(st), p(bs), p(bm), p(dr))
+        assert np.array_equal(out["do_ref"][sb, 0, :2], dr[0, :2]) and out["do_ref"][sb, 1, 0] == dr[1, 0], ("do_ref", opt["name"], sb, out["do_ref"][sb], dr)
         for r, (l, ri) in enumerate(((0, 0), (0, 1), (1, 0))):
-            assert np.array_equal(out["bs"][r, sb], bs[l, ri]) and np.array_equal(out["bm"][r, sb], bm[l, ri]), ("tables", sb, r)
-        assert np.array_equal(out["do_ref"][sb, 0, :2], dr[0, :2]) and out["do_ref"][sb, 1, 0] == dr[1, 0], ("do_ref", sb)
+            if dr[l, ri]:  # a pruned reference is not searched by the reference: its tables are don't-care
+                assert np.array_equal(out["bs"][r, sb], bs[l, ri]) and np.array_equal(out["bm"][r, sb], bm[l, ri]), ("tables", opt["name"], sb, r)
         assert np.array_equal(out["total"][sb], tot) and np.array_equal(out["cand"][sb], cands) and np.array_equal(out["mv"][sb], mvs), ("MeSbResults", sb)
         assert out["stats"][sb] == st[0], ("stats", sb, out["stats"][sb], st[0])
