@@ -193,8 +193,8 @@ void   svt_hip_hme_chain_batch(const SvtHipHmeLevelParams *params, const uint8_t
 /* Integer ME of a whole picture from its HME results = set_final_seach_centre_sb (motion_estimation.c:2182-2368: per (reference, SB) the first
  * strictly smallest SAD over the search regions) + integer_search_b64's search-area geometry (:1294-1325, :1458-1508: min(sa_min * dist, sa_max),
  * enlargement for long search-centre components, division by reduce_me_sr_divisor, width rounded up to 8, centred on the HME result, clipped to the
- * picture + 63-sample border) + svt_hip_me_fullpel_search_batch.  Covers the option set without content-dependent probes (me_early_exit_th = 0,
- * is_ref = 0, me_sr_adjustment < 2, me_8x8_var off), which need a pre-search per SB and stay with the caller.
+ * picture + 63-sample border) + svt_hip_me_fullpel_search_batch, including hme_prune_ref_and_adjust_sr, the zero-motion early exit, check_00_center
+ * and the 8x8-variance probe.  Not covered: me_sr_adjustment = 2 (its second rule makes the references of an SB depend on each other's final SADs).
  * hme_sad / hme_sc: the last HME level's outputs in svt_hip_hme_level_batch's item order ((ref * n_sb + sb) * regions + region).
  * do_ref ([n_sb][2][4] = search_results[list][ref].do_ref as svt_hip_me_results_batch takes it, or NULL = all; in/out: HME-based pruning clears entries): a 0 entry gets a 1 x 1 placeholder search whose results must
  * be ignored (the reference skips the reference picture, :1292-1293).  divisor ([n_sb][n_refs] uint32, or NULL = 1) = me_ctx->reduce_me_sr_divisor
@@ -226,6 +226,14 @@ typedef struct SvtHipMeIntegerSearchParams {
     uint16_t reduce_me_sr_based_on_mv_length_th, stationary_hme_sad_abs_th, stationary_me_sr_divisor, reduce_me_sr_based_on_hme_sad_abs_th,
              me_sr_divisor_for_low_hme_sad;
     uint32_t me_early_exit_th;                /* 0 = off; else zz_sad < th / 6 searches a single point (:1322-1327) */
+    /* content-dependent steps of integer_search_b64 (extra per-item SADs / a single-point pre-search on the device): */
+    uint8_t  is_ref;                          /* me_ctx->is_ref: with me_early_exit_th = 0, a non-zero search centre is checked against (0, 0) on the
+                                                 sub-sampled 64x64 SAD (check_00_center, :1139-1206), after being clipped to the picture + 63 */
+    uint8_t  me_8x8_var_enabled;              /* me_8x8_var_ctrls: areas > 24 positions first search the centre alone; the variance of its 64 8x8 SADs
+                                                 scales the area (:1388-1420); the centre's results take part in the final minimum */
+    uint8_t  pad3[2];
+    uint32_t me_sr_div4_th, me_sr_div2_th, me_sr_mult2_th;
+    uint32_t ref_width, ref_height;           /* EbPictureBufferDesc width / height of the references (check_00_center clips against them) */
 } SvtHipMeIntegerSearchParams;
 size_t svt_hip_me_integer_search_workspace(const SvtHipMeIntegerSearchParams *params);
 void   svt_hip_me_integer_search_batch(const SvtHipMeIntegerSearchParams *params, const uint8_t *src_base, const uint8_t *ref_base,
@@ -397,6 +405,8 @@ typedef struct SvtHipMeStageParams {
     uint16_t reduce_me_sr_based_on_mv_length_th, stationary_hme_sad_abs_th, stationary_me_sr_divisor, reduce_me_sr_based_on_hme_sad_abs_th,
              me_sr_divisor_for_low_hme_sad;
     uint32_t me_early_exit_th;           /* 0 = off */
+    uint8_t  is_ref, me_8x8_var_enabled, pad1[2]; /* as SvtHipMeIntegerSearchParams */
+    uint32_t me_sr_div4_th, me_sr_div2_th, me_sr_mult2_th;
     SvtHipMeResultsParams results;       /* formatting parameters (n_sb is filled in by the session) */
 } SvtHipMeStageParams;
 int svt_hip_me_session_enable_stage(void *session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,

@@ -211,7 +211,9 @@ class MeIntegerSearchParams(C.Structure):
                 ("ref_org_x", C.c_uint32), ("ref_org_y", C.c_uint32), ("ref_off", C.c_uint64 * 8), ("n_refs_list0", C.c_uint8),
                 ("hme_prune_enabled", C.c_uint8), ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16), ("sr_adjustment", C.c_uint8), ("pad2", C.c_uint8),
                 ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16), ("stationary_me_sr_divisor", C.c_uint16),
-                ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("me_early_exit_th", C.c_uint32)]
+                ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("me_early_exit_th", C.c_uint32),
+                ("is_ref", C.c_uint8), ("me_8x8_var_enabled", C.c_uint8), ("pad3", C.c_uint8 * 2), ("me_sr_div4_th", C.c_uint32), ("me_sr_div2_th", C.c_uint32),
+                ("me_sr_mult2_th", C.c_uint32), ("ref_width", C.c_uint32), ("ref_height", C.c_uint32)]
 
 
 class TfParams(C.Structure):
@@ -240,7 +242,8 @@ class MeStageParams(C.Structure):
                 ("hme_l0_sa_width_ref", C.c_int16 * 8), ("hme_l0_sa_height_ref", C.c_int16 * 8), ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16),
                 ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16), ("stationary_me_sr_divisor", C.c_uint16),
                 ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("me_early_exit_th", C.c_uint32),
-                ("results", MeResultsParams)]
+                ("is_ref", C.c_uint8), ("me_8x8_var_enabled", C.c_uint8), ("pad1", C.c_uint8 * 2), ("me_sr_div4_th", C.c_uint32), ("me_sr_div2_th", C.c_uint32),
+                ("me_sr_mult2_th", C.c_uint32), ("results", MeResultsParams)]
 
 
 class MeResultsHost(C.Structure):

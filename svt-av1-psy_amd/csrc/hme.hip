@@ -57,15 +57,23 @@ inline HmeWs hme_ws(uint32_t n) {
 // ---- integer ME from the HME results.  One thread per SB walks its reference slots three times, as the reference's per-SB code does: final search
 // centre per slot (set_final_seach_centre_sb), then hme_prune_ref_and_adjust_sr over all slots (needs the best HME SAD of the SB), then
 // integer_search_b64's area geometry per slot -> SvtHipMeSearchDesc.  Item index = ref * n_sb + sb.
+struct MeIntRec { // per item, between the phases of the probing form
+    int16_t  cx, cy, w, h; // search centre (after check_00_center), area before the variance scaling
+    uint8_t  live, check00, probe, pad;
+};
+// PHASE 0: all in one kernel (no probes).  PHASE 1: up to the base area -> records (+ single-point descriptors for the variance probe).
+// PHASE 2: records (+ probe tables) -> final descriptors.
+template <int PHASE>
 __global__ __launch_bounds__(64) void me_int_descs_kernel(const SvtHipMeIntegerSearchParams P, const unsigned long long* __restrict__ hme_sad,
                                                           const int16_t* __restrict__ hme_sc, uint8_t* __restrict__ do_ref, uint32_t* __restrict__ divisor,
                                                           const uint32_t* __restrict__ zz_sad, SvtHipMeSearchDesc* __restrict__ descs,
-                                                          int16_t* __restrict__ sc_out, unsigned long long* __restrict__ sad_out) {
+                                                          int16_t* __restrict__ sc_out, unsigned long long* __restrict__ sad_out,
+                                                          MeIntRec* __restrict__ recs, const uint32_t* __restrict__ probe_sad) {
     const uint32_t n_sb = P.sbs_x * P.sbs_y, sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= n_sb) return;
     int16_t            cx[8], cy[8];
     unsigned long long csad[8], best_all = 0xffffffffull; // slots HME never touched keep MAX_U32 (init_me_hme_data, :3061)
-    for (uint32_t r = 0; r < P.n_refs; r++) {
+    for (uint32_t r = 0; r < P.n_refs && PHASE != 2; r++) {
         const uint32_t i = r * n_sb + sb;
         // set_final_seach_centre_sb: first strictly smaller SAD, regions in sr_h-outer / sr_w-inner order
         const unsigned long long* ps = hme_sad + (size_t)i * P.regions;
@@ -80,8 +88,14 @@ __global__ __launch_bounds__(64) void me_int_descs_kernel(const SvtHipMeIntegerS
     }
     for (uint32_t r = 0; r < P.n_refs; r++) {
         const uint32_t i = r * n_sb + sb;
+        const int      b64_origin_x = (int)(sb % P.sbs_x) * 64, b64_origin_y = (int)(sb / P.sbs_x) * 64;
+        const int16_t  pad_width = 63, pad_height = 63, org_x = (int16_t)b64_origin_x, org_y = (int16_t)b64_origin_y;
+        const int      picture_width = (int16_t)P.aligned_width, picture_height = (int16_t)P.aligned_height;
+        int16_t x_search_center, y_search_center, search_area_width, search_area_height;
+        bool    live;
+        if (PHASE != 2) {
         const size_t dri = (size_t)sb * 8 + (r < P.n_refs_list0 ? 0 : 4) + P.ref_pic_index[r]; // search_results[list][ref] layout, as svt_hip_me_results_batch
-        bool     live = do_ref ? do_ref[dri] != 0 : true;
+        live = do_ref ? do_ref[dri] != 0 : true;
         // hme_prune_ref_and_adjust_sr: references (other than the first of each list) whose HME SAD is th % above the best are dropped ...
         if (P.hme_prune_enabled && P.ref_pic_index[r] != 0 && (csad[r] - best_all) * 100 > (unsigned long long)P.prune_ref_if_hme_sad_dev_bigger_than_th * best_all) {
             live = false;
@@ -97,12 +111,8 @@ __global__ __launch_bounds__(64) void me_int_descs_kernel(const SvtHipMeIntegerS
                 div = P.me_sr_divisor_for_low_hme_sad;
             if (divisor) divisor[(size_t)sb * P.n_refs + r] = div;
         }
-        const int16_t x_search_center = cx[r], y_search_center = cy[r];
-
-        const int      b64_origin_x = (int)(sb % P.sbs_x) * 64, b64_origin_y = (int)(sb / P.sbs_x) * 64;
-        const int16_t  pad_width = 63, pad_height = 63, org_x = (int16_t)b64_origin_x, org_y = (int16_t)b64_origin_y;
-        const int      picture_width = (int16_t)P.aligned_width, picture_height = (int16_t)P.aligned_height;
-        int16_t search_area_width = P.sa_min_width, search_area_height = P.sa_min_height;
+        x_search_center = cx[r]; y_search_center = cy[r];
+        search_area_width = P.sa_min_width; search_area_height = P.sa_min_height;
         {
             const int w = search_area_width * P.dist[r], h = search_area_height * P.dist[r];
             search_area_width  = (int16_t)(w < (uint16_t)P.sa_max_width ? w : (uint16_t)P.sa_max_width);
@@ -118,6 +128,39 @@ __global__ __launch_bounds__(64) void me_int_descs_kernel(const SvtHipMeIntegerS
             search_area_height = (int16_t)(h > 3 ? h : 3);
         }
         if (P.me_early_exit_th && zz_sad[i] < P.me_early_exit_th / 6) { search_area_width = 1; search_area_height = 1; } // :1322-1327
+        if (PHASE == 1) {
+            MeIntRec rec;
+            rec.cx = x_search_center; rec.cy = y_search_center; rec.w = search_area_width; rec.h = search_area_height;
+            rec.live = live; rec.check00 = live && !P.me_early_exit_th && P.is_ref && (x_search_center != 0 || y_search_center != 0); rec.probe = 0; rec.pad = 0;
+            recs[i] = rec;
+            continue;
+        }
+        } else { // PHASE 2: centre possibly replaced by check_00_center, then the variance scaling of the area (:1388-1420)
+            const MeIntRec rec = recs[i];
+            x_search_center = rec.cx; y_search_center = rec.cy; search_area_width = rec.w; search_area_height = rec.h; live = rec.live;
+            if (rec.probe) {
+                const uint32_t* t = probe_sad + (size_t)i * 85;
+                const uint32_t  mean = t[0] / 64;
+                uint32_t        ssq = 0;
+                for (int k = 0; k < 64; k++) { const int32_t diff = (int32_t)t[21 + k] - (int32_t)mean; ssq += (uint32_t)(diff * diff); }
+                const uint32_t var = ssq / 64;
+                if (var > P.me_sr_mult2_th) {
+                    const int w = search_area_width * 3 / 2, h = search_area_height * 3 / 2;
+                    search_area_width  = (int16_t)(((w > 1 ? w : 1) + 7) & ~0x7);
+                    search_area_height = (int16_t)(h > 1 ? h : 1);
+                }
+                if (var < P.me_sr_div4_th) {
+                    const int w = search_area_width >> 2, h = search_area_height >> 2;
+                    search_area_width  = (int16_t)(((w > 1 ? w : 1) + 7) & ~0x7);
+                    search_area_height = (int16_t)((h > 1 ? h : 1) > 3 ? (h > 1 ? h : 1) : 3);
+                } else if (var < P.me_sr_div2_th) {
+                    const int w = search_area_width >> 1 < search_area_width ? search_area_width >> 1 : search_area_width;
+                    const int h = search_area_height >> 1 < search_area_height ? search_area_height >> 1 : search_area_height;
+                    search_area_width  = (int16_t)((w + 7) & ~0x7);
+                    search_area_height = (int16_t)(h > 3 ? h : 3);
+                }
+            }
+        }
         int16_t x_search_area_origin = (int16_t)(x_search_center - (search_area_width >> 1));
         int16_t y_search_area_origin = (int16_t)(y_search_center - (search_area_height >> 1));
         // origin and size are corrected by separate conditionals, the size one evaluated with the corrected origin (:1462-1467): the left / top
@@ -157,6 +200,65 @@ __global__ __launch_bounds__(64) void me_int_descs_kernel(const SvtHipMeIntegerS
     }
 }
 
+// sub-sampled 64 x h SAD of the SB against the reference at displacement (dx, dy): svt_nxm_sad_kernel(src, stride << 1, ref, stride << 1, h >> 1, w), one wave
+__device__ __forceinline__ uint32_t sb_sub_sad(const uint8_t* __restrict__ s, const uint32_t ss, const uint8_t* __restrict__ f, const uint32_t fs, const uint32_t bw,
+                                               const uint32_t bh, const uint32_t l) {
+    uint32_t sad = 0;
+    for (uint32_t y = l >> 1; y < (bh >> 1); y += 32)
+        for (uint32_t x = (l & 1) * 32; x < bw && x < (l & 1) * 32 + 32; x++) {
+            const int d = (int)s[(size_t)(2 * y) * ss + x] - (int)f[(size_t)(2 * y) * fs + x];
+            sad += (uint32_t)(d < 0 ? -d : d);
+        }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sad += (uint32_t)__shfl_xor((int)sad, m);
+    return sad;
+}
+// check_00_center (:1139-1206), one wave per item flagged by phase 1: clip the HME centre to the picture + 63, compare its sub-sampled SAD with the
+// zero-motion one, keep (0, 0) when that is not worse; then decide whether the variance probe applies and emit its single-point descriptor.
+__global__ __launch_bounds__(256) void me_int_probe_kernel(const SvtHipMeIntegerSearchParams P, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                           MeIntRec* __restrict__ recs, SvtHipMeSearchDesc* __restrict__ probe_descs, const uint32_t n) {
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (i >= n) return;
+    const uint32_t n_sb = P.sbs_x * P.sbs_y, sb = i % n_sb, r = i / n_sb;
+    const uint32_t fx = (sb % P.sbs_x) * 64, fy = (sb / P.sbs_x) * 64;
+    const uint32_t bw = P.aligned_width - fx < 64 ? P.aligned_width - fx : 64, bh = P.aligned_height - fy < 64 ? P.aligned_height - fy : 64;
+    MeIntRec rec = recs[i];
+    if (rec.check00) {
+        const int16_t org_x = (int16_t)fx, org_y = (int16_t)fy, pad = 63, ref_w = (int16_t)P.ref_width, ref_h = (int16_t)P.ref_height;
+        int16_t x = rec.cx, y = rec.cy;
+        x = (int16_t)(((org_x + x) < -pad) ? -pad - org_x : x);
+        x = (int16_t)(((org_x + x) > ref_w - 1) ? x - ((org_x + x) - (ref_w - 1)) : x);
+        y = (int16_t)(((org_y + y) < -pad) ? -pad - org_y : y);
+        y = (int16_t)(((org_y + y) > ref_h - 1) ? y - ((org_y + y) - (ref_h - 1)) : y);
+        const uint8_t* s  = src_base + P.src_off + (size_t)fy * P.src_stride + fx;
+        const uint8_t* f0 = ref_base + P.ref_off[r] + (size_t)(P.ref_org_y + fy) * P.ref_stride + P.ref_org_x + fx;
+        const uint8_t* f1 = ref_base + P.ref_off[r] + (size_t)((int)(P.ref_org_y + fy) + y) * P.ref_stride + (int)(P.ref_org_x + fx) + x;
+        const uint32_t zero = sb_sub_sad(s, P.src_stride, f0, P.ref_stride, bw, bh, l) << 1, hme = sb_sub_sad(s, P.src_stride, f1, P.ref_stride, bw, bh, l) << 1;
+        if (zero <= hme) { x = 0; y = 0; } // MIN(zero cost, hme cost) == zero cost
+        rec.cx = x; rec.cy = y;
+    }
+    rec.probe = rec.live && P.me_8x8_var_enabled && (int)rec.w * (int)rec.h > 24;
+    if (l == 0) {
+        recs[i] = rec;
+        SvtHipMeSearchDesc d;
+        d.src_off    = P.src_off + (uint64_t)fy * P.src_stride + fx;
+        d.ref_off    = P.ref_off[r] + (uint64_t)((long long)((int)(P.ref_org_y + fy) + (rec.probe ? rec.cy : 0)) * (long long)P.ref_stride +
+                                                 (long long)((int)(P.ref_org_x + fx) + (rec.probe ? rec.cx : 0)));
+        d.src_stride = P.src_stride; d.ref_stride = P.ref_stride;
+        d.x_search_area_origin = rec.probe ? rec.cx : 0; d.y_search_area_origin = rec.probe ? rec.cy : 0;
+        d.search_area_width = 1; d.search_area_height = 1;
+        probe_descs[i] = d;
+    }
+}
+// the probe's single point was searched first and is never re-initialised (:1366, :1398-1404): it stays the winner unless the area search is strictly better
+__global__ __launch_bounds__(256) void me_int_merge_kernel(const MeIntRec* __restrict__ recs, const uint32_t* __restrict__ probe_sad, const uint32_t* __restrict__ probe_mv,
+                                                           uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, const uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 85) return;
+    if (!recs[t / 85].probe) return;
+    if (probe_sad[t] <= best_sad[t]) { best_sad[t] = probe_sad[t]; best_mv[t] = probe_mv[t]; }
+}
+
 // init_zz_sad: one wave per (reference, SB): lane = (row pair of the sub-sampled block, half row); sub-sampled SAD at the co-located position
 __global__ __launch_bounds__(256) void me_zz_sad_kernel(const SvtHipMeIntegerSearchParams P, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
                                                         uint32_t* __restrict__ zz_out, const uint32_t n) {
@@ -188,6 +290,7 @@ inline void me_int_max_area(const SvtHipMeIntegerSearchParams* P, uint32_t& mw, 
     if (P->mv_adj_enabled) { w *= P->mv_adj_sa_multiplier; h *= P->mv_adj_sa_multiplier; }
     mw = ((w > 1 ? w : 1) + 7) & ~7u;
     mh = h > 3 ? h : 3;
+    if (P->me_8x8_var_enabled) { mw = ((mw * 3 / 2) + 7) & ~7u; mh = mh * 3 / 2; } // me_sr_mult2_th
 }
 
 } // namespace
@@ -232,7 +335,8 @@ size_t svt_hip_me_integer_search_workspace(const SvtHipMeIntegerSearchParams* pa
     const uint32_t n = params->n_refs * params->sbs_x * params->sbs_y;
     uint32_t mw, mh;
     me_int_max_area(params, mw, mh);
-    return svthip::align_up((size_t)n * sizeof(SvtHipMeSearchDesc), 256) + svt_hip_me_fullpel_search_workspace(n, mw, mh);
+    return 2 * svthip::align_up((size_t)n * sizeof(SvtHipMeSearchDesc), 256) + svthip::align_up((size_t)n * sizeof(MeIntRec), 256) +
+           2 * svthip::align_up((size_t)n * 85 * 4, 256) + svt_hip_me_fullpel_search_workspace(n, mw, mh);
 }
 
 void svt_hip_me_zz_sad_batch(const SvtHipMeIntegerSearchParams* params, const uint8_t* src_base, const uint8_t* ref_base, uint32_t* zz_out, void* stream) {
@@ -253,15 +357,41 @@ void svt_hip_me_integer_search_batch(const SvtHipMeIntegerSearchParams* params, 
         fprintf(stderr, "libsvtav1_hip: svt_hip_me_integer_search_batch: bad parameters\n");
         abort();
     }
-    SvtHipMeSearchDesc* descs = (SvtHipMeSearchDesc*)workspace;
-    void*               ws2   = (uint8_t*)workspace + svthip::align_up((size_t)n * sizeof(SvtHipMeSearchDesc), 256);
+    uint8_t* w = (uint8_t*)workspace;
+    SvtHipMeSearchDesc* descs  = (SvtHipMeSearchDesc*)w;  w += svthip::align_up((size_t)n * sizeof(SvtHipMeSearchDesc), 256);
+    SvtHipMeSearchDesc* pdescs = (SvtHipMeSearchDesc*)w;  w += svthip::align_up((size_t)n * sizeof(SvtHipMeSearchDesc), 256);
+    MeIntRec*           recs   = (MeIntRec*)w;            w += svthip::align_up((size_t)n * sizeof(MeIntRec), 256);
+    uint32_t*           psad   = (uint32_t*)w;            w += svthip::align_up((size_t)n * 85 * 4, 256);
+    uint32_t*           pmv    = (uint32_t*)w;            w += svthip::align_up((size_t)n * 85 * 4, 256);
+    void*               ws2    = w;
     const uint32_t n_sb = params->sbs_x * params->sbs_y;
-    hipLaunchKernelGGL(me_int_descs_kernel, dim3((n_sb + 63) / 64), dim3(64), 0, (hipStream_t)stream, *params, (const unsigned long long*)hme_sad, hme_sc, do_ref,
-                       divisor, zz_sad, descs, sc_out, (unsigned long long*)sad_out);
-    SVT_LAUNCH_CHECK();
+    const dim3     gsb((n_sb + 63) / 64), bsb(64);
+    hipStream_t    st = (hipStream_t)stream;
     uint32_t mw, mh;
     me_int_max_area(params, mw, mh);
+    const bool probing = (params->is_ref && !params->me_early_exit_th) || params->me_8x8_var_enabled;
+    if (!probing) {
+        hipLaunchKernelGGL(me_int_descs_kernel<0>, gsb, bsb, 0, st, *params, (const unsigned long long*)hme_sad, hme_sc, do_ref, divisor, zz_sad, descs, sc_out,
+                           (unsigned long long*)sad_out, (MeIntRec*)nullptr, (const uint32_t*)nullptr);
+        SVT_LAUNCH_CHECK();
+        svt_hip_me_fullpel_search_batch(src_base, ref_base, descs, n, mw, mh, params->sub_sad, best_sad, best_mv, ws2, stream);
+        return;
+    }
+    hipLaunchKernelGGL(me_int_descs_kernel<1>, gsb, bsb, 0, st, *params, (const unsigned long long*)hme_sad, hme_sc, do_ref, divisor, zz_sad, descs, sc_out,
+                       (unsigned long long*)sad_out, recs, (const uint32_t*)nullptr);
+    SVT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(me_int_probe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, *params, src_base, ref_base, recs, pdescs, n);
+    SVT_LAUNCH_CHECK();
+    if (params->me_8x8_var_enabled) svt_hip_me_fullpel_search_batch(src_base, ref_base, pdescs, n, 1, 1, params->sub_sad, psad, pmv, ws2, stream);
+    hipLaunchKernelGGL(me_int_descs_kernel<2>, gsb, bsb, 0, st, *params, (const unsigned long long*)hme_sad, hme_sc, do_ref, divisor, zz_sad, descs, sc_out,
+                       (unsigned long long*)sad_out, recs, (const uint32_t*)psad);
+    SVT_LAUNCH_CHECK();
     svt_hip_me_fullpel_search_batch(src_base, ref_base, descs, n, mw, mh, params->sub_sad, best_sad, best_mv, ws2, stream);
+    if (params->me_8x8_var_enabled) {
+        hipLaunchKernelGGL(me_int_merge_kernel, dim3((n * 85 + 255) / 256), dim3(256), 0, st, (const MeIntRec*)recs, (const uint32_t*)psad, (const uint32_t*)pmv, best_sad,
+                           best_mv, n);
+        SVT_LAUNCH_CHECK();
+    }
 }
 
 } // extern "C"

@@ -271,6 +271,8 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         Q.stationary_hme_sad_abs_th = stage->stationary_hme_sad_abs_th; Q.stationary_me_sr_divisor = stage->stationary_me_sr_divisor;
         Q.reduce_me_sr_based_on_hme_sad_abs_th = stage->reduce_me_sr_based_on_hme_sad_abs_th;
         Q.me_sr_divisor_for_low_hme_sad = stage->me_sr_divisor_for_low_hme_sad; Q.me_early_exit_th = stage->me_early_exit_th;
+        Q.is_ref = stage->is_ref; Q.me_8x8_var_enabled = stage->me_8x8_var_enabled; Q.me_sr_div4_th = stage->me_sr_div4_th;
+        Q.me_sr_div2_th = stage->me_sr_div2_th; Q.me_sr_mult2_th = stage->me_sr_mult2_th; Q.ref_width = s->width; Q.ref_height = s->height;
         // search_results[].do_ref of the stage lives where the formatting step expects it, so HME-based pruning carries over to me_prune_ref
         uint8_t* d_do_ref = nullptr;
         if (fmt) {
@@ -335,8 +337,15 @@ int svt_hip_me_session_enable_stage(void* session, uint32_t quarter_pad, uint32_
     s->max_regions = max_regions; s->max_area_w = max_me_area_width; s->max_area_h = max_me_area_height;
     s->hme_items = (size_t)s->max_refs * s->sbs * max_regions;
     const size_t n = (size_t)s->sbs * s->max_refs;
-    s->int_ws = svthip::align_up(n * sizeof(SvtHipMeSearchDesc), 256) +
-                svt_hip_me_fullpel_search_workspace((uint32_t)n, (max_me_area_width + 7) & ~7u, max_me_area_height < 3 ? 3 : max_me_area_height);
+    { // workspace of the integer-search stage at the largest area the caller announced (including the variance probe's 3/2 enlargement)
+        SvtHipMeIntegerSearchParams D;
+        memset(&D, 0, sizeof(D));
+        D.sbs_x = (s->width + 63) / 64; D.sbs_y = s->sbs / D.sbs_x; D.n_refs = s->max_refs; D.regions = 1;
+        D.sa_min_width = D.sa_max_width = (int16_t)max_me_area_width; D.sa_min_height = D.sa_max_height = (int16_t)max_me_area_height;
+        for (int k = 0; k < 8; k++) D.dist[k] = 1;
+        D.me_8x8_var_enabled = 1;
+        s->int_ws = svt_hip_me_integer_search_workspace(&D);
+    }
     const size_t per_slot = 3 * (svthip::align_up(s->hme_items * 8, 256) + svthip::align_up(s->hme_items * 4, 256)) + svthip::align_up(n * 4, 256) +
                             svthip::align_up(n * 8, 256) + s->int_ws + svthip::align_up(n * 4, 256) + 256; // ... + zz_sad
     for (auto& sl : s->slots) HIP_CHECK(hipMalloc((void**)&sl.hme, per_slot));

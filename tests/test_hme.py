@@ -377,7 +377,13 @@ STAGE_OPTS = [dict(name="baseline"),
               dict(name="early_exit", me_early_exit_th=64 * 64 * 8),
               dict(name="early_exit_low", me_early_exit_th=64 * 64 * 3, l0=(32, 16, 96, 48)),
               dict(name="hme_prune_sr_adjust", hme_prune=25, sr=(1, 6, 9000, 4, 20000, 2), l0=(32, 16, 64, 32)),
-              dict(name="all", me_early_exit_th=64 * 64 * 6, hme_prune=40, sr=(1, 4, 12000, 3, 30000, 2), l0=(48, 24, 96, 48))]
+              dict(name="all", me_early_exit_th=64 * 64 * 6, hme_prune=40, sr=(1, 4, 12000, 3, 30000, 2), l0=(48, 24, 96, 48)),
+              dict(name="is_ref", is_ref=1),
+              dict(name="var_probe_lvl2", var=(80000, 150000, 0xffffffff), me=(16, 9, 48, 24)),
+              dict(name="var_probe_lvl1", var=(0, 0, 900000), me=(16, 9, 32, 16)),
+              dict(name="var_probe_mid", var=(2000, 20000, 200000), me=(16, 9, 32, 16), is_ref=1, hme_prune=40, sr=(1, 4, 12000, 3, 30000, 2)),
+              dict(name="preset8_like", me_early_exit_th=64 * 64 * 8, var=(80000, 150000, 0xffffffff), me=(16, 9, 32, 16), is_ref=1, hme_prune=30,
+                   sr=(1, 4, 12000, 3, 30000, 2), l0=(32, 16, 96, 48))]
 
 
 @pytest.mark.parametrize("oi", range(len(STAGE_OPTS)))
@@ -409,13 +415,17 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
     order = [2, 1, 0]
     dist = [scaled_distance(abs(numbers[3] - numbers[i])) for i in order]
     sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 4, 3, 48, 24, 2)
-    assert lib.svt_hip_me_session_enable_stage(sess, 32, 16, nw * nh, 48, 24) == 0
+    assert lib.svt_hip_me_session_enable_stage(sess, 32, 16, nw * nh, 96, 48) == 0
     S = pkg.MeStageParams()
     S.num_hme_sa_w, S.num_hme_sa_h, S.hme_sub_sampled, S.me_sub_sad = nw, nh, 0, 0
     for lv, (a, b) in enumerate(((16, 8), (8, 3), (8, 3))):
         S.hme_sa_width[lv], S.hme_sa_height[lv] = a, b
-    S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = 8, 3, 24, 12
+    me_sa = opt.get("me", (8, 3, 24, 12))
+    S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = me_sa
     S.mv_adj_enabled, S.mv_adj_nearest_ref_only, S.mv_adj_mv_size_th, S.mv_adj_sa_multiplier = 1, 1, 4, 2
+    S.is_ref = opt.get("is_ref", 0)
+    if "var" in opt:
+        S.me_8x8_var_enabled, (S.me_sr_div4_th, S.me_sr_div2_th, S.me_sr_mult2_th) = 1, opt["var"]
     rpi = [0, 1, 0]
     for r in range(3):
         S.dist[r], S.ref_pic_index[r] = dist[r], rpi[r]
@@ -486,9 +496,11 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
         (O.sr_adjustment, O.reduce_me_sr_based_on_mv_length_th, O.stationary_hme_sad_abs_th, O.stationary_me_sr_divisor, O.reduce_me_sr_based_on_hme_sad_abs_th,
          O.me_sr_divisor_for_low_hme_sad) = opt["sr"]
     O.hme_l1_w, O.hme_l1_h, O.hme_l2_w, O.hme_l2_h = 8, 3, 8, 3
-    O.me_min_w, O.me_min_h, O.me_max_w, O.me_max_h = 8, 3, 24, 12
+    O.me_min_w, O.me_min_h, O.me_max_w, O.me_max_h = me_sa
     O.mv_adj_enabled, O.mv_adj_nearest_ref_only, O.mv_adj_mv_size_th, O.mv_adj_sa_multiplier = 1, 1, 4, 2
-    O.temporal_layer_index, O.is_ref = 1, 0
+    O.temporal_layer_index, O.is_ref = 1, opt.get("is_ref", 0)
+    if "var" in opt:
+        O.me_8x8_var_enabled, (O.me_sr_div4_th, O.me_sr_div2_th, O.me_sr_mult2_th) = 1, opt["var"]
     for sb in range(n_sb):
         tot, mvs, cands = np.zeros(85, np.uint8), np.zeros(85 * R.max_refs, np.uint32), np.zeros(85 * R.max_cand, np.uint8)
         st, bs, bm, dr = np.zeros(1, pkg.MeSbStats), np.zeros((2, 4, 85), np.uint32), np.zeros((2, 4, 85), np.uint32), np.zeros((2, 4), np.uint8)

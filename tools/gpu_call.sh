@@ -1,3 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_hme.py tests/test_me_results.py tests/test_sad.py -m gpu -x -q 2>&1 | tail -3
-python tools/microbench.py mesessionstage mesession --steps 20 --warmup 3 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_hme.py tests/test_me_results.py -m gpu -x -q 2>&1 | tail -3
+python tools/microbench.py mestage mesessionstage --steps 20 --warmup 3 2>&1 | tail -1
