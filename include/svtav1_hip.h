@@ -178,6 +178,11 @@ typedef struct SvtHipHmeLevelParams {
     uint8_t  per_ref_area;           /* 1: level-0 areas differ per reference (get_hme_l0_search_area, :1800-1866): use sa_*_ref[ref] instead of sa_width / sa_height */
     uint8_t  pad1[3];
     int16_t  sa_width_ref[8], sa_height_ref[8];
+    uint8_t  n_refs_list0;           /* slots [0, n_refs_list0) are list 0 (needed with do_ref / pre-HME inputs) */
+    uint8_t  ref_pic_index[8];       /* index of each slot inside its list */
+    uint8_t  prehme_enabled;         /* chain form: after level 0 the worst of the 2 x 2 regions is replaced by the better pre-HME result if that beats it
+                                        (hme_level0_b64 :2001-2031) */
+    uint8_t  pad2[2];
     uint32_t zz_skip_th;             /* me_early_exit_th >> 2 (0 = off): items whose zero-motion SAD zz_sad[ref][sb] is below it skip the level with centre (0, 0) and SAD 0 (hme_level0_b64 :1922-1935, hme_level1_b64 :2057-2070; never applied at level 2) */
 } SvtHipHmeLevelParams;
 size_t svt_hip_hme_level_workspace(const SvtHipHmeLevelParams *params);
@@ -185,10 +190,37 @@ void   svt_hip_hme_level_batch(const SvtHipHmeLevelParams *params, const uint8_t
                                const uint32_t *zz_sad, uint64_t *sad_out, int16_t *sc_out, void *workspace, void *stream);
 /* Levels 0, 1 and 2 of every item in ONE launch (one wave walks an item through the three levels: level N+1 only needs level N's result of the same
  * item).  params[3] = the three levels (same n_refs / SB grid / regions; params[1].prev_shift = 1); src_base / ref_base / sad_out / sc_out: one
- * pointer per level; results identical to three svt_hip_hme_level_batch calls.  sc_out[lv] is in/out like there.  zz_sad (device, [ref][sb], or NULL):
- * see zz_skip_th. */
+ * pointer per level; results identical to three svt_hip_hme_level_batch calls.  sc_out[lv] is in/out like there. */
+typedef struct SvtHipPrehmeResult { /* me_ctx->prehme_data[list][ref][sr_i] (SearchInfo) of one (reference slot, SB, search region) */
+    uint64_t sad;
+    int16_t  mv_x, mv_y; /* best_mv.as_mv.col / row, full-resolution units */
+    uint8_t  valid, performed, pad[2];
+} SvtHipPrehmeResult;
+typedef struct SvtHipHmeChainInputs { /* optional device inputs of the chain, any may be NULL */
+    const uint32_t           *zz_sad;  /* [ref][sb]: see zz_skip_th */
+    const uint8_t            *do_ref;  /* [sb][2][4] = search_results[list][ref].do_ref: a 0 entry skips levels 0 and 1 with centre (0, 0), SAD MAX_U32 (:1963-1973, :2071-2082) */
+    const SvtHipPrehmeResult *prehme;  /* [ref][sb][2]: svt_hip_prehme_batch's output, used when params[0].prehme_enabled */
+} SvtHipHmeChainInputs;
 void   svt_hip_hme_chain_batch(const SvtHipHmeLevelParams *params, const uint8_t *const *src_base, const uint8_t *const *ref_base,
-                               const uint32_t *zz_sad, uint64_t *const *sad_out, int16_t *const *sc_out, void *stream);
+                               const SvtHipHmeChainInputs *inputs, uint64_t *const *sad_out, int16_t *const *sc_out, void *stream);
+/* What precedes the HME levels in hme_b64 (motion_estimation.c:2441-2450), for every SB of a picture:
+ * svt_hip_me_ref_gate_batch = the second half of init_zz_sad (:2402-2417): when the best zero-motion SAD of the SB is below zz_sad_th, references other than the
+ * first of each list whose zz_sad is zz_sad_pct % above it are dropped (temporal layers > 0 only).  do_ref [sb][2][4] in/out.
+ * svt_hip_prehme_batch = prehme_b64 (:1722-1798): two long thin search regions (vertical, horizontal) on the 1/16-area planes per reference through
+ * prehme_core (:1568-1666), with check_prehme_early_exit (zero-motion SAD below me_early_exit_th; list-1 shortcut from the list-0 result of the same
+ * index), then reference pruning on the pre-HME SADs (:1781-1797).  out [ref][sb][2]; do_ref in/out. */
+typedef struct SvtHipPrehmeParams {
+    SvtHipHmeLevelParams plane;       /* level = 0 plane geometry, SB grid, n_refs, n_refs_list0, ref_pic_index, sub_sampled (areas / regions unused) */
+    uint16_t sa_min_width[2], sa_min_height[2], sa_max_width[2], sa_max_height[2]; /* prehme_ctrl.prehme_sa_cfg[sr_i] */
+    uint16_t hme_sr_factor[8];        /* per slot: svt_aom_get_scaled_picture_distance(picture distance) */
+    uint8_t  skip_search_line, l1_early_exit, temporal_layer_gt0, pad;
+    uint32_t me_early_exit_th;        /* 0 = off */
+    uint32_t phme_sad_th; uint16_t phme_sad_pct; uint16_t pad2; /* me_hme_prune_ctrls */
+} SvtHipPrehmeParams;
+void   svt_hip_me_ref_gate_batch(const SvtHipHmeLevelParams *plane, const uint32_t *zz_sad, uint32_t zz_sad_th, uint32_t zz_sad_pct,
+                                 int temporal_layer_gt0, uint8_t *do_ref, void *stream);
+void   svt_hip_prehme_batch(const SvtHipPrehmeParams *params, const uint8_t *src_base, const uint8_t *ref_base, const uint32_t *zz_sad, uint8_t *do_ref,
+                            SvtHipPrehmeResult *out, void *stream);
 
 /* Integer ME of a whole picture from its HME results = set_final_seach_centre_sb (motion_estimation.c:2182-2368: per (reference, SB) the first
  * strictly smallest SAD over the search regions) + integer_search_b64's search-area geometry (:1294-1325, :1458-1508: min(sa_min * dist, sa_max),
@@ -407,6 +439,11 @@ typedef struct SvtHipMeStageParams {
     uint32_t me_early_exit_th;           /* 0 = off */
     uint8_t  is_ref, me_8x8_var_enabled, pad1[2]; /* as SvtHipMeIntegerSearchParams */
     uint32_t me_sr_div4_th, me_sr_div2_th, me_sr_mult2_th;
+    uint8_t  temporal_layer_gt0;         /* me_ctx->temporal_layer_index > 0 (list 1 takes part in pre-HME / HME, reference gating is active) */
+    uint8_t  prehme_enabled, prehme_skip_search_line, prehme_l1_early_exit; /* me_ctx->prehme_ctrl */
+    uint16_t prehme_sa_min_width[2], prehme_sa_min_height[2], prehme_sa_max_width[2], prehme_sa_max_height[2];
+    uint32_t zz_sad_th, phme_sad_th;     /* me_hme_prune_ctrls (0 = off) */
+    uint16_t zz_sad_pct, phme_sad_pct;
     SvtHipMeResultsParams results;       /* formatting parameters (n_sb is filled in by the session) */
 } SvtHipMeStageParams;
 int svt_hip_me_session_enable_stage(void *session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,

@@ -200,6 +200,9 @@ typedef struct RefMeStageOptions {
     uint16_t reduce_me_sr_based_on_mv_length_th, stationary_hme_sad_abs_th, stationary_me_sr_divisor, reduce_me_sr_based_on_hme_sad_abs_th,
              me_sr_divisor_for_low_hme_sad;
     uint8_t  distance_based_hme_resizing;
+    uint8_t  prehme_enabled, prehme_skip_search_line, prehme_l1_early_exit;
+    uint16_t prehme_sa_min_width[2], prehme_sa_min_height[2], prehme_sa_max_width[2], prehme_sa_max_height[2];
+    uint32_t zz_sad_th, phme_sad_th; uint16_t zz_sad_pct, phme_sad_pct;
 } RefMeStageOptions;
 void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsParams *P, const RefPicture *src, const RefPicture *refs /*[2][4]*/,
                                int pic_width, int pic_height, int b64_origin_x, int b64_origin_y, uint8_t *total_me_candidate_index,
@@ -280,6 +283,13 @@ void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsPar
     ctx->me_hme_prune_ctrls.enable_me_hme_ref_pruning = O->hme_prune_enabled || P->prune_ref;
     ctx->me_hme_prune_ctrls.prune_ref_if_hme_sad_dev_bigger_than_th = O->hme_prune_enabled ? O->prune_ref_if_hme_sad_dev_bigger_than_th : (uint16_t)~0;
     ctx->me_hme_prune_ctrls.prune_ref_if_me_sad_dev_bigger_than_th  = P->prune_ref ? P->prune_ref_if_me_sad_dev_bigger_than_th : (uint16_t)~0;
+    ctx->me_hme_prune_ctrls.zz_sad_th = O->zz_sad_th; ctx->me_hme_prune_ctrls.zz_sad_pct = O->zz_sad_pct;
+    ctx->me_hme_prune_ctrls.phme_sad_th = O->phme_sad_th; ctx->me_hme_prune_ctrls.phme_sad_pct = O->phme_sad_pct;
+    ctx->prehme_ctrl.enable = O->prehme_enabled; ctx->prehme_ctrl.skip_search_line = O->prehme_skip_search_line; ctx->prehme_ctrl.l1_early_exit = O->prehme_l1_early_exit;
+    for (int k = 0; k < 2; k++) {
+        ctx->prehme_ctrl.prehme_sa_cfg[k].sa_min.width = O->prehme_sa_min_width[k]; ctx->prehme_ctrl.prehme_sa_cfg[k].sa_min.height = O->prehme_sa_min_height[k];
+        ctx->prehme_ctrl.prehme_sa_cfg[k].sa_max.width = O->prehme_sa_max_width[k]; ctx->prehme_ctrl.prehme_sa_cfg[k].sa_max.height = O->prehme_sa_max_height[k];
+    }
     ctx->prune_me_candidates_th = P->prune_me_candidates_th;
     ctx->use_best_unipred_cand_only = P->use_best_unipred_cand_only;
     svt_aom_motion_estimation_b64(pcs, 0, (uint32_t)b64_origin_x, (uint32_t)b64_origin_y, ctx, &pics[0][2]);

@@ -84,6 +84,8 @@ PROTOTYPES = {
     "svt_hip_me_integer_search_batch": (None, [vp] * 14),
     "svt_hip_hme_chain_batch": (None, [vp] * 7),
     "svt_hip_me_zz_sad_batch": (None, [vp] * 5),
+    "svt_hip_me_ref_gate_batch": (None, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
+    "svt_hip_prehme_batch": (None, [vp] * 7),
     "svt_hip_hme_level_workspace": (C.c_size_t, [vp]),
     "svt_hip_hme_level_batch": (None, [vp] * 9),
     "svt_av1_apply_temporal_filter_planewise_medium_hip": (None, [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
@@ -198,7 +200,23 @@ class HmeLevelParams(C.Structure):
                 ("aligned_height", C.c_uint32), ("src_off", C.c_uint64), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32), ("ref_org_x", C.c_uint32),
                 ("ref_org_y", C.c_uint32), ("ref_width", C.c_uint32), ("ref_height", C.c_uint32), ("ref_off", C.c_uint64 * 8),
                 ("per_ref_area", C.c_uint8), ("pad1", C.c_uint8 * 3), ("sa_width_ref", C.c_int16 * 8), ("sa_height_ref", C.c_int16 * 8),
+                ("n_refs_list0", C.c_uint8), ("ref_pic_index", C.c_uint8 * 8), ("prehme_enabled", C.c_uint8), ("pad2", C.c_uint8 * 2),
                 ("zz_skip_th", C.c_uint32)]
+
+
+class HmeChainInputs(C.Structure):
+    _fields_ = [("zz_sad", vp), ("do_ref", vp), ("prehme", vp)]
+
+
+class PrehmeParams(C.Structure):
+    _fields_ = [("plane", HmeLevelParams), ("sa_min_width", C.c_uint16 * 2), ("sa_min_height", C.c_uint16 * 2), ("sa_max_width", C.c_uint16 * 2),
+                ("sa_max_height", C.c_uint16 * 2), ("hme_sr_factor", C.c_uint16 * 8), ("skip_search_line", C.c_uint8), ("l1_early_exit", C.c_uint8),
+                ("temporal_layer_gt0", C.c_uint8), ("pad", C.c_uint8), ("me_early_exit_th", C.c_uint32), ("phme_sad_th", C.c_uint32),
+                ("phme_sad_pct", C.c_uint16), ("pad2", C.c_uint16)]
+
+
+PrehmeResult = np.dtype([("sad", "<u8"), ("mv_x", "<i2"), ("mv_y", "<i2"), ("valid", "u1"), ("performed", "u1"), ("pad", "u1", (2,))])
+assert PrehmeResult.itemsize == 16
 
 
 class MeIntegerSearchParams(C.Structure):
@@ -243,7 +261,10 @@ class MeStageParams(C.Structure):
                 ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16), ("stationary_me_sr_divisor", C.c_uint16),
                 ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("me_early_exit_th", C.c_uint32),
                 ("is_ref", C.c_uint8), ("me_8x8_var_enabled", C.c_uint8), ("pad1", C.c_uint8 * 2), ("me_sr_div4_th", C.c_uint32), ("me_sr_div2_th", C.c_uint32),
-                ("me_sr_mult2_th", C.c_uint32), ("results", MeResultsParams)]
+                ("me_sr_mult2_th", C.c_uint32), ("temporal_layer_gt0", C.c_uint8), ("prehme_enabled", C.c_uint8), ("prehme_skip_search_line", C.c_uint8),
+                ("prehme_l1_early_exit", C.c_uint8), ("prehme_sa_min_width", C.c_uint16 * 2), ("prehme_sa_min_height", C.c_uint16 * 2),
+                ("prehme_sa_max_width", C.c_uint16 * 2), ("prehme_sa_max_height", C.c_uint16 * 2), ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32),
+                ("zz_sad_pct", C.c_uint16), ("phme_sad_pct", C.c_uint16), ("results", MeResultsParams)]
 
 
 class MeResultsHost(C.Structure):

@@ -237,9 +237,24 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
             for (uint32_t k = 0; k < n_refs; k++) L.ref_off[k] = (uint64_t)ref_r[k] * pb;
             HIP_CHECK(hipMemsetAsync(scs[lv], 0, items * 4, sl.st)); // init_me_hme_data leaves the centres at 0
         }
-        uint32_t* zz = nullptr;
-        if (stage->me_early_exit_th) { // init_zz_sad: the zero-motion SAD gates HME levels 0 / 1 and the integer search
-            zz = (uint32_t*)((uint8_t*)int_ws + s->int_ws);
+        // search_results[].do_ref of the stage lives where the formatting step expects it, so every pruning step carries over to me_prune_ref
+        uint8_t* d_do_ref = nullptr;
+        if (fmt) {
+            const uint32_t  n_pus = fmt->enable_me_16x16 ? (fmt->enable_me_8x8 ? 85 : 21) : 5;
+            const FmtLayout L     = fmt_layout(s->sbs, n_pus, fmt->max_refs, fmt->max_cand);
+            d_do_ref = sl.fmt + L.do_ref;
+            if (out->do_ref) HIP_CHECK(hipMemcpyAsync(d_do_ref, out->do_ref, (size_t)s->sbs * 8, hipMemcpyHostToDevice, sl.st));
+            else HIP_CHECK(hipMemsetAsync(d_do_ref, 1, (size_t)s->sbs * 8, sl.st));
+        }
+        const uint8_t n_l0 = stage->results.num_of_ref_pic_to_search[0];
+        for (int lv = 0; lv < 3; lv++) {
+            P[lv].n_refs_list0 = n_l0;
+            for (uint32_t k = 0; k < n_refs; k++) P[lv].ref_pic_index[k] = stage->ref_pic_index[k];
+        }
+        uint32_t*           zz  = (uint32_t*)((uint8_t*)int_ws + s->int_ws);
+        SvtHipPrehmeResult* pre = (SvtHipPrehmeResult*)((uint8_t*)zz + svthip::align_up((size_t)s->max_refs * s->sbs * 4, 256));
+        const bool need_zz = stage->me_early_exit_th != 0; // hme_b64 only runs init_zz_sad then (:2444-2445), zz_sad_th alone has no effect
+        if (need_zz) { // init_zz_sad: the zero-motion SAD gates pre-HME, HME levels 0 / 1, the integer search and (zz_sad_th) the reference list
             SvtHipMeIntegerSearchParams Z;
             memset(&Z, 0, sizeof(Z));
             Z.sbs_x = sbs_x; Z.sbs_y = sbs_y; Z.n_refs = n_refs; Z.aligned_width = aw; Z.aligned_height = ah;
@@ -247,13 +262,30 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
             Z.src_stride = s->stride; Z.ref_stride = s->stride; Z.ref_org_x = s->org_x; Z.ref_org_y = s->org_y;
             for (uint32_t k = 0; k < n_refs; k++) Z.ref_off[k] = (uint64_t)ref_r[k] * s->plane_bytes;
             svt_hip_me_zz_sad_batch(&Z, s->planes, s->planes, zz, sl.st);
-            P[0].zz_skip_th = P[1].zz_skip_th = stage->me_early_exit_th >> 2;
+            if (stage->zz_sad_th && d_do_ref) svt_hip_me_ref_gate_batch(&P[2], zz, stage->zz_sad_th, stage->zz_sad_pct, stage->temporal_layer_gt0, d_do_ref, sl.st);
+            if (stage->me_early_exit_th) P[0].zz_skip_th = P[1].zz_skip_th = stage->me_early_exit_th >> 2;
+        }
+        if (stage->prehme_enabled) {
+            SvtHipPrehmeParams H;
+            memset(&H, 0, sizeof(H));
+            H.plane = P[0];
+            for (int k = 0; k < 2; k++) {
+                H.sa_min_width[k] = stage->prehme_sa_min_width[k]; H.sa_min_height[k] = stage->prehme_sa_min_height[k];
+                H.sa_max_width[k] = stage->prehme_sa_max_width[k]; H.sa_max_height[k] = stage->prehme_sa_max_height[k];
+            }
+            for (uint32_t k = 0; k < n_refs; k++) H.hme_sr_factor[k] = stage->dist[k];
+            H.skip_search_line = stage->prehme_skip_search_line; H.l1_early_exit = stage->prehme_l1_early_exit; H.temporal_layer_gt0 = stage->temporal_layer_gt0;
+            H.me_early_exit_th = stage->me_early_exit_th; H.phme_sad_th = stage->phme_sad_th; H.phme_sad_pct = stage->phme_sad_pct;
+            svt_hip_prehme_batch(&H, s->lvl_planes[1], s->lvl_planes[1], need_zz ? zz : nullptr, d_do_ref, pre, sl.st);
+            P[0].prehme_enabled = 1;
         }
         if (stage->hme_l0_per_ref) {
             P[0].per_ref_area = 1;
             for (uint32_t k = 0; k < n_refs; k++) { P[0].sa_width_ref[k] = stage->hme_l0_sa_width_ref[k]; P[0].sa_height_ref[k] = stage->hme_l0_sa_height_ref[k]; }
         }
-        svt_hip_hme_chain_batch(P, bases, bases, zz, (uint64_t* const*)sads, scs, sl.st);
+        SvtHipHmeChainInputs in;
+        in.zz_sad = stage->me_early_exit_th ? zz : nullptr; in.do_ref = d_do_ref; in.prehme = stage->prehme_enabled ? pre : nullptr;
+        svt_hip_hme_chain_batch(P, bases, bases, &in, (uint64_t* const*)sads, scs, sl.st);
         SvtHipMeIntegerSearchParams Q;
         memset(&Q, 0, sizeof(Q));
         Q.sbs_x = sbs_x; Q.sbs_y = sbs_y; Q.n_refs = n_refs; Q.regions = regions; Q.aligned_width = aw; Q.aligned_height = ah;
@@ -273,16 +305,7 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         Q.me_sr_divisor_for_low_hme_sad = stage->me_sr_divisor_for_low_hme_sad; Q.me_early_exit_th = stage->me_early_exit_th;
         Q.is_ref = stage->is_ref; Q.me_8x8_var_enabled = stage->me_8x8_var_enabled; Q.me_sr_div4_th = stage->me_sr_div4_th;
         Q.me_sr_div2_th = stage->me_sr_div2_th; Q.me_sr_mult2_th = stage->me_sr_mult2_th; Q.ref_width = s->width; Q.ref_height = s->height;
-        // search_results[].do_ref of the stage lives where the formatting step expects it, so HME-based pruning carries over to me_prune_ref
-        uint8_t* d_do_ref = nullptr;
-        if (fmt) {
-            const uint32_t  n_pus = fmt->enable_me_16x16 ? (fmt->enable_me_8x8 ? 85 : 21) : 5;
-            const FmtLayout L     = fmt_layout(s->sbs, n_pus, fmt->max_refs, fmt->max_cand);
-            d_do_ref = sl.fmt + L.do_ref;
-            if (out->do_ref) HIP_CHECK(hipMemcpyAsync(d_do_ref, out->do_ref, (size_t)s->sbs * 8, hipMemcpyHostToDevice, sl.st));
-            else HIP_CHECK(hipMemsetAsync(d_do_ref, 1, (size_t)s->sbs * 8, sl.st));
-        }
-        svt_hip_me_integer_search_batch(&Q, s->planes, s->planes, (const uint64_t*)sads[2], scs[2], d_do_ref, nullptr, zz, sl.sad, sl.mv, fin_sc,
+        svt_hip_me_integer_search_batch(&Q, s->planes, s->planes, (const uint64_t*)sads[2], scs[2], d_do_ref, nullptr, stage->me_early_exit_th ? zz : nullptr, sl.sad, sl.mv, fin_sc,
                                         (uint64_t*)fin_sad, int_ws, sl.st);
     }
     if (best_sad_host) HIP_CHECK(hipMemcpyAsync(best_sad_host, sl.sad, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
@@ -347,7 +370,8 @@ int svt_hip_me_session_enable_stage(void* session, uint32_t quarter_pad, uint32_
         s->int_ws = svt_hip_me_integer_search_workspace(&D);
     }
     const size_t per_slot = 3 * (svthip::align_up(s->hme_items * 8, 256) + svthip::align_up(s->hme_items * 4, 256)) + svthip::align_up(n * 4, 256) +
-                            svthip::align_up(n * 8, 256) + s->int_ws + svthip::align_up(n * 4, 256) + 256; // ... + zz_sad
+                            svthip::align_up(n * 8, 256) + s->int_ws + svthip::align_up(n * 4, 256) + svthip::align_up(n * 2 * sizeof(SvtHipPrehmeResult), 256) +
+                            256; // ... + zz_sad + pre-HME results
     for (auto& sl : s->slots) HIP_CHECK(hipMalloc((void**)&sl.hme, per_slot));
     s->stage = true;
     return 0;

@@ -714,52 +714,210 @@ struct HmeChainArgs {
     unsigned long long* sad_out[3];
     int16_t* sc_out[3];
     const uint32_t* zz_sad;
+    const uint8_t* do_ref;
+    const SvtHipPrehmeResult* prehme;
     uint32_t n;
     int win_budget, src_budget;
 };
 __global__ __launch_bounds__(256) void hme_chain_kernel(const HmeChainArgs A) {
     HIP_DYNAMIC_SHARED(uint32_t, smem)
+    __shared__ unsigned long long sh_l0[4]; // level-0 SADs of the workgroup's four items (the 2 x 2 regions of one (reference, SB) in the pre-HME form)
     const int      l = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t item = blockIdx.x * 4 + wv;
-    if (item >= A.n) return;
+    const bool     have = item < A.n; // (kept alive for the workgroup barrier of the pre-HME form; the grid is exact then)
     uint32_t* src_lds = smem + wv * ((A.win_budget + A.src_budget) / 4);
     uint32_t* win     = src_lds + A.src_budget / 4;
+    const uint32_t regions = (uint32_t)A.P[0].num_hme_sa_w * A.P[0].num_hme_sa_h, n_sb = A.P[0].sbs_x * A.P[0].sbs_y;
+    const uint32_t rs = (have ? item : 0) / regions, sb = rs % n_sb, r = rs / n_sb; // [ref][sb] index of this item = rs
+    // per-(reference, SB) gates, the same for every region: zero-motion SAD below the threshold (centre 0, SAD 0) has priority over a dropped reference
+    // (centre 0, SAD MAX_U32); both only at levels 0 and 1 (hme_level0_b64 :1922-1973, hme_level1_b64 :2057-2082)
+    const bool zz_skip = have && A.P[0].zz_skip_th && A.zz_sad && A.zz_sad[rs] < A.P[0].zz_skip_th;
+    const bool dropped = have && A.do_ref && !A.do_ref[(size_t)sb * 8 + (r < A.P[0].n_refs_list0 ? 0 : 4) + A.P[0].ref_pic_index[r]];
     int16_t px = 0, py = 0;
 #pragma unroll 1
     for (int lv = 0; lv < 3; lv++) {
         const SvtHipHmeLevelParams& P = A.P[lv];
-        if (P.zz_skip_th && A.zz_sad && lv < 2 && A.zz_sad[item / ((uint32_t)P.num_hme_sa_w * P.num_hme_sa_h)] < P.zz_skip_th) { // zero-motion SAD already low
+        if (lv < 2 && (zz_skip || dropped)) {
             px = py = 0;
-            if (l == 0) { A.sad_out[lv][item] = 0; A.sc_out[lv][2 * item] = 0; A.sc_out[lv][2 * item + 1] = 0; }
-            continue;
+            if (l == 0) { A.sad_out[lv][item] = zz_skip ? 0ull : 0xffffffffull; A.sc_out[lv][2 * item] = 0; A.sc_out[lv][2 * item + 1] = 0; }
+            continue; // (uniform over the workgroup in the pre-HME form: its four items share (reference, SB))
         }
-        SvtHipSadLoopDesc d;
-        int16_t ox, oy;
-        hme_item_geometry(P, item, px, py, d, ox, oy);
-        const int W = d.search_area_width;
         uint32_t sad = 0xffffff; // svt_sad_loop_kernel's initial best (compute_sad_c.c:71)
-        int      pos = -1;
-        if (sad_loop_ring_eligible(d, A.win_budget, A.src_budget)) {
-            const int      rstep = (int)(d.ref_stride / d.src_stride_raw);
-            const uint32_t best  = d.block_height * rstep == d.block_width ? sad_loop_ring_wave<false>(src_lds, win, A.src[lv], A.ref[lv], d, l)
-                                                                           : sad_loop_ring_wave<true>(src_lds, win, A.src[lv], A.ref[lv], d, l);
-            if (best != 0xffffffffu && (best >> 12) < sad) { sad = best >> 12; pos = (int)(best & 0xfffu); }
-            __builtin_amdgcn_wave_barrier(); // the LDS slices are restaged by the next level
-        } else if (W > 0 && d.search_area_height > 0) {
-            const unsigned long long best = sad_loop_plain_wave(A.src[lv], A.ref[lv], d, l);
-            if ((uint32_t)(best >> 32) < sad) { sad = (uint32_t)(best >> 32); pos = (int)(uint32_t)best; }
+        if (have) {
+            SvtHipSadLoopDesc d;
+            int16_t ox, oy;
+            hme_item_geometry(P, item, px, py, d, ox, oy);
+            const int W = d.search_area_width;
+            int       pos = -1;
+            if (sad_loop_ring_eligible(d, A.win_budget, A.src_budget)) {
+                const int      rstep = (int)(d.ref_stride / d.src_stride_raw);
+                const uint32_t best  = d.block_height * rstep == d.block_width ? sad_loop_ring_wave<false>(src_lds, win, A.src[lv], A.ref[lv], d, l)
+                                                                               : sad_loop_ring_wave<true>(src_lds, win, A.src[lv], A.ref[lv], d, l);
+                if (best != 0xffffffffu && (best >> 12) < sad) { sad = best >> 12; pos = (int)(best & 0xfffu); }
+                __builtin_amdgcn_wave_barrier(); // the LDS slices are restaged by the next level
+            } else if (W > 0 && d.search_area_height > 0) {
+                const unsigned long long best = sad_loop_plain_wave(A.src[lv], A.ref[lv], d, l);
+                if ((uint32_t)(best >> 32) < sad) { sad = (uint32_t)(best >> 32); pos = (int)(uint32_t)best; }
+            }
+            // an empty or all-skipped area leaves the reference's centre variable untouched: sc_out is in/out, like svt_hip_hme_level_batch
+            int16_t x = A.sc_out[lv][2 * item], y = A.sc_out[lv][2 * item + 1];
+            if (pos >= 0) { y = (int16_t)(pos / W); x = (int16_t)(pos - (pos / W) * W); }
+            const int scale = P.level == 0 ? 4 : (P.level == 1 ? 2 : 1);
+            px = (int16_t)((int16_t)(x + ox) * scale);
+            py = (int16_t)((int16_t)(y + oy) * scale);
         }
-        // an empty or all-skipped area leaves the reference's centre variable untouched: sc_out is in/out, like svt_hip_hme_level_batch
-        int16_t x = A.sc_out[lv][2 * item], y = A.sc_out[lv][2 * item + 1];
-        if (pos >= 0) { y = (int16_t)(pos / W); x = (int16_t)(pos - (pos / W) * W); }
-        const int scale = P.level == 0 ? 4 : (P.level == 1 ? 2 : 1);
-        px = (int16_t)((int16_t)(x + ox) * scale);
-        py = (int16_t)((int16_t)(y + oy) * scale);
-        if (l == 0) {
-            A.sad_out[lv][item]        = P.sub_sampled ? (unsigned long long)sad * 2 : (unsigned long long)sad;
+        unsigned long long lsad = P.sub_sampled ? (unsigned long long)sad * 2 : (unsigned long long)sad;
+        if (lv == 0 && P.prehme_enabled && A.prehme) { // replace the worst of the four regions by the better pre-HME result when that beats it
+            if (l == 0) sh_l0[wv] = lsad;
+            __syncthreads();
+            int worst = 0; // get_worst_quadrant (:1872-1900): first strictly larger SAD in region order (w0h0), (w1h0), (w0h1), (w1h1), starting from 0
+            unsigned long long mx = 0;
+            for (int k = 0; k < 4; k++)
+                if (sh_l0[k] > mx) { mx = sh_l0[k]; worst = k; }
+            const SvtHipPrehmeResult* pr = A.prehme + (size_t)rs * 2;
+            const int sr = pr[0].sad <= pr[1].sad ? 0 : 1;
+            if (have && wv == worst && pr[sr].sad < sh_l0[worst]) { lsad = pr[sr].sad; px = pr[sr].mv_x; py = pr[sr].mv_y; }
+        }
+        if (have && l == 0) {
+            A.sad_out[lv][item]        = lsad;
             A.sc_out[lv][2 * item]     = px;
             A.sc_out[lv][2 * item + 1] = py;
         }
+    }
+}
+
+// ---- pre-HME of one (SB, reference index) pair per workgroup: waves 0, 1 = the two search regions of list 0's reference, waves 2, 3 = list 1's (they
+// may shortcut from list 0's result of the same index, so they run second).
+struct PrehmeArgs {
+    SvtHipPrehmeParams P;
+    const uint8_t *src, *ref;
+    const uint32_t* zz_sad;
+    const uint8_t* do_ref;
+    SvtHipPrehmeResult* out;
+    int win_budget, src_budget, n_l1;
+};
+__device__ __forceinline__ void prehme_wave(const PrehmeArgs& A, uint32_t* src_lds, uint32_t* win, const uint32_t sb, const uint32_t slot, const int sr_i, const int l,
+                                            SvtHipPrehmeResult& res) {
+    const SvtHipHmeLevelParams& G = A.P.plane;
+    const uint32_t n_sb = G.sbs_x * G.sbs_y;
+    const uint32_t fx = (sb % G.sbs_x) * 64, fy = (sb / G.sbs_x) * 64;
+    const uint32_t b64_w = G.aligned_width - fx < 64 ? G.aligned_width - fx : 64, b64_h = G.aligned_height - fy < 64 ? G.aligned_height - fy : 64;
+    const int16_t  org_x = (int16_t)((int16_t)fx >> 2), org_y = (int16_t)((int16_t)fy >> 2);
+    // prehme_core (:1568-1666): area centred on the co-located block, clipped like integer_search_b64 (origin and size in separate conditionals)
+    const uint32_t fw = (uint32_t)A.P.sa_min_width[sr_i] * A.P.hme_sr_factor[slot], fh = (uint32_t)A.P.sa_min_height[sr_i] * A.P.hme_sr_factor[slot];
+    int16_t search_area_width  = (int16_t)(uint16_t)(fw < A.P.sa_max_width[sr_i] ? fw : A.P.sa_max_width[sr_i]);
+    int16_t search_area_height = (int16_t)(uint16_t)(fh < A.P.sa_max_height[sr_i] ? fh : A.P.sa_max_height[sr_i]);
+    const int16_t pad_width = (int16_t)((int)G.ref_org_x - 1), pad_height = (int16_t)((int)G.ref_org_y - 1), ref_w = (int16_t)G.ref_width, ref_h = (int16_t)G.ref_height;
+    int16_t xo = (int16_t)(-(int16_t)(search_area_width >> 1)), yo = (int16_t)(-(int16_t)(search_area_height >> 1));
+    xo = (int16_t)(((org_x + xo) < -pad_width) ? -pad_width - org_x : xo);
+    search_area_width = (int16_t)(((org_x + xo) < -pad_width) ? search_area_width - (-pad_width - (org_x + xo)) : search_area_width);
+    xo = (int16_t)(((org_x + xo) > ref_w - 1) ? xo - ((org_x + xo) - (ref_w - 1)) : xo);
+    if ((org_x + xo + search_area_width) > ref_w) { const int w = search_area_width - ((org_x + xo + search_area_width) - ref_w); search_area_width = (int16_t)(w > 1 ? w : 1); }
+    yo = (int16_t)(((org_y + yo) < -pad_height) ? -pad_height - org_y : yo);
+    search_area_height = (int16_t)(((org_y + yo) < -pad_height) ? search_area_height - (-pad_height - (org_y + yo)) : search_area_height);
+    yo = (int16_t)(((org_y + yo) > ref_h - 1) ? yo - ((org_y + yo) - (ref_h - 1)) : yo);
+    if ((org_y + yo + search_area_height) > ref_h) { const int h = search_area_height - ((org_y + yo + search_area_height) - ref_h); search_area_height = (int16_t)(h > 1 ? h : 1); }
+    const int16_t  x_tl = (int16_t)(((int16_t)G.ref_org_x + org_x) + xo), y_tl = (int16_t)(((int16_t)G.ref_org_y + org_y) + yo);
+    const uint32_t step = G.sub_sampled ? 2 : 1;
+    SvtHipSadLoopDesc d;
+    d.src_off = G.src_off + (uint64_t)org_y * G.src_stride + (uint64_t)org_x;
+    d.ref_off = G.ref_off[slot] + (uint32_t)(x_tl + y_tl * (int)G.ref_stride);
+    d.src_stride = G.src_stride * step; d.ref_stride = G.ref_stride * step; d.src_stride_raw = G.ref_stride;
+    d.block_width = (uint16_t)(b64_w >> 2); d.block_height = (uint16_t)((b64_h >> 2) / step);
+    d.search_area_width = search_area_width; d.search_area_height = search_area_height; d.skip_search_line = A.P.skip_search_line;
+    uint32_t sad = 0xffffff;
+    int      pos = -1;
+    const int W = search_area_width;
+    if (sad_loop_ring_eligible(d, A.win_budget, A.src_budget)) {
+        const int      rstep = (int)(d.ref_stride / d.src_stride_raw);
+        const uint32_t best  = d.block_height * rstep == d.block_width ? sad_loop_ring_wave<false>(src_lds, win, A.src, A.ref, d, l)
+                                                                       : sad_loop_ring_wave<true>(src_lds, win, A.src, A.ref, d, l);
+        if (best != 0xffffffffu && (best >> 12) < sad) { sad = best >> 12; pos = (int)(best & 0xfffu); }
+    } else if (W > 0 && search_area_height > 0) {
+        // lane-per-position search honouring skip_search_line (compute_sad_c.c:74-79)
+        unsigned long long best = ~0ull;
+        const int bw = d.block_width, bh = d.block_height;
+        for (int p = l; p < W * search_area_height; p += 64) {
+            const int yy = p / W, xx = p - yy * W;
+            if (bw == 16 && bh <= 16 && d.skip_search_line && (yy & 1) == 0) continue;
+            const uint8_t* s = A.src + d.src_off;
+            const uint8_t* f = A.ref + d.ref_off + (size_t)yy * d.src_stride_raw + xx;
+            uint32_t v = 0;
+            for (int y = 0; y < bh; y++)
+                for (int x = 0; x < bw; x++) { const int df = (int)s[(size_t)y * d.src_stride + x] - (int)f[(size_t)y * d.ref_stride + x]; v += (uint32_t)(df < 0 ? -df : df); }
+            const unsigned long long key = ((unsigned long long)v << 32) | (uint32_t)p;
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)best, m);
+            best = o < best ? o : best;
+        }
+        if (best != ~0ull && (uint32_t)(best >> 32) < sad) { sad = (uint32_t)(best >> 32); pos = (int)(uint32_t)best; }
+    }
+    // svt_sad_loop_kernel leaves the centre untouched when nothing beat 0xffffff: the reference's SearchInfo then keeps its previous content; start from 0
+    const int16_t x = pos >= 0 ? (int16_t)(pos - (pos / W) * W) : (int16_t)0, y = pos >= 0 ? (int16_t)(pos / W) : (int16_t)0;
+    res.sad  = G.sub_sampled ? (unsigned long long)sad * 2 : (unsigned long long)sad;
+    res.mv_x = (int16_t)((int16_t)(x + xo) * 4);
+    res.mv_y = (int16_t)((int16_t)(y + yo) * 4);
+    res.valid = 1; res.performed = 1;
+    (void)n_sb;
+}
+__global__ __launch_bounds__(256) void prehme_kernel(const PrehmeArgs A) {
+    HIP_DYNAMIC_SHARED(uint32_t, smem)
+    __shared__ SvtHipPrehmeResult sh_l0[2];
+    const SvtHipHmeLevelParams& G = A.P.plane;
+    const int      l = threadIdx.x & 63, wv = threadIdx.x >> 6, list = wv >> 1, sr_i = wv & 1;
+    const uint32_t n_sb = G.sbs_x * G.sbs_y, sb = blockIdx.x, ref_i = blockIdx.y;
+    const int      n_l0 = G.n_refs_list0, n_l1 = A.n_l1;
+    uint32_t* src_lds = smem + wv * ((A.win_budget + A.src_budget) / 4);
+    uint32_t* win     = src_lds + A.src_budget / 4;
+    const bool have = list == 0 ? (int)ref_i < n_l0 : (int)ref_i < n_l1;
+    const uint32_t slot = list == 0 ? ref_i : (uint32_t)n_l0 + ref_i;
+    for (int phase = 0; phase < 2; phase++) {
+        if (phase == list && have) {
+            const size_t o = ((size_t)slot * n_sb + sb) * 2 + sr_i;
+            SvtHipPrehmeResult res;
+            res.sad = 0; res.mv_x = 0; res.mv_y = 0; res.valid = 0; res.performed = 0; res.pad[0] = res.pad[1] = 0;
+            bool done = false;
+            if (list == 1 && !A.P.temporal_layer_gt0) { // :1762-1770: list 1 mirrors list 0 when it is not searched at this layer
+                const SvtHipPrehmeResult& z = sh_l0[sr_i];
+                res.sad = z.sad; res.mv_x = (int16_t)-z.mv_x; res.mv_y = (int16_t)-z.mv_y; done = true;
+            }
+            // check_prehme_early_exit (:1690-1717)
+            if (!done && A.P.me_early_exit_th && A.zz_sad[(size_t)slot * n_sb + sb] < A.P.me_early_exit_th) { res.valid = 1; done = true; } // mv 0, sad 0
+            if (!done && A.P.l1_early_exit && list == 1 && (int)ref_i < n_l0) {
+                const SvtHipPrehmeResult& z = sh_l0[sr_i];
+                const int ax = z.mv_x < 0 ? -z.mv_x : z.mv_x, ay = z.mv_y < 0 ? -z.mv_y : z.mv_y;
+                if (z.valid && (z.sad < 32 * 32 || (ax < 16 && ay < 16))) { res.sad = z.sad; res.mv_x = (int16_t)-z.mv_x; res.mv_y = (int16_t)-z.mv_y; res.valid = 1; done = true; }
+            }
+            if (!done && A.do_ref && !A.do_ref[(size_t)sb * 8 + list * 4 + ref_i]) { res.sad = 0xffffffffull; done = true; } // :1737-1742
+            if (!done) prehme_wave(A, src_lds, win, sb, slot, sr_i, l, res);
+            if (l == 0) {
+                A.out[o] = res;
+                if (list == 0) sh_l0[sr_i] = res;
+            }
+        }
+        __syncthreads();
+    }
+}
+// reference pruning on the pre-HME SADs (:1781-1797) and on the zero-motion SADs (init_zz_sad :2402-2417): one thread per SB
+__global__ void ref_prune_pct_kernel(const SvtHipHmeLevelParams G, const SvtHipPrehmeResult* __restrict__ pre, const uint32_t* __restrict__ zz, const uint32_t th,
+                                     const uint32_t pct, const int tl_gt0, uint8_t* __restrict__ do_ref) {
+    const uint32_t n_sb = G.sbs_x * G.sbs_y, sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= n_sb || !tl_gt0) return;
+    uint32_t v[8], best = 0xffffffffu;
+    for (uint32_t r = 0; r < G.n_refs; r++) {
+        if (pre) { const SvtHipPrehmeResult* p = pre + ((size_t)r * n_sb + sb) * 2; v[r] = (uint32_t)(p[0].sad < p[1].sad ? p[0].sad : p[1].sad); }
+        else v[r] = zz[(size_t)r * n_sb + sb];
+        best = v[r] < best ? v[r] : best;
+    }
+    if (!(best < th)) return;
+    for (uint32_t r = 0; r < G.n_refs; r++) {
+        const size_t dri = (size_t)sb * 8 + (r < G.n_refs_list0 ? 0 : 4) + G.ref_pic_index[r];
+        if (G.ref_pic_index[r] == 0) continue;
+        if (pre && !do_ref[dri]) continue;
+        if ((uint32_t)((v[r] - best) * 100) > (uint32_t)(pct * best)) do_ref[dri] = 0;
     }
 }
 
@@ -942,8 +1100,8 @@ void svt_hip_sad_loop_batch(const uint8_t* src_base, const uint8_t* ref_base, co
     SVT_LAUNCH_CHECK();
 }
 
-void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* const* src_base, const uint8_t* const* ref_base, const uint32_t* zz_sad,
-                             uint64_t* const* sad_out, int16_t* const* sc_out, void* stream) {
+void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* const* src_base, const uint8_t* const* ref_base,
+                             const SvtHipHmeChainInputs* inputs, uint64_t* const* sad_out, int16_t* const* sc_out, void* stream) {
     svthip::ensure_device();
     const uint32_t n = params[0].n_refs * params[0].sbs_x * params[0].sbs_y * params[0].num_hme_sa_w * params[0].num_hme_sa_h;
     if (n == 0) return;
@@ -970,9 +1128,56 @@ void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* 
     }
     src_budget = (src_budget > SLR_SRC_BYTES ? SLR_SRC_BYTES : src_budget + 15) & ~15;
     win_budget = (win_budget > SLR_WIN_BYTES ? SLR_WIN_BYTES : win_budget + 15) & ~15;
-    A.n = n; A.win_budget = win_budget; A.src_budget = src_budget; A.zz_sad = zz_sad;
+    A.n = n; A.win_budget = win_budget; A.src_budget = src_budget;
+    if (inputs) { A.zz_sad = inputs->zz_sad; A.do_ref = inputs->do_ref; A.prehme = inputs->prehme; }
+    if (params[0].prehme_enabled && A.prehme && (params[0].num_hme_sa_w != 2 || params[0].num_hme_sa_h != 2)) {
+        fprintf(stderr, "libsvtav1_hip: svt_hip_hme_chain_batch: the pre-HME replacement needs 2 x 2 search regions (get_worst_quadrant)\n");
+        abort();
+    }
     hipLaunchKernelGGL(hme_chain_kernel, dim3((n + 3) / 4), dim3(256), 4 * (size_t)(src_budget + win_budget) + 64, (hipStream_t)stream, A);
     SVT_LAUNCH_CHECK();
+}
+
+void svt_hip_me_ref_gate_batch(const SvtHipHmeLevelParams* plane, const uint32_t* zz_sad, uint32_t zz_sad_th, uint32_t zz_sad_pct, int temporal_layer_gt0,
+                               uint8_t* do_ref, void* stream) {
+    svthip::ensure_device();
+    const uint32_t n_sb = plane->sbs_x * plane->sbs_y;
+    if (!n_sb || !zz_sad_th) return;
+    hipLaunchKernelGGL(ref_prune_pct_kernel, dim3((n_sb + 63) / 64), dim3(64), 0, (hipStream_t)stream, *plane, (const SvtHipPrehmeResult*)nullptr, zz_sad, zz_sad_th,
+                       zz_sad_pct, temporal_layer_gt0, do_ref);
+    SVT_LAUNCH_CHECK();
+}
+
+void svt_hip_prehme_batch(const SvtHipPrehmeParams* params, const uint8_t* src_base, const uint8_t* ref_base, const uint32_t* zz_sad, uint8_t* do_ref,
+                          SvtHipPrehmeResult* out, void* stream) {
+    svthip::ensure_device();
+    const SvtHipHmeLevelParams& G = params->plane;
+    const uint32_t n_sb = G.sbs_x * G.sbs_y;
+    if (!n_sb || !G.n_refs) return;
+    if (params->me_early_exit_th && !zz_sad) { fprintf(stderr, "libsvtav1_hip: svt_hip_prehme_batch: zz_sad is required with me_early_exit_th\n"); abort(); }
+    PrehmeArgs A;
+    memset(&A, 0, sizeof(A));
+    A.P = *params; A.src = src_base; A.ref = ref_base; A.zz_sad = zz_sad; A.do_ref = do_ref; A.out = out;
+    const int n_l0 = G.n_refs_list0, n_l1 = (int)G.n_refs - n_l0;
+    A.n_l1 = n_l1;
+    // per-wave LDS slices for the largest region: 16 x 16 (16 x 8 sub-sampled) block, window (16 + W - 1) x (H + rows - 1)
+    const int step = G.sub_sampled ? 2 : 1, bh = 16 / step;
+    int win = 0;
+    for (int k = 0; k < 2; k++) {
+        const int W = params->sa_max_width[k], H = params->sa_max_height[k];
+        const int wb = ((((16 + W + 3) >> 2) + 3) & ~1) * 4 * (H + step * (bh - 1));
+        win = wb > win ? wb : win;
+    }
+    A.src_budget = (16 * bh + 15) & ~15;
+    A.win_budget = ((win > 36 * 1024 ? 36 * 1024 : win) + 15) & ~15; // 4 waves x 36 KB + sources < 160 KB; larger areas take the plain path
+    const dim3 grid(n_sb, n_l0 > n_l1 ? n_l0 : n_l1);
+    hipLaunchKernelGGL(prehme_kernel, grid, dim3(256), 4 * (size_t)(A.src_budget + A.win_budget) + 64, (hipStream_t)stream, A);
+    SVT_LAUNCH_CHECK();
+    if (params->phme_sad_th && do_ref) {
+        hipLaunchKernelGGL(ref_prune_pct_kernel, dim3((n_sb + 63) / 64), dim3(64), 0, (hipStream_t)stream, G, (const SvtHipPrehmeResult*)out, (const uint32_t*)nullptr,
+                           params->phme_sad_th, (uint32_t)params->phme_sad_pct, (int)params->temporal_layer_gt0, do_ref);
+        SVT_LAUNCH_CHECK();
+    }
 }
 
 size_t svt_hip_me_fullpel_search_workspace(uint32_t n, uint32_t max_w, uint32_t max_h) {

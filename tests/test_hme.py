@@ -366,7 +366,11 @@ class RefMeStageOptions(C.Structure):
                 ("sr_adjustment", C.c_uint8), ("me_8x8_var_enabled", C.c_uint8), ("me_sr_div4_th", C.c_uint32), ("me_sr_div2_th", C.c_uint32),
                 ("me_sr_mult2_th", C.c_uint32), ("hme_prune_enabled", C.c_uint8), ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16),
                 ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16), ("stationary_me_sr_divisor", C.c_uint16),
-                ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("distance_based_hme_resizing", C.c_uint8)]
+                ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("distance_based_hme_resizing", C.c_uint8),
+                ("prehme_enabled", C.c_uint8), ("prehme_skip_search_line", C.c_uint8), ("prehme_l1_early_exit", C.c_uint8),
+                ("prehme_sa_min_width", C.c_uint16 * 2), ("prehme_sa_min_height", C.c_uint16 * 2), ("prehme_sa_max_width", C.c_uint16 * 2),
+                ("prehme_sa_max_height", C.c_uint16 * 2), ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32), ("zz_sad_pct", C.c_uint16),
+                ("phme_sad_pct", C.c_uint16)]
 
 
 def scaled_distance(d):  # svt_aom_get_scaled_picture_distance (motion_estimation.c:1239-1243)
@@ -383,7 +387,14 @@ STAGE_OPTS = [dict(name="baseline"),
               dict(name="var_probe_lvl1", var=(0, 0, 900000), me=(16, 9, 32, 16)),
               dict(name="var_probe_mid", var=(2000, 20000, 200000), me=(16, 9, 32, 16), is_ref=1, hme_prune=40, sr=(1, 4, 12000, 3, 30000, 2)),
               dict(name="preset8_like", me_early_exit_th=64 * 64 * 8, var=(80000, 150000, 0xffffffff), me=(16, 9, 32, 16), is_ref=1, hme_prune=30,
-                   sr=(1, 4, 12000, 3, 30000, 2), l0=(32, 16, 96, 48))]
+                   sr=(1, 4, 12000, 3, 30000, 2), l0=(32, 16, 96, 48)),
+              dict(name="zz_gate_inactive", zz=(20 * 64 * 64, 5)),  # init_zz_sad only runs with me_early_exit_th
+              dict(name="zz_gate", zz=(20 * 64 * 64, 30), me_early_exit_th=64 * 64 * 3),
+              dict(name="prehme", prehme=dict(skip=0, l1=0, sa=((8, 20, 8, 40), (24, 3, 48, 3)))),
+              dict(name="prehme_lvl4", prehme=dict(skip=1, l1=1, sa=((8, 24, 8, 48), (16, 7, 32, 7)), phme=(10 * 64 * 64, 5)), zz=(20 * 64 * 64, 5)),
+              dict(name="preset8", me_early_exit_th=64 * 64 * 8, var=(80000, 150000, 0xffffffff), me=(16, 9, 32, 16), is_ref=1, hme_prune=5,
+                   sr=(1, 4, 12000, 8, 12000, 8), l0=(32, 32, 96, 96), zz=(20 * 64 * 64, 5), sub=1,
+                   prehme=dict(skip=1, l1=1, sa=((8, 24, 8, 48), (16, 7, 32, 7)), phme=(10 * 64 * 64, 5)))]
 
 
 @pytest.mark.parametrize("oi", range(len(STAGE_OPTS)))
@@ -424,6 +435,17 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
     S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = me_sa
     S.mv_adj_enabled, S.mv_adj_nearest_ref_only, S.mv_adj_mv_size_th, S.mv_adj_sa_multiplier = 1, 1, 4, 2
     S.is_ref = opt.get("is_ref", 0)
+    S.temporal_layer_gt0 = 1
+    S.hme_sub_sampled = S.me_sub_sad = opt.get("sub", 0)
+    if "zz" in opt:
+        S.zz_sad_th, S.zz_sad_pct = opt["zz"]
+    if "prehme" in opt:
+        ph = opt["prehme"]
+        S.prehme_enabled, S.prehme_skip_search_line, S.prehme_l1_early_exit = 1, ph["skip"], ph["l1"]
+        for k in range(2):
+            S.prehme_sa_min_width[k], S.prehme_sa_min_height[k], S.prehme_sa_max_width[k], S.prehme_sa_max_height[k] = ph["sa"][k]
+        if "phme" in ph:
+            S.phme_sad_th, S.phme_sad_pct = ph["phme"]
     if "var" in opt:
         S.me_8x8_var_enabled, (S.me_sr_div4_th, S.me_sr_div2_th, S.me_sr_mult2_th) = 1, opt["var"]
     rpi = [0, 1, 0]
@@ -499,6 +521,16 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
     O.me_min_w, O.me_min_h, O.me_max_w, O.me_max_h = me_sa
     O.mv_adj_enabled, O.mv_adj_nearest_ref_only, O.mv_adj_mv_size_th, O.mv_adj_sa_multiplier = 1, 1, 4, 2
     O.temporal_layer_index, O.is_ref = 1, opt.get("is_ref", 0)
+    O.hme_sub_sampled = O.me_sub_sad = opt.get("sub", 0)
+    if "zz" in opt:
+        O.zz_sad_th, O.zz_sad_pct = opt["zz"]
+    if "prehme" in opt:
+        ph = opt["prehme"]
+        O.prehme_enabled, O.prehme_skip_search_line, O.prehme_l1_early_exit = 1, ph["skip"], ph["l1"]
+        for k in range(2):
+            O.prehme_sa_min_width[k], O.prehme_sa_min_height[k], O.prehme_sa_max_width[k], O.prehme_sa_max_height[k] = ph["sa"][k]
+        if "phme" in ph:
+            O.phme_sad_th, O.phme_sad_pct = ph["phme"]
     if "var" in opt:
         O.me_8x8_var_enabled, (O.me_sr_div4_th, O.me_sr_div2_th, O.me_sr_mult2_th) = 1, opt["var"]
     for sb in range(n_sb):
