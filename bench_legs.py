@@ -356,7 +356,8 @@ def me_session(torch, lib, pkg, stream, steps, warmup, npics=32):
     sbs = ((W + 63) // 64) * ((H + 63) // 64)
     hp = [lib.svt_hip_host_alloc(nbytes) for _ in range(8)]
     for q in hp:
-        C.memmove(q, g.integers(0, 256, nbytes, dtype=np.uint8).ctypes.data, nbytes)
+        a = g.integers(0, 256, nbytes, dtype=np.uint8)  # (kept alive across the copy)
+        C.memmove(q, a.ctypes.data, nbytes)
     res = [(lib.svt_hip_host_alloc(4 * sbs * 85 * 4), lib.svt_hip_host_alloc(4 * sbs * 85 * 4)) for _ in range(2)]
     sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, 2)
 
@@ -427,7 +428,8 @@ def me_results(torch, lib, pkg, stream, steps, warmup, npics=32):
     nbytes = stride * rows
     hp = [lib.svt_hip_host_alloc(nbytes) for _ in range(8)]
     for q in hp:
-        C.memmove(q, g.integers(0, 256, nbytes, dtype=np.uint8).ctypes.data, nbytes)
+        a = g.integers(0, 256, nbytes, dtype=np.uint8)  # (kept alive across the copy)
+        C.memmove(q, a.ctypes.data, nbytes)
     Q = pkg.MeResultsParams()
     C.memmove(C.addressof(Q), C.addressof(P), C.sizeof(P))
     Q.num_of_ref_pic_to_search[0], Q.num_of_ref_pic_to_search[1] = 2, 2
@@ -644,6 +646,33 @@ def me_stage(torch, lib, pkg, stream, steps, warmup):
                                      "note": "decimate x2, HME L0-L2 (one fused launch), final centre + integer search (8x3..16x9), MeSbResults: device-resident chain"}}
 
 
+def _preset8_stage_params(pkg, S, dist):
+    """ME / HME settings of preset 8 at 1080p (enc_mode_config.c:138-216, 296-335, 542-590, 418-426, 479-486, 533-536, 795-818), default QP scaling left out"""
+    def sd(d):  # svt_aom_get_scaled_picture_distance
+        return d * 5 // 8 + (1 if d % 8 else 0)
+    S.num_hme_sa_w, S.num_hme_sa_h, S.hme_sub_sampled, S.me_sub_sad = 2, 2, 1, 1
+    S.hme_l0_per_ref = 1
+    for r, d in enumerate(dist):
+        f = sd(d)
+        S.dist[r] = f
+        S.hme_l0_sa_width_ref[r] = min((((16 // 2) * f) + 15) & ~15, ((192 // 2) + 15) & ~15)
+        S.hme_l0_sa_height_ref[r] = min((16 // 2) * f, 192 // 2)
+    for lv in (1, 2):
+        S.hme_sa_width[lv], S.hme_sa_height[lv] = 8, 3
+    S.hme_sa_width[0], S.hme_sa_height[0] = 96, 96
+    S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = 16, 6, 16, 9
+    S.me_early_exit_th = 64 * 64 * 8
+    S.is_ref, S.temporal_layer_gt0 = 1, 1
+    S.me_8x8_var_enabled, S.me_sr_div4_th, S.me_sr_div2_th, S.me_sr_mult2_th = 1, 80000, 150000, 0xffffffff
+    S.hme_prune_enabled, S.prune_ref_if_hme_sad_dev_bigger_than_th = 1, 5
+    (S.sr_adjustment, S.reduce_me_sr_based_on_mv_length_th, S.stationary_hme_sad_abs_th, S.stationary_me_sr_divisor, S.reduce_me_sr_based_on_hme_sad_abs_th,
+     S.me_sr_divisor_for_low_hme_sad) = 1, 4, 12000, 8, 12000, 8
+    S.zz_sad_th, S.zz_sad_pct, S.phme_sad_th, S.phme_sad_pct = 20 * 64 * 64, 5, 10 * 64 * 64, 5
+    S.prehme_enabled, S.prehme_skip_search_line, S.prehme_l1_early_exit = 1, 1, 1
+    for k, v in enumerate(((8, 100, 8, 350), (32, 7, 128, 7))):
+        S.prehme_sa_min_width[k], S.prehme_sa_min_height[k], S.prehme_sa_max_width[k], S.prehme_sa_max_height[k] = v
+
+
 def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=32):
     """PCIe-inclusive WHOLE ME stage from pinned host pictures: upload once, quarter / sixteenth planes on the device, HME levels 0-2, final centre +
     integer search, MeSbResults returned to pinned host memory; 4 references (2 + 2), two submissions in flight."""
@@ -655,7 +684,8 @@ def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=32):
     sbs = ((W + 63) // 64) * ((H + 63) // 64)
     hp = [lib.svt_hip_host_alloc(nbytes) for _ in range(8)]
     for q in hp:
-        C.memmove(q, g.integers(0, 256, nbytes, dtype=np.uint8).ctypes.data, nbytes)
+        a = g.integers(0, 256, nbytes, dtype=np.uint8)  # (kept alive across the copy)
+        C.memmove(q, a.ctypes.data, nbytes)
     S = pkg.MeStageParams()
     S.num_hme_sa_w, S.num_hme_sa_h = 2, 2
     for lv, (a, b) in enumerate(((16, 16), (8, 3), (8, 3))):
@@ -663,6 +693,10 @@ def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=32):
     S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = 8, 3, 16, 9
     for r in range(4):
         S.dist[r], S.ref_pic_index[r] = 1 + r, r % 2
+    S8 = pkg.MeStageParams()
+    for r in range(4):
+        S8.ref_pic_index[r] = r % 2
+    _preset8_stage_params(pkg, S8, [1, 2, 1, 2])
     R = S.results
     R.num_of_list_to_search = 2
     R.num_of_ref_pic_to_search[0], R.num_of_ref_pic_to_search[1] = 2, 2
@@ -675,7 +709,9 @@ def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=32):
         b = [lib.svt_hip_host_alloc(n) for n in sizes]
         hosts.append((b, pkg.MeResultsHost(None, b[0], b[1], b[2], b[3], None, None)))
 
-    def run(sess, n):
+    C.memmove(C.addressof(S8.results), C.addressof(R), C.sizeof(R))
+
+    def run(sess, n, S=S):
         pending = []
         for k in range(n):
             refs = np.array([k - 1, k - 2, k - 3, k - 4], np.int64)
@@ -687,21 +723,26 @@ def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=32):
                 lib.svt_hip_me_session_wait(sess, pending.pop(0))
         for slot in pending:
             lib.svt_hip_me_session_wait(sess, slot)
-    ts = []
+    ts, ts8 = [], []
     for it in range(max(steps // 4, 2) + 1):
-        sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, 2)
-        assert lib.svt_hip_me_session_enable_stage(sess, 32, 16, 4, 16, 9) == 0
-        t0 = _t.perf_counter()
-        run(sess, npics if it else 8)
-        if it:
-            ts.append(_t.perf_counter() - t0)
-        lib.svt_hip_me_session_destroy(sess)
+        for cfg, acc in ((S, ts), (S8, ts8)):
+            sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, 2)
+            assert lib.svt_hip_me_session_enable_stage(sess, 32, 16, 4, 32, 16) == 0
+            t0 = _t.perf_counter()
+            run(sess, npics if it else 8, cfg)
+            if it:
+                acc.append(_t.perf_counter() - t0)
+            lib.svt_hip_me_session_destroy(sess)
     for q in hp:
         lib.svt_hip_host_free(q)
     for b, _ in hosts:
         for q in b:
             lib.svt_hip_host_free(q)
-    t = min(ts)
+    t, t8 = min(ts), min(ts8)
     return {"me_session_stage_1080p_host": {"pictures_per_s": npics / t, "us_per_picture": t / npics * 1e6, "h2d_MB_per_picture": nbytes / 1e6,
                                             "d2h_MB_per_picture": sum(sizes) / 1e6,
-                                            "note": "decimation + HME 0-2 + integer search + MeSbResults per picture, 4 references, PCIe inclusive"}}
+                                            "note": "decimation + HME 0-2 + integer search + MeSbResults per picture, 4 references, PCIe inclusive"},
+            "me_session_stage_1080p_host_preset8": {"pictures_per_s": npics / t8, "us_per_picture": t8 / npics * 1e6,
+                                                    "note": "preset-8 ME settings: zero-motion gating, pre-HME (8x100..350 / 32..128x7), per-reference HME level-0 areas, "
+                                                            "HME pruning + search-range divisors, check_00_center, 8x8-variance probe, sub-sampled SADs; synthetic noise "
+                                                            "pictures, so no early exit fires"}}
