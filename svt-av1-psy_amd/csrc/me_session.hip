@@ -20,6 +20,7 @@ struct Slot {
     uint8_t*            fmt   = nullptr; // formatted results: do_ref | total | cand | pad | mv | stats (see fmt_layout)
     uint8_t*            hme   = nullptr; // stage form: per level sad (u64) and centres (2 x i16) of every item, then final centre / sad, then workspace
     bool                busy  = false;
+    std::vector<int>    reads;           // ring entries the slot's picture in flight reads (its source and references)
 };
 struct Session {
     uint32_t width, height, stride, org_x, org_y, rows, ring, max_refs, sbs;
@@ -176,8 +177,11 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
             if (!used) { src_r = (int)r; s->next_ring = (r + 1) % s->ring; break; }
         }
         if (src_r < 0) return -3; // ring smaller than n_refs + 1
-        for (auto& other : s->slots) // searches in flight may still read the plane being replaced
-            if (other.busy) HIP_CHECK(hipStreamWaitEvent(sl.st, other.done, 0));
+        for (auto& other : s->slots) { // a picture in flight that still reads the ring entry being replaced has to finish first; the others overlap
+            bool reads = false;
+            for (int r : other.reads) reads |= r == src_r;
+            if (other.busy && reads) HIP_CHECK(hipStreamWaitEvent(sl.st, other.done, 0));
+        }
         HIP_CHECK(hipMemcpyAsync(s->planes + (size_t)src_r * s->plane_bytes, plane_host, s->plane_bytes, hipMemcpyHostToDevice, sl.st));
         if (s->stage) { // quarter from the full picture, sixteenth from the quarter, each with its replicated border (pic_analysis_process.c:2138-2200)
             const uint8_t* full = s->planes + (size_t)src_r * s->plane_bytes + (size_t)s->org_y * s->stride + s->org_x;
@@ -192,6 +196,8 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
     } else {
         HIP_CHECK(hipStreamWaitEvent(sl.st, s->uploaded[src_r], 0));
     }
+    sl.reads.assign(ref_r.begin(), ref_r.end());
+    sl.reads.push_back(src_r);
     if (n_refs == 0) { sl.busy = true; HIP_CHECK(hipEventRecord(sl.done, sl.st)); s->next_slot = (s->next_slot + 1) % (uint32_t)s->slots.size(); return si; }
     unsigned long long offs[64];
     for (uint32_t k = 0; k < n_refs && k < 64; k++) {

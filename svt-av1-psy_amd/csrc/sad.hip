@@ -112,11 +112,16 @@ __device__ __forceinline__ void stage_rows_store(const uint32_t (&v)[NIT][4], ui
 template <int NT = 256> // cooperating threads (256 = workgroup, 64 = one wave)
 __device__ __forceinline__ void stage_rows_wide_any(uint32_t* lds, int pitch_dw, const uint8_t* g, uint32_t gstride, int width, int rows, int tid) {
     const int cpr = (pitch_dw + 3) >> 2, total = rows * cpr; // chunks per LDS row (the last may be partial in LDS too)
+    // chunk idx = tid + NT * j -> (row, chunk in row), advanced incrementally: one division per call instead of two per chunk
+    const int dr = NT / cpr, dc = NT - dr * cpr;
+    int       r = tid / cpr, c = tid - r * cpr;
     for (int base = 0; base < total; base += 4 * NT) {
         uint32_t v[4][4];
+        int      rk[4], ck[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int  idx = base + tid + NT * k, r = idx / cpr, col = (idx - r * cpr) * 16;
+            const int  idx = base + tid + NT * k, col = c * 16;
+            rk[k] = r; ck[k] = c;
             const bool live = idx < total && col < width;
             const int  left = width - col;
             const int  back = (live && left < 16) ? 16 - left : 0;
@@ -133,12 +138,14 @@ __device__ __forceinline__ void stage_rows_wide_any(uint32_t* lds, int pitch_dw,
                 x3 = __builtin_amdgcn_alignbyte(0u, x3, bs);
             }
             v[k][0] = x0; v[k][1] = x1; v[k][2] = x2; v[k][3] = x3;
+            r += dr; c += dc;
+            if (c >= cpr) { c -= cpr; r++; }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int idx = base + tid + NT * k, r = idx / cpr, c4 = (idx - r * cpr) * 4;
+            const int idx = base + tid + NT * k, c4 = ck[k] * 4;
             if (idx < total) {
-                uint32_t* o = lds + r * pitch_dw + c4;
+                uint32_t* o = lds + rk[k] * pitch_dw + c4;
                 if (c4 + 0 < pitch_dw) *(u32x2_a8*)(o + 0) = u32x2_a8{v[k][0], v[k][1]};
                 if (c4 + 2 < pitch_dw) *(u32x2_a8*)(o + 2) = u32x2_a8{v[k][2], v[k][3]};
             }
@@ -658,14 +665,14 @@ __device__ __forceinline__ uint32_t sad_loop_ring_wave(uint32_t* src_lds, uint32
         const uint32_t o = (uint32_t)__shfl_xor((int)best, m);
         best = o < best ? o : best;
     }
-    return best;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)best); // every lane holds the minimum: tell the compiler it is wave-uniform
 }
 __global__ __launch_bounds__(256) void sad_loop_ring_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
                                                             const SvtHipSadLoopDesc* __restrict__ descs, const uint32_t n,
                                                             unsigned long long* __restrict__ keys, uint32_t* __restrict__ todo, const int win_budget,
                                                             const int src_budget) {
     HIP_DYNAMIC_SHARED(uint32_t, smem)
-    const int      l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int      l = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform: descriptor math on the SALU
     const uint32_t item = blockIdx.x * 4 + wv;
     const bool     have = item < n;
     const SvtHipSadLoopDesc d = descs[have ? item : 0];
@@ -706,7 +713,8 @@ __device__ __forceinline__ unsigned long long sad_loop_plain_wave(const uint8_t*
         const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)best, m);
         best = o < best ? o : best;
     }
-    return best;
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(best >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)best);
 }
 struct HmeChainArgs {
     SvtHipHmeLevelParams P[3];
@@ -719,10 +727,11 @@ struct HmeChainArgs {
     uint32_t n;
     int win_budget, src_budget;
 };
-__global__ __launch_bounds__(256) void hme_chain_kernel(const HmeChainArgs A) {
+__global__ __launch_bounds__(256, 4) void hme_chain_kernel(const HmeChainArgs A) {
     HIP_DYNAMIC_SHARED(uint32_t, smem)
     __shared__ unsigned long long sh_l0[4]; // level-0 SADs of the workgroup's four items (the 2 x 2 regions of one (reference, SB) in the pre-HME form)
-    const int      l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // everything but the pixel work is wave-uniform (item index, geometry, descriptors, winners): kept on the SALU through readfirstlane
+    const int      l = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t item = blockIdx.x * 4 + wv;
     const bool     have = item < A.n; // (kept alive for the workgroup barrier of the pre-HME form; the grid is exact then)
     uint32_t* src_lds = smem + wv * ((A.win_budget + A.src_budget) / 4);
@@ -772,11 +781,14 @@ __global__ __launch_bounds__(256) void hme_chain_kernel(const HmeChainArgs A) {
             __syncthreads();
             int worst = 0; // get_worst_quadrant (:1872-1900): first strictly larger SAD in region order (w0h0), (w1h0), (w0h1), (w1h1), starting from 0
             unsigned long long mx = 0;
-            for (int k = 0; k < 4; k++)
-                if (sh_l0[k] > mx) { mx = sh_l0[k]; worst = k; }
+            for (int k = 0; k < 4; k++) {
+                const unsigned long long v = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sh_l0[k] >> 32)) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sh_l0[k]);
+                if (v > mx) { mx = v; worst = k; }
+            }
             const SvtHipPrehmeResult* pr = A.prehme + (size_t)rs * 2;
             const int sr = pr[0].sad <= pr[1].sad ? 0 : 1;
-            if (have && wv == worst && pr[sr].sad < sh_l0[worst]) { lsad = pr[sr].sad; px = pr[sr].mv_x; py = pr[sr].mv_y; }
+            if (have && wv == worst && pr[sr].sad < mx) { lsad = pr[sr].sad; px = pr[sr].mv_x; py = pr[sr].mv_y; }
         }
         if (have && l == 0) {
             A.sad_out[lv][item]        = lsad;
@@ -867,7 +879,7 @@ __global__ __launch_bounds__(256) void prehme_kernel(const PrehmeArgs A) {
     HIP_DYNAMIC_SHARED(uint32_t, smem)
     __shared__ SvtHipPrehmeResult sh_l0[2];
     const SvtHipHmeLevelParams& G = A.P.plane;
-    const int      l = threadIdx.x & 63, wv = threadIdx.x >> 6, list = wv >> 1, sr_i = wv & 1;
+    const int      l = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), list = wv >> 1, sr_i = wv & 1;
     const uint32_t n_sb = G.sbs_x * G.sbs_y, sb = blockIdx.x, ref_i = blockIdx.y;
     const int      n_l0 = G.n_refs_list0, n_l1 = A.n_l1;
     uint32_t* src_lds = smem + wv * ((A.win_budget + A.src_budget) / 4);

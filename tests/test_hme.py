@@ -347,6 +347,66 @@ def test_me_session_stage_from_host_pictures(be, oracle):
     M.same(want, (out["total"], out["mv"], out["cand"], out["stats"], None), "stage session")
 
 
+def test_me_session_stage_pictures_in_flight(be, oracle):
+    """Two pictures in flight (each on its own stream; the next upload only waits for a picture that still reads the ring entry it replaces) give the
+    same MeSbResults as one picture at a time, for a ring with and without such conflicts."""
+    import test_me_results as M
+    pkg, g, lib = load_pkg(), rng(2101), be.lib
+    W, H, PAD = (192, 136, 68) if not be.is_gpu else (640, 360, 68)
+    stride, rows = W + 2 * PAD, H + 2 * PAD + 64
+    n_pics = 6 if not be.is_gpu else 12
+    pics = []
+    for k in range(n_pics):
+        a = np.zeros((rows, stride), np.uint8)
+        a[PAD:PAD + H, PAD:PAD + W] = g.integers(0, 256, (H, W), dtype=np.uint8) // 2 + ((np.add.outer(np.arange(H), np.arange(W)) + 3 * k) % 120).astype(np.uint8)
+        oracle.oracle_generate_padding(p(a), stride, W, H, PAD, PAD)
+        pics.append(a)
+    S = pkg.MeStageParams()
+    S.num_hme_sa_w, S.num_hme_sa_h, S.hme_sub_sampled, S.me_sub_sad = 2, 2, 1, 1
+    for lv, (a, b) in enumerate(((16, 8), (8, 3), (8, 3))):
+        S.hme_sa_width[lv], S.hme_sa_height[lv] = a, b
+    S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = 8, 3, 24, 12
+    S.me_early_exit_th, S.temporal_layer_gt0, S.is_ref = 64 * 64 * 8, 1, 1
+    S.prehme_enabled, S.prehme_skip_search_line, S.prehme_l1_early_exit = 1, 1, 1
+    for k, (mw, mh, xw, xh) in enumerate(((8, 20, 8, 60), (16, 5, 48, 5))):
+        S.prehme_sa_min_width[k], S.prehme_sa_min_height[k], S.prehme_sa_max_width[k], S.prehme_sa_max_height[k] = mw, mh, xw, xh
+    for r, (d, i) in enumerate(((1, 0), (2, 1), (3, 0))):
+        S.dist[r], S.ref_pic_index[r] = d, i
+    cfg = (2, 2, 1, 1, 1, 0, 0, 1, 30, 40, 0, 1, 1)
+    R = M.make_params(pkg, cfg, 0, g)
+    C.memmove(C.addressof(S.results), C.addressof(R), C.sizeof(R))
+    aw, ah = (W + 7) & ~7, (H + 7) & ~7
+    n_sb = ((aw + 63) // 64) * ((ah + 63) // 64)
+
+    def run(ring, in_flight):
+        sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, ring, 3, 32, 16, 2)
+        assert lib.svt_hip_me_session_enable_stage(sess, 32, 16, 4, 48, 16) == 0
+        res, pending = [], []
+        for k in range(n_pics):
+            out = dict(total=np.full((n_sb, 85), 7, np.uint8), mv=np.full((n_sb, 85 * R.max_refs), 7, np.uint32), cand=np.full((n_sb, 85 * R.max_cand), 7, np.uint8),
+                       stats=np.zeros(n_sb, pkg.MeSbStats), bs=np.zeros((3, n_sb, 85), np.uint32), bm=np.zeros((3, n_sb, 85), np.uint32))
+            Hst = pkg.MeResultsHost(None, p(out["total"]), p(out["mv"]), p(out["cand"]), p(out["stats"]), p(out["bs"]), p(out["bm"]))
+            refs = np.array([k - 1, k - 2, k - 3], np.int64)
+            slot = lib.svt_hip_me_session_submit_stage(sess, k, p(pics[k]), p(refs) if k >= 3 else None, 3 if k >= 3 else 0, C.addressof(S),
+                                                       C.addressof(Hst) if k >= 3 else None)
+            assert slot >= 0, (ring, k, slot)
+            res.append((out, Hst, refs))
+            pending.append(slot)
+            while len(pending) >= in_flight:
+                lib.svt_hip_me_session_wait(sess, pending.pop(0))
+        for slot in pending:
+            lib.svt_hip_me_session_wait(sess, slot)
+        lib.svt_hip_me_session_destroy(sess)
+        return [r[0] for r in res]
+    serial = run(6, 1)
+    for ring in (4, 6):  # 4: every upload replaces an entry the picture before it still reads; 6: never
+        got = run(ring, 2)
+        for k in range(3, n_pics):
+            for key in ("total", "mv", "cand", "stats", "bs", "bm"):
+                assert np.array_equal(serial[k][key], got[k][key]), (ring, k, key)
+    assert any(serial[k]["total"].min() < 7 for k in range(3, n_pics))
+
+
 # ------------------------------------------------------ the device stage vs the reference's TOP-LEVEL svt_aom_motion_estimation_b64, SB by SB
 class RefPlane(C.Structure):
     _fields_ = [("buf", C.c_void_p), ("stride", C.c_uint32), ("org_x", C.c_uint32), ("org_y", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]

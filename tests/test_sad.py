@@ -348,6 +348,44 @@ def test_initialize_buffer_32bits(be):
     assert (buf[:85] == be.pkg.MAX_SAD_VALUE).all() and (buf[85:] == 0).all()
 
 
+def test_me_session_ring_reuse_overlap(be, oracle):
+    """Pictures in flight overlap unless one of them still reads the ring entry the next upload replaces: with a ring of 3 and 2 references every
+    upload lands on an entry the previous picture reads (so it has to wait); with a ring of 5 it never does (so two pictures run concurrently).
+    Both must give the oracle's results for every picture."""
+    g = rng(78)
+    W, H, PAD = (384, 200, 68) if be.is_gpu else (128, 72, 20)
+    stride, rows = W + 2 * PAD, H + 2 * PAD + 64
+    aw, ah = 16, 9
+    lib = be.lib
+    sbs = ((W + 63) // 64) * ((H + 63) // 64)
+    n_pics = 9 if be.is_gpu else 6
+    pics = [g.integers(0, 256, (rows, stride), dtype=np.uint8) for _ in range(n_pics)]
+    descs = be.pkg.me_descs_for_frame(W, H, stride, PAD, PAD, aw, ah, rows * stride, n_refs=1, src_plane=0, ref_plane0=1)
+    want = {}
+    for ring in (3, 5):
+        sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, ring, 2, aw, ah, 2)
+        outs = []
+        for k in range(n_pics):
+            refs = np.array([k - 1, k - 2][:min(k, 2)], np.int64)
+            bs, bm = np.zeros((len(refs), sbs, 85), np.uint32), np.zeros((len(refs), sbs, 85), np.uint32)
+            slot = lib.svt_hip_me_session_submit(sess, k, p(pics[k]), p(refs) if k else None, len(refs), aw, ah, 0, p(bs) if k else None, p(bm) if k else None)
+            assert slot >= 0, (ring, k, slot)
+            outs.append((k, refs, bs, bm, slot))
+            if len(outs) >= 2: lib.svt_hip_me_session_wait(sess, outs[-2][4])  # two in flight
+        lib.svt_hip_me_session_wait(sess, outs[-1][4])
+        for (k, refs, bs, bm, slot) in outs:
+            for ri, rid in enumerate(refs):
+                for i in (range(sbs) if not be.is_gpu else [0, sbs // 2, sbs - 1]):
+                    key = (k, int(rid), int(i))
+                    if key not in want:
+                        planes = np.stack([pics[k], pics[int(rid)]])
+                        want[key] = oracle_me(oracle, planes.reshape(-1), planes.reshape(-1), descs[i], 0)
+                    assert np.array_equal(bs[ri][i], want[key][0]) and np.array_equal(bm[ri][i], want[key][1]), (ring,) + key
+        lib.svt_hip_me_session_destroy(sess)
+
+
+
+
 def test_me_session_host_pictures(be, oracle):
     """The ME stage as a service over host pictures: planes are uploaded once as sources and then referenced by id; results of overlapping
     submissions equal the oracle's open_loop_me_fullpel_search_sblock for every (SB, reference)."""
