@@ -206,8 +206,8 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
     }
     const uint32_t n = s->sbs * n_refs;
     unsigned long long* d_offs = (unsigned long long*)(sl.descs + (size_t)s->sbs * s->max_refs);
-    HIP_CHECK(hipMemcpyAsync(d_offs, offs, n_refs * 8, hipMemcpyHostToDevice, sl.st));
     if (!stage) {
+        HIP_CHECK(hipMemcpyAsync(d_offs, offs, n_refs * 8, hipMemcpyHostToDevice, sl.st));
         hipLaunchKernelGGL(me_build_descs_kernel, dim3((n + 255) / 256), dim3(256), 0, sl.st, sl.descs, (s->width + 63) / 64, s->sbs, n_refs, s->stride, s->org_x,
                            s->org_y, (unsigned long long)src_r * s->plane_bytes, (const unsigned long long*)d_offs, (int)area_w, (int)area_h);
         SVT_LAUNCH_CHECK();
@@ -241,8 +241,9 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
             L.src_stride = stride; L.ref_stride = stride; L.ref_org_x = pad_x; L.ref_org_y = pad_y;
             L.ref_width = s->width >> (2 - lv); L.ref_height = s->height >> (2 - lv);
             for (uint32_t k = 0; k < n_refs; k++) L.ref_off[k] = (uint64_t)ref_r[k] * pb;
-            HIP_CHECK(hipMemsetAsync(scs[lv], 0, items * 4, sl.st)); // init_me_hme_data leaves the centres at 0
         }
+        // init_me_hme_data leaves the centres at 0: one fill over the three levels' (sad, centre) arrays (the SADs are rewritten by the chain kernel)
+        HIP_CHECK(hipMemsetAsync(sads[0], 0, (size_t)((uint8_t*)scs[2] - (uint8_t*)sads[0]) + items * 4, sl.st));
         // search_results[].do_ref of the stage lives where the formatting step expects it, so every pruning step carries over to me_prune_ref
         uint8_t* d_do_ref = nullptr;
         if (fmt) {

@@ -109,48 +109,56 @@ __device__ __forceinline__ void stage_rows_store(const uint32_t (&v)[NIT][4], ui
 
 // stage_rows_u8 for any number of rows / chunks per row, four 16-byte loads in flight per thread (same tail rule as stage_rows_load:
 // nothing outside [row, row + width) is read).  Needs width >= 16 and an even pitch_dw.
+// U chunks per thread in flight (the body of stage_rows_wide_any): loads first, LDS stores after
+template <int NT, int U>
+__device__ __forceinline__ void stage_rows_wide_step(uint32_t* lds, const int pitch_dw, const uint8_t* g, const uint32_t gstride, const int width, const int total,
+                                                     const int cpr, const int dr, const int dc, const int base, const int tid, int& r, int& c) {
+    uint32_t v[U][4];
+    int      rk[U], ck[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const int  idx = base + tid + NT * k, col = c * 16;
+        rk[k] = r; ck[k] = c;
+        const bool live = idx < total && col < width;
+        const int  left = width - col;
+        const int  back = (live && left < 16) ? 16 - left : 0;
+        const uint8_t* p = g + (live ? (uint32_t)r * gstride + (uint32_t)(col - back) : 0u);
+        const u32x4_a1 t = *(const u32x4_a1*)p;
+        uint32_t x0 = live ? t.x : 0u, x1 = live ? t.y : 0u, x2 = live ? t.z : 0u, x3 = live ? t.w : 0u;
+        if (back) {
+            if (back & 4) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
+            if (back & 8) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
+            const uint32_t bs = (uint32_t)back & 3u;
+            x0 = __builtin_amdgcn_alignbyte(x1, x0, bs);
+            x1 = __builtin_amdgcn_alignbyte(x2, x1, bs);
+            x2 = __builtin_amdgcn_alignbyte(x3, x2, bs);
+            x3 = __builtin_amdgcn_alignbyte(0u, x3, bs);
+        }
+        v[k][0] = x0; v[k][1] = x1; v[k][2] = x2; v[k][3] = x3;
+        r += dr; c += dc;
+        if (c >= cpr) { c -= cpr; r++; }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const int idx = base + tid + NT * k, c4 = ck[k] * 4;
+        if (idx < total) {
+            uint32_t* o = lds + rk[k] * pitch_dw + c4;
+            if (c4 + 0 < pitch_dw) *(u32x2_a8*)(o + 0) = u32x2_a8{v[k][0], v[k][1]};
+            if (c4 + 2 < pitch_dw) *(u32x2_a8*)(o + 2) = u32x2_a8{v[k][2], v[k][3]};
+        }
+    }
+}
 template <int NT = 256> // cooperating threads (256 = workgroup, 64 = one wave)
 __device__ __forceinline__ void stage_rows_wide_any(uint32_t* lds, int pitch_dw, const uint8_t* g, uint32_t gstride, int width, int rows, int tid) {
     const int cpr = (pitch_dw + 3) >> 2, total = rows * cpr; // chunks per LDS row (the last may be partial in LDS too)
     // chunk idx = tid + NT * j -> (row, chunk in row), advanced incrementally: one division per call instead of two per chunk
     const int dr = NT / cpr, dc = NT - dr * cpr;
     int       r = tid / cpr, c = tid - r * cpr;
-    for (int base = 0; base < total; base += 4 * NT) {
-        uint32_t v[4][4];
-        int      rk[4], ck[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int  idx = base + tid + NT * k, col = c * 16;
-            rk[k] = r; ck[k] = c;
-            const bool live = idx < total && col < width;
-            const int  left = width - col;
-            const int  back = (live && left < 16) ? 16 - left : 0;
-            const uint8_t* p = g + (live ? (size_t)r * gstride + (size_t)(col - back) : (size_t)0);
-            const u32x4_a1 t = *(const u32x4_a1*)p;
-            uint32_t x0 = live ? t.x : 0u, x1 = live ? t.y : 0u, x2 = live ? t.z : 0u, x3 = live ? t.w : 0u;
-            if (back) {
-                if (back & 4) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
-                if (back & 8) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
-                const uint32_t bs = (uint32_t)back & 3u;
-                x0 = __builtin_amdgcn_alignbyte(x1, x0, bs);
-                x1 = __builtin_amdgcn_alignbyte(x2, x1, bs);
-                x2 = __builtin_amdgcn_alignbyte(x3, x2, bs);
-                x3 = __builtin_amdgcn_alignbyte(0u, x3, bs);
-            }
-            v[k][0] = x0; v[k][1] = x1; v[k][2] = x2; v[k][3] = x3;
-            r += dr; c += dc;
-            if (c >= cpr) { c -= cpr; r++; }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = base + tid + NT * k, c4 = ck[k] * 4;
-            if (idx < total) {
-                uint32_t* o = lds + rk[k] * pitch_dw + c4;
-                if (c4 + 0 < pitch_dw) *(u32x2_a8*)(o + 0) = u32x2_a8{v[k][0], v[k][1]};
-                if (c4 + 2 < pitch_dw) *(u32x2_a8*)(o + 2) = u32x2_a8{v[k][2], v[k][3]};
-            }
-        }
-    }
+    // four chunks per thread in flight while that many remain, then two / one: the small windows of the HME levels do not pay for idle chunk slots
+    int base = 0;
+    for (; total - base > 2 * NT; base += 4 * NT) stage_rows_wide_step<NT, 4>(lds, pitch_dw, g, gstride, width, total, cpr, dr, dc, base, tid, r, c);
+    if (total - base > NT) stage_rows_wide_step<NT, 2>(lds, pitch_dw, g, gstride, width, total, cpr, dr, dc, base, tid, r, c);
+    else if (total - base > 0) stage_rows_wide_step<NT, 1>(lds, pitch_dw, g, gstride, width, total, cpr, dr, dc, base, tid, r, c);
 }
 
 __device__ __forceinline__ uint32_t dpp_add_quad_xor1(uint32_t v) {
