@@ -883,14 +883,14 @@ __device__ __forceinline__ void prehme_wave(const PrehmeArgs& A, uint32_t* src_l
     res.valid = 1; res.performed = 1;
     (void)n_sb;
 }
-__global__ __launch_bounds__(256) void prehme_kernel(const PrehmeArgs A) {
+__global__ __launch_bounds__(256, 4) void prehme_kernel(const PrehmeArgs A) {
     HIP_DYNAMIC_SHARED(uint32_t, smem)
     __shared__ SvtHipPrehmeResult sh_l0[2];
     const SvtHipHmeLevelParams& G = A.P.plane;
     const int      l = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), list = wv >> 1, sr_i = wv & 1;
     const uint32_t n_sb = G.sbs_x * G.sbs_y, sb = blockIdx.x, ref_i = blockIdx.y;
     const int      n_l0 = G.n_refs_list0, n_l1 = A.n_l1;
-    uint32_t* src_lds = smem + wv * ((A.win_budget + A.src_budget) / 4);
+    uint32_t* src_lds = smem + sr_i * ((A.win_budget + A.src_budget) / 4); // the lists run in different phases: list 1's waves reuse list 0's slices
     uint32_t* win     = src_lds + A.src_budget / 4;
     const bool have = list == 0 ? (int)ref_i < n_l0 : (int)ref_i < n_l1;
     const uint32_t slot = list == 0 ? ref_i : (uint32_t)n_l0 + ref_i;
@@ -1189,9 +1189,9 @@ void svt_hip_prehme_batch(const SvtHipPrehmeParams* params, const uint8_t* src_b
         win = wb > win ? wb : win;
     }
     A.src_budget = (16 * bh + 15) & ~15;
-    A.win_budget = ((win > 36 * 1024 ? 36 * 1024 : win) + 15) & ~15; // 4 waves x 36 KB + sources < 160 KB; larger areas take the plain path
+    A.win_budget = ((win > 36 * 1024 ? 36 * 1024 : win) + 15) & ~15; // 2 slices x 36 KB + sources; larger areas take the plain path
     const dim3 grid(n_sb, n_l0 > n_l1 ? n_l0 : n_l1);
-    hipLaunchKernelGGL(prehme_kernel, grid, dim3(256), 4 * (size_t)(A.src_budget + A.win_budget) + 64, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(prehme_kernel, grid, dim3(256), 2 * (size_t)(A.src_budget + A.win_budget) + 64, (hipStream_t)stream, A);
     SVT_LAUNCH_CHECK();
     if (params->phme_sad_th && do_ref) {
         hipLaunchKernelGGL(ref_prune_pct_kernel, dim3((n_sb + 63) / 64), dim3(64), 0, (hipStream_t)stream, G, (const SvtHipPrehmeResult*)out, (const uint32_t*)nullptr,
