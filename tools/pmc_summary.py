@@ -2,6 +2,7 @@
 """Condense rocprofv3 output directories (gpurun_out/, scratch) into the small tracked files under profiles/.
 
   python tools/pmc_summary.py <round-tag> <stats_dir> <pmc_fetch_dir> <pmc_write_dir> "<command that was profiled>"
+  python tools/pmc_summary.py <round-tag> <stats_dir> - - "<command>"        (kernel statistics only)
 
 Writes profiles/<tag>_kernel_stats.txt (the --kernel-trace --stats table, our kernels first) and profiles/<tag>_pmc_traffic.json
 (HBM bytes per launch and kernel).  Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are
@@ -30,6 +31,8 @@ def main():
         for r in rows:
             f.write("%-60s %6s %12.1f %12.2f %7s\n" % (short(r["Name"])[:60], r["Calls"], float(r["TotalDurationNs"]) / 1e3,
                                                     float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    if fdir == "-":  # kernel statistics only
+        return
     traffic = collections.defaultdict(dict)
     for d, ctr in ((fdir, "FETCH_SIZE"), (wdir, "WRITE_SIZE")):
         agg = collections.defaultdict(list)
