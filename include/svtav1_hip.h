@@ -200,6 +200,10 @@ typedef struct SvtHipHmeChainInputs { /* optional device inputs of the chain, an
     const uint32_t           *zz_sad;  /* [ref][sb]: see zz_skip_th */
     const uint8_t            *do_ref;  /* [sb][2][4] = search_results[list][ref].do_ref: a 0 entry skips levels 0 and 1 with centre (0, 0), SAD MAX_U32 (:1963-1973, :2071-2082) */
     const SvtHipPrehmeResult *prehme;  /* [ref][sb][2]: svt_hip_prehme_batch's output, used when params[0].prehme_enabled */
+    uint32_t prev_me_stage_based_exit_th; /* me_ctx->prev_me_stage_based_exit_th (0 = off): a level is skipped, keeping the previous stage's centre and SAD, when that
+                                           * SAD is already small -- level 0 from the better performed pre-HME region below th >> 4 (:1937-1957), level 1 from
+                                           * level 0 below th >> 5 (:2086-2096), level 2 from level 1 below th >> 2 (:2144-2154) */
+    uint32_t pad;
 } SvtHipHmeChainInputs;
 void   svt_hip_hme_chain_batch(const SvtHipHmeLevelParams *params, const uint8_t *const *src_base, const uint8_t *const *ref_base,
                                const SvtHipHmeChainInputs *inputs, uint64_t *const *sad_out, int16_t *const *sc_out, void *stream);
@@ -444,6 +448,7 @@ typedef struct SvtHipMeStageParams {
     uint16_t prehme_sa_min_width[2], prehme_sa_min_height[2], prehme_sa_max_width[2], prehme_sa_max_height[2];
     uint32_t zz_sad_th, phme_sad_th;     /* me_hme_prune_ctrls (0 = off) */
     uint16_t zz_sad_pct, phme_sad_pct;
+    uint32_t prev_me_stage_based_exit_th; /* as SvtHipHmeChainInputs (0 = off; the RTC screen-content and the temporal-filter ME settings use 64 * 64 * 4) */
     SvtHipMeResultsParams results;       /* formatting parameters (n_sb is filled in by the session) */
 } SvtHipMeStageParams;
 int svt_hip_me_session_enable_stage(void *session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,

@@ -205,7 +205,7 @@ class HmeLevelParams(C.Structure):
 
 
 class HmeChainInputs(C.Structure):
-    _fields_ = [("zz_sad", vp), ("do_ref", vp), ("prehme", vp)]
+    _fields_ = [("zz_sad", vp), ("do_ref", vp), ("prehme", vp), ("prev_me_stage_based_exit_th", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class PrehmeParams(C.Structure):
@@ -264,7 +264,7 @@ class MeStageParams(C.Structure):
                 ("me_sr_mult2_th", C.c_uint32), ("temporal_layer_gt0", C.c_uint8), ("prehme_enabled", C.c_uint8), ("prehme_skip_search_line", C.c_uint8),
                 ("prehme_l1_early_exit", C.c_uint8), ("prehme_sa_min_width", C.c_uint16 * 2), ("prehme_sa_min_height", C.c_uint16 * 2),
                 ("prehme_sa_max_width", C.c_uint16 * 2), ("prehme_sa_max_height", C.c_uint16 * 2), ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32),
-                ("zz_sad_pct", C.c_uint16), ("phme_sad_pct", C.c_uint16), ("results", MeResultsParams)]
+                ("zz_sad_pct", C.c_uint16), ("phme_sad_pct", C.c_uint16), ("prev_me_stage_based_exit_th", C.c_uint32), ("results", MeResultsParams)]
 
 
 class MeResultsHost(C.Structure):

@@ -291,6 +291,8 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
             for (uint32_t k = 0; k < n_refs; k++) { P[0].sa_width_ref[k] = stage->hme_l0_sa_width_ref[k]; P[0].sa_height_ref[k] = stage->hme_l0_sa_height_ref[k]; }
         }
         SvtHipHmeChainInputs in;
+        memset(&in, 0, sizeof(in));
+        in.prev_me_stage_based_exit_th = stage->prev_me_stage_based_exit_th;
         in.zz_sad = stage->me_early_exit_th ? zz : nullptr; in.do_ref = d_do_ref; in.prehme = stage->prehme_enabled ? pre : nullptr;
         svt_hip_hme_chain_batch(P, bases, bases, &in, (uint64_t* const*)sads, scs, sl.st);
         SvtHipMeIntegerSearchParams Q;

@@ -732,7 +732,7 @@ struct HmeChainArgs {
     const uint32_t* zz_sad;
     const uint8_t* do_ref;
     const SvtHipPrehmeResult* prehme;
-    uint32_t n;
+    uint32_t n, prev_stage_th;
     int win_budget, src_budget;
 };
 __global__ __launch_bounds__(256, 4) void hme_chain_kernel(const HmeChainArgs A) {
@@ -751,13 +751,25 @@ __global__ __launch_bounds__(256, 4) void hme_chain_kernel(const HmeChainArgs A)
     const bool zz_skip = have && A.P[0].zz_skip_th && A.zz_sad && A.zz_sad[rs] < A.P[0].zz_skip_th;
     const bool dropped = have && A.do_ref && !A.do_ref[(size_t)sb * 8 + (r < A.P[0].n_refs_list0 ? 0 : 4) + A.P[0].ref_pic_index[r]];
     int16_t px = 0, py = 0;
+    unsigned long long prev_lsad = 0; // the previous level's stored SAD of this item
 #pragma unroll 1
     for (int lv = 0; lv < 3; lv++) {
         const SvtHipHmeLevelParams& P = A.P[lv];
-        if (lv < 2 && (zz_skip || dropped)) {
-            px = py = 0;
-            if (l == 0) { A.sad_out[lv][item] = zz_skip ? 0ull : 0xffffffffull; A.sc_out[lv][2 * item] = 0; A.sc_out[lv][2 * item + 1] = 0; }
-            continue; // (uniform over the workgroup in the pre-HME form: its four items share (reference, SB))
+        // gates in the reference's order: zero-motion exit, (level 0) pre-HME result good enough, dropped reference, (levels 1, 2) previous level good enough
+        bool gated = false;
+        if (lv < 2 && zz_skip) { px = py = 0; prev_lsad = 0ull; gated = true; }
+        if (!gated && lv == 0 && have && A.prev_stage_th && A.prehme) {
+            // prev_me_stage_based_exit_th (:1937-1957): every region of the (reference, SB) takes the better pre-HME region, provided that one was searched
+            const SvtHipPrehmeResult* pr = A.prehme + (size_t)rs * 2;
+            const int sr = pr[0].sad <= pr[1].sad ? 0 : 1;
+            if (pr[sr].performed && pr[sr].sad < (A.prev_stage_th >> 4)) { px = pr[sr].mv_x; py = pr[sr].mv_y; prev_lsad = pr[sr].sad; gated = true; }
+        }
+        if (!gated && lv < 2 && dropped) { px = py = 0; prev_lsad = 0xffffffffull; gated = true; }
+        // (:2086-2096, :2144-2154) the previous level's centre and SAD are kept as they are
+        if (!gated && lv > 0 && have && A.prev_stage_th && prev_lsad < (A.prev_stage_th >> (lv == 1 ? 5 : 2))) gated = true;
+        if (gated) { // (level 0 / 1 gates but the last are uniform over the workgroup in the pre-HME form: its four items share (reference, SB))
+            if (have && l == 0) { A.sad_out[lv][item] = prev_lsad; A.sc_out[lv][2 * item] = px; A.sc_out[lv][2 * item + 1] = py; }
+            continue;
         }
         uint32_t sad = 0xffffff; // svt_sad_loop_kernel's initial best (compute_sad_c.c:71)
         if (have) {
@@ -798,6 +810,7 @@ __global__ __launch_bounds__(256, 4) void hme_chain_kernel(const HmeChainArgs A)
             const int sr = pr[0].sad <= pr[1].sad ? 0 : 1;
             if (have && wv == worst && pr[sr].sad < mx) { lsad = pr[sr].sad; px = pr[sr].mv_x; py = pr[sr].mv_y; }
         }
+        prev_lsad = lsad;
         if (have && l == 0) {
             A.sad_out[lv][item]        = lsad;
             A.sc_out[lv][2 * item]     = px;
@@ -1149,7 +1162,7 @@ void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* 
     src_budget = (src_budget > SLR_SRC_BYTES ? SLR_SRC_BYTES : src_budget + 15) & ~15;
     win_budget = (win_budget > SLR_WIN_BYTES ? SLR_WIN_BYTES : win_budget + 15) & ~15;
     A.n = n; A.win_budget = win_budget; A.src_budget = src_budget;
-    if (inputs) { A.zz_sad = inputs->zz_sad; A.do_ref = inputs->do_ref; A.prehme = inputs->prehme; }
+    if (inputs) { A.zz_sad = inputs->zz_sad; A.do_ref = inputs->do_ref; A.prehme = inputs->prehme; A.prev_stage_th = inputs->prev_me_stage_based_exit_th; }
     if (params[0].prehme_enabled && A.prehme && (params[0].num_hme_sa_w != 2 || params[0].num_hme_sa_h != 2)) {
         fprintf(stderr, "libsvtav1_hip: svt_hip_hme_chain_batch: the pre-HME replacement needs 2 x 2 search regions (get_worst_quadrant)\n");
         abort();
