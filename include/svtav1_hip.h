@@ -223,6 +223,9 @@ typedef struct SvtHipPrehmeParams {
 } SvtHipPrehmeParams;
 void   svt_hip_me_ref_gate_batch(const SvtHipHmeLevelParams *plane, const uint32_t *zz_sad, uint32_t zz_sad_th, uint32_t zz_sad_pct,
                                  int temporal_layer_gt0, uint8_t *do_ref, void *stream);
+/* me_safe_limit_zz_th (init_zz_sad :2416-2436): where zz_sad of both lists' nearest references is below the threshold, every reference with ref_pic_index > 0
+ * is dropped.  The picture-level conditions (hierarchical_levels > 0, top temporal layer, similar_brightness_refs) are the caller's: pass 0 when they fail. */
+void   svt_hip_me_ref_safe_limit_batch(const SvtHipHmeLevelParams *plane, const uint32_t *zz_sad, uint32_t safe_limit_zz_th, uint8_t *do_ref, void *stream);
 void   svt_hip_prehme_batch(const SvtHipPrehmeParams *params, const uint8_t *src_base, const uint8_t *ref_base, const uint32_t *zz_sad, uint8_t *do_ref,
                             SvtHipPrehmeResult *out, void *stream);
 
@@ -449,6 +452,7 @@ typedef struct SvtHipMeStageParams {
     uint32_t zz_sad_th, phme_sad_th;     /* me_hme_prune_ctrls (0 = off) */
     uint16_t zz_sad_pct, phme_sad_pct;
     uint32_t prev_me_stage_based_exit_th; /* as SvtHipHmeChainInputs (0 = off; the RTC screen-content and the temporal-filter ME settings use 64 * 64 * 4) */
+    uint32_t me_safe_limit_zz_th;         /* me_ctx->me_safe_limit_zz_th when the picture qualifies (see svt_hip_me_ref_safe_limit_batch), else 0 */
     SvtHipMeResultsParams results;       /* formatting parameters (n_sb is filled in by the session) */
 } SvtHipMeStageParams;
 int svt_hip_me_session_enable_stage(void *session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,

@@ -203,7 +203,7 @@ typedef struct RefMeStageOptions {
     uint8_t  prehme_enabled, prehme_skip_search_line, prehme_l1_early_exit;
     uint16_t prehme_sa_min_width[2], prehme_sa_min_height[2], prehme_sa_max_width[2], prehme_sa_max_height[2];
     uint32_t zz_sad_th, phme_sad_th; uint16_t zz_sad_pct, phme_sad_pct;
-    uint32_t prev_me_stage_based_exit_th;
+    uint32_t prev_me_stage_based_exit_th, me_safe_limit_zz_th;
 } RefMeStageOptions;
 void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsParams *P, const RefPicture *src, const RefPicture *refs /*[2][4]*/,
                                int pic_width, int pic_height, int b64_origin_x, int b64_origin_y, uint8_t *total_me_candidate_index,
@@ -287,6 +287,8 @@ void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsPar
     ctx->me_hme_prune_ctrls.zz_sad_th = O->zz_sad_th; ctx->me_hme_prune_ctrls.zz_sad_pct = O->zz_sad_pct;
     ctx->me_hme_prune_ctrls.phme_sad_th = O->phme_sad_th; ctx->me_hme_prune_ctrls.phme_sad_pct = O->phme_sad_pct;
     ctx->prev_me_stage_based_exit_th = O->prev_me_stage_based_exit_th;
+    ctx->me_safe_limit_zz_th = O->me_safe_limit_zz_th; // the picture-level conditions of init_zz_sad (:2419-2421) are made true: top layer of a 1-level hierarchy
+    pcs->hierarchical_levels = 1; pcs->temporal_layer_index = O->temporal_layer_index; pcs->similar_brightness_refs = 1;
     ctx->prehme_ctrl.enable = O->prehme_enabled; ctx->prehme_ctrl.skip_search_line = O->prehme_skip_search_line; ctx->prehme_ctrl.l1_early_exit = O->prehme_l1_early_exit;
     for (int k = 0; k < 2; k++) {
         ctx->prehme_ctrl.prehme_sa_cfg[k].sa_min.width = O->prehme_sa_min_width[k]; ctx->prehme_ctrl.prehme_sa_cfg[k].sa_min.height = O->prehme_sa_min_height[k];

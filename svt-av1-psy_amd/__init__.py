@@ -85,6 +85,7 @@ PROTOTYPES = {
     "svt_hip_hme_chain_batch": (None, [vp] * 7),
     "svt_hip_me_zz_sad_batch": (None, [vp] * 5),
     "svt_hip_me_ref_gate_batch": (None, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
+    "svt_hip_me_ref_safe_limit_batch": (None, [vp, vp, C.c_uint32, vp, vp]),
     "svt_hip_prehme_batch": (None, [vp] * 7),
     "svt_hip_hme_level_workspace": (C.c_size_t, [vp]),
     "svt_hip_hme_level_batch": (None, [vp] * 9),
@@ -264,7 +265,7 @@ class MeStageParams(C.Structure):
                 ("me_sr_mult2_th", C.c_uint32), ("temporal_layer_gt0", C.c_uint8), ("prehme_enabled", C.c_uint8), ("prehme_skip_search_line", C.c_uint8),
                 ("prehme_l1_early_exit", C.c_uint8), ("prehme_sa_min_width", C.c_uint16 * 2), ("prehme_sa_min_height", C.c_uint16 * 2),
                 ("prehme_sa_max_width", C.c_uint16 * 2), ("prehme_sa_max_height", C.c_uint16 * 2), ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32),
-                ("zz_sad_pct", C.c_uint16), ("phme_sad_pct", C.c_uint16), ("prev_me_stage_based_exit_th", C.c_uint32), ("results", MeResultsParams)]
+                ("zz_sad_pct", C.c_uint16), ("phme_sad_pct", C.c_uint16), ("prev_me_stage_based_exit_th", C.c_uint32), ("me_safe_limit_zz_th", C.c_uint32), ("results", MeResultsParams)]
 
 
 class MeResultsHost(C.Structure):

@@ -260,7 +260,7 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         }
         uint32_t*           zz  = (uint32_t*)((uint8_t*)int_ws + s->int_ws);
         SvtHipPrehmeResult* pre = (SvtHipPrehmeResult*)((uint8_t*)zz + svthip::align_up((size_t)s->max_refs * s->sbs * 4, 256));
-        const bool need_zz = stage->me_early_exit_th != 0; // hme_b64 only runs init_zz_sad then (:2444-2445), zz_sad_th alone has no effect
+        const bool need_zz = stage->me_early_exit_th != 0 || stage->me_safe_limit_zz_th != 0; // hme_b64 only runs init_zz_sad then (:2444-2445), zz_sad_th alone has no effect
         if (need_zz) { // init_zz_sad: the zero-motion SAD gates pre-HME, HME levels 0 / 1, the integer search and (zz_sad_th) the reference list
             SvtHipMeIntegerSearchParams Z;
             memset(&Z, 0, sizeof(Z));
@@ -270,6 +270,7 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
             for (uint32_t k = 0; k < n_refs; k++) Z.ref_off[k] = (uint64_t)ref_r[k] * s->plane_bytes;
             svt_hip_me_zz_sad_batch(&Z, s->planes, s->planes, zz, sl.st);
             if (stage->zz_sad_th && d_do_ref) svt_hip_me_ref_gate_batch(&P[2], zz, stage->zz_sad_th, stage->zz_sad_pct, stage->temporal_layer_gt0, d_do_ref, sl.st);
+            if (stage->me_safe_limit_zz_th && d_do_ref) svt_hip_me_ref_safe_limit_batch(&P[2], zz, stage->me_safe_limit_zz_th, d_do_ref, sl.st);
             if (stage->me_early_exit_th) P[0].zz_skip_th = P[1].zz_skip_th = stage->me_early_exit_th >> 2;
         }
         if (stage->prehme_enabled) {

@@ -1171,6 +1171,22 @@ void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* 
     SVT_LAUNCH_CHECK();
 }
 
+// me_safe_limit_zz_th (init_zz_sad :2416-2436): when both lists' nearest references are (almost) static for the SB, every other reference is dropped
+__global__ void ref_safe_limit_kernel(const SvtHipHmeLevelParams G, const uint32_t* __restrict__ zz, const uint32_t th, uint8_t* __restrict__ do_ref) {
+    const uint32_t n_sb = G.sbs_x * G.sbs_y, sb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sb >= n_sb || G.n_refs_list0 == 0 || G.n_refs <= G.n_refs_list0) return; // two lists are searched
+    if (!(zz[sb] < th && zz[(size_t)G.n_refs_list0 * n_sb + sb] < th)) return;    // zz_sad[0][0], zz_sad[1][0]
+    for (uint32_t r = 0; r < G.n_refs; r++)
+        if (G.ref_pic_index[r] > 0) do_ref[(size_t)sb * 8 + (r < G.n_refs_list0 ? 0 : 4) + G.ref_pic_index[r]] = 0;
+}
+void svt_hip_me_ref_safe_limit_batch(const SvtHipHmeLevelParams* plane, const uint32_t* zz_sad, uint32_t safe_limit_zz_th, uint8_t* do_ref, void* stream) {
+    svthip::ensure_device();
+    const uint32_t n_sb = plane->sbs_x * plane->sbs_y;
+    if (!n_sb || !safe_limit_zz_th) return;
+    hipLaunchKernelGGL(ref_safe_limit_kernel, dim3((n_sb + 63) / 64), dim3(64), 0, (hipStream_t)stream, *plane, zz_sad, safe_limit_zz_th, do_ref);
+    SVT_LAUNCH_CHECK();
+}
+
 void svt_hip_me_ref_gate_batch(const SvtHipHmeLevelParams* plane, const uint32_t* zz_sad, uint32_t zz_sad_th, uint32_t zz_sad_pct, int temporal_layer_gt0,
                                uint8_t* do_ref, void* stream) {
     svthip::ensure_device();

@@ -430,7 +430,7 @@ class RefMeStageOptions(C.Structure):
                 ("prehme_enabled", C.c_uint8), ("prehme_skip_search_line", C.c_uint8), ("prehme_l1_early_exit", C.c_uint8),
                 ("prehme_sa_min_width", C.c_uint16 * 2), ("prehme_sa_min_height", C.c_uint16 * 2), ("prehme_sa_max_width", C.c_uint16 * 2),
                 ("prehme_sa_max_height", C.c_uint16 * 2), ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32), ("zz_sad_pct", C.c_uint16),
-                ("phme_sad_pct", C.c_uint16), ("prev_me_stage_based_exit_th", C.c_uint32)]
+                ("phme_sad_pct", C.c_uint16), ("prev_me_stage_based_exit_th", C.c_uint32), ("me_safe_limit_zz_th", C.c_uint32)]
 
 
 def scaled_distance(d):  # svt_aom_get_scaled_picture_distance (motion_estimation.c:1239-1243)
@@ -457,6 +457,8 @@ STAGE_OPTS = [dict(name="baseline"),
               dict(name="prev_stage_exit_prehme", prev_stage=64 * 64 * 24, prehme=dict(skip=1, l1=1, sa=((8, 24, 8, 48), (16, 7, 32, 7)), phme=(10 * 64 * 64, 5)),
                    hme_prune=30, sr=(1, 4, 12000, 3, 30000, 2)),
               dict(name="tf_me_like", prev_stage=64 * 64 * 4, me_early_exit_th=0, sub=1, me=(8, 5, 16, 9), l0=(16, 16, 32, 32)),
+              dict(name="safe_limit_zz", safe_zz=64 * 64 * 6),
+              dict(name="safe_limit_zz_with_gate", safe_zz=64 * 64 * 5, zz=(20 * 64 * 64, 5), me_early_exit_th=64 * 64 * 3),
               dict(name="preset8", me_early_exit_th=64 * 64 * 8, var=(80000, 150000, 0xffffffff), me=(16, 9, 32, 16), is_ref=1, hme_prune=5,
                    sr=(1, 4, 12000, 8, 12000, 8), l0=(32, 32, 96, 96), zz=(20 * 64 * 64, 5), sub=1,
                    prehme=dict(skip=1, l1=1, sa=((8, 24, 8, 48), (16, 7, 32, 7)), phme=(10 * 64 * 64, 5)))]
@@ -512,6 +514,7 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
         if "phme" in ph:
             S.phme_sad_th, S.phme_sad_pct = ph["phme"]
     S.prev_me_stage_based_exit_th = opt.get("prev_stage", 0)
+    S.me_safe_limit_zz_th = opt.get("safe_zz", 0)
     if "var" in opt:
         S.me_8x8_var_enabled, (S.me_sr_div4_th, S.me_sr_div2_th, S.me_sr_mult2_th) = 1, opt["var"]
     rpi = [0, 1, 0]
@@ -598,6 +601,7 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
         if "phme" in ph:
             O.phme_sad_th, O.phme_sad_pct = ph["phme"]
     O.prev_me_stage_based_exit_th = opt.get("prev_stage", 0)
+    O.me_safe_limit_zz_th = opt.get("safe_zz", 0)
     if "var" in opt:
         O.me_8x8_var_enabled, (O.me_sr_div4_th, O.me_sr_div2_th, O.me_sr_mult2_th) = 1, opt["var"]
     for sb in range(n_sb):
