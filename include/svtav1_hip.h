@@ -273,6 +273,9 @@ typedef struct SvtHipMeIntegerSearchParams {
     uint8_t  pad3[2];
     uint32_t me_sr_div4_th, me_sr_div2_th, me_sr_mult2_th;
     uint32_t ref_width, ref_height;           /* EbPictureBufferDesc width / height of the references (check_00_center clips against them) */
+    uint32_t tf_me_exit_th;                   /* ME_MCTF (svt_aom_motion_estimation_b64 :3109-3113): 0 = off; an SB whose first reference's HME SAD is below it is not
+                                               * searched at all (its tables keep their initial content; the temporal filter then uses the 64x64 prediction only) */
+    uint32_t pad4;
 } SvtHipMeIntegerSearchParams;
 size_t svt_hip_me_integer_search_workspace(const SvtHipMeIntegerSearchParams *params);
 void   svt_hip_me_integer_search_batch(const SvtHipMeIntegerSearchParams *params, const uint8_t *src_base, const uint8_t *ref_base,
@@ -349,6 +352,8 @@ typedef struct SvtHipMeResultsHost {
     uint8_t         *me_candidate_array;       /* [n_sb][n_pus * max_cand] */
     SvtHipMeSbStats *sb_stats;                 /* [n_sb] */
     uint32_t        *best_sad, *best_mv;       /* [n_refs][n_sb][85], or NULL */
+    int16_t         *hme_sc;                   /* stage form: [n_refs][n_sb][2] = search_results[list][ref].hme_sc_x / hme_sc_y, or NULL */
+    uint64_t        *hme_sad;                  /* stage form: [n_refs][n_sb] = search_results[list][ref].hme_sad, or NULL */
 } SvtHipMeResultsHost;
 int svt_hip_me_session_submit_results(void *session, int64_t pic_id, const uint8_t *plane_host, const int64_t *ref_ids, uint32_t n_refs,
                                       uint32_t area_w, uint32_t area_h, int sub_sad, const SvtHipMeResultsParams *params,
@@ -438,7 +443,9 @@ typedef struct SvtHipMeStageParams {
     uint16_t dist[8];                    /* as SvtHipMeIntegerSearchParams */
     uint8_t  ref_pic_index[8];
     uint8_t  hme_l0_per_ref;             /* level-0 areas per reference (get_hme_l0_search_area) instead of hme_sa_width/height[0] */
-    uint8_t  hme_prune_enabled, sr_adjustment, pad0; /* as SvtHipMeIntegerSearchParams */
+    uint8_t  hme_prune_enabled, sr_adjustment; /* as SvtHipMeIntegerSearchParams */
+    uint8_t  me_type_mctf;               /* me_type == ME_MCTF (the temporal filter's ME): dist[] holds the UNSCALED picture distances -- the integer search uses them as
+                                          * they are (:1300-1302), pre-HME scales them itself -- and tf_me_exit_th applies */
     int16_t  hme_l0_sa_width_ref[8], hme_l0_sa_height_ref[8];
     uint16_t prune_ref_if_hme_sad_dev_bigger_than_th;
     uint16_t reduce_me_sr_based_on_mv_length_th, stationary_hme_sad_abs_th, stationary_me_sr_divisor, reduce_me_sr_based_on_hme_sad_abs_th,
@@ -453,6 +460,9 @@ typedef struct SvtHipMeStageParams {
     uint16_t zz_sad_pct, phme_sad_pct;
     uint32_t prev_me_stage_based_exit_th; /* as SvtHipHmeChainInputs (0 = off; the RTC screen-content and the temporal-filter ME settings use 64 * 64 * 4) */
     uint32_t me_safe_limit_zz_th;         /* me_ctx->me_safe_limit_zz_th when the picture qualifies (see svt_hip_me_ref_safe_limit_batch), else 0 */
+    uint32_t tf_me_exit_th;               /* the temporal filter's ME (me_type == ME_MCTF): as SvtHipMeIntegerSearchParams; that caller also passes dist[] unscaled
+                                           * (:1300-1302), leaves hme_prune_enabled / sr_adjustment / results.prune_ref at 0 and takes the raw tables (out->best_sad /
+                                           * best_mv, total_me_candidate_index = NULL: no MeSbResults are formatted) */
     SvtHipMeResultsParams results;       /* formatting parameters (n_sb is filled in by the session) */
 } SvtHipMeStageParams;
 int svt_hip_me_session_enable_stage(void *session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,

@@ -204,7 +204,9 @@ typedef struct RefMeStageOptions {
     uint16_t prehme_sa_min_width[2], prehme_sa_min_height[2], prehme_sa_max_width[2], prehme_sa_max_height[2];
     uint32_t zz_sad_th, phme_sad_th; uint16_t zz_sad_pct, phme_sad_pct;
     uint32_t prev_me_stage_based_exit_th, me_safe_limit_zz_th;
+    uint32_t me_type_mctf, tf_me_exit_th; /* the temporal filter's form of the call */
 } RefMeStageOptions;
+static MeContext *g_last_ctx; /* the context of the last ref_motion_estimation_b64 call, for ref_me_last_hme */
 void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsParams *P, const RefPicture *src, const RefPicture *refs /*[2][4]*/,
                                int pic_width, int pic_height, int b64_origin_x, int b64_origin_y, uint8_t *total_me_candidate_index,
                                uint32_t *me_mv_array, uint8_t *me_candidate_array, RefMeSbStats *st, uint32_t *best_sad /*[2][4][85]*/,
@@ -240,7 +242,8 @@ void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsPar
 #define FILL(dst, pl) do { memset(&(dst), 0, sizeof(dst)); (dst).buffer_y = (pl).buf; (dst).stride_y = (uint16_t)(pl).stride; (dst).org_x = (uint16_t)(pl).org_x; \
                            (dst).org_y = (uint16_t)(pl).org_y; (dst).width = (uint16_t)(pl).width; (dst).height = (uint16_t)(pl).height; } while (0)
     for (int k = 0; k < 3; k++) FILL(pics[0][k], src->lvl[k]);
-    ctx->me_type = ME_OPEN_LOOP;
+    ctx->me_type = O->me_type_mctf ? ME_MCTF : ME_OPEN_LOOP; ctx->tf_me_exit_th = O->tf_me_exit_th; ctx->tf_use_pred_64x64_only_th = 0;
+    ctx->tf_tot_horz_blks = ctx->tf_tot_vert_blks = 0; g_last_ctx = ctx;
     ctx->num_of_list_to_search = P->num_of_list_to_search;
     ctx->num_of_ref_pic_to_search[0] = P->num_of_ref_pic_to_search[0]; ctx->num_of_ref_pic_to_search[1] = P->num_of_ref_pic_to_search[1];
     ctx->temporal_layer_index = O->temporal_layer_index; ctx->is_ref = O->is_ref;
@@ -306,3 +309,13 @@ void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsPar
         for (int r = 0; r < 4; r++) do_ref_out[l * 4 + r] = ctx->search_results[l][r].do_ref;
 #undef FILL
 }
+/* search_results[list][ref].hme_sc_x / hme_sc_y / hme_sad of the last call, and what the ME_MCTF form leaves for the temporal filter */
+void ref_me_last_hme(int16_t *sc /*[2][4][2]*/, uint32_t *sad /*[2][4]*/, uint32_t *tf /*[3]: tf_use_pred_64x64_only_th, horz, vert*/) {
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < 4; r++) {
+            sc[(l * 4 + r) * 2] = g_last_ctx->search_results[l][r].hme_sc_x; sc[(l * 4 + r) * 2 + 1] = g_last_ctx->search_results[l][r].hme_sc_y;
+            sad[l * 4 + r] = g_last_ctx->search_results[l][r].hme_sad;
+        }
+    tf[0] = g_last_ctx->tf_use_pred_64x64_only_th; tf[1] = g_last_ctx->tf_tot_horz_blks; tf[2] = g_last_ctx->tf_tot_vert_blks;
+}
+

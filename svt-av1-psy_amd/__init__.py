@@ -232,7 +232,7 @@ class MeIntegerSearchParams(C.Structure):
                 ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16), ("stationary_me_sr_divisor", C.c_uint16),
                 ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("me_early_exit_th", C.c_uint32),
                 ("is_ref", C.c_uint8), ("me_8x8_var_enabled", C.c_uint8), ("pad3", C.c_uint8 * 2), ("me_sr_div4_th", C.c_uint32), ("me_sr_div2_th", C.c_uint32),
-                ("me_sr_mult2_th", C.c_uint32), ("ref_width", C.c_uint32), ("ref_height", C.c_uint32)]
+                ("me_sr_mult2_th", C.c_uint32), ("ref_width", C.c_uint32), ("ref_height", C.c_uint32), ("tf_me_exit_th", C.c_uint32), ("pad4", C.c_uint32)]
 
 
 class TfParams(C.Structure):
@@ -257,7 +257,7 @@ class MeStageParams(C.Structure):
                 ("hme_sa_width", C.c_int16 * 3), ("hme_sa_height", C.c_int16 * 3), ("me_sa_min_width", C.c_int16), ("me_sa_min_height", C.c_int16),
                 ("me_sa_max_width", C.c_int16), ("me_sa_max_height", C.c_int16), ("mv_adj_enabled", C.c_uint8), ("mv_adj_nearest_ref_only", C.c_uint8),
                 ("mv_adj_mv_size_th", C.c_uint16), ("mv_adj_sa_multiplier", C.c_uint16), ("dist", C.c_uint16 * 8), ("ref_pic_index", C.c_uint8 * 8),
-                ("hme_l0_per_ref", C.c_uint8), ("hme_prune_enabled", C.c_uint8), ("sr_adjustment", C.c_uint8), ("pad0", C.c_uint8),
+                ("hme_l0_per_ref", C.c_uint8), ("hme_prune_enabled", C.c_uint8), ("sr_adjustment", C.c_uint8), ("me_type_mctf", C.c_uint8),
                 ("hme_l0_sa_width_ref", C.c_int16 * 8), ("hme_l0_sa_height_ref", C.c_int16 * 8), ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16),
                 ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16), ("stationary_me_sr_divisor", C.c_uint16),
                 ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("me_early_exit_th", C.c_uint32),
@@ -265,13 +265,13 @@ class MeStageParams(C.Structure):
                 ("me_sr_mult2_th", C.c_uint32), ("temporal_layer_gt0", C.c_uint8), ("prehme_enabled", C.c_uint8), ("prehme_skip_search_line", C.c_uint8),
                 ("prehme_l1_early_exit", C.c_uint8), ("prehme_sa_min_width", C.c_uint16 * 2), ("prehme_sa_min_height", C.c_uint16 * 2),
                 ("prehme_sa_max_width", C.c_uint16 * 2), ("prehme_sa_max_height", C.c_uint16 * 2), ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32),
-                ("zz_sad_pct", C.c_uint16), ("phme_sad_pct", C.c_uint16), ("prev_me_stage_based_exit_th", C.c_uint32), ("me_safe_limit_zz_th", C.c_uint32), ("results", MeResultsParams)]
+                ("zz_sad_pct", C.c_uint16), ("phme_sad_pct", C.c_uint16), ("prev_me_stage_based_exit_th", C.c_uint32), ("me_safe_limit_zz_th", C.c_uint32), ("tf_me_exit_th", C.c_uint32), ("results", MeResultsParams)]
 
 
 class MeResultsHost(C.Structure):
     """SvtHipMeResultsHost: host destinations of svt_hip_me_session_submit_results."""
     _fields_ = [("do_ref", vp), ("total_me_candidate_index", vp), ("me_mv_array", vp), ("me_candidate_array", vp), ("sb_stats", vp), ("best_sad", vp),
-                ("best_mv", vp)]
+                ("best_mv", vp), ("hme_sc", vp), ("hme_sad", vp)]
 
 
 MeSbStats = np.dtype([("me_64x64_distortion", "<u4"), ("me_32x32_distortion", "<u4"), ("me_16x16_distortion", "<u4"), ("me_8x8_distortion", "<u4"),

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(64) void me_int_descs_kernel(const SvtHipMeIntegerS
         if (PHASE != 2) {
         const size_t dri = (size_t)sb * 8 + (r < P.n_refs_list0 ? 0 : 4) + P.ref_pic_index[r]; // search_results[list][ref] layout, as svt_hip_me_results_batch
         live = do_ref ? do_ref[dri] != 0 : true;
+        if (P.tf_me_exit_th && csad[0] < P.tf_me_exit_th) live = false; // ME_MCTF: search_results[0][0].hme_sad below tf_me_exit_th ends the SB before the search (:3109-3113)
         // hme_prune_ref_and_adjust_sr: references (other than the first of each list) whose HME SAD is th % above the best are dropped ...
         if (P.hme_prune_enabled && P.ref_pic_index[r] != 0 && (csad[r] - best_all) * 100 > (unsigned long long)P.prune_ref_if_hme_sad_dev_bigger_than_th * best_all) {
             live = false;

@@ -281,7 +281,8 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
                 H.sa_min_width[k] = stage->prehme_sa_min_width[k]; H.sa_min_height[k] = stage->prehme_sa_min_height[k];
                 H.sa_max_width[k] = stage->prehme_sa_max_width[k]; H.sa_max_height[k] = stage->prehme_sa_max_height[k];
             }
-            for (uint32_t k = 0; k < n_refs; k++) H.hme_sr_factor[k] = stage->dist[k];
+            for (uint32_t k = 0; k < n_refs; k++) // svt_aom_get_scaled_picture_distance (:1239-1243) when the caller's distances are the raw ones
+                H.hme_sr_factor[k] = stage->me_type_mctf ? (uint16_t)(stage->dist[k] * 5 / 8 + (stage->dist[k] % 8 ? 1 : 0)) : stage->dist[k];
             H.skip_search_line = stage->prehme_skip_search_line; H.l1_early_exit = stage->prehme_l1_early_exit; H.temporal_layer_gt0 = stage->temporal_layer_gt0;
             H.me_early_exit_th = stage->me_early_exit_th; H.phme_sad_th = stage->phme_sad_th; H.phme_sad_pct = stage->phme_sad_pct;
             svt_hip_prehme_batch(&H, s->lvl_planes[1], s->lvl_planes[1], need_zz ? zz : nullptr, d_do_ref, pre, sl.st);
@@ -306,6 +307,7 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         for (uint32_t k = 0; k < n_refs; k++) { Q.dist[k] = stage->dist[k]; Q.ref_pic_index[k] = stage->ref_pic_index[k]; Q.ref_off[k] = (uint64_t)ref_r[k] * s->plane_bytes; }
         Q.src_off = (uint64_t)src_r * s->plane_bytes + (uint64_t)s->org_y * s->stride + s->org_x;
         Q.src_stride = s->stride; Q.ref_stride = s->stride; Q.ref_org_x = s->org_x; Q.ref_org_y = s->org_y;
+        Q.tf_me_exit_th = stage->me_type_mctf ? stage->tf_me_exit_th : 0;
         if (svt_hip_me_integer_search_workspace(&Q) > s->int_ws) return -5; // areas larger than the session was sized for
         Q.n_refs_list0 = stage->results.num_of_ref_pic_to_search[0];
         Q.hme_prune_enabled = stage->hme_prune_enabled; Q.prune_ref_if_hme_sad_dev_bigger_than_th = stage->prune_ref_if_hme_sad_dev_bigger_than_th;
@@ -317,6 +319,8 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         Q.me_sr_div2_th = stage->me_sr_div2_th; Q.me_sr_mult2_th = stage->me_sr_mult2_th; Q.ref_width = s->width; Q.ref_height = s->height;
         svt_hip_me_integer_search_batch(&Q, s->planes, s->planes, (const uint64_t*)sads[2], scs[2], d_do_ref, nullptr, stage->me_early_exit_th ? zz : nullptr, sl.sad, sl.mv, fin_sc,
                                         (uint64_t*)fin_sad, int_ws, sl.st);
+        if (out && out->hme_sc) HIP_CHECK(hipMemcpyAsync(out->hme_sc, fin_sc, (size_t)n * 4, hipMemcpyDeviceToHost, sl.st));
+        if (out && out->hme_sad) HIP_CHECK(hipMemcpyAsync(out->hme_sad, fin_sad, (size_t)n * 8, hipMemcpyDeviceToHost, sl.st));
     }
     if (best_sad_host) HIP_CHECK(hipMemcpyAsync(best_sad_host, sl.sad, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));
     if (best_mv_host) HIP_CHECK(hipMemcpyAsync(best_mv_host, sl.mv, (size_t)n * SVT_HIP_ME_NUM_BLOCKS * 4, hipMemcpyDeviceToHost, sl.st));

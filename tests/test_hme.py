@@ -430,7 +430,7 @@ class RefMeStageOptions(C.Structure):
                 ("prehme_enabled", C.c_uint8), ("prehme_skip_search_line", C.c_uint8), ("prehme_l1_early_exit", C.c_uint8),
                 ("prehme_sa_min_width", C.c_uint16 * 2), ("prehme_sa_min_height", C.c_uint16 * 2), ("prehme_sa_max_width", C.c_uint16 * 2),
                 ("prehme_sa_max_height", C.c_uint16 * 2), ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32), ("zz_sad_pct", C.c_uint16),
-                ("phme_sad_pct", C.c_uint16), ("prev_me_stage_based_exit_th", C.c_uint32), ("me_safe_limit_zz_th", C.c_uint32)]
+                ("phme_sad_pct", C.c_uint16), ("prev_me_stage_based_exit_th", C.c_uint32), ("me_safe_limit_zz_th", C.c_uint32), ("me_type_mctf", C.c_uint32), ("tf_me_exit_th", C.c_uint32)]
 
 
 def scaled_distance(d):  # svt_aom_get_scaled_picture_distance (motion_estimation.c:1239-1243)
@@ -459,6 +459,10 @@ STAGE_OPTS = [dict(name="baseline"),
               dict(name="tf_me_like", prev_stage=64 * 64 * 4, me_early_exit_th=0, sub=1, me=(8, 5, 16, 9), l0=(16, 16, 32, 32)),
               dict(name="safe_limit_zz", safe_zz=64 * 64 * 6),
               dict(name="safe_limit_zz_with_gate", safe_zz=64 * 64 * 5, zz=(20 * 64 * 64, 5), me_early_exit_th=64 * 64 * 3),
+              # the temporal filter's form of the call (ME_MCTF): unscaled distances, no pruning, raw tables only, early exit on the first reference's HME SAD
+              dict(name="mctf", mctf=0, prev_stage=64 * 64 * 4, sub=1, me=(8, 5, 16, 9), l0=(16, 16, 32, 32)),
+              dict(name="mctf_exit", mctf=12000, prev_stage=64 * 64 * 4, me=(8, 5, 16, 9)),
+              dict(name="mctf_exit_prehme", mctf=20000, sub=1, prehme=dict(skip=1, l1=1, sa=((8, 24, 8, 48), (16, 7, 32, 7))), me_early_exit_th=64 * 64 * 3),
               dict(name="preset8", me_early_exit_th=64 * 64 * 8, var=(80000, 150000, 0xffffffff), me=(16, 9, 32, 16), is_ref=1, hme_prune=5,
                    sr=(1, 4, 12000, 8, 12000, 8), l0=(32, 32, 96, 96), zz=(20 * 64 * 64, 5), sub=1,
                    prehme=dict(skip=1, l1=1, sa=((8, 24, 8, 48), (16, 7, 32, 7)), phme=(10 * 64 * 64, 5)))]
@@ -514,12 +518,14 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
         if "phme" in ph:
             S.phme_sad_th, S.phme_sad_pct = ph["phme"]
     S.prev_me_stage_based_exit_th = opt.get("prev_stage", 0)
+    if "mctf" in opt:
+        S.me_type_mctf, S.tf_me_exit_th = 1, opt["mctf"]
     S.me_safe_limit_zz_th = opt.get("safe_zz", 0)
     if "var" in opt:
         S.me_8x8_var_enabled, (S.me_sr_div4_th, S.me_sr_div2_th, S.me_sr_mult2_th) = 1, opt["var"]
     rpi = [0, 1, 0]
     for r in range(3):
-        S.dist[r], S.ref_pic_index[r] = dist[r], rpi[r]
+        S.dist[r], S.ref_pic_index[r] = (abs(numbers[3] - numbers[order[r]]) if "mctf" in opt else dist[r]), rpi[r]
     l0 = opt.get("l0", (32, 16, 32, 16))  # total level-0 area: min w, min h, max w, max h (hme_l0_sa)
     S.hme_l0_per_ref = 1
     for r in range(3):  # get_hme_l0_search_area (:1853-1866) without distance-based resizing
@@ -546,7 +552,10 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
     out = dict(total=np.zeros((n_sb, 85), np.uint8), mv=np.zeros((n_sb, 85 * R.max_refs), np.uint32), cand=np.zeros((n_sb, 85 * R.max_cand), np.uint8),
                stats=np.zeros(n_sb, pkg.MeSbStats), bs=np.zeros((3, n_sb, 85), np.uint32), bm=np.zeros((3, n_sb, 85), np.uint32),
                do_ref=np.ones((n_sb, 2, 4), np.uint8))
-    Hst = pkg.MeResultsHost(p(out["do_ref"]), p(out["total"]), p(out["mv"]), p(out["cand"]), p(out["stats"]), p(out["bs"]), p(out["bm"]))
+    out["hme_sc"], out["hme_sad"] = np.full((3, n_sb, 2), 77, np.int16), np.zeros((3, n_sb), np.uint64)
+    Hst = pkg.MeResultsHost(p(out["do_ref"]), p(out["total"]), p(out["mv"]), p(out["cand"]), p(out["stats"]), p(out["bs"]), p(out["bm"]), p(out["hme_sc"]), p(out["hme_sad"]))
+    if "mctf" in opt:  # raw tables only
+        Hst = pkg.MeResultsHost(None, None, None, None, None, p(out["bs"]), p(out["bm"]), p(out["hme_sc"]), p(out["hme_sad"]))
     slot = lib.svt_hip_me_session_submit_stage(sess, 3, p(pics[3]), p(np.array(order, np.int64)), 3, C.addressof(S), C.addressof(Hst))
     assert slot >= 0
     lib.svt_hip_me_session_wait(sess, slot)
@@ -601,17 +610,38 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
         if "phme" in ph:
             O.phme_sad_th, O.phme_sad_pct = ph["phme"]
     O.prev_me_stage_based_exit_th = opt.get("prev_stage", 0)
+    if "mctf" in opt:
+        O.me_type_mctf, O.tf_me_exit_th = 1, opt["mctf"]
     O.me_safe_limit_zz_th = opt.get("safe_zz", 0)
     if "var" in opt:
         O.me_8x8_var_enabled, (O.me_sr_div4_th, O.me_sr_div2_th, O.me_sr_mult2_th) = 1, opt["var"]
+    n_exit = 0
     for sb in range(n_sb):
         tot, mvs, cands = np.zeros(85, np.uint8), np.zeros(85 * R.max_refs, np.uint32), np.zeros(85 * R.max_cand, np.uint8)
         st, bs, bm, dr = np.zeros(1, pkg.MeSbStats), np.zeros((2, 4, 85), np.uint32), np.zeros((2, 4, 85), np.uint32), np.zeros((2, 4), np.uint8)
         refme.ref_motion_estimation_b64(C.byref(O), C.byref(R), C.byref(srcp), C.byref(refs), W, H, (sb % sbs_x) * 64, (sb // sbs_x) * 64, p(tot), p(mvs), p(cands),
                                         p(st), p(bs), p(bm), p(dr))
+        h_sc, h_sad, tf = np.zeros((2, 4, 2), np.int16), np.zeros((2, 4), np.uint32), np.zeros(3, np.uint32)
+        refme.ref_me_last_hme(p(h_sc), p(h_sad), p(tf))
+        for r, (l, ri) in enumerate(((0, 0), (0, 1), (1, 0))):  # search_results[list][ref].hme_sc_x / hme_sc_y / hme_sad
+            assert np.array_equal(out["hme_sc"][r, sb], h_sc[l, ri]), ("hme centre", opt["name"], sb, r, out["hme_sc"][r, sb], h_sc[l, ri])
+            if "mctf" in opt:  # (otherwise me_prune_ref has reused the field as its accumulator, :1529-1560)
+                assert int(out["hme_sad"][r, sb]) == int(h_sad[l, ri]), ("hme sad", opt["name"], sb, r, out["hme_sad"][r, sb], h_sad[l, ri])
+        if "mctf" in opt:
+            exited = opt["mctf"] != 0 and int(h_sad[0, 0]) < opt["mctf"]
+            assert (tf[0] == 255) == exited, ("tf exit", sb, tf, h_sad[0, 0])
+            n_exit += exited
+            horz = abs(int(h_sc[0, 0, 0])) > abs(int(h_sc[0, 0, 1]))  # tf_tot_horz_blks / tf_tot_vert_blks (hme_b64 :2469-2474) follow from the returned centres
+            assert (int(tf[1]), int(tf[2])) == ((1, 0) if horz else (0, 1))
+            if not exited:
+                for r, (l, ri) in enumerate(((0, 0), (0, 1), (1, 0))):
+                    assert np.array_equal(out["bs"][r, sb], bs[l, ri]) and np.array_equal(out["bm"][r, sb], bm[l, ri]), ("mctf tables", opt["name"], sb, r)
+            continue
         assert np.array_equal(out["do_ref"][sb, 0, :2], dr[0, :2]) and out["do_ref"][sb, 1, 0] == dr[1, 0], ("do_ref", opt["name"], sb, out["do_ref"][sb], dr)
         for r, (l, ri) in enumerate(((0, 0), (0, 1), (1, 0))):
             if dr[l, ri]:  # a pruned reference is not searched by the reference: its tables are don't-care
                 assert np.array_equal(out["bs"][r, sb], bs[l, ri]) and np.array_equal(out["bm"][r, sb], bm[l, ri]), ("tables", opt["name"], sb, r)
         assert np.array_equal(out["total"][sb], tot) and np.array_equal(out["cand"][sb], cands) and np.array_equal(out["mv"][sb], mvs), ("MeSbResults", sb)
         assert out["stats"][sb] == st[0], ("stats", sb, out["stats"][sb], st[0])
+    if opt.get("mctf"):
+        assert 0 < n_exit < n_sb, (n_exit, n_sb)  # both outcomes of the temporal filter's early exit were exercised
