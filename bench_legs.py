@@ -358,29 +358,30 @@ def me_session(torch, lib, pkg, stream, steps, warmup, npics=32):
     for q in hp:
         a = g.integers(0, 256, nbytes, dtype=np.uint8)  # (kept alive across the copy)
         C.memmove(q, a.ctypes.data, nbytes)
-    res = [(lib.svt_hip_host_alloc(4 * sbs * 85 * 4), lib.svt_hip_host_alloc(4 * sbs * 85 * 4)) for _ in range(2)]
-    sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, 2)
+    SLOTS = 3  # pictures in flight (each on its own stream)
+    res = [(lib.svt_hip_host_alloc(4 * sbs * 85 * 4), lib.svt_hip_host_alloc(4 * sbs * 85 * 4)) for _ in range(SLOTS)]
+    sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, SLOTS)
 
     def run(n):
         pending = []
         for k in range(n):
             nref = min(k, 4)
             refs = np.array([k - 1 - r for r in range(nref)], np.int64)
-            out = res[k & 1]
+            out = res[k % SLOTS]
             slot = lib.svt_hip_me_session_submit(sess, k, hp[k % 8], refs.ctypes.data if nref else None, nref, 16, 9, 0, out[0], out[1])
             assert slot >= 0, slot
             pending.append(slot)
-            if len(pending) == 2:
+            if len(pending) == SLOTS:
                 lib.svt_hip_me_session_wait(sess, pending.pop(0))
         for slot in pending:
             lib.svt_hip_me_session_wait(sess, slot)
     lib.svt_hip_me_session_destroy(sess)
-    sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, 2)
+    sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, SLOTS)
     run(8)
     lib.svt_hip_me_session_destroy(sess)
     ts = []
     for _ in range(max(steps // 4, 2)):
-        sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, 2)
+        sess = lib.svt_hip_me_session_create(W, H, stride, PAD, PAD, rows, 8, 4, 16, 9, SLOTS)
         t0 = _t.perf_counter()
         run(npics)
         ts.append(_t.perf_counter() - t0)
