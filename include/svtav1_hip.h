@@ -35,6 +35,8 @@ const char *svt_hip_device_name(void);
  * `_hip` variants.  Call right after svt_aom_setup_rtcd_internal() (Source/Lib/Globals/enc_handle.c:1444-1445).
  * Returns the number of pointers installed. */
 int         svt_hip_setup_rtcd(uint64_t flags);
+/* SVT_HIP_COUNT mode (csrc/rtcd_hook.hip): calls made so far through each installed pointer; returns the number of counted pointers */
+int         svt_hip_rtcd_call_counts(const char **names, uint64_t *counts, int max);
 /* Cross-lane / packed-byte instruction self-test used by the GPU test-suite (returns 0 when the silicon agrees
  * with the C model that the CPU-side interpreter in tests/emu uses). */
 int         svt_hip_selftest(uint32_t *results /* device, 64*8 u32 */, void *stream);
@@ -489,7 +491,8 @@ typedef struct SvtHipInvTxfmDesc {
     uint64_t recon_off;  /* pixels from recon_base (output_w; may alias the prediction) */
     uint32_t pred_stride, recon_stride;
     uint8_t  tx_type;
-    uint8_t  pad[7];
+    uint8_t  wht_full; /* svt_hip_iwht4x4_add_batch only: 1 = eob > 1 (16-coefficient form), 0 = DC-only form (inv_transforms.c:2826-2831) */
+    uint8_t  pad[6];
 } SvtHipInvTxfmDesc;
 /* n inverse 2-D transforms + reconstruction (svt_av1_inv_txfm2d_add_WxH -> inv_txfm2d_add_c, inv_transforms.c:2459-2535) */
 void svt_hip_inv_txfm2d_add_batch(const int32_t *coeff_base, const uint16_t *pred_base, uint16_t *recon_base,
@@ -503,7 +506,26 @@ void svt_av1_fwd_txfm2d_hip(int16_t *input, int32_t *output, uint32_t input_stri
 void svt_av1_inv_txfm2d_add_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w,
                                 int tx_type, int tx_size, int32_t bd);
 void svt_av1_inv_txfm_add_u8_hip(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w, int tx_type,
-                                 int tx_size);
+                                 int tx_size, int lossless, int eob);
+/* svt_av1_inv_txfm_add (common_dsp_rtcd.h:144) -> svt_av1_inv_txfm_add_c (inv_transforms.c:3177-3192), exact prototype.
+ * SvtHipTxfmParam is TxfmParam (definitions.h:1043-1055; TxType / TxSize are packed one-byte enums). */
+typedef struct SvtHipTxfmParam {
+    uint8_t tx_type, tx_size;
+    int32_t lossless, bd, is_hbd;
+    int32_t tx_set_type;
+    int32_t eob;
+} SvtHipTxfmParam;
+void svt_av1_inv_txfm_add_hip(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w,
+                              const SvtHipTxfmParam *txfm_param);
+/* Lossless mode: 4x4 Walsh-Hadamard.  svt_av1_fwht4x4 (aom_dsp_rtcd.h:208) -> svt_av1_fwht4x4_c (transforms.c:3099-3152);
+ * inverse = svt_av1_highbd_iwht4x4_16_add_c / _1_add_c (inv_transforms.c:2735-2825; reached through svt_av1_inv_txfm_add and
+ * svt_av1_highbd_inv_txfm_add_4x4 when TxfmParam.lossless is set).  Batched: one 4x4 block per descriptor; coeff_out[n][16]. */
+void svt_av1_fwht4x4_hip(int16_t *input, int32_t *output, uint32_t stride);
+void svt_hip_fwht4x4_batch(const int16_t *residual_base, const SvtHipFwdTxfmDesc *descs, uint32_t n, int32_t *coeff_out, void *stream);
+void svt_hip_iwht4x4_add_batch(const int32_t *coeff_base, const uint16_t *pred_base, uint16_t *recon_base, const SvtHipInvTxfmDesc *descs,
+                               uint32_t n, int bd, void *stream);
+void svt_hip_iwht4x4_add_batch_u8(const int32_t *coeff_base, const uint8_t *pred_base, uint8_t *recon_base, const SvtHipInvTxfmDesc *descs,
+                                  uint32_t n, void *stream);
 
 /* ---------------------------------------------------------------- quantization (a11, a15, a16) ------- */
 typedef struct SvtHipQuantParams { /* DC/AC pairs of MacroblockPlane's tables (md_config_process.c:111-189) */

@@ -204,3 +204,69 @@ void oracle_inv_txfm2d_add(const int32_t *input, const uint16_t *out_r, int stri
 
 int oracle_tx_width(int tx_size) { return TXW[tx_size]; }
 int oracle_tx_height(int tx_size) { return TXH[tx_size]; }
+
+/* ---- lossless mode: 4x4 Walsh-Hadamard ----------------------------------------------------------------------------------
+ * Forward: svt_av1_fwht4x4_c (Source/Lib/Codec/transforms.c:3099-3152).  Each 1-D pass maps (a, b, c, d) to
+ * (a', c', d', b') -- the reference's output order -- and the second pass scales by UNIT_QUANT_FACTOR = 4. */
+static void wht_fwd_1d(int64_t a, int64_t b, int64_t c, int64_t d, int64_t o[4]) {
+    a += b;
+    d -= c;
+    const int64_t e = (a - d) >> 1;
+    b = e - b;
+    c = e - c;
+    a -= c;
+    d += b;
+    o[0] = a; o[1] = c; o[2] = d; o[3] = b;
+}
+void oracle_fwht4x4(const int16_t *input, int32_t *output, uint32_t stride) {
+    int64_t t[16], o[4];
+    for (int i = 0; i < 4; i++) { /* columns of the input become rows of t */
+        wht_fwd_1d(input[0 * stride + i], input[1 * stride + i], input[2 * stride + i], input[3 * stride + i], o);
+        for (int k = 0; k < 4; k++) t[4 * i + k] = (int32_t)o[k];
+    }
+    for (int i = 0; i < 4; i++) {
+        wht_fwd_1d(t[i], t[4 + i], t[8 + i], t[12 + i], o);
+        for (int k = 0; k < 4; k++) output[4 * k + i] = (int32_t)(o[k] * 4);
+    }
+}
+/* Inverse + reconstruction: svt_av1_highbd_iwht4x4_16_add_c (eob > 1) and svt_av1_highbd_iwht4x4_1_add_c (eob <= 1)
+ * (inv_transforms.c:2735-2825), selected by highbd_iwht4x4_add (:2826-2831). */
+static void wht_inv_1d(int32_t a, int32_t c, int32_t d, int32_t b, int32_t o[4]) {
+    a += c;
+    d -= b;
+    const int32_t e = (a - d) >> 1;
+    b = e - b;
+    c = e - c;
+    a -= b;
+    d += c;
+    o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+}
+void oracle_iwht4x4_add(const int32_t *input, const uint16_t *out_r, int stride_r, uint16_t *out_w, int stride_w, int eob, int bd) {
+    int32_t t[16], o[4];
+    if (eob > 1) {
+        for (int i = 0; i < 4; i++) {
+            wht_inv_1d(input[4 * i] >> 2, input[4 * i + 1] >> 2, input[4 * i + 2] >> 2, input[4 * i + 3] >> 2, o);
+            for (int k = 0; k < 4; k++) t[4 * i + k] = o[k];
+        }
+        for (int i = 0; i < 4; i++) {
+            wht_inv_1d(t[i], t[4 + i], t[8 + i], t[12 + i], o);
+            for (int k = 0; k < 4; k++) t[4 * k + i] = o[k];
+        }
+    } else {
+        int32_t a = input[0] >> 2;
+        const int32_t e = a >> 1;
+        a -= e;
+        const int32_t row[4] = {a, e, e, e};
+        for (int i = 0; i < 4; i++) {
+            const int32_t e1 = row[i] >> 1;
+            t[i] = row[i] - e1;
+            t[4 + i] = t[8 + i] = t[12 + i] = e1;
+        }
+    }
+    const int32_t mx = (1 << bd) - 1;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            const int32_t px = (int32_t)out_r[r * stride_r + c] + t[4 * r + c];
+            out_w[r * stride_w + c] = (uint16_t)(px < 0 ? 0 : (px > mx ? mx : px));
+        }
+}

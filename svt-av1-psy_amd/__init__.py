@@ -122,7 +122,10 @@ def allowed_tx_types(tx_size):
 
 FwdTxfmDesc = np.dtype([("in_off", "<u8"), ("in_stride", "<u4"), ("tx_type", "u1"), ("pad", "u1", (3,))])
 InvTxfmDesc = np.dtype([("coeff_off", "<u8"), ("pred_off", "<u8"), ("recon_off", "<u8"), ("pred_stride", "<u4"), ("recon_stride", "<u4"),
-                        ("tx_type", "u1"), ("pad", "u1", (7,))])
+                        ("tx_type", "u1"), ("wht_full", "u1"), ("pad", "u1", (6,))])
+TxfmParam = np.dtype([("tx_type", "u1"), ("tx_size", "u1"), ("lossless", "<i4"), ("bd", "<i4"), ("is_hbd", "<i4"), ("tx_set_type", "<i4"),
+                      ("eob", "<i4")], align=True)  # TxfmParam, definitions.h:1043-1055
+assert TxfmParam.itemsize == 24
 assert FwdTxfmDesc.itemsize == 16 and InvTxfmDesc.itemsize == 40
 PROTOTYPES.update({
     "svt_hip_fwd_txfm2d_batch": (None, [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp]),
@@ -130,7 +133,13 @@ PROTOTYPES.update({
     "svt_hip_inv_txfm2d_add_batch_u8": (None, [vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),
     "svt_av1_fwd_txfm2d_hip": (None, [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_uint8, C.c_int]),
     "svt_av1_inv_txfm2d_add_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int, C.c_int32]),
-    "svt_av1_inv_txfm_add_u8_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int]),
+    "svt_av1_inv_txfm_add_u8_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "svt_av1_inv_txfm_add_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, vp]),
+    "svt_av1_fwht4x4_hip": (None, [vp, vp, C.c_uint32]),
+    "svt_hip_fwht4x4_batch": (None, [vp, vp, C.c_uint32, vp, vp]),
+    "svt_hip_iwht4x4_add_batch": (None, [vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),
+    "svt_hip_iwht4x4_add_batch_u8": (None, [vp, vp, vp, vp, C.c_uint32, vp]),
+    "svt_hip_rtcd_call_counts": (C.c_int, [vp, vp, C.c_int]),
 })
 for _i, (_w, _h) in enumerate(TX_SIZES):
     for _sfx in ("", "_N2", "_N4"):

@@ -227,6 +227,100 @@ __global__ __launch_bounds__(256) void inv_txfm2d_kernel(const int32_t* __restri
     }
 }
 
+
+// ---- 4x4 Walsh-Hadamard (lossless mode) ---------------------------------------------------------------------------
+// svt_av1_fwht4x4_c (transforms.c:3099-3152) and svt_av1_highbd_iwht4x4_{16,1}_add_c (inv_transforms.c:2735-2825): sixteen values,
+// a handful of adds -- one lane owns a whole block.  The forward keeps the reference's odd output order (a, c, d, b).
+__global__ __launch_bounds__(64) void fwht4x4_kernel(const int16_t* __restrict__ base, const SvtHipFwdTxfmDesc* __restrict__ descs, const uint32_t n,
+                                                     int32_t* __restrict__ out) {
+    const uint32_t blk = blockIdx.x * 64 + threadIdx.x;
+    if (blk >= n) return;
+    const SvtHipFwdTxfmDesc d  = descs[blk];
+    const int16_t*          in = base + d.in_off;
+    int32_t                 t[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { // pass 0: column i of the input -> row i of t
+        int32_t a1 = in[0 * (size_t)d.in_stride + i], b1 = in[1 * (size_t)d.in_stride + i], c1 = in[2 * (size_t)d.in_stride + i],
+                d1 = in[3 * (size_t)d.in_stride + i];
+        a1 += b1;
+        d1 -= c1;
+        const int32_t e1 = (a1 - d1) >> 1;
+        b1 = e1 - b1;
+        c1 = e1 - c1;
+        a1 -= c1;
+        d1 += b1;
+        t[4 * i + 0] = a1; t[4 * i + 1] = c1; t[4 * i + 2] = d1; t[4 * i + 3] = b1;
+    }
+    int32_t* o = out + (size_t)blk * 16;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { // pass 1: down column i of t
+        int32_t a1 = t[i], b1 = t[4 + i], c1 = t[8 + i], d1 = t[12 + i];
+        a1 += b1;
+        d1 -= c1;
+        const int32_t e1 = (a1 - d1) >> 1;
+        b1 = e1 - b1;
+        c1 = e1 - c1;
+        a1 -= c1;
+        d1 += b1;
+        o[i] = a1 * 4; o[4 + i] = c1 * 4; o[8 + i] = d1 * 4; o[12 + i] = b1 * 4; // UNIT_QUANT_FACTOR
+    }
+}
+
+template <typename PIX>
+__global__ __launch_bounds__(64) void iwht4x4_add_kernel(const int32_t* __restrict__ coeff_base, const PIX* __restrict__ pred_base, PIX* __restrict__ recon_base,
+                                                         const SvtHipInvTxfmDesc* __restrict__ descs, const uint32_t n, const int bd) {
+    const uint32_t blk = blockIdx.x * 64 + threadIdx.x;
+    if (blk >= n) return;
+    const SvtHipInvTxfmDesc d  = descs[blk];
+    const int32_t*          ip = coeff_base + d.coeff_off;
+    int32_t                 t[16];
+    if (d.wht_full) { // eob > 1: svt_av1_highbd_iwht4x4_16_add_c
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int32_t a1 = ip[4 * i + 0] >> 2, c1 = ip[4 * i + 1] >> 2, d1 = ip[4 * i + 2] >> 2, b1 = ip[4 * i + 3] >> 2; // UNIT_QUANT_SHIFT
+            a1 += c1;
+            d1 -= b1;
+            const int32_t e1 = (a1 - d1) >> 1;
+            b1 = e1 - b1;
+            c1 = e1 - c1;
+            a1 -= b1;
+            d1 += c1;
+            t[4 * i + 0] = a1; t[4 * i + 1] = b1; t[4 * i + 2] = c1; t[4 * i + 3] = d1;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int32_t a1 = t[i], c1 = t[4 + i], d1 = t[8 + i], b1 = t[12 + i];
+            a1 += c1;
+            d1 -= b1;
+            const int32_t e1 = (a1 - d1) >> 1;
+            b1 = e1 - b1;
+            c1 = e1 - c1;
+            a1 -= b1;
+            d1 += c1;
+            t[i] = a1; t[4 + i] = b1; t[8 + i] = c1; t[12 + i] = d1;
+        }
+    } else { // eob <= 1: svt_av1_highbd_iwht4x4_1_add_c -- only the DC term, which matters (not an optimisation) for lossless
+        int32_t       a1 = ip[0] >> 2;
+        const int32_t e1 = a1 >> 1;
+        a1 -= e1;
+        const int32_t row[4] = {a1, e1, e1, e1};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int32_t e = row[i] >> 1, a = row[i] - e;
+            t[i] = a; t[4 + i] = e; t[8 + i] = e; t[12 + i] = e;
+        }
+    }
+    const int32_t mx = (1 << bd) - 1;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            int32_t px = (int32_t)pred_base[d.pred_off + (size_t)r * d.pred_stride + c] + t[4 * r + c];
+            px         = px < 0 ? 0 : (px > mx ? mx : px);
+            recon_base[d.recon_off + (size_t)r * d.recon_stride + c] = (PIX)px;
+        }
+}
+
 constexpr int kTxW[19] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64};
 constexpr int kTxH[19] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16};
 
@@ -288,7 +382,47 @@ void svt_hip_inv_txfm2d_add_batch_u8(const int32_t* coeff_base, const uint8_t* p
     inv_dispatch<uint8_t>(coeff_base, pred_base, recon_base, descs, n, tx_size, 8, (hipStream_t)stream);
 }
 
+void svt_hip_fwht4x4_batch(const int16_t* residual_base, const SvtHipFwdTxfmDesc* descs, uint32_t n, int32_t* coeff_out, void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    hipLaunchKernelGGL(fwht4x4_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, residual_base, descs, n, coeff_out);
+    SVT_LAUNCH_CHECK();
+}
+void svt_hip_iwht4x4_add_batch(const int32_t* coeff_base, const uint16_t* pred_base, uint16_t* recon_base, const SvtHipInvTxfmDesc* descs, uint32_t n,
+                               int bd, void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(iwht4x4_add_kernel<uint16_t>), dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, coeff_base, pred_base,
+                       recon_base, descs, n, bd);
+    SVT_LAUNCH_CHECK();
+}
+void svt_hip_iwht4x4_add_batch_u8(const int32_t* coeff_base, const uint8_t* pred_base, uint8_t* recon_base, const SvtHipInvTxfmDesc* descs, uint32_t n,
+                                  void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(iwht4x4_add_kernel<uint8_t>), dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, coeff_base, pred_base,
+                       recon_base, descs, n, 8);
+    SVT_LAUNCH_CHECK();
+}
+
 // ---- RTCD-signature single-call forms --------------------------------------------------------------------------------
+// svt_av1_fwht4x4 (aom_dsp_rtcd.h:208) -> svt_av1_fwht4x4_c (transforms.c:3099)
+void svt_av1_fwht4x4_hip(int16_t* input, int32_t* output, uint32_t stride) {
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve(4096, 4096);
+    int16_t*           din  = (int16_t*)c.dalloc(4 * 16);
+    SvtHipFwdTxfmDesc* dd   = (SvtHipFwdTxfmDesc*)c.dalloc(sizeof(SvtHipFwdTxfmDesc));
+    int32_t*           dout = (int32_t*)c.dalloc(64);
+    c.up2d(din, 16, input, (size_t)stride * 2, 8, 4);
+    SvtHipFwdTxfmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.in_stride = 8;
+    c.up(dd, &d, sizeof(d));
+    svt_hip_fwht4x4_batch(din, dd, 1, dout, c.stream);
+    c.down(output, dout, 64);
+}
+
 void svt_av1_fwd_txfm2d_hip(int16_t* input, int32_t* output, uint32_t input_stride, int tx_type, int tx_size, uint8_t bit_depth, int pf) {
     const int w = kTxW[tx_size], h = kTxH[tx_size];
     svthip::HostCall& c = svthip::host_call();
@@ -331,9 +465,10 @@ void svt_av1_inv_txfm2d_add_hip(const int32_t* input, uint16_t* output_r, int32_
     c.down2d(output_w, (size_t)stride_w * 2, drc, pitch, (size_t)w * 2, h);
 }
 
-// svt_av1_inv_txfm_add -> svt_av1_inv_txfm_add_c (inv_transforms.c:3177-3192): 8-bit destination form
+// svt_av1_inv_txfm_add -> svt_av1_inv_txfm_add_c (inv_transforms.c:3177-3192): 8-bit destination form.  lossless != 0 with TX_4X4 selects the
+// Walsh-Hadamard inverse (svt_av1_highbd_inv_txfm_add_4x4, inv_transforms.c:2833-2848), whose eob <= 1 form differs from the eob > 1 form.
 void svt_av1_inv_txfm_add_u8_hip(const int32_t* dqcoeff, uint8_t* dst_r, int32_t stride_r, uint8_t* dst_w, int32_t stride_w, int tx_type,
-                                 int tx_size) {
+                                 int tx_size, int lossless, int eob) {
     const int w = kTxW[tx_size], h = kTxH[tx_size];
     const int iw = w > 32 ? 32 : w, ih = h > 32 ? 32 : h;
     svthip::HostCall& c = svthip::host_call();
@@ -349,10 +484,22 @@ void svt_av1_inv_txfm_add_u8_hip(const int32_t* dqcoeff, uint8_t* dst_r, int32_t
     SvtHipInvTxfmDesc d;
     memset(&d, 0, sizeof(d));
     d.pred_stride = d.recon_stride = (uint32_t)pitch;
-    d.tx_type = (uint8_t)tx_type;
+    d.tx_type  = (uint8_t)tx_type;
+    d.wht_full = eob > 1;
     c.up(dd, &d, sizeof(d));
-    svt_hip_inv_txfm2d_add_batch_u8(dco, dpr, drc, dd, 1, tx_size, c.stream);
+    if (lossless && tx_size == 0) svt_hip_iwht4x4_add_batch_u8(dco, dpr, drc, dd, 1, c.stream);
+    else svt_hip_inv_txfm2d_add_batch_u8(dco, dpr, drc, dd, 1, tx_size, c.stream);
     c.down2d(dst_w, (size_t)stride_w, drc, pitch, (size_t)w, h);
+}
+// the pointer's exact prototype (common_dsp_rtcd.h:144); SvtHipTxfmParam == TxfmParam (definitions.h:1043-1055).  bd / is_hbd are fixed by the
+// 8-bit destination (svt_av1_inv_txfm_add_c widens to u16 and narrows again: identical to clipping at 255 for bd = 8, which is what every caller
+// passes -- svt_aom_inv_transform_recon8bit, inv_transforms.c:3089-3113); tx_set_type is unused by the reference as well.
+void svt_av1_inv_txfm_add_hip(const int32_t* dqcoeff, uint8_t* dst_r, int32_t stride_r, uint8_t* dst_w, int32_t stride_w, const SvtHipTxfmParam* p) {
+    if (p->bd != 8) {
+        fprintf(stderr, "libsvtav1_hip: svt_av1_inv_txfm_add with bd = %d on an 8-bit destination\n", p->bd);
+        abort();
+    }
+    svt_av1_inv_txfm_add_u8_hip(dqcoeff, dst_r, stride_r, dst_w, stride_w, p->tx_type, p->tx_size, p->lossless, p->eob);
 }
 
 // the 19 (+38 partial-frequency) forward and 19 inverse fixed-size symbols of the RTCD tables

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <algorithm>
 #include <functional>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -176,7 +177,11 @@ inline void run_block(int nthreads) {
         }
     }
 }
+// The fiber state (and every kernel's `__shared__` storage) is global, so launches from different host threads -- the encoder's
+// worker threads in tests/test_encoder_identity.py -- are serialised.
+inline std::mutex launch_mutex;
 template <typename F> inline void launch(F&& f, dim3 grid, dim3 block, size_t shmem) {
+    std::lock_guard<std::mutex> lock(launch_mutex);
     g.block_dim = block;
     g.grid_dim  = grid;
     bDim        = block;

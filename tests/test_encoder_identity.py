@@ -1,0 +1,50 @@
+"""Integration-level parity (VERDICT r1 row g): the HIP variant installed in the REAL reference encoder must leave the
+bitstream and the reconstruction byte-identical to the C-only encoder -- the reference's own CI invariant across ISA levels
+(.gitlab/workflows/linux/.gitlab-ci.yml:351-367).  oracle/_ref/enc/SvtAv1EncApp = the reference built C-only by oracle/Makefile
+with the binding of INTEGRATION.md §1 (oracle/ref_wrap/enc_handle_binding.c).
+
+CPU (`-m "not gpu"`): tiny clips through the lock-step emulator build of the same kernel sources.
+GPU (`-m gpu`): 256x144 clips, presets 4 / 6 / 8, 8- and 10-bit, --lp 1 / 2 / 4, quantisation matrices, lossless, through libsvtav1_hip.so;
+the per-pointer call counts land in gpurun_out/identity/identity.json (copied to profiles/ per round)."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+from conftest import EMU_LIB, PKG_DIR, ROOT
+
+spec = importlib.util.spec_from_file_location("enc_identity", os.path.join(ROOT, "tools", "enc_identity.py"))
+enc_identity = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(enc_identity)
+
+needs_encoder = pytest.mark.skipif(not os.path.exists(enc_identity.ENC), reason="oracle/_ref/enc/SvtAv1EncApp not built (reference sources absent)")
+
+
+def _check(res):
+    assert res["rc_c"] == 0 and res["rc_hip"] == 0, res.get("stderr_tail")
+    assert res["hook_line"], "the encoder did not install the HIP variant"
+    assert res["identical"], "bitstream / reconstruction differ from the C-only encoder: %s" % res["case"]
+    assert res["pointers_hit"] >= 20 and res["calls"] > 1000, res
+
+
+@needs_encoder
+@pytest.mark.parametrize("case", ["tiny_p8_8bit", "tiny_p8_10bit", "tiny_p8_lossless"])
+def test_encoder_identity_emulator(case, tmp_path):
+    from conftest import EmuBackend  # builds the emulator library if needed
+    EmuBackend()
+    _check(enc_identity.run_case(case, EMU_LIB, str(tmp_path), timeout=900))
+
+
+@needs_encoder
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", enc_identity.GPU_CASES)
+def test_encoder_identity_gpu(case):
+    lib = os.path.join(PKG_DIR, "libsvtav1_hip.so")
+    assert os.path.exists(lib), "libsvtav1_hip.so missing (no CPU fallback)"
+    out = os.path.join(ROOT, "gpurun_out", "identity")
+    res = enc_identity.run_case(case, lib, out, timeout=1500)
+    import json
+    with open(os.path.join(out, case + ".json"), "w") as f:
+        json.dump(res, f, indent=1)
+    _check(res)

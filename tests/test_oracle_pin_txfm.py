@@ -135,3 +135,38 @@ def test_txfm_oracle_vs_golden(oracle):
         packed = np.ascontiguousarray(a.reshape(h, w)[:ih, :iw]).reshape(-1)
         oracle.oracle_inv_txfm2d_add(p(packed), p(pred), w, p(o), w, tx_type, ts, bd)
         assert np.array_equal(o, z["recon_%d" % i])
+
+
+def test_wht4x4_vs_reference(oracle, ref):
+    """Lossless-mode Walsh-Hadamard: svt_av1_fwht4x4_c, svt_av1_highbd_iwht4x4_16_add_c / _1_add_c and the 8-bit wrapper
+    svt_av1_inv_txfm_add_c with TxfmParam.lossless (inv_transforms.c:2833-2848, 3177-3192)."""
+    from conftest import load_pkg
+    pkg = load_pkg()
+    g = rng(77)
+    for it in range(200):
+        bd = (8, 10, 12)[it % 3]
+        amp = (1 << bd) - 1
+        stride = 4 + it % 5
+        res = g.integers(-amp, amp + 1, 4 * stride).astype(np.int16)
+        if it < 4:
+            res[:] = (amp, -amp, amp, -amp)[it]
+        a, b = np.zeros(16, np.int32), np.zeros(16, np.int32)
+        oracle.oracle_fwht4x4(p(res), p(a), stride)
+        ref.svt_av1_fwht4x4_c(p(res), p(b), stride)
+        assert np.array_equal(a, b)
+        coeff = a if it % 2 else g.integers(-(amp << 4), (amp << 4) + 1, 16).astype(np.int32)
+        pred = g.integers(0, amp + 1, 4 * stride).astype(np.uint16)
+        for eob in (1, 16):
+            w1, w2 = pred.copy(), pred.copy()
+            oracle.oracle_iwht4x4_add(p(coeff), p(pred), stride, p(w1), stride, eob, bd)
+            # CONVERT_TO_BYTEPTR(x) = (uint8_t*)((uintptr_t)x >> 1)  (definitions.h)
+            f = ref.svt_av1_highbd_iwht4x4_16_add_c if eob > 1 else ref.svt_av1_highbd_iwht4x4_1_add_c
+            f(p(coeff), C.c_void_p(pred.ctypes.data >> 1), stride, C.c_void_p(w2.ctypes.data >> 1), stride, bd)
+            assert np.array_equal(w1, w2), (it, eob, bd)
+            if bd == 8:  # the 8-bit pointer form with the whole TxfmParam
+                tp = np.zeros(1, pkg.TxfmParam)
+                tp[0] = (0, 0, 1, 8, 0, 0, eob)
+                p8 = pred.astype(np.uint8)
+                w8 = p8.copy()
+                ref.svt_av1_inv_txfm_add_c(p(coeff), p(p8), stride, p(w8), stride, p(tp))
+                assert np.array_equal(w8.astype(np.uint16), w1), (it, eob)

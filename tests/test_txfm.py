@@ -61,7 +61,7 @@ def test_inv_txfm2d_add_batch(be, oracle, ts):
             res = g.integers(-amp, amp + 1, h * w).astype(np.int16)
             full = oracle_fwd(oracle, res, w, tt, ts, bd)
             coeffs[i] = np.ascontiguousarray(full.reshape(h, w)[:ih, :iw]).reshape(-1)
-            descs[i] = (i * iw * ih, i * h * stride, i * h * stride, stride, stride, tt, (0,) * 7)
+            descs[i] = (i * iw * ih, i * h * stride, i * h * stride, stride, stride, tt, 0, (0,) * 6)
         dco, dpr, dd = be.dev(coeffs), be.dev(pred), be.dev(descs)
         drc = be.empty(n * h * stride, np.uint16)
         be.lib.svt_hip_inv_txfm2d_add_batch(be.ptr(dco), be.ptr(dpr), be.ptr(drc), be.ptr(dd), n, ts, bd, be.stream)
@@ -99,5 +99,55 @@ def test_txfm_single_call_symbols(be, oracle):
         assert np.array_equal(got, want)
         pred8 = pred.astype(np.uint8)
         got8 = pred8.copy()
-        be.lib.svt_av1_inv_txfm_add_u8_hip(p(packed), p(got8), w + 4, p(got8), w + 4, tt, ts)
+        be.lib.svt_av1_inv_txfm_add_u8_hip(p(packed), p(got8), w + 4, p(got8), w + 4, tt, ts, 0, 64)
         assert np.array_equal(got8.astype(np.uint16), want)
+
+
+def test_wht4x4(be, oracle):
+    """Lossless mode: svt_av1_fwht4x4_hip, the batched forward / inverse WHT and svt_av1_inv_txfm_add_hip (exact pointer prototype,
+    TxfmParam.lossless / eob honoured: eob <= 1 is a different function in the reference, not a shortcut)."""
+    g = rng(91)
+    n = 300 if be.is_gpu else 40
+    for bd in (8, 10, 12):
+        amp = (1 << bd) - 1
+        stride = 7
+        res = g.integers(-amp, amp + 1, (n, 4 * stride)).astype(np.int16)
+        res[0, :], res[1, :] = amp, -amp
+        fd = np.zeros(n, dtype=be.pkg.FwdTxfmDesc)
+        for i in range(n):
+            fd[i] = (i * 4 * stride, stride, 0, (0, 0, 0))
+        out = be.empty(n * 16, np.int32)
+        dres, dfd = be.dev(res), be.dev(fd)
+        be.lib.svt_hip_fwht4x4_batch(be.ptr(dres), be.ptr(dfd), n, be.ptr(out), be.stream)
+        got = be.host(out).reshape(n, 16)
+        want = np.zeros((n, 16), np.int32)
+        for i in range(n):
+            oracle.oracle_fwht4x4(p(res[i]), p(want[i]), stride)
+        assert np.array_equal(got, want)
+        single = np.zeros(16, np.int32)
+        be.lib.svt_av1_fwht4x4_hip(p(res[2]), p(single), stride)
+        assert np.array_equal(single, want[2])
+        coeffs = want.copy()
+        coeffs[n // 2:] = g.integers(-(amp << 4), (amp << 4) + 1, (n - n // 2, 16))
+        pred = g.integers(0, amp + 1, (n, 4 * stride)).astype(np.uint16)
+        idesc = np.zeros(n, dtype=be.pkg.InvTxfmDesc)
+        for i in range(n):
+            idesc[i] = (i * 16, i * 4 * stride, i * 4 * stride, stride, stride, 0, i & 1, (0,) * 6)
+        dco, dpr, dd = be.dev(coeffs), be.dev(pred), be.dev(idesc)
+        drc = be.empty(n * 4 * stride, np.uint16)
+        be.lib.svt_hip_iwht4x4_add_batch(be.ptr(dco), be.ptr(dpr), be.ptr(drc), be.ptr(dd), n, bd, be.stream)
+        rec = be.host(drc).reshape(n, 4, stride)
+        for i in range(n):
+            w = np.zeros(4 * stride, np.uint16)
+            oracle.oracle_iwht4x4_add(p(coeffs[i]), p(pred[i]), stride, p(w), stride, 16 if i & 1 else 1, bd)
+            assert np.array_equal(rec[i][:, :4], w.reshape(4, stride)[:, :4]), (bd, i)
+        if bd == 8:
+            for i in range(6):
+                for eob in (0, 1, 2, 16):
+                    tp = np.zeros(1, be.pkg.TxfmParam)
+                    tp[0] = (0, 0, 1, 8, 0, 0, eob)
+                    p8 = pred[i].astype(np.uint8)
+                    w8, w16 = p8.copy(), np.zeros(4 * stride, np.uint16)
+                    be.lib.svt_av1_inv_txfm_add_hip(p(coeffs[i]), p(p8), stride, p(w8), stride, p(tp))
+                    oracle.oracle_iwht4x4_add(p(coeffs[i]), p(pred[i]), stride, p(w16), stride, eob, 8)
+                    assert np.array_equal(w8.reshape(4, stride)[:, :4].astype(np.uint16), w16.reshape(4, stride)[:, :4]), (i, eob)

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Bitstream-identity check of the HIP variant inside the REAL reference encoder (SURVEY 8c "integration-level parity").
+
+The reference's own CI invariant is that every ISA level produces the same bitstream
+(/root/reference/.gitlab/workflows/linux/.gitlab-ci.yml:351-367).  oracle/_ref/enc/SvtAv1EncApp is the reference encoder built
+C-only by oracle/Makefile with the binding of INTEGRATION.md §1 (oracle/ref_wrap/enc_handle_binding.c): with SVT_HIP unset it is
+the `--asm c` encoder; with SVT_HIP=<device> svt_hip_setup_rtcd() overwrites the dispatch pointers right after
+enc_handle.c:1444-1445.  This script encodes a synthetic clip both ways and compares the .ivf and the reconstruction byte by byte;
+SVT_HIP_COUNT gives the number of calls that went through every installed pointer.
+
+    python tools/enc_identity.py --lib svt-av1-psy_amd/libsvtav1_hip.so --case all --out gpurun_out/identity
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENC = os.path.join(ROOT, "oracle", "_ref", "enc", "SvtAv1EncApp")
+
+# name: (width, height, frames, bit depth, extra encoder arguments)
+CASES = {
+    "p8_8bit_lp1": (256, 144, 8, 8, ["--preset", "8", "--lp", "1"]),
+    "p8_10bit_lp1": (256, 144, 8, 10, ["--preset", "8", "--lp", "1"]),
+    "p4_8bit_lp1": (256, 144, 6, 8, ["--preset", "4", "--lp", "1"]),
+    "p4_10bit_lp4": (256, 144, 6, 10, ["--preset", "4", "--lp", "4"]),
+    "p8_8bit_lp4": (256, 144, 8, 8, ["--preset", "8", "--lp", "4"]),
+    "p8_8bit_lossless": (128, 128, 4, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
+    "p8_10bit_lossless": (128, 128, 4, 10, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
+    "p6_8bit_qm_lp2": (256, 144, 6, 8, ["--preset", "6", "--lp", "2", "--enable-qm", "1", "--qm-min", "2", "--qm-max", "10"]),
+    # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
+    "tiny_p8_8bit": (64, 64, 3, 8, ["--preset", "8", "--lp", "1"]),
+    "tiny_p8_10bit": (64, 64, 2, 10, ["--preset", "8", "--lp", "1"]),
+    "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
+}
+GPU_CASES = [k for k in CASES if not k.startswith("tiny_")]
+
+
+def make_clip(path, w, h, n, bd, seed=7):
+    """Textured luma sliding by (2, 1) pixels per frame plus noise, smooth chroma; 4:2:0 planar, 16-bit little endian above 8 bit."""
+    g = np.random.default_rng(seed)
+    W, H = w + 64, h + 64
+    base = np.kron(g.integers(0, 256, (H // 8 + 2, W // 8 + 2)).astype(np.float32), np.ones((8, 8), np.float32))[:H, :W]
+    yy, xx = np.mgrid[0:H, 0:W]
+    tex = base * 0.5 + 64 + 40 * np.sin(xx / 9.0) + 30 * np.cos(yy / 7.0)
+    with open(path, "wb") as f:
+        for i in range(n):
+            ox, oy = 2 * i, i
+            y = np.clip(tex[oy:oy + h, ox:ox + w] + g.normal(0, 2, (h, w)), 0, 255)
+            u = np.clip(128 + 20 * np.sin((xx[:h // 2, :w // 2] + ox) / 5.0), 0, 255)
+            v = np.clip(128 + 20 * np.cos((yy[:h // 2, :w // 2] + oy) / 6.0), 0, 255)
+            for p in (y, u, v):
+                f.write(p.astype(np.uint8).tobytes() if bd == 8 else (p.astype(np.uint16) << (bd - 8)).astype("<u2").tobytes())
+
+
+def encode(clip, w, h, n, bd, extra, out_prefix, env_extra=None, timeout=1800):
+    env = dict(os.environ)
+    for k in ("SVT_HIP", "SVT_HIP_LIB", "SVT_HIP_COUNT", "SVT_HIP_ONLY", "SVT_HIP_SKIP"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    cmd = [ENC, "-i", clip, "-w", str(w), "-h", str(h), "--fps", "30", "-n", str(n), "--input-depth", str(bd)] + extra + \
+          ["-b", out_prefix + ".ivf", "-o", out_prefix + ".rec"]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+    return r, time.time() - t0
+
+
+def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
+    w, h, n, bd, extra = CASES[name]
+    os.makedirs(outdir, exist_ok=True)
+    clip = os.path.join(outdir, name + ".yuv")
+    make_clip(clip, w, h, n, bd)
+    rc, tc = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_c"), timeout=timeout)
+    counts_file = os.path.join(outdir, name + "_counts.txt")
+    env = {"SVT_HIP": str(device), "SVT_HIP_LIB": lib, "SVT_HIP_COUNT": counts_file}
+    if only:
+        env["SVT_HIP_ONLY"] = only
+    if skip:
+        env["SVT_HIP_SKIP"] = skip
+    rh, th = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_hip"), env, timeout=timeout)
+    res = {"case": name, "width": w, "height": h, "frames": n, "bit_depth": bd, "args": extra, "rc_c": rc.returncode, "rc_hip": rh.returncode,
+           "seconds_c": round(tc, 2), "seconds_hip": round(th, 2)}
+    hooked = [ln for ln in rh.stderr.splitlines() if ln.startswith("SVT_HIP:")]
+    res["hook_line"] = hooked[0] if hooked else None
+    if rc.returncode or rh.returncode or not hooked:
+        res["identical"] = False
+        res["stderr_tail"] = (rc.stderr[-1500:] if rc.returncode else rh.stderr[-1500:])
+        return res
+    same = True
+    for ext in (".ivf", ".rec"):
+        a = open(os.path.join(outdir, name + "_c" + ext), "rb").read()
+        b = open(os.path.join(outdir, name + "_hip" + ext), "rb").read()
+        res["bytes" + ext] = len(a)
+        same = same and len(a) > 0 and a == b
+    res["identical"] = same
+    counts = {}
+    if os.path.exists(counts_file):
+        for ln in open(counts_file):
+            k, v = ln.split()
+            counts[k] = int(v)
+    res["pointers_installed"] = len(counts)
+    res["pointers_hit"] = sum(1 for v in counts.values() if v)
+    res["calls"] = sum(counts.values())
+    res["counts"] = {k: v for k, v in sorted(counts.items(), key=lambda kv: -kv[1]) if v}
+    for f in (clip, os.path.join(outdir, name + "_c.rec"), os.path.join(outdir, name + "_hip.rec")):
+        os.remove(f)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=os.path.join(ROOT, "svt-av1-psy_amd", "libsvtav1_hip.so"))
+    ap.add_argument("--case", default="all", help="case name, comma list, or 'all' (the GPU set)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "identity"))
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--skip", default=None)
+    ap.add_argument("--timeout", type=int, default=1800)
+    a = ap.parse_args()
+    if not os.path.exists(ENC):
+        sys.exit("oracle/_ref/enc/SvtAv1EncApp is missing: run `make -C oracle enc` where /root/reference exists")
+    names = GPU_CASES if a.case == "all" else a.case.split(",")
+    results, union = [], {}
+    for nme in names:
+        r = run_case(nme, os.path.abspath(a.lib), a.out, only=a.only, skip=a.skip, timeout=a.timeout)
+        results.append(r)
+        for k, v in r.get("counts", {}).items():
+            union[k] = union.get(k, 0) + v
+        print("%-20s identical=%s  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs" % (nme, r["identical"], r.get("calls"), r.get("pointers_hit"),
+                                                                                    r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"]), flush=True)
+        if not r["identical"]:
+            print(r.get("stderr_tail", ""))
+    summary = {"all_identical": all(r["identical"] for r in results), "pointers_hit_union": len(union), "calls_total": sum(union.values()),
+               "hit_table": dict(sorted(union.items(), key=lambda kv: -kv[1])), "cases": results}
+    with open(os.path.join(a.out, "identity.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print("ALL IDENTICAL" if summary["all_identical"] else "MISMATCH", "- %d distinct pointers hit, %d calls" % (len(union), sum(union.values())))
+    sys.exit(0 if summary["all_identical"] else 1)
+
+
+if __name__ == "__main__":
+    main()
