@@ -271,6 +271,63 @@ def test_me_full_frame_properties(be, oracle):
             assert np.array_equal(bs[i], ws) and np.array_equal(bm[i], wm), (aw, ah, int(i))
 
 
+def ref_me_many(ref, oracle, src_base, ref_base, descs, sub_sad, simd="avx2"):
+    """All items through the REAL reference kernels (oracle/_ref, AVX2 or C) driven in open_loop_me_fullpel_search_sblock's call order
+    (oracle/ref_drivers.c), one host thread per core."""
+    import concurrent.futures as cf
+    import os
+    fn = lambda nme: C.cast(getattr(ref, nme), C.c_void_p)  # noqa: E731
+    fns = [fn("svt_ext_all_sad_calculation_8x8_16x16_" + simd), fn("svt_ext_eight_sad_calculation_32x32_64x64_" + simd),
+           fn("svt_ext_sad_calculation_8x8_16x16_c"), fn("svt_ext_sad_calculation_32x32_64x64_c")]
+    drv = oracle.oracle_drive_ref_me_search_many
+    drv.restype = C.c_uint64
+    drv.argtypes = [C.c_void_p] * 7 + [C.c_uint32] * 4 + [C.c_int, C.c_void_p, C.c_void_p]
+    dd = np.ascontiguousarray(descs)
+    n = len(dd)
+    bs, bm = np.zeros((n, 85), np.uint32), np.zeros((n, 85), np.uint32)
+    cores = max(1, len(os.sched_getaffinity(0)))
+    with cf.ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(lambda k: drv(*fns, src_base.ctypes.data, ref_base.ctypes.data, dd.ctypes.data, n, k, cores, 1, sub_sad,
+                                        bs.ctypes.data, bm.ctypes.data), range(cores)))
+    assert done == n
+    return bs, bm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("area,sub_sad,n_refs", [((16, 9), 0, 4), ((16, 9), 1, 4), ((64, 32), 0, 4), ((64, 32), 1, 4), ((256, 256), 0, 1),
+                                                  ((256, 256), 1, 1), ((255, 130), 0, 1)])
+def test_me_full_frame_exhaustive(oracle, ref, area, sub_sad, n_refs):
+    """BASELINE configs[1] at FULL size, every item compared: all 510 SBs x n_refs references of a 1080p frame, 85 x (SAD, MV) each, against
+    the reference's own kernels run on the host cores.  256x256 (the M1 maximum, enc_mode_config.c:300-301) takes the
+    multi-tile path (global 64-bit atomicMin + finalize kernel); 255x130 adds the remainder-column positions on that path."""
+    from conftest import GpuBackend, _backends
+    be = _backends.setdefault("gpu", GpuBackend())
+    g = rng(2024 + area[0] + sub_sad)
+    aw, ah = area
+    W, H = 1920, 1080
+    PAD = 68 if aw <= 128 else 160  # search windows stay inside the allocation (the reference clips the area to the padded picture)
+    stride, rows = W + 2 * PAD, H + 2 * PAD
+    plane = rows * stride
+    base = g.integers(0, 256, (rows + 40, stride + 40), dtype=np.uint8)
+    base = (base.astype(np.uint16) * 3 // 4 + np.kron(g.integers(0, 64, ((rows + 40) // 8 + 1, (stride + 40) // 8 + 1)), np.ones((8, 8), np.int64))[:rows + 40, :stride + 40]).astype(np.uint8)
+    planes = np.empty((1 + n_refs, rows, stride), np.uint8)
+    planes[0] = base[20:20 + rows, 20:20 + stride]
+    shifts = [(3, -2), (-5, 1), (0, 0), (7, 4)]
+    for k in range(n_refs):
+        dx, dy = shifts[k]
+        noise = g.integers(0, 4 if k < 3 else 256, (rows, stride), dtype=np.uint8)  # the last reference is unrelated content
+        planes[k + 1] = base[20 - dy:20 - dy + rows, 20 - dx:20 - dx + stride] // (1 if k < 3 else 255) + noise
+    flat = planes.reshape(-1)
+    descs = be.pkg.me_descs_for_frame(W, H, stride, PAD, PAD, aw, ah, plane, n_refs=n_refs, src_plane=0, ref_plane0=1)
+    bs, bm = run_me_batch(be, flat, flat, descs, aw, ah, sub_sad)
+    ws, wm = ref_me_many(ref, oracle, flat, flat, descs, sub_sad)
+    bad = np.nonzero((bs != ws).any(1) | (bm != wm).any(1))[0]
+    assert bad.size == 0, (area, sub_sad, bad[:8], bs[bad[0]][:6], ws[bad[0]][:6])
+    if area == (16, 9) and sub_sad == 0:  # and the same through the reference's plain-C kernels
+        cs, cm = ref_me_many(ref, oracle, flat, flat, descs, sub_sad, simd="c")
+        assert np.array_equal(cs, bs) and np.array_equal(cm, bm)
+
+
 def test_me_fullpel_mixed_areas_and_empty(be, oracle):
     """Items of one launch may have different (smaller) search areas; an empty area reports MAX_SAD_VALUE."""
     g = rng(4)
