@@ -126,6 +126,9 @@ void  svt_hip_me_session_destroy(void *session);
 int   svt_hip_me_session_submit(void *session, int64_t pic_id, const uint8_t *plane_host, const int64_t *ref_ids, uint32_t n_refs, uint32_t area_w,
                                 uint32_t area_h, int sub_sad, uint32_t *best_sad_host, uint32_t *best_mv_host);
 void  svt_hip_me_session_wait(void *session, int slot);
+/* forget a resident picture whose host content changed (the next submission naming it as the source uploads it again); is a picture resident? */
+void  svt_hip_me_session_invalidate(void *session, int64_t pic_id);
+int   svt_hip_me_session_resident(void *session, int64_t pic_id);
 
 /* ---- batched forms (device pointers) ---- */
 typedef struct SvtHipSadPair {
@@ -205,7 +208,10 @@ typedef struct SvtHipHmeChainInputs { /* optional device inputs of the chain, an
     uint32_t prev_me_stage_based_exit_th; /* me_ctx->prev_me_stage_based_exit_th (0 = off): a level is skipped, keeping the previous stage's centre and SAD, when that
                                            * SAD is already small -- level 0 from the better performed pre-HME region below th >> 4 (:1937-1957), level 1 from
                                            * level 0 below th >> 5 (:2086-2096), level 2 from level 1 below th >> 2 (:2144-2154) */
-    uint32_t pad;
+    uint8_t  n_levels;     /* 3 (or 0): levels 0-2; 2: enable_hme_level2_flag = 0 (presets M7 and above, enc_mode_config.c:1636-1640): levels 0 and 1 only,
+                            * params[2] / sad_out[2] / sc_out[2] are not touched and the final centre is taken from level 1 (:2267-2309) */
+    uint8_t  list1_no_hme; /* temporal_layer_index == 0: list 1's references take no part in HME (:1983, :2055, :2127): their items are skipped */
+    uint8_t  pad[2];
 } SvtHipHmeChainInputs;
 void   svt_hip_hme_chain_batch(const SvtHipHmeLevelParams *params, const uint8_t *const *src_base, const uint8_t *const *ref_base,
                                const SvtHipHmeChainInputs *inputs, uint64_t *const *sad_out, int16_t *const *sc_out, void *stream);
@@ -250,7 +256,8 @@ typedef struct SvtHipMeIntegerSearchParams {
     int16_t  sa_min_width, sa_min_height, sa_max_width, sa_max_height; /* me_ctx->me_sa */
     uint8_t  sub_sad;                         /* me_search_method == SUB_SAD_SEARCH */
     uint8_t  mv_adj_enabled, mv_adj_nearest_ref_only; /* me_ctx->mv_based_sa_adj */
-    uint8_t  pad0;
+    uint8_t  list1_no_hme;                    /* temporal_layer_index == 0 with two lists: set_final_seach_centre_sb (:2211, :2362-2373) gives list 1's slots the centre (0, 0)
+                                               * and -- the variable is not reset -- the HME SAD of the last list-0 slot; their zz_sad stays ~0 (init_zz_sad :2390) */
     uint16_t mv_adj_mv_size_th, mv_adj_sa_multiplier;
     uint16_t dist[8];                         /* per slot: picture distance, through svt_aom_get_scaled_picture_distance unless ME_MCTF (:1300-1302) */
     uint8_t  ref_pic_index[8];                /* per slot: index inside its list (nearest_ref_only) */
@@ -453,9 +460,12 @@ typedef struct SvtHipMeStageParams {
     uint16_t reduce_me_sr_based_on_mv_length_th, stationary_hme_sad_abs_th, stationary_me_sr_divisor, reduce_me_sr_based_on_hme_sad_abs_th,
              me_sr_divisor_for_low_hme_sad;
     uint32_t me_early_exit_th;           /* 0 = off */
-    uint8_t  is_ref, me_8x8_var_enabled, pad1[2]; /* as SvtHipMeIntegerSearchParams */
+    uint8_t  is_ref, me_8x8_var_enabled; /* as SvtHipMeIntegerSearchParams */
+    uint8_t  hme_levels;                 /* 3 (or 0): enable_hme_level0/1/2_flag all set; 2: enable_hme_level2_flag = 0 (M7 and above): the integer search starts from level 1 */
+    uint8_t  pad1;
     uint32_t me_sr_div4_th, me_sr_div2_th, me_sr_mult2_th;
-    uint8_t  temporal_layer_gt0;         /* me_ctx->temporal_layer_index > 0 (list 1 takes part in pre-HME / HME, reference gating is active) */
+    uint8_t  temporal_layer_gt0;         /* me_ctx->temporal_layer_index > 0 (list 1 takes part in pre-HME / HME, reference gating is active); 0 = base layer: list 1's
+                                          * references skip HME, start the integer search at (0, 0) and inherit the last list-0 slot's HME SAD for the pruning steps */
     uint8_t  prehme_enabled, prehme_skip_search_line, prehme_l1_early_exit; /* me_ctx->prehme_ctrl */
     uint16_t prehme_sa_min_width[2], prehme_sa_min_height[2], prehme_sa_max_width[2], prehme_sa_max_height[2];
     uint32_t zz_sad_th, phme_sad_th;     /* me_hme_prune_ctrls (0 = off) */

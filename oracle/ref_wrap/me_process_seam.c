@@ -1,0 +1,328 @@
+/* me_process_seam.c -- TEST / BASELINE INFRASTRUCTURE: the reference's open-loop ME process with the per-picture batching seam of
+ * INTEGRATION.md §3.
+ *
+ * This translation unit IS Source/Lib/Codec/me_process.c of the reference (included below where it lies; nothing is copied).  The one
+ * change: inside svt_aom_motion_estimation_kernel's 64x64 loop (me_process.c:174-266) the call
+ *
+ *     svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_pic);
+ *
+ * is given a macro name for the duration of the #include and lands in seam_motion_estimation_b64() below.  With SVT_HIP_ME_SEAM unset (or
+ * the HIP library not loaded) that function IS the reference call.  With SVT_HIP_ME_SEAM=1 the first SB of a picture to arrive hands the
+ * WHOLE picture to the device stage -- one svt_hip_me_session_submit_stage() per picture, parameters filled field by field from the
+ * MeContext that the reference's own svt_aom_sig_deriv_me() (enc_mode_config.c:681) has just derived for this picture -- and every SB
+ * (this one and the ones the other segments / threads bring) copies its slice of the result into pcs->pa_me_data->me_results[b64_index]
+ * and the per-SB statistics arrays, which is everything svt_aom_motion_estimation_b64 leaves behind for a PAME task
+ * (motion_estimation.c:3076-3152).  Segments, the processed-SB counter, global motion, open-loop intra search: untouched reference code.
+ *
+ * A picture whose settings the device stage does not cover (super-resolution / resize re-ME, RTC's data-dependent HME resizing,
+ * enable_me_sr_adjustment == 2, HME without level 1) is DECLINED as a whole and runs the reference's C code; declines are counted and the
+ * identity tests require zero of them for the configurations they claim.  SVT_HIP_ME_SEAM_STATS=<file> receives the counters at exit.
+ */
+#define _GNU_SOURCE /* RTLD_DEFAULT */
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "motion_estimation.h" /* declares svt_aom_motion_estimation_b64 before the macro below exists */
+#include "me_context.h"
+#include "pcs.h"
+#include "sequence_control_set.h"
+#include "reference_object.h"
+#include "svtav1_hip.h" /* include/svtav1_hip.h of this repository: the C ABI */
+
+static EbErrorType seam_motion_estimation_b64(PictureParentControlSet *pcs, uint32_t b64_index, uint32_t b64_origin_x, uint32_t b64_origin_y,
+                                              MeContext *me_ctx, EbPictureBufferDesc *input_ptr);
+
+/* ---- the C ABI, resolved from the library enc_handle_binding.c has dlopen()ed with RTLD_GLOBAL ---- */
+static struct {
+    void *(*create)(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
+    int (*enable_stage)(void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
+    int (*submit_stage)(void *, int64_t, const uint8_t *, const int64_t *, uint32_t, const SvtHipMeStageParams *, const SvtHipMeResultsHost *);
+    void (*wait)(void *, int);
+    void (*invalidate)(void *, int64_t);
+    int (*resident)(void *, int64_t);
+    void *(*host_alloc)(size_t);
+} abi;
+
+enum { SEAM_RING = 24, SEAM_MAX_REFS = 7, SEAM_RECS = 64 };
+typedef struct SeamPicture { /* results of one picture, consumed SB by SB */
+    PictureParentControlSet *pcs;
+    uint64_t                 picture_number;
+    int                      state; /* 0 free, 1 being computed, 2 ready, 3 declined (run the reference) */
+    uint32_t                 n_sb, n_pus, max_refs, max_cand, consumed;
+    uint8_t                 *total, *cand;
+    uint32_t                *mv;
+    SvtHipMeSbStats         *stats;
+    size_t                   cap_total, cap_cand, cap_mv, cap_stats;
+} SeamPicture;
+static struct {
+    pthread_mutex_t lock;
+    pthread_cond_t  ready;
+    int             mode; /* -1 unknown, 0 off, 1 on */
+    void           *session;
+    uint32_t        width, height, stride, org_x, org_y, rows;
+    SeamPicture     rec[SEAM_RECS];
+    uint64_t        sum[SEAM_RING * 2][2]; /* (picture id, plane checksum) of what is resident */
+    uint64_t        n_pictures, n_declined, n_sb, n_uploads, n_reuploads;
+    char            why[128];
+} G = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, -1};
+
+static void seam_stats(void) {
+    const char *f = getenv("SVT_HIP_ME_SEAM_STATS");
+    FILE       *o = f ? fopen(f, "w") : NULL;
+    if (!o) return;
+    fprintf(o, "pictures_offloaded %llu\npictures_declined %llu\nsb_results %llu\nplane_uploads %llu\nplane_reuploads %llu\nlast_decline %s\n",
+            (unsigned long long)G.n_pictures, (unsigned long long)G.n_declined, (unsigned long long)G.n_sb, (unsigned long long)G.n_uploads,
+            (unsigned long long)G.n_reuploads, G.why[0] ? G.why : "-");
+    fclose(o);
+}
+static int seam_on(void) {
+    if (G.mode >= 0) return G.mode;
+    G.mode = 0;
+    const char *e = getenv("SVT_HIP_ME_SEAM");
+    if (!e || !atoi(e) || !getenv("SVT_HIP")) return 0;
+#define SYM(field, name) *(void **)&abi.field = dlsym(RTLD_DEFAULT, name)
+    SYM(create, "svt_hip_me_session_create"); SYM(enable_stage, "svt_hip_me_session_enable_stage"); SYM(submit_stage, "svt_hip_me_session_submit_stage");
+    SYM(wait, "svt_hip_me_session_wait"); SYM(invalidate, "svt_hip_me_session_invalidate"); SYM(resident, "svt_hip_me_session_resident");
+    SYM(host_alloc, "svt_hip_host_alloc");
+#undef SYM
+    if (!abi.create || !abi.enable_stage || !abi.submit_stage || !abi.wait || !abi.invalidate || !abi.resident) {
+        fprintf(stderr, "SVT_HIP_ME_SEAM: libsvtav1_hip is not loaded\n");
+        abort();
+    }
+    atexit(seam_stats);
+    fprintf(stderr, "SVT_HIP_ME_SEAM: open-loop ME runs as one device stage per picture\n");
+    return G.mode = 1;
+}
+
+static uint64_t plane_sum(const EbPictureBufferDesc *p) { /* content check of the visible luma samples (padding is a function of them) */
+    uint64_t h = 1469598103934665603ull;
+    for (uint32_t y = 0; y < p->height; y++) {
+        const uint8_t *r = p->buffer_y + (size_t)(p->org_y + y) * p->stride_y + p->org_x;
+        uint64_t       a = 0;
+        for (uint32_t x = 0; x + 8 <= p->width; x += 8) { uint64_t v; memcpy(&v, r + x, 8); a = a * 1099511628211ull + v; }
+        h = (h ^ a) * 1099511628211ull;
+    }
+    return h;
+}
+static int sum_slot(uint64_t id, int make) {
+    int free_i = -1;
+    for (int i = 0; i < SEAM_RING * 2; i++) {
+        if (G.sum[i][1] && G.sum[i][0] == id) return i;
+        if (!G.sum[i][1] && free_i < 0) free_i = i;
+    }
+    if (!make) return -1;
+    if (free_i < 0) { memset(G.sum, 0, sizeof(G.sum)); free_i = 0; }
+    G.sum[free_i][0] = id;
+    return free_i;
+}
+/* make `pic` (picture id `id`) resident with its current content: upload it when it is absent or its host content changed since the upload */
+static int ensure_resident(uint64_t id, const EbPictureBufferDesc *pic, const SvtHipMeStageParams *S) {
+    const uint64_t now = plane_sum(pic) | 1;
+    const int      k   = sum_slot(id, 1);
+    if (abi.resident(G.session, (int64_t)id)) {
+        if (G.sum[k][1] == now) return 0;
+        abi.invalidate(G.session, (int64_t)id); /* e.g. temporally filtered in place after it was uploaded */
+        G.n_reuploads++;
+    }
+    const int slot = abi.submit_stage(G.session, (int64_t)id, pic->buffer_y, NULL, 0, S, NULL);
+    if (slot < 0) return slot;
+    abi.wait(G.session, slot); /* the host plane is pageable memory the encoder may rewrite: finish the copy before returning */
+    G.sum[k][1] = now;
+    G.n_uploads++;
+    return 0;
+}
+
+static int decline(const char *why) {
+    snprintf(G.why, sizeof(G.why), "%s", why);
+    return -1;
+}
+/* SvtHipMeStageParams from the MeContext svt_aom_sig_deriv_me filled + the per-picture set-up of me_process.c:236-262 (same field names) */
+static int fill_stage(PictureParentControlSet *pcs, MeContext *c, SvtHipMeStageParams *S, int64_t *ref_ids, const EbPictureBufferDesc **ref_pics,
+                      uint32_t *n_refs_out) {
+    SequenceControlSet *scs = pcs->scs;
+    memset(S, 0, sizeof(*S));
+    if (pcs->frame_superres_enabled || pcs->frame_resize_enabled) return decline("super-resolution / resize");
+    if (!c->enable_hme_flag || !c->enable_hme_level0_flag || !c->enable_hme_level1_flag) return decline("HME without levels 0 and 1");
+    if (c->me_sr_adjustment_ctrls.enable_me_sr_adjustment > 1) return decline("enable_me_sr_adjustment == 2");
+    if (c->reduce_hme_l0_sr_th_min || c->reduce_hme_l0_sr_th_max) return decline("RTC level-0 resizing from list 0's motion");
+    if (c->num_hme_sa_w * c->num_hme_sa_h > 4) return decline("more than 2 x 2 HME regions");
+    const uint32_t n0 = c->num_of_ref_pic_to_search[0], n1 = c->num_of_list_to_search > 1 ? c->num_of_ref_pic_to_search[1] : 0, n = n0 + n1;
+    if (n == 0 || n > SEAM_MAX_REFS || n0 > 4 || n1 > 4) return decline("reference count");
+    S->num_hme_sa_w = (uint8_t)c->num_hme_sa_w; S->num_hme_sa_h = (uint8_t)c->num_hme_sa_h;
+    S->hme_sub_sampled = c->hme_search_method != FULL_SAD_SEARCH;
+    S->me_sub_sad      = c->me_search_method == SUB_SAD_SEARCH;
+    S->hme_levels      = c->enable_hme_level2_flag ? 3 : 2;
+    S->hme_sa_width[1] = (int16_t)c->hme_l1_sa.width; S->hme_sa_height[1] = (int16_t)c->hme_l1_sa.height;
+    S->hme_sa_width[2] = (int16_t)c->hme_l2_sa.width; S->hme_sa_height[2] = (int16_t)c->hme_l2_sa.height;
+    S->me_sa_min_width = (int16_t)c->me_sa.sa_min.width; S->me_sa_min_height = (int16_t)c->me_sa.sa_min.height;
+    S->me_sa_max_width = (int16_t)c->me_sa.sa_max.width; S->me_sa_max_height = (int16_t)c->me_sa.sa_max.height;
+    S->mv_adj_enabled = c->mv_based_sa_adj.enabled; S->mv_adj_nearest_ref_only = c->mv_based_sa_adj.nearest_ref_only;
+    S->mv_adj_mv_size_th = c->mv_based_sa_adj.mv_size_th; S->mv_adj_sa_multiplier = c->mv_based_sa_adj.sa_multiplier;
+    const MeHmeRefPruneCtrls *pr = &c->me_hme_prune_ctrls;
+    const MeSrCtrls          *sr = &c->me_sr_adjustment_ctrls;
+    /* hme_prune_ref_and_adjust_sr runs when prune_ref = enable_hme_flag && me_type != ME_MCTF (motion_estimation.c:3103, :3115-3117) */
+    S->hme_prune_enabled = pr->enable_me_hme_ref_pruning && pr->prune_ref_if_hme_sad_dev_bigger_than_th != (uint16_t)~0;
+    S->prune_ref_if_hme_sad_dev_bigger_than_th = pr->prune_ref_if_hme_sad_dev_bigger_than_th;
+    S->sr_adjustment = sr->enable_me_sr_adjustment;
+    S->reduce_me_sr_based_on_mv_length_th = sr->reduce_me_sr_based_on_mv_length_th; S->stationary_hme_sad_abs_th = sr->stationary_hme_sad_abs_th;
+    S->stationary_me_sr_divisor = sr->stationary_me_sr_divisor; S->reduce_me_sr_based_on_hme_sad_abs_th = sr->reduce_me_sr_based_on_hme_sad_abs_th;
+    S->me_sr_divisor_for_low_hme_sad = sr->me_sr_divisor_for_low_hme_sad;
+    S->me_early_exit_th = c->me_early_exit_th;
+    S->is_ref = c->is_ref;
+    S->me_8x8_var_enabled = c->me_8x8_var_ctrls.enabled; S->me_sr_div4_th = c->me_8x8_var_ctrls.me_sr_div4_th;
+    S->me_sr_div2_th = c->me_8x8_var_ctrls.me_sr_div2_th; S->me_sr_mult2_th = c->me_8x8_var_ctrls.me_sr_mult2_th;
+    S->temporal_layer_gt0 = c->temporal_layer_index > 0;
+    S->prehme_enabled = c->prehme_ctrl.enable; S->prehme_skip_search_line = c->prehme_ctrl.skip_search_line; S->prehme_l1_early_exit = c->prehme_ctrl.l1_early_exit;
+    for (int k = 0; k < 2; k++) {
+        S->prehme_sa_min_width[k] = c->prehme_ctrl.prehme_sa_cfg[k].sa_min.width; S->prehme_sa_min_height[k] = c->prehme_ctrl.prehme_sa_cfg[k].sa_min.height;
+        S->prehme_sa_max_width[k] = c->prehme_ctrl.prehme_sa_cfg[k].sa_max.width; S->prehme_sa_max_height[k] = c->prehme_ctrl.prehme_sa_cfg[k].sa_max.height;
+    }
+    S->zz_sad_th = pr->zz_sad_th; S->zz_sad_pct = (uint16_t)pr->zz_sad_pct; S->phme_sad_th = pr->phme_sad_th; S->phme_sad_pct = (uint16_t)pr->phme_sad_pct;
+    S->prev_me_stage_based_exit_th = c->prev_me_stage_based_exit_th;
+    /* init_zz_sad's picture-level conditions (motion_estimation.c:2419-2421) */
+    S->me_safe_limit_zz_th = (c->me_safe_limit_zz_th && pcs->hierarchical_levels > 0 && c->num_of_list_to_search == 2 &&
+                              pcs->temporal_layer_index >= pcs->hierarchical_levels && pcs->similar_brightness_refs) ? c->me_safe_limit_zz_th : 0;
+    /* per reference slot, list 0 first: picture distance through svt_aom_get_scaled_picture_distance (:1239-1243, :1300-1302) and the level-0 search area of
+     * get_hme_l0_search_area (:1806-1866; distance-based resizing in its non-RTC form divides the base area by 1 + ref index, hme_level0_b64 restores it) */
+    S->hme_l0_per_ref = 1;
+    uint32_t k = 0;
+    for (uint32_t li = 0; li < c->num_of_list_to_search; li++)
+        for (uint32_t ri = 0; ri < c->num_of_ref_pic_to_search[li]; ri++, k++) {
+            EbPaReferenceObject *ro = (EbPaReferenceObject *)pcs->ref_pa_pic_ptr_array[li][ri]->object_ptr;
+            ref_ids[k] = (int64_t)ro->picture_number; ref_pics[k] = ro->input_padded_pic;
+            const int64_t  d64  = (int64_t)pcs->picture_number - (int64_t)ro->picture_number;
+            const uint16_t dist = (uint16_t)(int16_t)(d64 < 0 ? -d64 : d64), f = (uint16_t)((dist * 5) / 8 + ((dist % 8) ? 1 : 0));
+            S->dist[k] = f; S->ref_pic_index[k] = (uint8_t)ri;
+            SearchAreaMinMax a = c->hme_l0_sa;
+            if (sr->enable_me_sr_adjustment && sr->distance_based_hme_resizing) {
+                a.sa_min.width /= 1 + ri; a.sa_min.height /= 1 + ri; a.sa_max.width /= 1 + ri; a.sa_max.height /= 1 + ri;
+            }
+            int w = a.sa_min.width / c->num_hme_sa_w, h = a.sa_min.height / c->num_hme_sa_h;
+            const int wmax = ((a.sa_max.width / c->num_hme_sa_w) + 15) & ~15, hmax = a.sa_max.height / c->num_hme_sa_h;
+            w = ((w * f) + 15) & ~15; h = h * f;
+            S->hme_l0_sa_width_ref[k] = (int16_t)(w < wmax ? w : wmax); S->hme_l0_sa_height_ref[k] = (int16_t)(h < hmax ? h : hmax);
+            S->results.ref_picture_number[li][ri] = ro->picture_number;
+        }
+    SvtHipMeResultsParams *R = &S->results;
+    R->num_of_list_to_search = c->num_of_list_to_search; R->num_of_ref_pic_to_search[0] = (uint8_t)n0; R->num_of_ref_pic_to_search[1] = (uint8_t)n1;
+    R->max_cand = pcs->pa_me_data->max_cand; R->max_refs = pcs->pa_me_data->max_refs; R->max_l0 = pcs->pa_me_data->max_l0;
+    R->enable_me_16x16 = pcs->enable_me_16x16; R->enable_me_8x8 = pcs->enable_me_8x8;
+    R->only_l_bwd = scs->mrp_ctrls.only_l_bwd;
+    R->use_best_unipred_cand_only = c->use_best_unipred_cand_only;
+    R->prune_ref = pr->enable_me_hme_ref_pruning && pr->prune_ref_if_me_sad_dev_bigger_than_th != (uint16_t)~0; /* me_prune_ref's second half (:1545-1563) */
+    R->prune_ref_if_me_sad_dev_bigger_than_th = pr->prune_ref_if_me_sad_dev_bigger_than_th;
+    R->low_resolution = scs->input_resolution <= INPUT_SIZE_480p_RANGE;
+    R->gm_enabled = pcs->gm_ctrls.enabled; R->gm_use_distance_based_active_th = pcs->gm_ctrls.use_distance_based_active_th;
+    R->prune_me_candidates_th = c->prune_me_candidates_th;
+    R->picture_number = pcs->picture_number;
+    *n_refs_out = n;
+    return 0;
+}
+
+static void reserve(void **p, size_t *cap, size_t bytes) {
+    if (bytes <= *cap) return;
+    *p = abi.host_alloc ? abi.host_alloc(bytes) : malloc(bytes); /* (the previous, smaller buffer is left to the process: sizes settle after the first picture) */
+    *cap = bytes;
+}
+
+/* the whole picture on the device; called with G.lock held by the thread that brought the picture's first SB */
+static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *c, const EbPictureBufferDesc *src) {
+    SvtHipMeStageParams        S;
+    int64_t                    ref_ids[8];
+    const EbPictureBufferDesc *ref_pics[8];
+    uint32_t                   n_refs = 0;
+    if (fill_stage(pcs, c, &S, ref_ids, ref_pics, &n_refs)) return -1;
+    EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
+    if (!G.session) {
+        G.width = src->width; G.height = src->height; G.stride = src->stride_y; G.org_x = src->org_x; G.org_y = src->org_y;
+        G.rows = src->luma_size / src->stride_y;
+        /* largest ME area any preset derives is 256 x 256 (x 2 by the MV-based adjustment, x 3 / 2 by the variance probe); sized once for the encode */
+        G.session = abi.create(G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 2);
+        if (!G.session || abi.enable_stage(G.session, pa->quarter_downsampled_picture_ptr->org_x, pa->sixteenth_downsampled_picture_ptr->org_x, 4, 768, 768)) {
+            fprintf(stderr, "SVT_HIP_ME_SEAM: cannot create the ME session\n");
+            abort();
+        }
+    }
+    if (src->width != G.width || src->height != G.height || src->stride_y != G.stride || src->org_x != G.org_x || src->org_y != G.org_y)
+        return decline("picture geometry changed");
+    for (int pass = 0;; pass++) { /* an upload may evict a reference another upload just brought in (round-robin ring): repeat until all are there */
+        int missing = 0;
+        for (uint32_t k = 0; k < n_refs; k++) {
+            if (ref_pics[k]->width != G.width || ref_pics[k]->stride_y != G.stride) return decline("reference geometry");
+            if (ensure_resident((uint64_t)ref_ids[k], ref_pics[k], &S)) return decline("reference upload");
+        }
+        for (uint32_t k = 0; k < n_refs; k++) missing += !abi.resident(G.session, ref_ids[k]);
+        if (!missing) break;
+        if (pass == 3) return decline("ring too small for the reference set");
+    }
+    P->n_sb = pcs->b64_total_count;
+    P->n_pus = pcs->enable_me_16x16 ? (pcs->enable_me_8x8 ? 85 : 21) : 5;
+    P->max_refs = S.results.max_refs; P->max_cand = S.results.max_cand;
+    reserve((void **)&P->total, &P->cap_total, (size_t)P->n_sb * P->n_pus);
+    reserve((void **)&P->cand, &P->cap_cand, (size_t)P->n_sb * P->n_pus * P->max_cand);
+    reserve((void **)&P->mv, &P->cap_mv, (size_t)P->n_sb * P->n_pus * P->max_refs * 4);
+    reserve((void **)&P->stats, &P->cap_stats, (size_t)P->n_sb * sizeof(SvtHipMeSbStats));
+    SvtHipMeResultsHost H;
+    memset(&H, 0, sizeof(H));
+    H.total_me_candidate_index = P->total; H.me_mv_array = P->mv; H.me_candidate_array = P->cand; H.sb_stats = P->stats;
+    /* the source: always (re)uploaded when its content differs from what is resident (the same picture may have served as a reference before its own ME) */
+    const uint64_t now = plane_sum(src) | 1;
+    const int      ks  = sum_slot(pcs->picture_number, 1);
+    if (abi.resident(G.session, (int64_t)pcs->picture_number) && G.sum[ks][1] != now) { abi.invalidate(G.session, (int64_t)pcs->picture_number); G.n_reuploads++; }
+    if (!abi.resident(G.session, (int64_t)pcs->picture_number)) G.n_uploads++;
+    G.sum[ks][1] = now;
+    const int slot = abi.submit_stage(G.session, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, n_refs, &S, &H);
+    if (slot < 0) {
+        char why[64];
+        snprintf(why, sizeof(why), "svt_hip_me_session_submit_stage returned %d", slot);
+        return decline(why);
+    }
+    abi.wait(G.session, slot);
+    return 0;
+}
+
+static EbErrorType seam_motion_estimation_b64(PictureParentControlSet *pcs, uint32_t b64_index, uint32_t b64_origin_x, uint32_t b64_origin_y,
+                                              MeContext *me_ctx, EbPictureBufferDesc *input_ptr) {
+    if (!seam_on() || me_ctx->me_type != ME_OPEN_LOOP)
+        return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_ptr);
+    pthread_mutex_lock(&G.lock);
+    SeamPicture *P = NULL, *spare = NULL;
+    for (int i = 0; i < SEAM_RECS; i++) {
+        if (G.rec[i].state && G.rec[i].pcs == pcs && G.rec[i].picture_number == pcs->picture_number) { P = &G.rec[i]; break; }
+        if (!G.rec[i].state && !spare) spare = &G.rec[i];
+    }
+    if (!P) { /* first SB of this picture: compute everything now */
+        if (!spare) { fprintf(stderr, "SVT_HIP_ME_SEAM: more than %d pictures in flight\n", SEAM_RECS); abort(); }
+        P = spare;
+        P->pcs = pcs; P->picture_number = pcs->picture_number; P->consumed = 0; P->state = 1;
+        EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
+        const int rc = run_picture(P, pcs, me_ctx, pa->input_padded_pic); /* (other pictures queue on the lock: one stage at a time) */
+        if (rc) { P->state = 3; P->n_sb = pcs->b64_total_count; G.n_declined++; }
+        else    { P->state = 2; G.n_pictures++; }
+        pthread_cond_broadcast(&G.ready);
+    }
+    while (P->state == 1) pthread_cond_wait(&G.ready, &G.lock);
+    const int declined = P->state == 3;
+    if (!declined) {
+        MeSbResults *r = pcs->pa_me_data->me_results[b64_index];
+        memcpy(r->total_me_candidate_index, P->total + (size_t)b64_index * P->n_pus, P->n_pus);
+        memcpy(r->me_candidate_array, P->cand + (size_t)b64_index * P->n_pus * P->max_cand, (size_t)P->n_pus * P->max_cand);
+        memcpy(r->me_mv_array, P->mv + (size_t)b64_index * P->n_pus * P->max_refs, (size_t)P->n_pus * P->max_refs * 4);
+        const SvtHipMeSbStats *st = &P->stats[b64_index];
+        pcs->me_64x64_distortion[b64_index] = st->me_64x64_distortion; pcs->me_32x32_distortion[b64_index] = st->me_32x32_distortion;
+        pcs->me_16x16_distortion[b64_index] = st->me_16x16_distortion; pcs->me_8x8_distortion[b64_index] = st->me_8x8_distortion;
+        pcs->me_8x8_cost_variance[b64_index] = st->me_8x8_cost_variance; pcs->rc_me_distortion[b64_index] = st->rc_me_distortion;
+        pcs->stationary_block_present_sb[b64_index] = st->stationary_block_present_sb; pcs->rc_me_allow_gm[b64_index] = st->rc_me_allow_gm;
+        G.n_sb++;
+    }
+    if (++P->consumed == P->n_sb) P->state = 0; /* every SB has fetched its slice: the record is free again */
+    pthread_mutex_unlock(&G.lock);
+    if (declined) return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_ptr);
+    return EB_ErrorNone;
+}
+
+#define svt_aom_motion_estimation_b64(pcs, i, x, y, ctx, pic) seam_motion_estimation_b64(pcs, i, x, y, ctx, pic)
+#include "me_process.c" /* resolves through -I$(REF)/Source/Lib/Codec */

@@ -205,6 +205,8 @@ typedef struct RefMeStageOptions {
     uint32_t zz_sad_th, phme_sad_th; uint16_t zz_sad_pct, phme_sad_pct;
     uint32_t prev_me_stage_based_exit_th, me_safe_limit_zz_th;
     uint32_t me_type_mctf, tf_me_exit_th; /* the temporal filter's form of the call */
+    uint8_t  hme_level2_off;              /* enable_hme_level2_flag = 0 (presets M7 and above, enc_mode_config.c:1636-1640) */
+    uint8_t  pad[3];
 } RefMeStageOptions;
 static MeContext *g_last_ctx; /* the context of the last ref_motion_estimation_b64 call, for ref_me_last_hme */
 void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsParams *P, const RefPicture *src, const RefPicture *refs /*[2][4]*/,
@@ -264,7 +266,7 @@ void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsPar
     ctx->quarter_b64_buffer_stride = pics[0][1].stride_y;
     ctx->sixteenth_b64_buffer = pics[0][0].buffer_y + (pics[0][0].org_y + (b64_origin_y >> 2)) * pics[0][0].stride_y + pics[0][0].org_x + (b64_origin_x >> 2);
     ctx->sixteenth_b64_buffer_stride = pics[0][0].stride_y;
-    ctx->enable_hme_flag = 1; ctx->enable_hme_level0_flag = 1; ctx->enable_hme_level1_flag = 1; ctx->enable_hme_level2_flag = 1;
+    ctx->enable_hme_flag = 1; ctx->enable_hme_level0_flag = 1; ctx->enable_hme_level1_flag = 1; ctx->enable_hme_level2_flag = !O->hme_level2_off;
     ctx->num_hme_sa_w = O->num_hme_sa_w; ctx->num_hme_sa_h = O->num_hme_sa_h;
     ctx->hme_search_method = O->hme_sub_sampled ? SUB_SAD_SEARCH : FULL_SAD_SEARCH;
     ctx->me_search_method  = O->me_sub_sad ? SUB_SAD_SEARCH : FULL_SAD_SEARCH;
@@ -319,3 +321,59 @@ void ref_me_last_hme(int16_t *sc /*[2][4][2]*/, uint32_t *sad /*[2][4]*/, uint32
     tf[0] = g_last_ctx->tf_use_pred_64x64_only_th; tf[1] = g_last_ctx->tf_tot_horz_blks; tf[2] = g_last_ctx->tf_tot_vert_blks;
 }
 
+
+/* The reference's OWN derivation of the ME settings for a picture: svt_aom_sig_deriv_me (enc_mode_config.c:681-815) run on a zeroed SequenceControlSet /
+ * PictureParentControlSet carrying the handful of inputs it reads, with the picture-level HME flags the way svt_aom_sig_deriv_multi_processes sets them
+ * (enc_mode_config.c:1630-1642: level 2 only up to M6 or for screen content).  The context fields come back in the RefMeStageOptions layout, so a test can
+ * pin "what preset 8 means at 1080p" on the reference instead of on a reading of it.  extra[0..5] = prune_ref_if_me_sad_dev_bigger_than_th,
+ * prune_me_candidates_th, enable_me_hme_ref_pruning, hme_level2 flag, hme_level1 flag, me_safe_limit_zz_th. */
+void svt_aom_sig_deriv_me(SequenceControlSet *scs, PictureParentControlSet *pcs, MeContext *me_ctx);
+void ref_sig_deriv_me(int enc_mode, int input_resolution, int qp, int sc_class1, int temporal_layer_index, int hierarchical_levels, int low_delay,
+                      RefMeStageOptions *O, int32_t *extra) {
+    SequenceControlSet      *scs = calloc(1, sizeof(*scs));
+    PictureParentControlSet *pcs = calloc(1, sizeof(*pcs));
+    MeContext               *c   = calloc(1, sizeof(*c));
+    pcs->scs = scs;
+    pcs->enc_mode = (EncMode)enc_mode; pcs->sc_class1 = (uint8_t)sc_class1; pcs->temporal_layer_index = (uint8_t)temporal_layer_index;
+    pcs->hierarchical_levels = (uint8_t)hierarchical_levels; pcs->input_resolution = (uint8_t)input_resolution;
+    scs->input_resolution = (EbInputResolution)input_resolution;
+    scs->static_config.qp = (uint32_t)qp;
+    scs->static_config.pred_structure = low_delay ? SVT_AV1_PRED_LOW_DELAY_B : SVT_AV1_PRED_RANDOM_ACCESS;
+    scs->frame_rate = 30; /* < 1 << 16: not the low-frame-rate case (enc_mode_config.c:339-343 tests frame_rate >> 16) */
+    pcs->enable_hme_flag = 1; pcs->enable_hme_level0_flag = 1; pcs->enable_hme_level1_flag = 1;
+    pcs->enable_hme_level2_flag = (sc_class1 || enc_mode <= ENC_M6) ? 1 : 0; /* enc_mode_config.c:1632-1642 */
+    svt_aom_sig_deriv_me(scs, pcs, c);
+    memset(O, 0, sizeof(*O));
+    O->num_hme_sa_w = (uint8_t)c->num_hme_sa_w; O->num_hme_sa_h = (uint8_t)c->num_hme_sa_h;
+    O->hme_sub_sampled = c->hme_search_method != FULL_SAD_SEARCH; O->me_sub_sad = c->me_search_method == SUB_SAD_SEARCH;
+    O->hme_l0_min_w = c->hme_l0_sa.sa_min.width; O->hme_l0_min_h = c->hme_l0_sa.sa_min.height; O->hme_l0_max_w = c->hme_l0_sa.sa_max.width; O->hme_l0_max_h = c->hme_l0_sa.sa_max.height;
+    O->hme_l1_w = c->hme_l1_sa.width; O->hme_l1_h = c->hme_l1_sa.height; O->hme_l2_w = c->hme_l2_sa.width; O->hme_l2_h = c->hme_l2_sa.height;
+    O->me_min_w = c->me_sa.sa_min.width; O->me_min_h = c->me_sa.sa_min.height; O->me_max_w = c->me_sa.sa_max.width; O->me_max_h = c->me_sa.sa_max.height;
+    O->mv_adj_enabled = c->mv_based_sa_adj.enabled; O->mv_adj_nearest_ref_only = c->mv_based_sa_adj.nearest_ref_only;
+    O->mv_adj_mv_size_th = c->mv_based_sa_adj.mv_size_th; O->mv_adj_sa_multiplier = c->mv_based_sa_adj.sa_multiplier;
+    O->temporal_layer_index = (uint8_t)temporal_layer_index;
+    O->me_early_exit_th = c->me_early_exit_th;
+    O->sr_adjustment = c->me_sr_adjustment_ctrls.enable_me_sr_adjustment; O->distance_based_hme_resizing = c->me_sr_adjustment_ctrls.distance_based_hme_resizing;
+    O->reduce_me_sr_based_on_mv_length_th = c->me_sr_adjustment_ctrls.reduce_me_sr_based_on_mv_length_th;
+    O->stationary_hme_sad_abs_th = c->me_sr_adjustment_ctrls.stationary_hme_sad_abs_th; O->stationary_me_sr_divisor = c->me_sr_adjustment_ctrls.stationary_me_sr_divisor;
+    O->reduce_me_sr_based_on_hme_sad_abs_th = c->me_sr_adjustment_ctrls.reduce_me_sr_based_on_hme_sad_abs_th;
+    O->me_sr_divisor_for_low_hme_sad = c->me_sr_adjustment_ctrls.me_sr_divisor_for_low_hme_sad;
+    O->me_8x8_var_enabled = c->me_8x8_var_ctrls.enabled; O->me_sr_div4_th = c->me_8x8_var_ctrls.me_sr_div4_th; O->me_sr_div2_th = c->me_8x8_var_ctrls.me_sr_div2_th;
+    O->me_sr_mult2_th = c->me_8x8_var_ctrls.me_sr_mult2_th;
+    O->hme_prune_enabled = c->me_hme_prune_ctrls.enable_me_hme_ref_pruning && c->me_hme_prune_ctrls.prune_ref_if_hme_sad_dev_bigger_than_th != (uint16_t)~0;
+    O->prune_ref_if_hme_sad_dev_bigger_than_th = c->me_hme_prune_ctrls.prune_ref_if_hme_sad_dev_bigger_than_th;
+    O->prehme_enabled = c->prehme_ctrl.enable; O->prehme_skip_search_line = c->prehme_ctrl.skip_search_line; O->prehme_l1_early_exit = c->prehme_ctrl.l1_early_exit;
+    for (int k = 0; k < 2; k++) {
+        O->prehme_sa_min_width[k] = c->prehme_ctrl.prehme_sa_cfg[k].sa_min.width; O->prehme_sa_min_height[k] = c->prehme_ctrl.prehme_sa_cfg[k].sa_min.height;
+        O->prehme_sa_max_width[k] = c->prehme_ctrl.prehme_sa_cfg[k].sa_max.width; O->prehme_sa_max_height[k] = c->prehme_ctrl.prehme_sa_cfg[k].sa_max.height;
+    }
+    O->zz_sad_th = c->me_hme_prune_ctrls.zz_sad_th; O->zz_sad_pct = (uint16_t)c->me_hme_prune_ctrls.zz_sad_pct;
+    O->phme_sad_th = c->me_hme_prune_ctrls.phme_sad_th; O->phme_sad_pct = (uint16_t)c->me_hme_prune_ctrls.phme_sad_pct;
+    O->prev_me_stage_based_exit_th = c->prev_me_stage_based_exit_th;
+    O->me_safe_limit_zz_th = c->me_safe_limit_zz_th;
+    O->hme_level2_off = !c->enable_hme_level2_flag;
+    extra[0] = c->me_hme_prune_ctrls.prune_ref_if_me_sad_dev_bigger_than_th; extra[1] = c->prune_me_candidates_th;
+    extra[2] = c->me_hme_prune_ctrls.enable_me_hme_ref_pruning; extra[3] = c->enable_hme_level2_flag; extra[4] = c->enable_hme_level1_flag;
+    extra[5] = (int32_t)c->me_safe_limit_zz_th;
+    free(c); free(pcs); free(scs);
+}

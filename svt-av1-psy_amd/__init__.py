@@ -76,6 +76,8 @@ PROTOTYPES = {
     "svt_hip_me_session_destroy": (None, [vp]),
     "svt_hip_me_session_submit": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
     "svt_hip_me_session_wait": (None, [vp, C.c_int]),
+    "svt_hip_me_session_invalidate": (None, [vp, C.c_int64]),
+    "svt_hip_me_session_resident": (C.c_int, [vp, C.c_int64]),
     "svt_hip_me_session_enable_stage": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "svt_hip_me_session_submit_stage": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, vp, vp]),
     "svt_hip_me_session_submit_results": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
@@ -270,7 +272,7 @@ class MeStageParams(C.Structure):
                 ("hme_l0_sa_width_ref", C.c_int16 * 8), ("hme_l0_sa_height_ref", C.c_int16 * 8), ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16),
                 ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16), ("stationary_me_sr_divisor", C.c_uint16),
                 ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16), ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("me_early_exit_th", C.c_uint32),
-                ("is_ref", C.c_uint8), ("me_8x8_var_enabled", C.c_uint8), ("pad1", C.c_uint8 * 2), ("me_sr_div4_th", C.c_uint32), ("me_sr_div2_th", C.c_uint32),
+                ("is_ref", C.c_uint8), ("me_8x8_var_enabled", C.c_uint8), ("hme_levels", C.c_uint8), ("pad1", C.c_uint8), ("me_sr_div4_th", C.c_uint32), ("me_sr_div2_th", C.c_uint32),
                 ("me_sr_mult2_th", C.c_uint32), ("temporal_layer_gt0", C.c_uint8), ("prehme_enabled", C.c_uint8), ("prehme_skip_search_line", C.c_uint8),
                 ("prehme_l1_early_exit", C.c_uint8), ("prehme_sa_min_width", C.c_uint16 * 2), ("prehme_sa_min_height", C.c_uint16 * 2),
                 ("prehme_sa_max_width", C.c_uint16 * 2), ("prehme_sa_max_height", C.c_uint16 * 2), ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32),
@@ -287,6 +289,67 @@ MeSbStats = np.dtype([("me_64x64_distortion", "<u4"), ("me_32x32_distortion", "<
                       ("me_8x8_cost_variance", "<u4"), ("rc_me_distortion", "<u4"), ("stationary_block_present_sb", "u1"), ("rc_me_allow_gm", "u1"),
                       ("pad", "u1", (2,))])
 assert MeSbStats.itemsize == 28
+
+
+def scaled_picture_distance(d):
+    """svt_aom_get_scaled_picture_distance (motion_estimation.c:1239-1243)."""
+    return d * 5 // 8 + (1 if d % 8 else 0)
+
+
+def m8_me_settings(qp=35, temporal_layer=1, resolution_1080p_or_above=True):
+    """What svt_aom_sig_deriv_me (enc_mode_config.c:681-815) derives for preset 8 (ENC_M8), random access, non-screen content, >= 5 hierarchical levels
+    -- restated as a dict so that bench.py and the tests use ONE table; tests/test_hme.py::test_m8_me_settings_vs_reference pins every entry against the
+    reference function itself (oracle/ref_wrap/ref_static_me.c: ref_sig_deriv_me).  Areas are modulated by the sequence QP (:203-209, :326-333)."""
+    clip = lambda lo, hi, v: max(lo, min(hi, v))  # noqa: E731
+    qw_hme = clip(500, 1000, 3 * (8 * qp - 125))            # q_mult = 3 (:166-201)
+    qw_me = clip(500, 1000, (7 * (31 * qp - 700)) >> 3)     # q_mult = 7 (:306-321)
+    me = (16, 6, 16, 9) if resolution_1080p_or_above else (16, 16, 32, 16)
+    base = temporal_layer == 0
+    return dict(
+        num_hme_sa=(2, 2), hme_levels=2,                    # enable_hme_level2_flag = 0 above M6 (enc_mode_config.c:1636-1640)
+        hme_l0=(max(8, 16 * qw_hme // 1000), max(8, 16 * qw_hme // 1000), max(96, 192 * qw_hme // 1000), max(96, 192 * qw_hme // 1000)),
+        hme_l1=(8, 3), hme_l2=(8, 3),
+        me=(max(8, me[0] * qw_me // 1000), max(3, me[1] * qw_me // 1000), max(8, me[2] * qw_me // 1000), max(3, me[3] * qw_me // 1000)),
+        sub_sampled=1,                                       # hme_search_method = me_search_method = SUB_SAD_SEARCH (:698-699)
+        prehme=dict(skip=1, l1=1, sa=((8, 100, 8, 350), (32, 7, 128, 7))),  # level 4 (:731-733, :594-603)
+        hme_prune=80 if base else 5, me_prune=0xffff if base else 60,        # ref-prune level 1 (base) / 6 (:762-763)
+        zz=(0, 0) if base else (20 * 64 * 64, 5), phme=(0, 0) if base else (10 * 64 * 64, 5),
+        sr=dict(level=1, mv_length_th=4, stationary_th=12000 // 4, stationary_div=8, low_sad_th=12000 // 4, low_sad_div=8, distance_based=1),  # level 3, / 4: no level 2 (:479-486, :510-515)
+        mv_adj=0, var=(80000, 150000, 0xffffffff),           # me_8x8_var level 2 (:533-538)
+        prune_me_candidates_th=65, me_early_exit_th=64 * 64 * 8, prev_me_stage_based_exit_th=0)
+
+
+def fill_m8_stage_params(S, dists, ref_pic_index, qp=35, temporal_layer=1, is_ref=1):
+    """SvtHipMeStageParams (search part) for preset 8 from m8_me_settings; dists = raw picture distances per reference slot (list 0 first)."""
+    m = m8_me_settings(qp, temporal_layer)
+    nw, nh = m["num_hme_sa"]
+    S.num_hme_sa_w, S.num_hme_sa_h, S.hme_sub_sampled, S.me_sub_sad, S.hme_levels = nw, nh, m["sub_sampled"], m["sub_sampled"], m["hme_levels"]
+    S.hme_l0_per_ref = 1
+    for r, (d, ri) in enumerate(zip(dists, ref_pic_index)):
+        f = scaled_picture_distance(d)
+        S.dist[r], S.ref_pic_index[r] = f, ri
+        b = [v // (1 + ri) for v in m["hme_l0"]] if m["sr"]["distance_based"] else m["hme_l0"]  # get_hme_l0_search_area (:1806-1866), non-RTC form
+        S.hme_l0_sa_width_ref[r] = min((((b[0] // nw) * f) + 15) & ~15, ((b[2] // nw) + 15) & ~15)
+        S.hme_l0_sa_height_ref[r] = min((b[1] // nh) * f, b[3] // nh)
+    S.hme_sa_width[1], S.hme_sa_height[1] = m["hme_l1"]
+    S.hme_sa_width[2], S.hme_sa_height[2] = m["hme_l2"]
+    S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = m["me"]
+    S.me_early_exit_th, S.is_ref, S.temporal_layer_gt0 = m["me_early_exit_th"], is_ref, int(temporal_layer > 0)
+    S.me_8x8_var_enabled, (S.me_sr_div4_th, S.me_sr_div2_th, S.me_sr_mult2_th) = 1, m["var"]
+    S.hme_prune_enabled, S.prune_ref_if_hme_sad_dev_bigger_than_th = 1, m["hme_prune"]
+    sr = m["sr"]
+    (S.sr_adjustment, S.reduce_me_sr_based_on_mv_length_th, S.stationary_hme_sad_abs_th, S.stationary_me_sr_divisor, S.reduce_me_sr_based_on_hme_sad_abs_th,
+     S.me_sr_divisor_for_low_hme_sad) = sr["level"], sr["mv_length_th"], sr["stationary_th"], sr["stationary_div"], sr["low_sad_th"], sr["low_sad_div"]
+    S.zz_sad_th, S.zz_sad_pct = m["zz"]
+    S.phme_sad_th, S.phme_sad_pct = m["phme"]
+    ph = m["prehme"]
+    S.prehme_enabled, S.prehme_skip_search_line, S.prehme_l1_early_exit = 1, ph["skip"], ph["l1"]
+    for k, v in enumerate(ph["sa"]):
+        S.prehme_sa_min_width[k], S.prehme_sa_min_height[k], S.prehme_sa_max_width[k], S.prehme_sa_max_height[k] = v
+    S.results.prune_ref = int(m["me_prune"] != 0xffff)
+    S.results.prune_ref_if_me_sad_dev_bigger_than_th = m["me_prune"]
+    S.results.prune_me_candidates_th = m["prune_me_candidates_th"]
+    return m
 
 
 def me_max_allocated_refs(l0, l1):

@@ -75,6 +75,12 @@ __global__ __launch_bounds__(64) void me_int_descs_kernel(const SvtHipMeIntegerS
     unsigned long long csad[8], best_all = 0xffffffffull; // slots HME never touched keep MAX_U32 (init_me_hme_data, :3061)
     for (uint32_t r = 0; r < P.n_refs && PHASE != 2; r++) {
         const uint32_t i = r * n_sb + sb;
+        if (P.list1_no_hme && r >= P.n_refs_list0) { // base layer: no HME for list 1 (:2211, :2362-2373): centre (0, 0); hmeMvSad still holds the last list-0 slot's value
+            cx[r] = 0; cy[r] = 0; csad[r] = r ? csad[r - 1] : 0ull;
+            sc_out[2 * i] = 0; sc_out[2 * i + 1] = 0; sad_out[i] = csad[r];
+            best_all = csad[r] < best_all ? csad[r] : best_all;
+            continue;
+        }
         // set_final_seach_centre_sb: first strictly smaller SAD, regions in sr_h-outer / sr_w-inner order
         const unsigned long long* ps = hme_sad + (size_t)i * P.regions;
         const int16_t*            pc = hme_sc + (size_t)i * P.regions * 2;
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256) void me_zz_sad_kernel(const SvtHipMeIntegerSea
         }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) sad += (uint32_t)__shfl_xor((int)sad, m);
-    if (l == 0) zz_out[i] = ((sad << 1) * 64u * 64u) / (bw * bh);
+    if (l == 0) zz_out[i] = (P.list1_no_hme && r >= P.n_refs_list0) ? 0xffffffffu : ((sad << 1) * 64u * 64u) / (bw * bh); // (:2390: list 1 keeps init_me_hme_data's ~0 at the base layer)
 }
 
 // upper bounds of the area the geometry above can produce (host side, for the search kernel's tile / workspace sizing)

@@ -125,6 +125,7 @@ void* svt_hip_me_session_create(uint32_t width, uint32_t height, uint32_t stride
 void svt_hip_me_session_destroy(void* session) {
     Session* s = (Session*)session;
     if (!s) return;
+    svthip::ensure_device();
     for (auto& sl : s->slots) {
         HIP_CHECK(hipStreamSynchronize(sl.st));
         HIP_CHECK(hipStreamDestroy(sl.st));
@@ -145,6 +146,7 @@ void svt_hip_me_session_destroy(void* session) {
 static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
                              uint32_t area_h, int sub_sad, uint32_t* best_sad_host, uint32_t* best_mv_host, const SvtHipMeResultsParams* fmt,
                              const SvtHipMeResultsHost* out, const SvtHipMeStageParams* stage = nullptr) {
+    svthip::ensure_device(); // an encoder worker thread that did not create the session binds to the device here
     Session* s = (Session*)session;
     if (n_refs > s->max_refs) return -2;
     if (stage && (!s->stage || n_refs > 8 || (uint32_t)stage->num_hme_sa_w * stage->num_hme_sa_h > s->max_regions ||
@@ -153,6 +155,19 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
     if (fmt && ((uint32_t)fmt->num_of_ref_pic_to_search[0] + fmt->num_of_ref_pic_to_search[1] != n_refs || n_refs == 0 || fmt->max_refs > s->max_refs ||
                 fmt->max_cand > s->max_cand))
         return -4;
+    if (stage && n_refs) { // every refusal happens here, before anything is enqueued or any session state changes
+        if (stage->sr_adjustment > 1) return -5;                                  // enable_me_sr_adjustment == 2 (screen-content levels 4 / 5): not covered
+        if (stage->hme_levels != 0 && stage->hme_levels != 2 && stage->hme_levels != 3) return -5;
+        if (stage->prehme_enabled && (stage->num_hme_sa_w != 2 || stage->num_hme_sa_h != 2)) return -5; // get_worst_quadrant is written for 2 x 2 regions
+        if ((uint32_t)stage->results.num_of_ref_pic_to_search[0] + stage->results.num_of_ref_pic_to_search[1] != n_refs) return -4;
+        SvtHipMeIntegerSearchParams V; // the fields svt_hip_me_integer_search_workspace / me_int_max_area read
+        memset(&V, 0, sizeof(V));
+        V.sbs_x = (s->width + 63) / 64; V.sbs_y = s->sbs / V.sbs_x; V.n_refs = n_refs;
+        V.sa_min_width = stage->me_sa_min_width; V.sa_min_height = stage->me_sa_min_height; V.sa_max_width = stage->me_sa_max_width; V.sa_max_height = stage->me_sa_max_height;
+        V.mv_adj_enabled = stage->mv_adj_enabled; V.mv_adj_sa_multiplier = stage->mv_adj_sa_multiplier; V.me_8x8_var_enabled = stage->me_8x8_var_enabled;
+        for (uint32_t k = 0; k < n_refs; k++) V.dist[k] = stage->dist[k];
+        if (svt_hip_me_integer_search_workspace(&V) > s->int_ws) return -5;        // areas larger than the session was sized for (variance-probe enlargement included)
+    }
     const int si = (int)s->next_slot;
     Slot&     sl = s->slots[si];
     if (sl.busy) { HIP_CHECK(hipEventSynchronize(sl.done)); sl.busy = false; } // the slot's previous picture (results already fetched or abandoned)
@@ -254,6 +269,8 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
             else HIP_CHECK(hipMemsetAsync(d_do_ref, 1, (size_t)s->sbs * 8, sl.st));
         }
         const uint8_t n_l0 = stage->results.num_of_ref_pic_to_search[0];
+        const uint8_t list1_no_hme = !stage->me_type_mctf && !stage->temporal_layer_gt0 && n_refs > n_l0; // base layer, two lists (:1983, :2055, :2127, :2211)
+        const int     hme_levels   = stage->hme_levels ? stage->hme_levels : 3;
         for (int lv = 0; lv < 3; lv++) {
             P[lv].n_refs_list0 = n_l0;
             for (uint32_t k = 0; k < n_refs; k++) P[lv].ref_pic_index[k] = stage->ref_pic_index[k];
@@ -267,6 +284,7 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
             Z.sbs_x = sbs_x; Z.sbs_y = sbs_y; Z.n_refs = n_refs; Z.aligned_width = aw; Z.aligned_height = ah;
             Z.src_off = (uint64_t)src_r * s->plane_bytes + (uint64_t)s->org_y * s->stride + s->org_x;
             Z.src_stride = s->stride; Z.ref_stride = s->stride; Z.ref_org_x = s->org_x; Z.ref_org_y = s->org_y;
+            Z.n_refs_list0 = n_l0; Z.list1_no_hme = list1_no_hme;
             for (uint32_t k = 0; k < n_refs; k++) Z.ref_off[k] = (uint64_t)ref_r[k] * s->plane_bytes;
             svt_hip_me_zz_sad_batch(&Z, s->planes, s->planes, zz, sl.st);
             if (stage->zz_sad_th && d_do_ref) svt_hip_me_ref_gate_batch(&P[2], zz, stage->zz_sad_th, stage->zz_sad_pct, stage->temporal_layer_gt0, d_do_ref, sl.st);
@@ -296,6 +314,7 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         memset(&in, 0, sizeof(in));
         in.prev_me_stage_based_exit_th = stage->prev_me_stage_based_exit_th;
         in.zz_sad = stage->me_early_exit_th ? zz : nullptr; in.do_ref = d_do_ref; in.prehme = stage->prehme_enabled ? pre : nullptr;
+        in.n_levels = (uint8_t)hme_levels; in.list1_no_hme = list1_no_hme;
         svt_hip_hme_chain_batch(P, bases, bases, &in, (uint64_t* const*)sads, scs, sl.st);
         SvtHipMeIntegerSearchParams Q;
         memset(&Q, 0, sizeof(Q));
@@ -308,7 +327,7 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         Q.src_off = (uint64_t)src_r * s->plane_bytes + (uint64_t)s->org_y * s->stride + s->org_x;
         Q.src_stride = s->stride; Q.ref_stride = s->stride; Q.ref_org_x = s->org_x; Q.ref_org_y = s->org_y;
         Q.tf_me_exit_th = stage->me_type_mctf ? stage->tf_me_exit_th : 0;
-        if (svt_hip_me_integer_search_workspace(&Q) > s->int_ws) return -5; // areas larger than the session was sized for
+        Q.list1_no_hme = list1_no_hme;
         Q.n_refs_list0 = stage->results.num_of_ref_pic_to_search[0];
         Q.hme_prune_enabled = stage->hme_prune_enabled; Q.prune_ref_if_hme_sad_dev_bigger_than_th = stage->prune_ref_if_hme_sad_dev_bigger_than_th;
         Q.sr_adjustment = stage->sr_adjustment; Q.reduce_me_sr_based_on_mv_length_th = stage->reduce_me_sr_based_on_mv_length_th;
@@ -317,7 +336,7 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         Q.me_sr_divisor_for_low_hme_sad = stage->me_sr_divisor_for_low_hme_sad; Q.me_early_exit_th = stage->me_early_exit_th;
         Q.is_ref = stage->is_ref; Q.me_8x8_var_enabled = stage->me_8x8_var_enabled; Q.me_sr_div4_th = stage->me_sr_div4_th;
         Q.me_sr_div2_th = stage->me_sr_div2_th; Q.me_sr_mult2_th = stage->me_sr_mult2_th; Q.ref_width = s->width; Q.ref_height = s->height;
-        svt_hip_me_integer_search_batch(&Q, s->planes, s->planes, (const uint64_t*)sads[2], scs[2], d_do_ref, nullptr, stage->me_early_exit_th ? zz : nullptr, sl.sad, sl.mv, fin_sc,
+        svt_hip_me_integer_search_batch(&Q, s->planes, s->planes, (const uint64_t*)sads[hme_levels - 1], scs[hme_levels - 1], d_do_ref, nullptr, stage->me_early_exit_th ? zz : nullptr, sl.sad, sl.mv, fin_sc,
                                         (uint64_t*)fin_sad, int_ws, sl.st);
         if (out && out->hme_sc) HIP_CHECK(hipMemcpyAsync(out->hme_sc, fin_sc, (size_t)n * 4, hipMemcpyDeviceToHost, sl.st));
         if (out && out->hme_sad) HIP_CHECK(hipMemcpyAsync(out->hme_sad, fin_sad, (size_t)n * 8, hipMemcpyDeviceToHost, sl.st));
@@ -359,6 +378,7 @@ int svt_hip_me_session_submit_results(void* session, int64_t pic_id, const uint8
 
 int svt_hip_me_session_enable_stage(void* session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,
                                     uint32_t max_me_area_height) {
+    svthip::ensure_device();
     Session* s = (Session*)session;
     if (s->stage || !max_regions || s->max_refs > 8) return -1;
     const uint32_t pads[2] = {quarter_pad, sixteenth_pad};
@@ -398,7 +418,22 @@ int svt_hip_me_session_submit_stage(void* session, int64_t pic_id, const uint8_t
                              fmt ? &stage->results : nullptr, out, stage);
 }
 
+// Forget a resident picture (its host content changed, e.g. after in-place temporal filtering): the next submission that names it as the source uploads it again.
+void svt_hip_me_session_invalidate(void* session, int64_t pic_id) {
+    Session* s = (Session*)session;
+    for (uint32_t r = 0; r < s->ring; r++)
+        if (s->ids[r] == pic_id) s->ids[r] = -1;
+}
+// 1 when the picture is resident in the ring (usable as a reference), else 0
+int svt_hip_me_session_resident(void* session, int64_t pic_id) {
+    Session* s = (Session*)session;
+    for (uint32_t r = 0; r < s->ring; r++)
+        if (s->ids[r] == pic_id) return 1;
+    return 0;
+}
+
 void svt_hip_me_session_wait(void* session, int slot) {
+    svthip::ensure_device();
     Session* s = (Session*)session;
     if (slot < 0 || slot >= (int)s->slots.size()) return;
     HIP_CHECK(hipEventSynchronize(s->slots[slot].done));

@@ -1,11 +1,13 @@
 // runtime.hip -- device binding, per-thread host-call context, instruction self-test.
+#include <atomic>
+
 #include "svt_hip_common.h"
 #include "../../include/svtav1_hip.h"
 
 namespace svthip {
 
-static int  g_device      = -1;
-static bool g_initialised = false;
+static std::atomic<int>  g_device{-1};
+static std::atomic<bool> g_initialised{false}; // written by svt_hip_init, read by every worker thread on first entry
 static char g_name[256]   = "uninitialised";
 
 void ensure_device() {

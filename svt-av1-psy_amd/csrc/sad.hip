@@ -734,6 +734,7 @@ struct HmeChainArgs {
     const SvtHipPrehmeResult* prehme;
     uint32_t n, prev_stage_th;
     int win_budget, src_budget;
+    int n_levels, list1_skip;
 };
 __global__ __launch_bounds__(256, 4) void hme_chain_kernel(const HmeChainArgs A) {
     HIP_DYNAMIC_SHARED(uint32_t, smem)
@@ -750,10 +751,12 @@ __global__ __launch_bounds__(256, 4) void hme_chain_kernel(const HmeChainArgs A)
     // (centre 0, SAD MAX_U32); both only at levels 0 and 1 (hme_level0_b64 :1922-1973, hme_level1_b64 :2057-2082)
     const bool zz_skip = have && A.P[0].zz_skip_th && A.zz_sad && A.zz_sad[rs] < A.P[0].zz_skip_th;
     const bool dropped = have && A.do_ref && !A.do_ref[(size_t)sb * 8 + (r < A.P[0].n_refs_list0 ? 0 : 4) + A.P[0].ref_pic_index[r]];
+    // base layer: list 1 is not searched by HME at all (:1983, :2055, :2127); uniform over the workgroup in the pre-HME form (its items share the reference)
+    if (A.list1_skip && r >= A.P[0].n_refs_list0) return;
     int16_t px = 0, py = 0;
     unsigned long long prev_lsad = 0; // the previous level's stored SAD of this item
 #pragma unroll 1
-    for (int lv = 0; lv < 3; lv++) {
+    for (int lv = 0; lv < A.n_levels; lv++) {
         const SvtHipHmeLevelParams& P = A.P[lv];
         // gates in the reference's order: zero-motion exit, (level 0) pre-HME result good enough, dropped reference, (levels 1, 2) previous level good enough
         bool gated = false;
@@ -1141,7 +1144,14 @@ void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* 
     HmeChainArgs A;
     memset(&A, 0, sizeof(A));
     int src_budget = 0, win_budget = 0;
-    for (int lv = 0; lv < 3; lv++) {
+    const int n_levels = (inputs && inputs->n_levels) ? inputs->n_levels : 3;
+    if (n_levels < 2 || n_levels > 3) {
+        fprintf(stderr, "libsvtav1_hip: svt_hip_hme_chain_batch: n_levels must be 2 or 3\n");
+        abort();
+    }
+    A.n_levels = n_levels;
+    A.list1_skip = inputs ? inputs->list1_no_hme : 0;
+    for (int lv = 0; lv < n_levels; lv++) {
         const SvtHipHmeLevelParams& P = params[lv];
         if (P.level != lv || P.n_refs != params[0].n_refs || P.sbs_x != params[0].sbs_x || P.sbs_y != params[0].sbs_y ||
             P.num_hme_sa_w != params[0].num_hme_sa_w || P.num_hme_sa_h != params[0].num_hme_sa_h || P.n_refs > 8) {

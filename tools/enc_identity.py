@@ -32,12 +32,25 @@ CASES = {
     "p8_8bit_lossless": (128, 128, 4, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
     "p8_10bit_lossless": (128, 128, 4, 10, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
     "p6_8bit_qm_lp2": (256, 144, 6, 8, ["--preset", "6", "--lp", "2", "--enable-qm", "1", "--qm-min", "2", "--qm-max", "10"]),
+    # the open-loop ME stage as ONE device call per picture (oracle/ref_wrap/me_process_seam.c): SVT_HIP_ME_SEAM=1, parameters from the reference's own
+    # svt_aom_sig_deriv_me for every picture; "+hook" = the per-call RTCD variants are installed as well
+    "seam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+seam"]),
+    "seam_p8_10bit_lp4": (448, 264, 10, 10, ["--preset", "8", "--lp", "4", "+seam"]),
+    "seam_p4_8bit_lp2": (256, 144, 8, 8, ["--preset", "4", "--lp", "2", "+seam"]),
+    "seam_p6_8bit_hook": (256, 144, 8, 8, ["--preset", "6", "--lp", "1", "+seam", "+hook"]),
+    "seam_p10_8bit": (448, 264, 10, 8, ["--preset", "10", "--lp", "1", "+seam"]),
+    "seam_p2_8bit": (256, 144, 6, 8, ["--preset", "2", "--lp", "1", "+seam"]),
+    # BASELINE.json metric, second half: encoder fps @1080p preset 8 (C-only reference vs the same encoder with the ME stage on the MI355X), all host cores
+    "fps_1080p_p8": (1920, 1080, 24, 8, ["--preset", "8", "+seam"]),
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
+    "tiny_seam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam"]),
+    "tiny_seam_p5_lp2": (128, 128, 6, 8, ["--preset", "5", "--lp", "2", "+seam"]),
     "tiny_p8_8bit": (64, 64, 3, 8, ["--preset", "8", "--lp", "1"]),
     "tiny_p8_10bit": (64, 64, 2, 10, ["--preset", "8", "--lp", "1"]),
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
-GPU_CASES = [k for k in CASES if not k.startswith("tiny_")]
+GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith("seam_")]
 
 
 def make_clip(path, w, h, n, bd, seed=7):
@@ -74,9 +87,16 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
     os.makedirs(outdir, exist_ok=True)
     clip = os.path.join(outdir, name + ".yuv")
     make_clip(clip, w, h, n, bd)
+    seam, with_hook = "+seam" in extra, "+hook" in extra
+    extra = [a for a in extra if not a.startswith("+")]
     rc, tc = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_c"), timeout=timeout)
     counts_file = os.path.join(outdir, name + "_counts.txt")
+    seam_file = os.path.join(outdir, name + "_seam.txt")
     env = {"SVT_HIP": str(device), "SVT_HIP_LIB": lib, "SVT_HIP_COUNT": counts_file}
+    if seam:
+        env.update({"SVT_HIP_ME_SEAM": "1", "SVT_HIP_ME_SEAM_STATS": seam_file})
+        if not with_hook and not only:
+            only = "-"  # no RTCD pointer matches: the seam alone
     if only:
         env["SVT_HIP_ONLY"] = only
     if skip:
@@ -84,6 +104,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
     rh, th = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_hip"), env, timeout=timeout)
     res = {"case": name, "width": w, "height": h, "frames": n, "bit_depth": bd, "args": extra, "rc_c": rc.returncode, "rc_hip": rh.returncode,
            "seconds_c": round(tc, 2), "seconds_hip": round(th, 2)}
+    for tag, r in (("c", rc), ("hip", rh)):  # the encoder's own speed line
+        for ln in (r.stdout + r.stderr).splitlines():
+            if "Average Speed" in ln:
+                res["fps_" + tag] = float(ln.split(":")[1].split()[0])
     hooked = [ln for ln in rh.stderr.splitlines() if ln.startswith("SVT_HIP:")]
     res["hook_line"] = hooked[0] if hooked else None
     if rc.returncode or rh.returncode or not hooked:
@@ -97,6 +121,11 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
         res["bytes" + ext] = len(a)
         same = same and len(a) > 0 and a == b
     res["identical"] = same
+    if seam:
+        st = dict(ln.split(None, 1) for ln in open(seam_file).read().splitlines()) if os.path.exists(seam_file) else {}
+        res["seam"] = {k: (int(v) if v.strip().isdigit() else v.strip()) for k, v in st.items()}
+        # the claim is void unless every picture really went through the device stage
+        res["identical"] = same and res["seam"].get("pictures_offloaded", 0) > 0 and res["seam"].get("pictures_declined", 1) == 0
     counts = {}
     if os.path.exists(counts_file):
         for ln in open(counts_file):
@@ -129,8 +158,11 @@ def main():
         results.append(r)
         for k, v in r.get("counts", {}).items():
             union[k] = union.get(k, 0) + v
-        print("%-20s identical=%s  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs" % (nme, r["identical"], r.get("calls"), r.get("pointers_hit"),
-                                                                                    r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"]), flush=True)
+        print("%-20s identical=%s  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs  %s" % (nme, r["identical"], r.get("calls"), r.get("pointers_hit"),
+                                                                                        r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"],
+                                                                                        r.get("seam", "")), flush=True)
+        if "fps_c" in r:
+            print("    encoder fps: C-only %.2f, with HIP %.2f" % (r["fps_c"], r.get("fps_hip", 0.0)), flush=True)
         if not r["identical"]:
             print(r.get("stderr_tail", ""))
     summary = {"all_identical": all(r["identical"] for r in results), "pointers_hit_union": len(union), "calls_total": sum(union.values()),
