@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the block-DSP hot path on MI355X (contract: see the task statement / DESIGN.md section 6).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode frames|strips]
 
-Workload at N = 1 (BASELINE.json configs[1]): batched open-loop ME integer search, 1080p 8-bit, every 64x64 SB of
-FRAMES source frames against REFS reference frames each, search area 16x9 (the preset-8 1080p maximum,
-Source/Lib/Codec/enc_mode_config.c:325-326), inputs resident in HBM.  One "step" = one launch of
-svt_hip_me_fullpel_search_batch over the whole batch.  `value` = M(SB x search position)/s, i.e. one "block" is one
-candidate position of one 64x64 SB against one reference = the 85 block SADs of SURVEY 8(d).
-N > 1: every rank processes its own batch of frames (frame-level sharding, no data-path collective) -> "weak".
+`--gpus N` with no RANK / WORLD_SIZE in the environment launches the N ranks itself (one process per GPU, RCCL rendezvous on 127.0.0.1);
+under torch.distributed.run it uses the ranks it is given.  Rank 0 prints ONE JSON line.
 
-Extra objects on the JSON line: `roofline` (dominant kernel vs the HBM roofline, algorithmic bytes of SURVEY 8(d)),
-`cpu_baseline` (the reference's own AVX2 kernels from oracle/_ref timed on the host cores, bounded sample) and
-`kernels` (the other primitives of the metric, each with its own algorithmic-bytes roofline).
+Workload at N = 1 (BASELINE.json configs[1]): batched open-loop ME integer search, 1080p 8-bit, every 64x64 SB of FRAMES source frames
+against REFS reference frames each, search area 16x9 (the preset-8 1080p maximum, Source/Lib/Codec/enc_mode_config.c:325-326; at the default
+CRF 35 the reference's QP modulation shrinks it to 8x4, see pkg.m8_me_settings), inputs resident in HBM.  One "step" = one launch of
+svt_hip_me_fullpel_search_batch over the whole batch.  `value` = M(SB x search position)/s, i.e. one "block" is one candidate position of one
+64x64 SB against one reference = the 85 block SADs of SURVEY 8(d).
+
+Multi-GPU, both measured in the same run when N > 1:
+  * --mode frames (default, `value`): every rank searches its own batch of frames -- the reference's picture-level parallelism, no data-path
+    collective, "weak" scaling;
+  * frame partition (`frame_partition` object; `value` with --mode strips): ONE picture per step cut into contiguous SB-row strips
+    (1080p: 17 rows -> 3,2,2,2,2,2,2,2 at N = 8), reference planes resident on every GPU (broadcast once, outside the timed region), every rank
+    searches its strip against all references, the per-strip 85 x (SAD, MV) tables are all-gathered over RCCL -- "strong" scaling.
+
+Before a leg is timed its output is compared with the CPU checker on a slice (oracle/ = test infrastructure, used here only as the checker
+and for the `cpu_baseline` legs); a mismatch aborts the run.  Extra objects on the JSON line: `roofline` (dominant kernel, algorithmic bytes of
+SURVEY 8(d) / event-timed kernel duration, against the 8 TB/s HBM peak and against the 6.3 TB/s copy ceiling of MI355X_MICROARCH.md),
+`cpu_baseline` (the reference's own AVX2 kernels from oracle/_ref on the host cores, bounded sample) and `kernels` (the other primitives of
+the metric and the stages around them, each with its own roofline).
 """
 import argparse
 import ctypes as C
@@ -27,7 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_CEILING_GBS = 6300.0  # measured copy ceiling (MI355X_MICROARCH.md:35,293): what a kernel that streams every byte once can reach
 QSAD_PEAK = 1024 * 2.4e9 / 22.4 * 64 * 16  # |a-b| per second if every SIMD issued nothing but v_qsad_pk_u16_u8 (16 per lane)
 W, H, PAD = 1920, 1080, 68  # luma plane padded 68 px each side (enc_handle.c:4084) -> stride 2056
 STRIDE, ROWS = W + 2 * PAD, H + 2 * PAD
@@ -171,28 +183,87 @@ def ref_libs():
     return C.CDLL(ref_path), C.CDLL(ora_path)
 
 
-def bench_sad_pairs(torch, lib, pkg, stream, a):
-    """config 1 on the GPU: 64x64 SAD of co-located SB pairs, 120 distinct planes (300 MB > the 256 MB Infinity Cache) so the
-    byte rate is an HBM rate: algorithmic bytes = 2 * 64 * 64 per block."""
-    nplanes = 120
-    planes = torch.randint(0, 256, (nplanes * PLANE,), dtype=torch.uint8, device="cuda")
-    pairs = np.zeros((nplanes - 1) * 510, dtype=pkg.SadPair)
-    i = 0
-    for f in range(nplanes - 1):
-        for sy in range(17):
-            for sx in range(30):
-                o = (PAD + sy * 64) * STRIDE + PAD + sx * 64
-                pairs[i] = (f * PLANE + o, (f + 1) * PLANE + o + 3 + 2 * STRIDE, STRIDE, STRIDE)
-                i += 1
+def roofline(bytes_alg, seconds, kernel, traffic_kernel=None, **extra):
+    """HBM roofline object of one leg: ALGORITHMIC bytes per launch / event-timed launch duration."""
+    gbs = bytes_alg / seconds / 1e9
+    tr = pmc_traffic(traffic_kernel or kernel) or {}
+    r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+         "frac_of_copy_ceiling": gbs / HBM_COPY_CEILING_GBS, "traffic": tr.get("hbm_bytes_per_launch"), "traffic_detail": tr or None,
+         "algorithmic_bytes_per_launch": bytes_alg, "kernel": kernel, "kernel_us": seconds * 1e6}
+    r.update(extra)
+    return r
+
+
+def must_equal(name, got, want):
+    """In-run parity gate: no number is recorded for a leg whose output differs from the CPU checker."""
+    if not np.array_equal(np.asarray(got), np.asarray(want)):
+        bad = np.nonzero(np.asarray(got).reshape(-1) != np.asarray(want).reshape(-1))[0]
+        sys.exit("bench.py: parity check FAILED for %s (%d mismatches, first at %s) -- no numbers recorded" % (name, bad.size, bad[:4]))
+    return int(np.asarray(want).size)
+
+
+NO_CHECK = False  # --no-parity-check: profiling passes only (the small-frame check launches would pollute per-kernel averages)
+
+
+def oracle_lib():
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    return C.CDLL(path) if os.path.exists(path) and not NO_CHECK else None
+
+
+def vp(a, off=0):
+    return C.c_void_p(a.ctypes.data + off)
+
+
+def bench_sad_pairs(torch, lib, pkg, stream, a, cpu):
+    """config 1 on the GPU: 64x64 SAD of co-located SB pairs.  DISJOINT source and reference plane sets, every plane read by exactly one launch
+    item set, so no byte is fetched twice within a launch and nothing a previous launch left in the 256 MiB Infinity Cache helps (footprint
+    1.2 GB): the byte rate is a DRAM rate.  Algorithmic bytes = 2 * 64 * 64 per block."""
+    n_src = 240
+    planes = torch.randint(0, 256, (2 * n_src * PLANE,), dtype=torch.uint8, device="cuda")
+    pairs = np.zeros(n_src * 510, dtype=pkg.SadPair)
+    o = ((PAD + np.arange(17)[:, None] * 64) * STRIDE + PAD + np.arange(30)[None, :] * 64).reshape(-1).astype(np.uint64)
+    for f in range(n_src):
+        pairs["src_off"][f * 510:(f + 1) * 510] = np.uint64(f * PLANE) + o
+        pairs["ref_off"][f * 510:(f + 1) * 510] = np.uint64((n_src + f) * PLANE + 3 + 2 * STRIDE) + o  # reference blocks sit at arbitrary byte offsets in ME
+    pairs["src_stride"] = pairs["ref_stride"] = STRIDE
     d_pairs = torch.from_numpy(pairs.view(np.uint8)).cuda()
     d_out = torch.zeros(len(pairs), dtype=torch.int32, device="cuda")
     fn = lambda: lib.svt_hip_sad_nxm_batch(planes.data_ptr(), planes.data_ptr(), d_pairs.data_ptr(), len(pairs), 64, 64, d_out.data_ptr(), stream)  # noqa: E731
+    fn()
+    torch.cuda.synchronize()
+    # parity: the first and the last plane pair against a plain |a - b| sum
+    got = d_out.cpu().numpy().view(np.uint32)
+    checked = 0
+    for f in (0, n_src - 1):
+        hs = planes[f * PLANE:(f + 1) * PLANE].cpu().numpy().reshape(ROWS, STRIDE).astype(np.int32)
+        hr = planes[(n_src + f) * PLANE:(n_src + f + 1) * PLANE].cpu().numpy().reshape(ROWS, STRIDE).astype(np.int32)
+        want = np.array([np.abs(hs[PAD + sy * 64:PAD + sy * 64 + 64, PAD + sx * 64:PAD + sx * 64 + 64] -
+                                hr[PAD + sy * 64 + 2:PAD + sy * 64 + 66, PAD + sx * 64 + 3:PAD + sx * 64 + 67]).sum() for sy in range(17) for sx in range(30)], np.uint32)
+        checked += must_equal("sad64x64_pairs", got[f * 510:(f + 1) * 510], want)
     _, dv = time_steps(torch, fn, a.steps, a.warmup)
-    gbs = len(pairs) * 8192 / (dv / a.steps) / 1e9
-    return {"value": len(pairs) / (dv / a.steps) / 1e6, "unit": "Mblocks/s (64x64 pairs)", "kernel": "sad_nxm_kernel", "footprint_MB": nplanes * PLANE / 1e6,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": (pmc_traffic("sad_nxm_kernel") or {}).get("hbm_bytes_per_launch"), "traffic_detail": pmc_traffic("sad_nxm_kernel"),
-                         "algorithmic_bytes_per_launch": len(pairs) * 8192, "algorithmic_bytes_per_block": 8192}}
+    per = dv / a.steps
+    out = {"value": len(pairs) / per / 1e6, "unit": "Mblocks/s (64x64 pairs)", "footprint_MB": 2 * n_src * PLANE / 1e6, "parity_checked_values": checked,
+           "roofline": roofline(len(pairs) * 8192, per, "sad_nxm_kernel", algorithmic_bytes_per_block=8192,
+                                note="disjoint src / ref plane sets, each byte read once per launch; footprint 1.2 GB")}
+    if cpu:
+        ref, oracle = ref_libs()
+        if ref is not None and " avx2 " in open("/proc/cpuinfo").read():
+            f = oracle.oracle_time_sad_pairs
+            f.restype = C.c_uint64
+            f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_void_p]
+            nh = 120  # host sample: 120 + 120 planes (600 MB: beyond the 256 MB of L3 an EPYC socket has), the same pair geometry
+            hp = np.concatenate([planes[:nh * PLANE].cpu().numpy(), planes[n_src * PLANE:(n_src + nh) * PLANE].cpu().numpy()])
+            hd = pairs[:nh * 510].copy()
+            hd["ref_off"] -= np.uint64((n_src - nh) * PLANE)
+            sums = np.zeros(host_cores() + 1, np.uint64)
+            for kind, sym in ((0, "svt_aom_sad64x64_avx2"), (1, "svt_nxm_sad_kernel_helper_avx2")):
+                fp = C.cast(getattr(ref, sym), C.c_void_p)
+                run = lambda i0, st, sec: f(fp, kind, hp.ctypes.data, hp.ctypes.data, hd.ctypes.data, len(hd), i0, st, sec, sums[i0:].ctypes.data)  # noqa: E731
+                rate, one, cores = cpu_pool(run, 3.0)
+                key = "cpu_baseline" if kind == 0 else "cpu_baseline_nxm_helper"
+                out[key] = {"value": rate / 1e6, "unit": "Mblocks/s (64x64 pairs)", "cores": cores, "kind": "reference", "single_thread_value": one / 1e6,
+                            "sample": "%s over 120 + 120 host planes (600 MB), same pair geometry, 3 s per leg" % sym}
+    return out
 
 
 def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
@@ -206,17 +277,74 @@ def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
     d_res, d_desc = torch.from_numpy(res).cuda(), torch.from_numpy(descs.view(np.uint8)).cuda()
     d_out = torch.zeros(n * 1024, dtype=torch.int32, device="cuda")
     fn = lambda: lib.svt_hip_fwd_txfm2d_batch(d_res.data_ptr(), d_desc.data_ptr(), n, ts, 10, 0, d_out.data_ptr(), stream)  # noqa: E731
+    fn()
+    torch.cuda.synchronize()
+    checked, oracle = 0, oracle_lib()
+    coeff = d_out.cpu().numpy()
+    if oracle is not None:
+        for b in list(range(24)) + [n - 1]:
+            want = np.zeros(1024, np.int32)
+            oracle.oracle_fwd_txfm2d(vp(res, b * 2048), vp(want), 32, 0, ts, 10, 0)
+            checked += must_equal("fwd_txfm2d_32x32", coeff[b * 1024:(b + 1) * 1024], want)
     _, dv = time_steps(torch, fn, a.steps, a.warmup)
-    gbs = n * 6144 / (dv / a.steps) / 1e9
-    out = {"value": n / (dv / a.steps) / 1e6, "unit": "Mblocks/s (32x32)", "kernel": "fwd_txfm2d_kernel<32,32>", "blocks_per_step": n,
-           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "traffic": (pmc_traffic("fwd_txfm2d_kernel<32, 32>") or {}).get("hbm_bytes_per_launch"),
-                        "traffic_detail": pmc_traffic("fwd_txfm2d_kernel<32, 32>"), "algorithmic_bytes_per_launch": n * 6144,
-                        "algorithmic_bytes_per_block": 6144, "note": "butterfly network: VALU/int32-multiply bound, not a dense contraction (DESIGN.md 4.2)"}}
+    per = dv / a.steps
+    out = {"fwd_txfm2d_32x32": {"value": n / per / 1e6, "unit": "Mblocks/s (32x32)", "blocks_per_step": n, "parity_checked_values": checked,
+                                "roofline": roofline(n * 6144, per, "fwd_txfm2d_kernel<32,32>", "fwd_txfm2d_kernel<32, 32>", algorithmic_bytes_per_block=6144,
+                                                     note="butterfly network: VALU/int32-multiply bound, not a dense contraction (DESIGN.md 4.2)")}}
+    # ---- quantize_b (high bit depth form, log_scale 1) on the coefficients just produced: 4 B in + 8 B out per coefficient
+    import bench_legs
+    qd = np.zeros(n, dtype=pkg.QuantDesc)
+    qpar = bench_legs._qparams(pkg, 88, 112, 1)
+    iscan = np.arange(1024, dtype=np.int16)
+    d_qd, d_qp, d_is = (torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1)).cuda() for x in (qd, qpar, iscan))
+    d_q, d_dq = torch.zeros(n * 1024, dtype=torch.int32, device="cuda"), torch.zeros(n * 1024, dtype=torch.int32, device="cuda")
+    d_eob = torch.zeros(n, dtype=torch.int16, device="cuda")
+    fq = lambda: lib.svt_hip_quantize_batch(1, d_out.data_ptr(), n, 1024, d_qp.data_ptr(), d_is.data_ptr(), None, None, d_qd.data_ptr(), d_q.data_ptr(),  # noqa: E731
+                                            d_dq.data_ptr(), d_eob.data_ptr(), stream)
+    fq()
+    torch.cuda.synchronize()
+    checked = 0
+    hq, hdq, heob = d_q.cpu().numpy(), d_dq.cpu().numpy(), d_eob.cpu().numpy().view(np.uint16)
+    if oracle is not None:
+        P = {k: np.ascontiguousarray(qpar[k][0]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")}
+        for b in list(range(16)) + [n - 1]:
+            q, dq, eob = np.zeros(1024, np.int32), np.zeros(1024, np.int32), C.c_uint16(0)
+            cb = np.ascontiguousarray(coeff[b * 1024:(b + 1) * 1024])
+            oracle.oracle_quantize(1, vp(cb), 1024, vp(P["zbin"]), vp(P["round"]), vp(P["quant"]), vp(P["quant_shift"]), vp(q), vp(dq), vp(P["dequant"]), C.byref(eob),
+                                   vp(iscan), None, None, 1)
+            checked += must_equal("quantize_b_32x32 qcoeff", hq[b * 1024:(b + 1) * 1024], q) + must_equal("quantize_b_32x32 dqcoeff", hdq[b * 1024:(b + 1) * 1024], dq)
+            must_equal("quantize_b_32x32 eob", [int(heob[b])], [eob.value])
+    _, dv = time_steps(torch, fq, a.steps, a.warmup)
+    per = dv / a.steps
+    out["quantize_b_32x32"] = {"value": n / per / 1e6, "unit": "Mblocks/s (32x32, highbd quantize_b, log_scale 1)", "parity_checked_values": checked,
+                               "roofline": roofline(n * (12 * 1024 + 2), per, "quant_kernel<1, false>", algorithmic_bytes_per_block=12 * 1024 + 2)}
+    # ---- inverse 32x32 + reconstruction (10-bit) from the dequantised coefficients: 4 B/coeff in + 2 B/px prediction + 2 B/px reconstruction
+    idesc = np.zeros(n, dtype=pkg.InvTxfmDesc)
+    idesc["coeff_off"] = np.arange(n, dtype=np.uint64) * 1024
+    idesc["pred_off"] = idesc["recon_off"] = np.arange(n, dtype=np.uint64) * 1024
+    idesc["pred_stride"] = idesc["recon_stride"] = 32
+    pred = g.integers(0, 1024, n * 1024).astype(np.uint16)
+    d_id, d_pred = torch.from_numpy(idesc.view(np.uint8)).cuda(), torch.from_numpy(pred.view(np.int16)).cuda()
+    d_rec = torch.zeros(n * 1024, dtype=torch.int16, device="cuda")
+    fi = lambda: lib.svt_hip_inv_txfm2d_add_batch(d_dq.data_ptr(), d_pred.data_ptr(), d_rec.data_ptr(), d_id.data_ptr(), n, ts, 10, stream)  # noqa: E731
+    fi()
+    torch.cuda.synchronize()
+    checked = 0
+    hrec = d_rec.cpu().numpy().view(np.uint16)
+    if oracle is not None:
+        for b in list(range(24)) + [n - 1]:
+            want = np.zeros(1024, np.uint16)
+            cb = np.ascontiguousarray(hdq[b * 1024:(b + 1) * 1024])
+            oracle.oracle_inv_txfm2d_add(vp(cb), vp(pred, b * 2048), 32, vp(want), 32, 0, ts, 10)
+            checked += must_equal("inv_txfm2d_add_32x32", hrec[b * 1024:(b + 1) * 1024], want)
+    _, dv = time_steps(torch, fi, a.steps, a.warmup)
+    per = dv / a.steps
+    out["inv_txfm2d_add_32x32"] = {"value": n / per / 1e6, "unit": "Mblocks/s (32x32, 10-bit)", "parity_checked_values": checked,
+                                   "roofline": roofline(n * 8192, per, "inv_txfm2d_kernel<unsigned short, 32, 32>", algorithmic_bytes_per_block=8192)}
     if cpu:
-        ref, oracle = ref_libs()
+        ref, oracle2 = ref_libs()
         if ref is not None and " avx2 " in open("/proc/cpuinfo").read():
-            f = oracle.oracle_time_fwd_txfm
+            f = oracle2.oracle_time_fwd_txfm
             f.restype = C.c_uint64
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32, C.c_double]
             fnp = C.cast(ref.svt_av1_fwd_txfm2d_32x32_avx2, C.c_void_p)
@@ -225,9 +353,10 @@ def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
             for b_in, _ in bufs:
                 b_in[:] = res[:ns * 1024]
             run = lambda i0, st, sec: f(fnp, bufs[i0][0].ctypes.data, ns, 32, 32, bufs[i0][1].ctypes.data, 0, 10, 0, 1, sec)  # noqa: E731
-            rate, one, cores = cpu_pool(run, 4.0)
-            out["cpu_baseline"] = {"value": rate / 1e6, "unit": "Mblocks/s (32x32)", "cores": cores, "kind": "reference", "single_thread_value": one / 1e6,
-                                   "sample": "svt_av1_fwd_txfm2d_32x32_avx2, 512 private blocks per thread, 4 s per leg"}
+            rate, one, cores = cpu_pool(run, 3.0)
+            out["fwd_txfm2d_32x32"]["cpu_baseline"] = {"value": rate / 1e6, "unit": "Mblocks/s (32x32)", "cores": cores, "kind": "reference",
+                                                       "single_thread_value": one / 1e6,
+                                                       "sample": "svt_av1_fwd_txfm2d_32x32_avx2, 512 private blocks per thread, 3 s per leg"}
     return out
 
 
@@ -235,40 +364,62 @@ def bench_cdef(torch, lib, pkg, stream, a, cpu):
     """config 4: CDEF over a 4K 10-bit luma plane: strength search (all 64 luma strengths) and apply (pri 4, sec 2)."""
     Wc, Hc, bd = 3840, 2160, 10
     g = np.random.default_rng(4)
-    yy, xx = np.mgrid[0:Hc, 0:Wc]
-    plane = np.clip(((xx * 2 + yy * 3) % 1024) // 2 + (((xx // 8 + yy // 8) % 5) << 5) + g.integers(-16, 17, (Hc, Wc)), 0, 1023).astype(np.uint16)
-    src = np.clip(plane.astype(np.int32) + g.integers(-6, 7, plane.shape), 0, 1023).astype(np.uint16)
-    nhfb, nvfb = Wc // 64, (Hc + 63) // 64
-    nfb = nhfb * nvfb
-    skip = np.zeros((nvfb * 8, nhfb * 8), np.uint8)
+
+    def synth(w, h):
+        yy, xx = np.mgrid[0:h, 0:w]
+        pl = np.clip(((xx * 2 + yy * 3) % 1024) // 2 + (((xx // 8 + yy // 8) % 5) << 5) + g.integers(-16, 17, (h, w)), 0, 1023).astype(np.uint16)
+        return pl, np.clip(pl.astype(np.int32) + g.integers(-6, 7, pl.shape), 0, 1023).astype(np.uint16)
     cands = [(pr, sc) for pr in range(16) for sc in (0, 1, 2, 4)]
     pri, sec = np.array([c[0] for c in cands], np.int32), np.array([c[1] for c in cands], np.int32)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1)).cuda()  # noqa: E731
-    d_pl, d_src, d_out, d_skip, d_pri, d_sec = t(plane), t(src), t(plane), t(skip), t(pri), t(sec)
-    d_dir, d_var = torch.zeros(nfb * 64, dtype=torch.uint8, device="cuda"), torch.zeros(nfb * 64, dtype=torch.int32, device="cuda")
-    d_mse = torch.zeros(nfb * 64, dtype=torch.int64, device="cuda")
-    apri, asec = t(np.full(nfb, 4, np.int32)), t(np.full(nfb, 2, np.int32))
 
-    def params(mode):
-        return pkg.CdefParams(d_pl.data_ptr(), d_src.data_ptr(), d_out.data_ptr(), Wc, Wc, Wc, Wc, Hc, 0, 0, 0, 1, bd - 8, 4, 4, 1, 64 if mode else 0,
-                              d_skip.data_ptr(), (d_pri if mode else apri).data_ptr(), (d_sec if mode else asec).data_ptr(), d_dir.data_ptr(), d_var.data_ptr(),
-                              d_mse.data_ptr())
+    def setup(w, h):
+        plane, src = synth(w, h)
+        nhfb, nvfb = (w + 63) // 64, (h + 63) // 64
+        nfb = nhfb * nvfb
+        skip = np.zeros((nvfb * 8, nhfb * 8), np.uint8)
+        D = dict(plane=plane, src=src, nfb=nfb, skip=skip, d_pl=t(plane), d_src=t(src), d_out=t(plane), d_skip=t(skip), d_pri=t(pri), d_sec=t(sec),
+                 d_dir=torch.zeros(nfb * 64, dtype=torch.uint8, device="cuda"), d_var=torch.zeros(nfb * 64, dtype=torch.int32, device="cuda"),
+                 d_mse=torch.zeros(nfb * 64, dtype=torch.int64, device="cuda"), apri=t(np.full(nfb, 4, np.int32)), asec=t(np.full(nfb, 2, np.int32)), w=w, h=h)
+        return D
+
+    def params(D, mode):
+        return pkg.CdefParams(D["d_pl"].data_ptr(), D["d_src"].data_ptr(), D["d_out"].data_ptr(), D["w"], D["w"], D["w"], D["w"], D["h"], 0, 0, 0, 1, bd - 8, 4, 4, 1,
+                              64 if mode else 0, D["d_skip"].data_ptr(), (D["d_pri"] if mode else D["apri"]).data_ptr(), (D["d_sec"] if mode else D["asec"]).data_ptr(),
+                              D["d_dir"].data_ptr(), D["d_var"].data_ptr(), D["d_mse"].data_ptr())
+    # ---- parity on a small frame (same kernels, 5 x 3 filter blocks incl. partial ones): all 64 strengths + the apply pass against the CPU checker
+    checked, oracle = 0, oracle_lib()
+    if oracle is not None:
+        S = setup(304, 168)
+        for mode in (1, 0):
+            P = params(S, mode)
+            lib.svt_hip_cdef_frame(mode, C.byref(P), stream)
+            torch.cuda.synchronize()
+            o_out, o_dir, o_var = S["plane"].copy(), np.zeros(S["nfb"] * 64, np.uint8), np.zeros(S["nfb"] * 64, np.int32)
+            o_mse = np.zeros(S["nfb"] * 64, np.uint64)
+            pr, sc = (pri, sec) if mode else (np.full(S["nfb"], 4, np.int32), np.full(S["nfb"], 2, np.int32))
+            oracle.oracle_cdef_frame(mode, vp(S["plane"]), 304, vp(S["src"]), 304, vp(o_out), 304, 304, 168, 0, 0, 0, 1, bd - 8, 4, 4, 1, vp(S["skip"]), vp(pr), vp(sc),
+                                     64 if mode else 0, vp(o_dir), vp(o_var), vp(o_mse))
+            if mode:
+                checked += must_equal("cdef search mse", S["d_mse"].cpu().numpy().view(np.uint64), o_mse) + must_equal("cdef dir", S["d_dir"].cpu().numpy(), o_dir)
+            else:
+                checked += must_equal("cdef apply", S["d_out"].cpu().numpy().view(np.uint16).reshape(168, 304), o_out)
+    D = setup(Wc, Hc)
     out = {}
     n8 = (Wc // 8) * (Hc // 8)
     for mode, name in ((1, "cdef_search_4k10_64strengths"), (0, "cdef_apply_4k10")):
-        P = params(mode)
+        P = params(D, mode)
         fn = lambda: lib.svt_hip_cdef_frame(mode, C.byref(P), stream)  # noqa: E731
-        st = max(3, a.steps // 4)
-        _, dv = time_steps(torch, fn, st, 1)
+        st = max(3, a.steps // (8 if mode else 2))
+        _, dv = time_steps(torch, fn, st, 2)
         per = dv / st
         units = n8 * (64 if mode else 1)
-        bytes_alg = Wc * Hc * 2 * (2 if mode == 0 else 2) + (nfb * 64 * 8 if mode else 0)  # apply: read + write; search: recon + source, 8 B per (fb, strength)
-        gbs = bytes_alg / per / 1e9
-        out[name] = {"value": units / per / 1e6, "unit": "M(8x8 block x strength)/s" if mode else "M(8x8 blocks)/s", "frames_per_s": 1 / per, "kernel": "cdef_frame_kernel",
-                     "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                                  "algorithmic_bytes_per_frame": bytes_alg}}
+        bytes_alg = Wc * Hc * 2 * 2 + (D["nfb"] * 64 * 8 if mode else 0)  # apply: read + write; search: recon + source, 8 B per (fb, strength)
+        out[name] = {"value": units / per / 1e6, "unit": "M(8x8 block x strength)/s" if mode else "M(8x8 blocks)/s", "frames_per_s": 1 / per,
+                     "parity_checked_values": checked,
+                     "roofline": roofline(bytes_alg, per, "cdef_frame_kernel<unsigned short, %d>" % mode, algorithmic_bytes_per_frame=bytes_alg)}
     if cpu:
-        ref, oracle = ref_libs()
+        ref, oracle2 = ref_libs()
         if ref is not None and " avx2 " in open("/proc/cpuinfo").read():
             ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))
             ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
@@ -276,47 +427,161 @@ def bench_cdef(torch, lib, pkg, stream, a, cpu):
                              ("svt_cdef_filter_block", "svt_cdef_filter_block_avx2"),
                              ("svt_cdef_filter_block_8xn_16", "svt_cdef_filter_block_8xn_16_avx2")):  # SIMD-internal pointer, NULL in a C-only setup
                 C.c_void_p.in_dll(ref, ptr).value = C.cast(getattr(ref, fnn), C.c_void_p).value  # what RTCD would select with AVX2 detected
-            f = oracle.oracle_time_cdef_apply
+            f = oracle2.oracle_time_cdef_apply
             f.restype = C.c_uint64
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_double]
             fb = C.cast(ref.svt_cdef_filter_fb, C.c_void_p)
             pl = aligned_zeros(Wc * Hc, np.uint16).reshape(Hc, Wc)  # the AVX2 kernels use aligned loads / stores
-            pl[:] = plane
+            pl[:] = D["plane"]
             cpu_out = aligned_zeros(Wc * Hc, np.uint16).reshape(Hc, Wc)
             run = lambda i0, stp, s: f(fb, pl.ctypes.data, Wc, Wc, Hc, cpu_out.ctypes.data, 4, 2, 4, 2, i0, stp, s)  # noqa: E731
-            rate, one, cores = cpu_pool(run, 4.0)
+            rate, one, cores = cpu_pool(run, 3.0)
             out["cdef_apply_4k10"]["cpu_baseline"] = {"value": rate * 64 / 1e6, "unit": "M(8x8 blocks)/s", "cores": cores, "kind": "reference",
                                                       "single_thread_value": one * 64 / 1e6,
-                                                      "sample": "svt_cdef_filter_fb + svt_cdef_filter_block_avx2 / find_dir_dual_avx2 over the same 4K plane, 4 s per leg"}
+                                                      "sample": "svt_cdef_filter_fb + svt_cdef_filter_block_avx2 / find_dir_dual_avx2 over the same 4K plane, 3 s per leg"}
     return out
+
+
+def check_lr_small(torch, lib, pkg, stream):
+    """parity of the loop-restoration frame kernel on a small 10-bit plane (Wiener / self-guided / none units mixed) before its 4K legs are timed"""
+    oracle = oracle_lib()
+    if oracle is None:
+        return 0
+    g = np.random.default_rng(9)
+    w, h, us, bd = 328, 200, 64, 10
+    yy, xx = np.mgrid[0:h, 0:w]
+    plane = np.clip(((xx * 3 + yy * 2) % 1024) // 2 + g.integers(0, 256, (h, w)), 0, 1023).astype(np.uint16)
+    nstripes = (h + 8 + 63) // 64
+    above, below = g.integers(0, 1024, (2 * nstripes, w)).astype(np.uint16), g.integers(0, 1024, (2 * nstripes, w)).astype(np.uint16)
+    nvu, nhu = max((h + us // 2) // us, 1), max((w + us // 2) // us, 1)
+    units = np.zeros(nvu * nhu, dtype=pkg.LrUnit)
+    for i in range(len(units)):
+        f = [int(g.integers(-5, 11)), int(g.integers(-23, 9)), int(g.integers(-17, 47))]
+        taps = [f[0], f[1], f[2], -2 * sum(f), f[2], f[1], f[0], 0]
+        units[i] = ((1, 2, 0)[i % 3], taps, taps, int(g.integers(0, 16)), (int(g.integers(-96, 32)), int(g.integers(-32, 96))))
+    want = np.zeros((h, w), np.uint16)
+    oracle.oracle_lr_filter_frame(vp(plane), w, vp(above), vp(below), w, vp(want), w, w, h, 0, us, vp(units), bd, 1)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1)).cuda()  # noqa: E731
+    d_pl, d_ab, d_bl, d_un = t(plane), t(above), t(below), t(units)
+    d_out = torch.zeros(h * w, dtype=torch.int16, device="cuda")
+    P = pkg.LrParams(d_pl.data_ptr(), d_ab.data_ptr(), d_bl.data_ptr(), d_out.data_ptr(), w, w, w, w, h, us, 0, 0, 1, bd, d_un.data_ptr())
+    lib.svt_hip_lr_filter_frame(C.byref(P), stream)
+    torch.cuda.synchronize()
+    return must_equal("lr_filter_frame", d_out.cpu().numpy().view(np.uint16).reshape(h, w), want)
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks here (one process per GPU), rank 0's stdout is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SVT_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.exit(max(rcs))
+
+
+def strip_rows(total_rows, rank, world):
+    """contiguous SB-row strip of `rank`: 1080p (17 rows) over 8 ranks -> 3,2,2,2,2,2,2,2"""
+    base, rem = divmod(total_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def bench_frame_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle):
+    """north_star's frame-partition case: ONE 1080p picture per step, SB-row strips across the ranks, references resident everywhere, all-gather of the tables."""
+    aw, ah = (int(v) for v in a.area.split("x"))
+    planes = synth_planes(1 + a.refs, 99)            # the same picture on every rank ...
+    d_planes = torch.from_numpy(planes.reshape(-1)).cuda()
+    if dist is not None:
+        dist.broadcast(d_planes, src=0)                # ... made so by ONE broadcast of the source + reference planes, outside the timed region
+    full = pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, aw, ah, PLANE, n_refs=a.refs, src_plane=0, ref_plane0=1)  # [ref][sb_row][sb_col]
+    sbs_x, sbs_y = (W + 63) // 64, (H + 63) // 64
+    r0, r1 = strip_rows(sbs_y, rank, world)
+    max_rows = strip_rows(sbs_y, 0, world)[1]
+    mine = np.concatenate([full[r * sbs_x * sbs_y + r0 * sbs_x:r * sbs_x * sbs_y + r1 * sbs_x] for r in range(a.refs)]) if r1 > r0 else full[:0]
+    n_mine, n_pad = len(mine), a.refs * max_rows * sbs_x
+    d_descs = torch.from_numpy(np.ascontiguousarray(mine).view(np.uint8).copy()).cuda() if n_mine else torch.zeros(32, dtype=torch.uint8, device="cuda")
+    local = torch.zeros(2 * n_pad * 85, dtype=torch.int32, device="cuda")  # [sad | mv], padded to the largest strip so that the all-gather is regular
+    gathered = torch.zeros(world * 2 * n_pad * 85, dtype=torch.int32, device="cuda")
+
+    def step():
+        if n_mine:
+            lib.svt_hip_me_fullpel_search_batch(d_planes.data_ptr(), d_planes.data_ptr(), d_descs.data_ptr(), n_mine, aw, ah, 0, local.data_ptr(),
+                                                local.data_ptr() + n_pad * 85 * 4, None, stream)
+        if dist is not None:
+            dist.all_gather_into_tensor(gathered, local)
+    step()
+    torch.cuda.synchronize()
+    checked = 0
+    if rank == 0:  # the assembled picture-wide table against the CPU checker (a sample of SBs from every strip)
+        g_all = (gathered if dist is not None else local).cpu().numpy().view(np.uint32).reshape(world if dist is not None else 1, 2, n_pad, 85)
+        if oracle is not None:
+            for rk in range(world):
+                q0, q1 = strip_rows(sbs_y, rk, world)
+                for (rf, row, col) in ((0, q0, 0), (a.refs - 1, q1 - 1, sbs_x - 1)):
+                    if q1 <= q0:
+                        continue
+                    d = full[rf * sbs_x * sbs_y + row * sbs_x + col]
+                    ws, wm = np.zeros(85, np.uint32), np.zeros(85, np.uint32)
+                    oracle.oracle_me_fullpel_search(vp(planes, int(d["src_off"])), STRIDE, vp(planes, int(d["ref_off"])), STRIDE, int(d["x_origin"]), int(d["y_origin"]), aw, ah, 0,
+                                                    vp(ws), vp(wm))
+                    k = rf * (q1 - q0) * sbs_x + (row - q0) * sbs_x + col
+                    checked += must_equal("frame partition sad", g_all[rk, 0, k], ws) + must_equal("frame partition mv", g_all[rk, 1, k], wm)
+    wall, dev = time_steps(torch, step, a.steps, a.warmup, dist)
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    n_total = len(full)
+    return {"value": n_total * aw * ah * a.steps / wall / 1e6, "unit": "Mblocks/s (whole job: one 1080p picture x %d references per step)" % a.refs, "scaling": "strong",
+            "ms_per_step": wall / a.steps * 1e3, "pictures_per_s": a.steps / wall, "strip_rows": [strip_rows(sbs_y, k, world)[1] - strip_rows(sbs_y, k, world)[0] for k in range(world)],
+            "collective": ("all_gather_into_tensor over RCCL, %d B per rank per step" % (2 * n_pad * 85 * 4)) if dist is not None else "none (1 GPU)",
+            "parity_checked_values": checked}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", choices=("frames", "strips"), default="frames", help="what `value` reports at N > 1 (both are measured)")
     ap.add_argument("--frames", type=int, default=32, help="source frames per step and per GPU")
     ap.add_argument("--refs", type=int, default=4)
     ap.add_argument("--area", type=str, default="16x9")
     ap.add_argument("--probe", action="store_true", help="print VALU issue rates and exit")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--extra", action="store_true", help="also sweep the other search areas / sub_sad (reported under kernels)")
+    ap.add_argument("--no-parity-check", action="store_true", help="profiling passes only: skip the in-run comparisons with the CPU checker")
+    ap.add_argument("--only-me", action="store_true", help="skip the per-kernel legs (profiling passes over the dominant kernel)")
+    ap.add_argument("--extra", action="store_true", help="also sweep the other search areas / sub_sad and the remaining stages (reported under kernels)")
     a = ap.parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        self_launch(a)
+    global NO_CHECK
+    NO_CHECK = a.no_parity_check
 
     import torch
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     dist = None
-    if a.gpus > 1 or world > 1:
-        import torch.distributed as dist  # RCCL; used for the barrier / max-over-ranks only: the path needs no exchange
+    if world > 1:
+        import torch.distributed as dist  # RCCL: barrier, max-over-ranks timing, and the frame-partition all-gather
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == world == a.gpus or "SVT_BENCH_CHILD" not in os.environ
     torch.cuda.set_device(local)
     pkg = entry._pkg()
     lib = pkg.load(init_device=local)
     stream = torch.cuda.current_stream().cuda_stream
     aw, ah = (int(v) for v in a.area.split("x"))
+    oracle = oracle_lib()
 
     if a.probe:
         sink = torch.zeros(4, dtype=torch.int32, device="cuda")
@@ -330,7 +595,7 @@ def main():
                   (nm, ops / dev / 1e9, 2.4e9 * 1024 * 64 / (ops / dev)))
         return
 
-    # ---------------- config 2: batched ME full-pel search -------------------------------------------------------
+    # ---------------- config 2: batched ME full-pel search, frame-sharded -----------------------------------------
     nplanes = a.frames + a.refs
     planes = synth_planes(nplanes, 1234 + rank)
     descs = np.concatenate([pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, aw, ah, PLANE, n_refs=a.refs, src_plane=f, ref_plane0=f + 1)
@@ -346,6 +611,17 @@ def main():
     def step(sub=0, w=aw, h=ah, dd=d_descs, nn=n):
         lib.svt_hip_me_fullpel_search_batch(d_planes.data_ptr(), d_planes.data_ptr(), dd.data_ptr(), nn, w, h, sub, d_sad.data_ptr(),
                                             d_mv.data_ptr(), d_ws.data_ptr() if ws_bytes else None, stream)
+    step()
+    torch.cuda.synchronize()
+    me_checked = 0
+    if oracle is not None:  # in-run parity: 64 (SB, reference) items spread over the batch against the CPU checker
+        hs, hm = d_sad.cpu().numpy().view(np.uint32).reshape(n, 85), d_mv.cpu().numpy().view(np.uint32).reshape(n, 85)
+        for i in np.linspace(0, n - 1, 64).astype(int):
+            d = descs[i]
+            ws_, wm_ = np.zeros(85, np.uint32), np.zeros(85, np.uint32)
+            oracle.oracle_me_fullpel_search(vp(planes, int(d["src_off"])), STRIDE, vp(planes, int(d["ref_off"])), STRIDE, int(d["x_origin"]), int(d["y_origin"]), aw, ah, 0,
+                                            vp(ws_), vp(wm_))
+            me_checked += must_equal("me_fullpel sad", hs[i], ws_) + must_equal("me_fullpel mv", hm[i], wm_)
     wall, dev = time_steps(torch, step, a.steps, a.warmup, dist)
     t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     if dist is not None:
@@ -356,9 +632,14 @@ def main():
     # roofline of the dominant kernel: algorithmic bytes per (SB, ref) = 64*64 + (64+W-1)(64+H-1) + 85*8
     bytes_item = 64 * 64 + (64 + aw - 1) * (64 + ah - 1) + 85 * 8
     kernel_s = dev / a.steps
-    achieved = n * bytes_item / kernel_s / 1e9
     default_workload = (a.frames, a.refs, a.area) == (32, 4, "16x9")  # the workload the committed PMC passes were run on
-    me_traffic = (pmc_traffic("me_fullpel_kernel<false>") or {}) if default_workload else {}
+    rf = roofline(n * bytes_item, kernel_s, "me_fullpel_kernel<false>", None if default_workload else "-", kernel_ms=kernel_s * 1e3,
+                  algorithmic_bytes_per_sb_ref=bytes_item,
+                  note="search is VALU(packed-SAD)-bound, see valu_frac; HBM figure = SURVEY 8(d) algorithmic bytes / time",
+                  sad_ops_per_s=n * aw * ah * 4096 / kernel_s,
+                  # measured v_qsad_pk_u16_u8 issue cost: 22.4 cycles per wave64 instruction per SIMD (profiles/r01_call1_valu_issue_rates.txt)
+                  valu_peak_sad_ops_per_s=QSAD_PEAK, valu_frac=n * aw * ah * 4096 / kernel_s / QSAD_PEAK)
+    fp = bench_frame_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle)
     out = {
         "metric": "Mblocks/s per kernel (SAD, FwdTxfm2d, CDEF) + encoder fps @1080p preset 8", "value": value,
         "unit": "Mblocks/s (block = one search position of one 64x64 SB vs one reference = 85 block SADs)",
@@ -366,20 +647,27 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "configs[1]: batched open-loop ME integer full-pel search (SAD 8x8..64x64), 1080p 8-bit, all 64x64 SBs",
                    "frames_per_step_per_gpu": a.frames, "refs": a.refs, "search_area": a.area, "sb_refs_per_step_per_gpu": n,
-                   "sub_sad": 0, "parallelism": "frame-sharded x%d (no collective)" % world},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": me_traffic.get("hbm_bytes_per_launch"), "traffic_detail": me_traffic or None,
-                     "algorithmic_bytes_per_launch": n * bytes_item, "kernel": "me_fullpel_kernel<false>", "kernel_ms": kernel_s * 1e3,
-                     "algorithmic_bytes_per_sb_ref": bytes_item,
-                     "note": "search is VALU(packed-SAD)-bound, see sad_ops; HBM figure = SURVEY 8(d) algorithmic bytes / time",
-                     "sad_ops_per_s": n * aw * ah * 4096 / kernel_s,
-                     # measured v_qsad_pk_u16_u8 issue cost: 22.4 cycles per wave64 instruction per SIMD (profiles/r01_call1_valu_issue_rates.txt)
-                     "valu_peak_sad_ops_per_s": QSAD_PEAK, "valu_frac": n * aw * ah * 4096 / kernel_s / QSAD_PEAK},
+                   "sub_sad": 0, "parallelism": "frame-sharded x%d (no collective)" % world, "mode": a.mode},
+        "parity_checked_values": me_checked, "roofline": rf, "frame_partition": fp,
     }
+    if a.mode == "strips":  # report the frame-partition figure as the headline instead
+        out.update({"value": fp["value"], "ms_per_step": fp["ms_per_step"], "scaling": "strong"})
+        out["config"]["parallelism"] = "SB-row strips of one picture x%d + RCCL all-gather" % world
+        out["frames_mode_value"] = value
     kernels = {}
-    kernels["sad64x64_pairs"] = bench_sad_pairs(torch, lib, pkg, stream, a)
-    kernels["fwd_txfm2d_32x32"] = bench_fwd_txfm(torch, lib, pkg, stream, a, cpu=(rank == 0 and world == 1 and not a.no_cpu))
-    kernels.update(bench_cdef(torch, lib, pkg, stream, a, cpu=(rank == 0 and world == 1 and not a.no_cpu)))
+    cpu = rank == 0 and world == 1 and not a.no_cpu
+    if not a.only_me:
+        kernels["sad64x64_pairs"] = bench_sad_pairs(torch, lib, pkg, stream, a, cpu)
+        kernels.update(bench_fwd_txfm(torch, lib, pkg, stream, a, cpu))
+        kernels.update(bench_cdef(torch, lib, pkg, stream, a, cpu))
+        import bench_legs
+        lr_checked = check_lr_small(torch, lib, pkg, stream)
+        lr = bench_legs.lr_frames(torch, lib, pkg, stream, max(a.steps // 10, 4), 2)
+        for v in lr.values():
+            v["parity_checked_values"] = lr_checked
+        kernels.update(lr)
+        kernels.update(bench_legs.hme_chain(torch, lib, pkg, stream, max(a.steps // 4, 8), 2))
+        kernels.update(bench_legs.me_session_stage(torch, lib, pkg, stream, 12, 1))
     if a.extra:
         for (w2, h2, sub) in [(16, 9, 1), (64, 32, 0), (256, 256, 0)]:
             nf = a.frames if w2 < 64 else (4 if w2 < 256 else 1)
@@ -398,32 +686,31 @@ def main():
             ws2 = torch.zeros(max(wsb, 8), dtype=torch.uint8, device="cuda")
             f2 = lambda: lib.svt_hip_me_fullpel_search_batch(d_planes.data_ptr(), d_planes.data_ptr(), tdd.data_ptr(), len(dd), w2, h2, sub,  # noqa: E731
                                                              d_sad.data_ptr(), d_mv.data_ptr(), ws2.data_ptr() if wsb else None, stream)
-            st = a.steps if w2 < 64 else 2
+            st = min(a.steps, 40) if w2 < 64 else 2
             _, dv = time_steps(torch, f2, st, 1)
             kernels["me_search_%dx%d_sub%d" % (w2, h2, sub)] = {"value": len(dd) * w2 * h2 / (dv / st) / 1e6, "unit": "Mblocks/s",
                                                                "sb_refs": len(dd), "sad_ops_per_s": len(dd) * w2 * h2 * (2048 if sub else 4096) / (dv / st)}
         import bench_legs
-        kernels.update(bench_legs.hme_sad_loop(torch, lib, pkg, stream, a.steps, a.warmup))
-        kernels.update(bench_legs.lr_frames(torch, lib, pkg, stream, max(a.steps // 2, 2), 2))
-        kernels.update(bench_legs.picprep(torch, lib, pkg, stream, max(a.steps // 2, 2), 1))
-        kernels.update(bench_legs.deblock(torch, lib, pkg, stream, max(a.steps // 2, 2), 1))
-        kernels.update(bench_legs.lr_stats(torch, lib, pkg, stream, max(a.steps // 2, 2), 1))
-        kernels.update(bench_legs.cdef_chain(torch, lib, pkg, stream, max(a.steps // 4, 2), 1))
-        kernels.update(bench_legs.me_session(torch, lib, pkg, stream, a.steps, 1))
-        kernels.update(bench_legs.me_results(torch, lib, pkg, stream, a.steps, 1))
-        kernels.update(bench_legs.hme_chain(torch, lib, pkg, stream, a.steps, 1))
-        kernels.update(bench_legs.me_stage(torch, lib, pkg, stream, a.steps, 1))
-        kernels.update(bench_legs.me_session_stage(torch, lib, pkg, stream, a.steps, 1))
-        kernels.update(bench_legs.tf_frames(torch, lib, pkg, stream, a.steps, 1))
-        kernels["txfm_quant_roundtrip"] = bench_legs.txfm_roundtrip(torch, lib, pkg, stream, max(a.steps // 4, 3), 1)
+        es = min(a.steps, 20)
+        kernels.update(bench_legs.hme_sad_loop(torch, lib, pkg, stream, es, 3))
+        kernels.update(bench_legs.picprep(torch, lib, pkg, stream, max(es // 2, 2), 1))
+        kernels.update(bench_legs.deblock(torch, lib, pkg, stream, max(es // 2, 2), 1))
+        kernels.update(bench_legs.lr_stats(torch, lib, pkg, stream, max(es // 2, 2), 1))
+        kernels.update(bench_legs.cdef_chain(torch, lib, pkg, stream, max(es // 4, 2), 1))
+        kernels.update(bench_legs.me_session(torch, lib, pkg, stream, es, 1))
+        kernels.update(bench_legs.me_results(torch, lib, pkg, stream, es, 1))
+        kernels.update(bench_legs.me_stage(torch, lib, pkg, stream, es, 1))
+        kernels.update(bench_legs.tf_frames(torch, lib, pkg, stream, es, 1))
+        kernels["txfm_quant_roundtrip"] = bench_legs.txfm_roundtrip(torch, lib, pkg, stream, max(es // 4, 3), 1)
     out["kernels"] = kernels
-    if rank == 0 and world == 1 and not a.no_cpu:
+    if cpu:
         host_descs = pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, aw, ah, PLANE, n_refs=1, src_plane=0, ref_plane0=1)
-        out["cpu_baseline"] = cpu_me_baseline(host_descs, planes, planes, (aw, ah))
+        out["cpu_baseline"] = cpu_me_baseline(host_descs, planes, planes, (aw, ah), budget_s=10.0)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

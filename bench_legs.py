@@ -647,33 +647,6 @@ def me_stage(torch, lib, pkg, stream, steps, warmup):
                                      "note": "decimate x2, HME L0-L2 (one fused launch), final centre + integer search (8x3..16x9), MeSbResults: device-resident chain"}}
 
 
-def _preset8_stage_params(pkg, S, dist):
-    """ME / HME settings of preset 8 at 1080p (enc_mode_config.c:138-216, 296-335, 542-590, 418-426, 479-486, 533-536, 795-818), default QP scaling left out"""
-    def sd(d):  # svt_aom_get_scaled_picture_distance
-        return d * 5 // 8 + (1 if d % 8 else 0)
-    S.num_hme_sa_w, S.num_hme_sa_h, S.hme_sub_sampled, S.me_sub_sad = 2, 2, 1, 1
-    S.hme_l0_per_ref = 1
-    for r, d in enumerate(dist):
-        f = sd(d)
-        S.dist[r] = f
-        S.hme_l0_sa_width_ref[r] = min((((16 // 2) * f) + 15) & ~15, ((192 // 2) + 15) & ~15)
-        S.hme_l0_sa_height_ref[r] = min((16 // 2) * f, 192 // 2)
-    for lv in (1, 2):
-        S.hme_sa_width[lv], S.hme_sa_height[lv] = 8, 3
-    S.hme_sa_width[0], S.hme_sa_height[0] = 96, 96
-    S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = 16, 6, 16, 9
-    S.me_early_exit_th = 64 * 64 * 8
-    S.is_ref, S.temporal_layer_gt0 = 1, 1
-    S.me_8x8_var_enabled, S.me_sr_div4_th, S.me_sr_div2_th, S.me_sr_mult2_th = 1, 80000, 150000, 0xffffffff
-    S.hme_prune_enabled, S.prune_ref_if_hme_sad_dev_bigger_than_th = 1, 5
-    (S.sr_adjustment, S.reduce_me_sr_based_on_mv_length_th, S.stationary_hme_sad_abs_th, S.stationary_me_sr_divisor, S.reduce_me_sr_based_on_hme_sad_abs_th,
-     S.me_sr_divisor_for_low_hme_sad) = 1, 4, 12000, 8, 12000, 8
-    S.zz_sad_th, S.zz_sad_pct, S.phme_sad_th, S.phme_sad_pct = 20 * 64 * 64, 5, 10 * 64 * 64, 5
-    S.prehme_enabled, S.prehme_skip_search_line, S.prehme_l1_early_exit = 1, 1, 1
-    for k, v in enumerate(((8, 100, 8, 350), (32, 7, 128, 7))):
-        S.prehme_sa_min_width[k], S.prehme_sa_min_height[k], S.prehme_sa_max_width[k], S.prehme_sa_max_height[k] = v
-
-
 def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=48, slots=None):
     """PCIe-inclusive WHOLE ME stage from pinned host pictures: upload once, quarter / sixteenth planes on the device, HME levels 0-2, final centre +
     integer search, MeSbResults returned to pinned host memory; 4 references (2 + 2), two submissions in flight."""
@@ -695,10 +668,7 @@ def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=48, slots=Non
     S.me_sa_min_width, S.me_sa_min_height, S.me_sa_max_width, S.me_sa_max_height = 8, 3, 16, 9
     for r in range(4):
         S.dist[r], S.ref_pic_index[r] = 1 + r, r % 2
-    S8 = pkg.MeStageParams()
-    for r in range(4):
-        S8.ref_pic_index[r] = r % 2
-    _preset8_stage_params(pkg, S8, [1, 2, 1, 2])
+    S8 = pkg.MeStageParams()  # what the reference's svt_aom_sig_deriv_me gives for preset 8 at 1080p, CRF 35 (pkg.m8_me_settings, pinned in tests/test_hme.py)
     R = S.results
     R.num_of_list_to_search = 2
     R.num_of_ref_pic_to_search[0], R.num_of_ref_pic_to_search[1] = 2, 2
@@ -712,6 +682,7 @@ def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=48, slots=Non
         hosts.append((b, pkg.MeResultsHost(None, b[0], b[1], b[2], b[3], None, None)))
 
     C.memmove(C.addressof(S8.results), C.addressof(R), C.sizeof(R))
+    m8 = pkg.fill_m8_stage_params(S8, [1, 2, 1, 2], [0, 1, 0, 1], qp=35, temporal_layer=1)
 
     sub = [0.0]
 
@@ -751,6 +722,8 @@ def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=48, slots=Non
                                             "d2h_MB_per_picture": sum(sizes) / 1e6,
                                             "note": "decimation + HME 0-2 + integer search + MeSbResults per picture, 4 references, PCIe inclusive"},
             "me_session_stage_1080p_host_preset8": {"pictures_per_s": npics / t8, "us_per_picture": t8 / npics * 1e6, "host_submit_us_per_picture": hs8 / npics * 1e6,
-                                                    "note": "preset-8 ME settings: zero-motion gating, pre-HME (8x100..350 / 32..128x7), per-reference HME level-0 areas, "
-                                                            "HME pruning + search-range divisors, check_00_center, 8x8-variance probe, sub-sampled SADs; synthetic noise "
-                                                            "pictures, so no early exit fires"}}
+                                                    "settings": {k: v for k, v in m8.items() if k in ("hme_levels", "hme_l0", "me", "hme_prune", "zz")},
+                                                    "note": "the reference's own preset-8 derivation (svt_aom_sig_deriv_me at ENC_M8, 1080p, CRF 35): HME levels 0-1 only, "
+                                                            "zero-motion gating, pre-HME (8x100..350 / 32..128x7), level-0 areas by reference index, HME pruning + "
+                                                            "search-range divisors, 8x8-variance probe, sub-sampled SADs, ME area 8x3..8x4; synthetic noise pictures, so "
+                                                            "no early exit fires"}}

@@ -135,3 +135,21 @@ uint64_t oracle_time_cdef_apply(CdefFilterFbFn fb, const uint16_t *plane, int st
             if (now_s() >= t_end) { free(tile); return done; }
         }
 }
+
+/* 64x64 SAD of (src, ref) plane pairs through a reference kernel, for bench.py's `sad64x64_pairs` cpu_baseline leg: pairs idx0, idx0 + step, ... of the
+ * descriptor list (byte offsets + strides, = SvtHipSadPair) until `seconds` elapse.  kind 0: fn(src, stride, ref, stride) -- svt_aom_sad64x64_avx2
+ * (aom_dsp_rtcd.h:335); kind 1: fn(src, stride, ref, stride, h, w) -- svt_nxm_sad_kernel_helper_avx2 (the svt_nxm_sad_kernel variant). */
+typedef struct { uint64_t src_off, ref_off; uint32_t src_stride, ref_stride; } OracleSadPair;
+typedef uint32_t (*Sad4Fn)(const uint8_t *, int, const uint8_t *, int);
+typedef uint32_t (*Sad6Fn)(const uint8_t *, uint32_t, const uint8_t *, uint32_t, uint32_t, uint32_t);
+uint64_t oracle_time_sad_pairs(void *fn, int kind, const uint8_t *src_base, const uint8_t *ref_base, const OracleSadPair *d, uint32_t n, uint32_t idx0, uint32_t step,
+                               double seconds, uint64_t *checksum) {
+    uint64_t     done = 0, sum = 0;
+    const double t_end = now_s() + seconds;
+    for (;;)
+        for (uint32_t i = idx0; i < n; i += step) {
+            sum += kind ? ((Sad6Fn)fn)(src_base + d[i].src_off, d[i].src_stride, ref_base + d[i].ref_off, d[i].ref_stride, 64, 64)
+                        : ((Sad4Fn)fn)(src_base + d[i].src_off, (int)d[i].src_stride, ref_base + d[i].ref_off, (int)d[i].ref_stride);
+            if ((++done & 255) == 0 && now_s() >= t_end) { *checksum = sum; return done; }
+        }
+}

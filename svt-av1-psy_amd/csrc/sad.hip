@@ -27,6 +27,7 @@ constexpr uint32_t MAX_SAD_VALUE = 128 * 128 * 255; // motion_estimation.h:85
 constexpr int      ME_TW         = 64;              // search tile, positions
 constexpr int      ME_TH         = 32;
 constexpr int      KEY_POS_BITS  = 11; // tile raster index: yl * 64 + xl < 2048
+constexpr uint32_t ME_WAVE_MAX_W = 24, ME_WAVE_MAX_H = 16; // areas up to this size take the one-wave-per-item kernel
 
 // ---- helpers -------------------------------------------------------------------------------------------------
 // Copy rows x width bytes (arbitrary global alignment / stride) into LDS rows of pitch_dw dwords, zero padded.
@@ -161,6 +162,16 @@ __device__ __forceinline__ void stage_rows_wide_any(uint32_t* lds, int pitch_dw,
     else if (total - base > 0) stage_rows_wide_step<NT, 1>(lds, pitch_dw, g, gstride, width, total, cpr, dr, dc, base, tid, r, c);
 }
 
+// the same with the chunks per row given by the caller (= ceil(width / 16) <= (pitch_dw + 3) / 4): no dead chunks for windows narrower than the LDS pitch
+template <int NT>
+__device__ __forceinline__ void stage_rows_wide_cpr(uint32_t* lds, int pitch_dw, const uint8_t* g, uint32_t gstride, int width, int rows, int cpr, int tid) {
+    const int total = rows * cpr, dr = NT / cpr, dc = NT - dr * cpr;
+    int       r = tid / cpr, c = tid - r * cpr, base = 0;
+    for (; total - base > 2 * NT; base += 4 * NT) stage_rows_wide_step<NT, 4>(lds, pitch_dw, g, gstride, width, total, cpr, dr, dc, base, tid, r, c);
+    if (total - base > NT) stage_rows_wide_step<NT, 2>(lds, pitch_dw, g, gstride, width, total, cpr, dr, dc, base, tid, r, c);
+    else if (total - base > 0) stage_rows_wide_step<NT, 1>(lds, pitch_dw, g, gstride, width, total, cpr, dr, dc, base, tid, r, c);
+}
+
 __device__ __forceinline__ uint32_t dpp_add_quad_xor1(uint32_t v) {
     return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
 }
@@ -190,16 +201,16 @@ constexpr int ME_PITCH = 34; // window row pitch in dwords: >= 17 + 64 / 4, even
 // All strips of one wave. keys: 8x8 -> (sad16 << 16) | pos   (one v_lshl_or / v_and_or per position, straight from the packed u16 lanes)
 //                               16x16/32x32/64x64 -> (sad << 11) | pos   (sad64 < 2^20, pos < 2^11)
 // FULL: the tile width is a multiple of 4, no strip has invalid positions.
-template <bool SUB, bool FULL>
-__device__ __forceinline__ void me_search_strips(const uint32_t* __restrict__ win, const uint32_t (&s)[8][2], int Wt, int Ht, int wv, int l,
+template <bool SUB, bool FULL, int PITCH = ME_PITCH>
+__device__ __forceinline__ void me_search_strips(const uint32_t* __restrict__ win, const uint32_t (&s)[8][2], int Wt, int Ht, int g0, int gstep, int l,
                                                  uint32_t& best8, uint32_t& best16, uint32_t& best32, uint32_t& best64) {
     const int bx = (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4);
     const int by = ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4);
     const int q  = l & 3;
     const int      G    = (Wt + 3) >> 2;
     const uint32_t qsel = 0x0c0c0100u + 0x0202u * (uint32_t)q; // v_perm_b32 selector: u16 number q of {thi:tlo}, zero extended
-    for (int g = wv; g < G; g += 4) {
-        const uint32_t* colp   = win + (by * 8) * ME_PITCH + bx * 2 + g;
+    for (int g = g0; g < G; g += gstep) {
+        const uint32_t* colp   = win + (by * 8) * PITCH + bx * 2 + g;
         const int       nvalid = (Wt - 4 * g) < 4 ? (Wt - 4 * g) : 4;
         // invalid positions (last strip when Wt % 4 != 0) are pushed to the top of the key space
         const uint32_t inv1 = nvalid > 1 ? 0u : 0xffffffffu, inv2 = nvalid > 2 ? 0u : 0xffffffffu, inv3 = nvalid > 3 ? 0u : 0xffffffffu;
@@ -208,17 +219,17 @@ __device__ __forceinline__ void me_search_strips(const uint32_t* __restrict__ wi
         U64A4 ra[8], rb[8];
 #pragma unroll
         for (int r = 0; r < 7; r++) {
-            ra[r] = *(const U64A4*)(colp + r * ME_PITCH);
-            rb[r] = *(const U64A4*)(colp + r * ME_PITCH + 1);
+            ra[r] = *(const U64A4*)(colp + r * PITCH);
+            rb[r] = *(const U64A4*)(colp + r * PITCH + 1);
         }
         uint32_t pos = (uint32_t)(4 * g), posq = (uint32_t)(4 * g + q);
         for (int yb = 0; yb < Ht; yb += 8) {
-            const uint32_t* rowp = colp + (yb + 7) * ME_PITCH;
+            const uint32_t* rowp = colp + (yb + 7) * PITCH;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 if (yb + i < Ht) {
-                    ra[(i + 7) & 7] = *(const U64A4*)(rowp + i * ME_PITCH);
-                    rb[(i + 7) & 7] = *(const U64A4*)(rowp + i * ME_PITCH + 1);
+                    ra[(i + 7) & 7] = *(const U64A4*)(rowp + i * PITCH);
+                    rb[(i + 7) & 7] = *(const U64A4*)(rowp + i * PITCH + 1);
                     unsigned long long acc = 0;
 #pragma unroll
                     for (int r = 0; r < 8; r += (SUB ? 2 : 1)) {
@@ -309,8 +320,8 @@ __global__ __launch_bounds__(256, 4) void me_fullpel_kernel(const uint8_t* __res
         }
     }
     uint32_t best8 = 0xffffffffu, best16 = 0xffffffffu, best32 = 0xffffffffu, best64 = 0xffffffffu;
-    if ((Wt & 3) == 0) me_search_strips<SUB, true>(win, s, Wt, Ht, wv, l, best8, best16, best32, best64);
-    else me_search_strips<SUB, false>(win, s, Wt, Ht, wv, l, best8, best16, best32, best64);
+    if ((Wt & 3) == 0) me_search_strips<SUB, true>(win, s, Wt, Ht, wv, 4, l, best8, best16, best32, best64);
+    else me_search_strips<SUB, false>(win, s, Wt, Ht, wv, 4, l, best8, best16, best32, best64);
 
     atomicMin(&best_lds[21 + l], best8);
     atomicMin(&best_lds[5 + (l >> 2)], best16);
@@ -330,6 +341,72 @@ __global__ __launch_bounds__(256, 4) void me_fullpel_kernel(const uint8_t* __res
             atomicMin(&keys[o], ((unsigned long long)sad << 32) | (unsigned long long)(uint32_t)(Y * W + X));
         }
     }
+}
+
+// ---- the same search with ONE WAVE per (SB, reference) item, for the small areas of the fast presets (16x9 is the preset-8 maximum at 1080p, 8x4 what
+// CRF 35 leaves of it; enc_mode_config.c:311-333).  With four cooperating waves per item the fixed work around the search -- staging the source block and the
+// window through LDS, two workgroup barriers, LDS atomics to merge the waves -- was ~230 VALU instructions per wave against 9 search steps (25 % of the kernel
+// at 16x9).  Here a wave owns its item: the lane's 8x8 source block comes straight from global memory into its 16 VGPRs (eight 8-byte
+// loads), the window goes into the wave's private LDS slice (no workgroup barrier: LDS program order within a wave is enough), the wave walks ALL strips of
+// the area, and the 16x16 / 32x32 / 64x64 winners are merged with DPP / row-swap minima instead of LDS atomics.  Same keys, same tie-breaks (first minimum in
+// raster order = smallest (sad, position) key), bit-identical tables.
+struct __attribute__((packed, aligned(1))) u32x2_a1 { uint32_t x, y; };
+__device__ __forceinline__ uint32_t dpp_min_quad_xor1(uint32_t v) { return umin32(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xf, 0xf, false)); }
+__device__ __forceinline__ uint32_t dpp_min_quad_xor2(uint32_t v) { return umin32(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xf, 0xf, false)); }
+__device__ __forceinline__ uint32_t dpp_min_row_ror4(uint32_t v) { return umin32(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x124, 0xf, 0xf, false)); }
+__device__ __forceinline__ uint32_t dpp_min_row_ror8(uint32_t v) { return umin32(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x128, 0xf, 0xf, false)); }
+
+template <bool SUB, int PITCH>
+__global__ __launch_bounds__(256) void me_fullpel_wave_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                              const SvtHipMeSearchDesc* __restrict__ descs, const uint32_t n, const int win_dw,
+                                                              uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv) {
+    HIP_DYNAMIC_SHARED(uint32_t, smem)
+    const int      l    = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x) * 4 + (uint32_t)wv; // four consecutive items (neighbouring SBs of one reference) per workgroup
+    if (item >= n) return;
+    const SvtHipMeSearchDesc d = descs[item];
+    const int    W = d.search_area_width, H = d.search_area_height;
+    const size_t o = (size_t)item * SVT_HIP_ME_NUM_BLOCKS;
+    if (W <= 0 || H <= 0) { // an empty search area reports "nothing found"
+        for (int k = l; k < SVT_HIP_ME_NUM_BLOCKS; k += 64) { best_sad[o + k] = MAX_SAD_VALUE; best_mv[o + k] = 0; }
+        return;
+    }
+    uint32_t* win = smem + wv * win_dw;
+    const int bx = (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4);
+    const int by = ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4);
+    uint32_t  s[8][2];
+    {
+        const uint8_t* sp = src_base + d.src_off + (size_t)(by * 8) * d.src_stride + bx * 8;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const u32x2_a1 t = *(const u32x2_a1*)(sp + (size_t)r * d.src_stride);
+            s[r][0] = t.x; s[r][1] = t.y;
+        }
+    }
+    const int width = 64 + W - 1;
+    stage_rows_wide_cpr<64>(win, PITCH, ref_base + d.ref_off, d.ref_stride, width, 64 + H - 1, (width + 15) >> 4, l);
+    __builtin_amdgcn_wave_barrier(); // the slice belongs to this wave alone: LDS program order is enough on the hardware
+
+    uint32_t best8 = 0xffffffffu, best16 = 0xffffffffu, best32 = 0xffffffffu, best64 = 0xffffffffu;
+    if ((W & 3) == 0) me_search_strips<SUB, true, PITCH>(win, s, W, H, 0, 1, l, best8, best16, best32, best64);
+    else me_search_strips<SUB, false, PITCH>(win, s, W, H, 0, 1, l, best8, best16, best32, best64);
+    // lane q of a quad tracked position q of every strip: the block's winner is the smallest key of the lanes that share the block
+    best16 = dpp_min_quad_xor2(dpp_min_quad_xor1(best16));
+    best32 = dpp_min_row_ror8(dpp_min_row_ror4(dpp_min_quad_xor2(dpp_min_quad_xor1(best32))));
+    best64 = dpp_min_row_ror8(dpp_min_row_ror4(dpp_min_quad_xor2(dpp_min_quad_xor1(best64))));
+    best64 = umin32(best64, (uint32_t)__shfl_xor((int)best64, 16));
+    best64 = umin32(best64, (uint32_t)__shfl_xor((int)best64, 32));
+    const int xo = d.x_search_area_origin, yo = d.y_search_area_origin;
+    auto emit = [&](const int idx, const uint32_t key, const bool is8) {
+        const uint32_t sad = is8 ? (key >> 16) : (key >> KEY_POS_BITS);
+        const int      X = (int)(key & 63u), Y = (int)((key >> 6) & 31u);
+        best_sad[o + idx] = sad;
+        best_mv[o + idx]  = ((uint32_t)(uint16_t)(Y + yo) << 16) | (uint16_t)(X + xo);
+    };
+    emit(21 + l, best8, true);
+    if ((l & 3) == 0) emit(5 + (l >> 2), best16, false);
+    if ((l & 15) == 0) emit(1 + (l >> 4), best32, false);
+    if (l == 0) emit(0, best64, false);
 }
 
 __global__ void me_finalize_kernel(const SvtHipMeSearchDesc* __restrict__ descs, uint32_t n, const unsigned long long* __restrict__ keys,
@@ -1251,6 +1328,19 @@ void svt_hip_me_fullpel_search_batch(const uint8_t* src_base, const uint8_t* ref
     if (n == 0) return;
     if (max_w == 0) max_w = 1;
     if (max_h == 0) max_h = 1;
+    if (max_w <= ME_WAVE_MAX_W && max_h <= ME_WAVE_MAX_H) { // small areas: one wave per item (see me_fullpel_wave_kernel)
+        const int    G = (int)(max_w + 3) >> 2, pitch = 16 + G <= 18 ? 18 : 26; // dwords a ring load may touch: 16 + G; pitch = 2 mod 8 (bank spread of the 8 x 8 block grid)
+        const int    win_dw = pitch * (64 + (int)max_h - 1);
+        const size_t shm    = (size_t)4 * win_dw * 4;
+        const dim3   grid((n + 3) / 4);
+        hipStream_t  st = (hipStream_t)stream;
+#define ME_WAVE_LAUNCH(SUBV, PITCHV) hipLaunchKernelGGL(HIP_KERNEL_NAME(me_fullpel_wave_kernel<SUBV, PITCHV>), grid, dim3(256), shm, st, src_base, ref_base, descs, n, win_dw, best_sad, best_mv)
+        if (pitch == 18) { if (sub_sad) ME_WAVE_LAUNCH(true, 18); else ME_WAVE_LAUNCH(false, 18); }
+        else             { if (sub_sad) ME_WAVE_LAUNCH(true, 26); else ME_WAVE_LAUNCH(false, 26); }
+#undef ME_WAVE_LAUNCH
+        SVT_LAUNCH_CHECK();
+        return;
+    }
     const uint32_t tiles_x = (max_w + ME_TW - 1) / ME_TW, tiles_y = (max_h + ME_TH - 1) / ME_TH;
     const int      tw = max_w < (uint32_t)ME_TW ? (int)max_w : ME_TW, th = max_h < (uint32_t)ME_TH ? (int)max_h : ME_TH;
     const int      win_rows = 64 + th - 1;

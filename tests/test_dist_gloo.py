@@ -50,3 +50,59 @@ def test_frame_sharding_world_size_2():
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\\n".join(o[1][-2000:] for o in outs)
     assert "DIST_OK" in outs[0][0]
+
+
+STRIP_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+    from conftest import EmuBackend
+    from test_sad import run_me_batch, oracle_me
+    import ctypes as C, bench
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    be = EmuBackend()
+    W, H, PAD, refs, aw, ah = 192, 200, 40, 2, 16, 9                    # 3 x 4 SBs: strips of 2 and 2 SB rows
+    stride, rows = W + 2 * PAD, H + 2 * PAD + 64
+    plane = stride * rows
+    planes = torch.zeros((1 + refs) * plane, dtype=torch.uint8)
+    if rank == 0:
+        planes = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (1 + refs) * plane, dtype=np.uint8))
+    dist.broadcast(planes, src=0)                                        # source + reference planes to every rank, once
+    host = planes.numpy()
+    full = be.pkg.me_descs_for_frame(W, H, stride, PAD, PAD, aw, ah, plane, n_refs=refs, src_plane=0, ref_plane0=1)
+    sbs_x, sbs_y = (W + 63) // 64, (H + 63) // 64
+    r0, r1 = bench.strip_rows(sbs_y, rank, world)
+    max_rows = bench.strip_rows(sbs_y, 0, world)[1]
+    mine = np.concatenate([full[r * sbs_x * sbs_y + r0 * sbs_x:r * sbs_x * sbs_y + r1 * sbs_x] for r in range(refs)])
+    bs, bm = run_me_batch(be, host, host, mine, aw, ah, 0)
+    n_pad = refs * max_rows * sbs_x
+    local = torch.zeros(2, n_pad, 85, dtype=torch.int32)
+    local[0, :len(mine)] = torch.from_numpy(bs.view(np.int32)); local[1, :len(mine)] = torch.from_numpy(bm.view(np.int32))
+    gathered = torch.zeros(world * 2 * n_pad * 85, dtype=torch.int32)    # flat, like bench.py's device buffers
+    dist.all_gather_into_tensor(gathered, local.reshape(-1))             # the data-path collective of the frame-partition mode
+    # every rank now holds the picture-wide tables: reassemble [ref][sb] and compare with the CPU checker
+    oracle = C.CDLL(os.path.join(sys.argv[1], "oracle", "liboracle.so"))
+    got = gathered.numpy().view(np.uint32).reshape(world, 2, n_pad, 85)
+    for rk in range(world):
+        q0, q1 = bench.strip_rows(sbs_y, rk, world)
+        for rf in range(refs):
+            for row in range(q0, q1):
+                for col in range(sbs_x):
+                    k = rf * (q1 - q0) * sbs_x + (row - q0) * sbs_x + col
+                    ws, wm = oracle_me(oracle, host, host, full[rf * sbs_x * sbs_y + row * sbs_x + col], 0)
+                    assert np.array_equal(got[rk, 0, k], ws) and np.array_equal(got[rk, 1, k], wm), (rk, rf, row, col)
+    assert [bench.strip_rows(17, k, 8) for k in range(8)][:3] == [(0, 3), (3, 5), (5, 7)] and bench.strip_rows(17, 7, 8) == (15, 17)
+    print("STRIPS_OK", rank)
+    dist.destroy_process_group()
+''')
+
+
+def test_frame_partition_strips_world_size_2():
+    """north_star's frame-partition case on CPU (gloo): one picture, SB-row strips per rank, planes broadcast once, all-gather of the per-strip tables."""
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, "-c", STRIP_WORKER, ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
+    assert "STRIPS_OK" in outs[0][0] and "STRIPS_OK" in outs[1][0]
