@@ -98,6 +98,15 @@ def txfm_roundtrip(torch, lib, pkg, stream, steps, warmup):
                 fwd()
                 quant()
                 inv()
+            rd = np.zeros(n, dtype=pkg.RoundtripDesc)
+            rd["in_off"] = rd["pred_off"] = rd["recon_off"] = np.arange(n, dtype=np.uint64) * pels
+            rd["in_stride"] = rd["pred_stride"] = rd["recon_stride"] = w
+            rd["tx_type"] = fd["tx_type"]
+            d_rd = _dev(torch, rd)
+
+            def fused():  # the same round trip in ONE launch, coefficients kept in LDS (qcoeff out, no dqcoeff)
+                lib.svt_hip_txfm_quant_roundtrip_batch(d_res.data_ptr(), d_pred.data_ptr(), d_rec.data_ptr(), d_rd.data_ptr(), n, ts, bd, mode, d_qp.data_ptr(),
+                                                       d_iscan.data_ptr(), None, None, d_q.data_ptr(), None, d_eob.data_ptr(), stream)
             # note: for 64-point sizes handle_transform repacks in place, so quant reads the packed layout; chain order keeps that valid
             tf, tc = _time(torch, fwd, steps, warmup), None
             if big == 64:  # re-run fwd once so that d_coef holds a packed block set for the isolated quant timing
@@ -105,12 +114,16 @@ def txfm_roundtrip(torch, lib, pkg, stream, steps, warmup):
             tq = _time(torch, quant, steps, warmup)
             ti = _time(torch, inv, steps, warmup)
             tc = _time(torch, chain, steps, warmup)
+            tfu = _time(torch, fused, steps, warmup)
+            b_fused = 2 * pels + 4 * ncoef + 2 + 4 * pels  # residual in, qcoeff + eob out, prediction in, reconstruction out (u16 pixels: SURVEY 8d's 10 B/px)
             # algorithmic bytes per block: fwd 2*pels in + 4*pels out; quant 4*ncoef in + 8*ncoef out + 2; inv 4*ncoef in + 2*pels pred + 2*pels recon
             b_f, b_q, b_i = 6 * pels, 12 * ncoef + 2, 4 * ncoef + 4 * pels
             out["%dx%d_bd%d" % (w, h, bd)] = {
                 "blocks": n, "chain_Mblocks_s": n / tc / 1e6, "fwd_Mblocks_s": n / tf / 1e6, "quant_Mblocks_s": n / tq / 1e6, "inv_Mblocks_s": n / ti / 1e6,
                 "chain_GBs": n * (b_f + b_q + b_i) / tc / 1e9, "fwd_GBs": n * b_f / tf / 1e9, "quant_GBs": n * b_q / tq / 1e9, "inv_GBs": n * b_i / ti / 1e9,
-                "chain_hbm_frac": n * (b_f + b_q + b_i) / tc / 1e9 / HBM_PEAK_GBS}
+                "chain_hbm_frac": n * (b_f + b_q + b_i) / tc / 1e9 / HBM_PEAK_GBS,
+                "fused_Mblocks_s": n / tfu / 1e6, "fused_GBs": n * b_fused / tfu / 1e9, "fused_hbm_frac": n * b_fused / tfu / 1e9 / HBM_PEAK_GBS,
+                "fused_speedup_vs_chain": tc / tfu}
             del d_res, d_coef, d_q, d_dq, d_rec, d_pred
     return out
 
@@ -128,7 +141,11 @@ def lr_frames(torch, lib, pkg, stream, steps, warmup):
     d_pl, d_ab, d_bl = _dev(torch, plane), _dev(torch, above), _dev(torch, below)
     d_out = torch.zeros(Hc * Wc, dtype=torch.int16, device="cuda")
     out = {}
+    import os
+    only = os.environ.get("SVT_LR_ONLY")  # profiling passes: one unit type per process, so that per-kernel counters are not a mix
     for name, tsel in (("wiener", [1]), ("sgrproj", [2]), ("mixed", [1, 2, 0, 2, 1])):
+        if only and name != only:
+            continue
         units = np.zeros(nvu * nhu, dtype=pkg.LrUnit)
         for i in range(len(units)):
             f = [int(g.integers(-5, 11)), int(g.integers(-23, 9)), int(g.integers(-17, 47))]

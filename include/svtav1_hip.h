@@ -564,6 +564,23 @@ void     svt_quantize_hip(int mode, const int32_t *coeff_ptr, intptr_t n_coeffs,
                           const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int log_scale);
 uint64_t svt_handle_transform_hip(int32_t *output, int tx_size, int n2_n4);
 
+/* BASELINE config 3 in ONE launch: forward transform -> (the 32x32 corner svt_handle_transform keeps of a 64-point block) -> quantize / dequantize -> inverse
+ * transform + reconstruction; the coefficients stay in LDS between the stages (10 B/px of HBM traffic instead of 26; + 4 B/px when dqcoeff != NULL).
+ * Bit-identical to svt_hip_fwd_txfm2d_batch(pf 0) -> svt_hip_handle_transform_batch -> svt_hip_quantize_batch -> svt_hip_inv_txfm2d_add_batch.
+ * quant_mode as svt_hip_quantize_batch (0 / 2 with 8-bit pixels, 1 / 3 with 16-bit pixels); qcoeff / dqcoeff [n][min(W,32) * min(H,32)]; qm tables may be NULL. */
+typedef struct SvtHipRoundtripDesc {
+    uint64_t in_off;      /* int16 elements from residual_base */
+    uint64_t pred_off;    /* pixels from pred_base */
+    uint64_t recon_off;   /* pixels from recon_base (may alias the prediction) */
+    uint32_t in_stride, pred_stride, recon_stride;
+    uint32_t qparam_idx, iscan_idx, qm_idx; /* as SvtHipQuantDesc */
+    uint8_t  tx_type;
+    uint8_t  pad[7];
+} SvtHipRoundtripDesc;
+void svt_hip_txfm_quant_roundtrip_batch(const int16_t *residual_base, const void *pred_base, void *recon_base, const SvtHipRoundtripDesc *descs, uint32_t n,
+                                        int tx_size, int bd, int quant_mode, const SvtHipQuantParams *qparams, const int16_t *iscan_tables,
+                                        const uint8_t *qm_tables, const uint8_t *iqm_tables, int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob, void *stream);
+
 /* ------------------------------------------- picture preparation for ME ------------------------- */
 /* downsample_2d -> svt_aom_downsample_2d_c (aom_dsp_rtcd.h:841, pic_analysis_process.c:130-160): out(x, y) = (2x2 box at the centre of cell
  * (x, y) of decim_step x decim_step input pixels + 2) >> 2; host pointers (RTCD form). */

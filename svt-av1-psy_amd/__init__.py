@@ -128,7 +128,9 @@ InvTxfmDesc = np.dtype([("coeff_off", "<u8"), ("pred_off", "<u8"), ("recon_off",
 TxfmParam = np.dtype([("tx_type", "u1"), ("tx_size", "u1"), ("lossless", "<i4"), ("bd", "<i4"), ("is_hbd", "<i4"), ("tx_set_type", "<i4"),
                       ("eob", "<i4")], align=True)  # TxfmParam, definitions.h:1043-1055
 assert TxfmParam.itemsize == 24
-assert FwdTxfmDesc.itemsize == 16 and InvTxfmDesc.itemsize == 40
+RoundtripDesc = np.dtype([("in_off", "<u8"), ("pred_off", "<u8"), ("recon_off", "<u8"), ("in_stride", "<u4"), ("pred_stride", "<u4"), ("recon_stride", "<u4"),
+                          ("qparam_idx", "<u4"), ("iscan_idx", "<u4"), ("qm_idx", "<u4"), ("tx_type", "u1"), ("pad", "u1", (7,))])
+assert FwdTxfmDesc.itemsize == 16 and InvTxfmDesc.itemsize == 40 and RoundtripDesc.itemsize == 56
 PROTOTYPES.update({
     "svt_hip_fwd_txfm2d_batch": (None, [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp]),
     "svt_hip_inv_txfm2d_add_batch": (None, [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp]),
@@ -137,6 +139,7 @@ PROTOTYPES.update({
     "svt_av1_inv_txfm2d_add_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int, C.c_int32]),
     "svt_av1_inv_txfm_add_u8_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int]),
     "svt_av1_inv_txfm_add_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, vp]),
+    "svt_hip_txfm_quant_roundtrip_batch": (None, [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "svt_av1_fwht4x4_hip": (None, [vp, vp, C.c_uint32]),
     "svt_hip_fwht4x4_batch": (None, [vp, vp, C.c_uint32, vp, vp]),
     "svt_hip_iwht4x4_add_batch": (None, [vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),

@@ -37,68 +37,74 @@ __device__ __forceinline__ int rd_px(const void* p, const int highbd, const size
     return highbd ? ((const uint16_t*)p)[off] : ((const uint8_t*)p)[off];
 }
 // Source row of plane row y for this unit (restoration.c:288-332 stripe boundary substitution + svt_extend_frame row replication); the
-// column is clamped by the caller.  Raw mode (w == 0): the block's own rows.
-__device__ __forceinline__ const void* src_row(const TileSrc& s, const int y) {
-    const size_t px = s.highbd ? 2 : 1;
-    if (s.w == 0) return (const uint8_t*)s.data + (long long)y * s.stride * (long long)px;
-    if (y < s.stripe_top && s.stripe_top != 0) {
-        const int i = y - s.stripe_top;
-        return (const uint8_t*)s.above + (size_t)(2 * s.stripe_idx + (i + 2 > 0 ? i + 2 : 0)) * s.bstride * px;
-    }
-    if (y >= s.stripe_bot && s.stripe_bot < s.h) {
-        const int i = y - s.stripe_bot;
-        return (const uint8_t*)s.below + (size_t)(2 * s.stripe_idx + (i < 1 ? i : 1)) * s.bstride * px;
-    }
-    return (const uint8_t*)s.data + (size_t)clampi(y, 0, s.h - 1) * s.stride * px;
+// column is clamped by the caller.  Raw mode (w == 0): the block's own rows.  Written as selects on (base address, row index, stride): a
+// three-way choice between the pointers of the struct made the compiler index the struct through scratch memory.
+__device__ __forceinline__ const uint8_t* src_row(const TileSrc& s, const int y) {
+    const int  px = s.highbd ? 2 : 1;
+    const bool raw = s.w == 0;
+    const bool up = !raw && y < s.stripe_top && s.stripe_top != 0, dn = !raw && !up && y >= s.stripe_bot && s.stripe_bot < s.h;
+    const int  iu = y - s.stripe_top + 2, id = y - s.stripe_bot;
+    const long long row = up ? (long long)(2 * s.stripe_idx + (iu > 0 ? iu : 0)) : (dn ? (long long)(2 * s.stripe_idx + (id < 1 ? id : 1)) : (raw ? (long long)y : (long long)clampi(y, 0, s.h - 1)));
+    // (bit masks, not ?: on the struct's fields: a select between loads of struct members is rewritten into an indexed load of the struct, which then lives in scratch)
+    const uintptr_t d = (uintptr_t)s.data, mu = (uintptr_t)0 - (uintptr_t)up, md = (uintptr_t)0 - (uintptr_t)dn;
+    const uintptr_t base = d ^ ((d ^ (uintptr_t)s.above) & mu) ^ ((d ^ (uintptr_t)s.below) & md);
+    const uint32_t  st = (uint32_t)s.stride, stride = st ^ ((st ^ (uint32_t)s.bstride) & (uint32_t)(mu | md));
+    return (const uint8_t*)(base + (uintptr_t)(row * (long long)stride * px));
 }
 struct __attribute__((packed, aligned(2))) LrRow8A2 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(1))) LrRow8A1 { uint32_t v[2]; };
 struct __attribute__((aligned(16))) LrRow8A16 { uint32_t v[4]; };
 // tile[(r) * TW + c] <- pixel (y0 - 3 + r, x0 - 3 + c), r < uh + 6, c < uw + 6, zero beyond (the extra columns feed tap 7, always x 0).
-// A thread owns 8-pixel chunks (9 per row); chunks that lie inside the plane are fetched with one vector load each, all issued before the
-// first LDS store, so a workgroup pays one memory round trip; only chunks that cross the plane's left / right edge or the unit's last
-// column go pixel by pixel.
+// A row is nine 8-pixel chunks.  WAVE w stages rows w, w + 4, ...: the row is wave-uniform, so the whole stripe-boundary / edge-replication logic of
+// src_row runs on the scalar unit and a row costs the vector unit one load (scalar base + a loop-invariant lane offset) and one LDS store; lanes 0-8 own the
+// chunks.  (The first version spread (row, chunk) pairs over all 256 lanes: every lane then evaluated src_row with 64-bit vector arithmetic, and staging
+// was ~60 % of the kernel's 750 VALU instructions per wave -- profiles/r02_call5_lr_counters.txt.)  Up to ten rows per wave are in flight before the first
+// LDS store; chunks that cross the plane's left / right edge or the unit's last column go pixel by pixel.
 __device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, const int tid) {
-    const int rows = s.uh + 6, cols = s.uw + 6, total = rows * 9;
-    uint32_t  v[3][4];
+    constexpr int NR = 10;
+    const int  rows = s.uh + 6, cols = s.uw + 6;
+    const int  wv = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
+    const int  x = s.x0 - 3 + 8 * c;
+    const bool live = c < 9;
+    const bool cfast = live && 8 * c + 8 <= cols && (s.w == 0 || (x >= 0 && x + 8 <= s.w));
+    const uint32_t xoff = cfast ? (uint32_t)(x * (s.highbd ? 2 : 1)) : 0u; // (raw mode: x may be negative -- the block's own border -- hence the signed add below)
+    for (int r0 = wv; r0 < rows; r0 += 4 * NR) {
+        uint32_t v[NR][4];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int  i = tid + 256 * k, r = i / 9, c = i - r * 9;
-        const int  x = s.x0 - 3 + 8 * c;
-        const bool fast = i < total && 8 * c + 8 <= cols && (s.w == 0 || (x >= 0 && x + 8 <= s.w));
-        const uint8_t* row = (const uint8_t*)src_row(s, s.y0 - 3 + (i < total ? r : 0));
-        const uint8_t* p   = fast ? row + (long long)x * (s.highbd ? 2 : 1) : (const uint8_t*)src_row(s, s.y0);
-        if (s.highbd) {
-            const LrRow8A2 t = *(const LrRow8A2*)p;
-            v[k][0] = t.v[0]; v[k][1] = t.v[1]; v[k][2] = t.v[2]; v[k][3] = t.v[3];
-        } else {
-            const LrRow8A1 t = *(const LrRow8A1*)p;
-            v[k][0] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c010c00u); v[k][1] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c030c02u);
-            v[k][2] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c010c00u); v[k][3] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c030c02u);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int i = tid + 256 * k, r = i / 9, c = i - r * 9;
-        if (i >= total) continue;
-        const int  x = s.x0 - 3 + 8 * c;
-        const bool fast = 8 * c + 8 <= cols && (s.w == 0 || (x >= 0 && x + 8 <= s.w));
-        if (!fast) {
-            const void* row = src_row(s, s.y0 - 3 + r);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                uint32_t px[2];
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int cc = 8 * c + 2 * e + h;
-                    int       xx = x + 2 * e + h;
-                    if (s.w != 0) xx = clampi(xx, 0, s.w - 1);
-                    px[h] = cc < cols ? (uint32_t)rd_px(row, s.highbd, (size_t)0 + (long long)xx) : 0u;
-                }
-                v[k][e] = px[0] | (px[1] << 16);
+        for (int k = 0; k < NR; k++) {
+            const int      r = r0 + 4 * k;
+            const uint8_t* row = src_row(s, s.y0 - 3 + (r < rows ? r : rows - 1));
+            const uint8_t* p = row + (int)xoff;
+            if (s.highbd) {
+                const LrRow8A2 t = *(const LrRow8A2*)p;
+                v[k][0] = t.v[0]; v[k][1] = t.v[1]; v[k][2] = t.v[2]; v[k][3] = t.v[3];
+            } else {
+                const LrRow8A1 t = *(const LrRow8A1*)p;
+                v[k][0] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c010c00u); v[k][1] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c030c02u);
+                v[k][2] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c010c00u); v[k][3] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c030c02u);
             }
         }
-        *(LrRow8A16*)(tile + r * TW + 8 * c) = LrRow8A16{{v[k][0], v[k][1], v[k][2], v[k][3]}};
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int r = r0 + 4 * k;
+            if (r >= rows || !live) continue;
+            if (!cfast) {
+                const uint8_t* row = src_row(s, s.y0 - 3 + r);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    uint32_t px[2];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int cc = 8 * c + 2 * e + h;
+                        int       xx = x + 2 * e + h;
+                        if (s.w != 0) xx = clampi(xx, 0, s.w - 1);
+                        px[h] = cc < cols ? (uint32_t)rd_px(row, s.highbd, (size_t)0 + (long long)xx) : 0u;
+                    }
+                    v[k][e] = px[0] | (px[1] << 16);
+                }
+            }
+            *(LrRow8A16*)(tile + r * TW + 8 * c) = LrRow8A16{{v[k][0], v[k][1], v[k][2], v[k][3]}};
+        }
     }
 }
 struct WienerTaps { int16_t fx[8], fy[8]; };
@@ -151,8 +157,7 @@ template <typename OUT> __device__ __forceinline__ void wiener_tile(const uint16
             const int sh = lr_sdot2(__builtin_amdgcn_perm(d[1], d[0], 0x07060302u), g01,
                            lr_sdot2(__builtin_amdgcn_perm(d[3], d[2], 0x07060302u), g23,
                            lr_sdot2(__builtin_amdgcn_perm(d[5], d[4], 0x07060302u), g45, lr_sdot2(d[6] >> 16, g6, o))));
-            out(r, c, clampi(rpot(sl, r1), 0, (1 << bd) - 1));
-            if (c + 1 < uw) out(r, c + 1, clampi(rpot(sh, r1), 0, (1 << bd) - 1));
+            out(r, c, clampi(rpot(sl, r1), 0, (1 << bd) - 1), clampi(rpot(sh, r1), 0, (1 << bd) - 1), c + 1 < uw);
         }
     }
 }
@@ -174,7 +179,7 @@ __device__ __forceinline__ void sgr_ab_pass(const uint16_t* tile, uint16_t* A16,
     const uint32_t s = (uint32_t)kSgrS[idx][pass], n = (uint32_t)((2 * r + 1) * (2 * r + 1)), obx = one_by_x(n);
     const int      nrows = pass == 0 ? 33 : 66; // pass 0 only needs the positions with ii even (i = ii - 1 odd)
     for (int e = tid; e < nrows * 33; e += 256) {
-        const int rr = e / 33, jj = (e - rr * 33) * 2, ii = pass == 0 ? 2 * rr : rr; // i = ii - 1, j = jj - 1 (and jj)
+        const int rr = (e * 1986) >> 16, jj = (e - rr * 33) * 2, ii = pass == 0 ? 2 * rr : rr; // rr = e / 33 exactly for e < 2178; i = ii - 1, j = jj - 1 (and jj)
         if (ii > uh + 1 || jj > uw + 1) continue;
         const uint16_t* p = tile + (ii + 2 - r) * TW + jj; // first of the six pixels jj .. jj + 5 of the window's top row (dword aligned)
         uint32_t tot = 0, tot2 = 0, ea = 0, ea2 = 0, eb = 0, eb2 = 0; // r = 2: totals over six pixels minus an edge; r = 1: centre pair plus an edge
@@ -296,8 +301,7 @@ __device__ __forceinline__ void sgr_tile(const uint16_t* tile, uint16_t* A16, in
         if (r < uh && c < uw) {
             int32_t f[2] = {0, 0};
             if (p1) sgr_flt_pair(tile, A16, B32, 1, r, c, f);
-            out_flt1_or_apply(r, c, f0[2 * k], f[0]);
-            if (c + 1 < uw) out_flt1_or_apply(r, c + 1, f0[2 * k + 1], f[1]);
+            out_flt1_or_apply(r, c, f0[2 * k], f[0], f0[2 * k + 1], f[1], c + 1 < uw);
         }
     }
 }
@@ -357,9 +361,19 @@ __global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, c
     void* dst = P.dst;
     const size_t dstride = P.dst_stride;
     const int x0 = s.x0, y0 = s.y0;
-    auto store = [&](int r, int c, int v) {
-        if (highbd) ((uint16_t*)dst)[(size_t)(y0 + r) * dstride + x0 + c] = (uint16_t)v;
-        else ((uint8_t*)dst)[(size_t)(y0 + r) * dstride + x0 + c] = (uint8_t)v;
+    // two horizontally adjacent samples per store instruction (one dword / one halfword when the address allows it): single-sample stores
+    // touched every 64-byte line twice and the write traffic was 5.5 x the plane (profiles/r02_call3_pmc_traffic.json)
+    auto store = [&](int r, int c, int v0, int v1, bool has1) {
+        const size_t o = (size_t)(y0 + r) * dstride + x0 + c;
+        if (highbd) {
+            uint16_t* q = (uint16_t*)dst + o;
+            if (has1 && !((uintptr_t)q & 3)) *(uint32_t*)q = (uint32_t)v0 | ((uint32_t)v1 << 16);
+            else { q[0] = (uint16_t)v0; if (has1) q[1] = (uint16_t)v1; }
+        } else {
+            uint8_t* q = (uint8_t*)dst + o;
+            if (has1 && !((uintptr_t)q & 1)) *(uint16_t*)q = (uint16_t)(v0 | (v1 << 8));
+            else { q[0] = (uint8_t)v0; if (has1) q[1] = (uint8_t)v1; }
+        }
     };
     stage_tile(tile, s, tid);
     __syncthreads();
@@ -371,11 +385,14 @@ __global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, c
     } else if (u.rtype == 2) {
         const int idx = u.ep & 15;
         sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, bd, tid, [](int, int, int32_t) {},
-                 [&](int r, int c, int32_t f0, int32_t f1) { store(r, c, sgr_combine(tile[(r + 3) * TW + c + 3], f0, f1, idx, u.xqd[0], u.xqd[1], bd)); });
+                 [&](int r, int c, int32_t f0a, int32_t f1a, int32_t f0b, int32_t f1b, bool has1) {
+                     store(r, c, sgr_combine(tile[(r + 3) * TW + c + 3], f0a, f1a, idx, u.xqd[0], u.xqd[1], bd),
+                           sgr_combine(tile[(r + 3) * TW + c + 4], f0b, f1b, idx, u.xqd[0], u.xqd[1], bd), has1);
+                 });
     } else {
-        for (int i = tid; i < s.uh * 64; i += 256) {
-            const int r = i >> 6, c = i & 63;
-            if (c < s.uw) store(r, c, tile[(r + 3) * TW + c + 3]);
+        for (int i = tid; i < s.uh * 32; i += 256) {
+            const int r = i >> 5, c = (i & 31) * 2;
+            if (c < s.uw) store(r, c, tile[(r + 3) * TW + c + 3], tile[(r + 3) * TW + c + 4], c + 1 < s.uw);
         }
     }
 }
@@ -398,9 +415,10 @@ __global__ __launch_bounds__(256) void lr_block_kernel(const void* src /* origin
     s.x0 = blockIdx.x * 64; s.y0 = blockIdx.y * 64;
     s.uw = w - s.x0 < 64 ? w - s.x0 : 64; s.uh = h - s.y0 < 64 ? h - s.y0 : 64;
     const int x0 = s.x0, y0 = s.y0;
-    auto store = [&](int r, int c, int v) {
-        if (highbd) ((uint16_t*)dst)[(size_t)(y0 + r) * dstride + x0 + c] = (uint16_t)v;
-        else ((uint8_t*)dst)[(size_t)(y0 + r) * dstride + x0 + c] = (uint8_t)v;
+    auto store = [&](int r, int c, int v0, int v1, bool has1) {
+        const size_t o = (size_t)(y0 + r) * dstride + x0 + c;
+        if (highbd) { ((uint16_t*)dst)[o] = (uint16_t)v0; if (has1) ((uint16_t*)dst)[o + 1] = (uint16_t)v1; }
+        else { ((uint8_t*)dst)[o] = (uint8_t)v0; if (has1) ((uint8_t*)dst)[o + 1] = (uint8_t)v1; }
     };
     stage_tile(tile, s, tid);
     __syncthreads();
@@ -408,11 +426,15 @@ __global__ __launch_bounds__(256) void lr_block_kernel(const void* src /* origin
         wiener_tile(tile, mid, taps, s.uw, s.uh, bd, tid, store);
     } else if (kind == 1) {
         sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, bd, tid, [](int, int, int32_t) {},
-                 [&](int r, int c, int32_t a, int32_t b) { store(r, c, sgr_combine(tile[(r + 3) * TW + c + 3], a, b, idx, xqd0, xqd1, bd)); });
+                 [&](int r, int c, int32_t a0, int32_t b0, int32_t a1, int32_t b1, bool has1) {
+                     store(r, c, sgr_combine(tile[(r + 3) * TW + c + 3], a0, b0, idx, xqd0, xqd1, bd), sgr_combine(tile[(r + 3) * TW + c + 4], a1, b1, idx, xqd0, xqd1, bd), has1);
+                 });
     } else {
         const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
         sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, bd, tid, [&](int r, int c, int32_t v) { if (p0) f0out[(size_t)(y0 + r) * fstride + x0 + c] = v; },
-                 [&](int r, int c, int32_t, int32_t b) { if (p1) f1out[(size_t)(y0 + r) * fstride + x0 + c] = b; });
+                 [&](int r, int c, int32_t, int32_t b0, int32_t, int32_t b1, bool has1) {
+                     if (p1) { f1out[(size_t)(y0 + r) * fstride + x0 + c] = b0; if (has1) f1out[(size_t)(y0 + r) * fstride + x0 + c + 1] = b1; }
+                 });
     }
 }
 
