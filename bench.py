@@ -418,6 +418,12 @@ def bench_cdef(torch, lib, pkg, stream, a, cpu):
         out[name] = {"value": units / per / 1e6, "unit": "M(8x8 block x strength)/s" if mode else "M(8x8 blocks)/s", "frames_per_s": 1 / per,
                      "parity_checked_values": checked,
                      "roofline": roofline(bytes_alg, per, "cdef_frame_kernel<unsigned short, %d>" % mode, algorithmic_bytes_per_frame=bytes_alg)}
+    # apply with the directions the search pass just wrote (mode 2: what the CDEF stage runs after its strength search)
+    P2 = params(D, 0)
+    fn2 = lambda: lib.svt_hip_cdef_frame(2, C.byref(P2), stream)  # noqa: E731
+    st = max(3, a.steps // 2)
+    _, dv = time_steps(torch, fn2, st, 2)
+    out["cdef_apply_4k10"]["frames_per_s_given_directions"] = st / dv
     if cpu:
         ref, oracle2 = ref_libs()
         if ref is not None and " avx2 " in open("/proc/cpuinfo").read():

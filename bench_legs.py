@@ -354,8 +354,8 @@ def cdef_chain(torch, lib, pkg, stream, steps, warmup):
             st = lev[gi]
             a_pri[k].copy_(st // 4)
             a_sec[k].copy_(sec_map[(st % 4).long()])
-        for pl in range(3):
-            lib.svt_hip_cdef_frame(0, C.byref(P_apply[pl]), stream)
+        for pl in range(3):  # (the luma directions / variances are the ones the search pass just wrote: mode 2 does not search them again)
+            lib.svt_hip_cdef_frame(2 if pl == 0 else 0, C.byref(P_apply[pl]), stream)
     t = _time(torch, fn, steps, warmup)
     return {"cdef_stage_4k10_420": {"frames_per_s": 1 / t, "ms": t * 1e3, "filter_blocks": nfb, "strengths_searched": 64, "pairs_selected": 8,
                                     "note": "Y+U+V search, joint strength search (8 greedy + 32 refinement rounds), per-block assignment, Y+U+V apply"}}

@@ -639,7 +639,8 @@ typedef struct SvtHipCdefParams {
     int32_t       *var;   /* [nfb][64]                                                              */
     uint64_t      *mse;   /* search: [nfb][ncand] = svt_compute_cdef_dist of every candidate        */
 } SvtHipCdefParams;
-/* mode 0 = apply (svt_cdef_filter_fb over the frame, enc_cdef.c:284), 1 = strength search (cdef_process.c:106).
+/* mode 0 = apply (svt_cdef_filter_fb over the frame, enc_cdef.c:284), 1 = strength search (cdef_process.c:106), 2 = apply with the luma directions /
+ * variances taken from dir / var (what the search pass over the same reconstruction wrote; the reference recomputes identical values, cdef.c:367-386).
  * All pointers inside `params` are DEVICE pointers; the struct itself is read on the host. */
 void svt_hip_cdef_frame(int mode, const SvtHipCdefParams *params, void *stream);
 /* Strength selection over the search output: svt_search_one_dual -> svt_search_one_dual_c (aom_dsp_rtcd.h:242,

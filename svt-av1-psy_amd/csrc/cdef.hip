@@ -466,7 +466,7 @@ __device__ __forceinline__ void apply_pass(const LaneCtx& L, const TapOffs& o, c
 // 4g-th .. (4g+3)-th distinct non-zero primary levels of the candidate list, each against all four secondary strengths; g = 0 also takes
 // primary level 0).  A quad owns an 8x8 (4x4 / 4x8 / 8x4 for subsampled chroma) unit; a lane filters uh / 4 rows, two pixels per packed op.
 template <typename PIX, int MODE>
-__global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefParams P) {
+__global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefParams P, const int gpw, const int reuse_dir) {
     HIP_DYNAMIC_SHARED(uint16_t, tile_raw)
     __shared__ int                sh_any, sh_dc[4][64], sh_dd[4][64], sh_do[4][64];
     __shared__ unsigned long long sh_cells[20]; // [4 levels][4 secondary] + [level 0][4 secondary]
@@ -477,21 +477,15 @@ __global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefPara
     const int nhfb = (pw + bw - 1) / bw, nvfb = (ph + bh - 1) / bh;
     const int fb = blockIdx.x, fbr = fb / nhfb, fbc = fb % nhfb;
     const int pitch = tile_pitch(bw, uh);
-    const int g = blockIdx.y, ncand = MODE == 1 ? (int)P.ncand : 0;
-
-    // search: which primary levels does this group own?  (uniform; the list has at most 64 entries)
-    int  lv[4] = {0, 0, 0, 0}, nlv = 0;
-    bool do0 = false;
+    // search: this workgroup takes the level groups g0 .. g0 + gpw - 1 of its filter block one after the other, on ONE staged tile (large frames: gpw = 2
+    // or 4, so the tile, the source block and the direction search are not repeated per group; small frames keep gpw = 1 to fill the chip)
+    const int g0 = MODE == 1 ? (int)blockIdx.y * gpw : 0, ncand = MODE == 1 ? (int)P.ncand : 0;
+    uint32_t all_levels = 0;
     if (MODE == 1) {
-        uint32_t levels = 0;
-        for (int c = 0; c < ncand; c++) levels |= 1u << (P.pri[c] & 15);
-        do0 = (levels & 1u) && g == 0;
-        levels &= ~1u;
-        for (int k = 0; k < 4 * g && levels; k++) levels &= levels - 1; // drop the levels of the groups before this one
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (levels) { lv[k] = __builtin_ctz(levels); levels &= levels - 1; nlv = k + 1; }
-        if (nlv == 0 && !do0 && g != 0) return;
+        for (int c = 0; c < ncand; c++) all_levels |= 1u << (P.pri[c] & 15);
+        uint32_t rest = all_levels & ~1u;
+        for (int k = 0; k < 4 * g0 && rest; k++) rest &= rest - 1;
+        if (rest == 0 && !((all_levels & 1u) && g0 == 0) && g0 != 0) return; // nothing left for this workgroup's groups
     }
 
     const int b = tid >> 2, q = tid & 3, by = b >> 3, bx = b & 7;
@@ -503,7 +497,7 @@ __global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefPara
     if (act) sh_any = 1;
     __syncthreads();
     if (sh_any == 0) {
-        if (MODE == 1 && g == 0)
+        if (MODE == 1 && g0 == 0)
             for (int c = tid; c < ncand; c += 256) P.mse[(size_t)fb * P.ncand + c] = 0;
         return;
     }
@@ -522,10 +516,10 @@ __global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefPara
     L.in  = tile_raw + VB * pitch + HB;
     L.org = tile_raw + (bh + 2 * VB) * pitch; // search mode: the source block, pitch bw
     int dir = 0, var = 0;
-    if (pli == 0) {
+    if (pli == 0 && !reuse_dir) {
         block_find_dir(L.in, pitch, cs, tid, b, sh_dc, sh_dd, sh_do, dir, var); // every unit is searched (inactive ones: result unused)
         if (!act) { dir = 0; var = 0; }
-        if (q == 0 && g == 0) { P.dir[(size_t)fb * 64 + b] = (uint8_t)dir; P.var[(size_t)fb * 64 + b] = var; }
+        if (q == 0 && g0 == 0) { P.dir[(size_t)fb * 64 + b] = (uint8_t)dir; P.var[(size_t)fb * 64 + b] = var; }
     } else {
         dir = P.dir[(size_t)fb * 64 + b] & 7;
         if (xdec != ydec) // cdef.c:388-395: conv422 = {7,0,2,4,5,6,6,6}, conv440 = {1,2,2,2,3,4,6,0}, one nibble per direction
@@ -551,6 +545,24 @@ __global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefPara
         return;
     }
     const bool weighted = pli == 0 && uw == 8 && uh == 8;
+    for (int gi = 0; gi < gpw; gi++) {
+    const int g = g0 + gi;
+    // which primary levels does group g own?  (uniform; the list has at most 64 entries)
+    int  lv[4] = {0, 0, 0, 0}, nlv = 0;
+    bool do0 = (all_levels & 1u) && g == 0;
+    {
+        uint32_t levels = all_levels & ~1u;
+        for (int k = 0; k < 4 * g && levels; k++) levels &= levels - 1; // drop the levels of the groups before this one
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (levels) { lv[k] = __builtin_ctz(levels); levels &= levels - 1; nlv = k + 1; }
+    }
+    if (nlv == 0 && !do0) break;
+    if (gi) { // the cells of the previous group have been read out
+        __syncthreads();
+        if (tid < 20) sh_cells[tid] = 0;
+        __syncthreads();
+    }
     acc16    a_s, a_s2, a_sd; // vector values, not arrays: they must never become stack objects
     uint32_t d_s = 0, d_s2 = 0;
     if (nlv) {
@@ -577,6 +589,7 @@ __global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefPara
         }
         if (cell >= 0) P.mse[(size_t)fb * P.ncand + c] = sh_cells[cell] >> (2 * cs);
     }
+    } // group loop
 }
 
 // ---- single-call kernels ---------------------------------------------------------------------------------------------
@@ -626,13 +639,20 @@ __global__ void copy_rect8_to_16_kernel(uint16_t* dst, const uint8_t* src, int n
     if (i < n) dst[i] = src[i];
 }
 
-template <int MODE> void launch_frame(const SvtHipCdefParams& P, hipStream_t st) {
+template <int MODE> void launch_frame(const SvtHipCdefParams& P, hipStream_t st, const int reuse_dir = 0) {
     const int bw = 64 >> P.xdec, bh = 64 >> P.ydec;
     const int nhfb = ((int)P.width + bw - 1) / bw, nvfb = ((int)P.height + bh - 1) / bh;
     const size_t shmem = (size_t)((bh + 2 * VB) * tile_pitch(bw, 8 >> P.ydec) + (MODE == 1 ? bh * bw : 0)) * 2 + 64;
-    const dim3 grid(nhfb * nvfb, MODE == 1 ? 4 : 1); // search: four groups of four primary levels
-    if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE>), grid, dim3(256), shmem, st, P);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE>), grid, dim3(256), shmem, st, P);
+    // search: four groups of four primary levels; a workgroup takes gpw of them on one staged tile as long as >= 4096 workgroups remain (256 CUs x 4 x 4 rounds)
+    int gpw = 1;
+    if (MODE == 1) {
+        const char* e = getenv("SVT_HIP_CDEF_GPW"); // (measurement override)
+        gpw = e ? atoi(e) : (nhfb * nvfb >= 2040 ? 4 : (nhfb * nvfb >= 1020 ? 2 : 1)); // 4K luma: 378 us with 4, 386 with 2, 418 with 1 (profiles/r02_call8_*)
+        gpw = gpw == 4 ? 4 : (gpw == 2 ? 2 : 1);
+    }
+    const dim3 grid(nhfb * nvfb, MODE == 1 ? 4 / gpw : 1);
+    if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
     SVT_LAUNCH_CHECK();
 }
 const int kBlkW[4] = {4, 4, 8, 8}, kBlkH[4] = {4, 8, 4, 8}; // BLOCK_4X4, 4X8, 8X4, 8X8 (definitions.h)
@@ -645,6 +665,7 @@ void svt_hip_cdef_frame(int mode, const SvtHipCdefParams* params, void* stream) 
     svthip::ensure_device();
     if (mode == 1 && params->ncand == 0) return;
     if (mode == 0) launch_frame<0>(*params, (hipStream_t)stream);
+    else if (mode == 2) launch_frame<0>(*params, (hipStream_t)stream, 1);
     else launch_frame<1>(*params, (hipStream_t)stream);
 }
 

@@ -55,56 +55,56 @@ struct __attribute__((packed, aligned(2))) LrRow8A2 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(1))) LrRow8A1 { uint32_t v[2]; };
 struct __attribute__((aligned(16))) LrRow8A16 { uint32_t v[4]; };
 // tile[(r) * TW + c] <- pixel (y0 - 3 + r, x0 - 3 + c), r < uh + 6, c < uw + 6, zero beyond (the extra columns feed tap 7, always x 0).
-// A row is nine 8-pixel chunks.  WAVE w stages rows w, w + 4, ...: the row is wave-uniform, so the whole stripe-boundary / edge-replication logic of
-// src_row runs on the scalar unit and a row costs the vector unit one load (scalar base + a loop-invariant lane offset) and one LDS store; lanes 0-8 own the
-// chunks.  (The first version spread (row, chunk) pairs over all 256 lanes: every lane then evaluated src_row with 64-bit vector arithmetic, and staging
-// was ~60 % of the kernel's 750 VALU instructions per wave -- profiles/r02_call5_lr_counters.txt.)  Up to ten rows per wave are in flight before the first
-// LDS store; chunks that cross the plane's left / right edge or the unit's last column go pixel by pixel.
+// A row is nine 8-pixel chunks; the sixteen lanes of a row group own chunk (lane & 15) < 9 of row (tid >> 4) + 16 k, so the (row, chunk) of a
+// thread costs no division and the row pointer is computed once per k.  Chunks that lie inside the plane are fetched with one vector load each, all
+// issued before the first LDS store (one memory round trip per workgroup); only chunks that cross the plane's left / right edge or the unit's last
+// column go pixel by pixel.  NIT * 16 >= rows.  (A wave-uniform row loop -- src_row on the scalar unit, one load per row and wave -- was tried and was
+// twice as slow: 1 365 scalar instructions per wave and serialised loads, profiles/r02_call7_lr_row_uniform_staging.txt.)
+template <int NIT>
 __device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, const int tid) {
-    constexpr int NR = 10;
     const int  rows = s.uh + 6, cols = s.uw + 6;
-    const int  wv = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
+    const int  c = tid & 15, rb = tid >> 4;
     const int  x = s.x0 - 3 + 8 * c;
-    const bool live = c < 9;
-    const bool cfast = live && 8 * c + 8 <= cols && (s.w == 0 || (x >= 0 && x + 8 <= s.w));
-    const uint32_t xoff = cfast ? (uint32_t)(x * (s.highbd ? 2 : 1)) : 0u; // (raw mode: x may be negative -- the block's own border -- hence the signed add below)
-    for (int r0 = wv; r0 < rows; r0 += 4 * NR) {
-        uint32_t v[NR][4];
+    // a chunk that only STARTS inside the needed columns is still fetched whole when its 8 pixels exist (inside the plane / the raw block's border): the
+    // columns beyond uw + 6 are multiplied by tap 7 = 0 (Wiener) or never read (self-guided), so they need not be zero.  Before, chunk 8 (6 of 8 pixels
+    // needed) took the pixel-by-pixel path in EVERY workgroup: ~180 VALU instructions per wave and a second dependent memory round trip.
+    const bool cfast = c < 9 && 8 * c < cols && (s.w == 0 || (x >= 0 && x + 8 <= s.w));
+    uint32_t   v[NIT][4];
 #pragma unroll
-        for (int k = 0; k < NR; k++) {
-            const int      r = r0 + 4 * k;
-            const uint8_t* row = src_row(s, s.y0 - 3 + (r < rows ? r : rows - 1));
-            const uint8_t* p = row + (int)xoff;
-            if (s.highbd) {
-                const LrRow8A2 t = *(const LrRow8A2*)p;
-                v[k][0] = t.v[0]; v[k][1] = t.v[1]; v[k][2] = t.v[2]; v[k][3] = t.v[3];
-            } else {
-                const LrRow8A1 t = *(const LrRow8A1*)p;
-                v[k][0] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c010c00u); v[k][1] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c030c02u);
-                v[k][2] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c010c00u); v[k][3] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c030c02u);
-            }
+    for (int k = 0; k < NIT; k++) {
+        const int  r = rb + 16 * k;
+        const bool fast = cfast && r < rows;
+        const uint8_t* row = src_row(s, s.y0 - 3 + (r < rows ? r : 0));
+        const uint8_t* p   = fast ? row + (long long)x * (s.highbd ? 2 : 1) : row; // (idle / slow lanes read the row start: always mapped)
+        if (s.highbd) {
+            const LrRow8A2 t = *(const LrRow8A2*)p;
+            v[k][0] = t.v[0]; v[k][1] = t.v[1]; v[k][2] = t.v[2]; v[k][3] = t.v[3];
+        } else {
+            const LrRow8A1 t = *(const LrRow8A1*)p;
+            v[k][0] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c010c00u); v[k][1] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c030c02u);
+            v[k][2] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c010c00u); v[k][3] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c030c02u);
         }
+    }
 #pragma unroll
-        for (int k = 0; k < NR; k++) {
-            const int r = r0 + 4 * k;
-            if (r >= rows || !live) continue;
-            if (!cfast) {
-                const uint8_t* row = src_row(s, s.y0 - 3 + r);
+    for (int k = 0; k < NIT; k++) {
+        const int r = rb + 16 * k;
+        if (r >= rows || c >= 9) continue;
+        if (!cfast) {
+            const uint8_t* row = src_row(s, s.y0 - 3 + r);
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    uint32_t px[2];
+            for (int e = 0; e < 4; e++) {
+                uint32_t px[2];
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int cc = 8 * c + 2 * e + h;
-                        int       xx = x + 2 * e + h;
-                        if (s.w != 0) xx = clampi(xx, 0, s.w - 1);
-                        px[h] = cc < cols ? (uint32_t)rd_px(row, s.highbd, (size_t)0 + (long long)xx) : 0u;
-                    }
-                    v[k][e] = px[0] | (px[1] << 16);
+                for (int h = 0; h < 2; h++) {
+                    const int cc = 8 * c + 2 * e + h;
+                    int       xx = x + 2 * e + h;
+                    if (s.w != 0) xx = clampi(xx, 0, s.w - 1);
+                    px[h] = cc < cols ? (uint32_t)rd_px(row, s.highbd, (size_t)0 + (long long)xx) : 0u;
                 }
+                v[k][e] = px[0] | (px[1] << 16);
             }
-            *(LrRow8A16*)(tile + r * TW + 8 * c) = LrRow8A16{{v[k][0], v[k][1], v[k][2], v[k][3]}};
         }
+        *(LrRow8A16*)(tile + r * TW + 8 * c) = LrRow8A16{{v[k][0], v[k][1], v[k][2], v[k][3]}};
     }
 }
 struct WienerTaps { int16_t fx[8], fy[8]; };
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, c
             else { q[0] = (uint8_t)v0; if (has1) q[1] = (uint8_t)v1; }
         }
     };
-    stage_tile(tile, s, tid);
+    stage_tile<(LR_UR + 6 + 15) / 16>(tile, s, tid);
     __syncthreads();
     if (u.rtype == 1) {
         WienerTaps t;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void lr_block_kernel(const void* src /* origin
         if (highbd) { ((uint16_t*)dst)[o] = (uint16_t)v0; if (has1) ((uint16_t*)dst)[o + 1] = (uint16_t)v1; }
         else { ((uint8_t*)dst)[o] = (uint8_t)v0; if (has1) ((uint8_t*)dst)[o + 1] = (uint8_t)v1; }
     };
-    stage_tile(tile, s, tid);
+    stage_tile<(TH + 15) / 16>(tile, s, tid);
     __syncthreads();
     if (kind == 0) {
         wiener_tile(tile, mid, taps, s.uw, s.uh, bd, tid, store);

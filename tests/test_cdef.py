@@ -16,7 +16,7 @@ def synth_plane(g, w, h, bd):
     return np.clip(base + g.integers(-(1 << (bd - 6)), (1 << (bd - 6)) + 1, (h, w)), 0, (1 << bd) - 1)
 
 
-def run_frame(be, oracle, mode, recon, source, xdec, ydec, pli, bd, skip, pri, sec, dir_in, var_in, sub=1, damping=5):
+def run_frame(be, oracle, mode, recon, source, xdec, ydec, pli, bd, skip, pri, sec, dir_in, var_in, sub=1, damping=5, dev_mode=None):
     is16 = bd > 8
     dt = np.uint16 if is16 else np.uint8
     h, w = recon.shape
@@ -38,7 +38,7 @@ def run_frame(be, oracle, mode, recon, source, xdec, ydec, pli, bd, skip, pri, s
     d_mse = be.empty(max(nfb * max(ncand, 1), 1), np.uint64)
     P = be.pkg.CdefParams(be.ptr(d_rec), be.ptr(d_src), be.ptr(d_out), w, w, w, w, h, xdec, ydec, pli, int(is16), bd - 8, damping, damping, sub, ncand,
                           be.ptr(d_skip), be.ptr(d_pri), be.ptr(d_sec), be.ptr(d_dir), be.ptr(d_var), be.ptr(d_mse))
-    be.lib.svt_hip_cdef_frame(mode, C.byref(P), be.stream)
+    be.lib.svt_hip_cdef_frame(mode if dev_mode is None else dev_mode, C.byref(P), be.stream)
     g_out, g_dir, g_var, g_mse = be.host(d_out), be.host(d_dir), be.host(d_var), be.host(d_mse)
     if pli == 0:
         assert np.array_equal(g_dir, o_dir), np.nonzero(g_dir != o_dir)[0][:10]
@@ -69,6 +69,7 @@ def test_cdef_frame_apply_and_search(be, oracle, bd, damping):
         apri = np.where(g.random(nfb) < 0.2, 0, 4).astype(np.int32)
         asec = np.where(apri == 0, (g.random(nfb) < 0.5) * 1, 2).astype(np.int32)  # level 0 with a secondary strength filters along dir 0
         run_frame(be, oracle, 0, luma, src_l, 0, 0, 0, bd, skip, apri, asec, dir0, var0, damping=damping)
+        run_frame(be, oracle, 0, luma, src_l, 0, 0, 0, bd, skip, apri, asec, d, v, damping=damping, dev_mode=2)  # apply with the search pass's directions
         # chroma 4:2:0 uses the luma directions
         cw, ch = W // 2, H // 2
         chroma = synth_plane(g, cw, ch, bd)
