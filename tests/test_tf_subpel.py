@@ -1,0 +1,92 @@
+"""Temporal filter sub-pel refinement (temporal_filtering.c:1560-2250): the luma motion compensation (8-tap regular / bilinear,
+svt_aom_simple_luma_unipred) + block variance + the half / quarter / eighth-pel rings with their early exits.
+  * oracle (oracle/oracle_tf_subpel.c) pinned against the reference's own svt_aom_simple_luma_unipred and (static) tf_subpel_search, compiled where they lie
+    through oracle/ref_wrap/ref_tf_subpel.c;
+  * device: svt_hip_tf_subpel_search_batch vs the oracle (emulator here, MI355X with -m gpu)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REF_LIB, ROOT, load_pkg, p, rng
+
+REF_ME_LIB = os.path.join(ROOT, "oracle", "_ref", "libsvtref_me.so")
+
+
+class SubpelParams(C.Structure):
+    _fields_ = [("half_pel_mode", C.c_uint8), ("quarter_pel_mode", C.c_uint8), ("eight_pel_mode", C.c_uint8), ("subsampling_shift", C.c_uint8),
+                ("bit_depth", C.c_uint8), ("pad", C.c_uint8 * 3), ("early_exit_th", C.c_uint32), ("mi_rows", C.c_uint32), ("mi_cols", C.c_uint32),
+                ("ref_org_x", C.c_uint32), ("ref_org_y", C.c_uint32), ("ref_stride", C.c_uint32)]
+
+
+def make_pictures(g, W, H, PAD, bd, shift=(3, 2)):
+    """source picture + padded reference = the source displaced by a fractional amount (smooth content so that sub-pel positions matter) + noise"""
+    yy, xx = np.mgrid[0:H + 2 * PAD, 0:W + 2 * PAD].astype(np.float64)
+    amp = (1 << bd) - 1
+    tex = lambda x, y: 0.5 + 0.22 * np.sin(x / 3.1) * np.cos(y / 4.3) + 0.2 * np.sin((x + 2 * y) / 7.7) + 0.05 * np.sin(x * 1.9)  # noqa: E731
+    ref = np.clip(tex(xx, yy) * amp + g.normal(0, amp / 200, xx.shape), 0, amp)
+    src = np.clip(tex(xx[PAD:PAD + H, PAD:PAD + W] + shift[0] + 0.375, yy[PAD:PAD + H, PAD:PAD + W] + shift[1] - 0.25) * amp + g.normal(0, amp / 200, (H, W)), 0, amp)
+    dt = np.uint16 if bd > 8 else np.uint8
+    return np.ascontiguousarray(src.astype(dt)), np.ascontiguousarray(ref.astype(dt))
+
+
+def params(mode, ss, bd, th, W, H, PAD, stride):
+    P = SubpelParams()
+    P.half_pel_mode, P.quarter_pel_mode, P.eight_pel_mode = mode
+    P.subsampling_shift, P.bit_depth, P.early_exit_th = ss, bd, th
+    P.mi_rows, P.mi_cols, P.ref_org_x, P.ref_org_y, P.ref_stride = H // 4, W // 4, PAD, PAD, stride
+    return P
+
+
+CASES = [((1, 1, 1), 0, 0), ((1, 1, 0), 1, 0), ((2, 2, 2), 0, 0), ((1, 2, 0), 1, 35), ((1, 0, 0), 0, 3), ((2, 1, 1), 1, 0)]
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_tf_subpel_oracle_vs_reference(oracle, ref, bd):
+    if not os.path.exists(REF_ME_LIB):
+        pytest.skip("oracle/_ref/libsvtref_me.so not available")
+    ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))
+    ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
+    C.CDLL(REF_LIB, mode=C.RTLD_GLOBAL)
+    refme = C.CDLL(REF_ME_LIB)
+    g = rng(600 + bd)
+    W, H, PAD = 192, 128, 80
+    stride = W + 2 * PAD
+    src, refp = make_pictures(g, W, H, PAD, bd)
+    dt = src.dtype
+    # 1. the prediction alone: every phase pair, block sizes, MVs that reach far outside the picture (clamped), bilinear and regular
+    P = params((1, 1, 1), 0, bd, 0, W, H, PAD, stride)
+    for it in range(160):
+        bsize = (8, 16, 32, 64)[it % 4]
+        pu_x, pu_y = int(g.integers(0, (W - bsize) // 4 + 1)) * 4, int(g.integers(0, (H - bsize) // 4 + 1)) * 4
+        mvx, mvy = (int(g.integers(-40, 41)), int(g.integers(-40, 41))) if it % 5 else (int(g.integers(-3000, 3001)), int(g.integers(-2000, 2001)))
+        if it < 16:
+            mvx, mvy = it % 8 + 8 * (it // 8), 8 - it % 8
+        bil, ss = (it // 3) % 2, (it // 7) % 2
+        a = np.zeros(64 * 64, np.uint16)
+        oracle.oracle_tf_luma_pred(C.byref(P), p(refp), pu_x, pu_y, bsize, mvx, mvy, bil, ss, p(a))
+        b = np.zeros((64, 64), dt)
+        refme.ref_tf_luma_pred(C.byref(P), p(refp), W, H, pu_x, pu_y, bsize, mvx, mvy, bil, ss, p(b))
+        want = b[0:bsize:(1 << ss), :bsize].astype(np.uint16)
+        assert np.array_equal(a[:bsize * (bsize >> ss)].reshape(bsize >> ss, bsize), want), (it, bsize, mvx, mvy, bil, ss)
+    # 2. the search: every ring mode, sub-sampling, early exits, all block sizes, starting MVs near and far from the true displacement
+    n_moved = 0
+    for (mode, ss, th) in CASES:
+        P = params(mode, ss, bd, th, W, H, PAD, stride)
+        for it in range(40):
+            bsize = (64, 32, 16, 8)[it % 4]
+            nb = 64 // bsize
+            sbx, sby = int(g.integers(0, W // 64)) * 64, int(g.integers(0, H // 64)) * 64
+            ix, iy = int(g.integers(0, nb)), int(g.integers(0, nb))
+            start = ((3 + int(g.integers(-1, 2))) * 8, (2 + int(g.integers(-1, 2))) * 8) if it % 3 else (int(g.integers(-6, 7)) * 8, int(g.integers(-6, 7)) * 8)
+            bil = it % 2
+            blk = src[sby:, sbx:]
+            mx1, my1, d1 = C.c_int16(start[0]), C.c_int16(start[1]), C.c_uint64(0x7fffffff)
+            mx2, my2, d2 = C.c_int16(start[0]), C.c_int16(start[1]), C.c_uint64(0x7fffffff)
+            oracle.oracle_tf_subpel_search(C.byref(P), C.c_void_p(blk.ctypes.data + (iy * bsize * W + ix * bsize) * src.itemsize), W, p(refp), sbx + ix * bsize,
+                                           sby + iy * bsize, bsize, bil, C.byref(mx1), C.byref(my1), C.byref(d1))
+            refme.ref_tf_subpel_search(C.byref(P), C.c_void_p(blk.ctypes.data), W, p(refp), W, H, sbx, sby, bsize, ix, iy, bil, C.byref(mx2), C.byref(my2), C.byref(d2))
+            assert (mx1.value, my1.value, d1.value) == (mx2.value, my2.value, d2.value), (mode, ss, th, it, bsize, start)
+            n_moved += (mx1.value, my1.value) != start
+    assert n_moved > 40  # the refinement really moves the vectors

@@ -40,6 +40,7 @@ CASES = {
     "seam_p6_8bit_hook": (256, 144, 8, 8, ["--preset", "6", "--lp", "1", "+seam", "+hook"]),
     "seam_p10_8bit": (448, 264, 10, 8, ["--preset", "10", "--lp", "1", "+seam"]),
     "seam_p2_8bit": (256, 144, 6, 8, ["--preset", "2", "--lp", "1", "+seam"]),
+    "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
     # BASELINE.json metric, second half: encoder fps @1080p preset 8 (C-only reference vs the same encoder with the ME stage on the MI355X), all host cores
     "fps_1080p_p8": (1920, 1080, 24, 8, ["--preset", "8", "+seam"]),
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
