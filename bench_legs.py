@@ -530,6 +530,39 @@ def tf_frames(torch, lib, pkg, stream, steps, warmup):
     return out
 
 
+def tf_subpel(torch, lib, pkg, stream, steps, warmup):
+    """SURVEY 8f rank 4, the temporal filter's sub-pel refinement: one 1080p 8-bit central picture against 6 reference pictures, the preset-8 search shape
+    (64x64 and 32x32 blocks bilinear with tf_ctrls.use_2tap, 16x16 regular; half + quarter pel, no eighth, sub_sampling_shift 1) = 6 x (510 + 2040 + 8160)
+    blocks in one launch.  Compute bound (8-tap separable interpolation): reported as blocks/s and candidate samples/s, not against HBM."""
+    g = np.random.default_rng(17)
+    W, H, PAD, n_refs = 1920, 1088, 80, 6
+    stride, rows = W + 2 * PAD, H + 2 * PAD
+    yy, xx = np.mgrid[0:rows, 0:stride].astype(np.float32)
+    base = (0.5 + 0.25 * np.sin(xx / 3.3) * np.cos(yy / 4.1) + 0.2 * np.sin((xx + 2 * yy) / 9.1)) * 255
+    refs = np.stack([np.clip(np.roll(base, (r - 3, 2 * r - 5), (0, 1)) + g.normal(0, 2, base.shape), 0, 255).astype(np.uint8) for r in range(n_refs)])
+    src = np.ascontiguousarray(np.clip(base[PAD:PAD + H, PAD:PAD + W] + g.normal(0, 2, (H, W)), 0, 255).astype(np.uint8))
+    blocks = [(x, y, b) for b in (64, 32, 16) for y in range(0, H, b) for x in range(0, W, b)]
+    a = np.array(blocks * n_refs)
+    n = len(a)
+    d = np.zeros(n, pkg.TfSubpelDesc)
+    d["pu_x"], d["pu_y"], d["bsize"], d["src_stride"], d["bilinear"] = a[:, 0], a[:, 1], a[:, 2], W, a[:, 2] >= 32
+    d["src_off"] = a[:, 1].astype(np.uint64) * W + a[:, 0].astype(np.uint64)
+    r = np.repeat(np.arange(n_refs), len(blocks))
+    d["ref_off"] = r.astype(np.uint64) * (rows * stride)
+    d["mv_x"], d["mv_y"] = 8 * ((2 * r - 5) + g.integers(-1, 2, n)), 8 * ((r - 3) + g.integers(-1, 2, n))
+    P = pkg.TfSubpelParams()
+    P.half_pel_mode, P.quarter_pel_mode, P.eight_pel_mode, P.subsampling_shift, P.bit_depth = 1, 1, 0, 1, 8
+    P.mi_rows, P.mi_cols, P.ref_org_x, P.ref_org_y, P.ref_stride = H // 4, W // 4, PAD, PAD, stride
+    d_src, d_ref, d_d = _dev(torch, src), _dev(torch, refs), torch.from_numpy(d.view(np.uint8).reshape(-1)).cuda()
+    d_out = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+    t = _time(torch, lambda: lib.svt_hip_tf_subpel_search_batch(C.addressof(P), d_src.data_ptr(), d_ref.data_ptr(), d_d.data_ptr(), n, d_out.data_ptr(), stream),
+              steps, warmup, batches=3)
+    res = d_out.cpu().numpy().view(pkg.TfSubpelResult)
+    cand_px = float(np.sum(a[:, 2].astype(np.float64) ** 2 / 2)) * 17  # 1 + 8 + 8 candidates, every other row
+    return {"tf_subpel_1080p8_6refs": {"us": t * 1e6, "blocks_per_s": n / t, "pictures_per_s": 1 / t, "candidate_Gsamples_per_s": cand_px / t / 1e9,
+                                        "moved_frac": float(np.mean((res["mv_x"] != d["mv_x"]) | (res["mv_y"] != d["mv_y"])))}}
+
+
 def hme_chain(torch, lib, pkg, stream, steps, warmup):
     """The three HME levels of a 1080p picture against 4 references, chained on the device (svt_hip_hme_level_batch x 3: descriptor kernel ->
     svt_hip_sad_loop_batch -> rescale kernel per level): level 0 on the 1/16-area planes (2 x 2 regions of 16x16), levels 1 and 2 with 8x3 areas

@@ -434,6 +434,41 @@ typedef struct SvtHipTfPlanes {
 void svt_hip_tf_filter_frame(const SvtHipTfParams *params, const SvtHipTfPlanes *central, const SvtHipTfPlanes *preds, uint32_t n_refs,
                              const SvtHipTfBlock *blocks, uint32_t nbx, uint32_t nby, const SvtHipTfPlanes *out, void *stream);
 
+/* The temporal filter's sub-pel motion refinement, batched: replaces tf_subpel_search + svt_check_position (temporal_filtering.c:1560-1790) as
+ * tf_64x64_sub_pel_search / tf_32x32_ / tf_16x16_ / tf_8x8_sub_pel_search (:1793-2250) call it for each block of a (central picture, reference
+ * picture) pair.  Per block: the centre (predicted on the sub-sampled rows), then the half-, quarter- and eighth-pel rings around the running
+ * best MV; each candidate = luma motion compensation (svt_aom_simple_luma_unipred: MV clamped to picture + border, EIGHTTAP_REGULAR or
+ * bilinear kernels, the svt_av1_[highbd_]convolve_*_sr_c roundings) + svt_aom_mefn_ptr[bsize].vf / vf_hbd_10 against the source on every
+ * (1 << subsampling_shift)-th row, << subsampling_shift; the reference's skip rules (mode >= 2: no diagonals; best == 0; early_exit_th) apply
+ * in its order (x offset outer loop).  Blocks start from distortion INT_MAX like the callers (:1866, :1980, :2117).  All pointers device;
+ * samples u8 (bit_depth 8) or u16 (10).  One wave per block; the result is bit-exact with the reference's (dist, mv_x, mv_y). */
+typedef struct SvtHipTfSubpelParams {
+    uint8_t  half_pel_mode, quarter_pel_mode, eight_pel_mode; /* pcs->tf_ctrls.*: 0 = off, 1 = all 8 neighbours, >= 2 = no diagonals */
+    uint8_t  subsampling_shift;                               /* pcs->tf_ctrls.sub_sampling_shift */
+    uint8_t  bit_depth;                                       /* 8 or 10 */
+    uint8_t  pad[3];
+    uint32_t early_exit_th;                                   /* me_ctx->tf_subpel_early_exit_th (0 = off) */
+    uint32_t mi_rows, mi_cols;                                /* pcs->av1_cm->mi_rows / mi_cols (MV clamp) */
+    uint32_t ref_org_x, ref_org_y, ref_stride;                /* reference pictures: padding origin and stride (samples) */
+} SvtHipTfSubpelParams;
+typedef struct SvtHipTfSubpelDesc {
+    uint64_t src_off;    /* samples from src_base to the block's top-left source sample */
+    uint64_t ref_off;    /* samples from ref_base to this block's reference picture's buffer_y (the padded plane's first sample) */
+    uint32_t src_stride; /* samples */
+    uint16_t pu_x, pu_y; /* block origin in the picture (luma samples) */
+    uint8_t  bsize;      /* 8, 16, 32 or 64 (square) */
+    uint8_t  bilinear;   /* me_ctx->tf_ctrls.use_2tap for the 64x64 / 32x32 searches (:1801-1804, :1911-1914): BILINEAR; 16x16 and 8x8 always EIGHTTAP_REGULAR */
+    int16_t  mv_x, mv_y; /* starting MV, 1/8 pel (the integer ME vector << 3) */
+    uint16_t pad;
+} SvtHipTfSubpelDesc;
+typedef struct SvtHipTfSubpelResult {
+    uint64_t dist;       /* best distortion (tf_*_block_error) */
+    int16_t  mv_x, mv_y; /* best MV, 1/8 pel */
+    uint32_t pad;
+} SvtHipTfSubpelResult;
+void svt_hip_tf_subpel_search_batch(const SvtHipTfSubpelParams *params, const void *src_base, const void *ref_base, const SvtHipTfSubpelDesc *descs,
+                                    uint32_t n, SvtHipTfSubpelResult *results, void *stream);
+
 /* The whole open-loop ME stage from a HOST picture: upload -> quarter / sixteenth planes (made once per picture on the device, kept in the ring
  * with the full plane) -> HME levels 0-2 -> final search centre + integer_search_b64 geometry + full-pel search -> MeSbResults (+ raw tables on
  * request) -> download, on the submission's own stream like svt_hip_me_session_submit.  svt_hip_me_session_enable_stage sizes the extra

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "svt_hip_estimate_noise_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "svt_hip_estimate_noise_batch": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_tf_filter_frame": (None, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp]),
+    "svt_hip_tf_subpel_search_batch": (None, [vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svt_hip_sad_nxm_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_sad_loop_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -258,6 +259,20 @@ class TfParams(C.Structure):
 assert C.sizeof(TfParams) == 20
 TfBlock = np.dtype([("block_error", "<u8", (4,)), ("mv_x", "<i2", (4,)), ("mv_y", "<i2", (4,)), ("split", "u1"), ("pad", "u1", (7,))])
 assert TfBlock.itemsize == 56
+
+
+class TfSubpelParams(C.Structure):
+    """SvtHipTfSubpelParams: the picture-level inputs of tf_subpel_search (temporal_filtering.c:1670)."""
+    _fields_ = [("half_pel_mode", C.c_uint8), ("quarter_pel_mode", C.c_uint8), ("eight_pel_mode", C.c_uint8), ("subsampling_shift", C.c_uint8),
+                ("bit_depth", C.c_uint8), ("pad", C.c_uint8 * 3), ("early_exit_th", C.c_uint32), ("mi_rows", C.c_uint32), ("mi_cols", C.c_uint32),
+                ("ref_org_x", C.c_uint32), ("ref_org_y", C.c_uint32), ("ref_stride", C.c_uint32)]
+
+
+assert C.sizeof(TfSubpelParams) == 32
+TfSubpelDesc = np.dtype([("src_off", "<u8"), ("ref_off", "<u8"), ("src_stride", "<u4"), ("pu_x", "<u2"), ("pu_y", "<u2"), ("bsize", "u1"), ("bilinear", "u1"),
+                         ("mv_x", "<i2"), ("mv_y", "<i2"), ("pad", "<u2")])
+TfSubpelResult = np.dtype([("dist", "<u8"), ("mv_x", "<i2"), ("mv_y", "<i2"), ("pad", "<u4")])
+assert TfSubpelDesc.itemsize == 32 and TfSubpelResult.itemsize == 16
 
 
 class TfPlanes(C.Structure):

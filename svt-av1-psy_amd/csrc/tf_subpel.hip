@@ -1,0 +1,271 @@
+// tf_subpel.hip -- the temporal filter's sub-pel motion refinement, batched (the caller of the ME_MCTF search).
+//
+// Reference: tf_subpel_search + svt_check_position (Source/Lib/Codec/temporal_filtering.c:1560-1790), called by tf_{64x64,32x32,16x16,8x8}_sub_pel_search
+// (:1793-2250) for every block of every (central picture, reference picture) pair.  A block's refinement is independent of every other block: starting from
+// the integer ME vector (<< 3, 1/8 pel) it evaluates the centre, then the half-, quarter- and eighth-pel rings around the running best -- each candidate =
+// luma motion compensation (svt_aom_simple_luma_unipred: MV clamped to the picture + border, 8-tap EIGHTTAP_REGULAR or bilinear kernels, the
+// svt_av1_[highbd_]convolve_{2d,x,y,2d_copy}_sr_c roundings, inter_prediction.c:311-420, 737-790) + the block's variance against the source
+// (svt_aom_varianceWxH_c / svt_aom_highbd_10_varianceWxH_c on every (1 << sub_sampling_shift)-th row) -- with the early exits of svt_check_position.
+//
+// Mapping: ONE WAVE per block (four blocks per workgroup).  The candidate loop is sequential and data dependent, but wave-uniform: the 64 lanes split the
+// block's pixels, the distortion is a wave reduction, the accept / early-exit decisions are scalar.  The horizontally filtered intermediate of the 2-D
+// case ((rows + 7) x W int16, rounded exactly as the reference's im_block) lives in the wave's private LDS slice; nothing is written to memory but the
+// winner.  Only the prediction rows the variance reads are produced (the reference predicts all rows of a non-centre candidate and then reads every
+// other one when sub-sampling is on).
+#include "svt_hip_common.h"
+#include "../../include/svtav1_hip.h"
+
+namespace {
+
+// av1 sub_pel_filters_8 (EIGHTTAP_REGULAR), sub_pel_filters_4 (block dimension <= 4: inter_prediction.h:147-153) -- inter_prediction.c:205-254; bilinear =
+// {128 - 8p, 8p} at taps 3, 4.  Phase 0 (the tap 128) is never evaluated: a zero phase selects the copy / one-directional kernels instead.
+constexpr int8_t kReg8[16][8] = {{0, 0, 0, 0, 0, 0, 0, 0},        {0, 2, -6, 126, 8, -2, 0, 0},    {0, 2, -10, 122, 18, -4, 0, 0},  {0, 2, -12, 116, 28, -8, 2, 0},
+                                 {0, 2, -14, 110, 38, -10, 2, 0}, {0, 2, -14, 102, 48, -12, 2, 0}, {0, 2, -16, 94, 58, -12, 2, 0},  {0, 2, -14, 84, 66, -14, 2, 0},
+                                 {0, 2, -14, 76, 76, -14, 2, 0},  {0, 2, -14, 66, 84, -14, 2, 0},  {0, 2, -12, 58, 94, -16, 2, 0},  {0, 2, -12, 48, 102, -14, 2, 0},
+                                 {0, 2, -10, 38, 110, -14, 2, 0}, {0, 2, -8, 28, 116, -12, 2, 0},  {0, 0, -4, 18, 122, -10, 2, 0},  {0, 0, -2, 8, 126, -6, 2, 0}};
+constexpr int8_t kReg4[16][8] = {{0, 0, 0, 0, 0, 0, 0, 0},       {0, 0, -4, 126, 8, -2, 0, 0},    {0, 0, -8, 122, 18, -4, 0, 0},   {0, 0, -10, 116, 28, -6, 0, 0},
+                                 {0, 0, -12, 110, 38, -8, 0, 0}, {0, 0, -12, 102, 48, -10, 0, 0}, {0, 0, -14, 94, 58, -10, 0, 0},  {0, 0, -12, 84, 66, -10, 0, 0},
+                                 {0, 0, -12, 76, 76, -12, 0, 0}, {0, 0, -10, 66, 84, -12, 0, 0},  {0, 0, -10, 58, 94, -14, 0, 0},  {0, 0, -10, 48, 102, -12, 0, 0},
+                                 {0, 0, -8, 38, 110, -12, 0, 0}, {0, 0, -6, 28, 116, -10, 0, 0},  {0, 0, -4, 18, 122, -8, 0, 0},   {0, 0, -2, 8, 126, -4, 0, 0}};
+// the taps of one (kernel, phase), packed for the dot instructions: b4 = four signed bytes per dword, h2 = two signed halves per dword; for the bilinear
+// kernel only taps 3 and 4 are stored (b4[0] bytes 0-1, h2[0])
+struct PackedTaps { uint32_t b4[2], h2[4]; };
+struct TapTables { PackedTaps t[3][16]; }; // [regular 8 | regular 4 | bilinear][phase]
+constexpr TapTables make_tap_tables() {
+    TapTables T{};
+    for (int kind = 0; kind < 2; kind++)
+        for (int p = 0; p < 16; p++) {
+            for (int k = 0; k < 8; k++) {
+                const int f = kind ? kReg4[p][k] : kReg8[p][k];
+                T.t[kind][p].b4[k >> 2] |= (uint32_t)(f & 0xff) << (8 * (k & 3));
+                T.t[kind][p].h2[k >> 1] |= (uint32_t)(f & 0xffff) << (16 * (k & 1));
+            }
+        }
+    for (int p = 1; p < 16; p++) {
+        T.t[2][p].b4[0] = (uint32_t)(128 - 8 * p) | ((uint32_t)(8 * p) << 8);
+        T.t[2][p].h2[0] = (uint32_t)(128 - 8 * p) | ((uint32_t)(8 * p) << 16);
+    }
+    return T;
+}
+__device__ constexpr TapTables kTaps = make_tap_tables();
+__device__ __forceinline__ int tap_of(const PackedTaps& t, const int k) { return (int)(int16_t)(t.h2[k >> 1] >> (16 * (k & 1))); } // tap T0 + k
+
+__device__ __forceinline__ int rpot(const int v, const int n) { return n ? (v + (1 << (n - 1))) >> n : v; }
+
+// sum over each row of 16 lanes (4 DPP steps), then the four row sums through SGPRs: no LDS round trips on the per-candidate critical path
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false); // row_ror:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); // row_ror:8
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(const int v) {
+    const int r = (int)row16_sum((uint32_t)v);
+    return __builtin_amdgcn_readlane(r, 0) + __builtin_amdgcn_readlane(r, 16) + __builtin_amdgcn_readlane(r, 32) + __builtin_amdgcn_readlane(r, 48);
+}
+__device__ __forceinline__ unsigned long long wave_sum_u32_wide(const uint32_t v) { // each row's sum must fit 32 bits, the total need not
+    const int r = (int)row16_sum(v);
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(r, 0) + (uint32_t)__builtin_amdgcn_readlane(r, 16) + (uint32_t)__builtin_amdgcn_readlane(r, 32) +
+           (uint32_t)__builtin_amdgcn_readlane(r, 48);
+}
+
+__device__ __forceinline__ int sdot2(const uint32_t a, const uint32_t b, const int c) { // c + a.lo * b.lo + a.hi * b.hi, signed 16 bit (v_dot2_i32_i16)
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    s2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    return __builtin_amdgcn_sdot2(x, y, c, false);
+}
+struct __attribute__((packed, aligned(1))) u16_a1 { uint16_t x; };
+struct __attribute__((packed, aligned(1))) u32_a1 { uint32_t x; };
+struct __attribute__((packed, aligned(1))) u32x2_a1 { uint32_t x, y; };
+struct __attribute__((packed, aligned(1))) u32x4_a1 { uint32_t x, y, z, w; };
+
+// sum over the NT taps of tap * sample for the samples starting at q (= the first evaluated tap's sample), one unaligned load:
+// 8 bit: v_dot4_i32_i8 on (sample - 128) -- every AV1 kernel's taps sum to 128, so the bias is the constant 128 * 128; 10 bit: v_dot2_i32_i16
+template <int NT> __device__ __forceinline__ int hsum(const uint8_t* q, const PackedTaps& t) {
+    if (NT == 8) {
+        const u32x2_a1 v = *reinterpret_cast<const u32x2_a1*>(q);
+        return __builtin_amdgcn_sdot4((int)(v.x ^ 0x80808080u), (int)t.b4[0], __builtin_amdgcn_sdot4((int)(v.y ^ 0x80808080u), (int)t.b4[1], 16384, false), false);
+    }
+    const uint32_t v = reinterpret_cast<const u16_a1*>(q)->x;
+    return __builtin_amdgcn_sdot4((int)(v ^ 0x8080u), (int)t.b4[0], 16384, false);
+}
+template <int NT> __device__ __forceinline__ int hsum(const uint16_t* q, const PackedTaps& t) {
+    if (NT == 8) {
+        const u32x4_a1 v = *reinterpret_cast<const u32x4_a1*>(q);
+        return sdot2(v.x, t.h2[0], sdot2(v.y, t.h2[1], sdot2(v.z, t.h2[2], sdot2(v.w, t.h2[3], 0))));
+    }
+    return sdot2(reinterpret_cast<const u32_a1*>(q)->x, t.h2[0], 0);
+}
+
+// distortion of one candidate MV (1/8 pel) for the block; every lane returns the same value.  NT = 8: the regular kernels (taps 0..7 around x - 3);
+// NT = 2: bilinear, whose only non-zero taps are 3 and 4 (x, x + 1)
+template <typename PIX, int NT>
+__device__ unsigned long long candidate_dist(const SvtHipTfSubpelParams& P, const SvtHipTfSubpelDesc& d, const PIX* __restrict__ src, const PIX* __restrict__ refy,
+                                             const int mvx, const int mvy, const int pss, uint32_t* __restrict__ imp, const int l) {
+    constexpr bool HBD = sizeof(PIX) == 2;
+    const int W = d.bsize, ss = P.subsampling_shift, bd = HBD ? P.bit_depth : 8;
+    const int nrows = W >> ss;                  // prediction rows the variance reads
+    const int rstep = pss ? 1 : (1 << ss);      // ... every rstep-th row of this candidate's prediction
+    const int rmul  = 1 << pss;                 // the centre is predicted with the reference stride doubled (tf_inter_predictor: src_stride << shift)
+    const int hpred = pss ? nrows : W;          // block height svt_inter_predictor sees (selects the 4-tap kernel when <= 4)
+    // clamp_mv_to_umv_border_sb (enc_inter_prediction.c:30-50) in 1/16 pel
+    const int bmi = W >> 2, mirow = d.pu_y >> 2, micol = d.pu_x >> 2;
+    const int to_top = -((mirow * 4) * 8), to_bottom = (((int)P.mi_rows - bmi - mirow) * 4) * 8, to_left = -((micol * 4) * 8), to_right = (((int)P.mi_cols - bmi - micol) * 4) * 8;
+    const int spel_l = (4 + W) << 4, spel_r = spel_l - 16;
+    int row = (int16_t)(mvy * 2), col = (int16_t)(mvx * 2);
+    const int min_col = to_left * 2 - spel_l, max_col = to_right * 2 + spel_r, min_row = to_top * 2 - spel_l, max_row = to_bottom * 2 + spel_r;
+    col = col < min_col ? min_col : (col > max_col ? max_col : col);
+    row = row < min_row ? min_row : (row > max_row ? max_row : row);
+    col = (int16_t)col; row = (int16_t)row;
+    const int  sx = col & 15, sy = row & 15;
+    const long rs = (long)P.ref_stride;
+    const PIX* p0 = refy + P.ref_org_x + (long)P.ref_org_y * rs + (d.pu_x + (col >> 4)) + (long)(d.pu_y + (row >> 4)) * rs;
+    const long rsm = rs * rmul; // row stride between consecutive rows of this candidate's prediction
+    int r0 = 3, r1 = 11;        // get_conv_params_no_round (convolve.h:40-64)
+    if (bd + 7 - r0 + 2 > 16) { r1 -= bd + 7 - r0 + 2 - 16; r0 += bd + 7 - r0 + 2 - 16; }
+    const int mx = (1 << bd) - 1;
+    constexpr int T0 = NT == 8 ? 0 : 3; // first tap evaluated
+    const PackedTaps tx = kTaps.t[NT == 2 ? 2 : 0][sx], ty = kTaps.t[NT == 2 ? 2 : (hpred <= 4 ? 1 : 0)][sy]; // (W >= 8: never the 4-tap kernel horizontally)
+    const int lw = 31 - __clz(W); // log2 W
+    int      sum_l = 0; // per lane: <= 64 samples of |diff| <= 1023 -> both fit 32 bits
+    uint32_t sse_l = 0;
+    const int offset_bits = bd + 14 - r0, npx = nrows * W;
+    const uint32_t urs = (uint32_t)rsm, sstep = (uint32_t)d.src_stride << ss;
+    auto finish = [&](const int i, int px) {
+        px = px < 0 ? 0 : (px > mx ? mx : px);
+        const int diff = px - (int)src[(uint32_t)(i >> lw) * sstep + (uint32_t)(i & (W - 1))];
+        sum_l += diff;
+        sse_l += (uint32_t)(diff * diff);
+    };
+    // the four kernels of svt_av1_[highbd_]convolve_{2d_copy,x,y,2d}_sr_c; the choice is wave-uniform, offsets are unsigned from a per-candidate base
+    if (!sx && !sy) {
+        for (int i = l; i < npx; i += 64) finish(i, (int)p0[(uint32_t)((i >> lw) * rstep) * urs + (uint32_t)(i & (W - 1))]);
+    } else if (!sy) {
+        const PIX* pb = p0 - 3 + T0;
+        for (int i = l; i < npx; i += 64) {
+            const uint32_t o = (uint32_t)((i >> lw) * rstep) * urs + (uint32_t)(i & (W - 1));
+            finish(i, rpot(rpot(hsum<NT>(pb + o, tx), r0), 7 - r0));
+        }
+    } else if (!sx) {
+        const PIX* pb = p0 - (long)(3 - T0) * rsm;
+        for (int i = l; i < npx; i += 64) {
+            const uint32_t o = (uint32_t)((i >> lw) * rstep) * urs + (uint32_t)(i & (W - 1));
+            int            s = 0;
+#pragma unroll
+            for (int k = 0; k < NT; k++) s += tap_of(ty, k) * (int)(pb + o)[(long)k * rsm];
+            finish(i, rpot(s, 7));
+        }
+    } else {
+        // horizontal pass of every row a needed output row touches -> im, rounded like the reference's im_block (int16); im row y <-> prediction row
+        // y - 3 + T0.  A lane filters rows 2m and 2m + 1 at one x and stores them as ONE dword, so that the vertical pass is v_dot2_i32_i16 on row pairs.
+        const PIX* pb     = p0 - (long)(3 - T0) * rsm - 3 + T0;
+        const int  imrows = (nrows - 1) * rstep + NT, npairs = (imrows + 1) >> 1;
+        for (int i = l; i < (npairs << lw); i += 64) {
+            const int      m = i >> lw;
+            const uint32_t o = (uint32_t)(2 * m) * urs + (uint32_t)(i & (W - 1));
+            const int      a = rpot(hsum<NT>(pb + o, tx) + (1 << (bd + 6)), r0);
+            const int      b = 2 * m + 1 < imrows ? rpot(hsum<NT>(pb + o + rsm, tx) + (1 << (bd + 6)), r0) : 0; // (never read; keeps the loads inside the rows the reference reads)
+            imp[i] = (uint32_t)(a & 0xffff) | ((uint32_t)b << 16);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int sub = (1 << (offset_bits - r1)) + (1 << (offset_bits - r1 - 1));
+        for (int i = l; i < npx; i += 64) {
+            const int       y = (i >> lw) * rstep;
+            const uint32_t* c = imp + ((y >> 1) << lw) + (i & (W - 1));
+            const uint32_t  sh = (uint32_t)(y & 1) << 4; // odd rows: the pair (y, y + 1) straddles two stored pairs
+            int             s = 1 << offset_bits;
+            uint32_t        lo = c[0];
+#pragma unroll
+            for (int j = 0; j < NT / 2; j++) {
+                const uint32_t hi = c[(j + 1) << lw];
+                s  = sdot2(__builtin_amdgcn_alignbit(hi, lo, sh), ty.h2[j], s);
+                lo = hi;
+            }
+            int res = rpot(s, r1) - sub;
+            if (!HBD) res = (int16_t)res; // the 8-bit kernel narrows to ConvBufType first (inter_prediction.c:345)
+            finish(i, rpot(res, 14 - r0 - r1));
+        }
+        __builtin_amdgcn_wave_barrier(); // the slice is rewritten by the next candidate
+    }
+    const long long          sum = wave_sum_i32(sum_l);        // |total| <= 4096 * 1023
+    const unsigned long long sse = wave_sum_u32_wide(sse_l);   // a row of 16 lanes: <= 1024 * 1023^2
+    const int                ln  = 2 * lw - ss; // log2(W * nrows): the reference's division by the sample count is a shift of a non-negative square
+    unsigned long long var;
+    if (!HBD) {
+        const uint32_t s32 = (uint32_t)sse;
+        const int      su  = (int)sum;
+        var = (uint32_t)(s32 - (uint32_t)(((long long)su * su) >> ln)); // svt_aom_varianceWxH_c (variance.c:300-306)
+    } else { // highbd_10_variance (svt_psnr.c:160-177)
+        const uint32_t s32 = (uint32_t)((sse + 8) >> 4);
+        const int      su  = (int)((sum + 2) >> 2);
+        const long long v  = (long long)s32 - (((long long)su * su) >> ln);
+        var = v >= 0 ? (uint32_t)v : 0;
+    }
+    return var << ss;
+}
+
+constexpr int kSlice = 36 * 64; // dwords
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void tf_subpel_kernel(const SvtHipTfSubpelParams P, const PIX* __restrict__ src_base, const PIX* __restrict__ ref_base,
+                                                        const SvtHipTfSubpelDesc* __restrict__ descs, const uint32_t n, SvtHipTfSubpelResult* __restrict__ out) {
+    HIP_DYNAMIC_SHARED(uint32_t, smem)
+    const int      l = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t item = blockIdx.x * 4 + (uint32_t)wv;
+    if (item >= n) return;
+    uint32_t* im = smem + wv * kSlice; // the wave's private intermediate: (rows + 7 + 1) / 2 row pairs x 64 columns
+    const SvtHipTfSubpelDesc d = descs[item];
+    const PIX* src  = src_base + d.src_off;
+    const PIX* refy = ref_base + d.ref_off;
+    const int  hbd = sizeof(PIX) == 2, ss = P.subsampling_shift;
+    unsigned long long best = 0x7fffffffull; // INT_MAX: the callers' starting distortion (temporal_filtering.c:1866, :1980, :2117)
+    int16_t bx = d.mv_x, by = d.mv_y;
+    const int modes[4] = {P.half_pel_mode, P.half_pel_mode, P.quarter_pel_mode, P.eight_pel_mode};
+#pragma unroll 1
+    for (int ring = 0; ring < 4; ring++) { // centre, half, quarter, eighth (tf_subpel_search :1670-1790)
+        if (ring && !modes[ring]) continue;
+        const int16_t base_x = bx, base_y = by;
+        const int     st = ring == 0 ? 0 : (8 >> ring);
+#pragma unroll 1
+        for (int c = 0; c < (ring ? 9 : 1); c++) {
+            const int i = ring ? (c / 3 - 1) * st : 0, j = ring ? (c % 3 - 1) * st : 0; // xd outer, yd inner
+            if (ring && i == 0 && j == 0) continue;
+            // svt_check_position (:1561-1664)
+            if (modes[ring] >= 2 && i != 0 && j != 0) continue;
+            if (best == 0) continue;
+            if (P.early_exit_th && best < (((unsigned long long)(d.bsize * d.bsize) * P.early_exit_th) << hbd)) continue;
+            const int16_t cx = (int16_t)(base_x + i), cy = (int16_t)(base_y + j);
+            const int                pss  = (i == 0 && j == 0) ? ss : 0;
+            const unsigned long long dist = d.bilinear ? candidate_dist<PIX, 2>(P, d, src, refy, cx, cy, pss, im, l) : candidate_dist<PIX, 8>(P, d, src, refy, cx, cy, pss, im, l);
+            if (dist < best) { best = dist; bx = cx; by = cy; }
+        }
+    }
+    if (l == 0) {
+        SvtHipTfSubpelResult r;
+        r.dist = best; r.mv_x = bx; r.mv_y = by; r.pad = 0;
+        out[item] = r;
+    }
+}
+
+} // namespace
+
+extern "C" void svt_hip_tf_subpel_search_batch(const SvtHipTfSubpelParams* params, const void* src_base, const void* ref_base, const SvtHipTfSubpelDesc* descs, uint32_t n,
+                                               SvtHipTfSubpelResult* results, void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    if (params->bit_depth != 8 && params->bit_depth != 10) {
+        fprintf(stderr, "libsvtav1_hip: svt_hip_tf_subpel_search_batch: bit depth %d (8 and 10 are what svt_aom_mefn_ptr[].vf / vf_hbd_10 cover)\n", params->bit_depth);
+        abort();
+    }
+    const size_t shm = (size_t)4 * kSlice * 4;
+    if (params->bit_depth > 8)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_subpel_kernel<uint16_t>), dim3((n + 3) / 4), dim3(256), shm, (hipStream_t)stream, *params, (const uint16_t*)src_base,
+                           (const uint16_t*)ref_base, descs, n, results);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_subpel_kernel<uint8_t>), dim3((n + 3) / 4), dim3(256), shm, (hipStream_t)stream, *params, (const uint8_t*)src_base,
+                           (const uint8_t*)ref_base, descs, n, results);
+    SVT_LAUNCH_CHECK();
+}

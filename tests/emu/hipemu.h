@@ -279,6 +279,7 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 inline int      __builtin_amdgcn_readfirstlane(int v) { return (int)hipemu::wave_xchg((uint32_t)v, 0); }
+inline int      __builtin_amdgcn_readlane(int v, int lane) { return (int)hipemu::wave_xchg((uint32_t)v, lane); }
 inline int      __builtin_amdgcn_ds_bpermute(int addr, int v) { return (int)hipemu::wave_xchg((uint32_t)v, (addr >> 2) & 63); }
 inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned, unsigned) { return 0; }
 inline unsigned __lane_id() { return hipemu::lane_id(); }
@@ -410,6 +411,10 @@ inline hipemu_u2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src0, 
 }
 inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) { // v_dot4_u32_u8
     for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xff) * ((b >> (8 * i)) & 0xff);
+    return c;
+}
+inline int __builtin_amdgcn_sdot4(int a, int b, int c, bool) { // v_dot4_i32_i8
+    for (int i = 0; i < 4; i++) c += (int)(int8_t)((unsigned)a >> (8 * i)) * (int)(int8_t)((unsigned)b >> (8 * i));
     return c;
 }
 inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned sel) {

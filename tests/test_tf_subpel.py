@@ -90,3 +90,100 @@ def test_tf_subpel_oracle_vs_reference(oracle, ref, bd):
             assert (mx1.value, my1.value, d1.value) == (mx2.value, my2.value, d2.value), (mode, ss, th, it, bsize, start)
             n_moved += (mx1.value, my1.value) != start
     assert n_moved > 40  # the refinement really moves the vectors
+
+
+def subpel_batch(g, pkg, src, W, H, n, far_every=3):
+    """n random block descriptors over one source picture (all four block sizes, both filters, starting MVs near / far from the true displacement)"""
+    d = np.zeros(n, pkg.TfSubpelDesc)
+    for i in range(n):
+        bsize = (64, 32, 16, 8)[i % 4]
+        x, y = int(g.integers(0, W // bsize)) * bsize, int(g.integers(0, H // bsize)) * bsize
+        d[i]["src_off"], d[i]["src_stride"], d[i]["pu_x"], d[i]["pu_y"], d[i]["bsize"], d[i]["bilinear"] = y * W + x, W, x, y, bsize, (i // 4) % 2
+        near = ((3 + int(g.integers(-1, 2))) * 8, (2 + int(g.integers(-1, 2))) * 8)
+        d[i]["mv_x"], d[i]["mv_y"] = near if i % far_every else (int(g.integers(-40, 41)) * 8, int(g.integers(-30, 31)) * 8)
+    return d
+
+
+def oracle_subpel(oracle, P, src, refp, descs):
+    out = np.zeros(len(descs), [("dist", "<u8"), ("mv_x", "<i2"), ("mv_y", "<i2")])
+    for i, d in enumerate(descs):
+        mx, my, dist = C.c_int16(int(d["mv_x"])), C.c_int16(int(d["mv_y"])), C.c_uint64(0x7fffffff)
+        oracle.oracle_tf_subpel_search(C.byref(P), C.c_void_p(src.ctypes.data + int(d["src_off"]) * src.itemsize), int(d["src_stride"]),
+                                       C.c_void_p(refp.ctypes.data + int(d["ref_off"]) * refp.itemsize), int(d["pu_x"]), int(d["pu_y"]), int(d["bsize"]),
+                                       int(d["bilinear"]), C.byref(mx), C.byref(my), C.byref(dist))
+        out[i] = (dist.value, mx.value, my.value)
+    return out
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_tf_subpel_search_batch_hip(be, oracle, bd):
+    """svt_hip_tf_subpel_search_batch == oracle_tf_subpel_search for every ring mode / sub-sampling / early-exit setting, two reference pictures in one batch"""
+    pkg = be.pkg
+    g = rng(640 + bd)
+    W, H, PAD = 192, 128, 80
+    stride = W + 2 * PAD
+    src, ref0 = make_pictures(g, W, H, PAD, bd)
+    _, ref1 = make_pictures(g, W, H, PAD, bd, shift=(-5, 1))
+    refs = np.ascontiguousarray(np.stack([ref0, ref1]))
+    d_src, d_ref = be.dev(src), be.dev(refs)
+    n = 24 if not be.is_gpu else 400
+    moved = 0
+    for (mode, ss, th) in CASES:
+        P = params(mode, ss, bd, th, W, H, PAD, stride)
+        descs = subpel_batch(g, pkg, src, W, H, n)
+        descs["ref_off"] = (np.arange(n) % 2) * ref0.size
+        want = oracle_subpel(oracle, P, src, refs.reshape(-1), descs)
+        d_out = be.empty((n,), pkg.TfSubpelResult)
+        PP = pkg.TfSubpelParams.from_buffer_copy(bytes(P))
+        be.lib.svt_hip_tf_subpel_search_batch(C.byref(PP), be.ptr(d_src), be.ptr(d_ref), be.ptr(be.dev(descs)), n, be.ptr(d_out), be.stream)
+        got = be.host(d_out)
+        for k in ("dist", "mv_x", "mv_y"):
+            bad = np.nonzero(got[k] != want[k])[0]
+            assert bad.size == 0, (mode, ss, th, k, bad[:5], got[bad[:5]], want[bad[:5]], descs[bad[:5]])
+        moved += int(np.count_nonzero((got["mv_x"] != descs["mv_x"]) | (got["mv_y"] != descs["mv_y"])))
+    assert moved > n  # the refinement really moves vectors
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_tf_subpel_full_picture_properties(be, oracle, bd):
+    """1080p, every 64/32/16/8 block of the picture against one reference (43 350 blocks): (1) a reference equal to the source -> distortion 0 at the starting
+    MV (0, 0) for every block (best == 0 stops the search); (2) determinism over two launches; (3) a sample of blocks against the oracle."""
+    if not be.is_gpu:
+        pytest.skip("full-picture sizes run on the GPU only")
+    pkg = be.pkg
+    g = rng(660 + bd)
+    W, H, PAD = 1920, 1088, 80
+    stride = W + 2 * PAD
+    amp = (1 << bd) - 1
+    dt = np.uint16 if bd > 8 else np.uint8
+    yy, xx = np.mgrid[0:H + 2 * PAD, 0:W + 2 * PAD].astype(np.float32)
+    refp = np.clip((0.5 + 0.25 * np.sin(xx / 3.3) * np.cos(yy / 4.1) + 0.2 * np.sin((xx + 2 * yy) / 9.1)) * amp + g.normal(0, amp / 150, xx.shape), 0, amp).astype(dt)
+    same = np.ascontiguousarray(refp[PAD:PAD + H, PAD:PAD + W])
+    moved = np.ascontiguousarray(refp[PAD + 2:PAD + 2 + H, PAD - 3:PAD - 3 + W])  # true displacement (-3, +2) full-pel
+    blocks = [(x, y, b) for b in (64, 32, 16, 8) for y in range(0, H, b) for x in range(0, W, b)]
+    n = len(blocks)
+    descs = np.zeros(n, pkg.TfSubpelDesc)
+    a = np.array(blocks)
+    descs["pu_x"], descs["pu_y"], descs["bsize"], descs["src_stride"] = a[:, 0], a[:, 1], a[:, 2], W
+    descs["src_off"] = a[:, 1].astype(np.uint64) * W + a[:, 0].astype(np.uint64)
+    P = params((1, 1, 1), 1, bd, 0, W, H, PAD, stride)
+    PP = pkg.TfSubpelParams.from_buffer_copy(bytes(P))
+    d_ref, d_descs, d_out = be.dev(refp), be.dev(descs), be.empty((n,), pkg.TfSubpelResult)
+    be.lib.svt_hip_tf_subpel_search_batch(C.byref(PP), be.ptr(be.dev(same)), be.ptr(d_ref), be.ptr(d_descs), n, be.ptr(d_out), be.stream)
+    got = be.host(d_out)
+    assert not got["dist"].any() and not got["mv_x"].any() and not got["mv_y"].any()
+    descs["mv_x"], descs["mv_y"] = -3 * 8 + 8 * g.integers(-1, 2, n), 2 * 8 + 8 * g.integers(-1, 2, n)
+    d_descs, d_moved = be.dev(descs), be.dev(moved)
+    outs = []
+    for _ in range(2):
+        d_out = be.empty((n,), pkg.TfSubpelResult)
+        be.lib.svt_hip_tf_subpel_search_batch(C.byref(PP), be.ptr(d_moved), be.ptr(d_ref), be.ptr(d_descs), n, be.ptr(d_out), be.stream)
+        outs.append(be.host(d_out))
+    assert np.array_equal(outs[0], outs[1])
+    pick = g.choice(n, 300, replace=False)
+    want = oracle_subpel(oracle, P, moved, refp.reshape(-1), descs[pick])
+    for k in ("dist", "mv_x", "mv_y"):
+        assert np.array_equal(outs[0][k][pick], want[k]), k
+    # blocks that started one pel off found the true displacement (interior blocks, exact copy -> distortion 0)
+    inner = (a[:, 0] >= 64) & (a[:, 1] >= 64) & (a[:, 0] + a[:, 2] <= W - 64) & (a[:, 1] + a[:, 2] <= H - 64) & (descs["mv_x"] == -24) & (descs["mv_y"] == 16)
+    assert inner.sum() > 1000 and not outs[0]["dist"][inner].any()
