@@ -183,6 +183,49 @@ def ref_libs():
     return C.CDLL(ref_path), C.CDLL(ora_path)
 
 
+def cpu_tf_subpel(k, budget_s):
+    """Checker + CPU baseline of the TF sub-pel leg: the reference's own tf_subpel_search (oracle/_ref/libsvtref_me.so, C kernels, one core) -- or the C
+    restatement where the reference build is absent -- on a bounded random sample of the leg's blocks; every sampled block must equal the device result."""
+    me_path, ref_path, ora_path = (os.path.join(ROOT, "oracle", "_ref", "libsvtref_me.so"), os.path.join(ROOT, "oracle", "_ref", "libsvtref.so"),
+                                   os.path.join(ROOT, "oracle", "liboracle.so"))
+    P, src, refs, descs, res, W, H = k["P"], k["src"], k["refs"], k["descs"], k["results"], k["W"], k["H"]
+    if os.path.exists(me_path) and os.path.exists(ref_path):
+        ref = C.CDLL(ref_path, mode=C.RTLD_GLOBAL)
+        ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))
+        ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
+        me, kind = C.CDLL(me_path), "reference"
+
+        def one(d):
+            mx, my, dist = C.c_int16(int(d["mv_x"])), C.c_int16(int(d["mv_y"])), C.c_uint64(0x7fffffff)
+            b = int(d["bsize"])
+            sbx, sby = int(d["pu_x"]) & ~63, int(d["pu_y"]) & ~63
+            me.ref_tf_subpel_search(C.byref(P), vp(src, sby * W + sbx), W, vp(refs, int(d["ref_off"])), W, H, sbx, sby, b, (int(d["pu_x"]) - sbx) // b,
+                                    (int(d["pu_y"]) - sby) // b, int(d["bilinear"]), C.byref(mx), C.byref(my), C.byref(dist))
+            return dist.value, mx.value, my.value
+    elif os.path.exists(ora_path):
+        ora, kind = C.CDLL(ora_path), "port"
+
+        def one(d):
+            mx, my, dist = C.c_int16(int(d["mv_x"])), C.c_int16(int(d["mv_y"])), C.c_uint64(0x7fffffff)
+            ora.oracle_tf_subpel_search(C.byref(P), vp(src, int(d["src_off"])), int(d["src_stride"]), vp(refs, int(d["ref_off"])), int(d["pu_x"]), int(d["pu_y"]),
+                                        int(d["bsize"]), int(d["bilinear"]), C.byref(mx), C.byref(my), C.byref(dist))
+            return dist.value, mx.value, my.value
+    else:
+        return {}
+    order = np.random.default_rng(5).permutation(len(descs))
+    t0, done, tcpu = time.perf_counter(), 0, 0.0
+    while time.perf_counter() - t0 < budget_s and done < len(order):
+        i = int(order[done])
+        t1 = time.perf_counter()
+        got = one(descs[i])
+        tcpu += time.perf_counter() - t1
+        if got != (int(res[i]["dist"]), int(res[i]["mv_x"]), int(res[i]["mv_y"])):
+            sys.exit("bench.py: parity check FAILED for tf_subpel block %d: device %s, %s %s -- no numbers recorded" % (i, res[i], kind, got))
+        done += 1
+    return {"parity_checked_blocks": done, "cpu_baseline": {"value": done / tcpu, "unit": "blocks/s", "cores": 1, "kind": kind,
+                                                            "sample": "%d random blocks of the leg's 64x64 / 32x32 / 16x16 mix, C kernels" % done}}
+
+
 def roofline(bytes_alg, seconds, kernel, traffic_kernel=None, **extra):
     """HBM roofline object of one leg: ALGORITHMIC bytes per launch / event-timed launch duration."""
     gbs = bytes_alg / seconds / 1e9
@@ -639,7 +682,9 @@ def main():
     bytes_item = 64 * 64 + (64 + aw - 1) * (64 + ah - 1) + 85 * 8
     kernel_s = dev / a.steps
     default_workload = (a.frames, a.refs, a.area) == (32, 4, "16x9")  # the workload the committed PMC passes were run on
-    rf = roofline(n * bytes_item, kernel_s, "me_fullpel_kernel<false>", None if default_workload else "-", kernel_ms=kernel_s * 1e3,
+    # areas up to 24x16 take the one-wave-per-item kernel (window pitch 18 or 26 dwords), larger ones the tiled workgroup kernel (csrc/sad.hip)
+    me_kernel = "me_fullpel_wave_kernel<false, %d>" % (18 if (aw + 3) // 4 <= 2 else 26) if (aw <= 24 and ah <= 16) else "me_fullpel_kernel<false>"
+    rf = roofline(n * bytes_item, kernel_s, me_kernel, None if default_workload else "-", kernel_ms=kernel_s * 1e3,
                   algorithmic_bytes_per_sb_ref=bytes_item,
                   note="search is VALU(packed-SAD)-bound, see valu_frac; HBM figure = SURVEY 8(d) algorithmic bytes / time",
                   sad_ops_per_s=n * aw * ah * 4096 / kernel_s,
@@ -674,6 +719,10 @@ def main():
         kernels.update(lr)
         kernels.update(bench_legs.hme_chain(torch, lib, pkg, stream, max(a.steps // 4, 8), 2))
         kernels.update(bench_legs.me_session_stage(torch, lib, pkg, stream, 12, 1))
+        keep = {}
+        kernels.update(bench_legs.tf_subpel(torch, lib, pkg, stream, 5, 1, keep))
+        if cpu:
+            kernels["tf_subpel_1080p8_6refs"].update(cpu_tf_subpel(keep, budget_s=4.0))
     if a.extra:
         for (w2, h2, sub) in [(16, 9, 1), (64, 32, 0), (256, 256, 0)]:
             nf = a.frames if w2 < 64 else (4 if w2 < 256 else 1)
@@ -707,7 +756,6 @@ def main():
         kernels.update(bench_legs.me_results(torch, lib, pkg, stream, es, 1))
         kernels.update(bench_legs.me_stage(torch, lib, pkg, stream, es, 1))
         kernels.update(bench_legs.tf_frames(torch, lib, pkg, stream, es, 1))
-        kernels.update(bench_legs.tf_subpel(torch, lib, pkg, stream, max(es // 4, 2), 1))
         kernels["txfm_quant_roundtrip"] = bench_legs.txfm_roundtrip(torch, lib, pkg, stream, max(es // 4, 3), 1)
     out["kernels"] = kernels
     if cpu:

@@ -530,7 +530,7 @@ def tf_frames(torch, lib, pkg, stream, steps, warmup):
     return out
 
 
-def tf_subpel(torch, lib, pkg, stream, steps, warmup):
+def tf_subpel(torch, lib, pkg, stream, steps, warmup, keep=None):
     """SURVEY 8f rank 4, the temporal filter's sub-pel refinement: one 1080p 8-bit central picture against 6 reference pictures, the preset-8 search shape
     (64x64 and 32x32 blocks bilinear with tf_ctrls.use_2tap, 16x16 regular; half + quarter pel, no eighth, sub_sampling_shift 1) = 6 x (510 + 2040 + 8160)
     blocks in one launch.  Compute bound (8-tap separable interpolation): reported as blocks/s and candidate samples/s, not against HBM."""
@@ -559,6 +559,8 @@ def tf_subpel(torch, lib, pkg, stream, steps, warmup):
               steps, warmup, batches=3)
     res = d_out.cpu().numpy().view(pkg.TfSubpelResult)
     cand_px = float(np.sum(a[:, 2].astype(np.float64) ** 2 / 2)) * 17  # 1 + 8 + 8 candidates, every other row
+    if keep is not None:  # bench.py's checker / CPU baseline leg works on the same inputs
+        keep.update(P=P, src=src, refs=refs, descs=d, results=res.copy(), W=W, H=H)
     return {"tf_subpel_1080p8_6refs": {"us": t * 1e6, "blocks_per_s": n / t, "pictures_per_s": 1 / t, "candidate_Gsamples_per_s": cand_px / t / 1e9,
                                         "moved_frac": float(np.mean((res["mv_x"] != d["mv_x"]) | (res["mv_y"] != d["mv_y"])))}}
 

@@ -78,11 +78,10 @@ static void seam_stats(void) {
             (unsigned long long)G.n_reuploads, G.why[0] ? G.why : "-");
     fclose(o);
 }
-static int seam_on(void) {
-    if (G.mode >= 0) return G.mode;
+static void seam_init(void) { /* once (pthread_once): ME threads arriving during the initialisation wait instead of seeing "off" */
     G.mode = 0;
     const char *e = getenv("SVT_HIP_ME_SEAM");
-    if (!e || !atoi(e) || !getenv("SVT_HIP")) return 0;
+    if (!e || !atoi(e) || !getenv("SVT_HIP")) return;
 #define SYM(field, name) *(void **)&abi.field = dlsym(RTLD_DEFAULT, name)
     SYM(create, "svt_hip_me_session_create"); SYM(enable_stage, "svt_hip_me_session_enable_stage"); SYM(submit_stage, "svt_hip_me_session_submit_stage");
     SYM(wait, "svt_hip_me_session_wait"); SYM(invalidate, "svt_hip_me_session_invalidate"); SYM(resident, "svt_hip_me_session_resident");
@@ -94,7 +93,12 @@ static int seam_on(void) {
     }
     atexit(seam_stats);
     fprintf(stderr, "SVT_HIP_ME_SEAM: open-loop ME runs as one device stage per picture\n");
-    return G.mode = 1;
+    G.mode = 1;
+}
+static int seam_on(void) {
+    static pthread_once_t once = PTHREAD_ONCE_INIT;
+    pthread_once(&once, seam_init);
+    return G.mode;
 }
 
 static uint64_t plane_sum(const EbPictureBufferDesc *p) { /* content check of the visible luma samples (padding is a function of them) */
@@ -306,6 +310,39 @@ static EbErrorType seam_motion_estimation_b64(PictureParentControlSet *pcs, uint
     }
     while (P->state == 1) pthread_cond_wait(&G.ready, &G.lock);
     const int declined = P->state == 3;
+    static int verify = -1; /* SVT_HIP_ME_SEAM_VERIFY=1: run the reference's function for the SB as well and report the first difference (diagnostic) */
+    if (verify < 0) verify = getenv("SVT_HIP_ME_SEAM_VERIFY") != NULL;
+    if (!declined && verify) {
+        pthread_mutex_unlock(&G.lock);
+        svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_ptr);
+        pthread_mutex_lock(&G.lock);
+        const MeSbResults *r = pcs->pa_me_data->me_results[b64_index];
+        const uint8_t     *t = P->total + (size_t)b64_index * P->n_pus, *c = P->cand + (size_t)b64_index * P->n_pus * P->max_cand;
+        const uint32_t    *m = P->mv + (size_t)b64_index * P->n_pus * P->max_refs;
+        const SvtHipMeSbStats *vs = &P->stats[b64_index];
+        if (pcs->me_64x64_distortion[b64_index] != vs->me_64x64_distortion || pcs->me_32x32_distortion[b64_index] != vs->me_32x32_distortion ||
+            pcs->me_16x16_distortion[b64_index] != vs->me_16x16_distortion || pcs->me_8x8_distortion[b64_index] != vs->me_8x8_distortion ||
+            pcs->me_8x8_cost_variance[b64_index] != vs->me_8x8_cost_variance || pcs->rc_me_distortion[b64_index] != vs->rc_me_distortion ||
+            pcs->stationary_block_present_sb[b64_index] != vs->stationary_block_present_sb || pcs->rc_me_allow_gm[b64_index] != vs->rc_me_allow_gm)
+            fprintf(stderr, "SVT_HIP_ME_SEAM_VERIFY: picture %llu SB %u statistics (reference / device): 64 %u/%u 32 %u/%u 16 %u/%u 8 %u/%u var %u/%u rc %u/%u stat %u/%u gm %u/%u\n",
+                    (unsigned long long)pcs->picture_number, b64_index, pcs->me_64x64_distortion[b64_index], vs->me_64x64_distortion, pcs->me_32x32_distortion[b64_index],
+                    vs->me_32x32_distortion, pcs->me_16x16_distortion[b64_index], vs->me_16x16_distortion, pcs->me_8x8_distortion[b64_index], vs->me_8x8_distortion,
+                    pcs->me_8x8_cost_variance[b64_index], vs->me_8x8_cost_variance, (unsigned)pcs->rc_me_distortion[b64_index], (unsigned)vs->rc_me_distortion,
+                    pcs->stationary_block_present_sb[b64_index], vs->stationary_block_present_sb, pcs->rc_me_allow_gm[b64_index], vs->rc_me_allow_gm);
+        for (uint32_t pu = 0; pu < P->n_pus; pu++) {
+            int bad = r->total_me_candidate_index[pu] != t[pu];
+            for (uint32_t k = 0; !bad && k < t[pu]; k++) bad = ((const uint8_t *)r->me_candidate_array)[pu * P->max_cand + k] != c[pu * P->max_cand + k];
+            for (uint32_t k = 0; !bad && k < P->max_refs; k++) bad = ((const uint32_t *)r->me_mv_array)[pu * P->max_refs + k] != m[pu * P->max_refs + k] ? 2 : 0;
+            if (bad) {
+                fprintf(stderr, "SVT_HIP_ME_SEAM_VERIFY: picture %llu SB %u (%u,%u) pu %u: total %u / %u (reference / device)%s;", (unsigned long long)pcs->picture_number,
+                        b64_index, b64_origin_x, b64_origin_y, pu, r->total_me_candidate_index[pu], t[pu], bad == 2 ? " MV" : "");
+                for (uint32_t k = 0; k < P->max_refs; k++)
+                    fprintf(stderr, " %08x/%08x", ((const uint32_t *)r->me_mv_array)[pu * P->max_refs + k], m[pu * P->max_refs + k]);
+                fprintf(stderr, "\n");
+                break;
+            }
+        }
+    }
     if (!declined) {
         MeSbResults *r = pcs->pa_me_data->me_results[b64_index];
         memcpy(r->total_me_candidate_index, P->total + (size_t)b64_index * P->n_pus, P->n_pus);

@@ -1,5 +1,5 @@
 """Integration-level parity (VERDICT r1 row g): the HIP variant installed in the REAL reference encoder must leave the
-bitstream and the reconstruction byte-identical to the C-only encoder -- the reference's own CI invariant across ISA levels
+bitstream byte-identical to the C-only encoder (and with it the reconstruction, a function of the bitstream) -- the reference's own CI invariant across ISA levels
 (.gitlab/workflows/linux/.gitlab-ci.yml:351-367).  oracle/_ref/enc/SvtAv1EncApp = the reference built C-only by oracle/Makefile
 with the binding of INTEGRATION.md §1 (oracle/ref_wrap/enc_handle_binding.c).
 
@@ -22,9 +22,11 @@ needs_encoder = pytest.mark.skipif(not os.path.exists(enc_identity.ENC), reason=
 
 
 def _check(res):
+    if not res.get("reference_deterministic", True):  # (no such case in the committed lists; see tools/enc_identity.py on 10-bit preset 8 with --lp >= 2)
+        pytest.skip("the C-only reference encoder does not reproduce its own bitstream for this configuration")
     assert res["rc_c"] == 0 and res["rc_hip"] == 0, res.get("stderr_tail")
     assert res["hook_line"], "the encoder did not install the HIP variant"
-    assert res["identical"], "bitstream / reconstruction differ from the C-only encoder: %s" % res["case"]
+    assert res["identical"], "the bitstream differs from the C-only encoder: %s" % res["case"]
     if "seam" in res:  # the ME stage ran as one device call per picture for EVERY inter picture (a declined picture would run the reference's C code)
         assert res["seam"]["pictures_offloaded"] > 0 and res["seam"]["pictures_declined"] == 0, res["seam"]
     else:
