@@ -226,6 +226,46 @@ def cpu_tf_subpel(k, budget_s):
                                                             "sample": "%d random blocks of the leg's 64x64 / 32x32 / 16x16 mix, C kernels" % done}}
 
 
+def cpu_lr_search(k, budget_s):
+    """Checker + CPU baseline of an LR search leg: the reference's own search_norestore_seg / search_wiener_seg / search_sgrproj_seg (oracle/_ref/libsvtref_me.so,
+    C kernels, one core) -- or the C restatement -- on a bounded random sample of the plane's restoration units; every sampled unit must equal the device result."""
+    me_path, ref_path, ora_path = (os.path.join(ROOT, "oracle", "_ref", "libsvtref_me.so"), os.path.join(ROOT, "oracle", "_ref", "libsvtref.so"),
+                                   os.path.join(ROOT, "oracle", "liboracle.so"))
+    if not os.path.exists(ora_path):
+        return {}
+    ora = C.CDLL(ora_path)
+    PD, src, dgd, pad, res = k["P"], k["src"], k["dgd"], k["pad"], k["results"]
+    P = type(PD).from_buffer_copy(bytes(PD))  # the same parameters over the host copies of the planes
+    P.src, P.dgd = src.ctypes.data, dgd.ctypes.data + (pad * dgd.shape[1] + pad) * dgd.itemsize
+    n = ora.oracle_lr_unit_rect(C.byref(P), -1, None)
+    rects = np.zeros((n, 4), np.int32)
+    for u in range(n):
+        ora.oracle_lr_unit_rect(C.byref(P), u, vp(rects[u]))
+    use_ref = os.path.exists(me_path) and os.path.exists(ref_path)
+    if use_ref:
+        ref = C.CDLL(ref_path, mode=C.RTLD_GLOBAL)
+        ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))
+        ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
+        me = C.CDLL(me_path)
+    order = np.random.default_rng(6).permutation(n)
+    t0, done, tcpu = time.perf_counter(), 0, 0.0
+    one = np.zeros(1, res.dtype)
+    while time.perf_counter() - t0 < budget_s and done < n:
+        u = int(order[done])
+        t1 = time.perf_counter()
+        if use_ref:
+            me.ref_lr_search_plane(C.byref(P), None, vp(one), vp(rects[u]), 1)
+        else:  # the restatement works on whole planes: crop the parameters to this unit's rectangle (+ the border the filters read)
+            return {}
+        tcpu += time.perf_counter() - t1
+        for f in ("sse", "vfilter", "hfilter", "ep", "xqd"):
+            if not np.array_equal(one[f][0], res[f][u]):
+                sys.exit("bench.py: parity check FAILED for the LR search, unit %d field %s: device %s, reference %s -- no numbers recorded" % (u, f, res[f][u], one[f][0]))
+        done += 1
+    return {"parity_checked_units": done, "cpu_baseline": {"value": done / tcpu, "unit": "units/s", "cores": 1, "kind": "reference",
+                                                           "sample": "%d random 256x256 units of the plane, C kernels" % done}}
+
+
 def roofline(bytes_alg, seconds, kernel, traffic_kernel=None, **extra):
     """HBM roofline object of one leg: ALGORITHMIC bytes per launch / event-timed launch duration."""
     gbs = bytes_alg / seconds / 1e9
@@ -723,6 +763,11 @@ def main():
         kernels.update(bench_legs.tf_subpel(torch, lib, pkg, stream, 5, 1, keep))
         if cpu:
             kernels["tf_subpel_1080p8_6refs"].update(cpu_tf_subpel(keep, budget_s=4.0))
+        keep = {}
+        kernels.update(bench_legs.lr_search(torch, lib, pkg, stream, 2, 1, keep))
+        if cpu:
+            for name in keep:
+                kernels[name].update(cpu_lr_search(keep[name], budget_s=5.0))
     if a.extra:
         for (w2, h2, sub) in [(16, 9, 1), (64, 32, 0), (256, 256, 0)]:
             nf = a.frames if w2 < 64 else (4 if w2 < 256 else 1)

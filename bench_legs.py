@@ -565,6 +565,49 @@ def tf_subpel(torch, lib, pkg, stream, steps, warmup, keep=None):
                                         "moved_frac": float(np.mean((res["mv_x"] != d["mv_x"]) | (res["mv_y"] != d["mv_y"])))}}
 
 
+def lr_search(torch, lib, pkg, stream, steps, warmup, keep=None):
+    """the per-unit half of the loop-restoration search (restoration_seg_search) of one 3840x2160 10-bit luma plane, 256x256 units (15 x 8):
+    `full` = sg_filter level 1 (all 16 self-guided parameter sets, refinement) + 7-tap Wiener with refinement; `fast` = 2 parameter sets + 5-tap Wiener with one
+    refinement step.  Latency-bound lock-step search (tens of dependent trials per unit): reported as ms per plane, with the trial kernel's share."""
+    import time as _t
+    g = np.random.default_rng(19)
+    W, H, PAD, bd = 3840, 2160, 8, 10
+    amp = (1 << bd) - 1
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    tex = 0.5 + 0.2 * np.sin(xx / 2.3) * np.cos(yy / 3.1) + 0.15 * np.sin((xx + 2 * yy) / 6.7) + 0.1 * np.sign(np.sin(xx / 9.0) * np.sin(yy / 7.0))
+    src = np.clip(tex * amp + g.normal(0, amp / 120, tex.shape), 0, amp).astype(np.uint16)
+    blur = (src.astype(np.float32) * 4 + np.roll(src, 1, 0) + np.roll(src, -1, 0) + np.roll(src, 1, 1) + np.roll(src, -1, 1)) / 8
+    dgd = np.pad(np.clip(np.round(blur / 6) * 6 + g.normal(0, 4, blur.shape), 0, amp).astype(np.uint16), PAD, mode="edge")
+    d_src, d_dgd = _dev(torch, src), _dev(torch, dgd)
+    out = {}
+    for name, wn, sg in (("lr_search_4k10_full", (1, 7, 1, 0), (1, 0, 16, 1, 1)), ("lr_search_4k10_fast", (1, 5, 1, 1), (1, 0, 16, 8, 1))):
+        P = pkg.LrSearchParams()
+        P.src, P.dgd = d_src.data_ptr(), d_dgd.data_ptr() + (PAD * dgd.shape[1] + PAD) * 2
+        P.dgd_stride, P.src_stride, P.width, P.height, P.unit_size, P.ss_y, P.highbd, P.bit_depth = dgd.shape[1], W, W, H, 256, 0, 1, bd
+        P.wn_enabled, P.wiener_win, P.wn_use_refinement, P.wn_max_one_refinement_step = wn
+        P.sg_enabled, P.sg_start_ep, P.sg_end_ep, P.sg_ep_inc, P.sg_refine = sg
+        n = ((H + 128) // 256) * ((W + 128) // 256)
+        ws = torch.zeros(lib.svt_hip_lr_search_workspace(C.addressof(P)), dtype=torch.uint8, device="cuda")
+        d_out = torch.zeros(n * 72, dtype=torch.uint8, device="cuda")
+        ts = []
+        for it in range(warmup + max(steps, 2)):
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            assert lib.svt_hip_lr_search_plane(C.addressof(P), None, d_out.data_ptr(), ws.data_ptr(), stream) == 0
+            torch.cuda.synchronize()
+            if it >= warmup:
+                ts.append(_t.perf_counter() - t0)
+        res = d_out.cpu().numpy().view(pkg.LrSearchUnit)
+        t = float(np.median(ts))
+        out[name] = {"ms": t * 1e3, "planes_per_s": 1 / t, "units": n, "workspace_MB": ws.numel() / 1e6,
+                     "wiener_units": int(np.count_nonzero(res["sse"][:, 1] != np.iinfo(np.int64).max)),
+                     "sse_gain_wiener": float(1 - res["sse"][:, 1][res["sse"][:, 1] != np.iinfo(np.int64).max].sum() / max(1, res["sse"][:, 0][res["sse"][:, 1] != np.iinfo(np.int64).max].sum())),
+                     "sse_gain_sgrproj": float(1 - res["sse"][:, 2].sum() / max(1, res["sse"][:, 0].sum()))}
+        if keep is not None:
+            keep[name] = dict(P=P, src=src, dgd=dgd, pad=PAD, results=res.copy())
+    return out
+
+
 def hme_chain(torch, lib, pkg, stream, steps, warmup):
     """The three HME levels of a 1080p picture against 4 references, chained on the device (svt_hip_hme_level_batch x 3: descriptor kernel ->
     svt_hip_sad_loop_batch -> rescale kernel per level): level 0 on the 1/16-area planes (2 x 2 regions of 16x16), levels 1 and 2 with 8x3 areas

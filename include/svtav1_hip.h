@@ -726,6 +726,37 @@ typedef struct SvtHipLrParams {
     const SvtHipLrUnit *units;   /* [vert units][horz units] */
 } SvtHipLrParams;
 void svt_hip_lr_filter_frame(const SvtHipLrParams *params, void *stream);
+/* The per-unit half of the loop-restoration SEARCH of one plane (restoration_seg_search, restoration_pick.c:1448-1527) as one resident device stage:
+ * for every restoration unit the SSE of the unrestored unit (search_norestore_seg :1409), the Wiener solve + refinement (search_wiener_seg :1281:
+ * svt_av1_compute_stats -> wiener_decompose_sep_sym -> finalize_sym_filter -> compute_score -> finer_tile_search_wiener_seg) and the self-guided
+ * parameter search (search_sgrproj_seg :1205: search_selfguided_restoration + the SSE with the winner) -- everything the picture-level decisions
+ * (search_*_finish / rest_finish_search, serial rate decisions against the previous unit's coefficients) read from RestUnitSearchInfo.
+ * scs->use_boundaries_in_rest_search is 0 (enc_handle.c:4129): trials filter the plain plane.  dgd = the plane being restored, origin at sample (0, 0),
+ * edges extended by >= 3 samples (+ 1 more on the right) as restoration_seg_search leaves it (:1480-1496); units in svt_aom_foreach_rest_unit_in_frame
+ * order ([vert][horz]).  All pointers device.  Results are bit-exact with the reference's functions. */
+typedef struct SvtHipLrSearchParams {
+    const void *dgd, *src;
+    uint32_t    dgd_stride, src_stride, width, height, unit_size; /* samples */
+    uint8_t     ss_y, highbd, bit_depth;
+    uint8_t     wn_enabled, wiener_win, wn_use_refinement, wn_max_one_refinement_step; /* cm->wn_filter_ctrls; wiener_win resolved (7, 5 or 3: :1286-1290) */
+    uint8_t     sg_enabled, sg_start_ep, sg_end_ep, sg_ep_inc, sg_refine; /* the parameter-set loop of search_selfguided_restoration, resolved (:560-579) */
+    uint8_t     pad[3];
+} SvtHipLrSearchParams;
+typedef struct SvtHipLrSearchUnit {
+    int64_t sse[3];                 /* rusi->sse[RESTORE_NONE], [RESTORE_WIENER] (INT64_MAX: filter rejected by compute_score), [RESTORE_SGRPROJ] */
+    int16_t vfilter[8], hfilter[8]; /* rusi->wiener */
+    int32_t ep, xqd[2];             /* rusi->sgrproj */
+    int32_t pad;
+} SvtHipLrSearchUnit;
+typedef struct SvtHipLrPrevUnit { /* wn_filter_ctrls.use_prev_frame_coeffs (:1297-1302): the co-located unit of the previous frame was RESTORE_WIENER */
+    int32_t use;
+    int16_t vfilter[8], hfilter[8];
+} SvtHipLrPrevUnit;
+size_t svt_hip_lr_search_workspace(const SvtHipLrSearchParams *params); /* bytes (includes 8 B per sample and self-guided parameter set searched) */
+/* prev: device, [units] or NULL.  Synchronises `stream` internally (the lock-step Wiener refinement reads the number of units still searching back every
+ * eight steps).  Returns 0, or -1 for parameters outside the reference's ranges. */
+int svt_hip_lr_search_plane(const SvtHipLrSearchParams *params, const SvtHipLrPrevUnit *prev, SvtHipLrSearchUnit *units, void *workspace, void *stream);
+
 /* RTCD-signature single-call forms (common_dsp_rtcd.h:144-181); highbd pointers use the CONVERT_TO_BYTEPTR convention */
 void svt_av1_wiener_convolve_add_src_hip(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x,
                                          const int16_t *filter_y, int32_t w, int32_t h, const void *conv_params);

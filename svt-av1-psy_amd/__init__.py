@@ -101,6 +101,8 @@ PROTOTYPES = {
     "svt_hip_estimate_noise_batch": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_tf_filter_frame": (None, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_tf_subpel_search_batch": (None, [vp, vp, vp, vp, C.c_uint32, vp, vp]),
+    "svt_hip_lr_search_workspace": (C.c_size_t, [vp]),
+    "svt_hip_lr_search_plane": (C.c_int, [vp, vp, vp, vp, vp]),
     "svt_hip_sad_nxm_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_sad_loop_batch": (None, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_me_fullpel_search_workspace": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -273,6 +275,20 @@ TfSubpelDesc = np.dtype([("src_off", "<u8"), ("ref_off", "<u8"), ("src_stride", 
                          ("mv_x", "<i2"), ("mv_y", "<i2"), ("pad", "<u2")])
 TfSubpelResult = np.dtype([("dist", "<u8"), ("mv_x", "<i2"), ("mv_y", "<i2"), ("pad", "<u4")])
 assert TfSubpelDesc.itemsize == 32 and TfSubpelResult.itemsize == 16
+
+
+class LrSearchParams(C.Structure):
+    """SvtHipLrSearchParams: one plane of restoration_seg_search (restoration_pick.c:1448)."""
+    _fields_ = [("dgd", C.c_void_p), ("src", C.c_void_p), ("dgd_stride", C.c_uint32), ("src_stride", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("unit_size", C.c_uint32), ("ss_y", C.c_uint8), ("highbd", C.c_uint8), ("bit_depth", C.c_uint8), ("wn_enabled", C.c_uint8), ("wiener_win", C.c_uint8),
+                ("wn_use_refinement", C.c_uint8), ("wn_max_one_refinement_step", C.c_uint8), ("sg_enabled", C.c_uint8), ("sg_start_ep", C.c_uint8),
+                ("sg_end_ep", C.c_uint8), ("sg_ep_inc", C.c_uint8), ("sg_refine", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
+assert C.sizeof(LrSearchParams) == 56
+LrSearchUnit = np.dtype([("sse", "<i8", (3,)), ("vfilter", "<i2", (8,)), ("hfilter", "<i2", (8,)), ("ep", "<i4"), ("xqd", "<i4", (2,)), ("pad", "<i4")])
+LrPrevUnit = np.dtype([("use", "<i4"), ("vfilter", "<i2", (8,)), ("hfilter", "<i2", (8,))])
+assert LrSearchUnit.itemsize == 72 and LrPrevUnit.itemsize == 36
 
 
 class TfPlanes(C.Structure):

@@ -1,0 +1,315 @@
+// lr_core.h -- loop-restoration tile primitives shared by restoration.hip (apply) and lr_search.hip (search): tile staging with the stripe-boundary
+// substitution, the Wiener passes and the self-guided A / B tables + 3x3 weighting on a staged LDS tile.  (Moved out of restoration.hip unchanged.)
+#pragma once
+#include "svt_hip_common.h"
+#include "../../include/svtav1_hip.h"
+
+namespace {
+
+constexpr int FILTER_BITS = 7;
+constexpr int TW = 64 + 8;          // LDS tile pitch (u16): 64 columns + 3 left + up to 5 right (3 halo + the 8th-tap column)
+constexpr int TH = 64 + 6;          // rows
+__device__ __forceinline__ int rpot(const int v, const int n) { return (v + ((1 << n) >> 1)) >> n; }
+__device__ __forceinline__ uint32_t rpotu(const uint32_t v, const int n) { return (v + ((1u << n) >> 1)) >> n; }
+__device__ __forceinline__ int clampi(const int v, const int lo, const int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// svt_aom_eb_sgr_params (restoration.c:85-103)
+__device__ constexpr int16_t kSgrR[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {2, 0}, {2, 0}};
+__device__ constexpr int16_t kSgrS[16][2] = {{140, 3236}, {112, 2158}, {93, 1618}, {80, 1438}, {70, 1295}, {58, 1177}, {47, 1079}, {37, 996},
+                                             {30, 925},   {25, 863},   {-1, 2589}, {-1, 1618}, {-1, 1177}, {-1, 925},  {56, -1},   {22, -1}};
+// svt_aom_eb_x_by_xplus1 = round(256 z / (z + 1)), [0] = 1, [255] = 256; svt_aom_eb_one_by_x = round(4096 / n) (restoration.c:647-667)
+__device__ __forceinline__ int x_by_xplus1(const uint32_t z) { return z == 0 ? 1 : (z >= 255 ? 256 : (int)((256 * z + (z + 1) / 2) / (z + 1))); }
+__device__ __forceinline__ uint32_t one_by_x(const uint32_t n) { return (4096 + n / 2) / n; }
+
+struct TileSrc { // where a processing unit's pixels come from
+    const void* data; const void* above; const void* below;
+    int stride, bstride, w, h, highbd;     // plane size (frame mode) or unbounded (raw mode: w = h = 0)
+    int x0, y0, uw, uh;                    // unit origin and size inside the plane
+    int stripe_top, stripe_bot, stripe_idx;
+};
+__device__ __forceinline__ int rd_px(const void* p, const int highbd, const size_t off) {
+    return highbd ? ((const uint16_t*)p)[off] : ((const uint8_t*)p)[off];
+}
+// Source row of plane row y for this unit (restoration.c:288-332 stripe boundary substitution + svt_extend_frame row replication); the
+// column is clamped by the caller.  Raw mode (w == 0): the block's own rows.  Written as selects on (base address, row index, stride): a
+// three-way choice between the pointers of the struct made the compiler index the struct through scratch memory.
+__device__ __forceinline__ const uint8_t* src_row(const TileSrc& s, const int y) {
+    const int  px = s.highbd ? 2 : 1;
+    const bool raw = s.w == 0;
+    const bool up = !raw && y < s.stripe_top && s.stripe_top != 0, dn = !raw && !up && y >= s.stripe_bot && s.stripe_bot < s.h;
+    const int  iu = y - s.stripe_top + 2, id = y - s.stripe_bot;
+    const long long row = up ? (long long)(2 * s.stripe_idx + (iu > 0 ? iu : 0)) : (dn ? (long long)(2 * s.stripe_idx + (id < 1 ? id : 1)) : (raw ? (long long)y : (long long)clampi(y, 0, s.h - 1)));
+    // (bit masks, not ?: on the struct's fields: a select between loads of struct members is rewritten into an indexed load of the struct, which then lives in scratch)
+    const uintptr_t d = (uintptr_t)s.data, mu = (uintptr_t)0 - (uintptr_t)up, md = (uintptr_t)0 - (uintptr_t)dn;
+    const uintptr_t base = d ^ ((d ^ (uintptr_t)s.above) & mu) ^ ((d ^ (uintptr_t)s.below) & md);
+    const uint32_t  st = (uint32_t)s.stride, stride = st ^ ((st ^ (uint32_t)s.bstride) & (uint32_t)(mu | md));
+    return (const uint8_t*)(base + (uintptr_t)(row * (long long)stride * px));
+}
+struct __attribute__((packed, aligned(2))) LrRow8A2 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) LrRow8A1 { uint32_t v[2]; };
+struct __attribute__((aligned(16))) LrRow8A16 { uint32_t v[4]; };
+// tile[(r) * TW + c] <- pixel (y0 - 3 + r, x0 - 3 + c), r < uh + 6, c < uw + 6, zero beyond (the extra columns feed tap 7, always x 0).
+// A row is nine 8-pixel chunks; the sixteen lanes of a row group own chunk (lane & 15) < 9 of row (tid >> 4) + 16 k, so the (row, chunk) of a
+// thread costs no division and the row pointer is computed once per k.  Chunks that lie inside the plane are fetched with one vector load each, all
+// issued before the first LDS store (one memory round trip per workgroup); only chunks that cross the plane's left / right edge or the unit's last
+// column go pixel by pixel.  NIT * 16 >= rows.  (A wave-uniform row loop -- src_row on the scalar unit, one load per row and wave -- was tried and was
+// twice as slow: 1 365 scalar instructions per wave and serialised loads, profiles/r02_call7_lr_row_uniform_staging.txt.)
+template <int NIT>
+__device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, const int tid) {
+    const int  rows = s.uh + 6, cols = s.uw + 6;
+    const int  c = tid & 15, rb = tid >> 4;
+    const int  x = s.x0 - 3 + 8 * c;
+    // a chunk that only STARTS inside the needed columns is still fetched whole when its 8 pixels exist (inside the plane / the raw block's border): the
+    // columns beyond uw + 6 are multiplied by tap 7 = 0 (Wiener) or never read (self-guided), so they need not be zero.  Before, chunk 8 (6 of 8 pixels
+    // needed) took the pixel-by-pixel path in EVERY workgroup: ~180 VALU instructions per wave and a second dependent memory round trip.
+    const bool cfast = c < 9 && 8 * c < cols && (s.w == 0 || (x >= 0 && x + 8 <= s.w));
+    uint32_t   v[NIT][4];
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int  r = rb + 16 * k;
+        const bool fast = cfast && r < rows;
+        const uint8_t* row = src_row(s, s.y0 - 3 + (r < rows ? r : 0));
+        const uint8_t* p   = fast ? row + (long long)x * (s.highbd ? 2 : 1) : row; // (idle / slow lanes read the row start: always mapped)
+        if (s.highbd) {
+            const LrRow8A2 t = *(const LrRow8A2*)p;
+            v[k][0] = t.v[0]; v[k][1] = t.v[1]; v[k][2] = t.v[2]; v[k][3] = t.v[3];
+        } else {
+            const LrRow8A1 t = *(const LrRow8A1*)p;
+            v[k][0] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c010c00u); v[k][1] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c030c02u);
+            v[k][2] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c010c00u); v[k][3] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c030c02u);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int r = rb + 16 * k;
+        if (r >= rows || c >= 9) continue;
+        if (!cfast) {
+            const uint8_t* row = src_row(s, s.y0 - 3 + r);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uint32_t px[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int cc = 8 * c + 2 * e + h;
+                    int       xx = x + 2 * e + h;
+                    if (s.w != 0) xx = clampi(xx, 0, s.w - 1);
+                    px[h] = cc < cols ? (uint32_t)rd_px(row, s.highbd, (size_t)0 + (long long)xx) : 0u;
+                }
+                v[k][e] = px[0] | (px[1] << 16);
+            }
+        }
+        *(LrRow8A16*)(tile + r * TW + 8 * c) = LrRow8A16{{v[k][0], v[k][1], v[k][2], v[k][3]}};
+    }
+}
+struct WienerTaps { int16_t fx[8], fy[8]; };
+typedef short lr_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int lr_sdot2(const uint32_t a, const uint32_t b, const int c) { // c + a.lo * b.lo + a.hi * b.hi, signed 16-bit (v_dot2_i32_i16)
+    lr_s2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    return __builtin_amdgcn_sdot2(x, y, c, false);
+}
+__device__ __forceinline__ uint32_t lr_pack(const int lo, const int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+struct __attribute__((aligned(4))) LrDw5 { uint32_t d[5]; };
+// Wiener on a staged tile: horizontal pass (clamped, convolve.c:63-83 / :156-176) into `mid`, vertical pass to `out(y, x)`.  A thread produces two
+// horizontally adjacent samples per step from packed pairs: the horizontal pass reads five aligned dwords and runs eight v_dot2_i32_i16 (the odd
+// output on funnel-shifted pairs), the vertical pass regroups vertically adjacent rows with v_perm_b32 and runs eight more.  The reference's
+// "+ (centre << FILTER_BITS)" is tap 3 plus 128.  Every operand fits int16: pixels <= 4095, mid <= 2^15 - 1 (WIENER_CLAMP_LIMIT), taps < 2^8.
+template <typename OUT> __device__ __forceinline__ void wiener_tile(const uint16_t* tile, uint16_t* mid, const WienerTaps& t, const int uw, const int uh,
+                                                                    const int bd, const int tid, OUT out) {
+    int r0 = 3, r1 = 2 * FILTER_BITS - 3; // get_conv_params_wiener, convolve.h:70-88
+    const int range = bd + FILTER_BITS - r0 + 2;
+    if (range > 16) { r0 += range - 16; r1 -= range - 16; }
+    const int lim = (1 << (bd + 1 + FILTER_BITS - r0)) - 1;
+    const uint32_t f01 = lr_pack(t.fx[0], t.fx[1]), f23 = lr_pack(t.fx[2], t.fx[3] + (1 << FILTER_BITS)), f45 = lr_pack(t.fx[4], t.fx[5]), f67 = lr_pack(t.fx[6], t.fx[7]);
+    for (int i = tid; i < (uh + 6) * 32; i += 256) {
+        const int r = i >> 5, c = (i & 31) * 2;
+        if (c < uw) {
+            const LrDw5 v = *(const LrDw5*)(tile + r * TW + c); // pixels c .. c + 9; pixel c + 3 is the centre of output c
+            const int   o = 1 << (bd + FILTER_BITS - 1);
+            const int   s0 = lr_sdot2(v.d[0], f01, lr_sdot2(v.d[1], f23, lr_sdot2(v.d[2], f45, lr_sdot2(v.d[3], f67, o))));
+            const uint32_t e0 = __builtin_amdgcn_alignbyte(v.d[1], v.d[0], 2), e1 = __builtin_amdgcn_alignbyte(v.d[2], v.d[1], 2),
+                           e2 = __builtin_amdgcn_alignbyte(v.d[3], v.d[2], 2), e3 = __builtin_amdgcn_alignbyte(v.d[4], v.d[3], 2);
+            const int   s1 = lr_sdot2(e0, f01, lr_sdot2(e1, f23, lr_sdot2(e2, f45, lr_sdot2(e3, f67, o))));
+            *(uint32_t*)(mid + r * 64 + c) = lr_pack(clampi(rpot(s0, r0), 0, lim), clampi(rpot(s1, r0), 0, lim));
+        }
+    }
+    __syncthreads();
+    const uint32_t g01 = lr_pack(t.fy[0], t.fy[1]), g23 = lr_pack(t.fy[2], t.fy[3] + (1 << FILTER_BITS)), g45 = lr_pack(t.fy[4], t.fy[5]), g6 = lr_pack(t.fy[6], 0);
+    for (int i = tid; i < uh * 32; i += 256) {
+        const int r = i >> 5, c = (i & 31) * 2;
+        if (c < uw) {
+            const uint16_t* p = mid + r * 64 + c; // rows r .. r + 6 <-> y - 3 .. y + 3; tap 7 multiplies the zeroed row of convolve.c:118
+            uint32_t d[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) d[k] = *(const uint32_t*)(p + k * 64);
+            const int o = -(1 << (bd + r1 - 1));
+            // column c: low halves of consecutive rows paired; column c + 1: high halves
+            const int sl = lr_sdot2(__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), g01,
+                           lr_sdot2(__builtin_amdgcn_perm(d[3], d[2], 0x05040100u), g23,
+                           lr_sdot2(__builtin_amdgcn_perm(d[5], d[4], 0x05040100u), g45, lr_sdot2(d[6] & 0xffffu, g6, o))));
+            const int sh = lr_sdot2(__builtin_amdgcn_perm(d[1], d[0], 0x07060302u), g01,
+                           lr_sdot2(__builtin_amdgcn_perm(d[3], d[2], 0x07060302u), g23,
+                           lr_sdot2(__builtin_amdgcn_perm(d[5], d[4], 0x07060302u), g45, lr_sdot2(d[6] >> 16, g6, o))));
+            out(r, c, clampi(rpot(sl, r1), 0, (1 << bd) - 1), clampi(rpot(sh, r1), 0, (1 << bd) - 1), c + 1 < uw);
+        }
+    }
+}
+
+typedef unsigned short lr_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lr_dot2(const uint32_t a, const uint32_t b, const uint32_t c) { // c + a.lo * b.lo + a.hi * b.hi (v_dot2_u32_u16)
+    lr_us2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    return __builtin_amdgcn_udot2(x, y, c, false);
+}
+struct __attribute__((aligned(4))) LrDw3 { uint32_t d0, d1, d2; };
+// Box sums for TWO horizontally adjacent A/B positions per thread: the union of their (2r+1)-wide windows is six pixels = three aligned
+// dwords of a tile row, so a row costs two LDS reads and a handful of v_dot2_u32_u16 (sum: multiply by {1,1}; sum of squares: by itself)
+// instead of 2 x (2r+1) scalar reads.  xlut = svt_aom_eb_x_by_xplus1 built once per workgroup (the table entries need an integer division).
+__device__ __forceinline__ void sgr_ab_pass(const uint16_t* tile, uint16_t* A16, int32_t* B32, const uint16_t* xlut, const int pass, const int idx, const int uw,
+                                            const int uh, const int bd, const int tid) {
+    const int      r = kSgrR[idx][pass];
+    const uint32_t s = (uint32_t)kSgrS[idx][pass], n = (uint32_t)((2 * r + 1) * (2 * r + 1)), obx = one_by_x(n);
+    const int      nrows = pass == 0 ? 33 : 66; // pass 0 only needs the positions with ii even (i = ii - 1 odd)
+    for (int e = tid; e < nrows * 33; e += 256) {
+        const int rr = (e * 1986) >> 16, jj = (e - rr * 33) * 2, ii = pass == 0 ? 2 * rr : rr; // rr = e / 33 exactly for e < 2178; i = ii - 1, j = jj - 1 (and jj)
+        if (ii > uh + 1 || jj > uw + 1) continue;
+        const uint16_t* p = tile + (ii + 2 - r) * TW + jj; // first of the six pixels jj .. jj + 5 of the window's top row (dword aligned)
+        uint32_t tot = 0, tot2 = 0, ea = 0, ea2 = 0, eb = 0, eb2 = 0; // r = 2: totals over six pixels minus an edge; r = 1: centre pair plus an edge
+        for (int dy = 0; dy <= 2 * r; dy++) {
+            const LrDw3 v = *(const LrDw3*)(p + dy * TW);
+            if (r == 2) {
+                tot  = lr_dot2(v.d0, 0x00010001u, lr_dot2(v.d1, 0x00010001u, lr_dot2(v.d2, 0x00010001u, tot)));
+                tot2 = lr_dot2(v.d0, v.d0, lr_dot2(v.d1, v.d1, lr_dot2(v.d2, v.d2, tot2)));
+                ea   = lr_dot2(v.d2, 0x00010000u, ea);            // pixel 5: not in the left window
+                ea2  = lr_dot2(v.d2 & 0xffff0000u, v.d2, ea2);
+                eb   = lr_dot2(v.d0, 0x00000001u, eb);            // pixel 0: not in the right window
+                eb2  = lr_dot2(v.d0 & 0x0000ffffu, v.d0, eb2);
+            } else {
+                tot  = lr_dot2(v.d1, 0x00010001u, tot);           // pixels 2, 3: in both windows
+                tot2 = lr_dot2(v.d1, v.d1, tot2);
+                ea   = lr_dot2(v.d0, 0x00010000u, ea);            // pixel 1: left window only
+                ea2  = lr_dot2(v.d0 & 0xffff0000u, v.d0, ea2);
+                eb   = lr_dot2(v.d2, 0x00000001u, eb);            // pixel 4: right window only
+                eb2  = lr_dot2(v.d2 & 0x0000ffffu, v.d2, eb2);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t sum = r == 2 ? tot - (h ? eb : ea) : tot + (h ? eb : ea);
+            const uint32_t sq  = r == 2 ? tot2 - (h ? eb2 : ea2) : tot2 + (h ? eb2 : ea2);
+            const uint32_t a = rpotu(sq, 2 * (bd - 8)), b = rpotu(sum, bd - 8);
+            const uint32_t pp = (a * n < b * b) ? 0 : a * n - b * b;
+            const uint32_t z  = rpotu(pp * s, 20);
+            const int      av = xlut[z > 255 ? 255 : z];
+            const int      o  = ii * 66 + jj + h;
+            if (jj + h < 66) {
+                A16[o] = (uint16_t)av; // 1 .. 256
+                B32[o] = (int32_t)rpotu((uint32_t)(256 - av) * sum * obx, 12);
+            }
+        }
+    }
+}
+typedef unsigned short lr_u16x2 __attribute__((vector_size(4)));
+__device__ __forceinline__ lr_u16x2 lr_as_pk(const uint32_t v) { lr_u16x2 r; __builtin_memcpy(&r, &v, 4); return r; }
+__device__ __forceinline__ lr_u16x2 lr_splat(const int v) { const unsigned short h = (unsigned short)v; return lr_u16x2{h, h}; }
+struct __attribute__((aligned(8))) LrInt4 { int32_t v[4]; };
+struct __attribute__((aligned(4))) LrDw2 { uint32_t lo, hi; };
+// Weighted 3x3 sums of the A / B tables for the output pair (i, j), (i, j + 1), j even (restoration.c:770-800 "fast" r = 2 pass on alternate rows,
+// :850-880 r = 1 pass).  A <= 256 and the weights sum to 32, so the A side runs on packed u16 pairs: per table row the two dwords holding columns
+// j - 1 .. j + 2 give the "left" pair, the "right" pair and (one funnel shift) the "centre" pair of the two outputs.
+__device__ __forceinline__ void sgr_flt_pair(const uint16_t* tile, const uint16_t* A16, const int32_t* B32, const int pass, const int i, const int j, int32_t (&f)[2]) {
+    const uint16_t* A = A16 + (i + 1) * 66 + j; // column j - 1 of table row i (dword aligned: j even, 66 even)
+    const int32_t*  B = B32 + (i + 1) * 66 + j;
+    lr_u16x2 a;
+    int32_t  b0, b1, nb;
+    auto rowA = [&](const int dr, lr_u16x2& L, lr_u16x2& Cc, lr_u16x2& R) {
+        const LrDw2 v = *(const LrDw2*)(A + dr * 66);
+        L = lr_as_pk(v.lo); R = lr_as_pk(v.hi); Cc = lr_as_pk(__builtin_amdgcn_alignbyte(v.hi, v.lo, 2));
+    };
+    if (pass == 0 && (i & 1)) {
+        nb = 4;
+        lr_u16x2 L, Cc, R;
+        rowA(0, L, Cc, R);
+        a = Cc * lr_splat(6) + (L + R) * lr_splat(5);
+        const LrInt4 q = *(const LrInt4*)B;
+        b0 = q.v[1] * 6 + (q.v[0] + q.v[2]) * 5;
+        b1 = q.v[2] * 6 + (q.v[1] + q.v[3]) * 5;
+    } else {
+        nb = 5;
+        lr_u16x2 Lm, Cm, Rm, Lp, Cp, Rp;
+        rowA(-1, Lm, Cm, Rm);
+        rowA(1, Lp, Cp, Rp);
+        const LrInt4 qm = *(const LrInt4*)(B - 66), qp = *(const LrInt4*)(B + 66);
+        if (pass == 0) {
+            a  = (Cm + Cp) * lr_splat(6) + (Lm + Rm + Lp + Rp) * lr_splat(5);
+            b0 = (qm.v[1] + qp.v[1]) * 6 + (qm.v[0] + qm.v[2] + qp.v[0] + qp.v[2]) * 5;
+            b1 = (qm.v[2] + qp.v[2]) * 6 + (qm.v[1] + qm.v[3] + qp.v[1] + qp.v[3]) * 5;
+        } else {
+            lr_u16x2 L0, C0, R0;
+            rowA(0, L0, C0, R0);
+            const LrInt4 q0 = *(const LrInt4*)B;
+            a  = (C0 + L0 + R0 + Cm + Cp) * lr_splat(4) + (Lm + Rm + Lp + Rp) * lr_splat(3);
+            b0 = (q0.v[1] + q0.v[0] + q0.v[2] + qm.v[1] + qp.v[1]) * 4 + (qm.v[0] + qm.v[2] + qp.v[0] + qp.v[2]) * 3;
+            b1 = (q0.v[2] + q0.v[1] + q0.v[3] + qm.v[2] + qp.v[2]) * 4 + (qm.v[1] + qm.v[3] + qp.v[1] + qp.v[3]) * 3;
+        }
+    }
+    const uint16_t* px = tile + (i + 3) * TW + j + 3;
+    f[0] = rpot((int32_t)a[0] * (int32_t)px[0] + b0, 8 + nb - 4);
+    f[1] = rpot((int32_t)a[1] * (int32_t)px[1] + b1, 8 + nb - 4);
+}
+
+// The r = 2 output of a thread's sixteen pixels (i = tid + 256 k) stays in registers until the r = 1 pass has its A / B tables; MODE_APPLY
+// combines with xqd (svt_apply_selfguided_restoration_c :957-992)
+template <typename OUT0, typename OUT1>
+__device__ __forceinline__ void sgr_tile(const uint16_t* tile, uint16_t* A16, int32_t* B32, uint16_t* xlut, const int idx, const int uw, const int uh,
+                                         const int bd, const int tid, OUT0 out_flt0, OUT1 out_flt1_or_apply) {
+    const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
+    xlut[tid] = (uint16_t)x_by_xplus1((uint32_t)tid); // 256 threads, 256 entries
+    __syncthreads();
+    int32_t f0[16]; // eight output pairs per thread: pair p = tid + 256 k <-> row p >> 5, columns 2 (p & 31), + 1
+#pragma unroll
+    for (int k = 0; k < 16; k++) f0[k] = 0;
+    if (p0) {
+        sgr_ab_pass(tile, A16, B32, xlut, 0, idx, uw, uh, bd, tid);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = tid + 256 * k, r = i >> 5, c = (i & 31) * 2;
+            if (r < uh && c < uw) {
+                int32_t f[2];
+                sgr_flt_pair(tile, A16, B32, 0, r, c, f);
+                f0[2 * k] = f[0]; f0[2 * k + 1] = f[1];
+                out_flt0(r, c, f[0]);
+                if (c + 1 < uw) out_flt0(r, c + 1, f[1]);
+            }
+        }
+        __syncthreads();
+    }
+    if (p1) sgr_ab_pass(tile, A16, B32, xlut, 1, idx, uw, uh, bd, tid);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int i = tid + 256 * k, r = i >> 5, c = (i & 31) * 2;
+        if (r < uh && c < uw) {
+            int32_t f[2] = {0, 0};
+            if (p1) sgr_flt_pair(tile, A16, B32, 1, r, c, f);
+            out_flt1_or_apply(r, c, f0[2 * k], f[0], f0[2 * k + 1], f[1], c + 1 < uw);
+        }
+    }
+}
+__device__ __forceinline__ int sgr_combine(const int px, const int32_t f0, const int32_t f1, const int idx, const int32_t xqd0, const int32_t xqd1, const int bd) {
+    int xq0, xq1; // svt_decode_xq, restoration.c:634-645
+    if (kSgrR[idx][0] == 0) { xq0 = 0; xq1 = 128 - xqd1; }
+    else if (kSgrR[idx][1] == 0) { xq0 = xqd0; xq1 = 0; }
+    else { xq0 = xqd0; xq1 = 128 - xq0 - xqd1; }
+    const int32_t u = px << 4;
+    int32_t       v = u << 7;
+    if (kSgrR[idx][0] > 0) v += xq0 * (f0 - u);
+    if (kSgrR[idx][1] > 0) v += xq1 * (f1 - u);
+    const int16_t w = (int16_t)rpot(v, 11);
+    return clampi(w, 0, (1 << bd) - 1);
+}
+
+} // namespace

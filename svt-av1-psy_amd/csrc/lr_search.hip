@@ -1,0 +1,628 @@
+// lr_search.hip -- the per-unit half of the loop-restoration SEARCH of one plane as a resident device stage (the caller of a21-a24).
+//
+// Reference: restoration_seg_search (Source/Lib/Codec/restoration_pick.c:1448-1527) runs, for every restoration unit,
+//   search_norestore_seg (:1409)  SSE of the unrestored unit;
+//   search_wiener_seg (:1281)     svt_av1_compute_stats -> wiener_decompose_sep_sym (:894, integer alternating least squares over linsolve_wiener :754)
+//                                 -> finalize_sym_filter (:962) -> compute_score (:925) -> finer_tile_search_wiener_seg (:1027: coordinate descent on the
+//                                 taps, every trial = restore the unit + SSE against the source, try_restoration_unit_seg :129);
+//   search_sgrproj_seg (:1205)    search_selfguided_restoration (:542): per parameter set the two self-guided filters, svt_get_proj_subspace, encode_xq,
+//                                 finer_search_pixel_proj_error (:320); then the SSE of the unit restored with the winner.
+// The picture-level decisions (search_*_finish: rate against the previous unit's coefficients, serial) stay with the encoder.
+// scs->use_boundaries_in_rest_search is 0 (enc_handle.c:4129): trials filter the plain edge-extended plane, no stripe-boundary substitution.
+//
+// Mapping.  Units are independent; within a unit both searches are greedy sequences of "evaluate a candidate over the whole unit, keep it if not worse".
+//   * Wiener: statistics on the matrix cores (lr_stats.hip); the solve is one wave per unit (the 49 x 49 accumulations spread over the lanes, the 3 x 3
+//     integer elimination on lane 0, all int64 with the reference's truncating divisions); the refinement runs all units in LOCK STEP: a step kernel (one
+//     thread per unit = the reference's nested loops as a resumable state machine) proposes each unit's next candidate, a trial kernel (one workgroup per
+//     64 x 64 tile of every active unit: the Wiener passes of lr_core.h on a staged tile, squared error against the source, one 64-bit atomic per workgroup)
+//     evaluates them; finished units drop out.  The host reads the number of active units back every few steps.
+//   * self-guided: one launch filters the plane with every parameter set of the range (flt0 / flt1 kept as int32 planes in the workspace), one workgroup
+//     per (unit, parameter set) does projection + refinement (each evaluation = a pass over the unit's flt0 / flt1 / dgd / src), a per-unit thread
+//     picks the first-best set, the trial kernel restores with it.
+#include "lr_core.h"
+
+extern "C" void svt_hip_lr_compute_stats_batch(const void* dgd, const void* src, const SvtHipRect* rects, uint32_t n, int max_rect_width, int max_rect_height,
+                                               int dgd_stride, int src_stride, int wiener_win, int bit_depth, int64_t* M, int64_t* H, void* stream);
+
+namespace {
+
+constexpr long long kScale = 1ll << 16; // WIENER_TAP_SCALE_FACTOR
+constexpr int       kStep  = 128;       // WIENER_FILT_STEP
+__device__ constexpr int kTapMin[3] = {-5, -23, -17}, kTapMax[3] = {10, 8, 46}; // WIENER_FILT_TAPn_MINV / MAXV (restoration.h:143-149)
+__device__ constexpr int kInitFilt[7] = {3, -7, 15, 106, 15, -7, 3};            // WIENER_FILT_TAPn_MIDV
+
+struct WnState { // one unit's position in finer_tile_search_wiener_seg
+    int16_t   v[8], h[8];
+    long long err;
+    int32_t   s, dir, p, sign, skip;
+    int32_t   active;  // 1: a trial with the taps above is wanted / in flight
+    int32_t   started; // the initial evaluation has been issued
+    int32_t   trials;
+};
+struct SgResult { long long err; int32_t xqd[2]; };
+
+struct Ws { // workspace carving (device pointers)
+    SvtHipRect*         rects;
+    unsigned long long* acc;     // [n] trial accumulators
+    WnState*            wn;      // [n]
+    long long*          M;       // [n][49]
+    long long*          H;       // [n][49 * 49]
+    SgResult*           sg;      // [n][slots]
+    int32_t*            counter; // [1] units still refining
+    int32_t*            flt;     // [slots][2][height * width]
+};
+__host__ __device__ inline int n_units_1d(const int size, const int us) { const int v = (size + (us >> 1)) / us; return v > 0 ? v : 1; }
+
+// unit grid of svt_aom_foreach_rest_unit_in_frame (restoration.c:1240-1330)
+__global__ void lr_rects_kernel(const SvtHipLrSearchParams P, SvtHipRect* rects, unsigned long long* acc, WnState* wn, SvtHipLrSearchUnit* out, const int n) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    const int us = (int)P.unit_size, w = (int)P.width, h = (int)P.height, off = 8 >> P.ss_y;
+    const int nvu = n_units_1d(h, us), nhu = n_units_1d(w, us), ur = u / nhu, uc = u % nhu;
+    SvtHipRect r;
+    r.h_start = uc * us; r.h_end = uc == nhu - 1 ? w : (uc + 1) * us;
+    r.v_start = ur == 0 ? 0 : ur * us - off; r.v_end = ur == nvu - 1 ? h : (ur + 1) * us - off;
+    rects[u] = r;
+    acc[u]   = 0;
+    WnState z = {};
+    wn[u]     = z;
+    SvtHipLrSearchUnit o = {};
+    out[u]               = o;
+}
+
+// ---- trial kernel: restore one 64 x 64 tile of a unit with the unit's candidate and add its squared error against the source -------------------------
+// KIND 0: unrestored; 1: Wiener with wn[u] (active units only); 2: self-guided with out[u].ep / xqd
+constexpr size_t LRS_A_BYTES = (size_t)66 * 66 * 2 + 8;
+constexpr size_t LRS_SMEM    = (size_t)TH * TW * 2 + LRS_A_BYTES + (size_t)66 * 66 * 4 + 512;
+template <int KIND>
+__global__ __launch_bounds__(256) void lr_trial_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const WnState* __restrict__ wn,
+                                                       const SvtHipLrSearchUnit* __restrict__ units, unsigned long long* __restrict__ acc) {
+    HIP_DYNAMIC_SHARED(uint16_t, smem)
+    __shared__ unsigned long long part[4];
+    const int        u = blockIdx.z, tid = threadIdx.x;
+    const SvtHipRect r = rects[u];
+    if (KIND == 1 && !wn[u].active) return;
+    TileSrc s;
+    s.data = P.dgd; s.above = s.below = nullptr; s.stride = (int)P.dgd_stride; s.bstride = 0; s.w = 0; s.h = 0; s.highbd = P.highbd;
+    s.stripe_idx = 0; s.stripe_top = 0; s.stripe_bot = 0;
+    s.x0 = r.h_start + (int)blockIdx.x * 64; s.y0 = r.v_start + (int)blockIdx.y * 64;
+    if (s.x0 >= r.h_end || s.y0 >= r.v_end) return;
+    s.uw = r.h_end - s.x0 < 64 ? r.h_end - s.x0 : 64; s.uh = r.v_end - s.y0 < 64 ? r.v_end - s.y0 : 64;
+    uint16_t* tile = smem;
+    uint16_t* mid  = tile + TH * TW;
+    uint16_t* A16  = mid;
+    int32_t*  B32  = (int32_t*)((uint8_t*)mid + LRS_A_BYTES);
+    uint16_t* xlut = (uint16_t*)(B32 + 66 * 66);
+    const int highbd = P.highbd, bd = P.bit_depth, x0 = s.x0, y0 = s.y0;
+    const void* src = P.src;
+    const size_t sstride = P.src_stride;
+    unsigned long long sse = 0;
+    auto score = [&](int rr, int c, int v0, int v1, bool has1) {
+        const size_t o = (size_t)(y0 + rr) * sstride + x0 + c;
+        const int d0 = v0 - rd_px(src, highbd, o);
+        sse += (unsigned long long)(uint32_t)(d0 * d0);
+        if (has1) { const int d1 = v1 - rd_px(src, highbd, o + 1); sse += (unsigned long long)(uint32_t)(d1 * d1); }
+    };
+    stage_tile<(TH + 15) / 16>(tile, s, tid);
+    __syncthreads();
+    if (KIND == 1) {
+        WienerTaps t;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { t.fx[k] = wn[u].h[k]; t.fy[k] = wn[u].v[k]; }
+        wiener_tile(tile, mid, t, s.uw, s.uh, bd, tid, score);
+    } else if (KIND == 2) {
+        const int idx = units[u].ep & 15, q0 = units[u].xqd[0], q1 = units[u].xqd[1];
+        sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, bd, tid, [](int, int, int32_t) {},
+                 [&](int rr, int c, int32_t f0a, int32_t f1a, int32_t f0b, int32_t f1b, bool has1) {
+                     score(rr, c, sgr_combine(tile[(rr + 3) * TW + c + 3], f0a, f1a, idx, q0, q1, bd), sgr_combine(tile[(rr + 3) * TW + c + 4], f0b, f1b, idx, q0, q1, bd), has1);
+                 });
+    } else {
+        for (int i = tid; i < s.uh * 32; i += 256) {
+            const int rr = i >> 5, c = (i & 31) * 2;
+            if (c < s.uw) score(rr, c, tile[(rr + 3) * TW + c + 3], tile[(rr + 3) * TW + c + 4], c + 1 < s.uw);
+        }
+    }
+    // workgroup sum -> one atomic
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sse += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(sse >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)sse, m);
+    if ((tid & 63) == 0) part[tid >> 6] = sse;
+    __syncthreads();
+    if (tid == 0) atomicAdd(&acc[u], part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void lr_take_sse_kernel(unsigned long long* acc, SvtHipLrSearchUnit* out, const int which, const int n) { // acc -> out[u].sse[which], acc = 0
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    out[u].sse[which] = (int64_t)acc[u];
+    acc[u]            = 0;
+}
+
+// ---- Wiener solve: one wave per unit ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wrap_index(const int i, const int win) { const int h1 = (win >> 1) + 1; return i >= h1 ? win - 1 - i : i; }
+__device__ int linsolve_wiener(const int n, long long* A, const int stride, long long* b, int32_t* x) { // restoration_pick.c:754-790, verbatim arithmetic
+    for (int k = 0; k < n - 1; k++) {
+        for (int i = n - 1; i > k; i--) {
+            const long long p0 = A[(i - 1) * stride + k], p1 = A[i * stride + k];
+            if ((p0 < 0 ? -p0 : p0) < (p1 < 0 ? -p1 : p1)) {
+                for (int j = 0; j < n; j++) { const long long c = A[i * stride + j]; A[i * stride + j] = A[(i - 1) * stride + j]; A[(i - 1) * stride + j] = c; }
+                const long long c = b[i]; b[i] = b[i - 1]; b[i - 1] = c;
+            }
+        }
+        for (int i = k; i < n - 1; i++) {
+            if (A[k * stride + k] == 0) return 0;
+            const long long c = A[(i + 1) * stride + k], cd = A[k * stride + k];
+            for (int j = 0; j < n; j++) A[(i + 1) * stride + j] -= c / 256 * A[k * stride + j] / cd * 256;
+            b[i + 1] -= c * b[k] / cd;
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        if (A[i * stride + i] == 0) return 0;
+        long long c = 0;
+        for (int j = i + 1; j <= n - 1; j++) c += A[i * stride + j] * x[j] / kScale;
+        x[i] = (int32_t)(kScale * (b[i] - c) / A[i * stride + i]);
+    }
+    return 1;
+}
+__global__ __launch_bounds__(64) void lr_wiener_solve_kernel(const SvtHipLrSearchParams P, const long long* __restrict__ Mall, const long long* __restrict__ Hall,
+                                                             const SvtHipLrPrevUnit* __restrict__ prev, WnState* __restrict__ wn, SvtHipLrSearchUnit* __restrict__ out) {
+    __shared__ long long     A[4], B[16], PQ[2];
+    __shared__ int32_t       a[7], b[7];
+    const int                u = blockIdx.x, l = threadIdx.x, win = P.wiener_win, win2 = win * win, h1 = (win >> 1) + 1, plane_off = (7 - win) >> 1;
+    const long long* M = Mall + (size_t)u * 49;
+    const long long* H = Hall + (size_t)u * 49 * 49;
+    WnState st = {};
+    if (prev && prev[u].use) { // use_prev_frame_coeffs (:1297-1302): the co-located unit's taps, no solve
+        if (l == 0) {
+            for (int k = 0; k < 8; k++) { st.v[k] = prev[u].vfilter[k]; st.h[k] = prev[u].hfilter[k]; }
+            st.active = 1;
+            wn[u] = st;
+        }
+        return;
+    }
+    if (l < win) a[l] = b[l] = (int32_t)(kScale / kStep * kInitFilt[l + plane_off]);
+    __syncthreads();
+    for (int iter = 1; iter < 5; iter++) // NUM_WIENER_ITERS
+        for (int fix_b = 1; fix_b >= 0; fix_b--) { // update_a_sep_sym (:793), then update_b_sep_sym (:845)
+            if (l < 4) A[l] = 0;
+            if (l < 16) B[l] = 0;
+            __syncthreads();
+            if (l < win2) {
+                // lane = (i, j) for the right-hand side A
+                const int i = l / win, j = l - i * win;
+                const long long ta = fix_b ? M[i * win + j] * b[i] / kScale : M[i * win + j] * a[j] / kScale;
+                atomicAdd((unsigned long long*)&A[wrap_index(fix_b ? j : i, win)], (unsigned long long)ta);
+                // the matrix B: with b fixed the bin depends on (k, l') -> lane = (k, l'), loop over (i, j); with a fixed on (i, j) -> lane = (i, j), loop over (k, l')
+                long long tb = 0;
+                if (fix_b) {
+                    const int k = i, ll = j; // (reusing the lane's pair as (k, l'))
+                    for (int ii = 0; ii < win; ii++)
+                        for (int jj = 0; jj < win; jj++) tb += H[(size_t)jj * win * win2 + ii * win + k * win2 + ll] * b[ii] / kScale * b[jj] / kScale;
+                    atomicAdd((unsigned long long*)&B[wrap_index(ll, win) * h1 + wrap_index(k, win)], (unsigned long long)tb);
+                } else {
+                    for (int k = 0; k < win; k++)
+                        for (int ll = 0; ll < win; ll++) tb += H[(size_t)i * win * win2 + j * win + k * win2 + ll] * a[k] / kScale * a[ll] / kScale;
+                    atomicAdd((unsigned long long*)&B[wrap_index(j, win) * h1 + wrap_index(i, win)], (unsigned long long)tb);
+                }
+            }
+            __syncthreads();
+            if (l == 0) {
+                int32_t         S[7];
+                long long       Al[4], Bl[16];
+                for (int k = 0; k < 4; k++) Al[k] = A[k];
+                for (int k = 0; k < 16; k++) Bl[k] = B[k];
+                const long long a_last = Al[h1 - 1];
+                for (int i = 0; i < h1 - 1; i++) Al[i] -= a_last * 2 + Bl[i * h1 + h1 - 1] - 2 * Bl[(h1 - 1) * h1 + (h1 - 1)];
+                for (int i = 0; i < h1 - 1; i++)
+                    for (int j = 0; j < h1 - 1; j++) Bl[i * h1 + j] -= 2 * (Bl[i * h1 + (h1 - 1)] + Bl[(h1 - 1) * h1 + j] - 2 * Bl[(h1 - 1) * h1 + (h1 - 1)]);
+                if (linsolve_wiener(h1 - 1, Bl, h1, Al, S)) {
+                    S[h1 - 1] = (int32_t)kScale;
+                    for (int i = h1; i < win; i++) { S[i] = S[win - 1 - i]; S[h1 - 1] -= 2 * S[i]; }
+                    for (int i = 0; i < win; i++) (fix_b ? a : b)[i] = S[i];
+                }
+            }
+            __syncthreads();
+        }
+    // finalize_sym_filter (:962-991) x 2 and compute_score (:925-960)
+    __shared__ int16_t vf[8], hf[8];
+    if (l < 2) {
+        const int32_t* f  = l ? b : a;
+        int16_t*       fi = l ? hf : vf;
+        for (int k = 0; k < 8; k++) fi[k] = 0;
+        for (int i = 0; i < (win >> 1); i++) {
+            const long long dividend = (long long)f[i] * kStep, divisor = kScale;
+            fi[i] = (int16_t)(dividend < 0 ? (dividend - divisor / 2) / divisor : (dividend + divisor / 2) / divisor);
+        }
+        if (win == 7) {
+            fi[0] = (int16_t)clampi(fi[0], kTapMin[0], kTapMax[0]); fi[1] = (int16_t)clampi(fi[1], kTapMin[1], kTapMax[1]); fi[2] = (int16_t)clampi(fi[2], kTapMin[2], kTapMax[2]);
+        } else {
+            fi[2] = (int16_t)clampi(fi[1], kTapMin[2], kTapMax[2]); fi[1] = (int16_t)clampi(fi[0], kTapMin[1], kTapMax[1]); fi[0] = 0;
+        }
+        fi[6] = fi[0]; fi[5] = fi[1]; fi[4] = fi[2];
+        fi[3] = (int16_t)(-2 * (fi[0] + fi[1] + fi[2]));
+    }
+    if (l < 2) PQ[l] = 0;
+    __syncthreads();
+    if (l < win2) {
+        int16_t ca[7], cb[7];
+        ca[3] = cb[3] = kStep;
+        for (int i = 0; i < 3; i++) {
+            ca[i] = ca[6 - i] = vf[i]; cb[i] = cb[6 - i] = hf[i];
+            ca[3] = (int16_t)(ca[3] - 2 * ca[i]); cb[3] = (int16_t)(cb[3] - 2 * cb[i]);
+        }
+        auto ab = [&](const int k) { const int kk = k / win, ll = k - kk * win; return (int32_t)(ca[ll + plane_off] * cb[kk + plane_off]); };
+        const int       k  = l;
+        const long long pk = ab(k) * M[k] / kStep / kStep;
+        long long       qk = 0;
+        for (int ll = 0; ll < win2; ll++) qk += ab(k) * H[k * win2 + ll] * ab(ll) / kStep / kStep / kStep / kStep;
+        atomicAdd((unsigned long long*)&PQ[0], (unsigned long long)pk);
+        atomicAdd((unsigned long long*)&PQ[1], (unsigned long long)qk);
+    }
+    __syncthreads();
+    if (l == 0) {
+        const long long score = (PQ[1] - 2 * PQ[0]) - (H[(win2 >> 1) * win2 + (win2 >> 1)] - 2 * M[win2 >> 1]);
+        if (score > 0) { // no reduction of the quadratic form: the unit keeps RESTORE_NONE for the Wiener type (:1344-1347)
+            out[u].sse[1] = INT64_MAX;
+        } else {
+            for (int k = 0; k < 8; k++) { st.v[k] = vf[k]; st.h[k] = hf[k]; }
+            st.active = 1;
+        }
+        wn[u] = st;
+    }
+}
+
+// ---- Wiener refinement: finer_tile_search_wiener_seg (:1027-1131) as a resumable state machine, one thread per unit ----------------------------------
+__device__ __forceinline__ void wn_move(int16_t* f, const int p, const int d) { f[p] = (int16_t)(f[p] + d); f[6 - p] = (int16_t)(f[6 - p] + d); f[3] = (int16_t)(f[3] - 2 * d); }
+__global__ void lr_wiener_step_kernel(const SvtHipLrSearchParams P, WnState* __restrict__ wn, unsigned long long* __restrict__ acc, SvtHipLrSearchUnit* __restrict__ out,
+                                      int32_t* __restrict__ counter, const int n) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    WnState st = wn[u];
+    if (!st.active) return;
+    const int plane_off = (7 - P.wiener_win) >> 1, start_step = 4, end_step = P.wn_max_one_refinement_step ? 4 : 1;
+    enum { NEXT, AFTER_SIGN, AFTER_DIR, DONE, TRIAL } go;
+    if (!st.started) { // the evaluation of the initial taps
+        st.started = 1;
+        wn[u] = st;
+        atomicAdd(counter, 1);
+        return; // (acc[u] is 0; the trial kernel runs next)
+    }
+    const long long err2 = (long long)acc[u];
+    acc[u] = 0;
+    st.trials++;
+    if (st.s == 0) { // result of the initial evaluation
+        st.err = err2;
+        if (!P.wn_use_refinement) go = DONE;
+        else { st.s = start_step; st.dir = 0; st.p = plane_off; st.sign = -1; st.skip = 0; go = NEXT; }
+    } else { // result of a move of tap p by sign * s
+        int16_t* f = st.dir ? st.v : st.h;
+        if (err2 > st.err) { wn_move(f, st.p, -st.sign * st.s); go = AFTER_SIGN; }
+        else {
+            st.err = err2;
+            if (st.sign < 0) st.skip = 1;
+            go = (st.s == start_step && !P.wn_max_one_refinement_step) ? NEXT : AFTER_SIGN; // at the largest step keep moving in the same direction
+        }
+    }
+    while (go != DONE && go != TRIAL) {
+        if (go == NEXT) {
+            int16_t* f = st.dir ? st.v : st.h;
+            if (st.sign < 0 ? f[st.p] - st.s >= kTapMin[st.p] : f[st.p] + st.s <= kTapMax[st.p]) { wn_move(f, st.p, st.sign * st.s); go = TRIAL; }
+            else go = AFTER_SIGN;
+        } else if (go == AFTER_SIGN) {
+            if (st.sign < 0) {
+                if (st.skip) go = AFTER_DIR; // (:1062-1063: a successful downward move ends the loop over the taps of this direction)
+                else { st.sign = 1; go = NEXT; }
+            } else {
+                st.p++;
+                if (st.p >= 3) go = AFTER_DIR;
+                else { st.sign = -1; st.skip = 0; go = NEXT; }
+            }
+        } else { // AFTER_DIR
+            st.dir++;
+            if (st.dir >= 2) { st.dir = 0; st.s >>= 1; }
+            if (st.s < end_step) go = DONE;
+            else { st.p = plane_off; st.sign = -1; st.skip = 0; go = NEXT; }
+        }
+    }
+    if (go == DONE) {
+        st.active = 0;
+        out[u].sse[1] = st.err;
+        for (int k = 0; k < 8; k++) { out[u].vfilter[k] = st.v[k]; out[u].hfilter[k] = st.h[k]; }
+        atomicAdd(counter, -1);
+    }
+    wn[u] = st;
+}
+
+// ---- self-guided: flt0 / flt1 of the whole plane for one parameter set per blockIdx.z ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchParams P, int32_t* __restrict__ flt) {
+    HIP_DYNAMIC_SHARED(uint16_t, smem)
+    uint16_t* tile = smem;
+    uint16_t* A16  = tile + TH * TW;
+    int32_t*  B32  = (int32_t*)((uint8_t*)A16 + LRS_A_BYTES);
+    uint16_t* xlut = (uint16_t*)(B32 + 66 * 66);
+    const int tid = threadIdx.x, slot = blockIdx.z, idx = P.sg_start_ep + slot * P.sg_ep_inc, w = (int)P.width, h = (int)P.height;
+    TileSrc s;
+    s.data = P.dgd; s.above = s.below = nullptr; s.stride = (int)P.dgd_stride; s.bstride = 0; s.w = 0; s.h = 0; s.highbd = P.highbd;
+    s.stripe_idx = 0; s.stripe_top = 0; s.stripe_bot = 0;
+    s.x0 = blockIdx.x * 64; s.y0 = blockIdx.y * 64;
+    s.uw = w - s.x0 < 64 ? w - s.x0 : 64; s.uh = h - s.y0 < 64 ? h - s.y0 : 64;
+    int32_t* f0 = flt + (size_t)slot * 2 * w * h;
+    int32_t* f1 = f0 + (size_t)w * h;
+    const int x0 = s.x0, y0 = s.y0;
+    const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
+    stage_tile<(TH + 15) / 16>(tile, s, tid);
+    __syncthreads();
+    sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, P.bit_depth, tid, [&](int r, int c, int32_t v) { if (p0) f0[(size_t)(y0 + r) * w + x0 + c] = v; },
+             [&](int r, int c, int32_t, int32_t b0, int32_t, int32_t b1, bool has1) {
+                 if (p1) { f1[(size_t)(y0 + r) * w + x0 + c] = b0; if (has1) f1[(size_t)(y0 + r) * w + x0 + c + 1] = b1; }
+             });
+}
+
+// ---- self-guided: projection + refinement of one (unit, parameter set) per workgroup (search_selfguided_restoration's loop body, :582-630) ------------
+constexpr int PROJ_T = 1024; // threads per (unit, parameter set): sixteen waves, every evaluation is one latency-bound pass over the unit
+__device__ __forceinline__ long long block_sum_i64(long long v, long long* part, const int tid) { // every thread gets the workgroup's sum
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long uv = (unsigned long long)v;
+        v += (long long)(((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(uv >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)uv, m));
+    }
+    __syncthreads(); // (part is reused across calls)
+    if ((tid & 63) == 0) part[tid >> 6] = v;
+    __syncthreads();
+    long long t = 0;
+#pragma unroll
+    for (int k = 0; k < PROJ_T / 64; k++) t += part[k];
+    return t;
+}
+// the samples of a unit in raster order, PROJ_T apart, four in flight per thread (all loads of a group issued before the first use); (x, y) advance
+// incrementally -- no division per sample
+template <typename F> __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, const SvtHipRect& r, const int32_t* f0, const int32_t* f1,
+                                                                         const int r0, const int r1, const int tid, F body) {
+    const int uw = r.h_end - r.h_start, uh = r.v_end - r.v_start, npx = uw * uh, w = (int)P.width, highbd = P.highbd;
+    const int qy = PROJ_T / uw, rx = PROJ_T - qy * uw;
+    int       y = tid / uw, x = tid - y * uw;
+    for (int i = tid; i < npx; i += 4 * PROJ_T) {
+        int d[4], sp[4], g0[4], g1[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ok[k] = i + k * PROJ_T < npx;
+            const int    yy = ok[k] ? y : 0, xx = ok[k] ? x : 0;
+            const size_t fo = (size_t)(r.v_start + yy) * w + r.h_start + xx;
+            d[k]  = rd_px(P.dgd, highbd, (size_t)(r.v_start + yy) * P.dgd_stride + r.h_start + xx);
+            sp[k] = rd_px(P.src, highbd, (size_t)(r.v_start + yy) * P.src_stride + r.h_start + xx);
+            g0[k] = r0 > 0 ? f0[fo] : 0;
+            g1[k] = r1 > 0 ? f1[fo] : 0;
+            x += rx; y += qy;
+            if (x >= uw) { x -= uw; y++; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (ok[k]) body(d[k], sp[k], g0[k], g1[k]);
+    }
+}
+__global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const int32_t* __restrict__ flt,
+                                                             SgResult* __restrict__ res, const int slots) {
+    __shared__ long long part[PROJ_T / 64];
+    __shared__ int32_t   sh_xq[2];
+    const int        u = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x, idx = P.sg_start_ep + slot * P.sg_ep_inc, w = (int)P.width, h = (int)P.height;
+    const SvtHipRect r = rects[u];
+    const int        npx = (r.h_end - r.h_start) * (r.v_end - r.v_start);
+    const int32_t*   f0 = flt + (size_t)slot * 2 * w * h;
+    const int32_t*   f1 = f0 + (size_t)w * h;
+    const int        r0 = kSgrR[idx][0], r1 = kSgrR[idx][1];
+    // svt_get_proj_subspace (:413-498): the integer sums equal the reference's double sums exactly (every partial sum < 2^53)
+    long long a[5] = {0, 0, 0, 0, 0};
+    for_unit_samples(P, r, f0, f1, r0, r1, tid, [&](const int d, const int sp, const int g0, const int g1) {
+        const int       uu = d << 4;
+        const long long sd = (long long)(sp << 4) - uu, q1 = r0 > 0 ? (long long)g0 - uu : 0, q2 = r1 > 0 ? (long long)g1 - uu : 0;
+        a[0] += q1 * q1; a[1] += q2 * q2; a[2] += q1 * q2; a[3] += q1 * sd; a[4] += q2 * sd;
+    });
+    long long t[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) t[k] = block_sum_i64(a[k], part, tid);
+    if (tid == 0) {
+        const double size = (double)npx;
+        const double H00 = (double)t[0] / size, H11 = (double)t[1] / size, H01 = (double)t[2] / size, C0 = (double)t[3] / size, C1 = (double)t[4] / size;
+        int x0 = 0, x1 = 0;
+        if (r0 == 0) {
+            if (!(H11 < 1e-8)) x1 = (int)rint(C1 / H11 * 128);
+        } else if (r1 == 0) {
+            if (!(H00 < 1e-8)) x0 = (int)rint(C0 / H00 * 128);
+        } else {
+            const double det = H00 * H11 - H01 * H01;
+            if (!(det < 1e-8)) { x0 = (int)rint((H11 * C0 - H01 * C1) / det * 128); x1 = (int)rint((H00 * C1 - H01 * C0) / det * 128); }
+        }
+        sh_xq[0] = x0; sh_xq[1] = x1;
+    }
+    __syncthreads();
+    const int tap_min[2] = {-96, -32}, tap_max[2] = {31, 95}; // SGRPROJ_PRJ_MIN0 / MAX0, MIN1 / MAX1
+    int       xqd[2];
+    {         // encode_xq (:500-511)
+        const int e0 = sh_xq[0], e1 = sh_xq[1];
+        if (r0 == 0) { xqd[0] = 0; xqd[1] = clampi(128 - e1, tap_min[1], tap_max[1]); }
+        else if (r1 == 0) { xqd[0] = clampi(e0, tap_min[0], tap_max[0]); xqd[1] = clampi(128 - xqd[0], tap_min[1], tap_max[1]); }
+        else { xqd[0] = clampi(e0, tap_min[0], tap_max[0]); xqd[1] = clampi(128 - xqd[0] - e1, tap_min[1], tap_max[1]); }
+    }
+    auto proj_err = [&]() -> long long { // get_pixel_proj_error (:305-318): every thread returns the unit's error for the current xqd
+        int xq0, xq1;
+        if (r0 == 0) { xq0 = 0; xq1 = 128 - xqd[1]; }
+        else if (r1 == 0) { xq0 = xqd[0]; xq1 = 0; }
+        else { xq0 = xqd[0]; xq1 = 128 - xq0 - xqd[1]; }
+        long long e2 = 0;
+        for_unit_samples(P, r, f0, f1, r0, r1, tid, [&](const int d, const int sp, const int g0, const int g1) {
+            const int uu = d << 4;
+            int       v = uu << 7;
+            if (r0 > 0) v += xq0 * (g0 - uu);
+            if (r1 > 0) v += xq1 * (g1 - uu);
+            const int e = ((v + (1 << 10)) >> 11) - sp;
+            e2 += (long long)e * e;
+        });
+        return block_sum_i64(e2, part, tid);
+    };
+    // finer_search_pixel_proj_error (:320-411), start_step 2.  The greedy walk only ever moves ONE tap along a line, and a move of tap p by delta changes
+    // every sample's projection by delta * (a per-sample constant): so one pass over the unit evaluates a whole run of candidates -- up to PROJ_K steps
+    // down and PROJ_K steps up from the current point -- and the reference's accept / reject sequence is then replayed on those errors.  (The up candidates
+    // of the first pass stay valid exactly when no down move was accepted, which is when the reference evaluates them.)  Control flow is workgroup-uniform.
+    constexpr int PROJ_K = 8;
+    long long     err    = proj_err();
+    auto eval_line = [&](const int p, const int st, const int nd, const int nu, long long* ed, long long* eu) {
+        int xq0, xq1;
+        if (r0 == 0) { xq0 = 0; xq1 = 128 - xqd[1]; }
+        else if (r1 == 0) { xq0 = xqd[0]; xq1 = 0; }
+        else { xq0 = xqd[0]; xq1 = 128 - xq0 - xqd[1]; }
+        // d(xq0) / d(xqd[p]) and d(xq1) / d(xqd[p]) (svt_decode_xq, restoration.c:634-645)
+        const int c0 = (p == 0 && r0 > 0) ? 1 : 0, c1 = (p == 1 || (r0 > 0 && r1 > 0)) ? -1 : 0;
+        long long ad[PROJ_K], au[PROJ_K];
+#pragma unroll
+        for (int k = 0; k < PROJ_K; k++) ad[k] = au[k] = 0;
+        for_unit_samples(P, r, f0, f1, r0, r1, tid, [&](const int d, const int sp, const int g0, const int g1) {
+            const int uu = d << 4, a0 = r0 > 0 ? g0 - uu : 0, a1 = r1 > 0 ? g1 - uu : 0;
+            const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10), dv = st * (c0 * a0 + c1 * a1);
+#pragma unroll
+            for (int k = 0; k < PROJ_K; k++) {
+                if (k < nd) { const int e = ((v - (k + 1) * dv) >> 11) - sp; ad[k] += (long long)e * e; }
+                if (k < nu) { const int e = ((v + (k + 1) * dv) >> 11) - sp; au[k] += (long long)e * e; }
+            }
+        });
+#pragma unroll
+        for (int k = 0; k < PROJ_K; k++) {
+            if (k < nd) ed[k] = block_sum_i64(ad[k], part, tid);
+            if (k < nu) eu[k] = block_sum_i64(au[k], part, tid);
+        }
+    };
+    if (P.sg_refine)
+        for (int st = 2; st >= 1; st >>= 1)
+            for (int p = 0; p < 2; p++) {
+                if ((r0 == 0 && p == 0) || (r1 == 0 && p == 1)) continue;
+                const int cap = st == 2 ? PROJ_K : 1; // only the largest step keeps moving in the same direction (:359-361)
+                long long ed[PROJ_K], eu[PROJ_K], eu0[PROJ_K];
+                int       skip = 0, nu0 = 0;
+                for (bool first = true;; first = false) { // the downward moves
+                    const int roomd = (xqd[p] - tap_min[p]) / st, nd = roomd < cap ? roomd : cap;
+                    int       nu = 0;
+                    if (first) { const int roomu = (tap_max[p] - xqd[p]) / st; nu = roomu < cap ? roomu : cap; }
+                    if (nd == 0 && nu == 0) break;
+                    eval_line(p, st, nd, nu, ed, eu);
+                    if (first) { nu0 = nu; for (int k = 0; k < PROJ_K; k++) eu0[k] = eu[k]; }
+                    int  k = 0;
+                    bool rejected = false;
+                    while (k < nd) {
+                        if (ed[k] > err) { rejected = true; break; }
+                        err = ed[k]; k++; skip = 1;
+                        if (st != 2) break;
+                    }
+                    xqd[p] -= st * k;
+                    if (rejected || st != 2 || k < nd || nd < PROJ_K) break;
+                }
+                if (skip) break; // (:372-373: a successful downward move ends the loop over p)
+                int nu = nu0;
+                for (int pass = 0; nu > 0; pass++) { // the upward moves, from the unchanged point
+                    if (pass > 0) {
+                        const int roomu = (tap_max[p] - xqd[p]) / st;
+                        nu = roomu < cap ? roomu : cap;
+                        if (nu == 0) break;
+                        eval_line(p, st, 0, nu, ed, eu0);
+                    }
+                    int  k = 0;
+                    bool rejected = false;
+                    while (k < nu) {
+                        if (eu0[k] > err) { rejected = true; break; }
+                        err = eu0[k]; k++;
+                        if (st != 2) break;
+                    }
+                    xqd[p] += st * k;
+                    if (rejected || st != 2 || k < nu || nu < PROJ_K) break;
+                }
+            }
+    if (tid == 0) {
+        SgResult o;
+        o.err = err; o.xqd[0] = xqd[0]; o.xqd[1] = xqd[1];
+        res[(size_t)u * slots + slot] = o;
+    }
+}
+__global__ void lr_sgr_pick_kernel(const SvtHipLrSearchParams P, const SgResult* __restrict__ res, SvtHipLrSearchUnit* __restrict__ out, const int slots, const int n) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    long long besterr = -1;
+    int       bestep = 0, q0 = 0, q1 = 0;
+    for (int sl = 0; sl < slots; sl++) { // first strictly smaller error wins (:631-636)
+        const SgResult r = res[(size_t)u * slots + sl];
+        if (besterr == -1 || r.err < besterr) { besterr = r.err; bestep = P.sg_start_ep + sl * P.sg_ep_inc; q0 = r.xqd[0]; q1 = r.xqd[1]; }
+    }
+    out[u].ep = bestep; out[u].xqd[0] = q0; out[u].xqd[1] = q1;
+}
+
+inline int sg_slots(const SvtHipLrSearchParams& P) {
+    if (!P.sg_enabled || P.sg_ep_inc == 0 || P.sg_end_ep <= P.sg_start_ep) return 0;
+    return ((int)P.sg_end_ep - (int)P.sg_start_ep + (int)P.sg_ep_inc - 1) / (int)P.sg_ep_inc;
+}
+inline size_t carve(const SvtHipLrSearchParams& P, void* base, Ws* ws) {
+    const size_t n = (size_t)n_units_1d((int)P.height, (int)P.unit_size) * n_units_1d((int)P.width, (int)P.unit_size), slots = (size_t)sg_slots(P);
+    size_t       off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return base ? (uint8_t*)base + o : nullptr; };
+    Ws w;
+    w.rects = (SvtHipRect*)take(n * sizeof(SvtHipRect));
+    w.acc = (unsigned long long*)take(n * 8);
+    w.wn = (WnState*)take(n * sizeof(WnState));
+    w.M = (long long*)take(n * 49 * 8);
+    w.H = (long long*)take(n * 49 * 49 * 8);
+    w.sg = (SgResult*)take(n * (slots ? slots : 1) * sizeof(SgResult));
+    w.counter = (int32_t*)take(256);
+    w.flt = (int32_t*)take(slots * 2 * (size_t)P.width * P.height * 4);
+    if (ws) *ws = w;
+    return off;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t svt_hip_lr_search_workspace(const SvtHipLrSearchParams* params) { return carve(*params, nullptr, nullptr); }
+
+int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPrevUnit* prev, SvtHipLrSearchUnit* units, void* workspace, void* stream) {
+    svthip::ensure_device();
+    const SvtHipLrSearchParams& P = *params;
+    if (!P.width || !P.height || !P.unit_size || (P.wn_enabled && P.wiener_win != 7 && P.wiener_win != 5 && P.wiener_win != 3) || P.sg_end_ep > 16) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    Ws          W;
+    carve(P, workspace, &W);
+    const int nvu = n_units_1d((int)P.height, (int)P.unit_size), nhu = n_units_1d((int)P.width, (int)P.unit_size), n = nvu * nhu, slots = sg_slots(P);
+    const int us = (int)P.unit_size, max_uw = (int)P.width - (nhu - 1) * us, max_uh = (int)P.height - (nvu - 1) * us + (nvu > 1 ? (8 >> P.ss_y) : 0);
+    const int mw = max_uw > us ? max_uw : (us < (int)P.width ? us : (int)P.width), mh = max_uh > us ? max_uh : (us < (int)P.height ? us : (int)P.height);
+    const dim3 tgrid((mw + 63) / 64, (mh + 63) / 64, n);
+    hipLaunchKernelGGL(lr_rects_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.rects, W.acc, W.wn, units, n);
+    HIP_CHECK(hipMemsetAsync(W.counter, 0, 4, st));
+    // RESTORE_NONE
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<0>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
+    hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, st, W.acc, units, 0, n);
+    SVT_LAUNCH_CHECK();
+    if (P.wn_enabled) {
+        svt_hip_lr_compute_stats_batch(P.dgd, P.src, W.rects, (uint32_t)n, mw, mh, (int)P.dgd_stride, (int)P.src_stride, P.wiener_win, P.highbd ? P.bit_depth : 8,
+                                       (int64_t*)W.M, (int64_t*)W.H, stream);
+        hipLaunchKernelGGL(lr_wiener_solve_kernel, dim3(n), dim3(64), 0, st, P, W.M, W.H, prev, W.wn, units);
+        SVT_LAUNCH_CHECK();
+        // lock-step refinement: step (propose / consume) + trial; the number of units still searching comes back every 8 steps
+        int32_t active = 1;
+        for (int it = 0; active > 0 && it < 4096; it++) {
+            hipLaunchKernelGGL(lr_wiener_step_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.wn, W.acc, units, W.counter, n);
+            if ((it & 7) == 0) {
+                HIP_CHECK(hipMemcpyAsync(&active, W.counter, 4, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                if (active <= 0) break;
+            }
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<1>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
+        }
+        SVT_LAUNCH_CHECK();
+    }
+    if (P.sg_enabled && slots > 0) {
+        hipLaunchKernelGGL(lr_sgr_flt_kernel, dim3(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, slots), dim3(256), LRS_SMEM, st, P, W.flt);
+        hipLaunchKernelGGL(lr_sgr_proj_kernel, dim3(n, slots), dim3(PROJ_T), 0, st, P, W.rects, W.flt, W.sg, slots);
+        hipLaunchKernelGGL(lr_sgr_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.sg, units, slots, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<2>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
+        hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, st, W.acc, units, 2, n);
+        SVT_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+} // extern "C"

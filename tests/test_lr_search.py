@@ -141,3 +141,59 @@ def test_wiener_solve_oracle_vs_reference(oracle, ref):
         s2 = refme.ref_wiener_solve(win, p(M2), p(H2), p(vf2), p(hf2), p(vd2), p(hd2))
         assert np.array_equal(vd1, vd2) and np.array_equal(hd1, hd2), (it, win, vd1, vd2)
         assert np.array_equal(vf1, vf2) and np.array_equal(hf1, hf2) and s1 == s2, (it, win, vf1, vf2, s1, s2)
+
+
+def run_device(be, P, n, prev):
+    pkg = be.pkg
+    ws = be.empty((be.lib.svt_hip_lr_search_workspace(C.byref(P)),), np.uint8)
+    d_out = be.empty((n,), pkg.LrSearchUnit)
+    d_prev = be.dev(prev) if prev is not None else None
+    rc = be.lib.svt_hip_lr_search_plane(C.byref(P), be.ptr(d_prev) if d_prev is not None else None, be.ptr(d_out), be.ptr(ws), be.stream)
+    assert rc == 0
+    return be.host(d_out)
+
+
+def random_prev(g, n, win):
+    prev = np.zeros(n, PrevUnit)
+    prev["use"] = np.arange(n) % 2
+    off = (7 - win) // 2
+    for u in range(n):
+        for f in ("vfilter", "hfilter"):
+            t = [int(g.integers(lo, hi + 1)) for lo, hi in ((-5, 10), (-23, 8), (-17, 46))]
+            for i in range(off):
+                t[i] = 0
+            prev[f][u][:7] = t + [-2 * sum(t)] + t[::-1]
+    return prev
+
+
+# small planes (the lock-step emulator runs every trial of every unit): (width, height, bit depth, unit, ss_y, wiener, self-guided, previous-frame taps)
+DEV_CASES = [(80, 72, 8, 32, 0, (1, 7, 1, 0), (1, 0, 16, 5, 1), False),
+             (72, 40, 10, 64, 0, (1, 5, 1, 0), (1, 12, 16, 1, 1), True),
+             (60, 50, 8, 32, 1, (1, 3, 1, 1), (1, 3, 4, 1, 0), False)]
+GPU_CASES = [(500, 300, 8, 64, 0, (1, 7, 1, 0), (1, 0, 16, 1, 1), False),
+             (420, 260, 10, 128, 0, (1, 7, 1, 0), (1, 0, 16, 1, 1), True),
+             (300, 200, 10, 64, 1, (1, 5, 1, 1), (1, 2, 14, 4, 0), False),
+             (330, 170, 8, 64, 0, (1, 3, 0, 0), (1, 10, 16, 1, 1), True)]
+
+
+@pytest.mark.parametrize("case", range(len(GPU_CASES)))
+def test_lr_search_plane_hip(be, oracle, case):
+    """svt_hip_lr_search_plane == oracle_lr_search_plane: SSEs, Wiener taps, self-guided parameter set and projection for every unit"""
+    cases = GPU_CASES if be.is_gpu else DEV_CASES
+    if case >= len(cases):
+        pytest.skip("GPU-sized case")
+    w, h, bd, unit, ss_y, wn, sg, use_prev = cases[case]
+    g = rng(740 + case)
+    src, dgd, pad = make_planes(g, w, h, bd)
+    P = search_params(src, dgd, pad, w, h, bd, unit, ss_y, wn, sg)
+    n = oracle.oracle_lr_unit_rect(C.byref(P), -1, None)
+    prev = random_prev(g, n, wn[1]) if use_prev else None
+    want = np.zeros(n, SearchUnit)
+    oracle.oracle_lr_search_plane(C.byref(P), p(prev) if use_prev else None, p(want), None)
+    d_src, d_dgd = be.dev(src), be.dev(dgd)
+    PD = be.pkg.LrSearchParams.from_buffer_copy(bytes(P))
+    PD.src = be.ptr(d_src)
+    PD.dgd = be.ptr(d_dgd) + (pad * dgd.shape[1] + pad) * dgd.itemsize
+    got = run_device(be, PD, n, prev)
+    for k in ("sse", "vfilter", "hfilter", "ep", "xqd"):
+        assert np.array_equal(got[k], want[k]), (k, got[k], want[k])
