@@ -756,6 +756,9 @@ size_t svt_hip_lr_search_workspace(const SvtHipLrSearchParams *params); /* bytes
 /* prev: device, [units] or NULL.  Synchronises `stream` internally (the lock-step Wiener refinement reads the number of units still searching back every
  * eight steps).  Returns 0, or -1 for parameters outside the reference's ranges. */
 int svt_hip_lr_search_plane(const SvtHipLrSearchParams *params, const SvtHipLrPrevUnit *prev, SvtHipLrSearchUnit *units, void *workspace, void *stream);
+/* The same from HOST planes (what a seam around restoration_seg_search, rest_process.c:612, calls once per plane): dgd / src / prev / units are host pointers,
+ * dgd readable 3 rows above / below and 3 (left) / 4 (right) samples beside the plane; uploads, runs on the calling thread's stream, downloads. */
+int svt_hip_lr_search_plane_host(const SvtHipLrSearchParams *params, const SvtHipLrPrevUnit *prev, SvtHipLrSearchUnit *units);
 
 /* RTCD-signature single-call forms (common_dsp_rtcd.h:144-181); highbd pointers use the CONVERT_TO_BYTEPTR convention */
 void svt_av1_wiener_convolve_add_src_hip(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x,

@@ -1,0 +1,152 @@
+/* rest_process_seam.c -- TEST / BASELINE INFRASTRUCTURE: the reference's restoration process with the per-picture batching seam of INTEGRATION.md §3.
+ *
+ * This translation unit IS Source/Lib/Codec/rest_process.c of the reference (included below where it lies; nothing is copied).  The one change: the call
+ *
+ *     restoration_seg_search(context_ptr->rst_tmpbuf, &org_fts, &cpi_source, &trial_frame_rst, pcs, cdef_results->segment_index);      (rest_process.c:612)
+ *
+ * is given a macro name for the duration of the #include and lands in seam_restoration_seg_search() below.  With SVT_HIP_LR_SEAM unset (or the HIP library not
+ * loaded) that function IS the reference call.  With SVT_HIP_LR_SEAM=1 the first segment of a picture to arrive runs the per-unit half of the search for ALL
+ * units of every searched plane on the device -- one svt_hip_lr_search_plane_host() per plane, parameters taken field by field from cm->wn_filter_ctrls /
+ * cm->sg_filter_ctrls as restoration_seg_search and the functions below it read them (restoration_pick.c:1205-1527) -- and writes what search_norestore_seg /
+ * search_wiener_seg / search_sgrproj_seg leave behind: pcs->rusi_picture[plane][unit].sse / .wiener / .sgrproj, cm->sg_frame_ep_cnt[], the extended borders of
+ * the searched planes and pcs->rest_extend_flag[].  The other segments of the picture find the work done.  rest_finish_search (the serial rate decisions) and the
+ * frame filtering that follow are untouched reference code.  SVT_HIP_LR_SEAM_STATS=<file> receives the counters at exit.
+ */
+#define _GNU_SOURCE /* RTLD_DEFAULT */
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pcs.h"
+#include "sequence_control_set.h"
+#include "restoration.h"
+#include "svtav1_hip.h" /* include/svtav1_hip.h of this repository: the C ABI */
+
+void restoration_seg_search(int32_t *rst_tmpbuf, Yv12BufferConfig *org_fts, const Yv12BufferConfig *src, Yv12BufferConfig *trial_frame_rst,
+                            PictureControlSet *pcs, uint32_t segment_index);
+
+static struct {
+    pthread_mutex_t lock;
+    int             mode; /* 0 off, 1 on */
+    int (*search_host)(const SvtHipLrSearchParams *, const SvtHipLrPrevUnit *, SvtHipLrSearchUnit *);
+    PictureControlSet *done_pcs[64]; /* pictures whose search has been done by the seam (keyed by pcs + picture number) ... */
+    uint64_t           done_num[64];
+    uint32_t           seen[64];     /* ... and how many of their segments have passed: the record is dropped with the last one */
+    uint64_t           n_pictures, n_planes, n_units, n_declined;
+} L = {PTHREAD_MUTEX_INITIALIZER};
+
+static void lr_seam_stats(void) {
+    const char *f = getenv("SVT_HIP_LR_SEAM_STATS");
+    FILE       *o = f ? fopen(f, "w") : NULL;
+    if (!o) return;
+    fprintf(o, "pictures_offloaded %llu\nplanes_searched %llu\nunits_searched %llu\npictures_declined %llu\n", (unsigned long long)L.n_pictures,
+            (unsigned long long)L.n_planes, (unsigned long long)L.n_units, (unsigned long long)L.n_declined);
+    fclose(o);
+}
+static void lr_seam_init(void) {
+    const char *e = getenv("SVT_HIP_LR_SEAM");
+    if (!e || !atoi(e) || !getenv("SVT_HIP")) return;
+    *(void **)&L.search_host = dlsym(RTLD_DEFAULT, "svt_hip_lr_search_plane_host");
+    if (!L.search_host) { fprintf(stderr, "SVT_HIP_LR_SEAM: libsvtav1_hip is not loaded\n"); abort(); }
+    atexit(lr_seam_stats);
+    fprintf(stderr, "SVT_HIP_LR_SEAM: the loop-restoration unit search runs as one device stage per plane\n");
+    L.mode = 1;
+}
+static int lr_seam_on(void) {
+    static pthread_once_t once = PTHREAD_ONCE_INIT;
+    pthread_once(&once, lr_seam_init);
+    return L.mode;
+}
+
+/* one plane: restoration_seg_search's body for `plane` (restoration_pick.c:1470-1525) with the three unit loops on the device */
+static void search_plane(const Yv12BufferConfig *org_fts, const Yv12BufferConfig *src, PictureControlSet *pcs, int plane) {
+    Av1Common *const cm     = pcs->ppcs->av1_cm;
+    const int        is_uv  = plane > 0, highbd = cm->use_highbitdepth;
+    const int        w = src->crop_widths[is_uv], h = src->crop_heights[is_uv];
+    uint8_t         *dgd8 = org_fts->buffers[plane];
+    if (!pcs->rest_extend_flag[plane]) { /* :1480-1496, same arguments */
+        const int32_t align16_pad = (w % 16) ? 16 - (w % 16) : 0;
+        svt_extend_frame(dgd8, w, h, org_fts->strides[is_uv], RESTORATION_BORDER + 1 + align16_pad, RESTORATION_BORDER, highbd);
+        pcs->rest_extend_flag[plane] = true;
+    }
+    const WnFilterCtrls *wn = &cm->wn_filter_ctrls;
+    const SgFilterCtrls *sg = &cm->sg_filter_ctrls;
+    SvtHipLrSearchParams P;
+    memset(&P, 0, sizeof(P));
+    P.dgd = highbd ? (const void *)CONVERT_TO_SHORTPTR(dgd8) : (const void *)dgd8;
+    P.src = highbd ? (const void *)CONVERT_TO_SHORTPTR(src->buffers[plane]) : (const void *)src->buffers[plane];
+    P.dgd_stride = (uint32_t)org_fts->strides[is_uv]; P.src_stride = (uint32_t)src->strides[is_uv];
+    P.width = (uint32_t)w; P.height = (uint32_t)h;
+    P.unit_size = (uint32_t)pcs->rst_info[plane].restoration_unit_size;
+    P.ss_y = (uint8_t)(is_uv && cm->subsampling_y); P.highbd = (uint8_t)highbd; P.bit_depth = (uint8_t)cm->bit_depth;
+    P.wn_enabled = wn->enabled && (!plane || wn->use_chroma);
+    const int wn_luma = wn->filter_tap_lvl == 1 ? WIENER_WIN : (wn->filter_tap_lvl == 2 ? WIENER_WIN_CHROMA : WIENER_WIN_3TAP); /* :1286-1290 */
+    P.wiener_win = (uint8_t)(plane == AOM_PLANE_Y ? wn_luma : (wn_luma < WIENER_WIN_CHROMA ? wn_luma : WIENER_WIN_CHROMA));
+    P.wn_use_refinement = wn->use_refinement; P.wn_max_one_refinement_step = wn->max_one_refinement_step;
+    P.sg_enabled = sg->enabled && (!plane || sg->use_chroma);
+    if (sg->step_range < 16) { /* the reference-frame based range of search_selfguided_restoration (:560-572) */
+        const int8_t *e = cm->sg_ref_frame_ep, step = sg->step_range;
+        const int     none = e[0] < 0 && e[1] < 0, mid = none ? 0 : (e[1] < 0 ? e[0] : (e[0] < 0 ? e[1] : (e[0] + e[1]) / 2));
+        P.sg_start_ep = (uint8_t)(none ? 0 : AOMMAX(0, mid - step)); P.sg_end_ep = (uint8_t)(none ? SGRPROJ_PARAMS : AOMMIN(SGRPROJ_PARAMS, mid + step));
+        P.sg_ep_inc = 1; P.sg_refine = 1;
+    } else {
+        P.sg_start_ep = (uint8_t)sg->start_ep[is_uv]; P.sg_end_ep = (uint8_t)sg->end_ep[is_uv]; P.sg_ep_inc = (uint8_t)sg->ep_inc[is_uv]; P.sg_refine = (uint8_t)sg->refine[is_uv];
+    }
+    const int           n    = pcs->rst_info[plane].units_per_tile;
+    SvtHipLrSearchUnit *out  = calloc((size_t)n, sizeof(*out));
+    SvtHipLrPrevUnit   *prev = NULL;
+    const FrameType     ft   = pcs->ppcs->frm_hdr.frame_type;
+    if (P.wn_enabled && wn->use_prev_frame_coeffs && ft != KEY_FRAME && ft != INTRA_ONLY_FRAME) { /* :1297-1302 */
+        prev = calloc((size_t)n, sizeof(*prev));
+        for (int u = 0; u < n; u++)
+            if (pcs->rst_info[plane].unit_info[u].restoration_type == RESTORE_WIENER) {
+                prev[u].use = 1;
+                memcpy(prev[u].vfilter, pcs->rst_info[plane].unit_info[u].wiener_info.vfilter, 16);
+                memcpy(prev[u].hfilter, pcs->rst_info[plane].unit_info[u].wiener_info.hfilter, 16);
+            }
+    }
+    if (L.search_host(&P, prev, out)) { fprintf(stderr, "SVT_HIP_LR_SEAM: svt_hip_lr_search_plane_host refused the parameters\n"); abort(); }
+    RestUnitSearchInfo *rusi = pcs->rusi_picture[plane];
+    for (int u = 0; u < n; u++) {
+        rusi[u].sse[RESTORE_NONE] = out[u].sse[0];
+        if (P.wn_enabled) {
+            rusi[u].sse[RESTORE_WIENER] = out[u].sse[1];
+            if (out[u].sse[1] != INT64_MAX) { memcpy(rusi[u].wiener.vfilter, out[u].vfilter, 16); memcpy(rusi[u].wiener.hfilter, out[u].hfilter, 16); }
+        }
+        if (P.sg_enabled) {
+            rusi[u].sse[RESTORE_SGRPROJ] = out[u].sse[2];
+            rusi[u].sgrproj.ep = out[u].ep; rusi[u].sgrproj.xqd[0] = out[u].xqd[0]; rusi[u].sgrproj.xqd[1] = out[u].xqd[1];
+            cm->sg_frame_ep_cnt[out[u].ep]++; /* :1239-1241 (this thread is the only one searching the picture) */
+        }
+    }
+    L.n_planes++; L.n_units += (uint64_t)n;
+    free(prev); free(out);
+}
+
+static void seam_restoration_seg_search(int32_t *rst_tmpbuf, Yv12BufferConfig *org_fts, const Yv12BufferConfig *src, Yv12BufferConfig *trial_frame_rst,
+                                        PictureControlSet *pcs, uint32_t segment_index) {
+    if (!lr_seam_on()) { restoration_seg_search(rst_tmpbuf, org_fts, src, trial_frame_rst, pcs, segment_index); return; }
+    pthread_mutex_lock(&L.lock); /* (one picture at a time; the other segments of this picture wait here and then find it done) */
+    int slot = -1, free_slot = -1;
+    for (int i = 0; i < 64; i++) {
+        if (L.done_pcs[i] == pcs && L.done_num[i] == pcs->picture_number) slot = i;
+        if (!L.done_pcs[i] && free_slot < 0) free_slot = i;
+    }
+    if (slot < 0) {
+        Av1Common *const cm        = pcs->ppcs->av1_cm;
+        const int32_t    plane_end = ((cm->wn_filter_ctrls.enabled && cm->wn_filter_ctrls.use_chroma) || (cm->sg_filter_ctrls.enabled && cm->sg_filter_ctrls.use_chroma))
+               ? AOM_PLANE_V : AOM_PLANE_Y; /* :1462-1466 */
+        for (int32_t plane = AOM_PLANE_Y; plane <= plane_end; ++plane) search_plane(org_fts, src, pcs, plane);
+        L.n_pictures++;
+        if (free_slot < 0) { fprintf(stderr, "SVT_HIP_LR_SEAM: more than 64 pictures in the restoration stage\n"); abort(); }
+        slot = free_slot;
+        L.done_pcs[slot] = pcs; L.done_num[slot] = pcs->picture_number; L.seen[slot] = 0;
+    }
+    if (++L.seen[slot] == pcs->rest_segments_total_count) L.done_pcs[slot] = NULL; /* every segment has passed */
+    pthread_mutex_unlock(&L.lock);
+}
+
+#define restoration_seg_search(a, b, c, d, e, f) seam_restoration_seg_search(a, b, c, d, e, f)
+#include "rest_process.c" /* resolves through -I$(REF)/Source/Lib/Codec */

@@ -625,4 +625,34 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     return 0;
 }
 
+// Host-pointer form (what a seam in rest_process.c calls): uploads the plane with the 3 (+1 right) sample border the filters read and the source plane
+// through the calling thread's pinned arena, runs the stage on that thread's stream, downloads the per-unit results.
+int svt_hip_lr_search_plane_host(const SvtHipLrSearchParams* params, const SvtHipLrPrevUnit* prev, SvtHipLrSearchUnit* units) {
+    svthip::ensure_device();
+    SvtHipLrSearchParams P = *params;
+    const size_t px = P.highbd ? 2 : 1, w = P.width, h = P.height;
+    const size_t dpitch = svthip::align_up((w + 8) * px, 16), spitch = svthip::align_up(w * px, 16);
+    const int    n = n_units_1d((int)h, (int)P.unit_size) * n_units_1d((int)w, (int)P.unit_size);
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    P.dgd_stride = (uint32_t)(dpitch / px); P.src_stride = (uint32_t)(spitch / px);
+    const size_t wsb = carve(P, nullptr, nullptr);
+    const size_t dev = dpitch * (h + 6) + spitch * h + wsb + (size_t)n * (sizeof(SvtHipLrSearchUnit) + sizeof(SvtHipLrPrevUnit)) + 8192;
+    c.reserve(dev, dpitch * (h + 6) + spitch * h + (size_t)n * (2 * sizeof(SvtHipLrSearchUnit) + sizeof(SvtHipLrPrevUnit)) + 8192);
+    uint8_t* d_dgd = (uint8_t*)c.dalloc(dpitch * (h + 6));
+    uint8_t* d_src = (uint8_t*)c.dalloc(spitch * h);
+    void*    d_ws  = c.dalloc(wsb);
+    SvtHipLrSearchUnit* d_units = (SvtHipLrSearchUnit*)c.dalloc((size_t)n * sizeof(SvtHipLrSearchUnit));
+    SvtHipLrPrevUnit*   d_prev  = prev ? (SvtHipLrPrevUnit*)c.dalloc((size_t)n * sizeof(SvtHipLrPrevUnit)) : nullptr;
+    c.up2d(d_dgd, dpitch, (const uint8_t*)params->dgd - ((size_t)3 * params->dgd_stride + 3) * px, (size_t)params->dgd_stride * px, (w + 7) * px, h + 6);
+    c.up2d(d_src, spitch, params->src, (size_t)params->src_stride * px, w * px, h);
+    if (prev) c.up(d_prev, prev, (size_t)n * sizeof(SvtHipLrPrevUnit));
+    P.dgd = d_dgd + 3 * dpitch + 3 * px;
+    P.src = d_src;
+    const int rc = svt_hip_lr_search_plane(&P, d_prev, d_units, d_ws, c.stream);
+    if (rc) return rc;
+    c.down(units, d_units, (size_t)n * sizeof(SvtHipLrSearchUnit));
+    return 0;
+}
+
 } // extern "C"

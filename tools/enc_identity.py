@@ -43,10 +43,17 @@ CASES = {
     "seam_p6_8bit_hook": (256, 144, 8, 8, ["--preset", "6", "--lp", "1", "+seam", "+hook"]),
     "seam_p10_8bit": (448, 264, 10, 8, ["--preset", "10", "--lp", "1", "+seam"]),
     "seam_p2_8bit": (256, 144, 6, 8, ["--preset", "2", "--lp", "1", "+seam"]),
+    # the per-unit half of the loop-restoration search as one device stage per plane (oracle/ref_wrap/rest_process_seam.c): SVT_HIP_LR_SEAM=1
+    "lrseam_p4_8bit": (256, 144, 6, 8, ["--preset", "4", "--lp", "1", "+lrseam"]),
+    "lrseam_p2_10bit": (256, 144, 5, 10, ["--preset", "2", "--lp", "1", "+lrseam"]),
+    "lrseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "+lrseam"]),
+    "lrseam_me_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+lrseam", "+seam"]),  # both seams at once
+    "lrseam_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+lrseam"]),  # 1080p: tens of restoration units per plane, all host cores
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
     # BASELINE.json metric, second half: encoder fps @1080p preset 8 (C-only reference vs the same encoder with the ME stage on the MI355X), all host cores
     "fps_1080p_p8": (1920, 1080, 24, 8, ["--preset", "8", "+seam"]),
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
+    "tiny_lrseam_p4": (96, 64, 3, 8, ["--preset", "4", "--lp", "1", "+lrseam"]),
     "tiny_seam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam"]),
     "tiny_seam_p5_lp2": (128, 128, 6, 8, ["--preset", "5", "--lp", "2", "+seam"]),
     "tiny_p8_8bit": (64, 64, 3, 8, ["--preset", "8", "--lp", "1"]),
@@ -54,7 +61,7 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
-SEAM_CASES = [k for k in GPU_CASES if k.startswith("seam_")]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith("seam_") or k.startswith("lrseam_")]
 
 
 def make_clip(path, w, h, n, bd, seed=7):
@@ -93,7 +100,7 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
     os.makedirs(outdir, exist_ok=True)
     clip = os.path.join(outdir, name + ".yuv")
     make_clip(clip, w, h, n, bd)
-    seam, with_hook = "+seam" in extra, "+hook" in extra
+    seam, with_hook, lrseam = "+seam" in extra, "+hook" in extra, "+lrseam" in extra
     extra = [a for a in extra if not a.startswith("+")]
     rc, tc = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_c"), timeout=timeout)
     deterministic = True
@@ -104,10 +111,13 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
     counts_file = os.path.join(outdir, name + "_counts.txt")
     seam_file = os.path.join(outdir, name + "_seam.txt")
     env = {"SVT_HIP": str(device), "SVT_HIP_LIB": lib, "SVT_HIP_COUNT": counts_file}
+    lrseam_file = os.path.join(outdir, name + "_lrseam.txt")
     if seam:
         env.update({"SVT_HIP_ME_SEAM": "1", "SVT_HIP_ME_SEAM_STATS": seam_file})
-        if not with_hook and not only:
-            only = "-"  # no RTCD pointer matches: the seam alone
+    if lrseam:
+        env.update({"SVT_HIP_LR_SEAM": "1", "SVT_HIP_LR_SEAM_STATS": lrseam_file})
+    if (seam or lrseam) and not with_hook and not only:
+        only = "-"  # no RTCD pointer matches: the seam(s) alone
     if only:
         env["SVT_HIP_ONLY"] = only
     if skip:
@@ -141,6 +151,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
         res["seam"] = {k: (int(v) if v.strip().isdigit() else v.strip()) for k, v in st.items()}
         # the claim is void unless every picture really went through the device stage
         res["identical"] = same and res["seam"].get("pictures_offloaded", 0) > 0 and res["seam"].get("pictures_declined", 1) == 0
+    if lrseam:
+        st = dict(ln.split(None, 1) for ln in open(lrseam_file).read().splitlines()) if os.path.exists(lrseam_file) else {}
+        res["lrseam"] = {k: int(v) for k, v in st.items()}
+        res["identical"] = res["identical"] and res["lrseam"].get("units_searched", 0) > 0  # void unless restoration units really went through the device stage
     counts = {}
     if os.path.exists(counts_file):
         for ln in open(counts_file):
@@ -175,7 +189,7 @@ def main():
             union[k] = union.get(k, 0) + v
         print("%-20s identical=%s  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs  %s" % (nme, r["identical"], r.get("calls"), r.get("pointers_hit"),
                                                                                         r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"],
-                                                                                        r.get("seam", "")), flush=True)
+                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", ""))), flush=True)
         if "fps_c" in r:
             print("    encoder fps: C-only %.2f, with HIP %.2f" % (r["fps_c"], r.get("fps_hip", 0.0)), flush=True)
         if not r["identical"]:
