@@ -726,6 +726,9 @@ typedef struct SvtHipLrParams {
     const SvtHipLrUnit *units;   /* [vert units][horz units] */
 } SvtHipLrParams;
 void svt_hip_lr_filter_frame(const SvtHipLrParams *params, void *stream);
+/* The same from HOST memory (a seam around svt_av1_loop_restoration_filter_frame, rest_process.c:632, calls it per restored plane): every pointer of params is
+ * a host pointer, boundary_above / below point at frame column 0 (past the reference's RESTORATION_EXTRA_HORZ margin), dst may equal data; synchronous. */
+void svt_hip_lr_filter_frame_host(const SvtHipLrParams *params);
 /* The per-unit half of the loop-restoration SEARCH of one plane (restoration_seg_search, restoration_pick.c:1448-1527) as one resident device stage:
  * for every restoration unit the SSE of the unrestored unit (search_norestore_seg :1409), the Wiener solve + refinement (search_wiener_seg :1281:
  * svt_av1_compute_stats -> wiener_decompose_sep_sym -> finalize_sym_filter -> compute_score -> finer_tile_search_wiener_seg) and the self-guided

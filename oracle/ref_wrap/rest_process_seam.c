@@ -26,30 +26,33 @@
 
 void restoration_seg_search(int32_t *rst_tmpbuf, Yv12BufferConfig *org_fts, const Yv12BufferConfig *src, Yv12BufferConfig *trial_frame_rst,
                             PictureControlSet *pcs, uint32_t segment_index);
+void svt_av1_loop_restoration_filter_frame(int32_t *rst_tmpbuf, Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr);
 
 static struct {
     pthread_mutex_t lock;
     int             mode; /* 0 off, 1 on */
     int (*search_host)(const SvtHipLrSearchParams *, const SvtHipLrPrevUnit *, SvtHipLrSearchUnit *);
+    void (*filter_host)(const SvtHipLrParams *);
     PictureControlSet *done_pcs[64]; /* pictures whose search has been done by the seam (keyed by pcs + picture number) ... */
     uint64_t           done_num[64];
     uint32_t           seen[64];     /* ... and how many of their segments have passed: the record is dropped with the last one */
-    uint64_t           n_pictures, n_planes, n_units, n_declined;
+    uint64_t           n_pictures, n_planes, n_units, n_declined, n_filtered_planes;
 } L = {PTHREAD_MUTEX_INITIALIZER};
 
 static void lr_seam_stats(void) {
     const char *f = getenv("SVT_HIP_LR_SEAM_STATS");
     FILE       *o = f ? fopen(f, "w") : NULL;
     if (!o) return;
-    fprintf(o, "pictures_offloaded %llu\nplanes_searched %llu\nunits_searched %llu\npictures_declined %llu\n", (unsigned long long)L.n_pictures,
-            (unsigned long long)L.n_planes, (unsigned long long)L.n_units, (unsigned long long)L.n_declined);
+    fprintf(o, "pictures_offloaded %llu\nplanes_searched %llu\nunits_searched %llu\npictures_declined %llu\nplanes_filtered %llu\n", (unsigned long long)L.n_pictures,
+            (unsigned long long)L.n_planes, (unsigned long long)L.n_units, (unsigned long long)L.n_declined, (unsigned long long)L.n_filtered_planes);
     fclose(o);
 }
 static void lr_seam_init(void) {
     const char *e = getenv("SVT_HIP_LR_SEAM");
     if (!e || !atoi(e) || !getenv("SVT_HIP")) return;
     *(void **)&L.search_host = dlsym(RTLD_DEFAULT, "svt_hip_lr_search_plane_host");
-    if (!L.search_host) { fprintf(stderr, "SVT_HIP_LR_SEAM: libsvtav1_hip is not loaded\n"); abort(); }
+    *(void **)&L.filter_host = dlsym(RTLD_DEFAULT, "svt_hip_lr_filter_frame_host");
+    if (!L.search_host || !L.filter_host) { fprintf(stderr, "SVT_HIP_LR_SEAM: libsvtav1_hip is not loaded\n"); abort(); }
     atexit(lr_seam_stats);
     fprintf(stderr, "SVT_HIP_LR_SEAM: the loop-restoration unit search runs as one device stage per plane\n");
     L.mode = 1;
@@ -148,5 +151,45 @@ static void seam_restoration_seg_search(int32_t *rst_tmpbuf, Yv12BufferConfig *o
     pthread_mutex_unlock(&L.lock);
 }
 
+/* svt_av1_loop_restoration_filter_frame (restoration.c:1179-1247) with the unit loop of every restored plane as one device launch: the same border
+ * extension, the units of rst_info[plane].unit_info, the saved deblocked boundary lines of rsi->boundaries; the filtered plane replaces the frame's plane
+ * (the reference filters into cm->rst_frame and copies it back, :1241). */
+static void seam_loop_restoration_filter_frame(int32_t *rst_tmpbuf, Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr) {
+    if (!lr_seam_on() || optimized_lr) { svt_av1_loop_restoration_filter_frame(rst_tmpbuf, frame, cm, optimized_lr); return; }
+    const int32_t highbd = cm->use_highbitdepth;
+    for (int32_t plane = 0; plane < 3; ++plane) {
+        RestorationInfo *rsi = &cm->child_pcs->rst_info[plane];
+        rsi->optimized_lr    = optimized_lr;
+        if (rsi->frame_restoration_type == RESTORE_NONE) continue;
+        const int32_t is_uv = plane > 0, w = frame->crop_widths[is_uv], h = frame->crop_heights[is_uv];
+        svt_extend_frame(frame->buffers[plane], w, h, frame->strides[is_uv], RESTORATION_BORDER, RESTORATION_BORDER, highbd);
+        const int     n = rsi->units_per_tile;
+        SvtHipLrUnit *units = calloc((size_t)n, sizeof(*units));
+        for (int u = 0; u < n; u++) {
+            const RestorationUnitInfo *ri = &rsi->unit_info[u];
+            units[u].rtype = (int32_t)ri->restoration_type;
+            memcpy(units[u].vfilter, ri->wiener_info.vfilter, 16); memcpy(units[u].hfilter, ri->wiener_info.hfilter, 16);
+            units[u].ep = ri->sgrproj_info.ep; units[u].xqd[0] = ri->sgrproj_info.xqd[0]; units[u].xqd[1] = ri->sgrproj_info.xqd[1];
+        }
+        SvtHipLrParams P;
+        memset(&P, 0, sizeof(P));
+        void *data = highbd ? (void *)CONVERT_TO_SHORTPTR(frame->buffers[plane]) : (void *)frame->buffers[plane];
+        P.data = data; P.dst = data;
+        /* buffer column c of the saved lines holds frame column c - RESTORATION_EXTRA_HORZ (restoration.c:296-300) */
+        P.boundary_above = rsi->boundaries.stripe_boundary_above + (RESTORATION_EXTRA_HORZ << highbd);
+        P.boundary_below = rsi->boundaries.stripe_boundary_below + (RESTORATION_EXTRA_HORZ << highbd);
+        P.stride = P.dst_stride = (uint32_t)frame->strides[is_uv]; P.boundary_stride = (uint32_t)rsi->boundaries.stripe_boundary_stride;
+        P.width = (uint32_t)w; P.height = (uint32_t)h; P.unit_size = (uint32_t)rsi->restoration_unit_size;
+        P.ss_x = (uint8_t)(is_uv && cm->subsampling_x); P.ss_y = (uint8_t)(is_uv && cm->subsampling_y); P.highbd = (uint8_t)highbd; P.bit_depth = (uint8_t)cm->bit_depth;
+        P.units = units;
+        L.filter_host(&P);
+        free(units);
+        pthread_mutex_lock(&L.lock);
+        L.n_filtered_planes++;
+        pthread_mutex_unlock(&L.lock);
+    }
+}
+
 #define restoration_seg_search(a, b, c, d, e, f) seam_restoration_seg_search(a, b, c, d, e, f)
+#define svt_av1_loop_restoration_filter_frame(a, b, c, d) seam_loop_restoration_filter_frame(a, b, c, d)
 #include "rest_process.c" /* resolves through -I$(REF)/Source/Lib/Codec */

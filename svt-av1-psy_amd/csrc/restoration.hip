@@ -179,6 +179,35 @@ void svt_hip_lr_filter_frame(const SvtHipLrParams* params, void* stream) {
     SVT_LAUNCH_CHECK();
 }
 
+// Host-pointer form of the frame filter (what a seam around svt_av1_loop_restoration_filter_frame, rest_process.c:632, calls per restored plane): data, the two
+// boundary-line buffers (pointing at frame column 0, i.e. past the reference's RESTORATION_EXTRA_HORZ margin), units and dst are host pointers; dst may be data.
+void svt_hip_lr_filter_frame_host(const SvtHipLrParams* params) {
+    svthip::ensure_device();
+    SvtHipLrParams P = *params;
+    const size_t px = P.highbd ? 2 : 1, w = P.width, h = P.height;
+    const int    sh = 64 >> P.ss_y, off = 8 >> P.ss_y, us = (int)P.unit_size;
+    const size_t n_stripes = ((size_t)h + off + sh - 1) / sh, pitch = svthip::align_up(w * px, 16);
+    int nvu = ((int)h + (us >> 1)) / us, nhu = ((int)w + (us >> 1)) / us;
+    nvu = nvu > 0 ? nvu : 1; nhu = nhu > 0 ? nhu : 1;
+    const size_t ub = (size_t)nvu * nhu * sizeof(SvtHipLrUnit);
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve(pitch * (2 * h + 4 * n_stripes) + ub + 8192, pitch * (2 * h + 4 * n_stripes) + ub + 8192);
+    uint8_t* d_data  = (uint8_t*)c.dalloc(pitch * h);
+    uint8_t* d_dst   = (uint8_t*)c.dalloc(pitch * h);
+    uint8_t* d_above = (uint8_t*)c.dalloc(pitch * 2 * n_stripes);
+    uint8_t* d_below = (uint8_t*)c.dalloc(pitch * 2 * n_stripes);
+    SvtHipLrUnit* d_units = (SvtHipLrUnit*)c.dalloc(ub);
+    c.up2d(d_data, pitch, params->data, (size_t)params->stride * px, w * px, h);
+    c.up2d(d_above, pitch, params->boundary_above, (size_t)params->boundary_stride * px, w * px, 2 * n_stripes);
+    c.up2d(d_below, pitch, params->boundary_below, (size_t)params->boundary_stride * px, w * px, 2 * n_stripes);
+    c.up(d_units, params->units, ub);
+    P.data = d_data; P.dst = d_dst; P.boundary_above = d_above; P.boundary_below = d_below; P.units = d_units;
+    P.stride = P.dst_stride = P.boundary_stride = (uint32_t)(pitch / px);
+    svt_hip_lr_filter_frame(&P, c.stream);
+    c.down2d(params->dst, (size_t)params->dst_stride * px, d_dst, pitch, w * px, h);
+}
+
 // svt_av1_wiener_convolve_add_src -> _c (convolve.c:100-147); conv_params is rebuilt from the bit depth exactly as
 // get_conv_params_wiener does (convolve.h:70-88), which is what every caller passes (restoration.c:443, :1021)
 void svt_av1_wiener_convolve_add_src_hip(const uint8_t* src, ptrdiff_t src_stride, uint8_t* dst, ptrdiff_t dst_stride, const int16_t* filter_x,

@@ -48,6 +48,8 @@ CASES = {
     "lrseam_p2_10bit": (256, 144, 5, 10, ["--preset", "2", "--lp", "1", "+lrseam"]),
     "lrseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "+lrseam"]),
     "lrseam_me_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+lrseam", "+seam"]),  # both seams at once
+    "lrseam_p4_8bit_crf55": (448, 264, 6, 8, ["--preset", "4", "--lp", "1", "--crf", "55", "+lrseam"]),  # coarse quantisation: restoration wins more often
+    "lrseam_p3_10bit_crf50": (256, 144, 5, 10, ["--preset", "3", "--lp", "1", "--crf", "50", "+lrseam"]),
     "lrseam_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+lrseam"]),  # 1080p: tens of restoration units per plane, all host cores
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
     # BASELINE.json metric, second half: encoder fps @1080p preset 8 (C-only reference vs the same encoder with the ME stage on the MI355X), all host cores
