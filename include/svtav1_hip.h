@@ -678,6 +678,19 @@ typedef struct SvtHipCdefParams {
  * variances taken from dir / var (what the search pass over the same reconstruction wrote; the reference recomputes identical values, cdef.c:367-386).
  * All pointers inside `params` are DEVICE pointers; the struct itself is read on the host. */
 void svt_hip_cdef_frame(int mode, const SvtHipCdefParams *params, void *stream);
+/* svt_av1_cdef_frame (enc_cdef.c:284-560) for a 4:2:0 picture from HOST memory -- what a seam at cdef_process.c:458 calls: planes filtered IN PLACE (the
+ * reference keeps the neighbours' unfiltered samples in line / column buffers, which is what filtering out of place on the device gives), skip = the 8x8
+ * units svt_sb_compute_cdef_list leaves out (and every unit of a filter block the reference skips: all four strengths zero), pri / sec per filter block from
+ * frm_hdr->cdef_params.cdef_y_strength / cdef_uv_strength[mbmi.cdef_strength] (sec 3 -> 4).  width / height = mi_cols * 4, mi_rows * 4.  Synchronous. */
+typedef struct SvtHipCdefApplyHost {
+    void          *plane[3];
+    uint32_t       stride[3]; /* samples */
+    uint32_t       width, height;
+    uint8_t        num_planes, is_16bit, coeff_shift, damping; /* scs encoder_bit_depth - 8; frm_hdr->cdef_params.cdef_damping */
+    const uint8_t *skip;      /* [(fb rows * 8)][(fb cols * 8)] */
+    const int32_t *pri_y, *sec_y, *pri_uv, *sec_uv; /* [fb rows * fb cols] */
+} SvtHipCdefApplyHost;
+void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost *params);
 /* Strength selection over the search output: svt_search_one_dual -> svt_search_one_dual_c (aom_dsp_rtcd.h:242,
  * enc_cdef.c:627-683).  mse0 / mse1 = [sb_count][64] luma / chroma distortion tables (device; svt_hip_cdef_frame(mode 1) writes exactly this
  * layout), lev0 / lev1 = device arrays holding the nb_strengths pairs selected so far, entry [nb_strengths] receives the new pair,

@@ -669,6 +669,50 @@ void svt_hip_cdef_frame(int mode, const SvtHipCdefParams* params, void* stream) 
     else launch_frame<1>(*params, (hipStream_t)stream);
 }
 
+// Host-pointer form of the frame apply for all planes of a 4:2:0 picture (what a seam around svt_av1_cdef_frame, cdef_process.c:458, calls): uploads the
+// planes, the 8x8 skip map and the per-filter-block strengths, filters luma (which produces the directions / variances) then chroma out of place on the
+// device, downloads the filtered planes IN PLACE.  Every pointer is a host pointer.
+void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost* a) {
+    svthip::ensure_device();
+    const size_t px = a->is_16bit ? 2 : 1;
+    const uint32_t nhfb = (a->width + 63) / 64, nvfb = (a->height + 63) / 64, nfb = nhfb * nvfb;
+    size_t pitch[3], rows[3], wid[3], total = 0;
+    for (int p = 0; p < a->num_planes; p++) {
+        wid[p]   = p ? a->width >> 1 : a->width;
+        rows[p]  = p ? a->height >> 1 : a->height;
+        pitch[p] = svthip::align_up(wid[p] * px, 16);
+        total += 2 * pitch[p] * rows[p];
+    }
+    const size_t side = (size_t)nfb * 64 * (1 + 4) + (size_t)nvfb * 8 * nhfb * 8 + (size_t)nfb * 4 * 4 + 16384;
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve(total + side, total + side);
+    uint8_t* d_skip = (uint8_t*)c.dalloc((size_t)nvfb * 8 * nhfb * 8);
+    int32_t* d_str[4];
+    const int32_t* h_str[4] = {a->pri_y, a->sec_y, a->pri_uv, a->sec_uv};
+    for (int k = 0; k < 4; k++) { d_str[k] = (int32_t*)c.dalloc((size_t)nfb * 4); c.up(d_str[k], h_str[k], (size_t)nfb * 4); }
+    uint8_t* d_dir = (uint8_t*)c.dalloc((size_t)nfb * 64);
+    int32_t* d_var = (int32_t*)c.dalloc((size_t)nfb * 64 * 4);
+    c.up(d_skip, a->skip, (size_t)nvfb * 8 * nhfb * 8);
+    uint8_t *d_in[3], *d_out[3];
+    for (int p = 0; p < a->num_planes; p++) {
+        d_in[p]  = (uint8_t*)c.dalloc(pitch[p] * rows[p]);
+        d_out[p] = (uint8_t*)c.dalloc(pitch[p] * rows[p]);
+        c.up2d(d_in[p], pitch[p], a->plane[p], (size_t)a->stride[p] * px, wid[p] * px, rows[p]);
+        HIP_CHECK(hipMemcpyAsync(d_out[p], d_in[p], pitch[p] * rows[p], hipMemcpyDeviceToDevice, c.stream));
+        SvtHipCdefParams P;
+        memset(&P, 0, sizeof(P));
+        P.recon = d_in[p]; P.out = d_out[p];
+        P.recon_stride = P.out_stride = (uint32_t)(pitch[p] / px);
+        P.width = (uint32_t)wid[p]; P.height = (uint32_t)rows[p];
+        P.xdec = P.ydec = (uint8_t)(p ? 1 : 0); P.pli = (uint8_t)p; P.is_16bit = a->is_16bit;
+        P.coeff_shift = a->coeff_shift; P.pri_damping = P.sec_damping = a->damping; P.subsampling = 1;
+        P.skip = d_skip; P.pri = d_str[p ? 2 : 0]; P.sec = d_str[p ? 3 : 1]; P.dir = d_dir; P.var = d_var;
+        svt_hip_cdef_frame(0, &P, c.stream);
+    }
+    for (int p = 0; p < a->num_planes; p++) c.down2d(a->plane[p], (size_t)a->stride[p] * px, d_out[p], pitch[p], wid[p] * px, rows[p]);
+}
+
 uint8_t svt_aom_cdef_find_dir_hip(const uint16_t* img, int32_t stride, int32_t* var, int32_t coeff_shift) {
     svthip::HostCall& c = svthip::host_call();
     c.begin();

@@ -27,11 +27,13 @@ def _check(res):
     assert res["rc_c"] == 0 and res["rc_hip"] == 0, res.get("stderr_tail")
     assert res["hook_line"], "the encoder did not install the HIP variant"
     assert res["identical"], "the bitstream differs from the C-only encoder: %s" % res["case"]
+    if "cdefseam" in res:  # pictures were CDEF-filtered on the device, none declined
+        assert res["cdefseam"]["filter_blocks"] > 0 and res["cdefseam"]["pictures_declined"] == 0, res["cdefseam"]
     if "lrseam" in res:  # restoration units were searched on the device
         assert res["lrseam"]["units_searched"] > 0 and res["lrseam"]["pictures_offloaded"] > 0, res["lrseam"]
     if "seam" in res:  # the ME stage ran as one device call per picture for EVERY inter picture (a declined picture would run the reference's C code)
         assert res["seam"]["pictures_offloaded"] > 0 and res["seam"]["pictures_declined"] == 0, res["seam"]
-    elif "lrseam" not in res:
+    elif "lrseam" not in res and "cdefseam" not in res:
         assert res["pointers_hit"] >= 20 and res["calls"] > 1000, res
 
 

@@ -50,11 +50,22 @@ CASES = {
     "lrseam_me_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+lrseam", "+seam"]),  # both seams at once
     "lrseam_p4_8bit_crf55": (448, 264, 6, 8, ["--preset", "4", "--lp", "1", "--crf", "55", "+lrseam"]),  # coarse quantisation: restoration wins more often
     "lrseam_p3_10bit_crf50": (256, 144, 5, 10, ["--preset", "3", "--lp", "1", "--crf", "50", "+lrseam"]),
+    # CDEF applied to the whole picture by one device call (oracle/ref_wrap/cdef_process_seam.c): SVT_HIP_CDEF_SEAM=1
+    "cdefseam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+cdefseam"]),
+    "cdefseam_p4_10bit": (256, 144, 6, 10, ["--preset", "4", "--lp", "1", "+cdefseam"]),
+    "cdefseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "--crf", "45", "+cdefseam"]),
+    "allseams_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+seam", "+lrseam", "+cdefseam"]),
+    "allseams_1080p_p6": (1920, 1080, 6, 8, ["--preset", "6", "+seam", "+lrseam", "+cdefseam"]),
     "lrseam_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+lrseam"]),  # 1080p: tens of restoration units per plane, all host cores
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
     # BASELINE.json metric, second half: encoder fps @1080p preset 8 (C-only reference vs the same encoder with the ME stage on the MI355X), all host cores
     "fps_1080p_p8": (1920, 1080, 24, 8, ["--preset", "8", "+seam"]),
+    "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+lrseam", "+cdefseam"]),
+    "fps_1080p_p8_me": (1920, 1080, 60, 8, ["--preset", "8", "+seam"]),
+    "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+lrseam", "+cdefseam"]),
+    "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+lrseam", "+cdefseam"]),
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
+    "tiny_cdefseam_p8": (128, 64, 3, 8, ["--preset", "8", "--lp", "1", "+cdefseam"]),
     "tiny_lrseam_p4": (96, 64, 3, 8, ["--preset", "4", "--lp", "1", "+lrseam"]),
     "tiny_seam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam"]),
     "tiny_seam_p5_lp2": (128, 128, 6, 8, ["--preset", "5", "--lp", "2", "+seam"]),
@@ -63,7 +74,7 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
-SEAM_CASES = [k for k in GPU_CASES if k.startswith("seam_") or k.startswith("lrseam_")]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_"))]
 
 
 def make_clip(path, w, h, n, bd, seed=7):
@@ -102,7 +113,7 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
     os.makedirs(outdir, exist_ok=True)
     clip = os.path.join(outdir, name + ".yuv")
     make_clip(clip, w, h, n, bd)
-    seam, with_hook, lrseam = "+seam" in extra, "+hook" in extra, "+lrseam" in extra
+    seam, with_hook, lrseam, cdefseam = "+seam" in extra, "+hook" in extra, "+lrseam" in extra, "+cdefseam" in extra
     extra = [a for a in extra if not a.startswith("+")]
     rc, tc = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_c"), timeout=timeout)
     deterministic = True
@@ -118,7 +129,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
         env.update({"SVT_HIP_ME_SEAM": "1", "SVT_HIP_ME_SEAM_STATS": seam_file})
     if lrseam:
         env.update({"SVT_HIP_LR_SEAM": "1", "SVT_HIP_LR_SEAM_STATS": lrseam_file})
-    if (seam or lrseam) and not with_hook and not only:
+    cdefseam_file = os.path.join(outdir, name + "_cdefseam.txt")
+    if cdefseam:
+        env.update({"SVT_HIP_CDEF_SEAM": "1", "SVT_HIP_CDEF_SEAM_STATS": cdefseam_file})
+    if (seam or lrseam or cdefseam) and not with_hook and not only:
         only = "-"  # no RTCD pointer matches: the seam(s) alone
     if only:
         env["SVT_HIP_ONLY"] = only
@@ -157,6 +171,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
         st = dict(ln.split(None, 1) for ln in open(lrseam_file).read().splitlines()) if os.path.exists(lrseam_file) else {}
         res["lrseam"] = {k: int(v) for k, v in st.items()}
         res["identical"] = res["identical"] and res["lrseam"].get("units_searched", 0) > 0  # void unless restoration units really went through the device stage
+    if cdefseam:
+        st = dict(ln.split(None, 1) for ln in open(cdefseam_file).read().splitlines()) if os.path.exists(cdefseam_file) else {}
+        res["cdefseam"] = {k: int(v) for k, v in st.items()}
+        res["identical"] = res["identical"] and res["cdefseam"].get("filter_blocks", 0) > 0 and res["cdefseam"].get("pictures_declined", 1) == 0
     counts = {}
     if os.path.exists(counts_file):
         for ln in open(counts_file):
@@ -191,7 +209,7 @@ def main():
             union[k] = union.get(k, 0) + v
         print("%-20s identical=%s  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs  %s" % (nme, r["identical"], r.get("calls"), r.get("pointers_hit"),
                                                                                         r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"],
-                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", ""))), flush=True)
+                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", ""))), flush=True)
         if "fps_c" in r:
             print("    encoder fps: C-only %.2f, with HIP %.2f" % (r["fps_c"], r.get("fps_hip", 0.0)), flush=True)
         if not r["identical"]:
