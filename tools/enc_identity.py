@@ -80,7 +80,7 @@ SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefsea
 def make_clip(path, w, h, n, bd, seed=7):
     """Textured luma sliding by (2, 1) pixels per frame plus noise, smooth chroma; 4:2:0 planar, 16-bit little endian above 8 bit."""
     g = np.random.default_rng(seed)
-    W, H = w + 64, h + 64
+    W, H = w + max(64, 2 * n + 2), h + max(64, n + 2)  # (margin for the slide; unchanged for the clips of up to 31 frames)
     base = np.kron(g.integers(0, 256, (H // 8 + 2, W // 8 + 2)).astype(np.float32), np.ones((8, 8), np.float32))[:H, :W]
     yy, xx = np.mgrid[0:H, 0:W]
     tex = base * 0.5 + 64 + 40 * np.sin(xx / 9.0) + 30 * np.cos(yy / 7.0)
