@@ -691,6 +691,23 @@ typedef struct SvtHipCdefApplyHost {
     const int32_t *pri_y, *sec_y, *pri_uv, *sec_uv; /* [fb rows * fb cols] */
 } SvtHipCdefApplyHost;
 void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost *params);
+/* cdef_seg_search (cdef_process.c:106-345) for ALL filter blocks of a 4:2:0 picture from HOST memory: for each plane the distortion
+ * (svt_compute_cdef_dist of the filtered block, NOT yet multiplied by the sub-sampling factor) of every candidate (pri, sec) and every filter block, plus the
+ * luma directions / variances (pcs->cdef_dir_data).  Candidates: cdef_ctrls->default_first_pass_fs[] then default_second_pass_fs[] as (fs / 4, fs % 4 with 3 -> 4);
+ * the chroma list leaves out the entries whose *_fs_uv is -1.  subsampling[] = cdef_ctrls->subsampling_factor capped as :215-219 (luma 4, chroma 1).  Synchronous. */
+typedef struct SvtHipCdefSearchHost {
+    const void    *recon[3], *source[3]; /* pcs->cdef_input_recon / cdef_input_source */
+    uint32_t       recon_stride[3], source_stride[3];
+    uint32_t       width, height; /* mi_cols * 4, mi_rows * 4 */
+    uint8_t        is_16bit, coeff_shift, damping, subsampling[2], pad[3];
+    const uint8_t *skip;          /* [(fb rows * 8)][(fb cols * 8)] from svt_sb_compute_cdef_list */
+    uint32_t       ncand_y, ncand_uv;
+    const int32_t *pri_y, *sec_y, *pri_uv, *sec_uv;
+    uint64_t      *mse_y, *mse_u, *mse_v; /* [nfb][ncand] */
+    uint8_t       *dir;                   /* [nfb][64] */
+    int32_t       *var;                   /* [nfb][64] */
+} SvtHipCdefSearchHost;
+void svt_hip_cdef_search_host(const SvtHipCdefSearchHost *params);
 /* Strength selection over the search output: svt_search_one_dual -> svt_search_one_dual_c (aom_dsp_rtcd.h:242,
  * enc_cdef.c:627-683).  mse0 / mse1 = [sb_count][64] luma / chroma distortion tables (device; svt_hip_cdef_frame(mode 1) writes exactly this
  * layout), lev0 / lev1 = device arrays holding the nb_strengths pairs selected so far, entry [nb_strengths] receives the new pair,

@@ -713,6 +713,65 @@ void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost* a) {
     for (int p = 0; p < a->num_planes; p++) c.down2d(a->plane[p], (size_t)a->stride[p] * px, d_out[p], pitch[p], wid[p] * px, rows[p]);
 }
 
+// Host-pointer form of the strength SEARCH for the three planes of a 4:2:0 picture (what a seam around cdef_seg_search, cdef_process.c:443, calls once per
+// picture): the distortion of every candidate strength for every filter block, luma directions / variances included.  Every pointer is a host pointer.
+void svt_hip_cdef_search_host(const SvtHipCdefSearchHost* a) {
+    svthip::ensure_device();
+    const size_t   px = a->is_16bit ? 2 : 1;
+    const uint32_t nhfb = (a->width + 63) / 64, nvfb = (a->height + 63) / 64, nfb = nhfb * nvfb;
+    size_t pitch[3], rows[3], wid[3], total = 0;
+    for (int p = 0; p < 3; p++) {
+        wid[p]   = p ? a->width >> 1 : a->width;
+        rows[p]  = p ? a->height >> 1 : a->height;
+        pitch[p] = svthip::align_up(wid[p] * px, 16);
+        total += 2 * pitch[p] * rows[p];
+    }
+    const size_t nmse = (size_t)nfb * (a->ncand_y + 2 * (size_t)a->ncand_uv);
+    const size_t side = (size_t)nfb * 64 * 5 + (size_t)nvfb * 8 * nhfb * 8 + nmse * 8 + ((size_t)a->ncand_y + a->ncand_uv) * 8 + 16384;
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve(total + side, total + side + nmse * 8);
+    uint8_t* d_skip = (uint8_t*)c.dalloc((size_t)nvfb * 8 * nhfb * 8);
+    c.up(d_skip, a->skip, (size_t)nvfb * 8 * nhfb * 8);
+    int32_t *d_pri[2], *d_sec[2];
+    const int32_t* h_pri[2] = {a->pri_y, a->pri_uv};
+    const int32_t* h_sec[2] = {a->sec_y, a->sec_uv};
+    const uint32_t nc[2] = {a->ncand_y, a->ncand_uv};
+    for (int k = 0; k < 2; k++) {
+        d_pri[k] = (int32_t*)c.dalloc((size_t)(nc[k] ? nc[k] : 1) * 4); d_sec[k] = (int32_t*)c.dalloc((size_t)(nc[k] ? nc[k] : 1) * 4);
+        if (nc[k]) { c.up(d_pri[k], h_pri[k], (size_t)nc[k] * 4); c.up(d_sec[k], h_sec[k], (size_t)nc[k] * 4); }
+    }
+    uint8_t* d_dir = (uint8_t*)c.dalloc((size_t)nfb * 64);
+    int32_t* d_var = (int32_t*)c.dalloc((size_t)nfb * 64 * 4);
+    HIP_CHECK(hipMemsetAsync(d_dir, 0, (size_t)nfb * 64, c.stream));
+    HIP_CHECK(hipMemsetAsync(d_var, 0, (size_t)nfb * 64 * 4, c.stream));
+    uint64_t* d_mse[3];
+    uint64_t* h_mse[3] = {a->mse_y, a->mse_u, a->mse_v};
+    for (int p = 0; p < 3; p++) {
+        const uint32_t ncand = nc[p ? 1 : 0];
+        d_mse[p] = (uint64_t*)c.dalloc((size_t)nfb * (ncand ? ncand : 1) * 8);
+        if (!ncand) continue;
+        uint8_t* d_rec = (uint8_t*)c.dalloc(pitch[p] * rows[p]);
+        uint8_t* d_src = (uint8_t*)c.dalloc(pitch[p] * rows[p]);
+        c.up2d(d_rec, pitch[p], a->recon[p], (size_t)a->recon_stride[p] * px, wid[p] * px, rows[p]);
+        c.up2d(d_src, pitch[p], a->source[p], (size_t)a->source_stride[p] * px, wid[p] * px, rows[p]);
+        HIP_CHECK(hipMemsetAsync(d_mse[p], 0, (size_t)nfb * ncand * 8, c.stream));
+        SvtHipCdefParams P;
+        memset(&P, 0, sizeof(P));
+        P.recon = d_rec; P.source = d_src;
+        P.recon_stride = P.source_stride = (uint32_t)(pitch[p] / px);
+        P.width = (uint32_t)wid[p]; P.height = (uint32_t)rows[p];
+        P.xdec = P.ydec = (uint8_t)(p ? 1 : 0); P.pli = (uint8_t)p; P.is_16bit = a->is_16bit;
+        P.coeff_shift = a->coeff_shift; P.pri_damping = P.sec_damping = a->damping; P.subsampling = a->subsampling[p ? 1 : 0];
+        P.ncand = ncand; P.skip = d_skip; P.pri = d_pri[p ? 1 : 0]; P.sec = d_sec[p ? 1 : 0]; P.dir = d_dir; P.var = d_var; P.mse = d_mse[p];
+        svt_hip_cdef_frame(1, &P, c.stream);
+    }
+    for (int p = 0; p < 3; p++)
+        if (nc[p ? 1 : 0]) c.down(h_mse[p], d_mse[p], (size_t)nfb * nc[p ? 1 : 0] * 8);
+    c.down(a->dir, d_dir, (size_t)nfb * 64);
+    c.down(a->var, d_var, (size_t)nfb * 64 * 4);
+}
+
 uint8_t svt_aom_cdef_find_dir_hip(const uint16_t* img, int32_t stride, int32_t* var, int32_t coeff_shift) {
     svthip::HostCall& c = svthip::host_call();
     c.begin();
