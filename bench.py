@@ -23,7 +23,8 @@ Before a leg is timed its output is compared with the CPU checker on a slice (or
 and for the `cpu_baseline` legs); a mismatch aborts the run.  Extra objects on the JSON line: `roofline` (dominant kernel, algorithmic bytes of
 SURVEY 8(d) / event-timed kernel duration, against the 8 TB/s HBM peak and against the 6.3 TB/s copy ceiling of MI355X_MICROARCH.md),
 `cpu_baseline` (the reference's own AVX2 kernels from oracle/_ref on the host cores, bounded sample) and `kernels` (the other primitives of
-the metric and the stages around them, each with its own roofline).
+the metric and the stages around them, each with its own roofline), and `encoder_fps_1080p_preset8` (the metric's second half: the reference encoder built
+C-only under oracle/_ref/enc, encoding one clip with SVT_HIP unset and then with the ME / CDEF / LR stage seams on this GPU -- identical bitstream required).
 """
 import argparse
 import ctypes as C
@@ -264,6 +265,27 @@ def cpu_lr_search(k, budget_s):
         done += 1
     return {"parity_checked_units": done, "cpu_baseline": {"value": done / tcpu, "unit": "units/s", "cores": 1, "kind": "reference",
                                                            "sample": "%d random 256x256 units of the plane, C kernels" % done}}
+
+
+def encoder_fps():
+    """The second half of BASELINE.json's metric: encoder fps at 1080p preset 8.  The reference's own encoder (oracle/_ref/enc, C-only build with the binding of
+    INTEGRATION.md section 1) encodes one synthetic 60-frame 1080p clip with SVT_HIP unset, then with the ME, CDEF (search + apply) and LR (search + filter) stage
+    seams on this GPU; the two bitstreams must be identical or no number is recorded.  ~10 s; None when the encoder build is absent."""
+    import importlib.util
+    import tempfile
+    spec = importlib.util.spec_from_file_location("enc_identity", os.path.join(ROOT, "tools", "enc_identity.py"))
+    ei = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ei)
+    lib = os.path.join(ROOT, "svt-av1-psy_amd", "libsvtav1_hip.so")
+    if not (os.path.exists(ei.ENC) and os.path.exists(lib)):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        r = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600)
+    if not r.get("identical"):
+        sys.exit("bench.py: the encoder's bitstream with the stage seams differs from the C-only encoder -- no numbers recorded (%s)" % r.get("stderr_tail", ""))
+    return {"fps_c_only": r.get("fps_c"), "fps_with_stage_seams": r.get("fps_hip"), "bitstream_identical": True, "frames": r["frames"],
+            "config": "1080p 8-bit, preset 8, CRF 35, all host threads; reference encoder built C-only (no nasm on the box)",
+            "stages_on_gpu": {"me": r.get("seam"), "lr": r.get("lrseam"), "cdef": r.get("cdefseam")}}
 
 
 def roofline(bytes_alg, seconds, kernel, traffic_kernel=None, **extra):
@@ -806,6 +828,8 @@ def main():
     if cpu:
         host_descs = pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, aw, ah, PLANE, n_refs=1, src_plane=0, ref_plane0=1)
         out["cpu_baseline"] = cpu_me_baseline(host_descs, planes, planes, (aw, ah), budget_s=10.0)
+        if not a.only_me:
+            out["encoder_fps_1080p_preset8"] = encoder_fps()
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
