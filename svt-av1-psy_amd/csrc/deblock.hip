@@ -169,7 +169,11 @@ void lpf_host(void* s, int pitch, int is16, int vertical, int len, int blimit, i
     e.blimit = (uint8_t)blimit; e.limit = (uint8_t)limit; e.thresh = (uint8_t)thresh;
     c.up(de, &e, sizeof(e));
     svt_hip_lpf_edges_batch(d, (uint32_t)(dp / px), is16, bd, de, 1, c.stream);
-    c.down2d(h0, (size_t)pitch * px, d + mx * px, dp, rw * px, rh);
+    // write back only the samples this filter length can modify -- the C kernels' store footprint: 2 per side for lengths 4 and 6 (p1 .. q1), 3 for 8
+    // (p2 .. q2), 6 for 14 (p5 .. q5) -- so that neighbouring edges filtered concurrently by other DLF threads are never rewritten with stale values
+    const int mod = len == 14 ? 6 : (len == 8 ? 3 : 2), skip = half - mod;
+    if (vertical) c.down2d(h0 + (size_t)skip * px, (size_t)pitch * px, d + (mx + skip) * px, dp, (size_t)2 * mod * px, rh);
+    else c.down2d(h0 + (size_t)skip * pitch * px, (size_t)pitch * px, d + (size_t)skip * dp, dp, rw * px, (size_t)2 * mod);
 }
 
 } // namespace
