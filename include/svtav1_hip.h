@@ -744,7 +744,8 @@ typedef struct SvtHipLrUnit {          /* RestorationUnitInfo (restoration.h:184
 /* One plane of svt_av1_loop_restoration_filter_frame (restoration.c:1179): restoration units of unit_size pixels
  * (shifted up by 8 >> ss_y, the last one absorbing a remainder < 3/2 unit), 64 >> ss_y row stripes, 64 >> ss_x column
  * processing units, stripe boundaries taken from the saved deblocked lines (2 rows per stripe, restoration.c:288-332),
- * frame edges replicated (svt_extend_frame).  Out of place.  All pointers are device pointers. */
+ * frame edges replicated (svt_extend_frame).  Out of place.  All pointers are device pointers.  unit_size >= 64 >> ss_x, as in AV1 (RESTORATION_UNITSIZE
+ * 64 / 128 / 256 on luma, halved on 4:2:0 chroma): a 64 >> ss_x column processing unit takes the coefficients of the unit its first column lies in. */
 typedef struct SvtHipLrParams {
     const void *data;            /* CDEF output plane */
     const void *boundary_above;  /* rsb->stripe_boundary_above: rows 2*stripe, 2*stripe+1 */

@@ -411,6 +411,20 @@ PROTOTYPES.update({
     "svt_compute_cdef_dist_8bit_hip": (C.c_uint64, [vp, C.c_int32, vp, vp, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_uint8]),
     "svt_aom_copy_rect8_8bit_to_16bit_hip": (None, [vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32]),
 })
+class CdefApplyHost(C.Structure):
+    """SvtHipCdefApplyHost: svt_av1_cdef_frame from host planes (in place)."""
+    _fields_ = [("plane", vp * 3), ("stride", C.c_uint32 * 3), ("width", C.c_uint32), ("height", C.c_uint32), ("num_planes", C.c_uint8), ("is_16bit", C.c_uint8),
+                ("coeff_shift", C.c_uint8), ("damping", C.c_uint8), ("skip", vp), ("pri_y", vp), ("sec_y", vp), ("pri_uv", vp), ("sec_uv", vp)]
+
+
+class CdefSearchHost(C.Structure):
+    """SvtHipCdefSearchHost: cdef_seg_search for all filter blocks of a picture from host planes."""
+    _fields_ = [("recon", vp * 3), ("source", vp * 3), ("recon_stride", C.c_uint32 * 3), ("source_stride", C.c_uint32 * 3), ("width", C.c_uint32),
+                ("height", C.c_uint32), ("is_16bit", C.c_uint8), ("coeff_shift", C.c_uint8), ("damping", C.c_uint8), ("subsampling", C.c_uint8 * 2),
+                ("pad", C.c_uint8 * 3), ("skip", vp), ("ncand_y", C.c_uint32), ("ncand_uv", C.c_uint32), ("pri_y", vp), ("sec_y", vp), ("pri_uv", vp),
+                ("sec_uv", vp), ("mse_y", vp), ("mse_u", vp), ("mse_v", vp), ("dir", vp), ("var", vp)]
+
+
 LrUnit = np.dtype([("rtype", "<i4"), ("vfilter", "<i2", (8,)), ("hfilter", "<i2", (8,)), ("ep", "<i4"), ("xqd", "<i4", (2,))])
 assert LrUnit.itemsize == 48
 
