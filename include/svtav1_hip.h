@@ -641,6 +641,12 @@ typedef struct SvtHipLpfEdge {
     uint8_t  vertical, length, blimit, limit, thresh, pad[3];
 } SvtHipLpfEdge; /* 16 bytes */
 void svt_hip_lpf_edges_batch(void *plane, uint32_t stride, int is_16bit, int bd, const SvtHipLpfEdge *edges, uint32_t n, void *stream);
+/* One plane of svt_av1_loop_filter_frame (deblocking_filter.c:625) from HOST memory: all vertical-edge segments, then all horizontal-edge segments (the order
+ * the standard defines; the reference's SB-by-SB schedule with its one-SB lag for horizontal edges gives the same picture), in place.  The plane must be
+ * readable 16 samples left / right of its rows (the reference's picture padding).  A seam records the segments by running the reference's own driver with
+ * recording leaf functions.  Synchronous. */
+void svt_hip_lpf_plane_host(void *plane, uint32_t stride, uint32_t width, uint32_t height, int is_16bit, int bd, const SvtHipLpfEdge *vert, uint32_t n_vert,
+                            const SvtHipLpfEdge *horz, uint32_t n_horz);
 #define SVT_HIP_LPF_DECL(LEN)                                                                                                              \
     void svt_aom_lpf_horizontal_##LEN##_hip(uint8_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh); \
     void svt_aom_lpf_vertical_##LEN##_hip(uint8_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh);   \

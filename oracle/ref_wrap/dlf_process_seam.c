@@ -1,0 +1,138 @@
+/* dlf_process_seam.c -- TEST / BASELINE INFRASTRUCTURE: the reference's deblocking process with the frame-filter seam of INTEGRATION.md §3.
+ *
+ * This translation unit IS Source/Lib/Codec/dlf_process.c of the reference (included below where it lies; nothing is copied).  The one change: the call
+ *
+ *     svt_av1_loop_filter_frame(recon_buffer, pcs, 0, 3);                                                                       (dlf_process.c:122)
+ *
+ * is given a macro name for the duration of the #include and lands in seam_loop_filter_frame() below.  With SVT_HIP_DLF_SEAM unset (or the HIP library not
+ * loaded) that function IS the reference call.  With SVT_HIP_DLF_SEAM=1 the reference's own driver (svt_av1_loop_filter_frame -> svt_aom_loop_filter_sb ->
+ * set_lpf_parameters: filter levels, transform-size edges, skip -- the serial, mode-info dependent part) still runs, but the sixteen leaf pointers
+ * svt_aom_[highbd_]lpf_{horizontal,vertical}_{4,6,8,14} are recording functions while this thread is inside the seam: they append the 4-sample segment
+ * (position, length, blimit / limit / thresh) to a list instead of filtering.  The driver's decisions do not depend on sample values, so the list is exactly
+ * what it would have filtered; every plane is then filtered by ONE svt_hip_lpf_plane_host() call (all vertical-edge segments, then all horizontal ones).
+ * Outside the seam (other threads, svt_av1_pick_filter_level's trial filterings) the recording functions forward to the pointers they replaced.
+ * SVT_HIP_DLF_SEAM_STATS=<file> receives the counters at exit.
+ */
+#define _GNU_SOURCE /* RTLD_DEFAULT */
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pcs.h"
+#include "sequence_control_set.h"
+#include "aom_dsp_rtcd.h"
+#include "svtav1_hip.h" /* include/svtav1_hip.h of this repository: the C ABI */
+
+void svt_av1_loop_filter_frame(EbPictureBufferDesc *frame_buffer, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end);
+
+typedef void (*LpfFn)(uint8_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh);
+typedef void (*LpfHbdFn)(uint16_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh, int32_t bd);
+static struct {
+    pthread_mutex_t lock;
+    int             mode;
+    void (*plane_host)(void *, uint32_t, uint32_t, uint32_t, int, int, const SvtHipLpfEdge *, uint32_t, const SvtHipLpfEdge *, uint32_t);
+    LpfFn    orig[2][4];     /* [vertical][length index 4, 6, 8, 14] */
+    LpfHbdFn orig_hbd[2][4];
+    uint64_t n_pictures, n_segments;
+} F = {PTHREAD_MUTEX_INITIALIZER};
+
+typedef struct { SvtHipLpfEdge *e; uint32_t n, cap; } EdgeList;
+static __thread struct {
+    int            on;
+    const uint8_t *base[3];   /* byte address of sample (0, 0) of each plane */
+    size_t         stride[3]; /* samples */
+    uint32_t       rows[3];
+    int            px;
+    EdgeList       list[3][2]; /* [plane][vertical] */
+} T;
+
+static void record(const void *s, int vertical, int len, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh) {
+    for (int pl = 0; pl < 3; pl++) {
+        const ptrdiff_t off = (const uint8_t *)s - T.base[pl];
+        if (off < 0 || (size_t)off >= T.stride[pl] * T.rows[pl] * T.px) continue;
+        EdgeList *L = &T.list[pl][vertical];
+        if (L->n == L->cap) { L->cap = L->cap ? 2 * L->cap : 4096; L->e = realloc(L->e, (size_t)L->cap * sizeof(*L->e)); }
+        SvtHipLpfEdge *e = &L->e[L->n++];
+        memset(e, 0, sizeof(*e));
+        e->y = (uint32_t)((size_t)off / T.px / T.stride[pl]); e->x = (uint32_t)((size_t)off / T.px % T.stride[pl]);
+        e->vertical = (uint8_t)vertical; e->length = (uint8_t)len; e->blimit = *blimit; e->limit = *limit; e->thresh = *thresh;
+        return;
+    }
+    fprintf(stderr, "SVT_HIP_DLF_SEAM: a segment outside the picture's planes\n");
+    abort();
+}
+#define REC(V, VN, LI, LEN)                                                                                                                              \
+    static void rec_##VN##_##LEN(uint8_t *s, int32_t pitch, const uint8_t *b, const uint8_t *l, const uint8_t *t) {                                      \
+        if (T.on) record(s, V, LEN, b, l, t); else F.orig[V][LI](s, pitch, b, l, t);                                                                     \
+    }                                                                                                                                                    \
+    static void rec_hbd_##VN##_##LEN(uint16_t *s, int32_t pitch, const uint8_t *b, const uint8_t *l, const uint8_t *t, int32_t bd) {                     \
+        if (T.on) record(s, V, LEN, b, l, t); else F.orig_hbd[V][LI](s, pitch, b, l, t, bd);                                                             \
+    }
+REC(0, horizontal, 0, 4) REC(0, horizontal, 1, 6) REC(0, horizontal, 2, 8) REC(0, horizontal, 3, 14)
+REC(1, vertical, 0, 4) REC(1, vertical, 1, 6) REC(1, vertical, 2, 8) REC(1, vertical, 3, 14)
+
+static void dlf_seam_stats(void) {
+    const char *f = getenv("SVT_HIP_DLF_SEAM_STATS");
+    FILE       *o = f ? fopen(f, "w") : NULL;
+    if (!o) return;
+    fprintf(o, "pictures_filtered %llu\nsegments %llu\n", (unsigned long long)F.n_pictures, (unsigned long long)F.n_segments);
+    fclose(o);
+}
+static void dlf_seam_init(void) {
+    const char *e = getenv("SVT_HIP_DLF_SEAM");
+    if (!e || !atoi(e) || !getenv("SVT_HIP")) return;
+    *(void **)&F.plane_host = dlsym(RTLD_DEFAULT, "svt_hip_lpf_plane_host");
+    if (!F.plane_host) { fprintf(stderr, "SVT_HIP_DLF_SEAM: libsvtav1_hip is not loaded\n"); abort(); }
+#define SWAP(V, VN, LI, LEN)                                                                               \
+    F.orig[V][LI] = svt_aom_lpf_##VN##_##LEN; svt_aom_lpf_##VN##_##LEN = rec_##VN##_##LEN;                  \
+    F.orig_hbd[V][LI] = svt_aom_highbd_lpf_##VN##_##LEN; svt_aom_highbd_lpf_##VN##_##LEN = rec_hbd_##VN##_##LEN;
+    SWAP(0, horizontal, 0, 4) SWAP(0, horizontal, 1, 6) SWAP(0, horizontal, 2, 8) SWAP(0, horizontal, 3, 14)
+    SWAP(1, vertical, 0, 4) SWAP(1, vertical, 1, 6) SWAP(1, vertical, 2, 8) SWAP(1, vertical, 3, 14)
+    atexit(dlf_seam_stats);
+    fprintf(stderr, "SVT_HIP_DLF_SEAM: the deblocking filter of a picture runs as one device call per plane\n");
+    F.mode = 1;
+}
+static int dlf_seam_on(void) {
+    static pthread_once_t once = PTHREAD_ONCE_INIT;
+    pthread_once(&once, dlf_seam_init);
+    return F.mode;
+}
+
+static void seam_loop_filter_frame(EbPictureBufferDesc *fb, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end) {
+    if (!dlf_seam_on()) { svt_av1_loop_filter_frame(fb, pcs, plane_start, plane_end); return; }
+    const bool is_16bit = pcs->scs->is_16bit_pipeline;
+    T.px = is_16bit ? 2 : 1;
+    const uint32_t strides[3] = {fb->stride_y, fb->stride_cb, fb->stride_cr};
+    uint8_t       *bufs[3]    = {fb->buffer_y, fb->buffer_cb, fb->buffer_cr};
+    uint32_t       w[3], h[3];
+    for (int pl = 0; pl < 3; pl++) {
+        const int ss = pl > 0;
+        const uint32_t ox = fb->org_x >> ss, oy = fb->org_y >> ss;
+        w[pl] = (fb->width + ss) >> ss; h[pl] = (fb->height + ss) >> ss;
+        T.stride[pl] = strides[pl]; T.rows[pl] = ((h[pl] + 7) & ~7u) + 8; /* (segments may start up to the 8-aligned height) */
+        T.base[pl]   = bufs[pl] + ((size_t)oy * strides[pl] + ox) * T.px;
+        T.list[pl][0].n = T.list[pl][1].n = 0;
+    }
+    T.on = 1;
+    svt_av1_loop_filter_frame(fb, pcs, plane_start, plane_end); /* the reference's driver, recording */
+    T.on = 0;
+    const int bd = is_16bit ? (int)pcs->scs->static_config.encoder_bit_depth : 8;
+    uint64_t  segs = 0;
+    for (int pl = 0; pl < 3; pl++) {
+        const uint32_t nv = T.list[pl][1].n, nh = T.list[pl][0].n;
+        if (!(nv + nh)) continue;
+        uint32_t rows = 0; /* upload only the rows the segments reach */
+        for (uint32_t i = 0; i < nv; i++) { const uint32_t r = T.list[pl][1].e[i].y + 4; rows = r > rows ? r : rows; }
+        for (uint32_t i = 0; i < nh; i++) { const uint32_t r = T.list[pl][0].e[i].y + 8; rows = r > rows ? r : rows; }
+        F.plane_host((void *)T.base[pl], strides[pl], ((w[pl] + 7) & ~7u), rows, is_16bit, bd, T.list[pl][1].e, nv, T.list[pl][0].e, nh);
+        segs += nv + nh;
+    }
+    pthread_mutex_lock(&F.lock);
+    F.n_pictures++; F.n_segments += segs;
+    pthread_mutex_unlock(&F.lock);
+}
+
+#define svt_av1_loop_filter_frame(a, b, c, d) seam_loop_filter_frame(a, b, c, d)
+#include "dlf_process.c" /* resolves through -I$(REF)/Source/Lib/Codec */

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "svt_hip_tf_subpel_search_batch": (None, [vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svt_hip_lr_filter_frame_host": (None, [vp]),
     "svt_hip_cdef_apply_host": (None, [vp]),
+    "svt_hip_lpf_plane_host": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, C.c_uint32, vp, C.c_uint32]),
     "svt_hip_cdef_search_host": (None, [vp]),
     "svt_hip_lr_search_workspace": (C.c_size_t, [vp]),
     "svt_hip_lr_search_plane": (C.c_int, [vp, vp, vp, vp, vp]),

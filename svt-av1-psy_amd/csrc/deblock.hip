@@ -189,6 +189,29 @@ void svt_hip_lpf_edges_batch(void* plane, uint32_t stride, int is_16bit, int bd,
     SVT_LAUNCH_CHECK();
 }
 
+// Host-pointer form for one plane of a picture (what a seam around svt_av1_loop_filter_frame, dlf_process.c:122, calls after recording the edge segments the
+// reference's own driver would filter): uploads the plane with a 16-sample margin either side (the reference's picture padding), runs all vertical-edge
+// segments, then all horizontal-edge segments, downloads the plane in place.  x / y of a segment = its first q0 sample inside the plane.
+void svt_hip_lpf_plane_host(void* plane, uint32_t stride, uint32_t width, uint32_t height, int is_16bit, int bd, const SvtHipLpfEdge* vert, uint32_t n_vert,
+                            const SvtHipLpfEdge* horz, uint32_t n_horz) {
+    svthip::ensure_device();
+    if (n_vert + n_horz == 0) return;
+    const size_t px = is_16bit ? 2 : 1, M = 16, pitch = svthip::align_up((width + 2 * M) * px, 16), nb = (size_t)(n_vert + n_horz) * sizeof(SvtHipLpfEdge);
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve(pitch * height + nb + 8192, 2 * pitch * height + nb + 8192);
+    uint8_t*       d  = (uint8_t*)c.dalloc(pitch * height);
+    SvtHipLpfEdge* de = (SvtHipLpfEdge*)c.dalloc(nb ? nb : 16);
+    c.up2d(d, pitch, (const uint8_t*)plane - M * px, (size_t)stride * px, (width + 2 * M) * px, height);
+    SvtHipLpfEdge* he = (SvtHipLpfEdge*)c.palloc(nb);
+    for (uint32_t i = 0; i < n_vert; i++) { he[i] = vert[i]; he[i].x += (uint32_t)M; }
+    for (uint32_t i = 0; i < n_horz; i++) { he[n_vert + i] = horz[i]; he[n_vert + i].x += (uint32_t)M; }
+    HIP_CHECK(hipMemcpyAsync(de, he, nb, hipMemcpyHostToDevice, c.stream));
+    if (n_vert) svt_hip_lpf_edges_batch(d, (uint32_t)(pitch / px), is_16bit, bd, de, n_vert, c.stream);
+    if (n_horz) svt_hip_lpf_edges_batch(d, (uint32_t)(pitch / px), is_16bit, bd, de + n_vert, n_horz, c.stream);
+    c.down2d(plane, (size_t)stride * px, d + M * px, pitch, width * px, height);
+}
+
 #define LPF_PAIR(LEN)                                                                                                                                        \
     void svt_aom_lpf_horizontal_##LEN##_hip(uint8_t* s, int32_t pitch, const uint8_t* blimit, const uint8_t* limit, const uint8_t* thresh) {               \
         lpf_host(s, pitch, 0, 0, LEN, *blimit, *limit, *thresh, 8);                                                                                         \

@@ -27,18 +27,20 @@ def _check(res):
     assert res["rc_c"] == 0 and res["rc_hip"] == 0, res.get("stderr_tail")
     assert res["hook_line"], "the encoder did not install the HIP variant"
     assert res["identical"], "the bitstream differs from the C-only encoder: %s" % res["case"]
+    if "dlfseam" in res:  # deblocking segments were filtered on the device
+        assert res["dlfseam"]["segments"] > 0, res["dlfseam"]
     if "cdefseam" in res:  # pictures were CDEF-filtered on the device, none declined
         assert res["cdefseam"]["filter_blocks"] > 0 and res["cdefseam"]["pictures_declined"] == 0, res["cdefseam"]
     if "lrseam" in res:  # restoration units were searched on the device
         assert res["lrseam"]["units_searched"] > 0 and res["lrseam"]["pictures_offloaded"] > 0, res["lrseam"]
     if "seam" in res:  # the ME stage ran as one device call per picture for EVERY inter picture (a declined picture would run the reference's C code)
         assert res["seam"]["pictures_offloaded"] > 0 and res["seam"]["pictures_declined"] == 0, res["seam"]
-    elif "lrseam" not in res and "cdefseam" not in res:
+    elif "lrseam" not in res and "cdefseam" not in res and "dlfseam" not in res:
         assert res["pointers_hit"] >= 20 and res["calls"] > 1000, res
 
 
 @needs_encoder
-@pytest.mark.parametrize("case", ["tiny_p8_8bit", "tiny_p8_10bit", "tiny_p8_lossless", "tiny_seam_p8", "tiny_seam_p5_lp2", "tiny_lrseam_p4", "tiny_cdefseam_p8"])
+@pytest.mark.parametrize("case", ["tiny_p8_8bit", "tiny_p8_10bit", "tiny_p8_lossless", "tiny_seam_p8", "tiny_seam_p5_lp2", "tiny_lrseam_p4", "tiny_cdefseam_p8", "tiny_dlfseam_p4"])
 def test_encoder_identity_emulator(case, tmp_path):
     from conftest import EmuBackend  # builds the emulator library if needed
     EmuBackend()

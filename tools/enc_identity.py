@@ -54,17 +54,23 @@ CASES = {
     "cdefseam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+cdefseam"]),
     "cdefseam_p4_10bit": (256, 144, 6, 10, ["--preset", "4", "--lp", "1", "+cdefseam"]),
     "cdefseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "--crf", "45", "+cdefseam"]),
-    "allseams_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+seam", "+lrseam", "+cdefseam"]),
-    "allseams_1080p_p6": (1920, 1080, 6, 8, ["--preset", "6", "+seam", "+lrseam", "+cdefseam"]),
+    "allseams_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "allseams_1080p_p6": (1920, 1080, 6, 8, ["--preset", "6", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    # the deblocking filter of a picture as one device call per plane, segments recorded from the reference's own driver (oracle/ref_wrap/dlf_process_seam.c)
+    "dlfseam_p4_8bit": (256, 144, 6, 8, ["--preset", "4", "--lp", "1", "+dlfseam"]),
+    "dlfseam_p2_10bit": (256, 144, 5, 10, ["--preset", "2", "--lp", "1", "+dlfseam"]),
+    "dlfseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "+dlfseam"]),
+    "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+dlfseam", "+cdefseam", "+lrseam"]),
     "lrseam_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+lrseam"]),  # 1080p: tens of restoration units per plane, all host cores
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
     # BASELINE.json metric, second half: encoder fps @1080p preset 8 (C-only reference vs the same encoder with the ME stage on the MI355X), all host cores
     "fps_1080p_p8": (1920, 1080, 24, 8, ["--preset", "8", "+seam"]),
-    "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+lrseam", "+cdefseam"]),
+    "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
     "fps_1080p_p8_me": (1920, 1080, 60, 8, ["--preset", "8", "+seam"]),
-    "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+lrseam", "+cdefseam"]),
-    "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+lrseam", "+cdefseam"]),
+    "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
+    "tiny_dlfseam_p4": (128, 64, 3, 8, ["--preset", "4", "--lp", "1", "+dlfseam"]),
     "tiny_cdefseam_p8": (128, 64, 3, 8, ["--preset", "8", "--lp", "1", "+cdefseam"]),
     "tiny_lrseam_p4": (96, 64, 3, 8, ["--preset", "4", "--lp", "1", "+lrseam"]),
     "tiny_seam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam"]),
@@ -74,7 +80,7 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
-SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_"))]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_"))]
 
 
 def make_clip(path, w, h, n, bd, seed=7):
@@ -113,7 +119,7 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
     os.makedirs(outdir, exist_ok=True)
     clip = os.path.join(outdir, name + ".yuv")
     make_clip(clip, w, h, n, bd)
-    seam, with_hook, lrseam, cdefseam = "+seam" in extra, "+hook" in extra, "+lrseam" in extra, "+cdefseam" in extra
+    seam, with_hook, lrseam, cdefseam, dlfseam = "+seam" in extra, "+hook" in extra, "+lrseam" in extra, "+cdefseam" in extra, "+dlfseam" in extra
     extra = [a for a in extra if not a.startswith("+")]
     rc, tc = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_c"), timeout=timeout)
     deterministic = True
@@ -132,7 +138,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
     cdefseam_file = os.path.join(outdir, name + "_cdefseam.txt")
     if cdefseam:
         env.update({"SVT_HIP_CDEF_SEAM": "1", "SVT_HIP_CDEF_SEAM_STATS": cdefseam_file})
-    if (seam or lrseam or cdefseam) and not with_hook and not only:
+    dlfseam_file = os.path.join(outdir, name + "_dlfseam.txt")
+    if dlfseam:
+        env.update({"SVT_HIP_DLF_SEAM": "1", "SVT_HIP_DLF_SEAM_STATS": dlfseam_file})
+    if (seam or lrseam or cdefseam or dlfseam) and not with_hook and not only:
         only = "-"  # no RTCD pointer matches: the seam(s) alone
     if only:
         env["SVT_HIP_ONLY"] = only
@@ -171,6 +180,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
         st = dict(ln.split(None, 1) for ln in open(lrseam_file).read().splitlines()) if os.path.exists(lrseam_file) else {}
         res["lrseam"] = {k: int(v) for k, v in st.items()}
         res["identical"] = res["identical"] and res["lrseam"].get("units_searched", 0) > 0  # void unless restoration units really went through the device stage
+    if dlfseam:
+        st = dict(ln.split(None, 1) for ln in open(dlfseam_file).read().splitlines()) if os.path.exists(dlfseam_file) else {}
+        res["dlfseam"] = {k: int(v) for k, v in st.items()}
+        res["identical"] = res["identical"] and res["dlfseam"].get("segments", 0) > 0
     if cdefseam:
         st = dict(ln.split(None, 1) for ln in open(cdefseam_file).read().splitlines()) if os.path.exists(cdefseam_file) else {}
         res["cdefseam"] = {k: int(v) for k, v in st.items()}
@@ -209,7 +222,7 @@ def main():
             union[k] = union.get(k, 0) + v
         print("%-20s identical=%s  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs  %s" % (nme, r["identical"], r.get("calls"), r.get("pointers_hit"),
                                                                                         r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"],
-                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", ""))), flush=True)
+                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", ""))), flush=True)
         if "fps_c" in r:
             print("    encoder fps: C-only %.2f, with HIP %.2f" % (r["fps_c"], r.get("fps_hip", 0.0)), flush=True)
         if not r["identical"]:
