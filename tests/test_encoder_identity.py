@@ -27,8 +27,8 @@ def _check(res):
     assert res["rc_c"] == 0 and res["rc_hip"] == 0, res.get("stderr_tail")
     assert res["hook_line"], "the encoder did not install the HIP variant"
     assert res["identical"], "the bitstream differs from the C-only encoder: %s" % res["case"]
-    if "dlfseam" in res:  # deblocking segments were filtered on the device
-        assert res["dlfseam"]["segments"] > 0, res["dlfseam"]
+    if "dlfseam" in res and res["case"].startswith(("dlfseam_", "tiny_dlfseam")):  # deblocking segments were filtered on the device
+        assert res["dlfseam"].get("segments", 0) > 0, res["dlfseam"]
     if "cdefseam" in res:  # pictures were CDEF-filtered on the device, none declined
         assert res["cdefseam"]["filter_blocks"] > 0 and res["cdefseam"]["pictures_declined"] == 0, res["cdefseam"]
     if "lrseam" in res:  # restoration units were searched on the device
