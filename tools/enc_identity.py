@@ -57,7 +57,7 @@ CASES = {
     "allseams_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
     "allseams_1080p_p6": (1920, 1080, 6, 8, ["--preset", "6", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
     # the deblocking filter of a picture as one device call per plane, segments recorded from the reference's own driver (oracle/ref_wrap/dlf_process_seam.c)
-    "dlfseam_p4_8bit": (256, 144, 6, 8, ["--preset", "4", "--lp", "1", "--crf", "50", "+dlfseam"]),
+    "dlfseam_p5_8bit": (448, 264, 8, 8, ["--preset", "5", "--lp", "1", "+dlfseam"]),
     "dlfseam_p2_10bit": (256, 144, 5, 10, ["--preset", "2", "--lp", "1", "+dlfseam"]),
     "dlfseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "+dlfseam"]),
     "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+dlfseam", "+cdefseam", "+lrseam"]),
