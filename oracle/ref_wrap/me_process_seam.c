@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "motion_estimation.h" /* declares svt_aom_motion_estimation_b64 before the macro below exists */
 #include "me_context.h"
@@ -66,6 +67,7 @@ static struct {
     SeamPicture     rec[SEAM_RECS];
     uint64_t        sum[SEAM_RING * 2][2]; /* (picture id, plane checksum) of what is resident */
     uint64_t        n_pictures, n_declined, n_sb, n_uploads, n_reuploads;
+    double          t_stage, t_hash; /* seconds inside run_picture (under the lock) / of that, hashing planes */
     char            why[128];
 } G = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, -1};
 
@@ -76,6 +78,7 @@ static void seam_stats(void) {
     fprintf(o, "pictures_offloaded %llu\npictures_declined %llu\nsb_results %llu\nplane_uploads %llu\nplane_reuploads %llu\nlast_decline %s\n",
             (unsigned long long)G.n_pictures, (unsigned long long)G.n_declined, (unsigned long long)G.n_sb, (unsigned long long)G.n_uploads,
             (unsigned long long)G.n_reuploads, G.why[0] ? G.why : "-");
+    fprintf(o, "ms_in_stage_calls %llu\nms_hashing_planes %llu\n", (unsigned long long)(G.t_stage * 1e3), (unsigned long long)(G.t_hash * 1e3));
     fclose(o);
 }
 static void seam_init(void) { /* once (pthread_once): ME threads arriving during the initialisation wait instead of seeing "off" */
@@ -101,7 +104,15 @@ static int seam_on(void) {
     return G.mode;
 }
 
-static uint64_t plane_sum(const EbPictureBufferDesc *p) { /* content check of the visible luma samples (padding is a function of them) */
+static double seam_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static uint64_t plane_sum_(const EbPictureBufferDesc *p);
+static uint64_t plane_sum(const EbPictureBufferDesc *p) {
+    const double   t0 = seam_now();
+    const uint64_t h  = plane_sum_(p);
+    G.t_hash += seam_now() - t0;
+    return h;
+}
+static uint64_t plane_sum_(const EbPictureBufferDesc *p) { /* content check of the visible luma samples (padding is a function of them) */
     uint64_t h = 1469598103934665603ull;
     for (uint32_t y = 0; y < p->height; y++) {
         const uint8_t *r = p->buffer_y + (size_t)(p->org_y + y) * p->stride_y + p->org_x;
@@ -303,7 +314,9 @@ static EbErrorType seam_motion_estimation_b64(PictureParentControlSet *pcs, uint
         P = spare;
         P->pcs = pcs; P->picture_number = pcs->picture_number; P->consumed = 0; P->state = 1;
         EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
+        const double t0 = seam_now();
         const int rc = run_picture(P, pcs, me_ctx, pa->input_padded_pic); /* (other pictures queue on the lock: one stage at a time) */
+        G.t_stage += seam_now() - t0;
         if (rc) { P->state = 3; P->n_sb = pcs->b64_total_count; G.n_declined++; }
         else    { P->state = 2; G.n_pictures++; }
         pthread_cond_broadcast(&G.ready);
