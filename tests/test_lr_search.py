@@ -169,14 +169,18 @@ def random_prev(g, n, win):
 # small planes (the lock-step emulator runs every trial of every unit): (width, height, bit depth, unit, ss_y, wiener, self-guided, previous-frame taps)
 DEV_CASES = [(80, 72, 8, 32, 0, (1, 7, 1, 0), (1, 0, 16, 5, 1), False),
              (72, 40, 10, 64, 0, (1, 5, 1, 0), (1, 12, 16, 1, 1), True),
-             (60, 50, 8, 32, 1, (1, 3, 1, 1), (1, 3, 4, 1, 0), False)]
+             (60, 50, 8, 32, 1, (1, 3, 1, 1), (1, 3, 4, 1, 0), False),
+             (70, 50, 10, 64, 0, (1, 7, 1, 0), (0, 0, 0, 1, 0), False),   # one unit (plane smaller than 3/2 unit), Wiener only
+             (50, 40, 8, 64, 0, (0, 7, 0, 0), (1, 9, 10, 1, 1), False)]   # one unit, self-guided only, a single parameter set
 GPU_CASES = [(500, 300, 8, 64, 0, (1, 7, 1, 0), (1, 0, 16, 1, 1), False),
              (420, 260, 10, 128, 0, (1, 7, 1, 0), (1, 0, 16, 1, 1), True),
              (300, 200, 10, 64, 1, (1, 5, 1, 1), (1, 2, 14, 4, 0), False),
-             (330, 170, 8, 64, 0, (1, 3, 0, 0), (1, 10, 16, 1, 1), True)]
+             (330, 170, 8, 64, 0, (1, 3, 0, 0), (1, 10, 16, 1, 1), True),
+             (70, 50, 10, 64, 0, (1, 7, 1, 0), (0, 0, 0, 1, 0), False),
+             (1000, 90, 8, 256, 0, (0, 7, 0, 0), (1, 9, 10, 1, 1), False)]  # one row of wide units (the last one 1.4 units wide)
 
 
-@pytest.mark.parametrize("case", range(len(GPU_CASES)))
+@pytest.mark.parametrize("case", range(max(len(GPU_CASES), len(DEV_CASES))))
 def test_lr_search_plane_hip(be, oracle, case):
     """svt_hip_lr_search_plane == oracle_lr_search_plane: SSEs, Wiener taps, self-guided parameter set and projection for every unit"""
     cases = GPU_CASES if be.is_gpu else DEV_CASES
