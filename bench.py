@@ -823,6 +823,7 @@ def main():
         kernels.update(bench_legs.me_results(torch, lib, pkg, stream, es, 1))
         kernels.update(bench_legs.me_stage(torch, lib, pkg, stream, es, 1))
         kernels.update(bench_legs.tf_frames(torch, lib, pkg, stream, es, 1))
+        kernels.update(bench_legs.tf_inter_pred(torch, lib, pkg, stream, max(es // 2, 2), 1))
         kernels["txfm_quant_roundtrip"] = bench_legs.txfm_roundtrip(torch, lib, pkg, stream, max(es // 4, 3), 1)
     out["kernels"] = kernels
     if cpu:

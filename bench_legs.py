@@ -608,6 +608,36 @@ def lr_search(torch, lib, pkg, stream, steps, warmup, keep=None):
     return out
 
 
+def tf_inter_pred(torch, lib, pkg, stream, steps, warmup):
+    """The temporal filter's final motion compensation: one 1080p 8-bit 4:2:0 central picture against 6 reference pictures, every 16x16 block (luma + chroma,
+    MULTITAP_SHARP) = 6 x 8 160 blocks in one launch, predictions written as picture-sized planes.  Bytes: 1.5 B per sample out + the interpolation window in."""
+    g = np.random.default_rng(23)
+    W, H, PAD, n_refs = 1920, 1088, 80, 6
+    shapes = [(H + 2 * PAD, W + 2 * PAD), (H // 2 + PAD, W // 2 + PAD), (H // 2 + PAD, W // 2 + PAD)]
+    refs = [torch.randint(0, 256, (n_refs,) + s, dtype=torch.uint8, device="cuda") for s in shapes]
+    pshape = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+    preds = [torch.zeros((n_refs,) + s, dtype=torch.uint8, device="cuda") for s in pshape]
+    blocks = [(x, y) for y in range(0, H, 16) for x in range(0, W, 16)]
+    n = len(blocks) * n_refs
+    d = np.zeros(n, pkg.TfMcDesc)
+    a = np.array(blocks * n_refs)
+    r = np.repeat(np.arange(n_refs), len(blocks))
+    d["pu_x"], d["pu_y"], d["bsize"] = a[:, 0], a[:, 1], 16
+    d["mv_x"], d["mv_y"] = g.integers(-40, 41, n), g.integers(-40, 41, n)
+    for pl in range(3):
+        d["ref_off"][:, pl] = r.astype(np.uint64) * (shapes[pl][0] * shapes[pl][1])
+        d["pred_off"][:, pl] = r.astype(np.uint64) * (pshape[pl][0] * pshape[pl][1])
+    P = pkg.TfSubpelParams()
+    P.bit_depth, P.mi_rows, P.mi_cols, P.ref_org_x, P.ref_org_y, P.ref_stride = 8, H // 4, W // 4, PAD, PAD, shapes[0][1]
+    PL = pkg.TfMcPlanes()
+    for pl in range(3):
+        PL.ref[pl], PL.pred[pl], PL.ref_stride[pl], PL.pred_stride[pl] = refs[pl].data_ptr(), preds[pl].data_ptr(), shapes[pl][1], pshape[pl][1]
+    d_d = torch.from_numpy(d.view(np.uint8).reshape(-1)).cuda()
+    t = _time(torch, lambda: lib.svt_hip_tf_inter_pred_batch(C.addressof(P), C.addressof(PL), d_d.data_ptr(), n, 1, stream), steps, warmup, batches=3)
+    out_bytes = n_refs * W * H * 1.5
+    return {"tf_inter_pred_1080p8_6refs": {"us": t * 1e6, "blocks_per_s": n / t, "GBps_out": out_bytes / t / 1e9, "hbm_frac_out_plus_in": 2 * out_bytes / t / 8e12}}
+
+
 def hme_chain(torch, lib, pkg, stream, steps, warmup):
     """The three HME levels of a 1080p picture against 4 references, chained on the device (svt_hip_hme_level_batch x 3: descriptor kernel ->
     svt_hip_sad_loop_batch -> rescale kernel per level): level 0 on the 1/16-area planes (2 x 2 regions of 16x16), levels 1 and 2 with 8x3 areas

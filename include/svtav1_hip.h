@@ -469,6 +469,27 @@ typedef struct SvtHipTfSubpelResult {
 void svt_hip_tf_subpel_search_batch(const SvtHipTfSubpelParams *params, const void *src_base, const void *ref_base, const SvtHipTfSubpelDesc *descs,
                                     uint32_t n, SvtHipTfSubpelResult *results, void *stream);
 
+/* The temporal filter's final motion compensation, batched: replaces tf_64x64_inter_prediction / tf_32x32_ / tf_16x16_ / tf_8x8_inter_prediction
+ * (temporal_filtering.c:2256-2620) for the blocks of a (central picture, reference picture) pair -- svt_aom_inter_prediction's uni-directional
+ * SIMPLE_TRANSLATION path (enc_inter_prediction.c:4102) with MULTITAP_SHARP kernels (the 4-tap regular kernel for a chroma dimension <= 4), the MV
+ * clamped per plane, luma + (chroma != 0: me_ctx->tf_chroma) both 4:2:0 chroma blocks at ((pu >> 3) << 3) / 2.  The prediction of a block lands at the
+ * block's position in picture-sized planes -- the `preds` svt_hip_tf_filter_frame reads.  params: bit_depth, mi_rows / mi_cols, ref_org_x / ref_org_y (the
+ * LUMA padding origin of the reference pictures; chroma: half); the strides come from `planes`.  All pointers device. */
+typedef struct SvtHipTfMcPlanes {
+    const void *ref[3];  /* base of the reference pictures' Y / U / V buffers */
+    void       *pred[3]; /* base of the prediction planes */
+    uint32_t    ref_stride[3], pred_stride[3]; /* samples */
+} SvtHipTfMcPlanes;
+typedef struct SvtHipTfMcDesc {
+    uint64_t ref_off[3];  /* samples from ref[pl] to this block's reference picture's padded buffer of plane pl */
+    uint64_t pred_off[3]; /* samples from pred[pl] to sample (0, 0) of this block's prediction plane pl */
+    uint16_t pu_x, pu_y;  /* block origin (luma samples) */
+    uint8_t  bsize, pad;  /* 8, 16, 32 or 64 */
+    int16_t  mv_x, mv_y;  /* 1/8 pel (me_ctx->tf_*_mv_x / _y) */
+    uint16_t pad2[3];
+} SvtHipTfMcDesc;
+void svt_hip_tf_inter_pred_batch(const SvtHipTfSubpelParams *params, const SvtHipTfMcPlanes *planes, const SvtHipTfMcDesc *descs, uint32_t n, int chroma, void *stream);
+
 /* The whole open-loop ME stage from a HOST picture: upload -> quarter / sixteenth planes (made once per picture on the device, kept in the ring
  * with the full plane) -> HME levels 0-2 -> final search centre + integer_search_b64 geometry + full-pel search -> MeSbResults (+ raw tables on
  * request) -> download, on the submission's own stream like svt_hip_me_session_submit.  svt_hip_me_session_enable_stage sizes the extra

@@ -169,3 +169,79 @@ void oracle_tf_subpel_search(const OracleTfSubpelParams *P, const void *src, int
     *mv_x = bx; *mv_y = by;
     free(pred);
 }
+
+/* ---- the temporal filter's final motion compensation (tf_{64x64,32x32,16x16,8x8}_inter_prediction, temporal_filtering.c:2256-2620): one square block,
+ * luma and -- with tf_chroma -- both 4:2:0 chroma blocks, through svt_aom_inter_prediction's uni-directional SIMPLE_TRANSLATION path
+ * (enc_inter_prediction.c:4102-4400 -> svt_aom_enc_make_inter_predictor): MULTITAP_SHARP kernels (the 4-tap regular kernel for a chroma dimension <= 4,
+ * inter_prediction.h:133-142), MV clamped per plane (clamp_mv_to_umv_border_sb with the plane's sub-sampling), chroma block origin ((pu >> 3) << 3) / 2. ---- */
+static const int16_t SHARP[16][8] = {{0, 0, 0, 128, 0, 0, 0, 0},         {-2, 2, -6, 126, 8, -2, 2, 0},     {-2, 6, -12, 124, 16, -6, 4, -2},  {-2, 8, -18, 120, 26, -10, 6, -2},
+                                     {-4, 10, -22, 116, 38, -14, 6, -2}, {-4, 10, -22, 108, 48, -18, 8, -2}, {-4, 10, -24, 100, 60, -20, 8, -2}, {-4, 10, -24, 90, 70, -22, 10, -2},
+                                     {-4, 12, -24, 80, 80, -24, 12, -4}, {-2, 10, -22, 70, 90, -24, 10, -4}, {-2, 8, -20, 60, 100, -24, 10, -4}, {-2, 8, -18, 48, 108, -22, 10, -4},
+                                     {-2, 6, -14, 38, 116, -22, 10, -4}, {-2, 6, -10, 26, 120, -18, 8, -2},  {-2, 4, -6, 16, 124, -12, 6, -2},   {0, 2, -2, 8, 126, -6, 2, -2}};
+static void convolve_sharp(const void *ref, long rs, int hbd, int bd, int w, int h, int sx, int sy, uint16_t *dst, int dpitch) {
+    const int16_t *fx = w <= 4 ? REGULAR4[sx] : SHARP[sx], *fy = h <= 4 ? REGULAR4[sy] : SHARP[sy];
+    int r0 = 3, r1 = 11;
+    if (bd + 7 - r0 + 2 > 16) { r1 -= bd + 7 - r0 + 2 - 16; r0 += bd + 7 - r0 + 2 - 16; }
+    if (!sx && !sy) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) dst[y * dpitch + x] = (uint16_t)px_at(ref, hbd, y * rs + x);
+    } else if (sx && !sy) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int res = 0;
+                for (int k = 0; k < 8; k++) res += fx[k] * px_at(ref, hbd, y * rs + x - 3 + k);
+                dst[y * dpitch + x] = (uint16_t)clip_bd(rpot(rpot(res, r0), 7 - r0), bd);
+            }
+    } else if (!sx && sy) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int res = 0;
+                for (int k = 0; k < 8; k++) res += fy[k] * px_at(ref, hbd, (y - 3 + k) * rs + x);
+                dst[y * dpitch + x] = (uint16_t)clip_bd(rpot(res, 7), bd);
+            }
+    } else {
+        int16_t  *im = (int16_t *)malloc(sizeof(int16_t) * (size_t)(h + 7) * w);
+        const int bits = 14 - r0 - r1, offset_bits = bd + 14 - r0;
+        for (int y = 0; y < h + 7; y++)
+            for (int x = 0; x < w; x++) {
+                int sum = 1 << (bd + 6);
+                for (int k = 0; k < 8; k++) sum += fx[k] * px_at(ref, hbd, (y - 3) * rs + x - 3 + k);
+                im[y * w + x] = (int16_t)rpot(sum, r0);
+            }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int sum = 1 << offset_bits;
+                for (int k = 0; k < 8; k++) sum += fy[k] * im[(y + k) * w + x];
+                int res = rpot(sum, r1) - ((1 << (offset_bits - r1)) + (1 << (offset_bits - r1 - 1)));
+                if (!hbd) res = (int16_t)res;
+                dst[y * dpitch + x] = (uint16_t)clip_bd(rpot(res, bits), bd);
+            }
+        free(im);
+    }
+}
+/* planes[3] = the reference picture's padded buffers (buffer_y / buffer_cb / buffer_cr), strides[3]; P->ref_org_x / ref_org_y = the LUMA padding origin (the
+ * chroma origin is half of it); out[3] with pitches opitch[3] receive the bsize x bsize luma block and the two (bsize / 2)^2 chroma blocks */
+void oracle_tf_inter_pred(const OracleTfSubpelParams *P, const void *const *planes, const uint32_t *strides, int pu_x, int pu_y, int bsize, int mv_x, int mv_y,
+                          int chroma, uint16_t *const *out, const int *opitch) {
+    const int hbd = P->bit_depth > 8;
+    for (int pl = 0; pl < (chroma ? 3 : 1); pl++) {
+        const int ss = pl > 0, bw = bsize >> ss, bmi = bsize >> 2; /* (the MacroBlockD edges are the luma block's, :2318-2324) */
+        const int mirow = pu_y >> 2, micol = pu_x >> 2;
+        const int to_top = -((mirow * 4) * 8), to_bottom = (((int)P->mi_rows - bmi - mirow) * 4) * 8;
+        const int to_left = -((micol * 4) * 8), to_right = (((int)P->mi_cols - bmi - micol) * 4) * 8;
+        /* clamp_mv_to_umv_border_sb (enc_inter_prediction.c:30-50) with the plane's sub-sampling */
+        const int spel_left = (4 + bw) << 4, spel_right = spel_left - 16, spel_top = (4 + bw) << 4, spel_bottom = spel_top - 16;
+        int row = (int16_t)(mv_y * (1 << (1 - ss))), col = (int16_t)(mv_x * (1 << (1 - ss)));
+        const int min_col = to_left * (1 << (1 - ss)) - spel_left, max_col = to_right * (1 << (1 - ss)) + spel_right;
+        const int min_row = to_top * (1 << (1 - ss)) - spel_top, max_row = to_bottom * (1 << (1 - ss)) + spel_bottom;
+        col = col < min_col ? min_col : (col > max_col ? max_col : col);
+        row = row < min_row ? min_row : (row > max_row ? max_row : row);
+        col = (int16_t)col; row = (int16_t)row;
+        const int  sx = col & 15, sy = row & 15;
+        const int  ox = ss ? ((pu_x >> 3) << 3) / 2 : pu_x, oy = ss ? ((pu_y >> 3) << 3) / 2 : pu_y;
+        const long rs = (long)strides[pl], org = (long)(P->ref_org_x >> ss) + (long)(P->ref_org_y >> ss) * rs;
+        const long pos = org + ox + (col >> 4) + (long)(oy + (row >> 4)) * rs;
+        const void *src = hbd ? (const void *)((const uint16_t *)planes[pl] + pos) : (const void *)((const uint8_t *)planes[pl] + pos);
+        convolve_sharp(src, rs, hbd, P->bit_depth, bw, bw, sx, sy, out[pl], opitch[pl]);
+    }
+}

@@ -96,3 +96,46 @@ void ref_tf_luma_pred(const RefTfSubpelParams *P, void *ref_buffer_y, int pic_w,
                                 &blk_struct, 0, &mv_unit, (uint16_t)pu_x, (uint16_t)pu_y, (uint8_t)bsize, (uint8_t)bsize, &ref_pic, &prediction_ptr, 0, 0, P->bit_depth,
                                 (uint8_t)subsampling_shift);
 }
+
+/* The final motion compensation of one block exactly as tf_{64x64,32x32,16x16,8x8}_inter_prediction issue it (:2256-2620): svt_aom_inter_prediction, one
+ * direction, SIMPLE_TRANSLATION, MULTITAP_SHARP, luma (+ chroma with tf_chroma) into a 64-pitch prediction buffer at the block's local origin.
+ * planes[3] / strides[3]: the reference picture's padded buffers (u8, or u16 for the high-bit-depth path = pcs_ref->altref_buffer_highbd). */
+void svt_aom_build_blk_geom(GeomIndex geom);
+void ref_tf_inter_pred(const RefTfSubpelParams *P, void *const *planes, const uint32_t *strides, int pic_w, int pic_h, int sb_origin_x, int sb_origin_y, int bsize,
+                       int idx_x, int idx_y, int mv_x, int mv_y, int chroma, void *const *pred64 /* y: 64 x 64, u / v: 32 x 32, pitch 64 / 32 */) {
+    static SequenceControlSet *scs;
+    if (!scs) {
+        scs = calloc(1, sizeof(*scs));
+        svt_aom_asm_set_convolve_asm_table();
+        svt_aom_asm_set_convolve_hbd_asm_table();
+        svt_aom_build_blk_geom(GEOM_0);
+    }
+    svt_av1_setup_scale_factors_for_frame(&scs->sf_identity, pic_w, pic_h, pic_w, pic_h);
+    const bool is_highbd = P->bit_depth > 8;
+    EbPictureBufferDesc ref_pic, prediction_ptr;
+    memset(&ref_pic, 0, sizeof(ref_pic)); memset(&prediction_ptr, 0, sizeof(prediction_ptr));
+    ref_pic.buffer_y = planes[0]; ref_pic.buffer_cb = planes[1]; ref_pic.buffer_cr = planes[2];
+    ref_pic.org_x = (uint16_t)P->ref_org_x; ref_pic.org_y = (uint16_t)P->ref_org_y;
+    ref_pic.stride_y = (uint16_t)strides[0]; ref_pic.stride_cb = (uint16_t)strides[1]; ref_pic.stride_cr = (uint16_t)strides[2];
+    ref_pic.width = (uint16_t)pic_w; ref_pic.height = (uint16_t)pic_h;
+    prediction_ptr.stride_y = BW; prediction_ptr.stride_cb = BW >> 1; prediction_ptr.stride_cr = BW >> 1;
+    prediction_ptr.buffer_y = pred64[0]; prediction_ptr.buffer_cb = pred64[1]; prediction_ptr.buffer_cr = pred64[2];
+    BlkStruct   blk_ptr;
+    MacroBlockD av1xd;
+    MvUnit      mv_unit;
+    memset(&blk_ptr, 0, sizeof(blk_ptr)); memset(&av1xd, 0, sizeof(av1xd)); memset(&mv_unit, 0, sizeof(mv_unit));
+    blk_ptr.av1xd = &av1xd;
+    mv_unit.pred_direction = UNI_PRED_LIST_0;
+    const uint16_t local_origin_x = (uint16_t)(idx_x * bsize), local_origin_y = (uint16_t)(idx_y * bsize);
+    const uint16_t pu_origin_x = (uint16_t)(sb_origin_x + local_origin_x), pu_origin_y = (uint16_t)(sb_origin_y + local_origin_y);
+    const int32_t  mirow = pu_origin_y >> MI_SIZE_LOG2, micol = pu_origin_x >> MI_SIZE_LOG2, bmi = bsize >> 2;
+    blk_ptr.mds_idx         = get_mds_idx(local_origin_x, local_origin_y, (uint32_t)bsize, 0);
+    av1xd.mb_to_top_edge    = -(int32_t)((mirow * MI_SIZE) * 8);
+    av1xd.mb_to_bottom_edge = (((int32_t)P->mi_rows - bmi - mirow) * MI_SIZE) * 8;
+    av1xd.mb_to_left_edge   = -(int32_t)((micol * MI_SIZE) * 8);
+    av1xd.mb_to_right_edge  = (((int32_t)P->mi_cols - bmi - micol) * MI_SIZE) * 8;
+    mv_unit.mv->x = (int16_t)mv_x; mv_unit.mv->y = (int16_t)mv_y;
+    svt_aom_inter_prediction(scs, NULL, (uint32_t)av1_make_interp_filters(MULTITAP_SHARP, MULTITAP_SHARP), &blk_ptr, 0, &mv_unit, 0, SIMPLE_TRANSLATION, 0, 0, 1, NULL,
+                             NULL, NULL, NULL, 0, 0, 0, 0, pu_origin_x, pu_origin_y, (uint8_t)bsize, (uint8_t)bsize, &ref_pic, NULL, &prediction_ptr, local_origin_x,
+                             local_origin_y, chroma ? PICTURE_BUFFER_DESC_FULL_MASK : PICTURE_BUFFER_DESC_LUMA_MASK, P->bit_depth, is_highbd);
+}

@@ -101,6 +101,7 @@ PROTOTYPES = {
     "svt_hip_estimate_noise_batch": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_tf_filter_frame": (None, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_tf_subpel_search_batch": (None, [vp, vp, vp, vp, C.c_uint32, vp, vp]),
+    "svt_hip_tf_inter_pred_batch": (None, [vp, vp, vp, C.c_uint32, C.c_int, vp]),
     "svt_hip_lr_filter_frame_host": (None, [vp]),
     "svt_hip_cdef_apply_host": (None, [vp]),
     "svt_hip_lpf_plane_host": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, C.c_uint32, vp, C.c_uint32]),
@@ -278,6 +279,16 @@ class TfSubpelParams(C.Structure):
 assert C.sizeof(TfSubpelParams) == 32
 TfSubpelDesc = np.dtype([("src_off", "<u8"), ("ref_off", "<u8"), ("src_stride", "<u4"), ("pu_x", "<u2"), ("pu_y", "<u2"), ("bsize", "u1"), ("bilinear", "u1"),
                          ("mv_x", "<i2"), ("mv_y", "<i2"), ("pad", "<u2")])
+TfMcDesc = np.dtype([("ref_off", "<u8", (3,)), ("pred_off", "<u8", (3,)), ("pu_x", "<u2"), ("pu_y", "<u2"), ("bsize", "u1"), ("pad", "u1"), ("mv_x", "<i2"), ("mv_y", "<i2"),
+                     ("pad2", "<u2", (3,))])
+assert TfMcDesc.itemsize == 64
+
+
+class TfMcPlanes(C.Structure):
+    """SvtHipTfMcPlanes: reference and prediction plane bases + strides (samples)."""
+    _fields_ = [("ref", vp * 3), ("pred", vp * 3), ("ref_stride", C.c_uint32 * 3), ("pred_stride", C.c_uint32 * 3)]
+
+
 TfSubpelResult = np.dtype([("dist", "<u8"), ("mv_x", "<i2"), ("mv_y", "<i2"), ("pad", "<u4")])
 assert TfSubpelDesc.itemsize == 32 and TfSubpelResult.itemsize == 16
 

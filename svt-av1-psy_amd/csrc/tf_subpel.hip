@@ -27,20 +27,26 @@ constexpr int8_t kReg4[16][8] = {{0, 0, 0, 0, 0, 0, 0, 0},       {0, 0, -4, 126,
                                  {0, 0, -12, 110, 38, -8, 0, 0}, {0, 0, -12, 102, 48, -10, 0, 0}, {0, 0, -14, 94, 58, -10, 0, 0},  {0, 0, -12, 84, 66, -10, 0, 0},
                                  {0, 0, -12, 76, 76, -12, 0, 0}, {0, 0, -10, 66, 84, -12, 0, 0},  {0, 0, -10, 58, 94, -14, 0, 0},  {0, 0, -10, 48, 102, -12, 0, 0},
                                  {0, 0, -8, 38, 110, -12, 0, 0}, {0, 0, -6, 28, 116, -10, 0, 0},  {0, 0, -4, 18, 122, -8, 0, 0},   {0, 0, -2, 8, 126, -4, 0, 0}};
+constexpr int8_t kSharp8[16][8] = {{0, 0, 0, 0, 0, 0, 0, 0},           {-2, 2, -6, 126, 8, -2, 2, 0},      {-2, 6, -12, 124, 16, -6, 4, -2},  {-2, 8, -18, 120, 26, -10, 6, -2},
+                                   {-4, 10, -22, 116, 38, -14, 6, -2}, {-4, 10, -22, 108, 48, -18, 8, -2}, {-4, 10, -24, 100, 60, -20, 8, -2}, {-4, 10, -24, 90, 70, -22, 10, -2},
+                                   {-4, 12, -24, 80, 80, -24, 12, -4}, {-2, 10, -22, 70, 90, -24, 10, -4}, {-2, 8, -20, 60, 100, -24, 10, -4}, {-2, 8, -18, 48, 108, -22, 10, -4},
+                                   {-2, 6, -14, 38, 116, -22, 10, -4}, {-2, 6, -10, 26, 120, -18, 8, -2},  {-2, 4, -6, 16, 124, -12, 6, -2},   {0, 2, -2, 8, 126, -6, 2, -2}}; // MULTITAP_SHARP
 // the taps of one (kernel, phase), packed for the dot instructions: b4 = four signed bytes per dword, h2 = two signed halves per dword; for the bilinear
 // kernel only taps 3 and 4 are stored (b4[0] bytes 0-1, h2[0])
 struct PackedTaps { uint32_t b4[2], h2[4]; };
-struct TapTables { PackedTaps t[3][16]; }; // [regular 8 | regular 4 | bilinear][phase]
+struct TapTables { PackedTaps t[4][16]; }; // [regular 8 | regular 4 | bilinear | sharp 8][phase]
 constexpr TapTables make_tap_tables() {
     TapTables T{};
-    for (int kind = 0; kind < 2; kind++)
+    for (int kind = 0; kind < 4; kind++) {
+        if (kind == 2) continue;
         for (int p = 0; p < 16; p++) {
             for (int k = 0; k < 8; k++) {
-                const int f = kind ? kReg4[p][k] : kReg8[p][k];
+                const int f = kind == 0 ? kReg8[p][k] : (kind == 1 ? kReg4[p][k] : kSharp8[p][k]);
                 T.t[kind][p].b4[k >> 2] |= (uint32_t)(f & 0xff) << (8 * (k & 3));
                 T.t[kind][p].h2[k >> 1] |= (uint32_t)(f & 0xffff) << (16 * (k & 1));
             }
         }
+    }
     for (int p = 1; p < 16; p++) {
         T.t[2][p].b4[0] = (uint32_t)(128 - 8 * p) | ((uint32_t)(8 * p) << 8);
         T.t[2][p].h2[0] = (uint32_t)(128 - 8 * p) | ((uint32_t)(8 * p) << 16);
@@ -100,47 +106,18 @@ template <int NT> __device__ __forceinline__ int hsum(const uint16_t* q, const P
     return sdot2(reinterpret_cast<const u32_a1*>(q)->x, t.h2[0], 0);
 }
 
-// distortion of one candidate MV (1/8 pel) for the block; every lane returns the same value.  NT = 8: the regular kernels (taps 0..7 around x - 3);
-// NT = 2: bilinear, whose only non-zero taps are 3 and 4 (x, x + 1)
-template <typename PIX, int NT>
-__device__ unsigned long long candidate_dist(const SvtHipTfSubpelParams& P, const SvtHipTfSubpelDesc& d, const PIX* __restrict__ src, const PIX* __restrict__ refy,
-                                             const int mvx, const int mvy, const int pss, uint32_t* __restrict__ imp, const int l) {
+// The W x nrows samples of one prediction (every rstep-th row of the block at p0, row stride rsm) -> finish(i, unclamped sample), i = row * W + column, split over the
+// wave's lanes.  NT = 8: an 8-tap kernel (taps 0..7 around x - 3); NT = 2: bilinear (taps 3, 4).  The four cases are the four kernels of
+// svt_av1_[highbd_]convolve_{2d_copy,x,y,2d}_sr_c; the choice is wave-uniform, offsets are unsigned from a per-prediction base.
+template <typename PIX, int NT, typename F>
+__device__ __forceinline__ void predict_rows(const PIX* __restrict__ p0, const long rsm, const int W, const int nrows, const int rstep, const int sx, const int sy,
+                                             const PackedTaps& tx, const PackedTaps& ty, const int bd, uint32_t* __restrict__ imp, const int l, F finish) {
     constexpr bool HBD = sizeof(PIX) == 2;
-    const int W = d.bsize, ss = P.subsampling_shift, bd = HBD ? P.bit_depth : 8;
-    const int nrows = W >> ss;                  // prediction rows the variance reads
-    const int rstep = pss ? 1 : (1 << ss);      // ... every rstep-th row of this candidate's prediction
-    const int rmul  = 1 << pss;                 // the centre is predicted with the reference stride doubled (tf_inter_predictor: src_stride << shift)
-    const int hpred = pss ? nrows : W;          // block height svt_inter_predictor sees (selects the 4-tap kernel when <= 4)
-    // clamp_mv_to_umv_border_sb (enc_inter_prediction.c:30-50) in 1/16 pel
-    const int bmi = W >> 2, mirow = d.pu_y >> 2, micol = d.pu_x >> 2;
-    const int to_top = -((mirow * 4) * 8), to_bottom = (((int)P.mi_rows - bmi - mirow) * 4) * 8, to_left = -((micol * 4) * 8), to_right = (((int)P.mi_cols - bmi - micol) * 4) * 8;
-    const int spel_l = (4 + W) << 4, spel_r = spel_l - 16;
-    int row = (int16_t)(mvy * 2), col = (int16_t)(mvx * 2);
-    const int min_col = to_left * 2 - spel_l, max_col = to_right * 2 + spel_r, min_row = to_top * 2 - spel_l, max_row = to_bottom * 2 + spel_r;
-    col = col < min_col ? min_col : (col > max_col ? max_col : col);
-    row = row < min_row ? min_row : (row > max_row ? max_row : row);
-    col = (int16_t)col; row = (int16_t)row;
-    const int  sx = col & 15, sy = row & 15;
-    const long rs = (long)P.ref_stride;
-    const PIX* p0 = refy + P.ref_org_x + (long)P.ref_org_y * rs + (d.pu_x + (col >> 4)) + (long)(d.pu_y + (row >> 4)) * rs;
-    const long rsm = rs * rmul; // row stride between consecutive rows of this candidate's prediction
-    int r0 = 3, r1 = 11;        // get_conv_params_no_round (convolve.h:40-64)
+    constexpr int  T0  = NT == 8 ? 0 : 3; // first tap evaluated
+    int r0 = 3, r1 = 11;                  // get_conv_params_no_round (convolve.h:40-64)
     if (bd + 7 - r0 + 2 > 16) { r1 -= bd + 7 - r0 + 2 - 16; r0 += bd + 7 - r0 + 2 - 16; }
-    const int mx = (1 << bd) - 1;
-    constexpr int T0 = NT == 8 ? 0 : 3; // first tap evaluated
-    const PackedTaps tx = kTaps.t[NT == 2 ? 2 : 0][sx], ty = kTaps.t[NT == 2 ? 2 : (hpred <= 4 ? 1 : 0)][sy]; // (W >= 8: never the 4-tap kernel horizontally)
-    const int lw = 31 - __clz(W); // log2 W
-    int      sum_l = 0; // per lane: <= 64 samples of |diff| <= 1023 -> both fit 32 bits
-    uint32_t sse_l = 0;
-    const int offset_bits = bd + 14 - r0, npx = nrows * W;
-    const uint32_t urs = (uint32_t)rsm, sstep = (uint32_t)d.src_stride << ss;
-    auto finish = [&](const int i, int px) {
-        px = px < 0 ? 0 : (px > mx ? mx : px);
-        const int diff = px - (int)src[(uint32_t)(i >> lw) * sstep + (uint32_t)(i & (W - 1))];
-        sum_l += diff;
-        sse_l += (uint32_t)(diff * diff);
-    };
-    // the four kernels of svt_av1_[highbd_]convolve_{2d_copy,x,y,2d}_sr_c; the choice is wave-uniform, offsets are unsigned from a per-candidate base
+    const int      lw = 31 - __clz(W), offset_bits = bd + 14 - r0, npx = nrows * W;
+    const uint32_t urs = (uint32_t)rsm;
     if (!sx && !sy) {
         for (int i = l; i < npx; i += 64) finish(i, (int)p0[(uint32_t)((i >> lw) * rstep) * urs + (uint32_t)(i & (W - 1))]);
     } else if (!sy) {
@@ -190,6 +167,45 @@ __device__ unsigned long long candidate_dist(const SvtHipTfSubpelParams& P, cons
         }
         __builtin_amdgcn_wave_barrier(); // the slice is rewritten by the next candidate
     }
+}
+
+// distortion of one candidate MV (1/8 pel) for the block; every lane returns the same value.  NT = 8: the regular kernels (taps 0..7 around x - 3);
+// NT = 2: bilinear, whose only non-zero taps are 3 and 4 (x, x + 1)
+template <typename PIX, int NT>
+__device__ unsigned long long candidate_dist(const SvtHipTfSubpelParams& P, const SvtHipTfSubpelDesc& d, const PIX* __restrict__ src, const PIX* __restrict__ refy,
+                                             const int mvx, const int mvy, const int pss, uint32_t* __restrict__ imp, const int l) {
+    constexpr bool HBD = sizeof(PIX) == 2;
+    const int W = d.bsize, ss = P.subsampling_shift, bd = HBD ? P.bit_depth : 8;
+    const int nrows = W >> ss;                  // prediction rows the variance reads
+    const int rstep = pss ? 1 : (1 << ss);      // ... every rstep-th row of this candidate's prediction
+    const int rmul  = 1 << pss;                 // the centre is predicted with the reference stride doubled (tf_inter_predictor: src_stride << shift)
+    const int hpred = pss ? nrows : W;          // block height svt_inter_predictor sees (selects the 4-tap kernel when <= 4)
+    // clamp_mv_to_umv_border_sb (enc_inter_prediction.c:30-50) in 1/16 pel
+    const int bmi = W >> 2, mirow = d.pu_y >> 2, micol = d.pu_x >> 2;
+    const int to_top = -((mirow * 4) * 8), to_bottom = (((int)P.mi_rows - bmi - mirow) * 4) * 8, to_left = -((micol * 4) * 8), to_right = (((int)P.mi_cols - bmi - micol) * 4) * 8;
+    const int spel_l = (4 + W) << 4, spel_r = spel_l - 16;
+    int row = (int16_t)(mvy * 2), col = (int16_t)(mvx * 2);
+    const int min_col = to_left * 2 - spel_l, max_col = to_right * 2 + spel_r, min_row = to_top * 2 - spel_l, max_row = to_bottom * 2 + spel_r;
+    col = col < min_col ? min_col : (col > max_col ? max_col : col);
+    row = row < min_row ? min_row : (row > max_row ? max_row : row);
+    col = (int16_t)col; row = (int16_t)row;
+    const int  sx = col & 15, sy = row & 15;
+    const long rs = (long)P.ref_stride;
+    const PIX* p0 = refy + P.ref_org_x + (long)P.ref_org_y * rs + (d.pu_x + (col >> 4)) + (long)(d.pu_y + (row >> 4)) * rs;
+    const long rsm = rs * rmul; // row stride between consecutive rows of this candidate's prediction
+    const int mx = (1 << bd) - 1;
+    const PackedTaps tx = kTaps.t[NT == 2 ? 2 : 0][sx], ty = kTaps.t[NT == 2 ? 2 : (hpred <= 4 ? 1 : 0)][sy]; // (W >= 8: never the 4-tap kernel horizontally)
+    const int lw = 31 - __clz(W); // log2 W
+    int      sum_l = 0; // per lane: <= 64 samples of |diff| <= 1023 -> both fit 32 bits
+    uint32_t sse_l = 0;
+    const uint32_t sstep = (uint32_t)d.src_stride << ss;
+    auto finish = [&](const int i, int px) {
+        px = px < 0 ? 0 : (px > mx ? mx : px);
+        const int diff = px - (int)src[(uint32_t)(i >> lw) * sstep + (uint32_t)(i & (W - 1))];
+        sum_l += diff;
+        sse_l += (uint32_t)(diff * diff);
+    };
+    predict_rows<PIX, NT>(p0, rsm, W, nrows, rstep, sx, sy, tx, ty, bd, imp, l, finish);
     const long long          sum = wave_sum_i32(sum_l);        // |total| <= 4096 * 1023
     const unsigned long long sse = wave_sum_u32_wide(sse_l);   // a row of 16 lanes: <= 1024 * 1023^2
     const int                ln  = 2 * lw - ss; // log2(W * nrows): the reference's division by the sample count is a shift of a non-negative square
@@ -250,6 +266,43 @@ __global__ __launch_bounds__(256) void tf_subpel_kernel(const SvtHipTfSubpelPara
     }
 }
 
+// ---- final motion compensation (tf_{64x64,32x32,16x16,8x8}_inter_prediction, temporal_filtering.c:2256-2620): one wave per (block, plane) ------------------------
+// svt_aom_inter_prediction's uni-directional SIMPLE_TRANSLATION path with MULTITAP_SHARP kernels (the 4-tap regular kernel for a chroma dimension <= 4), the MV
+// clamped per plane, the chroma block at ((pu >> 3) << 3) / 2; the prediction lands in a picture-sized plane at the block's position (what
+// svt_hip_tf_filter_frame reads).
+template <typename PIX>
+__global__ __launch_bounds__(256) void tf_mc_kernel(const SvtHipTfSubpelParams P, const SvtHipTfMcPlanes PL, const SvtHipTfMcDesc* __restrict__ descs, const uint32_t n,
+                                                    const int chroma) {
+    HIP_DYNAMIC_SHARED(uint32_t, smem)
+    const int      l = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t item = blockIdx.x * 4 + (uint32_t)wv, blk = item / 3;
+    const int      pl = (int)(item - blk * 3);
+    if (blk >= n || (pl && !chroma)) return;
+    uint32_t*            im = smem + wv * kSlice;
+    const SvtHipTfMcDesc d  = descs[blk];
+    const int ss = pl > 0, W = d.bsize >> ss, bmi = d.bsize >> 2, bd = sizeof(PIX) == 2 ? P.bit_depth : 8, mx = (1 << bd) - 1;
+    const int mirow = d.pu_y >> 2, micol = d.pu_x >> 2; // (the MacroBlockD edges are the luma block's, :2318-2324)
+    const int to_top = -((mirow * 4) * 8), to_bottom = (((int)P.mi_rows - bmi - mirow) * 4) * 8, to_left = -((micol * 4) * 8), to_right = (((int)P.mi_cols - bmi - micol) * 4) * 8;
+    const int spel_l = (4 + W) << 4, spel_r = spel_l - 16, sc = 1 << (1 - ss); // clamp_mv_to_umv_border_sb with the plane's sub-sampling (enc_inter_prediction.c:30-50)
+    int row = (int16_t)(d.mv_y * sc), col = (int16_t)(d.mv_x * sc);
+    const int min_col = to_left * sc - spel_l, max_col = to_right * sc + spel_r, min_row = to_top * sc - spel_l, max_row = to_bottom * sc + spel_r;
+    col = col < min_col ? min_col : (col > max_col ? max_col : col);
+    row = row < min_row ? min_row : (row > max_row ? max_row : row);
+    col = (int16_t)col; row = (int16_t)row;
+    const int  sx = col & 15, sy = row & 15;
+    const int  ox = ss ? ((d.pu_x >> 3) << 3) / 2 : d.pu_x, oy = ss ? ((d.pu_y >> 3) << 3) / 2 : d.pu_y;
+    const long rs = (long)PL.ref_stride[pl];
+    const PIX* p0 = (const PIX*)PL.ref[pl] + d.ref_off[pl] + (P.ref_org_x >> ss) + (long)(P.ref_org_y >> ss) * rs + ox + (col >> 4) + (long)(oy + (row >> 4)) * rs;
+    PIX*       out = (PIX*)PL.pred[pl] + d.pred_off[pl] + ox + (size_t)oy * PL.pred_stride[pl];
+    const uint32_t ps = PL.pred_stride[pl];
+    const int      kind = W <= 4 ? 1 : 3, lw = 31 - __clz(W);
+    const PackedTaps tx = kTaps.t[kind][sx], ty = kTaps.t[kind][sy];
+    predict_rows<PIX, 8>(p0, rs, W, W, 1, sx, sy, tx, ty, bd, im, l, [&](const int i, int px) {
+        px = px < 0 ? 0 : (px > mx ? mx : px);
+        out[(uint32_t)(i >> lw) * ps + (uint32_t)(i & (W - 1))] = (PIX)px;
+    });
+}
+
 } // namespace
 
 extern "C" void svt_hip_tf_subpel_search_batch(const SvtHipTfSubpelParams* params, const void* src_base, const void* ref_base, const SvtHipTfSubpelDesc* descs, uint32_t n,
@@ -267,5 +320,22 @@ extern "C" void svt_hip_tf_subpel_search_batch(const SvtHipTfSubpelParams* param
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_subpel_kernel<uint8_t>), dim3((n + 3) / 4), dim3(256), shm, (hipStream_t)stream, *params, (const uint8_t*)src_base,
                            (const uint8_t*)ref_base, descs, n, results);
+    SVT_LAUNCH_CHECK();
+}
+
+extern "C" void svt_hip_tf_inter_pred_batch(const SvtHipTfSubpelParams* params, const SvtHipTfMcPlanes* planes, const SvtHipTfMcDesc* descs, uint32_t n, int chroma,
+                                            void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    if (params->bit_depth != 8 && params->bit_depth != 10) {
+        fprintf(stderr, "libsvtav1_hip: svt_hip_tf_inter_pred_batch: bit depth %d\n", params->bit_depth);
+        abort();
+    }
+    const size_t   shm = (size_t)4 * kSlice * 4;
+    const uint32_t items = n * 3;
+    if (params->bit_depth > 8)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_mc_kernel<uint16_t>), dim3((items + 3) / 4), dim3(256), shm, (hipStream_t)stream, *params, *planes, descs, n, chroma);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_mc_kernel<uint8_t>), dim3((items + 3) / 4), dim3(256), shm, (hipStream_t)stream, *params, *planes, descs, n, chroma);
     SVT_LAUNCH_CHECK();
 }

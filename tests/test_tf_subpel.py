@@ -187,3 +187,108 @@ def test_tf_subpel_full_picture_properties(be, oracle, bd):
     # blocks that started one pel off found the true displacement (interior blocks, exact copy -> distortion 0)
     inner = (a[:, 0] >= 64) & (a[:, 1] >= 64) & (a[:, 0] + a[:, 2] <= W - 64) & (a[:, 1] + a[:, 2] <= H - 64) & (descs["mv_x"] == -24) & (descs["mv_y"] == 16)
     assert inner.sum() > 1000 and not outs[0]["dist"][inner].any()
+
+
+def make_yuv(g, W, H, PAD, bd):
+    """a padded 4:2:0 reference picture: luma like make_pictures, smooth chroma + noise (chroma padding PAD / 2)"""
+    _, y = make_pictures(g, W, H, PAD, bd)
+    amp = (1 << bd) - 1
+    dt = y.dtype
+    yy, xx = np.mgrid[0:H // 2 + PAD, 0:W // 2 + PAD].astype(np.float64)
+    u = np.clip((0.5 + 0.3 * np.sin(xx / 4.7) * np.cos(yy / 3.9)) * amp + g.normal(0, amp / 100, xx.shape), 0, amp).astype(dt)
+    v = np.clip((0.5 + 0.3 * np.cos((xx + yy) / 5.3)) * amp + g.normal(0, amp / 100, xx.shape), 0, amp).astype(dt)
+    return [y, np.ascontiguousarray(u), np.ascontiguousarray(v)]
+
+
+def oracle_mc(oracle, P, planes, pu_x, pu_y, bsize, mvx, mvy, chroma):
+    outs = [np.zeros((bsize, bsize), np.uint16), np.zeros((bsize // 2, bsize // 2), np.uint16), np.zeros((bsize // 2, bsize // 2), np.uint16)]
+    pl = (C.c_void_p * 3)(*[x.ctypes.data for x in planes])
+    st = (C.c_uint32 * 3)(*[x.shape[1] for x in planes])
+    op = (C.c_void_p * 3)(*[o.ctypes.data for o in outs])
+    pit = (C.c_int * 3)(bsize, bsize // 2, bsize // 2)
+    oracle.oracle_tf_inter_pred(C.byref(P), pl, st, pu_x, pu_y, bsize, mvx, mvy, int(chroma), op, pit)
+    return outs
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_tf_inter_pred_oracle_vs_reference(oracle, ref, bd):
+    """oracle_tf_inter_pred == svt_aom_inter_prediction as the temporal filter calls it (MULTITAP_SHARP, luma + 4:2:0 chroma, 8x8 .. 64x64 blocks, MVs that reach far
+    outside the picture)"""
+    if not os.path.exists(REF_ME_LIB):
+        pytest.skip("oracle/_ref/libsvtref_me.so not available")
+    ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))
+    ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
+    C.CDLL(REF_LIB, mode=C.RTLD_GLOBAL)
+    refme = C.CDLL(REF_ME_LIB)
+    g = rng(900 + bd)
+    W, H, PAD = 192, 128, 80
+    planes = make_yuv(g, W, H, PAD, bd)
+    P = params((1, 1, 1), 0, bd, 0, W, H, PAD, planes[0].shape[1])
+    dt = planes[0].dtype
+    pl = (C.c_void_p * 3)(*[x.ctypes.data for x in planes])
+    st = (C.c_uint32 * 3)(*[x.shape[1] for x in planes])
+    for it in range(120):
+        bsize = (64, 32, 16, 8)[it % 4]
+        nb = 64 // bsize
+        sbx, sby = int(g.integers(0, W // 64)) * 64, int(g.integers(0, H // 64)) * 64
+        ix, iy = int(g.integers(0, nb)), int(g.integers(0, nb))
+        mvx, mvy = (int(g.integers(-60, 61)), int(g.integers(-60, 61))) if it % 5 else (int(g.integers(-3000, 3001)), int(g.integers(-2000, 2001)))
+        if it < 16:
+            mvx, mvy = it % 8, 8 - it % 8 - (it // 8) * 8
+        chroma = it % 3 != 2
+        want = oracle_mc(oracle, P, planes, sbx + ix * bsize, sby + iy * bsize, bsize, mvx, mvy, chroma)
+        pred = [np.zeros((64, 64), dt), np.zeros((32, 32), dt), np.zeros((32, 32), dt)]
+        pp = (C.c_void_p * 3)(*[x.ctypes.data for x in pred])
+        refme.ref_tf_inter_pred(C.byref(P), pl, st, W, H, sbx, sby, bsize, ix, iy, mvx, mvy, int(chroma), pp)
+        got_y = pred[0][iy * bsize:(iy + 1) * bsize, ix * bsize:(ix + 1) * bsize]
+        assert np.array_equal(got_y, want[0]), (it, bsize, mvx, mvy)
+        if chroma:
+            cb = bsize // 2
+            cy, cx = (((iy * bsize) >> 3) << 3) // 2, (((ix * bsize) >> 3) << 3) // 2
+            for k in (1, 2):
+                assert np.array_equal(pred[k][cy:cy + cb, cx:cx + cb], want[k]), (it, k, bsize, mvx, mvy)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_tf_inter_pred_batch_hip(be, oracle, bd):
+    """svt_hip_tf_inter_pred_batch == oracle_tf_inter_pred: non-overlapping blocks of all four sizes from two reference pictures into picture-sized prediction planes"""
+    pkg = be.pkg
+    g = rng(920 + bd)
+    W, H, PAD = (448, 256, 80) if be.is_gpu else (256, 192, 80)
+    refs = [make_yuv(g, W, H, PAD, bd), make_yuv(g, W, H, PAD, bd)]
+    dt = refs[0][0].dtype
+    ref_all = [np.ascontiguousarray(np.stack([r[pl] for r in refs])) for pl in range(3)]
+    P = params((1, 1, 1), 0, bd, 0, W, H, PAD, refs[0][0].shape[1])
+    # one block per 64x64 cell, random size / position inside it (so blocks never overlap), random reference
+    blocks = []
+    for sy in range(0, H, 64):
+        for sx in range(0, W, 64):
+            bsize = (64, 32, 16, 8)[int(g.integers(0, 4))]
+            nb = 64 // bsize
+            blocks.append((sx + int(g.integers(0, nb)) * bsize, sy + int(g.integers(0, nb)) * bsize, bsize, int(g.integers(0, 2))))
+    n = len(blocks)
+    d = np.zeros(n, pkg.TfMcDesc)
+    pred_shape = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+    want = [np.zeros((2,) + s, dt) for s in pred_shape]
+    for i, (x, y, b, r) in enumerate(blocks):
+        far = i % 7 == 3
+        mvx, mvy = (int(g.integers(-2500, 2501)), int(g.integers(-1500, 1501))) if far else (int(g.integers(-70, 71)), int(g.integers(-70, 71)))
+        d[i]["pu_x"], d[i]["pu_y"], d[i]["bsize"], d[i]["mv_x"], d[i]["mv_y"] = x, y, b, mvx, mvy
+        for pl in range(3):
+            d[i]["ref_off"][pl] = r * refs[0][pl].size
+            d[i]["pred_off"][pl] = r * pred_shape[pl][0] * pred_shape[pl][1]
+        o = oracle_mc(oracle, P, refs[r], x, y, b, mvx, mvy, True)
+        want[0][r, y:y + b, x:x + b] = o[0]
+        cx, cy = ((x >> 3) << 3) // 2, ((y >> 3) << 3) // 2
+        for pl in (1, 2):
+            want[pl][r, cy:cy + b // 2, cx:cx + b // 2] = o[pl]
+    d_ref = [be.dev(a) for a in ref_all]
+    d_pred = [be.empty((2,) + s, dt) for s in pred_shape]
+    PL = pkg.TfMcPlanes()
+    for pl in range(3):
+        PL.ref[pl], PL.pred[pl], PL.ref_stride[pl], PL.pred_stride[pl] = be.ptr(d_ref[pl]), be.ptr(d_pred[pl]), refs[0][pl].shape[1], pred_shape[pl][1]
+    PP = pkg.TfSubpelParams.from_buffer_copy(bytes(P))
+    be.lib.svt_hip_tf_inter_pred_batch(C.byref(PP), C.byref(PL), be.ptr(be.dev(d)), n, 1, be.stream)
+    for pl in range(3):
+        got = be.host(d_pred[pl])
+        assert np.array_equal(got, want[pl]), (pl, np.argwhere(got != want[pl])[:5])

@@ -55,6 +55,8 @@ def main():
             out.update(bench_legs.tf_frames(torch, lib, pkg, stream, a.steps, a.warmup))
         elif leg == "tfsubpel":
             out.update(bench_legs.tf_subpel(torch, lib, pkg, stream, a.steps, a.warmup))
+        elif leg == "tfmc":
+            out.update(bench_legs.tf_inter_pred(torch, lib, pkg, stream, a.steps, a.warmup))
         elif leg == "lrsearch":
             out.update(bench_legs.lr_search(torch, lib, pkg, stream, a.steps, a.warmup))
         elif leg == "meresults":
