@@ -71,6 +71,7 @@ static struct {
     char            why[128];
 } G = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, -1};
 
+static uint64_t tf_pairs, tf_sb, tf_declined; /* the temporal filter's (picture, reference) pairs through the stage, see the end of this file */
 static void seam_stats(void) {
     const char *f = getenv("SVT_HIP_ME_SEAM_STATS");
     FILE       *o = f ? fopen(f, "w") : NULL;
@@ -78,6 +79,7 @@ static void seam_stats(void) {
     fprintf(o, "pictures_offloaded %llu\npictures_declined %llu\nsb_results %llu\nplane_uploads %llu\nplane_reuploads %llu\nlast_decline %s\n",
             (unsigned long long)G.n_pictures, (unsigned long long)G.n_declined, (unsigned long long)G.n_sb, (unsigned long long)G.n_uploads,
             (unsigned long long)G.n_reuploads, G.why[0] ? G.why : "-");
+    fprintf(o, "tf_pairs_offloaded %llu\ntf_sb_results %llu\ntf_pairs_declined %llu\n", (unsigned long long)tf_pairs, (unsigned long long)tf_sb, (unsigned long long)tf_declined);
     fprintf(o, "ms_in_stage_calls %llu\nms_hashing_planes %llu\n", (unsigned long long)(G.t_stage * 1e3), (unsigned long long)(G.t_hash * 1e3));
     fclose(o);
 }
@@ -156,7 +158,7 @@ static int decline(const char *why) {
 }
 /* SvtHipMeStageParams from the MeContext svt_aom_sig_deriv_me filled + the per-picture set-up of me_process.c:236-262 (same field names) */
 static int fill_stage(PictureParentControlSet *pcs, MeContext *c, SvtHipMeStageParams *S, int64_t *ref_ids, const EbPictureBufferDesc **ref_pics,
-                      uint32_t *n_refs_out) {
+                      uint32_t *n_refs_out, int tf /* the temporal filter's call: me_type == ME_MCTF, one reference taken from the context */) {
     SequenceControlSet *scs = pcs->scs;
     memset(S, 0, sizeof(*S));
     if (pcs->frame_superres_enabled || pcs->frame_resize_enabled) return decline("super-resolution / resize");
@@ -206,11 +208,15 @@ static int fill_stage(PictureParentControlSet *pcs, MeContext *c, SvtHipMeStageP
     uint32_t k = 0;
     for (uint32_t li = 0; li < c->num_of_list_to_search; li++)
         for (uint32_t ri = 0; ri < c->num_of_ref_pic_to_search[li]; ri++, k++) {
-            EbPaReferenceObject *ro = (EbPaReferenceObject *)pcs->ref_pa_pic_ptr_array[li][ri]->object_ptr;
-            ref_ids[k] = (int64_t)ro->picture_number; ref_pics[k] = ro->input_padded_pic;
-            const int64_t  d64  = (int64_t)pcs->picture_number - (int64_t)ro->picture_number;
+            /* open-loop ME: the PA reference objects of the picture; temporal filter: the one reference temporal_filtering.c:3159-3168 put into the context */
+            const uint64_t             ref_number = tf ? c->me_ds_ref_array[li][ri].picture_number
+                                                       : ((EbPaReferenceObject *)pcs->ref_pa_pic_ptr_array[li][ri]->object_ptr)->picture_number;
+            const EbPictureBufferDesc *ref_padded = tf ? c->me_ds_ref_array[li][ri].picture_ptr
+                                                       : ((EbPaReferenceObject *)pcs->ref_pa_pic_ptr_array[li][ri]->object_ptr)->input_padded_pic;
+            ref_ids[k] = (int64_t)ref_number; ref_pics[k] = ref_padded;
+            const int64_t  d64  = (int64_t)pcs->picture_number - (int64_t)ref_number;
             const uint16_t dist = (uint16_t)(int16_t)(d64 < 0 ? -d64 : d64), f = (uint16_t)((dist * 5) / 8 + ((dist % 8) ? 1 : 0));
-            S->dist[k] = f; S->ref_pic_index[k] = (uint8_t)ri;
+            S->dist[k] = tf ? dist : f; S->ref_pic_index[k] = (uint8_t)ri; /* (ME_MCTF: the integer search takes the distance unscaled, :1300-1302) */
             SearchAreaMinMax a = c->hme_l0_sa;
             if (sr->enable_me_sr_adjustment && sr->distance_based_hme_resizing) {
                 a.sa_min.width /= 1 + ri; a.sa_min.height /= 1 + ri; a.sa_max.width /= 1 + ri; a.sa_max.height /= 1 + ri;
@@ -219,11 +225,16 @@ static int fill_stage(PictureParentControlSet *pcs, MeContext *c, SvtHipMeStageP
             const int wmax = ((a.sa_max.width / c->num_hme_sa_w) + 15) & ~15, hmax = a.sa_max.height / c->num_hme_sa_h;
             w = ((w * f) + 15) & ~15; h = h * f;
             S->hme_l0_sa_width_ref[k] = (int16_t)(w < wmax ? w : wmax); S->hme_l0_sa_height_ref[k] = (int16_t)(h < hmax ? h : hmax);
-            S->results.ref_picture_number[li][ri] = ro->picture_number;
+            S->results.ref_picture_number[li][ri] = ref_number;
         }
     SvtHipMeResultsParams *R = &S->results;
     R->num_of_list_to_search = c->num_of_list_to_search; R->num_of_ref_pic_to_search[0] = (uint8_t)n0; R->num_of_ref_pic_to_search[1] = (uint8_t)n1;
-    R->max_cand = pcs->pa_me_data->max_cand; R->max_refs = pcs->pa_me_data->max_refs; R->max_l0 = pcs->pa_me_data->max_l0;
+    if (tf) { /* raw tables only: no candidate formatting */
+        S->me_type_mctf = 1; S->tf_me_exit_th = c->tf_me_exit_th;
+        R->max_cand = 1; R->max_refs = 1; R->max_l0 = 1;
+    } else {
+        R->max_cand = pcs->pa_me_data->max_cand; R->max_refs = pcs->pa_me_data->max_refs; R->max_l0 = pcs->pa_me_data->max_l0;
+    }
     R->enable_me_16x16 = pcs->enable_me_16x16; R->enable_me_8x8 = pcs->enable_me_8x8;
     R->only_l_bwd = scs->mrp_ctrls.only_l_bwd;
     R->use_best_unipred_cand_only = c->use_best_unipred_cand_only;
@@ -243,18 +254,13 @@ static void reserve(void **p, size_t *cap, size_t bytes) {
     *cap = bytes;
 }
 
-/* the whole picture on the device; called with G.lock held by the thread that brought the picture's first SB */
-static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *c, const EbPictureBufferDesc *src) {
-    SvtHipMeStageParams        S;
-    int64_t                    ref_ids[8];
-    const EbPictureBufferDesc *ref_pics[8];
-    uint32_t                   n_refs = 0;
-    if (fill_stage(pcs, c, &S, ref_ids, ref_pics, &n_refs)) return -1;
-    EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
+/* the session (picture ring + stage buffers) is sized once for the encode, from the first picture that reaches a seam */
+static int ensure_session(PictureParentControlSet *pcs, const EbPictureBufferDesc *src) {
     if (!G.session) {
+        EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
         G.width = src->width; G.height = src->height; G.stride = src->stride_y; G.org_x = src->org_x; G.org_y = src->org_y;
         G.rows = src->luma_size / src->stride_y;
-        /* largest ME area any preset derives is 256 x 256 (x 2 by the MV-based adjustment, x 3 / 2 by the variance probe); sized once for the encode */
+        /* largest ME area any preset derives is 256 x 256 (x 2 by the MV-based adjustment, x 3 / 2 by the variance probe) */
         G.session = abi.create(G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 2);
         if (!G.session || abi.enable_stage(G.session, pa->quarter_downsampled_picture_ptr->org_x, pa->sixteenth_downsampled_picture_ptr->org_x, 4, 768, 768)) {
             fprintf(stderr, "SVT_HIP_ME_SEAM: cannot create the ME session\n");
@@ -263,6 +269,17 @@ static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *
     }
     if (src->width != G.width || src->height != G.height || src->stride_y != G.stride || src->org_x != G.org_x || src->org_y != G.org_y)
         return decline("picture geometry changed");
+    return 0;
+}
+
+/* the whole picture on the device; called with G.lock held by the thread that brought the picture's first SB */
+static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *c, const EbPictureBufferDesc *src) {
+    SvtHipMeStageParams        S;
+    int64_t                    ref_ids[8];
+    const EbPictureBufferDesc *ref_pics[8];
+    uint32_t                   n_refs = 0;
+    if (fill_stage(pcs, c, &S, ref_ids, ref_pics, &n_refs, 0)) return -1;
+    if (ensure_session(pcs, src)) return -1;
     for (int pass = 0;; pass++) { /* an upload may evict a reference another upload just brought in (round-robin ring): repeat until all are there */
         int missing = 0;
         for (uint32_t k = 0; k < n_refs; k++) {
@@ -371,6 +388,110 @@ static EbErrorType seam_motion_estimation_b64(PictureParentControlSet *pcs, uint
     if (++P->consumed == P->n_sb) P->state = 0; /* every SB has fetched its slice: the record is free again */
     pthread_mutex_unlock(&G.lock);
     if (declined) return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_ptr);
+    return EB_ErrorNone;
+}
+
+
+/* ---- the temporal filter's ME (temporal_filtering.c:3180: svt_aom_motion_estimation_b64 with me_type == ME_MCTF, one reference per call) ---------------------------
+ * temporal_filtering.c enters the encoder library through ref_wrap/temporal_filtering_seam.c, which renames that one call to the function below.  With
+ * SVT_HIP_TF_ME_SEAM=1 the first 64x64 block of a (central picture, reference picture) pair to arrive runs the stage for ALL blocks of the pair in its ME_MCTF
+ * form (unscaled distance, tf_me_exit_th, no pruning, raw tables) and every block then receives what the reference's call leaves in the MeContext for the
+ * temporal filter: search_results[0][0].hme_sc_x / hme_sc_y / hme_sad, the tf_tot_horz_blks / tf_tot_vert_blks vote (motion_estimation.c:2469-2474), the early
+ * exit (tf_use_pred_64x64_only_th = ~0, :3109-3113) or p_sb_best_sad / p_sb_best_mv[0][0][85] with the p_best_* pointers on them (:1372-1395). */
+enum { TF_RECS = 32 };
+typedef struct SeamTfPair {
+    PictureParentControlSet *pcs;
+    uint64_t                 picture_number, ref_number;
+    int                      state; /* 0 free, 2 ready, 3 declined */
+    uint32_t                 n_sb, consumed;
+    uint32_t                *best_sad, *best_mv;
+    int16_t                 *hme_sc;
+    uint64_t                *hme_sad;
+    size_t                   cap_sad, cap_mv, cap_sc, cap_hs;
+} SeamTfPair;
+static SeamTfPair tf_rec[TF_RECS];
+static int        tf_mode = -1;
+
+static int run_tf_pair(SeamTfPair *T, PictureParentControlSet *pcs, MeContext *c) {
+    SvtHipMeStageParams        S;
+    int64_t                    ref_ids[8];
+    const EbPictureBufferDesc *ref_pics[8];
+    uint32_t                   n_refs = 0;
+    if (c->num_of_list_to_search != 1 || c->num_of_ref_pic_to_search[0] != 1) return decline("temporal filter: more than one reference per call");
+    if (fill_stage(pcs, c, &S, ref_ids, ref_pics, &n_refs, 1)) return -1;
+    EbPaReferenceObject       *pa  = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
+    const EbPictureBufferDesc *src = pa->input_padded_pic; /* same luma as input_picture_ptr_central at this point, in the session's geometry */
+    if (ensure_session(pcs, src)) return -1;
+    if (ref_pics[0]->width != G.width || ref_pics[0]->stride_y != G.stride) return decline("reference geometry");
+    for (int pass = 0;; pass++) {
+        if (ensure_resident((uint64_t)ref_ids[0], ref_pics[0], &S)) return decline("reference upload");
+        if (abi.resident(G.session, ref_ids[0])) break;
+        if (pass == 3) return decline("ring too small for the reference set");
+    }
+    T->n_sb = pcs->b64_total_count;
+    reserve((void **)&T->best_sad, &T->cap_sad, (size_t)T->n_sb * 85 * 4);
+    reserve((void **)&T->best_mv, &T->cap_mv, (size_t)T->n_sb * 85 * 4);
+    reserve((void **)&T->hme_sc, &T->cap_sc, (size_t)T->n_sb * 2 * sizeof(int16_t));
+    reserve((void **)&T->hme_sad, &T->cap_hs, (size_t)T->n_sb * sizeof(uint64_t));
+    SvtHipMeResultsHost H;
+    memset(&H, 0, sizeof(H));
+    H.best_sad = T->best_sad; H.best_mv = T->best_mv; H.hme_sc = T->hme_sc; H.hme_sad = T->hme_sad;
+    const uint64_t now = plane_sum(src) | 1;
+    const int      ks  = sum_slot(pcs->picture_number, 1);
+    if (abi.resident(G.session, (int64_t)pcs->picture_number) && G.sum[ks][1] != now) { abi.invalidate(G.session, (int64_t)pcs->picture_number); G.n_reuploads++; }
+    if (!abi.resident(G.session, (int64_t)pcs->picture_number)) G.n_uploads++;
+    G.sum[ks][1] = now;
+    const int slot = abi.submit_stage(G.session, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, 1, &S, &H);
+    if (slot < 0) return decline("svt_hip_me_session_submit_stage (ME_MCTF form) refused the parameters");
+    abi.wait(G.session, slot);
+    return 0;
+}
+
+EbErrorType svt_hip_seam_tf_motion_estimation_b64(PictureParentControlSet *pcs, uint32_t b64_index, uint32_t b64_origin_x, uint32_t b64_origin_y, MeContext *c,
+                                                  EbPictureBufferDesc *input_ptr) {
+    if (tf_mode < 0) { const char *e = getenv("SVT_HIP_TF_ME_SEAM"); tf_mode = e && atoi(e); }
+    if (!tf_mode || !seam_on() || c->me_type != ME_MCTF) return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, c, input_ptr);
+    const uint64_t ref_number = c->me_ds_ref_array[0][0].picture_number;
+    pthread_mutex_lock(&G.lock);
+    SeamTfPair *T = NULL, *spare = NULL;
+    for (int i = 0; i < TF_RECS; i++) {
+        if (tf_rec[i].state && tf_rec[i].pcs == pcs && tf_rec[i].picture_number == pcs->picture_number && tf_rec[i].ref_number == ref_number) { T = &tf_rec[i]; break; }
+        if (!tf_rec[i].state && !spare) spare = &tf_rec[i];
+    }
+    if (!T) {
+        if (!spare) { fprintf(stderr, "SVT_HIP_TF_ME_SEAM: more than %d (picture, reference) pairs in flight\n", TF_RECS); abort(); }
+        T = spare;
+        T->pcs = pcs; T->picture_number = pcs->picture_number; T->ref_number = ref_number; T->consumed = 0;
+        const double t0 = seam_now();
+        const int rc = run_tf_pair(T, pcs, c);
+        G.t_stage += seam_now() - t0;
+        if (rc) { T->state = 3; T->n_sb = pcs->b64_total_count; tf_declined++; }
+        else    { T->state = 2; tf_pairs++; }
+    }
+    const int declined = T->state == 3;
+    if (!declined) {
+        /* what svt_aom_motion_estimation_b64 leaves behind for the temporal filter (see the header of this section) */
+        const uint16_t aw = (uint16_t)ALIGN_POWER_OF_TWO(input_ptr->width, 3), ah = (uint16_t)ALIGN_POWER_OF_TWO(input_ptr->height, 3);
+        c->b64_width  = (aw - b64_origin_x) < BLOCK_SIZE_64 ? aw - b64_origin_x : BLOCK_SIZE_64;
+        c->b64_height = (ah - b64_origin_y) < BLOCK_SIZE_64 ? ah - b64_origin_y : BLOCK_SIZE_64;
+        c->search_results[0][0].hme_sc_x = T->hme_sc[2 * b64_index]; c->search_results[0][0].hme_sc_y = T->hme_sc[2 * b64_index + 1];
+        c->search_results[0][0].hme_sad  = T->hme_sad[b64_index];
+        if (ABS(c->search_results[0][0].hme_sc_x) > ABS(c->search_results[0][0].hme_sc_y)) c->tf_tot_horz_blks++;
+        else c->tf_tot_vert_blks++;
+        if (c->search_results[0][0].hme_sad < c->tf_me_exit_th) c->tf_use_pred_64x64_only_th = (uint8_t)~0;
+        else {
+            memcpy(c->p_sb_best_sad[0][0], T->best_sad + (size_t)b64_index * 85, 85 * sizeof(uint32_t));
+            memcpy(c->p_sb_best_mv[0][0], T->best_mv + (size_t)b64_index * 85, 85 * sizeof(uint32_t));
+            c->p_best_sad_64x64 = &c->p_sb_best_sad[0][0][ME_TIER_ZERO_PU_64x64]; c->p_best_sad_32x32 = &c->p_sb_best_sad[0][0][ME_TIER_ZERO_PU_32x32_0];
+            c->p_best_sad_16x16 = &c->p_sb_best_sad[0][0][ME_TIER_ZERO_PU_16x16_0]; c->p_best_sad_8x8 = &c->p_sb_best_sad[0][0][ME_TIER_ZERO_PU_8x8_0];
+            c->p_best_mv64x64 = &c->p_sb_best_mv[0][0][ME_TIER_ZERO_PU_64x64]; c->p_best_mv32x32 = &c->p_sb_best_mv[0][0][ME_TIER_ZERO_PU_32x32_0];
+            c->p_best_mv16x16 = &c->p_sb_best_mv[0][0][ME_TIER_ZERO_PU_16x16_0]; c->p_best_mv8x8 = &c->p_sb_best_mv[0][0][ME_TIER_ZERO_PU_8x8_0];
+        }
+        tf_sb++;
+    }
+    if (++T->consumed == T->n_sb) T->state = 0;
+    pthread_mutex_unlock(&G.lock);
+    if (declined) return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, c, input_ptr);
     return EB_ErrorNone;
 }
 

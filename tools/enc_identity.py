@@ -62,6 +62,10 @@ CASES = {
     "dlfseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "+dlfseam"]),
     "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+dlfseam", "+cdefseam", "+lrseam"]),
     "everyseam_4k10_p8_lp1": (3840, 2160, 6, 10, ["--preset", "8", "--lp", "1", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),  # config-5 format, single-threaded (reproducible)
+    # the temporal filter's ME (ME_MCTF form of the stage, one call per (central picture, reference picture) pair): SVT_HIP_TF_ME_SEAM=1 on top of the ME seam
+    "tfseam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
+    "tfseam_p4_10bit": (256, 144, 8, 10, ["--preset", "4", "--lp", "1", "+seam", "+tfseam"]),
+    "tfseam_p6_8bit_lp4": (448, 264, 10, 8, ["--preset", "6", "--lp", "4", "+seam", "+tfseam"]),
     "lrseam_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+lrseam"]),  # 1080p: tens of restoration units per plane, all host cores
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
     # BASELINE.json metric, second half: encoder fps @1080p preset 8 (C-only reference vs the same encoder with the ME stage on the MI355X), all host cores
@@ -74,6 +78,7 @@ CASES = {
     "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
     "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
+    "tiny_tfseam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tiny_dlfseam_p4": (128, 64, 3, 8, ["--preset", "4", "--lp", "1", "+dlfseam"]),
     "tiny_cdefseam_p8": (128, 64, 3, 8, ["--preset", "8", "--lp", "1", "+cdefseam"]),
     "tiny_lrseam_p4": (96, 64, 3, 8, ["--preset", "4", "--lp", "1", "+lrseam"]),
@@ -84,7 +89,7 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
-SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_"))]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_"))]
 
 
 def make_clip(path, w, h, n, bd, seed=7):
@@ -137,6 +142,8 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
     lrseam_file = os.path.join(outdir, name + "_lrseam.txt")
     if seam:
         env.update({"SVT_HIP_ME_SEAM": "1", "SVT_HIP_ME_SEAM_STATS": seam_file})
+        if "+tfseam" in CASES[name][4]:
+            env["SVT_HIP_TF_ME_SEAM"] = "1"
     if lrseam:
         env.update({"SVT_HIP_LR_SEAM": "1", "SVT_HIP_LR_SEAM_STATS": lrseam_file})
     cdefseam_file = os.path.join(outdir, name + "_cdefseam.txt")
@@ -180,6 +187,8 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
         res["seam"] = {k: (int(v) if v.strip().isdigit() else v.strip()) for k, v in st.items()}
         # the claim is void unless every picture really went through the device stage
         res["identical"] = same and res["seam"].get("pictures_offloaded", 0) > 0 and res["seam"].get("pictures_declined", 1) == 0
+        if "+tfseam" in CASES[name][4]:  # temporal-filter pairs really went through the stage, none declined
+            res["identical"] = res["identical"] and res["seam"].get("tf_pairs_offloaded", 0) > 0 and res["seam"].get("tf_pairs_declined", 1) == 0
     if lrseam:
         st = dict(ln.split(None, 1) for ln in open(lrseam_file).read().splitlines()) if os.path.exists(lrseam_file) else {}
         res["lrseam"] = {k: int(v) for k, v in st.items()}
