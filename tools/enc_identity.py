@@ -54,14 +54,14 @@ CASES = {
     "cdefseam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+cdefseam"]),
     "cdefseam_p4_10bit": (256, 144, 6, 10, ["--preset", "4", "--lp", "1", "+cdefseam"]),
     "cdefseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "--crf", "45", "+cdefseam"]),
-    "allseams_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
-    "allseams_1080p_p6": (1920, 1080, 6, 8, ["--preset", "6", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "allseams_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "allseams_1080p_p6": (1920, 1080, 6, 8, ["--preset", "6", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
     # the deblocking filter of a picture as one device call per plane, segments recorded from the reference's own driver (oracle/ref_wrap/dlf_process_seam.c)
     "dlfseam_p5_8bit": (448, 264, 8, 8, ["--preset", "5", "--lp", "1", "+dlfseam"]),
     "dlfseam_p2_10bit": (256, 144, 5, 10, ["--preset", "2", "--lp", "1", "+dlfseam"]),
     "dlfseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "+dlfseam"]),
-    "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+dlfseam", "+cdefseam", "+lrseam"]),
-    "everyseam_4k10_p8_lp1": (3840, 2160, 6, 10, ["--preset", "8", "--lp", "1", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),  # config-5 format, single-threaded (reproducible)
+    "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+dlfseam", "+cdefseam", "+lrseam"]),
+    "everyseam_4k10_p8_lp1": (3840, 2160, 6, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),  # config-5 format, single-threaded (reproducible)
     # the temporal filter's ME (ME_MCTF form of the stage, one call per (central picture, reference picture) pair): SVT_HIP_TF_ME_SEAM=1 on top of the ME seam
     "tfseam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tfseam_p4_10bit": (256, 144, 8, 10, ["--preset", "4", "--lp", "1", "+seam", "+tfseam"]),
@@ -70,13 +70,13 @@ CASES = {
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
     # BASELINE.json metric, second half: encoder fps @1080p preset 8 (C-only reference vs the same encoder with the ME stage on the MI355X), all host cores
     "fps_1080p_p8": (1920, 1080, 24, 8, ["--preset", "8", "+seam"]),
-    "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
     # 3840x2160 10-bit, preset 8, 60 frames (10-bit preset 8 is where the multi-threaded C-only reference was seen not to reproduce its own
     # bitstream; run_case reports `reference_deterministic` and the identity verdict next to the two speeds)
-    "fps_4k10_p8_all": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_4k10_p8_all": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
     "fps_1080p_p8_me": (1920, 1080, 60, 8, ["--preset", "8", "+seam"]),
-    "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
-    "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
     "tiny_tfseam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tiny_dlfseam_p4": (128, 64, 3, 8, ["--preset", "4", "--lp", "1", "+dlfseam"]),
