@@ -269,8 +269,8 @@ def cpu_lr_search(k, budget_s):
 
 def encoder_fps():
     """The second half of BASELINE.json's metric: encoder fps at 1080p preset 8.  The reference's own encoder (oracle/_ref/enc, C-only build with the binding of
-    INTEGRATION.md section 1) encodes one synthetic 60-frame 1080p clip with SVT_HIP unset, then with the ME, deblocking, CDEF (search + apply) and LR (search +
-    filter) stage seams on this GPU; the two bitstreams must be identical or no number is recorded.  ~10 s; None when the encoder build is absent."""
+    INTEGRATION.md section 1) encodes one synthetic 60-frame 1080p clip with SVT_HIP unset, then with the ME (open-loop and the temporal filter's), deblocking, CDEF (search + apply) and LR
+    (search + filter) stage seams on this GPU; the two bitstreams must be identical or no number is recorded.  ~10 s; None when the encoder build is absent."""
     import importlib.util
     import tempfile
     spec = importlib.util.spec_from_file_location("enc_identity", os.path.join(ROOT, "tools", "enc_identity.py"))
