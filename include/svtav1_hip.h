@@ -468,6 +468,10 @@ typedef struct SvtHipTfSubpelResult {
 } SvtHipTfSubpelResult;
 void svt_hip_tf_subpel_search_batch(const SvtHipTfSubpelParams *params, const void *src_base, const void *ref_base, const SvtHipTfSubpelDesc *descs,
                                     uint32_t n, SvtHipTfSubpelResult *results, void *stream);
+/* The same from HOST memory (a seam around tf_subpel_search, temporal_filtering.c:1670, calls it once per (central picture, reference picture) pair for every
+ * block the reference may ask for): src_buf / ref_buf = the two pictures' whole padded luma buffers, the descs' offsets relative to them.  Synchronous. */
+void svt_hip_tf_subpel_search_host(const SvtHipTfSubpelParams *params, const void *src_buf, size_t src_samples, const void *ref_buf, size_t ref_samples,
+                                   const SvtHipTfSubpelDesc *descs, uint32_t n, SvtHipTfSubpelResult *results);
 
 /* The temporal filter's final motion compensation, batched: replaces tf_64x64_inter_prediction / tf_32x32_ / tf_16x16_ / tf_8x8_inter_prediction
  * (temporal_filtering.c:2256-2620) for the blocks of a (central picture, reference picture) pair -- svt_aom_inter_prediction's uni-directional

@@ -402,8 +402,10 @@ enum { TF_RECS = 32 };
 typedef struct SeamTfPair {
     PictureParentControlSet *pcs;
     uint64_t                 picture_number, ref_number;
-    int                      state; /* 0 free, 2 ready, 3 declined */
+    int                      state; /* 0 free / complete (the tables stay readable until the slot is reused), 2 ready, 3 declined */
     uint32_t                 n_sb, consumed;
+    uint64_t                 stamp; /* order of creation: the oldest complete record is reused first */
+    int                      tables_valid; /* the stage ran for this pair (not declined) */
     uint32_t                *best_sad, *best_mv;
     int16_t                 *hme_sc;
     uint64_t                *hme_sad;
@@ -453,20 +455,21 @@ EbErrorType svt_hip_seam_tf_motion_estimation_b64(PictureParentControlSet *pcs, 
     if (!tf_mode || !seam_on() || c->me_type != ME_MCTF) return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, c, input_ptr);
     const uint64_t ref_number = c->me_ds_ref_array[0][0].picture_number;
     pthread_mutex_lock(&G.lock);
+    static uint64_t stamp;
     SeamTfPair *T = NULL, *spare = NULL;
     for (int i = 0; i < TF_RECS; i++) {
         if (tf_rec[i].state && tf_rec[i].pcs == pcs && tf_rec[i].picture_number == pcs->picture_number && tf_rec[i].ref_number == ref_number) { T = &tf_rec[i]; break; }
-        if (!tf_rec[i].state && !spare) spare = &tf_rec[i];
+        if (!tf_rec[i].state && (!spare || tf_rec[i].stamp < spare->stamp)) spare = &tf_rec[i];
     }
     if (!T) {
         if (!spare) { fprintf(stderr, "SVT_HIP_TF_ME_SEAM: more than %d (picture, reference) pairs in flight\n", TF_RECS); abort(); }
         T = spare;
-        T->pcs = pcs; T->picture_number = pcs->picture_number; T->ref_number = ref_number; T->consumed = 0;
+        T->pcs = pcs; T->picture_number = pcs->picture_number; T->ref_number = ref_number; T->consumed = 0; T->stamp = ++stamp;
         const double t0 = seam_now();
         const int rc = run_tf_pair(T, pcs, c);
         G.t_stage += seam_now() - t0;
-        if (rc) { T->state = 3; T->n_sb = pcs->b64_total_count; tf_declined++; }
-        else    { T->state = 2; tf_pairs++; }
+        if (rc) { T->state = 3; T->tables_valid = 0; T->n_sb = pcs->b64_total_count; tf_declined++; }
+        else    { T->state = 2; T->tables_valid = 1; tf_pairs++; }
     }
     const int declined = T->state == 3;
     if (!declined) {
@@ -493,6 +496,24 @@ EbErrorType svt_hip_seam_tf_motion_estimation_b64(PictureParentControlSet *pcs, 
     pthread_mutex_unlock(&G.lock);
     if (declined) return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, c, input_ptr);
     return EB_ErrorNone;
+}
+
+
+/* the pair's whole-picture tables for the sub-pel seam (ref_wrap/temporal_filtering_seam.c); copied out under the lock.  best_mv: [n_sb][85], hme_sc: [n_sb][2],
+ * hme_sad: [n_sb].  0 when the pair did not go through the stage. */
+int svt_hip_seam_tf_pair_tables(PictureParentControlSet *pcs, uint64_t ref_number, uint32_t n_sb, uint32_t *best_mv, int16_t *hme_sc, uint64_t *hme_sad) {
+    int ok = 0;
+    pthread_mutex_lock(&G.lock);
+    for (int i = 0; i < TF_RECS; i++) {
+        const SeamTfPair *T = &tf_rec[i];
+        if (T->pcs == pcs && T->picture_number == pcs->picture_number && T->ref_number == ref_number && T->tables_valid && T->n_sb == n_sb) {
+            memcpy(best_mv, T->best_mv, (size_t)n_sb * 85 * 4); memcpy(hme_sc, T->hme_sc, (size_t)n_sb * 2 * sizeof(int16_t)); memcpy(hme_sad, T->hme_sad, (size_t)n_sb * 8);
+            ok = 1;
+            break;
+        }
+    }
+    pthread_mutex_unlock(&G.lock);
+    return ok;
 }
 
 #define svt_aom_motion_estimation_b64(pcs, i, x, y, ctx, pic) seam_motion_estimation_b64(pcs, i, x, y, ctx, pic)

@@ -1,18 +1,205 @@
-/* temporal_filtering_seam.c -- TEST / BASELINE INFRASTRUCTURE: the reference's temporal filter with its ME call routed through the ME seam.
+/* temporal_filtering_seam.c -- TEST / BASELINE INFRASTRUCTURE: the reference's temporal filter with two seams.
  *
- * This translation unit IS Source/Lib/Codec/temporal_filtering.c of the reference (included below where it lies; nothing is copied).  The one change: the call
+ * This translation unit IS Source/Lib/Codec/temporal_filtering.c of the reference (included below where it lies; nothing is copied).  Two calls are renamed for
+ * the duration of the #include:
  *
- *     svt_aom_motion_estimation_b64(centre_pcs, blk_row * blk_cols + blk_col, blk_col * BW, blk_row * BH, ctx, input_picture_ptr_central);        (:3180)
+ * 1. svt_aom_motion_estimation_b64(centre_pcs, ...) (:3180, me_type == ME_MCTF) lands in svt_hip_seam_tf_motion_estimation_b64() (ref_wrap/me_process_seam.c,
+ *    which owns the device session and the picture ring).  With SVT_HIP_TF_ME_SEAM unset that function IS the reference call.
  *
- * is given a macro name for the duration of the #include and lands in svt_hip_seam_tf_motion_estimation_b64() (ref_wrap/me_process_seam.c, which owns the
- * device session and the picture ring).  With SVT_HIP_TF_ME_SEAM unset that function IS the reference call.
+ * 2. tf_subpel_search(...) -- `static`, defined at :1670 and called from tf_64x64_ / tf_32x32_ / tf_16x16_ / tf_8x8_sub_pel_search (:1886, :1998, :2118, :2237).
+ *    The macro appends __COUNTER__ (unused anywhere else in this translation unit): the DEFINITION becomes tf_subpel_search_use0 -- the reference's body,
+ *    untouched -- and the four call sites tf_subpel_search_use1 .. _use4, all of which are seam_tf_subpel_search() below.  With SVT_HIP_TF_SUBPEL_SEAM=1 (on top
+ *    of the ME seams) the first block of a (central picture, reference picture) pair to arrive has the refinement of EVERY block the reference may ask for --
+ *    64x64, 32x32, 16x16 (and 8x8 with tf_ctrls.enable_8x8_pred) of every 64x64 block, starting from the vectors the pair's ME tables hold -- computed by ONE
+ *    svt_hip_tf_subpel_search_host() call; a block's search is then a table lookup.  The refinement of a block depends only on the pictures, the block and its
+ *    starting vector, not on the 64 / 32 / 16 decisions the reference takes between the searches, which stay the reference's own code.  Every lookup checks
+ *    the caller's starting vector and interpolation filter against what the batch assumed and runs the reference's function when they differ (or when the
+ *    pair is outside what the batch covers: the high-bit-depth path, a pair that did not go through the ME stage).
  */
+#define _GNU_SOURCE /* RTLD_DEFAULT */
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include "motion_estimation.h" /* declares svt_aom_motion_estimation_b64 before the macro below exists */
 #include "me_context.h"
 #include "pcs.h"
+#include "temporal_filtering.h"
+#include "svtav1_hip.h" /* include/svtav1_hip.h of this repository: the C ABI */
 
 EbErrorType svt_hip_seam_tf_motion_estimation_b64(PictureParentControlSet *pcs, uint32_t b64_index, uint32_t b64_origin_x, uint32_t b64_origin_y, MeContext *me_ctx,
                                                   EbPictureBufferDesc *input_ptr);
+int         svt_hip_seam_tf_pair_tables(PictureParentControlSet *pcs, uint64_t ref_number, uint32_t n_sb, uint32_t *best_mv, int16_t *hme_sc, uint64_t *hme_sad);
 
+#define TF_SUBPEL_ARGS                                                                                                                                          \
+    TF_SUBPEL_SEARCH_PARAMS *tf_sp_param, PictureParentControlSet *pcs, MeContext *me_ctx, BlkStruct *blk_ptr, EbPictureBufferDesc *pic_ptr_ref,               \
+        EbPictureBufferDesc *prediction_ptr, EbByte *pred, uint16_t **pred_16bit, uint32_t *stride_pred, EbByte *src, uint16_t **src_16bit, uint32_t *stride_src, \
+        uint64_t *best_dist, int16_t *best_mv_x, int16_t *best_mv_y
+#define TF_SUBPEL_PASS \
+    tf_sp_param, pcs, me_ctx, blk_ptr, pic_ptr_ref, prediction_ptr, pred, pred_16bit, stride_pred, src, src_16bit, stride_src, best_dist, best_mv_x, best_mv_y
+static void tf_subpel_search_use0(TF_SUBPEL_ARGS); /* the reference's function (defined by the #include) */
+static void seam_tf_subpel_search(TF_SUBPEL_ARGS);
+static void tf_subpel_search_use1(TF_SUBPEL_ARGS) { seam_tf_subpel_search(TF_SUBPEL_PASS); }
+static void tf_subpel_search_use2(TF_SUBPEL_ARGS) { seam_tf_subpel_search(TF_SUBPEL_PASS); }
+static void tf_subpel_search_use3(TF_SUBPEL_ARGS) { seam_tf_subpel_search(TF_SUBPEL_PASS); }
+static void tf_subpel_search_use4(TF_SUBPEL_ARGS) { seam_tf_subpel_search(TF_SUBPEL_PASS); }
+
+#define SEAM_CAT_(a, b) a##b
+#define SEAM_CAT(a, b) SEAM_CAT_(a, b)
+#define tf_subpel_search(...) SEAM_CAT(tf_subpel_search_use, __COUNTER__)(__VA_ARGS__)
 #define svt_aom_motion_estimation_b64(pcs, i, x, y, ctx, pic) svt_hip_seam_tf_motion_estimation_b64(pcs, i, x, y, ctx, pic)
 #include "temporal_filtering.c" /* resolves through -I$(REF)/Source/Lib/Codec */
+#undef tf_subpel_search
+#undef svt_aom_motion_estimation_b64
+
+/* ---- the sub-pel seam (after the #include: the block-numbering tables of temporal_filtering.c:44-90 are in scope) ---- */
+enum { SP_RECS = 16 };
+typedef struct SubpelBatch {
+    PictureParentControlSet *pcs;
+    uint64_t                 picture_number;
+    const EbPictureBufferDesc *ref;
+    int                      live;
+    uint32_t                 n_sb, per_sb, seen64;
+    uint64_t                 stamp;
+    SvtHipTfSubpelDesc      *descs;
+    SvtHipTfSubpelResult    *res;
+    size_t                   cap;
+} SubpelBatch;
+static struct {
+    pthread_mutex_t lock;
+    int             mode; /* -1 unknown */
+    void (*search_host)(const SvtHipTfSubpelParams *, const void *, size_t, const void *, size_t, const SvtHipTfSubpelDesc *, uint32_t, SvtHipTfSubpelResult *);
+    SubpelBatch rec[SP_RECS];
+    uint64_t    n_batches, n_blocks, n_served, n_fallback, stamp;
+} SPS = {PTHREAD_MUTEX_INITIALIZER, -1};
+
+static void sp_stats(void) {
+    const char *f = getenv("SVT_HIP_TF_SUBPEL_SEAM_STATS");
+    FILE       *o = f ? fopen(f, "w") : NULL;
+    if (!o) return;
+    fprintf(o, "pairs_batched %llu\nblocks_computed %llu\nsearches_served %llu\nsearches_by_reference %llu\n", (unsigned long long)SPS.n_batches,
+            (unsigned long long)SPS.n_blocks, (unsigned long long)SPS.n_served, (unsigned long long)SPS.n_fallback);
+    fclose(o);
+}
+static int sp_on(void) {
+    if (SPS.mode < 0) {
+        pthread_mutex_lock(&SPS.lock);
+        if (SPS.mode < 0) {
+            const char *e = getenv("SVT_HIP_TF_SUBPEL_SEAM");
+            int         m = e && atoi(e) && getenv("SVT_HIP") && getenv("SVT_HIP_TF_ME_SEAM");
+            if (m) {
+                *(void **)&SPS.search_host = dlsym(RTLD_DEFAULT, "svt_hip_tf_subpel_search_host");
+                if (!SPS.search_host) { fprintf(stderr, "SVT_HIP_TF_SUBPEL_SEAM: libsvtav1_hip is not loaded\n"); abort(); }
+                atexit(sp_stats);
+                fprintf(stderr, "SVT_HIP_TF_SUBPEL_SEAM: the temporal filter's sub-pel refinement runs as one device call per (picture, reference) pair\n");
+            }
+            SPS.mode = m;
+        }
+        pthread_mutex_unlock(&SPS.lock);
+    }
+    return SPS.mode;
+}
+static int is_bilinear(uint32_t interp_filters) { return interp_filters == (uint32_t)av1_make_interp_filters(BILINEAR, BILINEAR); }
+
+/* every block of the pair the reference may search, with the starting vector its caller would pass (:1866-1870, :1980-1982, :2113-2115, :2232-2234) */
+static int build_batch(SubpelBatch *B, PictureParentControlSet *pcs, MeContext *me_ctx, EbPictureBufferDesc *ref, EbByte src_sb, uint32_t src_stride,
+                       const TF_SUBPEL_SEARCH_PARAMS *sp) {
+    const uint32_t n_sb = pcs->b64_total_count, with8 = pcs->tf_ctrls.enable_8x8_pred ? 64 : 0, per_sb = 1 + 4 + 16 + with8, n = n_sb * per_sb;
+    uint32_t *best_mv = malloc((size_t)n_sb * 85 * 4);
+    int16_t  *hme_sc  = malloc((size_t)n_sb * 2 * sizeof(int16_t));
+    uint64_t *hme_sad = malloc((size_t)n_sb * 8);
+    if (!svt_hip_seam_tf_pair_tables(pcs, me_ctx->me_ds_ref_array[0][0].picture_number, n_sb, best_mv, hme_sc, hme_sad)) { free(best_mv); free(hme_sc); free(hme_sad); return 0; }
+    if (n > B->cap) { B->descs = realloc(B->descs, (size_t)n * sizeof(*B->descs)); B->res = realloc(B->res, (size_t)n * sizeof(*B->res)); B->cap = n; }
+    memset(B->descs, 0, (size_t)n * sizeof(*B->descs));
+    /* the central picture's luma: src_sb is the top-left sample of the caller's 64x64 block (sb origin = pu origin - local origin) */
+    const uint32_t sb_x0 = sp->pu_origin_x - sp->local_origin_x, sb_y0 = sp->pu_origin_y - sp->local_origin_y;
+    EbPictureBufferDesc *cen = pcs->enhanced_pic;
+    const uint8_t *src_buf = cen->buffer_y;
+    const size_t   src_pic0 = (size_t)(src_sb - src_buf) - ((size_t)sb_y0 * src_stride + sb_x0); /* offset of picture sample (0, 0) in the buffer */
+    if (src_stride != cen->stride_y || src_pic0 != (size_t)cen->org_y * cen->stride_y + cen->org_x) { free(best_mv); free(hme_sc); free(hme_sad); return 0; }
+    const uint32_t pic_w_sb = (pcs->aligned_width + 63) / 64;
+    const int      only64 = pcs->tf_ctrls.use_pred_64x64_only_th == (uint8_t)~0;
+    for (uint32_t sb = 0; sb < n_sb; sb++) {
+        const uint32_t  x0 = (sb % pic_w_sb) * 64, y0 = (sb / pic_w_sb) * 64;
+        const uint32_t *mv = best_mv + (size_t)sb * 85;
+        SvtHipTfSubpelDesc *d = B->descs + (size_t)sb * per_sb;
+        const int exited = hme_sad[sb] < me_ctx->tf_me_exit_th; /* the ME call's early exit: no tables, 64x64 only, from the HME centre (:1866-1870) */
+#define SP_SET(D, PX, PY, BS, BIL, MVW, FROM_SC)                                                                                                  \
+    do {                                                                                                                                          \
+        (D)->src_off = src_pic0 + (size_t)(PY) * src_stride + (PX); (D)->src_stride = src_stride; (D)->pu_x = (uint16_t)(PX); (D)->pu_y = (uint16_t)(PY); \
+        (D)->bsize = (uint8_t)(BS); (D)->bilinear = (uint8_t)(BIL);                                                                               \
+        (D)->mv_x = (int16_t)((FROM_SC) ? hme_sc[2 * sb] << 3 : (_MVXT(MVW)) << 3); (D)->mv_y = (int16_t)((FROM_SC) ? hme_sc[2 * sb + 1] << 3 : (_MVYT(MVW)) << 3); \
+    } while (0)
+        const int two_tap = pcs->tf_ctrls.use_2tap; /* (me_ctx->tf_ctrls mirrors it; the 64 / 32 searches take BILINEAR with it, :1801-1804, :1911-1914) */
+        SP_SET(&d[0], x0, y0, 64, two_tap, mv[0], exited || only64);
+        for (uint32_t i = 0; i < 4; i++) SP_SET(&d[1 + i], x0 + (i & 1) * 32, y0 + (i >> 1) * 32, 32, two_tap, mv[1 + i], 0);
+        for (uint32_t i32 = 0; i32 < 4; i32++)
+            for (uint32_t i16 = 0; i16 < 4; i16++) {
+                const uint32_t pu = idx_32x32_to_idx_16x16[i32][i16], iy = subblock_xy_16x16[pu][0], ix = subblock_xy_16x16[pu][1];
+                SP_SET(&d[5 + iy * 4 + ix], x0 + ix * 16, y0 + iy * 16, 16, 0, mv[5 + tab16x16[pu]], 0);
+            }
+        if (with8)
+            for (uint32_t i32 = 0; i32 < 4; i32++)
+                for (uint32_t i16 = 0; i16 < 4; i16++)
+                    for (uint32_t i8 = 0; i8 < 4; i8++) {
+                        const uint32_t pu = idx_32x32_to_idx_8x8[i32][i16][i8], iy = subblock_xy_8x8[pu][0], ix = subblock_xy_8x8[pu][1];
+                        SP_SET(&d[21 + iy * 8 + ix], x0 + ix * 8, y0 + iy * 8, 8, 0, mv[21 + tab8x8[pu]], 0);
+                    }
+#undef SP_SET
+        (void)exited;
+    }
+    SvtHipTfSubpelParams P;
+    memset(&P, 0, sizeof(P));
+    P.half_pel_mode = pcs->tf_ctrls.half_pel_mode; P.quarter_pel_mode = pcs->tf_ctrls.quarter_pel_mode; P.eight_pel_mode = pcs->tf_ctrls.eight_pel_mode;
+    P.subsampling_shift = pcs->tf_ctrls.sub_sampling_shift; P.bit_depth = 8; P.early_exit_th = me_ctx->tf_subpel_early_exit_th;
+    P.mi_rows = (uint32_t)pcs->av1_cm->mi_rows; P.mi_cols = (uint32_t)pcs->av1_cm->mi_cols;
+    P.ref_org_x = ref->org_x; P.ref_org_y = ref->org_y; P.ref_stride = ref->stride_y;
+    SPS.search_host(&P, src_buf, cen->luma_size, ref->buffer_y, ref->luma_size, B->descs, n, B->res);
+    B->n_sb = n_sb; B->per_sb = per_sb;
+    SPS.n_batches++; SPS.n_blocks += n;
+    free(best_mv); free(hme_sc); free(hme_sad);
+    return 1;
+}
+
+static void seam_tf_subpel_search(TF_SUBPEL_ARGS) {
+    if (!sp_on() || tf_sp_param->is_highbd) { tf_subpel_search_use0(TF_SUBPEL_PASS); return; }
+    pthread_mutex_lock(&SPS.lock);
+    SubpelBatch *B = NULL, *spare = NULL;
+    for (int i = 0; i < SP_RECS; i++) {
+        SubpelBatch *r = &SPS.rec[i];
+        if (r->live && r->pcs == pcs && r->picture_number == pcs->picture_number && r->ref == pic_ptr_ref) { B = r; break; }
+        if (!r->live && (!spare || r->stamp < spare->stamp)) spare = r;
+    }
+    if (!B && spare) {
+        spare->pcs = pcs; spare->picture_number = pcs->picture_number; spare->ref = pic_ptr_ref; spare->seen64 = 0; spare->stamp = ++SPS.stamp;
+        /* src[C_Y] = the caller's 64x64 source block (produce_temporally_filtered_pic hands the block's plane pointers on) */
+        if (build_batch(spare, pcs, me_ctx, pic_ptr_ref, src[C_Y], stride_src[C_Y], tf_sp_param)) { spare->live = 1; B = spare; }
+    }
+    int served = 0;
+    if (B) {
+        const uint32_t pic_w_sb = (pcs->aligned_width + 63) / 64;
+        const uint32_t sb_x0 = tf_sp_param->pu_origin_x - tf_sp_param->local_origin_x, sb_y0 = tf_sp_param->pu_origin_y - tf_sp_param->local_origin_y;
+        const uint32_t sb = (sb_y0 / 64) * pic_w_sb + sb_x0 / 64, lx = tf_sp_param->local_origin_x, ly = tf_sp_param->local_origin_y, bs = tf_sp_param->bsize;
+        int slot = -1;
+        if (bs == 64) slot = 0;
+        else if (bs == 32) slot = 1 + (ly / 32) * 2 + lx / 32;
+        else if (bs == 16) slot = 5 + (ly / 16) * 4 + lx / 16;
+        else if (bs == 8 && B->per_sb > 21) slot = 21 + (ly / 8) * 8 + lx / 8;
+        if (slot >= 0 && sb < B->n_sb) {
+            const SvtHipTfSubpelDesc   *d = &B->descs[(size_t)sb * B->per_sb + slot];
+            const SvtHipTfSubpelResult *r = &B->res[(size_t)sb * B->per_sb + slot];
+            if (d->bsize == bs && d->pu_x == tf_sp_param->pu_origin_x && d->pu_y == tf_sp_param->pu_origin_y && d->mv_x == *best_mv_x && d->mv_y == *best_mv_y &&
+                d->bilinear == is_bilinear(tf_sp_param->interp_filters) && *best_dist == (uint64_t)INT_MAX &&
+                tf_sp_param->subsampling_shift == pcs->tf_ctrls.sub_sampling_shift) {
+                *best_dist = r->dist; *best_mv_x = r->mv_x; *best_mv_y = r->mv_y;
+                served = 1;
+            }
+        }
+        if (bs == 64 && ++B->seen64 == B->n_sb) B->live = 0; /* every 64x64 block of the pair has passed: exactly one 64x64 search per (block, reference) */
+    }
+    if (served) SPS.n_served++; else SPS.n_fallback++;
+    pthread_mutex_unlock(&SPS.lock);
+    if (!served) tf_subpel_search_use0(TF_SUBPEL_PASS);
+}

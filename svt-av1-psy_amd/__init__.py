@@ -102,6 +102,7 @@ PROTOTYPES = {
     "svt_hip_tf_filter_frame": (None, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_tf_subpel_search_batch": (None, [vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svt_hip_tf_inter_pred_batch": (None, [vp, vp, vp, C.c_uint32, C.c_int, vp]),
+    "svt_hip_tf_subpel_search_host": (None, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, vp]),
     "svt_hip_lr_filter_frame_host": (None, [vp]),
     "svt_hip_cdef_apply_host": (None, [vp]),
     "svt_hip_lpf_plane_host": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, C.c_uint32, vp, C.c_uint32]),

@@ -339,3 +339,24 @@ extern "C" void svt_hip_tf_inter_pred_batch(const SvtHipTfSubpelParams* params, 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_mc_kernel<uint8_t>), dim3((items + 3) / 4), dim3(256), shm, (hipStream_t)stream, *params, *planes, descs, n, chroma);
     SVT_LAUNCH_CHECK();
 }
+
+// Host-pointer form of the refinement batch (what a seam inside temporal_filtering.c calls once per (central picture, reference picture) pair): src_buf / ref_buf
+// = the two pictures' whole padded luma buffers (src_samples / ref_samples samples), descs / results host arrays; the descs' offsets are relative to the buffers.
+extern "C" void svt_hip_tf_subpel_search_host(const SvtHipTfSubpelParams* params, const void* src_buf, size_t src_samples, const void* ref_buf, size_t ref_samples,
+                                              const SvtHipTfSubpelDesc* descs, uint32_t n, SvtHipTfSubpelResult* results) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    const size_t px = params->bit_depth > 8 ? 2 : 1, db = (size_t)n * sizeof(SvtHipTfSubpelDesc), rb = (size_t)n * sizeof(SvtHipTfSubpelResult);
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve((src_samples + ref_samples) * px + db + rb + 8192, (src_samples + ref_samples) * px + db + rb + 8192);
+    void* d_src = c.dalloc(src_samples * px);
+    void* d_ref = c.dalloc(ref_samples * px);
+    SvtHipTfSubpelDesc*   d_d = (SvtHipTfSubpelDesc*)c.dalloc(db);
+    SvtHipTfSubpelResult* d_r = (SvtHipTfSubpelResult*)c.dalloc(rb);
+    c.up(d_src, src_buf, src_samples * px);
+    c.up(d_ref, ref_buf, ref_samples * px);
+    c.up(d_d, descs, db);
+    svt_hip_tf_subpel_search_batch(params, d_src, d_ref, d_d, n, d_r, c.stream);
+    c.down(results, d_r, rb);
+}

@@ -54,30 +54,36 @@ CASES = {
     "cdefseam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+cdefseam"]),
     "cdefseam_p4_10bit": (256, 144, 6, 10, ["--preset", "4", "--lp", "1", "+cdefseam"]),
     "cdefseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "--crf", "45", "+cdefseam"]),
-    "allseams_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
-    "allseams_1080p_p6": (1920, 1080, 6, 8, ["--preset", "6", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "allseams_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "allseams_1080p_p6": (1920, 1080, 6, 8, ["--preset", "6", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
     # the deblocking filter of a picture as one device call per plane, segments recorded from the reference's own driver (oracle/ref_wrap/dlf_process_seam.c)
     "dlfseam_p5_8bit": (448, 264, 8, 8, ["--preset", "5", "--lp", "1", "+dlfseam"]),
     "dlfseam_p2_10bit": (256, 144, 5, 10, ["--preset", "2", "--lp", "1", "+dlfseam"]),
     "dlfseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "+dlfseam"]),
-    "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+dlfseam", "+cdefseam", "+lrseam"]),
-    "everyseam_4k10_p8_lp1": (3840, 2160, 6, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),  # config-5 format, single-threaded (reproducible)
+    "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+tfsubpel", "+dlfseam", "+cdefseam", "+lrseam"]),
+    "everyseam_4k10_p8_lp1": (3840, 2160, 6, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),  # config-5 format, single-threaded (reproducible)
     # the temporal filter's ME (ME_MCTF form of the stage, one call per (central picture, reference picture) pair): SVT_HIP_TF_ME_SEAM=1 on top of the ME seam
     "tfseam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tfseam_p4_10bit": (256, 144, 8, 10, ["--preset", "4", "--lp", "1", "+seam", "+tfseam"]),
     "tfseam_p6_8bit_lp4": (448, 264, 10, 8, ["--preset", "6", "--lp", "4", "+seam", "+tfseam"]),
+    # the temporal filter's sub-pel refinement as one device call per (picture, reference) pair (tf_subpel_search served from the batch): SVT_HIP_TF_SUBPEL_SEAM=1
+    "tfsubpel_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
+    "tfsubpel_p4_8bit": (256, 144, 8, 8, ["--preset", "4", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
+    "tfsubpel_p6_8bit_lp4": (448, 264, 10, 8, ["--preset", "6", "--lp", "4", "+seam", "+tfseam", "+tfsubpel"]),
+    "tfsubpel_p2_10bit": (256, 144, 6, 10, ["--preset", "2", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),  # high bit depth: the seam hands those searches to the reference
     "lrseam_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+lrseam"]),  # 1080p: tens of restoration units per plane, all host cores
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
     # BASELINE.json metric, second half: encoder fps @1080p preset 8 (C-only reference vs the same encoder with the ME stage on the MI355X), all host cores
     "fps_1080p_p8": (1920, 1080, 24, 8, ["--preset", "8", "+seam"]),
-    "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
     # 3840x2160 10-bit, preset 8, 60 frames (10-bit preset 8 is where the multi-threaded C-only reference was seen not to reproduce its own
     # bitstream; run_case reports `reference_deterministic` and the identity verdict next to the two speeds)
-    "fps_4k10_p8_all": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_4k10_p8_all": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
     "fps_1080p_p8_me": (1920, 1080, 60, 8, ["--preset", "8", "+seam"]),
-    "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
-    "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+tfseam", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
+    "tiny_tfsubpel_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
     "tiny_tfseam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tiny_dlfseam_p4": (128, 64, 3, 8, ["--preset", "4", "--lp", "1", "+dlfseam"]),
     "tiny_cdefseam_p8": (128, 64, 3, 8, ["--preset", "8", "--lp", "1", "+cdefseam"]),
@@ -89,7 +95,7 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
-SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_"))]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_"))]
 
 
 def make_clip(path, w, h, n, bd, seed=7):
@@ -144,6 +150,8 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
         env.update({"SVT_HIP_ME_SEAM": "1", "SVT_HIP_ME_SEAM_STATS": seam_file})
         if "+tfseam" in CASES[name][4]:
             env["SVT_HIP_TF_ME_SEAM"] = "1"
+        if "+tfsubpel" in CASES[name][4]:
+            env.update({"SVT_HIP_TF_SUBPEL_SEAM": "1", "SVT_HIP_TF_SUBPEL_SEAM_STATS": os.path.join(outdir, name + "_tfsubpel.txt")})
     if lrseam:
         env.update({"SVT_HIP_LR_SEAM": "1", "SVT_HIP_LR_SEAM_STATS": lrseam_file})
     cdefseam_file = os.path.join(outdir, name + "_cdefseam.txt")
@@ -189,6 +197,12 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
         res["identical"] = same and res["seam"].get("pictures_offloaded", 0) > 0 and res["seam"].get("pictures_declined", 1) == 0
         if "+tfseam" in CASES[name][4]:  # temporal-filter pairs really went through the stage, none declined
             res["identical"] = res["identical"] and res["seam"].get("tf_pairs_offloaded", 0) > 0 and res["seam"].get("tf_pairs_declined", 1) == 0
+    if "+tfsubpel" in CASES[name][4]:
+        f = os.path.join(outdir, name + "_tfsubpel.txt")
+        st = dict(ln.split(None, 1) for ln in open(f).read().splitlines()) if os.path.exists(f) else {}
+        res["tfsubpel"] = {k: int(v) for k, v in st.items()}
+        if bd == 8:  # the dedicated 8-bit cases must really be served from the device batch
+            res["identical"] = res["identical"] and res["tfsubpel"].get("searches_served", 0) > 0
     if lrseam:
         st = dict(ln.split(None, 1) for ln in open(lrseam_file).read().splitlines()) if os.path.exists(lrseam_file) else {}
         res["lrseam"] = {k: int(v) for k, v in st.items()}
@@ -236,7 +250,7 @@ def main():
             union[k] = union.get(k, 0) + v
         print("%-20s identical=%s  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs  %s" % (nme, r["identical"], r.get("calls"), r.get("pointers_hit"),
                                                                                         r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"],
-                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", ""))), flush=True)
+                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", "")) + " " + str(r.get("tfsubpel", ""))), flush=True)
         if "fps_c" in r:
             print("    encoder fps: C-only %.2f, with HIP %.2f" % (r["fps_c"], r.get("fps_hip", 0.0)), flush=True)
         if not r["identical"]:
