@@ -269,7 +269,7 @@ def cpu_lr_search(k, budget_s):
 
 def encoder_fps():
     """The second half of BASELINE.json's metric: encoder fps at 1080p preset 8.  The reference's own encoder (oracle/_ref/enc, C-only build with the binding of
-    INTEGRATION.md section 1) encodes one synthetic 60-frame 1080p clip with SVT_HIP unset, then with the ME (open-loop and the temporal filter's), deblocking, CDEF (search + apply) and LR
+    INTEGRATION.md section 1) encodes one synthetic 60-frame 1080p clip with SVT_HIP unset, then with the ME (open-loop and the temporal filter's, incl. its sub-pel refinement), deblocking, CDEF (search + apply) and LR
     (search + filter) stage seams on this GPU; the two bitstreams must be identical or no number is recorded.  ~10 s; None when the encoder build is absent."""
     import importlib.util
     import tempfile
@@ -285,7 +285,7 @@ def encoder_fps():
         sys.exit("bench.py: the encoder's bitstream with the stage seams differs from the C-only encoder -- no numbers recorded (%s)" % r.get("stderr_tail", ""))
     return {"fps_c_only": r.get("fps_c"), "fps_with_stage_seams": r.get("fps_hip"), "bitstream_identical": True, "frames": r["frames"],
             "config": "1080p 8-bit, preset 8, CRF 35, all host threads; reference encoder built C-only (no nasm on the box)",
-            "stages_on_gpu": {"me": r.get("seam"), "dlf": r.get("dlfseam"), "cdef": r.get("cdefseam"), "lr": r.get("lrseam")}}
+            "stages_on_gpu": {"me": r.get("seam"), "tf_subpel": r.get("tfsubpel"), "dlf": r.get("dlfseam"), "cdef": r.get("cdefseam"), "lr": r.get("lrseam")}}
 
 
 def roofline(bytes_alg, seconds, kernel, traffic_kernel=None, **extra):

@@ -55,7 +55,7 @@ static void tf_subpel_search_use4(TF_SUBPEL_ARGS) { seam_tf_subpel_search(TF_SUB
 #undef svt_aom_motion_estimation_b64
 
 /* ---- the sub-pel seam (after the #include: the block-numbering tables of temporal_filtering.c:44-90 are in scope) ---- */
-enum { SP_RECS = 16 };
+enum { SP_RECS = 24 }; /* > the (picture, reference) pairs that can be in the filter at once */
 typedef struct SubpelBatch {
     PictureParentControlSet *pcs;
     uint64_t                 picture_number;
@@ -170,7 +170,7 @@ static void seam_tf_subpel_search(TF_SUBPEL_ARGS) {
     for (int i = 0; i < SP_RECS; i++) {
         SubpelBatch *r = &SPS.rec[i];
         if (r->live && r->pcs == pcs && r->picture_number == pcs->picture_number && r->ref == pic_ptr_ref) { B = r; break; }
-        if (!r->live && (!spare || r->stamp < spare->stamp)) spare = r;
+        if (!spare || r->stamp < spare->stamp) spare = r; /* the oldest batch (or a never-used slot: stamp 0) */
     }
     if (!B && spare) {
         spare->pcs = pcs; spare->picture_number = pcs->picture_number; spare->ref = pic_ptr_ref; spare->seen64 = 0; spare->stamp = ++SPS.stamp;
@@ -197,7 +197,8 @@ static void seam_tf_subpel_search(TF_SUBPEL_ARGS) {
                 served = 1;
             }
         }
-        if (bs == 64 && ++B->seen64 == B->n_sb) B->live = 0; /* every 64x64 block of the pair has passed: exactly one 64x64 search per (block, reference) */
+        /* (a batch stays until its slot is reused for a newer pair -- the oldest first; a pair's key never recurs.  Ending it with the last 64x64 search would
+         * take it away from the 32x32 / 16x16 searches that follow in that block and in the blocks other threads are still working on.) */
     }
     if (served) SPS.n_served++; else SPS.n_fallback++;
     pthread_mutex_unlock(&SPS.lock);
