@@ -34,16 +34,21 @@ __device__ __forceinline__ int rd_px(const void* p, const int highbd, const size
 // column is clamped by the caller.  Raw mode (w == 0): the block's own rows.  Written as selects on (base address, row index, stride): a
 // three-way choice between the pointers of the struct made the compiler index the struct through scratch memory.
 __device__ __forceinline__ const uint8_t* src_row(const TileSrc& s, const int y) {
-    const int  px = s.highbd ? 2 : 1;
+    // raw mode has stripe_top = stripe_bot = h = 0, so `up` and `dn` are false there and only the clamp needs the flag
     const bool raw = s.w == 0;
-    const bool up = !raw && y < s.stripe_top && s.stripe_top != 0, dn = !raw && !up && y >= s.stripe_bot && s.stripe_bot < s.h;
-    const int  iu = y - s.stripe_top + 2, id = y - s.stripe_bot;
-    const long long row = up ? (long long)(2 * s.stripe_idx + (iu > 0 ? iu : 0)) : (dn ? (long long)(2 * s.stripe_idx + (id < 1 ? id : 1)) : (raw ? (long long)y : (long long)clampi(y, 0, s.h - 1)));
+    const bool up = y < s.stripe_top && s.stripe_top != 0, dn = y >= s.stripe_bot && s.stripe_bot < s.h;
+    const int  lo = raw ? INT32_MIN : 0, hi = raw ? INT32_MAX : s.h - 1;                       // (wave-uniform)
+    const int  k2 = 2 * s.stripe_idx, ku = k2 - s.stripe_top + 2, kd = k2 - s.stripe_bot;     // (wave-uniform)
+    const int  ru = y + ku > k2 ? y + ku : k2;            // 2 idx + max(y - stripe_top + 2, 0)
+    const int  rd = y + kd < k2 + 1 ? y + kd : k2 + 1;    // 2 idx + min(y - stripe_bot, 1)
+    const int  rm = clampi(y, lo, hi);
+    const int  row = up ? ru : (dn ? rd : rm);
     // (bit masks, not ?: on the struct's fields: a select between loads of struct members is rewritten into an indexed load of the struct, which then lives in scratch)
     const uintptr_t d = (uintptr_t)s.data, mu = (uintptr_t)0 - (uintptr_t)up, md = (uintptr_t)0 - (uintptr_t)dn;
     const uintptr_t base = d ^ ((d ^ (uintptr_t)s.above) & mu) ^ ((d ^ (uintptr_t)s.below) & md);
-    const uint32_t  st = (uint32_t)s.stride, stride = st ^ ((st ^ (uint32_t)s.bstride) & (uint32_t)(mu | md));
-    return (const uint8_t*)(base + (uintptr_t)(row * (long long)stride * px));
+    const int       sb = s.highbd ? 2 * s.stride : s.stride, bb = s.highbd ? 2 * s.bstride : s.bstride; // bytes (wave-uniform)
+    const int       stride = sb ^ ((sb ^ bb) & (int)(uint32_t)(mu | md));
+    return (const uint8_t*)(base + (uintptr_t)((long long)row * (long long)stride));
 }
 struct __attribute__((packed, aligned(2))) LrRow8A2 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(1))) LrRow8A1 { uint32_t v[2]; };
@@ -64,12 +69,19 @@ __device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, con
     // needed) took the pixel-by-pixel path in EVERY workgroup: ~180 VALU instructions per wave and a second dependent memory round trip.
     const bool cfast = c < 9 && 8 * c < cols && (s.w == 0 || (x >= 0 && x + 8 <= s.w));
     uint32_t   v[NIT][4];
+    // Rows that are neither substituted (stripe boundary) nor replicated (plane edge) sit at data + y * stride: one 64-bit multiply-add per thread, then
+    // a wave-uniform increment per k.  Only the waves that hold one of the <= 6 special rows take the general src_row (40 VALU instructions; before, every
+    // wave paid it for every k -- a third of the Wiener kernel's instructions).
+    const int      px = s.highbd ? 2 : 1, sbytes = s.stride * px;
+    const bool     raw = s.w == 0;
+    const int      ilo = raw ? INT32_MIN : (s.stripe_top != 0 ? s.stripe_top : 0), ihi = raw ? INT32_MAX : (s.stripe_bot < s.h ? s.stripe_bot : s.h);
+    const uint8_t* pint = (const uint8_t*)s.data + (long long)(s.y0 - 3 + rb) * sbytes + (cfast ? (long long)x * px : 0ll);
 #pragma unroll
     for (int k = 0; k < NIT; k++) {
-        const int  r = rb + 16 * k;
-        const bool fast = cfast && r < rows;
-        const uint8_t* row = src_row(s, s.y0 - 3 + (r < rows ? r : 0));
-        const uint8_t* p   = fast ? row + (long long)x * (s.highbd ? 2 : 1) : row; // (idle / slow lanes read the row start: always mapped)
+        const int  r = rb + 16 * k, y = s.y0 - 3 + r;
+        const uint8_t* p = pint + (long long)(16 * k) * sbytes;
+        if (r >= rows) p = (const uint8_t*)s.data;                                   // idle lanes read the plane start: always mapped
+        else if (y < ilo || y >= ihi) p = src_row(s, y) + (cfast ? (long long)x * px : 0ll); // (slow lanes read the row start)
         if (s.highbd) {
             const LrRow8A2 t = *(const LrRow8A2*)p;
             v[k][0] = t.v[0]; v[k][1] = t.v[1]; v[k][2] = t.v[2]; v[k][3] = t.v[3];
@@ -111,47 +123,61 @@ __device__ __forceinline__ int lr_sdot2(const uint32_t a, const uint32_t b, cons
 }
 __device__ __forceinline__ uint32_t lr_pack(const int lo, const int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
 struct __attribute__((aligned(4))) LrDw5 { uint32_t d[5]; };
-// Wiener on a staged tile: horizontal pass (clamped, convolve.c:63-83 / :156-176) into `mid`, vertical pass to `out(y, x)`.  A thread produces two
-// horizontally adjacent samples per step from packed pairs: the horizontal pass reads five aligned dwords and runs eight v_dot2_i32_i16 (the odd
-// output on funnel-shifted pairs), the vertical pass regroups vertically adjacent rows with v_perm_b32 and runs eight more.  The reference's
-// "+ (centre << FILTER_BITS)" is tap 3 plus 128.  Every operand fits int16: pixels <= 4095, mid <= 2^15 - 1 (WIENER_CLAMP_LIMIT), taps < 2^8.
+struct __attribute__((aligned(4))) LrDw2 { uint32_t lo, hi; };
+struct __attribute__((aligned(8))) LrDw2A8 { uint32_t lo, hi; };
+// Wiener on a staged tile: horizontal pass (clamped, convolve.c:63-83 / :156-176) into `mid`, vertical pass to `out(y, x)`.  A thread produces a
+// 2 x 2 block of samples per step, everything on packed pairs (v_dot2_i32_i16).  Horizontal: two tile rows, five aligned dwords each, the odd column on
+// the same pairs with the taps shifted by one; the four results are stored as ONE b64 with VERTICALLY adjacent rows paired in a dword -- mid2[row pair][column] = (row 2p | row
+// 2p + 1 << 16).  Vertical: output rows 2q and 2q + 1 both read row pairs q .. q + 3 (four b64 reads for two columns); the even row takes the taps paired
+// (g0,g1)(g2,g3)(g4,g5)(g6,0), the odd row (0,g0)(g1,g2)(g3,g4)(g5,g6), so no regrouping instruction is needed: 16 dot products per four output samples
+// (the row-major `mid` of before cost 16 + 12 v_perm and seven LDS reads per TWO samples; 531 -> see profiles/ VALU instructions per wave).  The
+// reference's "+ (centre << FILTER_BITS)" is tap 3 plus 128; the rounding constants ride in the accumulator seeds.  Every operand fits int16: pixels
+// <= 4095, mid <= 2^15 - 1 (WIENER_CLAMP_LIMIT), taps < 2^8.  A row past the staged ones (uh odd) only ever meets a zero tap or an output row >= uh.
 template <typename OUT> __device__ __forceinline__ void wiener_tile(const uint16_t* tile, uint16_t* mid, const WienerTaps& t, const int uw, const int uh,
                                                                     const int bd, const int tid, OUT out) {
     int r0 = 3, r1 = 2 * FILTER_BITS - 3; // get_conv_params_wiener, convolve.h:70-88
     const int range = bd + FILTER_BITS - r0 + 2;
     if (range > 16) { r0 += range - 16; r1 -= range - 16; }
     const int lim = (1 << (bd + 1 + FILTER_BITS - r0)) - 1;
-    const uint32_t f01 = lr_pack(t.fx[0], t.fx[1]), f23 = lr_pack(t.fx[2], t.fx[3] + (1 << FILTER_BITS)), f45 = lr_pack(t.fx[4], t.fx[5]), f67 = lr_pack(t.fx[6], t.fx[7]);
-    for (int i = tid; i < (uh + 6) * 32; i += 256) {
-        const int r = i >> 5, c = (i & 31) * 2;
+    uint32_t* mid2 = (uint32_t*)mid;
+    const int      f3 = t.fx[3] + (1 << FILTER_BITS);
+    const uint32_t f01 = lr_pack(t.fx[0], t.fx[1]), f23 = lr_pack(t.fx[2], f3), f45 = lr_pack(t.fx[4], t.fx[5]), f67 = lr_pack(t.fx[6], t.fx[7]);
+    const uint32_t fz0 = lr_pack(0, t.fx[0]), f12 = lr_pack(t.fx[1], t.fx[2]), f34 = lr_pack(f3, t.fx[4]), f56 = lr_pack(t.fx[5], t.fx[6]), f7z = lr_pack(t.fx[7], 0);
+    const int      oh = (1 << (bd + FILTER_BITS - 1)) + ((1 << r0) >> 1);
+    const int      nrp = (uh + 7) >> 1; // row pairs of the uh + 6 staged rows
+    for (int i = tid; i < nrp * 32; i += 256) {
+        const int rp = i >> 5, c = (i & 31) * 2;
         if (c < uw) {
-            const LrDw5 v = *(const LrDw5*)(tile + r * TW + c); // pixels c .. c + 9; pixel c + 3 is the centre of output c
-            const int   o = 1 << (bd + FILTER_BITS - 1);
-            const int   s0 = lr_sdot2(v.d[0], f01, lr_sdot2(v.d[1], f23, lr_sdot2(v.d[2], f45, lr_sdot2(v.d[3], f67, o))));
-            const uint32_t e0 = __builtin_amdgcn_alignbyte(v.d[1], v.d[0], 2), e1 = __builtin_amdgcn_alignbyte(v.d[2], v.d[1], 2),
-                           e2 = __builtin_amdgcn_alignbyte(v.d[3], v.d[2], 2), e3 = __builtin_amdgcn_alignbyte(v.d[4], v.d[3], 2);
-            const int   s1 = lr_sdot2(e0, f01, lr_sdot2(e1, f23, lr_sdot2(e2, f45, lr_sdot2(e3, f67, o))));
-            *(uint32_t*)(mid + r * 64 + c) = lr_pack(clampi(rpot(s0, r0), 0, lim), clampi(rpot(s1, r0), 0, lim));
+            uint32_t pk[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const LrDw5 v = *(const LrDw5*)(tile + (2 * rp + h) * TW + c); // pixels c .. c + 9; pixel c + 3 is the centre of output c
+                const int   s0 = lr_sdot2(v.d[0], f01, lr_sdot2(v.d[1], f23, lr_sdot2(v.d[2], f45, lr_sdot2(v.d[3], f67, oh))));
+                // output c + 1 on the same aligned pairs with the taps shifted by one (as the vertical pass does for odd rows)
+                const int   s1 = lr_sdot2(v.d[0], fz0, lr_sdot2(v.d[1], f12, lr_sdot2(v.d[2], f34, lr_sdot2(v.d[3], f56, lr_sdot2(v.d[4], f7z, oh)))));
+                pk[h][0] = (uint32_t)clampi(s0 >> r0, 0, lim); pk[h][1] = (uint32_t)clampi(s1 >> r0, 0, lim);
+            }
+            *(LrDw2A8*)(mid2 + rp * 64 + c) = LrDw2A8{pk[0][0] | (pk[1][0] << 16), pk[0][1] | (pk[1][1] << 16)};
         }
     }
     __syncthreads();
-    const uint32_t g01 = lr_pack(t.fy[0], t.fy[1]), g23 = lr_pack(t.fy[2], t.fy[3] + (1 << FILTER_BITS)), g45 = lr_pack(t.fy[4], t.fy[5]), g6 = lr_pack(t.fy[6], 0);
-    for (int i = tid; i < uh * 32; i += 256) {
-        const int r = i >> 5, c = (i & 31) * 2;
+    const int      g3 = t.fy[3] + (1 << FILTER_BITS);
+    const uint32_t g01 = lr_pack(t.fy[0], t.fy[1]), g23 = lr_pack(t.fy[2], g3), g45 = lr_pack(t.fy[4], t.fy[5]), g6z = lr_pack(t.fy[6], 0);
+    const uint32_t gz0 = lr_pack(0, t.fy[0]), g12 = lr_pack(t.fy[1], t.fy[2]), g34 = lr_pack(g3, t.fy[4]), g56 = lr_pack(t.fy[5], t.fy[6]);
+    const int      ov = ((1 << r1) >> 1) - (1 << (bd + r1 - 1)), pmax = (1 << bd) - 1;
+    for (int i = tid; i < ((uh + 1) >> 1) * 32; i += 256) {
+        const int q = i >> 5, c = (i & 31) * 2;
         if (c < uw) {
-            const uint16_t* p = mid + r * 64 + c; // rows r .. r + 6 <-> y - 3 .. y + 3; tap 7 multiplies the zeroed row of convolve.c:118
-            uint32_t d[7];
-#pragma unroll
-            for (int k = 0; k < 7; k++) d[k] = *(const uint32_t*)(p + k * 64);
-            const int o = -(1 << (bd + r1 - 1));
-            // column c: low halves of consecutive rows paired; column c + 1: high halves
-            const int sl = lr_sdot2(__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), g01,
-                           lr_sdot2(__builtin_amdgcn_perm(d[3], d[2], 0x05040100u), g23,
-                           lr_sdot2(__builtin_amdgcn_perm(d[5], d[4], 0x05040100u), g45, lr_sdot2(d[6] & 0xffffu, g6, o))));
-            const int sh = lr_sdot2(__builtin_amdgcn_perm(d[1], d[0], 0x07060302u), g01,
-                           lr_sdot2(__builtin_amdgcn_perm(d[3], d[2], 0x07060302u), g23,
-                           lr_sdot2(__builtin_amdgcn_perm(d[5], d[4], 0x07060302u), g45, lr_sdot2(d[6] >> 16, g6, o))));
-            out(r, c, clampi(rpot(sl, r1), 0, (1 << bd) - 1), clampi(rpot(sh, r1), 0, (1 << bd) - 1), c + 1 < uw);
+            const uint32_t* p = mid2 + q * 64 + c; // row pairs q .. q + 3 <-> rows 2q .. 2q + 7 <-> y - 3 .. y + 4 of output row 2q
+            const LrDw2A8 d0 = *(const LrDw2A8*)p, d1 = *(const LrDw2A8*)(p + 64), d2 = *(const LrDw2A8*)(p + 128), d3 = *(const LrDw2A8*)(p + 192);
+            const int a0 = lr_sdot2(d0.lo, g01, lr_sdot2(d1.lo, g23, lr_sdot2(d2.lo, g45, lr_sdot2(d3.lo, g6z, ov))));
+            const int a1 = lr_sdot2(d0.hi, g01, lr_sdot2(d1.hi, g23, lr_sdot2(d2.hi, g45, lr_sdot2(d3.hi, g6z, ov))));
+            out(2 * q, c, clampi(a0 >> r1, 0, pmax), clampi(a1 >> r1, 0, pmax), c + 1 < uw);
+            if (2 * q + 1 < uh) {
+                const int b0 = lr_sdot2(d0.lo, gz0, lr_sdot2(d1.lo, g12, lr_sdot2(d2.lo, g34, lr_sdot2(d3.lo, g56, ov))));
+                const int b1 = lr_sdot2(d0.hi, gz0, lr_sdot2(d1.hi, g12, lr_sdot2(d2.hi, g34, lr_sdot2(d3.hi, g56, ov))));
+                out(2 * q + 1, c, clampi(b0 >> r1, 0, pmax), clampi(b1 >> r1, 0, pmax), c + 1 < uw);
+            }
         }
     }
 }
@@ -215,7 +241,6 @@ typedef unsigned short lr_u16x2 __attribute__((vector_size(4)));
 __device__ __forceinline__ lr_u16x2 lr_as_pk(const uint32_t v) { lr_u16x2 r; __builtin_memcpy(&r, &v, 4); return r; }
 __device__ __forceinline__ lr_u16x2 lr_splat(const int v) { const unsigned short h = (unsigned short)v; return lr_u16x2{h, h}; }
 struct __attribute__((aligned(8))) LrInt4 { int32_t v[4]; };
-struct __attribute__((aligned(4))) LrDw2 { uint32_t lo, hi; };
 // Weighted 3x3 sums of the A / B tables for the output pair (i, j), (i, j + 1), j even (restoration.c:770-800 "fast" r = 2 pass on alternate rows,
 // :850-880 r = 1 pass).  A <= 256 and the weights sum to 32, so the A side runs on packed u16 pairs: per table row the two dwords holding columns
 // j - 1 .. j + 2 give the "left" pair, the "right" pair and (one funnel shift) the "centre" pair of the two outputs.

@@ -25,7 +25,8 @@ constexpr size_t LR_FRAME_A   = (size_t)(LR_UR + 2) * 66 * 2 + 8;
 constexpr size_t LR_FRAME_MID = (size_t)(LR_UR + 6) * 64 * 2;
 constexpr size_t LR_FRAME_AB  = LR_FRAME_A + (size_t)(LR_UR + 2) * 66 * 4;
 constexpr size_t LR_FRAME_SMEM = (size_t)(LR_UR + 6) * TW * 2 + (LR_FRAME_AB > LR_FRAME_MID ? LR_FRAME_AB : LR_FRAME_MID) + 512;
-__global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, const int nsplit) {
+// grid (unit columns, halves of a stripe, stripes); nhu x nvu restoration units, ushift = log2(unit_size) or -1 (the host does the divisions once)
+__global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, const int nhu, const int nvu, const int ushift) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
     uint16_t* tile = smem;
     uint16_t* mid  = tile + (LR_UR + 6) * TW;                  // Wiener only
@@ -37,17 +38,15 @@ __global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, c
     TileSrc s;
     s.data = P.data; s.above = P.boundary_above; s.below = P.boundary_below;
     s.stride = (int)P.stride; s.bstride = (int)P.boundary_stride; s.w = pw; s.h = ph; s.highbd = P.highbd;
-    s.stripe_idx = blockIdx.y / nsplit;
+    s.stripe_idx = blockIdx.z;
     s.stripe_top = s.stripe_idx * sh - off < 0 ? 0 : s.stripe_idx * sh - off;
     s.stripe_bot = (s.stripe_idx + 1) * sh - off > ph ? ph : (s.stripe_idx + 1) * sh - off;
-    s.x0 = blockIdx.x * cw; s.y0 = s.stripe_top + (int)(blockIdx.y % nsplit) * LR_UR;
+    s.x0 = blockIdx.x * cw; s.y0 = s.stripe_top + (int)blockIdx.y * LR_UR;
     s.uw = pw - s.x0 < cw ? pw - s.x0 : cw;
     s.uh = s.stripe_bot - s.y0 < LR_UR ? s.stripe_bot - s.y0 : LR_UR;
     if (s.uh <= 0 || s.uw <= 0) return;
-    const int us  = (int)P.unit_size;
-    int       nvu = (ph + (us >> 1)) / us, nhu = (pw + (us >> 1)) / us;
-    nvu = nvu > 0 ? nvu : 1; nhu = nhu > 0 ? nhu : 1;
-    int ur = (s.y0 + off) / us, uc = s.x0 / us;
+    const int us = (int)P.unit_size;
+    int       ur = ushift >= 0 ? (s.y0 + off) >> ushift : (s.y0 + off) / us, uc = ushift >= 0 ? s.x0 >> ushift : s.x0 / us;
     ur = ur >= nvu ? nvu - 1 : ur; uc = uc >= nhu ? nhu - 1 : uc;
     const SvtHipLrUnit u = P.units[ur * nhu + uc];
     const int highbd = P.highbd, bd = P.bit_depth;
@@ -55,16 +54,20 @@ __global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, c
     const size_t dstride = P.dst_stride;
     const int x0 = s.x0, y0 = s.y0;
     // two horizontally adjacent samples per store instruction (one dword / one halfword when the address allows it): single-sample stores
-    // touched every 64-byte line twice and the write traffic was 5.5 x the plane (profiles/r02_call3_pmc_traffic.json)
+    // touched every 64-byte line twice and the write traffic was 5.5 x the plane (profiles/r02_call3_pmc_traffic.json).  The unit's first output
+    // sample is a wave-uniform address and everything after it a 32-bit byte offset (r < 64, c < 64: fits for any stride the API accepts as int32 / 64),
+    // and whether pair stores are aligned is decided once per workgroup (base and row pitch both multiples of the pair size).
+    const int      pxb = highbd ? 2 : 1;
+    uint8_t* const dst0 = (uint8_t*)dst + ((size_t)y0 * dstride + (size_t)x0) * pxb;
+    const uint32_t dpitch = (uint32_t)dstride * pxb;
+    const bool     pair_ok = !(((uintptr_t)dst0 | dpitch) & (uintptr_t)(2 * pxb - 1));
     auto store = [&](int r, int c, int v0, int v1, bool has1) {
-        const size_t o = (size_t)(y0 + r) * dstride + x0 + c;
+        uint8_t* q = dst0 + ((uint32_t)r * dpitch + (uint32_t)(c * pxb));
         if (highbd) {
-            uint16_t* q = (uint16_t*)dst + o;
-            if (has1 && !((uintptr_t)q & 3)) *(uint32_t*)q = (uint32_t)v0 | ((uint32_t)v1 << 16);
-            else { q[0] = (uint16_t)v0; if (has1) q[1] = (uint16_t)v1; }
+            if (has1 && pair_ok) *(uint32_t*)q = (uint32_t)v0 | ((uint32_t)v1 << 16);
+            else { ((uint16_t*)q)[0] = (uint16_t)v0; if (has1) ((uint16_t*)q)[1] = (uint16_t)v1; }
         } else {
-            uint8_t* q = (uint8_t*)dst + o;
-            if (has1 && !((uintptr_t)q & 1)) *(uint16_t*)q = (uint16_t)(v0 | (v1 << 8));
+            if (has1 && pair_ok) *(uint16_t*)q = (uint16_t)(v0 | (v1 << 8));
             else { q[0] = (uint8_t)v0; if (has1) q[1] = (uint8_t)v1; }
         }
     };
@@ -175,7 +178,11 @@ void svt_hip_lr_filter_frame(const SvtHipLrParams* params, void* stream) {
     const int n_stripes = ((int)P.height + off + sh - 1) / sh;
     const int n_cols    = ((int)P.width + cw - 1) / cw;
     const int nsplit    = (sh + LR_UR - 1) / LR_UR;
-    hipLaunchKernelGGL(lr_frame_kernel, dim3(n_cols, n_stripes * nsplit), dim3(256), LR_FRAME_SMEM, (hipStream_t)stream, P, nsplit);
+    const int us        = (int)P.unit_size;
+    int       nvu = ((int)P.height + (us >> 1)) / us, nhu = ((int)P.width + (us >> 1)) / us, ushift = -1;
+    nvu = nvu > 0 ? nvu : 1; nhu = nhu > 0 ? nhu : 1;
+    if (us > 0 && !(us & (us - 1))) ushift = __builtin_ctz((unsigned)us);
+    hipLaunchKernelGGL(lr_frame_kernel, dim3(n_cols, nsplit, n_stripes), dim3(256), LR_FRAME_SMEM, (hipStream_t)stream, P, nhu, nvu, ushift);
     SVT_LAUNCH_CHECK();
 }
 
