@@ -221,6 +221,7 @@ __device__ __forceinline__ void sgr_ab_pass(const uint16_t* tile, uint16_t* A16,
                 eb2  = lr_dot2(v.d2 & 0x0000ffffu, v.d2, eb2);
             }
         }
+        uint32_t av2[2], bv2[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t sum = r == 2 ? tot - (h ? eb : ea) : tot + (h ? eb : ea);
@@ -228,13 +229,13 @@ __device__ __forceinline__ void sgr_ab_pass(const uint16_t* tile, uint16_t* A16,
             const uint32_t a = rpotu(sq, 2 * (bd - 8)), b = rpotu(sum, bd - 8);
             const uint32_t pp = (a * n < b * b) ? 0 : a * n - b * b;
             const uint32_t z  = rpotu(pp * s, 20);
-            const int      av = xlut[z > 255 ? 255 : z];
-            const int      o  = ii * 66 + jj + h;
-            if (jj + h < 66) {
-                A16[o] = (uint16_t)av; // 1 .. 256
-                B32[o] = (int32_t)rpotu((uint32_t)(256 - av) * sum * obx, 12);
-            }
+            av2[h] = xlut[z > 255 ? 255 : z]; // 1 .. 256
+            bv2[h] = rpotu((256u - av2[h]) * sum * obx, 12);
         }
+        // jj <= 64, so both positions of the pair lie inside the 66-wide tables: one dword / one qword store (ii * 66 + jj is even)
+        const int o = ii * 66 + jj;
+        *(uint32_t*)(A16 + o) = av2[0] | (av2[1] << 16);
+        *(LrDw2A8*)(B32 + o)  = LrDw2A8{bv2[0], bv2[1]};
     }
 }
 typedef unsigned short lr_u16x2 __attribute__((vector_size(4)));

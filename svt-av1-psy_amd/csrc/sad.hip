@@ -477,7 +477,10 @@ __global__ __launch_bounds__(256) void sad_nxm_kernel(const uint8_t* __restrict_
                                                       const SvtHipSadPair* __restrict__ pairs, uint32_t n, int width, int height,
                                                       uint32_t* __restrict__ sad_out) {
     const int      l    = threadIdx.x & 63;
-    const uint32_t pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware order: consecutive pairs are usually neighbouring blocks of one picture row (64-byte rows at a 2 KB pitch: two neighbours share every
+    // 128-byte line, and an unaligned reference row straddles two), so each XCD takes a contiguous run of pair groups and the shared lines hit in ITS L2
+    // instead of being fetched by two XCDs (HBM traffic was 1.59 x the algorithmic bytes, profiles/r02_reg6_pmc_traffic.json)
+    const uint32_t pair = xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     if (pair >= n) return;
     const SvtHipSadPair p   = pairs[pair];
     const uint8_t*      src = src_base + p.src_off;

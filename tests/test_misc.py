@@ -107,7 +107,7 @@ def test_lr_search_statistics(be, oracle, bd):
     S, Hh = (400, 300) if be.is_gpu else (120, 90)
     dgd = g.integers(0, 1 << bd, (Hh, S)).astype(dt)
     src = np.clip(dgd.astype(np.int32) + g.integers(-9, 10, dgd.shape), 0, (1 << bd) - 1).astype(dt)
-    rect_list = [(5, 69, 4, 68), (70, 110, 10, 43), (8, 9 + 33, 40, 40 + 17)] + ([(100, 356, 20, 276)] if be.is_gpu else [])
+    rect_list = [(5, 69, 4, 68), (70, 110, 10, 43), (8, 9 + 33, 40, 40 + 17), (100, 356, 20, 276)] if be.is_gpu else [(5, 41, 4, 30), (70, 110, 10, 27), (8, 9 + 17, 40, 40 + 9)]
     rects = np.array(rect_list, np.int32).view(be.pkg.Rect).reshape(-1)
     for win in ((7, 5) if be.is_gpu else (7,)):
         dd, ds, dr = be.dev(dgd), be.dev(src), be.dev(rects)
@@ -119,7 +119,7 @@ def test_lr_search_statistics(be, oracle, bd):
             M0, H0 = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
             oracle.oracle_compute_stats(win, p(dgd), p(src), hs, he, vs, ve, S, S, p(M0), p(H0), bd)
             assert np.array_equal(gM[i][:win * win], M0[:win * win]) and np.array_equal(gH[i][:win ** 4], H0[:win ** 4]), (bd, win, i)
-    W, H = 48, 30
+    W, H = (48, 30) if be.is_gpu else (24, 14)
     M0, H0, M1, H1 = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64), np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
     oracle.oracle_compute_stats(7, p(dgd), p(src), 6, 6 + W, 5, 5 + H, S, S, p(M0), p(H0), bd)
     if bd == 8:

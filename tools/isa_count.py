@@ -34,7 +34,10 @@ def main():
         elif op.startswith(("global_", "buffer_", "flat_", "scratch_")): cur[1]["mem"] += 1
         elif op.startswith("s_"):
             cur[1]["s"] += 1
-            if "branch" in op: cur[2].append(op.replace("s_", "") + "->" + t.split()[1])
+            if "branch" in op:  # a branch ends the basic block even when the fall-through block carries no label
+                cur[2].append(op.replace("s_", "") + "->" + t.split()[1])
+                blocks.append(cur)
+                cur = [cur[0].rstrip("+") + "+", {"v": 0, "s": 0, "ds": 0, "mem": 0}, []]
     blocks.append(cur)
     tot = {"v": 0, "s": 0, "ds": 0, "mem": 0}
     for b, c, br in blocks:
