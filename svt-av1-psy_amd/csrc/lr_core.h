@@ -59,8 +59,12 @@ struct __attribute__((aligned(16))) LrRow8A16 { uint32_t v[4]; };
 // issued before the first LDS store (one memory round trip per workgroup); only chunks that cross the plane's left / right edge or the unit's last
 // column go pixel by pixel.  NIT * 16 >= rows.  (A wave-uniform row loop -- src_row on the scalar unit, one load per row and wave -- was tried and was
 // twice as slow: 1 365 scalar instructions per wave and serialised loads, profiles/r02_call7_lr_row_uniform_staging.txt.)
+template <int NIT> struct StageRegs { uint32_t v[NIT][4]; };
+// stage_load issues the global loads of a tile into registers (nothing waits on them), stage_commit writes them to LDS (and fetches the few edge
+// chunks pixel by pixel); the frame kernel loads the NEXT half-stripe's tile between the two so that its memory latency hides behind the filter.
 template <int NIT>
-__device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, const int tid) {
+__device__ __forceinline__ void stage_load(StageRegs<NIT>& R, const TileSrc& s, const int tid) {
+    uint32_t (&v)[NIT][4] = R.v;
     const int  rows = s.uh + 6, cols = s.uw + 6;
     const int  c = tid & 15, rb = tid >> 4;
     const int  x = s.x0 - 3 + 8 * c;
@@ -68,7 +72,6 @@ __device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, con
     // columns beyond uw + 6 are multiplied by tap 7 = 0 (Wiener) or never read (self-guided), so they need not be zero.  Before, chunk 8 (6 of 8 pixels
     // needed) took the pixel-by-pixel path in EVERY workgroup: ~180 VALU instructions per wave and a second dependent memory round trip.
     const bool cfast = c < 9 && 8 * c < cols && (s.w == 0 || (x >= 0 && x + 8 <= s.w));
-    uint32_t   v[NIT][4];
     // Rows that are neither substituted (stripe boundary) nor replicated (plane edge) sit at data + y * stride: one 64-bit multiply-add per thread, then
     // a wave-uniform increment per k.  Only the waves that hold one of the <= 6 special rows take the general src_row (40 VALU instructions; before, every
     // wave paid it for every k -- a third of the Wiener kernel's instructions).
@@ -91,6 +94,14 @@ __device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, con
             v[k][2] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c010c00u); v[k][3] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c030c02u);
         }
     }
+}
+template <int NIT>
+__device__ __forceinline__ void stage_commit(uint16_t* tile, StageRegs<NIT>& R, const TileSrc& s, const int tid) {
+    uint32_t (&v)[NIT][4] = R.v;
+    const int  rows = s.uh + 6, cols = s.uw + 6;
+    const int  c = tid & 15, rb = tid >> 4;
+    const int  x = s.x0 - 3 + 8 * c;
+    const bool cfast = c < 9 && 8 * c < cols && (s.w == 0 || (x >= 0 && x + 8 <= s.w));
 #pragma unroll
     for (int k = 0; k < NIT; k++) {
         const int r = rb + 16 * k;
@@ -112,6 +123,12 @@ __device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, con
         }
         *(LrRow8A16*)(tile + r * TW + 8 * c) = LrRow8A16{{v[k][0], v[k][1], v[k][2], v[k][3]}};
     }
+}
+template <int NIT>
+__device__ __forceinline__ void stage_tile(uint16_t* tile, const TileSrc& s, const int tid) {
+    StageRegs<NIT> R;
+    stage_load<NIT>(R, s, tid);
+    stage_commit<NIT>(tile, R, s, tid);
 }
 struct WienerTaps { int16_t fx[8], fy[8]; };
 typedef short lr_s2 __attribute__((ext_vector_type(2)));

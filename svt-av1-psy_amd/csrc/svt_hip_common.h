@@ -10,6 +10,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+// Redefines a 32-bit per-lane value through an empty asm: everything computed from it afterwards is no longer loop invariant for the compiler, which
+// otherwise hoists dozens of per-lane LDS / global addresses out of a short outer loop and doubles the kernel's VGPR count.  (The CPU emulator used by the
+// tests defines it as a no-op first.)
+#ifndef SVT_HIP_OPAQUE_I32
+#define SVT_HIP_OPAQUE_I32(x) asm volatile("" : "+v"(x))
+#endif
+
 #define HIP_CHECK(expr)                                                                                         \
     do {                                                                                                        \
         hipError_t e_ = (expr);                                                                                 \

@@ -101,6 +101,35 @@ def test_nxm_sad_batch_frame(be, oracle):
         assert got[i] == want, i
 
 
+@pytest.mark.parametrize("wh", [(16, 8), (64, 64), (32, 32)])
+def test_sad_nxm_batch_many_pairs_pipelined(be, oracle, wh):
+    """>= 1024 pairs of at most 256 16-byte chunks take the pipelined kernel (a wave walks four pairs, loads of the next pair in flight while it reduces):
+    ragged pair count (not a multiple of the 16 pairs a workgroup walks), unaligned reference offsets, every pair checked."""
+    w, h = wh
+    if not be.is_gpu and w * h > 1024:
+        pytest.skip("emulator: the 16x8 case covers the pipelined path")
+    g = rng(400 + w)
+    n = 1024 + 37
+    cols = 48
+    stride = cols * w + 40
+    rows = ((n + cols - 1) // cols) * h + 8
+    a = g.integers(0, 256, (rows, stride), dtype=np.uint8)
+    b = (a.astype(np.int16) + g.integers(-20, 21, a.shape)).clip(0, 255).astype(np.uint8)
+    pairs = np.zeros(n, dtype=be.pkg.SadPair)
+    for i in range(n):
+        o = (i // cols) * h * stride + (i % cols) * w
+        pairs[i] = (o, o + (i % 5) + (i % 3) * stride, stride, stride)
+    da, db, dp = be.dev(a), be.dev(b), be.dev(pairs)
+    out = be.empty(n, np.uint32)
+    be.lib.svt_hip_sad_nxm_batch(be.ptr(da), be.ptr(db), be.ptr(dp), n, w, h, be.ptr(out), be.stream)
+    got = be.host(out)
+    A, B = a.astype(np.int32), b.astype(np.int32)
+    for i in range(n):
+        y, x = (i // cols) * h, (i % cols) * w
+        dy, dx = i % 3, i % 5
+        assert got[i] == np.abs(A[y:y + h, x:x + w] - B[y + dy:y + dy + h, x + dx:x + dx + w]).sum(), i
+
+
 LOOP_AREAS = [(8, 15), (16, 31), (12, 31), (64, 25), (15, 6), (32, 12), (96, 24), (70, 40)]  # SadTest.cc:433-444 subset
 
 
