@@ -25,90 +25,71 @@ constexpr size_t LR_FRAME_A   = (size_t)(LR_UR + 2) * 66 * 2 + 8;
 constexpr size_t LR_FRAME_MID = (size_t)(LR_UR + 6) * 64 * 2;
 constexpr size_t LR_FRAME_AB  = LR_FRAME_A + (size_t)(LR_UR + 2) * 66 * 4;
 constexpr size_t LR_FRAME_SMEM = (size_t)(LR_UR + 6) * TW * 2 + (LR_FRAME_AB > LR_FRAME_MID ? LR_FRAME_AB : LR_FRAME_MID) + 512;
-// grid (unit columns, stripe halves / nwalk, stripes); nhu x nvu restoration units, ushift = log2(unit_size) or -1 (the host does the divisions once).
-// A workgroup walks `nwalk` consecutive halves of its stripe: the global loads of the next half's tile are issued into registers before the current half is
-// filtered, so only the first half's memory round trip is exposed (every workgroup of a 4K plane is resident at once -- 8 per CU -- and they all start by
-// waiting on memory; with one half per workgroup that wait was paid twice per CU, back to back).
-__global__ __launch_bounds__(256, 8) void lr_frame_kernel(const SvtHipLrParams P, const int nhu, const int nvu, const int ushift, const int nwalk) {
+// grid (unit columns, halves of a stripe, stripes); nhu x nvu restoration units, ushift = log2(unit_size) or -1 (the host does the divisions once)
+__global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, const int nhu, const int nvu, const int ushift) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
     uint16_t* tile = smem;
     uint16_t* mid  = tile + (LR_UR + 6) * TW;                  // Wiener only
     uint16_t* A16  = mid;                                      // self-guided only (aliases mid)
     int32_t*  B32  = (int32_t*)((uint8_t*)mid + LR_FRAME_A);
     uint16_t* xlut = (uint16_t*)((uint8_t*)mid + (LR_FRAME_AB > LR_FRAME_MID ? LR_FRAME_AB : LR_FRAME_MID));
-    int       tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int pw = (int)P.width, ph = (int)P.height, off = 8 >> P.ss_y, sh = 64 >> P.ss_y, cw = 64 >> P.ss_x;
-    constexpr int NIT = (LR_UR + 6 + 15) / 16;
     TileSrc s;
     s.data = P.data; s.above = P.boundary_above; s.below = P.boundary_below;
     s.stride = (int)P.stride; s.bstride = (int)P.boundary_stride; s.w = pw; s.h = ph; s.highbd = P.highbd;
     s.stripe_idx = blockIdx.z;
     s.stripe_top = s.stripe_idx * sh - off < 0 ? 0 : s.stripe_idx * sh - off;
     s.stripe_bot = (s.stripe_idx + 1) * sh - off > ph ? ph : (s.stripe_idx + 1) * sh - off;
-    s.x0 = blockIdx.x * cw;
+    s.x0 = blockIdx.x * cw; s.y0 = s.stripe_top + (int)blockIdx.y * LR_UR;
     s.uw = pw - s.x0 < cw ? pw - s.x0 : cw;
-    const int half0 = (int)blockIdx.y * nwalk;
-    s.y0 = s.stripe_top + half0 * LR_UR;
     s.uh = s.stripe_bot - s.y0 < LR_UR ? s.stripe_bot - s.y0 : LR_UR;
     if (s.uh <= 0 || s.uw <= 0) return;
-    const int us = (int)P.unit_size, highbd = P.highbd, bd = P.bit_depth, x0 = s.x0;
+    const int us = (int)P.unit_size;
+    int       ur = ushift >= 0 ? (s.y0 + off) >> ushift : (s.y0 + off) / us, uc = ushift >= 0 ? s.x0 >> ushift : s.x0 / us;
+    ur = ur >= nvu ? nvu - 1 : ur; uc = uc >= nhu ? nhu - 1 : uc;
+    const SvtHipLrUnit u = P.units[ur * nhu + uc];
+    const int highbd = P.highbd, bd = P.bit_depth;
     void* dst = P.dst;
     const size_t dstride = P.dst_stride;
+    const int x0 = s.x0, y0 = s.y0;
+    // two horizontally adjacent samples per store instruction (one dword / one halfword when the address allows it): single-sample stores
+    // touched every 64-byte line twice and the write traffic was 5.5 x the plane (profiles/r02_call3_pmc_traffic.json).  The unit's first output
+    // sample is a wave-uniform address and everything after it a 32-bit byte offset (r < 64, c < 64: fits for any stride the API accepts as int32 / 64),
+    // and whether pair stores are aligned is decided once per workgroup (base and row pitch both multiples of the pair size).
     const int      pxb = highbd ? 2 : 1;
+    uint8_t* const dst0 = (uint8_t*)dst + ((size_t)y0 * dstride + (size_t)x0) * pxb;
     const uint32_t dpitch = (uint32_t)dstride * pxb;
-    StageRegs<NIT> R;
-    stage_load<NIT>(R, s, tid);
-    for (int half = half0;; half++) {
-        SVT_HIP_OPAQUE_I32(tid); // keep the per-lane addresses of the body inside the loop (123 -> 64 VGPRs: 8 workgroups per CU)
-        stage_commit<NIT>(tile, R, s, tid);
-        __syncthreads();
-        const int y0 = s.y0, uw = s.uw, uh = s.uh;
-        bool more = false;
-        if (half + 1 < half0 + nwalk) { // the next half of the stripe: its loads fly while this one is filtered
-            s.y0 = y0 + LR_UR;
-            s.uh = s.stripe_bot - s.y0 < LR_UR ? s.stripe_bot - s.y0 : LR_UR;
-            more = s.uh > 0;
-            if (more) stage_load<NIT>(R, s, tid);
-        }
-        int ur = ushift >= 0 ? (y0 + off) >> ushift : (y0 + off) / us, uc = ushift >= 0 ? x0 >> ushift : x0 / us;
-        ur = ur >= nvu ? nvu - 1 : ur; uc = uc >= nhu ? nhu - 1 : uc;
-        const SvtHipLrUnit u = P.units[ur * nhu + uc];
-        // two horizontally adjacent samples per store instruction (one dword / one halfword when the address allows it): single-sample stores
-        // touched every 64-byte line twice and the write traffic was 5.5 x the plane (profiles/r02_call3_pmc_traffic.json).  The unit's first output
-        // sample is a wave-uniform address and everything after it a 32-bit byte offset (r < 64, c < 64: fits for any stride the API accepts as int32 / 64),
-        // and whether pair stores are aligned is decided once per workgroup (base and row pitch both multiples of the pair size).
-        uint8_t* const dst0 = (uint8_t*)dst + ((size_t)y0 * dstride + (size_t)x0) * pxb;
-        const bool     pair_ok = !(((uintptr_t)dst0 | dpitch) & (uintptr_t)(2 * pxb - 1));
-        auto store = [&](int r, int c, int v0, int v1, bool has1) {
-            uint8_t* q = dst0 + ((uint32_t)r * dpitch + (uint32_t)(c * pxb));
-            if (highbd) {
-                if (has1 && pair_ok) *(uint32_t*)q = (uint32_t)v0 | ((uint32_t)v1 << 16);
-                else { ((uint16_t*)q)[0] = (uint16_t)v0; if (has1) ((uint16_t*)q)[1] = (uint16_t)v1; }
-            } else {
-                if (has1 && pair_ok) *(uint16_t*)q = (uint16_t)(v0 | (v1 << 8));
-                else { q[0] = (uint8_t)v0; if (has1) q[1] = (uint8_t)v1; }
-            }
-        };
-        if (u.rtype == 1) {
-            WienerTaps t;
-#pragma unroll
-            for (int k = 0; k < 8; k++) { t.fx[k] = u.hfilter[k]; t.fy[k] = u.vfilter[k]; }
-            wiener_tile(tile, mid, t, uw, uh, bd, tid, store);
-        } else if (u.rtype == 2) {
-            const int idx = u.ep & 15;
-            sgr_tile(tile, A16, B32, xlut, idx, uw, uh, bd, tid, [](int, int, int32_t) {},
-                     [&](int r, int c, int32_t f0a, int32_t f1a, int32_t f0b, int32_t f1b, bool has1) {
-                         store(r, c, sgr_combine(tile[(r + 3) * TW + c + 3], f0a, f1a, idx, u.xqd[0], u.xqd[1], bd),
-                               sgr_combine(tile[(r + 3) * TW + c + 4], f0b, f1b, idx, u.xqd[0], u.xqd[1], bd), has1);
-                     });
+    const bool     pair_ok = !(((uintptr_t)dst0 | dpitch) & (uintptr_t)(2 * pxb - 1));
+    auto store = [&](int r, int c, int v0, int v1, bool has1) {
+        uint8_t* q = dst0 + ((uint32_t)r * dpitch + (uint32_t)(c * pxb));
+        if (highbd) {
+            if (has1 && pair_ok) *(uint32_t*)q = (uint32_t)v0 | ((uint32_t)v1 << 16);
+            else { ((uint16_t*)q)[0] = (uint16_t)v0; if (has1) ((uint16_t*)q)[1] = (uint16_t)v1; }
         } else {
-            for (int i = tid; i < uh * 32; i += 256) {
-                const int r = i >> 5, c = (i & 31) * 2;
-                if (c < uw) store(r, c, tile[(r + 3) * TW + c + 3], tile[(r + 3) * TW + c + 4], c + 1 < uw);
-            }
+            if (has1 && pair_ok) *(uint16_t*)q = (uint16_t)(v0 | (v1 << 8));
+            else { q[0] = (uint8_t)v0; if (has1) q[1] = (uint8_t)v1; }
         }
-        if (!more) break;
-        __syncthreads(); // every wave is done with the tile and the tables before the next half overwrites them
+    };
+    stage_tile<(LR_UR + 6 + 15) / 16>(tile, s, tid);
+    __syncthreads();
+    if (u.rtype == 1) {
+        WienerTaps t;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { t.fx[k] = u.hfilter[k]; t.fy[k] = u.vfilter[k]; }
+        wiener_tile(tile, mid, t, s.uw, s.uh, bd, tid, store);
+    } else if (u.rtype == 2) {
+        const int idx = u.ep & 15;
+        sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, bd, tid, [](int, int, int32_t) {},
+                 [&](int r, int c, int32_t f0a, int32_t f1a, int32_t f0b, int32_t f1b, bool has1) {
+                     store(r, c, sgr_combine(tile[(r + 3) * TW + c + 3], f0a, f1a, idx, u.xqd[0], u.xqd[1], bd),
+                           sgr_combine(tile[(r + 3) * TW + c + 4], f0b, f1b, idx, u.xqd[0], u.xqd[1], bd), has1);
+                 });
+    } else {
+        for (int i = tid; i < s.uh * 32; i += 256) {
+            const int r = i >> 5, c = (i & 31) * 2;
+            if (c < s.uw) store(r, c, tile[(r + 3) * TW + c + 3], tile[(r + 3) * TW + c + 4], c + 1 < s.uw);
+        }
     }
 }
 
@@ -201,9 +182,7 @@ void svt_hip_lr_filter_frame(const SvtHipLrParams* params, void* stream) {
     int       nvu = ((int)P.height + (us >> 1)) / us, nhu = ((int)P.width + (us >> 1)) / us, ushift = -1;
     nvu = nvu > 0 ? nvu : 1; nhu = nhu > 0 ? nhu : 1;
     if (us > 0 && !(us & (us - 1))) ushift = __builtin_ctz((unsigned)us);
-    static const int walk = [] { const char* e = getenv("SVT_HIP_LR_WALK"); return e ? atoi(e) : 1; }(); // 0: one workgroup per stripe half (the round-1 form)
-    const int nwalk = walk ? nsplit : 1;
-    hipLaunchKernelGGL(lr_frame_kernel, dim3(n_cols, nsplit / nwalk, n_stripes), dim3(256), LR_FRAME_SMEM, (hipStream_t)stream, P, nhu, nvu, ushift, nwalk);
+    hipLaunchKernelGGL(lr_frame_kernel, dim3(n_cols, nsplit, n_stripes), dim3(256), LR_FRAME_SMEM, (hipStream_t)stream, P, nhu, nvu, ushift);
     SVT_LAUNCH_CHECK();
 }
 
