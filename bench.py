@@ -348,7 +348,7 @@ def bench_sad_pairs(torch, lib, pkg, stream, a, cpu):
     _, dv = time_steps(torch, fn, a.steps, a.warmup)
     per = dv / a.steps
     out = {"value": len(pairs) / per / 1e6, "unit": "Mblocks/s (64x64 pairs)", "footprint_MB": 2 * n_src * PLANE / 1e6, "parity_checked_values": checked,
-           "roofline": roofline(len(pairs) * 8192, per, "sad_nxm_kernel", algorithmic_bytes_per_block=8192,
+           "roofline": roofline(len(pairs) * 8192, per, "sad_nxm_pipe_kernel", algorithmic_bytes_per_block=8192,
                                 note="disjoint src / ref plane sets, each byte read once per launch; footprint 1.2 GB")}
     if cpu:
         ref, oracle = ref_libs()
