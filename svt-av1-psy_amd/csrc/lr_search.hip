@@ -332,7 +332,13 @@ __global__ void lr_wiener_step_kernel(const SvtHipLrSearchParams P, WnState* __r
     wn[u] = st;
 }
 
+__host__ __device__ inline size_t lrs_dq_dwords(const int w, const int h) { return (((size_t)w * h + 1) / 2 + 63) & ~(size_t)63; } // the int16 plane, in dwords
 // ---- self-guided: flt0 / flt1 of the whole plane for one parameter set per blockIdx.z ----------------------------------------------------------------
+// COMPACT (bit depth <= 10): what the projection search needs of a sample is q1 = flt0 - (dgd << 4), q2 = flt1 - (dgd << 4) and dgd - src, and at <= 10 bits
+// all three fit int16 (flt <= 32 (256 * 1.003 pmax + .5) / 512 < 16.05 pmax + 1 = 16 420 for pmax = 1023, so |q| < 2^15).  The plane-sized buffers then hold
+// one packed dword per sample and parameter set plus one int16 per sample shared by all sets -- 4 + 2 bytes instead of 4 + 4 + 2 + 2 per sample and pass of
+// lr_sgr_proj_kernel, which re-reads its unit about nine times per parameter set (14 GB per 4K plane before, profiles/r02_reg7_pmc_traffic.json).
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchParams P, int32_t* __restrict__ flt) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
     uint16_t* tile = smem;
@@ -345,16 +351,34 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
     s.stripe_idx = 0; s.stripe_top = 0; s.stripe_bot = 0;
     s.x0 = blockIdx.x * 64; s.y0 = blockIdx.y * 64;
     s.uw = w - s.x0 < 64 ? w - s.x0 : 64; s.uh = h - s.y0 < 64 ? h - s.y0 : 64;
-    int32_t* f0 = flt + (size_t)slot * 2 * w * h;
-    int32_t* f1 = f0 + (size_t)w * h;
     const int x0 = s.x0, y0 = s.y0;
     const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
     stage_tile<(TH + 15) / 16>(tile, s, tid);
     __syncthreads();
-    sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, P.bit_depth, tid, [&](int r, int c, int32_t v) { if (p0) f0[(size_t)(y0 + r) * w + x0 + c] = v; },
-             [&](int r, int c, int32_t, int32_t b0, int32_t, int32_t b1, bool has1) {
-                 if (p1) { f1[(size_t)(y0 + r) * w + x0 + c] = b0; if (has1) f1[(size_t)(y0 + r) * w + x0 + c + 1] = b1; }
-             });
+    if (COMPACT) {
+        int16_t*  dq = (int16_t*)flt;                                                        // [h][w]: dgd - src
+        uint32_t* q  = (uint32_t*)flt + lrs_dq_dwords(w, h) + (size_t)slot * w * h;          // [h][w]: q1 | q2 << 16
+        const int highbd = P.highbd;
+        sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, P.bit_depth, tid, [](int, int, int32_t) {},
+                 [&](int r, int c, int32_t f0a, int32_t f1a, int32_t f0b, int32_t f1b, bool has1) {
+                     const size_t o = (size_t)(y0 + r) * w + x0 + c;
+                     const int    da = tile[(r + 3) * TW + c + 3], db = tile[(r + 3) * TW + c + 4];
+                     q[o] = (uint32_t)((p0 ? f0a - (da << 4) : 0) & 0xffff) | ((uint32_t)(p1 ? f1a - (da << 4) : 0) << 16);
+                     if (has1) q[o + 1] = (uint32_t)((p0 ? f0b - (db << 4) : 0) & 0xffff) | ((uint32_t)(p1 ? f1b - (db << 4) : 0) << 16);
+                     if (slot == 0) {
+                         const size_t so = (size_t)(y0 + r) * P.src_stride + x0 + c;
+                         dq[o] = (int16_t)(da - rd_px(P.src, highbd, so));
+                         if (has1) dq[o + 1] = (int16_t)(db - rd_px(P.src, highbd, so + 1));
+                     }
+                 });
+    } else {
+        int32_t* f0 = flt + (size_t)slot * 2 * w * h;
+        int32_t* f1 = f0 + (size_t)w * h;
+        sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, P.bit_depth, tid, [&](int r, int c, int32_t v) { if (p0) f0[(size_t)(y0 + r) * w + x0 + c] = v; },
+                 [&](int r, int c, int32_t, int32_t b0, int32_t, int32_t b1, bool has1) {
+                     if (p1) { f1[(size_t)(y0 + r) * w + x0 + c] = b0; if (has1) f1[(size_t)(y0 + r) * w + x0 + c + 1] = b1; }
+                 });
+    }
 }
 
 // ---- self-guided: projection + refinement of one (unit, parameter set) per workgroup (search_selfguided_restoration's loop body, :582-630) ------------
@@ -374,9 +398,11 @@ __device__ __forceinline__ long long block_sum_i64(long long v, long long* part,
     return t;
 }
 // the samples of a unit in raster order, PROJ_T apart, four in flight per thread (all loads of a group issued before the first use); (x, y) advance
-// incrementally -- no division per sample
-template <typename F> __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, const SvtHipRect& r, const int32_t* f0, const int32_t* f1,
-                                                                         const int r0, const int r1, const int tid, F body) {
+// incrementally -- no division per sample.  body(uu, spx, a0, a1): uu = dgd << 4, spx = src, a0 = flt0 - uu, a1 = flt1 - uu (0 for a pass that is off).  The
+// compact buffers deliver the same projection with uu = 0 and spx = src - dgd: ((dgd << 11) + y + 1024 >> 11) - src = (y + 1024 >> 11) - (src - dgd) exactly.
+template <bool COMPACT, typename F>
+__device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, const SvtHipRect& r, const int32_t* f0, const int32_t* f1, const int r0, const int r1,
+                                                 const int tid, F body) {
     const int uw = r.h_end - r.h_start, uh = r.v_end - r.v_start, npx = uw * uh, w = (int)P.width, highbd = P.highbd;
     const int qy = PROJ_T / uw, rx = PROJ_T - qy * uw;
     int       y = tid / uw, x = tid - y * uw;
@@ -388,10 +414,16 @@ template <typename F> __device__ __forceinline__ void for_unit_samples(const Svt
             ok[k] = i + k * PROJ_T < npx;
             const int    yy = ok[k] ? y : 0, xx = ok[k] ? x : 0;
             const size_t fo = (size_t)(r.v_start + yy) * w + r.h_start + xx;
-            d[k]  = rd_px(P.dgd, highbd, (size_t)(r.v_start + yy) * P.dgd_stride + r.h_start + xx);
-            sp[k] = rd_px(P.src, highbd, (size_t)(r.v_start + yy) * P.src_stride + r.h_start + xx);
-            g0[k] = r0 > 0 ? f0[fo] : 0;
-            g1[k] = r1 > 0 ? f1[fo] : 0;
+            if (COMPACT) {
+                const uint32_t pk = ((const uint32_t*)f1)[fo];
+                d[k] = 0; sp[k] = -(int)((const int16_t*)f0)[fo];
+                g0[k] = (int)(int16_t)(pk & 0xffffu); g1[k] = (int)pk >> 16;
+            } else {
+                d[k]  = rd_px(P.dgd, highbd, (size_t)(r.v_start + yy) * P.dgd_stride + r.h_start + xx) << 4;
+                sp[k] = rd_px(P.src, highbd, (size_t)(r.v_start + yy) * P.src_stride + r.h_start + xx);
+                g0[k] = r0 > 0 ? f0[fo] - d[k] : 0;
+                g1[k] = r1 > 0 ? f1[fo] - d[k] : 0;
+            }
             x += rx; y += qy;
             if (x >= uw) { x -= uw; y++; }
         }
@@ -400,6 +432,7 @@ template <typename F> __device__ __forceinline__ void for_unit_samples(const Svt
             if (ok[k]) body(d[k], sp[k], g0[k], g1[k]);
     }
 }
+template <bool COMPACT>
 __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const int32_t* __restrict__ flt,
                                                              SgResult* __restrict__ res, const int slots) {
     __shared__ long long part[PROJ_T / 64];
@@ -407,14 +440,14 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
     const int        u = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x, idx = P.sg_start_ep + slot * P.sg_ep_inc, w = (int)P.width, h = (int)P.height;
     const SvtHipRect r = rects[u];
     const int        npx = (r.h_end - r.h_start) * (r.v_end - r.v_start);
-    const int32_t*   f0 = flt + (size_t)slot * 2 * w * h;
-    const int32_t*   f1 = f0 + (size_t)w * h;
+    // compact: f0 = the shared int16 plane (dgd - src), f1 = this parameter set's packed (q1, q2) plane
+    const int32_t*   f0 = COMPACT ? flt : flt + (size_t)slot * 2 * w * h;
+    const int32_t*   f1 = COMPACT ? flt + lrs_dq_dwords(w, h) + (size_t)slot * w * h : f0 + (size_t)w * h;
     const int        r0 = kSgrR[idx][0], r1 = kSgrR[idx][1];
     // svt_get_proj_subspace (:413-498): the integer sums equal the reference's double sums exactly (every partial sum < 2^53)
     long long a[5] = {0, 0, 0, 0, 0};
-    for_unit_samples(P, r, f0, f1, r0, r1, tid, [&](const int d, const int sp, const int g0, const int g1) {
-        const int       uu = d << 4;
-        const long long sd = (long long)(sp << 4) - uu, q1 = r0 > 0 ? (long long)g0 - uu : 0, q2 = r1 > 0 ? (long long)g1 - uu : 0;
+    for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
+        const long long sd = (long long)sp * 16 - uu, q1 = a0, q2 = a1;
         a[0] += q1 * q1; a[1] += q2 * q2; a[2] += q1 * q2; a[3] += q1 * sd; a[4] += q2 * sd;
     });
     long long t[5];
@@ -449,11 +482,8 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
         else if (r1 == 0) { xq0 = xqd[0]; xq1 = 0; }
         else { xq0 = xqd[0]; xq1 = 128 - xq0 - xqd[1]; }
         long long e2 = 0;
-        for_unit_samples(P, r, f0, f1, r0, r1, tid, [&](const int d, const int sp, const int g0, const int g1) {
-            const int uu = d << 4;
-            int       v = uu << 7;
-            if (r0 > 0) v += xq0 * (g0 - uu);
-            if (r1 > 0) v += xq1 * (g1 - uu);
+        for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
+            const int v = (uu << 7) + xq0 * a0 + xq1 * a1;
             const int e = ((v + (1 << 10)) >> 11) - sp;
             e2 += (long long)e * e;
         });
@@ -475,8 +505,7 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
         long long ad[PROJ_K], au[PROJ_K];
 #pragma unroll
         for (int k = 0; k < PROJ_K; k++) ad[k] = au[k] = 0;
-        for_unit_samples(P, r, f0, f1, r0, r1, tid, [&](const int d, const int sp, const int g0, const int g1) {
-            const int uu = d << 4, a0 = r0 > 0 ? g0 - uu : 0, a1 = r1 > 0 ? g1 - uu : 0;
+        for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
             const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10), dv = st * (c0 * a0 + c1 * a1);
 #pragma unroll
             for (int k = 0; k < PROJ_K; k++) {
@@ -615,8 +644,14 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
         SVT_LAUNCH_CHECK();
     }
     if (P.sg_enabled && slots > 0) {
-        hipLaunchKernelGGL(lr_sgr_flt_kernel, dim3(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, slots), dim3(256), LRS_SMEM, st, P, W.flt);
-        hipLaunchKernelGGL(lr_sgr_proj_kernel, dim3(n, slots), dim3(PROJ_T), 0, st, P, W.rects, W.flt, W.sg, slots);
+        const dim3 fgrid(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, slots);
+        if (P.bit_depth <= 10) { // int16 differences (see lr_sgr_flt_kernel); 12-bit keeps the int32 planes
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, st, P, W.flt);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, slots), dim3(PROJ_T), 0, st, P, W.rects, W.flt, W.sg, slots);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, st, P, W.flt);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, slots), dim3(PROJ_T), 0, st, P, W.rects, W.flt, W.sg, slots);
+        }
         hipLaunchKernelGGL(lr_sgr_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.sg, units, slots, n);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<2>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
         hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, st, W.acc, units, 2, n);
