@@ -397,6 +397,8 @@ __device__ __forceinline__ long long block_sum_i64(long long v, long long* part,
     for (int k = 0; k < PROJ_T / 64; k++) t += part[k];
     return t;
 }
+struct __attribute__((aligned(16))) LrsQuad { uint32_t v[4]; };
+struct __attribute__((aligned(8))) LrsPair { uint32_t v[2]; };
 // the samples of a unit in raster order, PROJ_T apart, four in flight per thread (all loads of a group issued before the first use); (x, y) advance
 // incrementally -- no division per sample.  body(uu, spx, a0, a1): uu = dgd << 4, spx = src, a0 = flt0 - uu, a1 = flt1 - uu (0 for a pass that is off).  The
 // compact buffers deliver the same projection with uu = 0 and spx = src - dgd: ((dgd << 11) + y + 1024 >> 11) - src = (y + 1024 >> 11) - (src - dgd) exactly.
@@ -404,6 +406,34 @@ template <bool COMPACT, typename F>
 __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, const SvtHipRect& r, const int32_t* f0, const int32_t* f1, const int r0, const int r1,
                                                  const int tid, F body) {
     const int uw = r.h_end - r.h_start, uh = r.v_end - r.v_start, npx = uw * uh, w = (int)P.width, highbd = P.highbd;
+    if (COMPACT && !((w | uw | r.h_start) & 3)) { // four consecutive samples per load pair: one b128 of packed (q1, q2) + one b64 of dgd - src
+        const int qpr = uw >> 2, nq = qpr * uh, qy = PROJ_T / qpr, rx = PROJ_T - qy * qpr;
+        int       y = tid / qpr, x = tid - y * qpr;
+        for (int i = tid; i < nq; i += 4 * PROJ_T) {
+            LrsQuad Q[4];
+            LrsPair D[4];
+            bool    ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ok[k] = i + k * PROJ_T < nq;
+                const size_t fo = (size_t)(r.v_start + (ok[k] ? y : 0)) * w + r.h_start + 4 * (ok[k] ? x : 0);
+                Q[k] = *(const LrsQuad*)((const uint32_t*)f1 + fo);
+                D[k] = *(const LrsPair*)((const int16_t*)f0 + fo);
+                x += rx; y += qy;
+                if (x >= qpr) { x -= qpr; y++; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (ok[k]) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t pk = Q[k].v[j], dw = D[k].v[j >> 1];
+                        body(0, -(int)(int16_t)((j & 1) ? dw >> 16 : dw & 0xffffu), (int)(int16_t)(pk & 0xffffu), (int)pk >> 16);
+                    }
+                }
+        }
+        return;
+    }
     const int qy = PROJ_T / uw, rx = PROJ_T - qy * uw;
     int       y = tid / uw, x = tid - y * uw;
     for (int i = tid; i < npx; i += 4 * PROJ_T) {
