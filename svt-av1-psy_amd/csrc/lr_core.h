@@ -311,7 +311,7 @@ __device__ __forceinline__ void sgr_tile(const uint16_t* tile, uint16_t* A16, in
     const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
     xlut[tid] = (uint16_t)x_by_xplus1((uint32_t)tid); // 256 threads, 256 entries
     __syncthreads();
-    int32_t f0[16]; // eight output pairs per thread: pair p = tid + 256 k <-> row p >> 5, columns 2 (p & 31), + 1
+    int32_t f0[16]; // eight output pairs per thread: k <-> row 8 k + 4 ((tid >> 5) & 1) + (tid >> 6), columns 2 (tid & 31), + 1
 #pragma unroll
     for (int k = 0; k < 16; k++) f0[k] = 0;
     if (p0) {
@@ -319,7 +319,8 @@ __device__ __forceinline__ void sgr_tile(const uint16_t* tile, uint16_t* A16, in
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int i = tid + 256 * k, r = i >> 5, c = (i & 31) * 2;
+            const int r = 8 * k + ((tid >> 5) & 1) * 4 + (tid >> 6), c = (tid & 31) * 2; // a wave holds rows r and r + 4: same parity, so the
+                                                                                         // even-row / odd-row forms of the r = 2 pass do not diverge inside it
             if (r < uh && c < uw) {
                 int32_t f[2];
                 sgr_flt_pair(tile, A16, B32, 0, r, c, f);
@@ -334,7 +335,7 @@ __device__ __forceinline__ void sgr_tile(const uint16_t* tile, uint16_t* A16, in
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const int i = tid + 256 * k, r = i >> 5, c = (i & 31) * 2;
+        const int r = 8 * k + ((tid >> 5) & 1) * 4 + (tid >> 6), c = (tid & 31) * 2; // (the same pixel pair as above: f0[] stays in registers)
         if (r < uh && c < uw) {
             int32_t f[2] = {0, 0};
             if (p1) sgr_flt_pair(tile, A16, B32, 1, r, c, f);
