@@ -18,8 +18,15 @@ __device__ constexpr int16_t kSgrR[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2,
 __device__ constexpr int16_t kSgrS[16][2] = {{140, 3236}, {112, 2158}, {93, 1618}, {80, 1438}, {70, 1295}, {58, 1177}, {47, 1079}, {37, 996},
                                              {30, 925},   {25, 863},   {-1, 2589}, {-1, 1618}, {-1, 1177}, {-1, 925},  {56, -1},   {22, -1}};
 // svt_aom_eb_x_by_xplus1 = round(256 z / (z + 1)), [0] = 1, [255] = 256; svt_aom_eb_one_by_x = round(4096 / n) (restoration.c:647-667)
-__device__ __forceinline__ int x_by_xplus1(const uint32_t z) { return z == 0 ? 1 : (z >= 255 ? 256 : (int)((256 * z + (z + 1) / 2) / (z + 1))); }
 __device__ __forceinline__ uint32_t one_by_x(const uint32_t n) { return (4096 + n / 2) / n; }
+// the 256 entries as a compile-time table (every workgroup copies it into LDS: one 2-byte load per thread instead of an integer division)
+struct XByXplus1 { uint16_t v[256]; };
+constexpr XByXplus1 make_x_by_xplus1() {
+    XByXplus1 t{};
+    for (uint32_t z = 0; z < 256; z++) t.v[z] = (uint16_t)(z == 0 ? 1 : (z >= 255 ? 256 : (256 * z + (z + 1) / 2) / (z + 1)));
+    return t;
+}
+__device__ constexpr XByXplus1 kXByXplus1 = make_x_by_xplus1();
 
 struct TileSrc { // where a processing unit's pixels come from
     const void* data; const void* above; const void* below;
@@ -309,7 +316,7 @@ template <typename OUT0, typename OUT1>
 __device__ __forceinline__ void sgr_tile(const uint16_t* tile, uint16_t* A16, int32_t* B32, uint16_t* xlut, const int idx, const int uw, const int uh,
                                          const int bd, const int tid, OUT0 out_flt0, OUT1 out_flt1_or_apply) {
     const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
-    xlut[tid] = (uint16_t)x_by_xplus1((uint32_t)tid); // 256 threads, 256 entries
+    xlut[tid] = kXByXplus1.v[tid]; // 256 threads, 256 entries
     __syncthreads();
     int32_t f0[16]; // eight output pairs per thread: k <-> row 8 k + 4 ((tid >> 5) & 1) + (tid >> 6), columns 2 (tid & 31), + 1
 #pragma unroll
