@@ -87,7 +87,7 @@ def test_lr_host_forms(be, oracle, bd):
     """svt_hip_lr_search_plane_host == oracle_lr_search_plane; svt_hip_lr_filter_frame_host == oracle_lr_filter_frame (in place, with the saved boundary lines)"""
     pkg = be.pkg
     g = rng(820 + bd)
-    w, h, unit = (300, 200, 64) if be.is_gpu else (100, 56, 64)  # (a 64-column processing unit never spans two restoration units: unit >= 64 >> ss_x)
+    w, h, unit = (300, 200, 64) if be.is_gpu else (96, 40, 64)  # (a 64-column processing unit never spans two restoration units: unit >= 64 >> ss_x)
     src, dgd, pad = make_planes(g, w, h, bd)
     P = search_params(src, dgd, pad, w, h, bd, unit, 0, (1, 7, 1, 0), (1, 2, 12, 3, 1) if be.is_gpu else (1, 2, 9, 4, 1))
     n = oracle.oracle_lr_unit_rect(C.byref(P), -1, None)

@@ -167,10 +167,10 @@ def random_prev(g, n, win):
 
 
 # small planes (the lock-step emulator runs every trial of every unit): (width, height, bit depth, unit, ss_y, wiener, self-guided, previous-frame taps)
-DEV_CASES = [(64, 48, 8, 32, 0, (1, 7, 1, 0), (1, 0, 16, 6, 1), False),
+DEV_CASES = [(48, 40, 8, 32, 0, (1, 7, 1, 0), (1, 0, 16, 6, 1), False),
              (72, 40, 10, 64, 0, (1, 5, 1, 0), (1, 12, 16, 1, 1), True),
              (60, 50, 8, 32, 1, (1, 3, 1, 1), (1, 3, 4, 1, 0), False),
-             (70, 50, 10, 64, 0, (1, 7, 1, 0), (0, 0, 0, 1, 0), False),   # one unit (plane smaller than 3/2 unit), Wiener only
+             (44, 36, 10, 64, 0, (1, 7, 1, 0), (0, 0, 0, 1, 0), False),   # one unit (plane smaller than 3/2 unit), Wiener only
              (50, 40, 8, 64, 0, (0, 7, 0, 0), (1, 9, 10, 1, 1), False),   # one unit, self-guided only, a single parameter set
              (48, 40, 12, 32, 0, (0, 7, 0, 0), (1, 6, 15, 4, 1), False)]  # 12-bit: the int32 flt planes (<= 10 bit packs int16 differences)
 GPU_CASES = [(500, 300, 8, 64, 0, (1, 7, 1, 0), (1, 0, 16, 1, 1), False),
