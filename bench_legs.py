@@ -130,7 +130,8 @@ def txfm_roundtrip(torch, lib, pkg, stream, steps, warmup):
 
 def lr_frames(torch, lib, pkg, stream, steps, warmup):
     """config 4, restoration half: one 3840x2160 10-bit luma plane, 256x256 units, every unit Wiener / every unit self-guided / mixed."""
-    Wc, Hc, bd, us = 3840, 2160, 10, 256
+    import os
+    Wc, Hc, bd, us = 3840, int(os.environ.get("SVT_LR_H", "2160")), 10, 256  # (SVT_LR_H: plane-height sweep for the fixed-cost / throughput split)
     g = np.random.default_rng(44)
     yy, xx = np.mgrid[0:Hc, 0:Wc]
     plane = np.clip(((xx * 3 + yy * 2) % 1024) // 2 + ((xx // 8 + yy // 8) % 2) * 24 + g.integers(0, 64, (Hc, Wc)), 0, 1023).astype(np.uint16)
@@ -143,8 +144,8 @@ def lr_frames(torch, lib, pkg, stream, steps, warmup):
     out = {}
     import os
     only = os.environ.get("SVT_LR_ONLY")  # profiling passes: one unit type per process, so that per-kernel counters are not a mix
-    for name, tsel in (("wiener", [1]), ("sgrproj", [2]), ("mixed", [1, 2, 0, 2, 1])):
-        if only and name != only:
+    for name, tsel in (("wiener", [1]), ("sgrproj", [2]), ("mixed", [1, 2, 0, 2, 1]), ("copy", [0])):  # "copy": every unit RESTORE_NONE = staging + stores only
+        if (only and name != only) or (name == "copy" and only != "copy"):
             continue
         units = np.zeros(nvu * nhu, dtype=pkg.LrUnit)
         for i in range(len(units)):
@@ -152,7 +153,9 @@ def lr_frames(torch, lib, pkg, stream, steps, warmup):
             taps = [f[0], f[1], f[2], -2 * sum(f), f[2], f[1], f[0], 0]
             units[i] = (tsel[i % len(tsel)], taps, taps, int(g.integers(0, 16)), (int(g.integers(-96, 32)), int(g.integers(-32, 96))))
         d_un = _dev(torch, units)
-        P = pkg.LrParams(d_pl.data_ptr(), d_ab.data_ptr(), d_bl.data_ptr(), d_out.data_ptr(), Wc, Wc, Wc, Wc, Hc, us, 0, 0, 1, bd, d_un.data_ptr())
+        sh = int(os.environ.get("SVT_LR_SHIFT", "0"))  # alignment experiment: the plane starts `sh` samples into the buffer (width reduced accordingly)
+        P = pkg.LrParams(d_pl.data_ptr() + 2 * sh, d_ab.data_ptr() + 2 * sh, d_bl.data_ptr() + 2 * sh, d_out.data_ptr(), Wc, Wc, Wc, Wc - 2 * sh, Hc, us, 0, 0, 1, bd,
+                         d_un.data_ptr())
         t = _time(torch, lambda: lib.svt_hip_lr_filter_frame(C.byref(P), stream), steps, warmup)
         nbytes = Wc * Hc * 4 + 4 * nstripes * Wc * 2
         out["lr_%s_4k10" % name] = {"frames_per_s": 1 / t, "Mpx_s": Wc * Hc / t / 1e6, "ms": t * 1e3,

@@ -93,12 +93,12 @@ __device__ __forceinline__ void stage_load(StageRegs<NIT>& R, const TileSrc& s, 
         if (r >= rows) p = (const uint8_t*)s.data;                                   // idle lanes read the plane start: always mapped
         else if (y < ilo || y >= ihi) p = src_row(s, y) + (cfast ? (long long)x * px : 0ll); // (slow lanes read the row start)
         if (s.highbd) {
-            const LrRow8A2 t = *(const LrRow8A2*)p;
-            v[k][0] = t.v[0]; v[k][1] = t.v[1]; v[k][2] = t.v[2]; v[k][3] = t.v[3];
+            const svt_u32x4_a2 t = svt_hip_global_load_x4(p);
+            v[k][0] = t[0]; v[k][1] = t[1]; v[k][2] = t[2]; v[k][3] = t[3];
         } else {
-            const LrRow8A1 t = *(const LrRow8A1*)p;
-            v[k][0] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c010c00u); v[k][1] = __builtin_amdgcn_perm(0u, t.v[0], 0x0c030c02u);
-            v[k][2] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c010c00u); v[k][3] = __builtin_amdgcn_perm(0u, t.v[1], 0x0c030c02u);
+            const svt_u32x2_a1 t = svt_hip_global_load_x2(p);
+            v[k][0] = __builtin_amdgcn_perm(0u, t[0], 0x0c010c00u); v[k][1] = __builtin_amdgcn_perm(0u, t[0], 0x0c030c02u);
+            v[k][2] = __builtin_amdgcn_perm(0u, t[1], 0x0c010c00u); v[k][3] = __builtin_amdgcn_perm(0u, t[1], 0x0c030c02u);
         }
     }
 }

@@ -13,6 +13,17 @@
 // Redefines a 32-bit per-lane value through an empty asm: everything computed from it afterwards is no longer loop invariant for the compiler, which
 // otherwise hoists dozens of per-lane LDS / global addresses out of a short outer loop and doubles the kernel's VGPR count.  (The CPU emulator used by the
 // tests defines it as a no-op first.)
+// A pointer rebuilt from integer arithmetic (row maps that select between planes), or taken from a struct passed by value, has no address space and
+// the compiler emits FLAT loads, which also occupy the LDS queue; picture planes are always global memory, so the staging loads say so.  Native vector
+// types only: a struct would be copied through its (generic-reference) copy constructor and the address space would be lost again.  (The CPU emulator
+// defines SVT_HIP_GLOBAL_AS as nothing.)
+#ifndef SVT_HIP_GLOBAL_AS
+#define SVT_HIP_GLOBAL_AS __attribute__((address_space(1)))
+#endif
+typedef uint32_t svt_u32x4_a2 __attribute__((vector_size(16), aligned(2))); // 16 bytes at any even address
+typedef uint32_t svt_u32x2_a1 __attribute__((vector_size(8), aligned(1)));  // 8 bytes at any address
+__device__ __forceinline__ svt_u32x4_a2 svt_hip_global_load_x4(const void* p) { return *(const SVT_HIP_GLOBAL_AS svt_u32x4_a2*)p; }
+__device__ __forceinline__ svt_u32x2_a1 svt_hip_global_load_x2(const void* p) { return *(const SVT_HIP_GLOBAL_AS svt_u32x2_a1*)p; }
 #ifndef SVT_HIP_OPAQUE_I32
 #define SVT_HIP_OPAQUE_I32(x) asm volatile("" : "+v"(x))
 #endif
