@@ -20,19 +20,20 @@ constexpr size_t LR_SMEM    = (size_t)TH * TW * 2 + LR_A_BYTES + (size_t)66 * 66
 // One workgroup = 64 >> ss_x columns x at most LR_UR rows of one stripe (a 64-row luma stripe is cut in two: twice the workgroups, half the
 // LDS -> 8 resident workgroups per CU to hide the staging round trip; the cut is invisible to the filters because the rows on the far
 // side of it are ordinary rows of the same stripe).
-constexpr int    LR_UR        = 32;
-constexpr size_t LR_FRAME_A   = (size_t)(LR_UR + 2) * 66 * 2 + 8;
-constexpr size_t LR_FRAME_MID = (size_t)(LR_UR + 6) * 64 * 2;
-constexpr size_t LR_FRAME_AB  = LR_FRAME_A + (size_t)(LR_UR + 2) * 66 * 4;
-constexpr size_t LR_FRAME_SMEM = (size_t)(LR_UR + 6) * TW * 2 + (LR_FRAME_AB > LR_FRAME_MID ? LR_FRAME_AB : LR_FRAME_MID) + 512;
+constexpr size_t lr_frame_a(const int ur) { return (size_t)(ur + 2) * 66 * 2 + 8; }
+constexpr size_t lr_frame_mid(const int ur) { return (size_t)(ur + 6) * 64 * 2; }
+constexpr size_t lr_frame_ab(const int ur) { return lr_frame_a(ur) + (size_t)(ur + 2) * 66 * 4; }
+constexpr size_t lr_frame_union(const int ur) { return lr_frame_ab(ur) > lr_frame_mid(ur) ? lr_frame_ab(ur) : lr_frame_mid(ur); }
+constexpr size_t lr_frame_smem(const int ur) { return (size_t)(ur + 6) * TW * 2 + lr_frame_union(ur) + 512; }
 // grid (unit columns, halves of a stripe, stripes); nhu x nvu restoration units, ushift = log2(unit_size) or -1 (the host does the divisions once)
+template <int LR_UR> // rows of a stripe per workgroup: 32 (two workgroups per 64-row luma stripe) or 64
 __global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, const int nhu, const int nvu, const int ushift) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
     uint16_t* tile = smem;
     uint16_t* mid  = tile + (LR_UR + 6) * TW;                  // Wiener only
     uint16_t* A16  = mid;                                      // self-guided only (aliases mid)
-    int32_t*  B32  = (int32_t*)((uint8_t*)mid + LR_FRAME_A);
-    uint16_t* xlut = (uint16_t*)((uint8_t*)mid + (LR_FRAME_AB > LR_FRAME_MID ? LR_FRAME_AB : LR_FRAME_MID));
+    int32_t*  B32  = (int32_t*)((uint8_t*)mid + lr_frame_a(LR_UR));
+    uint16_t* xlut = (uint16_t*)((uint8_t*)mid + lr_frame_union(LR_UR));
     const int tid = threadIdx.x;
     const int pw = (int)P.width, ph = (int)P.height, off = 8 >> P.ss_y, sh = 64 >> P.ss_y, cw = 64 >> P.ss_x;
     TileSrc s;
@@ -177,12 +178,19 @@ void svt_hip_lr_filter_frame(const SvtHipLrParams* params, void* stream) {
     const int sh = 64 >> P.ss_y, off = 8 >> P.ss_y, cw = 64 >> P.ss_x;
     const int n_stripes = ((int)P.height + off + sh - 1) / sh;
     const int n_cols    = ((int)P.width + cw - 1) / cw;
-    const int nsplit    = (sh + LR_UR - 1) / LR_UR;
+    static const int ur_env = [] { const char* e = getenv("SVT_HIP_LR_UR"); return e ? atoi(e) : 32; }(); // 64: one workgroup per whole stripe (experiment)
     const int us        = (int)P.unit_size;
     int       nvu = ((int)P.height + (us >> 1)) / us, nhu = ((int)P.width + (us >> 1)) / us, ushift = -1;
     nvu = nvu > 0 ? nvu : 1; nhu = nhu > 0 ? nhu : 1;
     if (us > 0 && !(us & (us - 1))) ushift = __builtin_ctz((unsigned)us);
-    hipLaunchKernelGGL(lr_frame_kernel, dim3(n_cols, nsplit, n_stripes), dim3(256), LR_FRAME_SMEM, (hipStream_t)stream, P, nhu, nvu, ushift);
+    if (ur_env == 64) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_frame_kernel<64>), dim3(n_cols, 1, n_stripes), dim3(256), lr_frame_smem(64), (hipStream_t)stream, P, nhu, nvu, ushift);
+    } else if (ur_env == 16) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_frame_kernel<16>), dim3(n_cols, (sh + 15) / 16, n_stripes), dim3(256), lr_frame_smem(16), (hipStream_t)stream, P, nhu, nvu, ushift);
+    } else {
+        const int nsplit = (sh + 31) / 32;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_frame_kernel<32>), dim3(n_cols, nsplit, n_stripes), dim3(256), lr_frame_smem(32), (hipStream_t)stream, P, nhu, nvu, ushift);
+    }
     SVT_LAUNCH_CHECK();
 }
 
