@@ -110,7 +110,13 @@ def test_lr_host_forms(be, oracle, bd):
     units["vfilter"], units["hfilter"], units["ep"], units["xqd"] = want["vfilter"], want["hfilter"], want["ep"], want["xqd"]
     out = np.zeros((h, w), dt)
     oracle.oracle_lr_filter_frame(p(plane), w, p(above), p(below), w, p(out), w, w, h, 0, unit, p(units), bd, int(bd > 8))
-    work = plane.copy()
-    L = pkg.LrParams(work.ctypes.data, above.ctypes.data, below.ctypes.data, work.ctypes.data, w, w, w, w, h, unit, 0, 0, int(bd > 8), bd, units.ctypes.data)
-    be.lib.svt_hip_lr_filter_frame_host(C.byref(L))
-    assert np.array_equal(work, out), np.argwhere(work != out)[:5]
+    import os
+    for ur in ("32", "16", "64"):  # rows of a stripe per workgroup (SVT_HIP_LR_UR: 32 is the default; the other two instantiations stay covered)
+        os.environ["SVT_HIP_LR_UR"] = ur
+        try:
+            work = plane.copy()
+            L = pkg.LrParams(work.ctypes.data, above.ctypes.data, below.ctypes.data, work.ctypes.data, w, w, w, w, h, unit, 0, 0, int(bd > 8), bd, units.ctypes.data)
+            be.lib.svt_hip_lr_filter_frame_host(C.byref(L))
+        finally:
+            del os.environ["SVT_HIP_LR_UR"]
+        assert np.array_equal(work, out), (ur, np.argwhere(work != out)[:5])
