@@ -211,6 +211,14 @@ __device__ __forceinline__ void load_taps(const uint16_t* pair, const TapOffs& o
         mx   = pk_max(mx, t[k]);
     }
 }
+// taps K0 .. K1 - 1 only, no min / max: the single-strength forms of apply_pass
+template <int K0, int K1> __device__ __forceinline__ void load_taps_range(const uint16_t* pair, const TapOffs& o, s16x2 (&t)[12]) {
+#pragma unroll
+    for (int k = K0; k < K1; k++) {
+        const DwPairA4 v = *(const DwPairA4*)((const char*)pair + o.oa[k]);
+        t[k] = as_pk(__builtin_amdgcn_alignbyte(v.hi, v.lo, o.sh[k >> 1]));
+    }
+}
 __device__ __forceinline__ s16x2 pri_sum(const s16x2 x, const s16x2 (&t)[12], const s16x2 thr, const s16x2 sh, const s16x2 w0, const s16x2 w1) {
     return w0 * (constrain2(t[0] - x, thr, sh) + constrain2(t[1] - x, thr, sh)) + w1 * (constrain2(t[2] - x, thr, sh) + constrain2(t[3] - x, thr, sh));
 }
@@ -449,11 +457,25 @@ __device__ __forceinline__ void apply_pass(const LaneCtx& L, const TapOffs& o, c
     for (int r = r0; r < L.uh; r += rstep) {
         const int   ri = (L.by * L.uh + r) * L.pitch + L.bx * L.uw + 2 * jq;
         const s16x2 x  = ld_pair_even(L.in + ri);
-        s16x2 t[12], mn, mx, sum = splat(0);
-        load_taps(L.in + ri, o, x, t, mn, mx);
-        if (lvl) sum = pri_sum_level(L, lvl, x, t);
-        if (sec) sum = sum + sec_sum_strength(L, sec, x, t);
-        const uint32_t y  = as_u32(finish_px(x, sum, mn, mx));
+        s16x2 t[12], yv;
+        // With only ONE of the two strengths non-zero the reference's clamp to [min, max] of the taps (cdef.c:300) cannot bind: every constrained difference lies
+        // between 0 and its tap's difference, the four primary (eight secondary) weights sum to 12 of 16, and (12 D + 8) >> 4 <= D for every D >= 0 (likewise
+        // downwards) -- so the result already lies between the centre and the extreme valid tap.  Those filter blocks (strengths are per filter block, the branch
+        // is workgroup-uniform) read 4 or 8 taps instead of 12 and skip the 24 packed min / max operations.  Out-of-frame taps constrain to 0 either way.
+        if (sec == 0) {
+            load_taps_range<0, 4>(L.in + ri, o, t);
+            const s16x2 sum = pri_sum_level(L, lvl, x, t);
+            yv = x + ((sum + splat(8) + (sum >> 15)) >> 4);
+        } else if (lvl == 0) {
+            load_taps_range<4, 12>(L.in + ri, o, t);
+            const s16x2 sum = sec_sum_strength(L, sec, x, t);
+            yv = x + ((sum + splat(8) + (sum >> 15)) >> 4);
+        } else {
+            s16x2 mn, mx;
+            load_taps(L.in + ri, o, x, t, mn, mx);
+            yv = finish_px(x, pri_sum_level(L, lvl, x, t) + sec_sum_strength(L, sec, x, t), mn, mx);
+        }
+        const uint32_t y  = as_u32(yv);
         const size_t   gy = (size_t)(fbr * (L.uh * 8) + L.by * L.uh + r);
         const int      gx = fbc * L.bw + L.bx * L.uw + 2 * jq;
         PIX*           op = out + gy * out_stride + gx;

@@ -66,8 +66,9 @@ def test_cdef_frame_apply_and_search(be, oracle, bd, damping):
         pri, sec = np.array([c[0] for c in cands], np.int32), np.array([c[1] for c in cands], np.int32)
         d, v = run_frame(be, oracle, 1, luma, src_l, 0, 0, 0, bd, skip, pri, sec, dir0, var0, sub=2 if skip_frac else 1, damping=damping)
         # apply: per-block strengths, (4, 2) with some zero-strength and some secondary-only blocks
-        apri = np.where(g.random(nfb) < 0.2, 0, 4).astype(np.int32)
-        asec = np.where(apri == 0, (g.random(nfb) < 0.5) * 1, 2).astype(np.int32)  # level 0 with a secondary strength filters along dir 0
+        apri = g.choice(np.array([0, 4, 9, 15], np.int32), nfb, p=[0.2, 0.4, 0.2, 0.2]).astype(np.int32)
+        # level 0 with a secondary strength filters along dir 0; a primary level alone / a secondary strength alone take the 4- / 8-tap forms without the clamp
+        asec = np.where(apri == 0, (g.random(nfb) < 0.5) * 1, np.where(g.random(nfb) < 0.4, 0, g.choice(np.array([1, 2, 4], np.int32), nfb))).astype(np.int32)
         run_frame(be, oracle, 0, luma, src_l, 0, 0, 0, bd, skip, apri, asec, dir0, var0, damping=damping)
         run_frame(be, oracle, 0, luma, src_l, 0, 0, 0, bd, skip, apri, asec, d, v, damping=damping, dev_mode=2)  # apply with the search pass's directions
         # chroma 4:2:0 uses the luma directions
