@@ -101,6 +101,8 @@ def test_misc_oracle_vs_reference(oracle, ref):
 
 @pytest.mark.parametrize("bd", [8, 10, 12])
 def test_lr_search_statistics(be, oracle, bd):
+    if not be.is_gpu and bd == 12:
+        pytest.skip("emulator: 12 bit takes the same u16 path as 10 bit (covered); the GPU run keeps all three")
     g = rng(60 + bd)
     dt = np.uint16 if bd > 8 else np.uint8
     oracle.oracle_pixel_proj_error.restype = C.c_int64
