@@ -68,7 +68,8 @@ CASES = [(150, 100, 8, 64, 0, (1, 7, 1, 0), (1, 0, 16, 1, 1), False),
          (150, 100, 10, 64, 0, (1, 7, 1, 0), (1, 0, 16, 1, 1), False),
          (96, 70, 8, 32, 1, (1, 5, 1, 1), (1, 2, 14, 4, 0), False),
          (130, 64, 10, 64, 0, (1, 3, 0, 0), (1, 10, 16, 1, 1), True),
-         (100, 90, 8, 64, 0, (1, 5, 1, 0), (0, 0, 0, 1, 0), True)]
+         (100, 90, 8, 64, 0, (1, 5, 1, 0), (0, 0, 0, 1, 0), True),
+         (96, 70, 12, 64, 0, (1, 7, 1, 0), (1, 4, 12, 4, 1), False)]  # 12 bit (the device keeps int32 flt planes there)
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
