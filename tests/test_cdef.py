@@ -50,6 +50,30 @@ def run_frame(be, oracle, mode, recon, source, xdec, ydec, pli, bd, skip, pri, s
     return o_dir, o_var
 
 
+@pytest.mark.parametrize("bd,damping", [(8, 3), (10, 6), (12, 4)])
+def test_cdef_apply_single_strength_blocks_extreme_content(be, oracle, bd, damping):
+    """Filter blocks with ONE non-zero strength take the 4- / 8-tap forms that leave out the reference's clamp to the taps' [min, max] (it cannot bind
+    there).  Adversarial content for that claim: every sample 0, the maximum or uniform noise, so the constrained differences reach their limits in both
+    directions; every primary level 1..15 alone and every secondary strength alone, a quarter of the blocks skipped, luma (variance-adjusted primary)
+    and 4:2:0 chroma."""
+    g = rng(900 + bd + damping)
+    W, H = (704, 392) if be.is_gpu else (200, 136)
+    pm = (1 << bd) - 1
+    kind = g.integers(0, 3, (H, W))
+    luma = np.where(kind == 0, 0, np.where(kind == 1, pm, g.integers(0, pm + 1, (H, W)))).astype(np.int64)
+    luma[H // 3:H // 3 + 24, :] = np.where(g.random((24, W)) < 0.5, 0, pm)  # a band of pure extremes
+    nhfb, nvfb = (W + 63) // 64, (H + 63) // 64
+    nfb = nhfb * nvfb
+    skip = (g.random((nvfb * 8, nhfb * 8)) < 0.25).astype(np.uint8)
+    one = g.random(nfb) < 0.5
+    apri = np.where(one, g.integers(1, 16, nfb), 0).astype(np.int32)
+    asec = np.where(one, 0, g.choice(np.array([1, 2, 4], np.int32), nfb)).astype(np.int32)
+    dir0, var0 = np.zeros(nfb * 64, np.uint8), np.zeros(nfb * 64, np.int32)
+    d, v = run_frame(be, oracle, 0, luma, luma, 0, 0, 0, bd, skip, apri, asec, dir0, var0, damping=damping)
+    chroma = luma[::2, ::2].copy()
+    run_frame(be, oracle, 0, chroma, chroma, 1, 1, 1, bd, skip, apri, asec, d, v, damping=damping)
+
+
 @pytest.mark.parametrize("bd,damping", [(8, 5), (10, 5), (12, 6), (10, 3)])
 def test_cdef_frame_apply_and_search(be, oracle, bd, damping):
     g = rng(50 + bd + damping)
