@@ -292,8 +292,9 @@ __global__ __launch_bounds__(256) void tf_mc_kernel(const SvtHipTfSubpelParams P
     const int  sx = col & 15, sy = row & 15;
     const int  ox = ss ? ((d.pu_x >> 3) << 3) / 2 : d.pu_x, oy = ss ? ((d.pu_y >> 3) << 3) / 2 : d.pu_y;
     const long rs = (long)PL.ref_stride[pl];
-    const PIX* p0 = (const PIX*)PL.ref[pl] + d.ref_off[pl] + (P.ref_org_x >> ss) + (long)(P.ref_org_y >> ss) * rs + ox + (col >> 4) + (long)(oy + (row >> 4)) * rs;
-    PIX*       out = (PIX*)PL.pred[pl] + d.pred_off[pl] + ox + (size_t)oy * PL.pred_stride[pl];
+    // (ref_off / pred_off are read from the descriptor in memory: indexing the register copy `d` with the runtime plane index put the whole struct in scratch)
+    const PIX* p0 = (const PIX*)PL.ref[pl] + descs[blk].ref_off[pl] + (P.ref_org_x >> ss) + (long)(P.ref_org_y >> ss) * rs + ox + (col >> 4) + (long)(oy + (row >> 4)) * rs;
+    PIX*       out = (PIX*)PL.pred[pl] + descs[blk].pred_off[pl] + ox + (size_t)oy * PL.pred_stride[pl];
     const uint32_t ps = PL.pred_stride[pl];
     const int      kind = W <= 4 ? 1 : 3, lw = 31 - __clz(W);
     const PackedTaps tx = kTaps.t[kind][sx], ty = kTaps.t[kind][sy];
