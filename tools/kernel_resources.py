@@ -33,7 +33,7 @@ def main():
             text = open(asm).read()
             # static instruction mix per kernel body
             mix = {}
-            for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+            for m in re.finditer(r"^([A-Za-z_]\w*):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S | re.M):  # (a kernel may hold several s_endpgm: early returns)
                 c = {"v": 0, "s": 0, "ds": 0, "mem": 0}
                 for line in m.group(2).split("\n"):
                     op = line.strip().split(" ")[0].split("\t")[0]
