@@ -85,3 +85,40 @@ def test_handle_transform_vs_reference(oracle, ref):
             ea, eb = oracle.oracle_handle_transform(p(a), w, h, n2n4), f(p(b))
             kept = min(w, 32) * min(h, 32)
             assert ea == eb and np.array_equal(a[:kept], b[:kept]), (w, h, n2n4)
+
+
+def test_reference_tables_golden_and_quantizers(oracle, ref):
+    """tests/golden/quant_tables.npz == what the reference's svt_av1_build_quantizer / av1_scan_orders produce here (when the wrapper library exists),
+    and the oracle's quantizers == the reference's `_c` quantizers on exactly those tables and scans."""
+    import os
+    from conftest import REF_LIB
+    from quant_common import _qt, real_qparams, real_scans
+    me_path = os.path.join(os.path.dirname(REF_LIB), "libsvtref_me.so")
+    T = _qt()
+    if os.path.exists(me_path):
+        me = C.CDLL(me_path)
+        if hasattr(me, "ref_build_quantizer_y"):
+            for b, bd in enumerate((8, 10)):
+                for i, q in enumerate(T["q"]):
+                    t = np.zeros((7, 2), np.int16)
+                    me.ref_build_quantizer_y(bd, 0, 0, int(q), p(t))
+                    assert np.array_equal(t, T["tables"][b, i]), (bd, int(q))
+            for ts in range(19):
+                for tt in range(16):
+                    sc, isc = np.zeros(1024, np.int16), np.zeros(1024, np.int16)
+                    n = me.ref_scan_order(ts, tt, p(sc), p(isc))
+                    assert np.array_equal(sc[:n], T["scan_%d" % ts][tt]) and np.array_equal(isc[:n], T["iscan_%d" % ts][tt]), (ts, tt)
+    g = rng(77)
+    for ts in (0, 1, 2, 3, 4, 9, 12, 13, 17):
+        scans, iscans = real_scans(ts)
+        n = scans.shape[1]
+        pels = [16, 64, 256, 1024, 4096, 32, 32, 128, 128, 512, 512, 2048, 2048, 64, 64, 256, 256, 1024, 1024][ts]
+        ls = int(pels > 256) + int(pels > 1024)
+        for mode in range(4):
+            bd = 10 if mode in (1, 3) else 8
+            for P in real_qparams(bd, mode >= 2):
+                for tt in (0, 3, 9, 10, 11):
+                    c = gen_coeff(g, n, 1 << (bd + 5), int(g.integers(0, 3)))
+                    scan, iscan = np.ascontiguousarray(scans[tt]), np.ascontiguousarray(iscans[tt])
+                    assert_same(run_oracle(oracle, mode, False, c, n, P, scan, None, None, ls), run_ref(ref, mode, False, c, n, P, scan, iscan, None, None, ls),
+                                (ts, mode, tt))

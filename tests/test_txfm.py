@@ -153,74 +153,116 @@ def test_wht4x4(be, oracle):
                     assert np.array_equal(w8.reshape(4, stride)[:, :4].astype(np.uint16), w16.reshape(4, stride)[:, :4]), (i, eob)
 
 
-@pytest.mark.parametrize("ts", range(19))
-def test_txfm_quant_roundtrip_fused(be, oracle, ts):
-    """BASELINE config 3 in one launch (svt_hip_txfm_quant_roundtrip_batch) == the four-launch chain fwd -> svt_handle_transform -> quantize -> inverse, which is
-    itself pinned stage by stage against the oracle: recon, qcoeff, dqcoeff and eob bit-identical, every TX size, 8 and 10 bit, both quantizer families,
-    five quantizer steps spanning q_index 0..255 (QuantAsmTest.cc:86-96), with and without quantization matrices."""
-    import sys as _s, os as _o
-    _s.path.insert(0, _o.path.dirname(_o.path.abspath(__file__)))
-    from quant_common import make_qparams, make_scan
-    g = rng(800 + ts)
+def _roundtrip_case(be, oracle, ts, g, bd, fp, types, plist, scans, iscans, qmt, iqmt, n, check_chain):
+    """One svt_hip_txfm_quant_roundtrip_batch launch checked against the CPU checker's composition oracle_fwd_txfm2d -> oracle_handle_transform ->
+    oracle_quantize -> oracle_inv_txfm2d_add block by block (qcoeff, dqcoeff, eob, recon), and -- check_chain -- against the HIP four-launch chain."""
+    from quant_common import oracle_roundtrip
     w, h = TXW[ts], TXH[ts]
     iw, ih = min(w, 32), min(h, 32)
     ncoef, pels = iw * ih, w * h
     ls = int(pels > 256) + int(pels > 1024)
+    qm = qmt is not None
+    qmode = (1 if bd > 8 else 0) + 2 * fp
+    amp = (1 << bd) - 1
+    dt = np.uint16 if bd > 8 else np.uint8
+    stride = w + 3
+    res = g.integers(-amp, amp + 1, (n, h * stride)).astype(np.int16)
+    res[0, :] = amp  # extreme block
+    if n > 2:
+        res[2, :] = g.integers(-3, 4, h * stride)  # nearly flat residual: mostly-zero qcoeff, small eob
+    pred = g.integers(0, amp + 1, (n, h * stride)).astype(dt)
+    params = np.zeros(len(plist), dtype=be.pkg.QuantParams)
+    for i, P in enumerate(plist):
+        params[i] = (P["zbin"], P["round"], P["quant"], P["quant_shift"], P["dequant"], ls)
+    nqm = 1 if not qm else qmt.shape[0]
+    rd = np.zeros(n, dtype=be.pkg.RoundtripDesc)
+    for i in range(n):
+        tt = types[i % len(types)]
+        rd[i] = (i * h * stride, i * h * stride, i * h * stride, stride, stride, stride, i % len(plist), tt if scans.shape[0] == 16 else i % scans.shape[0],
+                 (i // 2) % nqm, tt, (0,) * 7)
+    d_res, d_pred, d_rd, d_par, d_is = be.dev(res), be.dev(pred), be.dev(rd), be.dev(params), be.dev(iscans)
+    d_qm, d_iqm = (be.dev(qmt), be.dev(iqmt)) if qm else (None, None)
+    q1, dq1, e1, rec1 = be.empty((n, ncoef), np.int32), be.empty((n, ncoef), np.int32), be.empty(n, np.uint16), be.empty((n, h * stride), dt)
+    be.lib.svt_hip_txfm_quant_roundtrip_batch(be.ptr(d_res), be.ptr(d_pred), be.ptr(rec1), be.ptr(d_rd), n, ts, bd, qmode, be.ptr(d_par), be.ptr(d_is),
+                                              be.ptr(d_qm) if qm else None, be.ptr(d_iqm) if qm else None, be.ptr(q1), be.ptr(dq1), be.ptr(e1), be.stream)
+    gq, gdq, ge, grec = be.host(q1), be.host(dq1), be.host(e1), be.host(rec1).reshape(n, h, stride)[:, :, :w]
+    for i in range(n):
+        d = rd[i]
+        si, qi = int(d["iscan_idx"]), int(d["qm_idx"])
+        wq, wdq, weob, wrec = oracle_roundtrip(oracle, res[i], stride, pred[i].astype(np.uint16), stride, w, h, int(d["tx_type"]), ts, bd, qmode,
+                                               plist[int(d["qparam_idx"])], scans[si], qmt[qi] if qm else None, iqmt[qi] if qm else None, ls)
+        tag = (TX_SIZES[ts], bd, qmode, int(d["tx_type"]), int(d["qparam_idx"]), i)
+        assert np.array_equal(gq[i], wq), ("qcoeff",) + tag
+        assert np.array_equal(gdq[i], wdq), ("dqcoeff",) + tag
+        assert int(ge[i]) == weob, ("eob",) + tag
+        assert np.array_equal(grec[i].astype(np.uint16), wrec), ("recon",) + tag
+    assert np.count_nonzero(gq) > 0
+    if not check_chain:
+        return
+    fd, idesc, qd = np.zeros(n, dtype=be.pkg.FwdTxfmDesc), np.zeros(n, dtype=be.pkg.InvTxfmDesc), np.zeros(n, dtype=be.pkg.QuantDesc)
+    for i in range(n):
+        tt = int(rd[i]["tx_type"])
+        fd[i] = (i * h * stride, stride, tt, (0, 0, 0))
+        idesc[i] = (i * ncoef, i * h * stride, i * h * stride, stride, stride, tt, 0, (0,) * 6)
+        qd[i] = (int(rd[i]["qparam_idx"]), int(rd[i]["iscan_idx"]), int(rd[i]["qm_idx"]), 0)
+    d_fd, d_id, d_qd = be.dev(fd), be.dev(idesc), be.dev(qd)
+    co = be.empty((n, pels), np.int32)
+    be.lib.svt_hip_fwd_txfm2d_batch(be.ptr(d_res), be.ptr(d_fd), n, ts, bd, 0, be.ptr(co), be.stream)
+    if max(w, h) == 64:
+        en = be.empty(n, np.uint64)
+        be.lib.svt_hip_handle_transform_batch(be.ptr(co), n, ts, 0, be.ptr(en), be.stream)
+        co = be.dev(be.host(co).reshape(n, pels)[:, :ncoef].copy())  # packed in place to 32-wide rows; the blocks still start W*H apart
+    q2, dq2, e2, rec2 = be.empty((n, ncoef), np.int32), be.empty((n, ncoef), np.int32), be.empty(n, np.uint16), be.empty((n, h * stride), dt)
+    be.lib.svt_hip_quantize_batch(qmode, be.ptr(co), n, ncoef, be.ptr(d_par), be.ptr(d_is), be.ptr(d_qm) if qm else None, be.ptr(d_iqm) if qm else None,
+                                  be.ptr(d_qd), be.ptr(q2), be.ptr(dq2), be.ptr(e2), be.stream)
+    if bd > 8:
+        be.lib.svt_hip_inv_txfm2d_add_batch(be.ptr(dq2), be.ptr(d_pred), be.ptr(rec2), be.ptr(d_id), n, ts, bd, be.stream)
+    else:
+        be.lib.svt_hip_inv_txfm2d_add_batch_u8(be.ptr(dq2), be.ptr(d_pred), be.ptr(rec2), be.ptr(d_id), n, ts, be.stream)
+    assert np.array_equal(gq, be.host(q2)) and np.array_equal(gdq, be.host(dq2)) and np.array_equal(ge, be.host(e2)), (TX_SIZES[ts], bd, qmode, "chain")
+    assert np.array_equal(grec, be.host(rec2).reshape(n, h, stride)[:, :, :w]), (TX_SIZES[ts], bd, qmode, "chain recon")
+
+
+@pytest.mark.parametrize("ts", range(19))
+def test_txfm_quant_roundtrip_fused(be, oracle, ts):
+    """BASELINE config 3 in one launch (svt_hip_txfm_quant_roundtrip_batch) against the ORACLE composition (fwd -> svt_handle_transform -> quantize ->
+    inverse + reconstruction): qcoeff, dqcoeff, eob and recon bit-identical for every TX size, 8 and 10 bit, both quantizer families, five
+    quantizer steps spanning q_index 0..255, with and without quantization matrices, shuffled scans (any permutation must work); on the GPU also
+    against the HIP four-launch chain."""
+    from quant_common import make_qparams, make_scan
+    g = rng(800 + ts)
+    w, h = TXW[ts], TXH[ts]
+    ncoef, pels = min(w, 32) * min(h, 32), w * h
     types = allowed_types(ts)
     if not be.is_gpu and pels >= 2048:
         types = types[:1]
     steps = [(4, 4), (20, 22), (88, 112), (336, 460), (1336, 1828)]  # (dc, ac) dequant steps from q_index 0 up to 255 (8-bit tables)
-    per = 2 if be.is_gpu else 1
-    n = len(types) * len(steps) * per
+    n = len(types) * len(steps) * (2 if be.is_gpu else 1)
     if not be.is_gpu:
-        n = min(n, 6 if pels >= 1024 else 20)
+        n = min(n, 4 if pels >= 1024 else 12)
     for bd, fp, qm in ((8, 0, False), (10, 0, False), (10, 1, True), (8, 1, False)) if be.is_gpu else ((10, 0, False), (8, 1, True)):
-        qmode = (1 if bd > 8 else 0) + 2 * fp
-        amp = (1 << bd) - 1
-        dt = np.uint16 if bd > 8 else np.uint8
-        stride = w + 3
-        res = g.integers(-amp, amp + 1, (n, h * stride)).astype(np.int16)
-        pred = g.integers(0, amp + 1, (n, h * stride)).astype(dt)
-        params = np.zeros(len(steps), dtype=be.pkg.QuantParams)
-        for i, (dc, ac) in enumerate(steps):
-            P = make_qparams(dc * (4 if bd > 8 else 1), ac * (4 if bd > 8 else 1), fp=bool(fp))
-            params[i] = (P["zbin"], P["round"], P["quant"], P["quant_shift"], P["dequant"], ls)
-        scans = [make_scan(ncoef, g) for _ in range(2)]
-        iscans = np.stack([sc[1] for sc in scans])
-        qmt, iqmt = g.integers(16, 255, (2, ncoef)).astype(np.uint8), g.integers(16, 64, (2, ncoef)).astype(np.uint8)
-        rd = np.zeros(n, dtype=be.pkg.RoundtripDesc)
-        fd, idesc, qd = np.zeros(n, dtype=be.pkg.FwdTxfmDesc), np.zeros(n, dtype=be.pkg.InvTxfmDesc), np.zeros(n, dtype=be.pkg.QuantDesc)
-        for i in range(n):
-            tt = types[i % len(types)]
-            rd[i] = (i * h * stride, i * h * stride, i * h * stride, stride, stride, stride, i % len(steps), i % 2, (i // 2) % 2, tt, (0,) * 7)
-            fd[i] = (i * h * stride, stride, tt, (0, 0, 0))
-            idesc[i] = (i * ncoef, i * h * stride, i * h * stride, stride, stride, tt, 0, (0,) * 6)
-            qd[i] = (i % len(steps), i % 2, (i // 2) % 2, 0)
-        d_res, d_pred, d_rd, d_par, d_is = be.dev(res), be.dev(pred), be.dev(rd), be.dev(params), be.dev(iscans)
-        d_qm, d_iqm = be.dev(qmt), be.dev(iqmt)
-        q1, dq1, e1, rec1 = be.empty((n, ncoef), np.int32), be.empty((n, ncoef), np.int32), be.empty(n, np.uint16), be.empty((n, h * stride), dt)
-        be.lib.svt_hip_txfm_quant_roundtrip_batch(be.ptr(d_res), be.ptr(d_pred), be.ptr(rec1), be.ptr(d_rd), n, ts, bd, qmode, be.ptr(d_par), be.ptr(d_is),
-                                                  be.ptr(d_qm) if qm else None, be.ptr(d_iqm) if qm else None, be.ptr(q1), be.ptr(dq1), be.ptr(e1), be.stream)
-        # the chain
-        d_fd, d_id, d_qd = be.dev(fd), be.dev(idesc), be.dev(qd)
-        co = be.empty((n, pels), np.int32)
-        be.lib.svt_hip_fwd_txfm2d_batch(be.ptr(d_res), be.ptr(d_fd), n, ts, bd, 0, be.ptr(co), be.stream)
-        if max(w, h) == 64:
-            en = be.empty(n, np.uint64)
-            be.lib.svt_hip_handle_transform_batch(be.ptr(co), n, ts, 0, be.ptr(en), be.stream)
-        q2, dq2, e2, rec2 = be.empty((n, ncoef), np.int32), be.empty((n, ncoef), np.int32), be.empty(n, np.uint16), be.empty((n, h * stride), dt)
-        if max(w, h) == 64:  # handle_transform packed every block to 32-wide rows in place: the blocks still start W*H apart
-            packed = be.host(co).reshape(n, pels)[:, :ncoef].copy()
-            co = be.dev(packed)
-        be.lib.svt_hip_quantize_batch(qmode, be.ptr(co), n, ncoef, be.ptr(d_par), be.ptr(d_is), be.ptr(d_qm) if qm else None, be.ptr(d_iqm) if qm else None,
-                                      be.ptr(d_qd), be.ptr(q2), be.ptr(dq2), be.ptr(e2), be.stream)
-        if bd > 8:
-            be.lib.svt_hip_inv_txfm2d_add_batch(be.ptr(dq2), be.ptr(d_pred), be.ptr(rec2), be.ptr(d_id), n, ts, bd, be.stream)
-        else:
-            be.lib.svt_hip_inv_txfm2d_add_batch_u8(be.ptr(dq2), be.ptr(d_pred), be.ptr(rec2), be.ptr(d_id), n, ts, be.stream)
-        assert np.array_equal(be.host(q1), be.host(q2)), (TX_SIZES[ts], bd, qmode, "qcoeff")
-        assert np.array_equal(be.host(dq1), be.host(dq2)), (TX_SIZES[ts], bd, qmode, "dqcoeff")
-        assert np.array_equal(be.host(e1), be.host(e2)), (TX_SIZES[ts], bd, qmode, "eob")
-        a, b = be.host(rec1).reshape(n, h, stride)[:, :, :w], be.host(rec2).reshape(n, h, stride)[:, :, :w]
-        assert np.array_equal(a, b), (TX_SIZES[ts], bd, qmode, "recon")
-        assert np.count_nonzero(be.host(q1)) > 0
+        plist = [make_qparams(dc * (4 if bd > 8 else 1), ac * (4 if bd > 8 else 1), fp=bool(fp)) for (dc, ac) in steps]
+        sc = [make_scan(ncoef, g) for _ in range(2)]
+        scans, iscans = np.stack([s[0] for s in sc]), np.stack([s[1] for s in sc])
+        qmt = g.integers(16, 255, (2, ncoef)).astype(np.uint8) if qm else None
+        iqmt = g.integers(16, 64, (2, ncoef)).astype(np.uint8) if qm else None
+        _roundtrip_case(be, oracle, ts, g, bd, fp, types, plist, scans, iscans, qmt, iqmt, n, check_chain=be.is_gpu)
+
+
+@pytest.mark.parametrize("ts", range(19))
+def test_config3_reference_tables(be, oracle, ts):
+    """SURVEY 8(d) config 3 on the reference's own data: quantizer tables from svt_av1_build_quantizer (md_config_process.c:111-189) at
+    q in {0, 60, 120, 180, 255} (QuantAsmTest.cc:86-96), scans from av1_scan_orders[tx_size][tx_type] (coefficients.h:2197) -- both frozen from the
+    reference in tests/golden/quant_tables.npz --, tx types cycling through the allowed set (TxfmCommon.h:160-209), residuals uniform in
+    +-(2^bd - 1), 8 and 10 bit, quantize_b and quantize_fp.  fwd coeffs -> qcoeff, dqcoeff, eob, recon all equal to the oracle composition."""
+    from quant_common import real_qparams, real_scans
+    g = rng(13596 + ts)
+    w, h = TXW[ts], TXH[ts]
+    pels = w * h
+    types = allowed_types(ts)
+    scans, iscans = real_scans(ts)
+    n = len(types) * 5 * (2 if be.is_gpu else 1)
+    if not be.is_gpu:
+        n = min(n, 5 if pels >= 1024 else 10)
+    for bd, fp in ((8, 0), (10, 0), (8, 1), (10, 1)) if be.is_gpu else ((8, 0), (10, 1)):
+        _roundtrip_case(be, oracle, ts, g, bd, fp, types, real_qparams(bd, fp), scans, iscans, None, None, n, check_chain=False)

@@ -251,7 +251,29 @@ def gen_txfm(ref, oracle):
     np.savez_compressed(os.path.join(GOLDEN, "txfm.npz"), cfg=np.array(cfg, np.int32), **arrays)
 
 
-FAMILIES = {"sad": gen_sad, "txfm": gen_txfm, "filters": gen_filters, "stage": gen_stage}
+def gen_quant_tables(ref, oracle):
+    """SURVEY 8(d) config 3 data: the reference's own luma quantizer tables (svt_av1_build_quantizer, md_config_process.c:111-189, base_q_idx 0,
+    sharpness 0, as QuantAsmTest.cc:86-96 builds them) at q in {0, 60, 120, 180, 255} for 8 and 10 bit, and av1_scan_orders (coefficients.h:2197)
+    for every TX size and type, through oracle/ref_wrap/ref_quant_tables.c."""
+    me = C.CDLL(os.path.join(os.path.dirname(REF_LIB), "libsvtref_me.so"))
+    qs = np.array([0, 60, 120, 180, 255], np.int32)
+    tabs = np.zeros((2, len(qs), 7, 2), np.int16)  # [bd 8|10][q][zbin, round, quant, quant_shift, dequant, quant_fp, round_fp][dc, ac]
+    for b, bd in enumerate((8, 10)):
+        for i, q in enumerate(qs):
+            me.ref_build_quantizer_y(bd, 0, 0, int(q), p(tabs[b, i]))
+    out = {"q": qs, "tables": tabs}
+    for ts in range(19):
+        scans, iscans = [], []
+        for tt in range(16):
+            sc, isc = np.zeros(1024, np.int16), np.zeros(1024, np.int16)
+            n = me.ref_scan_order(ts, tt, p(sc), p(isc))
+            scans.append(sc[:n].copy())
+            iscans.append(isc[:n].copy())
+        out["scan_%d" % ts], out["iscan_%d" % ts] = np.stack(scans), np.stack(iscans)
+    np.savez_compressed(os.path.join(GOLDEN, "quant_tables.npz"), **out)
+
+
+FAMILIES = {"sad": gen_sad, "txfm": gen_txfm, "filters": gen_filters, "stage": gen_stage, "quant_tables": gen_quant_tables}
 
 if __name__ == "__main__":
     os.system("make -s -C %s oracle ref" % os.path.join(ROOT, "oracle"))
