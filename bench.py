@@ -47,17 +47,76 @@ STRIDE, ROWS = W + 2 * PAD, H + 2 * PAD
 PLANE = STRIDE * ROWS
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_traffic.json, written by
-    tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command's default workload).
-    bench.py cannot read PMC counters itself; None when no summary is committed or the workload flags differ from the profiled ones."""
+LIVE_PMC = None  # {kernel: {...}} collected by live_pmc() in THIS run; the committed summary is only the fallback
+
+
+def _short_kernel(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def live_pmc(a):
+    """HBM traffic per launch and kernel, measured in THIS run: two child runs of this script's GPU legs (`--pmc-child`: no CPU legs, no parity checks, a few
+    launches per leg) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes: the two counters do not fit one,
+    MI355X_MICROARCH.md), counters in KiB, FETCH_SIZE doubled (the guide's gfx950 correction).  Launches of a kernel are grouped by grid size and the group with
+    the most bytes is the leg's own workload.  Returns None when rocprofv3 is missing or a pass fails (then the newest committed summary is the fallback)."""
+    import collections
+    import csv
     import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    res = collections.defaultdict(dict)
+    t0 = time.perf_counter()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        td = tempfile.mkdtemp(prefix="svt_pmc_", dir="/tmp")
+        cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", td, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+               "--frames", str(a.frames), "--refs", str(a.refs), "--area", a.area]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=300, capture_output=True)
+            files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            agg = collections.defaultdict(list)
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == ctr:
+                    agg[(_short_kernel(row["Kernel_Name"]), int(row["Grid_Size"]))].append(float(row["Counter_Value"]))
+            best = {}
+            for (k, gsz), v in agg.items():
+                if k.startswith("at::") or "rocclr" in k:
+                    continue
+                if k not in best or sum(v) / len(v) > best[k][0]:
+                    best[k] = (sum(v) / len(v), len(v))
+            for k, (kib, nl) in best.items():
+                res[k]["read" if ctr == "FETCH_SIZE" else "write"] = kib * 1024 * (2 if ctr == "FETCH_SIZE" else 1)
+                res[k]["launches_" + ctr] = nl
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    out = {}
+    for k, t in res.items():
+        rd, wr = t.get("read", 0.0), t.get("write", 0.0)
+        out[k] = {"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr, "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run",
+                  "launches": [t.get("launches_FETCH_SIZE"), t.get("launches_WRITE_SIZE")]}
+    out["_seconds"] = time.perf_counter() - t0
+    return out
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel`: from this run's own PMC passes (live_pmc) when they ran; otherwise from the newest committed PMC summary
+    (profiles/*_pmc_traffic.json, written by tools/pmc_summary.py from the same two rocprofv3 passes over the default workload), marked as such in `source`."""
+    import glob
+    if LIVE_PMC is not None:
+        return LIVE_PMC.get(kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return None
     k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
     return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "read": k["hbm_read_bytes_per_launch"],
-                                   "write": k["hbm_write_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}
+                                   "write": k["hbm_write_bytes_per_launch"], "source": "committed: " + os.path.relpath(files[-1], ROOT)}
 
 
 def synth_planes(n, seed):
@@ -69,6 +128,29 @@ def synth_planes(n, seed):
         base = (xx + 2 * i + yy + 3 * i) & 255
         out[i] = np.clip(base + g.integers(-8, 9, base.shape), 0, 255).astype(np.uint8)
     return out
+
+
+MIN_TIMED_S = 0.3  # every leg is timed over at least this much device time (--steps 20 used to time 9 ms, before the clocks had ramped)
+
+
+def calibrate_launches(torch, fn, steps, min_s, dist=None):
+    """How many back-to-back launches make one `step` so that `steps` steps last >= min_s: one untimed launch, three event-timed ones, the MAX over ranks."""
+    import math
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    t = max(e0.elapsed_time(e1) / 3e3, 1e-7)
+    L = max(1, int(math.ceil(min_s / (steps * t)))) if min_s > 0 else 1
+    if dist is not None:
+        tl = torch.tensor([L], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        L = int(tl.item())
+    return L
 
 
 def time_steps(torch, fn, steps, warmup, dist=None):
@@ -88,6 +170,28 @@ def time_steps(torch, fn, steps, warmup, dist=None):
         dist.barrier()
     wall = time.perf_counter() - t0
     return wall, ev0.elapsed_time(ev1) / 1e3  # seconds: host wall, device span on the launch stream
+
+
+def time_leg(torch, fn, min_s=None, batches=5):
+    """Seconds per launch of a per-kernel leg: launches back to back, `batches` event-timed batches of >= min_s / batches each after a warm-up of the same
+    length, the median batch reported (HIP events on the launch stream = torch's current stream).  Returns (seconds per launch, launches per batch)."""
+    import math
+    min_s = MIN_TIMED_S if min_s is None else min_s
+    reps = calibrate_launches(torch, fn, batches, min_s)
+    reps = max(reps, 3)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(batches):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 1e3 / reps)
+    return sorted(ts)[len(ts) // 2], reps
 
 
 def cpu_me_baseline(descs, planes_src, planes_ref, area, budget_s=12.0):
@@ -345,9 +449,8 @@ def bench_sad_pairs(torch, lib, pkg, stream, a, cpu):
         want = np.array([np.abs(hs[PAD + sy * 64:PAD + sy * 64 + 64, PAD + sx * 64:PAD + sx * 64 + 64] -
                                 hr[PAD + sy * 64 + 2:PAD + sy * 64 + 66, PAD + sx * 64 + 3:PAD + sx * 64 + 67]).sum() for sy in range(17) for sx in range(30)], np.uint32)
         checked += must_equal("sad64x64_pairs", got[f * 510:(f + 1) * 510], want)
-    _, dv = time_steps(torch, fn, a.steps, a.warmup)
-    per = dv / a.steps
-    out = {"value": len(pairs) / per / 1e6, "unit": "Mblocks/s (64x64 pairs)", "footprint_MB": 2 * n_src * PLANE / 1e6, "parity_checked_values": checked,
+    per, reps = time_leg(torch, fn, a.min_leg_s)
+    out = {"launches_per_timed_batch": reps, "value": len(pairs) / per / 1e6, "unit": "Mblocks/s (64x64 pairs)", "footprint_MB": 2 * n_src * PLANE / 1e6, "parity_checked_values": checked,
            "roofline": roofline(len(pairs) * 8192, per, "sad_nxm_pipe_kernel", algorithmic_bytes_per_block=8192,
                                 note="disjoint src / ref plane sets, each byte read once per launch; footprint 1.2 GB")}
     if cpu:
@@ -391,9 +494,8 @@ def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
             want = np.zeros(1024, np.int32)
             oracle.oracle_fwd_txfm2d(vp(res, b * 2048), vp(want), 32, 0, ts, 10, 0)
             checked += must_equal("fwd_txfm2d_32x32", coeff[b * 1024:(b + 1) * 1024], want)
-    _, dv = time_steps(torch, fn, a.steps, a.warmup)
-    per = dv / a.steps
-    out = {"fwd_txfm2d_32x32": {"value": n / per / 1e6, "unit": "Mblocks/s (32x32)", "blocks_per_step": n, "parity_checked_values": checked,
+    per, reps = time_leg(torch, fn, a.min_leg_s)
+    out = {"fwd_txfm2d_32x32": {"launches_per_timed_batch": reps, "value": n / per / 1e6, "unit": "Mblocks/s (32x32)", "blocks_per_step": n, "parity_checked_values": checked,
                                 "roofline": roofline(n * 6144, per, "fwd_txfm2d_kernel<32,32>", "fwd_txfm2d_kernel<32, 32>", algorithmic_bytes_per_block=6144,
                                                      note="butterfly network: VALU/int32-multiply bound, not a dense contraction (DESIGN.md 4.2)")}}
     # ---- quantize_b (high bit depth form, log_scale 1) on the coefficients just produced: 4 B in + 8 B out per coefficient
@@ -419,8 +521,7 @@ def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
                                    vp(iscan), None, None, 1)
             checked += must_equal("quantize_b_32x32 qcoeff", hq[b * 1024:(b + 1) * 1024], q) + must_equal("quantize_b_32x32 dqcoeff", hdq[b * 1024:(b + 1) * 1024], dq)
             must_equal("quantize_b_32x32 eob", [int(heob[b])], [eob.value])
-    _, dv = time_steps(torch, fq, a.steps, a.warmup)
-    per = dv / a.steps
+    per, _ = time_leg(torch, fq, a.min_leg_s)
     out["quantize_b_32x32"] = {"value": n / per / 1e6, "unit": "Mblocks/s (32x32, highbd quantize_b, log_scale 1)", "parity_checked_values": checked,
                                "roofline": roofline(n * (12 * 1024 + 2), per, "quant_kernel<1, false>", algorithmic_bytes_per_block=12 * 1024 + 2)}
     # ---- inverse 32x32 + reconstruction (10-bit) from the dequantised coefficients: 4 B/coeff in + 2 B/px prediction + 2 B/px reconstruction
@@ -442,8 +543,7 @@ def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
             cb = np.ascontiguousarray(hdq[b * 1024:(b + 1) * 1024])
             oracle.oracle_inv_txfm2d_add(vp(cb), vp(pred, b * 2048), 32, vp(want), 32, 0, ts, 10)
             checked += must_equal("inv_txfm2d_add_32x32", hrec[b * 1024:(b + 1) * 1024], want)
-    _, dv = time_steps(torch, fi, a.steps, a.warmup)
-    per = dv / a.steps
+    per, _ = time_leg(torch, fi, a.min_leg_s)
     out["inv_txfm2d_add_32x32"] = {"value": n / per / 1e6, "unit": "Mblocks/s (32x32, 10-bit)", "parity_checked_values": checked,
                                    "roofline": roofline(n * 8192, per, "inv_txfm2d_kernel<unsigned short, 32, 32>", algorithmic_bytes_per_block=8192)}
     if cpu:
@@ -463,6 +563,74 @@ def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
                                                        "single_thread_value": one / 1e6,
                                                        "sample": "svt_av1_fwd_txfm2d_32x32_avx2, 512 private blocks per thread, 3 s per leg"}
     return out
+
+
+def bench_config3(torch, lib, pkg, stream, a):
+    """BASELINE configs[2] / SURVEY 8(d) config 3 on the reference's own data: residual -> FwdTxfm2d -> (svt_handle_transform) -> quantize_b -> InvTxfm2d_add ->
+    reconstruction in ONE launch (svt_hip_txfm_quant_roundtrip_batch), all 19 TX sizes x {8, 10} bit; N = 65536 / 16384 / 4096 blocks per launch, residuals uniform in
+    +-(2^bd - 1) (seed 13596), tx types cycling through the allowed set, quantizer tables from svt_av1_build_quantizer at q in {0, 60, 120, 180, 255} and scans from
+    av1_scan_orders (tests/golden/quant_tables.npz, frozen from the reference).  Before a size is timed, blocks covering every (q, tx type) pair are compared
+    with the CPU checker's composition fwd -> handle_transform -> quantize -> inverse (qcoeff, dqcoeff, eob, recon)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from quant_common import oracle_roundtrip, real_qparams, real_scans
+    oracle = oracle_lib()
+    g = np.random.default_rng(13596)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1)).cuda()  # noqa: E731
+    rows, fr, checked_sizes, checked = {}, [], 0, 0
+    for ts, (w, h) in enumerate(pkg.TX_SIZES):
+        big = max(w, h)
+        n = 65536 if big <= 16 else (16384 if big == 32 else 4096)
+        if a.pmc_child:
+            n //= 8
+        ncoef, pels = min(w, 32) * min(h, 32), w * h
+        ls = int(pels > 256) + int(pels > 1024)
+        types = pkg.allowed_tx_types(ts)
+        scans, iscans = real_scans(ts)
+        for bd in (8, 10):
+            amp = (1 << bd) - 1
+            dt = np.uint16 if bd > 8 else np.uint8
+            plist = real_qparams(bd, False)
+            params = np.zeros(len(plist), dtype=pkg.QuantParams)
+            for i, P in enumerate(plist):
+                params[i] = (P["zbin"], P["round"], P["quant"], P["quant_shift"], P["dequant"], ls)
+            res = g.integers(-amp, amp + 1, n * pels, dtype=np.int16)
+            pred = g.integers(0, amp + 1, n * pels).astype(dt)
+            rd = np.zeros(n, dtype=pkg.RoundtripDesc)
+            rd["in_off"] = rd["pred_off"] = rd["recon_off"] = np.arange(n, dtype=np.uint64) * pels
+            rd["in_stride"] = rd["pred_stride"] = rd["recon_stride"] = w
+            rd["tx_type"] = np.array(types, np.uint8)[np.arange(n) % len(types)]
+            rd["qparam_idx"] = (np.arange(n) // len(types)) % len(plist)
+            rd["iscan_idx"] = rd["tx_type"]
+            d_res, d_pred, d_rd, d_par, d_is = t(res), t(pred), t(rd), t(params), t(iscans)
+            d_rec = torch.zeros(n * pels * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda")
+            d_q, d_dq = torch.zeros(n * ncoef, dtype=torch.int32, device="cuda"), torch.zeros(n * ncoef, dtype=torch.int32, device="cuda")
+            d_eob = torch.zeros(n, dtype=torch.int16, device="cuda")
+            mode = 1 if bd > 8 else 0
+            fn = lambda dq=True: lib.svt_hip_txfm_quant_roundtrip_batch(d_res.data_ptr(), d_pred.data_ptr(), d_rec.data_ptr(), d_rd.data_ptr(), n, ts, bd, mode,  # noqa: E731
+                                                                        d_par.data_ptr(), d_is.data_ptr(), None, None, d_q.data_ptr(), d_dq.data_ptr() if dq else None,
+                                                                        d_eob.data_ptr(), stream)
+            fn()
+            torch.cuda.synchronize()
+            if oracle is not None:
+                hq, hdq, he = d_q.cpu().numpy().reshape(n, ncoef), d_dq.cpu().numpy().reshape(n, ncoef), d_eob.cpu().numpy().view(np.uint16)
+                hrec = d_rec.cpu().numpy().view(dt).reshape(n, h, w)
+                for b in list(range(min(len(types) * len(plist), 20 if pels >= 1024 else 80))) + [n - 1]:
+                    tt, qi = int(rd["tx_type"][b]), int(rd["qparam_idx"][b])
+                    wq, wdq, weob, wrec = oracle_roundtrip(oracle, res[b * pels:(b + 1) * pels], w, pred[b * pels:(b + 1) * pels].astype(np.uint16), w, w, h, tt, ts, bd,
+                                                           mode, plist[qi], np.ascontiguousarray(scans[tt]), None, None, ls)
+                    tag = "config3 %dx%d bd%d block %d " % (w, h, bd, b)
+                    checked += must_equal(tag + "qcoeff", hq[b], wq) + must_equal(tag + "dqcoeff", hdq[b], wdq) + must_equal(tag + "recon", hrec[b].astype(np.uint16), wrec)
+                    must_equal(tag + "eob", [int(he[b])], [weob])
+                checked_sizes += 1
+            per, _ = time_leg(torch, lambda: fn(False), a.min_leg_s / 4)
+            b_alg = (2 + 2 * np.dtype(dt).itemsize) * pels + 4 * ncoef + 2  # residual in, prediction in, reconstruction out, qcoeff + eob out (10 B/px at 16-bit pixels)
+            frac = n * b_alg / per / 1e9 / HBM_PEAK_GBS
+            fr.append(frac)
+            rows["%dx%d_bd%d" % (w, h, bd)] = [round(n / per / 1e6, 1), round(frac, 3)]
+            del d_res, d_pred, d_rec, d_q, d_dq
+    return {"unit": "[Mblocks/s, fraction of the 8 TB/s HBM peak at SURVEY 8(d)'s 10 B/px] per TX size and bit depth, fused single launch", "sizes": rows,
+            "sizes_checked": checked_sizes, "parity_checked_values": checked, "hbm_frac_min_max": [round(min(fr), 3), round(max(fr), 3)],
+            "tables": "svt_av1_build_quantizer q in {0,60,120,180,255} + av1_scan_orders (tests/golden/quant_tables.npz)", "bound": "VALU (butterfly network, DESIGN.md 4.2)"}
 
 
 def bench_cdef(torch, lib, pkg, stream, a, cpu):
@@ -515,20 +683,17 @@ def bench_cdef(torch, lib, pkg, stream, a, cpu):
     for mode, name in ((1, "cdef_search_4k10_64strengths"), (0, "cdef_apply_4k10")):
         P = params(D, mode)
         fn = lambda: lib.svt_hip_cdef_frame(mode, C.byref(P), stream)  # noqa: E731
-        st = max(3, a.steps // (8 if mode else 2))
-        _, dv = time_steps(torch, fn, st, 2)
-        per = dv / st
+        per, reps = time_leg(torch, fn, a.min_leg_s)
         units = n8 * (64 if mode else 1)
         bytes_alg = Wc * Hc * 2 * 2 + (D["nfb"] * 64 * 8 if mode else 0)  # apply: read + write; search: recon + source, 8 B per (fb, strength)
-        out[name] = {"value": units / per / 1e6, "unit": "M(8x8 block x strength)/s" if mode else "M(8x8 blocks)/s", "frames_per_s": 1 / per,
+        out[name] = {"launches_per_timed_batch": reps, "value": units / per / 1e6, "unit": "M(8x8 block x strength)/s" if mode else "M(8x8 blocks)/s", "frames_per_s": 1 / per,
                      "parity_checked_values": checked,
                      "roofline": roofline(bytes_alg, per, "cdef_frame_kernel<unsigned short, %d>" % mode, algorithmic_bytes_per_frame=bytes_alg)}
     # apply with the directions the search pass just wrote (mode 2: what the CDEF stage runs after its strength search)
     P2 = params(D, 0)
     fn2 = lambda: lib.svt_hip_cdef_frame(2, C.byref(P2), stream)  # noqa: E731
-    st = max(3, a.steps // 2)
-    _, dv = time_steps(torch, fn2, st, 2)
-    out["cdef_apply_4k10"]["frames_per_s_given_directions"] = st / dv
+    per2, _ = time_leg(torch, fn2, a.min_leg_s)
+    out["cdef_apply_4k10"]["frames_per_s_given_directions"] = 1 / per2
     if cpu:
         ref, oracle2 = ref_libs()
         if ref is not None and " avx2 " in open("/proc/cpuinfo").read():
@@ -646,14 +811,19 @@ def bench_frame_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle)
                                                     vp(ws), vp(wm))
                     k = rf * (q1 - q0) * sbs_x + (row - q0) * sbs_x + col
                     checked += must_equal("frame partition sad", g_all[rk, 0, k], ws) + must_equal("frame partition mv", g_all[rk, 1, k], wm)
-    wall, dev = time_steps(torch, step, a.steps, a.warmup, dist)
+    L = calibrate_launches(torch, step, a.steps, a.min_leg_s, dist)  # pictures per step, so that the timed region lasts >= min_leg_s
+
+    def step_l():
+        for _ in range(L):
+            step()
+    wall, dev = time_steps(torch, step_l, a.steps, a.warmup, dist)
     t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
     n_total = len(full)
-    return {"value": n_total * aw * ah * a.steps / wall / 1e6, "unit": "Mblocks/s (whole job: one 1080p picture x %d references per step)" % a.refs, "scaling": "strong",
-            "ms_per_step": wall / a.steps * 1e3, "pictures_per_s": a.steps / wall, "strip_rows": [strip_rows(sbs_y, k, world)[1] - strip_rows(sbs_y, k, world)[0] for k in range(world)],
+    return {"value": n_total * aw * ah * a.steps * L / wall / 1e6, "unit": "Mblocks/s (whole job: one 1080p picture x %d references per launch)" % a.refs, "scaling": "strong",
+            "ms_per_step": wall / a.steps * 1e3, "pictures_per_step": L, "timed_region_s": wall, "pictures_per_s": a.steps * L / wall, "strip_rows": [strip_rows(sbs_y, k, world)[1] - strip_rows(sbs_y, k, world)[0] for k in range(world)],
             "collective": ("all_gather_into_tensor over RCCL, %d B per rank per step" % (2 * n_pad * 85 * 4)) if dist is not None else "none (1 GPU)",
             "parity_checked_values": checked}
 
@@ -671,12 +841,20 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="profiling passes only: skip the in-run comparisons with the CPU checker")
     ap.add_argument("--only-me", action="store_true", help="skip the per-kernel legs (profiling passes over the dominant kernel)")
+    ap.add_argument("--min-leg-s", type=float, default=MIN_TIMED_S, help="minimum device time of every timed region (a step = as many launches as that takes)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip this run's own rocprofv3 --pmc child passes (roofline.traffic then comes from the committed summary)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--extra", action="store_true", help="also sweep the other search areas / sub_sad and the remaining stages (reported under kernels)")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:
         self_launch(a)
-    global NO_CHECK
+    global NO_CHECK, LIVE_PMC
+    if a.pmc_child:  # one of live_pmc()'s passes: every GPU leg of the default line, a few launches each, no CPU legs, no checks, no nested PMC
+        a.no_cpu = a.no_parity_check = a.no_pmc = True
+        a.steps, a.warmup, a.min_leg_s = 3, 1, 0.0
     NO_CHECK = a.no_parity_check
+    if not a.no_pmc and a.gpus == 1 and "RANK" not in os.environ and not a.only_me:
+        LIVE_PMC = live_pmc(a)  # before this process touches the GPU; None -> fallback to the committed summary
 
     import torch
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -733,20 +911,26 @@ def main():
             oracle.oracle_me_fullpel_search(vp(planes, int(d["src_off"])), STRIDE, vp(planes, int(d["ref_off"])), STRIDE, int(d["x_origin"]), int(d["y_origin"]), aw, ah, 0,
                                             vp(ws_), vp(wm_))
             me_checked += must_equal("me_fullpel sad", hs[i], ws_) + must_equal("me_fullpel mv", hm[i], wm_)
-    wall, dev = time_steps(torch, step, a.steps, a.warmup, dist)
+    # a "step" = L back-to-back launches over the resident batch (L batches of frames x refs x 510 SBs), L chosen so that the K timed steps last >= min_leg_s
+    L = calibrate_launches(torch, step, a.steps, a.min_leg_s, dist)
+
+    def step_l():
+        for _ in range(L):
+            step()
+    wall, dev = time_steps(torch, step_l, a.steps, a.warmup, dist)
     t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
-    positions = n * aw * ah
+    positions = n * aw * ah * L
     value = world * positions * a.steps / wall / 1e6
     # roofline of the dominant kernel: algorithmic bytes per (SB, ref) = 64*64 + (64+W-1)(64+H-1) + 85*8
     bytes_item = 64 * 64 + (64 + aw - 1) * (64 + ah - 1) + 85 * 8
-    kernel_s = dev / a.steps
+    kernel_s = dev / (a.steps * L)  # per launch
     default_workload = (a.frames, a.refs, a.area) == (32, 4, "16x9")  # the workload the committed PMC passes were run on
     # areas up to 24x16 take the one-wave-per-item kernel (window pitch 18 or 26 dwords), larger ones the tiled workgroup kernel (csrc/sad.hip)
     me_kernel = "me_fullpel_wave_kernel<false, %d>" % (18 if (aw + 3) // 4 <= 2 else 26) if (aw <= 24 and ah <= 16) else "me_fullpel_kernel<false>"
-    rf = roofline(n * bytes_item, kernel_s, me_kernel, None if default_workload else "-", kernel_ms=kernel_s * 1e3,
+    rf = roofline(n * bytes_item, kernel_s, me_kernel, None if (default_workload or LIVE_PMC is not None) else "-", kernel_ms=kernel_s * 1e3,
                   algorithmic_bytes_per_sb_ref=bytes_item,
                   note="search is VALU(packed-SAD)-bound, see valu_frac; HBM figure = SURVEY 8(d) algorithmic bytes / time",
                   sad_ops_per_s=n * aw * ah * 4096 / kernel_s,
@@ -759,7 +943,8 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "configs[1]: batched open-loop ME integer full-pel search (SAD 8x8..64x64), 1080p 8-bit, all 64x64 SBs",
-                   "frames_per_step_per_gpu": a.frames, "refs": a.refs, "search_area": a.area, "sb_refs_per_step_per_gpu": n,
+                   "launches_per_step": L, "frames_per_launch_per_gpu": a.frames, "frames_per_step_per_gpu": a.frames * L, "refs": a.refs, "search_area": a.area,
+                   "sb_refs_per_launch_per_gpu": n, "sb_refs_per_step_per_gpu": n * L, "timed_region_s": wall,
                    "sub_sad": 0, "parallelism": "frame-sharded x%d (no collective)" % world, "mode": a.mode},
         "parity_checked_values": me_checked, "roofline": rf, "frame_partition": fp,
     }
@@ -769,11 +954,13 @@ def main():
         out["frames_mode_value"] = value
     kernels = {}
     cpu = rank == 0 and world == 1 and not a.no_cpu
+    import bench_legs
+    bench_legs.MIN_S = a.min_leg_s
     if not a.only_me:
         kernels["sad64x64_pairs"] = bench_sad_pairs(torch, lib, pkg, stream, a, cpu)
         kernels.update(bench_fwd_txfm(torch, lib, pkg, stream, a, cpu))
+        kernels["config3_roundtrip"] = bench_config3(torch, lib, pkg, stream, a)
         kernels.update(bench_cdef(torch, lib, pkg, stream, a, cpu))
-        import bench_legs
         lr_checked = check_lr_small(torch, lib, pkg, stream)
         lr = bench_legs.lr_frames(torch, lib, pkg, stream, max(a.steps // 10, 4), 2)
         for v in lr.values():
@@ -829,10 +1016,33 @@ def main():
     if cpu:
         host_descs = pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, aw, ah, PLANE, n_refs=1, src_plane=0, ref_plane0=1)
         out["cpu_baseline"] = cpu_me_baseline(host_descs, planes, planes, (aw, ah), budget_s=10.0)
+        out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if not a.only_me:
             out["encoder_fps_1080p_preset8"] = encoder_fps()
     elif rank == 0:
         out["cpu_baseline"] = None
+    # The claims of north_star inside the two objects every record of this line keeps (a tail-truncated stdout loses `kernels`): per kernel the HBM fraction by
+    # the contract formula, moved bytes / algorithmic bytes from this run's PMC passes, and the reference's AVX2 figure on the host cores beside the GPU's.
+    rf["traffic_source"] = (rf.get("traffic_detail") or {}).get("source")
+    rf["pmc_seconds"] = (LIVE_PMC or {}).get("_seconds")
+    rf["kernels"] = {}
+    for name, k in kernels.items():
+        r = k.get("roofline") if isinstance(k, dict) else None
+        if r:
+            rf["kernels"][name] = {"kernel": r["kernel"], "frac": round(r["frac"], 4), "GBps": round(r["achieved"], 1), "us": round(r["kernel_us"], 2),
+                                   "moved_over_algorithmic": round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3) if r.get("traffic") else None}
+    if "sad64x64_pairs" in kernels:  # the kernel north_star's ">= 50 % of HBM on the SAD path" applies to
+        rf["sad_path_hbm_frac"] = kernels["sad64x64_pairs"]["roofline"]["frac"]
+    if "config3_roundtrip" in kernels:
+        rf["kernels"]["config3_roundtrip"] = {"sizes_checked_vs_oracle": kernels["config3_roundtrip"]["sizes_checked"],
+                                              "hbm_frac_min_max": kernels["config3_roundtrip"]["hbm_frac_min_max"]}
+    if out.get("cpu_baseline"):
+        cb = out["cpu_baseline"]["kernels"] = {}
+        for name, k in kernels.items():
+            c = k.get("cpu_baseline") if isinstance(k, dict) else None
+            if c and "value" in k:
+                cb[name] = {"cpu": round(c["value"], 2), "gpu": round(k["value"], 1), "gpu_over_cpu": round(k["value"] / c["value"], 1), "unit": c["unit"], "cores": c["cores"],
+                            "kind": c["kind"]}
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

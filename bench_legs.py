@@ -8,11 +8,23 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0
 
 
+MIN_S = 0.3  # bench.py sets this from --min-leg-s: every leg is timed over at least this much device time
+
+
 def _time(torch, fn, steps, warmup, batches=5):
-    """seconds per call: median over `batches` event-timed runs of `steps` back-to-back launches (short kernels see clock ramps)"""
-    for _ in range(warmup):
+    """seconds per call: median over `batches` event-timed runs of back-to-back launches; `steps` per run is raised until the runs together last >= MIN_S
+    (short kernels see clock ramps and the ~5 us dispatch gap otherwise)"""
+    import math
+    for _ in range(max(warmup, 1)):
         fn()
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    t1 = max(e0.elapsed_time(e1) / 1e3, 1e-7)
+    steps = max(steps, int(math.ceil(MIN_S / batches / t1))) if MIN_S > 0 else steps
     ts = []
     for _ in range(batches):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

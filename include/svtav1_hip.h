@@ -31,6 +31,8 @@ extern "C" {
 int         svt_hip_init(int device);
 void        svt_hip_shutdown(void);
 const char *svt_hip_device_name(void);
+/* The measurement knobs SVT_HIP_LR_UR / SVT_HIP_CDEF_GPW are read from the environment once, at first use; this re-reads them (tests that sweep a knob). */
+void svt_hip_tuning_reload(void);
 /* Overwrite the reference's RTCD pointers (weak symbols; present only when linked into libSvtAv1Enc) with the
  * `_hip` variants.  Call right after svt_aom_setup_rtcd_internal() (Source/Lib/Globals/enc_handle.c:1444-1445).
  * Returns the number of pointers installed. */
@@ -117,7 +119,9 @@ void svt_pme_sad_loop_kernel_hip(const SvtHipMvCostParams *mv_cost_params, uint8
  * build -> svt_hip_me_fullpel_search_batch over every 64x64 SB x n_refs, search centre (0, 0) -> result download), so the copies of one picture overlap
  * the search of another.  Host buffers should come from svt_hip_host_alloc (pinned) for the copies to be asynchronous.
  * submit returns a slot (>= 0) to wait on; -1: a reference (or the unsent source) is not resident, -2: n_refs > max_refs, -3: ring too small.
- * Results: best_sad_host / best_mv_host [n_refs][SBs][85], valid after svt_hip_me_session_wait(slot). */
+ * Results: best_sad_host / best_mv_host [n_refs][SBs][85], valid after svt_hip_me_session_wait(slot).
+ * THREADING: a session is NOT internally synchronised -- submit / invalidate / resident / wait of one session must be serialised by the caller (the ME
+ * seam holds its picture lock around them); different sessions are independent.  A re-upload after invalidate reuses the freed ring entry. */
 void *svt_hip_host_alloc(size_t bytes);
 void  svt_hip_host_free(void *p);
 void *svt_hip_me_session_create(uint32_t width, uint32_t height, uint32_t stride, uint32_t org_x, uint32_t org_y, uint32_t rows, uint32_t ring_planes,
@@ -819,7 +823,9 @@ typedef struct SvtHipLrPrevUnit { /* wn_filter_ctrls.use_prev_frame_coeffs (:129
 } SvtHipLrPrevUnit;
 size_t svt_hip_lr_search_workspace(const SvtHipLrSearchParams *params); /* bytes (includes 8 B per sample and self-guided parameter set searched) */
 /* prev: device, [units] or NULL.  Synchronises `stream` internally (the lock-step Wiener refinement reads the number of units still searching back every
- * eight steps).  Returns 0, or -1 for parameters outside the reference's ranges. */
+ * eight steps).  Returns 0, -1 for parameters outside the reference's ranges, or -2 when the lock-step Wiener refinement hit its 4096-step cap with units
+ * still searching (results of the plane must then not be used; the reference's own loops are bounded far below that).  sse[1] / sse[2] of a tool that is
+ * disabled (wn_enabled / sg_enabled == 0) are 0 and carry no meaning: callers read them only for enabled tools (as integration/rest_process_seam.c does). */
 int svt_hip_lr_search_plane(const SvtHipLrSearchParams *params, const SvtHipLrPrevUnit *prev, SvtHipLrSearchUnit *units, void *workspace, void *stream);
 /* The same from HOST planes (what a seam around restoration_seg_search, rest_process.c:612, calls once per plane): dgd / src / prev / units are host pointers,
  * dgd readable 3 rows above / below and 3 (left) / 4 (right) samples beside the plane; uploads, runs on the calling thread's stream, downloads. */

@@ -1,4 +1,4 @@
-/* dlf_process_seam.c -- TEST / BASELINE INFRASTRUCTURE: the reference's deblocking process with the frame-filter seam of INTEGRATION.md §3.
+/* dlf_process_seam.c -- REFERENCE-SIDE BINDING (what a maintainer of the reference adds; built into the reference encoder by oracle/Makefile for the identity / fps runs): the reference's deblocking process with the frame-filter seam of INTEGRATION.md §3.
  *
  * This translation unit IS Source/Lib/Codec/dlf_process.c of the reference (included below where it lies; nothing is copied).  The one change: the call
  *

@@ -1,4 +1,4 @@
-/* enc_handle_binding.c -- TEST / BASELINE INFRASTRUCTURE: the reference encoder with the binding of INTEGRATION.md §1.
+/* enc_handle_binding.c -- REFERENCE-SIDE BINDING (what a maintainer of the reference adds; built into the reference encoder by oracle/Makefile for the identity / fps runs): the reference encoder with the binding of INTEGRATION.md §1.
  *
  * This translation unit IS Source/Lib/Globals/enc_handle.c of the reference (included below where it lies; nothing is copied)
  * plus the few lines a maintainer adds after enc_handle.c:1444-1445, where svt_av1_enc_init() assigns the run-time dispatch

@@ -1,4 +1,4 @@
-/* me_process_seam.c -- TEST / BASELINE INFRASTRUCTURE: the reference's open-loop ME process with the per-picture batching seam of
+/* me_process_seam.c -- REFERENCE-SIDE BINDING (what a maintainer of the reference adds; built into the reference encoder by oracle/Makefile for the identity / fps runs): the reference's open-loop ME process with the per-picture batching seam of
  * INTEGRATION.md §3.
  *
  * This translation unit IS Source/Lib/Codec/me_process.c of the reference (included below where it lies; nothing is copied).  The one
@@ -393,7 +393,7 @@ static EbErrorType seam_motion_estimation_b64(PictureParentControlSet *pcs, uint
 
 
 /* ---- the temporal filter's ME (temporal_filtering.c:3180: svt_aom_motion_estimation_b64 with me_type == ME_MCTF, one reference per call) ---------------------------
- * temporal_filtering.c enters the encoder library through ref_wrap/temporal_filtering_seam.c, which renames that one call to the function below.  With
+ * temporal_filtering.c enters the encoder library through integration/temporal_filtering_seam.c, which renames that one call to the function below.  With
  * SVT_HIP_TF_ME_SEAM=1 the first 64x64 block of a (central picture, reference picture) pair to arrive runs the stage for ALL blocks of the pair in its ME_MCTF
  * form (unscaled distance, tf_me_exit_th, no pruning, raw tables) and every block then receives what the reference's call leaves in the MeContext for the
  * temporal filter: search_results[0][0].hme_sc_x / hme_sc_y / hme_sad, the tf_tot_horz_blks / tf_tot_vert_blks vote (motion_estimation.c:2469-2474), the early
@@ -499,7 +499,7 @@ EbErrorType svt_hip_seam_tf_motion_estimation_b64(PictureParentControlSet *pcs, 
 }
 
 
-/* the pair's whole-picture tables for the sub-pel seam (ref_wrap/temporal_filtering_seam.c); copied out under the lock.  best_mv: [n_sb][85], hme_sc: [n_sb][2],
+/* the pair's whole-picture tables for the sub-pel seam (integration/temporal_filtering_seam.c); copied out under the lock.  best_mv: [n_sb][85], hme_sc: [n_sb][2],
  * hme_sad: [n_sb].  0 when the pair did not go through the stage. */
 int svt_hip_seam_tf_pair_tables(PictureParentControlSet *pcs, uint64_t ref_number, uint32_t n_sb, uint32_t *best_mv, int16_t *hme_sc, uint64_t *hme_sad) {
     int ok = 0;

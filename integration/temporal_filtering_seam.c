@@ -1,9 +1,9 @@
-/* temporal_filtering_seam.c -- TEST / BASELINE INFRASTRUCTURE: the reference's temporal filter with two seams.
+/* temporal_filtering_seam.c -- REFERENCE-SIDE BINDING (what a maintainer of the reference adds; built into the reference encoder by oracle/Makefile for the identity / fps runs): the reference's temporal filter with two seams.
  *
  * This translation unit IS Source/Lib/Codec/temporal_filtering.c of the reference (included below where it lies; nothing is copied).  Two calls are renamed for
  * the duration of the #include:
  *
- * 1. svt_aom_motion_estimation_b64(centre_pcs, ...) (:3180, me_type == ME_MCTF) lands in svt_hip_seam_tf_motion_estimation_b64() (ref_wrap/me_process_seam.c,
+ * 1. svt_aom_motion_estimation_b64(centre_pcs, ...) (:3180, me_type == ME_MCTF) lands in svt_hip_seam_tf_motion_estimation_b64() (integration/me_process_seam.c,
  *    which owns the device session and the picture ring).  With SVT_HIP_TF_ME_SEAM unset that function IS the reference call.
  *
  * 2. tf_subpel_search(...) -- `static`, defined at :1670 and called from tf_64x64_ / tf_32x32_ / tf_16x16_ / tf_8x8_sub_pel_search (:1886, :1998, :2118, :2237).

@@ -38,6 +38,7 @@ PROTOTYPES = {
     "svt_hip_init": (C.c_int, [C.c_int]),
     "svt_hip_shutdown": (None, []),
     "svt_hip_device_name": (C.c_char_p, []),
+    "svt_hip_tuning_reload": (None, []),
     "svt_hip_setup_rtcd": (C.c_int, [C.c_uint64]),
     "svt_hip_selftest": (C.c_int, [vp, vp]),
     "svt_hip_rate_probe": (None, [C.c_int, C.c_uint32, C.c_uint32, vp, vp]),
@@ -230,7 +231,8 @@ class HmeLevelParams(C.Structure):
 
 
 class HmeChainInputs(C.Structure):
-    _fields_ = [("zz_sad", vp), ("do_ref", vp), ("prehme", vp), ("prev_me_stage_based_exit_th", C.c_uint32), ("pad", C.c_uint32)]
+    _fields_ = [("zz_sad", vp), ("do_ref", vp), ("prehme", vp), ("prev_me_stage_based_exit_th", C.c_uint32), ("n_levels", C.c_uint8), ("list1_no_hme", C.c_uint8),
+                ("pad", C.c_uint8 * 2)]
 
 
 class PrehmeParams(C.Structure):
@@ -249,7 +251,7 @@ class MeIntegerSearchParams(C.Structure):
     _fields_ = [("sbs_x", C.c_uint32), ("sbs_y", C.c_uint32), ("n_refs", C.c_uint32), ("regions", C.c_uint32), ("aligned_width", C.c_uint32),
                 ("aligned_height", C.c_uint32), ("sa_min_width", C.c_int16), ("sa_min_height", C.c_int16), ("sa_max_width", C.c_int16),
                 ("sa_max_height", C.c_int16), ("sub_sad", C.c_uint8), ("mv_adj_enabled", C.c_uint8), ("mv_adj_nearest_ref_only", C.c_uint8),
-                ("pad0", C.c_uint8), ("mv_adj_mv_size_th", C.c_uint16), ("mv_adj_sa_multiplier", C.c_uint16), ("dist", C.c_uint16 * 8),
+                ("list1_no_hme", C.c_uint8), ("mv_adj_mv_size_th", C.c_uint16), ("mv_adj_sa_multiplier", C.c_uint16), ("dist", C.c_uint16 * 8),
                 ("ref_pic_index", C.c_uint8 * 8), ("src_off", C.c_uint64), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32),
                 ("ref_org_x", C.c_uint32), ("ref_org_y", C.c_uint32), ("ref_off", C.c_uint64 * 8), ("n_refs_list0", C.c_uint8),
                 ("hme_prune_enabled", C.c_uint8), ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16), ("sr_adjustment", C.c_uint8), ("pad2", C.c_uint8),

@@ -668,9 +668,8 @@ template <int MODE> void launch_frame(const SvtHipCdefParams& P, hipStream_t st,
     // search: four groups of four primary levels; a workgroup takes gpw of them on one staged tile as long as >= 4096 workgroups remain (256 CUs x 4 x 4 rounds)
     int gpw = 1;
     if (MODE == 1) {
-        const char* e = getenv("SVT_HIP_CDEF_GPW"); // (measurement override)
-        gpw = e ? atoi(e) : (nhfb * nvfb >= 2040 ? 4 : (nhfb * nvfb >= 1020 ? 2 : 1)); // 4K luma: 378 us with 4, 386 with 2, 418 with 1 (profiles/r02_call8_*)
-        gpw = gpw == 4 ? 4 : (gpw == 2 ? 2 : 1);
+        const int e = svthip::tuning_cdef_groups_per_workgroup(); // SVT_HIP_CDEF_GPW (measurement override, read once)
+        gpw = e ? e : (nhfb * nvfb >= 2040 ? 4 : (nhfb * nvfb >= 1020 ? 2 : 1)); // 4K luma: 378 us with 4, 386 with 2, 418 with 1 (profiles/r02_call8_*)
     }
     const dim3 grid(nhfb * nvfb, MODE == 1 ? 4 / gpw : 1);
     if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
@@ -700,8 +699,8 @@ void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost* a) {
     const uint32_t nhfb = (a->width + 63) / 64, nvfb = (a->height + 63) / 64, nfb = nhfb * nvfb;
     size_t pitch[3], rows[3], wid[3], total = 0;
     for (int p = 0; p < a->num_planes; p++) {
-        wid[p]   = p ? a->width >> 1 : a->width;
-        rows[p]  = p ? a->height >> 1 : a->height;
+        wid[p]   = p ? (a->width + 1) >> 1 : a->width; // 4:2:0 chroma of an odd luma size: (w + ss_x) >> ss_x, as the reference's picture buffers
+        rows[p]  = p ? (a->height + 1) >> 1 : a->height;
         pitch[p] = svthip::align_up(wid[p] * px, 16);
         total += 2 * pitch[p] * rows[p];
     }
@@ -712,7 +711,10 @@ void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost* a) {
     uint8_t* d_skip = (uint8_t*)c.dalloc((size_t)nvfb * 8 * nhfb * 8);
     int32_t* d_str[4];
     const int32_t* h_str[4] = {a->pri_y, a->sec_y, a->pri_uv, a->sec_uv};
-    for (int k = 0; k < 4; k++) { d_str[k] = (int32_t*)c.dalloc((size_t)nfb * 4); c.up(d_str[k], h_str[k], (size_t)nfb * 4); }
+    for (int k = 0; k < (a->num_planes > 1 ? 4 : 2); k++) { // a monochrome caller (num_planes == 1) passes no chroma strengths
+        d_str[k] = (int32_t*)c.dalloc((size_t)nfb * 4);
+        c.up(d_str[k], h_str[k], (size_t)nfb * 4);
+    }
     uint8_t* d_dir = (uint8_t*)c.dalloc((size_t)nfb * 64);
     int32_t* d_var = (int32_t*)c.dalloc((size_t)nfb * 64 * 4);
     c.up(d_skip, a->skip, (size_t)nvfb * 8 * nhfb * 8);
@@ -743,8 +745,8 @@ void svt_hip_cdef_search_host(const SvtHipCdefSearchHost* a) {
     const uint32_t nhfb = (a->width + 63) / 64, nvfb = (a->height + 63) / 64, nfb = nhfb * nvfb;
     size_t pitch[3], rows[3], wid[3], total = 0;
     for (int p = 0; p < 3; p++) {
-        wid[p]   = p ? a->width >> 1 : a->width;
-        rows[p]  = p ? a->height >> 1 : a->height;
+        wid[p]   = p ? (a->width + 1) >> 1 : a->width;
+        rows[p]  = p ? (a->height + 1) >> 1 : a->height;
         pitch[p] = svthip::align_up(wid[p] * px, 16);
         total += 2 * pitch[p] * rows[p];
     }

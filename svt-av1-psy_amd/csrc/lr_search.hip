@@ -672,6 +672,7 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
             hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<1>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
         }
         SVT_LAUNCH_CHECK();
+        if (active > 0) return -2; // the lock-step cap was hit with units still searching: their sse[1] is not final -- the caller must not use this plane's result
     }
     if (P.sg_enabled && slots > 0) {
         const dim3 fgrid(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, slots);

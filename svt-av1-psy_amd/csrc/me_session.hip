@@ -184,8 +184,11 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
     }
     if (src_r < 0) {
         if (!plane_host) return -1;
-        // pick the next ring slot that is not one of this picture's references
-        for (uint32_t tries = 0; tries < s->ring; tries++) {
+        // a freed entry first (svt_hip_me_session_invalidate left id -1 there: re-uploading an invalidated picture must not push a live reference out of the
+        // ring), otherwise the next ring slot that is not one of this picture's references
+        for (uint32_t r = 0; r < s->ring && src_r < 0; r++)
+            if (s->ids[r] == -1) src_r = (int)r;
+        for (uint32_t tries = 0; tries < s->ring && src_r < 0; tries++) {
             const uint32_t r = (s->next_ring + tries) % s->ring;
             bool used = false;
             for (uint32_t k = 0; k < n_refs; k++) used |= ref_r[k] == (int)r;
@@ -421,12 +424,14 @@ int svt_hip_me_session_submit_stage(void* session, int64_t pic_id, const uint8_t
 // Forget a resident picture (its host content changed, e.g. after in-place temporal filtering): the next submission that names it as the source uploads it again.
 void svt_hip_me_session_invalidate(void* session, int64_t pic_id) {
     Session* s = (Session*)session;
+    if (!s) return;
     for (uint32_t r = 0; r < s->ring; r++)
         if (s->ids[r] == pic_id) s->ids[r] = -1;
 }
 // 1 when the picture is resident in the ring (usable as a reference), else 0
 int svt_hip_me_session_resident(void* session, int64_t pic_id) {
     Session* s = (Session*)session;
+    if (!s) return 0;
     for (uint32_t r = 0; r < s->ring; r++)
         if (s->ids[r] == pic_id) return 1;
     return 0;

@@ -178,8 +178,7 @@ void svt_hip_lr_filter_frame(const SvtHipLrParams* params, void* stream) {
     const int sh = 64 >> P.ss_y, off = 8 >> P.ss_y, cw = 64 >> P.ss_x;
     const int n_stripes = ((int)P.height + off + sh - 1) / sh;
     const int n_cols    = ((int)P.width + cw - 1) / cw;
-    const char* ur_s   = getenv("SVT_HIP_LR_UR"); // rows of a stripe per workgroup: 32 (default, the measured optimum), 16 or 64 (profiles/r02_lr_walk_experiment.txt)
-    const int   ur_env = ur_s ? atoi(ur_s) : 32;
+    const int ur_env = svthip::tuning_lr_rows_per_workgroup(); // SVT_HIP_LR_UR, read once: 32 (default, the measured optimum), 16 or 64 (profiles/r02_lr_walk_experiment.txt)
     const int us        = (int)P.unit_size;
     int       nvu = ((int)P.height + (us >> 1)) / us, nhu = ((int)P.width + (us >> 1)) / us, ushift = -1;
     nvu = nvu > 0 ? nvu : 1; nhu = nhu > 0 ? nhu : 1;

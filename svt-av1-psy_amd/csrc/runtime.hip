@@ -97,6 +97,23 @@ void HostCall::down2d(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch
 }
 void HostCall::sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
 
+static std::atomic<int> g_tune_lr_ur{-1}, g_tune_cdef_gpw{-1}; // -1: not read yet
+static void tuning_read() {
+    const char* a = getenv("SVT_HIP_LR_UR");
+    const char* b = getenv("SVT_HIP_CDEF_GPW");
+    const int   ur = a ? atoi(a) : 32, gp = b ? atoi(b) : 0;
+    g_tune_lr_ur    = (ur == 16 || ur == 64) ? ur : 32;
+    g_tune_cdef_gpw = (gp == 1 || gp == 2 || gp == 4) ? gp : 0;
+}
+int tuning_lr_rows_per_workgroup() {
+    if (g_tune_lr_ur < 0) tuning_read();
+    return g_tune_lr_ur;
+}
+int tuning_cdef_groups_per_workgroup() {
+    if (g_tune_cdef_gpw < 0) tuning_read();
+    return g_tune_cdef_gpw;
+}
+
 } // namespace svthip
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -200,6 +217,7 @@ void svt_hip_shutdown(void) {
 }
 
 const char* svt_hip_device_name(void) { return svthip::g_name; }
+void svt_hip_tuning_reload(void) { svthip::tuning_read(); }
 
 // ---- HIP graphs: every batched entry point only enqueues work on the stream it is given (no host synchronisation, no host-side state), so a
 // whole per-picture sequence (padding + decimations, the transform chain, the in-loop filter chain) can be captured once and replayed.

@@ -69,4 +69,9 @@ HostCall& host_call();
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Measurement knobs (environment table): read from the environment ONCE (first use) instead of getenv() on every launch -- getenv is hot-path
+// work and is not safe against a concurrent setenv in a multi-threaded encoder.  svt_hip_tuning_reload() re-reads them (tests that sweep a knob call it).
+int tuning_lr_rows_per_workgroup(); // SVT_HIP_LR_UR: 16 / 32 / 64, default 32
+int tuning_cdef_groups_per_workgroup(); // SVT_HIP_CDEF_GPW: 1 / 2 / 4, 0 = by frame size
+
 } // namespace svthip

@@ -393,8 +393,37 @@ void svt_av1_inv_txfm_add_u8_hip(const int32_t* dqcoeff, uint8_t* dst_r, int32_t
 // passes -- svt_aom_inv_transform_recon8bit, inv_transforms.c:3089-3113); tx_set_type is unused by the reference as well.
 void svt_av1_inv_txfm_add_hip(const int32_t* dqcoeff, uint8_t* dst_r, int32_t stride_r, uint8_t* dst_w, int32_t stride_w, const SvtHipTxfmParam* p) {
     if (p->bd != 8) {
-        fprintf(stderr, "libsvtav1_hip: svt_av1_inv_txfm_add with bd = %d on an 8-bit destination\n", p->bd);
-        abort();
+        // No caller passes this (svt_aom_inv_transform_recon8bit sets bd = 8), but the reference function is defined for it: widen the 8-bit destination
+        // to u16, run the high-bit-depth inverse with p->bd (clip at 2^bd - 1), narrow by truncation -- exactly svt_av1_inv_txfm_add_c's three steps.
+        const int w = kTxW[p->tx_size], h = kTxH[p->tx_size];
+        const int iw = w > 32 ? 32 : w, ih = h > 32 ? 32 : h;
+        svthip::HostCall& c = svthip::host_call();
+        c.begin();
+        const size_t pitch = svthip::align_up((size_t)w * 2, 16);
+        c.reserve((size_t)iw * ih * 4 + 2 * pitch * h + 4096, (size_t)iw * ih * 4 + 3 * pitch * h + 4096);
+        int32_t*           dco = (int32_t*)c.dalloc((size_t)iw * ih * 4);
+        uint16_t*          dpr = (uint16_t*)c.dalloc(pitch * h);
+        uint16_t*          drc = (uint16_t*)c.dalloc(pitch * h);
+        SvtHipInvTxfmDesc* dd  = (SvtHipInvTxfmDesc*)c.dalloc(sizeof(SvtHipInvTxfmDesc));
+        c.up(dco, dqcoeff, (size_t)iw * ih * 4);
+        uint16_t* wide = (uint16_t*)c.palloc(pitch * h);
+        for (int r = 0; r < h; r++)
+            for (int x = 0; x < w; x++) wide[r * (pitch / 2) + x] = dst_r[r * stride_r + x];
+        HIP_CHECK(hipMemcpyAsync(dpr, wide, pitch * h, hipMemcpyHostToDevice, c.stream));
+        SvtHipInvTxfmDesc d;
+        memset(&d, 0, sizeof(d));
+        d.pred_stride = d.recon_stride = (uint32_t)(pitch / 2);
+        d.tx_type  = (uint8_t)p->tx_type;
+        d.wht_full = p->eob > 1;
+        c.up(dd, &d, sizeof(d));
+        if (p->lossless && p->tx_size == 0) svt_hip_iwht4x4_add_batch(dco, dpr, drc, dd, 1, p->bd, c.stream);
+        else svt_hip_inv_txfm2d_add_batch(dco, dpr, drc, dd, 1, p->tx_size, p->bd, c.stream);
+        uint16_t* back = (uint16_t*)c.palloc(pitch * h);
+        HIP_CHECK(hipMemcpyAsync(back, drc, pitch * h, hipMemcpyDeviceToHost, c.stream));
+        c.sync();
+        for (int r = 0; r < h; r++)
+            for (int x = 0; x < w; x++) dst_w[r * stride_w + x] = (uint8_t)back[r * (pitch / 2) + x];
+        return;
     }
     svt_av1_inv_txfm_add_u8_hip(dqcoeff, dst_r, stride_r, dst_w, stride_w, p->tx_type, p->tx_size, p->lossless, p->eob);
 }

@@ -1,7 +1,7 @@
 """Integration-level parity (VERDICT r1 row g): the HIP variant installed in the REAL reference encoder must leave the
 bitstream byte-identical to the C-only encoder (and with it the reconstruction, a function of the bitstream) -- the reference's own CI invariant across ISA levels
 (.gitlab/workflows/linux/.gitlab-ci.yml:351-367).  oracle/_ref/enc/SvtAv1EncApp = the reference built C-only by oracle/Makefile
-with the binding of INTEGRATION.md §1 (oracle/ref_wrap/enc_handle_binding.c).
+with the binding of INTEGRATION.md §1 (integration/enc_handle_binding.c).
 
 CPU (`-m "not gpu"`): tiny clips through the lock-step emulator build of the same kernel sources.
 GPU (`-m gpu`): 256x144 clips, presets 4 / 6 / 8, 8- and 10-bit, --lp 1 / 2 / 4, quantisation matrices, lossless, through libsvtav1_hip.so;

@@ -159,6 +159,22 @@ def test_hme_three_level_chain_hip(be, oracle):
     be.lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(planes_p), C.addressof(planes_p), None, C.addressof(sad_p), C.addressof(sc_p), be.stream)
     for lv in range(3):
         assert np.array_equal(be.host(d_sads[lv]), fused[lv][2]) and np.array_equal(be.host(d_scs[lv]), fused[lv][3]), ("fused", lv)
+    # SvtHipHmeChainInputs by name: n_levels = 2 (enable_hme_level2_flag = 0: level 2 buffers untouched) and list1_no_hme = 1 (temporal layer 0: list 1's
+    # items -- the second reference here -- take no part in HME and their entries are left as the caller filled them)
+    for p_ in PA:
+        p_.n_refs_list0 = 1
+    X = pkg.HmeChainInputs()
+    X.n_levels, X.list1_no_hme = 2, 1
+    mark_sad, mark_sc = np.full(n, 0x1234567, np.uint64), np.full((n, 2), -77, np.int16)
+    d_sads, d_scs = [be.dev(mark_sad) for _ in range(3)], [be.dev(mark_sc) for _ in range(3)]
+    sad_p, sc_p = (C.c_void_p * 3)(*[be.ptr(x) for x in d_sads]), (C.c_void_p * 3)(*[be.ptr(x) for x in d_scs])
+    be.lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(planes_p), C.addressof(planes_p), C.addressof(X), C.addressof(sad_p), C.addressof(sc_p), be.stream)
+    l0 = n // n_refs  # items are reference-major: the first n / n_refs belong to list 0
+    for lv in range(2):
+        gs, gc = be.host(d_sads[lv]), be.host(d_scs[lv])
+        assert np.array_equal(gs[:l0], fused[lv][2][:l0]) and np.array_equal(gc[:l0], fused[lv][3][:l0]), ("two-level chain, list 0", lv)
+        assert np.array_equal(gs[l0:], mark_sad[l0:]) and np.array_equal(gc[l0:], mark_sc[l0:]), ("two-level chain, list 1 untouched", lv)
+    assert np.array_equal(be.host(d_sads[2]), mark_sad) and np.array_equal(be.host(d_scs[2]), mark_sc), "level 2 untouched"
 
 
 # ------------------------------------------------------------------ integer ME from HME results (set_final_seach_centre_sb + integer_search_b64)

@@ -113,10 +113,12 @@ def test_lr_host_forms(be, oracle, bd):
     import os
     for ur in ("32", "16", "64"):  # rows of a stripe per workgroup (SVT_HIP_LR_UR: 32 is the default; the other two instantiations stay covered)
         os.environ["SVT_HIP_LR_UR"] = ur
+        be.lib.svt_hip_tuning_reload()  # the knob is read once, not per launch
         try:
             work = plane.copy()
             L = pkg.LrParams(work.ctypes.data, above.ctypes.data, below.ctypes.data, work.ctypes.data, w, w, w, w, h, unit, 0, 0, int(bd > 8), bd, units.ctypes.data)
             be.lib.svt_hip_lr_filter_frame_host(C.byref(L))
         finally:
             del os.environ["SVT_HIP_LR_UR"]
+            be.lib.svt_hip_tuning_reload()
         assert np.array_equal(work, out), (ur, np.argwhere(work != out)[:5])

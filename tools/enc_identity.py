@@ -3,7 +3,7 @@
 
 The reference's own CI invariant is that every ISA level produces the same bitstream
 (/root/reference/.gitlab/workflows/linux/.gitlab-ci.yml:351-367).  oracle/_ref/enc/SvtAv1EncApp is the reference encoder built
-C-only by oracle/Makefile with the binding of INTEGRATION.md §1 (oracle/ref_wrap/enc_handle_binding.c): with SVT_HIP unset it is
+C-only by oracle/Makefile with the binding of INTEGRATION.md §1 (integration/enc_handle_binding.c): with SVT_HIP unset it is
 the `--asm c` encoder; with SVT_HIP=<device> svt_hip_setup_rtcd() overwrites the dispatch pointers right after
 enc_handle.c:1444-1445.  This script encodes a synthetic clip both ways and compares the .ivf byte by byte;
 SVT_HIP_COUNT gives the number of calls that went through every installed pointer.
@@ -32,7 +32,7 @@ CASES = {
     "p8_8bit_lossless": (128, 128, 4, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
     "p8_10bit_lossless": (128, 128, 4, 10, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
     "p6_8bit_qm_lp2": (256, 144, 6, 8, ["--preset", "6", "--lp", "2", "--enable-qm", "1", "--qm-min", "2", "--qm-max", "10"]),
-    # the open-loop ME stage as ONE device call per picture (oracle/ref_wrap/me_process_seam.c): SVT_HIP_ME_SEAM=1, parameters from the reference's own
+    # the open-loop ME stage as ONE device call per picture (integration/me_process_seam.c): SVT_HIP_ME_SEAM=1, parameters from the reference's own
     # svt_aom_sig_deriv_me for every picture; "+hook" = the per-call RTCD variants are installed as well
     "seam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+seam"]),
     # (10-bit preset 8 with --lp >= 2 is not used: the C-only reference encoder itself produces a different bitstream from run to run there -- 5 different
@@ -43,20 +43,20 @@ CASES = {
     "seam_p6_8bit_hook": (256, 144, 8, 8, ["--preset", "6", "--lp", "1", "+seam", "+hook"]),
     "seam_p10_8bit": (448, 264, 10, 8, ["--preset", "10", "--lp", "1", "+seam"]),
     "seam_p2_8bit": (256, 144, 6, 8, ["--preset", "2", "--lp", "1", "+seam"]),
-    # the per-unit half of the loop-restoration search as one device stage per plane (oracle/ref_wrap/rest_process_seam.c): SVT_HIP_LR_SEAM=1
+    # the per-unit half of the loop-restoration search as one device stage per plane (integration/rest_process_seam.c): SVT_HIP_LR_SEAM=1
     "lrseam_p4_8bit": (256, 144, 6, 8, ["--preset", "4", "--lp", "1", "+lrseam"]),
     "lrseam_p2_10bit": (256, 144, 5, 10, ["--preset", "2", "--lp", "1", "+lrseam"]),
     "lrseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "+lrseam"]),
     "lrseam_me_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+lrseam", "+seam"]),  # both seams at once
     "lrseam_p4_8bit_crf55": (448, 264, 6, 8, ["--preset", "4", "--lp", "1", "--crf", "55", "+lrseam"]),  # coarse quantisation: restoration wins more often
     "lrseam_p3_10bit_crf50": (256, 144, 5, 10, ["--preset", "3", "--lp", "1", "--crf", "50", "+lrseam"]),
-    # CDEF applied to the whole picture by one device call (oracle/ref_wrap/cdef_process_seam.c): SVT_HIP_CDEF_SEAM=1
+    # CDEF applied to the whole picture by one device call (integration/cdef_process_seam.c): SVT_HIP_CDEF_SEAM=1
     "cdefseam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+cdefseam"]),
     "cdefseam_p4_10bit": (256, 144, 6, 10, ["--preset", "4", "--lp", "1", "+cdefseam"]),
     "cdefseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "--crf", "45", "+cdefseam"]),
     "allseams_p5_8bit_lp2": (448, 264, 8, 8, ["--preset", "5", "--lp", "2", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
     "allseams_1080p_p6": (1920, 1080, 6, 8, ["--preset", "6", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
-    # the deblocking filter of a picture as one device call per plane, segments recorded from the reference's own driver (oracle/ref_wrap/dlf_process_seam.c)
+    # the deblocking filter of a picture as one device call per plane, segments recorded from the reference's own driver (integration/dlf_process_seam.c)
     "dlfseam_p5_8bit": (448, 264, 8, 8, ["--preset", "5", "--lp", "1", "+dlfseam"]),
     "dlfseam_p2_10bit": (256, 144, 5, 10, ["--preset", "2", "--lp", "1", "+dlfseam"]),
     "dlfseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "+dlfseam"]),
