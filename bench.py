@@ -138,14 +138,18 @@ def calibrate_launches(torch, fn, steps, min_s, dist=None):
     import math
     fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(3):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    t = max(e0.elapsed_time(e1) / 3e3, 1e-7)
-    L = max(1, int(math.ceil(min_s / (steps * t)))) if min_s > 0 else 1
+    t = 1.0
+    for reps in (3, 12):  # the second, longer probe runs at ramped clocks
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = max(e0.elapsed_time(e1) / (reps * 1e3), 1e-7)
+        if t * reps > 0.02 or min_s <= 0:
+            break
+    L = max(1, int(math.ceil(1.1 * min_s / (steps * t)))) if min_s > 0 else 1
     if dist is not None:
         tl = torch.tensor([L], dtype=torch.int64, device="cuda")
         dist.all_reduce(tl, op=dist.ReduceOp.MAX)
@@ -1028,9 +1032,15 @@ def main():
     rf["kernels"] = {}
     for name, k in kernels.items():
         r = k.get("roofline") if isinstance(k, dict) else None
-        if r:
-            rf["kernels"][name] = {"kernel": r["kernel"], "frac": round(r["frac"], 4), "GBps": round(r["achieved"], 1), "us": round(r["kernel_us"], 2),
-                                   "moved_over_algorithmic": round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3) if r.get("traffic") else None}
+        if r and "frac" in r:
+            e = {"bound": r.get("bound"), "frac": round(r["frac"], 4), "achieved": round(r["achieved"], 1), "unit": r.get("unit")}
+            if "kernel" in r:
+                e["kernel"] = r["kernel"]
+            if "kernel_us" in r:
+                e["us"] = round(r["kernel_us"], 2)
+            if r.get("traffic") and r.get("algorithmic_bytes_per_launch"):
+                e["moved_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
+            rf["kernels"][name] = e
     if "sad64x64_pairs" in kernels:  # the kernel north_star's ">= 50 % of HBM on the SAD path" applies to
         rf["sad_path_hbm_frac"] = kernels["sad64x64_pairs"]["roofline"]["frac"]
     if "config3_roundtrip" in kernels:

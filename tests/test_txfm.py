@@ -107,7 +107,8 @@ def test_txfm_single_call_symbols(be, oracle):
         tp[0] = (tt, ts, 0, 10, 0, 0, 64)
         g10, w10 = pred8.copy(), np.zeros(h * (w + 4), np.uint16)
         be.lib.svt_av1_inv_txfm_add_hip(p(packed), p(g10), w + 4, p(g10), w + 4, p(tp))
-        oracle.oracle_inv_txfm2d_add(p(packed), p(pred8.astype(np.uint16)), w + 4, p(w10), w + 4, tt, ts, 10)
+        pred16 = pred8.astype(np.uint16)  # (named: p() of a temporary would hand the oracle freed memory)
+        oracle.oracle_inv_txfm2d_add(p(packed), p(pred16), w + 4, p(w10), w + 4, tt, ts, 10)
         assert np.array_equal(g10[:h * (w + 4)].reshape(h, w + 4)[:, :w], w10.reshape(h, w + 4)[:, :w].astype(np.uint8)), (ts, "bd 10 on u8")
 
 
