@@ -885,6 +885,67 @@ void     svt_get_proj_subspace_hip(const uint8_t *src8, int32_t width, int32_t h
                                    int32_t use_highbitdepth, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride, int32_t *xq,
                                    const void *params);
 
+/* ------------------------------------------------ TPL dispenser, source-based half ---------------------------------------------
+ * tpl_mc_flow_dispenser_sb_generic (Codec/src_ops_process.c:519-969), the part that runs when pcs->tpl_src_data_ready == 0: per 16x16 (dispenser level 0) or
+ * 32x32 (level 1; complete 64x64 SBs only, :2048-2051) block of a picture the DC intra cost from SOURCE neighbours (:620-657), the SAD of every
+ * uni-directional ME candidate against its reference's source picture at the clamped full-pel vector (:761-890), the winner (:892) and, for NEWMV, the forward
+ * transform (N2 / N4 shape, rows subsampled by 1 << subsample_tx) + svt_av1_quantize_fp reconstruction error of its residual (get_quantize_error, :224-247).
+ * Output = exactly the TplSrcStats the reference stores per 16x16 cell (:958-967), which its own "else" branch (:969-977) consumes: a seam around
+ * tpl_mc_flow_dispenser (:1848) fills pa_me_data->tpl_src_stats_buffer from one call per picture and lets the reference run the reconstruction half.
+ * Covered option set = tpl levels 4 and 5 of set_tpl_params (initial_rc_process.c:343-378: every preset from M3 up): use_sad_in_src_search = 1, intra_mode_end = DC_PRED,
+ * subpel_depth = FULL_PEL, compute_rate = 0, scs->in_loop_ois = 1; the caller must run the reference's C for anything else.  8-bit pictures (the reference's TPL is
+ * 8-bit only: "10BIT not supported", :464). */
+typedef struct SvtHipTplRef {           /* one per rf_idx = list * 4 + ref_idx (= svt_get_ref_frame_type(list, ref_idx) - 1, :783) */
+    uint64_t plane_off;                 /* bytes from ref_base to the reference picture's buffer_y (tpl_ref_ds_ptr_array[list][ref].picture_ptr: input_padded_pic, :141) */
+    uint64_t picture_number;            /* tpl_ref_ds_ptr_array[list][ref].picture_number */
+    uint32_t stride, org_x, org_y;      /* stride_y, org_x, org_y of that picture */
+    uint16_t max_width, max_height;     /* its max_width / max_height (the vector clamp, :791-801) */
+    uint8_t  valid;                     /* 0: no such reference, or excluded: ref_tpl_group_idx > 0 && !base_pcs->tpl_valid_pic[idx] (:779-781) */
+    uint8_t  pad[3];
+} SvtHipTplRef;
+typedef struct SvtHipTplSrcParams {
+    uint32_t width, height;             /* pcs->enhanced_pic->width / height */
+    uint32_t aligned_width;             /* pcs->aligned_width: the statistics grid is ((aligned_width + 15) >> 4) cells wide (:552) */
+    uint32_t sbs_x, n_sb;               /* 64x64 SB grid of scs->b64_geom (raster); SBs cut by the aligned picture run at dispenser level 0 */
+    uint32_t src_stride;                /* enhanced_pic->stride_y */
+    uint64_t src_off;                   /* bytes from src_base to picture sample (0, 0) of enhanced_pic */
+    uint8_t  dispenser_search_level;    /* tpl_ctrls: 0 = 16x16 blocks, 1 = 32x32 */
+    uint8_t  subsample_tx;              /* 0, 1, 2: the transform sees every (1 << subsample_tx)-th row */
+    uint8_t  pf_shape;                  /* EB_TRANS_COEFF_SHAPE: 0 DEFAULT, 1 N2, 2 N4 */
+    uint8_t  disable_intra_pred;        /* tpl_ctrls.disable_intra_pred_nref && temporal_layer_index == hierarchical_levels (:557) */
+    uint8_t  i_slice;                   /* pcs->slice_type == I_SLICE: no ME candidates (:767) */
+    uint8_t  enable_me_16x16, enable_me_8x8; /* PU count of the ME tables: 85 / 21 / 5 */
+    uint8_t  max_cand, max_refs, max_l0; /* pa_me_data */
+    uint8_t  pad[2];
+    int16_t  quant_fp[2], round_fp[2], dequant[2]; /* quants_8bit.y_quant_fp / y_round_fp[qIndex], deq_8bit.y_dequant_qtx[qIndex] (DC, AC; :541-547) */
+    SvtHipTplRef refs[8];
+} SvtHipTplSrcParams;
+typedef struct SvtHipTplSrcStats {      /* TplSrcStats (coding_unit.h:323-331) with explicit layout */
+    int64_t  srcrf_dist, srcrf_rate;
+    uint64_t ref_frame_poc;
+    int16_t  mv_row, mv_col;            /* MV in 1/8 sample units */
+    int32_t  best_rf_idx;               /* -1: no inter candidate */
+    uint8_t  best_mode;                 /* PredictionMode: DC_PRED (0) or NEWMV (16) */
+    uint8_t  best_intra_mode;           /* DC_PRED */
+    uint8_t  written;                   /* 1 for cells the reference writes (at least half of the block inside the picture, :580), else the cell is left untouched */
+    uint8_t  pad[5];
+} SvtHipTplSrcStats;
+/* Device form: total_me_candidate_index / me_mv_array / me_candidate_array as svt_hip_me_results_batch writes them ([n_sb][n_pus], [n_sb][n_pus * max_refs],
+ * [n_sb][n_pus * max_cand]); stats [rows16][cols16] with cols16 = (aligned_width + 15) >> 4 -- only the cells of processed blocks are written. */
+void svt_hip_tpl_src_stage(const SvtHipTplSrcParams *params, const uint8_t *src_base, const uint8_t *ref_base, const uint8_t *total_me_candidate_index,
+                           const uint32_t *me_mv_array, const uint8_t *me_candidate_array, SvtHipTplSrcStats *stats, void *stream);
+/* Host form (what the seam calls once per picture): every pointer is a host pointer.  src_buf / ref_buf[rf_idx] = start of each picture's luma buffer, *_rows the
+ * rows it holds (stride x rows bytes are uploaded; references that share a buffer are uploaded once); params->src_off and refs[].plane_off are offsets INSIDE
+ * those buffers.  stats: host, [rows16 * cols16], zero-filled for cells no block writes.  Returns 0, or -1 for an option set outside the covered one. */
+typedef struct SvtHipTplHostPlanes {
+    const uint8_t *src_buf;
+    uint32_t       src_rows;
+    uint32_t       ref_rows[8];
+    const uint8_t *ref_buf[8];
+} SvtHipTplHostPlanes;
+int svt_hip_tpl_src_stage_host(const SvtHipTplSrcParams *params, const SvtHipTplHostPlanes *planes, const uint8_t *total_me_candidate_index,
+                               const uint32_t *me_mv_array, const uint8_t *me_candidate_array, SvtHipTplSrcStats *stats);
+
 #ifdef __cplusplus
 }
 #endif

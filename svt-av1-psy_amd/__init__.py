@@ -39,6 +39,8 @@ PROTOTYPES = {
     "svt_hip_shutdown": (None, []),
     "svt_hip_device_name": (C.c_char_p, []),
     "svt_hip_tuning_reload": (None, []),
+    "svt_hip_tpl_src_stage": (None, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    "svt_hip_tpl_src_stage_host": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "svt_hip_setup_rtcd": (C.c_int, [C.c_uint64]),
     "svt_hip_selftest": (C.c_int, [vp, vp]),
     "svt_hip_rate_probe": (None, [C.c_int, C.c_uint32, C.c_uint32, vp, vp]),

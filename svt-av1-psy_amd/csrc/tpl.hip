@@ -1,0 +1,297 @@
+// tpl.hip -- the SOURCE-BASED half of the TPL dispenser as one device stage per picture.
+//
+// Reference: tpl_mc_flow_dispenser_sb_generic, Codec/src_ops_process.c:519-969 (tpl levels 4 / 5 of initial_rc_process.c:343-378: SAD costs, DC intra only,
+// full-pel vectors, no rate).  Per 16x16 / 32x32 block: DC intra cost from source neighbours, SAD of every uni-directional ME candidate at its clamped vector,
+// the winner, and for NEWMV the forward transform (partial-frequency shape, subsampled rows) + svt_av1_quantize_fp reconstruction error of the residual.
+// Blocks only read source pictures, the ME tables and the quantizer row: they are independent, so a picture is ONE launch (two at level 1: 32x32 blocks of the
+// complete SBs, 16x16 blocks of the SBs the picture edge cuts).
+//
+// Mapping: SIZE lanes per block (lane t owns row t of the block, then column t / row t of the transform), 256 / SIZE blocks per workgroup.  A row is one or two
+// unaligned 16-byte loads kept in registers for the whole block; costs are v_sad_u8 on the raw dwords reduced over the block's lanes with shuffles (the lanes of a
+// block are contiguous inside one wave); the best candidate's reference row stays in registers, so the residual needs no second fetch.  The residual goes through
+// the transform tile in LDS exactly like fwd_txfm2d_kernel (txfm.hip) -- same 1-D flow graphs (txfm_core.h), same shifts -- and the kept corner is quantised and
+// compared in registers (quant_core.h is not needed: quantize_fp at log_scale 0 without matrices is three lines).  HBM traffic = the picture once + one block
+// row set per candidate; at 1080p (8 160 blocks x ~5 candidates) the launch is latency-sized -- the point of the stage is to take the work off the host.
+#include "svt_hip_common.h"
+#include "../../include/svtav1_hip.h"
+#include "txfm_core.h"
+
+namespace {
+
+struct __attribute__((packed, aligned(1))) tpl_u32x4_a1 { uint32_t x, y, z, w; }; // 16 bytes at any byte address
+
+constexpr int TPL_PAD = 32;          // TPL_PADX / TPL_PADY (encode_context.h:43-44)
+constexpr int TPL_NEWMV = 16;        // PredictionMode NEWMV (definitions.h:1143); DC_PRED = 0
+constexpr int TPL_COST_SCALE_LOG2 = 4; // TPL_DEP_COST_SCALE_LOG2 (definitions.h:49)
+
+template <int T> __device__ __forceinline__ uint32_t group_sum(uint32_t v) { // sum over the T contiguous lanes of a block; every lane gets the total
+#pragma unroll
+    for (int m = T >> 1; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m);
+    return v;
+}
+template <int NW> __device__ __forceinline__ void load_row(uint32_t (&r)[NW], const uint8_t* p) {
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) {
+        const tpl_u32x4_a1 v = *(const tpl_u32x4_a1*)(p + 16 * i);
+        r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+    }
+}
+template <int NW> __device__ __forceinline__ uint32_t row_sad(const uint32_t (&a)[NW], const uint32_t (&b)[NW]) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) s = __builtin_amdgcn_sad_u8(a[i], b[i], s);
+    return s;
+}
+
+// SIZE: block edge (16 / 32); TXH: rows the transform sees (SIZE >> subsample_tx); ONLY_INCOMPLETE: 0 = every SB (level 0), 1 = SBs the picture edge cuts
+// (level 1, second launch); for SIZE 32 only complete SBs are processed.
+template <int SIZE, int TXH>
+__global__ __launch_bounds__(256) void tpl_src_kernel(const SvtHipTplSrcParams P, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                      const uint8_t* __restrict__ tot_base, const uint32_t* __restrict__ mv_base, const uint8_t* __restrict__ cand_base,
+                                                      SvtHipTplSrcStats* __restrict__ stats, const int only_incomplete) {
+    constexpr int T = SIZE, BPW = 256 / T, W = SIZE, PITCH = W + 1, NW = SIZE / 4, PER = 64 / SIZE, ST = SIZE == 2 * TXH ? 1 : (SIZE == 4 * TXH ? 2 : 0);
+    constexpr int FS0 = fwd_shift0(W, TXH), FS1 = -fwd_shift1(W, TXH), FS2 = -fwd_shift2(W, TXH);
+    constexpr int CBC = kFwdCosCol[ilog2c(W) - 2][ilog2c(TXH) - 2], CBR = kFwdCosRow[ilog2c(W) - 2][ilog2c(TXH) - 2];
+    constexpr bool RECT1 = (W == 2 * TXH) || (TXH == 2 * W);
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    __shared__ SvtHipTplRef s_refs[8]; // indexed per lane below: a run-time index into the kernel-argument struct would put the table in scratch
+    if (threadIdx.x < 8) s_refs[threadIdx.x] = P.refs[threadIdx.x];
+    __syncthreads();
+    const int      tid = threadIdx.x, sub = tid / T, t = tid % T;
+    const uint32_t item = blockIdx.x * BPW + sub, sb = item / (PER * PER), k = item % (PER * PER);
+    int32_t*       buf = smem + sub * (TXH * PITCH);
+    const int      aligned_h = (int)((P.height + 7) & ~7u);
+    bool           active = sb < P.n_sb;
+    const int      sx = (int)(sb % P.sbs_x) * 64, sy = (int)(sb / P.sbs_x) * 64;
+    const bool     complete = ((int)P.aligned_width - sx >= 64) && (aligned_h - sy >= 64);
+    if (SIZE == 32) active = active && complete;
+    else if (only_incomplete) active = active && !complete;
+    const int bx = (int)k % PER, by = (int)k / PER, x0 = sx + bx * SIZE, y0 = sy + by * SIZE;
+    active = active && !(x0 + (SIZE >> 1) > (int)P.width || y0 + (SIZE >> 1) > (int)P.height); // at least half of the block inside (:580)
+    const int n_pus = P.enable_me_8x8 ? 85 : (P.enable_me_16x16 ? 21 : 5);
+    int       pu    = SIZE == 32 ? 1 + by * 2 + bx : 5 + by * 4 + bx; // tpl_blk_idx_tab[1] (:355): z-order block -> raster PU of the ME tables
+    if (!P.enable_me_16x16) pu = (pu - 1) / 4;                          // :762-763
+    const uint32_t ss  = P.src_stride;
+    const uint8_t* src = src_base + P.src_off;
+    uint32_t       srow[NW], brow[NW];
+#pragma unroll
+    for (int i = 0; i < NW; i++) { srow[i] = 0; brow[i] = 0; }
+    // ---- intra: DC from the source's neighbours (:620-657; border forms of svt_aom_update_neighbor_samples_array_open_loop_mb: fill values 127 / 129) ----
+    uint32_t best_intra = 0xffffffffu; // (INT64_MAX in the reference; every SAD is < 2^24)
+    if (active) load_row<NW>(srow, src + (size_t)(y0 + t) * ss + x0);
+    {
+        uint32_t a = 0, l = 0;
+        if (active && !P.disable_intra_pred) {
+            if (y0 > 0) a = (x0 + t < (int)P.width) ? src[(size_t)(y0 - 1) * ss + x0 + t] : 127u;
+            if (x0 > 0) l = (y0 + t < (int)P.height) ? src[(size_t)(y0 + t) * ss + x0 - 1] : 129u;
+        }
+        const uint32_t sa = group_sum<T>(a), sl = group_sum<T>(l);
+        uint32_t dc;
+        if (x0 > 0 && y0 > 0) dc = (sa + sl + SIZE) / (2 * SIZE);
+        else if (x0 > 0) dc = (sl + (SIZE >> 1)) / SIZE;
+        else if (y0 > 0) dc = (sa + (SIZE >> 1)) / SIZE;
+        else dc = 128;
+        uint32_t dcrow[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) dcrow[i] = dc * 0x01010101u;
+        const uint32_t s = group_sum<T>(row_sad<NW>(srow, dcrow));
+        if (active && !P.disable_intra_pred) best_intra = s;
+    }
+    // ---- inter: the PU's uni-directional candidates in table order, first strict minimum (:761-890) ----
+    uint32_t best_inter = 0xffffffffu;
+    int      best_rf = -1, mvr = 0, mvc = 0;
+    const int n_cand = (active && !P.i_slice) ? (int)tot_base[(size_t)sb * n_pus + pu] : 0;
+    for (int i = 0; i < (int)P.max_cand; i++) { // uniform trip count: the shuffles below are executed by every lane of the workgroup
+        bool     ok = i < n_cand;
+        uint32_t rrow[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++) rrow[j] = 0;
+        int rf = 0, xm = 0, ym = 0;
+        if (ok) {
+            const uint32_t c = cand_base[((size_t)sb * n_pus + pu) * P.max_cand + i];
+            const int dir = (int)(c & 3), r0 = (int)((c >> 2) & 3), r1 = (int)((c >> 4) & 3);
+            const int list = dir & 1, ref = list == 0 ? r0 : r1;
+            rf = list * 4 + ref;
+            ok = dir <= 1 && s_refs[rf].valid;
+            if (ok) {
+                const SvtHipTplRef& R = s_refs[rf];
+                const uint32_t m = mv_base[((size_t)sb * n_pus + pu) * P.max_refs + (list ? P.max_l0 : 0) + ref];
+                xm = (int)(int16_t)((int16_t)(m & 0xffff) << 3);
+                ym = (int)(int16_t)((int16_t)(m >> 16) << 3);
+                if (x0 + (xm >> 3) < -TPL_PAD) xm = (int)(int16_t)((-TPL_PAD - x0) << 3);
+                if (x0 + SIZE + (xm >> 3) > TPL_PAD + (int)R.max_width - 1) xm = (int)(int16_t)(((TPL_PAD + (int)R.max_width - 1) - (x0 + SIZE)) << 3);
+                if (y0 + (ym >> 3) < -TPL_PAD) ym = (int)(int16_t)((-TPL_PAD - y0) << 3);
+                if (y0 + SIZE + (ym >> 3) > TPL_PAD + (int)R.max_height - 1) ym = (int)(int16_t)(((TPL_PAD + (int)R.max_height - 1) - (y0 + SIZE)) << 3);
+                load_row<NW>(rrow, ref_base + R.plane_off + (size_t)((int)R.org_y + y0 + t + ym / 8) * R.stride + (int)R.org_x + x0 + xm / 8);
+            }
+        }
+        const uint32_t cost = group_sum<T>(row_sad<NW>(srow, rrow));
+        if (ok && cost < best_inter) {
+            best_inter = cost; best_rf = rf; mvr = ym; mvc = xm;
+#pragma unroll
+            for (int j = 0; j < NW; j++) brow[j] = rrow[j];
+        }
+    }
+    const bool newmv = active && best_inter < best_intra; // :892 (both INT64_MAX in the reference when nothing was evaluated: not less)
+    // ---- NEWMV: residual rows -> forward DCT_DCT (svt_av1_wht_fwd_txfm = svt_av1_highbd_fwd_txfm[_n2/_n4], transforms.c:3640) -> quantize_fp error ----
+    if (newmv && (t & ((1 << ST) - 1)) == 0) {
+        const int r = t >> ST;
+#pragma unroll
+        for (int j = 0; j < NW; j++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int d = (int)((srow[j] >> (8 * b)) & 255u) - (int)((brow[j] >> (8 * b)) & 255u);
+                buf[r * PITCH + 4 * j + b] = (int32_t)((uint32_t)d << FS0);
+            }
+    }
+    __syncthreads();
+    if (newmv) { // column t (T == W)
+        int32_t v[TXH];
+#pragma unroll
+        for (int r = 0; r < TXH; r++) v[r] = buf[r * PITCH + t];
+        fwd1d<TXH, CBC>(K_DCT, v);
+#pragma unroll
+        for (int r = 0; r < TXH; r++) buf[r * PITCH + t] = FS1 ? rshift_round(v[r], FS1 ? FS1 : 1) : v[r];
+    }
+    __syncthreads();
+    uint32_t err_lo = 0, err_hi = 0;
+    if (newmv && t < TXH) {
+        int32_t v[W];
+#pragma unroll
+        for (int c = 0; c < W; c++) v[c] = buf[t * PITCH + c];
+        fwd1d<W, CBR>(K_DCT, v);
+        const int kw = W >> P.pf_shape, kh = TXH >> P.pf_shape; // the partial-frequency shapes keep the top-left corner, the rest is 0 (transforms.c:5202-5273)
+        unsigned long long err = 0;
+        if (t < kh) {
+#pragma unroll
+            for (int c = 0; c < W; c++) {
+                if (c < kw) {
+                    int32_t x = FS2 ? rshift_round(v[c], FS2 ? FS2 : 1) : v[c];
+                    if (RECT1) x = mul_sqrt2_like(x, 5793);
+                    // svt_av1_quantize_fp (quantize_fp_helper_c, full_loop.c:282-342; log_scale 0, no matrices) and svt_av1_block_error's term
+                    const int     kk = (t | c) != 0;
+                    const int32_t sign = x < 0 ? -1 : 0, a = (x ^ sign) - sign;
+                    int32_t       dq = 0;
+                    if (((long long)a << 1) >= (int32_t)P.dequant[kk]) {
+                        long long tt = (long long)a + P.round_fp[kk];
+                        tt = tt < -32768 ? -32768 : (tt > 32767 ? 32767 : tt);
+                        const int32_t q = (int32_t)((tt * P.quant_fp[kk]) >> 16);
+                        if (q) dq = (((int32_t)((uint32_t)q * (uint32_t)(int32_t)P.dequant[kk])) ^ sign) - sign;
+                    }
+                    const long long df = (long long)x - dq;
+                    err += (unsigned long long)(df * df);
+                }
+            }
+        }
+        err_lo = (uint32_t)err; err_hi = (uint32_t)(err >> 32);
+    }
+    // 64-bit sum over the block's lanes (carry through a 3 x 22-bit split is not needed: add the halves separately and propagate the carry count)
+    {
+        // split into three 22-bit limbs so that T <= 32 partial sums cannot overflow 32 bits
+        const unsigned long long e = ((unsigned long long)err_hi << 32) | err_lo;
+        const uint32_t l0 = group_sum<T>((uint32_t)(e & 0x3fffffu)), l1 = group_sum<T>((uint32_t)((e >> 22) & 0x3fffffu)), l2 = group_sum<T>((uint32_t)(e >> 44));
+        const unsigned long long tot = (unsigned long long)l0 + ((unsigned long long)l1 << 22) + ((unsigned long long)l2 << 44);
+        err_lo = (uint32_t)tot; err_hi = (uint32_t)(tot >> 32);
+    }
+    if (active && t == 0) {
+        SvtHipTplSrcStats o = {};
+        o.written = 1;
+        o.best_mode = newmv ? TPL_NEWMV : 0;
+        o.best_intra_mode = 0;
+        o.best_rf_idx = best_rf;
+        o.ref_frame_poc = best_rf >= 0 ? s_refs[best_rf].picture_number : 0;
+        o.mv_row = (int16_t)mvr; o.mv_col = (int16_t)mvc;
+        if (newmv) {
+            long long e = (long long)(((unsigned long long)err_hi << 32) | err_lo);
+            e >>= (SIZE == 32 && TXH == 32) ? 0 : 2; // get_quantize_error: shift = tx_size == TX_32X32 ? 0 : 2 (:227)
+            if (e < 1) e = 1;
+            o.srcrf_dist = (e << TPL_COST_SCALE_LOG2) << ST;
+        }
+        stats[(size_t)(y0 >> 4) * ((P.aligned_width + 15) >> 4) + (x0 >> 4)] = o;
+    }
+}
+
+template <int SIZE, int TXH>
+void launch_tpl(const SvtHipTplSrcParams& P, const uint8_t* src, const uint8_t* ref, const uint8_t* tot, const uint32_t* mv, const uint8_t* cand,
+                SvtHipTplSrcStats* stats, int only_incomplete, hipStream_t st) {
+    constexpr int BPW = 256 / SIZE, PER = 64 / SIZE;
+    const uint32_t items = P.n_sb * PER * PER;
+    const size_t   shmem = (size_t)BPW * TXH * (SIZE + 1) * 4;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tpl_src_kernel<SIZE, TXH>), dim3((items + BPW - 1) / BPW), dim3(256), shmem, st, P, src, ref, tot, mv, cand, stats, only_incomplete);
+    SVT_LAUNCH_CHECK();
+}
+
+bool tpl_supported(const SvtHipTplSrcParams& P) {
+    if (P.dispenser_search_level > 1 || P.subsample_tx > 2 || P.pf_shape > 2 || !P.n_sb || !P.sbs_x) return false;
+    if (P.dispenser_search_level == 1 && P.subsample_tx != 2) return false; // 32x32 blocks exist with TX_32X8 only (tpl level 5)
+    if (P.dispenser_search_level == 0 && P.subsample_tx == 1) return false; // TX_16X8: no tpl level uses it
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+void svt_hip_tpl_src_stage(const SvtHipTplSrcParams* params, const uint8_t* src_base, const uint8_t* ref_base, const uint8_t* total_me_candidate_index,
+                           const uint32_t* me_mv_array, const uint8_t* me_candidate_array, SvtHipTplSrcStats* stats, void* stream) {
+    svthip::ensure_device();
+    const SvtHipTplSrcParams& P = *params;
+    if (!tpl_supported(P)) {
+        fprintf(stderr, "libsvtav1_hip: svt_hip_tpl_src_stage: option set outside tpl levels 4 / 5 (level %d, subsample_tx %d, pf_shape %d)\n", P.dispenser_search_level,
+                P.subsample_tx, P.pf_shape);
+        abort();
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (P.dispenser_search_level == 0) {
+        if (P.subsample_tx == 0) launch_tpl<16, 16>(P, src_base, ref_base, total_me_candidate_index, me_mv_array, me_candidate_array, stats, 0, st);
+        else launch_tpl<16, 4>(P, src_base, ref_base, total_me_candidate_index, me_mv_array, me_candidate_array, stats, 0, st);
+    } else {
+        launch_tpl<32, 8>(P, src_base, ref_base, total_me_candidate_index, me_mv_array, me_candidate_array, stats, 0, st);
+        launch_tpl<16, 4>(P, src_base, ref_base, total_me_candidate_index, me_mv_array, me_candidate_array, stats, 1, st); // SBs the picture edge cuts: level 0 (:2048-2051)
+    }
+}
+
+int svt_hip_tpl_src_stage_host(const SvtHipTplSrcParams* params, const SvtHipTplHostPlanes* planes, const uint8_t* total_me_candidate_index,
+                               const uint32_t* me_mv_array, const uint8_t* me_candidate_array, SvtHipTplSrcStats* stats) {
+    svthip::ensure_device();
+    SvtHipTplSrcParams P = *params;
+    if (!tpl_supported(P)) return -1;
+    const int    n_pus = P.enable_me_8x8 ? 85 : (P.enable_me_16x16 ? 21 : 5);
+    const size_t cols16 = (P.aligned_width + 15) >> 4, rows16 = ((((size_t)P.height + 7) & ~(size_t)7) + 15) >> 4, cells = cols16 * rows16;
+    const size_t tot_b = (size_t)P.n_sb * n_pus, mv_b = tot_b * P.max_refs * 4, cand_b = tot_b * P.max_cand;
+    // distinct picture buffers: the source, then every valid reference whose buffer was not seen before
+    const uint8_t* bufs[9];
+    size_t         bytes[9], doff[9];
+    int            nb = 0, ref_slot[8];
+    bufs[nb] = planes->src_buf; bytes[nb] = (size_t)P.src_stride * planes->src_rows; nb++;
+    for (int r = 0; r < 8; r++) {
+        ref_slot[r] = -1;
+        if (!P.refs[r].valid || P.i_slice) continue;
+        for (int b = 0; b < nb; b++)
+            if (bufs[b] == planes->ref_buf[r]) ref_slot[r] = b;
+        if (ref_slot[r] < 0) { bufs[nb] = planes->ref_buf[r]; bytes[nb] = (size_t)P.refs[r].stride * planes->ref_rows[r]; ref_slot[r] = nb++; }
+    }
+    size_t total = 0;
+    for (int b = 0; b < nb; b++) { doff[b] = total; total += svthip::align_up(bytes[b], 256); }
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    const size_t side = tot_b + mv_b + cand_b + cells * sizeof(SvtHipTplSrcStats) + 8192;
+    c.reserve(total + side + 4096, total + side + cells * sizeof(SvtHipTplSrcStats) + 4096);
+    uint8_t* d_planes = (uint8_t*)c.dalloc(total);
+    for (int b = 0; b < nb; b++) c.up(d_planes + doff[b], bufs[b], bytes[b]);
+    uint8_t*  d_tot  = (uint8_t*)c.dalloc(tot_b);
+    uint32_t* d_mv   = (uint32_t*)c.dalloc(mv_b ? mv_b : 4);
+    uint8_t*  d_cand = (uint8_t*)c.dalloc(cand_b ? cand_b : 4);
+    SvtHipTplSrcStats* d_stats = (SvtHipTplSrcStats*)c.dalloc(cells * sizeof(SvtHipTplSrcStats));
+    c.up(d_tot, total_me_candidate_index, tot_b);
+    if (mv_b) c.up(d_mv, me_mv_array, mv_b);
+    if (cand_b) c.up(d_cand, me_candidate_array, cand_b);
+    HIP_CHECK(hipMemsetAsync(d_stats, 0, cells * sizeof(SvtHipTplSrcStats), c.stream));
+    for (int r = 0; r < 8; r++)
+        if (ref_slot[r] >= 0) P.refs[r].plane_off += doff[ref_slot[r]];
+    svt_hip_tpl_src_stage(&P, d_planes, d_planes, d_tot, d_mv, d_cand, d_stats, c.stream);
+    c.down(stats, d_stats, cells * sizeof(SvtHipTplSrcStats));
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,176 @@
+"""TPL dispenser, source-based half (Codec/src_ops_process.c:519-969): the oracle restatement against the reference's own static
+function (compiled where it lies through oracle/ref_wrap/ref_tpl.c), and the device stage svt_hip_tpl_src_stage against the oracle -- bit-exact TplSrcStats
+for every 16x16 / 32x32 block of a picture, incl. partial superblocks, picture borders, clamped far vectors, excluded references, I slices and pictures with
+intra prediction disabled."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REF_LIB, load_pkg, p, rng
+
+PAD = 96  # luma border of every test plane (the reference pads 68 + and TPL vectors are clamped to the picture + 32)
+
+
+class TplRef(C.Structure):
+    _fields_ = [("plane_off", C.c_uint64), ("picture_number", C.c_uint64), ("stride", C.c_uint32), ("org_x", C.c_uint32), ("org_y", C.c_uint32),
+                ("max_width", C.c_uint16), ("max_height", C.c_uint16), ("valid", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
+class TplParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("aligned_width", C.c_uint32), ("sbs_x", C.c_uint32), ("n_sb", C.c_uint32), ("src_stride", C.c_uint32),
+                ("src_off", C.c_uint64), ("dispenser_search_level", C.c_uint8), ("subsample_tx", C.c_uint8), ("pf_shape", C.c_uint8), ("disable_intra_pred", C.c_uint8),
+                ("i_slice", C.c_uint8), ("enable_me_16x16", C.c_uint8), ("enable_me_8x8", C.c_uint8), ("max_cand", C.c_uint8), ("max_refs", C.c_uint8),
+                ("max_l0", C.c_uint8), ("pad", C.c_uint8 * 2), ("quant_fp", C.c_int16 * 2), ("round_fp", C.c_int16 * 2), ("dequant", C.c_int16 * 2),
+                ("refs", TplRef * 8)]
+
+
+SrcStats = np.dtype([("srcrf_dist", "<i8"), ("srcrf_rate", "<i8"), ("ref_frame_poc", "<u8"), ("mv_row", "<i2"), ("mv_col", "<i2"), ("best_rf_idx", "<i4"),
+                     ("best_mode", "u1"), ("best_intra_mode", "u1"), ("written", "u1"), ("pad", "u1", (5,))])
+assert SrcStats.itemsize == 40 and C.sizeof(TplParams) == 376 and C.sizeof(TplRef) == 40
+
+CASES = [  # (W, H, level, subsample_tx, pf_shape, disable_intra, i_slice, me16, me8, n_l0, n_l1, q_index)
+    dict(W=200, H=136, level=0, ss=0, pf=2, noi=0, isl=0, me16=1, me8=0, l0=2, l1=1, q=120),
+    dict(W=200, H=136, level=0, ss=0, pf=1, noi=1, isl=0, me16=1, me8=1, l0=1, l1=1, q=60),
+    dict(W=264, H=152, level=1, ss=2, pf=2, noi=0, isl=0, me16=1, me8=0, l0=2, l1=2, q=180),
+    dict(W=136, H=72, level=0, ss=0, pf=0, noi=0, isl=1, me16=1, me8=0, l0=1, l1=0, q=30),
+    dict(W=200, H=136, level=0, ss=0, pf=2, noi=0, isl=0, me16=0, me8=0, l0=3, l1=2, q=255),
+    dict(W=328, H=200, level=1, ss=2, pf=1, noi=1, isl=0, me16=1, me8=0, l0=1, l1=1, q=0),
+]
+
+
+def make_case(c, seed):
+    g = rng(seed)
+    W, H = c["W"], c["H"]
+    aw, ah = (W + 7) & ~7, (H + 7) & ~7
+    sbs_x, sbs_y = (aw + 63) // 64, (ah + 63) // 64
+    stride, rows = aw + 2 * PAD + 24, ah + 2 * PAD + 16
+    yy, xx = np.mgrid[0:rows, 0:stride]
+    base = ((xx * 3 + yy * 2) & 255).astype(np.int32) + (((xx // 16 + yy // 16) % 7) << 3)
+    n_ref = c["l0"] + c["l1"]
+    planes = np.zeros((1 + n_ref, rows, stride), np.uint8)
+    planes[0] = np.clip(base + g.integers(-12, 13, base.shape), 0, 255)
+    for r in range(n_ref):  # shifted + noisy copies: some candidates beat the DC prediction, some do not
+        planes[1 + r] = np.clip(np.roll(planes[0].astype(np.int32), (r + 1, -2 * r - 1), (0, 1)) + g.integers(-6 - 8 * r, 7 + 8 * r, base.shape), 0, 255)
+    planes[0, PAD + 32:PAD + 64, PAD + 16:PAD + 80] = 77  # flat area: DC prediction exact, intra wins
+    P = TplParams()
+    P.width, P.height, P.aligned_width, P.sbs_x, P.n_sb, P.src_stride = W, H, aw, sbs_x, sbs_x * sbs_y, stride
+    P.src_off = PAD * stride + PAD
+    P.dispenser_search_level, P.subsample_tx, P.pf_shape, P.disable_intra_pred, P.i_slice = c["level"], c["ss"], c["pf"], c["noi"], c["isl"]
+    P.enable_me_16x16, P.enable_me_8x8 = c["me16"], c["me8"]
+    n_pus = 85 if c["me8"] else (21 if c["me16"] else 5)
+    P.max_refs, P.max_l0 = n_ref, c["l0"]
+    P.max_cand = max_cand = min(3 + n_ref, 9)
+    for l in range(2):
+        for r in range(4):
+            R = P.refs[l * 4 + r]
+            have = r < (c["l0"] if l == 0 else c["l1"])
+            slot = r if l == 0 else c["l0"] + r
+            R.plane_off = (1 + slot) * rows * stride if have else 0
+            R.picture_number = 100 + 10 * l + r
+            R.stride, R.org_x, R.org_y, R.max_width, R.max_height = stride, PAD, PAD, W, H
+            R.valid = 1 if have else 0
+    if n_ref >= 3:
+        P.refs[1].valid = 0  # an excluded reference (:779-781): its candidates are skipped
+    n_sb = P.n_sb
+    tot = g.integers(0, max_cand + 1, (n_sb, n_pus)).astype(np.uint8)
+    cand = np.zeros((n_sb, n_pus, max_cand), np.uint8)
+    d = g.integers(0, 3, cand.shape)  # 0 / 1: uni-directional from list 0 / 1, 2: bi-directional (ignored by TPL)
+    if c["l1"] == 0:
+        d[:] = np.where(d == 1, 0, d)
+    r0 = g.integers(0, max(c["l0"], 1), cand.shape)
+    r1 = g.integers(0, max(c["l1"], 1), cand.shape)
+    cand[:] = d | (r0 << 2) | (r1 << 4) | (g.integers(0, 2, cand.shape) << 6)
+    mvx = g.integers(-24, 25, (n_sb, n_pus, n_ref)).astype(np.int16)
+    mvy = g.integers(-16, 17, (n_sb, n_pus, n_ref)).astype(np.int16)
+    far = g.random(mvx.shape) < 0.08  # vectors far outside the picture: clamped to the picture + 32 (:791-801)
+    mvx[far] = g.integers(-400, 401, int(far.sum())).astype(np.int16)
+    mvy[far] = g.integers(-300, 301, int(far.sum())).astype(np.int16)
+    mvs = (mvy.astype(np.uint16).astype(np.uint32) << 16) | mvx.astype(np.uint16).astype(np.uint32)
+    return P, planes, tot, np.ascontiguousarray(mvs), cand, n_pus, (aw + 15) // 16 * ((ah + 15) // 16)
+
+
+def ref_lib():
+    path = os.path.join(os.path.dirname(REF_LIB), "libsvtref_me.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libsvtref_me.so not available")
+    lib = C.CDLL(path)
+    if not hasattr(lib, "ref_tpl_dispenser_picture"):
+        pytest.skip("libsvtref_me.so predates ref_tpl.c")
+    return lib
+
+
+def run_oracle(oracle, P, planes, tot, mvs, cand, cells):
+    out = np.zeros(cells, SrcStats)
+    oracle.oracle_tpl_src_picture(C.byref(P), p(planes), p(planes), p(tot), p(mvs), p(cand), p(out))
+    return out
+
+
+def same_stats(a, b, tag):
+    for f in SrcStats.names:
+        if f != "pad":
+            bad = np.nonzero(a[f] != b[f])[0]
+            assert bad.size == 0, (tag, f, bad[:6], a[f][bad[:6]], b[f][bad[:6]])
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_tpl_src_oracle_vs_reference(oracle, ref, ci):
+    """oracle_tpl_src_picture == the TplSrcStats the reference's tpl_mc_flow_dispenser_sb_generic stores, every block of the picture."""
+    me = ref_lib()
+    P, planes, tot, mvs, cand, n_pus, cells = make_case(CASES[ci], 4000 + ci)
+    want = np.zeros(cells, SrcStats)
+    me.ref_tpl_dispenser_picture(C.byref(P), CASES[ci]["q"], p(planes), PAD, PAD, p(planes), p(tot), p(mvs), p(cand), n_pus, p(want), None, None)
+    got = run_oracle(oracle, P, planes, tot, mvs, cand, cells)
+    same_stats(got, want, ci)
+    assert want["written"].sum() > 0
+    if not CASES[ci]["isl"]:
+        assert (want["best_mode"] == 16).any()
+    if not CASES[ci]["noi"]:
+        assert (want["best_mode"][want["written"] == 1] == 0).any()
+
+
+class TplHostPlanes(C.Structure):
+    _fields_ = [("src_buf", C.c_void_p), ("src_rows", C.c_uint32), ("ref_rows", C.c_uint32 * 8), ("ref_buf", C.c_void_p * 8)]
+
+
+GPU_CASES = [dict(W=1920, H=1080, level=0, ss=0, pf=2, noi=0, isl=0, me16=1, me8=0, l0=2, l1=2, q=140),
+             dict(W=1920, H=1080, level=1, ss=2, pf=2, noi=1, isl=0, me16=1, me8=0, l0=1, l1=1, q=140),
+             dict(W=3840, H=2160, level=0, ss=0, pf=2, noi=0, isl=0, me16=1, me8=1, l0=2, l1=1, q=100)]
+
+
+@pytest.mark.parametrize("ci", range(len(CASES) + len(GPU_CASES)))
+def test_tpl_src_stage_device(be, oracle, ci):
+    """svt_hip_tpl_src_stage (device arrays) and svt_hip_tpl_src_stage_host (host pictures) == the oracle, every cell of the statistics grid; on the GPU also
+    whole 1080p / 4K pictures."""
+    if ci >= len(CASES) and not be.is_gpu:
+        pytest.skip("full-size pictures run on the GPU only")
+    c = CASES[ci] if ci < len(CASES) else GPU_CASES[ci - len(CASES)]
+    P, planes, tot, mvs, cand, n_pus, cells = make_case(c, 5000 + ci)
+    path = os.path.join(os.path.dirname(REF_LIB), "libsvtref_me.so")
+    if os.path.exists(path) and hasattr(C.CDLL(path), "ref_tpl_dispenser_picture") and ci < len(CASES):  # the quantizer row of the reference's own tables
+        scratch = np.zeros(cells, SrcStats)
+        C.CDLL(path).ref_tpl_dispenser_picture(C.byref(P), c["q"], p(planes), PAD, PAD, p(planes), p(tot), p(mvs), p(cand), n_pus, p(scratch), None, None)
+    else:  # no reference at hand, or a full-size picture: a legal quantizer row (q index 120 of the 8-bit tables)
+        P.quant_fp[0], P.quant_fp[1], P.round_fp[0], P.round_fp[1], P.dequant[0], P.dequant[1] = 532, 431, 61, 76, 123, 152
+    want = run_oracle(oracle, P, planes, tot, mvs, cand, cells)
+    d_pl, d_tot, d_mv, d_cand = be.dev(planes), be.dev(tot), be.dev(mvs), be.dev(cand)
+    d_out = be.empty(cells * SrcStats.itemsize, np.uint8)
+    be.lib.svt_hip_tpl_src_stage(C.addressof(P), be.ptr(d_pl), be.ptr(d_pl), be.ptr(d_tot), be.ptr(d_mv), be.ptr(d_cand), be.ptr(d_out), be.stream)
+    got = be.host(d_out).view(SrcStats)
+    same_stats(got, want, ("device", ci))
+    # host form: the reference pictures as separate host buffers (two references sharing one buffer are uploaded once)
+    HP = TplHostPlanes()
+    rows = planes.shape[1]
+    psize = planes.shape[1] * planes.shape[2]
+    PH = TplParams.from_buffer_copy(P)
+    HP.src_buf, HP.src_rows = planes[0].ctypes.data, rows
+    for r in range(8):
+        if P.refs[r].valid:
+            k = P.refs[r].plane_off // psize
+            HP.ref_buf[r], HP.ref_rows[r] = planes[k].ctypes.data, rows
+            PH.refs[r].plane_off = 0
+    got_h = np.zeros(cells, SrcStats)
+    assert be.lib.svt_hip_tpl_src_stage_host(C.addressof(PH), C.addressof(HP), p(tot), p(mvs), p(cand), p(got_h)) == 0
+    same_stats(got_h, want, ("host form", ci))
+    assert want["written"].sum() > 0
