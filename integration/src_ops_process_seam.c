@@ -1,0 +1,173 @@
+/* src_ops_process_seam.c -- REFERENCE-SIDE BINDING (what a maintainer of the reference adds; built into the reference encoder by oracle/Makefile for the identity / fps runs): the reference's source-based-operations process with the TPL dispenser seam of INTEGRATION.md §3.
+ *
+ * This translation unit IS Source/Lib/Codec/src_ops_process.c of the reference (included below where it lies; nothing is copied).  One call is renamed for the
+ * duration of the #include: tpl_mc_flow_dispenser(...) -- `static`, defined at :1347 and called once per (TPL group, picture) from tpl_mc_flow (:1848).  The macro
+ * appends __COUNTER__ (unused anywhere else in the file): the DEFINITION becomes tpl_mc_flow_dispenser_use0 -- the reference's body, untouched -- and the call site
+ * tpl_mc_flow_dispenser_use1 = the seam below.
+ *
+ * With SVT_HIP_TPL_SEAM=1 and a picture whose source-based statistics are still to be made (pcs->tpl_src_data_ready == 0) the seam computes them for EVERY block
+ * of the picture with ONE svt_hip_tpl_src_stage_host() call -- DC intra cost from source neighbours, SAD of each uni-directional ME candidate, winner, forward
+ * transform + quantisation error of the NEWMV residual (src_ops_process.c:606-957) --, writes them where the reference itself would store them
+ * (pa_me_data->tpl_src_stats_buffer, :958-967) and runs the reference's dispenser with pcs->tpl_src_data_ready = 1, i.e. through its own "statistics already
+ * there" branch (:969-977): the reconstruction half (prediction from the TPL recon pictures, transform, inverse transform, result_model_store) stays the
+ * reference's C, segment threads and all.  The source-based half of a block reads only source pictures, the ME results and the quantizer row, so doing it for the
+ * whole picture before the first segment is an exact reordering.  Pictures outside the covered option set (tpl levels 4 / 5: use_sad_in_src_search, DC only,
+ * full-pel, no rate, no QPS) run the reference unchanged.  SVT_HIP_TPL_SEAM_STATS=<file> receives the counters at exit.
+ */
+#define _GNU_SOURCE /* RTLD_DEFAULT */
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pcs.h"
+#include "sequence_control_set.h"
+#include "encode_context.h"
+#include "svtav1_hip.h" /* include/svtav1_hip.h of this repository: the C ABI */
+
+struct SourceBasedOperationsContext;
+#define TPL_DISP_ARGS                                                                                                                                         \
+    EncodeContext *enc_ctx, SequenceControlSet *scs, int32_t *base_rdmult, PictureParentControlSet *pcs, int32_t frame_idx, struct SourceBasedOperationsContext *context_ptr
+#define TPL_DISP_PASS enc_ctx, scs, base_rdmult, pcs, frame_idx, context_ptr
+static void tpl_mc_flow_dispenser_use0(TPL_DISP_ARGS); /* the reference's function (defined by the #include) */
+static void tpl_mc_flow_dispenser_use1(TPL_DISP_ARGS); /* the seam */
+
+#define SEAM_CAT_(a, b) a##b
+#define SEAM_CAT(a, b) SEAM_CAT_(a, b)
+#define tpl_mc_flow_dispenser(...) SEAM_CAT(tpl_mc_flow_dispenser_use, __COUNTER__)(__VA_ARGS__)
+#include "src_ops_process.c" /* resolves through -I$(REF)/Source/Lib/Codec */
+#undef tpl_mc_flow_dispenser
+
+static struct {
+    pthread_mutex_t lock;
+    int             mode;
+    int (*stage_host)(const SvtHipTplSrcParams *, const SvtHipTplHostPlanes *, const uint8_t *, const uint32_t *, const uint8_t *, SvtHipTplSrcStats *);
+    uint64_t n_pictures, n_blocks, n_newmv, n_declined, n_reused;
+    double   ms_stage;
+} TS = {PTHREAD_MUTEX_INITIALIZER};
+
+static void tpl_seam_stats(void) {
+    const char *f = getenv("SVT_HIP_TPL_SEAM_STATS");
+    FILE       *o = f ? fopen(f, "w") : NULL;
+    if (!o) return;
+    fprintf(o, "pictures_offloaded %llu\nblocks %llu\nblocks_newmv %llu\npictures_declined %llu\npictures_with_stored_statistics %llu\nms_in_stage_calls %.0f\n",
+            (unsigned long long)TS.n_pictures, (unsigned long long)TS.n_blocks, (unsigned long long)TS.n_newmv, (unsigned long long)TS.n_declined,
+            (unsigned long long)TS.n_reused, TS.ms_stage);
+    fclose(o);
+}
+static void tpl_seam_init(void) {
+    const char *e = getenv("SVT_HIP_TPL_SEAM");
+    if (!e || !atoi(e) || !getenv("SVT_HIP")) return;
+    *(void **)&TS.stage_host = dlsym(RTLD_DEFAULT, "svt_hip_tpl_src_stage_host");
+    if (!TS.stage_host) { fprintf(stderr, "SVT_HIP_TPL_SEAM: libsvtav1_hip is not loaded\n"); abort(); }
+    atexit(tpl_seam_stats);
+    fprintf(stderr, "SVT_HIP_TPL_SEAM: the source-based half of the TPL dispenser runs as one device stage per picture\n");
+    TS.mode = 1;
+}
+static int tpl_seam_on(void) {
+    static pthread_once_t once = PTHREAD_ONCE_INIT;
+    pthread_once(&once, tpl_seam_init);
+    return TS.mode;
+}
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec / 1e6;
+}
+
+/* the option set svt_hip_tpl_src_stage covers (tpl levels 4 / 5, initial_rc_process.c:343-378) on an 8-bit single-tile-grid picture */
+static int tpl_seam_covers(const SequenceControlSet *scs, const PictureParentControlSet *pcs) {
+    const TplControls *tc = &pcs->tpl_ctrls;
+    if (!scs->in_loop_ois || !tc->use_sad_in_src_search || tc->intra_mode_end != DC_PRED || tc->subpel_depth != FULL_PEL || tc->compute_rate || tc->enable_tpl_qps)
+        return 0;
+    if (!((tc->dispenser_search_level == 0 && tc->subsample_tx == 0) || (tc->dispenser_search_level == 1 && tc->subsample_tx == 2))) return 0;
+    if (scs->b64_size != 64) return 0;
+    return 1;
+}
+
+static void tpl_mc_flow_dispenser_use1(TPL_DISP_ARGS) {
+    if (!tpl_seam_on() || pcs->tpl_src_data_ready || !tpl_seam_covers(scs, pcs)) {
+        if (TS.mode) {
+            pthread_mutex_lock(&TS.lock);
+            if (pcs->tpl_src_data_ready) TS.n_reused++; else TS.n_declined++;
+            pthread_mutex_unlock(&TS.lock);
+        }
+        tpl_mc_flow_dispenser_use0(TPL_DISP_PASS);
+        return;
+    }
+    const double t0 = now_ms();
+    const EbPictureBufferDesc *inp = pcs->enhanced_pic;
+    MotionEstimationData      *med = pcs->pa_me_data;
+    const int32_t q_index = quantizer_to_qindex[(uint8_t)scs->static_config.qp]; /* tpl_mc_flow_dispenser :1352 (enable_tpl_qps == 0: no delta) */
+    SvtHipTplSrcParams P;
+    SvtHipTplHostPlanes H;
+    memset(&P, 0, sizeof(P));
+    memset(&H, 0, sizeof(H));
+    P.width = inp->width; P.height = inp->height; P.aligned_width = pcs->aligned_width;
+    P.sbs_x = (pcs->aligned_width + 63) >> 6; P.n_sb = pcs->b64_total_count;
+    P.src_stride = inp->stride_y; P.src_off = (uint64_t)inp->org_y * inp->stride_y + inp->org_x;
+    P.dispenser_search_level = pcs->tpl_ctrls.dispenser_search_level; P.subsample_tx = pcs->tpl_ctrls.subsample_tx; P.pf_shape = (uint8_t)pcs->tpl_ctrls.pf_shape;
+    P.disable_intra_pred = pcs->tpl_ctrls.disable_intra_pred_nref && (pcs->temporal_layer_index == pcs->hierarchical_levels); /* :557 */
+    P.i_slice = pcs->slice_type == I_SLICE;
+    P.enable_me_16x16 = pcs->enable_me_16x16; P.enable_me_8x8 = pcs->enable_me_8x8;
+    P.max_cand = med->max_cand; P.max_refs = med->max_refs; P.max_l0 = med->max_l0;
+    for (int i = 0; i < 2; i++) {
+        P.quant_fp[i] = scs->enc_ctx->quants_8bit.y_quant_fp[q_index][i];
+        P.round_fp[i] = scs->enc_ctx->quants_8bit.y_round_fp[q_index][i];
+        P.dequant[i]  = scs->enc_ctx->deq_8bit.y_dequant_qtx[q_index][i];
+    }
+    H.src_buf = inp->buffer_y; H.src_rows = inp->luma_size / inp->stride_y;
+    if (!P.i_slice)
+        for (int l = 0; l < 2; l++) {
+            const int cnt = l == 0 ? pcs->tpl_data.tpl_ref0_count : pcs->tpl_data.tpl_ref1_count;
+            for (int r = 0; r < cnt && r < 4; r++) {
+                const EbPictureBufferDesc *rp = (const EbPictureBufferDesc *)pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_ptr;
+                SvtHipTplRef *R = &P.refs[l * 4 + r];
+                if (!rp) continue;
+                const int32_t grp = pcs->tpl_data.ref_tpl_group_idx[l][r];
+                R->valid = !(grp > 0 && pcs->tpl_data.base_pcs->tpl_valid_pic[grp] == 0); /* :779-781 */
+                R->plane_off = 0; R->picture_number = pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_number;
+                R->stride = rp->stride_y; R->org_x = rp->org_x; R->org_y = rp->org_y; R->max_width = rp->max_width; R->max_height = rp->max_height;
+                H.ref_buf[l * 4 + r] = rp->buffer_y; H.ref_rows[l * 4 + r] = rp->luma_size / rp->stride_y;
+            }
+        }
+    /* the picture's MeSbResults, SB after SB, in the flat layout of the C ABI */
+    const uint32_t n_pus = pcs->enable_me_8x8 ? 85 : (pcs->enable_me_16x16 ? 21 : 5);
+    uint8_t  *tot  = malloc((size_t)P.n_sb * n_pus);
+    uint32_t *mvs  = malloc((size_t)P.n_sb * n_pus * (P.max_refs ? P.max_refs : 1) * 4);
+    uint8_t  *cand = malloc((size_t)P.n_sb * n_pus * (P.max_cand ? P.max_cand : 1));
+    for (uint32_t sb = 0; sb < P.n_sb; sb++) {
+        const MeSbResults *m = med->me_results[sb];
+        memcpy(tot + (size_t)sb * n_pus, m->total_me_candidate_index, n_pus);
+        memcpy(mvs + (size_t)sb * n_pus * P.max_refs, m->me_mv_array, (size_t)n_pus * P.max_refs * 4);
+        memcpy(cand + (size_t)sb * n_pus * P.max_cand, m->me_candidate_array, (size_t)n_pus * P.max_cand);
+    }
+    const uint32_t cols16 = (pcs->aligned_width + 15) >> 4, rows16 = (((inp->height + 7) & ~7u) + 15) >> 4, cells = cols16 * rows16;
+    SvtHipTplSrcStats *st = malloc((size_t)cells * sizeof(*st));
+    if (TS.stage_host(&P, &H, tot, mvs, cand, st)) { fprintf(stderr, "SVT_HIP_TPL_SEAM: svt_hip_tpl_src_stage_host refused the parameters\n"); abort(); }
+    /* into the buffer the reference's own "already computed" branch reads (:969-977); a sequence without stored statistics (tpl_lad_mg == 0) has none: lend one */
+    TplSrcStats *own = med->tpl_src_stats_buffer, *buf = own;
+    const uint32_t ref_cells = ((pcs->aligned_width + 15) >> 4) * ((inp->height + 15) >> 4 > rows16 ? (inp->height + 15) >> 4 : rows16);
+    if (!buf) buf = calloc(ref_cells, sizeof(*buf));
+    uint64_t nb = 0, nn = 0;
+    for (uint32_t i = 0; i < cells; i++) {
+        if (!st[i].written) continue;
+        TplSrcStats *d = &buf[i];
+        d->srcrf_dist = st[i].srcrf_dist; d->srcrf_rate = st[i].srcrf_rate; d->ref_frame_poc = st[i].ref_frame_poc;
+        d->mv.row = st[i].mv_row; d->mv.col = st[i].mv_col; d->best_mode = st[i].best_mode; d->best_rf_idx = st[i].best_rf_idx;
+        d->best_intra_mode = (PredictionMode)st[i].best_intra_mode;
+        nb++; nn += st[i].best_mode == NEWMV;
+    }
+    const double t1 = now_ms();
+    med->tpl_src_stats_buffer = buf;
+    pcs->tpl_src_data_ready   = 1;
+    tpl_mc_flow_dispenser_use0(TPL_DISP_PASS); /* the reference's dispenser: segments, reconstruction half, result_model_store */
+    pcs->tpl_src_data_ready   = 0;              /* tpl_mc_flow sets it itself when the statistics are kept (:1856-1858) */
+    med->tpl_src_stats_buffer = own;
+    if (!own) free(buf);
+    free(tot); free(mvs); free(cand); free(st);
+    pthread_mutex_lock(&TS.lock);
+    TS.n_pictures++; TS.n_blocks += nb; TS.n_newmv += nn; TS.ms_stage += t1 - t0;
+    pthread_mutex_unlock(&TS.lock);
+}

@@ -60,8 +60,8 @@ CASES = {
     "dlfseam_p5_8bit": (448, 264, 8, 8, ["--preset", "5", "--lp", "1", "+dlfseam"]),
     "dlfseam_p2_10bit": (256, 144, 5, 10, ["--preset", "2", "--lp", "1", "+dlfseam"]),
     "dlfseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "+dlfseam"]),
-    "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+tfsubpel", "+dlfseam", "+cdefseam", "+lrseam"]),
-    "everyseam_4k10_p8_lp1": (3840, 2160, 6, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),  # config-5 format, single-threaded (reproducible)
+    "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+tfsubpel", "+dlfseam", "+cdefseam", "+lrseam", "+tplseam"]),
+    "everyseam_4k10_p8_lp1": (3840, 2160, 6, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),  # config-5 format, single-threaded (reproducible)
     # the temporal filter's ME (ME_MCTF form of the stage, one call per (central picture, reference picture) pair): SVT_HIP_TF_ME_SEAM=1 on top of the ME seam
     "tfseam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tfseam_p4_10bit": (256, 144, 8, 10, ["--preset", "4", "--lp", "1", "+seam", "+tfseam"]),
@@ -75,14 +75,24 @@ CASES = {
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
     # BASELINE.json metric, second half: encoder fps @1080p preset 8 (C-only reference vs the same encoder with the ME stage on the MI355X), all host cores
     "fps_1080p_p8": (1920, 1080, 24, 8, ["--preset", "8", "+seam"]),
-    "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     # 3840x2160 10-bit, preset 8, 60 frames (10-bit preset 8 is where the multi-threaded C-only reference was seen not to reproduce its own
     # bitstream; run_case reports `reference_deterministic` and the identity verdict next to the two speeds)
-    "fps_4k10_p8_all": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_4k10_p8_all": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "fps_1080p_p8_me": (1920, 1080, 60, 8, ["--preset", "8", "+seam"]),
-    "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
-    "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    # the TPL dispenser's source-based half as one device stage per picture (integration/src_ops_process_seam.c): SVT_HIP_TPL_SEAM=1
+    "tplseam_p8_8bit": (448, 264, 20, 8, ["--preset", "8", "--lp", "1", "+tplseam"]),
+    "tplseam_p6_8bit_lp4": (448, 264, 20, 8, ["--preset", "6", "--lp", "4", "+tplseam"]),
+    "tplseam_p4_8bit": (256, 144, 18, 8, ["--preset", "4", "--lp", "1", "+tplseam"]),
+    "tplseam_p10_8bit": (448, 264, 20, 8, ["--preset", "10", "--lp", "1", "+tplseam"]),  # tpl level 5: 32x32 blocks, TX_32X8, partial SBs at 16x16
+    "tplseam_p8_10bit": (256, 144, 18, 10, ["--preset", "8", "--lp", "1", "+tplseam"]),  # TPL works on the 8-bit MSB picture of a 10-bit encode
+    "tplseam_1080p_p8": (1920, 1080, 20, 8, ["--preset", "8", "+tplseam"]),
+    "tplseam_me_p8_8bit": (448, 264, 20, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+tplseam"]),  # ME results produced by the device stage feed the TPL stage
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
+    "tiny_tplseam_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+tplseam"]),
+    "tiny_tplseam_p10": (192, 136, 18, 8, ["--preset", "10", "--lp", "1", "+tplseam"]),
     "tiny_tfsubpel_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
     "tiny_tfseam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tiny_dlfseam_p4": (128, 64, 3, 8, ["--preset", "4", "--lp", "1", "+dlfseam"]),
@@ -95,7 +105,7 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
-SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_"))]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tplseam_"))]
 
 
 def make_clip(path, w, h, n, bd, seed=7):
@@ -135,6 +145,7 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
     clip = os.path.join(outdir, name + ".yuv")
     make_clip(clip, w, h, n, bd)
     seam, with_hook, lrseam, cdefseam, dlfseam = "+seam" in extra, "+hook" in extra, "+lrseam" in extra, "+cdefseam" in extra, "+dlfseam" in extra
+    tplseam = "+tplseam" in extra
     extra = [a for a in extra if not a.startswith("+")]
     rc, tc = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_c"), timeout=timeout)
     deterministic = True
@@ -160,7 +171,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
     dlfseam_file = os.path.join(outdir, name + "_dlfseam.txt")
     if dlfseam:
         env.update({"SVT_HIP_DLF_SEAM": "1", "SVT_HIP_DLF_SEAM_STATS": dlfseam_file})
-    if (seam or lrseam or cdefseam or dlfseam) and not with_hook and not only:
+    tplseam_file = os.path.join(outdir, name + "_tplseam.txt")
+    if tplseam:
+        env.update({"SVT_HIP_TPL_SEAM": "1", "SVT_HIP_TPL_SEAM_STATS": tplseam_file})
+    if (seam or lrseam or cdefseam or dlfseam or tplseam) and not with_hook and not only:
         only = "-"  # no RTCD pointer matches: the seam(s) alone
     if only:
         env["SVT_HIP_ONLY"] = only
@@ -212,6 +226,11 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
         res["dlfseam"] = {k: int(v) for k, v in st.items()}
         if name.startswith(("dlfseam_", "tiny_dlfseam")):  # the dedicated cases must really filter segments on the device (other configurations may pick
             res["identical"] = res["identical"] and res["dlfseam"].get("segments", 0) > 0  # filter level 0, or deblock SB by SB inside the coding loop)
+    if tplseam:
+        st = dict(ln.split(None, 1) for ln in open(tplseam_file).read().splitlines()) if os.path.exists(tplseam_file) else {}
+        res["tplseam"] = {k: int(float(v)) for k, v in st.items()}
+        if name.startswith(("tplseam_", "tiny_tplseam")):  # void unless pictures really went through the device stage and none was declined
+            res["identical"] = res["identical"] and res["tplseam"].get("pictures_offloaded", 0) > 0 and res["tplseam"].get("pictures_declined", 1) == 0
     if cdefseam:
         st = dict(ln.split(None, 1) for ln in open(cdefseam_file).read().splitlines()) if os.path.exists(cdefseam_file) else {}
         res["cdefseam"] = {k: int(v) for k, v in st.items()}
@@ -250,7 +269,7 @@ def main():
             union[k] = union.get(k, 0) + v
         print("%-20s identical=%s  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs  %s" % (nme, r["identical"], r.get("calls"), r.get("pointers_hit"),
                                                                                         r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"],
-                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", "")) + " " + str(r.get("tfsubpel", ""))), flush=True)
+                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", "")) + " " + str(r.get("tfsubpel", "")) + " " + str(r.get("tplseam", ""))), flush=True)
         if "fps_c" in r:
             print("    encoder fps: C-only %.2f, with HIP %.2f" % (r["fps_c"], r.get("fps_hip", 0.0)), flush=True)
         if not r["identical"]:
