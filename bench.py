@@ -388,12 +388,18 @@ def encoder_fps():
     if not (os.path.exists(ei.ENC) and os.path.exists(lib)):
         return None
     with tempfile.TemporaryDirectory() as td:
-        r = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600)
-    if not r.get("identical"):
+        have_x = os.path.exists(ei.ENC_AVX2)
+        r = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="avx2" if have_x else "c")
+        rc_ = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="c") if have_x else r  # the round-1/2 figure: C-only host + stages, for continuity
+    if not r.get("identical") or not rc_.get("identical"):
         sys.exit("bench.py: the encoder's bitstream with the stage seams differs from the C-only encoder -- no numbers recorded (%s)" % r.get("stderr_tail", ""))
-    return {"fps_c_only": r.get("fps_c"), "fps_with_stage_seams": r.get("fps_hip"), "bitstream_identical": True, "frames": r["frames"],
-            "config": "1080p 8-bit, preset 8, CRF 35, all host threads; reference encoder built C-only (no nasm on the box)",
-            "stages_on_gpu": {"me": r.get("seam"), "tf_subpel": r.get("tfsubpel"), "dlf": r.get("dlfseam"), "cdef": r.get("cdefseam"), "lr": r.get("lrseam")}}
+    return {"fps_c_only": r.get("fps_c"), "fps_avx2_intrinsics": r.get("fps_avx2"), "fps_avx2_host_with_stage_seams": r.get("fps_hip") if have_x else None,
+            "fps_c_host_with_stage_seams": rc_.get("fps_hip"), "bitstream_identical": True, "avx2_bitstream_identical_to_c": r.get("avx2_identical_to_c"),
+            "frames": r["frames"], "host_threads": len(os.sched_getaffinity(0)),
+            "config": "1080p 8-bit, preset 8, CRF 35, all host threads; the reference encoder built (a) C-only and (b) with its SSE2..AVX2 intrinsic kernels (177 NASM kernels "
+                      "stay at their C versions: no nasm here); the stage seams (ME, temporal filter ME + sub-pel, TPL source half, deblocking, CDEF, LR) on the MI355X",
+            "stages_on_gpu": {"me": r.get("seam"), "tf_subpel": r.get("tfsubpel"), "tpl": r.get("tplseam"), "dlf": r.get("dlfseam"), "cdef": r.get("cdefseam"),
+                              "lr": r.get("lrseam")}}
 
 
 def roofline(bytes_alg, seconds, kernel, traffic_kernel=None, **extra):

@@ -63,3 +63,30 @@ def test_encoder_identity_gpu(case):
     with open(os.path.join(out, case + ".json"), "w") as f:
         json.dump(res, f, indent=1)
     _check(res)
+
+
+@needs_encoder
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["everyseam_p4_8bit_lp2", "tplseam_1080p_p8", "allseams_1080p_p6", "p8_8bit_lp1"])
+def test_encoder_identity_gpu_avx2_host(case):
+    """The same seams inside the reference built WITH its x86 intrinsic kernels (oracle/_ref/enc_avx2): that encoder alone reproduces the C-only bitstream, and so
+    does it with the stages on the MI355X -- the configuration a deployment would run."""
+    if not os.path.exists(enc_identity.ENC_AVX2):
+        pytest.skip("oracle/_ref/enc_avx2 not built")
+    lib = os.path.join(PKG_DIR, "libsvtav1_hip.so")
+    assert os.path.exists(lib), "libsvtav1_hip.so missing (no CPU fallback)"
+    res = enc_identity.run_case(case, lib, os.path.join(ROOT, "gpurun_out", "identity_avx2"), timeout=1500, host="avx2")
+    assert res.get("avx2_identical_to_c"), "the intrinsics encoder does not reproduce the C-only bitstream"
+    _check(res)
+
+
+@needs_encoder
+@pytest.mark.parametrize("case", ["tiny_tplseam_p8", "tiny_seam_p8"])
+def test_encoder_identity_emulator_avx2_host(case, tmp_path):
+    if not os.path.exists(enc_identity.ENC_AVX2):
+        pytest.skip("oracle/_ref/enc_avx2 not built")
+    from conftest import EmuBackend
+    EmuBackend()
+    res = enc_identity.run_case(case, EMU_LIB, str(tmp_path), timeout=900, host="avx2")
+    assert res.get("avx2_identical_to_c")
+    _check(res)

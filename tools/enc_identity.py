@@ -21,6 +21,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ENC = os.path.join(ROOT, "oracle", "_ref", "enc", "SvtAv1EncApp")
+# the same reference encoder with its x86 intrinsic kernels compiled in (oracle/Makefile `enc_avx2`: ASM_SSE2 .. ASM_AVX2/*.c, NASM kernels at their C versions):
+# the CPU baseline a user of the reference actually runs, and -- with the seams on -- the host half of a deployment.  Its bitstream equals the C-only encoder's.
+ENC_AVX2 = os.path.join(ROOT, "oracle", "_ref", "enc_avx2", "SvtAv1EncApp")
 
 # name: (width, height, frames, bit depth, extra encoder arguments)
 CASES = {
@@ -125,12 +128,12 @@ def make_clip(path, w, h, n, bd, seed=7):
                 f.write(p.astype(np.uint8).tobytes() if bd == 8 else (p.astype(np.uint16) << (bd - 8)).astype("<u2").tobytes())
 
 
-def encode(clip, w, h, n, bd, extra, out_prefix, env_extra=None, timeout=1800):
+def encode(clip, w, h, n, bd, extra, out_prefix, env_extra=None, timeout=1800, enc=None):
     env = dict(os.environ)
     for k in ("SVT_HIP", "SVT_HIP_LIB", "SVT_HIP_COUNT", "SVT_HIP_ONLY", "SVT_HIP_SKIP"):
         env.pop(k, None)
     env.update(env_extra or {})
-    cmd = [ENC, "-i", clip, "-w", str(w), "-h", str(h), "--fps", "30", "-n", str(n), "--input-depth", str(bd)] + extra + \
+    cmd = [enc or ENC, "-i", clip, "-w", str(w), "-h", str(h), "--fps", "30", "-n", str(n), "--input-depth", str(bd)] + extra + \
           ["-b", out_prefix + ".ivf"]
     # (no `-o` reconstruction file: the reconstruction is a function of the bitstream, and with -o the reference APP busy-polls svt_av1_get_recon on its
     # main thread, which starves the encoder's own threads on a CPU-limited box -- a 1 s encode was seen to take minutes there)
@@ -139,7 +142,9 @@ def encode(clip, w, h, n, bd, extra, out_prefix, env_extra=None, timeout=1800):
     return r, time.time() - t0
 
 
-def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
+def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, host="c"):
+    """host = "c": the C-only encoder with and without the HIP library (the identity anchor).  host = "avx2": additionally the intrinsics encoder without anything
+    (`fps_avx2`, bitstream must equal the C-only one) and the HIP run uses THAT encoder (`fps_hip` = AVX2 host kernels + device stages)."""
     w, h, n, bd, extra = CASES[name]
     os.makedirs(outdir, exist_ok=True)
     clip = os.path.join(outdir, name + ".yuv")
@@ -180,10 +185,13 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
         env["SVT_HIP_ONLY"] = only
     if skip:
         env["SVT_HIP_SKIP"] = skip
-    rh, th = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_hip"), env, timeout=timeout)
-    res = {"case": name, "width": w, "height": h, "frames": n, "bit_depth": bd, "args": extra, "rc_c": rc.returncode, "rc_hip": rh.returncode,
+    rx = None
+    if host == "avx2":
+        rx, tx = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_x"), timeout=timeout, enc=ENC_AVX2)
+    rh, th = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_hip"), env, timeout=timeout, enc=ENC_AVX2 if host == "avx2" else None)
+    res = {"case": name, "host": host, "width": w, "height": h, "frames": n, "bit_depth": bd, "args": extra, "rc_c": rc.returncode, "rc_hip": rh.returncode,
            "seconds_c": round(tc, 2), "seconds_hip": round(th, 2), "reference_deterministic": deterministic}
-    for tag, r in (("c", rc), ("hip", rh)):  # the encoder's own speed line
+    for tag, r in (("c", rc), ("hip", rh)) + ((("avx2", rx),) if rx is not None else ()):  # the encoder's own speed line
         for ln in (r.stdout + r.stderr).splitlines():
             if "Average Speed" in ln:
                 res["fps_" + tag] = float(ln.split(":")[1].split()[0])
@@ -203,6 +211,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800):
         b = open(os.path.join(outdir, name + "_hip" + ext), "rb").read()
         res["bytes" + ext] = len(a)
         same = same and len(a) > 0 and a == b
+    if rx is not None:  # the intrinsics encoder alone must reproduce the C-only bitstream too
+        x = open(os.path.join(outdir, name + "_x.ivf"), "rb").read() if rx.returncode == 0 else b""
+        res["avx2_identical_to_c"] = len(x) > 0 and x == open(os.path.join(outdir, name + "_c.ivf"), "rb").read()
+        same = same and res["avx2_identical_to_c"]
     res["identical"] = same
     if seam:
         st = dict(ln.split(None, 1) for ln in open(seam_file).read().splitlines()) if os.path.exists(seam_file) else {}
@@ -257,13 +269,14 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--skip", default=None)
     ap.add_argument("--timeout", type=int, default=1800)
+    ap.add_argument("--host", choices=("c", "avx2"), default="c", help="host build the HIP run uses (avx2: oracle/_ref/enc_avx2, also timed alone)")
     a = ap.parse_args()
     if not os.path.exists(ENC):
         sys.exit("oracle/_ref/enc/SvtAv1EncApp is missing: run `make -C oracle enc` where /root/reference exists")
     names = GPU_CASES if a.case == "all" else a.case.split(",")
     results, union = [], {}
     for nme in names:
-        r = run_case(nme, os.path.abspath(a.lib), a.out, only=a.only, skip=a.skip, timeout=a.timeout)
+        r = run_case(nme, os.path.abspath(a.lib), a.out, only=a.only, skip=a.skip, timeout=a.timeout, host=a.host)
         results.append(r)
         for k, v in r.get("counts", {}).items():
             union[k] = union.get(k, 0) + v
@@ -271,7 +284,8 @@ def main():
                                                                                         r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"],
                                                                                         str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", "")) + " " + str(r.get("tfsubpel", "")) + " " + str(r.get("tplseam", ""))), flush=True)
         if "fps_c" in r:
-            print("    encoder fps: C-only %.2f, with HIP %.2f" % (r["fps_c"], r.get("fps_hip", 0.0)), flush=True)
+            print("    encoder fps: C-only %.2f, %swith HIP (host = %s) %.2f" % (r["fps_c"], ("AVX2 intrinsics %.2f, " % r["fps_avx2"]) if "fps_avx2" in r else "", r["host"],
+                                                                               r.get("fps_hip", 0.0)), flush=True)
         if not r["identical"]:
             print(r.get("stderr_tail", ""))
     summary = {"all_identical": all(r["identical"] for r in results), "pointers_hit_union": len(union), "calls_total": sum(union.values()),
