@@ -1,14 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-.}
-O=gpurun_out/r03_call1; mkdir -p $O
-timeout 600 python -m pytest tests/test_txfm.py tests/test_hme.py tests/test_host_forms.py tests/test_quant.py -q -m gpu -x > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
-timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -c 1500 $O/bench_default.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --steps 20 --warmup 5 --no-cpu --no-parity-check --no-pmc > $O/stats.log 2>&1
-find $O -name "*kernel_trace.csv" -size +8M -delete
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/r03_call1/bench_default.json"))
-print({k:d[k] for k in ("value","ms_per_step","steps")}, d["config"].get("launches_per_step"), d["config"].get("timed_region_s"))
-print(json.dumps(d["roofline"])[:3000])
-print(json.dumps(d["cpu_baseline"])[:1500])
-print(json.dumps(d.get("encoder_fps_1080p_preset8"))[:800])
-PY
+O=gpurun_out/r03_call2; mkdir -p $O
+timeout 300 python -m pytest tests/test_tpl.py -q -m gpu -x > $O/pytest_tpl.txt 2>&1; tail -2 $O/pytest_tpl.txt
+timeout 900 python tools/enc_identity.py --case tplseam_p8_8bit,tplseam_p6_8bit_lp4,tplseam_p4_8bit,tplseam_p10_8bit,tplseam_p8_10bit,tplseam_1080p_p8,tplseam_me_p8_8bit,everyseam_p4_8bit_lp2 --out $O/identity > $O/identity.log 2>&1; grep -v "^    \|^$" $O/identity.log | cut -c1-400 | tail -12
+timeout 900 python tools/enc_identity.py --case fps_1080p_p8_all,fps_1080p_p6_all,fps_1080p_p8_me --host avx2 --out $O/fps > $O/fps.log 2>&1; cut -c1-900 $O/fps.log | tail -14
+rm -f $O/identity/*.ivf $O/fps/*.ivf
+nproc; grep -m1 "model name" /proc/cpuinfo
