@@ -59,17 +59,20 @@ typedef struct SeamPicture { /* results of one picture, consumed SB by SB */
     size_t                   cap_total, cap_cand, cap_mv, cap_stats;
 } SeamPicture;
 static struct {
-    pthread_mutex_t lock;
+    pthread_mutex_t lock;  /* the record tables (rec[], tf_rec[]) and the counters: held for table look-ups only, never across device work */
     pthread_cond_t  ready;
+    pthread_mutex_t dev;   /* the device session (picture ring, checksum table): held while residency is decided and a stage is ENQUEUED, not while it runs --
+                            * several pictures are in flight on the device at once (session slots), their owners wait outside both locks */
     int             mode; /* -1 unknown, 0 off, 1 on */
     void           *session;
     uint32_t        width, height, stride, org_x, org_y, rows;
     SeamPicture     rec[SEAM_RECS];
     uint64_t        sum[SEAM_RING * 2][2]; /* (picture id, plane checksum) of what is resident */
     uint64_t        n_pictures, n_declined, n_sb, n_uploads, n_reuploads;
-    double          t_stage, t_hash; /* seconds inside run_picture (under the lock) / of that, hashing planes */
+    double          t_stage, t_hash, t_first, t_dev_lock; /* seconds: in run_picture / run_tf_pair (all threads), hashing planes, the first stage call (session creation,
+                                                           * kernel code loading), holding the device lock */
     char            why[128];
-} G = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, -1};
+} G = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, -1};
 
 static uint64_t tf_pairs, tf_sb, tf_declined; /* the temporal filter's (picture, reference) pairs through the stage, see the end of this file */
 static void seam_stats(void) {
@@ -80,7 +83,8 @@ static void seam_stats(void) {
             (unsigned long long)G.n_pictures, (unsigned long long)G.n_declined, (unsigned long long)G.n_sb, (unsigned long long)G.n_uploads,
             (unsigned long long)G.n_reuploads, G.why[0] ? G.why : "-");
     fprintf(o, "tf_pairs_offloaded %llu\ntf_sb_results %llu\ntf_pairs_declined %llu\n", (unsigned long long)tf_pairs, (unsigned long long)tf_sb, (unsigned long long)tf_declined);
-    fprintf(o, "ms_in_stage_calls %llu\nms_hashing_planes %llu\n", (unsigned long long)(G.t_stage * 1e3), (unsigned long long)(G.t_hash * 1e3));
+    fprintf(o, "ms_in_stage_calls %llu\nms_hashing_planes %llu\nms_first_stage_call %llu\nms_holding_device_lock %llu\n", (unsigned long long)(G.t_stage * 1e3),
+            (unsigned long long)(G.t_hash * 1e3), (unsigned long long)(G.t_first * 1e3), (unsigned long long)(G.t_dev_lock * 1e3));
     fclose(o);
 }
 static void seam_init(void) { /* once (pthread_once): ME threads arriving during the initialisation wait instead of seeing "off" */
@@ -108,10 +112,13 @@ static int seam_on(void) {
 
 static double seam_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static uint64_t plane_sum_(const EbPictureBufferDesc *p);
-static uint64_t plane_sum(const EbPictureBufferDesc *p) {
+static uint64_t plane_sum(const EbPictureBufferDesc *p) { /* called OUTSIDE the locks */
     const double   t0 = seam_now();
     const uint64_t h  = plane_sum_(p);
-    G.t_hash += seam_now() - t0;
+    const double   dt = seam_now() - t0;
+    pthread_mutex_lock(&G.lock);
+    G.t_hash += dt;
+    pthread_mutex_unlock(&G.lock);
     return h;
 }
 static uint64_t plane_sum_(const EbPictureBufferDesc *p) { /* content check of the visible luma samples (padding is a function of them) */
@@ -136,9 +143,11 @@ static int sum_slot(uint64_t id, int make) {
     return free_i;
 }
 /* make `pic` (picture id `id`) resident with its current content: upload it when it is absent or its host content changed since the upload */
-static int ensure_resident(uint64_t id, const EbPictureBufferDesc *pic, const SvtHipMeStageParams *S) {
-    const uint64_t now = plane_sum(pic) | 1;
-    const int      k   = sum_slot(id, 1);
+/* (device lock held; `now` = the plane's checksum, computed by the caller outside the lock.)  The copy of a REFERENCE is waited for here: its host plane is pageable
+ * memory that another encoder thread may rewrite later (a picture is temporally filtered in place after it served as a neighbour's reference), and the runtime may
+ * still be reading it when hipMemcpyAsync returns.  ~0.1-0.3 ms per upload, ~1.3 uploads per picture. */
+static int ensure_resident(uint64_t id, const EbPictureBufferDesc *pic, const SvtHipMeStageParams *S, uint64_t now) {
+    const int k = sum_slot(id, 1);
     if (abi.resident(G.session, (int64_t)id)) {
         if (G.sum[k][1] == now) return 0;
         abi.invalidate(G.session, (int64_t)id); /* e.g. temporally filtered in place after it was uploaded */
@@ -146,7 +155,7 @@ static int ensure_resident(uint64_t id, const EbPictureBufferDesc *pic, const Sv
     }
     const int slot = abi.submit_stage(G.session, (int64_t)id, pic->buffer_y, NULL, 0, S, NULL);
     if (slot < 0) return slot;
-    abi.wait(G.session, slot); /* the host plane is pageable memory the encoder may rewrite: finish the copy before returning */
+    abi.wait(G.session, slot);
     G.sum[k][1] = now;
     G.n_uploads++;
     return 0;
@@ -261,7 +270,7 @@ static int ensure_session(PictureParentControlSet *pcs, const EbPictureBufferDes
         G.width = src->width; G.height = src->height; G.stride = src->stride_y; G.org_x = src->org_x; G.org_y = src->org_y;
         G.rows = src->luma_size / src->stride_y;
         /* largest ME area any preset derives is 256 x 256 (x 2 by the MV-based adjustment, x 3 / 2 by the variance probe) */
-        G.session = abi.create(G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 2);
+        G.session = abi.create(G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 4); /* four pictures in flight */
         if (!G.session || abi.enable_stage(G.session, pa->quarter_downsampled_picture_ptr->org_x, pa->sixteenth_downsampled_picture_ptr->org_x, 4, 768, 768)) {
             fprintf(stderr, "SVT_HIP_ME_SEAM: cannot create the ME session\n");
             abort();
@@ -272,24 +281,16 @@ static int ensure_session(PictureParentControlSet *pcs, const EbPictureBufferDes
     return 0;
 }
 
-/* the whole picture on the device; called with G.lock held by the thread that brought the picture's first SB */
+/* the whole picture on the device; called by the thread that brought the picture's first SB, WITHOUT G.lock (the record is in state 1: it belongs to this thread) */
 static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *c, const EbPictureBufferDesc *src) {
     SvtHipMeStageParams        S;
     int64_t                    ref_ids[8];
     const EbPictureBufferDesc *ref_pics[8];
+    uint64_t                   ref_sum[8];
     uint32_t                   n_refs = 0;
     if (fill_stage(pcs, c, &S, ref_ids, ref_pics, &n_refs, 0)) return -1;
-    if (ensure_session(pcs, src)) return -1;
-    for (int pass = 0;; pass++) { /* an upload may evict a reference another upload just brought in (round-robin ring): repeat until all are there */
-        int missing = 0;
-        for (uint32_t k = 0; k < n_refs; k++) {
-            if (ref_pics[k]->width != G.width || ref_pics[k]->stride_y != G.stride) return decline("reference geometry");
-            if (ensure_resident((uint64_t)ref_ids[k], ref_pics[k], &S)) return decline("reference upload");
-        }
-        for (uint32_t k = 0; k < n_refs; k++) missing += !abi.resident(G.session, ref_ids[k]);
-        if (!missing) break;
-        if (pass == 3) return decline("ring too small for the reference set");
-    }
+    for (uint32_t k = 0; k < n_refs; k++) ref_sum[k] = plane_sum(ref_pics[k]) | 1; /* content checks outside the locks */
+    const uint64_t now = plane_sum(src) | 1;
     P->n_sb = pcs->b64_total_count;
     P->n_pus = pcs->enable_me_16x16 ? (pcs->enable_me_8x8 ? 85 : 21) : 5;
     P->max_refs = S.results.max_refs; P->max_cand = S.results.max_cand;
@@ -300,19 +301,36 @@ static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *
     SvtHipMeResultsHost H;
     memset(&H, 0, sizeof(H));
     H.total_me_candidate_index = P->total; H.me_mv_array = P->mv; H.me_candidate_array = P->cand; H.sb_stats = P->stats;
-    /* the source: always (re)uploaded when its content differs from what is resident (the same picture may have served as a reference before its own ME) */
-    const uint64_t now = plane_sum(src) | 1;
-    const int      ks  = sum_slot(pcs->picture_number, 1);
-    if (abi.resident(G.session, (int64_t)pcs->picture_number) && G.sum[ks][1] != now) { abi.invalidate(G.session, (int64_t)pcs->picture_number); G.n_reuploads++; }
-    if (!abi.resident(G.session, (int64_t)pcs->picture_number)) G.n_uploads++;
-    G.sum[ks][1] = now;
-    const int slot = abi.submit_stage(G.session, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, n_refs, &S, &H);
-    if (slot < 0) {
-        char why[64];
-        snprintf(why, sizeof(why), "svt_hip_me_session_submit_stage returned %d", slot);
-        return decline(why);
+    pthread_mutex_lock(&G.dev);
+    const double td0 = seam_now();
+    int rc = ensure_session(pcs, src), slot = -1;
+    for (int pass = 0; !rc; pass++) { /* an upload may evict a reference another upload just brought in (round-robin ring): repeat until all are there */
+        int missing = 0;
+        for (uint32_t k = 0; k < n_refs && !rc; k++) {
+            if (ref_pics[k]->width != G.width || ref_pics[k]->stride_y != G.stride) rc = decline("reference geometry");
+            else if (ensure_resident((uint64_t)ref_ids[k], ref_pics[k], &S, ref_sum[k])) rc = decline("reference upload");
+        }
+        for (uint32_t k = 0; k < n_refs && !rc; k++) missing += !abi.resident(G.session, ref_ids[k]);
+        if (rc || !missing) break;
+        if (pass == 3) rc = decline("ring too small for the reference set");
     }
-    abi.wait(G.session, slot);
+    if (!rc) {
+        /* the source: (re)uploaded when its content differs from what is resident (the same picture may have served as a reference before its own ME) */
+        const int ks = sum_slot(pcs->picture_number, 1);
+        if (abi.resident(G.session, (int64_t)pcs->picture_number) && G.sum[ks][1] != now) { abi.invalidate(G.session, (int64_t)pcs->picture_number); G.n_reuploads++; }
+        if (!abi.resident(G.session, (int64_t)pcs->picture_number)) G.n_uploads++;
+        G.sum[ks][1] = now;
+        slot = abi.submit_stage(G.session, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, n_refs, &S, &H);
+        if (slot < 0) {
+            char why[64];
+            snprintf(why, sizeof(why), "svt_hip_me_session_submit_stage returned %d", slot);
+            rc = decline(why);
+        }
+    }
+    G.t_dev_lock += seam_now() - td0;
+    pthread_mutex_unlock(&G.dev);
+    if (rc) return -1;
+    abi.wait(G.session, slot); /* outside the locks: other pictures enqueue their stages meanwhile */
     return 0;
 }
 
@@ -331,9 +349,13 @@ static EbErrorType seam_motion_estimation_b64(PictureParentControlSet *pcs, uint
         P = spare;
         P->pcs = pcs; P->picture_number = pcs->picture_number; P->consumed = 0; P->state = 1;
         EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
+        pthread_mutex_unlock(&G.lock); /* the record is ours (state 1); the other SBs of this picture wait on the condition, other pictures proceed */
         const double t0 = seam_now();
-        const int rc = run_picture(P, pcs, me_ctx, pa->input_padded_pic); /* (other pictures queue on the lock: one stage at a time) */
-        G.t_stage += seam_now() - t0;
+        const int rc = run_picture(P, pcs, me_ctx, pa->input_padded_pic);
+        const double dt = seam_now() - t0;
+        pthread_mutex_lock(&G.lock);
+        G.t_stage += dt;
+        if (G.n_pictures + G.n_declined + tf_pairs + tf_declined == 0) G.t_first = dt;
         if (rc) { P->state = 3; P->n_sb = pcs->b64_total_count; G.n_declined++; }
         else    { P->state = 2; G.n_pictures++; }
         pthread_cond_broadcast(&G.ready);
@@ -402,7 +424,7 @@ enum { TF_RECS = 32 };
 typedef struct SeamTfPair {
     PictureParentControlSet *pcs;
     uint64_t                 picture_number, ref_number;
-    int                      state; /* 0 free / complete (the tables stay readable until the slot is reused), 2 ready, 3 declined */
+    int                      state; /* 0 free / complete (the tables stay readable until the slot is reused), 1 being computed, 2 ready, 3 declined */
     uint32_t                 n_sb, consumed;
     uint64_t                 stamp; /* order of creation: the oldest complete record is reused first */
     int                      tables_valid; /* the stage ran for this pair (not declined) */
@@ -423,13 +445,7 @@ static int run_tf_pair(SeamTfPair *T, PictureParentControlSet *pcs, MeContext *c
     if (fill_stage(pcs, c, &S, ref_ids, ref_pics, &n_refs, 1)) return -1;
     EbPaReferenceObject       *pa  = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
     const EbPictureBufferDesc *src = pa->input_padded_pic; /* same luma as input_picture_ptr_central at this point, in the session's geometry */
-    if (ensure_session(pcs, src)) return -1;
-    if (ref_pics[0]->width != G.width || ref_pics[0]->stride_y != G.stride) return decline("reference geometry");
-    for (int pass = 0;; pass++) {
-        if (ensure_resident((uint64_t)ref_ids[0], ref_pics[0], &S)) return decline("reference upload");
-        if (abi.resident(G.session, ref_ids[0])) break;
-        if (pass == 3) return decline("ring too small for the reference set");
-    }
+    const uint64_t ref_now = plane_sum(ref_pics[0]) | 1, now = plane_sum(src) | 1; /* outside the locks */
     T->n_sb = pcs->b64_total_count;
     reserve((void **)&T->best_sad, &T->cap_sad, (size_t)T->n_sb * 85 * 4);
     reserve((void **)&T->best_mv, &T->cap_mv, (size_t)T->n_sb * 85 * 4);
@@ -438,13 +454,26 @@ static int run_tf_pair(SeamTfPair *T, PictureParentControlSet *pcs, MeContext *c
     SvtHipMeResultsHost H;
     memset(&H, 0, sizeof(H));
     H.best_sad = T->best_sad; H.best_mv = T->best_mv; H.hme_sc = T->hme_sc; H.hme_sad = T->hme_sad;
-    const uint64_t now = plane_sum(src) | 1;
-    const int      ks  = sum_slot(pcs->picture_number, 1);
-    if (abi.resident(G.session, (int64_t)pcs->picture_number) && G.sum[ks][1] != now) { abi.invalidate(G.session, (int64_t)pcs->picture_number); G.n_reuploads++; }
-    if (!abi.resident(G.session, (int64_t)pcs->picture_number)) G.n_uploads++;
-    G.sum[ks][1] = now;
-    const int slot = abi.submit_stage(G.session, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, 1, &S, &H);
-    if (slot < 0) return decline("svt_hip_me_session_submit_stage (ME_MCTF form) refused the parameters");
+    pthread_mutex_lock(&G.dev);
+    const double td0 = seam_now();
+    int rc = ensure_session(pcs, src), slot = -1;
+    if (!rc && (ref_pics[0]->width != G.width || ref_pics[0]->stride_y != G.stride)) rc = decline("reference geometry");
+    for (int pass = 0; !rc; pass++) {
+        if (ensure_resident((uint64_t)ref_ids[0], ref_pics[0], &S, ref_now)) rc = decline("reference upload");
+        else if (abi.resident(G.session, ref_ids[0])) break;
+        else if (pass == 3) rc = decline("ring too small for the reference set");
+    }
+    if (!rc) {
+        const int ks = sum_slot(pcs->picture_number, 1);
+        if (abi.resident(G.session, (int64_t)pcs->picture_number) && G.sum[ks][1] != now) { abi.invalidate(G.session, (int64_t)pcs->picture_number); G.n_reuploads++; }
+        if (!abi.resident(G.session, (int64_t)pcs->picture_number)) G.n_uploads++;
+        G.sum[ks][1] = now;
+        slot = abi.submit_stage(G.session, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, 1, &S, &H);
+        if (slot < 0) rc = decline("svt_hip_me_session_submit_stage (ME_MCTF form) refused the parameters");
+    }
+    G.t_dev_lock += seam_now() - td0;
+    pthread_mutex_unlock(&G.dev);
+    if (rc) return -1;
     abi.wait(G.session, slot);
     return 0;
 }
@@ -465,12 +494,19 @@ EbErrorType svt_hip_seam_tf_motion_estimation_b64(PictureParentControlSet *pcs, 
         if (!spare) { fprintf(stderr, "SVT_HIP_TF_ME_SEAM: more than %d (picture, reference) pairs in flight\n", TF_RECS); abort(); }
         T = spare;
         T->pcs = pcs; T->picture_number = pcs->picture_number; T->ref_number = ref_number; T->consumed = 0; T->stamp = ++stamp;
+        T->state = 1; T->tables_valid = 0; /* being computed: the record is this thread's, the pair's other blocks wait on the condition */
+        pthread_mutex_unlock(&G.lock);
         const double t0 = seam_now();
         const int rc = run_tf_pair(T, pcs, c);
-        G.t_stage += seam_now() - t0;
+        const double dt = seam_now() - t0;
+        pthread_mutex_lock(&G.lock);
+        G.t_stage += dt;
+        if (G.n_pictures + G.n_declined + tf_pairs + tf_declined == 0) G.t_first = dt;
         if (rc) { T->state = 3; T->tables_valid = 0; T->n_sb = pcs->b64_total_count; tf_declined++; }
         else    { T->state = 2; T->tables_valid = 1; tf_pairs++; }
+        pthread_cond_broadcast(&G.ready);
     }
+    while (T->state == 1) pthread_cond_wait(&G.ready, &G.lock);
     const int declined = T->state == 3;
     if (!declined) {
         /* what svt_aom_motion_estimation_b64 leaves behind for the temporal filter (see the header of this section) */
