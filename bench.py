@@ -396,6 +396,8 @@ def encoder_fps():
     return {"fps_c_only": r.get("fps_c"), "fps_avx2_intrinsics": r.get("fps_avx2"), "fps_avx2_host_with_stage_seams": r.get("fps_hip") if have_x else None,
             "fps_c_host_with_stage_seams": rc_.get("fps_hip"), "bitstream_identical": True, "avx2_bitstream_identical_to_c": r.get("avx2_identical_to_c"),
             "frames": r["frames"], "host_threads": len(os.sched_getaffinity(0)),
+            "host_ms_per_me_stage_call": (lambda m: round(m.get("ms_in_stage_calls", 0) / max(m.get("pictures_offloaded", 0) + m.get("tf_pairs_offloaded", 0), 1), 3))(r.get("seam") or {}),
+            "host_ms_first_stage_call": (r.get("seam") or {}).get("ms_first_stage_call"),
             "config": "1080p 8-bit, preset 8, CRF 35, all host threads; the reference encoder built (a) C-only and (b) with its SSE2..AVX2 intrinsic kernels (177 NASM kernels "
                       "stay at their C versions: no nasm here); the stage seams (ME, temporal filter ME + sub-pel, TPL source half, deblocking, CDEF, LR) on the MI355X",
             "stages_on_gpu": {"me": r.get("seam"), "tf_subpel": r.get("tfsubpel"), "tpl": r.get("tplseam"), "dlf": r.get("dlfseam"), "cdef": r.get("cdefseam"),
