@@ -12,6 +12,17 @@
  * what it would have filtered; every plane is then filtered by ONE svt_hip_lpf_plane_host() call (all vertical-edge segments, then all horizontal ones).
  * Outside the seam (other threads, svt_av1_pick_filter_level's trial filterings) the recording functions forward to the pointers they replaced.
  * SVT_HIP_DLF_SEAM_STATS=<file> receives the counters at exit.
+ *
+ * Round 3 -- the path presets >= 7 actually take (dlf_ctrls.sb_based_dlf, enc_mode_config.c:1466-1487): there the picture is deblocked SB by SB INSIDE the coding loop
+ * (coding_loop.c:2278-2298: svt_aom_loop_filter_sb right after an SB is reconstructed) and this process only passes it on.  integration/coding_loop_seam.c sends that
+ * one call to svt_hip_seam_loop_filter_sb() below: the reference's svt_aom_loop_filter_sb still runs (filter levels, transform edges, skip: its own decisions) with
+ * the RECORDING leaf functions, the segments of every SB are appended to the picture's lists, and the picture is filtered by one device call per plane when it
+ * reaches this process -- before anything reads the deblocked reconstruction (the restoration boundary lines, CDEF: dlf_process.c:133-160; the call that marks the
+ * spot is the svt_aom_get_recon_pic of the pre-CDEF preparation, :136, told apart from the file's other calls with __COUNTER__).  Nothing between an SB's
+ * reconstruction and this point reads deblocked samples: intra prediction of later SBs uses the pre-filter neighbour arrays, and the picture becomes a reference
+ * only after the in-loop filters.  The set of segments is the one the frame-level driver produces (it calls the same svt_aom_loop_filter_sb for every SB,
+ * deblocking_filter.c:642-653), and the device applies all vertical edges, then all horizontal ones -- the order of the standard, which the reference's staggered
+ * in-place order must (and does) reproduce.
  */
 #define _GNU_SOURCE /* RTLD_DEFAULT */
 #include <dlfcn.h>
@@ -23,6 +34,7 @@
 #include "pcs.h"
 #include "sequence_control_set.h"
 #include "aom_dsp_rtcd.h"
+#include "deblocking_filter.h" /* svt_aom_loop_filter_sb */
 #include "svtav1_hip.h" /* include/svtav1_hip.h of this repository: the C ABI */
 
 void svt_av1_loop_filter_frame(EbPictureBufferDesc *frame_buffer, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end);
@@ -35,7 +47,7 @@ static struct {
     void (*plane_host)(void *, uint32_t, uint32_t, uint32_t, int, int, const SvtHipLpfEdge *, uint32_t, const SvtHipLpfEdge *, uint32_t);
     LpfFn    orig[2][4];     /* [vertical][length index 4, 6, 8, 14] */
     LpfHbdFn orig_hbd[2][4];
-    uint64_t n_pictures, n_segments;
+    uint64_t n_pictures, n_segments, n_sb_pictures, n_sb_calls;
 } F = {PTHREAD_MUTEX_INITIALIZER};
 
 typedef struct { SvtHipLpfEdge *e; uint32_t n, cap; } EdgeList;
@@ -77,7 +89,8 @@ static void dlf_seam_stats(void) {
     const char *f = getenv("SVT_HIP_DLF_SEAM_STATS");
     FILE       *o = f ? fopen(f, "w") : NULL;
     if (!o) return;
-    fprintf(o, "pictures_filtered %llu\nsegments %llu\n", (unsigned long long)F.n_pictures, (unsigned long long)F.n_segments);
+    fprintf(o, "pictures_filtered %llu\nsegments %llu\npictures_filtered_from_sb_records %llu\nsb_calls_recorded %llu\n", (unsigned long long)F.n_pictures,
+            (unsigned long long)F.n_segments, (unsigned long long)F.n_sb_pictures, (unsigned long long)F.n_sb_calls);
     fclose(o);
 }
 static void dlf_seam_init(void) {
@@ -100,13 +113,12 @@ static int dlf_seam_on(void) {
     return F.mode;
 }
 
-static void seam_loop_filter_frame(EbPictureBufferDesc *fb, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end) {
-    if (!dlf_seam_on()) { svt_av1_loop_filter_frame(fb, pcs, plane_start, plane_end); return; }
+/* geometry of the picture's three planes for the recorders (both seams) */
+static void set_planes(EbPictureBufferDesc *fb, const PictureControlSet *pcs, uint32_t *w, uint32_t *h) {
     const bool is_16bit = pcs->scs->is_16bit_pipeline;
     T.px = is_16bit ? 2 : 1;
     const uint32_t strides[3] = {fb->stride_y, fb->stride_cb, fb->stride_cr};
     uint8_t       *bufs[3]    = {fb->buffer_y, fb->buffer_cb, fb->buffer_cr};
-    uint32_t       w[3], h[3];
     for (int pl = 0; pl < 3; pl++) {
         const int ss = pl > 0;
         const uint32_t ox = fb->org_x >> ss, oy = fb->org_y >> ss;
@@ -115,24 +127,111 @@ static void seam_loop_filter_frame(EbPictureBufferDesc *fb, PictureControlSet *p
         T.base[pl]   = bufs[pl] + ((size_t)oy * strides[pl] + ox) * T.px;
         T.list[pl][0].n = T.list[pl][1].n = 0;
     }
+}
+/* one device call per plane over the given lists */
+static uint64_t filter_planes(const PictureControlSet *pcs, const uint32_t *w, EdgeList (*list)[2]) {
+    const bool is_16bit = pcs->scs->is_16bit_pipeline;
+    const int  bd = is_16bit ? (int)pcs->scs->static_config.encoder_bit_depth : 8;
+    uint64_t   segs = 0;
+    for (int pl = 0; pl < 3; pl++) {
+        const uint32_t nv = list[pl][1].n, nh = list[pl][0].n;
+        if (!(nv + nh)) continue;
+        uint32_t rows = 0; /* upload only the rows the segments reach */
+        for (uint32_t i = 0; i < nv; i++) { const uint32_t r = list[pl][1].e[i].y + 4; rows = r > rows ? r : rows; }
+        for (uint32_t i = 0; i < nh; i++) { const uint32_t r = list[pl][0].e[i].y + 8; rows = r > rows ? r : rows; }
+        F.plane_host((void *)T.base[pl], (uint32_t)T.stride[pl], ((w[pl] + 7) & ~7u), rows, is_16bit, bd, list[pl][1].e, nv, list[pl][0].e, nh);
+        segs += nv + nh;
+    }
+    return segs;
+}
+
+/* ---- SB-based deblocking (coding_loop.c:2297 through integration/coding_loop_seam.c): per-picture segment lists filled SB by SB from the EncDec threads ---- */
+enum { SB_RECS = 64 };
+typedef struct SbPicture {
+    PictureControlSet *pcs;
+    uint64_t           picture_number;
+    int                live;
+    uint32_t           calls;
+    EdgeList           list[3][2];
+} SbPicture;
+static SbPicture sb_rec[SB_RECS];
+
+void svt_hip_seam_loop_filter_sb(EbPictureBufferDesc *fb, PictureControlSet *pcs, int32_t mi_row, int32_t mi_col, int32_t plane_start, int32_t plane_end, uint8_t last_col) {
+    if (!dlf_seam_on()) { svt_aom_loop_filter_sb(fb, pcs, mi_row, mi_col, plane_start, plane_end, last_col); return; }
+    uint32_t w[3], h[3];
+    set_planes(fb, pcs, w, h);
+    T.on = 1;
+    svt_aom_loop_filter_sb(fb, pcs, mi_row, mi_col, plane_start, plane_end, last_col); /* the reference's per-SB driver, recording */
+    T.on = 0;
+    pthread_mutex_lock(&F.lock);
+    SbPicture *R = NULL, *spare = NULL;
+    for (int i = 0; i < SB_RECS; i++) {
+        if (sb_rec[i].live && sb_rec[i].pcs == pcs && sb_rec[i].picture_number == pcs->picture_number) { R = &sb_rec[i]; break; }
+        if (!sb_rec[i].live && !spare) spare = &sb_rec[i];
+    }
+    if (!R) {
+        if (!spare) { fprintf(stderr, "SVT_HIP_DLF_SEAM: more than %d pictures between the coding loop and the deblocking process\n", SB_RECS); abort(); }
+        R = spare; R->live = 1; R->pcs = pcs; R->picture_number = pcs->picture_number; R->calls = 0;
+        for (int pl = 0; pl < 3; pl++) R->list[pl][0].n = R->list[pl][1].n = 0;
+    }
+    for (int pl = 0; pl < 3; pl++)
+        for (int v = 0; v < 2; v++) {
+            const EdgeList *src = &T.list[pl][v];
+            EdgeList       *dst = &R->list[pl][v];
+            if (!src->n) continue;
+            if (dst->n + src->n > dst->cap) { dst->cap = 2 * (dst->n + src->n) + 4096; dst->e = realloc(dst->e, (size_t)dst->cap * sizeof(*dst->e)); }
+            memcpy(dst->e + dst->n, src->e, (size_t)src->n * sizeof(*src->e));
+            dst->n += src->n;
+        }
+    R->calls++;
+    F.n_sb_calls++;
+    pthread_mutex_unlock(&F.lock);
+}
+/* the picture has reached the deblocking process: apply what its SBs recorded (nothing when the picture was not deblocked SB by SB) */
+static void flush_sb_picture(PictureControlSet *pcs) {
+    if (!dlf_seam_on()) return;
+    pthread_mutex_lock(&F.lock);
+    SbPicture *R = NULL;
+    for (int i = 0; i < SB_RECS; i++)
+        if (sb_rec[i].live && sb_rec[i].pcs == pcs && sb_rec[i].picture_number == pcs->picture_number) { R = &sb_rec[i]; break; }
+    pthread_mutex_unlock(&F.lock);
+    if (!R) return; /* (every SB of the picture has passed the coding loop: nobody appends to the record any more) */
+    EbPictureBufferDesc *fb;
+    svt_aom_get_recon_pic(pcs, &fb, pcs->scs->is_16bit_pipeline);
+    uint32_t w[3], h[3];
+    set_planes(fb, pcs, w, h);
+    const uint64_t segs = filter_planes(pcs, w, R->list);
+    pthread_mutex_lock(&F.lock);
+    R->live = 0;
+    F.n_pictures++; F.n_sb_pictures++; F.n_segments += segs;
+    pthread_mutex_unlock(&F.lock);
+}
+
+static void seam_loop_filter_frame(EbPictureBufferDesc *fb, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end) {
+    if (!dlf_seam_on()) { svt_av1_loop_filter_frame(fb, pcs, plane_start, plane_end); return; }
+    uint32_t w[3], h[3];
+    set_planes(fb, pcs, w, h);
     T.on = 1;
     svt_av1_loop_filter_frame(fb, pcs, plane_start, plane_end); /* the reference's driver, recording */
     T.on = 0;
-    const int bd = is_16bit ? (int)pcs->scs->static_config.encoder_bit_depth : 8;
-    uint64_t  segs = 0;
-    for (int pl = 0; pl < 3; pl++) {
-        const uint32_t nv = T.list[pl][1].n, nh = T.list[pl][0].n;
-        if (!(nv + nh)) continue;
-        uint32_t rows = 0; /* upload only the rows the segments reach */
-        for (uint32_t i = 0; i < nv; i++) { const uint32_t r = T.list[pl][1].e[i].y + 4; rows = r > rows ? r : rows; }
-        for (uint32_t i = 0; i < nh; i++) { const uint32_t r = T.list[pl][0].e[i].y + 8; rows = r > rows ? r : rows; }
-        F.plane_host((void *)T.base[pl], strides[pl], ((w[pl] + 7) & ~7u), rows, is_16bit, bd, T.list[pl][1].e, nv, T.list[pl][0].e, nh);
-        segs += nv + nh;
-    }
+    const uint64_t segs = filter_planes(pcs, w, T.list);
     pthread_mutex_lock(&F.lock);
     F.n_pictures++; F.n_segments += segs;
     pthread_mutex_unlock(&F.lock);
 }
 
+/* svt_aom_get_recon_pic's uses in dlf_process.c, in file order: the two prototypes (:23, :28), the 8-bit -> 16-bit conversion (:90, :91), the frame filter (:108) and
+ * the pre-CDEF preparation (:136) -- the point every picture passes after its deblocking and before anything reads the result */
+void svt_aom_get_recon_pic(PictureControlSet *pcs, EbPictureBufferDesc **recon_ptr, bool is_highbd);
+static void get_recon_use2(PictureControlSet *pcs, EbPictureBufferDesc **r, bool hbd) { svt_aom_get_recon_pic(pcs, r, hbd); }
+static void get_recon_use3(PictureControlSet *pcs, EbPictureBufferDesc **r, bool hbd) { svt_aom_get_recon_pic(pcs, r, hbd); }
+static void get_recon_use4(PictureControlSet *pcs, EbPictureBufferDesc **r, bool hbd) { svt_aom_get_recon_pic(pcs, r, hbd); }
+static void get_recon_use5(PictureControlSet *pcs, EbPictureBufferDesc **r, bool hbd) {
+    flush_sb_picture(pcs);
+    svt_aom_get_recon_pic(pcs, r, hbd);
+}
+#define SEAM_CAT_(a, b) a##b
+#define SEAM_CAT(a, b) SEAM_CAT_(a, b)
+#define svt_aom_get_recon_pic(...) SEAM_CAT(get_recon_use, __COUNTER__)(__VA_ARGS__)
 #define svt_av1_loop_filter_frame(a, b, c, d) seam_loop_filter_frame(a, b, c, d)
 #include "dlf_process.c" /* resolves through -I$(REF)/Source/Lib/Codec */

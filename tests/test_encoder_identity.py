@@ -29,6 +29,8 @@ def _check(res):
     assert res["identical"], "the bitstream differs from the C-only encoder: %s" % res["case"]
     if "dlfseam" in res and res["case"].startswith(("dlfseam_", "tiny_dlfseam")):  # deblocking segments were filtered on the device
         assert res["dlfseam"].get("segments", 0) > 0, res["dlfseam"]
+    if "dlfseam" in res and "_sb_" in res["case"]:  # presets >= 7: the segments came from the per-SB records of the coding loop
+        assert res["dlfseam"].get("pictures_filtered_from_sb_records", 0) > 0, res["dlfseam"]
     if "cdefseam" in res:  # pictures were CDEF-filtered on the device, none declined
         assert res["cdefseam"]["filter_blocks"] > 0 and res["cdefseam"]["pictures_declined"] == 0, res["cdefseam"]
     if "lrseam" in res:  # restoration units were searched on the device
@@ -44,7 +46,7 @@ def _check(res):
 
 
 @needs_encoder
-@pytest.mark.parametrize("case", ["tiny_p8_8bit", "tiny_p8_10bit", "tiny_p8_lossless", "tiny_seam_p8", "tiny_seam_p5_lp2", "tiny_lrseam_p4", "tiny_cdefseam_p8", "tiny_dlfseam_p4", "tiny_tfseam_p8", "tiny_tfsubpel_p8", "tiny_tplseam_p8", "tiny_tplseam_p10"])
+@pytest.mark.parametrize("case", ["tiny_p8_8bit", "tiny_p8_10bit", "tiny_p8_lossless", "tiny_seam_p8", "tiny_seam_p5_lp2", "tiny_lrseam_p4", "tiny_cdefseam_p8", "tiny_dlfseam_p4", "tiny_tfseam_p8", "tiny_tfsubpel_p8", "tiny_tplseam_p8", "tiny_tplseam_p10", "tiny_dlfseam_sb_p8", "tiny_dlfseam_sb_p8_lp2"])
 def test_encoder_identity_emulator(case, tmp_path):
     from conftest import EmuBackend  # builds the emulator library if needed
     EmuBackend()

@@ -63,6 +63,11 @@ CASES = {
     "dlfseam_p5_8bit": (448, 264, 8, 8, ["--preset", "5", "--lp", "1", "+dlfseam"]),
     "dlfseam_p2_10bit": (256, 144, 5, 10, ["--preset", "2", "--lp", "1", "+dlfseam"]),
     "dlfseam_p6_8bit_lp4": (448, 264, 8, 8, ["--preset", "6", "--lp", "4", "+dlfseam"]),
+    # presets >= 7 deblock SB by SB inside the coding loop (coding_loop.c:2278): recorded per SB, filtered per picture on the device
+    "dlfseam_sb_p8_8bit": (448, 264, 12, 8, ["--preset", "8", "--lp", "1", "+dlfseam"]),
+    "dlfseam_sb_p8_8bit_lp4": (448, 264, 12, 8, ["--preset", "8", "--lp", "4", "+dlfseam"]),
+    "dlfseam_sb_p10_10bit": (256, 144, 10, 10, ["--preset", "10", "--lp", "1", "+dlfseam"]),
+    "dlfseam_sb_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+dlfseam"]),
     "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+tfsubpel", "+dlfseam", "+cdefseam", "+lrseam", "+tplseam"]),
     "everyseam_4k10_p8_lp1": (3840, 2160, 6, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),  # config-5 format, single-threaded (reproducible)
     # the temporal filter's ME (ME_MCTF form of the stage, one call per (central picture, reference picture) pair): SVT_HIP_TF_ME_SEAM=1 on top of the ME seam
@@ -101,6 +106,8 @@ CASES = {
     "tiny_tfsubpel_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
     "tiny_tfseam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tiny_dlfseam_p4": (128, 64, 3, 8, ["--preset", "4", "--lp", "1", "+dlfseam"]),
+    "tiny_dlfseam_sb_p8": (192, 128, 6, 8, ["--preset", "8", "--lp", "1", "+dlfseam"]),
+    "tiny_dlfseam_sb_p8_lp2": (192, 128, 6, 8, ["--preset", "8", "--lp", "2", "+dlfseam"]),
     "tiny_cdefseam_p8": (128, 64, 3, 8, ["--preset", "8", "--lp", "1", "+cdefseam"]),
     "tiny_lrseam_p4": (96, 64, 3, 8, ["--preset", "4", "--lp", "1", "+lrseam"]),
     "tiny_seam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam"]),
@@ -239,8 +246,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     if dlfseam:
         st = dict(ln.split(None, 1) for ln in open(dlfseam_file).read().splitlines()) if os.path.exists(dlfseam_file) else {}
         res["dlfseam"] = {k: int(v) for k, v in st.items()}
-        if name.startswith(("dlfseam_", "tiny_dlfseam")):  # the dedicated cases must really filter segments on the device (other configurations may pick
-            res["identical"] = res["identical"] and res["dlfseam"].get("segments", 0) > 0  # filter level 0, or deblock SB by SB inside the coding loop)
+        if name.startswith(("dlfseam_", "tiny_dlfseam", "fps_1080p_p8_all", "everyseam_4k10_p8")):  # the dedicated cases and the metric's preset-8 case must really
+            res["identical"] = res["identical"] and res["dlfseam"].get("segments", 0) > 0               # filter segments on the device (other configurations may pick level 0)
+        if "_sb_" in name or name.startswith("fps_1080p_p8_all"):  # ... and, at presets >= 7, from the per-SB records of the coding loop
+            res["identical"] = res["identical"] and res["dlfseam"].get("pictures_filtered_from_sb_records", 0) > 0
     if tplseam:
         st = dict(ln.split(None, 1) for ln in open(tplseam_file).read().splitlines()) if os.path.exists(tplseam_file) else {}
         res["tplseam"] = {k: int(float(v)) for k, v in st.items()}
