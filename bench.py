@@ -73,7 +73,7 @@ def live_pmc(a):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         td = tempfile.mkdtemp(prefix="svt_pmc_", dir="/tmp")
         cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", td, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
-               "--frames", str(a.frames), "--refs", str(a.refs), "--area", a.area]
+               "--frames", str(a.frames), "--refs", str(a.refs), "--area", a.area] + (["--legs", a.legs] if a.legs else [])
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=300, capture_output=True)
             files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
@@ -463,7 +463,7 @@ def bench_sad_pairs(torch, lib, pkg, stream, a, cpu):
         checked += must_equal("sad64x64_pairs", got[f * 510:(f + 1) * 510], want)
     per, reps = time_leg(torch, fn, a.min_leg_s)
     out = {"launches_per_timed_batch": reps, "value": len(pairs) / per / 1e6, "unit": "Mblocks/s (64x64 pairs)", "footprint_MB": 2 * n_src * PLANE / 1e6, "parity_checked_values": checked,
-           "roofline": roofline(len(pairs) * 8192, per, "sad_nxm_pipe_kernel", algorithmic_bytes_per_block=8192,
+           "roofline": roofline(len(pairs) * 8192, per, "sad_nxm_pipe_kernel" if os.environ.get("SVT_HIP_SAD_FORM") == "1" else "sad_nxm_strip_kernel", algorithmic_bytes_per_block=8192,
                                 note="disjoint src / ref plane sets, each byte read once per launch; footprint 1.2 GB")}
     if cpu:
         ref, oracle = ref_libs()
@@ -700,7 +700,8 @@ def bench_cdef(torch, lib, pkg, stream, a, cpu):
         bytes_alg = Wc * Hc * 2 * 2 + (D["nfb"] * 64 * 8 if mode else 0)  # apply: read + write; search: recon + source, 8 B per (fb, strength)
         out[name] = {"launches_per_timed_batch": reps, "value": units / per / 1e6, "unit": "M(8x8 block x strength)/s" if mode else "M(8x8 blocks)/s", "frames_per_s": 1 / per,
                      "parity_checked_values": checked,
-                     "roofline": roofline(bytes_alg, per, "cdef_frame_kernel<unsigned short, %d>" % mode, algorithmic_bytes_per_frame=bytes_alg)}
+                     "roofline": roofline(bytes_alg, per, "cdef_frame_kernel<unsigned short, %d, %s>" % (mode, (os.environ.get("SVT_HIP_CDEF_MINB") or "3") if mode else "4"),
+                                          algorithmic_bytes_per_frame=bytes_alg)}
     # apply with the directions the search pass just wrote (mode 2: what the CDEF stage runs after its strength search)
     P2 = params(D, 0)
     fn2 = lambda: lib.svt_hip_cdef_frame(2, C.byref(P2), stream)  # noqa: E731
@@ -856,6 +857,7 @@ def main():
     ap.add_argument("--min-leg-s", type=float, default=MIN_TIMED_S, help="minimum device time of every timed region (a step = as many launches as that takes)")
     ap.add_argument("--no-pmc", action="store_true", help="skip this run's own rocprofv3 --pmc child passes (roofline.traffic then comes from the committed summary)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (sad, txfm, config3, cdef, lr, hme, session, tf, lrsearch): A/B measurements")
     ap.add_argument("--extra", action="store_true", help="also sweep the other search areas / sub_sad and the remaining stages (reported under kernels)")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -968,27 +970,37 @@ def main():
     cpu = rank == 0 and world == 1 and not a.no_cpu
     import bench_legs
     bench_legs.MIN_S = a.min_leg_s
+    want = (lambda leg: not a.legs or leg in a.legs.split(","))
     if not a.only_me:
-        kernels["sad64x64_pairs"] = bench_sad_pairs(torch, lib, pkg, stream, a, cpu)
-        kernels.update(bench_fwd_txfm(torch, lib, pkg, stream, a, cpu))
-        kernels["config3_roundtrip"] = bench_config3(torch, lib, pkg, stream, a)
-        kernels.update(bench_cdef(torch, lib, pkg, stream, a, cpu))
-        lr_checked = check_lr_small(torch, lib, pkg, stream)
-        lr = bench_legs.lr_frames(torch, lib, pkg, stream, max(a.steps // 10, 4), 2)
-        for v in lr.values():
-            v["parity_checked_values"] = lr_checked
-        kernels.update(lr)
-        kernels.update(bench_legs.hme_chain(torch, lib, pkg, stream, max(a.steps // 4, 8), 2))
-        kernels.update(bench_legs.me_session_stage(torch, lib, pkg, stream, 12, 1))
-        keep = {}
-        kernels.update(bench_legs.tf_subpel(torch, lib, pkg, stream, 5, 1, keep))
-        if cpu:
-            kernels["tf_subpel_1080p8_6refs"].update(cpu_tf_subpel(keep, budget_s=4.0))
-        keep = {}
-        kernels.update(bench_legs.lr_search(torch, lib, pkg, stream, 2, 1, keep))
-        if cpu:
-            for name in keep:
-                kernels[name].update(cpu_lr_search(keep[name], budget_s=5.0))
+        if want("sad"):
+            kernels["sad64x64_pairs"] = bench_sad_pairs(torch, lib, pkg, stream, a, cpu)
+        if want("txfm"):
+            kernels.update(bench_fwd_txfm(torch, lib, pkg, stream, a, cpu))
+        if want("config3"):
+            kernels["config3_roundtrip"] = bench_config3(torch, lib, pkg, stream, a)
+        if want("cdef"):
+            kernels.update(bench_cdef(torch, lib, pkg, stream, a, cpu))
+        if want("lr"):
+            lr_checked = check_lr_small(torch, lib, pkg, stream)
+            lr = bench_legs.lr_frames(torch, lib, pkg, stream, max(a.steps // 10, 4), 2)
+            for v in lr.values():
+                v["parity_checked_values"] = lr_checked
+            kernels.update(lr)
+        if want("hme"):
+            kernels.update(bench_legs.hme_chain(torch, lib, pkg, stream, max(a.steps // 4, 8), 2))
+        if want("session"):
+            kernels.update(bench_legs.me_session_stage(torch, lib, pkg, stream, 12, 1))
+        if want("tf"):
+            keep = {}
+            kernels.update(bench_legs.tf_subpel(torch, lib, pkg, stream, 5, 1, keep))
+            if cpu:
+                kernels["tf_subpel_1080p8_6refs"].update(cpu_tf_subpel(keep, budget_s=4.0))
+        if want("lrsearch"):
+            keep = {}
+            kernels.update(bench_legs.lr_search(torch, lib, pkg, stream, 2, 1, keep))
+            if cpu:
+                for name in keep:
+                    kernels[name].update(cpu_lr_search(keep[name], budget_s=5.0))
     if a.extra:
         for (w2, h2, sub) in [(16, 9, 1), (64, 32, 0), (256, 256, 0)]:
             nf = a.frames if w2 < 64 else (4 if w2 < 256 else 1)
@@ -1029,7 +1041,7 @@ def main():
         host_descs = pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, aw, ah, PLANE, n_refs=1, src_plane=0, ref_plane0=1)
         out["cpu_baseline"] = cpu_me_baseline(host_descs, planes, planes, (aw, ah), budget_s=10.0)
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        if not a.only_me:
+        if not a.only_me and not a.legs:
             out["encoder_fps_1080p_preset8"] = encoder_fps()
     elif rank == 0:
         out["cpu_baseline"] = None
@@ -1054,6 +1066,8 @@ def main():
     if "config3_roundtrip" in kernels:
         rf["kernels"]["config3_roundtrip"] = {"sizes_checked_vs_oracle": kernels["config3_roundtrip"]["sizes_checked"],
                                               "hbm_frac_min_max": kernels["config3_roundtrip"]["hbm_frac_min_max"]}
+    if a.legs:
+        out.pop("frame_partition", None)
     if out.get("cpu_baseline"):
         cb = out["cpu_baseline"]["kernels"] = {}
         for name, k in kernels.items():

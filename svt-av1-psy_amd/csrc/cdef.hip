@@ -364,11 +364,19 @@ struct LaneCtx {
     const uint16_t* org; // search mode: source block, pitch bw
     int pitch, bw, by, bx, uw, uh, q, sub, cs, pdamp, sdamp, vm;
 };
+// LEAN (the search pass): the two tap weights are rebuilt from one per-level value inside the row loop instead of living in two registers per level -- the pass
+// keeps 48 running sums and was 4 VGPRs over the 168 that three workgroups per CU allow (the opaque copy keeps the compiler from hoisting them back out).
+template <bool LEAN = false>
 __device__ __forceinline__ s16x2 pri_sum_level(const LaneCtx& L, const int lvl, const s16x2 x, const s16x2 (&t)[12]) {
     const int t_  = ((lvl << L.cs) * L.vm + 8) >> 4; // adjust_strength (cdef.c:130-134); lane-varying for luma, identity for chroma (vm = 16)
     int       sh  = L.pdamp - msb_u32((uint32_t)t_);
     sh            = sh < 0 ? 0 : sh;
     const int odd = (t_ >> L.cs) & 1; // svt_aom_eb_cdef_pri_taps (cdef.c:249)
+    if (LEAN) {
+        int ov = odd * 0x10001; // the packed pair (odd, odd)
+        SVT_HIP_OPAQUE_I32(ov);
+        return pri_sum(x, t, splat(t_), splat(sh), splat(4) - as_pk((uint32_t)ov), splat(2) + as_pk((uint32_t)ov));
+    }
     return pri_sum(x, t, splat(t_), splat(sh), splat(4 - odd), splat(2 + odd));
 }
 __device__ __forceinline__ s16x2 sec_sum_strength(const LaneCtx& L, const int sec, const s16x2 x, const s16x2 (&t)[12]) {
@@ -487,8 +495,11 @@ __device__ __forceinline__ void apply_pass(const LaneCtx& L, const TapOffs& o, c
 // One workgroup = one 64x64 filter block (apply) or one filter block x one group of four primary levels (search: blockIdx.y = g takes the
 // 4g-th .. (4g+3)-th distinct non-zero primary levels of the candidate list, each against all four secondary strengths; g = 0 also takes
 // primary level 0).  A quad owns an 8x8 (4x4 / 4x8 / 8x4 for subsampled chroma) unit; a lane filters uh / 4 rows, two pixels per packed op.
-template <typename PIX, int MODE>
-__global__ __launch_bounds__(256, 4) void cdef_frame_kernel(const SvtHipCdefParams P, const int gpw, const int reuse_dir) {
+// MINB = workgroups per CU the register budget is cut for (__launch_bounds__): the apply kernel fits 4 (101 VGPRs); the search pass keeps 48 running sums (16 cells x
+// {s, s^2, s*d}) + 12 taps + 7 partial sums per lane and at 4 (128 VGPRs) spilt 172 bytes per lane -- 89 MB of scratch traffic per 4K plane (profiles/r02_kernel_resources.txt,
+// r02_reg9_pmc_traffic.json) -- so it is built for 3 (up to 170 VGPRs, no scratch).
+template <typename PIX, int MODE, int MINB = (MODE == 1 ? 3 : 4)>
+__global__ __launch_bounds__(256, MINB) void cdef_frame_kernel(const SvtHipCdefParams P, const int gpw, const int reuse_dir) {
     HIP_DYNAMIC_SHARED(uint16_t, tile_raw)
     __shared__ int                sh_any, sh_dc[4][64], sh_dd[4][64], sh_do[4][64];
     __shared__ unsigned long long sh_cells[20]; // [4 levels][4 secondary] + [level 0][4 secondary]
@@ -672,7 +683,13 @@ template <int MODE> void launch_frame(const SvtHipCdefParams& P, hipStream_t st,
         gpw = e ? e : (nhfb * nvfb >= 2040 ? 4 : (nhfb * nvfb >= 1020 ? 2 : 1)); // 4K luma: 378 us with 4, 386 with 2, 418 with 1 (profiles/r02_call8_*)
     }
     const dim3 grid(nhfb * nvfb, MODE == 1 ? 4 / gpw : 1);
-    if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
+    if (MODE == 1 && svthip::tuning_cdef_search_minb() == 4) { // (measurement knob SVT_HIP_CDEF_MINB=4: the round-2 build of the search kernel, 128 VGPRs + scratch)
+        if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE, 4>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE, 4>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
+    } else if (MODE == 1 && svthip::tuning_cdef_search_minb() == 2) { // (SVT_HIP_CDEF_MINB=2: 172 VGPRs, no scratch at all, two workgroups per CU)
+        if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE, 2>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE, 2>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
+    } else if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
     SVT_LAUNCH_CHECK();
 }

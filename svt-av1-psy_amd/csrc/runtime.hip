@@ -97,17 +97,29 @@ void HostCall::down2d(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch
 }
 void HostCall::sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
 
-static std::atomic<int> g_tune_lr_ur{-1}, g_tune_cdef_gpw{-1}; // -1: not read yet
+static std::atomic<int> g_tune_lr_ur{-1}, g_tune_cdef_gpw{-1}, g_tune_cdef_minb{3}, g_tune_sad_form{0}; // -1: not read yet
 static void tuning_read() {
     const char* a = getenv("SVT_HIP_LR_UR");
     const char* b = getenv("SVT_HIP_CDEF_GPW");
     const int   ur = a ? atoi(a) : 32, gp = b ? atoi(b) : 0;
     g_tune_lr_ur    = (ur == 16 || ur == 64) ? ur : 32;
     g_tune_cdef_gpw = (gp == 1 || gp == 2 || gp == 4) ? gp : 0;
+    const char* sf = getenv("SVT_HIP_SAD_FORM");
+    g_tune_sad_form = (sf && atoi(sf) == 1) ? 1 : 0;
+    const char* m = getenv("SVT_HIP_CDEF_MINB");
+    g_tune_cdef_minb = (m && (atoi(m) == 4 || atoi(m) == 2)) ? atoi(m) : 3;
 }
 int tuning_lr_rows_per_workgroup() {
     if (g_tune_lr_ur < 0) tuning_read();
     return g_tune_lr_ur;
+}
+int tuning_sad_form() {
+    if (g_tune_cdef_gpw < 0) tuning_read();
+    return g_tune_sad_form;
+}
+int tuning_cdef_search_minb() {
+    if (g_tune_cdef_gpw < 0) tuning_read();
+    return g_tune_cdef_minb;
 }
 int tuning_cdef_groups_per_workgroup() {
     if (g_tune_cdef_gpw < 0) tuning_read();

@@ -555,6 +555,84 @@ __global__ __launch_bounds__(256) void sad_nxm_pipe_kernel(const uint8_t* __rest
     }
 }
 
+// Strip form (round 3): the wave's 64 lanes are laid over FOUR ROWS x 256 BYTES -- 16 / cpr blocks side by side (four 64-wide blocks), cpr lanes per block row -- and
+// walk down the blocks four rows per step.  With horizontally adjacent blocks (the 510 SBs of a picture row by row: config 1) one wave instruction then reads four
+// runs of 256 CONTIGUOUS bytes = 12 cache-line requests, two thirds of them fully used, where the pair-per-wave forms read sixteen separate 64-byte row pieces =
+// 32 line requests, every line shared with the neighbouring block's wave (rows start at byte 68 of a 2056-byte pitch: each 64-byte piece straddles two 128-byte
+// lines; traffic was 1.35 x the algorithmic bytes, profiles/r03_call1_bench_default.json).  Nothing requires the blocks to be adjacent -- every lane addresses its
+// own pair's descriptor -- adjacency only decides how well the requests coalesce.  Loads are pipelined two groups of four steps deep across the strips a wave walks.
+constexpr int SADS_SPW = 4; // strips per wave
+struct StripRegs { uint32_t a[4][4], b[4][4]; };
+__device__ __forceinline__ void strip_issue(StripRegs& r, const uint8_t* __restrict__ sp, const uint8_t* __restrict__ rp, const uint32_t ss, const uint32_t rs,
+                                            const int row0, const int ro, const int height, const bool live) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = row0 + 4 * k; // relative to the lane's own first row `ro` (already in sp / rp)
+        u32x4_a1  a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (live && row + ro < height) {
+            a = *(const u32x4_a1*)(sp + (size_t)row * ss);
+            b = *(const u32x4_a1*)(rp + (size_t)row * rs);
+        }
+        r.a[k][0] = a.x; r.a[k][1] = a.y; r.a[k][2] = a.z; r.a[k][3] = a.w;
+        r.b[k][0] = b.x; r.b[k][1] = b.y; r.b[k][2] = b.z; r.b[k][3] = b.w;
+    }
+}
+__device__ __forceinline__ uint32_t strip_consume(const StripRegs& r, uint32_t sad) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sad = __builtin_amdgcn_sad_u8(r.a[k][j], r.b[k][j], sad);
+    return sad;
+}
+__global__ __launch_bounds__(256) void sad_nxm_strip_kernel(const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                            const SvtHipSadPair* __restrict__ pairs, const uint32_t n, const int cshift /* log2(width / 16) */,
+                                                            const int height, uint32_t* __restrict__ sad_out) {
+    const int      l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int      cpr = 1 << cshift, nb = 16 >> cshift;            // lanes per block row, blocks per strip
+    const int      sb = (l & 15) >> cshift, j = l & (cpr - 1), ro = l >> 4;
+    const int      groups = (height + 15) >> 4;                    // groups of four steps (16 rows)
+    const uint32_t strip0 = (xcd_remap(blockIdx.x, gridDim.x) * 4 + (uint32_t)w) * SADS_SPW;
+    if (strip0 * (uint32_t)nb >= n) return;
+    // unit u = (strip k, group g); the loads of unit u + 1 are issued before unit u is reduced
+    const uint8_t *sp = nullptr, *rp = nullptr;
+    uint32_t       ss = 0, rs = 0;
+    bool           live = false;
+    auto open_strip = [&](const int k) {
+        const uint32_t pair = (strip0 + (uint32_t)k) * (uint32_t)nb + (uint32_t)sb;
+        live = k < SADS_SPW && pair < n;
+        if (live) {
+            const SvtHipSadPair p = pairs[pair];
+            sp = src_base + p.src_off + (size_t)ro * p.src_stride + j * 16;
+            rp = ref_base + p.ref_off + (size_t)ro * p.ref_stride + j * 16;
+            ss = p.src_stride; rs = p.ref_stride;
+        }
+    };
+    StripRegs cur, nxt;
+    open_strip(0);
+    strip_issue(cur, sp, rp, ss, rs, 0, ro, height, live);
+    for (int k = 0; k < SADS_SPW; ++k) {
+        if ((strip0 + (uint32_t)k) * (uint32_t)nb >= n) break;
+        const bool     mine = live; // this lane's block of strip k exists
+        uint32_t       sad  = 0;
+        const uint32_t out  = (strip0 + (uint32_t)k) * (uint32_t)nb + (uint32_t)sb;
+        for (int g = 0; g < groups; ++g) {
+            if (g + 1 < groups) {
+                strip_issue(nxt, sp, rp, ss, rs, 16 * (g + 1), ro, height, live);
+            } else {
+                open_strip(k + 1); // (past the last strip: live = false, nothing is loaded)
+                strip_issue(nxt, sp, rp, ss, rs, 0, ro, height, live);
+            }
+            sad = strip_consume(cur, sad);
+            cur = nxt;
+        }
+        // lanes of one block: cpr lanes of a row (low bits) x four row phases (lanes + 16, + 32)
+        for (int m = 1; m < cpr; m <<= 1) sad += (uint32_t)__shfl_xor((int)sad, m);
+        sad += (uint32_t)__shfl_xor((int)sad, 16);
+        sad += (uint32_t)__shfl_xor((int)sad, 32);
+        if (mine && j == 0 && ro == 0) sad_out[out] = sad;
+    }
+}
+
 __global__ __launch_bounds__(64) void sad_16b_kernel(const uint16_t* __restrict__ src, uint32_t src_stride, const uint16_t* __restrict__ ref,
                                                      uint32_t ref_stride, int width, int height, uint32_t* __restrict__ out) {
     const int l     = threadIdx.x;
@@ -1221,7 +1299,12 @@ void svt_hip_sad_nxm_batch(const uint8_t* src_base, const uint8_t* ref_base, con
     svthip::ensure_device();
     if (n == 0) return;
     const uint32_t cpr = width >> 4;
-    if ((width & 15) == 0 && cpr != 0 && !(cpr & (cpr - 1)) && cpr * height <= 256 && n >= 4 * SADP_PPW * 64) { // enough pairs to fill the chip with walking waves
+    const int form = svthip::tuning_sad_form(); // SVT_HIP_SAD_FORM (measurement knob): 0 = strip form where it applies (default), 1 = the round-2 pair-per-wave forms
+    if (form == 0 && (width & 15) == 0 && cpr != 0 && !(cpr & (cpr - 1)) && cpr <= 16 && n >= 4 * SADS_SPW * (16 / cpr) * 64) {
+        const uint32_t per_wg = 4 * SADS_SPW * (16 / cpr); // pairs per workgroup
+        hipLaunchKernelGGL(sad_nxm_strip_kernel, dim3((n + per_wg - 1) / per_wg), dim3(256), 0, (hipStream_t)stream, src_base, ref_base, pairs, n, __builtin_ctz(cpr),
+                           (int)height, sad_out);
+    } else if ((width & 15) == 0 && cpr != 0 && !(cpr & (cpr - 1)) && cpr * height <= 256 && n >= 4 * SADP_PPW * 64) { // enough pairs to fill the chip with walking waves
         hipLaunchKernelGGL(sad_nxm_pipe_kernel, dim3((n + 4 * SADP_PPW - 1) / (4 * SADP_PPW)), dim3(256), 0, (hipStream_t)stream, src_base, ref_base, pairs, n,
                            __builtin_ctz(cpr), (int)(cpr * height), sad_out);
     } else {

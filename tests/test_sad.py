@@ -130,6 +130,45 @@ def test_sad_nxm_batch_many_pairs_pipelined(be, oracle, wh):
         assert got[i] == np.abs(A[y:y + h, x:x + w] - B[y + dy:y + dy + h, x + dx:x + dx + w]).sum(), i
 
 
+@pytest.mark.parametrize("wh", [(16, 8), (16, 10), (32, 16), (64, 64), (128, 6), (256, 5)])
+def test_sad_nxm_batch_strip_form(be, oracle, wh):
+    """Enough pairs for the strip kernel (a wave lies over four rows x 256 bytes = 16 / (width / 16) blocks side by side and walks down them; svt_hip_sad_nxm_batch
+    picks it from 64 workgroups' worth of pairs on): heights that are not a multiple of the four rows per step, a ragged pair count, runs of horizontally adjacent
+    blocks broken by row ends, unaligned reference offsets; every pair checked.  The pair-per-wave forms (SVT_HIP_SAD_FORM=1) must agree."""
+    import os
+    w, h = wh
+    if not be.is_gpu and w * h > 2048:
+        pytest.skip("emulator: the small shapes cover the strip path")
+    g = rng(700 + w + h)
+    nb = 16 // (w // 16)
+    n = 4 * 4 * nb * 64 + 37
+    cols = 30
+    stride = cols * w + 72
+    rows = ((n + cols - 1) // cols) * h + 8
+    a = g.integers(0, 256, (rows, stride), dtype=np.uint8)
+    b = (a.astype(np.int16) + g.integers(-20, 21, a.shape)).clip(0, 255).astype(np.uint8)
+    i = np.arange(n)
+    pairs = np.zeros(n, dtype=be.pkg.SadPair)
+    o = (i // cols) * h * stride + (i % cols) * w
+    pairs["src_off"], pairs["ref_off"], pairs["src_stride"], pairs["ref_stride"] = o, o + 3 + 2 * stride, stride, stride
+    da, db, dp = be.dev(a), be.dev(b), be.dev(pairs)
+    A, B = a.astype(np.int32), b.astype(np.int32)
+    y, x = (i // cols) * h, (i % cols) * w
+    want = np.array([np.abs(A[y[k]:y[k] + h, x[k]:x[k] + w] - B[y[k] + 2:y[k] + 2 + h, x[k] + 3:x[k] + 3 + w]).sum() for k in range(n)], np.uint32)
+    for form in ("0", "1"):
+        os.environ["SVT_HIP_SAD_FORM"] = form
+        be.lib.svt_hip_tuning_reload()
+        try:
+            out = be.empty(n, np.uint32)
+            be.lib.svt_hip_sad_nxm_batch(be.ptr(da), be.ptr(db), be.ptr(dp), n, w, h, be.ptr(out), be.stream)
+            got = be.host(out)
+        finally:
+            del os.environ["SVT_HIP_SAD_FORM"]
+            be.lib.svt_hip_tuning_reload()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (form, bad[:8], got[bad[:8]], want[bad[:8]])
+
+
 LOOP_AREAS = [(8, 15), (16, 31), (12, 31), (64, 25), (15, 6), (32, 12), (96, 24), (70, 40)]  # SadTest.cc:433-444 subset
 
 
