@@ -463,7 +463,7 @@ def bench_sad_pairs(torch, lib, pkg, stream, a, cpu):
         checked += must_equal("sad64x64_pairs", got[f * 510:(f + 1) * 510], want)
     per, reps = time_leg(torch, fn, a.min_leg_s)
     out = {"launches_per_timed_batch": reps, "value": len(pairs) / per / 1e6, "unit": "Mblocks/s (64x64 pairs)", "footprint_MB": 2 * n_src * PLANE / 1e6, "parity_checked_values": checked,
-           "roofline": roofline(len(pairs) * 8192, per, "sad_nxm_pipe_kernel" if os.environ.get("SVT_HIP_SAD_FORM") == "1" else "sad_nxm_strip_kernel", algorithmic_bytes_per_block=8192,
+           "roofline": roofline(len(pairs) * 8192, per, "sad_nxm_strip_kernel" if os.environ.get("SVT_HIP_SAD_FORM") == "1" else "sad_nxm_pipe_kernel", algorithmic_bytes_per_block=8192,
                                 note="disjoint src / ref plane sets, each byte read once per launch; footprint 1.2 GB")}
     if cpu:
         ref, oracle = ref_libs()

@@ -390,13 +390,17 @@ __device__ __forceinline__ s16x2 sec_sum_strength(const LaneCtx& L, const int se
 // {0,1,2,4}; NP = 0 is the pass for primary level 0, which the reference filters with dir = 0 (cdef.c:411).  Pixel-pair-major: the twelve
 // taps are read from LDS once per pair, the three secondary sums and the NP primary sums are evaluated once, and each of the grid's cells only
 // adds, rounds, clamps and updates its three running sums (sum s, sum s^2, sum s*d).  Nothing filtered is written.
+// scache (search with several level groups per workgroup): the three secondary sums of a pixel pair depend on the pixel, the direction and the secondary strength
+// only -- not on the primary level -- so the first group's pass stores them ([value][row step][thread]: lane-contiguous dwords, conflict-free) and the passes of the
+// other groups read them back instead of spending 3 x 59 packed operations per pair again (28 % of the kernel's VALU instructions at four groups).
 template <int NP>
 __device__ __forceinline__ void search_pass(const LaneCtx& L, const TapOffs& o, const int (&lv)[4], const bool acc_src,
-                                            acc16& a_s, acc16& a_s2, acc16& a_sd, uint32_t& d_s, uint32_t& d_s2) {
+                                            acc16& a_s, acc16& a_s2, acc16& a_sd, uint32_t& d_s, uint32_t& d_s2, uint32_t* scache = nullptr, const bool cached = false) {
     // the quad's lanes sit side by side on one pixel row (lane = pixel pair; 4-wide units: two rows of two pairs) and walk down the unit:
     // a wave instruction then reads two runs of 64 adjacent pixels, which is what the LDS banks like
     const int ppr = L.uw >> 1, jq = L.q & (ppr - 1), r0 = L.uw == 8 ? 0 : L.q >> 1, rstep = 4 / ppr;
-    for (int r = r0; r < L.uh; r += rstep) {
+    int it = 0;
+    for (int r = r0; r < L.uh; r += rstep, ++it) {
         if ((r & (L.sub - 1)) != 0) continue;
         {
             const int       ri   = (L.by * L.uh + r) * L.pitch + L.bx * L.uw + 2 * jq; // pixel index of this lane's pair relative to L.in (even)
@@ -405,9 +409,15 @@ __device__ __forceinline__ void search_pass(const LaneCtx& L, const TapOffs& o, 
             s16x2 t[12], mn, mx, S[4];
             load_taps(L.in + ri, o, x, t, mn, mx);
             S[0] = splat(0);
-            S[1] = sec_sum_strength(L, 1, x, t);
-            S[2] = sec_sum_strength(L, 2, x, t);
-            S[3] = sec_sum_strength(L, 4, x, t);
+            uint32_t* sc = scache + it * 256; // (+ the value's plane of 8 x 256 dwords)
+            if (NP && scache && cached) {
+                S[1] = as_pk(sc[0]); S[2] = as_pk(sc[2048]); S[3] = as_pk(sc[4096]);
+            } else {
+                S[1] = sec_sum_strength(L, 1, x, t);
+                S[2] = sec_sum_strength(L, 2, x, t);
+                S[3] = sec_sum_strength(L, 4, x, t);
+                if (NP && scache) { sc[0] = as_u32(S[1]); sc[2048] = as_u32(S[2]); sc[4096] = as_u32(S[3]); }
+            }
             const uint32_t dpair = as_u32(ld_pair_even(orow));
             if (acc_src) {
                 d_s += dpair; // u16 halves: at most 8 pixels of 4095 each per half
@@ -508,7 +518,8 @@ __global__ __launch_bounds__(256, MINB) void cdef_frame_kernel(const SvtHipCdefP
     const int bw = 64 >> xdec, bh = 64 >> ydec, uw = 8 >> xdec, uh = 8 >> ydec;
     const int pw = (int)P.width, ph = (int)P.height;
     const int nhfb = (pw + bw - 1) / bw, nvfb = (ph + bh - 1) / bh;
-    const int fb = blockIdx.x, fbr = fb / nhfb, fbc = fb % nhfb;
+    // XCD-aware order: a filter block's tile shares its halo lines with the neighbouring blocks' tiles (the apply pass moved 2.2 x the algorithmic bytes)
+    const int fb = (int)xcd_remap(blockIdx.x, gridDim.x), fbr = fb / nhfb, fbc = fb % nhfb;
     const int pitch = tile_pitch(bw, uh);
     // search: this workgroup takes the level groups g0 .. g0 + gpw - 1 of its filter block one after the other, on ONE staged tile (large frames: gpw = 2
     // or 4, so the tile, the source block and the direction search are not repeated per group; small frames keep gpw = 1 to fill the chip)
@@ -578,6 +589,9 @@ __global__ __launch_bounds__(256, MINB) void cdef_frame_kernel(const SvtHipCdefP
         return;
     }
     const bool weighted = pli == 0 && uw == 8 && uh == 8;
+    // secondary-sum cache of the lane's pixel pairs (3 values x 8 row steps x 256 threads), behind the tile and the source block; only with several groups per workgroup
+    uint32_t*  scache  = gpw > 1 ? (uint32_t*)(tile_raw + (((bh + 2 * VB) * pitch + bh * bw + 1) & ~1)) + tid : nullptr;
+    bool       s_ready = false; // (uniform) a pass with the block's own direction has filled the cache
     for (int gi = 0; gi < gpw; gi++) {
     const int g = g0 + gi;
     // which primary levels does group g own?  (uniform; the list has at most 64 entries)
@@ -600,7 +614,8 @@ __global__ __launch_bounds__(256, MINB) void cdef_frame_kernel(const SvtHipCdefP
     uint32_t d_s = 0, d_s2 = 0;
     if (nlv) {
         a_s = a_s2 = a_sd = acc16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (act) search_pass<4>(L, tap_offs(dir, pitch), lv, true, a_s, a_s2, a_sd, d_s, d_s2);
+        if (act) search_pass<4>(L, tap_offs(dir, pitch), lv, true, a_s, a_s2, a_sd, d_s, d_s2, scache, s_ready);
+        s_ready = true; // (a lane reads back only what it wrote itself: no barrier needed)
         search_reduce<4>(a_s, a_s2, a_sd, d_s, d_s2, q, act, weighted, cs, sh_cells);
     }
     if (do0) {
@@ -675,13 +690,14 @@ __global__ void copy_rect8_to_16_kernel(uint16_t* dst, const uint8_t* src, int n
 template <int MODE> void launch_frame(const SvtHipCdefParams& P, hipStream_t st, const int reuse_dir = 0) {
     const int bw = 64 >> P.xdec, bh = 64 >> P.ydec;
     const int nhfb = ((int)P.width + bw - 1) / bw, nvfb = ((int)P.height + bh - 1) / bh;
-    const size_t shmem = (size_t)((bh + 2 * VB) * tile_pitch(bw, 8 >> P.ydec) + (MODE == 1 ? bh * bw : 0)) * 2 + 64;
+    size_t shmem = (size_t)((bh + 2 * VB) * tile_pitch(bw, 8 >> P.ydec) + (MODE == 1 ? bh * bw : 0)) * 2 + 64;
     // search: four groups of four primary levels; a workgroup takes gpw of them on one staged tile as long as >= 4096 workgroups remain (256 CUs x 4 x 4 rounds)
     int gpw = 1;
     if (MODE == 1) {
         const int e = svthip::tuning_cdef_groups_per_workgroup(); // SVT_HIP_CDEF_GPW (measurement override, read once)
         gpw = e ? e : (nhfb * nvfb >= 2040 ? 4 : (nhfb * nvfb >= 1020 ? 2 : 1)); // 4K luma: 378 us with 4, 386 with 2, 418 with 1 (profiles/r02_call8_*)
     }
+    if (MODE == 1 && gpw > 1) shmem += 3 * 8 * 256 * 4; // the secondary-sum cache (search_pass)
     const dim3 grid(nhfb * nvfb, MODE == 1 ? 4 / gpw : 1);
     if (MODE == 1 && svthip::tuning_cdef_search_minb() == 4) { // (measurement knob SVT_HIP_CDEF_MINB=4: the round-2 build of the search kernel, 128 VGPRs + scratch)
         if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE, 4>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);

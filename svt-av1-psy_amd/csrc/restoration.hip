@@ -39,10 +39,13 @@ __global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, c
     TileSrc s;
     s.data = P.data; s.above = P.boundary_above; s.below = P.boundary_below;
     s.stride = (int)P.stride; s.bstride = (int)P.boundary_stride; s.w = pw; s.h = ph; s.highbd = P.highbd;
-    s.stripe_idx = blockIdx.z;
+    // XCD-aware order over the linear workgroup index (x fastest): neighbouring stripe columns / halves share their 3-sample halos' cache lines
+    const uint32_t lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int      bx = (int)(lin % gridDim.x), byz = (int)(lin / gridDim.x), bhalf = byz % (int)gridDim.y, bz = byz / (int)gridDim.y;
+    s.stripe_idx = bz;
     s.stripe_top = s.stripe_idx * sh - off < 0 ? 0 : s.stripe_idx * sh - off;
     s.stripe_bot = (s.stripe_idx + 1) * sh - off > ph ? ph : (s.stripe_idx + 1) * sh - off;
-    s.x0 = blockIdx.x * cw; s.y0 = s.stripe_top + (int)blockIdx.y * LR_UR;
+    s.x0 = bx * cw; s.y0 = s.stripe_top + bhalf * LR_UR;
     s.uw = pw - s.x0 < cw ? pw - s.x0 : cw;
     s.uh = s.stripe_bot - s.y0 < LR_UR ? s.stripe_bot - s.y0 : LR_UR;
     if (s.uh <= 0 || s.uw <= 0) return;

@@ -188,11 +188,6 @@ __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < 
 
 // XCD-aware item order: hardware places workgroup b on XCD b % 8; give each XCD a contiguous run of items so
 // neighbouring superblocks (whose reference windows overlap) share one L2.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
-    const uint32_t per = n >> 3;
-    if (per == 0 || b >= per * 8) return b;
-    return (b & 7) * per + (b >> 3);
-}
 
 // ---- frame-batched integer full-pel ME search ---------------------------------------------------------------
 constexpr int ME_PITCH = 34; // window row pitch in dwords: >= 17 + 64 / 4, even (8-byte LDS stores) and = 2 mod 8, so the 8 block rows x
@@ -555,7 +550,7 @@ __global__ __launch_bounds__(256) void sad_nxm_pipe_kernel(const uint8_t* __rest
     }
 }
 
-// Strip form (round 3): the wave's 64 lanes are laid over FOUR ROWS x 256 BYTES -- 16 / cpr blocks side by side (four 64-wide blocks), cpr lanes per block row -- and
+// Strip form (round 3, an experiment that LOST -- see svt_hip_sad_nxm_batch): the wave's 64 lanes are laid over FOUR ROWS x 256 BYTES -- 16 / cpr blocks side by side (four 64-wide blocks), cpr lanes per block row -- and
 // walk down the blocks four rows per step.  With horizontally adjacent blocks (the 510 SBs of a picture row by row: config 1) one wave instruction then reads four
 // runs of 256 CONTIGUOUS bytes = 12 cache-line requests, two thirds of them fully used, where the pair-per-wave forms read sixteen separate 64-byte row pieces =
 // 32 line requests, every line shared with the neighbouring block's wave (rows start at byte 68 of a 2056-byte pitch: each 64-byte piece straddles two 128-byte
@@ -1299,8 +1294,10 @@ void svt_hip_sad_nxm_batch(const uint8_t* src_base, const uint8_t* ref_base, con
     svthip::ensure_device();
     if (n == 0) return;
     const uint32_t cpr = width >> 4;
-    const int form = svthip::tuning_sad_form(); // SVT_HIP_SAD_FORM (measurement knob): 0 = strip form where it applies (default), 1 = the round-2 pair-per-wave forms
-    if (form == 0 && (width & 15) == 0 && cpr != 0 && !(cpr & (cpr - 1)) && cpr <= 16 && n >= 4 * SADS_SPW * (16 / cpr) * 64) {
+    // SVT_HIP_SAD_FORM (measurement knob): 0 = pair-per-wave forms (default), 1 = the strip form, which measured SLOWER on the MI355X (221 vs 204 us per 122 400 64x64
+    // pairs, 1.53 vs 1.35 x the algorithmic bytes moved: profiles/r03_call3_ab_sad_cdef.txt) and is kept for that comparison only
+    const int form = svthip::tuning_sad_form();
+    if (form == 1 && (width & 15) == 0 && cpr != 0 && !(cpr & (cpr - 1)) && cpr <= 16 && n >= 4 * SADS_SPW * (16 / cpr) * 64) {
         const uint32_t per_wg = 4 * SADS_SPW * (16 / cpr); // pairs per workgroup
         hipLaunchKernelGGL(sad_nxm_strip_kernel, dim3((n + per_wg - 1) / per_wg), dim3(256), 0, (hipStream_t)stream, src_base, ref_base, pairs, n, __builtin_ctz(cpr),
                            (int)height, sad_out);

@@ -28,6 +28,14 @@ __device__ __forceinline__ svt_u32x2_a1 svt_hip_global_load_x2(const void* p) { 
 #define SVT_HIP_OPAQUE_I32(x) asm volatile("" : "+v"(x))
 #endif
 
+// Workgroups are handed to the eight XCDs round-robin (workgroup b runs on XCD b % 8, each XCD with its own L2): give every XCD a CONTIGUOUS run of work items, so
+// that items which share cache lines (neighbouring SBs / filter blocks / stripe columns of a picture) meet in one L2 instead of being fetched by two.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
+    const uint32_t per = n >> 3;
+    if (per == 0 || b >= per * 8) return b;
+    return (b & 7) * per + (b >> 3);
+}
+
 #define HIP_CHECK(expr)                                                                                         \
     do {                                                                                                        \
         hipError_t e_ = (expr);                                                                                 \
@@ -73,7 +81,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // work and is not safe against a concurrent setenv in a multi-threaded encoder.  svt_hip_tuning_reload() re-reads them (tests that sweep a knob call it).
 int tuning_lr_rows_per_workgroup(); // SVT_HIP_LR_UR: 16 / 32 / 64, default 32
 int tuning_cdef_groups_per_workgroup(); // SVT_HIP_CDEF_GPW: 1 / 2 / 4, 0 = by frame size
-int tuning_sad_form(); // SVT_HIP_SAD_FORM: 0 (default: strip form) / 1 (pair-per-wave forms): which independent-pairs SAD kernel runs (A/B measurement)
+int tuning_sad_form(); // SVT_HIP_SAD_FORM: 0 (default: pair-per-wave forms) / 1 (strip form, measured slower): which independent-pairs SAD kernel runs
 int tuning_cdef_search_minb(); // SVT_HIP_CDEF_MINB: 3 (default) / 4: which register budget of the CDEF search kernel runs (A/B measurement)
 
 } // namespace svthip

@@ -109,6 +109,34 @@ def test_cdef_frame_apply_and_search(be, oracle, bd, damping):
                 run_frame(be, oracle, 0, c2, s2, xd, yd, 2, bd, skip, apri, asec, d, v, damping=damping)
 
 
+@pytest.mark.parametrize("gpw", ["2", "4"])
+def test_cdef_search_groups_per_workgroup(be, oracle, gpw):
+    """Search with several primary-level groups per workgroup (what large frames run: SVT_HIP_CDEF_GPW forces it on a small one): the later groups take the
+    secondary sums from the LDS cache the first group's pass filled.  Luma (weighted distortion), 4:2:0 chroma (4x4 units), skipped units, row sub-sampling."""
+    import os
+    g = rng(77 + int(gpw))
+    bd, (W, H) = 10, ((704, 392) if be.is_gpu else (200, 136))
+    luma = synth_plane(g, W, H, bd)
+    src_l = np.clip(luma + g.integers(-6, 7, luma.shape), 0, (1 << bd) - 1)
+    nhfb, nvfb = (W + 63) // 64, (H + 63) // 64
+    nfb = nhfb * nvfb
+    cands = [(pr, sc) for pr in range(16) for sc in (0, 1, 2, 4)] if be.is_gpu else [(pr, sc) for pr in (0, 1, 2, 3, 5, 7, 8, 11, 12, 15) for sc in (0, 2, 4)] + [(4, 1)]
+    pri, sec = np.array([c[0] for c in cands], np.int32), np.array([c[1] for c in cands], np.int32)
+    os.environ["SVT_HIP_CDEF_GPW"] = gpw
+    be.lib.svt_hip_tuning_reload()
+    try:
+        for skip_frac, sub in ((0.0, 1), (0.25, 2)):
+            skip = (g.random((nvfb * 8, nhfb * 8)) < skip_frac).astype(np.uint8)
+            dir0, var0 = np.zeros(nfb * 64, np.uint8), np.zeros(nfb * 64, np.int32)
+            d, v = run_frame(be, oracle, 1, luma, src_l, 0, 0, 0, bd, skip, pri, sec, dir0, var0, sub=sub)
+            chroma = synth_plane(g, W // 2, H // 2, bd)
+            src_c = np.clip(chroma + g.integers(-6, 7, chroma.shape), 0, (1 << bd) - 1)
+            run_frame(be, oracle, 1, chroma, src_c, 1, 1, 1, bd, skip, pri, sec, d, v)
+    finally:
+        del os.environ["SVT_HIP_CDEF_GPW"]
+        be.lib.svt_hip_tuning_reload()
+
+
 def test_cdef_single_call_symbols(be, oracle):
     """svt_aom_cdef_find_dir(_dual), svt_cdef_filter_block, svt_compute_cdef_dist_*, copy_rect8_8bit_to_16bit (CdefTest.cc)."""
     g = rng(3)

@@ -133,8 +133,8 @@ def test_sad_nxm_batch_many_pairs_pipelined(be, oracle, wh):
 @pytest.mark.parametrize("wh", [(16, 8), (16, 10), (32, 16), (64, 64), (128, 6), (256, 5)])
 def test_sad_nxm_batch_strip_form(be, oracle, wh):
     """Enough pairs for the strip kernel (a wave lies over four rows x 256 bytes = 16 / (width / 16) blocks side by side and walks down them; svt_hip_sad_nxm_batch
-    picks it from 64 workgroups' worth of pairs on): heights that are not a multiple of the four rows per step, a ragged pair count, runs of horizontally adjacent
-    blocks broken by row ends, unaligned reference offsets; every pair checked.  The pair-per-wave forms (SVT_HIP_SAD_FORM=1) must agree."""
+    runs it with SVT_HIP_SAD_FORM=1 from 64 workgroups' worth of pairs on; it measured slower than the pair-per-wave forms and is kept as a comparison): heights that are not a multiple of the four rows per step, a ragged pair count, runs of horizontally adjacent
+    blocks broken by row ends, unaligned reference offsets; every pair checked in both forms."""
     import os
     w, h = wh
     if not be.is_gpu and w * h > 2048:
