@@ -31,6 +31,13 @@ extern "C" {
 int         svt_hip_init(int device);
 void        svt_hip_shutdown(void);
 const char *svt_hip_device_name(void);
+/* Several GPUs from one process (frame-level sharding): the device is selected PER HOST THREAD, like HIP's own current device.  svt_hip_set_thread_device(d)
+ * binds the calling thread to device d for every later call of this library on that thread (host-call arenas and streams are per thread AND device); -1 returns the
+ * thread to the default device of svt_hip_init.  Returns 0, or -1 when d is not a device.  Objects that live on a device (ME sessions) remember it and make it current
+ * inside their own entry points, whatever the calling thread's selection is. */
+int svt_hip_device_count(void);
+int svt_hip_set_thread_device(int device);
+int svt_hip_get_thread_device(void);
 /* The measurement knobs SVT_HIP_LR_UR / SVT_HIP_CDEF_GPW are read from the environment once, at first use; this re-reads them (tests that sweep a knob). */
 void svt_hip_tuning_reload(void);
 /* Overwrite the reference's RTCD pointers (weak symbols; present only when linked into libSvtAv1Enc) with the
@@ -126,6 +133,10 @@ void *svt_hip_host_alloc(size_t bytes);
 void  svt_hip_host_free(void *p);
 void *svt_hip_me_session_create(uint32_t width, uint32_t height, uint32_t stride, uint32_t org_x, uint32_t org_y, uint32_t rows, uint32_t ring_planes,
                                 uint32_t max_refs, uint32_t max_area_width, uint32_t max_area_height, uint32_t n_slots);
+/* the same on a named GPU: the session's ring, slots and launches live on `device`, and its entry points make that device current for their duration whatever
+ * the calling thread has selected -- one session per GPU is how an encoder shards pictures over several devices (frame-level sharding) */
+void *svt_hip_me_session_create_on(int device, uint32_t width, uint32_t height, uint32_t stride, uint32_t org_x, uint32_t org_y, uint32_t rows, uint32_t ring_planes,
+                                   uint32_t max_refs, uint32_t max_area_width, uint32_t max_area_height, uint32_t n_slots);
 void  svt_hip_me_session_destroy(void *session);
 int   svt_hip_me_session_submit(void *session, int64_t pic_id, const uint8_t *plane_host, const int64_t *ref_ids, uint32_t n_refs, uint32_t area_w,
                                 uint32_t area_h, int sub_sad, uint32_t *best_sad_host, uint32_t *best_mv_host);

@@ -34,6 +34,7 @@ void    svt_av1_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs);
 void    svt_aom_get_recon_pic(PictureControlSet *pcs, EbPictureBufferDesc **recon_ptr, bool is_highbd);
 int32_t svt_sb_compute_cdef_list(PictureControlSet *pcs, const Av1Common *const cm, int32_t mi_row, int32_t mi_col, CdefList *dlist, BlockSize bs);
 
+int svt_hip_seam_bind(unsigned long long picture_number); /* integration/enc_handle_binding.c: SVT_HIP_DEVICES sharding */
 static struct {
     pthread_mutex_t lock;
     int             mode;
@@ -114,6 +115,7 @@ static void seam_av1_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs)
     A.coeff_shift = (uint8_t)AOMMAX(scs->static_config.encoder_bit_depth - 8, 0);
     A.damping = (uint8_t)frm_hdr->cdef_params.cdef_damping;
     A.skip = skip; A.pri_y = pri_y; A.sec_y = sec_y; A.pri_uv = pri_uv; A.sec_uv = sec_uv;
+    svt_hip_seam_bind(pcs->picture_number);
     if (filtered) D.apply_host(&A);
     pthread_mutex_lock(&D.lock);
     D.n_pictures++; D.n_fbs += filtered;
@@ -171,6 +173,7 @@ static void search_picture(PictureControlSet *pcs, SequenceControlSet *scs) {
     A.skip = skip; A.ncand_y = (uint32_t)ncand; A.ncand_uv = (uint32_t)ncand_uv;
     A.pri_y = pri_y; A.sec_y = sec_y; A.pri_uv = pri_uv; A.sec_uv = sec_uv;
     A.mse_y = mse_y; A.mse_u = mse_u; A.mse_v = mse_v; A.dir = dir; A.var = var;
+    svt_hip_seam_bind(pcs->picture_number);
     if (searched) D.search_host(&A);
     for (int32_t fb = 0; fb < nfb; fb++) {
         if (!count[fb]) continue;

@@ -129,7 +129,9 @@ static void set_planes(EbPictureBufferDesc *fb, const PictureControlSet *pcs, ui
     }
 }
 /* one device call per plane over the given lists */
+int svt_hip_seam_bind(unsigned long long picture_number); /* integration/enc_handle_binding.c: SVT_HIP_DEVICES sharding */
 static uint64_t filter_planes(const PictureControlSet *pcs, const uint32_t *w, EdgeList (*list)[2]) {
+    svt_hip_seam_bind(pcs->picture_number);
     const bool is_16bit = pcs->scs->is_16bit_pipeline;
     const int  bd = is_16bit ? (int)pcs->scs->static_config.encoder_bit_depth : 8;
     uint64_t   segs = 0;

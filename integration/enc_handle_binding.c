@@ -23,6 +23,32 @@
 
 #include "aom_dsp_rtcd.h" /* declares svt_aom_setup_rtcd_internal before the macro below exists */
 
+/* ---- several GPUs for one encode (frame-level sharding, no exchange step) -------------------------------------------------------------------
+ * SVT_HIP_DEVICES=<d0,d1,...>: every picture-level stage seam runs the stages of picture n on device d[n % count].  A seam calls svt_hip_seam_bind(picture_number)
+ * on the worker thread that is about to issue the picture's device calls: the thread is bound to that device (svt_hip_set_thread_device: host-call arenas and
+ * streams are per thread and device) and the index into the list comes back -- the ME seam keeps one resident session per index.  Unset: one device, index 0. */
+static struct {
+    int n, ids[16];
+    int (*set_thread_device)(int);
+    unsigned long long per_device[16];
+} SVT_HIP_SHARD;
+int svt_hip_seam_device_count(void) { return SVT_HIP_SHARD.n > 0 ? SVT_HIP_SHARD.n : 1; }
+int svt_hip_seam_device_id(int index) { return SVT_HIP_SHARD.n > 0 ? SVT_HIP_SHARD.ids[index] : -1; }
+int svt_hip_seam_bind(unsigned long long picture_number) {
+    if (SVT_HIP_SHARD.n <= 0) return 0;
+    const int k = (int)(picture_number % (unsigned long long)SVT_HIP_SHARD.n);
+    if (SVT_HIP_SHARD.set_thread_device(SVT_HIP_SHARD.ids[k])) { fprintf(stderr, "SVT_HIP_DEVICES: device %d is not available\n", SVT_HIP_SHARD.ids[k]); abort(); }
+    __atomic_fetch_add(&SVT_HIP_SHARD.per_device[k], 1, __ATOMIC_RELAXED);
+    return k;
+}
+static void svt_hip_shard_stats(void) {
+    const char *f = getenv("SVT_HIP_DEVICES_STATS");
+    FILE       *o = f ? fopen(f, "w") : NULL;
+    if (!o) return;
+    for (int k = 0; k < SVT_HIP_SHARD.n; k++) fprintf(o, "stage_calls_bound_to_device_%d %llu\n", SVT_HIP_SHARD.ids[k], SVT_HIP_SHARD.per_device[k]);
+    fclose(o);
+}
+
 static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
     svt_aom_setup_rtcd_internal(flags);
     const char *dev = getenv("SVT_HIP");
@@ -39,6 +65,21 @@ static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
     if (!init || !setup || init(atoi(dev)) != 0) {
         fprintf(stderr, "SVT_HIP: svt_hip_init(%s) failed\n", dev);
         abort();
+    }
+    const char *list = getenv("SVT_HIP_DEVICES");
+    if (list && *list) {
+        int (*count)(void) = (int (*)(void))dlsym(h, "svt_hip_device_count");
+        *(void **)&SVT_HIP_SHARD.set_thread_device = dlsym(h, "svt_hip_set_thread_device");
+        const int have = count ? count() : 0;
+        for (const char *p = list; *p && SVT_HIP_SHARD.n < 16;) {
+            const int d = atoi(p);
+            if (d < 0 || d >= have || !SVT_HIP_SHARD.set_thread_device) { fprintf(stderr, "SVT_HIP_DEVICES: device %d of \"%s\" is not available (%d devices)\n", d, list, have); abort(); }
+            SVT_HIP_SHARD.ids[SVT_HIP_SHARD.n++] = d;
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        fprintf(stderr, "SVT_HIP_DEVICES: pictures are sharded over %d device(s) by picture number\n", SVT_HIP_SHARD.n);
+        atexit(svt_hip_shard_stats);
     }
     int n = setup((unsigned long long)flags);
     fprintf(stderr, "SVT_HIP: %d dispatch pointers now select the HIP variant\n", n);

@@ -39,6 +39,7 @@ static EbErrorType seam_motion_estimation_b64(PictureParentControlSet *pcs, uint
 /* ---- the C ABI, resolved from the library enc_handle_binding.c has dlopen()ed with RTLD_GLOBAL ---- */
 static struct {
     void *(*create)(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
+    void *(*create_on)(int, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
     int (*enable_stage)(void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
     int (*submit_stage)(void *, int64_t, const uint8_t *, const int64_t *, uint32_t, const SvtHipMeStageParams *, const SvtHipMeResultsHost *);
     void (*wait)(void *, int);
@@ -47,7 +48,11 @@ static struct {
     void *(*host_alloc)(size_t);
 } abi;
 
-enum { SEAM_RING = 24, SEAM_MAX_REFS = 7, SEAM_RECS = 64 };
+enum { SEAM_RING = 24, SEAM_MAX_REFS = 7, SEAM_RECS = 64, SEAM_DEVS = 16 };
+/* integration/enc_handle_binding.c: SVT_HIP_DEVICES=<d0,d1,...> shards pictures over GPUs by picture number; one resident session (ring, checksums, lock) per index */
+int svt_hip_seam_bind(unsigned long long picture_number);
+int svt_hip_seam_device_count(void);
+int svt_hip_seam_device_id(int index);
 typedef struct SeamPicture { /* results of one picture, consumed SB by SB */
     PictureParentControlSet *pcs;
     uint64_t                 picture_number;
@@ -61,18 +66,21 @@ typedef struct SeamPicture { /* results of one picture, consumed SB by SB */
 static struct {
     pthread_mutex_t lock;  /* the record tables (rec[], tf_rec[]) and the counters: held for table look-ups only, never across device work */
     pthread_cond_t  ready;
-    pthread_mutex_t dev;   /* the device session (picture ring, checksum table): held while residency is decided and a stage is ENQUEUED, not while it runs --
+    pthread_mutex_t dev[SEAM_DEVS]; /* the device session (picture ring, checksum table): held while residency is decided and a stage is ENQUEUED, not while it runs --
                             * several pictures are in flight on the device at once (session slots), their owners wait outside both locks */
     int             mode; /* -1 unknown, 0 off, 1 on */
-    void           *session;
+    void           *session[SEAM_DEVS];
     uint32_t        width, height, stride, org_x, org_y, rows;
     SeamPicture     rec[SEAM_RECS];
-    uint64_t        sum[SEAM_RING * 2][2]; /* (picture id, plane checksum) of what is resident */
+    uint64_t        sum[SEAM_DEVS][SEAM_RING * 2][2]; /* per device: (picture id, plane checksum) of what is resident */
+    uint64_t        n_per_dev[SEAM_DEVS];
     uint64_t        n_pictures, n_declined, n_sb, n_uploads, n_reuploads;
     double          t_stage, t_hash, t_first, t_dev_lock; /* seconds: in run_picture / run_tf_pair (all threads), hashing planes, the first stage call (session creation,
                                                            * kernel code loading), holding the device lock */
     char            why[128];
-} G = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, -1};
+} G = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER,
+      PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER,
+      PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER}, -1};
 
 static uint64_t tf_pairs, tf_sb, tf_declined; /* the temporal filter's (picture, reference) pairs through the stage, see the end of this file */
 static void seam_stats(void) {
@@ -83,6 +91,8 @@ static void seam_stats(void) {
             (unsigned long long)G.n_pictures, (unsigned long long)G.n_declined, (unsigned long long)G.n_sb, (unsigned long long)G.n_uploads,
             (unsigned long long)G.n_reuploads, G.why[0] ? G.why : "-");
     fprintf(o, "tf_pairs_offloaded %llu\ntf_sb_results %llu\ntf_pairs_declined %llu\n", (unsigned long long)tf_pairs, (unsigned long long)tf_sb, (unsigned long long)tf_declined);
+    for (int k = 0; k < svt_hip_seam_device_count() && svt_hip_seam_device_count() > 1; k++)
+        fprintf(o, "stage_calls_on_device_%d %llu\n", svt_hip_seam_device_id(k), (unsigned long long)G.n_per_dev[k]);
     fprintf(o, "ms_in_stage_calls %llu\nms_hashing_planes %llu\nms_first_stage_call %llu\nms_holding_device_lock %llu\n", (unsigned long long)(G.t_stage * 1e3),
             (unsigned long long)(G.t_hash * 1e3), (unsigned long long)(G.t_first * 1e3), (unsigned long long)(G.t_dev_lock * 1e3));
     fclose(o);
@@ -92,7 +102,7 @@ static void seam_init(void) { /* once (pthread_once): ME threads arriving during
     const char *e = getenv("SVT_HIP_ME_SEAM");
     if (!e || !atoi(e) || !getenv("SVT_HIP")) return;
 #define SYM(field, name) *(void **)&abi.field = dlsym(RTLD_DEFAULT, name)
-    SYM(create, "svt_hip_me_session_create"); SYM(enable_stage, "svt_hip_me_session_enable_stage"); SYM(submit_stage, "svt_hip_me_session_submit_stage");
+    SYM(create, "svt_hip_me_session_create"); SYM(create_on, "svt_hip_me_session_create_on"); SYM(enable_stage, "svt_hip_me_session_enable_stage"); SYM(submit_stage, "svt_hip_me_session_submit_stage");
     SYM(wait, "svt_hip_me_session_wait"); SYM(invalidate, "svt_hip_me_session_invalidate"); SYM(resident, "svt_hip_me_session_resident");
     SYM(host_alloc, "svt_hip_host_alloc");
 #undef SYM
@@ -131,32 +141,32 @@ static uint64_t plane_sum_(const EbPictureBufferDesc *p) { /* content check of t
     }
     return h;
 }
-static int sum_slot(uint64_t id, int make) {
+static int sum_slot(int di, uint64_t id, int make) {
     int free_i = -1;
     for (int i = 0; i < SEAM_RING * 2; i++) {
-        if (G.sum[i][1] && G.sum[i][0] == id) return i;
-        if (!G.sum[i][1] && free_i < 0) free_i = i;
+        if (G.sum[di][i][1] && G.sum[di][i][0] == id) return i;
+        if (!G.sum[di][i][1] && free_i < 0) free_i = i;
     }
     if (!make) return -1;
-    if (free_i < 0) { memset(G.sum, 0, sizeof(G.sum)); free_i = 0; }
-    G.sum[free_i][0] = id;
+    if (free_i < 0) { memset(G.sum[di], 0, sizeof(G.sum[di])); free_i = 0; }
+    G.sum[di][free_i][0] = id;
     return free_i;
 }
 /* make `pic` (picture id `id`) resident with its current content: upload it when it is absent or its host content changed since the upload */
 /* (device lock held; `now` = the plane's checksum, computed by the caller outside the lock.)  The copy of a REFERENCE is waited for here: its host plane is pageable
  * memory that another encoder thread may rewrite later (a picture is temporally filtered in place after it served as a neighbour's reference), and the runtime may
  * still be reading it when hipMemcpyAsync returns.  ~0.1-0.3 ms per upload, ~1.3 uploads per picture. */
-static int ensure_resident(uint64_t id, const EbPictureBufferDesc *pic, const SvtHipMeStageParams *S, uint64_t now) {
-    const int k = sum_slot(id, 1);
-    if (abi.resident(G.session, (int64_t)id)) {
-        if (G.sum[k][1] == now) return 0;
-        abi.invalidate(G.session, (int64_t)id); /* e.g. temporally filtered in place after it was uploaded */
+static int ensure_resident(int di, uint64_t id, const EbPictureBufferDesc *pic, const SvtHipMeStageParams *S, uint64_t now) {
+    const int k = sum_slot(di, id, 1);
+    if (abi.resident(G.session[di], (int64_t)id)) {
+        if (G.sum[di][k][1] == now) return 0;
+        abi.invalidate(G.session[di], (int64_t)id); /* e.g. temporally filtered in place after it was uploaded */
         G.n_reuploads++;
     }
-    const int slot = abi.submit_stage(G.session, (int64_t)id, pic->buffer_y, NULL, 0, S, NULL);
+    const int slot = abi.submit_stage(G.session[di], (int64_t)id, pic->buffer_y, NULL, 0, S, NULL);
     if (slot < 0) return slot;
-    abi.wait(G.session, slot);
-    G.sum[k][1] = now;
+    abi.wait(G.session[di], slot);
+    G.sum[di][k][1] = now;
     G.n_uploads++;
     return 0;
 }
@@ -264,14 +274,16 @@ static void reserve(void **p, size_t *cap, size_t bytes) {
 }
 
 /* the session (picture ring + stage buffers) is sized once for the encode, from the first picture that reaches a seam */
-static int ensure_session(PictureParentControlSet *pcs, const EbPictureBufferDesc *src) {
-    if (!G.session) {
+static int ensure_session(int di, PictureParentControlSet *pcs, const EbPictureBufferDesc *src) {
+    if (!G.session[di]) {
         EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
         G.width = src->width; G.height = src->height; G.stride = src->stride_y; G.org_x = src->org_x; G.org_y = src->org_y;
         G.rows = src->luma_size / src->stride_y;
         /* largest ME area any preset derives is 256 x 256 (x 2 by the MV-based adjustment, x 3 / 2 by the variance probe) */
-        G.session = abi.create(G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 4); /* four pictures in flight */
-        if (!G.session || abi.enable_stage(G.session, pa->quarter_downsampled_picture_ptr->org_x, pa->sixteenth_downsampled_picture_ptr->org_x, 4, 768, 768)) {
+        const int dev_id = svt_hip_seam_device_id(di); /* -1: no sharding, the default device */
+        G.session[di] = dev_id >= 0 && abi.create_on ? abi.create_on(dev_id, G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 4)
+                                                     : abi.create(G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 4); /* four pictures in flight */
+        if (!G.session[di] || abi.enable_stage(G.session[di], pa->quarter_downsampled_picture_ptr->org_x, pa->sixteenth_downsampled_picture_ptr->org_x, 4, 768, 768)) {
             fprintf(stderr, "SVT_HIP_ME_SEAM: cannot create the ME session\n");
             abort();
         }
@@ -301,36 +313,39 @@ static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *
     SvtHipMeResultsHost H;
     memset(&H, 0, sizeof(H));
     H.total_me_candidate_index = P->total; H.me_mv_array = P->mv; H.me_candidate_array = P->cand; H.sb_stats = P->stats;
-    pthread_mutex_lock(&G.dev);
+    const int di = svt_hip_seam_bind(pcs->picture_number); /* the device this picture is sharded to (0 without SVT_HIP_DEVICES) */
+    pthread_mutex_lock(&G.dev[di]);
     const double td0 = seam_now();
-    int rc = ensure_session(pcs, src), slot = -1;
+    int rc = ensure_session(di, pcs, src), slot = -1;
+    void *ses = G.session[di];
     for (int pass = 0; !rc; pass++) { /* an upload may evict a reference another upload just brought in (round-robin ring): repeat until all are there */
         int missing = 0;
         for (uint32_t k = 0; k < n_refs && !rc; k++) {
             if (ref_pics[k]->width != G.width || ref_pics[k]->stride_y != G.stride) rc = decline("reference geometry");
-            else if (ensure_resident((uint64_t)ref_ids[k], ref_pics[k], &S, ref_sum[k])) rc = decline("reference upload");
+            else if (ensure_resident(di, (uint64_t)ref_ids[k], ref_pics[k], &S, ref_sum[k])) rc = decline("reference upload");
         }
-        for (uint32_t k = 0; k < n_refs && !rc; k++) missing += !abi.resident(G.session, ref_ids[k]);
+        for (uint32_t k = 0; k < n_refs && !rc; k++) missing += !abi.resident(ses, ref_ids[k]);
         if (rc || !missing) break;
         if (pass == 3) rc = decline("ring too small for the reference set");
     }
     if (!rc) {
         /* the source: (re)uploaded when its content differs from what is resident (the same picture may have served as a reference before its own ME) */
-        const int ks = sum_slot(pcs->picture_number, 1);
-        if (abi.resident(G.session, (int64_t)pcs->picture_number) && G.sum[ks][1] != now) { abi.invalidate(G.session, (int64_t)pcs->picture_number); G.n_reuploads++; }
-        if (!abi.resident(G.session, (int64_t)pcs->picture_number)) G.n_uploads++;
-        G.sum[ks][1] = now;
-        slot = abi.submit_stage(G.session, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, n_refs, &S, &H);
+        const int ks = sum_slot(di, pcs->picture_number, 1);
+        if (abi.resident(ses, (int64_t)pcs->picture_number) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)pcs->picture_number); G.n_reuploads++; }
+        if (!abi.resident(ses, (int64_t)pcs->picture_number)) G.n_uploads++;
+        G.sum[di][ks][1] = now;
+        slot = abi.submit_stage(ses, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, n_refs, &S, &H);
         if (slot < 0) {
             char why[64];
             snprintf(why, sizeof(why), "svt_hip_me_session_submit_stage returned %d", slot);
             rc = decline(why);
         }
     }
+    G.n_per_dev[di]++;
     G.t_dev_lock += seam_now() - td0;
-    pthread_mutex_unlock(&G.dev);
+    pthread_mutex_unlock(&G.dev[di]);
     if (rc) return -1;
-    abi.wait(G.session, slot); /* outside the locks: other pictures enqueue their stages meanwhile */
+    abi.wait(ses, slot); /* outside the locks: other pictures enqueue their stages meanwhile */
     return 0;
 }
 
@@ -454,27 +469,30 @@ static int run_tf_pair(SeamTfPair *T, PictureParentControlSet *pcs, MeContext *c
     SvtHipMeResultsHost H;
     memset(&H, 0, sizeof(H));
     H.best_sad = T->best_sad; H.best_mv = T->best_mv; H.hme_sc = T->hme_sc; H.hme_sad = T->hme_sad;
-    pthread_mutex_lock(&G.dev);
+    const int di = svt_hip_seam_bind(pcs->picture_number);
+    pthread_mutex_lock(&G.dev[di]);
     const double td0 = seam_now();
-    int rc = ensure_session(pcs, src), slot = -1;
+    int rc = ensure_session(di, pcs, src), slot = -1;
+    void *ses = G.session[di];
     if (!rc && (ref_pics[0]->width != G.width || ref_pics[0]->stride_y != G.stride)) rc = decline("reference geometry");
     for (int pass = 0; !rc; pass++) {
-        if (ensure_resident((uint64_t)ref_ids[0], ref_pics[0], &S, ref_now)) rc = decline("reference upload");
-        else if (abi.resident(G.session, ref_ids[0])) break;
+        if (ensure_resident(di, (uint64_t)ref_ids[0], ref_pics[0], &S, ref_now)) rc = decline("reference upload");
+        else if (abi.resident(ses, ref_ids[0])) break;
         else if (pass == 3) rc = decline("ring too small for the reference set");
     }
     if (!rc) {
-        const int ks = sum_slot(pcs->picture_number, 1);
-        if (abi.resident(G.session, (int64_t)pcs->picture_number) && G.sum[ks][1] != now) { abi.invalidate(G.session, (int64_t)pcs->picture_number); G.n_reuploads++; }
-        if (!abi.resident(G.session, (int64_t)pcs->picture_number)) G.n_uploads++;
-        G.sum[ks][1] = now;
-        slot = abi.submit_stage(G.session, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, 1, &S, &H);
+        const int ks = sum_slot(di, pcs->picture_number, 1);
+        if (abi.resident(ses, (int64_t)pcs->picture_number) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)pcs->picture_number); G.n_reuploads++; }
+        if (!abi.resident(ses, (int64_t)pcs->picture_number)) G.n_uploads++;
+        G.sum[di][ks][1] = now;
+        slot = abi.submit_stage(ses, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, 1, &S, &H);
         if (slot < 0) rc = decline("svt_hip_me_session_submit_stage (ME_MCTF form) refused the parameters");
     }
+    G.n_per_dev[di]++;
     G.t_dev_lock += seam_now() - td0;
-    pthread_mutex_unlock(&G.dev);
+    pthread_mutex_unlock(&G.dev[di]);
     if (rc) return -1;
-    abi.wait(G.session, slot);
+    abi.wait(ses, slot);
     return 0;
 }
 

@@ -28,6 +28,7 @@ void restoration_seg_search(int32_t *rst_tmpbuf, Yv12BufferConfig *org_fts, cons
                             PictureControlSet *pcs, uint32_t segment_index);
 void svt_av1_loop_restoration_filter_frame(int32_t *rst_tmpbuf, Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr);
 
+int svt_hip_seam_bind(unsigned long long picture_number); /* integration/enc_handle_binding.c: SVT_HIP_DEVICES sharding */
 static struct {
     pthread_mutex_t lock;
     int             mode; /* 0 off, 1 on */
@@ -110,6 +111,7 @@ static void search_plane(const Yv12BufferConfig *org_fts, const Yv12BufferConfig
                 memcpy(prev[u].hfilter, pcs->rst_info[plane].unit_info[u].wiener_info.hfilter, 16);
             }
     }
+    svt_hip_seam_bind(pcs->picture_number);
     if (L.search_host(&P, prev, out)) { fprintf(stderr, "SVT_HIP_LR_SEAM: svt_hip_lr_search_plane_host refused the parameters\n"); abort(); }
     RestUnitSearchInfo *rusi = pcs->rusi_picture[plane];
     for (int u = 0; u < n; u++) {
@@ -182,6 +184,7 @@ static void seam_loop_restoration_filter_frame(int32_t *rst_tmpbuf, Yv12BufferCo
         P.width = (uint32_t)w; P.height = (uint32_t)h; P.unit_size = (uint32_t)rsi->restoration_unit_size;
         P.ss_x = (uint8_t)(is_uv && cm->subsampling_x); P.ss_y = (uint8_t)(is_uv && cm->subsampling_y); P.highbd = (uint8_t)highbd; P.bit_depth = (uint8_t)cm->bit_depth;
         P.units = units;
+        svt_hip_seam_bind(cm->child_pcs->picture_number);
         L.filter_host(&P);
         free(units);
         pthread_mutex_lock(&L.lock);

@@ -39,6 +39,7 @@ static void tpl_mc_flow_dispenser_use1(TPL_DISP_ARGS); /* the seam */
 #include "src_ops_process.c" /* resolves through -I$(REF)/Source/Lib/Codec */
 #undef tpl_mc_flow_dispenser
 
+int svt_hip_seam_bind(unsigned long long picture_number); /* integration/enc_handle_binding.c: SVT_HIP_DEVICES sharding */
 static struct {
     pthread_mutex_t lock;
     int             mode;
@@ -145,6 +146,7 @@ static void tpl_mc_flow_dispenser_use1(TPL_DISP_ARGS) {
     }
     const uint32_t cols16 = (pcs->aligned_width + 15) >> 4, rows16 = (((inp->height + 7) & ~7u) + 15) >> 4, cells = cols16 * rows16;
     SvtHipTplSrcStats *st = malloc((size_t)cells * sizeof(*st));
+    svt_hip_seam_bind(pcs->picture_number);
     if (TS.stage_host(&P, &H, tot, mvs, cand, st)) { fprintf(stderr, "SVT_HIP_TPL_SEAM: svt_hip_tpl_src_stage_host refused the parameters\n"); abort(); }
     /* into the buffer the reference's own "already computed" branch reads (:969-977); a sequence without stored statistics (tpl_lad_mg == 0) has none: lend one */
     TplSrcStats *own = med->tpl_src_stats_buffer, *buf = own;

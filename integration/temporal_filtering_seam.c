@@ -67,6 +67,7 @@ typedef struct SubpelBatch {
     SvtHipTfSubpelResult    *res;
     size_t                   cap;
 } SubpelBatch;
+int svt_hip_seam_bind(unsigned long long picture_number); /* integration/enc_handle_binding.c: SVT_HIP_DEVICES sharding */
 static struct {
     pthread_mutex_t lock;
     int             mode; /* -1 unknown */
@@ -156,6 +157,7 @@ static int build_batch(SubpelBatch *B, PictureParentControlSet *pcs, MeContext *
     P.subsampling_shift = pcs->tf_ctrls.sub_sampling_shift; P.bit_depth = 8; P.early_exit_th = me_ctx->tf_subpel_early_exit_th;
     P.mi_rows = (uint32_t)pcs->av1_cm->mi_rows; P.mi_cols = (uint32_t)pcs->av1_cm->mi_cols;
     P.ref_org_x = ref->org_x; P.ref_org_y = ref->org_y; P.ref_stride = ref->stride_y;
+    svt_hip_seam_bind(pcs->picture_number);
     SPS.search_host(&P, src_buf, cen->luma_size, ref->buffer_y, ref->luma_size, B->descs, n, B->res);
     B->n_sb = n_sb; B->per_sb = per_sb;
     SPS.n_batches++; SPS.n_blocks += n;

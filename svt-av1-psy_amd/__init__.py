@@ -39,6 +39,9 @@ PROTOTYPES = {
     "svt_hip_shutdown": (None, []),
     "svt_hip_device_name": (C.c_char_p, []),
     "svt_hip_tuning_reload": (None, []),
+    "svt_hip_device_count": (C.c_int, []),
+    "svt_hip_set_thread_device": (C.c_int, [C.c_int]),
+    "svt_hip_get_thread_device": (C.c_int, []),
     "svt_hip_tpl_src_stage": (None, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "svt_hip_tpl_src_stage_host": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "svt_hip_setup_rtcd": (C.c_int, [C.c_uint64]),
@@ -76,6 +79,7 @@ PROTOTYPES = {
     "svt_hip_host_alloc": (vp, [C.c_size_t]),
     "svt_hip_host_free": (None, [vp]),
     "svt_hip_me_session_create": (vp, [C.c_uint32] * 11),
+    "svt_hip_me_session_create_on": (vp, [C.c_int] + [C.c_uint32] * 11),
     "svt_hip_me_session_destroy": (None, [vp]),
     "svt_hip_me_session_submit": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
     "svt_hip_me_session_wait": (None, [vp, C.c_int]),

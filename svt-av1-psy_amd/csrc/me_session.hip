@@ -23,6 +23,7 @@ struct Slot {
     std::vector<int>    reads;           // ring entries the slot's picture in flight reads (its source and references)
 };
 struct Session {
+    int      device = 0;                 // the GPU the ring, the slots and every launch of this session live on (svt_hip_me_session_create_on)
     uint32_t width, height, stride, org_x, org_y, rows, ring, max_refs, sbs;
     size_t   plane_bytes, ws_bytes;
     uint8_t* sb_size = nullptr;          // [sbs][2] B64Geom width, height
@@ -93,7 +94,15 @@ void svt_hip_host_free(void* p) { if (p) HIP_CHECK(hipHostFree(p)); }
 void* svt_hip_me_session_create(uint32_t width, uint32_t height, uint32_t stride, uint32_t org_x, uint32_t org_y, uint32_t rows, uint32_t ring_planes,
                                 uint32_t max_refs, uint32_t max_area_width, uint32_t max_area_height, uint32_t n_slots) {
     svthip::ensure_device();
+    return svt_hip_me_session_create_on(svthip::current_device(), width, height, stride, org_x, org_y, rows, ring_planes, max_refs, max_area_width, max_area_height,
+                                        n_slots);
+}
+void* svt_hip_me_session_create_on(int device, uint32_t width, uint32_t height, uint32_t stride, uint32_t org_x, uint32_t org_y, uint32_t rows, uint32_t ring_planes,
+                                   uint32_t max_refs, uint32_t max_area_width, uint32_t max_area_height, uint32_t n_slots) {
+    if (device < 0 || device >= svt_hip_device_count()) return nullptr;
+    svthip::DeviceGuard guard(device);
     Session* s = new Session;
+    s->device = device;
     s->width = width; s->height = height; s->stride = stride; s->org_x = org_x; s->org_y = org_y; s->rows = rows;
     s->ring = ring_planes < 2 ? 2 : ring_planes; s->max_refs = max_refs ? max_refs : 1;
     s->sbs = ((width + 63) / 64) * ((height + 63) / 64);
@@ -125,6 +134,8 @@ void* svt_hip_me_session_create(uint32_t width, uint32_t height, uint32_t stride
 void svt_hip_me_session_destroy(void* session) {
     Session* s = (Session*)session;
     if (!s) return;
+    svthip::DeviceGuard guard(s->device);
+    if (!s) return;
     svthip::ensure_device();
     for (auto& sl : s->slots) {
         HIP_CHECK(hipStreamSynchronize(sl.st));
@@ -146,8 +157,8 @@ void svt_hip_me_session_destroy(void* session) {
 static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
                              uint32_t area_h, int sub_sad, uint32_t* best_sad_host, uint32_t* best_mv_host, const SvtHipMeResultsParams* fmt,
                              const SvtHipMeResultsHost* out, const SvtHipMeStageParams* stage = nullptr) {
-    svthip::ensure_device(); // an encoder worker thread that did not create the session binds to the device here
     Session* s = (Session*)session;
+    svthip::DeviceGuard guard(s->device); // an encoder worker thread that did not create the session binds to the session's device here
     if (n_refs > s->max_refs) return -2;
     if (stage && (!s->stage || n_refs > 8 || (uint32_t)stage->num_hme_sa_w * stage->num_hme_sa_h > s->max_regions ||
                   stage->num_hme_sa_w == 0 || stage->num_hme_sa_h == 0))
@@ -381,8 +392,8 @@ int svt_hip_me_session_submit_results(void* session, int64_t pic_id, const uint8
 
 int svt_hip_me_session_enable_stage(void* session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,
                                     uint32_t max_me_area_height) {
-    svthip::ensure_device();
     Session* s = (Session*)session;
+    svthip::DeviceGuard guard(s->device);
     if (s->stage || !max_regions || s->max_refs > 8) return -1;
     const uint32_t pads[2] = {quarter_pad, sixteenth_pad};
     for (int k = 0; k < 2; k++) {
@@ -438,8 +449,8 @@ int svt_hip_me_session_resident(void* session, int64_t pic_id) {
 }
 
 void svt_hip_me_session_wait(void* session, int slot) {
-    svthip::ensure_device();
     Session* s = (Session*)session;
+    svthip::DeviceGuard guard(s->device);
     if (slot < 0 || slot >= (int)s->slots.size()) return;
     HIP_CHECK(hipEventSynchronize(s->slots[slot].done));
 }

@@ -6,9 +6,19 @@
 
 namespace svthip {
 
-static std::atomic<int>  g_device{-1};
+static std::atomic<int>  g_device{-1};         // the default device (svt_hip_init)
 static std::atomic<bool> g_initialised{false}; // written by svt_hip_init, read by every worker thread on first entry
+static std::atomic<bool> g_multi{false};       // a thread or a session has asked for a device of its own: the binding is re-established on every entry
 static char g_name[256]   = "uninitialised";
+constexpr int MAX_DEVICES = 16;
+
+// Device selection is PER HOST THREAD (as HIP's own current device): svt_hip_set_thread_device() / a session's DeviceGuard set t_want, everything else runs on
+// the default device.  One encoder process can therefore drive several GPUs -- a seam binds the calling worker thread to the device its picture is sharded to
+// (frame-level sharding) and every host-call arena, stream and session below belongs to exactly one device.
+static thread_local int t_want  = -1; // device this thread asked for (-1: the default)
+static thread_local int t_bound = -1; // device this library last made current on this thread
+
+int current_device() { return t_want >= 0 ? t_want : (int)g_device; }
 
 void ensure_device() {
     if (!g_initialised) {
@@ -20,20 +30,28 @@ void ensure_device() {
         }
     }
     // the current device is per host thread: the encoder's worker threads (pointers are called concurrently from ME / EncDec /
-    // CDEF / REST threads) bind to the device chosen at svt_hip_init the first time they enter the library
-    static thread_local bool t_bound = false;
-    if (!t_bound) {
-        HIP_CHECK(hipSetDevice(g_device));
-        t_bound = true;
+    // CDEF / REST threads) bind to their device the first time they enter the library, and again whenever it changes
+    const int d = current_device();
+    if (t_bound != d || g_multi) {
+        HIP_CHECK(hipSetDevice(d));
+        t_bound = d;
     }
 }
 
-static thread_local HostCall t_call;
+DeviceGuard::DeviceGuard(int device) : prev(t_want) {
+    t_want = device;
+    g_multi = true;
+    ensure_device();
+}
+DeviceGuard::~DeviceGuard() { t_want = prev; } // (the previous device is made current again at this thread's next entry into the library)
+
+static thread_local HostCall t_calls[MAX_DEVICES]; // one arena + stream per (thread, device)
 
 HostCall& host_call() {
     ensure_device();
-    if (!t_call.stream) HIP_CHECK(hipStreamCreateWithFlags(&t_call.stream, hipStreamNonBlocking));
-    return t_call;
+    HostCall& c = t_calls[current_device()];
+    if (!c.stream) HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    return c;
 }
 
 void HostCall::begin() {
@@ -209,7 +227,7 @@ int svt_hip_init(int device) {
     using namespace svthip;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -1;
-    if (device < 0 || device >= n) return -1;
+    if (device < 0 || device >= n || device >= svthip::MAX_DEVICES) return -1;
     if (hipSetDevice(device) != hipSuccess) return -1;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
@@ -221,11 +239,34 @@ int svt_hip_init(int device) {
 
 void svt_hip_shutdown(void) {
     using namespace svthip;
-    if (t_call.dev) (void)hipFree(t_call.dev);
-    if (t_call.pin) (void)hipHostFree(t_call.pin);
-    if (t_call.stream) (void)hipStreamDestroy(t_call.stream);
-    t_call        = HostCall();
+    for (int d = 0; d < MAX_DEVICES; d++) { // the calling thread's arenas
+        HostCall& c = t_calls[d];
+        if (!c.dev && !c.pin && !c.stream) continue;
+        (void)hipSetDevice(d);
+        if (c.dev) (void)hipFree(c.dev);
+        if (c.pin) (void)hipHostFree(c.pin);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+        c = HostCall();
+    }
+    t_bound       = -1;
     g_initialised = false;
+}
+
+int svt_hip_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+int svt_hip_set_thread_device(int device) {
+    using namespace svthip;
+    if (device >= MAX_DEVICES || device >= svt_hip_device_count()) return -1;
+    t_want = device < 0 ? -1 : device;
+    if (device >= 0 && device != (int)g_device) g_multi = true;
+    ensure_device();
+    return 0;
+}
+int svt_hip_get_thread_device(void) {
+    svthip::ensure_device();
+    return svthip::current_device();
 }
 
 const char* svt_hip_device_name(void) { return svthip::g_name; }

@@ -50,7 +50,15 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 
 namespace svthip {
 
-void ensure_device(); // aborts with a clear message when svt_hip_init() found no GPU
+void ensure_device(); // binds the calling thread to its device (the default of svt_hip_init, or the one svt_hip_set_thread_device / a DeviceGuard chose);
+                      // aborts with a clear message when svt_hip_init() found no GPU
+int  current_device();
+// Makes `device` the calling thread's device for the guard's lifetime: every entry point of an object that lives on one device (an ME session) opens with it.
+struct DeviceGuard {
+    int prev;
+    explicit DeviceGuard(int device);
+    ~DeviceGuard();
+};
 
 // Bump allocator over one device buffer and one pinned host buffer; reset at the start of every host call.
 struct HostCall {

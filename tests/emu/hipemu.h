@@ -24,6 +24,7 @@
 #include <cstring>
 #include <algorithm>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -222,14 +223,45 @@ template <typename T> inline T from_u64(uint64_t u) {
 #define gridDim hipemu::gDim
 #define warpSize 64
 
+// ---- several emulated devices (SVT_HIPEMU_DEVICES=N) ------------------------------------------------------------------------------------
+// The current device is per host thread (as in HIP); every device allocation and every created stream remembers the device that was current when
+// it was made, and a copy / memset / kernel launch that names memory or a stream of ANOTHER device than the current one aborts with a message --
+// on real hardware that is an invalid-device-pointer fault (no peer access is enabled anywhere in the library).  This is how the multi-device
+// paths (sessions bound to a device, the seams' picture -> device sharding) are exercised on a machine without a GPU.
 namespace hipemu {
+struct Stream { int device; };
+struct Alloc { size_t n; int device; };
+inline int device_count() {
+    static const int n = [] { const char* e = getenv("SVT_HIPEMU_DEVICES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    return n;
+}
+inline int& cur_device() { static thread_local int d = 0; return d; }
+inline std::map<uintptr_t, Alloc>& allocs() { static std::map<uintptr_t, Alloc> m; return m; }
+inline std::mutex& alloc_lock() { static std::mutex m; return m; }
+inline void check_ptr(const void* p, const char* what) {
+    if (device_count() == 1 || !p) return;
+    std::lock_guard<std::mutex> g(alloc_lock());
+    auto it = allocs().upper_bound((uintptr_t)p);
+    if (it == allocs().begin()) return; // not a device allocation (host memory)
+    --it;
+    if ((uintptr_t)p < it->first + it->second.n && it->second.device != cur_device()) {
+        fprintf(stderr, "hipemu: %s touches memory of device %d while device %d is current\n", what, it->second.device, cur_device());
+        abort();
+    }
+}
+inline void check_stream(void* s, const char* what) {
+    if (s && ((Stream*)s)->device != cur_device()) {
+        fprintf(stderr, "hipemu: %s on a stream of device %d while device %d is current\n", what, ((Stream*)s)->device, cur_device());
+        abort();
+    }
+}
 template <typename... P, typename... A> inline void launch_k(void (*k)(P...), dim3 grid, dim3 block, size_t shmem, A... a) {
     launch([=]() { k(a...); }, grid, block, shmem);
 }
 } // namespace hipemu
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipemu::launch_k(kernel, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__)
+    (hipemu::check_stream((hipStream_t)(stream), #kernel), hipemu::launch_k(kernel, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__))
 
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
@@ -463,9 +495,9 @@ template <typename T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return 
 inline hipError_t  hipGetLastError() { return hipSuccess; }
 inline hipError_t  hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
-inline hipError_t  hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-inline hipError_t  hipSetDevice(int) { return hipSuccess; }
-inline hipError_t  hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t  hipGetDeviceCount(int* n) { *n = hipemu::device_count(); return hipSuccess; }
+inline hipError_t  hipSetDevice(int d) { if (d < 0 || d >= hipemu::device_count()) return hipErrorInvalidValue; hipemu::cur_device() = d; return hipSuccess; }
+inline hipError_t  hipGetDevice(int* d) { *d = hipemu::cur_device(); return hipSuccess; }
 inline hipError_t  hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     memset(p, 0, sizeof(*p));
     strcpy(p->name, "hipemu lock-step interpreter");
@@ -473,21 +505,39 @@ inline hipError_t  hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->multiProcessorCount = 1;
     return hipSuccess;
 }
-inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~size_t(255)); return *p ? hipSuccess : 2; }
-inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+inline hipError_t hipMalloc(void** p, size_t n) {
+    *p = aligned_alloc(256, (n + 255) & ~size_t(255));
+    if (*p && hipemu::device_count() > 1) { std::lock_guard<std::mutex> g(hipemu::alloc_lock()); hipemu::allocs()[(uintptr_t)*p] = hipemu::Alloc{n, hipemu::cur_device()}; }
+    return *p ? hipSuccess : 2;
+}
+inline hipError_t hipFree(void* p) {
+    if (p && hipemu::device_count() > 1) { std::lock_guard<std::mutex> g(hipemu::alloc_lock()); hipemu::allocs().erase((uintptr_t)p); }
+    free(p);
+    return hipSuccess;
+}
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = aligned_alloc(256, (n + 255) & ~size_t(255)); return *p ? hipSuccess : 2; }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
-inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = nullptr) {
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { hipemu::check_ptr(d, "hipMemcpy"); hipemu::check_ptr(s, "hipMemcpy"); memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st = nullptr) {
+    hipemu::check_stream(st, "hipMemcpyAsync"); hipemu::check_ptr(d, "hipMemcpyAsync"); hipemu::check_ptr(s, "hipMemcpyAsync");
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t st = nullptr) {
+    hipemu::check_stream(st, "hipMemcpy2DAsync"); hipemu::check_ptr(d, "hipMemcpy2DAsync"); hipemu::check_ptr(s, "hipMemcpy2DAsync");
     for (size_t y = 0; y < h; y++) memcpy((char*)d + y * dp, (const char*)s + y * sp, w);
     return hipSuccess;
 }
-inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
-inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
-inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
-inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { hipemu::check_ptr(d, "hipMemset"); memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = nullptr) {
+    hipemu::check_stream(st, "hipMemsetAsync"); hipemu::check_ptr(d, "hipMemsetAsync");
+    memset(d, v, n);
+    return hipSuccess;
+}
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipemu::Stream{hipemu::cur_device()}; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hipemu::Stream{hipemu::cur_device()}; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { delete (hipemu::Stream*)s; return hipSuccess; }
+inline hipError_t hipStreamGetDevice(hipStream_t s, int* d) { *d = s ? ((hipemu::Stream*)s)->device : hipemu::cur_device(); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 // HIP graphs: the interpreter executes a launch when it is issued, so "capture" runs the work once and a graph launch cannot replay it;
 // the product's graph entry points link, CPU tests do not use them.

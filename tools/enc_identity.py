@@ -101,6 +101,9 @@ CASES = {
     "tplseam_1080p_p8": (1920, 1080, 20, 8, ["--preset", "8", "+tplseam"]),
     "tplseam_me_p8_8bit": (448, 264, 20, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+tplseam"]),  # ME results produced by the device stage feed the TPL stage
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
+    # one encode over TWO (emulated) devices: SVT_HIP_DEVICES=0,1 shards the pictures by picture number; every seam at once
+    "tiny_2dev_everyseam_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "tiny_2dev_everyseam_p4": (128, 128, 6, 8, ["--preset", "4", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "tiny_tplseam_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+tplseam"]),
     "tiny_tplseam_p10": (192, 136, 18, 8, ["--preset", "10", "--lp", "1", "+tplseam"]),
     "tiny_tfsubpel_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
@@ -189,6 +192,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     tplseam_file = os.path.join(outdir, name + "_tplseam.txt")
     if tplseam:
         env.update({"SVT_HIP_TPL_SEAM": "1", "SVT_HIP_TPL_SEAM_STATS": tplseam_file})
+    devices = next((a[9:] for a in CASES[name][4] if a.startswith("+devices:")), None)
+    shard_file = os.path.join(outdir, name + "_devices.txt")
+    if devices:
+        env.update({"SVT_HIP_DEVICES": devices, "SVT_HIP_DEVICES_STATS": shard_file, "SVT_HIPEMU_DEVICES": str(len(devices.split(",")))})  # (the last one: emulator only)
     if (seam or lrseam or cdefseam or dlfseam or tplseam) and not with_hook and not only:
         only = "-"  # no RTCD pointer matches: the seam(s) alone
     if only:
@@ -250,6 +257,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
             res["identical"] = res["identical"] and res["dlfseam"].get("segments", 0) > 0               # filter segments on the device (other configurations may pick level 0)
         if "_sb_" in name or name.startswith("fps_1080p_p8_all"):  # ... and, at presets >= 7, from the per-SB records of the coding loop
             res["identical"] = res["identical"] and res["dlfseam"].get("pictures_filtered_from_sb_records", 0) > 0
+    if devices:  # every listed device must really have received stage calls
+        st = dict(ln.split(None, 1) for ln in open(shard_file).read().splitlines()) if os.path.exists(shard_file) else {}
+        res["devices"] = {k: int(v) for k, v in st.items()}
+        res["identical"] = res["identical"] and len(res["devices"]) == len(devices.split(",")) and all(v > 0 for v in res["devices"].values())
     if tplseam:
         st = dict(ln.split(None, 1) for ln in open(tplseam_file).read().splitlines()) if os.path.exists(tplseam_file) else {}
         res["tplseam"] = {k: int(float(v)) for k, v in st.items()}
@@ -294,7 +305,7 @@ def main():
             union[k] = union.get(k, 0) + v
         print("%-20s identical=%s  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs  %s" % (nme, r["identical"], r.get("calls"), r.get("pointers_hit"),
                                                                                         r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"],
-                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", "")) + " " + str(r.get("tfsubpel", "")) + " " + str(r.get("tplseam", ""))), flush=True)
+                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", "")) + " " + str(r.get("tfsubpel", "")) + " " + str(r.get("tplseam", "")) + " " + str(r.get("devices", ""))), flush=True)
         if "fps_c" in r:
             print("    encoder fps: C-only %.2f, %swith HIP (host = %s) %.2f" % (r["fps_c"], ("AVX2 intrinsics %.2f, " % r["fps_avx2"]) if "fps_avx2" in r else "", r["host"],
                                                                                r.get("fps_hip", 0.0)), flush=True)
