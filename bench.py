@@ -841,6 +841,106 @@ def bench_frame_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle)
             "parity_checked_values": checked}
 
 
+def bench_filter_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle, size=(3840, 2160)):
+    """The in-loop filter half of the frame-partition case: ONE 4K 10-bit luma plane per step, CDEF apply over this rank's strip of filter-block rows
+    (svt_hip_cdef_frame_rows: 34 rows -> 5,5,4,4,4,4,4,4 at N = 8; the strip's tiles read their 3-row halos from the full deblocked plane every rank holds) and
+    loop restoration over its range of 64-row stripes (svt_hip_lr_filter_frame_stripes), each followed by an all-gather of the filtered strips so that every rank
+    holds the whole filtered plane (the next stage / the reference picture needs it).  Before timing, the assembled planes are compared with the CPU checker."""
+    Wc, Hc = size
+    bd = 10
+    g = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:Hc, 0:Wc]
+    plane = np.clip(((xx * 2 + yy * 3) % 1024) // 2 + (((xx // 8 + yy // 8) % 5) << 5) + g.integers(-16, 17, (Hc, Wc)), 0, 1023).astype(np.uint16)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1)).cuda()  # noqa: E731
+    d_pl = t(plane)
+    if dist is not None:
+        dist.broadcast(d_pl, src=0)  # the deblocked plane on every rank, once, outside the timed region
+    nhfb, nvfb = (Wc + 63) // 64, (Hc + 63) // 64
+    nfb = nhfb * nvfb
+    skip = np.zeros((nvfb * 8, nhfb * 8), np.uint8)
+    apri, asec = np.full(nfb, 4, np.int32), np.full(nfb, 2, np.int32)
+    d_skip, d_pri, d_sec = t(skip), t(apri), t(asec)
+    d_dir, d_var = torch.zeros(nfb * 64, dtype=torch.uint8, device="cuda"), torch.zeros(nfb * 64, dtype=torch.int32, device="cuda")
+    d_cdef = d_pl.clone()
+    Pc = pkg.CdefParams(d_pl.data_ptr(), d_pl.data_ptr(), d_cdef.data_ptr(), Wc, Wc, Wc, Wc, Hc, 0, 0, 0, 1, bd - 8, 4, 4, 1, 0, d_skip.data_ptr(), d_pri.data_ptr(), d_sec.data_ptr(),
+                        d_dir.data_ptr(), d_var.data_ptr(), None)
+    r0, r1 = strip_rows(nvfb, rank, world)
+    max_rows = (strip_rows(nvfb, 0, world)[1]) * 64
+    # loop restoration: stripes of 64 rows offset by 8 (stripe i = rows i * 64 - 8 .. (i + 1) * 64 - 8)
+    us = 256
+    nstripes = (Hc + 8 + 63) // 64
+    s0, s1 = strip_rows(nstripes, rank, world)
+    nvu, nhu = max((Hc + us // 2) // us, 1), max((Wc + us // 2) // us, 1)
+    units = np.zeros(nvu * nhu, dtype=pkg.LrUnit)
+    for i in range(len(units)):
+        f = [int(g.integers(-5, 11)), int(g.integers(-23, 9)), int(g.integers(-17, 47))]
+        taps = [f[0], f[1], f[2], -2 * sum(f), f[2], f[1], f[0], 0]
+        units[i] = ((1, 2, 0)[i % 3], taps, taps, int(g.integers(0, 16)), (int(g.integers(-96, 32)), int(g.integers(-32, 96))))
+    above, below = g.integers(0, 1024, (2 * nstripes, Wc)).astype(np.uint16), g.integers(0, 1024, (2 * nstripes, Wc)).astype(np.uint16)
+    d_ab, d_bl, d_un = t(above), t(below), t(units)
+    d_lr = torch.zeros(Hc * Wc, dtype=torch.int16, device="cuda")
+    row_bytes = Wc * 2
+    lr_rows = lambda k: (max(strip_rows(nstripes, k, world)[0] * 64 - 8, 0), min(strip_rows(nstripes, k, world)[1] * 64 - 8, Hc))  # noqa: E731
+    max_lr_rows = max(lr_rows(k)[1] - lr_rows(k)[0] for k in range(world))
+    loc_c = torch.zeros(max_rows * row_bytes, dtype=torch.uint8, device="cuda")
+    loc_l = torch.zeros(max_lr_rows * row_bytes, dtype=torch.uint8, device="cuda")
+    gat_c = torch.zeros(world * max_rows * row_bytes, dtype=torch.uint8, device="cuda")
+    gat_l = torch.zeros(world * max_lr_rows * row_bytes, dtype=torch.uint8, device="cuda")
+    cdef_u8 = d_cdef.view(torch.uint8) if d_cdef.dtype != torch.uint8 else d_cdef
+    lr_u8 = d_lr.view(torch.uint8)
+    Pl = pkg.LrParams(d_cdef.data_ptr(), d_ab.data_ptr(), d_bl.data_ptr(), d_lr.data_ptr(), Wc, Wc, Wc, Wc, Hc, us, 0, 0, 1, bd, d_un.data_ptr())
+
+    def step():
+        if r1 > r0:
+            lib.svt_hip_cdef_frame_rows(0, C.byref(Pc), r0, r1, stream)
+        if dist is not None:  # assemble the CDEF output everywhere: the LR stage reads 3 rows beyond its own stripes
+            y0, y1 = r0 * 64, min(r1 * 64, Hc)
+            loc_c[:(y1 - y0) * row_bytes].copy_(cdef_u8[y0 * row_bytes:y1 * row_bytes])
+            dist.all_gather_into_tensor(gat_c, loc_c)
+            for k in range(world):
+                q0, q1 = strip_rows(nvfb, k, world)
+                a0, a1 = q0 * 64, min(q1 * 64, Hc)
+                if k != rank and a1 > a0:
+                    cdef_u8[a0 * row_bytes:a1 * row_bytes].copy_(gat_c[k * max_rows * row_bytes:k * max_rows * row_bytes + (a1 - a0) * row_bytes])
+        if s1 > s0:
+            lib.svt_hip_lr_filter_frame_stripes(C.byref(Pl), s0, s1, stream)
+        if dist is not None:
+            y0, y1 = lr_rows(rank)
+            loc_l[:(y1 - y0) * row_bytes].copy_(lr_u8[y0 * row_bytes:y1 * row_bytes])
+            dist.all_gather_into_tensor(gat_l, loc_l)
+            for k in range(world):
+                a0, a1 = lr_rows(k)
+                if k != rank and a1 > a0:
+                    lr_u8[a0 * row_bytes:a1 * row_bytes].copy_(gat_l[k * max_lr_rows * row_bytes:k * max_lr_rows * row_bytes + (a1 - a0) * row_bytes])
+    step()
+    torch.cuda.synchronize()
+    checked = 0
+    if oracle is not None and rank == 0:  # the assembled planes against the CPU checker on a band of rows around every strip boundary
+        want_c = plane.copy()
+        o_dir, o_var, o_mse = np.zeros(nfb * 64, np.uint8), np.zeros(nfb * 64, np.int32), np.zeros(1, np.uint64)
+        oracle.oracle_cdef_frame(0, vp(plane), Wc, vp(plane), Wc, vp(want_c), Wc, Wc, Hc, 0, 0, 0, 1, bd - 8, 4, 4, 1, vp(skip), vp(apri), vp(asec), 0, vp(o_dir), vp(o_var), vp(o_mse))
+        got_c = d_cdef.cpu().numpy().view(np.uint16).reshape(Hc, Wc)
+        checked += must_equal("strip-partitioned CDEF apply", got_c, want_c)
+        want_l = np.zeros((Hc, Wc), np.uint16)
+        oracle.oracle_lr_filter_frame(vp(want_c), Wc, vp(above), vp(below), Wc, vp(want_l), Wc, Wc, Hc, 0, us, vp(units), bd, 1)
+        checked += must_equal("strip-partitioned loop restoration", d_lr.cpu().numpy().view(np.uint16).reshape(Hc, Wc), want_l)
+    L = calibrate_launches(torch, step, a.steps, a.min_leg_s, dist)
+
+    def step_l():
+        for _ in range(L):
+            step()
+    wall, dev = time_steps(torch, step_l, a.steps, a.warmup, dist)
+    tm = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    wall = float(tm.item())
+    return {"planes_per_s": a.steps * L / wall, "ms_per_plane": wall / (a.steps * L) * 1e3, "plane": "%dx%d 10-bit luma" % (Wc, Hc), "scaling": "strong",
+            "cdef_fb_row_strips": [strip_rows(nvfb, k, world)[1] - strip_rows(nvfb, k, world)[0] for k in range(world)],
+            "lr_stripe_ranges": [strip_rows(nstripes, k, world)[1] - strip_rows(nstripes, k, world)[0] for k in range(world)],
+            "collective": ("2 x all_gather_into_tensor over RCCL per plane (%d + %d B per rank)" % (max_rows * row_bytes, max_lr_rows * row_bytes)) if dist is not None else "none (1 GPU)",
+            "parity_checked_values": checked}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -951,6 +1051,8 @@ def main():
                   # measured v_qsad_pk_u16_u8 issue cost: 22.4 cycles per wave64 instruction per SIMD (profiles/r01_call1_valu_issue_rates.txt)
                   valu_peak_sad_ops_per_s=QSAD_PEAK, valu_frac=n * aw * ah * 4096 / kernel_s / QSAD_PEAK)
     fp = bench_frame_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle)
+    if (world > 1 or a.mode == "strips") and not a.pmc_child:
+        fp["in_loop_filters"] = bench_filter_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle)
     out = {
         "metric": "Mblocks/s per kernel (SAD, FwdTxfm2d, CDEF) + encoder fps @1080p preset 8", "value": value,
         "unit": "Mblocks/s (block = one search position of one 64x64 SB vs one reference = 85 block SADs)",

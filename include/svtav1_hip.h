@@ -724,6 +724,9 @@ typedef struct SvtHipCdefParams {
  * variances taken from dir / var (what the search pass over the same reconstruction wrote; the reference recomputes identical values, cdef.c:367-386).
  * All pointers inside `params` are DEVICE pointers; the struct itself is read on the host. */
 void svt_hip_cdef_frame(int mode, const SvtHipCdefParams *params, void *stream);
+/* the same over the filter-block rows [fb_row_begin, fb_row_end) of the plane only (fb_row_end < 0: to the last row) -- one GPU's strip when a picture is split
+ * over several devices; halos above / below the strip are read from the full input plane, outputs outside the strip are not touched */
+void svt_hip_cdef_frame_rows(int mode, const SvtHipCdefParams *params, int fb_row_begin, int fb_row_end, void *stream);
 /* svt_av1_cdef_frame (enc_cdef.c:284-560) for a 4:2:0 picture from HOST memory -- what a seam at cdef_process.c:458 calls: planes filtered IN PLACE (the
  * reference keeps the neighbours' unfiltered samples in line / column buffers, which is what filtering out of place on the device gives), skip = the 8x8
  * units svt_sb_compute_cdef_list leaves out (and every unit of a filter block the reference skips: all four strengths zero), pri / sec per filter block from
@@ -803,6 +806,8 @@ typedef struct SvtHipLrParams {
     const SvtHipLrUnit *units;   /* [vert units][horz units] */
 } SvtHipLrParams;
 void svt_hip_lr_filter_frame(const SvtHipLrParams *params, void *stream);
+/* the same over the 64-row stripes [stripe_begin, stripe_end) only (stripe_end < 0: to the last one): one GPU's strip of a picture split over several devices */
+void svt_hip_lr_filter_frame_stripes(const SvtHipLrParams *params, int stripe_begin, int stripe_end, void *stream);
 /* The same from HOST memory (a seam around svt_av1_loop_restoration_filter_frame, rest_process.c:632, calls it per restored plane): every pointer of params is
  * a host pointer, boundary_above / below point at frame column 0 (past the reference's RESTORATION_EXTRA_HORZ margin), dst may equal data; synchronous. */
 void svt_hip_lr_filter_frame_host(const SvtHipLrParams *params);

@@ -425,6 +425,7 @@ class CdefParams(C.Structure):
 
 PROTOTYPES.update({
     "svt_hip_cdef_frame": (None, [C.c_int, C.POINTER(CdefParams), vp]),
+    "svt_hip_cdef_frame_rows": (None, [C.c_int, C.POINTER(CdefParams), C.c_int, C.c_int, vp]),
     "svt_aom_cdef_find_dir_hip": (C.c_uint8, [vp, C.c_int32, vp, C.c_int32]),
     "svt_aom_cdef_find_dir_dual_hip": (None, [vp, vp, C.c_int, vp, vp, C.c_int32, vp, vp]),
     "svt_cdef_filter_block_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint8]),
@@ -458,6 +459,7 @@ class LrParams(C.Structure):
 
 PROTOTYPES.update({
     "svt_hip_lr_filter_frame": (None, [C.POINTER(LrParams), vp]),
+    "svt_hip_lr_filter_frame_stripes": (None, [C.POINTER(LrParams), C.c_int, C.c_int, vp]),
     "svt_av1_wiener_convolve_add_src_hip": (None, [vp, C.c_ssize_t, vp, C.c_ssize_t, vp, vp, C.c_int32, C.c_int32, vp]),
     "svt_av1_highbd_wiener_convolve_add_src_hip": (None, [vp, C.c_ssize_t, vp, C.c_ssize_t, vp, vp, C.c_int32, C.c_int32, vp, C.c_int32]),
     "svt_av1_selfguided_restoration_hip": (None, [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

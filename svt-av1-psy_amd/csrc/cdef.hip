@@ -509,7 +509,7 @@ __device__ __forceinline__ void apply_pass(const LaneCtx& L, const TapOffs& o, c
 // {s, s^2, s*d}) + 12 taps + 7 partial sums per lane and at 4 (128 VGPRs) spilt 172 bytes per lane -- 89 MB of scratch traffic per 4K plane (profiles/r02_kernel_resources.txt,
 // r02_reg9_pmc_traffic.json) -- so it is built for 3 (up to 170 VGPRs, no scratch).
 template <typename PIX, int MODE, int MINB = (MODE == 1 ? 3 : 4)>
-__global__ __launch_bounds__(256, MINB) void cdef_frame_kernel(const SvtHipCdefParams P, const int gpw, const int reuse_dir) {
+__global__ __launch_bounds__(256, MINB) void cdef_frame_kernel(const SvtHipCdefParams P, const int gpw, const int reuse_dir, const int fb0 /* first filter block of the launch */) {
     HIP_DYNAMIC_SHARED(uint16_t, tile_raw)
     __shared__ int                sh_any, sh_dc[4][64], sh_dd[4][64], sh_do[4][64];
     __shared__ unsigned long long sh_cells[20]; // [4 levels][4 secondary] + [level 0][4 secondary]
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256, MINB) void cdef_frame_kernel(const SvtHipCdefP
     const int pw = (int)P.width, ph = (int)P.height;
     const int nhfb = (pw + bw - 1) / bw, nvfb = (ph + bh - 1) / bh;
     // XCD-aware order: a filter block's tile shares its halo lines with the neighbouring blocks' tiles (the apply pass moved 2.2 x the algorithmic bytes)
-    const int fb = (int)xcd_remap(blockIdx.x, gridDim.x), fbr = fb / nhfb, fbc = fb % nhfb;
+    const int fb = fb0 + (int)xcd_remap(blockIdx.x, gridDim.x), fbr = fb / nhfb, fbc = fb % nhfb;
     const int pitch = tile_pitch(bw, uh);
     // search: this workgroup takes the level groups g0 .. g0 + gpw - 1 of its filter block one after the other, on ONE staged tile (large frames: gpw = 2
     // or 4, so the tile, the source block and the direction search are not repeated per group; small frames keep gpw = 1 to fill the chip)
@@ -687,9 +687,15 @@ __global__ void copy_rect8_to_16_kernel(uint16_t* dst, const uint8_t* src, int n
     if (i < n) dst[i] = src[i];
 }
 
-template <int MODE> void launch_frame(const SvtHipCdefParams& P, hipStream_t st, const int reuse_dir = 0) {
+// fbr0 / fbr1: filter-block rows [fbr0, fbr1) of the plane (the whole plane by default; a strip of rows when a picture is split over several GPUs -- the tiles of
+// the strip's first and last row still read their halos from the full input plane)
+template <int MODE> void launch_frame(const SvtHipCdefParams& P, hipStream_t st, const int reuse_dir = 0, int fbr0 = 0, int fbr1 = -1) {
     const int bw = 64 >> P.xdec, bh = 64 >> P.ydec;
-    const int nhfb = ((int)P.width + bw - 1) / bw, nvfb = ((int)P.height + bh - 1) / bh;
+    const int nhfb = ((int)P.width + bw - 1) / bw, nvfb_all = ((int)P.height + bh - 1) / bh;
+    if (fbr1 < 0 || fbr1 > nvfb_all) fbr1 = nvfb_all;
+    if (fbr0 < 0) fbr0 = 0;
+    if (fbr0 >= fbr1) return;
+    const int nvfb = fbr1 - fbr0, fb0 = fbr0 * nhfb;
     size_t shmem = (size_t)((bh + 2 * VB) * tile_pitch(bw, 8 >> P.ydec) + (MODE == 1 ? bh * bw : 0)) * 2 + 64;
     // search: four groups of four primary levels; a workgroup takes gpw of them on one staged tile as long as >= 4096 workgroups remain (256 CUs x 4 x 4 rounds)
     int gpw = 1;
@@ -700,13 +706,13 @@ template <int MODE> void launch_frame(const SvtHipCdefParams& P, hipStream_t st,
     if (MODE == 1 && gpw > 1) shmem += 3 * 8 * 256 * 4; // the secondary-sum cache (search_pass)
     const dim3 grid(nhfb * nvfb, MODE == 1 ? 4 / gpw : 1);
     if (MODE == 1 && svthip::tuning_cdef_search_minb() == 4) { // (measurement knob SVT_HIP_CDEF_MINB=4: the round-2 build of the search kernel, 128 VGPRs + scratch)
-        if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE, 4>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE, 4>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
+        if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE, 4>), grid, dim3(256), shmem, st, P, gpw, reuse_dir, fb0);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE, 4>), grid, dim3(256), shmem, st, P, gpw, reuse_dir, fb0);
     } else if (MODE == 1 && svthip::tuning_cdef_search_minb() == 2) { // (SVT_HIP_CDEF_MINB=2: 172 VGPRs, no scratch at all, two workgroups per CU)
-        if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE, 2>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE, 2>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
-    } else if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE>), grid, dim3(256), shmem, st, P, gpw, reuse_dir);
+        if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE, 2>), grid, dim3(256), shmem, st, P, gpw, reuse_dir, fb0);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE, 2>), grid, dim3(256), shmem, st, P, gpw, reuse_dir, fb0);
+    } else if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE>), grid, dim3(256), shmem, st, P, gpw, reuse_dir, fb0);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE>), grid, dim3(256), shmem, st, P, gpw, reuse_dir, fb0);
     SVT_LAUNCH_CHECK();
 }
 const int kBlkW[4] = {4, 4, 8, 8}, kBlkH[4] = {4, 8, 4, 8}; // BLOCK_4X4, 4X8, 8X4, 8X8 (definitions.h)
@@ -715,12 +721,13 @@ const int kBlkW[4] = {4, 4, 8, 8}, kBlkH[4] = {4, 8, 4, 8}; // BLOCK_4X4, 4X8, 8
 
 extern "C" {
 
-void svt_hip_cdef_frame(int mode, const SvtHipCdefParams* params, void* stream) {
+void svt_hip_cdef_frame(int mode, const SvtHipCdefParams* params, void* stream) { svt_hip_cdef_frame_rows(mode, params, 0, -1, stream); }
+void svt_hip_cdef_frame_rows(int mode, const SvtHipCdefParams* params, int fb_row_begin, int fb_row_end, void* stream) {
     svthip::ensure_device();
     if (mode == 1 && params->ncand == 0) return;
-    if (mode == 0) launch_frame<0>(*params, (hipStream_t)stream);
-    else if (mode == 2) launch_frame<0>(*params, (hipStream_t)stream, 1);
-    else launch_frame<1>(*params, (hipStream_t)stream);
+    if (mode == 0) launch_frame<0>(*params, (hipStream_t)stream, 0, fb_row_begin, fb_row_end);
+    else if (mode == 2) launch_frame<0>(*params, (hipStream_t)stream, 1, fb_row_begin, fb_row_end);
+    else launch_frame<1>(*params, (hipStream_t)stream, 0, fb_row_begin, fb_row_end);
 }
 
 // Host-pointer form of the frame apply for all planes of a 4:2:0 picture (what a seam around svt_av1_cdef_frame, cdef_process.c:458, calls): uploads the

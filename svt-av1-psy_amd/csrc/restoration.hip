@@ -27,7 +27,7 @@ constexpr size_t lr_frame_union(const int ur) { return lr_frame_ab(ur) > lr_fram
 constexpr size_t lr_frame_smem(const int ur) { return (size_t)(ur + 6) * TW * 2 + lr_frame_union(ur) + 512; }
 // grid (unit columns, halves of a stripe, stripes); nhu x nvu restoration units, ushift = log2(unit_size) or -1 (the host does the divisions once)
 template <int LR_UR> // rows of a stripe per workgroup: 32 (two workgroups per 64-row luma stripe) or 64
-__global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, const int nhu, const int nvu, const int ushift) {
+__global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, const int nhu, const int nvu, const int ushift, const int stripe0 /* first stripe of the launch */) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
     uint16_t* tile = smem;
     uint16_t* mid  = tile + (LR_UR + 6) * TW;                  // Wiener only
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void lr_frame_kernel(const SvtHipLrParams P, c
     // XCD-aware order over the linear workgroup index (x fastest): neighbouring stripe columns / halves share their 3-sample halos' cache lines
     const uint32_t lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
     const int      bx = (int)(lin % gridDim.x), byz = (int)(lin / gridDim.x), bhalf = byz % (int)gridDim.y, bz = byz / (int)gridDim.y;
-    s.stripe_idx = bz;
+    s.stripe_idx = stripe0 + bz;
     s.stripe_top = s.stripe_idx * sh - off < 0 ? 0 : s.stripe_idx * sh - off;
     s.stripe_bot = (s.stripe_idx + 1) * sh - off > ph ? ph : (s.stripe_idx + 1) * sh - off;
     s.x0 = bx * cw; s.y0 = s.stripe_top + bhalf * LR_UR;
@@ -175,11 +175,18 @@ void lr_block_host(const void* src, int sstride, void* dst, int dstride, int w, 
 
 extern "C" {
 
-void svt_hip_lr_filter_frame(const SvtHipLrParams* params, void* stream) {
+void svt_hip_lr_filter_frame(const SvtHipLrParams* params, void* stream) { svt_hip_lr_filter_frame_stripes(params, 0, -1, stream); }
+// stripes [stripe_begin, stripe_end) of the plane only (a strip of rows when a picture is split over several GPUs: the staging still reads the 3-sample halos and
+// the saved boundary lines from the full inputs); stripe_end < 0 = to the last stripe
+void svt_hip_lr_filter_frame_stripes(const SvtHipLrParams* params, int stripe_begin, int stripe_end, void* stream) {
     svthip::ensure_device();
     const SvtHipLrParams& P = *params;
     const int sh = 64 >> P.ss_y, off = 8 >> P.ss_y, cw = 64 >> P.ss_x;
-    const int n_stripes = ((int)P.height + off + sh - 1) / sh;
+    const int all_stripes = ((int)P.height + off + sh - 1) / sh;
+    if (stripe_end < 0 || stripe_end > all_stripes) stripe_end = all_stripes;
+    if (stripe_begin < 0) stripe_begin = 0;
+    if (stripe_begin >= stripe_end) return;
+    const int n_stripes = stripe_end - stripe_begin;
     const int n_cols    = ((int)P.width + cw - 1) / cw;
     const int ur_env = svthip::tuning_lr_rows_per_workgroup(); // SVT_HIP_LR_UR, read once: 32 (default, the measured optimum), 16 or 64 (profiles/r02_lr_walk_experiment.txt)
     const int us        = (int)P.unit_size;
@@ -187,12 +194,12 @@ void svt_hip_lr_filter_frame(const SvtHipLrParams* params, void* stream) {
     nvu = nvu > 0 ? nvu : 1; nhu = nhu > 0 ? nhu : 1;
     if (us > 0 && !(us & (us - 1))) ushift = __builtin_ctz((unsigned)us);
     if (ur_env == 64) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_frame_kernel<64>), dim3(n_cols, 1, n_stripes), dim3(256), lr_frame_smem(64), (hipStream_t)stream, P, nhu, nvu, ushift);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_frame_kernel<64>), dim3(n_cols, 1, n_stripes), dim3(256), lr_frame_smem(64), (hipStream_t)stream, P, nhu, nvu, ushift, stripe_begin);
     } else if (ur_env == 16) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_frame_kernel<16>), dim3(n_cols, (sh + 15) / 16, n_stripes), dim3(256), lr_frame_smem(16), (hipStream_t)stream, P, nhu, nvu, ushift);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_frame_kernel<16>), dim3(n_cols, (sh + 15) / 16, n_stripes), dim3(256), lr_frame_smem(16), (hipStream_t)stream, P, nhu, nvu, ushift, stripe_begin);
     } else {
         const int nsplit = (sh + 31) / 32;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_frame_kernel<32>), dim3(n_cols, nsplit, n_stripes), dim3(256), lr_frame_smem(32), (hipStream_t)stream, P, nhu, nvu, ushift);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_frame_kernel<32>), dim3(n_cols, nsplit, n_stripes), dim3(256), lr_frame_smem(32), (hipStream_t)stream, P, nhu, nvu, ushift, stripe_begin);
     }
     SVT_LAUNCH_CHECK();
 }

@@ -137,6 +137,40 @@ def test_cdef_search_groups_per_workgroup(be, oracle, gpw):
         be.lib.svt_hip_tuning_reload()
 
 
+def test_cdef_frame_in_row_strips(be, oracle):
+    """A picture split over several GPUs: svt_hip_cdef_frame_rows over the strips 3,2,... of filter-block rows, each strip reading its 3-row halos from the
+    full input plane and writing only its own rows; the strips together == the whole-frame result, for the search tables and for the applied plane."""
+    g = rng(4242)
+    bd, (W, H) = 10, ((1920, 1080) if be.is_gpu else (200, 328))  # (sizes are multiples of 8: the reference aligns pictures to 8x8 units)
+    luma = synth_plane(g, W, H, bd)
+    src = np.clip(luma + g.integers(-6, 7, luma.shape), 0, (1 << bd) - 1)
+    nhfb, nvfb = (W + 63) // 64, (H + 63) // 64
+    nfb = nhfb * nvfb
+    skip = (g.random((nvfb * 8, nhfb * 8)) < 0.2).astype(np.uint8)
+    cands = [(0, 0), (4, 2), (15, 4), (1, 0), (0, 1), (7, 1), (9, 0)]
+    pri, sec = np.array([c[0] for c in cands], np.int32), np.array([c[1] for c in cands], np.int32)
+    apri, asec = g.choice(np.array([0, 4, 9], np.int32), nfb).astype(np.int32), g.choice(np.array([0, 1, 2, 4], np.int32), nfb).astype(np.int32)
+    rec, so = luma.astype(np.uint16), src.astype(np.uint16)
+    world = 3
+    base, rem = divmod(nvfb, world)
+    strips = [(k * base + min(k, rem), k * base + min(k, rem) + base + (1 if k < rem else 0)) for k in range(world)]
+    for mode, P_, S_, ncand in ((1, pri, sec, len(cands)), (0, apri, asec, 0)):
+        o_out, o_dir, o_var, o_mse = rec.copy(), np.zeros(nfb * 64, np.uint8), np.zeros(nfb * 64, np.int32), np.zeros(max(nfb * max(ncand, 1), 1), np.uint64)
+        oracle.oracle_cdef_frame(mode, p(rec), W, p(so), W, p(o_out), W, W, H, 0, 0, 0, 1, bd - 8, 5, 5, 1, p(skip), p(P_), p(S_), ncand, p(o_dir), p(o_var), p(o_mse))
+        d_rec, d_src, d_out = be.dev(rec), be.dev(so), be.dev(rec)
+        d_skip, d_pri, d_sec = be.dev(skip), be.dev(P_), be.dev(S_)
+        d_dir, d_var, d_mse = be.dev(np.zeros(nfb * 64, np.uint8)), be.dev(np.zeros(nfb * 64, np.int32)), be.empty(max(nfb * max(ncand, 1), 1), np.uint64)
+        P = be.pkg.CdefParams(be.ptr(d_rec), be.ptr(d_src), be.ptr(d_out), W, W, W, W, H, 0, 0, 0, 1, bd - 8, 5, 5, 1, ncand, be.ptr(d_skip), be.ptr(d_pri), be.ptr(d_sec),
+                              be.ptr(d_dir), be.ptr(d_var), be.ptr(d_mse))
+        for (r0, r1) in reversed(strips):  # any order
+            be.lib.svt_hip_cdef_frame_rows(mode, C.byref(P), r0, r1, be.stream)
+        assert np.array_equal(be.host(d_dir), o_dir) and np.array_equal(be.host(d_var), o_var)
+        if mode:
+            assert np.array_equal(be.host(d_mse)[:nfb * ncand], o_mse[:nfb * ncand])
+        else:
+            assert np.array_equal(be.host(d_out).reshape(H, W), o_out)
+
+
 def test_cdef_single_call_symbols(be, oracle):
     """svt_aom_cdef_find_dir(_dual), svt_cdef_filter_block, svt_compute_cdef_dist_*, copy_rect8_8bit_to_16bit (CdefTest.cc)."""
     g = rng(3)

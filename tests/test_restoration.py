@@ -36,6 +36,31 @@ def test_lr_filter_frame(be, oracle, cfg):
     assert np.array_equal(got, want), np.argwhere(got != want)[:8]
 
 
+def test_lr_filter_frame_in_stripe_ranges(be, oracle):
+    """A picture split over several GPUs: svt_hip_lr_filter_frame_stripes over ranges of 64-row stripes, every range reading its halos and the saved
+    boundary lines from the full inputs; together == the whole-frame result."""
+    bd, ss, us = 10, 0, 64
+    w, h = (1920, 1080) if be.is_gpu else (136, 328)
+    g = rng(808)
+    dt = np.uint16
+    nstripes = (h + 8 + 63) // 64
+    yy, xx = np.mgrid[0:h, 0:w]
+    plane = np.clip(((xx * 3 + yy * 2) % (1 << bd)) // 2 + g.integers(0, 1 << (bd - 2), (h, w)), 0, (1 << bd) - 1).astype(dt)
+    above, below = g.integers(0, 1 << bd, (2 * nstripes, w)).astype(dt), g.integers(0, 1 << bd, (2 * nstripes, w)).astype(dt)
+    nvu, nhu = unit_grid(w, h, us)
+    units = make_units(g, nvu, nhu, be.pkg.LrUnit)
+    want = np.zeros((h, w), dt)
+    oracle.oracle_lr_filter_frame(p(plane), w, p(above), p(below), w, p(want), w, w, h, ss, us, p(units), bd, 1)
+    d_pl, d_ab, d_bl, d_un = be.dev(plane), be.dev(above), be.dev(below), be.dev(units)
+    d_out = be.empty((h, w), dt)
+    P = be.pkg.LrParams(be.ptr(d_pl), be.ptr(d_ab), be.ptr(d_bl), be.ptr(d_out), w, w, w, w, h, us, ss, ss, 1, bd, be.ptr(d_un))
+    cuts = [0, nstripes // 3, nstripes // 3 + 1, nstripes]
+    for a, b in reversed(list(zip(cuts[:-1], cuts[1:]))):
+        be.lib.svt_hip_lr_filter_frame_stripes(C.byref(P), a, b, be.stream)
+    got = be.host(d_out)
+    assert np.array_equal(got, want), np.argwhere(got != want)[:8]
+
+
 @pytest.mark.parametrize("bd", [8, 10, 12])
 def test_restoration_single_call_symbols(be, oracle, bd):
     """svt_av1_[highbd_]wiener_convolve_add_src, svt_av1_selfguided_restoration, svt_apply_selfguided_restoration
