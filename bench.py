@@ -1168,7 +1168,7 @@ def main():
     if "config3_roundtrip" in kernels:
         rf["kernels"]["config3_roundtrip"] = {"sizes_checked_vs_oracle": kernels["config3_roundtrip"]["sizes_checked"],
                                               "hbm_frac_min_max": kernels["config3_roundtrip"]["hbm_frac_min_max"]}
-    if a.legs:
+    if a.legs and a.mode != "strips":
         out.pop("frame_partition", None)
     if out.get("cpu_baseline"):
         cb = out["cpu_baseline"]["kernels"] = {}
