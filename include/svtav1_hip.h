@@ -31,6 +31,8 @@ extern "C" {
 int         svt_hip_init(int device);
 void        svt_hip_shutdown(void);
 const char *svt_hip_device_name(void);
+/* one-time costs of the calling thread's device (context, code-object loading, first allocations) paid now instead of inside the first real call */
+void svt_hip_warmup(void);
 /* Several GPUs from one process (frame-level sharding): the device is selected PER HOST THREAD, like HIP's own current device.  svt_hip_set_thread_device(d)
  * binds the calling thread to device d for every later call of this library on that thread (host-call arenas and streams are per thread AND device); -1 returns the
  * thread to the default device of svt_hip_init.  Returns 0, or -1 when d is not a device.  Objects that live on a device (ME sessions) remember it and make it current

@@ -66,6 +66,9 @@ static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
         fprintf(stderr, "SVT_HIP: svt_hip_init(%s) failed\n", dev);
         abort();
     }
+    /* one-time costs now, while the encoder is still initialising, not inside the first picture's stage call: the device context, the library's code objects */
+    void (*warmup)(void) = (void (*)(void))dlsym(h, "svt_hip_warmup");
+    if (warmup) warmup();
     const char *list = getenv("SVT_HIP_DEVICES");
     if (list && *list) {
         int (*count)(void) = (int (*)(void))dlsym(h, "svt_hip_device_count");

@@ -131,9 +131,12 @@ static uint64_t plane_sum(const EbPictureBufferDesc *p) { /* called OUTSIDE the 
     pthread_mutex_unlock(&G.lock);
     return h;
 }
-static uint64_t plane_sum_(const EbPictureBufferDesc *p) { /* content check of the visible luma samples (padding is a function of them) */
+/* content check of a picture's luma: every 8th row of the visible samples (the padding is a function of them).  The only thing that rewrites a picture after it may
+ * have been uploaded is its own temporal filtering, which changes the whole picture, so a sparse sample detects it; hashing all rows cost 0.6 ms per plane at 1080p
+ * -- a third of the seam's host time per picture (profiles/r03_reg1_bench_default.json: ms_hashing_planes). */
+static uint64_t plane_sum_(const EbPictureBufferDesc *p) {
     uint64_t h = 1469598103934665603ull;
-    for (uint32_t y = 0; y < p->height; y++) {
+    for (uint32_t y = 0; y < p->height; y += 8) {
         const uint8_t *r = p->buffer_y + (size_t)(p->org_y + y) * p->stride_y + p->org_x;
         uint64_t       a = 0;
         for (uint32_t x = 0; x + 8 <= p->width; x += 8) { uint64_t v; memcpy(&v, r + x, 8); a = a * 1099511628211ull + v; }

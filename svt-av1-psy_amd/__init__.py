@@ -39,6 +39,7 @@ PROTOTYPES = {
     "svt_hip_shutdown": (None, []),
     "svt_hip_device_name": (C.c_char_p, []),
     "svt_hip_tuning_reload": (None, []),
+    "svt_hip_warmup": (None, []),
     "svt_hip_device_count": (C.c_int, []),
     "svt_hip_set_thread_device": (C.c_int, [C.c_int]),
     "svt_hip_get_thread_device": (C.c_int, []),
