@@ -705,9 +705,8 @@ template <int MODE> void launch_frame(const SvtHipCdefParams& P, hipStream_t st,
     }
     if (MODE == 1 && gpw > 1) shmem += 3 * 8 * 256 * 4; // the secondary-sum cache (search_pass)
     const dim3 grid(nhfb * nvfb, MODE == 1 ? 4 / gpw : 1);
-    if (MODE == 1 && svthip::tuning_cdef_search_minb() == 4) { // (measurement knob SVT_HIP_CDEF_MINB=4: the round-2 build of the search kernel, 128 VGPRs + scratch)
-        if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE, 4>), grid, dim3(256), shmem, st, P, gpw, reuse_dir, fb0);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE, 4>), grid, dim3(256), shmem, st, P, gpw, reuse_dir, fb0);
+    // (the round-2 register budget of the search kernel -- 128 VGPRs, 196 B of scratch, 343 us on the 4K luma plane against 288 us -- is gone: profiles/r03_call3_ab_sad_cdef.txt)
+    if (false) {
     } else if (MODE == 1 && svthip::tuning_cdef_search_minb() == 2) { // (SVT_HIP_CDEF_MINB=2: 172 VGPRs, no scratch at all, two workgroups per CU)
         if (P.is_16bit) hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint16_t, MODE, 2>), grid, dim3(256), shmem, st, P, gpw, reuse_dir, fb0);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(cdef_frame_kernel<uint8_t, MODE, 2>), grid, dim3(256), shmem, st, P, gpw, reuse_dir, fb0);

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void lr_wiener_solve_kernel(const SvtHipLrSearc
             __syncthreads();
         }
     // finalize_sym_filter (:962-991) x 2 and compute_score (:925-960)
-    __shared__ int16_t vf[8], hf[8];
+    __shared__ int16_t vf[8], hf[8], sc[2][7];
     if (l < 2) {
         const int32_t* f  = l ? b : a;
         int16_t*       fi = l ? hf : vf;
@@ -239,16 +239,15 @@ __global__ __launch_bounds__(64) void lr_wiener_solve_kernel(const SvtHipLrSearc
         }
         fi[6] = fi[0]; fi[5] = fi[1]; fi[4] = fi[2];
         fi[3] = (int16_t)(-2 * (fi[0] + fi[1] + fi[2]));
+        // the full symmetric taps compute_score multiplies (indexed per lane at run time: LDS, not a private array)
+        int16_t mid = kStep;
+        for (int i = 0; i < 3; i++) { sc[l][i] = sc[l][6 - i] = fi[i]; mid = (int16_t)(mid - 2 * fi[i]); }
+        sc[l][3] = mid;
     }
     if (l < 2) PQ[l] = 0;
     __syncthreads();
     if (l < win2) {
-        int16_t ca[7], cb[7];
-        ca[3] = cb[3] = kStep;
-        for (int i = 0; i < 3; i++) {
-            ca[i] = ca[6 - i] = vf[i]; cb[i] = cb[6 - i] = hf[i];
-            ca[3] = (int16_t)(ca[3] - 2 * ca[i]); cb[3] = (int16_t)(cb[3] - 2 * cb[i]);
-        }
+        const int16_t *ca = sc[0], *cb = sc[1];
         auto ab = [&](const int k) { const int kk = k / win, ll = k - kk * win; return (int32_t)(ca[ll + plane_off] * cb[kk + plane_off]); };
         const int       k  = l;
         const long long pk = ab(k) * M[k] / kStep / kStep;
@@ -383,25 +382,44 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
 
 // ---- self-guided: projection + refinement of one (unit, parameter set) per workgroup (search_selfguided_restoration's loop body, :582-630) ------------
 constexpr int PROJ_T = 1024; // threads per (unit, parameter set): sixteen waves, every evaluation is one latency-bound pass over the unit
-__device__ __forceinline__ long long block_sum_i64(long long v, long long* part, const int tid) { // every thread gets the workgroup's sum
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const unsigned long long uv = (unsigned long long)v;
         v += (long long)(((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(uv >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)uv, m));
     }
-    __syncthreads(); // (part is reused across calls)
-    if ((tid & 63) == 0) part[tid >> 6] = v;
-    __syncthreads();
-    long long t = 0;
+    return v;
+}
+// The workgroup's sums of N per-thread values, written to out[0..N) in LDS (valid for every thread on return): one wave reduction per value, one pair of
+// barriers for the whole group.  use(k) says whether value k is wanted (workgroup-uniform).  part: [PROJ_T / 64][16].
+constexpr int PROJ_W = PROJ_T / 64;
+template <int N, typename U>
+__device__ __forceinline__ void block_sums_i64(const long long (&v)[N], long long (*part)[16], long long* out, const int tid, U use) {
+    static_assert(N <= 16, "part row");
+    __syncthreads(); // (part and out are reused across calls)
 #pragma unroll
-    for (int k = 0; k < PROJ_T / 64; k++) t += part[k];
-    return t;
+    for (int k = 0; k < N; k++)
+        if (use(k)) {
+            const long long w = wave_sum_i64(v[k]);
+            if ((tid & 63) == 0) part[tid >> 6][k] = w;
+        }
+    __syncthreads();
+    if (tid < N && use(tid)) {
+        long long t = 0;
+#pragma unroll
+        for (int w = 0; w < PROJ_W; w++) t += part[w][tid];
+        out[tid] = t;
+    }
+    __syncthreads();
 }
 struct __attribute__((aligned(16))) LrsQuad { uint32_t v[4]; };
 struct __attribute__((aligned(8))) LrsPair { uint32_t v[2]; };
 // the samples of a unit in raster order, PROJ_T apart, four in flight per thread (all loads of a group issued before the first use); (x, y) advance
 // incrementally -- no division per sample.  body(uu, spx, a0, a1): uu = dgd << 4, spx = src, a0 = flt0 - uu, a1 = flt1 - uu (0 for a pass that is off).  The
 // compact buffers deliver the same projection with uu = 0 and spx = src - dgd: ((dgd << 11) + y + 1024 >> 11) - src = (y + 1024 >> 11) - (src - dgd) exactly.
+#ifndef LRS_DEPTH
+#define LRS_DEPTH 4
+#endif
 template <bool COMPACT, typename F>
 __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, const SvtHipRect& r, const int32_t* f0, const int32_t* f1, const int r0, const int r1,
                                                  const int tid, F body) {
@@ -409,12 +427,12 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
     if (COMPACT && !((w | uw | r.h_start) & 3)) { // four consecutive samples per load pair: one b128 of packed (q1, q2) + one b64 of dgd - src
         const int qpr = uw >> 2, nq = qpr * uh, qy = PROJ_T / qpr, rx = PROJ_T - qy * qpr;
         int       y = tid / qpr, x = tid - y * qpr;
-        for (int i = tid; i < nq; i += 4 * PROJ_T) {
-            LrsQuad Q[4];
-            LrsPair D[4];
-            bool    ok[4];
+        for (int i = tid; i < nq; i += LRS_DEPTH * PROJ_T) {
+            LrsQuad Q[LRS_DEPTH];
+            LrsPair D[LRS_DEPTH];
+            bool    ok[LRS_DEPTH];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < LRS_DEPTH; k++) {
                 ok[k] = i + k * PROJ_T < nq;
                 const size_t fo = (size_t)(r.v_start + (ok[k] ? y : 0)) * w + r.h_start + 4 * (ok[k] ? x : 0);
                 Q[k] = *(const LrsQuad*)((const uint32_t*)f1 + fo);
@@ -423,7 +441,7 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
                 if (x >= qpr) { x -= qpr; y++; }
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++)
+            for (int k = 0; k < LRS_DEPTH; k++)
                 if (ok[k]) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
@@ -436,11 +454,11 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
     }
     const int qy = PROJ_T / uw, rx = PROJ_T - qy * uw;
     int       y = tid / uw, x = tid - y * uw;
-    for (int i = tid; i < npx; i += 4 * PROJ_T) {
-        int d[4], sp[4], g0[4], g1[4];
-        bool ok[4];
+    for (int i = tid; i < npx; i += LRS_DEPTH * PROJ_T) {
+        int d[LRS_DEPTH], sp[LRS_DEPTH], g0[LRS_DEPTH], g1[LRS_DEPTH];
+        bool ok[LRS_DEPTH];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < LRS_DEPTH; k++) {
             ok[k] = i + k * PROJ_T < npx;
             const int    yy = ok[k] ? y : 0, xx = ok[k] ? x : 0;
             const size_t fo = (size_t)(r.v_start + yy) * w + r.h_start + xx;
@@ -458,14 +476,16 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
             if (x >= uw) { x -= uw; y++; }
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < LRS_DEPTH; k++)
             if (ok[k]) body(d[k], sp[k], g0[k], g1[k]);
     }
 }
 template <bool COMPACT>
 __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const int32_t* __restrict__ flt,
                                                              SgResult* __restrict__ res, const int slots) {
-    __shared__ long long part[PROJ_T / 64];
+    __shared__ long long part[PROJ_W][16];
+    __shared__ long long sh_t[5], sh_err;
+    __shared__ long long sh_e[3][8]; // the candidate errors of a line (down, up, the first pass's up run): workgroup-uniform and indexed at run time -- LDS, not registers
     __shared__ int32_t   sh_xq[2];
     const int        u = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x, idx = P.sg_start_ep + slot * P.sg_ep_inc, w = (int)P.width, h = (int)P.height;
     const SvtHipRect r = rects[u];
@@ -480,10 +500,9 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
         const long long sd = (long long)sp * 16 - uu, q1 = a0, q2 = a1;
         a[0] += q1 * q1; a[1] += q2 * q2; a[2] += q1 * q2; a[3] += q1 * sd; a[4] += q2 * sd;
     });
-    long long t[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) t[k] = block_sum_i64(a[k], part, tid);
+    block_sums_i64(a, part, sh_t, tid, [](int) { return true; });
     if (tid == 0) {
+        const long long* t = sh_t;
         const double size = (double)npx;
         const double H00 = (double)t[0] / size, H11 = (double)t[1] / size, H01 = (double)t[2] / size, C0 = (double)t[3] / size, C1 = (double)t[4] / size;
         int x0 = 0, x1 = 0;
@@ -517,7 +536,9 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
             const int e = ((v + (1 << 10)) >> 11) - sp;
             e2 += (long long)e * e;
         });
-        return block_sum_i64(e2, part, tid);
+        const long long one[1] = {e2};
+        block_sums_i64(one, part, &sh_err, tid, [](int) { return true; });
+        return sh_err;
     };
     // finer_search_pixel_proj_error (:320-411), start_step 2.  The greedy walk only ever moves ONE tap along a line, and a move of tap p by delta changes
     // every sample's projection by delta * (a per-sample constant): so one pass over the unit evaluates a whole run of candidates -- up to PROJ_K steps
@@ -525,7 +546,8 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
     // of the first pass stay valid exactly when no down move was accepted, which is when the reference evaluates them.)  Control flow is workgroup-uniform.
     constexpr int PROJ_K = 8; // (4: more passes on long chains, 7.0 ms instead of 6.4 ms on the 4K bench plane)
     long long     err    = proj_err();
-    auto eval_line = [&](const int p, const int st, const int nd, const int nu, long long* ed, long long* eu) {
+    static_assert(PROJ_K <= 8, "sh_e rows");
+    auto eval_line = [&](const int p, const int st, const int nd, const int nu, long long* ed, long long* eu) { // ed, eu: rows of sh_e
         int xq0, xq1;
         if (r0 == 0) { xq0 = 0; xq1 = 128 - xqd[1]; }
         else if (r1 == 0) { xq0 = xqd[0]; xq1 = 0; }
@@ -543,18 +565,15 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
                 if (k < nu) { const int e = ((v + (k + 1) * dv) >> 11) - sp; au[k] += (long long)e * e; }
             }
         });
-#pragma unroll
-        for (int k = 0; k < PROJ_K; k++) {
-            if (k < nd) ed[k] = block_sum_i64(ad[k], part, tid);
-            if (k < nu) eu[k] = block_sum_i64(au[k], part, tid);
-        }
+        block_sums_i64(ad, part, ed, tid, [&](int k) { return k < nd; });
+        block_sums_i64(au, part, eu, tid, [&](int k) { return k < nu; });
     };
     if (P.sg_refine)
         for (int st = 2; st >= 1; st >>= 1)
             for (int p = 0; p < 2; p++) {
                 if ((r0 == 0 && p == 0) || (r1 == 0 && p == 1)) continue;
                 const int cap = st == 2 ? PROJ_K : 1; // only the largest step keeps moving in the same direction (:359-361)
-                long long ed[PROJ_K], eu[PROJ_K], eu0[PROJ_K];
+                long long *ed = sh_e[0], *eu = sh_e[1], *eu0 = sh_e[2];
                 int       skip = 0, nu0 = 0;
                 for (bool first = true;; first = false) { // the downward moves
                     const int roomd = (xqd[p] - tap_min[p]) / st, nd = roomd < cap ? roomd : cap;
@@ -562,7 +581,11 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
                     if (first) { const int roomu = (tap_max[p] - xqd[p]) / st; nu = roomu < cap ? roomu : cap; }
                     if (nd == 0 && nu == 0) break;
                     eval_line(p, st, nd, nu, ed, eu);
-                    if (first) { nu0 = nu; for (int k = 0; k < PROJ_K; k++) eu0[k] = eu[k]; }
+                    if (first) { // (the next writer of eu / eu0 passes block_sums_i64's first barrier before it writes)
+                        nu0 = nu;
+                        if (tid < PROJ_K) eu0[tid] = eu[tid];
+                        __syncthreads();
+                    }
                     int  k = 0;
                     bool rejected = false;
                     while (k < nd) {

@@ -68,17 +68,22 @@ __device__ __forceinline__ uint32_t pack_digits_lo(const int v0, const int v1, c
 
 struct __attribute__((aligned(4))) Dw5 { uint32_t w[5]; };
 
-// NG = 4 (win 7: 49 taps + source = 50 columns) or 2 (win 5: 26 columns)
-template <int NG>
+// WIN 7: 49 taps + source = 50 columns in NG = 4 groups of 16; WIN 5: 26 columns, NG = 2; WIN 3: 10 columns, NG = 1.  With the window a template parameter every
+// group but the last is known to hold taps only (16 (NG - 1) <= WIN^2), so only the last group keeps per-lane plane / pitch / mask registers.
+template <int WIN>
 __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, const void* src, const SvtHipRect* rects, const int dgd_stride, const int src_stride,
-                                                         const int win, const int is16, long long* Mout, long long* Hout) {
-    constexpr int NTRI = NG * (NG + 1) / 2, NTILE = 2 * NTRI + NG * NG;
+                                                         const int is16, long long* Mout, long long* Hout) {
+    constexpr int win = WIN, NG = (WIN * WIN + 1 + 15) / 16;
+    static_assert(16 * (NG - 1) <= WIN * WIN, "only the last group may hold the source column or padding");
+    // accumulator tiles: HH, LL and X over the upper triangle of group pairs, X(ga, gb) = H_ga L_gb^T (+ L_ga H_gb^T off the diagonal: both cross terms of an
+    // entry carry the same weight, so they share an accumulator -- 30 tiles instead of 36 for WIN 7, same 36 MFMAs per chunk)
+    constexpr int NTRI = NG * (NG + 1) / 2, NTILE = 3 * NTRI, NMFMA = 2 * NTRI + NG * NG;
     HIP_DYNAMIC_SHARED(uint32_t, smem)
     uint8_t* planes = (uint8_t*)smem; // [dgd hi][dgd lo][src hi][src lo]; later reused as int32 [NTILE][256]
     const int        tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
     const int        unit = blockIdx.z;
     const SvtHipRect R = rects[unit];
-    const int w2 = win * win, hw = win >> 1;
+    constexpr int w2 = win * win, hw = win >> 1;
     const int W = R.h_end - R.h_start, Hh = R.v_end - R.v_start;
     const int c0 = blockIdx.x * TC, rb0 = blockIdx.y * TR * BANDS; // origin of the workgroup's 64-row band group inside the unit
     if (c0 >= W || rb0 >= Hh) return;
@@ -88,24 +93,22 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     const int  avg = (int)((unsigned long long)H[w2] / (unsigned long long)((long long)W * Hh)); // H[w2] = sum of the degraded unit (stats_sum_kernel)
 
     // ---- per-lane operand addressing: group g -> tap t = 16 g + (l & 15); kg = l >> 4 selects pixels 16 kg .. 16 kg + 15 of a chunk ----
-    int      opoff[NG], oppitch[NG], ophi[NG], oplo[NG];
-    uint32_t opsh[NG], opmask[NG];
+    // (both pitches and the chunk step are multiples of 4 bytes, so the dword phase of an operand address is that of its lane offset)
+    int      opoff[NG], last_pitch = PP, last_hi = 0, last_lo = DGD_PLANE;
+    uint32_t last_mask = ~0u;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const int t = 16 * g + (l & 15), kg = l >> 4;
-        if (t < w2) { // tap index = (dx + hw) * win + (dy + hw)   (restoration_pick.c:673-679: k over columns, l over rows)
+        if (g < NG - 1 || t < w2) { // tap index = (dx + hw) * win + (dy + hw)   (restoration_pick.c:673-679: k over columns, l over rows)
             const int dx = t / win - hw, dy = t % win - hw;
-            const int off = (3 + dy) * PP + 4 + 16 * kg + dx;
-            opoff[g] = off & ~3; opsh[g] = (uint32_t)off & 3u; oppitch[g] = PP; ophi[g] = 0; oplo[g] = DGD_PLANE; opmask[g] = ~0u;
+            opoff[g] = (3 + dy) * PP + 4 + 16 * kg + dx;
         } else { // the source column (t == w2) or padding (contributes zeros)
-            opoff[g] = 16 * kg; opsh[g] = 0; oppitch[g] = TC; ophi[g] = 2 * DGD_PLANE; oplo[g] = 2 * DGD_PLANE + SRC_PLANE; opmask[g] = t == w2 ? ~0u : 0u;
+            opoff[g] = 16 * kg; last_pitch = TC; last_hi = 2 * DGD_PLANE; last_lo = 2 * DGD_PLANE + SRC_PLANE; last_mask = t == w2 ? ~0u : 0u;
         }
     }
-    i32x4 accHH[NTRI], accLL[NTRI], accHL[NG * NG];
+    i32x4 accHH[NTRI], accLL[NTRI], accX[NTRI];
 #pragma unroll
-    for (int i = 0; i < NTRI; i++) { accHH[i] = i32x4{0, 0, 0, 0}; accLL[i] = i32x4{0, 0, 0, 0}; }
-#pragma unroll
-    for (int i = 0; i < NG * NG; i++) accHL[i] = i32x4{0, 0, 0, 0};
+    for (int i = 0; i < NTRI; i++) { accHH[i] = i32x4{0, 0, 0, 0}; accLL[i] = i32x4{0, 0, 0, 0}; accX[i] = i32x4{0, 0, 0, 0}; }
 
     for (int band = 0; band < BANDS; band++) {
     const int r0 = rb0 + band * TR;
@@ -114,24 +117,27 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     if (band) __syncthreads(); // everyone is done reading the previous tile
     // ---- stage the digit planes: four samples per step, loads issued before the stores ----
     {
-        constexpr int SLOTS = PP / 4, NIT = ((TR + 6) * SLOTS + 255) / 256;
-        int v[NIT][4];
+        constexpr int SLOTS = PP / 4, NIT = ((TR + 6) * SLOTS + 255) / 256, HALF = (NIT + 1) / 2;
 #pragma unroll
-        for (int k = 0; k < NIT; k++) {
-            const int i = tid + 256 * k, r = i / SLOTS, s = i - r * SLOTS; // plane row r <-> tile row r - 3, slot s <-> tile columns 4 s - 4 ..
+        for (int k0 = 0; k0 < NIT; k0 += HALF) { // two batches: the accumulators leave no room for all NIT quads at once
+            int v[HALF][4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int tr = r - 3, tc = 4 * s - 4 + e;
-                const bool ok = i < (TR + 6) * SLOTS && tr >= -hw && tr < th + hw && tc >= -hw && tc < tw + hw;
-                v[k][e] = ok ? rd(dgd, is16, (size_t)((long long)(R.v_start + r0 + tr) * dgd_stride + (R.h_start + c0 + tc))) - avg : 0;
+            for (int k = 0; k < HALF; k++) {
+                const int i = tid + 256 * (k0 + k), r = i / SLOTS, s = i - r * SLOTS; // plane row r <-> tile row r - 3, slot s <-> tile columns 4 s - 4 ..
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int tr = r - 3, tc = 4 * s - 4 + e;
+                    const bool ok = k0 + k < NIT && i < (TR + 6) * SLOTS && tr >= -hw && tr < th + hw && tc >= -hw && tc < tw + hw;
+                    v[k][e] = ok ? rd(dgd, is16, (size_t)((long long)(R.v_start + r0 + tr) * dgd_stride + (R.h_start + c0 + tc))) - avg : 0;
+                }
             }
-        }
 #pragma unroll
-        for (int k = 0; k < NIT; k++) {
-            const int i = tid + 256 * k;
-            if (i < (TR + 6) * SLOTS) {
-                ((uint32_t*)planes)[i]                   = pack_digits_hi(v[k][0], v[k][1], v[k][2], v[k][3]);
-                ((uint32_t*)(planes + DGD_PLANE))[i]     = pack_digits_lo(v[k][0], v[k][1], v[k][2], v[k][3]);
+            for (int k = 0; k < HALF; k++) {
+                const int i = tid + 256 * (k0 + k);
+                if (k0 + k < NIT && i < (TR + 6) * SLOTS) {
+                    ((uint32_t*)planes)[i]               = pack_digits_hi(v[k][0], v[k][1], v[k][2], v[k][3]);
+                    ((uint32_t*)(planes + DGD_PLANE))[i] = pack_digits_lo(v[k][0], v[k][1], v[k][2], v[k][3]);
+                }
             }
         }
         constexpr int SSLOTS = TC / 4, SNIT = (TR * SSLOTS + 255) / 256;
@@ -165,17 +171,19 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
             const int nvalid = tw - ch * 64; // pixels of this chunk inside the unit (>= 64: all)
 #pragma unroll
             for (int g = 0; g < NG; g++) {
-                const int a  = row * oppitch[g] + 64 * ch + opoff[g];
-                const Dw5 vh = *(const Dw5*)(planes + ophi[g] + a), vl = *(const Dw5*)(planes + oplo[g] + a);
+                const bool last = g == NG - 1;
+                const int  af = row * (last ? last_pitch : PP) + 64 * ch + opoff[g], a = af & ~3;
+                const uint32_t sh = (uint32_t)af & 3u;
+                const Dw5 vh = *(const Dw5*)(planes + (last ? last_hi : 0) + a), vl = *(const Dw5*)(planes + (last ? last_lo : DGD_PLANE) + a);
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
-                    uint32_t m = g == NG - 1 ? opmask[g] : ~0u; // only the last group holds the source column and padding
+                    uint32_t m = last ? last_mask : ~0u; // only the last group holds the source column and padding
                     if (!FULL && nvalid < 64) { // pixel 16 kg + 4 d + e of the chunk is outside the unit -> its byte must be zero in every operand
                         const int first = 16 * (l >> 4) + 4 * d, left = nvalid - first;
                         m &= left >= 4 ? ~0u : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
                     }
-                    oH[g][d] = (int)(__builtin_amdgcn_alignbyte(vh.w[d + 1], vh.w[d], opsh[g]) & m);
-                    oL[g][d] = (int)(__builtin_amdgcn_alignbyte(vl.w[d + 1], vl.w[d], opsh[g]) & m);
+                    oH[g][d] = (int)(__builtin_amdgcn_alignbyte(vh.w[d + 1], vh.w[d], sh) & m);
+                    oL[g][d] = (int)(__builtin_amdgcn_alignbyte(vl.w[d + 1], vl.w[d], sh) & m);
                 }
             }
         };
@@ -188,10 +196,17 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
                     accHH[ti] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oH[ga], oH[gb], accHH[ti], 0, 0, 0);
                     accLL[ti] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oL[ga], oL[gb], accLL[ti], 0, 0, 0);
                 }
+            ti = 0;
 #pragma unroll
             for (int ga = 0; ga < NG; ga++)
 #pragma unroll
-                for (int gb = 0; gb < NG; gb++) accHL[ga * NG + gb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oH[ga], oL[gb], accHL[ga * NG + gb], 0, 0, 0);
+                for (int gb = ga; gb < NG; gb++, ti++) accX[ti] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oH[ga], oL[gb], accX[ti], 0, 0, 0);
+            ti = 0;
+#pragma unroll
+            for (int ga = 0; ga < NG; ga++)
+#pragma unroll
+                for (int gb = ga; gb < NG; gb++, ti++)
+                    if (gb != ga) accX[ti] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oL[ga], oH[gb], accX[ti], 0, 0, 0);
         };
         i32x4 aH[NG], aL[NG], bH[NG], bL[NG];
         if ((tw & 63) == 0 && nit > 0) {
@@ -210,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
                 fetch(i2, aH, aL, std::true_type{});
                 multiply(bH, bL);
 #pragma unroll
-                for (int k = 0; k < 2 * NTILE; k++) {
+                for (int k = 0; k < 2 * NMFMA; k++) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one LDS read
                     __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); // three VALU
@@ -225,9 +240,9 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     }
     }
 
-    // ---- merge the four waves in LDS (int32 is still exact: 4096 pixels), then one int64 atomic per matrix entry ----
+    // ---- merge the four waves in LDS (int32 is still exact: 4 waves x 16384 pixels x 2 x 128 x 127 < 2^31 for the shared cross-term tiles), then one int64 atomic per entry ----
     __syncthreads();
-    int* part = (int*)smem; // [NTILE][64 lanes][4]: HH tiles, LL tiles, HL tiles
+    int* part = (int*)smem; // [NTILE][64 lanes][4]: HH tiles, LL tiles, X tiles
     for (int i = tid; i < NTILE * 256; i += 256) part[i] = 0;
     __syncthreads();
 #pragma unroll
@@ -236,14 +251,11 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
         for (int d = 0; d < 4; d++) {
             atomicAdd(&part[(i * 64 + l) * 4 + d], accHH[i][d]);
             atomicAdd(&part[((NTRI + i) * 64 + l) * 4 + d], accLL[i][d]);
+            atomicAdd(&part[((2 * NTRI + i) * 64 + l) * 4 + d], accX[i][d]);
         }
-#pragma unroll
-    for (int i = 0; i < NG * NG; i++)
-#pragma unroll
-        for (int d = 0; d < 4; d++) atomicAdd(&part[((2 * NTRI + i) * 64 + l) * 4 + d], accHL[i][d]);
     __syncthreads();
     // C/D layout of the 16x16 MFMAs: lane = col + 16 * (row >> 2), register = row & 3
-    const int ncol = w2 + 1; // taps + source column
+    constexpr int ncol = w2 + 1; // taps + source column
     for (int e = tid; e < ncol * (ncol + 1) / 2; e += 256) {
         int a = 0, rem = e;
         while (rem >= ncol - a) { rem -= ncol - a; a++; }
@@ -253,8 +265,9 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
         const int tri = ga * NG - ga * (ga - 1) / 2 + (gb - ga);
         const int eab = (cb + 16 * (ra >> 2)) * 4 + (ra & 3), eba = (ca + 16 * (rb >> 2)) * 4 + (rb & 3);
         const long long hh = part[tri * 256 + eab], ll = part[(NTRI + tri) * 256 + eab];
-        const long long hl = part[(2 * NTRI + ga * NG + gb) * 256 + eab], lh = part[(2 * NTRI + gb * NG + ga) * 256 + eba];
-        const long long v  = 16384 * hh + 128 * (hl + lh) + ll;
+        // the cross terms sum_p H_a L_b + L_a H_b: already summed in an off-diagonal tile; entries (a, b) and (b, a) of a diagonal one
+        const long long x = (long long)part[(2 * NTRI + tri) * 256 + eab] + (ga == gb ? (long long)part[(2 * NTRI + tri) * 256 + eba] : 0);
+        const long long v = 16384 * hh + 128 * x + ll;
         unsigned long long* dst = (unsigned long long*)(b == w2 ? &M[a] : &H[a * w2 + b]);
         atomicAdd(dst, (unsigned long long)v);
     }
@@ -295,11 +308,14 @@ void svt_hip_lr_compute_stats_batch(const void* dgd, const void* src, const SvtH
     const dim3 grid((max_rect_width + TC - 1) / TC, (max_rect_height + TR * BANDS - 1) / (TR * BANDS), n);
     if (grid.x && grid.y) {
         if (wiener_win == 7) {
-            const size_t shmem = (size_t)(36 * 256 * 4 > LDS_PLANES ? 36 * 256 * 4 : LDS_PLANES) + 64;
-            hipLaunchKernelGGL(stats_mfma_kernel<4>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, wiener_win, is16, (long long*)M, (long long*)H);
-        } else {
-            const size_t shmem = (size_t)(10 * 256 * 4 > LDS_PLANES ? 10 * 256 * 4 : LDS_PLANES) + 64;
-            hipLaunchKernelGGL(stats_mfma_kernel<2>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, wiener_win, is16, (long long*)M, (long long*)H);
+            const size_t shmem = (size_t)(30 * 256 * 4 > LDS_PLANES ? 30 * 256 * 4 : LDS_PLANES) + 64;
+            hipLaunchKernelGGL(stats_mfma_kernel<7>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, is16, (long long*)M, (long long*)H);
+        } else if (wiener_win == 5) {
+            const size_t shmem = (size_t)(9 * 256 * 4 > LDS_PLANES ? 9 * 256 * 4 : LDS_PLANES) + 64;
+            hipLaunchKernelGGL(stats_mfma_kernel<5>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, is16, (long long*)M, (long long*)H);
+        } else { // WIENER_WIN_3TAP (restoration_pick.c:1289)
+            const size_t shmem = (size_t)(3 * 256 * 4 > LDS_PLANES ? 3 * 256 * 4 : LDS_PLANES) + 64;
+            hipLaunchKernelGGL(stats_mfma_kernel<3>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, is16, (long long*)M, (long long*)H);
         }
         SVT_LAUNCH_CHECK();
     }

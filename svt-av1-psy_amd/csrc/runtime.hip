@@ -125,7 +125,7 @@ static void tuning_read() {
     const char* sf = getenv("SVT_HIP_SAD_FORM");
     g_tune_sad_form = (sf && atoi(sf) == 1) ? 1 : 0;
     const char* m = getenv("SVT_HIP_CDEF_MINB");
-    g_tune_cdef_minb = (m && (atoi(m) == 4 || atoi(m) == 2)) ? atoi(m) : 3;
+    g_tune_cdef_minb = (m && atoi(m) == 2) ? 2 : 3;
 }
 int tuning_lr_rows_per_workgroup() {
     if (g_tune_lr_ur < 0) tuning_read();

@@ -90,6 +90,6 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 int tuning_lr_rows_per_workgroup(); // SVT_HIP_LR_UR: 16 / 32 / 64, default 32
 int tuning_cdef_groups_per_workgroup(); // SVT_HIP_CDEF_GPW: 1 / 2 / 4, 0 = by frame size
 int tuning_sad_form(); // SVT_HIP_SAD_FORM: 0 (default: pair-per-wave forms) / 1 (strip form, measured slower): which independent-pairs SAD kernel runs
-int tuning_cdef_search_minb(); // SVT_HIP_CDEF_MINB: 3 (default) / 4: which register budget of the CDEF search kernel runs (A/B measurement)
+int tuning_cdef_search_minb(); // SVT_HIP_CDEF_MINB: 3 (default) / 2: which register budget of the CDEF search kernel runs (A/B measurement)
 
 } // namespace svthip

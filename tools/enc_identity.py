@@ -90,6 +90,11 @@ CASES = {
     "fps_1080p_p8_me": (1920, 1080, 60, 8, ["--preset", "8", "+seam"]),
     # steady state: 300 frames (the 60-frame clip looped by the application), so that one-time costs (HIP context, session, kernel code loading) amortise
     "fps_1080p_p8_all_300": (1920, 1080, 300, 8, ["--preset", "8", "+clip60", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    # the same clip with the host side limited to a few threads (--lp): where the host is the bottleneck, what do the device stages buy
+    "fps_1080p_p8_all_lp4": (1920, 1080, 60, 8, ["--preset", "8", "--lp", "4", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p8_all_lp8": (1920, 1080, 60, 8, ["--preset", "8", "--lp", "8", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p8_all_lp16": (1920, 1080, 60, 8, ["--preset", "8", "--lp", "16", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p8_metf_300": (1920, 1080, 300, 8, ["--preset", "8", "+clip60", "+seam", "+tfseam", "+tfsubpel"]),
     "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     # the TPL dispenser's source-based half as one device stage per picture (integration/src_ops_process_seam.c): SVT_HIP_TPL_SEAM=1
