@@ -112,7 +112,13 @@ static void search_plane(const Yv12BufferConfig *org_fts, const Yv12BufferConfig
             }
     }
     svt_hip_seam_bind(pcs->picture_number);
-    if (L.search_host(&P, prev, out)) { fprintf(stderr, "SVT_HIP_LR_SEAM: svt_hip_lr_search_plane_host refused the parameters\n"); abort(); }
+    const int rc = L.search_host(&P, prev, out);
+    if (rc) {
+        fprintf(stderr, "SVT_HIP_LR_SEAM: svt_hip_lr_search_plane_host returned %d (picture %llu plane %d %ux%u unit %u win %u bd %u wn %d sg %d ep %u..%u/%u)\n", rc,
+                (unsigned long long)pcs->picture_number, plane, P.width, P.height, P.unit_size, P.wiener_win, P.bit_depth, P.wn_enabled, P.sg_enabled, P.sg_start_ep, P.sg_end_ep,
+                P.sg_ep_inc);
+        abort();
+    }
     RestUnitSearchInfo *rusi = pcs->rusi_picture[plane];
     for (int u = 0; u < n; u++) {
         rusi[u].sse[RESTORE_NONE] = out[u].sse[0];
