@@ -511,6 +511,48 @@ typedef struct SvtHipTfMcDesc {
 } SvtHipTfMcDesc;
 void svt_hip_tf_inter_pred_batch(const SvtHipTfSubpelParams *params, const SvtHipTfMcPlanes *planes, const SvtHipTfMcDesc *descs, uint32_t n, int chroma, void *stream);
 
+/* The temporal filter of ONE central picture as a single device stage: produce_temporally_filtered_pic's per-block loop (temporal_filtering.c:3037-3400) for every
+ * 64x64 block and every reference picture the caller kept (the picture-level skips of :3105-3131 -- ahd error, brightness change -- are the caller's), given the
+ * ME results of each (central, reference) pair:
+ *   1. the sub-pel refinements of every block size the reference may search (tf_64x64_ / tf_32x32_ / tf_16x16_ / tf_8x8_sub_pel_search, :1793-2250), batched;
+ *   2. per (block, reference) the reference's decision tree on those results: 64x64 only when the ME exited early (motion_estimation.c:3110) or
+ *      tf_use_64x64_pred says so (:2676, :3188-3190); else 64x64 when its error beats the four 32x32 (:3263-3270); else per 32x32 block one prediction
+ *      (error below pred_error_32x32_th, :3292) or the 16x16 / 8x8 split of derive_tf_32x32_block_split_flag (:237-286);
+ *   3. the final motion compensation of the chosen blocks (svt_hip_tf_inter_pred_batch) into picture-sized prediction planes;
+ *   4. the 32x32 block errors of the 64x64 predictions (convert_64x64_info_to_32x32_info, :2691-2758);
+ *   5. svt_hip_tf_filter_frame.
+ * Host form: whole padded buffers in, the filtered 64x64 blocks written to out_* (which may be the central picture's own buffers, like the reference's in-place
+ * result).  All pictures share one geometry (sp.ref_org_x / ref_org_y / ref_stride for luma, uv_stride and the halved origin for chroma; 4:2:0).
+ * Returns 0, or -1 for parameters outside what is built (n_refs > SVT_HIP_TF_MAX_REFS, n_refs == 0, not 4:2:0). */
+typedef struct SvtHipTfPictureParams {
+    SvtHipTfSubpelParams sp;  /* sub-pel controls, bit depth, mi_rows / mi_cols, the LUMA padding origin and stride of every picture */
+    SvtHipTfParams       tf;  /* the filter's MeContext fields (frame form: all of them) */
+    uint32_t pic_w_sb, pic_h_sb;      /* 64x64 blocks per row / column: blk_cols, blk_rows (:2823-2826); the ME tables hold pic_w_sb * pic_h_sb entries */
+    uint32_t uv_stride;               /* chroma stride (samples) */
+    uint32_t me_exit_th;              /* tf_ctrls.me_exit_th */
+    uint64_t pred_error_32x32_th;     /* tf_ctrls.pred_error_32x32_th */
+    uint8_t  use_2tap;                /* tf_ctrls.use_2tap: bilinear 64x64 / 32x32 searches */
+    uint8_t  enable_8x8_pred;         /* tf_ctrls.enable_8x8_pred */
+    uint8_t  use_pred_64x64_only_th;  /* tf_ctrls.use_pred_64x64_only_th */
+    uint8_t  pad[5];
+} SvtHipTfPictureParams;
+typedef struct SvtHipTfHostPicture {
+    const void *y, *u, *v;            /* buffer_y / buffer_cb / buffer_cr: the padded planes' first samples */
+    size_t      y_samples, uv_samples;/* samples per plane (luma_size / chroma_size) */
+} SvtHipTfHostPicture;
+typedef struct SvtHipTfMeTables { /* of one (central, reference) pair, [sb] = 64x64 block in raster order; the 85 entries in the ME order (64, 4 x 32, 16 x 16 z-order, 64 x 8 z-order) */
+    const uint32_t *best_sad, *best_mv; /* [n_sb][85]: p_best_sad_* / p_best_mv* ((y << 16) | x, full pel) */
+    const int16_t  *hme_sc;             /* [n_sb][2]: search_results[0][0].hme_sc_x / _y */
+    const uint64_t *hme_sad;            /* [n_sb] */
+} SvtHipTfMeTables;
+typedef struct SvtHipTfPictureStats { /* what the decisions were (sums over blocks and references) */
+    uint32_t blocks_64x64, blocks_32x32, blocks_16x16, blocks_8x8; /* predictions made per size */
+    uint32_t early_exit_blocks;                                     /* (block, reference) pairs whose ME exited early */
+    uint32_t pad[3];
+} SvtHipTfPictureStats;
+int svt_hip_tf_picture_host(const SvtHipTfPictureParams *params, const SvtHipTfHostPicture *central, const SvtHipTfHostPicture *refs, const SvtHipTfMeTables *me,
+                            uint32_t n_refs, void *out_y, void *out_u, void *out_v, SvtHipTfPictureStats *stats /* or NULL */);
+
 /* The whole open-loop ME stage from a HOST picture: upload -> quarter / sixteenth planes (made once per picture on the device, kept in the ring
  * with the full plane) -> HME levels 0-2 -> final search centre + integer_search_b64 geometry + full-pel search -> MeSbResults (+ raw tables on
  * request) -> download, on the submission's own stream like svt_hip_me_session_submit.  svt_hip_me_session_enable_stage sizes the extra

@@ -111,6 +111,7 @@ PROTOTYPES = {
     "svt_hip_tf_subpel_search_batch": (None, [vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svt_hip_tf_inter_pred_batch": (None, [vp, vp, vp, C.c_uint32, C.c_int, vp]),
     "svt_hip_tf_subpel_search_host": (None, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, vp]),
+    "svt_hip_tf_picture_host": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp]),
     "svt_hip_lr_filter_frame_host": (None, [vp]),
     "svt_hip_cdef_apply_host": (None, [vp]),
     "svt_hip_lpf_plane_host": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, C.c_uint32, vp, C.c_uint32]),
@@ -315,6 +316,30 @@ assert C.sizeof(LrSearchParams) == 56
 LrSearchUnit = np.dtype([("sse", "<i8", (3,)), ("vfilter", "<i2", (8,)), ("hfilter", "<i2", (8,)), ("ep", "<i4"), ("xqd", "<i4", (2,)), ("pad", "<i4")])
 LrPrevUnit = np.dtype([("use", "<i4"), ("vfilter", "<i2", (8,)), ("hfilter", "<i2", (8,))])
 assert LrSearchUnit.itemsize == 72 and LrPrevUnit.itemsize == 36
+
+
+class TfPictureParams(C.Structure):
+    """SvtHipTfPictureParams: one central picture of the temporal filter as a device stage (svt_hip_tf_picture_host)."""
+    _fields_ = [("sp", TfSubpelParams), ("tf", TfParams), ("pic_w_sb", C.c_uint32), ("pic_h_sb", C.c_uint32), ("uv_stride", C.c_uint32), ("me_exit_th", C.c_uint32),
+                ("pred_error_32x32_th", C.c_uint64), ("use_2tap", C.c_uint8), ("enable_8x8_pred", C.c_uint8), ("use_pred_64x64_only_th", C.c_uint8), ("pad", C.c_uint8 * 5)]
+
+
+class TfHostPicture(C.Structure):
+    """SvtHipTfHostPicture: whole padded host buffers of one picture."""
+    _fields_ = [("y", vp), ("u", vp), ("v", vp), ("y_samples", C.c_size_t), ("uv_samples", C.c_size_t)]
+
+
+class TfMeTables(C.Structure):
+    """SvtHipTfMeTables: the ME results of one (central, reference) pair."""
+    _fields_ = [("best_sad", vp), ("best_mv", vp), ("hme_sc", vp), ("hme_sad", vp)]
+
+
+class TfPictureStats(C.Structure):
+    _fields_ = [("blocks_64x64", C.c_uint32), ("blocks_32x32", C.c_uint32), ("blocks_16x16", C.c_uint32), ("blocks_8x8", C.c_uint32), ("early_exit_blocks", C.c_uint32),
+                ("pad", C.c_uint32 * 3)]
+
+
+assert C.sizeof(TfPictureParams) == 88 and C.sizeof(TfHostPicture) == 40 and C.sizeof(TfMeTables) == 32 and C.sizeof(TfPictureStats) == 32
 
 
 class TfPlanes(C.Structure):

@@ -1,0 +1,304 @@
+// The temporal filter of one central picture as a device stage (include/svtav1_hip.h: svt_hip_tf_picture_host): the glue between the three batched pieces that
+// already exist -- svt_hip_tf_subpel_search_batch, svt_hip_tf_inter_pred_batch, svt_hip_tf_filter_frame -- i.e. what produce_temporally_filtered_pic
+// (temporal_filtering.c:2782-3400) does per 64x64 block and reference between them: which blocks are searched from which vectors, the 64x64 / 32x32 / 16x16 / 8x8
+// decision tree on the search results, the descriptors of the final motion compensation, the per-32x32 records the filter reads, and the 32x32 errors of a 64x64
+// prediction.  Nothing returns to the host between the steps: the decisions are made by a kernel (one thread per (block, reference)), on device-resident results.
+//
+// Slots of a 64x64 block, everywhere in this file, follow the ME tables' order: 0 = 64x64; 1 + i32; 5 + 4 i32 + i16; 21 + 16 i32 + 4 i16 + i8 (z-order: index bit 0 =
+// right half, bit 1 = lower half at every level) -- tab16x16 / tab8x8 (motion_estimation.h:101-116) and idx_32x32_to_idx_16x16 / _8x8 (temporal_filtering.c:60-80) are
+// the two directions of that order.
+#include "../../include/svtav1_hip.h"
+#include "svt_hip_common.h"
+
+namespace {
+
+constexpr int MC_SLOTS = 64; // motion-compensation descriptors per (block, reference): 1 (64x64) .. 64 (all 8x8); unused ones keep bsize 0
+
+struct PicArgs {
+    SvtHipTfPictureParams P;
+    uint32_t n_refs, n_sb, per_sb;
+    uint64_t pic0;       // samples from a luma buffer's first sample to picture sample (0, 0)
+    uint64_t ref_pitch;  // samples between consecutive references' luma buffers (descriptor offsets are relative to reference 0)
+    uint64_t uv_pitch;   // ... chroma buffers
+    uint64_t pred_y_pitch, pred_uv_pitch; // samples between consecutive references' prediction planes
+    uint32_t pred_y_stride, pred_uv_stride;
+    const uint32_t*           best_sad;   // [n_refs][n_sb][85]
+    const uint32_t*           best_mv;
+    const int16_t*            hme_sc;     // [n_refs][n_sb][2]
+    const unsigned long long* hme_sad;    // [n_refs][n_sb]
+    SvtHipTfSubpelDesc*       sp_descs;   // [n_refs][n_sb][per_sb]
+    SvtHipTfSubpelResult*     sp_res;
+    SvtHipTfMcDesc*           mc_descs;   // [n_refs][n_sb][MC_SLOTS]
+    SvtHipTfBlock*            blocks;     // [n_refs][2 pic_h_sb][2 pic_w_sb]
+    uint8_t*                  path64;     // [n_refs][n_sb]
+    SvtHipTfPictureStats*     stats;
+};
+
+__device__ __forceinline__ void slot_geometry(const int slot, int& bs, int& lx, int& ly) {
+    if (slot == 0) { bs = 64; lx = ly = 0; }
+    else if (slot < 5) { const int i = slot - 1; bs = 32; lx = (i & 1) * 32; ly = (i >> 1) * 32; }
+    else if (slot < 21) { const int z = slot - 5; bs = 16; lx = ((z >> 2) & 1) * 32 + (z & 1) * 16; ly = ((z >> 3) & 1) * 32 + ((z >> 1) & 1) * 16; }
+    else { const int z = slot - 21; bs = 8; lx = ((z >> 4) & 1) * 32 + ((z >> 2) & 1) * 16 + (z & 1) * 8; ly = ((z >> 5) & 1) * 32 + ((z >> 3) & 1) * 16 + ((z >> 1) & 1) * 8; }
+}
+
+// every block the reference may search, with the starting vector its caller would pass (:1866-1870, :1980-1982, :2113-2115, :2232-2234)
+__global__ __launch_bounds__(256) void tf_pic_descs_kernel(const PicArgs A) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, total = A.n_refs * A.n_sb * A.per_sb;
+    if (i >= total) return;
+    const uint32_t pair = i / A.per_sb, slot = i - pair * A.per_sb, ref = pair / A.n_sb, sb = pair - ref * A.n_sb;
+    const uint32_t x0 = (sb % A.P.pic_w_sb) * 64, y0 = (sb / A.P.pic_w_sb) * 64;
+    int bs, lx, ly;
+    slot_geometry((int)slot, bs, lx, ly);
+    // the ME call's early exit leaves no tables: 64x64 only, from the HME centre (motion_estimation.c:3110; temporal_filtering.c:1866-1870)
+    const bool from_sc = slot == 0 && (A.hme_sad[pair] < A.P.me_exit_th || A.P.use_pred_64x64_only_th == 0xff);
+    const uint32_t mv = A.best_mv[(size_t)pair * 85 + slot];
+    SvtHipTfSubpelDesc d;
+    d.src_off    = A.pic0 + (uint64_t)(y0 + ly) * A.P.sp.ref_stride + x0 + lx;
+    d.ref_off    = (uint64_t)ref * A.ref_pitch;
+    d.src_stride = A.P.sp.ref_stride;
+    d.pu_x = (uint16_t)(x0 + lx); d.pu_y = (uint16_t)(y0 + ly);
+    d.bsize = (uint8_t)bs;
+    d.bilinear = (uint8_t)(bs >= 32 ? A.P.use_2tap : 0); // (:1801-1804, :1911-1914; the 16x16 and 8x8 searches always take the regular kernels)
+    d.mv_x = (int16_t)((from_sc ? A.hme_sc[2 * pair] : (int16_t)(mv & 0xffffu)) << 3);
+    d.mv_y = (int16_t)((from_sc ? A.hme_sc[2 * pair + 1] : (int16_t)(mv >> 16)) << 3);
+    d.pad = 0;
+    A.sp_descs[i] = d;
+}
+
+// the decision tree of :3183-3340 for one (block, reference); writes the motion-compensation descriptors and the four 32x32 records of the filter
+__global__ __launch_bounds__(64) void tf_pic_decide_kernel(const PicArgs A) {
+    const uint32_t pair = blockIdx.x * 64 + threadIdx.x;
+    if (pair >= A.n_refs * A.n_sb) return;
+    const uint32_t ref = pair / A.n_sb, sb = pair - ref * A.n_sb, sbx = sb % A.P.pic_w_sb, sby = sb / A.P.pic_w_sb, x0 = sbx * 64, y0 = sby * 64;
+    const SvtHipTfSubpelResult* R  = A.sp_res + (size_t)pair * A.per_sb;
+    const uint32_t*             sd = A.best_sad + (size_t)pair * 85;
+    const bool    exited = A.hme_sad[pair] < A.P.me_exit_th;
+    const uint8_t th     = exited ? (uint8_t)0xff : A.P.use_pred_64x64_only_th;
+    bool p64 = false;
+    if (th) {
+        if (th == 0xff) p64 = true;
+        else { // tf_use_64x64_pred (:2676-2690)
+            uint32_t d32 = 0;
+            for (int i = 0; i < 4; i++) d32 += sd[1 + i];
+            const long long a = (long long)(sd[0] > 1u ? sd[0] : 1u), b = (long long)(d32 > 1u ? d32 : 1u);
+            p64 = (a - b) * 100 / b < (long long)th;
+        }
+    }
+    const unsigned long long e64 = R[0].dist;
+    if (!p64) { // (:3263-3270)
+        const unsigned long long s32 = R[1].dist + R[2].dist + R[3].dist + R[4].dist;
+        p64 = e64 * 14 < s32 * 16 && e64 < (1ull << 18);
+    }
+    A.path64[pair] = p64 ? 1 : 0;
+    SvtHipTfMcDesc* M = A.mc_descs + (size_t)pair * MC_SLOTS; // (zeroed by the host: unused slots keep bsize 0)
+    auto mc = [&](const int k, const int slot, const int16_t mvx, const int16_t mvy) {
+        int bs, lx, ly;
+        slot_geometry(slot, bs, lx, ly);
+        SvtHipTfMcDesc d;
+        d.ref_off[0] = (uint64_t)ref * A.ref_pitch; d.ref_off[1] = d.ref_off[2] = (uint64_t)ref * A.uv_pitch;
+        d.pred_off[0] = (uint64_t)ref * A.pred_y_pitch; d.pred_off[1] = d.pred_off[2] = (uint64_t)ref * A.pred_uv_pitch;
+        d.pu_x = (uint16_t)(x0 + lx); d.pu_y = (uint16_t)(y0 + ly); d.bsize = (uint8_t)bs; d.pad = 0; d.mv_x = mvx; d.mv_y = mvy;
+        d.pad2[0] = d.pad2[1] = d.pad2[2] = 0;
+        M[k] = d;
+    };
+    const uint32_t nbx = 2 * A.P.pic_w_sb, nby = 2 * A.P.pic_h_sb;
+    uint32_t n64 = 0, n32 = 0, n16 = 0, n8 = 0;
+    if (p64) { mc(0, 0, R[0].mv_x, R[0].mv_y); n64 = 1; }
+    for (int i32 = 0; i32 < 4; i32++) {
+        SvtHipTfBlock B;
+        for (int k = 0; k < 4; k++) { B.block_error[k] = 0; B.mv_x[k] = 0; B.mv_y[k] = 0; }
+        B.split = 0;
+        for (int k = 0; k < 7; k++) B.pad[k] = 0;
+        if (p64) { // convert_64x64_info_to_32x32_info (:2691-2758): the 64x64 vector; the error comes from tf_pic_var32_kernel
+            B.mv_x[0] = R[0].mv_x; B.mv_y[0] = R[0].mv_y;
+        } else if (R[1 + i32].dist < A.P.pred_error_32x32_th) { // (:3292-3296)
+            B.block_error[0] = R[1 + i32].dist; B.mv_x[0] = R[1 + i32].mv_x; B.mv_y[0] = R[1 + i32].mv_y;
+            mc(16 * i32, 1 + i32, R[1 + i32].mv_x, R[1 + i32].mv_y); n32++;
+        } else { // derive_tf_32x32_block_split_flag (:237-286), int arithmetic as there
+            int  sum = 0, sub[4];
+            bool split16[4];
+            for (int i = 0; i < 4; i++) {
+                sub[i]     = (int)R[5 + 4 * i32 + i].dist;
+                split16[i] = false;
+                if (A.P.enable_8x8_pred) {
+                    int e8 = 0;
+                    for (int j = 0; j < 4; j++) e8 += (int)R[21 + 16 * i32 + 4 * i + j].dist;
+                    if (!(sub[i] * 8 < e8 * 16)) { split16[i] = true; sub[i] = e8; }
+                }
+                sum += sub[i];
+            }
+            const int  e32   = (int)R[1 + i32].dist;
+            const bool split = !(e32 * 14 < sum * 16);
+            if (!split) {
+                B.block_error[0] = R[1 + i32].dist; B.mv_x[0] = R[1 + i32].mv_x; B.mv_y[0] = R[1 + i32].mv_y;
+                mc(16 * i32, 1 + i32, R[1 + i32].mv_x, R[1 + i32].mv_y); n32++;
+            } else {
+                B.split = 1;
+                for (int i = 0; i < 4; i++) {
+                    const SvtHipTfSubpelResult r16 = R[5 + 4 * i32 + i];
+                    B.block_error[i] = split16[i] ? (unsigned long long)(long long)sub[i] : r16.dist; // (a split 16x16 carries the sum of its 8x8 errors, :262-264)
+                    B.mv_x[i] = r16.mv_x; B.mv_y[i] = r16.mv_y;
+                    if (split16[i]) {
+                        for (int j = 0; j < 4; j++) { const SvtHipTfSubpelResult r8 = R[21 + 16 * i32 + 4 * i + j]; mc(16 * i32 + 4 * i + j, 21 + 16 * i32 + 4 * i + j, r8.mv_x, r8.mv_y); }
+                        n8 += 4;
+                    } else { mc(16 * i32 + 4 * i, 5 + 4 * i32 + i, r16.mv_x, r16.mv_y); n16++; }
+                }
+            }
+        }
+        A.blocks[((size_t)ref * nby + 2 * sby + (i32 >> 1)) * nbx + 2 * sbx + (i32 & 1)] = B;
+    }
+    if (A.stats) {
+        if (n64) atomicAdd(&A.stats->blocks_64x64, n64);
+        if (n32) atomicAdd(&A.stats->blocks_32x32, n32);
+        if (n16) atomicAdd(&A.stats->blocks_16x16, n16);
+        if (n8) atomicAdd(&A.stats->blocks_8x8, n8);
+        if (exited) atomicAdd(&A.stats->early_exit_blocks, 1u);
+    }
+}
+
+// convert_64x64_info_to_32x32_info's block errors (:2718-2756): the variance of the 64x64 prediction against the source per 32x32 block, on every
+// (1 << subsampling_shift)-th row, << subsampling_shift (svt_aom_mefn_ptr[BLOCK_32X32 / 32X16].vf / vf_hbd_10).  One wave per (block, reference, 32x32).
+template <typename PIX>
+__global__ __launch_bounds__(256) void tf_pic_var32_kernel(const PicArgs A, const PIX* __restrict__ central_y, const PIX* __restrict__ pred_y) {
+    const int      l = threadIdx.x & 63;
+    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6), pair = item >> 2, i32 = item & 3;
+    if (pair >= A.n_refs * A.n_sb || !A.path64[pair]) return;
+    const uint32_t ref = pair / A.n_sb, sb = pair - ref * A.n_sb, sbx = sb % A.P.pic_w_sb, sby = sb / A.P.pic_w_sb;
+    const uint32_t x0 = sbx * 64 + (i32 & 1) * 32, y0 = sby * 64 + (i32 >> 1) * 32;
+    const int      ss = A.P.sp.subsampling_shift, rows = 32 >> ss;
+    const PIX*     s  = central_y + A.pic0 + (size_t)y0 * A.P.sp.ref_stride + x0;
+    const PIX*     p  = pred_y + (size_t)ref * A.pred_y_pitch + (size_t)y0 * A.pred_y_stride + x0;
+    int      sum = 0;
+    uint32_t sse = 0;
+    for (int i = l; i < 32 * rows; i += 64) {
+        const int r = (i >> 5) << ss, c = i & 31;
+        const int d = (int)p[(size_t)r * A.pred_y_stride + c] - (int)s[(size_t)r * A.P.sp.ref_stride + c];
+        sum += d;
+        sse += (uint32_t)(d * d); // per lane <= 16 * 1023^2
+    }
+    long long          ts = sum;
+    unsigned long long tq = sse;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        ts += (long long)__shfl_xor((int)ts, m); // |total| <= 1024 * 1023: fits 32 bits
+        const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(tq >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)tq, m);
+        tq += o;
+    }
+    const int ln = 10 - ss; // log2(32 * rows)
+    unsigned long long var;
+    if (sizeof(PIX) == 1) {
+        const int su = (int)ts;
+        var = (uint32_t)((uint32_t)tq - (uint32_t)(((long long)su * su) >> ln)); // svt_aom_varianceWxH_c (variance.c:300-306)
+    } else { // highbd_10_variance (svt_psnr.c:160-177)
+        const uint32_t  s32 = (uint32_t)((tq + 8) >> 4);
+        const int       su  = (int)((ts + 2) >> 2);
+        const long long v   = (long long)s32 - (((long long)su * su) >> ln);
+        var = v >= 0 ? (uint32_t)v : 0;
+    }
+    if (l == 0) {
+        const uint32_t nbx = 2 * A.P.pic_w_sb, nby = 2 * A.P.pic_h_sb;
+        A.blocks[((size_t)ref * nby + 2 * sby + (i32 >> 1)) * nbx + 2 * sbx + (i32 & 1)].block_error[0] = var << ss;
+    }
+}
+
+} // namespace
+
+extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, const SvtHipTfHostPicture* central, const SvtHipTfHostPicture* refs, const SvtHipTfMeTables* me,
+                                       uint32_t n_refs, void* out_y, void* out_u, void* out_v, SvtHipTfPictureStats* stats) {
+    svthip::ensure_device();
+    const SvtHipTfPictureParams& P = *params;
+    if (n_refs == 0 || n_refs > SVT_HIP_TF_MAX_REFS || !P.pic_w_sb || !P.pic_h_sb) return -1;
+    if (P.tf.tf_chroma && (P.tf.ss_x != 1 || P.tf.ss_y != 1)) return -1; // (the final motion compensation is built for 4:2:0)
+    if (P.sp.bit_depth != 8 && P.sp.bit_depth != 10) return -1;
+    const bool   hbd = P.sp.bit_depth > 8, chroma = P.tf.tf_chroma != 0;
+    const size_t px = hbd ? 2 : 1, n_sb = (size_t)P.pic_w_sb * P.pic_h_sb, per_sb = 21 + (P.enable_8x8_pred ? 64 : 0);
+    const size_t ysz = svthip::align_up(central->y_samples * px, 256), csz = svthip::align_up(central->uv_samples * px, 256);
+    const uint32_t pw = 64 * P.pic_w_sb, ph = 64 * P.pic_h_sb;
+    const size_t pysz = svthip::align_up((size_t)pw * ph * px, 256), pcsz = svthip::align_up((size_t)(pw / 2) * (ph / 2) * px, 256);
+    const size_t n_pairs = n_refs * n_sb, n_sp = n_pairs * per_sb, nblk = (size_t)n_refs * 4 * n_sb;
+    const size_t tables = n_pairs * (85 * 4 * 2 + 4 + 8);
+    for (uint32_t r = 0; r < n_refs; r++)
+        if (refs[r].y_samples != central->y_samples || refs[r].uv_samples != central->uv_samples) return -1;
+    const size_t dev = (1 + n_refs) * (ysz + 2 * csz) + n_refs * (pysz + 2 * pcsz) + tables + n_sp * (sizeof(SvtHipTfSubpelDesc) + sizeof(SvtHipTfSubpelResult)) +
+                       n_pairs * (MC_SLOTS * sizeof(SvtHipTfMcDesc) + 1) + nblk * sizeof(SvtHipTfBlock) + 65536;
+    const size_t pin = (2 + n_refs) * (ysz + 2 * csz) + tables + 65536; // uploads + the three downloads
+    svthip::HostCall& c = svthip::host_call();
+    c.begin();
+    c.reserve(dev, pin);
+    // pictures: central, then the references back to back (descriptor offsets are relative to reference 0)
+    uint8_t* d_cy = (uint8_t*)c.dalloc(ysz);
+    uint8_t* d_cu = (uint8_t*)c.dalloc(csz);
+    uint8_t* d_cv = (uint8_t*)c.dalloc(csz);
+    uint8_t* d_ry = (uint8_t*)c.dalloc(ysz * n_refs);
+    uint8_t* d_ru = (uint8_t*)c.dalloc(csz * n_refs);
+    uint8_t* d_rv = (uint8_t*)c.dalloc(csz * n_refs);
+    uint8_t* d_py = (uint8_t*)c.dalloc(pysz * n_refs);
+    uint8_t* d_pu = (uint8_t*)c.dalloc(pcsz * n_refs);
+    uint8_t* d_pv = (uint8_t*)c.dalloc(pcsz * n_refs);
+    c.up(d_cy, central->y, central->y_samples * px);
+    if (chroma) { c.up(d_cu, central->u, central->uv_samples * px); c.up(d_cv, central->v, central->uv_samples * px); }
+    for (uint32_t r = 0; r < n_refs; r++) {
+        c.up(d_ry + r * ysz, refs[r].y, refs[r].y_samples * px);
+        if (chroma) { c.up(d_ru + r * csz, refs[r].u, refs[r].uv_samples * px); c.up(d_rv + r * csz, refs[r].v, refs[r].uv_samples * px); }
+    }
+    PicArgs A;
+    memset(&A, 0, sizeof(A));
+    A.P = P; A.n_refs = n_refs; A.n_sb = (uint32_t)n_sb; A.per_sb = (uint32_t)per_sb;
+    A.pic0 = (uint64_t)P.sp.ref_org_y * P.sp.ref_stride + P.sp.ref_org_x;
+    A.ref_pitch = ysz / px; A.uv_pitch = csz / px; A.pred_y_pitch = pysz / px; A.pred_uv_pitch = pcsz / px; A.pred_y_stride = pw; A.pred_uv_stride = pw / 2;
+    uint32_t* d_sad = (uint32_t*)c.dalloc(n_pairs * 85 * 4);
+    uint32_t* d_mv  = (uint32_t*)c.dalloc(n_pairs * 85 * 4);
+    int16_t*  d_sc  = (int16_t*)c.dalloc(n_pairs * 4);
+    unsigned long long* d_hs = (unsigned long long*)c.dalloc(n_pairs * 8);
+    for (uint32_t r = 0; r < n_refs; r++) {
+        c.up(d_sad + r * n_sb * 85, me[r].best_sad, n_sb * 85 * 4);
+        c.up(d_mv + r * n_sb * 85, me[r].best_mv, n_sb * 85 * 4);
+        c.up(d_sc + r * n_sb * 2, me[r].hme_sc, n_sb * 4);
+        c.up(d_hs + r * n_sb, me[r].hme_sad, n_sb * 8);
+    }
+    A.best_sad = d_sad; A.best_mv = d_mv; A.hme_sc = d_sc; A.hme_sad = d_hs;
+    A.sp_descs = (SvtHipTfSubpelDesc*)c.dalloc(n_sp * sizeof(SvtHipTfSubpelDesc));
+    A.sp_res   = (SvtHipTfSubpelResult*)c.dalloc(n_sp * sizeof(SvtHipTfSubpelResult));
+    A.mc_descs = (SvtHipTfMcDesc*)c.dalloc(n_pairs * MC_SLOTS * sizeof(SvtHipTfMcDesc));
+    A.blocks   = (SvtHipTfBlock*)c.dalloc(nblk * sizeof(SvtHipTfBlock));
+    A.path64   = (uint8_t*)c.dalloc(n_pairs);
+    A.stats    = (SvtHipTfPictureStats*)c.dalloc(sizeof(SvtHipTfPictureStats));
+    hipStream_t st = c.stream;
+    HIP_CHECK(hipMemsetAsync(A.mc_descs, 0, n_pairs * MC_SLOTS * sizeof(SvtHipTfMcDesc), st));
+    HIP_CHECK(hipMemsetAsync(A.stats, 0, sizeof(SvtHipTfPictureStats), st));
+    // 1. sub-pel refinement of every block the reference may search
+    hipLaunchKernelGGL(tf_pic_descs_kernel, dim3((unsigned)((n_sp + 255) / 256)), dim3(256), 0, st, A);
+    SVT_LAUNCH_CHECK();
+    svt_hip_tf_subpel_search_batch(&P.sp, d_cy, d_ry, A.sp_descs, (uint32_t)n_sp, A.sp_res, st);
+    // 2. decisions
+    hipLaunchKernelGGL(tf_pic_decide_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, A);
+    SVT_LAUNCH_CHECK();
+    // 3. final motion compensation into picture-sized planes
+    SvtHipTfMcPlanes PL;
+    memset(&PL, 0, sizeof(PL));
+    PL.ref[0] = d_ry; PL.ref[1] = d_ru; PL.ref[2] = d_rv; PL.pred[0] = d_py; PL.pred[1] = d_pu; PL.pred[2] = d_pv;
+    PL.ref_stride[0] = P.sp.ref_stride; PL.ref_stride[1] = PL.ref_stride[2] = P.uv_stride;
+    PL.pred_stride[0] = pw; PL.pred_stride[1] = PL.pred_stride[2] = pw / 2;
+    svt_hip_tf_inter_pred_batch(&P.sp, &PL, A.mc_descs, (uint32_t)(n_pairs * MC_SLOTS), chroma ? 1 : 0, st);
+    // 4. the 32x32 errors of the 64x64 predictions
+    if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_pic_var32_kernel<uint16_t>), dim3((unsigned)n_pairs), dim3(256), 0, st, A, (const uint16_t*)d_cy, (const uint16_t*)d_py);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_pic_var32_kernel<uint8_t>), dim3((unsigned)n_pairs), dim3(256), 0, st, A, (const uint8_t*)d_cy, (const uint8_t*)d_py);
+    SVT_LAUNCH_CHECK();
+    // 5. the filter, in place on the device copy of the central picture
+    SvtHipTfParams T = P.tf;
+    T.encoder_bit_depth = P.sp.bit_depth;
+    const size_t cpic0 = (size_t)(P.sp.ref_org_y >> 1) * P.uv_stride + (P.sp.ref_org_x >> 1);
+    SvtHipTfPlanes cen = {d_cy + A.pic0 * px, d_cu + cpic0 * px, d_cv + cpic0 * px, P.sp.ref_stride, P.uv_stride};
+    SvtHipTfPlanes preds[SVT_HIP_TF_MAX_REFS];
+    for (uint32_t r = 0; r < n_refs; r++) preds[r] = SvtHipTfPlanes{d_py + r * pysz, d_pu + r * pcsz, d_pv + r * pcsz, pw, pw / 2};
+    svt_hip_tf_filter_frame(&T, &cen, preds, n_refs, A.blocks, 2 * P.pic_w_sb, 2 * P.pic_h_sb, &cen, st);
+    // the filtered blocks (every 64x64 block in full, as get_final_filtered_pixels writes them, :2608-2672)
+    c.down2d((uint8_t*)out_y + A.pic0 * px, (size_t)P.sp.ref_stride * px, cen.y, (size_t)P.sp.ref_stride * px, (size_t)pw * px, ph);
+    if (chroma) {
+        c.down2d((uint8_t*)out_u + cpic0 * px, (size_t)P.uv_stride * px, cen.u, (size_t)P.uv_stride * px, (size_t)(pw / 2) * px, ph / 2);
+        c.down2d((uint8_t*)out_v + cpic0 * px, (size_t)P.uv_stride * px, cen.v, (size_t)P.uv_stride * px, (size_t)(pw / 2) * px, ph / 2);
+    }
+    if (stats) c.down(stats, A.stats, sizeof(SvtHipTfPictureStats));
+    c.sync();
+    return 0;
+}

@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256) void tf_mc_kernel(const SvtHipTfSubpelParams P
     if (blk >= n || (pl && !chroma)) return;
     uint32_t*            im = smem + wv * kSlice;
     const SvtHipTfMcDesc d  = descs[blk];
+    if (d.bsize == 0) return; // an unused slot of a fixed-size descriptor table (tf_picture.hip)
     const int ss = pl > 0, W = d.bsize >> ss, bmi = d.bsize >> 2, bd = sizeof(PIX) == 2 ? P.bit_depth : 8, mx = (1 << bd) - 1;
     const int mirow = d.pu_y >> 2, micol = d.pu_x >> 2; // (the MacroBlockD edges are the luma block's, :2318-2324)
     const int to_top = -((mirow * 4) * 8), to_bottom = (((int)P.mi_rows - bmi - mirow) * 4) * 8, to_left = -((micol * 4) * 8), to_right = (((int)P.mi_cols - bmi - micol) * 4) * 8;
