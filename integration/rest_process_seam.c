@@ -90,7 +90,8 @@ static void search_plane(const Yv12BufferConfig *org_fts, const Yv12BufferConfig
     P.wiener_win = (uint8_t)(plane == AOM_PLANE_Y ? wn_luma : (wn_luma < WIENER_WIN_CHROMA ? wn_luma : WIENER_WIN_CHROMA));
     P.wn_use_refinement = wn->use_refinement; P.wn_max_one_refinement_step = wn->max_one_refinement_step;
     P.sg_enabled = sg->enabled && (!plane || sg->use_chroma);
-    if (sg->step_range < 16) { /* the reference-frame based range of search_selfguided_restoration (:560-572) */
+    if (!P.sg_enabled) { /* (the controls of a disabled tool are not initialised by the reference: whatever the structure held) */
+    } else if (sg->step_range < 16) { /* the reference-frame based range of search_selfguided_restoration (:560-572) */
         const int8_t *e = cm->sg_ref_frame_ep, step = sg->step_range;
         const int     none = e[0] < 0 && e[1] < 0, mid = none ? 0 : (e[1] < 0 ? e[0] : (e[0] < 0 ? e[1] : (e[0] + e[1]) / 2));
         P.sg_start_ep = (uint8_t)(none ? 0 : AOMMAX(0, mid - step)); P.sg_end_ep = (uint8_t)(none ? SGRPROJ_PARAMS : AOMMIN(SGRPROJ_PARAMS, mid + step));

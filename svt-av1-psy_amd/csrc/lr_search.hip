@@ -664,7 +664,7 @@ size_t svt_hip_lr_search_workspace(const SvtHipLrSearchParams* params) { return 
 int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPrevUnit* prev, SvtHipLrSearchUnit* units, void* workspace, void* stream) {
     svthip::ensure_device();
     const SvtHipLrSearchParams& P = *params;
-    if (!P.width || !P.height || !P.unit_size || (P.wn_enabled && P.wiener_win != 7 && P.wiener_win != 5 && P.wiener_win != 3) || P.sg_end_ep > 16) return -1;
+    if (!P.width || !P.height || !P.unit_size || (P.wn_enabled && P.wiener_win != 7 && P.wiener_win != 5 && P.wiener_win != 3) || (P.sg_enabled && P.sg_end_ep > 16)) return -1;
     hipStream_t st = (hipStream_t)stream;
     Ws          W;
     carve(P, workspace, &W);
