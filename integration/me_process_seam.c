@@ -556,6 +556,39 @@ EbErrorType svt_hip_seam_tf_motion_estimation_b64(PictureParentControlSet *pcs, 
 }
 
 
+/* The whole (central, reference) pair for the temporal filter's driver seam (integration/temporal_filtering_seam.c, SVT_HIP_TF_SEAM): runs the pair's ME stage
+ * like the first block's svt_hip_seam_tf_motion_estimation_b64 would (c = the MeContext set up as produce_temporally_filtered_pic does before its ME call,
+ * temporal_filtering.c:3140-3177) and hands out all four tables.  1 = tables filled; 0 = the seam is off or the pair is outside the stage (the caller then
+ * leaves the picture to the reference). */
+int svt_hip_seam_tf_pair_run(PictureParentControlSet *pcs, MeContext *c, uint32_t n_sb, uint32_t *best_sad, uint32_t *best_mv, int16_t *hme_sc, uint64_t *hme_sad) {
+    if (tf_mode < 0) { const char *e = getenv("SVT_HIP_TF_ME_SEAM"); tf_mode = e && atoi(e); }
+    if (!tf_mode || !seam_on() || c->me_type != ME_MCTF || n_sb != pcs->b64_total_count) return 0;
+    static SeamTfPair      mine[TF_RECS]; /* scratch records of this entry point: one per thread that may be inside it */
+    static pthread_mutex_t mlock = PTHREAD_MUTEX_INITIALIZER;
+    SeamTfPair *T = NULL;
+    pthread_mutex_lock(&mlock);
+    for (int i = 0; i < TF_RECS && !T; i++)
+        if (!mine[i].state) { T = &mine[i]; T->state = 1; }
+    pthread_mutex_unlock(&mlock);
+    if (!T) return 0;
+    const double t0 = seam_now();
+    const int rc = run_tf_pair(T, pcs, c);
+    const double dt = seam_now() - t0;
+    pthread_mutex_lock(&G.lock);
+    G.t_stage += dt;
+    if (G.n_pictures + G.n_declined + tf_pairs + tf_declined == 0) G.t_first = dt;
+    if (rc) tf_declined++; else { tf_pairs++; tf_sb += n_sb; }
+    pthread_mutex_unlock(&G.lock);
+    if (!rc) {
+        memcpy(best_sad, T->best_sad, (size_t)n_sb * 85 * 4); memcpy(best_mv, T->best_mv, (size_t)n_sb * 85 * 4);
+        memcpy(hme_sc, T->hme_sc, (size_t)n_sb * 2 * sizeof(int16_t)); memcpy(hme_sad, T->hme_sad, (size_t)n_sb * 8);
+    }
+    pthread_mutex_lock(&mlock);
+    T->state = 0;
+    pthread_mutex_unlock(&mlock);
+    return !rc;
+}
+
 /* the pair's whole-picture tables for the sub-pel seam (integration/temporal_filtering_seam.c); copied out under the lock.  best_mv: [n_sb][85], hme_sc: [n_sb][2],
  * hme_sad: [n_sb].  0 when the pair did not go through the stage. */
 int svt_hip_seam_tf_pair_tables(PictureParentControlSet *pcs, uint64_t ref_number, uint32_t n_sb, uint32_t *best_mv, int16_t *hme_sc, uint64_t *hme_sad) {

@@ -15,6 +15,15 @@
  *    starting vector, not on the 64 / 32 / 16 decisions the reference takes between the searches, which stay the reference's own code.  Every lookup checks
  *    the caller's starting vector and interpolation filter against what the batch assumed and runs the reference's function when they differ (or when the
  *    pair is outside what the batch covers: the high-bit-depth path, a pair that did not go through the ME stage).
+ *
+ * 3. produce_temporally_filtered_pic(...) -- `static`, defined at :2782, called once from svt_av1_init_temporal_filtering (:4244), per segment of the central
+ *    picture.  Same __COUNTER__ renaming (definition = _use5, the call = _use6 = seam_produce_temporally_filtered_pic() below).  With SVT_HIP_TF_SEAM=1 (on top of
+ *    the ME seams) the first segment of a central picture to arrive runs the WHOLE picture as one device stage -- svt_hip_tf_picture_host: sub-pel refinement, the
+ *    64x64 / 32x32 / 16x16 / 8x8 decisions, final motion compensation, filter -- and the picture's other segments return once it is done.  What stays the
+ *    reference's own code: the picture-level decisions (which frames are skipped, :3105-3131), the decay factors (the function's preamble, :2870-3035, executed by
+ *    calling the reference's function over an EMPTY block range: SEGMENT_END_IDX is redefined below to collapse the range while a thread-local flag is set), the
+ *    set-up of the ME context (:3140-3177).  Outside what the stage covers (high bit depth, more than SVT_HIP_TF_MAX_REFS frames, a pair the ME stage declined)
+ *    every segment runs the reference's function as before.
  */
 #define _GNU_SOURCE /* RTLD_DEFAULT */
 #include <dlfcn.h>
@@ -28,6 +37,12 @@
 #include "pcs.h"
 #include "temporal_filtering.h"
 #include "svtav1_hip.h" /* include/svtav1_hip.h of this repository: the C ABI */
+
+/* seam 3: the block range of a segment collapses while this thread asks the reference's function for its preamble only */
+static __thread int seam_tf_preamble_only;
+#undef SEGMENT_END_IDX
+#define SEGMENT_END_IDX(index, pic_size_in_sb, num_of_seg) \
+    (seam_tf_preamble_only ? SEGMENT_START_IDX(index, pic_size_in_sb, num_of_seg) : ((((index) + 1) * (pic_size_in_sb)) / (num_of_seg))) /* av1_common.h:30 */
 
 EbErrorType svt_hip_seam_tf_motion_estimation_b64(PictureParentControlSet *pcs, uint32_t b64_index, uint32_t b64_origin_x, uint32_t b64_origin_y, MeContext *me_ctx,
                                                   EbPictureBufferDesc *input_ptr);
@@ -49,9 +64,18 @@ static void tf_subpel_search_use4(TF_SUBPEL_ARGS) { seam_tf_subpel_search(TF_SUB
 #define SEAM_CAT_(a, b) a##b
 #define SEAM_CAT(a, b) SEAM_CAT_(a, b)
 #define tf_subpel_search(...) SEAM_CAT(tf_subpel_search_use, __COUNTER__)(__VA_ARGS__)
+#define TF_PIC_ARGS                                                                                                                                  \
+    PictureParentControlSet **pcs_list, EbPictureBufferDesc **list_input_picture_ptr, uint8_t index_center, MotionEstimationContext_t *me_context_ptr, \
+        const int32_t *noise_levels_log1p_fp16, int32_t segment_index, bool is_highbd
+#define TF_PIC_PASS pcs_list, list_input_picture_ptr, index_center, me_context_ptr, noise_levels_log1p_fp16, segment_index, is_highbd
+static EbErrorType produce_temporally_filtered_pic_use5(TF_PIC_ARGS); /* the reference's function (defined by the #include) */
+static EbErrorType seam_produce_temporally_filtered_pic(TF_PIC_ARGS);
+static EbErrorType produce_temporally_filtered_pic_use6(TF_PIC_ARGS) { return seam_produce_temporally_filtered_pic(TF_PIC_PASS); }
+#define produce_temporally_filtered_pic(...) SEAM_CAT(produce_temporally_filtered_pic_use, __COUNTER__)(__VA_ARGS__)
 #define svt_aom_motion_estimation_b64(pcs, i, x, y, ctx, pic) svt_hip_seam_tf_motion_estimation_b64(pcs, i, x, y, ctx, pic)
 #include "temporal_filtering.c" /* resolves through -I$(REF)/Source/Lib/Codec */
 #undef tf_subpel_search
+#undef produce_temporally_filtered_pic
 #undef svt_aom_motion_estimation_b64
 
 /* ---- the sub-pel seam (after the #include: the block-numbering tables of temporal_filtering.c:44-90 are in scope) ---- */
@@ -205,4 +229,185 @@ static void seam_tf_subpel_search(TF_SUBPEL_ARGS) {
     if (served) SPS.n_served++; else SPS.n_fallback++;
     pthread_mutex_unlock(&SPS.lock);
     if (!served) tf_subpel_search_use0(TF_SUBPEL_PASS);
+}
+
+
+/* ---- seam 3: one central picture = one device stage ------------------------------------------------------------------------------------------------------------ */
+int svt_hip_seam_tf_pair_run(PictureParentControlSet *pcs, MeContext *c, uint32_t n_sb, uint32_t *best_sad, uint32_t *best_mv, int16_t *hme_sc, uint64_t *hme_sad);
+enum { TFD_RECS = 16 };
+typedef struct TfPicRec {
+    PictureParentControlSet *pcs;
+    uint64_t                 picture_number;
+    int                      state; /* 0 free, 1 running, 2 done on the device, 3 left to the reference */
+    uint32_t                 seen;  /* segments that passed through */
+} TfPicRec;
+static struct {
+    pthread_mutex_t lock;
+    pthread_cond_t  ready;
+    int             mode; /* -1 unknown */
+    int (*picture_host)(const SvtHipTfPictureParams *, const SvtHipTfHostPicture *, const SvtHipTfHostPicture *, const SvtHipTfMeTables *, uint32_t, void *, void *, void *,
+                        SvtHipTfPictureStats *);
+    TfPicRec    rec[TFD_RECS];
+    uint64_t    n_pictures, n_declined, n_refs, n64, n32, n16, n8, n_exit;
+    const char *last_decline;
+} TFD = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, -1};
+
+static void tfd_stats(void) {
+    const char *f = getenv("SVT_HIP_TF_SEAM_STATS");
+    FILE       *o = f ? fopen(f, "w") : NULL;
+    if (!o) return;
+    fprintf(o, "pictures_filtered %llu\npictures_declined %llu\nreference_frames %llu\npred_64x64 %llu\npred_32x32 %llu\npred_16x16 %llu\npred_8x8 %llu\nearly_exit_blocks %llu\nlast_decline %s\n",
+            (unsigned long long)TFD.n_pictures, (unsigned long long)TFD.n_declined, (unsigned long long)TFD.n_refs, (unsigned long long)TFD.n64, (unsigned long long)TFD.n32,
+            (unsigned long long)TFD.n16, (unsigned long long)TFD.n8, (unsigned long long)TFD.n_exit, TFD.last_decline ? TFD.last_decline : "-");
+    fclose(o);
+}
+static int tfd_on(void) {
+    if (TFD.mode < 0) {
+        pthread_mutex_lock(&TFD.lock);
+        if (TFD.mode < 0) {
+            const char *e = getenv("SVT_HIP_TF_SEAM");
+            int         m = e && atoi(e) && getenv("SVT_HIP") && getenv("SVT_HIP_TF_ME_SEAM");
+            if (m) {
+                *(void **)&TFD.picture_host = dlsym(RTLD_DEFAULT, "svt_hip_tf_picture_host");
+                if (!TFD.picture_host) { fprintf(stderr, "SVT_HIP_TF_SEAM: libsvtav1_hip is not loaded\n"); abort(); }
+                atexit(tfd_stats);
+                fprintf(stderr, "SVT_HIP_TF_SEAM: the temporal filter of a central picture runs as one device stage\n");
+            }
+            TFD.mode = m;
+        }
+        pthread_mutex_unlock(&TFD.lock);
+    }
+    return TFD.mode;
+}
+static int tfd_decline(const char *why) { TFD.last_decline = why; return -1; }
+
+/* the whole picture on the device; 0 = the central picture's buffers hold the filtered blocks */
+static int tfd_run_picture(TF_PIC_ARGS) {
+    PictureParentControlSet *centre_pcs = pcs_list[index_center];
+    SequenceControlSet      *scs        = centre_pcs->scs;
+    EbPictureBufferDesc     *cen        = list_input_picture_ptr[index_center];
+    MeContext               *ctx        = me_context_ptr->me_ctx;
+    const uint32_t ss_x = scs->subsampling_x, ss_y = scs->subsampling_y;
+    if (is_highbd) return tfd_decline("high bit depth");
+    if (ss_x != 1 || ss_y != 1) return tfd_decline("not 4:2:0");
+    const uint32_t blk_cols = (uint32_t)(cen->width + BW - 1) / BW, blk_rows = (uint32_t)(cen->height + BH - 1) / BH, n_sb = blk_cols * blk_rows; /* :2823-2826 */
+    if (n_sb != centre_pcs->b64_total_count) return tfd_decline("block grid");
+    /* the frames the reference would use, in its order (:3086-3131) */
+    int       used[ALTREF_MAX_NFRAMES], n_used = 0;
+    const int start_frame_index[3] = {0, centre_pcs->past_altref_nframes, centre_pcs->past_altref_nframes + 1};
+    const int end_frame_index[3]   = {centre_pcs->past_altref_nframes - 1, centre_pcs->past_altref_nframes, centre_pcs->past_altref_nframes + centre_pcs->future_altref_nframes};
+    for (int segment_idx = 0; segment_idx < 3; segment_idx++)
+        for (int frame_index = start_frame_index[segment_idx]; frame_index <= end_frame_index[segment_idx]; frame_index = frame_index + ctx->tf_ctrls.ref_frame_factor) {
+            if (frame_index == index_center) continue;
+            const uint32_t low_ahd_err = centre_pcs->aligned_width * centre_pcs->aligned_height;
+            const uint8_t  th          = (centre_pcs->slice_type == I_SLICE) ? 20 : 40;
+            if (pcs_list[frame_index]->tf_ahd_error_to_central > low_ahd_err &&
+                ((int)(((int)pcs_list[frame_index]->tf_ahd_error_to_central - (int)centre_pcs->tf_avg_ahd_error) * 100)) > (th * (int)centre_pcs->tf_avg_ahd_error))
+                continue;
+            uint32_t bright_change_region_cnt = 0;
+            for (uint32_t rw = 0; rw < scs->picture_analysis_number_of_regions_per_width; rw++)
+                for (uint32_t rh = 0; rh < scs->picture_analysis_number_of_regions_per_height; rh++)
+                    if (ABS((int)pcs_list[frame_index]->average_intensity_per_region[rw][rh] - (int)centre_pcs->average_intensity_per_region[rw][rh]) > 2 &&
+                        pcs_list[frame_index]->avg_luma != centre_pcs->tf_avg_luma)
+                        bright_change_region_cnt++;
+            if (bright_change_region_cnt >= ((14 * scs->picture_analysis_number_of_regions_per_width * scs->picture_analysis_number_of_regions_per_height) / 16)) continue;
+            used[n_used++] = frame_index;
+        }
+    if (n_used == 0) return tfd_decline("no reference frame left"); /* (the reference then writes the central picture back unchanged: its own code does that) */
+    if (n_used > SVT_HIP_TF_MAX_REFS) return tfd_decline("more frames than SVT_HIP_TF_MAX_REFS");
+    for (int i = 0; i < n_used; i++) {
+        const EbPictureBufferDesc *r = list_input_picture_ptr[used[i]];
+        if (r->stride_y != cen->stride_y || r->stride_cb != cen->stride_cb || r->org_x != cen->org_x || r->org_y != cen->org_y || r->luma_size != cen->luma_size ||
+            r->chroma_size != cen->chroma_size)
+            return tfd_decline("frame geometry");
+    }
+    /* the preamble of the reference's function -- decay factors into ctx (:2870-3035) -- over an empty block range */
+    seam_tf_preamble_only = 1;
+    produce_temporally_filtered_pic_use5(TF_PIC_PASS);
+    seam_tf_preamble_only = 0;
+    /* the ME stage of every pair, context as the reference sets it up (:3140-3177) */
+    uint32_t *best_sad = malloc((size_t)n_used * n_sb * 85 * 4), *best_mv = malloc((size_t)n_used * n_sb * 85 * 4);
+    int16_t  *hme_sc   = malloc((size_t)n_used * n_sb * 2 * sizeof(int16_t));
+    uint64_t *hme_sad  = malloc((size_t)n_used * n_sb * 8);
+    int       rc       = 0;
+    SvtHipTfMeTables    me[SVT_HIP_TF_MAX_REFS];
+    SvtHipTfHostPicture refs[SVT_HIP_TF_MAX_REFS];
+    for (int i = 0; i < n_used && !rc; i++) {
+        const int frame_index = used[i];
+        ctx->tf_frame_index = frame_index; ctx->tf_index_center = index_center;
+        create_me_context_and_picture_control(me_context_ptr, pcs_list[frame_index], centre_pcs, cen, 0, 0, ss_x, ss_y);
+        ctx->num_of_list_to_search = 1; ctx->num_of_ref_pic_to_search[0] = 1; ctx->num_of_ref_pic_to_search[1] = 0;
+        ctx->temporal_layer_index = centre_pcs->temporal_layer_index; ctx->is_ref = centre_pcs->is_ref;
+        EbPaReferenceObject *ref_object = (EbPaReferenceObject *)ctx->alt_ref_reference_ptr;
+        ctx->me_ds_ref_array[0][0].picture_ptr = ref_object->input_padded_pic;
+        ctx->me_ds_ref_array[0][0].sixteenth_picture_ptr = ref_object->sixteenth_downsampled_picture_ptr;
+        ctx->me_ds_ref_array[0][0].quarter_picture_ptr = ref_object->quarter_downsampled_picture_ptr;
+        ctx->me_ds_ref_array[0][0].picture_number = ref_object->picture_number;
+        ctx->tf_me_exit_th = centre_pcs->tf_ctrls.me_exit_th; ctx->tf_use_pred_64x64_only_th = centre_pcs->tf_ctrls.use_pred_64x64_only_th;
+        ctx->tf_subpel_early_exit_th = centre_pcs->tf_ctrls.subpel_early_exit_th;
+        set_hme_search_params_mctf(ctx, 0);
+        me[i].best_sad = best_sad + (size_t)i * n_sb * 85; me[i].best_mv = best_mv + (size_t)i * n_sb * 85; me[i].hme_sc = hme_sc + (size_t)i * n_sb * 2; me[i].hme_sad = hme_sad + (size_t)i * n_sb;
+        if (!svt_hip_seam_tf_pair_run(centre_pcs, ctx, n_sb, (uint32_t *)me[i].best_sad, (uint32_t *)me[i].best_mv, (int16_t *)me[i].hme_sc, (uint64_t *)me[i].hme_sad))
+            rc = tfd_decline("a pair outside the ME stage");
+        const EbPictureBufferDesc *r = list_input_picture_ptr[frame_index];
+        refs[i].y = r->buffer_y; refs[i].u = r->buffer_cb; refs[i].v = r->buffer_cr; refs[i].y_samples = r->luma_size; refs[i].uv_samples = r->chroma_size;
+    }
+    if (!rc) {
+        SvtHipTfPictureParams P;
+        memset(&P, 0, sizeof(P));
+        P.sp.half_pel_mode = centre_pcs->tf_ctrls.half_pel_mode; P.sp.quarter_pel_mode = centre_pcs->tf_ctrls.quarter_pel_mode; P.sp.eight_pel_mode = centre_pcs->tf_ctrls.eight_pel_mode;
+        P.sp.subsampling_shift = centre_pcs->tf_ctrls.sub_sampling_shift; P.sp.bit_depth = 8; P.sp.early_exit_th = centre_pcs->tf_ctrls.subpel_early_exit_th;
+        P.sp.mi_rows = (uint32_t)centre_pcs->av1_cm->mi_rows; P.sp.mi_cols = (uint32_t)centre_pcs->av1_cm->mi_cols;
+        P.sp.ref_org_x = cen->org_x; P.sp.ref_org_y = cen->org_y; P.sp.ref_stride = cen->stride_y;
+        for (int k = 0; k < 3; k++) P.tf.tf_decay_factor_fp16[k] = ctx->tf_decay_factor_fp16[k];
+        P.tf.tf_mv_dist_th = ctx->tf_mv_dist_th; P.tf.tf_chroma = ctx->tf_chroma; P.tf.use_zz_based_filter = ctx->tf_ctrls.use_zz_based_filter;
+        P.tf.encoder_bit_depth = 8; P.tf.ss_x = (uint8_t)ss_x; P.tf.ss_y = (uint8_t)ss_y;
+        P.pic_w_sb = blk_cols; P.pic_h_sb = blk_rows; P.uv_stride = cen->stride_cb;
+        P.me_exit_th = centre_pcs->tf_ctrls.me_exit_th; P.pred_error_32x32_th = centre_pcs->tf_ctrls.pred_error_32x32_th;
+        P.use_2tap = centre_pcs->tf_ctrls.use_2tap; P.enable_8x8_pred = centre_pcs->tf_ctrls.enable_8x8_pred; P.use_pred_64x64_only_th = centre_pcs->tf_ctrls.use_pred_64x64_only_th;
+        SvtHipTfHostPicture  C = {cen->buffer_y, cen->buffer_cb, cen->buffer_cr, cen->luma_size, cen->chroma_size};
+        SvtHipTfPictureStats st;
+        memset(&st, 0, sizeof(st));
+        svt_hip_seam_bind(centre_pcs->picture_number);
+        if (TFD.picture_host(&P, &C, refs, me, (uint32_t)n_used, cen->buffer_y, cen->buffer_cb, cen->buffer_cr, &st)) rc = tfd_decline("svt_hip_tf_picture_host refused the parameters");
+        else {
+            /* the horizontal / vertical vote of the ME calls (motion_estimation.c:2469-2474): one per (block, frame), summed into the picture by the caller (:4255-4258) */
+            for (size_t k = 0; k < (size_t)n_used * n_sb; k++) {
+                if (ABS(hme_sc[2 * k]) > ABS(hme_sc[2 * k + 1])) ctx->tf_tot_horz_blks++;
+                else ctx->tf_tot_vert_blks++;
+            }
+            pthread_mutex_lock(&TFD.lock);
+            TFD.n_refs += (uint64_t)n_used; TFD.n64 += st.blocks_64x64; TFD.n32 += st.blocks_32x32; TFD.n16 += st.blocks_16x16; TFD.n8 += st.blocks_8x8; TFD.n_exit += st.early_exit_blocks;
+            pthread_mutex_unlock(&TFD.lock);
+        }
+    }
+    free(best_sad); free(best_mv); free(hme_sc); free(hme_sad);
+    return rc;
+}
+
+static EbErrorType seam_produce_temporally_filtered_pic(TF_PIC_ARGS) {
+    if (!tfd_on()) return produce_temporally_filtered_pic_use5(TF_PIC_PASS);
+    PictureParentControlSet *centre_pcs = pcs_list[index_center];
+    pthread_mutex_lock(&TFD.lock);
+    TfPicRec *R = NULL, *spare = NULL;
+    for (int i = 0; i < TFD_RECS; i++) {
+        if (TFD.rec[i].state && TFD.rec[i].pcs == centre_pcs && TFD.rec[i].picture_number == centre_pcs->picture_number) { R = &TFD.rec[i]; break; }
+        if (!TFD.rec[i].state && !spare) spare = &TFD.rec[i];
+    }
+    if (!R) {
+        if (!spare) { fprintf(stderr, "SVT_HIP_TF_SEAM: more than %d central pictures in flight\n", TFD_RECS); abort(); }
+        R = spare;
+        R->pcs = centre_pcs; R->picture_number = centre_pcs->picture_number; R->seen = 0; R->state = 1;
+        pthread_mutex_unlock(&TFD.lock);
+        const int rc = tfd_run_picture(TF_PIC_PASS); /* this segment's thread runs the picture; the others wait below */
+        pthread_mutex_lock(&TFD.lock);
+        R->state = rc ? 3 : 2;
+        if (rc) TFD.n_declined++; else TFD.n_pictures++;
+        pthread_cond_broadcast(&TFD.ready);
+    }
+    while (R->state == 1) pthread_cond_wait(&TFD.ready, &TFD.lock);
+    const int declined = R->state == 3;
+    if (++R->seen == centre_pcs->tf_segments_total_count) R->state = 0;
+    pthread_mutex_unlock(&TFD.lock);
+    return declined ? produce_temporally_filtered_pic_use5(TF_PIC_PASS) : EB_ErrorNone;
 }

@@ -68,8 +68,8 @@ CASES = {
     "dlfseam_sb_p8_8bit_lp4": (448, 264, 12, 8, ["--preset", "8", "--lp", "4", "+dlfseam"]),
     "dlfseam_sb_p10_10bit": (256, 144, 10, 10, ["--preset", "10", "--lp", "1", "+dlfseam"]),
     "dlfseam_sb_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+dlfseam"]),
-    "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+tfsubpel", "+dlfseam", "+cdefseam", "+lrseam", "+tplseam"]),
-    "everyseam_4k10_p8_lp1": (3840, 2160, 6, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),  # config-5 format, single-threaded (reproducible)
+    "everyseam_p4_8bit_lp2": (448, 264, 8, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+dlfseam", "+cdefseam", "+lrseam", "+tplseam"]),
+    "everyseam_4k10_p8_lp1": (3840, 2160, 6, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),  # config-5 format, single-threaded (reproducible)
     # the temporal filter's ME (ME_MCTF form of the stage, one call per (central picture, reference picture) pair): SVT_HIP_TF_ME_SEAM=1 on top of the ME seam
     "tfseam_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tfseam_p4_10bit": (256, 144, 8, 10, ["--preset", "4", "--lp", "1", "+seam", "+tfseam"]),
@@ -78,25 +78,33 @@ CASES = {
     "tfsubpel_p8_8bit": (448, 264, 10, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
     "tfsubpel_p4_8bit": (256, 144, 8, 8, ["--preset", "4", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
     "tfsubpel_p6_8bit_lp4": (448, 264, 10, 8, ["--preset", "6", "--lp", "4", "+seam", "+tfseam", "+tfsubpel"]),
+    # the temporal filter of a central picture as ONE device stage (sub-pel refinement, block-size decisions, final motion compensation, filter): SVT_HIP_TF_SEAM=1
+    "tfdriver_p8_8bit": (448, 264, 20, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
+    "tfdriver_p4_8bit": (256, 144, 18, 8, ["--preset", "4", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
+    "tfdriver_p6_8bit_lp4": (448, 264, 20, 8, ["--preset", "6", "--lp", "4", "+seam", "+tfseam", "+tfdriver"]),
+    "tfdriver_p2_8bit": (256, 144, 10, 8, ["--preset", "2", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
+    "tfdriver_p10_8bit": (448, 264, 20, 8, ["--preset", "10", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
+    "tfdriver_1080p_p8": (1920, 1080, 20, 8, ["--preset", "8", "+seam", "+tfseam", "+tfdriver"]),
+    "tfdriver_p8_10bit": (256, 144, 18, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),  # high bit depth: left to the reference, bitstream unchanged
     "tfsubpel_p2_10bit": (256, 144, 6, 10, ["--preset", "2", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),  # high bit depth: the seam hands those searches to the reference
     "lrseam_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+lrseam"]),  # 1080p: tens of restoration units per plane, all host cores
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
     # BASELINE.json metric, second half: encoder fps @1080p preset 8 (C-only reference vs the same encoder with the ME stage on the MI355X), all host cores
     "fps_1080p_p8": (1920, 1080, 24, 8, ["--preset", "8", "+seam"]),
-    "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     # 3840x2160 10-bit, preset 8, 60 frames (10-bit preset 8 is where the multi-threaded C-only reference was seen not to reproduce its own
     # bitstream; run_case reports `reference_deterministic` and the identity verdict next to the two speeds)
-    "fps_4k10_p8_all": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_4k10_p8_all": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "fps_1080p_p8_me": (1920, 1080, 60, 8, ["--preset", "8", "+seam"]),
     # steady state: 300 frames (the 60-frame clip looped by the application), so that one-time costs (HIP context, session, kernel code loading) amortise
-    "fps_1080p_p8_all_300": (1920, 1080, 300, 8, ["--preset", "8", "+clip60", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p8_all_300": (1920, 1080, 300, 8, ["--preset", "8", "+clip60", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     # the same clip with the host side limited to a few threads (--lp): where the host is the bottleneck, what do the device stages buy
-    "fps_1080p_p8_all_lp4": (1920, 1080, 60, 8, ["--preset", "8", "--lp", "4", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
-    "fps_1080p_p8_all_lp8": (1920, 1080, 60, 8, ["--preset", "8", "--lp", "8", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
-    "fps_1080p_p8_all_lp16": (1920, 1080, 60, 8, ["--preset", "8", "--lp", "16", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
-    "fps_1080p_p8_metf_300": (1920, 1080, 300, 8, ["--preset", "8", "+clip60", "+seam", "+tfseam", "+tfsubpel"]),
-    "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
-    "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p8_all_lp4": (1920, 1080, 60, 8, ["--preset", "8", "--lp", "4", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p8_all_lp8": (1920, 1080, 60, 8, ["--preset", "8", "--lp", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p8_all_lp16": (1920, 1080, 60, 8, ["--preset", "8", "--lp", "16", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p8_metf_300": (1920, 1080, 300, 8, ["--preset", "8", "+clip60", "+seam", "+tfseam", "+tfsubpel", "+tfdriver"]),
+    "fps_1080p_p6_all": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p4_all": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     # the TPL dispenser's source-based half as one device stage per picture (integration/src_ops_process_seam.c): SVT_HIP_TPL_SEAM=1
     "tplseam_p8_8bit": (448, 264, 20, 8, ["--preset", "8", "--lp", "1", "+tplseam"]),
     "tplseam_p6_8bit_lp4": (448, 264, 20, 8, ["--preset", "6", "--lp", "4", "+tplseam"]),
@@ -111,6 +119,8 @@ CASES = {
     "tiny_2dev_everyseam_p4": (128, 128, 6, 8, ["--preset", "4", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "tiny_tplseam_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+tplseam"]),
     "tiny_tplseam_p10": (192, 136, 18, 8, ["--preset", "10", "--lp", "1", "+tplseam"]),
+    "tiny_tfdriver_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
+    "tiny_tfdriver_p4_lp2": (128, 128, 10, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+tfdriver"]),
     "tiny_tfsubpel_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
     "tiny_tfseam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tiny_dlfseam_p4": (128, 64, 3, 8, ["--preset", "4", "--lp", "1", "+dlfseam"]),
@@ -125,7 +135,7 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
-SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tplseam_"))]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tfdriver_", "tplseam_"))]
 
 
 def make_clip(path, w, h, n, bd, seed=7):
@@ -186,6 +196,8 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
             env["SVT_HIP_TF_ME_SEAM"] = "1"
         if "+tfsubpel" in CASES[name][4]:
             env.update({"SVT_HIP_TF_SUBPEL_SEAM": "1", "SVT_HIP_TF_SUBPEL_SEAM_STATS": os.path.join(outdir, name + "_tfsubpel.txt")})
+        if "+tfdriver" in CASES[name][4]:
+            env.update({"SVT_HIP_TF_SEAM": "1", "SVT_HIP_TF_SEAM_STATS": os.path.join(outdir, name + "_tfdriver.txt")})
     if lrseam:
         env.update({"SVT_HIP_LR_SEAM": "1", "SVT_HIP_LR_SEAM_STATS": lrseam_file})
     cdefseam_file = os.path.join(outdir, name + "_cdefseam.txt")
@@ -249,8 +261,14 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
         f = os.path.join(outdir, name + "_tfsubpel.txt")
         st = dict(ln.split(None, 1) for ln in open(f).read().splitlines()) if os.path.exists(f) else {}
         res["tfsubpel"] = {k: int(v) for k, v in st.items()}
-        if bd == 8:  # the dedicated 8-bit cases must really be served from the device batch
+        if bd == 8 and "+tfdriver" not in CASES[name][4]:  # the dedicated 8-bit cases must really be served from the device batch (the driver seam replaces the callers)
             res["identical"] = res["identical"] and res["tfsubpel"].get("searches_served", 0) > 0
+    if "+tfdriver" in CASES[name][4]:
+        f = os.path.join(outdir, name + "_tfdriver.txt")
+        st = dict(ln.split(None, 1) for ln in open(f).read().splitlines()) if os.path.exists(f) else {}
+        res["tfdriver"] = {k: (int(v) if v.strip().isdigit() else v.strip()) for k, v in st.items()}
+        if bd == 8:  # void unless central pictures really went through the device stage, none left to the reference
+            res["identical"] = res["identical"] and res["tfdriver"].get("pictures_filtered", 0) > 0 and res["tfdriver"].get("pictures_declined", 1) == 0
     if lrseam:
         st = dict(ln.split(None, 1) for ln in open(lrseam_file).read().splitlines()) if os.path.exists(lrseam_file) else {}
         res["lrseam"] = {k: int(v) for k, v in st.items()}
@@ -310,7 +328,7 @@ def main():
             union[k] = union.get(k, 0) + v
         print("%-20s identical=%s  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs  %s" % (nme, r["identical"], r.get("calls"), r.get("pointers_hit"),
                                                                                         r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"],
-                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", "")) + " " + str(r.get("tfsubpel", "")) + " " + str(r.get("tplseam", "")) + " " + str(r.get("devices", ""))), flush=True)
+                                                                                        str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", "")) + " " + str(r.get("tfsubpel", "")) + " " + str(r.get("tfdriver", "")) + " " + str(r.get("tplseam", "")) + " " + str(r.get("devices", ""))), flush=True)
         if "fps_c" in r:
             print("    encoder fps: C-only %.2f, %swith HIP (host = %s) %.2f" % (r["fps_c"], ("AVX2 intrinsics %.2f, " % r["fps_avx2"]) if "fps_avx2" in r else "", r["host"],
                                                                                r.get("fps_hip", 0.0)), flush=True)
