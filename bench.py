@@ -73,7 +73,7 @@ def live_pmc(a):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         td = tempfile.mkdtemp(prefix="svt_pmc_", dir="/tmp")
         cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", td, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
-               "--frames", str(a.frames), "--refs", str(a.refs), "--area", a.area] + (["--legs", a.legs] if a.legs else [])
+               "--frames", str(a.frames), "--refs", str(a.refs), "--area", a.area] + (["--legs", a.legs] if a.legs else []) + (["--only-me"] if a.only_me else [])
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=300, capture_output=True)
             files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
@@ -967,7 +967,7 @@ def main():
         a.no_cpu = a.no_parity_check = a.no_pmc = True
         a.steps, a.warmup, a.min_leg_s = 3, 1, 0.0
     NO_CHECK = a.no_parity_check
-    if not a.no_pmc and a.gpus == 1 and "RANK" not in os.environ and not a.only_me:
+    if not a.no_pmc and a.gpus == 1 and "RANK" not in os.environ:
         LIVE_PMC = live_pmc(a)  # before this process touches the GPU; None -> fallback to the committed summary
 
     import torch
