@@ -404,6 +404,48 @@ def encoder_fps():
                               "lr": r.get("lrseam")}}
 
 
+def cpu_tpl_stage(k):
+    """Checker + CPU baseline of the TPL leg: the C restatement (oracle/oracle_tpl.c, one core) on the leg's whole picture; every statistics record must equal
+    the device's."""
+    ora_path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(ora_path):
+        return {}
+    ora = C.CDLL(ora_path)
+    want = np.zeros(k["cells"], k["out"].dtype)
+    t0 = time.perf_counter()
+    ora.oracle_tpl_src_picture(C.byref(k["P"]), vp(k["planes"]), vp(k["planes"]), vp(k["tot"]), vp(k["mvs"]), vp(k["cand"]), vp(want))
+    dt = time.perf_counter() - t0
+    for name in want.dtype.names:
+        if name != "pad":
+            must_equal("tpl_src_stage " + name, k["out"][name], want[name])
+    return {"parity_checked_values": int(k["cells"]) * 9, "cpu_baseline": {"value": 1 / dt, "unit": "pictures/s", "cores": 1, "kind": "port",
+                                                                            "sample": "the leg's whole 1080p picture, oracle/oracle_tpl.c"}}
+
+
+def cpu_tf_picture(k):
+    """Checker + CPU baseline of the temporal-filter picture leg: oracle/oracle_tf_picture.c (one core, the reference's block order) on the leg's picture; the
+    filtered planes must equal the device's."""
+    ora_path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(ora_path):
+        return {}
+    ora = C.CDLL(ora_path)
+    pics, tabs, n_refs = k["pics"], k["tabs"], k["n_refs"]
+    out = [x.copy() for x in pics[0]]
+    cen = (C.c_void_p * 3)(*[x.ctypes.data for x in pics[0]])
+    refs = (C.c_void_p * (3 * n_refs))(*[x.ctypes.data for pic in pics[1:] for x in pic])
+    arr = lambda j: (C.c_void_p * n_refs)(*[t[j].ctypes.data for t in tabs])  # noqa: E731
+    o = (C.c_void_p * 3)(*[x.ctypes.data for x in out])
+    stats = np.zeros(5, np.uint32)
+    t0 = time.perf_counter()
+    ora.oracle_tf_picture(C.byref(k["P"]), cen, refs, arr(0), arr(1), arr(2), arr(3), n_refs, o, vp(stats))
+    dt = time.perf_counter() - t0
+    n = 0
+    for pl in range(3):
+        n += must_equal("tf_picture_stage plane %d" % pl, k["out"][pl], out[pl])
+    return {"parity_checked_values": n, "cpu_baseline": {"value": 1 / dt, "unit": "pictures/s", "cores": 1, "kind": "port",
+                                                          "sample": "the leg's whole picture, oracle/oracle_tf_picture.c (C kernels, the reference's lazy block order)"}}
+
+
 def roofline(bytes_alg, seconds, kernel, traffic_kernel=None, **extra):
     """HBM roofline object of one leg: ALGORITHMIC bytes per launch / event-timed launch duration."""
     gbs = bytes_alg / seconds / 1e9
@@ -957,7 +999,7 @@ def main():
     ap.add_argument("--min-leg-s", type=float, default=MIN_TIMED_S, help="minimum device time of every timed region (a step = as many launches as that takes)")
     ap.add_argument("--no-pmc", action="store_true", help="skip this run's own rocprofv3 --pmc child passes (roofline.traffic then comes from the committed summary)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (sad, txfm, config3, cdef, lr, hme, session, tf, lrsearch): A/B measurements")
+    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (sad, txfm, config3, cdef, lr, hme, session, tf, tpl, tfpic, lrsearch): A/B measurements")
     ap.add_argument("--extra", action="store_true", help="also sweep the other search areas / sub_sad and the remaining stages (reported under kernels)")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -1097,6 +1139,16 @@ def main():
             kernels.update(bench_legs.tf_subpel(torch, lib, pkg, stream, 5, 1, keep))
             if cpu:
                 kernels["tf_subpel_1080p8_6refs"].update(cpu_tf_subpel(keep, budget_s=4.0))
+        if want("tpl"):
+            keep = {}
+            kernels.update(bench_legs.tpl_src_stage(torch, lib, pkg, stream, 10, 2, keep))
+            if cpu:
+                kernels["tpl_src_stage_1080p8"].update(cpu_tpl_stage(keep))
+        if want("tfpic"):
+            keep = {}
+            kernels.update(bench_legs.tf_picture_stage(torch, lib, pkg, stream, 5, 1, keep))
+            if cpu:
+                kernels["tf_picture_stage_1080p8_4refs_host"].update(cpu_tf_picture(keep))
         if want("lrsearch"):
             keep = {}
             kernels.update(bench_legs.lr_search(torch, lib, pkg, stream, 2, 1, keep))

@@ -867,3 +867,115 @@ def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=48, slots=Non
                                                             "zero-motion gating, pre-HME (8x100..350 / 32..128x7), level-0 areas by reference index, HME pruning + "
                                                             "search-range divisors, 8x8-variance probe, sub-sampled SADs, ME area 8x3..8x4; synthetic noise pictures, so "
                                                             "no early exit fires"}}
+
+
+def tpl_src_stage(torch, lib, pkg, stream, steps, warmup, keep=None):
+    """the TPL dispenser's source-based half (src_ops_process.c:519-969) of one 1080p 8-bit picture as one launch: tpl level 0 (16x16 blocks, 8 160 of
+    them), 2 + 2 reference pictures, up to 7 ME candidates per block from the 16x16 ME results, DC intra from source neighbours, the best mode's 16x16 forward DCT +
+    quantize_fp error.  Algorithmic bytes per block: the source block + one reference block per candidate evaluated (256 B each) + the candidate / vector tables +
+    the 40-byte statistics record."""
+    g = np.random.default_rng(23)
+    W, H, PAD, n_l0, n_l1 = 1920, 1080, 96, 2, 2
+    aw, ah = (W + 7) & ~7, (H + 7) & ~7
+    sbs_x, sbs_y, n_ref = (aw + 63) // 64, (ah + 63) // 64, n_l0 + n_l1
+    stride, rows = aw + 2 * PAD + 24, ah + 2 * PAD + 16
+    yy, xx = np.mgrid[0:rows, 0:stride]
+    base = ((xx * 3 + yy * 2) & 255).astype(np.int32) + (((xx // 16 + yy // 16) % 7) << 3)
+    planes = np.zeros((1 + n_ref, rows, stride), np.uint8)
+    planes[0] = np.clip(base + g.integers(-12, 13, base.shape), 0, 255)
+    for r in range(n_ref):
+        planes[1 + r] = np.clip(np.roll(planes[0].astype(np.int32), (r + 1, -2 * r - 1), (0, 1)) + g.integers(-6 - 8 * r, 7 + 8 * r, base.shape), 0, 255)
+    P = pkg.TplSrcParams()
+    P.width, P.height, P.aligned_width, P.sbs_x, P.n_sb, P.src_stride = W, H, aw, sbs_x, sbs_x * sbs_y, stride
+    P.src_off = PAD * stride + PAD
+    P.dispenser_search_level, P.subsample_tx, P.pf_shape, P.disable_intra_pred, P.i_slice, P.enable_me_16x16, P.enable_me_8x8 = 0, 0, 2, 0, 0, 1, 0
+    n_pus, max_cand = 21, 7
+    P.max_refs, P.max_l0, P.max_cand = n_ref, n_l0, max_cand
+    P.quant_fp[0], P.quant_fp[1], P.round_fp[0], P.round_fp[1], P.dequant[0], P.dequant[1] = 532, 431, 61, 76, 123, 152  # q index 120 of the 8-bit tables
+    for l in range(2):
+        for r in range(4):
+            R, have = P.refs[l * 4 + r], r < (n_l0 if l == 0 else n_l1)
+            slot = r if l == 0 else n_l0 + r
+            R.plane_off = (1 + slot) * rows * stride if have else 0
+            R.picture_number, R.stride, R.org_x, R.org_y, R.max_width, R.max_height, R.valid = 100 + 10 * l + r, stride, PAD, PAD, W, H, int(have)
+    n_sb = P.n_sb
+    tot = g.integers(2, max_cand + 1, (n_sb, n_pus)).astype(np.uint8)
+    shp = (n_sb, n_pus, max_cand)
+    cand = (g.integers(0, 2, shp) | (g.integers(0, n_l0, shp) << 2) | (g.integers(0, n_l1, shp) << 4)).astype(np.uint8)
+    mvx, mvy = g.integers(-24, 25, (n_sb, n_pus, n_ref)).astype(np.int16), g.integers(-16, 17, (n_sb, n_pus, n_ref)).astype(np.int16)
+    mvs = np.ascontiguousarray((mvy.astype(np.uint16).astype(np.uint32) << 16) | mvx.astype(np.uint16).astype(np.uint32))
+    cells = (aw + 15) // 16 * ((ah + 15) // 16)
+    d_pl, d_tot, d_mv, d_cand = _dev(torch, planes), _dev(torch, tot), _dev(torch, mvs), _dev(torch, cand)
+    d_out = torch.zeros(cells * 40, dtype=torch.uint8, device="cuda")
+    t = _time(torch, lambda: lib.svt_hip_tpl_src_stage(C.addressof(P), d_pl.data_ptr(), d_pl.data_ptr(), d_tot.data_ptr(), d_mv.data_ptr(), d_cand.data_ptr(), d_out.data_ptr(),
+                                                       stream), steps, warmup, batches=3)
+    out = d_out.cpu().numpy().view(pkg.TplSrcStats)
+    n_blk = int(out["written"].sum())
+    alg = n_blk * (256 + 40) + int(tot[:, 5:21].sum()) * 256 + tot.nbytes + mvs.nbytes + cand.nbytes
+    if keep is not None:
+        keep.update(P=P, planes=planes, tot=tot, mvs=mvs, cand=cand, out=out.copy(), cells=cells)
+    return {"tpl_src_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "blocks_16x16": n_blk, "Mblocks_per_s": n_blk / t / 1e6,
+                                      "inter_wins_frac": float(np.mean(out["best_mode"][out["written"] > 0] != 0)) if n_blk else 0.0,
+                                      "roofline": {"bound": "hbm", "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 1e9 / 8000.0,
+                                                   "algorithmic_bytes_per_launch": alg, "kernel": "tpl_src_kernel<16, 16>", "kernel_us": t * 1e6,
+                                                   "note": "VALU bound (per block: up to 7 SADs, a 16x16 forward DCT, quantisation); the HBM figure is the contract's"}}}
+
+
+def tf_picture_stage(torch, lib, pkg, stream, steps, warmup, keep=None, size=(1920, 1080)):
+    """The temporal filter of one 1080p 8-bit 4:2:0 central picture with 4 reference pictures as ONE stage call from HOST pictures (svt_hip_tf_picture_host: upload,
+    sub-pel refinement of every block size, decisions, final motion compensation, 32x32 errors, filter, download) -- PCIe-inclusive wall time, the form the encoder
+    seam calls.  Preset-8 controls (bilinear 64 / 32 searches, half + quarter pel, sub-sampled distortions, no 8x8)."""
+    import time
+    g = np.random.default_rng(29)
+    (W, H), PAD, n_refs = size, 80, 4
+    nsx, nsy = (W + 63) // 64, (H + 63) // 64
+    n_sb = nsx * nsy
+    stride, rows, cstride, crows = W + 2 * PAD, 64 * nsy + 2 * PAD, W // 2 + PAD, 32 * nsy + PAD
+    yy, xx = np.mgrid[0:rows, 0:stride].astype(np.float32)
+    base = (0.5 + 0.25 * np.sin(xx / 3.3) * np.cos(yy / 4.1) + 0.2 * np.sin((xx + 2 * yy) / 9.1)) * 255
+    cy, cx = np.mgrid[0:crows, 0:cstride].astype(np.float32)
+    cb = (0.5 + 0.3 * np.sin(cx / 4.7) * np.cos(cy / 3.9)) * 255
+    pics = []
+    for r in range(n_refs + 1):
+        y = np.clip(np.roll(base, (r, -r), (0, 1)) + g.normal(0, 2, base.shape), 0, 255).astype(np.uint8)
+        u = np.clip(np.roll(cb, r, 1) + g.normal(0, 2, cb.shape), 0, 255).astype(np.uint8)
+        v = np.clip(np.roll(cb.T.copy().T, -r, 0) + g.normal(0, 2, cb.shape), 0, 255).astype(np.uint8)
+        pics.append([np.ascontiguousarray(y), np.ascontiguousarray(u), np.ascontiguousarray(v)])
+    P = pkg.TfPictureParams()
+    P.sp.half_pel_mode, P.sp.quarter_pel_mode, P.sp.eight_pel_mode, P.sp.subsampling_shift, P.sp.bit_depth = 1, 1, 0, 1, 8
+    P.sp.mi_rows, P.sp.mi_cols, P.sp.ref_org_x, P.sp.ref_org_y, P.sp.ref_stride = H // 4, W // 4, PAD, PAD, stride
+    P.tf.tf_decay_factor_fp16[0], P.tf.tf_decay_factor_fp16[1], P.tf.tf_decay_factor_fp16[2] = 2400000, 5200000, 4800000
+    P.tf.tf_mv_dist_th, P.tf.tf_chroma, P.tf.use_zz_based_filter, P.tf.encoder_bit_depth, P.tf.ss_x, P.tf.ss_y = 135, 1, 0, 8, 1, 1
+    P.pic_w_sb, P.pic_h_sb, P.uv_stride, P.me_exit_th, P.pred_error_32x32_th = nsx, nsy, cstride, 0, 20 * 32 * 32
+    P.use_2tap, P.enable_8x8_pred, P.use_pred_64x64_only_th = 1, 0, 35
+    tabs = []
+    for r in range(n_refs):
+        mvx, mvy = g.integers(-1, 2, (n_sb, 85)) - (r + 1), g.integers(-1, 2, (n_sb, 85)) + (r + 1)
+        best_mv = ((mvy.astype(np.int16).astype(np.uint16).astype(np.uint32) << 16) | mvx.astype(np.int16).astype(np.uint16)).astype(np.uint32)
+        best_sad = g.integers(500, 4000, (n_sb, 85)).astype(np.uint32)
+        best_sad[:, 0] = (best_sad[:, 1:5].sum(1) * g.uniform(0.9, 1.8, n_sb)).astype(np.uint32)
+        hme_sc = np.stack([np.full(n_sb, -(r + 1)), np.full(n_sb, r + 1)], 1).astype(np.int16)
+        tabs.append([np.ascontiguousarray(x) for x in (best_sad, best_mv, hme_sc, np.full(n_sb, 10 ** 6, np.uint64))])
+    hp = lambda pic: pkg.TfHostPicture(pic[0].ctypes.data, pic[1].ctypes.data, pic[2].ctypes.data, pic[0].size, pic[1].size)  # noqa: E731
+    refs = (pkg.TfHostPicture * n_refs)(*[hp(x) for x in pics[1:]])
+    me = (pkg.TfMeTables * n_refs)(*[pkg.TfMeTables(*[x.ctypes.data for x in t]) for t in tabs])
+    out = [x.copy() for x in pics[0]]
+    st = pkg.TfPictureStats()
+
+    def run():
+        cen = hp(pics[0])
+        rc = lib.svt_hip_tf_picture_host(C.byref(P), C.byref(cen), refs, me, n_refs, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, C.byref(st))
+        assert rc == 0
+    for _ in range(max(warmup, 1)):
+        run()
+    n = max(steps, 3)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run()
+    t = (time.perf_counter() - t0) / n
+    up = sum(x.nbytes for pic in pics for x in pic)
+    if keep is not None:
+        keep.update(P=P, pics=pics, tabs=tabs, out=[x.copy() for x in out], n_refs=n_refs)
+    return {"tf_picture_stage_1080p8_4refs_host": {"ms": t * 1e3, "pictures_per_s": 1 / t, "uploaded_MB": up / 1e6, "pcie_inclusive": True,
+                                                    "pred_64x64": st.blocks_64x64, "pred_32x32": st.blocks_32x32, "pred_16x16": st.blocks_16x16, "pred_8x8": st.blocks_8x8,
+                                                    "note": "wall time of the synchronous host-picture call (what the encoder seam pays), not a kernel time"}}

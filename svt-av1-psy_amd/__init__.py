@@ -318,6 +318,27 @@ LrPrevUnit = np.dtype([("use", "<i4"), ("vfilter", "<i2", (8,)), ("hfilter", "<i
 assert LrSearchUnit.itemsize == 72 and LrPrevUnit.itemsize == 36
 
 
+class TplRef(C.Structure):
+    """SvtHipTplRef: one reference picture of the TPL stage."""
+    _fields_ = [("plane_off", C.c_uint64), ("picture_number", C.c_uint64), ("stride", C.c_uint32), ("org_x", C.c_uint32), ("org_y", C.c_uint32),
+                ("max_width", C.c_uint16), ("max_height", C.c_uint16), ("valid", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
+class TplSrcParams(C.Structure):
+    """SvtHipTplSrcParams: the TPL dispenser's source-based half of one picture (svt_hip_tpl_src_stage)."""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("aligned_width", C.c_uint32), ("sbs_x", C.c_uint32), ("n_sb", C.c_uint32), ("src_stride", C.c_uint32),
+                ("src_off", C.c_uint64), ("dispenser_search_level", C.c_uint8), ("subsample_tx", C.c_uint8), ("pf_shape", C.c_uint8), ("disable_intra_pred", C.c_uint8),
+                ("i_slice", C.c_uint8), ("enable_me_16x16", C.c_uint8), ("enable_me_8x8", C.c_uint8), ("max_cand", C.c_uint8), ("max_refs", C.c_uint8),
+                ("max_l0", C.c_uint8), ("pad", C.c_uint8 * 2), ("quant_fp", C.c_int16 * 2), ("round_fp", C.c_int16 * 2), ("dequant", C.c_int16 * 2),
+                ("refs", TplRef * 8)]
+
+
+assert C.sizeof(TplRef) == 40 and C.sizeof(TplSrcParams) == 376
+TplSrcStats = np.dtype([("srcrf_dist", "<i8"), ("srcrf_rate", "<i8"), ("ref_frame_poc", "<u8"), ("mv_row", "<i2"), ("mv_col", "<i2"), ("best_rf_idx", "<i4"),
+                        ("best_mode", "u1"), ("best_intra_mode", "u1"), ("written", "u1"), ("pad", "u1", (5,))])
+assert TplSrcStats.itemsize == 40
+
+
 class TfPictureParams(C.Structure):
     """SvtHipTfPictureParams: one central picture of the temporal filter as a device stage (svt_hip_tf_picture_host)."""
     _fields_ = [("sp", TfSubpelParams), ("tf", TfParams), ("pic_w_sb", C.c_uint32), ("pic_h_sb", C.c_uint32), ("uv_stride", C.c_uint32), ("me_exit_th", C.c_uint32),
