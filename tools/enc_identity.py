@@ -230,10 +230,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
             if "Average Speed" in ln:
                 res["fps_" + tag] = float(ln.split(":")[1].split()[0])
     hooked = [ln for ln in rh.stderr.splitlines() if ln.startswith("SVT_HIP:")]
-    diag = [ln for ln in rh.stderr.splitlines() if ln.startswith("SVT_HIP_ME_SEAM")]
+    diag = [ln for ln in rh.stderr.splitlines() if ln.startswith("SVT_HIP_ME_SEAM") and "runs as one device stage" not in ln]  # (not the seam's start-up line)
     if diag:  # SVT_HIP_ME_SEAM_VERIFY=1: per-SB differences against the reference's own function
         res["seam_diagnostics"] = diag[:40]
-        print("\n".join(diag[:40]))
+        print("\n".join(diag[:40]), file=sys.stderr)
     res["hook_line"] = hooked[0] if hooked else None
     if rc.returncode or rh.returncode or not hooked:
         res["identical"] = False

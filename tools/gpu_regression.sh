@@ -4,6 +4,7 @@
 # THE BOX into gpurun_out/<tag>/ (the raw traces are too large to travel).  Run from the repository root:  bash tools/gpu_regression.sh <tag> [quick]
 TAG=${1:-reg}
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-.}
+ulimit -c 0
 O=gpurun_out/$TAG; mkdir -p $O
 if [ "$2" != "quick" ]; then
   timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1
