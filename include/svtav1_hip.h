@@ -728,7 +728,8 @@ void svt_hip_lpf_edges_batch(void *plane, uint32_t stride, int is_16bit, int bd,
 /* One plane of svt_av1_loop_filter_frame (deblocking_filter.c:625) from HOST memory: all vertical-edge segments, then all horizontal-edge segments (the order
  * the standard defines; the reference's SB-by-SB schedule with its one-SB lag for horizontal edges gives the same picture), in place.  The plane must be
  * readable 16 samples left / right of its rows (the reference's picture padding).  A seam records the segments by running the reference's own driver with
- * recording leaf functions.  Synchronous. */
+ * recording leaf functions.  Synchronous.  The WHOLE width x height plane is downloaded in place: nothing else may write the plane while the call runs (the
+ * frame-level seams call it from the one thread that owns the picture at that stage). */
 void svt_hip_lpf_plane_host(void *plane, uint32_t stride, uint32_t width, uint32_t height, int is_16bit, int bd, const SvtHipLpfEdge *vert, uint32_t n_vert,
                             const SvtHipLpfEdge *horz, uint32_t n_horz);
 #define SVT_HIP_LPF_DECL(LEN)                                                                                                              \

@@ -313,7 +313,7 @@ static int tfd_run_picture(TF_PIC_ARGS) {
             if (bright_change_region_cnt >= ((14 * scs->picture_analysis_number_of_regions_per_width * scs->picture_analysis_number_of_regions_per_height) / 16)) continue;
             used[n_used++] = frame_index;
         }
-    if (n_used == 0) return tfd_decline("no reference frame left"); /* (the reference then writes the central picture back unchanged: its own code does that) */
+    if (n_used == 0) return 0; /* every frame skipped: accumulators hold 1000 x the central picture, the count is 1000 -- (1000 c + 500) / 1000 = c, the picture stays as it is (:2608-2672) */
     if (n_used > SVT_HIP_TF_MAX_REFS) return tfd_decline("more frames than SVT_HIP_TF_MAX_REFS");
     for (int i = 0; i < n_used; i++) {
         const EbPictureBufferDesc *r = list_input_picture_ptr[used[i]];

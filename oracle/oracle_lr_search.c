@@ -284,6 +284,7 @@ void oracle_lr_search_plane(const OracleLrSearchParams *P, const OracleLrPrevUni
         r.h0 = rc[0]; r.h1 = rc[1]; r.v0 = rc[2]; r.v1 = rc[3];
         OracleLrSearchUnit *o = &out[u];
         memset(o, 0, sizeof(*o));
+        o->sse[1] = o->sse[2] = INT64_MAX; /* a tool that is off never reads as a perfect restoration (the reference leaves rusi->sse[] of a disabled tool untouched) */
         o->sse[0] = unit_sse(P->dgd, P->dgd_stride, P->src, P->src_stride, hbd, r.h0, r.h1, r.v0, r.v1);
         if (trials) trials[u] = 0;
         if (P->wn_enabled) {

@@ -67,6 +67,7 @@ __global__ void lr_rects_kernel(const SvtHipLrSearchParams P, SvtHipRect* rects,
     WnState z = {};
     wn[u]     = z;
     SvtHipLrSearchUnit o = {};
+    o.sse[1] = o.sse[2] = INT64_MAX; // overwritten only by a search that ran to its end: a disabled tool must never read as a perfect restoration
     out[u]               = o;
 }
 

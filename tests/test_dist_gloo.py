@@ -19,26 +19,26 @@ WORKER = textwrap.dedent('''
     rank, world = dist.get_rank(), dist.get_world_size()
     be = EmuBackend()
     g = np.random.default_rng(7)
-    n, stride, rows = 6, 64 * 6 + 120, 64 + 24
+    n, stride, rows = 4, 64 * 4 + 120, 64 + 24
     src = g.integers(0, 256, (rows, stride), dtype=np.uint8)
     ref = g.integers(0, 256, (rows, stride), dtype=np.uint8)
     descs = np.zeros(n, dtype=be.pkg.MeSearchDesc)
     for i in range(n):
-        descs[i] = (i * 64, i * 64 + 2, stride, stride, -8, -4, 16, 9)
+        descs[i] = (i * 64, i * 64 + 2, stride, stride, -4, -1, 8, 3)
     lo, hi = be.pkg.shard_range(n, rank, world)
     dist.barrier()
     t0 = time.perf_counter()
-    bs, bm = run_me_batch(be, src, ref, descs[lo:hi], 16, 9, 0)
+    bs, bm = run_me_batch(be, src, ref, descs[lo:hi], 8, 3, 0)
     dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # the bench's max-over-ranks timing
     full = [None, None]
     dist.all_gather_object(full, (lo, hi, bs, bm))              # test-only gather
     if rank == 0:
-        all_bs, all_bm = run_me_batch(be, src, ref, descs, 16, 9, 0)
+        all_bs, all_bm = run_me_batch(be, src, ref, descs, 8, 3, 0)
         for (a, b, s, m) in full:
             assert np.array_equal(all_bs[a:b], s) and np.array_equal(all_bm[a:b], m)
-        assert sorted((a, b) for (a, b, _, _) in full) == [(0, 3), (3, 6)] and t.item() > 0
+        assert sorted((a, b) for (a, b, _, _) in full) == [(0, 2), (2, 4)] and t.item() > 0
         print("DIST_OK")
     dist.destroy_process_group()
 ''')

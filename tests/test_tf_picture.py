@@ -86,7 +86,7 @@ def test_tf_picture_stage(be, oracle, case):
     bd, n_refs, th64, exit_th, th32, with8, two_tap, ss, chroma, zz = CASES[case]
     if not be.is_gpu and case == 3:
         pytest.skip("emulator: the 10-bit case runs on the GPU (the u16 paths of every piece are covered by their own emulator tests)")
-    W, H, PAD = (320, 200, 80) if be.is_gpu else (128, 72, 80)  # (a partial last block row: H is not a multiple of 64)
+    W, H, PAD = (320, 200, 80) if be.is_gpu else ((64, 72, 80) if case == 0 else (128, 72, 80))  # (a partial last block row: H is not a multiple of 64)
     g = rng(500 + case)
     P, pics, tabs = make_case(g, be.pkg, W, H, PAD, bd, n_refs, th64, exit_th, th32, with8, two_tap, ss, chroma, zz)
     want, wstats = run_oracle(oracle, P, pics, tabs)
