@@ -437,7 +437,7 @@ def cpu_tf_picture(k):
     o = (C.c_void_p * 3)(*[x.ctypes.data for x in out])
     stats = np.zeros(5, np.uint32)
     t0 = time.perf_counter()
-    ora.oracle_tf_picture(C.byref(k["P"]), cen, refs, arr(0), arr(1), arr(2), arr(3), n_refs, o, vp(stats))
+    ora.oracle_tf_picture(C.byref(k["P"]), cen, refs, arr(0), arr(1), arr(2), arr(3), n_refs, o, vp(stats), None, None)
     dt = time.perf_counter() - t0
     n = 0
     for pl in range(3):

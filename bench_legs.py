@@ -956,7 +956,7 @@ def tf_picture_stage(torch, lib, pkg, stream, steps, warmup, keep=None, size=(19
         best_sad[:, 0] = (best_sad[:, 1:5].sum(1) * g.uniform(0.9, 1.8, n_sb)).astype(np.uint32)
         hme_sc = np.stack([np.full(n_sb, -(r + 1)), np.full(n_sb, r + 1)], 1).astype(np.int16)
         tabs.append([np.ascontiguousarray(x) for x in (best_sad, best_mv, hme_sc, np.full(n_sb, 10 ** 6, np.uint64))])
-    hp = lambda pic: pkg.TfHostPicture(pic[0].ctypes.data, pic[1].ctypes.data, pic[2].ctypes.data, pic[0].size, pic[1].size)  # noqa: E731
+    hp = lambda pic: pkg.TfHostPicture(pic[0].ctypes.data, pic[1].ctypes.data, pic[2].ctypes.data, pic[0].size, pic[1].size, None)  # noqa: E731
     refs = (pkg.TfHostPicture * n_refs)(*[hp(x) for x in pics[1:]])
     me = (pkg.TfMeTables * n_refs)(*[pkg.TfMeTables(*[x.ctypes.data for x in t]) for t in tabs])
     out = [x.copy() for x in pics[0]]

@@ -523,6 +523,8 @@ void svt_hip_tf_inter_pred_batch(const SvtHipTfSubpelParams *params, const SvtHi
  *   5. svt_hip_tf_filter_frame.
  * Host form: whole padded buffers in, the filtered 64x64 blocks written to out_* (which may be the central picture's own buffers, like the reference's in-place
  * result).  All pictures share one geometry (sp.ref_org_x / ref_org_y / ref_stride for luma, uv_stride and the halved origin for chroma; 4:2:0).
+ * High bit depth (sp.bit_depth 10): the planes are the packed 16-bit pictures the reference filters (altref_buffer_highbd); with subpel_8bit the searches of step 1 read the 8-bit
+ * luma of the same pictures instead, as the reference does with tf_ctrls.use_8bit_subpel.
  * Returns 0, or -1 for parameters outside what is built (n_refs > SVT_HIP_TF_MAX_REFS, n_refs == 0, not 4:2:0). */
 typedef struct SvtHipTfPictureParams {
     SvtHipTfSubpelParams sp;  /* sub-pel controls, bit depth, mi_rows / mi_cols, the LUMA padding origin and stride of every picture */
@@ -534,11 +536,13 @@ typedef struct SvtHipTfPictureParams {
     uint8_t  use_2tap;                /* tf_ctrls.use_2tap: bilinear 64x64 / 32x32 searches */
     uint8_t  enable_8x8_pred;         /* tf_ctrls.enable_8x8_pred */
     uint8_t  use_pred_64x64_only_th;  /* tf_ctrls.use_pred_64x64_only_th */
-    uint8_t  pad[5];
+    uint8_t  subpel_8bit;             /* high bit depth only: tf_ctrls.use_8bit_subpel -- the sub-pel searches run on the pictures' 8-bit luma (`y8`), everything else on the 16-bit planes (:3203, :3242) */
+    uint8_t  pad[4];
 } SvtHipTfPictureParams;
 typedef struct SvtHipTfHostPicture {
-    const void *y, *u, *v;            /* buffer_y / buffer_cb / buffer_cr: the padded planes' first samples */
+    const void *y, *u, *v;            /* the padded planes' first samples: buffer_y / buffer_cb / buffer_cr (8 bit), altref_buffer_highbd[C_Y / C_U / C_V] (sp.bit_depth 10: uint16) */
     size_t      y_samples, uv_samples;/* samples per plane (luma_size / chroma_size) */
+    const void *y8;                   /* subpel_8bit: the picture's 8-bit luma buffer (buffer_y of the 10-bit picture: its 8 MSBs), same geometry; else NULL */
 } SvtHipTfHostPicture;
 typedef struct SvtHipTfMeTables { /* of one (central, reference) pair, [sb] = 64x64 block in raster order; the 85 entries in the ME order (64, 4 x 32, 16 x 16 z-order, 64 x 8 z-order) */
     const uint32_t *best_sad, *best_mv; /* [n_sb][85]: p_best_sad_* / p_best_mv* ((y << 16) | x, full pel) */

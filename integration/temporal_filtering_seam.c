@@ -22,7 +22,7 @@
  *    64x64 / 32x32 / 16x16 / 8x8 decisions, final motion compensation, filter -- and the picture's other segments return once it is done.  What stays the
  *    reference's own code: the picture-level decisions (which frames are skipped, :3105-3131), the decay factors (the function's preamble, :2870-3035, executed by
  *    calling the reference's function over an EMPTY block range: SEGMENT_END_IDX is redefined below to collapse the range while a thread-local flag is set), the
- *    set-up of the ME context (:3140-3177).  Outside what the stage covers (high bit depth, more than SVT_HIP_TF_MAX_REFS frames, a pair the ME stage declined)
+ *    set-up of the ME context (:3140-3177).  Outside what the stage covers (more than SVT_HIP_TF_MAX_REFS frames, a pair the ME stage declined)
  *    every segment runs the reference's function as before.
  */
 #define _GNU_SOURCE /* RTLD_DEFAULT */
@@ -288,7 +288,11 @@ static int tfd_run_picture(TF_PIC_ARGS) {
     EbPictureBufferDesc     *cen        = list_input_picture_ptr[index_center];
     MeContext               *ctx        = me_context_ptr->me_ctx;
     const uint32_t ss_x = scs->subsampling_x, ss_y = scs->subsampling_y;
-    if (is_highbd) return tfd_decline("high bit depth");
+    /* high bit depth: the reference filters the packed 16-bit copies of the pictures (altref_buffer_highbd, made by svt_av1_init_temporal_filtering :4171-4190);
+     * with tf_ctrls.use_8bit_subpel its sub-pel searches read the 8-bit luma of the same pictures (:3203, :3242) */
+    const int enc_bd = scs->static_config.encoder_bit_depth, sp8 = is_highbd && ctx->tf_ctrls.use_8bit_subpel;
+    if (is_highbd && enc_bd != 10) return tfd_decline("bit depth");
+    if (is_highbd && (cen->stride_bit_inc_cb != cen->stride_cb || cen->stride_bit_inc_cr != cen->stride_cr)) return tfd_decline("chroma stride of the packed planes");
     if (ss_x != 1 || ss_y != 1) return tfd_decline("not 4:2:0");
     const uint32_t blk_cols = (uint32_t)(cen->width + BW - 1) / BW, blk_rows = (uint32_t)(cen->height + BH - 1) / BH, n_sb = blk_cols * blk_rows; /* :2823-2826 */
     if (n_sb != centre_pcs->b64_total_count) return tfd_decline("block grid");
@@ -350,26 +354,36 @@ static int tfd_run_picture(TF_PIC_ARGS) {
         if (!svt_hip_seam_tf_pair_run(centre_pcs, ctx, n_sb, (uint32_t *)me[i].best_sad, (uint32_t *)me[i].best_mv, (int16_t *)me[i].hme_sc, (uint64_t *)me[i].hme_sad))
             rc = tfd_decline("a pair outside the ME stage");
         const EbPictureBufferDesc *r = list_input_picture_ptr[frame_index];
-        refs[i].y = r->buffer_y; refs[i].u = r->buffer_cb; refs[i].v = r->buffer_cr; refs[i].y_samples = r->luma_size; refs[i].uv_samples = r->chroma_size;
+        if (!is_highbd) { refs[i].y = r->buffer_y; refs[i].u = r->buffer_cb; refs[i].v = r->buffer_cr; refs[i].y8 = NULL; }
+        else {
+            uint16_t **hb = pcs_list[frame_index]->altref_buffer_highbd;
+            refs[i].y = hb[C_Y]; refs[i].u = hb[C_U]; refs[i].v = hb[C_V]; refs[i].y8 = sp8 ? r->buffer_y : NULL;
+            if (!hb[C_Y] || (ctx->tf_chroma && (!hb[C_U] || !hb[C_V]))) rc = tfd_decline("a packed 16-bit frame is missing");
+        }
+        refs[i].y_samples = r->luma_size; refs[i].uv_samples = r->chroma_size;
     }
     if (!rc) {
         SvtHipTfPictureParams P;
         memset(&P, 0, sizeof(P));
         P.sp.half_pel_mode = centre_pcs->tf_ctrls.half_pel_mode; P.sp.quarter_pel_mode = centre_pcs->tf_ctrls.quarter_pel_mode; P.sp.eight_pel_mode = centre_pcs->tf_ctrls.eight_pel_mode;
-        P.sp.subsampling_shift = centre_pcs->tf_ctrls.sub_sampling_shift; P.sp.bit_depth = 8; P.sp.early_exit_th = centre_pcs->tf_ctrls.subpel_early_exit_th;
+        P.sp.subsampling_shift = centre_pcs->tf_ctrls.sub_sampling_shift; P.sp.bit_depth = (uint8_t)(is_highbd ? enc_bd : 8); P.sp.early_exit_th = centre_pcs->tf_ctrls.subpel_early_exit_th;
+        P.subpel_8bit = (uint8_t)sp8;
         P.sp.mi_rows = (uint32_t)centre_pcs->av1_cm->mi_rows; P.sp.mi_cols = (uint32_t)centre_pcs->av1_cm->mi_cols;
         P.sp.ref_org_x = cen->org_x; P.sp.ref_org_y = cen->org_y; P.sp.ref_stride = cen->stride_y;
         for (int k = 0; k < 3; k++) P.tf.tf_decay_factor_fp16[k] = ctx->tf_decay_factor_fp16[k];
         P.tf.tf_mv_dist_th = ctx->tf_mv_dist_th; P.tf.tf_chroma = ctx->tf_chroma; P.tf.use_zz_based_filter = ctx->tf_ctrls.use_zz_based_filter;
-        P.tf.encoder_bit_depth = 8; P.tf.ss_x = (uint8_t)ss_x; P.tf.ss_y = (uint8_t)ss_y;
+        P.tf.encoder_bit_depth = (uint8_t)(is_highbd ? enc_bd : 8); P.tf.ss_x = (uint8_t)ss_x; P.tf.ss_y = (uint8_t)ss_y;
         P.pic_w_sb = blk_cols; P.pic_h_sb = blk_rows; P.uv_stride = cen->stride_cb;
         P.me_exit_th = centre_pcs->tf_ctrls.me_exit_th; P.pred_error_32x32_th = centre_pcs->tf_ctrls.pred_error_32x32_th;
         P.use_2tap = centre_pcs->tf_ctrls.use_2tap; P.enable_8x8_pred = centre_pcs->tf_ctrls.enable_8x8_pred; P.use_pred_64x64_only_th = centre_pcs->tf_ctrls.use_pred_64x64_only_th;
-        SvtHipTfHostPicture  C = {cen->buffer_y, cen->buffer_cb, cen->buffer_cr, cen->luma_size, cen->chroma_size};
+        uint16_t **chb = centre_pcs->altref_buffer_highbd;
+        SvtHipTfHostPicture C = {cen->buffer_y, cen->buffer_cb, cen->buffer_cr, cen->luma_size, cen->chroma_size, NULL};
+        if (is_highbd) { C.y = chb[C_Y]; C.u = chb[C_U]; C.v = chb[C_V]; C.y8 = sp8 ? cen->buffer_y : NULL; }
         SvtHipTfPictureStats st;
         memset(&st, 0, sizeof(st));
         svt_hip_seam_bind(centre_pcs->picture_number);
-        if (TFD.picture_host(&P, &C, refs, me, (uint32_t)n_used, cen->buffer_y, cen->buffer_cb, cen->buffer_cr, &st)) rc = tfd_decline("svt_hip_tf_picture_host refused the parameters");
+        if (is_highbd && (!chb[C_Y] || (ctx->tf_chroma && (!chb[C_U] || !chb[C_V])))) rc = tfd_decline("the central picture's packed 16-bit copy is missing");
+        else if (TFD.picture_host(&P, &C, refs, me, (uint32_t)n_used, (void *)C.y, (void *)C.u, (void *)C.v, &st)) rc = tfd_decline("svt_hip_tf_picture_host refused the parameters");
         else {
             /* the horizontal / vertical vote of the ME calls (motion_estimation.c:2469-2474): one per (block, frame), summed into the picture by the caller (:4255-4258) */
             for (size_t k = 0; k < (size_t)n_used * n_sb; k++) {

@@ -27,7 +27,7 @@ typedef struct OracleTfPictureParams { /* = SvtHipTfPictureParams */
     OracleTfParams       tf;
     uint32_t pic_w_sb, pic_h_sb, uv_stride, me_exit_th;
     uint64_t pred_error_32x32_th;
-    uint8_t  use_2tap, enable_8x8_pred, use_pred_64x64_only_th, pad[5];
+    uint8_t  use_2tap, enable_8x8_pred, use_pred_64x64_only_th, subpel_8bit, pad[4];
 } OracleTfPictureParams;
 
 void oracle_tf_subpel_search(const OracleTfSubpelParams *P, const void *src, int src_stride, const void *ref_buffer_y, int pu_x, int pu_y, int bsize, int bilinear,
@@ -47,6 +47,7 @@ static void slot_geometry(int slot, int *bs, int *lx, int *ly) {
 
 typedef struct Ctx {
     const OracleTfPictureParams *P;
+    const OracleTfSubpelParams  *sp; /* the searches' parameters: P->sp, or its 8-bit form with subpel_8bit (tf_ctrls.use_8bit_subpel, :3203) */
     const void *cy, *ry;     /* central / reference luma buffers */
     long        pic0;
     int         hbd, x0, y0; /* block origin */
@@ -60,7 +61,7 @@ static void search(const Ctx *c, int slot, int from_sc_x, int from_sc_y, int fro
     *mvx = (int16_t)((from_sc ? from_sc_x : (int16_t)(c->mv[slot] & 0xffffu)) << 3);
     *mvy = (int16_t)((from_sc ? from_sc_y : (int16_t)(c->mv[slot] >> 16)) << 3);
     *err = INT_MAX; /* (:1866, :1980, :2117, :2236) */
-    oracle_tf_subpel_search(&c->P->sp, src, (int)c->P->sp.ref_stride, c->ry, c->x0 + lx, c->y0 + ly, bs, bs >= 32 ? c->P->use_2tap : 0, mvx, mvy, err);
+    oracle_tf_subpel_search(c->sp, src, (int)c->P->sp.ref_stride, c->ry, c->x0 + lx, c->y0 + ly, bs, bs >= 32 ? c->P->use_2tap : 0, mvx, mvy, err);
 }
 
 static uint64_t var32(const void *pred, int pstride, const void *src, long sstride, int hbd, int ss) { /* :2718-2756 */
@@ -87,7 +88,8 @@ static uint64_t var32(const void *pred, int pstride, const void *src, long sstri
 /* central[3] / refs[n_refs][3]: whole padded buffers (one geometry); tables per reference: [n_sb][85], [n_sb][2], [n_sb]; out[3] may be central.
  * stats[5]: predictions per size 64 / 32 / 16 / 8, early-exit blocks */
 int oracle_tf_picture(const OracleTfPictureParams *P, const void *const central[3], const void *const *refs, const uint32_t *const *best_sad,
-                      const uint32_t *const *best_mv, const int16_t *const *hme_sc, const uint64_t *const *hme_sad, int n_refs, void *const out[3], uint32_t stats[5]) {
+                      const uint32_t *const *best_mv, const int16_t *const *hme_sc, const uint64_t *const *hme_sad, int n_refs, void *const out[3], uint32_t stats[5],
+                      const void *central_y8, const void *const *refs_y8 /* subpel_8bit: the pictures' 8-bit luma buffers; else NULL */) {
     const int  hbd = P->sp.bit_depth > 8, px = hbd ? 2 : 1, chroma = P->tf.tf_chroma, ss = P->sp.subsampling_shift;
     const int  nsbx = (int)P->pic_w_sb, nsby = (int)P->pic_h_sb, n_sb = nsbx * nsby, pw = 64 * nsbx, ph = 64 * nsby, nbx = 2 * nsbx, nby = 2 * nsby;
     const long pic0 = (long)P->sp.ref_org_y * P->sp.ref_stride + P->sp.ref_org_x, cpic0 = (long)(P->sp.ref_org_y >> 1) * P->uv_stride + (P->sp.ref_org_x >> 1);
@@ -96,6 +98,9 @@ int oracle_tf_picture(const OracleTfPictureParams *P, const void *const central[
     uint16_t *tmp[3] = {malloc(64 * 64 * 2), malloc(32 * 32 * 2), malloc(32 * 32 * 2)};
     const int tp[3] = {64, 32, 32};
     if (stats) memset(stats, 0, 5 * sizeof(uint32_t));
+    const int            sp8 = hbd && P->subpel_8bit;
+    OracleTfSubpelParams SP8 = P->sp;
+    SP8.bit_depth = 8;
     for (int r = 0; r < n_refs; r++) {
         pred[3 * r] = calloc((size_t)pw * ph, px);
         pred[3 * r + 1] = calloc((size_t)(pw / 2) * (ph / 2), px);
@@ -104,7 +109,7 @@ int oracle_tf_picture(const OracleTfPictureParams *P, const void *const central[
         const uint32_t    strides[3] = {P->sp.ref_stride, P->uv_stride, P->uv_stride};
         for (int sb = 0; sb < n_sb; sb++) {
             const int x0 = (sb % nsbx) * 64, y0 = (sb / nsbx) * 64;
-            Ctx c = {P, central[0], refs[3 * r], pic0, hbd, x0, y0, best_mv[r] + (size_t)sb * 85};
+            Ctx c = {P, sp8 ? &SP8 : &P->sp, sp8 ? central_y8 : central[0], sp8 ? refs_y8[r] : refs[3 * r], pic0, sp8 ? 0 : hbd, x0, y0, best_mv[r] + (size_t)sb * 85};
             const uint32_t *sd = best_sad[r] + (size_t)sb * 85;
             const int     exited = hme_sad[r][sb] < P->me_exit_th; /* motion_estimation.c:3110-3111 */
             const uint8_t th = exited ? (uint8_t)0xff : P->use_pred_64x64_only_th;

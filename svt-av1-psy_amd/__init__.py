@@ -342,12 +342,12 @@ assert TplSrcStats.itemsize == 40
 class TfPictureParams(C.Structure):
     """SvtHipTfPictureParams: one central picture of the temporal filter as a device stage (svt_hip_tf_picture_host)."""
     _fields_ = [("sp", TfSubpelParams), ("tf", TfParams), ("pic_w_sb", C.c_uint32), ("pic_h_sb", C.c_uint32), ("uv_stride", C.c_uint32), ("me_exit_th", C.c_uint32),
-                ("pred_error_32x32_th", C.c_uint64), ("use_2tap", C.c_uint8), ("enable_8x8_pred", C.c_uint8), ("use_pred_64x64_only_th", C.c_uint8), ("pad", C.c_uint8 * 5)]
+                ("pred_error_32x32_th", C.c_uint64), ("use_2tap", C.c_uint8), ("enable_8x8_pred", C.c_uint8), ("use_pred_64x64_only_th", C.c_uint8), ("subpel_8bit", C.c_uint8), ("pad", C.c_uint8 * 4)]
 
 
 class TfHostPicture(C.Structure):
     """SvtHipTfHostPicture: whole padded host buffers of one picture."""
-    _fields_ = [("y", vp), ("u", vp), ("v", vp), ("y_samples", C.c_size_t), ("uv_samples", C.c_size_t)]
+    _fields_ = [("y", vp), ("u", vp), ("v", vp), ("y_samples", C.c_size_t), ("uv_samples", C.c_size_t), ("y8", vp)]
 
 
 class TfMeTables(C.Structure):
@@ -360,7 +360,7 @@ class TfPictureStats(C.Structure):
                 ("pad", C.c_uint32 * 3)]
 
 
-assert C.sizeof(TfPictureParams) == 88 and C.sizeof(TfHostPicture) == 40 and C.sizeof(TfMeTables) == 32 and C.sizeof(TfPictureStats) == 32
+assert C.sizeof(TfPictureParams) == 88 and C.sizeof(TfHostPicture) == 48 and C.sizeof(TfMeTables) == 32 and C.sizeof(TfPictureStats) == 32
 
 
 class TfPlanes(C.Structure):

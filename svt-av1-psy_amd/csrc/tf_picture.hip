@@ -19,6 +19,7 @@ struct PicArgs {
     uint32_t n_refs, n_sb, per_sb;
     uint64_t pic0;       // samples from a luma buffer's first sample to picture sample (0, 0)
     uint64_t ref_pitch;  // samples between consecutive references' luma buffers (descriptor offsets are relative to reference 0)
+    uint64_t sp_ref_pitch; // ... of the planes the sub-pel searches read (the 8-bit luma copies with subpel_8bit, else = ref_pitch)
     uint64_t uv_pitch;   // ... chroma buffers
     uint64_t pred_y_pitch, pred_uv_pitch; // samples between consecutive references' prediction planes
     uint32_t pred_y_stride, pred_uv_stride;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void tf_pic_descs_kernel(const PicArgs A) {
     const uint32_t mv = A.best_mv[(size_t)pair * 85 + slot];
     SvtHipTfSubpelDesc d;
     d.src_off    = A.pic0 + (uint64_t)(y0 + ly) * A.P.sp.ref_stride + x0 + lx;
-    d.ref_off    = (uint64_t)ref * A.ref_pitch;
+    d.ref_off    = (uint64_t)ref * A.sp_ref_pitch;
     d.src_stride = A.P.sp.ref_stride;
     d.pu_x = (uint16_t)(x0 + lx); d.pu_y = (uint16_t)(y0 + ly);
     d.bsize = (uint8_t)bs;
@@ -210,7 +211,8 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     if (n_refs == 0 || n_refs > SVT_HIP_TF_MAX_REFS || !P.pic_w_sb || !P.pic_h_sb) return -1;
     if (P.tf.tf_chroma && (P.tf.ss_x != 1 || P.tf.ss_y != 1)) return -1; // (the final motion compensation is built for 4:2:0)
     if (P.sp.bit_depth != 8 && P.sp.bit_depth != 10) return -1;
-    const bool   hbd = P.sp.bit_depth > 8, chroma = P.tf.tf_chroma != 0;
+    const bool   hbd = P.sp.bit_depth > 8, chroma = P.tf.tf_chroma != 0, sp8 = hbd && P.subpel_8bit;
+    if (sp8 && !central->y8) return -1;
     const size_t px = hbd ? 2 : 1, n_sb = (size_t)P.pic_w_sb * P.pic_h_sb, per_sb = 21 + (P.enable_8x8_pred ? 64 : 0);
     const size_t ysz = svthip::align_up(central->y_samples * px, 256), csz = svthip::align_up(central->uv_samples * px, 256);
     const uint32_t pw = 64 * P.pic_w_sb, ph = 64 * P.pic_h_sb;
@@ -218,10 +220,11 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     const size_t n_pairs = n_refs * n_sb, n_sp = n_pairs * per_sb, nblk = (size_t)n_refs * 4 * n_sb;
     const size_t tables = n_pairs * (85 * 4 * 2 + 4 + 8);
     for (uint32_t r = 0; r < n_refs; r++)
-        if (refs[r].y_samples != central->y_samples || refs[r].uv_samples != central->uv_samples) return -1;
-    const size_t dev = (1 + n_refs) * (ysz + 2 * csz) + n_refs * (pysz + 2 * pcsz) + tables + n_sp * (sizeof(SvtHipTfSubpelDesc) + sizeof(SvtHipTfSubpelResult)) +
+        if (refs[r].y_samples != central->y_samples || refs[r].uv_samples != central->uv_samples || (sp8 && !refs[r].y8)) return -1;
+    const size_t y8sz = sp8 ? svthip::align_up(central->y_samples, 256) : 0;
+    const size_t dev = (1 + n_refs) * (ysz + 2 * csz + y8sz) + n_refs * (pysz + 2 * pcsz) + tables + n_sp * (sizeof(SvtHipTfSubpelDesc) + sizeof(SvtHipTfSubpelResult)) +
                        n_pairs * (MC_SLOTS * sizeof(SvtHipTfMcDesc) + 1) + nblk * sizeof(SvtHipTfBlock) + 65536;
-    const size_t pin = (2 + n_refs) * (ysz + 2 * csz) + tables + 65536; // uploads + the three downloads
+    const size_t pin = (2 + n_refs) * (ysz + 2 * csz + y8sz) + tables + 65536; // uploads + the three downloads
     svthip::HostCall& c = svthip::host_call();
     c.begin();
     c.reserve(dev, pin);
@@ -235,6 +238,12 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     uint8_t* d_py = (uint8_t*)c.dalloc(pysz * n_refs);
     uint8_t* d_pu = (uint8_t*)c.dalloc(pcsz * n_refs);
     uint8_t* d_pv = (uint8_t*)c.dalloc(pcsz * n_refs);
+    uint8_t* d_c8 = sp8 ? (uint8_t*)c.dalloc(y8sz) : nullptr;
+    uint8_t* d_r8 = sp8 ? (uint8_t*)c.dalloc(y8sz * n_refs) : nullptr;
+    if (sp8) {
+        c.up(d_c8, central->y8, central->y_samples);
+        for (uint32_t r = 0; r < n_refs; r++) c.up(d_r8 + r * y8sz, refs[r].y8, refs[r].y_samples);
+    }
     c.up(d_cy, central->y, central->y_samples * px);
     if (chroma) { c.up(d_cu, central->u, central->uv_samples * px); c.up(d_cv, central->v, central->uv_samples * px); }
     for (uint32_t r = 0; r < n_refs; r++) {
@@ -245,7 +254,7 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     memset(&A, 0, sizeof(A));
     A.P = P; A.n_refs = n_refs; A.n_sb = (uint32_t)n_sb; A.per_sb = (uint32_t)per_sb;
     A.pic0 = (uint64_t)P.sp.ref_org_y * P.sp.ref_stride + P.sp.ref_org_x;
-    A.ref_pitch = ysz / px; A.uv_pitch = csz / px; A.pred_y_pitch = pysz / px; A.pred_uv_pitch = pcsz / px; A.pred_y_stride = pw; A.pred_uv_stride = pw / 2;
+    A.ref_pitch = ysz / px; A.sp_ref_pitch = sp8 ? y8sz : ysz / px; A.uv_pitch = csz / px; A.pred_y_pitch = pysz / px; A.pred_uv_pitch = pcsz / px; A.pred_y_stride = pw; A.pred_uv_stride = pw / 2;
     uint32_t* d_sad = (uint32_t*)c.dalloc(n_pairs * 85 * 4);
     uint32_t* d_mv  = (uint32_t*)c.dalloc(n_pairs * 85 * 4);
     int16_t*  d_sc  = (int16_t*)c.dalloc(n_pairs * 4);
@@ -269,7 +278,9 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     // 1. sub-pel refinement of every block the reference may search
     hipLaunchKernelGGL(tf_pic_descs_kernel, dim3((unsigned)((n_sp + 255) / 256)), dim3(256), 0, st, A);
     SVT_LAUNCH_CHECK();
-    svt_hip_tf_subpel_search_batch(&P.sp, d_cy, d_ry, A.sp_descs, (uint32_t)n_sp, A.sp_res, st);
+    SvtHipTfSubpelParams SP = P.sp;
+    if (sp8) SP.bit_depth = 8;
+    svt_hip_tf_subpel_search_batch(&SP, sp8 ? d_c8 : d_cy, sp8 ? d_r8 : d_ry, A.sp_descs, (uint32_t)n_sp, A.sp_res, st);
     // 2. decisions
     hipLaunchKernelGGL(tf_pic_decide_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, A);
     SVT_LAUNCH_CHECK();

@@ -41,7 +41,7 @@ def _check(res):
         assert len(res["devices"]) >= 2 and all(v > 0 for v in res["devices"].values()), res["devices"]
     if "tplseam" in res and res["case"].startswith(("tplseam_", "tiny_tplseam")):  # the TPL source-based statistics of every picture came from the device stage
         assert res["tplseam"]["pictures_offloaded"] > 0 and res["tplseam"]["pictures_declined"] == 0 and res["tplseam"]["blocks"] > 0, res["tplseam"]
-    if "tfdriver" in res and res["bit_depth"] == 8:  # central pictures were temporally filtered by the device stage, none left to the reference
+    if "tfdriver" in res:  # central pictures were temporally filtered by the device stage, none left to the reference
         assert res["tfdriver"]["pictures_filtered"] > 0 and res["tfdriver"]["pictures_declined"] == 0 and res["tfdriver"]["reference_frames"] > 0, res["tfdriver"]
     if "seam" in res:
         pass
@@ -50,7 +50,7 @@ def _check(res):
 
 
 @needs_encoder
-@pytest.mark.parametrize("case", ["tiny_p8_8bit", "tiny_p8_10bit", "tiny_p8_lossless", "tiny_seam_p8", "tiny_seam_p5_lp2", "tiny_lrseam_p4", "tiny_cdefseam_p8", "tiny_dlfseam_p4", "tiny_tfseam_p8", "tiny_tfsubpel_p8", "tiny_tfdriver_p8", "tiny_tplseam_p8", "tiny_tplseam_p10", "tiny_dlfseam_sb_p8", "tiny_dlfseam_sb_p8_lp2", "tiny_2dev_everyseam_p8"])
+@pytest.mark.parametrize("case", ["tiny_p8_8bit", "tiny_p8_10bit", "tiny_p8_lossless", "tiny_seam_p8", "tiny_seam_p5_lp2", "tiny_lrseam_p4", "tiny_cdefseam_p8", "tiny_dlfseam_p4", "tiny_tfseam_p8", "tiny_tfsubpel_p8", "tiny_tfdriver_p8", "tiny_tfdriver_p8_10bit", "tiny_tplseam_p8", "tiny_tplseam_p10", "tiny_dlfseam_sb_p8", "tiny_dlfseam_sb_p8_lp2", "tiny_2dev_everyseam_p8"])
 def test_encoder_identity_emulator(case, tmp_path):
     from conftest import EmuBackend  # builds the emulator library if needed
     EmuBackend()

@@ -11,7 +11,7 @@ from conftest import p, rng
 from test_tf_subpel import make_yuv
 
 
-def make_case(g, pkg, W, H, PAD, bd, n_refs, th64, exit_th, th32, with8, two_tap, ss, chroma, zz, mode=(1, 1, 1)):
+def make_case(g, pkg, W, H, PAD, bd, n_refs, th64, exit_th, th32, with8, two_tap, ss, chroma, zz, mode=(1, 1, 1), sp8=False):
     nsx, nsy = (W + 63) // 64, (H + 63) // 64
     n_sb = nsx * nsy
     pics = []
@@ -30,7 +30,7 @@ def make_case(g, pkg, W, H, PAD, bd, n_refs, th64, exit_th, th32, with8, two_tap
     P.tf.tf_decay_factor_fp16[0], P.tf.tf_decay_factor_fp16[1], P.tf.tf_decay_factor_fp16[2] = 2400000, 5200000, 4800000
     P.tf.tf_mv_dist_th, P.tf.tf_chroma, P.tf.use_zz_based_filter, P.tf.encoder_bit_depth, P.tf.ss_x, P.tf.ss_y = 135, int(chroma), int(zz), bd, 1, 1
     P.pic_w_sb, P.pic_h_sb, P.uv_stride, P.me_exit_th, P.pred_error_32x32_th = nsx, nsy, pics[0][1].shape[1], exit_th, th32
-    P.use_2tap, P.enable_8x8_pred, P.use_pred_64x64_only_th = int(two_tap), int(with8), th64
+    P.use_2tap, P.enable_8x8_pred, P.use_pred_64x64_only_th, P.subpel_8bit = int(two_tap), int(with8), th64, int(sp8)
     tabs = []
     for r in range(n_refs):
         mvx, mvy = g.integers(-6, 7, (n_sb, 85)) - (r + 1), g.integers(-6, 7, (n_sb, 85)) + (r + 1)  # near the true displacement (-r, +r), full pel
@@ -54,19 +54,23 @@ def run_oracle(oracle, P, pics, tabs):
     o = (C.c_void_p * 3)(*[x.ctypes.data for x in out])
     stats = np.zeros(5, np.uint32)
     oracle.oracle_tf_picture.restype = C.c_int
-    assert oracle.oracle_tf_picture(C.byref(P), cen, refs, arr(0), arr(1), arr(2), arr(3), n_refs, o, p(stats)) == 0
+    y8 = [np.ascontiguousarray((pic[0] >> 2).astype(np.uint8)) for pic in pics] if P.subpel_8bit else None  # the 8 MSBs of a 10-bit picture = its 8-bit luma buffer
+    r8 = (C.c_void_p * n_refs)(*[x.ctypes.data for x in y8[1:]]) if y8 else None
+    assert oracle.oracle_tf_picture(C.byref(P), cen, refs, arr(0), arr(1), arr(2), arr(3), n_refs, o, p(stats), C.c_void_p(y8[0].ctypes.data) if y8 else None, r8) == 0
     return out, stats
 
 
 def run_device(be, P, pics, tabs):
     pkg = be.pkg
     n_refs = len(tabs)
-    hp = lambda pic: pkg.TfHostPicture(pic[0].ctypes.data, pic[1].ctypes.data, pic[2].ctypes.data, pic[0].size, pic[1].size)  # noqa: E731
+    y8 = {id(pic[0]): np.ascontiguousarray((pic[0] >> 2).astype(np.uint8)) for pic in pics} if P.subpel_8bit else {}
+    hp = lambda pic, k=None: pkg.TfHostPicture(pic[0].ctypes.data, pic[1].ctypes.data, pic[2].ctypes.data, pic[0].size, pic[1].size,  # noqa: E731
+                                               y8[id(k if k is not None else pic[0])].ctypes.data if y8 else None)
     cen = hp(pics[0])
     refs = (pkg.TfHostPicture * n_refs)(*[hp(x) for x in pics[1:]])
     me = (pkg.TfMeTables * n_refs)(*[pkg.TfMeTables(*[x.ctypes.data for x in t]) for t in tabs])
     out = [x.copy() for x in pics[0]]  # in place, like the reference: the output buffers start as the central picture
-    cen_inplace = hp(out)
+    cen_inplace = hp(out, pics[0][0])
     st = pkg.TfPictureStats()
     rc = be.lib.svt_hip_tf_picture_host(C.byref(P), C.byref(cen_inplace), refs, me, n_refs, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, C.byref(st))
     assert rc == 0
@@ -78,7 +82,8 @@ def run_device(be, P, pics, tabs):
 CASES = [(8, 2, 0, 0, 0, True, False, 0, True, False),          # every 32x32 goes through derive_tf_32x32_block_split_flag, with 8x8
          (8, 3, 20, 900, 3000, False, True, 1, True, False),    # tf_use_64x64_pred, early exits, bilinear searches, sub-sampled distortions; odd reference count
          (8, 1, 255, 0, 1 << 20, False, False, 0, False, True), # 64x64 only; luma only; the zero-motion filter
-         (10, 2, 35, 500, 20000, True, False, 1, True, False)]  # 10 bit
+         (10, 2, 35, 500, 20000, True, False, 1, True, False),  # 10 bit
+         (10, 2, 30, 300, 2500, False, True, 1, True, False)]   # 10 bit with the searches on the 8-bit luma (tf_ctrls.use_8bit_subpel)
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
@@ -86,9 +91,9 @@ def test_tf_picture_stage(be, oracle, case):
     bd, n_refs, th64, exit_th, th32, with8, two_tap, ss, chroma, zz = CASES[case]
     if not be.is_gpu and case == 3:
         pytest.skip("emulator: the 10-bit case runs on the GPU (the u16 paths of every piece are covered by their own emulator tests)")
-    W, H, PAD = (320, 200, 80) if be.is_gpu else ((64, 72, 80) if case == 0 else (128, 72, 80))  # (a partial last block row: H is not a multiple of 64)
+    W, H, PAD = (320, 200, 80) if be.is_gpu else ((64, 72, 80) if case in (0, 4) else (128, 72, 80))  # (a partial last block row: H is not a multiple of 64)
     g = rng(500 + case)
-    P, pics, tabs = make_case(g, be.pkg, W, H, PAD, bd, n_refs, th64, exit_th, th32, with8, two_tap, ss, chroma, zz)
+    P, pics, tabs = make_case(g, be.pkg, W, H, PAD, bd, n_refs, th64, exit_th, th32, with8, two_tap, ss, chroma, zz, sp8=(case == 4))
     want, wstats = run_oracle(oracle, P, pics, tabs)
     got, gstats = run_device(be, P, pics, tabs)
     assert np.array_equal(wstats, gstats), (wstats, gstats)
