@@ -225,7 +225,7 @@ typedef struct SvtHipHmeChainInputs { /* optional device inputs of the chain, an
     uint32_t prev_me_stage_based_exit_th; /* me_ctx->prev_me_stage_based_exit_th (0 = off): a level is skipped, keeping the previous stage's centre and SAD, when that
                                            * SAD is already small -- level 0 from the better performed pre-HME region below th >> 4 (:1937-1957), level 1 from
                                            * level 0 below th >> 5 (:2086-2096), level 2 from level 1 below th >> 2 (:2144-2154) */
-    uint8_t  n_levels;     /* 3 (or 0): levels 0-2; 2: enable_hme_level2_flag = 0 (presets M7 and above, enc_mode_config.c:1636-1640): levels 0 and 1 only,
+    uint8_t  n_levels;     /* 3 (or 0): levels 0-2; 1: level 0 only (final centre = the best level-0 region, :2215-2262); 2: enable_hme_level2_flag = 0 (presets M7 and above, enc_mode_config.c:1636-1640): levels 0 and 1 only,
                             * params[2] / sad_out[2] / sc_out[2] are not touched and the final centre is taken from level 1 (:2267-2309) */
     uint8_t  list1_no_hme; /* temporal_layer_index == 0: list 1's references take no part in HME (:1983, :2055, :2127): their items are skipped */
     uint8_t  pad[2];
@@ -584,7 +584,7 @@ typedef struct SvtHipMeStageParams {
              me_sr_divisor_for_low_hme_sad;
     uint32_t me_early_exit_th;           /* 0 = off */
     uint8_t  is_ref, me_8x8_var_enabled; /* as SvtHipMeIntegerSearchParams */
-    uint8_t  hme_levels;                 /* 3 (or 0): enable_hme_level0/1/2_flag all set; 2: enable_hme_level2_flag = 0 (M7 and above): the integer search starts from level 1 */
+    uint8_t  hme_levels;                 /* 3 (or 0): enable_hme_level0/1/2_flag all set; 1: level 0 only (the temporal filter at hme_me_level 3 / 4); 2: enable_hme_level2_flag = 0 (M7 and above): the integer search starts from level 1 */
     uint8_t  pad1;
     uint32_t me_sr_div4_th, me_sr_div2_th, me_sr_mult2_th;
     uint8_t  temporal_layer_gt0;         /* me_ctx->temporal_layer_index > 0 (list 1 takes part in pre-HME / HME, reference gating is active); 0 = base layer: list 1's

@@ -184,7 +184,7 @@ static int fill_stage(PictureParentControlSet *pcs, MeContext *c, SvtHipMeStageP
     SequenceControlSet *scs = pcs->scs;
     memset(S, 0, sizeof(*S));
     if (pcs->frame_superres_enabled || pcs->frame_resize_enabled) return decline("super-resolution / resize");
-    if (!c->enable_hme_flag || !c->enable_hme_level0_flag || !c->enable_hme_level1_flag) return decline("HME without levels 0 and 1");
+    if (!c->enable_hme_flag || !c->enable_hme_level0_flag || (!c->enable_hme_level1_flag && c->enable_hme_level2_flag)) return decline("HME without level 0, or level 2 without level 1");
     if (c->me_sr_adjustment_ctrls.enable_me_sr_adjustment > 1) return decline("enable_me_sr_adjustment == 2");
     if (c->reduce_hme_l0_sr_th_min || c->reduce_hme_l0_sr_th_max) return decline("RTC level-0 resizing from list 0's motion");
     if (c->num_hme_sa_w * c->num_hme_sa_h > 4) return decline("more than 2 x 2 HME regions");
@@ -193,7 +193,7 @@ static int fill_stage(PictureParentControlSet *pcs, MeContext *c, SvtHipMeStageP
     S->num_hme_sa_w = (uint8_t)c->num_hme_sa_w; S->num_hme_sa_h = (uint8_t)c->num_hme_sa_h;
     S->hme_sub_sampled = c->hme_search_method != FULL_SAD_SEARCH;
     S->me_sub_sad      = c->me_search_method == SUB_SAD_SEARCH;
-    S->hme_levels      = c->enable_hme_level2_flag ? 3 : 2;
+    S->hme_levels      = c->enable_hme_level2_flag ? 3 : (c->enable_hme_level1_flag ? 2 : 1); /* (1: the temporal filter at tf_ctrls.hme_me_level 3 / 4, enc_mode_config.c:1655-1661) */
     S->hme_sa_width[1] = (int16_t)c->hme_l1_sa.width; S->hme_sa_height[1] = (int16_t)c->hme_l1_sa.height;
     S->hme_sa_width[2] = (int16_t)c->hme_l2_sa.width; S->hme_sa_height[2] = (int16_t)c->hme_l2_sa.height;
     S->me_sa_min_width = (int16_t)c->me_sa.sa_min.width; S->me_sa_min_height = (int16_t)c->me_sa.sa_min.height;

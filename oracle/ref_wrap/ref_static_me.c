@@ -266,7 +266,7 @@ void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsPar
     ctx->quarter_b64_buffer_stride = pics[0][1].stride_y;
     ctx->sixteenth_b64_buffer = pics[0][0].buffer_y + (pics[0][0].org_y + (b64_origin_y >> 2)) * pics[0][0].stride_y + pics[0][0].org_x + (b64_origin_x >> 2);
     ctx->sixteenth_b64_buffer_stride = pics[0][0].stride_y;
-    ctx->enable_hme_flag = 1; ctx->enable_hme_level0_flag = 1; ctx->enable_hme_level1_flag = 1; ctx->enable_hme_level2_flag = !O->hme_level2_off;
+    ctx->enable_hme_flag = 1; ctx->enable_hme_level0_flag = 1; ctx->enable_hme_level1_flag = O->hme_level2_off < 2; ctx->enable_hme_level2_flag = !O->hme_level2_off; /* 0: three levels, 1: levels 0 and 1, 2: level 0 only */
     ctx->num_hme_sa_w = O->num_hme_sa_w; ctx->num_hme_sa_h = O->num_hme_sa_h;
     ctx->hme_search_method = O->hme_sub_sampled ? SUB_SAD_SEARCH : FULL_SAD_SEARCH;
     ctx->me_search_method  = O->me_sub_sad ? SUB_SAD_SEARCH : FULL_SAD_SEARCH;
@@ -371,7 +371,7 @@ void ref_sig_deriv_me(int enc_mode, int input_resolution, int qp, int sc_class1,
     O->phme_sad_th = c->me_hme_prune_ctrls.phme_sad_th; O->phme_sad_pct = (uint16_t)c->me_hme_prune_ctrls.phme_sad_pct;
     O->prev_me_stage_based_exit_th = c->prev_me_stage_based_exit_th;
     O->me_safe_limit_zz_th = c->me_safe_limit_zz_th;
-    O->hme_level2_off = !c->enable_hme_level2_flag;
+    O->hme_level2_off = !c->enable_hme_level2_flag + !c->enable_hme_level1_flag;
     extra[0] = c->me_hme_prune_ctrls.prune_ref_if_me_sad_dev_bigger_than_th; extra[1] = c->prune_me_candidates_th;
     extra[2] = c->me_hme_prune_ctrls.enable_me_hme_ref_pruning; extra[3] = c->enable_hme_level2_flag; extra[4] = c->enable_hme_level1_flag;
     extra[5] = (int32_t)c->me_safe_limit_zz_th;

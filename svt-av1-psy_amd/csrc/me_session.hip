@@ -168,7 +168,7 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         return -4;
     if (stage && n_refs) { // every refusal happens here, before anything is enqueued or any session state changes
         if (stage->sr_adjustment > 1) return -5;                                  // enable_me_sr_adjustment == 2 (screen-content levels 4 / 5): not covered
-        if (stage->hme_levels != 0 && stage->hme_levels != 2 && stage->hme_levels != 3) return -5;
+        if (stage->hme_levels > 3) return -5;
         if (stage->prehme_enabled && (stage->num_hme_sa_w != 2 || stage->num_hme_sa_h != 2)) return -5; // get_worst_quadrant is written for 2 x 2 regions
         if ((uint32_t)stage->results.num_of_ref_pic_to_search[0] + stage->results.num_of_ref_pic_to_search[1] != n_refs) return -4;
         SvtHipMeIntegerSearchParams V; // the fields svt_hip_me_integer_search_workspace / me_int_max_area read

@@ -1362,8 +1362,8 @@ void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* 
     memset(&A, 0, sizeof(A));
     int src_budget = 0, win_budget = 0;
     const int n_levels = (inputs && inputs->n_levels) ? inputs->n_levels : 3;
-    if (n_levels < 2 || n_levels > 3) {
-        fprintf(stderr, "libsvtav1_hip: svt_hip_hme_chain_batch: n_levels must be 2 or 3\n");
+    if (n_levels < 1 || n_levels > 3) {
+        fprintf(stderr, "libsvtav1_hip: svt_hip_hme_chain_batch: n_levels must be 1, 2 or 3\n");
         abort();
     }
     A.n_levels = n_levels;

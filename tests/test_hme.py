@@ -487,6 +487,8 @@ STAGE_OPTS = [dict(name="baseline"),
               # what the reference's own derivation gives at preset 8 (svt_aom_sig_deriv_me, enc_mode_config.c:681-815; HME flags :1630-1640): HME level 2 is OFF,
               # the level-0 area shrinks with the reference index (distance_based_hme_resizing), base-layer pictures search two lists without HME for list 1
               dict(name="two_levels", levels=2),
+              dict(name="level0_only", levels=1),
+              dict(name="mctf_level0_only", levels=1, mctf=2000, me=(8, 5, 16, 9)),  # the temporal filter's ME at tf_ctrls.hme_me_level 3 / 4 (enc_mode_config.c:1655-1661)
               dict(name="two_levels_exits", levels=2, prev_stage=64 * 64 * 24, me_early_exit_th=64 * 64 * 3, sub=1, hme_prune=30, sr=(1, 4, 3000, 8, 3000, 8)),
               dict(name="l0_resize_by_ref_index", dbr=1, sr=(1, 4, 12000, 8, 12000, 8), l0=(32, 32, 96, 96)),
               dict(name="base_layer", tl=0),
@@ -634,7 +636,7 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
     O.me_min_w, O.me_min_h, O.me_max_w, O.me_max_h = me_sa
     O.mv_adj_enabled, O.mv_adj_nearest_ref_only, O.mv_adj_mv_size_th, O.mv_adj_sa_multiplier = 1, 1, 4, 2
     O.temporal_layer_index, O.is_ref = opt.get("tl", 1), opt.get("is_ref", 0)
-    O.hme_level2_off = 1 if opt.get("levels", 3) == 2 else 0
+    O.hme_level2_off = 3 - opt.get("levels", 3)  # 0: three levels, 1: levels 0 and 1, 2: level 0 only
     O.distance_based_hme_resizing = opt.get("dbr", 0)
     O.hme_sub_sampled = O.me_sub_sad = opt.get("sub", 0)
     if "zz" in opt:

@@ -83,7 +83,7 @@ CASES = {
     "tfdriver_p4_8bit": (256, 144, 18, 8, ["--preset", "4", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
     "tfdriver_p6_8bit_lp4": (448, 264, 20, 8, ["--preset", "6", "--lp", "4", "+seam", "+tfseam", "+tfdriver"]),
     "tfdriver_p2_8bit": (256, 144, 10, 8, ["--preset", "2", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
-    # (preset 10: the temporal filter's HME runs level 0 only -- tf_ctrls.hme_me_level 3 / 4, enc_mode_config.c:1655-1661 -- which the ME stage declines per pair, so the picture stays the reference's)
+    "tfdriver_p10_8bit": (448, 264, 20, 8, ["--preset", "10", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),  # the temporal filter's HME runs level 0 only there (tf_ctrls.hme_me_level 3 / 4)
     "tfdriver_1080p_p8": (1920, 1080, 20, 8, ["--preset", "8", "+seam", "+tfseam", "+tfdriver"]),
     "tfdriver_p8_10bit": (256, 144, 18, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),  # high bit depth: the packed 16-bit planes, searches on the 8-bit luma
     "tfdriver_p4_10bit": (256, 144, 12, 10, ["--preset", "4", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
