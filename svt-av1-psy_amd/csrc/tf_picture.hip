@@ -2,7 +2,9 @@
 // already exist -- svt_hip_tf_subpel_search_batch, svt_hip_tf_inter_pred_batch, svt_hip_tf_filter_frame -- i.e. what produce_temporally_filtered_pic
 // (temporal_filtering.c:2782-3400) does per 64x64 block and reference between them: which blocks are searched from which vectors, the 64x64 / 32x32 / 16x16 / 8x8
 // decision tree on the search results, the descriptors of the final motion compensation, the per-32x32 records the filter reads, and the 32x32 errors of a 64x64
-// prediction.  Nothing returns to the host between the steps: the decisions are made by a kernel (one thread per (block, reference)), on device-resident results.
+// prediction.  Nothing returns to the host between the steps: the decisions are made by kernels, on device-resident results.  The sub-pel refinement runs in THREE
+// passes -- 64x64, then the 32x32 blocks of the (block, reference) pairs the 64x64-only tests let through, then the 16x16 (and 8x8) blocks of the 32x32 blocks that
+// need them -- so that, like the reference, a size is searched only where its result can be used: at preset 8 that is one search per pair instead of 21.
 //
 // Slots of a 64x64 block, everywhere in this file, follow the ME tables' order: 0 = 64x64; 1 + i32; 5 + 4 i32 + i16; 21 + 16 i32 + 4 i16 + i8 (z-order: index bit 0 =
 // right half, bit 1 = lower half at every level) -- tab16x16 / tab8x8 (motion_estimation.h:101-116) and idx_32x32_to_idx_16x16 / _8x8 (temporal_filtering.c:60-80) are
@@ -27,8 +29,8 @@ struct PicArgs {
     const uint32_t*           best_mv;
     const int16_t*            hme_sc;     // [n_refs][n_sb][2]
     const unsigned long long* hme_sad;    // [n_refs][n_sb]
-    SvtHipTfSubpelDesc*       sp_descs;   // [n_refs][n_sb][per_sb]
-    SvtHipTfSubpelResult*     sp_res;
+    SvtHipTfSubpelDesc*       sp_descs;   // [n_refs][n_sb][per_sb]: three regions, one per pass -- [pair] | [pair][4] | [pair][per_sb - 5]
+    SvtHipTfSubpelResult*     sp_res;     // same layout
     SvtHipTfMcDesc*           mc_descs;   // [n_refs][n_sb][MC_SLOTS]
     SvtHipTfBlock*            blocks;     // [n_refs][2 pic_h_sb][2 pic_w_sb]
     uint8_t*                  path64;     // [n_refs][n_sb]
@@ -42,14 +44,48 @@ __device__ __forceinline__ void slot_geometry(const int slot, int& bs, int& lx, 
     else { const int z = slot - 21; bs = 8; lx = ((z >> 4) & 1) * 32 + ((z >> 2) & 1) * 16 + (z & 1) * 8; ly = ((z >> 5) & 1) * 32 + ((z >> 3) & 1) * 16 + ((z >> 1) & 1) * 8; }
 }
 
-// every block the reference may search, with the starting vector its caller would pass (:1866-1870, :1980-1982, :2113-2115, :2232-2234)
-__global__ __launch_bounds__(256) void tf_pic_descs_kernel(const PicArgs A) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x, total = A.n_refs * A.n_sb * A.per_sb;
+// where the results of a pair live: slot 0 -> region 0, slots 1-4 -> region 1, slots 5.. -> region 2
+__device__ __forceinline__ size_t res_index(const PicArgs& A, const uint32_t pair, const int slot) {
+    const size_t np = (size_t)A.n_refs * A.n_sb;
+    if (slot == 0) return pair;
+    if (slot < 5) return np + (size_t)pair * 4 + (slot - 1);
+    return np * 5 + (size_t)pair * (A.per_sb - 5) + (slot - 5);
+}
+// tf_use_64x64_pred (:2676-2690) on the pair's ME SADs, and the early exit of the ME call (motion_estimation.c:3110): both known before any search
+__device__ __forceinline__ bool only_64x64_before_search(const PicArgs& A, const uint32_t pair) {
+    const uint8_t th = A.hme_sad[pair] < A.P.me_exit_th ? (uint8_t)0xff : A.P.use_pred_64x64_only_th;
+    if (!th) return false;
+    if (th == 0xff) return true;
+    const uint32_t* sd = A.best_sad + (size_t)pair * 85;
+    uint32_t d32 = 0;
+    for (int i = 0; i < 4; i++) d32 += sd[1 + i];
+    const long long a = (long long)(sd[0] > 1u ? sd[0] : 1u), b = (long long)(d32 > 1u ? d32 : 1u);
+    return (a - b) * 100 / b < (long long)th;
+}
+// (:3263-3270) the 64x64 prediction wins against the four 32x32
+__device__ __forceinline__ bool pred_64x64_wins(const PicArgs& A, const uint32_t pair) {
+    const unsigned long long e64 = A.sp_res[res_index(A, pair, 0)].dist;
+    unsigned long long s32 = 0;
+    for (int i = 0; i < 4; i++) s32 += A.sp_res[res_index(A, pair, 1 + i)].dist;
+    return e64 * 14 < s32 * 16 && e64 < (1ull << 18);
+}
+
+// The descriptors of one pass (level 0: 64x64; 1: 32x32; 2: 16x16 and 8x8) with the starting vector the reference's caller would pass (:1866-1870, :1980-1982,
+// :2113-2115, :2232-2234); a block the reference would not search at this point gets bsize 0 and the search kernel skips it.
+__global__ __launch_bounds__(256) void tf_pic_descs_kernel(const PicArgs A, const int level) {
+    const uint32_t per = level == 0 ? 1u : (level == 1 ? 4u : A.per_sb - 5u), first = level == 0 ? 0u : (level == 1 ? 1u : 5u);
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, total = A.n_refs * A.n_sb * per;
     if (i >= total) return;
-    const uint32_t pair = i / A.per_sb, slot = i - pair * A.per_sb, ref = pair / A.n_sb, sb = pair - ref * A.n_sb;
+    const uint32_t pair = i / per, slot = first + (i - pair * per), ref = pair / A.n_sb, sb = pair - ref * A.n_sb;
     const uint32_t x0 = (sb % A.P.pic_w_sb) * 64, y0 = (sb / A.P.pic_w_sb) * 64;
     int bs, lx, ly;
     slot_geometry((int)slot, bs, lx, ly);
+    bool wanted = true;
+    if (level >= 1) wanted = !only_64x64_before_search(A, pair);
+    if (level == 2 && wanted) {
+        const int i32 = slot < 21 ? (int)(slot - 5) >> 2 : (int)(slot - 21) >> 4;
+        wanted = !pred_64x64_wins(A, pair) && !(A.sp_res[res_index(A, pair, 1 + i32)].dist < A.P.pred_error_32x32_th); // (:3292-3296)
+    }
     // the ME call's early exit leaves no tables: 64x64 only, from the HME centre (motion_estimation.c:3110; temporal_filtering.c:1866-1870)
     const bool from_sc = slot == 0 && (A.hme_sad[pair] < A.P.me_exit_th || A.P.use_pred_64x64_only_th == 0xff);
     const uint32_t mv = A.best_mv[(size_t)pair * 85 + slot];
@@ -58,12 +94,12 @@ __global__ __launch_bounds__(256) void tf_pic_descs_kernel(const PicArgs A) {
     d.ref_off    = (uint64_t)ref * A.sp_ref_pitch;
     d.src_stride = A.P.sp.ref_stride;
     d.pu_x = (uint16_t)(x0 + lx); d.pu_y = (uint16_t)(y0 + ly);
-    d.bsize = (uint8_t)bs;
+    d.bsize = (uint8_t)(wanted ? bs : 0);
     d.bilinear = (uint8_t)(bs >= 32 ? A.P.use_2tap : 0); // (:1801-1804, :1911-1914; the 16x16 and 8x8 searches always take the regular kernels)
     d.mv_x = (int16_t)((from_sc ? A.hme_sc[2 * pair] : (int16_t)(mv & 0xffffu)) << 3);
     d.mv_y = (int16_t)((from_sc ? A.hme_sc[2 * pair + 1] : (int16_t)(mv >> 16)) << 3);
     d.pad = 0;
-    A.sp_descs[i] = d;
+    A.sp_descs[res_index(A, pair, (int)slot)] = d;
 }
 
 // the decision tree of :3183-3340 for one (block, reference); writes the motion-compensation descriptors and the four 32x32 records of the filter
@@ -71,25 +107,9 @@ __global__ __launch_bounds__(64) void tf_pic_decide_kernel(const PicArgs A) {
     const uint32_t pair = blockIdx.x * 64 + threadIdx.x;
     if (pair >= A.n_refs * A.n_sb) return;
     const uint32_t ref = pair / A.n_sb, sb = pair - ref * A.n_sb, sbx = sb % A.P.pic_w_sb, sby = sb / A.P.pic_w_sb, x0 = sbx * 64, y0 = sby * 64;
-    const SvtHipTfSubpelResult* R  = A.sp_res + (size_t)pair * A.per_sb;
-    const uint32_t*             sd = A.best_sad + (size_t)pair * 85;
-    const bool    exited = A.hme_sad[pair] < A.P.me_exit_th;
-    const uint8_t th     = exited ? (uint8_t)0xff : A.P.use_pred_64x64_only_th;
-    bool p64 = false;
-    if (th) {
-        if (th == 0xff) p64 = true;
-        else { // tf_use_64x64_pred (:2676-2690)
-            uint32_t d32 = 0;
-            for (int i = 0; i < 4; i++) d32 += sd[1 + i];
-            const long long a = (long long)(sd[0] > 1u ? sd[0] : 1u), b = (long long)(d32 > 1u ? d32 : 1u);
-            p64 = (a - b) * 100 / b < (long long)th;
-        }
-    }
-    const unsigned long long e64 = R[0].dist;
-    if (!p64) { // (:3263-3270)
-        const unsigned long long s32 = R[1].dist + R[2].dist + R[3].dist + R[4].dist;
-        p64 = e64 * 14 < s32 * 16 && e64 < (1ull << 18);
-    }
+    auto R = [&](const int slot) -> const SvtHipTfSubpelResult& { return A.sp_res[res_index(A, pair, slot)]; }; // (only slots the passes searched are read)
+    const bool exited = A.hme_sad[pair] < A.P.me_exit_th;
+    const bool p64    = only_64x64_before_search(A, pair) || pred_64x64_wins(A, pair);
     A.path64[pair] = p64 ? 1 : 0;
     SvtHipTfMcDesc* M = A.mc_descs + (size_t)pair * MC_SLOTS; // (zeroed by the host: unused slots keep bsize 0)
     auto mc = [&](const int k, const int slot, const int16_t mvx, const int16_t mvy) {
@@ -104,43 +124,43 @@ __global__ __launch_bounds__(64) void tf_pic_decide_kernel(const PicArgs A) {
     };
     const uint32_t nbx = 2 * A.P.pic_w_sb, nby = 2 * A.P.pic_h_sb;
     uint32_t n64 = 0, n32 = 0, n16 = 0, n8 = 0;
-    if (p64) { mc(0, 0, R[0].mv_x, R[0].mv_y); n64 = 1; }
+    if (p64) { mc(0, 0, R(0).mv_x, R(0).mv_y); n64 = 1; }
     for (int i32 = 0; i32 < 4; i32++) {
         SvtHipTfBlock B;
         for (int k = 0; k < 4; k++) { B.block_error[k] = 0; B.mv_x[k] = 0; B.mv_y[k] = 0; }
         B.split = 0;
         for (int k = 0; k < 7; k++) B.pad[k] = 0;
         if (p64) { // convert_64x64_info_to_32x32_info (:2691-2758): the 64x64 vector; the error comes from tf_pic_var32_kernel
-            B.mv_x[0] = R[0].mv_x; B.mv_y[0] = R[0].mv_y;
-        } else if (R[1 + i32].dist < A.P.pred_error_32x32_th) { // (:3292-3296)
-            B.block_error[0] = R[1 + i32].dist; B.mv_x[0] = R[1 + i32].mv_x; B.mv_y[0] = R[1 + i32].mv_y;
-            mc(16 * i32, 1 + i32, R[1 + i32].mv_x, R[1 + i32].mv_y); n32++;
+            B.mv_x[0] = R(0).mv_x; B.mv_y[0] = R(0).mv_y;
+        } else if (R(1 + i32).dist < A.P.pred_error_32x32_th) { // (:3292-3296)
+            B.block_error[0] = R(1 + i32).dist; B.mv_x[0] = R(1 + i32).mv_x; B.mv_y[0] = R(1 + i32).mv_y;
+            mc(16 * i32, 1 + i32, R(1 + i32).mv_x, R(1 + i32).mv_y); n32++;
         } else { // derive_tf_32x32_block_split_flag (:237-286), int arithmetic as there
             int  sum = 0, sub[4];
             bool split16[4];
             for (int i = 0; i < 4; i++) {
-                sub[i]     = (int)R[5 + 4 * i32 + i].dist;
+                sub[i]     = (int)R(5 + 4 * i32 + i).dist;
                 split16[i] = false;
                 if (A.P.enable_8x8_pred) {
                     int e8 = 0;
-                    for (int j = 0; j < 4; j++) e8 += (int)R[21 + 16 * i32 + 4 * i + j].dist;
+                    for (int j = 0; j < 4; j++) e8 += (int)R(21 + 16 * i32 + 4 * i + j).dist;
                     if (!(sub[i] * 8 < e8 * 16)) { split16[i] = true; sub[i] = e8; }
                 }
                 sum += sub[i];
             }
-            const int  e32   = (int)R[1 + i32].dist;
+            const int  e32   = (int)R(1 + i32).dist;
             const bool split = !(e32 * 14 < sum * 16);
             if (!split) {
-                B.block_error[0] = R[1 + i32].dist; B.mv_x[0] = R[1 + i32].mv_x; B.mv_y[0] = R[1 + i32].mv_y;
-                mc(16 * i32, 1 + i32, R[1 + i32].mv_x, R[1 + i32].mv_y); n32++;
+                B.block_error[0] = R(1 + i32).dist; B.mv_x[0] = R(1 + i32).mv_x; B.mv_y[0] = R(1 + i32).mv_y;
+                mc(16 * i32, 1 + i32, R(1 + i32).mv_x, R(1 + i32).mv_y); n32++;
             } else {
                 B.split = 1;
                 for (int i = 0; i < 4; i++) {
-                    const SvtHipTfSubpelResult r16 = R[5 + 4 * i32 + i];
+                    const SvtHipTfSubpelResult r16 = R(5 + 4 * i32 + i);
                     B.block_error[i] = split16[i] ? (unsigned long long)(long long)sub[i] : r16.dist; // (a split 16x16 carries the sum of its 8x8 errors, :262-264)
                     B.mv_x[i] = r16.mv_x; B.mv_y[i] = r16.mv_y;
                     if (split16[i]) {
-                        for (int j = 0; j < 4; j++) { const SvtHipTfSubpelResult r8 = R[21 + 16 * i32 + 4 * i + j]; mc(16 * i32 + 4 * i + j, 21 + 16 * i32 + 4 * i + j, r8.mv_x, r8.mv_y); }
+                        for (int j = 0; j < 4; j++) { const SvtHipTfSubpelResult r8 = R(21 + 16 * i32 + 4 * i + j); mc(16 * i32 + 4 * i + j, 21 + 16 * i32 + 4 * i + j, r8.mv_x, r8.mv_y); }
                         n8 += 4;
                     } else { mc(16 * i32 + 4 * i, 5 + 4 * i32 + i, r16.mv_x, r16.mv_y); n16++; }
                 }
@@ -275,12 +295,15 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     hipStream_t st = c.stream;
     HIP_CHECK(hipMemsetAsync(A.mc_descs, 0, n_pairs * MC_SLOTS * sizeof(SvtHipTfMcDesc), st));
     HIP_CHECK(hipMemsetAsync(A.stats, 0, sizeof(SvtHipTfPictureStats), st));
-    // 1. sub-pel refinement of every block the reference may search
-    hipLaunchKernelGGL(tf_pic_descs_kernel, dim3((unsigned)((n_sp + 255) / 256)), dim3(256), 0, st, A);
-    SVT_LAUNCH_CHECK();
+    // 1. sub-pel refinement in three passes: a size is searched only where the reference would search it
     SvtHipTfSubpelParams SP = P.sp;
     if (sp8) SP.bit_depth = 8;
-    svt_hip_tf_subpel_search_batch(&SP, sp8 ? d_c8 : d_cy, sp8 ? d_r8 : d_ry, A.sp_descs, (uint32_t)n_sp, A.sp_res, st);
+    for (int level = 0; level < 3; level++) {
+        const size_t per = level == 0 ? 1 : (level == 1 ? 4 : per_sb - 5), first = level == 0 ? 0 : (level == 1 ? n_pairs : 5 * n_pairs), cnt = n_pairs * per;
+        hipLaunchKernelGGL(tf_pic_descs_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, A, level);
+        SVT_LAUNCH_CHECK();
+        svt_hip_tf_subpel_search_batch(&SP, sp8 ? d_c8 : d_cy, sp8 ? d_r8 : d_ry, A.sp_descs + first, (uint32_t)cnt, A.sp_res + first, st);
+    }
     // 2. decisions
     hipLaunchKernelGGL(tf_pic_decide_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, A);
     SVT_LAUNCH_CHECK();

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void tf_subpel_kernel(const SvtHipTfSubpelPara
     if (item >= n) return;
     uint32_t* im = smem + wv * kSlice; // the wave's private intermediate: (rows + 7 + 1) / 2 row pairs x 64 columns
     const SvtHipTfSubpelDesc d = descs[item];
+    if (d.bsize == 0) return; // a block its caller decided not to search (tf_picture.hip): no result is written
     const PIX* src  = src_base + d.src_off;
     const PIX* refy = ref_base + d.ref_off;
     const int  hbd = sizeof(PIX) == 2, ss = P.subsampling_shift;
