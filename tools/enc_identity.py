@@ -96,6 +96,8 @@ CASES = {
     # 3840x2160 10-bit, preset 8, 60 frames (10-bit preset 8 is where the multi-threaded C-only reference was seen not to reproduce its own
     # bitstream; run_case reports `reference_deterministic` and the identity verdict next to the two speeds)
     "fps_4k10_p8_all": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    # larger pictures: more work per stage call against the same fixed latency
+    "fps_4k8_p8_all": (3840, 2160, 30, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "fps_1080p_p8_me": (1920, 1080, 60, 8, ["--preset", "8", "+seam"]),
     # steady state: 300 frames (the 60-frame clip looped by the application), so that one-time costs (HIP context, session, kernel code loading) amortise
     "fps_1080p_p8_all_300": (1920, 1080, 300, 8, ["--preset", "8", "+clip60", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
