@@ -443,7 +443,7 @@ void svt_hip_estimate_noise_batch(const void *plane, uint32_t width, uint32_t he
  * out (svt_aom_get_final_filtered_pixels_c, :2608-2672) -- produce_temporally_filtered_pic's steps 2-3 (:3360-3400) in one launch, accum and
  * count never leaving registers.  Planes are device pointers, strides in samples; out may alias central.  blocks: device,
  * [n_refs][nby][nbx]; nbx x nby 32x32 blocks are processed (the planes must cover them, as the reference's padded pictures do). */
-#define SVT_HIP_TF_MAX_REFS 8
+#define SVT_HIP_TF_MAX_REFS 12 /* = ALTREF_MAX_NFRAMES - 1 (definitions.h): every frame count the reference's temporal filter can use */
 typedef struct SvtHipTfPlanes {
     void    *y, *u, *v;
     uint32_t y_stride, uv_stride;

@@ -140,7 +140,7 @@ struct FrameArgs {
 //   1. issue every load of the workgroup (central + all predictions + the block records) before the first use: one memory round trip;
 //   2. squared errors per (reference, plane): packed dot products on the raw dwords (sum a^2 + sum b^2 - 2 sum ab), a 4-step DPP row
 //      reduction, row sums handed over through LDS;
-//   3. lane (plane * 8 + ref) turns its sum into a weight -- all references and planes at once, one pass of the expensive arithmetic;
+//   3. lane (plane * 16 + ref) turns its sum into a weight -- all references and planes at once, one pass of the expensive arithmetic;
 //   4. broadcast the weights and accumulate, normalise (exact float-reciprocal division), store.
 // The kernel is VALU-issue bound (about 600 wave instructions per 32x32 block at 6 references), not HBM bound; NR = reference count rounded
 // up to even, so that dead references cost nothing.
@@ -171,10 +171,10 @@ __global__ __launch_bounds__(256) void tf_frame_kernel(const SvtHipTfParams P, c
     const int cy = by * (32 >> P.ss_y) + ((q >> 1) << lh) + cyq, cx = bx * (32 >> P.ss_x) + ((q & 1) << lw) + cxq;
     const int n_refs = (int)A.n_refs;
 
-    // 1. loads.  The weight lanes (plane * 8 + ref) fetch their block record in the same round trip; 32-bit sample offsets from uniform
+    // 1. loads.  The weight lanes (plane * 16 + ref) fetch their block record in the same round trip; 32-bit sample offsets from uniform
     // plane pointers (SGPR base + VGPR offset form, no 64-bit address pairs to recycle); references beyond n_refs (at most one) re-read the
     // central picture and get weight 0, so there is no branch between the loads.
-    const int  wr = lane & 7, wc = lane >> 3;
+    const int  wr = lane & 15, wc = lane >> 4; // weight lanes: plane * 16 + reference (up to 12 references x 3 planes)
     const bool wlane = wr < n_refs && wc < (CPX ? 3 : 1);
     SvtHipTfBlock B = {};
     if (wlane) B = A.blocks[((size_t)wr * A.nby + by) * A.nbx + bx];
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void tf_frame_kernel(const SvtHipTfParams P, c
             if ((lane & 15) == 0) { sh_sum[q][0][r][lane >> 4] = sY; sh_sum[q][1][r][lane >> 4] = sU; sh_sum[q][2][r][lane >> 4] = sV; }
         }
     }
-    // 3. lane = plane * 8 + ref: one weight each (same-wave LDS traffic only: program order suffices on the hardware)
+    // 3. lane = plane * 16 + ref: one weight each (same-wave LDS traffic only: program order suffices on the hardware)
     __builtin_amdgcn_wave_barrier();
     uint32_t weight = 0;
     if (wlane) {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void tf_frame_kernel(const SvtHipTfParams P, c
 #pragma unroll
         for (int i = 0; i < 4; i++) accY[i] += wY * raw_px<PIX>(rawY[r], i);
         if (CPX) {
-            const uint32_t wU = (uint32_t)__shfl((int)weight, 8 + r), wV = (uint32_t)__shfl((int)weight, 16 + r);
+            const uint32_t wU = (uint32_t)__shfl((int)weight, 16 + r), wV = (uint32_t)__shfl((int)weight, 32 + r);
             cntU = (uint16_t)(cntU + wU);
             cntV = (uint16_t)(cntV + wV);
 #pragma unroll
@@ -445,7 +445,8 @@ void svt_hip_tf_filter_frame(const SvtHipTfParams* params, const SvtHipTfPlanes*
     const dim3 grid(nbx * nby), blk(256);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(PIX, C, NR) hipLaunchKernelGGL((tf_frame_kernel<PIX, C, NR>), grid, blk, 0, st, *params, A)
-#define BY_NR(PIX, C) do { if (nr == 2) LAUNCH(PIX, C, 2); else if (nr == 4) LAUNCH(PIX, C, 4); else if (nr == 6) LAUNCH(PIX, C, 6); else LAUNCH(PIX, C, 8); } while (0)
+#define BY_NR(PIX, C) do { if (nr == 2) LAUNCH(PIX, C, 2); else if (nr == 4) LAUNCH(PIX, C, 4); else if (nr == 6) LAUNCH(PIX, C, 6); else if (nr == 8) LAUNCH(PIX, C, 8); \
+                           else if (nr == 10) LAUNCH(PIX, C, 10); else LAUNCH(PIX, C, 12); } while (0)
 #define BY_C(PIX) do { if (cpx == 0) BY_NR(PIX, 0); else if (cpx == 1) BY_NR(PIX, 1); else if (cpx == 2) BY_NR(PIX, 2); else BY_NR(PIX, 4); } while (0)
     if (hbd) BY_C(uint16_t); else BY_C(uint8_t);
 #undef BY_C

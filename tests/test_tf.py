@@ -201,10 +201,12 @@ def test_tf_planewise_symbols_hip(be, oracle, bd, zz):
 def test_tf_filter_frame_hip(be, oracle, bd, zz):
     """Whole-picture form: central + n references + normalisation in one launch vs the oracle's per-block chain; in place and out of place."""
     pkg, g = load_pkg(), rng(1400 + bd + zz)
-    for it, ss in enumerate([(1, 1), (1, 0), (0, 0), (1, 1), (0, 1), (1, 1)]):
+    for it, ss in enumerate([(1, 1), (1, 0), (0, 0), (1, 1), (0, 1), (1, 1), (1, 1), (1, 1)]):
         chroma = it != 3
         nbx, nby = (3, 2) if not be.is_gpu else (9, 5)
-        n_refs = [3, 1, 6, 0, 2, 8][it] if be.is_gpu or it != 2 else 2
+        if not be.is_gpu and it == 6:
+            continue  # (the emulator keeps one of the two large reference counts)
+        n_refs = [3, 1, 6, 0, 2, 8, 9, 12][it] if be.is_gpu or it != 2 else 2  # (12 = ALTREF_MAX_NFRAMES - 1: the largest set the reference's filter uses)
         P = make_params(pkg, g, bd, zz, chroma, ss)
         W, H = nbx * 32, nby * 32
         cw, chh = W >> ss[0], H >> ss[1]
