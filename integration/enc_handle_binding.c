@@ -88,5 +88,20 @@ static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
     fprintf(stderr, "SVT_HIP: %d dispatch pointers now select the HIP variant\n", n);
 }
 
+/* The second insertion: the LAST statement of svt_av1_enc_init (enc_handle.c:2318, `svt_print_memory_usage();`, a no-op macro outside DEBUG_MEMORY_USAGE builds) is given
+ * this body, so that with the ME seam on the device sessions are created while the encoder initialises -- from the geometry of a real object of the PA-reference pool
+ * the function has just built -- instead of inside the first picture's stage call. */
+#include "enc_handle.h"
+#include "svt_malloc.h"
+#include "sys_resource_manager.h"
+void svt_hip_seam_me_prepare(const void *pa_reference_object); /* integration/me_process_seam.c */
+static void svt_hip_after_enc_init(EbEncHandle *h) {
+    if (!getenv("SVT_HIP") || !getenv("SVT_HIP_ME_SEAM") || !h || !h->pa_reference_picture_pool_ptr_array) return;
+    EbSystemResource *pool = h->pa_reference_picture_pool_ptr_array[0];
+    if (pool && pool->object_total_count && pool->wrapper_ptr_pool && pool->wrapper_ptr_pool[0]) svt_hip_seam_me_prepare(pool->wrapper_ptr_pool[0]->object_ptr);
+}
+#undef svt_print_memory_usage
+#define svt_print_memory_usage() svt_hip_after_enc_init(enc_handle_ptr)
+
 #define svt_aom_setup_rtcd_internal(flags) svt_aom_setup_rtcd_then_hip(flags)
 #include "enc_handle.c" /* resolves through -I$(REF)/Source/Lib/Globals */

@@ -277,20 +277,36 @@ static void reserve(void **p, size_t *cap, size_t bytes) {
 }
 
 /* the session (picture ring + stage buffers) is sized once for the encode, from the first picture that reaches a seam */
-static int ensure_session(int di, PictureParentControlSet *pcs, const EbPictureBufferDesc *src) {
-    if (!G.session[di]) {
-        EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
-        G.width = src->width; G.height = src->height; G.stride = src->stride_y; G.org_x = src->org_x; G.org_y = src->org_y;
-        G.rows = src->luma_size / src->stride_y;
-        /* largest ME area any preset derives is 256 x 256 (x 2 by the MV-based adjustment, x 3 / 2 by the variance probe) */
-        const int dev_id = svt_hip_seam_device_id(di); /* -1: no sharding, the default device */
-        G.session[di] = dev_id >= 0 && abi.create_on ? abi.create_on(dev_id, G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 4)
-                                                     : abi.create(G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 4); /* four pictures in flight */
-        if (!G.session[di] || abi.enable_stage(G.session[di], pa->quarter_downsampled_picture_ptr->org_x, pa->sixteenth_downsampled_picture_ptr->org_x, 4, 768, 768)) {
-            fprintf(stderr, "SVT_HIP_ME_SEAM: cannot create the ME session\n");
-            abort();
-        }
+static void create_session(int di, const EbPaReferenceObject *pa) {
+    const EbPictureBufferDesc *src = pa->input_padded_pic;
+    G.width = src->width; G.height = src->height; G.stride = src->stride_y; G.org_x = src->org_x; G.org_y = src->org_y;
+    G.rows = src->luma_size / src->stride_y;
+    /* largest ME area any preset derives is 256 x 256 (x 2 by the MV-based adjustment, x 3 / 2 by the variance probe) */
+    const int dev_id = svt_hip_seam_device_id(di); /* -1: no sharding, the default device */
+    G.session[di] = dev_id >= 0 && abi.create_on ? abi.create_on(dev_id, G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 4)
+                                                 : abi.create(G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 4); /* four pictures in flight */
+    if (!G.session[di] || abi.enable_stage(G.session[di], pa->quarter_downsampled_picture_ptr->org_x, pa->sixteenth_downsampled_picture_ptr->org_x, 4, 768, 768)) {
+        fprintf(stderr, "SVT_HIP_ME_SEAM: cannot create the ME session\n");
+        abort();
     }
+}
+/* Called by the binding at the end of svt_av1_enc_init (integration/enc_handle_binding.c) with an object of the encoder's PA-reference pool: the sessions of all
+ * devices -- ring, stage buffers, pinned slots: ~40 ms -- are created while the encoder initialises instead of inside the first picture's stage call. */
+void svt_hip_seam_me_prepare(const void *pa_reference_object) {
+    if (!seam_on() || !pa_reference_object) return;
+    const EbPaReferenceObject *pa = (const EbPaReferenceObject *)pa_reference_object;
+    if (!pa->input_padded_pic || !pa->quarter_downsampled_picture_ptr || !pa->sixteenth_downsampled_picture_ptr) return;
+    for (int di = 0; di < svt_hip_seam_device_count() && di < SEAM_DEVS; di++) {
+        pthread_mutex_lock(&G.dev[di]);
+        if (!G.session[di]) {
+            if (svt_hip_seam_device_count() > 1) svt_hip_seam_bind((unsigned long long)di); /* (binds this thread to device di: picture numbers di, di + N, ... map to it) */
+            create_session(di, pa);
+        }
+        pthread_mutex_unlock(&G.dev[di]);
+    }
+}
+static int ensure_session(int di, PictureParentControlSet *pcs, const EbPictureBufferDesc *src) {
+    if (!G.session[di]) create_session(di, (const EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr);
     if (src->width != G.width || src->height != G.height || src->stride_y != G.stride || src->org_x != G.org_x || src->org_y != G.org_y)
         return decline("picture geometry changed");
     return 0;
