@@ -398,6 +398,9 @@ def encoder_fps():
             "frames": r["frames"], "host_threads": len(os.sched_getaffinity(0)),
             "host_ms_per_me_stage_call": (lambda m: round(m.get("ms_in_stage_calls", 0) / max(m.get("pictures_offloaded", 0) + m.get("tf_pairs_offloaded", 0), 1), 3))(r.get("seam") or {}),
             "host_ms_first_stage_call": (r.get("seam") or {}).get("ms_first_stage_call"),
+            # wall time the encoder's threads spent inside stage calls (uploads + kernels + downloads), summed over the run: where the host side of the offload goes
+            "host_ms_in_stage_calls": {k: (r.get(v) or {}).get("ms_in_stage_calls") for k, v in (("me", "seam"), ("tf_picture", "tfdriver"), ("tpl", "tplseam"), ("dlf", "dlfseam"),
+                                                                                                   ("cdef", "cdefseam"), ("lr", "lrseam"))},
             "config": "1080p 8-bit, preset 8, CRF 35, all host threads; the reference encoder built (a) C-only and (b) with its SSE2..AVX2 intrinsic kernels (177 NASM kernels "
                       "stay at their C versions: no nasm here); the stage seams (ME, the temporal filter as one stage per central picture, TPL source half, deblocking, CDEF, LR) on the MI355X",
             "stages_on_gpu": {"me": r.get("seam"), "tf_subpel": r.get("tfsubpel"), "tf_picture": r.get("tfdriver"), "tpl": r.get("tplseam"), "dlf": r.get("dlfseam"), "cdef": r.get("cdefseam"),

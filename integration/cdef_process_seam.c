@@ -35,11 +35,14 @@ void    svt_aom_get_recon_pic(PictureControlSet *pcs, EbPictureBufferDesc **reco
 int32_t svt_sb_compute_cdef_list(PictureControlSet *pcs, const Av1Common *const cm, int32_t mi_row, int32_t mi_col, CdefList *dlist, BlockSize bs);
 
 int svt_hip_seam_bind(unsigned long long picture_number); /* integration/enc_handle_binding.c: SVT_HIP_DEVICES sharding */
+#include <time.h>
+static double seam_ms_now(void) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); return 1e3 * (double)t_.tv_sec + 1e-6 * (double)t_.tv_nsec; }
 static struct {
     pthread_mutex_t lock;
     int             mode;
     void (*apply_host)(const SvtHipCdefApplyHost *);
     void (*search_host)(const SvtHipCdefSearchHost *);
+    unsigned long long us_stage; /* microseconds inside the two stage calls */
     PictureControlSet *done_pcs[64]; /* pictures whose search the seam has run, and how many of their segments have passed */
     uint64_t           done_num[64];
     uint32_t           seen[64];
@@ -50,6 +53,7 @@ static void cdef_seam_stats(void) {
     const char *f = getenv("SVT_HIP_CDEF_SEAM_STATS");
     FILE       *o = f ? fopen(f, "w") : NULL;
     if (!o) return;
+    fprintf(o, "ms_in_stage_calls %llu\n", (unsigned long long)(D.us_stage / 1000));
     fprintf(o, "pictures_filtered %llu\nfilter_blocks %llu\npictures_declined %llu\npictures_searched %llu\nfilter_blocks_searched %llu\n",
             (unsigned long long)D.n_pictures, (unsigned long long)D.n_fbs, (unsigned long long)D.n_declined, (unsigned long long)D.n_searched,
             (unsigned long long)D.n_search_fbs);
@@ -116,7 +120,9 @@ static void seam_av1_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs)
     A.damping = (uint8_t)frm_hdr->cdef_params.cdef_damping;
     A.skip = skip; A.pri_y = pri_y; A.sec_y = sec_y; A.pri_uv = pri_uv; A.sec_uv = sec_uv;
     svt_hip_seam_bind(pcs->picture_number);
+    const double ta_ = seam_ms_now();
     if (filtered) D.apply_host(&A);
+    __atomic_fetch_add(&D.us_stage, (unsigned long long)((seam_ms_now() - ta_) * 1e3), __ATOMIC_RELAXED);
     pthread_mutex_lock(&D.lock);
     D.n_pictures++; D.n_fbs += filtered;
     pthread_mutex_unlock(&D.lock);
@@ -174,7 +180,9 @@ static void search_picture(PictureControlSet *pcs, SequenceControlSet *scs) {
     A.pri_y = pri_y; A.sec_y = sec_y; A.pri_uv = pri_uv; A.sec_uv = sec_uv;
     A.mse_y = mse_y; A.mse_u = mse_u; A.mse_v = mse_v; A.dir = dir; A.var = var;
     svt_hip_seam_bind(pcs->picture_number);
+    const double ts_ = seam_ms_now();
     if (searched) D.search_host(&A);
+    __atomic_fetch_add(&D.us_stage, (unsigned long long)((seam_ms_now() - ts_) * 1e3), __ATOMIC_RELAXED);
     for (int32_t fb = 0; fb < nfb; fb++) {
         if (!count[fb]) continue;
         for (int gi = 0; gi < ncand; gi++) {

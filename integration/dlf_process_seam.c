@@ -41,10 +41,13 @@ void svt_av1_loop_filter_frame(EbPictureBufferDesc *frame_buffer, PictureControl
 
 typedef void (*LpfFn)(uint8_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh);
 typedef void (*LpfHbdFn)(uint16_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh, int32_t bd);
+#include <time.h>
+static double seam_ms_now(void) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); return 1e3 * (double)t_.tv_sec + 1e-6 * (double)t_.tv_nsec; }
 static struct {
     pthread_mutex_t lock;
     int             mode;
     void (*plane_host)(void *, uint32_t, uint32_t, uint32_t, int, int, const SvtHipLpfEdge *, uint32_t, const SvtHipLpfEdge *, uint32_t);
+    unsigned long long us_stage; /* microseconds inside svt_hip_lpf_plane_host */
     LpfFn    orig[2][4];     /* [vertical][length index 4, 6, 8, 14] */
     LpfHbdFn orig_hbd[2][4];
     uint64_t n_pictures, n_segments, n_sb_pictures, n_sb_calls;
@@ -89,6 +92,7 @@ static void dlf_seam_stats(void) {
     const char *f = getenv("SVT_HIP_DLF_SEAM_STATS");
     FILE       *o = f ? fopen(f, "w") : NULL;
     if (!o) return;
+    fprintf(o, "ms_in_stage_calls %llu\n", (unsigned long long)(F.us_stage / 1000));
     fprintf(o, "pictures_filtered %llu\nsegments %llu\npictures_filtered_from_sb_records %llu\nsb_calls_recorded %llu\n", (unsigned long long)F.n_pictures,
             (unsigned long long)F.n_segments, (unsigned long long)F.n_sb_pictures, (unsigned long long)F.n_sb_calls);
     fclose(o);
@@ -141,7 +145,9 @@ static uint64_t filter_planes(const PictureControlSet *pcs, const uint32_t *w, E
         uint32_t rows = 0; /* upload only the rows the segments reach */
         for (uint32_t i = 0; i < nv; i++) { const uint32_t r = list[pl][1].e[i].y + 4; rows = r > rows ? r : rows; }
         for (uint32_t i = 0; i < nh; i++) { const uint32_t r = list[pl][0].e[i].y + 8; rows = r > rows ? r : rows; }
+        const double t0_ = seam_ms_now();
         F.plane_host((void *)T.base[pl], (uint32_t)T.stride[pl], ((w[pl] + 7) & ~7u), rows, is_16bit, bd, list[pl][1].e, nv, list[pl][0].e, nh);
+        __atomic_fetch_add(&F.us_stage, (unsigned long long)((seam_ms_now() - t0_) * 1e3), __ATOMIC_RELAXED);
         segs += nv + nh;
     }
     return segs;

@@ -29,11 +29,14 @@ void restoration_seg_search(int32_t *rst_tmpbuf, Yv12BufferConfig *org_fts, cons
 void svt_av1_loop_restoration_filter_frame(int32_t *rst_tmpbuf, Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr);
 
 int svt_hip_seam_bind(unsigned long long picture_number); /* integration/enc_handle_binding.c: SVT_HIP_DEVICES sharding */
+#include <time.h>
+static double seam_ms_now(void) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); return 1e3 * (double)t_.tv_sec + 1e-6 * (double)t_.tv_nsec; }
 static struct {
     pthread_mutex_t lock;
     int             mode; /* 0 off, 1 on */
     int (*search_host)(const SvtHipLrSearchParams *, const SvtHipLrPrevUnit *, SvtHipLrSearchUnit *);
     void (*filter_host)(const SvtHipLrParams *);
+    unsigned long long us_stage; /* microseconds inside the stage calls */
     PictureControlSet *done_pcs[64]; /* pictures whose search has been done by the seam (keyed by pcs + picture number) ... */
     uint64_t           done_num[64];
     uint32_t           seen[64];     /* ... and how many of their segments have passed: the record is dropped with the last one */
@@ -44,6 +47,7 @@ static void lr_seam_stats(void) {
     const char *f = getenv("SVT_HIP_LR_SEAM_STATS");
     FILE       *o = f ? fopen(f, "w") : NULL;
     if (!o) return;
+    fprintf(o, "ms_in_stage_calls %llu\n", (unsigned long long)(L.us_stage / 1000));
     fprintf(o, "pictures_offloaded %llu\nplanes_searched %llu\nunits_searched %llu\npictures_declined %llu\nplanes_filtered %llu\n", (unsigned long long)L.n_pictures,
             (unsigned long long)L.n_planes, (unsigned long long)L.n_units, (unsigned long long)L.n_declined, (unsigned long long)L.n_filtered_planes);
     fclose(o);
@@ -113,7 +117,9 @@ static void search_plane(const Yv12BufferConfig *org_fts, const Yv12BufferConfig
             }
     }
     svt_hip_seam_bind(pcs->picture_number);
+    const double ts_ = seam_ms_now();
     const int rc = L.search_host(&P, prev, out);
+    __atomic_fetch_add(&L.us_stage, (unsigned long long)((seam_ms_now() - ts_) * 1e3), __ATOMIC_RELAXED);
     if (rc) {
         fprintf(stderr, "SVT_HIP_LR_SEAM: svt_hip_lr_search_plane_host returned %d (picture %llu plane %d %ux%u unit %u win %u bd %u wn %d sg %d ep %u..%u/%u)\n", rc,
                 (unsigned long long)pcs->picture_number, plane, P.width, P.height, P.unit_size, P.wiener_win, P.bit_depth, P.wn_enabled, P.sg_enabled, P.sg_start_ep, P.sg_end_ep,
@@ -192,7 +198,9 @@ static void seam_loop_restoration_filter_frame(int32_t *rst_tmpbuf, Yv12BufferCo
         P.ss_x = (uint8_t)(is_uv && cm->subsampling_x); P.ss_y = (uint8_t)(is_uv && cm->subsampling_y); P.highbd = (uint8_t)highbd; P.bit_depth = (uint8_t)cm->bit_depth;
         P.units = units;
         svt_hip_seam_bind(cm->child_pcs->picture_number);
+        const double tf_ = seam_ms_now();
         L.filter_host(&P);
+        __atomic_fetch_add(&L.us_stage, (unsigned long long)((seam_ms_now() - tf_) * 1e3), __ATOMIC_RELAXED);
         free(units);
         pthread_mutex_lock(&L.lock);
         L.n_filtered_planes++;

@@ -232,6 +232,8 @@ static void seam_tf_subpel_search(TF_SUBPEL_ARGS) {
 }
 
 
+#include <time.h>
+static double seam_ms_now(void) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); return 1e3 * (double)t_.tv_sec + 1e-6 * (double)t_.tv_nsec; }
 /* ---- seam 3: one central picture = one device stage ------------------------------------------------------------------------------------------------------------ */
 int svt_hip_seam_tf_pair_run(PictureParentControlSet *pcs, MeContext *c, uint32_t n_sb, uint32_t *best_sad, uint32_t *best_mv, int16_t *hme_sc, uint64_t *hme_sad);
 enum { TFD_RECS = 16 };
@@ -249,6 +251,7 @@ static struct {
                         SvtHipTfPictureStats *);
     TfPicRec    rec[TFD_RECS];
     uint64_t    n_pictures, n_declined, n_refs, n64, n32, n16, n8, n_exit;
+    unsigned long long us_stage, us_pairs; /* microseconds inside svt_hip_tf_picture_host / inside the pairs' ME stage calls */
     const char *last_decline;
 } TFD = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, -1};
 
@@ -256,6 +259,7 @@ static void tfd_stats(void) {
     const char *f = getenv("SVT_HIP_TF_SEAM_STATS");
     FILE       *o = f ? fopen(f, "w") : NULL;
     if (!o) return;
+    fprintf(o, "ms_in_stage_calls %llu\nms_in_me_pairs %llu\n", (unsigned long long)(TFD.us_stage / 1000), (unsigned long long)(TFD.us_pairs / 1000));
     fprintf(o, "pictures_filtered %llu\npictures_declined %llu\nreference_frames %llu\npred_64x64 %llu\npred_32x32 %llu\npred_16x16 %llu\npred_8x8 %llu\nearly_exit_blocks %llu\nlast_decline %s\n",
             (unsigned long long)TFD.n_pictures, (unsigned long long)TFD.n_declined, (unsigned long long)TFD.n_refs, (unsigned long long)TFD.n64, (unsigned long long)TFD.n32,
             (unsigned long long)TFD.n16, (unsigned long long)TFD.n8, (unsigned long long)TFD.n_exit, TFD.last_decline ? TFD.last_decline : "-");
@@ -351,8 +355,10 @@ static int tfd_run_picture(TF_PIC_ARGS) {
         ctx->tf_subpel_early_exit_th = centre_pcs->tf_ctrls.subpel_early_exit_th;
         set_hme_search_params_mctf(ctx, 0);
         me[i].best_sad = best_sad + (size_t)i * n_sb * 85; me[i].best_mv = best_mv + (size_t)i * n_sb * 85; me[i].hme_sc = hme_sc + (size_t)i * n_sb * 2; me[i].hme_sad = hme_sad + (size_t)i * n_sb;
+        const double tp_ = seam_ms_now();
         if (!svt_hip_seam_tf_pair_run(centre_pcs, ctx, n_sb, (uint32_t *)me[i].best_sad, (uint32_t *)me[i].best_mv, (int16_t *)me[i].hme_sc, (uint64_t *)me[i].hme_sad))
             rc = tfd_decline("a pair outside the ME stage");
+        __atomic_fetch_add(&TFD.us_pairs, (unsigned long long)((seam_ms_now() - tp_) * 1e3), __ATOMIC_RELAXED);
         const EbPictureBufferDesc *r = list_input_picture_ptr[frame_index];
         if (!is_highbd) { refs[i].y = r->buffer_y; refs[i].u = r->buffer_cb; refs[i].v = r->buffer_cr; refs[i].y8 = NULL; }
         else {
@@ -383,8 +389,10 @@ static int tfd_run_picture(TF_PIC_ARGS) {
         memset(&st, 0, sizeof(st));
         svt_hip_seam_bind(centre_pcs->picture_number);
         if (is_highbd && (!chb[C_Y] || (ctx->tf_chroma && (!chb[C_U] || !chb[C_V])))) rc = tfd_decline("the central picture's packed 16-bit copy is missing");
-        else if (TFD.picture_host(&P, &C, refs, me, (uint32_t)n_used, (void *)C.y, (void *)C.u, (void *)C.v, &st)) rc = tfd_decline("svt_hip_tf_picture_host refused the parameters");
-        else {
+        const double ts_ = seam_ms_now();
+        if (!rc && TFD.picture_host(&P, &C, refs, me, (uint32_t)n_used, (void *)C.y, (void *)C.u, (void *)C.v, &st)) rc = tfd_decline("svt_hip_tf_picture_host refused the parameters");
+        __atomic_fetch_add(&TFD.us_stage, (unsigned long long)((seam_ms_now() - ts_) * 1e3), __ATOMIC_RELAXED);
+        if (!rc) {
             /* the horizontal / vertical vote of the ME calls (motion_estimation.c:2469-2474): one per (block, frame), summed into the picture by the caller (:4255-4258) */
             for (size_t k = 0; k < (size_t)n_used * n_sb; k++) {
                 if (ABS(hme_sc[2 * k]) > ABS(hme_sc[2 * k + 1])) ctx->tf_tot_horz_blks++;
