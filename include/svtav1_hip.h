@@ -443,13 +443,19 @@ void svt_hip_estimate_noise_batch(const void *plane, uint32_t width, uint32_t he
  * out (svt_aom_get_final_filtered_pixels_c, :2608-2672) -- produce_temporally_filtered_pic's steps 2-3 (:3360-3400) in one launch, accum and
  * count never leaving registers.  Planes are device pointers, strides in samples; out may alias central.  blocks: device,
  * [n_refs][nby][nbx]; nbx x nby 32x32 blocks are processed (the planes must cover them, as the reference's padded pictures do). */
-#define SVT_HIP_TF_MAX_REFS 12 /* = ALTREF_MAX_NFRAMES - 1 (definitions.h): every frame count the reference's temporal filter can use */
+#define SVT_HIP_TF_MAX_REFS 12   /* reference frames one launch of the frame kernel takes */
+#define SVT_HIP_TF_MAX_FRAMES 32 /* = ALTREF_MAX_NFRAMES - 1 (definitions.h:304): every frame count the reference's temporal filter can use (chunked form, picture stage) */
 typedef struct SvtHipTfPlanes {
     void    *y, *u, *v;
     uint32_t y_stride, uv_stride;
 } SvtHipTfPlanes;
 void svt_hip_tf_filter_frame(const SvtHipTfParams *params, const SvtHipTfPlanes *central, const SvtHipTfPlanes *preds, uint32_t n_refs,
                              const SvtHipTfBlock *blocks, uint32_t nbx, uint32_t nby, const SvtHipTfPlanes *out, void *stream);
+/* The same for up to SVT_HIP_TF_MAX_FRAMES reference frames: chunks of SVT_HIP_TF_MAX_REFS, the accumulators of the frames so far travelling between the launches through
+ * `workspace` (svt_hip_tf_filter_frame_workspace bytes, any content); only the last launch writes pixels, so out may still alias central. */
+size_t svt_hip_tf_filter_frame_workspace(const SvtHipTfParams *params, uint32_t nbx, uint32_t nby);
+void   svt_hip_tf_filter_frame_chunked(const SvtHipTfParams *params, const SvtHipTfPlanes *central, const SvtHipTfPlanes *preds, uint32_t n_refs,
+                                       const SvtHipTfBlock *blocks, uint32_t nbx, uint32_t nby, const SvtHipTfPlanes *out, void *workspace, void *stream);
 
 /* The temporal filter's sub-pel motion refinement, batched: replaces tf_subpel_search + svt_check_position (temporal_filtering.c:1560-1790) as
  * tf_64x64_sub_pel_search / tf_32x32_ / tf_16x16_ / tf_8x8_sub_pel_search (:1793-2250) call it for each block of a (central picture, reference
@@ -525,7 +531,7 @@ void svt_hip_tf_inter_pred_batch(const SvtHipTfSubpelParams *params, const SvtHi
  * result).  All pictures share one geometry (sp.ref_org_x / ref_org_y / ref_stride for luma, uv_stride and the halved origin for chroma; 4:2:0).
  * High bit depth (sp.bit_depth 10): the planes are the packed 16-bit pictures the reference filters (altref_buffer_highbd); with subpel_8bit the searches of step 1 read the 8-bit
  * luma of the same pictures instead, as the reference does with tf_ctrls.use_8bit_subpel.
- * Returns 0, or -1 for parameters outside what is built (n_refs > SVT_HIP_TF_MAX_REFS, n_refs == 0, not 4:2:0). */
+ * Returns 0, or -1 for parameters outside what is built (n_refs > SVT_HIP_TF_MAX_FRAMES, n_refs == 0, not 4:2:0). */
 typedef struct SvtHipTfPictureParams {
     SvtHipTfSubpelParams sp;  /* sub-pel controls, bit depth, mi_rows / mi_cols, the LUMA padding origin and stride of every picture */
     SvtHipTfParams       tf;  /* the filter's MeContext fields (frame form: all of them) */

@@ -22,7 +22,7 @@
  *    64x64 / 32x32 / 16x16 / 8x8 decisions, final motion compensation, filter -- and the picture's other segments return once it is done.  What stays the
  *    reference's own code: the picture-level decisions (which frames are skipped, :3105-3131), the decay factors (the function's preamble, :2870-3035, executed by
  *    calling the reference's function over an EMPTY block range: SEGMENT_END_IDX is redefined below to collapse the range while a thread-local flag is set), the
- *    set-up of the ME context (:3140-3177).  Outside what the stage covers (more than SVT_HIP_TF_MAX_REFS frames, a pair the ME stage declined)
+ *    set-up of the ME context (:3140-3177).  Outside what the stage covers (a pair the ME stage declined)
  *    every segment runs the reference's function as before.
  */
 #define _GNU_SOURCE /* RTLD_DEFAULT */
@@ -322,7 +322,7 @@ static int tfd_run_picture(TF_PIC_ARGS) {
             used[n_used++] = frame_index;
         }
     if (n_used == 0) return 0; /* every frame skipped: accumulators hold 1000 x the central picture, the count is 1000 -- (1000 c + 500) / 1000 = c, the picture stays as it is (:2608-2672) */
-    if (n_used > SVT_HIP_TF_MAX_REFS) return tfd_decline("more frames than SVT_HIP_TF_MAX_REFS");
+    if (n_used > SVT_HIP_TF_MAX_FRAMES) return tfd_decline("more frames than SVT_HIP_TF_MAX_FRAMES");
     for (int i = 0; i < n_used; i++) {
         const EbPictureBufferDesc *r = list_input_picture_ptr[used[i]];
         if (r->stride_y != cen->stride_y || r->stride_cb != cen->stride_cb || r->org_x != cen->org_x || r->org_y != cen->org_y || r->luma_size != cen->luma_size ||
@@ -338,8 +338,8 @@ static int tfd_run_picture(TF_PIC_ARGS) {
     int16_t  *hme_sc   = malloc((size_t)n_used * n_sb * 2 * sizeof(int16_t));
     uint64_t *hme_sad  = malloc((size_t)n_used * n_sb * 8);
     int       rc       = 0;
-    SvtHipTfMeTables    me[SVT_HIP_TF_MAX_REFS];
-    SvtHipTfHostPicture refs[SVT_HIP_TF_MAX_REFS];
+    SvtHipTfMeTables    me[SVT_HIP_TF_MAX_FRAMES];
+    SvtHipTfHostPicture refs[SVT_HIP_TF_MAX_FRAMES];
     for (int i = 0; i < n_used && !rc; i++) {
         const int frame_index = used[i];
         ctx->tf_frame_index = frame_index; ctx->tf_index_center = index_center;

@@ -112,6 +112,8 @@ PROTOTYPES = {
     "svt_hip_tf_inter_pred_batch": (None, [vp, vp, vp, C.c_uint32, C.c_int, vp]),
     "svt_hip_tf_subpel_search_host": (None, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, vp]),
     "svt_hip_tf_picture_host": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp]),
+    "svt_hip_tf_filter_frame_workspace": (C.c_size_t, [vp, C.c_uint32, C.c_uint32]),
+    "svt_hip_tf_filter_frame_chunked": (None, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, vp]),
     "svt_hip_lr_filter_frame_host": (None, [vp]),
     "svt_hip_cdef_apply_host": (None, [vp]),
     "svt_hip_lpf_plane_host": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, C.c_uint32, vp, C.c_uint32]),

@@ -134,6 +134,10 @@ struct FrameArgs {
     SvtHipTfPlanes central, out, preds[SVT_HIP_TF_MAX_REFS];
     const SvtHipTfBlock* blocks; // [n_refs][nby][nbx]
     uint32_t n_refs, nbx, nby;
+    // more reference frames than one launch takes: the accumulators travel between launches (svt_hip_tf_filter_frame_chunked)
+    uint32_t* acc[3];      // per pixel
+    uint16_t* cnt[3];      // per lane group: written at the group's first pixel
+    uint32_t  acc_stride[2], chain; // chain bit 0: start from acc / cnt instead of the central picture; bit 1: store acc / cnt instead of the normalised pixels
 };
 // The weights are uniform per (reference, plane, quadrant) and cost ~300 instructions of scalar-looking arithmetic each (integer divisions,
 // the square-root and exponential tables).  Evaluated per reference in every lane they were 15x the pixel work, so the kernel is staged:
@@ -248,10 +252,22 @@ __global__ __launch_bounds__(256) void tf_frame_kernel(const SvtHipTfParams P, c
     }
     // 4. accumulate with broadcast weights, normalise, store
     uint32_t accY[4], accU[CP], accV[CP], cntY = TF_WEIGHT_SCALE, cntU = TF_WEIGHT_SCALE, cntV = TF_WEIGHT_SCALE;
+    const uint32_t aoy = (uint32_t)ly * A.acc_stride[0] + (uint32_t)lx, aoc = (uint32_t)cy * A.acc_stride[1] + (uint32_t)cx;
+    if (A.chain & 1u) { // (workgroup-uniform) a later chunk of the reference frames: the sums so far
 #pragma unroll
-    for (int i = 0; i < 4; i++) accY[i] = TF_WEIGHT_SCALE * raw_px<PIX>(rawS, i);
+        for (int i = 0; i < 4; i++) accY[i] = A.acc[0][aoy + i];
+        cntY = A.cnt[0][aoy];
+        if (CPX) {
 #pragma unroll
-    for (int i = 0; i < CP; i++) { accU[i] = CPX ? TF_WEIGHT_SCALE * rawSU[i] : 0; accV[i] = CPX ? TF_WEIGHT_SCALE * rawSV[i] : 0; }
+            for (int i = 0; i < CP; i++) { accU[i] = A.acc[1][aoc + i]; accV[i] = A.acc[2][aoc + i]; }
+            cntU = A.cnt[1][aoc]; cntV = A.cnt[2][aoc];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) accY[i] = TF_WEIGHT_SCALE * raw_px<PIX>(rawS, i);
+#pragma unroll
+        for (int i = 0; i < CP; i++) { accU[i] = CPX ? TF_WEIGHT_SCALE * rawSU[i] : 0; accV[i] = CPX ? TF_WEIGHT_SCALE * rawSV[i] : 0; }
+    }
 #pragma unroll
     for (int r = 0; r < NR; r++) {
         const uint32_t wY = (uint32_t)__shfl((int)weight, r);
@@ -265,6 +281,17 @@ __global__ __launch_bounds__(256) void tf_frame_kernel(const SvtHipTfParams P, c
 #pragma unroll
             for (int i = 0; i < CP; i++) { accU[i] += wU * rawU[r][i]; accV[i] += wV * rawV[r][i]; }
         }
+    }
+    if (A.chain & 2u) { // not the last chunk: hand the sums on
+#pragma unroll
+        for (int i = 0; i < 4; i++) A.acc[0][aoy + i] = accY[i];
+        A.cnt[0][aoy] = (uint16_t)cntY;
+        if (CPX) {
+#pragma unroll
+            for (int i = 0; i < CP; i++) { A.acc[1][aoc + i] = accU[i]; A.acc[2][aoc + i] = accV[i]; }
+            A.cnt[1][aoc] = (uint16_t)cntU; A.cnt[2][aoc] = (uint16_t)cntV;
+        }
+        return;
     }
     Px4<PIX>    o;
     const float rY = 1.0f / (float)cntY;
@@ -430,20 +457,27 @@ void svt_hip_estimate_noise_batch(const void* plane, uint32_t width, uint32_t he
 int32_t svt_estimate_noise_fp16_hip(const uint8_t* src, uint16_t width, uint16_t height, uint16_t stride_y) { return noise_host(src, width, height, stride_y, 8); }
 int32_t svt_estimate_noise_highbd_fp16_hip(const uint16_t* src, int width, int height, int stride, int bd) { return noise_host(src, width, height, stride, bd); }
 
-void svt_hip_tf_filter_frame(const SvtHipTfParams* params, const SvtHipTfPlanes* central, const SvtHipTfPlanes* preds, uint32_t n_refs,
-                             const SvtHipTfBlock* blocks, uint32_t nbx, uint32_t nby, const SvtHipTfPlanes* out, void* stream) {
-    svthip::ensure_device();
-    if (n_refs > SVT_HIP_TF_MAX_REFS) { fprintf(stderr, "libsvtav1_hip: svt_hip_tf_filter_frame: n_refs %u > %d\n", n_refs, SVT_HIP_TF_MAX_REFS); abort(); }
-    if (!nbx || !nby) return;
+static void tf_frame_launch(const SvtHipTfParams* params, const SvtHipTfPlanes* central, const SvtHipTfPlanes* preds, uint32_t n_refs, const SvtHipTfBlock* blocks,
+                            uint32_t nbx, uint32_t nby, const SvtHipTfPlanes* out, void* state, uint32_t chain, hipStream_t st) {
     FrameArgs A;
     memset(&A, 0, sizeof(A));
-    A.central = *central; A.out = *out; A.blocks = blocks; A.n_refs = n_refs; A.nbx = nbx; A.nby = nby;
+    A.central = *central; A.out = *out; A.blocks = blocks; A.n_refs = n_refs; A.nbx = nbx; A.nby = nby; A.chain = chain;
     for (uint32_t r = 0; r < n_refs; r++) A.preds[r] = preds[r];
+    if (state) { // [acc y][acc u][acc v][cnt y][cnt u][cnt v], luma pitch 32 nbx, chroma pitch (32 nbx) >> ss_x
+        const size_t W = (size_t)nbx * 32, H = (size_t)nby * 32, cw = W >> params->ss_x, chh = H >> params->ss_y;
+        uint8_t* p = (uint8_t*)state;
+        A.acc[0] = (uint32_t*)p; p += W * H * 4;
+        A.acc[1] = (uint32_t*)p; p += cw * chh * 4;
+        A.acc[2] = (uint32_t*)p; p += cw * chh * 4;
+        A.cnt[0] = (uint16_t*)p; p += W * H * 2;
+        A.cnt[1] = (uint16_t*)p; p += cw * chh * 2;
+        A.cnt[2] = (uint16_t*)p;
+        A.acc_stride[0] = (uint32_t)W; A.acc_stride[1] = (uint32_t)cw;
+    }
     const int  cpx = !params->tf_chroma ? 0 : (16 >> params->ss_x) * (16 >> params->ss_y) / 64;
     const bool hbd = params->encoder_bit_depth > 8;
     const int  nr  = n_refs <= 2 ? 2 : (int)((n_refs + 1) & ~1u);
     const dim3 grid(nbx * nby), blk(256);
-    hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(PIX, C, NR) hipLaunchKernelGGL((tf_frame_kernel<PIX, C, NR>), grid, blk, 0, st, *params, A)
 #define BY_NR(PIX, C) do { if (nr == 2) LAUNCH(PIX, C, 2); else if (nr == 4) LAUNCH(PIX, C, 4); else if (nr == 6) LAUNCH(PIX, C, 6); else if (nr == 8) LAUNCH(PIX, C, 8); \
                            else if (nr == 10) LAUNCH(PIX, C, 10); else LAUNCH(PIX, C, 12); } while (0)
@@ -453,6 +487,31 @@ void svt_hip_tf_filter_frame(const SvtHipTfParams* params, const SvtHipTfPlanes*
 #undef BY_NR
 #undef LAUNCH
     SVT_LAUNCH_CHECK();
+}
+
+void svt_hip_tf_filter_frame(const SvtHipTfParams* params, const SvtHipTfPlanes* central, const SvtHipTfPlanes* preds, uint32_t n_refs,
+                             const SvtHipTfBlock* blocks, uint32_t nbx, uint32_t nby, const SvtHipTfPlanes* out, void* stream) {
+    svthip::ensure_device();
+    if (n_refs > SVT_HIP_TF_MAX_REFS) { fprintf(stderr, "libsvtav1_hip: svt_hip_tf_filter_frame: n_refs %u > %d\n", n_refs, SVT_HIP_TF_MAX_REFS); abort(); }
+    if (!nbx || !nby) return;
+    tf_frame_launch(params, central, preds, n_refs, blocks, nbx, nby, out, nullptr, 0, (hipStream_t)stream);
+}
+
+size_t svt_hip_tf_filter_frame_workspace(const SvtHipTfParams* params, uint32_t nbx, uint32_t nby) {
+    const size_t W = (size_t)nbx * 32, H = (size_t)nby * 32, cw = W >> params->ss_x, chh = H >> params->ss_y;
+    return (W * H + 2 * cw * chh) * 6 + 256;
+}
+void svt_hip_tf_filter_frame_chunked(const SvtHipTfParams* params, const SvtHipTfPlanes* central, const SvtHipTfPlanes* preds, uint32_t n_refs,
+                                     const SvtHipTfBlock* blocks, uint32_t nbx, uint32_t nby, const SvtHipTfPlanes* out, void* workspace, void* stream) {
+    svthip::ensure_device();
+    if (n_refs > SVT_HIP_TF_MAX_FRAMES) { fprintf(stderr, "libsvtav1_hip: svt_hip_tf_filter_frame_chunked: n_refs %u > %d\n", n_refs, SVT_HIP_TF_MAX_FRAMES); abort(); }
+    if (!nbx || !nby) return;
+    if (n_refs <= SVT_HIP_TF_MAX_REFS) { tf_frame_launch(params, central, preds, n_refs, blocks, nbx, nby, out, nullptr, 0, (hipStream_t)stream); return; }
+    for (uint32_t r0 = 0; r0 < n_refs; r0 += SVT_HIP_TF_MAX_REFS) { // the sums of the frames so far travel through the workspace; only the last launch writes pixels
+        const uint32_t n = n_refs - r0 < SVT_HIP_TF_MAX_REFS ? n_refs - r0 : SVT_HIP_TF_MAX_REFS;
+        const uint32_t chain = (r0 ? 1u : 0u) | (r0 + n < n_refs ? 2u : 0u);
+        tf_frame_launch(params, central, preds + r0, n, blocks + (size_t)r0 * nbx * nby, nbx, nby, out, workspace, chain, (hipStream_t)stream);
+    }
 }
 
 void svt_av1_apply_temporal_filter_planewise_medium_hip(const SvtHipTfParams* params, const SvtHipTfBlock* block, const uint8_t* y_src, int y_src_stride,

@@ -228,7 +228,7 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
                                        uint32_t n_refs, void* out_y, void* out_u, void* out_v, SvtHipTfPictureStats* stats) {
     svthip::ensure_device();
     const SvtHipTfPictureParams& P = *params;
-    if (n_refs == 0 || n_refs > SVT_HIP_TF_MAX_REFS || !P.pic_w_sb || !P.pic_h_sb) return -1;
+    if (n_refs == 0 || n_refs > SVT_HIP_TF_MAX_FRAMES || !P.pic_w_sb || !P.pic_h_sb) return -1;
     if (P.tf.tf_chroma && (P.tf.ss_x != 1 || P.tf.ss_y != 1)) return -1; // (the final motion compensation is built for 4:2:0)
     if (P.sp.bit_depth != 8 && P.sp.bit_depth != 10) return -1;
     const bool   hbd = P.sp.bit_depth > 8, chroma = P.tf.tf_chroma != 0, sp8 = hbd && P.subpel_8bit;
@@ -242,7 +242,9 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     for (uint32_t r = 0; r < n_refs; r++)
         if (refs[r].y_samples != central->y_samples || refs[r].uv_samples != central->uv_samples || (sp8 && !refs[r].y8)) return -1;
     const size_t y8sz = sp8 ? svthip::align_up(central->y_samples, 256) : 0;
-    const size_t dev = (1 + n_refs) * (ysz + 2 * csz + y8sz) + n_refs * (pysz + 2 * pcsz) + tables + n_sp * (sizeof(SvtHipTfSubpelDesc) + sizeof(SvtHipTfSubpelResult)) +
+    SvtHipTfParams TW = P.tf;
+    const size_t state_bytes = n_refs > SVT_HIP_TF_MAX_REFS ? svt_hip_tf_filter_frame_workspace(&TW, 2 * P.pic_w_sb, 2 * P.pic_h_sb) : 0;
+    const size_t dev = state_bytes + (1 + n_refs) * (ysz + 2 * csz + y8sz) + n_refs * (pysz + 2 * pcsz) + tables + n_sp * (sizeof(SvtHipTfSubpelDesc) + sizeof(SvtHipTfSubpelResult)) +
                        n_pairs * (MC_SLOTS * sizeof(SvtHipTfMcDesc) + 1) + nblk * sizeof(SvtHipTfBlock) + 65536;
     const size_t pin = (2 + n_refs) * (ysz + 2 * csz + y8sz) + tables + 65536; // uploads + the three downloads
     svthip::HostCall& c = svthip::host_call();
@@ -292,6 +294,7 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     A.blocks   = (SvtHipTfBlock*)c.dalloc(nblk * sizeof(SvtHipTfBlock));
     A.path64   = (uint8_t*)c.dalloc(n_pairs);
     A.stats    = (SvtHipTfPictureStats*)c.dalloc(sizeof(SvtHipTfPictureStats));
+    void* d_state = n_refs > SVT_HIP_TF_MAX_REFS ? c.dalloc(state_bytes) : nullptr; // the filter's accumulators between its launches (more than 12 frames)
     hipStream_t st = c.stream;
     HIP_CHECK(hipMemsetAsync(A.mc_descs, 0, n_pairs * MC_SLOTS * sizeof(SvtHipTfMcDesc), st));
     HIP_CHECK(hipMemsetAsync(A.stats, 0, sizeof(SvtHipTfPictureStats), st));
@@ -323,9 +326,9 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     T.encoder_bit_depth = P.sp.bit_depth;
     const size_t cpic0 = (size_t)(P.sp.ref_org_y >> 1) * P.uv_stride + (P.sp.ref_org_x >> 1);
     SvtHipTfPlanes cen = {d_cy + A.pic0 * px, d_cu + cpic0 * px, d_cv + cpic0 * px, P.sp.ref_stride, P.uv_stride};
-    SvtHipTfPlanes preds[SVT_HIP_TF_MAX_REFS];
+    SvtHipTfPlanes preds[SVT_HIP_TF_MAX_FRAMES];
     for (uint32_t r = 0; r < n_refs; r++) preds[r] = SvtHipTfPlanes{d_py + r * pysz, d_pu + r * pcsz, d_pv + r * pcsz, pw, pw / 2};
-    svt_hip_tf_filter_frame(&T, &cen, preds, n_refs, A.blocks, 2 * P.pic_w_sb, 2 * P.pic_h_sb, &cen, st);
+    svt_hip_tf_filter_frame_chunked(&T, &cen, preds, n_refs, A.blocks, 2 * P.pic_w_sb, 2 * P.pic_h_sb, &cen, d_state, st);
     // the filtered blocks (every 64x64 block in full, as get_final_filtered_pixels writes them, :2608-2672)
     c.down2d((uint8_t*)out_y + A.pic0 * px, (size_t)P.sp.ref_stride * px, cen.y, (size_t)P.sp.ref_stride * px, (size_t)pw * px, ph);
     if (chroma) {

@@ -201,12 +201,12 @@ def test_tf_planewise_symbols_hip(be, oracle, bd, zz):
 def test_tf_filter_frame_hip(be, oracle, bd, zz):
     """Whole-picture form: central + n references + normalisation in one launch vs the oracle's per-block chain; in place and out of place."""
     pkg, g = load_pkg(), rng(1400 + bd + zz)
-    for it, ss in enumerate([(1, 1), (1, 0), (0, 0), (1, 1), (0, 1), (1, 1), (1, 1), (1, 1)]):
+    for it, ss in enumerate([(1, 1), (1, 0), (0, 0), (1, 1), (0, 1), (1, 1), (1, 1), (1, 1), (1, 1)]):
         chroma = it != 3
         nbx, nby = (3, 2) if not be.is_gpu else (9, 5)
         if not be.is_gpu and it == 6:
             continue  # (the emulator keeps one of the two large reference counts)
-        n_refs = [3, 1, 6, 0, 2, 8, 9, 12][it] if be.is_gpu or it != 2 else 2  # (12 = ALTREF_MAX_NFRAMES - 1: the largest set the reference's filter uses)
+        n_refs = [3, 1, 6, 0, 2, 8, 9, 12, 27][it] if be.is_gpu or it != 2 else 2  # (27 > SVT_HIP_TF_MAX_REFS: the chunked form, three launches; the reference's filter takes up to 32)
         P = make_params(pkg, g, bd, zz, chroma, ss)
         W, H = nbx * 32, nby * 32
         cw, chh = W >> ss[0], H >> ss[1]
@@ -234,10 +234,16 @@ def test_tf_filter_frame_hip(be, oracle, bd, zz):
         cen = PL(be.ptr(d_c[0]), be.ptr(d_c[1]), be.ptr(d_c[2]), cstride[0], cstride[1])
         out = PL(be.ptr(d_o[0]), be.ptr(d_o[1]), be.ptr(d_o[2]), cstride[0], cstride[1])
         prs = (PL * max(n_refs, 1))(*[PL(be.ptr(d_p[r][0]), be.ptr(d_p[r][1]), be.ptr(d_p[r][2]), pstrides[r][0], pstrides[r][1]) for r in range(n_refs)])
-        be.lib.svt_hip_tf_filter_frame(C.addressof(P), C.addressof(cen), C.addressof(prs), n_refs, be.ptr(d_b), nbx, nby, C.addressof(out), be.stream)
+        def frame(dst):
+            if n_refs > 12:
+                ws = be.empty(be.lib.svt_hip_tf_filter_frame_workspace(C.addressof(P), nbx, nby), np.uint8)
+                be.lib.svt_hip_tf_filter_frame_chunked(C.addressof(P), C.addressof(cen), C.addressof(prs), n_refs, be.ptr(d_b), nbx, nby, C.addressof(dst), be.ptr(ws), be.stream)
+            else:
+                be.lib.svt_hip_tf_filter_frame(C.addressof(P), C.addressof(cen), C.addressof(prs), n_refs, be.ptr(d_b), nbx, nby, C.addressof(dst), be.stream)
+        frame(out)
         for c in range(3 if chroma else 1):
             assert np.array_equal(be.host(d_o[c]), want[c]), (bd, zz, it, c, "out of place")
-        be.lib.svt_hip_tf_filter_frame(C.addressof(P), C.addressof(cen), C.addressof(prs), n_refs, be.ptr(d_b), nbx, nby, C.addressof(cen), be.stream)
+        frame(cen)
         for c in range(3 if chroma else 1):
             assert np.array_equal(be.host(d_c[c]), want[c]), (bd, zz, it, c, "in place")
 

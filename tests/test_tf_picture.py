@@ -83,13 +83,14 @@ CASES = [(8, 2, 0, 0, 0, True, False, 0, True, False),          # every 32x32 go
          (8, 3, 20, 900, 3000, False, True, 1, True, False),    # tf_use_64x64_pred, early exits, bilinear searches, sub-sampled distortions; odd reference count
          (8, 1, 255, 0, 1 << 20, False, False, 0, False, True), # 64x64 only; luma only; the zero-motion filter
          (10, 2, 35, 500, 20000, True, False, 1, True, False),  # 10 bit
-         (10, 2, 30, 300, 2500, False, True, 1, True, False)]   # 10 bit with the searches on the 8-bit luma (tf_ctrls.use_8bit_subpel)
+         (10, 2, 30, 300, 2500, False, True, 1, True, False),   # 10 bit with the searches on the 8-bit luma (tf_ctrls.use_8bit_subpel)
+         (8, 14, 25, 400, 3000, False, False, 0, True, False)]  # more frames than one launch of the filter takes (chunked accumulation)
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_tf_picture_stage(be, oracle, case):
     bd, n_refs, th64, exit_th, th32, with8, two_tap, ss, chroma, zz = CASES[case]
-    if not be.is_gpu and case == 3:
+    if not be.is_gpu and case in (3, 5):
         pytest.skip("emulator: the 10-bit case runs on the GPU (the u16 paths of every piece are covered by their own emulator tests)")
     W, H, PAD = (320, 200, 80) if be.is_gpu else ((64, 72, 80) if case in (0, 4) else (128, 72, 80))  # (a partial last block row: H is not a multiple of 64)
     g = rng(500 + case)
