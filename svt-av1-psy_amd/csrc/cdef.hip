@@ -744,7 +744,8 @@ void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost* a) {
         total += 2 * pitch[p] * rows[p];
     }
     const size_t side = (size_t)nfb * 64 * (1 + 4) + (size_t)nvfb * 8 * nhfb * 8 + (size_t)nfb * 4 * 4 + 16384;
-    svthip::HostCall& c = svthip::host_call();
+    svthip::HostCallLease lease; // (a pooled arena: see svt_hip_common.h)
+    svthip::HostCall& c = *lease;
     c.begin();
     c.reserve(total + side, total + side);
     uint8_t* d_skip = (uint8_t*)c.dalloc((size_t)nvfb * 8 * nhfb * 8);
@@ -791,7 +792,8 @@ void svt_hip_cdef_search_host(const SvtHipCdefSearchHost* a) {
     }
     const size_t nmse = (size_t)nfb * (a->ncand_y + 2 * (size_t)a->ncand_uv);
     const size_t side = (size_t)nfb * 64 * 5 + (size_t)nvfb * 8 * nhfb * 8 + nmse * 8 + ((size_t)a->ncand_y + a->ncand_uv) * 8 + 16384;
-    svthip::HostCall& c = svthip::host_call();
+    svthip::HostCallLease lease; // (a pooled arena: see svt_hip_common.h)
+    svthip::HostCall& c = *lease;
     c.begin();
     c.reserve(total + side, total + side + nmse * 8);
     uint8_t* d_skip = (uint8_t*)c.dalloc((size_t)nvfb * 8 * nhfb * 8);

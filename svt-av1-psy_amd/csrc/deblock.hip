@@ -197,7 +197,8 @@ void svt_hip_lpf_plane_host(void* plane, uint32_t stride, uint32_t width, uint32
     svthip::ensure_device();
     if (n_vert + n_horz == 0) return;
     const size_t px = is_16bit ? 2 : 1, M = 16, pitch = svthip::align_up((width + 2 * M) * px, 16), nb = (size_t)(n_vert + n_horz) * sizeof(SvtHipLpfEdge);
-    svthip::HostCall& c = svthip::host_call();
+    svthip::HostCallLease lease; // (a pooled arena: see svt_hip_common.h)
+    svthip::HostCall& c = *lease;
     c.begin();
     c.reserve(pitch * height + nb + 8192, 2 * pitch * height + nb + 8192);
     uint8_t*       d  = (uint8_t*)c.dalloc(pitch * height);

@@ -723,7 +723,8 @@ int svt_hip_lr_search_plane_host(const SvtHipLrSearchParams* params, const SvtHi
     const size_t px = P.highbd ? 2 : 1, w = P.width, h = P.height;
     const size_t dpitch = svthip::align_up((w + 8) * px, 16), spitch = svthip::align_up(w * px, 16);
     const int    n = n_units_1d((int)h, (int)P.unit_size) * n_units_1d((int)w, (int)P.unit_size);
-    svthip::HostCall& c = svthip::host_call();
+    svthip::HostCallLease lease; // (a pooled arena: see svt_hip_common.h)
+    svthip::HostCall& c = *lease;
     c.begin();
     P.dgd_stride = (uint32_t)(dpitch / px); P.src_stride = (uint32_t)(spitch / px);
     const size_t wsb = carve(P, nullptr, nullptr);

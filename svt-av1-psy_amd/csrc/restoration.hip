@@ -215,7 +215,8 @@ void svt_hip_lr_filter_frame_host(const SvtHipLrParams* params) {
     int nvu = ((int)h + (us >> 1)) / us, nhu = ((int)w + (us >> 1)) / us;
     nvu = nvu > 0 ? nvu : 1; nhu = nhu > 0 ? nhu : 1;
     const size_t ub = (size_t)nvu * nhu * sizeof(SvtHipLrUnit);
-    svthip::HostCall& c = svthip::host_call();
+    svthip::HostCallLease lease; // (a pooled arena: see svt_hip_common.h)
+    svthip::HostCall& c = *lease;
     c.begin();
     c.reserve(pitch * (2 * h + 4 * n_stripes) + ub + 8192, pitch * (2 * h + 4 * n_stripes) + ub + 8192);
     uint8_t* d_data  = (uint8_t*)c.dalloc(pitch * h);

@@ -1,4 +1,6 @@
 // runtime.hip -- device binding, per-thread host-call context, instruction self-test.
+#include <mutex>
+#include <vector>
 #include <atomic>
 
 #include "svt_hip_common.h"
@@ -52,6 +54,26 @@ HostCall& host_call() {
     HostCall& c = t_calls[current_device()];
     if (!c.stream) HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     return c;
+}
+
+static std::mutex              g_lease_m;
+static std::vector<HostCall*> g_lease_pool[MAX_DEVICES];
+HostCallLease::HostCallLease() {
+    ensure_device();
+    device = current_device();
+    c = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_lease_m);
+        if (!g_lease_pool[device].empty()) { c = g_lease_pool[device].back(); g_lease_pool[device].pop_back(); }
+    }
+    if (!c) {
+        c = new HostCall();
+        HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
+}
+HostCallLease::~HostCallLease() {
+    std::lock_guard<std::mutex> g(g_lease_m);
+    g_lease_pool[device].push_back(c); // (most recently used first: the arena that has already grown is the one that is taken again)
 }
 
 void HostCall::begin() {

@@ -82,6 +82,19 @@ struct HostCall {
     void sync();
 };
 HostCall& host_call();
+// The stage-sized host forms (a whole picture's planes per call: svt_hip_tf_picture_host, svt_hip_tpl_src_stage_host, the CDEF / LR / deblocking / sub-pel host forms)
+// do not use the calling thread's own arena: an encoder calls them from dozens of worker threads, and every thread growing a private 20-50 MB pinned + device arena
+// on its first call costs 10-20 ms each (pinned allocation).  They lease an arena from a per-device pool for the duration of the call instead -- as many arenas as
+// calls are ever in flight at once.  (All of these forms synchronise before they return, so a returned arena is idle.)
+struct HostCallLease {
+    HostCall* c;
+    int       device;
+    HostCallLease();
+    ~HostCallLease();
+    HostCallLease(const HostCallLease&) = delete;
+    HostCallLease& operator=(const HostCallLease&) = delete;
+    HostCall& operator*() { return *c; }
+};
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

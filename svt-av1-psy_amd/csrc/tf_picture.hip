@@ -247,7 +247,8 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     const size_t dev = state_bytes + (1 + n_refs) * (ysz + 2 * csz + y8sz) + n_refs * (pysz + 2 * pcsz) + tables + n_sp * (sizeof(SvtHipTfSubpelDesc) + sizeof(SvtHipTfSubpelResult)) +
                        n_pairs * (MC_SLOTS * sizeof(SvtHipTfMcDesc) + 1) + nblk * sizeof(SvtHipTfBlock) + 65536;
     const size_t pin = (2 + n_refs) * (ysz + 2 * csz + y8sz) + tables + 65536; // uploads + the three downloads
-    svthip::HostCall& c = svthip::host_call();
+    svthip::HostCallLease lease; // (a pooled arena: see svt_hip_common.h)
+    svthip::HostCall& c = *lease;
     c.begin();
     c.reserve(dev, pin);
     // pictures: central, then the references back to back (descriptor offsets are relative to reference 0)

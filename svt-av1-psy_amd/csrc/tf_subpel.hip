@@ -350,7 +350,8 @@ extern "C" void svt_hip_tf_subpel_search_host(const SvtHipTfSubpelParams* params
     svthip::ensure_device();
     if (n == 0) return;
     const size_t px = params->bit_depth > 8 ? 2 : 1, db = (size_t)n * sizeof(SvtHipTfSubpelDesc), rb = (size_t)n * sizeof(SvtHipTfSubpelResult);
-    svthip::HostCall& c = svthip::host_call();
+    svthip::HostCallLease lease; // (a pooled arena: see svt_hip_common.h)
+    svthip::HostCall& c = *lease;
     c.begin();
     c.reserve((src_samples + ref_samples) * px + db + rb + 8192, (src_samples + ref_samples) * px + db + rb + 8192);
     void* d_src = c.dalloc(src_samples * px);

@@ -273,7 +273,8 @@ int svt_hip_tpl_src_stage_host(const SvtHipTplSrcParams* params, const SvtHipTpl
     }
     size_t total = 0;
     for (int b = 0; b < nb; b++) { doff[b] = total; total += svthip::align_up(bytes[b], 256); }
-    svthip::HostCall& c = svthip::host_call();
+    svthip::HostCallLease lease; // (a pooled arena: see svt_hip_common.h)
+    svthip::HostCall& c = *lease;
     c.begin();
     const size_t side = tot_b + mv_b + cand_b + cells * sizeof(SvtHipTplSrcStats) + 8192;
     c.reserve(total + side + 4096, total + side + cells * sizeof(SvtHipTplSrcStats) + 4096);
