@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-.}
 ulimit -c 0
-O=gpurun_out/r03_call11; mkdir -p $O
-timeout 600 python -m pytest tests/test_tf_picture.py tests/test_tf.py -q -m gpu -x > $O/pytest.txt 2>&1; tail -1 $O/pytest.txt
-for h in c avx2; do timeout 900 python tools/enc_identity.py --case fps_1080p_p6_all,fps_1080p_p8_all --host $h --out /tmp/fps_$h > $O/fps_$h.log 2>&1; grep -a "identical=\|encoder fps\|MISMATCH\|returned" $O/fps_$h.log | cut -c1-130; grep -ao "'ms_in_stage_calls': [0-9]*\|'ms_in_me_pairs': [0-9]*\|'pictures_filtered': [0-9]*, 'pictures_declined': [0-9]*, 'reference_frames': [0-9]*\|'last_decline': '[^']*'" $O/fps_$h.log | tr '\n' ' '; echo; done
+O=gpurun_out/r03_call13; mkdir -p $O
+for i in 1 2 3 4; do timeout 900 python tools/enc_identity.py --case fps_1080p_p8_all_300,fps_1080p_p8_all --host avx2 --out /tmp/fps_avx2_$i > $O/fps_avx2_$i.log 2>&1; grep -a "identical=\|encoder fps\|MISMATCH\|returned" $O/fps_avx2_$i.log | cut -c1-100; done
+timeout 900 python tools/enc_identity.py --case fps_4k8_p8_all,fps_1080p_p6_all,fps_1080p_p4_all --host avx2 --out /tmp/fps_avx2_x > $O/fps_avx2_x.log 2>&1; grep -a "identical=\|encoder fps\|MISMATCH\|returned" $O/fps_avx2_x.log | cut -c1-100
