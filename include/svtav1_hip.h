@@ -33,6 +33,11 @@ void        svt_hip_shutdown(void);
 const char *svt_hip_device_name(void);
 /* one-time costs of the calling thread's device (context, code-object loading, first allocations) paid now instead of inside the first real call */
 void svt_hip_warmup(void);
+/* Page-locks a host buffer the caller will hand to the host-pointer forms again and again (an encoder's picture buffers): copies from / to it then go by DMA without
+ * the runtime's staging pass.  Portable across devices.  0 on success; a buffer that is already registered, or that the runtime refuses, is left as it is (non-zero) --
+ * registration is an optimisation, never a requirement.  Unregister before the buffer is freed. */
+int svt_hip_host_register(void *buffer, size_t bytes);
+int svt_hip_host_unregister(void *buffer);
 /* Several GPUs from one process (frame-level sharding): the device is selected PER HOST THREAD, like HIP's own current device.  svt_hip_set_thread_device(d)
  * binds the calling thread to device d for every later call of this library on that thread (host-call arenas and streams are per thread AND device); -1 returns the
  * thread to the default device of svt_hip_init.  Returns 0, or -1 when d is not a device.  Objects that live on a device (ME sessions) remember it and make it current

@@ -95,10 +95,19 @@ static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
 #include "svt_malloc.h"
 #include "sys_resource_manager.h"
 void svt_hip_seam_me_prepare(const void *pa_reference_object); /* integration/me_process_seam.c */
+void svt_hip_seam_me_register_buffer(void *buffer, size_t bytes);
 static void svt_hip_after_enc_init(EbEncHandle *h) {
     if (!getenv("SVT_HIP") || !getenv("SVT_HIP_ME_SEAM") || !h || !h->pa_reference_picture_pool_ptr_array) return;
     EbSystemResource *pool = h->pa_reference_picture_pool_ptr_array[0];
-    if (pool && pool->object_total_count && pool->wrapper_ptr_pool && pool->wrapper_ptr_pool[0]) svt_hip_seam_me_prepare(pool->wrapper_ptr_pool[0]->object_ptr);
+    if (!pool || !pool->object_total_count || !pool->wrapper_ptr_pool || !pool->wrapper_ptr_pool[0]) return;
+    svt_hip_seam_me_prepare(pool->wrapper_ptr_pool[0]->object_ptr);
+    /* the 8-bit luma planes every ME stage call uploads (the y8b pool of :1781-1796; pa_ref->input_padded_pic->buffer_y points into it): page-locked once, here */
+    EbSystemResource *y8b = h->input_y8b_buffer_resource_ptr;
+    for (uint32_t i = 0; y8b && y8b->wrapper_ptr_pool && i < y8b->object_total_count; i++) {
+        const EbBufferHeaderType *hdr = y8b->wrapper_ptr_pool[i] ? (const EbBufferHeaderType *)y8b->wrapper_ptr_pool[i]->object_ptr : NULL;
+        const EbPictureBufferDesc *pic = hdr ? (const EbPictureBufferDesc *)hdr->p_buffer : NULL;
+        if (pic && pic->buffer_y) svt_hip_seam_me_register_buffer(pic->buffer_y, pic->luma_size);
+    }
 }
 #undef svt_print_memory_usage
 #define svt_print_memory_usage() svt_hip_after_enc_init(enc_handle_ptr)

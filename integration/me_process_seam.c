@@ -74,7 +74,7 @@ static struct {
     SeamPicture     rec[SEAM_RECS];
     uint64_t        sum[SEAM_DEVS][SEAM_RING * 2][2]; /* per device: (picture id, plane checksum) of what is resident */
     uint64_t        n_per_dev[SEAM_DEVS];
-    uint64_t        n_pictures, n_declined, n_sb, n_uploads, n_reuploads;
+    uint64_t        n_pictures, n_declined, n_sb, n_uploads, n_reuploads, n_registered;
     double          t_stage, t_hash, t_first, t_dev_lock; /* seconds: in run_picture / run_tf_pair (all threads), hashing planes, the first stage call (session creation,
                                                            * kernel code loading), holding the device lock */
     char            why[128];
@@ -87,6 +87,7 @@ static void seam_stats(void) {
     const char *f = getenv("SVT_HIP_ME_SEAM_STATS");
     FILE       *o = f ? fopen(f, "w") : NULL;
     if (!o) return;
+    fprintf(o, "picture_buffers_page_locked %llu\n", (unsigned long long)G.n_registered);
     fprintf(o, "pictures_offloaded %llu\npictures_declined %llu\nsb_results %llu\nplane_uploads %llu\nplane_reuploads %llu\nlast_decline %s\n",
             (unsigned long long)G.n_pictures, (unsigned long long)G.n_declined, (unsigned long long)G.n_sb, (unsigned long long)G.n_uploads,
             (unsigned long long)G.n_reuploads, G.why[0] ? G.why : "-");
@@ -304,6 +305,15 @@ void svt_hip_seam_me_prepare(const void *pa_reference_object) {
         }
         pthread_mutex_unlock(&G.dev[di]);
     }
+}
+/* Also at init, for every picture of the encoder's 8-bit luma pool (input_y8b_buffer_resource_ptr: the planes pa_ref->input_padded_pic->buffer_y points at,
+ * resource_coordination_process.c:1130 -- what every ME stage call uploads): the buffer is page-locked, so that the upload is one DMA instead of a staged copy
+ * from pageable memory (svt_hip_host_register; a refusal leaves the buffer as it is). */
+void svt_hip_seam_me_register_buffer(void *buffer, size_t bytes) {
+    if (!seam_on() || !buffer || !bytes) return;
+    static int (*reg)(void *, size_t);
+    if (!reg) *(void **)&reg = dlsym(RTLD_DEFAULT, "svt_hip_host_register");
+    if (reg && reg(buffer, bytes) == 0) __atomic_fetch_add(&G.n_registered, 1, __ATOMIC_RELAXED);
 }
 static int ensure_session(int di, PictureParentControlSet *pcs, const EbPictureBufferDesc *src) {
     if (!G.session[di]) create_session(di, (const EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr);

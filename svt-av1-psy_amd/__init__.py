@@ -40,6 +40,8 @@ PROTOTYPES = {
     "svt_hip_device_name": (C.c_char_p, []),
     "svt_hip_tuning_reload": (None, []),
     "svt_hip_warmup": (None, []),
+    "svt_hip_host_register": (C.c_int, [vp, C.c_size_t]),
+    "svt_hip_host_unregister": (C.c_int, [vp]),
     "svt_hip_device_count": (C.c_int, []),
     "svt_hip_set_thread_device": (C.c_int, [C.c_int]),
     "svt_hip_get_thread_device": (C.c_int, []),

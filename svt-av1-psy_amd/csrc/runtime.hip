@@ -329,6 +329,20 @@ void svt_hip_warmup(void) {
     c.sync();
 }
 
+int svt_hip_host_register(void* buffer, size_t bytes) {
+    svthip::ensure_device();
+    if (!buffer || !bytes) return -1;
+    const hipError_t e = hipHostRegister(buffer, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; } // (already registered, or not lockable: the caller keeps using it as pageable memory)
+    return 0;
+}
+int svt_hip_host_unregister(void* buffer) {
+    svthip::ensure_device();
+    const hipError_t e = hipHostUnregister(buffer);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    return 0;
+}
+
 int svt_hip_selftest(uint32_t* results, void* stream) {
     svthip::ensure_device();
     hipLaunchKernelGGL(svt_hip_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, results);

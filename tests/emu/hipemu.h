@@ -517,6 +517,9 @@ inline hipError_t hipFree(void* p) {
 }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = aligned_alloc(256, (n + 255) & ~size_t(255)); return *p ? hipSuccess : 2; }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+enum { hipHostRegisterPortable = 1 };
+inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { hipemu::check_ptr(d, "hipMemcpy"); hipemu::check_ptr(s, "hipMemcpy"); memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st = nullptr) {
     hipemu::check_stream(st, "hipMemcpyAsync"); hipemu::check_ptr(d, "hipMemcpyAsync"); hipemu::check_ptr(s, "hipMemcpyAsync");
