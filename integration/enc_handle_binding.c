@@ -109,6 +109,21 @@ static void svt_hip_after_enc_init(EbEncHandle *h) {
         if (pic && pic->buffer_y) svt_hip_seam_me_register_buffer(pic->buffer_y, pic->luma_size);
     }
 }
+/* ... and the page locks are released at the start of svt_av1_enc_deinit (enc_handle.c:2364: its first svt_shutdown_process call; queues are drained by then), before
+ * svt_av1_enc_deinit_handle destroys the pool that owns the buffers. */
+void svt_hip_seam_me_unregister_buffer(void *buffer);
+static void svt_hip_before_enc_deinit(EbEncHandle *h) {
+    static int done;
+    if (done || !getenv("SVT_HIP") || !getenv("SVT_HIP_ME_SEAM") || !h) return;
+    done = 1;
+    EbSystemResource *y8b = h->input_y8b_buffer_resource_ptr;
+    for (uint32_t i = 0; y8b && y8b->wrapper_ptr_pool && i < y8b->object_total_count; i++) {
+        const EbBufferHeaderType *hdr = y8b->wrapper_ptr_pool[i] ? (const EbBufferHeaderType *)y8b->wrapper_ptr_pool[i]->object_ptr : NULL;
+        const EbPictureBufferDesc *pic = hdr ? (const EbPictureBufferDesc *)hdr->p_buffer : NULL;
+        if (pic && pic->buffer_y) svt_hip_seam_me_unregister_buffer(pic->buffer_y);
+    }
+}
+#define svt_shutdown_process(r) (svt_hip_before_enc_deinit(handle), svt_shutdown_process(r)) /* (every use is inside svt_av1_enc_deinit, where `handle` is the encoder) */
 #undef svt_print_memory_usage
 #define svt_print_memory_usage() svt_hip_after_enc_init(enc_handle_ptr)
 

@@ -315,6 +315,12 @@ void svt_hip_seam_me_register_buffer(void *buffer, size_t bytes) {
     if (!reg) *(void **)&reg = dlsym(RTLD_DEFAULT, "svt_hip_host_register");
     if (reg && reg(buffer, bytes) == 0) __atomic_fetch_add(&G.n_registered, 1, __ATOMIC_RELAXED);
 }
+void svt_hip_seam_me_unregister_buffer(void *buffer) { /* before the pool that owns the buffer is destroyed */
+    if (!seam_on() || !buffer || !G.n_registered) return;
+    static int (*unreg)(void *);
+    if (!unreg) *(void **)&unreg = dlsym(RTLD_DEFAULT, "svt_hip_host_unregister");
+    if (unreg) unreg(buffer);
+}
 static int ensure_session(int di, PictureParentControlSet *pcs, const EbPictureBufferDesc *src) {
     if (!G.session[di]) create_session(di, (const EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr);
     if (src->width != G.width || src->height != G.height || src->stride_y != G.stride || src->org_x != G.org_x || src->org_y != G.org_y)
