@@ -118,7 +118,17 @@ void HostCall::up2d(void* ddst, size_t dpitch, const void* hsrc, size_t spitch, 
     for (size_t y = 0; y < rows; y++) memcpy(p + y * dpitch, (const uint8_t*)hsrc + y * spitch, width_bytes);
     HIP_CHECK(hipMemcpyAsync(ddst, p, dpitch * rows, hipMemcpyHostToDevice, stream));
 }
+// page-locked by the caller (svt_hip_host_register, or its own pinned allocation)?  Then the copy engine reads it directly: no staging pass through the arena.
+static bool host_is_locked(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; } // (plain malloc memory is unknown to the runtime)
+    return a.type == hipMemoryTypeHost;
+}
 void HostCall::up(void* ddst, const void* hsrc, size_t bytes) {
+    if (bytes >= (256u << 10) && host_is_locked(hsrc)) { // (every host form synchronises before it returns: the source outlives the copy)
+        HIP_CHECK(hipMemcpyAsync(ddst, hsrc, bytes, hipMemcpyHostToDevice, stream));
+        return;
+    }
     uint8_t* p = (uint8_t*)palloc(bytes);
     memcpy(p, hsrc, bytes);
     HIP_CHECK(hipMemcpyAsync(ddst, p, bytes, hipMemcpyHostToDevice, stream));
