@@ -1022,6 +1022,59 @@ typedef struct SvtHipTplHostPlanes {
 int svt_hip_tpl_src_stage_host(const SvtHipTplSrcParams *params, const SvtHipTplHostPlanes *planes, const uint8_t *total_me_candidate_index,
                                const uint32_t *me_mv_array, const uint8_t *me_candidate_array, SvtHipTplSrcStats *stats);
 
+/* ---- the fixed-size symbols of the RTCD tables (what svt_hip_setup_rtcd installs): thin aliases of the generic forms above, declared here so that a caller can
+ * also bind them by name.  Prototypes as the reference's pointers (aom_dsp_rtcd.h / common_dsp_rtcd.h). ---- */
+#define SVT_HIP_FOR_ALL_SAD_SIZES(X)                                                                                                              \
+    X(128, 128) X(128, 64) X(64, 128) X(64, 64) X(64, 32) X(32, 64) X(32, 32) X(32, 16) X(16, 32) X(16, 16) X(16, 8) X(8, 16) X(8, 8) X(8, 4) X(4, 8) \
+    X(4, 4) X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
+#define SVT_HIP_SAD_DECL(W, H)                                                                                              \
+    uint32_t svt_aom_sad##W##x##H##_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride);            \
+    void     svt_aom_sad##W##x##H##x4d_hip(const uint8_t *src, int src_stride, const uint8_t *const ref_array[], int ref_stride, uint32_t *sad_array);
+SVT_HIP_FOR_ALL_SAD_SIZES(SVT_HIP_SAD_DECL)
+#undef SVT_HIP_SAD_DECL
+#define SVT_HIP_FOR_ALL_TX_SIZES(X)                                                                                                                \
+    X(4, 4) X(8, 8) X(16, 16) X(32, 32) X(64, 64) X(4, 8) X(8, 4) X(8, 16) X(16, 8) X(16, 32) X(32, 16) X(32, 64) X(64, 32) X(4, 16) X(16, 4) X(8, 32) \
+    X(32, 8) X(16, 64) X(64, 16)
+#define SVT_HIP_FWD_DECL(W, H)                                                                                                        \
+    void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd);           \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd);        \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd);
+SVT_HIP_FOR_ALL_TX_SIZES(SVT_HIP_FWD_DECL)
+#undef SVT_HIP_FWD_DECL
+/* inverse: squares (input, r, stride_r, w, stride_w, tx_type, bd); 4x8 / 8x4 / 4x16 / 16x4 add tx_size; the rest add tx_size, eob (common_dsp_rtcd.h:106-116) */
+#define SVT_HIP_INV_SQ_DECL(N) \
+    void svt_av1_inv_txfm2d_add_##N##x##N##_hip(const int32_t *in, uint16_t *r, int32_t sr, uint16_t *w, int32_t sw, uint8_t tx_type, int32_t bd);
+#define SVT_HIP_INV_R1_DECL(W, H) \
+    void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *in, uint16_t *r, int32_t sr, uint16_t *w, int32_t sw, uint8_t tx_type, uint8_t tx_size, int32_t bd);
+#define SVT_HIP_INV_R2_DECL(W, H) \
+    void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *in, uint16_t *r, int32_t sr, uint16_t *w, int32_t sw, uint8_t tx_type, uint8_t tx_size, int32_t eob, int32_t bd);
+SVT_HIP_INV_SQ_DECL(4) SVT_HIP_INV_SQ_DECL(8) SVT_HIP_INV_SQ_DECL(16) SVT_HIP_INV_SQ_DECL(32) SVT_HIP_INV_SQ_DECL(64)
+SVT_HIP_INV_R1_DECL(4, 8) SVT_HIP_INV_R1_DECL(8, 4) SVT_HIP_INV_R1_DECL(4, 16) SVT_HIP_INV_R1_DECL(16, 4)
+SVT_HIP_INV_R2_DECL(8, 16) SVT_HIP_INV_R2_DECL(16, 8) SVT_HIP_INV_R2_DECL(16, 32) SVT_HIP_INV_R2_DECL(32, 16) SVT_HIP_INV_R2_DECL(32, 64) SVT_HIP_INV_R2_DECL(64, 32)
+SVT_HIP_INV_R2_DECL(8, 32) SVT_HIP_INV_R2_DECL(32, 8) SVT_HIP_INV_R2_DECL(16, 64) SVT_HIP_INV_R2_DECL(64, 16)
+#undef SVT_HIP_INV_SQ_DECL
+#undef SVT_HIP_INV_R1_DECL
+#undef SVT_HIP_INV_R2_DECL
+/* the ten quantizer pointers (aom_dsp_rtcd.h: svt_aom_quantize_b ... svt_av1_highbd_quantize_fp_qm) and the ten svt_handle_transformWxH[_N2_N4] */
+#define SVT_HIP_QARGS                                                                                                                       \
+    const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,                \
+        const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, \
+        const int16_t *iscan
+void svt_aom_quantize_b_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, const int32_t log_scale);
+void svt_aom_highbd_quantize_b_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, const int32_t log_scale);
+void svt_av1_quantize_fp_hip(SVT_HIP_QARGS);
+void svt_av1_quantize_fp_32x32_hip(SVT_HIP_QARGS);
+void svt_av1_quantize_fp_64x64_hip(SVT_HIP_QARGS);
+void svt_av1_quantize_fp_qm_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale);
+void svt_av1_highbd_quantize_fp_hip(SVT_HIP_QARGS, int16_t log_scale);
+void svt_av1_highbd_quantize_fp_qm_hip(SVT_HIP_QARGS, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale);
+#undef SVT_HIP_QARGS
+#define SVT_HIP_HT_DECL(W, H)                                   \
+    uint64_t svt_handle_transform##W##x##H##_hip(int32_t *output); \
+    uint64_t svt_handle_transform##W##x##H##_N2_N4_hip(int32_t *output);
+SVT_HIP_HT_DECL(64, 64) SVT_HIP_HT_DECL(32, 64) SVT_HIP_HT_DECL(64, 32) SVT_HIP_HT_DECL(16, 64) SVT_HIP_HT_DECL(64, 16)
+#undef SVT_HIP_HT_DECL
+
 #ifdef __cplusplus
 }
 #endif

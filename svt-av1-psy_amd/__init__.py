@@ -33,7 +33,7 @@ MeSearchDesc = np.dtype([("src_off", "<u8"), ("ref_off", "<u8"), ("src_stride", 
                          ("x_origin", "<i2"), ("y_origin", "<i2"), ("width", "<u2"), ("height", "<u2")])
 assert SadPair.itemsize == 24 and SadLoopDesc.itemsize == 40 and SadLoopResult.itemsize == 16 and MeSearchDesc.itemsize == 32
 
-# symbol -> (restype, argtypes); everything include/svtav1_hip.h declares must be listed here (tests check both ways)
+# symbol -> (restype, argtypes); exactly the functions include/svtav1_hip.h declares (tests/test_abi.py checks both directions and the libraries' exports)
 PROTOTYPES = {
     "svt_hip_init": (C.c_int, [C.c_int]),
     "svt_hip_shutdown": (None, []),
