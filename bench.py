@@ -391,10 +391,13 @@ def encoder_fps():
         have_x = os.path.exists(ei.ENC_AVX2)
         r = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="avx2" if have_x else "c")
         rc_ = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="c") if have_x else r  # the round-1/2 figure: C-only host + stages, for continuity
-    if not r.get("identical") or not rc_.get("identical"):
+        r300 = ei.run_case("fps_1080p_p8_all_300", lib, td, timeout=600, host="avx2") if have_x else {}  # steady state: the clip looped five times
+    if not r.get("identical") or not rc_.get("identical") or (r300 and not r300.get("identical")):
         sys.exit("bench.py: the encoder's bitstream with the stage seams differs from the C-only encoder -- no numbers recorded (%s)" % r.get("stderr_tail", ""))
     return {"fps_c_only": r.get("fps_c"), "fps_avx2_intrinsics": r.get("fps_avx2"), "fps_avx2_host_with_stage_seams": r.get("fps_hip") if have_x else None,
-            "fps_c_host_with_stage_seams": rc_.get("fps_hip"), "bitstream_identical": True, "avx2_bitstream_identical_to_c": r.get("avx2_identical_to_c"),
+            "fps_c_host_with_stage_seams": rc_.get("fps_hip"), "bitstream_identical": True,
+            "steady_state_300_frames": {"fps_c_only": r300.get("fps_c"), "fps_avx2_intrinsics": r300.get("fps_avx2"), "fps_avx2_host_with_stage_seams": r300.get("fps_hip"),
+                                        "note": "single run each; run-to-run spread on this box class is +- 5 % (profiles/r03_call13..15)"} if r300 else None, "avx2_bitstream_identical_to_c": r.get("avx2_identical_to_c"),
             "frames": r["frames"], "host_threads": len(os.sched_getaffinity(0)),
             "host_ms_per_me_stage_call": (lambda m: round(m.get("ms_in_stage_calls", 0) / max(m.get("pictures_offloaded", 0) + m.get("tf_pairs_offloaded", 0), 1), 3))(r.get("seam") or {}),
             "host_ms_first_stage_call": (r.get("seam") or {}).get("ms_first_stage_call"),
