@@ -567,6 +567,19 @@ typedef struct SvtHipTfPictureStats { /* what the decisions were (sums over bloc
 } SvtHipTfPictureStats;
 int svt_hip_tf_picture_host(const SvtHipTfPictureParams *params, const SvtHipTfHostPicture *central, const SvtHipTfHostPicture *refs, const SvtHipTfMeTables *me,
                             uint32_t n_refs, void *out_y, void *out_u, void *out_v, SvtHipTfPictureStats *stats /* or NULL */);
+/* Device-resident form (for a caller whose pictures and ME tables are in HBM already, e.g. right after the ME stage): the reference frames' planes lie back to back
+ * (ref_pitch / ref_uv_pitch samples apart), the ME tables are device arrays over all frames ([n_refs][n_sb][85] ...: `me` points to ONE SvtHipTfMeTables of device
+ * pointers), the filtered 64x64 blocks replace the central picture in place, stats_dev (or NULL) receives the counts; asynchronous on `stream`. */
+typedef struct SvtHipTfDevicePictures {
+    void    *central[3];               /* the central picture's padded planes (first samples) */
+    void    *refs[3];                  /* first reference frame's planes; frame r at + r * ref_pitch / ref_uv_pitch samples */
+    uint64_t ref_pitch, ref_uv_pitch;  /* samples */
+    void    *central_y8, *refs_y8;     /* subpel_8bit: the 8-bit luma copies (refs_y8: frames ref_y8_pitch samples apart); else NULL */
+    uint64_t ref_y8_pitch;
+} SvtHipTfDevicePictures;
+size_t svt_hip_tf_picture_workspace(const SvtHipTfPictureParams *params, uint32_t n_refs); /* bytes; 0 for parameters outside what is built */
+int    svt_hip_tf_picture(const SvtHipTfPictureParams *params, const SvtHipTfDevicePictures *pictures, const SvtHipTfMeTables *me, uint32_t n_refs, void *workspace,
+                          SvtHipTfPictureStats *stats_dev, void *stream);
 
 /* The whole open-loop ME stage from a HOST picture: upload -> quarter / sixteenth planes (made once per picture on the device, kept in the ring
  * with the full plane) -> HME levels 0-2 -> final search centre + integer_search_b64 geometry + full-pel search -> MeSbResults (+ raw tables on

@@ -114,6 +114,8 @@ PROTOTYPES = {
     "svt_hip_tf_inter_pred_batch": (None, [vp, vp, vp, C.c_uint32, C.c_int, vp]),
     "svt_hip_tf_subpel_search_host": (None, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, vp]),
     "svt_hip_tf_picture_host": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp]),
+    "svt_hip_tf_picture_workspace": (C.c_size_t, [vp, C.c_uint32]),
+    "svt_hip_tf_picture": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp]),
     "svt_hip_tf_filter_frame_workspace": (C.c_size_t, [vp, C.c_uint32, C.c_uint32]),
     "svt_hip_tf_filter_frame_chunked": (None, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, vp]),
     "svt_hip_lr_filter_frame_host": (None, [vp]),
@@ -352,6 +354,11 @@ class TfPictureParams(C.Structure):
 class TfHostPicture(C.Structure):
     """SvtHipTfHostPicture: whole padded host buffers of one picture."""
     _fields_ = [("y", vp), ("u", vp), ("v", vp), ("y_samples", C.c_size_t), ("uv_samples", C.c_size_t), ("y8", vp)]
+
+
+class TfDevicePictures(C.Structure):
+    """SvtHipTfDevicePictures: device-resident pictures of svt_hip_tf_picture."""
+    _fields_ = [("central", vp * 3), ("refs", vp * 3), ("ref_pitch", C.c_uint64), ("ref_uv_pitch", C.c_uint64), ("central_y8", vp), ("refs_y8", vp), ("ref_y8_pitch", C.c_uint64)]
 
 
 class TfMeTables(C.Structure):

@@ -224,43 +224,136 @@ __global__ __launch_bounds__(256) void tf_pic_var32_kernel(const PicArgs A, cons
 
 } // namespace
 
+namespace {
+struct PicSizes {
+    size_t px, n_sb, per_sb, n_pairs, n_sp, nblk, pysz, pcsz, state_bytes;
+    uint32_t pw, ph;
+};
+PicSizes pic_sizes(const SvtHipTfPictureParams& P, uint32_t n_refs) {
+    PicSizes z;
+    z.px = P.sp.bit_depth > 8 ? 2 : 1;
+    z.n_sb = (size_t)P.pic_w_sb * P.pic_h_sb; z.per_sb = 21 + (P.enable_8x8_pred ? 64 : 0);
+    z.pw = 64 * P.pic_w_sb; z.ph = 64 * P.pic_h_sb;
+    z.pysz = svthip::align_up((size_t)z.pw * z.ph * z.px, 256); z.pcsz = svthip::align_up((size_t)(z.pw / 2) * (z.ph / 2) * z.px, 256);
+    z.n_pairs = n_refs * z.n_sb; z.n_sp = z.n_pairs * z.per_sb; z.nblk = (size_t)n_refs * 4 * z.n_sb;
+    SvtHipTfParams TW = P.tf;
+    z.state_bytes = n_refs > SVT_HIP_TF_MAX_REFS ? svt_hip_tf_filter_frame_workspace(&TW, 2 * P.pic_w_sb, 2 * P.pic_h_sb) : 0;
+    return z;
+}
+bool pic_params_ok(const SvtHipTfPictureParams& P, uint32_t n_refs) {
+    if (n_refs == 0 || n_refs > SVT_HIP_TF_MAX_FRAMES || !P.pic_w_sb || !P.pic_h_sb) return false;
+    if (P.tf.tf_chroma && (P.tf.ss_x != 1 || P.tf.ss_y != 1)) return false; // (the final motion compensation is built for 4:2:0)
+    return P.sp.bit_depth == 8 || P.sp.bit_depth == 10;
+}
+} // namespace
+
+extern "C" size_t svt_hip_tf_picture_workspace(const SvtHipTfPictureParams* params, uint32_t n_refs) {
+    if (!pic_params_ok(*params, n_refs)) return 0;
+    const PicSizes z = pic_sizes(*params, n_refs);
+    return z.state_bytes + n_refs * (z.pysz + 2 * z.pcsz) + z.n_sp * (sizeof(SvtHipTfSubpelDesc) + sizeof(SvtHipTfSubpelResult)) + z.n_pairs * (MC_SLOTS * sizeof(SvtHipTfMcDesc) + 1) +
+           z.nblk * sizeof(SvtHipTfBlock) + sizeof(SvtHipTfPictureStats) + 16 * 256;
+}
+
+// Device-resident form: the pictures and the pairs' ME tables are in HBM already (e.g. left there by the ME stage), the filtered 64x64 blocks replace the central picture
+// in place, nothing touches the host.
+extern "C" int svt_hip_tf_picture(const SvtHipTfPictureParams* params, const SvtHipTfDevicePictures* pics, const SvtHipTfMeTables* me, uint32_t n_refs, void* workspace,
+                                  SvtHipTfPictureStats* stats_dev, void* stream) {
+    svthip::ensure_device();
+    const SvtHipTfPictureParams& P = *params;
+    if (!pic_params_ok(P, n_refs)) return -1;
+    const bool hbd = P.sp.bit_depth > 8, chroma = P.tf.tf_chroma != 0, sp8 = hbd && P.subpel_8bit;
+    if (sp8 && (!pics->central_y8 || !pics->refs_y8)) return -1;
+    const PicSizes z = pic_sizes(P, n_refs);
+    const size_t px = z.px, n_pairs = z.n_pairs;
+    uint8_t* w = (uint8_t*)workspace;
+    auto take = [&](size_t bytes) { uint8_t* p = w; w += svthip::align_up(bytes, 256); return p; };
+    uint8_t *d_cy = (uint8_t*)pics->central[0], *d_cu = (uint8_t*)pics->central[1], *d_cv = (uint8_t*)pics->central[2];
+    uint8_t *d_ry = (uint8_t*)pics->refs[0], *d_ru = (uint8_t*)pics->refs[1], *d_rv = (uint8_t*)pics->refs[2];
+    uint8_t* d_py = take(z.pysz * n_refs);
+    uint8_t* d_pu = take(z.pcsz * n_refs);
+    uint8_t* d_pv = take(z.pcsz * n_refs);
+    PicArgs A;
+    memset(&A, 0, sizeof(A));
+    A.P = P; A.n_refs = n_refs; A.n_sb = (uint32_t)z.n_sb; A.per_sb = (uint32_t)z.per_sb;
+    A.pic0 = (uint64_t)P.sp.ref_org_y * P.sp.ref_stride + P.sp.ref_org_x;
+    A.ref_pitch = pics->ref_pitch; A.sp_ref_pitch = sp8 ? pics->ref_y8_pitch : pics->ref_pitch; A.uv_pitch = pics->ref_uv_pitch;
+    A.pred_y_pitch = z.pysz / px; A.pred_uv_pitch = z.pcsz / px; A.pred_y_stride = z.pw; A.pred_uv_stride = z.pw / 2;
+    A.best_sad = me->best_sad; A.best_mv = me->best_mv; A.hme_sc = me->hme_sc; A.hme_sad = (const unsigned long long*)me->hme_sad;
+    A.sp_descs = (SvtHipTfSubpelDesc*)take(z.n_sp * sizeof(SvtHipTfSubpelDesc));
+    A.sp_res   = (SvtHipTfSubpelResult*)take(z.n_sp * sizeof(SvtHipTfSubpelResult));
+    A.mc_descs = (SvtHipTfMcDesc*)take(n_pairs * MC_SLOTS * sizeof(SvtHipTfMcDesc));
+    A.blocks   = (SvtHipTfBlock*)take(z.nblk * sizeof(SvtHipTfBlock));
+    A.path64   = take(n_pairs);
+    SvtHipTfPictureStats* own_stats = (SvtHipTfPictureStats*)take(sizeof(SvtHipTfPictureStats));
+    A.stats    = stats_dev ? stats_dev : own_stats;
+    void* d_state = z.state_bytes ? take(z.state_bytes) : nullptr; // the filter's accumulators between its launches (more than 12 frames)
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipMemsetAsync(A.mc_descs, 0, n_pairs * MC_SLOTS * sizeof(SvtHipTfMcDesc), st));
+    HIP_CHECK(hipMemsetAsync(A.stats, 0, sizeof(SvtHipTfPictureStats), st));
+    // 1. sub-pel refinement in three passes: a size is searched only where the reference would search it
+    SvtHipTfSubpelParams SP = P.sp;
+    if (sp8) SP.bit_depth = 8;
+    for (int level = 0; level < 3; level++) {
+        const size_t per = level == 0 ? 1 : (level == 1 ? 4 : z.per_sb - 5), first = level == 0 ? 0 : (level == 1 ? n_pairs : 5 * n_pairs), cnt = n_pairs * per;
+        hipLaunchKernelGGL(tf_pic_descs_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, A, level);
+        SVT_LAUNCH_CHECK();
+        svt_hip_tf_subpel_search_batch(&SP, sp8 ? pics->central_y8 : (const void*)d_cy, sp8 ? pics->refs_y8 : (const void*)d_ry, A.sp_descs + first, (uint32_t)cnt, A.sp_res + first, st);
+    }
+    // 2. decisions
+    hipLaunchKernelGGL(tf_pic_decide_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, A);
+    SVT_LAUNCH_CHECK();
+    // 3. final motion compensation into picture-sized planes
+    SvtHipTfMcPlanes PL;
+    memset(&PL, 0, sizeof(PL));
+    PL.ref[0] = d_ry; PL.ref[1] = d_ru; PL.ref[2] = d_rv; PL.pred[0] = d_py; PL.pred[1] = d_pu; PL.pred[2] = d_pv;
+    PL.ref_stride[0] = P.sp.ref_stride; PL.ref_stride[1] = PL.ref_stride[2] = P.uv_stride;
+    PL.pred_stride[0] = z.pw; PL.pred_stride[1] = PL.pred_stride[2] = z.pw / 2;
+    svt_hip_tf_inter_pred_batch(&P.sp, &PL, A.mc_descs, (uint32_t)(n_pairs * MC_SLOTS), chroma ? 1 : 0, st);
+    // 4. the 32x32 errors of the 64x64 predictions
+    if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_pic_var32_kernel<uint16_t>), dim3((unsigned)n_pairs), dim3(256), 0, st, A, (const uint16_t*)d_cy, (const uint16_t*)d_py);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_pic_var32_kernel<uint8_t>), dim3((unsigned)n_pairs), dim3(256), 0, st, A, (const uint8_t*)d_cy, (const uint8_t*)d_py);
+    SVT_LAUNCH_CHECK();
+    // 5. the filter, in place on the central picture
+    SvtHipTfParams T = P.tf;
+    T.encoder_bit_depth = P.sp.bit_depth;
+    const size_t cpic0 = (size_t)(P.sp.ref_org_y >> 1) * P.uv_stride + (P.sp.ref_org_x >> 1);
+    SvtHipTfPlanes cen = {d_cy + A.pic0 * px, d_cu ? d_cu + cpic0 * px : nullptr, d_cv ? d_cv + cpic0 * px : nullptr, P.sp.ref_stride, P.uv_stride};
+    SvtHipTfPlanes preds[SVT_HIP_TF_MAX_FRAMES];
+    for (uint32_t r = 0; r < n_refs; r++) preds[r] = SvtHipTfPlanes{d_py + r * z.pysz, d_pu + r * z.pcsz, d_pv + r * z.pcsz, z.pw, z.pw / 2};
+    svt_hip_tf_filter_frame_chunked(&T, &cen, preds, n_refs, A.blocks, 2 * P.pic_w_sb, 2 * P.pic_h_sb, &cen, d_state, st);
+    return 0;
+}
+
 extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, const SvtHipTfHostPicture* central, const SvtHipTfHostPicture* refs, const SvtHipTfMeTables* me,
                                        uint32_t n_refs, void* out_y, void* out_u, void* out_v, SvtHipTfPictureStats* stats) {
     svthip::ensure_device();
     const SvtHipTfPictureParams& P = *params;
-    if (n_refs == 0 || n_refs > SVT_HIP_TF_MAX_FRAMES || !P.pic_w_sb || !P.pic_h_sb) return -1;
-    if (P.tf.tf_chroma && (P.tf.ss_x != 1 || P.tf.ss_y != 1)) return -1; // (the final motion compensation is built for 4:2:0)
-    if (P.sp.bit_depth != 8 && P.sp.bit_depth != 10) return -1;
+    if (!pic_params_ok(P, n_refs)) return -1;
     const bool   hbd = P.sp.bit_depth > 8, chroma = P.tf.tf_chroma != 0, sp8 = hbd && P.subpel_8bit;
     if (sp8 && !central->y8) return -1;
-    const size_t px = hbd ? 2 : 1, n_sb = (size_t)P.pic_w_sb * P.pic_h_sb, per_sb = 21 + (P.enable_8x8_pred ? 64 : 0);
+    const PicSizes z = pic_sizes(P, n_refs);
+    const size_t px = z.px, n_sb = z.n_sb, n_pairs = z.n_pairs;
     const size_t ysz = svthip::align_up(central->y_samples * px, 256), csz = svthip::align_up(central->uv_samples * px, 256);
-    const uint32_t pw = 64 * P.pic_w_sb, ph = 64 * P.pic_h_sb;
-    const size_t pysz = svthip::align_up((size_t)pw * ph * px, 256), pcsz = svthip::align_up((size_t)(pw / 2) * (ph / 2) * px, 256);
-    const size_t n_pairs = n_refs * n_sb, n_sp = n_pairs * per_sb, nblk = (size_t)n_refs * 4 * n_sb;
-    const size_t tables = n_pairs * (85 * 4 * 2 + 4 + 8);
+    const size_t tables = n_pairs * (85 * 4 * 2 + 4 + 8) + 4 * 256;
     for (uint32_t r = 0; r < n_refs; r++)
         if (refs[r].y_samples != central->y_samples || refs[r].uv_samples != central->uv_samples || (sp8 && !refs[r].y8)) return -1;
     const size_t y8sz = sp8 ? svthip::align_up(central->y_samples, 256) : 0;
-    SvtHipTfParams TW = P.tf;
-    const size_t state_bytes = n_refs > SVT_HIP_TF_MAX_REFS ? svt_hip_tf_filter_frame_workspace(&TW, 2 * P.pic_w_sb, 2 * P.pic_h_sb) : 0;
-    const size_t dev = state_bytes + (1 + n_refs) * (ysz + 2 * csz + y8sz) + n_refs * (pysz + 2 * pcsz) + tables + n_sp * (sizeof(SvtHipTfSubpelDesc) + sizeof(SvtHipTfSubpelResult)) +
-                       n_pairs * (MC_SLOTS * sizeof(SvtHipTfMcDesc) + 1) + nblk * sizeof(SvtHipTfBlock) + 65536;
+    const size_t wsb  = svt_hip_tf_picture_workspace(params, n_refs);
+    const size_t dev = wsb + (1 + n_refs) * (ysz + 2 * csz + y8sz) + tables + 65536;
     const size_t pin = (2 + n_refs) * (ysz + 2 * csz + y8sz) + tables + 65536; // uploads + the three downloads
     svthip::HostCallLease lease; // (a pooled arena: see svt_hip_common.h)
     svthip::HostCall& c = *lease;
     c.begin();
     c.reserve(dev, pin);
     // pictures: central, then the references back to back (descriptor offsets are relative to reference 0)
+    SvtHipTfDevicePictures D;
+    memset(&D, 0, sizeof(D));
     uint8_t* d_cy = (uint8_t*)c.dalloc(ysz);
     uint8_t* d_cu = (uint8_t*)c.dalloc(csz);
     uint8_t* d_cv = (uint8_t*)c.dalloc(csz);
     uint8_t* d_ry = (uint8_t*)c.dalloc(ysz * n_refs);
     uint8_t* d_ru = (uint8_t*)c.dalloc(csz * n_refs);
     uint8_t* d_rv = (uint8_t*)c.dalloc(csz * n_refs);
-    uint8_t* d_py = (uint8_t*)c.dalloc(pysz * n_refs);
-    uint8_t* d_pu = (uint8_t*)c.dalloc(pcsz * n_refs);
-    uint8_t* d_pv = (uint8_t*)c.dalloc(pcsz * n_refs);
     uint8_t* d_c8 = sp8 ? (uint8_t*)c.dalloc(y8sz) : nullptr;
     uint8_t* d_r8 = sp8 ? (uint8_t*)c.dalloc(y8sz * n_refs) : nullptr;
     if (sp8) {
@@ -273,70 +366,31 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
         c.up(d_ry + r * ysz, refs[r].y, refs[r].y_samples * px);
         if (chroma) { c.up(d_ru + r * csz, refs[r].u, refs[r].uv_samples * px); c.up(d_rv + r * csz, refs[r].v, refs[r].uv_samples * px); }
     }
-    PicArgs A;
-    memset(&A, 0, sizeof(A));
-    A.P = P; A.n_refs = n_refs; A.n_sb = (uint32_t)n_sb; A.per_sb = (uint32_t)per_sb;
-    A.pic0 = (uint64_t)P.sp.ref_org_y * P.sp.ref_stride + P.sp.ref_org_x;
-    A.ref_pitch = ysz / px; A.sp_ref_pitch = sp8 ? y8sz : ysz / px; A.uv_pitch = csz / px; A.pred_y_pitch = pysz / px; A.pred_uv_pitch = pcsz / px; A.pred_y_stride = pw; A.pred_uv_stride = pw / 2;
+    D.central[0] = d_cy; D.central[1] = d_cu; D.central[2] = d_cv; D.refs[0] = d_ry; D.refs[1] = d_ru; D.refs[2] = d_rv;
+    D.ref_pitch = ysz / px; D.ref_uv_pitch = csz / px; D.central_y8 = d_c8; D.refs_y8 = d_r8; D.ref_y8_pitch = y8sz;
     uint32_t* d_sad = (uint32_t*)c.dalloc(n_pairs * 85 * 4);
     uint32_t* d_mv  = (uint32_t*)c.dalloc(n_pairs * 85 * 4);
     int16_t*  d_sc  = (int16_t*)c.dalloc(n_pairs * 4);
-    unsigned long long* d_hs = (unsigned long long*)c.dalloc(n_pairs * 8);
+    uint64_t* d_hs  = (uint64_t*)c.dalloc(n_pairs * 8);
     for (uint32_t r = 0; r < n_refs; r++) {
         c.up(d_sad + r * n_sb * 85, me[r].best_sad, n_sb * 85 * 4);
         c.up(d_mv + r * n_sb * 85, me[r].best_mv, n_sb * 85 * 4);
         c.up(d_sc + r * n_sb * 2, me[r].hme_sc, n_sb * 4);
         c.up(d_hs + r * n_sb, me[r].hme_sad, n_sb * 8);
     }
-    A.best_sad = d_sad; A.best_mv = d_mv; A.hme_sc = d_sc; A.hme_sad = d_hs;
-    A.sp_descs = (SvtHipTfSubpelDesc*)c.dalloc(n_sp * sizeof(SvtHipTfSubpelDesc));
-    A.sp_res   = (SvtHipTfSubpelResult*)c.dalloc(n_sp * sizeof(SvtHipTfSubpelResult));
-    A.mc_descs = (SvtHipTfMcDesc*)c.dalloc(n_pairs * MC_SLOTS * sizeof(SvtHipTfMcDesc));
-    A.blocks   = (SvtHipTfBlock*)c.dalloc(nblk * sizeof(SvtHipTfBlock));
-    A.path64   = (uint8_t*)c.dalloc(n_pairs);
-    A.stats    = (SvtHipTfPictureStats*)c.dalloc(sizeof(SvtHipTfPictureStats));
-    void* d_state = n_refs > SVT_HIP_TF_MAX_REFS ? c.dalloc(state_bytes) : nullptr; // the filter's accumulators between its launches (more than 12 frames)
-    hipStream_t st = c.stream;
-    HIP_CHECK(hipMemsetAsync(A.mc_descs, 0, n_pairs * MC_SLOTS * sizeof(SvtHipTfMcDesc), st));
-    HIP_CHECK(hipMemsetAsync(A.stats, 0, sizeof(SvtHipTfPictureStats), st));
-    // 1. sub-pel refinement in three passes: a size is searched only where the reference would search it
-    SvtHipTfSubpelParams SP = P.sp;
-    if (sp8) SP.bit_depth = 8;
-    for (int level = 0; level < 3; level++) {
-        const size_t per = level == 0 ? 1 : (level == 1 ? 4 : per_sb - 5), first = level == 0 ? 0 : (level == 1 ? n_pairs : 5 * n_pairs), cnt = n_pairs * per;
-        hipLaunchKernelGGL(tf_pic_descs_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, A, level);
-        SVT_LAUNCH_CHECK();
-        svt_hip_tf_subpel_search_batch(&SP, sp8 ? d_c8 : d_cy, sp8 ? d_r8 : d_ry, A.sp_descs + first, (uint32_t)cnt, A.sp_res + first, st);
-    }
-    // 2. decisions
-    hipLaunchKernelGGL(tf_pic_decide_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, A);
-    SVT_LAUNCH_CHECK();
-    // 3. final motion compensation into picture-sized planes
-    SvtHipTfMcPlanes PL;
-    memset(&PL, 0, sizeof(PL));
-    PL.ref[0] = d_ry; PL.ref[1] = d_ru; PL.ref[2] = d_rv; PL.pred[0] = d_py; PL.pred[1] = d_pu; PL.pred[2] = d_pv;
-    PL.ref_stride[0] = P.sp.ref_stride; PL.ref_stride[1] = PL.ref_stride[2] = P.uv_stride;
-    PL.pred_stride[0] = pw; PL.pred_stride[1] = PL.pred_stride[2] = pw / 2;
-    svt_hip_tf_inter_pred_batch(&P.sp, &PL, A.mc_descs, (uint32_t)(n_pairs * MC_SLOTS), chroma ? 1 : 0, st);
-    // 4. the 32x32 errors of the 64x64 predictions
-    if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_pic_var32_kernel<uint16_t>), dim3((unsigned)n_pairs), dim3(256), 0, st, A, (const uint16_t*)d_cy, (const uint16_t*)d_py);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_pic_var32_kernel<uint8_t>), dim3((unsigned)n_pairs), dim3(256), 0, st, A, (const uint8_t*)d_cy, (const uint8_t*)d_py);
-    SVT_LAUNCH_CHECK();
-    // 5. the filter, in place on the device copy of the central picture
-    SvtHipTfParams T = P.tf;
-    T.encoder_bit_depth = P.sp.bit_depth;
-    const size_t cpic0 = (size_t)(P.sp.ref_org_y >> 1) * P.uv_stride + (P.sp.ref_org_x >> 1);
-    SvtHipTfPlanes cen = {d_cy + A.pic0 * px, d_cu + cpic0 * px, d_cv + cpic0 * px, P.sp.ref_stride, P.uv_stride};
-    SvtHipTfPlanes preds[SVT_HIP_TF_MAX_FRAMES];
-    for (uint32_t r = 0; r < n_refs; r++) preds[r] = SvtHipTfPlanes{d_py + r * pysz, d_pu + r * pcsz, d_pv + r * pcsz, pw, pw / 2};
-    svt_hip_tf_filter_frame_chunked(&T, &cen, preds, n_refs, A.blocks, 2 * P.pic_w_sb, 2 * P.pic_h_sb, &cen, d_state, st);
+    SvtHipTfMeTables M = {d_sad, d_mv, d_sc, d_hs};
+    SvtHipTfPictureStats* d_stats = (SvtHipTfPictureStats*)c.dalloc(sizeof(SvtHipTfPictureStats));
+    void* d_ws = c.dalloc(wsb);
+    const int rc = svt_hip_tf_picture(params, &D, &M, n_refs, d_ws, d_stats, c.stream);
+    if (rc) { c.sync(); return rc; }
     // the filtered blocks (every 64x64 block in full, as get_final_filtered_pixels writes them, :2608-2672)
-    c.down2d((uint8_t*)out_y + A.pic0 * px, (size_t)P.sp.ref_stride * px, cen.y, (size_t)P.sp.ref_stride * px, (size_t)pw * px, ph);
+    const size_t pic0 = (size_t)P.sp.ref_org_y * P.sp.ref_stride + P.sp.ref_org_x, cpic0 = (size_t)(P.sp.ref_org_y >> 1) * P.uv_stride + (P.sp.ref_org_x >> 1);
+    c.down2d((uint8_t*)out_y + pic0 * px, (size_t)P.sp.ref_stride * px, d_cy + pic0 * px, (size_t)P.sp.ref_stride * px, (size_t)z.pw * px, z.ph);
     if (chroma) {
-        c.down2d((uint8_t*)out_u + cpic0 * px, (size_t)P.uv_stride * px, cen.u, (size_t)P.uv_stride * px, (size_t)(pw / 2) * px, ph / 2);
-        c.down2d((uint8_t*)out_v + cpic0 * px, (size_t)P.uv_stride * px, cen.v, (size_t)P.uv_stride * px, (size_t)(pw / 2) * px, ph / 2);
+        c.down2d((uint8_t*)out_u + cpic0 * px, (size_t)P.uv_stride * px, d_cu + cpic0 * px, (size_t)P.uv_stride * px, (size_t)(z.pw / 2) * px, z.ph / 2);
+        c.down2d((uint8_t*)out_v + cpic0 * px, (size_t)P.uv_stride * px, d_cv + cpic0 * px, (size_t)P.uv_stride * px, (size_t)(z.pw / 2) * px, z.ph / 2);
     }
-    if (stats) c.down(stats, A.stats, sizeof(SvtHipTfPictureStats));
+    if (stats) c.down(stats, d_stats, sizeof(SvtHipTfPictureStats));
     c.sync();
     return 0;
 }
