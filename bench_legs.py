@@ -994,7 +994,7 @@ def tf_picture_stage(torch, lib, pkg, stream, steps, warmup, keep=None, size=(19
                 d_c[pl].copy_(d_c0[pl])  # (the stage filters in place: every timed call starts from the unfiltered picture)
             assert lib.svt_hip_tf_picture(C.byref(P), C.byref(D), C.byref(M), n_refs, ws.data_ptr(), None, stream) == 0
         td = _time(torch, dev_run, steps, warmup, batches=3)
-        same = all(np.array_equal(d_c[pl].cpu().numpy(), out[pl]) for pl in range(3))
+        same = all(np.array_equal(d_c[pl].cpu().numpy().reshape(out[pl].shape), out[pl]) for pl in range(3))
         if not same:
             raise SystemExit("bench: svt_hip_tf_picture (resident form) differs from svt_hip_tf_picture_host -- no numbers recorded")
         resident = {"tf_picture_stage_1080p8_4refs_resident": {"us": td * 1e6, "pictures_per_s": 1 / td, "equals_host_form": True,

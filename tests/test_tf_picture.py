@@ -78,6 +78,28 @@ def run_device(be, P, pics, tabs):
     return out, np.array([st.blocks_64x64, st.blocks_32x32, st.blocks_16x16, st.blocks_8x8, st.early_exit_blocks], np.uint32)
 
 
+def run_resident(be, P, pics, tabs):
+    """svt_hip_tf_picture: pictures and ME tables resident on the device, reference frames back to back, filtered in place"""
+    pkg, n_refs = be.pkg, len(tabs)
+    d_c = [be.dev(x) for x in pics[0]]
+    d_r = [be.dev(np.concatenate([pics[1 + r][pl].reshape(-1) for r in range(n_refs)])) for pl in range(3)]
+    d_t = [be.dev(np.concatenate([tabs[r][k].reshape(-1).view(np.uint8) for r in range(n_refs)])) for k in range(4)]
+    D = pkg.TfDevicePictures()
+    for pl in range(3):
+        D.central[pl], D.refs[pl] = be.ptr(d_c[pl]), be.ptr(d_r[pl])
+    D.ref_pitch, D.ref_uv_pitch = pics[0][0].size, pics[0][1].size
+    if P.subpel_8bit:
+        d_c8 = be.dev(np.ascontiguousarray((pics[0][0] >> 2).astype(np.uint8)))
+        d_r8 = be.dev(np.concatenate([(pics[1 + r][0] >> 2).astype(np.uint8).reshape(-1) for r in range(n_refs)]))
+        D.central_y8, D.refs_y8, D.ref_y8_pitch = be.ptr(d_c8), be.ptr(d_r8), pics[0][0].size
+    M = pkg.TfMeTables(*[be.ptr(x) for x in d_t])
+    ws = be.empty(be.lib.svt_hip_tf_picture_workspace(C.byref(P), n_refs), np.uint8)
+    d_st = be.empty(32, np.uint8)
+    assert be.lib.svt_hip_tf_picture(C.byref(P), C.byref(D), C.byref(M), n_refs, be.ptr(ws), be.ptr(d_st), be.stream) == 0
+    be.sync()
+    return [be.host(x) for x in d_c], be.host(d_st).view(np.uint32)[:5]
+
+
 #        bd  n_refs th64 exit_th th32    8x8 2tap ss chroma zz
 CASES = [(8, 2, 0, 0, 0, True, False, 0, True, False),          # every 32x32 goes through derive_tf_32x32_block_split_flag, with 8x8
          (8, 3, 20, 900, 3000, False, True, 1, True, False),    # tf_use_64x64_pred, early exits, bilinear searches, sub-sampled distortions; odd reference count
@@ -100,6 +122,10 @@ def test_tf_picture_stage(be, oracle, case):
     assert np.array_equal(wstats, gstats), (wstats, gstats)
     for pl in range(3):
         assert np.array_equal(want[pl], got[pl]), (case, pl, int((want[pl] != got[pl]).sum()))
+    res, rstats = run_resident(be, P, pics, tabs)  # the device-resident form: same result, in place
+    assert np.array_equal(rstats, gstats), (rstats, gstats)
+    for pl in range(3 if chroma else 1):
+        assert np.array_equal(res[pl], got[pl]), (case, pl, "resident form", int((res[pl] != got[pl]).sum()))
     assert not np.array_equal(want[0], pics[0][0])  # the filter changed the picture
     if not chroma:
         assert np.array_equal(got[1], pics[0][1]) and np.array_equal(got[2], pics[0][2])
