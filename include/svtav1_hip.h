@@ -521,6 +521,9 @@ typedef struct SvtHipTfMcDesc {
     uint16_t pad2[3];
 } SvtHipTfMcDesc;
 void svt_hip_tf_inter_pred_batch(const SvtHipTfSubpelParams *params, const SvtHipTfMcPlanes *planes, const SvtHipTfMcDesc *descs, uint32_t n, int chroma, void *stream);
+/* the same over a list whose length another kernel left in device memory (n_dev[0] <= max_n): the waves walk it with a grid stride, no host round trip for the count */
+void svt_hip_tf_inter_pred_list(const SvtHipTfSubpelParams *params, const SvtHipTfMcPlanes *planes, const SvtHipTfMcDesc *descs, uint32_t max_n, const uint32_t *n_dev,
+                                int chroma, void *stream);
 
 /* The temporal filter of ONE central picture as a single device stage: produce_temporally_filtered_pic's per-block loop (temporal_filtering.c:3037-3400) for every
  * 64x64 block and every reference picture the caller kept (the picture-level skips of :3105-3131 -- ahd error, brightness change -- are the caller's), given the

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "svt_hip_tf_filter_frame": (None, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_tf_subpel_search_batch": (None, [vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svt_hip_tf_inter_pred_batch": (None, [vp, vp, vp, C.c_uint32, C.c_int, vp]),
+    "svt_hip_tf_inter_pred_list": (None, [vp, vp, vp, C.c_uint32, vp, C.c_int, vp]),
     "svt_hip_tf_subpel_search_host": (None, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, vp]),
     "svt_hip_tf_picture_host": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp]),
     "svt_hip_tf_picture_workspace": (C.c_size_t, [vp, C.c_uint32]),

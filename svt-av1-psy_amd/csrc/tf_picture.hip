@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int MC_SLOTS = 64; // motion-compensation descriptors per (block, reference): 1 (64x64) .. 64 (all 8x8); unused ones keep bsize 0
+constexpr int MC_SLOTS = 64; // motion-compensation descriptors per (block, reference) at most: 1 (64x64) .. 64 (all 8x8) -- the capacity of the picture's list
 
 struct PicArgs {
     SvtHipTfPictureParams P;
@@ -31,7 +31,8 @@ struct PicArgs {
     const unsigned long long* hme_sad;    // [n_refs][n_sb]
     SvtHipTfSubpelDesc*       sp_descs;   // [n_refs][n_sb][per_sb]: three regions, one per pass -- [pair] | [pair][4] | [pair][per_sb - 5]
     SvtHipTfSubpelResult*     sp_res;     // same layout
-    SvtHipTfMcDesc*           mc_descs;   // [n_refs][n_sb][MC_SLOTS]
+    SvtHipTfMcDesc*           mc_descs;   // a list (capacity n_refs * n_sb * MC_SLOTS) the decision kernel appends to
+    uint32_t*                 mc_count;   // its length
     SvtHipTfBlock*            blocks;     // [n_refs][2 pic_h_sb][2 pic_w_sb]
     uint8_t*                  path64;     // [n_refs][n_sb]
     SvtHipTfPictureStats*     stats;
@@ -111,8 +112,7 @@ __global__ __launch_bounds__(64) void tf_pic_decide_kernel(const PicArgs A) {
     const bool exited = A.hme_sad[pair] < A.P.me_exit_th;
     const bool p64    = only_64x64_before_search(A, pair) || pred_64x64_wins(A, pair);
     A.path64[pair] = p64 ? 1 : 0;
-    SvtHipTfMcDesc* M = A.mc_descs + (size_t)pair * MC_SLOTS; // (zeroed by the host: unused slots keep bsize 0)
-    auto mc = [&](const int k, const int slot, const int16_t mvx, const int16_t mvy) {
+    auto mc = [&](const int, const int slot, const int16_t mvx, const int16_t mvy) { // appends to the picture's list: the order of the entries does not matter
         int bs, lx, ly;
         slot_geometry(slot, bs, lx, ly);
         SvtHipTfMcDesc d;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void tf_pic_decide_kernel(const PicArgs A) {
         d.pred_off[0] = (uint64_t)ref * A.pred_y_pitch; d.pred_off[1] = d.pred_off[2] = (uint64_t)ref * A.pred_uv_pitch;
         d.pu_x = (uint16_t)(x0 + lx); d.pu_y = (uint16_t)(y0 + ly); d.bsize = (uint8_t)bs; d.pad = 0; d.mv_x = mvx; d.mv_y = mvy;
         d.pad2[0] = d.pad2[1] = d.pad2[2] = 0;
-        M[k] = d;
+        A.mc_descs[atomicAdd(A.mc_count, 1u)] = d;
     };
     const uint32_t nbx = 2 * A.P.pic_w_sb, nby = 2 * A.P.pic_h_sb;
     uint32_t n64 = 0, n32 = 0, n16 = 0, n8 = 0;
@@ -288,7 +288,8 @@ extern "C" int svt_hip_tf_picture(const SvtHipTfPictureParams* params, const Svt
     A.stats    = stats_dev ? stats_dev : own_stats;
     void* d_state = z.state_bytes ? take(z.state_bytes) : nullptr; // the filter's accumulators between its launches (more than 12 frames)
     hipStream_t st = (hipStream_t)stream;
-    HIP_CHECK(hipMemsetAsync(A.mc_descs, 0, n_pairs * MC_SLOTS * sizeof(SvtHipTfMcDesc), st));
+    A.mc_count = (uint32_t*)take(256);
+    HIP_CHECK(hipMemsetAsync(A.mc_count, 0, 4, st));
     HIP_CHECK(hipMemsetAsync(A.stats, 0, sizeof(SvtHipTfPictureStats), st));
     // 1. sub-pel refinement in three passes: a size is searched only where the reference would search it
     SvtHipTfSubpelParams SP = P.sp;
@@ -308,7 +309,7 @@ extern "C" int svt_hip_tf_picture(const SvtHipTfPictureParams* params, const Svt
     PL.ref[0] = d_ry; PL.ref[1] = d_ru; PL.ref[2] = d_rv; PL.pred[0] = d_py; PL.pred[1] = d_pu; PL.pred[2] = d_pv;
     PL.ref_stride[0] = P.sp.ref_stride; PL.ref_stride[1] = PL.ref_stride[2] = P.uv_stride;
     PL.pred_stride[0] = z.pw; PL.pred_stride[1] = PL.pred_stride[2] = z.pw / 2;
-    svt_hip_tf_inter_pred_batch(&P.sp, &PL, A.mc_descs, (uint32_t)(n_pairs * MC_SLOTS), chroma ? 1 : 0, st);
+    svt_hip_tf_inter_pred_list(&P.sp, &PL, A.mc_descs, (uint32_t)(n_pairs * MC_SLOTS), A.mc_count, chroma ? 1 : 0, st);
     // 4. the 32x32 errors of the 64x64 predictions
     if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_pic_var32_kernel<uint16_t>), dim3((unsigned)n_pairs), dim3(256), 0, st, A, (const uint16_t*)d_cy, (const uint16_t*)d_py);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_pic_var32_kernel<uint8_t>), dim3((unsigned)n_pairs), dim3(256), 0, st, A, (const uint8_t*)d_cy, (const uint8_t*)d_py);

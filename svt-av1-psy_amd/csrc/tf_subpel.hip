@@ -271,17 +271,20 @@ __global__ __launch_bounds__(256) void tf_subpel_kernel(const SvtHipTfSubpelPara
 // svt_aom_inter_prediction's uni-directional SIMPLE_TRANSLATION path with MULTITAP_SHARP kernels (the 4-tap regular kernel for a chroma dimension <= 4), the MV
 // clamped per plane, the chroma block at ((pu >> 3) << 3) / 2; the prediction lands in a picture-sized plane at the block's position (what
 // svt_hip_tf_filter_frame reads).
+// (n_dev: the descriptor count lives in device memory -- a list another kernel just appended to; the waves then walk the list with a grid stride instead of one wave per slot)
 template <typename PIX>
-__global__ __launch_bounds__(256) void tf_mc_kernel(const SvtHipTfSubpelParams P, const SvtHipTfMcPlanes PL, const SvtHipTfMcDesc* __restrict__ descs, const uint32_t n,
-                                                    const int chroma) {
+__global__ __launch_bounds__(256) void tf_mc_kernel(const SvtHipTfSubpelParams P, const SvtHipTfMcPlanes PL, const SvtHipTfMcDesc* __restrict__ descs, const uint32_t n_host,
+                                                    const uint32_t* __restrict__ n_dev, const int chroma) {
     HIP_DYNAMIC_SHARED(uint32_t, smem)
     const int      l = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t item = blockIdx.x * 4 + (uint32_t)wv, blk = item / 3;
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    uint32_t*      im = smem + wv * kSlice;
+  for (uint32_t item = blockIdx.x * 4 + (uint32_t)wv; item < 3 * n; item += gridDim.x * 4) {
+    const uint32_t blk = item / 3;
     const int      pl = (int)(item - blk * 3);
-    if (blk >= n || (pl && !chroma)) return;
-    uint32_t*            im = smem + wv * kSlice;
+    if (pl && !chroma) continue;
     const SvtHipTfMcDesc d  = descs[blk];
-    if (d.bsize == 0) return; // an unused slot of a fixed-size descriptor table (tf_picture.hip)
+    if (d.bsize == 0) continue; // an unused slot of a descriptor table
     const int ss = pl > 0, W = d.bsize >> ss, bmi = d.bsize >> 2, bd = sizeof(PIX) == 2 ? P.bit_depth : 8, mx = (1 << bd) - 1;
     const int mirow = d.pu_y >> 2, micol = d.pu_x >> 2; // (the MacroBlockD edges are the luma block's, :2318-2324)
     const int to_top = -((mirow * 4) * 8), to_bottom = (((int)P.mi_rows - bmi - mirow) * 4) * 8, to_left = -((micol * 4) * 8), to_right = (((int)P.mi_cols - bmi - micol) * 4) * 8;
@@ -304,6 +307,8 @@ __global__ __launch_bounds__(256) void tf_mc_kernel(const SvtHipTfSubpelParams P
         px = px < 0 ? 0 : (px > mx ? mx : px);
         out[(uint32_t)(i >> lw) * ps + (uint32_t)(i & (W - 1))] = (PIX)px;
     });
+    __builtin_amdgcn_wave_barrier(); // (the wave's LDS slice is rewritten by its next item)
+  }
 }
 
 } // namespace
@@ -326,8 +331,19 @@ extern "C" void svt_hip_tf_subpel_search_batch(const SvtHipTfSubpelParams* param
     SVT_LAUNCH_CHECK();
 }
 
+static void tf_mc_launch(const SvtHipTfSubpelParams* params, const SvtHipTfMcPlanes* planes, const SvtHipTfMcDesc* descs, uint32_t n, const uint32_t* n_dev, int chroma,
+                         void* stream);
 extern "C" void svt_hip_tf_inter_pred_batch(const SvtHipTfSubpelParams* params, const SvtHipTfMcPlanes* planes, const SvtHipTfMcDesc* descs, uint32_t n, int chroma,
                                             void* stream) {
+    tf_mc_launch(params, planes, descs, n, nullptr, chroma, stream);
+}
+// the same over a list whose length another kernel left in device memory (at most max_n descriptors)
+extern "C" void svt_hip_tf_inter_pred_list(const SvtHipTfSubpelParams* params, const SvtHipTfMcPlanes* planes, const SvtHipTfMcDesc* descs, uint32_t max_n, const uint32_t* n_dev,
+                                           int chroma, void* stream) {
+    tf_mc_launch(params, planes, descs, max_n, n_dev, chroma, stream);
+}
+static void tf_mc_launch(const SvtHipTfSubpelParams* params, const SvtHipTfMcPlanes* planes, const SvtHipTfMcDesc* descs, uint32_t n, const uint32_t* n_dev, int chroma,
+                         void* stream) {
     svthip::ensure_device();
     if (n == 0) return;
     if (params->bit_depth != 8 && params->bit_depth != 10) {
@@ -335,11 +351,11 @@ extern "C" void svt_hip_tf_inter_pred_batch(const SvtHipTfSubpelParams* params, 
         abort();
     }
     const size_t   shm = (size_t)4 * kSlice * 4;
-    const uint32_t items = n * 3;
+    const uint32_t items = n * 3, wgs = (items + 3) / 4, grid = n_dev && wgs > 4096 ? 4096 : wgs; // (a device-side count: enough waves to fill the chip, then a stride)
     if (params->bit_depth > 8)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_mc_kernel<uint16_t>), dim3((items + 3) / 4), dim3(256), shm, (hipStream_t)stream, *params, *planes, descs, n, chroma);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_mc_kernel<uint16_t>), dim3(grid), dim3(256), shm, (hipStream_t)stream, *params, *planes, descs, n, n_dev, chroma);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_mc_kernel<uint8_t>), dim3((items + 3) / 4), dim3(256), shm, (hipStream_t)stream, *params, *planes, descs, n, chroma);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_mc_kernel<uint8_t>), dim3(grid), dim3(256), shm, (hipStream_t)stream, *params, *planes, descs, n, n_dev, chroma);
     SVT_LAUNCH_CHECK();
 }
 

@@ -7,7 +7,7 @@ import json
 d=json.loads(open("gpurun_out/r03_call16/bench_tfpic.json").read().strip().split("\n")[-1])
 for k,v in d["kernels"].items(): print(k, {x:v[x] for x in v if x in("ms","us","pictures_per_s","equals_host_form")})
 PY
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tf -o s -- python bench.py --no-cpu --legs tfpic --steps 10 --warmup 2 --no-pmc --no-parity-check > $O/prof.log 2>&1
+true
 python - <<'PY'
 import csv,glob
 for f in glob.glob("/tmp/prof_tf/**/*kernel_stats.csv", recursive=True):
