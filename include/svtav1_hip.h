@@ -211,6 +211,11 @@ typedef struct SvtHipHmeLevelParams {
                                         (hme_level0_b64 :2001-2031) */
     uint8_t  pad2[2];
     uint32_t zz_skip_th;             /* me_early_exit_th >> 2 (0 = off): items whose zero-motion SAD zz_sad[ref][sb] is below it skip the level with centre (0, 0) and SAD 0 (hme_level0_b64 :1922-1935, hme_level1_b64 :2057-2070; never applied at level 2) */
+    /* level-0 areas that depend on the motion list 0 / reference 0 found for the SAME superblock (get_hme_l0_search_area, :1809-1836; the low-delay settings,
+     * enc_mode_config.c:702-714): for every slot but 0 the divisor of the width is (1 + ref index) when that motion is horizontal (|x| > th_max, |y| < th_min), else
+     * (2 + ref index); likewise the height with "vertical".  sa_*_ref[] hold the (1 + index) areas, sa_*_ref2[] the (2 + index) ones; 0 / 0 = off.  Chain form only. */
+    uint16_t l0_mv_th_min, l0_mv_th_max;
+    int16_t  sa_width_ref2[8], sa_height_ref2[8];
 } SvtHipHmeLevelParams;
 size_t svt_hip_hme_level_workspace(const SvtHipHmeLevelParams *params);
 void   svt_hip_hme_level_batch(const SvtHipHmeLevelParams *params, const uint8_t *src_base, const uint8_t *ref_base, const int16_t *prev_sc,
@@ -626,6 +631,8 @@ typedef struct SvtHipMeStageParams {
                                            * (:1300-1302), leaves hme_prune_enabled / sr_adjustment / results.prune_ref at 0 and takes the raw tables (out->best_sad /
                                            * best_mv, total_me_candidate_index = NULL: no MeSbResults are formatted) */
     SvtHipMeResultsParams results;       /* formatting parameters (n_sb is filled in by the session) */
+    uint16_t reduce_hme_l0_sr_th_min, reduce_hme_l0_sr_th_max; /* me_ctx->reduce_hme_l0_sr_th_* when distance_based_hme_resizing is on (else 0): see SvtHipHmeLevelParams */
+    int16_t  hme_l0_sa_width_ref2[8], hme_l0_sa_height_ref2[8]; /* the level-0 areas with the (2 + ref index) divisors */
 } SvtHipMeStageParams;
 int svt_hip_me_session_enable_stage(void *session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,
                                     uint32_t max_me_area_height);

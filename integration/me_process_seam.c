@@ -187,7 +187,6 @@ static int fill_stage(PictureParentControlSet *pcs, MeContext *c, SvtHipMeStageP
     if (pcs->frame_superres_enabled || pcs->frame_resize_enabled) return decline("super-resolution / resize");
     if (!c->enable_hme_flag || !c->enable_hme_level0_flag || (!c->enable_hme_level1_flag && c->enable_hme_level2_flag)) return decline("HME without level 0, or level 2 without level 1");
     if (c->me_sr_adjustment_ctrls.enable_me_sr_adjustment > 1) return decline("enable_me_sr_adjustment == 2");
-    if (c->reduce_hme_l0_sr_th_min || c->reduce_hme_l0_sr_th_max) return decline("RTC level-0 resizing from list 0's motion");
     if (c->num_hme_sa_w * c->num_hme_sa_h > 4) return decline("more than 2 x 2 HME regions");
     const uint32_t n0 = c->num_of_ref_pic_to_search[0], n1 = c->num_of_list_to_search > 1 ? c->num_of_ref_pic_to_search[1] : 0, n = n0 + n1;
     if (n == 0 || n > SEAM_MAX_REFS || n0 > 4 || n1 > 4) return decline("reference count");
@@ -248,6 +247,17 @@ static int fill_stage(PictureParentControlSet *pcs, MeContext *c, SvtHipMeStageP
             const int wmax = ((a.sa_max.width / c->num_hme_sa_w) + 15) & ~15, hmax = a.sa_max.height / c->num_hme_sa_h;
             w = ((w * f) + 15) & ~15; h = h * f;
             S->hme_l0_sa_width_ref[k] = (int16_t)(w < wmax ? w : wmax); S->hme_l0_sa_height_ref[k] = (int16_t)(h < hmax ? h : hmax);
+            if (sr->enable_me_sr_adjustment && sr->distance_based_hme_resizing && c->reduce_hme_l0_sr_th_min && c->reduce_hme_l0_sr_th_max) {
+                /* the low-delay settings (enc_mode_config.c:702-714): per SB the divisor is (1 + index) or (2 + index), decided on the device from list 0 / reference 0's
+                 * level-0 motion (get_hme_l0_search_area :1809-1850); here the areas of the second form */
+                SearchAreaMinMax a2 = c->hme_l0_sa;
+                a2.sa_min.width /= 2 + ri; a2.sa_min.height /= 2 + ri; a2.sa_max.width /= 2 + ri; a2.sa_max.height /= 2 + ri;
+                int w2 = a2.sa_min.width / c->num_hme_sa_w, h2 = a2.sa_min.height / c->num_hme_sa_h;
+                const int w2max = ((a2.sa_max.width / c->num_hme_sa_w) + 15) & ~15, h2max = a2.sa_max.height / c->num_hme_sa_h;
+                w2 = ((w2 * f) + 15) & ~15; h2 = h2 * f;
+                S->hme_l0_sa_width_ref2[k] = (int16_t)(w2 < w2max ? w2 : w2max); S->hme_l0_sa_height_ref2[k] = (int16_t)(h2 < h2max ? h2 : h2max);
+                S->reduce_hme_l0_sr_th_min = c->reduce_hme_l0_sr_th_min; S->reduce_hme_l0_sr_th_max = c->reduce_hme_l0_sr_th_max;
+            }
             S->results.ref_picture_number[li][ri] = ref_number;
         }
     SvtHipMeResultsParams *R = &S->results;

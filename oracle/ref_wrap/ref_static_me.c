@@ -206,7 +206,8 @@ typedef struct RefMeStageOptions {
     uint32_t prev_me_stage_based_exit_th, me_safe_limit_zz_th;
     uint32_t me_type_mctf, tf_me_exit_th; /* the temporal filter's form of the call */
     uint8_t  hme_level2_off;              /* enable_hme_level2_flag = 0 (presets M7 and above, enc_mode_config.c:1636-1640) */
-    uint8_t  pad[3];
+    uint8_t  pad;
+    uint16_t reduce_hme_l0_sr_th_min, reduce_hme_l0_sr_th_max; /* the low-delay settings' level-0 resizing from list 0 / reference 0's motion (enc_mode_config.c:702-714) */
 } RefMeStageOptions;
 static MeContext *g_last_ctx; /* the context of the last ref_motion_estimation_b64 call, for ref_me_last_hme */
 void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsParams *P, const RefPicture *src, const RefPicture *refs /*[2][4]*/,
@@ -279,6 +280,7 @@ void ref_motion_estimation_b64(const RefMeStageOptions *O, const RefMeResultsPar
     ctx->me_early_exit_th = O->me_early_exit_th;
     ctx->me_sr_adjustment_ctrls.enable_me_sr_adjustment = O->sr_adjustment;
     ctx->me_sr_adjustment_ctrls.distance_based_hme_resizing = O->distance_based_hme_resizing;
+    ctx->reduce_hme_l0_sr_th_min = O->reduce_hme_l0_sr_th_min; ctx->reduce_hme_l0_sr_th_max = O->reduce_hme_l0_sr_th_max;
     ctx->me_sr_adjustment_ctrls.reduce_me_sr_based_on_mv_length_th = O->reduce_me_sr_based_on_mv_length_th;
     ctx->me_sr_adjustment_ctrls.stationary_hme_sad_abs_th = O->stationary_hme_sad_abs_th;
     ctx->me_sr_adjustment_ctrls.stationary_me_sr_divisor = O->stationary_me_sr_divisor;
@@ -354,6 +356,7 @@ void ref_sig_deriv_me(int enc_mode, int input_resolution, int qp, int sc_class1,
     O->temporal_layer_index = (uint8_t)temporal_layer_index;
     O->me_early_exit_th = c->me_early_exit_th;
     O->sr_adjustment = c->me_sr_adjustment_ctrls.enable_me_sr_adjustment; O->distance_based_hme_resizing = c->me_sr_adjustment_ctrls.distance_based_hme_resizing;
+    O->reduce_hme_l0_sr_th_min = c->reduce_hme_l0_sr_th_min; O->reduce_hme_l0_sr_th_max = c->reduce_hme_l0_sr_th_max;
     O->reduce_me_sr_based_on_mv_length_th = c->me_sr_adjustment_ctrls.reduce_me_sr_based_on_mv_length_th;
     O->stationary_hme_sad_abs_th = c->me_sr_adjustment_ctrls.stationary_hme_sad_abs_th; O->stationary_me_sr_divisor = c->me_sr_adjustment_ctrls.stationary_me_sr_divisor;
     O->reduce_me_sr_based_on_hme_sad_abs_th = c->me_sr_adjustment_ctrls.reduce_me_sr_based_on_hme_sad_abs_th;

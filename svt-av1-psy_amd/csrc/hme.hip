@@ -308,6 +308,10 @@ size_t svt_hip_hme_level_workspace(const SvtHipHmeLevelParams* params) { return 
 
 void svt_hip_hme_level_batch(const SvtHipHmeLevelParams* params, const uint8_t* src_base, const uint8_t* ref_base, const int16_t* prev_sc,
                              const uint32_t* zz_sad, uint64_t* sad_out, int16_t* sc_out, void* workspace, void* stream) {
+    if (params->l0_mv_th_min || params->l0_mv_th_max) { // (the other slots' level-0 areas depend on slot 0's result of the same SB: only the chain form orders that)
+        fprintf(stderr, "libsvtav1_hip: svt_hip_hme_level_batch: level-0 resizing from list 0's motion is built in svt_hip_hme_chain_batch only\n");
+        abort();
+    }
     svthip::ensure_device();
     const uint32_t n = hme_items(params);
     if (n == 0) return;

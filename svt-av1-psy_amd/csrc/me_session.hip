@@ -323,6 +323,10 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
         if (stage->hme_l0_per_ref) {
             P[0].per_ref_area = 1;
             for (uint32_t k = 0; k < n_refs; k++) { P[0].sa_width_ref[k] = stage->hme_l0_sa_width_ref[k]; P[0].sa_height_ref[k] = stage->hme_l0_sa_height_ref[k]; }
+            if (stage->reduce_hme_l0_sr_th_min && stage->reduce_hme_l0_sr_th_max) { // level-0 areas resized from list 0 / reference 0's level-0 motion (low-delay settings)
+                P[0].l0_mv_th_min = stage->reduce_hme_l0_sr_th_min; P[0].l0_mv_th_max = stage->reduce_hme_l0_sr_th_max;
+                for (uint32_t k = 0; k < n_refs; k++) { P[0].sa_width_ref2[k] = stage->hme_l0_sa_width_ref2[k]; P[0].sa_height_ref2[k] = stage->hme_l0_sa_height_ref2[k]; }
+            }
         }
         SvtHipHmeChainInputs in;
         memset(&in, 0, sizeof(in));

@@ -939,13 +939,14 @@ struct HmeChainArgs {
     uint32_t n, prev_stage_th;
     int win_budget, src_budget;
     int n_levels, list1_skip;
+    uint32_t item0; // first item of this launch (the level-0 resizing from list 0's motion runs reference 0 first)
 };
 __global__ __launch_bounds__(256, 4) void hme_chain_kernel(const HmeChainArgs A) {
     HIP_DYNAMIC_SHARED(uint32_t, smem)
     __shared__ unsigned long long sh_l0[4]; // level-0 SADs of the workgroup's four items (the 2 x 2 regions of one (reference, SB) in the pre-HME form)
     // everything but the pixel work is wave-uniform (item index, geometry, descriptors, winners): kept on the SALU through readfirstlane
     const int      l = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t item = blockIdx.x * 4 + wv;
+    const uint32_t item = A.item0 + blockIdx.x * 4 + wv;
     const bool     have = item < A.n; // (kept alive for the workgroup barrier of the pre-HME form; the grid is exact then)
     uint32_t* src_lds = smem + wv * ((A.win_budget + A.src_budget) / 4);
     uint32_t* win     = src_lds + A.src_budget / 4;
@@ -982,7 +983,14 @@ __global__ __launch_bounds__(256, 4) void hme_chain_kernel(const HmeChainArgs A)
         if (have) {
             SvtHipSadLoopDesc d;
             int16_t ox, oy;
-            hme_item_geometry(P, item, px, py, d, ox, oy);
+            int l0_flags = 0;
+            if (lv == 0 && P.l0_mv_th_min && P.l0_mv_th_max && r > 0) { // the motion list 0 / reference 0 found at level 0 for this SB, region (0, 0): an earlier launch wrote it
+                const uint32_t it0 = sb * regions;
+                const int      l0x = A.sc_out[0][2 * it0], l0y = A.sc_out[0][2 * it0 + 1], ax = l0x < 0 ? -l0x : l0x, ay = l0y < 0 ? -l0y : l0y;
+                const bool     is_ver = ax < (int)P.l0_mv_th_min && ay > (int)P.l0_mv_th_max, is_hor = ax > (int)P.l0_mv_th_max && ay < (int)P.l0_mv_th_min;
+                l0_flags = (is_hor ? 0 : 1) | (is_ver ? 0 : 2);
+            }
+            hme_item_geometry(P, item, px, py, d, ox, oy, l0_flags);
             const int W = d.search_area_width;
             int       pos = -1;
             if (sad_loop_ring_eligible(d, A.win_budget, A.src_budget)) {
@@ -1394,7 +1402,18 @@ void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* 
         fprintf(stderr, "libsvtav1_hip: svt_hip_hme_chain_batch: the pre-HME replacement needs 2 x 2 search regions (get_worst_quadrant)\n");
         abort();
     }
-    hipLaunchKernelGGL(hme_chain_kernel, dim3((n + 3) / 4), dim3(256), 4 * (size_t)(src_budget + win_budget) + 64, (hipStream_t)stream, A);
+    const size_t   shm  = 4 * (size_t)(src_budget + win_budget) + 64;
+    const uint32_t per0 = params[0].sbs_x * params[0].sbs_y * params[0].num_hme_sa_w * params[0].num_hme_sa_h; // the items of slot 0 (list 0, reference 0)
+    if (params[0].l0_mv_th_min && params[0].l0_mv_th_max && params[0].per_ref_area && n > per0) {
+        // level-0 areas of the other slots depend on slot 0's level-0 result of the same SB: slot 0 first (whole chain), then the rest
+        A.n = per0; A.item0 = 0;
+        hipLaunchKernelGGL(hme_chain_kernel, dim3((per0 + 3) / 4), dim3(256), shm, (hipStream_t)stream, A);
+        A.n = n; A.item0 = per0;
+        hipLaunchKernelGGL(hme_chain_kernel, dim3((n - per0 + 3) / 4), dim3(256), shm, (hipStream_t)stream, A);
+    } else {
+        A.item0 = 0;
+        hipLaunchKernelGGL(hme_chain_kernel, dim3((n + 3) / 4), dim3(256), shm, (hipStream_t)stream, A);
+    }
     SVT_LAUNCH_CHECK();
 }
 

@@ -448,7 +448,7 @@ class RefMeStageOptions(C.Structure):
                 ("prehme_sa_min_width", C.c_uint16 * 2), ("prehme_sa_min_height", C.c_uint16 * 2), ("prehme_sa_max_width", C.c_uint16 * 2),
                 ("prehme_sa_max_height", C.c_uint16 * 2), ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32), ("zz_sad_pct", C.c_uint16),
                 ("phme_sad_pct", C.c_uint16), ("prev_me_stage_based_exit_th", C.c_uint32), ("me_safe_limit_zz_th", C.c_uint32), ("me_type_mctf", C.c_uint32), ("tf_me_exit_th", C.c_uint32),
-                ("hme_level2_off", C.c_uint8), ("pad", C.c_uint8 * 3)]
+                ("hme_level2_off", C.c_uint8), ("pad", C.c_uint8), ("reduce_hme_l0_sr_th_min", C.c_uint16), ("reduce_hme_l0_sr_th_max", C.c_uint16)]
 
 
 def scaled_distance(d):  # svt_aom_get_scaled_picture_distance (motion_estimation.c:1239-1243)
@@ -491,6 +491,9 @@ STAGE_OPTS = [dict(name="baseline"),
               dict(name="mctf_level0_only", levels=1, mctf=2000, me=(8, 5, 16, 9)),  # the temporal filter's ME at tf_ctrls.hme_me_level 3 / 4 (enc_mode_config.c:1655-1661)
               dict(name="two_levels_exits", levels=2, prev_stage=64 * 64 * 24, me_early_exit_th=64 * 64 * 3, sub=1, hme_prune=30, sr=(1, 4, 3000, 8, 3000, 8)),
               dict(name="l0_resize_by_ref_index", dbr=1, sr=(1, 4, 12000, 8, 12000, 8), l0=(32, 32, 96, 96)),
+              # the low-delay settings: level-0 areas of every slot but (list 0, reference 0) resized from that slot's level-0 motion of the same SB (enc_mode_config.c:702-714)
+              dict(name="l0_resize_from_list0_motion", dbr=1, sr=(1, 4, 12000, 8, 12000, 8), l0=(64, 48, 128, 96), l0_th=(8, 12)),
+              dict(name="l0_resize_from_list0_motion_mixed", dbr=1, sr=(1, 4, 12000, 8, 12000, 8), l0=(16, 8, 32, 16), l0_th=(30, 2), levels=2, motion=5),  # thresholds under which SBs take all four width / height combinations
               dict(name="base_layer", tl=0),
               dict(name="base_layer_prune", tl=0, hme_prune=25, sr=(1, 4, 12000, 8, 12000, 8), me_early_exit_th=64 * 64 * 8, zz=(20 * 64 * 64, 5), is_ref=1,
                    prehme=dict(skip=1, l1=1, sa=((8, 24, 8, 48), (16, 7, 32, 7)), phme=(10 * 64 * 64, 5))),
@@ -519,11 +522,12 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
     W, H, PAD = (192, 136, 68) if not be.is_gpu else (448, 264, 68)
     stride, rows = W + 2 * PAD, H + 2 * PAD + 64
     nw, nh = 2, 2
-    base = g.integers(0, 256, (rows + 16, stride + 16), dtype=np.uint8) // 3 + (np.add.outer(np.arange(rows + 16), np.arange(stride + 16)) * 5 % 170).astype(np.uint8)
+    base = g.integers(0, 256, (rows + 80, stride + 80), dtype=np.uint8) // 3 + (np.add.outer(np.arange(rows + 80), np.arange(stride + 80)) * 5 % 170).astype(np.uint8)
     pics = []
+    mo = opt.get("motion", 1)  # displacement between consecutive pictures: (mo, 2 mo) samples (large values: the level-0 centres leave zero)
     for k in range(4):
         a = np.zeros((rows, stride), np.uint8)
-        a[PAD:PAD + H, PAD:PAD + W] = base[8 + k:8 + k + H, 8 + 2 * k:8 + 2 * k + W] + g.integers(0, 4, (H, W), dtype=np.uint8)
+        a[PAD:PAD + H, PAD:PAD + W] = base[8 + k * mo:8 + k * mo + H, 8 + 2 * k * mo:8 + 2 * k * mo + W] + g.integers(0, 4, (H, W), dtype=np.uint8)
         # a static region (zero-motion SAD small enough for the early exits) next to the moving one
         a[PAD:PAD + H, PAD:PAD + 100] = base[8:8 + H, 8:8 + 100] + g.integers(0, 2, (H, 100), dtype=np.uint8)
         oracle.oracle_generate_padding(p(a), stride, W, H, PAD, PAD)
@@ -568,6 +572,11 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
         b = [v // (1 + rpi[r]) for v in l0] if opt.get("dbr") else l0
         S.hme_l0_sa_width_ref[r] = min((((b[0] // nw) * dist[r]) + 15) & ~15, ((b[2] // nw) + 15) & ~15)
         S.hme_l0_sa_height_ref[r] = min((b[1] // nh) * dist[r], b[3] // nh)
+        b2 = [v // (2 + rpi[r]) for v in l0]  # the (2 + index) divisors of the low-delay resizing (:1829-1850)
+        S.hme_l0_sa_width_ref2[r] = min((((b2[0] // nw) * dist[r]) + 15) & ~15, ((b2[2] // nw) + 15) & ~15)
+        S.hme_l0_sa_height_ref2[r] = min((b2[1] // nh) * dist[r], b2[3] // nh)
+    if "l0_th" in opt:
+        S.reduce_hme_l0_sr_th_min, S.reduce_hme_l0_sr_th_max = opt["l0_th"]
     S.me_early_exit_th = opt.get("me_early_exit_th", 0)
     if "hme_prune" in opt:
         S.hme_prune_enabled, S.prune_ref_if_hme_sad_dev_bigger_than_th = 1, opt["hme_prune"]
@@ -638,6 +647,8 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
     O.temporal_layer_index, O.is_ref = opt.get("tl", 1), opt.get("is_ref", 0)
     O.hme_level2_off = 3 - opt.get("levels", 3)  # 0: three levels, 1: levels 0 and 1, 2: level 0 only
     O.distance_based_hme_resizing = opt.get("dbr", 0)
+    if "l0_th" in opt:
+        O.reduce_hme_l0_sr_th_min, O.reduce_hme_l0_sr_th_max = opt["l0_th"]
     O.hme_sub_sampled = O.me_sub_sad = opt.get("sub", 0)
     if "zz" in opt:
         O.zz_sad_th, O.zz_sad_pct = opt["zz"]
