@@ -556,7 +556,9 @@ typedef struct SvtHipTfPictureParams {
     uint8_t  enable_8x8_pred;         /* tf_ctrls.enable_8x8_pred */
     uint8_t  use_pred_64x64_only_th;  /* tf_ctrls.use_pred_64x64_only_th */
     uint8_t  subpel_8bit;             /* high bit depth only: tf_ctrls.use_8bit_subpel -- the sub-pel searches run on the pictures' 8-bit luma (`y8`), everything else on the 16-bit planes (:3203, :3242) */
-    uint8_t  pad[4];
+    uint8_t  zero_motion;             /* the low-delay form, produce_temporally_filtered_pic_ld (:3415-3846): no ME and no refinement, every block is predicted 64x64 at vector (0, 0)
+                                       * (:3711-3726); the ME tables are not read (me may be NULL) */
+    uint8_t  pad[3];
 } SvtHipTfPictureParams;
 typedef struct SvtHipTfHostPicture {
     const void *y, *u, *v;            /* the padded planes' first samples: buffer_y / buffer_cb / buffer_cr (8 bit), altref_buffer_highbd[C_Y / C_U / C_V] (sp.bit_depth 10: uint16) */

@@ -17,7 +17,9 @@
  *    pair is outside what the batch covers: the high-bit-depth path, a pair that did not go through the ME stage).
  *
  * 3. produce_temporally_filtered_pic(...) -- `static`, defined at :2782, called once from svt_av1_init_temporal_filtering (:4244), per segment of the central
- *    picture.  Same __COUNTER__ renaming (definition = _use5, the call = _use6 = seam_produce_temporally_filtered_pic() below).  With SVT_HIP_TF_SEAM=1 (on top of
+ *    picture.  Same __COUNTER__ renaming (definition = _use5, the call = _use8 = seam_produce_temporally_filtered_pic() below).  The low-delay form
+ *    produce_temporally_filtered_pic_ld (:3415, called at :4236 when pred_structure is low delay: no ME, every block predicted from the co-located block of
+ *    every frame of the window) takes the same route with its own name (definition = _ld_use6, call = _ld_use7) and the stage's zero_motion form.  With SVT_HIP_TF_SEAM=1 (on top of
  *    the ME seams) the first segment of a central picture to arrive runs the WHOLE picture as one device stage -- svt_hip_tf_picture_host: sub-pel refinement, the
  *    64x64 / 32x32 / 16x16 / 8x8 decisions, final motion compensation, filter -- and the picture's other segments return once it is done.  What stays the
  *    reference's own code: the picture-level decisions (which frames are skipped, :3105-3131), the decay factors (the function's preamble, :2870-3035, executed by
@@ -70,12 +72,19 @@ static void tf_subpel_search_use4(TF_SUBPEL_ARGS) { seam_tf_subpel_search(TF_SUB
 #define TF_PIC_PASS pcs_list, list_input_picture_ptr, index_center, me_context_ptr, noise_levels_log1p_fp16, segment_index, is_highbd
 static EbErrorType produce_temporally_filtered_pic_use5(TF_PIC_ARGS); /* the reference's function (defined by the #include) */
 static EbErrorType seam_produce_temporally_filtered_pic(TF_PIC_ARGS);
-static EbErrorType produce_temporally_filtered_pic_use6(TF_PIC_ARGS) { return seam_produce_temporally_filtered_pic(TF_PIC_PASS); }
+static EbErrorType seam_produce_temporally_filtered_pic_ld(TF_PIC_ARGS);
+/* __COUNTER__ in file order: the definition of produce_temporally_filtered_pic (:2782) takes 5, the definition of the low-delay form (:3415) 6, its call (:4236) 7, the
+ * call of the first (:4244) 8 */
+static EbErrorType produce_temporally_filtered_pic_ld_use6(TF_PIC_ARGS); /* the reference's low-delay function (defined by the #include) */
+static EbErrorType produce_temporally_filtered_pic_ld_use7(TF_PIC_ARGS) { return seam_produce_temporally_filtered_pic_ld(TF_PIC_PASS); }
+static EbErrorType produce_temporally_filtered_pic_use8(TF_PIC_ARGS) { return seam_produce_temporally_filtered_pic(TF_PIC_PASS); }
 #define produce_temporally_filtered_pic(...) SEAM_CAT(produce_temporally_filtered_pic_use, __COUNTER__)(__VA_ARGS__)
+#define produce_temporally_filtered_pic_ld(...) SEAM_CAT(produce_temporally_filtered_pic_ld_use, __COUNTER__)(__VA_ARGS__)
 #define svt_aom_motion_estimation_b64(pcs, i, x, y, ctx, pic) svt_hip_seam_tf_motion_estimation_b64(pcs, i, x, y, ctx, pic)
 #include "temporal_filtering.c" /* resolves through -I$(REF)/Source/Lib/Codec */
 #undef tf_subpel_search
 #undef produce_temporally_filtered_pic
+#undef produce_temporally_filtered_pic_ld
 #undef svt_aom_motion_estimation_b64
 
 /* ---- the sub-pel seam (after the #include: the block-numbering tables of temporal_filtering.c:44-90 are in scope) ---- */
@@ -286,7 +295,7 @@ static int tfd_on(void) {
 static int tfd_decline(const char *why) { TFD.last_decline = why; return -1; }
 
 /* the whole picture on the device; 0 = the central picture's buffers hold the filtered blocks */
-static int tfd_run_picture(TF_PIC_ARGS) {
+static int tfd_run_picture(TF_PIC_ARGS, int low_delay) {
     PictureParentControlSet *centre_pcs = pcs_list[index_center];
     SequenceControlSet      *scs        = centre_pcs->scs;
     EbPictureBufferDesc     *cen        = list_input_picture_ptr[index_center];
@@ -304,7 +313,10 @@ static int tfd_run_picture(TF_PIC_ARGS) {
     int       used[ALTREF_MAX_NFRAMES], n_used = 0;
     const int start_frame_index[3] = {0, centre_pcs->past_altref_nframes, centre_pcs->past_altref_nframes + 1};
     const int end_frame_index[3]   = {centre_pcs->past_altref_nframes - 1, centre_pcs->past_altref_nframes, centre_pcs->past_altref_nframes + centre_pcs->future_altref_nframes};
-    for (int segment_idx = 0; segment_idx < 3; segment_idx++)
+    /* the low-delay form filters with every frame of the window (:3665-3668) and takes no picture-level decision */
+    for (int frame_index = 0; low_delay && frame_index < centre_pcs->past_altref_nframes + centre_pcs->future_altref_nframes + 1; frame_index++)
+        if (frame_index != index_center) used[n_used++] = frame_index;
+    for (int segment_idx = 0; segment_idx < 3 && !low_delay; segment_idx++)
         for (int frame_index = start_frame_index[segment_idx]; frame_index <= end_frame_index[segment_idx]; frame_index = frame_index + ctx->tf_ctrls.ref_frame_factor) {
             if (frame_index == index_center) continue;
             const uint32_t low_ahd_err = centre_pcs->aligned_width * centre_pcs->aligned_height;
@@ -331,7 +343,8 @@ static int tfd_run_picture(TF_PIC_ARGS) {
     }
     /* the preamble of the reference's function -- decay factors into ctx (:2870-3035) -- over an empty block range */
     seam_tf_preamble_only = 1;
-    produce_temporally_filtered_pic_use5(TF_PIC_PASS);
+    if (low_delay) produce_temporally_filtered_pic_ld_use6(TF_PIC_PASS); /* (:3516-3607) */
+    else produce_temporally_filtered_pic_use5(TF_PIC_PASS);
     seam_tf_preamble_only = 0;
     /* the ME stage of every pair, context as the reference sets it up (:3140-3177) */
     uint32_t *best_sad = malloc((size_t)n_used * n_sb * 85 * 4), *best_mv = malloc((size_t)n_used * n_sb * 85 * 4);
@@ -343,6 +356,7 @@ static int tfd_run_picture(TF_PIC_ARGS) {
     for (int i = 0; i < n_used && !rc; i++) {
         const int frame_index = used[i];
         ctx->tf_frame_index = frame_index; ctx->tf_index_center = index_center;
+        if (!low_delay) {
         create_me_context_and_picture_control(me_context_ptr, pcs_list[frame_index], centre_pcs, cen, 0, 0, ss_x, ss_y);
         ctx->num_of_list_to_search = 1; ctx->num_of_ref_pic_to_search[0] = 1; ctx->num_of_ref_pic_to_search[1] = 0;
         ctx->temporal_layer_index = centre_pcs->temporal_layer_index; ctx->is_ref = centre_pcs->is_ref;
@@ -354,9 +368,12 @@ static int tfd_run_picture(TF_PIC_ARGS) {
         ctx->tf_me_exit_th = centre_pcs->tf_ctrls.me_exit_th; ctx->tf_use_pred_64x64_only_th = centre_pcs->tf_ctrls.use_pred_64x64_only_th;
         ctx->tf_subpel_early_exit_th = centre_pcs->tf_ctrls.subpel_early_exit_th;
         set_hme_search_params_mctf(ctx, 0);
+        }
         me[i].best_sad = best_sad + (size_t)i * n_sb * 85; me[i].best_mv = best_mv + (size_t)i * n_sb * 85; me[i].hme_sc = hme_sc + (size_t)i * n_sb * 2; me[i].hme_sad = hme_sad + (size_t)i * n_sb;
         const double tp_ = seam_ms_now();
-        if (!svt_hip_seam_tf_pair_run(centre_pcs, ctx, n_sb, (uint32_t *)me[i].best_sad, (uint32_t *)me[i].best_mv, (int16_t *)me[i].hme_sc, (uint64_t *)me[i].hme_sad))
+        if (low_delay) { /* no search: the prediction is the co-located block (:3711-3726) */
+            me[i].best_sad = me[i].best_mv = NULL; me[i].hme_sc = NULL; me[i].hme_sad = NULL;
+        } else if (!svt_hip_seam_tf_pair_run(centre_pcs, ctx, n_sb, (uint32_t *)me[i].best_sad, (uint32_t *)me[i].best_mv, (int16_t *)me[i].hme_sc, (uint64_t *)me[i].hme_sad))
             rc = tfd_decline("a pair outside the ME stage");
         __atomic_fetch_add(&TFD.us_pairs, (unsigned long long)((seam_ms_now() - tp_) * 1e3), __ATOMIC_RELAXED);
         const EbPictureBufferDesc *r = list_input_picture_ptr[frame_index];
@@ -373,7 +390,7 @@ static int tfd_run_picture(TF_PIC_ARGS) {
         memset(&P, 0, sizeof(P));
         P.sp.half_pel_mode = centre_pcs->tf_ctrls.half_pel_mode; P.sp.quarter_pel_mode = centre_pcs->tf_ctrls.quarter_pel_mode; P.sp.eight_pel_mode = centre_pcs->tf_ctrls.eight_pel_mode;
         P.sp.subsampling_shift = centre_pcs->tf_ctrls.sub_sampling_shift; P.sp.bit_depth = (uint8_t)(is_highbd ? enc_bd : 8); P.sp.early_exit_th = centre_pcs->tf_ctrls.subpel_early_exit_th;
-        P.subpel_8bit = (uint8_t)sp8;
+        P.subpel_8bit = (uint8_t)sp8; P.zero_motion = (uint8_t)low_delay;
         P.sp.mi_rows = (uint32_t)centre_pcs->av1_cm->mi_rows; P.sp.mi_cols = (uint32_t)centre_pcs->av1_cm->mi_cols;
         P.sp.ref_org_x = cen->org_x; P.sp.ref_org_y = cen->org_y; P.sp.ref_stride = cen->stride_y;
         for (int k = 0; k < 3; k++) P.tf.tf_decay_factor_fp16[k] = ctx->tf_decay_factor_fp16[k];
@@ -394,7 +411,7 @@ static int tfd_run_picture(TF_PIC_ARGS) {
         __atomic_fetch_add(&TFD.us_stage, (unsigned long long)((seam_ms_now() - ts_) * 1e3), __ATOMIC_RELAXED);
         if (!rc) {
             /* the horizontal / vertical vote of the ME calls (motion_estimation.c:2469-2474): one per (block, frame), summed into the picture by the caller (:4255-4258) */
-            for (size_t k = 0; k < (size_t)n_used * n_sb; k++) {
+            for (size_t k = 0; k < (size_t)n_used * n_sb && !low_delay; k++) {
                 if (ABS(hme_sc[2 * k]) > ABS(hme_sc[2 * k + 1])) ctx->tf_tot_horz_blks++;
                 else ctx->tf_tot_vert_blks++;
             }
@@ -407,8 +424,9 @@ static int tfd_run_picture(TF_PIC_ARGS) {
     return rc;
 }
 
-static EbErrorType seam_produce_temporally_filtered_pic(TF_PIC_ARGS) {
-    if (!tfd_on()) return produce_temporally_filtered_pic_use5(TF_PIC_PASS);
+static EbErrorType seam_tf_picture(TF_PIC_ARGS, int low_delay) {
+#define TF_REFERENCE_FORM() (low_delay ? produce_temporally_filtered_pic_ld_use6(TF_PIC_PASS) : produce_temporally_filtered_pic_use5(TF_PIC_PASS))
+    if (!tfd_on()) return TF_REFERENCE_FORM();
     PictureParentControlSet *centre_pcs = pcs_list[index_center];
     pthread_mutex_lock(&TFD.lock);
     TfPicRec *R = NULL, *spare = NULL;
@@ -421,7 +439,7 @@ static EbErrorType seam_produce_temporally_filtered_pic(TF_PIC_ARGS) {
         R = spare;
         R->pcs = centre_pcs; R->picture_number = centre_pcs->picture_number; R->seen = 0; R->state = 1;
         pthread_mutex_unlock(&TFD.lock);
-        const int rc = tfd_run_picture(TF_PIC_PASS); /* this segment's thread runs the picture; the others wait below */
+        const int rc = tfd_run_picture(TF_PIC_PASS, low_delay); /* this segment's thread runs the picture; the others wait below */
         pthread_mutex_lock(&TFD.lock);
         R->state = rc ? 3 : 2;
         if (rc) TFD.n_declined++; else TFD.n_pictures++;
@@ -431,5 +449,8 @@ static EbErrorType seam_produce_temporally_filtered_pic(TF_PIC_ARGS) {
     const int declined = R->state == 3;
     if (++R->seen == centre_pcs->tf_segments_total_count) R->state = 0;
     pthread_mutex_unlock(&TFD.lock);
-    return declined ? produce_temporally_filtered_pic_use5(TF_PIC_PASS) : EB_ErrorNone;
+    return declined ? TF_REFERENCE_FORM() : EB_ErrorNone;
+#undef TF_REFERENCE_FORM
 }
+static EbErrorType seam_produce_temporally_filtered_pic(TF_PIC_ARGS) { return seam_tf_picture(TF_PIC_PASS, 0); }
+static EbErrorType seam_produce_temporally_filtered_pic_ld(TF_PIC_ARGS) { return seam_tf_picture(TF_PIC_PASS, 1); }

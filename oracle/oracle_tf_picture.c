@@ -27,7 +27,7 @@ typedef struct OracleTfPictureParams { /* = SvtHipTfPictureParams */
     OracleTfParams       tf;
     uint32_t pic_w_sb, pic_h_sb, uv_stride, me_exit_th;
     uint64_t pred_error_32x32_th;
-    uint8_t  use_2tap, enable_8x8_pred, use_pred_64x64_only_th, subpel_8bit, pad[4];
+    uint8_t  use_2tap, enable_8x8_pred, use_pred_64x64_only_th, subpel_8bit, zero_motion, pad[3];
 } OracleTfPictureParams;
 
 void oracle_tf_subpel_search(const OracleTfSubpelParams *P, const void *src, int src_stride, const void *ref_buffer_y, int pu_x, int pu_y, int bsize, int bilinear,
@@ -109,6 +109,32 @@ int oracle_tf_picture(const OracleTfPictureParams *P, const void *const central[
         const uint32_t    strides[3] = {P->sp.ref_stride, P->uv_stride, P->uv_stride};
         for (int sb = 0; sb < n_sb; sb++) {
             const int x0 = (sb % nsbx) * 64, y0 = (sb / nsbx) * 64;
+#define MC(SLOT, MVX, MVY)                                                                                                                                      \
+    do {                                                                                                                                                       \
+        int bs_, lx_, ly_;                                                                                                                                      \
+        slot_geometry(SLOT, &bs_, &lx_, &ly_);                                                                                                                  \
+        oracle_tf_inter_pred(&P->sp, planes, strides, x0 + lx_, y0 + ly_, bs_, MVX, MVY, chroma, tmp, tp);                                                      \
+        for (int pl_ = 0; pl_ < (chroma ? 3 : 1); pl_++) {                                                                                                      \
+            const int s_ = pl_ > 0, w_ = bs_ >> s_, st_ = pw >> s_;                                                                                             \
+            const int ox_ = s_ ? (((x0 + lx_) >> 3) << 3) / 2 : x0 + lx_, oy_ = s_ ? (((y0 + ly_) >> 3) << 3) / 2 : y0 + ly_;                                    \
+            for (int yy = 0; yy < w_; yy++)                                                                                                                     \
+                for (int xx = 0; xx < w_; xx++) {                                                                                                               \
+                    const uint16_t v_ = tmp[pl_][yy * tp[pl_] + xx];                                                                                            \
+                    if (hbd) ((uint16_t *)pred[3 * r + pl_])[(long)(oy_ + yy) * st_ + ox_ + xx] = v_;                                                           \
+                    else pred[3 * r + pl_][(long)(oy_ + yy) * st_ + ox_ + xx] = (uint8_t)v_;                                                                    \
+                }                                                                                                                                               \
+        }                                                                                                                                                       \
+    } while (0)
+            if (P->zero_motion) { /* produce_temporally_filtered_pic_ld (:3415-3846): no ME, no refinement -- one 64x64 prediction at (0, 0), its 32x32 errors, the filter */
+                MC(0, 0, 0);
+                if (stats) stats[0]++;
+                for (int i = 0; i < 4; i++) {
+                    OracleTfBlock *B = &blocks[((size_t)r * nby + 2 * (sb / nsbx) + (i >> 1)) * nbx + 2 * (sb % nsbx) + (i & 1)];
+                    const long po = (long)(y0 + (i >> 1) * 32) * pw + x0 + (i & 1) * 32, so = pic0 + (long)(y0 + (i >> 1) * 32) * P->sp.ref_stride + x0 + (i & 1) * 32;
+                    B->block_error[0] = var32(pred[3 * r] + po * px, pw, (const uint8_t *)central[0] + so * px, P->sp.ref_stride, hbd, ss);
+                }
+                continue;
+            }
             Ctx c = {P, sp8 ? &SP8 : &P->sp, sp8 ? central_y8 : central[0], sp8 ? refs_y8[r] : refs[3 * r], pic0, sp8 ? 0 : hbd, x0, y0, best_mv[r] + (size_t)sb * 85};
             const uint32_t *sd = best_sad[r] + (size_t)sb * 85;
             const int     exited = hme_sad[r][sb] < P->me_exit_th; /* motion_estimation.c:3110-3111 */
@@ -152,22 +178,6 @@ int oracle_tf_picture(const OracleTfPictureParams *P, const void *const central[
                     }
             }
             /* motion compensation (tf_64x64_ / tf_32x32_inter_prediction, :2256-2605) into the reference's prediction planes */
-#define MC(SLOT, MVX, MVY)                                                                                                                                      \
-    do {                                                                                                                                                       \
-        int bs_, lx_, ly_;                                                                                                                                      \
-        slot_geometry(SLOT, &bs_, &lx_, &ly_);                                                                                                                  \
-        oracle_tf_inter_pred(&P->sp, planes, strides, x0 + lx_, y0 + ly_, bs_, MVX, MVY, chroma, tmp, tp);                                                      \
-        for (int pl_ = 0; pl_ < (chroma ? 3 : 1); pl_++) {                                                                                                      \
-            const int s_ = pl_ > 0, w_ = bs_ >> s_, st_ = pw >> s_;                                                                                             \
-            const int ox_ = s_ ? (((x0 + lx_) >> 3) << 3) / 2 : x0 + lx_, oy_ = s_ ? (((y0 + ly_) >> 3) << 3) / 2 : y0 + ly_;                                    \
-            for (int yy = 0; yy < w_; yy++)                                                                                                                     \
-                for (int xx = 0; xx < w_; xx++) {                                                                                                               \
-                    const uint16_t v_ = tmp[pl_][yy * tp[pl_] + xx];                                                                                            \
-                    if (hbd) ((uint16_t *)pred[3 * r + pl_])[(long)(oy_ + yy) * st_ + ox_ + xx] = v_;                                                           \
-                    else pred[3 * r + pl_][(long)(oy_ + yy) * st_ + ox_ + xx] = (uint8_t)v_;                                                                    \
-                }                                                                                                                                               \
-        }                                                                                                                                                       \
-    } while (0)
             if (p64) { MC(0, mv64x, mv64y); if (stats) stats[0]++; }
             for (int i = 0; i < 4; i++) {
                 OracleTfBlock *B = &blocks[((size_t)r * nby + 2 * (sb / nsbx) + (i >> 1)) * nbx + 2 * (sb % nsbx) + (i & 1)];

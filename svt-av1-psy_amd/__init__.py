@@ -349,7 +349,7 @@ assert TplSrcStats.itemsize == 40
 class TfPictureParams(C.Structure):
     """SvtHipTfPictureParams: one central picture of the temporal filter as a device stage (svt_hip_tf_picture_host)."""
     _fields_ = [("sp", TfSubpelParams), ("tf", TfParams), ("pic_w_sb", C.c_uint32), ("pic_h_sb", C.c_uint32), ("uv_stride", C.c_uint32), ("me_exit_th", C.c_uint32),
-                ("pred_error_32x32_th", C.c_uint64), ("use_2tap", C.c_uint8), ("enable_8x8_pred", C.c_uint8), ("use_pred_64x64_only_th", C.c_uint8), ("subpel_8bit", C.c_uint8), ("pad", C.c_uint8 * 4)]
+                ("pred_error_32x32_th", C.c_uint64), ("use_2tap", C.c_uint8), ("enable_8x8_pred", C.c_uint8), ("use_pred_64x64_only_th", C.c_uint8), ("subpel_8bit", C.c_uint8), ("zero_motion", C.c_uint8), ("pad", C.c_uint8 * 3)]
 
 
 class TfHostPicture(C.Structure):

@@ -109,8 +109,10 @@ __global__ __launch_bounds__(64) void tf_pic_decide_kernel(const PicArgs A) {
     if (pair >= A.n_refs * A.n_sb) return;
     const uint32_t ref = pair / A.n_sb, sb = pair - ref * A.n_sb, sbx = sb % A.P.pic_w_sb, sby = sb / A.P.pic_w_sb, x0 = sbx * 64, y0 = sby * 64;
     auto R = [&](const int slot) -> const SvtHipTfSubpelResult& { return A.sp_res[res_index(A, pair, slot)]; }; // (only slots the passes searched are read)
-    const bool exited = A.hme_sad[pair] < A.P.me_exit_th;
-    const bool p64    = only_64x64_before_search(A, pair) || pred_64x64_wins(A, pair);
+    const bool zm     = A.P.zero_motion != 0; // the low-delay form: nothing was searched, every block is one 64x64 prediction at vector (0, 0)
+    const bool exited = !zm && A.hme_sad[pair] < A.P.me_exit_th;
+    const bool p64    = zm || only_64x64_before_search(A, pair) || pred_64x64_wins(A, pair);
+    const int16_t mv64x = zm ? (int16_t)0 : R(0).mv_x, mv64y = zm ? (int16_t)0 : R(0).mv_y;
     A.path64[pair] = p64 ? 1 : 0;
     auto mc = [&](const int, const int slot, const int16_t mvx, const int16_t mvy) { // appends to the picture's list: the order of the entries does not matter
         int bs, lx, ly;
@@ -124,14 +126,14 @@ __global__ __launch_bounds__(64) void tf_pic_decide_kernel(const PicArgs A) {
     };
     const uint32_t nbx = 2 * A.P.pic_w_sb, nby = 2 * A.P.pic_h_sb;
     uint32_t n64 = 0, n32 = 0, n16 = 0, n8 = 0;
-    if (p64) { mc(0, 0, R(0).mv_x, R(0).mv_y); n64 = 1; }
+    if (p64) { mc(0, 0, mv64x, mv64y); n64 = 1; }
     for (int i32 = 0; i32 < 4; i32++) {
         SvtHipTfBlock B;
         for (int k = 0; k < 4; k++) { B.block_error[k] = 0; B.mv_x[k] = 0; B.mv_y[k] = 0; }
         B.split = 0;
         for (int k = 0; k < 7; k++) B.pad[k] = 0;
         if (p64) { // convert_64x64_info_to_32x32_info (:2691-2758): the 64x64 vector; the error comes from tf_pic_var32_kernel
-            B.mv_x[0] = R(0).mv_x; B.mv_y[0] = R(0).mv_y;
+            B.mv_x[0] = mv64x; B.mv_y[0] = mv64y;
         } else if (R(1 + i32).dist < A.P.pred_error_32x32_th) { // (:3292-3296)
             B.block_error[0] = R(1 + i32).dist; B.mv_x[0] = R(1 + i32).mv_x; B.mv_y[0] = R(1 + i32).mv_y;
             mc(16 * i32, 1 + i32, R(1 + i32).mv_x, R(1 + i32).mv_y); n32++;
@@ -278,7 +280,7 @@ extern "C" int svt_hip_tf_picture(const SvtHipTfPictureParams* params, const Svt
     A.pic0 = (uint64_t)P.sp.ref_org_y * P.sp.ref_stride + P.sp.ref_org_x;
     A.ref_pitch = pics->ref_pitch; A.sp_ref_pitch = sp8 ? pics->ref_y8_pitch : pics->ref_pitch; A.uv_pitch = pics->ref_uv_pitch;
     A.pred_y_pitch = z.pysz / px; A.pred_uv_pitch = z.pcsz / px; A.pred_y_stride = z.pw; A.pred_uv_stride = z.pw / 2;
-    A.best_sad = me->best_sad; A.best_mv = me->best_mv; A.hme_sc = me->hme_sc; A.hme_sad = (const unsigned long long*)me->hme_sad;
+    if (!P.zero_motion) { A.best_sad = me->best_sad; A.best_mv = me->best_mv; A.hme_sc = me->hme_sc; A.hme_sad = (const unsigned long long*)me->hme_sad; }
     A.sp_descs = (SvtHipTfSubpelDesc*)take(z.n_sp * sizeof(SvtHipTfSubpelDesc));
     A.sp_res   = (SvtHipTfSubpelResult*)take(z.n_sp * sizeof(SvtHipTfSubpelResult));
     A.mc_descs = (SvtHipTfMcDesc*)take(n_pairs * MC_SLOTS * sizeof(SvtHipTfMcDesc));
@@ -294,7 +296,7 @@ extern "C" int svt_hip_tf_picture(const SvtHipTfPictureParams* params, const Svt
     // 1. sub-pel refinement in three passes: a size is searched only where the reference would search it
     SvtHipTfSubpelParams SP = P.sp;
     if (sp8) SP.bit_depth = 8;
-    for (int level = 0; level < 3; level++) {
+    for (int level = 0; level < 3 && !P.zero_motion; level++) {
         const size_t per = level == 0 ? 1 : (level == 1 ? 4 : z.per_sb - 5), first = level == 0 ? 0 : (level == 1 ? n_pairs : 5 * n_pairs), cnt = n_pairs * per;
         hipLaunchKernelGGL(tf_pic_descs_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, A, level);
         SVT_LAUNCH_CHECK();
@@ -373,7 +375,7 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     uint32_t* d_mv  = (uint32_t*)c.dalloc(n_pairs * 85 * 4);
     int16_t*  d_sc  = (int16_t*)c.dalloc(n_pairs * 4);
     uint64_t* d_hs  = (uint64_t*)c.dalloc(n_pairs * 8);
-    for (uint32_t r = 0; r < n_refs; r++) {
+    for (uint32_t r = 0; r < n_refs && !P.zero_motion; r++) {
         c.up(d_sad + r * n_sb * 85, me[r].best_sad, n_sb * 85 * 4);
         c.up(d_mv + r * n_sb * 85, me[r].best_mv, n_sb * 85 * 4);
         c.up(d_sc + r * n_sb * 2, me[r].hme_sc, n_sb * 4);

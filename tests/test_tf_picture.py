@@ -133,3 +133,38 @@ def test_tf_picture_stage(be, oracle, case):
     if case == 0: assert gstats[3] > 0 and gstats[2] > 0  # noqa: E701
     if case == 1: assert gstats[4] > 0 and gstats[0] > 0 and gstats[1] > 0  # noqa: E701
     if case == 2: assert gstats[0] == n_refs * P.pic_w_sb * P.pic_h_sb and not gstats[1:4].any()  # noqa: E701
+
+
+@pytest.mark.parametrize("bd,zz,ss", [(8, False, 0), (8, True, 1), (10, False, 1)])
+def test_tf_picture_zero_motion(be, oracle, bd, zz, ss):
+    """the low-delay form (produce_temporally_filtered_pic_ld, temporal_filtering.c:3415-3846): no ME tables at all, every block is the co-located 64x64 prediction
+    of every frame, its 32x32 errors are variances, then the filter"""
+    if not be.is_gpu and bd == 10:
+        pytest.skip("emulator: the 10-bit case runs on the GPU")
+    W, H, PAD, n_refs = (320, 200, 80, 3) if be.is_gpu else (128, 72, 80, 3)
+    g = rng(560 + bd + ss)
+    P, pics, tabs = make_case(g, be.pkg, W, H, PAD, bd, n_refs, 20, 900, 3000, False, False, ss, True, zz)
+    P.zero_motion = 1
+    for r in range(1, n_refs + 1):  # a static scene: the frames are the central picture + noise (make_case's displaced textures get weight 0 at vector (0, 0))
+        pics[r] = [np.ascontiguousarray(np.clip(x.astype(np.int32) + g.integers(-4, 5, x.shape) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(x.dtype)) for x in pics[0]]
+    out = [x.copy() for x in pics[0]]
+    cen = (C.c_void_p * 3)(*[x.ctypes.data for x in pics[0]])
+    refs = (C.c_void_p * (3 * n_refs))(*[x.ctypes.data for pic in pics[1:] for x in pic])
+    o = (C.c_void_p * 3)(*[x.ctypes.data for x in out])
+    wstats = np.zeros(5, np.uint32)
+    oracle.oracle_tf_picture.restype = C.c_int
+    assert oracle.oracle_tf_picture(C.byref(P), cen, refs, None, None, None, None, n_refs, o, p(wstats), None, None) == 0
+    pkg = be.pkg
+    hp = lambda pic: pkg.TfHostPicture(pic[0].ctypes.data, pic[1].ctypes.data, pic[2].ctypes.data, pic[0].size, pic[1].size, None)  # noqa: E731
+    got = [x.copy() for x in pics[0]]
+    st = pkg.TfPictureStats()
+    hrefs = (pkg.TfHostPicture * n_refs)(*[hp(x) for x in pics[1:]])
+    hcen = hp(got)
+    assert be.lib.svt_hip_tf_picture_host(C.byref(P), C.byref(hcen), hrefs, None, n_refs, got[0].ctypes.data, got[1].ctypes.data, got[2].ctypes.data, C.byref(st)) == 0
+    assert st.blocks_64x64 == n_refs * P.pic_w_sb * P.pic_h_sb == wstats[0] and st.blocks_32x32 == st.blocks_16x16 == st.blocks_8x8 == st.early_exit_blocks == 0
+    for pl in range(3):
+        assert np.array_equal(out[pl], got[pl]), (pl, int((out[pl] != got[pl]).sum()))
+    assert not np.array_equal(out[0], pics[0][0])
+    # the ordinary form on the same pictures (searched vectors) gives another picture: the mode switch is observed
+    want2, _ = run_oracle(oracle, make_case(rng(560 + bd + ss), be.pkg, W, H, PAD, bd, n_refs, 20, 900, 3000, False, False, ss, True, zz)[0], pics, tabs)
+    assert not np.array_equal(want2[0], out[0])

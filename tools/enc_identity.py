@@ -87,6 +87,10 @@ CASES = {
     "tfdriver_1080p_p8": (1920, 1080, 20, 8, ["--preset", "8", "+seam", "+tfseam", "+tfdriver"]),
     "tfdriver_p8_10bit": (256, 144, 18, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),  # high bit depth: the packed 16-bit planes, searches on the 8-bit luma
     "tfdriver_p4_10bit": (256, 144, 12, 10, ["--preset", "4", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
+    # low delay (--pred-struct 1) from 720p up, a still scene: HME level-0 areas resized from list 0 / reference 0's motion, the zero-motion temporal filter
+    "lowdelay_720p_p8_8bit": (1280, 720, 24, 8, ["--preset", "8", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+static", "+seam", "+tfseam", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam"]),
+    "lowdelay_720p_p10_10bit": (1280, 720, 24, 10, ["--preset", "10", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+static", "+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam"]),
+    "lowdelay_1080p_p9_lp4": (1920, 1080, 24, 8, ["--preset", "9", "--lp", "4", "--pred-struct", "1", "--tune", "1", "+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam"]),  # (moving scene)
     "tfsubpel_p2_10bit": (256, 144, 6, 10, ["--preset", "2", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),  # high bit depth: the seam hands those searches to the reference
     "lrseam_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+lrseam"]),  # 1080p: tens of restoration units per plane, all host cores
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
@@ -125,6 +129,11 @@ CASES = {
     "tiny_tfdriver_p8": (128, 128, 12, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
     "tiny_tfdriver_p8_10bit": (128, 128, 12, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
     "tiny_tfdriver_p4_lp2": (128, 128, 10, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+tfdriver"]),
+    # low delay (--pred-struct 1): HME level-0 areas resized from list 0 / reference 0's motion, the zero-motion temporal filter, no TPL
+    "tiny_lowdelay_p8": (128, 128, 12, 8, ["--preset", "8", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+seam", "+cdefseam", "+dlfseam"]),
+    "tiny_lowdelay_p10_10bit": (128, 128, 10, 10, ["--preset", "10", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+seam", "+cdefseam", "+dlfseam"]),
+    "tiny_lowdelay_720p_tf_10bit": (1280, 720, 10, 10, ["--preset", "8", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+static", "+tfseam", "+tfdriver"]),
+    "tiny_lowdelay_720p_tf": (1280, 720, 10, 8, ["--preset", "8", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+static", "+tfseam", "+tfdriver"]),  # the low-delay temporal filter is on from 720p up (enc_handle.c:3303-3310)
     "tiny_tfsubpel_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
     "tiny_tfseam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tiny_dlfseam_p4": (128, 64, 3, 8, ["--preset", "4", "--lp", "1", "+dlfseam"]),
@@ -139,11 +148,12 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
-SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tfdriver_", "tplseam_"))]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tfdriver_", "tplseam_", "lowdelay_"))]
 
 
-def make_clip(path, w, h, n, bd, seed=7):
-    """Textured luma sliding by (2, 1) pixels per frame plus noise, smooth chroma; 4:2:0 planar, 16-bit little endian above 8 bit."""
+def make_clip(path, w, h, n, bd, seed=7, static=False):
+    """Textured luma sliding by (2, 1) pixels per frame plus noise, smooth chroma; 4:2:0 planar, 16-bit little endian above 8 bit.  static: no slide (a fixed
+    camera; the low-delay temporal filter predicts every block from the co-located one, so only a still scene gives it weights above zero)."""
     g = np.random.default_rng(seed)
     W, H = w + max(64, 2 * n + 2), h + max(64, n + 2)  # (margin for the slide; unchanged for the clips of up to 31 frames)
     base = np.kron(g.integers(0, 256, (H // 8 + 2, W // 8 + 2)).astype(np.float32), np.ones((8, 8), np.float32))[:H, :W]
@@ -151,7 +161,7 @@ def make_clip(path, w, h, n, bd, seed=7):
     tex = base * 0.5 + 64 + 40 * np.sin(xx / 9.0) + 30 * np.cos(yy / 7.0)
     with open(path, "wb") as f:
         for i in range(n):
-            ox, oy = 2 * i, i
+            ox, oy = (0, 0) if static else (2 * i, i)
             y = np.clip(tex[oy:oy + h, ox:ox + w] + g.normal(0, 2, (h, w)), 0, 255)
             u = np.clip(128 + 20 * np.sin((xx[:h // 2, :w // 2] + ox) / 5.0), 0, 255)
             v = np.clip(128 + 20 * np.cos((yy[:h // 2, :w // 2] + oy) / 6.0), 0, 255)
@@ -180,7 +190,7 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     os.makedirs(outdir, exist_ok=True)
     clip = os.path.join(outdir, name + ".yuv")
     clip_frames = next((int(a[5:]) for a in extra if a.startswith("+clip")), n)
-    make_clip(clip, w, h, min(clip_frames, n), bd)
+    make_clip(clip, w, h, min(clip_frames, n), bd, static="+static" in extra)
     seam, with_hook, lrseam, cdefseam, dlfseam = "+seam" in extra, "+hook" in extra, "+lrseam" in extra, "+cdefseam" in extra, "+dlfseam" in extra
     tplseam = "+tplseam" in extra
     extra = [a for a in extra if not a.startswith("+")]
@@ -194,8 +204,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     seam_file = os.path.join(outdir, name + "_seam.txt")
     env = {"SVT_HIP": str(device), "SVT_HIP_LIB": lib, "SVT_HIP_COUNT": counts_file}
     lrseam_file = os.path.join(outdir, name + "_lrseam.txt")
+    tf_alone = not seam and "+tfdriver" in CASES[name][4] and "--pred-struct" in extra  # the low-delay temporal filter has no ME: its stage can run without the ME seams' session
     if seam:
         env.update({"SVT_HIP_ME_SEAM": "1", "SVT_HIP_ME_SEAM_STATS": seam_file})
+    if seam or tf_alone:
         if "+tfseam" in CASES[name][4]:
             env["SVT_HIP_TF_ME_SEAM"] = "1"
         if "+tfsubpel" in CASES[name][4]:
@@ -217,7 +229,7 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     shard_file = os.path.join(outdir, name + "_devices.txt")
     if devices:
         env.update({"SVT_HIP_DEVICES": devices, "SVT_HIP_DEVICES_STATS": shard_file, "SVT_HIPEMU_DEVICES": str(len(devices.split(",")))})  # (the last one: emulator only)
-    if (seam or lrseam or cdefseam or dlfseam or tplseam) and not with_hook and not only:
+    if (seam or lrseam or cdefseam or dlfseam or tplseam or tf_alone) and not with_hook and not only:
         only = "-"  # no RTCD pointer matches: the seam(s) alone
     if only:
         env["SVT_HIP_ONLY"] = only
@@ -260,7 +272,8 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
         # the claim is void unless every picture really went through the device stage
         res["identical"] = same and res["seam"].get("pictures_offloaded", 0) > 0 and res["seam"].get("pictures_declined", 1) == 0
         if "+tfseam" in CASES[name][4]:  # temporal-filter pairs really went through the stage, none declined
-            res["identical"] = res["identical"] and res["seam"].get("tf_pairs_offloaded", 0) > 0 and res["seam"].get("tf_pairs_declined", 1) == 0
+            ld = "--pred-struct" in CASES[name][4]  # the low-delay temporal filter performs no ME (produce_temporally_filtered_pic_ld): no pair exists
+            res["identical"] = res["identical"] and (ld or res["seam"].get("tf_pairs_offloaded", 0) > 0) and res["seam"].get("tf_pairs_declined", 1) == 0
     if "+tfsubpel" in CASES[name][4]:
         f = os.path.join(outdir, name + "_tfsubpel.txt")
         st = dict(ln.split(None, 1) for ln in open(f).read().splitlines()) if os.path.exists(f) else {}
