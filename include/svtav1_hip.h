@@ -216,6 +216,10 @@ typedef struct SvtHipHmeLevelParams {
      * (2 + ref index); likewise the height with "vertical".  sa_*_ref[] hold the (1 + index) areas, sa_*_ref2[] the (2 + index) ones; 0 / 0 = off.  Chain form only. */
     uint16_t l0_mv_th_min, l0_mv_th_max;
     int16_t  sa_width_ref2[8], sa_height_ref2[8];
+    /* enable_me_sr_adjustment == 2 (the screen-content levels 4 / 5, enc_mode_config.c:485-505) adds: when that motion is small on both axes (|x|, |y| < 3 th_min) both
+     * divisors are (4 + ref index) (:1836-1841) -- sa_*_ref4[] */
+    uint8_t  l0_still_rule, pad3;
+    int16_t  sa_width_ref4[8], sa_height_ref4[8];
 } SvtHipHmeLevelParams;
 size_t svt_hip_hme_level_workspace(const SvtHipHmeLevelParams *params);
 void   svt_hip_hme_level_batch(const SvtHipHmeLevelParams *params, const uint8_t *src_base, const uint8_t *ref_base, const int16_t *prev_sc,
@@ -268,7 +272,7 @@ void   svt_hip_prehme_batch(const SvtHipPrehmeParams *params, const uint8_t *src
  * strictly smallest SAD over the search regions) + integer_search_b64's search-area geometry (:1294-1325, :1458-1508: min(sa_min * dist, sa_max),
  * enlargement for long search-centre components, division by reduce_me_sr_divisor, width rounded up to 8, centred on the HME result, clipped to the
  * picture + 63-sample border) + svt_hip_me_fullpel_search_batch, including hme_prune_ref_and_adjust_sr, the zero-motion early exit, check_00_center
- * and the 8x8-variance probe.  Not covered: me_sr_adjustment = 2 (its second rule makes the references of an SB depend on each other's final SADs).
+ * and the 8x8-variance probe.  With me_sr_adjustment = 2 the second rule makes the references of an SB depend on the first one's final SADs: two passes.
  * hme_sad / hme_sc: the last HME level's outputs in svt_hip_hme_level_batch's item order ((ref * n_sb + sb) * regions + region).
  * do_ref ([n_sb][2][4] = search_results[list][ref].do_ref as svt_hip_me_results_batch takes it, or NULL = all; in/out: HME-based pruning clears entries): a 0 entry gets a 1 x 1 placeholder search whose results must
  * be ignored (the reference skips the reference picture, :1292-1293).  divisor ([n_sb][n_refs] uint32, or NULL = 1) = me_ctx->reduce_me_sr_divisor
@@ -296,7 +300,10 @@ typedef struct SvtHipMeIntegerSearchParams {
     uint8_t  n_refs_list0;                    /* slots [0, n_refs_list0) are list 0 */
     uint8_t  hme_prune_enabled;               /* me_hme_prune_ctrls.enable_me_hme_ref_pruning with a threshold != (uint16_t)~0 */
     uint16_t prune_ref_if_hme_sad_dev_bigger_than_th;
-    uint8_t  sr_adjustment;                   /* me_sr_adjustment_ctrls.enable_me_sr_adjustment: 0 or 1 (2 adds content-dependent probes: not covered) */
+    uint8_t  sr_adjustment;                   /* me_sr_adjustment_ctrls.enable_me_sr_adjustment: 0, 1 or 2.  2 (screen-content levels 4 / 5) adds two rules to integer_search_b64
+                                               * (:1349-1364, only without me_early_exit_th): the height halves when the HME result is already good (check_00_center's SAD of an
+                                               * accurate centre, or -- is_ref -- the HME SAD, below 24 * 24); else both sides halve for every slot but the first when the first
+                                               * slot's final 64x64 SAD of the same SB is below 5000 -- the first slot is therefore searched before the geometry of the others */
     uint8_t  pad2;
     uint16_t reduce_me_sr_based_on_mv_length_th, stationary_hme_sad_abs_th, stationary_me_sr_divisor, reduce_me_sr_based_on_hme_sad_abs_th,
              me_sr_divisor_for_low_hme_sad;
@@ -635,6 +642,7 @@ typedef struct SvtHipMeStageParams {
     SvtHipMeResultsParams results;       /* formatting parameters (n_sb is filled in by the session) */
     uint16_t reduce_hme_l0_sr_th_min, reduce_hme_l0_sr_th_max; /* me_ctx->reduce_hme_l0_sr_th_* when distance_based_hme_resizing is on (else 0): see SvtHipHmeLevelParams */
     int16_t  hme_l0_sa_width_ref2[8], hme_l0_sa_height_ref2[8]; /* the level-0 areas with the (2 + ref index) divisors */
+    int16_t  hme_l0_sa_width_ref4[8], hme_l0_sa_height_ref4[8]; /* ... with the (4 + ref index) divisors: read with sr_adjustment == 2 only (SvtHipHmeLevelParams.l0_still_rule) */
 } SvtHipMeStageParams;
 int svt_hip_me_session_enable_stage(void *session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,
                                     uint32_t max_me_area_height);

@@ -14,8 +14,8 @@
  * and the per-SB statistics arrays, which is everything svt_aom_motion_estimation_b64 leaves behind for a PAME task
  * (motion_estimation.c:3076-3152).  Segments, the processed-SB counter, global motion, open-loop intra search: untouched reference code.
  *
- * A picture whose settings the device stage does not cover (super-resolution / resize re-ME, RTC's data-dependent HME resizing,
- * enable_me_sr_adjustment == 2, HME without level 1) is DECLINED as a whole and runs the reference's C code; declines are counted and the
+ * A picture whose settings the device stage does not cover (super-resolution / resize re-ME) is DECLINED as a whole and runs the reference's C code
+ * (the low-delay level-0 resizing, enable_me_sr_adjustment == 2 and level-0-only HME are covered since round 3); declines are counted and the
  * identity tests require zero of them for the configurations they claim.  SVT_HIP_ME_SEAM_STATS=<file> receives the counters at exit.
  */
 #define _GNU_SOURCE /* RTLD_DEFAULT */
@@ -186,7 +186,6 @@ static int fill_stage(PictureParentControlSet *pcs, MeContext *c, SvtHipMeStageP
     memset(S, 0, sizeof(*S));
     if (pcs->frame_superres_enabled || pcs->frame_resize_enabled) return decline("super-resolution / resize");
     if (!c->enable_hme_flag || !c->enable_hme_level0_flag || (!c->enable_hme_level1_flag && c->enable_hme_level2_flag)) return decline("HME without level 0, or level 2 without level 1");
-    if (c->me_sr_adjustment_ctrls.enable_me_sr_adjustment > 1) return decline("enable_me_sr_adjustment == 2");
     if (c->num_hme_sa_w * c->num_hme_sa_h > 4) return decline("more than 2 x 2 HME regions");
     const uint32_t n0 = c->num_of_ref_pic_to_search[0], n1 = c->num_of_list_to_search > 1 ? c->num_of_ref_pic_to_search[1] : 0, n = n0 + n1;
     if (n == 0 || n > SEAM_MAX_REFS || n0 > 4 || n1 > 4) return decline("reference count");
@@ -257,6 +256,14 @@ static int fill_stage(PictureParentControlSet *pcs, MeContext *c, SvtHipMeStageP
                 w2 = ((w2 * f) + 15) & ~15; h2 = h2 * f;
                 S->hme_l0_sa_width_ref2[k] = (int16_t)(w2 < w2max ? w2 : w2max); S->hme_l0_sa_height_ref2[k] = (int16_t)(h2 < h2max ? h2 : h2max);
                 S->reduce_hme_l0_sr_th_min = c->reduce_hme_l0_sr_th_min; S->reduce_hme_l0_sr_th_max = c->reduce_hme_l0_sr_th_max;
+                if (sr->enable_me_sr_adjustment == 2) { /* the screen-content levels: (4 + index) where list 0's motion is small on both axes (:1836-1841) */
+                    SearchAreaMinMax a4 = c->hme_l0_sa;
+                    a4.sa_min.width /= 4 + ri; a4.sa_min.height /= 4 + ri; a4.sa_max.width /= 4 + ri; a4.sa_max.height /= 4 + ri;
+                    int w4 = a4.sa_min.width / c->num_hme_sa_w, h4 = a4.sa_min.height / c->num_hme_sa_h;
+                    const int w4max = ((a4.sa_max.width / c->num_hme_sa_w) + 15) & ~15, h4max = a4.sa_max.height / c->num_hme_sa_h;
+                    w4 = ((w4 * f) + 15) & ~15; h4 = h4 * f;
+                    S->hme_l0_sa_width_ref4[k] = (int16_t)(w4 < w4max ? w4 : w4max); S->hme_l0_sa_height_ref4[k] = (int16_t)(h4 < h4max ? h4 : h4max);
+                }
             }
             S->results.ref_picture_number[li][ri] = ref_number;
         }

@@ -242,7 +242,8 @@ class HmeLevelParams(C.Structure):
                 ("ref_org_y", C.c_uint32), ("ref_width", C.c_uint32), ("ref_height", C.c_uint32), ("ref_off", C.c_uint64 * 8),
                 ("per_ref_area", C.c_uint8), ("pad1", C.c_uint8 * 3), ("sa_width_ref", C.c_int16 * 8), ("sa_height_ref", C.c_int16 * 8),
                 ("n_refs_list0", C.c_uint8), ("ref_pic_index", C.c_uint8 * 8), ("prehme_enabled", C.c_uint8), ("pad2", C.c_uint8 * 2),
-                ("zz_skip_th", C.c_uint32), ("l0_mv_th_min", C.c_uint16), ("l0_mv_th_max", C.c_uint16), ("sa_width_ref2", C.c_int16 * 8), ("sa_height_ref2", C.c_int16 * 8)]
+                ("zz_skip_th", C.c_uint32), ("l0_mv_th_min", C.c_uint16), ("l0_mv_th_max", C.c_uint16), ("sa_width_ref2", C.c_int16 * 8), ("sa_height_ref2", C.c_int16 * 8),
+                ("l0_still_rule", C.c_uint8), ("pad3", C.c_uint8), ("sa_width_ref4", C.c_int16 * 8), ("sa_height_ref4", C.c_int16 * 8)]
 
 
 class HmeChainInputs(C.Structure):
@@ -395,7 +396,8 @@ class MeStageParams(C.Structure):
                 ("prehme_l1_early_exit", C.c_uint8), ("prehme_sa_min_width", C.c_uint16 * 2), ("prehme_sa_min_height", C.c_uint16 * 2),
                 ("prehme_sa_max_width", C.c_uint16 * 2), ("prehme_sa_max_height", C.c_uint16 * 2), ("zz_sad_th", C.c_uint32), ("phme_sad_th", C.c_uint32),
                 ("zz_sad_pct", C.c_uint16), ("phme_sad_pct", C.c_uint16), ("prev_me_stage_based_exit_th", C.c_uint32), ("me_safe_limit_zz_th", C.c_uint32), ("tf_me_exit_th", C.c_uint32), ("results", MeResultsParams),
-                ("reduce_hme_l0_sr_th_min", C.c_uint16), ("reduce_hme_l0_sr_th_max", C.c_uint16), ("hme_l0_sa_width_ref2", C.c_int16 * 8), ("hme_l0_sa_height_ref2", C.c_int16 * 8)]
+                ("reduce_hme_l0_sr_th_min", C.c_uint16), ("reduce_hme_l0_sr_th_max", C.c_uint16), ("hme_l0_sa_width_ref2", C.c_int16 * 8), ("hme_l0_sa_height_ref2", C.c_int16 * 8),
+                ("hme_l0_sa_width_ref4", C.c_int16 * 8), ("hme_l0_sa_height_ref4", C.c_int16 * 8)]
 
 
 class MeResultsHost(C.Structure):

@@ -59,7 +59,7 @@ inline HmeWs hme_ws(uint32_t n) {
 // integer_search_b64's area geometry per slot -> SvtHipMeSearchDesc.  Item index = ref * n_sb + sb.
 struct MeIntRec { // per item, between the phases of the probing form
     int16_t  cx, cy, w, h; // search centre (after check_00_center), area before the variance scaling
-    uint8_t  live, check00, probe, pad;
+    uint8_t  live, check00, probe, hme_good; // hme_good: is_ref and the slot's HME SAD is below 24 * 24 (sr_adjustment 2, :1350-1351)
 };
 // PHASE 0: all in one kernel (no probes).  PHASE 1: up to the base area -> records (+ single-point descriptors for the variance probe).
 // PHASE 2: records (+ probe tables) -> final descriptors.
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(64) void me_int_descs_kernel(const SvtHipMeIntegerS
                                                           const int16_t* __restrict__ hme_sc, uint8_t* __restrict__ do_ref, uint32_t* __restrict__ divisor,
                                                           const uint32_t* __restrict__ zz_sad, SvtHipMeSearchDesc* __restrict__ descs,
                                                           int16_t* __restrict__ sc_out, unsigned long long* __restrict__ sad_out,
-                                                          MeIntRec* __restrict__ recs, const uint32_t* __restrict__ probe_sad) {
+                                                          MeIntRec* __restrict__ recs, const uint32_t* __restrict__ probe_sad, const uint32_t r_begin,
+                                                          const uint32_t r_end) { // [r_begin, r_end): the slots whose descriptors are produced (PHASE 2; the others: all)
     const uint32_t n_sb = P.sbs_x * P.sbs_y, sb = blockIdx.x * blockDim.x + threadIdx.x;
     if (sb >= n_sb) return;
     int16_t            cx[8], cy[8];
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(64) void me_int_descs_kernel(const SvtHipMeIntegerS
         sc_out[2 * i] = x; sc_out[2 * i + 1] = y; sad_out[i] = best;
         best_all = best < best_all ? best : best_all;
     }
-    for (uint32_t r = 0; r < P.n_refs; r++) {
+    for (uint32_t r = r_begin; r < r_end; r++) {
         const uint32_t i = r * n_sb + sb;
         const int      b64_origin_x = (int)(sb % P.sbs_x) * 64, b64_origin_y = (int)(sb / P.sbs_x) * 64;
         const int16_t  pad_width = 63, pad_height = 63, org_x = (int16_t)b64_origin_x, org_y = (int16_t)b64_origin_y;
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(64) void me_int_descs_kernel(const SvtHipMeIntegerS
         if (PHASE == 1) {
             MeIntRec rec;
             rec.cx = x_search_center; rec.cy = y_search_center; rec.w = search_area_width; rec.h = search_area_height;
-            rec.live = live; rec.check00 = live && !P.me_early_exit_th && P.is_ref && (x_search_center != 0 || y_search_center != 0); rec.probe = 0; rec.pad = 0;
+            rec.live = live; rec.check00 = live && !P.me_early_exit_th && P.is_ref && (x_search_center != 0 || y_search_center != 0); rec.probe = 0;
+            rec.hme_good = P.is_ref && csad[r] < 24 * 24;
             recs[i] = rec;
             continue;
         }
@@ -223,13 +225,15 @@ __device__ __forceinline__ uint32_t sb_sub_sad(const uint8_t* __restrict__ s, co
 // check_00_center (:1139-1206), one wave per item flagged by phase 1: clip the HME centre to the picture + 63, compare its sub-sampled SAD with the
 // zero-motion one, keep (0, 0) when that is not worse; then decide whether the variance probe applies and emit its single-point descriptor.
 __global__ __launch_bounds__(256) void me_int_probe_kernel(const SvtHipMeIntegerSearchParams P, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
-                                                           MeIntRec* __restrict__ recs, SvtHipMeSearchDesc* __restrict__ probe_descs, const uint32_t n) {
-    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+                                                           MeIntRec* __restrict__ recs, SvtHipMeSearchDesc* __restrict__ probe_descs, const uint32_t i0, const uint32_t n,
+                                                           const uint32_t* __restrict__ slot0_sad) { // items [i0, n); slot0_sad: the first slot's final tables (sr_adjustment 2, i0 > 0)
+    const uint32_t i = i0 + blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
     if (i >= n) return;
     const uint32_t n_sb = P.sbs_x * P.sbs_y, sb = i % n_sb, r = i / n_sb;
     const uint32_t fx = (sb % P.sbs_x) * 64, fy = (sb / P.sbs_x) * 64;
     const uint32_t bw = P.aligned_width - fx < 64 ? P.aligned_width - fx : 64, bh = P.aligned_height - fy < 64 ? P.aligned_height - fy : 64;
     MeIntRec rec = recs[i];
+    unsigned long long best_hme_sad = ~0ull;
     if (rec.check00) {
         const int16_t org_x = (int16_t)fx, org_y = (int16_t)fy, pad = 63, ref_w = (int16_t)P.ref_width, ref_h = (int16_t)P.ref_height;
         int16_t x = rec.cx, y = rec.cy;
@@ -243,6 +247,13 @@ __global__ __launch_bounds__(256) void me_int_probe_kernel(const SvtHipMeInteger
         const uint32_t zero = sb_sub_sad(s, P.src_stride, f0, P.ref_stride, bw, bh, l) << 1, hme = sb_sub_sad(s, P.src_stride, f1, P.ref_stride, bw, bh, l) << 1;
         if (zero <= hme) { x = 0; y = 0; } // MIN(zero cost, hme cost) == zero cost
         rec.cx = x; rec.cy = y;
+        best_hme_sad = hme; // check_00_center returns the SAD at the (clipped) HME centre
+    }
+    if (P.sr_adjustment == 2 && !P.me_early_exit_th) { // (:1349-1364; inside the branch without me_early_exit_th)
+        const int16_t h_before = rec.h;
+        const bool    hme_is_accurate = !(rec.check00 && rec.cx == 0 && rec.cy == 0);
+        if ((hme_is_accurate && best_hme_sad < 24 * 24) || rec.hme_good) rec.h = (int16_t)(rec.h / 2);
+        if (r > 0 && slot0_sad[(size_t)sb * 85] < 5000 && rec.h == h_before) { rec.h = (int16_t)(rec.h >> 1); rec.w = (int16_t)(rec.w >> 1); } // (the width was not touched before)
     }
     rec.probe = rec.live && P.me_8x8_var_enabled && (int)rec.w * (int)rec.h > 24;
     if (l == 0) {
@@ -364,7 +375,7 @@ void svt_hip_me_integer_search_batch(const SvtHipMeIntegerSearchParams* params, 
     svthip::ensure_device();
     const uint32_t n = params->n_refs * params->sbs_x * params->sbs_y;
     if (n == 0) return;
-    if (params->n_refs > 8 || params->regions == 0 || params->sr_adjustment > 1 || (params->me_early_exit_th && !zz_sad)) {
+    if (params->n_refs > 8 || params->regions == 0 || params->sr_adjustment > 2 || (params->me_early_exit_th && !zz_sad)) {
         fprintf(stderr, "libsvtav1_hip: svt_hip_me_integer_search_batch: bad parameters\n");
         abort();
     }
@@ -380,29 +391,37 @@ void svt_hip_me_integer_search_batch(const SvtHipMeIntegerSearchParams* params, 
     hipStream_t    st = (hipStream_t)stream;
     uint32_t mw, mh;
     me_int_max_area(params, mw, mh);
-    const bool probing = (params->is_ref && !params->me_early_exit_th) || params->me_8x8_var_enabled;
+    const bool sr2     = params->sr_adjustment == 2 && !params->me_early_exit_th; // two more area rules, one of which reads the first slot's final SADs
+    const bool probing = (params->is_ref && !params->me_early_exit_th) || params->me_8x8_var_enabled || sr2;
     if (!probing) {
         hipLaunchKernelGGL(me_int_descs_kernel<0>, gsb, bsb, 0, st, *params, (const unsigned long long*)hme_sad, hme_sc, do_ref, divisor, zz_sad, descs, sc_out,
-                           (unsigned long long*)sad_out, (MeIntRec*)nullptr, (const uint32_t*)nullptr);
+                           (unsigned long long*)sad_out, (MeIntRec*)nullptr, (const uint32_t*)nullptr, 0u, params->n_refs);
         SVT_LAUNCH_CHECK();
         svt_hip_me_fullpel_search_batch(src_base, ref_base, descs, n, mw, mh, params->sub_sad, best_sad, best_mv, ws2, stream);
         return;
     }
     hipLaunchKernelGGL(me_int_descs_kernel<1>, gsb, bsb, 0, st, *params, (const unsigned long long*)hme_sad, hme_sc, do_ref, divisor, zz_sad, descs, sc_out,
-                       (unsigned long long*)sad_out, recs, (const uint32_t*)nullptr);
+                       (unsigned long long*)sad_out, recs, (const uint32_t*)nullptr, 0u, params->n_refs);
     SVT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(me_int_probe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, *params, src_base, ref_base, recs, pdescs, n);
-    SVT_LAUNCH_CHECK();
-    if (params->me_8x8_var_enabled) svt_hip_me_fullpel_search_batch(src_base, ref_base, pdescs, n, 1, 1, params->sub_sad, psad, pmv, ws2, stream);
-    hipLaunchKernelGGL(me_int_descs_kernel<2>, gsb, bsb, 0, st, *params, (const unsigned long long*)hme_sad, hme_sc, do_ref, divisor, zz_sad, descs, sc_out,
-                       (unsigned long long*)sad_out, recs, (const uint32_t*)psad);
-    SVT_LAUNCH_CHECK();
-    svt_hip_me_fullpel_search_batch(src_base, ref_base, descs, n, mw, mh, params->sub_sad, best_sad, best_mv, ws2, stream);
-    if (params->me_8x8_var_enabled) {
-        hipLaunchKernelGGL(me_int_merge_kernel, dim3((n * 85 + 255) / 256), dim3(256), 0, st, (const MeIntRec*)recs, (const uint32_t*)psad, (const uint32_t*)pmv, best_sad,
-                           best_mv, n);
+    // item range [i0, i1) = slots [r0, r1): everything at once, or -- sr_adjustment 2 with more than one slot -- the first slot through to its final tables, then the others
+    auto pass = [&](const uint32_t r0, const uint32_t r1) {
+        const uint32_t i0 = r0 * n_sb, i1 = r1 * n_sb, m = i1 - i0;
+        hipLaunchKernelGGL(me_int_probe_kernel, dim3((m + 3) / 4), dim3(256), 0, st, *params, src_base, ref_base, recs, pdescs, i0, i1, (const uint32_t*)best_sad);
         SVT_LAUNCH_CHECK();
-    }
+        if (params->me_8x8_var_enabled)
+            svt_hip_me_fullpel_search_batch(src_base, ref_base, pdescs + i0, m, 1, 1, params->sub_sad, psad + (size_t)i0 * 85, pmv + (size_t)i0 * 85, ws2, stream);
+        hipLaunchKernelGGL(me_int_descs_kernel<2>, gsb, bsb, 0, st, *params, (const unsigned long long*)hme_sad, hme_sc, do_ref, divisor, zz_sad, descs, sc_out,
+                           (unsigned long long*)sad_out, recs, (const uint32_t*)psad, r0, r1);
+        SVT_LAUNCH_CHECK();
+        svt_hip_me_fullpel_search_batch(src_base, ref_base, descs + i0, m, mw, mh, params->sub_sad, best_sad + (size_t)i0 * 85, best_mv + (size_t)i0 * 85, ws2, stream);
+        if (params->me_8x8_var_enabled) {
+            hipLaunchKernelGGL(me_int_merge_kernel, dim3((m * 85 + 255) / 256), dim3(256), 0, st, (const MeIntRec*)recs + i0, (const uint32_t*)psad + (size_t)i0 * 85,
+                               (const uint32_t*)pmv + (size_t)i0 * 85, best_sad + (size_t)i0 * 85, best_mv + (size_t)i0 * 85, m);
+            SVT_LAUNCH_CHECK();
+        }
+    };
+    if (sr2 && params->n_refs > 1) { pass(0, 1); pass(1, params->n_refs); }
+    else pass(0, params->n_refs);
 }
 
 } // extern "C"

@@ -4,7 +4,8 @@
 #pragma once
 #include "../../include/svtav1_hip.h"
 
-// l0_flags (level 0 with l0_mv_th_*): bit 0 = the width takes the (2 + ref index) divisor, bit 1 = the height does (get_hme_l0_search_area :1809-1850)
+// l0_flags (level 0 with l0_mv_th_*): bit 0 = the width takes the (2 + ref index) divisor, bit 1 = the height does, bit 2 = both take (4 + ref index)
+// (get_hme_l0_search_area :1809-1850)
 __device__ __forceinline__ void hme_item_geometry(const SvtHipHmeLevelParams& P, const uint32_t i, const int16_t prev_x, const int16_t prev_y,
                                                   SvtHipSadLoopDesc& d, int16_t& out_origin_x, int16_t& out_origin_y, const int l0_flags = 0) {
     const uint32_t regions = (uint32_t)P.num_hme_sa_w * P.num_hme_sa_h, n_sb = P.sbs_x * P.sbs_y;
@@ -16,8 +17,8 @@ __device__ __forceinline__ void hme_item_geometry(const SvtHipHmeLevelParams& P,
     const int16_t  org_x = (int16_t)((int16_t)fx >> shift), org_y = (int16_t)((int16_t)fy >> shift);
     const uint32_t block_width = b64_w >> shift, block_height = b64_h >> shift;
 
-    int16_t       sa_width  = (int16_t)(((P.per_ref_area ? ((l0_flags & 1) ? P.sa_width_ref2[r] : P.sa_width_ref[r]) : P.sa_width) + 7) & ~0x07);
-    int16_t       sa_height = P.per_ref_area ? ((l0_flags & 2) ? P.sa_height_ref2[r] : P.sa_height_ref[r]) : P.sa_height;
+    int16_t       sa_width  = (int16_t)(((P.per_ref_area ? ((l0_flags & 4) ? P.sa_width_ref4[r] : (l0_flags & 1) ? P.sa_width_ref2[r] : P.sa_width_ref[r]) : P.sa_width) + 7) & ~0x07);
+    int16_t       sa_height = P.per_ref_area ? ((l0_flags & 4) ? P.sa_height_ref4[r] : (l0_flags & 2) ? P.sa_height_ref2[r] : P.sa_height_ref[r]) : P.sa_height;
     const int16_t pad_width = (int16_t)(P.level == 2 ? 63 : (int)P.ref_org_x - 1), pad_height = (int16_t)(P.level == 2 ? 63 : (int)P.ref_org_y - 1);
     const int16_t ref_w = (int16_t)P.ref_width, ref_h = (int16_t)P.ref_height;
     int16_t       sa_origin_x, sa_origin_y;

@@ -167,7 +167,7 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
                 fmt->max_cand > s->max_cand))
         return -4;
     if (stage && n_refs) { // every refusal happens here, before anything is enqueued or any session state changes
-        if (stage->sr_adjustment > 1) return -5;                                  // enable_me_sr_adjustment == 2 (screen-content levels 4 / 5): not covered
+        if (stage->sr_adjustment > 2) return -5;
         if (stage->hme_levels > 3) return -5;
         if (stage->prehme_enabled && (stage->num_hme_sa_w != 2 || stage->num_hme_sa_h != 2)) return -5; // get_worst_quadrant is written for 2 x 2 regions
         if ((uint32_t)stage->results.num_of_ref_pic_to_search[0] + stage->results.num_of_ref_pic_to_search[1] != n_refs) return -4;
@@ -326,6 +326,10 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
             if (stage->reduce_hme_l0_sr_th_min && stage->reduce_hme_l0_sr_th_max) { // level-0 areas resized from list 0 / reference 0's level-0 motion (low-delay settings)
                 P[0].l0_mv_th_min = stage->reduce_hme_l0_sr_th_min; P[0].l0_mv_th_max = stage->reduce_hme_l0_sr_th_max;
                 for (uint32_t k = 0; k < n_refs; k++) { P[0].sa_width_ref2[k] = stage->hme_l0_sa_width_ref2[k]; P[0].sa_height_ref2[k] = stage->hme_l0_sa_height_ref2[k]; }
+                if (stage->sr_adjustment == 2) {
+                    P[0].l0_still_rule = 1;
+                    for (uint32_t k = 0; k < n_refs; k++) { P[0].sa_width_ref4[k] = stage->hme_l0_sa_width_ref4[k]; P[0].sa_height_ref4[k] = stage->hme_l0_sa_height_ref4[k]; }
+                }
             }
         }
         SvtHipHmeChainInputs in;

@@ -988,7 +988,8 @@ __global__ __launch_bounds__(256, 4) void hme_chain_kernel(const HmeChainArgs A)
                 const uint32_t it0 = sb * regions;
                 const int      l0x = A.sc_out[0][2 * it0], l0y = A.sc_out[0][2 * it0 + 1], ax = l0x < 0 ? -l0x : l0x, ay = l0y < 0 ? -l0y : l0y;
                 const bool     is_ver = ax < (int)P.l0_mv_th_min && ay > (int)P.l0_mv_th_max, is_hor = ax > (int)P.l0_mv_th_max && ay < (int)P.l0_mv_th_min;
-                l0_flags = (is_hor ? 0 : 1) | (is_ver ? 0 : 2);
+                const bool     is_still = P.l0_still_rule && ax < 3 * (int)P.l0_mv_th_min && ay < 3 * (int)P.l0_mv_th_min; // (:1825-1826, :1836-1841)
+                l0_flags = (is_hor ? 0 : 1) | (is_ver ? 0 : 2) | (is_still ? 4 : 0);
             }
             hme_item_geometry(P, item, px, py, d, ox, oy, l0_flags);
             const int W = d.search_area_width;

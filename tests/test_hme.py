@@ -494,6 +494,14 @@ STAGE_OPTS = [dict(name="baseline"),
               # the low-delay settings: level-0 areas of every slot but (list 0, reference 0) resized from that slot's level-0 motion of the same SB (enc_mode_config.c:702-714)
               dict(name="l0_resize_from_list0_motion", dbr=1, sr=(1, 4, 12000, 8, 12000, 8), l0=(64, 48, 128, 96), l0_th=(8, 12)),
               dict(name="l0_resize_from_list0_motion_mixed", dbr=1, sr=(1, 4, 12000, 8, 12000, 8), l0=(16, 8, 32, 16), l0_th=(30, 2), levels=2, motion=5),  # thresholds under which SBs take all four width / height combinations
+              # enable_me_sr_adjustment == 2 (the screen-content levels 4 / 5, enc_mode_config.c:485-505): the height halves on a good HME result, else both sides halve for the
+              # slots after the first when the first slot's final 64x64 SAD is small (motion_estimation.c:1349-1364) -- the first slot is searched before the others' geometry
+              dict(name="sr2", sr=(2, 16, 20000, 8, 20000, 8), me=(16, 9, 48, 24)),
+              dict(name="sr2_is_ref_clean", sr=(2, 16, 20000, 8, 20000, 8), me=(16, 10, 48, 24), is_ref=1, noise=(1, 1)),  # noise-free pictures: HME SADs below 24 * 24, check_00_center's too
+              dict(name="sr2_is_ref_var_probe", sr=(2, 4, 12000, 2, 6000, 2), me=(24, 12, 48, 24), is_ref=1, noise=(2, 1), var=(2000, 20000, 200000), hme_prune=40, levels=2),
+              dict(name="sr2_early_exit", sr=(2, 16, 20000, 8, 20000, 8), me=(16, 9, 48, 24), me_early_exit_th=64 * 64 * 8, is_ref=1),  # with me_early_exit_th the two rules are off
+              dict(name="sr2_l0_still", dbr=1, sr=(2, 16, 20000, 8, 20000, 8), l0=(64, 48, 128, 96), l0_th=(3, 12), me=(16, 9, 48, 24)),  # + level-0 areas / (4 + index) where list 0's motion is small
+              dict(name="sr2_l0_still_small_areas", dbr=1, sr=(2, 16, 20000, 8, 20000, 8), l0=(16, 8, 32, 16), l0_th=(6, 30), motion=4, levels=1, me=(8, 3, 24, 12)),  # ... areas small enough for the (4 + index) divisor to lose the motion (the mutation without the rule fails here)
               dict(name="base_layer", tl=0),
               dict(name="base_layer_prune", tl=0, hme_prune=25, sr=(1, 4, 12000, 8, 12000, 8), me_early_exit_th=64 * 64 * 8, zz=(20 * 64 * 64, 5), is_ref=1,
                    prehme=dict(skip=1, l1=1, sa=((8, 24, 8, 48), (16, 7, 32, 7)), phme=(10 * 64 * 64, 5))),
@@ -527,9 +535,10 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
     mo = opt.get("motion", 1)  # displacement between consecutive pictures: (mo, 2 mo) samples (large values: the level-0 centres leave zero)
     for k in range(4):
         a = np.zeros((rows, stride), np.uint8)
-        a[PAD:PAD + H, PAD:PAD + W] = base[8 + k * mo:8 + k * mo + H, 8 + 2 * k * mo:8 + 2 * k * mo + W] + g.integers(0, 4, (H, W), dtype=np.uint8)
+        nz = opt.get("noise", (4, 2))  # noise amplitudes of the moving / the static region (1 = none)
+        a[PAD:PAD + H, PAD:PAD + W] = base[8 + k * mo:8 + k * mo + H, 8 + 2 * k * mo:8 + 2 * k * mo + W] + g.integers(0, nz[0], (H, W), dtype=np.uint8)
         # a static region (zero-motion SAD small enough for the early exits) next to the moving one
-        a[PAD:PAD + H, PAD:PAD + 100] = base[8:8 + H, 8:8 + 100] + g.integers(0, 2, (H, 100), dtype=np.uint8)
+        a[PAD:PAD + H, PAD:PAD + 100] = base[8:8 + H, 8:8 + 100] + g.integers(0, nz[1], (H, 100), dtype=np.uint8)
         oracle.oracle_generate_padding(p(a), stride, W, H, PAD, PAD)
         pics.append(a)
     numbers = {0: 41, 1: 38, 2: 39, 3: 40}  # picture 3 is the source; list 0 = pictures 2, 1 (past), list 1 = picture 0 (future)
@@ -575,6 +584,9 @@ def test_me_stage_vs_reference_motion_estimation_b64(be, oracle, ref, oi):
         b2 = [v // (2 + rpi[r]) for v in l0]  # the (2 + index) divisors of the low-delay resizing (:1829-1850)
         S.hme_l0_sa_width_ref2[r] = min((((b2[0] // nw) * dist[r]) + 15) & ~15, ((b2[2] // nw) + 15) & ~15)
         S.hme_l0_sa_height_ref2[r] = min((b2[1] // nh) * dist[r], b2[3] // nh)
+        b4 = [v // (4 + rpi[r]) for v in l0]  # enable_me_sr_adjustment == 2: small motion on both axes (:1836-1841)
+        S.hme_l0_sa_width_ref4[r] = min((((b4[0] // nw) * dist[r]) + 15) & ~15, ((b4[2] // nw) + 15) & ~15)
+        S.hme_l0_sa_height_ref4[r] = min((b4[1] // nh) * dist[r], b4[3] // nh)
     if "l0_th" in opt:
         S.reduce_hme_l0_sr_th_min, S.reduce_hme_l0_sr_th_max = opt["l0_th"]
     S.me_early_exit_th = opt.get("me_early_exit_th", 0)

@@ -91,6 +91,11 @@ CASES = {
     "lowdelay_720p_p8_8bit": (1280, 720, 24, 8, ["--preset", "8", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+static", "+seam", "+tfseam", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam"]),
     "lowdelay_720p_p10_10bit": (1280, 720, 24, 10, ["--preset", "10", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+static", "+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam"]),
     "lowdelay_1080p_p9_lp4": (1920, 1080, 24, 8, ["--preset", "9", "--lp", "4", "--pred-struct", "1", "--tune", "1", "+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam"]),  # (moving scene)
+    # screen content (--scm 1): enable_me_sr_adjustment == 2 -- search areas halved from check_00_center's SAD / the first reference's final SAD; with low delay also
+    # the (4 + index) level-0 areas
+    "screen_p8_8bit": (448, 264, 16, 8, ["--preset", "8", "--lp", "1", "--scm", "1", "+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam"]),
+    "screen_p5_8bit_lp2": (448, 264, 12, 8, ["--preset", "5", "--lp", "2", "--scm", "1", "+seam", "+tfseam", "+tfdriver"]),
+    "screen_lowdelay_720p_p9": (1280, 720, 16, 8, ["--preset", "9", "--lp", "1", "--scm", "1", "--pred-struct", "1", "--tune", "1", "+static", "+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam"]),
     "tfsubpel_p2_10bit": (256, 144, 6, 10, ["--preset", "2", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),  # high bit depth: the seam hands those searches to the reference
     "lrseam_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+lrseam"]),  # 1080p: tens of restoration units per plane, all host cores
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
@@ -134,6 +139,9 @@ CASES = {
     "tiny_lowdelay_p10_10bit": (128, 128, 10, 10, ["--preset", "10", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+seam", "+cdefseam", "+dlfseam"]),
     "tiny_lowdelay_720p_tf_10bit": (1280, 720, 10, 10, ["--preset", "8", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+static", "+tfseam", "+tfdriver"]),
     "tiny_lowdelay_720p_tf": (1280, 720, 10, 8, ["--preset", "8", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+static", "+tfseam", "+tfdriver"]),  # the low-delay temporal filter is on from 720p up (enc_handle.c:3303-3310)
+    "tiny_screen_p8": (128, 128, 10, 8, ["--preset", "8", "--lp", "1", "--scm", "1", "+seam"]),
+    "tiny_screen_p5_tf": (192, 128, 10, 8, ["--preset", "5", "--lp", "1", "--scm", "1", "+seam", "+tfseam", "+tfdriver"]),
+    "tiny_screen_lowdelay_p9": (192, 128, 12, 8, ["--preset", "9", "--lp", "1", "--scm", "1", "--pred-struct", "1", "--tune", "1", "+seam"]),
     "tiny_tfsubpel_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
     "tiny_tfseam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tiny_dlfseam_p4": (128, 64, 3, 8, ["--preset", "4", "--lp", "1", "+dlfseam"]),
@@ -148,7 +156,7 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
-SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tfdriver_", "tplseam_", "lowdelay_"))]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tfdriver_", "tplseam_", "lowdelay_", "screen_"))]
 
 
 def make_clip(path, w, h, n, bd, seed=7, static=False):
