@@ -95,7 +95,7 @@ CASES = {
     # the (4 + index) level-0 areas
     "screen_p8_8bit": (448, 264, 16, 8, ["--preset", "8", "--lp", "1", "--scm", "1", "+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam"]),
     "screen_p5_8bit_lp2": (448, 264, 12, 8, ["--preset", "5", "--lp", "2", "--scm", "1", "+seam", "+tfseam", "+tfdriver"]),
-    "screen_lowdelay_720p_p9": (1280, 720, 16, 8, ["--preset", "9", "--lp", "1", "--scm", "1", "--pred-struct", "1", "--tune", "1", "+static", "+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam"]),
+    "screen_lowdelay_720p_p9": (1280, 720, 16, 8, ["--preset", "9", "--lp", "1", "--scm", "1", "--pred-struct", "1", "--tune", "1", "+static", "+seam", "+cdefseam", "+dlfseam"]),  # (no temporal filter: off for screen content in low delay, enc_handle.c:3309)
     "tfsubpel_p2_10bit": (256, 144, 6, 10, ["--preset", "2", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),  # high bit depth: the seam hands those searches to the reference
     "lrseam_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+lrseam"]),  # 1080p: tens of restoration units per plane, all host cores
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
@@ -274,6 +274,7 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
         res["avx2_identical_to_c"] = len(x) > 0 and x == open(os.path.join(outdir, name + "_c.ivf"), "rb").read()
         same = same and res["avx2_identical_to_c"]
     res["identical"] = same
+    res["bitstream_equal"] = bool(same)  # the files alone; "identical" additionally demands that the stages the case names really ran
     if seam:
         st = dict(ln.split(None, 1) for ln in open(seam_file).read().splitlines()) if os.path.exists(seam_file) else {}
         res["seam"] = {k: (int(v) if v.strip().isdigit() else v.strip()) for k, v in st.items()}
@@ -351,7 +352,7 @@ def main():
         results.append(r)
         for k, v in r.get("counts", {}).items():
             union[k] = union.get(k, 0) + v
-        print("%-20s identical=%s  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs  %s" % (nme, r["identical"], r.get("calls"), r.get("pointers_hit"),
+        print("%-20s identical=%s (bitstream %s)  calls=%s  pointers hit=%s/%s  C %.1fs  HIP %.1fs  %s" % (nme, r["identical"], r.get("bitstream_equal"), r.get("calls"), r.get("pointers_hit"),
                                                                                         r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"],
                                                                                         str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", "")) + " " + str(r.get("tfsubpel", "")) + " " + str(r.get("tfdriver", "")) + " " + str(r.get("tplseam", "")) + " " + str(r.get("devices", ""))), flush=True)
         if "fps_c" in r:
