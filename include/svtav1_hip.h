@@ -1055,6 +1055,36 @@ typedef struct SvtHipTplHostPlanes {
 int svt_hip_tpl_src_stage_host(const SvtHipTplSrcParams *params, const SvtHipTplHostPlanes *planes, const uint8_t *total_me_candidate_index,
                                const uint32_t *me_mv_array, const uint8_t *me_candidate_array, SvtHipTplSrcStats *stats);
 
+/* ---- TPL dispenser, RECONSTRUCTION half (tpl_mc_flow_dispenser_sb_generic, src_ops_process.c:979-1198; same option set: tpl levels 4 / 5) ----
+ * Per block, from the statistics of the source-based half: the prediction into the picture's TPL reconstruction plane (mc_flow_rec_picture_buffer[frame_idx]) --
+ * NEWMV = the block at the full-pel vector of rec_refs[best_rf_idx] (:1016-1019: the TPL reconstruction of a frame inside the sliding window, else the
+ * reference's source picture), else DC from the RECONSTRUCTED neighbours (:1038-1070) --, residual against the source on the rows the transform sees -> forward
+ * DCT_DCT -> svt_av1_quantize_fp -> recon_error (:1112-1131), the inverse transform onto the prediction when (is_ref or intra prediction on) and a coefficient
+ * survived, skipped rows copied from the row above (:1135-1167), and the block's four statistics (:1170-1180) BEFORE result_model_store (:266), which stays the
+ * caller's (it depends on synth_blk_size only).  An intra block reads its left and upper neighbours' reconstruction: the stage walks the picture's blocks by
+ * anti-diagonals, one launch per diagonal (a valid order for the mixed 32x32 / 16x16 grid too: DESIGN 4.16). */
+typedef struct SvtHipTplReconParams {
+    SvtHipTplSrcParams src;        /* geometry, option set, quantizer row as for the source-based half (src.refs is not read) */
+    SvtHipTplRef       rec_refs[8]; /* per list * 4 + ref: the plane NEWMV blocks copy from, relative to rec_ref_base (valid / picture_number / max_* are not read) */
+    uint64_t           recon_off;  /* bytes from recon_base to picture sample (0, 0) of the reconstruction plane */
+    uint32_t           recon_stride;
+    uint8_t            is_ref;     /* pcs->tpl_data.is_ref */
+    uint8_t            pad[3];
+} SvtHipTplReconParams;
+typedef struct SvtHipTplReconStats { /* at the block's top-left 16x16 cell */
+    int64_t srcrf_dist, recrf_dist, srcrf_rate, recrf_rate;
+    uint8_t written;               /* as SvtHipTplSrcStats.written */
+    uint8_t coded;                 /* a coefficient survived the quantizer (eob != 0) */
+    uint8_t pad[6];
+} SvtHipTplReconStats;
+/* Device form: src_stats / out [rows16][cols16] as the source-based stage writes them; recon_base is read (neighbours) and written (every processed block). */
+void svt_hip_tpl_recon_stage(const SvtHipTplReconParams *params, const uint8_t *src_base, const uint8_t *rec_ref_base, const SvtHipTplSrcStats *src_stats,
+                             uint8_t *recon_base, SvtHipTplReconStats *out, void *stream);
+/* Host form: planes->src_buf / ref_buf[] as above with ref_buf[rf] = the buffer rec_refs[rf] lives in (only the references the statistics name are uploaded);
+ * recon_buf = start of the reconstruction picture's luma buffer (recon_rows rows of recon_stride bytes: uploaded, updated, downloaded). */
+int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams *params, const SvtHipTplHostPlanes *planes, const SvtHipTplSrcStats *src_stats, uint8_t *recon_buf,
+                                 uint32_t recon_rows, SvtHipTplReconStats *out);
+
 /* ---- the fixed-size symbols of the RTCD tables (what svt_hip_setup_rtcd installs): thin aliases of the generic forms above, declared here so that a caller can
  * also bind them by name.  Prototypes as the reference's pointers (aom_dsp_rtcd.h / common_dsp_rtcd.h). ---- */
 #define SVT_HIP_FOR_ALL_SAD_SIZES(X)                                                                                                              \

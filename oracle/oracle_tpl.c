@@ -162,3 +162,106 @@ void oracle_tpl_src_picture(const OracleTplParams *P, const uint8_t *src_base, c
             }
     }
 }
+
+/* ---- the RECONSTRUCTION half (tpl_mc_flow_dispenser_sb_generic, src_ops_process.c:979-1198), same option set ----------------------------------------------------
+ * Per block, in the reference's order (SBs in raster order, the blocks of an SB in z-order, tpl_blk_idx_tab :353):
+ *   1. prediction into the TPL reconstruction picture (mc_flow_rec_picture_buffer): NEWMV = the block at the full-pel vector of the reference's TPL picture
+ *      (:1016-1019: the reconstruction of a frame inside the sliding window, else its source picture; vectors are full-pel in this option set: subpel_depth =
+ *      FULL_PEL), else DC from the RECONSTRUCTED neighbours (:1038-1070: get_neighbor_samples_dc inside the picture,
+ *      svt_aom_update_neighbor_samples_array_open_loop_mb_recon, enc_intra_prediction.c:1214-1300, at its borders: the same 127 / 129 fill values as the source form);
+ *   2. residual against the source on every (1 << subsample_tx)-th row -> forward DCT_DCT (partial-frequency shape) -> svt_av1_quantize_fp -> recon_error
+ *      (get_quantize_error :224-247);
+ *   3. when the picture is a reference or intra prediction is on (:1135) and any coefficient survived: svt_aom_inv_transform_recon8bit (DCT_DCT, bd 8) onto the
+ *      prediction rows the transform saw, the rows between them become copies of the row above (:1149-1167);
+ *   4. recrf_dist = recon_error << 4 << subsample_tx; a block that is not NEWMV takes it as srcrf_dist too; recrf = max(srcrf, recrf) (:1170-1180).
+ * Output per block (at its top-left 16x16 cell): the four statistics BEFORE result_model_store (:266), which the caller applies. */
+void oracle_inv_txfm2d_add(const int32_t *input, const uint16_t *out_r, int stride_r, uint16_t *out_w, int stride_w, int tx_type, int tx_size, int bd);
+
+typedef struct OracleTplReconStats { /* = SvtHipTplReconStats */
+    int64_t srcrf_dist, recrf_dist, srcrf_rate, recrf_rate;
+    uint8_t written, coded, pad[6]; /* coded: a coefficient survived the quantizer (eob != 0) */
+} OracleTplReconStats;
+_Static_assert(sizeof(OracleTplReconStats) == 40, "layout");
+
+static void tpl_recon_block(const OracleTplParams *P, const OracleTplRef *rec_refs, int is_ref, const uint8_t *src, const uint8_t *rec_ref_base,
+                            const OracleTplSrcStats *s, uint8_t *rec, uint32_t rs, int x0, int y0, int size, OracleTplReconStats *o) {
+    const uint32_t ss = P->src_stride;
+    const int      W = (int)P->width, H = (int)P->height, st = P->subsample_tx, th = size >> st, n = size * th;
+    uint8_t       *dst = rec + (size_t)y0 * rs + x0;
+    if (s->best_mode == NEWMV_) {
+        const OracleTplRef *R = &rec_refs[s->best_rf_idx];
+        const uint8_t *rp = rec_ref_base + R->plane_off + (size_t)((int)R->org_y + y0 + (s->mv_row >> 3)) * R->stride + (int)R->org_x + x0 + (s->mv_col >> 3);
+        for (int y = 0; y < size; y++) memcpy(dst + (size_t)y * rs, rp + (size_t)y * R->stride, (size_t)size);
+    } else {
+        int sa = 0, sl = 0, dc;
+        for (int i = 0; i < size; i++) {
+            sa += (y0 > 0) ? ((x0 + i < W) ? rec[(size_t)(y0 - 1) * rs + x0 + i] : 127) : 0;
+            sl += (x0 > 0) ? ((y0 + i < H) ? rec[(size_t)(y0 + i) * rs + x0 - 1] : 129) : 0;
+        }
+        if (x0 > 0 && y0 > 0) dc = (sa + sl + size) / (2 * size);
+        else if (x0 > 0) dc = (sl + (size >> 1)) / size;
+        else if (y0 > 0) dc = (sa + (size >> 1)) / size;
+        else dc = 128;
+        for (int y = 0; y < size; y++) memset(dst + (size_t)y * rs, dc, (size_t)size);
+    }
+    int16_t diff[32 * 32];
+    int32_t coeff[32 * 32], dq[32 * 32];
+    const uint8_t *blk = src + (size_t)y0 * ss + x0;
+    for (int y = 0; y < th; y++)
+        for (int x = 0; x < size; x++) diff[y * size + x] = (int16_t)((int)blk[(size_t)(y << st) * ss + x] - (int)dst[(size_t)(y << st) * rs + x]);
+    oracle_fwd_txfm2d(diff, coeff, (uint32_t)size, 0 /* DCT_DCT */, tx_id(size, th), 8, P->pf_shape);
+    int64_t err = 0;
+    int     coded = 0;
+    for (int i = 0; i < n; i++) {
+        const int     k = i != 0;
+        const int32_t c = coeff[i], sign = c < 0 ? -1 : 0, a = (c ^ sign) - sign;
+        int32_t       d = 0;
+        if (((int64_t)a << 1) >= (int32_t)P->dequant[k]) {
+            int64_t t = (int64_t)a + P->round_fp[k];
+            t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+            const int32_t q = (int32_t)((t * P->quant_fp[k]) >> 16);
+            if (q) { d = (((int32_t)((uint32_t)q * (uint32_t)(int32_t)P->dequant[k])) ^ sign) - sign; coded = 1; }
+        }
+        dq[i] = d;
+        err += (int64_t)(c - d) * (c - d);
+    }
+    err >>= (size == 32 && th == 32) ? 0 : 2;
+    if (err < 1) err = 1;
+    if ((!P->disable_intra_pred || is_ref) && coded) {
+        uint16_t tmp[32 * 32]; /* svt_av1_inv_txfm_add_c (inv_transforms.c:3177-3193): widen, inverse at bd 8, narrow */
+        for (int y = 0; y < th; y++)
+            for (int x = 0; x < size; x++) tmp[y * size + x] = dst[(size_t)(y << st) * rs + x];
+        oracle_inv_txfm2d_add(dq, tmp, size, tmp, size, 0, tx_id(size, th), 8);
+        for (int y = 0; y < th; y++)
+            for (int x = 0; x < size; x++) dst[(size_t)(y << st) * rs + x] = (uint8_t)tmp[y * size + x];
+        for (int y = 0; y < size; y++)
+            if (y & ((1 << st) - 1)) memcpy(dst + (size_t)y * rs, dst + (size_t)(y & ~((1 << st) - 1)) * rs, (size_t)size);
+    }
+    memset(o, 0, sizeof(*o));
+    o->written = 1; o->coded = (uint8_t)coded;
+    o->recrf_dist = (err << TPL_DEP_COST_SCALE_LOG2_) << st;
+    o->recrf_rate = 0;
+    o->srcrf_dist = s->best_mode == NEWMV_ ? s->srcrf_dist : o->recrf_dist;
+    o->srcrf_rate = s->best_mode == NEWMV_ ? s->srcrf_rate : 0;
+    if (o->srcrf_dist > o->recrf_dist) o->recrf_dist = o->srcrf_dist;
+    if (o->srcrf_rate > o->recrf_rate) o->recrf_rate = o->srcrf_rate;
+}
+
+/* recon: sample (0, 0) of the picture's TPL reconstruction plane (read for the DC neighbours, written block by block); rec_refs[list * 4 + ref]: the plane NEWMV blocks copy from */
+void oracle_tpl_recon_picture(const OracleTplParams *P, const OracleTplRef *rec_refs, int is_ref, const uint8_t *src_base, const uint8_t *rec_ref_base,
+                              const OracleTplSrcStats *src_stats, uint8_t *recon, uint32_t recon_stride, OracleTplReconStats *out) {
+    const uint8_t *src = src_base + P->src_off;
+    const int      cols16 = (int)((P->aligned_width + 15) >> 4), aligned_h = (int)((P->height + 7) & ~7u);
+    for (uint32_t sb = 0; sb < P->n_sb; sb++) {
+        const int sx = (int)(sb % P->sbs_x) * 64, sy = (int)(sb / P->sbs_x) * 64;
+        const int bw = (int)P->aligned_width - sx < 64 ? (int)P->aligned_width - sx : 64, bh = aligned_h - sy < 64 ? aligned_h - sy : 64;
+        const int level = (bw == 64 && bh == 64) ? P->dispenser_search_level : 0, size = level ? 32 : 16, per = 64 / size;
+        for (int k = 0; k < per * per; k++) { /* z-order */
+            const int bx = (k & 1) | ((k >> 1) & 2), by = ((k >> 1) & 1) | ((k >> 2) & 2);
+            const int x0 = sx + bx * size, y0 = sy + by * size;
+            if (x0 + (size >> 1) > (int)P->width || y0 + (size >> 1) > (int)P->height) continue;
+            const size_t cell = (size_t)(y0 >> 4) * cols16 + (x0 >> 4);
+            tpl_recon_block(P, rec_refs, is_ref, src, rec_ref_base, &src_stats[cell], recon, recon_stride, x0, y0, size, &out[cell]);
+        }
+    }
+}

@@ -47,6 +47,8 @@ PROTOTYPES = {
     "svt_hip_get_thread_device": (C.c_int, []),
     "svt_hip_tpl_src_stage": (None, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "svt_hip_tpl_src_stage_host": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+    "svt_hip_tpl_recon_stage": (None, [vp, vp, vp, vp, vp, vp, vp]),
+    "svt_hip_tpl_recon_stage_host": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp]),
     "svt_hip_setup_rtcd": (C.c_int, [C.c_uint64]),
     "svt_hip_selftest": (C.c_int, [vp, vp]),
     "svt_hip_rate_probe": (None, [C.c_int, C.c_uint32, C.c_uint32, vp, vp]),
@@ -342,6 +344,19 @@ class TplSrcParams(C.Structure):
 
 
 assert C.sizeof(TplRef) == 40 and C.sizeof(TplSrcParams) == 376
+
+
+class TplReconParams(C.Structure):
+    """SvtHipTplReconParams: the TPL dispenser's reconstruction half of one picture (svt_hip_tpl_recon_stage)."""
+    _fields_ = [("src", TplSrcParams), ("rec_refs", TplRef * 8), ("recon_off", C.c_uint64), ("recon_stride", C.c_uint32), ("is_ref", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
+class TplReconStats(C.Structure):
+    _fields_ = [("srcrf_dist", C.c_int64), ("recrf_dist", C.c_int64), ("srcrf_rate", C.c_int64), ("recrf_rate", C.c_int64), ("written", C.c_uint8), ("coded", C.c_uint8),
+                ("pad", C.c_uint8 * 6)]
+
+
+assert C.sizeof(TplReconParams) == 376 + 320 + 16 and C.sizeof(TplReconStats) == 40
 TplSrcStats = np.dtype([("srcrf_dist", "<i8"), ("srcrf_rate", "<i8"), ("ref_frame_poc", "<u8"), ("mv_row", "<i2"), ("mv_col", "<i2"), ("best_rf_idx", "<i4"),
                         ("best_mode", "u1"), ("best_intra_mode", "u1"), ("written", "u1"), ("pad", "u1", (5,))])
 assert TplSrcStats.itemsize == 40

@@ -221,6 +221,189 @@ void launch_tpl(const SvtHipTplSrcParams& P, const uint8_t* src, const uint8_t* 
     SVT_LAUNCH_CHECK();
 }
 
+// ---- the reconstruction half -------------------------------------------------------------------------------------------------------------------------------------
+// One launch per anti-diagonal d of the 16x16 cell grid: the blocks whose top-left cell (cx, cy) has cx + cy == d.  A block reads the reconstruction of its left and
+// upper neighbours only (DC prediction), and those start on an earlier diagonal -- for the mixed grid too: SBs the picture edge cuts (16x16 blocks) lie right of /
+// below the complete ones (32x32 blocks), so a 32x32 block never has 16x16 neighbours on its left or above.  Same lane mapping as the source-based kernel; the
+// prediction tile lives in LDS (the column pass of the inverse adds it transposed), the quantised corner goes back into the transform tile for the inverse
+// (inv_txfm2d_kernel's two passes, txfm.hip).
+template <int SIZE, int TXH>
+__global__ __launch_bounds__(256) void tpl_recon_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                        const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,
+                                                        SvtHipTplReconStats* __restrict__ out, const int diag, const int cy_first, const int n_items) {
+    const SvtHipTplSrcParams& P = RP.src;
+    constexpr int T = SIZE, BPW = 256 / T, W = SIZE, PITCH = W + 1, NW = SIZE / 4, ST = SIZE == 2 * TXH ? 1 : (SIZE == 4 * TXH ? 2 : 0), PP = SIZE + 4;
+    constexpr int FS0 = fwd_shift0(W, TXH), FS1 = -fwd_shift1(W, TXH), FS2 = -fwd_shift2(W, TXH);
+    constexpr int CBC = kFwdCosCol[ilog2c(W) - 2][ilog2c(TXH) - 2], CBR = kFwdCosRow[ilog2c(W) - 2][ilog2c(TXH) - 2];
+    constexpr bool RECT1 = (W == 2 * TXH) || (TXH == 2 * W);
+    constexpr int  S0 = -inv_shift0(W, TXH);
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    __shared__ SvtHipTplRef s_refs[8];
+    if (threadIdx.x < 8) s_refs[threadIdx.x] = RP.rec_refs[threadIdx.x];
+    __syncthreads();
+    const int tid = threadIdx.x, sub = tid / T, t = tid % T;
+    const int item = (int)blockIdx.x * BPW + sub;
+    int32_t*  buf  = smem + sub * (TXH * PITCH);
+    uint8_t*  ptile = (uint8_t*)(smem + BPW * (TXH * PITCH)) + sub * (SIZE * PP); // prediction, then reconstruction: [SIZE rows][PP]
+    const int cy = cy_first + item, cx = diag - cy, x0 = cx * 16, y0 = cy * 16;
+    const int aligned_h = (int)((P.height + 7) & ~7u);
+    bool      active = item < n_items && cx >= 0;
+    const int sx = x0 & ~63, sy = y0 & ~63;
+    const bool complete = ((int)P.aligned_width - sx >= 64) && (aligned_h - sy >= 64);
+    const int  bsize = (complete && P.dispenser_search_level) ? 32 : 16;
+    active = active && bsize == SIZE && (SIZE == 16 || (((cx | cy) & 1) == 0));
+    active = active && x0 < (int)P.aligned_width && y0 < aligned_h && !(x0 + (SIZE >> 1) > (int)P.width || y0 + (SIZE >> 1) > (int)P.height);
+    const size_t cell = (size_t)cy * ((P.aligned_width + 15) >> 4) + (size_t)(cx < 0 ? 0 : cx);
+    SvtHipTplSrcStats s = {};
+    if (active) s = src_stats[cell];
+    active = active && s.written;
+    const bool newmv = active && s.best_mode == TPL_NEWMV;
+    const uint32_t ss = P.src_stride, rs = RP.recon_stride;
+    const uint8_t* src = src_base + P.src_off;
+    uint8_t*       rec = recon_base + RP.recon_off;
+    uint32_t       srow[NW], prow[NW];
+#pragma unroll
+    for (int i = 0; i < NW; i++) { srow[i] = 0; prow[i] = 0; }
+    if (active) load_row<NW>(srow, src + (size_t)(y0 + t) * ss + x0);
+    if (newmv) {
+        const SvtHipTplRef& R = s_refs[s.best_rf_idx & 7];
+        load_row<NW>(prow, ref_base + R.plane_off + (size_t)((int)R.org_y + y0 + t + (s.mv_row >> 3)) * R.stride + (int)R.org_x + x0 + (s.mv_col >> 3));
+    }
+    { // DC from the reconstructed neighbours (fill values 127 / 129 beyond the picture, forms by availability: as the source-based kernel, on the reconstruction)
+        uint32_t a = 0, l = 0;
+        if (active && !newmv) {
+            if (y0 > 0) a = (x0 + t < (int)P.width) ? rec[(size_t)(y0 - 1) * rs + x0 + t] : 127u;
+            if (x0 > 0) l = (y0 + t < (int)P.height) ? rec[(size_t)(y0 + t) * rs + x0 - 1] : 129u;
+        }
+        const uint32_t sa = group_sum<T>(a), sl = group_sum<T>(l);
+        uint32_t dc;
+        if (x0 > 0 && y0 > 0) dc = (sa + sl + SIZE) / (2 * SIZE);
+        else if (x0 > 0) dc = (sl + (SIZE >> 1)) / SIZE;
+        else if (y0 > 0) dc = (sa + (SIZE >> 1)) / SIZE;
+        else dc = 128;
+        if (!newmv) {
+#pragma unroll
+            for (int i = 0; i < NW; i++) prow[i] = dc * 0x01010101u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NW; j++) *(uint32_t*)(ptile + t * PP + 4 * j) = prow[j];
+    if (active && (t & ((1 << ST) - 1)) == 0) { // residual on the rows the transform sees
+        const int r = t >> ST;
+#pragma unroll
+        for (int j = 0; j < NW; j++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int d = (int)((srow[j] >> (8 * b)) & 255u) - (int)((prow[j] >> (8 * b)) & 255u);
+                buf[r * PITCH + 4 * j + b] = (int32_t)((uint32_t)d << FS0);
+            }
+    }
+    __syncthreads();
+    if (active) { // forward, column t
+        int32_t v[TXH];
+#pragma unroll
+        for (int r = 0; r < TXH; r++) v[r] = buf[r * PITCH + t];
+        fwd1d<TXH, CBC>(K_DCT, v);
+#pragma unroll
+        for (int r = 0; r < TXH; r++) buf[r * PITCH + t] = FS1 ? rshift_round(v[r], FS1 ? FS1 : 1) : v[r];
+    }
+    __syncthreads();
+    unsigned long long err = 0;
+    uint32_t           nz  = 0;
+    if (active && t < TXH) { // forward, row t; quantize_fp; the dequantised row goes back into the tile
+        int32_t v[W];
+#pragma unroll
+        for (int c = 0; c < W; c++) v[c] = buf[t * PITCH + c];
+        fwd1d<W, CBR>(K_DCT, v);
+        const int kw = W >> P.pf_shape, kh = TXH >> P.pf_shape;
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+            int32_t dq = 0;
+            if (t < kh && c < kw) {
+                int32_t x = FS2 ? rshift_round(v[c], FS2 ? FS2 : 1) : v[c];
+                if (RECT1) x = mul_sqrt2_like(x, 5793);
+                const int     kk = (t | c) != 0;
+                const int32_t sign = x < 0 ? -1 : 0, a = (x ^ sign) - sign;
+                if (((long long)a << 1) >= (int32_t)P.dequant[kk]) {
+                    long long tt = (long long)a + P.round_fp[kk];
+                    tt = tt < -32768 ? -32768 : (tt > 32767 ? 32767 : tt);
+                    const int32_t q = (int32_t)((tt * P.quant_fp[kk]) >> 16);
+                    if (q) { dq = (((int32_t)((uint32_t)q * (uint32_t)(int32_t)P.dequant[kk])) ^ sign) - sign; nz = 1; }
+                }
+                const long long df = (long long)x - dq;
+                err += (unsigned long long)(df * df);
+            }
+            buf[t * PITCH + c] = dq;
+        }
+    }
+    const uint32_t l0 = group_sum<T>((uint32_t)(err & 0x3fffffu)), l1 = group_sum<T>((uint32_t)((err >> 22) & 0x3fffffu)), l2 = group_sum<T>((uint32_t)(err >> 44));
+    const unsigned long long tot = (unsigned long long)l0 + ((unsigned long long)l1 << 22) + ((unsigned long long)l2 << 44);
+    const bool coded = group_sum<T>(nz) != 0;
+    const bool inverse = active && coded && (!P.disable_intra_pred || RP.is_ref); // (:1135-1136)
+    __syncthreads();
+    if (inverse && t < TXH) { // inverse, row t (inv_txfm2d_kernel's first pass, bd 8)
+        const int32_t rhi = (1 << 15) - 1, rlo = -(1 << 15);
+        int32_t v[W];
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+            int32_t x = buf[t * PITCH + c];
+            if (RECT1) x = mul_sqrt2_like(x, 2896);
+            v[c] = txfm1d::clamp_i32(x, rlo, rhi);
+        }
+        inv1d<W>(K_DCT, v, rlo, rhi);
+#pragma unroll
+        for (int c = 0; c < W; c++) buf[t * PITCH + c] = S0 ? rshift_round(v[c], S0 ? S0 : 1) : v[c];
+    }
+    __syncthreads();
+    if (inverse) { // inverse, column t, added to the prediction rows the transform saw
+        const int32_t chi = (1 << 15) - 1, clo = -(1 << 15);
+        int32_t v[TXH];
+#pragma unroll
+        for (int r = 0; r < TXH; r++) v[r] = txfm1d::clamp_i32(buf[r * PITCH + t], clo, chi);
+        inv1d<TXH>(K_DCT, v, clo, chi);
+#pragma unroll
+        for (int r = 0; r < TXH; r++) {
+            int32_t px = (int32_t)ptile[(r << ST) * PP + t] + rshift_round(v[r], 4);
+            ptile[(r << ST) * PP + t] = (uint8_t)(px < 0 ? 0 : (px > 255 ? 255 : px));
+        }
+    }
+    __syncthreads();
+    if (active) { // row t of the block: the reconstructed row the transform saw (the rows between are copies, :1149-1167), or the prediction
+        const int rr = inverse ? (t & ~((1 << ST) - 1)) : t;
+        uint8_t*  d  = rec + (size_t)(y0 + t) * rs + x0;
+#pragma unroll
+        for (int i = 0; i < NW / 4; i++) {
+            tpl_u32x4_a1 o;
+            o.x = *(const uint32_t*)(ptile + rr * PP + 16 * i); o.y = *(const uint32_t*)(ptile + rr * PP + 16 * i + 4);
+            o.z = *(const uint32_t*)(ptile + rr * PP + 16 * i + 8); o.w = *(const uint32_t*)(ptile + rr * PP + 16 * i + 12);
+            *(tpl_u32x4_a1*)(d + 16 * i) = o;
+        }
+        if (t == 0) {
+            long long e = (long long)tot;
+            e >>= (SIZE == 32 && TXH == 32) ? 0 : 2;
+            if (e < 1) e = 1;
+            SvtHipTplReconStats o = {};
+            o.written = 1; o.coded = coded;
+            o.recrf_dist = (e << TPL_COST_SCALE_LOG2) << ST;
+            o.srcrf_dist = newmv ? s.srcrf_dist : o.recrf_dist;
+            o.srcrf_rate = newmv ? s.srcrf_rate : 0;
+            if (o.srcrf_dist > o.recrf_dist) o.recrf_dist = o.srcrf_dist;
+            if (o.srcrf_rate > o.recrf_rate) o.recrf_rate = o.srcrf_rate;
+            out[cell] = o;
+        }
+    }
+}
+
+template <int SIZE, int TXH>
+void launch_tpl_recon(const SvtHipTplReconParams& P, const uint8_t* src, const uint8_t* ref, const SvtHipTplSrcStats* ss, uint8_t* rec, SvtHipTplReconStats* out,
+                      int diag, int cy_first, int n_items, hipStream_t st) {
+    constexpr int BPW = 256 / SIZE;
+    const size_t  shmem = (size_t)BPW * TXH * (SIZE + 1) * 4 + (size_t)BPW * SIZE * (SIZE + 4);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tpl_recon_kernel<SIZE, TXH>), dim3((n_items + BPW - 1) / BPW), dim3(256), shmem, st, P, src, ref, ss, rec, out, diag, cy_first,
+                       n_items);
+    SVT_LAUNCH_CHECK();
+}
+
 bool tpl_supported(const SvtHipTplSrcParams& P) {
     if (P.dispenser_search_level > 1 || P.subsample_tx > 2 || P.pf_shape > 2 || !P.n_sb || !P.sbs_x) return false;
     if (P.dispenser_search_level == 1 && P.subsample_tx != 2) return false; // 32x32 blocks exist with TX_32X8 only (tpl level 5)
@@ -292,6 +475,83 @@ int svt_hip_tpl_src_stage_host(const SvtHipTplSrcParams* params, const SvtHipTpl
         if (ref_slot[r] >= 0) P.refs[r].plane_off += doff[ref_slot[r]];
     svt_hip_tpl_src_stage(&P, d_planes, d_planes, d_tot, d_mv, d_cand, d_stats, c.stream);
     c.down(stats, d_stats, cells * sizeof(SvtHipTplSrcStats));
+    return 0;
+}
+
+void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* src_base, const uint8_t* rec_ref_base, const SvtHipTplSrcStats* src_stats,
+                             uint8_t* recon_base, SvtHipTplReconStats* out, void* stream) {
+    svthip::ensure_device();
+    const SvtHipTplReconParams& R = *params;
+    const SvtHipTplSrcParams&   P = R.src;
+    if (!tpl_supported(P)) {
+        fprintf(stderr, "libsvtav1_hip: svt_hip_tpl_recon_stage: option set outside tpl levels 4 / 5 (level %d, subsample_tx %d, pf_shape %d)\n", P.dispenser_search_level,
+                P.subsample_tx, P.pf_shape);
+        abort();
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int   aligned_h = (int)((P.height + 7) & ~7u), cols16 = (int)((P.aligned_width + 15) >> 4), rows16 = (aligned_h + 15) >> 4;
+    const bool  edge_sbs = (P.aligned_width & 63) || (aligned_h & 63); // SBs the picture edge cuts run at level 0 (:2048-2051)
+    for (int d = 0; d < cols16 + rows16 - 1; d++) {
+        const int cy0 = d - (cols16 - 1) > 0 ? d - (cols16 - 1) : 0, cy1 = d < rows16 - 1 ? d : rows16 - 1, n = cy1 - cy0 + 1;
+        if (P.dispenser_search_level == 0) {
+            if (P.subsample_tx == 0) launch_tpl_recon<16, 16>(R, src_base, rec_ref_base, src_stats, recon_base, out, d, cy0, n, st);
+            else launch_tpl_recon<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, d, cy0, n, st);
+        } else {
+            if (!(d & 1)) launch_tpl_recon<32, 8>(R, src_base, rec_ref_base, src_stats, recon_base, out, d, cy0, n, st); // 32x32 blocks start on even cells
+            if (edge_sbs) launch_tpl_recon<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, d, cy0, n, st);
+        }
+    }
+}
+
+int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams* params, const SvtHipTplHostPlanes* planes, const SvtHipTplSrcStats* src_stats, uint8_t* recon_buf,
+                                 uint32_t recon_rows, SvtHipTplReconStats* out) {
+    svthip::ensure_device();
+    SvtHipTplReconParams R = *params;
+    const SvtHipTplSrcParams& P = R.src;
+    if (!tpl_supported(P)) return -1;
+    const size_t cols16 = (P.aligned_width + 15) >> 4, rows16 = ((((size_t)P.height + 7) & ~(size_t)7) + 15) >> 4, cells = cols16 * rows16;
+    bool used[8] = {};
+    for (size_t i = 0; i < cells; i++)
+        if (src_stats[i].written && src_stats[i].best_mode == TPL_NEWMV) {
+            if (src_stats[i].best_rf_idx < 0 || src_stats[i].best_rf_idx > 7) return -2;
+            used[src_stats[i].best_rf_idx] = true;
+        }
+    const uint8_t* bufs[9];
+    size_t         bytes[9], doff[9];
+    int            nb = 0, ref_slot[8];
+    bufs[nb] = planes->src_buf; bytes[nb] = (size_t)P.src_stride * planes->src_rows; nb++;
+    for (int r = 0; r < 8; r++) {
+        ref_slot[r] = -1;
+        if (!used[r]) continue;
+        if (!planes->ref_buf[r]) return -3;
+        for (int b = 0; b < nb; b++)
+            if (bufs[b] == planes->ref_buf[r]) ref_slot[r] = b;
+        if (ref_slot[r] < 0) { bufs[nb] = planes->ref_buf[r]; bytes[nb] = (size_t)R.rec_refs[r].stride * planes->ref_rows[r]; ref_slot[r] = nb++; }
+    }
+    size_t total = 0;
+    for (int b = 0; b < nb; b++) { doff[b] = total; total += svthip::align_up(bytes[b], 256); }
+    const size_t rec_b = (size_t)R.recon_stride * recon_rows;
+    svthip::HostCallLease lease;
+    svthip::HostCall& c = *lease;
+    c.begin();
+    const size_t side = cells * (sizeof(SvtHipTplSrcStats) + sizeof(SvtHipTplReconStats)) + 8192;
+    c.reserve(total + rec_b + side + 4096, total + 2 * rec_b + 2 * side + 4096);
+    uint8_t* d_planes = (uint8_t*)c.dalloc(total);
+    for (int b = 0; b < nb; b++) c.up(d_planes + doff[b], bufs[b], bytes[b]);
+    uint8_t*             d_rec = (uint8_t*)c.dalloc(rec_b);
+    SvtHipTplSrcStats*   d_ss  = (SvtHipTplSrcStats*)c.dalloc(cells * sizeof(SvtHipTplSrcStats));
+    SvtHipTplReconStats* d_out = (SvtHipTplReconStats*)c.dalloc(cells * sizeof(SvtHipTplReconStats));
+    c.up(d_rec, recon_buf, rec_b);
+    c.up(d_ss, src_stats, cells * sizeof(SvtHipTplSrcStats));
+    HIP_CHECK(hipMemsetAsync(d_out, 0, cells * sizeof(SvtHipTplReconStats), c.stream));
+    for (int r = 0; r < 8; r++)
+        if (ref_slot[r] >= 0) R.rec_refs[r].plane_off += doff[ref_slot[r]];
+    svt_hip_tpl_recon_stage(&R, d_planes, d_planes, d_ss, d_rec, d_out, c.stream);
+    // the rows of the picture itself come back (the borders are the caller's: tpl_mc_flow_dispenser pads the plane afterwards, :1400-1406)
+    const size_t first = R.recon_off / R.recon_stride * R.recon_stride, last = first + (size_t)P.height * R.recon_stride;
+    const size_t n_down = (last < rec_b ? last : rec_b) - first;
+    c.down(recon_buf + first, d_rec + first, n_down);
+    c.down(out, d_out, cells * sizeof(SvtHipTplReconStats));
     return 0;
 }
 

@@ -174,3 +174,118 @@ def test_tpl_src_stage_device(be, oracle, ci):
     assert be.lib.svt_hip_tpl_src_stage_host(C.addressof(PH), C.addressof(HP), p(tot), p(mvs), p(cand), p(got_h)) == 0
     same_stats(got_h, want, ("host form", ci))
     assert want["written"].sum() > 0
+
+
+# ---- the reconstruction half (src_ops_process.c:979-1198) ----------------------------------------------------------------------------------------------------------
+ReconStats = np.dtype([("srcrf_dist", "<i8"), ("recrf_dist", "<i8"), ("srcrf_rate", "<i8"), ("recrf_rate", "<i8"), ("written", "u1"), ("coded", "u1"), ("pad", "u1", (6,))])
+assert ReconStats.itemsize == 40
+
+
+def recon_geometry(P, planes):
+    """a reconstruction plane of the test pictures' geometry (border PAD), zero-filled like the reference wrapper's"""
+    rows, stride = planes.shape[1], planes.shape[2]
+    return np.zeros((rows, stride), np.uint8), PAD * stride + PAD, stride
+
+
+def run_recon_oracle(oracle, P, planes, src_stats, is_ref):
+    rec, off, stride = recon_geometry(P, planes)
+    cells = src_stats.size
+    out = np.zeros(cells, ReconStats)
+    refs = (TplRef * 8)(*[P.refs[i] for i in range(8)])
+    oracle.oracle_tpl_recon_picture(C.byref(P), refs, is_ref, p(planes), p(planes), p(src_stats), C.c_void_p(rec.ctypes.data + off), stride, p(out))
+    return rec, out
+
+
+def expand_like_result_model_store(P, st, cols16):
+    """result_model_store (:266-341) for synth_blk_size 16: every statistic at least 1; a 32x32 block writes its four cells with the values / 4 (at least 1)"""
+    grid = np.zeros((st.size, 4), np.int64)
+    seen = np.zeros(st.size, bool)
+    aligned_h = (P.height + 7) & ~7
+    for i in np.nonzero(st["written"])[0]:
+        cy, cx = divmod(int(i), cols16)
+        complete = (P.aligned_width - (cx * 16 & ~63) >= 64) and (aligned_h - (cy * 16 & ~63) >= 64)
+        v = np.maximum(1, np.array([st["srcrf_dist"][i], st["recrf_dist"][i], st["srcrf_rate"][i], st["recrf_rate"][i]], np.int64))
+        if complete and P.dispenser_search_level:
+            v = np.maximum(1, v // 4)
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    grid[i + dy * cols16 + dx] = v
+                    seen[i + dy * cols16 + dx] = True
+        else:
+            grid[i] = v
+            seen[i] = True
+    return grid, seen
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_tpl_recon_oracle_vs_reference(oracle, ref, ci):
+    """oracle_tpl_recon_picture == the reference's whole dispenser: the TplStats grid result_model_store leaves behind and the reconstructed TPL picture."""
+    me = ref_lib()
+    c = CASES[ci]
+    P, planes, tot, mvs, cand, n_pus, cells = make_case(c, 4000 + ci)
+    src = np.zeros(cells, SrcStats)
+    want_stats = np.zeros((cells, 8), np.int64)
+    want_rec = np.zeros((P.height, P.width), np.uint8)
+    me.ref_tpl_dispenser_picture(C.byref(P), c["q"], p(planes), PAD, PAD, p(planes), p(tot), p(mvs), p(cand), n_pus, p(src), p(want_stats), p(want_rec))
+    rec, got = run_recon_oracle(oracle, P, planes, src, 1)
+    cols16 = (P.aligned_width + 15) // 16
+    grid, seen = expand_like_result_model_store(P, got, cols16)
+    assert seen.sum() > 0
+    bad = np.nonzero((grid != want_stats[:, :4]).any(1) & seen)[0]
+    assert bad.size == 0, (ci, bad[:5], grid[bad[:5]], want_stats[bad[:5], :4])
+    got_rec = rec[PAD:PAD + P.height, PAD:PAD + P.width]
+    assert np.array_equal(got_rec, want_rec), (ci, int((got_rec != want_rec).sum()), np.argwhere(got_rec != want_rec)[:4])
+    w = got["written"] == 1
+    assert got["coded"][w].any()                                       # the inverse transform ran for some blocks ...
+    if c["q"] == 255: assert (got["coded"][w] == 0).any()              # noqa: E701  ... and, at the coarsest quantizer, not for others
+    assert (src["best_mode"][w] == 0).any()                            # intra blocks (DC from the reconstruction) exist in every case
+
+
+@pytest.mark.parametrize("ci", range(len(CASES) + len(GPU_CASES)))
+@pytest.mark.parametrize("is_ref", [1, 0])
+def test_tpl_recon_stage_device(be, oracle, ci, is_ref):
+    """svt_hip_tpl_recon_stage (device arrays, one launch per anti-diagonal) and svt_hip_tpl_recon_stage_host == the oracle: statistics of every block and the whole
+    reconstruction plane; is_ref = 0 with intra prediction off leaves the prediction in place (:1135)."""
+    if ci >= len(CASES) and not be.is_gpu:
+        pytest.skip("full-size pictures run on the GPU only")
+    c = CASES[ci] if ci < len(CASES) else GPU_CASES[ci - len(CASES)]
+    if not is_ref and not c["noi"]:
+        pytest.skip("is_ref only matters with intra prediction disabled")
+    pkg = be.pkg
+    P, planes, tot, mvs, cand, n_pus, cells = make_case(c, 5000 + ci)
+    P.quant_fp[0], P.quant_fp[1], P.round_fp[0], P.round_fp[1], P.dequant[0], P.dequant[1] = 532, 431, 61, 76, 123, 152  # q index 120 of the 8-bit tables
+    src = run_oracle(oracle, P, planes, tot, mvs, cand, cells)
+    want_rec, want = run_recon_oracle(oracle, P, planes, src, is_ref)
+    R = pkg.TplReconParams()
+    C.memmove(C.addressof(R.src), C.addressof(P), C.sizeof(P))
+    for i in range(8):
+        C.memmove(C.addressof(R.rec_refs[i]), C.addressof(P.refs[i]), C.sizeof(TplRef))
+    rec0, off, stride = recon_geometry(P, planes)
+    R.recon_off, R.recon_stride, R.is_ref = off, stride, is_ref
+    d_pl, d_src, d_rec = be.dev(planes), be.dev(src.view(np.uint8)), be.dev(rec0)
+    d_out = be.dev(np.zeros(cells * ReconStats.itemsize, np.uint8))
+    be.lib.svt_hip_tpl_recon_stage(C.addressof(R), be.ptr(d_pl), be.ptr(d_pl), be.ptr(d_src), be.ptr(d_rec), be.ptr(d_out), be.stream)
+    be.sync()
+    got = be.host(d_out).view(ReconStats)
+    for f in ("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate", "written", "coded"):
+        bad = np.nonzero(got[f] != want[f])[0]
+        assert bad.size == 0, ("device", ci, f, bad[:6], got[f][bad[:6]], want[f][bad[:6]])
+    got_rec = be.host(d_rec).reshape(rec0.shape)
+    assert np.array_equal(got_rec, want_rec), ("device recon", ci, int((got_rec != want_rec).sum()), np.argwhere(got_rec != want_rec)[:4])
+    assert want["written"].sum() > 0 and want["coded"].any()
+    # host form: pictures as separate host buffers, the reconstruction buffer updated in place (picture rows)
+    HP = TplHostPlanes()
+    rows, psize = planes.shape[1], planes.shape[1] * planes.shape[2]
+    RH = pkg.TplReconParams.from_buffer_copy(R)
+    HP.src_buf, HP.src_rows = planes[0].ctypes.data, rows
+    for r in range(8):
+        if P.refs[r].valid:
+            k = P.refs[r].plane_off // psize
+            HP.ref_buf[r], HP.ref_rows[r] = planes[k].ctypes.data, rows
+            RH.rec_refs[r].plane_off = 0
+    rec_h = rec0.copy()
+    out_h = np.zeros(cells, ReconStats)
+    assert be.lib.svt_hip_tpl_recon_stage_host(C.addressof(RH), C.addressof(HP), p(src), p(rec_h), rows, p(out_h)) == 0
+    for f in ("srcrf_dist", "recrf_dist", "written", "coded"):
+        assert np.array_equal(out_h[f], want[f]), ("host form", ci, f)
+    assert np.array_equal(rec_h[PAD:PAD + P.height], want_rec[PAD:PAD + P.height]), ("host form recon", ci)
