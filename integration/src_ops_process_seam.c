@@ -1,9 +1,14 @@
 /* src_ops_process_seam.c -- REFERENCE-SIDE BINDING (what a maintainer of the reference adds; built into the reference encoder by oracle/Makefile for the identity / fps runs): the reference's source-based-operations process with the TPL dispenser seam of INTEGRATION.md §3.
  *
- * This translation unit IS Source/Lib/Codec/src_ops_process.c of the reference (included below where it lies; nothing is copied).  One call is renamed for the
- * duration of the #include: tpl_mc_flow_dispenser(...) -- `static`, defined at :1347 and called once per (TPL group, picture) from tpl_mc_flow (:1848).  The macro
- * appends __COUNTER__ (unused anywhere else in the file): the DEFINITION becomes tpl_mc_flow_dispenser_use0 -- the reference's body, untouched -- and the call site
- * tpl_mc_flow_dispenser_use1 = the seam below.
+ * This translation unit IS Source/Lib/Codec/src_ops_process.c of the reference (included below where it lies; nothing is copied).  Two `static` functions are renamed
+ * for the duration of the #include, with __COUNTER__ (unused anywhere else in the file) appended in file order: tpl_mc_flow_dispenser_sb_generic(...) -- defined at
+ * :519 (_use0: the reference's body, untouched), called per SB by the dispenser threads at :2060 / :2077 (_use3 / _use4 = the per-SB seam below) -- and
+ * tpl_mc_flow_dispenser(...) -- defined at :1347 (_use1), called once per (TPL group, picture) from tpl_mc_flow at :1848 (_use2 = the picture seam below).
+ *
+ * With SVT_HIP_TPL_RECON_SEAM=1 on top of SVT_HIP_TPL_SEAM the picture seam ALSO runs the reconstruction half of every block on the device
+ * (svt_hip_tpl_recon_stage_host: prediction into the picture's TPL reconstruction, transform, quantisation, inverse transform, the block's statistics), hands the
+ * statistics to the reference's own result_model_store() block by block, and lets the reference's dispenser run with the per-SB function reduced to nothing for that
+ * picture: its segment threads still walk the SBs, count them and release the picture, and tpl_mc_flow_dispenser pads the reconstruction (:1400-1406).
  *
  * With SVT_HIP_TPL_SEAM=1 and a picture whose source-based statistics are still to be made (pcs->tpl_src_data_ready == 0) the seam computes them for EVERY block
  * of the picture with ONE svt_hip_tpl_src_stage_host() call -- DC intra cost from source neighbours, SAD of each uni-directional ME candidate, winner, forward
@@ -30,14 +35,22 @@ struct SourceBasedOperationsContext;
 #define TPL_DISP_ARGS                                                                                                                                         \
     EncodeContext *enc_ctx, SequenceControlSet *scs, int32_t *base_rdmult, PictureParentControlSet *pcs, int32_t frame_idx, struct SourceBasedOperationsContext *context_ptr
 #define TPL_DISP_PASS enc_ctx, scs, base_rdmult, pcs, frame_idx, context_ptr
-static void tpl_mc_flow_dispenser_use0(TPL_DISP_ARGS); /* the reference's function (defined by the #include) */
-static void tpl_mc_flow_dispenser_use1(TPL_DISP_ARGS); /* the seam */
+static void tpl_mc_flow_dispenser_use1(TPL_DISP_ARGS); /* the reference's function (defined by the #include) */
+static void tpl_mc_flow_dispenser_use2(TPL_DISP_ARGS); /* the picture seam */
+#define TPL_SB_ARGS EncodeContext *enc_ctx, SequenceControlSet *scs, PictureParentControlSet *pcs, int32_t frame_idx, uint32_t sb_index, int32_t qIndex, uint8_t dispenser_search_level
+#define TPL_SB_PASS enc_ctx, scs, pcs, frame_idx, sb_index, qIndex, dispenser_search_level
+static void tpl_mc_flow_dispenser_sb_generic_use0(TPL_SB_ARGS); /* the reference's per-SB function (defined by the #include) */
+static void seam_tpl_sb(TPL_SB_ARGS);
+static void tpl_mc_flow_dispenser_sb_generic_use3(TPL_SB_ARGS) { seam_tpl_sb(TPL_SB_PASS); }
+static void tpl_mc_flow_dispenser_sb_generic_use4(TPL_SB_ARGS) { seam_tpl_sb(TPL_SB_PASS); }
 
 #define SEAM_CAT_(a, b) a##b
 #define SEAM_CAT(a, b) SEAM_CAT_(a, b)
 #define tpl_mc_flow_dispenser(...) SEAM_CAT(tpl_mc_flow_dispenser_use, __COUNTER__)(__VA_ARGS__)
+#define tpl_mc_flow_dispenser_sb_generic(...) SEAM_CAT(tpl_mc_flow_dispenser_sb_generic_use, __COUNTER__)(__VA_ARGS__)
 #include "src_ops_process.c" /* resolves through -I$(REF)/Source/Lib/Codec */
 #undef tpl_mc_flow_dispenser
+#undef tpl_mc_flow_dispenser_sb_generic
 
 int svt_hip_seam_bind(unsigned long long picture_number); /* integration/enc_handle_binding.c: SVT_HIP_DEVICES sharding */
 static struct {
@@ -46,6 +59,11 @@ static struct {
     int (*stage_host)(const SvtHipTplSrcParams *, const SvtHipTplHostPlanes *, const uint8_t *, const uint32_t *, const uint8_t *, SvtHipTplSrcStats *);
     uint64_t n_pictures, n_blocks, n_newmv, n_declined, n_reused;
     double   ms_stage;
+    int      recon; /* SVT_HIP_TPL_RECON_SEAM */
+    int (*recon_host)(const SvtHipTplReconParams *, const SvtHipTplHostPlanes *, const SvtHipTplSrcStats *, uint8_t *, uint32_t, SvtHipTplReconStats *);
+    uint64_t n_recon_pictures, n_recon_blocks, n_recon_coded, n_sb_calls_skipped;
+    double   ms_recon;
+    PictureParentControlSet *done[16]; /* pictures whose blocks were reconstructed on the device: the per-SB function has nothing left to do */
 } TS = {PTHREAD_MUTEX_INITIALIZER};
 
 static void tpl_seam_stats(void) {
@@ -55,6 +73,9 @@ static void tpl_seam_stats(void) {
     fprintf(o, "pictures_offloaded %llu\nblocks %llu\nblocks_newmv %llu\npictures_declined %llu\npictures_with_stored_statistics %llu\nms_in_stage_calls %.0f\n",
             (unsigned long long)TS.n_pictures, (unsigned long long)TS.n_blocks, (unsigned long long)TS.n_newmv, (unsigned long long)TS.n_declined,
             (unsigned long long)TS.n_reused, TS.ms_stage);
+    if (TS.recon)
+        fprintf(o, "recon_pictures %llu\nrecon_blocks %llu\nrecon_blocks_coded %llu\nsb_calls_skipped %llu\nms_in_recon_stage_calls %.0f\n", (unsigned long long)TS.n_recon_pictures,
+                (unsigned long long)TS.n_recon_blocks, (unsigned long long)TS.n_recon_coded, (unsigned long long)TS.n_sb_calls_skipped, TS.ms_recon);
     fclose(o);
 }
 static void tpl_seam_init(void) {
@@ -65,6 +86,13 @@ static void tpl_seam_init(void) {
     atexit(tpl_seam_stats);
     fprintf(stderr, "SVT_HIP_TPL_SEAM: the source-based half of the TPL dispenser runs as one device stage per picture\n");
     TS.mode = 1;
+    const char *r = getenv("SVT_HIP_TPL_RECON_SEAM");
+    if (r && atoi(r)) {
+        *(void **)&TS.recon_host = dlsym(RTLD_DEFAULT, "svt_hip_tpl_recon_stage_host");
+        if (!TS.recon_host) { fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: libsvtav1_hip is not loaded\n"); abort(); }
+        fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: the reconstruction half of the TPL dispenser runs as a device stage per picture too\n");
+        TS.recon = 1;
+    }
 }
 static int tpl_seam_on(void) {
     static pthread_once_t once = PTHREAD_ONCE_INIT;
@@ -87,14 +115,101 @@ static int tpl_seam_covers(const SequenceControlSet *scs, const PictureParentCon
     return 1;
 }
 
-static void tpl_mc_flow_dispenser_use1(TPL_DISP_ARGS) {
-    if (!tpl_seam_on() || pcs->tpl_src_data_ready || !tpl_seam_covers(scs, pcs)) {
+/* the per-SB seam: nothing for a picture the device reconstructed, else the reference's function */
+static void seam_tpl_sb(TPL_SB_ARGS) {
+    if (TS.recon) {
+        int done = 0;
+        pthread_mutex_lock(&TS.lock);
+        for (int i = 0; i < 16; i++) done |= TS.done[i] == pcs;
+        if (done) TS.n_sb_calls_skipped++;
+        pthread_mutex_unlock(&TS.lock);
+        if (done) return;
+    }
+    tpl_mc_flow_dispenser_sb_generic_use0(TPL_SB_PASS);
+}
+
+/* the reconstruction half of a whole picture on the device (src_ops_process.c:979-1198); st = the source-based statistics of every cell.  0 = done */
+static int tpl_recon_picture(EncodeContext *enc_ctx, SequenceControlSet *scs, PictureParentControlSet *pcs, int32_t frame_idx, const SvtHipTplSrcParams *P,
+                             const SvtHipTplSrcStats *st, uint32_t cells) {
+    const EbPictureBufferDesc *inp = pcs->enhanced_pic;
+    EbPictureBufferDesc       *rec = enc_ctx->mc_flow_rec_picture_buffer[frame_idx];
+    SvtHipTplReconParams R;
+    SvtHipTplHostPlanes  H;
+    memset(&R, 0, sizeof(R));
+    memset(&H, 0, sizeof(H));
+    R.src = *P;
+    R.recon_off = (uint64_t)rec->org_y * rec->stride_y + rec->org_x; R.recon_stride = rec->stride_y; R.is_ref = pcs->tpl_data.is_ref;
+    H.src_buf = inp->buffer_y; H.src_rows = inp->luma_size / inp->stride_y;
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < 4; r++) {
+            if (!P->refs[l * 4 + r].valid) continue;
+            const EbPictureBufferDesc *rp; /* (:1016-1023) */
+            if (pcs->tpl_data.ref_in_slide_window[l][r]) {
+                uint32_t k = 0;
+                while (k < MAX_TPL_LA_SW && enc_ctx->poc_map_idx[k] != pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_number) k++;
+                if (k == MAX_TPL_LA_SW) return -1;
+                rp = enc_ctx->mc_flow_rec_picture_buffer[k];
+            } else rp = (const EbPictureBufferDesc *)pcs->tpl_data.tpl_ref_ds_ptr_array[l][r].picture_ptr;
+            if (!rp) return -1;
+            SvtHipTplRef *Q = &R.rec_refs[l * 4 + r];
+            Q->valid = 1; Q->plane_off = 0; Q->stride = rp->stride_y; Q->org_x = rp->org_x; Q->org_y = rp->org_y; Q->max_width = rp->max_width; Q->max_height = rp->max_height;
+            H.ref_buf[l * 4 + r] = rp->buffer_y; H.ref_rows[l * 4 + r] = rp->luma_size / rp->stride_y;
+        }
+    SvtHipTplReconStats *out = malloc((size_t)cells * sizeof(*out));
+    const double t0 = now_ms();
+    const int    rc = TS.recon_host(&R, &H, st, rec->buffer_y, rec->luma_size / rec->stride_y, out);
+    const double t1 = now_ms();
+    if (rc) { free(out); return rc; }
+    const uint32_t cols16 = (pcs->aligned_width + 15) >> 4, aligned_h = (inp->height + 7) & ~7u;
+    uint64_t nb = 0, nc = 0;
+    for (uint32_t i = 0; i < cells; i++) {
+        if (!out[i].written) continue;
+        const uint32_t x0 = (i % cols16) << 4, y0 = (i / cols16) << 4;
+        const int complete = (pcs->aligned_width - (x0 & ~63u) >= 64) && (aligned_h - (y0 & ~63u) >= 64);
+        TplStats ts;
+        memset(&ts, 0, sizeof(ts));
+        ts.srcrf_dist = out[i].srcrf_dist; ts.recrf_dist = out[i].recrf_dist; ts.srcrf_rate = out[i].srcrf_rate; ts.recrf_rate = out[i].recrf_rate;
+        if (pcs->tpl_data.tpl_slice_type != I_SLICE && st[i].best_rf_idx != -1) { /* (:1182-1185) */
+            ts.mv.row = st[i].mv_row; ts.mv.col = st[i].mv_col; ts.ref_frame_poc = st[i].ref_frame_poc;
+        }
+        result_model_store(pcs, &ts, x0, y0, (complete && P->dispenser_search_level) ? 32 : 16); /* the reference's own function (:266) */
+        nb++; nc += out[i].coded;
+    }
+    free(out);
+    pthread_mutex_lock(&TS.lock);
+    TS.n_recon_pictures++; TS.n_recon_blocks += nb; TS.n_recon_coded += nc; TS.ms_recon += t1 - t0;
+    pthread_mutex_unlock(&TS.lock);
+    return 0;
+}
+/* mark / unmark a picture for the per-SB seam */
+static void tpl_recon_mark(PictureParentControlSet *pcs, int on) {
+    pthread_mutex_lock(&TS.lock);
+    for (int i = 0; i < 16; i++)
+        if (TS.done[i] == (on ? NULL : pcs)) { TS.done[i] = on ? pcs : NULL; break; }
+    pthread_mutex_unlock(&TS.lock);
+}
+/* the cells of the statistics grid that hold a block (the rule of :575-582 on the grid of :2048-2051), for statistics read back from the reference's own buffer */
+static void tpl_written_cells(const PictureParentControlSet *pcs, uint8_t level, uint8_t *written) {
+    const EbPictureBufferDesc *inp = pcs->enhanced_pic;
+    const uint32_t cols16 = (pcs->aligned_width + 15) >> 4, aligned_h = (inp->height + 7) & ~7u, sbs_x = (pcs->aligned_width + 63) >> 6;
+    for (uint32_t sb = 0; sb < pcs->b64_total_count; sb++) {
+        const uint32_t sx = (sb % sbs_x) * 64, sy = (sb / sbs_x) * 64;
+        const int      complete = (pcs->aligned_width - sx >= 64) && (aligned_h - sy >= 64);
+        const uint32_t size = (complete && level) ? 32 : 16;
+        for (uint32_t y0 = sy; y0 < sy + 64; y0 += size)
+            for (uint32_t x0 = sx; x0 < sx + 64; x0 += size)
+                if (x0 < pcs->aligned_width && y0 < aligned_h && !(x0 + (size >> 1) > inp->width || y0 + (size >> 1) > inp->height)) written[(y0 >> 4) * cols16 + (x0 >> 4)] = 1;
+    }
+}
+
+static void tpl_mc_flow_dispenser_use2(TPL_DISP_ARGS) {
+    if (!tpl_seam_on() || (pcs->tpl_src_data_ready && !TS.recon) || !tpl_seam_covers(scs, pcs)) {
         if (TS.mode) {
             pthread_mutex_lock(&TS.lock);
             if (pcs->tpl_src_data_ready) TS.n_reused++; else TS.n_declined++;
             pthread_mutex_unlock(&TS.lock);
         }
-        tpl_mc_flow_dispenser_use0(TPL_DISP_PASS);
+        tpl_mc_flow_dispenser_use1(TPL_DISP_PASS);
         return;
     }
     const double t0 = now_ms();
@@ -133,6 +248,7 @@ static void tpl_mc_flow_dispenser_use1(TPL_DISP_ARGS) {
                 H.ref_buf[l * 4 + r] = rp->buffer_y; H.ref_rows[l * 4 + r] = rp->luma_size / rp->stride_y;
             }
         }
+    const int stored = pcs->tpl_src_data_ready != 0; /* (reached with the reconstruction seam only) the source-based statistics of an earlier TPL group are kept: :969-977 */
     /* the picture's MeSbResults, SB after SB, in the flat layout of the C ABI */
     const uint32_t n_pus = pcs->enable_me_8x8 ? 85 : (pcs->enable_me_16x16 ? 21 : 5);
     uint8_t  *tot  = malloc((size_t)P.n_sb * n_pus);
@@ -147,13 +263,24 @@ static void tpl_mc_flow_dispenser_use1(TPL_DISP_ARGS) {
     const uint32_t cols16 = (pcs->aligned_width + 15) >> 4, rows16 = (((inp->height + 7) & ~7u) + 15) >> 4, cells = cols16 * rows16;
     SvtHipTplSrcStats *st = malloc((size_t)cells * sizeof(*st));
     svt_hip_seam_bind(pcs->picture_number);
-    if (TS.stage_host(&P, &H, tot, mvs, cand, st)) { fprintf(stderr, "SVT_HIP_TPL_SEAM: svt_hip_tpl_src_stage_host refused the parameters\n"); abort(); }
+    if (stored) {
+        uint8_t *wr = calloc(cells, 1);
+        tpl_written_cells(pcs, P.dispenser_search_level, wr);
+        memset(st, 0, (size_t)cells * sizeof(*st));
+        for (uint32_t i = 0; i < cells; i++) {
+            if (!wr[i]) continue;
+            const TplSrcStats *d = &med->tpl_src_stats_buffer[i];
+            st[i].written = 1; st[i].srcrf_dist = d->srcrf_dist; st[i].srcrf_rate = d->srcrf_rate; st[i].ref_frame_poc = d->ref_frame_poc;
+            st[i].mv_row = d->mv.row; st[i].mv_col = d->mv.col; st[i].best_mode = d->best_mode; st[i].best_rf_idx = d->best_rf_idx; st[i].best_intra_mode = (uint8_t)d->best_intra_mode;
+        }
+        free(wr);
+    } else if (TS.stage_host(&P, &H, tot, mvs, cand, st)) { fprintf(stderr, "SVT_HIP_TPL_SEAM: svt_hip_tpl_src_stage_host refused the parameters\n"); abort(); }
     /* into the buffer the reference's own "already computed" branch reads (:969-977); a sequence without stored statistics (tpl_lad_mg == 0) has none: lend one */
     TplSrcStats *own = med->tpl_src_stats_buffer, *buf = own;
     const uint32_t ref_cells = ((pcs->aligned_width + 15) >> 4) * ((inp->height + 15) >> 4 > rows16 ? (inp->height + 15) >> 4 : rows16);
     if (!buf) buf = calloc(ref_cells, sizeof(*buf));
     uint64_t nb = 0, nn = 0;
-    for (uint32_t i = 0; i < cells; i++) {
+    for (uint32_t i = 0; i < cells && !stored; i++) {
         if (!st[i].written) continue;
         TplSrcStats *d = &buf[i];
         d->srcrf_dist = st[i].srcrf_dist; d->srcrf_rate = st[i].srcrf_rate; d->ref_frame_poc = st[i].ref_frame_poc;
@@ -162,14 +289,23 @@ static void tpl_mc_flow_dispenser_use1(TPL_DISP_ARGS) {
         nb++; nn += st[i].best_mode == NEWMV;
     }
     const double t1 = now_ms();
+    int on_device = 0;
+    if (TS.recon) { /* the reconstruction half too: the per-SB function of this picture becomes a no-op */
+        const int rc = tpl_recon_picture(enc_ctx, scs, pcs, frame_idx, &P, st, cells);
+        if (rc) { fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: svt_hip_tpl_recon_stage_host refused the picture (%d)\n", rc); abort(); }
+        tpl_recon_mark(pcs, 1);
+        on_device = 1;
+    }
     med->tpl_src_stats_buffer = buf;
     pcs->tpl_src_data_ready   = 1;
-    tpl_mc_flow_dispenser_use0(TPL_DISP_PASS); /* the reference's dispenser: segments, reconstruction half, result_model_store */
-    pcs->tpl_src_data_ready   = 0;              /* tpl_mc_flow sets it itself when the statistics are kept (:1856-1858) */
+    tpl_mc_flow_dispenser_use1(TPL_DISP_PASS); /* the reference's dispenser: segments, (reconstruction half, result_model_store,) padding of the reconstruction */
+    pcs->tpl_src_data_ready   = (uint8_t)stored; /* tpl_mc_flow sets it itself when the statistics are kept (:1856-1858) */
+    if (on_device) tpl_recon_mark(pcs, 0);
     med->tpl_src_stats_buffer = own;
     if (!own) free(buf);
     free(tot); free(mvs); free(cand); free(st);
     pthread_mutex_lock(&TS.lock);
-    TS.n_pictures++; TS.n_blocks += nb; TS.n_newmv += nn; TS.ms_stage += t1 - t0;
+    if (stored) TS.n_reused++;
+    else { TS.n_pictures++; TS.n_blocks += nb; TS.n_newmv += nn; TS.ms_stage += t1 - t0; }
     pthread_mutex_unlock(&TS.lock);
 }

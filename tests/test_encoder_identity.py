@@ -41,6 +41,9 @@ def _check(res):
         assert len(res["devices"]) >= 2 and all(v > 0 for v in res["devices"].values()), res["devices"]
     if "tplseam" in res and res["case"].startswith(("tplseam_", "tiny_tplseam")):  # the TPL source-based statistics of every picture came from the device stage
         assert res["tplseam"]["pictures_offloaded"] > 0 and res["tplseam"]["pictures_declined"] == 0 and res["tplseam"]["blocks"] > 0, res["tplseam"]
+    if "tplseam" in res and "tplrecon" in res["case"]:  # the reconstruction half of every dispenser call ran on the device; the reference's per-SB function was skipped
+        t = res["tplseam"]
+        assert t["recon_pictures"] > 0 and t["recon_blocks_coded"] > 0 and t["sb_calls_skipped"] > 0 and t["pictures_declined"] == 0, t
     if "tfdriver" in res:  # central pictures were temporally filtered by the device stage, none left to the reference
         assert res["tfdriver"]["pictures_filtered"] > 0 and res["tfdriver"]["pictures_declined"] == 0 and res["tfdriver"]["reference_frames"] > 0, res["tfdriver"]
     if "seam" in res:
@@ -52,7 +55,8 @@ def _check(res):
 @needs_encoder
 @pytest.mark.parametrize("case", ["tiny_p8_8bit", "tiny_p8_10bit", "tiny_p8_lossless", "tiny_seam_p8", "tiny_seam_p5_lp2", "tiny_lrseam_p4", "tiny_cdefseam_p8", "tiny_dlfseam_p4", "tiny_tfseam_p8", "tiny_tfsubpel_p8", "tiny_tfdriver_p8", "tiny_tfdriver_p8_10bit", "tiny_tplseam_p8", "tiny_tplseam_p10", "tiny_dlfseam_sb_p8", "tiny_dlfseam_sb_p8_lp2", "tiny_2dev_everyseam_p8",
                                   "tiny_lowdelay_p8", "tiny_lowdelay_p10_10bit", "tiny_lowdelay_720p_tf",
-                                  "tiny_screen_p8", "tiny_screen_lowdelay_p9"])  # screen content: enable_me_sr_adjustment == 2  # low delay: level-0 HME areas from list-0 motion; the zero-motion temporal filter (on from 720p)
+                                  "tiny_screen_p8", "tiny_screen_lowdelay_p9",
+                                  "tiny_tplrecon_p8", "tiny_tplrecon_p10"])  # both halves of the TPL dispenser as device stages  # screen content: enable_me_sr_adjustment == 2  # low delay: level-0 HME areas from list-0 motion; the zero-motion temporal filter (on from 720p)
 def test_encoder_identity_emulator(case, tmp_path):
     from conftest import EmuBackend  # builds the emulator library if needed
     EmuBackend()

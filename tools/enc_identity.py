@@ -124,12 +124,19 @@ CASES = {
     "tplseam_p10_8bit": (448, 264, 20, 8, ["--preset", "10", "--lp", "1", "+tplseam"]),  # tpl level 5: 32x32 blocks, TX_32X8, partial SBs at 16x16
     "tplseam_p8_10bit": (256, 144, 18, 10, ["--preset", "8", "--lp", "1", "+tplseam"]),  # TPL works on the 8-bit MSB picture of a 10-bit encode
     "tplseam_1080p_p8": (1920, 1080, 20, 8, ["--preset", "8", "+tplseam"]),
+    # both halves of the TPL dispenser on the device (the reconstruction half walks the block grid by anti-diagonals)
+    "tplrecon_p8_8bit": (448, 264, 20, 8, ["--preset", "8", "--lp", "1", "+tplseam", "+tplrecon"]),
+    "tplrecon_p4_8bit_lp2": (448, 264, 12, 8, ["--preset", "4", "--lp", "2", "+tplseam", "+tplrecon"]),
+    "tplrecon_everyseam_1080p_p8": (1920, 1080, 20, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
     "tplseam_me_p8_8bit": (448, 264, 20, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+tplseam"]),  # ME results produced by the device stage feed the TPL stage
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
     # one encode over TWO (emulated) devices: SVT_HIP_DEVICES=0,1 shards the pictures by picture number; every seam at once
     "tiny_2dev_everyseam_p8": (128, 64, 12, 8, ["--preset", "8", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "tiny_2dev_everyseam_p4": (128, 128, 6, 8, ["--preset", "4", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "tiny_tplseam_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+tplseam"]),
+    "tiny_tplrecon_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+tplseam", "+tplrecon"]),
+    "tiny_tplrecon_p10": (192, 136, 18, 8, ["--preset", "10", "--lp", "1", "+tplseam", "+tplrecon"]),
+    "tiny_tplrecon_p4_lp2": (192, 136, 12, 8, ["--preset", "4", "--lp", "2", "+tplseam", "+tplrecon"]),
     "tiny_tplseam_p10": (192, 136, 18, 8, ["--preset", "10", "--lp", "1", "+tplseam"]),
     "tiny_tfdriver_p8": (128, 128, 12, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
     "tiny_tfdriver_p8_10bit": (128, 128, 12, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
@@ -156,7 +163,7 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
-SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tfdriver_", "tplseam_", "lowdelay_", "screen_"))]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tfdriver_", "tplseam_", "tplrecon_", "lowdelay_", "screen_"))]
 
 
 def make_clip(path, w, h, n, bd, seed=7, static=False):
@@ -233,6 +240,8 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     tplseam_file = os.path.join(outdir, name + "_tplseam.txt")
     if tplseam:
         env.update({"SVT_HIP_TPL_SEAM": "1", "SVT_HIP_TPL_SEAM_STATS": tplseam_file})
+        if "+tplrecon" in CASES[name][4]:
+            env["SVT_HIP_TPL_RECON_SEAM"] = "1"
     devices = next((a[9:] for a in CASES[name][4] if a.startswith("+devices:")), None)
     shard_file = os.path.join(outdir, name + "_devices.txt")
     if devices:
@@ -315,6 +324,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
         res["tplseam"] = {k: int(float(v)) for k, v in st.items()}
         if name.startswith(("tplseam_", "tiny_tplseam")):  # void unless pictures really went through the device stage and none was declined
             res["identical"] = res["identical"] and res["tplseam"].get("pictures_offloaded", 0) > 0 and res["tplseam"].get("pictures_declined", 1) == 0
+        if "+tplrecon" in CASES[name][4]:  # ... and the reconstruction half of every dispenser call ran on the device, the per-SB function skipped
+            t = res["tplseam"]
+            res["identical"] = res["identical"] and t.get("recon_pictures", 0) > 0 and t.get("recon_blocks_coded", 0) > 0 and t.get("sb_calls_skipped", 0) > 0 and \
+                t.get("recon_pictures", 0) == t.get("pictures_offloaded", 0) + t.get("pictures_with_stored_statistics", 0) and t.get("pictures_declined", 1) == 0
     if cdefseam:
         st = dict(ln.split(None, 1) for ln in open(cdefseam_file).read().splitlines()) if os.path.exists(cdefseam_file) else {}
         res["cdefseam"] = {k: int(v) for k, v in st.items()}
