@@ -410,6 +410,27 @@ def encoder_fps():
                               "lr": r.get("lrseam")}}
 
 
+def cpu_tpl_recon_stage(k):
+    """Checker + CPU baseline of the TPL reconstruction leg: oracle_tpl_recon_picture (one core) on the leg's whole picture; statistics and reconstruction plane must
+    equal the device's."""
+    ora_path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(ora_path):
+        return {}
+    ora = C.CDLL(ora_path)
+    P, planes = k["P"], k["planes"]
+    want = np.zeros(k["cells"], k["recon_out"].dtype)
+    rec = np.zeros_like(k["recon"])
+    refs = (type(P.refs[0]) * 8)(*[P.refs[i] for i in range(8)])
+    t0 = time.perf_counter()
+    ora.oracle_tpl_recon_picture(C.byref(P), refs, 1, vp(planes), vp(planes), vp(k["out"]), C.c_void_p(rec.ctypes.data + int(P.src_off)), k["recon_stride"], vp(want))
+    dt = time.perf_counter() - t0
+    for name in ("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate", "written", "coded"):
+        must_equal("tpl_recon_stage " + name, k["recon_out"][name], want[name])
+    must_equal("tpl_recon_stage reconstruction", k["recon"], rec)
+    return {"parity_checked_values": int(k["cells"]) * 6 + int(rec.size), "cpu_baseline": {"value": 1 / dt, "unit": "pictures/s", "cores": 1, "kind": "port",
+                                                                                            "sample": "the leg's whole 1080p picture, oracle/oracle_tpl.c"}}
+
+
 def cpu_tpl_stage(k):
     """Checker + CPU baseline of the TPL leg: the C restatement (oracle/oracle_tpl.c, one core) on the leg's whole picture; every statistics record must equal
     the device's."""
@@ -1150,6 +1171,9 @@ def main():
             kernels.update(bench_legs.tpl_src_stage(torch, lib, pkg, stream, 10, 2, keep))
             if cpu:
                 kernels["tpl_src_stage_1080p8"].update(cpu_tpl_stage(keep))
+            kernels.update(bench_legs.tpl_recon_stage(torch, lib, pkg, stream, 5, 1, keep))
+            if cpu:
+                kernels["tpl_recon_stage_1080p8"].update(cpu_tpl_recon_stage(keep))
         if want("tfpic"):
             keep = {}
             kernels.update(bench_legs.tf_picture_stage(torch, lib, pkg, stream, 5, 1, keep))

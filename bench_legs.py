@@ -921,6 +921,38 @@ def tpl_src_stage(torch, lib, pkg, stream, steps, warmup, keep=None):
                                                    "note": "VALU bound (per block: up to 7 SADs, a 16x16 forward DCT, quantisation); the HBM figure is the contract's"}}}
 
 
+def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
+    """the TPL dispenser's reconstruction half (src_ops_process.c:979-1198) of the tpl_src_stage leg's 1080p picture, device-resident: one launch per
+    anti-diagonal of the 16x16 block grid (187 at 1080p, tpl level 4).  Launch-latency bound by construction (csrc/tpl.hip); every run starts from a
+    zeroed reconstruction plane (the memset is inside the timed region: 2.6 MB)."""
+    P, planes, src = keep["P"], keep["planes"], keep["out"]
+    rows, stride = planes.shape[1], planes.shape[2]
+    R = pkg.TplReconParams()
+    C.memmove(C.addressof(R.src), C.addressof(P), C.sizeof(P))
+    for i in range(8):
+        C.memmove(C.addressof(R.rec_refs[i]), C.addressof(P.refs[i]), C.sizeof(pkg.TplRef))
+    R.recon_off, R.recon_stride, R.is_ref = P.src_off, stride, 1
+    d_pl, d_src = _dev(torch, planes), _dev(torch, src.view(np.uint8))
+    d_rec = torch.zeros(rows * stride, dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros(keep["cells"] * 40, dtype=torch.uint8, device="cuda")
+
+    def run():
+        d_rec.zero_()
+        lib.svt_hip_tpl_recon_stage(C.addressof(R), d_pl.data_ptr(), d_pl.data_ptr(), d_src.data_ptr(), d_rec.data_ptr(), d_out.data_ptr(), stream)
+    t = _time(torch, run, steps, warmup, batches=3)
+    out = d_out.cpu().numpy().view(pkg.TplReconStats)
+    n_blk = int(out["written"].sum())
+    keep.update(R=R, recon=d_rec.cpu().numpy().reshape(rows, stride), recon_out=out.copy(), recon_stride=stride)
+    cols16, rows16 = (P.aligned_width + 15) // 16, (((P.height + 7) & ~7) + 15) // 16
+    alg = n_blk * (3 * 256 + 80)
+    return {"tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "blocks_16x16": n_blk, "launches": cols16 + rows16 - 1, "us_per_launch": t * 1e6 / (cols16 + rows16 - 1),
+                                        "coded_frac": float(np.mean(out["coded"][out["written"] > 0])) if n_blk else 0.0,
+                                        "roofline": {"bound": "hbm", "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 1e9 / 8000.0,
+                                                     "algorithmic_bytes_per_launch": alg / (cols16 + rows16 - 1), "kernel": "tpl_recon_kernel<16, 16>",
+                                                     "kernel_us": t * 1e6 / (cols16 + rows16 - 1),
+                                                     "note": "launch-latency bound: a wavefront of 187 dependent launches of <= 68 blocks each; the HBM figure is the contract's"}}}
+
+
 def tf_picture_stage(torch, lib, pkg, stream, steps, warmup, keep=None, size=(1920, 1080)):
     """The temporal filter of one 1080p 8-bit 4:2:0 central picture with 4 reference pictures as ONE stage call from HOST pictures (svt_hip_tf_picture_host: upload,
     sub-pel refinement of every block size, decisions, final motion compensation, 32x32 errors, filter, download) -- PCIe-inclusive wall time, the form the encoder
