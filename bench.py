@@ -427,6 +427,11 @@ def cpu_tpl_recon_stage(k):
     for name in ("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate", "written", "coded"):
         must_equal("tpl_recon_stage " + name, k["recon_out"][name], want[name])
     must_equal("tpl_recon_stage reconstruction", k["recon"], rec)
+    for name in ("srcrf_dist", "recrf_dist", "written", "coded"):  # the opt-in row-wavefront form of the same stage
+        must_equal("tpl_recon_stage (row form) " + name, k["recon_out_rows_form"][name], want[name])
+    must_equal("tpl_recon_stage (row form) reconstruction", k["recon_rows_form"], rec)
+    must_equal("tpl_recon_stage (row form, XCD chunks) recrf_dist", k["recon_out_rows_xcd_form"]["recrf_dist"], want["recrf_dist"])
+    must_equal("tpl_recon_stage (row form, XCD chunks) reconstruction", k["recon_rows_xcd_form"], rec)
     return {"parity_checked_values": int(k["cells"]) * 6 + int(rec.size), "cpu_baseline": {"value": 1 / dt, "unit": "pictures/s", "cores": 1, "kind": "port",
                                                                                             "sample": "the leg's whole 1080p picture, oracle/oracle_tpl.c"}}
 

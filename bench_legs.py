@@ -939,13 +939,21 @@ def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
     def run():
         d_rec.zero_()
         lib.svt_hip_tpl_recon_stage(C.addressof(R), d_pl.data_ptr(), d_pl.data_ptr(), d_src.data_ptr(), d_rec.data_ptr(), d_out.data_ptr(), stream)
-    t = _time(torch, run, steps, warmup, batches=3)
-    out = d_out.cpu().numpy().view(pkg.TplReconStats)
+    import os
+    forms = {}
+    for form in (2, 1, 0):  # 2 = 1 with the rows given to the XCDs in contiguous chunks; 1 = the row wavefront in one launch (opt-in: SVT_HIP_TPL_RECON_FORM=1), 0 = one launch per anti-diagonal (the default); both are kept for the checker
+        os.environ["SVT_HIP_TPL_RECON_FORM"] = str(form)
+        t = _time(torch, run, steps, warmup, batches=3)
+        out = d_out.cpu().numpy().view(pkg.TplReconStats)
+        forms[form] = (t, d_rec.cpu().numpy().reshape(rows, stride), out.copy())
+    os.environ.pop("SVT_HIP_TPL_RECON_FORM", None)
+    t_rows, t_rows_xcd = forms[1][0], forms[2][0]
     n_blk = int(out["written"].sum())
-    keep.update(R=R, recon=d_rec.cpu().numpy().reshape(rows, stride), recon_out=out.copy(), recon_stride=stride)
+    keep.update(R=R, recon=forms[0][1], recon_out=forms[0][2], recon_rows_form=forms[1][1], recon_out_rows_form=forms[1][2], recon_rows_xcd_form=forms[2][1],
+                recon_out_rows_xcd_form=forms[2][2], recon_stride=stride)
     cols16, rows16 = (P.aligned_width + 15) // 16, (((P.height + 7) & ~7) + 15) // 16
     alg = n_blk * (3 * 256 + 80)
-    return {"tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "blocks_16x16": n_blk, "launches": cols16 + rows16 - 1, "us_per_launch": t * 1e6 / (cols16 + rows16 - 1),
+    return {"tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "row_wavefront_form_us": t_rows * 1e6, "row_wavefront_xcd_chunks_form_us": t_rows_xcd * 1e6, "blocks_16x16": n_blk, "launches": cols16 + rows16 - 1, "us_per_launch": t * 1e6 / (cols16 + rows16 - 1),
                                         "coded_frac": float(np.mean(out["coded"][out["written"] > 0])) if n_blk else 0.0,
                                         "roofline": {"bound": "hbm", "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 1e9 / 8000.0,
                                                      "algorithmic_bytes_per_launch": alg / (cols16 + rows16 - 1), "kernel": "tpl_recon_kernel<16, 16>",

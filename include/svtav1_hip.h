@@ -1075,7 +1075,8 @@ typedef struct SvtHipTplReconStats { /* at the block's top-left 16x16 cell */
     int64_t srcrf_dist, recrf_dist, srcrf_rate, recrf_rate;
     uint8_t written;               /* as SvtHipTplSrcStats.written */
     uint8_t coded;                 /* a coefficient survived the quantizer (eob != 0) */
-    uint8_t pad[6];
+    uint8_t pad[2];                /* pad[0] of a row's first cell: 0xEE = the row-wavefront form (SVT_HIP_TPL_RECON_FORM=1) gave up waiting for the row above */
+    uint32_t reserved;             /* the stage's own (row progress of the row-wavefront form); meaningless afterwards */
 } SvtHipTplReconStats;
 /* Device form: src_stats / out [rows16][cols16] as the source-based stage writes them; recon_base is read (neighbours) and written (every processed block). */
 void svt_hip_tpl_recon_stage(const SvtHipTplReconParams *params, const uint8_t *src_base, const uint8_t *rec_ref_base, const SvtHipTplSrcStats *src_stats,

@@ -179,7 +179,8 @@ void oracle_inv_txfm2d_add(const int32_t *input, const uint16_t *out_r, int stri
 
 typedef struct OracleTplReconStats { /* = SvtHipTplReconStats */
     int64_t srcrf_dist, recrf_dist, srcrf_rate, recrf_rate;
-    uint8_t written, coded, pad[6]; /* coded: a coefficient survived the quantizer (eob != 0) */
+    uint8_t  written, coded, pad[2]; /* coded: a coefficient survived the quantizer (eob != 0) */
+    uint32_t reserved;
 } OracleTplReconStats;
 _Static_assert(sizeof(OracleTplReconStats) == 40, "layout");
 

@@ -353,7 +353,7 @@ class TplReconParams(C.Structure):
 
 class TplReconStats(C.Structure):
     _fields_ = [("srcrf_dist", C.c_int64), ("recrf_dist", C.c_int64), ("srcrf_rate", C.c_int64), ("recrf_rate", C.c_int64), ("written", C.c_uint8), ("coded", C.c_uint8),
-                ("pad", C.c_uint8 * 6)]
+                ("pad", C.c_uint8 * 2), ("reserved", C.c_uint32)]
 
 
 assert C.sizeof(TplReconParams) == 376 + 320 + 16 and C.sizeof(TplReconStats) == 40

@@ -15,6 +15,7 @@
 #include "svt_hip_common.h"
 #include "../../include/svtav1_hip.h"
 #include "txfm_core.h"
+#include <type_traits>
 
 namespace {
 
@@ -227,48 +228,61 @@ void launch_tpl(const SvtHipTplSrcParams& P, const uint8_t* src, const uint8_t* 
 // below the complete ones (32x32 blocks), so a 32x32 block never has 16x16 neighbours on its left or above.  Same lane mapping as the source-based kernel; the
 // prediction tile lives in LDS (the column pass of the inverse adds it transposed), the quantised corner goes back into the transform tile for the inverse
 // (inv_txfm2d_kernel's two passes, txfm.hip).
-template <int SIZE, int TXH>
-__global__ __launch_bounds__(256) void tpl_recon_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
-                                                        const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,
-                                                        SvtHipTplReconStats* __restrict__ out, const int diag, const int cy_first, const int n_items) {
+// A block at cell (cx, cy) in two steps.  tpl_recon_fetch: everything that does not depend on the neighbours -- the block's statistics, its source row and (NEWMV)
+// the reference row of lane t.  tpl_recon_compute: the rest; every thread of the workgroup calls it (it contains workgroup barriers).  t = the lane's row / column
+// inside the block, live = the lane group has a block to do; buf: the block's transform tile [TXH][SIZE + 1] int32, ptile: its prediction / reconstruction tile
+// [SIZE][SIZE + 4] bytes.
+template <int SIZE> struct TplBlockIn {
+    SvtHipTplSrcStats s;
+    uint32_t          srow[SIZE / 4], prow[SIZE / 4];
+    bool              active, newmv;
+};
+template <int SIZE>
+__device__ __forceinline__ void tpl_recon_fetch(const SvtHipTplReconParams& RP, const SvtHipTplRef* s_refs, const uint8_t* __restrict__ src_base,
+                                                const uint8_t* __restrict__ ref_base, const SvtHipTplSrcStats* __restrict__ src_stats, const int cx, const int cy,
+                                                const bool live, const int t, TplBlockIn<SIZE>& B) {
     const SvtHipTplSrcParams& P = RP.src;
-    constexpr int T = SIZE, BPW = 256 / T, W = SIZE, PITCH = W + 1, NW = SIZE / 4, ST = SIZE == 2 * TXH ? 1 : (SIZE == 4 * TXH ? 2 : 0), PP = SIZE + 4;
-    constexpr int FS0 = fwd_shift0(W, TXH), FS1 = -fwd_shift1(W, TXH), FS2 = -fwd_shift2(W, TXH);
-    constexpr int CBC = kFwdCosCol[ilog2c(W) - 2][ilog2c(TXH) - 2], CBR = kFwdCosRow[ilog2c(W) - 2][ilog2c(TXH) - 2];
-    constexpr bool RECT1 = (W == 2 * TXH) || (TXH == 2 * W);
-    constexpr int  S0 = -inv_shift0(W, TXH);
-    HIP_DYNAMIC_SHARED(int32_t, smem)
-    __shared__ SvtHipTplRef s_refs[8];
-    if (threadIdx.x < 8) s_refs[threadIdx.x] = RP.rec_refs[threadIdx.x];
-    __syncthreads();
-    const int tid = threadIdx.x, sub = tid / T, t = tid % T;
-    const int item = (int)blockIdx.x * BPW + sub;
-    int32_t*  buf  = smem + sub * (TXH * PITCH);
-    uint8_t*  ptile = (uint8_t*)(smem + BPW * (TXH * PITCH)) + sub * (SIZE * PP); // prediction, then reconstruction: [SIZE rows][PP]
-    const int cy = cy_first + item, cx = diag - cy, x0 = cx * 16, y0 = cy * 16;
+    constexpr int NW = SIZE / 4;
+    const int x0 = cx * 16, y0 = cy * 16;
     const int aligned_h = (int)((P.height + 7) & ~7u);
-    bool      active = item < n_items && cx >= 0;
+    bool      active = live && cx >= 0;
     const int sx = x0 & ~63, sy = y0 & ~63;
     const bool complete = ((int)P.aligned_width - sx >= 64) && (aligned_h - sy >= 64);
     const int  bsize = (complete && P.dispenser_search_level) ? 32 : 16;
     active = active && bsize == SIZE && (SIZE == 16 || (((cx | cy) & 1) == 0));
     active = active && x0 < (int)P.aligned_width && y0 < aligned_h && !(x0 + (SIZE >> 1) > (int)P.width || y0 + (SIZE >> 1) > (int)P.height);
     const size_t cell = (size_t)cy * ((P.aligned_width + 15) >> 4) + (size_t)(cx < 0 ? 0 : cx);
-    SvtHipTplSrcStats s = {};
-    if (active) s = src_stats[cell];
-    active = active && s.written;
-    const bool newmv = active && s.best_mode == TPL_NEWMV;
-    const uint32_t ss = P.src_stride, rs = RP.recon_stride;
-    const uint8_t* src = src_base + P.src_off;
+    B.s = SvtHipTplSrcStats{};
+    if (active) B.s = src_stats[cell];
+    active = active && B.s.written;
+    B.active = active;
+    B.newmv  = active && B.s.best_mode == TPL_NEWMV;
+#pragma unroll
+    for (int i = 0; i < NW; i++) { B.srow[i] = 0; B.prow[i] = 0; }
+    if (active) load_row<NW>(B.srow, src_base + P.src_off + (size_t)(y0 + t) * P.src_stride + x0);
+    if (B.newmv) {
+        const SvtHipTplRef& R = s_refs[B.s.best_rf_idx & 7];
+        load_row<NW>(B.prow, ref_base + R.plane_off + (size_t)((int)R.org_y + y0 + t + (B.s.mv_row >> 3)) * R.stride + (int)R.org_x + x0 + (B.s.mv_col >> 3));
+    }
+}
+template <int SIZE, int TXH>
+__device__ __forceinline__ void tpl_recon_compute(const SvtHipTplReconParams& RP, uint8_t* __restrict__ recon_base, SvtHipTplReconStats* __restrict__ out, const int cx,
+                                                  const int cy, const TplBlockIn<SIZE>& B, const int t, int32_t* buf, uint8_t* ptile) {
+    const SvtHipTplSrcParams& P = RP.src;
+    constexpr int T = SIZE, W = SIZE, PITCH = W + 1, NW = SIZE / 4, ST = SIZE == 2 * TXH ? 1 : (SIZE == 4 * TXH ? 2 : 0), PP = SIZE + 4;
+    constexpr int FS0 = fwd_shift0(W, TXH), FS1 = -fwd_shift1(W, TXH), FS2 = -fwd_shift2(W, TXH);
+    constexpr int CBC = kFwdCosCol[ilog2c(W) - 2][ilog2c(TXH) - 2], CBR = kFwdCosRow[ilog2c(W) - 2][ilog2c(TXH) - 2];
+    constexpr bool RECT1 = (W == 2 * TXH) || (TXH == 2 * W);
+    constexpr int  S0 = -inv_shift0(W, TXH);
+    const int x0 = cx * 16, y0 = cy * 16;
+    const bool active = B.active, newmv = B.newmv;
+    const SvtHipTplSrcStats& s = B.s;
+    const size_t cell = (size_t)cy * ((P.aligned_width + 15) >> 4) + (size_t)(cx < 0 ? 0 : cx);
+    const uint32_t rs = RP.recon_stride;
     uint8_t*       rec = recon_base + RP.recon_off;
     uint32_t       srow[NW], prow[NW];
 #pragma unroll
-    for (int i = 0; i < NW; i++) { srow[i] = 0; prow[i] = 0; }
-    if (active) load_row<NW>(srow, src + (size_t)(y0 + t) * ss + x0);
-    if (newmv) {
-        const SvtHipTplRef& R = s_refs[s.best_rf_idx & 7];
-        load_row<NW>(prow, ref_base + R.plane_off + (size_t)((int)R.org_y + y0 + t + (s.mv_row >> 3)) * R.stride + (int)R.org_x + x0 + (s.mv_col >> 3));
-    }
+    for (int i = 0; i < NW; i++) { srow[i] = B.srow[i]; prow[i] = B.prow[i]; }
     { // DC from the reconstructed neighbours (fill values 127 / 129 beyond the picture, forms by availability: as the source-based kernel, on the reconstruction)
         uint32_t a = 0, l = 0;
         if (active && !newmv) {
@@ -395,6 +409,80 @@ __global__ __launch_bounds__(256) void tpl_recon_kernel(const SvtHipTplReconPara
 }
 
 template <int SIZE, int TXH>
+__global__ __launch_bounds__(256) void tpl_recon_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                        const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,
+                                                        SvtHipTplReconStats* __restrict__ out, const int diag, const int cy_first, const int n_items) {
+    constexpr int T = SIZE, BPW = 256 / T, PITCH = SIZE + 1, PP = SIZE + 4;
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    __shared__ SvtHipTplRef s_refs[8];
+    if (threadIdx.x < 8) s_refs[threadIdx.x] = RP.rec_refs[threadIdx.x];
+    __syncthreads();
+    const int tid = threadIdx.x, sub = tid / T, t = tid % T;
+    const int item = (int)blockIdx.x * BPW + sub;
+    int32_t*  buf  = smem + sub * (TXH * PITCH);
+    uint8_t*  ptile = (uint8_t*)(smem + BPW * (TXH * PITCH)) + sub * (SIZE * PP);
+    const int cy = cy_first + item;
+    TplBlockIn<SIZE> B;
+    tpl_recon_fetch<SIZE>(RP, s_refs, src_base, ref_base, src_stats, diag - cy, cy, item < n_items, t, B);
+    tpl_recon_compute<SIZE, TXH>(RP, recon_base, out, diag - cy, cy, B, t, buf, ptile);
+}
+
+// ---- the same blocks as a row wavefront in ONE launch (SVT_HIP_TPL_RECON_FORM=1; not the default until it has been timed on the device) -------------------------
+// One single-wave workgroup per block row walks its blocks left to right; before block cx it waits until the row above has published cells [cx, cx + SIZE / 16)
+// (progress counter of that cell row, in cells; kept in SvtHipTplReconStats.reserved of the row's first cell), after the block it publishes its own.  Row r only ever
+// waits for row r - 1 and the grid (<= 135 waves at 4K) is resident at once, so the wait always ends; it is bounded all the same (a timed-out row marks pad[0] of its
+// first cell and goes on: the caller sees it).  Stores are fenced at device scope before the counter moves, the reader fences after it saw the counter.
+constexpr uint32_t TPL_WAIT_POLLS = 1u << 22;
+template <int SIZE, int TXH>
+__global__ __launch_bounds__(64) void tpl_recon_rows_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                            const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,
+                                                            SvtHipTplReconStats* __restrict__ out, const int cy_first, const int xcds) {
+    constexpr int PITCH = SIZE + 1, PP = SIZE + 4, CELLS = SIZE / 16;
+    HIP_DYNAMIC_SHARED(int32_t, smem)
+    __shared__ SvtHipTplRef s_refs[8];
+    if (threadIdx.x < 8) s_refs[threadIdx.x] = RP.rec_refs[threadIdx.x];
+    __syncthreads();
+    constexpr int SUBS = 64 / SIZE; // the wave's other lane groups idle along (their own tiles: the block code stores its prediction row unconditionally)
+    const int t = (int)threadIdx.x % SIZE, sub = (int)threadIdx.x / SIZE;
+    int32_t*  buf = smem + sub * (TXH * PITCH);
+    uint8_t*  ptile = (uint8_t*)(smem + SUBS * (TXH * PITCH)) + sub * (SIZE * PP);
+    // xcds > 1 (form 2): workgroup ids go round-robin over the XCDs, so consecutive ROWS are given to ids of the same XCD (contiguous chunks of rows per XCD): the
+    // counter and the reconstruction a row hands to the next then stay inside one L2 except at the chunk borders
+    int row = (int)blockIdx.x;
+    if (xcds > 1) {
+        const int nb = (int)gridDim.x, x = row % xcds, k = row / xcds, q = nb / xcds, r = nb % xcds;
+        row = x * q + (x < r ? x : r) + k;
+    }
+    const int cols16 = (int)((RP.src.aligned_width + 15) >> 4), cy = cy_first + row * CELLS;
+    bool      timed_out = false;
+    TplBlockIn<SIZE> B;
+    tpl_recon_fetch<SIZE>(RP, s_refs, src_base, ref_base, src_stats, 0, cy, sub == 0, t, B);
+    for (int cx = 0; cx < cols16; cx += CELLS) {
+        // a NEWMV block reads nothing of the row above; only a DC block waits for it (the group's lanes agree on the mode; the other lane groups have no block)
+        const bool need_above = __shfl((int)(B.active && !B.newmv), 0) != 0; // (lane 0 belongs to the live group)
+        if (cy > 0 && need_above) {
+            const uint32_t need = (uint32_t)(cx + CELLS < cols16 ? cx + CELLS : cols16);
+            uint32_t*      flag = &out[(size_t)(cy - 1) * cols16].reserved;
+            uint32_t       polls = 0;
+            while (atomicAdd(flag, 0u) < need && polls < TPL_WAIT_POLLS) { polls++; __builtin_amdgcn_s_sleep(2); }
+            timed_out = timed_out || polls >= TPL_WAIT_POLLS;
+            __threadfence();
+        }
+        tpl_recon_compute<SIZE, TXH>(RP, recon_base, out, cx, cy, B, t, buf, ptile);
+        if (cx + CELLS < cols16) tpl_recon_fetch<SIZE>(RP, s_refs, src_base, ref_base, src_stats, cx + CELLS, cy, sub == 0, t, B); // in flight while the stores drain
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int k = 0; k < CELLS; k++) atomicExch(&out[(size_t)(cy + k) * cols16].reserved, (uint32_t)(cx + CELLS < cols16 ? cx + CELLS : cols16));
+    }
+    if (threadIdx.x == 0 && timed_out) out[(size_t)cy * cols16].pad[0] = 0xEE;
+}
+__global__ void tpl_recon_rows_reset_kernel(SvtHipTplReconStats* __restrict__ out, const int cols16, const int rows16) {
+    const int cy = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (cy < rows16) { out[(size_t)cy * cols16].reserved = 0; out[(size_t)cy * cols16].pad[0] = 0; }
+}
+
+template <int SIZE, int TXH>
 void launch_tpl_recon(const SvtHipTplReconParams& P, const uint8_t* src, const uint8_t* ref, const SvtHipTplSrcStats* ss, uint8_t* rec, SvtHipTplReconStats* out,
                       int diag, int cy_first, int n_items, hipStream_t st) {
     constexpr int BPW = 256 / SIZE;
@@ -491,6 +579,30 @@ void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* 
     hipStream_t st = (hipStream_t)stream;
     const int   aligned_h = (int)((P.height + 7) & ~7u), cols16 = (int)((P.aligned_width + 15) >> 4), rows16 = (aligned_h + 15) >> 4;
     const bool  edge_sbs = (P.aligned_width & 63) || (aligned_h & 63); // SBs the picture edge cuts run at level 0 (:2048-2051)
+    const char* form_env = getenv("SVT_HIP_TPL_RECON_FORM"); // (read per call: a picture-sized stage, and the tests switch it inside one process)
+    const int   form = form_env ? atoi(form_env) : 0;
+    if ((form == 1 || form == 2) && (P.dispenser_search_level == 0 || (P.aligned_width & 63) == 0)) { // the row wavefront: uniform block size per row (no SB column cut by the right edge)
+        hipLaunchKernelGGL(tpl_recon_rows_reset_kernel, dim3((rows16 + 63) / 64), dim3(64), 0, st, out, cols16, rows16);
+        SVT_LAUNCH_CHECK();
+        auto rows = [&](auto size_tag, auto txh_tag, int cy_first, int n_rows) {
+            constexpr int SIZE = decltype(size_tag)::value, TXH = decltype(txh_tag)::value, SUBS = 64 / SIZE;
+            if (n_rows <= 0) return;
+            const size_t shmem = (size_t)SUBS * TXH * (SIZE + 1) * 4 + (size_t)SUBS * SIZE * (SIZE + 4);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(tpl_recon_rows_kernel<SIZE, TXH>), dim3(n_rows), dim3(64), shmem, st, R, src_base, rec_ref_base, src_stats, recon_base, out,
+                               cy_first, form == 2 ? 8 : 1);
+            SVT_LAUNCH_CHECK();
+        };
+        using I16 = std::integral_constant<int, 16>; using I32 = std::integral_constant<int, 32>; using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
+        if (P.dispenser_search_level == 0) {
+            if (P.subsample_tx == 0) rows(I16{}, I16{}, 0, rows16);
+            else rows(I16{}, I4{}, 0, rows16);
+        } else {
+            const int full_sb_rows = aligned_h / 64; // complete SB rows hold 32x32 blocks, the SB row the bottom edge cuts 16x16 blocks (a later launch: stream order)
+            rows(I32{}, I8{}, 0, full_sb_rows * 2);
+            rows(I16{}, I4{}, full_sb_rows * 4, rows16 - full_sb_rows * 4);
+        }
+        return;
+    }
     for (int d = 0; d < cols16 + rows16 - 1; d++) {
         const int cy0 = d - (cols16 - 1) > 0 ? d - (cols16 - 1) : 0, cy1 = d < rows16 - 1 ? d : rows16 - 1, n = cy1 - cy0 + 1;
         if (P.dispenser_search_level == 0) {
@@ -552,6 +664,8 @@ int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams* params, const SvtHi
     const size_t n_down = (last < rec_b ? last : rec_b) - first;
     c.down(recon_buf + first, d_rec + first, n_down);
     c.down(out, d_out, cells * sizeof(SvtHipTplReconStats));
+    for (size_t r = 0; r < rows16; r++)
+        if (out[r * cols16].pad[0] == 0xEE) return -4; // the row-wavefront form gave up waiting (see tpl_recon_rows_kernel)
     return 0;
 }
 
