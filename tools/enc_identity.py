@@ -146,7 +146,7 @@ CASES = {
     "tiny_lowdelay_p10_10bit": (128, 128, 10, 10, ["--preset", "10", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+seam", "+cdefseam", "+dlfseam"]),
     "tiny_lowdelay_720p_tf_10bit": (1280, 720, 10, 10, ["--preset", "8", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+static", "+tfseam", "+tfdriver"]),
     "tiny_lowdelay_720p_tf": (1280, 720, 10, 8, ["--preset", "8", "--lp", "1", "--pred-struct", "1", "--tune", "1", "+static", "+tfseam", "+tfdriver"]),  # the low-delay temporal filter is on from 720p up (enc_handle.c:3303-3310)
-    "tiny_screen_p8": (128, 128, 10, 8, ["--preset", "8", "--lp", "1", "--scm", "1", "+seam"]),
+    "tiny_screen_p8": (128, 128, 6, 8, ["--preset", "8", "--lp", "1", "--scm", "1", "+seam"]),
     "tiny_screen_p5_tf": (192, 128, 10, 8, ["--preset", "5", "--lp", "1", "--scm", "1", "+seam", "+tfseam", "+tfdriver"]),
     "tiny_screen_lowdelay_p9": (192, 128, 12, 8, ["--preset", "9", "--lp", "1", "--scm", "1", "--pred-struct", "1", "--tune", "1", "+seam"]),
     "tiny_tfsubpel_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
