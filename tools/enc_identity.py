@@ -104,6 +104,7 @@ CASES = {
     "fps_1080p_p8_all": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     # 3840x2160 10-bit, preset 8, 60 frames (10-bit preset 8 is where the multi-threaded C-only reference was seen not to reproduce its own
     # bitstream; run_case reports `reference_deterministic` and the identity verdict next to the two speeds)
+    "fps_1080p_p8_all_tplrecon": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),  # A/B against fps_1080p_p8_all: the reconstruction half of the TPL dispenser on the device too
     "fps_4k10_p8_all": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     # larger pictures: more work per stage call against the same fixed latency
     "fps_4k8_p8_all": (3840, 2160, 30, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
