@@ -117,13 +117,10 @@ static int tpl_seam_covers(const SequenceControlSet *scs, const PictureParentCon
 
 /* the per-SB seam: nothing for a picture the device reconstructed, else the reference's function */
 static void seam_tpl_sb(TPL_SB_ARGS) {
-    if (TS.recon) {
+    if (TS.recon) { /* (every SB of every picture passes here from the dispenser threads: no lock) */
         int done = 0;
-        pthread_mutex_lock(&TS.lock);
-        for (int i = 0; i < 16; i++) done |= TS.done[i] == pcs;
-        if (done) TS.n_sb_calls_skipped++;
-        pthread_mutex_unlock(&TS.lock);
-        if (done) return;
+        for (int i = 0; i < 16; i++) done |= __atomic_load_n(&TS.done[i], __ATOMIC_ACQUIRE) == pcs;
+        if (done) { __atomic_fetch_add(&TS.n_sb_calls_skipped, 1, __ATOMIC_RELAXED); return; }
     }
     tpl_mc_flow_dispenser_sb_generic_use0(TPL_SB_PASS);
 }
@@ -184,8 +181,10 @@ static int tpl_recon_picture(EncodeContext *enc_ctx, SequenceControlSet *scs, Pi
 /* mark / unmark a picture for the per-SB seam */
 static void tpl_recon_mark(PictureParentControlSet *pcs, int on) {
     pthread_mutex_lock(&TS.lock);
-    for (int i = 0; i < 16; i++)
-        if (TS.done[i] == (on ? NULL : pcs)) { TS.done[i] = on ? pcs : NULL; break; }
+    int i = 0;
+    while (i < 16 && TS.done[i] != (on ? NULL : pcs)) i++;
+    if (i == 16 && on) { fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: more than 16 pictures inside the TPL dispenser at once\n"); abort(); }
+    if (i < 16) __atomic_store_n(&TS.done[i], on ? pcs : NULL, __ATOMIC_RELEASE);
     pthread_mutex_unlock(&TS.lock);
 }
 /* the cells of the statistics grid that hold a block (the rule of :575-582 on the grid of :2048-2051), for statistics read back from the reference's own buffer */
