@@ -94,6 +94,7 @@ static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
 #include "enc_handle.h"
 #include "svt_malloc.h"
 #include "sys_resource_manager.h"
+#include "reference_object.h" /* EbTplReferenceObject */
 void svt_hip_seam_me_prepare(const void *pa_reference_object); /* integration/me_process_seam.c */
 void svt_hip_seam_me_register_buffer(void *buffer, size_t bytes);
 static void svt_hip_after_enc_init(EbEncHandle *h) {
@@ -108,6 +109,12 @@ static void svt_hip_after_enc_init(EbEncHandle *h) {
         const EbPictureBufferDesc *pic = hdr ? (const EbPictureBufferDesc *)hdr->p_buffer : NULL;
         if (pic && pic->buffer_y) svt_hip_seam_me_register_buffer(pic->buffer_y, pic->luma_size);
     }
+    /* the TPL reconstruction pictures the reconstruction seam uploads / downloads whole (mc_flow_rec_picture_buffer[] = pictures of this pool, src_ops_process.c:1835) */
+    EbSystemResource *tpl = getenv("SVT_HIP_TPL_RECON_SEAM") && h->tpl_reference_picture_pool_ptr_array ? h->tpl_reference_picture_pool_ptr_array[0] : NULL;
+    for (uint32_t i = 0; tpl && tpl->wrapper_ptr_pool && i < tpl->object_total_count; i++) {
+        const EbTplReferenceObject *o = tpl->wrapper_ptr_pool[i] ? (const EbTplReferenceObject *)tpl->wrapper_ptr_pool[i]->object_ptr : NULL;
+        if (o && o->ref_picture_ptr && o->ref_picture_ptr->buffer_y) svt_hip_seam_me_register_buffer(o->ref_picture_ptr->buffer_y, o->ref_picture_ptr->luma_size);
+    }
 }
 /* ... and the page locks are released at the start of svt_av1_enc_deinit (enc_handle.c:2364: its first svt_shutdown_process call; queues are drained by then), before
  * svt_av1_enc_deinit_handle destroys the pool that owns the buffers. */
@@ -121,6 +128,11 @@ static void svt_hip_before_enc_deinit(EbEncHandle *h) {
         const EbBufferHeaderType *hdr = y8b->wrapper_ptr_pool[i] ? (const EbBufferHeaderType *)y8b->wrapper_ptr_pool[i]->object_ptr : NULL;
         const EbPictureBufferDesc *pic = hdr ? (const EbPictureBufferDesc *)hdr->p_buffer : NULL;
         if (pic && pic->buffer_y) svt_hip_seam_me_unregister_buffer(pic->buffer_y);
+    }
+    EbSystemResource *tpl = getenv("SVT_HIP_TPL_RECON_SEAM") && h->tpl_reference_picture_pool_ptr_array ? h->tpl_reference_picture_pool_ptr_array[0] : NULL;
+    for (uint32_t i = 0; tpl && tpl->wrapper_ptr_pool && i < tpl->object_total_count; i++) {
+        const EbTplReferenceObject *o = tpl->wrapper_ptr_pool[i] ? (const EbTplReferenceObject *)tpl->wrapper_ptr_pool[i]->object_ptr : NULL;
+        if (o && o->ref_picture_ptr && o->ref_picture_ptr->buffer_y) svt_hip_seam_me_unregister_buffer(o->ref_picture_ptr->buffer_y);
     }
 }
 #define svt_shutdown_process(r) (svt_hip_before_enc_deinit(handle), svt_shutdown_process(r)) /* (every use is inside svt_av1_enc_deinit, where `handle` is the encoder) */

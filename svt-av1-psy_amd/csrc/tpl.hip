@@ -653,7 +653,8 @@ int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams* params, const SvtHi
     uint8_t*             d_rec = (uint8_t*)c.dalloc(rec_b);
     SvtHipTplSrcStats*   d_ss  = (SvtHipTplSrcStats*)c.dalloc(cells * sizeof(SvtHipTplSrcStats));
     SvtHipTplReconStats* d_out = (SvtHipTplReconStats*)c.dalloc(cells * sizeof(SvtHipTplReconStats));
-    c.up(d_rec, recon_buf, rec_b);
+    // (the plane's content is never read: a DC block's neighbours are blocks of this picture, written earlier in the call; beyond the picture the fill values apply)
+    HIP_CHECK(hipMemsetAsync(d_rec, 0, rec_b, c.stream));
     c.up(d_ss, src_stats, cells * sizeof(SvtHipTplSrcStats));
     HIP_CHECK(hipMemsetAsync(d_out, 0, cells * sizeof(SvtHipTplReconStats), c.stream));
     for (int r = 0; r < 8; r++)
