@@ -436,7 +436,7 @@ constexpr uint32_t TPL_WAIT_POLLS = 1u << 22;
 template <int SIZE, int TXH>
 __global__ __launch_bounds__(64) void tpl_recon_rows_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
                                                             const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,
-                                                            SvtHipTplReconStats* __restrict__ out, const int cy_first, const int xcds) {
+                                                            SvtHipTplReconStats* __restrict__ out, const int cy_first, const int xcds, const int rel_acq) {
     constexpr int PITCH = SIZE + 1, PP = SIZE + 4, CELLS = SIZE / 16;
     HIP_DYNAMIC_SHARED(int32_t, smem)
     __shared__ SvtHipTplRef s_refs[8];
@@ -466,11 +466,13 @@ __global__ __launch_bounds__(64) void tpl_recon_rows_kernel(const SvtHipTplRecon
             uint32_t       polls = 0;
             while (atomicAdd(flag, 0u) < need && polls < TPL_WAIT_POLLS) { polls++; __builtin_amdgcn_s_sleep(2); }
             timed_out = timed_out || polls >= TPL_WAIT_POLLS;
-            __threadfence();
+            if (rel_acq) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // form 3: invalidate only
+            else __threadfence();
         }
         tpl_recon_compute<SIZE, TXH>(RP, recon_base, out, cx, cy, B, t, buf, ptile);
         if (cx + CELLS < cols16) tpl_recon_fetch<SIZE>(RP, s_refs, src_base, ref_base, src_stats, cx + CELLS, cy, sub == 0, t, B); // in flight while the stores drain
-        __threadfence();
+        if (rel_acq) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // form 3: write back only (the sequentially-consistent fence also invalidates the L2: DESIGN 4.16)
+        else __threadfence();
         __syncthreads();
         if (threadIdx.x == 0)
             for (int k = 0; k < CELLS; k++) atomicExch(&out[(size_t)(cy + k) * cols16].reserved, (uint32_t)(cx + CELLS < cols16 ? cx + CELLS : cols16));
@@ -581,7 +583,7 @@ void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* 
     const bool  edge_sbs = (P.aligned_width & 63) || (aligned_h & 63); // SBs the picture edge cuts run at level 0 (:2048-2051)
     const char* form_env = getenv("SVT_HIP_TPL_RECON_FORM"); // (read per call: a picture-sized stage, and the tests switch it inside one process)
     const int   form = form_env ? atoi(form_env) : 0;
-    if ((form == 1 || form == 2) && (P.dispenser_search_level == 0 || (P.aligned_width & 63) == 0)) { // the row wavefront: uniform block size per row (no SB column cut by the right edge)
+    if (form >= 1 && form <= 3 && (P.dispenser_search_level == 0 || (P.aligned_width & 63) == 0)) { // the row wavefront: uniform block size per row (no SB column cut by the right edge)
         hipLaunchKernelGGL(tpl_recon_rows_reset_kernel, dim3((rows16 + 63) / 64), dim3(64), 0, st, out, cols16, rows16);
         SVT_LAUNCH_CHECK();
         auto rows = [&](auto size_tag, auto txh_tag, int cy_first, int n_rows) {
@@ -589,7 +591,7 @@ void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* 
             if (n_rows <= 0) return;
             const size_t shmem = (size_t)SUBS * TXH * (SIZE + 1) * 4 + (size_t)SUBS * SIZE * (SIZE + 4);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(tpl_recon_rows_kernel<SIZE, TXH>), dim3(n_rows), dim3(64), shmem, st, R, src_base, rec_ref_base, src_stats, recon_base, out,
-                               cy_first, form == 2 ? 8 : 1);
+                               cy_first, form == 2 ? 8 : 1, form == 3 ? 1 : 0);
             SVT_LAUNCH_CHECK();
         };
         using I16 = std::integral_constant<int, 16>; using I32 = std::integral_constant<int, 32>; using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;

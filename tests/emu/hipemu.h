@@ -272,6 +272,7 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __threadfence() {}
+inline void __builtin_amdgcn_fence(int, const char*) {}
 inline void __builtin_amdgcn_s_sleep(int) {} // (a single host thread runs the workgroups in index order: nothing to wait for)
 inline void __threadfence_block() {}
 

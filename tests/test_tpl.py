@@ -243,7 +243,7 @@ def test_tpl_recon_oracle_vs_reference(oracle, ref, ci):
 
 
 @pytest.mark.parametrize("ci", range(len(CASES) + len(GPU_CASES)))
-@pytest.mark.parametrize("is_ref,form", [(1, 0), (0, 0), (1, 1), (1, 2)])
+@pytest.mark.parametrize("is_ref,form", [(1, 0), (0, 0), (1, 1), (1, 2), (1, 3)])
 def test_tpl_recon_stage_device(be, oracle, ci, is_ref, form, monkeypatch):
     """svt_hip_tpl_recon_stage (device arrays, one launch per anti-diagonal) and svt_hip_tpl_recon_stage_host == the oracle: statistics of every block and the whole
     reconstruction plane; is_ref = 0 with intra prediction off leaves the prediction in place (:1135)."""
@@ -256,6 +256,8 @@ def test_tpl_recon_stage_device(be, oracle, ci, is_ref, form, monkeypatch):
     # column is cut by the right picture edge at dispenser level 1
     if form == 2 and not be.is_gpu:
         pytest.skip("form 2 orders the rows for the device's XCDs; the emulator runs workgroups one after the other in id order (a row would wait for one not yet run)")
+    if form == 3 and be.is_gpu:
+        pytest.skip("form 3 (release / acquire fences instead of sequentially-consistent ones) is prepared for the next round's GPU time: logic checked on the emulator only")
     monkeypatch.setenv("SVT_HIP_TPL_RECON_FORM", str(form))
     pkg = be.pkg
     P, planes, tot, mvs, cand, n_pus, cells = make_case(c, 5000 + ci)
