@@ -132,7 +132,7 @@ CASES = {
     "tplseam_me_p8_8bit": (448, 264, 20, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+tplseam"]),  # ME results produced by the device stage feed the TPL stage
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
     # one encode over TWO (emulated) devices: SVT_HIP_DEVICES=0,1 shards the pictures by picture number; every seam at once
-    "tiny_2dev_everyseam_p8": (128, 64, 12, 8, ["--preset", "8", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "tiny_2dev_everyseam_p8": (128, 64, 12, 8, ["--preset", "8", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
     "tiny_2dev_everyseam_p4": (128, 128, 6, 8, ["--preset", "4", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "tiny_tplseam_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+tplseam"]),
     "tiny_tplrecon_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+tplseam", "+tplrecon"]),
