@@ -56,7 +56,7 @@ def _check(res):
 @pytest.mark.parametrize("case", ["tiny_p8_8bit", "tiny_p8_10bit", "tiny_p8_lossless", "tiny_seam_p8", "tiny_seam_p5_lp2", "tiny_lrseam_p4", "tiny_cdefseam_p8", "tiny_dlfseam_p4", "tiny_tfseam_p8", "tiny_tfsubpel_p8", "tiny_tfdriver_p8", "tiny_tfdriver_p8_10bit", "tiny_tplseam_p8", "tiny_tplseam_p10", "tiny_dlfseam_sb_p8", "tiny_dlfseam_sb_p8_lp2", "tiny_2dev_everyseam_p8",
                                   "tiny_lowdelay_p8", "tiny_lowdelay_p10_10bit", "tiny_lowdelay_720p_tf",
                                   "tiny_screen_p8", "tiny_screen_lowdelay_p9",
-                                  "tiny_tplrecon_p8", "tiny_tplrecon_p10"])  # both halves of the TPL dispenser as device stages  # screen content: enable_me_sr_adjustment == 2  # low delay: level-0 HME areas from list-0 motion; the zero-motion temporal filter (on from 720p)
+                                  "tiny_tplrecon_p8", "tiny_tplrecon_p10", "tiny_tiles_p8"])  # both halves of the TPL dispenser as device stages  # screen content: enable_me_sr_adjustment == 2  # low delay: level-0 HME areas from list-0 motion; the zero-motion temporal filter (on from 720p)
 def test_encoder_identity_emulator(case, tmp_path):
     from conftest import EmuBackend  # builds the emulator library if needed
     EmuBackend()

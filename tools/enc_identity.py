@@ -96,6 +96,7 @@ CASES = {
     "screen_p8_8bit": (448, 264, 16, 8, ["--preset", "8", "--lp", "1", "--scm", "1", "+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam"]),
     "screen_p5_8bit_lp2": (448, 264, 12, 8, ["--preset", "5", "--lp", "2", "--scm", "1", "+seam", "+tfseam", "+tfdriver"]),
     "screen_lowdelay_720p_p9": (1280, 720, 16, 8, ["--preset", "9", "--lp", "1", "--scm", "1", "--pred-struct", "1", "--tune", "1", "+static", "+seam", "+cdefseam", "+dlfseam"]),  # (no temporal filter: off for screen content in low delay, enc_handle.c:3309)
+    "tiles_p8_8bit": (448, 264, 16, 8, ["--preset", "8", "--lp", "1", "--tile-columns", "1", "--tile-rows", "1", "+seam", "+tfseam", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
     "tfsubpel_p2_10bit": (256, 144, 6, 10, ["--preset", "2", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),  # high bit depth: the seam hands those searches to the reference
     "lrseam_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+lrseam"]),  # 1080p: tens of restoration units per plane, all host cores
     "seam_1080p_p8": (1920, 1080, 10, 8, ["--preset", "8", "+seam"]),  # every picture's MeContext from svt_aom_sig_deriv_me at the real 1080p derivation, all 510 SBs
@@ -150,6 +151,7 @@ CASES = {
     "tiny_screen_p8": (128, 128, 6, 8, ["--preset", "8", "--lp", "1", "--scm", "1", "+seam"]),
     "tiny_screen_p5_tf": (192, 128, 10, 8, ["--preset", "5", "--lp", "1", "--scm", "1", "+seam", "+tfseam", "+tfdriver"]),
     "tiny_screen_lowdelay_p9": (192, 128, 12, 8, ["--preset", "9", "--lp", "1", "--scm", "1", "--pred-struct", "1", "--tune", "1", "+seam"]),
+    "tiny_tiles_p8": (256, 128, 8, 8, ["--preset", "8", "--lp", "1", "--tile-columns", "1", "--tile-rows", "1", "+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),  # 2 x 2 tiles: the TPL dispenser's tile path calls the per-SB function without segments (src_ops_process.c:2068-2080)
     "tiny_tfsubpel_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel"]),
     "tiny_tfseam_p8": (192, 128, 8, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam"]),
     "tiny_dlfseam_p4": (128, 64, 3, 8, ["--preset", "4", "--lp", "1", "+dlfseam"]),
@@ -164,7 +166,7 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
-SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tfdriver_", "tplseam_", "tplrecon_", "lowdelay_", "screen_"))]
+SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tfdriver_", "tplseam_", "tplrecon_", "lowdelay_", "screen_", "tiles_"))]
 
 
 def make_clip(path, w, h, n, bd, seed=7, static=False):
