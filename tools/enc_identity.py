@@ -165,7 +165,37 @@ CASES = {
     "tiny_p8_10bit": (64, 64, 2, 10, ["--preset", "8", "--lp", "1"]),
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
-GPU_CASES = [k for k in CASES if not k.startswith("tiny_") and not k.startswith("fps_")]
+# Option sweep (--case sweep): small encodes with the ME / TF / CDEF / deblocking / TPL (both halves) seams on, one encoder option set each; the claim is bitstream
+# equality and no declined picture (the TPL seams decline tpl level 1 = presets <= 2).  Sized for the CPU emulator (`--lib tests/emu/_build/libsvtav1_hipemu.so`).
+_SW = ["+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]
+SWEEP = {
+    "sweep_overlays": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--enable-overlays", "1"]),
+    "sweep_hl2": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--hierarchical-levels", "2"]),
+    "sweep_keyint6": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--keyint", "6"]),
+    "sweep_scd": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "--scd", "1", "--irefresh-type", "1", "--keyint", "8"]),
+    "sweep_no_cdef_dlf": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--enable-cdef", "0", "--enable-dlf", "0"]),
+    "sweep_no_tf": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--enable-tf", "0"]),
+    "sweep_vbr": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--tune", "1", "--rc", "1", "--tbr", "500"]),
+    "sweep_vbr_p10": (192, 128, 14, 8, ["--preset", "10", "--lp", "1", "--tune", "1", "--rc", "1", "--tbr", "300"]),
+    "sweep_two_pass": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--passes", "2", "--rc", "1", "--tbr", "400", "--tune", "1"]),
+    "sweep_cbr_lowdelay": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--tune", "1", "--rc", "2", "--tbr", "500", "--pred-struct", "1"]),
+    "sweep_lookahead0": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--lookahead", "0"]),
+    "sweep_film_grain": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--film-grain", "8"]),
+    "sweep_fast_decode": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--fast-decode", "1"]),
+    "sweep_tune0": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--tune", "0"]),
+    "sweep_tiles_10bit": (192, 128, 14, 10, ["--preset", "8", "--lp", "1", "--tile-columns", "1"]),
+    "sweep_lp3": (192, 128, 14, 8, ["--preset", "8", "--lp", "3"]),
+    "sweep_odd_size": (190, 130, 12, 8, ["--preset", "8", "--lp", "1"]),
+    "sweep_odd_size_10bit": (202, 138, 10, 10, ["--preset", "8", "--lp", "1"]),
+    "sweep_p12": (192, 128, 14, 8, ["--preset", "12", "--lp", "1"]),
+    "sweep_p6": (192, 128, 14, 8, ["--preset", "6", "--lp", "1"]),
+    "sweep_p3": (128, 64, 8, 8, ["--preset", "3", "--lp", "1"]),
+    "sweep_p2": (96, 64, 6, 8, ["--preset", "2", "--lp", "1"]),
+    "sweep_p0": (64, 64, 4, 8, ["--preset", "0", "--lp", "1"]),
+}
+for _k, (_w, _h, _n, _bd, _a) in SWEEP.items():
+    CASES[_k] = (_w, _h, _n, _bd, _a + _SW)
+GPU_CASES = [k for k in CASES if not k.startswith(("tiny_", "fps_", "sweep_"))]
 SEAM_CASES = [k for k in GPU_CASES if k.startswith(("seam_", "lrseam_", "cdefseam_", "allseams_", "dlfseam_", "everyseam_", "tfseam_", "tfsubpel_", "tfdriver_", "tplseam_", "tplrecon_", "lowdelay_", "screen_", "tiles_"))]
 
 
@@ -335,6 +365,8 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
         st = dict(ln.split(None, 1) for ln in open(cdefseam_file).read().splitlines()) if os.path.exists(cdefseam_file) else {}
         res["cdefseam"] = {k: int(v) for k, v in st.items()}
         res["identical"] = res["identical"] and res["cdefseam"].get("filter_blocks", 0) > 0 and res["cdefseam"].get("pictures_declined", 1) == 0
+    if name.startswith("sweep_"):  # the sweep's claim: equal bitstreams and no picture declined by the ME stage (a stage an option switches off has nothing to run)
+        res["identical"] = bool(res["bitstream_equal"]) and res.get("seam", {}).get("pictures_declined", 1) == 0
     counts = {}
     if os.path.exists(counts_file):
         for ln in open(counts_file):
@@ -361,7 +393,7 @@ def main():
     a = ap.parse_args()
     if not os.path.exists(ENC):
         sys.exit("oracle/_ref/enc/SvtAv1EncApp is missing: run `make -C oracle enc` where /root/reference exists")
-    names = GPU_CASES if a.case == "all" else a.case.split(",")
+    names = GPU_CASES if a.case == "all" else (list(SWEEP) if a.case == "sweep" else a.case.split(","))
     results, union = [], {}
     for nme in names:
         r = run_case(nme, os.path.abspath(a.lib), a.out, only=a.only, skip=a.skip, timeout=a.timeout, host=a.host)
