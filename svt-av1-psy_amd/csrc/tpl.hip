@@ -612,7 +612,9 @@ void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* 
             else launch_tpl_recon<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, d, cy0, n, st);
         } else {
             if (!(d & 1)) launch_tpl_recon<32, 8>(R, src_base, rec_ref_base, src_stats, recon_base, out, d, cy0, n, st); // 32x32 blocks start on even cells
-            if (edge_sbs) launch_tpl_recon<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, d, cy0, n, st);
+            // 16x16 blocks live in the SBs the picture edge cuts: cell rows from the last complete SB row on, cell columns from the last complete SB column on
+            const int edge_row = (aligned_h & 63) ? (aligned_h / 64) * 4 : rows16, edge_col = ((int)P.aligned_width & 63) ? ((int)P.aligned_width / 64) * 4 : cols16;
+            if (edge_sbs && (cy1 >= edge_row || d - cy0 >= edge_col)) launch_tpl_recon<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, d, cy0, n, st);
         }
     }
 }
