@@ -99,7 +99,7 @@ void* svt_hip_me_session_create(uint32_t width, uint32_t height, uint32_t stride
 }
 void* svt_hip_me_session_create_on(int device, uint32_t width, uint32_t height, uint32_t stride, uint32_t org_x, uint32_t org_y, uint32_t rows, uint32_t ring_planes,
                                    uint32_t max_refs, uint32_t max_area_width, uint32_t max_area_height, uint32_t n_slots) {
-    if (device < 0 || device >= svt_hip_device_count()) return nullptr;
+    if (device < 0 || device >= svt_hip_device_count() || device >= svthip::MAX_DEVICES) return nullptr; // (the per-device arenas are MAX_DEVICES wide)
     svthip::DeviceGuard guard(device);
     Session* s = new Session;
     s->device = device;

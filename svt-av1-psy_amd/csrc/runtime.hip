@@ -12,7 +12,6 @@ static std::atomic<int>  g_device{-1};         // the default device (svt_hip_in
 static std::atomic<bool> g_initialised{false}; // written by svt_hip_init, read by every worker thread on first entry
 static std::atomic<bool> g_multi{false};       // a thread or a session has asked for a device of its own: the binding is re-established on every entry
 static char g_name[256]   = "uninitialised";
-constexpr int MAX_DEVICES = 16;
 
 // Device selection is PER HOST THREAD (as HIP's own current device): svt_hip_set_thread_device() / a session's DeviceGuard set t_want, everything else runs on
 // the default device.  One encoder process can therefore drive several GPUs -- a seam binds the calling worker thread to the device its picture is sharded to
@@ -118,16 +117,25 @@ void HostCall::up2d(void* ddst, size_t dpitch, const void* hsrc, size_t spitch, 
     for (size_t y = 0; y < rows; y++) memcpy(p + y * dpitch, (const uint8_t*)hsrc + y * spitch, width_bytes);
     HIP_CHECK(hipMemcpyAsync(ddst, p, dpitch * rows, hipMemcpyHostToDevice, stream));
 }
-// page-locked by the caller (svt_hip_host_register, or its own pinned allocation)?  Then the copy engine reads it directly: no staging pass through the arena.
-static bool host_is_locked(const void* p) {
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; } // (plain malloc memory is unknown to the runtime)
-    return a.type == hipMemoryTypeHost;
+// Page-locked by the caller through svt_hip_host_register?  Then the copy engine reads the source directly: no staging pass through the arena.  The ranges
+// are kept by the library (filled by svt_hip_host_register / _unregister below): the WHOLE of [p, p + bytes) has to lie inside ONE registered range -- a source
+// that starts inside a registered buffer and runs past its end is staged like pageable memory -- and no runtime query is made per upload.
+struct LockedRange { uintptr_t lo, hi; };
+static std::mutex               g_locked_m;
+static std::vector<LockedRange> g_locked;
+static std::atomic<int>         g_locked_n{0}; // (read without the lock: most processes never register anything)
+static bool host_range_is_locked(const void* p, size_t bytes) {
+    if (g_locked_n.load(std::memory_order_acquire) == 0) return false;
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    std::lock_guard<std::mutex> g(g_locked_m);
+    for (const LockedRange& r : g_locked)
+        if (lo >= r.lo && hi <= r.hi) return true;
+    return false;
 }
 void HostCall::up(void* ddst, const void* hsrc, size_t bytes) {
-    if (bytes >= (256u << 10) && host_is_locked(hsrc)) { // (every host form synchronises before it returns: the source outlives the copy)
-        HIP_CHECK(hipMemcpyAsync(ddst, hsrc, bytes, hipMemcpyHostToDevice, stream));
-        return;
+    if (bytes >= (256u << 10) && host_range_is_locked(hsrc, bytes)) { // (every host form synchronises before it returns: the source outlives the copy)
+        if (hipMemcpyAsync(ddst, hsrc, bytes, hipMemcpyHostToDevice, stream) == hipSuccess) return;
+        (void)hipGetLastError(); // the runtime refused the direct copy: fall through to the staged one
     }
     uint8_t* p = (uint8_t*)palloc(bytes);
     memcpy(p, hsrc, bytes);
@@ -147,8 +155,11 @@ void HostCall::down2d(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch
 }
 void HostCall::sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
 
-static std::atomic<int> g_tune_lr_ur{-1}, g_tune_cdef_gpw{-1}, g_tune_cdef_minb{3}, g_tune_sad_form{0}; // -1: not read yet
+static std::atomic<int>  g_tune_lr_ur{32}, g_tune_cdef_gpw{0}, g_tune_cdef_minb{3}, g_tune_sad_form{0};
+static std::atomic<bool> g_tune_loaded{false}; // stored last, with release ordering: a getter that sees it sees every knob
+static std::mutex        g_tune_m;
 static void tuning_read() {
+    std::lock_guard<std::mutex> g(g_tune_m);
     const char* a = getenv("SVT_HIP_LR_UR");
     const char* b = getenv("SVT_HIP_CDEF_GPW");
     const int   ur = a ? atoi(a) : 32, gp = b ? atoi(b) : 0;
@@ -158,21 +169,25 @@ static void tuning_read() {
     g_tune_sad_form = (sf && atoi(sf) == 1) ? 1 : 0;
     const char* m = getenv("SVT_HIP_CDEF_MINB");
     g_tune_cdef_minb = (m && atoi(m) == 2) ? 2 : 3;
+    g_tune_loaded.store(true, std::memory_order_release);
+}
+static inline void tuning_ensure() {
+    if (!g_tune_loaded.load(std::memory_order_acquire)) tuning_read();
 }
 int tuning_lr_rows_per_workgroup() {
-    if (g_tune_lr_ur < 0) tuning_read();
+    tuning_ensure();
     return g_tune_lr_ur;
 }
 int tuning_sad_form() {
-    if (g_tune_cdef_gpw < 0) tuning_read();
+    tuning_ensure();
     return g_tune_sad_form;
 }
 int tuning_cdef_search_minb() {
-    if (g_tune_cdef_gpw < 0) tuning_read();
+    tuning_ensure();
     return g_tune_cdef_minb;
 }
 int tuning_cdef_groups_per_workgroup() {
-    if (g_tune_cdef_gpw < 0) tuning_read();
+    tuning_ensure();
     return g_tune_cdef_gpw;
 }
 
@@ -280,6 +295,20 @@ void svt_hip_shutdown(void) {
         if (c.stream) (void)hipStreamDestroy(c.stream);
         c = HostCall();
     }
+    {   // the leased stage arenas (the largest ones: 20-50 MB pinned + device each) of every device
+        std::lock_guard<std::mutex> g(g_lease_m);
+        for (int d = 0; d < MAX_DEVICES; d++) {
+            if (g_lease_pool[d].empty()) continue;
+            (void)hipSetDevice(d);
+            for (HostCall* c : g_lease_pool[d]) {
+                if (c->dev) (void)hipFree(c->dev);
+                if (c->pin) (void)hipHostFree(c->pin);
+                if (c->stream) (void)hipStreamDestroy(c->stream);
+                delete c;
+            }
+            g_lease_pool[d].clear();
+        }
+    }
     t_bound       = -1;
     g_initialised = false;
 }
@@ -344,10 +373,21 @@ int svt_hip_host_register(void* buffer, size_t bytes) {
     if (!buffer || !bytes) return -1;
     const hipError_t e = hipHostRegister(buffer, bytes, hipHostRegisterPortable);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; } // (already registered, or not lockable: the caller keeps using it as pageable memory)
+    {
+        std::lock_guard<std::mutex> g(svthip::g_locked_m);
+        svthip::g_locked.push_back({(uintptr_t)buffer, (uintptr_t)buffer + bytes});
+        svthip::g_locked_n.store((int)svthip::g_locked.size(), std::memory_order_release);
+    }
     return 0;
 }
 int svt_hip_host_unregister(void* buffer) {
     svthip::ensure_device();
+    {
+        std::lock_guard<std::mutex> g(svthip::g_locked_m);
+        for (size_t i = 0; i < svthip::g_locked.size(); i++)
+            if (svthip::g_locked[i].lo == (uintptr_t)buffer) { svthip::g_locked.erase(svthip::g_locked.begin() + i); break; }
+        svthip::g_locked_n.store((int)svthip::g_locked.size(), std::memory_order_release);
+    }
     const hipError_t e = hipHostUnregister(buffer);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     return 0;

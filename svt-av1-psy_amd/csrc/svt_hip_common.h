@@ -50,6 +50,8 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 
 namespace svthip {
 
+constexpr int MAX_DEVICES = 16; // width of the per-device tables (host-call arenas, the lease pool)
+
 void ensure_device(); // binds the calling thread to its device (the default of svt_hip_init, or the one svt_hip_set_thread_device / a DeviceGuard chose);
                       // aborts with a clear message when svt_hip_init() found no GPU
 int  current_device();

@@ -651,7 +651,7 @@ int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams* params, const SvtHi
     svthip::HostCall& c = *lease;
     c.begin();
     const size_t side = cells * (sizeof(SvtHipTplSrcStats) + sizeof(SvtHipTplReconStats)) + 8192;
-    c.reserve(total + rec_b + side + 4096, total + 2 * rec_b + 2 * side + 4096);
+    c.reserve(total + rec_b + side + 4096, total + 2 * rec_b + 2 * side + 8192);
     uint8_t* d_planes = (uint8_t*)c.dalloc(total);
     for (int b = 0; b < nb; b++) c.up(d_planes + doff[b], bufs[b], bytes[b]);
     uint8_t*             d_rec = (uint8_t*)c.dalloc(rec_b);
@@ -664,10 +664,20 @@ int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams* params, const SvtHi
     for (int r = 0; r < 8; r++)
         if (ref_slot[r] >= 0) R.rec_refs[r].plane_off += doff[ref_slot[r]];
     svt_hip_tpl_recon_stage(&R, d_planes, d_planes, d_ss, d_rec, d_out, c.stream);
-    // the rows of the picture itself come back (the borders are the caller's: tpl_mc_flow_dispenser pads the plane afterwards, :1400-1406)
-    const size_t first = R.recon_off / R.recon_stride * R.recon_stride, last = first + (size_t)P.height * R.recon_stride;
-    const size_t n_down = (last < rec_b ? last : rec_b) - first;
-    c.down(recon_buf + first, d_rec + first, n_down);
+    // Only the rectangle the blocks of this picture wrote comes back: a block is processed when at least half of it lies inside the picture (:580), so the written
+    // area is [0, covered_w) x [0, covered_h) with covered = ((size + 8) >> 4) << 4; everything else of the caller's plane -- its borders (tpl_mc_flow_dispenser pads
+    // the plane afterwards, :1400-1406) and, for picture sizes with (size % 16) in 1..7, the columns / rows of the skipped blocks -- keeps the caller's content,
+    // as it does in the reference.
+    const size_t covered_w = ((size_t)P.width + 8) >> 4 << 4, covered_h = ((size_t)P.height + 8) >> 4 << 4;
+    size_t       rows_down = covered_h;
+    while (rows_down && R.recon_off + (rows_down - 1) * R.recon_stride + covered_w > rec_b) rows_down--; // (never the case for a plane with the reference's borders)
+    if (rows_down) { // one DMA of the rows' span into the pinned arena, then the covered columns of each row
+        const size_t span = (rows_down - 1) * R.recon_stride + covered_w;
+        uint8_t*     pin  = (uint8_t*)c.palloc(span);
+        HIP_CHECK(hipMemcpyAsync(pin, d_rec + R.recon_off, span, hipMemcpyDeviceToHost, c.stream));
+        c.sync();
+        for (size_t y = 0; y < rows_down; y++) memcpy(recon_buf + R.recon_off + y * R.recon_stride, pin + y * R.recon_stride, covered_w);
+    }
     c.down(out, d_out, cells * sizeof(SvtHipTplReconStats));
     for (size_t r = 0; r < rows16; r++)
         if (out[r * cols16].pad[0] == 0xEE) return -4; // the row-wavefront form gave up waiting (see tpl_recon_rows_kernel)

@@ -38,6 +38,10 @@ CASES = [  # (W, H, level, subsample_tx, pf_shape, disable_intra, i_slice, me16,
     dict(W=200, H=136, level=0, ss=0, pf=2, noi=0, isl=0, me16=0, me8=0, l0=3, l1=2, q=255),
     dict(W=328, H=200, level=1, ss=2, pf=1, noi=1, isl=0, me16=1, me8=0, l0=1, l1=1, q=0),
     dict(W=256, H=152, level=1, ss=2, pf=2, noi=0, isl=0, me16=1, me8=0, l0=1, l1=1, q=90),  # no SB column cut by the right edge: 32x32 rows above 16x16 rows
+    # picture sizes with (size % 16) in 1..7: the last block column / row is less than half inside and the reference skips it (src_ops_process.c:580) -- its cells stay
+    # unwritten and its pixels of the reconstruction plane keep the caller's content
+    dict(W=195, H=131, level=0, ss=0, pf=2, noi=0, isl=0, me16=1, me8=0, l0=2, l1=1, q=120),
+    dict(W=261, H=149, level=1, ss=2, pf=2, noi=0, isl=0, me16=1, me8=0, l0=1, l1=1, q=90),
 ]
 
 
@@ -182,14 +186,18 @@ ReconStats = np.dtype([("srcrf_dist", "<i8"), ("recrf_dist", "<i8"), ("srcrf_rat
 assert ReconStats.itemsize == 40
 
 
-def recon_geometry(P, planes):
-    """a reconstruction plane of the test pictures' geometry (border PAD), zero-filled like the reference wrapper's"""
+def recon_geometry(P, planes, fill=0):
+    """a reconstruction plane of the test pictures' geometry (border PAD), zero-filled like the reference wrapper's (fill = 0) or holding earlier content (the device
+    tests: pixels no block writes must survive the stage)"""
     rows, stride = planes.shape[1], planes.shape[2]
-    return np.zeros((rows, stride), np.uint8), PAD * stride + PAD, stride
+    if not fill:
+        return np.zeros((rows, stride), np.uint8), PAD * stride + PAD, stride
+    yy, xx = np.mgrid[0:rows, 0:stride]
+    return ((xx * 7 + yy * 13 + fill) & 255).astype(np.uint8), PAD * stride + PAD, stride
 
 
-def run_recon_oracle(oracle, P, planes, src_stats, is_ref):
-    rec, off, stride = recon_geometry(P, planes)
+def run_recon_oracle(oracle, P, planes, src_stats, is_ref, fill=0):
+    rec, off, stride = recon_geometry(P, planes, fill)
     cells = src_stats.size
     out = np.zeros(cells, ReconStats)
     refs = (TplRef * 8)(*[P.refs[i] for i in range(8)])
@@ -263,12 +271,12 @@ def test_tpl_recon_stage_device(be, oracle, ci, is_ref, form, monkeypatch):
     P, planes, tot, mvs, cand, n_pus, cells = make_case(c, 5000 + ci)
     P.quant_fp[0], P.quant_fp[1], P.round_fp[0], P.round_fp[1], P.dequant[0], P.dequant[1] = 532, 431, 61, 76, 123, 152  # q index 120 of the 8-bit tables
     src = run_oracle(oracle, P, planes, tot, mvs, cand, cells)
-    want_rec, want = run_recon_oracle(oracle, P, planes, src, is_ref)
+    want_rec, want = run_recon_oracle(oracle, P, planes, src, is_ref, fill=0x5A)
     R = pkg.TplReconParams()
     C.memmove(C.addressof(R.src), C.addressof(P), C.sizeof(P))
     for i in range(8):
         C.memmove(C.addressof(R.rec_refs[i]), C.addressof(P.refs[i]), C.sizeof(TplRef))
-    rec0, off, stride = recon_geometry(P, planes)
+    rec0, off, stride = recon_geometry(P, planes, fill=0x5A)
     R.recon_off, R.recon_stride, R.is_ref = off, stride, is_ref
     d_pl, d_src, d_rec = be.dev(planes), be.dev(src.view(np.uint8)), be.dev(rec0)
     d_out = be.dev(np.zeros(cells * ReconStats.itemsize, np.uint8))
@@ -296,4 +304,5 @@ def test_tpl_recon_stage_device(be, oracle, ci, is_ref, form, monkeypatch):
     assert be.lib.svt_hip_tpl_recon_stage_host(C.addressof(RH), C.addressof(HP), p(src), p(rec_h), rows, p(out_h)) == 0
     for f in ("srcrf_dist", "recrf_dist", "written", "coded"):
         assert np.array_equal(out_h[f], want[f]), ("host form", ci, f)
-    assert np.array_equal(rec_h[PAD:PAD + P.height], want_rec[PAD:PAD + P.height]), ("host form recon", ci)
+    # the WHOLE plane: the written rectangle equals the oracle's, every other pixel (borders, skipped blocks) still holds what the caller had there
+    assert np.array_equal(rec_h, want_rec), ("host form recon", ci, int((rec_h != want_rec).sum()), np.argwhere(rec_h != want_rec)[:4])
