@@ -38,6 +38,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
+import bench_regions as regions  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_COPY_CEILING_GBS = 6300.0  # measured copy ceiling (MI355X_MICROARCH.md:35,293): what a kernel that streams every byte once can reach
@@ -54,13 +55,15 @@ def _short_kernel(name):
     return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 
 
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES"))
+
+
 def live_pmc(a):
-    """HBM traffic per launch and kernel, measured in THIS run: two child runs of this script's GPU legs (`--pmc-child`: no CPU legs, no parity checks, a few
-    launches per leg) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes: the two counters do not fit one,
-    MI355X_MICROARCH.md), counters in KiB, FETCH_SIZE doubled (the guide's gfx950 correction).  Launches of a kernel are grouped by grid size and the group with
-    the most bytes is the leg's own workload.  Returns None when rocprofv3 is missing or a pass fails (then the newest committed summary is the fallback)."""
-    import collections
-    import csv
+    """Counters of THIS run, by timed region: three child runs of this script's GPU legs (`--pmc-child`: no CPU legs, no parity checks; every timer runs its function
+    bench_regions.CALLS times between two marker launches) under `rocprofv3 --kernel-trace --pmc <counters>` -- FETCH_SIZE and WRITE_SIZE in separate passes (the two do
+    not fit one: MI355X_MICROARCH.md; KiB units, FETCH_SIZE doubled = the guide's gfx950 correction) and one pass of SQ counters for the VALU fractions.  Returns
+    {"regions": {tag: {"calls", "kernels": {kernel: {"launches", counter: total}}}}, "probe": {...}} or None when rocprofv3 is missing or a pass fails (then the traffic
+    fields stay null)."""
     import glob
     import shutil
     import subprocess
@@ -68,55 +71,43 @@ def live_pmc(a):
     rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rp):
         return None
-    res = collections.defaultdict(dict)
     t0 = time.perf_counter()
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    merged, probe = {}, {}
+    for ctrs in PMC_PASSES:
         td = tempfile.mkdtemp(prefix="svt_pmc_", dir="/tmp")
-        cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", td, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+        rfile = os.path.join(td, "regions.json")
+        cmd = [rp, "--kernel-trace", "--pmc"] + list(ctrs) + ["--output-format", "csv", "-d", td, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
                "--frames", str(a.frames), "--refs", str(a.refs), "--area", a.area] + (["--legs", a.legs] if a.legs else []) + (["--only-me"] if a.only_me else [])
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=300, capture_output=True)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", SVT_PMC_REGIONS_FILE=rfile), timeout=420, capture_output=True)
             files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
+            if r.returncode != 0 or not files or not os.path.exists(rfile):
+                sys.stderr.write("bench.py: counter pass %s failed (rc %d)\n%s\n" % (ctrs, r.returncode, r.stderr.decode(errors="replace")[-800:]))
                 return None
-            agg = collections.defaultdict(list)
-            for row in csv.DictReader(open(files[0])):
-                if row["Counter_Name"] == ctr:
-                    agg[(_short_kernel(row["Kernel_Name"]), int(row["Grid_Size"]))].append(float(row["Counter_Value"]))
-            best = {}
-            for (k, gsz), v in agg.items():
-                if k.startswith("at::") or "rocclr" in k:
-                    continue
-                if k not in best or sum(v) / len(v) > best[k][0]:
-                    best[k] = (sum(v) / len(v), len(v))
-            for k, (kib, nl) in best.items():
-                res[k]["read" if ctr == "FETCH_SIZE" else "write"] = kib * 1024 * (2 if ctr == "FETCH_SIZE" else 1)
-                res[k]["launches_" + ctr] = nl
-        except Exception:
+            meta = json.load(open(rfile))
+            got = regions.parse_counter_csv(files[0], meta["tags"], set(ctrs))
+            for tag, g in got.items():
+                m = merged.setdefault(tag, {"calls": meta["calls"], "kernels": {}})
+                for kn, kv in g["kernels"].items():
+                    m["kernels"].setdefault(kn, {}).update(kv)
+            if "SQ_ACTIVE_INST_VALU" in ctrs and "valu_probe#0" in got and meta.get("probe", {}).get("seconds"):
+                tot = {}
+                for kv in got["valu_probe#0"]["kernels"].values():
+                    for c, v in kv.items():
+                        tot[c] = tot.get(c, 0.0) + v
+                probe = dict(meta["probe"], counters=tot, active_per_s=tot.get("SQ_ACTIVE_INST_VALU", 0.0) / meta["calls"] / meta["probe"]["seconds"],
+                             wave_insts_measured=tot.get("SQ_INSTS_VALU", 0.0) / meta["calls"])
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("bench.py: counter pass %s: %r\n" % (ctrs, e))
             return None
         finally:
             shutil.rmtree(td, ignore_errors=True)
-    out = {}
-    for k, t in res.items():
-        rd, wr = t.get("read", 0.0), t.get("write", 0.0)
-        out[k] = {"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr, "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run",
-                  "launches": [t.get("launches_FETCH_SIZE"), t.get("launches_WRITE_SIZE")]}
-    out["_seconds"] = time.perf_counter() - t0
-    return out
+    return {"regions": merged, "probe": probe, "_seconds": time.perf_counter() - t0}
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel`: from this run's own PMC passes (live_pmc) when they ran; otherwise from the newest committed PMC summary
-    (profiles/*_pmc_traffic.json, written by tools/pmc_summary.py from the same two rocprofv3 passes over the default workload), marked as such in `source`."""
-    import glob
-    if LIVE_PMC is not None:
-        return LIVE_PMC.get(kernel)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None
-    k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
-    return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "read": k["hbm_read_bytes_per_launch"],
-                                   "write": k["hbm_write_bytes_per_launch"], "source": "committed: " + os.path.relpath(files[-1], ROOT)}
+    """(kept for the legs' constructors: the traffic of a leg is attached by region in finish_rooflines once every leg has run)"""
+    return None
 
 
 def synth_planes(n, seed):
@@ -158,6 +149,10 @@ def calibrate_launches(torch, fn, steps, min_s, dist=None):
 
 
 def time_steps(torch, fn, steps, warmup, dist=None):
+    idx = regions.open_region()
+    if regions.PMC_CHILD:
+        t = regions.pmc_run(fn, idx)
+        return t * steps, t * steps
     for _ in range(warmup):
         fn()
     if dist is not None:
@@ -180,6 +175,9 @@ def time_leg(torch, fn, min_s=None, batches=5):
     """Seconds per launch of a per-kernel leg: launches back to back, `batches` event-timed batches of >= min_s / batches each after a warm-up of the same
     length, the median batch reported (HIP events on the launch stream = torch's current stream).  Returns (seconds per launch, launches per batch)."""
     import math
+    idx = regions.open_region()
+    if regions.PMC_CHILD:
+        return regions.pmc_run(fn, idx), regions.CALLS
     min_s = MIN_TIMED_S if min_s is None else min_s
     reps = calibrate_launches(torch, fn, batches, min_s)
     reps = max(reps, 3)
@@ -283,6 +281,18 @@ def cpu_pool(run, seconds):
     with cf.ThreadPoolExecutor(cores) as ex:
         done = sum(ex.map(lambda k: run(k, cores, seconds), range(cores)))
     return done / (time.perf_counter() - t0), one, cores
+
+
+def cpu_has(*flags):
+    """x86 features of the host as /proc/cpuinfo lists them (the gate the reference's RTCD applies through cpuinfo: common_dsp_rtcd.c:97-140)"""
+    try:
+        fl = set(next(ln for ln in open("/proc/cpuinfo") if ln.startswith("flags")).split(":", 1)[1].split())
+    except Exception:  # noqa: BLE001
+        return False
+    return all(f in fl for f in flags)
+
+
+AVX512 = ("avx512f", "avx512bw", "avx512dq", "avx512vl", "avx512cd")  # HAS_AVX512F of the reference = this set (common_dsp_rtcd.c:123-129)
 
 
 def ref_libs():
@@ -392,13 +402,24 @@ def encoder_fps():
         r = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="avx2" if have_x else "c")
         rc_ = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="c") if have_x else r  # the round-1/2 figure: C-only host + stages, for continuity
         r300 = ei.run_case("fps_1080p_p8_all_300", lib, td, timeout=600, host="avx2") if have_x else {}  # steady state: the clip looped five times
-    if not r.get("identical") or not rc_.get("identical") or (r300 and not r300.get("identical")):
+        # the AVX-512 build of the reference (EN_AVX512_SUPPORT=1 + ASM_AVX512) where the host has AVX-512: alone and with the stages
+        have_512 = os.path.exists(ei.ENC_AVX512) and cpu_has(*AVX512)
+        r512 = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="avx512") if have_512 else {}
+        # K concurrent encodes sharing this GPU on the box's host cores: aggregate fps and host CPU seconds per frame, AVX2 host alone vs with the stages
+        inst = ei.run_instances("fps_1080p_p8_all", lib, td, 4, host="avx2", timeout=600) if have_x else {}
+    if not r.get("identical") or not rc_.get("identical") or (r300 and not r300.get("identical")) or (r512 and not r512.get("identical")) or (inst and not inst.get("identical")):
         sys.exit("bench.py: the encoder's bitstream with the stage seams differs from the C-only encoder -- no numbers recorded (%s)" % r.get("stderr_tail", ""))
     return {"fps_c_only": r.get("fps_c"), "fps_avx2_intrinsics": r.get("fps_avx2"), "fps_avx2_host_with_stage_seams": r.get("fps_hip") if have_x else None,
             "fps_c_host_with_stage_seams": rc_.get("fps_hip"), "bitstream_identical": True,
             "steady_state_300_frames": {"fps_c_only": r300.get("fps_c"), "fps_avx2_intrinsics": r300.get("fps_avx2"), "fps_avx2_host_with_stage_seams": r300.get("fps_hip"),
                                         "note": "single run each; run-to-run spread on this box class is +- 5 % (profiles/r03_call13..15)"} if r300 else None, "avx2_bitstream_identical_to_c": r.get("avx2_identical_to_c"),
-            "frames": r["frames"], "host_threads": len(os.sched_getaffinity(0)),
+            "fps_avx512_intrinsics": r512.get("fps_avx512"), "fps_avx512_host_with_stage_seams": r512.get("fps_hip"),
+            # user + system CPU seconds of the whole encoder process per frame (RUSAGE_CHILDREN): what the offload takes off the host
+            "host_cpu_s_per_frame": dict(r.get("host_cpu_s_per_frame") or {}, **{k: v for k, v in (r512.get("host_cpu_s_per_frame") or {}).items() if k != "c"}),
+            "instances": {"k": inst.get("instances"), "fps_avx2": inst.get("fps_avx2"), "fps_avx2_with_stages": inst.get("fps_avx2_with_stages"),
+                          "cpu_s_per_frame_avx2": inst.get("host_cpu_s_per_frame_avx2"), "cpu_s_per_frame_avx2_with_stages": inst.get("host_cpu_s_per_frame_avx2_with_stages"),
+                          "identical": inst.get("identical")} if inst else None,
+            "frames": r["frames"], "host_threads": len(os.sched_getaffinity(0)), "host_cores": host_cores(),
             "host_ms_per_me_stage_call": (lambda m: round(m.get("ms_in_stage_calls", 0) / max(m.get("pictures_offloaded", 0) + m.get("tf_pairs_offloaded", 0), 1), 3))(r.get("seam") or {}),
             "host_ms_first_stage_call": (r.get("seam") or {}).get("ms_first_stage_call"),
             # wall time the encoder's threads spent inside stage calls (uploads + kernels + downloads), summed over the run: where the host side of the offload goes
@@ -432,6 +453,8 @@ def cpu_tpl_recon_stage(k):
     must_equal("tpl_recon_stage (row form) reconstruction", k["recon_rows_form"], rec)
     must_equal("tpl_recon_stage (row form, XCD chunks) recrf_dist", k["recon_out_rows_xcd_form"]["recrf_dist"], want["recrf_dist"])
     must_equal("tpl_recon_stage (row form, XCD chunks) reconstruction", k["recon_rows_xcd_form"], rec)
+    must_equal("tpl_recon_stage (row form, release / acquire) recrf_dist", k["recon_out_rows_relacq_form"]["recrf_dist"], want["recrf_dist"])
+    must_equal("tpl_recon_stage (row form, release / acquire) reconstruction", k["recon_rows_relacq_form"], rec)
     return {"parity_checked_values": int(k["cells"]) * 6 + int(rec.size), "cpu_baseline": {"value": 1 / dt, "unit": "pictures/s", "cores": 1, "kind": "port",
                                                                                             "sample": "the leg's whole 1080p picture, oracle/oracle_tpl.c"}}
 
@@ -484,9 +507,68 @@ def roofline(bytes_alg, seconds, kernel, traffic_kernel=None, **extra):
     tr = pmc_traffic(traffic_kernel or kernel) or {}
     r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
          "frac_of_copy_ceiling": gbs / HBM_COPY_CEILING_GBS, "traffic": tr.get("hbm_bytes_per_launch"), "traffic_detail": tr or None,
-         "algorithmic_bytes_per_launch": bytes_alg, "kernel": kernel, "kernel_us": seconds * 1e6}
+         "algorithmic_bytes_per_launch": bytes_alg, "kernel": kernel, "kernel_us": seconds * 1e6, "region": regions.LAST}
     r.update(extra)
     return r
+
+
+VALU_CYCLES_PER_WAVE_INST = 4.5  # measured 4.4-5.0 for the plain integer opcodes (profiles/r01_call1_valu_issue_rates.txt); v_qsad_pk_u16_u8 costs 22.4
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+
+
+def finish_rooflines(kernels, rf, me_kernel_s):
+    """Attaches this run's counter passes to every leg's roofline object, by timed region: `traffic` = HBM bytes moved per call of the leg (FETCH_SIZE x 2 + WRITE_SIZE,
+    KiB units: MI355X_MICROARCH.md), `valu_frac` = SQ_INSTS_VALU per call x 4.5 cycles / (1024 SIMDs x 2.4 GHz x the leg's event-timed seconds) -- the share of the
+    chip's VALU issue slots the leg's instructions need at the plain-opcode rate -- and `valu_busy` = SQ_ACTIVE_INST_VALU per call against the same counter of a kernel
+    that issues nothing but VALU instructions (bench_regions.probe), i.e. a measured busy fraction that also sees the multi-cycle opcodes.  `binds` names the roof that
+    is closer: "valu", "hbm", or "latency" when neither reaches 0.35 (dependent launches / occupancy / LDS: DESIGN.md names which)."""
+    reg = (LIVE_PMC or {}).get("regions") or {}
+    probe = (LIVE_PMC or {}).get("probe") or {}
+    items = [("__me__", {"roofline": rf})] + [(n, k) for n, k in kernels.items() if isinstance(k, dict)]
+    c3 = kernels.get("config3_roundtrip")
+    if isinstance(c3, dict) and c3.get("size_rooflines"):
+        worst = c3["roofline"].get("size")
+        items = items[:1] + [("config3:" + sz, {"roofline": r}) for sz, r in c3["size_rooflines"].items()] + [i for i in items[1:] if i[0] != "config3_roundtrip"]
+    for name, k in items:
+        r = k.get("roofline")
+        if not isinstance(r, dict) or r.get("bound") == "pcie":
+            continue
+        g = reg.get(r.get("region"))
+        t = (r.get("kernel_us") or 0) * 1e-6
+        if g and t > 0:
+            tot = {}
+            for kn, kv in g["kernels"].items():
+                for c, v in kv.items():
+                    tot[c] = tot.get(c, 0.0) + v
+            calls = g.get("calls", regions.CALLS)
+            moved = (2 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)) * 1024 / calls
+            if "FETCH_SIZE" in tot or "WRITE_SIZE" in tot:
+                r["traffic"] = moved
+                r["traffic_detail"] = {"read": 2 * tot.get("FETCH_SIZE", 0.0) * 1024 / calls, "write": tot.get("WRITE_SIZE", 0.0) * 1024 / calls,
+                                       "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run, launches between the region's markers"}
+                if r.get("algorithmic_bytes_per_launch"):
+                    r["moved_over_algorithmic"] = moved / r["algorithmic_bytes_per_launch"]
+            if "SQ_INSTS_VALU" in tot:
+                r["valu_wave_insts_per_call"] = tot["SQ_INSTS_VALU"] / calls
+                r.setdefault("valu_frac", tot["SQ_INSTS_VALU"] / calls * VALU_CYCLES_PER_WAVE_INST / (SIMDS * CLOCK_HZ * t))
+                if name == "__me__":
+                    r["valu_frac_plain_opcode_rate"] = tot["SQ_INSTS_VALU"] / calls * VALU_CYCLES_PER_WAVE_INST / (SIMDS * CLOCK_HZ * t)
+            if "SQ_ACTIVE_INST_VALU" in tot and probe.get("active_per_s"):
+                r["valu_busy"] = tot["SQ_ACTIVE_INST_VALU"] / calls / t / probe["active_per_s"]
+            r["kernels_per_call"] = {kn: round(kv["launches"] / calls, 2) for kn, kv in g["kernels"].items()}
+        v = max(r.get("valu_busy") or 0.0, r.get("valu_frac") or 0.0)
+        h = r.get("frac") or 0.0
+        if r.get("bound") == "mfma":
+            r["binds"] = "mfma"
+        else:
+            r["binds"] = "valu" if (v >= h and v >= 0.35) else ("hbm" if (h > v and h >= 0.35) else "latency")
+    if isinstance(c3, dict) and c3.get("size_rooflines"):
+        for sz, r in c3["size_rooflines"].items():
+            if sz in c3["sizes"]:
+                c3["sizes"][sz] = c3["sizes"][sz][:2] + [round(max(r.get("valu_busy") or 0.0, r.get("valu_frac") or 0.0), 3)]
+        c3["roofline"] = dict(c3["size_rooflines"][worst], size=worst, note=c3["roofline"].get("note"))
+        vb = [max(r.get("valu_busy") or 0.0, r.get("valu_frac") or 0.0) for r in c3["size_rooflines"].values()]
+        c3["valu_frac_min_max"] = [round(min(vb), 3), round(max(vb), 3)]
 
 
 def must_equal(name, got, want):
@@ -550,11 +632,13 @@ def bench_sad_pairs(torch, lib, pkg, stream, a, cpu):
             hd = pairs[:nh * 510].copy()
             hd["ref_off"] -= np.uint64((n_src - nh) * PLANE)
             sums = np.zeros(host_cores() + 1, np.uint64)
-            for kind, sym in ((0, "svt_aom_sad64x64_avx2"), (1, "svt_nxm_sad_kernel_helper_avx2")):
+            legs = [(0, "svt_aom_sad64x64_avx2", "cpu_baseline"), (1, "svt_nxm_sad_kernel_helper_avx2", "cpu_baseline_nxm_helper")]
+            if cpu_has(*AVX512) and hasattr(ref, "svt_aom_sad64x64_avx512"):
+                legs.append((0, "svt_aom_sad64x64_avx512", "cpu_baseline_avx512"))
+            for kind, sym, key in legs:
                 fp = C.cast(getattr(ref, sym), C.c_void_p)
                 run = lambda i0, st, sec: f(fp, kind, hp.ctypes.data, hp.ctypes.data, hd.ctypes.data, len(hd), i0, st, sec, sums[i0:].ctypes.data)  # noqa: E731
                 rate, one, cores = cpu_pool(run, 3.0)
-                key = "cpu_baseline" if kind == 0 else "cpu_baseline_nxm_helper"
                 out[key] = {"value": rate / 1e6, "unit": "Mblocks/s (64x64 pairs)", "cores": cores, "kind": "reference", "single_thread_value": one / 1e6,
                             "sample": "%s over 120 + 120 host planes (600 MB), same pair geometry, 3 s per leg" % sym}
     return out
@@ -638,16 +722,40 @@ def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
             f = oracle2.oracle_time_fwd_txfm
             f.restype = C.c_uint64
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32, C.c_double]
-            fnp = C.cast(ref.svt_av1_fwd_txfm2d_32x32_avx2, C.c_void_p)
             ns = 512  # private input / output per thread (shared buffers serialise the cores through the cache hierarchy)
             bufs = [(aligned_zeros(ns * 1024, np.int16), aligned_zeros(2048, np.int32)) for _ in range(host_cores())]
             for b_in, _ in bufs:
                 b_in[:] = res[:ns * 1024]
-            run = lambda i0, st, sec: f(fnp, bufs[i0][0].ctypes.data, ns, 32, 32, bufs[i0][1].ctypes.data, 0, 10, 0, 1, sec)  # noqa: E731
-            rate, one, cores = cpu_pool(run, 3.0)
-            out["fwd_txfm2d_32x32"]["cpu_baseline"] = {"value": rate / 1e6, "unit": "Mblocks/s (32x32)", "cores": cores, "kind": "reference",
-                                                       "single_thread_value": one / 1e6,
-                                                       "sample": "svt_av1_fwd_txfm2d_32x32_avx2, 512 private blocks per thread, 3 s per leg"}
+            legs = [("svt_av1_fwd_txfm2d_32x32_avx2", "cpu_baseline")]
+            if cpu_has(*AVX512) and hasattr(ref, "svt_av1_fwd_txfm2d_32x32_avx512"):
+                legs.append(("svt_av1_fwd_txfm2d_32x32_avx512", "cpu_baseline_avx512"))
+            for sym, key in legs:
+                fnp = C.cast(getattr(ref, sym), C.c_void_p)
+                run = lambda i0, st, sec: f(fnp, bufs[i0][0].ctypes.data, ns, 32, 32, bufs[i0][1].ctypes.data, 0, 10, 0, 1, sec)  # noqa: E731
+                rate, one, cores = cpu_pool(run, 3.0)
+                out["fwd_txfm2d_32x32"][key] = {"value": rate / 1e6, "unit": "Mblocks/s (32x32)", "cores": cores, "kind": "reference", "single_thread_value": one / 1e6,
+                                                "sample": "%s, 512 private blocks per thread, 3 s per leg" % sym}
+            # the inverse 32x32 + reconstruction (10 bit): the reference's AVX2 variant is dav1d assembly (NASM: not buildable here), so the intrinsic variants it has --
+            # SSE4.1 and AVX-512 -- are timed (common_dsp_rtcd.c:515)
+            if hasattr(oracle2, "oracle_time_inv_txfm"):
+                fi2 = oracle2.oracle_time_inv_txfm
+                fi2.restype = C.c_uint64
+                fi2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32, C.c_double]
+                nsi = 256
+                ib = [(aligned_zeros(nsi * 1024, np.int32), aligned_zeros(1024, np.uint16)) for _ in range(host_cores())]
+                for b_in, _ in ib:
+                    b_in[:] = hdq[:nsi * 1024]
+                legs = [("svt_av1_inv_txfm2d_add_32x32_sse4_1", "cpu_baseline_sse4_1")]
+                if cpu_has(*AVX512) and hasattr(ref, "svt_av1_inv_txfm2d_add_32x32_avx512"):
+                    legs.append(("svt_av1_inv_txfm2d_add_32x32_avx512", "cpu_baseline_avx512"))
+                for sym, key in legs:
+                    if not hasattr(ref, sym):
+                        continue
+                    fnp = C.cast(getattr(ref, sym), C.c_void_p)
+                    run = lambda i0, st, sec: fi2(fnp, ib[i0][0].ctypes.data, nsi, 32, 32, ib[i0][1].ctypes.data, 0, 10, 0, 1, sec)  # noqa: E731
+                    rate, one, cores = cpu_pool(run, 3.0)
+                    out["inv_txfm2d_add_32x32"][key] = {"value": rate / 1e6, "unit": "Mblocks/s (32x32, 10-bit)", "cores": cores, "kind": "reference",
+                                                        "single_thread_value": one / 1e6, "sample": "%s, 256 private blocks per thread, 3 s per leg" % sym}
     return out
 
 
@@ -662,12 +770,10 @@ def bench_config3(torch, lib, pkg, stream, a):
     oracle = oracle_lib()
     g = np.random.default_rng(13596)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1)).cuda()  # noqa: E731
-    rows, fr, checked_sizes, checked = {}, [], 0, 0
+    rows, fr, checked_sizes, checked, rl = {}, [], 0, 0, {}
     for ts, (w, h) in enumerate(pkg.TX_SIZES):
         big = max(w, h)
         n = 65536 if big <= 16 else (16384 if big == 32 else 4096)
-        if a.pmc_child:
-            n //= 8
         ncoef, pels = min(w, 32) * min(h, 32), w * h
         ls = int(pels > 256) + int(pels > 1024)
         types = pkg.allowed_tx_types(ts)
@@ -713,8 +819,11 @@ def bench_config3(torch, lib, pkg, stream, a):
             frac = n * b_alg / per / 1e9 / HBM_PEAK_GBS
             fr.append(frac)
             rows["%dx%d_bd%d" % (w, h, bd)] = [round(n / per / 1e6, 1), round(frac, 3)]
+            rl["%dx%d_bd%d" % (w, h, bd)] = roofline(n * b_alg, per, "txfm_roundtrip_kernel<%s, %d, %d>" % ("unsigned short" if bd > 8 else "unsigned char", w, h))
             del d_res, d_pred, d_rec, d_q, d_dq
-    return {"unit": "[Mblocks/s, fraction of the 8 TB/s HBM peak at SURVEY 8(d)'s 10 B/px] per TX size and bit depth, fused single launch", "sizes": rows,
+    worst = min(rl, key=lambda k: rl[k]["frac"])
+    return {"unit": "[Mblocks/s, fraction of the 8 TB/s HBM peak at SURVEY 8(d)'s 10 B/px, VALU fraction] per TX size and bit depth, fused single launch", "sizes": rows,
+            "size_rooflines": rl, "roofline": dict(rl[worst], size=worst, note="the size furthest below the HBM roof; every size under size_rooflines"),
             "sizes_checked": checked_sizes, "parity_checked_values": checked, "hbm_frac_min_max": [round(min(fr), 3), round(max(fr), 3)],
             "tables": "svt_av1_build_quantizer q in {0,60,120,180,255} + av1_scan_orders (tests/golden/quant_tables.npz)", "bound": "VALU (butterfly network, DESIGN.md 4.2)"}
 
@@ -802,6 +911,12 @@ def bench_cdef(torch, lib, pkg, stream, a, cpu):
             out["cdef_apply_4k10"]["cpu_baseline"] = {"value": rate * 64 / 1e6, "unit": "M(8x8 blocks)/s", "cores": cores, "kind": "reference",
                                                       "single_thread_value": one * 64 / 1e6,
                                                       "sample": "svt_cdef_filter_fb + svt_cdef_filter_block_avx2 / find_dir_dual_avx2 over the same 4K plane, 3 s per leg"}
+            if cpu_has(*AVX512) and hasattr(ref, "svt_cdef_filter_block_8xn_16_avx512"):  # what RTCD adds on an AVX-512 host (common_dsp_rtcd.c:821)
+                C.c_void_p.in_dll(ref, "svt_cdef_filter_block_8xn_16").value = C.cast(ref.svt_cdef_filter_block_8xn_16_avx512, C.c_void_p).value
+                rate, one, cores = cpu_pool(run, 3.0)
+                out["cdef_apply_4k10"]["cpu_baseline_avx512"] = {"value": rate * 64 / 1e6, "unit": "M(8x8 blocks)/s", "cores": cores, "kind": "reference",
+                                                                 "single_thread_value": one * 64 / 1e6,
+                                                                 "sample": "as the AVX2 leg with svt_cdef_filter_block_8xn_16 = its _avx512 variant, 3 s per leg"}
     return out
 
 
@@ -1015,6 +1130,28 @@ def bench_filter_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle
             "parity_checked_values": checked}
 
 
+def emit(out, a):
+    """stdout gets ONE line of at most bench_line.MAX_LINE bytes (what the driver records and parses); the full object -- every leg with its roofline, CPU baseline,
+    parity counts, the encoder's per-stage statistics -- goes to bench_detail.json (gpurun_out/ when it exists, else the working directory) and to stderr."""
+    import bench_line
+    detail = json.dumps(out)
+    path = None
+    for d in (os.path.join(ROOT, "gpurun_out"), os.getcwd(), "/tmp"):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_detail%s.json" % ("" if (a.mode == "frames" and a.gpus == 1) else "_%s_n%d" % (a.mode, a.gpus)))
+            with open(path, "w") as f:
+                f.write(detail + "\n")
+            break
+        except OSError:
+            path = None
+    out["detail"] = os.path.relpath(path, ROOT) if path and path.startswith(ROOT) else path
+    sys.stderr.write("BENCH_DETAIL " + detail + "\n")
+    sys.stderr.flush()
+    sys.stdout.write(bench_line.compact(out) + "\n")
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1059,6 +1196,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     aw, ah = (int(v) for v in a.area.split("x"))
     oracle = oracle_lib()
+    regions.setup(torch, lib, stream, a.pmc_child)
+    regions.probe()
 
     if a.probe:
         sink = torch.zeros(4, dtype=torch.int32, device="cuda")
@@ -1234,39 +1373,20 @@ def main():
             out["encoder_fps_1080p_preset8"] = encoder_fps()
     elif rank == 0:
         out["cpu_baseline"] = None
-    # The claims of north_star inside the two objects every record of this line keeps (a tail-truncated stdout loses `kernels`): per kernel the HBM fraction by
-    # the contract formula, moved bytes / algorithmic bytes from this run's PMC passes, and the reference's AVX2 figure on the host cores beside the GPU's.
     rf["traffic_source"] = (rf.get("traffic_detail") or {}).get("source")
     rf["pmc_seconds"] = (LIVE_PMC or {}).get("_seconds")
-    rf["kernels"] = {}
-    for name, k in kernels.items():
-        r = k.get("roofline") if isinstance(k, dict) else None
-        if r and "frac" in r:
-            e = {"bound": r.get("bound"), "frac": round(r["frac"], 4), "achieved": round(r["achieved"], 1), "unit": r.get("unit")}
-            if "kernel" in r:
-                e["kernel"] = r["kernel"]
-            if "kernel_us" in r:
-                e["us"] = round(r["kernel_us"], 2)
-            if r.get("traffic") and r.get("algorithmic_bytes_per_launch"):
-                e["moved_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
-            rf["kernels"][name] = e
+    if rf.get("traffic") and rf.get("algorithmic_bytes_per_launch"):
+        rf["moved_over_algorithmic"] = rf["traffic"] / rf["algorithmic_bytes_per_launch"]
+    finish_rooflines(kernels, rf, kernel_s)
     if "sad64x64_pairs" in kernels:  # the kernel north_star's ">= 50 % of HBM on the SAD path" applies to
         rf["sad_path_hbm_frac"] = kernels["sad64x64_pairs"]["roofline"]["frac"]
-    if "config3_roundtrip" in kernels:
-        rf["kernels"]["config3_roundtrip"] = {"sizes_checked_vs_oracle": kernels["config3_roundtrip"]["sizes_checked"],
-                                              "hbm_frac_min_max": kernels["config3_roundtrip"]["hbm_frac_min_max"]}
     if a.legs and a.mode != "strips":
         out.pop("frame_partition", None)
-    if out.get("cpu_baseline"):
-        cb = out["cpu_baseline"]["kernels"] = {}
-        for name, k in kernels.items():
-            c = k.get("cpu_baseline") if isinstance(k, dict) else None
-            if c and "value" in k:
-                cb[name] = {"cpu": round(c["value"], 2), "gpu": round(k["value"], 1), "gpu_over_cpu": round(k["value"] / c["value"], 1), "unit": c["unit"], "cores": c["cores"],
-                            "kind": c["kind"]}
-    if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+    if a.pmc_child:
+        if os.environ.get("SVT_PMC_REGIONS_FILE"):
+            regions.dump(os.environ["SVT_PMC_REGIONS_FILE"])
+    elif rank == 0:
+        emit(out, a)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -5,7 +5,20 @@ import ctypes as C
 
 import numpy as np
 
+import bench_regions as regions
+
 HBM_PEAK_GBS = 8000.0
+
+
+def roof(alg_bytes, seconds, kernel=None, bound="hbm", **extra):
+    """roofline object of a leg: ALGORITHMIC bytes per call / event-timed seconds per call against the 8 TB/s HBM peak; `region` = the timed region it was
+    measured in, through which bench.py attaches this run's counter passes (HBM bytes moved, VALU instructions, VALU-active cycles)"""
+    r = {"bound": bound, "achieved": alg_bytes / seconds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / seconds / 1e9 / HBM_PEAK_GBS,
+         "algorithmic_bytes_per_launch": alg_bytes, "kernel_us": seconds * 1e6, "region": regions.LAST}
+    if kernel:
+        r["kernel"] = kernel
+    r.update(extra)
+    return r
 
 
 MIN_S = 0.3  # bench.py sets this from --min-leg-s: every leg is timed over at least this much device time
@@ -15,6 +28,9 @@ def _time(torch, fn, steps, warmup, batches=5):
     """seconds per call: median over `batches` event-timed runs of back-to-back launches; `steps` per run is raised until the runs together last >= MIN_S
     (short kernels see clock ramps and the ~5 us dispatch gap otherwise)"""
     import math
+    idx = regions.open_region()
+    if regions.PMC_CHILD:
+        return regions.pmc_run(fn, idx)
     for _ in range(max(warmup, 1)):
         fn()
     torch.cuda.synchronize()
@@ -171,8 +187,7 @@ def lr_frames(torch, lib, pkg, stream, steps, warmup):
         t = _time(torch, lambda: lib.svt_hip_lr_filter_frame(C.byref(P), stream), steps, warmup)
         nbytes = Wc * Hc * 4 + 4 * nstripes * Wc * 2
         out["lr_%s_4k10" % name] = {"frames_per_s": 1 / t, "Mpx_s": Wc * Hc / t / 1e6, "ms": t * 1e3,
-                                    "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                 "frac": nbytes / t / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": nbytes}}
+                                    "roofline": roof(nbytes, t, "lr_frame_kernel<%s>" % (os.environ.get("SVT_HIP_LR_UR") or "32"), algorithmic_bytes_per_frame=nbytes)}
     return out
 
 
@@ -576,7 +591,10 @@ def tf_subpel(torch, lib, pkg, stream, steps, warmup, keep=None):
     cand_px = float(np.sum(a[:, 2].astype(np.float64) ** 2 / 2)) * 17  # 1 + 8 + 8 candidates, every other row
     if keep is not None:  # bench.py's checker / CPU baseline leg works on the same inputs
         keep.update(P=P, src=src, refs=refs, descs=d, results=res.copy(), W=W, H=H)
+    # algorithmic bytes per block: the b x b source block + the (b + 8)^2 reference window an 8-tap sub-pel search around the full-pel vector touches + the 16-byte result
+    alg = int(np.sum(a[:, 2].astype(np.int64) ** 2 + (a[:, 2].astype(np.int64) + 8) ** 2 + 16))
     return {"tf_subpel_1080p8_6refs": {"us": t * 1e6, "blocks_per_s": n / t, "pictures_per_s": 1 / t, "candidate_Gsamples_per_s": cand_px / t / 1e9,
+                                        "roofline": roof(alg, t, "tf_subpel_kernel<unsigned char>"),
                                         "moved_frac": float(np.mean((res["mv_x"] != d["mv_x"]) | (res["mv_y"] != d["mv_y"])))}}
 
 
@@ -605,16 +623,23 @@ def lr_search(torch, lib, pkg, stream, steps, warmup, keep=None):
         ws = torch.zeros(lib.svt_hip_lr_search_workspace(C.addressof(P)), dtype=torch.uint8, device="cuda")
         d_out = torch.zeros(n * 72, dtype=torch.uint8, device="cuda")
         ts = []
-        for it in range(warmup + max(steps, 2)):
-            torch.cuda.synchronize()
-            t0 = _t.perf_counter()
+
+        def one():
             assert lib.svt_hip_lr_search_plane(C.addressof(P), None, d_out.data_ptr(), ws.data_ptr(), stream) == 0
             torch.cuda.synchronize()
+        tp = regions.hook(one, name="lr_search_" + name.rsplit("_", 1)[1])
+        for it in range(0 if tp is not None else warmup + max(steps, 2)):
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            one()
             if it >= warmup:
                 ts.append(_t.perf_counter() - t0)
+        if tp is not None:
+            ts = [tp]
         res = d_out.cpu().numpy().view(pkg.LrSearchUnit)
         t = float(np.median(ts))
-        out[name] = {"ms": t * 1e3, "planes_per_s": 1 / t, "units": n, "workspace_MB": ws.numel() / 1e6,
+        # algorithmic bytes: the source and the degraded plane once (2 B / sample each) + the 72-byte result per unit -- the search re-reads them per trial by design
+        out[name] = {"ms": t * 1e3, "planes_per_s": 1 / t, "units": n, "workspace_MB": ws.numel() / 1e6, "roofline": roof(2 * W * H * 2 + n * 72, t),
                      "wiener_units": int(np.count_nonzero(res["sse"][:, 1] != np.iinfo(np.int64).max)),
                      "sse_gain_wiener": float(1 - res["sse"][:, 1][res["sse"][:, 1] != np.iinfo(np.int64).max].sum() / max(1, res["sse"][:, 0][res["sse"][:, 1] != np.iinfo(np.int64).max].sum())),
                      "sse_gain_sgrproj": float(1 - res["sse"][:, 2].sum() / max(1, res["sse"][:, 0].sum()))}
@@ -693,8 +718,10 @@ def hme_chain(torch, lib, pkg, stream, steps, warmup):
     sp = (C.c_void_p * 3)(*[st[3].data_ptr() for st in stages])
     cp = (C.c_void_p * 3)(*[st[4].data_ptr() for st in stages])
     tf = _time(torch, lambda: lib.svt_hip_hme_chain_batch(C.addressof(PA), C.addressof(pl), C.addressof(pl), None, C.addressof(sp), C.addressof(cp), stream), steps, warmup)
+    # algorithmic bytes: every level's source and reference planes once (picture sizes, no borders) + the per-search result (8 B SAD + 4 B centre) of each level
+    alg = sum((1 + n_refs) * (W >> (2 - lv)) * (H >> (2 - lv)) for lv in (0, 1, 2)) + 3 * n * 12
     return {"hme_3level_1080p_4refs": {"us_per_picture": tf * 1e6, "pictures_per_s": 1 / tf, "searches_per_level": n, "launches": 1,
-                                       "us_per_picture_level_by_level": t * 1e6,
+                                       "us_per_picture_level_by_level": t * 1e6, "roofline": roof(alg, tf, "hme_chain_kernel"),
                                        "note": "level 0: 2x2 regions of 16x16 on 1/16-area planes; levels 1, 2: 8x3; one fused launch vs three level calls"}}
 
 
@@ -859,6 +886,10 @@ def me_session_stage(torch, lib, pkg, stream, steps, warmup, npics=48, slots=Non
     (t, hs), (t8, hs8) = min(ts), min(ts8)
     return {"me_session_stage_1080p_host": {"pictures_per_s": npics / t, "us_per_picture": t / npics * 1e6, "host_submit_us_per_picture": hs / npics * 1e6,
                                             "pictures_in_flight": slots, "h2d_MB_per_picture": nbytes / 1e6,
+                                            "roofline": {"bound": "pcie", "achieved": (nbytes + sum(sizes)) / (t / npics) / 1e9, "peak": 64.0, "unit": "GB/s",
+                                                         "frac": (nbytes + sum(sizes)) / (t / npics) / 1e9 / 64.0, "kernel_us": t / npics * 1e6, "binds": "pcie",
+                                                         "algorithmic_bytes_per_launch": nbytes + sum(sizes),
+                                                         "note": "host form: one picture up, its MeSbResults down per call; peak = PCIe 5.0 x16 per direction"},
                                             "d2h_MB_per_picture": sum(sizes) / 1e6,
                                             "note": "decimation + HME 0-2 + integer search + MeSbResults per picture, 4 references, PCIe inclusive"},
             "me_session_stage_1080p_host_preset8": {"pictures_per_s": npics / t8, "us_per_picture": t8 / npics * 1e6, "host_submit_us_per_picture": hs8 / npics * 1e6,
@@ -916,9 +947,7 @@ def tpl_src_stage(torch, lib, pkg, stream, steps, warmup, keep=None):
         keep.update(P=P, planes=planes, tot=tot, mvs=mvs, cand=cand, out=out.copy(), cells=cells)
     return {"tpl_src_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "blocks_16x16": n_blk, "Mblocks_per_s": n_blk / t / 1e6,
                                       "inter_wins_frac": float(np.mean(out["best_mode"][out["written"] > 0] != 0)) if n_blk else 0.0,
-                                      "roofline": {"bound": "hbm", "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 1e9 / 8000.0,
-                                                   "algorithmic_bytes_per_launch": alg, "kernel": "tpl_src_kernel<16, 16>", "kernel_us": t * 1e6,
-                                                   "note": "VALU bound (per block: up to 7 SADs, a 16x16 forward DCT, quantisation); the HBM figure is the contract's"}}}
+                                      "roofline": roof(alg, t, "tpl_src_kernel<16, 16>")}}
 
 
 def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
@@ -941,24 +970,21 @@ def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
         lib.svt_hip_tpl_recon_stage(C.addressof(R), d_pl.data_ptr(), d_pl.data_ptr(), d_src.data_ptr(), d_rec.data_ptr(), d_out.data_ptr(), stream)
     import os
     forms = {}
-    for form in (2, 1, 0):  # 2 = 1 with the rows given to the XCDs in contiguous chunks; 1 = the row wavefront in one launch (opt-in: SVT_HIP_TPL_RECON_FORM=1), 0 = one launch per anti-diagonal (the default); both are kept for the checker
+    for form in (3, 2, 1, 0):  # 3 = 1 with release / acquire fences; 2 = 1 with the rows given to the XCDs in contiguous chunks; 1 = the row wavefront in one launch (opt-in: SVT_HIP_TPL_RECON_FORM=1), 0 = one launch per anti-diagonal (the default); both are kept for the checker
         os.environ["SVT_HIP_TPL_RECON_FORM"] = str(form)
         t = _time(torch, run, steps, warmup, batches=3)
         out = d_out.cpu().numpy().view(pkg.TplReconStats)
         forms[form] = (t, d_rec.cpu().numpy().reshape(rows, stride), out.copy())
     os.environ.pop("SVT_HIP_TPL_RECON_FORM", None)
-    t_rows, t_rows_xcd = forms[1][0], forms[2][0]
+    t_rows, t_rows_xcd, t_rows_relacq = forms[1][0], forms[2][0], forms[3][0]
     n_blk = int(out["written"].sum())
     keep.update(R=R, recon=forms[0][1], recon_out=forms[0][2], recon_rows_form=forms[1][1], recon_out_rows_form=forms[1][2], recon_rows_xcd_form=forms[2][1],
-                recon_out_rows_xcd_form=forms[2][2], recon_stride=stride)
+                recon_out_rows_xcd_form=forms[2][2], recon_rows_relacq_form=forms[3][1], recon_out_rows_relacq_form=forms[3][2], recon_stride=stride)
     cols16, rows16 = (P.aligned_width + 15) // 16, (((P.height + 7) & ~7) + 15) // 16
     alg = n_blk * (3 * 256 + 80)
-    return {"tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "row_wavefront_form_us": t_rows * 1e6, "row_wavefront_xcd_chunks_form_us": t_rows_xcd * 1e6, "blocks_16x16": n_blk, "launches": cols16 + rows16 - 1, "us_per_launch": t * 1e6 / (cols16 + rows16 - 1),
+    return {"tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "row_wavefront_form_us": t_rows * 1e6, "row_wavefront_xcd_chunks_form_us": t_rows_xcd * 1e6, "row_wavefront_release_acquire_form_us": t_rows_relacq * 1e6, "blocks_16x16": n_blk, "launches": cols16 + rows16 - 1, "us_per_launch": t * 1e6 / (cols16 + rows16 - 1),
                                         "coded_frac": float(np.mean(out["coded"][out["written"] > 0])) if n_blk else 0.0,
-                                        "roofline": {"bound": "hbm", "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 1e9 / 8000.0,
-                                                     "algorithmic_bytes_per_launch": alg / (cols16 + rows16 - 1), "kernel": "tpl_recon_kernel<16, 16>",
-                                                     "kernel_us": t * 1e6 / (cols16 + rows16 - 1),
-                                                     "note": "launch-latency bound: a wavefront of 187 dependent launches of <= 68 blocks each; the HBM figure is the contract's"}}}
+                                        "roofline": roof(alg, t, "tpl_recon_kernel<16, 16>", launches_per_call=cols16 + rows16 - 1)}}
 
 
 def tf_picture_stage(torch, lib, pkg, stream, steps, warmup, keep=None, size=(1920, 1080)):
@@ -1037,8 +1063,12 @@ def tf_picture_stage(torch, lib, pkg, stream, steps, warmup, keep=None, size=(19
         same = all(np.array_equal(d_c[pl].cpu().numpy().reshape(out[pl].shape), out[pl]) for pl in range(3))
         if not same:
             raise SystemExit("bench: svt_hip_tf_picture (resident form) differs from svt_hip_tf_picture_host -- no numbers recorded")
-        resident = {"tf_picture_stage_1080p8_4refs_resident": {"us": td * 1e6, "pictures_per_s": 1 / td, "equals_host_form": True,
+        alg_tf = (2 + n_refs) * sum(W * H // (1 if pl == 0 else 4) for pl in range(3)) + 4 * n_refs * n_sb * 85 * 8
+        resident = {"tf_picture_stage_1080p8_4refs_resident": {"us": td * 1e6, "pictures_per_s": 1 / td, "equals_host_form": True, "roofline": roof(alg_tf, td),
                                                                "note": "pictures and ME tables resident in HBM, filtered in place; includes a 3-plane device copy that resets the central picture"}}
+    moved = up + sum(x.nbytes for x in out)
     return {**resident, "tf_picture_stage_1080p8_4refs_host": {"ms": t * 1e3, "pictures_per_s": 1 / t, "uploaded_MB": up / 1e6, "pcie_inclusive": True,
+                                                    "roofline": {"bound": "pcie", "achieved": moved / t / 1e9, "peak": 64.0, "unit": "GB/s", "frac": moved / t / 1e9 / 64.0,
+                                                                 "kernel_us": t * 1e6, "binds": "pcie", "algorithmic_bytes_per_launch": moved},
                                                     "pred_64x64": st.blocks_64x64, "pred_32x32": st.blocks_32x32, "pred_16x16": st.blocks_16x16, "pred_8x8": st.blocks_8x8,
                                                     "note": "wall time of the synchronous host-picture call (what the encoder seam pays), not a kernel time"}}

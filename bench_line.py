@@ -1,0 +1,106 @@
+"""The ONE line bench.py prints on stdout, built from the full result object.
+
+The driver keeps only a few KB of stdout: round 3's line had grown to 19 KB and its record came back unparsed.  So the full object goes to
+`bench_detail.json` (and to stderr, one line); stdout carries a line of at most MAX_LINE bytes that holds exactly the claims the contract names: metric / value /
+config, `roofline` of the dominant kernel, `cpu_baseline`, the encoder fps half of the metric, and a fixed-width row per leg (time, HBM fraction, VALU fraction, which
+roof binds).  compact() never raises on a missing field -- a leg that did not run is simply absent -- and shrinks itself (drops the least important parts first) until
+the line fits; tests/test_bench_line.py runs it on canned results.
+"""
+import json
+
+MAX_LINE = 4000  # bytes; asserted before printing
+
+
+def _r(v, sig=5):
+    """numbers rounded to `sig` significant digits (floats only), everything else unchanged"""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, v))
+    return v
+
+
+def _pick(d, keys, sig=5):
+    return {k: _r(d[k], sig) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def leg_row(k):
+    """[microseconds per launch or stage call, HBM fraction (algorithmic bytes / time / 8 TB/s), VALU fraction, binding roof] of one leg; None where unmeasured"""
+    r = k.get("roofline") if isinstance(k, dict) else None
+    if not isinstance(r, dict):
+        return None
+    us = r.get("kernel_us")
+    frac = r.get("frac")
+    vf = r.get("valu_busy", r.get("valu_frac"))
+    return [_r(us, 4), _r(frac, 3), _r(vf, 3), r.get("binds")]
+
+
+def compact(out):
+    rf, cb, enc = out.get("roofline") or {}, out.get("cpu_baseline") or {}, out.get("encoder_fps_1080p_preset8") or {}
+    kernels = out.get("kernels") or {}
+    line = {k: _r(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["unit"] = "Mblocks/s"  # (block = one search position of one 64x64 SB against one reference = 85 block SADs: config.workload / DESIGN.md 6)
+    line["config"] = _pick(out.get("config") or {}, ("workload", "launches_per_step", "frames_per_step_per_gpu", "refs", "search_area", "sb_refs_per_step_per_gpu",
+                                                     "timed_region_s", "parallelism", "mode"))
+    line["parity_checked_values"] = out.get("parity_checked_values")
+    line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel", "kernel_us", "valu_frac", "valu_busy",
+                                  "binds", "sad_path_hbm_frac", "moved_over_algorithmic", "traffic_source"))
+    if "traffic" not in line["roofline"]:
+        line["roofline"]["traffic"] = None
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind", "single_thread_value", "gpu_over_cpu", "sample"))
+        ck = {}
+        for name in ("sad64x64_pairs", "fwd_txfm2d_32x32", "inv_txfm2d_add_32x32", "cdef_apply_4k10"):
+            k = kernels.get(name) or {}
+            e = {}
+            if "value" in k:
+                e["gpu"] = _r(k["value"], 4)
+            for tag, key in (("avx2", "cpu_baseline"), ("avx512", "cpu_baseline_avx512"), ("sse4_1", "cpu_baseline_sse4_1")):
+                if isinstance(k.get(key), dict) and "value" in k[key]:
+                    e[tag] = _r(k[key]["value"], 4)
+                    e["cores"] = k[key].get("cores")
+            if e:
+                ck[name] = e
+        if ck:
+            c["kernels"] = ck
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = None
+    if enc:
+        e = _pick(enc, ("fps_c_only", "fps_avx2_intrinsics", "fps_avx512_intrinsics", "fps_avx2_host_with_stage_seams", "fps_avx512_host_with_stage_seams",
+                        "fps_c_host_with_stage_seams", "frames", "bitstream_identical", "host_cpu_s_per_frame", "instances"), 4)
+        ss = enc.get("steady_state_300_frames")
+        if isinstance(ss, dict):
+            e["steady_state_300_frames"] = _pick(ss, ("fps_avx2_intrinsics", "fps_avx2_host_with_stage_seams", "fps_avx512_intrinsics", "fps_avx512_host_with_stage_seams"), 4)
+        line["encoder_fps_1080p_preset8"] = e
+    fp = out.get("frame_partition")
+    if isinstance(fp, dict):
+        line["frame_partition"] = _pick(fp, ("value", "unit", "ms_per_step", "scaling", "collective"), 4)
+    legs = {}
+    for name, k in kernels.items():
+        row = leg_row(k)
+        if row is not None:
+            legs[name] = row
+    if legs:
+        line["legs"] = {"_columns": ["us", "hbm_frac", "valu_frac", "binds"], **legs}
+    if out.get("detail"):
+        line["detail"] = out["detail"]
+    # shrink until it fits: the leg table first (it is in the detail file), then the optional objects
+    s = json.dumps(line, separators=(",", ":"))
+    for drop in ("legs", "frame_partition", "detail"):
+        if len(s) <= MAX_LINE:
+            break
+        if drop == "legs" and "legs" in line:  # first try without the binding column / with fewer digits
+            line["legs"] = {k: (v if k == "_columns" else [_r(x, 3) if not isinstance(x, str) else x for x in v]) for k, v in line["legs"].items()}
+            s = json.dumps(line, separators=(",", ":"))
+            if len(s) <= MAX_LINE:
+                break
+        line.pop(drop, None)
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) > MAX_LINE and isinstance(line.get("cpu_baseline"), dict):
+        line["cpu_baseline"].pop("sample", None)
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) <= MAX_LINE, "bench line is %d bytes" % len(s)
+    return s

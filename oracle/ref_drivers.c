@@ -153,3 +153,19 @@ uint64_t oracle_time_sad_pairs(void *fn, int kind, const uint8_t *src_base, cons
             if ((++done & 255) == 0 && now_s() >= t_end) { *checksum = sum; return done; }
         }
 }
+
+/* inverse transform + reconstruction through a reference kernel (svt_av1_inv_txfm2d_add_WxH_*: common_dsp_rtcd.h), for bench.py's cpu_baseline legs: blocks idx0,
+ * idx0 + step, ... of `n` contiguous w*h coefficient blocks, reconstructed onto one private w*h tile (read = write, as the encoder calls it) */
+typedef void (*InvTxfmFn)(const int32_t *, uint16_t *, int32_t, uint16_t *, int32_t, uint8_t, int32_t);
+uint64_t oracle_time_inv_txfm(InvTxfmFn fn, const int32_t *coeff, uint32_t n, int w, int h, uint16_t *tile, uint8_t tx_type, uint8_t bd, uint32_t idx0, uint32_t step,
+                              double seconds) {
+    uint64_t     done = 0;
+    const double t_end = now_s() + seconds;
+    (void)idx0;
+    for (;;)
+        for (uint32_t i = 0; i < n; i += step) {
+            if ((done & 15) == 0) memset(tile, 0, sizeof(uint16_t) * w * h); /* (keeps the accumulating reconstruction away from the clamp) */
+            fn(coeff + (size_t)i * w * h, tile, w, tile, w, tx_type, bd);
+            if ((++done & 63) == 0 && now_s() >= t_end) return done;
+        }
+}

@@ -264,8 +264,6 @@ def test_tpl_recon_stage_device(be, oracle, ci, is_ref, form, monkeypatch):
     # column is cut by the right picture edge at dispenser level 1
     if form == 2 and not be.is_gpu:
         pytest.skip("form 2 orders the rows for the device's XCDs; the emulator runs workgroups one after the other in id order (a row would wait for one not yet run)")
-    if form == 3 and be.is_gpu:
-        pytest.skip("form 3 (release / acquire fences instead of sequentially-consistent ones) is prepared for the next round's GPU time: logic checked on the emulator only")
     monkeypatch.setenv("SVT_HIP_TPL_RECON_FORM", str(form))
     pkg = be.pkg
     P, planes, tot, mvs, cand, n_pus, cells = make_case(c, 5000 + ci)

@@ -24,6 +24,10 @@ ENC = os.path.join(ROOT, "oracle", "_ref", "enc", "SvtAv1EncApp")
 # the same reference encoder with its x86 intrinsic kernels compiled in (oracle/Makefile `enc_avx2`: ASM_SSE2 .. ASM_AVX2/*.c, NASM kernels at their C versions):
 # the CPU baseline a user of the reference actually runs, and -- with the seams on -- the host half of a deployment.  Its bitstream equals the C-only encoder's.
 ENC_AVX2 = os.path.join(ROOT, "oracle", "_ref", "enc_avx2", "SvtAv1EncApp")
+# ... and with EN_AVX512_SUPPORT=1 + ASM_AVX512/*.c (oracle/Makefile `enc_avx512`): what the reference selects on an AVX-512 host
+ENC_AVX512 = os.path.join(ROOT, "oracle", "_ref", "enc_avx512", "SvtAv1EncApp")
+HOST_ENC = {"c": None, "avx2": ENC_AVX2, "avx512": ENC_AVX512}
+LAST_CPU_S = [0.0]  # user + system CPU seconds of the most recent encode() child (RUSAGE_CHILDREN delta)
 
 # name: (width, height, frames, bit depth, extra encoder arguments)
 CASES = {
@@ -226,9 +230,14 @@ def encode(clip, w, h, n, bd, extra, out_prefix, env_extra=None, timeout=1800, e
           ["-b", out_prefix + ".ivf"]
     # (no `-o` reconstruction file: the reconstruction is a function of the bitstream, and with -o the reference APP busy-polls svt_av1_get_recon on its
     # main thread, which starves the encoder's own threads on a CPU-limited box -- a 1 s encode was seen to take minutes there)
+    import resource
+    u0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     t0 = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
-    return r, time.time() - t0
+    dt = time.time() - t0
+    u1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+    LAST_CPU_S[0] = (u1.ru_utime - u0.ru_utime) + (u1.ru_stime - u0.ru_stime)  # (encodes run one at a time here: the delta is this child's)
+    return r, dt
 
 
 def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, host="c"):
@@ -243,6 +252,7 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     tplseam = "+tplseam" in extra
     extra = [a for a in extra if not a.startswith("+")]
     rc, tc = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_c"), timeout=timeout)
+    cpu_s = {"c": LAST_CPU_S[0]}
     deterministic = True
     if "--lp" not in extra or extra[extra.index("--lp") + 1] != "1":  # multi-threaded: is the C-only reference reproducible at all for this configuration?
         rc2, _ = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_c2"), timeout=timeout)
@@ -286,12 +296,16 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     if skip:
         env["SVT_HIP_SKIP"] = skip
     rx = None
-    if host == "avx2":
-        rx, tx = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_x"), timeout=timeout, enc=ENC_AVX2)
-    rh, th = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_hip"), env, timeout=timeout, enc=ENC_AVX2 if host == "avx2" else None)
+    if host != "c":
+        rx, tx = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_x"), timeout=timeout, enc=HOST_ENC[host])
+        cpu_s[host] = LAST_CPU_S[0]
+    rh, th = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_hip"), env, timeout=timeout, enc=HOST_ENC[host])
+    cpu_s[host + "_with_stages"] = LAST_CPU_S[0]
     res = {"case": name, "host": host, "width": w, "height": h, "frames": n, "bit_depth": bd, "args": extra, "rc_c": rc.returncode, "rc_hip": rh.returncode,
-           "seconds_c": round(tc, 2), "seconds_hip": round(th, 2), "reference_deterministic": deterministic}
-    for tag, r in (("c", rc), ("hip", rh)) + ((("avx2", rx),) if rx is not None else ()):  # the encoder's own speed line
+           "seconds_c": round(tc, 2), "seconds_hip": round(th, 2), "reference_deterministic": deterministic,
+           # host CPU seconds (user + system, every thread) per frame: what the offload takes off the host
+           "host_cpu_s_per_frame": {k: round(v / n, 5) for k, v in cpu_s.items()}}
+    for tag, r in (("c", rc), ("hip", rh)) + (((host, rx),) if rx is not None else ()):  # the encoder's own speed line
         for ln in (r.stdout + r.stderr).splitlines():
             if "Average Speed" in ln:
                 res["fps_" + tag] = float(ln.split(":")[1].split()[0])
@@ -313,8 +327,8 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
         same = same and len(a) > 0 and a == b
     if rx is not None:  # the intrinsics encoder alone must reproduce the C-only bitstream too
         x = open(os.path.join(outdir, name + "_x.ivf"), "rb").read() if rx.returncode == 0 else b""
-        res["avx2_identical_to_c"] = len(x) > 0 and x == open(os.path.join(outdir, name + "_c.ivf"), "rb").read()
-        same = same and res["avx2_identical_to_c"]
+        res[host + "_identical_to_c"] = len(x) > 0 and x == open(os.path.join(outdir, name + "_c.ivf"), "rb").read()
+        same = same and res[host + "_identical_to_c"]
     res["identical"] = same
     res["bitstream_equal"] = bool(same)  # the files alone; "identical" additionally demands that the stages the case names really ran
     if seam:
@@ -381,6 +395,72 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     return res
 
 
+def seam_env(name, lib, outdir, tag, device=0):
+    """the environment run_case() gives the HIP run of `name` (every seam the case names), statistics files suffixed with `tag`"""
+    flags = CASES[name][4]
+    env = {"SVT_HIP": str(device), "SVT_HIP_LIB": lib}
+    f = lambda k: os.path.join(outdir, "%s_%s_%s.txt" % (name, tag, k))  # noqa: E731
+    if "+seam" in flags:
+        env.update({"SVT_HIP_ME_SEAM": "1", "SVT_HIP_ME_SEAM_STATS": f("seam")})
+        if "+tfseam" in flags:
+            env["SVT_HIP_TF_ME_SEAM"] = "1"
+        if "+tfsubpel" in flags:
+            env.update({"SVT_HIP_TF_SUBPEL_SEAM": "1", "SVT_HIP_TF_SUBPEL_SEAM_STATS": f("tfsubpel")})
+        if "+tfdriver" in flags:
+            env.update({"SVT_HIP_TF_SEAM": "1", "SVT_HIP_TF_SEAM_STATS": f("tfdriver")})
+    for flag, var in (("+lrseam", "SVT_HIP_LR_SEAM"), ("+cdefseam", "SVT_HIP_CDEF_SEAM"), ("+dlfseam", "SVT_HIP_DLF_SEAM"), ("+tplseam", "SVT_HIP_TPL_SEAM")):
+        if flag in flags:
+            env.update({var: "1", var + "_STATS": f(var.lower())})
+    if "+tplrecon" in flags:
+        env["SVT_HIP_TPL_RECON_SEAM"] = "1"
+    if "+hook" not in flags:
+        env["SVT_HIP_ONLY"] = "-"
+    return env
+
+
+def run_instances(name, lib, outdir, k, host="avx2", timeout=1800):
+    """K concurrent encodes of case `name` (each its own process, all host threads, one shared MI355X): aggregate fps and host CPU seconds per frame of the intrinsics
+    host alone vs the same host with the case's stage seams on the GPU.  Every one of the 2K bitstreams must equal the C-only encoder's (the one
+    thing offload can buy a host that is already fast is CPU time -- visible as aggregate throughput once the host cores are saturated)."""
+    import resource
+    w, h, n, bd, extra = CASES[name]
+    os.makedirs(outdir, exist_ok=True)
+    clip = os.path.join(outdir, name + "_inst.yuv")
+    clip_frames = next((int(a[5:]) for a in extra if a.startswith("+clip")), n)
+    make_clip(clip, w, h, min(clip_frames, n), bd, static="+static" in extra)
+    args = [a for a in extra if not a.startswith("+")]
+    rc, _ = encode(clip, w, h, n, bd, args, os.path.join(outdir, name + "_inst_c"), timeout=timeout)
+    want = open(os.path.join(outdir, name + "_inst_c.ivf"), "rb").read() if rc.returncode == 0 else b""
+    res = {"case": name, "instances": k, "host": host, "frames": n, "identical": len(want) > 0}
+    for tag, with_stages in ((host, False), (host + "_with_stages", True)):
+        procs = []
+        u0 = resource.getrusage(resource.RUSAGE_CHILDREN)
+        t0 = time.time()
+        for i in range(k):
+            env = dict(os.environ)
+            for v in ("SVT_HIP", "SVT_HIP_LIB", "SVT_HIP_COUNT", "SVT_HIP_ONLY", "SVT_HIP_SKIP"):
+                env.pop(v, None)
+            if with_stages:
+                env.update(seam_env(name, lib, outdir, "inst%d" % i))
+            out = os.path.join(outdir, "%s_inst_%s_%d" % (name, "s" if with_stages else "x", i))
+            cmd = [HOST_ENC[host], "-i", clip, "-w", str(w), "-h", str(h), "--fps", "30", "-n", str(n), "--input-depth", str(bd)] + args + ["-b", out + ".ivf"]
+            procs.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env), out))
+        outs = [(p.communicate(timeout=timeout), p.returncode, o) for p, o in procs]
+        wall = time.time() - t0
+        u1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+        same = all(rcode == 0 and open(o + ".ivf", "rb").read() == want for _, rcode, o in outs)
+        res["identical"] = res["identical"] and same
+        res["fps_" + tag] = round(k * n / wall, 2)
+        res["host_cpu_s_per_frame_" + tag] = round(((u1.ru_utime - u0.ru_utime) + (u1.ru_stime - u0.ru_stime)) / (k * n), 5)
+        if not same:
+            res["stderr_tail"] = next((e[-1200:] for (_, e), rcode, _o in outs if rcode), "")
+        for _, _, o in outs:
+            if os.path.exists(o + ".ivf"):
+                os.remove(o + ".ivf")
+    os.remove(clip)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=os.path.join(ROOT, "svt-av1-psy_amd", "libsvtav1_hip.so"))
@@ -389,11 +469,19 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--skip", default=None)
     ap.add_argument("--timeout", type=int, default=1800)
-    ap.add_argument("--host", choices=("c", "avx2"), default="c", help="host build the HIP run uses (avx2: oracle/_ref/enc_avx2, also timed alone)")
+    ap.add_argument("--host", choices=("c", "avx2", "avx512"), default="c", help="host build the HIP run uses (avx2 / avx512: oracle/_ref/enc_avx2 / enc_avx512, also timed alone)")
+    ap.add_argument("--instances", type=int, default=0, help="K > 0: run_instances() instead -- K concurrent encodes of the case on one GPU, host alone vs host + stages")
     a = ap.parse_args()
     if not os.path.exists(ENC):
         sys.exit("oracle/_ref/enc/SvtAv1EncApp is missing: run `make -C oracle enc` where /root/reference exists")
     names = GPU_CASES if a.case == "all" else (list(SWEEP) if a.case == "sweep" else a.case.split(","))
+    if a.instances:
+        ok = True
+        for nme in names:
+            r = run_instances(nme, os.path.abspath(a.lib), a.out, a.instances, host=a.host if a.host != "c" else "avx2", timeout=a.timeout)
+            print(json.dumps(r), flush=True)
+            ok = ok and r["identical"]
+        sys.exit(0 if ok else 1)
     results, union = [], {}
     for nme in names:
         r = run_case(nme, os.path.abspath(a.lib), a.out, only=a.only, skip=a.skip, timeout=a.timeout, host=a.host)
@@ -404,8 +492,9 @@ def main():
                                                                                         r.get("pointers_installed"), r["seconds_c"], r["seconds_hip"],
                                                                                         str(r.get("seam", "")) + " " + str(r.get("lrseam", "")) + " " + str(r.get("cdefseam", "")) + " " + str(r.get("dlfseam", "")) + " " + str(r.get("tfsubpel", "")) + " " + str(r.get("tfdriver", "")) + " " + str(r.get("tplseam", "")) + " " + str(r.get("devices", ""))), flush=True)
         if "fps_c" in r:
-            print("    encoder fps: C-only %.2f, %swith HIP (host = %s) %.2f" % (r["fps_c"], ("AVX2 intrinsics %.2f, " % r["fps_avx2"]) if "fps_avx2" in r else "", r["host"],
-                                                                               r.get("fps_hip", 0.0)), flush=True)
+            print("    encoder fps: C-only %.2f, %swith HIP (host = %s) %.2f; host CPU s / frame %s" % (
+                r["fps_c"], ("%s intrinsics %.2f, " % (r["host"], r["fps_" + r["host"]])) if ("fps_" + r["host"]) in r and r["host"] != "c" else "", r["host"],
+                r.get("fps_hip", 0.0), r.get("host_cpu_s_per_frame")), flush=True)
         if not r["identical"]:
             print(r.get("stderr_tail", ""))
     summary = {"all_identical": all(r["identical"] for r in results), "pointers_hit_union": len(union), "calls_total": sum(union.values()),
