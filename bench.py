@@ -519,8 +519,8 @@ SIMDS, CLOCK_HZ = 1024, 2.4e9
 def finish_rooflines(kernels, rf, me_kernel_s):
     """Attaches this run's counter passes to every leg's roofline object, by timed region: `traffic` = HBM bytes moved per call of the leg (FETCH_SIZE x 2 + WRITE_SIZE,
     KiB units: MI355X_MICROARCH.md), `valu_frac` = SQ_INSTS_VALU per call x 4.5 cycles / (1024 SIMDs x 2.4 GHz x the leg's event-timed seconds) -- the share of the
-    chip's VALU issue slots the leg's instructions need at the plain-opcode rate -- and `valu_busy` = SQ_ACTIVE_INST_VALU per call against the same counter of a kernel
-    that issues nothing but VALU instructions (bench_regions.probe), i.e. a measured busy fraction that also sees the multi-cycle opcodes.  `binds` names the roof that
+    chip's VALU issue slots the leg's instructions need at the plain-opcode rate (a lower bound where multi-cycle opcodes dominate: the ME search states its own
+    figure from the measured v_qsad_pk_u16_u8 rate; ~1.0 = the leg runs at the VALU issue roof and only fewer instructions make it faster).  `binds` names the roof that
     is closer: "valu", "hbm", or "latency" when neither reaches 0.35 (dependent launches / occupancy / LDS: DESIGN.md names which)."""
     reg = (LIVE_PMC or {}).get("regions") or {}
     probe = (LIVE_PMC or {}).get("probe") or {}
@@ -553,10 +553,10 @@ def finish_rooflines(kernels, rf, me_kernel_s):
                 r.setdefault("valu_frac", tot["SQ_INSTS_VALU"] / calls * VALU_CYCLES_PER_WAVE_INST / (SIMDS * CLOCK_HZ * t))
                 if name == "__me__":
                     r["valu_frac_plain_opcode_rate"] = tot["SQ_INSTS_VALU"] / calls * VALU_CYCLES_PER_WAVE_INST / (SIMDS * CLOCK_HZ * t)
-            if "SQ_ACTIVE_INST_VALU" in tot and probe.get("active_per_s"):
-                r["valu_busy"] = tot["SQ_ACTIVE_INST_VALU"] / calls / t / probe["active_per_s"]
+            if "SQ_ACTIVE_INST_VALU" in tot:  # raw, for the record only: the counter runs ahead of time for the multi-cycle opcodes (> 1 "busy" for the packed-SAD search)
+                r["sq_active_inst_valu_per_call"] = tot["SQ_ACTIVE_INST_VALU"] / calls
             r["kernels_per_call"] = {kn: round(kv["launches"] / calls, 2) for kn, kv in g["kernels"].items()}
-        v = max(r.get("valu_busy") or 0.0, r.get("valu_frac") or 0.0)
+        v = r.get("valu_frac") or 0.0
         h = r.get("frac") or 0.0
         if r.get("bound") == "mfma":
             r["binds"] = "mfma"
@@ -565,9 +565,9 @@ def finish_rooflines(kernels, rf, me_kernel_s):
     if isinstance(c3, dict) and c3.get("size_rooflines"):
         for sz, r in c3["size_rooflines"].items():
             if sz in c3["sizes"]:
-                c3["sizes"][sz] = c3["sizes"][sz][:2] + [round(max(r.get("valu_busy") or 0.0, r.get("valu_frac") or 0.0), 3)]
+                c3["sizes"][sz] = c3["sizes"][sz][:2] + [round(r.get("valu_frac") or 0.0, 3)]
         c3["roofline"] = dict(c3["size_rooflines"][worst], size=worst, note=c3["roofline"].get("note"))
-        vb = [max(r.get("valu_busy") or 0.0, r.get("valu_frac") or 0.0) for r in c3["size_rooflines"].values()]
+        vb = [r.get("valu_frac") or 0.0 for r in c3["size_rooflines"].values()]
         c3["valu_frac_min_max"] = [round(min(vb), 3), round(max(vb), 3)]
 
 

@@ -33,7 +33,7 @@ def leg_row(k):
         return None
     us = r.get("kernel_us")
     frac = r.get("frac")
-    vf = r.get("valu_busy", r.get("valu_frac"))
+    vf = r.get("valu_frac")
     return [_r(us, 4), _r(frac, 3), _r(vf, 3), r.get("binds")]
 
 
@@ -45,7 +45,7 @@ def compact(out):
     line["config"] = _pick(out.get("config") or {}, ("workload", "launches_per_step", "frames_per_step_per_gpu", "refs", "search_area", "sb_refs_per_step_per_gpu",
                                                      "timed_region_s", "parallelism", "mode"))
     line["parity_checked_values"] = out.get("parity_checked_values")
-    line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel", "kernel_us", "valu_frac", "valu_busy",
+    line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel", "kernel_us", "valu_frac",
                                   "binds", "sad_path_hbm_frac", "moved_over_algorithmic", "traffic_source"))
     if "traffic" not in line["roofline"]:
         line["roofline"]["traffic"] = None

@@ -24,7 +24,7 @@ def canned():
         if isinstance(k, dict) and isinstance(k.get("roofline"), dict):
             k["roofline"].update(valu_frac=0.4321, valu_busy=0.51234, binds="valu", region="x#0", kernels_per_call={"k": 1.0}, traffic=123456789.0)
     d["kernels"]["sad64x64_pairs"]["cpu_baseline_avx512"] = dict(d["kernels"]["sad64x64_pairs"]["cpu_baseline"], value=1234.5)
-    d["kernels"]["hme_3level_1080p_4refs"]["roofline"] = {"bound": "hbm", "frac": 0.03, "kernel_us": 62.0, "valu_busy": 0.7, "binds": "valu"}
+    d["kernels"]["hme_3level_1080p_4refs"]["roofline"] = {"bound": "hbm", "frac": 0.03, "kernel_us": 62.0, "valu_frac": 0.7, "binds": "valu"}
     d["encoder_fps_1080p_preset8"]["host_cpu_s_per_frame"] = {"c": 0.61, "avx2": 0.082, "avx2_with_stages": 0.074}
     d["encoder_fps_1080p_preset8"]["instances"] = {"k": 4, "fps_avx2": 201.2, "fps_avx2_with_stages": 214.9, "identical": True}
     return d
@@ -71,11 +71,11 @@ def test_degenerate_objects():
     assert json.loads(bench_line.compact(e))["roofline"]["traffic"] is None
     e = copy.deepcopy(d)  # a run with hundreds of legs still fits (the leg table gives way first)
     for i in range(400):
-        e["kernels"]["extra_leg_%03d" % i] = {"roofline": {"kernel_us": 12.345, "frac": 0.123, "valu_busy": 0.456, "binds": "valu"}}
+        e["kernels"]["extra_leg_%03d" % i] = {"roofline": {"kernel_us": 12.345, "frac": 0.123, "valu_frac": 0.456, "binds": "valu"}}
     o = check(bench_line.compact(e))
     assert "legs" not in o
     e = copy.deepcopy(d)  # NaN / inf never reach the line
-    e["roofline"]["valu_busy"] = float("nan")
+    e["roofline"]["valu_frac"] = float("nan")
     assert "NaN" not in bench_line.compact(e)
 
 
