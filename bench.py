@@ -407,6 +407,8 @@ def encoder_fps():
         r512 = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="avx512") if have_512 else {}
         # K concurrent encodes sharing this GPU on the box's host cores: aggregate fps and host CPU seconds per frame, AVX2 host alone vs with the stages
         inst = ei.run_instances("fps_1080p_p8_all", lib, td, 4, host="avx2", timeout=600) if have_x else {}
+        # thread CPU time per stage (integration/seam_cpu.h), a run of its own: the brackets cost two clock reads per SB in the ME stage
+        rcpu = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="avx2", cpu_stats=True) if have_x else {}
     if not r.get("identical") or not rc_.get("identical") or (r300 and not r300.get("identical")) or (r512 and not r512.get("identical")) or (inst and not inst.get("identical")):
         sys.exit("bench.py: the encoder's bitstream with the stage seams differs from the C-only encoder -- no numbers recorded (%s)" % r.get("stderr_tail", ""))
     return {"fps_c_only": r.get("fps_c"), "fps_avx2_intrinsics": r.get("fps_avx2"), "fps_avx2_host_with_stage_seams": r.get("fps_hip") if have_x else None,
@@ -419,6 +421,7 @@ def encoder_fps():
             "instances": {"k": inst.get("instances"), "fps_avx2": inst.get("fps_avx2"), "fps_avx2_with_stages": inst.get("fps_avx2_with_stages"),
                           "cpu_s_per_frame_avx2": inst.get("host_cpu_s_per_frame_avx2"), "cpu_s_per_frame_avx2_with_stages": inst.get("host_cpu_s_per_frame_avx2_with_stages"),
                           "identical": inst.get("identical")} if inst else None,
+            "stage_cpu_ms_per_frame": rcpu.get("stage_cpu_ms_per_frame"), "host_cpu_s_per_frame_in_that_run": rcpu.get("host_cpu_s_per_frame"),
             "frames": r["frames"], "host_threads": len(os.sched_getaffinity(0)), "host_cores": host_cores(),
             "host_ms_per_me_stage_call": (lambda m: round(m.get("ms_in_stage_calls", 0) / max(m.get("pictures_offloaded", 0) + m.get("tf_pairs_offloaded", 0), 1), 3))(r.get("seam") or {}),
             "host_ms_first_stage_call": (r.get("seam") or {}).get("ms_first_stage_call"),
@@ -448,13 +451,10 @@ def cpu_tpl_recon_stage(k):
     for name in ("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate", "written", "coded"):
         must_equal("tpl_recon_stage " + name, k["recon_out"][name], want[name])
     must_equal("tpl_recon_stage reconstruction", k["recon"], rec)
-    for name in ("srcrf_dist", "recrf_dist", "written", "coded"):  # the opt-in row-wavefront form of the same stage
-        must_equal("tpl_recon_stage (row form) " + name, k["recon_out_rows_form"][name], want[name])
-    must_equal("tpl_recon_stage (row form) reconstruction", k["recon_rows_form"], rec)
-    must_equal("tpl_recon_stage (row form, XCD chunks) recrf_dist", k["recon_out_rows_xcd_form"]["recrf_dist"], want["recrf_dist"])
-    must_equal("tpl_recon_stage (row form, XCD chunks) reconstruction", k["recon_rows_xcd_form"], rec)
-    must_equal("tpl_recon_stage (row form, release / acquire) recrf_dist", k["recon_out_rows_relacq_form"]["recrf_dist"], want["recrf_dist"])
-    must_equal("tpl_recon_stage (row form, release / acquire) reconstruction", k["recon_rows_relacq_form"], rec)
+    for form, (f_rec, f_out) in sorted(k["recon_forms"].items()):  # every form of the stage the leg timed
+        for name in ("srcrf_dist", "recrf_dist", "written", "coded"):
+            must_equal("tpl_recon_stage (form %d) %s" % (form, name), f_out[name], want[name])
+        must_equal("tpl_recon_stage (form %d) reconstruction" % form, f_rec, rec)
     return {"parity_checked_values": int(k["cells"]) * 6 + int(rec.size), "cpu_baseline": {"value": 1 / dt, "unit": "pictures/s", "cores": 1, "kind": "port",
                                                                                             "sample": "the leg's whole 1080p picture, oracle/oracle_tpl.c"}}
 

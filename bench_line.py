@@ -71,6 +71,9 @@ def compact(out):
     if enc:
         e = _pick(enc, ("fps_c_only", "fps_avx2_intrinsics", "fps_avx512_intrinsics", "fps_avx2_host_with_stage_seams", "fps_avx512_host_with_stage_seams",
                         "fps_c_host_with_stage_seams", "frames", "bitstream_identical", "host_cpu_s_per_frame", "instances"), 4)
+        sc = enc.get("stage_cpu_ms_per_frame")
+        if isinstance(sc, dict):  # host CPU ms per frame inside the stages of SURVEY 8: the reference's AVX2 code vs the device stage calls
+            e["stage_cpu_ms_per_frame"] = {k: v for k, v in sc.items() if k != "c" and v}
         ss = enc.get("steady_state_300_frames")
         if isinstance(ss, dict):
             e["steady_state_300_frames"] = _pick(ss, ("fps_avx2_intrinsics", "fps_avx2_host_with_stage_seams", "fps_avx512_intrinsics", "fps_avx512_host_with_stage_seams"), 4)

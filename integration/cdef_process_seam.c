@@ -19,6 +19,7 @@
  * SVT_HIP_CDEF_SEAM_STATS=<file> receives the counters.
  */
 #define _GNU_SOURCE /* RTLD_DEFAULT */
+#include "../integration/seam_cpu.h"
 #include <dlfcn.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -75,7 +76,7 @@ static int cdef_seam_on(void) {
     return D.mode;
 }
 
-static void seam_av1_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs) {
+static void seam_av1_cdef_frame_body(SequenceControlSet *scs, PictureControlSet *pcs) {
     if (!cdef_seam_on() || scs->super_block_size == 128 || av1_num_planes(&scs->seq_header.color_config) != 3) {
         if (D.mode) { pthread_mutex_lock(&D.lock); D.n_declined++; pthread_mutex_unlock(&D.lock); }
         svt_av1_cdef_frame(scs, pcs);
@@ -128,6 +129,12 @@ static void seam_av1_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs)
     pthread_mutex_unlock(&D.lock);
     free(str); free(skip);
 }
+static void seam_av1_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs) {
+    SEAM_CPU_BEGIN();
+    seam_av1_cdef_frame_body(scs, pcs);
+    SEAM_CPU_END(SEAM_CPU_CDEF);
+}
+
 
 /* ---- the search: cdef_seg_search_use0 = the reference's function (defined by the #include below), cdef_seg_search_use1 = what its call site reaches ---- */
 static void cdef_seg_search_use0(PictureControlSet *pcs, SequenceControlSet *scs, uint32_t segment_index);
@@ -199,7 +206,7 @@ static void search_picture(PictureControlSet *pcs, SequenceControlSet *scs) {
     D.n_searched++; D.n_search_fbs += searched;
     free(var); free(dir); free(mse); free(count); free(skip);
 }
-static void cdef_seg_search_use1(PictureControlSet *pcs, SequenceControlSet *scs, uint32_t segment_index) {
+static void cdef_seg_search_use1_body(PictureControlSet *pcs, SequenceControlSet *scs, uint32_t segment_index) {
     if (!cdef_seam_on() || scs->super_block_size == 128) { cdef_seg_search_use0(pcs, scs, segment_index); return; }
     pthread_mutex_lock(&D.lock);
     int slot = -1, free_slot = -1;
@@ -216,6 +223,12 @@ static void cdef_seg_search_use1(PictureControlSet *pcs, SequenceControlSet *scs
     if (++D.seen[slot] == pcs->cdef_segments_total_count) D.done_pcs[slot] = NULL;
     pthread_mutex_unlock(&D.lock);
 }
+static void cdef_seg_search_use1(PictureControlSet *pcs, SequenceControlSet *scs, uint32_t segment_index) {
+    SEAM_CPU_BEGIN();
+    cdef_seg_search_use1_body(pcs, scs, segment_index);
+    SEAM_CPU_END(SEAM_CPU_CDEF);
+}
+
 
 #define SEAM_CAT_(a, b) a##b
 #define SEAM_CAT(a, b) SEAM_CAT_(a, b)

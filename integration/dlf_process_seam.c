@@ -25,6 +25,7 @@
  * in-place order must (and does) reproduce.
  */
 #define _GNU_SOURCE /* RTLD_DEFAULT */
+#include "../integration/seam_cpu.h"
 #include <dlfcn.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -164,7 +165,7 @@ typedef struct SbPicture {
 } SbPicture;
 static SbPicture sb_rec[SB_RECS];
 
-void svt_hip_seam_loop_filter_sb(EbPictureBufferDesc *fb, PictureControlSet *pcs, int32_t mi_row, int32_t mi_col, int32_t plane_start, int32_t plane_end, uint8_t last_col) {
+static void svt_hip_seam_loop_filter_sb_body(EbPictureBufferDesc *fb, PictureControlSet *pcs, int32_t mi_row, int32_t mi_col, int32_t plane_start, int32_t plane_end, uint8_t last_col) {
     if (!dlf_seam_on()) { svt_aom_loop_filter_sb(fb, pcs, mi_row, mi_col, plane_start, plane_end, last_col); return; }
     uint32_t w[3], h[3];
     set_planes(fb, pcs, w, h);
@@ -195,6 +196,12 @@ void svt_hip_seam_loop_filter_sb(EbPictureBufferDesc *fb, PictureControlSet *pcs
     F.n_sb_calls++;
     pthread_mutex_unlock(&F.lock);
 }
+void svt_hip_seam_loop_filter_sb(EbPictureBufferDesc *fb, PictureControlSet *pcs, int32_t mi_row, int32_t mi_col, int32_t plane_start, int32_t plane_end, uint8_t last_col) {
+    SEAM_CPU_BEGIN();
+    svt_hip_seam_loop_filter_sb_body(fb, pcs, mi_row, mi_col, plane_start, plane_end, last_col);
+    SEAM_CPU_END(SEAM_CPU_DLF);
+}
+
 /* the picture has reached the deblocking process: apply what its SBs recorded (nothing when the picture was not deblocked SB by SB) */
 static void flush_sb_picture(PictureControlSet *pcs) {
     if (!dlf_seam_on()) return;
@@ -215,7 +222,7 @@ static void flush_sb_picture(PictureControlSet *pcs) {
     pthread_mutex_unlock(&F.lock);
 }
 
-static void seam_loop_filter_frame(EbPictureBufferDesc *fb, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end) {
+static void seam_loop_filter_frame_body(EbPictureBufferDesc *fb, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end) {
     if (!dlf_seam_on()) { svt_av1_loop_filter_frame(fb, pcs, plane_start, plane_end); return; }
     uint32_t w[3], h[3];
     set_planes(fb, pcs, w, h);
@@ -227,6 +234,12 @@ static void seam_loop_filter_frame(EbPictureBufferDesc *fb, PictureControlSet *p
     F.n_pictures++; F.n_segments += segs;
     pthread_mutex_unlock(&F.lock);
 }
+static void seam_loop_filter_frame(EbPictureBufferDesc *fb, PictureControlSet *pcs, int32_t plane_start, int32_t plane_end) {
+    SEAM_CPU_BEGIN();
+    seam_loop_filter_frame_body(fb, pcs, plane_start, plane_end);
+    SEAM_CPU_END(SEAM_CPU_DLF);
+}
+
 
 /* svt_aom_get_recon_pic's uses in dlf_process.c, in file order: the two prototypes (:23, :28), the 8-bit -> 16-bit conversion (:90, :91), the frame filter (:108) and
  * the pre-CDEF preparation (:136) -- the point every picture passes after its deblocking and before anything reads the result */

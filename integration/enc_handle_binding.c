@@ -49,6 +49,30 @@ static void svt_hip_shard_stats(void) {
     fclose(o);
 }
 
+/* ---- host CPU time per stage (integration/seam_cpu.h) ---- */
+#include "../integration/seam_cpu.h"
+static struct { int on; unsigned long long ns[SEAM_CPU_STAGES], calls[SEAM_CPU_STAGES]; } SVT_HIP_CPU = {-1, {0}, {0}};
+static void svt_hip_seam_cpu_stats(void) {
+    static const char *names[SEAM_CPU_STAGES] = {"me", "tf", "tpl", "dlf", "cdef", "lr"};
+    const char *f = getenv("SVT_HIP_SEAM_CPU_STATS");
+    FILE       *o = f ? fopen(f, "w") : NULL;
+    if (!o) return;
+    for (int k = 0; k < SEAM_CPU_STAGES; k++) fprintf(o, "%s_cpu_ms %llu\n%s_calls %llu\n", names[k], SVT_HIP_CPU.ns[k] / 1000000ull, names[k], SVT_HIP_CPU.calls[k]);
+    fclose(o);
+}
+int svt_hip_seam_cpu_on(void) {
+    if (SVT_HIP_CPU.on < 0) { /* (racing first calls both arrive at the same answer; atexit may then be registered twice: the second write repeats the first) */
+        const int on = getenv("SVT_HIP_SEAM_CPU_STATS") != NULL;
+        if (on) atexit(svt_hip_seam_cpu_stats);
+        SVT_HIP_CPU.on = on;
+    }
+    return SVT_HIP_CPU.on;
+}
+void svt_hip_seam_cpu_add(int stage, unsigned long long ns) {
+    __atomic_fetch_add(&SVT_HIP_CPU.ns[stage], ns, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&SVT_HIP_CPU.calls[stage], 1, __ATOMIC_RELAXED);
+}
+
 static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
     svt_aom_setup_rtcd_internal(flags);
     const char *dev = getenv("SVT_HIP");

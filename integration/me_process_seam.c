@@ -19,6 +19,7 @@
  * identity tests require zero of them for the configurations they claim.  SVT_HIP_ME_SEAM_STATS=<file> receives the counters at exit.
  */
 #define _GNU_SOURCE /* RTLD_DEFAULT */
+#include "../integration/seam_cpu.h"
 #include <dlfcn.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -82,20 +83,24 @@ static struct {
       PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER,
       PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER}, -1};
 
+static int      seam_hash = -1;
+static uint64_t n_invalidated;
 static uint64_t tf_pairs, tf_sb, tf_declined; /* the temporal filter's (picture, reference) pairs through the stage, see the end of this file */
 static void seam_stats(void) {
     const char *f = getenv("SVT_HIP_ME_SEAM_STATS");
     FILE       *o = f ? fopen(f, "w") : NULL;
     if (!o) return;
     fprintf(o, "picture_buffers_page_locked %llu\n", (unsigned long long)G.n_registered);
-    fprintf(o, "pictures_offloaded %llu\npictures_declined %llu\nsb_results %llu\nplane_uploads %llu\nplane_reuploads %llu\nlast_decline %s\n",
+    fprintf(o, "pictures_offloaded %llu\npictures_declined %llu\nsb_results %llu\nplane_uploads %llu\nplane_reuploads_by_checksum %llu\nlast_decline %s\n",
             (unsigned long long)G.n_pictures, (unsigned long long)G.n_declined, (unsigned long long)G.n_sb, (unsigned long long)G.n_uploads,
             (unsigned long long)G.n_reuploads, G.why[0] ? G.why : "-");
     fprintf(o, "tf_pairs_offloaded %llu\ntf_sb_results %llu\ntf_pairs_declined %llu\n", (unsigned long long)tf_pairs, (unsigned long long)tf_sb, (unsigned long long)tf_declined);
     for (int k = 0; k < svt_hip_seam_device_count() && svt_hip_seam_device_count() > 1; k++)
         fprintf(o, "stage_calls_on_device_%d %llu\n", svt_hip_seam_device_id(k), (unsigned long long)G.n_per_dev[k]);
-    fprintf(o, "ms_in_stage_calls %llu\nms_hashing_planes %llu\nms_first_stage_call %llu\nms_holding_device_lock %llu\n", (unsigned long long)(G.t_stage * 1e3),
-            (unsigned long long)(G.t_hash * 1e3), (unsigned long long)(G.t_first * 1e3), (unsigned long long)(G.t_dev_lock * 1e3));
+    fprintf(o, "planes_invalidated_after_temporal_filtering %llu\n", (unsigned long long)n_invalidated);
+    fprintf(o, "ms_in_stage_calls %llu\nms_first_stage_call %llu\nms_holding_device_lock %llu\n", (unsigned long long)(G.t_stage * 1e3),
+            (unsigned long long)(G.t_first * 1e3), (unsigned long long)(G.t_dev_lock * 1e3));
+    if (seam_hash > 0) fprintf(o, "ms_hashing_planes %llu\n", (unsigned long long)(G.t_hash * 1e3));
     fclose(o);
 }
 static void seam_init(void) { /* once (pthread_once): ME threads arriving during the initialisation wait instead of seeing "off" */
@@ -123,7 +128,13 @@ static int seam_on(void) {
 
 static double seam_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static uint64_t plane_sum_(const EbPictureBufferDesc *p);
+/* Residency is decided by EXPLICIT invalidation: the one writer that changes a picture after it may have been uploaded is its own temporal filtering, and the
+ * temporal-filter seam reports it (svt_hip_seam_me_invalidate below, called after every produce_temporally_filtered_pic[_ld] call, offloaded or not).  The sampled
+ * checksum of round 3 (every 8th row: right only with high probability, 7 ms of hashing per 60 frames) remains as a debugging aid: SVT_HIP_ME_SEAM_HASH=1 compares
+ * on top and counts what the explicit rule missed (`plane_reuploads_by_checksum`, expected 0). */
 static uint64_t plane_sum(const EbPictureBufferDesc *p) { /* called OUTSIDE the locks */
+    if (seam_hash < 0) { const char *e = getenv("SVT_HIP_ME_SEAM_HASH"); seam_hash = e && atoi(e); }
+    if (!seam_hash) return 2; /* (constant: the comparison with the stored value never asks for an upload) */
     const double   t0 = seam_now();
     const uint64_t h  = plane_sum_(p);
     const double   dt = seam_now() - t0;
@@ -144,6 +155,22 @@ static uint64_t plane_sum_(const EbPictureBufferDesc *p) {
         h = (h ^ a) * 1099511628211ull;
     }
     return h;
+}
+/* the device-side identity of a picture's luma planes: an overlay picture carries the picture number of the alt-ref it overlays (and names that alt-ref as its own
+ * reference, pd_process.c:4163) with different samples -- the unfiltered source -- so it gets an id of its own */
+#define SEAM_ID(pcs) ((uint64_t)(pcs)->picture_number * 2 + ((pcs)->is_overlay ? 1 : 0))
+/* the picture's host planes were rewritten (temporal filtering): whatever copy a device holds is stale */
+void svt_hip_seam_me_invalidate(unsigned long long picture_number) {
+    if (G.mode != 1) return; /* (not seam_on(): a temporal filter that runs before any ME call has nothing resident to invalidate) */
+    for (int di = 0; di < SEAM_DEVS; di++) {
+        if (!__atomic_load_n(&G.session[di], __ATOMIC_ACQUIRE)) continue;
+        pthread_mutex_lock(&G.dev[di]);
+        if (G.session[di] && abi.resident(G.session[di], (int64_t)(picture_number * 2))) {
+            abi.invalidate(G.session[di], (int64_t)(picture_number * 2));
+            n_invalidated++;
+        }
+        pthread_mutex_unlock(&G.dev[di]);
+    }
 }
 static int sum_slot(int di, uint64_t id, int make) {
     int free_i = -1;
@@ -234,7 +261,7 @@ static int fill_stage(PictureParentControlSet *pcs, MeContext *c, SvtHipMeStageP
                                                        : ((EbPaReferenceObject *)pcs->ref_pa_pic_ptr_array[li][ri]->object_ptr)->picture_number;
             const EbPictureBufferDesc *ref_padded = tf ? c->me_ds_ref_array[li][ri].picture_ptr
                                                        : ((EbPaReferenceObject *)pcs->ref_pa_pic_ptr_array[li][ri]->object_ptr)->input_padded_pic;
-            ref_ids[k] = (int64_t)ref_number; ref_pics[k] = ref_padded;
+            ref_ids[k] = (int64_t)(ref_number * 2); ref_pics[k] = ref_padded; /* (references are never overlay pictures: SEAM_ID below) */
             const int64_t  d64  = (int64_t)pcs->picture_number - (int64_t)ref_number;
             const uint16_t dist = (uint16_t)(int16_t)(d64 < 0 ? -d64 : d64), f = (uint16_t)((dist * 5) / 8 + ((dist % 8) ? 1 : 0));
             S->dist[k] = tf ? dist : f; S->ref_pic_index[k] = (uint8_t)ri; /* (ME_MCTF: the integer search takes the distance unscaled, :1300-1302) */
@@ -382,11 +409,11 @@ static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *
     }
     if (!rc) {
         /* the source: (re)uploaded when its content differs from what is resident (the same picture may have served as a reference before its own ME) */
-        const int ks = sum_slot(di, pcs->picture_number, 1);
-        if (abi.resident(ses, (int64_t)pcs->picture_number) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)pcs->picture_number); G.n_reuploads++; }
-        if (!abi.resident(ses, (int64_t)pcs->picture_number)) G.n_uploads++;
+        const int ks = sum_slot(di, SEAM_ID(pcs), 1);
+        if (abi.resident(ses, (int64_t)SEAM_ID(pcs)) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)SEAM_ID(pcs)); G.n_reuploads++; }
+        if (!abi.resident(ses, (int64_t)SEAM_ID(pcs))) G.n_uploads++;
         G.sum[di][ks][1] = now;
-        slot = abi.submit_stage(ses, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, n_refs, &S, &H);
+        slot = abi.submit_stage(ses, (int64_t)SEAM_ID(pcs), src->buffer_y, ref_ids, n_refs, &S, &H);
         if (slot < 0) {
             char why[64];
             snprintf(why, sizeof(why), "svt_hip_me_session_submit_stage returned %d", slot);
@@ -401,7 +428,7 @@ static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *
     return 0;
 }
 
-static EbErrorType seam_motion_estimation_b64(PictureParentControlSet *pcs, uint32_t b64_index, uint32_t b64_origin_x, uint32_t b64_origin_y,
+static EbErrorType seam_motion_estimation_b64_body(PictureParentControlSet *pcs, uint32_t b64_index, uint32_t b64_origin_x, uint32_t b64_origin_y,
                                               MeContext *me_ctx, EbPictureBufferDesc *input_ptr) {
     if (!seam_on() || me_ctx->me_type != ME_OPEN_LOOP)
         return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_ptr);
@@ -479,6 +506,13 @@ static EbErrorType seam_motion_estimation_b64(PictureParentControlSet *pcs, uint
     if (declined) return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_ptr);
     return EB_ErrorNone;
 }
+static EbErrorType seam_motion_estimation_b64(PictureParentControlSet *pcs, uint32_t b64_index, uint32_t b64_origin_x, uint32_t b64_origin_y, MeContext *me_ctx, EbPictureBufferDesc *input_ptr) {
+    SEAM_CPU_BEGIN();
+    const EbErrorType r_ = seam_motion_estimation_b64_body(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_ptr);
+    SEAM_CPU_END(SEAM_CPU_ME);
+    return r_;
+}
+
 
 
 /* ---- the temporal filter's ME (temporal_filtering.c:3180: svt_aom_motion_estimation_b64 with me_type == ME_MCTF, one reference per call) ---------------------------
@@ -533,11 +567,11 @@ static int run_tf_pair(SeamTfPair *T, PictureParentControlSet *pcs, MeContext *c
         else if (pass == 3) rc = decline("ring too small for the reference set");
     }
     if (!rc) {
-        const int ks = sum_slot(di, pcs->picture_number, 1);
-        if (abi.resident(ses, (int64_t)pcs->picture_number) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)pcs->picture_number); G.n_reuploads++; }
-        if (!abi.resident(ses, (int64_t)pcs->picture_number)) G.n_uploads++;
+        const int ks = sum_slot(di, SEAM_ID(pcs), 1);
+        if (abi.resident(ses, (int64_t)SEAM_ID(pcs)) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)SEAM_ID(pcs)); G.n_reuploads++; }
+        if (!abi.resident(ses, (int64_t)SEAM_ID(pcs))) G.n_uploads++;
         G.sum[di][ks][1] = now;
-        slot = abi.submit_stage(ses, (int64_t)pcs->picture_number, src->buffer_y, ref_ids, 1, &S, &H);
+        slot = abi.submit_stage(ses, (int64_t)SEAM_ID(pcs), src->buffer_y, ref_ids, 1, &S, &H);
         if (slot < 0) rc = decline("svt_hip_me_session_submit_stage (ME_MCTF form) refused the parameters");
     }
     G.n_per_dev[di]++;

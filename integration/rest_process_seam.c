@@ -13,6 +13,7 @@
  * frame filtering that follow are untouched reference code.  SVT_HIP_LR_SEAM_STATS=<file> receives the counters at exit.
  */
 #define _GNU_SOURCE /* RTLD_DEFAULT */
+#include "../integration/seam_cpu.h"
 #include <dlfcn.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -143,7 +144,7 @@ static void search_plane(const Yv12BufferConfig *org_fts, const Yv12BufferConfig
     free(prev); free(out);
 }
 
-static void seam_restoration_seg_search(int32_t *rst_tmpbuf, Yv12BufferConfig *org_fts, const Yv12BufferConfig *src, Yv12BufferConfig *trial_frame_rst,
+static void seam_restoration_seg_search_body(int32_t *rst_tmpbuf, Yv12BufferConfig *org_fts, const Yv12BufferConfig *src, Yv12BufferConfig *trial_frame_rst,
                                         PictureControlSet *pcs, uint32_t segment_index) {
     if (!lr_seam_on()) { restoration_seg_search(rst_tmpbuf, org_fts, src, trial_frame_rst, pcs, segment_index); return; }
     pthread_mutex_lock(&L.lock); /* (one picture at a time; the other segments of this picture wait here and then find it done) */
@@ -165,11 +166,17 @@ static void seam_restoration_seg_search(int32_t *rst_tmpbuf, Yv12BufferConfig *o
     if (++L.seen[slot] == pcs->rest_segments_total_count) L.done_pcs[slot] = NULL; /* every segment has passed */
     pthread_mutex_unlock(&L.lock);
 }
+static void seam_restoration_seg_search(int32_t *rst_tmpbuf, Yv12BufferConfig *org_fts, const Yv12BufferConfig *src, Yv12BufferConfig *trial_frame_rst, PictureControlSet *pcs, uint32_t segment_index) {
+    SEAM_CPU_BEGIN();
+    seam_restoration_seg_search_body(rst_tmpbuf, org_fts, src, trial_frame_rst, pcs, segment_index);
+    SEAM_CPU_END(SEAM_CPU_LR);
+}
+
 
 /* svt_av1_loop_restoration_filter_frame (restoration.c:1179-1247) with the unit loop of every restored plane as one device launch: the same border
  * extension, the units of rst_info[plane].unit_info, the saved deblocked boundary lines of rsi->boundaries; the filtered plane replaces the frame's plane
  * (the reference filters into cm->rst_frame and copies it back, :1241). */
-static void seam_loop_restoration_filter_frame(int32_t *rst_tmpbuf, Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr) {
+static void seam_loop_restoration_filter_frame_body(int32_t *rst_tmpbuf, Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr) {
     if (!lr_seam_on() || optimized_lr) { svt_av1_loop_restoration_filter_frame(rst_tmpbuf, frame, cm, optimized_lr); return; }
     const int32_t highbd = cm->use_highbitdepth;
     for (int32_t plane = 0; plane < 3; ++plane) {
@@ -207,6 +214,12 @@ static void seam_loop_restoration_filter_frame(int32_t *rst_tmpbuf, Yv12BufferCo
         pthread_mutex_unlock(&L.lock);
     }
 }
+static void seam_loop_restoration_filter_frame(int32_t *rst_tmpbuf, Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr) {
+    SEAM_CPU_BEGIN();
+    seam_loop_restoration_filter_frame_body(rst_tmpbuf, frame, cm, optimized_lr);
+    SEAM_CPU_END(SEAM_CPU_LR);
+}
+
 
 #define restoration_seg_search(a, b, c, d, e, f) seam_restoration_seg_search(a, b, c, d, e, f)
 #define svt_av1_loop_restoration_filter_frame(a, b, c, d) seam_loop_restoration_filter_frame(a, b, c, d)

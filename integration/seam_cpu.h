@@ -1,0 +1,20 @@
+/* seam_cpu.h -- REFERENCE-SIDE MEASUREMENT AID (integration/): host CPU time per pipeline stage.
+ *
+ * With SVT_HIP_SEAM_CPU_STATS=<file> every stage entry the seams wrap -- the reference's own function when the seam is off, the device stage call when it is on --
+ * is bracketed with the calling thread's CPU clock (CLOCK_THREAD_CPUTIME_ID: user + system time of that thread only, spinning included) and the sums are written at
+ * exit: `<stage>_cpu_ms N` and `<stage>_calls N` for me, tf, tpl, dlf, cdef, lr.  This is the accounting VERDICT r3 asks for: what each stage of SURVEY 8 costs the
+ * HOST with the reference's own kernels (the AVX2 / AVX-512 builds, no seam) and what it costs with the stage on the MI355X.  Unset: one predictable branch per call. */
+#ifndef SVT_HIP_SEAM_CPU_H
+#define SVT_HIP_SEAM_CPU_H
+#include <time.h>
+enum { SEAM_CPU_ME, SEAM_CPU_TF, SEAM_CPU_TPL, SEAM_CPU_DLF, SEAM_CPU_CDEF, SEAM_CPU_LR, SEAM_CPU_STAGES };
+int  svt_hip_seam_cpu_on(void);                              /* integration/enc_handle_binding.c */
+void svt_hip_seam_cpu_add(int stage, unsigned long long ns);
+static inline unsigned long long seam_cpu_ns(void) {
+    struct timespec t_;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t_);
+    return (unsigned long long)t_.tv_sec * 1000000000ull + (unsigned long long)t_.tv_nsec;
+}
+#define SEAM_CPU_BEGIN() const int seam_cpu_on_ = svt_hip_seam_cpu_on(); const unsigned long long seam_cpu_t0_ = seam_cpu_on_ ? seam_cpu_ns() : 0
+#define SEAM_CPU_END(stage) do { if (seam_cpu_on_) svt_hip_seam_cpu_add(stage, seam_cpu_ns() - seam_cpu_t0_); } while (0)
+#endif

@@ -20,6 +20,7 @@
  * full-pel, no rate, no QPS) run the reference unchanged.  SVT_HIP_TPL_SEAM_STATS=<file> receives the counters at exit.
  */
 #define _GNU_SOURCE /* RTLD_DEFAULT */
+#include "../integration/seam_cpu.h"
 #include <dlfcn.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -201,7 +202,7 @@ static void tpl_written_cells(const PictureParentControlSet *pcs, uint8_t level,
     }
 }
 
-static void tpl_mc_flow_dispenser_use2(TPL_DISP_ARGS) {
+static void tpl_mc_flow_dispenser_use2_body(TPL_DISP_ARGS) {
     if (!tpl_seam_on() || (pcs->tpl_src_data_ready && !TS.recon) || !tpl_seam_covers(scs, pcs)) {
         if (TS.mode) {
             pthread_mutex_lock(&TS.lock);
@@ -308,3 +309,9 @@ static void tpl_mc_flow_dispenser_use2(TPL_DISP_ARGS) {
     else { TS.n_pictures++; TS.n_blocks += nb; TS.n_newmv += nn; TS.ms_stage += t1 - t0; }
     pthread_mutex_unlock(&TS.lock);
 }
+static void tpl_mc_flow_dispenser_use2(TPL_DISP_ARGS) {
+    SEAM_CPU_BEGIN();
+    tpl_mc_flow_dispenser_use2_body(TPL_DISP_PASS);
+    SEAM_CPU_END(SEAM_CPU_TPL);
+}
+

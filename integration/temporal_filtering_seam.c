@@ -28,6 +28,7 @@
  *    every segment runs the reference's function as before.
  */
 #define _GNU_SOURCE /* RTLD_DEFAULT */
+#include "../integration/seam_cpu.h"
 #include <dlfcn.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -452,5 +453,20 @@ static EbErrorType seam_tf_picture(TF_PIC_ARGS, int low_delay) {
     return declined ? TF_REFERENCE_FORM() : EB_ErrorNone;
 #undef TF_REFERENCE_FORM
 }
-static EbErrorType seam_produce_temporally_filtered_pic(TF_PIC_ARGS) { return seam_tf_picture(TF_PIC_PASS, 0); }
-static EbErrorType seam_produce_temporally_filtered_pic_ld(TF_PIC_ARGS) { return seam_tf_picture(TF_PIC_PASS, 1); }
+/* Every call rewrites (its segment of) the central picture in place, on the device or by the reference's own code: the copy the ME stage may hold of it is stale
+ * from here on (integration/me_process_seam.c decides residency by this notice, not by content) */
+void svt_hip_seam_me_invalidate(unsigned long long picture_number);
+static EbErrorType seam_produce_temporally_filtered_pic(TF_PIC_ARGS) {
+    SEAM_CPU_BEGIN();
+    const EbErrorType e = seam_tf_picture(TF_PIC_PASS, 0);
+    svt_hip_seam_me_invalidate(pcs_list[index_center]->picture_number);
+    SEAM_CPU_END(SEAM_CPU_TF);
+    return e;
+}
+static EbErrorType seam_produce_temporally_filtered_pic_ld(TF_PIC_ARGS) {
+    SEAM_CPU_BEGIN();
+    const EbErrorType e = seam_tf_picture(TF_PIC_PASS, 1);
+    svt_hip_seam_me_invalidate(pcs_list[index_center]->picture_number);
+    SEAM_CPU_END(SEAM_CPU_TF);
+    return e;
+}

@@ -75,6 +75,28 @@ HostCallLease::~HostCallLease() {
     g_lease_pool[device].push_back(c); // (most recently used first: the arena that has already grown is the one that is taken again)
 }
 
+// Four zeroed device words for ONE launch sequence on `st` (tickets / counters of a kernel that orders its own workgroups): slots of a per-device ring, cleared in
+// stream order.  A slot is taken again after RING later requests -- far more than launch sequences are ever in flight on one device.
+uint32_t* stream_scratch_u32x4(hipStream_t st) {
+    constexpr uint32_t RING = 4096;
+    static std::mutex            m;
+    static uint32_t*             ring[MAX_DEVICES] = {};
+    static std::atomic<uint32_t> next[MAX_DEVICES];
+    ensure_device();
+    const int d = current_device();
+    if (!ring[d]) {
+        std::lock_guard<std::mutex> g(m);
+        if (!ring[d]) {
+            uint32_t* p = nullptr;
+            HIP_CHECK(hipMalloc((void**)&p, (size_t)RING * 16));
+            ring[d] = p;
+        }
+    }
+    uint32_t* p = ring[d] + 4 * (next[d].fetch_add(1) % RING);
+    HIP_CHECK(hipMemsetAsync(p, 0, 16, st));
+    return p;
+}
+
 void HostCall::begin() {
     dev_used = 0;
     pin_used = 0;

@@ -84,6 +84,7 @@ struct HostCall {
     void sync();
 };
 HostCall& host_call();
+uint32_t* stream_scratch_u32x4(hipStream_t st); // four zeroed device words for one launch sequence on `st` (runtime.hip)
 // The stage-sized host forms (a whole picture's planes per call: svt_hip_tf_picture_host, svt_hip_tpl_src_stage_host, the CDEF / LR / deblocking / sub-pel host forms)
 // do not use the calling thread's own arena: an encoder calls them from dozens of worker threads, and every thread growing a private 20-50 MB pinned + device arena
 // on its first call costs 10-20 ms each (pinned allocation).  They lease an arena from a per-device pool for the duration of the call instead -- as many arenas as

@@ -240,7 +240,15 @@ def encode(clip, w, h, n, bd, extra, out_prefix, env_extra=None, timeout=1800, e
     return r, dt
 
 
-def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, host="c"):
+def _stage_cpu(path, n):
+    """integration/seam_cpu.h's per-stage thread-CPU sums of one encode -> {stage: ms per frame}"""
+    if not os.path.exists(path):
+        return None
+    st = dict(ln.split() for ln in open(path).read().splitlines() if ln.strip())
+    return {k[:-7]: round(int(v) / n, 3) for k, v in st.items() if k.endswith("_cpu_ms")}
+
+
+def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, host="c", cpu_stats=False):
     """host = "c": the C-only encoder with and without the HIP library (the identity anchor).  host = "avx2": additionally the intrinsics encoder without anything
     (`fps_avx2`, bitstream must equal the C-only one) and the HIP run uses THAT encoder (`fps_hip` = AVX2 host kernels + device stages)."""
     w, h, n, bd, extra = CASES[name]
@@ -251,7 +259,8 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     seam, with_hook, lrseam, cdefseam, dlfseam = "+seam" in extra, "+hook" in extra, "+lrseam" in extra, "+cdefseam" in extra, "+dlfseam" in extra
     tplseam = "+tplseam" in extra
     extra = [a for a in extra if not a.startswith("+")]
-    rc, tc = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_c"), timeout=timeout)
+    cpu_env = (lambda tag: {"SVT_HIP_SEAM_CPU_STATS": os.path.join(outdir, "%s_%s_cpu.txt" % (name, tag))}) if cpu_stats else (lambda tag: {})
+    rc, tc = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_c"), cpu_env("c"), timeout=timeout)
     cpu_s = {"c": LAST_CPU_S[0]}
     deterministic = True
     if "--lp" not in extra or extra[extra.index("--lp") + 1] != "1":  # multi-threaded: is the C-only reference reproducible at all for this configuration?
@@ -297,14 +306,17 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
         env["SVT_HIP_SKIP"] = skip
     rx = None
     if host != "c":
-        rx, tx = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_x"), timeout=timeout, enc=HOST_ENC[host])
+        rx, tx = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_x"), cpu_env(host), timeout=timeout, enc=HOST_ENC[host])
         cpu_s[host] = LAST_CPU_S[0]
+    env.update(cpu_env(host + "_with_stages"))
     rh, th = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_hip"), env, timeout=timeout, enc=HOST_ENC[host])
     cpu_s[host + "_with_stages"] = LAST_CPU_S[0]
     res = {"case": name, "host": host, "width": w, "height": h, "frames": n, "bit_depth": bd, "args": extra, "rc_c": rc.returncode, "rc_hip": rh.returncode,
            "seconds_c": round(tc, 2), "seconds_hip": round(th, 2), "reference_deterministic": deterministic,
            # host CPU seconds (user + system, every thread) per frame: what the offload takes off the host
            "host_cpu_s_per_frame": {k: round(v / n, 5) for k, v in cpu_s.items()}}
+    if cpu_stats:  # thread CPU time inside each stage of SURVEY 8 (the reference's own functions without the seams, the device stage calls with them)
+        res["stage_cpu_ms_per_frame"] = {tag: _stage_cpu(os.path.join(outdir, "%s_%s_cpu.txt" % (name, tag)), n) for tag in cpu_s}
     for tag, r in (("c", rc), ("hip", rh)) + (((host, rx),) if rx is not None else ()):  # the encoder's own speed line
         for ln in (r.stdout + r.stderr).splitlines():
             if "Average Speed" in ln:
