@@ -399,16 +399,17 @@ def encoder_fps():
         return None
     with tempfile.TemporaryDirectory() as td:
         have_x = os.path.exists(ei.ENC_AVX2)
-        r = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="avx2" if have_x else "c")
-        rc_ = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="c") if have_x else r  # the round-1/2 figure: C-only host + stages, for continuity
-        r300 = ei.run_case("fps_1080p_p8_all_300", lib, td, timeout=600, host="avx2") if have_x else {}  # steady state: the clip looped five times
+        CASE = "fps_1080p_p8_all_tplrecon"  # every stage seam, the TPL dispenser's reconstruction half included (round 4: one launch per picture)
+        r = ei.run_case(CASE, lib, td, timeout=600, host="avx2" if have_x else "c")
+        rc_ = ei.run_case(CASE, lib, td, timeout=600, host="c") if have_x else r  # the round-1/2 figure: C-only host + stages, for continuity
+        r300 = ei.run_case(CASE + "_300", lib, td, timeout=600, host="avx2") if have_x else {}  # steady state: the clip looped five times
         # the AVX-512 build of the reference (EN_AVX512_SUPPORT=1 + ASM_AVX512) where the host has AVX-512: alone and with the stages
         have_512 = os.path.exists(ei.ENC_AVX512) and cpu_has(*AVX512)
-        r512 = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="avx512") if have_512 else {}
+        r512 = ei.run_case(CASE, lib, td, timeout=600, host="avx512") if have_512 else {}
         # K concurrent encodes sharing this GPU on the box's host cores: aggregate fps and host CPU seconds per frame, AVX2 host alone vs with the stages
-        inst = ei.run_instances("fps_1080p_p8_all", lib, td, 4, host="avx2", timeout=600) if have_x else {}
+        inst = ei.run_instances(CASE, lib, td, 4, host="avx2", timeout=600) if have_x else {}
         # thread CPU time per stage (integration/seam_cpu.h), a run of its own: the brackets cost two clock reads per SB in the ME stage
-        rcpu = ei.run_case("fps_1080p_p8_all", lib, td, timeout=600, host="avx2", cpu_stats=True) if have_x else {}
+        rcpu = ei.run_case(CASE, lib, td, timeout=600, host="avx2", cpu_stats=True) if have_x else {}
     if not r.get("identical") or not rc_.get("identical") or (r300 and not r300.get("identical")) or (r512 and not r512.get("identical")) or (inst and not inst.get("identical")):
         sys.exit("bench.py: the encoder's bitstream with the stage seams differs from the C-only encoder -- no numbers recorded (%s)" % r.get("stderr_tail", ""))
     return {"fps_c_only": r.get("fps_c"), "fps_avx2_intrinsics": r.get("fps_avx2"), "fps_avx2_host_with_stage_seams": r.get("fps_hip") if have_x else None,
@@ -419,6 +420,8 @@ def encoder_fps():
             # user + system CPU seconds of the whole encoder process per frame (RUSAGE_CHILDREN): what the offload takes off the host
             "host_cpu_s_per_frame": dict(r.get("host_cpu_s_per_frame") or {}, **{k: v for k, v in (r512.get("host_cpu_s_per_frame") or {}).items() if k != "c"}),
             "instances": {"k": inst.get("instances"), "fps_avx2": inst.get("fps_avx2"), "fps_avx2_with_stages": inst.get("fps_avx2_with_stages"),
+                          "fps_sum_of_encoder_reports_avx2": inst.get("fps_sum_of_encoder_reports_avx2"),
+                          "fps_sum_of_encoder_reports_avx2_with_stages": inst.get("fps_sum_of_encoder_reports_avx2_with_stages"),
                           "cpu_s_per_frame_avx2": inst.get("host_cpu_s_per_frame_avx2"), "cpu_s_per_frame_avx2_with_stages": inst.get("host_cpu_s_per_frame_avx2_with_stages"),
                           "identical": inst.get("identical")} if inst else None,
             "stage_cpu_ms_per_frame": rcpu.get("stage_cpu_ms_per_frame"), "host_cpu_s_per_frame_in_that_run": rcpu.get("host_cpu_s_per_frame"),
@@ -429,7 +432,7 @@ def encoder_fps():
             "host_ms_in_stage_calls": {k: (r.get(v) or {}).get("ms_in_stage_calls") for k, v in (("me", "seam"), ("tf_picture", "tfdriver"), ("tpl", "tplseam"), ("dlf", "dlfseam"),
                                                                                                    ("cdef", "cdefseam"), ("lr", "lrseam"))},
             "config": "1080p 8-bit, preset 8, CRF 35, all host threads; the reference encoder built (a) C-only and (b) with its SSE2..AVX2 intrinsic kernels (177 NASM kernels "
-                      "stay at their C versions: no nasm here); the stage seams (ME, the temporal filter as one stage per central picture, TPL source half, deblocking, CDEF, LR) on the MI355X",
+                      "stay at their C versions: no nasm here); the stage seams (ME, the temporal filter as one stage per central picture, both halves of the TPL dispenser, deblocking, CDEF, LR) on the MI355X",
             "stages_on_gpu": {"me": r.get("seam"), "tf_subpel": r.get("tfsubpel"), "tf_picture": r.get("tfdriver"), "tpl": r.get("tplseam"), "dlf": r.get("dlfseam"), "cdef": r.get("cdefseam"),
                               "lr": r.get("lrseam")}}
 

@@ -432,8 +432,21 @@ static EbErrorType seam_motion_estimation_b64_body(PictureParentControlSet *pcs,
                                               MeContext *me_ctx, EbPictureBufferDesc *input_ptr) {
     if (!seam_on() || me_ctx->me_type != ME_OPEN_LOOP)
         return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_ptr);
-    pthread_mutex_lock(&G.lock);
+    static int verify = -1; /* SVT_HIP_ME_SEAM_VERIFY=1: run the reference's function for the SB as well and report the first difference (diagnostic) */
+    if (verify < 0) verify = getenv("SVT_HIP_ME_SEAM_VERIFY") != NULL;
+    /* The common case -- the picture's stage has run, this SB only fetches its slice -- takes NO lock: 510 SBs x every picture x dozens of ME threads on one mutex
+     * cost more host CPU per SB (14 us) than the reference's AVX2 search of the SB (10 us; profiles/r04_call2_*).  A record in state 2 / 3 is immutable until its
+     * last SB has fetched (consumed == n_sb), and every SB of the picture comes here exactly once, so a reader that found it cannot lose it. */
     SeamPicture *P = NULL, *spare = NULL;
+    for (int i = 0; i < SEAM_RECS && !verify; i++) {
+        if (__atomic_load_n(&G.rec[i].state, __ATOMIC_ACQUIRE) >= 2 && G.rec[i].pcs == pcs && G.rec[i].picture_number == pcs->picture_number &&
+            __atomic_load_n(&G.rec[i].state, __ATOMIC_ACQUIRE) >= 2) { /* (still ready after the comparison: the slot was not freed and claimed anew meanwhile) */
+            P = &G.rec[i];
+            break;
+        }
+    }
+    if (P) goto fetch;
+    pthread_mutex_lock(&G.lock);
     for (int i = 0; i < SEAM_RECS; i++) {
         if (G.rec[i].state && G.rec[i].pcs == pcs && G.rec[i].picture_number == pcs->picture_number) { P = &G.rec[i]; break; }
         if (!G.rec[i].state && !spare) spare = &G.rec[i];
@@ -441,7 +454,8 @@ static EbErrorType seam_motion_estimation_b64_body(PictureParentControlSet *pcs,
     if (!P) { /* first SB of this picture: compute everything now */
         if (!spare) { fprintf(stderr, "SVT_HIP_ME_SEAM: more than %d pictures in flight\n", SEAM_RECS); abort(); }
         P = spare;
-        P->pcs = pcs; P->picture_number = pcs->picture_number; P->consumed = 0; P->state = 1;
+        P->pcs = pcs; P->picture_number = pcs->picture_number; P->consumed = 0;
+        __atomic_store_n(&P->state, 1, __ATOMIC_RELEASE);
         EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
         pthread_mutex_unlock(&G.lock); /* the record is ours (state 1); the other SBs of this picture wait on the condition, other pictures proceed */
         const double t0 = seam_now();
@@ -450,15 +464,15 @@ static EbErrorType seam_motion_estimation_b64_body(PictureParentControlSet *pcs,
         pthread_mutex_lock(&G.lock);
         G.t_stage += dt;
         if (G.n_pictures + G.n_declined + tf_pairs + tf_declined == 0) G.t_first = dt;
-        if (rc) { P->state = 3; P->n_sb = pcs->b64_total_count; G.n_declined++; }
-        else    { P->state = 2; G.n_pictures++; }
+        if (rc) { P->n_sb = pcs->b64_total_count; G.n_declined++; __atomic_store_n(&P->state, 3, __ATOMIC_RELEASE); }
+        else    { G.n_pictures++; __atomic_store_n(&P->state, 2, __ATOMIC_RELEASE); }
         pthread_cond_broadcast(&G.ready);
     }
     while (P->state == 1) pthread_cond_wait(&G.ready, &G.lock);
-    const int declined = P->state == 3;
-    static int verify = -1; /* SVT_HIP_ME_SEAM_VERIFY=1: run the reference's function for the SB as well and report the first difference (diagnostic) */
-    if (verify < 0) verify = getenv("SVT_HIP_ME_SEAM_VERIFY") != NULL;
-    if (!declined && verify) {
+    if (!verify) pthread_mutex_unlock(&G.lock);
+fetch:;
+    const int declined = __atomic_load_n(&P->state, __ATOMIC_ACQUIRE) == 3;
+    if (!declined && verify) { /* (diagnostic mode: the lock is still held) */
         pthread_mutex_unlock(&G.lock);
         svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_ptr);
         pthread_mutex_lock(&G.lock);
@@ -499,10 +513,11 @@ static EbErrorType seam_motion_estimation_b64_body(PictureParentControlSet *pcs,
         pcs->me_16x16_distortion[b64_index] = st->me_16x16_distortion; pcs->me_8x8_distortion[b64_index] = st->me_8x8_distortion;
         pcs->me_8x8_cost_variance[b64_index] = st->me_8x8_cost_variance; pcs->rc_me_distortion[b64_index] = st->rc_me_distortion;
         pcs->stationary_block_present_sb[b64_index] = st->stationary_block_present_sb; pcs->rc_me_allow_gm[b64_index] = st->rc_me_allow_gm;
-        G.n_sb++;
+        __atomic_fetch_add(&G.n_sb, 1, __ATOMIC_RELAXED);
     }
-    if (++P->consumed == P->n_sb) P->state = 0; /* every SB has fetched its slice: the record is free again */
-    pthread_mutex_unlock(&G.lock);
+    const uint32_t n_sb_rec = P->n_sb; /* (read before the count: the record may be claimed anew the moment the last SB has fetched) */
+    if (__atomic_add_fetch(&P->consumed, 1, __ATOMIC_ACQ_REL) == n_sb_rec) __atomic_store_n(&P->state, 0, __ATOMIC_RELEASE); /* every SB has fetched its slice: free again */
+    if (verify) pthread_mutex_unlock(&G.lock);
     if (declined) return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_ptr);
     return EB_ErrorNone;
 }

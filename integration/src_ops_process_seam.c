@@ -42,8 +42,9 @@ static void tpl_mc_flow_dispenser_use2(TPL_DISP_ARGS); /* the picture seam */
 #define TPL_SB_PASS enc_ctx, scs, pcs, frame_idx, sb_index, qIndex, dispenser_search_level
 static void tpl_mc_flow_dispenser_sb_generic_use0(TPL_SB_ARGS); /* the reference's per-SB function (defined by the #include) */
 static void seam_tpl_sb(TPL_SB_ARGS);
-static void tpl_mc_flow_dispenser_sb_generic_use3(TPL_SB_ARGS) { seam_tpl_sb(TPL_SB_PASS); }
-static void tpl_mc_flow_dispenser_sb_generic_use4(TPL_SB_ARGS) { seam_tpl_sb(TPL_SB_PASS); }
+/* (the per-SB calls run on the TPL dispenser threads: they are where the reference spends the stage's CPU time, so they carry the accounting of seam_cpu.h) */
+static void tpl_mc_flow_dispenser_sb_generic_use3(TPL_SB_ARGS) { SEAM_CPU_BEGIN(); seam_tpl_sb(TPL_SB_PASS); SEAM_CPU_END(SEAM_CPU_TPL); }
+static void tpl_mc_flow_dispenser_sb_generic_use4(TPL_SB_ARGS) { SEAM_CPU_BEGIN(); seam_tpl_sb(TPL_SB_PASS); SEAM_CPU_END(SEAM_CPU_TPL); }
 
 #define SEAM_CAT_(a, b) a##b
 #define SEAM_CAT(a, b) SEAM_CAT_(a, b)

@@ -298,6 +298,13 @@ int svt_hip_init(int device) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -1;
     if (device < 0 || device >= n || device >= svthip::MAX_DEVICES) return -1;
     if (hipSetDevice(device) != hipSuccess) return -1;
+    // SVT_HIP_SYNC=block: host threads SLEEP while they wait for the device (hipDeviceScheduleBlockingSync) instead of spinning on the completion signal, the
+    // runtime's default.  A stage call of an encoder seam is one synchronous round trip; on a host whose cores are all busy with the encoder's own threads the
+    // spinning costs CPU time another worker could use (environment table; profiles/r04_*: host CPU seconds per frame).
+    const char* sync_env = getenv("SVT_HIP_SYNC");
+    if (sync_env && sync_env[0] == 'b') {
+        if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError(); // (refused once the context is active: keep the default)
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
     snprintf(g_name, sizeof(g_name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);

@@ -486,68 +486,60 @@ __global__ void tpl_recon_rows_reset_kernel(SvtHipTplReconStats* __restrict__ ou
 
 // ---- the same blocks with the wavefront expressed as DATA dependencies, everything else in parallel (form 4, the default) ----------------------------------------------
 // The anti-diagonal and the row forms both serialise blocks that do not depend on each other: only a DC (intra) block reads its neighbours' reconstruction, a NEWMV
-// block reads nothing of this picture.  Here every block is in flight at once: the workgroups of ONE launch take tickets in anti-diagonal order (ticket -> diagonal u of
-// the block grid, chunk k of BPW block rows; block (u - by, by)), so that the upper and the left neighbour of any block belong to a ticket drawn EARLIER -- a waiting
-// workgroup can only wait for workgroups that are already running, whatever the residency of the grid.  Each 16x16 cell of the statistics grid carries a "reconstructed"
-// flag (SvtHipTplReconStats.reserved, cleared by tpl_recon_rows_reset_kernel): a DC block polls the flags of the cells above and left of it, everybody publishes its own
-// cells after its stores are fenced.  The dependency chains that remain are runs of adjacent intra blocks -- the critical path of an inter picture is a few blocks, not
-// cols + rows of them; an all-intra picture degenerates to the wavefront the other forms always pay.  Level 1 (32x32 blocks in complete SBs, 16x16 blocks in SBs cut by
-// the picture edge) is two launches in stream order: a 32x32 block never has a 16x16 neighbour on its left or above, so the first launch owns the cells of the complete
-// SBs and the second one finds them published.
+// block reads nothing of this picture.  Here every block is in flight at once, ONE WAVE PER BLOCK (a block waiting for its neighbours then holds up nobody else: with
+// sixteen blocks per workgroup, a third of them intra, every workgroup waited and the launch degenerated into the full wavefront -- 1.64 ms, profiles/r04_call2_*).
+// The waves of the launch take tickets in anti-diagonal order (ticket -> diagonal u of the block grid, block row by; block (u - by, by)), so that the upper and the
+// left neighbour of any block belong to a ticket drawn EARLIER: a waiting wave can only wait for waves that are already running, whatever the residency of the grid.
+// Each 16x16 cell of the statistics grid carries a "reconstructed" flag (SvtHipTplReconStats.reserved, cleared by tpl_recon_rows_reset_kernel): a DC block polls the
+// flags of the cells above and left of it, everybody publishes its own cells after its stores are fenced.  The dependency chains that remain are runs of adjacent intra
+// blocks -- the critical path of an inter picture is a few blocks, not cols + rows of them; an all-intra picture degenerates to the wavefront the other forms always
+// pay.  Level 1 (32x32 blocks in complete SBs, 16x16 blocks in SBs cut by the picture edge) is two launches in stream order: a 32x32 block never has a 16x16 neighbour
+// on its left or above, so the first launch owns the cells of the complete SBs and the second one finds them published.
 template <int SIZE, int TXH>
-__global__ __launch_bounds__(256) void tpl_recon_dep_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
-                                                            const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,
-                                                            SvtHipTplReconStats* __restrict__ out, uint32_t* __restrict__ sync, const int ticket_slot, const int cols_b,
-                                                            const int rows_b, const int nchunks, const int rel_acq) {
-    constexpr int T = SIZE, BPW = 256 / T, PITCH = SIZE + 1, PP = SIZE + 4, UNIT = SIZE / 16;
+__global__ __launch_bounds__(64) void tpl_recon_dep_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+                                                           const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,
+                                                           SvtHipTplReconStats* __restrict__ out, uint32_t* __restrict__ sync, const int ticket_slot, const int cols_b,
+                                                           const int rows_b, const int rel_acq) {
+    constexpr int PITCH = SIZE + 1, PP = SIZE + 4, UNIT = SIZE / 16, SUBS = 64 / SIZE;
     HIP_DYNAMIC_SHARED(int32_t, smem)
     __shared__ SvtHipTplRef s_refs[8];
-    __shared__ uint32_t     s_ticket, s_any;
+    __shared__ uint32_t     s_ticket;
     if (threadIdx.x < 8) s_refs[threadIdx.x] = RP.rec_refs[threadIdx.x];
-    if (threadIdx.x == 0) { s_ticket = atomicAdd(&sync[ticket_slot], 1u); s_any = 0; }
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&sync[ticket_slot], 1u);
     __syncthreads();
     const SvtHipTplSrcParams& P = RP.src;
-    const int tid = threadIdx.x, sub = tid / T, t = tid % T;
-    const int u = (int)s_ticket / nchunks, k = (int)s_ticket % nchunks;
-    const int by = k * BPW + sub, bx = u - by;
-    const bool live = by < rows_b && bx >= 0 && bx < cols_b;
-    const int  cx = bx * UNIT, cy = by * UNIT;
-    int32_t*   buf   = smem + sub * (TXH * PITCH);
-    uint8_t*   ptile = (uint8_t*)(smem + BPW * (TXH * PITCH)) + sub * (SIZE * PP);
-    const int  aligned_h = (int)((P.height + 7) & ~7u), cols16 = (int)((P.aligned_width + 15) >> 4), rows16 = (aligned_h + 15) >> 4;
-    // the cells this lane group answers for in THIS launch: the blocks of its size class, processed or not (a skipped block's neighbours must not wait for ever)
-    bool mine = live;
-    if (live) {
-        const bool complete = ((int)P.aligned_width - ((cx * 16) & ~63) >= 64) && (aligned_h - ((cy * 16) & ~63) >= 64);
-        mine = ((complete && P.dispenser_search_level) ? 32 : 16) == SIZE;
-    }
-    if (mine && t == 0) atomicOr(&s_any, 1u);
+    const int t = (int)threadIdx.x % SIZE, sub = (int)threadIdx.x / SIZE; // (lane groups 1 .. SUBS - 1 idle along on tiles of their own: the block code stores its prediction row unconditionally)
+    const int u = (int)s_ticket / rows_b, by = (int)s_ticket % rows_b, bx = u - by;
+    if (bx < 0 || bx >= cols_b) return; // (uniform) no block under this ticket
+    const int cx = bx * UNIT, cy = by * UNIT;
+    int32_t*  buf   = smem + sub * (TXH * PITCH);
+    uint8_t*  ptile = (uint8_t*)(smem + SUBS * (TXH * PITCH)) + sub * (SIZE * PP);
+    const int aligned_h = (int)((P.height + 7) & ~7u), cols16 = (int)((P.aligned_width + 15) >> 4), rows16 = (aligned_h + 15) >> 4;
+    // the cells this wave answers for in THIS launch: the blocks of its size class, processed or not (a skipped block's neighbours must not wait for ever)
+    const bool complete = ((int)P.aligned_width - ((cx * 16) & ~63) >= 64) && (aligned_h - ((cy * 16) & ~63) >= 64);
+    if (((complete && P.dispenser_search_level) ? 32 : 16) != SIZE) return; // (uniform) the other launch's block
     TplBlockIn<SIZE> B;
-    tpl_recon_fetch<SIZE>(RP, s_refs, src_base, ref_base, src_stats, cx, cy, mine, t, B);
-    __syncthreads();
-    if (!s_any) return; // (uniform: no block of this size class under this ticket)
-    if (B.active && !B.newmv && t == 0) { // a DC block: its upper and left cells must be reconstructed
-        bool timed_out = false;
-        auto wait = [&](const int ccx, const int ccy) {
-            uint32_t* flag  = &out[(size_t)ccy * cols16 + ccx].reserved;
+    tpl_recon_fetch<SIZE>(RP, s_refs, src_base, ref_base, src_stats, cx, cy, sub == 0, t, B);
+    const bool dc = __shfl((int)(B.active && !B.newmv), 0) != 0; // (lane 0 belongs to the live group)
+    if (dc) { // its upper and left cells must be reconstructed; one lane per cell polls
+        const int  n_up = cy > 0 ? (cols16 - cx < UNIT ? cols16 - cx : UNIT) : 0, n_left = cx > 0 ? (rows16 - cy < UNIT ? rows16 - cy : UNIT) : 0;
+        const int  l = (int)threadIdx.x;
+        bool       timed_out = false;
+        if (l < n_up + n_left) {
+            uint32_t* flag  = l < n_up ? &out[(size_t)(cy - 1) * cols16 + cx + l].reserved : &out[(size_t)(cy + l - n_up) * cols16 + cx - 1].reserved;
             uint32_t  polls = 0;
             while (atomicAdd(flag, 0u) == 0u && polls < TPL_WAIT_POLLS) { polls++; __builtin_amdgcn_s_sleep(1); }
-            timed_out = timed_out || polls >= TPL_WAIT_POLLS;
-        };
-        if (cy > 0)
-            for (int i = 0; i < UNIT && cx + i < cols16; i++) wait(cx + i, cy - 1);
-        if (cx > 0)
-            for (int i = 0; i < UNIT && cy + i < rows16; i++) wait(cx - 1, cy + i);
+            timed_out = polls >= TPL_WAIT_POLLS;
+        }
         if (timed_out) atomicAdd(&sync[1], 1u);
+        if (rel_acq) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        else __threadfence();
     }
-    __syncthreads();
-    if (rel_acq) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    else __threadfence();
     tpl_recon_compute<SIZE, TXH>(RP, recon_base, out, cx, cy, B, t, buf, ptile);
     if (rel_acq) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     else __threadfence();
     __syncthreads();
-    if (mine && t == 0)
+    if (threadIdx.x == 0)
         for (int j = 0; j < UNIT && cy + j < rows16; j++)
             for (int i = 0; i < UNIT && cx + i < cols16; i++) atomicExch(&out[(size_t)(cy + j) * cols16 + cx + i].reserved, 1u);
 }
@@ -557,11 +549,11 @@ __global__ void tpl_recon_dep_finish_kernel(SvtHipTplReconStats* __restrict__ ou
 template <int SIZE, int TXH>
 void launch_tpl_recon_dep(const SvtHipTplReconParams& P, const uint8_t* src, const uint8_t* ref, const SvtHipTplSrcStats* ss, uint8_t* rec, SvtHipTplReconStats* out,
                           uint32_t* sync, int ticket_slot, int cols16, int rows16, int rel_acq, hipStream_t st) {
-    constexpr int BPW = 256 / SIZE, UNIT = SIZE / 16;
-    const int     cols_b = (cols16 + UNIT - 1) / UNIT, rows_b = (rows16 + UNIT - 1) / UNIT, nchunks = (rows_b + BPW - 1) / BPW;
-    const size_t  shmem = (size_t)BPW * TXH * (SIZE + 1) * 4 + (size_t)BPW * SIZE * (SIZE + 4);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(tpl_recon_dep_kernel<SIZE, TXH>), dim3((cols_b + rows_b - 1) * nchunks), dim3(256), shmem, st, P, src, ref, ss, rec, out, sync,
-                       ticket_slot, cols_b, rows_b, nchunks, rel_acq);
+    constexpr int SUBS = 64 / SIZE, UNIT = SIZE / 16;
+    const int     cols_b = (cols16 + UNIT - 1) / UNIT, rows_b = (rows16 + UNIT - 1) / UNIT;
+    const size_t  shmem = (size_t)SUBS * TXH * (SIZE + 1) * 4 + (size_t)SUBS * SIZE * (SIZE + 4);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tpl_recon_dep_kernel<SIZE, TXH>), dim3((cols_b + rows_b - 1) * rows_b), dim3(64), shmem, st, P, src, ref, ss, rec, out, sync,
+                       ticket_slot, cols_b, rows_b, rel_acq);
     SVT_LAUNCH_CHECK();
 }
 

@@ -519,7 +519,8 @@ inline hipError_t hipFree(void* p) {
 }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = aligned_alloc(256, (n + 255) & ~size_t(255)); return *p ? hipSuccess : 2; }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
-enum { hipHostRegisterPortable = 1, hipMemoryTypeHost = 1 };
+enum { hipHostRegisterPortable = 1, hipMemoryTypeHost = 1, hipDeviceScheduleBlockingSync = 4 };
+inline hipError_t hipSetDeviceFlags(unsigned) { return hipSuccess; }
 struct hipPointerAttribute_t { int type; };
 inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->type = 0; return 1; } // (the emulator has no page-locked memory: always the staged path)
 inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }

@@ -116,6 +116,7 @@ CASES = {
     "fps_1080p_p8_me": (1920, 1080, 60, 8, ["--preset", "8", "+seam"]),
     # steady state: 300 frames (the 60-frame clip looped by the application), so that one-time costs (HIP context, session, kernel code loading) amortise
     "fps_1080p_p8_all_300": (1920, 1080, 300, 8, ["--preset", "8", "+clip60", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "fps_1080p_p8_all_tplrecon_300": (1920, 1080, 300, 8, ["--preset", "8", "+clip60", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
     # the same clip with the host side limited to a few threads (--lp): where the host is the bottleneck, what do the device stages buy
     "fps_1080p_p8_all_lp4": (1920, 1080, 60, 8, ["--preset", "8", "--lp", "4", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "fps_1080p_p8_all_lp8": (1920, 1080, 60, 8, ["--preset", "8", "--lp", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
@@ -461,6 +462,8 @@ def run_instances(name, lib, outdir, k, host="avx2", timeout=1800):
         wall = time.time() - t0
         u1 = resource.getrusage(resource.RUSAGE_CHILDREN)
         same = all(rcode == 0 and open(o + ".ivf", "rb").read() == want for _, rcode, o in outs)
+        own = [float(ln.split(":")[1].split()[0]) for (so, se), _, _ in outs for ln in (so + se).splitlines() if "Average Speed" in ln]
+        res["fps_sum_of_encoder_reports_" + tag] = round(sum(own), 2)  # (the encoders' own speed lines: without process start-up and device initialisation)
         res["identical"] = res["identical"] and same
         res["fps_" + tag] = round(k * n / wall, 2)
         res["host_cpu_s_per_frame_" + tag] = round(((u1.ru_utime - u0.ru_utime) + (u1.ru_stime - u0.ru_stime)) / (k * n), 5)
@@ -482,6 +485,7 @@ def main():
     ap.add_argument("--skip", default=None)
     ap.add_argument("--timeout", type=int, default=1800)
     ap.add_argument("--host", choices=("c", "avx2", "avx512"), default="c", help="host build the HIP run uses (avx2 / avx512: oracle/_ref/enc_avx2 / enc_avx512, also timed alone)")
+    ap.add_argument("--cpu-stats", action="store_true", help="per-stage thread CPU time of every encode (integration/seam_cpu.h)")
     ap.add_argument("--instances", type=int, default=0, help="K > 0: run_instances() instead -- K concurrent encodes of the case on one GPU, host alone vs host + stages")
     a = ap.parse_args()
     if not os.path.exists(ENC):
@@ -496,7 +500,7 @@ def main():
         sys.exit(0 if ok else 1)
     results, union = [], {}
     for nme in names:
-        r = run_case(nme, os.path.abspath(a.lib), a.out, only=a.only, skip=a.skip, timeout=a.timeout, host=a.host)
+        r = run_case(nme, os.path.abspath(a.lib), a.out, only=a.only, skip=a.skip, timeout=a.timeout, host=a.host, cpu_stats=a.cpu_stats)
         results.append(r)
         for k, v in r.get("counts", {}).items():
             union[k] = union.get(k, 0) + v
@@ -507,6 +511,8 @@ def main():
             print("    encoder fps: C-only %.2f, %swith HIP (host = %s) %.2f; host CPU s / frame %s" % (
                 r["fps_c"], ("%s intrinsics %.2f, " % (r["host"], r["fps_" + r["host"]])) if ("fps_" + r["host"]) in r and r["host"] != "c" else "", r["host"],
                 r.get("fps_hip", 0.0), r.get("host_cpu_s_per_frame")), flush=True)
+        if r.get("stage_cpu_ms_per_frame"):
+            print("    stage CPU ms / frame: %s" % json.dumps(r["stage_cpu_ms_per_frame"]), flush=True)
         if not r["identical"]:
             print(r.get("stderr_tail", ""))
     summary = {"all_identical": all(r["identical"] for r in results), "pointers_hit_union": len(union), "calls_total": sum(union.values()),
