@@ -1085,6 +1085,14 @@ void svt_hip_tpl_recon_stage(const SvtHipTplReconParams *params, const uint8_t *
  * recon_buf = start of the reconstruction picture's luma buffer (recon_rows rows of recon_stride bytes: uploaded, updated, downloaded). */
 int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams *params, const SvtHipTplHostPlanes *planes, const SvtHipTplSrcStats *src_stats, uint8_t *recon_buf,
                                  uint32_t recon_rows, SvtHipTplReconStats *out);
+/* Both halves of tpl_mc_flow_dispenser_sb_generic (src_ops_process.c:519-1198) for one picture in ONE host call: src_planes as svt_hip_tpl_src_stage_host takes them,
+ * rec_planes->ref_buf[rf] = the buffer params->rec_refs[rf] lives in (every valid reference; src_buf unused).  Every distinct buffer is uploaded once, the source-based
+ * statistics stay on the device between the halves and come back in src_stats (for the caller's TplSrcStats buffer), the written rectangle of the reconstruction and
+ * `out` as svt_hip_tpl_recon_stage_host returns them; one synchronisation.  Returns 0, -1 (option set not covered), -3 (a reference buffer is missing), -4 (a block
+ * gave up waiting for its neighbours). */
+int svt_hip_tpl_stage_host(const SvtHipTplReconParams *params, const SvtHipTplHostPlanes *src_planes, const SvtHipTplHostPlanes *rec_planes,
+                           const uint8_t *total_me_candidate_index, const uint32_t *me_mv_array, const uint8_t *me_candidate_array, SvtHipTplSrcStats *src_stats,
+                           uint8_t *recon_buf, uint32_t recon_rows, SvtHipTplReconStats *out);
 
 /* ---- the fixed-size symbols of the RTCD tables (what svt_hip_setup_rtcd installs): thin aliases of the generic forms above, declared here so that a caller can
  * also bind them by name.  Prototypes as the reference's pointers (aom_dsp_rtcd.h / common_dsp_rtcd.h). ---- */

@@ -63,7 +63,9 @@ static struct {
     double   ms_stage;
     int      recon; /* SVT_HIP_TPL_RECON_SEAM */
     int (*recon_host)(const SvtHipTplReconParams *, const SvtHipTplHostPlanes *, const SvtHipTplSrcStats *, uint8_t *, uint32_t, SvtHipTplReconStats *);
-    uint64_t n_recon_pictures, n_recon_blocks, n_recon_coded, n_sb_calls_skipped;
+    int (*fused_host)(const SvtHipTplReconParams *, const SvtHipTplHostPlanes *, const SvtHipTplHostPlanes *, const uint8_t *, const uint32_t *, const uint8_t *,
+                      SvtHipTplSrcStats *, uint8_t *, uint32_t, SvtHipTplReconStats *); /* both halves in one call (svt_hip_tpl_stage_host) */
+    uint64_t n_recon_pictures, n_recon_blocks, n_recon_coded, n_sb_calls_skipped, n_fused;
     double   ms_recon;
     PictureParentControlSet *done[16]; /* pictures whose blocks were reconstructed on the device: the per-SB function has nothing left to do */
 } TS = {PTHREAD_MUTEX_INITIALIZER};
@@ -76,8 +78,8 @@ static void tpl_seam_stats(void) {
             (unsigned long long)TS.n_pictures, (unsigned long long)TS.n_blocks, (unsigned long long)TS.n_newmv, (unsigned long long)TS.n_declined,
             (unsigned long long)TS.n_reused, TS.ms_stage);
     if (TS.recon)
-        fprintf(o, "recon_pictures %llu\nrecon_blocks %llu\nrecon_blocks_coded %llu\nsb_calls_skipped %llu\nms_in_recon_stage_calls %.0f\n", (unsigned long long)TS.n_recon_pictures,
-                (unsigned long long)TS.n_recon_blocks, (unsigned long long)TS.n_recon_coded, (unsigned long long)TS.n_sb_calls_skipped, TS.ms_recon);
+        fprintf(o, "recon_pictures %llu\nrecon_blocks %llu\nrecon_blocks_coded %llu\nsb_calls_skipped %llu\nms_in_recon_stage_calls %.0f\npictures_both_halves_in_one_call %llu\n", (unsigned long long)TS.n_recon_pictures,
+                (unsigned long long)TS.n_recon_blocks, (unsigned long long)TS.n_recon_coded, (unsigned long long)TS.n_sb_calls_skipped, TS.ms_recon, (unsigned long long)TS.n_fused);
     fclose(o);
 }
 static void tpl_seam_init(void) {
@@ -91,6 +93,7 @@ static void tpl_seam_init(void) {
     const char *r = getenv("SVT_HIP_TPL_RECON_SEAM");
     if (r && atoi(r)) {
         *(void **)&TS.recon_host = dlsym(RTLD_DEFAULT, "svt_hip_tpl_recon_stage_host");
+        *(void **)&TS.fused_host = dlsym(RTLD_DEFAULT, "svt_hip_tpl_stage_host");
         if (!TS.recon_host) { fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: libsvtav1_hip is not loaded\n"); abort(); }
         fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: the reconstruction half of the TPL dispenser runs as a device stage per picture too\n");
         TS.recon = 1;
@@ -128,8 +131,10 @@ static void seam_tpl_sb(TPL_SB_ARGS) {
 }
 
 /* the reconstruction half of a whole picture on the device (src_ops_process.c:979-1198); st = the source-based statistics of every cell.  0 = done */
+/* fused != NULL: the source-based half runs in the same call (svt_hip_tpl_stage_host) -- fused = the source half's host planes, tot / mvs / cand its ME tables, and
+ * st receives the statistics instead of supplying them */
 static int tpl_recon_picture(EncodeContext *enc_ctx, SequenceControlSet *scs, PictureParentControlSet *pcs, int32_t frame_idx, const SvtHipTplSrcParams *P,
-                             const SvtHipTplSrcStats *st, uint32_t cells) {
+                             SvtHipTplSrcStats *st, uint32_t cells, const SvtHipTplHostPlanes *fused, const uint8_t *tot, const uint32_t *mvs, const uint8_t *cand) {
     const EbPictureBufferDesc *inp = pcs->enhanced_pic;
     EbPictureBufferDesc       *rec = enc_ctx->mc_flow_rec_picture_buffer[frame_idx];
     SvtHipTplReconParams R;
@@ -156,7 +161,8 @@ static int tpl_recon_picture(EncodeContext *enc_ctx, SequenceControlSet *scs, Pi
         }
     SvtHipTplReconStats *out = malloc((size_t)cells * sizeof(*out));
     const double t0 = now_ms();
-    const int    rc = TS.recon_host(&R, &H, st, rec->buffer_y, rec->luma_size / rec->stride_y, out);
+    const int    rc = fused ? TS.fused_host(&R, fused, &H, tot, mvs, cand, st, rec->buffer_y, rec->luma_size / rec->stride_y, out)
+                            : TS.recon_host(&R, &H, st, rec->buffer_y, rec->luma_size / rec->stride_y, out);
     const double t1 = now_ms();
     if (rc) { free(out); return rc; }
     const uint32_t cols16 = (pcs->aligned_width + 15) >> 4, aligned_h = (inp->height + 7) & ~7u;
@@ -176,7 +182,7 @@ static int tpl_recon_picture(EncodeContext *enc_ctx, SequenceControlSet *scs, Pi
     }
     free(out);
     pthread_mutex_lock(&TS.lock);
-    TS.n_recon_pictures++; TS.n_recon_blocks += nb; TS.n_recon_coded += nc; TS.ms_recon += t1 - t0;
+    TS.n_recon_pictures++; TS.n_recon_blocks += nb; TS.n_recon_coded += nc; TS.ms_recon += t1 - t0; TS.n_fused += fused != NULL;
     pthread_mutex_unlock(&TS.lock);
     return 0;
 }
@@ -264,6 +270,7 @@ static void tpl_mc_flow_dispenser_use2_body(TPL_DISP_ARGS) {
     const uint32_t cols16 = (pcs->aligned_width + 15) >> 4, rows16 = (((inp->height + 7) & ~7u) + 15) >> 4, cells = cols16 * rows16;
     SvtHipTplSrcStats *st = malloc((size_t)cells * sizeof(*st));
     svt_hip_seam_bind(pcs->picture_number);
+    int fused_done = 0;
     if (stored) {
         uint8_t *wr = calloc(cells, 1);
         tpl_written_cells(pcs, P.dispenser_search_level, wr);
@@ -275,6 +282,10 @@ static void tpl_mc_flow_dispenser_use2_body(TPL_DISP_ARGS) {
             st[i].mv_row = d->mv.row; st[i].mv_col = d->mv.col; st[i].best_mode = d->best_mode; st[i].best_rf_idx = d->best_rf_idx; st[i].best_intra_mode = (uint8_t)d->best_intra_mode;
         }
         free(wr);
+    } else if (TS.recon && TS.fused_host) { /* both halves in one device call: one upload of every picture buffer, one synchronisation */
+        const int rc = tpl_recon_picture(enc_ctx, scs, pcs, frame_idx, &P, st, cells, &H, tot, mvs, cand);
+        if (rc) { fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: svt_hip_tpl_stage_host refused the picture (%d)\n", rc); abort(); }
+        fused_done = 1;
     } else if (TS.stage_host(&P, &H, tot, mvs, cand, st)) { fprintf(stderr, "SVT_HIP_TPL_SEAM: svt_hip_tpl_src_stage_host refused the parameters\n"); abort(); }
     /* into the buffer the reference's own "already computed" branch reads (:969-977); a sequence without stored statistics (tpl_lad_mg == 0) has none: lend one */
     TplSrcStats *own = med->tpl_src_stats_buffer, *buf = own;
@@ -292,7 +303,7 @@ static void tpl_mc_flow_dispenser_use2_body(TPL_DISP_ARGS) {
     const double t1 = now_ms();
     int on_device = 0;
     if (TS.recon) { /* the reconstruction half too: the per-SB function of this picture becomes a no-op */
-        const int rc = tpl_recon_picture(enc_ctx, scs, pcs, frame_idx, &P, st, cells);
+        const int rc = fused_done ? 0 : tpl_recon_picture(enc_ctx, scs, pcs, frame_idx, &P, st, cells, NULL, NULL, NULL, NULL);
         if (rc) { fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: svt_hip_tpl_recon_stage_host refused the picture (%d)\n", rc); abort(); }
         tpl_recon_mark(pcs, 1);
         on_device = 1;

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "svt_hip_tpl_src_stage_host": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "svt_hip_tpl_recon_stage": (None, [vp, vp, vp, vp, vp, vp, vp]),
     "svt_hip_tpl_recon_stage_host": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp]),
+    "svt_hip_tpl_stage_host": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp]),
     "svt_hip_setup_rtcd": (C.c_int, [C.c_uint64]),
     "svt_hip_selftest": (C.c_int, [vp, vp]),
     "svt_hip_rate_probe": (None, [C.c_int, C.c_uint32, C.c_uint32, vp, vp]),

@@ -772,4 +772,81 @@ int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams* params, const SvtHi
     return 0;
 }
 
+// Both halves of the dispenser for one picture in ONE host call: every distinct picture buffer -- the source, the source pictures of its references (source-based
+// half), the TPL reconstructions of its references (reconstruction half) -- is uploaded once, the source-based statistics stay on the device between the halves (they
+// come back for the caller's TplSrcStats buffer all the same), one synchronisation at the end.  What the seam calls for a picture whose statistics are not stored yet.
+int svt_hip_tpl_stage_host(const SvtHipTplReconParams* params, const SvtHipTplHostPlanes* src_planes, const SvtHipTplHostPlanes* rec_planes,
+                           const uint8_t* total_me_candidate_index, const uint32_t* me_mv_array, const uint8_t* me_candidate_array, SvtHipTplSrcStats* src_stats,
+                           uint8_t* recon_buf, uint32_t recon_rows, SvtHipTplReconStats* out) {
+    svthip::ensure_device();
+    SvtHipTplReconParams R = *params;
+    SvtHipTplSrcParams&  P = R.src;
+    if (!tpl_supported(P)) return -1;
+    const int    n_pus = P.enable_me_8x8 ? 85 : (P.enable_me_16x16 ? 21 : 5);
+    const size_t cols16 = (P.aligned_width + 15) >> 4, rows16 = ((((size_t)P.height + 7) & ~(size_t)7) + 15) >> 4, cells = cols16 * rows16;
+    const size_t tot_b = (size_t)P.n_sb * n_pus, mv_b = tot_b * P.max_refs * 4, cand_b = tot_b * P.max_cand;
+    const uint8_t* bufs[17];
+    size_t         bytes[17], doff[17];
+    int            nb = 0, src_slot[8], rec_slot[8];
+    auto slot_of = [&](const uint8_t* b, size_t n) {
+        for (int i = 0; i < nb; i++)
+            if (bufs[i] == b) return i;
+        bufs[nb] = b; bytes[nb] = n;
+        return nb++;
+    };
+    slot_of(src_planes->src_buf, (size_t)P.src_stride * src_planes->src_rows);
+    for (int r = 0; r < 8; r++) {
+        src_slot[r] = rec_slot[r] = -1;
+        if (!P.refs[r].valid || P.i_slice) continue;
+        if (!src_planes->ref_buf[r] || !rec_planes->ref_buf[r]) return -3;
+        src_slot[r] = slot_of(src_planes->ref_buf[r], (size_t)P.refs[r].stride * src_planes->ref_rows[r]);
+        rec_slot[r] = slot_of(rec_planes->ref_buf[r], (size_t)R.rec_refs[r].stride * rec_planes->ref_rows[r]);
+    }
+    size_t total = 0;
+    for (int b = 0; b < nb; b++) { doff[b] = total; total += svthip::align_up(bytes[b], 256); }
+    const size_t rec_b = (size_t)R.recon_stride * recon_rows;
+    svthip::HostCallLease lease;
+    svthip::HostCall& c = *lease;
+    c.begin();
+    const size_t side = tot_b + mv_b + cand_b + cells * (sizeof(SvtHipTplSrcStats) + sizeof(SvtHipTplReconStats)) + 16384;
+    c.reserve(total + rec_b + side + 4096, total + 2 * rec_b + 2 * side + 8192);
+    uint8_t* d_planes = (uint8_t*)c.dalloc(total);
+    for (int b = 0; b < nb; b++) c.up(d_planes + doff[b], bufs[b], bytes[b]);
+    uint8_t*             d_tot  = (uint8_t*)c.dalloc(tot_b);
+    uint32_t*            d_mv   = (uint32_t*)c.dalloc(mv_b ? mv_b : 4);
+    uint8_t*             d_cand = (uint8_t*)c.dalloc(cand_b ? cand_b : 4);
+    SvtHipTplSrcStats*   d_ss   = (SvtHipTplSrcStats*)c.dalloc(cells * sizeof(SvtHipTplSrcStats));
+    uint8_t*             d_rec  = (uint8_t*)c.dalloc(rec_b);
+    SvtHipTplReconStats* d_out  = (SvtHipTplReconStats*)c.dalloc(cells * sizeof(SvtHipTplReconStats));
+    c.up(d_tot, total_me_candidate_index, tot_b);
+    if (mv_b) c.up(d_mv, me_mv_array, mv_b);
+    if (cand_b) c.up(d_cand, me_candidate_array, cand_b);
+    HIP_CHECK(hipMemsetAsync(d_ss, 0, cells * sizeof(SvtHipTplSrcStats), c.stream));
+    HIP_CHECK(hipMemsetAsync(d_out, 0, cells * sizeof(SvtHipTplReconStats), c.stream));
+    HIP_CHECK(hipMemsetAsync(d_rec, 0, rec_b, c.stream)); // (never read before it is written: a DC block's neighbours are blocks of this picture; only the written rectangle comes back)
+    for (int r = 0; r < 8; r++) {
+        if (src_slot[r] >= 0) P.refs[r].plane_off += doff[src_slot[r]];
+        if (rec_slot[r] >= 0) R.rec_refs[r].plane_off += doff[rec_slot[r]];
+    }
+    svt_hip_tpl_src_stage(&P, d_planes, d_planes, d_tot, d_mv, d_cand, d_ss, c.stream);
+    svt_hip_tpl_recon_stage(&R, d_planes, d_planes, d_ss, d_rec, d_out, c.stream);
+    const size_t covered_w = ((size_t)P.width + 8) >> 4 << 4, covered_h = ((size_t)P.height + 8) >> 4 << 4;
+    size_t       rows_down = covered_h;
+    while (rows_down && R.recon_off + (rows_down - 1) * R.recon_stride + covered_w > rec_b) rows_down--;
+    const size_t span = rows_down ? (rows_down - 1) * R.recon_stride + covered_w : 0;
+    uint8_t*     pin_rec = span ? (uint8_t*)c.palloc(span) : nullptr;
+    uint8_t*     pin_ss  = (uint8_t*)c.palloc(cells * sizeof(SvtHipTplSrcStats));
+    uint8_t*     pin_out = (uint8_t*)c.palloc(cells * sizeof(SvtHipTplReconStats));
+    if (span) HIP_CHECK(hipMemcpyAsync(pin_rec, d_rec + R.recon_off, span, hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipMemcpyAsync(pin_ss, d_ss, cells * sizeof(SvtHipTplSrcStats), hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipMemcpyAsync(pin_out, d_out, cells * sizeof(SvtHipTplReconStats), hipMemcpyDeviceToHost, c.stream));
+    c.sync(); // the one synchronisation of the call
+    for (size_t y = 0; y < rows_down; y++) memcpy(recon_buf + R.recon_off + y * R.recon_stride, pin_rec + y * R.recon_stride, covered_w);
+    memcpy(src_stats, pin_ss, cells * sizeof(SvtHipTplSrcStats));
+    memcpy(out, pin_out, cells * sizeof(SvtHipTplReconStats));
+    for (size_t r = 0; r < rows16; r++)
+        if (out[r * cols16].pad[0] == 0xEE) return -4;
+    return 0;
+}
+
 } // extern "C"

@@ -305,3 +305,23 @@ def test_tpl_recon_stage_device(be, oracle, ci, is_ref, form, monkeypatch):
         assert np.array_equal(out_h[f], want[f]), ("host form", ci, f)
     # the WHOLE plane: the written rectangle equals the oracle's, every other pixel (borders, skipped blocks) still holds what the caller had there
     assert np.array_equal(rec_h, want_rec), ("host form recon", ci, int((rec_h != want_rec).sum()), np.argwhere(rec_h != want_rec)[:4])
+    # both halves in one host call (svt_hip_tpl_stage_host): the source pictures as the source-based half sees them, the reconstruction references as separate buffers
+    # (here: copies of the same test planes), statistics of both halves and the reconstruction as the two separate calls give them
+    SP, RP = TplHostPlanes(), TplHostPlanes()
+    rec_copies = {}
+    RF = pkg.TplReconParams.from_buffer_copy(R)
+    SP.src_buf, SP.src_rows = planes[0].ctypes.data, rows
+    for r in range(8):
+        if P.refs[r].valid:
+            k = P.refs[r].plane_off // psize
+            rec_copies[k] = rec_copies.get(k, planes[k].copy())
+            SP.ref_buf[r], SP.ref_rows[r] = planes[k].ctypes.data, rows
+            RP.ref_buf[r], RP.ref_rows[r] = rec_copies[k].ctypes.data, rows
+            RF.rec_refs[r].plane_off = 0
+            RF.src.refs[r].plane_off = 0
+    rec_f, out_f, src_f = rec0.copy(), np.zeros(cells, ReconStats), np.zeros(cells, SrcStats)
+    assert be.lib.svt_hip_tpl_stage_host(C.addressof(RF), C.addressof(SP), C.addressof(RP), p(tot), p(mvs), p(cand), p(src_f), p(rec_f), rows, p(out_f)) == 0
+    same_stats(src_f, src, ("fused host form, source-based statistics", ci))
+    for f in ("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate", "written", "coded"):
+        assert np.array_equal(out_f[f], want[f]), ("fused host form", ci, f)
+    assert np.array_equal(rec_f, want_rec), ("fused host form recon", ci, int((rec_f != want_rec).sum()))
