@@ -970,22 +970,22 @@ def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
         lib.svt_hip_tpl_recon_stage(C.addressof(R), d_pl.data_ptr(), d_pl.data_ptr(), d_src.data_ptr(), d_rec.data_ptr(), d_out.data_ptr(), stream)
     import os
     forms = {}
-    # 4 = the default: ONE launch, every block in flight, DC blocks wait for the cells above / left of them; 5 = 4 with release / acquire fences; 0 = one launch per
+    # 5 = the default: ONE launch, every block in flight, DC blocks wait for the cells above / left of them, release / acquire fences; 4 = 5 with sequentially-consistent fences; 0 = one launch per
     # anti-diagonal; 1 = the row wavefront in one launch; 2 = 1 with the rows given to the XCDs in contiguous chunks; 3 = 1 with release / acquire fences.  All are kept
     # for the checker.
-    for form in (5, 3, 2, 1, 0, 4):
+    for form in (4, 3, 2, 1, 0, 5):
         os.environ["SVT_HIP_TPL_RECON_FORM"] = str(form)
         t = _time(torch, run, steps, warmup, batches=3)
         out = d_out.cpu().numpy().view(pkg.TplReconStats)
         forms[form] = (t, d_rec.cpu().numpy().reshape(rows, stride), out.copy())
     os.environ.pop("SVT_HIP_TPL_RECON_FORM", None)
     n_blk = int(out["written"].sum())
-    keep.update(R=R, recon=forms[4][1], recon_out=forms[4][2], recon_forms={f: (v[1], v[2]) for f, v in forms.items()}, recon_stride=stride)
+    keep.update(R=R, recon=forms[5][1], recon_out=forms[5][2], recon_forms={f: (v[1], v[2]) for f, v in forms.items()}, recon_stride=stride)
     cols16, rows16 = (P.aligned_width + 15) // 16, (((P.height + 7) & ~7) + 15) // 16
     alg = n_blk * (3 * 256 + 80)  # per block: source, prediction (reference or neighbours), reconstruction, the two statistics records
     n_dc = int(np.sum((src["best_mode"] == 0) & (src["written"] > 0)))
-    return {"tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "form": "4: one launch, dependencies as data (csrc/tpl.hip tpl_recon_dep_kernel)",
-                                        "release_acquire_fences_form_us": forms[5][0] * 1e6, "anti_diagonal_launches_form_us": forms[0][0] * 1e6,
+    return {"tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "form": "5: one launch, one wave per block, dependencies as data, release / acquire fences (csrc/tpl.hip tpl_recon_dep_kernel)",
+                                        "sequentially_consistent_fences_form_us": forms[4][0] * 1e6, "anti_diagonal_launches_form_us": forms[0][0] * 1e6,
                                         "row_wavefront_form_us": forms[1][0] * 1e6, "row_wavefront_xcd_chunks_form_us": forms[2][0] * 1e6,
                                         "row_wavefront_release_acquire_form_us": forms[3][0] * 1e6, "blocks_16x16": n_blk, "intra_blocks": n_dc,
                                         "anti_diagonals": cols16 + rows16 - 1, "coded_frac": float(np.mean(out["coded"][out["written"] > 0])) if n_blk else 0.0,

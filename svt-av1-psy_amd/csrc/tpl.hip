@@ -655,8 +655,9 @@ void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* 
     const int   aligned_h = (int)((P.height + 7) & ~7u), cols16 = (int)((P.aligned_width + 15) >> 4), rows16 = (aligned_h + 15) >> 4;
     const bool  edge_sbs = (P.aligned_width & 63) || (aligned_h & 63); // SBs the picture edge cuts run at level 0 (:2048-2051)
     const char* form_env = getenv("SVT_HIP_TPL_RECON_FORM"); // (read per call: a picture-sized stage, and the tests switch it inside one process)
-    const int   form = form_env ? atoi(form_env) : 4;
-    if (form == 4 || form == 5) { // the default: dependencies as data, every block in flight (5: with release / acquire fences instead of sequentially-consistent ones)
+    const int   form = form_env ? atoi(form_env) : 5;
+    if (form == 4 || form == 5) { // dependencies as data, every block in flight: 5 (the default) with release / acquire fences at agent scope, 4 with sequentially-consistent
+                                  // ones (416 us against 339 us for a 1080p picture with a third of its blocks intra: profiles/r04_call3_tpl_forms.txt)
         uint32_t* sync = svthip::stream_scratch_u32x4(st); // [0] tickets of the first launch, [1] blocks that gave up waiting, [2] tickets of the second launch
         hipLaunchKernelGGL(tpl_recon_rows_reset_kernel, dim3((cols16 * rows16 + 255) / 256), dim3(256), 0, st, out, 1, cols16 * rows16); // every cell's flag
         SVT_LAUNCH_CHECK();

@@ -251,7 +251,7 @@ def test_tpl_recon_oracle_vs_reference(oracle, ref, ci):
 
 
 @pytest.mark.parametrize("ci", range(len(CASES) + len(GPU_CASES)))
-@pytest.mark.parametrize("is_ref,form", [(1, 4), (0, 4), (1, 5), (1, 0), (0, 0), (1, 1), (1, 2), (1, 3)])
+@pytest.mark.parametrize("is_ref,form", [(1, 5), (0, 5), (1, 4), (1, 0), (0, 0), (1, 1), (1, 2), (1, 3)])
 def test_tpl_recon_stage_device(be, oracle, ci, is_ref, form, monkeypatch):
     """svt_hip_tpl_recon_stage (device arrays, one launch per anti-diagonal) and svt_hip_tpl_recon_stage_host == the oracle: statistics of every block and the whole
     reconstruction plane; is_ref = 0 with intra prediction off leaves the prediction in place (:1135)."""
@@ -260,7 +260,7 @@ def test_tpl_recon_stage_device(be, oracle, ci, is_ref, form, monkeypatch):
     c = CASES[ci] if ci < len(CASES) else GPU_CASES[ci - len(CASES)]
     if not is_ref and not c["noi"]:
         pytest.skip("is_ref only matters with intra prediction disabled")
-    # form 4 (the default) = one launch, every block in flight, DC blocks wait for their neighbours' cells (5: the same with release / acquire fences);
+    # form 5 (the default) = one launch, one wave per block, DC blocks wait for their neighbours' cells, release / acquire fences (4: sequentially-consistent fences);
     # form 1 = the row wavefront in one launch (SVT_HIP_TPL_RECON_FORM=1; csrc/tpl.hip: tpl_recon_rows_kernel), which falls back to the diagonal launches when an SB
     # column is cut by the right picture edge at dispenser level 1
     if form == 2 and not be.is_gpu:
