@@ -1094,6 +1094,29 @@ int svt_hip_tpl_stage_host(const SvtHipTplReconParams *params, const SvtHipTplHo
                            const uint8_t *total_me_candidate_index, const uint32_t *me_mv_array, const uint8_t *me_candidate_array, SvtHipTplSrcStats *src_stats,
                            uint8_t *recon_buf, uint32_t recon_rows, SvtHipTplReconStats *out);
 
+/* ---- ONE picture over several GPUs from a C host (the frame-partition case; csrc/partition.hip) ----
+ * devices[0] = the HOME device: every pointer of the calls below lives there and `stream` belongs to it.  Each call is the batched primitive of the same name cut
+ * into contiguous strips (ME: descriptor ranges = bands of SB rows; CDEF: filter-block rows; LR: 64-row stripes), strip k on devices[k]: the inputs are copied home ->
+ * k (hipMemcpyPeerAsync, xGMI inside a node), the strip runs on k, its output rows are copied back into the caller's arrays exactly where the single-device call
+ * writes them; the call returns with everything enqueued (the home stream waits for the peers).  Results are bit-identical to the single-device call.  A partition
+ * is used by one host thread at a time.  create returns NULL for an empty / repeated / unavailable device list. */
+void *svt_hip_frame_partition_create(const int *devices, int n);
+void  svt_hip_frame_partition_destroy(void *partition);
+int   svt_hip_frame_partition_size(const void *partition);
+void  svt_hip_frame_partition_stats(const void *partition, uint64_t *calls, uint64_t *peer_bytes_in, uint64_t *peer_bytes_out);
+/* svt_hip_me_fullpel_search_batch over items [0, n): src_bytes / ref_bytes = the extent of the plane sets behind src_base / ref_base (mirrored whole) */
+int   svt_hip_frame_partition_me(void *partition, const uint8_t *src_base, size_t src_bytes, const uint8_t *ref_base, size_t ref_bytes, const SvtHipMeSearchDesc *descs,
+                                 uint32_t n, uint32_t max_w, uint32_t max_h, int sub_sad, uint32_t *best_sad, uint32_t *best_mv, void *workspace, void *stream);
+/* svt_hip_cdef_frame (modes 0 / 1 / 2) */
+int   svt_hip_frame_partition_cdef(void *partition, int mode, const SvtHipCdefParams *params, void *stream);
+/* svt_hip_lr_filter_frame */
+int   svt_hip_frame_partition_lr(void *partition, const SvtHipLrParams *params, void *stream);
+/* The host forms' switch: with n > 1 devices set, svt_hip_cdef_apply_host / svt_hip_cdef_search_host / svt_hip_lr_filter_frame_host run their frame launches through a
+ * partition of the calling thread (home = devices[0], which must be the thread's device; other threads keep the single-device path); n <= 1 switches it off.
+ * The binding of the reference encoder sets it from SVT_HIP_STRIPS=<d0,d1,...>.  Returns 0, or -1 for an invalid list. */
+int   svt_hip_set_frame_partition(const int *devices, int n);
+unsigned long long svt_hip_frame_partition_host_calls(void); /* frame launches of host forms that went through a partition so far */
+
 /* ---- the fixed-size symbols of the RTCD tables (what svt_hip_setup_rtcd installs): thin aliases of the generic forms above, declared here so that a caller can
  * also bind them by name.  Prototypes as the reference's pointers (aom_dsp_rtcd.h / common_dsp_rtcd.h). ---- */
 #define SVT_HIP_FOR_ALL_SAD_SIZES(X)                                                                                                              \

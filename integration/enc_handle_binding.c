@@ -73,6 +73,14 @@ void svt_hip_seam_cpu_add(int stage, unsigned long long ns) {
     __atomic_fetch_add(&SVT_HIP_CPU.calls[stage], 1, __ATOMIC_RELAXED);
 }
 
+static unsigned long long (*SVT_HIP_STRIPS_CALLS)(void);
+static void svt_hip_strips_stats(void) {
+    const char *f = getenv("SVT_HIP_STRIPS_STATS");
+    FILE       *o = f ? fopen(f, "w") : NULL;
+    if (!o) return;
+    fprintf(o, "frame_launches_through_a_partition %llu\n", SVT_HIP_STRIPS_CALLS ? SVT_HIP_STRIPS_CALLS() : 0ull);
+    fclose(o);
+}
 static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
     svt_aom_setup_rtcd_internal(flags);
     const char *dev = getenv("SVT_HIP");
@@ -107,6 +115,22 @@ static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
         }
         fprintf(stderr, "SVT_HIP_DEVICES: pictures are sharded over %d device(s) by picture number\n", SVT_HIP_SHARD.n);
         atexit(svt_hip_shard_stats);
+    }
+    /* SVT_HIP_STRIPS=<d0,d1,...>: ONE picture over several GPUs (the frame-partition case): the picture-sized host forms of the in-loop filters -- what
+     * the CDEF and REST seams call -- cut their frame launches into strips over the listed devices (svt_hip_set_frame_partition; d0 = the device of SVT_HIP). */
+    const char *strips = getenv("SVT_HIP_STRIPS");
+    if (strips && *strips) {
+        int ids[16], ns = 0;
+        for (const char *p = strips; *p && ns < 16;) {
+            ids[ns++] = atoi(p);
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        int (*set_part)(const int *, int) = (int (*)(const int *, int))dlsym(h, "svt_hip_set_frame_partition");
+        if (!set_part || set_part(ids, ns)) { fprintf(stderr, "SVT_HIP_STRIPS: \"%s\" is not a list of available devices\n", strips); abort(); }
+        *(void **)&SVT_HIP_STRIPS_CALLS = dlsym(h, "svt_hip_frame_partition_host_calls");
+        fprintf(stderr, "SVT_HIP_STRIPS: the in-loop filter stages cut every picture into strips over %d device(s)\n", ns);
+        atexit(svt_hip_strips_stats);
     }
     int n = setup((unsigned long long)flags);
     fprintf(stderr, "SVT_HIP: %d dispatch pointers now select the HIP variant\n", n);

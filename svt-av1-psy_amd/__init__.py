@@ -50,6 +50,15 @@ PROTOTYPES = {
     "svt_hip_tpl_recon_stage": (None, [vp, vp, vp, vp, vp, vp, vp]),
     "svt_hip_tpl_recon_stage_host": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp]),
     "svt_hip_tpl_stage_host": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp]),
+    "svt_hip_frame_partition_create": (vp, [vp, C.c_int]),
+    "svt_hip_frame_partition_destroy": (None, [vp]),
+    "svt_hip_frame_partition_size": (C.c_int, [vp]),
+    "svt_hip_frame_partition_stats": (None, [vp, vp, vp, vp]),
+    "svt_hip_frame_partition_me": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp, vp]),
+    "svt_hip_frame_partition_cdef": (C.c_int, [vp, C.c_int, vp, vp]),
+    "svt_hip_frame_partition_lr": (C.c_int, [vp, vp, vp]),
+    "svt_hip_set_frame_partition": (C.c_int, [vp, C.c_int]),
+    "svt_hip_frame_partition_host_calls": (C.c_ulonglong, []),
     "svt_hip_setup_rtcd": (C.c_int, [C.c_uint64]),
     "svt_hip_selftest": (C.c_int, [vp, vp]),
     "svt_hip_rate_probe": (None, [C.c_int, C.c_uint32, C.c_uint32, vp, vp]),

@@ -772,7 +772,7 @@ void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost* a) {
         P.xdec = P.ydec = (uint8_t)(p ? 1 : 0); P.pli = (uint8_t)p; P.is_16bit = a->is_16bit;
         P.coeff_shift = a->coeff_shift; P.pri_damping = P.sec_damping = a->damping; P.subsampling = 1;
         P.skip = d_skip; P.pri = d_str[p ? 2 : 0]; P.sec = d_str[p ? 3 : 1]; P.dir = d_dir; P.var = d_var;
-        svt_hip_cdef_frame(0, &P, c.stream);
+        svthip::cdef_frame_dispatch(0, &P, c.stream);
     }
     for (int p = 0; p < a->num_planes; p++) c.down2d(a->plane[p], (size_t)a->stride[p] * px, d_out[p], pitch[p], wid[p] * px, rows[p]);
 }
@@ -829,7 +829,7 @@ void svt_hip_cdef_search_host(const SvtHipCdefSearchHost* a) {
         P.xdec = P.ydec = (uint8_t)(p ? 1 : 0); P.pli = (uint8_t)p; P.is_16bit = a->is_16bit;
         P.coeff_shift = a->coeff_shift; P.pri_damping = P.sec_damping = a->damping; P.subsampling = a->subsampling[p ? 1 : 0];
         P.ncand = ncand; P.skip = d_skip; P.pri = d_pri[p ? 1 : 0]; P.sec = d_sec[p ? 1 : 0]; P.dir = d_dir; P.var = d_var; P.mse = d_mse[p];
-        svt_hip_cdef_frame(1, &P, c.stream);
+        svthip::cdef_frame_dispatch(1, &P, c.stream);
     }
     for (int p = 0; p < 3; p++)
         if (nc[p ? 1 : 0]) c.down(h_mse[p], d_mse[p], (size_t)nfb * nc[p ? 1 : 0] * 8);

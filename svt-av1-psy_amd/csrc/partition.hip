@@ -1,0 +1,331 @@
+// partition.hip -- ONE picture over several MI355X from a C host (the frame-partition case; BASELINE north_star: "RCCL over xGMI only for the
+// frame-partition case").
+//
+// A partition is a list of devices; devices[0] is the HOME device: the caller's buffers live there and the caller's stream belongs to it.  Every entry point below
+// is the batched primitive of the single-device ABI with the picture cut into contiguous strips (SB rows for ME, filter-block rows for CDEF, 64-row stripes for the
+// loop restoration -- the units the primitives already take as ranges), strip k on devices[k]:
+//
+//     home stream --record--> [ready]                      (the inputs are final)
+//     device k:   wait [ready]; inputs home -> k (hipMemcpyPeerAsync: over xGMI between the GPUs of one node); the strip's launch on k; the strip's OUTPUT ROWS
+//                 k -> home, into the caller's arrays where the single-device call would have written them; --record--> [done k]
+//     home:       its own strip on the caller's stream; wait [done k] for every k.  The call returns with everything ENQUEUED, like the primitives it wraps.
+//
+// "Broadcast in, all-gather out" of SURVEY 8(e) with point-to-point copies: the exchange is one-to-all and all-to-one with the home device as root (the reference
+// encoder consumes the result on the host, behind the home device), so a ring collective has nothing to add -- each remote device moves the planes once in and its
+// strip once out over its own xGMI link to the home device, all links in parallel.  No RCCL dependency inside the library: the peer copies are plain HIP, which is also
+// what lets the CPU emulator run the path (tests/emu: a peer copy is legal when each pointer belongs to the device it is said to live on).
+// The per-device mirrors of the inputs live in an arena per (partition, device) that only grows; a partition is used by one host thread at a time.
+#include <vector>
+
+#include "svt_hip_common.h"
+#include "../../include/svtav1_hip.h"
+
+namespace {
+
+struct Peer {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t  done   = nullptr;
+    uint8_t*    arena  = nullptr;
+    size_t      cap = 0, used = 0;
+};
+struct Partition {
+    int               n = 0;
+    std::vector<Peer> peer; // peer[0] = the home device (no stream / arena of its own: the caller's)
+    hipEvent_t        ready = nullptr;
+    uint64_t          bytes_in = 0, bytes_out = 0, calls = 0; // peer traffic so far (svt_hip_frame_partition_stats)
+};
+
+// contiguous strips, the first (total % n) one unit longer (the rule of bench.py --mode strips and of the gloo tests)
+inline size_t plane_bytes(size_t stride, size_t width, size_t rows, size_t px) { return rows ? ((rows - 1) * stride + width) * px : 0; } // (the last row ends at `width`)
+inline void strip_of(int total, int k, int n, int& b, int& e) {
+    const int q = total / n, r = total % n;
+    b = k * q + (k < r ? k : r);
+    e = b + q + (k < r ? 1 : 0);
+}
+void arena_begin(Peer& p, size_t need) {
+    need += 4096;
+    if (need > p.cap) { // (grows between calls only: the previous call's work on this device has been waited for by the home stream, and is drained here)
+        svthip::DeviceGuard g(p.device);
+        HIP_CHECK(hipStreamSynchronize(p.stream));
+        if (p.arena) HIP_CHECK(hipFree(p.arena));
+        p.cap = svthip::align_up(need + need / 4, 1 << 20);
+        HIP_CHECK(hipMalloc((void**)&p.arena, p.cap));
+    }
+    p.used = 0;
+}
+void* arena_take(Peer& p, size_t bytes) {
+    const size_t off = svthip::align_up(p.used, 256);
+    if (off + bytes > p.cap) { fprintf(stderr, "libsvtav1_hip: frame-partition arena overflow\n"); abort(); }
+    p.used = off + bytes;
+    return p.arena + off;
+}
+// input `src` (home device) -> a mirror on peer p, in p's stream
+void* mirror_in(Partition& P, Peer& p, const void* src, size_t bytes) {
+    if (!src || !bytes) return nullptr;
+    void* d = arena_take(p, bytes);
+    HIP_CHECK(hipMemcpyPeerAsync(d, p.device, src, P.peer[0].device, bytes, p.stream));
+    P.bytes_in += bytes;
+    return d;
+}
+void rows_out(Partition& P, Peer& p, void* dst_home, const void* src_peer, size_t bytes) {
+    if (!bytes) return;
+    HIP_CHECK(hipMemcpyPeerAsync(dst_home, P.peer[0].device, src_peer, p.device, bytes, p.stream));
+    P.bytes_out += bytes;
+}
+void open_call(Partition& P, hipStream_t home) {
+    HIP_CHECK(hipEventRecord(P.ready, home));
+    P.calls++;
+}
+void close_call(Partition& P, hipStream_t home) {
+    for (int k = 1; k < P.n; k++) HIP_CHECK(hipStreamWaitEvent(home, P.peer[k].done, 0));
+}
+
+} // namespace
+
+// ---- the host forms' switch (svt_hip_set_frame_partition): with a device list set, the picture-sized HOST forms of the in-loop filters (svt_hip_cdef_apply_host,
+// svt_hip_cdef_search_host, svt_hip_lr_filter_frame_host -- what the encoder's CDEF / REST seams call) run their frame launches through a partition instead of on
+// the calling thread's device alone.  Partitions are per calling thread (a partition serves one thread at a time; the seams call from several worker threads) and are
+// made on first use with the thread's current device as home; a thread whose device is not the list's first entry keeps the single-device path.
+#include <atomic>
+#include <mutex>
+namespace svthip {
+static std::mutex       g_strips_m;
+static int              g_strips_n = 0, g_strips_dev[MAX_DEVICES];
+static std::atomic<int> g_strips_on{0};
+static std::atomic<unsigned long long> g_strips_calls{0};
+struct ThreadPartition {
+    void* part = nullptr;
+    int   gen  = -1;
+    ~ThreadPartition() { /* (worker threads end with the encoder: the arenas go with the process) */ }
+};
+static std::atomic<int>      g_strips_gen{0};
+static thread_local ThreadPartition t_part;
+void* thread_partition() {
+    if (!g_strips_on.load(std::memory_order_acquire)) return nullptr;
+    const int gen = g_strips_gen.load();
+    if (t_part.gen != gen) {
+        int devs[MAX_DEVICES], n;
+        { std::lock_guard<std::mutex> g(g_strips_m); n = g_strips_n; for (int i = 0; i < n; i++) devs[i] = g_strips_dev[i]; }
+        t_part.part = (n > 1 && devs[0] == current_device()) ? svt_hip_frame_partition_create(devs, n) : nullptr; // (an earlier partition of this thread is left to the process)
+        t_part.gen  = gen;
+    }
+    if (t_part.part) g_strips_calls.fetch_add(1);
+    return t_part.part;
+}
+void cdef_frame_dispatch(int mode, const SvtHipCdefParams* P, hipStream_t st) {
+    void* part = thread_partition();
+    if (part) svt_hip_frame_partition_cdef(part, mode, P, st);
+    else svt_hip_cdef_frame(mode, P, st);
+}
+void lr_frame_dispatch(const SvtHipLrParams* P, hipStream_t st) {
+    void* part = thread_partition();
+    if (part) svt_hip_frame_partition_lr(part, P, st);
+    else svt_hip_lr_filter_frame(P, st);
+}
+} // namespace svthip
+
+extern "C" {
+
+int svt_hip_set_frame_partition(const int* devices, int n) {
+    using namespace svthip;
+    if (n < 0 || n > MAX_DEVICES || (n > 0 && !devices)) return -1;
+    const int have = svt_hip_device_count();
+    for (int k = 0; k < n; k++)
+        if (devices[k] < 0 || devices[k] >= have) return -1;
+    std::lock_guard<std::mutex> g(g_strips_m);
+    g_strips_n = n;
+    for (int k = 0; k < n; k++) g_strips_dev[k] = devices[k];
+    g_strips_gen.fetch_add(1);
+    g_strips_on.store(n > 1, std::memory_order_release);
+    return 0;
+}
+unsigned long long svt_hip_frame_partition_host_calls(void) { return svthip::g_strips_calls.load(); }
+
+void* svt_hip_frame_partition_create(const int* devices, int n) {
+    if (!devices || n < 1 || n > svthip::MAX_DEVICES) return nullptr;
+    const int have = svt_hip_device_count();
+    for (int k = 0; k < n; k++) {
+        if (devices[k] < 0 || devices[k] >= have) return nullptr;
+        for (int j = 0; j < k; j++)
+            if (devices[j] == devices[k]) return nullptr;
+    }
+    Partition* P = new Partition;
+    P->n = n;
+    P->peer.resize(n);
+    for (int k = 0; k < n; k++) {
+        P->peer[k].device = devices[k];
+        svthip::DeviceGuard g(devices[k]);
+        if (k == 0) {
+            HIP_CHECK(hipEventCreateWithFlags(&P->ready, hipEventDisableTiming));
+            continue;
+        }
+        HIP_CHECK(hipStreamCreateWithFlags(&P->peer[k].stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&P->peer[k].done, hipEventDisableTiming));
+        int can = 0; // direct xGMI access where the platform offers it (the copies work without it, staged by the runtime)
+        if (hipDeviceCanAccessPeer(&can, devices[k], devices[0]) == hipSuccess && can) {
+            if (hipDeviceEnablePeerAccess(devices[0], 0) != hipSuccess) (void)hipGetLastError(); // (already enabled: fine)
+        } else (void)hipGetLastError();
+    }
+    return P;
+}
+void svt_hip_frame_partition_destroy(void* part) {
+    Partition* P = (Partition*)part;
+    if (!P) return;
+    for (int k = 0; k < P->n; k++) {
+        svthip::DeviceGuard g(P->peer[k].device);
+        if (k == 0) { (void)hipEventDestroy(P->ready); continue; }
+        (void)hipStreamSynchronize(P->peer[k].stream);
+        if (P->peer[k].arena) (void)hipFree(P->peer[k].arena);
+        (void)hipEventDestroy(P->peer[k].done);
+        (void)hipStreamDestroy(P->peer[k].stream);
+    }
+    delete P;
+}
+int svt_hip_frame_partition_size(const void* part) { return part ? ((const Partition*)part)->n : 0; }
+void svt_hip_frame_partition_stats(const void* part, uint64_t* calls, uint64_t* bytes_in, uint64_t* bytes_out) {
+    const Partition* P = (const Partition*)part;
+    if (calls) *calls = P ? P->calls : 0;
+    if (bytes_in) *bytes_in = P ? P->bytes_in : 0;
+    if (bytes_out) *bytes_out = P ? P->bytes_out : 0;
+}
+
+// ---- open-loop ME: items (SB x reference descriptors) [0, n) in contiguous strips; the caller orders them SB row after SB row, so a strip is a band of SB rows --------
+int svt_hip_frame_partition_me(void* part, const uint8_t* src_base, size_t src_bytes, const uint8_t* ref_base, size_t ref_bytes, const SvtHipMeSearchDesc* descs,
+                               uint32_t n, uint32_t max_w, uint32_t max_h, int sub_sad, uint32_t* best_sad, uint32_t* best_mv, void* workspace, void* stream) {
+    Partition* P = (Partition*)part;
+    if (!P) return -1;
+    hipStream_t home = (hipStream_t)stream;
+    svthip::DeviceGuard gh(P->peer[0].device);
+    open_call(*P, home);
+    const size_t row = (size_t)SVT_HIP_ME_NUM_BLOCKS * 4;
+    for (int k = 1; k < P->n; k++) {
+        int b, e;
+        strip_of((int)n, k, P->n, b, e);
+        Peer& p = P->peer[k];
+        if (e <= b) { svthip::DeviceGuard g(p.device); HIP_CHECK(hipEventRecord(p.done, p.stream)); continue; }
+        const uint32_t cnt = (uint32_t)(e - b);
+        const size_t   ws  = svt_hip_me_fullpel_search_workspace(cnt, max_w, max_h);
+        const bool     one = src_base == ref_base;
+        arena_begin(p, src_bytes + (one ? 0 : ref_bytes) + (size_t)cnt * (sizeof(SvtHipMeSearchDesc) + 2 * row) + ws + 8 * 256);
+        svthip::DeviceGuard g(p.device);
+        HIP_CHECK(hipStreamWaitEvent(p.stream, P->ready, 0));
+        const uint8_t* m_src = (const uint8_t*)mirror_in(*P, p, src_base, src_bytes);
+        const uint8_t* m_ref = one ? m_src : (const uint8_t*)mirror_in(*P, p, ref_base, ref_bytes);
+        const SvtHipMeSearchDesc* m_d = (const SvtHipMeSearchDesc*)mirror_in(*P, p, descs + b, (size_t)cnt * sizeof(SvtHipMeSearchDesc));
+        uint32_t* o_sad = (uint32_t*)arena_take(p, cnt * row);
+        uint32_t* o_mv  = (uint32_t*)arena_take(p, cnt * row);
+        void*     m_ws  = ws ? arena_take(p, ws) : nullptr;
+        svt_hip_me_fullpel_search_batch(m_src, m_ref, m_d, cnt, max_w, max_h, sub_sad, o_sad, o_mv, m_ws, p.stream);
+        rows_out(*P, p, (uint8_t*)best_sad + (size_t)b * row, o_sad, cnt * row);
+        rows_out(*P, p, (uint8_t*)best_mv + (size_t)b * row, o_mv, cnt * row);
+        HIP_CHECK(hipEventRecord(p.done, p.stream));
+    }
+    int b0, e0;
+    strip_of((int)n, 0, P->n, b0, e0);
+    if (e0 > b0)
+        svt_hip_me_fullpel_search_batch(src_base, ref_base, descs + b0, (uint32_t)(e0 - b0), max_w, max_h, sub_sad, best_sad + (size_t)b0 * SVT_HIP_ME_NUM_BLOCKS,
+                                        best_mv + (size_t)b0 * SVT_HIP_ME_NUM_BLOCKS, workspace, home);
+    close_call(*P, home);
+    return 0;
+}
+
+// ---- CDEF (search, apply, apply with the search's directions): filter-block rows in strips ------------------------------------------------------------------------------
+int svt_hip_frame_partition_cdef(void* part, int mode, const SvtHipCdefParams* params, void* stream) {
+    Partition* P = (Partition*)part;
+    if (!P || !params) return -1;
+    const SvtHipCdefParams& C = *params;
+    if (mode == 1 && C.ncand == 0) return 0;
+    hipStream_t home = (hipStream_t)stream;
+    svthip::DeviceGuard gh(P->peer[0].device);
+    open_call(*P, home);
+    const int    bw = 64 >> C.xdec, bh = 64 >> C.ydec, px = C.is_16bit ? 2 : 1;
+    const int    nhfb = ((int)C.width + bw - 1) / bw, nvfb = ((int)C.height + bh - 1) / bh, nfb = nhfb * nvfb;
+    const size_t recon_b = plane_bytes(C.recon_stride, C.width, C.height, px), source_b = mode == 1 ? plane_bytes(C.source_stride, C.width, C.height, px) : 0;
+    const size_t out_b = mode == 1 ? 0 : plane_bytes(C.out_stride, C.width, C.height, px), skip_b = (size_t)nvfb * 8 * nhfb * 8;
+    const size_t str_b = (size_t)(mode == 1 ? C.ncand : (uint32_t)nfb) * 4, dir_b = (size_t)nfb * 64, var_b = (size_t)nfb * 64 * 4, mse_b = mode == 1 ? (size_t)nfb * C.ncand * 8 : 0;
+    const bool   dir_in = C.pli != 0 || mode == 2; // chroma planes and the apply behind a search read the luma directions / variances
+    for (int k = 1; k < P->n; k++) {
+        int b, e;
+        strip_of(nvfb, k, P->n, b, e);
+        Peer& p = P->peer[k];
+        svthip::DeviceGuard g(p.device);
+        if (e <= b) { HIP_CHECK(hipEventRecord(p.done, p.stream)); continue; }
+        arena_begin(p, recon_b + source_b + out_b + skip_b + 2 * str_b + dir_b + var_b + mse_b + 16 * 256);
+        HIP_CHECK(hipStreamWaitEvent(p.stream, P->ready, 0));
+        SvtHipCdefParams M = C;
+        M.recon  = mirror_in(*P, p, C.recon, recon_b);
+        M.source = mode == 1 ? mirror_in(*P, p, C.source, source_b) : nullptr;
+        M.skip   = (const uint8_t*)mirror_in(*P, p, C.skip, skip_b);
+        M.pri    = (const int32_t*)mirror_in(*P, p, C.pri, str_b);
+        M.sec    = (const int32_t*)mirror_in(*P, p, C.sec, str_b);
+        // (always mirrored, also where they are outputs: a filter block without a single unit to filter leaves its entries as the caller had them)
+        M.dir    = (uint8_t*)mirror_in(*P, p, C.dir, dir_b);
+        M.var    = (int32_t*)mirror_in(*P, p, C.var, var_b);
+        M.mse    = mode == 1 ? (uint64_t*)arena_take(p, mse_b) : nullptr;
+        // apply writes out of place onto a pre-copied plane (skipped units are not touched): the strip's rows of the caller's `out` are that pre-copy
+        const int    y0 = b * bh, y1 = e * bh < (int)C.height ? e * bh : (int)C.height;
+        const size_t orow = (size_t)C.out_stride * px;
+        M.out = mode == 1 ? nullptr : arena_take(p, out_b);
+        const size_t strip_b = plane_bytes(C.out_stride, C.width, (size_t)(y1 - y0), px);
+        if (mode != 1) HIP_CHECK(hipMemcpyPeerAsync((uint8_t*)M.out + y0 * orow, p.device, (const uint8_t*)C.out + y0 * orow, P->peer[0].device, strip_b, p.stream));
+        svt_hip_cdef_frame_rows(mode, &M, b, e, p.stream);
+        const size_t f0 = (size_t)b * nhfb, fn = (size_t)(e - b) * nhfb;
+        if (mode == 1) rows_out(*P, p, C.mse + f0 * C.ncand, M.mse + f0 * C.ncand, fn * C.ncand * 8);
+        else rows_out(*P, p, (uint8_t*)C.out + y0 * orow, (const uint8_t*)M.out + y0 * orow, strip_b);
+        if (!dir_in) { // luma: the strip's directions / variances are results too
+            rows_out(*P, p, C.dir + f0 * 64, M.dir + f0 * 64, fn * 64);
+            rows_out(*P, p, C.var + f0 * 64, M.var + f0 * 64, fn * 64 * 4);
+        }
+        HIP_CHECK(hipEventRecord(p.done, p.stream));
+    }
+    int b0, e0;
+    strip_of(nvfb, 0, P->n, b0, e0);
+    if (e0 > b0) svt_hip_cdef_frame_rows(mode, params, b0, e0, home);
+    close_call(*P, home);
+    return 0;
+}
+
+// ---- loop restoration filter: 64-row stripes (offset by 8 rows, restoration.c:1082-1098) in strips ------------------------------------------------------------------
+int svt_hip_frame_partition_lr(void* part, const SvtHipLrParams* params, void* stream) {
+    Partition* P = (Partition*)part;
+    if (!P || !params) return -1;
+    const SvtHipLrParams& L = *params;
+    hipStream_t home = (hipStream_t)stream;
+    svthip::DeviceGuard gh(P->peer[0].device);
+    open_call(*P, home);
+    const int    px = L.highbd ? 2 : 1, sh = 64 >> L.ss_y, off = 8 >> L.ss_y;
+    const int    nstripes = ((int)L.height + off + sh - 1) / sh;
+    const int    us = (int)L.unit_size, nvu = ((int)L.height + us / 2) / us > 0 ? ((int)L.height + us / 2) / us : 1, nhu = ((int)L.width + us / 2) / us > 0 ? ((int)L.width + us / 2) / us : 1;
+    const size_t data_b = plane_bytes(L.stride, L.width, L.height, px), bnd_b = plane_bytes(L.boundary_stride, L.width, (size_t)2 * nstripes, px);
+    const size_t dst_b = plane_bytes(L.dst_stride, L.width, L.height, px);
+    const size_t unit_b = (size_t)nvu * nhu * sizeof(SvtHipLrUnit);
+    for (int k = 1; k < P->n; k++) {
+        int b, e;
+        strip_of(nstripes, k, P->n, b, e);
+        Peer& p = P->peer[k];
+        svthip::DeviceGuard g(p.device);
+        if (e <= b) { HIP_CHECK(hipEventRecord(p.done, p.stream)); continue; }
+        arena_begin(p, data_b + 2 * bnd_b + dst_b + unit_b + 8 * 256);
+        HIP_CHECK(hipStreamWaitEvent(p.stream, P->ready, 0));
+        SvtHipLrParams M = L;
+        M.data           = mirror_in(*P, p, L.data, data_b);
+        M.boundary_above = mirror_in(*P, p, L.boundary_above, bnd_b);
+        M.boundary_below = mirror_in(*P, p, L.boundary_below, bnd_b);
+        M.units          = (const SvtHipLrUnit*)mirror_in(*P, p, L.units, unit_b);
+        M.dst            = arena_take(p, dst_b);
+        svt_hip_lr_filter_frame_stripes(&M, b, e, p.stream);
+        // stripe s covers picture rows [s * sh - off, (s + 1) * sh - off) clipped to the plane
+        const int    y0 = b * sh - off > 0 ? b * sh - off : 0, y1 = e * sh - off < (int)L.height ? e * sh - off : (int)L.height;
+        const size_t drow = (size_t)L.dst_stride * px;
+        rows_out(*P, p, (uint8_t*)L.dst + y0 * drow, (const uint8_t*)M.dst + y0 * drow, plane_bytes(L.dst_stride, L.width, (size_t)(y1 - y0), px));
+        HIP_CHECK(hipEventRecord(p.done, p.stream));
+    }
+    int b0, e0;
+    strip_of(nstripes, 0, P->n, b0, e0);
+    if (e0 > b0) svt_hip_lr_filter_frame_stripes(params, b0, e0, home);
+    close_call(*P, home);
+    return 0;
+}
+
+} // extern "C"

@@ -230,7 +230,7 @@ void svt_hip_lr_filter_frame_host(const SvtHipLrParams* params) {
     c.up(d_units, params->units, ub);
     P.data = d_data; P.dst = d_dst; P.boundary_above = d_above; P.boundary_below = d_below; P.units = d_units;
     P.stride = P.dst_stride = P.boundary_stride = (uint32_t)(pitch / px);
-    svt_hip_lr_filter_frame(&P, c.stream);
+    svthip::lr_frame_dispatch(&P, c.stream);
     c.down2d(params->dst, (size_t)params->dst_stride * px, d_dst, pitch, w * px, h);
 }
 

@@ -48,6 +48,9 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 
 #define SVT_LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
 
+struct SvtHipCdefParams;
+struct SvtHipLrParams;
+
 namespace svthip {
 
 constexpr int MAX_DEVICES = 16; // width of the per-device tables (host-call arenas, the lease pool)
@@ -107,5 +110,9 @@ int tuning_lr_rows_per_workgroup(); // SVT_HIP_LR_UR: 16 / 32 / 64, default 32
 int tuning_cdef_groups_per_workgroup(); // SVT_HIP_CDEF_GPW: 1 / 2 / 4, 0 = by frame size
 int tuning_sad_form(); // SVT_HIP_SAD_FORM: 0 (default: pair-per-wave forms) / 1 (strip form, measured slower): which independent-pairs SAD kernel runs
 int tuning_cdef_search_minb(); // SVT_HIP_CDEF_MINB: 3 (default) / 2: which register budget of the CDEF search kernel runs (A/B measurement)
+
+// frame launches of the picture-sized host forms: through the calling thread's frame partition when svt_hip_set_frame_partition named several devices (partition.hip)
+void cdef_frame_dispatch(int mode, const ::SvtHipCdefParams* P, hipStream_t st);
+void lr_frame_dispatch(const ::SvtHipLrParams* P, hipStream_t st);
 
 } // namespace svthip

@@ -531,6 +531,30 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind
     memcpy(d, s, n);
     return hipSuccess;
 }
+// a peer copy is LEGAL between devices: each pointer must belong to the device it is said to live on (a home-device pointer passed off as a peer's, or the other
+// way round, is the bug this catches); the stream may be either device's
+namespace hipemu {
+inline int device_of(const void* p) {
+    if (device_count() == 1 || !p) return cur_device();
+    std::lock_guard<std::mutex> g(alloc_lock());
+    auto it = allocs().upper_bound((uintptr_t)p);
+    if (it == allocs().begin()) return -1;
+    --it;
+    return (uintptr_t)p < it->first + it->second.n ? it->second.device : -1;
+}
+} // namespace hipemu
+inline hipError_t hipMemcpyPeerAsync(void* d, int dd, const void* s, int sd, size_t n, hipStream_t st = nullptr) {
+    // (memory the emulator did not allocate -- the tests' numpy arrays standing in for the home device's buffers -- has no owner and passes)
+    if (hipemu::device_count() > 1 && ((hipemu::device_of(d) >= 0 && hipemu::device_of(d) != dd) || (hipemu::device_of(s) >= 0 && hipemu::device_of(s) != sd))) {
+        fprintf(stderr, "hipemu: hipMemcpyPeerAsync: destination lives on device %d (said %d), source on device %d (said %d)\n", hipemu::device_of(d), dd, hipemu::device_of(s), sd);
+        abort();
+    }
+    if (st && ((hipemu::Stream*)st)->device != dd && ((hipemu::Stream*)st)->device != sd) { fprintf(stderr, "hipemu: hipMemcpyPeerAsync on a stream of a third device\n"); abort(); }
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t st = nullptr) {
     hipemu::check_stream(st, "hipMemcpy2DAsync"); hipemu::check_ptr(d, "hipMemcpy2DAsync"); hipemu::check_ptr(s, "hipMemcpy2DAsync");
     for (size_t y = 0; y < h; y++) memcpy((char*)d + y * dp, (const char*)s + y * sp, w);

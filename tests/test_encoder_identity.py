@@ -37,6 +37,8 @@ def _check(res):
         assert res["lrseam"]["units_searched"] > 0 and res["lrseam"]["pictures_offloaded"] > 0, res["lrseam"]
     if "seam" in res:  # the ME stage ran as one device call per picture for EVERY inter picture (a declined picture would run the reference's C code)
         assert res["seam"]["pictures_offloaded"] > 0 and res["seam"]["pictures_declined"] == 0, res["seam"]
+    if "strips" in res:  # the frame-partition case: frame launches of the in-loop filter host forms went through a partition
+        assert res["strips"]["frame_launches_through_a_partition"] > 0, res["strips"]
     if "devices" in res:  # one encode over several (emulated) GPUs: every device received stage calls
         assert len(res["devices"]) >= 2 and all(v > 0 for v in res["devices"].values()), res["devices"]
     if "tplseam" in res and res["case"].startswith(("tplseam_", "tiny_tplseam")):  # the TPL source-based statistics of every picture came from the device stage
@@ -56,7 +58,8 @@ def _check(res):
 @pytest.mark.parametrize("case", ["tiny_p8_8bit", "tiny_p8_10bit", "tiny_p8_lossless", "tiny_seam_p8", "tiny_seam_p5_lp2", "tiny_lrseam_p4", "tiny_cdefseam_p8", "tiny_dlfseam_p4", "tiny_tfseam_p8", "tiny_tfsubpel_p8", "tiny_tfdriver_p8", "tiny_tfdriver_p8_10bit", "tiny_tplseam_p8", "tiny_tplseam_p10", "tiny_dlfseam_sb_p8", "tiny_dlfseam_sb_p8_lp2", "tiny_2dev_everyseam_p8",
                                   "tiny_lowdelay_p8", "tiny_lowdelay_p10_10bit", "tiny_lowdelay_720p_tf",
                                   "tiny_screen_p8", "tiny_screen_lowdelay_p9",
-                                  "tiny_tplrecon_p8", "tiny_tplrecon_p10", "tiny_tiles_p8"])  # both halves of the TPL dispenser as device stages  # screen content: enable_me_sr_adjustment == 2  # low delay: level-0 HME areas from list-0 motion; the zero-motion temporal filter (on from 720p)
+                                  "tiny_tplrecon_p8", "tiny_tplrecon_p10", "tiny_tiles_p8",
+                                  "tiny_strips_cdef_lr_p4", "tiny_strips_cdef_lr_p8_10bit"])  # SVT_HIP_STRIPS: one picture's CDEF / LR launches over two emulated devices  # both halves of the TPL dispenser as device stages  # screen content: enable_me_sr_adjustment == 2  # low delay: level-0 HME areas from list-0 motion; the zero-motion temporal filter (on from 720p)
 def test_encoder_identity_emulator(case, tmp_path):
     from conftest import EmuBackend  # builds the emulator library if needed
     EmuBackend()

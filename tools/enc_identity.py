@@ -139,6 +139,9 @@ CASES = {
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
     # one encode over TWO (emulated) devices: SVT_HIP_DEVICES=0,1 shards the pictures by picture number; every seam at once
     "tiny_2dev_everyseam_p8": (128, 64, 12, 8, ["--preset", "8", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
+    # the frame-partition case from the C host: ONE picture's CDEF / loop-restoration launches cut into strips over two (emulated) devices (SVT_HIP_STRIPS)
+    "tiny_strips_cdef_lr_p4": (192, 136, 6, 8, ["--preset", "4", "--lp", "2", "+strips:0,1", "+lrseam", "+cdefseam"]),
+    "tiny_strips_cdef_lr_p8_10bit": (192, 136, 8, 10, ["--preset", "8", "--lp", "1", "+strips:0,1", "+lrseam", "+cdefseam"]),
     "tiny_2dev_everyseam_p4": (128, 128, 6, 8, ["--preset", "4", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "tiny_tplseam_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+tplseam"]),
     "tiny_tplrecon_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+tplseam", "+tplrecon"]),
@@ -299,6 +302,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     shard_file = os.path.join(outdir, name + "_devices.txt")
     if devices:
         env.update({"SVT_HIP_DEVICES": devices, "SVT_HIP_DEVICES_STATS": shard_file, "SVT_HIPEMU_DEVICES": str(len(devices.split(",")))})  # (the last one: emulator only)
+    strips = next((a[8:] for a in CASES[name][4] if a.startswith("+strips:")), None)
+    strips_file = os.path.join(outdir, name + "_strips.txt")
+    if strips:
+        env.update({"SVT_HIP_STRIPS": strips, "SVT_HIP_STRIPS_STATS": strips_file, "SVT_HIPEMU_DEVICES": str(len(strips.split(",")))})  # (the last one: emulator only)
     if (seam or lrseam or cdefseam or dlfseam or tplseam or tf_alone) and not with_hook and not only:
         only = "-"  # no RTCD pointer matches: the seam(s) alone
     if only:
@@ -379,6 +386,10 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
         st = dict(ln.split(None, 1) for ln in open(shard_file).read().splitlines()) if os.path.exists(shard_file) else {}
         res["devices"] = {k: int(v) for k, v in st.items()}
         res["identical"] = res["identical"] and len(res["devices"]) == len(devices.split(",")) and all(v > 0 for v in res["devices"].values())
+    if strips:  # frame launches really went through a partition of the listed devices
+        st = dict(ln.split(None, 1) for ln in open(strips_file).read().splitlines()) if os.path.exists(strips_file) else {}
+        res["strips"] = {k: int(v) for k, v in st.items()}
+        res["identical"] = res["identical"] and res["strips"].get("frame_launches_through_a_partition", 0) > 0
     if tplseam:
         st = dict(ln.split(None, 1) for ln in open(tplseam_file).read().splitlines()) if os.path.exists(tplseam_file) else {}
         res["tplseam"] = {k: int(float(v)) for k, v in st.items()}
