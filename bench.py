@@ -437,6 +437,30 @@ def encoder_fps():
                               "lr": r.get("lrseam")}}
 
 
+def attach_encoder_baselines(kernels, enc):
+    """The stage legs' CPU baseline of kind "reference": the reference's OWN functions with their AVX2 kernels, timed inside the reference encoder (oracle/_ref/enc_avx2,
+    no seam) by the thread CPU clock around the stage entries (integration/seam_cpu.h) over the encoder leg's 1080p preset-8 clip -- CPU milliseconds per picture the
+    stage handled, quoted as pictures per second of ONE host core.  (The one-core C restatements of oracle/ stay in the detail object as `cpu_baseline_port`: they are
+    the parity checkers, not the reference's CPU path.)"""
+    if not enc or not enc.get("stage_cpu_ms_per_frame") or not enc["stage_cpu_ms_per_frame"].get("avx2"):
+        return
+    ref, frames, st = enc["stage_cpu_ms_per_frame"]["avx2"], enc.get("frames") or 0, enc.get("stages_on_gpu") or {}
+    pics = {"tpl": (st.get("tpl") or {}).get("recon_pictures"), "tf": (st.get("tf_picture") or {}).get("pictures_filtered"), "me": (st.get("me") or {}).get("pictures_offloaded")}
+    for leg, stage, what in (("tpl_recon_stage_1080p8", "tpl", "tpl_mc_flow_dispenser + its per-SB calls (both halves of the dispenser; the leg times the reconstruction half)"),
+                             ("tpl_src_stage_1080p8", "tpl", "tpl_mc_flow_dispenser + its per-SB calls (both halves of the dispenser; the leg times the source-based half)"),
+                             ("tf_picture_stage_1080p8_4refs_host", "tf", "produce_temporally_filtered_pic, every segment"),
+                             ("tf_picture_stage_1080p8_4refs_resident", "tf", "produce_temporally_filtered_pic, every segment"),
+                             ("me_session_stage_1080p_host_preset8", "me", "svt_aom_motion_estimation_b64, every SB")):
+        k = kernels.get(leg)
+        if not isinstance(k, dict) or not pics.get(stage) or not ref.get(stage) or not frames:
+            continue
+        ms_per_picture = ref[stage] * frames / pics[stage]
+        if "cpu_baseline" in k:
+            k["cpu_baseline_port"] = k.pop("cpu_baseline")
+        k["cpu_baseline"] = {"value": 1e3 / ms_per_picture, "unit": "pictures/s per host core", "cores": 1, "kind": "reference", "cpu_ms_per_picture": ms_per_picture,
+                             "sample": "%s in oracle/_ref/enc_avx2 over the encoder leg's %d-frame 1080p preset-8 clip (%d pictures), thread CPU time" % (what, frames, pics[stage])}
+
+
 def cpu_tpl_recon_stage(k):
     """Checker + CPU baseline of the TPL reconstruction leg: oracle_tpl_recon_picture (one core) on the leg's whole picture; statistics and reconstruction plane must
     equal the device's."""
@@ -1374,6 +1398,7 @@ def main():
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if not a.only_me and not a.legs:
             out["encoder_fps_1080p_preset8"] = encoder_fps()
+            attach_encoder_baselines(kernels, out["encoder_fps_1080p_preset8"])
     elif rank == 0:
         out["cpu_baseline"] = None
     rf["traffic_source"] = (rf.get("traffic_detail") or {}).get("source")

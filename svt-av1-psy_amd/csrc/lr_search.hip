@@ -339,13 +339,14 @@ __host__ __device__ inline size_t lrs_dq_dwords(const int w, const int h) { retu
 // one packed dword per sample and parameter set plus one int16 per sample shared by all sets -- 4 + 2 bytes instead of 4 + 4 + 2 + 2 per sample and pass of
 // lr_sgr_proj_kernel, which re-reads its unit about nine times per parameter set (14 GB per 4K plane before, profiles/r02_reg7_pmc_traffic.json).
 template <bool COMPACT>
-__global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchParams P, int32_t* __restrict__ flt) {
+__global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchParams P, int32_t* __restrict__ flt, const int slot0 /* first parameter set of this group */) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
     uint16_t* tile = smem;
     uint16_t* A16  = tile + TH * TW;
     int32_t*  B32  = (int32_t*)((uint8_t*)A16 + LRS_A_BYTES);
     uint16_t* xlut = (uint16_t*)(B32 + 66 * 66);
-    const int tid = threadIdx.x, slot = blockIdx.z, idx = P.sg_start_ep + slot * P.sg_ep_inc, w = (int)P.width, h = (int)P.height;
+    // (slot = the set's place in the GROUP's buffers; the parameter set itself is slot0 + slot)
+    const int tid = threadIdx.x, slot = blockIdx.z, idx = P.sg_start_ep + (slot0 + slot) * P.sg_ep_inc, w = (int)P.width, h = (int)P.height;
     TileSrc s;
     s.data = P.dgd; s.above = s.below = nullptr; s.stride = (int)P.dgd_stride; s.bstride = 0; s.w = 0; s.h = 0; s.highbd = P.highbd;
     s.stripe_idx = 0; s.stripe_top = 0; s.stripe_bot = 0;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
                      const int    da = tile[(r + 3) * TW + c + 3], db = tile[(r + 3) * TW + c + 4];
                      q[o] = (uint32_t)((p0 ? f0a - (da << 4) : 0) & 0xffff) | ((uint32_t)(p1 ? f1a - (da << 4) : 0) << 16);
                      if (has1) q[o + 1] = (uint32_t)((p0 ? f0b - (db << 4) : 0) & 0xffff) | ((uint32_t)(p1 ? f1b - (db << 4) : 0) << 16);
-                     if (slot == 0) {
+                     if (slot0 + slot == 0) { // (shared by every set and group: written once)
                          const size_t so = (size_t)(y0 + r) * P.src_stride + x0 + c;
                          dq[o] = (int16_t)(da - rd_px(P.src, highbd, so));
                          if (has1) dq[o + 1] = (int16_t)(db - rd_px(P.src, highbd, so + 1));
@@ -483,12 +484,12 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
 }
 template <bool COMPACT>
 __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const int32_t* __restrict__ flt,
-                                                             SgResult* __restrict__ res, const int slots) {
+                                                             SgResult* __restrict__ res, const int slots, const int slot0) {
     __shared__ long long part[PROJ_W][16];
     __shared__ long long sh_t[5], sh_err;
     __shared__ long long sh_e[3][8]; // the candidate errors of a line (down, up, the first pass's up run): workgroup-uniform and indexed at run time -- LDS, not registers
     __shared__ int32_t   sh_xq[2];
-    const int        u = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x, idx = P.sg_start_ep + slot * P.sg_ep_inc, w = (int)P.width, h = (int)P.height;
+    const int        u = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x, idx = P.sg_start_ep + (slot0 + slot) * P.sg_ep_inc, w = (int)P.width, h = (int)P.height;
     const SvtHipRect r = rects[u];
     const int        npx = (r.h_end - r.h_start) * (r.v_end - r.v_start);
     // compact: f0 = the shared int16 plane (dgd - src), f1 = this parameter set's packed (q1, q2) plane
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
     if (tid == 0) {
         SgResult o;
         o.err = err; o.xqd[0] = xqd[0]; o.xqd[1] = xqd[1];
-        res[(size_t)u * slots + slot] = o;
+        res[(size_t)u * slots + slot0 + slot] = o;
     }
 }
 __global__ void lr_sgr_pick_kernel(const SvtHipLrSearchParams P, const SgResult* __restrict__ res, SvtHipLrSearchUnit* __restrict__ out, const int slots, const int n) {
@@ -639,6 +640,17 @@ inline int sg_slots(const SvtHipLrSearchParams& P) {
     if (!P.sg_enabled || P.sg_ep_inc == 0 || P.sg_end_ep <= P.sg_start_ep) return 0;
     return ((int)P.sg_end_ep - (int)P.sg_start_ep + (int)P.sg_ep_inc - 1) / (int)P.sg_ep_inc;
 }
+// The self-guided planes are kept for a GROUP of parameter sets at a time (the filter launch of a group, then its projection launch, in stream order): all 16
+// sets of a 4K plane were 1.06 GB of workspace.  Group size: as many sets as fit 192 MB, at least one.
+inline int sg_group(const SvtHipLrSearchParams& P, const int slots) {
+    if (slots <= 0) return 0;
+    const size_t per_set = (size_t)P.width * P.height * (P.bit_depth <= 10 ? 4 : 8);
+    size_t       g = per_set ? ((size_t)192 << 20) / per_set : (size_t)slots;
+    const char*  e = getenv("SVT_HIP_LR_SG_GROUP"); // (tests: force small groups on small planes; read per call -- a picture-sized stage)
+    if (e && atoi(e) > 0) g = (size_t)atoi(e);
+    g = g < 1 ? 1 : g;
+    return (int)(g < (size_t)slots ? g : (size_t)slots);
+}
 inline size_t carve(const SvtHipLrSearchParams& P, void* base, Ws* ws) {
     const size_t n = (size_t)n_units_1d((int)P.height, (int)P.unit_size) * n_units_1d((int)P.width, (int)P.unit_size), slots = (size_t)sg_slots(P);
     size_t       off = 0;
@@ -651,7 +663,9 @@ inline size_t carve(const SvtHipLrSearchParams& P, void* base, Ws* ws) {
     w.H = (long long*)take(n * 49 * 49 * 8);
     w.sg = (SgResult*)take(n * (slots ? slots : 1) * sizeof(SgResult));
     w.counter = (int32_t*)take(256);
-    w.flt = (int32_t*)take(slots * 2 * (size_t)P.width * P.height * 4);
+    const size_t group = (size_t)sg_group(P, (int)slots), wh = (size_t)P.width * P.height;
+    // <= 10 bit: one int16 plane (dgd - src) shared by every set + one packed dword plane per set of the group; 12 bit: two int32 planes per set of the group
+    w.flt = (int32_t*)take(P.bit_depth <= 10 ? (lrs_dq_dwords((int)P.width, (int)P.height) + group * wh) * 4 : group * 2 * wh * 4);
     if (ws) *ws = w;
     return off;
 }
@@ -699,13 +713,17 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
         if (active > 0) return -2; // the lock-step cap was hit with units still searching: their sse[1] is not final -- the caller must not use this plane's result
     }
     if (P.sg_enabled && slots > 0) {
-        const dim3 fgrid(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, slots);
-        if (P.bit_depth <= 10) { // int16 differences (see lr_sgr_flt_kernel); 12-bit keeps the int32 planes
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, st, P, W.flt);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, slots), dim3(PROJ_T), 0, st, P, W.rects, W.flt, W.sg, slots);
-        } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, st, P, W.flt);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, slots), dim3(PROJ_T), 0, st, P, W.rects, W.flt, W.sg, slots);
+        const int group = sg_group(P, slots);
+        for (int s0 = 0; s0 < slots; s0 += group) { // a group's planes are overwritten by the next group's filter launch: stream order keeps the projection before it
+            const int  gs = slots - s0 < group ? slots - s0 : group;
+            const dim3 fgrid(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, gs);
+            if (P.bit_depth <= 10) { // int16 differences (see lr_sgr_flt_kernel); 12-bit keeps the int32 planes
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, st, P, W.flt, s0);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, gs), dim3(PROJ_T), 0, st, P, W.rects, W.flt, W.sg, slots, s0);
+            } else {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, st, P, W.flt, s0);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, gs), dim3(PROJ_T), 0, st, P, W.rects, W.flt, W.sg, slots, s0);
+            }
         }
         hipLaunchKernelGGL(lr_sgr_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.sg, units, slots, n);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<2>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
