@@ -641,15 +641,17 @@ inline int sg_slots(const SvtHipLrSearchParams& P) {
     return ((int)P.sg_end_ep - (int)P.sg_start_ep + (int)P.sg_ep_inc - 1) / (int)P.sg_ep_inc;
 }
 // The self-guided planes are kept for a GROUP of parameter sets at a time (the filter launch of a group, then its projection launch, in stream order): all 16
-// sets of a 4K plane were 1.06 GB of workspace.  Group size: as many sets as fit 192 MB, at least one.
+// sets of a 4K plane were 1.06 GB of workspace.  Group size: as many sets as fit 240 MB, at least one, then evened out over the groups
+// (16 sets of a 4K 10-bit plane: 6 + 6 + 4, 216 MB; four groups of four cost 11 % of the stage's time, profiles/r04_call4_*).
 inline int sg_group(const SvtHipLrSearchParams& P, const int slots) {
     if (slots <= 0) return 0;
     const size_t per_set = (size_t)P.width * P.height * (P.bit_depth <= 10 ? 4 : 8);
-    size_t       g = per_set ? ((size_t)192 << 20) / per_set : (size_t)slots;
+    size_t       g = per_set ? ((size_t)240 << 20) / per_set : (size_t)slots;
     const char*  e = getenv("SVT_HIP_LR_SG_GROUP"); // (tests: force small groups on small planes; read per call -- a picture-sized stage)
     if (e && atoi(e) > 0) g = (size_t)atoi(e);
-    g = g < 1 ? 1 : g;
-    return (int)(g < (size_t)slots ? g : (size_t)slots);
+    g = g < 1 ? 1 : (g < (size_t)slots ? g : (size_t)slots);
+    const size_t groups = ((size_t)slots + g - 1) / g;
+    return (int)(((size_t)slots + groups - 1) / groups);
 }
 inline size_t carve(const SvtHipLrSearchParams& P, void* base, Ws* ws) {
     const size_t n = (size_t)n_units_1d((int)P.height, (int)P.unit_size) * n_units_1d((int)P.width, (int)P.unit_size), slots = (size_t)sg_slots(P);

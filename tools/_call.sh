@@ -1,19 +1,15 @@
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-.}
 ulimit -c 0
-O=gpurun_out/r04_call3; mkdir -p $O
-timeout 600 python -m pytest tests/test_tpl.py -q -m gpu > $O/pytest_tpl.txt 2>&1; tail -3 $O/pytest_tpl.txt
-timeout 600 python bench.py --steps 20 --warmup 5 --legs tpl > $O/bench_tpl.json 2> $O/bench_tpl.err; echo "tpl rc=$?"; grep -v BENCH_DETAIL $O/bench_tpl.err | tail -5
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/bench_detail.json'))
-k=d['kernels']['tpl_recon_stage_1080p8']; print({x:k[x] for x in k if x.endswith('_us') or x in ('us','intra_blocks','blocks_16x16')}); print(k['roofline'])
-PY
-E="python tools/enc_identity.py --host avx2 --out /tmp/idt"
-echo "== tplrecon, cpu stats (default sync)"; timeout 300 $E --case fps_1080p_p8_all_tplrecon --cpu-stats > $O/enc_tplrecon.log 2>&1; grep -a "identical=\|encoder fps\|stage CPU" $O/enc_tplrecon.log | cut -c1-420
-echo "== fps repeated x4 (default, block)"; for i in 1 2 3 4; do timeout 200 $E --case fps_1080p_p8_all_tplrecon 2>&1 | grep -a "encoder fps"; SVT_HIP_SYNC=block timeout 200 $E --case fps_1080p_p8_all_tplrecon 2>&1 | grep -a "encoder fps"; done
-echo "== instances 4 (default, block)"
-timeout 300 $E --case fps_1080p_p8_all_tplrecon --instances 4; SVT_HIP_SYNC=block timeout 300 $E --case fps_1080p_p8_all_tplrecon --instances 4
-echo "== 300 frames x2"; for i in 1 2; do timeout 300 $E --case fps_1080p_p8_all_tplrecon_300 2>&1 | grep -a "encoder fps"; done
-echo "== avx512 host"; timeout 300 python tools/enc_identity.py --host avx512 --out /tmp/idt --case fps_1080p_p8_all_tplrecon --cpu-stats 2>&1 | grep -a "identical=\|encoder fps\|stage CPU" | cut -c1-420
-echo "== full regression"
-timeout 1500 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt
+O=gpurun_out/r04_call4; mkdir -p $O
+# the default line as the driver runs it, then the strips line, then the kernel statistics of the default workload
+timeout 1200 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo "default rc=$? bytes=$(wc -c < $O/bench_default.json)"
+grep -v BENCH_DETAIL $O/bench_default.err | tail -8
+cp gpurun_out/bench_detail.json $O/bench_detail.json 2>/dev/null
+cat $O/bench_default.json
+timeout 600 python bench.py --steps 20 --warmup 5 --mode strips --no-cpu --no-pmc --legs none > $O/bench_strips.json 2> $O/bench_strips.err; echo "strips rc=$? bytes=$(wc -c < $O/bench_strips.json)"; cat $O/bench_strips.json
+P="--steps 20 --warmup 5 --no-cpu --no-parity-check --no-pmc"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py $P > $O/stats.log 2>&1
+python tools/pmc_summary.py r04_call4 $O/stats - - "python bench.py $P" > /dev/null 2>&1 && mv profiles/r04_call4_kernel_stats.txt $O/kernel_stats.txt
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; rm -rf $O/stats
+head -40 $O/kernel_stats.txt | cut -c1-150
+timeout 300 python -m pytest tests/test_partition.py tests/test_lr_search.py -q -m gpu > $O/pytest_part_lr.txt 2>&1; tail -2 $O/pytest_part_lr.txt
