@@ -407,7 +407,7 @@ def encoder_fps():
         have_512 = os.path.exists(ei.ENC_AVX512) and cpu_has(*AVX512)
         r512 = ei.run_case(CASE, lib, td, timeout=600, host="avx512") if have_512 else {}
         # K concurrent encodes sharing this GPU on the box's host cores: aggregate fps and host CPU seconds per frame, AVX2 host alone vs with the stages
-        inst = ei.run_instances(CASE, lib, td, 4, host="avx2", timeout=600) if have_x else {}
+        inst = ei.run_instances(CASE + "_300", lib, td, 4, host="avx2", timeout=900) if have_x else {}  # (300 frames: a 60-frame encode is over in 0.5 s, less than a process's start-up)
         # thread CPU time per stage (integration/seam_cpu.h), a run of its own: the brackets cost two clock reads per SB in the ME stage
         rcpu = ei.run_case(CASE, lib, td, timeout=600, host="avx2", cpu_stats=True) if have_x else {}
     if not r.get("identical") or not rc_.get("identical") or (r300 and not r300.get("identical")) or (r512 and not r512.get("identical")) or (inst and not inst.get("identical")):
@@ -419,7 +419,7 @@ def encoder_fps():
             "fps_avx512_intrinsics": r512.get("fps_avx512"), "fps_avx512_host_with_stage_seams": r512.get("fps_hip"),
             # user + system CPU seconds of the whole encoder process per frame (RUSAGE_CHILDREN): what the offload takes off the host
             "host_cpu_s_per_frame": dict(r.get("host_cpu_s_per_frame") or {}, **{k: v for k, v in (r512.get("host_cpu_s_per_frame") or {}).items() if k != "c"}),
-            "instances": {"k": inst.get("instances"), "fps_avx2": inst.get("fps_avx2"), "fps_avx2_with_stages": inst.get("fps_avx2_with_stages"),
+            "instances": {"k": inst.get("instances"), "frames_each": inst.get("frames"), "fps_avx2": inst.get("fps_avx2"), "fps_avx2_with_stages": inst.get("fps_avx2_with_stages"),
                           "fps_sum_of_encoder_reports_avx2": inst.get("fps_sum_of_encoder_reports_avx2"),
                           "fps_sum_of_encoder_reports_avx2_with_stages": inst.get("fps_sum_of_encoder_reports_avx2_with_stages"),
                           "cpu_s_per_frame_avx2": inst.get("host_cpu_s_per_frame_avx2"), "cpu_s_per_frame_avx2_with_stages": inst.get("host_cpu_s_per_frame_avx2_with_stages"),

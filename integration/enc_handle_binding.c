@@ -73,6 +73,8 @@ void svt_hip_seam_cpu_add(int stage, unsigned long long ns) {
     __atomic_fetch_add(&SVT_HIP_CPU.calls[stage], 1, __ATOMIC_RELAXED);
 }
 
+#include <time.h>
+static double svt_hip_ms_now(void) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); return 1e3 * (double)t_.tv_sec + 1e-6 * (double)t_.tv_nsec; }
 static unsigned long long (*SVT_HIP_STRIPS_CALLS)(void);
 static void svt_hip_strips_stats(void) {
     const char *f = getenv("SVT_HIP_STRIPS_STATS");
@@ -86,8 +88,11 @@ static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
     const char *dev = getenv("SVT_HIP");
     if (!dev)
         return;
+    const int    timing = getenv("SVT_HIP_INIT_TIMING") != NULL; /* one-time costs of the binding, phase by phase, to stderr */
+    const double t_a = svt_hip_ms_now();
     const char *path = getenv("SVT_HIP_LIB");
     void       *h    = dlopen(path ? path : "libsvtav1_hip.so", RTLD_NOW | RTLD_GLOBAL);
+    const double t_b = svt_hip_ms_now();
     if (!h) {
         fprintf(stderr, "SVT_HIP: cannot load the HIP variant: %s\n", dlerror());
         abort(); /* no silent CPU fallback: the identity check must not pass on the C kernels */
@@ -99,8 +104,10 @@ static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
         abort();
     }
     /* one-time costs now, while the encoder is still initialising, not inside the first picture's stage call: the device context, the library's code objects */
+    const double t_c = svt_hip_ms_now();
     void (*warmup)(void) = (void (*)(void))dlsym(h, "svt_hip_warmup");
     if (warmup) warmup();
+    if (timing) fprintf(stderr, "SVT_HIP_INIT_TIMING: dlopen %.1f ms, svt_hip_init (device context) %.1f ms, warm-up (code objects, first arenas) %.1f ms\n", t_b - t_a, t_c - t_b, svt_hip_ms_now() - t_c);
     const char *list = getenv("SVT_HIP_DEVICES");
     if (list && *list) {
         int (*count)(void) = (int (*)(void))dlsym(h, "svt_hip_device_count");
@@ -149,7 +156,10 @@ static void svt_hip_after_enc_init(EbEncHandle *h) {
     if (!getenv("SVT_HIP") || !getenv("SVT_HIP_ME_SEAM") || !h || !h->pa_reference_picture_pool_ptr_array) return;
     EbSystemResource *pool = h->pa_reference_picture_pool_ptr_array[0];
     if (!pool || !pool->object_total_count || !pool->wrapper_ptr_pool || !pool->wrapper_ptr_pool[0]) return;
+    const int    timing = getenv("SVT_HIP_INIT_TIMING") != NULL;
+    const double t_a = svt_hip_ms_now();
     svt_hip_seam_me_prepare(pool->wrapper_ptr_pool[0]->object_ptr);
+    const double t_b = svt_hip_ms_now();
     /* the 8-bit luma planes every ME stage call uploads (the y8b pool of :1781-1796; pa_ref->input_padded_pic->buffer_y points into it): page-locked once, here */
     EbSystemResource *y8b = h->input_y8b_buffer_resource_ptr;
     for (uint32_t i = 0; y8b && y8b->wrapper_ptr_pool && i < y8b->object_total_count; i++) {
@@ -163,6 +173,7 @@ static void svt_hip_after_enc_init(EbEncHandle *h) {
         const EbTplReferenceObject *o = tpl->wrapper_ptr_pool[i] ? (const EbTplReferenceObject *)tpl->wrapper_ptr_pool[i]->object_ptr : NULL;
         if (o && o->ref_picture_ptr && o->ref_picture_ptr->buffer_y) svt_hip_seam_me_register_buffer(o->ref_picture_ptr->buffer_y, o->ref_picture_ptr->luma_size);
     }
+    if (timing) fprintf(stderr, "SVT_HIP_INIT_TIMING: ME session(s) %.1f ms, page-locking the luma / TPL pools %.1f ms\n", t_b - t_a, svt_hip_ms_now() - t_b);
 }
 /* ... and the page locks are released at the start of svt_av1_enc_deinit (enc_handle.c:2364: its first svt_shutdown_process call; queues are drained by then), before
  * svt_av1_enc_deinit_handle destroys the pool that owns the buffers. */
