@@ -190,7 +190,7 @@ static int sum_slot(int di, uint64_t id, int make) {
 static int ensure_resident(int di, uint64_t id, const EbPictureBufferDesc *pic, const SvtHipMeStageParams *S, uint64_t now) {
     const int k = sum_slot(di, id, 1);
     if (abi.resident(G.session[di], (int64_t)id)) {
-        if (G.sum[di][k][1] == now) return 0;
+        if (seam_hash <= 0 || G.sum[di][k][1] == now) return 0; /* (without the checksum aid a resident picture is current: invalidation is explicit) */
         abi.invalidate(G.session[di], (int64_t)id); /* e.g. temporally filtered in place after it was uploaded */
         G.n_reuploads++;
     }
@@ -410,7 +410,7 @@ static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *
     if (!rc) {
         /* the source: (re)uploaded when its content differs from what is resident (the same picture may have served as a reference before its own ME) */
         const int ks = sum_slot(di, SEAM_ID(pcs), 1);
-        if (abi.resident(ses, (int64_t)SEAM_ID(pcs)) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)SEAM_ID(pcs)); G.n_reuploads++; }
+        if (seam_hash > 0 && abi.resident(ses, (int64_t)SEAM_ID(pcs)) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)SEAM_ID(pcs)); G.n_reuploads++; }
         if (!abi.resident(ses, (int64_t)SEAM_ID(pcs))) G.n_uploads++;
         G.sum[di][ks][1] = now;
         slot = abi.submit_stage(ses, (int64_t)SEAM_ID(pcs), src->buffer_y, ref_ids, n_refs, &S, &H);
@@ -583,7 +583,7 @@ static int run_tf_pair(SeamTfPair *T, PictureParentControlSet *pcs, MeContext *c
     }
     if (!rc) {
         const int ks = sum_slot(di, SEAM_ID(pcs), 1);
-        if (abi.resident(ses, (int64_t)SEAM_ID(pcs)) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)SEAM_ID(pcs)); G.n_reuploads++; }
+        if (seam_hash > 0 && abi.resident(ses, (int64_t)SEAM_ID(pcs)) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)SEAM_ID(pcs)); G.n_reuploads++; }
         if (!abi.resident(ses, (int64_t)SEAM_ID(pcs))) G.n_uploads++;
         G.sum[di][ks][1] = now;
         slot = abi.submit_stage(ses, (int64_t)SEAM_ID(pcs), src->buffer_y, ref_ids, 1, &S, &H);

@@ -146,8 +146,8 @@ CASES = {
     # one encode over TWO (emulated) devices: SVT_HIP_DEVICES=0,1 shards the pictures by picture number; every seam at once
     "tiny_2dev_everyseam_p8": (128, 64, 12, 8, ["--preset", "8", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
     # the frame-partition case from the C host: ONE picture's CDEF / loop-restoration launches cut into strips over two (emulated) devices (SVT_HIP_STRIPS)
-    "tiny_strips_cdef_lr_p4": (192, 136, 6, 8, ["--preset", "4", "--lp", "2", "+strips:0,1", "+lrseam", "+cdefseam"]),
-    "tiny_strips_cdef_lr_p8_10bit": (192, 136, 8, 10, ["--preset", "8", "--lp", "1", "+strips:0,1", "+lrseam", "+cdefseam"]),
+    "tiny_strips_cdef_lr_p4": (128, 136, 3, 8, ["--preset", "4", "--lp", "2", "+strips:0,1", "+lrseam", "+cdefseam"]),
+    "tiny_strips_cdef_lr_p8_10bit": (128, 136, 4, 10, ["--preset", "8", "--lp", "1", "+strips:0,1", "+lrseam", "+cdefseam"]),
     "tiny_2dev_everyseam_p4": (128, 128, 6, 8, ["--preset", "4", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "tiny_tplseam_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+tplseam"]),
     "tiny_tplrecon_p8": (192, 128, 18, 8, ["--preset", "8", "--lp", "1", "+tplseam", "+tplrecon"]),
