@@ -984,7 +984,54 @@ def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
     cols16, rows16 = (P.aligned_width + 15) // 16, (((P.height + 7) & ~7) + 15) // 16
     alg = n_blk * (3 * 256 + 80)  # per block: source, prediction (reference or neighbours), reconstruction, the two statistics records
     n_dc = int(np.sum((src["best_mode"] == 0) & (src["written"] > 0)))
-    return {"tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "form": "5: one launch, one wave per block, dependencies as data, release / acquire fences (csrc/tpl.hip tpl_recon_dep_kernel)",
+    # both halves as ONE host call from page-locked host pictures (svt_hip_tpl_stage_host: what the encoder seam calls; the reference's pools are page-locked at init):
+    # source + 4 source references + 4 reconstruction references uploaded, statistics of both halves and the written rectangle downloaded -- wall clock, PCIe inclusive
+    import time as _t
+
+    class HostPlanes(C.Structure):
+        _fields_ = [("src_buf", C.c_void_p), ("src_rows", C.c_uint32), ("ref_rows", C.c_uint32 * 8), ("ref_buf", C.c_void_p * 8)]
+    psize = rows * stride
+    pinned = [lib.svt_hip_host_alloc(psize) for _ in range(planes.shape[0] * 2 - 1)]  # the source, its references, and copies standing for their TPL reconstructions
+    for k in range(planes.shape[0]):
+        C.memmove(pinned[k], planes[k].ctypes.data, psize)
+        if k:
+            C.memmove(pinned[planes.shape[0] + k - 1], planes[k].ctypes.data, psize)
+    rec_pin = lib.svt_hip_host_alloc(psize)
+    SP, RP = HostPlanes(), HostPlanes()
+    RF = pkg.TplReconParams.from_buffer_copy(R)
+    SP.src_buf, SP.src_rows = pinned[0], rows
+    for r in range(8):
+        if P.refs[r].valid:
+            k = P.refs[r].plane_off // psize
+            SP.ref_buf[r], SP.ref_rows[r] = pinned[k], rows
+            RP.ref_buf[r], RP.ref_rows[r] = pinned[planes.shape[0] + k - 1], rows
+            RF.rec_refs[r].plane_off = 0
+            RF.src.refs[r].plane_off = 0
+    tot, mvs, cand = keep["tot"], keep["mvs"], keep["cand"]
+    h_src, h_out = np.zeros(keep["cells"], src.dtype), np.zeros(keep["cells"], pkg.TplReconStats)
+    vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+
+    def fused():
+        assert lib.svt_hip_tpl_stage_host(C.addressof(RF), C.addressof(SP), C.addressof(RP), vp(tot), vp(mvs), vp(cand), vp(h_src), rec_pin, rows, vp(h_out)) == 0
+    t_fused = regions.hook(fused, name="tpl_stage_host")
+    if t_fused is None:
+        for _ in range(2):
+            fused()
+        t0 = _t.perf_counter()
+        for _ in range(10):
+            fused()
+        t_fused = (_t.perf_counter() - t0) / 10
+    fused_ok = all(np.array_equal(h_out[f], forms[5][2][f]) for f in ("srcrf_dist", "recrf_dist", "written", "coded")) and np.array_equal(h_src["srcrf_dist"], src["srcrf_dist"])
+    if not fused_ok:
+        raise SystemExit("bench: svt_hip_tpl_stage_host differs from the two device stages -- no numbers recorded")
+    for q in pinned + [rec_pin]:
+        lib.svt_hip_host_free(q)
+    up_mb = (planes.shape[0] * 2 - 1) * psize / 1e6
+    return {"tpl_stage_host_1080p8": {"ms": t_fused * 1e3, "pictures_per_s": 1 / t_fused, "uploaded_MB": up_mb, "pcie_inclusive": True, "equals_device_stages": True,
+                                      "roofline": {"bound": "pcie", "achieved": up_mb * 1e6 / t_fused / 1e9, "peak": 64.0, "unit": "GB/s", "frac": up_mb * 1e6 / t_fused / 1e9 / 64.0,
+                                                   "kernel_us": t_fused * 1e6, "binds": "pcie", "algorithmic_bytes_per_launch": up_mb * 1e6},
+                                      "note": "both halves of the TPL dispenser in one host call from page-locked pictures (9 planes up), wall clock"},
+            "tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "form": "5: one launch, one wave per block, dependencies as data, release / acquire fences (csrc/tpl.hip tpl_recon_dep_kernel)",
                                         "sequentially_consistent_fences_form_us": forms[4][0] * 1e6, "anti_diagonal_launches_form_us": forms[0][0] * 1e6,
                                         "row_wavefront_form_us": forms[1][0] * 1e6, "row_wavefront_xcd_chunks_form_us": forms[2][0] * 1e6,
                                         "row_wavefront_release_acquire_form_us": forms[3][0] * 1e6, "blocks_16x16": n_blk, "intra_blocks": n_dc,
