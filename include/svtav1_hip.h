@@ -1093,6 +1093,21 @@ int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams *params, const SvtHi
 int svt_hip_tpl_stage_host(const SvtHipTplReconParams *params, const SvtHipTplHostPlanes *src_planes, const SvtHipTplHostPlanes *rec_planes,
                            const uint8_t *total_me_candidate_index, const uint32_t *me_mv_array, const uint8_t *me_candidate_array, SvtHipTplSrcStats *src_stats,
                            uint8_t *recon_buf, uint32_t recon_rows, SvtHipTplReconStats *out);
+/* The same with the planes kept RESIDENT on the device across calls.  ids names the CONTENT of every buffer (0 = do not keep): a buffer found under its (pointer, id)
+ * is not uploaded again, an uploaded one stays for later calls, and the reconstruction this call produces stays under (recon_buf, ids->recon) with its borders
+ * replicated as svt_aom_generate_padding replicates the host copy's after the dispenser (recon_width / height / org: the reconstruction picture's geometry).  A picture
+ * of a TPL group is the source of one call and a reference of several others: with ids a call uploads one new plane instead of up to nine.
+ * total_me_candidate_index == NULL: the source-based statistics are the CALLER's (src_stats is an input: an earlier TPL group's, src_ops_process.c:969-977) and only
+ * the reconstruction half runs.  svt_hip_tpl_plane_drop(buffer): the host rewrote that buffer by other means -- forget what the device holds of it. */
+typedef struct SvtHipTplPlaneIds {
+    uint64_t src, src_ref[8], rec_ref[8], recon;
+    uint32_t recon_width, recon_height, recon_org_x, recon_org_y;
+} SvtHipTplPlaneIds;
+int  svt_hip_tpl_stage_host_resident(const SvtHipTplReconParams *params, const SvtHipTplHostPlanes *src_planes, const SvtHipTplHostPlanes *rec_planes,
+                                     const SvtHipTplPlaneIds *ids, const uint8_t *total_me_candidate_index, const uint32_t *me_mv_array, const uint8_t *me_candidate_array,
+                                     SvtHipTplSrcStats *src_stats, uint8_t *recon_buf, uint32_t recon_rows, SvtHipTplReconStats *out);
+void svt_hip_tpl_plane_drop(const void *host_buffer);
+void svt_hip_tpl_plane_counts(uint64_t *hits, uint64_t *misses); /* resident-plane look-ups of the calling thread's device so far */
 
 /* ---- ONE picture over several GPUs from a C host (the frame-partition case; csrc/partition.hip) ----
  * devices[0] = the HOME device: every pointer of the calls below lives there and `stream` belongs to it.  Each call is the batched primitive of the same name cut

@@ -63,8 +63,11 @@ static struct {
     double   ms_stage;
     int      recon; /* SVT_HIP_TPL_RECON_SEAM */
     int (*recon_host)(const SvtHipTplReconParams *, const SvtHipTplHostPlanes *, const SvtHipTplSrcStats *, uint8_t *, uint32_t, SvtHipTplReconStats *);
-    int (*fused_host)(const SvtHipTplReconParams *, const SvtHipTplHostPlanes *, const SvtHipTplHostPlanes *, const uint8_t *, const uint32_t *, const uint8_t *,
-                      SvtHipTplSrcStats *, uint8_t *, uint32_t, SvtHipTplReconStats *); /* both halves in one call (svt_hip_tpl_stage_host) */
+    int (*fused_host)(const SvtHipTplReconParams *, const SvtHipTplHostPlanes *, const SvtHipTplHostPlanes *, const SvtHipTplPlaneIds *, const uint8_t *, const uint32_t *,
+                      const uint8_t *, SvtHipTplSrcStats *, uint8_t *, uint32_t, SvtHipTplReconStats *); /* both halves (or the second alone) in one call, planes kept resident
+                                                                                                          * on the device across calls (svt_hip_tpl_stage_host_resident) */
+    void (*plane_drop)(const void *);
+    void (*plane_counts)(uint64_t *, uint64_t *);
     uint64_t n_recon_pictures, n_recon_blocks, n_recon_coded, n_sb_calls_skipped, n_fused;
     double   ms_recon;
     PictureParentControlSet *done[16]; /* pictures whose blocks were reconstructed on the device: the per-SB function has nothing left to do */
@@ -77,6 +80,11 @@ static void tpl_seam_stats(void) {
     fprintf(o, "pictures_offloaded %llu\nblocks %llu\nblocks_newmv %llu\npictures_declined %llu\npictures_with_stored_statistics %llu\nms_in_stage_calls %.0f\n",
             (unsigned long long)TS.n_pictures, (unsigned long long)TS.n_blocks, (unsigned long long)TS.n_newmv, (unsigned long long)TS.n_declined,
             (unsigned long long)TS.n_reused, TS.ms_stage);
+    if (TS.recon && TS.plane_counts) {
+        uint64_t h_ = 0, m_ = 0;
+        TS.plane_counts(&h_, &m_);
+        fprintf(o, "planes_found_resident %llu\nplanes_uploaded %llu\n", (unsigned long long)h_, (unsigned long long)m_);
+    }
     if (TS.recon)
         fprintf(o, "recon_pictures %llu\nrecon_blocks %llu\nrecon_blocks_coded %llu\nsb_calls_skipped %llu\nms_in_recon_stage_calls %.0f\npictures_both_halves_in_one_call %llu\n", (unsigned long long)TS.n_recon_pictures,
                 (unsigned long long)TS.n_recon_blocks, (unsigned long long)TS.n_recon_coded, (unsigned long long)TS.n_sb_calls_skipped, TS.ms_recon, (unsigned long long)TS.n_fused);
@@ -93,7 +101,9 @@ static void tpl_seam_init(void) {
     const char *r = getenv("SVT_HIP_TPL_RECON_SEAM");
     if (r && atoi(r)) {
         *(void **)&TS.recon_host = dlsym(RTLD_DEFAULT, "svt_hip_tpl_recon_stage_host");
-        *(void **)&TS.fused_host = dlsym(RTLD_DEFAULT, "svt_hip_tpl_stage_host");
+        *(void **)&TS.fused_host = dlsym(RTLD_DEFAULT, "svt_hip_tpl_stage_host_resident");
+        *(void **)&TS.plane_drop = dlsym(RTLD_DEFAULT, "svt_hip_tpl_plane_drop");
+        *(void **)&TS.plane_counts = dlsym(RTLD_DEFAULT, "svt_hip_tpl_plane_counts");
         if (!TS.recon_host) { fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: libsvtav1_hip is not loaded\n"); abort(); }
         fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: the reconstruction half of the TPL dispenser runs as a device stage per picture too\n");
         TS.recon = 1;
@@ -130,6 +140,35 @@ static void seam_tpl_sb(TPL_SB_ARGS) {
     tpl_mc_flow_dispenser_sb_generic_use0(TPL_SB_PASS);
 }
 
+/* The CONTENT id of a TPL reconstruction buffer: a picture's reconstruction is made again in a later TPL group (other quantizer, other references) into a buffer that may
+ * be the same one, so (picture number) alone does not name what a buffer holds -- a device that mirrored the first version would serve it for the second (seen as a
+ * bitstream difference with two devices: the rewriting device refreshes its own copy, the other one kept the old upload).  Every reconstruction the seam produces gets a
+ * fresh serial; references look their buffer's current serial up; a buffer the seam did not write (a reference outside the sliding window, a declined picture) has none
+ * and is uploaded per call. */
+static struct { const void *buf; uint64_t id; } tpl_rec_ids[64];
+static uint64_t tpl_rec_serial;
+static uint64_t tpl_rec_id(const void *buf, int fresh) { /* (TS.lock is not held by the callers) */
+    uint64_t id = 0;
+    pthread_mutex_lock(&TS.lock);
+    int slot = -1, spare = -1;
+    for (int i = 0; i < 64; i++) {
+        if (tpl_rec_ids[i].buf == buf) slot = i;
+        if (!tpl_rec_ids[i].buf && spare < 0) spare = i;
+    }
+    if (fresh) {
+        if (slot < 0) slot = spare >= 0 ? spare : (int)(tpl_rec_serial % 64);
+        tpl_rec_ids[slot].buf = buf;
+        tpl_rec_ids[slot].id  = id = (++tpl_rec_serial << 20) | 0x80000; /* (never equal to a picture number + 1 used for source planes of the same buffer address) */
+    } else if (slot >= 0) id = tpl_rec_ids[slot].id;
+    pthread_mutex_unlock(&TS.lock);
+    return id;
+}
+static void tpl_rec_forget(const void *buf) {
+    pthread_mutex_lock(&TS.lock);
+    for (int i = 0; i < 64; i++)
+        if (tpl_rec_ids[i].buf == buf) { tpl_rec_ids[i].buf = NULL; tpl_rec_ids[i].id = 0; }
+    pthread_mutex_unlock(&TS.lock);
+}
 /* the reconstruction half of a whole picture on the device (src_ops_process.c:979-1198); st = the source-based statistics of every cell.  0 = done */
 /* fused != NULL: the source-based half runs in the same call (svt_hip_tpl_stage_host) -- fused = the source half's host planes, tot / mvs / cand its ME tables, and
  * st receives the statistics instead of supplying them */
@@ -161,8 +200,24 @@ static int tpl_recon_picture(EncodeContext *enc_ctx, SequenceControlSet *scs, Pi
         }
     SvtHipTplReconStats *out = malloc((size_t)cells * sizeof(*out));
     const double t0 = now_ms();
-    const int    rc = fused ? TS.fused_host(&R, fused, &H, tot, mvs, cand, st, rec->buffer_y, rec->luma_size / rec->stride_y, out)
-                            : TS.recon_host(&R, &H, st, rec->buffer_y, rec->luma_size / rec->stride_y, out);
+    /* the content of every buffer, by picture number: a picture of a TPL group is the source of one call and a reference of several others, and its TPL reconstruction
+     * is produced on the device -- named, they stay there (one upload per call instead of up to nine) */
+    SvtHipTplPlaneIds ids;
+    SvtHipTplHostPlanes S;
+    memset(&ids, 0, sizeof(ids));
+    memset(&S, 0, sizeof(S));
+    if (fused) S = *fused;
+    else { S.src_buf = inp->buffer_y; S.src_rows = inp->luma_size / inp->stride_y; } /* the reconstruction half alone (stored statistics): the source is still read, its references are not */
+    ids.src = pcs->picture_number + 1;
+    for (int i = 0; i < 8; i++)
+        if (P->refs[i].valid) { ids.src_ref[i] = fused ? P->refs[i].picture_number + 1 : 0; ids.rec_ref[i] = tpl_rec_id(H.ref_buf[i], 0); }
+    ids.recon = tpl_rec_id(rec->buffer_y, 1);
+    ids.recon_width = rec->width; ids.recon_height = rec->height; ids.recon_org_x = rec->org_x; ids.recon_org_y = rec->org_y;
+    static int resident = -1; /* SVT_HIP_TPL_RESIDENT=0: every call uploads its planes again (A/B and bisecting aid) */
+    if (resident < 0) { const char *e_ = getenv("SVT_HIP_TPL_RESIDENT"); resident = !(e_ && !atoi(e_)); }
+    const int    rc = TS.fused_host ? TS.fused_host(&R, &S, &H, resident ? &ids : NULL, fused ? tot : NULL, fused ? mvs : NULL, fused ? cand : NULL, st, rec->buffer_y,
+                                                    rec->luma_size / rec->stride_y, out)
+                                    : TS.recon_host(&R, &H, st, rec->buffer_y, rec->luma_size / rec->stride_y, out);
     const double t1 = now_ms();
     if (rc) { free(out); return rc; }
     const uint32_t cols16 = (pcs->aligned_width + 15) >> 4, aligned_h = (inp->height + 7) & ~7u;
@@ -211,6 +266,11 @@ static void tpl_written_cells(const PictureParentControlSet *pcs, uint8_t level,
 
 static void tpl_mc_flow_dispenser_use2_body(TPL_DISP_ARGS) {
     if (!tpl_seam_on() || (pcs->tpl_src_data_ready && !TS.recon) || !tpl_seam_covers(scs, pcs)) {
+        /* the reference's dispenser rewrites this picture's TPL reconstruction on the host: whatever a device holds of that buffer is stale from here on */
+        if (TS.recon && enc_ctx->mc_flow_rec_picture_buffer[frame_idx]) {
+            tpl_rec_forget(enc_ctx->mc_flow_rec_picture_buffer[frame_idx]->buffer_y);
+            if (TS.plane_drop) TS.plane_drop(enc_ctx->mc_flow_rec_picture_buffer[frame_idx]->buffer_y);
+        }
         if (TS.mode) {
             pthread_mutex_lock(&TS.lock);
             if (pcs->tpl_src_data_ready) TS.n_reused++; else TS.n_declined++;

@@ -50,6 +50,9 @@ PROTOTYPES = {
     "svt_hip_tpl_recon_stage": (None, [vp, vp, vp, vp, vp, vp, vp]),
     "svt_hip_tpl_recon_stage_host": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp]),
     "svt_hip_tpl_stage_host": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp]),
+    "svt_hip_tpl_stage_host_resident": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp]),
+    "svt_hip_tpl_plane_drop": (None, [vp]),
+    "svt_hip_tpl_plane_counts": (None, [vp, vp]),
     "svt_hip_frame_partition_create": (vp, [vp, C.c_int]),
     "svt_hip_frame_partition_destroy": (None, [vp]),
     "svt_hip_frame_partition_size": (C.c_int, [vp]),

@@ -97,6 +97,78 @@ uint32_t* stream_scratch_u32x4(hipStream_t st) {
     return p;
 }
 
+// ---- device-resident copies of host picture planes, across host calls (the TPL stage: a picture of a TPL group is the source of one dispenser call and a
+// reference of several others; its TPL reconstruction is produced on the device and read by later pictures) ------------------------------------------------------------
+// Key = (host buffer, id): the caller names the CONTENT (e.g. picture number + 1), so a pool buffer that is reused for another picture never aliases.  An entry is
+// LOADING while the call that creates it runs (other callers then take their own staged copy) and READY after that call's synchronisation; entries are pinned for the
+// duration of a call and recycled least-recently-used.  One table per device.
+namespace {
+struct CachedPlane { uintptr_t ptr = 0; uint64_t id = 0; uint8_t* dev = nullptr; size_t cap = 0; uint64_t stamp = 0; int pins = 0, state = 0; }; // state: 0 empty, 1 loading, 2 ready
+constexpr int PLANE_CACHE_ENTRIES = 48;
+struct PlaneCache { std::mutex m; CachedPlane e[PLANE_CACHE_ENTRIES]; uint64_t clock = 0, hits = 0, misses = 0; };
+PlaneCache g_plane_cache[MAX_DEVICES];
+} // namespace
+// -> the entry's device buffer, pinned; *hit = its content is valid.  nullptr: not cacheable right now (someone else is loading it, or every entry is pinned).
+uint8_t* plane_cache_acquire(const void* host_ptr, uint64_t id, size_t bytes, bool* hit, int* token) {
+    *hit = false; *token = -1;
+    if (!host_ptr || !id) return nullptr;
+    ensure_device();
+    PlaneCache& C = g_plane_cache[current_device()];
+    std::lock_guard<std::mutex> g(C.m);
+    int victim = -1;
+    for (int i = 0; i < PLANE_CACHE_ENTRIES; i++) {
+        CachedPlane& e = C.e[i];
+        if (e.state && e.ptr == (uintptr_t)host_ptr && e.id == id) {
+            if (e.state == 1 || e.cap < bytes) return nullptr;
+            e.pins++; e.stamp = ++C.clock; *hit = true; *token = i; C.hits++;
+            return e.dev;
+        }
+        if (e.pins == 0 && e.state != 1 && (victim < 0 || e.stamp < C.e[victim].stamp)) victim = i;
+    }
+    if (victim < 0) return nullptr;
+    CachedPlane& e = C.e[victim];
+    if (e.cap < bytes) {
+        if (e.dev) HIP_CHECK(hipFree(e.dev));
+        HIP_CHECK(hipMalloc((void**)&e.dev, bytes));
+        e.cap = bytes;
+    }
+    e.ptr = (uintptr_t)host_ptr; e.id = id; e.state = 1; e.pins = 1; e.stamp = ++C.clock; C.misses++;
+    *token = victim;
+    return e.dev;
+}
+void plane_cache_release(int token, bool now_ready) {
+    if (token < 0) return;
+    PlaneCache& C = g_plane_cache[current_device()];
+    std::lock_guard<std::mutex> g(C.m);
+    CachedPlane& e = C.e[token];
+    if (e.state == 1) e.state = now_ready ? 2 : 0;
+    if (e.pins > 0) e.pins--;
+}
+// the host rewrote (or is about to rewrite) the buffer by other means: whatever the device holds of it is stale
+void plane_cache_drop(const void* host_ptr) { // (on every device: the host buffer is one, its mirrors may be several)
+    for (int d = 0; d < MAX_DEVICES; d++) {
+        PlaneCache& C = g_plane_cache[d];
+        std::lock_guard<std::mutex> g(C.m);
+        for (CachedPlane& e : C.e)
+            if (e.state == 2 && e.pins == 0 && e.ptr == (uintptr_t)host_ptr) e.state = 0;
+    }
+}
+void plane_cache_counts(uint64_t* hits, uint64_t* misses) {
+    PlaneCache& C = g_plane_cache[current_device()];
+    std::lock_guard<std::mutex> g(C.m);
+    *hits = C.hits; *misses = C.misses;
+}
+static void plane_cache_free_all() {
+    for (int d = 0; d < MAX_DEVICES; d++) {
+        PlaneCache& C = g_plane_cache[d];
+        std::lock_guard<std::mutex> g(C.m);
+        for (CachedPlane& e : C.e) {
+            if (e.dev) { (void)hipSetDevice(d); (void)hipFree(e.dev); }
+            e = CachedPlane();
+        }
+    }
+}
+
 void HostCall::begin() {
     dev_used = 0;
     pin_used = 0;
@@ -338,6 +410,7 @@ void svt_hip_shutdown(void) {
             g_lease_pool[d].clear();
         }
     }
+    plane_cache_free_all();
     t_bound       = -1;
     g_initialised = false;
 }

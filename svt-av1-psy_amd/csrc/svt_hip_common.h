@@ -87,7 +87,12 @@ struct HostCall {
     void sync();
 };
 HostCall& host_call();
-uint32_t* stream_scratch_u32x4(hipStream_t st); // four zeroed device words for one launch sequence on `st` (runtime.hip)
+uint32_t* stream_scratch_u32x4(hipStream_t st);
+// device-resident copies of host picture planes kept across host calls (runtime.hip): acquire pins an entry for (host buffer, content id) on the current device
+uint8_t* plane_cache_acquire(const void* host_ptr, uint64_t id, size_t bytes, bool* hit, int* token);
+void     plane_cache_release(int token, bool now_ready);
+void     plane_cache_drop(const void* host_ptr);
+void     plane_cache_counts(uint64_t* hits, uint64_t* misses); // four zeroed device words for one launch sequence on `st` (runtime.hip)
 // The stage-sized host forms (a whole picture's planes per call: svt_hip_tf_picture_host, svt_hip_tpl_src_stage_host, the CDEF / LR / deblocking / sub-pel host forms)
 // do not use the calling thread's own arena: an encoder calls them from dozens of worker threads, and every thread growing a private 20-50 MB pinned + device arena
 // on its first call costs 10-20 ms each (pinned allocation).  They lease an arena from a per-device pool for the duration of the call instead -- as many arenas as

@@ -776,9 +776,15 @@ int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams* params, const SvtHi
 // Both halves of the dispenser for one picture in ONE host call: every distinct picture buffer -- the source, the source pictures of its references (source-based
 // half), the TPL reconstructions of its references (reconstruction half) -- is uploaded once, the source-based statistics stay on the device between the halves (they
 // come back for the caller's TplSrcStats buffer all the same), one synchronisation at the end.  What the seam calls for a picture whose statistics are not stored yet.
-int svt_hip_tpl_stage_host(const SvtHipTplReconParams* params, const SvtHipTplHostPlanes* src_planes, const SvtHipTplHostPlanes* rec_planes,
-                           const uint8_t* total_me_candidate_index, const uint32_t* me_mv_array, const uint8_t* me_candidate_array, SvtHipTplSrcStats* src_stats,
-                           uint8_t* recon_buf, uint32_t recon_rows, SvtHipTplReconStats* out) {
+//
+// `ids` (the _resident form; NULL otherwise) names the CONTENT of every buffer -- picture number + 1 for a source picture, the same for a picture's TPL
+// reconstruction -- so that a plane stays on the device across calls (svthip::plane_cache_*): a picture of a TPL group is the source of one call and a reference of
+// several others, and its reconstruction is PRODUCED on the device; with ids a call uploads one new plane (its source) instead of up to nine.  The reconstruction
+// kept on the device gets the borders the host's copy gets from svt_aom_generate_padding after the dispenser (src_ops_process.c:1400-1406) -- later pictures' vectors
+// reach up to 32 samples past the picture --, which is why ids carries its geometry.
+static int tpl_stage_host_impl(const SvtHipTplReconParams* params, const SvtHipTplHostPlanes* src_planes, const SvtHipTplHostPlanes* rec_planes, const SvtHipTplPlaneIds* ids,
+                               const uint8_t* total_me_candidate_index, const uint32_t* me_mv_array, const uint8_t* me_candidate_array, SvtHipTplSrcStats* src_stats,
+                               uint8_t* recon_buf, uint32_t recon_rows, SvtHipTplReconStats* out) {
     svthip::ensure_device();
     SvtHipTplReconParams R = *params;
     SvtHipTplSrcParams&  P = R.src;
@@ -787,50 +793,70 @@ int svt_hip_tpl_stage_host(const SvtHipTplReconParams* params, const SvtHipTplHo
     const size_t cols16 = (P.aligned_width + 15) >> 4, rows16 = ((((size_t)P.height + 7) & ~(size_t)7) + 15) >> 4, cells = cols16 * rows16;
     const size_t tot_b = (size_t)P.n_sb * n_pus, mv_b = tot_b * P.max_refs * 4, cand_b = tot_b * P.max_cand;
     const uint8_t* bufs[17];
-    size_t         bytes[17], doff[17];
+    size_t         bytes[17];
+    uint64_t       bid[17];
     int            nb = 0, src_slot[8], rec_slot[8];
-    auto slot_of = [&](const uint8_t* b, size_t n) {
+    auto slot_of = [&](const uint8_t* b, size_t n, uint64_t id) {
         for (int i = 0; i < nb; i++)
             if (bufs[i] == b) return i;
-        bufs[nb] = b; bytes[nb] = n;
+        bufs[nb] = b; bytes[nb] = n; bid[nb] = id;
         return nb++;
     };
-    slot_of(src_planes->src_buf, (size_t)P.src_stride * src_planes->src_rows);
+    const bool stored = total_me_candidate_index == nullptr; // the source-based statistics come from the caller (an earlier TPL group's: :969-977): reconstruction half only
+    slot_of(src_planes->src_buf, (size_t)P.src_stride * src_planes->src_rows, ids ? ids->src : 0);
     for (int r = 0; r < 8; r++) {
         src_slot[r] = rec_slot[r] = -1;
         if (!P.refs[r].valid || P.i_slice) continue;
-        if (!src_planes->ref_buf[r] || !rec_planes->ref_buf[r]) return -3;
-        src_slot[r] = slot_of(src_planes->ref_buf[r], (size_t)P.refs[r].stride * src_planes->ref_rows[r]);
-        rec_slot[r] = slot_of(rec_planes->ref_buf[r], (size_t)R.rec_refs[r].stride * rec_planes->ref_rows[r]);
+        if ((!stored && !src_planes->ref_buf[r]) || !rec_planes->ref_buf[r]) return -3;
+        if (!stored) src_slot[r] = slot_of(src_planes->ref_buf[r], (size_t)P.refs[r].stride * src_planes->ref_rows[r], ids ? ids->src_ref[r] : 0); // (only the source-based half reads them)
+        rec_slot[r] = slot_of(rec_planes->ref_buf[r], (size_t)R.rec_refs[r].stride * rec_planes->ref_rows[r], ids ? ids->rec_ref[r] : 0);
     }
-    size_t total = 0;
-    for (int b = 0; b < nb; b++) { doff[b] = total; total += svthip::align_up(bytes[b], 256); }
     const size_t rec_b = (size_t)R.recon_stride * recon_rows;
+    // resident planes first (pinned for the call), the rest into the call's arena
+    uint8_t* dptr[17];
+    int      token[17], rec_token = -1;
+    bool     hit[17], rec_hit = false;
+    size_t   staged = 0;
+    for (int b = 0; b < nb; b++) {
+        dptr[b] = svthip::plane_cache_acquire(bufs[b], bid[b], bytes[b], &hit[b], &token[b]);
+        if (!dptr[b]) staged += svthip::align_up(bytes[b], 256);
+    }
+    uint8_t* d_rec = (ids && ids->recon) ? svthip::plane_cache_acquire(recon_buf, ids->recon, rec_b, &rec_hit, &rec_token) : nullptr;
     svthip::HostCallLease lease;
     svthip::HostCall& c = *lease;
     c.begin();
     const size_t side = tot_b + mv_b + cand_b + cells * (sizeof(SvtHipTplSrcStats) + sizeof(SvtHipTplReconStats)) + 16384;
-    c.reserve(total + rec_b + side + 4096, total + 2 * rec_b + 2 * side + 8192);
-    uint8_t* d_planes = (uint8_t*)c.dalloc(total);
-    for (int b = 0; b < nb; b++) c.up(d_planes + doff[b], bufs[b], bytes[b]);
+    size_t       pin_need = 2 * rec_b + 2 * side + 8192;
+    for (int b = 0; b < nb; b++) pin_need += svthip::align_up(bytes[b], 256); // (a staged upload of a plane that is neither page-locked nor resident)
+    c.reserve(staged + rec_b + side + 4096, pin_need);
+    for (int b = 0; b < nb; b++) {
+        if (!dptr[b]) dptr[b] = (uint8_t*)c.dalloc(bytes[b]);
+        if (!hit[b]) c.up(dptr[b], bufs[b], bytes[b]);
+    }
     uint8_t*             d_tot  = (uint8_t*)c.dalloc(tot_b);
     uint32_t*            d_mv   = (uint32_t*)c.dalloc(mv_b ? mv_b : 4);
     uint8_t*             d_cand = (uint8_t*)c.dalloc(cand_b ? cand_b : 4);
     SvtHipTplSrcStats*   d_ss   = (SvtHipTplSrcStats*)c.dalloc(cells * sizeof(SvtHipTplSrcStats));
-    uint8_t*             d_rec  = (uint8_t*)c.dalloc(rec_b);
+    if (!d_rec) d_rec = (uint8_t*)c.dalloc(rec_b);
     SvtHipTplReconStats* d_out  = (SvtHipTplReconStats*)c.dalloc(cells * sizeof(SvtHipTplReconStats));
-    c.up(d_tot, total_me_candidate_index, tot_b);
-    if (mv_b) c.up(d_mv, me_mv_array, mv_b);
-    if (cand_b) c.up(d_cand, me_candidate_array, cand_b);
-    HIP_CHECK(hipMemsetAsync(d_ss, 0, cells * sizeof(SvtHipTplSrcStats), c.stream));
+    if (stored) c.up(d_ss, src_stats, cells * sizeof(SvtHipTplSrcStats));
+    else {
+        c.up(d_tot, total_me_candidate_index, tot_b);
+        if (mv_b) c.up(d_mv, me_mv_array, mv_b);
+        if (cand_b) c.up(d_cand, me_candidate_array, cand_b);
+        HIP_CHECK(hipMemsetAsync(d_ss, 0, cells * sizeof(SvtHipTplSrcStats), c.stream));
+    }
     HIP_CHECK(hipMemsetAsync(d_out, 0, cells * sizeof(SvtHipTplReconStats), c.stream));
     HIP_CHECK(hipMemsetAsync(d_rec, 0, rec_b, c.stream)); // (never read before it is written: a DC block's neighbours are blocks of this picture; only the written rectangle comes back)
+    // the kernels address every plane as base + offset: with planes in separate allocations the base is 0 and the offsets are the addresses
+    const uint8_t* base0 = nullptr;
+    P.src_off += (uint64_t)(uintptr_t)dptr[0];
     for (int r = 0; r < 8; r++) {
-        if (src_slot[r] >= 0) P.refs[r].plane_off += doff[src_slot[r]];
-        if (rec_slot[r] >= 0) R.rec_refs[r].plane_off += doff[rec_slot[r]];
+        if (src_slot[r] >= 0) P.refs[r].plane_off += (uint64_t)(uintptr_t)dptr[src_slot[r]];
+        if (rec_slot[r] >= 0) R.rec_refs[r].plane_off += (uint64_t)(uintptr_t)dptr[rec_slot[r]];
     }
-    svt_hip_tpl_src_stage(&P, d_planes, d_planes, d_tot, d_mv, d_cand, d_ss, c.stream);
-    svt_hip_tpl_recon_stage(&R, d_planes, d_planes, d_ss, d_rec, d_out, c.stream);
+    if (!stored) svt_hip_tpl_src_stage(&P, base0, base0, d_tot, d_mv, d_cand, d_ss, c.stream);
+    svt_hip_tpl_recon_stage(&R, base0, base0, d_ss, d_rec, d_out, c.stream);
     const size_t covered_w = ((size_t)P.width + 8) >> 4 << 4, covered_h = ((size_t)P.height + 8) >> 4 << 4;
     size_t       rows_down = covered_h;
     while (rows_down && R.recon_off + (rows_down - 1) * R.recon_stride + covered_w > rec_b) rows_down--;
@@ -839,15 +865,35 @@ int svt_hip_tpl_stage_host(const SvtHipTplReconParams* params, const SvtHipTplHo
     uint8_t*     pin_ss  = (uint8_t*)c.palloc(cells * sizeof(SvtHipTplSrcStats));
     uint8_t*     pin_out = (uint8_t*)c.palloc(cells * sizeof(SvtHipTplReconStats));
     if (span) HIP_CHECK(hipMemcpyAsync(pin_rec, d_rec + R.recon_off, span, hipMemcpyDeviceToHost, c.stream));
-    HIP_CHECK(hipMemcpyAsync(pin_ss, d_ss, cells * sizeof(SvtHipTplSrcStats), hipMemcpyDeviceToHost, c.stream));
+    if (!stored) HIP_CHECK(hipMemcpyAsync(pin_ss, d_ss, cells * sizeof(SvtHipTplSrcStats), hipMemcpyDeviceToHost, c.stream));
     HIP_CHECK(hipMemcpyAsync(pin_out, d_out, cells * sizeof(SvtHipTplReconStats), hipMemcpyDeviceToHost, c.stream));
+    const bool keep_rec = rec_token >= 0 && ids->recon_width && ids->recon_height && covered_w >= ids->recon_width && covered_h >= ids->recon_height;
+    if (keep_rec) // the device copy's borders, as svt_aom_generate_padding leaves the host's after the dispenser
+        svt_hip_generate_padding(d_rec + R.recon_off - (size_t)ids->recon_org_y * R.recon_stride - ids->recon_org_x, R.recon_stride, ids->recon_width, ids->recon_height,
+                                 ids->recon_org_x, ids->recon_org_y, c.stream);
     c.sync(); // the one synchronisation of the call
     for (size_t y = 0; y < rows_down; y++) memcpy(recon_buf + R.recon_off + y * R.recon_stride, pin_rec + y * R.recon_stride, covered_w);
-    memcpy(src_stats, pin_ss, cells * sizeof(SvtHipTplSrcStats));
+    if (!stored) memcpy(src_stats, pin_ss, cells * sizeof(SvtHipTplSrcStats));
     memcpy(out, pin_out, cells * sizeof(SvtHipTplReconStats));
+    int rc = 0;
     for (size_t r = 0; r < rows16; r++)
-        if (out[r * cols16].pad[0] == 0xEE) return -4;
-    return 0;
+        if (out[r * cols16].pad[0] == 0xEE) rc = -4;
+    for (int b = 0; b < nb; b++) svthip::plane_cache_release(token[b], rc == 0); // (uploaded planes are valid from here on; hits just lose their pin)
+    svthip::plane_cache_release(rec_token, rc == 0 && keep_rec);
+    return rc;
 }
+int svt_hip_tpl_stage_host(const SvtHipTplReconParams* params, const SvtHipTplHostPlanes* src_planes, const SvtHipTplHostPlanes* rec_planes,
+                           const uint8_t* total_me_candidate_index, const uint32_t* me_mv_array, const uint8_t* me_candidate_array, SvtHipTplSrcStats* src_stats,
+                           uint8_t* recon_buf, uint32_t recon_rows, SvtHipTplReconStats* out) {
+    if (!total_me_candidate_index) return -1;
+    return tpl_stage_host_impl(params, src_planes, rec_planes, nullptr, total_me_candidate_index, me_mv_array, me_candidate_array, src_stats, recon_buf, recon_rows, out);
+}
+int svt_hip_tpl_stage_host_resident(const SvtHipTplReconParams* params, const SvtHipTplHostPlanes* src_planes, const SvtHipTplHostPlanes* rec_planes,
+                                    const SvtHipTplPlaneIds* ids, const uint8_t* total_me_candidate_index, const uint32_t* me_mv_array, const uint8_t* me_candidate_array,
+                                    SvtHipTplSrcStats* src_stats, uint8_t* recon_buf, uint32_t recon_rows, SvtHipTplReconStats* out) {
+    return tpl_stage_host_impl(params, src_planes, rec_planes, ids, total_me_candidate_index, me_mv_array, me_candidate_array, src_stats, recon_buf, recon_rows, out);
+}
+void svt_hip_tpl_plane_drop(const void* host_buffer) { svthip::plane_cache_drop(host_buffer); }
+void svt_hip_tpl_plane_counts(uint64_t* hits, uint64_t* misses) { svthip::ensure_device(); svthip::plane_cache_counts(hits, misses); }
 
 } // extern "C"

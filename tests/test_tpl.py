@@ -325,3 +325,105 @@ def test_tpl_recon_stage_device(be, oracle, ci, is_ref, form, monkeypatch):
     for f in ("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate", "written", "coded"):
         assert np.array_equal(out_f[f], want[f]), ("fused host form", ci, f)
     assert np.array_equal(rec_f, want_rec), ("fused host form recon", ci, int((rec_f != want_rec).sum()))
+
+
+class TplPlaneIds(C.Structure):
+    _fields_ = [("src", C.c_uint64), ("src_ref", C.c_uint64 * 8), ("rec_ref", C.c_uint64 * 8), ("recon", C.c_uint64), ("recon_width", C.c_uint32),
+                ("recon_height", C.c_uint32), ("recon_org_x", C.c_uint32), ("recon_org_y", C.c_uint32)]
+
+
+@pytest.mark.parametrize("ci", [0, 2, 6])
+def test_tpl_stage_host_resident(be, oracle, ci):
+    """svt_hip_tpl_stage_host_resident: planes kept on the device across calls.  Picture 1 is processed with ids (every plane uploaded once, its reconstruction stays on
+    the device with replicated borders); picture 2 takes picture 1's reconstruction as the TPL reconstruction of its first reference and far vectors reach into that
+    plane's border -- served from the device copy (look-ups hit), it must give what the call without ids gives from the host's copy padded like svt_aom_generate_padding
+    pads it; a third call with only the reconstruction half (stored statistics) goes through the same path; a dropped buffer is uploaded again."""
+    pkg, lib = be.pkg, be.lib
+    c = CASES[ci]
+    P, planes, tot, mvs, cand, n_pus, cells = make_case(c, 6100 + ci)
+    P.quant_fp[0], P.quant_fp[1], P.round_fp[0], P.round_fp[1], P.dequant[0], P.dequant[1] = 532, 431, 61, 76, 123, 152
+    rows, stride = planes.shape[1], planes.shape[2]
+    W, H = P.width, P.height
+
+    def params(planes_of_refs):
+        R = pkg.TplReconParams()
+        C.memmove(C.addressof(R.src), C.addressof(P), C.sizeof(P))
+        for i in range(8):
+            C.memmove(C.addressof(R.rec_refs[i]), C.addressof(P.refs[i]), C.sizeof(TplRef))
+            R.rec_refs[i].plane_off = 0
+            R.src.refs[i].plane_off = 0
+        R.recon_off, R.recon_stride, R.is_ref = PAD * stride + PAD, stride, 1
+        SP, RP = TplHostPlanes(), TplHostPlanes()
+        SP.src_buf, SP.src_rows = planes[0].ctypes.data, rows
+        for r in range(8):
+            if P.refs[r].valid:
+                k = P.refs[r].plane_off // (rows * stride)
+                SP.ref_buf[r], SP.ref_rows[r] = planes[k].ctypes.data, rows
+                RP.ref_buf[r], RP.ref_rows[r] = planes_of_refs[k].ctypes.data, rows
+        return R, SP, RP
+
+    def ids_for(rec_id_of, recon_id):
+        I = TplPlaneIds()
+        I.src, I.recon = 100, recon_id
+        for r in range(8):
+            if P.refs[r].valid:
+                k = P.refs[r].plane_off // (rows * stride)
+                I.src_ref[r], I.rec_ref[r] = 200 + k, rec_id_of(k)
+        I.recon_width, I.recon_height, I.recon_org_x, I.recon_org_y = W, H, PAD, PAD
+        return I
+
+    def call(R, SP, RP, I, rec, stored=None):
+        out, src = np.zeros(cells, ReconStats), (np.zeros(cells, SrcStats) if stored is None else stored.copy())
+        f = lib.svt_hip_tpl_stage_host_resident
+        a = (p(tot), p(mvs), p(cand)) if stored is None else (None, None, None)
+        assert f(C.addressof(R), C.addressof(SP), C.addressof(RP), C.addressof(I) if I is not None else None, a[0], a[1], a[2], p(src), p(rec), rows, p(out)) == 0
+        return src, out
+
+    def counts():
+        h, m = C.c_uint64(0), C.c_uint64(0)
+        lib.svt_hip_tpl_plane_counts(C.byref(h), C.byref(m))
+        return h.value, m.value
+    rec_copies = [planes[k].copy() for k in range(planes.shape[0])]  # the references' TPL reconstructions: separate host buffers
+    # picture 1, with ids and without: the same results; nothing was resident yet
+    R, SP, RP = params(rec_copies)
+    rec1, rec1_plain = np.zeros((rows, stride), np.uint8), np.zeros((rows, stride), np.uint8)
+    h0, m0 = counts()
+    s1, o1 = call(R, SP, RP, ids_for(lambda k: 300 + k, 999), rec1)
+    s1p, o1p = call(R, SP, RP, None, rec1_plain)
+    same_stats(s1, s1p, "resident vs plain, picture 1")
+    assert np.array_equal(o1["recrf_dist"], o1p["recrf_dist"]) and np.array_equal(rec1, rec1_plain)
+    h1, m1 = counts()
+    assert m1 > m0 and h1 == h0
+    # what svt_aom_generate_padding makes of the host's reconstruction after the dispenser
+    rec1_padded = rec1.copy()
+    rec1_padded[0:H + 2 * PAD, 0:W + 2 * PAD] = np.pad(rec1[PAD:PAD + H, PAD:PAD + W], PAD, mode="edge")
+    # picture 2: the first valid reference's TPL reconstruction IS picture 1's reconstruction
+    first = next(r for r in range(8) if P.refs[r].valid) if not c["isl"] else None
+    if first is not None:
+        k0 = P.refs[first].plane_off // (rows * stride)
+        recs2 = list(rec_copies)
+        recs2[k0] = rec1_padded
+        R2, SP2, RP2 = params(recs2)
+        rec2, rec2_plain = np.zeros((rows, stride), np.uint8), np.zeros((rows, stride), np.uint8)
+        # (the device copy lives under the HOST buffer's address: the padded copy is a different buffer, so name picture 1's own buffer for the resident call)
+        RP2r = TplHostPlanes.from_buffer_copy(RP2)
+        RP2r.ref_buf[first] = rec1.ctypes.data
+        s2, o2 = call(R2, SP2, RP2r, ids_for(lambda k: 999 if k == k0 else 300 + k, 1000), rec2)
+        s2p, o2p = call(R2, SP2, RP2, None, rec2_plain)
+        h2, m2 = counts()
+        assert h2 > h1, "picture 2 found nothing resident"
+        same_stats(s2, s2p, "resident vs plain, picture 2")
+        for f in ("srcrf_dist", "recrf_dist", "written", "coded"):
+            assert np.array_equal(o2[f], o2p[f]), ("picture 2", f)
+        assert np.array_equal(rec2, rec2_plain)
+        # the reconstruction half alone with the caller's statistics (a later TPL group), still from resident planes
+        rec3 = np.zeros((rows, stride), np.uint8)
+        _, o3 = call(R2, SP2, RP2r, ids_for(lambda k: 999 if k == k0 else 300 + k, 1001), rec3, stored=s2)
+        assert np.array_equal(o3["recrf_dist"], o2["recrf_dist"]) and np.array_equal(rec3, rec2)
+        # a dropped buffer is uploaded again (a miss), with the same result
+        lib.svt_hip_tpl_plane_drop(C.c_void_p(planes[0].ctypes.data))
+        h3, m3 = counts()
+        rec4 = np.zeros((rows, stride), np.uint8)
+        call(R2, SP2, RP2r, ids_for(lambda k: 999 if k == k0 else 300 + k, 1002), rec4)
+        h4, m4 = counts()
+        assert m4 > m3 and np.array_equal(rec4, rec2)
