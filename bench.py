@@ -446,7 +446,8 @@ def attach_encoder_baselines(kernels, enc):
         return
     ref, frames, st = enc["stage_cpu_ms_per_frame"]["avx2"], enc.get("frames") or 0, enc.get("stages_on_gpu") or {}
     pics = {"tpl": (st.get("tpl") or {}).get("recon_pictures"), "tf": (st.get("tf_picture") or {}).get("pictures_filtered"), "me": (st.get("me") or {}).get("pictures_offloaded")}
-    for leg, stage, what in (("tpl_stage_host_1080p8", "tpl", "tpl_mc_flow_dispenser + its per-SB calls: both halves of the dispenser, what the leg's one call replaces"),
+    for leg, stage, what in (("tpl_stage_host_resident_1080p8", "tpl", "tpl_mc_flow_dispenser + its per-SB calls: both halves of the dispenser, what the leg's one call replaces"),
+                             ("tpl_stage_host_1080p8", "tpl", "tpl_mc_flow_dispenser + its per-SB calls: both halves of the dispenser, what the leg's one call replaces"),
                              ("tpl_recon_stage_1080p8", "tpl", "tpl_mc_flow_dispenser + its per-SB calls (both halves of the dispenser; the leg times the reconstruction half)"),
                              ("tpl_src_stage_1080p8", "tpl", "tpl_mc_flow_dispenser + its per-SB calls (both halves of the dispenser; the leg times the source-based half)"),
                              ("tf_picture_stage_1080p8_4refs_host", "tf", "produce_temporally_filtered_pic, every segment"),

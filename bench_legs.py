@@ -1024,13 +1024,46 @@ def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
     fused_ok = all(np.array_equal(h_out[f], forms[5][2][f]) for f in ("srcrf_dist", "recrf_dist", "written", "coded")) and np.array_equal(h_src["srcrf_dist"], src["srcrf_dist"])
     if not fused_ok:
         raise SystemExit("bench: svt_hip_tpl_stage_host differs from the two device stages -- no numbers recorded")
+    # the same with the planes RESIDENT across calls (svt_hip_tpl_stage_host_resident, what the seam calls): every call brings a new source picture and makes a new
+    # reconstruction; its references -- sources and reconstructions of pictures of earlier calls -- are found on the device
+    class PlaneIds(C.Structure):
+        _fields_ = [("src", C.c_uint64), ("src_ref", C.c_uint64 * 8), ("rec_ref", C.c_uint64 * 8), ("recon", C.c_uint64), ("recon_width", C.c_uint32),
+                    ("recon_height", C.c_uint32), ("recon_org_x", C.c_uint32), ("recon_org_y", C.c_uint32)]
+    I = PlaneIds()
+    for r in range(8):
+        if P.refs[r].valid:
+            k = P.refs[r].plane_off // psize
+            I.src_ref[r], I.rec_ref[r] = 1000 + k, 2000 + k
+    I.recon_width, I.recon_height, I.recon_org_x, I.recon_org_y = P.width, P.height, int(P.src_off % stride), int(P.src_off // stride)
+    serial = [10 ** 6]
+
+    def resident():
+        serial[0] += 1
+        I.src, I.recon = serial[0], 10 ** 7 + serial[0]  # (new content every call: uploaded / produced anew)
+        assert lib.svt_hip_tpl_stage_host_resident(C.addressof(RF), C.addressof(SP), C.addressof(RP), C.addressof(I), vp(tot), vp(mvs), vp(cand), vp(h_src), rec_pin, rows,
+                                                   vp(h_out)) == 0
+    t_res = regions.hook(resident, name="tpl_stage_host_resident")
+    if t_res is None:
+        for _ in range(3):
+            resident()
+        t0 = _t.perf_counter()
+        for _ in range(10):
+            resident()
+        t_res = (_t.perf_counter() - t0) / 10
+    if not all(np.array_equal(h_out[f], forms[5][2][f]) for f in ("srcrf_dist", "recrf_dist", "written", "coded")):
+        raise SystemExit("bench: svt_hip_tpl_stage_host_resident differs from the two device stages -- no numbers recorded")
     for q in pinned + [rec_pin]:
+        lib.svt_hip_tpl_plane_drop(q)
         lib.svt_hip_host_free(q)
     up_mb = (planes.shape[0] * 2 - 1) * psize / 1e6
     return {"tpl_stage_host_1080p8": {"ms": t_fused * 1e3, "pictures_per_s": 1 / t_fused, "uploaded_MB": up_mb, "pcie_inclusive": True, "equals_device_stages": True,
                                       "roofline": {"bound": "pcie", "achieved": up_mb * 1e6 / t_fused / 1e9, "peak": 64.0, "unit": "GB/s", "frac": up_mb * 1e6 / t_fused / 1e9 / 64.0,
                                                    "kernel_us": t_fused * 1e6, "binds": "pcie", "algorithmic_bytes_per_launch": up_mb * 1e6},
                                       "note": "both halves of the TPL dispenser in one host call from page-locked pictures (9 planes up), wall clock"},
+            "tpl_stage_host_resident_1080p8": {"ms": t_res * 1e3, "pictures_per_s": 1 / t_res, "uploaded_MB": psize / 1e6, "pcie_inclusive": True, "equals_device_stages": True,
+                                               "roofline": {"bound": "pcie", "achieved": 2 * psize / t_res / 1e9, "peak": 64.0, "unit": "GB/s", "frac": 2 * psize / t_res / 1e9 / 64.0,
+                                                            "kernel_us": t_res * 1e6, "binds": "pcie", "algorithmic_bytes_per_launch": 2 * psize},
+                                               "note": "the same call with the references' planes resident on the device: one new source picture up, the written rectangle and the statistics down"},
             "tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "form": "5: one launch, one wave per block, dependencies as data, release / acquire fences (csrc/tpl.hip tpl_recon_dep_kernel)",
                                         "sequentially_consistent_fences_form_us": forms[4][0] * 1e6, "anti_diagonal_launches_form_us": forms[0][0] * 1e6,
                                         "row_wavefront_form_us": forms[1][0] * 1e6, "row_wavefront_xcd_chunks_form_us": forms[2][0] * 1e6,
