@@ -104,8 +104,8 @@ uint32_t* stream_scratch_u32x4(hipStream_t st) {
 // duration of a call and recycled least-recently-used.  One table per device.
 namespace {
 struct CachedPlane { uintptr_t ptr = 0; uint64_t id = 0; uint8_t* dev = nullptr; size_t cap = 0; uint64_t stamp = 0; int pins = 0, state = 0; }; // state: 0 empty, 1 loading, 2 ready
-constexpr int PLANE_CACHE_ENTRIES = 48;
-struct PlaneCache { std::mutex m; CachedPlane e[PLANE_CACHE_ENTRIES]; uint64_t clock = 0, hits = 0, misses = 0; };
+constexpr int PLANE_CACHE_ENTRIES = 32;
+struct PlaneCache { std::mutex m; CachedPlane e[PLANE_CACHE_ENTRIES]; uint64_t clock = 0, hits = 0, misses = 0; std::vector<void*> slabs; /* every device allocation made for the table */ };
 PlaneCache g_plane_cache[MAX_DEVICES];
 } // namespace
 // -> the entry's device buffer, pinned; *hit = its content is valid.  nullptr: not cacheable right now (someone else is loading it, or every entry is pinned).
@@ -128,9 +128,18 @@ uint8_t* plane_cache_acquire(const void* host_ptr, uint64_t id, size_t bytes, bo
     if (victim < 0) return nullptr;
     CachedPlane& e = C.e[victim];
     if (e.cap < bytes) {
-        if (e.dev) HIP_CHECK(hipFree(e.dev));
-        HIP_CHECK(hipMalloc((void**)&e.dev, bytes));
-        e.cap = bytes;
+        // Rounded up to 4 MB (the source planes and the reconstruction planes of one encode differ by their borders only, and a recycled entry must fit either), and
+        // taken eight entries at a time: hipMalloc / hipFree synchronise the device, which an encoder with several stages in flight pays for -- after the first
+        // few pictures the table allocates nothing.  An outgrown slice is left to the table's slab list (freed at shutdown).
+        const size_t cap = align_up(bytes, (size_t)4 << 20);
+        int fresh[8], nf = 0;
+        fresh[nf++] = victim;
+        for (int i = 0; i < PLANE_CACHE_ENTRIES && nf < 8; i++)
+            if (i != victim && !C.e[i].dev && C.e[i].state == 0 && C.e[i].pins == 0) fresh[nf++] = i;
+        uint8_t* slab = nullptr;
+        HIP_CHECK(hipMalloc((void**)&slab, cap * nf));
+        C.slabs.push_back(slab);
+        for (int k = 0; k < nf; k++) { C.e[fresh[k]].dev = slab + (size_t)k * cap; C.e[fresh[k]].cap = cap; }
     }
     e.ptr = (uintptr_t)host_ptr; e.id = id; e.state = 1; e.pins = 1; e.stamp = ++C.clock; C.misses++;
     *token = victim;
@@ -162,10 +171,9 @@ static void plane_cache_free_all() {
     for (int d = 0; d < MAX_DEVICES; d++) {
         PlaneCache& C = g_plane_cache[d];
         std::lock_guard<std::mutex> g(C.m);
-        for (CachedPlane& e : C.e) {
-            if (e.dev) { (void)hipSetDevice(d); (void)hipFree(e.dev); }
-            e = CachedPlane();
-        }
+        for (void* p : C.slabs) { (void)hipSetDevice(d); (void)hipFree(p); }
+        C.slabs.clear();
+        for (CachedPlane& e : C.e) e = CachedPlane();
     }
 }
 

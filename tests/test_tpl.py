@@ -332,6 +332,16 @@ class TplPlaneIds(C.Structure):
                 ("recon_height", C.c_uint32), ("recon_org_x", C.c_uint32), ("recon_org_y", C.c_uint32)]
 
 
+_id_ranges = [0]
+
+
+def _fresh_id_range():
+    import os
+    import time
+    _id_ranges[0] += 1
+    return (int(time.time() * 1000) % (1 << 30) + os.getpid()) * 100000 + _id_ranges[0] * 10000
+
+
 @pytest.mark.parametrize("ci", [0, 2, 6])
 def test_tpl_stage_host_resident(be, oracle, ci):
     """svt_hip_tpl_stage_host_resident: planes kept on the device across calls.  Picture 1 is processed with ids (every plane uploaded once, its reconstruction stays on
@@ -362,13 +372,17 @@ def test_tpl_stage_host_resident(be, oracle, ci):
                 RP.ref_buf[r], RP.ref_rows[r] = planes_of_refs[k].ctypes.data, rows
         return R, SP, RP
 
+    # (ids name CONTENT: they must never repeat for other content at the same host address -- numpy hands freed addresses out again, so every run of this test takes
+    # its ids from a fresh range)
+    base = _fresh_id_range()
+
     def ids_for(rec_id_of, recon_id):
         I = TplPlaneIds()
-        I.src, I.recon = 100, recon_id
+        I.src, I.recon = base + 100, base + recon_id
         for r in range(8):
             if P.refs[r].valid:
                 k = P.refs[r].plane_off // (rows * stride)
-                I.src_ref[r], I.rec_ref[r] = 200 + k, rec_id_of(k)
+                I.src_ref[r], I.rec_ref[r] = base + 200 + k, base + rec_id_of(k)
         I.recon_width, I.recon_height, I.recon_org_x, I.recon_org_y = W, H, PAD, PAD
         return I
 
