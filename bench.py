@@ -1197,7 +1197,7 @@ def main():
     ap.add_argument("--min-leg-s", type=float, default=MIN_TIMED_S, help="minimum device time of every timed region (a step = as many launches as that takes)")
     ap.add_argument("--no-pmc", action="store_true", help="skip this run's own rocprofv3 --pmc child passes (roofline.traffic then comes from the committed summary)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (sad, txfm, config3, cdef, lr, hme, session, tf, tpl, tfpic, lrsearch): A/B measurements")
+    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (me, sad, txfm, config3, cdef, lr, hme, session, tf, tpl, tfpic, lrsearch): A/B measurements")
     ap.add_argument("--extra", action="store_true", help="also sweep the other search areas / sub_sad and the remaining stages (reported under kernels)")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -1316,6 +1316,31 @@ def main():
     bench_legs.MIN_S = a.min_leg_s
     want = (lambda leg: not a.legs or leg in a.legs.split(","))
     if not a.only_me:
+        if want("me"):  # the same batched search at the areas preset 8 really derives at its default CRF 35 (8 x 4 and 8 x 3: pkg.m8_me_settings): HBM-bound there
+            for (w2, h2) in ((8, 4), (8, 3)):
+                dd = np.concatenate([pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, w2, h2, PLANE, n_refs=a.refs, src_plane=f, ref_plane0=f + 1) for f in range(a.frames)])
+                tdd = torch.from_numpy(dd.view(np.uint8)).cuda()
+                f2 = lambda: lib.svt_hip_me_fullpel_search_batch(d_planes.data_ptr(), d_planes.data_ptr(), tdd.data_ptr(), len(dd), w2, h2, 0, d_sad.data_ptr(),  # noqa: E731
+                                                                 d_mv.data_ptr(), None, stream)
+                f2()
+                torch.cuda.synchronize()
+                chk = 0
+                if oracle is not None:
+                    hs, hm = d_sad.cpu().numpy().view(np.uint32).reshape(-1, 85), d_mv.cpu().numpy().view(np.uint32).reshape(-1, 85)
+                    for i in np.linspace(0, len(dd) - 1, 24).astype(int):
+                        d = dd[i]
+                        ws_, wm_ = np.zeros(85, np.uint32), np.zeros(85, np.uint32)
+                        oracle.oracle_me_fullpel_search(vp(planes, int(d["src_off"])), STRIDE, vp(planes, int(d["ref_off"])), STRIDE, int(d["x_origin"]), int(d["y_origin"]), w2, h2, 0,
+                                                        vp(ws_), vp(wm_))
+                        chk += must_equal("me_fullpel %dx%d sad" % (w2, h2), hs[i], ws_) + must_equal("me_fullpel %dx%d mv" % (w2, h2), hm[i], wm_)
+                per, _ = time_leg(torch, f2, a.min_leg_s)
+                b_item = 64 * 64 + (64 + w2 - 1) * (64 + h2 - 1) + 85 * 8
+                kernels["me_search_%dx%d_preset8_area" % (w2, h2)] = {
+                    "value": len(dd) * w2 * h2 / per / 1e6, "unit": "Mblocks/s", "sb_refs": len(dd), "parity_checked_values": chk,
+                    "roofline": roofline(len(dd) * b_item, per, "me_fullpel_wave_kernel<false, 18>", algorithmic_bytes_per_sb_ref=b_item,
+                                         valu_frac=len(dd) * w2 * h2 * 4096 / per / QSAD_PEAK,
+                                         note="valu_frac from the measured v_qsad_pk_u16_u8 rate, as the headline leg's")}
+            step()  # (the shared result arrays hold the headline search again)
         if want("sad"):
             kernels["sad64x64_pairs"] = bench_sad_pairs(torch, lib, pkg, stream, a, cpu)
         if want("txfm"):

@@ -49,6 +49,9 @@ def compact(out):
                                   "binds", "sad_path_hbm_frac", "moved_over_algorithmic", "traffic_source"))
     if "traffic" not in line["roofline"]:
         line["roofline"]["traffic"] = None
+    a84 = (kernels.get("me_search_8x4_preset8_area") or {}).get("roofline")
+    if isinstance(a84, dict) and a84.get("frac") is not None:  # the same kernel at the area preset 8 derives at its default CRF: where the HBM roof binds
+        line["roofline"]["hbm_frac_at_preset8_area_8x4"] = _r(a84["frac"], 4)
     if cb:
         c = _pick(cb, ("value", "unit", "cores", "kind", "single_thread_value", "gpu_over_cpu", "sample"))
         ck = {}
