@@ -184,10 +184,11 @@ static int sum_slot(int di, uint64_t id, int make) {
     return free_i;
 }
 /* make `pic` (picture id `id`) resident with its current content: upload it when it is absent or its host content changed since the upload */
-/* (device lock held; `now` = the plane's checksum, computed by the caller outside the lock.)  The copy of a REFERENCE is waited for here: its host plane is pageable
- * memory that another encoder thread may rewrite later (a picture is temporally filtered in place after it served as a neighbour's reference), and the runtime may
- * still be reading it when hipMemcpyAsync returns.  ~0.1-0.3 ms per upload, ~1.3 uploads per picture. */
-static int ensure_resident(int di, uint64_t id, const EbPictureBufferDesc *pic, const SvtHipMeStageParams *S, uint64_t now) {
+/* (device lock held; `now` = the plane's checksum, computed by the caller outside the lock.)  The copy of a REFERENCE must be complete before the caller returns to
+ * the encoder: another encoder thread may rewrite its host plane later (a picture is temporally filtered in place after it served as a neighbour's reference).  It is
+ * not waited for HERE any more (that kept the per-device lock for 0.1-0.3 ms per upload, ~1.3 uploads per picture, while other pictures queued behind it): the upload's
+ * slot goes to `pend`, and the caller waits for it after it has released the lock -- the stage it submits is ordered behind the upload by the session's events. */
+static int ensure_resident(int di, uint64_t id, const EbPictureBufferDesc *pic, const SvtHipMeStageParams *S, uint64_t now, int *pend, int *n_pend) {
     const int k = sum_slot(di, id, 1);
     if (abi.resident(G.session[di], (int64_t)id)) {
         if (seam_hash <= 0 || G.sum[di][k][1] == now) return 0; /* (without the checksum aid a resident picture is current: invalidation is explicit) */
@@ -196,7 +197,8 @@ static int ensure_resident(int di, uint64_t id, const EbPictureBufferDesc *pic, 
     }
     const int slot = abi.submit_stage(G.session[di], (int64_t)id, pic->buffer_y, NULL, 0, S, NULL);
     if (slot < 0) return slot;
-    abi.wait(G.session[di], slot);
+    if (*n_pend < 16) pend[(*n_pend)++] = slot;
+    else abi.wait(G.session[di], slot);
     G.sum[di][k][1] = now;
     G.n_uploads++;
     return 0;
@@ -395,13 +397,13 @@ static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *
     const int di = svt_hip_seam_bind(pcs->picture_number); /* the device this picture is sharded to (0 without SVT_HIP_DEVICES) */
     pthread_mutex_lock(&G.dev[di]);
     const double td0 = seam_now();
-    int rc = ensure_session(di, pcs, src), slot = -1;
+    int rc = ensure_session(di, pcs, src), slot = -1, pend[16], n_pend = 0;
     void *ses = G.session[di];
     for (int pass = 0; !rc; pass++) { /* an upload may evict a reference another upload just brought in (round-robin ring): repeat until all are there */
         int missing = 0;
         for (uint32_t k = 0; k < n_refs && !rc; k++) {
             if (ref_pics[k]->width != G.width || ref_pics[k]->stride_y != G.stride) rc = decline("reference geometry");
-            else if (ensure_resident(di, (uint64_t)ref_ids[k], ref_pics[k], &S, ref_sum[k])) rc = decline("reference upload");
+            else if (ensure_resident(di, (uint64_t)ref_ids[k], ref_pics[k], &S, ref_sum[k], pend, &n_pend)) rc = decline("reference upload");
         }
         for (uint32_t k = 0; k < n_refs && !rc; k++) missing += !abi.resident(ses, ref_ids[k]);
         if (rc || !missing) break;
@@ -423,6 +425,7 @@ static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *
     G.n_per_dev[di]++;
     G.t_dev_lock += seam_now() - td0;
     pthread_mutex_unlock(&G.dev[di]);
+    for (int k = 0; k < n_pend; k++) abi.wait(ses, pend[k]); /* the reference uploads (outside the locks; complete before the stage below is) */
     if (rc) return -1;
     abi.wait(ses, slot); /* outside the locks: other pictures enqueue their stages meanwhile */
     return 0;
@@ -573,11 +576,11 @@ static int run_tf_pair(SeamTfPair *T, PictureParentControlSet *pcs, MeContext *c
     const int di = svt_hip_seam_bind(pcs->picture_number);
     pthread_mutex_lock(&G.dev[di]);
     const double td0 = seam_now();
-    int rc = ensure_session(di, pcs, src), slot = -1;
+    int rc = ensure_session(di, pcs, src), slot = -1, pend[16], n_pend = 0;
     void *ses = G.session[di];
     if (!rc && (ref_pics[0]->width != G.width || ref_pics[0]->stride_y != G.stride)) rc = decline("reference geometry");
     for (int pass = 0; !rc; pass++) {
-        if (ensure_resident(di, (uint64_t)ref_ids[0], ref_pics[0], &S, ref_now)) rc = decline("reference upload");
+        if (ensure_resident(di, (uint64_t)ref_ids[0], ref_pics[0], &S, ref_now, pend, &n_pend)) rc = decline("reference upload");
         else if (abi.resident(ses, ref_ids[0])) break;
         else if (pass == 3) rc = decline("ring too small for the reference set");
     }
@@ -592,6 +595,7 @@ static int run_tf_pair(SeamTfPair *T, PictureParentControlSet *pcs, MeContext *c
     G.n_per_dev[di]++;
     G.t_dev_lock += seam_now() - td0;
     pthread_mutex_unlock(&G.dev[di]);
+    for (int k = 0; k < n_pend; k++) abi.wait(ses, pend[k]);
     if (rc) return -1;
     abi.wait(ses, slot);
     return 0;
