@@ -49,7 +49,7 @@ static struct {
     void *(*host_alloc)(size_t);
 } abi;
 
-enum { SEAM_RING = 24, SEAM_MAX_REFS = 7, SEAM_RECS = 64, SEAM_DEVS = 16 };
+enum { SEAM_RING = 24, SEAM_MAX_REFS = 7, SEAM_RECS = 64, SEAM_DEVS = 16, SEAM_SLOTS = 4 }; /* SEAM_SLOTS: submissions in flight per device session (eight changed neither the time under the per-device lock nor the fps: profiles/r04_call12_*) */
 /* integration/enc_handle_binding.c: SVT_HIP_DEVICES=<d0,d1,...> shards pictures over GPUs by picture number; one resident session (ring, checksums, lock) per index */
 int svt_hip_seam_bind(unsigned long long picture_number);
 int svt_hip_seam_device_count(void);
@@ -330,8 +330,8 @@ static void create_session(int di, const EbPaReferenceObject *pa) {
     G.rows = src->luma_size / src->stride_y;
     /* largest ME area any preset derives is 256 x 256 (x 2 by the MV-based adjustment, x 3 / 2 by the variance probe) */
     const int dev_id = svt_hip_seam_device_id(di); /* -1: no sharding, the default device */
-    G.session[di] = dev_id >= 0 && abi.create_on ? abi.create_on(dev_id, G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 4)
-                                                 : abi.create(G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, 4); /* four pictures in flight */
+    G.session[di] = dev_id >= 0 && abi.create_on ? abi.create_on(dev_id, G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, SEAM_SLOTS)
+                                                 : abi.create(G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, SEAM_SLOTS); /* four pictures in flight */
     if (!G.session[di] || abi.enable_stage(G.session[di], pa->quarter_downsampled_picture_ptr->org_x, pa->sixteenth_downsampled_picture_ptr->org_x, 4, 768, 768)) {
         fprintf(stderr, "SVT_HIP_ME_SEAM: cannot create the ME session\n");
         abort();

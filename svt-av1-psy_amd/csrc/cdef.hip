@@ -348,6 +348,21 @@ __device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
     return v;
 }
 
+// Reduce-scatter over a quad: lane q of the quad receives the quad's total of v_q (q = 0..3) -- three DPP adds and six selects for FOUR values, where summing all
+// four values into every lane (quad_sum x 4) and then picking one by lane costs eight DPP adds and a select chain.  Step 1 (partner q ^ 1): a lane keeps the two
+// values whose index has its own bit 0 and hands the other two over; step 2 (partner q ^ 2): the same with bit 1.
+__device__ __forceinline__ uint32_t quad_reduce_scatter(const uint32_t v0, const uint32_t v1, const uint32_t v2, const uint32_t v3, const int q) {
+    const bool b0 = (q & 1) != 0, b1 = (q & 2) != 0;
+    uint32_t k0 = b0 ? v1 : v0, k1 = b0 ? v3 : v2;
+    const uint32_t s0 = b0 ? v0 : v1, s1 = b0 ? v2 : v3;
+    k0 += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
+    k1 += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xf, 0xf, false);
+    uint32_t       kk = b1 ? k1 : k0;
+    const uint32_t ss = b1 ? k0 : k1;
+    kk += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ss, 0x4E, 0xf, 0xf, false); // quad_perm [2,3,0,1]
+    return kk;
+}
+
 typedef uint32_t acc16 __attribute__((vector_size(64)));
 
 // Tile row pitch in pixels: block + two 8-pixel halos, padded by whole 8-pixel chunks until one row of units (uh pixel rows) is half the LDS
@@ -443,23 +458,21 @@ __device__ __forceinline__ void search_pass(const LaneCtx& L, const TapOffs& o, 
 template <int NG>
 __device__ __forceinline__ void search_reduce(acc16& a_s, acc16& a_s2, acc16& a_sd, const uint32_t d_s, const uint32_t d_s2,
                                               const int q, const bool act, const bool weighted, const int cs, unsigned long long* cells) {
-    const unsigned long long sd = quad_sum((d_s & 0xffffu) + (d_s >> 16)), sd2 = quad_sum(d_s2);
-#pragma unroll
-    for (int c = 0; c < 4 * NG; c++) {
-        a_s[c]  = quad_sum((a_s[c] & 0xffffu) + (a_s[c] >> 16));
-        a_s2[c] = quad_sum(a_s2[c]);
-        a_sd[c] = quad_sum(a_sd[c]);
-    }
+    // (every quantity of an 8x8 unit fits 32 bits -- 64 samples of at most 4095: sum <= 262 080, sum of squares / products <= 1.08e9 -- so the integer side stays in
+    // dwords and the conversions to double are single instructions; only sum * sum needs 64 bits)
+    const uint32_t sd = quad_sum((d_s & 0xffffu) + (d_s >> 16)), sd2 = quad_sum(d_s2);
 #pragma unroll
     for (int k = 0; k < NG; k++) {
-        const unsigned long long ss  = q == 0 ? a_s[4 * k] : q == 1 ? a_s[4 * k + 1] : q == 2 ? a_s[4 * k + 2] : a_s[4 * k + 3];
-        const unsigned long long ss2 = q == 0 ? a_s2[4 * k] : q == 1 ? a_s2[4 * k + 1] : q == 2 ? a_s2[4 * k + 2] : a_s2[4 * k + 3];
-        const unsigned long long ssd = q == 0 ? a_sd[4 * k] : q == 1 ? a_sd[4 * k + 1] : q == 2 ? a_sd[4 * k + 2] : a_sd[4 * k + 3];
+        // lane q of the quad takes cell 4 k + q: the quad's totals of that cell's three sums by reduce-scatter
+        const uint32_t ss  = quad_reduce_scatter((a_s[4 * k] & 0xffffu) + (a_s[4 * k] >> 16), (a_s[4 * k + 1] & 0xffffu) + (a_s[4 * k + 1] >> 16),
+                                                 (a_s[4 * k + 2] & 0xffffu) + (a_s[4 * k + 2] >> 16), (a_s[4 * k + 3] & 0xffffu) + (a_s[4 * k + 3] >> 16), q);
+        const uint32_t ss2 = quad_reduce_scatter(a_s2[4 * k], a_s2[4 * k + 1], a_s2[4 * k + 2], a_s2[4 * k + 3], q);
+        const uint32_t ssd = quad_reduce_scatter(a_sd[4 * k], a_sd[4 * k + 1], a_sd[4 * k + 2], a_sd[4 * k + 3], q);
         if (act) {
-            unsigned long long dist = sd2 + ss2 - 2 * ssd; // = sum (d - s)^2
+            unsigned long long dist = (unsigned long long)sd2 + ss2 - 2ull * ssd; // = sum (d - s)^2
             if (weighted) { // dist_8xn_*_c, enc_cdef.c:23-48: IEEE double, no contraction (-ffp-contract=off)
-                const unsigned long long svar = ss2 - ((ss * ss + 32) >> 6), dvar = sd2 - ((sd * sd + 32) >> 6);
-                const double num = (double)(sd2 + ss2 - 2 * ssd) * .5 * (double)(svar + dvar + (unsigned long long)(400 << 2 * cs));
+                const uint32_t svar = ss2 - (uint32_t)(((unsigned long long)ss * ss + 32) >> 6), dvar = sd2 - (uint32_t)(((unsigned long long)sd * sd + 32) >> 6);
+                const double num = (double)dist * .5 * (double)((unsigned long long)svar + dvar + (unsigned long long)(400 << 2 * cs));
                 const double den = sqrt((double)(20000 << 4 * cs) + (double)svar * (double)dvar);
                 dist = (unsigned long long)floor(.5 + num / den);
             }
