@@ -9,7 +9,8 @@ O=gpurun_out/$TAG; mkdir -p $O
 if [ "$2" != "quick" ]; then
   timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1
 fi
-timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+cp gpurun_out/bench_detail.json $O/bench_detail.json 2>/dev/null; grep -v BENCH_DETAIL $O/bench_default.err > $O/bench_default.err.short; mv $O/bench_default.err.short $O/bench_default.err
 timeout 600 python bench.py --steps 20 --warmup 5 --mode strips --no-cpu --no-pmc --legs none > $O/bench_strips.json 2> $O/bench_strips.err
 P="--steps 20 --warmup 5 --no-cpu --no-parity-check --no-pmc"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py $P > $O/stats.log 2>&1
