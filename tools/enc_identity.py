@@ -448,6 +448,30 @@ def seam_env(name, lib, outdir, tag, device=0):
     return env
 
 
+def repeat_pairs(name, lib, outdir, want_ivf, pairs=2, host="avx2", timeout=600):
+    """`pairs` more (host alone, host + the case's stage seams) encodes of case `name`, each bitstream compared with `want_ivf` (bytes): the fps of a 0.5 s encode spreads
+    by +- 5 % from run to run, so bench.py quotes the median of several pairs.  -> {"fps_alone": [...], "fps_with_stages": [...], "identical": bool}"""
+    w, h, n, bd, extra = CASES[name]
+    clip = os.path.join(outdir, name + "_rep.yuv")
+    clip_frames = next((int(a[5:]) for a in extra if a.startswith("+clip")), n)
+    make_clip(clip, w, h, min(clip_frames, n), bd, static="+static" in extra)
+    args = [a for a in extra if not a.startswith("+")]
+    res = {"fps_alone": [], "fps_with_stages": [], "identical": True}
+    for i in range(pairs):
+        for key, env in (("fps_alone", None), ("fps_with_stages", seam_env(name, lib, outdir, "rep%d" % i))):
+            out = os.path.join(outdir, "%s_rep_%s_%d" % (name, key, i))
+            r, _ = encode(clip, w, h, n, bd, args, out, env, timeout=timeout, enc=HOST_ENC[host])
+            ok = r.returncode == 0 and open(out + ".ivf", "rb").read() == want_ivf
+            res["identical"] = res["identical"] and ok
+            for ln in (r.stdout + r.stderr).splitlines():
+                if "Average Speed" in ln:
+                    res[key].append(float(ln.split(":")[1].split()[0]))
+            if os.path.exists(out + ".ivf"):
+                os.remove(out + ".ivf")
+    os.remove(clip)
+    return res
+
+
 def run_instances(name, lib, outdir, k, host="avx2", timeout=1800):
     """K concurrent encodes of case `name` (each its own process, all host threads, one shared MI355X): aggregate fps and host CPU seconds per frame of the intrinsics
     host alone vs the same host with the case's stage seams on the GPU.  Every one of the 2K bitstreams must equal the C-only encoder's (the one
