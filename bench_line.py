@@ -83,7 +83,7 @@ def compact(out):
         line["encoder_fps_1080p_preset8"] = e
     fp = out.get("frame_partition")
     if isinstance(fp, dict):
-        line["frame_partition"] = _pick(fp, ("value", "unit", "ms_per_step", "scaling", "collective"), 4)
+        line["frame_partition"] = _pick(fp, ("value", "ms_per_step", "scaling", "collective"), 4)  # (Mblocks/s of one picture x its references per launch: detail file)
     legs = {}
     for name, k in kernels.items():
         row = leg_row(k)

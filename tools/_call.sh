@@ -1,5 +1,12 @@
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-.}
 ulimit -c 0
-O=gpurun_out/r04_call14; mkdir -p $O
-timeout 1200 python tools/enc_identity.py --case sweep --out /tmp/idt_sweep > $O/sweep.log 2>&1; grep -a "identical=\|ALL IDENT\|MISMATCH" $O/sweep.log | cut -c1-64
-echo "== the same with the AVX-512 host build"; timeout 600 python tools/enc_identity.py --host avx512 --case tplrecon_p8_8bit,everyseam_p4_8bit_lp2,tfdriver_p8_10bit --out /tmp/idt512 2>&1 | grep -a "identical=\|ALL IDENT\|MISMATCH\|encoder fps" | cut -c1-120
+O=gpurun_out/r04_call15; mkdir -p $O
+timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo "default rc=$? bytes=$(wc -c < $O/bench_default.json)"
+grep -v BENCH_DETAIL $O/bench_default.err | tail -5
+cp gpurun_out/bench_detail.json $O/bench_detail.json
+python - <<'PY'
+import json
+l=json.loads(open('gpurun_out/r04_call15/bench_default.json').read().strip().splitlines()[-1])
+print(l['encoder_fps_1080p_preset8'])
+d=json.load(open('gpurun_out/bench_detail.json')); print(d['encoder_fps_1080p_preset8'].get('fps_avx2_pairs'))
+PY
