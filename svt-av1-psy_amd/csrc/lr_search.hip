@@ -642,7 +642,7 @@ inline int sg_slots(const SvtHipLrSearchParams& P) {
 }
 // The self-guided planes are kept for a GROUP of parameter sets at a time (the filter launch of a group, then its projection launch, in stream order): all 16
 // sets of a 4K plane were 1.06 GB of workspace.  Group size: as many sets as fit 240 MB, at least one, then evened out over the groups
-// (16 sets of a 4K 10-bit plane: 6 + 6 + 4, 216 MB; four groups of four cost 11 % of the stage's time, profiles/r04_call4_*).
+// (16 sets of a 4K 10-bit plane: 6 + 6 + 4, 216 MB; grouping costs ~11 % of the stage's time whichever way the sets are split: profiles/r04_call4_*, r04_final_*).
 inline int sg_group(const SvtHipLrSearchParams& P, const int slots) {
     if (slots <= 0) return 0;
     const size_t per_set = (size_t)P.width * P.height * (P.bit_depth <= 10 ? 4 : 8);
