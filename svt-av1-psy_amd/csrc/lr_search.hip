@@ -43,7 +43,8 @@ struct SgResult { long long err; int32_t xqd[2]; };
 
 struct Ws { // workspace carving (device pointers)
     SvtHipRect*         rects;
-    unsigned long long* acc;     // [n] trial accumulators
+    unsigned long long* acc;     // [n] trial accumulators (RESTORE_NONE, Wiener)
+    unsigned long long* acc2;    // [n] the self-guided branch's own (it runs beside the Wiener refinement on a second stream)
     WnState*            wn;      // [n]
     long long*          M;       // [n][49]
     long long*          H;       // [n][49 * 49]
@@ -660,6 +661,7 @@ inline size_t carve(const SvtHipLrSearchParams& P, void* base, Ws* ws) {
     Ws w;
     w.rects = (SvtHipRect*)take(n * sizeof(SvtHipRect));
     w.acc = (unsigned long long*)take(n * 8);
+    w.acc2 = (unsigned long long*)take(n * 8);
     w.wn = (WnState*)take(n * sizeof(WnState));
     w.M = (long long*)take(n * 49 * 8);
     w.H = (long long*)take(n * 49 * 49 * 8);
@@ -695,6 +697,42 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<0>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
     hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, st, W.acc, units, 0, n);
     SVT_LAUNCH_CHECK();
+    // The two searches are independent (they write different fields of a unit's record and keep separate accumulators): the self-guided one -- two or three long
+    // launches per group of parameter sets -- runs on the calling thread's second stream BESIDE the Wiener refinement, which is tens of short dependent launches with a
+    // host read-back every eight steps and leaves the chip mostly idle.  Fork after the unit rectangles / the RESTORE_NONE pass, join before returning.
+    const bool  both = P.wn_enabled && P.sg_enabled && slots > 0;
+    hipStream_t sg_st = st;
+    hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
+    if (both) {
+        svthip::thread_fork(&sg_st, &ev_fork, &ev_join);
+        HIP_CHECK(hipMemsetAsync(W.acc2, 0, (size_t)n * 8, st));
+        HIP_CHECK(hipEventRecord(ev_fork, st));
+        HIP_CHECK(hipStreamWaitEvent(sg_st, ev_fork, 0));
+    }
+    unsigned long long* sg_acc = both ? W.acc2 : W.acc;
+    auto self_guided = [&]() {
+        const int group = sg_group(P, slots);
+        for (int s0 = 0; s0 < slots; s0 += group) { // a group's planes are overwritten by the next group's filter launch: stream order keeps the projection before it
+            const int  gs = slots - s0 < group ? slots - s0 : group;
+            const dim3 fgrid(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, gs);
+            if (P.bit_depth <= 10) { // int16 differences (see lr_sgr_flt_kernel); 12-bit keeps the int32 planes
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, sg_st, P, W.flt, s0);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, gs), dim3(PROJ_T), 0, sg_st, P, W.rects, W.flt, W.sg, slots, s0);
+            } else {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, sg_st, P, W.flt, s0);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, gs), dim3(PROJ_T), 0, sg_st, P, W.rects, W.flt, W.sg, slots, s0);
+            }
+        }
+        hipLaunchKernelGGL(lr_sgr_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, sg_st, P, W.sg, units, slots, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<2>), tgrid, dim3(256), LRS_SMEM, sg_st, P, W.rects, W.wn, units, sg_acc);
+        hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, sg_st, sg_acc, units, 2, n);
+        SVT_LAUNCH_CHECK();
+    };
+    if (both) { // enqueued first: it is already running while the host steps through the Wiener refinement
+        self_guided();
+        HIP_CHECK(hipEventRecord(ev_join, sg_st));
+    }
+    int rc_wn = 0;
     if (P.wn_enabled) {
         svt_hip_lr_compute_stats_batch(P.dgd, P.src, W.rects, (uint32_t)n, mw, mh, (int)P.dgd_stride, (int)P.src_stride, P.wiener_win, P.highbd ? P.bit_depth : 8,
                                        (int64_t*)W.M, (int64_t*)W.H, stream);
@@ -712,26 +750,11 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
             hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<1>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
         }
         SVT_LAUNCH_CHECK();
-        if (active > 0) return -2; // the lock-step cap was hit with units still searching: their sse[1] is not final -- the caller must not use this plane's result
+        if (active > 0) rc_wn = -2; // the lock-step cap was hit with units still searching: their sse[1] is not final -- the caller must not use this plane's result
     }
-    if (P.sg_enabled && slots > 0) {
-        const int group = sg_group(P, slots);
-        for (int s0 = 0; s0 < slots; s0 += group) { // a group's planes are overwritten by the next group's filter launch: stream order keeps the projection before it
-            const int  gs = slots - s0 < group ? slots - s0 : group;
-            const dim3 fgrid(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, gs);
-            if (P.bit_depth <= 10) { // int16 differences (see lr_sgr_flt_kernel); 12-bit keeps the int32 planes
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, st, P, W.flt, s0);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, gs), dim3(PROJ_T), 0, st, P, W.rects, W.flt, W.sg, slots, s0);
-            } else {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, st, P, W.flt, s0);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, gs), dim3(PROJ_T), 0, st, P, W.rects, W.flt, W.sg, slots, s0);
-            }
-        }
-        hipLaunchKernelGGL(lr_sgr_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.sg, units, slots, n);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<2>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
-        hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, st, W.acc, units, 2, n);
-        SVT_LAUNCH_CHECK();
-    }
+    if (both) HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0)); // (also on the failure path: the second stream's work must not outlive the call's ordering)
+    if (rc_wn) return rc_wn;
+    if (!both && P.sg_enabled && slots > 0) self_guided();
     return 0;
 }
 

@@ -75,6 +75,21 @@ HostCallLease::~HostCallLease() {
     g_lease_pool[device].push_back(c); // (most recently used first: the arena that has already grown is the one that is taken again)
 }
 
+// A second stream + two events of the calling thread on its current device (made on first use, kept): for a stage that runs two independent launch sequences side
+// by side and joins them (the loop-restoration search: Wiener refinement beside the self-guided search).
+struct ThreadFork { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static thread_local ThreadFork t_fork[MAX_DEVICES];
+void thread_fork(hipStream_t* aux, hipEvent_t* fork, hipEvent_t* join) {
+    ensure_device();
+    ThreadFork& f = t_fork[current_device()];
+    if (!f.st) {
+        HIP_CHECK(hipStreamCreateWithFlags(&f.st, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&f.join, hipEventDisableTiming));
+    }
+    *aux = f.st; *fork = f.fork; *join = f.join;
+}
+
 // Four zeroed device words for ONE launch sequence on `st` (tickets / counters of a kernel that orders its own workgroups): slots of a per-device ring, cleared in
 // stream order.  A slot is taken again after RING later requests -- far more than launch sequences are ever in flight on one device.
 uint32_t* stream_scratch_u32x4(hipStream_t st) {

@@ -87,6 +87,7 @@ struct HostCall {
     void sync();
 };
 HostCall& host_call();
+void      thread_fork(hipStream_t* aux, hipEvent_t* fork, hipEvent_t* join); // the calling thread's second stream + fork / join events on its device (runtime.hip)
 uint32_t* stream_scratch_u32x4(hipStream_t st);
 // device-resident copies of host picture planes kept across host calls (runtime.hip): acquire pins an entry for (host buffer, content id) on the current device
 uint8_t* plane_cache_acquire(const void* host_ptr, uint64_t id, size_t bytes, bool* hit, int* token);
