@@ -787,7 +787,8 @@ void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost* a) {
         P.skip = d_skip; P.pri = d_str[p ? 2 : 0]; P.sec = d_str[p ? 3 : 1]; P.dir = d_dir; P.var = d_var;
         svthip::cdef_frame_dispatch(0, &P, c.stream);
     }
-    for (int p = 0; p < a->num_planes; p++) c.down2d(a->plane[p], (size_t)a->stride[p] * px, d_out[p], pitch[p], wid[p] * px, rows[p]);
+    for (int p = 0; p < a->num_planes; p++) c.down2d_later(a->plane[p], (size_t)a->stride[p] * px, d_out[p], pitch[p], wid[p] * px, rows[p]);
+    c.finish(); // (one synchronisation for the three planes)
 }
 
 // Host-pointer form of the strength SEARCH for the three planes of a 4:2:0 picture (what a seam around cdef_seg_search, cdef_process.c:443, calls once per
@@ -845,9 +846,10 @@ void svt_hip_cdef_search_host(const SvtHipCdefSearchHost* a) {
         svthip::cdef_frame_dispatch(1, &P, c.stream);
     }
     for (int p = 0; p < 3; p++)
-        if (nc[p ? 1 : 0]) c.down(h_mse[p], d_mse[p], (size_t)nfb * nc[p ? 1 : 0] * 8);
-    c.down(a->dir, d_dir, (size_t)nfb * 64);
-    c.down(a->var, d_var, (size_t)nfb * 64 * 4);
+        if (nc[p ? 1 : 0]) c.down_later(h_mse[p], d_mse[p], (size_t)nfb * nc[p ? 1 : 0] * 8);
+    c.down_later(a->dir, d_dir, (size_t)nfb * 64);
+    c.down_later(a->var, d_var, (size_t)nfb * 64 * 4);
+    c.finish(); // (one synchronisation for the five arrays)
 }
 
 uint8_t svt_aom_cdef_find_dir_hip(const uint16_t* img, int32_t stride, int32_t* var, int32_t coeff_shift) {

@@ -195,6 +195,7 @@ static void plane_cache_free_all() {
 void HostCall::begin() {
     dev_used = 0;
     pin_used = 0;
+    n_pend   = 0;
 }
 void HostCall::reserve(size_t dev_bytes, size_t pin_bytes) {
     dev_bytes += 4096;
@@ -269,6 +270,19 @@ void HostCall::down2d(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch
     HIP_CHECK(hipMemcpyAsync(p, dsrc, dpitch * rows, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     for (size_t y = 0; y < rows; y++) memcpy((uint8_t*)hdst + y * hpitch, p + y * dpitch, width_bytes);
+}
+void HostCall::down2d_later(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch, size_t width_bytes, size_t rows) {
+    if (n_pend == 16) finish();
+    uint8_t* p = (uint8_t*)palloc(dpitch * rows);
+    HIP_CHECK(hipMemcpyAsync(p, dsrc, dpitch * rows, hipMemcpyDeviceToHost, stream));
+    pend[n_pend++] = Pending{hdst, p, hpitch, dpitch, width_bytes, rows};
+}
+void HostCall::down_later(void* hdst, const void* dsrc, size_t bytes) { down2d_later(hdst, bytes, dsrc, bytes, bytes, 1); }
+void HostCall::finish() {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for (int i = 0; i < n_pend; i++)
+        for (size_t y = 0; y < pend[i].rows; y++) memcpy((uint8_t*)pend[i].h + y * pend[i].hpitch, pend[i].p + y * pend[i].dpitch, pend[i].width);
+    n_pend = 0;
 }
 void HostCall::sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
 

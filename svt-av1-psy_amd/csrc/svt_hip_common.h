@@ -84,6 +84,14 @@ struct HostCall {
     void up(void* ddst, const void* hsrc, size_t bytes);
     void down(void* hdst, const void* dsrc, size_t bytes);
     void down2d(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch, size_t width_bytes, size_t rows);
+    // the same, DEFERRED: the device-to-pinned copy is enqueued now, the copy into the caller's memory happens in finish() after ONE synchronisation -- a host form
+    // that returns several arrays pays one wait instead of one per array (up to 16 pending copies)
+    void down_later(void* hdst, const void* dsrc, size_t bytes);
+    void down2d_later(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch, size_t width_bytes, size_t rows);
+    void finish();
+    struct Pending { void* h; const uint8_t* p; size_t hpitch, dpitch, width, rows; };
+    Pending pend[16];
+    int     n_pend = 0;
     void sync();
 };
 HostCall& host_call();

@@ -388,12 +388,12 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     if (rc) { c.sync(); return rc; }
     // the filtered blocks (every 64x64 block in full, as get_final_filtered_pixels writes them, :2608-2672)
     const size_t pic0 = (size_t)P.sp.ref_org_y * P.sp.ref_stride + P.sp.ref_org_x, cpic0 = (size_t)(P.sp.ref_org_y >> 1) * P.uv_stride + (P.sp.ref_org_x >> 1);
-    c.down2d((uint8_t*)out_y + pic0 * px, (size_t)P.sp.ref_stride * px, d_cy + pic0 * px, (size_t)P.sp.ref_stride * px, (size_t)z.pw * px, z.ph);
+    c.down2d_later((uint8_t*)out_y + pic0 * px, (size_t)P.sp.ref_stride * px, d_cy + pic0 * px, (size_t)P.sp.ref_stride * px, (size_t)z.pw * px, z.ph);
     if (chroma) {
-        c.down2d((uint8_t*)out_u + cpic0 * px, (size_t)P.uv_stride * px, d_cu + cpic0 * px, (size_t)P.uv_stride * px, (size_t)(z.pw / 2) * px, z.ph / 2);
-        c.down2d((uint8_t*)out_v + cpic0 * px, (size_t)P.uv_stride * px, d_cv + cpic0 * px, (size_t)P.uv_stride * px, (size_t)(z.pw / 2) * px, z.ph / 2);
+        c.down2d_later((uint8_t*)out_u + cpic0 * px, (size_t)P.uv_stride * px, d_cu + cpic0 * px, (size_t)P.uv_stride * px, (size_t)(z.pw / 2) * px, z.ph / 2);
+        c.down2d_later((uint8_t*)out_v + cpic0 * px, (size_t)P.uv_stride * px, d_cv + cpic0 * px, (size_t)P.uv_stride * px, (size_t)(z.pw / 2) * px, z.ph / 2);
     }
-    if (stats) c.down(stats, d_stats, sizeof(SvtHipTfPictureStats));
-    c.sync();
+    if (stats) c.down_later(stats, d_stats, sizeof(SvtHipTfPictureStats));
+    c.finish(); // (one synchronisation for the three planes and the statistics)
     return 0;
 }
