@@ -1025,7 +1025,10 @@ typedef struct SvtHipTplSrcParams {
     uint8_t  i_slice;                   /* pcs->slice_type == I_SLICE: no ME candidates (:767) */
     uint8_t  enable_me_16x16, enable_me_8x8; /* PU count of the ME tables: 85 / 21 / 5 */
     uint8_t  max_cand, max_refs, max_l0; /* pa_me_data */
-    uint8_t  pad[2];
+    uint8_t  intra_mode_end;            /* tpl_ctrls.intra_mode_end: DC_PRED (0) .. PAETH_PRED (12) */
+    uint8_t  search_flags;              /* bit 0: !use_sad_in_src_search (transform + SATD costs), bit 1: compute_rate, bits 2-3: sub-pel rounds of tpl_subpel_search
+                                           (0 FULL_PEL, 1 HALF_PEL, 2 QUARTER_PEL), bit 4: subpel_diag_refinement == 4.  Both 0 = tpl levels 4 / 5 (the fast kernels);
+                                           anything else = the option set of tpl levels 0-3 (csrc/tpl_full.hip; 16x16 blocks, subsample_tx 0) */
     int16_t  quant_fp[2], round_fp[2], dequant[2]; /* quants_8bit.y_quant_fp / y_round_fp[qIndex], deq_8bit.y_dequant_qtx[qIndex] (DC, AC; :541-547) */
     SvtHipTplRef refs[8];
 } SvtHipTplSrcParams;
@@ -1034,8 +1037,8 @@ typedef struct SvtHipTplSrcStats {      /* TplSrcStats (coding_unit.h:323-331) w
     uint64_t ref_frame_poc;
     int16_t  mv_row, mv_col;            /* MV in 1/8 sample units */
     int32_t  best_rf_idx;               /* -1: no inter candidate */
-    uint8_t  best_mode;                 /* PredictionMode: DC_PRED (0) or NEWMV (16) */
-    uint8_t  best_intra_mode;           /* DC_PRED */
+    uint8_t  best_mode;                 /* PredictionMode: the best intra mode (DC_PRED 0 .. PAETH_PRED 12) or NEWMV (16) */
+    uint8_t  best_intra_mode;           /* DC_PRED .. intra_mode_end */
     uint8_t  written;                   /* 1 for cells the reference writes (at least half of the block inside the picture, :580), else the cell is left untouched */
     uint8_t  pad[5];
 } SvtHipTplSrcStats;

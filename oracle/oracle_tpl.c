@@ -31,7 +31,7 @@ typedef struct OracleTplParams { /* = SvtHipTplSrcParams */
     uint32_t width, height, aligned_width, sbs_x, n_sb;
     uint32_t src_stride;
     uint64_t src_off;
-    uint8_t  dispenser_search_level, subsample_tx, pf_shape, disable_intra_pred, i_slice, enable_me_16x16, enable_me_8x8, max_cand, max_refs, max_l0, pad[2];
+    uint8_t  dispenser_search_level, subsample_tx, pf_shape, disable_intra_pred, i_slice, enable_me_16x16, enable_me_8x8, max_cand, max_refs, max_l0, intra_mode_end, search_flags; /* the last two must be 0 here: this restatement covers tpl levels 4 / 5 */
     int16_t  quant_fp[2], round_fp[2], dequant[2];
     OracleTplRef refs[8];
 } OracleTplParams;

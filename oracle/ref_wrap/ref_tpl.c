@@ -11,6 +11,8 @@
  */
 #include "src_ops_process.c"
 #include "md_config_process.h"
+void init_fn_ptr(void);
+void svt_av1_init_me_luts(void);
 
 typedef struct RefTplRef { /* = SvtHipTplRef */
     uint64_t plane_off, picture_number;
@@ -22,7 +24,10 @@ typedef struct RefTplParams { /* = SvtHipTplSrcParams (include/svtav1_hip.h) */
     uint32_t width, height, aligned_width, sbs_x, n_sb;
     uint32_t src_stride;
     uint64_t src_off; /* of picture sample (0, 0) */
-    uint8_t  dispenser_search_level, subsample_tx, pf_shape, disable_intra_pred, i_slice, enable_me_16x16, enable_me_8x8, max_cand, max_refs, max_l0, pad[2];
+    uint8_t  dispenser_search_level, subsample_tx, pf_shape, disable_intra_pred, i_slice, enable_me_16x16, enable_me_8x8, max_cand, max_refs, max_l0;
+    uint8_t  intra_mode_end; /* tpl_ctrls.intra_mode_end: DC_PRED (0) .. PAETH_PRED (12) */
+    uint8_t  search_flags;   /* bit 0: !use_sad_in_src_search (transform + SATD costs), bit 1: compute_rate, bits 2-3: sub-pel rounds (0 FULL_PEL, 1 HALF_PEL,
+                                2 QUARTER_PEL), bit 4: subpel_diag_refinement = 4 */
     int16_t  quant_fp[2], round_fp[2], dequant[2];
     RefTplRef refs[8];
 } RefTplParams;
@@ -49,6 +54,8 @@ void ref_tpl_dispenser_picture(RefTplParams *P, int q_index, const uint8_t *src_
         svt_aom_init_intra_dc_predictors_c_internal();
         svt_aom_asm_set_convolve_hbd_asm_table();
         svt_aom_init_intra_predictors_internal();
+        init_fn_ptr();          /* svt_aom_mefn_ptr: the variance functions of the sub-pel search (enc_handle.c:1460) */
+        svt_av1_init_me_luts(); /* sad_per_bit tables read by svt_tpl_init_mv_cost_params (enc_handle.c:1459) */
         rtcd_done = 1;
     }
     SequenceControlSet      *scs  = calloc(1, sizeof(*scs));
@@ -104,7 +111,12 @@ void ref_tpl_dispenser_picture(RefTplParams *P, int q_index, const uint8_t *src_
     cm->mi_cols = (int32_t)(P->aligned_width >> 2);
     /* controls: the set the device stage covers (tpl levels 4 and 5 of set_tpl_params, initial_rc_process.c:331-378) */
     TplControls *tc = &pcs->tpl_ctrls;
-    tc->enable = 1; tc->compute_rate = 0; tc->enable_tpl_qps = 0; tc->intra_mode_end = DC_PRED; tc->use_sad_in_src_search = 1; tc->subpel_depth = FULL_PEL;
+    tc->enable = 1; tc->enable_tpl_qps = 0;
+    /* ... and, with intra_mode_end / search_flags set, the rest of set_tpl_params' levels (0-3: :301-342) */
+    tc->intra_mode_end = P->intra_mode_end; tc->use_sad_in_src_search = !(P->search_flags & 1); tc->compute_rate = (P->search_flags >> 1) & 1;
+    tc->subpel_depth = (SUBPEL_FORCE_STOP)(FULL_PEL - ((P->search_flags >> 2) & 3)); tc->subpel_diag_refinement = (P->search_flags & 16) ? 4 : 0;
+    scs->static_config.qp = 35; pcs->update_type = SVT_AV1_ARF_UPDATE; /* read by tpl_subpel_search's MV-cost set-up only (MV_COST_NONE: no effect on the result) */
+    svt_av1_setup_scale_factors_for_frame(&scs->sf_identity, P->width, P->height, P->width, P->height);
     tc->disable_intra_pred_nref = P->disable_intra_pred; /* with temporal_layer_index == hierarchical_levels below */
     tc->pf_shape = (EB_TRANS_COEFF_SHAPE)P->pf_shape;
     tc->dispenser_search_level = P->dispenser_search_level;

@@ -50,6 +50,10 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 
 struct SvtHipCdefParams;
 struct SvtHipLrParams;
+struct SvtHipTplSrcParams;
+struct SvtHipTplReconParams;
+struct SvtHipTplSrcStats;
+struct SvtHipTplReconStats;
 
 namespace svthip {
 
@@ -97,6 +101,13 @@ struct HostCall {
 HostCall& host_call();
 void      thread_fork(hipStream_t* aux, hipEvent_t* fork, hipEvent_t* join); // the calling thread's second stream + fork / join events on its device (runtime.hip)
 uint32_t* stream_scratch_u32x4(hipStream_t st);
+// the TPL dispenser with the option set of tpl levels 0-3 (tpl_full.hip): every intra mode, SATD costs, sub-pel vectors, rate
+bool tpl_full_wanted(const ::SvtHipTplSrcParams& P);
+bool tpl_full_supported(const ::SvtHipTplSrcParams& P);
+void tpl_full_src_launch(const ::SvtHipTplSrcParams& P, const uint8_t* src, const uint8_t* ref, const uint8_t* tot, const uint32_t* mv, const uint8_t* cand,
+                         ::SvtHipTplSrcStats* stats, hipStream_t st);
+void tpl_full_recon_launch(const ::SvtHipTplReconParams& R, const uint8_t* src, const uint8_t* ref, const ::SvtHipTplSrcStats* ss, uint8_t* rec,
+                           ::SvtHipTplReconStats* out, uint32_t* sync, int cols16, int rows16, hipStream_t st);
 // device-resident copies of host picture planes kept across host calls (runtime.hip): acquire pins an entry for (host buffer, content id) on the current device
 uint8_t* plane_cache_acquire(const void* host_ptr, uint64_t id, size_t bytes, bool* hit, int* token);
 void     plane_cache_release(int token, bool now_ready);

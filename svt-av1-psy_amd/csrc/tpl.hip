@@ -568,6 +568,7 @@ void launch_tpl_recon(const SvtHipTplReconParams& P, const uint8_t* src, const u
 }
 
 bool tpl_supported(const SvtHipTplSrcParams& P) {
+    if (svthip::tpl_full_wanted(P)) return svthip::tpl_full_supported(P); // the option set of tpl levels 0-3: tpl_full.hip
     if (P.dispenser_search_level > 1 || P.subsample_tx > 2 || P.pf_shape > 2 || !P.n_sb || !P.sbs_x) return false;
     if (P.dispenser_search_level == 1 && P.subsample_tx != 2) return false; // 32x32 blocks exist with TX_32X8 only (tpl level 5)
     if (P.dispenser_search_level == 0 && P.subsample_tx == 1) return false; // TX_16X8: no tpl level uses it
@@ -583,11 +584,15 @@ void svt_hip_tpl_src_stage(const SvtHipTplSrcParams* params, const uint8_t* src_
     svthip::ensure_device();
     const SvtHipTplSrcParams& P = *params;
     if (!tpl_supported(P)) {
-        fprintf(stderr, "libsvtav1_hip: svt_hip_tpl_src_stage: option set outside tpl levels 4 / 5 (level %d, subsample_tx %d, pf_shape %d)\n", P.dispenser_search_level,
+        fprintf(stderr, "libsvtav1_hip: svt_hip_tpl_src_stage: option set not covered (level %d, subsample_tx %d, pf_shape %d)\n", P.dispenser_search_level,
                 P.subsample_tx, P.pf_shape);
         abort();
     }
     hipStream_t st = (hipStream_t)stream;
+    if (svthip::tpl_full_wanted(P)) {
+        svthip::tpl_full_src_launch(P, src_base, ref_base, total_me_candidate_index, me_mv_array, me_candidate_array, stats, st);
+        return;
+    }
     if (P.dispenser_search_level == 0) {
         if (P.subsample_tx == 0) launch_tpl<16, 16>(P, src_base, ref_base, total_me_candidate_index, me_mv_array, me_candidate_array, stats, 0, st);
         else launch_tpl<16, 4>(P, src_base, ref_base, total_me_candidate_index, me_mv_array, me_candidate_array, stats, 0, st);
@@ -647,7 +652,7 @@ void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* 
     const SvtHipTplReconParams& R = *params;
     const SvtHipTplSrcParams&   P = R.src;
     if (!tpl_supported(P)) {
-        fprintf(stderr, "libsvtav1_hip: svt_hip_tpl_recon_stage: option set outside tpl levels 4 / 5 (level %d, subsample_tx %d, pf_shape %d)\n", P.dispenser_search_level,
+        fprintf(stderr, "libsvtav1_hip: svt_hip_tpl_recon_stage: option set not covered (level %d, subsample_tx %d, pf_shape %d)\n", P.dispenser_search_level,
                 P.subsample_tx, P.pf_shape);
         abort();
     }
@@ -656,6 +661,15 @@ void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* 
     const bool  edge_sbs = (P.aligned_width & 63) || (aligned_h & 63); // SBs the picture edge cuts run at level 0 (:2048-2051)
     const char* form_env = getenv("SVT_HIP_TPL_RECON_FORM"); // (read per call: a picture-sized stage, and the tests switch it inside one process)
     const int   form = form_env ? atoi(form_env) : 5;
+    if (svthip::tpl_full_wanted(P)) { // tpl levels 0-3: one launch, dependencies as data (the only form of that option set)
+        uint32_t* sync = svthip::stream_scratch_u32x4(st);
+        hipLaunchKernelGGL(tpl_recon_rows_reset_kernel, dim3((cols16 * rows16 + 255) / 256), dim3(256), 0, st, out, 1, cols16 * rows16);
+        SVT_LAUNCH_CHECK();
+        svthip::tpl_full_recon_launch(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, cols16, rows16, st);
+        hipLaunchKernelGGL(tpl_recon_dep_finish_kernel, dim3(1), dim3(64), 0, st, out, sync);
+        SVT_LAUNCH_CHECK();
+        return;
+    }
     if (form == 4 || form == 5) { // dependencies as data, every block in flight: 5 (the default) with release / acquire fences at agent scope, 4 with sequentially-consistent
                                   // ones (416 us against 339 us for a 1080p picture with a third of its blocks intra: profiles/r04_call3_tpl_forms.txt)
         uint32_t* sync = svthip::stream_scratch_u32x4(st); // [0] tickets of the first launch, [1] blocks that gave up waiting, [2] tickets of the second launch

@@ -22,7 +22,7 @@ class TplParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("aligned_width", C.c_uint32), ("sbs_x", C.c_uint32), ("n_sb", C.c_uint32), ("src_stride", C.c_uint32),
                 ("src_off", C.c_uint64), ("dispenser_search_level", C.c_uint8), ("subsample_tx", C.c_uint8), ("pf_shape", C.c_uint8), ("disable_intra_pred", C.c_uint8),
                 ("i_slice", C.c_uint8), ("enable_me_16x16", C.c_uint8), ("enable_me_8x8", C.c_uint8), ("max_cand", C.c_uint8), ("max_refs", C.c_uint8),
-                ("max_l0", C.c_uint8), ("pad", C.c_uint8 * 2), ("quant_fp", C.c_int16 * 2), ("round_fp", C.c_int16 * 2), ("dequant", C.c_int16 * 2),
+                ("max_l0", C.c_uint8), ("intra_mode_end", C.c_uint8), ("search_flags", C.c_uint8), ("quant_fp", C.c_int16 * 2), ("round_fp", C.c_int16 * 2), ("dequant", C.c_int16 * 2),
                 ("refs", TplRef * 8)]
 
 
