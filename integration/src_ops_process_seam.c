@@ -121,13 +121,34 @@ static double now_ms(void) {
 }
 
 /* the option set svt_hip_tpl_src_stage covers (tpl levels 4 / 5, initial_rc_process.c:343-378) on an 8-bit single-tile-grid picture */
+/* search_flags of SvtHipTplSrcParams for this picture's controls; 0 with intra_mode_end == DC_PRED = the option set of tpl levels 4 / 5 (the fast kernels) */
+static uint8_t tpl_search_flags(const TplControls *tc) {
+    return (uint8_t)((tc->use_sad_in_src_search ? 0 : 1) | (tc->compute_rate ? 2 : 0) | ((FULL_PEL - tc->subpel_depth) << 2) | (tc->subpel_diag_refinement >= 4 ? 16 : 0));
+}
 static int tpl_seam_covers(const SequenceControlSet *scs, const PictureParentControlSet *pcs) {
     const TplControls *tc = &pcs->tpl_ctrls;
-    if (!scs->in_loop_ois || !tc->use_sad_in_src_search || tc->intra_mode_end != DC_PRED || tc->subpel_depth != FULL_PEL || tc->compute_rate || tc->enable_tpl_qps)
-        return 0;
-    if (!((tc->dispenser_search_level == 0 && tc->subsample_tx == 0) || (tc->dispenser_search_level == 1 && tc->subsample_tx == 2))) return 0;
-    if (scs->b64_size != 64) return 0;
+    if (!scs->in_loop_ois || scs->b64_size != 64) return 0;
+    if (tc->intra_mode_end == DC_PRED && !tpl_search_flags(tc)) /* tpl levels 4 / 5 */
+        return (tc->dispenser_search_level == 0 && tc->subsample_tx == 0) || (tc->dispenser_search_level == 1 && tc->subsample_tx == 2);
+    /* tpl levels 0-3 (set_tpl_params, initial_rc_process.c:301-342): 16x16 blocks, every intra mode, SATD costs, sub-pel vectors, rate */
+    if (tc->dispenser_search_level != 0 || tc->subsample_tx != 0 || tc->intra_mode_end > PAETH_PRED) return 0;
+    if (tc->subpel_depth < QUARTER_PEL || tc->subpel_depth > FULL_PEL) return 0;
+    if (tc->subpel_diag_refinement != 0 && tc->subpel_diag_refinement < 4) return 0; /* (1-3 scale org_error: no level selects them) */
+    const EbPictureBufferDesc *inp = pcs->enhanced_pic; /* the block-edge geometry the device derives (init_xd_tpl, :403-416) must be the picture's */
+    if (pcs->av1_cm->mi_rows != (int32_t)(((inp->height + 7) & ~7u) >> 2) || pcs->av1_cm->mi_cols != (int32_t)(pcs->aligned_width >> 2)) return 0;
     return 1;
+}
+/* the dispenser's qIndex: tpl_mc_flow_dispenser :1352-1372 (with enable_tpl_qps the picture's quantizer moves with its temporal layer) */
+static int32_t tpl_q_index(const SequenceControlSet *scs, const PictureParentControlSet *pcs) {
+    int32_t q = quantizer_to_qindex[(uint8_t)scs->static_config.qp];
+    if (pcs->tpl_ctrls.enable_tpl_qps) {
+        static const double rate[6][6] = {{1, 1, 1, 1, 1, 1}, {0.6, 1, 1, 1, 1, 1}, {0.6, 0.8, 1, 1, 1, 1}, {0.6, 0.8, 0.9, 1, 1, 1}, {0.35, 0.6, 0.8, 0.9, 1, 1},
+                                           {0.35, 0.6, 0.8, 0.9, 0.95, 1}};
+        const double q_val = svt_av1_convert_qindex_to_q(q, 8);
+        q += pcs->tpl_data.tpl_slice_type == I_SLICE ? svt_av1_compute_qdelta(q_val, q_val * 0.25, 8)
+                                                     : svt_av1_compute_qdelta(q_val, q_val * rate[pcs->hierarchical_levels][pcs->tpl_data.tpl_temporal_layer_index], 8);
+    }
+    return q;
 }
 
 /* the per-SB seam: nothing for a picture the device reconstructed, else the reference's function */
@@ -282,7 +303,7 @@ static void tpl_mc_flow_dispenser_use2_body(TPL_DISP_ARGS) {
     const double t0 = now_ms();
     const EbPictureBufferDesc *inp = pcs->enhanced_pic;
     MotionEstimationData      *med = pcs->pa_me_data;
-    const int32_t q_index = quantizer_to_qindex[(uint8_t)scs->static_config.qp]; /* tpl_mc_flow_dispenser :1352 (enable_tpl_qps == 0: no delta) */
+    const int32_t q_index = tpl_q_index(scs, pcs);
     SvtHipTplSrcParams P;
     SvtHipTplHostPlanes H;
     memset(&P, 0, sizeof(P));
@@ -293,6 +314,7 @@ static void tpl_mc_flow_dispenser_use2_body(TPL_DISP_ARGS) {
     P.dispenser_search_level = pcs->tpl_ctrls.dispenser_search_level; P.subsample_tx = pcs->tpl_ctrls.subsample_tx; P.pf_shape = (uint8_t)pcs->tpl_ctrls.pf_shape;
     P.disable_intra_pred = pcs->tpl_ctrls.disable_intra_pred_nref && (pcs->temporal_layer_index == pcs->hierarchical_levels); /* :557 */
     P.i_slice = pcs->slice_type == I_SLICE;
+    P.intra_mode_end = pcs->tpl_ctrls.intra_mode_end; P.search_flags = tpl_search_flags(&pcs->tpl_ctrls);
     P.enable_me_16x16 = pcs->enable_me_16x16; P.enable_me_8x8 = pcs->enable_me_8x8;
     P.max_cand = med->max_cand; P.max_refs = med->max_refs; P.max_l0 = med->max_l0;
     for (int i = 0; i < 2; i++) {

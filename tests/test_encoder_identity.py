@@ -59,6 +59,7 @@ def _check(res):
                                   "tiny_lowdelay_p8", "tiny_lowdelay_p10_10bit", "tiny_lowdelay_720p_tf",
                                   "tiny_screen_p8", "tiny_screen_lowdelay_p9",
                                   "tiny_tplrecon_p8", "tiny_tplrecon_p10", "tiny_tiles_p8",
+                                  "tiny_tplrecon_p2",  # tpl level 1 (presets <= M2): every intra mode, SATD costs, quarter-pel vectors, rate (csrc/tpl_full.hip)
                                   "tiny_strips_cdef_lr_p4"])  # SVT_HIP_STRIPS: one picture's CDEF / LR launches over two emulated devices  # both halves of the TPL dispenser as device stages  # screen content: enable_me_sr_adjustment == 2  # low delay: level-0 HME areas from list-0 motion; the zero-motion temporal filter (on from 720p)
 def test_encoder_identity_emulator(case, tmp_path):
     from conftest import EmuBackend  # builds the emulator library if needed

@@ -141,6 +141,8 @@ CASES = {
     "tplrecon_p8_8bit": (448, 264, 20, 8, ["--preset", "8", "--lp", "1", "+tplseam", "+tplrecon"]),
     "tplrecon_p4_8bit_lp2": (448, 264, 12, 8, ["--preset", "4", "--lp", "2", "+tplseam", "+tplrecon"]),
     "tplrecon_everyseam_1080p_p8": (1920, 1080, 20, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
+    "tplrecon_p2_8bit": (448, 264, 18, 8, ["--preset", "2", "--lp", "2", "+tplseam", "+tplrecon"]),  # tpl level 1 (csrc/tpl_full.hip)
+    "tplrecon_everyseam_p1_8bit": (256, 144, 12, 8, ["--preset", "1", "--lp", "2", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
     "tplseam_me_p8_8bit": (448, 264, 20, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+tplseam"]),  # ME results produced by the device stage feed the TPL stage
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
     # one encode over TWO (emulated) devices: SVT_HIP_DEVICES=0,1 shards the pictures by picture number; every seam at once
@@ -154,6 +156,9 @@ CASES = {
     "tiny_tplrecon_p10": (192, 136, 18, 8, ["--preset", "10", "--lp", "1", "+tplseam", "+tplrecon"]),
     "tiny_tplrecon_p4_lp2": (192, 136, 12, 8, ["--preset", "4", "--lp", "2", "+tplseam", "+tplrecon"]),
     "tiny_tplseam_p10": (192, 136, 18, 8, ["--preset", "10", "--lp", "1", "+tplseam"]),
+    # tpl level 1 (presets <= M2: every intra mode, SATD costs, quarter-pel vectors, rate, per-layer quantizer; csrc/tpl_full.hip), both halves on the device
+    "tiny_tplrecon_p2": (128, 72, 10, 8, ["--preset", "2", "--lp", "1", "+tplseam", "+tplrecon"]),
+    "tiny_tplseam_p2": (128, 72, 10, 8, ["--preset", "2", "--lp", "1", "+tplseam"]),
     "tiny_tfdriver_p8": (128, 128, 12, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
     "tiny_tfdriver_p8_10bit": (128, 128, 12, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
     "tiny_tfdriver_p4_lp2": (128, 128, 10, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+tfdriver"]),
