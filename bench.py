@@ -497,6 +497,35 @@ def cpu_tpl_recon_stage(k):
                                                                                             "sample": "the leg's whole 1080p picture, oracle/oracle_tpl.c"}}
 
 
+def cpu_tpl_level1(k):
+    """Checker + CPU baseline (kind "reference") of the tpl-level-1 legs: the reference's own tpl_mc_flow_dispenser_sb_generic (oracle/_ref/libsvtref_me.so, one core) on
+    the leg's whole picture with the leg's quantizer row; source-based statistics, the TplStats grid and the reconstruction must equal the device's."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libsvtref_me.so")
+    if not os.path.exists(path):
+        return {}
+    me = C.CDLL(path)
+    P, planes, pad = k["P"], k["planes"], k["pad"]
+    Q = type(P).from_buffer_copy(P)
+    want = np.zeros(k["cells"], k["out"].dtype)
+    grid = np.zeros((k["cells"], 8), np.int64)
+    rec = np.zeros((P.height, P.width), np.uint8)
+    t0 = time.perf_counter()
+    me.ref_tpl_dispenser_picture(C.byref(Q), 120, vp(planes), pad, pad, vp(planes), vp(k["tot"]), vp(k["mvs"]), vp(k["cand"]), k["n_pus"], vp(want), vp(grid), vp(rec))
+    dt = time.perf_counter() - t0
+    if any(Q.quant_fp[i] != P.quant_fp[i] or Q.round_fp[i] != P.round_fp[i] or Q.dequant[i] != P.dequant[i] for i in range(2)):
+        raise SystemExit("bench: the tpl level 1 leg's quantizer row is not row 120 of the reference's tables")
+    for name in want.dtype.names:
+        if name != "pad":
+            must_equal("tpl_level1 source-based " + name, k["out"][name], want[name])
+    w = want["written"] > 0
+    ro = k["recon_out"]
+    for j, name in enumerate(("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate")):  # (16x16 blocks, synth size 16: result_model_store only clamps to >= 1)
+        must_equal("tpl_level1 " + name, np.maximum(1, ro[name][w]), grid[w, j])
+    must_equal("tpl_level1 reconstruction", k["recon"][pad:pad + P.height, pad:pad + P.width], rec)
+    return {"parity_checked_values": int(k["cells"]) * 13 + int(rec.size), "cpu_baseline": {"value": 1 / dt, "unit": "pictures/s", "cores": 1, "kind": "reference",
+                                                                                             "sample": "the leg's whole 1080p picture: both halves of the reference's dispenser (C kernels) through oracle/ref_wrap/ref_tpl.c"}}
+
+
 def cpu_tpl_stage(k):
     """Checker + CPU baseline of the TPL leg: the C restatement (oracle/oracle_tpl.c, one core) on the leg's whole picture; every statistics record must equal
     the device's."""
@@ -1206,7 +1235,7 @@ def main():
     ap.add_argument("--min-leg-s", type=float, default=MIN_TIMED_S, help="minimum device time of every timed region (a step = as many launches as that takes)")
     ap.add_argument("--no-pmc", action="store_true", help="skip this run's own rocprofv3 --pmc child passes (roofline.traffic then comes from the committed summary)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (me, sad, txfm, config3, cdef, lr, hme, session, tf, tpl, tfpic, lrsearch): A/B measurements")
+    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (me, sad, txfm, config3, cdef, lr, hme, session, tf, tpl, tpl1, tfpic, lrsearch): A/B measurements")
     ap.add_argument("--extra", action="store_true", help="also sweep the other search areas / sub_sad and the remaining stages (reported under kernels)")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -1381,6 +1410,14 @@ def main():
             kernels.update(bench_legs.tpl_recon_stage(torch, lib, pkg, stream, 5, 1, keep))
             if cpu:
                 kernels["tpl_recon_stage_1080p8"].update(cpu_tpl_recon_stage(keep))
+        if want("tpl1"):
+            keep = {}
+            kernels.update(bench_legs.tpl_level1_stage(torch, lib, pkg, stream, 3, 1, keep))
+            if cpu:
+                chk = cpu_tpl_level1(keep)
+                kernels["tpl_l1_src_1080p8"].update(chk)
+                if "cpu_baseline" in chk:
+                    kernels["tpl_l1_recon_1080p8"]["cpu_baseline_both_halves"] = chk["cpu_baseline"]
         if want("tfpic"):
             keep = {}
             kernels.update(bench_legs.tf_picture_stage(torch, lib, pkg, stream, 5, 1, keep))

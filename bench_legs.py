@@ -950,6 +950,82 @@ def tpl_src_stage(torch, lib, pkg, stream, steps, warmup, keep=None):
                                       "roofline": roof(alg, t, "tpl_src_kernel<16, 16>")}}
 
 
+def tpl_level1_stage(torch, lib, pkg, stream, steps, warmup, keep, size=(1920, 1080)):
+    """SURVEY 8f / VERDICT r3 item 9: both halves of the TPL dispenser with the option set of tpl level 1 (presets M0-M2: every intra mode DC..PAETH, transform + SATD
+    costs, quarter-pel vectors, rate; csrc/tpl_full.hip) on a 1080p 8-bit picture, device-resident.  Smooth content and references displaced by whole and half samples,
+    so that the inter path and its sub-pel search decide most blocks.  One wave per 16x16 block; VALU / latency bound (13 transforms per block for the intra modes, ~15
+    bilinear variances per inter candidate)."""
+    g = np.random.default_rng(29)
+    W, H, PAD, n_l0, n_l1 = size[0], size[1], 96, 2, 2
+    aw, ah = (W + 7) & ~7, (H + 7) & ~7
+    sbs_x, sbs_y, n_ref = (aw + 63) // 64, (ah + 63) // 64, n_l0 + n_l1
+    stride, rows = aw + 2 * PAD + 24, ah + 2 * PAD + 16
+    yy, xx = np.mgrid[0:rows, 0:stride]
+    img = 128 + 60 * np.sin(xx / 9.0 + yy / 23.0) + 40 * np.sin(yy / 7.0 - xx / 31.0) + 25 * ((xx // 24 + yy // 20) % 2)
+    planes = np.zeros((1 + n_ref, rows, stride), np.uint8)
+    planes[0] = np.clip(img + g.integers(-4, 5, img.shape), 0, 255)
+    for r in range(n_ref):
+        a = np.roll(planes[0].astype(np.int32), (r + 1, -2 * r - 1), (0, 1))
+        b = np.roll(planes[0].astype(np.int32), (r + 1 + (r & 1), -2 * r), (0, 1))
+        planes[1 + r] = np.clip(((a + b + 1) >> 1) + g.integers(-2 - r, 3 + r, a.shape), 0, 255)
+    P = pkg.TplSrcParams()
+    P.width, P.height, P.aligned_width, P.sbs_x, P.n_sb, P.src_stride = W, H, aw, sbs_x, sbs_x * sbs_y, stride
+    P.src_off = PAD * stride + PAD
+    P.dispenser_search_level, P.subsample_tx, P.pf_shape, P.disable_intra_pred, P.i_slice, P.enable_me_16x16, P.enable_me_8x8 = 0, 0, 0, 0, 0, 1, 0
+    P.intra_mode_end, P.search_flags = 12, 1 | 2 | (2 << 2)
+    n_pus, max_cand = 21, 7
+    P.max_refs, P.max_l0, P.max_cand = n_ref, n_l0, max_cand
+    P.quant_fp[0], P.quant_fp[1], P.round_fp[0], P.round_fp[1], P.dequant[0], P.dequant[1] = 532, 431, 61, 76, 123, 152  # q index 120 of the 8-bit tables
+    for l in range(2):
+        for r in range(4):
+            R, have = P.refs[l * 4 + r], r < (n_l0 if l == 0 else n_l1)
+            slot = r if l == 0 else n_l0 + r
+            R.plane_off = (1 + slot) * rows * stride if have else 0
+            R.picture_number, R.stride, R.org_x, R.org_y, R.max_width, R.max_height, R.valid = 100 + 10 * l + r, stride, PAD, PAD, W, H, int(have)
+    n_sb = P.n_sb
+    tot = g.integers(1, 4, (n_sb, n_pus)).astype(np.uint8)  # 1-3 candidates per block (what the 16x16 ME results of an M2 encode hold)
+    shp = (n_sb, n_pus, max_cand)
+    cand = (g.integers(0, 2, shp) | (g.integers(0, n_l0, shp) << 2) | (g.integers(0, n_l1, shp) << 4)).astype(np.uint8)
+    mvx = np.zeros((n_sb, n_pus, n_ref), np.int16)
+    mvy = np.zeros((n_sb, n_pus, n_ref), np.int16)
+    for r in range(n_ref):
+        mvx[:, :, r] = -2 * r - 1 + g.integers(-1, 2, (n_sb, n_pus))
+        mvy[:, :, r] = r + 1 + g.integers(-1, 2, (n_sb, n_pus))
+    bad = g.random((n_sb, n_pus)) < 0.35  # a third of the blocks get vectors that miss: the intra modes win there and the reconstruction half has its dependency chains
+    mvx[bad] += 9
+    mvy[bad] -= 7
+    mvs = np.ascontiguousarray((mvy.astype(np.uint16).astype(np.uint32) << 16) | mvx.astype(np.uint16).astype(np.uint32))
+    cells = (aw + 15) // 16 * ((ah + 15) // 16)
+    d_pl, d_tot, d_mv, d_cand = _dev(torch, planes), _dev(torch, tot), _dev(torch, mvs), _dev(torch, cand)
+    d_out = torch.zeros(cells * 40, dtype=torch.uint8, device="cuda")
+    t_src = _time(torch, lambda: lib.svt_hip_tpl_src_stage(C.addressof(P), d_pl.data_ptr(), d_pl.data_ptr(), d_tot.data_ptr(), d_mv.data_ptr(), d_cand.data_ptr(),
+                                                           d_out.data_ptr(), stream), steps, warmup, batches=2)
+    out = d_out.cpu().numpy().view(pkg.TplSrcStats)
+    R = pkg.TplReconParams()
+    C.memmove(C.addressof(R.src), C.addressof(P), C.sizeof(P))
+    for i in range(8):
+        C.memmove(C.addressof(R.rec_refs[i]), C.addressof(P.refs[i]), C.sizeof(pkg.TplRef))
+    R.recon_off, R.recon_stride, R.is_ref = P.src_off, stride, 1
+    d_rec = torch.zeros(rows * stride, dtype=torch.uint8, device="cuda")
+    d_rs = torch.zeros(cells * 40, dtype=torch.uint8, device="cuda")
+
+    def run():
+        d_rec.zero_()
+        lib.svt_hip_tpl_recon_stage(C.addressof(R), d_pl.data_ptr(), d_pl.data_ptr(), d_out.data_ptr(), d_rec.data_ptr(), d_rs.data_ptr(), stream)
+    t_rec = _time(torch, run, steps, warmup, batches=2)
+    rs = d_rs.cpu().numpy().view(pkg.TplReconStats)
+    n_blk = int(out["written"].sum())
+    w = out["written"] > 0
+    keep.update(P=P, planes=planes, tot=tot, mvs=mvs, cand=cand, out=out.copy(), cells=cells, recon=d_rec.cpu().numpy().reshape(rows, stride), recon_out=rs.copy(), pad=PAD, n_pus=n_pus)
+    n_cand = int(tot[:, 5:21].sum())
+    alg_src = n_blk * (256 + 40) + n_cand * 17 * 17 * 15 + tot.nbytes + mvs.nbytes + cand.nbytes  # per candidate: ~15 bilinear variances of a 17x17 window
+    alg_rec = n_blk * (3 * 256 + 80)
+    return {"tpl_l1_src_1080p8": {"us": t_src * 1e6, "pictures_per_s": 1 / t_src, "blocks_16x16": n_blk, "inter_wins_frac": float(np.mean(out["best_mode"][w] == 16)),
+                                             "fractional_vectors_frac": float(np.mean(((out["mv_row"][w] | out["mv_col"][w]) & 7) != 0)),
+                                             "intra_modes_chosen": int(len(np.unique(out["best_intra_mode"][w]))), "roofline": roof(alg_src, t_src, "tpl_full_src_kernel")},
+            "tpl_l1_recon_1080p8": {"us": t_rec * 1e6, "pictures_per_s": 1 / t_rec, "blocks_16x16": n_blk, "roofline": roof(alg_rec, t_rec, "tpl_full_recon_kernel")}}
+
+
 def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
     """the TPL dispenser's reconstruction half (src_ops_process.c:979-1198) of the tpl_src_stage leg's 1080p picture, device-resident: one launch per
     anti-diagonal of the 16x16 block grid (187 at 1080p, tpl level 4).  Launch-latency bound by construction (csrc/tpl.hip); every run starts from a

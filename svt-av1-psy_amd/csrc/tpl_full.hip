@@ -43,6 +43,7 @@ constexpr Iscan16 make_iscan16() {
 __device__ constexpr Iscan16 kIscan16 = make_iscan16();
 __device__ constexpr uint8_t kSmW16[16] = {255, 225, 196, 170, 145, 123, 102, 84, 68, 54, 43, 33, 26, 20, 17, 16}; // sm_weight_arrays + 16
 // per intra mode: p_angle (mode_to_angle_map; 0 = not directional), dx, dy (eb_dr_intra_derivative, intra_prediction.c:245-296)
+__device__ constexpr int8_t kEdgeKernel[3][5] = {{0, 4, 8, 4, 0}, {0, 5, 6, 5, 0}, {2, 4, 4, 4, 2}}; // svt_av1_filter_intra_edge_c, by strength - 1
 __device__ constexpr int16_t kAngle[13] = {0, 90, 180, 45, 135, 113, 157, 203, 67, 0, 0, 0, 0};
 __device__ constexpr int16_t kDx[13]    = {0, 0, 0, 64, 64, 27, 151, 1, 27, 0, 0, 0, 0};
 __device__ constexpr int16_t kDy[13]    = {0, 0, 0, 1, 64, 151, 27, 27, 1, 0, 0, 0, 0};
@@ -100,13 +101,12 @@ __device__ __forceinline__ void filter_edges(const int angle, const int x0, cons
         auto pass = [&](const uint8_t* E0, const int corner, const int sz, const int strength) -> int { // p = &E[-1], p[i] with i = k + 1
             const int i = k + 1;
             if (i < 1 || i >= sz || !strength) return k < 0 ? corner : E0[NB + k];
-            const int kern[3][5] = {{0, 4, 8, 4, 0}, {0, 5, 6, 5, 0}, {2, 4, 4, 4, 2}};
             int s = 0;
 #pragma unroll
             for (int j = 0; j < 5; j++) {
                 int q = i - 2 + j;
                 q = q < 0 ? 0 : (q > sz - 1 ? sz - 1 : q);
-                s += (q == 0 ? corner : (int)E0[NB + q - 1]) * kern[strength - 1][j];
+                s += (q == 0 ? corner : (int)E0[NB + q - 1]) * (int)kEdgeKernel[strength - 1][j];
             }
             return (s + 8) >> 4;
         };
@@ -498,10 +498,9 @@ __global__ __launch_bounds__(64) void tpl_full_recon_kernel(const SvtHipTplRecon
             inter_predict(P, ref_base + R.plane_off + (size_t)R.org_y * R.stride + R.org_x, (long)R.stride, x0, y0, s.mv_row, s.mv_col, S.pred, S.im, l);
         } else {
             // the neighbours' reconstruction must be there: one lane per cell polls
-            int  dxs[4] = {0, -1, -1, 1}, dys[4] = {-1, 0, -1, -1};
             bool timed_out = false;
-            if (l < 4) {
-                const int nx = cx + dxs[l], ny = cy + dys[l];
+            if (l < 4) { // lane 0: above, 1: left, 2: above-left, 3: above-right (the first block column only)
+                const int nx = cx + (l == 0 ? 0 : (l == 3 ? 1 : -1)), ny = cy + (l == 1 ? 0 : -1);
                 if (nx >= 0 && ny >= 0 && nx < cols16 && (l < 3 || cx == 0)) {
                     uint32_t* flag  = &out[(size_t)ny * cols16 + nx].reserved;
                     uint32_t  polls = 0;
