@@ -1001,6 +1001,9 @@ def tpl_level1_stage(torch, lib, pkg, stream, steps, warmup, keep, size=(1920, 1
     t_src = _time(torch, lambda: lib.svt_hip_tpl_src_stage(C.addressof(P), d_pl.data_ptr(), d_pl.data_ptr(), d_tot.data_ptr(), d_mv.data_ptr(), d_cand.data_ptr(),
                                                            d_out.data_ptr(), stream), steps, warmup, batches=2)
     out = d_out.cpu().numpy().view(pkg.TplSrcStats)
+    n_blk, n_cand = int(out["written"].sum()), int(tot[:, 5:21].sum())
+    alg_src = n_blk * (256 + 40) + n_cand * 17 * 17 * 15 + tot.nbytes + mvs.nbytes + cand.nbytes  # per candidate: ~15 bilinear variances of a 17x17 window
+    roof_src = roof(alg_src, t_src, "tpl_full_src_kernel")  # (here: the roofline object remembers the region timed LAST)
     R = pkg.TplReconParams()
     C.memmove(C.addressof(R.src), C.addressof(P), C.sizeof(P))
     for i in range(8):
@@ -1014,15 +1017,12 @@ def tpl_level1_stage(torch, lib, pkg, stream, steps, warmup, keep, size=(1920, 1
         lib.svt_hip_tpl_recon_stage(C.addressof(R), d_pl.data_ptr(), d_pl.data_ptr(), d_out.data_ptr(), d_rec.data_ptr(), d_rs.data_ptr(), stream)
     t_rec = _time(torch, run, steps, warmup, batches=2)
     rs = d_rs.cpu().numpy().view(pkg.TplReconStats)
-    n_blk = int(out["written"].sum())
     w = out["written"] > 0
     keep.update(P=P, planes=planes, tot=tot, mvs=mvs, cand=cand, out=out.copy(), cells=cells, recon=d_rec.cpu().numpy().reshape(rows, stride), recon_out=rs.copy(), pad=PAD, n_pus=n_pus)
-    n_cand = int(tot[:, 5:21].sum())
-    alg_src = n_blk * (256 + 40) + n_cand * 17 * 17 * 15 + tot.nbytes + mvs.nbytes + cand.nbytes  # per candidate: ~15 bilinear variances of a 17x17 window
     alg_rec = n_blk * (3 * 256 + 80)
     return {"tpl_l1_src_1080p8": {"us": t_src * 1e6, "pictures_per_s": 1 / t_src, "blocks_16x16": n_blk, "inter_wins_frac": float(np.mean(out["best_mode"][w] == 16)),
                                              "fractional_vectors_frac": float(np.mean(((out["mv_row"][w] | out["mv_col"][w]) & 7) != 0)),
-                                             "intra_modes_chosen": int(len(np.unique(out["best_intra_mode"][w]))), "roofline": roof(alg_src, t_src, "tpl_full_src_kernel")},
+                                             "intra_modes_chosen": int(len(np.unique(out["best_intra_mode"][w]))), "roofline": roof_src},
             "tpl_l1_recon_1080p8": {"us": t_rec * 1e6, "pictures_per_s": 1 / t_rec, "blocks_16x16": n_blk, "roofline": roof(alg_rec, t_rec, "tpl_full_recon_kernel")}}
 
 
