@@ -123,7 +123,8 @@ static double now_ms(void) {
 /* the option set svt_hip_tpl_src_stage covers (tpl levels 4 / 5, initial_rc_process.c:343-378) on an 8-bit single-tile-grid picture */
 /* search_flags of SvtHipTplSrcParams for this picture's controls; 0 with intra_mode_end == DC_PRED = the option set of tpl levels 4 / 5 (the fast kernels) */
 static uint8_t tpl_search_flags(const TplControls *tc) {
-    return (uint8_t)((tc->use_sad_in_src_search ? 0 : 1) | (tc->compute_rate ? 2 : 0) | ((FULL_PEL - tc->subpel_depth) << 2) | (tc->subpel_diag_refinement >= 4 ? 16 : 0));
+    const int rounds = FULL_PEL - tc->subpel_depth; /* (subpel_diag_refinement is read by the sub-pel search only: levels 4 / 5 set it to 4 with FULL_PEL) */
+    return (uint8_t)((tc->use_sad_in_src_search ? 0 : 1) | (tc->compute_rate ? 2 : 0) | (rounds << 2) | (rounds && tc->subpel_diag_refinement >= 4 ? 16 : 0));
 }
 static int tpl_seam_covers(const SequenceControlSet *scs, const PictureParentControlSet *pcs) {
     const TplControls *tc = &pcs->tpl_ctrls;
@@ -133,7 +134,7 @@ static int tpl_seam_covers(const SequenceControlSet *scs, const PictureParentCon
     /* tpl levels 0-3 (set_tpl_params, initial_rc_process.c:301-342): 16x16 blocks, every intra mode, SATD costs, sub-pel vectors, rate */
     if (tc->dispenser_search_level != 0 || tc->subsample_tx != 0 || tc->intra_mode_end > PAETH_PRED) return 0;
     if (tc->subpel_depth < QUARTER_PEL || tc->subpel_depth > FULL_PEL) return 0;
-    if (tc->subpel_diag_refinement != 0 && tc->subpel_diag_refinement < 4) return 0; /* (1-3 scale org_error: no level selects them) */
+    if (tc->subpel_depth != FULL_PEL && tc->subpel_diag_refinement != 0 && tc->subpel_diag_refinement < 4) return 0; /* (1-3 scale org_error: no level selects them) */
     const EbPictureBufferDesc *inp = pcs->enhanced_pic; /* the block-edge geometry the device derives (init_xd_tpl, :403-416) must be the picture's */
     if (pcs->av1_cm->mi_rows != (int32_t)(((inp->height + 7) & ~7u) >> 2) || pcs->av1_cm->mi_cols != (int32_t)(pcs->aligned_width >> 2)) return 0;
     return 1;
