@@ -168,19 +168,33 @@ __device__ __forceinline__ uint32_t dot2(const uint32_t a, const uint32_t b, con
     __builtin_memcpy(&y, &b, 4);
     return __builtin_amdgcn_udot2(x, y, c, false);
 }
-// constrain() of cdef.c:85-91 on a pixel pair = clamp(diff, -m, m) with m = max(0, threshold - (|diff| >> shift)), one saturating
-// v_pk_sub_u16 for the max(0, .); threshold 0 yields 0 for any shift
+// constrain() of cdef.c:85-91 on a pixel pair = clamp(diff, -m, m) with m = max(0, threshold - (|diff| >> shift)) = sign(diff) * min(|diff|, m).  |diff| and the
+// sign multiplier (+1 / -1) of a tap do not depend on the strength: a pass that evaluates several strengths on the same taps (the search: four primary levels, three
+// secondary strengths) shares them, and what is left per (tap, strength) is one shift, one saturating v_pk_sub_u16 for the max(0, .), one unsigned minimum and the
+// multiply-add that applies the sign while it accumulates (five packed operations plus an add before).  threshold 0 yields 0 for any shift.
+__device__ __forceinline__ s16x2 pk_minu(const s16x2 a, const s16x2 b) { const u16x2 x = (u16x2)a, y = (u16x2)b; return (s16x2)(x < y ? x : y); }
+struct TapMag { s16x2 ad, sg; };
+__device__ __forceinline__ TapMag tap_mag(const s16x2 t, const s16x2 x) {
+    const s16x2 z = {0, 0}, one = {1, 1}, diff = t - x;
+    TapMag m;
+    m.ad = pk_max(diff, z - diff);
+    m.sg = (diff >> 15) | one;
+    return m;
+}
+// the same in one piece, for passes that evaluate ONE strength per tap (the apply pass): two packed operations fewer than magnitude + sign there
 __device__ __forceinline__ s16x2 constrain2(const s16x2 diff, const s16x2 thr, const s16x2 shift) {
     const s16x2 z  = {0, 0};
     const s16x2 ad = pk_max(diff, z - diff);
     const s16x2 m  = (s16x2)__builtin_elementwise_sub_sat((u16x2)thr, (u16x2)(ad >> shift));
     return pk_max(pk_min(diff, m), z - m);
 }
+__device__ __forceinline__ s16x2 constrain_mag(const s16x2 ad, const s16x2 thr, const s16x2 shift) { // min(|diff|, m); |diff| = 0x8000 (diff = -32768) shifts to >= 0xf800: m = 0
+    return pk_minu(ad, (s16x2)__builtin_elementwise_sub_sat((u16x2)thr, (u16x2)(ad >> shift)));
+}
 // Out-of-frame pixels of the frame kernel's tile.  The reference marks them CDEF_VERY_LARGE (0x7f7f): constrain() of such a tap is 0 and the tap
 // is left out of the max (cdef.c:277-301) while it can never win the min.  0x8000 has the same three properties at two packed ops per tap
 // instead of three: signed max ignores it (-32768), unsigned min ignores it (32768), and |0x8000 - x| >> shift still exceeds every threshold.
 constexpr int OUTSIDE = 0x8000;
-__device__ __forceinline__ s16x2 pk_minu(const s16x2 a, const s16x2 b) { const u16x2 x = (u16x2)a, y = (u16x2)b; return (s16x2)(x < y ? x : y); }
 
 // Tap k of a lane: byte offset (dword aligned) from the lane's own pixel pair and funnel-shift amount.  The pair sits at an even pixel index, so
 // both depend on the direction only and are computed once per unit, not once per pixel.
@@ -219,12 +233,29 @@ template <int K0, int K1> __device__ __forceinline__ void load_taps_range(const 
         t[k] = as_pk(__builtin_amdgcn_alignbyte(v.hi, v.lo, o.sh[k >> 1]));
     }
 }
+// SHARED: the caller evaluates several strengths on the same taps (magnitude / sign form, shared through common subexpressions)
+template <bool SHARED>
 __device__ __forceinline__ s16x2 pri_sum(const s16x2 x, const s16x2 (&t)[12], const s16x2 thr, const s16x2 sh, const s16x2 w0, const s16x2 w1) {
-    return w0 * (constrain2(t[0] - x, thr, sh) + constrain2(t[1] - x, thr, sh)) + w1 * (constrain2(t[2] - x, thr, sh) + constrain2(t[3] - x, thr, sh));
+    if (!SHARED) return w0 * (constrain2(t[0] - x, thr, sh) + constrain2(t[1] - x, thr, sh)) + w1 * (constrain2(t[2] - x, thr, sh) + constrain2(t[3] - x, thr, sh));
+    const TapMag m0 = tap_mag(t[0], x), m1 = tap_mag(t[1], x), m2 = tap_mag(t[2], x), m3 = tap_mag(t[3], x);
+    const s16x2  k0 = constrain_mag(m0.ad, thr, sh) * m0.sg + constrain_mag(m1.ad, thr, sh) * m1.sg;
+    const s16x2  k1 = constrain_mag(m2.ad, thr, sh) * m2.sg + constrain_mag(m3.ad, thr, sh) * m3.sg;
+    return w0 * k0 + w1 * k1;
 }
+template <bool SHARED>
 __device__ __forceinline__ s16x2 sec_sum(const s16x2 x, const s16x2 (&t)[12], const s16x2 thr, const s16x2 sh) {
-    const s16x2 k0 = constrain2(t[4] - x, thr, sh) + constrain2(t[5] - x, thr, sh) + constrain2(t[6] - x, thr, sh) + constrain2(t[7] - x, thr, sh);
-    const s16x2 k1 = constrain2(t[8] - x, thr, sh) + constrain2(t[9] - x, thr, sh) + constrain2(t[10] - x, thr, sh) + constrain2(t[11] - x, thr, sh);
+    s16x2 k0 = {0, 0}, k1 = {0, 0};
+#pragma unroll
+    for (int k = 4; k < 8; k++) {
+        if (SHARED) {
+            const TapMag a = tap_mag(t[k], x), b = tap_mag(t[k + 4], x);
+            k0 += constrain_mag(a.ad, thr, sh) * a.sg;
+            k1 += constrain_mag(b.ad, thr, sh) * b.sg;
+        } else {
+            k0 += constrain2(t[k] - x, thr, sh);
+            k1 += constrain2(t[k + 4] - x, thr, sh);
+        }
+    }
     return k0 + k0 + k1;
 }
 __device__ __forceinline__ s16x2 finish_px(const s16x2 x, const s16x2 sum, const s16x2 mn, const s16x2 mx) { // cdef.c:302-303
@@ -379,26 +410,21 @@ struct LaneCtx {
     const uint16_t* org; // search mode: source block, pitch bw
     int pitch, bw, by, bx, uw, uh, q, sub, cs, pdamp, sdamp, vm;
 };
-// LEAN (the search pass): the two tap weights are rebuilt from one per-level value inside the row loop instead of living in two registers per level -- the pass
-// keeps 48 running sums and was 4 VGPRs over the 168 that three workgroups per CU allow (the opaque copy keeps the compiler from hoisting them back out).
-template <bool LEAN = false>
+// SHARED (the search pass): four levels are evaluated on the same taps -- the magnitude / sign form of constrain (see tap_mag)
+template <bool SHARED = false>
 __device__ __forceinline__ s16x2 pri_sum_level(const LaneCtx& L, const int lvl, const s16x2 x, const s16x2 (&t)[12]) {
     const int t_  = ((lvl << L.cs) * L.vm + 8) >> 4; // adjust_strength (cdef.c:130-134); lane-varying for luma, identity for chroma (vm = 16)
     int       sh  = L.pdamp - msb_u32((uint32_t)t_);
     sh            = sh < 0 ? 0 : sh;
     const int odd = (t_ >> L.cs) & 1; // svt_aom_eb_cdef_pri_taps (cdef.c:249)
-    if (LEAN) {
-        int ov = odd * 0x10001; // the packed pair (odd, odd)
-        SVT_HIP_OPAQUE_I32(ov);
-        return pri_sum(x, t, splat(t_), splat(sh), splat(4) - as_pk((uint32_t)ov), splat(2) + as_pk((uint32_t)ov));
-    }
-    return pri_sum(x, t, splat(t_), splat(sh), splat(4 - odd), splat(2 + odd));
+    return pri_sum<SHARED>(x, t, splat(t_), splat(sh), splat(4 - odd), splat(2 + odd));
 }
+template <bool SHARED = false>
 __device__ __forceinline__ s16x2 sec_sum_strength(const LaneCtx& L, const int sec, const s16x2 x, const s16x2 (&t)[12]) {
     const int st = sec << L.cs;
     int       sh = L.sdamp - msb_u32((uint32_t)st);
     sh           = sh < 0 ? 0 : sh;
-    return sec_sum(x, t, splat(st), splat(sh));
+    return sec_sum<SHARED>(x, t, splat(st), splat(sh));
 }
 
 // Search: one pass over the lane's pixel pairs for a static grid of NP primary levels (lv[], uniform) x the four secondary strengths
@@ -428,9 +454,9 @@ __device__ __forceinline__ void search_pass(const LaneCtx& L, const TapOffs& o, 
             if (NP && scache && cached) {
                 S[1] = as_pk(sc[0]); S[2] = as_pk(sc[2048]); S[3] = as_pk(sc[4096]);
             } else {
-                S[1] = sec_sum_strength(L, 1, x, t);
-                S[2] = sec_sum_strength(L, 2, x, t);
-                S[3] = sec_sum_strength(L, 4, x, t);
+                S[1] = sec_sum_strength<true>(L, 1, x, t);
+                S[2] = sec_sum_strength<true>(L, 2, x, t);
+                S[3] = sec_sum_strength<true>(L, 4, x, t);
                 if (NP && scache) { sc[0] = as_u32(S[1]); sc[2048] = as_u32(S[2]); sc[4096] = as_u32(S[3]); }
             }
             const uint32_t dpair = as_u32(ld_pair_even(orow));
@@ -440,7 +466,7 @@ __device__ __forceinline__ void search_pass(const LaneCtx& L, const TapOffs& o, 
             }
 #pragma unroll
             for (int pi = 0; pi < (NP ? NP : 1); pi++) {
-                const s16x2 Pv = NP ? pri_sum_level(L, lv[pi], x, t) : splat(0);
+                const s16x2 Pv = NP ? pri_sum_level<true>(L, lv[pi], x, t) : splat(0);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t yu = as_u32(finish_px(x, Pv + S[k], mn, mx));
