@@ -447,8 +447,11 @@ __device__ __forceinline__ void search_pass(const LaneCtx& L, const TapOffs& o, 
             const int       ri   = (L.by * L.uh + r) * L.pitch + L.bx * L.uw + 2 * jq; // pixel index of this lane's pair relative to L.in (even)
             const uint16_t* orow = L.org + (L.by * L.uh + r) * L.bw + L.bx * L.uw + 2 * jq;
             const s16x2 x = ld_pair_even(L.in + ri);
-            s16x2 t[12], mn, mx, S[4];
-            load_taps(L.in + ri, o, x, t, mn, mx);
+            s16x2 t[12], mn = x, mx = x, S[4];
+            // a cell with only ONE of its two strengths non-zero cannot be bound by the clamp to the taps' [min, max] (see apply_pass): the pass for primary level 0
+            // (NP = 0) needs no min / max at all and reads the eight secondary taps only, the other passes skip the clamp for their sec = 0 cells
+            if (NP) load_taps(L.in + ri, o, x, t, mn, mx);
+            else load_taps_range<4, 12>(L.in + ri, o, t);
             S[0] = splat(0);
             uint32_t* sc = scache + it * 256; // (+ the value's plane of 8 x 256 dwords)
             if (NP && scache && cached) {
@@ -469,7 +472,8 @@ __device__ __forceinline__ void search_pass(const LaneCtx& L, const TapOffs& o, 
                 const s16x2 Pv = NP ? pri_sum_level<true>(L, lv[pi], x, t) : splat(0);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t yu = as_u32(finish_px(x, Pv + S[k], mn, mx));
+                    const s16x2    sum = Pv + S[k];
+                    const uint32_t yu  = as_u32((NP && k) ? finish_px(x, sum, mn, mx) : x + ((sum + splat(8) + (sum >> 15)) >> 4));
                     const int      c  = 4 * pi + k;
                     a_s[c] += yu;
                     a_s2[c] = dot2(yu, yu, a_s2[c]);
