@@ -423,10 +423,9 @@ struct __attribute__((aligned(8))) LrsPair { uint32_t v[2]; };
 #ifndef LRS_DEPTH
 #define LRS_DEPTH 4
 #endif
-// after(): called once per thread after every group of at most 4 * LRS_DEPTH = 16 samples (the point where 32-bit partial sums are folded into the 64-bit ones)
-template <bool COMPACT, typename F, typename G>
+template <bool COMPACT, typename F>
 __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, const SvtHipRect& r, const int32_t* f0, const int32_t* f1, const int r0, const int r1,
-                                                 const int tid, F body, G after) {
+                                                 const int tid, F body) {
     const int uw = r.h_end - r.h_start, uh = r.v_end - r.v_start, npx = uw * uh, w = (int)P.width, highbd = P.highbd;
     if (COMPACT && !((w | uw | r.h_start) & 3)) { // four consecutive samples per load pair: one b128 of packed (q1, q2) + one b64 of dgd - src
         const int qpr = uw >> 2, nq = qpr * uh, qy = PROJ_T / qpr, rx = PROJ_T - qy * qpr;
@@ -453,7 +452,6 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
                         body(0, -(int)(int16_t)((j & 1) ? dw >> 16 : dw & 0xffffu), (int)(int16_t)(pk & 0xffffu), (int)pk >> 16);
                     }
                 }
-            after();
         }
         return;
     }
@@ -483,13 +481,7 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
 #pragma unroll
         for (int k = 0; k < LRS_DEPTH; k++)
             if (ok[k]) body(d[k], sp[k], g0[k], g1[k]);
-        after();
     }
-}
-template <bool COMPACT, typename F>
-__device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, const SvtHipRect& r, const int32_t* f0, const int32_t* f1, const int r0, const int r1,
-                                                 const int tid, F body) {
-    for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, body, []() {});
 }
 template <bool COMPACT>
 __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const int32_t* __restrict__ flt,
@@ -542,14 +534,6 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
         else if (r1 == 0) { xq0 = xqd[0]; xq1 = 0; }
         else { xq0 = xqd[0]; xq1 = 128 - xq0 - xqd[1]; }
         long long e2 = 0;
-        if (COMPACT) { // (dword partial sums per group of samples: see eval_line)
-            uint32_t p2 = 0;
-            for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
-                const int v = (uu << 7) + xq0 * a0 + xq1 * a1;
-                const int e = ((v + (1 << 10)) >> 11) - sp;
-                p2 += (uint32_t)(e * e);
-            }, [&]() { e2 += p2; p2 = 0; });
-        } else
         for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
             const int v = (uu << 7) + xq0 * a0 + xq1 * a1;
             const int e = ((v + (1 << 10)) >> 11) - sp;
@@ -576,25 +560,6 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
         long long ad[PROJ_K], au[PROJ_K];
 #pragma unroll
         for (int k = 0; k < PROJ_K; k++) ad[k] = au[k] = 0;
-        if (COMPACT) {
-            // the compact planes hold int16 differences: |v >> 11| <= (96 + 256) * 32767 >> 11 = 5632 and |src - dgd| <= 4095, so a candidate's error is below 9728
-            // and sixteen squares (one group of samples) stay below 2^32: the squares are summed in dwords (one v_mad_u32_u24 per candidate and sample instead of
-            // two multiplies and a 64-bit add) and folded into the 64-bit sums once per group
-            uint32_t pd[PROJ_K], pu[PROJ_K];
-#pragma unroll
-            for (int k = 0; k < PROJ_K; k++) pd[k] = pu[k] = 0;
-            for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
-                const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10), dv = st * (c0 * a0 + c1 * a1);
-#pragma unroll
-                for (int k = 0; k < PROJ_K; k++) {
-                    if (k < nd) { const int e = ((v - (k + 1) * dv) >> 11) - sp; pd[k] += (uint32_t)(e * e); }
-                    if (k < nu) { const int e = ((v + (k + 1) * dv) >> 11) - sp; pu[k] += (uint32_t)(e * e); }
-                }
-            }, [&]() {
-#pragma unroll
-                for (int k = 0; k < PROJ_K; k++) { ad[k] += pd[k]; au[k] += pu[k]; pd[k] = pu[k] = 0; }
-            });
-        } else
         for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
             const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10), dv = st * (c0 * a0 + c1 * a1);
 #pragma unroll
