@@ -159,6 +159,7 @@ CASES = {
     # tpl level 1 (presets <= M2: every intra mode, SATD costs, quarter-pel vectors, rate, per-layer quantizer; csrc/tpl_full.hip), both halves on the device
     "tiny_tplrecon_p2": (128, 72, 10, 8, ["--preset", "2", "--lp", "1", "+tplseam", "+tplrecon"]),
     "tiny_tplseam_p2": (128, 72, 10, 8, ["--preset", "2", "--lp", "1", "+tplseam"]),
+    "tiny_2dev_tplrecon_p2": (128, 72, 10, 8, ["--preset", "2", "--lp", "2", "+devices:0,1", "+tplseam", "+tplrecon"]),  # the same over two (emulated) devices: resident planes by content id
     "tiny_tfdriver_p8": (128, 128, 12, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
     "tiny_tfdriver_p8_10bit": (128, 128, 12, 10, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfdriver"]),
     "tiny_tfdriver_p4_lp2": (128, 128, 10, 8, ["--preset", "4", "--lp", "2", "+seam", "+tfseam", "+tfdriver"]),
