@@ -137,6 +137,8 @@ def test_sad_nxm_batch_strip_form(be, oracle, wh):
     blocks broken by row ends, unaligned reference offsets; every pair checked in both forms."""
     import os
     w, h = wh
+    if not be.is_gpu and wh in ((16, 8), (32, 16)):
+        pytest.skip("an experiment that lost (kept as a comparison): the emulator runs four of the six sizes")
     if not be.is_gpu and w * h > 2048:
         pytest.skip("emulator: the small shapes cover the strip path")
     g = rng(700 + w + h)
