@@ -1001,9 +1001,10 @@ void     svt_get_proj_subspace_hip(const uint8_t *src8, int32_t width, int32_t h
  * transform (N2 / N4 shape, rows subsampled by 1 << subsample_tx) + svt_av1_quantize_fp reconstruction error of its residual (get_quantize_error, :224-247).
  * Output = exactly the TplSrcStats the reference stores per 16x16 cell (:958-967), which its own "else" branch (:969-977) consumes: a seam around
  * tpl_mc_flow_dispenser (:1848) fills pa_me_data->tpl_src_stats_buffer from one call per picture and lets the reference run the reconstruction half.
- * Covered option set = tpl levels 4 and 5 of set_tpl_params (initial_rc_process.c:343-378: every preset from M3 up): use_sad_in_src_search = 1, intra_mode_end = DC_PRED,
- * subpel_depth = FULL_PEL, compute_rate = 0, scs->in_loop_ois = 1; the caller must run the reference's C for anything else.  8-bit pictures (the reference's TPL is
- * 8-bit only: "10BIT not supported", :464). */
+ * Covered option sets: tpl levels 4 and 5 of set_tpl_params (initial_rc_process.c:343-378: every preset from M3 up) -- use_sad_in_src_search = 1, intra_mode_end = DC_PRED,
+ * subpel_depth = FULL_PEL, compute_rate = 0 -- with intra_mode_end = search_flags = 0, and tpl levels 0-3 (:301-342; level 1 = presets M0-M2: every intra mode, transform +
+ * SATD costs, quarter-pel vectors, rate; 16x16 blocks only) through those two fields (csrc/tpl_full.hip).  scs->in_loop_ois = 1; the caller must run the reference's C for
+ * anything else (the host forms return -1).  8-bit pictures (the reference's TPL is 8-bit only: "10BIT not supported", :464). */
 typedef struct SvtHipTplRef {           /* one per rf_idx = list * 4 + ref_idx (= svt_get_ref_frame_type(list, ref_idx) - 1, :783) */
     uint64_t plane_off;                 /* bytes from ref_base to the reference picture's buffer_y (tpl_ref_ds_ptr_array[list][ref].picture_ptr: input_padded_pic, :141) */
     uint64_t picture_number;            /* tpl_ref_ds_ptr_array[list][ref].picture_number */
@@ -1058,7 +1059,7 @@ typedef struct SvtHipTplHostPlanes {
 int svt_hip_tpl_src_stage_host(const SvtHipTplSrcParams *params, const SvtHipTplHostPlanes *planes, const uint8_t *total_me_candidate_index,
                                const uint32_t *me_mv_array, const uint8_t *me_candidate_array, SvtHipTplSrcStats *stats);
 
-/* ---- TPL dispenser, RECONSTRUCTION half (tpl_mc_flow_dispenser_sb_generic, src_ops_process.c:979-1198; same option set: tpl levels 4 / 5) ----
+/* ---- TPL dispenser, RECONSTRUCTION half (tpl_mc_flow_dispenser_sb_generic, src_ops_process.c:979-1198; same option sets) ----
  * Per block, from the statistics of the source-based half: the prediction into the picture's TPL reconstruction plane (mc_flow_rec_picture_buffer[frame_idx]) --
  * NEWMV = the block at the full-pel vector of rec_refs[best_rf_idx] (:1016-1019: the TPL reconstruction of a frame inside the sliding window, else the
  * reference's source picture), else DC from the RECONSTRUCTED neighbours (:1038-1070) --, residual against the source on the rows the transform sees -> forward
