@@ -344,14 +344,9 @@ __device__ __forceinline__ void subpel_search(const SvtHipTplSrcParams& P, const
     const bool no_diag = (P.search_flags & 16) != 0; // subpel_diag_refinement 4: org_error = 0 -- no diagonal check, no second level
     // the sub-pel limits: svt_av1_set_mv_search_range + svt_av1_set_subpel_mv_search_range around ref_mv (0, 0) (:448-455)
     const int aligned_h = (int)((P.height + 7) & ~7u);
-    auto lim = [](int lo_fp, int hi_fp, int& lo, int& hi) {
-        lo_fp = lo_fp < -1023 ? -1023 : lo_fp; hi_fp = hi_fp > 1023 ? 1023 : hi_fp;
-        lo = lo_fp * 8 > -8184 ? lo_fp * 8 : -8184; hi = hi_fp * 8 < 8184 ? hi_fp * 8 : 8184;
-        lo = lo > -16383 ? lo : -16383; hi = hi < 16383 ? hi : 16383;
-    };
-    int cmin, cmax, rmin, rmax;
-    lim(-(x0 + 16 + 4), (int)P.aligned_width - x0 + 4, cmin, cmax);
-    lim(-(y0 + 16 + 4), aligned_h - y0 + 4, rmin, rmax);
+    auto lim_lo = [](int lo_fp) { lo_fp = lo_fp < -1023 ? -1023 : lo_fp; const int lo = lo_fp * 8 > -8184 ? lo_fp * 8 : -8184; return lo > -16383 ? lo : -16383; };
+    auto lim_hi = [](int hi_fp) { hi_fp = hi_fp > 1023 ? 1023 : hi_fp; const int hi = hi_fp * 8 < 8184 ? hi_fp * 8 : 8184; return hi < 16383 ? hi : 16383; };
+    const int cmin = lim_lo(-(x0 + 16 + 4)), cmax = lim_hi((int)P.aligned_width - x0 + 4), rmin = lim_lo(-(y0 + 16 + 4)), rmax = lim_hi(aligned_h - y0 + 4);
     int br = mvr, bc = mvc;
     uint32_t besterr = subpel_variance(ref, rs, x0, y0, br, bc, src, bil, l); // svt_upsampled_setup_center_error: the variance at the full-pel start, no MV cost
     auto check = [&](const int r, const int c) -> uint32_t { // svt_check_better_fast
