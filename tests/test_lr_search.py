@@ -213,8 +213,6 @@ def test_lr_search_plane_projection_form1(be, oracle, case, monkeypatch):
     cases = GPU_CASES if be.is_gpu else DEV_CASES[:5] + [(192, 128, 10, 128, 0, (0, 7, 0, 0), (1, 9, 10, 1, 1), False)]
     if case >= len(cases) or not cases[case][6][0] or cases[case][2] > 10:
         pytest.skip("no self-guided search / 12-bit planes: the form does not apply")
-    if not be.is_gpu and case in (0, 2):
-        pytest.skip("emulator: cases 1, 4 and 5 cover the form (the CPU suite's time budget)")
     monkeypatch.delenv("SVT_HIP_LR_SG_GROUP", raising=False)
     monkeypatch.setenv("SVT_HIP_LR_PROJ_FORM", "1")
     _check_plane(be, oracle, cases[case], case)
