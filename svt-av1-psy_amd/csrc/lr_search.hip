@@ -423,13 +423,9 @@ struct __attribute__((aligned(8))) LrsPair { uint32_t v[2]; };
 #ifndef LRS_DEPTH
 #define LRS_DEPTH 4
 #endif
-// cache (form 1 of the projection kernel): the quads of a thread's FIRST group (LRS_DEPTH x (16 + 8) bytes per thread = 96 KB per workgroup: a quarter of a 256x256 unit)
-// stay in LDS from the first pass on -- mode 1 stores what it loads, mode 2 reads it back (a thread reads only what it wrote itself: no barrier) -- so the ~10 passes over
-// a unit fetch a quarter less from L2 / HBM.
-struct LrsCache { uint32_t* lds; int mode; };
 template <bool COMPACT, typename F>
 __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, const SvtHipRect& r, const int32_t* f0, const int32_t* f1, const int r0, const int r1,
-                                                 const int tid, F body, const LrsCache cache = LrsCache{nullptr, 0}) {
+                                                 const int tid, F body) {
     const int uw = r.h_end - r.h_start, uh = r.v_end - r.v_start, npx = uw * uh, w = (int)P.width, highbd = P.highbd;
     if (COMPACT && !((w | uw | r.h_start) & 3)) { // four consecutive samples per load pair: one b128 of packed (q1, q2) + one b64 of dgd - src
         const int qpr = uw >> 2, nq = qpr * uh, qy = PROJ_T / qpr, rx = PROJ_T - qy * qpr;
@@ -442,14 +438,8 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
             for (int k = 0; k < LRS_DEPTH; k++) {
                 ok[k] = i + k * PROJ_T < nq;
                 const size_t fo = (size_t)(r.v_start + (ok[k] ? y : 0)) * w + r.h_start + 4 * (ok[k] ? x : 0);
-                LrsQuad* cq = (LrsQuad*)cache.lds + k * PROJ_T + tid;                       // [k][tid], 16 bytes per lane
-                LrsPair* cd = (LrsPair*)(cache.lds + 4 * LRS_DEPTH * PROJ_T) + k * PROJ_T + tid; // behind the quads, 8 bytes per lane
-                if (cache.mode == 2 && i == tid) { Q[k] = *cq; D[k] = *cd; }
-                else {
-                    Q[k] = *(const LrsQuad*)((const uint32_t*)f1 + fo);
-                    D[k] = *(const LrsPair*)((const int16_t*)f0 + fo);
-                    if (cache.mode == 1 && i == tid) { *cq = Q[k]; *cd = D[k]; }
-                }
+                Q[k] = *(const LrsQuad*)((const uint32_t*)f1 + fo);
+                D[k] = *(const LrsPair*)((const int16_t*)f0 + fo);
                 x += rx; y += qy;
                 if (x >= qpr) { x -= qpr; y++; }
             }
@@ -493,16 +483,9 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
             if (ok[k]) body(d[k], sp[k], g0[k], g1[k]);
     }
 }
-// FORM1 (SVT_HIP_LR_PROJ_FORM=1; compact planes only; NOT the default until it has been timed on the device): a quarter of the unit cached in LDS (LrsCache) and the
-// candidates' squared errors summed in dwords per group of samples.  The passes over a unit are balanced between the re-read of its samples and ~4 000 VALU
-// instructions per thread: dword sums alone changed nothing (profiles/r04_call22_lr_search_ab.txt), the two together lower both sides.
-constexpr size_t LRS_CACHE_BYTES = (size_t)LRS_DEPTH * PROJ_T * (16 + 8);
-template <bool COMPACT, bool FORM1 = false>
+template <bool COMPACT>
 __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const int32_t* __restrict__ flt,
                                                              SgResult* __restrict__ res, const int slots, const int slot0) {
-    static_assert(!FORM1 || COMPACT, "form 1 reads the compact planes");
-    HIP_DYNAMIC_SHARED(uint32_t, lrs_cache_lds)
-    const LrsCache c_fill = LrsCache{lrs_cache_lds, FORM1 ? 1 : 0}, c_use = LrsCache{lrs_cache_lds, FORM1 ? 2 : 0};
     __shared__ long long part[PROJ_W][16];
     __shared__ long long sh_t[5], sh_err;
     __shared__ long long sh_e[3][8]; // the candidate errors of a line (down, up, the first pass's up run): workgroup-uniform and indexed at run time -- LDS, not registers
@@ -519,7 +502,7 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
     for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
         const long long sd = (long long)sp * 16 - uu, q1 = a0, q2 = a1;
         a[0] += q1 * q1; a[1] += q2 * q2; a[2] += q1 * q2; a[3] += q1 * sd; a[4] += q2 * sd;
-    }, c_fill);
+    });
     block_sums_i64(a, part, sh_t, tid, [](int) { return true; });
     if (tid == 0) {
         const long long* t = sh_t;
@@ -551,15 +534,6 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
         else if (r1 == 0) { xq0 = xqd[0]; xq1 = 0; }
         else { xq0 = xqd[0]; xq1 = 128 - xq0 - xqd[1]; }
         long long e2 = 0;
-        if (FORM1) { // (one dword per thread: see eval_line)
-            uint32_t p2 = 0;
-            for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
-                const int v = (uu << 7) + xq0 * a0 + xq1 * a1;
-                const int e = ((v + (1 << 10)) >> 11) - sp;
-                p2 += (uint32_t)(e * e);
-            }, c_use);
-            e2 = p2;
-        } else
         for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
             const int v = (uu << 7) + xq0 * a0 + xq1 * a1;
             const int e = ((v + (1 << 10)) >> 11) - sp;
@@ -586,25 +560,6 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
         long long ad[PROJ_K], au[PROJ_K];
 #pragma unroll
         for (int k = 0; k < PROJ_K; k++) ad[k] = au[k] = 0;
-        if (FORM1) {
-            // the compact planes exist for bit depths up to 10: |q1|, |q2| <= 16 420 (see lr_sgr_flt_kernel), xq0 in [-96, 31], xq1 in [0, 256], so |v >> 11| <= 2 823 and,
-            // with |src - dgd| <= 1 023, a candidate's error is below 3 848: a thread's at most 144 samples (units of up to 384 x 384 over 1 024 threads) sum to less than
-            // 2^31 -- the squares are summed in ONE dword per candidate (one v_mad_u32_u24 per candidate and sample instead of two multiplies and a 64-bit add) and
-            // widened after the pass
-            uint32_t pd[PROJ_K], pu[PROJ_K];
-#pragma unroll
-            for (int k = 0; k < PROJ_K; k++) pd[k] = pu[k] = 0;
-            for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
-                const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10), dv = st * (c0 * a0 + c1 * a1);
-#pragma unroll
-                for (int k = 0; k < PROJ_K; k++) {
-                    if (k < nd) { const int e = ((v - (k + 1) * dv) >> 11) - sp; pd[k] += (uint32_t)(e * e); }
-                    if (k < nu) { const int e = ((v + (k + 1) * dv) >> 11) - sp; pu[k] += (uint32_t)(e * e); }
-                }
-            }, c_use);
-#pragma unroll
-            for (int k = 0; k < PROJ_K; k++) { ad[k] = pd[k]; au[k] = pu[k]; }
-        } else
         for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
             const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10), dv = st * (c0 * a0 + c1 * a1);
 #pragma unroll
@@ -755,8 +710,6 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
         HIP_CHECK(hipStreamWaitEvent(sg_st, ev_fork, 0));
     }
     unsigned long long* sg_acc = both ? W.acc2 : W.acc;
-    const char* form_env   = getenv("SVT_HIP_LR_PROJ_FORM"); // (read per call: a plane-sized stage, and the tests switch it inside one process)
-    const bool  proj_form1 = form_env && atoi(form_env) == 1 && P.unit_size <= 256; // (its dword sums are sized for units of at most 1.5 x 256 samples a side)
     auto self_guided = [&]() {
         const int group = sg_group(P, slots);
         for (int s0 = 0; s0 < slots; s0 += group) { // a group's planes are overwritten by the next group's filter launch: stream order keeps the projection before it
@@ -764,8 +717,7 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
             const dim3 fgrid(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, gs);
             if (P.bit_depth <= 10) { // int16 differences (see lr_sgr_flt_kernel); 12-bit keeps the int32 planes
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, sg_st, P, W.flt, s0);
-                if (proj_form1) hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true, true>), dim3(n, gs), dim3(PROJ_T), LRS_CACHE_BYTES, sg_st, P, W.rects, W.flt, W.sg, slots, s0);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, gs), dim3(PROJ_T), 0, sg_st, P, W.rects, W.flt, W.sg, slots, s0);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, gs), dim3(PROJ_T), 0, sg_st, P, W.rects, W.flt, W.sg, slots, s0);
             } else {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, sg_st, P, W.flt, s0);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, gs), dim3(PROJ_T), 0, sg_st, P, W.rects, W.flt, W.sg, slots, s0);

@@ -202,24 +202,7 @@ def test_lr_search_plane_hip(be, oracle, case, group, monkeypatch):
         monkeypatch.delenv("SVT_HIP_LR_SG_GROUP", raising=False)
     if case >= len(cases):
         pytest.skip("GPU-sized case")
-    _check_plane(be, oracle, cases[case], case)
-
-
-@pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
-def test_lr_search_plane_projection_form1(be, oracle, case, monkeypatch):
-    """SVT_HIP_LR_PROJ_FORM=1 (csrc/lr_search.hip: a quarter of every unit cached in LDS across the projection passes, the candidates' squared errors summed in dwords;
-    opt-in until it has been timed on the device): the same results, for the bit depths that take the compact planes (<= 10)"""
-    # (emulator: case 5 = one unit of 192 x 128 = 6 144 quads, more than the 4 096 the cache holds -- later groups of samples still come from memory)
-    cases = GPU_CASES if be.is_gpu else DEV_CASES[:5] + [(192, 128, 10, 128, 0, (0, 7, 0, 0), (1, 9, 10, 1, 1), False)]
-    if case >= len(cases) or not cases[case][6][0] or cases[case][2] > 10:
-        pytest.skip("no self-guided search / 12-bit planes: the form does not apply")
-    monkeypatch.delenv("SVT_HIP_LR_SG_GROUP", raising=False)
-    monkeypatch.setenv("SVT_HIP_LR_PROJ_FORM", "1")
-    _check_plane(be, oracle, cases[case], case)
-
-
-def _check_plane(be, oracle, c, case):
-    w, h, bd, unit, ss_y, wn, sg, use_prev = c
+    w, h, bd, unit, ss_y, wn, sg, use_prev = cases[case]
     g = rng(740 + case)
     src, dgd, pad = make_planes(g, w, h, bd)
     P = search_params(src, dgd, pad, w, h, bd, unit, ss_y, wn, sg)
