@@ -186,7 +186,7 @@ CASES = {
     "tiny_p8_lossless": (64, 64, 2, 8, ["--preset", "8", "--lp", "1", "--lossless", "1", "--tune", "1"]),
 }
 # Option sweep (--case sweep): small encodes with the ME / TF / CDEF / deblocking / TPL (both halves) seams on, one encoder option set each; the claim is bitstream
-# equality and no declined picture (the TPL seams decline tpl level 1 = presets <= 2).  Sized for the CPU emulator (`--lib tests/emu/_build/libsvtav1_hipemu.so`).
+# equality and no declined picture (since the end of round 4 also at tpl level 1 = presets <= 2: csrc/tpl_full.hip).  Sized for the CPU emulator (`--lib tests/emu/_build/libsvtav1_hipemu.so`).
 _SW = ["+seam", "+tfseam", "+tfdriver", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]
 SWEEP = {
     "sweep_overlays": (192, 128, 14, 8, ["--preset", "8", "--lp", "1", "--enable-overlays", "1"]),
