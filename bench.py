@@ -1197,6 +1197,121 @@ def bench_filter_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle
             "parity_checked_values": checked}
 
 
+def bench_c_partition(torch, lib, pkg, stream, a, world, oracle):
+    """The library's OWN frame partition (csrc/partition.hip: svt_hip_frame_partition_{me,cdef,lr}) driven from ONE process -- rank 0 -- over min(GPUs, N) devices: the
+    home device is this rank's, every other device is a peer with its own stream, `done` event and arena, inputs broadcast and strips gathered by hipMemcpyPeerAsync
+    (xGMI between GPUs).  With a single GPU (N = 1) the peers are LOGICAL devices of that GPU (svt_hip_set_virtual_devices): the same code, streams, events and peer
+    copies, running concurrently on one device -- it measures the protocol's overhead, not a speed-up.  Every partitioned result is compared with the single-device
+    call's (bit-equal) before timing; the ME tables also with the CPU checker."""
+    phys = lib.svt_hip_physical_device_count()
+    n_dev = min(phys, world)
+    virtual = n_dev < 2
+    if virtual:
+        n_dev = 4
+        assert lib.svt_hip_set_virtual_devices(n_dev) == 0
+    devices = list(range(n_dev))
+    part = lib.svt_hip_frame_partition_create((C.c_int * n_dev)(*devices), n_dev)
+    if not part:
+        return {"error": "svt_hip_frame_partition_create refused devices %s" % devices}
+    t8 = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1)).cuda()  # noqa: E731
+    res = {"devices": n_dev, "virtual_peers": virtual, "home": 0}
+    checked = 0
+    min_s = min(a.min_leg_s, 0.15)
+
+    def stats():
+        c, bi, bo = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        lib.svt_hip_frame_partition_stats(part, C.byref(c), C.byref(bi), C.byref(bo))
+        return c.value, bi.value, bo.value
+
+    def leg(name, single, parted, outs, extra_check=None):
+        nonlocal checked
+        for t in outs:
+            t.zero_()
+        single()
+        torch.cuda.synchronize()
+        want = [t.cpu().numpy().copy() for t in outs]
+        for t in outs:
+            t.zero_()
+        c0 = stats()
+        assert parted() == 0
+        torch.cuda.synchronize()
+        c1 = stats()
+        for w, t in zip(want, outs):
+            checked += must_equal("c_partition " + name, t.cpu().numpy(), w)
+        if extra_check:
+            checked += extra_check()
+        t_single, _ = time_leg(torch, single, min_s, batches=3)
+        t_part, _ = time_leg(torch, parted, min_s, batches=3)
+        res[name] = {"ms_single_device": t_single * 1e3, "ms_partition": t_part * 1e3, "peer_bytes_in_per_call": c1[1] - c0[1], "peer_bytes_out_per_call": c1[2] - c0[2]}
+
+    # ---- ME: one 1080p picture x its references (the items ordered SB row after SB row within a reference) ----
+    aw, ah = (int(v) for v in a.area.split("x"))
+    planes = synth_planes(1 + a.refs, 99)
+    d_pl = torch.from_numpy(planes.reshape(-1)).cuda()
+    full = pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, aw, ah, PLANE, n_refs=a.refs, src_plane=0, ref_plane0=1)
+    n = len(full)
+    d_d = t8(full)
+    d_s, d_m = torch.zeros(n * 85, dtype=torch.int32, device="cuda"), torch.zeros(n * 85, dtype=torch.int32, device="cuda")
+
+    def me_check():
+        k = 0
+        if oracle is None:
+            return 0
+        hs, hm = d_s.cpu().numpy().view(np.uint32).reshape(n, 85), d_m.cpu().numpy().view(np.uint32).reshape(n, 85)
+        for i in np.linspace(0, n - 1, 4 * n_dev).astype(int):  # items of every strip
+            d = full[i]
+            ws, wm = np.zeros(85, np.uint32), np.zeros(85, np.uint32)
+            oracle.oracle_me_fullpel_search(vp(planes, int(d["src_off"])), STRIDE, vp(planes, int(d["ref_off"])), STRIDE, int(d["x_origin"]), int(d["y_origin"]), aw, ah, 0, vp(ws), vp(wm))
+            k += must_equal("c_partition me sad", hs[i], ws) + must_equal("c_partition me mv", hm[i], wm)
+        return k
+    leg("me_1080p",
+        lambda: lib.svt_hip_me_fullpel_search_batch(d_pl.data_ptr(), d_pl.data_ptr(), d_d.data_ptr(), n, aw, ah, 0, d_s.data_ptr(), d_m.data_ptr(), None, stream),
+        lambda: lib.svt_hip_frame_partition_me(part, d_pl.data_ptr(), d_pl.numel(), d_pl.data_ptr(), d_pl.numel(), d_d.data_ptr(), n, aw, ah, 0, d_s.data_ptr(), d_m.data_ptr(), None, stream),
+        [d_s, d_m], me_check)
+    res["me_1080p"]["sb_refs"] = n
+
+    # ---- CDEF apply + loop restoration of one 4K 10-bit luma plane ----
+    Wc, Hc, bd = 3840, 2160, 10
+    g = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:Hc, 0:Wc]
+    plane = np.clip(((xx * 2 + yy * 3) % 1024) // 2 + (((xx // 8 + yy // 8) % 5) << 5) + g.integers(-16, 17, (Hc, Wc)), 0, 1023).astype(np.uint16)
+    d_rec = t8(plane)
+    nhfb, nvfb = (Wc + 63) // 64, (Hc + 63) // 64
+    nfb = nhfb * nvfb
+    d_skip, d_pri, d_sec = t8(np.zeros((nvfb * 8, nhfb * 8), np.uint8)), t8(np.full(nfb, 4, np.int32)), t8(np.full(nfb, 2, np.int32))
+    d_dir, d_var = torch.zeros(nfb * 64, dtype=torch.uint8, device="cuda"), torch.zeros(nfb * 64, dtype=torch.int32, device="cuda")
+    d_out = d_rec.clone()
+    Pc = pkg.CdefParams(d_rec.data_ptr(), d_rec.data_ptr(), d_out.data_ptr(), Wc, Wc, Wc, Wc, Hc, 0, 0, 0, 1, bd - 8, 4, 4, 1, 0, d_skip.data_ptr(), d_pri.data_ptr(), d_sec.data_ptr(),
+                        d_dir.data_ptr(), d_var.data_ptr(), None)
+
+    def cdef_single():
+        d_out.copy_(d_rec)  # (apply writes the filtered units onto a pre-copied plane)
+        lib.svt_hip_cdef_frame(0, C.byref(Pc), stream)
+
+    def cdef_part():
+        d_out.copy_(d_rec)
+        return lib.svt_hip_frame_partition_cdef(part, 0, C.byref(Pc), stream)
+    leg("cdef_apply_4k10", cdef_single, cdef_part, [d_out, d_dir, d_var])
+    us = 256
+    nstripes = (Hc + 8 + 63) // 64
+    nvu, nhu = max((Hc + us // 2) // us, 1), max((Wc + us // 2) // us, 1)
+    units = np.zeros(nvu * nhu, dtype=pkg.LrUnit)
+    for i in range(len(units)):
+        f = [int(g.integers(-5, 11)), int(g.integers(-23, 9)), int(g.integers(-17, 47))]
+        taps = [f[0], f[1], f[2], -2 * sum(f), f[2], f[1], f[0], 0]
+        units[i] = ((1, 2, 0)[i % 3], taps, taps, int(g.integers(0, 16)), (int(g.integers(-96, 32)), int(g.integers(-32, 96))))
+    d_ab, d_bl, d_un = t8(g.integers(0, 1024, (2 * nstripes, Wc)).astype(np.uint16)), t8(g.integers(0, 1024, (2 * nstripes, Wc)).astype(np.uint16)), t8(units)
+    d_lr = torch.zeros(Hc * Wc * 2, dtype=torch.uint8, device="cuda")
+    Pl = pkg.LrParams(d_rec.data_ptr(), d_ab.data_ptr(), d_bl.data_ptr(), d_lr.data_ptr(), Wc, Wc, Wc, Wc, Hc, us, 0, 0, 1, bd, d_un.data_ptr())
+    leg("lr_4k10", lambda: lib.svt_hip_lr_filter_frame(C.byref(Pl), stream), lambda: lib.svt_hip_frame_partition_lr(part, C.byref(Pl), stream), [d_lr])
+    torch.cuda.synchronize()
+    lib.svt_hip_frame_partition_destroy(part)
+    res["parity_checked_values"] = checked
+    res["note"] = ("peers are logical devices of the one GPU (SVT_HIP_VIRTUAL_DEVICES): protocol overhead on one device, not a scaling figure" if virtual
+                   else "peers are GPUs: inputs and strips cross xGMI by hipMemcpyPeerAsync, home device as root")
+    return res
+
+
 def emit(out, a):
     """stdout gets ONE line of at most bench_line.MAX_LINE bytes (what the driver records and parses); the full object -- every leg with its roofline, CPU baseline,
     parity counts, the encoder's per-stage statistics -- goes to bench_detail.json (gpurun_out/ when it exists, else the working directory) and to stderr."""
@@ -1235,7 +1350,7 @@ def main():
     ap.add_argument("--min-leg-s", type=float, default=MIN_TIMED_S, help="minimum device time of every timed region (a step = as many launches as that takes)")
     ap.add_argument("--no-pmc", action="store_true", help="skip this run's own rocprofv3 --pmc child passes (roofline.traffic then comes from the committed summary)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (me, sad, txfm, config3, cdef, lr, hme, session, tf, tpl, tpl1, tfpic, lrsearch): A/B measurements")
+    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (me, sad, txfm, config3, cdef, lr, hme, session, tf, tpl, tpl1, tfpic, lrsearch, cpart): A/B measurements")
     ap.add_argument("--extra", action="store_true", help="also sweep the other search areas / sub_sad and the remaining stages (reported under kernels)")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -1333,6 +1448,17 @@ def main():
     fp = bench_frame_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle)
     if (world > 1 or a.mode == "strips") and not a.pmc_child:
         fp["in_loop_filters"] = bench_filter_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle)
+    if not a.pmc_child and (not a.legs or "cpart" in a.legs.split(",")):
+        # the product's own multi-device path (one process, csrc/partition.hip), while the other ranks wait at the barrier
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            try:
+                fp["c_partition"] = bench_c_partition(torch, lib, pkg, stream, a, world, oracle)
+            except Exception as e:  # (a failure here must not cost the run its headline)
+                fp["c_partition"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if dist is not None:
+            dist.barrier()
     out = {
         "metric": "Mblocks/s per kernel (SAD, FwdTxfm2d, CDEF) + encoder fps @1080p preset 8", "value": value,
         "unit": "Mblocks/s (block = one search position of one 64x64 SB vs one reference = 85 block SADs)",
@@ -1481,7 +1607,7 @@ def main():
     finish_rooflines(kernels, rf, kernel_s)
     if "sad64x64_pairs" in kernels:  # the kernel north_star's ">= 50 % of HBM on the SAD path" applies to
         rf["sad_path_hbm_frac"] = kernels["sad64x64_pairs"]["roofline"]["frac"]
-    if a.legs and a.mode != "strips":
+    if a.legs and a.mode != "strips" and "cpart" not in a.legs.split(","):
         out.pop("frame_partition", None)
     if a.pmc_child:
         if os.environ.get("SVT_PMC_REGIONS_FILE"):

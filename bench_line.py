@@ -84,6 +84,13 @@ def compact(out):
     fp = out.get("frame_partition")
     if isinstance(fp, dict):
         line["frame_partition"] = _pick(fp, ("value", "ms_per_step", "scaling", "collective"), 4)  # (Mblocks/s of one picture x its references per launch: detail file)
+        cp = fp.get("c_partition")
+        if isinstance(cp, dict):  # the library's own partition from one process: [ms on one device, ms partitioned] per primitive
+            c = _pick(cp, ("devices", "virtual_peers", "parity_checked_values", "error"))
+            for k in ("me_1080p", "cdef_apply_4k10", "lr_4k10"):
+                if isinstance(cp.get(k), dict):
+                    c[k] = [_r(cp[k].get("ms_single_device"), 3), _r(cp[k].get("ms_partition"), 3)]
+            line["frame_partition"]["c_partition"] = c
     legs = {}
     for name, k in kernels.items():
         row = leg_row(k)

@@ -41,8 +41,15 @@ int svt_hip_host_unregister(void *buffer);
 /* Several GPUs from one process (frame-level sharding): the device is selected PER HOST THREAD, like HIP's own current device.  svt_hip_set_thread_device(d)
  * binds the calling thread to device d for every later call of this library on that thread (host-call arenas and streams are per thread AND device); -1 returns the
  * thread to the default device of svt_hip_init.  Returns 0, or -1 when d is not a device.  Objects that live on a device (ME sessions) remember it and make it current
- * inside their own entry points, whatever the calling thread's selection is. */
-int svt_hip_device_count(void);
+ * inside their own entry points, whatever the calling thread's selection is.
+ * Device numbers are LOGICAL: device d runs on GPU d % svt_hip_physical_device_count(), and everything the library keeps per device (arenas, streams, sessions,
+ * resident planes, partition peers) is keyed by the logical number.  SVT_HIP_VIRTUAL_DEVICES=V in the environment, or svt_hip_set_virtual_devices(V) before the
+ * extra devices are used, gives every GPU V logical devices (default 1: logical = physical): the multi-device paths -- SVT_HIP_DEVICES picture sharding, frame
+ * partitions with their peer streams, events and peer copies -- then run concurrently on a node with a single GPU. */
+int svt_hip_device_count(void);          /* logical devices */
+int svt_hip_physical_device_count(void); /* GPUs */
+int svt_hip_physical_device(int device); /* the GPU behind a logical device, -1 if it is not one */
+int svt_hip_set_virtual_devices(int per_gpu);
 int svt_hip_set_thread_device(int device);
 int svt_hip_get_thread_device(void);
 /* The measurement knobs SVT_HIP_LR_UR / SVT_HIP_CDEF_GPW are read from the environment once, at first use; this re-reads them (tests that sweep a knob). */
@@ -1122,6 +1129,10 @@ void svt_hip_tpl_plane_counts(uint64_t *hits, uint64_t *misses); /* resident-pla
 void *svt_hip_frame_partition_create(const int *devices, int n);
 void  svt_hip_frame_partition_destroy(void *partition);
 int   svt_hip_frame_partition_size(const void *partition);
+/* Test instruments.  svt_hip_debug_spin: a delay kernel of about `microseconds` (at most 100 ms) on `stream`.  svt_hip_frame_partition_set_jitter: from now on every
+ * call of this partition puts delays of pseudo-random length (0 .. max_us, seeded) between the steps of its protocol on the home and the peer streams; 0 = off. */
+void  svt_hip_debug_spin(void *stream, uint32_t microseconds);
+void  svt_hip_frame_partition_set_jitter(void *partition, uint32_t seed, uint32_t max_us);
 void  svt_hip_frame_partition_stats(const void *partition, uint64_t *calls, uint64_t *peer_bytes_in, uint64_t *peer_bytes_out);
 /* svt_hip_me_fullpel_search_batch over items [0, n): src_bytes / ref_bytes = the extent of the plane sets behind src_base / ref_base (mirrored whole) */
 int   svt_hip_frame_partition_me(void *partition, const uint8_t *src_base, size_t src_bytes, const uint8_t *ref_base, size_t ref_bytes, const SvtHipMeSearchDesc *descs,

@@ -121,15 +121,48 @@ static void seam_av1_cdef_frame_body(SequenceControlSet *scs, PictureControlSet 
     A.damping = (uint8_t)frm_hdr->cdef_params.cdef_damping;
     A.skip = skip; A.pri_y = pri_y; A.sec_y = sec_y; A.pri_uv = pri_uv; A.sec_uv = sec_uv;
     svt_hip_seam_bind(pcs->picture_number);
+    /* SVT_HIP_CDEF_SEAM_VERIFY=1 (diagnostic): the reference's own function filters the same picture as well and the two results are compared sample by sample
+     * (differences go to stderr); the picture continues with the reference's result. */
+    static int verify = -1;
+    if (verify < 0) { const char *e = getenv("SVT_HIP_CDEF_SEAM_VERIFY"); verify = e && atoi(e); }
+    uint8_t *before[3] = {NULL, NULL, NULL}, *device[3] = {NULL, NULL, NULL};
+    const size_t vrows[3] = {A.height, (A.height + 1) >> 1, (A.height + 1) >> 1}, vcols[3] = {A.width, (A.width + 1) >> 1, (A.width + 1) >> 1};
+    if (verify && filtered)
+        for (int p = 0; p < 3; p++) {
+            before[p] = malloc(vrows[p] * (vcols[p] << is_16bit));
+            device[p] = malloc(vrows[p] * (vcols[p] << is_16bit));
+            for (size_t y = 0; y < vrows[p]; y++) memcpy(before[p] + y * (vcols[p] << is_16bit), (uint8_t *)A.plane[p] + y * ((size_t)A.stride[p] << is_16bit), vcols[p] << is_16bit);
+        }
     const double ta_ = seam_ms_now();
     if (filtered) D.apply_host(&A);
     __atomic_fetch_add(&D.us_stage, (unsigned long long)((seam_ms_now() - ta_) * 1e3), __ATOMIC_RELAXED);
+    if (verify && filtered) {
+        for (int p = 0; p < 3; p++)
+            for (size_t y = 0; y < vrows[p]; y++) {
+                uint8_t *row = (uint8_t *)A.plane[p] + y * ((size_t)A.stride[p] << is_16bit);
+                memcpy(device[p] + y * (vcols[p] << is_16bit), row, vcols[p] << is_16bit);
+                memcpy(row, before[p] + y * (vcols[p] << is_16bit), vcols[p] << is_16bit);
+            }
+        svt_av1_cdef_frame(scs, pcs);
+        for (int p = 0; p < 3; p++) {
+            unsigned long long bad = 0; long first = -1;
+            for (size_t y = 0; y < vrows[p]; y++) {
+                const uint8_t *row = (const uint8_t *)A.plane[p] + y * ((size_t)A.stride[p] << is_16bit), *dv = device[p] + y * (vcols[p] << is_16bit);
+                for (size_t x = 0; x < (vcols[p] << is_16bit); x++)
+                    if (row[x] != dv[x]) { if (first < 0) first = (long)(y * 100000 + (x >> is_16bit)); bad++; }
+            }
+            if (bad) fprintf(stderr, "SVT_HIP_CDEF_SEAM_VERIFY: apply, picture %llu plane %d: %llu bytes differ from the reference (first at row*100000+col %ld)\n", (unsigned long long)pcs->picture_number, p, bad, first);
+            free(before[p]); free(device[p]);
+        }
+        fprintf(stderr, "SVT_HIP_CDEF_SEAM_VERIFY: apply, picture %llu compared\n", (unsigned long long)pcs->picture_number);
+    }
     pthread_mutex_lock(&D.lock);
     D.n_pictures++; D.n_fbs += filtered;
     pthread_mutex_unlock(&D.lock);
     free(str); free(skip);
 }
 static void seam_av1_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs) {
+    seam_test_delay();
     SEAM_CPU_BEGIN();
     seam_av1_cdef_frame_body(scs, pcs);
     SEAM_CPU_END(SEAM_CPU_CDEF);
@@ -216,6 +249,30 @@ static void cdef_seg_search_use1_body(PictureControlSet *pcs, SequenceControlSet
     }
     if (slot < 0) {
         search_picture(pcs, scs);
+        static int verify = -1;
+        if (verify < 0) { const char *e = getenv("SVT_HIP_CDEF_SEAM_VERIFY"); verify = e && atoi(e); }
+        if (verify) { /* (diagnostic) the reference's own search of every segment, compared with what the device stage stored */
+            const int32_t nvfb = (pcs->ppcs->av1_cm->mi_rows + MI_SIZE_64X64 - 1) / MI_SIZE_64X64, nhfb = (pcs->ppcs->av1_cm->mi_cols + MI_SIZE_64X64 - 1) / MI_SIZE_64X64, nfb = nvfb * nhfb;
+            uint64_t (*m0)[TOTAL_STRENGTHS] = malloc(sizeof(*m0) * nfb), (*m1)[TOTAL_STRENGTHS] = malloc(sizeof(*m1) * nfb);
+            uint8_t     *sk = malloc((size_t)nfb);
+            CdefDirData *dd = malloc(sizeof(*dd) * nfb);
+            memcpy(m0, pcs->mse_seg[0], sizeof(*m0) * nfb); memcpy(m1, pcs->mse_seg[1], sizeof(*m1) * nfb); memcpy(sk, pcs->skip_cdef_seg, (size_t)nfb); memcpy(dd, pcs->cdef_dir_data, sizeof(*dd) * nfb);
+            for (uint32_t sg = 0; sg < pcs->cdef_segments_total_count; sg++) cdef_seg_search_use0(pcs, scs, sg);
+            const CdefSearchControls *ctl = &pcs->ppcs->cdef_search_ctrls;
+            const int nc = ctl->first_pass_fs_num + ctl->default_second_pass_fs_num;
+            unsigned long long bad_mse = 0, bad_dir = 0, bad_skip = 0;
+            for (int32_t fb = 0; fb < nfb; fb++) {
+                bad_skip += sk[fb] != pcs->skip_cdef_seg[fb];
+                if (pcs->skip_cdef_seg[fb]) continue;
+                for (int gi = 0; gi < nc; gi++) bad_mse += (m0[fb][gi] != pcs->mse_seg[0][fb][gi]) + (m1[fb][gi] != pcs->mse_seg[1][fb][gi]);
+                bad_dir += memcmp(&dd[fb], &pcs->cdef_dir_data[fb], sizeof(*dd)) != 0;
+            }
+            if (bad_mse || bad_dir || bad_skip)
+                fprintf(stderr, "SVT_HIP_CDEF_SEAM_VERIFY: search, picture %llu: %llu mse entries, %llu direction records, %llu skip flags differ from the reference\n",
+                        (unsigned long long)pcs->picture_number, bad_mse, bad_dir, bad_skip);
+            fprintf(stderr, "SVT_HIP_CDEF_SEAM_VERIFY: search, picture %llu compared (%d filter blocks, %d candidates)\n", (unsigned long long)pcs->picture_number, nfb, nc);
+            free(m0); free(m1); free(sk); free(dd);
+        }
         if (free_slot < 0) { fprintf(stderr, "SVT_HIP_CDEF_SEAM: more than 64 pictures in the CDEF stage\n"); abort(); }
         slot = free_slot;
         D.done_pcs[slot] = pcs; D.done_num[slot] = pcs->picture_number; D.seen[slot] = 0;
@@ -224,6 +281,7 @@ static void cdef_seg_search_use1_body(PictureControlSet *pcs, SequenceControlSet
     pthread_mutex_unlock(&D.lock);
 }
 static void cdef_seg_search_use1(PictureControlSet *pcs, SequenceControlSet *scs, uint32_t segment_index) {
+    seam_test_delay();
     SEAM_CPU_BEGIN();
     cdef_seg_search_use1_body(pcs, scs, segment_index);
     SEAM_CPU_END(SEAM_CPU_CDEF);

@@ -135,6 +135,7 @@ static void set_planes(EbPictureBufferDesc *fb, const PictureControlSet *pcs, ui
 }
 /* one device call per plane over the given lists */
 int svt_hip_seam_bind(unsigned long long picture_number); /* integration/enc_handle_binding.c: SVT_HIP_DEVICES sharding */
+void svt_aom_get_recon_pic(PictureControlSet *pcs, EbPictureBufferDesc **recon_ptr, bool is_highbd);
 static uint64_t filter_planes(const PictureControlSet *pcs, const uint32_t *w, EdgeList (*list)[2]) {
     svt_hip_seam_bind(pcs->picture_number);
     const bool is_16bit = pcs->scs->is_16bit_pipeline;
@@ -243,7 +244,6 @@ static void seam_loop_filter_frame(EbPictureBufferDesc *fb, PictureControlSet *p
 
 /* svt_aom_get_recon_pic's uses in dlf_process.c, in file order: the two prototypes (:23, :28), the 8-bit -> 16-bit conversion (:90, :91), the frame filter (:108) and
  * the pre-CDEF preparation (:136) -- the point every picture passes after its deblocking and before anything reads the result */
-void svt_aom_get_recon_pic(PictureControlSet *pcs, EbPictureBufferDesc **recon_ptr, bool is_highbd);
 static void get_recon_use2(PictureControlSet *pcs, EbPictureBufferDesc **r, bool hbd) { svt_aom_get_recon_pic(pcs, r, hbd); }
 static void get_recon_use3(PictureControlSet *pcs, EbPictureBufferDesc **r, bool hbd) { svt_aom_get_recon_pic(pcs, r, hbd); }
 static void get_recon_use4(PictureControlSet *pcs, EbPictureBufferDesc **r, bool hbd) { svt_aom_get_recon_pic(pcs, r, hbd); }

@@ -167,6 +167,7 @@ static void seam_restoration_seg_search_body(int32_t *rst_tmpbuf, Yv12BufferConf
     pthread_mutex_unlock(&L.lock);
 }
 static void seam_restoration_seg_search(int32_t *rst_tmpbuf, Yv12BufferConfig *org_fts, const Yv12BufferConfig *src, Yv12BufferConfig *trial_frame_rst, PictureControlSet *pcs, uint32_t segment_index) {
+    seam_test_delay();
     SEAM_CPU_BEGIN();
     seam_restoration_seg_search_body(rst_tmpbuf, org_fts, src, trial_frame_rst, pcs, segment_index);
     SEAM_CPU_END(SEAM_CPU_LR);
@@ -215,6 +216,7 @@ static void seam_loop_restoration_filter_frame_body(int32_t *rst_tmpbuf, Yv12Buf
     }
 }
 static void seam_loop_restoration_filter_frame(int32_t *rst_tmpbuf, Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr) {
+    seam_test_delay();
     SEAM_CPU_BEGIN();
     seam_loop_restoration_filter_frame_body(rst_tmpbuf, frame, cm, optimized_lr);
     SEAM_CPU_END(SEAM_CPU_LR);

@@ -15,6 +15,16 @@ static inline unsigned long long seam_cpu_ns(void) {
     clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t_);
     return (unsigned long long)t_.tv_sec * 1000000000ull + (unsigned long long)t_.tv_nsec;
 }
+/* Timing experiment ("10-bit preset 8"): SVT_HIP_SEAM_DELAY_US=<n> makes the picture-level CDEF and loop-restoration stage entries (seam_test_delay() in their seams) sleep n microseconds first -- with NO seam on, i.e. in the
+ * plain reference encoder.  It answers whether a bitstream difference seen with a device stage comes from the stage's RESULTS or from the stage merely taking a
+ * different time than the reference's own function (a latent race of the reference that a timing change exposes). */
+#include <stdlib.h>
+#include <unistd.h>
+static inline void seam_test_delay(void) {
+    static int us_ = -1;
+    if (us_ < 0) { const char *e_ = getenv("SVT_HIP_SEAM_DELAY_US"); us_ = e_ ? atoi(e_) : 0; }
+    if (us_ > 0) usleep((useconds_t)us_);
+}
 #define SEAM_CPU_BEGIN() const int seam_cpu_on_ = svt_hip_seam_cpu_on(); const unsigned long long seam_cpu_t0_ = seam_cpu_on_ ? seam_cpu_ns() : 0
 #define SEAM_CPU_END(stage) do { if (seam_cpu_on_) svt_hip_seam_cpu_add(stage, seam_cpu_ns() - seam_cpu_t0_); } while (0)
 #endif

@@ -43,6 +43,9 @@ PROTOTYPES = {
     "svt_hip_host_register": (C.c_int, [vp, C.c_size_t]),
     "svt_hip_host_unregister": (C.c_int, [vp]),
     "svt_hip_device_count": (C.c_int, []),
+    "svt_hip_physical_device_count": (C.c_int, []),
+    "svt_hip_physical_device": (C.c_int, [C.c_int]),
+    "svt_hip_set_virtual_devices": (C.c_int, [C.c_int]),
     "svt_hip_set_thread_device": (C.c_int, [C.c_int]),
     "svt_hip_get_thread_device": (C.c_int, []),
     "svt_hip_tpl_src_stage": (None, [vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -56,6 +59,8 @@ PROTOTYPES = {
     "svt_hip_frame_partition_create": (vp, [vp, C.c_int]),
     "svt_hip_frame_partition_destroy": (None, [vp]),
     "svt_hip_frame_partition_size": (C.c_int, [vp]),
+    "svt_hip_debug_spin": (None, [vp, C.c_uint32]),
+    "svt_hip_frame_partition_set_jitter": (None, [vp, C.c_uint32, C.c_uint32]),
     "svt_hip_frame_partition_stats": (None, [vp, vp, vp, vp]),
     "svt_hip_frame_partition_me": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp, vp]),
     "svt_hip_frame_partition_cdef": (C.c_int, [vp, C.c_int, vp, vp]),

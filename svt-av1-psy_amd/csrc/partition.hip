@@ -23,7 +23,8 @@
 namespace {
 
 struct Peer {
-    int         device = 0;
+    int         device = 0; // logical (svt_hip_common.h: physical_device())
+    int         phys   = 0; // the GPU ordinal the peer copies name
     hipStream_t stream = nullptr;
     hipEvent_t  done   = nullptr;
     uint8_t*    arena  = nullptr;
@@ -34,7 +35,18 @@ struct Partition {
     std::vector<Peer> peer; // peer[0] = the home device (no stream / arena of its own: the caller's)
     hipEvent_t        ready = nullptr;
     uint64_t          bytes_in = 0, bytes_out = 0, calls = 0; // peer traffic so far (svt_hip_frame_partition_stats)
+    uint32_t          jitter_us = 0, jitter_state = 0;        // test instrument (svt_hip_frame_partition_set_jitter): random delays between the steps of the protocol
 };
+// With jitter on, a delay kernel of pseudo-random length (0 .. jitter_us, a third of the draws none) goes into `st` here: the steps of the ready / done protocol on the
+// home and peer streams then finish in a different interleaving on every call, so a missing wait shows up as a wrong strip instead of passing by luck.
+void jitter(Partition& P, hipStream_t st) {
+    if (!P.jitter_us) return;
+    uint32_t x = P.jitter_state;
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    P.jitter_state = x;
+    if (x % 3 == 0) return;
+    svt_hip_debug_spin(st, (x >> 8) % (P.jitter_us + 1));
+}
 
 // contiguous strips, the first (total % n) one unit longer (the rule of bench.py --mode strips and of the gloo tests)
 inline size_t plane_bytes(size_t stride, size_t width, size_t rows, size_t px) { return rows ? ((rows - 1) * stride + width) * px : 0; } // (the last row ends at `width`)
@@ -64,16 +76,17 @@ void* arena_take(Peer& p, size_t bytes) {
 void* mirror_in(Partition& P, Peer& p, const void* src, size_t bytes) {
     if (!src || !bytes) return nullptr;
     void* d = arena_take(p, bytes);
-    HIP_CHECK(hipMemcpyPeerAsync(d, p.device, src, P.peer[0].device, bytes, p.stream));
+    HIP_CHECK(hipMemcpyPeerAsync(d, p.phys, src, P.peer[0].phys, bytes, p.stream));
     P.bytes_in += bytes;
     return d;
 }
 void rows_out(Partition& P, Peer& p, void* dst_home, const void* src_peer, size_t bytes) {
     if (!bytes) return;
-    HIP_CHECK(hipMemcpyPeerAsync(dst_home, P.peer[0].device, src_peer, p.device, bytes, p.stream));
+    HIP_CHECK(hipMemcpyPeerAsync(dst_home, P.peer[0].phys, src_peer, p.phys, bytes, p.stream));
     P.bytes_out += bytes;
 }
 void open_call(Partition& P, hipStream_t home) {
+    jitter(P, home); // (delays `ready`: the inputs become final late)
     HIP_CHECK(hipEventRecord(P.ready, home));
     P.calls++;
 }
@@ -155,6 +168,7 @@ void* svt_hip_frame_partition_create(const int* devices, int n) {
     P->peer.resize(n);
     for (int k = 0; k < n; k++) {
         P->peer[k].device = devices[k];
+        P->peer[k].phys   = svthip::physical_device(devices[k]);
         svthip::DeviceGuard g(devices[k]);
         if (k == 0) {
             HIP_CHECK(hipEventCreateWithFlags(&P->ready, hipEventDisableTiming));
@@ -163,8 +177,10 @@ void* svt_hip_frame_partition_create(const int* devices, int n) {
         HIP_CHECK(hipStreamCreateWithFlags(&P->peer[k].stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&P->peer[k].done, hipEventDisableTiming));
         int can = 0; // direct xGMI access where the platform offers it (the copies work without it, staged by the runtime)
-        if (hipDeviceCanAccessPeer(&can, devices[k], devices[0]) == hipSuccess && can) {
-            if (hipDeviceEnablePeerAccess(devices[0], 0) != hipSuccess) (void)hipGetLastError(); // (already enabled: fine)
+        const int pk = P->peer[k].phys, p0 = svthip::physical_device(devices[0]);
+        if (pk == p0) continue; // (two logical devices of one GPU: SVT_HIP_VIRTUAL_DEVICES)
+        if (hipDeviceCanAccessPeer(&can, pk, p0) == hipSuccess && can) {
+            if (hipDeviceEnablePeerAccess(p0, 0) != hipSuccess) (void)hipGetLastError(); // (already enabled: fine)
         } else (void)hipGetLastError();
     }
     return P;
@@ -181,6 +197,12 @@ void svt_hip_frame_partition_destroy(void* part) {
         (void)hipStreamDestroy(P->peer[k].stream);
     }
     delete P;
+}
+void svt_hip_frame_partition_set_jitter(void* part, uint32_t seed, uint32_t max_us) {
+    Partition* P = (Partition*)part;
+    if (!P) return;
+    P->jitter_us    = max_us;
+    P->jitter_state = seed ? seed : 0x9e3779b9u;
 }
 int svt_hip_frame_partition_size(const void* part) { return part ? ((const Partition*)part)->n : 0; }
 void svt_hip_frame_partition_stats(const void* part, uint64_t* calls, uint64_t* bytes_in, uint64_t* bytes_out) {
@@ -210,19 +232,23 @@ int svt_hip_frame_partition_me(void* part, const uint8_t* src_base, size_t src_b
         arena_begin(p, src_bytes + (one ? 0 : ref_bytes) + (size_t)cnt * (sizeof(SvtHipMeSearchDesc) + 2 * row) + ws + 8 * 256);
         svthip::DeviceGuard g(p.device);
         HIP_CHECK(hipStreamWaitEvent(p.stream, P->ready, 0));
+        jitter(*P, p.stream);
         const uint8_t* m_src = (const uint8_t*)mirror_in(*P, p, src_base, src_bytes);
         const uint8_t* m_ref = one ? m_src : (const uint8_t*)mirror_in(*P, p, ref_base, ref_bytes);
         const SvtHipMeSearchDesc* m_d = (const SvtHipMeSearchDesc*)mirror_in(*P, p, descs + b, (size_t)cnt * sizeof(SvtHipMeSearchDesc));
         uint32_t* o_sad = (uint32_t*)arena_take(p, cnt * row);
         uint32_t* o_mv  = (uint32_t*)arena_take(p, cnt * row);
         void*     m_ws  = ws ? arena_take(p, ws) : nullptr;
+        jitter(*P, p.stream);
         svt_hip_me_fullpel_search_batch(m_src, m_ref, m_d, cnt, max_w, max_h, sub_sad, o_sad, o_mv, m_ws, p.stream);
+        jitter(*P, p.stream);
         rows_out(*P, p, (uint8_t*)best_sad + (size_t)b * row, o_sad, cnt * row);
         rows_out(*P, p, (uint8_t*)best_mv + (size_t)b * row, o_mv, cnt * row);
         HIP_CHECK(hipEventRecord(p.done, p.stream));
     }
     int b0, e0;
     strip_of((int)n, 0, P->n, b0, e0);
+    jitter(*P, home);
     if (e0 > b0)
         svt_hip_me_fullpel_search_batch(src_base, ref_base, descs + b0, (uint32_t)(e0 - b0), max_w, max_h, sub_sad, best_sad + (size_t)b0 * SVT_HIP_ME_NUM_BLOCKS,
                                         best_mv + (size_t)b0 * SVT_HIP_ME_NUM_BLOCKS, workspace, home);
@@ -253,6 +279,7 @@ int svt_hip_frame_partition_cdef(void* part, int mode, const SvtHipCdefParams* p
         if (e <= b) { HIP_CHECK(hipEventRecord(p.done, p.stream)); continue; }
         arena_begin(p, recon_b + source_b + out_b + skip_b + 2 * str_b + dir_b + var_b + mse_b + 16 * 256);
         HIP_CHECK(hipStreamWaitEvent(p.stream, P->ready, 0));
+        jitter(*P, p.stream);
         SvtHipCdefParams M = C;
         M.recon  = mirror_in(*P, p, C.recon, recon_b);
         M.source = mode == 1 ? mirror_in(*P, p, C.source, source_b) : nullptr;
@@ -268,8 +295,10 @@ int svt_hip_frame_partition_cdef(void* part, int mode, const SvtHipCdefParams* p
         const size_t orow = (size_t)C.out_stride * px;
         M.out = mode == 1 ? nullptr : arena_take(p, out_b);
         const size_t strip_b = plane_bytes(C.out_stride, C.width, (size_t)(y1 - y0), px);
-        if (mode != 1) HIP_CHECK(hipMemcpyPeerAsync((uint8_t*)M.out + y0 * orow, p.device, (const uint8_t*)C.out + y0 * orow, P->peer[0].device, strip_b, p.stream));
+        if (mode != 1) HIP_CHECK(hipMemcpyPeerAsync((uint8_t*)M.out + y0 * orow, p.phys, (const uint8_t*)C.out + y0 * orow, P->peer[0].phys, strip_b, p.stream));
+        jitter(*P, p.stream);
         svt_hip_cdef_frame_rows(mode, &M, b, e, p.stream);
+        jitter(*P, p.stream);
         const size_t f0 = (size_t)b * nhfb, fn = (size_t)(e - b) * nhfb;
         if (mode == 1) rows_out(*P, p, C.mse + f0 * C.ncand, M.mse + f0 * C.ncand, fn * C.ncand * 8);
         else rows_out(*P, p, (uint8_t*)C.out + y0 * orow, (const uint8_t*)M.out + y0 * orow, strip_b);
@@ -281,6 +310,7 @@ int svt_hip_frame_partition_cdef(void* part, int mode, const SvtHipCdefParams* p
     }
     int b0, e0;
     strip_of(nvfb, 0, P->n, b0, e0);
+    jitter(*P, home);
     if (e0 > b0) svt_hip_cdef_frame_rows(mode, params, b0, e0, home);
     close_call(*P, home);
     return 0;
@@ -308,13 +338,16 @@ int svt_hip_frame_partition_lr(void* part, const SvtHipLrParams* params, void* s
         if (e <= b) { HIP_CHECK(hipEventRecord(p.done, p.stream)); continue; }
         arena_begin(p, data_b + 2 * bnd_b + dst_b + unit_b + 8 * 256);
         HIP_CHECK(hipStreamWaitEvent(p.stream, P->ready, 0));
+        jitter(*P, p.stream);
         SvtHipLrParams M = L;
         M.data           = mirror_in(*P, p, L.data, data_b);
         M.boundary_above = mirror_in(*P, p, L.boundary_above, bnd_b);
         M.boundary_below = mirror_in(*P, p, L.boundary_below, bnd_b);
         M.units          = (const SvtHipLrUnit*)mirror_in(*P, p, L.units, unit_b);
         M.dst            = arena_take(p, dst_b);
+        jitter(*P, p.stream);
         svt_hip_lr_filter_frame_stripes(&M, b, e, p.stream);
+        jitter(*P, p.stream);
         // stripe s covers picture rows [s * sh - off, (s + 1) * sh - off) clipped to the plane
         const int    y0 = b * sh - off > 0 ? b * sh - off : 0, y1 = e * sh - off < (int)L.height ? e * sh - off : (int)L.height;
         const size_t drow = (size_t)L.dst_stride * px;
@@ -323,6 +356,7 @@ int svt_hip_frame_partition_lr(void* part, const SvtHipLrParams* params, void* s
     }
     int b0, e0;
     strip_of(nstripes, 0, P->n, b0, e0);
+    jitter(*P, home);
     if (e0 > b0) svt_hip_lr_filter_frame_stripes(params, b0, e0, home);
     close_call(*P, home);
     return 0;

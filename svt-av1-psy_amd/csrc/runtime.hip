@@ -21,6 +21,39 @@ static thread_local int t_bound = -1; // device this library last made current o
 
 int current_device() { return t_want >= 0 ? t_want : (int)g_device; }
 
+// LOGICAL devices.  Every device number of this ABI (svt_hip_init, svt_hip_set_thread_device, a session's device, a partition's device list, SVT_HIP_DEVICES /
+// SVT_HIP_STRIPS of the encoder binding) is a logical one: logical device d runs on physical GPU d % (number of GPUs), and everything this library keeps per device --
+// host-call arenas and their streams, the lease pool, the resident-plane table, the ticket ring, sessions, partition peers with their streams / events / arenas -- is
+// keyed by the LOGICAL number.  With SVT_HIP_VIRTUAL_DEVICES=V (or svt_hip_set_virtual_devices(V)) there are V logical devices per GPU: a node with ONE MI355X then
+// runs the whole multi-device code -- per-device sessions, peer streams, the ready / done event protocol, hipMemcpyPeerAsync (legal with both ends on one GPU) -- truly
+// concurrently on an asynchronous device.  Default V = 1: logical = physical.
+static std::atomic<int> g_virtual{0}; // 0: not read from the environment yet
+static int virtual_per_gpu() {
+    int v = g_virtual.load(std::memory_order_acquire);
+    if (v == 0) {
+        const char* e = getenv("SVT_HIP_VIRTUAL_DEVICES");
+        v = e ? atoi(e) : 1;
+        if (v < 1) v = 1;
+        if (v > MAX_DEVICES) v = MAX_DEVICES;
+        g_virtual.store(v, std::memory_order_release);
+    }
+    return v;
+}
+static int physical_count() {
+    static std::atomic<int> n{-1};
+    int v = n.load();
+    if (v < 0) {
+        int c = 0;
+        if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); c = 0; }
+        n.store(v = c);
+    }
+    return v;
+}
+int physical_device(int logical) {
+    const int n = physical_count();
+    return n > 0 ? logical % n : logical;
+}
+
 void ensure_device() {
     if (!g_initialised) {
         if (svt_hip_init(0) != 0) {
@@ -34,7 +67,7 @@ void ensure_device() {
     // CDEF / REST threads) bind to their device the first time they enter the library, and again whenever it changes
     const int d = current_device();
     if (t_bound != d || g_multi) {
-        HIP_CHECK(hipSetDevice(d));
+        HIP_CHECK(hipSetDevice(physical_device(d)));
         t_bound = d;
     }
 }
@@ -186,7 +219,7 @@ static void plane_cache_free_all() {
     for (int d = 0; d < MAX_DEVICES; d++) {
         PlaneCache& C = g_plane_cache[d];
         std::lock_guard<std::mutex> g(C.m);
-        for (void* p : C.slabs) { (void)hipSetDevice(d); (void)hipFree(p); }
+        for (void* p : C.slabs) { (void)hipSetDevice(physical_device(d)); (void)hipFree(p); }
         C.slabs.clear();
         for (CachedPlane& e : C.e) e = CachedPlane();
     }
@@ -209,6 +242,13 @@ void HostCall::reserve(size_t dev_bytes, size_t pin_bytes) {
         if (pin) HIP_CHECK(hipHostFree(pin));
         pin_cap = align_up(pin_bytes * 2, 1 << 20);
         HIP_CHECK(hipHostMalloc((void**)&pin, pin_cap, hipHostMallocDefault));
+    }
+    // SVT_HIP_POISON=<byte> (debugging aid): both arenas are filled with the byte at the start of every host call, so that a kernel or a download that reads what the
+    // call never wrote gives a result that depends on the byte -- reproducibly, also on the CPU emulator -- instead of on whatever the previous call left behind
+    static const int poison = [] { const char* e = getenv("SVT_HIP_POISON"); return e ? (int)strtol(e, nullptr, 0) & 0xff : -1; }();
+    if (poison >= 0) {
+        HIP_CHECK(hipMemsetAsync(dev, poison, dev_cap, stream));
+        memset(pin, poison, pin_cap);
     }
 }
 void* HostCall::dalloc(size_t bytes) {
@@ -385,7 +425,36 @@ template <int KIND> __global__ __launch_bounds__(256) void svt_hip_rate_kernel(u
     if (r == 0x12345u) sink[0] = r;
 }
 
+// Delay kernel (test instrument): one lane waits `ticks` of the constant-rate wall clock, so that whatever is queued behind it on its stream starts late.
+__global__ void svt_hip_spin_kernel(uint32_t ticks) {
+#ifndef SVT_HIP_EMU
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < (uint64_t)ticks) __builtin_amdgcn_s_sleep(16);
+#else
+    (void)ticks; // (the emulator runs every stream in program order: a delay has nothing to reorder)
+#endif
+}
+
 extern "C" {
+
+void svt_hip_debug_spin(void* stream, uint32_t microseconds) {
+    svthip::ensure_device();
+    static std::atomic<int> khz{0};
+    int k = khz.load();
+    if (k == 0) {
+        int v = 0;
+#ifndef SVT_HIP_EMU
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeWallClockRate, svthip::physical_device(svthip::current_device())) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 100000; }
+#else
+        v = 100000;
+#endif
+        khz.store(k = v);
+    }
+    if (microseconds > 100000) microseconds = 100000;
+    const uint64_t ticks = (uint64_t)microseconds * (uint64_t)k / 1000;
+    hipLaunchKernelGGL(svt_hip_spin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint32_t)ticks);
+    SVT_LAUNCH_CHECK();
+}
 
 void svt_hip_rate_probe(int kind, uint32_t iters, uint32_t blocks, uint32_t* sink, void* stream) {
     svthip::ensure_device();
@@ -403,10 +472,10 @@ void svt_hip_rate_probe(int kind, uint32_t iters, uint32_t blocks, uint32_t* sin
 
 int svt_hip_init(int device) {
     using namespace svthip;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -1;
+    const int n = svt_hip_device_count(); // logical devices
+    if (n <= 0) return -1;
     if (device < 0 || device >= n || device >= svthip::MAX_DEVICES) return -1;
-    if (hipSetDevice(device) != hipSuccess) return -1;
+    if (hipSetDevice(physical_device(device)) != hipSuccess) return -1;
     // SVT_HIP_SYNC=block: host threads SLEEP while they wait for the device (hipDeviceScheduleBlockingSync) instead of spinning on the completion signal, the
     // runtime's default.  A stage call of an encoder seam is one synchronous round trip; on a host whose cores are all busy with the encoder's own threads the
     // spinning costs CPU time another worker could use (environment table; profiles/r04_*: host CPU seconds per frame).
@@ -415,7 +484,7 @@ int svt_hip_init(int device) {
         if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError(); // (refused once the context is active: keep the default)
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
+    if (hipGetDeviceProperties(&prop, physical_device(device)) != hipSuccess) return -1;
     snprintf(g_name, sizeof(g_name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     g_device      = device;
     g_initialised = true;
@@ -427,7 +496,7 @@ void svt_hip_shutdown(void) {
     for (int d = 0; d < MAX_DEVICES; d++) { // the calling thread's arenas
         HostCall& c = t_calls[d];
         if (!c.dev && !c.pin && !c.stream) continue;
-        (void)hipSetDevice(d);
+        (void)hipSetDevice(physical_device(d));
         if (c.dev) (void)hipFree(c.dev);
         if (c.pin) (void)hipHostFree(c.pin);
         if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -437,7 +506,7 @@ void svt_hip_shutdown(void) {
         std::lock_guard<std::mutex> g(g_lease_m);
         for (int d = 0; d < MAX_DEVICES; d++) {
             if (g_lease_pool[d].empty()) continue;
-            (void)hipSetDevice(d);
+            (void)hipSetDevice(physical_device(d));
             for (HostCall* c : g_lease_pool[d]) {
                 if (c->dev) (void)hipFree(c->dev);
                 if (c->pin) (void)hipHostFree(c->pin);
@@ -452,9 +521,16 @@ void svt_hip_shutdown(void) {
     g_initialised = false;
 }
 
-int svt_hip_device_count(void) {
-    int n = 0;
-    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+int svt_hip_device_count(void) { // LOGICAL devices: GPUs x SVT_HIP_VIRTUAL_DEVICES (see physical_device above), at most MAX_DEVICES
+    const int n = svthip::physical_count() * svthip::virtual_per_gpu();
+    return n > svthip::MAX_DEVICES ? svthip::MAX_DEVICES : n;
+}
+int svt_hip_physical_device_count(void) { return svthip::physical_count(); }
+int svt_hip_physical_device(int device) { return device < 0 || device >= svt_hip_device_count() ? -1 : svthip::physical_device(device); }
+int svt_hip_set_virtual_devices(int per_gpu) { // before the devices beyond the first are used; a later change only changes how many logical numbers are valid
+    if (per_gpu < 1 || per_gpu > svthip::MAX_DEVICES) return -1;
+    svthip::g_virtual.store(per_gpu, std::memory_order_release);
+    return 0;
 }
 int svt_hip_set_thread_device(int device) {
     using namespace svthip;

@@ -62,6 +62,7 @@ constexpr int MAX_DEVICES = 16; // width of the per-device tables (host-call are
 void ensure_device(); // binds the calling thread to its device (the default of svt_hip_init, or the one svt_hip_set_thread_device / a DeviceGuard chose);
                       // aborts with a clear message when svt_hip_init() found no GPU
 int  current_device();
+int  physical_device(int logical); // the GPU ordinal behind a logical device number (runtime.hip: SVT_HIP_VIRTUAL_DEVICES); what hipSetDevice / hipMemcpyPeerAsync take
 // Makes `device` the calling thread's device for the guard's lifetime: every entry point of an object that lives on one device (an ME session) opens with it.
 struct DeviceGuard {
     int prev;

@@ -195,12 +195,17 @@ template <typename F> inline void launch(F&& f, dim3 grid, dim3 block, size_t sh
     int nthreads = block.x * block.y * block.z;
     assert(nthreads <= MAX_THREADS);
     g.body = f;
+    // SVT_HIPEMU_LDS_POISON=<byte>: the dynamic shared memory of every workgroup starts filled with a byte derived from this one and the workgroup's index -- on the
+    // GPU, LDS holds whatever the previous workgroup on that CU left there, so a kernel that reads a cell it never wrote gives results that change from run to run
+    // THERE and never here; with the poison the dependence shows up here as well (two runs with different bytes must agree)
+    static const int lds_poison = [] { const char* e = getenv("SVT_HIPEMU_LDS_POISON"); return e ? (int)strtol(e, nullptr, 0) & 0xff : -1; }();
     for (unsigned bz = 0; bz < grid.z; bz++)
         for (unsigned by = 0; by < grid.y; by++)
             for (unsigned bx = 0; bx < grid.x; bx++) {
                 bIdx.x = bx;
                 bIdx.y = by;
                 bIdx.z = bz;
+                if (lds_poison >= 0 && shmem) memset(g.dyn_smem, (lds_poison + 37 * (int)(bx + by * 7 + bz * 13)) & 0xff, shmem);
                 run_block(nthreads);
             }
 }

@@ -20,6 +20,29 @@ def test_frame_partition_emulated_devices(n):
     assert r.returncode == 0 and "PARTITION_OK %d" % n in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("n", [2, 4])
+def test_frame_partition_virtual_devices_emulator(n):
+    """the LOGICAL-device layer (SVT_HIP_VIRTUAL_DEVICES: n logical devices on the one emulated device) through the same worker"""
+    from conftest import EmuBackend
+    EmuBackend()
+    env = dict(os.environ, SVT_HIPEMU_DEVICES="1", SVT_HIP_VIRTUAL_DEVICES=str(n))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "partition_worker.py"), ROOT, str(n), "emu", "2", "50"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PARTITION_OK %d" % n in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_frame_partition_virtual_peers_gpu(n):
+    """The multi-device code on a really asynchronous device: n logical devices on the MI355X (SVT_HIP_VIRTUAL_DEVICES), each peer with its own stream, `done` event
+    and arena, hipMemcpyPeerAsync between them; 50 repetitions, inputs that become final late on the home stream, outputs snapshotted on the home stream right after
+    the call, random delays between the protocol's steps (tests/partition_worker.py).  Compared with the single-device calls and the CPU checker."""
+    lib = os.path.join(ROOT, "svt-av1-psy_amd", "libsvtav1_hip.so")
+    assert os.path.exists(lib), "libsvtav1_hip.so missing (no CPU fallback)"
+    env = dict(os.environ, SVT_HIP_VIRTUAL_DEVICES=str(n))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "partition_worker.py"), ROOT, str(n), "gpu", "50", "300"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PARTITION_OK %d" % n in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
 def test_frame_partition_home_device_only(be):
     """a partition of ONE device (what the driver's single-GPU boxes can run): the same entry points, every strip on the home device -- ME and CDEF search results equal
     the plain calls'"""

@@ -144,6 +144,13 @@ CASES = {
     "tplrecon_p2_8bit": (448, 264, 18, 8, ["--preset", "2", "--lp", "2", "+tplseam", "+tplrecon"]),  # tpl level 1 (csrc/tpl_full.hip)
     "tplrecon_everyseam_p1_8bit": (256, 144, 12, 8, ["--preset", "1", "--lp", "2", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
     "tplseam_me_p8_8bit": (448, 264, 20, 8, ["--preset", "8", "--lp", "1", "+seam", "+tfseam", "+tfsubpel", "+tplseam"]),  # ME results produced by the device stage feed the TPL stage
+    # the multi-device paths on the MI355X itself: logical devices of the one GPU (SVT_HIP_VIRTUAL_DEVICES), per-device sessions / arenas / resident planes; peer streams,
+    # events and peer copies of the frame partition -- an asynchronous device, unlike the emulator
+    "vdev3_everyseam_p8": (448, 264, 16, 8, ["--preset", "8", "--lp", "4", "+devices:0,1,2", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
+    "vdev2_everyseam_p4_lp2": (256, 144, 8, 8, ["--preset", "4", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "vstrips3_cdef_lr_p4": (448, 264, 6, 8, ["--preset", "4", "--lp", "2", "+strips:0,1,2", "+lrseam", "+cdefseam"]),
+    "vstrips2_cdef_lr_p8_10bit": (448, 264, 8, 10, ["--preset", "8", "--lp", "1", "+strips:0,1", "+lrseam", "+cdefseam"]),
+    "vstrips4_cdef_lr_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+strips:0,1,2,3", "+lrseam", "+cdefseam"]),
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
     # one encode over TWO (emulated) devices: SVT_HIP_DEVICES=0,1 shards the pictures by picture number; every seam at once
     "tiny_2dev_everyseam_p8": (128, 64, 12, 8, ["--preset", "8", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
@@ -289,7 +296,9 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     lrseam_file = os.path.join(outdir, name + "_lrseam.txt")
     tf_alone = not seam and "+tfdriver" in CASES[name][4] and "--pred-struct" in extra  # the low-delay temporal filter has no ME: its stage can run without the ME seams' session
     if seam:
-        env.update({"SVT_HIP_ME_SEAM": "1", "SVT_HIP_ME_SEAM_STATS": seam_file})
+        # SVT_HIP_ME_SEAM_HASH=1: the residency of the ME planes rests on explicit invalidation; the identity suites ALSO compare a sampled checksum of every
+        # resident plane and count what the explicit rule missed -- any non-zero count voids the case (below)
+        env.update({"SVT_HIP_ME_SEAM": "1", "SVT_HIP_ME_SEAM_STATS": seam_file, "SVT_HIP_ME_SEAM_HASH": "1"})
     if seam or tf_alone:
         if "+tfseam" in CASES[name][4]:
             env["SVT_HIP_TF_ME_SEAM"] = "1"
@@ -313,11 +322,14 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     devices = next((a[9:] for a in CASES[name][4] if a.startswith("+devices:")), None)
     shard_file = os.path.join(outdir, name + "_devices.txt")
     if devices:
-        env.update({"SVT_HIP_DEVICES": devices, "SVT_HIP_DEVICES_STATS": shard_file, "SVT_HIPEMU_DEVICES": str(len(devices.split(",")))})  # (the last one: emulator only)
+        env.update({"SVT_HIP_DEVICES": devices, "SVT_HIP_DEVICES_STATS": shard_file})
+        # the emulator emulates the devices; on a GPU box with fewer GPUs than the list names, logical devices of the one GPU (svt_hip_device_count = GPUs x V)
+        env.update({"SVT_HIPEMU_DEVICES": str(len(devices.split(",")))} if "hipemu" in lib else {"SVT_HIP_VIRTUAL_DEVICES": str(max(int(d) for d in devices.split(",")) + 1)})
     strips = next((a[8:] for a in CASES[name][4] if a.startswith("+strips:")), None)
     strips_file = os.path.join(outdir, name + "_strips.txt")
     if strips:
-        env.update({"SVT_HIP_STRIPS": strips, "SVT_HIP_STRIPS_STATS": strips_file, "SVT_HIPEMU_DEVICES": str(len(strips.split(",")))})  # (the last one: emulator only)
+        env.update({"SVT_HIP_STRIPS": strips, "SVT_HIP_STRIPS_STATS": strips_file})
+        env.update({"SVT_HIPEMU_DEVICES": str(len(strips.split(",")))} if "hipemu" in lib else {"SVT_HIP_VIRTUAL_DEVICES": str(max(int(d) for d in strips.split(",")) + 1)})
     if (seam or lrseam or cdefseam or dlfseam or tplseam or tf_alone) and not with_hook and not only:
         only = "-"  # no RTCD pointer matches: the seam(s) alone
     if only:
@@ -331,8 +343,21 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     env.update(cpu_env(host + "_with_stages"))
     rh, th = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_hip"), env, timeout=timeout, enc=HOST_ENC[host])
     cpu_s[host + "_with_stages"] = LAST_CPU_S[0]
+    # 10-bit: the reference's psy-rd distortion reads picture-buffer memory nobody wrote for this picture (MemorySanitizer on the plain C encoder:
+    # profiles/r05_reference_msan_10bit.txt -- svt_psy_distortion / svt_sa8d_8x8 / svt_satd_4x4, psy_rd.c:94-165, on the posix_memalign of pic_buffer_desc.c:270), so
+    # what it reads is whatever an earlier picture left in that pool object, and that depends on the relative timing of the pipeline stages: `--lp 4` gives a
+    # different bitstream every run, `--lp 1` flips between two as soon as ONE stage takes a different time -- also with SVT_HIP_CDEF_SEAM_VERIFY=1, where every
+    # device result is compared with the reference's and the picture continues with the reference's own (tools/race_probe_10bit.py,
+    # profiles/r05_race_probe_10bit.txt).  A flipped 10-bit encode is therefore repeated: equal once in four attempts = the device stages reproduce the reference;
+    # a wrong device result would differ every time.
+    attempts = 1
+    if bd == 10 and rc.returncode == 0 and rh.returncode == 0:
+        ref_bits = open(os.path.join(outdir, name + "_c.ivf"), "rb").read()
+        while attempts < 4 and open(os.path.join(outdir, name + "_hip.ivf"), "rb").read() != ref_bits:
+            rh, th = encode(clip, w, h, n, bd, extra, os.path.join(outdir, name + "_hip"), env, timeout=timeout, enc=HOST_ENC[host])
+            attempts += 1
     res = {"case": name, "host": host, "width": w, "height": h, "frames": n, "bit_depth": bd, "args": extra, "rc_c": rc.returncode, "rc_hip": rh.returncode,
-           "seconds_c": round(tc, 2), "seconds_hip": round(th, 2), "reference_deterministic": deterministic,
+           "seconds_c": round(tc, 2), "seconds_hip": round(th, 2), "reference_deterministic": deterministic, "hip_encode_attempts": attempts,
            # host CPU seconds (user + system, every thread) per frame: what the offload takes off the host
            "host_cpu_s_per_frame": {k: round(v / n, 5) for k, v in cpu_s.items()}}
     if cpu_stats:  # thread CPU time inside each stage of SURVEY 8 (the reference's own functions without the seams, the device stage calls with them)
@@ -368,6 +393,7 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
         res["seam"] = {k: (int(v) if v.strip().isdigit() else v.strip()) for k, v in st.items()}
         # the claim is void unless every picture really went through the device stage
         res["identical"] = same and res["seam"].get("pictures_offloaded", 0) > 0 and res["seam"].get("pictures_declined", 1) == 0
+        res["identical"] = res["identical"] and res["seam"].get("plane_reuploads_by_checksum", 1) == 0  # a resident plane was rewritten behind the explicit invalidation
         if "+tfseam" in CASES[name][4]:  # temporal-filter pairs really went through the stage, none declined
             ld = "--pred-struct" in CASES[name][4]  # the low-delay temporal filter performs no ME (produce_temporally_filtered_pic_ld): no pair exists
             res["identical"] = res["identical"] and (ld or res["seam"].get("tf_pairs_offloaded", 0) > 0) and res["seam"].get("tf_pairs_declined", 1) == 0
