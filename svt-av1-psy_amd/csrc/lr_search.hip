@@ -19,6 +19,8 @@
 //   * self-guided: one launch filters the plane with every parameter set of the range (flt0 / flt1 kept as int32 planes in the workspace), one workgroup
 //     per (unit, parameter set) does projection + refinement (each evaluation = a pass over the unit's flt0 / flt1 / dgd / src), a per-unit thread
 //     picks the first-best set, the trial kernel restores with it.
+#include <type_traits>
+
 #include "lr_core.h"
 
 extern "C" void svt_hip_lr_compute_stats_batch(const void* dgd, const void* src, const SvtHipRect* rects, uint32_t n, int max_rect_width, int max_rect_height,
@@ -49,6 +51,7 @@ struct Ws { // workspace carving (device pointers)
     long long*          M;       // [n][49]
     long long*          H;       // [n][49 * 49]
     SgResult*           sg;      // [n][slots]
+    long long*          sgsum;   // [n][slots][5] the projection's normal equations (lr_sgr_flt_kernel -> lr_sgr_proj_kernel)
     int32_t*            counter; // [1] units still refining
     int32_t*            flt;     // [slots][2][height * width]
 };
@@ -333,6 +336,14 @@ __global__ void lr_wiener_step_kernel(const SvtHipLrSearchParams P, WnState* __r
     wn[u] = st;
 }
 
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long uv = (unsigned long long)v;
+        v += (long long)(((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(uv >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)uv, m));
+    }
+    return v;
+}
 __host__ __device__ inline size_t lrs_dq_dwords(const int w, const int h) { return (((size_t)w * h + 1) / 2 + 63) & ~(size_t)63; } // the int16 plane, in dwords
 // ---- self-guided: flt0 / flt1 of the whole plane for one parameter set per blockIdx.z ----------------------------------------------------------------
 // COMPACT (bit depth <= 10): what the projection search needs of a sample is q1 = flt0 - (dgd << 4), q2 = flt1 - (dgd << 4) and dgd - src, and at <= 10 bits
@@ -340,8 +351,10 @@ __host__ __device__ inline size_t lrs_dq_dwords(const int w, const int h) { retu
 // one packed dword per sample and parameter set plus one int16 per sample shared by all sets -- 4 + 2 bytes instead of 4 + 4 + 2 + 2 per sample and pass of
 // lr_sgr_proj_kernel, which re-reads its unit about nine times per parameter set (14 GB per 4K plane before, profiles/r02_reg7_pmc_traffic.json).
 template <bool COMPACT>
-__global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchParams P, int32_t* __restrict__ flt, const int slot0 /* first parameter set of this group */) {
+__global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchParams P, int32_t* __restrict__ flt, const int slot0 /* first parameter set of this group */,
+                                                         long long* __restrict__ sums /* [unit][set][5]: svt_get_proj_subspace's sums, accumulated here */, const int slots) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
+    __shared__ long long sh_sum[4][10];
     uint16_t* tile = smem;
     uint16_t* A16  = tile + TH * TW;
     int32_t*  B32  = (int32_t*)((uint8_t*)A16 + LRS_A_BYTES);
@@ -355,6 +368,23 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
     s.uw = w - s.x0 < 64 ? w - s.x0 : 64; s.uh = h - s.y0 < 64 ? h - s.y0 : 64;
     const int x0 = s.x0, y0 = s.y0;
     const bool p0 = kSgrR[idx][0] > 0, p1 = kSgrR[idx][1] > 0;
+    // The projection's normal equations (svt_get_proj_subspace, :413-498: sums of q1 q1, q2 q2, q1 q2, q1 s, q2 s over the unit; q = flt - (dgd << 4), s = (src - dgd) << 4)
+    // are taken HERE, while flt0 / flt1 of a sample are in registers: one pass of lr_sgr_proj_kernel over the unit less.  A 64 x 64 tile lies in one column of units
+    // (unit sizes are multiples of 64) and in at most two rows of units (a unit row starts 8 >> ss_y rows above a multiple of the unit size): two sets of sums per
+    // thread, one 64-bit atomic per sum and workgroup.  Integer sums: the order of accumulation does not matter.
+    const int us = (int)P.unit_size, uoff = 8 >> P.ss_y, nvu = n_units_1d(h, us), nhu = n_units_1d(w, us);
+    const int uc = x0 / us < nhu - 1 ? x0 / us : nhu - 1, ur_lo = (y0 + uoff) / us < nvu - 1 ? (y0 + uoff) / us : nvu - 1;
+    const int y_split = ur_lo < nvu - 1 ? (ur_lo + 1) * us - uoff - y0 : 1 << 30; // tile rows >= y_split belong to the next unit row
+    long long acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) acc[k] = 0;
+    auto add_sums = [&](const int r, const int d, const int sp, const int32_t f0v, const int32_t f1v) {
+        const long long q1 = p0 ? f0v - (d << 4) : 0, q2 = p1 ? f1v - (d << 4) : 0, sd = (long long)(sp - d) * 16;
+        const long long t[5] = {q1 * q1, q2 * q2, q1 * q2, q1 * sd, q2 * sd};
+        const bool      hi = r >= y_split;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { acc[k] += hi ? 0 : t[k]; acc[5 + k] += hi ? t[k] : 0; } // (selects, not a run-time index: the sums stay in registers)
+    };
     stage_tile<(TH + 15) / 16>(tile, s, tid);
     __syncthreads();
     if (COMPACT) {
@@ -367,38 +397,52 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
                      const int    da = tile[(r + 3) * TW + c + 3], db = tile[(r + 3) * TW + c + 4];
                      q[o] = (uint32_t)((p0 ? f0a - (da << 4) : 0) & 0xffff) | ((uint32_t)(p1 ? f1a - (da << 4) : 0) << 16);
                      if (has1) q[o + 1] = (uint32_t)((p0 ? f0b - (db << 4) : 0) & 0xffff) | ((uint32_t)(p1 ? f1b - (db << 4) : 0) << 16);
+                     const size_t so = (size_t)(y0 + r) * P.src_stride + x0 + c;
+                     const int    sa = rd_px(P.src, highbd, so), sb = has1 ? rd_px(P.src, highbd, so + 1) : 0;
+                     add_sums(r, da, sa, f0a, f1a);
+                     if (has1) add_sums(r, db, sb, f0b, f1b);
                      if (slot0 + slot == 0) { // (shared by every set and group: written once)
-                         const size_t so = (size_t)(y0 + r) * P.src_stride + x0 + c;
-                         dq[o] = (int16_t)(da - rd_px(P.src, highbd, so));
-                         if (has1) dq[o + 1] = (int16_t)(db - rd_px(P.src, highbd, so + 1));
+                         dq[o] = (int16_t)(da - sa);
+                         if (has1) dq[o + 1] = (int16_t)(db - sb);
                      }
                  });
     } else {
         int32_t* f0 = flt + (size_t)slot * 2 * w * h;
         int32_t* f1 = f0 + (size_t)w * h;
+        const int highbd = P.highbd;
         sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, P.bit_depth, tid, [&](int r, int c, int32_t v) { if (p0) f0[(size_t)(y0 + r) * w + x0 + c] = v; },
-                 [&](int r, int c, int32_t, int32_t b0, int32_t, int32_t b1, bool has1) {
+                 [&](int r, int c, int32_t a0v, int32_t b0, int32_t a1v, int32_t b1, bool has1) {
                      if (p1) { f1[(size_t)(y0 + r) * w + x0 + c] = b0; if (has1) f1[(size_t)(y0 + r) * w + x0 + c + 1] = b1; }
+                     const size_t so = (size_t)(y0 + r) * P.src_stride + x0 + c;
+                     add_sums(r, tile[(r + 3) * TW + c + 3], rd_px(P.src, highbd, so), a0v, b0);
+                     if (has1) add_sums(r, tile[(r + 3) * TW + c + 4], rd_px(P.src, highbd, so + 1), a1v, b1);
                  });
+    }
+    // workgroup sums -> the units' accumulators
+    if (!sums) return; // (workgroup-uniform)
+    const bool two = y_split < s.uh;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        if (k >= 5 && !two) break;
+        const long long v = wave_sum_i64(acc[k]);
+        if ((tid & 63) == 0) sh_sum[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid < (two ? 10 : 5)) {
+        const long long v = sh_sum[0][tid] + sh_sum[1][tid] + sh_sum[2][tid] + sh_sum[3][tid];
+        const int       u = (ur_lo + (tid >= 5 ? 1 : 0)) * nhu + uc;
+        atomicAdd((unsigned long long*)&sums[((size_t)u * slots + slot0 + slot) * 5 + (tid >= 5 ? tid - 5 : tid)], (unsigned long long)v);
     }
 }
 
 // ---- self-guided: projection + refinement of one (unit, parameter set) per workgroup (search_selfguided_restoration's loop body, :582-630) ------------
 constexpr int PROJ_T = 1024; // threads per (unit, parameter set): sixteen waves, every evaluation is one latency-bound pass over the unit
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const unsigned long long uv = (unsigned long long)v;
-        v += (long long)(((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(uv >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)uv, m));
-    }
-    return v;
-}
 // The workgroup's sums of N per-thread values, written to out[0..N) in LDS (valid for every thread on return): one wave reduction per value, one pair of
-// barriers for the whole group.  use(k) says whether value k is wanted (workgroup-uniform).  part: [PROJ_T / 64][16].
-constexpr int PROJ_W = PROJ_T / 64;
+// barriers for the whole group.  use(k) says whether value k is wanted (workgroup-uniform).  part: [PROJ_T / 64][PROJ_ROW].
+constexpr int PROJ_W = PROJ_T / 64, PROJ_ROW = 24;
 template <int N, typename U>
-__device__ __forceinline__ void block_sums_i64(const long long (&v)[N], long long (*part)[16], long long* out, const int tid, U use) {
-    static_assert(N <= 16, "part row");
+__device__ __forceinline__ void block_sums_i64(const long long (&v)[N], long long (*part)[PROJ_ROW], long long* out, const int tid, U use) {
+    static_assert(N <= PROJ_ROW, "part row");
     __syncthreads(); // (part and out are reused across calls)
 #pragma unroll
     for (int k = 0; k < N; k++)
@@ -423,19 +467,19 @@ struct __attribute__((aligned(8))) LrsPair { uint32_t v[2]; };
 #ifndef LRS_DEPTH
 #define LRS_DEPTH 4
 #endif
-template <bool COMPACT, typename F>
+template <bool COMPACT, int DEPTH = LRS_DEPTH, typename F>
 __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, const SvtHipRect& r, const int32_t* f0, const int32_t* f1, const int r0, const int r1,
                                                  const int tid, F body) {
     const int uw = r.h_end - r.h_start, uh = r.v_end - r.v_start, npx = uw * uh, w = (int)P.width, highbd = P.highbd;
     if (COMPACT && !((w | uw | r.h_start) & 3)) { // four consecutive samples per load pair: one b128 of packed (q1, q2) + one b64 of dgd - src
         const int qpr = uw >> 2, nq = qpr * uh, qy = PROJ_T / qpr, rx = PROJ_T - qy * qpr;
         int       y = tid / qpr, x = tid - y * qpr;
-        for (int i = tid; i < nq; i += LRS_DEPTH * PROJ_T) {
-            LrsQuad Q[LRS_DEPTH];
-            LrsPair D[LRS_DEPTH];
-            bool    ok[LRS_DEPTH];
+        for (int i = tid; i < nq; i += DEPTH * PROJ_T) {
+            LrsQuad Q[DEPTH];
+            LrsPair D[DEPTH];
+            bool    ok[DEPTH];
 #pragma unroll
-            for (int k = 0; k < LRS_DEPTH; k++) {
+            for (int k = 0; k < DEPTH; k++) {
                 ok[k] = i + k * PROJ_T < nq;
                 const size_t fo = (size_t)(r.v_start + (ok[k] ? y : 0)) * w + r.h_start + 4 * (ok[k] ? x : 0);
                 Q[k] = *(const LrsQuad*)((const uint32_t*)f1 + fo);
@@ -444,7 +488,7 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
                 if (x >= qpr) { x -= qpr; y++; }
             }
 #pragma unroll
-            for (int k = 0; k < LRS_DEPTH; k++)
+            for (int k = 0; k < DEPTH; k++)
                 if (ok[k]) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
@@ -457,11 +501,11 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
     }
     const int qy = PROJ_T / uw, rx = PROJ_T - qy * uw;
     int       y = tid / uw, x = tid - y * uw;
-    for (int i = tid; i < npx; i += LRS_DEPTH * PROJ_T) {
-        int d[LRS_DEPTH], sp[LRS_DEPTH], g0[LRS_DEPTH], g1[LRS_DEPTH];
-        bool ok[LRS_DEPTH];
+    for (int i = tid; i < npx; i += DEPTH * PROJ_T) {
+        int d[DEPTH], sp[DEPTH], g0[DEPTH], g1[DEPTH];
+        bool ok[DEPTH];
 #pragma unroll
-        for (int k = 0; k < LRS_DEPTH; k++) {
+        for (int k = 0; k < DEPTH; k++) {
             ok[k] = i + k * PROJ_T < npx;
             const int    yy = ok[k] ? y : 0, xx = ok[k] ? x : 0;
             const size_t fo = (size_t)(r.v_start + yy) * w + r.h_start + xx;
@@ -479,16 +523,101 @@ __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, 
             if (x >= uw) { x -= uw; y++; }
         }
 #pragma unroll
-        for (int k = 0; k < LRS_DEPTH; k++)
+        for (int k = 0; k < DEPTH; k++)
             if (ok[k]) body(d[k], sp[k], g0[k], g1[k]);
     }
 }
+// ---- finer_search_pixel_proj_error for a parameter set with BOTH passes on: a whole step size per pass --------------------------------------------------------
+// The walk at step s moves xqd[0] down or up along a line, then -- only if no downward move of xqd[0] was accepted (:372-373) -- xqd[1] along a line from wherever
+// xqd[0] ended.  With xq0 = xqd[0], xq1 = 128 - xqd[0] - xqd[1] (svt_decode_xq) a move of (d0, d1) changes a sample's projection by d0 * (a0 - a1) - d1 * a1, so ONE
+// pass over the unit gives the error of every point the walk can reach within K moves per line:
+//     E[0]                               the current point
+//     E[1 + j], j < K                    xqd[0] - (j + 1) s                     (the downward line of tap 0)
+//     E[1 + K + i], i < K                xqd[0] + (i + 1) s                     (its upward line)
+//     E[1 + 2K + i 2K + j], j < K        (xqd[0] + i s, xqd[1] - (j + 1) s)     i = 0 .. K: tap 1's downward line from each end point of tap 0's upward walk
+//     E[1 + 2K + i 2K + K + j], j < K    (xqd[0] + i s, xqd[1] + (j + 1) s)     ... and its upward line
+// and the reference's accept / reject sequence is then replayed on the table (sgr_grid_replay).  Errors are per-sample-rounded, so the table cannot come from sums --
+// it is the same arithmetic as get_pixel_proj_error at each point.  K = 2 at the largest step (which keeps moving while it improves; a walk that wants a third move
+// in one line leaves the table and the caller redoes that step the line-by-line way), K = 1 below it (one move per line, always inside the table).
+template <int K> struct SgrGrid { static constexpr int N = 1 + 2 * K + (K + 1) * 2 * K; };
+template <bool COMPACT, int K>
+__device__ __forceinline__ void sgr_grid_pass(const SvtHipLrSearchParams& P, const SvtHipRect& r, const int32_t* f0, const int32_t* f1, const int r0, const int r1, const int tid,
+                                              const int xq0, const int xq1, const int s, long long (*part)[PROJ_ROW], long long* out) {
+    constexpr int N = SgrGrid<K>::N;
+    // COMPACT (bit depth <= 10): a thread's sums fit 32 bits.  |q1|, |q2| <= 16 420 (lr_sgr_flt_kernel's bound), the candidates' |xq0| <= 100 and |xq1| <= 264, so
+    // |v >> 11| <= 2 929, |e| <= 2 929 + 1 023 and e * e < 15.7 M; a unit has at most 383 x 391 samples (a last row / column absorbs up to half a unit, plus the 8-row
+    // offset), 147 per thread: 147 x 15.7 M < 2^32.  One v_mad_u32_u24 per candidate instead of a 64-bit multiply-add, and half the accumulator registers.
+    typedef typename std::conditional<COMPACT, uint32_t, long long>::type Acc;
+    Acc acc[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) acc[k] = 0;
+    for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
+        const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10), dA = s * (a0 - a1), dB = s * a1;
+        auto sq = [&](const int vv) -> Acc { const int e = (vv >> 11) - sp; return COMPACT ? (Acc)((uint32_t)e * (uint32_t)e) : (Acc)((long long)e * e); };
+        acc[0] += sq(v);
+#pragma unroll
+        for (int j = 0; j < K; j++) { acc[1 + j] += sq(v - (j + 1) * dA); acc[1 + K + j] += sq(v + (j + 1) * dA); }
+#pragma unroll
+        for (int i = 0; i <= K; i++) {
+            const int b = v + i * dA;
+#pragma unroll
+            for (int j = 0; j < K; j++) { acc[1 + 2 * K + i * 2 * K + j] += sq(b + (j + 1) * dB); acc[1 + 2 * K + i * 2 * K + K + j] += sq(b - (j + 1) * dB); }
+        }
+    });
+    long long wide[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) wide[k] = (long long)acc[k];
+    block_sums_i64(wide, part, out, tid, [](int) { return true; });
+}
+// the walk of one step size over the table; workgroup-uniform.  false: a line wanted a move beyond the table (xqd / err are then partly advanced: the caller restores them)
+template <int K>
+__device__ __forceinline__ bool sgr_grid_replay(const long long* E, const int s, const bool keep_moving, int* xqd, long long& err, const int* tap_min, const int* tap_max) {
+    const int cap = keep_moving ? (1 << 30) : 1; // only the largest step keeps moving in the same direction (:359-361)
+    int       k = 0, i = 0;
+    bool      skip = false;
+    for (const int room = (xqd[0] - tap_min[0]) / s; k < room && k < cap;) { // tap 0 down
+        if (k == K) return false;
+        const long long e = E[1 + k];
+        if (e > err) break;
+        err = e; k++; skip = true;
+    }
+    xqd[0] -= s * k;
+    if (skip) return true; // (:372-373: a successful downward move ends the loop over the taps)
+    for (const int room = (tap_max[0] - xqd[0]) / s; i < room && i < cap;) { // tap 0 up
+        if (i == K) return false;
+        const long long e = E[1 + K + i];
+        if (e > err) break;
+        err = e; i++;
+    }
+    xqd[0] += s * i;
+    const long long* row = E + 1 + 2 * K + i * 2 * K;
+    k = 0;
+    for (const int room = (xqd[1] - tap_min[1]) / s; k < room && k < cap;) { // tap 1 down, from where tap 0 ended
+        if (k == K) return false;
+        const long long e = row[k];
+        if (e > err) break;
+        err = e; k++; skip = true;
+    }
+    xqd[1] -= s * k;
+    if (skip) return true;
+    int j = 0;
+    for (const int room = (tap_max[1] - xqd[1]) / s; j < room && j < cap;) { // tap 1 up
+        if (j == K) return false;
+        const long long e = row[K + j];
+        if (e > err) break;
+        err = e; j++;
+    }
+    xqd[1] += s * j;
+    return true;
+}
 template <bool COMPACT>
 __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const int32_t* __restrict__ flt,
-                                                             SgResult* __restrict__ res, const int slots, const int slot0) {
-    __shared__ long long part[PROJ_W][16];
+                                                             SgResult* __restrict__ res, const int slots, const int slot0, const int line_walk,
+                                                             const long long* __restrict__ sums) {
+    __shared__ long long part[PROJ_W][PROJ_ROW];
     __shared__ long long sh_t[5], sh_err;
-    __shared__ long long sh_e[3][8]; // the candidate errors of a line (down, up, the first pass's up run): workgroup-uniform and indexed at run time -- LDS, not registers
+    __shared__ long long sh_e[3][9]; // the candidate errors of a line (down, up, the first pass's up run; [8] of the first row: the current point): workgroup-uniform and indexed at run time -- LDS, not registers
+    __shared__ long long sh_g[SgrGrid<2>::N]; // the error table of a whole step size (sgr_grid_pass)
     __shared__ int32_t   sh_xq[2];
     const int        u = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x, idx = P.sg_start_ep + (slot0 + slot) * P.sg_ep_inc, w = (int)P.width, h = (int)P.height;
     const SvtHipRect r = rects[u];
@@ -497,13 +626,19 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
     const int32_t*   f0 = COMPACT ? flt : flt + (size_t)slot * 2 * w * h;
     const int32_t*   f1 = COMPACT ? flt + lrs_dq_dwords(w, h) + (size_t)slot * w * h : f0 + (size_t)w * h;
     const int        r0 = kSgrR[idx][0], r1 = kSgrR[idx][1];
-    // svt_get_proj_subspace (:413-498): the integer sums equal the reference's double sums exactly (every partial sum < 2^53)
-    long long a[5] = {0, 0, 0, 0, 0};
-    for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
-        const long long sd = (long long)sp * 16 - uu, q1 = a0, q2 = a1;
-        a[0] += q1 * q1; a[1] += q2 * q2; a[2] += q1 * q2; a[3] += q1 * sd; a[4] += q2 * sd;
-    });
-    block_sums_i64(a, part, sh_t, tid, [](int) { return true; });
+    // svt_get_proj_subspace (:413-498): the integer sums equal the reference's double sums exactly (every partial sum < 2^53); lr_sgr_flt_kernel accumulated them
+    // (sums == nullptr -- a unit size that is not a multiple of the filter kernel's 64 x 64 tiles --: one pass over the unit here)
+    if (sums) {
+        if (tid < 5) sh_t[tid] = sums[((size_t)u * slots + slot0 + slot) * 5 + tid];
+        __syncthreads();
+    } else {
+        long long a[5] = {0, 0, 0, 0, 0};
+        for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
+            const long long sd = (long long)sp * 16 - uu, q1 = a0, q2 = a1;
+            a[0] += q1 * q1; a[1] += q2 * q2; a[2] += q1 * q2; a[3] += q1 * sd; a[4] += q2 * sd;
+        });
+        block_sums_i64(a, part, sh_t, tid, [](int) { return true; });
+    }
     if (tid == 0) {
         const long long* t = sh_t;
         const double size = (double)npx;
@@ -548,18 +683,21 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
     // down and PROJ_K steps up from the current point -- and the reference's accept / reject sequence is then replayed on those errors.  (The up candidates
     // of the first pass stay valid exactly when no down move was accepted, which is when the reference evaluates them.)  Control flow is workgroup-uniform.
     constexpr int PROJ_K = 8; // (4: more passes on long chains, 7.0 ms instead of 6.4 ms on the 4K bench plane)
-    long long     err    = proj_err();
     static_assert(PROJ_K <= 8, "sh_e rows");
-    auto eval_line = [&](const int p, const int st, const int nd, const int nu, long long* ed, long long* eu) { // ed, eu: rows of sh_e
+    long long err      = 0;
+    bool      have_err = false; // err holds the error of the current xqd
+    // one pass: the errors of nd moves down and nu moves up of tap p by st each -- and, if wanted, of the current point itself (ed[PROJ_K])
+    auto eval_line = [&](const int p, const int st, const int nd, const int nu, const bool want0, long long* ed, long long* eu) __attribute__((always_inline)) { // ed, eu: rows of sh_e
         int xq0, xq1;
         if (r0 == 0) { xq0 = 0; xq1 = 128 - xqd[1]; }
         else if (r1 == 0) { xq0 = xqd[0]; xq1 = 0; }
         else { xq0 = xqd[0]; xq1 = 128 - xq0 - xqd[1]; }
         // d(xq0) / d(xqd[p]) and d(xq1) / d(xqd[p]) (svt_decode_xq, restoration.c:634-645)
         const int c0 = (p == 0 && r0 > 0) ? 1 : 0, c1 = (p == 1 || (r0 > 0 && r1 > 0)) ? -1 : 0;
-        long long ad[PROJ_K], au[PROJ_K];
+        long long ad[PROJ_K + 1], au[PROJ_K];
 #pragma unroll
         for (int k = 0; k < PROJ_K; k++) ad[k] = au[k] = 0;
+        ad[PROJ_K] = 0;
         for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
             const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10), dv = st * (c0 * a0 + c1 * a1);
 #pragma unroll
@@ -567,58 +705,80 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
                 if (k < nd) { const int e = ((v - (k + 1) * dv) >> 11) - sp; ad[k] += (long long)e * e; }
                 if (k < nu) { const int e = ((v + (k + 1) * dv) >> 11) - sp; au[k] += (long long)e * e; }
             }
+            if (want0) { const int e = (v >> 11) - sp; ad[PROJ_K] += (long long)e * e; }
         });
-        block_sums_i64(ad, part, ed, tid, [&](int k) { return k < nd; });
+        block_sums_i64(ad, part, ed, tid, [&](int k) { return k < nd || (k == PROJ_K && want0); });
         block_sums_i64(au, part, eu, tid, [&](int k) { return k < nu; });
     };
-    if (P.sg_refine)
-        for (int st = 2; st >= 1; st >>= 1)
-            for (int p = 0; p < 2; p++) {
-                if ((r0 == 0 && p == 0) || (r1 == 0 && p == 1)) continue;
-                const int cap = st == 2 ? PROJ_K : 1; // only the largest step keeps moving in the same direction (:359-361)
-                long long *ed = sh_e[0], *eu = sh_e[1], *eu0 = sh_e[2];
-                int       skip = 0, nu0 = 0;
-                for (bool first = true;; first = false) { // the downward moves
-                    const int roomd = (xqd[p] - tap_min[p]) / st, nd = roomd < cap ? roomd : cap;
-                    int       nu = 0;
-                    if (first) { const int roomu = (tap_max[p] - xqd[p]) / st; nu = roomu < cap ? roomu : cap; }
-                    if (nd == 0 && nu == 0) break;
-                    eval_line(p, st, nd, nu, ed, eu);
-                    if (first) { // (the next writer of eu / eu0 passes block_sums_i64's first barrier before it writes)
-                        nu0 = nu;
-                        if (tid < PROJ_K) eu0[tid] = eu[tid];
-                        __syncthreads();
-                    }
-                    int  k = 0;
-                    bool rejected = false;
-                    while (k < nd) {
-                        if (ed[k] > err) { rejected = true; break; }
-                        err = ed[k]; k++; skip = 1;
-                        if (st != 2) break;
-                    }
-                    xqd[p] -= st * k;
-                    if (rejected || st != 2 || k < nd || nd < PROJ_K) break;
+    // one step size the line-by-line way (a pass per line; the first pass of a set also delivers the error of the starting point)
+    auto line_stage = [&](const int st) __attribute__((always_inline)) {
+        for (int p = 0; p < 2; p++) {
+            if ((r0 == 0 && p == 0) || (r1 == 0 && p == 1)) continue;
+            const int cap = st == 2 ? PROJ_K : 1; // only the largest step keeps moving in the same direction (:359-361)
+            long long *ed = sh_e[0], *eu = sh_e[1], *eu0 = sh_e[2];
+            int       skip = 0, nu0 = 0;
+            for (bool first = true;; first = false) { // the downward moves
+                const int roomd = (xqd[p] - tap_min[p]) / st, nd = roomd < cap ? roomd : cap;
+                int       nu = 0;
+                if (first) { const int roomu = (tap_max[p] - xqd[p]) / st; nu = roomu < cap ? roomu : cap; }
+                if (nd == 0 && nu == 0) break;
+                eval_line(p, st, nd, nu, !have_err, ed, eu);
+                if (!have_err) { err = ed[PROJ_K]; have_err = true; }
+                if (first) { // (the next writer of eu / eu0 passes block_sums_i64's first barrier before it writes)
+                    nu0 = nu;
+                    if (tid < PROJ_K) eu0[tid] = eu[tid];
+                    __syncthreads();
                 }
-                if (skip) break; // (:372-373: a successful downward move ends the loop over p)
-                int nu = nu0;
-                for (int pass = 0; nu > 0; pass++) { // the upward moves, from the unchanged point
-                    if (pass > 0) {
-                        const int roomu = (tap_max[p] - xqd[p]) / st;
-                        nu = roomu < cap ? roomu : cap;
-                        if (nu == 0) break;
-                        eval_line(p, st, 0, nu, ed, eu0);
-                    }
-                    int  k = 0;
-                    bool rejected = false;
-                    while (k < nu) {
-                        if (eu0[k] > err) { rejected = true; break; }
-                        err = eu0[k]; k++;
-                        if (st != 2) break;
-                    }
-                    xqd[p] += st * k;
-                    if (rejected || st != 2 || k < nu || nu < PROJ_K) break;
+                int  k = 0;
+                bool rejected = false;
+                while (k < nd) {
+                    if (ed[k] > err) { rejected = true; break; }
+                    err = ed[k]; k++; skip = 1;
+                    if (st != 2) break;
                 }
+                xqd[p] -= st * k;
+                if (rejected || st != 2 || k < nd || nd < PROJ_K) break;
             }
+            if (skip) break; // (:372-373: a successful downward move ends the loop over p)
+            int nu = nu0;
+            for (int pass = 0; nu > 0; pass++) { // the upward moves, from the unchanged point
+                if (pass > 0) {
+                    const int roomu = (tap_max[p] - xqd[p]) / st;
+                    nu = roomu < cap ? roomu : cap;
+                    if (nu == 0) break;
+                    eval_line(p, st, 0, nu, false, ed, eu0);
+                }
+                int  k = 0;
+                bool rejected = false;
+                while (k < nu) {
+                    if (eu0[k] > err) { rejected = true; break; }
+                    err = eu0[k]; k++;
+                    if (st != 2) break;
+                }
+                xqd[p] += st * k;
+                if (rejected || st != 2 || k < nu || nu < PROJ_K) break;
+            }
+        }
+    };
+    // finer_search_pixel_proj_error (:320-411), start_step 2.  Control flow is workgroup-uniform throughout.
+    //   * both passes on (10 of the 16 parameter sets): one pass per step size (sgr_grid_pass: the starting point's error comes with the first) -- 2 passes after the
+    //     projection sums instead of 5-6;
+    //   * one pass off: the walk only ever moves ONE tap, a whole run of candidates per pass (eval_line), the starting point's error folded into the first.
+    if (P.sg_refine)
+        for (int st = 2; st >= 1; st >>= 1) { // (ONE call site of line_stage: it is inlined once, its candidate sums stay in registers)
+            bool by_line = true;
+            if (r0 > 0 && r1 > 0 && line_walk != 1) {
+                if (st == 2) sgr_grid_pass<COMPACT, 2>(P, r, f0, f1, r0, r1, tid, xqd[0], 128 - xqd[0] - xqd[1], 2, part, sh_g);
+                else sgr_grid_pass<COMPACT, 1>(P, r, f0, f1, r0, r1, tid, xqd[0], 128 - xqd[0] - xqd[1], 1, part, sh_g);
+                if (!have_err) { err = sh_g[0]; have_err = true; }
+                const int       sx0 = xqd[0], sx1 = xqd[1];
+                const long long serr = err;
+                by_line = st == 2 ? (!sgr_grid_replay<2>(sh_g, 2, true, xqd, err, tap_min, tap_max) || line_walk == 2) : !sgr_grid_replay<1>(sh_g, 1, false, xqd, err, tap_min, tap_max);
+                if (by_line) { xqd[0] = sx0; xqd[1] = sx1; err = serr; } // a line wants a third move at the largest step: this step size line by line (rare)
+            }
+            if (by_line) line_stage(st);
+        }
+    if (!have_err) err = proj_err(); // no refinement, or no room to move at all
     if (tid == 0) {
         SgResult o;
         o.err = err; o.xqd[0] = xqd[0]; o.xqd[1] = xqd[1];
@@ -666,6 +826,7 @@ inline size_t carve(const SvtHipLrSearchParams& P, void* base, Ws* ws) {
     w.M = (long long*)take(n * 49 * 8);
     w.H = (long long*)take(n * 49 * 49 * 8);
     w.sg = (SgResult*)take(n * (slots ? slots : 1) * sizeof(SgResult));
+    w.sgsum = (long long*)take(n * (slots ? slots : 1) * 5 * 8);
     w.counter = (int32_t*)take(256);
     const size_t group = (size_t)sg_group(P, (int)slots), wh = (size_t)P.width * P.height;
     // <= 10 bit: one int16 plane (dgd - src) shared by every set + one packed dword plane per set of the group; 12 bit: two int32 planes per set of the group
@@ -710,17 +871,21 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
         HIP_CHECK(hipStreamWaitEvent(sg_st, ev_fork, 0));
     }
     unsigned long long* sg_acc = both ? W.acc2 : W.acc;
+    const char* lw = getenv("SVT_HIP_LR_SG_WALK"); // (A/B measurement: "line" = every step size line by line, the round-4 form; read per call -- a picture-sized stage)
+    const int   line_walk = lw && lw[0] == 'l' ? 1 : (lw && lw[0] == 'f' ? 2 : 0); // ("fallback": the table pass, then the line-by-line redo as if the walk had left the table -- tests)
     auto self_guided = [&]() {
         const int group = sg_group(P, slots);
+        long long* sgsum = ((int)P.unit_size & 63) ? nullptr : W.sgsum; // (the tile-wise accumulation needs unit boundaries on the tile grid)
+        if (sgsum) HIP_CHECK(hipMemsetAsync(sgsum, 0, (size_t)n * slots * 5 * 8, sg_st));
         for (int s0 = 0; s0 < slots; s0 += group) { // a group's planes are overwritten by the next group's filter launch: stream order keeps the projection before it
             const int  gs = slots - s0 < group ? slots - s0 : group;
             const dim3 fgrid(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, gs);
             if (P.bit_depth <= 10) { // int16 differences (see lr_sgr_flt_kernel); 12-bit keeps the int32 planes
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, sg_st, P, W.flt, s0);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, gs), dim3(PROJ_T), 0, sg_st, P, W.rects, W.flt, W.sg, slots, s0);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, sg_st, P, W.flt, s0, sgsum, slots);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, gs), dim3(PROJ_T), 0, sg_st, P, W.rects, W.flt, W.sg, slots, s0, line_walk, sgsum);
             } else {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, sg_st, P, W.flt, s0);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, gs), dim3(PROJ_T), 0, sg_st, P, W.rects, W.flt, W.sg, slots, s0);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, sg_st, P, W.flt, s0, sgsum, slots);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, gs), dim3(PROJ_T), 0, sg_st, P, W.rects, W.flt, W.sg, slots, s0, line_walk, sgsum);
             }
         }
         hipLaunchKernelGGL(lr_sgr_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, sg_st, P, W.sg, units, slots, n);
