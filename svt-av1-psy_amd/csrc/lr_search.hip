@@ -351,7 +351,8 @@ __host__ __device__ inline size_t lrs_dq_dwords(const int w, const int h) { retu
 // one packed dword per sample and parameter set plus one int16 per sample shared by all sets -- 4 + 2 bytes instead of 4 + 4 + 2 + 2 per sample and pass of
 // lr_sgr_proj_kernel, which re-reads its unit about nine times per parameter set (14 GB per 4K plane before, profiles/r02_reg7_pmc_traffic.json).
 template <bool COMPACT>
-__global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchParams P, int32_t* __restrict__ flt, const int slot0 /* first parameter set of this group */,
+__global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchParams P, int32_t* __restrict__ flt /* the shared dgd - src plane */, int32_t* __restrict__ qbase /* this group's planes */,
+                                                         const int slot0 /* first parameter set of this group */,
                                                          long long* __restrict__ sums /* [unit][set][5]: svt_get_proj_subspace's sums, accumulated here */, const int slots) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
     __shared__ long long sh_sum[4][10];
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
     __syncthreads();
     if (COMPACT) {
         int16_t*  dq = (int16_t*)flt;                                                        // [h][w]: dgd - src
-        uint32_t* q  = (uint32_t*)flt + lrs_dq_dwords(w, h) + (size_t)slot * w * h;          // [h][w]: q1 | q2 << 16
+        uint32_t* q  = (uint32_t*)qbase + (size_t)slot * w * h;                              // [h][w]: q1 | q2 << 16
         const int highbd = P.highbd;
         sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, P.bit_depth, tid, [](int, int, int32_t) {},
                  [&](int r, int c, int32_t f0a, int32_t f1a, int32_t f0b, int32_t f1b, bool has1) {
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
                      }
                  });
     } else {
-        int32_t* f0 = flt + (size_t)slot * 2 * w * h;
+        int32_t* f0 = qbase + (size_t)slot * 2 * w * h;
         int32_t* f1 = f0 + (size_t)w * h;
         const int highbd = P.highbd;
         sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, P.bit_depth, tid, [&](int r, int c, int32_t v) { if (p0) f0[(size_t)(y0 + r) * w + x0 + c] = v; },
@@ -552,8 +553,9 @@ __device__ __forceinline__ void sgr_grid_pass(const SvtHipLrSearchParams& P, con
 #pragma unroll
     for (int k = 0; k < N; k++) acc[k] = 0;
     for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
-        const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10), dA = s * (a0 - a1), dB = s * a1;
-        auto sq = [&](const int vv) -> Acc { const int e = (vv >> 11) - sp; return COMPACT ? (Acc)((uint32_t)e * (uint32_t)e) : (Acc)((long long)e * e); };
+        // ((v >> 11) - sp == (v - (sp << 11)) >> 11 exactly: the source sample is folded into v once, a candidate is then an add, a shift and a multiply-add)
+        const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10) - (sp << 11), dA = s * (a0 - a1), dB = s * a1;
+        auto sq = [&](const int vv) -> Acc { const int e = vv >> 11; return COMPACT ? (Acc)((uint32_t)e * (uint32_t)e) : (Acc)((long long)e * e); };
         acc[0] += sq(v);
 #pragma unroll
         for (int j = 0; j < K; j++) { acc[1 + j] += sq(v - (j + 1) * dA); acc[1 + K + j] += sq(v + (j + 1) * dA); }
@@ -611,9 +613,9 @@ __device__ __forceinline__ bool sgr_grid_replay(const long long* E, const int s,
     return true;
 }
 template <bool COMPACT>
-__global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const int32_t* __restrict__ flt,
-                                                             SgResult* __restrict__ res, const int slots, const int slot0, const int line_walk,
-                                                             const long long* __restrict__ sums) {
+__global__ __launch_bounds__(PROJ_T) __attribute__((amdgpu_waves_per_eu(5, 5))) void lr_sgr_proj_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const int32_t* __restrict__ flt,
+                                                             const int32_t* __restrict__ qbase, SgResult* __restrict__ res, const int slots, const int slot0, const int line_walk,
+                                                             const long long* __restrict__ sums, int32_t* __restrict__ dbg /* nullptr, or [1..3]: table passes, line passes, tables left */) {
     __shared__ long long part[PROJ_W][PROJ_ROW];
     __shared__ long long sh_t[5], sh_err;
     __shared__ long long sh_e[3][9]; // the candidate errors of a line (down, up, the first pass's up run; [8] of the first row: the current point): workgroup-uniform and indexed at run time -- LDS, not registers
@@ -623,8 +625,8 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
     const SvtHipRect r = rects[u];
     const int        npx = (r.h_end - r.h_start) * (r.v_end - r.v_start);
     // compact: f0 = the shared int16 plane (dgd - src), f1 = this parameter set's packed (q1, q2) plane
-    const int32_t*   f0 = COMPACT ? flt : flt + (size_t)slot * 2 * w * h;
-    const int32_t*   f1 = COMPACT ? flt + lrs_dq_dwords(w, h) + (size_t)slot * w * h : f0 + (size_t)w * h;
+    const int32_t*   f0 = COMPACT ? flt : qbase + (size_t)slot * 2 * w * h;
+    const int32_t*   f1 = COMPACT ? qbase + (size_t)slot * w * h : f0 + (size_t)w * h;
     const int        r0 = kSgrR[idx][0], r1 = kSgrR[idx][1];
     // svt_get_proj_subspace (:413-498): the integer sums equal the reference's double sums exactly (every partial sum < 2^53); lr_sgr_flt_kernel accumulated them
     // (sums == nullptr -- a unit size that is not a multiple of the filter kernel's 64 x 64 tiles --: one pass over the unit here)
@@ -694,21 +696,32 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
         else { xq0 = xqd[0]; xq1 = 128 - xq0 - xqd[1]; }
         // d(xq0) / d(xqd[p]) and d(xq1) / d(xqd[p]) (svt_decode_xq, restoration.c:634-645)
         const int c0 = (p == 0 && r0 > 0) ? 1 : 0, c1 = (p == 1 || (r0 > 0 && r1 > 0)) ? -1 : 0;
-        long long ad[PROJ_K + 1], au[PROJ_K];
+        // COMPACT (bit depth <= 10): a thread's sums fit 32 bits -- |q1|, |q2| <= 16 420, the candidates' |xq0| <= 112 and |xq1| <= 280, so |e| <= 3 143 + 1 023 and
+        // e * e < 17.4 M; at most 147 samples of a unit per thread (383 x 391 / 1 024): 147 x 17.4 M < 2^32.  The source sample is folded into v
+        // ((v >> 11) - sp == (v - (sp << 11)) >> 11 exactly), the candidates of a line are successive adds: per candidate an add, a shift, a multiply-add.
+        typedef typename std::conditional<COMPACT, uint32_t, long long>::type Acc;
+        Acc ad[PROJ_K + 1], au[PROJ_K];
 #pragma unroll
         for (int k = 0; k < PROJ_K; k++) ad[k] = au[k] = 0;
         ad[PROJ_K] = 0;
         for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
-            const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10), dv = st * (c0 * a0 + c1 * a1);
+            const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10) - (sp << 11), dv = st * (c0 * a0 + c1 * a1);
+            auto sq = [&](const int vv) -> Acc { const int e = vv >> 11; return COMPACT ? (Acc)((uint32_t)e * (uint32_t)e) : (Acc)((long long)e * e); };
+            int vd = v, vu = v;
 #pragma unroll
             for (int k = 0; k < PROJ_K; k++) {
-                if (k < nd) { const int e = ((v - (k + 1) * dv) >> 11) - sp; ad[k] += (long long)e * e; }
-                if (k < nu) { const int e = ((v + (k + 1) * dv) >> 11) - sp; au[k] += (long long)e * e; }
+                vd -= dv; vu += dv;
+                if (k < nd) ad[k] += sq(vd);
+                if (k < nu) au[k] += sq(vu);
             }
-            if (want0) { const int e = (v >> 11) - sp; ad[PROJ_K] += (long long)e * e; }
+            if (want0) ad[PROJ_K] += sq(v);
         });
-        block_sums_i64(ad, part, ed, tid, [&](int k) { return k < nd || (k == PROJ_K && want0); });
-        block_sums_i64(au, part, eu, tid, [&](int k) { return k < nu; });
+        long long wd[PROJ_K + 1], wu[PROJ_K];
+#pragma unroll
+        for (int k = 0; k < PROJ_K; k++) { wd[k] = (long long)ad[k]; wu[k] = (long long)au[k]; }
+        wd[PROJ_K] = (long long)ad[PROJ_K];
+        block_sums_i64(wd, part, ed, tid, [&](int k) { return k < nd || (k == PROJ_K && want0); });
+        block_sums_i64(wu, part, eu, tid, [&](int k) { return k < nu; });
     };
     // one step size the line-by-line way (a pass per line; the first pass of a set also delivers the error of the starting point)
     auto line_stage = [&](const int st) __attribute__((always_inline)) {
@@ -723,6 +736,7 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
                 if (first) { const int roomu = (tap_max[p] - xqd[p]) / st; nu = roomu < cap ? roomu : cap; }
                 if (nd == 0 && nu == 0) break;
                 eval_line(p, st, nd, nu, !have_err, ed, eu);
+                if (dbg && tid == 0) atomicAdd(&dbg[2], 1);
                 if (!have_err) { err = ed[PROJ_K]; have_err = true; }
                 if (first) { // (the next writer of eu / eu0 passes block_sums_i64's first barrier before it writes)
                     nu0 = nu;
@@ -747,6 +761,7 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
                     nu = roomu < cap ? roomu : cap;
                     if (nu == 0) break;
                     eval_line(p, st, 0, nu, false, ed, eu0);
+                    if (dbg && tid == 0) atomicAdd(&dbg[2], 1);
                 }
                 int  k = 0;
                 bool rejected = false;
@@ -767,13 +782,14 @@ __global__ __launch_bounds__(PROJ_T) void lr_sgr_proj_kernel(const SvtHipLrSearc
     if (P.sg_refine)
         for (int st = 2; st >= 1; st >>= 1) { // (ONE call site of line_stage: it is inlined once, its candidate sums stay in registers)
             bool by_line = true;
-            if (r0 > 0 && r1 > 0 && line_walk != 1) {
+            if (r0 > 0 && r1 > 0 && line_walk != 1 && (st == 1 || line_walk >= 2)) {
                 if (st == 2) sgr_grid_pass<COMPACT, 2>(P, r, f0, f1, r0, r1, tid, xqd[0], 128 - xqd[0] - xqd[1], 2, part, sh_g);
                 else sgr_grid_pass<COMPACT, 1>(P, r, f0, f1, r0, r1, tid, xqd[0], 128 - xqd[0] - xqd[1], 1, part, sh_g);
                 if (!have_err) { err = sh_g[0]; have_err = true; }
                 const int       sx0 = xqd[0], sx1 = xqd[1];
                 const long long serr = err;
                 by_line = st == 2 ? (!sgr_grid_replay<2>(sh_g, 2, true, xqd, err, tap_min, tap_max) || line_walk == 2) : !sgr_grid_replay<1>(sh_g, 1, false, xqd, err, tap_min, tap_max);
+                if (dbg && tid == 0) { atomicAdd(&dbg[1], 1); if (by_line) atomicAdd(&dbg[3], 1); }
                 if (by_line) { xqd[0] = sx0; xqd[1] = sx1; err = serr; } // a line wants a third move at the largest step: this step size line by line (rare)
             }
             if (by_line) line_stage(st);
@@ -807,7 +823,7 @@ inline int sg_slots(const SvtHipLrSearchParams& P) {
 inline int sg_group(const SvtHipLrSearchParams& P, const int slots) {
     if (slots <= 0) return 0;
     const size_t per_set = (size_t)P.width * P.height * (P.bit_depth <= 10 ? 4 : 8);
-    size_t       g = per_set ? ((size_t)240 << 20) / per_set : (size_t)slots;
+    size_t       g = per_set ? ((size_t)140 << 20) / per_set : (size_t)slots; // (per buffer: there are two, see svt_hip_lr_search_plane)
     const char*  e = getenv("SVT_HIP_LR_SG_GROUP"); // (tests: force small groups on small planes; read per call -- a picture-sized stage)
     if (e && atoi(e) > 0) g = (size_t)atoi(e);
     g = g < 1 ? 1 : (g < (size_t)slots ? g : (size_t)slots);
@@ -830,7 +846,7 @@ inline size_t carve(const SvtHipLrSearchParams& P, void* base, Ws* ws) {
     w.counter = (int32_t*)take(256);
     const size_t group = (size_t)sg_group(P, (int)slots), wh = (size_t)P.width * P.height;
     // <= 10 bit: one int16 plane (dgd - src) shared by every set + one packed dword plane per set of the group; 12 bit: two int32 planes per set of the group
-    w.flt = (int32_t*)take(P.bit_depth <= 10 ? (lrs_dq_dwords((int)P.width, (int)P.height) + group * wh) * 4 : group * 2 * wh * 4);
+    w.flt = (int32_t*)take(P.bit_depth <= 10 ? (lrs_dq_dwords((int)P.width, (int)P.height) + 2 * group * wh) * 4 : 2 * group * 2 * wh * 4); // two group buffers
     if (ws) *ws = w;
     return off;
 }
@@ -853,74 +869,97 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     const int mw = max_uw > us ? max_uw : (us < (int)P.width ? us : (int)P.width), mh = max_uh > us ? max_uh : (us < (int)P.height ? us : (int)P.height);
     const dim3 tgrid((mw + 63) / 64, (mh + 63) / 64, n);
     hipLaunchKernelGGL(lr_rects_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.rects, W.acc, W.wn, units, n);
-    HIP_CHECK(hipMemsetAsync(W.counter, 0, 4, st));
+    HIP_CHECK(hipMemsetAsync(W.counter, 0, 16, st));
     // RESTORE_NONE
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<0>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
     hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, st, W.acc, units, 0, n);
     SVT_LAUNCH_CHECK();
-    // The two searches are independent (they write different fields of a unit's record and keep separate accumulators): the self-guided one -- two or three long
-    // launches per group of parameter sets -- runs on the calling thread's second stream BESIDE the Wiener refinement, which is tens of short dependent launches with a
-    // host read-back every eight steps and leaves the chip mostly idle.  Fork after the unit rectangles / the RESTORE_NONE pass, join before returning.
-    const bool  both = P.wn_enabled && P.sg_enabled && slots > 0;
-    hipStream_t sg_st = st;
-    hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
-    if (both) {
-        svthip::thread_fork(&sg_st, &ev_fork, &ev_join);
+    // Three independent launch sequences behind the unit rectangles / the RESTORE_NONE pass, on the calling thread's side streams (fork here, join before returning):
+    //   * the self-guided search, group after group of parameter sets (filter launch, projection launch), the groups ALTERNATING between two streams and two sets of
+    //     plane buffers: a projection launch ends in a long tail -- one 1 024-thread workgroup per CU, 4 to 12 passes each --, which the other stream's group fills;
+    //   * the Wiener refinement -- tens of short dependent launches with a host read-back every eight steps -- on the highest-priority stream, so that its launches
+    //     are not queued behind the long self-guided workgroups.
+    // They write different fields of a unit's record and keep separate accumulators.
+    const bool  sg_on = P.sg_enabled && slots > 0;
+    const svthip::ThreadStreams& TS = svthip::thread_streams();
+    hipStream_t sg_st[2] = {TS.st[0], TS.st[1]}, wn_st = TS.st[2];
+    hipEvent_t  ev_fork = TS.ev[0], ev_sg0 = TS.ev[1], ev_sg1 = TS.ev[2], ev_wn = TS.ev[3], ev_dq = TS.ev[4];
+    const char* lw = getenv("SVT_HIP_LR_SG_WALK"); // (A/B measurement, read per call -- a picture-sized stage)
+    int32_t*    sg_dbg = getenv("SVT_HIP_LR_SG_STATS") ? W.counter : nullptr; // (diagnostic: pass counts of the projection walk, printed below)
+    // default: the largest step line by line (its walks are long where the projection's least-squares start is clamped: 8 moves per pass and direction), the last step
+    // from one table pass (always inside its table).  "line": both steps line by line (the round-4 form); "table": the largest step from a K = 2 table as well (a walk
+    // that leaves it is redone line by line -- measured: every both-pass set of the bench plane does, profiles/r05_lr_search_walk_forms.txt); "fallback": as "table",
+    // every walk treated as if it had left the table (tests)
+    const int   line_walk = !lw ? 0 : lw[0] == 'l' ? 1 : lw[0] == 'f' ? 2 : lw[0] == 't' ? 3 : 0;
+    long long*  sgsum = ((int)P.unit_size & 63) ? nullptr : W.sgsum; // (the tile-wise accumulation needs unit boundaries on the tile grid)
+    if (sg_on) {
         HIP_CHECK(hipMemsetAsync(W.acc2, 0, (size_t)n * 8, st));
-        HIP_CHECK(hipEventRecord(ev_fork, st));
-        HIP_CHECK(hipStreamWaitEvent(sg_st, ev_fork, 0));
+        if (sgsum) HIP_CHECK(hipMemsetAsync(sgsum, 0, (size_t)n * slots * 5 * 8, st));
     }
-    unsigned long long* sg_acc = both ? W.acc2 : W.acc;
-    const char* lw = getenv("SVT_HIP_LR_SG_WALK"); // (A/B measurement: "line" = every step size line by line, the round-4 form; read per call -- a picture-sized stage)
-    const int   line_walk = lw && lw[0] == 'l' ? 1 : (lw && lw[0] == 'f' ? 2 : 0); // ("fallback": the table pass, then the line-by-line redo as if the walk had left the table -- tests)
+    HIP_CHECK(hipEventRecord(ev_fork, st));
+    unsigned long long* sg_acc = W.acc2;
     auto self_guided = [&]() {
-        const int group = sg_group(P, slots);
-        long long* sgsum = ((int)P.unit_size & 63) ? nullptr : W.sgsum; // (the tile-wise accumulation needs unit boundaries on the tile grid)
-        if (sgsum) HIP_CHECK(hipMemsetAsync(sgsum, 0, (size_t)n * slots * 5 * 8, sg_st));
-        for (int s0 = 0; s0 < slots; s0 += group) { // a group's planes are overwritten by the next group's filter launch: stream order keeps the projection before it
-            const int  gs = slots - s0 < group ? slots - s0 : group;
-            const dim3 fgrid(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, gs);
-            if (P.bit_depth <= 10) { // int16 differences (see lr_sgr_flt_kernel); 12-bit keeps the int32 planes
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, sg_st, P, W.flt, s0, sgsum, slots);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, gs), dim3(PROJ_T), 0, sg_st, P, W.rects, W.flt, W.sg, slots, s0, line_walk, sgsum);
+        const int    group = sg_group(P, slots);
+        const size_t wh = (size_t)P.width * P.height;
+        const bool   compact = P.bit_depth <= 10; // int16 differences (see lr_sgr_flt_kernel); 12-bit keeps the int32 planes
+        HIP_CHECK(hipStreamWaitEvent(sg_st[0], ev_fork, 0));
+        HIP_CHECK(hipStreamWaitEvent(sg_st[1], ev_fork, 0));
+        int gi = 0;
+        for (int s0 = 0; s0 < slots; s0 += group, gi++) { // group gi: stream gi & 1, buffer gi & 1 (a buffer's next filter launch follows its projection launch in stream order)
+            const int   gs = slots - s0 < group ? slots - s0 : group, b = gi & 1;
+            const dim3  fgrid(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, gs);
+            int32_t*    qb = compact ? W.flt + lrs_dq_dwords((int)P.width, (int)P.height) + (size_t)b * group * wh : W.flt + (size_t)b * group * 2 * wh;
+            hipStream_t s_ = sg_st[b];
+            if (compact) {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, s_, P, W.flt, qb, s0, sgsum, slots);
+                if (gi == 0) HIP_CHECK(hipEventRecord(ev_dq, s_)); // (the first group's filter launch also writes the dgd - src plane every projection launch reads)
+                if (gi == 1) HIP_CHECK(hipStreamWaitEvent(s_, ev_dq, 0));
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, gs), dim3(PROJ_T), 0, s_, P, W.rects, W.flt, qb, W.sg, slots, s0, line_walk, sgsum, sg_dbg);
             } else {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, sg_st, P, W.flt, s0, sgsum, slots);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, gs), dim3(PROJ_T), 0, sg_st, P, W.rects, W.flt, W.sg, slots, s0, line_walk, sgsum);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, s_, P, W.flt, qb, s0, sgsum, slots);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, gs), dim3(PROJ_T), 0, s_, P, W.rects, W.flt, qb, W.sg, slots, s0, line_walk, sgsum, sg_dbg);
             }
         }
-        hipLaunchKernelGGL(lr_sgr_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, sg_st, P, W.sg, units, slots, n);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<2>), tgrid, dim3(256), LRS_SMEM, sg_st, P, W.rects, W.wn, units, sg_acc);
-        hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, sg_st, sg_acc, units, 2, n);
+        HIP_CHECK(hipEventRecord(ev_sg1, sg_st[1]));
+        HIP_CHECK(hipStreamWaitEvent(sg_st[0], ev_sg1, 0));
+        hipLaunchKernelGGL(lr_sgr_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, sg_st[0], P, W.sg, units, slots, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<2>), tgrid, dim3(256), LRS_SMEM, sg_st[0], P, W.rects, W.wn, units, sg_acc);
+        hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, sg_st[0], sg_acc, units, 2, n);
         SVT_LAUNCH_CHECK();
+        HIP_CHECK(hipEventRecord(ev_sg0, sg_st[0]));
     };
-    if (both) { // enqueued first: it is already running while the host steps through the Wiener refinement
-        self_guided();
-        HIP_CHECK(hipEventRecord(ev_join, sg_st));
-    }
+    if (sg_on) self_guided(); // enqueued first: it is already running while the host steps through the Wiener refinement
     int rc_wn = 0;
     if (P.wn_enabled) {
+        HIP_CHECK(hipStreamWaitEvent(wn_st, ev_fork, 0));
         svt_hip_lr_compute_stats_batch(P.dgd, P.src, W.rects, (uint32_t)n, mw, mh, (int)P.dgd_stride, (int)P.src_stride, P.wiener_win, P.highbd ? P.bit_depth : 8,
-                                       (int64_t*)W.M, (int64_t*)W.H, stream);
-        hipLaunchKernelGGL(lr_wiener_solve_kernel, dim3(n), dim3(64), 0, st, P, W.M, W.H, prev, W.wn, units);
+                                       (int64_t*)W.M, (int64_t*)W.H, wn_st);
+        hipLaunchKernelGGL(lr_wiener_solve_kernel, dim3(n), dim3(64), 0, wn_st, P, W.M, W.H, prev, W.wn, units);
         SVT_LAUNCH_CHECK();
         // lock-step refinement: step (propose / consume) + trial; the number of units still searching comes back every 8 steps
         int32_t active = 1;
         for (int it = 0; active > 0 && it < 4096; it++) {
-            hipLaunchKernelGGL(lr_wiener_step_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.wn, W.acc, units, W.counter, n);
+            hipLaunchKernelGGL(lr_wiener_step_kernel, dim3((n + 63) / 64), dim3(64), 0, wn_st, P, W.wn, W.acc, units, W.counter, n);
             if ((it & 7) == 0) {
-                HIP_CHECK(hipMemcpyAsync(&active, W.counter, 4, hipMemcpyDeviceToHost, st));
-                HIP_CHECK(hipStreamSynchronize(st));
+                HIP_CHECK(hipMemcpyAsync(&active, W.counter, 4, hipMemcpyDeviceToHost, wn_st));
+                HIP_CHECK(hipStreamSynchronize(wn_st));
                 if (active <= 0) break;
             }
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<1>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<1>), tgrid, dim3(256), LRS_SMEM, wn_st, P, W.rects, W.wn, units, W.acc);
         }
         SVT_LAUNCH_CHECK();
         if (active > 0) rc_wn = -2; // the lock-step cap was hit with units still searching: their sse[1] is not final -- the caller must not use this plane's result
+        HIP_CHECK(hipEventRecord(ev_wn, wn_st));
+        HIP_CHECK(hipStreamWaitEvent(st, ev_wn, 0)); // (also on the failure path: the side streams' work must not outlive the call's ordering)
     }
-    if (both) HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0)); // (also on the failure path: the second stream's work must not outlive the call's ordering)
-    if (rc_wn) return rc_wn;
-    if (!both && P.sg_enabled && slots > 0) self_guided();
-    return 0;
+    if (sg_dbg && sg_on) {
+        int32_t c[4];
+        HIP_CHECK(hipStreamSynchronize(sg_st[0]));
+        HIP_CHECK(hipMemcpy(c, W.counter, 16, hipMemcpyDeviceToHost));
+        fprintf(stderr, "SVT_HIP_LR_SG_STATS: %d units x %d sets: %d table passes (%d left their table), %d line passes\n", n, slots, c[1], c[3], c[2]);
+    }
+    if (sg_on) HIP_CHECK(hipStreamWaitEvent(st, ev_sg0, 0));
+    return rc_wn;
 }
 
 // Host-pointer form (what a seam in rest_process.c calls): uploads the plane with the 3 (+1 right) sample border the filters read and the source plane

@@ -108,19 +108,22 @@ HostCallLease::~HostCallLease() {
     g_lease_pool[device].push_back(c); // (most recently used first: the arena that has already grown is the one that is taken again)
 }
 
-// A second stream + two events of the calling thread on its current device (made on first use, kept): for a stage that runs two independent launch sequences side
-// by side and joins them (the loop-restoration search: Wiener refinement beside the self-guided search).
-struct ThreadFork { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-static thread_local ThreadFork t_fork[MAX_DEVICES];
-void thread_fork(hipStream_t* aux, hipEvent_t* fork, hipEvent_t* join) {
+// Side streams + events of the calling thread on its current device (made on first use, kept): for a stage that runs independent launch sequences side by side and
+// joins them (the loop-restoration search: the self-guided search's groups of parameter sets on two streams, the Wiener refinement -- a chain of short dependent
+// launches -- on a third one with the highest priority, so that its launches are not queued behind the long self-guided workgroups).
+static thread_local ThreadStreams t_streams[MAX_DEVICES];
+const ThreadStreams& thread_streams() {
     ensure_device();
-    ThreadFork& f = t_fork[current_device()];
-    if (!f.st) {
-        HIP_CHECK(hipStreamCreateWithFlags(&f.st, hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&f.join, hipEventDisableTiming));
+    ThreadStreams& f = t_streams[current_device()];
+    if (!f.st[0]) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; } // (hi = the numerically lowest value = the highest priority)
+        HIP_CHECK(hipStreamCreateWithFlags(&f.st[0], hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&f.st[1], hipStreamNonBlocking));
+        if (hipStreamCreateWithPriority(&f.st[2], hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); HIP_CHECK(hipStreamCreateWithFlags(&f.st[2], hipStreamNonBlocking)); }
+        for (hipEvent_t& e : f.ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    *aux = f.st; *fork = f.fork; *join = f.join;
+    return f;
 }
 
 // Four zeroed device words for ONE launch sequence on `st` (tickets / counters of a kernel that orders its own workgroups): slots of a per-device ring, cleared in

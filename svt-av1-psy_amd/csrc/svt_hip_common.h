@@ -100,7 +100,8 @@ struct HostCall {
     void sync();
 };
 HostCall& host_call();
-void      thread_fork(hipStream_t* aux, hipEvent_t* fork, hipEvent_t* join); // the calling thread's second stream + fork / join events on its device (runtime.hip)
+struct ThreadStreams { hipStream_t st[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev[6] = {}; }; // st[2]: highest priority
+const ThreadStreams& thread_streams(); // the calling thread's side streams + events on its current device (runtime.hip)
 uint32_t* stream_scratch_u32x4(hipStream_t st);
 // the TPL dispenser with the option set of tpl levels 0-3 (tpl_full.hip): every intra mode, SATD costs, sub-pel vectors, rate
 bool tpl_full_wanted(const ::SvtHipTplSrcParams& P);

@@ -573,6 +573,7 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = null
 }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipemu::Stream{hipemu::cur_device()}; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hipemu::Stream{hipemu::cur_device()}; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned f, int) { return hipStreamCreateWithFlags(s, f); }
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete (hipemu::Stream*)s; return hipSuccess; }
 inline hipError_t hipStreamGetDevice(hipStream_t s, int* d) { *d = s ? ((hipemu::Stream*)s)->device : hipemu::cur_device(); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
@@ -591,6 +592,7 @@ inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 #define hipHostMallocDefault 0u
 #define hipEventDisableTiming 2u
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemuEvent{0}; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{0}; return hipSuccess; }

@@ -188,11 +188,11 @@ GPU_CASES = [(500, 300, 8, 64, 0, (1, 7, 1, 0), (1, 0, 16, 1, 1), False),
              (300, 200, 12, 64, 0, (1, 7, 1, 0), (1, 0, 16, 3, 1), False)]   # 12-bit: the int32 flt planes
 
 
-@pytest.mark.parametrize("walk", ["line", "fallback"])
+@pytest.mark.parametrize("walk", ["line", "fallback", "table"])
 @pytest.mark.parametrize("case", [1, 3])
 def test_lr_search_plane_hip_walk_forms(be, oracle, case, walk, monkeypatch):
-    """the self-guided projection refinement's other two forms give the same units: SVT_HIP_LR_SG_WALK=line (every step size line by line, the round-4 form) and
-    =fallback (the one-pass error table of a step size, then the line-by-line redo a walk that leaves the table takes -- forced for every set)"""
+    """the self-guided projection refinement's other forms give the same units: SVT_HIP_LR_SG_WALK=line (every step size line by line, the round-4 form), =table (the
+    largest step from a one-pass error table too) and =fallback (as table, then the line-by-line redo a walk that leaves the table takes -- forced for every set)"""
     monkeypatch.setenv("SVT_HIP_LR_SG_WALK", walk)
     test_lr_search_plane_hip(be, oracle, case, 0, monkeypatch)
 
