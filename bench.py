@@ -295,6 +295,11 @@ def cpu_has(*flags):
 AVX512 = ("avx512f", "avx512bw", "avx512dq", "avx512vl", "avx512cd")  # HAS_AVX512F of the reference = this set (common_dsp_rtcd.c:123-129)
 
 
+def CPU_HELPERS():
+    """what bench_cpu.py needs of this module"""
+    return {"cpu_pool": cpu_pool, "aligned_zeros": aligned_zeros, "ref_libs": ref_libs, "cpu_has": cpu_has, "AVX512": AVX512, "host_cores": host_cores}
+
+
 def ref_libs():
     ref_path, ora_path = os.path.join(ROOT, "oracle", "_ref", "libsvtref.so"), os.path.join(ROOT, "oracle", "liboracle.so")
     if not (os.path.exists(ref_path) and os.path.exists(ora_path)):
@@ -381,8 +386,51 @@ def cpu_lr_search(k, budget_s):
             if not np.array_equal(one[f][0], res[f][u]):
                 sys.exit("bench.py: parity check FAILED for the LR search, unit %d field %s: device %s, reference %s -- no numbers recorded" % (u, f, res[f][u], one[f][0]))
         done += 1
-    return {"parity_checked_units": done, "cpu_baseline": {"value": done / tcpu, "unit": "units/s", "cores": 1, "kind": "reference",
-                                                           "sample": "%d random 256x256 units of the plane, C kernels" % done}}
+    out = {"parity_checked_units": done, "cpu_baseline_c_one_core": {"value": done / tcpu, "unit": "units/s", "cores": 1, "kind": "reference",
+                                                                     "sample": "%d random 256x256 units of the plane, C kernels (the parity check's own run)" % done}}
+    # the CPU path the contract names: the SAME reference function with the dispatch pointers it goes through pointed at the AVX2 kernels oracle/_ref holds, the units
+    # spread over every host core (the wrapper builds its own search context per call: thread-safe)
+    if use_ref and " avx2 " in open("/proc/cpuinfo").read():
+        patched = []
+        for ptr, fnn in (("svt_av1_compute_stats", "svt_av1_compute_stats_avx2"), ("svt_av1_compute_stats_highbd", "svt_av1_compute_stats_highbd_avx2"),
+                         ("svt_av1_highbd_pixel_proj_error", "svt_av1_highbd_pixel_proj_error_avx2"), ("svt_av1_lowbd_pixel_proj_error", "svt_av1_lowbd_pixel_proj_error_avx2"),
+                         ("svt_av1_selfguided_restoration", "svt_av1_selfguided_restoration_avx2"), ("svt_apply_selfguided_restoration", "svt_apply_selfguided_restoration_avx2"),
+                         ("svt_av1_highbd_wiener_convolve_add_src", "svt_av1_highbd_wiener_convolve_add_src_avx2"), ("svt_av1_wiener_convolve_add_src", "svt_av1_wiener_convolve_add_src_avx2"),
+                         ("svt_get_proj_subspace", "svt_get_proj_subspace_avx2"), ("svt_spatial_full_distortion_kernel", "svt_spatial_full_distortion_kernel_avx2"),
+                         ("svt_full_distortion_kernel16_bits", "svt_full_distortion_kernel16_bits_avx2")):
+            if hasattr(ref, fnn):
+                try:
+                    C.c_void_p.in_dll(ref, ptr).value = C.cast(getattr(ref, fnn), C.c_void_p).value
+                    patched.append(fnn)
+                except ValueError:
+                    pass
+        import concurrent.futures as cf
+        cores = host_cores()
+        sample = [int(u) for u in order[:min(n, max(cores * 2, 16))]]
+        shares = [sample[i::cores] for i in range(cores)]
+        outs = [np.zeros(max(len(sh), 1), res.dtype) for sh in shares]
+
+        def work(i):
+            if shares[i]:
+                rr = np.ascontiguousarray(rects[shares[i]])
+                me.ref_lr_search_plane(C.byref(P), None, vp(outs[i]), vp(rr), len(shares[i]))
+        t1 = time.perf_counter()
+        with cf.ThreadPoolExecutor(cores) as ex:
+            list(ex.map(work, range(cores)))
+        dt = time.perf_counter() - t1
+        for i, sh in enumerate(shares):  # (the AVX2 kernels must give the device's units too: the reference's own cross-ISA invariant)
+            for j, u in enumerate(sh):
+                for f in ("sse", "vfilter", "hfilter", "ep", "xqd"):
+                    if not np.array_equal(outs[i][f][j], res[f][u]):
+                        sys.exit("bench.py: parity check FAILED for the LR search (AVX2 reference kernels), unit %d field %s -- no numbers recorded" % (u, f))
+        out["cpu_baseline"] = {"value": len(sample) / dt / n, "unit": "planes/s (%d units per plane)" % n, "cores": cores, "kind": "reference", "units_per_s": len(sample) / dt,
+                               "sample": "%d units through the reference's search_norestore / search_wiener / search_sgrproj_seg (ref_wrap/ref_lr_search.c), %d of its dispatch "
+                                         "pointers at AVX2 kernels (%s), all cores at once" % (len(sample), len(patched), ", ".join(x.replace("svt_", "").replace("_avx2", "") for x in patched))}
+        ref.svt_aom_setup_common_rtcd_internal(C.c_uint64(0))  # back to the C table for whatever runs next
+        ref.svt_aom_setup_rtcd_internal(C.c_uint64(0))
+    else:
+        out["cpu_baseline"] = dict(out["cpu_baseline_c_one_core"])
+    return out
 
 
 def encoder_fps():
@@ -412,6 +460,17 @@ def encoder_fps():
         inst = ei.run_instances(CASE + "_300", lib, td, 4, host="avx2", timeout=900) if have_x else {}  # (300 frames: a 60-frame encode is over in 0.5 s, less than a process's start-up)
         # thread CPU time per stage (integration/seam_cpu.h), a run of its own: the brackets cost two clock reads per SB in the ME stage
         rcpu = ei.run_case(CASE, lib, td, timeout=600, host="avx2", cpu_stats=True) if have_x else {}
+        # tpl level 1 (presets <= M2) inside the AVX2 encoder, no seam: thread CPU time of the dispenser (integration/seam_cpu.h) over a short 1080p preset-2 encode --
+        # the reference-kind CPU figure of the tpl_l1_* legs (not a one-core C run)
+        p2 = {}
+        if have_x:
+            clip2, n2 = os.path.join(td, "p2.yuv"), 6
+            ei.make_clip(clip2, 1920, 1080, n2, 8)
+            st2 = os.path.join(td, "p2_cpu.txt")
+            r2, dt2 = ei.encode(clip2, 1920, 1080, n2, 8, ["--preset", "2"], os.path.join(td, "p2"), {"SVT_HIP_SEAM_CPU_STATS": st2}, timeout=900, enc=ei.ENC_AVX2)
+            if r2.returncode == 0 and os.path.exists(st2):
+                kv = dict(ln.split() for ln in open(st2).read().splitlines() if ln.strip())
+                p2 = {"frames": n2, "seconds": round(dt2, 2), "tpl_cpu_ms": int(kv.get("tpl_cpu_ms", 0)), "tpl_calls": int(kv.get("tpl_calls", 0)), "sbs_per_picture": 510}
     if rep and not rep.get("identical"):
         sys.exit("bench.py: a repeated encode's bitstream differs -- no numbers recorded")
     med = lambda v: sorted(v)[len(v) // 2] if v else None  # noqa: E731
@@ -434,6 +493,7 @@ def encoder_fps():
                           "cpu_s_per_frame_avx2": inst.get("host_cpu_s_per_frame_avx2"), "cpu_s_per_frame_avx2_with_stages": inst.get("host_cpu_s_per_frame_avx2_with_stages"),
                           "identical": inst.get("identical")} if inst else None,
             "stage_cpu_ms_per_frame": rcpu.get("stage_cpu_ms_per_frame"), "host_cpu_s_per_frame_in_that_run": rcpu.get("host_cpu_s_per_frame"),
+            "preset2_tpl_cpu": p2 or None,
             "frames": r["frames"], "host_threads": len(os.sched_getaffinity(0)), "host_cores": host_cores(),
             "host_ms_per_me_stage_call": (lambda m: round(m.get("ms_in_stage_calls", 0) / max(m.get("pictures_offloaded", 0) + m.get("tf_pairs_offloaded", 0), 1), 3))(r.get("seam") or {}),
             "host_ms_first_stage_call": (r.get("seam") or {}).get("ms_first_stage_call"),
@@ -451,6 +511,19 @@ def attach_encoder_baselines(kernels, enc):
     no seam) by the thread CPU clock around the stage entries (integration/seam_cpu.h) over the encoder leg's 1080p preset-8 clip -- CPU milliseconds per picture the
     stage handled, quoted as pictures per second of ONE host core.  (The one-core C restatements of oracle/ stay in the detail object as `cpu_baseline_port`: they are
     the parity checkers, not the reference's CPU path.)"""
+    p2 = (enc or {}).get("preset2_tpl_cpu")
+    if p2 and p2.get("tpl_calls") and p2.get("tpl_cpu_ms"):
+        # one dispenser call = one picture = 1 + 510 bracketed entries (the dispenser + its per-SB function): pictures = calls / 511
+        pictures = p2["tpl_calls"] / (p2["sbs_per_picture"] + 1.0)
+        ms = p2["tpl_cpu_ms"] / max(pictures, 1e-9)
+        for leg, key in (("tpl_l1_src_1080p8", "cpu_baseline"), ("tpl_l1_recon_1080p8", "cpu_baseline_both_halves")):
+            k = kernels.get(leg)
+            if isinstance(k, dict):
+                if key in k:
+                    k[key + "_c_one_core"] = k.pop(key)
+                k[key] = {"value": 1e3 / ms, "unit": "pictures/s per host core (both halves of the dispenser)", "cores": 1, "kind": "reference", "cpu_ms_per_picture": ms,
+                          "sample": "tpl_mc_flow_dispenser + its per-SB calls at tpl level 1 in oracle/_ref/enc_avx2 over a %d-frame 1080p preset-2 encode (%.1f dispenser "
+                                    "calls), thread CPU time" % (p2["frames"], pictures)}
     if not enc or not enc.get("stage_cpu_ms_per_frame") or not enc["stage_cpu_ms_per_frame"].get("avx2"):
         return
     ref, frames, st = enc["stage_cpu_ms_per_frame"]["avx2"], enc.get("frames") or 0, enc.get("stages_on_gpu") or {}
@@ -802,6 +875,8 @@ def bench_fwd_txfm(torch, lib, pkg, stream, a, cpu):
                 rate, one, cores = cpu_pool(run, 3.0)
                 out["fwd_txfm2d_32x32"][key] = {"value": rate / 1e6, "unit": "Mblocks/s (32x32)", "cores": cores, "kind": "reference", "single_thread_value": one / 1e6,
                                                 "sample": "%s, 512 private blocks per thread, 3 s per leg" % sym}
+            import bench_cpu
+            bench_cpu.quantize(out, CPU_HELPERS(), coeff, qpar, iscan)
             # the inverse 32x32 + reconstruction (10 bit): the reference's AVX2 variant is dav1d assembly (NASM: not buildable here), so the intrinsic variants it has --
             # SSE4.1 and AVX-512 -- are timed (common_dsp_rtcd.c:515)
             if hasattr(oracle2, "oracle_time_inv_txfm"):
@@ -1350,7 +1425,7 @@ def main():
     ap.add_argument("--min-leg-s", type=float, default=MIN_TIMED_S, help="minimum device time of every timed region (a step = as many launches as that takes)")
     ap.add_argument("--no-pmc", action="store_true", help="skip this run's own rocprofv3 --pmc child passes (roofline.traffic then comes from the committed summary)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (me, sad, txfm, config3, cdef, lr, hme, session, tf, tpl, tpl1, tfpic, lrsearch, cpart): A/B measurements")
+    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (me, sad, txfm, config3, cdef, lr, hme, session, tf, tpl, tpl1, tfpic, lrsearch, cpart, satd): A/B measurements")
     ap.add_argument("--extra", action="store_true", help="also sweep the other search areas / sub_sad and the remaining stages (reported under kernels)")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -1445,6 +1520,25 @@ def main():
                   sad_ops_per_s=n * aw * ah * 4096 / kernel_s,
                   # measured v_qsad_pk_u16_u8 issue cost: 22.4 cycles per wave64 instruction per SIMD (profiles/r01_call1_valu_issue_rates.txt)
                   valu_peak_sad_ops_per_s=QSAD_PEAK, valu_frac=n * aw * ah * 4096 / kernel_s / QSAD_PEAK)
+    if not a.pmc_child and rank == 0:
+        # the denominators of valu_frac, measured in THIS run: lane-operations per second of a kernel that issues nothing but independent
+        # v_qsad_pk_u16_u8 / v_add + v_xor instructions on every SIMD -- rates, so no clock has to be assumed; the "cycles" figures divide by the 2.4 GHz the device
+        # property reports and are only a unit conversion of those rates
+        sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+        pb, pi, probe = 256 * 8, 4096, {}
+        for kind, nm in ((1, "v_qsad_pk_u16_u8"), (2, "v_add_xor_pair")):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            lib.svt_hip_rate_probe(kind, pi, pb, sink.data_ptr(), stream)
+            e0.record()
+            for _ in range(4):
+                lib.svt_hip_rate_probe(kind, pi, pb, sink.data_ptr(), stream)
+            e1.record()
+            torch.cuda.synchronize()
+            lane_ops = 4 * pb * 256 * pi * 8 / (e0.elapsed_time(e1) / 1e3)
+            probe[nm] = {"lane_ops_per_s": lane_ops, "ns_per_wave64_inst_per_simd": 1e9 * 64 * 1024 / lane_ops, "cycles_per_wave64_inst_at_2.4GHz": 2.4e9 * 64 * 1024 / lane_ops}
+        rf["valu_probe_this_run"] = probe
+        rf["valu_cycles_per_inst"] = probe["v_add_xor_pair"]["cycles_per_wave64_inst_at_2.4GHz"]
+        rf["valu_frac_vs_this_runs_qsad_rate"] = (n * aw * ah * 4096 / kernel_s) / (probe["v_qsad_pk_u16_u8"]["lane_ops_per_s"] * 16)
     fp = bench_frame_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle)
     if (world > 1 or a.mode == "strips") and not a.pmc_child:
         fp["in_loop_filters"] = bench_filter_partition(torch, lib, pkg, stream, a, dist, rank, world, oracle)
@@ -1521,6 +1615,8 @@ def main():
             kernels.update(lr)
         if want("hme"):
             kernels.update(bench_legs.hme_chain(torch, lib, pkg, stream, max(a.steps // 4, 8), 2))
+        if want("satd"):
+            kernels.update(bench_legs.hadamard_satd(torch, lib, pkg, stream, max(a.steps // 4, 8), 2, oracle))
         if want("session"):
             kernels.update(bench_legs.me_session_stage(torch, lib, pkg, stream, 12, 1))
         if want("tf"):
@@ -1591,10 +1687,18 @@ def main():
         kernels.update(bench_legs.tf_inter_pred(torch, lib, pkg, stream, max(es // 2, 2), 1))
         kernels["txfm_quant_roundtrip"] = bench_legs.txfm_roundtrip(torch, lib, pkg, stream, max(es // 4, 3), 1)
     out["kernels"] = kernels
+    if cpu and not a.only_me:
+        import bench_cpu
+        bench_cpu.attach(kernels, CPU_HELPERS())  # the reference's AVX2 / AVX-512 kernels on all host cores for the legs that had no such figure
     if cpu:
         host_descs = pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, aw, ah, PLANE, n_refs=1, src_plane=0, ref_plane0=1)
         out["cpu_baseline"] = cpu_me_baseline(host_descs, planes, planes, (aw, ah), budget_s=10.0)
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        for (w2, h2) in ((8, 4), (8, 3)):  # the same reference kernels at the areas preset 8 derives
+            leg = kernels.get("me_search_%dx%d_preset8_area" % (w2, h2))
+            if isinstance(leg, dict):
+                hd = pkg.me_descs_for_frame(W, H, STRIDE, PAD, PAD, w2, h2, PLANE, n_refs=1, src_plane=0, ref_plane0=1)
+                leg["cpu_baseline"] = cpu_me_baseline(hd, planes, planes, (w2, h2), budget_s=3.0)
         if not a.only_me and not a.legs:
             out["encoder_fps_1080p_preset8"] = encoder_fps()
             attach_encoder_baselines(kernels, out["encoder_fps_1080p_preset8"])

@@ -648,6 +648,37 @@ def lr_search(torch, lib, pkg, stream, steps, warmup, keep=None):
     return out
 
 
+def hadamard_satd(torch, lib, pkg, stream, steps, warmup, oracle=None):
+    """SURVEY a8 / a9 (north_star: "SAD/SATD search"): hadamard_path_c's body -- residual of an 8-bit block against its prediction -> svt_aom_hadamard_32x32 ->
+    svt_aom_satd -- for every 32x32 block of a 1080p picture x 8 candidate predictions (16 320 blocks per launch).  Bytes: 2 x 1 KB in + 4 B out per block."""
+    g = np.random.default_rng(41)
+    W, H, n_pred = 1920, 1088, 8
+    src = g.integers(0, 256, (H, W), dtype=np.uint8)
+    preds = np.clip(src[None].astype(np.int16) + g.integers(-24, 25, (n_pred, H, W)), 0, 255).astype(np.uint8)
+    blocks = [(x, y) for y in range(0, H, 32) for x in range(0, W, 32)]
+    n = len(blocks) * n_pred
+    d = np.zeros(n, dtype=pkg.SatdDesc)
+    xy = np.array(blocks * n_pred)
+    d["in_off"] = xy[:, 1].astype(np.uint64) * W + xy[:, 0].astype(np.uint64)
+    d["pred_off"] = np.repeat(np.arange(n_pred, dtype=np.uint64), len(blocks)) * (H * W) + d["in_off"]
+    d["in_stride"] = d["pred_stride"] = W
+    d_src, d_pred, d_d = _dev(torch, src), _dev(torch, preds), _dev(torch, d)
+    d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    fn = lambda: lib.svt_hip_hadamard_satd_batch(d_src.data_ptr(), d_pred.data_ptr(), d_d.data_ptr(), n, 32, d_out.data_ptr(), None, stream)  # noqa: E731
+    fn()
+    torch.cuda.synchronize()
+    got, checked = d_out.cpu().numpy().view(np.uint32), 0
+    if oracle is not None:
+        oracle.oracle_hadamard_satd.restype = C.c_uint32
+        for i in np.linspace(0, n - 1, 48).astype(int):
+            want = oracle.oracle_hadamard_satd(C.c_void_p(src.ctypes.data + int(d["in_off"][i])), W, C.c_void_p(preds.ctypes.data + int(d["pred_off"][i])), W, 32)
+            assert int(got[i]) == int(want), ("hadamard_satd_32x32", i, int(got[i]), int(want))
+            checked += 1
+    t = _time(torch, fn, steps, warmup)
+    return {"hadamard_satd_32x32": {"value": n / t / 1e6, "unit": "Mblocks/s (32x32: residual + Hadamard + SATD)", "blocks_per_launch": n, "parity_checked_values": checked,
+                                    "roofline": roof(n * (2 * 1024 + 4), t)}}
+
+
 def tf_inter_pred(torch, lib, pkg, stream, steps, warmup):
     """The temporal filter's final motion compensation: one 1080p 8-bit 4:2:0 central picture against 6 reference pictures, every 16x16 block (luma + chroma,
     MULTITAP_SHARP) = 6 x 8 160 blocks in one launch, predictions written as picture-sized planes.  Bytes: 1.5 B per sample out + the interpolation window in."""

@@ -46,7 +46,7 @@ def compact(out):
                                                      "timed_region_s", "parallelism", "mode"))
     line["parity_checked_values"] = out.get("parity_checked_values")
     line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel", "kernel_us", "valu_frac",
-                                  "binds", "sad_path_hbm_frac", "moved_over_algorithmic", "traffic_source"))
+                                  "binds", "sad_path_hbm_frac", "moved_over_algorithmic", "traffic_source", "valu_cycles_per_inst", "valu_frac_vs_this_runs_qsad_rate"))
     if "traffic" not in line["roofline"]:
         line["roofline"]["traffic"] = None
     a84 = (kernels.get("me_search_8x4_preset8_area") or {}).get("roofline")
@@ -68,6 +68,8 @@ def compact(out):
                 ck[name] = e
         if ck:
             c["kernels"] = ck
+        have = [n for n, k in kernels.items() if isinstance(k, dict) and any(isinstance(k.get(x), dict) and k[x].get("kind") == "reference" for x in k if x.startswith("cpu_baseline"))]
+        c["legs_with_reference_cpu"] = [len(have), len([n for n, k in kernels.items() if isinstance(k, dict) and not n.startswith("_")])]  # (every figure: the detail file)
         line["cpu_baseline"] = c
     else:
         line["cpu_baseline"] = None

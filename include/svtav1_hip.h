@@ -58,6 +58,17 @@ void svt_hip_tuning_reload(void);
  * `_hip` variants.  Call right after svt_aom_setup_rtcd_internal() (Source/Lib/Globals/enc_handle.c:1444-1445).
  * Returns the number of pointers installed. */
 int         svt_hip_setup_rtcd(uint64_t flags);
+/* Error policy (SURVEY 8b "errors": a `_hip` variant must never propagate an error; Source/Lib/Codec/aom_dsp_rtcd.c:188: the reference's kernels cannot fail).
+ * The FIRST HIP error inside the library (a failed allocation, copy, launch, synchronisation, or an arena limit) switches the device path OFF for the rest of the
+ * process: it is recorded (svt_hip_last_error), every dispatch pointer svt_hip_setup_rtcd overwrote is put back to the variant the reference had selected, the
+ * `_hip` call in flight finishes through that saved pointer, and every stage / host-form entry point (`svt_hip_*_host`, `svt_hip_*_stage*`, the ME session) returns
+ * SVT_HIP_E_DEVICE (or NULL) from then on -- the encoder's seams decline and run the reference's own function.  Nothing aborts; there is no CPU path in here.
+ * The device-pointer batch entry points (callers that own streams and device buffers: tests, bench) throw through to their caller's guard or terminate. */
+#define SVT_HIP_E_DEVICE (-100)
+const char *svt_hip_last_error(void); /* NULL while the device path is on */
+int         svt_hip_failed(void);
+void        svt_hip_rtcd_unhook(void); /* puts the saved dispatch pointers back (what the first error does) */
+int         svt_hip_debug_inject_failure(void); /* test instrument: behaves as if a HIP call had just failed */
 /* SVT_HIP_COUNT mode (csrc/rtcd_hook.hip): calls made so far through each installed pointer; returns the number of counted pointers */
 int         svt_hip_rtcd_call_counts(const char **names, uint64_t *counts, int max);
 /* Cross-lane / packed-byte instruction self-test used by the GPU test-suite (returns 0 when the silicon agrees
@@ -154,7 +165,7 @@ void *svt_hip_me_session_create_on(int device, uint32_t width, uint32_t height, 
 void  svt_hip_me_session_destroy(void *session);
 int   svt_hip_me_session_submit(void *session, int64_t pic_id, const uint8_t *plane_host, const int64_t *ref_ids, uint32_t n_refs, uint32_t area_w,
                                 uint32_t area_h, int sub_sad, uint32_t *best_sad_host, uint32_t *best_mv_host);
-void  svt_hip_me_session_wait(void *session, int slot);
+int  svt_hip_me_session_wait(void *session, int slot);
 /* forget a resident picture whose host content changed (the next submission naming it as the source uploads it again); is a picture resident? */
 void  svt_hip_me_session_invalidate(void *session, int64_t pic_id);
 int   svt_hip_me_session_resident(void *session, int64_t pic_id);
@@ -517,7 +528,7 @@ void svt_hip_tf_subpel_search_batch(const SvtHipTfSubpelParams *params, const vo
                                     uint32_t n, SvtHipTfSubpelResult *results, void *stream);
 /* The same from HOST memory (a seam around tf_subpel_search, temporal_filtering.c:1670, calls it once per (central picture, reference picture) pair for every
  * block the reference may ask for): src_buf / ref_buf = the two pictures' whole padded luma buffers, the descs' offsets relative to them.  Synchronous. */
-void svt_hip_tf_subpel_search_host(const SvtHipTfSubpelParams *params, const void *src_buf, size_t src_samples, const void *ref_buf, size_t ref_samples,
+int svt_hip_tf_subpel_search_host(const SvtHipTfSubpelParams *params, const void *src_buf, size_t src_samples, const void *ref_buf, size_t ref_samples,
                                    const SvtHipTfSubpelDesc *descs, uint32_t n, SvtHipTfSubpelResult *results);
 
 /* The temporal filter's final motion compensation, batched: replaces tf_64x64_inter_prediction / tf_32x32_ / tf_16x16_ / tf_8x8_inter_prediction
@@ -785,7 +796,7 @@ void svt_hip_lpf_edges_batch(void *plane, uint32_t stride, int is_16bit, int bd,
  * readable 16 samples left / right of its rows (the reference's picture padding).  A seam records the segments by running the reference's own driver with
  * recording leaf functions.  Synchronous.  The WHOLE width x height plane is downloaded in place: nothing else may write the plane while the call runs (the
  * frame-level seams call it from the one thread that owns the picture at that stage). */
-void svt_hip_lpf_plane_host(void *plane, uint32_t stride, uint32_t width, uint32_t height, int is_16bit, int bd, const SvtHipLpfEdge *vert, uint32_t n_vert,
+int svt_hip_lpf_plane_host(void *plane, uint32_t stride, uint32_t width, uint32_t height, int is_16bit, int bd, const SvtHipLpfEdge *vert, uint32_t n_vert,
                             const SvtHipLpfEdge *horz, uint32_t n_horz);
 #define SVT_HIP_LPF_DECL(LEN)                                                                                                              \
     void svt_aom_lpf_horizontal_##LEN##_hip(uint8_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh); \
@@ -839,7 +850,7 @@ typedef struct SvtHipCdefApplyHost {
     const uint8_t *skip;      /* [(fb rows * 8)][(fb cols * 8)] */
     const int32_t *pri_y, *sec_y, *pri_uv, *sec_uv; /* [fb rows * fb cols] */
 } SvtHipCdefApplyHost;
-void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost *params);
+int svt_hip_cdef_apply_host(const SvtHipCdefApplyHost *params);
 /* cdef_seg_search (cdef_process.c:106-345) for ALL filter blocks of a 4:2:0 picture from HOST memory: for each plane the distortion
  * (svt_compute_cdef_dist of the filtered block, NOT yet multiplied by the sub-sampling factor) of every candidate (pri, sec) and every filter block, plus the
  * luma directions / variances (pcs->cdef_dir_data).  Candidates: cdef_ctrls->default_first_pass_fs[] then default_second_pass_fs[] as (fs / 4, fs % 4 with 3 -> 4);
@@ -856,7 +867,7 @@ typedef struct SvtHipCdefSearchHost {
     uint8_t       *dir;                   /* [nfb][64] */
     int32_t       *var;                   /* [nfb][64] */
 } SvtHipCdefSearchHost;
-void svt_hip_cdef_search_host(const SvtHipCdefSearchHost *params);
+int svt_hip_cdef_search_host(const SvtHipCdefSearchHost *params);
 /* Strength selection over the search output: svt_search_one_dual -> svt_search_one_dual_c (aom_dsp_rtcd.h:242,
  * enc_cdef.c:627-683).  mse0 / mse1 = [sb_count][64] luma / chroma distortion tables (device; svt_hip_cdef_frame(mode 1) writes exactly this
  * layout), lev0 / lev1 = device arrays holding the nb_strengths pairs selected so far, entry [nb_strengths] receives the new pair,
@@ -910,7 +921,7 @@ void svt_hip_lr_filter_frame(const SvtHipLrParams *params, void *stream);
 void svt_hip_lr_filter_frame_stripes(const SvtHipLrParams *params, int stripe_begin, int stripe_end, void *stream);
 /* The same from HOST memory (a seam around svt_av1_loop_restoration_filter_frame, rest_process.c:632, calls it per restored plane): every pointer of params is
  * a host pointer, boundary_above / below point at frame column 0 (past the reference's RESTORATION_EXTRA_HORZ margin), dst may equal data; synchronous. */
-void svt_hip_lr_filter_frame_host(const SvtHipLrParams *params);
+int svt_hip_lr_filter_frame_host(const SvtHipLrParams *params);
 /* The per-unit half of the loop-restoration SEARCH of one plane (restoration_seg_search, restoration_pick.c:1448-1527) as one resident device stage:
  * for every restoration unit the SSE of the unrestored unit (search_norestore_seg :1409), the Wiener solve + refinement (search_wiener_seg :1281:
  * svt_av1_compute_stats -> wiener_decompose_sep_sym -> finalize_sym_filter -> compute_score -> finer_tile_search_wiener_seg) and the self-guided

@@ -41,8 +41,8 @@ static double seam_ms_now(void) { struct timespec t_; clock_gettime(CLOCK_MONOTO
 static struct {
     pthread_mutex_t lock;
     int             mode;
-    void (*apply_host)(const SvtHipCdefApplyHost *);
-    void (*search_host)(const SvtHipCdefSearchHost *);
+    int (*apply_host)(const SvtHipCdefApplyHost *);  /* non-zero: the device path is off (svtav1_hip.h, error policy): the picture takes the reference's own function */
+    int (*search_host)(const SvtHipCdefSearchHost *);
     unsigned long long us_stage; /* microseconds inside the two stage calls */
     PictureControlSet *done_pcs[64]; /* pictures whose search the seam has run, and how many of their segments have passed */
     uint64_t           done_num[64];
@@ -134,8 +134,15 @@ static void seam_av1_cdef_frame_body(SequenceControlSet *scs, PictureControlSet 
             for (size_t y = 0; y < vrows[p]; y++) memcpy(before[p] + y * (vcols[p] << is_16bit), (uint8_t *)A.plane[p] + y * ((size_t)A.stride[p] << is_16bit), vcols[p] << is_16bit);
         }
     const double ta_ = seam_ms_now();
-    if (filtered) D.apply_host(&A);
+    const int apply_rc = filtered ? D.apply_host(&A) : 0; /* (the host form writes the planes after its last device operation: a failed call has changed nothing) */
     __atomic_fetch_add(&D.us_stage, (unsigned long long)((seam_ms_now() - ta_) * 1e3), __ATOMIC_RELAXED);
+    if (apply_rc) {
+        pthread_mutex_lock(&D.lock); D.n_declined++; pthread_mutex_unlock(&D.lock);
+        svt_av1_cdef_frame(scs, pcs);
+        for (int p = 0; p < 3; p++) { free(before[p]); free(device[p]); }
+        free(str); free(skip);
+        return;
+    }
     if (verify && filtered) {
         for (int p = 0; p < 3; p++)
             for (size_t y = 0; y < vrows[p]; y++) {
@@ -171,7 +178,7 @@ static void seam_av1_cdef_frame(SequenceControlSet *scs, PictureControlSet *pcs)
 
 /* ---- the search: cdef_seg_search_use0 = the reference's function (defined by the #include below), cdef_seg_search_use1 = what its call site reaches ---- */
 static void cdef_seg_search_use0(PictureControlSet *pcs, SequenceControlSet *scs, uint32_t segment_index);
-static void search_picture(PictureControlSet *pcs, SequenceControlSet *scs) {
+static int search_picture(PictureControlSet *pcs, SequenceControlSet *scs) {
     struct PictureParentControlSet *ppcs     = pcs->ppcs;
     Av1Common                      *cm       = ppcs->av1_cm;
     const bool                      is_16bit = scs->is_16bit_pipeline;
@@ -221,8 +228,9 @@ static void search_picture(PictureControlSet *pcs, SequenceControlSet *scs) {
     A.mse_y = mse_y; A.mse_u = mse_u; A.mse_v = mse_v; A.dir = dir; A.var = var;
     svt_hip_seam_bind(pcs->picture_number);
     const double ts_ = seam_ms_now();
-    if (searched) D.search_host(&A);
+    const int search_rc = searched ? D.search_host(&A) : 0;
     __atomic_fetch_add(&D.us_stage, (unsigned long long)((seam_ms_now() - ts_) * 1e3), __ATOMIC_RELAXED);
+    if (search_rc) { free(var); free(dir); free(mse); free(count); free(skip); return search_rc; }
     for (int32_t fb = 0; fb < nfb; fb++) {
         if (!count[fb]) continue;
         for (int gi = 0; gi < ncand; gi++) {
@@ -238,6 +246,7 @@ static void search_picture(PictureControlSet *pcs, SequenceControlSet *scs) {
     }
     D.n_searched++; D.n_search_fbs += searched;
     free(var); free(dir); free(mse); free(count); free(skip);
+    return 0;
 }
 static void cdef_seg_search_use1_body(PictureControlSet *pcs, SequenceControlSet *scs, uint32_t segment_index) {
     if (!cdef_seam_on() || scs->super_block_size == 128) { cdef_seg_search_use0(pcs, scs, segment_index); return; }
@@ -248,7 +257,10 @@ static void cdef_seg_search_use1_body(PictureControlSet *pcs, SequenceControlSet
         if (!D.done_pcs[i] && free_slot < 0) free_slot = i;
     }
     if (slot < 0) {
-        search_picture(pcs, scs);
+        if (search_picture(pcs, scs)) { /* the device path is off: the reference's own search of every segment of this picture, here and now (the others find it done) */
+            for (uint32_t sg = 0; sg < pcs->cdef_segments_total_count; sg++) cdef_seg_search_use0(pcs, scs, sg);
+            D.n_declined++;
+        }
         static int verify = -1;
         if (verify < 0) { const char *e = getenv("SVT_HIP_CDEF_SEAM_VERIFY"); verify = e && atoi(e); }
         if (verify) { /* (diagnostic) the reference's own search of every segment, compared with what the device stage stored */

@@ -47,11 +47,11 @@ static double seam_ms_now(void) { struct timespec t_; clock_gettime(CLOCK_MONOTO
 static struct {
     pthread_mutex_t lock;
     int             mode;
-    void (*plane_host)(void *, uint32_t, uint32_t, uint32_t, int, int, const SvtHipLpfEdge *, uint32_t, const SvtHipLpfEdge *, uint32_t);
+    int (*plane_host)(void *, uint32_t, uint32_t, uint32_t, int, int, const SvtHipLpfEdge *, uint32_t, const SvtHipLpfEdge *, uint32_t); /* non-zero: the device path is off */
     unsigned long long us_stage; /* microseconds inside svt_hip_lpf_plane_host */
     LpfFn    orig[2][4];     /* [vertical][length index 4, 6, 8, 14] */
     LpfHbdFn orig_hbd[2][4];
-    uint64_t n_pictures, n_segments, n_sb_pictures, n_sb_calls;
+    uint64_t n_pictures, n_segments, n_sb_pictures, n_sb_calls, n_replayed;
 } F = {PTHREAD_MUTEX_INITIALIZER};
 
 typedef struct { SvtHipLpfEdge *e; uint32_t n, cap; } EdgeList;
@@ -94,8 +94,8 @@ static void dlf_seam_stats(void) {
     FILE       *o = f ? fopen(f, "w") : NULL;
     if (!o) return;
     fprintf(o, "ms_in_stage_calls %llu\n", (unsigned long long)(F.us_stage / 1000));
-    fprintf(o, "pictures_filtered %llu\nsegments %llu\npictures_filtered_from_sb_records %llu\nsb_calls_recorded %llu\n", (unsigned long long)F.n_pictures,
-            (unsigned long long)F.n_segments, (unsigned long long)F.n_sb_pictures, (unsigned long long)F.n_sb_calls);
+    fprintf(o, "pictures_filtered %llu\nsegments %llu\npictures_filtered_from_sb_records %llu\nsb_calls_recorded %llu\nplanes_declined %llu\n", (unsigned long long)F.n_pictures,
+            (unsigned long long)F.n_segments, (unsigned long long)F.n_sb_pictures, (unsigned long long)F.n_sb_calls, (unsigned long long)F.n_replayed);
     fclose(o);
 }
 static void dlf_seam_init(void) {
@@ -148,8 +148,20 @@ static uint64_t filter_planes(const PictureControlSet *pcs, const uint32_t *w, E
         for (uint32_t i = 0; i < nv; i++) { const uint32_t r = list[pl][1].e[i].y + 4; rows = r > rows ? r : rows; }
         for (uint32_t i = 0; i < nh; i++) { const uint32_t r = list[pl][0].e[i].y + 8; rows = r > rows ? r : rows; }
         const double t0_ = seam_ms_now();
-        F.plane_host((void *)T.base[pl], (uint32_t)T.stride[pl], ((w[pl] + 7) & ~7u), rows, is_16bit, bd, list[pl][1].e, nv, list[pl][0].e, nh);
+        const int rc = F.plane_host((void *)T.base[pl], (uint32_t)T.stride[pl], ((w[pl] + 7) & ~7u), rows, is_16bit, bd, list[pl][1].e, nv, list[pl][0].e, nh);
         __atomic_fetch_add(&F.us_stage, (unsigned long long)((seam_ms_now() - t0_) * 1e3), __ATOMIC_RELAXED);
+        if (rc) { /* the device path is off (the host form writes the plane last: nothing has changed): the recorded segments through the reference's OWN edge filters --
+                   * the pointers the recorders replaced --, every vertical one in the recorded order, then every horizontal one: the order of the device stage */
+            static const int li_of[15] = {0, 0, 0, 0, 0, 0, 1, 0, 2, 0, 0, 0, 0, 0, 3};
+            for (int v = 1; v >= 0; v--)
+                for (uint32_t i = 0; i < list[pl][v].n; i++) {
+                    const SvtHipLpfEdge *e = &list[pl][v].e[i];
+                    uint8_t *sp = (uint8_t *)T.base[pl] + ((size_t)e->y * T.stride[pl] + e->x) * T.px;
+                    if (is_16bit) F.orig_hbd[v][li_of[e->length]]((uint16_t *)sp, (int32_t)T.stride[pl], &e->blimit, &e->limit, &e->thresh, bd);
+                    else F.orig[v][li_of[e->length]](sp, (int32_t)T.stride[pl], &e->blimit, &e->limit, &e->thresh);
+                }
+            __atomic_fetch_add(&F.n_replayed, 1, __ATOMIC_RELAXED);
+        }
         segs += nv + nh;
     }
     return segs;

@@ -43,7 +43,7 @@ static struct {
     void *(*create_on)(int, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
     int (*enable_stage)(void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
     int (*submit_stage)(void *, int64_t, const uint8_t *, const int64_t *, uint32_t, const SvtHipMeStageParams *, const SvtHipMeResultsHost *);
-    void (*wait)(void *, int);
+    int (*wait)(void *, int); /* non-zero: the device path is off (svtav1_hip.h, error policy) -- the picture is declined and runs the reference's ME */
     void (*invalidate)(void *, int64_t);
     int (*resident)(void *, int64_t);
     void *(*host_alloc)(size_t);
@@ -71,6 +71,7 @@ static struct {
                             * several pictures are in flight on the device at once (session slots), their owners wait outside both locks */
     int             mode; /* -1 unknown, 0 off, 1 on */
     void           *session[SEAM_DEVS];
+    int             session_failed[SEAM_DEVS]; /* the session could not be made (the device path is off): pictures of this device are declined */
     uint32_t        width, height, stride, org_x, org_y, rows;
     SeamPicture     rec[SEAM_RECS];
     uint64_t        sum[SEAM_DEVS][SEAM_RING * 2][2]; /* per device: (picture id, plane checksum) of what is resident */
@@ -333,8 +334,9 @@ static void create_session(int di, const EbPaReferenceObject *pa) {
     G.session[di] = dev_id >= 0 && abi.create_on ? abi.create_on(dev_id, G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, SEAM_SLOTS)
                                                  : abi.create(G.width, G.height, G.stride, G.org_x, G.org_y, G.rows, SEAM_RING, SEAM_MAX_REFS, 768, 768, SEAM_SLOTS); /* four pictures in flight */
     if (!G.session[di] || abi.enable_stage(G.session[di], pa->quarter_downsampled_picture_ptr->org_x, pa->sixteenth_downsampled_picture_ptr->org_x, 4, 768, 768)) {
-        fprintf(stderr, "SVT_HIP_ME_SEAM: cannot create the ME session\n");
-        abort();
+        fprintf(stderr, "SVT_HIP_ME_SEAM: cannot create the ME session (svt_hip_last_error): every picture of this device takes the reference's ME\n");
+        G.session[di] = NULL; /* (a half-made session is left to the process; ensure_session declines from here on) */
+        G.session_failed[di] = 1;
     }
 }
 /* Called by the binding at the end of svt_av1_enc_init (integration/enc_handle_binding.c) with an object of the encoder's PA-reference pool: the sessions of all
@@ -345,7 +347,7 @@ void svt_hip_seam_me_prepare(const void *pa_reference_object) {
     if (!pa->input_padded_pic || !pa->quarter_downsampled_picture_ptr || !pa->sixteenth_downsampled_picture_ptr) return;
     for (int di = 0; di < svt_hip_seam_device_count() && di < SEAM_DEVS; di++) {
         pthread_mutex_lock(&G.dev[di]);
-        if (!G.session[di]) {
+        if (!G.session[di] && !G.session_failed[di]) {
             if (svt_hip_seam_device_count() > 1) svt_hip_seam_bind((unsigned long long)di); /* (binds this thread to device di: picture numbers di, di + N, ... map to it) */
             create_session(di, pa);
         }
@@ -368,7 +370,8 @@ void svt_hip_seam_me_unregister_buffer(void *buffer) { /* before the pool that o
     if (unreg) unreg(buffer);
 }
 static int ensure_session(int di, PictureParentControlSet *pcs, const EbPictureBufferDesc *src) {
-    if (!G.session[di]) create_session(di, (const EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr);
+    if (!G.session[di] && !G.session_failed[di]) create_session(di, (const EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr);
+    if (!G.session[di]) return decline("no ME session (the device path is off)");
     if (src->width != G.width || src->height != G.height || src->stride_y != G.stride || src->org_x != G.org_x || src->org_y != G.org_y)
         return decline("picture geometry changed");
     return 0;
@@ -427,7 +430,7 @@ static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *
     pthread_mutex_unlock(&G.dev[di]);
     for (int k = 0; k < n_pend; k++) abi.wait(ses, pend[k]); /* the reference uploads (outside the locks; complete before the stage below is) */
     if (rc) return -1;
-    abi.wait(ses, slot); /* outside the locks: other pictures enqueue their stages meanwhile */
+    if (abi.wait(ses, slot)) { decline("the device path is off (svt_hip_last_error)"); return -1; } /* outside the locks: other pictures enqueue their stages meanwhile */
     return 0;
 }
 
@@ -597,7 +600,7 @@ static int run_tf_pair(SeamTfPair *T, PictureParentControlSet *pcs, MeContext *c
     pthread_mutex_unlock(&G.dev[di]);
     for (int k = 0; k < n_pend; k++) abi.wait(ses, pend[k]);
     if (rc) return -1;
-    abi.wait(ses, slot);
+    if (abi.wait(ses, slot)) { decline("the device path is off (svt_hip_last_error)"); return -1; }
     return 0;
 }
 

@@ -36,7 +36,7 @@ static struct {
     pthread_mutex_t lock;
     int             mode; /* 0 off, 1 on */
     int (*search_host)(const SvtHipLrSearchParams *, const SvtHipLrPrevUnit *, SvtHipLrSearchUnit *);
-    void (*filter_host)(const SvtHipLrParams *);
+    int (*filter_host)(const SvtHipLrParams *); /* (non-zero from either: the device path is off -- svtav1_hip.h, error policy) */
     unsigned long long us_stage; /* microseconds inside the stage calls */
     PictureControlSet *done_pcs[64]; /* pictures whose search has been done by the seam (keyed by pcs + picture number) ... */
     uint64_t           done_num[64];
@@ -70,7 +70,8 @@ static int lr_seam_on(void) {
 }
 
 /* one plane: restoration_seg_search's body for `plane` (restoration_pick.c:1470-1525) with the three unit loops on the device */
-static void search_plane(const Yv12BufferConfig *org_fts, const Yv12BufferConfig *src, PictureControlSet *pcs, int plane) {
+/* -> 0, or the stage's return code: nothing of the picture's search state has been touched then */
+static int search_plane(const Yv12BufferConfig *org_fts, const Yv12BufferConfig *src, PictureControlSet *pcs, int plane, SvtHipLrSearchUnit **out_p, SvtHipLrSearchParams *P_out) {
     Av1Common *const cm     = pcs->ppcs->av1_cm;
     const int        is_uv  = plane > 0, highbd = cm->use_highbitdepth;
     const int        w = src->crop_widths[is_uv], h = src->crop_heights[is_uv];
@@ -121,12 +122,22 @@ static void search_plane(const Yv12BufferConfig *org_fts, const Yv12BufferConfig
     const double ts_ = seam_ms_now();
     const int rc = L.search_host(&P, prev, out);
     __atomic_fetch_add(&L.us_stage, (unsigned long long)((seam_ms_now() - ts_) * 1e3), __ATOMIC_RELAXED);
-    if (rc) {
-        fprintf(stderr, "SVT_HIP_LR_SEAM: svt_hip_lr_search_plane_host returned %d (picture %llu plane %d %ux%u unit %u win %u bd %u wn %d sg %d ep %u..%u/%u)\n", rc,
+    free(prev);
+    if (rc) { /* the device path is off (or the stage refused): the caller runs the reference's search for the whole picture */
+        fprintf(stderr, "SVT_HIP_LR_SEAM: svt_hip_lr_search_plane_host returned %d (picture %llu plane %d %ux%u unit %u win %u bd %u wn %d sg %d ep %u..%u/%u): the reference's search takes the picture\n", rc,
                 (unsigned long long)pcs->picture_number, plane, P.width, P.height, P.unit_size, P.wiener_win, P.bit_depth, P.wn_enabled, P.sg_enabled, P.sg_start_ep, P.sg_end_ep,
                 P.sg_ep_inc);
-        abort();
+        free(out);
+        return rc;
     }
+    *out_p = out; *P_out = P;
+    return 0;
+}
+/* the results of one plane into the picture's search state (restoration_seg_search's stores) */
+static void commit_plane(PictureControlSet *pcs, int plane, const SvtHipLrSearchParams *Pp, SvtHipLrSearchUnit *out) {
+    Av1Common *const cm = pcs->ppcs->av1_cm;
+    const SvtHipLrSearchParams P = *Pp;
+    const int n = pcs->rst_info[plane].units_per_tile;
     RestUnitSearchInfo *rusi = pcs->rusi_picture[plane];
     for (int u = 0; u < n; u++) {
         rusi[u].sse[RESTORE_NONE] = out[u].sse[0];
@@ -141,7 +152,7 @@ static void search_plane(const Yv12BufferConfig *org_fts, const Yv12BufferConfig
         }
     }
     L.n_planes++; L.n_units += (uint64_t)n;
-    free(prev); free(out);
+    free(out);
 }
 
 static void seam_restoration_seg_search_body(int32_t *rst_tmpbuf, Yv12BufferConfig *org_fts, const Yv12BufferConfig *src, Yv12BufferConfig *trial_frame_rst,
@@ -157,8 +168,18 @@ static void seam_restoration_seg_search_body(int32_t *rst_tmpbuf, Yv12BufferConf
         Av1Common *const cm        = pcs->ppcs->av1_cm;
         const int32_t    plane_end = ((cm->wn_filter_ctrls.enabled && cm->wn_filter_ctrls.use_chroma) || (cm->sg_filter_ctrls.enabled && cm->sg_filter_ctrls.use_chroma))
                ? AOM_PLANE_V : AOM_PLANE_Y; /* :1462-1466 */
-        for (int32_t plane = AOM_PLANE_Y; plane <= plane_end; ++plane) search_plane(org_fts, src, pcs, plane);
-        L.n_pictures++;
+        SvtHipLrSearchUnit  *outs[3] = {NULL, NULL, NULL};
+        SvtHipLrSearchParams Ps[3];
+        int                  rc = 0;
+        for (int32_t plane = AOM_PLANE_Y; plane <= plane_end && !rc; ++plane) rc = search_plane(org_fts, src, pcs, plane, &outs[plane], &Ps[plane]);
+        if (!rc) {
+            for (int32_t plane = AOM_PLANE_Y; plane <= plane_end; ++plane) commit_plane(pcs, plane, &Ps[plane], outs[plane]);
+            L.n_pictures++;
+        } else { /* nothing committed: every segment of the picture through the reference's own function, here and now (the other segments find it done) */
+            for (int32_t plane = AOM_PLANE_Y; plane <= plane_end; ++plane) free(outs[plane]);
+            for (uint32_t sg = 0; sg < pcs->rest_segments_total_count; sg++) restoration_seg_search(rst_tmpbuf, org_fts, src, trial_frame_rst, pcs, sg);
+            L.n_declined++;
+        }
         if (free_slot < 0) { fprintf(stderr, "SVT_HIP_LR_SEAM: more than 64 pictures in the restoration stage\n"); abort(); }
         slot = free_slot;
         L.done_pcs[slot] = pcs; L.done_num[slot] = pcs->picture_number; L.seen[slot] = 0;
@@ -207,9 +228,18 @@ static void seam_loop_restoration_filter_frame_body(int32_t *rst_tmpbuf, Yv12Buf
         P.units = units;
         svt_hip_seam_bind(cm->child_pcs->picture_number);
         const double tf_ = seam_ms_now();
-        L.filter_host(&P);
+        const int frc = L.filter_host(&P); /* (in place: the plane is written after the call's last device operation -- a failed call has changed nothing) */
         __atomic_fetch_add(&L.us_stage, (unsigned long long)((seam_ms_now() - tf_) * 1e3), __ATOMIC_RELAXED);
         free(units);
+        if (frc) { /* the device path is off: the reference's frame function for this plane and the ones after it -- it skips planes of type RESTORE_NONE, which is what
+                    * the planes already filtered above are told to be for the duration of the call */
+            RestorationType keep[3];
+            for (int32_t q = 0; q < 3; q++) { keep[q] = cm->child_pcs->rst_info[q].frame_restoration_type; if (q < plane) cm->child_pcs->rst_info[q].frame_restoration_type = RESTORE_NONE; }
+            svt_av1_loop_restoration_filter_frame(rst_tmpbuf, frame, cm, optimized_lr);
+            for (int32_t q = 0; q < 3; q++) cm->child_pcs->rst_info[q].frame_restoration_type = keep[q];
+            pthread_mutex_lock(&L.lock); L.n_declined++; pthread_mutex_unlock(&L.lock);
+            return;
+        }
         pthread_mutex_lock(&L.lock);
         L.n_filtered_planes++;
         pthread_mutex_unlock(&L.lock);

@@ -302,6 +302,7 @@ static void tpl_mc_flow_dispenser_use2_body(TPL_DISP_ARGS) {
         return;
     }
     const double t0 = now_ms();
+    int          tpl_decline_rc = 0;
     const EbPictureBufferDesc *inp = pcs->enhanced_pic;
     MotionEstimationData      *med = pcs->pa_me_data;
     const int32_t q_index = tpl_q_index(scs, pcs);
@@ -367,9 +368,9 @@ static void tpl_mc_flow_dispenser_use2_body(TPL_DISP_ARGS) {
         free(wr);
     } else if (TS.recon && TS.fused_host) { /* both halves in one device call: one upload of every picture buffer, one synchronisation */
         const int rc = tpl_recon_picture(enc_ctx, scs, pcs, frame_idx, &P, st, cells, &H, tot, mvs, cand);
-        if (rc) { fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: svt_hip_tpl_stage_host refused the picture (%d)\n", rc); abort(); }
+        if (rc) { tpl_decline_rc = rc; goto decline; }
         fused_done = 1;
-    } else if (TS.stage_host(&P, &H, tot, mvs, cand, st)) { fprintf(stderr, "SVT_HIP_TPL_SEAM: svt_hip_tpl_src_stage_host refused the parameters\n"); abort(); }
+    } else if ((tpl_decline_rc = TS.stage_host(&P, &H, tot, mvs, cand, st)) != 0) goto decline;
     /* into the buffer the reference's own "already computed" branch reads (:969-977); a sequence without stored statistics (tpl_lad_mg == 0) has none: lend one */
     TplSrcStats *own = med->tpl_src_stats_buffer, *buf = own;
     const uint32_t ref_cells = ((pcs->aligned_width + 15) >> 4) * ((inp->height + 15) >> 4 > rows16 ? (inp->height + 15) >> 4 : rows16);
@@ -387,7 +388,11 @@ static void tpl_mc_flow_dispenser_use2_body(TPL_DISP_ARGS) {
     int on_device = 0;
     if (TS.recon) { /* the reconstruction half too: the per-SB function of this picture becomes a no-op */
         const int rc = fused_done ? 0 : tpl_recon_picture(enc_ctx, scs, pcs, frame_idx, &P, st, cells, NULL, NULL, NULL, NULL);
-        if (rc) { fprintf(stderr, "SVT_HIP_TPL_RECON_SEAM: svt_hip_tpl_recon_stage_host refused the picture (%d)\n", rc); abort(); }
+        if (rc) { /* (the statistics already copied into `buf` are the values the reference's own first half writes there again) */
+            if (!own) free(buf);
+            tpl_decline_rc = rc;
+            goto decline;
+        }
         tpl_recon_mark(pcs, 1);
         on_device = 1;
     }
@@ -403,6 +408,21 @@ static void tpl_mc_flow_dispenser_use2_body(TPL_DISP_ARGS) {
     if (stored) TS.n_reused++;
     else { TS.n_pictures++; TS.n_blocks += nb; TS.n_newmv += nn; TS.ms_stage += t1 - t0; }
     pthread_mutex_unlock(&TS.lock);
+    return;
+decline:
+    /* A stage call returned non-zero -- the device path is off (svtav1_hip.h, error policy), a block gave up waiting for a neighbour (-4), or the parameters were
+     * refused: this picture takes the reference's dispenser, both halves, as if the seam were off.  Nothing of the picture's state has been changed; what a device
+     * holds of the picture's TPL reconstruction buffer is stale from here on (the reference rewrites it on the host). */
+    fprintf(stderr, "SVT_HIP_TPL_SEAM: a stage call returned %d for picture %llu: the reference's dispenser takes it\n", tpl_decline_rc, (unsigned long long)pcs->picture_number);
+    free(tot); free(mvs); free(cand); free(st);
+    if (TS.recon && enc_ctx->mc_flow_rec_picture_buffer[frame_idx]) {
+        tpl_rec_forget(enc_ctx->mc_flow_rec_picture_buffer[frame_idx]->buffer_y);
+        if (TS.plane_drop) TS.plane_drop(enc_ctx->mc_flow_rec_picture_buffer[frame_idx]->buffer_y);
+    }
+    pthread_mutex_lock(&TS.lock);
+    TS.n_declined++;
+    pthread_mutex_unlock(&TS.lock);
+    tpl_mc_flow_dispenser_use1(TPL_DISP_PASS);
 }
 static void tpl_mc_flow_dispenser_use2(TPL_DISP_ARGS) {
     SEAM_CPU_BEGIN();

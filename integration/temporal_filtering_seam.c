@@ -105,7 +105,7 @@ int svt_hip_seam_bind(unsigned long long picture_number); /* integration/enc_han
 static struct {
     pthread_mutex_t lock;
     int             mode; /* -1 unknown */
-    void (*search_host)(const SvtHipTfSubpelParams *, const void *, size_t, const void *, size_t, const SvtHipTfSubpelDesc *, uint32_t, SvtHipTfSubpelResult *);
+    int (*search_host)(const SvtHipTfSubpelParams *, const void *, size_t, const void *, size_t, const SvtHipTfSubpelDesc *, uint32_t, SvtHipTfSubpelResult *); /* non-zero: the device path is off */
     SubpelBatch rec[SP_RECS];
     uint64_t    n_batches, n_blocks, n_served, n_fallback, stamp;
 } SPS = {PTHREAD_MUTEX_INITIALIZER, -1};
@@ -192,7 +192,10 @@ static int build_batch(SubpelBatch *B, PictureParentControlSet *pcs, MeContext *
     P.mi_rows = (uint32_t)pcs->av1_cm->mi_rows; P.mi_cols = (uint32_t)pcs->av1_cm->mi_cols;
     P.ref_org_x = ref->org_x; P.ref_org_y = ref->org_y; P.ref_stride = ref->stride_y;
     svt_hip_seam_bind(pcs->picture_number);
-    SPS.search_host(&P, src_buf, cen->luma_size, ref->buffer_y, ref->luma_size, B->descs, n, B->res);
+    if (SPS.search_host(&P, src_buf, cen->luma_size, ref->buffer_y, ref->luma_size, B->descs, n, B->res)) { /* no batch: every search of the pair takes the reference's function */
+        free(best_mv); free(hme_sc); free(hme_sad);
+        return 0;
+    }
     B->n_sb = n_sb; B->per_sb = per_sb;
     SPS.n_batches++; SPS.n_blocks += n;
     free(best_mv); free(hme_sc); free(hme_sad);

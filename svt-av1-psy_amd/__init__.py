@@ -43,6 +43,10 @@ PROTOTYPES = {
     "svt_hip_host_register": (C.c_int, [vp, C.c_size_t]),
     "svt_hip_host_unregister": (C.c_int, [vp]),
     "svt_hip_device_count": (C.c_int, []),
+    "svt_hip_last_error": (C.c_char_p, []),
+    "svt_hip_failed": (C.c_int, []),
+    "svt_hip_rtcd_unhook": (None, []),
+    "svt_hip_debug_inject_failure": (C.c_int, []),
     "svt_hip_physical_device_count": (C.c_int, []),
     "svt_hip_physical_device": (C.c_int, [C.c_int]),
     "svt_hip_set_virtual_devices": (C.c_int, [C.c_int]),
@@ -105,7 +109,7 @@ PROTOTYPES = {
     "svt_hip_me_session_create_on": (vp, [C.c_int] + [C.c_uint32] * 11),
     "svt_hip_me_session_destroy": (None, [vp]),
     "svt_hip_me_session_submit": (C.c_int, [vp, C.c_int64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
-    "svt_hip_me_session_wait": (None, [vp, C.c_int]),
+    "svt_hip_me_session_wait": (C.c_int, [vp, C.c_int]),
     "svt_hip_me_session_invalidate": (None, [vp, C.c_int64]),
     "svt_hip_me_session_resident": (C.c_int, [vp, C.c_int64]),
     "svt_hip_me_session_enable_stage": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -133,16 +137,16 @@ PROTOTYPES = {
     "svt_hip_tf_subpel_search_batch": (None, [vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svt_hip_tf_inter_pred_batch": (None, [vp, vp, vp, C.c_uint32, C.c_int, vp]),
     "svt_hip_tf_inter_pred_list": (None, [vp, vp, vp, C.c_uint32, vp, C.c_int, vp]),
-    "svt_hip_tf_subpel_search_host": (None, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, vp]),
+    "svt_hip_tf_subpel_search_host": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, vp]),
     "svt_hip_tf_picture_host": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp]),
     "svt_hip_tf_picture_workspace": (C.c_size_t, [vp, C.c_uint32]),
     "svt_hip_tf_picture": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp]),
     "svt_hip_tf_filter_frame_workspace": (C.c_size_t, [vp, C.c_uint32, C.c_uint32]),
     "svt_hip_tf_filter_frame_chunked": (None, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, vp]),
-    "svt_hip_lr_filter_frame_host": (None, [vp]),
-    "svt_hip_cdef_apply_host": (None, [vp]),
-    "svt_hip_lpf_plane_host": (None, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, C.c_uint32, vp, C.c_uint32]),
-    "svt_hip_cdef_search_host": (None, [vp]),
+    "svt_hip_lr_filter_frame_host": (C.c_int, [vp]),
+    "svt_hip_cdef_apply_host": (C.c_int, [vp]),
+    "svt_hip_lpf_plane_host": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, C.c_uint32, vp, C.c_uint32]),
+    "svt_hip_cdef_search_host": (C.c_int, [vp]),
     "svt_hip_lr_search_workspace": (C.c_size_t, [vp]),
     "svt_hip_lr_search_plane": (C.c_int, [vp, vp, vp, vp, vp]),
     "svt_hip_lr_search_plane_host": (C.c_int, [vp, vp, vp]),

@@ -775,7 +775,8 @@ void svt_hip_cdef_frame_rows(int mode, const SvtHipCdefParams* params, int fb_ro
 // Host-pointer form of the frame apply for all planes of a 4:2:0 picture (what a seam around svt_av1_cdef_frame, cdef_process.c:458, calls): uploads the
 // planes, the 8x8 skip map and the per-filter-block strengths, filters luma (which produces the directions / variances) then chroma out of place on the
 // device, downloads the filtered planes IN PLACE.  Every pointer is a host pointer.
-void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost* a) {
+int svt_hip_cdef_apply_host(const SvtHipCdefApplyHost* a) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     const size_t px = a->is_16bit ? 2 : 1;
     const uint32_t nhfb = (a->width + 63) / 64, nvfb = (a->height + 63) / 64, nfb = nhfb * nvfb;
@@ -819,11 +820,14 @@ void svt_hip_cdef_apply_host(const SvtHipCdefApplyHost* a) {
     }
     for (int p = 0; p < a->num_planes; p++) c.down2d_later(a->plane[p], (size_t)a->stride[p] * px, d_out[p], pitch[p], wid[p] * px, rows[p]);
     c.finish(); // (one synchronisation for the three planes)
+    return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 // Host-pointer form of the strength SEARCH for the three planes of a 4:2:0 picture (what a seam around cdef_seg_search, cdef_process.c:443, calls once per
 // picture): the distortion of every candidate strength for every filter block, luma directions / variances included.  Every pointer is a host pointer.
-void svt_hip_cdef_search_host(const SvtHipCdefSearchHost* a) {
+int svt_hip_cdef_search_host(const SvtHipCdefSearchHost* a) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     const size_t   px = a->is_16bit ? 2 : 1;
     const uint32_t nhfb = (a->width + 63) / 64, nvfb = (a->height + 63) / 64, nfb = nhfb * nvfb;
@@ -880,6 +884,8 @@ void svt_hip_cdef_search_host(const SvtHipCdefSearchHost* a) {
     c.down_later(a->dir, d_dir, (size_t)nfb * 64);
     c.down_later(a->var, d_var, (size_t)nfb * 64 * 4);
     c.finish(); // (one synchronisation for the five arrays)
+    return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 uint8_t svt_aom_cdef_find_dir_hip(const uint16_t* img, int32_t stride, int32_t* var, int32_t coeff_shift) {

@@ -192,10 +192,11 @@ void svt_hip_lpf_edges_batch(void* plane, uint32_t stride, int is_16bit, int bd,
 // Host-pointer form for one plane of a picture (what a seam around svt_av1_loop_filter_frame, dlf_process.c:122, calls after recording the edge segments the
 // reference's own driver would filter): uploads the plane with a 16-sample margin either side (the reference's picture padding), runs all vertical-edge
 // segments, then all horizontal-edge segments, downloads the plane in place.  x / y of a segment = its first q0 sample inside the plane.
-void svt_hip_lpf_plane_host(void* plane, uint32_t stride, uint32_t width, uint32_t height, int is_16bit, int bd, const SvtHipLpfEdge* vert, uint32_t n_vert,
+int svt_hip_lpf_plane_host(void* plane, uint32_t stride, uint32_t width, uint32_t height, int is_16bit, int bd, const SvtHipLpfEdge* vert, uint32_t n_vert,
                             const SvtHipLpfEdge* horz, uint32_t n_horz) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
-    if (n_vert + n_horz == 0) return;
+    if (n_vert + n_horz == 0) return 0;
     const size_t px = is_16bit ? 2 : 1, M = 16, pitch = svthip::align_up((width + 2 * M) * px, 16), nb = (size_t)(n_vert + n_horz) * sizeof(SvtHipLpfEdge);
     svthip::HostCallLease lease; // (a pooled arena: see svt_hip_common.h)
     svthip::HostCall& c = *lease;
@@ -211,6 +212,8 @@ void svt_hip_lpf_plane_host(void* plane, uint32_t stride, uint32_t width, uint32
     if (n_vert) svt_hip_lpf_edges_batch(d, (uint32_t)(pitch / px), is_16bit, bd, de, n_vert, c.stream);
     if (n_horz) svt_hip_lpf_edges_batch(d, (uint32_t)(pitch / px), is_16bit, bd, de + n_vert, n_horz, c.stream);
     c.down2d(plane, (size_t)stride * px, d + M * px, pitch, width * px, height);
+    return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 #define LPF_PAIR(LEN)                                                                                                                                        \

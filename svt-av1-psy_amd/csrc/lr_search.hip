@@ -858,6 +858,7 @@ extern "C" {
 size_t svt_hip_lr_search_workspace(const SvtHipLrSearchParams* params) { return carve(*params, nullptr, nullptr); }
 
 int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPrevUnit* prev, SvtHipLrSearchUnit* units, void* workspace, void* stream) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     const SvtHipLrSearchParams& P = *params;
     if (!P.width || !P.height || !P.unit_size || (P.wn_enabled && P.wiener_win != 7 && P.wiener_win != 5 && P.wiener_win != 3) || (P.sg_enabled && P.sg_end_ep > 16)) return -1;
@@ -960,11 +961,13 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     }
     if (sg_on) HIP_CHECK(hipStreamWaitEvent(st, ev_sg0, 0));
     return rc_wn;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 // Host-pointer form (what a seam in rest_process.c calls): uploads the plane with the 3 (+1 right) sample border the filters read and the source plane
 // through the calling thread's pinned arena, runs the stage on that thread's stream, downloads the per-unit results.
 int svt_hip_lr_search_plane_host(const SvtHipLrSearchParams* params, const SvtHipLrPrevUnit* prev, SvtHipLrSearchUnit* units) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     SvtHipLrSearchParams P = *params;
     const size_t px = P.highbd ? 2 : 1, w = P.width, h = P.height;
@@ -991,6 +994,7 @@ int svt_hip_lr_search_plane_host(const SvtHipLrSearchParams* params, const SvtHi
     if (rc) return rc;
     c.down(units, d_units, (size_t)n * sizeof(SvtHipLrSearchUnit));
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 } // extern "C"

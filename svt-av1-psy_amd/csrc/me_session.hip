@@ -84,21 +84,28 @@ inline FmtLayout fmt_layout(uint32_t sbs, uint32_t n_pus, uint32_t max_refs, uin
 extern "C" {
 
 void* svt_hip_host_alloc(size_t bytes) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     void* p = nullptr;
     HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
     return p;
+    SVT_HIP_ENTRY_CATCH(nullptr)
 }
-void svt_hip_host_free(void* p) { if (p) HIP_CHECK(hipHostFree(p)); }
+void svt_hip_host_free(void* p) {
+    SVT_HIP_ENTRY_TRY if (p) HIP_CHECK(hipHostFree(p));     SVT_HIP_ENTRY_CATCH((void)0)
+}
 
 void* svt_hip_me_session_create(uint32_t width, uint32_t height, uint32_t stride, uint32_t org_x, uint32_t org_y, uint32_t rows, uint32_t ring_planes,
                                 uint32_t max_refs, uint32_t max_area_width, uint32_t max_area_height, uint32_t n_slots) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     return svt_hip_me_session_create_on(svthip::current_device(), width, height, stride, org_x, org_y, rows, ring_planes, max_refs, max_area_width, max_area_height,
                                         n_slots);
+    SVT_HIP_ENTRY_CATCH(nullptr)
 }
 void* svt_hip_me_session_create_on(int device, uint32_t width, uint32_t height, uint32_t stride, uint32_t org_x, uint32_t org_y, uint32_t rows, uint32_t ring_planes,
                                    uint32_t max_refs, uint32_t max_area_width, uint32_t max_area_height, uint32_t n_slots) {
+    SVT_HIP_ENTRY_TRY
     if (device < 0 || device >= svt_hip_device_count() || device >= svthip::MAX_DEVICES) return nullptr; // (the per-device arenas are MAX_DEVICES wide)
     svthip::DeviceGuard guard(device);
     Session* s = new Session;
@@ -129,9 +136,11 @@ void* svt_hip_me_session_create_on(int device, uint32_t width, uint32_t height, 
         HIP_CHECK(hipMalloc((void**)&sl.fmt, fmt_layout(s->sbs, SVT_HIP_ME_NUM_BLOCKS, s->max_refs, s->max_cand).bytes));
     }
     return s;
+    SVT_HIP_ENTRY_CATCH(nullptr)
 }
 
 void svt_hip_me_session_destroy(void* session) {
+    SVT_HIP_ENTRY_TRY
     Session* s = (Session*)session;
     if (!s) return;
     svthip::DeviceGuard guard(s->device);
@@ -152,6 +161,7 @@ void svt_hip_me_session_destroy(void* session) {
     for (auto& e : s->uploaded) HIP_CHECK(hipEventDestroy(e));
     HIP_CHECK(hipFree(s->planes));
     delete s;
+    SVT_HIP_ENTRY_CATCH((void)0)
 }
 
 static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
@@ -391,7 +401,9 @@ static int me_session_submit(void* session, int64_t pic_id, const uint8_t* plane
 
 int svt_hip_me_session_submit(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
                               uint32_t area_h, int sub_sad, uint32_t* best_sad_host, uint32_t* best_mv_host) {
+    SVT_HIP_ENTRY_TRY
     return me_session_submit(session, pic_id, plane_host, ref_ids, n_refs, area_w, area_h, sub_sad, best_sad_host, best_mv_host, nullptr, nullptr);
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 int svt_hip_me_session_submit_results(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
                                       uint32_t area_h, int sub_sad, const SvtHipMeResultsParams* params, const SvtHipMeResultsHost* out) {
@@ -400,6 +412,7 @@ int svt_hip_me_session_submit_results(void* session, int64_t pic_id, const uint8
 
 int svt_hip_me_session_enable_stage(void* session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,
                                     uint32_t max_me_area_height) {
+    SVT_HIP_ENTRY_TRY
     Session* s = (Session*)session;
     svthip::DeviceGuard guard(s->device);
     if (s->stage || !max_regions || s->max_refs > 8) return -1;
@@ -431,36 +444,46 @@ int svt_hip_me_session_enable_stage(void* session, uint32_t quarter_pad, uint32_
     for (auto& sl : s->slots) HIP_CHECK(hipMalloc((void**)&sl.hme, per_slot));
     s->stage = true;
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 int svt_hip_me_session_submit_stage(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs,
                                     const SvtHipMeStageParams* stage, const SvtHipMeResultsHost* out) {
+    SVT_HIP_ENTRY_TRY
     if (!stage) return -5;
     const bool fmt = n_refs > 0 && out && out->total_me_candidate_index;
     return me_session_submit(session, pic_id, plane_host, ref_ids, n_refs, 0, 0, 0, out ? out->best_sad : nullptr, out ? out->best_mv : nullptr,
                              fmt ? &stage->results : nullptr, out, stage);
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 // Forget a resident picture (its host content changed, e.g. after in-place temporal filtering): the next submission that names it as the source uploads it again.
 void svt_hip_me_session_invalidate(void* session, int64_t pic_id) {
+    SVT_HIP_ENTRY_TRY
     Session* s = (Session*)session;
     if (!s) return;
     for (uint32_t r = 0; r < s->ring; r++)
         if (s->ids[r] == pic_id) s->ids[r] = -1;
+    SVT_HIP_ENTRY_CATCH((void)0)
 }
 // 1 when the picture is resident in the ring (usable as a reference), else 0
 int svt_hip_me_session_resident(void* session, int64_t pic_id) {
+    SVT_HIP_ENTRY_TRY
     Session* s = (Session*)session;
     if (!s) return 0;
     for (uint32_t r = 0; r < s->ring; r++)
         if (s->ids[r] == pic_id) return 1;
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
-void svt_hip_me_session_wait(void* session, int slot) {
+int svt_hip_me_session_wait(void* session, int slot) {
+    SVT_HIP_ENTRY_TRY
     Session* s = (Session*)session;
     svthip::DeviceGuard guard(s->device);
-    if (slot < 0 || slot >= (int)s->slots.size()) return;
+    if (slot < 0 || slot >= (int)s->slots.size()) return 0;
     HIP_CHECK(hipEventSynchronize(s->slots[slot].done));
+    return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 } // extern "C"

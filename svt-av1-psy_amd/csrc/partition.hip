@@ -68,7 +68,7 @@ void arena_begin(Peer& p, size_t need) {
 }
 void* arena_take(Peer& p, size_t bytes) {
     const size_t off = svthip::align_up(p.used, 256);
-    if (off + bytes > p.cap) { fprintf(stderr, "libsvtav1_hip: frame-partition arena overflow\n"); abort(); }
+    if (off + bytes > p.cap) svthip::device_fail(-3, "frame-partition arena overflow", __FILE__, __LINE__);
     p.used = off + bytes;
     return p.arena + off;
 }
@@ -141,6 +141,7 @@ void lr_frame_dispatch(const SvtHipLrParams* P, hipStream_t st) {
 extern "C" {
 
 int svt_hip_set_frame_partition(const int* devices, int n) {
+    SVT_HIP_ENTRY_TRY
     using namespace svthip;
     if (n < 0 || n > MAX_DEVICES || (n > 0 && !devices)) return -1;
     const int have = svt_hip_device_count();
@@ -152,10 +153,12 @@ int svt_hip_set_frame_partition(const int* devices, int n) {
     g_strips_gen.fetch_add(1);
     g_strips_on.store(n > 1, std::memory_order_release);
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 unsigned long long svt_hip_frame_partition_host_calls(void) { return svthip::g_strips_calls.load(); }
 
 void* svt_hip_frame_partition_create(const int* devices, int n) {
+    SVT_HIP_ENTRY_TRY
     if (!devices || n < 1 || n > svthip::MAX_DEVICES) return nullptr;
     const int have = svt_hip_device_count();
     for (int k = 0; k < n; k++) {
@@ -184,8 +187,10 @@ void* svt_hip_frame_partition_create(const int* devices, int n) {
         } else (void)hipGetLastError();
     }
     return P;
+    SVT_HIP_ENTRY_CATCH(nullptr)
 }
 void svt_hip_frame_partition_destroy(void* part) {
+    SVT_HIP_ENTRY_TRY
     Partition* P = (Partition*)part;
     if (!P) return;
     for (int k = 0; k < P->n; k++) {
@@ -197,6 +202,7 @@ void svt_hip_frame_partition_destroy(void* part) {
         (void)hipStreamDestroy(P->peer[k].stream);
     }
     delete P;
+    SVT_HIP_ENTRY_CATCH((void)0)
 }
 void svt_hip_frame_partition_set_jitter(void* part, uint32_t seed, uint32_t max_us) {
     Partition* P = (Partition*)part;
@@ -215,6 +221,7 @@ void svt_hip_frame_partition_stats(const void* part, uint64_t* calls, uint64_t* 
 // ---- open-loop ME: items (SB x reference descriptors) [0, n) in contiguous strips; the caller orders them SB row after SB row, so a strip is a band of SB rows --------
 int svt_hip_frame_partition_me(void* part, const uint8_t* src_base, size_t src_bytes, const uint8_t* ref_base, size_t ref_bytes, const SvtHipMeSearchDesc* descs,
                                uint32_t n, uint32_t max_w, uint32_t max_h, int sub_sad, uint32_t* best_sad, uint32_t* best_mv, void* workspace, void* stream) {
+    SVT_HIP_ENTRY_TRY
     Partition* P = (Partition*)part;
     if (!P) return -1;
     hipStream_t home = (hipStream_t)stream;
@@ -254,10 +261,12 @@ int svt_hip_frame_partition_me(void* part, const uint8_t* src_base, size_t src_b
                                         best_mv + (size_t)b0 * SVT_HIP_ME_NUM_BLOCKS, workspace, home);
     close_call(*P, home);
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 // ---- CDEF (search, apply, apply with the search's directions): filter-block rows in strips ------------------------------------------------------------------------------
 int svt_hip_frame_partition_cdef(void* part, int mode, const SvtHipCdefParams* params, void* stream) {
+    SVT_HIP_ENTRY_TRY
     Partition* P = (Partition*)part;
     if (!P || !params) return -1;
     const SvtHipCdefParams& C = *params;
@@ -314,10 +323,12 @@ int svt_hip_frame_partition_cdef(void* part, int mode, const SvtHipCdefParams* p
     if (e0 > b0) svt_hip_cdef_frame_rows(mode, params, b0, e0, home);
     close_call(*P, home);
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 // ---- loop restoration filter: 64-row stripes (offset by 8 rows, restoration.c:1082-1098) in strips ------------------------------------------------------------------
 int svt_hip_frame_partition_lr(void* part, const SvtHipLrParams* params, void* stream) {
+    SVT_HIP_ENTRY_TRY
     Partition* P = (Partition*)part;
     if (!P || !params) return -1;
     const SvtHipLrParams& L = *params;
@@ -360,6 +371,7 @@ int svt_hip_frame_partition_lr(void* part, const SvtHipLrParams* params, void* s
     if (e0 > b0) svt_hip_lr_filter_frame_stripes(params, b0, e0, home);
     close_call(*P, home);
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 } // extern "C"

@@ -206,7 +206,8 @@ void svt_hip_lr_filter_frame_stripes(const SvtHipLrParams* params, int stripe_be
 
 // Host-pointer form of the frame filter (what a seam around svt_av1_loop_restoration_filter_frame, rest_process.c:632, calls per restored plane): data, the two
 // boundary-line buffers (pointing at frame column 0, i.e. past the reference's RESTORATION_EXTRA_HORZ margin), units and dst are host pointers; dst may be data.
-void svt_hip_lr_filter_frame_host(const SvtHipLrParams* params) {
+int svt_hip_lr_filter_frame_host(const SvtHipLrParams* params) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     SvtHipLrParams P = *params;
     const size_t px = P.highbd ? 2 : 1, w = P.width, h = P.height;
@@ -232,6 +233,8 @@ void svt_hip_lr_filter_frame_host(const SvtHipLrParams* params) {
     P.stride = P.dst_stride = P.boundary_stride = (uint32_t)(pitch / px);
     svthip::lr_frame_dispatch(&P, c.stream);
     c.down2d(params->dst, (size_t)params->dst_stride * px, d_dst, pitch, w * px, h);
+    return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 // svt_av1_wiener_convolve_add_src -> _c (convolve.c:100-147); conv_params is rebuilt from the bit depth exactly as

@@ -54,14 +54,30 @@ int physical_device(int logical) {
     return n > 0 ? logical % n : logical;
 }
 
-void ensure_device() {
-    if (!g_initialised) {
-        if (svt_hip_init(0) != 0) {
-            fprintf(stderr,
-                    "libsvtav1_hip: no usable HIP device (gfx950 expected). This library has no CPU path; "
-                    "use the reference's own C/AVX2 variants instead.\n");
-            abort();
+// ---- error policy (svt_hip_common.h: HIP_CHECK) ------------------------------------------------------------------------------------------------------------
+static std::atomic<bool> g_failed{false};
+static std::mutex        g_fail_m;
+static char              g_last_error[512] = "";
+bool failed() { return g_failed.load(std::memory_order_acquire); }
+extern "C" void svt_hip_rtcd_unhook(void); // rtcd_hook.hip
+void device_fail(const int code, const char* what, const char* file, const int line) {
+    {
+        std::lock_guard<std::mutex> g(g_fail_m);
+        if (!g_failed.load()) {
+            snprintf(g_last_error, sizeof(g_last_error), "%s failed: %s (%s:%d)", what, code > 0 ? hipGetErrorString((hipError_t)code) : "library limit", file, line);
+            fprintf(stderr, "libsvtav1_hip: %s -- the device path is off from here on: dispatch pointers restored, stage entry points decline\n", g_last_error);
+            g_failed.store(true, std::memory_order_release);
+            svt_hip_rtcd_unhook();
         }
+    }
+    (void)hipGetLastError();
+    throw DeviceError{code};
+}
+
+void ensure_device() {
+    if (failed()) throw DeviceError{-1}; // (every entry point opens with ensure_device: after the first error nothing touches the device any more)
+    if (!g_initialised) {
+        if (svt_hip_init(0) != 0) device_fail(-2, "svt_hip_init(0): no usable HIP device (gfx950 expected)", __FILE__, __LINE__);
     }
     // the current device is per host thread: the encoder's worker threads (pointers are called concurrently from ME / EncDec /
     // CDEF / REST threads) bind to their device the first time they enter the library, and again whenever it changes
@@ -131,19 +147,20 @@ const ThreadStreams& thread_streams() {
 uint32_t* stream_scratch_u32x4(hipStream_t st) {
     constexpr uint32_t RING = 4096;
     static std::mutex            m;
-    static uint32_t*             ring[MAX_DEVICES] = {};
-    static std::atomic<uint32_t> next[MAX_DEVICES];
+    static std::atomic<uint32_t*> ring[MAX_DEVICES]; // (read outside the mutex by every worker thread: atomic)
+    static std::atomic<uint32_t>  next[MAX_DEVICES];
     ensure_device();
     const int d = current_device();
-    if (!ring[d]) {
+    uint32_t* base = ring[d].load(std::memory_order_acquire);
+    if (!base) {
         std::lock_guard<std::mutex> g(m);
-        if (!ring[d]) {
-            uint32_t* p = nullptr;
-            HIP_CHECK(hipMalloc((void**)&p, (size_t)RING * 16));
-            ring[d] = p;
+        base = ring[d].load(std::memory_order_relaxed);
+        if (!base) {
+            HIP_CHECK(hipMalloc((void**)&base, (size_t)RING * 16));
+            ring[d].store(base, std::memory_order_release);
         }
     }
-    uint32_t* p = ring[d] + 4 * (next[d].fetch_add(1) % RING);
+    uint32_t* p = base + 4 * (next[d].fetch_add(1) % RING);
     HIP_CHECK(hipMemsetAsync(p, 0, 16, st));
     return p;
 }
@@ -164,14 +181,15 @@ uint8_t* plane_cache_acquire(const void* host_ptr, uint64_t id, size_t bytes, bo
     *hit = false; *token = -1;
     if (!host_ptr || !id) return nullptr;
     ensure_device();
-    PlaneCache& C = g_plane_cache[current_device()];
+    const int   dev_ = current_device();
+    PlaneCache& C = g_plane_cache[dev_];
     std::lock_guard<std::mutex> g(C.m);
     int victim = -1;
     for (int i = 0; i < PLANE_CACHE_ENTRIES; i++) {
         CachedPlane& e = C.e[i];
         if (e.state && e.ptr == (uintptr_t)host_ptr && e.id == id) {
             if (e.state == 1 || e.cap < bytes) return nullptr;
-            e.pins++; e.stamp = ++C.clock; *hit = true; *token = i; C.hits++;
+            e.pins++; e.stamp = ++C.clock; *hit = true; *token = dev_ * PLANE_CACHE_ENTRIES + i; C.hits++;
             return e.dev;
         }
         if (e.pins == 0 && e.state != 1 && (victim < 0 || e.stamp < C.e[victim].stamp)) victim = i;
@@ -188,19 +206,19 @@ uint8_t* plane_cache_acquire(const void* host_ptr, uint64_t id, size_t bytes, bo
         for (int i = 0; i < PLANE_CACHE_ENTRIES && nf < 8; i++)
             if (i != victim && !C.e[i].dev && C.e[i].state == 0 && C.e[i].pins == 0) fresh[nf++] = i;
         uint8_t* slab = nullptr;
-        HIP_CHECK(hipMalloc((void**)&slab, cap * nf));
+        if (hipMalloc((void**)&slab, cap * nf) != hipSuccess) { (void)hipGetLastError(); return nullptr; } // (not cacheable right now: the caller stages the plane in its own arena)
         C.slabs.push_back(slab);
         for (int k = 0; k < nf; k++) { C.e[fresh[k]].dev = slab + (size_t)k * cap; C.e[fresh[k]].cap = cap; }
     }
     e.ptr = (uintptr_t)host_ptr; e.id = id; e.state = 1; e.pins = 1; e.stamp = ++C.clock; C.misses++;
-    *token = victim;
+    *token = dev_ * PLANE_CACHE_ENTRIES + victim;
     return e.dev;
 }
-void plane_cache_release(int token, bool now_ready) {
+void plane_cache_release(int token, bool now_ready) { // (the token names the table it came from: the releasing thread's current device does not matter)
     if (token < 0) return;
-    PlaneCache& C = g_plane_cache[current_device()];
+    PlaneCache& C = g_plane_cache[token / PLANE_CACHE_ENTRIES];
     std::lock_guard<std::mutex> g(C.m);
-    CachedPlane& e = C.e[token];
+    CachedPlane& e = C.e[token % PLANE_CACHE_ENTRIES];
     if (e.state == 1) e.state = now_ready ? 2 : 0;
     if (e.pins > 0) e.pins--;
 }
@@ -257,8 +275,7 @@ void HostCall::reserve(size_t dev_bytes, size_t pin_bytes) {
 void* HostCall::dalloc(size_t bytes) {
     size_t off = align_up(dev_used, 256);
     if (off + bytes > dev_cap) {
-        fprintf(stderr, "libsvtav1_hip: host-call device arena overflow (%zu + %zu > %zu)\n", off, bytes, dev_cap);
-        abort();
+        device_fail(-3, "host-call device arena overflow", __FILE__, __LINE__);
     }
     dev_used = off + bytes;
     return dev + off;
@@ -266,8 +283,7 @@ void* HostCall::dalloc(size_t bytes) {
 void* HostCall::palloc(size_t bytes) {
     size_t off = align_up(pin_used, 64);
     if (off + bytes > pin_cap) {
-        fprintf(stderr, "libsvtav1_hip: host-call pinned arena overflow\n");
-        abort();
+        device_fail(-3, "host-call pinned arena overflow", __FILE__, __LINE__);
     }
     pin_used = off + bytes;
     return pin + off;
@@ -522,6 +538,7 @@ void svt_hip_shutdown(void) {
     plane_cache_free_all();
     t_bound       = -1;
     g_initialised = false;
+    g_failed      = false; // (a later svt_hip_init starts clean; the dispatch pointers stay restored until svt_hip_setup_rtcd is called again)
 }
 
 int svt_hip_device_count(void) { // LOGICAL devices: GPUs x SVT_HIP_VIRTUAL_DEVICES (see physical_device above), at most MAX_DEVICES
@@ -536,19 +553,30 @@ int svt_hip_set_virtual_devices(int per_gpu) { // before the devices beyond the 
     return 0;
 }
 int svt_hip_set_thread_device(int device) {
+    SVT_HIP_ENTRY_TRY
     using namespace svthip;
     if (device >= MAX_DEVICES || device >= svt_hip_device_count()) return -1;
     t_want = device < 0 ? -1 : device;
     if (device >= 0 && device != (int)g_device) g_multi = true;
     ensure_device();
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 int svt_hip_get_thread_device(void) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     return svthip::current_device();
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 const char* svt_hip_device_name(void) { return svthip::g_name; }
+const char* svt_hip_last_error(void) { return svthip::failed() ? svthip::g_last_error : nullptr; }
+int         svt_hip_failed(void) { return svthip::failed() ? 1 : 0; }
+// test instrument: the next HIP_CHECK-level failure is simulated now (as if a hipMalloc had failed inside the calling entry point)
+int svt_hip_debug_inject_failure(void) {
+    try { svthip::device_fail((int)hipErrorOutOfMemory, "injected failure (svt_hip_debug_inject_failure)", __FILE__, __LINE__); } catch (const svthip::DeviceError&) {}
+    return 0;
+}
 void svt_hip_tuning_reload(void) { svthip::tuning_read(); }
 
 // ---- HIP graphs: every batched entry point only enqueues work on the stream it is given (no host synchronisation, no host-side state), so a
@@ -559,8 +587,12 @@ void* svt_hip_stream_create(void) {
     HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     return (void*)st;
 }
-void svt_hip_stream_destroy(void* stream) { HIP_CHECK(hipStreamDestroy((hipStream_t)stream)); }
-void svt_hip_stream_synchronize(void* stream) { HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }
+void svt_hip_stream_destroy(void* stream) {
+    SVT_HIP_ENTRY_TRY HIP_CHECK(hipStreamDestroy((hipStream_t)stream));     SVT_HIP_ENTRY_CATCH((void)0)
+}
+void svt_hip_stream_synchronize(void* stream) {
+    SVT_HIP_ENTRY_TRY HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));     SVT_HIP_ENTRY_CATCH((void)0)
+}
 void svt_hip_graph_capture_begin(void* stream) { HIP_CHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal)); }
 void* svt_hip_graph_capture_end(void* stream) {
     hipGraph_t     graph = nullptr;
@@ -576,6 +608,7 @@ void svt_hip_graph_destroy(void* graph_exec) { HIP_CHECK(hipGraphExecDestroy((hi
 // Pays the one-time costs of the calling thread's device up front (an encoder calls it while it initialises): the HIP context, the loading of this library's code
 // objects (the runtime loads them at the first launch), the first pinned and device allocations.  ~60 ms that would otherwise sit inside the first picture's stage.
 void svt_hip_warmup(void) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     svthip::HostCall& c = svthip::host_call();
     c.begin();
@@ -584,9 +617,11 @@ void svt_hip_warmup(void) {
     hipLaunchKernelGGL(svt_hip_selftest_kernel, dim3(1), dim3(64), 0, c.stream, d);
     SVT_LAUNCH_CHECK();
     c.sync();
+    SVT_HIP_ENTRY_CATCH((void)0)
 }
 
 int svt_hip_host_register(void* buffer, size_t bytes) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     if (!buffer || !bytes) return -1;
     const hipError_t e = hipHostRegister(buffer, bytes, hipHostRegisterPortable);
@@ -597,8 +632,10 @@ int svt_hip_host_register(void* buffer, size_t bytes) {
         svthip::g_locked_n.store((int)svthip::g_locked.size(), std::memory_order_release);
     }
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 int svt_hip_host_unregister(void* buffer) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     {
         std::lock_guard<std::mutex> g(svthip::g_locked_m);
@@ -609,13 +646,16 @@ int svt_hip_host_unregister(void* buffer) {
     const hipError_t e = hipHostUnregister(buffer);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 int svt_hip_selftest(uint32_t* results, void* stream) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     hipLaunchKernelGGL(svt_hip_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, results);
     SVT_LAUNCH_CHECK();
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 } // extern "C"

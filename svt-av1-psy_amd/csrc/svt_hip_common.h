@@ -1,5 +1,8 @@
 // svt_hip_common.h -- host-side plumbing shared by every kernel family of libsvtav1_hip.so.
-//  * HIP_CHECK: fail loudly (the reference's DSP kernels cannot report errors, and this library has no CPU path).
+//  * HIP_CHECK: a HIP error never propagates into the encoder and never kills it (SURVEY 8b "errors").  The first one is recorded (svt_hip_last_error), the dispatch
+//    pointers svt_hip_setup_rtcd overwrote are put back -- the encoder continues on the SIMD variant the reference had selected --, every stage entry point returns
+//    non-zero from then on (the seams decline and run the reference's own function), and the call in flight unwinds with a C++ exception to the entry point that
+//    catches it (the per-pointer guard of rtcd_hook.hip finishes the call through the saved pointer).  There is no CPU path in this library.
 //  * HostCall: per-thread stream + growable device arena + pinned staging, used by the `*_hip` RTCD-signature
 //    functions that receive plain host pointers (Source/Lib/Codec/aom_dsp_rtcd.h contract: synchronous,
 //    re-entrant, caller owns every buffer, arbitrary strides).
@@ -36,15 +39,22 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
     return (b & 7) * per + (b >> 3);
 }
 
-#define HIP_CHECK(expr)                                                                                         \
-    do {                                                                                                        \
-        hipError_t e_ = (expr);                                                                                 \
-        if (e_ != hipSuccess) {                                                                                 \
-            fprintf(stderr, "libsvtav1_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, \
-                    __LINE__);                                                                                  \
-            abort();                                                                                            \
-        }                                                                                                       \
+namespace svthip {
+struct DeviceError { int code; };                                                     // thrown by device_fail, caught at the guarded entry points
+[[noreturn]] void device_fail(int code, const char* what, const char* file, int line); // runtime.hip
+bool               failed();                                                          // a HIP error has switched the device path off
+}
+#define HIP_CHECK(expr)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) svthip::device_fail((int)e_, #expr, __FILE__, __LINE__);       \
     } while (0)
+// the body of a stage / host-form entry point that returns int: non-zero (SVT_HIP_E_DEVICE) once the device path is off, or when this call hits the first error
+#ifndef SVT_HIP_E_DEVICE
+#define SVT_HIP_E_DEVICE (-100)
+#endif
+#define SVT_HIP_ENTRY_TRY try {
+#define SVT_HIP_ENTRY_CATCH(ret) } catch (const svthip::DeviceError&) { return ret; }
 
 #define SVT_LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
 

@@ -329,6 +329,7 @@ extern "C" int svt_hip_tf_picture(const SvtHipTfPictureParams* params, const Svt
 
 extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, const SvtHipTfHostPicture* central, const SvtHipTfHostPicture* refs, const SvtHipTfMeTables* me,
                                        uint32_t n_refs, void* out_y, void* out_u, void* out_v, SvtHipTfPictureStats* stats) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     const SvtHipTfPictureParams& P = *params;
     if (!pic_params_ok(P, n_refs)) return -1;
@@ -396,4 +397,5 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     if (stats) c.down_later(stats, d_stats, sizeof(SvtHipTfPictureStats));
     c.finish(); // (one synchronisation for the three planes and the statistics)
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }

@@ -211,10 +211,11 @@ static void tf_mc_launch(const SvtHipTfSubpelParams* params, const SvtHipTfMcPla
 
 // Host-pointer form of the refinement batch (what a seam inside temporal_filtering.c calls once per (central picture, reference picture) pair): src_buf / ref_buf
 // = the two pictures' whole padded luma buffers (src_samples / ref_samples samples), descs / results host arrays; the descs' offsets are relative to the buffers.
-extern "C" void svt_hip_tf_subpel_search_host(const SvtHipTfSubpelParams* params, const void* src_buf, size_t src_samples, const void* ref_buf, size_t ref_samples,
+extern "C" int svt_hip_tf_subpel_search_host(const SvtHipTfSubpelParams* params, const void* src_buf, size_t src_samples, const void* ref_buf, size_t ref_samples,
                                               const SvtHipTfSubpelDesc* descs, uint32_t n, SvtHipTfSubpelResult* results) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
-    if (n == 0) return;
+    if (n == 0) return 0;
     const size_t px = params->bit_depth > 8 ? 2 : 1, db = (size_t)n * sizeof(SvtHipTfSubpelDesc), rb = (size_t)n * sizeof(SvtHipTfSubpelResult);
     svthip::HostCallLease lease; // (a pooled arena: see svt_hip_common.h)
     svthip::HostCall& c = *lease;
@@ -229,4 +230,6 @@ extern "C" void svt_hip_tf_subpel_search_host(const SvtHipTfSubpelParams* params
     c.up(d_d, descs, db);
     svt_hip_tf_subpel_search_batch(params, d_src, d_ref, d_d, n, d_r, c.stream);
     c.down(results, d_r, rb);
+    return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }

@@ -604,6 +604,7 @@ void svt_hip_tpl_src_stage(const SvtHipTplSrcParams* params, const uint8_t* src_
 
 int svt_hip_tpl_src_stage_host(const SvtHipTplSrcParams* params, const SvtHipTplHostPlanes* planes, const uint8_t* total_me_candidate_index,
                                const uint32_t* me_mv_array, const uint8_t* me_candidate_array, SvtHipTplSrcStats* stats) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     SvtHipTplSrcParams P = *params;
     if (!tpl_supported(P)) return -1;
@@ -644,6 +645,7 @@ int svt_hip_tpl_src_stage_host(const SvtHipTplSrcParams* params, const SvtHipTpl
     svt_hip_tpl_src_stage(&P, d_planes, d_planes, d_tot, d_mv, d_cand, d_stats, c.stream);
     c.down(stats, d_stats, cells * sizeof(SvtHipTplSrcStats));
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* src_base, const uint8_t* rec_ref_base, const SvtHipTplSrcStats* src_stats,
@@ -724,6 +726,7 @@ void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* 
 
 int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams* params, const SvtHipTplHostPlanes* planes, const SvtHipTplSrcStats* src_stats, uint8_t* recon_buf,
                                  uint32_t recon_rows, SvtHipTplReconStats* out) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     SvtHipTplReconParams R = *params;
     const SvtHipTplSrcParams& P = R.src;
@@ -785,6 +788,7 @@ int svt_hip_tpl_recon_stage_host(const SvtHipTplReconParams* params, const SvtHi
     for (size_t r = 0; r < rows16; r++)
         if (out[r * cols16].pad[0] == 0xEE) return -4; // the row-wavefront form gave up waiting (see tpl_recon_rows_kernel)
     return 0;
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 // Both halves of the dispenser for one picture in ONE host call: every distinct picture buffer -- the source, the source pictures of its references (source-based
@@ -899,15 +903,23 @@ static int tpl_stage_host_impl(const SvtHipTplReconParams* params, const SvtHipT
 int svt_hip_tpl_stage_host(const SvtHipTplReconParams* params, const SvtHipTplHostPlanes* src_planes, const SvtHipTplHostPlanes* rec_planes,
                            const uint8_t* total_me_candidate_index, const uint32_t* me_mv_array, const uint8_t* me_candidate_array, SvtHipTplSrcStats* src_stats,
                            uint8_t* recon_buf, uint32_t recon_rows, SvtHipTplReconStats* out) {
+    SVT_HIP_ENTRY_TRY
     if (!total_me_candidate_index) return -1;
     return tpl_stage_host_impl(params, src_planes, rec_planes, nullptr, total_me_candidate_index, me_mv_array, me_candidate_array, src_stats, recon_buf, recon_rows, out);
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 int svt_hip_tpl_stage_host_resident(const SvtHipTplReconParams* params, const SvtHipTplHostPlanes* src_planes, const SvtHipTplHostPlanes* rec_planes,
                                     const SvtHipTplPlaneIds* ids, const uint8_t* total_me_candidate_index, const uint32_t* me_mv_array, const uint8_t* me_candidate_array,
                                     SvtHipTplSrcStats* src_stats, uint8_t* recon_buf, uint32_t recon_rows, SvtHipTplReconStats* out) {
+    SVT_HIP_ENTRY_TRY
     return tpl_stage_host_impl(params, src_planes, rec_planes, ids, total_me_candidate_index, me_mv_array, me_candidate_array, src_stats, recon_buf, recon_rows, out);
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
-void svt_hip_tpl_plane_drop(const void* host_buffer) { svthip::plane_cache_drop(host_buffer); }
-void svt_hip_tpl_plane_counts(uint64_t* hits, uint64_t* misses) { svthip::ensure_device(); svthip::plane_cache_counts(hits, misses); }
+void svt_hip_tpl_plane_drop(const void* host_buffer) {
+    SVT_HIP_ENTRY_TRY svthip::plane_cache_drop(host_buffer);     SVT_HIP_ENTRY_CATCH((void)0)
+}
+void svt_hip_tpl_plane_counts(uint64_t* hits, uint64_t* misses) {
+    SVT_HIP_ENTRY_TRY svthip::ensure_device(); svthip::plane_cache_counts(hits, misses);     SVT_HIP_ENTRY_CATCH((void)0)
+}
 
 } // extern "C"

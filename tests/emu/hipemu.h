@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <functional>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -53,7 +54,7 @@ struct hipemuEvent {
     double t;
 };
 typedef hipemuEvent* hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNoDevice = 100 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipHostRegisterDefault = 0 };
 struct hipDeviceProp_t {
@@ -501,7 +502,17 @@ template <typename T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return 
 // ---- host runtime subset -----------------------------------------------------------------
 inline hipError_t  hipGetLastError() { return hipSuccess; }
 inline hipError_t  hipPeekAtLastError() { return hipSuccess; }
-inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+inline const char* hipGetErrorString(hipError_t e) { return e == hipErrorOutOfMemory ? "hipemu: injected failure (SVT_HIPEMU_FAIL_AFTER)" : "hipemu"; }
+// SVT_HIPEMU_FAIL_AFTER=<n>: the n-th device allocation / copy / synchronisation of the process and every one after it FAILS (hipErrorOutOfMemory) -- the library's
+// error policy (svt_hip_common.h: HIP_CHECK) can then be exercised on the CPU: the encoder must finish, on the reference's own kernels, with an identical bitstream.
+namespace hipemu {
+inline bool inject_failure() {
+    static const long limit = [] { const char* e = getenv("SVT_HIPEMU_FAIL_AFTER"); return e ? atol(e) : -1L; }();
+    if (limit < 0) return false;
+    static std::atomic<long> calls{0};
+    return calls.fetch_add(1) >= limit;
+}
+} // namespace hipemu
 inline hipError_t  hipGetDeviceCount(int* n) { *n = hipemu::device_count(); return hipSuccess; }
 inline hipError_t  hipSetDevice(int d) { if (d < 0 || d >= hipemu::device_count()) return hipErrorInvalidValue; hipemu::cur_device() = d; return hipSuccess; }
 inline hipError_t  hipGetDevice(int* d) { *d = hipemu::cur_device(); return hipSuccess; }
@@ -513,6 +524,7 @@ inline hipError_t  hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     return hipSuccess;
 }
 inline hipError_t hipMalloc(void** p, size_t n) {
+    if (hipemu::inject_failure()) return hipErrorOutOfMemory;
     *p = aligned_alloc(256, (n + 255) & ~size_t(255));
     if (*p && hipemu::device_count() > 1) { std::lock_guard<std::mutex> g(hipemu::alloc_lock()); hipemu::allocs()[(uintptr_t)*p] = hipemu::Alloc{n, hipemu::cur_device()}; }
     return *p ? hipSuccess : 2;
@@ -532,6 +544,7 @@ inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; 
 inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { hipemu::check_ptr(d, "hipMemcpy"); hipemu::check_ptr(s, "hipMemcpy"); memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st = nullptr) {
+    if (hipemu::inject_failure()) return hipErrorOutOfMemory;
     hipemu::check_stream(st, "hipMemcpyAsync"); hipemu::check_ptr(d, "hipMemcpyAsync"); hipemu::check_ptr(s, "hipMemcpyAsync");
     memcpy(d, s, n);
     return hipSuccess;
@@ -576,7 +589,7 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new 
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned f, int) { return hipStreamCreateWithFlags(s, f); }
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete (hipemu::Stream*)s; return hipSuccess; }
 inline hipError_t hipStreamGetDevice(hipStream_t s, int* d) { *d = s ? ((hipemu::Stream*)s)->device : hipemu::cur_device(); return hipSuccess; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipemu::inject_failure() ? (hipError_t)hipErrorOutOfMemory : (hipError_t)hipSuccess; }
 // HIP graphs: the interpreter executes a launch when it is issued, so "capture" runs the work once and a graph launch cannot replay it;
 // the product's graph entry points link, CPU tests do not use them.
 typedef void* hipGraph_t;

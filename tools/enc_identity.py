@@ -151,6 +151,13 @@ CASES = {
     "vstrips3_cdef_lr_p4": (448, 264, 6, 8, ["--preset", "4", "--lp", "2", "+strips:0,1,2", "+lrseam", "+cdefseam"]),
     "vstrips2_cdef_lr_p8_10bit": (448, 264, 8, 10, ["--preset", "8", "--lp", "1", "+strips:0,1", "+lrseam", "+cdefseam"]),
     "vstrips4_cdef_lr_1080p_p6": (1920, 1080, 5, 8, ["--preset", "6", "+strips:0,1,2,3", "+lrseam", "+cdefseam"]),
+    # the error policy (SURVEY 8b "errors"): a HIP failure in the middle of the encode -- at the N-th device allocation / copy / synchronisation -- switches the device
+    # path off; the encoder finishes on the reference's own kernels and functions with the same bitstream (emulator: SVT_HIPEMU_FAIL_AFTER)
+    "tiny_fail_everyseam_p8_a": (128, 128, 10, 8, ["--preset", "8", "--lp", "2", "+failafter:40", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
+    "tiny_fail_everyseam_p8_b": (128, 128, 10, 8, ["--preset", "8", "--lp", "2", "+failafter:400", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
+    "tiny_fail_everyseam_p4": (128, 128, 6, 8, ["--preset", "4", "--lp", "1", "+failafter:150", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "tiny_fail_hooks_p8": (64, 64, 3, 8, ["--preset", "8", "--lp", "1", "+failafter:3000"]),  # the per-call dispatch pointers: a `_hip` call fails in flight and finishes through the saved pointer
+    "tiny_fail_at_init": (64, 64, 3, 8, ["--preset", "8", "--lp", "1", "+failafter:0", "+seam", "+cdefseam"]),  # the very first device operation fails
     # small cases for the CPU lock-step emulator (tests/test_encoder_identity.py, -m "not gpu")
     # one encode over TWO (emulated) devices: SVT_HIP_DEVICES=0,1 shards the pictures by picture number; every seam at once
     "tiny_2dev_everyseam_p8": (128, 64, 12, 8, ["--preset", "8", "--lp", "2", "+devices:0,1", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
@@ -330,6 +337,11 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
     if strips:
         env.update({"SVT_HIP_STRIPS": strips, "SVT_HIP_STRIPS_STATS": strips_file})
         env.update({"SVT_HIPEMU_DEVICES": str(len(strips.split(",")))} if "hipemu" in lib else {"SVT_HIP_VIRTUAL_DEVICES": str(max(int(d) for d in strips.split(",")) + 1)})
+    # "+failafter:N" (emulator): the N-th device allocation / copy / synchronisation of the encode and every later one fail (tests/emu/hipemu.h).  The claim (SURVEY 8b
+    # "errors"): the encoder finishes, the bitstream is identical, the library reported the switch-off -- stages before the failure ran on the device, later ones declined
+    fail_after = next((a[11:] for a in CASES[name][4] if a.startswith("+failafter:")), None)
+    if fail_after is not None:
+        env["SVT_HIPEMU_FAIL_AFTER"] = fail_after
     if (seam or lrseam or cdefseam or dlfseam or tplseam or tf_alone) and not with_hook and not only:
         only = "-"  # no RTCD pointer matches: the seam(s) alone
     if only:
@@ -388,6 +400,11 @@ def run_case(name, lib, outdir, device=0, only=None, skip=None, timeout=1800, ho
         same = same and res[host + "_identical_to_c"]
     res["identical"] = same
     res["bitstream_equal"] = bool(same)  # the files alone; "identical" additionally demands that the stages the case names really ran
+    if fail_after is not None:
+        res["device_path_switched_off"] = "the device path is off from here on" in rh.stderr
+        res["last_error_line"] = next((ln for ln in rh.stderr.splitlines() if ln.startswith("libsvtav1_hip:")), None)
+        res["identical"] = bool(same) and res["device_path_switched_off"]
+        return res
     if seam:
         st = dict(ln.split(None, 1) for ln in open(seam_file).read().splitlines()) if os.path.exists(seam_file) else {}
         res["seam"] = {k: (int(v) if v.strip().isdigit() else v.strip()) for k, v in st.items()}
