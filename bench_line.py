@@ -75,7 +75,16 @@ def compact(out):
         line["cpu_baseline"] = None
     if enc:
         e = _pick(enc, ("fps_c_only", "fps_avx2_intrinsics", "fps_avx512_intrinsics", "fps_avx2_host_with_stage_seams", "fps_avx512_host_with_stage_seams",
-                        "fps_c_host_with_stage_seams", "frames", "bitstream_identical", "host_cpu_s_per_frame", "instances"), 4)
+                        "fps_c_host_with_stage_seams", "frames", "bitstream_identical", "host_cpu_s_per_frame", "instances", "error"), 4)
+        sp = {}
+        for tag, key in (("avx2", "fps_avx2_pairs"), ("avx512", "fps_avx512_pairs")):
+            pr = enc.get(key)
+            if isinstance(pr, dict) and pr.get("alone") and pr.get("with_stages"):  # [pairs, min / max alone, min / max with the stages]: the medians are quoted above
+                al, wi = [v for v in pr["alone"] if v], [v for v in pr["with_stages"] if v]
+                if al and wi:
+                    sp[tag] = [len(al), _r(min(al), 4), _r(max(al), 4), _r(min(wi), 4), _r(max(wi), 4)]
+        if sp:
+            e["fps_pairs_n_min_max_alone_min_max_with"] = sp
         sc = enc.get("stage_cpu_ms_per_frame")
         if isinstance(sc, dict):  # host CPU ms per frame inside the stages of SURVEY 8: the reference's AVX2 code vs the device stage calls
             e["stage_cpu_ms_per_frame"] = {k: v for k, v in sc.items() if k != "c" and v}

@@ -180,7 +180,13 @@ static int sum_slot(int di, uint64_t id, int make) {
         if (!G.sum[di][i][1] && free_i < 0) free_i = i;
     }
     if (!make) return -1;
-    if (free_i < 0) { memset(G.sum[di], 0, sizeof(G.sum[di])); free_i = 0; }
+    if (free_i < 0) { /* the table (2 x the ring) is full: drop the entries of pictures that have left the device's ring -- never one of a RESIDENT picture, whose stored
+                       * checksum is what SVT_HIP_ME_SEAM_HASH compares against (clearing the whole table, as before, made every resident picture read as
+                       * "content changed" once per wrap: 5 false re-uploads in a 60-frame encode, none in the shorter identity clips) */
+        for (int i = 0; i < SEAM_RING * 2; i++)
+            if (!G.session[di] || !abi.resident(G.session[di], (int64_t)G.sum[di][i][0])) { G.sum[di][i][1] = 0; if (free_i < 0) free_i = i; }
+        if (free_i < 0) { memset(G.sum[di], 0, sizeof(G.sum[di])); free_i = 0; } /* (cannot happen: at most SEAM_RING pictures are resident) */
+    }
     G.sum[di][free_i][0] = id;
     return free_i;
 }

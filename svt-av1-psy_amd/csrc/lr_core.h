@@ -90,7 +90,8 @@ __device__ __forceinline__ void stage_load(StageRegs<NIT>& R, const TileSrc& s, 
     for (int k = 0; k < NIT; k++) {
         const int  r = rb + 16 * k, y = s.y0 - 3 + r;
         const uint8_t* p = pint + (long long)(16 * k) * sbytes;
-        if (r >= rows) p = (const uint8_t*)s.data;                                   // idle lanes read the plane start: always mapped
+        if (r >= rows) p = (const uint8_t*)s.data + (long long)s.y0 * sbytes;        // idle lanes read the start of the unit's first row: always mapped (also when
+                                                                                     // `data` is the virtual base of a band of rows: csrc/partition.hip)
         else if (y < ilo || y >= ihi) p = src_row(s, y) + (cfast ? (long long)x * px : 0ll); // (slow lanes read the row start)
         if (s.highbd) {
             const svt_u32x4_a2 t = svt_hip_global_load_x4(p);

@@ -80,6 +80,17 @@ void* mirror_in(Partition& P, Peer& p, const void* src, size_t bytes) {
     P.bytes_in += bytes;
     return d;
 }
+// rows [r0, r1) of a plane (row pitch `row_bytes`, the last row ending after `width_bytes`) -> a mirror of just those rows on peer p; returns the VIRTUAL plane base:
+// the address row 0 would have, so that the strip kernels -- which address the full plane -- find row y of the band at base + y * row_bytes.  Only rows of the band
+// may be touched through it (the strip's own rows + the halo the caller adds).
+uint8_t* mirror_rows(Partition& P, Peer& p, const void* src, size_t row_bytes, size_t width_bytes, int r0, int r1) {
+    if (!src || r1 <= r0) return nullptr;
+    const size_t bytes = (size_t)(r1 - r0 - 1) * row_bytes + width_bytes;
+    uint8_t* d = (uint8_t*)arena_take(p, bytes);
+    HIP_CHECK(hipMemcpyPeerAsync(d, p.phys, (const uint8_t*)src + (size_t)r0 * row_bytes, P.peer[0].phys, bytes, p.stream));
+    P.bytes_in += bytes;
+    return d - (size_t)r0 * row_bytes;
+}
 void rows_out(Partition& P, Peer& p, void* dst_home, const void* src_peer, size_t bytes) {
     if (!bytes) return;
     HIP_CHECK(hipMemcpyPeerAsync(dst_home, P.peer[0].phys, src_peer, p.phys, bytes, p.stream));
@@ -286,29 +297,32 @@ int svt_hip_frame_partition_cdef(void* part, int mode, const SvtHipCdefParams* p
         Peer& p = P->peer[k];
         svthip::DeviceGuard g(p.device);
         if (e <= b) { HIP_CHECK(hipEventRecord(p.done, p.stream)); continue; }
-        arena_begin(p, recon_b + source_b + out_b + skip_b + 2 * str_b + dir_b + var_b + mse_b + 16 * 256);
+        // the strip's rows of every plane-sized input plus the halo the tiles read (VB = 3 rows of the neighbouring filter blocks; 8 taken), the strip's rows of the
+        // 8x8 skip map and of the per-filter-block arrays -- not the whole picture per peer: peer traffic is ~ one picture per call, whatever n is
+        const int    y0 = b * bh, y1 = e * bh < (int)C.height ? e * bh : (int)C.height;
+        const int    h0 = y0 - 8 > 0 ? y0 - 8 : 0, h1 = y1 + 8 < (int)C.height ? y1 + 8 : (int)C.height;
+        const size_t rrow = (size_t)C.recon_stride * px, srow = (size_t)C.source_stride * px, orow = (size_t)C.out_stride * px, wb = (size_t)C.width * px;
+        const size_t f0 = (size_t)b * nhfb, fn = (size_t)(e - b) * nhfb;
+        arena_begin(p, (size_t)(h1 - h0) * rrow + (mode == 1 ? (size_t)(y1 - y0) * srow : (size_t)(y1 - y0) * orow) + (size_t)(e - b) * 8 * nhfb * 8 + 2 * str_b + fn * 64 * 5 +
+                           (mode == 1 ? fn * C.ncand * 8 : 0) + 16 * 256);
         HIP_CHECK(hipStreamWaitEvent(p.stream, P->ready, 0));
         jitter(*P, p.stream);
         SvtHipCdefParams M = C;
-        M.recon  = mirror_in(*P, p, C.recon, recon_b);
-        M.source = mode == 1 ? mirror_in(*P, p, C.source, source_b) : nullptr;
-        M.skip   = (const uint8_t*)mirror_in(*P, p, C.skip, skip_b);
+        M.recon  = mirror_rows(*P, p, C.recon, rrow, wb, h0, h1);
+        M.source = mode == 1 ? mirror_rows(*P, p, C.source, srow, wb, y0, y1) : nullptr;
+        M.skip   = mirror_rows(*P, p, C.skip, (size_t)nhfb * 8, (size_t)nhfb * 8, b * 8, e * 8);
         M.pri    = (const int32_t*)mirror_in(*P, p, C.pri, str_b);
         M.sec    = (const int32_t*)mirror_in(*P, p, C.sec, str_b);
         // (always mirrored, also where they are outputs: a filter block without a single unit to filter leaves its entries as the caller had them)
-        M.dir    = (uint8_t*)mirror_in(*P, p, C.dir, dir_b);
-        M.var    = (int32_t*)mirror_in(*P, p, C.var, var_b);
-        M.mse    = mode == 1 ? (uint64_t*)arena_take(p, mse_b) : nullptr;
+        M.dir    = mirror_rows(*P, p, C.dir, (size_t)nhfb * 64, (size_t)nhfb * 64, b, e);
+        M.var    = (int32_t*)mirror_rows(*P, p, C.var, (size_t)nhfb * 64 * 4, (size_t)nhfb * 64 * 4, b, e);
+        M.mse    = mode == 1 ? (uint64_t*)((uint8_t*)arena_take(p, fn * C.ncand * 8) - f0 * C.ncand * 8) : nullptr;
         // apply writes out of place onto a pre-copied plane (skipped units are not touched): the strip's rows of the caller's `out` are that pre-copy
-        const int    y0 = b * bh, y1 = e * bh < (int)C.height ? e * bh : (int)C.height;
-        const size_t orow = (size_t)C.out_stride * px;
-        M.out = mode == 1 ? nullptr : arena_take(p, out_b);
+        M.out = mode == 1 ? nullptr : (void*)mirror_rows(*P, p, C.out, orow, wb, y0, y1);
         const size_t strip_b = plane_bytes(C.out_stride, C.width, (size_t)(y1 - y0), px);
-        if (mode != 1) HIP_CHECK(hipMemcpyPeerAsync((uint8_t*)M.out + y0 * orow, p.phys, (const uint8_t*)C.out + y0 * orow, P->peer[0].phys, strip_b, p.stream));
         jitter(*P, p.stream);
         svt_hip_cdef_frame_rows(mode, &M, b, e, p.stream);
         jitter(*P, p.stream);
-        const size_t f0 = (size_t)b * nhfb, fn = (size_t)(e - b) * nhfb;
         if (mode == 1) rows_out(*P, p, C.mse + f0 * C.ncand, M.mse + f0 * C.ncand, fn * C.ncand * 8);
         else rows_out(*P, p, (uint8_t*)C.out + y0 * orow, (const uint8_t*)M.out + y0 * orow, strip_b);
         if (!dir_in) { // luma: the strip's directions / variances are results too
@@ -347,21 +361,23 @@ int svt_hip_frame_partition_lr(void* part, const SvtHipLrParams* params, void* s
         Peer& p = P->peer[k];
         svthip::DeviceGuard g(p.device);
         if (e <= b) { HIP_CHECK(hipEventRecord(p.done, p.stream)); continue; }
-        arena_begin(p, data_b + 2 * bnd_b + dst_b + unit_b + 8 * 256);
+        // stripe s covers picture rows [s * sh - off, (s + 1) * sh - off) clipped to the plane; the filters read 3 rows beyond a stripe (8 taken) and the stripe's
+        // own two saved boundary lines above / below: the strip's rows + halo and boundary lines [2 b, 2 e) only, not the whole planes
+        const int    y0 = b * sh - off > 0 ? b * sh - off : 0, y1 = e * sh - off < (int)L.height ? e * sh - off : (int)L.height;
+        const int    h0 = y0 - 8 > 0 ? y0 - 8 : 0, h1 = y1 + 8 < (int)L.height ? y1 + 8 : (int)L.height;
+        const size_t drow_in = (size_t)L.stride * px, brow = (size_t)L.boundary_stride * px, drow = (size_t)L.dst_stride * px, wb = (size_t)L.width * px;
+        arena_begin(p, (size_t)(h1 - h0) * drow_in + 2 * (size_t)(2 * (e - b)) * brow + (size_t)(y1 - y0) * drow + unit_b + 8 * 256);
         HIP_CHECK(hipStreamWaitEvent(p.stream, P->ready, 0));
         jitter(*P, p.stream);
         SvtHipLrParams M = L;
-        M.data           = mirror_in(*P, p, L.data, data_b);
-        M.boundary_above = mirror_in(*P, p, L.boundary_above, bnd_b);
-        M.boundary_below = mirror_in(*P, p, L.boundary_below, bnd_b);
+        M.data           = mirror_rows(*P, p, L.data, drow_in, wb, h0, h1);
+        M.boundary_above = mirror_rows(*P, p, L.boundary_above, brow, wb, 2 * b, 2 * e);
+        M.boundary_below = mirror_rows(*P, p, L.boundary_below, brow, wb, 2 * b, 2 * e);
         M.units          = (const SvtHipLrUnit*)mirror_in(*P, p, L.units, unit_b);
-        M.dst            = arena_take(p, dst_b);
+        M.dst            = (uint8_t*)arena_take(p, plane_bytes(L.dst_stride, L.width, (size_t)(y1 - y0), px)) - (size_t)y0 * drow;
         jitter(*P, p.stream);
         svt_hip_lr_filter_frame_stripes(&M, b, e, p.stream);
         jitter(*P, p.stream);
-        // stripe s covers picture rows [s * sh - off, (s + 1) * sh - off) clipped to the plane
-        const int    y0 = b * sh - off > 0 ? b * sh - off : 0, y1 = e * sh - off < (int)L.height ? e * sh - off : (int)L.height;
-        const size_t drow = (size_t)L.dst_stride * px;
         rows_out(*P, p, (uint8_t*)L.dst + y0 * drow, (const uint8_t*)M.dst + y0 * drow, plane_bytes(L.dst_stride, L.width, (size_t)(y1 - y0), px));
         HIP_CHECK(hipEventRecord(p.done, p.stream));
     }
