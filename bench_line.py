@@ -84,7 +84,7 @@ def compact(out):
                 if al and wi:
                     sp[tag] = [len(al), _r(min(al), 4), _r(max(al), 4), _r(min(wi), 4), _r(max(wi), 4)]
         if sp:
-            e["fps_pairs_n_min_max_alone_min_max_with"] = sp
+            e["fps_pairs"] = dict(sp, _cols="n,min,max alone,min,max with stages")
         sc = enc.get("stage_cpu_ms_per_frame")
         if isinstance(sc, dict):  # host CPU ms per frame inside the stages of SURVEY 8: the reference's AVX2 code vs the device stage calls
             e["stage_cpu_ms_per_frame"] = {k: v for k, v in sc.items() if k != "c" and v}
@@ -111,20 +111,44 @@ def compact(out):
         line["legs"] = {"_columns": ["us", "hbm_frac", "valu_frac", "binds"], **legs}
     if out.get("detail"):
         line["detail"] = out["detail"]
-    # shrink until it fits: the leg table first (it is in the detail file), then the optional objects
-    s = json.dumps(line, separators=(",", ":"))
-    for drop in ("legs", "frame_partition", "detail"):
-        if len(s) <= MAX_LINE:
-            break
-        if drop == "legs" and "legs" in line:  # first try without the binding column / with fewer digits
+    # shrink until it fits, the least important parts first (everything is in the detail file); the leg table goes last
+    def size():
+        return len(json.dumps(line, separators=(",", ":")))
+
+    def steps():
+        if "legs" in line:  # fewer digits
             line["legs"] = {k: (v if k == "_columns" else [_r(x, 3) if not isinstance(x, str) else x for x in v]) for k, v in line["legs"].items()}
-            s = json.dumps(line, separators=(",", ":"))
-            if len(s) <= MAX_LINE:
-                break
-        line.pop(drop, None)
-        s = json.dumps(line, separators=(",", ":"))
-    if len(s) > MAX_LINE and isinstance(line.get("cpu_baseline"), dict):
-        line["cpu_baseline"].pop("sample", None)
-        s = json.dumps(line, separators=(",", ":"))
+        yield
+        if isinstance(line.get("cpu_baseline"), dict) and isinstance(line["cpu_baseline"].get("sample"), str):
+            line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:72]
+        yield
+        e = line.get("encoder_fps_1080p_preset8")
+        if isinstance(e, dict) and isinstance(e.get("instances"), dict):
+            for k in ("fps_sum_of_encoder_reports_avx2", "fps_sum_of_encoder_reports_avx2_with_stages", "frames_each"):
+                e["instances"].pop(k, None)
+        yield
+        if isinstance(e, dict):
+            e.pop("steady_state_300_frames", None)
+        yield
+        if isinstance(line.get("config"), dict):
+            for k in ("launches_per_step", "frames_per_step_per_gpu", "sb_refs_per_step_per_gpu", "mode"):
+                line["config"].pop(k, None)
+        yield
+        if isinstance(e, dict):
+            e.pop("instances", None)
+        yield
+        if isinstance(line.get("frame_partition"), dict):
+            line["frame_partition"].pop("collective", None)
+        yield
+        if isinstance(e, dict):
+            e.pop("stage_cpu_ms_per_frame", None)
+        yield
+        for drop in ("detail", "legs", "frame_partition"):
+            line.pop(drop, None)
+            yield
+    for _ in steps():
+        if size() <= MAX_LINE:
+            break
+    s = json.dumps(line, separators=(",", ":"))
     assert len(s) <= MAX_LINE, "bench line is %d bytes" % len(s)
     return s

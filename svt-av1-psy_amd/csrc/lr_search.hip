@@ -751,6 +751,7 @@ __global__ __launch_bounds__(PROJ_T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     if (st != 2) break;
                 }
                 xqd[p] -= st * k;
+                if (dbg && tid == 0 && st == 2 && first) atomicAdd(&dbg[4 + (k < 9 ? k : 9)], 1); // (diagnostic: moves accepted down in a line's first pass)
                 if (rejected || st != 2 || k < nd || nd < PROJ_K) break;
             }
             if (skip) break; // (:372-373: a successful downward move ends the loop over p)
@@ -771,6 +772,7 @@ __global__ __launch_bounds__(PROJ_T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     if (st != 2) break;
                 }
                 xqd[p] += st * k;
+                if (dbg && tid == 0 && st == 2 && pass == 0) atomicAdd(&dbg[14 + (k < 9 ? k : 9)], 1); // (... and up, where no downward move was accepted)
                 if (rejected || st != 2 || k < nu || nu < PROJ_K) break;
             }
         }
@@ -870,7 +872,7 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     const int mw = max_uw > us ? max_uw : (us < (int)P.width ? us : (int)P.width), mh = max_uh > us ? max_uh : (us < (int)P.height ? us : (int)P.height);
     const dim3 tgrid((mw + 63) / 64, (mh + 63) / 64, n);
     hipLaunchKernelGGL(lr_rects_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.rects, W.acc, W.wn, units, n);
-    HIP_CHECK(hipMemsetAsync(W.counter, 0, 16, st));
+    HIP_CHECK(hipMemsetAsync(W.counter, 0, 128, st));
     // RESTORE_NONE
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<0>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
     hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, st, W.acc, units, 0, n);
@@ -954,10 +956,15 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
         HIP_CHECK(hipStreamWaitEvent(st, ev_wn, 0)); // (also on the failure path: the side streams' work must not outlive the call's ordering)
     }
     if (sg_dbg && sg_on) {
-        int32_t c[4];
+        int32_t c[32];
         HIP_CHECK(hipStreamSynchronize(sg_st[0]));
-        HIP_CHECK(hipMemcpy(c, W.counter, 16, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(c, W.counter, 128, hipMemcpyDeviceToHost));
         fprintf(stderr, "SVT_HIP_LR_SG_STATS: %d units x %d sets: %d table passes (%d left their table), %d line passes\n", n, slots, c[1], c[3], c[2]);
+        fprintf(stderr, "SVT_HIP_LR_SG_STATS: step-2 lines, moves accepted in the first pass, down 0..8,9+:");
+        for (int k = 0; k < 10; k++) fprintf(stderr, " %d", c[4 + k]);
+        fprintf(stderr, "; up (no down move) 0..8,9+:");
+        for (int k = 0; k < 10; k++) fprintf(stderr, " %d", c[14 + k]);
+        fprintf(stderr, "\n");
     }
     if (sg_on) HIP_CHECK(hipStreamWaitEvent(st, ev_sg0, 0));
     return rc_wn;
