@@ -458,6 +458,10 @@ def encoder_fps():
         have_512 = os.path.exists(ei.ENC_AVX512) and cpu_has(*AVX512)
         r512 = ei.run_case(CASE, lib, td, timeout=600, host="avx512") if have_512 else {}
         rep512 = ei.repeat_pairs(CASE, lib, td, want_bits, pairs=4, host="avx512") if have_512 and r512.get("identical") else {}
+        # ... and the subset of stages that pays at this preset (ME, temporal filter, TPL, CDEF: tools/seam_subset_probe.py), five pairs per host
+        PAY = "fps_1080p_p8_paying"
+        pay = ei.repeat_pairs(PAY, lib, td, want_bits, pairs=5, host="avx2") if have_x and r.get("identical") else {}
+        pay512 = ei.repeat_pairs(PAY, lib, td, want_bits, pairs=5, host="avx512") if have_512 and r.get("identical") else {}
         # K concurrent encodes sharing this GPU on the box's host cores: aggregate fps and host CPU seconds per frame, AVX2 host alone vs with the stages
         inst = ei.run_instances(CASE + "_300", lib, td, 4, host="avx2", timeout=900) if have_x else {}  # (300 frames: a 60-frame encode is over in 0.5 s, less than a process's start-up)
         # thread CPU time per stage (integration/seam_cpu.h), a run of its own: the brackets cost two clock reads per SB in the ME stage
@@ -493,6 +497,11 @@ def encoder_fps():
                                         "note": "single run each; run-to-run spread on this box class is +- 5 % (profiles/r03_call13..15)"} if r300 else None, "avx2_bitstream_identical_to_c": r.get("avx2_identical_to_c"),
             "fps_avx512_intrinsics": med(alone_512) if alone_512 else r512.get("fps_avx512"), "fps_avx512_host_with_stage_seams": med(with_512) if with_512 else r512.get("fps_hip"),
             "fps_avx512_pairs": {"alone": alone_512, "with_stages": with_512, "quoted": "median"} if alone_512 else None,
+            # the same clip with only the stages that pay at preset 8 on the device (no LR / deblocking seam); identical bitstreams or no number
+            "paying_stages": {"stages": "ME, temporal filter, TPL (both halves), CDEF", "identical": bool(pay.get("identical")) and (not pay512 or bool(pay512.get("identical"))),
+                              "fps_avx2": med(pay.get("fps_alone") or []), "fps_avx2_with": med(pay.get("fps_with_stages") or []),
+                              "fps_avx512": med(pay512.get("fps_alone") or []), "fps_avx512_with": med(pay512.get("fps_with_stages") or []),
+                              "pairs": {"avx2": pay, "avx512": pay512}} if pay and pay.get("identical") and (not pay512 or pay512.get("identical")) else None,
             # user + system CPU seconds of the whole encoder process per frame (RUSAGE_CHILDREN): what the offload takes off the host
             "host_cpu_s_per_frame": dict(r.get("host_cpu_s_per_frame") or {}, **{k: v for k, v in (r512.get("host_cpu_s_per_frame") or {}).items() if k != "c"}),
             "instances": {"k": inst.get("instances"), "frames_each": inst.get("frames"), "fps_avx2": inst.get("fps_avx2"), "fps_avx2_with_stages": inst.get("fps_avx2_with_stages"),

@@ -76,6 +76,9 @@ def compact(out):
     if enc:
         e = _pick(enc, ("fps_c_only", "fps_avx2_intrinsics", "fps_avx512_intrinsics", "fps_avx2_host_with_stage_seams", "fps_avx512_host_with_stage_seams",
                         "fps_c_host_with_stage_seams", "frames", "bitstream_identical", "host_cpu_s_per_frame", "instances", "error"), 4)
+        ps = enc.get("paying_stages")
+        if isinstance(ps, dict):  # only ME / TF / TPL / CDEF on the device: [alone, with] medians of five pairs per host
+            e["paying_stages"] = {"avx2": [_r(ps.get("fps_avx2"), 4), _r(ps.get("fps_avx2_with"), 4)], "avx512": [_r(ps.get("fps_avx512"), 4), _r(ps.get("fps_avx512_with"), 4)]}
         sp = {}
         for tag, key in (("avx2", "fps_avx2_pairs"), ("avx512", "fps_avx512_pairs")):
             pr = enc.get(key)

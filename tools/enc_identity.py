@@ -110,6 +110,9 @@ CASES = {
     # 3840x2160 10-bit, preset 8, 60 frames (10-bit preset 8 is where the multi-threaded C-only reference was seen not to reproduce its own
     # bitstream; run_case reports `reference_deterministic` and the identity verdict next to the two speeds)
     "fps_1080p_p8_all_tplrecon": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),  # A/B against fps_1080p_p8_all: the reconstruction half of the TPL dispenser on the device too
+    # the stages that PAY at preset 8 against a vectorised host (tools/seam_subset_probe.py, profiles/r05_seam_subsets_fps.txt): without the loop-restoration and deblocking seams,
+    # whose reference code is cheap at this preset (0.35 / 0.8 ms of CPU per frame) while their stage calls sit at the end of every picture's pipeline
+    "fps_1080p_p8_paying": (1920, 1080, 60, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+cdefseam", "+tplseam", "+tplrecon"]),
     "fps_4k10_p8_all": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     # larger pictures: more work per stage call against the same fixed latency
     "fps_4k8_p8_all": (3840, 2160, 30, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
