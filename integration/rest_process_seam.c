@@ -38,6 +38,7 @@ static struct {
     int (*search_host)(const SvtHipLrSearchParams *, const SvtHipLrPrevUnit *, SvtHipLrSearchUnit *);
     int (*filter_host)(const SvtHipLrParams *); /* (non-zero from either: the device path is off -- svtav1_hip.h, error policy) */
     unsigned long long us_stage; /* microseconds inside the stage calls */
+    unsigned long long us_first, us_max, n_calls; /* the first stage call of the encode, the longest one, how many */
     PictureControlSet *done_pcs[64]; /* pictures whose search has been done by the seam (keyed by pcs + picture number) ... */
     uint64_t           done_num[64];
     uint32_t           seen[64];     /* ... and how many of their segments have passed: the record is dropped with the last one */
@@ -48,7 +49,7 @@ static void lr_seam_stats(void) {
     const char *f = getenv("SVT_HIP_LR_SEAM_STATS");
     FILE       *o = f ? fopen(f, "w") : NULL;
     if (!o) return;
-    fprintf(o, "ms_in_stage_calls %llu\n", (unsigned long long)(L.us_stage / 1000));
+    fprintf(o, "ms_in_stage_calls %llu\nus_first_search_call %llu\nus_longest_search_call %llu\nsearch_calls %llu\n", (unsigned long long)(L.us_stage / 1000), L.us_first, L.us_max, L.n_calls);
     fprintf(o, "pictures_offloaded %llu\nplanes_searched %llu\nunits_searched %llu\npictures_declined %llu\nplanes_filtered %llu\n", (unsigned long long)L.n_pictures,
             (unsigned long long)L.n_planes, (unsigned long long)L.n_units, (unsigned long long)L.n_declined, (unsigned long long)L.n_filtered_planes);
     fclose(o);
@@ -121,7 +122,10 @@ static int search_plane(const Yv12BufferConfig *org_fts, const Yv12BufferConfig 
     svt_hip_seam_bind(pcs->picture_number);
     const double ts_ = seam_ms_now();
     const int rc = L.search_host(&P, prev, out);
-    __atomic_fetch_add(&L.us_stage, (unsigned long long)((seam_ms_now() - ts_) * 1e3), __ATOMIC_RELAXED);
+    { const unsigned long long us_ = (unsigned long long)((seam_ms_now() - ts_) * 1e3);
+      __atomic_fetch_add(&L.us_stage, us_, __ATOMIC_RELAXED);
+      if (__atomic_fetch_add(&L.n_calls, 1, __ATOMIC_RELAXED) == 0) L.us_first = us_;
+      if (us_ > L.us_max) L.us_max = us_; }
     free(prev);
     if (rc) { /* the device path is off (or the stage refused): the caller runs the reference's search for the whole picture */
         fprintf(stderr, "SVT_HIP_LR_SEAM: svt_hip_lr_search_plane_host returned %d (picture %llu plane %d %ux%u unit %u win %u bd %u wn %d sg %d ep %u..%u/%u): the reference's search takes the picture\n", rc,

@@ -994,3 +994,5 @@ void svt_aom_copy_rect8_8bit_to_16bit_hip(uint16_t* dst, int32_t dstride, const 
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(cdef) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

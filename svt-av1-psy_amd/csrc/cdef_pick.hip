@@ -174,3 +174,5 @@ uint64_t svt_search_one_dual_hip(int* lev0, int* lev1, int nb_strengths, uint64_
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(cdef_pick) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

@@ -238,3 +238,5 @@ LPF_PAIR(14)
 #undef LPF_PAIR
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(deblock) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

@@ -425,3 +425,5 @@ void svt_hip_me_integer_search_batch(const SvtHipMeIntegerSearchParams* params, 
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(hme) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

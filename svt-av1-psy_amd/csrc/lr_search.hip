@@ -884,7 +884,8 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     //     are not queued behind the long self-guided workgroups.
     // They write different fields of a unit's record and keep separate accumulators.
     const bool  sg_on = P.sg_enabled && slots > 0;
-    const svthip::ThreadStreams& TS = svthip::thread_streams();
+    svthip::StreamSetLease       ts_lease; // (handed back when the call returns, its work possibly still in flight: see runtime.hip)
+    const svthip::ThreadStreams& TS = *ts_lease.set;
     hipStream_t sg_st[2] = {TS.st[0], TS.st[1]}, wn_st = TS.st[2];
     hipEvent_t  ev_fork = TS.ev[0], ev_sg0 = TS.ev[1], ev_sg1 = TS.ev[2], ev_wn = TS.ev[3], ev_dq = TS.ev[4];
     const char* lw = getenv("SVT_HIP_LR_SG_WALK"); // (A/B measurement, read per call -- a picture-sized stage)
@@ -1005,3 +1006,5 @@ int svt_hip_lr_search_plane_host(const SvtHipLrSearchParams* params, const SvtHi
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(lr_search) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

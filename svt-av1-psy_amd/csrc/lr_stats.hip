@@ -324,3 +324,5 @@ void svt_hip_lr_compute_stats_batch(const void* dgd, const void* src, const SvtH
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(lr_stats) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

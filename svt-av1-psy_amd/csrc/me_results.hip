@@ -288,3 +288,5 @@ extern "C" void svt_hip_me_results_batch(const SvtHipMeResultsParams* params, co
                        total_me_candidate_index, me_mv_array, me_candidate_array, sb_stats);
     SVT_LAUNCH_CHECK();
 }
+
+SVT_HIP_DEFINE_WARM(me_results) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

@@ -487,3 +487,5 @@ int svt_hip_me_session_wait(void* session, int slot) {
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(me_session) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

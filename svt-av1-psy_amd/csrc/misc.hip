@@ -343,3 +343,5 @@ void svt_get_proj_subspace_hip(const uint8_t* src8, int32_t width, int32_t heigh
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(misc) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

@@ -124,3 +124,5 @@ void svt_aom_downsample_2d_hip(uint8_t* input_samples, uint32_t input_stride, ui
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(picprep) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

@@ -156,3 +156,5 @@ void svt_pme_sad_loop_kernel_hip(const SvtHipMvCostParams* mv_cost_params, uint8
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(pme) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

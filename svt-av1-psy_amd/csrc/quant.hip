@@ -239,3 +239,5 @@ uint64_t svt_handle_transform_hip(int32_t* output, int tx_size, int n2_n4) {
 HT(64, 64, 4) HT(32, 64, 11) HT(64, 32, 12) HT(16, 64, 17) HT(64, 16, 18)
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(quant) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

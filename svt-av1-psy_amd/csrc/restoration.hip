@@ -265,3 +265,5 @@ void svt_apply_selfguided_restoration_hip(const uint8_t* dat8, int32_t width, in
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(restoration) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

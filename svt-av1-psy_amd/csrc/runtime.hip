@@ -6,6 +6,30 @@
 #include "svt_hip_common.h"
 #include "../../include/svtav1_hip.h"
 
+namespace svthip { // (one per kernel file: SVT_HIP_DEFINE_WARM)
+void warm_cdef(hipStream_t st);
+void warm_cdef_pick(hipStream_t st);
+void warm_deblock(hipStream_t st);
+void warm_hme(hipStream_t st);
+void warm_lr_search(hipStream_t st);
+void warm_lr_stats(hipStream_t st);
+void warm_me_results(hipStream_t st);
+void warm_me_session(hipStream_t st);
+void warm_misc(hipStream_t st);
+void warm_picprep(hipStream_t st);
+void warm_pme(hipStream_t st);
+void warm_quant(hipStream_t st);
+void warm_restoration(hipStream_t st);
+void warm_sad(hipStream_t st);
+void warm_tf(hipStream_t st);
+void warm_tf_picture(hipStream_t st);
+void warm_tf_subpel(hipStream_t st);
+void warm_tpl(hipStream_t st);
+void warm_tpl_full(hipStream_t st);
+void warm_txfm(hipStream_t st);
+void warm_txfm_fused(hipStream_t st);
+}
+
 namespace svthip {
 
 static std::atomic<int>  g_device{-1};         // the default device (svt_hip_init)
@@ -124,22 +148,35 @@ HostCallLease::~HostCallLease() {
     g_lease_pool[device].push_back(c); // (most recently used first: the arena that has already grown is the one that is taken again)
 }
 
-// Side streams + events of the calling thread on its current device (made on first use, kept): for a stage that runs independent launch sequences side by side and
-// joins them (the loop-restoration search: the self-guided search's groups of parameter sets on two streams, the Wiener refinement -- a chain of short dependent
-// launches -- on a third one with the highest priority, so that its launches are not queued behind the long self-guided workgroups).
-static thread_local ThreadStreams t_streams[MAX_DEVICES];
-const ThreadStreams& thread_streams() {
+// Side streams + events for a stage that runs independent launch sequences side by side and joins them (the loop-restoration search: the self-guided search's groups
+// of parameter sets on two streams, the Wiener refinement -- a chain of short dependent launches -- on a third one with the highest priority, so that its launches are
+// not queued behind the long self-guided workgroups).  The sets are POOLED per device, not kept per thread: an encoder calls the stage from whichever worker thread
+// holds the picture, and a set made per thread cost every new thread three stream creations -- 5 ms per call at 1080p (profiles/r05_lr_seam_calls.txt).  A set is
+// taken for the duration of a call and handed back with its work possibly still in flight: streams are in-order and every event is recorded again before it is waited
+// for, so the next user's work simply queues behind.
+static std::mutex                   g_streams_m;
+static std::vector<ThreadStreams*> g_streams_pool[MAX_DEVICES];
+StreamSetLease::StreamSetLease() {
     ensure_device();
-    ThreadStreams& f = t_streams[current_device()];
-    if (!f.st[0]) {
+    device = current_device();
+    set = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_streams_m);
+        if (!g_streams_pool[device].empty()) { set = g_streams_pool[device].back(); g_streams_pool[device].pop_back(); }
+    }
+    if (!set) {
+        set = new ThreadStreams();
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; } // (hi = the numerically lowest value = the highest priority)
-        HIP_CHECK(hipStreamCreateWithFlags(&f.st[0], hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&f.st[1], hipStreamNonBlocking));
-        if (hipStreamCreateWithPriority(&f.st[2], hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); HIP_CHECK(hipStreamCreateWithFlags(&f.st[2], hipStreamNonBlocking)); }
-        for (hipEvent_t& e : f.ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_CHECK(hipStreamCreateWithFlags(&set->st[0], hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&set->st[1], hipStreamNonBlocking));
+        if (hipStreamCreateWithPriority(&set->st[2], hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); HIP_CHECK(hipStreamCreateWithFlags(&set->st[2], hipStreamNonBlocking)); }
+        for (hipEvent_t& e : set->ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    return f;
+}
+StreamSetLease::~StreamSetLease() {
+    std::lock_guard<std::mutex> g(g_streams_m);
+    g_streams_pool[device].push_back(set);
 }
 
 // Four zeroed device words for ONE launch sequence on `st` (tickets / counters of a kernel that orders its own workgroups): slots of a per-device ring, cleared in
@@ -616,7 +653,37 @@ void svt_hip_warmup(void) {
     uint32_t* d = (uint32_t*)c.dalloc(17 * 64 * 4);
     hipLaunchKernelGGL(svt_hip_selftest_kernel, dim3(1), dim3(64), 0, c.stream, d);
     SVT_LAUNCH_CHECK();
+    svthip::warm_cdef(c.stream);
+    svthip::warm_cdef_pick(c.stream);
+    svthip::warm_deblock(c.stream);
+    svthip::warm_hme(c.stream);
+    svthip::warm_lr_search(c.stream);
+    svthip::warm_lr_stats(c.stream);
+    svthip::warm_me_results(c.stream);
+    svthip::warm_me_session(c.stream);
+    svthip::warm_misc(c.stream);
+    svthip::warm_picprep(c.stream);
+    svthip::warm_pme(c.stream);
+    svthip::warm_quant(c.stream);
+    svthip::warm_restoration(c.stream);
+    svthip::warm_sad(c.stream);
+    svthip::warm_tf(c.stream);
+    svthip::warm_tf_picture(c.stream);
+    svthip::warm_tf_subpel(c.stream);
+    svthip::warm_tpl(c.stream);
+    svthip::warm_tpl_full(c.stream);
+    svthip::warm_txfm(c.stream);
+    svthip::warm_txfm_fused(c.stream);
+    SVT_LAUNCH_CHECK();
     c.sync();
+    {   // ... and what the stage-sized host forms take from pools on their first calls: three leased arenas (device + pinned: the pinned allocation is the slow part) and one
+        // set of side streams, made now instead of inside the first pictures' stage calls
+        svthip::HostCallLease a, b, c3;
+        (*a).begin(); (*a).reserve(96u << 20, 24u << 20);
+        (*b).begin(); (*b).reserve(96u << 20, 24u << 20);
+        (*c3).begin(); (*c3).reserve(96u << 20, 24u << 20);
+        svthip::StreamSetLease s1;
+    }
     SVT_HIP_ENTRY_CATCH((void)0)
 }
 

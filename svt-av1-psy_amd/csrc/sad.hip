@@ -1736,3 +1736,5 @@ void svt_initialize_buffer_32bits_hip(uint32_t* pointer, uint32_t count128, uint
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(sad) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

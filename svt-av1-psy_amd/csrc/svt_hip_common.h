@@ -111,7 +111,14 @@ struct HostCall {
 };
 HostCall& host_call();
 struct ThreadStreams { hipStream_t st[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev[6] = {}; }; // st[2]: highest priority
-const ThreadStreams& thread_streams(); // the calling thread's side streams + events on its current device (runtime.hip)
+struct StreamSetLease { // a pooled set of side streams + events on the calling thread's device, for the duration of one stage call (runtime.hip)
+    ThreadStreams* set;
+    int            device;
+    StreamSetLease();
+    ~StreamSetLease();
+    StreamSetLease(const StreamSetLease&) = delete;
+    StreamSetLease& operator=(const StreamSetLease&) = delete;
+};
 uint32_t* stream_scratch_u32x4(hipStream_t st);
 // the TPL dispenser with the option set of tpl levels 0-3 (tpl_full.hip): every intra mode, SATD costs, sub-pel vectors, rate
 bool tpl_full_wanted(const ::SvtHipTplSrcParams& P);
@@ -153,3 +160,10 @@ void cdef_frame_dispatch(int mode, const ::SvtHipCdefParams* P, hipStream_t st);
 void lr_frame_dispatch(const ::SvtHipLrParams* P, hipStream_t st);
 
 } // namespace svthip
+
+// The runtime loads a translation unit's code object at the first launch of one of its kernels (tens of milliseconds for the larger ones: the first loop-restoration
+// stage call of an encode took 51 ms, profiles/r05_lr_seam_calls.txt).  Every kernel file defines an empty kernel + a launcher with this macro; svt_hip_warmup()
+// (runtime.hip), which an encoder calls while it initialises, launches them all, so that no stage pays the load inside its first picture.
+#define SVT_HIP_DEFINE_WARM(tu)                                                                                              \
+    __global__ void svt_hip_warm_kernel_##tu(int) {}                                                                         \
+    namespace svthip { void warm_##tu(hipStream_t st) { hipLaunchKernelGGL(svt_hip_warm_kernel_##tu, dim3(1), dim3(1), 0, st, 0); } }

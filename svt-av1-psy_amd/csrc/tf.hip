@@ -570,3 +570,5 @@ void svt_av1_apply_zz_based_temporal_filter_planewise_medium_hbd_hip(const SvtHi
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(tf) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

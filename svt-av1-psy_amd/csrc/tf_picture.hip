@@ -399,3 +399,5 @@ extern "C" int svt_hip_tf_picture_host(const SvtHipTfPictureParams* params, cons
     return 0;
     SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
+
+SVT_HIP_DEFINE_WARM(tf_picture) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

@@ -233,3 +233,5 @@ extern "C" int svt_hip_tf_subpel_search_host(const SvtHipTfSubpelParams* params,
     return 0;
     SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
+
+SVT_HIP_DEFINE_WARM(tf_subpel) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

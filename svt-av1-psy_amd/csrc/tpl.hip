@@ -923,3 +923,5 @@ void svt_hip_tpl_plane_counts(uint64_t* hits, uint64_t* misses) {
 }
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(tpl) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

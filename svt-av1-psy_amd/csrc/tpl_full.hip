@@ -585,3 +585,5 @@ void tpl_full_recon_launch(const SvtHipTplReconParams& R, const uint8_t* src, co
 }
 
 } // namespace svthip
+
+SVT_HIP_DEFINE_WARM(tpl_full) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

@@ -465,3 +465,5 @@ INV_R2(7, 8, 16) INV_R2(8, 16, 8) INV_R2(9, 16, 32) INV_R2(10, 32, 16) INV_R2(11
 INV_R2(16, 32, 8) INV_R2(17, 16, 64) INV_R2(18, 64, 16)
 
 } // extern "C"
+
+SVT_HIP_DEFINE_WARM(txfm) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)

@@ -173,3 +173,5 @@ extern "C" void svt_hip_txfm_quant_roundtrip_batch(const int16_t* residual_base,
         }
     }
 }
+
+SVT_HIP_DEFINE_WARM(txfm_fused) // (svt_hip_warmup loads this translation unit's code object at encoder initialisation: svt_hip_common.h)
