@@ -1325,6 +1325,13 @@ def bench_c_partition(torch, lib, pkg, stream, a, world, oracle):
         for t in outs:
             t.zero_()
         c0 = stats()
+        home = torch.cuda.current_device()
+        parted_raw = parted
+
+        def parted():  # (real peers: whatever the library leaves current, torch's own calls -- synchronize(), events -- must see the home device)
+            rc = parted_raw()
+            torch.cuda.set_device(home)
+            return rc
         assert parted() == 0
         torch.cuda.synchronize()
         c1 = stats()

@@ -103,6 +103,9 @@ void open_call(Partition& P, hipStream_t home) {
 }
 void close_call(Partition& P, hipStream_t home) {
     for (int k = 1; k < P.n; k++) HIP_CHECK(hipStreamWaitEvent(home, P.peer[k].done, 0));
+    // the peers' guards left the LAST peer current on this host thread: a caller that relies on HIP's current device (a torch process, an encoder thread between two
+    // library calls) finds its home device current again
+    if (P.n > 1) HIP_CHECK(hipSetDevice(P.peer[0].phys));
 }
 
 } // namespace
