@@ -1080,7 +1080,7 @@ def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
     # 5 = the default: ONE launch, every block in flight, DC blocks wait for the cells above / left of them, release / acquire fences; 4 = 5 with sequentially-consistent fences; 0 = one launch per
     # anti-diagonal; 1 = the row wavefront in one launch; 2 = 1 with the rows given to the XCDs in contiguous chunks; 3 = 1 with release / acquire fences.  All are kept
     # for the checker.
-    for form in (4, 3, 2, 1, 0, 5):
+    for form in (4, 3, 2, 1, 0, 6, 5):
         os.environ["SVT_HIP_TPL_RECON_FORM"] = str(form)
         t = _time(torch, run, steps, warmup, batches=3)
         out = d_out.cpu().numpy().view(pkg.TplReconStats)
@@ -1172,7 +1172,7 @@ def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
                                                             "kernel_us": t_res * 1e6, "binds": "pcie", "algorithmic_bytes_per_launch": 2 * psize},
                                                "note": "the same call with the references' planes resident on the device: one new source picture up, the written rectangle and the statistics down"},
             "tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "form": "5: one launch, one wave per block, dependencies as data, release / acquire fences (csrc/tpl.hip tpl_recon_dep_kernel)",
-                                        "sequentially_consistent_fences_form_us": forms[4][0] * 1e6, "anti_diagonal_launches_form_us": forms[0][0] * 1e6,
+                                        "sequentially_consistent_fences_form_us": forms[4][0] * 1e6, "load_polling_form6_us": forms[6][0] * 1e6, "anti_diagonal_launches_form_us": forms[0][0] * 1e6,
                                         "row_wavefront_form_us": forms[1][0] * 1e6, "row_wavefront_xcd_chunks_form_us": forms[2][0] * 1e6,
                                         "row_wavefront_release_acquire_form_us": forms[3][0] * 1e6, "blocks_16x16": n_blk, "intra_blocks": n_dc,
                                         "anti_diagonals": cols16 + rows16 - 1, "coded_frac": float(np.mean(out["coded"][out["written"] > 0])) if n_blk else 0.0,

@@ -528,7 +528,9 @@ __global__ __launch_bounds__(64) void tpl_recon_dep_kernel(const SvtHipTplReconP
         if (l < n_up + n_left) {
             uint32_t* flag  = l < n_up ? &out[(size_t)(cy - 1) * cols16 + cx + l].reserved : &out[(size_t)(cy + l - n_up) * cols16 + cx - 1].reserved;
             uint32_t  polls = 0;
-            while (atomicAdd(flag, 0u) == 0u && polls < TPL_WAIT_POLLS) { polls++; __builtin_amdgcn_s_sleep(1); }
+            // (rel_acq == 2, form 6: the poll is an atomic LOAD at agent scope -- many waves poll the same neighbours' flags, and a read-modify-write per poll queues them at
+            // the L2's atomic unit, a load does not)
+            while ((rel_acq == 2 ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : atomicAdd(flag, 0u)) == 0u && polls < TPL_WAIT_POLLS) { polls++; __builtin_amdgcn_s_sleep(1); }
             timed_out = polls >= TPL_WAIT_POLLS;
         }
         if (timed_out) atomicAdd(&sync[1], 1u);
@@ -541,7 +543,10 @@ __global__ __launch_bounds__(64) void tpl_recon_dep_kernel(const SvtHipTplReconP
     __syncthreads();
     if (threadIdx.x == 0)
         for (int j = 0; j < UNIT && cy + j < rows16; j++)
-            for (int i = 0; i < UNIT && cx + i < cols16; i++) atomicExch(&out[(size_t)(cy + j) * cols16 + cx + i].reserved, 1u);
+            for (int i = 0; i < UNIT && cx + i < cols16; i++) {
+                if (rel_acq == 2) __hip_atomic_store(&out[(size_t)(cy + j) * cols16 + cx + i].reserved, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else atomicExch(&out[(size_t)(cy + j) * cols16 + cx + i].reserved, 1u);
+            }
 }
 __global__ void tpl_recon_dep_finish_kernel(SvtHipTplReconStats* __restrict__ out, const uint32_t* __restrict__ sync) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && sync[1]) out[0].pad[0] = 0xEE; // a block gave up waiting: the caller sees it (as the row form's marker)
@@ -672,17 +677,17 @@ void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* 
         SVT_LAUNCH_CHECK();
         return;
     }
-    if (form == 4 || form == 5) { // dependencies as data, every block in flight: 5 (the default) with release / acquire fences at agent scope, 4 with sequentially-consistent
+    if (form == 4 || form == 5 || form == 6) { // (6: as 5, polling with atomic loads instead of read-modify-writes) dependencies as data, every block in flight: 5 (the default) with release / acquire fences at agent scope, 4 with sequentially-consistent
                                   // ones (416 us against 339 us for a 1080p picture with a third of its blocks intra: profiles/r04_call3_tpl_forms.txt)
         uint32_t* sync = svthip::stream_scratch_u32x4(st); // [0] tickets of the first launch, [1] blocks that gave up waiting, [2] tickets of the second launch
         hipLaunchKernelGGL(tpl_recon_rows_reset_kernel, dim3((cols16 * rows16 + 255) / 256), dim3(256), 0, st, out, 1, cols16 * rows16); // every cell's flag
         SVT_LAUNCH_CHECK();
         if (P.dispenser_search_level == 0) {
-            if (P.subsample_tx == 0) launch_tpl_recon_dep<16, 16>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 5, st);
-            else launch_tpl_recon_dep<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 5, st);
+            if (P.subsample_tx == 0) launch_tpl_recon_dep<16, 16>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 6 ? 2 : (form == 5), st);
+            else launch_tpl_recon_dep<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 6 ? 2 : (form == 5), st);
         } else {
-            launch_tpl_recon_dep<32, 8>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 5, st);
-            if (edge_sbs) launch_tpl_recon_dep<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 2, cols16, rows16, form == 5, st);
+            launch_tpl_recon_dep<32, 8>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 6 ? 2 : (form == 5), st);
+            if (edge_sbs) launch_tpl_recon_dep<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 2, cols16, rows16, form == 6 ? 2 : (form == 5), st);
         }
         hipLaunchKernelGGL(tpl_recon_dep_finish_kernel, dim3(1), dim3(64), 0, st, out, sync);
         SVT_LAUNCH_CHECK();

@@ -279,6 +279,9 @@ inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __threadfence() {}
 inline void __builtin_amdgcn_fence(int, const char*) {}
+#define __HIP_MEMORY_SCOPE_AGENT 3
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 inline void __builtin_amdgcn_s_sleep(int) {} // (a single host thread runs the workgroups in index order: nothing to wait for)
 inline void __threadfence_block() {}
 
