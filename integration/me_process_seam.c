@@ -451,8 +451,10 @@ static EbErrorType seam_motion_estimation_b64_body(PictureParentControlSet *pcs,
      * last SB has fetched (consumed == n_sb), and every SB of the picture comes here exactly once, so a reader that found it cannot lose it. */
     SeamPicture *P = NULL, *spare = NULL;
     for (int i = 0; i < SEAM_RECS && !verify; i++) {
-        if (__atomic_load_n(&G.rec[i].state, __ATOMIC_ACQUIRE) >= 2 && G.rec[i].pcs == pcs && G.rec[i].picture_number == pcs->picture_number &&
-            __atomic_load_n(&G.rec[i].state, __ATOMIC_ACQUIRE) >= 2) { /* (still ready after the comparison: the slot was not freed and claimed anew meanwhile) */
+        /* (pcs / picture_number are written by a claimer under G.lock while this path reads them without it: relaxed atomics on both sides, published by the release
+         * store of `state` -- no plain-field data race for a compiler or TSan to object to) */
+        if (__atomic_load_n(&G.rec[i].state, __ATOMIC_ACQUIRE) >= 2 && __atomic_load_n(&G.rec[i].pcs, __ATOMIC_RELAXED) == pcs &&
+            __atomic_load_n(&G.rec[i].picture_number, __ATOMIC_RELAXED) == pcs->picture_number && __atomic_load_n(&G.rec[i].state, __ATOMIC_ACQUIRE) >= 2) { /* (still ready after the comparison: the slot was not freed and claimed anew meanwhile) */
             P = &G.rec[i];
             break;
         }
@@ -460,13 +462,14 @@ static EbErrorType seam_motion_estimation_b64_body(PictureParentControlSet *pcs,
     if (P) goto fetch;
     pthread_mutex_lock(&G.lock);
     for (int i = 0; i < SEAM_RECS; i++) {
-        if (G.rec[i].state && G.rec[i].pcs == pcs && G.rec[i].picture_number == pcs->picture_number) { P = &G.rec[i]; break; }
-        if (!G.rec[i].state && !spare) spare = &G.rec[i];
+        const int st_ = __atomic_load_n(&G.rec[i].state, __ATOMIC_ACQUIRE); /* (records are freed without the lock by a store of 0) */
+        if (st_ && G.rec[i].pcs == pcs && G.rec[i].picture_number == pcs->picture_number) { P = &G.rec[i]; break; }
+        if (!st_ && !spare) spare = &G.rec[i];
     }
     if (!P) { /* first SB of this picture: compute everything now */
         if (!spare) { fprintf(stderr, "SVT_HIP_ME_SEAM: more than %d pictures in flight\n", SEAM_RECS); abort(); }
         P = spare;
-        P->pcs = pcs; P->picture_number = pcs->picture_number; P->consumed = 0;
+        __atomic_store_n(&P->pcs, pcs, __ATOMIC_RELAXED); __atomic_store_n(&P->picture_number, pcs->picture_number, __ATOMIC_RELAXED); P->consumed = 0;
         __atomic_store_n(&P->state, 1, __ATOMIC_RELEASE);
         EbPaReferenceObject *pa = (EbPaReferenceObject *)pcs->pa_ref_pic_wrapper->object_ptr;
         pthread_mutex_unlock(&G.lock); /* the record is ours (state 1); the other SBs of this picture wait on the condition, other pictures proceed */

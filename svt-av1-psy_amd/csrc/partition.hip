@@ -112,8 +112,8 @@ void close_call(Partition& P, hipStream_t home) {
 
 // ---- the host forms' switch (svt_hip_set_frame_partition): with a device list set, the picture-sized HOST forms of the in-loop filters (svt_hip_cdef_apply_host,
 // svt_hip_cdef_search_host, svt_hip_lr_filter_frame_host -- what the encoder's CDEF / REST seams call) run their frame launches through a partition instead of on
-// the calling thread's device alone.  Partitions are per calling thread (a partition serves one thread at a time; the seams call from several worker threads) and are
-// made on first use with the thread's current device as home; a thread whose device is not the list's first entry keeps the single-device path.
+// the calling thread's device alone.  A partition serves one frame launch at a time and comes from a pool (below); its home is the thread's current device, and a
+// thread whose device is not the list's first entry keeps the single-device path.
 #include <atomic>
 #include <mutex>
 namespace svthip {
@@ -121,33 +121,54 @@ static std::mutex       g_strips_m;
 static int              g_strips_n = 0, g_strips_dev[MAX_DEVICES];
 static std::atomic<int> g_strips_on{0};
 static std::atomic<unsigned long long> g_strips_calls{0};
-struct ThreadPartition {
+// Partitions of the host forms are POOLED per device list (generation), not kept per worker thread: an encoder calls the filter stages from whichever thread holds the
+// picture, and a partition per thread multiplied the peers' streams and arenas by the number of seam threads and leaked them on a change of the list.  A
+// partition is taken for one frame launch and handed back with its work possibly in flight: the peers' streams are in-order, an arena that has to grow drains its
+// stream first, and `ready` / `done k` are recorded again before they are waited for.
+static std::atomic<int>   g_strips_gen{0};
+static std::vector<void*> g_part_pool; // (under g_strips_m) partitions of generation g_part_gen
+static int                g_part_gen = -1;
+struct PartitionLease {
     void* part = nullptr;
     int   gen  = -1;
-    ~ThreadPartition() { /* (worker threads end with the encoder: the arenas go with the process) */ }
-};
-static std::atomic<int>      g_strips_gen{0};
-static thread_local ThreadPartition t_part;
-void* thread_partition() {
-    if (!g_strips_on.load(std::memory_order_acquire)) return nullptr;
-    const int gen = g_strips_gen.load();
-    if (t_part.gen != gen) {
+    PartitionLease() {
+        if (!g_strips_on.load(std::memory_order_acquire)) return;
         int devs[MAX_DEVICES], n;
-        { std::lock_guard<std::mutex> g(g_strips_m); n = g_strips_n; for (int i = 0; i < n; i++) devs[i] = g_strips_dev[i]; }
-        t_part.part = (n > 1 && devs[0] == current_device()) ? svt_hip_frame_partition_create(devs, n) : nullptr; // (an earlier partition of this thread is left to the process)
-        t_part.gen  = gen;
+        {
+            std::lock_guard<std::mutex> g(g_strips_m);
+            gen = g_strips_gen.load();
+            if (g_part_gen != gen) { // the list changed: the old generation's partitions go
+                for (void* p : g_part_pool) svt_hip_frame_partition_destroy(p);
+                g_part_pool.clear();
+                g_part_gen = gen;
+            }
+            n = g_strips_n;
+            for (int i = 0; i < n; i++) devs[i] = g_strips_dev[i];
+            if (n > 1 && devs[0] == current_device() && !g_part_pool.empty()) { part = g_part_pool.back(); g_part_pool.pop_back(); }
+        }
+        if (!part && n > 1 && devs[0] == current_device()) part = svt_hip_frame_partition_create(devs, n); // (a thread whose device is not the home keeps the single-device path)
+        if (part) g_strips_calls.fetch_add(1);
     }
-    if (t_part.part) g_strips_calls.fetch_add(1);
-    return t_part.part;
+    ~PartitionLease() {
+        if (!part) return;
+        std::lock_guard<std::mutex> g(g_strips_m);
+        if (g_part_gen == gen) g_part_pool.push_back(part);
+        else svt_hip_frame_partition_destroy(part);
+    }
+};
+void partition_pool_free() { // svt_hip_shutdown
+    std::lock_guard<std::mutex> g(g_strips_m);
+    for (void* p : g_part_pool) svt_hip_frame_partition_destroy(p);
+    g_part_pool.clear();
 }
 void cdef_frame_dispatch(int mode, const SvtHipCdefParams* P, hipStream_t st) {
-    void* part = thread_partition();
-    if (part) svt_hip_frame_partition_cdef(part, mode, P, st);
+    PartitionLease L;
+    if (L.part) svt_hip_frame_partition_cdef(L.part, mode, P, st);
     else svt_hip_cdef_frame(mode, P, st);
 }
 void lr_frame_dispatch(const SvtHipLrParams* P, hipStream_t st) {
-    void* part = thread_partition();
-    if (part) svt_hip_frame_partition_lr(part, P, st);
+    PartitionLease L;
+    if (L.part) svt_hip_frame_partition_lr(L.part, P, st);
     else svt_hip_lr_filter_frame(P, st);
 }
 } // namespace svthip

@@ -573,6 +573,7 @@ void svt_hip_shutdown(void) {
         }
     }
     plane_cache_free_all();
+    partition_pool_free();
     t_bound       = -1;
     g_initialised = false;
     g_failed      = false; // (a later svt_hip_init starts clean; the dispatch pointers stay restored until svt_hip_setup_rtcd is called again)

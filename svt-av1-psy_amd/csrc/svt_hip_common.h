@@ -158,6 +158,7 @@ int tuning_cdef_search_minb(); // SVT_HIP_CDEF_MINB: 3 (default) / 2: which regi
 // frame launches of the picture-sized host forms: through the calling thread's frame partition when svt_hip_set_frame_partition named several devices (partition.hip)
 void cdef_frame_dispatch(int mode, const ::SvtHipCdefParams* P, hipStream_t st);
 void lr_frame_dispatch(const ::SvtHipLrParams* P, hipStream_t st);
+void partition_pool_free(); // the pooled partitions of the host forms (partition.hip), at svt_hip_shutdown
 
 } // namespace svthip
 
