@@ -680,7 +680,7 @@ void svt_hip_warmup(void) {
     {   // ... and what the stage-sized host forms take from pools on their first calls: three leased arenas (device + pinned: the pinned allocation is the slow part) and one
         // set of side streams, made now instead of inside the first pictures' stage calls
         svthip::HostCallLease a, b, c3;
-        (*a).begin(); (*a).reserve(96u << 20, 24u << 20);
+        (*a).begin(); (*a).reserve(192u << 20, 24u << 20); // (the LR search of a 1080p plane wants ~100 MB of device arena: the first one is made large enough for it)
         (*b).begin(); (*b).reserve(96u << 20, 24u << 20);
         (*c3).begin(); (*c3).reserve(96u << 20, 24u << 20);
         svthip::StreamSetLease s1;
