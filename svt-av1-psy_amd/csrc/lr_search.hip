@@ -336,6 +336,21 @@ __global__ void lr_wiener_step_kernel(const SvtHipLrSearchParams P, WnState* __r
     wn[u] = st;
 }
 
+// Wave sum of 32-bit values without an LDS round trip: the 16-bit halves are summed separately -- a row of 16 lanes by four DPP adds (each half's row sum < 2^20), the four
+// rows through scalar registers -- and recombined in 64 bits.  ~20 instructions; the ds_bpermute butterfly of wave_sum_i64 is twelve dependent LDS-pipe round trips.
+__device__ __forceinline__ uint32_t lrs_row16_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false); // row_ror:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); // row_ror:8
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_u32(const uint32_t v) {
+    const int lo = (int)lrs_row16_sum(v & 0xffffu), hi = (int)lrs_row16_sum(v >> 16);
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readlane(lo, 0) + (uint32_t)__builtin_amdgcn_readlane(lo, 16) + (uint32_t)__builtin_amdgcn_readlane(lo, 32) + (uint32_t)__builtin_amdgcn_readlane(lo, 48);
+    const uint32_t H = (uint32_t)__builtin_amdgcn_readlane(hi, 0) + (uint32_t)__builtin_amdgcn_readlane(hi, 16) + (uint32_t)__builtin_amdgcn_readlane(hi, 32) + (uint32_t)__builtin_amdgcn_readlane(hi, 48);
+    return (long long)((unsigned long long)L + ((unsigned long long)H << 16));
+}
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -438,17 +453,19 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
 
 // ---- self-guided: projection + refinement of one (unit, parameter set) per workgroup (search_selfguided_restoration's loop body, :582-630) ------------
 constexpr int PROJ_T = 1024; // threads per (unit, parameter set): sixteen waves, every evaluation is one latency-bound pass over the unit
-// The workgroup's sums of N per-thread values, written to out[0..N) in LDS (valid for every thread on return): one wave reduction per value, one pair of
-// barriers for the whole group.  use(k) says whether value k is wanted (workgroup-uniform).  part: [PROJ_T / 64][PROJ_ROW].
+// The workgroup's sums of N per-thread values (uint32_t or long long), value k written to *dst(k) in LDS (valid for every thread on return): one wave reduction per
+// value, TWO barriers for the whole group.  use(k) says whether value k is wanted (workgroup-uniform).  part: [PROJ_T / 64][PROJ_ROW].  No barrier at the start: `part`
+// is read only between the two barriers, and a thread has read whatever it wanted of an earlier call's results before it gets here (program order).
 constexpr int PROJ_W = PROJ_T / 64, PROJ_ROW = 24;
-template <int N, typename U>
-__device__ __forceinline__ void block_sums_i64(const long long (&v)[N], long long (*part)[PROJ_ROW], long long* out, const int tid, U use) {
+__device__ __forceinline__ long long wave_sum_any(const uint32_t v) { return wave_sum_u32(v); }
+__device__ __forceinline__ long long wave_sum_any(const long long v) { return wave_sum_i64(v); }
+template <typename T, int N, typename U, typename D>
+__device__ __forceinline__ void block_sums_to(const T (&v)[N], long long (*part)[PROJ_ROW], const int tid, U use, D dst) {
     static_assert(N <= PROJ_ROW, "part row");
-    __syncthreads(); // (part and out are reused across calls)
 #pragma unroll
     for (int k = 0; k < N; k++)
         if (use(k)) {
-            const long long w = wave_sum_i64(v[k]);
+            const long long w = wave_sum_any(v[k]);
             if ((tid & 63) == 0) part[tid >> 6][k] = w;
         }
     __syncthreads();
@@ -456,9 +473,13 @@ __device__ __forceinline__ void block_sums_i64(const long long (&v)[N], long lon
         long long t = 0;
 #pragma unroll
         for (int w = 0; w < PROJ_W; w++) t += part[w][tid];
-        out[tid] = t;
+        *dst(tid) = t;
     }
     __syncthreads();
+}
+template <typename T, int N, typename U>
+__device__ __forceinline__ void block_sums_i64(const T (&v)[N], long long (*part)[PROJ_ROW], long long* out, const int tid, U use) {
+    block_sums_to(v, part, tid, use, [&](const int k) { return out + k; });
 }
 struct __attribute__((aligned(16))) LrsQuad { uint32_t v[4]; };
 struct __attribute__((aligned(8))) LrsPair { uint32_t v[2]; };
@@ -467,6 +488,11 @@ struct __attribute__((aligned(8))) LrsPair { uint32_t v[2]; };
 // compact buffers deliver the same projection with uu = 0 and spx = src - dgd: ((dgd << 11) + y + 1024 >> 11) - src = (y + 1024 >> 11) - (src - dgd) exactly.
 #ifndef LRS_DEPTH
 #define LRS_DEPTH 4
+#endif
+#ifndef SVT_HIP_EMU
+#define LRS_NOW() wall_clock64() /* SVT_HIP_LR_SG_STATS: the constant-rate 100 MHz clock */
+#else
+#define LRS_NOW() 0ull
 #endif
 template <bool COMPACT, int DEPTH = LRS_DEPTH, typename F>
 __device__ __forceinline__ void for_unit_samples(const SvtHipLrSearchParams& P, const SvtHipRect& r, const int32_t* f0, const int32_t* f1, const int r0, const int r1,
@@ -566,10 +592,12 @@ __device__ __forceinline__ void sgr_grid_pass(const SvtHipLrSearchParams& P, con
             for (int j = 0; j < K; j++) { acc[1 + 2 * K + i * 2 * K + j] += sq(b + (j + 1) * dB); acc[1 + 2 * K + i * 2 * K + K + j] += sq(b - (j + 1) * dB); }
         }
     });
-    long long wide[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) wide[k] = (long long)acc[k];
-    block_sums_i64(wide, part, out, tid, [](int) { return true; });
+    block_sums_i64(acc, part, out, tid, [](int) { return true; });
+}
+// a workgroup-uniform value read from LDS: tell the compiler (scalar registers, scalar control flow -- the walk's state then costs no vector registers)
+__device__ __forceinline__ int       lrs_uni(const int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long lrs_uni64(const long long v) {
+    return (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((unsigned long long)v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
 }
 // the walk of one step size over the table; workgroup-uniform.  false: a line wanted a move beyond the table (xqd / err are then partly advanced: the caller restores them)
 template <int K>
@@ -579,7 +607,7 @@ __device__ __forceinline__ bool sgr_grid_replay(const long long* E, const int s,
     bool      skip = false;
     for (const int room = (xqd[0] - tap_min[0]) / s; k < room && k < cap;) { // tap 0 down
         if (k == K) return false;
-        const long long e = E[1 + k];
+        const long long e = lrs_uni64(E[1 + k]);
         if (e > err) break;
         err = e; k++; skip = true;
     }
@@ -587,7 +615,7 @@ __device__ __forceinline__ bool sgr_grid_replay(const long long* E, const int s,
     if (skip) return true; // (:372-373: a successful downward move ends the loop over the taps)
     for (const int room = (tap_max[0] - xqd[0]) / s; i < room && i < cap;) { // tap 0 up
         if (i == K) return false;
-        const long long e = E[1 + K + i];
+        const long long e = lrs_uni64(E[1 + K + i]);
         if (e > err) break;
         err = e; i++;
     }
@@ -596,7 +624,7 @@ __device__ __forceinline__ bool sgr_grid_replay(const long long* E, const int s,
     k = 0;
     for (const int room = (xqd[1] - tap_min[1]) / s; k < room && k < cap;) { // tap 1 down, from where tap 0 ended
         if (k == K) return false;
-        const long long e = row[k];
+        const long long e = lrs_uni64(row[k]);
         if (e > err) break;
         err = e; k++; skip = true;
     }
@@ -605,15 +633,16 @@ __device__ __forceinline__ bool sgr_grid_replay(const long long* E, const int s,
     int j = 0;
     for (const int room = (tap_max[1] - xqd[1]) / s; j < room && j < cap;) { // tap 1 up
         if (j == K) return false;
-        const long long e = row[K + j];
+        const long long e = lrs_uni64(row[K + j]);
         if (e > err) break;
         err = e; j++;
     }
     xqd[1] += s * j;
     return true;
 }
+// (96 VGPRs -- five waves per SIMD, four of them this workgroup's: the Wiener trial workgroups of the other stream fit beside it)
 template <bool COMPACT>
-__global__ __launch_bounds__(PROJ_T) __attribute__((amdgpu_waves_per_eu(5, 5))) void lr_sgr_proj_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const int32_t* __restrict__ flt,
+__global__ __launch_bounds__(PROJ_T) SVT_HIP_WAVES_PER_EU(5, 5) void lr_sgr_proj_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const int32_t* __restrict__ flt,
                                                              const int32_t* __restrict__ qbase, SgResult* __restrict__ res, const int slots, const int slot0, const int line_walk,
                                                              const long long* __restrict__ sums, int32_t* __restrict__ dbg /* nullptr, or [1..3]: table passes, line passes, tables left */) {
     __shared__ long long part[PROJ_W][PROJ_ROW];
@@ -628,6 +657,7 @@ __global__ __launch_bounds__(PROJ_T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const int32_t*   f0 = COMPACT ? flt : qbase + (size_t)slot * 2 * w * h;
     const int32_t*   f1 = COMPACT ? qbase + (size_t)slot * w * h : f0 + (size_t)w * h;
     const int        r0 = kSgrR[idx][0], r1 = kSgrR[idx][1];
+    const unsigned long long t_wg0 = (dbg && threadIdx.x == 0) ? LRS_NOW() : 0;
     // svt_get_proj_subspace (:413-498): the integer sums equal the reference's double sums exactly (every partial sum < 2^53); lr_sgr_flt_kernel accumulated them
     // (sums == nullptr -- a unit size that is not a multiple of the filter kernel's 64 x 64 tiles --: one pass over the unit here)
     if (sums) {
@@ -660,7 +690,7 @@ __global__ __launch_bounds__(PROJ_T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const int tap_min[2] = {-96, -32}, tap_max[2] = {31, 95}; // SGRPROJ_PRJ_MIN0 / MAX0, MIN1 / MAX1
     int       xqd[2];
     {         // encode_xq (:500-511)
-        const int e0 = sh_xq[0], e1 = sh_xq[1];
+        const int e0 = lrs_uni(sh_xq[0]), e1 = lrs_uni(sh_xq[1]);
         if (r0 == 0) { xqd[0] = 0; xqd[1] = clampi(128 - e1, tap_min[1], tap_max[1]); }
         else if (r1 == 0) { xqd[0] = clampi(e0, tap_min[0], tap_max[0]); xqd[1] = clampi(128 - xqd[0], tap_min[1], tap_max[1]); }
         else { xqd[0] = clampi(e0, tap_min[0], tap_max[0]); xqd[1] = clampi(128 - xqd[0] - e1, tap_min[1], tap_max[1]); }
@@ -678,7 +708,7 @@ __global__ __launch_bounds__(PROJ_T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         });
         const long long one[1] = {e2};
         block_sums_i64(one, part, &sh_err, tid, [](int) { return true; });
-        return sh_err;
+        return lrs_uni64(sh_err);
     };
     // finer_search_pixel_proj_error (:320-411), start_step 2.  The greedy walk only ever moves ONE tap along a line, and a move of tap p by delta changes
     // every sample's projection by delta * (a per-sample constant): so one pass over the unit evaluates a whole run of candidates -- up to PROJ_K steps
@@ -688,8 +718,12 @@ __global__ __launch_bounds__(PROJ_T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     static_assert(PROJ_K <= 8, "sh_e rows");
     long long err      = 0;
     bool      have_err = false; // err holds the error of the current xqd
-    // one pass: the errors of nd moves down and nu moves up of tap p by st each -- and, if wanted, of the current point itself (ed[PROJ_K])
-    auto eval_line = [&](const int p, const int st, const int nd, const int nu, const bool want0, long long* ed, long long* eu) __attribute__((always_inline)) { // ed, eu: rows of sh_e
+    // one pass: the errors of nd moves down and nu moves up of tap p by st each -- and, if wanted, of the current point itself (ed[PROJ_K]).  ND / NU (compile-time) bound
+    // nd / nu: a candidate costs an add, a shift and a multiply-add per sample whether its sum is wanted or not (the `k < nd` below is a select on the sum), so a pass
+    // is compiled for the shapes the walk really asks for -- (1, 1) the only look of a line at step 1, (PROJ_KF, PROJ_KF) the first look at step 2, (PROJ_K, 0) and
+    // (0, PROJ_K) the continuations -- instead of evaluating 2 PROJ_K + 1 candidates every time.
+    auto eval_line = [&](const int p, const int st, const int nd, const int nu, const bool want0, long long* ed, long long* eu, auto ndc, auto nuc) __attribute__((always_inline)) { // ed, eu: rows of sh_e
+        constexpr int ND = decltype(ndc)::value, NU = decltype(nuc)::value, NK = ND > NU ? ND : NU;
         int xq0, xq1;
         if (r0 == 0) { xq0 = 0; xq1 = 128 - xqd[1]; }
         else if (r1 == 0) { xq0 = xqd[0]; xq1 = 0; }
@@ -704,76 +738,87 @@ __global__ __launch_bounds__(PROJ_T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 #pragma unroll
         for (int k = 0; k < PROJ_K; k++) ad[k] = au[k] = 0;
         ad[PROJ_K] = 0;
+        const unsigned long long t_s0 = (dbg && tid == 0) ? LRS_NOW() : 0;
         for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
             const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10) - (sp << 11), dv = st * (c0 * a0 + c1 * a1);
             auto sq = [&](const int vv) -> Acc { const int e = vv >> 11; return COMPACT ? (Acc)((uint32_t)e * (uint32_t)e) : (Acc)((long long)e * e); };
             int vd = v, vu = v;
 #pragma unroll
-            for (int k = 0; k < PROJ_K; k++) {
+            for (int k = 0; k < NK; k++) {
                 vd -= dv; vu += dv;
-                if (k < nd) ad[k] += sq(vd);
-                if (k < nu) au[k] += sq(vu);
+                if (k < ND && k < nd) ad[k] += sq(vd);
+                if (k < NU && k < nu) au[k] += sq(vu);
             }
             if (want0) ad[PROJ_K] += sq(v);
         });
-        long long wd[PROJ_K + 1], wu[PROJ_K];
+        if (dbg && tid == 0) atomicAdd(&dbg[24], (int)(LRS_NOW() - t_s0)); // (diagnostic: thread 0's time inside the sample loops of the line passes)
+        // one reduction for both directions: values 0 .. PROJ_K are the downward sums (+ the current point), PROJ_K + 1 .. the upward ones
+        Acc all[2 * PROJ_K + 1];
 #pragma unroll
-        for (int k = 0; k < PROJ_K; k++) { wd[k] = (long long)ad[k]; wu[k] = (long long)au[k]; }
-        wd[PROJ_K] = (long long)ad[PROJ_K];
-        block_sums_i64(wd, part, ed, tid, [&](int k) { return k < nd || (k == PROJ_K && want0); });
-        block_sums_i64(wu, part, eu, tid, [&](int k) { return k < nu; });
+        for (int k = 0; k <= PROJ_K; k++) all[k] = ad[k];
+#pragma unroll
+        for (int k = 0; k < PROJ_K; k++) all[PROJ_K + 1 + k] = au[k];
+        block_sums_to(all, part, tid,
+                      [&](const int k) { return k < PROJ_K ? (k < ND && k < nd) : k == PROJ_K ? want0 : (k - PROJ_K - 1 < NU && k - PROJ_K - 1 < nu); },
+                      [&](const int k) { return k <= PROJ_K ? ed + k : eu + (k - PROJ_K - 1); });
     };
+    constexpr int PROJ_KF = 2; // how far the FIRST pass of a step-2 line looks in each direction (both directions and the start point in one pass)
+    typedef std::integral_constant<int, 0> K0_; typedef std::integral_constant<int, 1> K1_; typedef std::integral_constant<int, PROJ_KF> KF_; typedef std::integral_constant<int, PROJ_K> KK_;
     // one step size the line-by-line way (a pass per line; the first pass of a set also delivers the error of the starting point)
     auto line_stage = [&](const int st) __attribute__((always_inline)) {
         for (int p = 0; p < 2; p++) {
             if ((r0 == 0 && p == 0) || (r1 == 0 && p == 1)) continue;
-            const int cap = st == 2 ? PROJ_K : 1; // only the largest step keeps moving in the same direction (:359-361)
+            // only the largest step keeps moving in the same direction (:359-361).  The FIRST pass of such a line looks PROJ_KF moves each way (both directions and the start
+            // point in one pass); a walk that accepts them all goes on PROJ_K moves per pass in the direction it has taken
             long long *ed = sh_e[0], *eu = sh_e[1], *eu0 = sh_e[2];
             int       skip = 0, nu0 = 0;
             for (bool first = true;; first = false) { // the downward moves
+                const int cap = st == 2 ? (first ? PROJ_KF : PROJ_K) : 1;
                 const int roomd = (xqd[p] - tap_min[p]) / st, nd = roomd < cap ? roomd : cap;
                 int       nu = 0;
                 if (first) { const int roomu = (tap_max[p] - xqd[p]) / st; nu = roomu < cap ? roomu : cap; }
                 if (nd == 0 && nu == 0) break;
-                eval_line(p, st, nd, nu, !have_err, ed, eu);
+                // (a first pass leaves its upward sums in eu0, where the upward loop below looks for them; the continuation passes of the downward walk have none)
+                if (st != 2) eval_line(p, st, nd, nu, !have_err, ed, eu0, K1_{}, K1_{});
+                else if (first) eval_line(p, st, nd, nu, !have_err, ed, eu0, KF_{}, KF_{});
+                else eval_line(p, st, nd, 0, !have_err, ed, eu, KK_{}, K0_{});
                 if (dbg && tid == 0) atomicAdd(&dbg[2], 1);
-                if (!have_err) { err = ed[PROJ_K]; have_err = true; }
-                if (first) { // (the next writer of eu / eu0 passes block_sums_i64's first barrier before it writes)
-                    nu0 = nu;
-                    if (tid < PROJ_K) eu0[tid] = eu[tid];
-                    __syncthreads();
-                }
+                if (!have_err) { err = lrs_uni64(ed[PROJ_K]); have_err = true; }
+                if (first) nu0 = nu;
                 int  k = 0;
                 bool rejected = false;
                 while (k < nd) {
-                    if (ed[k] > err) { rejected = true; break; }
-                    err = ed[k]; k++; skip = 1;
+                    const long long e = lrs_uni64(ed[k]);
+                    if (e > err) { rejected = true; break; }
+                    err = e; k++; skip = 1;
                     if (st != 2) break;
                 }
                 xqd[p] -= st * k;
                 if (dbg && tid == 0 && st == 2 && first) atomicAdd(&dbg[4 + (k < 9 ? k : 9)], 1); // (diagnostic: moves accepted down in a line's first pass)
-                if (rejected || st != 2 || k < nd || nd < PROJ_K) break;
+                if (rejected || st != 2 || k < nd) break; // (all accepted: look further -- the next pass finds out whether there is room left)
             }
             if (skip) break; // (:372-373: a successful downward move ends the loop over p)
             int nu = nu0;
             for (int pass = 0; nu > 0; pass++) { // the upward moves, from the unchanged point
                 if (pass > 0) {
+                    const int cap = st == 2 ? PROJ_K : 1;
                     const int roomu = (tap_max[p] - xqd[p]) / st;
                     nu = roomu < cap ? roomu : cap;
                     if (nu == 0) break;
-                    eval_line(p, st, 0, nu, false, ed, eu0);
+                    eval_line(p, st, 0, nu, false, ed, eu0, K0_{}, KK_{});
                     if (dbg && tid == 0) atomicAdd(&dbg[2], 1);
                 }
                 int  k = 0;
                 bool rejected = false;
                 while (k < nu) {
-                    if (eu0[k] > err) { rejected = true; break; }
-                    err = eu0[k]; k++;
+                    const long long e = lrs_uni64(eu0[k]);
+                    if (e > err) { rejected = true; break; }
+                    err = e; k++;
                     if (st != 2) break;
                 }
                 xqd[p] += st * k;
                 if (dbg && tid == 0 && st == 2 && pass == 0) atomicAdd(&dbg[14 + (k < 9 ? k : 9)], 1); // (... and up, where no downward move was accepted)
-                if (rejected || st != 2 || k < nu || nu < PROJ_K) break;
+                if (rejected || st != 2 || k < nu) break;
             }
         }
     };
@@ -787,7 +832,7 @@ __global__ __launch_bounds__(PROJ_T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             if (r0 > 0 && r1 > 0 && line_walk != 1 && (st == 1 || line_walk >= 2)) {
                 if (st == 2) sgr_grid_pass<COMPACT, 2>(P, r, f0, f1, r0, r1, tid, xqd[0], 128 - xqd[0] - xqd[1], 2, part, sh_g);
                 else sgr_grid_pass<COMPACT, 1>(P, r, f0, f1, r0, r1, tid, xqd[0], 128 - xqd[0] - xqd[1], 1, part, sh_g);
-                if (!have_err) { err = sh_g[0]; have_err = true; }
+                if (!have_err) { err = lrs_uni64(sh_g[0]); have_err = true; }
                 const int       sx0 = xqd[0], sx1 = xqd[1];
                 const long long serr = err;
                 by_line = st == 2 ? (!sgr_grid_replay<2>(sh_g, 2, true, xqd, err, tap_min, tap_max) || line_walk == 2) : !sgr_grid_replay<1>(sh_g, 1, false, xqd, err, tap_min, tap_max);
@@ -801,6 +846,7 @@ __global__ __launch_bounds__(PROJ_T) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         SgResult o;
         o.err = err; o.xqd[0] = xqd[0]; o.xqd[1] = xqd[1];
         res[(size_t)u * slots + slot0 + slot] = o;
+        if (dbg) { atomicAdd(&dbg[25], (int)(LRS_NOW() - t_wg0)); atomicAdd(&dbg[26], 1); }
     }
 }
 __global__ void lr_sgr_pick_kernel(const SvtHipLrSearchParams P, const SgResult* __restrict__ res, SvtHipLrSearchUnit* __restrict__ out, const int slots, const int n) {
@@ -966,6 +1012,8 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
         fprintf(stderr, "; up (no down move) 0..8,9+:");
         for (int k = 0; k < 10; k++) fprintf(stderr, " %d", c[14 + k]);
         fprintf(stderr, "\n");
+        fprintf(stderr, "SVT_HIP_LR_SG_STATS: %d projection workgroups, %.1f us each on average, of which thread 0 spent %.1f us inside the sample loops of its line passes\n", c[26],
+                c[26] ? c[25] * 0.01 / c[26] : 0.0, c[26] ? c[24] * 0.01 / c[26] : 0.0);
     }
     if (sg_on) HIP_CHECK(hipStreamWaitEvent(st, ev_sg0, 0));
     return rc_wn;

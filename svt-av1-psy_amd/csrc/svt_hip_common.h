@@ -27,6 +27,9 @@ typedef uint32_t svt_u32x4_a2 __attribute__((vector_size(16), aligned(2))); // 1
 typedef uint32_t svt_u32x2_a1 __attribute__((vector_size(8), aligned(1)));  // 8 bytes at any address
 __device__ __forceinline__ svt_u32x4_a2 svt_hip_global_load_x4(const void* p) { return *(const SVT_HIP_GLOBAL_AS svt_u32x4_a2*)p; }
 __device__ __forceinline__ svt_u32x2_a1 svt_hip_global_load_x2(const void* p) { return *(const SVT_HIP_GLOBAL_AS svt_u32x2_a1*)p; }
+#ifndef SVT_HIP_WAVES_PER_EU // (waves per SIMD the register allocation of a kernel is cut for; the CPU emulator defines it as nothing)
+#define SVT_HIP_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
 #ifndef SVT_HIP_OPAQUE_I32
 #define SVT_HIP_OPAQUE_I32(x) asm volatile("" : "+v"(x))
 #endif

@@ -272,6 +272,7 @@ template <typename... P, typename... A> inline void launch_k(void (*k)(P...), di
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
 #define SVT_HIP_GLOBAL_AS /* no address spaces on the CPU */
+#define SVT_HIP_WAVES_PER_EU(lo, hi)
 #define SVT_HIP_OPAQUE_I32(x) ((void)0) /* device build: an empty asm that redefines x so loop-invariant code stays inside the loop */
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); } // lanes run as fibers here: same-wave LDS hand-offs need the rendezvous
 inline void __builtin_amdgcn_sched_barrier(int) {}

@@ -185,7 +185,8 @@ GPU_CASES = [(500, 300, 8, 64, 0, (1, 7, 1, 0), (1, 0, 16, 1, 1), False),
              (330, 170, 8, 64, 0, (1, 3, 0, 0), (1, 10, 16, 1, 1), True),
              (70, 50, 10, 64, 0, (1, 7, 1, 0), (0, 0, 0, 1, 0), False),
              (1000, 90, 8, 256, 0, (0, 7, 0, 0), (1, 9, 10, 1, 1), False),  # one row of wide units (the last one 1.4 units wide)
-             (300, 200, 12, 64, 0, (1, 7, 1, 0), (1, 0, 16, 3, 1), False)]   # 12-bit: the int32 flt planes
+             (300, 200, 12, 64, 0, (1, 7, 1, 0), (1, 0, 16, 3, 1), False),   # 12-bit: the int32 flt planes
+             (300, 380, 10, 256, 0, (0, 7, 0, 0), (1, 0, 16, 5, 1), False)]  # one unit of 114 000 samples (111 per thread of the projection kernel)
 
 
 @pytest.mark.parametrize("walk", ["line", "fallback", "table"])

@@ -33,7 +33,7 @@ for walk in (os.environ.get("WALKS", "default,table,line").split(",")):
     os.environ["SVT_HIP_LR_SG_WALK"] = walk
     for name, wn, sg in (("sg16", (0, 7, 1, 0), (1, 0, 16, 1, 1)), ("sg16_norefine", (0, 7, 1, 0), (1, 0, 16, 1, 0)), ("sg2", (0, 7, 1, 0), (1, 0, 16, 8, 1)), ("wn7", (1, 7, 1, 0), (0, 0, 16, 1, 1)),
                          ("full", (1, 7, 1, 0), (1, 0, 16, 1, 1)), ("fast", (1, 5, 1, 1), (1, 0, 16, 8, 1))):
-        if walk != "default" and name.startswith("wn"):
+        if (walk != "default" and name.startswith("wn")) or (os.environ.get("CONFIGS") and name not in os.environ["CONFIGS"].split(",")):
             continue
         P = pkg.LrSearchParams()
         P.src, P.dgd = d_src.data_ptr(), d_dgd.data_ptr() + (PAD * dgd.shape[1] + PAD) * 2
