@@ -123,8 +123,7 @@ static void seam_av1_cdef_frame_body(SequenceControlSet *scs, PictureControlSet 
     svt_hip_seam_bind(pcs->picture_number);
     /* SVT_HIP_CDEF_SEAM_VERIFY=1 (diagnostic): the reference's own function filters the same picture as well and the two results are compared sample by sample
      * (differences go to stderr); the picture continues with the reference's result. */
-    static int verify = -1;
-    if (verify < 0) { const char *e = getenv("SVT_HIP_CDEF_SEAM_VERIFY"); verify = e && atoi(e); }
+    SEAM_ENV_ONCE(verify, (getenv("SVT_HIP_CDEF_SEAM_VERIFY") && atoi(getenv("SVT_HIP_CDEF_SEAM_VERIFY"))));
     uint8_t *before[3] = {NULL, NULL, NULL}, *device[3] = {NULL, NULL, NULL};
     const size_t vrows[3] = {A.height, (A.height + 1) >> 1, (A.height + 1) >> 1}, vcols[3] = {A.width, (A.width + 1) >> 1, (A.width + 1) >> 1};
     if (verify && filtered)
@@ -261,8 +260,7 @@ static void cdef_seg_search_use1_body(PictureControlSet *pcs, SequenceControlSet
             for (uint32_t sg = 0; sg < pcs->cdef_segments_total_count; sg++) cdef_seg_search_use0(pcs, scs, sg);
             D.n_declined++;
         }
-        static int verify = -1;
-        if (verify < 0) { const char *e = getenv("SVT_HIP_CDEF_SEAM_VERIFY"); verify = e && atoi(e); }
+        SEAM_ENV_ONCE(verify, (getenv("SVT_HIP_CDEF_SEAM_VERIFY") && atoi(getenv("SVT_HIP_CDEF_SEAM_VERIFY"))));
         if (verify) { /* (diagnostic) the reference's own search of every segment, compared with what the device stage stored */
             const int32_t nvfb = (pcs->ppcs->av1_cm->mi_rows + MI_SIZE_64X64 - 1) / MI_SIZE_64X64, nhfb = (pcs->ppcs->av1_cm->mi_cols + MI_SIZE_64X64 - 1) / MI_SIZE_64X64, nfb = nvfb * nhfb;
             uint64_t (*m0)[TOTAL_STRENGTHS] = malloc(sizeof(*m0) * nfb), (*m1)[TOTAL_STRENGTHS] = malloc(sizeof(*m1) * nfb);

@@ -77,14 +77,15 @@ static struct {
     uint64_t        sum[SEAM_DEVS][SEAM_RING * 2][2]; /* per device: (picture id, plane checksum) of what is resident */
     uint64_t        n_per_dev[SEAM_DEVS];
     uint64_t        n_pictures, n_declined, n_sb, n_uploads, n_reuploads, n_registered;
-    double          t_stage, t_hash, t_first, t_dev_lock; /* seconds: in run_picture / run_tf_pair (all threads), hashing planes, the first stage call (session creation,
-                                                           * kernel code loading), holding the device lock */
+    double          t_stage, t_first; /* seconds in run_picture / run_tf_pair (all threads), in the first stage call (session creation, kernel code loading): under `lock` */
+    uint64_t        ns_hash, ns_dev_lock; /* hashing planes, holding a device lock -- added to from under DIFFERENT device locks (or none): relaxed atomics, like n_uploads /
+                                           * n_reuploads (ThreadSanitizer, profiles/r05_tsan_seams.txt) */
     char            why[128];
 } G = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER,
       PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER,
       PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER}, -1};
 
-static int      seam_hash = -1;
+static int      seam_hash_on(void) { SEAM_ENV_ONCE(on, (getenv("SVT_HIP_ME_SEAM_HASH") && atoi(getenv("SVT_HIP_ME_SEAM_HASH")))); return on; } /* SVT_HIP_ME_SEAM_HASH=1 */
 static uint64_t n_invalidated;
 static uint64_t tf_pairs, tf_sb, tf_declined; /* the temporal filter's (picture, reference) pairs through the stage, see the end of this file */
 static void seam_stats(void) {
@@ -100,12 +101,12 @@ static void seam_stats(void) {
         fprintf(o, "stage_calls_on_device_%d %llu\n", svt_hip_seam_device_id(k), (unsigned long long)G.n_per_dev[k]);
     fprintf(o, "planes_invalidated_after_temporal_filtering %llu\n", (unsigned long long)n_invalidated);
     fprintf(o, "ms_in_stage_calls %llu\nms_first_stage_call %llu\nms_holding_device_lock %llu\n", (unsigned long long)(G.t_stage * 1e3),
-            (unsigned long long)(G.t_first * 1e3), (unsigned long long)(G.t_dev_lock * 1e3));
-    if (seam_hash > 0) fprintf(o, "ms_hashing_planes %llu\n", (unsigned long long)(G.t_hash * 1e3));
+            (unsigned long long)(G.t_first * 1e3), (unsigned long long)(G.ns_dev_lock / 1000000));
+    if (seam_hash_on()) fprintf(o, "ms_hashing_planes %llu\n", (unsigned long long)(G.ns_hash / 1000000));
     fclose(o);
 }
 static void seam_init(void) { /* once (pthread_once): ME threads arriving during the initialisation wait instead of seeing "off" */
-    G.mode = 0;
+    __atomic_store_n(&G.mode, 0, __ATOMIC_RELEASE); /* (also read by svt_hip_seam_me_invalidate, which does not pass through the once) */
     const char *e = getenv("SVT_HIP_ME_SEAM");
     if (!e || !atoi(e) || !getenv("SVT_HIP")) return;
 #define SYM(field, name) *(void **)&abi.field = dlsym(RTLD_DEFAULT, name)
@@ -119,7 +120,7 @@ static void seam_init(void) { /* once (pthread_once): ME threads arriving during
     }
     atexit(seam_stats);
     fprintf(stderr, "SVT_HIP_ME_SEAM: open-loop ME runs as one device stage per picture\n");
-    G.mode = 1;
+    __atomic_store_n(&G.mode, 1, __ATOMIC_RELEASE);
 }
 static int seam_on(void) {
     static pthread_once_t once = PTHREAD_ONCE_INIT;
@@ -134,14 +135,11 @@ static uint64_t plane_sum_(const EbPictureBufferDesc *p);
  * checksum of round 3 (every 8th row: right only with high probability, 7 ms of hashing per 60 frames) remains as a debugging aid: SVT_HIP_ME_SEAM_HASH=1 compares
  * on top and counts what the explicit rule missed (`plane_reuploads_by_checksum`, expected 0). */
 static uint64_t plane_sum(const EbPictureBufferDesc *p) { /* called OUTSIDE the locks */
-    if (seam_hash < 0) { const char *e = getenv("SVT_HIP_ME_SEAM_HASH"); seam_hash = e && atoi(e); }
-    if (!seam_hash) return 2; /* (constant: the comparison with the stored value never asks for an upload) */
+    if (!seam_hash_on()) return 2; /* (constant: the comparison with the stored value never asks for an upload) */
     const double   t0 = seam_now();
     const uint64_t h  = plane_sum_(p);
     const double   dt = seam_now() - t0;
-    pthread_mutex_lock(&G.lock);
-    G.t_hash += dt;
-    pthread_mutex_unlock(&G.lock);
+    __atomic_fetch_add(&G.ns_hash, (uint64_t)(dt * 1e9), __ATOMIC_RELAXED);
     return h;
 }
 /* content check of a picture's luma: every 8th row of the visible samples (the padding is a function of them).  The only thing that rewrites a picture after it may
@@ -162,7 +160,7 @@ static uint64_t plane_sum_(const EbPictureBufferDesc *p) {
 #define SEAM_ID(pcs) ((uint64_t)(pcs)->picture_number * 2 + ((pcs)->is_overlay ? 1 : 0))
 /* the picture's host planes were rewritten (temporal filtering): whatever copy a device holds is stale */
 void svt_hip_seam_me_invalidate(unsigned long long picture_number) {
-    if (G.mode != 1) return; /* (not seam_on(): a temporal filter that runs before any ME call has nothing resident to invalidate) */
+    if (__atomic_load_n(&G.mode, __ATOMIC_ACQUIRE) != 1) return; /* (not seam_on(): a temporal filter that runs before any ME call has nothing resident to invalidate) */
     for (int di = 0; di < SEAM_DEVS; di++) {
         if (!__atomic_load_n(&G.session[di], __ATOMIC_ACQUIRE)) continue;
         pthread_mutex_lock(&G.dev[di]);
@@ -198,16 +196,16 @@ static int sum_slot(int di, uint64_t id, int make) {
 static int ensure_resident(int di, uint64_t id, const EbPictureBufferDesc *pic, const SvtHipMeStageParams *S, uint64_t now, int *pend, int *n_pend) {
     const int k = sum_slot(di, id, 1);
     if (abi.resident(G.session[di], (int64_t)id)) {
-        if (seam_hash <= 0 || G.sum[di][k][1] == now) return 0; /* (without the checksum aid a resident picture is current: invalidation is explicit) */
+        if (!seam_hash_on() || G.sum[di][k][1] == now) return 0; /* (without the checksum aid a resident picture is current: invalidation is explicit) */
         abi.invalidate(G.session[di], (int64_t)id); /* e.g. temporally filtered in place after it was uploaded */
-        G.n_reuploads++;
+        __atomic_fetch_add(&G.n_reuploads, 1, __ATOMIC_RELAXED);
     }
     const int slot = abi.submit_stage(G.session[di], (int64_t)id, pic->buffer_y, NULL, 0, S, NULL);
     if (slot < 0) return slot;
     if (*n_pend < 16) pend[(*n_pend)++] = slot;
     else abi.wait(G.session[di], slot);
     G.sum[di][k][1] = now;
-    G.n_uploads++;
+    __atomic_fetch_add(&G.n_uploads, 1, __ATOMIC_RELAXED);
     return 0;
 }
 
@@ -421,8 +419,8 @@ static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *
     if (!rc) {
         /* the source: (re)uploaded when its content differs from what is resident (the same picture may have served as a reference before its own ME) */
         const int ks = sum_slot(di, SEAM_ID(pcs), 1);
-        if (seam_hash > 0 && abi.resident(ses, (int64_t)SEAM_ID(pcs)) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)SEAM_ID(pcs)); G.n_reuploads++; }
-        if (!abi.resident(ses, (int64_t)SEAM_ID(pcs))) G.n_uploads++;
+        if (seam_hash_on() && abi.resident(ses, (int64_t)SEAM_ID(pcs)) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)SEAM_ID(pcs)); __atomic_fetch_add(&G.n_reuploads, 1, __ATOMIC_RELAXED); }
+        if (!abi.resident(ses, (int64_t)SEAM_ID(pcs))) __atomic_fetch_add(&G.n_uploads, 1, __ATOMIC_RELAXED);
         G.sum[di][ks][1] = now;
         slot = abi.submit_stage(ses, (int64_t)SEAM_ID(pcs), src->buffer_y, ref_ids, n_refs, &S, &H);
         if (slot < 0) {
@@ -432,7 +430,7 @@ static int run_picture(SeamPicture *P, PictureParentControlSet *pcs, MeContext *
         }
     }
     G.n_per_dev[di]++;
-    G.t_dev_lock += seam_now() - td0;
+    __atomic_fetch_add(&G.ns_dev_lock, (uint64_t)((seam_now() - td0) * 1e9), __ATOMIC_RELAXED);
     pthread_mutex_unlock(&G.dev[di]);
     for (int k = 0; k < n_pend; k++) abi.wait(ses, pend[k]); /* the reference uploads (outside the locks; complete before the stage below is) */
     if (rc) return -1;
@@ -444,8 +442,7 @@ static EbErrorType seam_motion_estimation_b64_body(PictureParentControlSet *pcs,
                                               MeContext *me_ctx, EbPictureBufferDesc *input_ptr) {
     if (!seam_on() || me_ctx->me_type != ME_OPEN_LOOP)
         return svt_aom_motion_estimation_b64(pcs, b64_index, b64_origin_x, b64_origin_y, me_ctx, input_ptr);
-    static int verify = -1; /* SVT_HIP_ME_SEAM_VERIFY=1: run the reference's function for the SB as well and report the first difference (diagnostic) */
-    if (verify < 0) verify = getenv("SVT_HIP_ME_SEAM_VERIFY") != NULL;
+    SEAM_ENV_ONCE(verify, (getenv("SVT_HIP_ME_SEAM_VERIFY") != NULL)); /* SVT_HIP_ME_SEAM_VERIFY=1: run the reference's function for the SB as well and report the first difference (diagnostic) */
     /* The common case -- the picture's stage has run, this SB only fetches its slice -- takes NO lock: 510 SBs x every picture x dozens of ME threads on one mutex
      * cost more host CPU per SB (14 us) than the reference's AVX2 search of the SB (10 us; profiles/r04_call2_*).  A record in state 2 / 3 is immutable until its
      * last SB has fetched (consumed == n_sb), and every SB of the picture comes here exactly once, so a reader that found it cannot lose it. */
@@ -598,14 +595,14 @@ static int run_tf_pair(SeamTfPair *T, PictureParentControlSet *pcs, MeContext *c
     }
     if (!rc) {
         const int ks = sum_slot(di, SEAM_ID(pcs), 1);
-        if (seam_hash > 0 && abi.resident(ses, (int64_t)SEAM_ID(pcs)) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)SEAM_ID(pcs)); G.n_reuploads++; }
-        if (!abi.resident(ses, (int64_t)SEAM_ID(pcs))) G.n_uploads++;
+        if (seam_hash_on() && abi.resident(ses, (int64_t)SEAM_ID(pcs)) && G.sum[di][ks][1] != now) { abi.invalidate(ses, (int64_t)SEAM_ID(pcs)); __atomic_fetch_add(&G.n_reuploads, 1, __ATOMIC_RELAXED); }
+        if (!abi.resident(ses, (int64_t)SEAM_ID(pcs))) __atomic_fetch_add(&G.n_uploads, 1, __ATOMIC_RELAXED);
         G.sum[di][ks][1] = now;
         slot = abi.submit_stage(ses, (int64_t)SEAM_ID(pcs), src->buffer_y, ref_ids, 1, &S, &H);
         if (slot < 0) rc = decline("svt_hip_me_session_submit_stage (ME_MCTF form) refused the parameters");
     }
     G.n_per_dev[di]++;
-    G.t_dev_lock += seam_now() - td0;
+    __atomic_fetch_add(&G.ns_dev_lock, (uint64_t)((seam_now() - td0) * 1e9), __ATOMIC_RELAXED);
     pthread_mutex_unlock(&G.dev[di]);
     for (int k = 0; k < n_pend; k++) abi.wait(ses, pend[k]);
     if (rc) return -1;

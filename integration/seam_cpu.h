@@ -20,9 +20,14 @@ static inline unsigned long long seam_cpu_ns(void) {
  * different time than the reference's own function (a latent race of the reference that a timing change exposes). */
 #include <stdlib.h>
 #include <unistd.h>
+/* A setting read from the environment on first use.  Every thread that gets there computes the same value, but several may get there together: relaxed atomics keep
+ * that a defined program (found by ThreadSanitizer on the seams' lazy statics: profiles/r05_tsan_seams.txt). */
+#define SEAM_ENV_ONCE(var, expr)                                                \
+    static int var##_cache_ = -1;                                               \
+    int        var          = __atomic_load_n(&var##_cache_, __ATOMIC_RELAXED); \
+    if (var < 0) { var = (expr); __atomic_store_n(&var##_cache_, var, __ATOMIC_RELAXED); }
 static inline void seam_test_delay(void) {
-    static int us_ = -1;
-    if (us_ < 0) { const char *e_ = getenv("SVT_HIP_SEAM_DELAY_US"); us_ = e_ ? atoi(e_) : 0; }
+    SEAM_ENV_ONCE(us_, (getenv("SVT_HIP_SEAM_DELAY_US") ? abs(atoi(getenv("SVT_HIP_SEAM_DELAY_US"))) : 0));
     if (us_ > 0) usleep((useconds_t)us_);
 }
 #define SEAM_CPU_BEGIN() const int seam_cpu_on_ = svt_hip_seam_cpu_on(); const unsigned long long seam_cpu_t0_ = seam_cpu_on_ ? seam_cpu_ns() : 0

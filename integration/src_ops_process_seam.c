@@ -235,8 +235,7 @@ static int tpl_recon_picture(EncodeContext *enc_ctx, SequenceControlSet *scs, Pi
         if (P->refs[i].valid) { ids.src_ref[i] = fused ? P->refs[i].picture_number + 1 : 0; ids.rec_ref[i] = tpl_rec_id(H.ref_buf[i], 0); }
     ids.recon = tpl_rec_id(rec->buffer_y, 1);
     ids.recon_width = rec->width; ids.recon_height = rec->height; ids.recon_org_x = rec->org_x; ids.recon_org_y = rec->org_y;
-    static int resident = -1; /* SVT_HIP_TPL_RESIDENT=0: every call uploads its planes again (A/B and bisecting aid) */
-    if (resident < 0) { const char *e_ = getenv("SVT_HIP_TPL_RESIDENT"); resident = !(e_ && !atoi(e_)); }
+    SEAM_ENV_ONCE(resident, (!(getenv("SVT_HIP_TPL_RESIDENT") && !atoi(getenv("SVT_HIP_TPL_RESIDENT"))))); /* SVT_HIP_TPL_RESIDENT=0: every call uploads its planes again (A/B and bisecting aid) */
     const int    rc = TS.fused_host ? TS.fused_host(&R, &S, &H, resident ? &ids : NULL, fused ? tot : NULL, fused ? mvs : NULL, fused ? cand : NULL, st, rec->buffer_y,
                                                     rec->luma_size / rec->stride_y, out)
                                     : TS.recon_host(&R, &H, st, rec->buffer_y, rec->luma_size / rec->stride_y, out);

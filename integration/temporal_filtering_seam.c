@@ -119,7 +119,7 @@ static void sp_stats(void) {
     fclose(o);
 }
 static int sp_on(void) {
-    if (SPS.mode < 0) {
+    if (__atomic_load_n(&SPS.mode, __ATOMIC_ACQUIRE) < 0) { /* (double-checked: the fast path reads outside the lock) */
         pthread_mutex_lock(&SPS.lock);
         if (SPS.mode < 0) {
             const char *e = getenv("SVT_HIP_TF_SUBPEL_SEAM");
@@ -130,11 +130,11 @@ static int sp_on(void) {
                 atexit(sp_stats);
                 fprintf(stderr, "SVT_HIP_TF_SUBPEL_SEAM: the temporal filter's sub-pel refinement runs as one device call per (picture, reference) pair\n");
             }
-            SPS.mode = m;
+            __atomic_store_n(&SPS.mode, m, __ATOMIC_RELEASE);
         }
         pthread_mutex_unlock(&SPS.lock);
     }
-    return SPS.mode;
+    return __atomic_load_n(&SPS.mode, __ATOMIC_ACQUIRE);
 }
 static int is_bilinear(uint32_t interp_filters) { return interp_filters == (uint32_t)av1_make_interp_filters(BILINEAR, BILINEAR); }
 
@@ -279,7 +279,7 @@ static void tfd_stats(void) {
     fclose(o);
 }
 static int tfd_on(void) {
-    if (TFD.mode < 0) {
+    if (__atomic_load_n(&TFD.mode, __ATOMIC_ACQUIRE) < 0) { /* (double-checked: the fast path reads outside the lock) */
         pthread_mutex_lock(&TFD.lock);
         if (TFD.mode < 0) {
             const char *e = getenv("SVT_HIP_TF_SEAM");
@@ -290,11 +290,11 @@ static int tfd_on(void) {
                 atexit(tfd_stats);
                 fprintf(stderr, "SVT_HIP_TF_SEAM: the temporal filter of a central picture runs as one device stage\n");
             }
-            TFD.mode = m;
+            __atomic_store_n(&TFD.mode, m, __ATOMIC_RELEASE);
         }
         pthread_mutex_unlock(&TFD.lock);
     }
-    return TFD.mode;
+    return __atomic_load_n(&TFD.mode, __ATOMIC_ACQUIRE);
 }
 static int tfd_decline(const char *why) { TFD.last_decline = why; return -1; }
 
