@@ -64,6 +64,19 @@ struct hipDeviceProp_t {
     size_t totalGlobalMem;
 };
 
+// ThreadSanitizer build of the emulator (profiles/r05_tsan_seams.txt: g++ -fsanitize=thread over the same sources, loaded by a TSan build of the reference encoder): every
+// lane is a ucontext fiber, and TSan has to be told about each switch or it sees one thread jumping between 1 024 stacks.
+#if defined(__SANITIZE_THREAD__)
+extern "C" {
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void  __tsan_destroy_fiber(void* fiber);
+void  __tsan_switch_to_fiber(void* fiber, unsigned flags);
+}
+#define HIPEMU_TSAN_SWITCH(f) __tsan_switch_to_fiber((f), 0)
+#else
+#define HIPEMU_TSAN_SWITCH(f) ((void)0)
+#endif
 namespace hipemu {
 constexpr int WAVE        = 64;
 constexpr int MAX_THREADS = 1024;
@@ -75,6 +88,8 @@ struct Fiber {
 };
 struct State {
     ucontext_t            main_ctx;
+    void*                 tsan_main = nullptr;        // (ThreadSanitizer builds: the launching thread's own context ...
+    void*                 tsan_fib[MAX_THREADS] = {}; //  ... and one per lane of the running workgroup)
     Fiber                 fib[MAX_THREADS];
     char*                 stacks = nullptr;
     int                   cur = 0, nthreads = 0, alive = 0;
@@ -90,7 +105,10 @@ inline State g;
 inline uint3_emu tIdx, bIdx;
 inline dim3      bDim, gDim;
 
-inline void yield() { swapcontext(&g.fib[g.cur].ctx, &g.main_ctx); }
+inline void yield() {
+    HIPEMU_TSAN_SWITCH(g.tsan_main);
+    swapcontext(&g.fib[g.cur].ctx, &g.main_ctx);
+}
 inline void set_tid(int t) {
     tIdx.x = t % g.block_dim.x;
     tIdx.y = (t / g.block_dim.x) % g.block_dim.y;
@@ -145,6 +163,7 @@ inline void fiber_entry() {
         g.wbar_count[w] = 0;
         g.wbar_gen[w]++;
     }
+    HIPEMU_TSAN_SWITCH(g.tsan_main);
     swapcontext(&g.fib[g.cur].ctx, &g.main_ctx);
 }
 inline void run_block(int nthreads) {
@@ -167,6 +186,10 @@ inline void run_block(int nthreads) {
         g.fib[t].done                 = false;
         makecontext(&g.fib[t].ctx, (void (*)())fiber_entry, 0);
     }
+#if defined(__SANITIZE_THREAD__)
+    g.tsan_main = __tsan_get_current_fiber();
+    for (int t = 0; t < nthreads; t++) g.tsan_fib[t] = __tsan_create_fiber(0);
+#endif
     int remaining = nthreads;
     while (remaining > 0) {
         remaining = 0;
@@ -174,10 +197,14 @@ inline void run_block(int nthreads) {
             if (g.fib[t].done) continue;
             g.cur = t;
             set_tid(t);
+            HIPEMU_TSAN_SWITCH(g.tsan_fib[t]);
             swapcontext(&g.main_ctx, &g.fib[t].ctx);
             if (!g.fib[t].done) remaining++;
         }
     }
+#if defined(__SANITIZE_THREAD__)
+    for (int t = 0; t < nthreads; t++) __tsan_destroy_fiber(g.tsan_fib[t]);
+#endif
 }
 // The fiber state (and every kernel's `__shared__` storage) is global, so launches from different host threads -- the encoder's
 // worker threads in tests/test_encoder_identity.py -- are serialised.
