@@ -591,8 +591,10 @@ __global__ __launch_bounds__(256, MINB) void cdef_frame_kernel(const SvtHipCdefP
     {   // stage the tile (cdef_process.c:208-228): real pixels where the neighbouring filter block exists, else OUTSIDE
         const int x0 = fbc * bw, y0 = fbr * bh;
         const int xs = x0 - (fbc != 0 ? HB : 0), ys = y0 - (fbr != 0 ? VB : 0);
-        const int xe = (x0 + bw < pw ? x0 + bw : pw) + (fbc + 1 < nhfb ? HB : 0);
-        const int ye = (y0 + bh < ph ? y0 + bh : ph) + (fbr + 1 < nvfb ? VB : 0);
+        // (never past the picture: a 4:2:0 chroma plane's last filter block can be 4 samples wide -- narrower than the 8-sample halo its left neighbour stages; the
+        // taps reach 2 samples, so what lies beyond the picture is never used, but it must not be READ either: AddressSanitizer on the emulator, last row of a plane)
+        const int xe_ = (x0 + bw < pw ? x0 + bw : pw) + (fbc + 1 < nhfb ? HB : 0), xe = xe_ < pw ? xe_ : pw;
+        const int ye_ = (y0 + bh < ph ? y0 + bh : ph) + (fbr + 1 < nvfb ? VB : 0), ye = ye_ < ph ? ye_ : ph;
         stage_tile<PIX, 3>(tile_raw, pitch, bh + 2 * VB, (bw + 2 * HB) >> 3, (const PIX*)P.recon, P.recon_stride, y0 - VB, x0 - HB, ys, ye, xs, xe, OUTSIDE, tid);
         if (MODE == 1)
             stage_tile<PIX, 2>(tile_raw + (bh + 2 * VB) * pitch, bw, bh, bw >> 3, (const PIX*)P.source, P.source_stride, y0, x0, y0,

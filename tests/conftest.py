@@ -21,7 +21,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_DIR = os.path.join(ROOT, "svt-av1-psy_amd")
-EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "libsvtav1_hipemu.so")
+# (SVT_HIP_EMU_LIB: another build of the emulator -- e.g. g++ -fsanitize=address over the same sources, run as `LD_PRELOAD=$(gcc -print-file-name=libasan.so) python -m pytest ...`:
+#  device buffers are plain heap blocks there, so a kernel's out-of-bounds access is a report with a stack)
+EMU_LIB = os.environ.get("SVT_HIP_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "_build", "libsvtav1_hipemu.so")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libsvtref.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
