@@ -100,25 +100,28 @@ template <int D> __device__ __forceinline__ int dir_cost(const uint16_t* img, co
             const int idx = D == 0 ? i + j : D == 1 ? i + j / 2 : D == 2 ? i : D == 3 ? 3 + i - j / 2 : D == 4 ? 7 + i - j : D == 5 ? 3 - i / 2 + j : D == 6 ? j : i / 2 + j;
             partial[idx] += x;
         }
-    int cost = 0;
+    // (unsigned arithmetic: the lanes of units outside the picture or skipped run the same code on whatever their tile holds -- OUTSIDE markers included --, and their
+    // results are dropped; a real unit's cost is at most 8 x 1 024^2 x 105 < 2^31 as in the reference)
+    auto sq = [](const int p) { return (uint32_t)p * (uint32_t)p; };
+    uint32_t cost = 0;
     if (D == 2 || D == 6) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) cost += partial[i] * partial[i];
-        cost *= 105;
+        for (int i = 0; i < 8; i++) cost += sq(partial[i]);
+        cost *= 105u;
     } else if (D == 0 || D == 4) {
-        constexpr int div[8] = {840, 420, 280, 210, 168, 140, 120, 105};
+        constexpr uint32_t div[8] = {840, 420, 280, 210, 168, 140, 120, 105};
 #pragma unroll
-        for (int i = 0; i < 7; i++) cost += (partial[i] * partial[i] + partial[14 - i] * partial[14 - i]) * div[i];
-        cost += partial[7] * partial[7] * 105;
+        for (int i = 0; i < 7; i++) cost += (sq(partial[i]) + sq(partial[14 - i])) * div[i];
+        cost += sq(partial[7]) * 105u;
     } else {
 #pragma unroll
-        for (int j = 0; j < 5; j++) cost += partial[3 + j] * partial[3 + j];
-        cost *= 105;
-        constexpr int div2[3] = {420, 210, 140};
+        for (int j = 0; j < 5; j++) cost += sq(partial[3 + j]);
+        cost *= 105u;
+        constexpr uint32_t div2[3] = {420, 210, 140};
 #pragma unroll
-        for (int j = 0; j < 3; j++) cost += (partial[j] * partial[j] + partial[10 - j] * partial[10 - j]) * div2[j];
+        for (int j = 0; j < 3; j++) cost += (sq(partial[j]) + sq(partial[10 - j])) * div2[j];
     }
-    return cost;
+    return (int)cost;
 }
 // lane q of a quad evaluates directions q and q+4; returns best dir / var in every lane of the quad
 __device__ __forceinline__ void quad_find_dir(const uint16_t* img, const int pitch, const int coeff_shift, const int q, int& best_dir, int& var) {
@@ -175,16 +178,17 @@ __device__ __forceinline__ uint32_t dot2(const uint32_t a, const uint32_t b, con
 __device__ __forceinline__ s16x2 pk_minu(const s16x2 a, const s16x2 b) { const u16x2 x = (u16x2)a, y = (u16x2)b; return (s16x2)(x < y ? x : y); }
 struct TapMag { s16x2 ad, sg; };
 __device__ __forceinline__ TapMag tap_mag(const s16x2 t, const s16x2 x) {
-    const s16x2 z = {0, 0}, one = {1, 1}, diff = t - x;
+    // (unsigned subtractions: an OUTSIDE tap is 0x8000, and 0x8000 - x / the negation of -32768 are meant to wrap -- as the packed 16-bit instructions do)
+    const s16x2 one = {1, 1}, diff = (s16x2)((u16x2)t - (u16x2)x);
     TapMag m;
-    m.ad = pk_max(diff, z - diff);
+    m.ad = pk_max(diff, (s16x2)(u16x2{0, 0} - (u16x2)diff));
     m.sg = (diff >> 15) | one;
     return m;
 }
 // the same in one piece, for passes that evaluate ONE strength per tap (the apply pass): two packed operations fewer than magnitude + sign there
 __device__ __forceinline__ s16x2 constrain2(const s16x2 diff, const s16x2 thr, const s16x2 shift) {
     const s16x2 z  = {0, 0};
-    const s16x2 ad = pk_max(diff, z - diff);
+    const s16x2 ad = pk_max(diff, (s16x2)(u16x2{0, 0} - (u16x2)diff)); // (wraps for -32768, see tap_mag)
     const s16x2 m  = (s16x2)__builtin_elementwise_sub_sat((u16x2)thr, (u16x2)(ad >> shift));
     return pk_max(pk_min(diff, m), z - m);
 }
@@ -236,7 +240,8 @@ template <int K0, int K1> __device__ __forceinline__ void load_taps_range(const 
 // SHARED: the caller evaluates several strengths on the same taps (magnitude / sign form, shared through common subexpressions)
 template <bool SHARED>
 __device__ __forceinline__ s16x2 pri_sum(const s16x2 x, const s16x2 (&t)[12], const s16x2 thr, const s16x2 sh, const s16x2 w0, const s16x2 w1) {
-    if (!SHARED) return w0 * (constrain2(t[0] - x, thr, sh) + constrain2(t[1] - x, thr, sh)) + w1 * (constrain2(t[2] - x, thr, sh) + constrain2(t[3] - x, thr, sh));
+    auto d = [&](const int k) { return (s16x2)((u16x2)t[k] - (u16x2)x); }; // (wrapping, see tap_mag)
+    if (!SHARED) return w0 * (constrain2(d(0), thr, sh) + constrain2(d(1), thr, sh)) + w1 * (constrain2(d(2), thr, sh) + constrain2(d(3), thr, sh));
     const TapMag m0 = tap_mag(t[0], x), m1 = tap_mag(t[1], x), m2 = tap_mag(t[2], x), m3 = tap_mag(t[3], x);
     const s16x2  k0 = constrain_mag(m0.ad, thr, sh) * m0.sg + constrain_mag(m1.ad, thr, sh) * m1.sg;
     const s16x2  k1 = constrain_mag(m2.ad, thr, sh) * m2.sg + constrain_mag(m3.ad, thr, sh) * m3.sg;
@@ -252,8 +257,8 @@ __device__ __forceinline__ s16x2 sec_sum(const s16x2 x, const s16x2 (&t)[12], co
             k0 += constrain_mag(a.ad, thr, sh) * a.sg;
             k1 += constrain_mag(b.ad, thr, sh) * b.sg;
         } else {
-            k0 += constrain2(t[k] - x, thr, sh);
-            k1 += constrain2(t[k + 4] - x, thr, sh);
+            k0 += constrain2((s16x2)((u16x2)t[k] - (u16x2)x), thr, sh);
+            k1 += constrain2((s16x2)((u16x2)t[k + 4] - (u16x2)x), thr, sh);
         }
     }
     return k0 + k0 + k1;
@@ -317,25 +322,28 @@ template <int D> __device__ __forceinline__ int dir_cost_regs(const s16x2 (&px)[
             const int idx = D == 0 ? i + j : D == 1 ? i + j / 2 : D == 2 ? i : D == 3 ? 3 + i - j / 2 : D == 4 ? 7 + i - j : D == 5 ? 3 - i / 2 + j : D == 6 ? j : i / 2 + j;
             partial[idx] += x;
         }
-    int cost = 0;
+    // (unsigned arithmetic: the lanes of units outside the picture or skipped run the same code on whatever their tile holds -- OUTSIDE markers included --, and their
+    // results are dropped; a real unit's cost is at most 8 x 1 024^2 x 105 < 2^31 as in the reference)
+    auto sq = [](const int p) { return (uint32_t)p * (uint32_t)p; };
+    uint32_t cost = 0;
     if (D == 2 || D == 6) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) cost += partial[i] * partial[i];
-        cost *= 105;
+        for (int i = 0; i < 8; i++) cost += sq(partial[i]);
+        cost *= 105u;
     } else if (D == 0 || D == 4) {
-        constexpr int div[8] = {840, 420, 280, 210, 168, 140, 120, 105};
+        constexpr uint32_t div[8] = {840, 420, 280, 210, 168, 140, 120, 105};
 #pragma unroll
-        for (int i = 0; i < 7; i++) cost += (partial[i] * partial[i] + partial[14 - i] * partial[14 - i]) * div[i];
-        cost += partial[7] * partial[7] * 105;
+        for (int i = 0; i < 7; i++) cost += (sq(partial[i]) + sq(partial[14 - i])) * div[i];
+        cost += sq(partial[7]) * 105u;
     } else {
 #pragma unroll
-        for (int j = 0; j < 5; j++) cost += partial[3 + j] * partial[3 + j];
-        cost *= 105;
-        constexpr int div2[3] = {420, 210, 140};
+        for (int j = 0; j < 5; j++) cost += sq(partial[3 + j]);
+        cost *= 105u;
+        constexpr uint32_t div2[3] = {420, 210, 140};
 #pragma unroll
-        for (int j = 0; j < 3; j++) cost += (partial[j] * partial[j] + partial[10 - j] * partial[10 - j]) * div2[j];
+        for (int j = 0; j < 3; j++) cost += (sq(partial[j]) + sq(partial[10 - j])) * div2[j];
     }
-    return cost;
+    return (int)cost;
 }
 // Direction search of all 64 units of a filter block by the whole workgroup, free of divergence: wave w evaluates directions w and w + 4
 // (a wave-uniform choice) for unit = lane, reading the unit with eight 16-byte LDS loads; the four partial winners meet in LDS.
@@ -352,7 +360,7 @@ __device__ __forceinline__ void block_find_dir(const uint16_t* in, const int pit
         for (int i = 0; i < 8; i++) {
             const Row8A16 r = *(const Row8A16*)(img + i * pitch);
 #pragma unroll
-            for (int j = 0; j < 4; j++) px[i][j] = (as_pk(r.v[j]) >> csv) - c128;
+            for (int j = 0; j < 4; j++) px[i][j] = (s16x2)((u16x2)(as_pk(r.v[j]) >> csv) - (u16x2)c128); // (wrapping: an OUTSIDE marker of a unit whose result is dropped)
         }
         int a, o;
         if (w == 0) { a = dir_cost_regs<0>(px); o = dir_cost_regs<4>(px); }

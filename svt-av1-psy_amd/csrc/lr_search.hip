@@ -580,7 +580,7 @@ __device__ __forceinline__ void sgr_grid_pass(const SvtHipLrSearchParams& P, con
     for (int k = 0; k < N; k++) acc[k] = 0;
     for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
         // ((v >> 11) - sp == (v - (sp << 11)) >> 11 exactly: the source sample is folded into v once, a candidate is then an add, a shift and a multiply-add)
-        const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10) - (sp << 11), dA = s * (a0 - a1), dB = s * a1;
+        const int v = uu * 128 + xq0 * a0 + xq1 * a1 + (1 << 10) - sp * 2048, dA = s * (a0 - a1), dB = s * a1; // (* 128, * 2048: uu << 7, sp << 11 for values of either sign)
         auto sq = [&](const int vv) -> Acc { const int e = vv >> 11; return COMPACT ? (Acc)((uint32_t)e * (uint32_t)e) : (Acc)((long long)e * e); };
         acc[0] += sq(v);
 #pragma unroll
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(PROJ_T) SVT_HIP_WAVES_PER_EU(5, 5) void lr_sgr_proj
         ad[PROJ_K] = 0;
         const unsigned long long t_s0 = (dbg && tid == 0) ? LRS_NOW() : 0;
         for_unit_samples<COMPACT>(P, r, f0, f1, r0, r1, tid, [&](const int uu, const int sp, const int a0, const int a1) {
-            const int v = (uu << 7) + xq0 * a0 + xq1 * a1 + (1 << 10) - (sp << 11), dv = st * (c0 * a0 + c1 * a1);
+            const int v = uu * 128 + xq0 * a0 + xq1 * a1 + (1 << 10) - sp * 2048, dv = st * (c0 * a0 + c1 * a1);
             auto sq = [&](const int vv) -> Acc { const int e = vv >> 11; return COMPACT ? (Acc)((uint32_t)e * (uint32_t)e) : (Acc)((long long)e * e); };
             int vd = v, vu = v;
 #pragma unroll

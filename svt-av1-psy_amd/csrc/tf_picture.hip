@@ -97,8 +97,8 @@ __global__ __launch_bounds__(256) void tf_pic_descs_kernel(const PicArgs A, cons
     d.pu_x = (uint16_t)(x0 + lx); d.pu_y = (uint16_t)(y0 + ly);
     d.bsize = (uint8_t)(wanted ? bs : 0);
     d.bilinear = (uint8_t)(bs >= 32 ? A.P.use_2tap : 0); // (:1801-1804, :1911-1914; the 16x16 and 8x8 searches always take the regular kernels)
-    d.mv_x = (int16_t)((from_sc ? A.hme_sc[2 * pair] : (int16_t)(mv & 0xffffu)) << 3);
-    d.mv_y = (int16_t)((from_sc ? A.hme_sc[2 * pair + 1] : (int16_t)(mv >> 16)) << 3);
+    d.mv_x = (int16_t)((from_sc ? A.hme_sc[2 * pair] : (int16_t)(mv & 0xffffu)) * 8);
+    d.mv_y = (int16_t)((from_sc ? A.hme_sc[2 * pair + 1] : (int16_t)(mv >> 16)) * 8);
     d.pad = 0;
     A.sp_descs[res_index(A, pair, (int)slot)] = d;
 }

@@ -117,12 +117,12 @@ __global__ __launch_bounds__(256) void tpl_src_kernel(const SvtHipTplSrcParams P
             if (ok) {
                 const SvtHipTplRef& R = s_refs[rf];
                 const uint32_t m = mv_base[((size_t)sb * n_pus + pu) * P.max_refs + (list ? P.max_l0 : 0) + ref];
-                xm = (int)(int16_t)((int16_t)(m & 0xffff) << 3);
-                ym = (int)(int16_t)((int16_t)(m >> 16) << 3);
-                if (x0 + (xm >> 3) < -TPL_PAD) xm = (int)(int16_t)((-TPL_PAD - x0) << 3);
-                if (x0 + SIZE + (xm >> 3) > TPL_PAD + (int)R.max_width - 1) xm = (int)(int16_t)(((TPL_PAD + (int)R.max_width - 1) - (x0 + SIZE)) << 3);
-                if (y0 + (ym >> 3) < -TPL_PAD) ym = (int)(int16_t)((-TPL_PAD - y0) << 3);
-                if (y0 + SIZE + (ym >> 3) > TPL_PAD + (int)R.max_height - 1) ym = (int)(int16_t)(((TPL_PAD + (int)R.max_height - 1) - (y0 + SIZE)) << 3);
+                xm = (int)(int16_t)((int16_t)(m & 0xffff) * 8);
+                ym = (int)(int16_t)((int16_t)(m >> 16) * 8);
+                if (x0 + (xm >> 3) < -TPL_PAD) xm = (int)(int16_t)((-TPL_PAD - x0) * 8);
+                if (x0 + SIZE + (xm >> 3) > TPL_PAD + (int)R.max_width - 1) xm = (int)(int16_t)(((TPL_PAD + (int)R.max_width - 1) - (x0 + SIZE)) * 8);
+                if (y0 + (ym >> 3) < -TPL_PAD) ym = (int)(int16_t)((-TPL_PAD - y0) * 8);
+                if (y0 + SIZE + (ym >> 3) > TPL_PAD + (int)R.max_height - 1) ym = (int)(int16_t)(((TPL_PAD + (int)R.max_height - 1) - (y0 + SIZE)) * 8);
                 load_row<NW>(rrow, ref_base + R.plane_off + (size_t)((int)R.org_y + y0 + t + ym / 8) * R.stride + (int)R.org_x + x0 + xm / 8);
             }
         }

@@ -420,11 +420,11 @@ __global__ __launch_bounds__(64) void tpl_full_src_kernel(const SvtHipTplSrcPara
         const SvtHipTplRef& R = S.refs[rf];
         if (!R.valid) continue;
         const uint32_t m = mv_base[((size_t)sb * n_pus + pu) * P.max_refs + (list ? P.max_l0 : 0) + ref];
-        int xm = (int)(int16_t)((int16_t)(m & 0xffff) << 3), ym = (int)(int16_t)((int16_t)(m >> 16) << 3);
-        if (x0 + (xm >> 3) < -TPL_PAD) xm = (int)(int16_t)((-TPL_PAD - x0) << 3);
-        if (x0 + 16 + (xm >> 3) > TPL_PAD + (int)R.max_width - 1) xm = (int)(int16_t)(((TPL_PAD + (int)R.max_width - 1) - (x0 + 16)) << 3);
-        if (y0 + (ym >> 3) < -TPL_PAD) ym = (int)(int16_t)((-TPL_PAD - y0) << 3);
-        if (y0 + 16 + (ym >> 3) > TPL_PAD + (int)R.max_height - 1) ym = (int)(int16_t)(((TPL_PAD + (int)R.max_height - 1) - (y0 + 16)) << 3);
+        int xm = (int)(int16_t)((int16_t)(m & 0xffff) * 8), ym = (int)(int16_t)((int16_t)(m >> 16) * 8);
+        if (x0 + (xm >> 3) < -TPL_PAD) xm = (int)(int16_t)((-TPL_PAD - x0) * 8);
+        if (x0 + 16 + (xm >> 3) > TPL_PAD + (int)R.max_width - 1) xm = (int)(int16_t)(((TPL_PAD + (int)R.max_width - 1) - (x0 + 16)) * 8);
+        if (y0 + (ym >> 3) < -TPL_PAD) ym = (int)(int16_t)((-TPL_PAD - y0) * 8);
+        if (y0 + 16 + (ym >> 3) > TPL_PAD + (int)R.max_height - 1) ym = (int)(int16_t)(((TPL_PAD + (int)R.max_height - 1) - (y0 + 16)) * 8);
         const uint8_t* rp = ref_base + R.plane_off + (size_t)R.org_y * R.stride + R.org_x; // sample (0, 0) of the reference picture
         int mvr = ym, mvc = xm;
         subpel_search(P, rp, (long)R.stride, x0, y0, mvr, mvc, S.src, S.bil, l);
