@@ -201,6 +201,11 @@ static void build_tile(uint16_t *tile /* (64+2*VBORDER) * BSTRIDE */, const void
     if (ye > ph) ye = ph;
     if (fbc + 1 < nhfb) xe += HBORDER;
     if (fbr + 1 < nvfb) ye += VBORDER;
+    /* (the reference copies the full halo out of a padded frame buffer; a 4:2:0 chroma plane's last filter block can be 4 samples wide, and the 4 halo columns beyond
+     * the picture are never reached by a tap -- 2 samples at most -- so a checker that is handed tightly allocated planes leaves them VERY_LARGE instead of reading
+     * past a row's end: AddressSanitizer, profiles/r05_asan_emulator.txt) */
+    if (xe > pw) xe = pw;
+    if (ye > ph) ye = ph;
     uint16_t *in = tile + VBORDER * BSTRIDE + HBORDER;
     for (int y = ys; y < ye; y++)
         for (int x = xs; x < xe; x++)

@@ -24,7 +24,7 @@ PKG_DIR = os.path.join(ROOT, "svt-av1-psy_amd")
 # (SVT_HIP_EMU_LIB: another build of the emulator -- e.g. g++ -fsanitize=address over the same sources, run as `LD_PRELOAD=$(gcc -print-file-name=libasan.so) python -m pytest ...`:
 #  device buffers are plain heap blocks there, so a kernel's out-of-bounds access is a report with a stack)
 EMU_LIB = os.environ.get("SVT_HIP_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "_build", "libsvtav1_hipemu.so")
-ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+ORACLE_LIB = os.environ.get("SVT_HIP_ORACLE_LIB") or os.path.join(ROOT, "oracle", "liboracle.so")  # (the override: a sanitizer build of the checker, see tools/sanitizer_emulator.sh)
 REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libsvtref.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
