@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
 }
 
 // ---- self-guided: projection + refinement of one (unit, parameter set) per workgroup (search_selfguided_restoration's loop body, :582-630) ------------
-constexpr int PROJ_T = 1024; // threads per (unit, parameter set): sixteen waves, every evaluation is one latency-bound pass over the unit
+constexpr int PROJ_T = 1024; // threads per (unit, parameter set): sixteen waves; a pass = 64 samples per thread x the candidates of its shape (VALU), one reduction, two barriers
 // The workgroup's sums of N per-thread values (uint32_t or long long), value k written to *dst(k) in LDS (valid for every thread on return): one wave reduction per
 // value, TWO barriers for the whole group.  use(k) says whether value k is wanted (workgroup-uniform).  part: [PROJ_T / 64][PROJ_ROW].  No barrier at the start: `part`
 // is read only between the two barriers, and a thread has read whatever it wanted of an earlier call's results before it gets here (program order).
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(PROJ_T) SVT_HIP_WAVES_PER_EU(5, 5) void lr_sgr_proj
     // every sample's projection by delta * (a per-sample constant): so one pass over the unit evaluates a whole run of candidates -- up to PROJ_K steps
     // down and PROJ_K steps up from the current point -- and the reference's accept / reject sequence is then replayed on those errors.  (The up candidates
     // of the first pass stay valid exactly when no down move was accepted, which is when the reference evaluates them.)  Control flow is workgroup-uniform.
-    constexpr int PROJ_K = 8; // (4: more passes on long chains, 7.0 ms instead of 6.4 ms on the 4K bench plane)
+    constexpr int PROJ_K = 8; // moves per continuation pass (round 2 measured 4: more passes on long chains, 7.0 ms instead of 6.4 ms on the 4K bench plane)
     static_assert(PROJ_K <= 8, "sh_e rows");
     long long err      = 0;
     bool      have_err = false; // err holds the error of the current xqd
