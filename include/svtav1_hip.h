@@ -26,6 +26,19 @@
 extern "C" {
 #endif
 
+/* PODs of this header that mirror a struct of the reference (SvtHipMv, SvtHipMvCostParams, SvtHipTxfmParam, SvtHipBuf2D, SvtHipCdefList, SvtHipSgrParams,
+ * SvtHipConvolveParams) are self-contained definitions with the reference's layout, so the header needs none of the reference's.  A translation unit that HAS the
+ * reference's headers (the in-encoder binding; tests/abi/abi_typecheck.c) defines SVT_HIP_REFERENCE_TYPES after including them: each of those names is then a
+ * typedef of the reference's own struct and every `_hip` prototype is spelled in the reference's types -- which is how tests/abi/abi_typecheck.c proves, at
+ * compile time, that each of the 193 variants of csrc/rtcd_hooks.def has its dispatch pointer's exact prototype.  tests/abi/abi_layout.c static-asserts that the
+ * self-contained definitions and the reference's structs agree in size and in every field offset. */
+
+#ifdef SVT_HIP_REFERENCE_TYPES
+typedef BlockSize SvtHipBlockSize;
+#else
+typedef uint8_t SvtHipBlockSize; /* BlockSize (definitions.h:764-791) is a packed one-byte enum */
+#endif
+
 /* ---------------------------------------------------------------- runtime ------------------------------------ */
 /* Bind the calling process to HIP device `device` (one process per GPU). 0 on success, -1 if no usable device. */
 int         svt_hip_init(int device);
@@ -131,6 +144,10 @@ void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint
 /* a7. svt_pme_sad_loop_kernel -> svt_pme_sad_loop_kernel_c (aom_dsp_rtcd.h:868, product_coding_loop.c:1900-1951): SAD + MV-rate search
  * of MD's predictive ME.  SvtHipMvCostParams is layout-identical to the reference's MV_COST_PARAMS (`struct svt_mv_cost_param`,
  * mcomp.h:37-48; MV = {int16 row, col}, block_structures.h:26; MV_COST_TYPE is a 1-byte enum, mcomp.h:29-36). */
+#ifdef SVT_HIP_REFERENCE_TYPES
+typedef MV SvtHipMv;
+typedef struct svt_mv_cost_param SvtHipMvCostParams;
+#else
 typedef struct SvtHipMv { int16_t row, col; } SvtHipMv;
 typedef struct SvtHipMvCostParams {
     const SvtHipMv *ref_mv;
@@ -140,6 +157,7 @@ typedef struct SvtHipMvCostParams {
     const int      *mvcost[2];    /* centred tables, index range [MV_LOW, MV_UPP] */
     int             error_per_bit, early_exit_th, sad_per_bit;
 } SvtHipMvCostParams;
+#endif
 void svt_pme_sad_loop_kernel_hip(const SvtHipMvCostParams *mv_cost_params, uint8_t *src, uint32_t src_stride, uint8_t *ref,
                                  uint32_t ref_stride, uint32_t block_height, uint32_t block_width, uint32_t *best_cost, int16_t *best_mvx,
                                  int16_t *best_mvy, int16_t search_position_start_x, int16_t search_position_start_y,
@@ -704,12 +722,16 @@ void svt_av1_inv_txfm_add_u8_hip(const int32_t *dqcoeff, uint8_t *dst_r, int32_t
                                  int tx_size, int lossless, int eob);
 /* svt_av1_inv_txfm_add (common_dsp_rtcd.h:144) -> svt_av1_inv_txfm_add_c (inv_transforms.c:3177-3192), exact prototype.
  * SvtHipTxfmParam is TxfmParam (definitions.h:1043-1055; TxType / TxSize are packed one-byte enums). */
+#ifdef SVT_HIP_REFERENCE_TYPES
+typedef TxfmParam SvtHipTxfmParam;
+#else
 typedef struct SvtHipTxfmParam {
     uint8_t tx_type, tx_size;
     int32_t lossless, bd, is_hbd;
-    int32_t tx_set_type;
+    uint8_t tx_set_type; /* TxSetType, a packed one-byte enum (definitions.h:1027-1041) */
     int32_t eob;
 } SvtHipTxfmParam;
+#endif
 void svt_av1_inv_txfm_add_hip(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w,
                               const SvtHipTxfmParam *txfm_param);
 /* Lossless mode: 4x4 Walsh-Hadamard.  svt_av1_fwht4x4 (aom_dsp_rtcd.h:208) -> svt_av1_fwht4x4_c (transforms.c:3099-3152);
@@ -889,10 +911,16 @@ void     svt_aom_cdef_find_dir_dual_hip(const uint16_t *img1, const uint16_t *im
 void     svt_cdef_filter_block_hip(uint8_t *dst8, uint16_t *dst16, int32_t dstride, const uint16_t *in, int32_t pri_strength,
                                    int32_t sec_strength, int32_t dir, int32_t pri_damping, int32_t sec_damping, int32_t bsize,
                                    int32_t coeff_shift, uint8_t subsampling_factor);
-uint64_t svt_compute_cdef_dist_16bit_hip(const uint16_t *dst, int32_t dstride, const uint16_t *src, const void *dlist, int32_t cdef_count,
-                                         uint8_t bsize, int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
-uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t *dst8, int32_t dstride, const uint8_t *src8, const void *dlist, int32_t cdef_count,
-                                        uint8_t bsize, int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
+/* SvtHipCdefList is CdefList (definitions.h:256-259): the (by, bx) 8x8 position of one non-skip block inside its 64x64 filter block */
+#ifdef SVT_HIP_REFERENCE_TYPES
+typedef CdefList SvtHipCdefList;
+#else
+typedef struct SvtHipCdefList { uint8_t by, bx; } SvtHipCdefList;
+#endif
+uint64_t svt_compute_cdef_dist_16bit_hip(const uint16_t *dst, int32_t dstride, const uint16_t *src, const SvtHipCdefList *dlist, int32_t cdef_count,
+                                         SvtHipBlockSize bsize, int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
+uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t *dst8, int32_t dstride, const uint8_t *src8, const SvtHipCdefList *dlist, int32_t cdef_count,
+                                        SvtHipBlockSize bsize, int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor);
 void     svt_aom_copy_rect8_8bit_to_16bit_hip(uint16_t *dst, int32_t dstride, const uint8_t *src, int32_t sstride, int32_t v, int32_t h);
 
 /* ---------------------------------------------------------------- loop restoration (a21-a23) ---------- */
@@ -958,12 +986,22 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams *params, const SvtHipLrPr
  * dgd readable 3 rows above / below and 3 (left) / 4 (right) samples beside the plane; uploads, runs on the calling thread's stream, downloads. */
 int svt_hip_lr_search_plane_host(const SvtHipLrSearchParams *params, const SvtHipLrPrevUnit *prev, SvtHipLrSearchUnit *units);
 
-/* RTCD-signature single-call forms (common_dsp_rtcd.h:144-181); highbd pointers use the CONVERT_TO_BYTEPTR convention */
+/* RTCD-signature single-call forms (common_dsp_rtcd.h:144-181); highbd pointers use the CONVERT_TO_BYTEPTR convention.
+ * SvtHipConvolveParams is ConvolveParams (definitions.h:572-585); the Wiener path reads round_0 / round_1 only (convolve.c:100-147). */
+#ifdef SVT_HIP_REFERENCE_TYPES
+typedef ConvolveParams SvtHipConvolveParams;
+#else
+typedef struct SvtHipConvolveParams {
+    int32_t   ref, do_average;
+    uint16_t *dst; /* ConvBufType */
+    int32_t   dst_stride, round_0, round_1, plane, is_compound, use_jnt_comp_avg, fwd_offset, bck_offset, use_dist_wtd_comp_avg;
+} SvtHipConvolveParams;
+#endif
 void svt_av1_wiener_convolve_add_src_hip(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x,
-                                         const int16_t *filter_y, int32_t w, int32_t h, const void *conv_params);
+                                         const int16_t *filter_y, int32_t w, int32_t h, const SvtHipConvolveParams *conv_params);
 void svt_av1_highbd_wiener_convolve_add_src_hip(const uint8_t *src8, ptrdiff_t src_stride, uint8_t *dst8, ptrdiff_t dst_stride,
                                                 const int16_t *filter_x, const int16_t *filter_y, int32_t w, int32_t h,
-                                                const void *conv_params, int32_t bd);
+                                                const SvtHipConvolveParams *conv_params, int32_t bd);
 void svt_av1_selfguided_restoration_hip(const uint8_t *dgd8, int32_t width, int32_t height, int32_t dgd_stride, int32_t *flt0, int32_t *flt1,
                                         int32_t flt_stride, int32_t sgr_params_idx, int32_t bit_depth, int32_t highbd);
 void svt_apply_selfguided_restoration_hip(const uint8_t *dat8, int32_t width, int32_t height, int32_t stride, int32_t eps, const int32_t *xqd,
@@ -993,24 +1031,39 @@ void     svt_aom_hadamard_8x8_hip(const int16_t *src_diff, ptrdiff_t src_stride,
 void     svt_aom_hadamard_16x16_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
 void     svt_aom_hadamard_32x32_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
 uint32_t svt_hadamard_path_hip(const uint8_t *input, uint32_t in_stride, const uint8_t *pred, uint32_t pred_stride, int block_size);
+/* hadamard_path (aom_dsp_rtcd.h:582) -> hadamard_path_c (enc_mode_config.c:2147-2215), exact prototype: four Buf2D BY VALUE (definitions.h:243-249; residual and
+ * coeff are scratch there) and the one-byte packed enum BlockSize (definitions.h:764-791).  Unpacks and calls svt_hadamard_path_hip. */
+#ifdef SVT_HIP_REFERENCE_TYPES
+typedef Buf2D SvtHipBuf2D;
+#else
+typedef struct SvtHipBuf2D { uint8_t *buf, *buf0; int width, height, stride; } SvtHipBuf2D;
+#endif
+uint32_t hadamard_path_hip(SvtHipBuf2D residual, SvtHipBuf2D coeff, SvtHipBuf2D input, SvtHipBuf2D pred, SvtHipBlockSize bsize);
 void     svt_residual_kernel8bit_hip(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, int16_t *residual,
                                      uint32_t residual_stride, uint32_t area_width, uint32_t area_height);
 void     svt_residual_kernel16bit_hip(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual,
                                       uint32_t residual_stride, uint32_t area_width, uint32_t area_height);
+/* SvtHipSgrParams is SgrParamsType (definitions.h:1750-1753).  `bit_depth` of svt_av1_compute_stats_highbd is the enum EbBitDepth (EbSvtAv1Formats.h:101-108), which
+ * gcc and clang give the type unsigned int. */
+#ifdef SVT_HIP_REFERENCE_TYPES
+typedef SgrParamsType SvtHipSgrParams;
+#else
+typedef struct SvtHipSgrParams { int32_t r[2], s[2]; } SvtHipSgrParams;
+#endif
 void     svt_av1_compute_stats_hip(int32_t wiener_win, const uint8_t *dgd, const uint8_t *src, int32_t h_start, int32_t h_end, int32_t v_start,
                                    int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H);
 void     svt_av1_compute_stats_highbd_hip(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end,
                                           int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H,
-                                          int bit_depth);
+                                          unsigned int bit_depth);
 int64_t  svt_av1_lowbd_pixel_proj_error_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8,
                                             int32_t dat_stride, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride,
-                                            int32_t xq[2], const void *params);
+                                            int32_t xq[2], const SvtHipSgrParams *params);
 int64_t  svt_av1_highbd_pixel_proj_error_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8,
                                              int32_t dat_stride, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride,
-                                             int32_t xq[2], const void *params);
+                                             int32_t xq[2], const SvtHipSgrParams *params);
 void     svt_get_proj_subspace_hip(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8, int32_t dat_stride,
                                    int32_t use_highbitdepth, int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride, int32_t *xq,
-                                   const void *params);
+                                   const SvtHipSgrParams *params);
 
 /* ------------------------------------------------ TPL dispenser, source-based half ---------------------------------------------
  * tpl_mc_flow_dispenser_sb_generic (Codec/src_ops_process.c:519-969), the part that runs when pcs->tpl_src_data_ready == 0: per 16x16 (dispenser level 0) or

@@ -172,10 +172,14 @@ def allowed_tx_types(tx_size):
     return list(range(16))
 
 
+class Buf2D(C.Structure):  # Buf2D, definitions.h:243-249 (passed BY VALUE to hadamard_path)
+    _fields_ = [("buf", C.c_void_p), ("buf0", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride", C.c_int)]
+
+
 FwdTxfmDesc = np.dtype([("in_off", "<u8"), ("in_stride", "<u4"), ("tx_type", "u1"), ("pad", "u1", (3,))])
 InvTxfmDesc = np.dtype([("coeff_off", "<u8"), ("pred_off", "<u8"), ("recon_off", "<u8"), ("pred_stride", "<u4"), ("recon_stride", "<u4"),
                         ("tx_type", "u1"), ("wht_full", "u1"), ("pad", "u1", (6,))])
-TxfmParam = np.dtype([("tx_type", "u1"), ("tx_size", "u1"), ("lossless", "<i4"), ("bd", "<i4"), ("is_hbd", "<i4"), ("tx_set_type", "<i4"),
+TxfmParam = np.dtype([("tx_type", "u1"), ("tx_size", "u1"), ("lossless", "<i4"), ("bd", "<i4"), ("is_hbd", "<i4"), ("tx_set_type", "u1"),
                       ("eob", "<i4")], align=True)  # TxfmParam, definitions.h:1043-1055
 assert TxfmParam.itemsize == 24
 RoundtripDesc = np.dtype([("in_off", "<u8"), ("pred_off", "<u8"), ("recon_off", "<u8"), ("in_stride", "<u4"), ("pred_stride", "<u4"), ("recon_stride", "<u4"),
@@ -573,6 +577,7 @@ PROTOTYPES.update({
     "svt_aom_satd_hip": (C.c_int, [vp, C.c_int]),
     "svt_aom_hadamard_nxn_hip": (None, [vp, C.c_ssize_t, vp, C.c_int]),
     "svt_hadamard_path_hip": (C.c_uint32, [vp, C.c_uint32, vp, C.c_uint32, C.c_int]),
+    "hadamard_path_hip": (C.c_uint32, [Buf2D, Buf2D, Buf2D, Buf2D, C.c_uint8]),
     "svt_residual_kernel8bit_hip": (None, [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "svt_residual_kernel16bit_hip": (None, [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "svt_av1_compute_stats_hip": (None, [C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp]),

@@ -981,11 +981,11 @@ static uint64_t cdef_dist_host(const void* dst, int32_t dstride, const void* src
     c.down(&r, o, 8);
     return r;
 }
-uint64_t svt_compute_cdef_dist_16bit_hip(const uint16_t* dst, int32_t dstride, const uint16_t* src, const void* dlist, int32_t cdef_count, uint8_t bsize,
+uint64_t svt_compute_cdef_dist_16bit_hip(const uint16_t* dst, int32_t dstride, const uint16_t* src, const SvtHipCdefList* dlist, int32_t cdef_count, SvtHipBlockSize bsize,
                                          int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor) {
     return cdef_dist_host(dst, dstride, src, (const uint8_t*)dlist, cdef_count, bsize, coeff_shift, pli, subsampling_factor, 2);
 }
-uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t* dst8, int32_t dstride, const uint8_t* src8, const void* dlist, int32_t cdef_count, uint8_t bsize,
+uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t* dst8, int32_t dstride, const uint8_t* src8, const SvtHipCdefList* dlist, int32_t cdef_count, SvtHipBlockSize bsize,
                                         int32_t coeff_shift, int32_t pli, uint8_t subsampling_factor) {
     return cdef_dist_host(dst8, dstride, src8, (const uint8_t*)dlist, cdef_count, bsize, coeff_shift, pli, subsampling_factor, 1);
 }

@@ -291,7 +291,7 @@ void svt_av1_compute_stats_hip(int32_t wiener_win, const uint8_t* dgd, const uin
     stats_host(wiener_win, dgd, src, h_start, h_end, v_start, v_end, dgd_stride, src_stride, M, H, 8);
 }
 void svt_av1_compute_stats_highbd_hip(int32_t wiener_win, const uint8_t* dgd8, const uint8_t* src8, int32_t h_start, int32_t h_end, int32_t v_start, int32_t v_end,
-                                      int32_t dgd_stride, int32_t src_stride, int64_t* M, int64_t* H, int bit_depth) {
+                                      int32_t dgd_stride, int32_t src_stride, int64_t* M, int64_t* H, unsigned int bit_depth) {
     stats_host(wiener_win, (const void*)((uintptr_t)dgd8 << 1), (const void*)((uintptr_t)src8 << 1), h_start, h_end, v_start, v_end, dgd_stride, src_stride, M, H,
                bit_depth);
 }
@@ -318,25 +318,21 @@ static void proj_host(int mode, const void* src, int width, int height, int src_
     if (mode == 0) c.down(err, de, 8);
     else c.down(xq, dx, 8);
 }
-struct SgrParamsAbi { int32_t r[2]; int32_t s[2]; }; // SgrParamsType (restoration.h)
 int64_t svt_av1_lowbd_pixel_proj_error_hip(const uint8_t* src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t* dat8, int32_t dat_stride,
-                                           int32_t* flt0, int32_t flt0_stride, int32_t* flt1, int32_t flt1_stride, int32_t xq[2], const void* params) {
-    const SgrParamsAbi* p = (const SgrParamsAbi*)params;
+                                           int32_t* flt0, int32_t flt0_stride, int32_t* flt1, int32_t flt1_stride, int32_t xq[2], const SvtHipSgrParams* p) {
     int64_t e = 0;
     proj_host(0, src8, width, height, src_stride, dat8, dat_stride, flt0, flt0_stride, flt1, flt1_stride, xq, p->r[0], p->r[1], 0, &e);
     return e;
 }
 int64_t svt_av1_highbd_pixel_proj_error_hip(const uint8_t* src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t* dat8, int32_t dat_stride,
-                                            int32_t* flt0, int32_t flt0_stride, int32_t* flt1, int32_t flt1_stride, int32_t xq[2], const void* params) {
-    const SgrParamsAbi* p = (const SgrParamsAbi*)params;
+                                            int32_t* flt0, int32_t flt0_stride, int32_t* flt1, int32_t flt1_stride, int32_t xq[2], const SvtHipSgrParams* p) {
     int64_t e = 0;
     proj_host(0, (const void*)((uintptr_t)src8 << 1), width, height, src_stride, (const void*)((uintptr_t)dat8 << 1), dat_stride, flt0, flt0_stride, flt1, flt1_stride, xq,
               p->r[0], p->r[1], 1, &e);
     return e;
 }
 void svt_get_proj_subspace_hip(const uint8_t* src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t* dat8, int32_t dat_stride,
-                               int32_t use_highbitdepth, int32_t* flt0, int32_t flt0_stride, int32_t* flt1, int32_t flt1_stride, int32_t* xq, const void* params) {
-    const SgrParamsAbi* p = (const SgrParamsAbi*)params;
+                               int32_t use_highbitdepth, int32_t* flt0, int32_t flt0_stride, int32_t* flt1, int32_t flt1_stride, int32_t* xq, const SvtHipSgrParams* p) {
     const void* s = use_highbitdepth ? (const void*)((uintptr_t)src8 << 1) : (const void*)src8;
     const void* d = use_highbitdepth ? (const void*)((uintptr_t)dat8 << 1) : (const void*)dat8;
     proj_host(1, s, width, height, src_stride, d, dat_stride, flt0, flt0_stride, flt1, flt1_stride, xq, p->r[0], p->r[1], use_highbitdepth, nullptr);

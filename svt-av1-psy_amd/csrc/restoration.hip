@@ -240,13 +240,13 @@ int svt_hip_lr_filter_frame_host(const SvtHipLrParams* params) {
 // svt_av1_wiener_convolve_add_src -> _c (convolve.c:100-147); conv_params is rebuilt from the bit depth exactly as
 // get_conv_params_wiener does (convolve.h:70-88), which is what every caller passes (restoration.c:443, :1021)
 void svt_av1_wiener_convolve_add_src_hip(const uint8_t* src, ptrdiff_t src_stride, uint8_t* dst, ptrdiff_t dst_stride, const int16_t* filter_x,
-                                         const int16_t* filter_y, int32_t w, int32_t h, const void* conv_params) {
+                                         const int16_t* filter_y, int32_t w, int32_t h, const SvtHipConvolveParams* conv_params) {
     (void)conv_params;
     lr_block_host(src, (int)src_stride, dst, (int)dst_stride, w, h, 0, 8, 0, filter_x, filter_y, 0, nullptr, nullptr, nullptr, 0);
 }
 // highbd forms take CONVERT_TO_BYTEPTR()-style pointers: real address = (uintptr_t)p << 1 (definitions.h)
 void svt_av1_highbd_wiener_convolve_add_src_hip(const uint8_t* src8, ptrdiff_t src_stride, uint8_t* dst8, ptrdiff_t dst_stride, const int16_t* filter_x,
-                                                const int16_t* filter_y, int32_t w, int32_t h, const void* conv_params, int32_t bd) {
+                                                const int16_t* filter_y, int32_t w, int32_t h, const SvtHipConvolveParams* conv_params, int32_t bd) {
     (void)conv_params;
     lr_block_host((const void*)((uintptr_t)src8 << 1), (int)src_stride, (void*)((uintptr_t)dst8 << 1), (int)dst_stride, w, h, 1, bd, 0, filter_x, filter_y, 0,
                   nullptr, nullptr, nullptr, 0);

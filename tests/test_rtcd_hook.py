@@ -44,7 +44,7 @@ CHILD = textwrap.dedent('''
     vp, i32, u32, u8 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint8
     # svt_av1_inv_txfm_add with the whole TxfmParam: regular 8x8 / 16x16, and lossless 4x4 (Walsh-Hadamard) in both eob forms (inv_transforms.c:2826-2848)
     class TxfmParam(C.Structure):
-        _fields_ = [("tx_type", u8), ("tx_size", u8), ("lossless", i32), ("bd", i32), ("is_hbd", i32), ("tx_set_type", i32), ("eob", i32)]
+        _fields_ = [("tx_type", u8), ("tx_size", u8), ("lossless", i32), ("bd", i32), ("is_hbd", i32), ("tx_set_type", u8), ("eob", i32)]
     f = through("svt_av1_inv_txfm_add", None, vp, vp, i32, vp, i32, vp)
     for (ts, w, h, lossless, eob, tt) in ((1, 8, 8, 0, 64, 3), (2, 16, 16, 0, 256, 0), (0, 4, 4, 1, 16, 0), (0, 4, 4, 1, 1, 0), (0, 4, 4, 0, 16, 5)):
         co = g.integers(-2000, 2001, w * h).astype(np.int32)
