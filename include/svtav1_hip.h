@@ -713,6 +713,15 @@ void svt_hip_inv_txfm2d_add_batch(const int32_t *coeff_base, const uint16_t *pre
 /* 8-bit pixel form (svt_av1_inv_txfm_add -> svt_av1_inv_txfm_add_c, inv_transforms.c:3177-3192) */
 void svt_hip_inv_txfm2d_add_batch_u8(const int32_t *coeff_base, const uint8_t *pred_base, uint8_t *recon_base,
                                      const SvtHipInvTxfmDesc *descs, uint32_t n, int tx_size, void *stream);
+/* The two entry points above compute the transform types AV1 allows for the size (test/TxfmCommon.h:160-209: DCT and identity only where a dimension is 32 or 64).
+ * The reference's `_c` functions accept more: av1_iadst32_new (inv_transforms.c:1119-1552) gives every ADST type a result on the seven sizes with a 32-point
+ * dimension, and the reference's own InvTxfm2dAddTest feeds them (test/InvTxfm2dAsmTest.cc:755-775).  The `_any_type` forms compute every type the `_c` function of
+ * the size computes; the single-call `_hip` symbols go through them.  They are separate kernels because the 32-point ADST costs the 32x32 kernel 3 of its 7
+ * waves per SIMD (71 -> 125 VGPRs); no bitstream reaches them. */
+void svt_hip_inv_txfm2d_add_batch_any_type(const int32_t *coeff_base, const uint16_t *pred_base, uint16_t *recon_base,
+                                           const SvtHipInvTxfmDesc *descs, uint32_t n, int tx_size, int bd, void *stream);
+void svt_hip_inv_txfm2d_add_batch_any_type_u8(const int32_t *coeff_base, const uint8_t *pred_base, uint8_t *recon_base,
+                                              const SvtHipInvTxfmDesc *descs, uint32_t n, int tx_size, void *stream);
 /* single-call generic forms; the fixed-size RTCD symbols svt_av1_fwd_txfm2d_WxH[_N2|_N4]_hip (57) and
  * svt_av1_inv_txfm2d_add_WxH_hip (19, three signature shapes, common_dsp_rtcd.h:106-116) are generated from these. */
 void svt_av1_fwd_txfm2d_hip(int16_t *input, int32_t *output, uint32_t input_stride, int tx_type, int tx_size, uint8_t bit_depth, int pf);

@@ -115,7 +115,8 @@ void oracle_inv_txfm1d(int kind, int n, const int32_t *in, int32_t *out, int cos
     switch (n) {
     case 4: o_iadst4(in, out, cos_bit); return;
     case 8: o_iadst8(in, out, cos_bit, clamp_bit); return;
-    default: o_iadst16(in, out, cos_bit, clamp_bit); return;
+    case 16: o_iadst16(in, out, cos_bit, clamp_bit); return;
+    default: o_iadst32(in, out, cos_bit, clamp_bit); return; /* av1_iadst32_new, inv_transforms.c:1119-1552: never signalled by AV1, accepted by the `_c` functions */
     }
 }
 

@@ -189,6 +189,8 @@ PROTOTYPES.update({
     "svt_hip_fwd_txfm2d_batch": (None, [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp]),
     "svt_hip_inv_txfm2d_add_batch": (None, [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp]),
     "svt_hip_inv_txfm2d_add_batch_u8": (None, [vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),
+    "svt_hip_inv_txfm2d_add_batch_any_type": (None, [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp]),
+    "svt_hip_inv_txfm2d_add_batch_any_type_u8": (None, [vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),
     "svt_av1_fwd_txfm2d_hip": (None, [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_uint8, C.c_int]),
     "svt_av1_inv_txfm2d_add_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int, C.c_int32]),
     "svt_av1_inv_txfm_add_u8_hip": (None, [vp, vp, C.c_int32, vp, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void fwd_txfm2d_kernel(const int16_t* __restri
 }
 
 // ---- inverse -----------------------------------------------------------------------------------------------------
-template <typename PIX, int W, int H>
+template <typename PIX, int W, int H, bool ADST32 = false>
 __global__ __launch_bounds__(256) void inv_txfm2d_kernel(const int32_t* __restrict__ coeff_base, const PIX* __restrict__ pred_base,
                                                          PIX* __restrict__ recon_base, const SvtHipInvTxfmDesc* __restrict__ descs,
                                                          const uint32_t n, const int bd) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void inv_txfm2d_kernel(const int32_t* __restri
             if (RECT1) x = mul_sqrt2_like(x, 2896);
             v[c] = txfm1d::clamp_i32(x, rlo, rhi);
         }
-        inv1d<W>(kRowKind[tx], v, rlo, rhi);
+        inv1d<W, ADST32>(kRowKind[tx], v, rlo, rhi);
 #pragma unroll
         for (int c = 0; c < W; c++) buf[t * PITCH + c] = S0 ? rshift_round(v[c], S0 ? S0 : 1) : v[c];
     }
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void inv_txfm2d_kernel(const int32_t* __restri
         const int cc = kLrFlip[tx] ? (W - 1 - t) : t;
 #pragma unroll
         for (int r = 0; r < H; r++) v[r] = txfm1d::clamp_i32(buf[r * PITCH + cc], clo, chi);
-        inv1d<H>(kColKind[tx], v, clo, chi);
+        inv1d<H, ADST32>(kColKind[tx], v, clo, chi);
         const PIX*    pr = pred_base + d.pred_off + t;
         PIX*          rc = recon_base + d.recon_off + t;
         const int32_t mx = (1 << bd) - 1;
@@ -227,21 +227,22 @@ template <int W, int H> void launch_fwd(const int16_t* base, const SvtHipFwdTxfm
     hipLaunchKernelGGL(HIP_KERNEL_NAME(fwd_txfm2d_kernel<W, H>), dim3((n + BPW - 1) / BPW), dim3(256), shmem, st, base, descs, n, pf, out);
     SVT_LAUNCH_CHECK();
 }
-template <typename PIX, int W, int H>
+template <typename PIX, int W, int H, bool ANY>
 void launch_inv(const int32_t* coeff, const PIX* pred, PIX* recon, const SvtHipInvTxfmDesc* descs, uint32_t n, int bd, hipStream_t st) {
-    constexpr int T = W > H ? W : H, BPW = 256 / T;
-    const size_t  shmem = (size_t)BPW * H * (W + 1) * 4;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(inv_txfm2d_kernel<PIX, W, H>), dim3((n + BPW - 1) / BPW), dim3(256), shmem, st, coeff, pred, recon, descs, n, bd);
+    constexpr int  T = W > H ? W : H, BPW = 256 / T;
+    constexpr bool ADST32 = ANY && (W == 32 || H == 32); // the other sizes have one kernel: every type their `_c` function computes is in it
+    const size_t   shmem = (size_t)BPW * H * (W + 1) * 4;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(inv_txfm2d_kernel<PIX, W, H, ADST32>), dim3((n + BPW - 1) / BPW), dim3(256), shmem, st, coeff, pred, recon, descs, n, bd);
     SVT_LAUNCH_CHECK();
 }
 #define FOR_ALL_TX_SIZES(X) \
     X(0, 4, 4) X(1, 8, 8) X(2, 16, 16) X(3, 32, 32) X(4, 64, 64) X(5, 4, 8) X(6, 8, 4) X(7, 8, 16) X(8, 16, 8) X(9, 16, 32) X(10, 32, 16) \
     X(11, 32, 64) X(12, 64, 32) X(13, 4, 16) X(14, 16, 4) X(15, 8, 32) X(16, 32, 8) X(17, 16, 64) X(18, 64, 16)
 
-template <typename PIX> void inv_dispatch(const int32_t* coeff, const PIX* pred, PIX* recon, const SvtHipInvTxfmDesc* descs, uint32_t n, int tx_size,
-                                          int bd, hipStream_t st) {
+template <typename PIX, bool ANY = false> void inv_dispatch(const int32_t* coeff, const PIX* pred, PIX* recon, const SvtHipInvTxfmDesc* descs, uint32_t n,
+                                                            int tx_size, int bd, hipStream_t st) {
     switch (tx_size) {
-#define X(ID, W, H) case ID: launch_inv<PIX, W, H>(coeff, pred, recon, descs, n, bd, st); break;
+#define X(ID, W, H) case ID: launch_inv<PIX, W, H, ANY>(coeff, pred, recon, descs, n, bd, st); break;
         FOR_ALL_TX_SIZES(X)
 #undef X
     default: fprintf(stderr, "libsvtav1_hip: bad tx_size %d\n", tx_size); abort();
@@ -277,6 +278,19 @@ void svt_hip_inv_txfm2d_add_batch_u8(const int32_t* coeff_base, const uint8_t* p
     svthip::ensure_device();
     if (n == 0) return;
     inv_dispatch<uint8_t>(coeff_base, pred_base, recon_base, descs, n, tx_size, 8, (hipStream_t)stream);
+}
+
+void svt_hip_inv_txfm2d_add_batch_any_type(const int32_t* coeff_base, const uint16_t* pred_base, uint16_t* recon_base, const SvtHipInvTxfmDesc* descs,
+                                           uint32_t n, int tx_size, int bd, void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    inv_dispatch<uint16_t, true>(coeff_base, pred_base, recon_base, descs, n, tx_size, bd, (hipStream_t)stream);
+}
+void svt_hip_inv_txfm2d_add_batch_any_type_u8(const int32_t* coeff_base, const uint8_t* pred_base, uint8_t* recon_base, const SvtHipInvTxfmDesc* descs,
+                                              uint32_t n, int tx_size, void* stream) {
+    svthip::ensure_device();
+    if (n == 0) return;
+    inv_dispatch<uint8_t, true>(coeff_base, pred_base, recon_base, descs, n, tx_size, 8, (hipStream_t)stream);
 }
 
 void svt_hip_fwht4x4_batch(const int16_t* residual_base, const SvtHipFwdTxfmDesc* descs, uint32_t n, int32_t* coeff_out, void* stream) {
@@ -358,7 +372,7 @@ void svt_av1_inv_txfm2d_add_hip(const int32_t* input, uint16_t* output_r, int32_
     d.pred_stride = d.recon_stride = (uint32_t)(pitch / 2);
     d.tx_type = (uint8_t)tx_type;
     c.up(dd, &d, sizeof(d));
-    svt_hip_inv_txfm2d_add_batch(dco, dpr, drc, dd, 1, tx_size, bd, c.stream);
+    svt_hip_inv_txfm2d_add_batch_any_type(dco, dpr, drc, dd, 1, tx_size, bd, c.stream);
     c.down2d(output_w, (size_t)stride_w * 2, drc, pitch, (size_t)w * 2, h);
 }
 
@@ -385,7 +399,7 @@ void svt_av1_inv_txfm_add_u8_hip(const int32_t* dqcoeff, uint8_t* dst_r, int32_t
     d.wht_full = eob > 1;
     c.up(dd, &d, sizeof(d));
     if (lossless && tx_size == 0) svt_hip_iwht4x4_add_batch_u8(dco, dpr, drc, dd, 1, c.stream);
-    else svt_hip_inv_txfm2d_add_batch_u8(dco, dpr, drc, dd, 1, tx_size, c.stream);
+    else svt_hip_inv_txfm2d_add_batch_any_type_u8(dco, dpr, drc, dd, 1, tx_size, c.stream);
     c.down2d(dst_w, (size_t)stride_w, drc, pitch, (size_t)w, h);
 }
 // the pointer's exact prototype (common_dsp_rtcd.h:144); SvtHipTxfmParam == TxfmParam (definitions.h:1043-1055).  bd / is_hbd are fixed by the
@@ -417,7 +431,7 @@ void svt_av1_inv_txfm_add_hip(const int32_t* dqcoeff, uint8_t* dst_r, int32_t st
         d.wht_full = p->eob > 1;
         c.up(dd, &d, sizeof(d));
         if (p->lossless && p->tx_size == 0) svt_hip_iwht4x4_add_batch(dco, dpr, drc, dd, 1, p->bd, c.stream);
-        else svt_hip_inv_txfm2d_add_batch(dco, dpr, drc, dd, 1, p->tx_size, p->bd, c.stream);
+        else svt_hip_inv_txfm2d_add_batch_any_type(dco, dpr, drc, dd, 1, p->tx_size, p->bd, c.stream);
         uint16_t* back = (uint16_t*)c.palloc(pitch * h);
         HIP_CHECK(hipMemcpyAsync(back, drc, pitch * h, hipMemcpyDeviceToHost, c.stream));
         c.sync();

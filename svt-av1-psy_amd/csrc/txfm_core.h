@@ -92,7 +92,10 @@ template <int N, int CB> __device__ __forceinline__ void fwd1d(const int kind, i
         else if constexpr (N == 16) txfm1d::fadst16<CB>(v);
     }
 }
-template <int N> __device__ __forceinline__ void inv1d(const int kind, int32_t (&v)[N], const int32_t lo, const int32_t hi) {
+// ADST32: also compile the 32-point inverse ADST (av1_iadst32_new, inv_transforms.c:1119-1552) -- a kernel no AV1 stream reaches (the 32-point dimensions allow
+// DCT and identity only, TxfmCommon.h:160-209) but that the reference's `_c` functions compute and its InvTxfm2dAddTest fixture feeds.  Its live set takes the
+// 32x32 inverse kernel from 71 to 125 VGPRs (7 -> 4 waves per SIMD), so the throughput kernels are built without it and the `_any_type` entry points with it.
+template <int N, bool ADST32 = false> __device__ __forceinline__ void inv1d(const int kind, int32_t (&v)[N], const int32_t lo, const int32_t hi) {
     if (kind == K_IDTX) {
         identity<N>(v);
     } else if (kind == K_DCT) {
@@ -105,6 +108,7 @@ template <int N> __device__ __forceinline__ void inv1d(const int kind, int32_t (
         if constexpr (N == 4) iadst4<INV_COS_BIT>(v);
         else if constexpr (N == 8) txfm1d::iadst8<INV_COS_BIT>(v, lo, hi);
         else if constexpr (N == 16) txfm1d::iadst16<INV_COS_BIT>(v, lo, hi);
+        else if constexpr (N == 32 && ADST32) txfm1d::iadst32<INV_COS_BIT>(v, lo, hi);
     }
 }
 

@@ -118,6 +118,44 @@ def test_2d_fwd_inv_vs_reference(oracle, ref, ts):
                 assert np.array_equal(o1, o2), ("inv", TX_SIZES[ts], tx_type, bd, it)
 
 
+COL_ADST = {1, 3, 4, 6, 7, 8, 12, 14}  # transform types whose column (vertical) 1-D kernel is an ADST / flipped ADST (inv_transforms.h:147-186)
+ROW_ADST = {2, 3, 5, 6, 7, 8, 13, 15}
+
+
+def c_defined_types(ts):
+    """Every transform type the reference's `_c` inverse computes for a size -- a superset of what AV1 allows (allowed_types): a 32-point ADST exists
+    (av1_iadst32_new, inv_transforms.c:1119-1552), a 64-point one does not (inv_transforms.h:190-195: TXFM_TYPE_INVALID)."""
+    w, h = TXW[ts], TXH[ts]
+    return [t for t in range(16) if not (h == 64 and t in COL_ADST) and not (w == 64 and t in ROW_ADST)]
+
+
+@pytest.mark.parametrize("ts", [t for t in range(19) if 32 in (TXW[t], TXH[t])])
+def test_2d_inverse_legacy_types_vs_reference(oracle, ref, ts):
+    """The types outside AV1's allowed set that the reference's own InvTxfm2dAddTest feeds its `_c` functions (test/InvTxfm2dAsmTest.cc:755-775, rows of
+    txfm_support_matrix with a 1): inverse input = the reference's C forward transform with that type, as the fixture makes it (:92-135), and raw random blocks."""
+    g = rng(300 + ts)
+    w, h = TXW[ts], TXH[ts]
+    iw, ih = min(w, 32), min(h, 32)
+    stride = w + 3
+    legacy = [t for t in c_defined_types(ts) if t not in allowed_types(ts)]
+    assert legacy
+    for bd in (8, 10):
+        amp = (1 << bd) - 1
+        for tx_type in legacy:
+            for it in range(4):
+                if it < 2:
+                    res = g.integers(-amp, amp + 1, h * stride).astype(np.int16)
+                    coeff = ref_fwd(ref, ts, res, stride, tx_type, bd)
+                    packed = np.ascontiguousarray(coeff.reshape(h, w)[:ih, :iw]).reshape(-1)
+                else:
+                    packed = g.integers(-(1 << (bd + 8)), 1 << (bd + 8), iw * ih).astype(np.int32)
+                pred = g.integers(0, 1 << bd, h * stride).astype(np.uint16)
+                o1, o2 = np.zeros(h * stride, np.uint16), np.zeros(h * stride, np.uint16)
+                oracle.oracle_inv_txfm2d_add(p(packed), p(pred), stride, p(o1), stride, tx_type, ts, bd)
+                call_ref_inv(ref, ts, packed, pred, stride, o2, tx_type, bd)
+                assert np.array_equal(o1, o2), ("inv legacy", TX_SIZES[ts], tx_type, bd, it)
+
+
 def test_txfm_oracle_vs_golden(oracle):
     path = os.path.join(GOLDEN, "txfm.npz")
     assert os.path.exists(path), "run tools/gen_golden.py txfm"

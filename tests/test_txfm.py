@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import p, rng
-from test_oracle_pin_txfm import TX_SIZES, TXH, TXW, allowed_types
+from test_oracle_pin_txfm import TX_SIZES, TXH, TXW, allowed_types, c_defined_types
 
 
 def oracle_fwd(oracle, res, stride, tx_type, ts, bd, pf=0):
@@ -70,6 +70,52 @@ def test_inv_txfm2d_add_batch(be, oracle, ts):
             want = np.zeros(h * stride, np.uint16)
             oracle.oracle_inv_txfm2d_add(p(coeffs[i]), p(pred[i]), stride, p(want), stride, int(descs[i]["tx_type"]), ts, bd)
             assert np.array_equal(got[i][:, :w], want.reshape(h, stride)[:, :w]), (TX_SIZES[ts], int(descs[i]["tx_type"]), bd, i)
+
+
+@pytest.mark.parametrize("ts", [t for t in range(19) if 32 in (TXW[t], TXH[t])])
+def test_inv_txfm2d_add_any_type(be, oracle, ts):
+    """The transform types outside AV1's allowed set that the reference's `_c` inverse still computes (32-point ADST, av1_iadst32_new, inv_transforms.c:1119-1552) and
+    its own InvTxfm2dAddTest feeds (test/InvTxfm2dAsmTest.cc:755-775): the `_any_type` batch forms and the single-call symbol, u16 and u8 destinations, against the
+    oracle (pinned on the reference for exactly these types: test_oracle_pin_txfm.py::test_2d_inverse_legacy_types_vs_reference)."""
+    g = rng(700 + ts)
+    w, h = TXW[ts], TXH[ts]
+    iw, ih = min(w, 32), min(h, 32)
+    types = c_defined_types(ts)
+    if not be.is_gpu:
+        types = [t for t in types if t not in allowed_types(ts)][:3] + allowed_types(ts)[:1]
+    n, stride = len(types), w + 3
+    for bd in ((8, 10, 12) if be.is_gpu else (10,)):
+        coeffs = g.integers(-(1 << (bd + 8)), 1 << (bd + 8), (n, iw * ih)).astype(np.int32)
+        coeffs[:, iw * ih // 2:] //= 64  # (most of the energy in the low frequencies, as a forward transform leaves it)
+        pred = g.integers(0, 1 << bd, (n, h * stride)).astype(np.uint16)
+        descs = np.zeros(n, dtype=be.pkg.InvTxfmDesc)
+        for i in range(n):
+            descs[i] = (i * iw * ih, i * h * stride, i * h * stride, stride, stride, types[i], 0, (0,) * 6)
+        dco, dpr, dd = be.dev(coeffs), be.dev(pred), be.dev(descs)
+        drc = be.empty(n * h * stride, np.uint16)
+        be.lib.svt_hip_inv_txfm2d_add_batch_any_type(be.ptr(dco), be.ptr(dpr), be.ptr(drc), be.ptr(dd), n, ts, bd, be.stream)
+        got = be.host(drc).reshape(n, h, stride)
+        want = np.zeros((n, h * stride), np.uint16)
+        for i in range(n):
+            oracle.oracle_inv_txfm2d_add(p(coeffs[i]), p(pred[i]), stride, p(want[i]), stride, types[i], ts, bd)
+            assert np.array_equal(got[i][:, :w], want[i].reshape(h, stride)[:, :w]), (TX_SIZES[ts], types[i], bd)
+        if bd == 8:
+            pred8 = pred.astype(np.uint8)
+            dpr8 = be.dev(pred8)
+            drc8 = be.empty(n * h * stride, np.uint8)
+            be.lib.svt_hip_inv_txfm2d_add_batch_any_type_u8(be.ptr(dco), be.ptr(dpr8), be.ptr(drc8), be.ptr(dd), n, ts, be.stream)
+            got8 = be.host(drc8).reshape(n, h, stride)
+            for i in range(n):
+                assert np.array_equal(got8[i][:, :w].astype(np.uint16), want[i].reshape(h, stride)[:, :w]), (TX_SIZES[ts], types[i], "u8")
+        # the single-call symbol (what the dispatch pointer receives) on the first legacy type
+        i = next(k for k in range(n) if types[k] not in allowed_types(ts))
+        one = pred[i].copy()
+        f = getattr(be.lib, "svt_av1_inv_txfm2d_add_%dx%d_hip" % (w, h))
+        if w == h:
+            f(p(coeffs[i]), p(one), stride, p(one), stride, types[i], bd)
+        else:
+            f(p(coeffs[i]), p(one), stride, p(one), stride, types[i], ts, w * h, bd)
+        assert np.array_equal(one.reshape(h, stride)[:, :w], want[i].reshape(h, stride)[:, :w]), (TX_SIZES[ts], types[i], bd, "single call")
 
 
 def test_txfm_single_call_symbols(be, oracle):

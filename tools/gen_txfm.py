@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gen_txfm.py -- generates the straight-line 1-D AV1 transform kernels (DCT 4..64, ADST 8/16; forward and inverse).
+"""gen_txfm.py -- generates the straight-line 1-D AV1 transform kernels (DCT 4..64, ADST 8/16; forward and inverse; the legacy 32-point inverse ADST).
 
 The AV1 DCT/ADST are fixed-point butterfly networks with a rounding shift after every rotation
 (half_btf, Source/Lib/Codec/inv_transforms.h:260-285), so a bit-exact implementation must realise the same flow graph.
@@ -14,6 +14,11 @@ states the graph's *recursive structure* and derives everything else:
               stride-2^t butterflies } -> final rotations (angles (64/N)/2 + (128/N) i) -> output permutation
   inverse   = the transposed graph run backwards (every rotation matrix transposed, every add/sub followed by the
               stage clamp of inv_transforms.c:86-92) -- checked against svt_av1_idct*/iadst* by tests.
+
+  iadst32   = NOT a transposed graph: the reference's av1_iadst32_new (inv_transforms.c:1119-1552; a transform type AV1 never signals for a 32-point
+              dimension, but svt_av1_inv_txfm2d_add_{16x32,32x16,8x32,32x8,32x64,64x32}_c accept it and the reference's own InvTxfm2dAddTest fixture feeds it,
+              test/InvTxfm2dAsmTest.cc:755-775) is the FORWARD network shape fadst(32) with clamp_buf over the whole array after every stage -- the signed
+              input permutation and the rotation outputs are clamped too, not only the adds.
 
 Outputs (committed, regenerate with `python tools/gen_txfm.py`):
   oracle/oracle_txfm1d_gen.h            plain C, used by the test oracle
@@ -110,6 +115,11 @@ ADST_IN = {  # signed input permutation of the forward ADST (slot i <- sign * x[
          (5, -1), (10, 1)],
 }
 ADST_OUT = {8: [1, 6, 3, 4, 5, 2, 7, 0], 16: [1, 14, 3, 12, 5, 10, 7, 8, 9, 6, 11, 4, 13, 2, 15, 0]}
+# the same two tables continued to N = 32 (slot i <- sign * x[src] is "even bit-reversed positions from the front, odd ones mirrored from the back, signs in the
+# +--+ -++- pattern of the smaller sizes"; the output takes odd slots ascending interleaved with even slots descending)
+ADST_IN[32] = [(0, 1), (31, -1), (15, -1), (16, 1), (7, -1), (24, 1), (8, 1), (23, -1), (3, -1), (28, 1), (12, 1), (19, -1), (4, 1), (27, -1), (11, -1), (20, 1),
+               (1, -1), (30, 1), (14, 1), (17, -1), (6, 1), (25, -1), (9, -1), (22, 1), (2, 1), (29, -1), (13, -1), (18, 1), (5, -1), (26, 1), (10, 1), (21, -1)]
+ADST_OUT[32] = [x for i in range(16) for x in (2 * i + 1, 30 - 2 * i)]
 
 
 def fadst_prog(N):
@@ -146,6 +156,17 @@ def fadst_prog(N):
     passes.append(ops)
     passes.append([("perm", [(s, 1) for s in ADST_OUT[N]])])
     return passes
+
+
+def clamp_all_prog(passes):
+    """the forward-shaped network with the stage clamp applied to every value a stage produces (legacy inverse ADST32)"""
+    out = []
+    for ops in passes:
+        if ops and ops[0][0] == "perm":
+            out.append([("permc", ops[0][1])])
+            continue
+        out.append([(("rotc",) + op[1:]) if op[0] == "rot" else (("addc",) + op[1:]) for op in ops])
+    return out
 
 
 def transpose_prog(passes, N):
@@ -192,11 +213,14 @@ def emit(name, passes, N, lang, inverse):
         for op in ops:
             if op[0] == "perm":
                 new = [cur[src] if sign > 0 else "NEG(%s)" % cur[src] for (src, sign) in op[1]]
-            elif op[0] == "rot":
+            elif op[0] == "permc":  # a negated value is clamped again: -(-2^(b-1)) is out of range
+                new = [cur[src] if sign > 0 else "CL(NEG(%s))" % cur[src] for (src, sign) in op[1]]
+            elif op[0] in ("rot", "rotc"):
                 _, j, p, wjj, wjp, wpj, wpp = op
                 a, b = nt(), nt()
-                lines.append("const int32_t %s = HB(%s, %s, %s, %s);" % (a, w(wjj), cur[j], w(wjp), cur[p]))
-                lines.append("const int32_t %s = HB(%s, %s, %s, %s);" % (b, w(wpj), cur[j], w(wpp), cur[p]))
+                fmt = "const int32_t %s = CL(HB(%s, %s, %s, %s));" if op[0] == "rotc" else "const int32_t %s = HB(%s, %s, %s, %s);"
+                lines.append(fmt % (a, w(wjj), cur[j], w(wjp), cur[p]))
+                lines.append(fmt % (b, w(wpj), cur[j], w(wpp), cur[p]))
                 new[j], new[p] = a, b
             else:
                 kind, x, y, sxx, sxy, syx, syy = op
@@ -241,6 +265,7 @@ def main():
         f = fadst_prog(N)
         progs.append(("fadst%d" % N, f, N, False))
         progs.append(("iadst%d" % N, transpose_prog(f, N), N, True))
+    progs.append(("iadst32", clamp_all_prog(fadst_prog(32)), 32, True))
 
     cos_tabs = [[int(round(math.cos(math.pi * j / 128.0) * (1 << bit))) for j in range(64)] for bit in range(10, 17)]
     head = "// GENERATED by tools/gen_txfm.py -- do not edit.  1-D AV1 DCT/ADST flow graphs (see the generator for the derivation).\n"
