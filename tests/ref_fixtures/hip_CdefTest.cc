@@ -1,0 +1,55 @@
+// hip_CdefTest.cc -- the reference's test/CdefTest.cc: svt_cdef_filter_block (4 block sizes x 16 boundary masks x 8/10/12 bit, every direction, strength and damping,
+// dst8 and dst16 forms), svt_aom_cdef_find_dir and its dual form, svt_aom_copy_rect8_8bit_to_16bit, svt_compute_cdef_dist_16bit / _8bit and svt_search_one_dual.
+// (svt_cdef_filter_block_8xn_16 -- the last tuple element of CDEFBlockTest -- is an internal pointer of the AVX2 / AVX-512 kernels, CdefTest.cc:42-45; it has no
+// meaning for the `_hip` function and stays 0 = "not used".)
+#include "hip_decl.h"
+#include "CdefTest.cc"
+
+namespace {
+// CdefTest.cc:378-386 (AVX2, CDEFBlockTest), boundary masks 1..15: the reference's test as it is (180 of its 192 parameter sets).
+// With boundary mask 0 its loops make 8.9 (8 bit) to 50 (12 bit) MILLION calls per parameter set (16 damping pairs x 128 levels x bd noise widths x 8 directions x
+// 17 primary x 4 secondary strengths x 2 sub-samplings, CdefTest.cc:133-245) -- sized for a 50 ns SIMD call, not for a function that crosses PCIe twice per call.
+// Those 12 sets run below through the fixture's own prepare_data() / run_test() with the three OUTER loops thinned; the inner ones (every direction, strength pair
+// and sub-sampling, dst8 and dst16) are the reference's.
+INSTANTIATE_TEST_SUITE_P(HIP, CDEFBlockTest,
+                         ::testing::Combine(::testing::Values(&svt_cdef_filter_block_hip), ::testing::Values(&svt_cdef_filter_block_c),
+                                            ::testing::Values(BLOCK_4X4, BLOCK_4X8, BLOCK_8X4, BLOCK_8X8), ::testing::Range(1, 16), ::testing::Range(8, 13, 2),
+                                            ::testing::Values(0)));
+
+class CDEFBlockInteriorTest : public CDEFBlockTest {
+  public:
+    // test_cdef(1) of CdefTest.cc:227-265 with: damping pairs (min, min) (min, max) (max, min) (max, max) + the two middle diagonal ones instead of all 16,
+    // four levels (0, 1/3, 2/3, top of the range) instead of 128, every noise width `bits` as there
+    void test_cdef_thinned() {
+        const int lo = 3 + bd_ - 8, hi = 6 + bd_ - 8;
+        const int damp[6][2] = {{lo, lo}, {lo, hi}, {hi, lo}, {hi, hi}, {lo + 1, lo + 1}, {lo + 2, lo + 2}};
+        const int top = (1 << bd_) - 1, levels[4] = {0, top / 3, 2 * top / 3, top - (2 << (bd_ - 8)) + 1};
+        for (const auto &d : damp)
+            for (const int level : levels)
+                for (int bits = 1; bits <= bd_; bits++) {
+                    prepare_data(level, bits);
+                    run_test(d[0], d[1], 1);
+                    if (bsize_ > BLOCK_4X4)  // (CdefTest.cc:250-258: the 2x sub-sampled 4x4 AVX2 kernel differs from C by design; kept as there)
+                        run_test(d[0], d[1], 2);
+                    if (::testing::Test::HasFatalFailure())
+                        return;
+                }
+    }
+};
+TEST_P(CDEFBlockInteriorTest, MatchTest) {
+    test_cdef_thinned();
+}
+INSTANTIATE_TEST_SUITE_P(HIP, CDEFBlockInteriorTest,
+                         ::testing::Combine(::testing::Values(&svt_cdef_filter_block_hip), ::testing::Values(&svt_cdef_filter_block_c),
+                                            ::testing::Values(BLOCK_4X4, BLOCK_4X8, BLOCK_8X4, BLOCK_8X8), ::testing::Values(0), ::testing::Range(8, 13, 2),
+                                            ::testing::Values(0)));
+// CdefTest.cc:507-510 (AVX2, CDEFFindDirTest)
+INSTANTIATE_TEST_SUITE_P(HIP, CDEFFindDirTest, ::testing::Values(make_tuple(&svt_aom_cdef_find_dir_hip, &svt_aom_cdef_find_dir_c)));
+// CdefTest.cc:652-655 (AVX2, CDEFFindDirDualTest)
+INSTANTIATE_TEST_SUITE_P(HIP, CDEFFindDirDualTest, ::testing::Values(make_tuple(&svt_aom_cdef_find_dir_dual_hip, &svt_aom_cdef_find_dir_dual_c)));
+}  // namespace
+// CdefTest.cc:752-754, :878-880, :985-987, :1156-1157 (AVX2)
+INSTANTIATE_TEST_SUITE_P(HIP, CDEFCopyRectTest, ::testing::Values(svt_aom_copy_rect8_8bit_to_16bit_hip));
+INSTANTIATE_TEST_SUITE_P(HIP, CDEFComputeCdefDist16Bit, ::testing::Values(svt_compute_cdef_dist_16bit_hip));
+INSTANTIATE_TEST_SUITE_P(HIP, CDEFComputeCdefDist8BitTest, ::testing::Values(svt_compute_cdef_dist_8bit_hip));
+INSTANTIATE_TEST_SUITE_P(HIP, CDEFSearchOneDualTest, ::testing::Values(svt_search_one_dual_hip));
