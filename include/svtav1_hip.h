@@ -46,6 +46,10 @@ void        svt_hip_shutdown(void);
 const char *svt_hip_device_name(void);
 /* one-time costs of the calling thread's device (context, code-object loading, first allocations) paid now instead of inside the first real call */
 void svt_hip_warmup(void);
+/* the same with the pooled stage arenas sized by the caller: stage_arenas = how many stage-sized host forms (`svt_hip_*_host`, `*_stage*`) will be in flight at once
+ * (0-3; 0 = dispatch pointers only: nothing is pre-reserved), first_arena_mb = device MB of the first one (the loop-restoration search of a 1080p plane takes ~100 MB, of a
+ * 4K plane ~400 MB; the other arenas get 96 MB).  svt_hip_warmup() = svt_hip_warmup_sized(3, 192). */
+void svt_hip_warmup_sized(int stage_arenas, uint32_t first_arena_mb);
 /* Page-locks a host buffer the caller will hand to the host-pointer forms again and again (an encoder's picture buffers): copies from / to it then go by DMA without
  * the runtime's staging pass.  Portable across devices.  0 on success; a buffer that is already registered, or that the runtime refuses, is left as it is (non-zero) --
  * registration is an optimisation, never a requirement.  Unregister before the buffer is freed. */
@@ -82,6 +86,9 @@ const char *svt_hip_last_error(void); /* NULL while the device path is on */
 int         svt_hip_failed(void);
 void        svt_hip_rtcd_unhook(void); /* puts the saved dispatch pointers back (what the first error does) */
 int         svt_hip_debug_inject_failure(void); /* test instrument: behaves as if a HIP call had just failed */
+/* test instrument: how often a host form issued a HIP operation AFTER it had already written caller memory (must stay 0: a failed call is finished through the
+ * reference's own function, csrc/rtcd_hook.hip, so nothing may be half done when an operation fails) */
+uint64_t    svt_hip_debug_commit_violations(void);
 /* SVT_HIP_COUNT mode (csrc/rtcd_hook.hip): calls made so far through each installed pointer; returns the number of counted pointers */
 int         svt_hip_rtcd_call_counts(const char **names, uint64_t *counts, int max);
 /* Cross-lane / packed-byte instruction self-test used by the GPU test-suite (returns 0 when the silicon agrees

@@ -153,12 +153,17 @@ static uint64_t filter_planes(const PictureControlSet *pcs, const uint32_t *w, E
         if (rc) { /* the device path is off (the host form writes the plane last: nothing has changed): the recorded segments through the reference's OWN edge filters --
                    * the pointers the recorders replaced --, every vertical one in the recorded order, then every horizontal one: the order of the device stage */
             static const int li_of[15] = {0, 0, 0, 0, 0, 0, 1, 0, 2, 0, 0, 0, 0, 0, 3};
+            /* The reference's SIMD edge filters LOAD 8 or 16 bytes from each threshold pointer and expect the value replicated (_mm_loadl_epi64 / _mm_loadu_si128 on
+             * _blimit, ASM_SSE2/dlf_intrin_sse2.c:273,605,634 -- LoopFilterThresh keeps mblim / lim / hev_thr as 16-byte arrays, deblocking_filter.h): the single bytes
+             * packed inside an SvtHipLpfEdge are not that.  Each replayed call gets three aligned 16-byte arrays filled with the edge's values. */
+            uint8_t bl[16] __attribute__((aligned(16))), li[16] __attribute__((aligned(16))), th[16] __attribute__((aligned(16)));
             for (int v = 1; v >= 0; v--)
                 for (uint32_t i = 0; i < list[pl][v].n; i++) {
                     const SvtHipLpfEdge *e = &list[pl][v].e[i];
                     uint8_t *sp = (uint8_t *)T.base[pl] + ((size_t)e->y * T.stride[pl] + e->x) * T.px;
-                    if (is_16bit) F.orig_hbd[v][li_of[e->length]]((uint16_t *)sp, (int32_t)T.stride[pl], &e->blimit, &e->limit, &e->thresh, bd);
-                    else F.orig[v][li_of[e->length]](sp, (int32_t)T.stride[pl], &e->blimit, &e->limit, &e->thresh);
+                    memset(bl, e->blimit, 16); memset(li, e->limit, 16); memset(th, e->thresh, 16);
+                    if (is_16bit) F.orig_hbd[v][li_of[e->length]]((uint16_t *)sp, (int32_t)T.stride[pl], bl, li, th, bd);
+                    else F.orig[v][li_of[e->length]](sp, (int32_t)T.stride[pl], bl, li, th);
                 }
             __atomic_fetch_add(&F.n_replayed, 1, __ATOMIC_RELAXED);
         }

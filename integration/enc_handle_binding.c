@@ -107,8 +107,17 @@ static void svt_aom_setup_rtcd_then_hip(EbCpuFlags flags) {
     }
     /* one-time costs now, while the encoder is still initialising, not inside the first picture's stage call: the device context, the library's code objects */
     const double t_c = svt_hip_ms_now();
-    void (*warmup)(void) = (void (*)(void))dlsym(h, "svt_hip_warmup");
-    if (warmup) warmup();
+    {   /* the pooled stage arenas are sized by what this encode will use: one per stage seam that is on (at most 3 are ever in flight), none for dispatch pointers only;
+         * the loop-restoration search is the stage with the large device arena (SVT_HIP_WARM_ARENA_MB overrides its size, e.g. 448 for 4K) */
+        static const char *const seams[] = {"SVT_HIP_ME_SEAM", "SVT_HIP_TF_ME_SEAM", "SVT_HIP_LR_SEAM", "SVT_HIP_CDEF_SEAM", "SVT_HIP_DLF_SEAM", "SVT_HIP_TPL_SEAM"};
+        int on = 0;
+        for (unsigned k = 0; k < sizeof(seams) / sizeof(seams[0]); k++) on += getenv(seams[k]) != NULL;
+        const char *mb = getenv("SVT_HIP_WARM_ARENA_MB");
+        void (*warm_sized)(int, unsigned) = (void (*)(int, unsigned))dlsym(h, "svt_hip_warmup_sized");
+        void (*warmup)(void)              = (void (*)(void))dlsym(h, "svt_hip_warmup");
+        if (warm_sized) warm_sized(on > 3 ? 3 : on, mb ? (unsigned)atoi(mb) : (getenv("SVT_HIP_LR_SEAM") ? 192u : 96u));
+        else if (warmup) warmup();
+    }
     if (timing) fprintf(stderr, "SVT_HIP_INIT_TIMING: dlopen %.1f ms, svt_hip_init (device context) %.1f ms, warm-up (code objects, first arenas) %.1f ms\n", t_b - t_a, t_c - t_b, svt_hip_ms_now() - t_c);
     const char *list = getenv("SVT_HIP_DEVICES");
     if (list && *list) {

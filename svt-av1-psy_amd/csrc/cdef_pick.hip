@@ -165,9 +165,10 @@ uint64_t svt_search_one_dual_hip(int* lev0, int* lev1, int nb_strengths, uint64_
     svt_hip_cdef_search_one_dual(d0, d1, dl0, dl1, nb_strengths, sb_count, start_gi, end_gi, dbest, ws, c.stream);
     uint64_t best;
     int      a, b;
-    c.down(&best, dbest, 8);
-    c.down(&a, dl0 + nb_strengths, 4);
-    c.down(&b, dl1 + nb_strengths, 4);
+    c.down_later(&best, dbest, 8); // ONE commit point: the caller's memory is written after the last HIP operation has succeeded (rtcd_hook.hip: Guard)
+    c.down_later(&a, dl0 + nb_strengths, 4);
+    c.down_later(&b, dl1 + nb_strengths, 4);
+    c.finish();
     lev0[nb_strengths] = a;
     lev1[nb_strengths] = b;
     return best;

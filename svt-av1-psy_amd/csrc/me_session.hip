@@ -407,7 +407,9 @@ int svt_hip_me_session_submit(void* session, int64_t pic_id, const uint8_t* plan
 }
 int svt_hip_me_session_submit_results(void* session, int64_t pic_id, const uint8_t* plane_host, const int64_t* ref_ids, uint32_t n_refs, uint32_t area_w,
                                       uint32_t area_h, int sub_sad, const SvtHipMeResultsParams* params, const SvtHipMeResultsHost* out) {
+    SVT_HIP_ENTRY_TRY
     return me_session_submit(session, pic_id, plane_host, ref_ids, n_refs, area_w, area_h, sub_sad, out->best_sad, out->best_mv, params, out);
+    SVT_HIP_ENTRY_CATCH(SVT_HIP_E_DEVICE)
 }
 
 int svt_hip_me_session_enable_stage(void* session, uint32_t quarter_pad, uint32_t sixteenth_pad, uint32_t max_regions, uint32_t max_me_area_width,

@@ -281,8 +281,9 @@ static void stats_host(int win, const void* dgd, const void* src, int h_start, i
     svt_hip_lr_compute_stats_batch(dd + (hw * dp + hw * px), ds, dr, 1, W, Hh, (int)(dp / px), (int)(sp / px), win, bit_depth, dM, dH, c.stream);
     const int w2 = win * win;
     int64_t   hM[49], hH[49 * 49];
-    c.down(hM, dM, 49 * 8);
-    c.down(hH, dH, 49 * 49 * 8);
+    c.down_later(hM, dM, 49 * 8);
+    c.down_later(hH, dH, 49 * 49 * 8);
+    c.finish();
     memcpy(M, hM, sizeof(int64_t) * w2);
     memcpy(H, hH, sizeof(int64_t) * w2 * w2);
 }

@@ -201,9 +201,10 @@ void svt_quantize_hip(int mode, const int32_t* coeff_ptr, intptr_t n_coeffs, con
     SvtHipQuantDesc d = {0, 0, 0, 0};
     c.up(dd, &d, sizeof(d));
     svt_hip_quantize_batch(mode, dco, 1, (uint32_t)n, dp, dis, qm ? dqm : nullptr, qm ? diq : nullptr, dd, dq, ddq, de, c.stream);
-    c.down(qcoeff_ptr, dq, n * 4);
-    c.down(dqcoeff_ptr, ddq, n * 4);
-    c.down(eob_ptr, de, 2);
+    c.down_later(qcoeff_ptr, dq, n * 4); // ONE commit point (rtcd_hook.hip: a failed call is finished through the saved pointer, so nothing may be half written)
+    c.down_later(dqcoeff_ptr, ddq, n * 4);
+    c.down_later(eob_ptr, de, 2);
+    c.finish();
 }
 
 #define QARGS const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr, \
@@ -229,8 +230,9 @@ uint64_t svt_handle_transform_hip(int32_t* output, int tx_size, int n2_n4) {
     c.up(d, output, n * 4);
     svt_hip_handle_transform_batch(d, 1, tx_size, n2_n4, de, c.stream);
     uint64_t e;
-    c.down(&e, de, 8);
-    c.down(output, d, n * 4);
+    c.down_later(&e, de, 8);
+    c.down_later(output, d, n * 4); // in place: written only once every HIP operation has succeeded
+    c.finish();
     return e;
 }
 #define HT(W, H, ID)                                                                                      \

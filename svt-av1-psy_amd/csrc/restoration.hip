@@ -163,9 +163,9 @@ void lr_block_host(const void* src, int sstride, void* dst, int dstride, int w, 
                        highbd, bd, kind, t, idx, xqd ? xqd[0] : 0, xqd ? xqd[1] : 0, d0, d1, w);
     SVT_LAUNCH_CHECK();
     if (kind == 2) {
-        if (kSgrRH[idx][0]) c.down2d(flt0, (size_t)fstride * 4, d0, (size_t)w * 4, (size_t)w * 4, h);
-        if (kSgrRH[idx][1]) c.down2d(flt1, (size_t)fstride * 4, d1, (size_t)w * 4, (size_t)w * 4, h);
-        c.sync();
+        if (kSgrRH[idx][0]) c.down2d_later(flt0, (size_t)fstride * 4, d0, (size_t)w * 4, (size_t)w * 4, h);
+        if (kSgrRH[idx][1]) c.down2d_later(flt1, (size_t)fstride * 4, d1, (size_t)w * 4, (size_t)w * 4, h);
+        c.finish(); // ONE commit point
     } else {
         c.down2d(dst, (size_t)dstride * px, dd, dpitch, (size_t)w * px, h);
     }

@@ -156,6 +156,22 @@ HostCallLease::~HostCallLease() {
 // for, so the next user's work simply queues behind.
 static std::mutex                   g_streams_m;
 static std::vector<ThreadStreams*> g_streams_pool[MAX_DEVICES];
+static void stream_set_free(ThreadStreams* set) { // the device of the set is current
+    for (hipStream_t s : set->st)
+        if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : set->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete set;
+}
+static void stream_pool_free_all() { // svt_hip_shutdown
+    std::lock_guard<std::mutex> g(g_streams_m);
+    for (int d = 0; d < MAX_DEVICES; d++) {
+        if (g_streams_pool[d].empty()) continue;
+        (void)hipSetDevice(physical_device(d));
+        for (ThreadStreams* s : g_streams_pool[d]) stream_set_free(s);
+        g_streams_pool[d].clear();
+    }
+}
 StreamSetLease::StreamSetLease() {
     ensure_device();
     device = current_device();
@@ -166,12 +182,18 @@ StreamSetLease::StreamSetLease() {
     }
     if (!set) {
         set = new ThreadStreams();
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; } // (hi = the numerically lowest value = the highest priority)
-        HIP_CHECK(hipStreamCreateWithFlags(&set->st[0], hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&set->st[1], hipStreamNonBlocking));
-        if (hipStreamCreateWithPriority(&set->st[2], hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); HIP_CHECK(hipStreamCreateWithFlags(&set->st[2], hipStreamNonBlocking)); }
-        for (hipEvent_t& e : set->ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        try {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; } // (hi = the numerically lowest value = the highest priority)
+            HIP_CHECK(hipStreamCreateWithFlags(&set->st[0], hipStreamNonBlocking));
+            HIP_CHECK(hipStreamCreateWithFlags(&set->st[1], hipStreamNonBlocking));
+            if (hipStreamCreateWithPriority(&set->st[2], hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); HIP_CHECK(hipStreamCreateWithFlags(&set->st[2], hipStreamNonBlocking)); }
+            for (hipEvent_t& e : set->ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        } catch (...) { // a half-built set is taken apart again (a constructor that throws runs no destructor)
+            stream_set_free(set);
+            set = nullptr;
+            throw;
+        }
     }
 }
 StreamSetLease::~StreamSetLease() {
@@ -283,12 +305,18 @@ static void plane_cache_free_all() {
     }
 }
 
+static std::atomic<uint64_t> g_commit_violations{0};
+void HostCall::touch() {
+    if (committed) g_commit_violations.fetch_add(1, std::memory_order_relaxed);
+}
 void HostCall::begin() {
-    dev_used = 0;
-    pin_used = 0;
-    n_pend   = 0;
+    dev_used  = 0;
+    pin_used  = 0;
+    n_pend    = 0;
+    committed = false;
 }
 void HostCall::reserve(size_t dev_bytes, size_t pin_bytes) {
+    touch();
     dev_bytes += 4096;
     pin_bytes += 4096;
     if (dev_bytes > dev_cap) {
@@ -326,6 +354,7 @@ void* HostCall::palloc(size_t bytes) {
     return pin + off;
 }
 void HostCall::up2d(void* ddst, size_t dpitch, const void* hsrc, size_t spitch, size_t width_bytes, size_t rows) {
+    touch();
     // pack through the pinned buffer so the device copy is one contiguous DMA
     uint8_t* p = (uint8_t*)palloc(dpitch * rows);
     for (size_t y = 0; y < rows; y++) memcpy(p + y * dpitch, (const uint8_t*)hsrc + y * spitch, width_bytes);
@@ -347,6 +376,7 @@ static bool host_range_is_locked(const void* p, size_t bytes) {
     return false;
 }
 void HostCall::up(void* ddst, const void* hsrc, size_t bytes) {
+    touch();
     if (bytes >= (256u << 10) && host_range_is_locked(hsrc, bytes)) { // (every host form synchronises before it returns: the source outlives the copy)
         if (hipMemcpyAsync(ddst, hsrc, bytes, hipMemcpyHostToDevice, stream) == hipSuccess) return;
         (void)hipGetLastError(); // the runtime refused the direct copy: fall through to the staged one
@@ -356,18 +386,23 @@ void HostCall::up(void* ddst, const void* hsrc, size_t bytes) {
     HIP_CHECK(hipMemcpyAsync(ddst, p, bytes, hipMemcpyHostToDevice, stream));
 }
 void HostCall::down(void* hdst, const void* dsrc, size_t bytes) {
+    touch();
     uint8_t* p = (uint8_t*)palloc(bytes);
     HIP_CHECK(hipMemcpyAsync(p, dsrc, bytes, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     memcpy(hdst, p, bytes);
+    committed = true;
 }
 void HostCall::down2d(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch, size_t width_bytes, size_t rows) {
+    touch();
     uint8_t* p = (uint8_t*)palloc(dpitch * rows);
     HIP_CHECK(hipMemcpyAsync(p, dsrc, dpitch * rows, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     for (size_t y = 0; y < rows; y++) memcpy((uint8_t*)hdst + y * hpitch, p + y * dpitch, width_bytes);
+    committed = true;
 }
 void HostCall::down2d_later(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch, size_t width_bytes, size_t rows) {
+    touch();
     if (n_pend == 16) finish();
     uint8_t* p = (uint8_t*)palloc(dpitch * rows);
     HIP_CHECK(hipMemcpyAsync(p, dsrc, dpitch * rows, hipMemcpyDeviceToHost, stream));
@@ -375,12 +410,18 @@ void HostCall::down2d_later(void* hdst, size_t hpitch, const void* dsrc, size_t 
 }
 void HostCall::down_later(void* hdst, const void* dsrc, size_t bytes) { down2d_later(hdst, bytes, dsrc, bytes, bytes, 1); }
 void HostCall::finish() {
+    touch();
     HIP_CHECK(hipStreamSynchronize(stream));
     for (int i = 0; i < n_pend; i++)
         for (size_t y = 0; y < pend[i].rows; y++) memcpy((uint8_t*)pend[i].h + y * pend[i].hpitch, pend[i].p + y * pend[i].dpitch, pend[i].width);
-    n_pend = 0;
+    committed = n_pend > 0 || committed;
+    n_pend    = 0;
 }
-void HostCall::sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
+void HostCall::sync() {
+    touch();
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+extern "C" uint64_t svt_hip_debug_commit_violations(void) { return g_commit_violations.load(std::memory_order_relaxed); }
 
 static std::atomic<int>  g_tune_lr_ur{32}, g_tune_cdef_gpw{0}, g_tune_cdef_minb{3}, g_tune_sad_form{0};
 static std::atomic<bool> g_tune_loaded{false}; // stored last, with release ordering: a getter that sees it sees every knob
@@ -572,6 +613,7 @@ void svt_hip_shutdown(void) {
             g_lease_pool[d].clear();
         }
     }
+    stream_pool_free_all(); // the pooled side-stream sets (3 streams + 6 events each)
     plane_cache_free_all();
     partition_pool_free();
     t_bound       = -1;
@@ -620,10 +662,12 @@ void svt_hip_tuning_reload(void) { svthip::tuning_read(); }
 // ---- HIP graphs: every batched entry point only enqueues work on the stream it is given (no host synchronisation, no host-side state), so a
 // whole per-picture sequence (padding + decimations, the transform chain, the in-loop filter chain) can be captured once and replayed.
 void* svt_hip_stream_create(void) {
+    SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     hipStream_t st;
     HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     return (void*)st;
+    SVT_HIP_ENTRY_CATCH(nullptr)
 }
 void svt_hip_stream_destroy(void* stream) {
     SVT_HIP_ENTRY_TRY HIP_CHECK(hipStreamDestroy((hipStream_t)stream));     SVT_HIP_ENTRY_CATCH((void)0)
@@ -631,21 +675,38 @@ void svt_hip_stream_destroy(void* stream) {
 void svt_hip_stream_synchronize(void* stream) {
     SVT_HIP_ENTRY_TRY HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));     SVT_HIP_ENTRY_CATCH((void)0)
 }
-void svt_hip_graph_capture_begin(void* stream) { HIP_CHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal)); }
+// (no exception leaves an extern "C" entry point: a failed graph call records the error -- svt_hip_last_error -- and returns; capture_end returns NULL)
+void svt_hip_graph_capture_begin(void* stream) {
+    SVT_HIP_ENTRY_TRY HIP_CHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));     SVT_HIP_ENTRY_CATCH((void)0)
+}
 void* svt_hip_graph_capture_end(void* stream) {
+    SVT_HIP_ENTRY_TRY
     hipGraph_t     graph = nullptr;
     hipGraphExec_t exec  = nullptr;
     HIP_CHECK(hipStreamEndCapture((hipStream_t)stream, &graph));
     HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIP_CHECK(hipGraphDestroy(graph));
     return (void*)exec;
+    SVT_HIP_ENTRY_CATCH(nullptr)
 }
-void svt_hip_graph_launch(void* graph_exec, void* stream) { HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream)); }
-void svt_hip_graph_destroy(void* graph_exec) { HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)graph_exec)); }
+void svt_hip_graph_launch(void* graph_exec, void* stream) {
+    SVT_HIP_ENTRY_TRY HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));     SVT_HIP_ENTRY_CATCH((void)0)
+}
+void svt_hip_graph_destroy(void* graph_exec) {
+    SVT_HIP_ENTRY_TRY HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)graph_exec));     SVT_HIP_ENTRY_CATCH((void)0)
+}
 
 // Pays the one-time costs of the calling thread's device up front (an encoder calls it while it initialises): the HIP context, the loading of this library's code
 // objects (the runtime loads them at the first launch), the first pinned and device allocations.  ~60 ms that would otherwise sit inside the first picture's stage.
-void svt_hip_warmup(void) {
+static void warmup_impl(int stage_arenas, size_t first_arena_bytes);
+void svt_hip_warmup(void) { warmup_impl(3, 192u << 20); }
+// the same with the pool pre-reservation sized by the caller: `stage_arenas` leased arenas (0-3: as many stage-sized host forms as will be in flight at once; 0 for an
+// encoder that only installs the dispatch pointers), the first one with `first_arena_mb` MB of device memory (the loop-restoration search of a 1080p plane wants ~100 MB,
+// a 4K one ~400 MB; the other stages 96 MB)
+void svt_hip_warmup_sized(int stage_arenas, uint32_t first_arena_mb) {
+    warmup_impl(stage_arenas < 0 ? 0 : (stage_arenas > 3 ? 3 : stage_arenas), (size_t)(first_arena_mb < 16 ? 16 : first_arena_mb) << 20);
+}
+static void warmup_impl(int stage_arenas, size_t first_arena_bytes) {
     SVT_HIP_ENTRY_TRY
     svthip::ensure_device();
     svthip::HostCall& c = svthip::host_call();
@@ -679,11 +740,20 @@ void svt_hip_warmup(void) {
     c.sync();
     {   // ... and what the stage-sized host forms take from pools on their first calls: three leased arenas (device + pinned: the pinned allocation is the slow part) and one
         // set of side streams, made now instead of inside the first pictures' stage calls
-        svthip::HostCallLease a, b, c3;
-        (*a).begin(); (*a).reserve(192u << 20, 24u << 20); // (the LR search of a 1080p plane wants ~100 MB of device arena: the first one is made large enough for it)
-        (*b).begin(); (*b).reserve(96u << 20, 24u << 20);
-        (*c3).begin(); (*c3).reserve(96u << 20, 24u << 20);
-        svthip::StreamSetLease s1;
+        // (all leases are held at once so that they are distinct arenas; they return to the pool at the end of the block)
+        if (stage_arenas >= 1) {
+            svthip::HostCallLease a;
+            (*a).begin(); (*a).reserve(first_arena_bytes, 24u << 20);
+            if (stage_arenas >= 2) {
+                svthip::HostCallLease b;
+                (*b).begin(); (*b).reserve(96u << 20, 24u << 20);
+                if (stage_arenas >= 3) {
+                    svthip::HostCallLease c3;
+                    (*c3).begin(); (*c3).reserve(96u << 20, 24u << 20);
+                }
+            }
+            svthip::StreamSetLease s1;
+        }
     }
     SVT_HIP_ENTRY_CATCH((void)0)
 }

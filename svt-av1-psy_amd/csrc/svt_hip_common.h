@@ -111,6 +111,12 @@ struct HostCall {
     Pending pend[16];
     int     n_pend = 0;
     void sync();
+    // Commit discipline (what rtcd_hook.hip's Guard relies on when it finishes a failed `_hip` call through the saved dispatch pointer, and what every seam relies on when a
+    // stage entry declines): a host form writes caller memory only after its LAST HIP operation has succeeded.  down() / down2d() / finish() mark the call committed;
+    // an upload, allocation, download or synchronisation issued after that is counted (svt_hip_debug_commit_violations) -- the reference-fixture binary and
+    // tests/test_rtcd_hook.py run every `_hip` wrapper and require the count to stay zero.
+    bool committed = false;
+    void touch();
 };
 HostCall& host_call();
 struct ThreadStreams { hipStream_t st[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev[6] = {}; }; // st[2]: highest priority

@@ -406,10 +406,10 @@ void accum_host(const SvtHipTfParams* P, const SvtHipTfBlock* B, const void* con
     hipLaunchKernelGGL(tf_accum_kernel<PIX>, dim3(1), dim3(256), 0, hc.stream, *P, *B, A);
     SVT_LAUNCH_CHECK();
     for (int c = 0; c < nc; c++) {
-        hc.down2d(accum[c], (size_t)pre_stride[c > 0] * 4, A.accum[c], w[c] * 4, w[c] * 4, h[c]);
-        hc.down2d(count[c], (size_t)pre_stride[c > 0] * 2, A.count[c], w[c] * 2, w[c] * 2, h[c]);
+        hc.down2d_later(accum[c], (size_t)pre_stride[c > 0] * 4, A.accum[c], w[c] * 4, w[c] * 4, h[c]); // in-place accumulators: ONE commit point
+        hc.down2d_later(count[c], (size_t)pre_stride[c > 0] * 2, A.count[c], w[c] * 2, w[c] * 2, h[c]);
     }
-    hc.sync();
+    hc.finish();
 }
 
 template <typename PIX> int32_t noise_host(const PIX* src, int width, int height, int stride, int bd) {

@@ -21,5 +21,10 @@ int main(int argc, char** argv) {
         fprintf(stderr, "SvtAv1HipFixtures: the device path switched itself off: %s\n", svt_hip_last_error());
         return 4;
     }
+    if (svt_hip_debug_commit_violations()) { // (include/svtav1_hip.h: a `_hip` wrapper touched the device after writing caller memory)
+        fprintf(stderr, "SvtAv1HipFixtures: %llu HIP operations were issued after a host form had written its caller's memory\n",
+                (unsigned long long)svt_hip_debug_commit_violations());
+        return 5;
+    }
     return rc;
 }

@@ -43,3 +43,21 @@ def test_encoder_survives_injected_failure(case, tmp_path):
     assert res["rc_c"] == 0 and res["rc_hip"] == 0, res.get("stderr_tail")
     assert res["bitstream_equal"], "the bitstream differs after the injected failure: %s" % case
     assert res["device_path_switched_off"], "the failure was not injected (too few device operations in this case?)"
+
+
+@pytest.mark.skipif(not os.path.exists(enc_identity.ENC), reason="oracle/_ref/enc/SvtAv1EncApp not built (reference sources absent)")
+@pytest.mark.parametrize("host", ["c", "avx2"])
+@pytest.mark.parametrize("case", ["tiny_fail_dlfseam_p4", "tiny_fail_dlfseam_sb_p8"])
+def test_deblocking_replay_after_injected_failure(case, host, tmp_path):
+    """The deblocking seam's fallback: its device call fails, the recorded segments go through the reference's OWN edge filters.  On the AVX2 host those are the SSE2 / AVX2
+    kernels, which load 16 bytes from each threshold pointer (dlf_intrin_sse2.c:273,605,634): the replay hands them replicated 16-byte arrays."""
+    if host == "avx2" and not os.path.exists(enc_identity.ENC_AVX2):
+        pytest.skip("oracle/_ref/enc_avx2 not built")
+    from conftest import EmuBackend
+    EmuBackend()
+    res = enc_identity.run_case(case, EMU_LIB, str(tmp_path), timeout=900, host=host)
+    assert res["rc_c"] == 0 and res["rc_hip"] == 0, res.get("stderr_tail")
+    assert res["device_path_switched_off"], "the failure was not injected"
+    assert res["bitstream_equal"], "the bitstream differs after the deblocking replay (%s host)" % host
+    st = dict(ln.split() for ln in open(os.path.join(str(tmp_path), case + "_dlfseam.txt")).read().splitlines() if ln.strip())
+    assert int(st["planes_declined"]) > 0, "no plane went through the replay"

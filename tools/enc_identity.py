@@ -159,6 +159,8 @@ CASES = {
     "tiny_fail_everyseam_p8_a": (128, 128, 10, 8, ["--preset", "8", "--lp", "2", "+failafter:40", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
     "tiny_fail_everyseam_p8_b": (128, 128, 10, 8, ["--preset", "8", "--lp", "2", "+failafter:400", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
     "tiny_fail_everyseam_p4": (128, 128, 6, 8, ["--preset", "4", "--lp", "1", "+failafter:150", "+seam", "+tfseam", "+tfsubpel", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
+    "tiny_fail_dlfseam_p4": (128, 128, 6, 8, ["--preset", "4", "--lp", "1", "+failafter:6", "+dlfseam"]),  # the deblocking stage alone: its device call fails and the recorded segments are replayed through the reference's own edge filters (run with host="avx2" too: those load 16 threshold bytes)
+    "tiny_fail_dlfseam_sb_p8": (128, 128, 8, 8, ["--preset", "8", "--lp", "1", "+failafter:6", "+dlfseam"]),  # the same through the SB-based recorder (presets >= 7)
     "tiny_fail_hooks_p8": (64, 64, 3, 8, ["--preset", "8", "--lp", "1", "+failafter:3000"]),  # the per-call dispatch pointers: a `_hip` call fails in flight and finishes through the saved pointer
     "tiny_fail_at_init": (64, 64, 3, 8, ["--preset", "8", "--lp", "1", "+failafter:0", "+seam", "+cdefseam"]),  # the very first device operation fails
     # 60 frames with the sampled checksum of every resident ME plane compared on top of the explicit invalidation: longer than the checksum table, so
