@@ -72,7 +72,7 @@ def live_pmc(a):
     if not os.path.exists(rp):
         return None
     t0 = time.perf_counter()
-    merged, probe = {}, {}
+    merged, probe, mem_known = {}, {}, {}
     for ctrs in PMC_PASSES:
         td = tempfile.mkdtemp(prefix="svt_pmc_", dir="/tmp")
         rfile = os.path.join(td, "regions.json")
@@ -90,6 +90,8 @@ def live_pmc(a):
                 m = merged.setdefault(tag, {"calls": meta["calls"], "kernels": {}})
                 for kn, kv in g["kernels"].items():
                     m["kernels"].setdefault(kn, {}).update(kv)
+            for tag, nbytes in (meta.get("mem_probe") or {}).items():  # the known byte counts of the calibration regions (identical in every pass)
+                mem_known[tag] = nbytes
             if "SQ_ACTIVE_INST_VALU" in ctrs and "valu_probe#0" in got and meta.get("probe", {}).get("seconds"):
                 tot = {}
                 for kv in got["valu_probe#0"]["kernels"].values():
@@ -102,7 +104,23 @@ def live_pmc(a):
             return None
         finally:
             shutil.rmtree(td, ignore_errors=True)
-    return {"regions": merged, "probe": probe, "_seconds": time.perf_counter() - t0}
+    return {"regions": merged, "probe": probe, "traffic_calibration": traffic_calibration(merged, mem_known), "_seconds": time.perf_counter() - t0}
+
+
+def traffic_calibration(merged, mem_known):
+    """bytes per KiB-unit of FETCH_SIZE / WRITE_SIZE for every access shape of bench_regions.MEM_SHAPES: known bytes of the calibration region / what the counter reported for
+    it.  {"read": {shape: factor}, "write": {shape: factor}}; a factor of 2048 = "the counter reports half the bytes" (MI355X_MICROARCH.md, wide streaming reads)."""
+    cal = {"read": {}, "write": {}}
+    for tag, nbytes in mem_known.items():
+        g = merged.get(tag)
+        if not g:
+            continue
+        kind, shape = ("write", tag.split("#")[0][len("mem_w_"):]) if tag.startswith("mem_w_") else ("read", tag.split("#")[0][len("mem_r_"):])
+        ctr = "WRITE_SIZE" if kind == "write" else "FETCH_SIZE"
+        tot = sum(kv.get(ctr, 0.0) for kv in g["kernels"].values()) / g.get("calls", regions.CALLS)
+        if tot > 0:
+            cal[kind][shape] = nbytes / tot
+    return cal
 
 
 def pmc_traffic(kernel):
@@ -523,6 +541,50 @@ def encoder_fps():
                               "lr": r.get("lrseam")}}
 
 
+def encoder_fps_4k10(n_devices=1):
+    """BASELINE.json configs[4] -- "full preset-8 encode of 4K30 10-bit synthetic YUV" -- at this node's GPU count: the reference encoder (AVX2 intrinsics host where built,
+    else C-only) alone, then with every stage seam of SURVEY 8 on the device(s); the two bitstreams and the C-only encoder's must be IDENTICAL, decided on the first
+    attempt (every encode of the comparison runs under tools/enc_identity.py's deterministic_env: the reference's 10-bit path is timing-dependent without it).
+    n_devices > 1: pictures go round-robin over SVT_HIP_DEVICES=0..n-1 (integration/enc_handle_binding.c) -- physical GPUs where the node has them.  ~1 min."""
+    import importlib.util
+    import tempfile
+    spec = importlib.util.spec_from_file_location("enc_identity", os.path.join(ROOT, "tools", "enc_identity.py"))
+    ei = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ei)
+    lib = os.path.join(ROOT, "svt-av1-psy_amd", "libsvtav1_hip.so")
+    if not (os.path.exists(ei.ENC) and os.path.exists(lib)):
+        return None
+    have_x = os.path.exists(ei.ENC_AVX2)
+    host = "avx2" if have_x else "c"
+    CASE = "fps_4k10_p8_30"
+    if n_devices > 1:
+        w_, h_, n_, bd_, extra_ = ei.CASES[CASE]
+        CASE = CASE + "_%ddev" % n_devices
+        ei.CASES[CASE] = (w_, h_, n_, bd_, extra_ + ["+devices:" + ",".join(str(i) for i in range(n_devices))])
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            os.environ["SVT_HIP_WARM_ARENA_MB"] = "448"  # (the loop-restoration search of a 4K plane: the pooled arena is made that large at initialisation, not inside the first picture)
+            r = ei.run_case(CASE, lib, td, timeout=1200, host=host)
+            want = open(os.path.join(td, CASE + "_c.ivf"), "rb").read() if r.get("identical") else b""
+            rep = ei.repeat_pairs(CASE, lib, td, want, pairs=2, host=host, timeout=1200) if (r.get("identical") and n_devices == 1) else {}
+    except Exception as e:  # noqa: BLE001  (the kernel legs stand on their own: the line is still printed)
+        return {"bitstream_identical": False, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    finally:
+        os.environ.pop("SVT_HIP_WARM_ARENA_MB", None)
+    if not r.get("identical") or (rep and not rep.get("identical")):
+        return {"bitstream_identical": False, "hip_encode_attempts": r.get("hip_encode_attempts"),
+                "error": "identity check failed (bitstream_equal %s, repeated pairs %s): no fps recorded" % (r.get("bitstream_equal"), rep.get("identical") if rep else None)}
+    med = lambda v: sorted(v)[len(v) // 2] if v else None  # noqa: E731
+    alone = [v for v in [r.get("fps_" + host)] + (rep.get("fps_alone") or []) if v]
+    with_ = [v for v in [r.get("fps_hip")] + (rep.get("fps_with_stages") or []) if v]
+    return {"workload": "configs[4]: 3840x2160 10-bit 4:2:0, preset 8, %d frames" % r["frames"], "frames": r["frames"], "host": host, "n_devices": n_devices,
+            "fps_c_only": r.get("fps_c"), "fps_host_alone": med(alone), "fps_host_with_stage_seams": med(with_), "pairs": {"alone": alone, "with_stages": with_, "quoted": "median"},
+            "bitstream_identical": True, "first_attempt": r.get("hip_encode_attempts") == 1, "host_cpu_s_per_frame": r.get("host_cpu_s_per_frame"),
+            "devices": r.get("devices"), "host_threads": len(os.sched_getaffinity(0)),
+            "note": "every encode (reference alone and with the stages) runs under the test-only deterministic harness: zero-filled heap + the child control set's 16-bit source "
+                    "zero-filled at acquisition (tools/enc_identity.py deterministic_env); the AVX2 host runs its 177 NASM kernels as C (no nasm in the image)"}
+
+
 def attach_encoder_baselines(kernels, enc):
     """The stage legs' CPU baseline of kind "reference": the reference's OWN functions with their AVX2 kernels, timed inside the reference encoder (oracle/_ref/enc_avx2,
     no seam) by the thread CPU clock around the stage entries (integration/seam_cpu.h) over the encoder leg's 1080p preset-8 clip -- CPU milliseconds per picture the
@@ -669,6 +731,7 @@ def roofline(bytes_alg, seconds, kernel, traffic_kernel=None, **extra):
     return r
 
 
+L3_BYTES = 256 << 20  # Infinity Cache (MI355X_MICROARCH.md)
 VALU_CYCLES_PER_WAVE_INST = 4.5  # measured 4.4-5.0 for the plain integer opcodes (profiles/r01_call1_valu_issue_rates.txt); v_qsad_pk_u16_u8 costs 22.4
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 
@@ -681,6 +744,8 @@ def finish_rooflines(kernels, rf, me_kernel_s):
     is closer: "valu", "hbm", or "latency" when neither reaches 0.35 (dependent launches / occupancy / LDS: DESIGN.md names which)."""
     reg = (LIVE_PMC or {}).get("regions") or {}
     probe = (LIVE_PMC or {}).get("probe") or {}
+    cal = (LIVE_PMC or {}).get("traffic_calibration") or {}
+    rf["traffic_calibration"] = cal or None
     items = [("__me__", {"roofline": rf})] + [(n, k) for n, k in kernels.items() if isinstance(k, dict)]
     c3 = kernels.get("config3_roundtrip")
     if isinstance(c3, dict) and c3.get("size_rooflines"):
@@ -698,11 +763,20 @@ def finish_rooflines(kernels, rf, me_kernel_s):
                 for c, v in kv.items():
                     tot[c] = tot.get(c, 0.0) + v
             calls = g.get("calls", regions.CALLS)
-            moved = (2 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)) * 1024 / calls
+            # bytes per counter unit, calibrated in THIS run on the leg's access shape (roofline["access"], default a contiguous 16 B/lane stream); where the calibration
+            # regions did not run, the guide's figures: FETCH_SIZE x 2 KiB, WRITE_SIZE x 1 KiB
+            shape = r.get("access") or "stream16"
+            f_rd = (cal.get("read") or {}).get(shape) or (cal.get("read") or {}).get("stream16") or 2048.0
+            f_wr = (cal.get("write") or {}).get(r.get("access_write") or "stream16") or 1024.0
+            moved = (f_rd * tot.get("FETCH_SIZE", 0.0) + f_wr * tot.get("WRITE_SIZE", 0.0)) / calls
             if "FETCH_SIZE" in tot or "WRITE_SIZE" in tot:
                 r["traffic"] = moved
-                r["traffic_detail"] = {"read": 2 * tot.get("FETCH_SIZE", 0.0) * 1024 / calls, "write": tot.get("WRITE_SIZE", 0.0) * 1024 / calls,
-                                       "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run, launches between the region's markers"}
+                r["traffic_detail"] = {"read": f_rd * tot.get("FETCH_SIZE", 0.0) / calls, "write": f_wr * tot.get("WRITE_SIZE", 0.0) / calls,
+                                       "bytes_per_fetch_unit": f_rd, "bytes_per_write_unit": f_wr, "access": shape, "calibrated": bool(cal.get("read")),
+                                       "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run, launches between the region's markers; "
+                                                 "counter units calibrated on svt_hip_mem_probe regions of known size in the leg's access shape"}
+                if t > 0:
+                    r["traffic_GBps"] = moved / t / 1e9  # what the memory side moved per second of the leg (L2 misses: Infinity-Cache hits are counted too)
                 if r.get("algorithmic_bytes_per_launch"):
                     r["moved_over_algorithmic"] = moved / r["algorithmic_bytes_per_launch"]
             if "SQ_INSTS_VALU" in tot:
@@ -719,6 +793,8 @@ def finish_rooflines(kernels, rf, me_kernel_s):
             r["binds"] = "mfma"
         else:
             r["binds"] = "valu" if (v >= h and v >= 0.35) else ("hbm" if (h > v and h >= 0.35) else "latency")
+            if r["binds"] == "hbm" and r.get("footprint_bytes") is not None and r["footprint_bytes"] <= L3_BYTES:
+                r["binds"] = "l3"  # the leg's whole working set sits in the 256 MiB Infinity Cache and every launch re-reads it: a cache rate, not a DRAM rate
     if isinstance(c3, dict) and c3.get("size_rooflines"):
         for sz, r in c3["size_rooflines"].items():
             if sz in c3["sizes"]:
@@ -776,7 +852,7 @@ def bench_sad_pairs(torch, lib, pkg, stream, a, cpu):
         checked += must_equal("sad64x64_pairs", got[f * 510:(f + 1) * 510], want)
     per, reps = time_leg(torch, fn, a.min_leg_s)
     out = {"launches_per_timed_batch": reps, "value": len(pairs) / per / 1e6, "unit": "Mblocks/s (64x64 pairs)", "footprint_MB": 2 * n_src * PLANE / 1e6, "parity_checked_values": checked,
-           "roofline": roofline(len(pairs) * 8192, per, "sad_nxm_strip_kernel" if os.environ.get("SVT_HIP_SAD_FORM") == "1" else "sad_nxm_pipe_kernel", algorithmic_bytes_per_block=8192,
+           "roofline": roofline(len(pairs) * 8192, per, "sad_nxm_strip_kernel" if os.environ.get("SVT_HIP_SAD_FORM") == "1" else "sad_nxm_pipe_kernel", algorithmic_bytes_per_block=8192, access="rows64_of_2056", footprint_bytes=int(2 * n_src * PLANE),
                                 note="disjoint src / ref plane sets, each byte read once per launch; footprint 1.2 GB")}
     if cpu:
         ref, oracle = ref_libs()
@@ -1044,6 +1120,32 @@ def bench_cdef(torch, lib, pkg, stream, a, cpu):
                      "parity_checked_values": checked,
                      "roofline": roofline(bytes_alg, per, "cdef_frame_kernel<unsigned short, %d, %s>" % (mode, (os.environ.get("SVT_HIP_CDEF_MINB") or "3") if mode else "4"),
                                           algorithmic_bytes_per_frame=bytes_alg)}
+    # ---- the whole 4:2:0 PICTURE of config 4 ("3840x2160 4:2:0 ... skip map all-non-skip and a 25 %-skip variant"): Y + U + V per call, both skip maps.
+    # The legs above time one luma plane (the unit the per-plane kernels are designed and priced in); these are what a picture costs.
+    Dc = [setup(Wc // 2, Hc // 2) for _ in range(2)]
+    gs = np.random.default_rng(41)
+    skip25 = (gs.random(D["skip"].shape) < 0.25).astype(np.uint8)  # 8x8 luma units left out (svt_sb_compute_cdef_list); chroma planes share the luma map
+    d_skip25 = t(skip25)
+
+    def pparams(Dp, mode, pl, skip_t, lum):
+        dec = 1 if pl else 0
+        return pkg.CdefParams(Dp["d_pl"].data_ptr(), Dp["d_src"].data_ptr(), Dp["d_out"].data_ptr(), Dp["w"], Dp["w"], Dp["w"], Dp["w"], Dp["h"], dec, dec, pl, 1, bd - 8, 4, 4, 1,
+                              64 if mode else 0, skip_t.data_ptr(), (Dp["d_pri"] if mode else Dp["apri"]).data_ptr(), (Dp["d_sec"] if mode else Dp["asec"]).data_ptr(),
+                              lum["d_dir"].data_ptr(), lum["d_var"].data_ptr(), Dp["d_mse"].data_ptr())
+    for tag, skip_t, frac_on in (("", D["d_skip"], 1.0), ("_skip25", d_skip25, float(1.0 - skip25.mean()))):
+        for mode, nm in ((1, "cdef_search_4k10_420%s" % tag), (0, "cdef_apply_4k10_420%s" % tag)):
+            PP = [pparams(D, mode, 0, skip_t, D), pparams(Dc[0], mode, 1, skip_t, D), pparams(Dc[1], mode, 2, skip_t, D)]
+
+            def fnp(PP=PP, mode=mode):
+                for q in PP:  # luma first: it writes the directions / variances the chroma planes read (cdef.c:367-386)
+                    lib.svt_hip_cdef_frame(mode, C.byref(q), stream)
+            perp, _ = time_leg(torch, fnp, a.min_leg_s)
+            px = Wc * Hc * 3 // 2
+            bytes_alg = int(px * 2 * 2 * (frac_on if not mode else 1.0)) + (3 * D["nfb"] * 64 * 8 if mode else 0)  # apply moves the filtered blocks; the search reads both pictures whole
+            out[nm] = {"frames_per_s": 1 / perp, "frame_us": perp * 1e6, "planes": 3, "units_on": round(frac_on, 4), "parity_checked_values": checked,
+                       "value": (n8 * 1.5 * frac_on) * (64 if mode else 1) / perp / 1e6, "unit": "M(8x8 block x strength)/s" if mode else "M(8x8 blocks)/s",
+                       "roofline": roofline(bytes_alg, perp, "cdef_frame_kernel<unsigned short, %d, ...> x 3 planes" % mode, algorithmic_bytes_per_frame=bytes_alg,
+                                            note="one 4:2:0 picture = three launches; tests/test_cdef.py compares the chroma planes and skip maps with the checker")}
     # apply with the directions the search pass just wrote (mode 2: what the CDEF stage runs after its strength search)
     P2 = params(D, 0)
     fn2 = lambda: lib.svt_hip_cdef_frame(2, C.byref(P2), stream)  # noqa: E731
@@ -1449,7 +1551,7 @@ def main():
     ap.add_argument("--min-leg-s", type=float, default=MIN_TIMED_S, help="minimum device time of every timed region (a step = as many launches as that takes)")
     ap.add_argument("--no-pmc", action="store_true", help="skip this run's own rocprofv3 --pmc child passes (roofline.traffic then comes from the committed summary)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (me, sad, txfm, config3, cdef, lr, hme, session, tf, tpl, tpl1, tfpic, lrsearch, cpart, satd): A/B measurements")
+    ap.add_argument("--legs", type=str, default="", help="comma list restricting the per-kernel legs (me, sad, txfm, config3, cdef, lr, hme, session, tf, tpl, tpl1, tfpic, lrstats, cdefchain, lrsearch, cpart, satd): A/B measurements")
     ap.add_argument("--extra", action="store_true", help="also sweep the other search areas / sub_sad and the remaining stages (reported under kernels)")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -1479,6 +1581,7 @@ def main():
     oracle = oracle_lib()
     regions.setup(torch, lib, stream, a.pmc_child)
     regions.probe()
+    regions.mem_probe()  # (counter passes only: known byte counts per access shape, the calibration of roofline.traffic)
 
     if a.probe:
         sink = torch.zeros(4, dtype=torch.int32, device="cuda")
@@ -1539,7 +1642,8 @@ def main():
     # areas up to 24x16 take the one-wave-per-item kernel (window pitch 18 or 26 dwords), larger ones the tiled workgroup kernel (csrc/sad.hip)
     me_kernel = "me_fullpel_wave_kernel<false, %d>" % (18 if (aw + 3) // 4 <= 2 else 26) if (aw <= 24 and ah <= 16) else "me_fullpel_kernel<false>"
     rf = roofline(n * bytes_item, kernel_s, me_kernel, None if (default_workload or LIVE_PMC is not None) else "-", kernel_ms=kernel_s * 1e3,
-                  algorithmic_bytes_per_sb_ref=bytes_item,
+                  algorithmic_bytes_per_sb_ref=bytes_item, access="rows128_of_2056",
+                  footprint_bytes=int(d_planes.numel() + d_descs.numel() + 2 * 4 * n * 85),  # planes + descriptors + both result tables: what the launches of a step re-read
                   note="search is VALU(packed-SAD)-bound, see valu_frac; HBM figure = SURVEY 8(d) algorithmic bytes / time",
                   sad_ops_per_s=n * aw * ah * 4096 / kernel_s,
                   # measured v_qsad_pk_u16_u8 issue cost: 22.4 cycles per wave64 instruction per SIMD (profiles/r01_call1_valu_issue_rates.txt)
@@ -1619,9 +1723,32 @@ def main():
                 b_item = 64 * 64 + (64 + w2 - 1) * (64 + h2 - 1) + 85 * 8
                 kernels["me_search_%dx%d_preset8_area" % (w2, h2)] = {
                     "value": len(dd) * w2 * h2 / per / 1e6, "unit": "Mblocks/s", "sb_refs": len(dd), "parity_checked_values": chk,
-                    "roofline": roofline(len(dd) * b_item, per, "me_fullpel_wave_kernel<false, 18>", algorithmic_bytes_per_sb_ref=b_item,
+                    "roofline": roofline(len(dd) * b_item, per, "me_fullpel_wave_kernel<false, 18>", algorithmic_bytes_per_sb_ref=b_item, access="rows128_of_2056",
+                                         footprint_bytes=int(d_planes.numel() + tdd.numel() + 2 * 4 * len(dd) * 85),
                                          valu_frac=len(dd) * w2 * h2 * 4096 / per / QSAD_PEAK,
-                                         note="valu_frac from the measured v_qsad_pk_u16_u8 rate, as the headline leg's")}
+                                         note="valu_frac from the measured v_qsad_pk_u16_u8 rate, as the headline leg's; the 134 MB working set stays in the 256 MiB "
+                                              "Infinity Cache from launch to launch (binds: l3) -- the _dram leg below rotates plane sets past it")}
+                # the same launch over ROT plane sets and result tables used in turn (footprint ROT x 134 MB > 256 MiB): no launch finds its planes in the Infinity Cache.
+                # Inside one launch every plane is still read as a source once and as a reference `refs` times -- that reuse is the algorithm's, the counters price it.
+                if True:
+                    ROT = 3
+                    rot_planes = [d_planes] + [d_planes.clone() for _ in range(ROT - 1)]
+                    rot_sad = [d_sad] + [torch.zeros_like(d_sad) for _ in range(ROT - 1)]
+                    rot_mv = [d_mv] + [torch.zeros_like(d_mv) for _ in range(ROT - 1)]
+                    turn = [0]
+
+                    def f3():
+                        k = turn[0] = (turn[0] + 1) % ROT
+                        lib.svt_hip_me_fullpel_search_batch(rot_planes[k].data_ptr(), rot_planes[k].data_ptr(), tdd.data_ptr(), len(dd), w2, h2, 0, rot_sad[k].data_ptr(),
+                                                            rot_mv[k].data_ptr(), None, stream)
+                    per3, _ = time_leg(torch, f3, a.min_leg_s)
+                    kernels["me_search_%dx%d_preset8_area_dram" % (w2, h2)] = {
+                        "value": len(dd) * w2 * h2 / per3 / 1e6, "unit": "Mblocks/s", "sb_refs": len(dd), "plane_sets_rotated": ROT,
+                        "roofline": roofline(len(dd) * b_item, per3, "me_fullpel_wave_kernel<false, 18>", algorithmic_bytes_per_sb_ref=b_item, access="rows128_of_2056",
+                                             footprint_bytes=int(ROT * (d_planes.numel() + 2 * 4 * len(dd) * 85) + tdd.numel()),
+                                             valu_frac=len(dd) * w2 * h2 * 4096 / per3 / QSAD_PEAK,
+                                             note="footprint beyond the Infinity Cache; identical results to the resident leg (same planes, same descriptors)")}
+                    del rot_planes, rot_sad, rot_mv
             step()  # (the shared result arrays hold the headline search again)
         if want("sad"):
             kernels["sad64x64_pairs"] = bench_sad_pairs(torch, lib, pkg, stream, a, cpu)
@@ -1669,6 +1796,10 @@ def main():
             kernels.update(bench_legs.tf_picture_stage(torch, lib, pkg, stream, 5, 1, keep))
             if cpu:
                 kernels["tf_picture_stage_1080p8_4refs_host"].update(cpu_tf_picture(keep))
+        if want("lrstats"):  # a24 on the matrix cores: the one MFMA kernel of the path, priced against the dense int8 peak (north_star: "MFMA utilisation against peak")
+            kernels.update(bench_legs.lr_stats(torch, lib, pkg, stream, 4, 1))
+        if want("cdefchain"):  # config 4's whole CDEF stage of a 4:2:0 picture: search (Y, U, V x 64 strengths) -> joint strength pick -> per-block assignment -> apply
+            kernels.update(bench_legs.cdef_chain(torch, lib, pkg, stream, 3, 1))
         if want("lrsearch"):
             keep = {}
             kernels.update(bench_legs.lr_search(torch, lib, pkg, stream, 2, 1, keep))
@@ -1702,8 +1833,6 @@ def main():
         kernels.update(bench_legs.hme_sad_loop(torch, lib, pkg, stream, es, 3))
         kernels.update(bench_legs.picprep(torch, lib, pkg, stream, max(es // 2, 2), 1))
         kernels.update(bench_legs.deblock(torch, lib, pkg, stream, max(es // 2, 2), 1))
-        kernels.update(bench_legs.lr_stats(torch, lib, pkg, stream, max(es // 2, 2), 1))
-        kernels.update(bench_legs.cdef_chain(torch, lib, pkg, stream, max(es // 4, 2), 1))
         kernels.update(bench_legs.me_session(torch, lib, pkg, stream, es, 1))
         kernels.update(bench_legs.me_results(torch, lib, pkg, stream, es, 1))
         kernels.update(bench_legs.me_stage(torch, lib, pkg, stream, es, 1))
@@ -1726,8 +1855,13 @@ def main():
         if not a.only_me and not a.legs:
             out["encoder_fps_1080p_preset8"] = encoder_fps()
             attach_encoder_baselines(kernels, out["encoder_fps_1080p_preset8"])
+            out["encoder_fps_4k10_preset8"] = encoder_fps_4k10(1)  # BASELINE configs[4] at one GPU (the N-GPU form: below, rank 0 of a --gpus N run)
     elif rank == 0:
         out["cpu_baseline"] = None
+        if world > 1 and not a.no_cpu and not a.pmc_child and not a.legs and not a.only_me:
+            # BASELINE configs[4] on this node's GPUs: the reference encoder with its pictures sharded over SVT_HIP_DEVICES=0..N-1 (the other ranks wait at the barrier below;
+            # their GPUs are idle by now).  Identity against the C-only encoder is decided inside; a failure is reported in the object, never raised.
+            out["encoder_fps_4k10_preset8"] = encoder_fps_4k10(world)
     rf["traffic_source"] = (rf.get("traffic_detail") or {}).get("source")
     rf["pmc_seconds"] = (LIVE_PMC or {}).get("_seconds")
     if rf.get("traffic") and rf.get("algorithmic_bytes_per_launch"):
@@ -1743,6 +1877,7 @@ def main():
     elif rank == 0:
         emit(out, a)
     if dist is not None:
+        dist.barrier()  # (rank 0 may just have spent a minute in the N-device encode)
         dist.destroy_process_group()
 
 

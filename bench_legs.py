@@ -188,6 +188,36 @@ def lr_frames(torch, lib, pkg, stream, steps, warmup):
         nbytes = Wc * Hc * 4 + 4 * nstripes * Wc * 2
         out["lr_%s_4k10" % name] = {"frames_per_s": 1 / t, "Mpx_s": Wc * Hc / t / 1e6, "ms": t * 1e3,
                                     "roofline": roof(nbytes, t, "lr_frame_kernel<%s>" % (os.environ.get("SVT_HIP_LR_UR") or "32"), algorithmic_bytes_per_frame=nbytes)}
+    if only:
+        return out
+    # ---- the whole 4:2:0 PICTURE: Y with 256-sample units + U, V at half size with 128-sample units (chroma units cover the same picture area,
+    # restoration.c:1146-1160; 64-row stripes become 32 chroma rows offset by 4), mixed unit types, one launch per plane
+    cw, ch, cus = Wc // 2, Hc // 2, us // 2
+    cstripes = (ch + 4 + 31) // 32
+    cplane = [np.ascontiguousarray(plane[::2, ::2]), np.ascontiguousarray(plane[1::2, 1::2])]
+    cnvu, cnhu = max((ch + cus // 2) // cus, 1), max((cw + cus // 2) // cus, 1)
+    Ps = [pkg.LrParams(d_pl.data_ptr(), d_ab.data_ptr(), d_bl.data_ptr(), d_out.data_ptr(), Wc, Wc, Wc, Wc, Hc, us, 0, 0, 1, bd, d_un.data_ptr())]
+    keepalive = []
+    for k in range(2):
+        cun = np.zeros(cnvu * cnhu, dtype=pkg.LrUnit)
+        for i in range(len(cun)):
+            f = [int(g.integers(-5, 11)), int(g.integers(-23, 9)), int(g.integers(-17, 47))]
+            taps = [0, f[1], f[2], -2 * (f[1] + f[2]), f[2], f[1], 0, 0]  # chroma: 5-tap Wiener (WIENER_WIN_CHROMA)
+            cun[i] = ([1, 2, 0, 2, 1][i % 5], taps, taps, int(g.integers(0, 16)), (int(g.integers(-96, 32)), int(g.integers(-32, 96))))
+        dcp, dcu = _dev(torch, cplane[k]), _dev(torch, cun)
+        dca, dcb = _dev(torch, g.integers(0, 1024, (2 * cstripes, cw)).astype(np.uint16)), _dev(torch, g.integers(0, 1024, (2 * cstripes, cw)).astype(np.uint16))
+        dco = torch.zeros(ch * cw, dtype=torch.int16, device="cuda")
+        keepalive += [dcp, dcu, dca, dcb, dco]
+        Ps.append(pkg.LrParams(dcp.data_ptr(), dca.data_ptr(), dcb.data_ptr(), dco.data_ptr(), cw, cw, cw, cw, ch, cus, 1, 1, 1, bd, dcu.data_ptr()))
+
+    def frame():
+        for q in Ps:
+            lib.svt_hip_lr_filter_frame(C.byref(q), stream)
+    t = _time(torch, frame, steps, warmup)
+    nbytes = (Wc * Hc * 4 + 4 * nstripes * Wc * 2) + 2 * (cw * ch * 4 + 4 * cstripes * cw * 2)
+    out["lr_mixed_4k10_420"] = {"frames_per_s": 1 / t, "frame_us": t * 1e6, "planes": 3, "Mpx_s": Wc * Hc * 1.5 / t / 1e6,
+                                "roofline": roof(nbytes, t, "lr_frame_kernel<%s> x 3 planes" % (os.environ.get("SVT_HIP_LR_UR") or "32"), algorithmic_bytes_per_frame=nbytes,
+                                                 note="one 4:2:0 picture = three launches (Y 256-sample units, U / V 128-sample units, sub-sampled stripes)")}
     return out
 
 
@@ -332,7 +362,8 @@ def lr_stats(torch, lib, pkg, stream, steps, warmup):
     issued = 3 * 64 * 64 * w * h * 2  # int8 ops (multiply + add) handed to the matrix cores
     return {"lr_compute_stats_4k10_win7": {"frames_per_s": 1 / t, "ms": t * 1e3, "units": n, "algorithmic_GMAC_s": w * h * 50 * 51 / 2 / t / 1e9,
                                            "roofline": {"bound": "mfma", "achieved": issued / t / 1e12, "peak": 5000.0, "unit": "TOP/s (int8, dense)",
-                                                        "frac": issued / t / 1e12 / 5000.0,
+                                                        "frac": issued / t / 1e12 / 5000.0, "kernel": "stats_mfma_kernel", "kernel_us": t * 1e6, "region": regions.LAST,
+                                                        "algorithmic_bytes_per_launch": w * h * 2 * 2 + n * (49 + 49 * 49) * 8,
                                                         "note": "issued int8 ops incl. 64-column padding and the three digit products; peak = 2x the 2.5 PFLOP/s bf16 dense figure"}}}
 
 

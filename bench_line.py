@@ -95,6 +95,10 @@ def compact(out):
         if isinstance(ss, dict):
             e["steady_state_300_frames"] = _pick(ss, ("fps_avx2_intrinsics", "fps_avx2_host_with_stage_seams", "fps_avx512_intrinsics", "fps_avx512_host_with_stage_seams"), 4)
         line["encoder_fps_1080p_preset8"] = e
+    e4 = out.get("encoder_fps_4k10_preset8")
+    if isinstance(e4, dict):  # BASELINE configs[4]: [host alone, host + every stage seam] fps, identity decided on the first attempt
+        line["encoder_fps_4k10_preset8"] = _pick(e4, ("frames", "host", "n_devices", "fps_c_only", "fps_host_alone", "fps_host_with_stage_seams", "bitstream_identical",
+                                                      "first_attempt", "error"), 4)
     fp = out.get("frame_partition")
     if isinstance(fp, dict):
         line["frame_partition"] = _pick(fp, ("value", "ms_per_step", "scaling", "collective"), 4)  # (Mblocks/s of one picture x its references per launch: detail file)

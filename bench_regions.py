@@ -80,9 +80,33 @@ def probe():
     PROBE["wave_insts_expected"] = blocks * 4 * iters * 16  # 256 threads = 4 waves per block, 8 chains x 2 instructions per iteration
 
 
+# access shapes the traffic counters are calibrated on: name -> (bytes per lane, segment bytes, pitch bytes); "stream" shapes are contiguous
+MEM_SHAPES = {"stream16": (16, 1 << 20, 1 << 20), "stream8": (8, 1 << 20, 1 << 20), "stream4": (4, 1 << 20, 1 << 20),
+              "rows64_of_2056": (16, 64, 2056),   # 64-byte block rows of a padded 1080p luma plane, 16 B/lane: the independent-pair SAD kernel
+              "rows128_of_2056": (4, 128, 2056)}  # dword reads of ~search-window rows of the same plane: the ME search kernels
+MEM_PROBE = {}     # tag -> bytes moved per call (child only)
+
+
+def mem_probe():
+    """the traffic calibration regions: svt_hip_mem_probe moves a KNOWN number of bytes in each access shape of MEM_SHAPES, reading and writing, over a buffer larger than the
+    256 MiB Infinity Cache; the parent divides the known bytes by the FETCH_SIZE / WRITE_SIZE the pass reports for the region."""
+    if not PMC_CHILD:
+        return
+    total = 768 << 20
+    buf = _torch.empty(total + (4 << 20), dtype=_torch.uint8, device="cuda")
+    for name, (w, seg, pitch) in MEM_SHAPES.items():
+        lanes = (total // pitch) * (seg // w)
+        for wr in (0, 1):
+            fn = lambda wr=wr, w=w, seg=seg, pitch=pitch, lanes=lanes: _lib.svt_hip_mem_probe(wr, w, buf.data_ptr(), lanes, seg, pitch, _sink.data_ptr(), _stream)  # noqa: E731
+            idx = open_region(1, "mem_%s_%s" % ("w" if wr else "r", name))
+            pmc_run(fn, idx)
+            MEM_PROBE[TAGS[idx]] = lanes * w
+    del buf
+
+
 def dump(path):
     with open(path, "w") as f:
-        json.dump({"tags": TAGS, "calls": CALLS, "probe": PROBE}, f)
+        json.dump({"tags": TAGS, "calls": CALLS, "probe": PROBE, "mem_probe": MEM_PROBE}, f)
 
 
 def parse_counter_csv(path, tags, counters):

@@ -107,6 +107,9 @@ void       *svt_hip_graph_capture_end(void *stream);   /* returns an executable 
 void        svt_hip_graph_launch(void *graph_exec, void *stream);
 void        svt_hip_graph_destroy(void *graph_exec);
 void        svt_hip_rate_probe(int kind, uint32_t iters, uint32_t blocks, uint32_t *sink, void *stream);
+/* Memory-traffic probe (bench.py calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE on it, per access shape): grid lane t moves `width` (4 / 8 / 16) bytes of segment
+ * t / (seg / width) -- segments of `seg` bytes every `pitch` bytes from `base` -- reading (write = 0) or storing (write = 1) every byte exactly once: lanes * width bytes. */
+void        svt_hip_mem_probe(int write, int width, void *base, uint64_t lanes, uint32_t seg, uint32_t pitch, uint32_t *sink, void *stream);
 
 /* ---------------------------------------------------------------- SAD family (a1-a6) -------------- */
 /* a1. svt_nxm_sad_kernel -> svt_nxm_sad_kernel_helper_c (Source/Lib/C_DEFAULT/compute_sad_c.c:209, body :20-37) */

@@ -522,6 +522,33 @@ template <int KIND> __global__ __launch_bounds__(256) void svt_hip_rate_kernel(u
     if (r == 0x12345u) sink[0] = r;
 }
 
+// Memory-traffic probe (bench.py's calibration of rocprofv3's FETCH_SIZE / WRITE_SIZE: MI355X_MICROARCH.md says the gfx950 factor of 2 holds for wide coalesced streaming
+// reads only and that every other access shape has to be calibrated on a known byte count).  Lane t of the grid moves W bytes of segment (t / (seg / W)), at offset
+// (t % (seg / W)) * W inside it; segment s starts at s * pitch -- so (W = 16, seg = pitch) is a contiguous 16 B/lane stream, (16, 64, 2056) is the 64-byte rows of a padded
+// 1080p luma plane that the independent-pair SAD kernel walks, (4, ...) the dword accesses of the search kernels.  READ: every byte is loaded once and folded into a word
+// that is (never) stored; WRITE: every byte is stored once.
+struct alignas(8) ProbeW2 { uint32_t x, y; };
+struct alignas(16) ProbeW4 { uint32_t x, y, z, w; };
+template <int W, bool WRITE> __global__ __launch_bounds__(256) void svt_hip_mem_probe_kernel(uint8_t* __restrict__ base, const uint64_t lanes, const uint32_t seg, const uint32_t pitch,
+                                                                                             uint32_t* __restrict__ sink) {
+    const uint32_t per = seg / W;
+    uint32_t       acc = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < lanes; t += (uint64_t)gridDim.x * 256) {
+        uint8_t* p = base + (t / per) * (uint64_t)pitch + (t % per) * W;
+        if constexpr (W == 4) {
+            if (WRITE) *(uint32_t*)p = (uint32_t)t;
+            else acc ^= *(const uint32_t*)p;
+        } else if constexpr (W == 8) {
+            if (WRITE) *(ProbeW2*)p = ProbeW2{(uint32_t)t, 1u};
+            else { const ProbeW2 v = *(const ProbeW2*)p; acc ^= v.x ^ v.y; }
+        } else {
+            if (WRITE) *(ProbeW4*)p = ProbeW4{(uint32_t)t, 1u, 2u, 3u};
+            else { const ProbeW4 v = *(const ProbeW4*)p; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+        }
+    }
+    if (!WRITE && acc == 0x9e3779b9u) sink[0] = acc;
+}
+
 // Delay kernel (test instrument): one lane waits `ticks` of the constant-rate wall clock, so that whatever is queued behind it on its stream starts late.
 __global__ void svt_hip_spin_kernel(uint32_t ticks) {
 #ifndef SVT_HIP_EMU
@@ -550,6 +577,20 @@ void svt_hip_debug_spin(void* stream, uint32_t microseconds) {
     if (microseconds > 100000) microseconds = 100000;
     const uint64_t ticks = (uint64_t)microseconds * (uint64_t)k / 1000;
     hipLaunchKernelGGL(svt_hip_spin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint32_t)ticks);
+    SVT_LAUNCH_CHECK();
+}
+
+// bytes moved = lanes * width; width 4 / 8 / 16, segment and pitch multiples of width, base aligned to it; the buffer holds ceil(lanes / (seg / width)) * pitch bytes
+void svt_hip_mem_probe(int write, int width, void* base, uint64_t lanes, uint32_t seg, uint32_t pitch, uint32_t* sink, void* stream) {
+    svthip::ensure_device();
+    hipStream_t  st = (hipStream_t)stream;
+    uint8_t*     b  = (uint8_t*)base;
+    const dim3   grid(256 * 32), blk(256);
+#define PROBE(W, WR) hipLaunchKernelGGL(HIP_KERNEL_NAME(svt_hip_mem_probe_kernel<W, WR>), grid, blk, 0, st, b, lanes, seg, pitch, sink)
+    if (width == 4) { if (write) PROBE(4, true); else PROBE(4, false); }
+    else if (width == 8) { if (write) PROBE(8, true); else PROBE(8, false); }
+    else { if (write) PROBE(16, true); else PROBE(16, false); }
+#undef PROBE
     SVT_LAUNCH_CHECK();
 }
 

@@ -117,6 +117,7 @@ CASES = {
     # larger pictures: more work per stage call against the same fixed latency
     "fps_4k8_p8_all": (3840, 2160, 30, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam"]),
     "fps_4k10_p8_all_tplrecon": (3840, 2160, 60, 10, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
+    "fps_4k10_p8_30": (3840, 2160, 30, 10, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),  # BASELINE configs[4] at one GPU: bench.py's encoder_fps_4k10_preset8 (30 frames)
     "fps_4k8_p8_all_tplrecon": (3840, 2160, 30, 8, ["--preset", "8", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
     "fps_1080p_p6_all_tplrecon": (1920, 1080, 32, 8, ["--preset", "6", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
     "fps_1080p_p4_all_tplrecon": (1920, 1080, 12, 8, ["--preset", "4", "+seam", "+tfseam", "+tfsubpel", "+tfdriver", "+lrseam", "+cdefseam", "+dlfseam", "+tplseam", "+tplrecon"]),
