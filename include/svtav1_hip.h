@@ -1042,6 +1042,11 @@ typedef struct SvtHipRect { int32_t h_start, h_end, v_start, v_end; } SvtHipRect
  * int32 / int64 accumulation: exact). */
 void svt_hip_lr_compute_stats_batch(const void *dgd, const void *src, const SvtHipRect *rects, uint32_t n, int max_rect_width, int max_rect_height,
                                     int dgd_stride, int src_stride, int wiener_win, int bit_depth, int64_t *M, int64_t *H, void *stream);
+/* the same with the sample size stated (1 or 2 bytes) instead of derived from the bit depth: the reference's highbd function takes 16-bit pictures at every bit depth,
+ * 8 included (an 8-bit encode in the 16-bit pipeline; av1_compute_stats_test_hbd runs it at EB_EIGHT_BIT, test/RestorationPickTest.cc:576-583).  The form above is
+ * this one with sample_bytes = bit_depth > 8 ? 2 : 1. */
+void svt_hip_lr_compute_stats_batch_samples(const void *dgd, const void *src, const SvtHipRect *rects, uint32_t n, int max_rect_width, int max_rect_height,
+                                            int dgd_stride, int src_stride, int wiener_win, int bit_depth, int sample_bytes, int64_t *M, int64_t *H, void *stream);
 /* single-call forms (aom_dsp_rtcd.h:62-81,210-215,276; common_dsp_rtcd.h:1075-1087) */
 int      svt_aom_satd_hip(const int32_t *coeff, int length);
 void     svt_aom_hadamard_nxn_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff, int n);

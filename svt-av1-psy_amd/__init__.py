@@ -579,6 +579,7 @@ _PE = [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp, C.c_int32, vp, C.
 PROTOTYPES.update({
     "svt_hip_hadamard_satd_batch": (None, [vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp]),
     "svt_hip_lr_compute_stats_batch": (None, [vp, vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "svt_hip_lr_compute_stats_batch_samples": (None, [vp, vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "svt_aom_satd_hip": (C.c_int, [vp, C.c_int]),
     "svt_aom_hadamard_nxn_hip": (None, [vp, C.c_ssize_t, vp, C.c_int]),
     "svt_hadamard_path_hip": (C.c_uint32, [vp, C.c_uint32, vp, C.c_uint32, C.c_int]),

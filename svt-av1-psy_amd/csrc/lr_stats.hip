@@ -297,10 +297,14 @@ extern "C" {
 
 void svt_hip_lr_compute_stats_batch(const void* dgd, const void* src, const SvtHipRect* rects, uint32_t n, int max_rect_width, int max_rect_height, int dgd_stride,
                                     int src_stride, int wiener_win, int bit_depth, int64_t* M, int64_t* H, void* stream) {
+    svt_hip_lr_compute_stats_batch_samples(dgd, src, rects, n, max_rect_width, max_rect_height, dgd_stride, src_stride, wiener_win, bit_depth, bit_depth > 8 ? 2 : 1, M, H, stream);
+}
+void svt_hip_lr_compute_stats_batch_samples(const void* dgd, const void* src, const SvtHipRect* rects, uint32_t n, int max_rect_width, int max_rect_height, int dgd_stride,
+                                            int src_stride, int wiener_win, int bit_depth, int sample_bytes, int64_t* M, int64_t* H, void* stream) {
     svthip::ensure_device();
     if (n == 0) return;
     hipStream_t st = (hipStream_t)stream;
-    const int   is16 = bit_depth > 8, w2 = wiener_win * wiener_win;
+    const int   is16 = sample_bytes == 2, w2 = wiener_win * wiener_win;
     HIP_CHECK(hipMemsetAsync(M, 0, (size_t)n * 49 * 8, st));
     HIP_CHECK(hipMemsetAsync(H, 0, (size_t)n * 49 * 49 * 8, st));
     hipLaunchKernelGGL(stats_sum_kernel, dim3((max_rect_height + 15) / 16, n), dim3(256), 0, st, dgd, rects, dgd_stride, is16, w2, (long long*)H);

@@ -261,9 +261,11 @@ void svt_residual_kernel16bit_hip(uint16_t* input, uint32_t is, uint16_t* pred, 
     residual_host(input, is, pred, ps, residual, rs, w, h, 1);
 }
 
+// px = bytes per sample of the caller's pictures: svt_av1_compute_stats_highbd takes 16-bit pictures at EVERY bit depth, 8 included (the 16-bit pipeline of an 8-bit encode;
+// the reference's own av1_compute_stats_test_hbd runs it at EB_EIGHT_BIT, test/RestorationPickTest.cc:576-583)
 static void stats_host(int win, const void* dgd, const void* src, int h_start, int h_end, int v_start, int v_end, int dgd_stride, int src_stride, int64_t* M,
-                       int64_t* H, int bit_depth) {
-    const int px = bit_depth > 8 ? 2 : 1, hw = win >> 1, W = h_end - h_start, Hh = v_end - v_start;
+                       int64_t* H, int bit_depth, int px) {
+    const int hw = win >> 1, W = h_end - h_start, Hh = v_end - v_start;
     svthip::HostCall& c = svthip::host_call();
     c.begin();
     const size_t dp = svthip::align_up((size_t)(W + 2 * hw) * px, 16), sp = svthip::align_up((size_t)W * px, 16);
@@ -278,7 +280,7 @@ static void stats_host(int win, const void* dgd, const void* src, int h_start, i
     SvtHipRect R = {0, W, 0, Hh};
     c.up(dr, &R, sizeof(R));
     // origin of the uploaded dgd rectangle is (hw, hw)
-    svt_hip_lr_compute_stats_batch(dd + (hw * dp + hw * px), ds, dr, 1, W, Hh, (int)(dp / px), (int)(sp / px), win, bit_depth, dM, dH, c.stream);
+    svt_hip_lr_compute_stats_batch_samples(dd + (hw * dp + hw * px), ds, dr, 1, W, Hh, (int)(dp / px), (int)(sp / px), win, bit_depth, px, dM, dH, c.stream);
     const int w2 = win * win;
     int64_t   hM[49], hH[49 * 49];
     c.down_later(hM, dM, 49 * 8);
@@ -289,12 +291,12 @@ static void stats_host(int win, const void* dgd, const void* src, int h_start, i
 }
 void svt_av1_compute_stats_hip(int32_t wiener_win, const uint8_t* dgd, const uint8_t* src, int32_t h_start, int32_t h_end, int32_t v_start, int32_t v_end,
                                int32_t dgd_stride, int32_t src_stride, int64_t* M, int64_t* H) {
-    stats_host(wiener_win, dgd, src, h_start, h_end, v_start, v_end, dgd_stride, src_stride, M, H, 8);
+    stats_host(wiener_win, dgd, src, h_start, h_end, v_start, v_end, dgd_stride, src_stride, M, H, 8, 1);
 }
 void svt_av1_compute_stats_highbd_hip(int32_t wiener_win, const uint8_t* dgd8, const uint8_t* src8, int32_t h_start, int32_t h_end, int32_t v_start, int32_t v_end,
                                       int32_t dgd_stride, int32_t src_stride, int64_t* M, int64_t* H, unsigned int bit_depth) {
     stats_host(wiener_win, (const void*)((uintptr_t)dgd8 << 1), (const void*)((uintptr_t)src8 << 1), h_start, h_end, v_start, v_end, dgd_stride, src_stride, M, H,
-               bit_depth);
+               (int)bit_depth, 2);
 }
 
 static void proj_host(int mode, const void* src, int width, int height, int src_stride, const void* dat, int dat_stride, const int32_t* flt0, int f0s,

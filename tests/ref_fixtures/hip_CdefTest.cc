@@ -43,10 +43,56 @@ INSTANTIATE_TEST_SUITE_P(HIP, CDEFBlockInteriorTest,
                          ::testing::Combine(::testing::Values(&svt_cdef_filter_block_hip), ::testing::Values(&svt_cdef_filter_block_c),
                                             ::testing::Values(BLOCK_4X4, BLOCK_4X8, BLOCK_8X4, BLOCK_8X8), ::testing::Values(0), ::testing::Range(8, 13, 2),
                                             ::testing::Values(0)));
-// CdefTest.cc:507-510 (AVX2, CDEFFindDirTest)
-INSTANTIATE_TEST_SUITE_P(HIP, CDEFFindDirTest, ::testing::Values(make_tuple(&svt_aom_cdef_find_dir_hip, &svt_aom_cdef_find_dir_c)));
-// CdefTest.cc:652-655 (AVX2, CDEFFindDirDualTest)
-INSTANTIATE_TEST_SUITE_P(HIP, CDEFFindDirDualTest, ::testing::Values(make_tuple(&svt_aom_cdef_find_dir_dual_hip, &svt_aom_cdef_find_dir_dual_c)));
+// CdefTest.cc:507-510 / :652-655 (AVX2, CDEFFindDirTest / CDEFFindDirDualTest).  The reference's loops call the function 512 x (256 levels x 8..12 noise widths) x 3 depths
+// = 3.9 million times (:459-481) -- 9 and 12 MINUTES of PCIe round trips for the two tests (profiles/r06_reference_fixtures.txt: both green).  They are instantiated under
+// the prefix HIPFULL, which tests/test_ref_fixtures.py runs only with SVT_HIP_FIXTURES=full; the default run takes the derived fixtures below: the same generator and the
+// same checks over 12 of the 512 repetitions (every depth, level and noise width kept).
+INSTANTIATE_TEST_SUITE_P(HIPFULL, CDEFFindDirTest, ::testing::Values(make_tuple(&svt_aom_cdef_find_dir_hip, &svt_aom_cdef_find_dir_c)));
+INSTANTIATE_TEST_SUITE_P(HIPFULL, CDEFFindDirDualTest, ::testing::Values(make_tuple(&svt_aom_cdef_find_dir_dual_hip, &svt_aom_cdef_find_dir_dual_c)));
+
+class CDEFFindDirFewerRepeatsTest : public CDEFFindDirTest {
+  public:
+    void test_finddir_repeats(const int repeats) {  // test_finddir() of CdefTest.cc:455-485 with `count < repeats`
+        for (int depth = 8; depth <= 12; depth += 2)
+            for (int count = 0; count < repeats; count++)
+                for (int level = 0, shift = depth - 8; level < (1 << depth); level += 1 << shift)
+                    for (int bits = 1; bits <= depth; bits++) {
+                        prepare_data(depth, bits, level);
+                        int32_t       var_ref = 0, var_tst = 0;
+                        const uint8_t res_ref = func_ref_(src_, size_, &var_ref, shift), res_tst = func_tst_(src_, size_, &var_tst, shift);
+                        ASSERT_EQ(res_tst, res_ref) << "direction, depth " << depth << " level " << level << " bits " << bits;
+                        ASSERT_EQ(var_tst, var_ref) << "variance, depth " << depth << " level " << level << " bits " << bits;
+                    }
+    }
+};
+TEST_P(CDEFFindDirFewerRepeatsTest, MatchTest) {
+    test_finddir_repeats(12);
+}
+INSTANTIATE_TEST_SUITE_P(HIP, CDEFFindDirFewerRepeatsTest, ::testing::Values(make_tuple(&svt_aom_cdef_find_dir_hip, &svt_aom_cdef_find_dir_c)));
+
+class CDEFFindDirDualFewerRepeatsTest : public CDEFFindDirDualTest {
+  public:
+    void test_finddir_repeats(const int repeats) {  // test_finddir() of CdefTest.cc:575-633 with `count < repeats`
+        for (int depth = 8; depth <= 12; depth += 2)
+            for (int count = 0; count < repeats; count++)
+                for (int level = 0, shift = depth - 8; level < (1 << depth); level += 1 << shift)
+                    for (int bits = 1; bits <= depth; bits++) {
+                        prepare_data(depth, bits, level);
+                        uint8_t r1 = 0, r2 = 0, t1 = 0, t2 = 0;
+                        int32_t vr1 = 0, vr2 = 0, vt1 = 0, vt2 = 0;
+                        func_ref_(src_, src2_, size_, &vr1, &vr2, shift, &r1, &r2);
+                        func_tst_(src_, src2_, size_, &vt1, &vt2, shift, &t1, &t2);
+                        ASSERT_EQ(t1, r1) << "direction 1, depth " << depth << " level " << level << " bits " << bits;
+                        ASSERT_EQ(t2, r2) << "direction 2, depth " << depth << " level " << level << " bits " << bits;
+                        ASSERT_EQ(vt1, vr1) << "variance 1, depth " << depth << " level " << level << " bits " << bits;
+                        ASSERT_EQ(vt2, vr2) << "variance 2, depth " << depth << " level " << level << " bits " << bits;
+                    }
+    }
+};
+TEST_P(CDEFFindDirDualFewerRepeatsTest, MatchTest) {
+    test_finddir_repeats(12);
+}
+INSTANTIATE_TEST_SUITE_P(HIP, CDEFFindDirDualFewerRepeatsTest, ::testing::Values(make_tuple(&svt_aom_cdef_find_dir_dual_hip, &svt_aom_cdef_find_dir_dual_c)));
 }  // namespace
 // CdefTest.cc:752-754, :878-880, :985-987, :1156-1157 (AVX2)
 INSTANTIATE_TEST_SUITE_P(HIP, CDEFCopyRectTest, ::testing::Values(svt_aom_copy_rect8_8bit_to_16bit_hip));

@@ -28,4 +28,25 @@ const QuantizeQmParam kQmParamArrayHip[]    = {QM_ALL(svt_av1_quantize_fp_qm_c, 
 const QuantizeQmParam kQmParamHbdArrayHip[] = {QM_ALL(svt_av1_highbd_quantize_fp_qm_c, svt_av1_highbd_quantize_fp_qm_hip, EB_TEN_BIT)};
 INSTANTIATE_TEST_SUITE_P(HIP, QuantizeQmTest, ::testing::ValuesIn(kQmParamArrayHip));
 INSTANTIATE_TEST_SUITE_P(HIP, QuantizeQmHbdTest, ::testing::ValuesIn(kQmParamHbdArrayHip));
+
+// The reference's MultipleQ test (quantize_func_test.cc:285-289 and its three siblings) calls the function 256 q indices x kTestNum = 1000 random blocks = 256 000 times per
+// parameter set, 47 sets: twelve million PCIe round trips (45 of the 60 CPU-minutes of the whole fixture run, profiles/r06_reference_fixtures.txt: all green).  The default run of
+// tests/test_ref_fixtures.py leaves `*.MultipleQ/*` to SVT_HIP_FIXTURES=full and takes these derived fixtures instead: the fixture's own QuantizeRun() -- generator, reference
+// call and element-wise checks -- over EVERY q index with 24 random blocks each.
+#define HIP_MULTIPLE_Q_FEWER_BLOCKS(Derived, Base)         \
+    class Derived : public Base {};                        \
+    TEST_P(Derived, EveryQ) {                              \
+        for (int q = 0; q < QINDEX_RANGE; ++q) {           \
+            QuantizeRun(true, q, 24);                      \
+            if (::testing::Test::HasFatalFailure())        \
+                return;                                    \
+        }                                                  \
+    }
+HIP_MULTIPLE_Q_FEWER_BLOCKS(QuantizeLbdFewerBlocksTest, QuantizeLbdTest)
+HIP_MULTIPLE_Q_FEWER_BLOCKS(QuantizeHbdFewerBlocksTest, QuantizeHbdTest)
+HIP_MULTIPLE_Q_FEWER_BLOCKS(QuantizeQmFewerBlocksTest, QuantizeQmTest)
+INSTANTIATE_TEST_SUITE_P(HIP, QuantizeLbdFewerBlocksTest, ::testing::ValuesIn(kQParamArrayHip));
+INSTANTIATE_TEST_SUITE_P(HIP, QuantizeHbdFewerBlocksTest, ::testing::ValuesIn(kQHbdParamArrayHip));
+INSTANTIATE_TEST_SUITE_P(HIP, QuantizeQmFewerBlocksTest, ::testing::ValuesIn(kQmParamArrayHip));
+INSTANTIATE_TEST_SUITE_P(HIP_HBD, QuantizeQmFewerBlocksTest, ::testing::ValuesIn(kQmParamHbdArrayHip));
 }  // namespace

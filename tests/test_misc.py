@@ -129,6 +129,22 @@ def test_lr_search_statistics(be, oracle, bd):
     else:
         be.lib.svt_av1_compute_stats_highbd_hip(7, byteptr(dgd), byteptr(src), 6, 6 + W, 5, 5 + H, S, S, p(M1), p(H1), bd)
     assert np.array_equal(M0, M1) and np.array_equal(H0, H1)
+    if bd == 8:
+        # the highbd entry point at bit depth 8 = 16-bit pictures holding 8-bit samples (an 8-bit encode in the 16-bit pipeline; the reference's own
+        # av1_compute_stats_test_hbd runs this, test/RestorationPickTest.cc:576-583 -- where round 6's fixture run found this library reading the pictures as bytes)
+        d16, s16 = dgd.astype(np.uint16), src.astype(np.uint16)
+        M2, H2 = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
+        be.lib.svt_av1_compute_stats_highbd_hip(7, byteptr(d16), byteptr(s16), 6, 6 + W, 5, 5 + H, S, S, p(M2), p(H2), 8)
+        assert np.array_equal(M0, M2) and np.array_equal(H0, H2), "highbd statistics at bit depth 8"
+        dd, ds, dr = be.dev(d16), be.dev(s16), be.dev(rects)
+        M, Hm = be.empty((len(rects), 49), np.int64), be.empty((len(rects), 49 * 49), np.int64)
+        be.lib.svt_hip_lr_compute_stats_batch_samples(be.ptr(dd), be.ptr(ds), be.ptr(dr), len(rects), max(r[1] - r[0] for r in rect_list), max(r[3] - r[2] for r in rect_list), S, S,
+                                                      5, 8, 2, be.ptr(M), be.ptr(Hm), be.stream)
+        gM, gH = be.host(M), be.host(Hm)
+        for i, (hs, he, vs, ve) in enumerate(rect_list):
+            M3, H3 = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
+            oracle.oracle_compute_stats(5, p(dgd), p(src), hs, he, vs, ve, S, S, p(M3), p(H3), 8)
+            assert np.array_equal(gM[i][:25], M3[:25]) and np.array_equal(gH[i][:625], H3[:625]), ("16-bit samples at bit depth 8", i)
     f0 = np.ascontiguousarray(((dgd[:H, :W].astype(np.int32) << 4) + g.integers(-300, 301, (H, W))).astype(np.int32))
     f1 = np.ascontiguousarray(((dgd[:H, :W].astype(np.int32) << 4) + g.integers(-300, 301, (H, W))).astype(np.int32))
     for (r0, r1) in ((2, 1), (0, 1), (2, 0)):
