@@ -82,8 +82,11 @@ def probe():
 
 # access shapes the traffic counters are calibrated on: name -> (bytes per lane, segment bytes, pitch bytes); "stream" shapes are contiguous
 MEM_SHAPES = {"stream16": (16, 1 << 20, 1 << 20), "stream8": (8, 1 << 20, 1 << 20), "stream4": (4, 1 << 20, 1 << 20),
-              "rows64_of_2056": (16, 64, 2056),   # 64-byte block rows of a padded 1080p luma plane, 16 B/lane: the independent-pair SAD kernel
-              "rows128_of_2056": (4, 128, 2056)}  # dword reads of ~search-window rows of the same plane: the ME search kernels
+              "rows64_of_2056": (16, 64, 2056),   # ISOLATED 64-byte segments, one per 2056-byte row (nothing else of the row is read): what a short strided access costs
+              "rows128_of_2056": (4, 128, 2056)}  # isolated 128-byte segments read as dwords
+# the block kernels' shape (svt_hip_mem_probe_blocks): 64x64-byte blocks tiling padded 1080p luma planes (pitch 2056, 30 blocks per block row), aligned and 3 bytes off --
+# the source and reference halves of the independent-pair SAD kernel's reads
+MEM_BLOCK_SHAPES = {"blocks64_aligned": 0, "blocks64_off3": 3}
 MEM_PROBE = {}     # tag -> bytes moved per call (child only)
 
 
@@ -101,6 +104,13 @@ def mem_probe():
             idx = open_region(1, "mem_%s_%s" % ("w" if wr else "r", name))
             pmc_run(fn, idx)
             MEM_PROBE[TAGS[idx]] = lanes * w
+    pitch, bpr = 2056, 30
+    nblk = (total // (64 * pitch)) * bpr
+    for name, mis in MEM_BLOCK_SHAPES.items():
+        fn = lambda mis=mis: _lib.svt_hip_mem_probe_blocks(buf.data_ptr(), nblk * 256, pitch, bpr, mis, _sink.data_ptr(), _stream)  # noqa: E731
+        idx = open_region(1, "mem_r_%s" % name)
+        pmc_run(fn, idx)
+        MEM_PROBE[TAGS[idx]] = nblk * 256 * 16
     del buf
 
 

@@ -110,6 +110,9 @@ void        svt_hip_rate_probe(int kind, uint32_t iters, uint32_t blocks, uint32
 /* Memory-traffic probe (bench.py calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE on it, per access shape): grid lane t moves `width` (4 / 8 / 16) bytes of segment
  * t / (seg / width) -- segments of `seg` bytes every `pitch` bytes from `base` -- reading (write = 0) or storing (write = 1) every byte exactly once: lanes * width bytes. */
 void        svt_hip_mem_probe(int write, int width, void *base, uint64_t lanes, uint32_t seg, uint32_t pitch, uint32_t *sink, void *stream);
+/* the block kernels' shape: 64x64-byte blocks tiling a picture of `pitch`-byte rows (blocks_per_row per block row, each starting `misalign` bytes into its 64-byte column),
+ * 256 lanes per block reading 64 rows x 4 x 16 bytes: lanes * 16 bytes, every byte once */
+void        svt_hip_mem_probe_blocks(const void *base, uint64_t lanes, uint32_t pitch, uint32_t blocks_per_row, uint32_t misalign, uint32_t *sink, void *stream);
 
 /* ---------------------------------------------------------------- SAD family (a1-a6) -------------- */
 /* a1. svt_nxm_sad_kernel -> svt_nxm_sad_kernel_helper_c (Source/Lib/C_DEFAULT/compute_sad_c.c:209, body :20-37) */

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "svt_hip_debug_commit_violations": (C.c_uint64, []),
     "svt_hip_warmup_sized": (None, [C.c_int, C.c_uint32]),
     "svt_hip_mem_probe": (None, [C.c_int, C.c_int, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp]),
+    "svt_hip_mem_probe_blocks": (None, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     "svt_hip_debug_inject_failure": (C.c_int, []),
     "svt_hip_physical_device_count": (C.c_int, []),
     "svt_hip_physical_device": (C.c_int, [C.c_int]),

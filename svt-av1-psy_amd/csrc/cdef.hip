@@ -900,7 +900,7 @@ int svt_hip_cdef_search_host(const SvtHipCdefSearchHost* a) {
 
 uint8_t svt_aom_cdef_find_dir_hip(const uint16_t* img, int32_t stride, int32_t* var, int32_t coeff_shift) {
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     c.reserve(4096, 4096);
     uint16_t* d = (uint16_t*)c.dalloc(128);
     int*      o = (int*)c.dalloc(8);
@@ -915,7 +915,7 @@ uint8_t svt_aom_cdef_find_dir_hip(const uint16_t* img, int32_t stride, int32_t* 
 void svt_aom_cdef_find_dir_dual_hip(const uint16_t* img1, const uint16_t* img2, int stride, int32_t* var1, int32_t* var2, int32_t coeff_shift,
                                     uint8_t* out1, uint8_t* out2) {
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     c.reserve(4096, 4096);
     uint16_t* d = (uint16_t*)c.dalloc(256);
     int*      o = (int*)c.dalloc(16);
@@ -932,7 +932,7 @@ void svt_cdef_filter_block_hip(uint8_t* dst8, uint16_t* dst16, int32_t dstride, 
                                int32_t pri_damping, int32_t sec_damping, int32_t bsize, int32_t coeff_shift, uint8_t subsampling_factor) {
     const int bw = kBlkW[bsize & 3], bh = kBlkH[bsize & 3], pitch = bw + 4;
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     c.reserve(8192, 8192);
     uint16_t* dt = (uint16_t*)c.dalloc((size_t)(bh + 4) * pitch * 2);
     void*     dd = c.dalloc(8 * 8 * 2);
@@ -992,7 +992,7 @@ uint64_t svt_compute_cdef_dist_8bit_hip(const uint8_t* dst8, int32_t dstride, co
 void svt_aom_copy_rect8_8bit_to_16bit_hip(uint16_t* dst, int32_t dstride, const uint8_t* src, int32_t sstride, int32_t v, int32_t h) {
     if (v <= 0 || h <= 0) return;
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     const size_t n = (size_t)v * h;
     c.reserve(n * 3 + 4096, n * 3 + 4096);
     uint8_t*  ds = (uint8_t*)c.dalloc(n);

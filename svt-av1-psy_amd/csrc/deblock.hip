@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void lpf_edges_kernel(PIX* __restrict__ plane,
 // RTCD single-call form: s = q0 of the first sample, host memory.  Uploads the 4 x (2 * 7) neighbourhood, filters, downloads.
 void lpf_host(void* s, int pitch, int is16, int vertical, int len, int blimit, int limit, int thresh, int bd) {
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     const size_t px = is16 ? 2 : 1;
     // rectangle in host memory: vertical edge -> 4 rows x 14 columns starting 7 left of s; horizontal -> 14 rows x 4 columns starting 7 above
     const int    half = len == 14 ? 7 : len / 2;
@@ -161,7 +161,8 @@ void lpf_host(void* s, int pitch, int is16, int vertical, int len, int blimit, i
     uint8_t* d = (uint8_t*)c.dalloc(dp * rh);
     SvtHipLpfEdge* de = (SvtHipLpfEdge*)c.dalloc(sizeof(SvtHipLpfEdge));
     uint8_t* h0 = (uint8_t*)s - (vertical ? (size_t)half * px : (size_t)half * pitch * px);
-    HIP_CHECK(hipMemsetAsync(d, 0, dp * rh, c.stream));
+    if (c.zc) memset(d, 0, dp * rh); // (the staging rectangle is pinned host memory in small-call mode)
+    else HIP_CHECK(hipMemsetAsync(d, 0, dp * rh, c.stream));
     c.up2d(d + mx * px, dp, h0, (size_t)pitch * px, rw * px, rh);
     SvtHipLpfEdge e;
     memset(&e, 0, sizeof(e));

@@ -11,7 +11,10 @@
 // symmetric (upper tile triangle only), HL is not.
 //
 // MFMA operand for (tap t, 64 consecutive pixels of a row): lane (t & 15, kg = lane >> 4) holds the 16 bytes of digit plane samples of pixels
-// 16 kg .. 16 kg + 15 displaced by the tap's offset = sixteen CONSECUTIVE bytes of an LDS digit plane -> five aligned dwords + v_alignbyte.
+// 16 kg .. 16 kg + 15 displaced by the tap's offset (dx, dy).  The tile's digit planes are kept in LDS once per horizontal displacement dx (WIN copies, copy dx holding
+// plane[c + dx] at column c), so those sixteen bytes are ONE 16-byte-aligned ds_read_b128 of copy dx, row + dy -- no funnel shifts, masks or address arithmetic beyond one
+// add in the K loop (until round 6 every operand was five dwords + eight v_alignbyte: the VALU work of the loop kept the matrix pipe at 12 % busy).  The copies are made
+// when the tile is staged: 7 shifted dwords per staged dword, once per tile instead of once per (tap, chunk).
 // The same registers serve as A (rows of Z^T) and as B (columns of Z): both use the lane <-> (tap, pixel) assignment, so the sum over K
 // visits every pixel exactly once whatever order the hardware walks K in.
 #include "svt_hip_common.h"
@@ -23,13 +26,15 @@ namespace {
 
 typedef int i32x4 __attribute__((vector_size(16)));
 
-constexpr int TR = 16, TC = 256;      // pixel tile staged at a time: 16 rows x 256 columns = 64 chunks of 64 pixels, 16 chunks per wave
-constexpr int BANDS = 4;              // a workgroup walks 4 such tiles (64 rows) with its accumulators in registers: 16384 pixels, still exact in
+constexpr int TR = 8, TC = 256;       // pixel tile staged at a time: 8 rows x 256 columns = 32 chunks of 64 pixels, 8 chunks per wave
+constexpr int BANDS = 8;              // a workgroup walks 8 such tiles (64 rows) with its accumulators in registers: 16384 pixels, still exact in
                                       // int32 (16384 * 127^2 < 2^31), a quarter of the merge traffic
-constexpr int PP = TC + 16;           // dgd digit-plane pitch (bytes); tile pixel (r, c) sits at byte (r + 3) * PP + c + 4
-constexpr int DGD_PLANE = (TR + 6) * PP;
+constexpr int NR = TR + 6;            // plane rows of a tile: 3 rows of halo above and below (win 7; smaller windows leave the outer ones unused)
+constexpr int PP = TC + 16;           // pitch of the staging rows (bytes); tile pixel (r, c) sits at byte (r + 3) * PP + c + 4
+constexpr int STAGE_PLANE = NR * PP;  // one digit of the unshifted tile with its halo columns
+constexpr int COPY_PLANE = NR * TC;   // one digit of one displacement copy: pitch TC, no halo columns (the displacement is in the copy)
 constexpr int SRC_PLANE = TR * TC;    // src digit plane, pitch TC, no halo
-constexpr int LDS_PLANES = 2 * DGD_PLANE + 2 * SRC_PLANE;
+template <int WIN> constexpr int lds_bytes() { return 2 * STAGE_PLANE + 2 * WIN * COPY_PLANE + 2 * SRC_PLANE; }
 
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
@@ -66,7 +71,6 @@ __device__ __forceinline__ uint32_t pack_digits_lo(const int v0, const int v1, c
     return (uint32_t)(v0 & 127) | ((uint32_t)(v1 & 127) << 8) | ((uint32_t)(v2 & 127) << 16) | ((uint32_t)(v3 & 127) << 24);
 }
 
-struct __attribute__((aligned(4))) Dw5 { uint32_t w[5]; };
 
 // WIN 7: 49 taps + source = 50 columns in NG = 4 groups of 16; WIN 5: 26 columns, NG = 2; WIN 3: 10 columns, NG = 1.  With the window a template parameter every
 // group but the last is known to hold taps only (16 (NG - 1) <= WIN^2), so only the last group keeps per-lane plane / pitch / mask registers.
@@ -79,7 +83,10 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     // entry carry the same weight, so they share an accumulator -- 30 tiles instead of 36 for WIN 7, same 36 MFMAs per chunk)
     constexpr int NTRI = NG * (NG + 1) / 2, NTILE = 3 * NTRI, NMFMA = 2 * NTRI + NG * NG;
     HIP_DYNAMIC_SHARED(uint32_t, smem)
-    uint8_t* planes = (uint8_t*)smem; // [dgd hi][dgd lo][src hi][src lo]; later reused as int32 [NTILE][256]
+    // LDS: [staging hi][staging lo] (unshifted tile rows with halo columns) | [hi copies: WIN x NR x TC][lo copies] | [src hi][src lo]; later reused as int32 [NTILE][256]
+    uint8_t* stage  = (uint8_t*)smem;
+    uint8_t* planes = stage + 2 * STAGE_PLANE;
+    constexpr int LO = WIN * COPY_PLANE, SRC_HI = 2 * WIN * COPY_PLANE, SRC_LO = SRC_HI + SRC_PLANE;
     const int        tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
     const int        unit = blockIdx.z;
     const SvtHipRect R = rects[unit];
@@ -93,17 +100,17 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     const int  avg = (int)((unsigned long long)H[w2] / (unsigned long long)((long long)W * Hh)); // H[w2] = sum of the degraded unit (stats_sum_kernel)
 
     // ---- per-lane operand addressing: group g -> tap t = 16 g + (l & 15); kg = l >> 4 selects pixels 16 kg .. 16 kg + 15 of a chunk ----
-    // (both pitches and the chunk step are multiples of 4 bytes, so the dword phase of an operand address is that of its lane offset)
-    int      opoff[NG], last_pitch = PP, last_hi = 0, last_lo = DGD_PLANE;
+    // every operand is sixteen bytes at a 16-byte-aligned address: displacement copy dx, plane row (row + 3 + dy), column 64 ch + 16 kg -- all pitches are TC
+    int      opoff[NG], last_hi = 0, last_lo = LO;
     uint32_t last_mask = ~0u;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const int t = 16 * g + (l & 15), kg = l >> 4;
         if (g < NG - 1 || t < w2) { // tap index = (dx + hw) * win + (dy + hw)   (restoration_pick.c:673-679: k over columns, l over rows)
             const int dx = t / win - hw, dy = t % win - hw;
-            opoff[g] = (3 + dy) * PP + 4 + 16 * kg + dx;
+            opoff[g] = ((dx + hw) * NR + 3 + dy) * TC + 16 * kg;
         } else { // the source column (t == w2) or padding (contributes zeros)
-            opoff[g] = 16 * kg; last_pitch = TC; last_hi = 2 * DGD_PLANE; last_lo = 2 * DGD_PLANE + SRC_PLANE; last_mask = t == w2 ? ~0u : 0u;
+            opoff[g] = 16 * kg; last_hi = SRC_HI; last_lo = SRC_LO; last_mask = t == w2 ? ~0u : 0u;
         }
     }
     i32x4 accHH[NTRI], accLL[NTRI], accX[NTRI];
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     if (band) __syncthreads(); // everyone is done reading the previous tile
     // ---- stage the digit planes: four samples per step, loads issued before the stores ----
     {
-        constexpr int SLOTS = PP / 4, NIT = ((TR + 6) * SLOTS + 255) / 256, HALF = (NIT + 1) / 2;
+        constexpr int SLOTS = PP / 4, NIT = (NR * SLOTS + 255) / 256, HALF = (NIT + 1) / 2;
 #pragma unroll
         for (int k0 = 0; k0 < NIT; k0 += HALF) { // two batches: the accumulators leave no room for all NIT quads at once
             int v[HALF][4];
@@ -127,16 +134,16 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int tr = r - 3, tc = 4 * s - 4 + e;
-                    const bool ok = k0 + k < NIT && i < (TR + 6) * SLOTS && tr >= -hw && tr < th + hw && tc >= -hw && tc < tw + hw;
+                    const bool ok = k0 + k < NIT && i < NR * SLOTS && tr >= -hw && tr < th + hw && tc >= -hw && tc < tw + hw;
                     v[k][e] = ok ? rd(dgd, is16, (size_t)((long long)(R.v_start + r0 + tr) * dgd_stride + (R.h_start + c0 + tc))) - avg : 0;
                 }
             }
 #pragma unroll
             for (int k = 0; k < HALF; k++) {
                 const int i = tid + 256 * (k0 + k);
-                if (k0 + k < NIT && i < (TR + 6) * SLOTS) {
-                    ((uint32_t*)planes)[i]               = pack_digits_hi(v[k][0], v[k][1], v[k][2], v[k][3]);
-                    ((uint32_t*)(planes + DGD_PLANE))[i] = pack_digits_lo(v[k][0], v[k][1], v[k][2], v[k][3]);
+                if (k0 + k < NIT && i < NR * SLOTS) {
+                    ((uint32_t*)stage)[i]                 = pack_digits_hi(v[k][0], v[k][1], v[k][2], v[k][3]);
+                    ((uint32_t*)(stage + STAGE_PLANE))[i] = pack_digits_lo(v[k][0], v[k][1], v[k][2], v[k][3]);
                 }
             }
         }
@@ -154,8 +161,26 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
 #pragma unroll
         for (int k = 0; k < SNIT; k++) {
             const int i = tid + 256 * k;
-            ((uint32_t*)(planes + 2 * DGD_PLANE))[i]             = pack_digits_hi(x[k][0], x[k][1], x[k][2], x[k][3]);
-            ((uint32_t*)(planes + 2 * DGD_PLANE + SRC_PLANE))[i] = pack_digits_lo(x[k][0], x[k][1], x[k][2], x[k][3]);
+            ((uint32_t*)(planes + SRC_HI))[i] = pack_digits_hi(x[k][0], x[k][1], x[k][2], x[k][3]);
+            ((uint32_t*)(planes + SRC_LO))[i] = pack_digits_lo(x[k][0], x[k][1], x[k][2], x[k][3]);
+        }
+    }
+    __syncthreads();
+    {   // ---- the displacement copies: copy dx, row r, columns 4 q .. 4 q + 3 = staging bytes (r * PP + 4 + 4 q + dx ..): two adjacent staging dwords, one funnel shift ----
+        constexpr int Q = TC / 4;
+        for (int i = tid; i < NR * Q; i += 256) {
+            const int r = i / Q, q = i - r * Q;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const uint32_t* row = (const uint32_t*)(stage + d * STAGE_PLANE + r * PP); // dword k of the row = tile columns 4 k - 4 .. 4 k - 1
+                const uint32_t  w0 = row[q], w1 = row[q + 1], w2_ = row[q + 2];
+                uint32_t*       out = (uint32_t*)(planes + d * LO + r * TC) + q;
+#pragma unroll
+                for (int dx = -hw; dx <= hw; dx++) { // columns 4 q + dx ..: dx < 0 starts in dword q (= columns 4 q - 4 ..), dx >= 0 in dword q + 1
+                    const uint32_t v = dx < 0 ? __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)(4 + dx)) : (dx == 0 ? w1 : __builtin_amdgcn_alignbyte(w2_, w1, (uint32_t)dx));
+                    out[(dx + hw) * (COPY_PLANE / 4)] = v;
+                }
+            }
         }
     }
     __syncthreads();
@@ -171,10 +196,14 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
             const int nvalid = tw - ch * 64; // pixels of this chunk inside the unit (>= 64: all)
 #pragma unroll
             for (int g = 0; g < NG; g++) {
-                const bool last = g == NG - 1;
-                const int  af = row * (last ? last_pitch : PP) + 64 * ch + opoff[g], a = af & ~3;
-                const uint32_t sh = (uint32_t)af & 3u;
-                const Dw5 vh = *(const Dw5*)(planes + (last ? last_hi : 0) + a), vl = *(const Dw5*)(planes + (last ? last_lo : DGD_PLANE) + a);
+                const bool  last = g == NG - 1;
+                const int   a = row * TC + 64 * ch + opoff[g]; // a multiple of 16
+                const i32x4 vh = *(const i32x4*)(planes + (last ? last_hi : 0) + a), vl = *(const i32x4*)(planes + (last ? last_lo : LO) + a);
+                if (FULL && !last) { // whole chunk, taps only: the LDS words ARE the operands
+                    oH[g] = vh;
+                    oL[g] = vl;
+                    continue;
+                }
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     uint32_t m = last ? last_mask : ~0u; // only the last group holds the source column and padding
@@ -182,8 +211,8 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
                         const int first = 16 * (l >> 4) + 4 * d, left = nvalid - first;
                         m &= left >= 4 ? ~0u : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
                     }
-                    oH[g][d] = (int)(__builtin_amdgcn_alignbyte(vh.w[d + 1], vh.w[d], sh) & m);
-                    oL[g][d] = (int)(__builtin_amdgcn_alignbyte(vl.w[d + 1], vl.w[d], sh) & m);
+                    oH[g][d] = (int)((uint32_t)vh[d] & m);
+                    oL[g][d] = (int)((uint32_t)vl[d] & m);
                 }
             }
         };
@@ -226,9 +255,9 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
                 multiply(bH, bL);
 #pragma unroll
                 for (int k = 0; k < 2 * NMFMA; k++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one LDS read
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); // three VALU
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); // four MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one LDS read (eight 16-byte reads per chunk against 36 MFMAs)
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); // one VALU (addresses, the last group's mask)
                 }
             }
         } else {
@@ -312,13 +341,13 @@ void svt_hip_lr_compute_stats_batch_samples(const void* dgd, const void* src, co
     const dim3 grid((max_rect_width + TC - 1) / TC, (max_rect_height + TR * BANDS - 1) / (TR * BANDS), n);
     if (grid.x && grid.y) {
         if (wiener_win == 7) {
-            const size_t shmem = (size_t)(30 * 256 * 4 > LDS_PLANES ? 30 * 256 * 4 : LDS_PLANES) + 64;
+            const size_t shmem = (size_t)(30 * 256 * 4 > lds_bytes<7>() ? 30 * 256 * 4 : lds_bytes<7>()) + 64;
             hipLaunchKernelGGL(stats_mfma_kernel<7>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, is16, (long long*)M, (long long*)H);
         } else if (wiener_win == 5) {
-            const size_t shmem = (size_t)(9 * 256 * 4 > LDS_PLANES ? 9 * 256 * 4 : LDS_PLANES) + 64;
+            const size_t shmem = (size_t)(9 * 256 * 4 > lds_bytes<5>() ? 9 * 256 * 4 : lds_bytes<5>()) + 64;
             hipLaunchKernelGGL(stats_mfma_kernel<5>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, is16, (long long*)M, (long long*)H);
         } else { // WIENER_WIN_3TAP (restoration_pick.c:1289)
-            const size_t shmem = (size_t)(3 * 256 * 4 > LDS_PLANES ? 3 * 256 * 4 : LDS_PLANES) + 64;
+            const size_t shmem = (size_t)(3 * 256 * 4 > lds_bytes<3>() ? 3 * 256 * 4 : lds_bytes<3>()) + 64;
             hipLaunchKernelGGL(stats_mfma_kernel<3>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, is16, (long long*)M, (long long*)H);
         }
         SVT_LAUNCH_CHECK();

@@ -314,11 +314,21 @@ void HostCall::begin() {
     pin_used  = 0;
     n_pend    = 0;
     committed = false;
+    zc        = false;
+}
+void HostCall::begin_small() {
+    begin();
+    static const bool off = [] { const char* e = getenv("SVT_HIP_NO_ZERO_COPY"); return e && *e && *e != '0'; }(); // (A/B measurements)
+    zc = !off;
 }
 void HostCall::reserve(size_t dev_bytes, size_t pin_bytes) {
     touch();
     dev_bytes += 4096;
     pin_bytes += 4096;
+    if (zc) { // everything lives in the pinned arena
+        pin_bytes += dev_bytes + 4096;
+        dev_bytes = 0;
+    }
     if (dev_bytes > dev_cap) {
         if (dev) HIP_CHECK(hipFree(dev));
         dev_cap = align_up(dev_bytes * 2, 1 << 20);
@@ -338,6 +348,10 @@ void HostCall::reserve(size_t dev_bytes, size_t pin_bytes) {
     }
 }
 void* HostCall::dalloc(size_t bytes) {
+    if (zc) { // (same 256-byte alignment as the device arena)
+        pin_used = align_up(pin_used, 256);
+        return palloc(bytes);
+    }
     size_t off = align_up(dev_used, 256);
     if (off + bytes > dev_cap) {
         device_fail(-3, "host-call device arena overflow", __FILE__, __LINE__);
@@ -355,6 +369,10 @@ void* HostCall::palloc(size_t bytes) {
 }
 void HostCall::up2d(void* ddst, size_t dpitch, const void* hsrc, size_t spitch, size_t width_bytes, size_t rows) {
     touch();
+    if (zc) { // the destination IS host memory the GPU reads in place
+        for (size_t y = 0; y < rows; y++) memcpy((uint8_t*)ddst + y * dpitch, (const uint8_t*)hsrc + y * spitch, width_bytes);
+        return;
+    }
     // pack through the pinned buffer so the device copy is one contiguous DMA
     uint8_t* p = (uint8_t*)palloc(dpitch * rows);
     for (size_t y = 0; y < rows; y++) memcpy(p + y * dpitch, (const uint8_t*)hsrc + y * spitch, width_bytes);
@@ -377,6 +395,7 @@ static bool host_range_is_locked(const void* p, size_t bytes) {
 }
 void HostCall::up(void* ddst, const void* hsrc, size_t bytes) {
     touch();
+    if (zc) { memcpy(ddst, hsrc, bytes); return; }
     if (bytes >= (256u << 10) && host_range_is_locked(hsrc, bytes)) { // (every host form synchronises before it returns: the source outlives the copy)
         if (hipMemcpyAsync(ddst, hsrc, bytes, hipMemcpyHostToDevice, stream) == hipSuccess) return;
         (void)hipGetLastError(); // the runtime refused the direct copy: fall through to the staged one
@@ -387,6 +406,12 @@ void HostCall::up(void* ddst, const void* hsrc, size_t bytes) {
 }
 void HostCall::down(void* hdst, const void* dsrc, size_t bytes) {
     touch();
+    if (zc) { // the kernel wrote pinned host memory: visible once the stream has drained
+        HIP_CHECK(hipStreamSynchronize(stream));
+        memcpy(hdst, dsrc, bytes);
+        committed = true;
+        return;
+    }
     uint8_t* p = (uint8_t*)palloc(bytes);
     HIP_CHECK(hipMemcpyAsync(p, dsrc, bytes, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -395,6 +420,12 @@ void HostCall::down(void* hdst, const void* dsrc, size_t bytes) {
 }
 void HostCall::down2d(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch, size_t width_bytes, size_t rows) {
     touch();
+    if (zc) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (size_t y = 0; y < rows; y++) memcpy((uint8_t*)hdst + y * hpitch, (const uint8_t*)dsrc + y * dpitch, width_bytes);
+        committed = true;
+        return;
+    }
     uint8_t* p = (uint8_t*)palloc(dpitch * rows);
     HIP_CHECK(hipMemcpyAsync(p, dsrc, dpitch * rows, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -404,6 +435,10 @@ void HostCall::down2d(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch
 void HostCall::down2d_later(void* hdst, size_t hpitch, const void* dsrc, size_t dpitch, size_t width_bytes, size_t rows) {
     touch();
     if (n_pend == 16) finish();
+    if (zc) { // nothing to enqueue: finish() copies from where the kernel wrote
+        pend[n_pend++] = Pending{hdst, (const uint8_t*)dsrc, hpitch, dpitch, width_bytes, rows};
+        return;
+    }
     uint8_t* p = (uint8_t*)palloc(dpitch * rows);
     HIP_CHECK(hipMemcpyAsync(p, dsrc, dpitch * rows, hipMemcpyDeviceToHost, stream));
     pend[n_pend++] = Pending{hdst, p, hpitch, dpitch, width_bytes, rows};
@@ -549,6 +584,23 @@ template <int W, bool WRITE> __global__ __launch_bounds__(256) void svt_hip_mem_
     if (!WRITE && acc == 0x9e3779b9u) sink[0] = acc;
 }
 
+// The same for the access shape of the block kernels: the buffer is a picture of `pitch`-byte rows; 64x64-byte blocks tile it (`bpr` blocks per block row, starting
+// `mis` bytes into the row -- a reference block sits at an arbitrary byte offset); 256 consecutive lanes read one block as 64 rows x 4 lanes x 16 bytes, the way
+// sad_nxm_pipe_kernel's waves do.  Every byte of every block is read once: lanes * 16 bytes.
+__global__ __launch_bounds__(256) void svt_hip_mem_probe_blocks_kernel(const uint8_t* __restrict__ base, const uint64_t lanes, const uint32_t pitch, const uint32_t bpr, const uint32_t mis,
+                                                                       uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < lanes; t += (uint64_t)gridDim.x * 256) {
+        const uint64_t b = t >> 8;
+        const uint32_t r = (uint32_t)(t >> 2) & 63u, q = (uint32_t)t & 3u;
+        const uint8_t* p = base + ((b / bpr) * 64 + r) * (uint64_t)pitch + (b % bpr) * 64 + q * 16 + mis;
+        uint32_t       w[4];
+        __builtin_memcpy(w, p, 16); // (unaligned 16-byte load, as u32x4_a1 in sad.hip)
+        acc ^= w[0] ^ w[1] ^ w[2] ^ w[3];
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;
+}
+
 // Delay kernel (test instrument): one lane waits `ticks` of the constant-rate wall clock, so that whatever is queued behind it on its stream starts late.
 __global__ void svt_hip_spin_kernel(uint32_t ticks) {
 #ifndef SVT_HIP_EMU
@@ -591,6 +643,12 @@ void svt_hip_mem_probe(int write, int width, void* base, uint64_t lanes, uint32_
     else if (width == 8) { if (write) PROBE(8, true); else PROBE(8, false); }
     else { if (write) PROBE(16, true); else PROBE(16, false); }
 #undef PROBE
+    SVT_LAUNCH_CHECK();
+}
+
+void svt_hip_mem_probe_blocks(const void* base, uint64_t lanes, uint32_t pitch, uint32_t blocks_per_row, uint32_t misalign, uint32_t* sink, void* stream) {
+    svthip::ensure_device();
+    hipLaunchKernelGGL(svt_hip_mem_probe_blocks_kernel, dim3(256 * 32), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)base, lanes, pitch, blocks_per_row, misalign, sink);
     SVT_LAUNCH_CHECK();
 }
 

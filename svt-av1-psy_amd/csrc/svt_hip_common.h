@@ -92,6 +92,11 @@ struct HostCall {
     size_t      pin_cap  = 0, pin_used = 0;
 
     void begin();
+    // The same for a wrapper that moves a few kilobytes (one block per call): the call's "device" allocations come from the PINNED HOST arena, which the GPU reads and
+    // writes directly over PCIe -- up() is a memcpy, down() a synchronisation + a memcpy, and the two or three DMA operations of a staged call (5-8 us each to submit, more
+    // to complete) disappear.  Only for kernels that touch those buffers with plain loads and stores (no atomics, no hipMemset on them).
+    void begin_small();
+    bool zc = false;
     // device allocation of `bytes` (256-B aligned); may grow the arena (only legal before any kernel was queued
     // in this call, which is how every wrapper uses it: reserve(total) first, then carve).
     void  reserve(size_t dev_bytes, size_t pin_bytes);

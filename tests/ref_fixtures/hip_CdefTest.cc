@@ -10,7 +10,8 @@ namespace {
 // With boundary mask 0 its loops make 8.9 (8 bit) to 50 (12 bit) MILLION calls per parameter set (16 damping pairs x 128 levels x bd noise widths x 8 directions x
 // 17 primary x 4 secondary strengths x 2 sub-samplings, CdefTest.cc:133-245) -- sized for a 50 ns SIMD call, not for a function that crosses PCIe twice per call.
 // Those 12 sets run below through the fixture's own prepare_data() / run_test() with the three OUTER loops thinned; the inner ones (every direction, strength pair
-// and sub-sampling, dst8 and dst16) are the reference's.
+// and sub-sampling, dst8 and dst16) are the reference's.  (Interior blocks at full density are what tests/test_cdef.py covers against the checker pinned on
+// svt_cdef_filter_block_c: whole 4K planes, every strength.)
 INSTANTIATE_TEST_SUITE_P(HIP, CDEFBlockTest,
                          ::testing::Combine(::testing::Values(&svt_cdef_filter_block_hip), ::testing::Values(&svt_cdef_filter_block_c),
                                             ::testing::Values(BLOCK_4X4, BLOCK_4X8, BLOCK_8X4, BLOCK_8X8), ::testing::Range(1, 16), ::testing::Range(8, 13, 2),
@@ -18,15 +19,15 @@ INSTANTIATE_TEST_SUITE_P(HIP, CDEFBlockTest,
 
 class CDEFBlockInteriorTest : public CDEFBlockTest {
   public:
-    // test_cdef(1) of CdefTest.cc:227-265 with: damping pairs (min, min) (min, max) (max, min) (max, max) + the two middle diagonal ones instead of all 16,
-    // four levels (0, 1/3, 2/3, top of the range) instead of 128, every noise width `bits` as there
+    // test_cdef(1) of CdefTest.cc:227-265 with: damping pairs (min, min) (min, max) (max, min) instead of all 16, three levels (0, the middle, the top of the range)
+    // instead of 128, noise widths 1, bd / 2 and bd instead of every one -- 27 pictures x 544 (x 2 sub-samplings) calls per parameter set
     void test_cdef_thinned() {
         const int lo = 3 + bd_ - 8, hi = 6 + bd_ - 8;
-        const int damp[6][2] = {{lo, lo}, {lo, hi}, {hi, lo}, {hi, hi}, {lo + 1, lo + 1}, {lo + 2, lo + 2}};
-        const int top = (1 << bd_) - 1, levels[4] = {0, top / 3, 2 * top / 3, top - (2 << (bd_ - 8)) + 1};
+        const int damp[3][2] = {{lo, lo}, {lo, hi}, {hi, lo}};
+        const int top = (1 << bd_) - 1, levels[3] = {0, top / 2, top - (2 << (bd_ - 8)) + 1}, widths[3] = {1, bd_ / 2, bd_};
         for (const auto &d : damp)
             for (const int level : levels)
-                for (int bits = 1; bits <= bd_; bits++) {
+                for (const int bits : widths) {
                     prepare_data(level, bits);
                     run_test(d[0], d[1], 1);
                     if (bsize_ > BLOCK_4X4)  // (CdefTest.cc:250-258: the 2x sub-sampled 4x4 AVX2 kernel differs from C by design; kept as there)

@@ -86,6 +86,11 @@ def _run_sharded(binary, gtest_filter, shards, timeout):
 
     with ThreadPoolExecutor(shards) as ex:
         results = list(ex.map(one, range(shards)))
+    keep = os.path.join(ROOT, "gpurun_out", "ref_fixtures")  # (the per-test times of the last run, for profiles/: gpurun merges gpurun_out/ back)
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")) and "Emu" not in binary:
+        import shutil
+        shutil.rmtree(keep, ignore_errors=True)
+        shutil.copytree(tmp, keep)
     tests = failures = 0
     failed = []
     for r, js in results:
@@ -105,7 +110,7 @@ def _run_sharded(binary, gtest_filter, shards, timeout):
 def test_reference_fixtures_on_the_hip_symbols():
     assert os.path.isfile(BIN_GPU), "oracle/_ref/fixtures/SvtAv1HipFixtures is missing: __graft_entry__.build() makes it where /root/reference exists, and it ships with the snapshot"
     total = _check_suite_list(BIN_GPU)
-    shards = max(2, min(32, (os.cpu_count() or 4)))
+    shards = max(2, min(24, (os.cpu_count() or 4)))
     tests, failures, failed = _run_sharded(BIN_GPU, FILTER, shards, timeout=2400 if FULL else 900)
     assert failures == 0, failed[:40]
     assert tests >= total, (tests, total)
