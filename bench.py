@@ -674,7 +674,7 @@ def cpu_tpl_level1(k):
     for j, name in enumerate(("srcrf_dist", "recrf_dist", "srcrf_rate", "recrf_rate")):  # (16x16 blocks, synth size 16: result_model_store only clamps to >= 1)
         must_equal("tpl_level1 " + name, np.maximum(1, ro[name][w]), grid[w, j])
     must_equal("tpl_level1 reconstruction", k["recon"][pad:pad + P.height, pad:pad + P.width], rec)
-    return {"parity_checked_values": int(k["cells"]) * 13 + int(rec.size), "cpu_baseline": {"value": 1 / dt, "unit": "pictures/s", "cores": 1, "kind": "reference",
+    return {"parity_checked_values": int(k["cells"]) * 13 + int(rec.size), "parity_checked_recon": int(w.sum()) * 4 + int(rec.size), "cpu_baseline": {"value": 1 / dt, "unit": "pictures/s", "cores": 1, "kind": "reference",
                                                                                              "sample": "the leg's whole 1080p picture: both halves of the reference's dispenser (C kernels) through oracle/ref_wrap/ref_tpl.c"}}
 
 
@@ -1795,6 +1795,10 @@ def main():
                 kernels["tpl_l1_src_1080p8"].update(chk)
                 if "cpu_baseline" in chk:
                     kernels["tpl_l1_recon_1080p8"]["cpu_baseline_both_halves"] = chk["cpu_baseline"]
+                if "parity_checked_recon" in chk:  # the reconstruction half's share of the same comparison: its four statistics per cell + the reconstructed picture
+                    kernels["tpl_l1_recon_1080p8"]["parity_checked_values"] = chk["parity_checked_recon"]
+                    kernels["tpl_l1_recon_1080p8"].setdefault("cpu_baseline", dict(chk.get("cpu_baseline") or {}, note="BOTH halves of the reference's dispenser on one core (the "
+                                                                                     "reference does not run the halves separately); the AVX2 all-thread figure: cpu_baseline_both_halves"))
         if want("tfpic"):
             keep = {}
             kernels.update(bench_legs.tf_picture_stage(torch, lib, pkg, stream, 5, 1, keep))

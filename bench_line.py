@@ -150,7 +150,25 @@ def compact(out):
         if isinstance(e, dict):
             e.pop("stage_cpu_ms_per_frame", None)
         yield
-        for drop in ("detail", "legs", "frame_partition"):
+        if "legs" in line:  # coarser rows: whole microseconds, two digits, the roof's first letter (v / h / l / m / p)
+            line["legs"] = {k: (["us", "hbm", "valu", "roof"] if k == "_columns" else [None if v[0] is None else (int(round(v[0])) if v[0] >= 10 else v[0]),
+                                                                                     None if v[1] is None else round(v[1], 2), None if v[2] is None else round(v[2], 2),
+                                                                                     (v[3] or "?")[0]]) for k, v in line["legs"].items()}
+        yield
+        line.pop("detail", None)
+        yield
+        # then leg by leg, the least important first (host forms and sub-variants before the kernels the metric names); the MFMA leg and the metric's kernels go last
+        keep_last = ("sad64x64_pairs", "fwd_txfm2d_32x32", "cdef_apply_4k10", "cdef_search_4k10_64strengths", "lr_compute_stats_4k10_win7", "inv_txfm2d_add_32x32", "quantize_b_32x32",
+                     "me_search_8x4_preset8_area_dram", "me_search_8x4_preset8_area", "lr_search_4k10_full", "cdef_stage_4k10_420", "cdef_apply_4k10_420", "lr_mixed_4k10_420",
+                     "hme_3level_1080p_4refs", "tf_picture_stage_1080p8_4refs_resident", "tpl_recon_stage_1080p8", "lr_wiener_4k10", "lr_sgrproj_4k10", "config3_roundtrip")
+        if "legs" in line:
+            order = [k for k in line["legs"] if k != "_columns" and k not in keep_last] + [k for k in reversed(keep_last) if k in line["legs"]]
+            for k in order:
+                if size() <= MAX_LINE:
+                    break
+                line["legs"].pop(k, None)
+            yield
+        for drop in ("frame_partition", "legs"):
             line.pop(drop, None)
             yield
     for _ in steps():

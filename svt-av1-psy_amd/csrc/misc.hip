@@ -187,7 +187,7 @@ void svt_hip_hadamard_satd_batch(const uint8_t* input_base, const uint8_t* pred_
 // ---- RTCD-signature single-call forms ---------------------------------------------------------------------------------
 int svt_aom_satd_hip(const int32_t* coeff, int length) {
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     c.reserve((size_t)length * 4 + 1024, (size_t)length * 4 + 1024);
     int32_t* d = (int32_t*)c.dalloc((size_t)length * 4);
     int*     o = (int*)c.dalloc(4);
@@ -200,7 +200,7 @@ int svt_aom_satd_hip(const int32_t* coeff, int length) {
 }
 void svt_aom_hadamard_nxn_hip(const int16_t* src_diff, ptrdiff_t src_stride, int32_t* coeff, int n) {
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     c.reserve((size_t)n * n * 8 + 4096, (size_t)n * n * 8 + 4096);
     int16_t*        d  = (int16_t*)c.dalloc((size_t)n * n * 2);
     int32_t*        o  = (int32_t*)c.dalloc((size_t)n * n * 4);
@@ -221,7 +221,7 @@ void svt_aom_hadamard_32x32_hip(const int16_t* s, ptrdiff_t st, int32_t* c) { sv
 uint32_t svt_hadamard_path_hip(const uint8_t* input, uint32_t in_stride, const uint8_t* pred, uint32_t pred_stride, int block_size) {
     const int tx = block_size > 32 ? 32 : block_size, nt = block_size / tx;
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     const size_t pitch = svthip::align_up((size_t)block_size, 16);
     c.reserve(2 * pitch * block_size + 4096, 2 * pitch * block_size + 4096);
     uint8_t*        di = (uint8_t*)c.dalloc(pitch * block_size);
@@ -242,7 +242,7 @@ uint32_t svt_hadamard_path_hip(const uint8_t* input, uint32_t in_stride, const u
 }
 static void residual_host(const void* input, uint32_t is, const void* pred, uint32_t ps, int16_t* residual, uint32_t rs, uint32_t w, uint32_t h, int is16) {
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     const size_t px = is16 ? 2 : 1, n = (size_t)w * h;
     c.reserve(n * (2 * px + 2) + 4096, n * (2 * px + 4) + 4096);
     void*    di = c.dalloc(n * px);

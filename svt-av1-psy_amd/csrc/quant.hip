@@ -170,7 +170,7 @@ void svt_quantize_hip(int mode, const int32_t* coeff_ptr, intptr_t n_coeffs, con
     (void)scan; // the kernel works position-wise and needs only the inverse scan
     const size_t n = (size_t)n_coeffs;
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     c.reserve(n * 16 + 8192, n * 24 + 8192);
     int32_t*           dco = (int32_t*)c.dalloc(n * 4);
     int32_t*           dq  = (int32_t*)c.dalloc(n * 4);
@@ -223,7 +223,7 @@ void svt_av1_highbd_quantize_fp_qm_hip(QARGS, const uint8_t* qm_ptr, const uint8
 uint64_t svt_handle_transform_hip(int32_t* output, int tx_size, int n2_n4) {
     const size_t n = (size_t)kTxW[tx_size] * kTxH[tx_size];
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     c.reserve(n * 4 + 1024, n * 8 + 1024);
     int32_t*  d  = (int32_t*)c.dalloc(n * 4);
     uint64_t* de = (uint64_t*)c.dalloc(8);

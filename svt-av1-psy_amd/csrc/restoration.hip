@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void lr_block_kernel(const void* src /* origin
 void lr_block_host(const void* src, int sstride, void* dst, int dstride, int w, int h, int highbd, int bd, int kind, const int16_t* fx, const int16_t* fy,
                    int idx, const int32_t* xqd, int32_t* flt0, int32_t* flt1, int fstride) {
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     const size_t px = highbd ? 2 : 1;
     const size_t pw = svthip::align_up((size_t)(w + 8) * px, 16), rows = (size_t)h + 6;
     const size_t dpitch = svthip::align_up((size_t)w * px, 16);

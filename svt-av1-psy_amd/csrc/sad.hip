@@ -940,13 +940,22 @@ struct HmeChainArgs {
     int win_budget, src_budget;
     int n_levels, list1_skip;
     uint32_t item0; // first item of this launch (the level-0 resizing from list 0's motion runs reference 0 first)
+    // XCD-aware placement: workgroups reach the 8 XCDs round-robin by their id, so raster-adjacent SBs -- whose search windows overlap almost entirely on the 1/16 and
+    // 1/4 planes -- landed on 8 different L2s and every L2 fetched its own copy of the overlap (7.7x the planes' bytes moved, BENCH_r05).  Workgroup b takes logical
+    // position (b % 8) * wg_per_xcd + b / 8 instead: each XCD walks one contiguous band of SB rows.  (An affinity for speed only; results do not depend on it.)  0 = off.
+    uint32_t wg_per_xcd, n_wg;
 };
 __global__ __launch_bounds__(256, 4) void hme_chain_kernel(const HmeChainArgs A) {
     HIP_DYNAMIC_SHARED(uint32_t, smem)
     __shared__ unsigned long long sh_l0[4]; // level-0 SADs of the workgroup's four items (the 2 x 2 regions of one (reference, SB) in the pre-HME form)
     // everything but the pixel work is wave-uniform (item index, geometry, descriptors, winners): kept on the SALU through readfirstlane
     const int      l = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t item = A.item0 + blockIdx.x * 4 + wv;
+    uint32_t wg = blockIdx.x;
+    if (A.wg_per_xcd) {
+        wg = (blockIdx.x & 7u) * A.wg_per_xcd + (blockIdx.x >> 3);
+        if (wg >= A.n_wg) return; // (the grid is rounded up to 8 bands: whole workgroups leave, ahead of every barrier)
+    }
+    const uint32_t item = A.item0 + wg * 4 + wv;
     const bool     have = item < A.n; // (kept alive for the workgroup barrier of the pre-HME form; the grid is exact then)
     uint32_t* src_lds = smem + wv * ((A.win_budget + A.src_budget) / 4);
     uint32_t* win     = src_lds + A.src_budget / 4;
@@ -1405,15 +1414,19 @@ void svt_hip_hme_chain_batch(const SvtHipHmeLevelParams* params, const uint8_t* 
     }
     const size_t   shm  = 4 * (size_t)(src_budget + win_budget) + 64;
     const uint32_t per0 = params[0].sbs_x * params[0].sbs_y * params[0].num_hme_sa_w * params[0].num_hme_sa_h; // the items of slot 0 (list 0, reference 0)
+    static const bool xcd_off = [] { const char* e = getenv("SVT_HIP_HME_XCD"); return e && *e == '0'; }(); // (A/B measurements)
+    auto launch = [&](const uint32_t first, const uint32_t end) {
+        A.n = end; A.item0 = first;
+        A.n_wg = (end - first + 3) / 4;
+        A.wg_per_xcd = (!xcd_off && A.n_wg >= 64) ? (A.n_wg + 7) / 8 : 0;
+        hipLaunchKernelGGL(hme_chain_kernel, dim3(A.wg_per_xcd ? 8 * A.wg_per_xcd : A.n_wg), dim3(256), shm, (hipStream_t)stream, A);
+    };
     if (params[0].l0_mv_th_min && params[0].l0_mv_th_max && params[0].per_ref_area && n > per0) {
         // level-0 areas of the other slots depend on slot 0's level-0 result of the same SB: slot 0 first (whole chain), then the rest
-        A.n = per0; A.item0 = 0;
-        hipLaunchKernelGGL(hme_chain_kernel, dim3((per0 + 3) / 4), dim3(256), shm, (hipStream_t)stream, A);
-        A.n = n; A.item0 = per0;
-        hipLaunchKernelGGL(hme_chain_kernel, dim3((n - per0 + 3) / 4), dim3(256), shm, (hipStream_t)stream, A);
+        launch(0, per0);
+        launch(per0, n);
     } else {
-        A.item0 = 0;
-        hipLaunchKernelGGL(hme_chain_kernel, dim3((n + 3) / 4), dim3(256), shm, (hipStream_t)stream, A);
+        launch(0, n);
     }
     SVT_LAUNCH_CHECK();
 }

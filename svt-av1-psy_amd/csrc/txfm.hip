@@ -320,7 +320,7 @@ void svt_hip_iwht4x4_add_batch_u8(const int32_t* coeff_base, const uint8_t* pred
 // svt_av1_fwht4x4 (aom_dsp_rtcd.h:208) -> svt_av1_fwht4x4_c (transforms.c:3099)
 void svt_av1_fwht4x4_hip(int16_t* input, int32_t* output, uint32_t stride) {
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     c.reserve(4096, 4096);
     int16_t*           din  = (int16_t*)c.dalloc(4 * 16);
     SvtHipFwdTxfmDesc* dd   = (SvtHipFwdTxfmDesc*)c.dalloc(sizeof(SvtHipFwdTxfmDesc));
@@ -337,7 +337,7 @@ void svt_av1_fwht4x4_hip(int16_t* input, int32_t* output, uint32_t stride) {
 void svt_av1_fwd_txfm2d_hip(int16_t* input, int32_t* output, uint32_t input_stride, int tx_type, int tx_size, uint8_t bit_depth, int pf) {
     const int w = kTxW[tx_size], h = kTxH[tx_size];
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     const size_t pitch = svthip::align_up((size_t)w * 2, 16);
     c.reserve(pitch * h + (size_t)w * h * 4 + 4096, pitch * h + (size_t)w * h * 4 + 4096);
     int16_t*           din = (int16_t*)c.dalloc(pitch * h);
@@ -358,7 +358,7 @@ void svt_av1_inv_txfm2d_add_hip(const int32_t* input, uint16_t* output_r, int32_
     const int w = kTxW[tx_size], h = kTxH[tx_size];
     const int iw = w > 32 ? 32 : w, ih = h > 32 ? 32 : h;
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     const size_t pitch = svthip::align_up((size_t)w * 2, 16);
     c.reserve((size_t)iw * ih * 4 + 2 * pitch * h + 4096, (size_t)iw * ih * 4 + 3 * pitch * h + 4096);
     int32_t*           dco = (int32_t*)c.dalloc((size_t)iw * ih * 4);
@@ -383,7 +383,7 @@ void svt_av1_inv_txfm_add_u8_hip(const int32_t* dqcoeff, uint8_t* dst_r, int32_t
     const int w = kTxW[tx_size], h = kTxH[tx_size];
     const int iw = w > 32 ? 32 : w, ih = h > 32 ? 32 : h;
     svthip::HostCall& c = svthip::host_call();
-    c.begin();
+    c.begin_small();
     const size_t pitch = svthip::align_up((size_t)w, 16);
     c.reserve((size_t)iw * ih * 4 + 2 * pitch * h + 4096, (size_t)iw * ih * 4 + 3 * pitch * h + 4096);
     int32_t*           dco = (int32_t*)c.dalloc((size_t)iw * ih * 4);

@@ -73,7 +73,8 @@ def test_degenerate_objects():
     for i in range(400):
         e["kernels"]["extra_leg_%03d" % i] = {"roofline": {"kernel_us": 12.345, "frac": 0.123, "valu_frac": 0.456, "binds": "valu"}}
     o = check(bench_line.compact(e))
-    assert "legs" not in o
+    # the leg table gives way leg by leg, the least important first: the kernels the metric names (and the MFMA leg) are still there when 400 others are not
+    assert "legs" in o and "sad64x64_pairs" in o["legs"] and sum(k.startswith("extra_leg_") for k in o["legs"]) < 400
     e = copy.deepcopy(d)  # NaN / inf never reach the line
     e["roofline"]["valu_frac"] = float("nan")
     assert "NaN" not in bench_line.compact(e)
