@@ -77,10 +77,12 @@ constexpr int kSlice = 36 * 64; // dwords
 
 template <typename PIX>
 __global__ __launch_bounds__(256) void tf_subpel_kernel(const SvtHipTfSubpelParams P, const PIX* __restrict__ src_base, const PIX* __restrict__ ref_base,
-                                                        const SvtHipTfSubpelDesc* __restrict__ descs, const uint32_t n, SvtHipTfSubpelResult* __restrict__ out) {
+                                                        const SvtHipTfSubpelDesc* __restrict__ descs, const uint32_t n, SvtHipTfSubpelResult* __restrict__ out,
+                                                        const uint32_t per_xcd) {
     HIP_DYNAMIC_SHARED(uint32_t, smem)
     const int      l = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t item = blockIdx.x * 4 + (uint32_t)wv;
+    const uint32_t wg = per_xcd ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x; // XCD-aware placement (svt_hip_common.h: xcd_band_per)
+    const uint32_t item = wg * 4 + (uint32_t)wv;
     if (item >= n) return;
     uint32_t* im = smem + wv * kSlice; // the wave's private intermediate: (rows + 7 + 1) / 2 row pairs x 64 columns
     const SvtHipTfSubpelDesc d = descs[item];
@@ -172,12 +174,14 @@ extern "C" void svt_hip_tf_subpel_search_batch(const SvtHipTfSubpelParams* param
         abort();
     }
     const size_t shm = (size_t)4 * kSlice * 4;
+    static const bool xcd_off = [] { const char* e = getenv("SVT_HIP_TF_XCD"); return e && *e == '0'; }(); // (A/B measurements)
+    const uint32_t n_wg = (n + 3) / 4, per = xcd_off ? 0 : svthip::xcd_band_per(n_wg), grid = per ? 8 * per : n_wg;
     if (params->bit_depth > 8)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_subpel_kernel<uint16_t>), dim3((n + 3) / 4), dim3(256), shm, (hipStream_t)stream, *params, (const uint16_t*)src_base,
-                           (const uint16_t*)ref_base, descs, n, results);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_subpel_kernel<uint16_t>), dim3(grid), dim3(256), shm, (hipStream_t)stream, *params, (const uint16_t*)src_base,
+                           (const uint16_t*)ref_base, descs, n, results, per);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_subpel_kernel<uint8_t>), dim3((n + 3) / 4), dim3(256), shm, (hipStream_t)stream, *params, (const uint8_t*)src_base,
-                           (const uint8_t*)ref_base, descs, n, results);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(tf_subpel_kernel<uint8_t>), dim3(grid), dim3(256), shm, (hipStream_t)stream, *params, (const uint8_t*)src_base,
+                           (const uint8_t*)ref_base, descs, n, results, per);
     SVT_LAUNCH_CHECK();
 }
 
