@@ -32,9 +32,21 @@ constexpr int BANDS = 8;              // a workgroup walks 8 such tiles (64 rows
 constexpr int NR = TR + 6;            // plane rows of a tile: 3 rows of halo above and below (win 7; smaller windows leave the outer ones unused)
 constexpr int PP = TC + 16;           // pitch of the staging rows (bytes); tile pixel (r, c) sits at byte (r + 3) * PP + c + 4
 constexpr int STAGE_PLANE = NR * PP;  // one digit of the unshifted tile with its halo columns
-constexpr int COPY_PLANE = NR * TC;   // one digit of one displacement copy: pitch TC, no halo columns (the displacement is in the copy)
-constexpr int SRC_PLANE = TR * TC;    // src digit plane, pitch TC, no halo
-template <int WIN> constexpr int lds_bytes() { return 2 * STAGE_PLANE + 2 * WIN * COPY_PLANE + 2 * SRC_PLANE; }
+constexpr int SRC_PLANE = TR * TC;    // src digit plane: [kg][row][chunk] cells of 16 bytes
+// The displacement copies as the MFMA operand reads see them.  A ds_read_b128 is served in four groups of sixteen lanes, each group = sixteen DIFFERENT taps (lane & 15) at
+// two of the four pixel quarters kg (lane >> 4) of a 64-pixel chunk, and a group is conflict-free when its sixteen 16-byte cells fall into the sixteen different 16-byte slots
+// of the 256-byte bank row.  So: one sub-plane per kg at a multiple of 256 bytes (kg never moves the slot); inside it 64-byte rows (four chunk cells), row index
+// Rr = A * plane_row + B * copy with (A, B) chosen so that Rr = (odd constant) * tap (mod 16) -- sixteen consecutive taps, sixteen different Rr mod 16; and the cell of
+// chunk ch stored at position ch ^ ((Rr >> 2) & 3), so that slot = 4 (Rr & 3) + (ch ^ ((Rr >> 2) & 3)) runs through all sixteen values.  (With all pitches 256 -- the
+// layout until round 6 -- every lane of a group hit one of two slots: eight LDS passes per group instead of one.)
+template <int WIN> struct CopyLayout {
+    static constexpr int A = WIN == 7 ? 7 : 1;                        // WIN 7: the seven copies of a plane row are adjacent rows (7 * 7 = 1 mod 16)
+    static constexpr int B = WIN == 7 ? 1 : (WIN == 5 ? 21 : 19);     // WIN 5 / 3: copy-major with a row count = WIN (mod 16)
+    static constexpr int ROWS = WIN == 7 ? NR * 7 : (WIN - 1) * B + NR;
+    static constexpr int KP = (ROWS * 64 + 255) / 256 * 256;          // one kg sub-plane
+    static constexpr int DP = 4 * KP;                                 // one digit
+};
+template <int WIN> constexpr int lds_bytes() { return 2 * STAGE_PLANE + 2 * CopyLayout<WIN>::DP + 2 * SRC_PLANE; }
 
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
@@ -43,25 +55,53 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 }
 __device__ __forceinline__ int rd(const void* p, const int is16, const size_t off) { return is16 ? ((const uint16_t*)p)[off] : ((const uint8_t*)p)[off]; }
 
-// find_average / find_average_highbd (restoration_pick.h): floor(sum / count) of the degraded unit.  One workgroup per (unit, 16-row band) adds its
-// partial sum to a lower-triangle slot of H (free until the finalize kernel mirrors the upper triangle); the consumers divide.
-__global__ __launch_bounds__(256) void stats_sum_kernel(const void* dgd, const SvtHipRect* rects, const int dgd_stride, const int is16, const int w2,
-                                                        long long* H) {
+// find_average / find_average_highbd (restoration_pick.h): floor(sum / count) of the degraded unit.  Workgroup (b, unit) sums band b of SUM_BANDS row bands and STORES
+// its partial in a lower-triangle slot of H (entry (1 + b, 0): the matrix kernel only touches the upper triangle, the finalize kernel overwrites the lower one with the
+// mirror image), so there is no atomic and nothing to clear first; the same workgroups zero the unit's M and the rest of its H -- the two fill launches that used to
+// precede this kernel are gone.  Rows are read as aligned 16-byte words where a word lies wholly inside the row (per-sample loads at the two ragged ends only).
+constexpr int SUM_BANDS = 8;
+struct alignas(16) Word16 { uint32_t x, y, z, w; };
+__device__ __forceinline__ int sum_slot(const int b, const int w2) { return (1 + b) * w2; }
+
+__global__ __launch_bounds__(256) void stats_sum_kernel(const void* dgd, const SvtHipRect* rects, const int dgd_stride, const int is16, const int w2, const int rows_per_band,
+                                                        long long* Mout, long long* Hout) {
     __shared__ long long wsum[4];
-    const int        tid = threadIdx.x;
-    const SvtHipRect R   = rects[blockIdx.y];
-    const int        W = R.h_end - R.h_start, Hh = R.v_end - R.v_start, r0 = blockIdx.x * 16;
-    if (r0 >= Hh || W <= 0) return;
-    const int rows = Hh - r0 < 16 ? Hh - r0 : 16;
-    long long s = 0;
-    for (int r = tid >> 6; r < rows; r += 4) { // a wave per row: coalesced
-        const size_t base = (size_t)((long long)(R.v_start + r0 + r) * dgd_stride + R.h_start);
-        for (int x = tid & 63; x < W; x += 64) s += rd(dgd, is16, base + x);
+    const int        tid = threadIdx.x, b = blockIdx.x, unit = blockIdx.y;
+    const SvtHipRect R   = rects[unit];
+    const int        W = R.h_end - R.h_start, Hh = R.v_end - R.v_start, r0 = b * rows_per_band;
+    long long*       H = Hout + (size_t)unit * 49 * 49;
+    {   // this workgroup's share of the clearing: every entry but the SUM_BANDS partial slots
+        const int n = w2 * w2, per = (n + SUM_BANDS - 1) / SUM_BANDS, hi = (b + 1) * per < n ? (b + 1) * per : n;
+        for (int e = b * per + tid; e < hi; e += 256)
+            if (!(e % w2 == 0 && e >= w2 && e <= SUM_BANDS * w2)) H[e] = 0;
+        if (b == 0 && tid < w2) Mout[(size_t)unit * 49 + tid] = 0;
     }
-    s = wave_sum_ll(s);
-    if ((tid & 63) == 0) wsum[tid >> 6] = s;
+    const int rows = W <= 0 ? 0 : (Hh - r0 < rows_per_band ? Hh - r0 : rows_per_band);
+    const int px = is16 ? 2 : 1;
+    unsigned long long s = 0;
+    for (int r = tid >> 6; r < rows; r += 4) { // a wave per row
+        const uintptr_t a0 = (uintptr_t)dgd + (size_t)px * (size_t)((long long)(R.v_start + r0 + r) * dgd_stride + R.h_start), a1 = a0 + (size_t)px * W;
+        const uintptr_t v0 = (a0 + 15) & ~(uintptr_t)15, v1 = a1 & ~(uintptr_t)15; // whole 16-byte words of the row: [v0, v1)
+        unsigned acc = 0; // <= 8 samples of 16 bits per word, a handful of words per lane and row: no overflow
+        if (v0 < v1) {
+            for (uintptr_t a = v0 + 16 * (uintptr_t)(tid & 63); a < v1; a += 16 * 64) {
+                const Word16 q = *(const Word16*)a;
+                if (is16) acc += (q.x & 0xffff) + (q.x >> 16) + (q.y & 0xffff) + (q.y >> 16) + (q.z & 0xffff) + (q.z >> 16) + (q.w & 0xffff) + (q.w >> 16);
+                else acc = __builtin_amdgcn_sad_u8(q.w, 0u, __builtin_amdgcn_sad_u8(q.z, 0u, __builtin_amdgcn_sad_u8(q.y, 0u, __builtin_amdgcn_sad_u8(q.x, 0u, acc))));
+            }
+            const int head = (int)((v0 - a0) / px), tail = (int)((a1 - v1) / px); // ragged ends, < 16 bytes each
+            const int l = tid & 63;
+            if (l < head) acc += is16 ? ((const uint16_t*)a0)[l] : ((const uint8_t*)a0)[l];
+            else if (l - head < tail) acc += is16 ? ((const uint16_t*)v1)[l - head] : ((const uint8_t*)v1)[l - head];
+        } else { // a row shorter than one aligned word
+            for (int x = tid & 63; x < W; x += 64) acc += is16 ? ((const uint16_t*)a0)[x] : ((const uint8_t*)a0)[x];
+        }
+        s += acc;
+    }
+    s = (unsigned long long)wave_sum_ll((long long)s);
+    if ((tid & 63) == 0) wsum[tid >> 6] = (long long)s;
     __syncthreads();
-    if (tid == 0) atomicAdd((unsigned long long*)&H[(size_t)blockIdx.y * 49 * 49 + w2], (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
+    if (tid == 0) H[sum_slot(b, w2)] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 __device__ __forceinline__ uint32_t pack_digits_hi(const int v0, const int v1, const int v2, const int v3) {
@@ -72,21 +112,72 @@ __device__ __forceinline__ uint32_t pack_digits_lo(const int v0, const int v1, c
 }
 
 
+// Four consecutive samples of a picture row as the digit planes want them.  The 8-byte (4-byte at 8 bits) load is ONE instruction whatever the alignment, it is issued
+// unconditionally -- a quad that sticks out of the readable range [lo, hi) of its row is loaded from the nearest window inside the range and shifted back, a quad that lies
+// wholly outside (or in a row outside the band) from the clamped position and dropped -- so a tile's loads are all in flight together.  (Until round 6 every sample was a
+// guarded 2-byte load and the compiler placed an s_waitcnt vmcnt(0) behind each: 24 memory round trips in series per tile.)
+struct QuadWhere { int col; int shift; uint32_t keep; }; // first column actually loaded, its distance from the quad's own first column, byte mask of the wanted samples
+__device__ __forceinline__ QuadWhere quad_where(const int tc0, const int lo, const int hi, const bool row_ok) {
+    QuadWhere q;
+    const int top = hi - 4;
+    q.col = hi - lo < 4 ? tc0 : (tc0 < lo ? lo : (tc0 > top ? top : tc0)); // (a range narrower than a quad has no window: its samples are loaded one by one, load_narrow)
+    q.shift = q.col - tc0;                                            // > 0: loaded window starts right of the quad, < 0: left of it
+    const int e0 = lo - tc0 > 0 ? lo - tc0 : 0, e1 = hi - tc0 < 4 ? hi - tc0 : 4; // wanted samples e0 .. e1 - 1
+    q.keep = (row_ok && e1 > e0) ? (e1 - e0 >= 4 ? ~0u : (((1u << (8 * (e1 - e0))) - 1u) << (8 * e0))) : 0u;
+    return q;
+}
+template <bool IS16> struct RawQuad;
+template <> struct RawQuad<true> {
+    uint32_t a, b;
+    __device__ __forceinline__ void load(const void* base, const size_t off) { const svt_u32x2_a1 v = svt_hip_global_load_x2((const uint16_t*)base + off); a = v[0]; b = v[1]; }
+    __device__ __forceinline__ void load_narrow(const void* base, const size_t row_off, const int tc0, const int lo, const int hi) { // sample e from column clamp(tc0 + e)
+        uint32_t v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const int c = tc0 + e < lo ? lo : (tc0 + e > hi - 1 ? hi - 1 : tc0 + e); v[e] = ((const uint16_t*)base)[(long long)row_off + c]; }
+        a = v[0] | (v[1] << 16); b = v[2] | (v[3] << 16);
+    }
+    __device__ __forceinline__ void digits(const QuadWhere q, const int avg, uint32_t& hi, uint32_t& lo) const {
+        unsigned long long w = ((unsigned long long)b << 32) | a;
+        if (q.keep == 0) { hi = lo = 0; return; }
+        w = q.shift > 0 ? w << (16 * q.shift) : w >> (16 * -q.shift);
+        const int v0 = (int)(w & 0xffff) - avg, v1 = (int)((w >> 16) & 0xffff) - avg, v2 = (int)((w >> 32) & 0xffff) - avg, v3 = (int)(w >> 48) - avg;
+        hi = pack_digits_hi(v0, v1, v2, v3) & q.keep;
+        lo = pack_digits_lo(v0, v1, v2, v3) & q.keep;
+    }
+};
+template <> struct RawQuad<false> {
+    uint32_t a;
+    __device__ __forceinline__ void load(const void* base, const size_t off) { uint32_t v; __builtin_memcpy(&v, (const uint8_t*)base + off, 4); a = v; }
+    __device__ __forceinline__ void load_narrow(const void* base, const size_t row_off, const int tc0, const int lo, const int hi) {
+        a = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const int c = tc0 + e < lo ? lo : (tc0 + e > hi - 1 ? hi - 1 : tc0 + e); a |= (uint32_t)((const uint8_t*)base)[(long long)row_off + c] << (8 * e); }
+    }
+    __device__ __forceinline__ void digits(const QuadWhere q, const int avg, uint32_t& hi, uint32_t& lo) const {
+        if (q.keep == 0) { hi = lo = 0; return; }
+        const uint32_t w = q.shift > 0 ? a << (8 * q.shift) : a >> (8 * -q.shift);
+        const int v0 = (int)(w & 255) - avg, v1 = (int)((w >> 8) & 255) - avg, v2 = (int)((w >> 16) & 255) - avg, v3 = (int)(w >> 24) - avg;
+        hi = pack_digits_hi(v0, v1, v2, v3) & q.keep;
+        lo = pack_digits_lo(v0, v1, v2, v3) & q.keep;
+    }
+};
+
 // WIN 7: 49 taps + source = 50 columns in NG = 4 groups of 16; WIN 5: 26 columns, NG = 2; WIN 3: 10 columns, NG = 1.  With the window a template parameter every
 // group but the last is known to hold taps only (16 (NG - 1) <= WIN^2), so only the last group keeps per-lane plane / pitch / mask registers.
-template <int WIN>
+template <int WIN, bool IS16>
 __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, const void* src, const SvtHipRect* rects, const int dgd_stride, const int src_stride,
-                                                         const int is16, long long* Mout, long long* Hout) {
+                                                         long long* Mout, long long* Hout) {
+    using L = CopyLayout<WIN>;
     constexpr int win = WIN, NG = (WIN * WIN + 1 + 15) / 16;
     static_assert(16 * (NG - 1) <= WIN * WIN, "only the last group may hold the source column or padding");
     // accumulator tiles: HH, LL and X over the upper triangle of group pairs, X(ga, gb) = H_ga L_gb^T (+ L_ga H_gb^T off the diagonal: both cross terms of an
     // entry carry the same weight, so they share an accumulator -- 30 tiles instead of 36 for WIN 7, same 36 MFMAs per chunk)
     constexpr int NTRI = NG * (NG + 1) / 2, NTILE = 3 * NTRI, NMFMA = 2 * NTRI + NG * NG;
     HIP_DYNAMIC_SHARED(uint32_t, smem)
-    // LDS: [staging hi][staging lo] (unshifted tile rows with halo columns) | [hi copies: WIN x NR x TC][lo copies] | [src hi][src lo]; later reused as int32 [NTILE][256]
+    // LDS: [staging hi][staging lo] (unshifted tile rows with halo columns) | [hi copies: 4 kg sub-planes][lo copies] | [src hi][src lo]; later reused as int32 [NTILE][256]
     uint8_t* stage  = (uint8_t*)smem;
     uint8_t* planes = stage + 2 * STAGE_PLANE;
-    constexpr int LO = WIN * COPY_PLANE, SRC_HI = 2 * WIN * COPY_PLANE, SRC_LO = SRC_HI + SRC_PLANE;
+    constexpr int LO = L::DP, SRC_HI = 2 * L::DP, SRC_LO = SRC_HI + SRC_PLANE;
     const int        tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
     const int        unit = blockIdx.z;
     const SvtHipRect R = rects[unit];
@@ -97,95 +188,106 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     const int tw = W - c0 < TC ? W - c0 : TC;
     long long* H = Hout + (size_t)unit * 49 * 49;
     long long* M = Mout + (size_t)unit * 49;
-    const int  avg = (int)((unsigned long long)H[w2] / (unsigned long long)((long long)W * Hh)); // H[w2] = sum of the degraded unit (stats_sum_kernel)
+    unsigned long long total = 0; // sum of the degraded unit: stats_sum_kernel's partials
+#pragma unroll
+    for (int b = 0; b < SUM_BANDS; b++) total += (unsigned long long)H[sum_slot(b, w2)];
+    const int avg = (int)(total / (unsigned long long)((long long)W * Hh));
 
     // ---- per-lane operand addressing: group g -> tap t = 16 g + (l & 15); kg = l >> 4 selects pixels 16 kg .. 16 kg + 15 of a chunk ----
-    // every operand is sixteen bytes at a 16-byte-aligned address: displacement copy dx, plane row (row + 3 + dy), column 64 ch + 16 kg -- all pitches are TC
-    int      opoff[NG], last_hi = 0, last_lo = LO;
+    // operand of (tile row, chunk ch) = the 16-byte cell (see CopyLayout) at  cell0[g] + 64 Rr + 16 (ch ^ ((Rr >> 2) & swz)),  Rr = rr0[g] + rstep * row
+    int      cell0[NG], rr0[NG], last_step = L::A, last_swz = 3, last_lo = LO;
     uint32_t last_mask = ~0u;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const int t = 16 * g + (l & 15), kg = l >> 4;
         if (g < NG - 1 || t < w2) { // tap index = (dx + hw) * win + (dy + hw)   (restoration_pick.c:673-679: k over columns, l over rows)
-            const int dx = t / win - hw, dy = t % win - hw;
-            opoff[g] = ((dx + hw) * NR + 3 + dy) * TC + 16 * kg;
-        } else { // the source column (t == w2) or padding (contributes zeros)
-            opoff[g] = 16 * kg; last_hi = SRC_HI; last_lo = SRC_LO; last_mask = t == w2 ? ~0u : 0u;
+            const int dxi = t / win, dyi = t % win;
+            cell0[g] = kg * L::KP;
+            rr0[g]   = L::A * (3 - hw + dyi) + L::B * dxi;
+        } else { // the source column (t == w2) or padding (contributes zeros): [kg][row][chunk] cells, no swizzle
+            cell0[g] = SRC_HI + kg * (TR * 64); rr0[g] = 0; last_step = 1; last_swz = 0; last_lo = SRC_PLANE; last_mask = t == w2 ? ~0u : 0u;
         }
     }
     i32x4 accHH[NTRI], accLL[NTRI], accX[NTRI];
 #pragma unroll
     for (int i = 0; i < NTRI; i++) { accHH[i] = i32x4{0, 0, 0, 0}; accLL[i] = i32x4{0, 0, 0, 0}; accX[i] = i32x4{0, 0, 0, 0}; }
 
+    // ---- the tile loads: quad i = tid + 256 k of the degraded tile (plane row i / SLOTS, staging dword i % SLOTS = tile columns 4 s - 4 ..), quad j of the source tile ----
+    constexpr int SLOTS = PP / 4, NIT = (NR * SLOTS + 255) / 256, SSLOTS = TC / 4, SNIT = (TR * SSLOTS + 255) / 256;
+    RawQuad<IS16> rawd[NIT], raws[SNIT];
+    // readable columns: [-hw, tw + hw) of the degraded rows, [0, tw) of the source rows (a tile of fewer than four columns loads sample by sample)
+    auto issue = [&](const int r0, const int th) {
+#pragma unroll
+        for (int k = 0; k < NIT; k++) {
+            const int i = tid + 256 * k, r = i / SLOTS, s = i - r * SLOTS;
+            int tr = r - 3;
+            tr = tr < -hw ? -hw : (tr > th + hw - 1 ? th + hw - 1 : tr);
+            const size_t row_off = (size_t)((long long)(R.v_start + r0 + tr) * dgd_stride + (R.h_start + c0));
+            if (tw + 2 * hw >= 4) rawd[k].load(dgd, row_off + quad_where(4 * s - 4, -hw, tw + hw, true).col);
+            else rawd[k].load_narrow(dgd, row_off, 4 * s - 4, -hw, tw + hw);
+        }
+#pragma unroll
+        for (int k = 0; k < SNIT; k++) {
+            const int i = tid + 256 * k, r = i / SSLOTS, s = i - r * SSLOTS;
+            const int tr = r > th - 1 ? th - 1 : r;
+            const size_t row_off = (size_t)((long long)(R.v_start + r0 + tr) * src_stride + (R.h_start + c0));
+            if (tw >= 4) raws[k].load(src, row_off + quad_where(4 * s, 0, tw, true).col);
+            else raws[k].load_narrow(src, row_off, 4 * s, 0, tw);
+        }
+    };
+    issue(rb0, Hh - rb0 < TR ? Hh - rb0 : TR);
+
     for (int band = 0; band < BANDS; band++) {
     const int r0 = rb0 + band * TR;
     if (r0 >= Hh) break;
     const int th = Hh - r0 < TR ? Hh - r0 : TR;
     if (band) __syncthreads(); // everyone is done reading the previous tile
-    // ---- stage the digit planes: four samples per step, loads issued before the stores ----
-    {
-        constexpr int SLOTS = PP / 4, NIT = (NR * SLOTS + 255) / 256, HALF = (NIT + 1) / 2;
+    // ---- the digit planes of the tile from the loaded quads ----
 #pragma unroll
-        for (int k0 = 0; k0 < NIT; k0 += HALF) { // two batches: the accumulators leave no room for all NIT quads at once
-            int v[HALF][4];
-#pragma unroll
-            for (int k = 0; k < HALF; k++) {
-                const int i = tid + 256 * (k0 + k), r = i / SLOTS, s = i - r * SLOTS; // plane row r <-> tile row r - 3, slot s <-> tile columns 4 s - 4 ..
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int tr = r - 3, tc = 4 * s - 4 + e;
-                    const bool ok = k0 + k < NIT && i < NR * SLOTS && tr >= -hw && tr < th + hw && tc >= -hw && tc < tw + hw;
-                    v[k][e] = ok ? rd(dgd, is16, (size_t)((long long)(R.v_start + r0 + tr) * dgd_stride + (R.h_start + c0 + tc))) - avg : 0;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < HALF; k++) {
-                const int i = tid + 256 * (k0 + k);
-                if (k0 + k < NIT && i < NR * SLOTS) {
-                    ((uint32_t*)stage)[i]                 = pack_digits_hi(v[k][0], v[k][1], v[k][2], v[k][3]);
-                    ((uint32_t*)(stage + STAGE_PLANE))[i] = pack_digits_lo(v[k][0], v[k][1], v[k][2], v[k][3]);
-                }
-            }
-        }
-        constexpr int SSLOTS = TC / 4, SNIT = (TR * SSLOTS + 255) / 256;
-        int x[SNIT][4];
-#pragma unroll
-        for (int k = 0; k < SNIT; k++) {
-            const int i = tid + 256 * k, r = i / SSLOTS, s = i - r * SSLOTS;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int tc = 4 * s + e;
-                x[k][e] = (r < th && tc < tw) ? rd(src, is16, (size_t)((long long)(R.v_start + r0 + r) * src_stride + (R.h_start + c0 + tc))) - avg : 0;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < SNIT; k++) {
-            const int i = tid + 256 * k;
-            ((uint32_t*)(planes + SRC_HI))[i] = pack_digits_hi(x[k][0], x[k][1], x[k][2], x[k][3]);
-            ((uint32_t*)(planes + SRC_LO))[i] = pack_digits_lo(x[k][0], x[k][1], x[k][2], x[k][3]);
+    for (int k = 0; k < NIT; k++) {
+        const int i = tid + 256 * k, r = i / SLOTS, s = i - r * SLOTS, tr = r - 3;
+        const QuadWhere q = quad_where(4 * s - 4, -hw, tw + hw, tr >= -hw && tr < th + hw);
+        uint32_t dh, dl;
+        rawd[k].digits(q, avg, dh, dl);
+        if (i < NR * SLOTS) {
+            ((uint32_t*)stage)[i]                 = dh;
+            ((uint32_t*)(stage + STAGE_PLANE))[i] = dl;
         }
     }
+#pragma unroll
+    for (int k = 0; k < SNIT; k++) { // source quad s of row r: chunk s / 16, quarter (s / 4) & 3, dword s & 3 of the cell
+        const int i = tid + 256 * k, r = i / SSLOTS, s = i - r * SSLOTS;
+        const QuadWhere q = quad_where(4 * s, 0, tw, r < th);
+        uint32_t xh, xl;
+        raws[k].digits(q, avg, xh, xl);
+        const int cell = ((s >> 2) & 3) * (TR * 64) + r * 64 + (s >> 4) * 16 + (s & 3) * 4;
+        *(uint32_t*)(planes + SRC_HI + cell) = xh;
+        *(uint32_t*)(planes + SRC_LO + cell) = xl;
+    }
     __syncthreads();
-    {   // ---- the displacement copies: copy dx, row r, columns 4 q .. 4 q + 3 = staging bytes (r * PP + 4 + 4 q + dx ..): two adjacent staging dwords, one funnel shift ----
+    {   // ---- the displacement copies: copy dx, plane row r, columns 4 q .. 4 q + 3 = staging bytes (r * PP + 4 + 4 q + dx ..): two adjacent staging dwords, one funnel shift.
+        // Item -> (row, dword) so that a wave's stores spread over the banks: lane bits 0-1 = dword of the cell, 2-3 = chunk, 4-5 = quarter.
         constexpr int Q = TC / 4;
         for (int i = tid; i < NR * Q; i += 256) {
-            const int r = i / Q, q = i - r * Q;
+            const int r = i / Q, m = i - r * Q, j = m & 3, ch = (m >> 2) & 3, kg = m >> 4, q = 16 * ch + 4 * kg + j;
 #pragma unroll
             for (int d = 0; d < 2; d++) {
                 const uint32_t* row = (const uint32_t*)(stage + d * STAGE_PLANE + r * PP); // dword k of the row = tile columns 4 k - 4 .. 4 k - 1
                 const uint32_t  w0 = row[q], w1 = row[q + 1], w2_ = row[q + 2];
-                uint32_t*       out = (uint32_t*)(planes + d * LO + r * TC) + q;
+                uint8_t*        out = planes + d * LO + kg * L::KP + 4 * j;
 #pragma unroll
                 for (int dx = -hw; dx <= hw; dx++) { // columns 4 q + dx ..: dx < 0 starts in dword q (= columns 4 q - 4 ..), dx >= 0 in dword q + 1
                     const uint32_t v = dx < 0 ? __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)(4 + dx)) : (dx == 0 ? w1 : __builtin_amdgcn_alignbyte(w2_, w1, (uint32_t)dx));
-                    out[(dx + hw) * (COPY_PLANE / 4)] = v;
+                    const int      Rr = L::A * r + L::B * (dx + hw);
+                    *(uint32_t*)(out + 64 * Rr + 16 * (ch ^ ((Rr >> 2) & 3))) = v;
                 }
             }
         }
     }
     __syncthreads();
-    {   // this wave's chunks of the tile: rows 4 wv .. 4 wv + 3, nch chunks each, flattened; software pipelined: the operands of chunk it + 1
-        // are fetched (LDS + funnel shifts) while the matrix pipe works through the 36 (10) MFMAs of chunk it
+    if (band + 1 < BANDS && r0 + TR < Hh) issue(r0 + TR, Hh - (r0 + TR) < TR ? Hh - (r0 + TR) : TR); // the next tile's loads fly while the matrix pipe works on this one
+    {   // this wave's chunks of the tile: rows 2 wv, 2 wv + 1, nch chunks each, flattened; software pipelined: the operands of chunk it + 1
+        // are fetched while the matrix pipe works through the 36 (10) MFMAs of chunk it
         const int nch = (tw + 63) >> 6;
         int nrow = th - wv * (TR / 4);
         nrow = nrow < 0 ? 0 : (nrow > TR / 4 ? TR / 4 : nrow);
@@ -197,8 +299,9 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 const bool  last = g == NG - 1;
-                const int   a = row * TC + 64 * ch + opoff[g]; // a multiple of 16
-                const i32x4 vh = *(const i32x4*)(planes + (last ? last_hi : 0) + a), vl = *(const i32x4*)(planes + (last ? last_lo : LO) + a);
+                const int   Rr = rr0[g] + (last ? last_step : L::A) * row;
+                const int   a = cell0[g] + 64 * Rr + 16 * (ch ^ ((Rr >> 2) & (last ? last_swz : 3)));
+                const i32x4 vh = *(const i32x4*)(planes + a), vl = *(const i32x4*)(planes + a + (last ? last_lo : LO));
                 if (FULL && !last) { // whole chunk, taps only: the LDS words ARE the operands
                     oH[g] = vh;
                     oL[g] = vl;
@@ -304,20 +407,23 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
 
 // upper triangle / M -> divide as the reference's `/=` (truncation toward zero, restoration_pick.c:733-742), mirror to the lower triangle
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const int win, const int bit_depth, long long* Mout, long long* Hout) {
-    const int w2 = win * win, div = bit_depth == 12 ? 16 : (bit_depth == 10 ? 4 : 1);
+    // `/=` by 1, 4 or 16 truncates toward zero: add (divisor - 1) to negative values, then shift (a 64-bit division costs a few hundred instructions per entry)
+    const int       w2 = win * win, sh = bit_depth == 12 ? 4 : (bit_depth == 10 ? 2 : 0);
+    const long long bias = (1ll << sh) - 1;
+    auto            quot = [&](const long long v) { return (v + ((v >> 63) & bias)) >> sh; };
     long long* H = Hout + (size_t)blockIdx.x * 49 * 49;
     long long* M = Mout + (size_t)blockIdx.x * 49;
     for (int e = threadIdx.x; e < w2 * w2; e += 256) {
         const int k = e / w2, l2 = e - k * w2;
         if (k < l2) {
-            const long long v = H[e] / div;
+            const long long v = quot(H[e]);
             H[e]              = v;
             H[l2 * w2 + k]    = v;
         } else if (k == l2) {
-            H[e] = H[e] / div;
+            H[e] = quot(H[e]);
         }
     }
-    for (int k = threadIdx.x; k < w2; k += 256) M[k] = M[k] / div;
+    for (int k = threadIdx.x; k < w2; k += 256) M[k] = quot(M[k]);
 }
 
 } // namespace
@@ -334,22 +440,22 @@ void svt_hip_lr_compute_stats_batch_samples(const void* dgd, const void* src, co
     if (n == 0) return;
     hipStream_t st = (hipStream_t)stream;
     const int   is16 = sample_bytes == 2, w2 = wiener_win * wiener_win;
-    HIP_CHECK(hipMemsetAsync(M, 0, (size_t)n * 49 * 8, st));
-    HIP_CHECK(hipMemsetAsync(H, 0, (size_t)n * 49 * 49 * 8, st));
-    hipLaunchKernelGGL(stats_sum_kernel, dim3((max_rect_height + 15) / 16, n), dim3(256), 0, st, dgd, rects, dgd_stride, is16, w2, (long long*)H);
+    const int rows_per_band = (max_rect_height + SUM_BANDS - 1) / SUM_BANDS > 0 ? (max_rect_height + SUM_BANDS - 1) / SUM_BANDS : 1;
+    hipLaunchKernelGGL(stats_sum_kernel, dim3(SUM_BANDS, n), dim3(256), 0, st, dgd, rects, dgd_stride, is16, w2, rows_per_band, (long long*)M, (long long*)H);
     SVT_LAUNCH_CHECK();
     const dim3 grid((max_rect_width + TC - 1) / TC, (max_rect_height + TR * BANDS - 1) / (TR * BANDS), n);
     if (grid.x && grid.y) {
-        if (wiener_win == 7) {
-            const size_t shmem = (size_t)(30 * 256 * 4 > lds_bytes<7>() ? 30 * 256 * 4 : lds_bytes<7>()) + 64;
-            hipLaunchKernelGGL(stats_mfma_kernel<7>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, is16, (long long*)M, (long long*)H);
-        } else if (wiener_win == 5) {
-            const size_t shmem = (size_t)(9 * 256 * 4 > lds_bytes<5>() ? 9 * 256 * 4 : lds_bytes<5>()) + 64;
-            hipLaunchKernelGGL(stats_mfma_kernel<5>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, is16, (long long*)M, (long long*)H);
-        } else { // WIENER_WIN_3TAP (restoration_pick.c:1289)
-            const size_t shmem = (size_t)(3 * 256 * 4 > lds_bytes<3>() ? 3 * 256 * 4 : lds_bytes<3>()) + 64;
-            hipLaunchKernelGGL(stats_mfma_kernel<3>, grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, is16, (long long*)M, (long long*)H);
-        }
+        auto go = [&](auto win_tag, auto is16_tag) {
+            constexpr int  WIN = decltype(win_tag)::value;
+            constexpr bool IS16 = decltype(is16_tag)::value;
+            constexpr int  NG = (WIN * WIN + 1 + 15) / 16, merge = 3 * (NG * (NG + 1) / 2) * 256 * 4; // the final merge reuses the tile's LDS
+            const size_t   shmem = (size_t)(merge > lds_bytes<WIN>() ? merge : lds_bytes<WIN>()) + 64;
+            hipLaunchKernelGGL((stats_mfma_kernel<WIN, IS16>), grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, (long long*)M, (long long*)H);
+        };
+        auto by_depth = [&](auto win_tag) { is16 ? go(win_tag, std::true_type{}) : go(win_tag, std::false_type{}); };
+        if (wiener_win == 7) by_depth(std::integral_constant<int, 7>{});
+        else if (wiener_win == 5) by_depth(std::integral_constant<int, 5>{});
+        else by_depth(std::integral_constant<int, 3>{}); // WIENER_WIN_3TAP (restoration_pick.c:1289)
         SVT_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(n), dim3(256), 0, st, wiener_win, bit_depth, (long long*)M, (long long*)H);
