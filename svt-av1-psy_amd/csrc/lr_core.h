@@ -158,8 +158,9 @@ struct __attribute__((aligned(8))) LrDw2A8 { uint32_t lo, hi; };
 // (the row-major `mid` of before cost 16 + 12 v_perm and seven LDS reads per TWO samples; 531 -> see profiles/ VALU instructions per wave).  The
 // reference's "+ (centre << FILTER_BITS)" is tap 3 plus 128; the rounding constants ride in the accumulator seeds.  Every operand fits int16: pixels
 // <= 4095, mid <= 2^15 - 1 (WIENER_CLAMP_LIMIT), taps < 2^8.  A row past the staged ones (uh odd) only ever meets a zero tap or an output row >= uh.
-template <typename OUT> __device__ __forceinline__ void wiener_tile(const uint16_t* tile, uint16_t* mid, const WienerTaps& t, const int uw, const int uh,
-                                                                    const int bd, const int tid, OUT out) {
+struct LrNoHook { __device__ __forceinline__ void operator()() const {} };
+template <typename OUT, typename HOOK = LrNoHook> __device__ __forceinline__ void wiener_tile(const uint16_t* tile, uint16_t* mid, const WienerTaps& t, const int uw, const int uh,
+                                                                    const int bd, const int tid, OUT out, HOOK between_passes = HOOK()) { // (between_passes: run by every thread ahead of the barrier that separates the passes)
     int r0 = 3, r1 = 2 * FILTER_BITS - 3; // get_conv_params_wiener, convolve.h:70-88
     const int range = bd + FILTER_BITS - r0 + 2;
     if (range > 16) { r0 += range - 16; r1 -= range - 16; }
@@ -185,6 +186,7 @@ template <typename OUT> __device__ __forceinline__ void wiener_tile(const uint16
             *(LrDw2A8*)(mid2 + rp * 64 + c) = LrDw2A8{pk[0][0] | (pk[1][0] << 16), pk[0][1] | (pk[1][1] << 16)};
         }
     }
+    between_passes();
     __syncthreads();
     const int      g3 = t.fy[3] + (1 << FILTER_BITS);
     const uint32_t g01 = lr_pack(t.fy[0], t.fy[1]), g23 = lr_pack(t.fy[2], g3), g45 = lr_pack(t.fy[4], t.fy[5]), g6z = lr_pack(t.fy[6], 0);

@@ -79,9 +79,14 @@ __global__ void lr_rects_kernel(const SvtHipLrSearchParams P, SvtHipRect* rects,
 // KIND 0: unrestored; 1: Wiener with wn[u] (active units only); 2: self-guided with out[u].ep / xqd
 constexpr size_t LRS_A_BYTES = (size_t)66 * 66 * 2 + 8;
 constexpr size_t LRS_SMEM    = (size_t)TH * TW * 2 + LRS_A_BYTES + (size_t)66 * 66 * 4 + 512;
+constexpr size_t LRS_WN_MID_BYTES = (size_t)36 * 64 * 4;                                   // the Wiener passes' row-pair plane (35 row pairs of 64 dwords)
+constexpr size_t LRS_WN_SMEM = (size_t)TH * TW * 2 + LRS_WN_MID_BYTES + (size_t)64 * 64 * 2; // KIND 1: tile + row-pair plane + source tile = 27.5 KB, five workgroups per CU
+constexpr unsigned long long WN_TICKET = 1ull << 48;
+__device__ void lr_wiener_step(const SvtHipLrSearchParams& P, WnState* wn, unsigned long long* acc, SvtHipLrSearchUnit* out, int32_t* counter, const int u, const long long err2);
 template <int KIND>
-__global__ __launch_bounds__(256) void lr_trial_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, const WnState* __restrict__ wn,
-                                                       const SvtHipLrSearchUnit* __restrict__ units, unsigned long long* __restrict__ acc) {
+__global__ __launch_bounds__(256) void lr_trial_kernel(const SvtHipLrSearchParams P, const SvtHipRect* __restrict__ rects, WnState* wn,
+                                                       const SvtHipLrSearchUnit* __restrict__ units, unsigned long long* __restrict__ acc,
+                                                       SvtHipLrSearchUnit* out_units, int32_t* counter) {
     HIP_DYNAMIC_SHARED(uint16_t, smem)
     __shared__ unsigned long long part[4];
     const int        u = blockIdx.z, tid = threadIdx.x;
@@ -108,13 +113,45 @@ __global__ __launch_bounds__(256) void lr_trial_kernel(const SvtHipLrSearchParam
         sse += (unsigned long long)(uint32_t)(d0 * d0);
         if (has1) { const int d1 = v1 - rd_px(src, highbd, o + 1); sse += (unsigned long long)(uint32_t)(d1 * d1); }
     };
+    // KIND 1 (a refinement round: a latency chain of tens of these launches): the tile's source samples are fetched with the degraded ones -- two 16-byte loads per
+    // thread instead of sixteen 2-byte loads inside the vertical pass -- and parked in LDS while the horizontal pass runs
+    uint16_t*    srct = mid + LRS_WN_MID_BYTES / 2; // [64][64]
+    svt_u32x4_a2 sq[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (KIND == 1) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int j = tid + 256 * k, rr = j >> 3, cx = (j & 7) * 8;
+            if (rr < s.uh && cx < s.uw) {
+                const size_t o = (size_t)(y0 + rr) * sstride + x0 + cx;
+                if (cx + 8 <= s.uw) {
+                    if (highbd) sq[k] = svt_hip_global_load_x4((const uint16_t*)src + o);
+                    else { const svt_u32x2_a1 b = svt_hip_global_load_x2((const uint8_t*)src + o); // eight bytes -> eight 16-bit samples
+                           sq[k][0] = (b[0] & 0xffu) | ((b[0] & 0xff00u) << 8); sq[k][1] = ((b[0] >> 16) & 0xffu) | ((b[0] >> 8) & 0xff0000u);
+                           sq[k][2] = (b[1] & 0xffu) | ((b[1] & 0xff00u) << 8); sq[k][3] = ((b[1] >> 16) & 0xffu) | ((b[1] >> 8) & 0xff0000u); }
+                } else { // the ragged right edge of a unit: sample by sample
+                    for (int e = 0; e < 8 && cx + e < s.uw; e++) sq[k][e >> 1] |= (uint32_t)rd_px(src, highbd, o + e) << (16 * (e & 1));
+                }
+            }
+        }
+    }
     stage_tile<(TH + 15) / 16>(tile, s, tid);
     __syncthreads();
     if (KIND == 1) {
         WienerTaps t;
 #pragma unroll
         for (int k = 0; k < 8; k++) { t.fx[k] = wn[u].h[k]; t.fy[k] = wn[u].v[k]; }
-        wiener_tile(tile, mid, t, s.uw, s.uh, bd, tid, score);
+        wiener_tile(tile, mid, t, s.uw, s.uh, bd, tid,
+                    [&](int rr, int c, int v0, int v1, bool has1) {
+                        const uint32_t sp = *(const uint32_t*)(srct + rr * 64 + c);
+                        const int      d0 = v0 - (int)(sp & 0xffffu);
+                        sse += (unsigned long long)(uint32_t)(d0 * d0);
+                        if (has1) { const int d1 = v1 - (int)(sp >> 16); sse += (unsigned long long)(uint32_t)(d1 * d1); }
+                    },
+                    [&]() {
+#pragma unroll
+                        for (int k = 0; k < 2; k++) { const int j = tid + 256 * k; typedef uint32_t u32x4_a16 __attribute__((vector_size(16))); // (a 16-byte aligned LDS address: one ds_write_b128)
+                                                      *(u32x4_a16*)(srct + (j >> 3) * 64 + (j & 7) * 8) = u32x4_a16{sq[k][0], sq[k][1], sq[k][2], sq[k][3]}; }
+                    });
     } else if (KIND == 2) {
         const int idx = units[u].ep & 15, q0 = units[u].xqd[0], q1 = units[u].xqd[1];
         sgr_tile(tile, A16, B32, xlut, idx, s.uw, s.uh, bd, tid, [](int, int, int32_t) {},
@@ -132,7 +169,18 @@ __global__ __launch_bounds__(256) void lr_trial_kernel(const SvtHipLrSearchParam
     for (int m = 32; m >= 1; m >>= 1) sse += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(sse >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)sse, m);
     if ((tid & 63) == 0) part[tid >> 6] = sse;
     __syncthreads();
-    if (tid == 0) atomicAdd(&acc[u], part[0] + part[1] + part[2] + part[3]);
+    if (tid == 0) {
+        if (KIND == 1) {
+            // the unit's last workgroup to arrive also consumes the result and proposes the next trial (lr_wiener_step): a round of the refinement is ONE launch.
+            // The arrival count rides in the accumulator's top 16 bits (a unit's squared error stays far below 2^48), so the atomic that adds this workgroup's
+            // share also hands back everyone else's.
+            const unsigned long long mine = part[0] + part[1] + part[2] + part[3], old = atomicAdd(&acc[u], mine + WN_TICKET);
+            const int tiles = ((r.h_end - r.h_start + 63) >> 6) * ((r.v_end - r.v_start + 63) >> 6);
+            if ((int)(old >> 48) == tiles - 1) lr_wiener_step(P, wn, acc, out_units, counter, u, (long long)((old + mine) & (WN_TICKET - 1)));
+        } else {
+            atomicAdd(&acc[u], part[0] + part[1] + part[2] + part[3]);
+        }
+    }
 }
 
 __global__ void lr_take_sse_kernel(unsigned long long* acc, SvtHipLrSearchUnit* out, const int which, const int n) { // acc -> out[u].sse[which], acc = 0
@@ -144,37 +192,15 @@ __global__ void lr_take_sse_kernel(unsigned long long* acc, SvtHipLrSearchUnit* 
 
 // ---- Wiener solve: one wave per unit ----------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wrap_index(const int i, const int win) { const int h1 = (win >> 1) + 1; return i >= h1 ? win - 1 - i : i; }
-__device__ int linsolve_wiener(const int n, long long* A, const int stride, long long* b, int32_t* x) { // restoration_pick.c:754-790, verbatim arithmetic
-    for (int k = 0; k < n - 1; k++) {
-        for (int i = n - 1; i > k; i--) {
-            const long long p0 = A[(i - 1) * stride + k], p1 = A[i * stride + k];
-            if ((p0 < 0 ? -p0 : p0) < (p1 < 0 ? -p1 : p1)) {
-                for (int j = 0; j < n; j++) { const long long c = A[i * stride + j]; A[i * stride + j] = A[(i - 1) * stride + j]; A[(i - 1) * stride + j] = c; }
-                const long long c = b[i]; b[i] = b[i - 1]; b[i - 1] = c;
-            }
-        }
-        for (int i = k; i < n - 1; i++) {
-            if (A[k * stride + k] == 0) return 0;
-            const long long c = A[(i + 1) * stride + k], cd = A[k * stride + k];
-            for (int j = 0; j < n; j++) A[(i + 1) * stride + j] -= c / 256 * A[k * stride + j] / cd * 256;
-            b[i + 1] -= c * b[k] / cd;
-        }
-    }
-    for (int i = n - 1; i >= 0; i--) {
-        if (A[i * stride + i] == 0) return 0;
-        long long c = 0;
-        for (int j = i + 1; j <= n - 1; j++) c += A[i * stride + j] * x[j] / kScale;
-        x[i] = (int32_t)(kScale * (b[i] - c) / A[i * stride + i]);
-    }
-    return 1;
-}
-__global__ __launch_bounds__(64) void lr_wiener_solve_kernel(const SvtHipLrSearchParams P, const long long* __restrict__ Mall, const long long* __restrict__ Hall,
-                                                             const SvtHipLrPrevUnit* __restrict__ prev, WnState* __restrict__ wn, SvtHipLrSearchUnit* __restrict__ out) {
+// The unit's statistics are read ~20 times each by the eight alternating updates and the score: they are copied to LDS once (256 threads, coalesced), so the
+// dependent chain of the solve waits on LDS instead of on 49 global loads in series per update (217 / 360 us per launch at win 5 / 7 before: profiles/r06_lr_search_timeline.txt).
+__global__ __launch_bounds__(256) void lr_wiener_solve_kernel(const SvtHipLrSearchParams P, const long long* __restrict__ Mall, const long long* __restrict__ Hall,
+                                                              const SvtHipLrPrevUnit* __restrict__ prev, WnState* __restrict__ wn, SvtHipLrSearchUnit* __restrict__ out) {
     __shared__ long long     A[4], B[16], PQ[2];
     __shared__ int32_t       a[7], b[7];
+    __shared__ long long     M[49], H[49 * 49];
+    __shared__ int           solved;
     const int                u = blockIdx.x, l = threadIdx.x, win = P.wiener_win, win2 = win * win, h1 = (win >> 1) + 1, plane_off = (7 - win) >> 1;
-    const long long* M = Mall + (size_t)u * 49;
-    const long long* H = Hall + (size_t)u * 49 * 49;
     WnState st = {};
     if (prev && prev[u].use) { // use_prev_frame_coeffs (:1297-1302): the co-located unit's taps, no solve
         if (l == 0) {
@@ -184,6 +210,8 @@ __global__ __launch_bounds__(64) void lr_wiener_solve_kernel(const SvtHipLrSearc
         }
         return;
     }
+    for (int i = l; i < win2 * win2; i += 256) H[i] = Hall[(size_t)u * 49 * 49 + i];
+    if (l < win2) M[l] = Mall[(size_t)u * 49 + l];
     if (l < win) a[l] = b[l] = (int32_t)(kScale / kStep * kInitFilt[l + plane_off]);
     __syncthreads();
     for (int iter = 1; iter < 5; iter++) // NUM_WIENER_ITERS
@@ -210,16 +238,53 @@ __global__ __launch_bounds__(64) void lr_wiener_solve_kernel(const SvtHipLrSearc
                 }
             }
             __syncthreads();
+            // the reduced system (h1 - 1 unknowns) in place, then linsolve_wiener (restoration_pick.c:754-790) with the rows of an elimination step -- and the
+            // columns of a row -- on different lanes: every 64-bit division by a run-time value is a few hundred dependent instructions, and the serial form
+            // had fifteen of them in a row per update (eight updates per unit), the row-parallel form five.  Same operations on the same values in the same order
+            // per entry: bit-identical.
+            const int n = h1 - 1;
             if (l == 0) {
-                int32_t         S[7];
-                long long       Al[4], Bl[16];
-                for (int k = 0; k < 4; k++) Al[k] = A[k];
-                for (int k = 0; k < 16; k++) Bl[k] = B[k];
-                const long long a_last = Al[h1 - 1];
-                for (int i = 0; i < h1 - 1; i++) Al[i] -= a_last * 2 + Bl[i * h1 + h1 - 1] - 2 * Bl[(h1 - 1) * h1 + (h1 - 1)];
-                for (int i = 0; i < h1 - 1; i++)
-                    for (int j = 0; j < h1 - 1; j++) Bl[i * h1 + j] -= 2 * (Bl[i * h1 + (h1 - 1)] + Bl[(h1 - 1) * h1 + j] - 2 * Bl[(h1 - 1) * h1 + (h1 - 1)]);
-                if (linsolve_wiener(h1 - 1, Bl, h1, Al, S)) {
+                const long long a_last = A[h1 - 1];
+                for (int i = 0; i < n; i++) A[i] -= a_last * 2 + B[i * h1 + h1 - 1] - 2 * B[(h1 - 1) * h1 + (h1 - 1)];
+                for (int i = 0; i < n; i++)
+                    for (int j = 0; j < n; j++) B[i * h1 + j] -= 2 * (B[i * h1 + (h1 - 1)] + B[(h1 - 1) * h1 + j] - 2 * B[(h1 - 1) * h1 + (h1 - 1)]);
+                solved = 1;
+            }
+            __syncthreads();
+            for (int k = 0; k < n - 1; k++) {
+                if (l == 0) { // partial pivoting by neighbour swaps, bottom up (:756-766)
+                    for (int i = n - 1; i > k; i--) {
+                        const long long p0 = B[(i - 1) * h1 + k], p1 = B[i * h1 + k];
+                        if ((p0 < 0 ? -p0 : p0) < (p1 < 0 ? -p1 : p1)) {
+                            for (int j = 0; j < n; j++) { const long long c = B[i * h1 + j]; B[i * h1 + j] = B[(i - 1) * h1 + j]; B[(i - 1) * h1 + j] = c; }
+                            const long long c = A[i]; A[i] = A[i - 1]; A[i - 1] = c;
+                        }
+                    }
+                    if (B[k * h1 + k] == 0) solved = 0;
+                }
+                __syncthreads();
+                if (!solved) break; // (uniform: read after the barrier)
+                // lane = (row i + 1 below the pivot row, column j; j == n: the right-hand side)
+                const bool mine = l < (n - 1 - k) * (n + 1);
+                long long  val = 0;
+                const int  i = k + l / (n + 1), j = l % (n + 1);
+                if (mine) {
+                    const long long c = B[(i + 1) * h1 + k], cd = B[k * h1 + k];
+                    val = j < n ? B[(i + 1) * h1 + j] - c / 256 * B[k * h1 + j] / cd * 256 : A[i + 1] - c * A[k] / cd;
+                }
+                __syncthreads(); // every lane has read the column of multipliers before it is overwritten
+                if (mine) { if (j < n) B[(i + 1) * h1 + j] = val; else A[i + 1] = val; }
+                __syncthreads();
+            }
+            if (l == 0 && solved) {
+                int32_t S[7];
+                for (int i = n - 1; i >= 0; i--) {
+                    if (B[i * h1 + i] == 0) { solved = 0; break; }
+                    long long c = 0;
+                    for (int j = i + 1; j <= n - 1; j++) c += B[i * h1 + j] * S[j] / kScale;
+                    S[i] = (int32_t)(kScale * (A[i] - c) / B[i * h1 + i]);
+                }
+                if (solved) {
                     S[h1 - 1] = (int32_t)kScale;
                     for (int i = h1; i < win; i++) { S[i] = S[win - 1 - i]; S[h1 - 1] -= 2 * S[i]; }
                     for (int i = 0; i < win; i++) (fix_b ? a : b)[i] = S[i];
@@ -276,21 +341,10 @@ __global__ __launch_bounds__(64) void lr_wiener_solve_kernel(const SvtHipLrSearc
 
 // ---- Wiener refinement: finer_tile_search_wiener_seg (:1027-1131) as a resumable state machine, one thread per unit ----------------------------------
 __device__ __forceinline__ void wn_move(int16_t* f, const int p, const int d) { f[p] = (int16_t)(f[p] + d); f[6 - p] = (int16_t)(f[6 - p] + d); f[3] = (int16_t)(f[3] - 2 * d); }
-__global__ void lr_wiener_step_kernel(const SvtHipLrSearchParams P, WnState* __restrict__ wn, unsigned long long* __restrict__ acc, SvtHipLrSearchUnit* __restrict__ out,
-                                      int32_t* __restrict__ counter, const int n) {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n) return;
+__device__ void lr_wiener_step(const SvtHipLrSearchParams& P, WnState* wn, unsigned long long* acc, SvtHipLrSearchUnit* out, int32_t* counter, const int u, const long long err2) {
     WnState st = wn[u];
-    if (!st.active) return;
     const int plane_off = (7 - P.wiener_win) >> 1, start_step = 4, end_step = P.wn_max_one_refinement_step ? 4 : 1;
     enum { NEXT, AFTER_SIGN, AFTER_DIR, DONE, TRIAL } go;
-    if (!st.started) { // the evaluation of the initial taps
-        st.started = 1;
-        wn[u] = st;
-        atomicAdd(counter, 1);
-        return; // (acc[u] is 0; the trial kernel runs next)
-    }
-    const long long err2 = (long long)acc[u];
     acc[u] = 0;
     st.trials++;
     if (st.s == 0) { // result of the initial evaluation
@@ -334,6 +388,15 @@ __global__ void lr_wiener_step_kernel(const SvtHipLrSearchParams P, WnState* __r
         atomicAdd(counter, -1);
     }
     wn[u] = st;
+}
+
+// the first step of a unit (nothing evaluated yet): ask for the evaluation of the initial taps
+__global__ void lr_wiener_start_kernel(WnState* __restrict__ wn, int32_t* __restrict__ counter, const int n) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    if (!wn[u].active || wn[u].started) return;
+    wn[u].started = 1;
+    atomicAdd(counter, 1); // (acc[u] is 0; the trial kernel runs next)
 }
 
 // Wave sum of 32-bit values without an LDS round trip: the 16-bit halves are summed separately -- a row of 16 lanes by four DPP adds (each half's row sum < 2^20), the four
@@ -920,7 +983,7 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     hipLaunchKernelGGL(lr_rects_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.rects, W.acc, W.wn, units, n);
     HIP_CHECK(hipMemsetAsync(W.counter, 0, 128, st));
     // RESTORE_NONE
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<0>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<0>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc, (SvtHipLrSearchUnit*)nullptr, (int32_t*)nullptr);
     hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, st, W.acc, units, 0, n);
     SVT_LAUNCH_CHECK();
     // Three independent launch sequences behind the unit rectangles / the RESTORE_NONE pass, on the calling thread's side streams (fork here, join before returning):
@@ -948,57 +1011,82 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     }
     HIP_CHECK(hipEventRecord(ev_fork, st));
     unsigned long long* sg_acc = W.acc2;
-    auto self_guided = [&]() {
+    // The self-guided launches in two parts, so that the host can slip the head of the Wiener chain in between: part 0 = the filter launches of the first two groups
+    // (hundreds of microseconds of work: everything enqueued behind them is early), part 1 = the rest.
+    auto self_guided = [&](const int part) {
         const int    group = sg_group(P, slots);
         const size_t wh = (size_t)P.width * P.height;
         const bool   compact = P.bit_depth <= 10; // int16 differences (see lr_sgr_flt_kernel); 12-bit keeps the int32 planes
-        HIP_CHECK(hipStreamWaitEvent(sg_st[0], ev_fork, 0));
-        HIP_CHECK(hipStreamWaitEvent(sg_st[1], ev_fork, 0));
+        if (part == 0) {
+            HIP_CHECK(hipStreamWaitEvent(sg_st[0], ev_fork, 0));
+            HIP_CHECK(hipStreamWaitEvent(sg_st[1], ev_fork, 0));
+        }
         int gi = 0;
         for (int s0 = 0; s0 < slots; s0 += group, gi++) { // group gi: stream gi & 1, buffer gi & 1 (a buffer's next filter launch follows its projection launch in stream order)
             const int   gs = slots - s0 < group ? slots - s0 : group, b = gi & 1;
             const dim3  fgrid(((int)P.width + 63) / 64, ((int)P.height + 63) / 64, gs);
             int32_t*    qb = compact ? W.flt + lrs_dq_dwords((int)P.width, (int)P.height) + (size_t)b * group * wh : W.flt + (size_t)b * group * 2 * wh;
             hipStream_t s_ = sg_st[b];
+            const bool  flt_now = (gi < 2) == (part == 0), proj_now = part == 1;
             if (compact) {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, s_, P, W.flt, qb, s0, sgsum, slots);
-                if (gi == 0) HIP_CHECK(hipEventRecord(ev_dq, s_)); // (the first group's filter launch also writes the dgd - src plane every projection launch reads)
-                if (gi == 1) HIP_CHECK(hipStreamWaitEvent(s_, ev_dq, 0));
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, gs), dim3(PROJ_T), 0, s_, P, W.rects, W.flt, qb, W.sg, slots, s0, line_walk, sgsum, sg_dbg);
+                if (flt_now) hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<true>), fgrid, dim3(256), LRS_SMEM, s_, P, W.flt, qb, s0, sgsum, slots);
+                if (flt_now && gi == 0) HIP_CHECK(hipEventRecord(ev_dq, s_)); // (the first group's filter launch also writes the dgd - src plane every projection launch reads)
+                if (proj_now && gi == 1) HIP_CHECK(hipStreamWaitEvent(s_, ev_dq, 0));
+                if (proj_now) hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<true>), dim3(n, gs), dim3(PROJ_T), 0, s_, P, W.rects, W.flt, qb, W.sg, slots, s0, line_walk, sgsum, sg_dbg);
             } else {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, s_, P, W.flt, qb, s0, sgsum, slots);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, gs), dim3(PROJ_T), 0, s_, P, W.rects, W.flt, qb, W.sg, slots, s0, line_walk, sgsum, sg_dbg);
+                if (flt_now) hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_flt_kernel<false>), fgrid, dim3(256), LRS_SMEM, s_, P, W.flt, qb, s0, sgsum, slots);
+                if (proj_now) hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_sgr_proj_kernel<false>), dim3(n, gs), dim3(PROJ_T), 0, s_, P, W.rects, W.flt, qb, W.sg, slots, s0, line_walk, sgsum, sg_dbg);
             }
         }
+        if (part == 0) return;
         HIP_CHECK(hipEventRecord(ev_sg1, sg_st[1]));
         HIP_CHECK(hipStreamWaitEvent(sg_st[0], ev_sg1, 0));
         hipLaunchKernelGGL(lr_sgr_pick_kernel, dim3((n + 63) / 64), dim3(64), 0, sg_st[0], P, W.sg, units, slots, n);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<2>), tgrid, dim3(256), LRS_SMEM, sg_st[0], P, W.rects, W.wn, units, sg_acc);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<2>), tgrid, dim3(256), LRS_SMEM, sg_st[0], P, W.rects, W.wn, units, sg_acc, (SvtHipLrSearchUnit*)nullptr, (int32_t*)nullptr);
         hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, sg_st[0], sg_acc, units, 2, n);
         SVT_LAUNCH_CHECK();
         HIP_CHECK(hipEventRecord(ev_sg0, sg_st[0]));
     };
-    if (sg_on) self_guided(); // enqueued first: it is already running while the host steps through the Wiener refinement
+    if (sg_on) self_guided(0);
+    // The Wiener chain is the longer one (statistics -> solve -> tens of dependent refinement rounds): its head is enqueued before the self-guided launches, the
+    // refinement rounds after them (the host steps through those while everything else already runs).
     int rc_wn = 0;
     if (P.wn_enabled) {
         HIP_CHECK(hipStreamWaitEvent(wn_st, ev_fork, 0));
         svt_hip_lr_compute_stats_batch(P.dgd, P.src, W.rects, (uint32_t)n, mw, mh, (int)P.dgd_stride, (int)P.src_stride, P.wiener_win, P.highbd ? P.bit_depth : 8,
                                        (int64_t*)W.M, (int64_t*)W.H, wn_st);
-        hipLaunchKernelGGL(lr_wiener_solve_kernel, dim3(n), dim3(64), 0, wn_st, P, W.M, W.H, prev, W.wn, units);
+        hipLaunchKernelGGL(lr_wiener_solve_kernel, dim3(n), dim3(256), 0, wn_st, P, W.M, W.H, prev, W.wn, units);
+        hipLaunchKernelGGL(lr_wiener_start_kernel, dim3((n + 63) / 64), dim3(64), 0, wn_st, W.wn, W.counter, n);
         SVT_LAUNCH_CHECK();
-        // lock-step refinement: step (propose / consume) + trial; the number of units still searching comes back every 8 steps
-        int32_t active = 1;
-        for (int it = 0; active > 0 && it < 4096; it++) {
-            hipLaunchKernelGGL(lr_wiener_step_kernel, dim3((n + 63) / 64), dim3(64), 0, wn_st, P, W.wn, W.acc, units, W.counter, n);
-            if ((it & 7) == 0) {
-                HIP_CHECK(hipMemcpyAsync(&active, W.counter, 4, hipMemcpyDeviceToHost, wn_st));
-                HIP_CHECK(hipStreamSynchronize(wn_st));
-                if (active <= 0) break;
-            }
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<1>), tgrid, dim3(256), LRS_SMEM, wn_st, P, W.rects, W.wn, units, W.acc);
+    }
+    if (sg_on) self_guided(1);
+    if (P.wn_enabled) {
+        // Lock-step refinement: a round = one trial launch whose last workgroup per unit consumes the result and proposes the next move.  The number of units still
+        // searching comes back every WN_BATCH rounds through a page-locked word, and the NEXT batch is enqueued before the host waits for it: the read-back costs no
+        // gap in the stream; the price is one batch of empty launches (every workgroup leaves at once) after the last unit has finished.
+        constexpr int WN_BATCH = 8;
+        volatile int32_t* active = TS.pinned;
+        hipEvent_t        ev_cnt = TS.ev[5];
+        bool              done = false;
+        int               rounds = 0;
+        auto batch = [&]() {
+            for (int k = 0; k < WN_BATCH; k++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<1>), tgrid, dim3(256), LRS_WN_SMEM, wn_st, P, W.rects, W.wn, units, W.acc, units, W.counter);
+            rounds += WN_BATCH;
+        };
+        batch();
+        while (!done && rounds < 4096) {
+            HIP_CHECK(hipMemcpyAsync((void*)active, W.counter, 4, hipMemcpyDeviceToHost, wn_st));
+            HIP_CHECK(hipEventRecord(ev_cnt, wn_st));
+            batch();
+            HIP_CHECK(hipEventSynchronize(ev_cnt));
+            done = *active <= 0;
         }
         SVT_LAUNCH_CHECK();
-        if (active > 0) rc_wn = -2; // the lock-step cap was hit with units still searching: their sse[1] is not final -- the caller must not use this plane's result
+        if (!done) { // the cap: was the last batch enough?
+            HIP_CHECK(hipMemcpyAsync((void*)active, W.counter, 4, hipMemcpyDeviceToHost, wn_st));
+            HIP_CHECK(hipStreamSynchronize(wn_st));
+            if (*active > 0) rc_wn = -2; // units still searching: their sse[1] is not final -- the caller must not use this plane's result
+        }
         HIP_CHECK(hipEventRecord(ev_wn, wn_st));
         HIP_CHECK(hipStreamWaitEvent(st, ev_wn, 0)); // (also on the failure path: the side streams' work must not outlive the call's ordering)
     }

@@ -46,7 +46,8 @@ template <int WIN> struct CopyLayout {
     static constexpr int KP = (ROWS * 64 + 255) / 256 * 256;          // one kg sub-plane
     static constexpr int DP = 4 * KP;                                 // one digit
 };
-template <int WIN> constexpr int lds_bytes() { return 2 * STAGE_PLANE + 2 * CopyLayout<WIN>::DP + 2 * SRC_PLANE; }
+constexpr int ZERO_BYTES = 64;        // four zero cells: what the padding columns of the last operand group read
+template <int WIN> constexpr int lds_bytes() { return 2 * STAGE_PLANE + 2 * CopyLayout<WIN>::DP + 2 * SRC_PLANE + ZERO_BYTES; }
 
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
@@ -77,26 +78,40 @@ __global__ __launch_bounds__(256) void stats_sum_kernel(const void* dgd, const S
         if (b == 0 && tid < w2) Mout[(size_t)unit * 49 + tid] = 0;
     }
     const int rows = W <= 0 ? 0 : (Hh - r0 < rows_per_band ? Hh - r0 : rows_per_band);
-    const int px = is16 ? 2 : 1;
+    const int px = is16 ? 2 : 1, l = tid & 63;
+    auto word_sum = [&](const Word16 q) -> unsigned { // <= 8 samples of 16 bits or 16 of 8 bits
+        return is16 ? (q.x & 0xffff) + (q.x >> 16) + (q.y & 0xffff) + (q.y >> 16) + (q.z & 0xffff) + (q.z >> 16) + (q.w & 0xffff) + (q.w >> 16)
+                    : __builtin_amdgcn_sad_u8(q.w, 0u, __builtin_amdgcn_sad_u8(q.z, 0u, __builtin_amdgcn_sad_u8(q.y, 0u, __builtin_amdgcn_sad_u8(q.x, 0u, 0u))));
+    };
     unsigned long long s = 0;
-    for (int r = tid >> 6; r < rows; r += 4) { // a wave per row
-        const uintptr_t a0 = (uintptr_t)dgd + (size_t)px * (size_t)((long long)(R.v_start + r0 + r) * dgd_stride + R.h_start), a1 = a0 + (size_t)px * W;
-        const uintptr_t v0 = (a0 + 15) & ~(uintptr_t)15, v1 = a1 & ~(uintptr_t)15; // whole 16-byte words of the row: [v0, v1)
-        unsigned acc = 0; // <= 8 samples of 16 bits per word, a handful of words per lane and row: no overflow
-        if (v0 < v1) {
-            for (uintptr_t a = v0 + 16 * (uintptr_t)(tid & 63); a < v1; a += 16 * 64) {
-                const Word16 q = *(const Word16*)a;
-                if (is16) acc += (q.x & 0xffff) + (q.x >> 16) + (q.y & 0xffff) + (q.y >> 16) + (q.z & 0xffff) + (q.z >> 16) + (q.w & 0xffff) + (q.w >> 16);
-                else acc = __builtin_amdgcn_sad_u8(q.w, 0u, __builtin_amdgcn_sad_u8(q.z, 0u, __builtin_amdgcn_sad_u8(q.y, 0u, __builtin_amdgcn_sad_u8(q.x, 0u, acc))));
-            }
-            const int head = (int)((v0 - a0) / px), tail = (int)((a1 - v1) / px); // ragged ends, < 16 bytes each
-            const int l = tid & 63;
-            if (l < head) acc += is16 ? ((const uint16_t*)a0)[l] : ((const uint8_t*)a0)[l];
-            else if (l - head < tail) acc += is16 ? ((const uint16_t*)v1)[l - head] : ((const uint8_t*)v1)[l - head];
-        } else { // a row shorter than one aligned word
-            for (int x = tid & 63; x < W; x += 64) acc += is16 ? ((const uint16_t*)a0)[x] : ((const uint8_t*)a0)[x];
+    constexpr int RU = 4; // rows in flight per wave: a row is one aligned 16-byte load per lane (+ one sample per lane at the two ragged ends), issued before any is summed
+    for (int rb = tid >> 6; rb < rows; rb += 4 * RU) {
+        uintptr_t a0[RU], v0[RU], v1[RU], a1[RU];
+        Word16    q[RU];
+        unsigned  e[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            const int r = rb + 4 * u;
+            a0[u] = (uintptr_t)dgd + (size_t)px * (size_t)((long long)(R.v_start + r0 + (r < rows ? r : rows - 1)) * dgd_stride + R.h_start);
+            a1[u] = r < rows ? a0[u] + (size_t)px * W : a0[u]; // (a row beyond the band: empty)
+            v0[u] = (a0[u] + 15) & ~(uintptr_t)15;
+            v1[u] = a1[u] & ~(uintptr_t)15; // whole 16-byte words of the row: [v0, v1)
+            q[u]  = Word16{0, 0, 0, 0};
+            e[u]  = 0;
+            const uintptr_t a = v0[u] + 16 * (uintptr_t)l;
+            if (a < v1[u]) q[u] = *(const Word16*)a;
+            // ragged ends (< 16 bytes each; everything when the row holds no whole word): lane k < head takes sample k, the next `tail` lanes the samples from v1 on
+            const uintptr_t hend = v0[u] < a1[u] ? v0[u] : a1[u], tbeg = v1[u] > hend ? v1[u] : hend;
+            const int       head = (int)((hend - a0[u]) / px), tail = (int)((a1[u] - tbeg) / px);
+            if (l < head) e[u] = is16 ? ((const uint16_t*)a0[u])[l] : ((const uint8_t*)a0[u])[l];
+            else if (l - head < tail) e[u] = is16 ? ((const uint16_t*)tbeg)[l - head] : ((const uint8_t*)tbeg)[l - head];
         }
-        s += acc;
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            unsigned acc = word_sum(q[u]) + e[u];
+            for (uintptr_t a = v0[u] + 16 * (uintptr_t)(l + 64); a < v1[u]; a += 16 * 64) acc += word_sum(*(const Word16*)a); // (rows wider than 64 words)
+            s += acc;
+        }
     }
     s = (unsigned long long)wave_sum_ll((long long)s);
     if ((tid & 63) == 0) wsum[tid >> 6] = (long long)s;
@@ -126,6 +141,17 @@ __device__ __forceinline__ QuadWhere quad_where(const int tc0, const int lo, con
     q.keep = (row_ok && e1 > e0) ? (e1 - e0 >= 4 ? ~0u : (((1u << (8 * (e1 - e0))) - 1u) << (8 * e0))) : 0u;
     return q;
 }
+// digits of four centred samples held as two packed pairs (x = [p0, p1], y = [p2, p3] in the order given by `sel`): v = 128 h + l, h = v >> 7 (arithmetic), l = v & 127;
+// v_pk_sub_i16 / v_pk_ashrrev_i16 / v_and / v_perm: eight instructions per quad
+typedef short s16x2 __attribute__((vector_size(4)));
+__device__ __forceinline__ s16x2    as_pk(const uint32_t v) { s16x2 r; __builtin_memcpy(&r, &v, 4); return r; }
+__device__ __forceinline__ uint32_t as_u32(const s16x2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
+__device__ __forceinline__ void pair_digits(const uint32_t x, const uint32_t y, const int avg, const uint32_t sel, const uint32_t keep, uint32_t& hi, uint32_t& lo) {
+    const short a16 = (short)avg;
+    const s16x2 av = {a16, a16}, cx = as_pk(x) - av, cy = as_pk(y) - av;
+    hi = __builtin_amdgcn_perm(as_u32(cy >> 7), as_u32(cx >> 7), sel) & keep;
+    lo = __builtin_amdgcn_perm(as_u32(cy) & 0x007f007fu, as_u32(cx) & 0x007f007fu, sel) & keep;
+}
 template <bool IS16> struct RawQuad;
 template <> struct RawQuad<true> {
     uint32_t a, b;
@@ -137,12 +163,13 @@ template <> struct RawQuad<true> {
         a = v[0] | (v[1] << 16); b = v[2] | (v[3] << 16);
     }
     __device__ __forceinline__ void digits(const QuadWhere q, const int avg, uint32_t& hi, uint32_t& lo) const {
-        unsigned long long w = ((unsigned long long)b << 32) | a;
-        if (q.keep == 0) { hi = lo = 0; return; }
-        w = q.shift > 0 ? w << (16 * q.shift) : w >> (16 * -q.shift);
-        const int v0 = (int)(w & 0xffff) - avg, v1 = (int)((w >> 16) & 0xffff) - avg, v2 = (int)((w >> 32) & 0xffff) - avg, v3 = (int)(w >> 48) - avg;
-        hi = pack_digits_hi(v0, v1, v2, v3) & q.keep;
-        lo = pack_digits_lo(v0, v1, v2, v3) & q.keep;
+        uint32_t x = a, y = b;
+        if (q.shift != 0 && q.keep != 0) { // a quad at the edge of the readable range (one or two lanes of a tile row): move the loaded window back over the quad
+            unsigned long long w = ((unsigned long long)b << 32) | a;
+            w = q.shift > 0 ? w << (16 * q.shift) : w >> (16 * -q.shift);
+            x = (uint32_t)w; y = (uint32_t)(w >> 32);
+        }
+        pair_digits(x, y, avg, 0x06040200u, q.keep, hi, lo); // x = [s0, s1], y = [s2, s3]
     }
 };
 template <> struct RawQuad<false> {
@@ -154,11 +181,9 @@ template <> struct RawQuad<false> {
         for (int e = 0; e < 4; e++) { const int c = tc0 + e < lo ? lo : (tc0 + e > hi - 1 ? hi - 1 : tc0 + e); a |= (uint32_t)((const uint8_t*)base)[(long long)row_off + c] << (8 * e); }
     }
     __device__ __forceinline__ void digits(const QuadWhere q, const int avg, uint32_t& hi, uint32_t& lo) const {
-        if (q.keep == 0) { hi = lo = 0; return; }
-        const uint32_t w = q.shift > 0 ? a << (8 * q.shift) : a >> (8 * -q.shift);
-        const int v0 = (int)(w & 255) - avg, v1 = (int)((w >> 8) & 255) - avg, v2 = (int)((w >> 16) & 255) - avg, v3 = (int)(w >> 24) - avg;
-        hi = pack_digits_hi(v0, v1, v2, v3) & q.keep;
-        lo = pack_digits_lo(v0, v1, v2, v3) & q.keep;
+        uint32_t w = a;
+        if (q.shift != 0 && q.keep != 0) w = q.shift > 0 ? w << (8 * q.shift) : w >> (8 * -q.shift);
+        pair_digits(w & 0x00ff00ffu, (w >> 8) & 0x00ff00ffu, avg, 0x06020400u, q.keep, hi, lo); // x = [s0, s2], y = [s1, s3]
     }
 };
 
@@ -166,7 +191,7 @@ template <> struct RawQuad<false> {
 // group but the last is known to hold taps only (16 (NG - 1) <= WIN^2), so only the last group keeps per-lane plane / pitch / mask registers.
 template <int WIN, bool IS16>
 __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, const void* src, const SvtHipRect* rects, const int dgd_stride, const int src_stride,
-                                                         long long* Mout, long long* Hout) {
+                                                         long long* Mout, long long* Hout, const int nbands) {
     using L = CopyLayout<WIN>;
     constexpr int win = WIN, NG = (WIN * WIN + 1 + 15) / 16;
     static_assert(16 * (NG - 1) <= WIN * WIN, "only the last group may hold the source column or padding");
@@ -183,31 +208,36 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     const SvtHipRect R = rects[unit];
     constexpr int w2 = win * win, hw = win >> 1;
     const int W = R.h_end - R.h_start, Hh = R.v_end - R.v_start;
-    const int c0 = blockIdx.x * TC, rb0 = blockIdx.y * TR * BANDS; // origin of the workgroup's 64-row band group inside the unit
+    const int c0 = blockIdx.x * TC, rb0 = blockIdx.y * TR * nbands; // origin of the workgroup's band group (nbands tiles of 8 rows, <= BANDS) inside the unit
     if (c0 >= W || rb0 >= Hh) return;
     const int tw = W - c0 < TC ? W - c0 : TC;
     long long* H = Hout + (size_t)unit * 49 * 49;
     long long* M = Mout + (size_t)unit * 49;
-    unsigned long long total = 0; // sum of the degraded unit: stats_sum_kernel's partials
-#pragma unroll
-    for (int b = 0; b < SUM_BANDS; b++) total += (unsigned long long)H[sum_slot(b, w2)];
-    const int avg = (int)(total / (unsigned long long)((long long)W * Hh));
+#ifdef SVT_HIP_STATS_CENSUS // (measurement build only, tools/stats_census.py: when and where each workgroup ran; the finalize launch is skipped, the results are not usable)
+    const unsigned long long census_t0 = wall_clock64();
+#endif
 
     // ---- per-lane operand addressing: group g -> tap t = 16 g + (l & 15); kg = l >> 4 selects pixels 16 kg .. 16 kg + 15 of a chunk ----
-    // operand of (tile row, chunk ch) = the 16-byte cell (see CopyLayout) at  cell0[g] + 64 Rr + 16 (ch ^ ((Rr >> 2) & swz)),  Rr = rr0[g] + rstep * row
-    int      cell0[NG], rr0[NG], last_step = L::A, last_swz = 3, last_lo = LO;
-    uint32_t last_mask = ~0u;
+    // A wave owns tile rows 2 wv and 2 wv + 1.  Operand of (row 2 wv + ri, chunk ch) = the 16-byte cell (see CopyLayout) at  obase[g] + ri * ostep + ((16 ch) ^ oswz[g][ri])
+    // -- one v_xad_u32 per operand in the K loop; hi and lo digit of a cell differ by a constant (the ds_read offset field).  The last group also holds the source
+    // column (its own [kg][row][chunk] planes, no swizzle) and padding columns, which read the zero cells: no masks.
+    constexpr int ZERO = SRC_LO + SRC_PLANE;
+    int obase[NG], oswz[NG][2], last_step = 64 * L::A, last_lo = LO;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const int t = 16 * g + (l & 15), kg = l >> 4;
         if (g < NG - 1 || t < w2) { // tap index = (dx + hw) * win + (dy + hw)   (restoration_pick.c:673-679: k over columns, l over rows)
-            const int dxi = t / win, dyi = t % win;
-            cell0[g] = kg * L::KP;
-            rr0[g]   = L::A * (3 - hw + dyi) + L::B * dxi;
-        } else { // the source column (t == w2) or padding (contributes zeros): [kg][row][chunk] cells, no swizzle
-            cell0[g] = SRC_HI + kg * (TR * 64); rr0[g] = 0; last_step = 1; last_swz = 0; last_lo = SRC_PLANE; last_mask = t == w2 ? ~0u : 0u;
+            const int dxi = t / win, dyi = t % win, Rr = L::A * (2 * wv + 3 - hw + dyi) + L::B * dxi;
+            obase[g]   = kg * L::KP + 64 * Rr;
+            oswz[g][0] = 16 * ((Rr >> 2) & 3);
+            oswz[g][1] = 16 * (((Rr + L::A) >> 2) & 3);
+        } else if (t == w2) { // the source column
+            obase[g] = SRC_HI + kg * (TR * 64) + 64 * 2 * wv; oswz[g][0] = oswz[g][1] = 0; last_step = 64; last_lo = SRC_PLANE;
+        } else { // padding
+            obase[g] = ZERO; oswz[g][0] = oswz[g][1] = 0; last_step = 0; last_lo = 0;
         }
     }
+    if (tid < ZERO_BYTES / 4) ((uint32_t*)(planes + ZERO))[tid] = 0; // (made visible by the first tile's barriers)
     i32x4 accHH[NTRI], accLL[NTRI], accX[NTRI];
 #pragma unroll
     for (int i = 0; i < NTRI; i++) { accHH[i] = i32x4{0, 0, 0, 0}; accLL[i] = i32x4{0, 0, 0, 0}; accX[i] = i32x4{0, 0, 0, 0}; }
@@ -216,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     constexpr int SLOTS = PP / 4, NIT = (NR * SLOTS + 255) / 256, SSLOTS = TC / 4, SNIT = (TR * SSLOTS + 255) / 256;
     RawQuad<IS16> rawd[NIT], raws[SNIT];
     // readable columns: [-hw, tw + hw) of the degraded rows, [0, tw) of the source rows (a tile of fewer than four columns loads sample by sample)
-    auto issue = [&](const int r0, const int th) {
+    auto issue = [&](const int r0, const int th, const int tid) { // (tid: the caller's per-tile copy, see btid)
 #pragma unroll
         for (int k = 0; k < NIT; k++) {
             const int i = tid + 256 * k, r = i / SLOTS, s = i - r * SLOTS;
@@ -235,17 +265,23 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
             else raws[k].load_narrow(src, row_off, 4 * s, 0, tw);
         }
     };
-    issue(rb0, Hh - rb0 < TR ? Hh - rb0 : TR);
+    issue(rb0, Hh - rb0 < TR ? Hh - rb0 : TR, tid);
+    unsigned long long total = 0; // sum of the degraded unit: stats_sum_kernel's partials (read behind the first tile's loads: one memory round trip, not two in series)
+#pragma unroll
+    for (int b = 0; b < SUM_BANDS; b++) total += (unsigned long long)H[sum_slot(b, w2)];
+    const int avg = (int)(total / (unsigned long long)((long long)W * Hh));
 
-    for (int band = 0; band < BANDS; band++) {
+    for (int band = 0; band < nbands; band++) {
     const int r0 = rb0 + band * TR;
     if (r0 >= Hh) break;
     const int th = Hh - r0 < TR ? Hh - r0 : TR;
     if (band) __syncthreads(); // everyone is done reading the previous tile
+    int btid = tid; // (re-defined per tile: the staging / copy addresses derived from it are loop invariant and would be hoisted out of the band loop -- into scratch, 480 B)
+    SVT_HIP_OPAQUE_I32(btid);
     // ---- the digit planes of the tile from the loaded quads ----
 #pragma unroll
     for (int k = 0; k < NIT; k++) {
-        const int i = tid + 256 * k, r = i / SLOTS, s = i - r * SLOTS, tr = r - 3;
+        const int i = btid + 256 * k, r = i / SLOTS, s = i - r * SLOTS, tr = r - 3;
         const QuadWhere q = quad_where(4 * s - 4, -hw, tw + hw, tr >= -hw && tr < th + hw);
         uint32_t dh, dl;
         rawd[k].digits(q, avg, dh, dl);
@@ -256,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     }
 #pragma unroll
     for (int k = 0; k < SNIT; k++) { // source quad s of row r: chunk s / 16, quarter (s / 4) & 3, dword s & 3 of the cell
-        const int i = tid + 256 * k, r = i / SSLOTS, s = i - r * SSLOTS;
+        const int i = btid + 256 * k, r = i / SSLOTS, s = i - r * SSLOTS;
         const QuadWhere q = quad_where(4 * s, 0, tw, r < th);
         uint32_t xh, xl;
         raws[k].digits(q, avg, xh, xl);
@@ -265,55 +301,60 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
         *(uint32_t*)(planes + SRC_LO + cell) = xl;
     }
     __syncthreads();
-    {   // ---- the displacement copies: copy dx, plane row r, columns 4 q .. 4 q + 3 = staging bytes (r * PP + 4 + 4 q + dx ..): two adjacent staging dwords, one funnel shift.
-        // Item -> (row, dword) so that a wave's stores spread over the banks: lane bits 0-1 = dword of the cell, 2-3 = chunk, 4-5 = quarter.
-        constexpr int Q = TC / 4;
-        for (int i = tid; i < NR * Q; i += 256) {
-            const int r = i / Q, m = i - r * Q, j = m & 3, ch = (m >> 2) & 3, kg = m >> 4, q = 16 * ch + 4 * kg + j;
+    {   // ---- the displacement copies, one 16-byte cell (plane row r, chunk ch, quarter kg: columns c = 64 ch + 16 kg .. c + 15) per thread: copy dx of the cell = staging
+        // bytes r * PP + 4 + c + dx .. + 15, i.e. six staging dwords funnel-shifted by dx; hi and lo digit share the address.  Item -> (ch, r & 1, kg, r >> 1): the eight
+        // lanes a ds_write_b128 serves together then hit the eight different 16-byte slots of the 128-byte bank row.
+        const int i = btid, ch = i & 3, r = 2 * (i >> 5) + ((i >> 2) & 1), kg = (i >> 3) & 3;
+        if (i < NR * 16) {
+            uint32_t wd[2][6];
 #pragma unroll
             for (int d = 0; d < 2; d++) {
-                const uint32_t* row = (const uint32_t*)(stage + d * STAGE_PLANE + r * PP); // dword k of the row = tile columns 4 k - 4 .. 4 k - 1
-                const uint32_t  w0 = row[q], w1 = row[q + 1], w2_ = row[q + 2];
-                uint8_t*        out = planes + d * LO + kg * L::KP + 4 * j;
+                const uint32_t* row = (const uint32_t*)(stage + d * STAGE_PLANE + r * PP) + 16 * ch + 4 * kg; // dword k of a staging row = tile columns 4 k - 4 .. 4 k - 1
+                const i32x4     v = *(const i32x4*)row;
+                wd[d][0] = (uint32_t)v[0]; wd[d][1] = (uint32_t)v[1]; wd[d][2] = (uint32_t)v[2]; wd[d][3] = (uint32_t)v[3];
+                wd[d][4] = row[4]; wd[d][5] = row[5];
+            }
+            uint8_t* out = planes + kg * L::KP;
 #pragma unroll
-                for (int dx = -hw; dx <= hw; dx++) { // columns 4 q + dx ..: dx < 0 starts in dword q (= columns 4 q - 4 ..), dx >= 0 in dword q + 1
-                    const uint32_t v = dx < 0 ? __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)(4 + dx)) : (dx == 0 ? w1 : __builtin_amdgcn_alignbyte(w2_, w1, (uint32_t)dx));
-                    const int      Rr = L::A * r + L::B * (dx + hw);
-                    *(uint32_t*)(out + 64 * Rr + 16 * (ch ^ ((Rr >> 2) & 3))) = v;
+            for (int dx = -hw; dx <= hw; dx++) { // columns c + dx ..: dx < 0 starts inside dword 0 (= columns c - 4 ..), dx >= 0 inside dword 1
+                const int Rr = L::A * r + L::B * (dx + hw);
+                uint8_t*  cell = out + 64 * Rr + 16 * (ch ^ ((Rr >> 2) & 3));
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    i32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        v[j] = (int)(dx < 0 ? __builtin_amdgcn_alignbyte(wd[d][j + 1], wd[d][j], (uint32_t)(4 + dx))
+                                            : (dx == 0 ? wd[d][j + 1] : __builtin_amdgcn_alignbyte(wd[d][j + 2], wd[d][j + 1], (uint32_t)dx)));
+                    *(i32x4*)(cell + d * LO) = v;
                 }
             }
         }
     }
     __syncthreads();
-    if (band + 1 < BANDS && r0 + TR < Hh) issue(r0 + TR, Hh - (r0 + TR) < TR ? Hh - (r0 + TR) : TR); // the next tile's loads fly while the matrix pipe works on this one
+    if (band + 1 < nbands && r0 + TR < Hh) issue(r0 + TR, Hh - (r0 + TR) < TR ? Hh - (r0 + TR) : TR, btid); // the next tile's loads fly while the matrix pipe works on this one
     {   // this wave's chunks of the tile: rows 2 wv, 2 wv + 1, nch chunks each, flattened; software pipelined: the operands of chunk it + 1
         // are fetched while the matrix pipe works through the 36 (10) MFMAs of chunk it
         const int nch = (tw + 63) >> 6;
-        int nrow = th - wv * (TR / 4);
+        int nrow = th - wv * (TR / 4); // (tile rows 2 wv, 2 wv + 1 of th)
         nrow = nrow < 0 ? 0 : (nrow > TR / 4 ? TR / 4 : nrow);
-        const int nit = nrow * nch;
-        auto fetch = [&](const int it, i32x4 (&oH)[NG], i32x4 (&oL)[NG], auto full_tag) {
+        auto fetch = [&](const int ri, const int ch, i32x4 (&oH)[NG], i32x4 (&oL)[NG], auto full_tag) { // chunk ch of this wave's tile row ri (0 / 1)
             constexpr bool FULL = decltype(full_tag)::value; // every chunk of the tile is 64 pixels wide: no per-byte masks
-            const int row = wv * (TR / 4) + it / nch, ch = it % nch;
             const int nvalid = tw - ch * 64; // pixels of this chunk inside the unit (>= 64: all)
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 const bool  last = g == NG - 1;
-                const int   Rr = rr0[g] + (last ? last_step : L::A) * row;
-                const int   a = cell0[g] + 64 * Rr + 16 * (ch ^ ((Rr >> 2) & (last ? last_swz : 3)));
+                const int   a = obase[g] + ri * (last ? last_step : 64 * L::A) + ((16 * ch) ^ (ri ? oswz[g][1] : oswz[g][0]));
                 const i32x4 vh = *(const i32x4*)(planes + a), vl = *(const i32x4*)(planes + a + (last ? last_lo : LO));
-                if (FULL && !last) { // whole chunk, taps only: the LDS words ARE the operands
+                if (FULL) { // whole chunk: the LDS words ARE the operands
                     oH[g] = vh;
                     oL[g] = vl;
                     continue;
                 }
 #pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    uint32_t m = last ? last_mask : ~0u; // only the last group holds the source column and padding
-                    if (!FULL && nvalid < 64) { // pixel 16 kg + 4 d + e of the chunk is outside the unit -> its byte must be zero in every operand
-                        const int first = 16 * (l >> 4) + 4 * d, left = nvalid - first;
-                        m &= left >= 4 ? ~0u : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
-                    }
+                for (int d = 0; d < 4; d++) { // pixel 16 kg + 4 d + e of the chunk is outside the unit -> its byte must be zero in every operand
+                    const int      first = 16 * (l >> 4) + 4 * d, left = nvalid - first;
+                    const uint32_t m = left >= 4 ? ~0u : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
                     oH[g][d] = (int)((uint32_t)vh[d] & m);
                     oL[g][d] = (int)((uint32_t)vl[d] & m);
                 }
@@ -341,61 +382,86 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
                     if (gb != ga) accX[ti] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oL[ga], oH[gb], accX[ti], 0, 0, 0);
         };
         i32x4 aH[NG], aL[NG], bH[NG], bL[NG];
+        const int nit = nrow * nch;
         if ((tw & 63) == 0 && nit > 0) {
-            // Straight-line two-chunk body (fetches clamp to the last chunk instead of branching; an odd tail multiplies zeros) so that the
-            // scheduler can place the next chunk's LDS reads and funnel shifts in the shadow of the current chunk's MFMAs: a wave issues in
-            // order, and 36 back-to-back MFMAs would otherwise keep the VALU idle for their whole 16-cycle latencies.
-            fetch(0, aH, aL, std::true_type{});
+            // Straight-line two-chunk body (the (row, chunk) of the next fetch advances with scalar compares and stops at the last chunk instead of branching; an odd
+            // tail multiplies zeros) so that the scheduler can place the next chunk's LDS reads in the shadow of the current chunk's MFMAs: a wave issues in order, and
+            // 36 back-to-back MFMAs would otherwise keep the LDS pipe idle for their whole latencies.  An operand address is a select and a v_xad_u32.
+            int  fr = 0, fc = 0; // the chunk the next fetch reads
+            auto advance = [&]() {
+                if (fc + 1 < nch) fc++;
+                else if (fr + 1 < nrow) { fc = 0; fr++; }
+            };
+            fetch(0, 0, aH, aL, std::true_type{});
+            advance();
             for (int it = 0; it < nit; it += 2) {
-                const int i1 = it + 1 < nit ? it + 1 : nit - 1, i2 = it + 2 < nit ? it + 2 : nit - 1;
-                fetch(i1, bH, bL, std::true_type{});
+                fetch(fr, fc, bH, bL, std::true_type{});
+                advance();
                 if (it + 1 >= nit) {
 #pragma unroll
                     for (int g = 0; g < NG; g++) { bH[g] = i32x4{0, 0, 0, 0}; bL[g] = i32x4{0, 0, 0, 0}; }
                 }
                 multiply(aH, aL);
-                fetch(i2, aH, aL, std::true_type{});
+                fetch(fr, fc, aH, aL, std::true_type{});
+                advance();
                 multiply(bH, bL);
 #pragma unroll
-                for (int k = 0; k < 2 * NMFMA; k++) {
+                for (int k = 0; k < 2 * NMFMA; k += 4) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); // four MFMAs
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one LDS read (eight 16-byte reads per chunk against 36 MFMAs)
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); // one VALU (addresses, the last group's mask)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one LDS read (sixteen 16-byte reads per chunk pair against 72 MFMAs)
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); // one VALU (an address)
                 }
             }
         } else {
-            for (int it = 0; it < nit; it++) {
-                fetch(it, aH, aL, std::false_type{});
-                multiply(aH, aL);
-            }
+            for (int ri = 0; ri < nrow; ri++)
+                for (int ch = 0; ch < nch; ch++) {
+                    fetch(ri, ch, aH, aL, std::false_type{});
+                    multiply(aH, aL);
+                }
         }
     }
     }
 
+#ifdef SVT_HIP_STATS_CENSUS
+    if (tid == 0) {
+        long long* c = H + (10 + blockIdx.y) * w2;
+        c[0] = (long long)census_t0; c[1] = (long long)wall_clock64();
+        c[2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); c[3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); // HW_ID, XCC_ID
+    }
+#endif
     // ---- merge the four waves in LDS (int32 is still exact: 4 waves x 16384 pixels x 2 x 128 x 127 < 2^31 for the shared cross-term tiles), then one int64 atomic per entry ----
     __syncthreads();
-    int* part = (int*)smem; // [NTILE][64 lanes][4]: HH tiles, LL tiles, X tiles
-    for (int i = tid; i < NTILE * 256; i += 256) part[i] = 0;
+    int* part = (int*)smem; // [NTILE][4 registers][64 lanes] (a wave's atomic touches 64 consecutive banks): HH tiles, LL tiles, X tiles
+    if (wv == 0) { // the first wave stores, the others add: no clearing pass
+#pragma unroll
+        for (int i = 0; i < NTRI; i++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                part[(i * 4 + d) * 64 + l]                = accHH[i][d];
+                part[((NTRI + i) * 4 + d) * 64 + l]       = accLL[i][d];
+                part[((2 * NTRI + i) * 4 + d) * 64 + l]   = accX[i][d];
+            }
+    }
     __syncthreads();
+    if (wv != 0) {
 #pragma unroll
-    for (int i = 0; i < NTRI; i++)
+        for (int i = 0; i < NTRI; i++)
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-            atomicAdd(&part[(i * 64 + l) * 4 + d], accHH[i][d]);
-            atomicAdd(&part[((NTRI + i) * 64 + l) * 4 + d], accLL[i][d]);
-            atomicAdd(&part[((2 * NTRI + i) * 64 + l) * 4 + d], accX[i][d]);
-        }
+            for (int d = 0; d < 4; d++) {
+                atomicAdd(&part[(i * 4 + d) * 64 + l], accHH[i][d]);
+                atomicAdd(&part[((NTRI + i) * 4 + d) * 64 + l], accLL[i][d]);
+                atomicAdd(&part[((2 * NTRI + i) * 4 + d) * 64 + l], accX[i][d]);
+            }
+    }
     __syncthreads();
     // C/D layout of the 16x16 MFMAs: lane = col + 16 * (row >> 2), register = row & 3
     constexpr int ncol = w2 + 1; // taps + source column
-    for (int e = tid; e < ncol * (ncol + 1) / 2; e += 256) {
-        int a = 0, rem = e;
-        while (rem >= ncol - a) { rem -= ncol - a; a++; }
-        const int b = a + rem; // a <= b
-        if (a == w2) continue;  // (source, source) is not an output
+    for (int e = tid; e < ncol * ncol; e += 256) { // (a, b) over the square, the upper triangle kept: a division by a constant instead of a search for the row
+        const int a = e / ncol, b = e - a * ncol;
+        if (b < a || a == w2) continue; // (source, source) is not an output
         const int ga = a >> 4, ra = a & 15, gb = b >> 4, cb = b & 15, rb = b & 15, ca = a & 15;
         const int tri = ga * NG - ga * (ga - 1) / 2 + (gb - ga);
-        const int eab = (cb + 16 * (ra >> 2)) * 4 + (ra & 3), eba = (ca + 16 * (rb >> 2)) * 4 + (rb & 3);
+        const int eab = (ra & 3) * 64 + cb + 16 * (ra >> 2), eba = (rb & 3) * 64 + ca + 16 * (rb >> 2);
         const long long hh = part[tri * 256 + eab], ll = part[(NTRI + tri) * 256 + eab];
         // the cross terms sum_p H_a L_b + L_a H_b: already summed in an off-diagonal tile; entries (a, b) and (b, a) of a diagonal one
         const long long x = (long long)part[(2 * NTRI + tri) * 256 + eab] + (ga == gb ? (long long)part[(2 * NTRI + tri) * 256 + eba] : 0);
@@ -413,7 +479,7 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const int win, cons
     auto            quot = [&](const long long v) { return (v + ((v >> 63) & bias)) >> sh; };
     long long* H = Hout + (size_t)blockIdx.x * 49 * 49;
     long long* M = Mout + (size_t)blockIdx.x * 49;
-    for (int e = threadIdx.x; e < w2 * w2; e += 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < w2 * w2; e += 256 * gridDim.y) {
         const int k = e / w2, l2 = e - k * w2;
         if (k < l2) {
             const long long v = quot(H[e]);
@@ -423,7 +489,8 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const int win, cons
             H[e] = quot(H[e]);
         }
     }
-    for (int k = threadIdx.x; k < w2; k += 256) M[k] = quot(M[k]);
+    if (blockIdx.y == 0)
+        for (int k = threadIdx.x; k < w2; k += 256) M[k] = quot(M[k]);
 }
 
 } // namespace
@@ -443,14 +510,23 @@ void svt_hip_lr_compute_stats_batch_samples(const void* dgd, const void* src, co
     const int rows_per_band = (max_rect_height + SUM_BANDS - 1) / SUM_BANDS > 0 ? (max_rect_height + SUM_BANDS - 1) / SUM_BANDS : 1;
     hipLaunchKernelGGL(stats_sum_kernel, dim3(SUM_BANDS, n), dim3(256), 0, st, dgd, rects, dgd_stride, is16, w2, rows_per_band, (long long*)M, (long long*)H);
     SVT_LAUNCH_CHECK();
-    const dim3 grid((max_rect_width + TC - 1) / TC, (max_rect_height + TR * BANDS - 1) / (TR * BANDS), n);
+    // Rows per workgroup: 8 nbands.  More bands per workgroup = fewer merges (120 LDS atomics per lane + 1 275 int64 atomics per workgroup), fewer = shorter workgroups.
+    // The launch should be many times the 512 resident workgroups of the chip: with one wave of 510 64-row workgroups (a 4K plane) the dispatcher left a dozen CUs
+    // with three and some with one, and the kernel took two workgroup lifetimes (gpurun_out/r06_call9/census.txt).
+    static const int env_bands = [] { const char* e = getenv("SVT_HIP_STATS_BANDS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= BANDS ? v : 0; }(); // (A/B measurement)
+    int nbands = env_bands ? env_bands : BANDS;
+    if (!env_bands) {
+        const long long wg8 = (long long)((max_rect_width + TC - 1) / TC) * ((max_rect_height + TR * BANDS - 1) / (TR * BANDS)) * n;
+        nbands = wg8 >= 4096 ? 8 : (wg8 >= 256 ? 4 : 2); // (a 4K plane, 120 units: 85 us at 4, 93 at 2, 97 at 8: gpurun_out/r06_call12)
+    }
+    const dim3 grid((max_rect_width + TC - 1) / TC, (max_rect_height + TR * nbands - 1) / (TR * nbands), n);
     if (grid.x && grid.y) {
         auto go = [&](auto win_tag, auto is16_tag) {
             constexpr int  WIN = decltype(win_tag)::value;
             constexpr bool IS16 = decltype(is16_tag)::value;
             constexpr int  NG = (WIN * WIN + 1 + 15) / 16, merge = 3 * (NG * (NG + 1) / 2) * 256 * 4; // the final merge reuses the tile's LDS
             const size_t   shmem = (size_t)(merge > lds_bytes<WIN>() ? merge : lds_bytes<WIN>()) + 64;
-            hipLaunchKernelGGL((stats_mfma_kernel<WIN, IS16>), grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, (long long*)M, (long long*)H);
+            hipLaunchKernelGGL((stats_mfma_kernel<WIN, IS16>), grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, (long long*)M, (long long*)H, nbands);
         };
         auto by_depth = [&](auto win_tag) { is16 ? go(win_tag, std::true_type{}) : go(win_tag, std::false_type{}); };
         if (wiener_win == 7) by_depth(std::integral_constant<int, 7>{});
@@ -458,7 +534,9 @@ void svt_hip_lr_compute_stats_batch_samples(const void* dgd, const void* src, co
         else by_depth(std::integral_constant<int, 3>{}); // WIENER_WIN_3TAP (restoration_pick.c:1289)
         SVT_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(n), dim3(256), 0, st, wiener_win, bit_depth, (long long*)M, (long long*)H);
+#ifndef SVT_HIP_STATS_CENSUS
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(n, 4), dim3(256), 0, st, wiener_win, bit_depth, (long long*)M, (long long*)H);
+#endif
     SVT_LAUNCH_CHECK();
 }
 

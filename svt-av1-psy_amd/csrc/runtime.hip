@@ -161,6 +161,7 @@ static void stream_set_free(ThreadStreams* set) { // the device of the set is cu
         if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : set->ev)
         if (e) (void)hipEventDestroy(e);
+    if (set->pinned) (void)hipHostFree(set->pinned);
     delete set;
 }
 static void stream_pool_free_all() { // svt_hip_shutdown
@@ -189,6 +190,7 @@ StreamSetLease::StreamSetLease() {
             HIP_CHECK(hipStreamCreateWithFlags(&set->st[1], hipStreamNonBlocking));
             if (hipStreamCreateWithPriority(&set->st[2], hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); HIP_CHECK(hipStreamCreateWithFlags(&set->st[2], hipStreamNonBlocking)); }
             for (hipEvent_t& e : set->ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_CHECK(hipHostMalloc((void**)&set->pinned, 64 * sizeof(int32_t), hipHostMallocDefault));
         } catch (...) { // a half-built set is taken apart again (a constructor that throws runs no destructor)
             stream_set_free(set);
             set = nullptr;

@@ -124,7 +124,7 @@ struct HostCall {
     void touch();
 };
 HostCall& host_call();
-struct ThreadStreams { hipStream_t st[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev[6] = {}; }; // st[2]: highest priority
+struct ThreadStreams { hipStream_t st[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev[6] = {}; int32_t* pinned = nullptr; }; // st[2]: highest priority; pinned: 64 page-locked host words (read-backs that must not stall the enqueueing thread)
 struct StreamSetLease { // a pooled set of side streams + events on the calling thread's device, for the duration of one stage call (runtime.hip)
     ThreadStreams* set;
     int            device;
