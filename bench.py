@@ -1589,7 +1589,8 @@ def main():
 
     if a.probe:
         sink = torch.zeros(4, dtype=torch.int32, device="cuda")
-        names = ["v_sad_u8", "v_qsad_pk_u16_u8", "v_add+v_xor", "v_mul_lo_u32(+add)", "v_mad_i64_i32", "v_alignbyte_b32"]
+        names = ["v_sad_u8", "v_qsad_pk_u16_u8", "v_add+v_xor", "v_mul_lo_u32(+add)", "v_mad_i64_i32", "v_alignbyte_b32",
+                 "mix: 6 qsad + 2 x (3 alignbyte + 4 sad_u8)", "mix: 4 qsad + 4 x (3 alignbyte + 4 sad_u8)", "mix: 8 x (3 alignbyte + 4 sad_u8)"]  # (6-8: the same 128 abs-diff lanes per round as 8 qsads)
         blocks, iters = 256 * 8, 4096
         for k, nm in enumerate(names):
             fn = lambda: lib.svt_hip_rate_probe(k, iters, blocks, sink.data_ptr(), stream)  # noqa: E731

@@ -551,6 +551,23 @@ template <int KIND> __global__ __launch_bounds__(256) void svt_hip_rate_kernel(u
             if (KIND == 3) a[i] = a[i] * k + 1u;
             if (KIND == 4) w[i] = (uint64_t)((int64_t)(int32_t)a[i] * (int64_t)(int32_t)k + (int64_t)w[i]);
             if (KIND == 5) a[i] = __builtin_amdgcn_alignbyte(a[i], k, a[i]);
+            // KIND 6 / 7 / 8 ("hybrid SAD issue"): the same 16 absolute differences per chain and round as one v_qsad_pk_u16_u8 -- four byte
+            // positions x four bytes -- with 2 / 4 / 8 of the eight chains computed by v_sad_u8 on funnel-shifted operands instead (3 v_alignbyte_b32 + 4 v_sad_u8;
+            // the 32-bit sums are NOT repacked into the u16 lanes the search's reductions want, so the mix is priced optimistically).  If a mix is not faster than
+            // KIND 1 here, no split of the search's SAD work between the two opcodes can be.
+            if (KIND >= 6) {
+                const int nsad = KIND == 6 ? 2 : (KIND == 7 ? 4 : 8);
+                if (i >= 8 - nsad) {
+                    uint32_t lo = (uint32_t)w[i], hi = (uint32_t)(w[i] >> 32);
+                    SVT_HIP_OPAQUE_I32(lo); // (the operands of a search step come from the window ring: not loop invariant)
+                    a[i] = __builtin_amdgcn_sad_u8(lo, k, a[i]);
+                    a[i] = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, 1u), k, a[i]);
+                    a[i] = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, 2u), k, a[i]);
+                    a[i] = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, 3u), k, a[i]);
+                } else {
+                    w[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[i], k, w[i]);
+                }
+            }
         }
     }
     uint32_t r = 0;
@@ -663,7 +680,10 @@ void svt_hip_rate_probe(int kind, uint32_t iters, uint32_t blocks, uint32_t* sin
     case 2: hipLaunchKernelGGL(svt_hip_rate_kernel<2>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
     case 3: hipLaunchKernelGGL(svt_hip_rate_kernel<3>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
     case 4: hipLaunchKernelGGL(svt_hip_rate_kernel<4>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
-    default: hipLaunchKernelGGL(svt_hip_rate_kernel<5>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
+    case 5: hipLaunchKernelGGL(svt_hip_rate_kernel<5>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
+    case 6: hipLaunchKernelGGL(svt_hip_rate_kernel<6>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
+    case 7: hipLaunchKernelGGL(svt_hip_rate_kernel<7>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
+    default: hipLaunchKernelGGL(svt_hip_rate_kernel<8>, dim3(blocks), dim3(256), 0, st, iters, sink); break;
     }
     SVT_LAUNCH_CHECK();
 }
