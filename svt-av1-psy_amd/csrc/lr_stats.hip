@@ -47,7 +47,7 @@ template <int WIN> struct CopyLayout {
     static constexpr int DP = 4 * KP;                                 // one digit
 };
 constexpr int ZERO_BYTES = 64;        // four zero cells: what the padding columns of the last operand group read
-template <int WIN> constexpr int lds_bytes() { return 2 * STAGE_PLANE + 2 * CopyLayout<WIN>::DP + 2 * SRC_PLANE + ZERO_BYTES; }
+template <int WIN> constexpr int lds_bytes() { return 2 * STAGE_PLANE + 2 * CopyLayout<WIN>::DP + 4 * SRC_PLANE + ZERO_BYTES; } // (two sets of source planes: see the band loop)
 
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
@@ -204,25 +204,29 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     uint8_t* planes = stage + 2 * STAGE_PLANE;
     constexpr int LO = L::DP, SRC_HI = 2 * L::DP, SRC_LO = SRC_HI + SRC_PLANE;
     const int        tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
-    const int        unit = blockIdx.z;
+    const int        unit = blockIdx.y, bgroup = blockIdx.z; // band groups are the SLOWEST grid dimension: the empty workgroups of short units sit at the end of the dispatch
     const SvtHipRect R = rects[unit];
     constexpr int w2 = win * win, hw = win >> 1;
     const int W = R.h_end - R.h_start, Hh = R.v_end - R.v_start;
-    const int c0 = blockIdx.x * TC, rb0 = blockIdx.y * TR * nbands; // origin of the workgroup's band group (nbands tiles of 8 rows, <= BANDS) inside the unit
+    const int c0 = blockIdx.x * TC, rb0 = bgroup * TR * nbands; // origin of the workgroup's band group (nbands tiles of 8 rows, <= BANDS) inside the unit
     if (c0 >= W || rb0 >= Hh) return;
     const int tw = W - c0 < TC ? W - c0 : TC;
     long long* H = Hout + (size_t)unit * 49 * 49;
     long long* M = Mout + (size_t)unit * 49;
-#ifdef SVT_HIP_STATS_CENSUS // (measurement build only, tools/stats_census.py: when and where each workgroup ran; the finalize launch is skipped, the results are not usable)
+#ifdef SVT_HIP_STATS_CENSUS // (measurement build only, tools/stats_census.py: when and where each workgroup ran, and thread 0's time per phase; the finalize launch is skipped, the results are not usable)
     const unsigned long long census_t0 = wall_clock64();
+    long long census_ph[6] = {0, 0, 0, 0, 0, 0}, census_c = clock64(); // prologue, top barrier + digits, copies, prefetch issue, K loop, merge
+#define CENSUS_PHASE(k) { const long long now_ = clock64(); census_ph[k] += now_ - census_c; census_c = now_; }
+#else
+#define CENSUS_PHASE(k)
 #endif
 
     // ---- per-lane operand addressing: group g -> tap t = 16 g + (l & 15); kg = l >> 4 selects pixels 16 kg .. 16 kg + 15 of a chunk ----
     // A wave owns tile rows 2 wv and 2 wv + 1.  Operand of (row 2 wv + ri, chunk ch) = the 16-byte cell (see CopyLayout) at  obase[g] + ri * ostep + ((16 ch) ^ oswz[g][ri])
     // -- one v_xad_u32 per operand in the K loop; hi and lo digit of a cell differ by a constant (the ds_read offset field).  The last group also holds the source
     // column (its own [kg][row][chunk] planes, no swizzle) and padding columns, which read the zero cells: no masks.
-    constexpr int ZERO = SRC_LO + SRC_PLANE;
-    int obase[NG], oswz[NG][2], last_step = 64 * L::A, last_lo = LO;
+    constexpr int SRC_SET = 2 * SRC_PLANE, ZERO = SRC_HI + 2 * SRC_SET; // source planes of even tiles | of odd tiles | zero cells
+    int obase[NG], oswz[NG][2], last_step = 64 * L::A, last_lo = LO, src_flip = 0; // src_flip: the source-column lanes alternate between the two sets of source planes
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const int t = 16 * g + (l & 15), kg = l >> 4;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
             oswz[g][0] = 16 * ((Rr >> 2) & 3);
             oswz[g][1] = 16 * (((Rr + L::A) >> 2) & 3);
         } else if (t == w2) { // the source column
-            obase[g] = SRC_HI + kg * (TR * 64) + 64 * 2 * wv; oswz[g][0] = oswz[g][1] = 0; last_step = 64; last_lo = SRC_PLANE;
+            obase[g] = SRC_HI + kg * (TR * 64) + 64 * 2 * wv; oswz[g][0] = oswz[g][1] = 0; last_step = 64; last_lo = SRC_PLANE; src_flip = SRC_SET;
         } else { // padding
             obase[g] = ZERO; oswz[g][0] = oswz[g][1] = 0; last_step = 0; last_lo = 0;
         }
@@ -271,11 +275,15 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
     for (int b = 0; b < SUM_BANDS; b++) total += (unsigned long long)H[sum_slot(b, w2)];
     const int avg = (int)(total / (unsigned long long)((long long)W * Hh));
 
+    CENSUS_PHASE(0)
     for (int band = 0; band < nbands; band++) {
     const int r0 = rb0 + band * TR;
     if (r0 >= Hh) break;
     const int th = Hh - r0 < TR ? Hh - r0 : TR;
-    if (band) __syncthreads(); // everyone is done reading the previous tile
+    // Two barriers per tile: what a wave writes ahead of the first one -- the staging rows and THIS tile's set of source planes -- is not read by the waves still in the
+    // previous tile's matrix loop (they read the displacement copies and the other set of source planes), so the digit extraction overlaps their tail; the first barrier
+    // then says both "the staging rows are complete" and "everyone is done with the previous tile's copies".
+    const int src_set = (band & 1) * SRC_SET;
     int btid = tid; // (re-defined per tile: the staging / copy addresses derived from it are loop invariant and would be hoisted out of the band loop -- into scratch, 480 B)
     SVT_HIP_OPAQUE_I32(btid);
     // ---- the digit planes of the tile from the loaded quads ----
@@ -297,10 +305,11 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
         uint32_t xh, xl;
         raws[k].digits(q, avg, xh, xl);
         const int cell = ((s >> 2) & 3) * (TR * 64) + r * 64 + (s >> 4) * 16 + (s & 3) * 4;
-        *(uint32_t*)(planes + SRC_HI + cell) = xh;
-        *(uint32_t*)(planes + SRC_LO + cell) = xl;
+        *(uint32_t*)(planes + SRC_HI + src_set + cell) = xh;
+        *(uint32_t*)(planes + SRC_LO + src_set + cell) = xl;
     }
     __syncthreads();
+    CENSUS_PHASE(1)
     {   // ---- the displacement copies, one 16-byte cell (plane row r, chunk ch, quarter kg: columns c = 64 ch + 16 kg .. c + 15) per thread: copy dx of the cell = staging
         // bytes r * PP + 4 + c + dx .. + 15, i.e. six staging dwords funnel-shifted by dx; hi and lo digit share the address.  Item -> (ch, r & 1, kg, r >> 1): the eight
         // lanes a ds_write_b128 serves together then hit the eight different 16-byte slots of the 128-byte bank row.
@@ -332,7 +341,9 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
         }
     }
     __syncthreads();
+    CENSUS_PHASE(2)
     if (band + 1 < nbands && r0 + TR < Hh) issue(r0 + TR, Hh - (r0 + TR) < TR ? Hh - (r0 + TR) : TR, btid); // the next tile's loads fly while the matrix pipe works on this one
+    CENSUS_PHASE(3)
     {   // this wave's chunks of the tile: rows 2 wv, 2 wv + 1, nch chunks each, flattened; software pipelined: the operands of chunk it + 1
         // are fetched while the matrix pipe works through the 36 (10) MFMAs of chunk it
         const int nch = (tw + 63) >> 6;
@@ -344,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 const bool  last = g == NG - 1;
-                const int   a = obase[g] + ri * (last ? last_step : 64 * L::A) + ((16 * ch) ^ (ri ? oswz[g][1] : oswz[g][0]));
+                const int   a = obase[g] + (last && (band & 1) ? src_flip : 0) + ri * (last ? last_step : 64 * L::A) + ((16 * ch) ^ (ri ? oswz[g][1] : oswz[g][0]));
                 const i32x4 vh = *(const i32x4*)(planes + a), vl = *(const i32x4*)(planes + a + (last ? last_lo : LO));
                 if (FULL) { // whole chunk: the LDS words ARE the operands
                     oH[g] = vh;
@@ -420,37 +431,33 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
                 }
         }
     }
+    CENSUS_PHASE(4)
     }
 
-#ifdef SVT_HIP_STATS_CENSUS
-    if (tid == 0) {
-        long long* c = H + (10 + blockIdx.y) * w2;
-        c[0] = (long long)census_t0; c[1] = (long long)wall_clock64();
-        c[2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); c[3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); // HW_ID, XCC_ID
-    }
-#endif
-    // ---- merge the four waves in LDS (int32 is still exact: 4 waves x 16384 pixels x 2 x 128 x 127 < 2^31 for the shared cross-term tiles), then one int64 atomic per entry ----
+    // ---- merge the four waves in LDS (int32 is still exact: 2 waves x 16384 pixels x 2 x 128 x 127 < 2^31 for the shared cross-term tiles of a copy), then one int64 atomic per entry ----
     __syncthreads();
     int* part = (int*)smem; // [NTILE][4 registers][64 lanes] (a wave's atomic touches 64 consecutive banks): HH tiles, LL tiles, X tiles
-    if (wv == 0) { // the first wave stores, the others add: no clearing pass
+    // two copies: waves 0 and 1 store theirs, waves 2 and 3 add theirs on top (LDS atomics of two waves in a row instead of three), the read-out below adds the copies
+    int* mine = part + (wv & 1) * (NTILE * 256);
+    if (wv < 2) {
 #pragma unroll
         for (int i = 0; i < NTRI; i++)
 #pragma unroll
             for (int d = 0; d < 4; d++) {
-                part[(i * 4 + d) * 64 + l]                = accHH[i][d];
-                part[((NTRI + i) * 4 + d) * 64 + l]       = accLL[i][d];
-                part[((2 * NTRI + i) * 4 + d) * 64 + l]   = accX[i][d];
+                mine[(i * 4 + d) * 64 + l]                = accHH[i][d];
+                mine[((NTRI + i) * 4 + d) * 64 + l]       = accLL[i][d];
+                mine[((2 * NTRI + i) * 4 + d) * 64 + l]   = accX[i][d];
             }
     }
     __syncthreads();
-    if (wv != 0) {
+    if (wv >= 2) {
 #pragma unroll
         for (int i = 0; i < NTRI; i++)
 #pragma unroll
             for (int d = 0; d < 4; d++) {
-                atomicAdd(&part[(i * 4 + d) * 64 + l], accHH[i][d]);
-                atomicAdd(&part[((NTRI + i) * 4 + d) * 64 + l], accLL[i][d]);
-                atomicAdd(&part[((2 * NTRI + i) * 4 + d) * 64 + l], accX[i][d]);
+                atomicAdd(&mine[(i * 4 + d) * 64 + l], accHH[i][d]);
+                atomicAdd(&mine[((NTRI + i) * 4 + d) * 64 + l], accLL[i][d]);
+                atomicAdd(&mine[((2 * NTRI + i) * 4 + d) * 64 + l], accX[i][d]);
             }
     }
     __syncthreads();
@@ -462,13 +469,24 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
         const int ga = a >> 4, ra = a & 15, gb = b >> 4, cb = b & 15, rb = b & 15, ca = a & 15;
         const int tri = ga * NG - ga * (ga - 1) / 2 + (gb - ga);
         const int eab = (ra & 3) * 64 + cb + 16 * (ra >> 2), eba = (rb & 3) * 64 + ca + 16 * (rb >> 2);
-        const long long hh = part[tri * 256 + eab], ll = part[(NTRI + tri) * 256 + eab];
+        constexpr int C2 = NTILE * 256; // the second copy
+        const long long hh = (long long)part[tri * 256 + eab] + part[C2 + tri * 256 + eab], ll = (long long)part[(NTRI + tri) * 256 + eab] + part[C2 + (NTRI + tri) * 256 + eab];
         // the cross terms sum_p H_a L_b + L_a H_b: already summed in an off-diagonal tile; entries (a, b) and (b, a) of a diagonal one
-        const long long x = (long long)part[(2 * NTRI + tri) * 256 + eab] + (ga == gb ? (long long)part[(2 * NTRI + tri) * 256 + eba] : 0);
+        const long long x = (long long)part[(2 * NTRI + tri) * 256 + eab] + part[C2 + (2 * NTRI + tri) * 256 + eab] +
+                            (ga == gb ? (long long)part[(2 * NTRI + tri) * 256 + eba] + part[C2 + (2 * NTRI + tri) * 256 + eba] : 0);
         const long long v = 16384 * hh + 128 * x + ll;
         unsigned long long* dst = (unsigned long long*)(b == w2 ? &M[a] : &H[a * w2 + b]);
         atomicAdd(dst, (unsigned long long)v);
     }
+#ifdef SVT_HIP_STATS_CENSUS
+    CENSUS_PHASE(5)
+    if (tid == 0 && bgroup < 30) {
+        long long* c = H + (10 + bgroup) * w2;
+        c[0] = (long long)census_t0; c[1] = (long long)wall_clock64();
+        c[2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); c[3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); // HW_ID, XCC_ID
+        for (int k = 0; k < 6; k++) c[4 + k] = census_ph[k];
+    }
+#endif
 }
 
 // upper triangle / M -> divide as the reference's `/=` (truncation toward zero, restoration_pick.c:733-742), mirror to the lower triangle
@@ -519,12 +537,12 @@ void svt_hip_lr_compute_stats_batch_samples(const void* dgd, const void* src, co
         const long long wg8 = (long long)((max_rect_width + TC - 1) / TC) * ((max_rect_height + TR * BANDS - 1) / (TR * BANDS)) * n;
         nbands = wg8 >= 4096 ? 8 : (wg8 >= 256 ? 4 : 2); // (a 4K plane, 120 units: 85 us at 4, 93 at 2, 97 at 8: gpurun_out/r06_call12)
     }
-    const dim3 grid((max_rect_width + TC - 1) / TC, (max_rect_height + TR * nbands - 1) / (TR * nbands), n);
-    if (grid.x && grid.y) {
+    const dim3 grid((max_rect_width + TC - 1) / TC, n, (max_rect_height + TR * nbands - 1) / (TR * nbands));
+    if (grid.x && grid.z) {
         auto go = [&](auto win_tag, auto is16_tag) {
             constexpr int  WIN = decltype(win_tag)::value;
             constexpr bool IS16 = decltype(is16_tag)::value;
-            constexpr int  NG = (WIN * WIN + 1 + 15) / 16, merge = 3 * (NG * (NG + 1) / 2) * 256 * 4; // the final merge reuses the tile's LDS
+            constexpr int  NG = (WIN * WIN + 1 + 15) / 16, merge = 2 * 3 * (NG * (NG + 1) / 2) * 256 * 4; // the final merge (two copies of the tiles) reuses the tile's LDS
             const size_t   shmem = (size_t)(merge > lds_bytes<WIN>() ? merge : lds_bytes<WIN>()) + 64;
             hipLaunchKernelGGL((stats_mfma_kernel<WIN, IS16>), grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, (long long*)M, (long long*)H, nbands);
         };

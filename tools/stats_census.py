@@ -50,12 +50,18 @@ for _ in range(3):
     lib.svt_hip_lr_compute_stats_batch(d_dgd.data_ptr(), d_src.data_ptr(), d_r.data_ptr(), n, mw, mh, stride, stride, 7, bd, d_M.data_ptr(), d_H.data_ptr(), None)
     torch.cuda.synchronize()
 H = d_H.cpu().numpy().reshape(n, 49, 49)
-wgs = []
+wgs, phases = [], []
 for u in range(n):
-    for y in range(6):
+    for y in range(30):
         t0, t1, hw, xcc = (int(v) for v in H[u, 10 + y, :4])
         if t1 > t0 > 0:
             wgs.append((t0, t1, (xcc & 0xf, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf), u, y))
+            phases.append([int(v) for v in H[u, 10 + y, 4:10]] + [t1 - t0])
+ph = np.array(phases, dtype=np.float64)
+tot = ph[:, :6].sum(axis=1)
+print("thread 0's clock64() ticks per workgroup, mean (share): " + ", ".join("%s %.0f (%.0f %%)" % (nm, ph[:, k].mean(), 100 * ph[:, k].mean() / tot.mean())
+      for k, nm in enumerate(("prologue", "barrier+digits", "copies", "prefetch issue", "K loop", "merge"))))
+print("ticks per workgroup %.0f over %.2f us of the 100 MHz clock -> %.0f MHz" % (tot.mean(), ph[:, 6].mean() / 100.0, tot.mean() / (ph[:, 6].mean() / 100.0)))
 base = min(x[0] for x in wgs)
 print("%d workgroups; first start -> last end %.1f us; mean life %.1f us (min %.1f, max %.1f)" % (
     len(wgs), (max(x[1] for x in wgs) - base) / 100.0, np.mean([x[1] - x[0] for x in wgs]) / 100.0, min(x[1] - x[0] for x in wgs) / 100.0, max(x[1] - x[0] for x in wgs) / 100.0))
