@@ -982,15 +982,19 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     const dim3 tgrid((mw + 63) / 64, (mh + 63) / 64, n);
     hipLaunchKernelGGL(lr_rects_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.rects, W.acc, W.wn, units, n);
     HIP_CHECK(hipMemsetAsync(W.counter, 0, 128, st));
-    // RESTORE_NONE
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<0>), tgrid, dim3(256), LRS_SMEM, st, P, W.rects, W.wn, units, W.acc, (SvtHipLrSearchUnit*)nullptr, (int32_t*)nullptr);
-    hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, st, W.acc, units, 0, n);
-    SVT_LAUNCH_CHECK();
+    // RESTORE_NONE: the unrestored unit's error.  Nothing of the searches depends on it: with the Wiener search on it runs at the head of that chain (same accumulator,
+    // stream order) instead of ahead of the fork, where it held back the self-guided chain -- the longer one of the fast settings -- by its 30 us.
+    auto restore_none = [&](hipStream_t s_) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lr_trial_kernel<0>), tgrid, dim3(256), LRS_SMEM, s_, P, W.rects, W.wn, units, W.acc, (SvtHipLrSearchUnit*)nullptr, (int32_t*)nullptr);
+        hipLaunchKernelGGL(lr_take_sse_kernel, dim3((n + 63) / 64), dim3(64), 0, s_, W.acc, units, 0, n);
+        SVT_LAUNCH_CHECK();
+    };
+    if (!P.wn_enabled) restore_none(st);
     // Three independent launch sequences behind the unit rectangles / the RESTORE_NONE pass, on the calling thread's side streams (fork here, join before returning):
     //   * the self-guided search, group after group of parameter sets (filter launch, projection launch), the groups ALTERNATING between two streams and two sets of
     //     plane buffers: a projection launch ends in a long tail -- one 1 024-thread workgroup per CU, 4 to 12 passes each --, which the other stream's group fills;
-    //   * the Wiener refinement -- tens of short dependent launches with a host read-back every eight steps -- on the highest-priority stream, so that its launches
-    //     are not queued behind the long self-guided workgroups.
+    //   * the Wiener chain -- RESTORE_NONE, statistics, solve, then tens of short dependent refinement launches with a read-back of the number of units still
+    //     searching every few rounds -- on the highest-priority stream, so that its launches are not queued behind the long self-guided workgroups.
     // They write different fields of a unit's record and keep separate accumulators.
     const bool  sg_on = P.sg_enabled && slots > 0;
     svthip::StreamSetLease       ts_lease; // (handed back when the call returns, its work possibly still in flight: see runtime.hip)
@@ -1053,6 +1057,7 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     int rc_wn = 0;
     if (P.wn_enabled) {
         HIP_CHECK(hipStreamWaitEvent(wn_st, ev_fork, 0));
+        restore_none(wn_st);
         svt_hip_lr_compute_stats_batch(P.dgd, P.src, W.rects, (uint32_t)n, mw, mh, (int)P.dgd_stride, (int)P.src_stride, P.wiener_win, P.highbd ? P.bit_depth : 8,
                                        (int64_t*)W.M, (int64_t*)W.H, wn_st);
         hipLaunchKernelGGL(lr_wiener_solve_kernel, dim3(n), dim3(256), 0, wn_st, P, W.M, W.H, prev, W.wn, units);
@@ -1064,7 +1069,7 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
         // Lock-step refinement: a round = one trial launch whose last workgroup per unit consumes the result and proposes the next move.  The number of units still
         // searching comes back every WN_BATCH rounds through a page-locked word, and the NEXT batch is enqueued before the host waits for it: the read-back costs no
         // gap in the stream; the price is one batch of empty launches (every workgroup leaves at once) after the last unit has finished.
-        constexpr int WN_BATCH = 8;
+        constexpr int WN_BATCH = 4; // (an empty launch costs ~5 us; the fast settings need 8 rounds, the full one ~40)
         volatile int32_t* active = TS.pinned;
         hipEvent_t        ev_cnt = TS.ev[5];
         bool              done = false;
