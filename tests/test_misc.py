@@ -99,6 +99,33 @@ def test_misc_oracle_vs_reference(oracle, ref):
             assert np.array_equal(x0, x1), (bd, r0, r1, x0, x1)
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+def test_lr_search_statistics_edge_shapes(be, oracle, bd):
+    """The tile loaders of round 6 (one unaligned load per quad of samples, clamped into the readable range of its row; aligned 16-byte row words + ragged ends in the
+    sum kernel) on the shapes that take their special paths: units 1-3 samples wide (no load window: sample by sample), a sliver right of a 256-column tile boundary,
+    single rows, odd origins (every alignment of a row start), and a picture allocated with exactly the halo the reference reads (win / 2 samples) around the unit --
+    one sample more read anywhere is an out-of-bounds access the sanitizer build of the emulator reports (tools/sanitizer_emulator.sh)."""
+    g = rng(70 + bd)
+    dt = np.uint16 if bd > 8 else np.uint8
+    shapes = [(1, 1), (2, 5), (3, 9), (5, 1), (17, 3)] + ([(257, 9), (259, 17), (64, 70)] if be.is_gpu else [(33, 10)])
+    for win in ((7, 5, 3) if be.is_gpu else ((3, 7) if bd == 8 else (5,))):
+        hw = win >> 1
+        for (W, H) in shapes:
+            for ox in ((0, 1, 3) if be.is_gpu else (1,)):  # extra columns left of the halo: moves every row start through the alignments
+                S, Hh = W + 2 * hw + ox, H + 2 * hw
+                dgd = g.integers(0, 1 << bd, (Hh, S)).astype(dt)
+                src = np.clip(dgd.astype(np.int32) + g.integers(-9, 10, dgd.shape), 0, (1 << bd) - 1).astype(dt)
+                rect_list = [(hw + ox, hw + ox + W, hw, hw + H)]
+                rects = np.array(rect_list, np.int32).view(be.pkg.Rect).reshape(-1)
+                dd, ds, dr = be.dev(dgd), be.dev(src), be.dev(rects)
+                M, Hm = be.empty((1, 49), np.int64), be.empty((1, 49 * 49), np.int64)
+                be.lib.svt_hip_lr_compute_stats_batch(be.ptr(dd), be.ptr(ds), be.ptr(dr), 1, W, H, S, S, win, bd, be.ptr(M), be.ptr(Hm), be.stream)
+                gM, gH = be.host(M), be.host(Hm)
+                M0, H0 = np.zeros(49, np.int64), np.zeros(49 * 49, np.int64)
+                oracle.oracle_compute_stats(win, p(dgd), p(src), hw + ox, hw + ox + W, hw, hw + H, S, S, p(M0), p(H0), bd)
+                assert np.array_equal(gM[0][:win * win], M0[:win * win]) and np.array_equal(gH[0][:win ** 4], H0[:win ** 4]), (bd, win, W, H, ox)
+
+
 @pytest.mark.parametrize("bd", [8, 10, 12])
 def test_lr_search_statistics(be, oracle, bd):
     if not be.is_gpu and bd == 12:

@@ -1,4 +1,4 @@
-bash tools/gpu_regression.sh r06_final2
-cd ${GRAFT_REPO_ROOT:-.}
-O=gpurun_out/r06_final2
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-.}
+ulimit -c 0
+O=gpurun_out/r06_call22; mkdir -p $O
+timeout 900 python -m pytest tests/test_misc.py -q -m gpu > $O/pytest_misc.txt 2>&1; tail -3 $O/pytest_misc.txt
