@@ -191,7 +191,7 @@ template <> struct RawQuad<false> {
 // group but the last is known to hold taps only (16 (NG - 1) <= WIN^2), so only the last group keeps per-lane plane / pitch / mask registers.
 template <int WIN, bool IS16>
 __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, const void* src, const SvtHipRect* rects, const int dgd_stride, const int src_stride,
-                                                         long long* Mout, long long* Hout, const int nbands, const int prio) {
+                                                         long long* Mout, long long* Hout, const int nbands) {
     using L = CopyLayout<WIN>;
     constexpr int win = WIN, NG = (WIN * WIN + 1 + 15) / 16;
     static_assert(16 * (NG - 1) <= WIN * WIN, "only the last group may hold the source column or padding");
@@ -394,7 +394,6 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
         };
         i32x4 aH[NG], aL[NG], bH[NG], bL[NG];
         const int nit = nrow * nch;
-        if (prio) __builtin_amdgcn_s_setprio(2); // (A/B, SVT_HIP_STATS_PRIO: the matrix loop ahead of the other workgroup's staging arithmetic on the same SIMD)
         if ((tw & 63) == 0 && nit > 0) {
             // Straight-line two-chunk body (the (row, chunk) of the next fetch advances with scalar compares and stops at the last chunk instead of branching; an odd
             // tail multiplies zeros) so that the scheduler can place the next chunk's LDS reads in the shadow of the current chunk's MFMAs: a wave issues in order, and
@@ -432,7 +431,6 @@ __global__ __launch_bounds__(256, 2) void stats_mfma_kernel(const void* dgd, con
                 }
         }
     }
-    if (prio) __builtin_amdgcn_s_setprio(0);
     CENSUS_PHASE(4)
     }
 
@@ -534,7 +532,6 @@ void svt_hip_lr_compute_stats_batch_samples(const void* dgd, const void* src, co
     // The launch should be many times the 512 resident workgroups of the chip: with one wave of 510 64-row workgroups (a 4K plane) the dispatcher left a dozen CUs
     // with three and some with one, and the kernel took two workgroup lifetimes (gpurun_out/r06_call9/census.txt).
     static const int env_bands = [] { const char* e = getenv("SVT_HIP_STATS_BANDS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= BANDS ? v : 0; }(); // (A/B measurement)
-    static const int env_prio = [] { const char* e = getenv("SVT_HIP_STATS_PRIO"); return e ? atoi(e) : 0; }(); // (A/B measurement)
     int nbands = env_bands ? env_bands : BANDS;
     if (!env_bands) {
         const long long wg8 = (long long)((max_rect_width + TC - 1) / TC) * ((max_rect_height + TR * BANDS - 1) / (TR * BANDS)) * n;
@@ -547,7 +544,7 @@ void svt_hip_lr_compute_stats_batch_samples(const void* dgd, const void* src, co
             constexpr bool IS16 = decltype(is16_tag)::value;
             constexpr int  NG = (WIN * WIN + 1 + 15) / 16, merge = 2 * 3 * (NG * (NG + 1) / 2) * 256 * 4; // the final merge (two copies of the tiles) reuses the tile's LDS
             const size_t   shmem = (size_t)(merge > lds_bytes<WIN>() ? merge : lds_bytes<WIN>()) + 64;
-            hipLaunchKernelGGL((stats_mfma_kernel<WIN, IS16>), grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, (long long*)M, (long long*)H, nbands, env_prio);
+            hipLaunchKernelGGL((stats_mfma_kernel<WIN, IS16>), grid, dim3(256), shmem, st, dgd, src, rects, dgd_stride, src_stride, (long long*)M, (long long*)H, nbands);
         };
         auto by_depth = [&](auto win_tag) { is16 ? go(win_tag, std::true_type{}) : go(win_tag, std::false_type{}); };
         if (wiener_win == 7) by_depth(std::integral_constant<int, 7>{});
