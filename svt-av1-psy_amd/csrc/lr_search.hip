@@ -457,12 +457,12 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
     long long acc[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) acc[k] = 0;
+    // acc[0..4]: the whole tile's sums; acc[5..9]: the share of the rows that belong to the next unit row (a branch only tiles across a unit-row boundary take).  Every
+    // factor fits 32 bits, so a term is one v_mad_i64_i32 into its 64-bit sum (the per-term 64-bit selects between two sets of sums cost eight times that).
     auto add_sums = [&](const int r, const int d, const int sp, const int32_t f0v, const int32_t f1v) {
-        const long long q1 = p0 ? f0v - (d << 4) : 0, q2 = p1 ? f1v - (d << 4) : 0, sd = (long long)(sp - d) * 16;
-        const long long t[5] = {q1 * q1, q2 * q2, q1 * q2, q1 * sd, q2 * sd};
-        const bool      hi = r >= y_split;
-#pragma unroll
-        for (int k = 0; k < 5; k++) { acc[k] += hi ? 0 : t[k]; acc[5 + k] += hi ? t[k] : 0; } // (selects, not a run-time index: the sums stay in registers)
+        const int q1 = p0 ? f0v - (d << 4) : 0, q2 = p1 ? f1v - (d << 4) : 0, sd = (sp - d) * 16;
+        acc[0] += (long long)q1 * q1; acc[1] += (long long)q2 * q2; acc[2] += (long long)q1 * q2; acc[3] += (long long)q1 * sd; acc[4] += (long long)q2 * sd;
+        if (r >= y_split) { acc[5] += (long long)q1 * q1; acc[6] += (long long)q2 * q2; acc[7] += (long long)q1 * q2; acc[8] += (long long)q1 * sd; acc[9] += (long long)q2 * sd; }
     };
     stage_tile<(TH + 15) / 16>(tile, s, tid);
     __syncthreads();
@@ -474,15 +474,25 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
                  [&](int r, int c, int32_t f0a, int32_t f1a, int32_t f0b, int32_t f1b, bool has1) {
                      const size_t o = (size_t)(y0 + r) * w + x0 + c;
                      const int    da = tile[(r + 3) * TW + c + 3], db = tile[(r + 3) * TW + c + 4];
-                     q[o] = (uint32_t)((p0 ? f0a - (da << 4) : 0) & 0xffff) | ((uint32_t)(p1 ? f1a - (da << 4) : 0) << 16);
-                     if (has1) q[o + 1] = (uint32_t)((p0 ? f0b - (db << 4) : 0) & 0xffff) | ((uint32_t)(p1 ? f1b - (db << 4) : 0) << 16);
-                     const size_t so = (size_t)(y0 + r) * P.src_stride + x0 + c;
-                     const int    sa = rd_px(P.src, highbd, so), sb = has1 ? rd_px(P.src, highbd, so + 1) : 0;
-                     add_sums(r, da, sa, f0a, f1a);
-                     if (has1) add_sums(r, db, sb, f0b, f1b);
-                     if (slot0 + slot == 0) { // (shared by every set and group: written once)
-                         dq[o] = (int16_t)(da - sa);
-                         if (has1) dq[o + 1] = (int16_t)(db - sb);
+                     const uint32_t qa = (uint32_t)((p0 ? f0a - (da << 4) : 0) & 0xffff) | ((uint32_t)(p1 ? f1a - (da << 4) : 0) << 16);
+                     const size_t   so = (size_t)(y0 + r) * P.src_stride + x0 + c;
+                     if (has1) { // the pair as one access each: an 8-byte store of the two packed samples, one load of the two source samples, one 4-byte store of the two differences
+                         const uint32_t qb = (uint32_t)((p0 ? f0b - (db << 4) : 0) & 0xffff) | ((uint32_t)(p1 ? f1b - (db << 4) : 0) << 16);
+                         *(LrDw2*)(q + o) = LrDw2{qa, qb};
+                         int sa, sb;
+                         if (highbd) { uint32_t v; __builtin_memcpy(&v, (const uint16_t*)P.src + so, 4); sa = (int)(v & 0xffffu); sb = (int)(v >> 16); }
+                         else { uint16_t v; __builtin_memcpy(&v, (const uint8_t*)P.src + so, 2); sa = v & 0xff; sb = v >> 8; }
+                         add_sums(r, da, sa, f0a, f1a);
+                         add_sums(r, db, sb, f0b, f1b);
+                         if (slot0 + slot == 0) { // (shared by every set and group: written once)
+                             const uint32_t dd = (uint32_t)((da - sa) & 0xffff) | ((uint32_t)(db - sb) << 16);
+                             __builtin_memcpy(dq + o, &dd, 4);
+                         }
+                     } else {
+                         q[o] = qa;
+                         const int sa = rd_px(P.src, highbd, so);
+                         add_sums(r, da, sa, f0a, f1a);
+                         if (slot0 + slot == 0) dq[o] = (int16_t)(da - sa);
                      }
                  });
     } else {
@@ -500,6 +510,8 @@ __global__ __launch_bounds__(256) void lr_sgr_flt_kernel(const SvtHipLrSearchPar
     // workgroup sums -> the units' accumulators
     if (!sums) return; // (workgroup-uniform)
     const bool two = y_split < s.uh;
+#pragma unroll
+    for (int k = 0; k < 5; k++) acc[k] -= acc[5 + k]; // whole tile -> the rows of the upper unit row
 #pragma unroll
     for (int k = 0; k < 10; k++) {
         if (k >= 5 && !two) break;
