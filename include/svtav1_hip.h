@@ -999,8 +999,8 @@ typedef struct SvtHipLrPrevUnit { /* wn_filter_ctrls.use_prev_frame_coeffs (:129
     int16_t vfilter[8], hfilter[8];
 } SvtHipLrPrevUnit;
 size_t svt_hip_lr_search_workspace(const SvtHipLrSearchParams *params); /* bytes (includes 8 B per sample and self-guided parameter set searched) */
-/* prev: device, [units] or NULL.  Synchronises `stream` internally (the lock-step Wiener refinement reads the number of units still searching back every
- * eight steps).  Returns 0, -1 for parameters outside the reference's ranges, or -2 when the lock-step Wiener refinement hit its 4096-step cap with units
+/* prev: device, [units] or NULL.  Waits on the device internally (the lock-step Wiener refinement reads the number of units still searching back every
+ * few rounds, through an event on its own side stream).  Returns 0, -1 for parameters outside the reference's ranges, or -2 when the lock-step Wiener refinement hit its 4096-step cap with units
  * still searching (results of the plane must then not be used; the reference's own loops are bounded far below that).  sse[1] / sse[2] of a tool that is
  * disabled (wn_enabled / sg_enabled == 0) are 0 and carry no meaning: callers read them only for enabled tools (as integration/rest_process_seam.c does). */
 int svt_hip_lr_search_plane(const SvtHipLrSearchParams *params, const SvtHipLrPrevUnit *prev, SvtHipLrSearchUnit *units, void *workspace, void *stream);
