@@ -1108,17 +1108,18 @@ def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
         lib.svt_hip_tpl_recon_stage(C.addressof(R), d_pl.data_ptr(), d_pl.data_ptr(), d_src.data_ptr(), d_rec.data_ptr(), d_out.data_ptr(), stream)
     import os
     forms = {}
-    # 5 = the default: ONE launch, every block in flight, DC blocks wait for the cells above / left of them, release / acquire fences; 4 = 5 with sequentially-consistent fences; 0 = one launch per
+    # 7 = the default: ONE launch, every block in flight, DC blocks wait for the cells above / left of them, write-through stores + drained flag on the producer's side, one acquire on the
+    # consumer's; 5 = release / acquire fences (round 4's default); 6 = 5 polling with loads; 4 = 5 with sequentially-consistent fences; 0 = one launch per
     # anti-diagonal; 1 = the row wavefront in one launch; 2 = 1 with the rows given to the XCDs in contiguous chunks; 3 = 1 with release / acquire fences.  All are kept
     # for the checker.
-    for form in (4, 3, 2, 1, 0, 6, 5):
+    for form in (4, 3, 2, 1, 0, 6, 5, 7):
         os.environ["SVT_HIP_TPL_RECON_FORM"] = str(form)
         t = _time(torch, run, steps, warmup, batches=3)
         out = d_out.cpu().numpy().view(pkg.TplReconStats)
         forms[form] = (t, d_rec.cpu().numpy().reshape(rows, stride), out.copy())
     os.environ.pop("SVT_HIP_TPL_RECON_FORM", None)
     n_blk = int(out["written"].sum())
-    keep.update(R=R, recon=forms[5][1], recon_out=forms[5][2], recon_forms={f: (v[1], v[2]) for f, v in forms.items()}, recon_stride=stride)
+    keep.update(R=R, recon=forms[7][1], recon_out=forms[7][2], recon_forms={f: (v[1], v[2]) for f, v in forms.items()}, recon_stride=stride)
     cols16, rows16 = (P.aligned_width + 15) // 16, (((P.height + 7) & ~7) + 15) // 16
     alg = n_blk * (3 * 256 + 80)  # per block: source, prediction (reference or neighbours), reconstruction, the two statistics records
     n_dc = int(np.sum((src["best_mode"] == 0) & (src["written"] > 0)))
@@ -1159,7 +1160,7 @@ def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
         for _ in range(10):
             fused()
         t_fused = (_t.perf_counter() - t0) / 10
-    fused_ok = all(np.array_equal(h_out[f], forms[5][2][f]) for f in ("srcrf_dist", "recrf_dist", "written", "coded")) and np.array_equal(h_src["srcrf_dist"], src["srcrf_dist"])
+    fused_ok = all(np.array_equal(h_out[f], forms[7][2][f]) for f in ("srcrf_dist", "recrf_dist", "written", "coded")) and np.array_equal(h_src["srcrf_dist"], src["srcrf_dist"])
     if not fused_ok:
         raise SystemExit("bench: svt_hip_tpl_stage_host differs from the two device stages -- no numbers recorded")
     # the same with the planes RESIDENT across calls (svt_hip_tpl_stage_host_resident, what the seam calls): every call brings a new source picture and makes a new
@@ -1188,7 +1189,7 @@ def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
         for _ in range(10):
             resident()
         t_res = (_t.perf_counter() - t0) / 10
-    if not all(np.array_equal(h_out[f], forms[5][2][f]) for f in ("srcrf_dist", "recrf_dist", "written", "coded")):
+    if not all(np.array_equal(h_out[f], forms[7][2][f]) for f in ("srcrf_dist", "recrf_dist", "written", "coded")):
         raise SystemExit("bench: svt_hip_tpl_stage_host_resident differs from the two device stages -- no numbers recorded")
     for q in pinned + [rec_pin]:
         lib.svt_hip_tpl_plane_drop(q)
@@ -1202,7 +1203,8 @@ def tpl_recon_stage(torch, lib, pkg, stream, steps, warmup, keep):
                                                "roofline": {"bound": "pcie", "achieved": 2 * psize / t_res / 1e9, "peak": 64.0, "unit": "GB/s", "frac": 2 * psize / t_res / 1e9 / 64.0,
                                                             "kernel_us": t_res * 1e6, "binds": "pcie", "algorithmic_bytes_per_launch": 2 * psize},
                                                "note": "the same call with the references' planes resident on the device: one new source picture up, the written rectangle and the statistics down"},
-            "tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "form": "5: one launch, one wave per block, dependencies as data, release / acquire fences (csrc/tpl.hip tpl_recon_dep_kernel)",
+            "tpl_recon_stage_1080p8": {"us": t * 1e6, "pictures_per_s": 1 / t, "form": "7: one launch, one wave per block, dependencies as data, write-through stores + drained flag / one acquire (csrc/tpl.hip tpl_recon_dep_kernel)",
+                                        "release_acquire_fences_form5_us": forms[5][0] * 1e6,
                                         "sequentially_consistent_fences_form_us": forms[4][0] * 1e6, "load_polling_form6_us": forms[6][0] * 1e6, "anti_diagonal_launches_form_us": forms[0][0] * 1e6,
                                         "row_wavefront_form_us": forms[1][0] * 1e6, "row_wavefront_xcd_chunks_form_us": forms[2][0] * 1e6,
                                         "row_wavefront_release_acquire_form_us": forms[3][0] * 1e6, "blocks_16x16": n_blk, "intra_blocks": n_dc,

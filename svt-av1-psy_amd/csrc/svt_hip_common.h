@@ -27,6 +27,26 @@ typedef uint32_t svt_u32x4_a2 __attribute__((vector_size(16), aligned(2))); // 1
 typedef uint32_t svt_u32x2_a1 __attribute__((vector_size(8), aligned(1)));  // 8 bytes at any address
 __device__ __forceinline__ svt_u32x4_a2 svt_hip_global_load_x4(const void* p) { return *(const SVT_HIP_GLOBAL_AS svt_u32x4_a2*)p; }
 __device__ __forceinline__ svt_u32x2_a1 svt_hip_global_load_x2(const void* p) { return *(const SVT_HIP_GLOBAL_AS svt_u32x2_a1*)p; }
+// Write-through hand-off between workgroups of ONE launch (MI355X_MICROARCH.md, "cross-CU hand-off"): the producer's payload leaves the XCD's L2 with `sc0 sc1` stores,
+// `s_waitcnt vmcnt(0)` drains them, a relaxed agent-scope store publishes the flag -- instead of an agent-scope release fence, which writes back the whole L2's dirty lines
+// (1.7-6.5 us per fence, per workgroup).  The consumer still polls the flag with relaxed agent loads and then executes ONE agent-scope acquire before its plain loads.
+// (s_nop: a store of more than 64 bits must not be followed directly by a write of its data registers -- the compiler pads that hazard for its own stores and cannot see
+//  into this one; without it the next instruction overwrote the first data dword: four wrong samples per row, gpurun call 36.  The CPU emulator defines SVT_HIP_EMU.)
+__device__ __forceinline__ void svt_hip_store_x4_wt(void* p, const uint32_t x, const uint32_t y, const uint32_t z, const uint32_t w) {
+#ifdef SVT_HIP_EMU
+    uint32_t v[4] = {x, y, z, w};
+    memcpy(p, v, 16);
+#else
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 d = {x, y, z, w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+#endif
+}
+__device__ __forceinline__ void svt_hip_drain_stores() {
+#ifndef SVT_HIP_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 #ifndef SVT_HIP_WAVES_PER_EU // (waves per SIMD the register allocation of a kernel is cut for; the CPU emulator defines it as nothing)
 #define SVT_HIP_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #endif
@@ -140,7 +160,7 @@ bool tpl_full_supported(const ::SvtHipTplSrcParams& P);
 void tpl_full_src_launch(const ::SvtHipTplSrcParams& P, const uint8_t* src, const uint8_t* ref, const uint8_t* tot, const uint32_t* mv, const uint8_t* cand,
                          ::SvtHipTplSrcStats* stats, hipStream_t st);
 void tpl_full_recon_launch(const ::SvtHipTplReconParams& R, const uint8_t* src, const uint8_t* ref, const ::SvtHipTplSrcStats* ss, uint8_t* rec,
-                           ::SvtHipTplReconStats* out, uint32_t* sync, int cols16, int rows16, hipStream_t st);
+                           ::SvtHipTplReconStats* out, uint32_t* sync, int cols16, int rows16, int wt, hipStream_t st);
 // device-resident copies of host picture planes kept across host calls (runtime.hip): acquire pins an entry for (host buffer, content id) on the current device
 uint8_t* plane_cache_acquire(const void* host_ptr, uint64_t id, size_t bytes, bool* hit, int* token);
 void     plane_cache_release(int token, bool now_ready);

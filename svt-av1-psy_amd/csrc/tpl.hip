@@ -20,6 +20,8 @@
 namespace {
 
 struct __attribute__((packed, aligned(1))) tpl_u32x4_a1 { uint32_t x, y, z, w; }; // 16 bytes at any byte address
+// The write-through hand-off of SVT_HIP_TPL_RECON_FORM=7 (svt_hip_common.h: svt_hip_store_x4_wt / svt_hip_drain_stores)
+__device__ __forceinline__ void tpl_store_x4_wt(uint8_t* p, const tpl_u32x4_a1 v) { svt_hip_store_x4_wt(p, v.x, v.y, v.z, v.w); }
 
 constexpr int TPL_PAD = 32;          // TPL_PADX / TPL_PADY (encode_context.h:43-44)
 constexpr int TPL_NEWMV = 16;        // PredictionMode NEWMV (definitions.h:1143); DC_PRED = 0
@@ -265,7 +267,7 @@ __device__ __forceinline__ void tpl_recon_fetch(const SvtHipTplReconParams& RP, 
         load_row<NW>(B.prow, ref_base + R.plane_off + (size_t)((int)R.org_y + y0 + t + (B.s.mv_row >> 3)) * R.stride + (int)R.org_x + x0 + (B.s.mv_col >> 3));
     }
 }
-template <int SIZE, int TXH>
+template <int SIZE, int TXH, bool WT = false> // WT: the reconstruction is handed to the neighbouring blocks' waves of the SAME launch with write-through stores / coherent loads
 __device__ __forceinline__ void tpl_recon_compute(const SvtHipTplReconParams& RP, uint8_t* __restrict__ recon_base, SvtHipTplReconStats* __restrict__ out, const int cx,
                                                   const int cy, const TplBlockIn<SIZE>& B, const int t, int32_t* buf, uint8_t* ptile) {
     const SvtHipTplSrcParams& P = RP.src;
@@ -390,7 +392,8 @@ __device__ __forceinline__ void tpl_recon_compute(const SvtHipTplReconParams& RP
             tpl_u32x4_a1 o;
             o.x = *(const uint32_t*)(ptile + rr * PP + 16 * i); o.y = *(const uint32_t*)(ptile + rr * PP + 16 * i + 4);
             o.z = *(const uint32_t*)(ptile + rr * PP + 16 * i + 8); o.w = *(const uint32_t*)(ptile + rr * PP + 16 * i + 12);
-            *(tpl_u32x4_a1*)(d + 16 * i) = o;
+            if (WT) tpl_store_x4_wt(d + 16 * i, o);
+            else *(tpl_u32x4_a1*)(d + 16 * i) = o;
         }
         if (t == 0) {
             long long e = (long long)tot;
@@ -403,7 +406,13 @@ __device__ __forceinline__ void tpl_recon_compute(const SvtHipTplReconParams& RP
             o.srcrf_rate = newmv ? s.srcrf_rate : 0;
             if (o.srcrf_dist > o.recrf_dist) o.recrf_dist = o.srcrf_dist;
             if (o.srcrf_rate > o.recrf_rate) o.recrf_rate = o.srcrf_rate;
-            out[cell] = o;
+            if (WT) { // everything but `reserved`: in this form the cell's flag is published by a write-through store a plain store of the whole record must not shadow
+                SvtHipTplReconStats* q = &out[cell];
+                q->srcrf_dist = o.srcrf_dist; q->recrf_dist = o.recrf_dist; q->srcrf_rate = o.srcrf_rate; q->recrf_rate = o.recrf_rate;
+                q->written = o.written; q->coded = o.coded; q->pad[0] = 0; q->pad[1] = 0;
+            } else {
+                out[cell] = o;
+            }
         }
     }
 }
@@ -530,21 +539,26 @@ __global__ __launch_bounds__(64) void tpl_recon_dep_kernel(const SvtHipTplReconP
             uint32_t  polls = 0;
             // (rel_acq == 2, form 6: the poll is an atomic LOAD at agent scope -- many waves poll the same neighbours' flags, and a read-modify-write per poll queues them at
             // the L2's atomic unit, a load does not)
-            while ((rel_acq == 2 ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : atomicAdd(flag, 0u)) == 0u && polls < TPL_WAIT_POLLS) { polls++; __builtin_amdgcn_s_sleep(1); }
+            while ((rel_acq >= 2 ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : atomicAdd(flag, 0u)) == 0u && polls < TPL_WAIT_POLLS) { polls++; __builtin_amdgcn_s_sleep(1); }
             timed_out = polls >= TPL_WAIT_POLLS;
         }
         if (timed_out) atomicAdd(&sync[1], 1u);
-        if (rel_acq) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (rel_acq) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (also form 7: the hand-off's consumer side is ONE acquire, then plain loads)
         else __threadfence();
     }
-    tpl_recon_compute<SIZE, TXH>(RP, recon_base, out, cx, cy, B, t, buf, ptile);
-    if (rel_acq) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    else __threadfence();
+    if (rel_acq == 3) {
+        tpl_recon_compute<SIZE, TXH, true>(RP, recon_base, out, cx, cy, B, t, buf, ptile);
+        svt_hip_drain_stores(); // every lane's write-through stores have left before the barrier lets lane 0 publish the cells
+    } else {
+        tpl_recon_compute<SIZE, TXH>(RP, recon_base, out, cx, cy, B, t, buf, ptile);
+        if (rel_acq) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        else __threadfence();
+    }
     __syncthreads();
     if (threadIdx.x == 0)
         for (int j = 0; j < UNIT && cy + j < rows16; j++)
             for (int i = 0; i < UNIT && cx + i < cols16; i++) {
-                if (rel_acq == 2) __hip_atomic_store(&out[(size_t)(cy + j) * cols16 + cx + i].reserved, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (rel_acq >= 2) __hip_atomic_store(&out[(size_t)(cy + j) * cols16 + cx + i].reserved, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else atomicExch(&out[(size_t)(cy + j) * cols16 + cx + i].reserved, 1u);
             }
 }
@@ -667,27 +681,27 @@ void svt_hip_tpl_recon_stage(const SvtHipTplReconParams* params, const uint8_t* 
     const int   aligned_h = (int)((P.height + 7) & ~7u), cols16 = (int)((P.aligned_width + 15) >> 4), rows16 = (aligned_h + 15) >> 4;
     const bool  edge_sbs = (P.aligned_width & 63) || (aligned_h & 63); // SBs the picture edge cuts run at level 0 (:2048-2051)
     const char* form_env = getenv("SVT_HIP_TPL_RECON_FORM"); // (read per call: a picture-sized stage, and the tests switch it inside one process)
-    const int   form = form_env ? atoi(form_env) : 5;
+    const int   form = form_env ? atoi(form_env) : 7;
     if (svthip::tpl_full_wanted(P)) { // tpl levels 0-3: one launch, dependencies as data (the only form of that option set)
         uint32_t* sync = svthip::stream_scratch_u32x4(st);
         hipLaunchKernelGGL(tpl_recon_rows_reset_kernel, dim3((cols16 * rows16 + 255) / 256), dim3(256), 0, st, out, 1, cols16 * rows16);
         SVT_LAUNCH_CHECK();
-        svthip::tpl_full_recon_launch(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, cols16, rows16, st);
+        svthip::tpl_full_recon_launch(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, cols16, rows16, form == 5 || form == 4 ? 0 : 1, st);
         hipLaunchKernelGGL(tpl_recon_dep_finish_kernel, dim3(1), dim3(64), 0, st, out, sync);
         SVT_LAUNCH_CHECK();
         return;
     }
-    if (form == 4 || form == 5 || form == 6) { // (6: as 5, polling with atomic loads instead of read-modify-writes) dependencies as data, every block in flight: 5 (the default) with release / acquire fences at agent scope, 4 with sequentially-consistent
+    if (form == 4 || form == 5 || form == 6 || form == 7) { // (6: as 5, polling with atomic loads instead of read-modify-writes) dependencies as data, every block in flight: 7 (the default) = 6 with write-through stores + drained flag instead of the release fence (213 us against 339: gpurun call 37); 5 with release / acquire fences at agent scope, 4 with sequentially-consistent
                                   // ones (416 us against 339 us for a 1080p picture with a third of its blocks intra: profiles/r04_call3_tpl_forms.txt)
         uint32_t* sync = svthip::stream_scratch_u32x4(st); // [0] tickets of the first launch, [1] blocks that gave up waiting, [2] tickets of the second launch
         hipLaunchKernelGGL(tpl_recon_rows_reset_kernel, dim3((cols16 * rows16 + 255) / 256), dim3(256), 0, st, out, 1, cols16 * rows16); // every cell's flag
         SVT_LAUNCH_CHECK();
         if (P.dispenser_search_level == 0) {
-            if (P.subsample_tx == 0) launch_tpl_recon_dep<16, 16>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 6 ? 2 : (form == 5), st);
-            else launch_tpl_recon_dep<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 6 ? 2 : (form == 5), st);
+            if (P.subsample_tx == 0) launch_tpl_recon_dep<16, 16>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 7 ? 3 : (form == 6 ? 2 : (form == 5)), st);
+            else launch_tpl_recon_dep<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 7 ? 3 : (form == 6 ? 2 : (form == 5)), st);
         } else {
-            launch_tpl_recon_dep<32, 8>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 6 ? 2 : (form == 5), st);
-            if (edge_sbs) launch_tpl_recon_dep<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 2, cols16, rows16, form == 6 ? 2 : (form == 5), st);
+            launch_tpl_recon_dep<32, 8>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 0, cols16, rows16, form == 7 ? 3 : (form == 6 ? 2 : (form == 5)), st);
+            if (edge_sbs) launch_tpl_recon_dep<16, 4>(R, src_base, rec_ref_base, src_stats, recon_base, out, sync, 2, cols16, rows16, form == 7 ? 3 : (form == 6 ? 2 : (form == 5)), st);
         }
         hipLaunchKernelGGL(tpl_recon_dep_finish_kernel, dim3(1), dim3(64), 0, st, out, sync);
         SVT_LAUNCH_CHECK();

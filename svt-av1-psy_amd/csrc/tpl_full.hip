@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64) void tpl_full_src_kernel(const SvtHipTplSrcPara
 // "reconstructed" flags live in SvtHipTplReconStats.reserved.
 __global__ __launch_bounds__(64) void tpl_full_recon_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
                                                             const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,
-                                                            SvtHipTplReconStats* __restrict__ out, uint32_t* __restrict__ sync, const int cols16, const int rows16) {
+                                                            SvtHipTplReconStats* __restrict__ out, uint32_t* __restrict__ sync, const int cols16, const int rows16, const int wt /* 1: write-through hand-off (svt_hip_common.h), 0: release fence */) {
     __shared__ FullLds  S;
     __shared__ uint32_t s_ticket;
     const SvtHipTplSrcParams& P = RP.src;
@@ -499,7 +499,8 @@ __global__ __launch_bounds__(64) void tpl_full_recon_kernel(const SvtHipTplRecon
                 if (nx >= 0 && ny >= 0 && nx < cols16 && (l < 3 || cx == 0)) {
                     uint32_t* flag  = &out[(size_t)ny * cols16 + nx].reserved;
                     uint32_t  polls = 0;
-                    while (atomicAdd(flag, 0u) == 0u && polls < FULL_WAIT_POLLS) { polls++; __builtin_amdgcn_s_sleep(1); }
+                    // (a relaxed agent-scope LOAD per poll: read-modify-writes queue the pollers of one flag at the memory side's atomic unit)
+                    while ((wt ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : atomicAdd(flag, 0u)) == 0u && polls < FULL_WAIT_POLLS) { polls++; __builtin_amdgcn_s_sleep(1); }
                     timed_out = polls >= FULL_WAIT_POLLS;
                 }
             }
@@ -540,10 +541,17 @@ __global__ __launch_bounds__(64) void tpl_full_recon_kernel(const SvtHipTplRecon
             }
             __syncthreads();
         }
+        if (wt) { // a row of sixteen samples per lane, one 16-byte write-through store each (sample-wide write-through stores would be one fabric write apiece)
+            if (l < 16) {
+                const uint32_t* pr = (const uint32_t*)(S.pred + 16 * l);
+                svt_hip_store_x4_wt(rec + (size_t)(y0 + l) * rs + x0, pr[0], pr[1], pr[2], pr[3]);
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = l + 64 * k;
-            rec[(size_t)(y0 + (i >> 4)) * rs + x0 + (i & 15)] = S.pred[i];
+            for (int k = 0; k < 4; k++) {
+                const int i = l + 64 * k;
+                rec[(size_t)(y0 + (i >> 4)) * rs + x0 + (i & 15)] = S.pred[i];
+            }
         }
         if (l == 0) {
             SvtHipTplReconStats o = {};
@@ -555,12 +563,22 @@ __global__ __launch_bounds__(64) void tpl_full_recon_kernel(const SvtHipTplRecon
             o.srcrf_rate = newmv ? s.srcrf_rate : rate;
             if (o.srcrf_dist > o.recrf_dist) o.recrf_dist = o.srcrf_dist;
             if (o.srcrf_rate > o.recrf_rate) o.recrf_rate = o.srcrf_rate;
-            out[cell] = o;
+            if (wt) { // everything but `reserved`: the cell's flag is published by a coherent store a plain store of the whole record must not shadow
+                SvtHipTplReconStats* q2 = &out[cell];
+                q2->srcrf_dist = o.srcrf_dist; q2->recrf_dist = o.recrf_dist; q2->srcrf_rate = o.srcrf_rate; q2->recrf_rate = o.recrf_rate;
+                q2->written = o.written; q2->coded = o.coded; q2->pad[0] = 0; q2->pad[1] = 0;
+            } else {
+                out[cell] = o;
+            }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (wt) svt_hip_drain_stores(); // the rows have left this XCD's L2 ...
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (l == 0) atomicExch(&out[cell].reserved, 1u);
+    if (l == 0) { // ... before the cell is published
+        if (wt) __hip_atomic_store(&out[cell].reserved, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else atomicExch(&out[cell].reserved, 1u);
+    }
 }
 
 } // namespace
@@ -579,8 +597,8 @@ void tpl_full_src_launch(const SvtHipTplSrcParams& P, const uint8_t* src, const 
 }
 // out's flags cleared and sync[0..1] zero on entry (the caller's reset kernel); the caller's finish kernel reports sync[1]
 void tpl_full_recon_launch(const SvtHipTplReconParams& R, const uint8_t* src, const uint8_t* ref, const SvtHipTplSrcStats* ss, uint8_t* rec, SvtHipTplReconStats* out,
-                           uint32_t* sync, int cols16, int rows16, hipStream_t st) {
-    hipLaunchKernelGGL(tpl_full_recon_kernel, dim3((cols16 + rows16 - 1) * rows16), dim3(64), 0, st, R, src, ref, ss, rec, out, sync, cols16, rows16);
+                           uint32_t* sync, int cols16, int rows16, int wt, hipStream_t st) {
+    hipLaunchKernelGGL(tpl_full_recon_kernel, dim3((cols16 + rows16 - 1) * rows16), dim3(64), 0, st, R, src, ref, ss, rec, out, sync, cols16, rows16, wt);
     SVT_LAUNCH_CHECK();
 }
 

@@ -251,7 +251,7 @@ def test_tpl_recon_oracle_vs_reference(oracle, ref, ci):
 
 
 @pytest.mark.parametrize("ci", range(len(CASES) + len(GPU_CASES)))
-@pytest.mark.parametrize("is_ref,form", [(1, 5), (0, 5), (1, 4), (1, 0), (0, 0), (1, 1), (1, 2), (1, 3), (1, 6)])
+@pytest.mark.parametrize("is_ref,form", [(1, 5), (0, 5), (1, 4), (1, 0), (0, 0), (1, 1), (1, 2), (1, 3), (1, 6), (1, 7), (0, 7)])
 def test_tpl_recon_stage_device(be, oracle, ci, is_ref, form, monkeypatch):
     """svt_hip_tpl_recon_stage (device arrays, one launch per anti-diagonal) and svt_hip_tpl_recon_stage_host == the oracle: statistics of every block and the whole
     reconstruction plane; is_ref = 0 with intra prediction off leaves the prediction in place (:1135)."""
