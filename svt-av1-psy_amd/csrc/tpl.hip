@@ -267,7 +267,8 @@ __device__ __forceinline__ void tpl_recon_fetch(const SvtHipTplReconParams& RP, 
         load_row<NW>(B.prow, ref_base + R.plane_off + (size_t)((int)R.org_y + y0 + t + (B.s.mv_row >> 3)) * R.stride + (int)R.org_x + x0 + (B.s.mv_col >> 3));
     }
 }
-template <int SIZE, int TXH, bool WT = false> // WT: the reconstruction is handed to the neighbouring blocks' waves of the SAME launch with write-through stores / coherent loads
+template <int SIZE, int TXH, bool WT = false, bool WSYNC = false> // WSYNC: the caller's workgroup holds several independent single-wave blocks -- every barrier below is
+// between lanes of ONE wave anyway (a block's lanes never span two waves), so it becomes a wave barrier (LDS traffic of a wave is served in order).  WT: the reconstruction is handed to the neighbouring blocks' waves of the SAME launch with write-through stores / coherent loads
 __device__ __forceinline__ void tpl_recon_compute(const SvtHipTplReconParams& RP, uint8_t* __restrict__ recon_base, SvtHipTplReconStats* __restrict__ out, const int cx,
                                                   const int cy, const TplBlockIn<SIZE>& B, const int t, int32_t* buf, uint8_t* ptile) {
     const SvtHipTplSrcParams& P = RP.src;
@@ -314,7 +315,7 @@ __device__ __forceinline__ void tpl_recon_compute(const SvtHipTplReconParams& RP
                 buf[r * PITCH + 4 * j + b] = (int32_t)((uint32_t)d << FS0);
             }
     }
-    __syncthreads();
+    if (WSYNC) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     if (active) { // forward, column t
         int32_t v[TXH];
 #pragma unroll
@@ -323,7 +324,7 @@ __device__ __forceinline__ void tpl_recon_compute(const SvtHipTplReconParams& RP
 #pragma unroll
         for (int r = 0; r < TXH; r++) buf[r * PITCH + t] = FS1 ? rshift_round(v[r], FS1 ? FS1 : 1) : v[r];
     }
-    __syncthreads();
+    if (WSYNC) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     unsigned long long err = 0;
     uint32_t           nz  = 0;
     if (active && t < TXH) { // forward, row t; quantize_fp; the dequantised row goes back into the tile
@@ -356,7 +357,7 @@ __device__ __forceinline__ void tpl_recon_compute(const SvtHipTplReconParams& RP
     const unsigned long long tot = (unsigned long long)l0 + ((unsigned long long)l1 << 22) + ((unsigned long long)l2 << 44);
     const bool coded = group_sum<T>(nz) != 0;
     const bool inverse = active && coded && (!P.disable_intra_pred || RP.is_ref); // (:1135-1136)
-    __syncthreads();
+    if (WSYNC) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     if (inverse && t < TXH) { // inverse, row t (inv_txfm2d_kernel's first pass, bd 8)
         const int32_t rhi = (1 << 15) - 1, rlo = -(1 << 15);
         int32_t v[W];
@@ -370,7 +371,7 @@ __device__ __forceinline__ void tpl_recon_compute(const SvtHipTplReconParams& RP
 #pragma unroll
         for (int c = 0; c < W; c++) buf[t * PITCH + c] = S0 ? rshift_round(v[c], S0 ? S0 : 1) : v[c];
     }
-    __syncthreads();
+    if (WSYNC) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     if (inverse) { // inverse, column t, added to the prediction rows the transform saw
         const int32_t chi = (1 << 15) - 1, clo = -(1 << 15);
         int32_t v[TXH];
@@ -383,7 +384,7 @@ __device__ __forceinline__ void tpl_recon_compute(const SvtHipTplReconParams& RP
             ptile[(r << ST) * PP + t] = (uint8_t)(px < 0 ? 0 : (px > 255 ? 255 : px));
         }
     }
-    __syncthreads();
+    if (WSYNC) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     if (active) { // row t of the block: the reconstructed row the transform saw (the rows between are copies, :1149-1167), or the prediction
         const int rr = inverse ? (t & ~((1 << ST) - 1)) : t;
         uint8_t*  d  = rec + (size_t)(y0 + t) * rs + x0;
@@ -504,8 +505,10 @@ __global__ void tpl_recon_rows_reset_kernel(SvtHipTplReconStats* __restrict__ ou
 // blocks -- the critical path of an inter picture is a few blocks, not cols + rows of them; an all-intra picture degenerates to the wavefront the other forms always
 // pay.  Level 1 (32x32 blocks in complete SBs, 16x16 blocks in SBs cut by the picture edge) is two launches in stream order: a 32x32 block never has a 16x16 neighbour
 // on its left or above, so the first launch owns the cells of the complete SBs and the second one finds them published.
+constexpr int DEP_WAVES = 4; // waves (= blocks in flight) per workgroup of the dependency form: ONE ticket draw per workgroup -- 8 160 returning atomics on one word, one per
+                             // single-wave workgroup, were 126 of the kernel's 213 us (the same kernel with the workgroup id as its ticket: 87 us, gpurun call 39)
 template <int SIZE, int TXH>
-__global__ __launch_bounds__(64) void tpl_recon_dep_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+__global__ __launch_bounds__(64 * DEP_WAVES) void tpl_recon_dep_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
                                                            const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,
                                                            SvtHipTplReconStats* __restrict__ out, uint32_t* __restrict__ sync, const int ticket_slot, const int cols_b,
                                                            const int rows_b, const int rel_acq) {
@@ -514,15 +517,18 @@ __global__ __launch_bounds__(64) void tpl_recon_dep_kernel(const SvtHipTplReconP
     __shared__ SvtHipTplRef s_refs[8];
     __shared__ uint32_t     s_ticket;
     if (threadIdx.x < 8) s_refs[threadIdx.x] = RP.rec_refs[threadIdx.x];
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&sync[ticket_slot], 1u);
-    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&sync[ticket_slot], (uint32_t)DEP_WAVES); // the workgroup's waves take consecutive tickets
+    __syncthreads(); // the ONLY workgroup barrier: from here on the waves are independent blocks (a wave waiting for its neighbours holds up nobody else)
     const SvtHipTplSrcParams& P = RP.src;
-    const int t = (int)threadIdx.x % SIZE, sub = (int)threadIdx.x / SIZE; // (lane groups 1 .. SUBS - 1 idle along on tiles of their own: the block code stores its prediction row unconditionally)
-    const int u = (int)s_ticket / rows_b, by = (int)s_ticket % rows_b, bx = u - by;
-    if (bx < 0 || bx >= cols_b) return; // (uniform) no block under this ticket
+    const int lane = (int)threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int t = lane % SIZE, sub = lane / SIZE; // (lane groups 1 .. SUBS - 1 idle along on tiles of their own: the block code stores its prediction row unconditionally)
+    const int ticket = (int)s_ticket + wv, u = ticket / rows_b, by = ticket % rows_b, bx = u - by;
+    if (bx < 0 || bx >= cols_b) return; // (wave-uniform) no block under this ticket
     const int cx = bx * UNIT, cy = by * UNIT;
-    int32_t*  buf   = smem + sub * (TXH * PITCH);
-    uint8_t*  ptile = (uint8_t*)(smem + SUBS * (TXH * PITCH)) + sub * (SIZE * PP);
+    constexpr int WAVE_DW = SUBS * (TXH * PITCH) + (SUBS * SIZE * PP + 3) / 4; // the wave's own LDS slice, in dwords
+    int32_t*  wsm   = smem + wv * WAVE_DW;
+    int32_t*  buf   = wsm + sub * (TXH * PITCH);
+    uint8_t*  ptile = (uint8_t*)(wsm + SUBS * (TXH * PITCH)) + sub * (SIZE * PP);
     const int aligned_h = (int)((P.height + 7) & ~7u), cols16 = (int)((P.aligned_width + 15) >> 4), rows16 = (aligned_h + 15) >> 4;
     // the cells this wave answers for in THIS launch: the blocks of its size class, processed or not (a skipped block's neighbours must not wait for ever)
     const bool complete = ((int)P.aligned_width - ((cx * 16) & ~63) >= 64) && (aligned_h - ((cy * 16) & ~63) >= 64);
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(64) void tpl_recon_dep_kernel(const SvtHipTplReconP
     const bool dc = __shfl((int)(B.active && !B.newmv), 0) != 0; // (lane 0 belongs to the live group)
     if (dc) { // its upper and left cells must be reconstructed; one lane per cell polls
         const int  n_up = cy > 0 ? (cols16 - cx < UNIT ? cols16 - cx : UNIT) : 0, n_left = cx > 0 ? (rows16 - cy < UNIT ? rows16 - cy : UNIT) : 0;
-        const int  l = (int)threadIdx.x;
+        const int  l = lane;
         bool       timed_out = false;
         if (l < n_up + n_left) {
             uint32_t* flag  = l < n_up ? &out[(size_t)(cy - 1) * cols16 + cx + l].reserved : &out[(size_t)(cy + l - n_up) * cols16 + cx - 1].reserved;
@@ -547,15 +553,15 @@ __global__ __launch_bounds__(64) void tpl_recon_dep_kernel(const SvtHipTplReconP
         else __threadfence();
     }
     if (rel_acq == 3) {
-        tpl_recon_compute<SIZE, TXH, true>(RP, recon_base, out, cx, cy, B, t, buf, ptile);
-        svt_hip_drain_stores(); // every lane's write-through stores have left before the barrier lets lane 0 publish the cells
+        tpl_recon_compute<SIZE, TXH, true, true>(RP, recon_base, out, cx, cy, B, t, buf, ptile);
+        svt_hip_drain_stores(); // every lane's write-through stores have left (a wave executes the wait as one) before lane 0 publishes the cells
     } else {
-        tpl_recon_compute<SIZE, TXH>(RP, recon_base, out, cx, cy, B, t, buf, ptile);
+        tpl_recon_compute<SIZE, TXH, false, true>(RP, recon_base, out, cx, cy, B, t, buf, ptile);
         if (rel_acq) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         else __threadfence();
     }
-    __syncthreads();
-    if (threadIdx.x == 0)
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0)
         for (int j = 0; j < UNIT && cy + j < rows16; j++)
             for (int i = 0; i < UNIT && cx + i < cols16; i++) {
                 if (rel_acq >= 2) __hip_atomic_store(&out[(size_t)(cy + j) * cols16 + cx + i].reserved, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -570,8 +576,9 @@ void launch_tpl_recon_dep(const SvtHipTplReconParams& P, const uint8_t* src, con
                           uint32_t* sync, int ticket_slot, int cols16, int rows16, int rel_acq, hipStream_t st) {
     constexpr int SUBS = 64 / SIZE, UNIT = SIZE / 16;
     const int     cols_b = (cols16 + UNIT - 1) / UNIT, rows_b = (rows16 + UNIT - 1) / UNIT;
-    const size_t  shmem = (size_t)SUBS * TXH * (SIZE + 1) * 4 + (size_t)SUBS * SIZE * (SIZE + 4);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(tpl_recon_dep_kernel<SIZE, TXH>), dim3((cols_b + rows_b - 1) * rows_b), dim3(64), shmem, st, P, src, ref, ss, rec, out, sync,
+    const size_t  wave_dw = (size_t)SUBS * TXH * (SIZE + 1) + ((size_t)SUBS * SIZE * (SIZE + 4) + 3) / 4, shmem = DEP_WAVES * wave_dw * 4;
+    const int     tickets = (cols_b + rows_b - 1) * rows_b;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tpl_recon_dep_kernel<SIZE, TXH>), dim3((tickets + DEP_WAVES - 1) / DEP_WAVES), dim3(64 * DEP_WAVES), shmem, st, P, src, ref, ss, rec, out, sync,
                        ticket_slot, cols_b, rows_b, rel_acq);
     SVT_LAUNCH_CHECK();
 }
