@@ -48,6 +48,9 @@ __device__ constexpr int16_t kAngle[13] = {0, 90, 180, 45, 135, 113, 157, 203, 6
 __device__ constexpr int16_t kDx[13]    = {0, 0, 0, 64, 64, 27, 151, 1, 27, 0, 0, 0, 0};
 __device__ constexpr int16_t kDy[13]    = {0, 0, 0, 1, 64, 151, 27, 27, 1, 0, 0, 0, 0};
 
+// Every block of this file is ONE wave (64 lanes per 16x16 block), so every barrier in it is between lanes of one wave: a wave barrier (LDS traffic of a wave is served in
+// order) -- which is what lets the reconstruction kernel put several independent blocks into one workgroup (one ticket draw per workgroup, see tpl_full_recon_kernel).
+#define TPLF_BARRIER() __builtin_amdgcn_wave_barrier()
 struct FullLds {
     uint8_t  src[256], pred[256], best[256];
     uint8_t  a0[64], l0[64], a[64], l[64]; // unfiltered / working neighbour arrays
@@ -158,7 +161,7 @@ __device__ __forceinline__ void intra_predict(const int mode, const int x0, cons
     const uint8_t *pa = A0, *pl = L0;
     if (directional) {
         filter_edges(angle, x0, y0, A0, L0, A, L, l);
-        __syncthreads();
+        TPLF_BARRIER();
         pa = A; pl = L;
     }
     int dc = 128;
@@ -174,7 +177,7 @@ __device__ __forceinline__ void intra_predict(const int mode, const int x0, cons
         const int i = l + 64 * k;
         out[i] = (uint8_t)intra_sample(mode, i >> 4, i & 15, pa, pl, dc);
     }
-    __syncthreads();
+    TPLF_BARRIER();
 }
 
 // ---- residual -> forward DCT_DCT 16x16 (svt_av1_highbd_fwd_txfm, shifts {2, -2, 0}); the coefficients end up in tr[row * TP + column] --------------------------------
@@ -187,7 +190,7 @@ __device__ __forceinline__ void fwd16(const uint8_t* __restrict__ src, const uin
         const int i = l + 64 * k;
         tr[(i >> 4) * TP + (i & 15)] = (int32_t)((uint32_t)((int)src[i] - (int)pred[i]) << FS0);
     }
-    __syncthreads();
+    TPLF_BARRIER();
     if (l < 16) {
         int32_t v[16];
 #pragma unroll
@@ -196,7 +199,7 @@ __device__ __forceinline__ void fwd16(const uint8_t* __restrict__ src, const uin
 #pragma unroll
         for (int r = 0; r < 16; r++) tr[r * TP + l] = rshift_round(v[r], FS1);
     }
-    __syncthreads();
+    TPLF_BARRIER();
     if (l < 16) {
         int32_t v[16];
 #pragma unroll
@@ -205,7 +208,7 @@ __device__ __forceinline__ void fwd16(const uint8_t* __restrict__ src, const uin
 #pragma unroll
         for (int c = 0; c < 16; c++) tr[l * TP + c] = v[c];
     }
-    __syncthreads();
+    TPLF_BARRIER();
 }
 // svt_aom_satd over the coefficients the partial-frequency shape keeps (the rest is zero: transforms.c:5202-5273)
 __device__ __forceinline__ uint32_t satd16(const int32_t* __restrict__ tr, const int keep, const int l) {
@@ -231,7 +234,7 @@ __device__ __forceinline__ uint32_t block_cost(const SvtHipTplSrcParams& P, Full
     if (!(P.search_flags & 1)) return sad16(S.src, pred, l);
     fwd16(S.src, pred, S.tr, l);
     const uint32_t c = satd16(S.tr, 16 >> P.pf_shape, l);
-    __syncthreads();
+    TPLF_BARRIER();
     return c;
 }
 
@@ -278,7 +281,7 @@ __device__ __forceinline__ QuantOut quantize16(const SvtHipTplSrcParams& P, int3
     for (int m = 32; m >= 1; m >>= 1) { const int other = __shfl_xor(e, m); e = other > e ? other : e; }
     o.eob  = e;
     o.rate = (wave_sum_i32(rate) + e + 1) << PROB_COST_SHIFT;
-    __syncthreads();
+    TPLF_BARRIER();
     return o;
 }
 
@@ -293,7 +296,7 @@ __device__ __forceinline__ void inter_predict(const SvtHipTplSrcParams& P, const
             const int i = l + 64 * k;
             out[i] = p0[(long)(i >> 4) * rs + (i & 15)];
         }
-        __syncthreads();
+        TPLF_BARRIER();
         return;
     }
     const int aligned_h = (int)((P.height + 7) & ~7u), mi_rows = aligned_h >> 2, mi_cols = (int)P.aligned_width >> 2, mirow = y0 >> 2, micol = x0 >> 2;
@@ -308,7 +311,7 @@ __device__ __forceinline__ void inter_predict(const SvtHipTplSrcParams& P, const
     const uint8_t* p0 = ref + (long)(y0 + (row >> 4)) * rs + x0 + (col >> 4);
     auto finish = [&](const int i, int px) { out[i] = (uint8_t)(px < 0 ? 0 : (px > 255 ? 255 : px)); };
     predict_rows<uint8_t, 8>(p0, rs, 16, 16, 1, sx, sy, kTaps.t[0][sx], kTaps.t[0][sy], 8, im, l, finish);
-    __syncthreads();
+    TPLF_BARRIER();
 }
 
 // ---- svt_aom_sub_pixel_variance16x16 (bilinear taps {128 - 16 o, 16 o}) of the reference block at vector (mvr, mvc) against the source block --------------------------
@@ -320,7 +323,7 @@ __device__ __forceinline__ uint32_t subpel_variance(const uint8_t* __restrict__ 
         const uint8_t* q = p0 + (long)(i >> 4) * rs + (i & 15);
         bil[i] = (uint16_t)(((int)q[0] * f0 + (int)q[1] * f1 + 64) >> 7);
     }
-    __syncthreads();
+    TPLF_BARRIER();
     int sum = 0;
     uint32_t sse = 0;
 #pragma unroll
@@ -332,7 +335,7 @@ __device__ __forceinline__ uint32_t subpel_variance(const uint8_t* __restrict__ 
     }
     const int          su = wave_sum_i32(sum);
     const uint32_t     ss = (uint32_t)wave_sum_i32((int)sse); // <= 256 * 255^2
-    __syncthreads();
+    TPLF_BARRIER();
     return ss - (uint32_t)(((long long)su * su) >> 8); // svt_aom_variance16x16_c
 }
 
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(64) void tpl_full_src_kernel(const SvtHipTplSrcPara
         S.src[i] = src[(size_t)(y0 + (i >> 4)) * ss + x0 + (i & 15)];
     }
     fill_neighbours(src, ss, x0, y0, (int)P.width, (int)P.height, S.a0, S.l0, l);
-    __syncthreads();
+    TPLF_BARRIER();
     // ---- intra (:611-757) ----
     uint32_t best_intra = 0xffffffffu;
     int      best_intra_mode = 0;
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(64) void tpl_full_src_kernel(const SvtHipTplSrcPara
 #pragma unroll
             for (int q = 0; q < 4; q++) S.best[l + 64 * q] = S.pred[l + 64 * q];
         }
-        __syncthreads();
+        TPLF_BARRIER();
     }
     // (the costs are below 2^31: "nothing evaluated" = INT64_MAX in the reference is never less than anything)
     const bool newmv = have_inter && (P.disable_intra_pred ? true : best_inter < best_intra);
@@ -460,17 +463,21 @@ __global__ __launch_bounds__(64) void tpl_full_src_kernel(const SvtHipTplSrcPara
 // One wave per block, every block in flight, tickets in anti-diagonal order (as tpl_recon_dep_kernel of tpl.hip: a waiting wave only waits for tickets drawn earlier).
 // An intra block reads the reconstruction above, left, above-left and -- in the first block column, whose top-right samples are real -- above-right of it; the cells'
 // "reconstructed" flags live in SvtHipTplReconStats.reserved.
-__global__ __launch_bounds__(64) void tpl_full_recon_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
+constexpr int REC_WAVES = 4; // independent blocks (waves) per workgroup of the reconstruction kernel
+__global__ __launch_bounds__(64 * REC_WAVES) void tpl_full_recon_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
                                                             const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,
                                                             SvtHipTplReconStats* __restrict__ out, uint32_t* __restrict__ sync, const int cols16, const int rows16, const int wt /* 1: write-through hand-off (svt_hip_common.h), 0: release fence */) {
-    __shared__ FullLds  S;
+    __shared__ FullLds  Sw[REC_WAVES];
     __shared__ uint32_t s_ticket;
     const SvtHipTplSrcParams& P = RP.src;
-    const int l = (int)threadIdx.x;
+    const int l = (int)threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    FullLds&  S = Sw[wv];
     if (l < 8) S.refs[l] = RP.rec_refs[l];
-    if (l == 0) s_ticket = atomicAdd(&sync[0], 1u);
+    // ONE ticket draw per workgroup, its waves take consecutive tickets (8 160 returning atomics on one word -- one per single-wave workgroup -- cost more than the blocks'
+    // work: csrc/tpl.hip tpl_recon_dep_kernel); this is the kernel's only workgroup barrier, afterwards the waves are independent blocks
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&sync[0], (uint32_t)REC_WAVES);
     __syncthreads();
-    const int u = (int)s_ticket / rows16, cy = (int)s_ticket % rows16, cx = u - cy;
+    const int ticket = (int)s_ticket + wv, u = ticket / rows16, cy = ticket % rows16, cx = u - cy;
     if (cx < 0 || cx >= cols16) return;
     const int    x0 = cx * 16, y0 = cy * 16;
     const size_t cell = (size_t)cy * cols16 + cx;
@@ -506,9 +513,9 @@ __global__ __launch_bounds__(64) void tpl_full_recon_kernel(const SvtHipTplRecon
             }
             if (timed_out) atomicAdd(&sync[1], 1u);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __syncthreads();
+            TPLF_BARRIER();
             fill_neighbours(rec, rs, x0, y0, (int)P.width, (int)P.height, S.a0, S.l0, l);
-            __syncthreads();
+            TPLF_BARRIER();
             intra_predict(s.best_intra_mode, x0, y0, S.a0, S.l0, S.a, S.l, S.pred, l);
         }
         // residual -> transform -> quantisation error, rate (:1112-1131)
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(64) void tpl_full_recon_kernel(const SvtHipTplRecon
 #pragma unroll
                 for (int c = 0; c < 16; c++) S.tr[l * TP + c] = S0 ? rshift_round(v[c], S0 ? S0 : 1) : v[c];
             }
-            __syncthreads();
+            TPLF_BARRIER();
             if (l < 16) {
                 const int32_t chi = (1 << 15) - 1, clo = -(1 << 15);
                 int32_t v[16];
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(64) void tpl_full_recon_kernel(const SvtHipTplRecon
                     S.pred[r * 16 + l] = (uint8_t)(px < 0 ? 0 : (px > 255 ? 255 : px));
                 }
             }
-            __syncthreads();
+            TPLF_BARRIER();
         }
         if (wt) { // a row of sixteen samples per lane, one 16-byte write-through store each (sample-wide write-through stores would be one fabric write apiece)
             if (l < 16) {
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(64) void tpl_full_recon_kernel(const SvtHipTplRecon
     }
     if (wt) svt_hip_drain_stores(); // the rows have left this XCD's L2 ...
     else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
+    TPLF_BARRIER();
     if (l == 0) { // ... before the cell is published
         if (wt) __hip_atomic_store(&out[cell].reserved, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else atomicExch(&out[cell].reserved, 1u);
@@ -598,7 +605,7 @@ void tpl_full_src_launch(const SvtHipTplSrcParams& P, const uint8_t* src, const 
 // out's flags cleared and sync[0..1] zero on entry (the caller's reset kernel); the caller's finish kernel reports sync[1]
 void tpl_full_recon_launch(const SvtHipTplReconParams& R, const uint8_t* src, const uint8_t* ref, const SvtHipTplSrcStats* ss, uint8_t* rec, SvtHipTplReconStats* out,
                            uint32_t* sync, int cols16, int rows16, int wt, hipStream_t st) {
-    hipLaunchKernelGGL(tpl_full_recon_kernel, dim3((cols16 + rows16 - 1) * rows16), dim3(64), 0, st, R, src, ref, ss, rec, out, sync, cols16, rows16, wt);
+    hipLaunchKernelGGL(tpl_full_recon_kernel, dim3(((cols16 + rows16 - 1) * rows16 + REC_WAVES - 1) / REC_WAVES), dim3(64 * REC_WAVES), 0, st, R, src, ref, ss, rec, out, sync, cols16, rows16, wt);
     SVT_LAUNCH_CHECK();
 }
 

@@ -308,9 +308,12 @@ inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __threadfence() {}
 inline void __builtin_amdgcn_fence(int, const char*) {}
 #define __HIP_MEMORY_SCOPE_AGENT 3
-#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_load(p, order, scope) (*(volatile __typeof__(*(p))*)(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
-inline void __builtin_amdgcn_s_sleep(int) {} // (a single host thread runs the workgroups in index order: nothing to wait for)
+// A sleeping lane gives the other fibers of its workgroup a turn: a wave that polls for a flag ANOTHER WAVE OF THE SAME WORKGROUP sets (the TPL reconstruction kernels put
+// several independent single-wave blocks into one workgroup) would otherwise spin for ever -- on the device the waves of a workgroup run side by side.  (Workgroups still run
+// one after the other in index order, so a wait for a LATER workgroup cannot end: the kernels only ever wait for earlier tickets.)
+inline void __builtin_amdgcn_s_sleep(int) { hipemu::yield(); }
 inline void __threadfence_block() {}
 
 // ---- wave-level data movement -------------------------------------------------------------

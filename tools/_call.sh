@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-.}
 ulimit -c 0
-O=gpurun_out/r06_call40; mkdir -p $O
+O=gpurun_out/r06_call41; mkdir -p $O
 for i in 1 2 3; do timeout 1500 python -m pytest tests/test_tpl.py tests/test_tpl_full.py -q -m gpu > $O/pytest_tpl_$i.txt 2>&1; tail -1 $O/pytest_tpl_$i.txt; done
 for i in 1 2; do timeout 900 python bench.py --legs tpl,tpl1 --no-cpu --no-pmc > $O/bench.txt 2> $O/bench_err.txt
 python - <<'PY'
