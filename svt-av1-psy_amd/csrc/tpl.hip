@@ -505,8 +505,9 @@ __global__ void tpl_recon_rows_reset_kernel(SvtHipTplReconStats* __restrict__ ou
 // blocks -- the critical path of an inter picture is a few blocks, not cols + rows of them; an all-intra picture degenerates to the wavefront the other forms always
 // pay.  Level 1 (32x32 blocks in complete SBs, 16x16 blocks in SBs cut by the picture edge) is two launches in stream order: a 32x32 block never has a 16x16 neighbour
 // on its left or above, so the first launch owns the cells of the complete SBs and the second one finds them published.
-constexpr int DEP_WAVES = 4; // waves (= blocks in flight) per workgroup of the dependency form: ONE ticket draw per workgroup -- 8 160 returning atomics on one word, one per
-                             // single-wave workgroup, were 126 of the kernel's 213 us (the same kernel with the workgroup id as its ticket: 87 us, gpurun call 39)
+constexpr int DEP_WAVES = 8; // waves (= blocks in flight) per workgroup of the dependency form: ONE ticket draw per workgroup -- 8 160 returning atomics on one word, one per
+                             // single-wave workgroup, were 126 of the kernel's 213 us (the same kernel with the workgroup id as its ticket: 87 us, gpurun call 39).  2 / 4 / 8 / 16 waves: 140 / 109 /
+                             // 97 / 123 us (call 42)
 template <int SIZE, int TXH>
 __global__ __launch_bounds__(64 * DEP_WAVES) void tpl_recon_dep_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
                                                            const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64) void tpl_full_src_kernel(const SvtHipTplSrcPara
 // One wave per block, every block in flight, tickets in anti-diagonal order (as tpl_recon_dep_kernel of tpl.hip: a waiting wave only waits for tickets drawn earlier).
 // An intra block reads the reconstruction above, left, above-left and -- in the first block column, whose top-right samples are real -- above-right of it; the cells'
 // "reconstructed" flags live in SvtHipTplReconStats.reserved.
-constexpr int REC_WAVES = 4; // independent blocks (waves) per workgroup of the reconstruction kernel
+constexpr int REC_WAVES = 8; // independent blocks (waves) per workgroup of the reconstruction kernel
 __global__ __launch_bounds__(64 * REC_WAVES) void tpl_full_recon_kernel(const SvtHipTplReconParams RP, const uint8_t* __restrict__ src_base, const uint8_t* __restrict__ ref_base,
                                                             const SvtHipTplSrcStats* __restrict__ src_stats, uint8_t* __restrict__ recon_base,
                                                             SvtHipTplReconStats* __restrict__ out, uint32_t* __restrict__ sync, const int cols16, const int rows16, const int wt /* 1: write-through hand-off (svt_hip_common.h), 0: release fence */) {
