@@ -552,6 +552,7 @@ __global__ __launch_bounds__(64 * DEP_WAVES) void tpl_recon_dep_kernel(const Svt
         if (timed_out) atomicAdd(&sync[1], 1u);
         if (rel_acq) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (also form 7: the hand-off's consumer side is ONE acquire, then plain loads)
         else __threadfence();
+        __builtin_amdgcn_wave_barrier(); // (nothing on the device, where the polling lanes hold their wave; the CPU emulator's lanes are fibers: the others must not read ahead)
     }
     if (rel_acq == 3) {
         tpl_recon_compute<SIZE, TXH, true, true>(RP, recon_base, out, cx, cy, B, t, buf, ptile);
