@@ -58,9 +58,16 @@ struct Ws { // workspace carving (device pointers)
 __host__ __device__ inline int n_units_1d(const int size, const int us) { const int v = (size + (us >> 1)) / us; return v > 0 ? v : 1; }
 
 // unit grid of svt_aom_foreach_rest_unit_in_frame (restoration.c:1240-1330)
-__global__ void lr_rects_kernel(const SvtHipLrSearchParams P, SvtHipRect* rects, unsigned long long* acc, WnState* wn, SvtHipLrSearchUnit* out, const int n) {
+// (also clears what the searches accumulate into -- the refinement's counters, the self-guided branch's accumulators and normal-equation sums: three fill launches less between
+//  the caller and the fork, each a host call on the stage's critical path)
+__global__ void lr_rects_kernel(const SvtHipLrSearchParams P, SvtHipRect* rects, unsigned long long* acc, WnState* wn, SvtHipLrSearchUnit* out, const int n, int32_t* counter,
+                                unsigned long long* acc2, long long* sgsum, const int sgsum_n) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < 32) counter[u] = 0;
+    if (sgsum)
+        for (int i = u; i < sgsum_n; i += (int)(gridDim.x * blockDim.x)) sgsum[i] = 0;
     if (u >= n) return;
+    if (acc2) acc2[u] = 0;
     const int us = (int)P.unit_size, w = (int)P.width, h = (int)P.height, off = 8 >> P.ss_y;
     const int nvu = n_units_1d(h, us), nhu = n_units_1d(w, us), ur = u / nhu, uc = u % nhu;
     SvtHipRect r;
@@ -992,8 +999,11 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     const int us = (int)P.unit_size, max_uw = (int)P.width - (nhu - 1) * us, max_uh = (int)P.height - (nvu - 1) * us + (nvu > 1 ? (8 >> P.ss_y) : 0);
     const int mw = max_uw > us ? max_uw : (us < (int)P.width ? us : (int)P.width), mh = max_uh > us ? max_uh : (us < (int)P.height ? us : (int)P.height);
     const dim3 tgrid((mw + 63) / 64, (mh + 63) / 64, n);
-    hipLaunchKernelGGL(lr_rects_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, W.rects, W.acc, W.wn, units, n);
-    HIP_CHECK(hipMemsetAsync(W.counter, 0, 128, st));
+    const int   slots0 = sg_slots(P);
+    const bool  sg_on0 = P.sg_enabled && slots0 > 0;
+    long long*  sgsum0 = (sg_on0 && !((int)P.unit_size & 63)) ? W.sgsum : nullptr; // (the tile-wise accumulation needs unit boundaries on the tile grid)
+    hipLaunchKernelGGL(lr_rects_kernel, dim3((n + 63) / 64 > 1 ? (n + 63) / 64 : 1), dim3(64), 0, st, P, W.rects, W.acc, W.wn, units, n, W.counter, sg_on0 ? W.acc2 : nullptr, sgsum0,
+                       sgsum0 ? n * slots0 * 5 : 0);
     // RESTORE_NONE: the unrestored unit's error.  Nothing of the searches depends on it: with the Wiener search on it runs at the head of that chain (same accumulator,
     // stream order) instead of ahead of the fork, where it held back the self-guided chain -- the longer one of the fast settings -- by its 30 us.
     auto restore_none = [&](hipStream_t s_) {
@@ -1021,10 +1031,6 @@ int svt_hip_lr_search_plane(const SvtHipLrSearchParams* params, const SvtHipLrPr
     // every walk treated as if it had left the table (tests)
     const int   line_walk = !lw ? 0 : lw[0] == 'l' ? 1 : lw[0] == 'f' ? 2 : lw[0] == 't' ? 3 : 0;
     long long*  sgsum = ((int)P.unit_size & 63) ? nullptr : W.sgsum; // (the tile-wise accumulation needs unit boundaries on the tile grid)
-    if (sg_on) {
-        HIP_CHECK(hipMemsetAsync(W.acc2, 0, (size_t)n * 8, st));
-        if (sgsum) HIP_CHECK(hipMemsetAsync(sgsum, 0, (size_t)n * slots * 5 * 8, st));
-    }
     HIP_CHECK(hipEventRecord(ev_fork, st));
     unsigned long long* sg_acc = W.acc2;
     // The self-guided launches in two parts, so that the host can slip the head of the Wiener chain in between: part 0 = the filter launches of the first two groups

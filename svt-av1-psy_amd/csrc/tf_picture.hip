@@ -114,7 +114,12 @@ __global__ __launch_bounds__(64) void tf_pic_decide_kernel(const PicArgs A) {
     const bool p64    = zm || only_64x64_before_search(A, pair) || pred_64x64_wins(A, pair);
     const int16_t mv64x = zm ? (int16_t)0 : R(0).mv_x, mv64y = zm ? (int16_t)0 : R(0).mv_y;
     A.path64[pair] = p64 ? 1 : 0;
+    // The decisions run twice: a first pass only COUNTS the prediction blocks of this (reference, SB), one atomic reserves their places in the picture's list, the second pass
+    // writes them -- instead of one returning atomic per entry, up to 21 (85 with 8x8 blocks) round trips to the memory side in series per thread.
+    uint32_t mc_n = 0, mc_at = 0;
+    bool     emit = false;
     auto mc = [&](const int, const int slot, const int16_t mvx, const int16_t mvy) { // appends to the picture's list: the order of the entries does not matter
+        if (!emit) { mc_n++; return; }
         int bs, lx, ly;
         slot_geometry(slot, bs, lx, ly);
         SvtHipTfMcDesc d;
@@ -122,10 +127,14 @@ __global__ __launch_bounds__(64) void tf_pic_decide_kernel(const PicArgs A) {
         d.pred_off[0] = (uint64_t)ref * A.pred_y_pitch; d.pred_off[1] = d.pred_off[2] = (uint64_t)ref * A.pred_uv_pitch;
         d.pu_x = (uint16_t)(x0 + lx); d.pu_y = (uint16_t)(y0 + ly); d.bsize = (uint8_t)bs; d.pad = 0; d.mv_x = mvx; d.mv_y = mvy;
         d.pad2[0] = d.pad2[1] = d.pad2[2] = 0;
-        A.mc_descs[atomicAdd(A.mc_count, 1u)] = d;
+        A.mc_descs[mc_at++] = d;
     };
     const uint32_t nbx = 2 * A.P.pic_w_sb, nby = 2 * A.P.pic_h_sb;
     uint32_t n64 = 0, n32 = 0, n16 = 0, n8 = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    emit = pass == 1;
+    if (emit) mc_at = mc_n ? atomicAdd(A.mc_count, mc_n) : 0u;
+    n64 = n32 = n16 = n8 = 0;
     if (p64) { mc(0, 0, mv64x, mv64y); n64 = 1; }
     for (int i32 = 0; i32 < 4; i32++) {
         SvtHipTfBlock B;
@@ -168,8 +177,9 @@ __global__ __launch_bounds__(64) void tf_pic_decide_kernel(const PicArgs A) {
                 }
             }
         }
-        A.blocks[((size_t)ref * nby + 2 * sby + (i32 >> 1)) * nbx + 2 * sbx + (i32 & 1)] = B;
+        if (emit) A.blocks[((size_t)ref * nby + 2 * sby + (i32 >> 1)) * nbx + 2 * sbx + (i32 & 1)] = B;
     }
+  }
     if (A.stats) {
         if (n64) atomicAdd(&A.stats->blocks_64x64, n64);
         if (n32) atomicAdd(&A.stats->blocks_32x32, n32);
